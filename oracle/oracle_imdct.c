@@ -1,0 +1,411 @@
+/*
+ * oracle/oracle_imdct.c -- TEST INFRASTRUCTURE ONLY (checker + CPU baseline).
+ *
+ * Scalar CPU restatement of the AAC-LC 1024-sample IMDCT + window/overlap-add
+ * path of libxaac's fixed-point decoder.  It is the parity oracle for the HIP
+ * kernels in libxaac_amd/csrc and the "port" CPU baseline of bench.py; nothing
+ * in the product library links or calls it.
+ *
+ * Parity status: PINNED.  tests/test_oracle_vs_reference.py drives this file
+ * and the compiled reference (oracle/_ref/libref_harness.so ->
+ * ixheaacd_imdct_process) on the same seeded inputs for every
+ * (previous,current) window-sequence pair, both window shapes and the whole
+ * block-exponent range and requires identical words; tests/golden/ holds
+ * vectors captured from the reference for the box where /root/reference is
+ * absent.
+ *
+ * Reference map (paths relative to the reference tree):
+ *   xo_block_exponent        decoder/ixheaacd_aac_tns.c:422  + lpfuncs.c:414-416,:669-671
+ *   xo_pre_rotate            decoder/ixheaacd_aac_imdct.c:165-329
+ *   xo_fft_radix8            decoder/ixheaacd_aac_imdct.c:834-1622
+ *   xo_post_rotate           decoder/ixheaacd_aac_imdct.c:331-504
+ *   xo_ola_long_long         decoder/ixheaacd_aac_imdct.c:506-832 (fused form)
+ *   xo_win_edge / xo_ola_*   decoder/ixheaacd_lpfuncs.c:94-345, ixheaacd_block.c:1193-1240
+ *   xo_imdct_process         decoder/ixheaacd_lpfuncs.c:347-802 (frame_length 1024 only)
+ *
+ * Structure is ours: the transform is written as index maps over a complex
+ * array (one radix-8 butterfly routine, a unified twiddle map), not as the
+ * reference's pointer-walking unrolled loops.  Where the reference uses only
+ * wrapping + - << (the FFT), ring identities mod 2^32 were used to merge its
+ * three butterfly variants into one; every saturating / rounding step is kept
+ * in the reference's order.
+ */
+#include <stdint.h>
+#include <string.h>
+
+#include "../libxaac_amd/csrc/fx.h"
+#include "../libxaac_amd/csrc/tables_imdct.inc"
+#include "oracle_imdct.h"
+
+typedef struct {
+  int32_t re, im;
+} cpx;
+
+/* ---- block exponent ---------------------------------------------------- */
+static int xo_headroom(const int32_t *x, int n) {
+  int32_t acc = 0;
+  for (int i = 0; i < n; i++) acc |= fx_abs_nrm(x[i]);
+  return fx_norm32(acc);
+}
+
+/* ---- rotation table: (X,Y) for complex bin c of an n2-bin transform ------
+ * pre_cs holds 257 pairs; bins in the first half walk it forwards, bins in the
+ * second half walk it backwards with the pair swapped.  st = 1 (1024) / 8 (128). */
+static void xo_rot(int c, int n2, int st, int16_t *X, int16_t *Y) {
+  int n4 = n2 >> 1;
+  if (c <= n4) {
+    int p = c * st;
+    *X = xaac_tab_pre_cs[2 * p];
+    *Y = xaac_tab_pre_cs[2 * p + 1];
+  } else {
+    int p = (n2 - c) * st;
+    *X = xaac_tab_pre_cs[2 * p + 1];
+    *Y = xaac_tab_pre_cs[2 * p];
+  }
+}
+
+/* z[c] = rot(spec[2c], spec[N-1-2c]) scaled by 2^-e  (e<0: wrapping left shift) */
+static void xo_pre_rotate(const int32_t *spec, cpx *z, int n, int e) {
+  int n2 = n >> 1, st = (n == 1024) ? 1 : 8;
+  for (int c = 0; c < n2; c++) {
+    int16_t X, Y;
+    int32_t a = spec[2 * c], b = spec[n - 1 - 2 * c];
+    xo_rot(c, n2, st, &X, &Y);
+    int32_t re = fx_add(fx_mul32x16(a, X), fx_mul32x16(b, Y));
+    int32_t im = fx_sub(fx_mul32x16(b, X), fx_mul32x16(a, Y));
+    if (e < 0) {
+      z[c].re = fx_shl(re, -e);
+      z[c].im = fx_shl(im, -e);
+    } else {
+      z[c].re = fx_shr(re, e);
+      z[c].im = fx_shr(im, e);
+    }
+  }
+}
+
+/* ---- radix-8 butterfly (all wrapping), outputs in storage-slot order ------ */
+static inline cpx c_add(cpx a, cpx b) { cpx r = {fx_add(a.re, b.re), fx_add(a.im, b.im)}; return r; }
+static inline cpx c_sub(cpx a, cpx b) { cpx r = {fx_sub(a.re, b.re), fx_sub(a.im, b.im)}; return r; }
+/* a - j*b and a + j*b */
+static inline cpx c_sub_j(cpx a, cpx b) { cpx r = {fx_add(a.re, b.im), fx_sub(a.im, b.re)}; return r; }
+static inline cpx c_add_j(cpx a, cpx b) { cpx r = {fx_sub(a.re, b.im), fx_add(a.im, b.re)}; return r; }
+#define XO_SQRT1_2 0x5A82 /* aac_imdct.c:971 */
+static inline int32_t xo_mulc(int32_t x) { return fx_mul32xlo(x, XO_SQRT1_2); }
+
+/* x[k] = k-th input; y[q] = value stored at base + q*del.  */
+static void xo_bfly8(const cpx x[8], cpx y[8]) {
+  cpx e0 = c_add(x[0], x[4]), e4 = c_sub(x[0], x[4]);
+  cpx e2 = c_add(x[2], x[6]), e6 = c_sub(x[2], x[6]);
+  cpx f0 = c_add(e0, e2), f2 = c_sub(e0, e2);
+  cpx f4 = c_sub_j(e4, e6), f6 = c_add_j(e4, e6);
+  cpx g1 = c_add(x[1], x[5]), g5 = c_sub(x[1], x[5]);
+  cpx g3 = c_add(x[3], x[7]), g7 = c_sub(x[3], x[7]);
+  cpx h1 = c_add(g1, g3), h3 = c_sub(g1, g3);
+  int32_t s5 = fx_add(g5.re, g5.im), d5 = fx_sub(g5.re, g5.im);
+  int32_t s7 = fx_add(g7.re, g7.im), d7 = fx_sub(g7.re, g7.im);
+  /* doubled odd-quadrant terms, then * 0x5A82 >> 16 */
+  int32_t p7i = fx_shlw(fx_sub(s5, d7), 1);
+  int32_t p5r = fx_shlw(fx_neg(fx_add(s5, d7)), 1);
+  int32_t p5i = fx_shlw(fx_sub(s7, d5), 1);
+  int32_t p7r = fx_shlw(fx_neg(fx_add(s7, d5)), 1);
+  cpx m7 = {xo_mulc(p7i), xo_mulc(p7r)};
+  cpx m5 = {xo_mulc(p5i), xo_mulc(p5r)};
+  y[0] = c_add(f0, h1);
+  y[4] = c_sub(f0, h1);
+  y[2] = c_sub_j(f2, h3);
+  y[6] = c_add_j(f2, h3);
+  y[1] = c_add(f4, m7);
+  y[5] = c_sub(f4, m7);
+  y[3] = c_add(f6, m5);
+  y[7] = c_sub(f6, m5);
+}
+
+/* packed twiddle w: hi16 = -sin, lo16 = cos; result doubled (wrapping) */
+static inline cpx xo_twiddle(cpx x, int32_t w) {
+  cpx r;
+  r.re = fx_shlw(fx_sub(fx_mul32xlo(x.re, w), fx_mul32xhi(x.im, w)), 1);
+  r.im = fx_shlw(fx_add(fx_mul32xhi(x.re, w), fx_mul32xlo(x.im, w)), 1);
+  return r;
+}
+
+/* n-point complex transform, n = 512 (3 passes) or 64 (2 passes); in -> out */
+static void xo_fft_radix8(const cpx *in, cpx *out, int n) {
+  cpx x[8], y[8];
+  const uint8_t *rev = (n == 512) ? xaac_tab_digrev_long : xaac_tab_digrev_short;
+  int nb = n >> 3;
+  for (int b = 0; b < nb; b++) { /* pass 1: digit-reversed gather, no twiddles */
+    for (int k = 0; k < 8; k++) x[k] = in[rev[b] + k * nb];
+    xo_bfly8(x, y);
+    for (int q = 0; q < 8; q++) out[8 * b + q] = y[q];
+  }
+  for (int del = 8; del < n; del <<= 3) {
+    int last = (del * 8 == n);
+    int tstep = 64 / del; /* twiddle index of x[k] in column m is tstep*m*k */
+    for (int base8 = 0; base8 < n; base8 += 8 * del) {
+      for (int m = 0; m < del; m++) {
+        int base = base8 + m;
+        x[0] = out[base];
+        for (int k = 1; k < 8; k++) {
+          cpx v = out[base + k * del];
+          /* column 0 of a middle pass is not multiplied at all; the last pass
+             multiplies column 0 by tw[0] (cos = 32767, not unity). */
+          x[k] = (m == 0 && !last) ? v : xo_twiddle(v, xaac_tab_fft_tw[tstep * m * k]);
+        }
+        xo_bfly8(x, y);
+        for (int q = 0; q < 8; q++) out[base + q * del] = y[q];
+      }
+    }
+  }
+}
+
+/* y[2c] / y[N-1-2c] from FFT bin c, with the small "adjust" cross term */
+static void xo_post_rotate(const cpx *z, int32_t *y, int n) {
+  int n2 = n >> 1, st = (n == 1024) ? 1 : 8;
+  int16_t adj = (n == 1024) ? 50 : 402; /* aac_imdct.c:338, :436 */
+  for (int c = 0; c < n2; c++) {
+    int16_t X, Y;
+    xo_rot(c, n2, st, &X, &Y);
+    int32_t r = fx_add(fx_mul32x16(z[c].re, X), fx_mul32x16(z[c].im, Y));
+    int32_t i = fx_sub(fx_mul32x16(z[c].re, Y), fx_mul32x16(z[c].im, X));
+    y[2 * c] = fx_add(r, fx_mul32x16(i, (int16_t)-adj));
+    y[n - 1 - 2 * c] = fx_add(i, fx_mul32x16(r, adj));
+  }
+}
+
+/* spectrum -> un-windowed time block y[n]; returns imdct_scale (= e + 2) */
+static int xo_inverse_transform(const int32_t *spec, int32_t *y, int n, int e) {
+  cpx z[512], w[512];
+  xo_pre_rotate(spec, z, n, e);
+  xo_fft_radix8(z, w, n >> 1);
+  xo_post_rotate(w, y, n);
+  return e + 2;
+}
+
+/* ---- windowing / overlap-add building blocks ---------------------------- */
+static const int16_t *xo_long_win(int shape) { return shape ? xaac_tab_win_long_kbd : xaac_tab_win_long_sine; }
+static const int16_t *xo_short_win(int shape) { return shape ? xaac_tab_win_short_kbd : xaac_tab_win_short_sine; }
+
+/* ovl[i] = round(src[i] >> (16-q))            lpfuncs.c:316 */
+static void xo_to_overlap(int32_t *ovl, const int32_t *src, int q, int n) {
+  for (int i = 0; i < n; i++) ovl[i] = fx_shr_rnd(src[i], 16 - q);
+}
+
+/* ONLY_LONG after ONLY_LONG/LONG_STOP: the reference's fused kernel
+   (aac_imdct.c:506).  y is the post-rotated block. */
+static void xo_ola_long_long(const int32_t *y, int32_t *ovl, int32_t *out, int s, const int16_t *win, int q) {
+  for (int t = 0; t < 512; t++) {
+    int32_t v = y[1023 - t];
+    int16_t w_lo = win[1022 - 2 * t], w_hi = win[1023 - 2 * t];
+    int32_t o = ovl[t];
+    int32_t a = fx_mul32x16(v, w_lo);
+    int32_t b = fx_mul32x16(fx_neg_sat(v), w_hi);
+    if (q > 0) {
+      a = fx_shl_sat(a, q);
+      b = fx_shl_sat(b, q);
+    } else {
+      a = fx_shr(a, -q);
+      b = fx_shr(b, -q);
+      o = (int16_t)o; /* the q<=0 branch reads the overlap word as WORD16 (aac_imdct.c:679) */
+    }
+    out[s * (511 - t)] = fx_sub_sat(a, fx_mul32x16_nosh_sat(o, w_hi));
+    out[s * (512 + t)] = fx_sub_sat(b, fx_mul32x16_nosh_sat(o, w_lo));
+    ovl[t] = fx_shr_rnd(y[t], 16 - q);
+  }
+}
+
+/* block.c:1193  (size n; coef points at a 2n block, only its upper half is read) */
+static void xo_ola1(const int32_t *coef, const int32_t *prev, int32_t *out, int s, const int16_t *win, int q, int n) {
+  for (int i = 0; i < n; i++) {
+    int16_t w1 = win[2 * n - 2 * i - 1], w2 = win[2 * n - 2 * i - 2];
+    int32_t c = coef[2 * n - 1 - i];
+    out[s * (n - 1 - i)] = fx_sub_sat(fx_shl_dir_sat_limit(fx_mul32x16(c, w2), q), fx_mul32x16_nosh_sat(prev[i], w1));
+    out[s * (n + i)] = fx_sub_sat(fx_shl_dir_sat_limit(fx_mul32x16(fx_neg_sat(c), w1), q), fx_mul32x16_nosh_sat(prev[i], w2));
+  }
+}
+
+/* block.c:1220  short/short overlap inside an EIGHT_SHORT frame, into the overlap buffer */
+static void xo_ola2(const int32_t *coef, const int32_t *prev, int32_t *out, const int16_t *win, int q, int n) {
+  for (int i = 0; i < n; i++) {
+    int32_t a = fx_sub_sat(fx_mul32x16(coef[n + i], win[2 * i]), fx_mul32x16(prev[n - 1 - i], win[2 * i + 1]));
+    out[i] = fx_shr_rnd(a, 16 - (q + 1));
+  }
+  for (int i = 0; i < n; i++) {
+    int32_t a = fx_sub_sat(fx_mul32x16(fx_neg_sat(coef[2 * n - 1 - i]), win[2 * n - 2 * i - 1]),
+                           fx_mul32x16(prev[i], win[2 * n - 2 * i - 2]));
+    out[n + i] = fx_shr_rnd(a, 16 - (q + 1));
+  }
+}
+
+/* lpfuncs.c:94  long block next to a short-window edge.  start!=0: the edge is
+   on the left (previous frame ended short), else on the right (LONG_STOP). */
+static void xo_win_edge(const int32_t *y, const int32_t *prev, int32_t *out, int s, const int16_t *wl,
+                        const int16_t *ws, int q, int start) {
+  const int u = 64;
+  const int32_t *cf = y + 15 * u;
+  const int16_t *wa, *wb;
+  const int32_t *pv;
+  if (start) {
+    for (int i = 0; i < 7 * u; i++) {
+      int32_t t = fx_shl_dir_sat_limit(fx_mul32x16(y[8 * u + i], wl[2 * i]), q + 1);
+      out[s * i] = fx_add_sat(t, fx_shlw(prev[i], 16));
+      t = fx_shl_dir_sat_limit(fx_mul32x16(fx_neg(y[15 * u - 1 - i]), wl[2 * (7 * u - i) - 1]), q);
+      out[s * (i + 9 * u)] = fx_shlw(t, 1);
+    }
+    wa = wl + 14 * u; /* read as (win1, win2) */
+    wb = ws;          /* read as (win4, win3) */
+    pv = prev + 8 * u - 1;
+  } else {
+    for (int i = 0; i < 7 * u; i++) {
+      out[s * i] = fx_mul32x16_nosh_sat(prev[8 * u - 1 - i], fx_neg16(wl[2 * i + 1]));
+      out[s * (9 * u + i)] = fx_sub_sat(fx_shl_dir_sat_limit(fx_neg(y[15 * u - 1 - i]), q - 1),
+                                        fx_mul32x16_nosh_sat(prev[i + u], wl[14 * u - 2 - 2 * i]));
+    }
+    wa = ws;
+    wb = wl + 14 * u;
+    pv = prev + u - 1;
+  }
+  for (int i = 0; i < u; i++) {
+    int32_t c = cf[i], p = pv[-i];
+    int16_t w1 = wa[2 * i], w2 = wa[2 * i + 1], w4 = wb[2 * i], w3 = wb[2 * i + 1];
+    int32_t a = fx_sub_sat(fx_shl_dir_sat_limit(fx_mul32x16(c, w1), q), fx_mul32x16_nosh_sat(p, w3));
+    int32_t b = fx_sub_sat(fx_shl_dir_sat_limit(fx_mul32x16(fx_neg_sat(c), w2), q), fx_mul32x16_nosh_sat(p, w4));
+    out[s * (7 * u + i)] = fx_shlw(a, start ? 1 : 0);
+    out[s * (9 * u - 1 - i)] = fx_shlw(b, start ? 1 : 0);
+  }
+}
+
+/* lpfuncs.c:180-284  EIGHT_SHORT after a long-tailed frame */
+static void xo_short_after_long(const int32_t *y, int32_t *prev, int32_t *out, int s, const int16_t *ws_cur,
+                                const int16_t *ws_prev, const int16_t *wl_prev, int q) {
+  const int u = 64;
+  for (int i = 0; i < 7 * u; i++) out[s * i] = fx_mul32x16_nosh_sat(prev[8 * u - 1 - i], fx_neg16(wl_prev[2 * i + 1]));
+  for (int i = 0; i < u; i++) {
+    out[s * (7 * u + i)] = fx_sub_sat(fx_shl_dir_sat_limit(fx_mul32x16(y[u + i], ws_prev[2 * i]), q),
+                                      fx_mul32x16_nosh_sat(prev[u - 1 - i], wl_prev[14 * u + 1 + 2 * i]));
+    out[s * (8 * u + i)] =
+        fx_sub_sat(fx_shl_dir_sat_limit(fx_mul32x16(fx_neg_sat(y[2 * u - 1 - i]), ws_prev[2 * u - 2 * i - 1]), q),
+                   fx_mul32x16_nosh_sat(prev[i], wl_prev[16 * u - 2 - 2 * i]));
+  }
+  for (int b = 0; b < 4; b++) {
+    int inc = 2 * u * b;
+    const int32_t *cur = y + u + inc;
+    const int32_t *pv = prev + u + inc;
+    int32_t *o = out + s * (9 * u + inc);
+    const int16_t *wl = wl_prev + 2 * (7 * u - inc);
+    for (int i = 0; i < u; i++) {
+      int32_t c1 = cur[3 * u - 1 - (u - 1 - i)], c2 = cur[-u + (u - 1 - i)];
+      int16_t sh1 = ws_cur[2 * u - 1 - 2 * (u - 1 - i)], sh2 = ws_cur[2 * u - 2 - 2 * (u - 1 - i)];
+      int32_t a = fx_sub(fx_mul32x16(c1, sh2), fx_mul32x16(c2, sh1));
+      o[s * i] = fx_sub_sat(fx_shl_dir_sat_limit(a, q), fx_mul32x16_nosh_sat(pv[i], wl[-2 - 2 * i]));
+      if (b != 3) {
+        int32_t d = fx_sub(fx_mul32x16(fx_neg_sat(c1), sh1), fx_mul32x16(c2, sh2));
+        o[s * (2 * u - 1 - i)] =
+            fx_sub_sat(fx_shl_dir_sat_limit(d, q), fx_mul32x16_nosh_sat(pv[2 * u - 1 - i], wl[-4 * u + 2 * i]));
+      }
+    }
+  }
+  for (int i = 0; i < u; i++) {
+    int32_t a = fx_sub(fx_mul32x16(fx_neg(y[10 * u - 1 - i]), ws_cur[2 * u - 2 * i - 1]),
+                       fx_mul32x16(y[6 * u + i], ws_cur[2 * u - 2 * i - 2]));
+    prev[i] = fx_round16(fx_shl_dir_sat_limit(a, q + 1));
+  }
+}
+
+/* ---- frame-level driver: lpfuncs.c:347-802, frame_length == 1024 ---------- */
+int xo_imdct_process(const int32_t *spec, int32_t *ovl, int16_t *prev_seq, int16_t *prev_shape, int seq, int shape,
+                     int32_t *out, int s) {
+  int32_t y[1024];
+  int qadj = 2;
+  const int u = 64;
+  const int pseq = *prev_seq;
+  const int prev_short_edge = (pseq == XO_LONG_START || pseq == XO_EIGHT_SHORT);
+  const int16_t *wl = xo_long_win(*prev_shape);
+  const int16_t *ws = xo_short_win(*prev_shape);
+
+  if (seq != XO_EIGHT_SHORT) {
+    int e = 8 - (xo_headroom(spec, 1024) - 1);
+    int q = xo_inverse_transform(spec, y, 1024, e) + 5;
+    if (seq == XO_ONLY_LONG) {
+      if (!prev_short_edge) {
+        xo_ola_long_long(y, ovl, out, s, wl, q);
+      } else {
+        xo_win_edge(y, ovl, out, s, wl, ws, q, 1);
+        xo_to_overlap(ovl, y, q, 8 * u);
+        qadj = 1;
+      }
+    } else if (seq == XO_LONG_START) {
+      if (!prev_short_edge) {
+        xo_ola1(y, ovl, out, s, wl, q, 8 * u);
+      } else {
+        xo_win_edge(y, ovl, out, s, wl, ws, q, 1);
+        qadj = 1;
+      }
+      for (int i = 0; i < 7 * u; i++) ovl[i] = fx_shr_rnd(fx_neg_sat(y[u + 7 * u - 1 - i]), 16 - q); /* lpfuncs.c:286 */
+      xo_to_overlap(ovl + 7 * u, y, q, u);
+    } else { /* LONG_STOP */
+      if (prev_short_edge) {
+        for (int i = 0; i < 7 * u; i++) out[s * i] = fx_shl_sat((int16_t)ovl[i], 15); /* lpfuncs.c:325 */
+        xo_ola1(y + 14 * u, ovl + 7 * u, out + s * 7 * u, s, ws, q, u);
+        for (int i = 0; i < 7 * u; i++) /* lpfuncs.c:297 */
+          out[s * (9 * u + i)] = fx_shl_dir_sat_limit(fx_neg_sat(y[8 * u + 7 * u - 1 - i]), q - 1);
+      } else {
+        xo_win_edge(y, ovl, out, s, wl, ws, q, 0);
+      }
+      xo_to_overlap(ovl, y, q, 8 * u);
+    }
+  } else {
+    const int16_t *ws_cur = xo_short_win(shape);
+    int e = 5 - (xo_headroom(spec, 1024) - 1);
+    int q = 0;
+    for (int w = 0; w < 8; w++) {
+      int sc = xo_inverse_transform(spec + 128 * w, y + 128 * w, 128, e);
+      if (w == 0) q = 31 + sc - 23;
+    }
+    if (prev_short_edge) {
+      int32_t loc[64];
+      for (int i = 0; i < 7 * u; i++) out[s * i] = fx_shl_sat((int16_t)ovl[i], 15);
+      xo_ola1(y, ovl + 7 * u, out + s * 7 * u, s, ws, q, u);
+      for (int b = 0; b < 3; b++) {
+        xo_to_overlap(loc, y + 2 * u * b, q, u);
+        xo_ola1(y + 2 * u + 2 * u * b, loc, out + s * (9 * u + 2 * u * b), s, ws_cur, q, u);
+      }
+      xo_ola2(y + 8 * u, y + 6 * u, ovl, ws_cur, q, u);
+      for (int i = 0; i < u; i++) { /* lpfuncs.c:335 */
+        out[s * (15 * u + i)] = fx_shl_sat((int16_t)ovl[i], 15);
+        ovl[i] = ovl[u + i];
+      }
+    } else {
+      xo_short_after_long(y, ovl, out, s, ws_cur, ws, wl, q);
+    }
+    for (int b = 0; b < 3; b++) xo_ola2(y + 10 * u + 2 * u * b, y + 8 * u + 2 * u * b, ovl + u + 2 * u * b, ws_cur, q, u);
+    xo_to_overlap(ovl + 7 * u, y + 14 * u, q, u);
+  }
+  *prev_shape = (int16_t)shape;
+  *prev_seq = (int16_t)seq;
+  return qadj;
+}
+
+/* WORD32 -> PCM16 hand-off.  mode 0: AAC-LC, limiter off: x * 2^qadj wrapping,
+   then round16 (peak_limiter.c:324 + api.c:3676-3681).  mode 1: SBR hand-off:
+   round16(shl32_sat(x, qadj)) (api.c:353-366). */
+void xo_pcm16(const int32_t *in, int in_stride, int16_t *pcm, int pcm_stride, int n, int qadj, int mode) {
+  for (int i = 0; i < n; i++) {
+    int32_t v = in[in_stride * i];
+    v = mode ? fx_shl_sat(v, qadj) : fx_shlw(v, qadj);
+    pcm[pcm_stride * i] = fx_round16(v);
+  }
+}
+
+/* Batch driver used as the CPU baseline: nch independent channel-frames. */
+void xo_imdct_batch(int nch, const int32_t *spec, int32_t *ovl, int16_t *prev_seq, int16_t *prev_shape,
+                    const uint8_t *seq, const uint8_t *shape, int32_t *out32, int16_t *pcm, int8_t *qadj,
+                    int pcm_mode) {
+  int32_t tmp[1024];
+  for (int c = 0; c < nch; c++) {
+    int32_t *o = out32 ? out32 + 1024 * (size_t)c : tmp;
+    int qa = xo_imdct_process(spec + 1024 * (size_t)c, ovl + 512 * (size_t)c, prev_seq + c, prev_shape + c, seq[c],
+                              shape[c], o, 1);
+    if (qadj) qadj[c] = (int8_t)qa;
+    if (pcm) xo_pcm16(o, 1, pcm + 1024 * (size_t)c, 1, 1024, qa, pcm_mode);
+  }
+}
