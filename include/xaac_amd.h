@@ -1,0 +1,112 @@
+/*
+ * xaac_amd.h -- C ABI of libxaac_amd.so: the MI355X (gfx950) back-end for the
+ * transform hot path of the libxaac decoder.
+ *
+ * This is the drop-in boundary.  Every entry point is `extern "C"`, takes plain
+ * pointers and sizes, allocates nothing behind the caller's back (all buffers
+ * are caller-owned, like the reference's memtab protocol, README_dec.md:44-55)
+ * and returns an IA_ERRORCODE-style int32: 0 = OK, bit 31 set = fatal
+ * (common/ixheaac_error_standards.h:23-25).
+ *
+ * Reference seam replaced (see INTEGRATION.md for the reference-side stub):
+ *   xaac_imdct_process_batch  <->  ixheaacd_imdct_process
+ *        decl decoder/ixheaacd_block.h:132, def decoder/ixheaacd_lpfuncs.c:347-802,
+ *        sole core call site decoder/ixheaacd_aacdecoder.c:988, plus the
+ *        WORD32->WORD16 hand-off that follows it
+ *        (decoder/ixheaacd_api.c:337-370 SBR case; decoder/ixheaacd_peak_limiter.c:324
+ *        + decoder/ixheaacd_api.c:3676-3681 AAC-LC case with -peak_limiter_off:1).
+ *   The per-op function pointers it subsumes are the ones the reference's
+ *   selector binds at decoder/x86/ixheaacd_function_selector_x86.c:89-125
+ *   (calc_max_spectral_line, pretwiddle_compute, imdct_using_fft, post_twiddle,
+ *   post_twid_overlap_add, over_lap_add1/2, spec_to_overlapbuf, overlap_buf_out,
+ *   overlap_out_copy, neg_shift_spec).
+ *
+ * One call processes N independent channel-frames ("channel-frame" = one
+ * channel of one 1024-sample access unit).  The reference processes one per
+ * call; the batch is the only change of shape.
+ */
+#ifndef XAAC_AMD_H
+#define XAAC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes (bit 31 = fatal, as in the reference) ------------------- */
+#define XAAC_OK 0
+#define XAAC_FATAL_NULL_ARG ((int32_t)0xFFFF8000)
+#define XAAC_FATAL_BAD_ARG ((int32_t)0xFFFF8001)
+#define XAAC_FATAL_NO_DEVICE ((int32_t)0xFFFF8002)
+#define XAAC_FATAL_HIP ((int32_t)0xFFFF8003)
+#define XAAC_FATAL_BAD_WINDOW_SEQ ((int32_t)0xFFFF8004)
+
+/* window_sequence / window_shape values: decoder/ixheaacd_cnst.h:100-103 */
+enum { XAAC_ONLY_LONG = 0, XAAC_LONG_START = 1, XAAC_EIGHT_SHORT = 2, XAAC_LONG_STOP = 3 };
+enum { XAAC_WIN_SINE = 0, XAAC_WIN_KBD = 1 };
+
+/* PCM16 hand-off flavour fused behind the IMDCT */
+enum {
+  XAAC_PCM_LC = 0, /* x * 2^qshift_adj wrapping, then round16: ixheaacd_scale_adjust + api.c:3676-3681 */
+  XAAC_PCM_SBR = 1 /* round16(shl32_sat(x, qshift_adj)): api.c:353-366 (core -> SBR hand-off) */
+};
+
+/* The two fields of ia_ics_info_struct (decoder/ixheaacd_channelinfo.h:33-47)
+ * the path reads; frame_length is fixed at 1024. */
+typedef struct xaac_ics_info {
+  uint8_t window_sequence;
+  uint8_t window_shape;
+} xaac_ics_info;
+
+/* Per-channel persistent IMDCT state besides the overlap samples: the
+ * window_shape / window_sequence members of ia_aac_dec_overlap_info
+ * (decoder/ixheaacd_channelinfo.h:88-100), updated by every call
+ * (lpfuncs.c:800-801). Zero-initialised for a new stream. */
+typedef struct xaac_ovl_state {
+  uint8_t window_sequence;
+  uint8_t window_shape;
+} xaac_ovl_state;
+
+/* Batch descriptor.  All pointers are DEVICE pointers for
+ * xaac_imdct_process_batch and HOST pointers for ..._batch_host.
+ * Channel-frame i belongs to access unit i / ch_fac, channel i % ch_fac, and
+ * its output sample n lands at index (i / ch_fac) * 1024 * ch_fac + n * ch_fac
+ * + i % ch_fac (the reference's interleaved `out_samples` at stride ch_fac). */
+typedef struct xaac_imdct_batch {
+  int32_t n_ch;               /* number of channel-frames, >= 0; multiple of ch_fac */
+  int32_t ch_fac;             /* output interleave stride, 1 or 2 */
+  const int32_t *spec;        /* [n_ch][1024]  spectral coefficients (not modified) */
+  const xaac_ics_info *ics;   /* [n_ch] */
+  int32_t *overlap;           /* [n_ch][512]   in/out: ptr_overlap_buf */
+  xaac_ovl_state *state;      /* [n_ch]        in/out */
+  int32_t *out32;             /* optional [n_ch*1024] WORD32 time samples (reference boundary) */
+  int16_t *pcm16;             /* optional [n_ch*1024] PCM16 after the qshift_adj hand-off */
+  int8_t *qshift_adj;         /* optional [n_ch] ics->qshift_adj as the reference sets it */
+  int32_t pcm_mode;           /* XAAC_PCM_LC or XAAC_PCM_SBR (used when pcm16 != NULL) */
+} xaac_imdct_batch;
+
+typedef struct xaac_ctx xaac_ctx;
+
+/* Create a context bound to HIP device `device`.  `hip_stream` is a
+ * hipStream_t to launch on (NULL: the context creates and owns one). */
+int32_t xaac_create(xaac_ctx **ctx, int32_t device, void *hip_stream);
+int32_t xaac_destroy(xaac_ctx *ctx);
+/* Block until everything queued on the context's stream has finished. */
+int32_t xaac_sync(xaac_ctx *ctx);
+
+/* Enqueue one IMDCT + overlap-add pass over the batch (asynchronous). */
+int32_t xaac_imdct_process_batch(xaac_ctx *ctx, const xaac_imdct_batch *batch);
+/* Same with host buffers: copies in, runs, copies the outputs and state back,
+ * synchronises.  PCIe-inclusive convenience path. */
+int32_t xaac_imdct_process_batch_host(xaac_ctx *ctx, const xaac_imdct_batch *batch);
+
+/* Launch geometry the library used for the last batch (for reports). */
+int32_t xaac_last_launch(xaac_ctx *ctx, int32_t *grid, int32_t *block, int32_t *lds_bytes);
+/* "libxaac_amd <version> gfx950" */
+const char *xaac_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XAAC_AMD_H */

@@ -1,0 +1,170 @@
+"""libxaac_amd -- MI355X (gfx950) back-end for the transform hot path of the
+libxaac decoder: host-side mirror of the reference's frame-level seam.
+
+The product is ``libxaac_amd/libxaac_amd.so`` (hand-written HIP + a C ABI,
+``include/xaac_amd.h``).  This module is the thin Python host layer used by the
+tests and ``bench.py``: it binds the C ABI with ctypes and uses PyTorch only to
+own device memory and streams.  There is no CPU fallback: importing works
+anywhere, but creating a context without the built library or without a HIP
+device raises.
+
+Reference seam mirrored (names, argument meaning, error behaviour):
+``ixheaacd_imdct_process`` -- decoder/ixheaacd_lpfuncs.c:347 (decl
+decoder/ixheaacd_block.h:132), here batched over N channel-frames.
+"""
+import ctypes
+import os
+
+__all__ = [
+    "ONLY_LONG_SEQUENCE", "LONG_START_SEQUENCE", "EIGHT_SHORT_SEQUENCE", "LONG_STOP_SEQUENCE",
+    "PCM_LC", "PCM_SBR", "XaacError", "XaacContext", "load_library", "library_path",
+]
+
+# decoder/ixheaacd_cnst.h:100-103
+ONLY_LONG_SEQUENCE, LONG_START_SEQUENCE, EIGHT_SHORT_SEQUENCE, LONG_STOP_SEQUENCE = 0, 1, 2, 3
+PCM_LC, PCM_SBR = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def library_path():
+    return os.path.join(_HERE, "libxaac_amd.so")
+
+
+class XaacError(RuntimeError):
+    """Non-zero IA_ERRORCODE-style return (bit 31 set = fatal)."""
+
+    def __init__(self, code, where):
+        self.code = code & 0xFFFFFFFF
+        super().__init__("%s failed: 0x%08X" % (where, self.code))
+
+
+class _ImdctBatch(ctypes.Structure):
+    # struct xaac_imdct_batch, include/xaac_amd.h
+    _fields_ = [("n_ch", ctypes.c_int32), ("ch_fac", ctypes.c_int32), ("spec", ctypes.c_void_p),
+                ("ics", ctypes.c_void_p), ("overlap", ctypes.c_void_p), ("state", ctypes.c_void_p),
+                ("out32", ctypes.c_void_p), ("pcm16", ctypes.c_void_p), ("qshift_adj", ctypes.c_void_p),
+                ("pcm_mode", ctypes.c_int32)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the product library; loud failure when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(or make -C libxaac_amd/csrc); there is no CPU fallback" % path)
+    lib = ctypes.CDLL(path)
+    lib.xaac_version.restype = ctypes.c_char_p
+    lib.xaac_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_void_p]
+    lib.xaac_destroy.argtypes = [ctypes.c_void_p]
+    lib.xaac_sync.argtypes = [ctypes.c_void_p]
+    lib.xaac_imdct_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_ImdctBatch)]
+    lib.xaac_imdct_process_batch_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(_ImdctBatch)]
+    lib.xaac_last_launch.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int32)] * 3
+    for f in ("xaac_create", "xaac_destroy", "xaac_sync", "xaac_imdct_process_batch",
+              "xaac_imdct_process_batch_host", "xaac_last_launch"):
+        getattr(lib, f).restype = ctypes.c_int32
+    _lib = lib
+    return lib
+
+
+def _ptr(t, dtype_name, numel=None, allow_none=False, device_ok=None):
+    """data pointer of a torch tensor or numpy array after shape/dtype checks"""
+    if t is None:
+        if allow_none:
+            return None
+        raise ValueError("required buffer is None")
+    if hasattr(t, "data_ptr"):  # torch
+        if not t.is_contiguous():
+            raise ValueError("buffer must be contiguous")
+        if str(t.dtype).replace("torch.", "") != dtype_name:
+            raise TypeError("expected %s, got %s" % (dtype_name, t.dtype))
+        if device_ok is not None and t.is_cuda != device_ok:
+            raise ValueError("buffer is on the wrong side of the PCIe bus")
+        n, p = t.numel(), t.data_ptr()
+    else:  # numpy
+        if not t.flags["C_CONTIGUOUS"]:
+            raise ValueError("buffer must be contiguous")
+        if t.dtype.name != dtype_name:
+            raise TypeError("expected %s, got %s" % (dtype_name, t.dtype))
+        if device_ok:
+            raise ValueError("host array passed where a device tensor is required")
+        n, p = t.size, t.ctypes.data
+    if numel is not None and n != numel:
+        raise ValueError("buffer has %d elements, expected %d" % (n, numel))
+    return p
+
+
+class XaacContext:
+    """One context per GPU / stream (xaac_create ... xaac_destroy)."""
+
+    def __init__(self, device=0, stream_handle=None):
+        self._lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self._lib.xaac_create(ctypes.byref(h), int(device), ctypes.c_void_p(stream_handle or 0))
+        if rc != 0:
+            raise XaacError(rc, "xaac_create")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.xaac_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        rc = self._lib.xaac_sync(self._h)
+        if rc != 0:
+            raise XaacError(rc, "xaac_sync")
+
+    def last_launch(self):
+        g, b, l = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        self._lib.xaac_last_launch(self._h, ctypes.byref(g), ctypes.byref(b), ctypes.byref(l))
+        return {"grid": g.value, "block": b.value, "lds_bytes": l.value}
+
+    def _batch(self, n_ch, spec, ics, overlap, state, out32, pcm16, qshift_adj, ch_fac, pcm_mode, on_device):
+        b = _ImdctBatch()
+        b.n_ch, b.ch_fac, b.pcm_mode = int(n_ch), int(ch_fac), int(pcm_mode)
+        b.spec = _ptr(spec, "int32", n_ch * 1024, device_ok=on_device)
+        b.ics = _ptr(ics, "uint8", n_ch * 2, device_ok=on_device)
+        b.overlap = _ptr(overlap, "int32", n_ch * 512, device_ok=on_device)
+        b.state = _ptr(state, "uint8", n_ch * 2, device_ok=on_device)
+        b.out32 = _ptr(out32, "int32", n_ch * 1024, allow_none=True, device_ok=on_device)
+        b.pcm16 = _ptr(pcm16, "int16", n_ch * 1024, allow_none=True, device_ok=on_device)
+        b.qshift_adj = _ptr(qshift_adj, "int8", n_ch, allow_none=True, device_ok=on_device)
+        return b
+
+    def imdct_process_batch(self, spec, ics, overlap, state, out32=None, pcm16=None, qshift_adj=None,
+                            ch_fac=1, pcm_mode=PCM_LC):
+        """Batched ixheaacd_imdct_process on device tensors (asynchronous).
+
+        spec int32[N,1024]; ics uint8[N,2] = (window_sequence, window_shape);
+        overlap int32[N,512] in/out; state uint8[N,2] in/out (previous
+        window_sequence, window_shape); optional outputs out32 int32[N*1024],
+        pcm16 int16[N*1024] (interleaved at stride ch_fac), qshift_adj int8[N]."""
+        n_ch = spec.shape[0] if spec.dim() == 2 else spec.numel() // 1024
+        b = self._batch(n_ch, spec, ics, overlap, state, out32, pcm16, qshift_adj, ch_fac, pcm_mode, True)
+        rc = self._lib.xaac_imdct_process_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_imdct_process_batch")
+
+    def imdct_process_batch_host(self, spec, ics, overlap, state, out32=None, pcm16=None, qshift_adj=None,
+                                 ch_fac=1, pcm_mode=PCM_LC):
+        """Same on host numpy arrays (copies over PCIe, synchronous)."""
+        n_ch = spec.shape[0]
+        b = self._batch(n_ch, spec, ics, overlap, state, out32, pcm16, qshift_adj, ch_fac, pcm_mode, False)
+        rc = self._lib.xaac_imdct_process_batch_host(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_imdct_process_batch_host")

@@ -1,0 +1,589 @@
+/*
+ * imdct_kernel.hip -- gfx950 kernel for the AAC 1024-sample IMDCT + window /
+ * overlap-add (+ fused PCM16 hand-off), one wave64 per channel-frame.
+ *
+ * Replaces, per channel-frame, the reference's ixheaacd_imdct_process
+ * (decoder/ixheaacd_lpfuncs.c:347-802, frame_length 1024) and everything it
+ * calls through the selector: calc_max_spectral_line (aac_tns.c:422),
+ * pretwiddle_compute (aac_imdct.c:165), imdct_using_fft (:834), post_twiddle
+ * (:331), post_twid_overlap_add (:506), process_win_seq / long_short_win_seq /
+ * nolap1_32 / neg_shift_spec / spec_to_overlapbuf / overlap_buf_out /
+ * overlap_out_copy (lpfuncs.c:94-345), over_lap_add1/2 (block.c:1193-1240) and
+ * the WORD32->WORD16 hand-off (api.c:353-366 / peak_limiter.c:324 + api.c:3676).
+ *
+ * MI355X mapping:
+ *   - persistent grid; a 256-thread workgroup = 4 independent waves, each wave
+ *     loops over channel-frames (no __syncthreads in the loop, LDS regions are
+ *     private to a wave, a wave's DS ops retire in order).
+ *   - HBM: spec (4 KB) and overlap (2 KB) come in as 16 B/lane coalesced loads;
+ *     PCM / overlap go out as 8-16 B/lane coalesced stores on the common path.
+ *   - 512-point complex FFT = 3 radix-8 passes, ONE butterfly per lane per pass,
+ *     data exchanged through a 4 KB LDS tile whose index swizzle
+ *     phi(A,B,C) = 64A + 8(B ^ (A&3)) + (A ^ C) makes every pass's ds_read_b64 /
+ *     ds_write_b64 bank-conflict free.
+ *   - rotation + FFT twiddle factors live in VGPRs for the lifetime of the wave
+ *     (pre-shifted so that every 32x16 multiply is a single v_mul_hi_i32);
+ *     windows (4.5 KB) are staged in LDS once per workgroup.
+ *   - integer only; no MFMA (fixed-size transforms, not a dense contraction).
+ * Arithmetic is the reference's Q-format behaviour bit for bit (fx.h).
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fx.h"
+#define XAAC_TAB_QUAL static __device__ const
+#include "tables_imdct.inc"
+#include "imdct_kernel.h"
+
+namespace {
+
+struct cpx {
+  int32_t re, im;
+};
+__device__ __forceinline__ cpx c_add(cpx a, cpx b) { return {fx_add(a.re, b.re), fx_add(a.im, b.im)}; }
+__device__ __forceinline__ cpx c_sub(cpx a, cpx b) { return {fx_sub(a.re, b.re), fx_sub(a.im, b.im)}; }
+__device__ __forceinline__ cpx c_sub_j(cpx a, cpx b) { return {fx_add(a.re, b.im), fx_sub(a.im, b.re)}; }
+__device__ __forceinline__ cpx c_add_j(cpx a, cpx b) { return {fx_sub(a.re, b.im), fx_add(a.im, b.re)}; }
+
+constexpr int32_t kSqrtHalfHi = (int32_t)(0x5A82u << 16); /* aac_imdct.c:971, pre-shifted for mulhi */
+
+/* radix-8 butterfly, wrapping arithmetic; y[q] is the value stored q*del after
+   the butterfly's base (aac_imdct.c:876-999 and its two twiddled variants,
+   merged by ring identities mod 2^32 -- see oracle/oracle_imdct.c:xo_bfly8). */
+__device__ __forceinline__ void bfly8(const cpx (&x)[8], cpx (&y)[8]) {
+  cpx e0 = c_add(x[0], x[4]), e4 = c_sub(x[0], x[4]);
+  cpx e2 = c_add(x[2], x[6]), e6 = c_sub(x[2], x[6]);
+  cpx f0 = c_add(e0, e2), f2 = c_sub(e0, e2);
+  cpx f4 = c_sub_j(e4, e6), f6 = c_add_j(e4, e6);
+  cpx g1 = c_add(x[1], x[5]), g5 = c_sub(x[1], x[5]);
+  cpx g3 = c_add(x[3], x[7]), g7 = c_sub(x[3], x[7]);
+  cpx h1 = c_add(g1, g3), h3 = c_sub(g1, g3);
+  int32_t s5 = fx_add(g5.re, g5.im), d5 = fx_sub(g5.re, g5.im);
+  int32_t s7 = fx_add(g7.re, g7.im), d7 = fx_sub(g7.re, g7.im);
+  int32_t p7i = fx_shlw(fx_sub(s5, d7), 1);
+  int32_t p5r = fx_shlw(fx_neg(fx_add(s5, d7)), 1);
+  int32_t p5i = fx_shlw(fx_sub(s7, d5), 1);
+  int32_t p7r = fx_shlw(fx_neg(fx_add(s7, d5)), 1);
+  cpx m7 = {fx_mulhi(p7i, kSqrtHalfHi), fx_mulhi(p7r, kSqrtHalfHi)};
+  cpx m5 = {fx_mulhi(p5i, kSqrtHalfHi), fx_mulhi(p5r, kSqrtHalfHi)};
+  y[0] = c_add(f0, h1);
+  y[4] = c_sub(f0, h1);
+  y[2] = c_sub_j(f2, h3);
+  y[6] = c_add_j(f2, h3);
+  y[1] = c_add(f4, m7);
+  y[5] = c_sub(f4, m7);
+  y[3] = c_add(f6, m5);
+  y[7] = c_sub(f6, m5);
+}
+
+/* packed twiddle: hi16 = -sin, lo16 = cos; product doubled (aac_imdct.c:1179-1185) */
+__device__ __forceinline__ cpx twiddle(cpx x, int32_t w) {
+  int32_t wl = (int32_t)((uint32_t)w << 16), wh = (int32_t)((uint32_t)w & 0xffff0000u);
+  cpx r;
+  r.re = fx_shlw(fx_sub(fx_mulhi(x.re, wl), fx_mulhi(x.im, wh)), 1);
+  r.im = fx_shlw(fx_add(fx_mulhi(x.re, wh), fx_mulhi(x.im, wl)), 1);
+  return r;
+}
+
+/* LDS exchange-tile swizzle for logical complex index 64A + 8B + C */
+__device__ __forceinline__ int phi(int A, int B, int C) { return (A << 6) | ((B ^ (A & 3)) << 3) | (A ^ C); }
+
+/* rotation pair for bin c of an n2-bin transform (pre- and post-twiddle share it):
+   aac_imdct.c:174-328 / :339-421; returned pre-shifted by 16 for mulhi */
+__device__ __forceinline__ void rot_pair(int c, int n2, int st, int32_t &X, int32_t &Y) {
+  int n4 = n2 >> 1;
+  int16_t x, y;
+  if (c <= n4) {
+    int p = c * st;
+    x = xaac_tab_pre_cs[2 * p];
+    y = xaac_tab_pre_cs[2 * p + 1];
+  } else {
+    int p = (n2 - c) * st;
+    x = xaac_tab_pre_cs[2 * p + 1];
+    y = xaac_tab_pre_cs[2 * p];
+  }
+  X = (int32_t)((uint32_t)(uint16_t)x << 16);
+  Y = (int32_t)((uint32_t)(uint16_t)y << 16);
+}
+
+/* pre-rotation scaling (aac_imdct.c:177-328): e < 0 -> wrapping left shift by -e,
+   else arithmetic right shift by e.  e = 9 - headroom (long) or 6 - headroom
+   (short) with headroom in [0,31], so both counts stay below 26 and the
+   reference's "count > 31" guards can never fire: two plain shifts, one of them by 0. */
+__device__ __forceinline__ int32_t scale_by_expo(int32_t v, int sl, int sr) { return fx_shlw(v, sl) >> sr; }
+
+__device__ __forceinline__ int32_t wave_or(int32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+  return v;
+}
+
+/* 16-bit multiplier from an LDS / register window value */
+__device__ __forceinline__ int32_t mul16(int32_t a, int16_t w) { return fx_mul32x16(a, w); }
+__device__ __forceinline__ int32_t nosh(int32_t a, int16_t w) {
+  /* full 48-bit product clamped to 32 bits, no shift (aac_imdct.c:95-106) */
+  int64_t p = (int64_t)a * (int64_t)w;
+  return fx_sat64(p);
+}
+
+/* where a finished time sample goes: WORD32 block and/or PCM16 after the qshift hand-off */
+struct Sink {
+  int32_t *o32;
+  int16_t *p16;
+  int stride;
+  int qadj;
+  int mode;
+  __device__ __forceinline__ int16_t to_pcm(int32_t v) const {
+    return fx_round16(mode ? fx_shl_sat(v, qadj) : fx_shlw(v, qadj));
+  }
+  __device__ __forceinline__ void put(int n, int32_t v) const {
+    if (o32) o32[n * stride] = v;
+    if (p16) p16[n * stride] = to_pcm(v);
+  }
+};
+
+/* ------------------------------------------------------------------------- */
+/* Lane-major constant tiles in LDS (filled once per workgroup): every read is
+   word [k*64 + lane] -> bank-conflict free, and keeps ~30 VGPRs free.
+     rx/ry[k][lane]  rotation pair of bin lane + 64k (n = 1024), pre-shifted << 16
+     tw2[k-1][lane]  pass-2 twiddle of column m = lane & 7 : tw[8*m*k]
+     tw3[k-1][lane]  pass-3 twiddle of column m = lane     : tw[m*k]           */
+struct ConstTiles {
+  const int32_t *rx, *ry, *tw2, *tw3;
+};
+
+__device__ __forceinline__ void fill_const_tiles(int32_t *base, int tid, int nthreads) {
+  for (int i = tid; i < 512; i += nthreads) {
+    int32_t X, Y;
+    rot_pair((i & 63) + 64 * (i >> 6), 512, 1, X, Y);
+    base[i] = X;
+    base[512 + i] = Y;
+  }
+  for (int i = tid; i < 448; i += nthreads) {
+    int k = (i >> 6) + 1, l = i & 63;
+    base[1024 + i] = xaac_tab_fft_tw[8 * (l & 7) * k];
+    base[1024 + 448 + i] = xaac_tab_fft_tw[l * k];
+  }
+}
+
+/* spec (16 words per lane, as 4 coalesced int4 rows) -> de-interleaved LDS tile:
+   E[i] = spec[2i] at word i, O[i] = spec[2i+1] at word 512 + i */
+__device__ __forceinline__ void stage_spec(int32_t *buf, const int4 (&v)[4], int lane) {
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    *reinterpret_cast<int2 *>(buf + 128 * r + 2 * lane) = make_int2(v[r].x, v[r].z);
+    *reinterpret_cast<int2 *>(buf + 512 + 128 * r + 2 * lane) = make_int2(v[r].y, v[r].w);
+  }
+}
+
+/* 1024-sample transform: staged spectrum in buf -> un-windowed block y[1024] in buf */
+__device__ __forceinline__ void long_transform(int32_t *buf, int lane, int e, const ConstTiles &wc) {
+  cpx x[8], y[8];
+  int2 *Z = reinterpret_cast<int2 *>(buf);
+  const int sl = e < 0 ? -e : 0, sr = e < 0 ? 0 : e;
+  /* pre-rotation of bins lane + 64k, fused with pass 1.  Lane l runs butterfly
+     b = digrev8(l) so that its inputs are the conflict-free column l. */
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    int c = lane + 64 * k;
+    int32_t a = buf[c], b = buf[512 + 511 - c];
+    int32_t re = fx_add(fx_mulhi(a, wc.rx[64 * k + lane]), fx_mulhi(b, wc.ry[64 * k + lane]));
+    int32_t im = fx_sub(fx_mulhi(b, wc.rx[64 * k + lane]), fx_mulhi(a, wc.ry[64 * k + lane]));
+    x[k].re = scale_by_expo(re, sl, sr);
+    x[k].im = scale_by_expo(im, sl, sr);
+  }
+  bfly8(x, y);
+  {
+    int A = lane & 7, B = lane >> 3;
+#pragma unroll
+    for (int q = 0; q < 8; q++) Z[phi(A, B, q)] = make_int2(y[q].re, y[q].im);
+  }
+  /* pass 2: del = 8; butterfly (group A, column m = C); column 0 is not twiddled */
+  {
+    int A = lane >> 3, C = lane & 7;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      int2 t = Z[phi(A, k, C)];
+      x[k] = {t.x, t.y};
+    }
+#pragma unroll
+    for (int k = 1; k < 8; k++) {
+      cpx t = twiddle(x[k], wc.tw2[64 * (k - 1) + lane]);
+      x[k] = (C == 0) ? x[k] : t;
+    }
+    bfly8(x, y);
+#pragma unroll
+    for (int q = 0; q < 8; q++) Z[phi(A, q, C)] = make_int2(y[q].re, y[q].im);
+  }
+  /* pass 3: del = 64; butterfly column m = lane (twiddled even for m = 0: tw[0] != 1) */
+  {
+    int B = lane >> 3, C = lane & 7;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      int2 t = Z[phi(k, B, C)];
+      x[k] = {t.x, t.y};
+    }
+#pragma unroll
+    for (int k = 1; k < 8; k++) x[k] = twiddle(x[k], wc.tw3[64 * (k - 1) + lane]);
+    bfly8(x, y);
+  }
+  /* post-rotation of bins 64q + lane (same rotation registers), +-50 cross term */
+  constexpr int32_t kAdjP = (int32_t)(50u << 16), kAdjN = (int32_t)((uint32_t)(uint16_t)(int16_t)-50 << 16);
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    int c = lane + 64 * q;
+    int32_t r = fx_add(fx_mulhi(y[q].re, wc.rx[64 * q + lane]), fx_mulhi(y[q].im, wc.ry[64 * q + lane]));
+    int32_t i = fx_sub(fx_mulhi(y[q].re, wc.ry[64 * q + lane]), fx_mulhi(y[q].im, wc.rx[64 * q + lane]));
+    buf[2 * c] = fx_add(r, fx_mulhi(i, kAdjN));
+    buf[1023 - 2 * c] = fx_add(i, fx_mulhi(r, kAdjP));
+  }
+}
+
+/* EIGHT_SHORT: eight 128-sample transforms; lane = (window w, butterfly b) */
+__device__ __forceinline__ void short_transform(int32_t *buf, int lane, int e) {
+  cpx x[8], y[8];
+  int2 *Z = reinterpret_cast<int2 *>(buf);
+  const int w = lane >> 3, b = lane & 7;
+  const int sl = e < 0 ? -e : 0, sr = e < 0 ? 0 : e;
+  int32_t rx[8], ry[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) rot_pair(b + 8 * k, 64, 8, rx[k], ry[k]);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    int c = b + 8 * k;
+    int32_t a = buf[64 * w + c], bb = buf[512 + 64 * w + 63 - c];
+    int32_t re = fx_add(fx_mulhi(a, rx[k]), fx_mulhi(bb, ry[k]));
+    int32_t im = fx_sub(fx_mulhi(bb, rx[k]), fx_mulhi(a, ry[k]));
+    x[k].re = scale_by_expo(re, sl, sr);
+    x[k].im = scale_by_expo(im, sl, sr);
+  }
+  bfly8(x, y);
+#pragma unroll
+  for (int q = 0; q < 8; q++) Z[64 * w + 8 * b + q] = make_int2(y[q].re, y[q].im);
+  /* last pass (del = 8), column m = b, twiddles tw[8*m*k] */
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    int2 t = Z[64 * w + b + 8 * k];
+    x[k] = {t.x, t.y};
+  }
+#pragma unroll
+  for (int k = 1; k < 8; k++) x[k] = twiddle(x[k], xaac_tab_fft_tw[8 * b * k]);
+  bfly8(x, y);
+  constexpr int32_t kAdjP = (int32_t)(402u << 16), kAdjN = (int32_t)((uint32_t)(uint16_t)(int16_t)-402 << 16);
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    int c = b + 8 * q;
+    int32_t r = fx_add(fx_mulhi(y[q].re, rx[q]), fx_mulhi(y[q].im, ry[q]));
+    int32_t i = fx_sub(fx_mulhi(y[q].re, ry[q]), fx_mulhi(y[q].im, rx[q]));
+    buf[128 * w + 2 * c] = fx_add(r, fx_mulhi(i, kAdjN));
+    buf[128 * w + 127 - 2 * c] = fx_add(i, fx_mulhi(r, kAdjP));
+  }
+}
+
+/* ---- window / overlap-add variants (y and old overlap are in LDS) ---------- */
+
+/* lpfuncs.c:316 */
+__device__ __forceinline__ int32_t to_ovl(int32_t v, int q) { return fx_shr_rnd(v, 16 - q); }
+
+/* block.c:1193: n-point ola1; coef -> 2n block (upper half read), prev -> n old-overlap words */
+__device__ __forceinline__ void ola1(const int32_t *coef, const int32_t *prev, const Sink &sk, int obase,
+                                     const int16_t *win, int q, int n, int lane) {
+  for (int i = lane; i < n; i += 64) {
+    int16_t w1 = win[2 * n - 2 * i - 1], w2 = win[2 * n - 2 * i - 2];
+    int32_t c = coef[2 * n - 1 - i], p = prev[i];
+    sk.put(obase + n - 1 - i, fx_sub_sat(fx_shl_dir_sat_limit(mul16(c, w2), q), nosh(p, w1)));
+    sk.put(obase + n + i, fx_sub_sat(fx_shl_dir_sat_limit(mul16(fx_neg_sat(c), w1), q), nosh(p, w2)));
+  }
+}
+
+/* block.c:1220: value i (0..2n-1) of the short/short overlap */
+__device__ __forceinline__ int32_t ola2_value(const int32_t *coef, const int32_t *prev, const int16_t *win, int q,
+                                              int n, int i) {
+  int32_t a;
+  if (i < n) {
+    a = fx_sub_sat(mul16(coef[n + i], win[2 * i]), mul16(prev[n - 1 - i], win[2 * i + 1]));
+  } else {
+    int j = i - n;
+    a = fx_sub_sat(mul16(fx_neg_sat(coef[2 * n - 1 - j]), win[2 * n - 2 * j - 1]),
+                   mul16(prev[j], win[2 * n - 2 * j - 2]));
+  }
+  return fx_shr_rnd(a, 16 - (q + 1));
+}
+
+/* lpfuncs.c:94: long block beside a short edge (start: edge on the left) */
+__device__ __forceinline__ void win_edge(const int32_t *y, const int32_t *ov, const Sink &sk, const int16_t *wl,
+                                         const int16_t *ws, int q, bool start, int lane) {
+  constexpr int u = 64;
+  if (start) {
+    for (int i = lane; i < 7 * u; i += 64) {
+      int32_t t = fx_shl_dir_sat_limit(mul16(y[8 * u + i], wl[2 * i]), q + 1);
+      sk.put(i, fx_add_sat(t, fx_shlw(ov[i], 16)));
+      t = fx_shl_dir_sat_limit(mul16(fx_neg(y[15 * u - 1 - i]), wl[2 * (7 * u - i) - 1]), q);
+      sk.put(i + 9 * u, fx_shlw(t, 1));
+    }
+  } else {
+    for (int i = lane; i < 7 * u; i += 64) {
+      sk.put(i, nosh(ov[8 * u - 1 - i], fx_neg16(wl[2 * i + 1])));
+      sk.put(9 * u + i, fx_sub_sat(fx_shl_dir_sat_limit(fx_neg(y[15 * u - 1 - i]), q - 1),
+                                   nosh(ov[i + u], wl[14 * u - 2 - 2 * i])));
+    }
+  }
+  {
+    const int i = lane;
+    const int16_t *wa = start ? wl + 14 * u : ws;
+    const int16_t *wb = start ? ws : wl + 14 * u;
+    int32_t c = y[15 * u + i];
+    int32_t p = start ? ov[8 * u - 1 - i] : ov[u - 1 - i];
+    int16_t w1 = wa[2 * i], w2 = wa[2 * i + 1], w4 = wb[2 * i], w3 = wb[2 * i + 1];
+    int32_t a = fx_sub_sat(fx_shl_dir_sat_limit(mul16(c, w1), q), nosh(p, w3));
+    int32_t b = fx_sub_sat(fx_shl_dir_sat_limit(mul16(fx_neg_sat(c), w2), q), nosh(p, w4));
+    sk.put(7 * u + i, fx_shlw(a, start ? 1 : 0));
+    sk.put(9 * u - 1 - i, fx_shlw(b, start ? 1 : 0));
+  }
+}
+
+/* lpfuncs.c:180-284: EIGHT_SHORT after a long-tailed frame; also yields new overlap[0..63] */
+__device__ __forceinline__ void short_after_long(const int32_t *y, const int32_t *ov, const Sink &sk,
+                                                 int32_t *ovl_out, const int16_t *wsc, const int16_t *wsp,
+                                                 const int16_t *wlp, int q, int lane) {
+  constexpr int u = 64;
+  for (int i = lane; i < 7 * u; i += 64) sk.put(i, nosh(ov[8 * u - 1 - i], fx_neg16(wlp[2 * i + 1])));
+  const int i = lane;
+  sk.put(7 * u + i,
+         fx_sub_sat(fx_shl_dir_sat_limit(mul16(y[u + i], wsp[2 * i]), q), nosh(ov[u - 1 - i], wlp[14 * u + 1 + 2 * i])));
+  sk.put(8 * u + i, fx_sub_sat(fx_shl_dir_sat_limit(mul16(fx_neg_sat(y[2 * u - 1 - i]), wsp[2 * u - 2 * i - 1]), q),
+                               nosh(ov[i], wlp[16 * u - 2 - 2 * i])));
+  for (int b = 0; b < 4; b++) {
+    int inc = 2 * u * b;
+    const int32_t *cur = y + u + inc;
+    const int32_t *pv = ov + u + inc;
+    const int16_t *wl = wlp + 2 * (7 * u - inc);
+    int32_t c1 = cur[2 * u + i], c2 = cur[-1 - i];
+    int16_t sh1 = wsc[2 * i + 1], sh2 = wsc[2 * i];
+    int32_t a = fx_sub(mul16(c1, sh2), mul16(c2, sh1));
+    sk.put(9 * u + inc + i, fx_sub_sat(fx_shl_dir_sat_limit(a, q), nosh(pv[i], wl[-2 - 2 * i])));
+    if (b != 3) {
+      int32_t d = fx_sub(mul16(fx_neg_sat(c1), sh1), mul16(c2, sh2));
+      sk.put(9 * u + inc + 2 * u - 1 - i,
+             fx_sub_sat(fx_shl_dir_sat_limit(d, q), nosh(pv[2 * u - 1 - i], wl[-4 * u + 2 * i])));
+    }
+  }
+  int32_t a = fx_sub(mul16(fx_neg(y[10 * u - 1 - i]), wsc[2 * u - 2 * i - 1]), mul16(y[6 * u + i], wsc[2 * u - 2 * i - 2]));
+  ovl_out[i] = fx_round16(fx_shl_dir_sat_limit(a, q + 1));
+}
+
+/* ONLY_LONG after a short edge, LONG_START, LONG_STOP (lpfuncs.c:489-655); returns qshift_adj */
+__device__ __noinline__ int long_transition_paths(const int32_t *y, const int32_t *ovs, Sink sk, int32_t *ovl,
+                                                  const int16_t *wl, const int16_t *ws, int q, int seq,
+                                                  bool prev_short_edge, int lane) {
+  constexpr int u = 64;
+  if (seq == XAAC_K_ONLY_LONG) { /* after LONG_START / EIGHT_SHORT */
+    sk.qadj = 1;
+    win_edge(y, ovs, sk, wl, ws, q, true, lane);
+    for (int i = lane; i < 8 * u; i += 64) ovl[i] = to_ovl(y[i], q);
+  } else if (seq == XAAC_K_LONG_START) {
+    if (!prev_short_edge) {
+      ola1(y, ovs, sk, 0, wl, q, 8 * u, lane);
+    } else {
+      sk.qadj = 1;
+      win_edge(y, ovs, sk, wl, ws, q, true, lane);
+    }
+    for (int i = lane; i < 7 * u; i += 64) ovl[i] = fx_shr_rnd(fx_neg_sat(y[8 * u - 1 - i]), 16 - q);
+    ovl[7 * u + lane] = to_ovl(y[lane], q);
+  } else { /* LONG_STOP */
+    if (prev_short_edge) {
+      for (int i = lane; i < 7 * u; i += 64) sk.put(i, fx_shl_sat((int16_t)ovs[i], 15));
+      ola1(y + 14 * u, ovs + 7 * u, sk, 7 * u, ws, q, u, lane);
+      for (int i = lane; i < 7 * u; i += 64)
+        sk.put(9 * u + i, fx_shl_dir_sat_limit(fx_neg_sat(y[15 * u - 1 - i]), q - 1));
+    } else {
+      win_edge(y, ovs, sk, wl, ws, q, false, lane);
+    }
+    for (int i = lane; i < 8 * u; i += 64) ovl[i] = to_ovl(y[i], q);
+  }
+  return sk.qadj;
+}
+
+/* EIGHT_SHORT (lpfuncs.c:657-798): transform + all its overlap handling; qshift_adj is always 2 */
+__device__ __noinline__ void eight_short_path(int32_t *buf, const int32_t *ovs, Sink sk, int32_t *ovl,
+                                              const int16_t *wl, const int16_t *ws, const int16_t *wsc,
+                                              int headroom, bool prev_short_edge, int lane) {
+  constexpr int u = 64;
+  const int e = 5 - (headroom - 1);
+  const int q = e + 2 + 8;
+  short_transform(buf, lane, e);
+  const int32_t *y = buf;
+  const int i = lane;
+  if (prev_short_edge) {
+    for (int n = lane; n < 7 * u; n += 64) sk.put(n, fx_shl_sat((int16_t)ovs[n], 15));
+    ola1(y, ovs + 7 * u, sk, 7 * u, ws, q, u, lane);
+    for (int b = 0; b < 3; b++) {
+      /* ola1 against the (requantised) tail of the previous short window */
+      const int32_t *coef = y + 2 * u + 2 * u * b;
+      int16_t w1 = wsc[2 * u - 2 * i - 1], w2 = wsc[2 * u - 2 * i - 2];
+      int32_t c = coef[2 * u - 1 - i], pr = to_ovl(y[2 * u * b + i], q);
+      sk.put(9 * u + 2 * u * b + u - 1 - i, fx_sub_sat(fx_shl_dir_sat_limit(mul16(c, w2), q), nosh(pr, w1)));
+      sk.put(9 * u + 2 * u * b + u + i, fx_sub_sat(fx_shl_dir_sat_limit(mul16(fx_neg_sat(c), w1), q), nosh(pr, w2)));
+    }
+    int32_t t_lo = ola2_value(y + 8 * u, y + 6 * u, wsc, q, u, i);
+    int32_t t_hi = ola2_value(y + 8 * u, y + 6 * u, wsc, q, u, u + i);
+    sk.put(15 * u + i, fx_shl_sat((int16_t)t_lo, 15)); /* lpfuncs.c:335 */
+    ovl[i] = t_hi;
+  } else {
+    short_after_long(y, ovs, sk, ovl, wsc, ws, wl, q, lane);
+  }
+  for (int b = 0; b < 3; b++) {
+    ovl[u + 2 * u * b + i] = ola2_value(y + 10 * u + 2 * u * b, y + 8 * u + 2 * u * b, wsc, q, u, i);
+    ovl[u + 2 * u * b + u + i] = ola2_value(y + 10 * u + 2 * u * b, y + 8 * u + 2 * u * b, wsc, q, u, u + i);
+  }
+  ovl[7 * u + i] = to_ovl(y[14 * u + i], q);
+}
+
+}  // namespace
+
+/* ========================================================================= */
+__global__ __launch_bounds__(XAAC_IMDCT_BLOCK) void xaac_imdct_ola_kernel(XaacImdctParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int16_t *s_win = reinterpret_cast<int16_t *>(smem); /* [long sine|long kbd|short sine|short kbd] */
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int32_t *s_const = reinterpret_cast<int32_t *>(smem + XAAC_IMDCT_LDS_WIN_BYTES);
+  int32_t *buf = s_const + XAAC_IMDCT_LDS_CONST_WORDS + wave * XAAC_IMDCT_LDS_WAVE_WORDS;
+  int32_t *ovs = buf + 1024; /* old overlap copy for the rare paths */
+
+  for (int i = tid; i < 1024; i += XAAC_IMDCT_BLOCK) {
+    s_win[i] = xaac_tab_win_long_sine[i];
+    s_win[1024 + i] = xaac_tab_win_long_kbd[i];
+  }
+  for (int i = tid; i < 128; i += XAAC_IMDCT_BLOCK) {
+    s_win[2048 + i] = xaac_tab_win_short_sine[i];
+    s_win[2176 + i] = xaac_tab_win_short_kbd[i];
+  }
+  fill_const_tiles(s_const, tid, XAAC_IMDCT_BLOCK);
+  const ConstTiles wc = {s_const, s_const + 512, s_const + 1024, s_const + 1024 + 448};
+  __syncthreads();
+
+  const int waves_total = gridDim.x * XAAC_IMDCT_WAVES;
+  for (int ch = blockIdx.x * XAAC_IMDCT_WAVES + wave; ch < p.n_ch; ch += waves_total) {
+    /* ---- loads: 4 KB spectrum + 2 KB overlap, 16 B per lane per instruction */
+    const int4 *sp = reinterpret_cast<const int4 *>(p.spec + (size_t)ch * 1024);
+    int32_t *ovl = p.overlap + (size_t)ch * 512;
+    int4 v[4], o4[2];
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = sp[64 * r + lane];
+    o4[0] = reinterpret_cast<const int4 *>(ovl)[lane];
+    o4[1] = reinterpret_cast<const int4 *>(ovl)[64 + lane];
+    const int seq = p.ics[ch].window_sequence, shape = p.ics[ch].window_shape;
+    const int pseq = p.state[ch].window_sequence, pshape = p.state[ch].window_shape;
+
+    /* block exponent: OR of abs_nrm over the frame (aac_tns.c:422) */
+    int32_t acc = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      acc |= fx_abs_nrm(v[r].x) | fx_abs_nrm(v[r].y) | fx_abs_nrm(v[r].z) | fx_abs_nrm(v[r].w);
+    const int headroom = fx_norm32(wave_or(acc));
+
+    stage_spec(buf, v, lane);
+
+    const bool prev_short_edge = (pseq == XAAC_K_LONG_START) || (pseq == XAAC_K_EIGHT_SHORT);
+    const int16_t *wl = s_win + 1024 * pshape;        /* previous shape, long */
+    const int16_t *ws = s_win + 2048 + 128 * pshape;  /* previous shape, short */
+    const int cf = p.ch_fac;
+    const size_t obase = (size_t)(ch / cf) * 1024 * cf + (ch % cf);
+    Sink sk;
+    sk.o32 = p.out32 ? p.out32 + obase : nullptr;
+    sk.p16 = p.pcm16 ? p.pcm16 + obase : nullptr;
+    sk.stride = cf;
+    sk.mode = p.pcm_mode;
+    sk.qadj = 2;
+
+    if (seq != XAAC_K_EIGHT_SHORT) {
+      const int e = 8 - (headroom - 1);
+      const int q = e + 2 + 5;
+      long_transform(buf, lane, e, wc);
+      const int32_t *y = buf;
+
+      if (seq == XAAC_K_ONLY_LONG && !prev_short_edge) {
+        /* ---- hot path (aac_imdct.c:506): lane owns t = 4l+j and 256+4l+j */
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+          const int t0 = 256 * g + 4 * lane;
+          int4 vv = *reinterpret_cast<const int4 *>(y + 1020 - t0);         /* y[1023-t], j = 3..0 */
+          int4 uu = *reinterpret_cast<const int4 *>(y + t0);                /* y[t]               */
+          int4 ww = *reinterpret_cast<const int4 *>(wl + 2 * (508 - t0));   /* W32[511-t], j = 3..0 */
+          const int32_t vj[4] = {vv.w, vv.z, vv.y, vv.x};
+          const int32_t wj[4] = {ww.w, ww.z, ww.y, ww.x};
+          const int32_t oj[4] = {o4[g].x, o4[g].y, o4[g].z, o4[g].w};
+          const int32_t uj[4] = {uu.x, uu.y, uu.z, uu.w};
+          int32_t lo[4], hi[4], nv[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            int32_t a = fx_mul32xlo(vj[j], wj[j]);
+            int32_t b = fx_mul32xhi(fx_neg_sat(vj[j]), wj[j]);
+            int32_t o = oj[j];
+            if (q > 0) {
+              a = fx_shl_sat(a, q);
+              b = fx_shl_sat(b, q);
+            } else {
+              a = fx_shr(a, -q);
+              b = fx_shr(b, -q);
+              o = (int16_t)o; /* aac_imdct.c:679 */
+            }
+            lo[j] = fx_sub_sat(a, nosh(o, (int16_t)(wj[j] >> 16)));   /* out[511-t] */
+            hi[j] = fx_sub_sat(b, nosh(o, (int16_t)wj[j]));           /* out[512+t] */
+            nv[j] = to_ovl(uj[j], q);
+          }
+          reinterpret_cast<int4 *>(ovl)[64 * g + lane] = make_int4(nv[0], nv[1], nv[2], nv[3]);
+          if (cf == 1) {
+            if (sk.o32) {
+              *reinterpret_cast<int4 *>(sk.o32 + 508 - t0) = make_int4(lo[3], lo[2], lo[1], lo[0]);
+              *reinterpret_cast<int4 *>(sk.o32 + 512 + t0) = make_int4(hi[0], hi[1], hi[2], hi[3]);
+            }
+            if (sk.p16) {
+              auto pk = [&](int32_t a, int32_t b) {
+                return (int32_t)((uint32_t)(uint16_t)sk.to_pcm(a) | ((uint32_t)(uint16_t)sk.to_pcm(b) << 16));
+              };
+              *reinterpret_cast<int2 *>(sk.p16 + 508 - t0) = make_int2(pk(lo[3], lo[2]), pk(lo[1], lo[0]));
+              *reinterpret_cast<int2 *>(sk.p16 + 512 + t0) = make_int2(pk(hi[0], hi[1]), pk(hi[2], hi[3]));
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              sk.put(511 - t0 - j, lo[j]);
+              sk.put(512 + t0 + j, hi[j]);
+            }
+          }
+        }
+      } else {
+        /* rare long-window transitions: out of line so that their register
+           appetite does not set the occupancy of the hot path */
+        reinterpret_cast<int4 *>(ovs)[lane] = o4[0];
+        reinterpret_cast<int4 *>(ovs)[64 + lane] = o4[1];
+        sk.qadj = long_transition_paths(buf, ovs, sk, ovl, wl, ws, q, seq, prev_short_edge, lane);
+      }
+    } else {
+      reinterpret_cast<int4 *>(ovs)[lane] = o4[0];
+      reinterpret_cast<int4 *>(ovs)[64 + lane] = o4[1];
+      eight_short_path(buf, ovs, sk, ovl, wl, ws, s_win + 2048 + 128 * shape, headroom, prev_short_edge, lane);
+    }
+
+    if (lane == 0) {
+      p.state[ch].window_sequence = (uint8_t)seq;
+      p.state[ch].window_shape = (uint8_t)shape;
+      if (p.qshift_adj) p.qshift_adj[ch] = (int8_t)sk.qadj;
+    }
+  }
+}
+
+extern "C" hipError_t xaac_launch_imdct(const XaacImdctParams *p, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL(xaac_imdct_ola_kernel, dim3(grid), dim3(XAAC_IMDCT_BLOCK), XAAC_IMDCT_LDS_BYTES, stream, *p);
+  return hipGetLastError();
+}
+
+/* resident workgroups per CU for this kernel (registers + LDS), for sizing the persistent grid */
+extern "C" int xaac_imdct_blocks_per_cu(void) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, xaac_imdct_ola_kernel, XAAC_IMDCT_BLOCK,
+                                                   XAAC_IMDCT_LDS_BYTES) != hipSuccess || n < 1)
+    n = 2;
+  return n;
+}

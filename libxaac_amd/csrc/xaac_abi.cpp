@@ -1,0 +1,183 @@
+/*
+ * xaac_abi.cpp -- the C-ABI layer of libxaac_amd.so (include/xaac_amd.h):
+ * argument validation, error codes in the reference's IA_ERRORCODE convention,
+ * launch geometry, and the host-buffer convenience path.  No arithmetic lives
+ * here; the work is in imdct_kernel.hip.  There is deliberately NO CPU fallback:
+ * without a HIP device xaac_create fails with XAAC_FATAL_NO_DEVICE.
+ */
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <new>
+
+#include "../../include/xaac_amd.h"
+#include "imdct_kernel.h"
+
+struct xaac_ctx {
+  int device;
+  hipStream_t stream;
+  bool owns_stream;
+  int num_cu;
+  int blocks_per_cu;
+  int last_grid, last_block, last_lds;
+};
+
+namespace {
+
+inline bool hip_ok(hipError_t e) { return e == hipSuccess; }
+
+/* persistent grid: enough workgroups to fill every CU at the kernel's
+   occupancy, never more than the batch needs */
+int pick_grid(const xaac_ctx *c, int n_ch) {
+  int blocks_needed = (n_ch + XAAC_IMDCT_WAVES - 1) / XAAC_IMDCT_WAVES;
+  int resident = c->num_cu * c->blocks_per_cu;
+  int g = blocks_needed < resident ? blocks_needed : resident;
+  return g < 1 ? 1 : g;
+}
+
+int32_t check_batch(const xaac_imdct_batch *b) {
+  if (!b) return XAAC_FATAL_NULL_ARG;
+  if (b->n_ch < 0) return XAAC_FATAL_BAD_ARG;
+  if (b->ch_fac != 1 && b->ch_fac != 2) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch % b->ch_fac) return XAAC_FATAL_BAD_ARG;
+  if (b->pcm_mode != XAAC_PCM_LC && b->pcm_mode != XAAC_PCM_SBR) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch > 0 && (!b->spec || !b->ics || !b->overlap || !b->state)) return XAAC_FATAL_NULL_ARG;
+  return XAAC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *xaac_version(void) { return "libxaac_amd 0.1 gfx950"; }
+
+int32_t xaac_create(xaac_ctx **out, int32_t device, void *hip_stream) {
+  if (!out) return XAAC_FATAL_NULL_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (!hip_ok(hipGetDeviceCount(&n)) || n <= 0) return XAAC_FATAL_NO_DEVICE;
+  if (device < 0 || device >= n) return XAAC_FATAL_BAD_ARG;
+  if (!hip_ok(hipSetDevice(device))) return XAAC_FATAL_HIP;
+  xaac_ctx *c = new (std::nothrow) xaac_ctx();
+  if (!c) return XAAC_FATAL_HIP;
+  c->device = device;
+  c->owns_stream = false;
+  c->stream = static_cast<hipStream_t>(hip_stream);
+  if (!hip_stream) {
+    if (!hip_ok(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking))) {
+      delete c;
+      return XAAC_FATAL_HIP;
+    }
+    c->owns_stream = true;
+  }
+  hipDeviceProp_t prop;
+  if (!hip_ok(hipGetDeviceProperties(&prop, device))) {
+    if (c->owns_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return XAAC_FATAL_HIP;
+  }
+  c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  c->blocks_per_cu = xaac_imdct_blocks_per_cu();
+  c->last_grid = c->last_block = c->last_lds = 0;
+  *out = c;
+  return XAAC_OK;
+}
+
+int32_t xaac_destroy(xaac_ctx *c) {
+  if (!c) return XAAC_FATAL_NULL_ARG;
+  if (c->owns_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return XAAC_OK;
+}
+
+int32_t xaac_sync(xaac_ctx *c) {
+  if (!c) return XAAC_FATAL_NULL_ARG;
+  return hip_ok(hipStreamSynchronize(c->stream)) ? XAAC_OK : XAAC_FATAL_HIP;
+}
+
+int32_t xaac_imdct_process_batch(xaac_ctx *c, const xaac_imdct_batch *b) {
+  if (!c) return XAAC_FATAL_NULL_ARG;
+  int32_t rc = check_batch(b);
+  if (rc != XAAC_OK) return rc;
+  if (b->n_ch == 0) return XAAC_OK;
+  XaacImdctParams p;
+  p.n_ch = b->n_ch;
+  p.ch_fac = b->ch_fac;
+  p.spec = b->spec;
+  p.ics = b->ics;
+  p.overlap = b->overlap;
+  p.state = b->state;
+  p.out32 = b->out32;
+  p.pcm16 = b->pcm16;
+  p.qshift_adj = b->qshift_adj;
+  p.pcm_mode = b->pcm_mode;
+  int grid = pick_grid(c, b->n_ch);
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  if (!hip_ok(xaac_launch_imdct(&p, grid, c->stream))) return XAAC_FATAL_HIP;
+  c->last_grid = grid;
+  c->last_block = XAAC_IMDCT_BLOCK;
+  c->last_lds = XAAC_IMDCT_LDS_BYTES;
+  return XAAC_OK;
+}
+
+int32_t xaac_imdct_process_batch_host(xaac_ctx *c, const xaac_imdct_batch *hb) {
+  if (!c) return XAAC_FATAL_NULL_ARG;
+  int32_t rc = check_batch(hb);
+  if (rc != XAAC_OK) return rc;
+  const size_t n = (size_t)hb->n_ch;
+  if (n == 0) return XAAC_OK;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  const size_t sz_spec = n * 1024 * 4, sz_ics = n * sizeof(xaac_ics_info), sz_ovl = n * 512 * 4,
+               sz_st = n * sizeof(xaac_ovl_state), sz_o32 = hb->out32 ? n * 1024 * 4 : 0,
+               sz_pcm = hb->pcm16 ? n * 1024 * 2 : 0, sz_q = hb->qshift_adj ? n : 0;
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t total = up(sz_spec) + up(sz_ics) + up(sz_ovl) + up(sz_st) + up(sz_o32) + up(sz_pcm) + up(sz_q);
+  char *d = nullptr;
+  if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d), total))) return XAAC_FATAL_HIP;
+  char *cur = d;
+  auto carve = [&](size_t v) {
+    char *r = cur;
+    cur += up(v);
+    return r;
+  };
+  xaac_imdct_batch db = *hb;
+  char *d_spec = carve(sz_spec), *d_ics = carve(sz_ics), *d_ovl = carve(sz_ovl), *d_st = carve(sz_st);
+  char *d_o32 = carve(sz_o32), *d_pcm = carve(sz_pcm), *d_q = carve(sz_q);
+  db.spec = reinterpret_cast<const int32_t *>(d_spec);
+  db.ics = reinterpret_cast<const xaac_ics_info *>(d_ics);
+  db.overlap = reinterpret_cast<int32_t *>(d_ovl);
+  db.state = reinterpret_cast<xaac_ovl_state *>(d_st);
+  db.out32 = hb->out32 ? reinterpret_cast<int32_t *>(d_o32) : nullptr;
+  db.pcm16 = hb->pcm16 ? reinterpret_cast<int16_t *>(d_pcm) : nullptr;
+  db.qshift_adj = hb->qshift_adj ? reinterpret_cast<int8_t *>(d_q) : nullptr;
+  bool ok = hip_ok(hipMemcpyAsync(d_spec, hb->spec, sz_spec, hipMemcpyHostToDevice, c->stream)) &&
+            hip_ok(hipMemcpyAsync(d_ics, hb->ics, sz_ics, hipMemcpyHostToDevice, c->stream)) &&
+            hip_ok(hipMemcpyAsync(d_ovl, hb->overlap, sz_ovl, hipMemcpyHostToDevice, c->stream)) &&
+            hip_ok(hipMemcpyAsync(d_st, hb->state, sz_st, hipMemcpyHostToDevice, c->stream));
+  if (ok) {
+    rc = xaac_imdct_process_batch(c, &db);
+    ok = (rc == XAAC_OK);
+  }
+  if (ok) {
+    ok = hip_ok(hipMemcpyAsync(hb->overlap, d_ovl, sz_ovl, hipMemcpyDeviceToHost, c->stream)) &&
+         hip_ok(hipMemcpyAsync(hb->state, d_st, sz_st, hipMemcpyDeviceToHost, c->stream));
+    if (ok && sz_o32) ok = hip_ok(hipMemcpyAsync(hb->out32, d_o32, sz_o32, hipMemcpyDeviceToHost, c->stream));
+    if (ok && sz_pcm) ok = hip_ok(hipMemcpyAsync(hb->pcm16, d_pcm, sz_pcm, hipMemcpyDeviceToHost, c->stream));
+    if (ok && sz_q) ok = hip_ok(hipMemcpyAsync(hb->qshift_adj, d_q, sz_q, hipMemcpyDeviceToHost, c->stream));
+  }
+  bool synced = hip_ok(hipStreamSynchronize(c->stream));
+  (void)hipFree(d);
+  if (rc != XAAC_OK) return rc;
+  return (ok && synced) ? XAAC_OK : XAAC_FATAL_HIP;
+}
+
+int32_t xaac_last_launch(xaac_ctx *c, int32_t *grid, int32_t *block, int32_t *lds_bytes) {
+  if (!c) return XAAC_FATAL_NULL_ARG;
+  if (grid) *grid = c->last_grid;
+  if (block) *block = c->last_block;
+  if (lds_bytes) *lds_bytes = c->last_lds;
+  return XAAC_OK;
+}
+
+}  // extern "C"

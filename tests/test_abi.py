@@ -1,0 +1,52 @@
+"""The C-ABI library loads on a GPU-less box and exports every symbol that
+include/xaac_amd.h declares; argument errors follow the reference's error-code
+convention.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import libxaac_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    txt = open(os.path.join(ROOT, "include", "xaac_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(xaac_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = libxaac_amd.load_library()
+    names = _declared_functions()
+    assert "xaac_imdct_process_batch" in names and "xaac_create" in names
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_version_string():
+    assert b"gfx950" in libxaac_amd.load_library().xaac_version()
+
+
+def test_null_and_bad_arguments_are_fatal_codes():
+    lib = libxaac_amd.load_library()
+    assert lib.xaac_create(None, 0, None) & 0x80000000
+    assert lib.xaac_destroy(None) & 0x80000000
+    assert lib.xaac_sync(None) & 0x80000000
+    assert lib.xaac_imdct_process_batch(None, None) & 0x80000000
+
+
+def test_struct_layout_matches_header():
+    # 2 x int32 + 7 pointers + int32 (+ tail padding) on LP64
+    assert ctypes.sizeof(libxaac_amd._ImdctBatch) == 72
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(libxaac_amd.XaacError) as e:
+        libxaac_amd.XaacContext(0)
+    assert e.value.code == 0xFFFF8002

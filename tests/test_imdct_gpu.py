@@ -1,0 +1,192 @@
+"""Parity tests proper: the HIP path through the C ABI vs the oracle
+(oracle/oracle_imdct.c, itself pinned to the reference) and vs the committed
+reference-generated vectors.  Bit-exact: integer path."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    import libxaac_amd
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    c = libxaac_amd.XaacContext(0, torch.cuda.current_stream().cuda_stream)
+    yield c
+    c.close()
+
+
+def run_gpu(ctx, spec, ics, ovl, state, ch_fac=1, pcm_mode=0, want_out32=True, want_pcm=True):
+    import torch
+    n = spec.shape[0]
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    t_spec, t_ics, t_ovl, t_state = d(spec), d(ics), d(ovl), d(state)
+    spec_before = t_spec.clone()
+    out32 = torch.full((n * 1024,), 0x5A5A5A5A, dtype=torch.int32, device="cuda") if want_out32 else None
+    pcm = torch.full((n * 1024,), 0x5A5A, dtype=torch.int16, device="cuda") if want_pcm else None
+    qadj = torch.full((n,), 99, dtype=torch.int8, device="cuda")
+    ctx.imdct_process_batch(t_spec, t_ics, t_ovl, t_state, out32, pcm, qadj, ch_fac=ch_fac, pcm_mode=pcm_mode)
+    torch.cuda.synchronize()
+    assert torch.equal(t_spec, spec_before), "spec must not be modified"
+    return {"out32": out32.cpu().numpy().reshape(n, 1024) if want_out32 else None,
+            "pcm16": pcm.cpu().numpy().reshape(n, 1024) if want_pcm else None,
+            "qshift_adj": qadj.cpu().numpy(), "overlap": t_ovl.cpu().numpy(), "state": t_state.cpu().numpy()}
+
+
+def assert_same(got, want, keys=("out32", "pcm16", "qshift_adj", "overlap", "state")):
+    for k in keys:
+        if got[k] is None:
+            continue
+        if not np.array_equal(got[k], want[k]):
+            bad = np.argwhere(np.asarray(got[k]) != np.asarray(want[k]))
+            raise AssertionError("%s differs at %d places, first %s: got %s want %s" % (
+                k, len(bad), bad[0], np.asarray(got[k])[tuple(bad[0])], np.asarray(want[k])[tuple(bad[0])]))
+
+
+def test_reference_golden_vectors(ctx):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "imdct_ref.npz"))
+    ics = np.ascontiguousarray(g["meta"][:, 2:4])
+    state = np.ascontiguousarray(g["meta"][:, 0:2])
+    r = run_gpu(ctx, g["spec"], ics, g["ovl"], state)
+    assert np.array_equal(r["out32"], g["out"])
+    assert np.array_equal(r["overlap"], g["ovl_out"])
+    assert np.array_equal(r["qshift_adj"], g["qadj"])
+    assert np.array_equal(r["state"], ics)
+
+
+@pytest.mark.parametrize("seq", [0, 1, 2, 3])
+@pytest.mark.parametrize("pseq", [0, 1, 2, 3])
+def test_every_window_transition(ctx, oracle, seq, pseq):
+    rng = np.random.default_rng(50 + 4 * seq + pseq)
+    n = 256
+    spec, ovl = oracle_lib.random_case(rng, n)
+    spec[0] = 0
+    spec[1] = np.int32(-2 ** 31)
+    spec[2] = np.int32(2 ** 31 - 1)
+    ovl[3] = np.int32(2 ** 31 - 1)
+    ovl[4] = np.int32(-2 ** 31)
+    ics = np.stack([np.full(n, seq), rng.integers(0, 2, n)], 1).astype(np.uint8)
+    state = np.stack([np.full(n, pseq), rng.integers(0, 2, n)], 1).astype(np.uint8)
+    for mode in (0, 1):
+        assert_same(run_gpu(ctx, spec, ics, ovl, state, pcm_mode=mode),
+                    oracle.imdct_batch(spec, ics, ovl, state, pcm_mode=mode))
+
+
+@pytest.mark.parametrize("ch_fac", [1, 2])
+def test_mixed_batch_and_interleave(ctx, oracle, ch_fac):
+    """ragged mix of every transition in one launch, stereo interleave, n not a multiple of the grid"""
+    rng = np.random.default_rng(77 + ch_fac)
+    n = 2 * 1237
+    spec, ovl = oracle_lib.random_case(rng, n)
+    ics = np.stack([rng.integers(0, 4, n), rng.integers(0, 2, n)], 1).astype(np.uint8)
+    state = np.stack([rng.integers(0, 4, n), rng.integers(0, 2, n)], 1).astype(np.uint8)
+    assert_same(run_gpu(ctx, spec, ics, ovl, state, ch_fac=ch_fac),
+                oracle.imdct_batch(spec, ics, ovl, state, ch_fac=ch_fac))
+
+
+def test_optional_outputs_and_empty_batch(ctx, oracle):
+    rng = np.random.default_rng(5)
+    spec, ovl = oracle_lib.random_case(rng, 64)
+    ics = np.zeros((64, 2), np.uint8)
+    state = np.zeros((64, 2), np.uint8)
+    want = oracle.imdct_batch(spec, ics, ovl, state)
+    assert_same(run_gpu(ctx, spec, ics, ovl, state, want_out32=False), want)
+    assert_same(run_gpu(ctx, spec, ics, ovl, state, want_pcm=False), want)
+    import torch
+    e = lambda dt, *s: torch.zeros(s, dtype=dt, device="cuda")
+    ctx.imdct_process_batch(e(torch.int32, 0, 1024), e(torch.uint8, 0, 2), e(torch.int32, 0, 512), e(torch.uint8, 0, 2))
+    ctx.sync()
+
+
+def test_stream_chain_state_carried_on_device(ctx, oracle):
+    """64 streams x 40 frames: overlap + window state stay on the GPU between launches"""
+    import torch
+    rng = np.random.default_rng(11)
+    ns, nf = 64, 40
+    nxt = {0: [0, 0, 0, 1], 1: [2, 3], 2: [2, 3], 3: [0, 1]}
+    seq = np.zeros(ns, np.int64)
+    o_ovl = np.zeros((ns, 512), np.int32)
+    o_state = np.zeros((ns, 2), np.uint8)
+    t_ovl = torch.zeros((ns, 512), dtype=torch.int32, device="cuda")
+    t_state = torch.zeros((ns, 2), dtype=torch.uint8, device="cuda")
+    for f in range(nf):
+        spec = rng.integers(-(1 << 17), 1 << 17, (ns, 1024)).astype(np.int32)
+        spec[:, 640:] = 0
+        ics = np.stack([seq, rng.integers(0, 2, ns)], 1).astype(np.uint8)
+        want = oracle.imdct_batch(spec, ics, o_ovl, o_state)
+        o_ovl, o_state = want["overlap"], want["state"]
+        pcm = torch.zeros(ns * 1024, dtype=torch.int16, device="cuda")
+        ctx.imdct_process_batch(torch.from_numpy(spec).cuda(), torch.from_numpy(ics).cuda(), t_ovl, t_state,
+                                None, pcm, None)
+        torch.cuda.synchronize()
+        assert np.array_equal(pcm.cpu().numpy().reshape(ns, 1024), want["pcm16"]), f
+        assert np.array_equal(t_ovl.cpu().numpy(), o_ovl), f
+        seq = np.array([rng.choice(nxt[int(s)]) for s in seq])
+
+
+def test_full_size_batch_properties(ctx, oracle):
+    """BASELINE config C2 size: 8192 stereo frames = 16384 channel-frames in one launch.
+    Checked through size-independent properties + an oracle spot check:
+      * silence in, silence out; overlap stays zero
+      * batch result is independent of position: a tile of 256 distinct frames repeated 64x
+        gives 64 identical output tiles (checksum of checksums)
+      * 512 sampled channel-frames match the oracle exactly"""
+    import torch
+    rng = np.random.default_rng(2026)
+    tile, reps = 256, 64
+    n = tile * reps
+    spec_t, ovl_t = oracle_lib.random_case(rng, tile, mag=17, ovl_mag=15)
+    spec_t[:, 640:] = 0
+    spec_t[0] = 0
+    ovl_t[0] = 0
+    ics_t = np.stack([np.zeros(tile), np.arange(tile) % 2], 1).astype(np.uint8)
+    ics_t[5::16, 0] = 1
+    st_t = np.zeros((tile, 2), np.uint8)
+    st_t[:, 1] = (np.arange(tile) // 2) % 2
+    spec = np.tile(spec_t, (reps, 1)); ovl = np.tile(ovl_t, (reps, 1))
+    ics = np.tile(ics_t, (reps, 1)); state = np.tile(st_t, (reps, 1))
+    r = run_gpu(ctx, spec, ics, ovl, state, ch_fac=2, want_out32=False)
+    pcm = r["pcm16"].reshape(reps, tile * 1024)
+    assert (pcm == pcm[0]).all(), "identical input tiles must give identical output tiles"
+    assert (r["overlap"].reshape(reps, tile * 512) == r["overlap"][:tile].reshape(-1)).all()
+    want = oracle.imdct_batch(spec_t, ics_t, ovl_t, st_t, ch_fac=2)
+    assert np.array_equal(r["pcm16"][:tile], want["pcm16"])
+    assert np.array_equal(r["overlap"][:tile], want["overlap"])
+    assert not want["pcm16"].reshape(tile // 2, 1024, 2)[0, :, 0].any(), "silent channel stays silent"
+
+
+def test_host_buffer_entry_point(ctx, oracle):
+    rng = np.random.default_rng(3)
+    n = 130
+    spec, ovl = oracle_lib.random_case(rng, n)
+    ics = np.stack([rng.integers(0, 4, n), rng.integers(0, 2, n)], 1).astype(np.uint8)
+    state = np.stack([rng.integers(0, 4, n), rng.integers(0, 2, n)], 1).astype(np.uint8)
+    want = oracle.imdct_batch(spec, ics, ovl, state)
+    h_ovl, h_state = ovl.copy(), state.copy()
+    out32 = np.zeros(n * 1024, np.int32); pcm = np.zeros(n * 1024, np.int16); q = np.zeros(n, np.int8)
+    ctx.imdct_process_batch_host(spec, ics, h_ovl, h_state, out32, pcm, q)
+    assert np.array_equal(out32.reshape(n, 1024), want["out32"])
+    assert np.array_equal(pcm.reshape(n, 1024), want["pcm16"])
+    assert np.array_equal(h_ovl, want["overlap"]) and np.array_equal(h_state, want["state"])
+    assert np.array_equal(q, want["qshift_adj"])
+
+
+def test_bad_arguments_rejected(ctx):
+    import torch
+    import libxaac_amd
+    z = lambda dt, *s: torch.zeros(s, dtype=dt, device="cuda")
+    with pytest.raises(libxaac_amd.XaacError):  # odd n_ch with ch_fac 2
+        ctx.imdct_process_batch(z(torch.int32, 3, 1024), z(torch.uint8, 3, 2), z(torch.int32, 3, 512),
+                                z(torch.uint8, 3, 2), ch_fac=2)
+    with pytest.raises(libxaac_amd.XaacError):
+        ctx.imdct_process_batch(z(torch.int32, 2, 1024), z(torch.uint8, 2, 2), z(torch.int32, 2, 512),
+                                z(torch.uint8, 2, 2), ch_fac=3)
+    with pytest.raises((ValueError, TypeError)):
+        ctx.imdct_process_batch(z(torch.int32, 2, 1024).cpu(), z(torch.uint8, 2, 2), z(torch.int32, 2, 512),
+                                z(torch.uint8, 2, 2))

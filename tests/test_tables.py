@@ -1,0 +1,51 @@
+"""The generated constant tables (tools/gen_tables.py -> tables_imdct.inc)."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def _parse_inc():
+    txt = open(os.path.join(ROOT, "libxaac_amd", "csrc", "tables_imdct.inc")).read()
+    out = {}
+    for m in re.finditer(r"xaac_tab_(\w+)\[(\d+)\] = \{([^}]*)\}", txt):
+        vals = np.array([int(v) for v in m.group(3).replace("\n", " ").split(",") if v.strip()], np.int64)
+        assert len(vals) == int(m.group(2))
+        out[m.group(1)] = vals
+    return out
+
+
+def test_committed_include_matches_generator():
+    import gen_tables
+    t = gen_tables.tables()
+    inc = _parse_inc()
+    for name in ("pre_cs", "win_long_sine", "win_long_kbd", "win_short_sine", "win_short_kbd", "digrev_long"):
+        assert np.array_equal(inc[name], t[name]), name
+    assert np.array_equal(inc["fft_tw"] >> 16, t["fft_tw_hi"])
+
+
+def test_window_power_complementarity():
+    """Princen-Bradley: w[i]^2 + w[N-1-i]^2 == 1 (to table precision) for every window"""
+    inc = _parse_inc()
+    for name in ("win_long_sine", "win_long_kbd", "win_short_sine", "win_short_kbd"):
+        w = inc[name].astype(np.float64) / 32768.0
+        s = w[0::2] ** 2 + w[1::2] ** 2
+        assert np.max(np.abs(s - 1.0)) < 1e-4, name
+
+
+def test_tables_equal_reference_rom():
+    import derive_table_fixups as d
+    so = os.path.join(ROOT, "oracle", "_ref", "libxaacdec_ref.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref not built")
+    import gen_tables
+    ref = d.reference_tables(so)
+    mine = gen_tables.tables()
+    for name, want in ref.items():
+        assert np.array_equal(mine[name], want), name
