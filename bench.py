@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- decoded audio frames/s of the MI355X transform back-end.
+
+Workload (BASELINE.json configs[1], SURVEY.md §8d "C2"): AAC-LC 48 kHz stereo,
+batch = 8192 frames per step = 16384 channel-frames through the 1024-sample
+IMDCT + window/overlap-add kernel with the fused PCM16 hand-off, stereo
+interleaved output.  Synthetic spectra (seeded, uniform in +-2^17 below bin 640,
+zero above; ONLY_LONG, window shape alternating per frame), overlap state
+carried in HBM.  Each rank owns `--sets` x 8192 independent streams and decodes
+one frame of 8192 of them per step, round-robin, so the working set (> 256 MiB)
+streams from HBM rather than from the Infinity Cache.
+
+A "step" = one pass of the hot path over one batch (one kernel launch).
+Inputs are resident in HBM before the timed region.  `value` = frames decoded by
+all ranks / wall time (max over ranks).  `roofline.achieved` = algorithmic bytes
+per launch (20480 B per stereo frame) / mean kernel duration from
+HIP events recorded on the launch stream.  `cpu_baseline` = the same workload on
+the host cores (the compiled reference when oracle/_ref travelled with the repo,
+else the bit-exact C restatement), bounded sample, rank 0 at N=1 only.
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FRAMES_PER_STEP = 8192          # stereo frames per batch (BASELINE configs[1])
+CH = 2
+ALG_BYTES_PER_FRAME = 20480     # R spec 2x4096 + ovl 2x2048, W pcm16 2x2048 + ovl 2x2048
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def make_inputs(torch, device, sets, seed):
+    """`sets` batches of 16384 channel-frames, generated on the device."""
+    g = torch.Generator(device=device)
+    g.manual_seed(0xC0FFEE + seed)
+    n = FRAMES_PER_STEP * CH
+    batches = []
+    for s in range(sets):
+        spec = torch.randint(-(1 << 17), 1 << 17, (n, 1024), generator=g, device=device, dtype=torch.int32)
+        spec[:, 640:] = 0
+        ics = torch.zeros((n, 2), dtype=torch.uint8, device=device)
+        batches.append({
+            "spec": spec, "ics": ics,
+            "overlap": torch.zeros((n, 512), dtype=torch.int32, device=device),
+            "state": torch.zeros((n, 2), dtype=torch.uint8, device=device),
+            "pcm": torch.zeros(n * 1024, dtype=torch.int16, device=device),
+        })
+    return batches
+
+
+def cpu_baseline(seconds_budget=12.0):
+    """Time the CPU path on a bounded sample of the same workload (all host cores,
+    one contiguous shard of channel-frames per thread)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    P32, P16, PU8 = oracle_lib.P32, oracle_lib.P16, oracle_lib.PU8
+    ref = oracle_lib.load_reference()
+    kind = "reference" if ref is not None and hasattr(ref.lib, "ref_imdct_batch") else "port"
+    orc = oracle_lib.load_oracle()
+    cores = os.cpu_count() or 1
+    per_thread = max(256, min(2048, 131072 // cores))   # channel-frames per thread per pass
+    rng = np.random.default_rng(0xC0FFEE)
+    n = per_thread * cores
+    spec0 = rng.integers(-(1 << 17), 1 << 17, (n, 1024)).astype(np.int32)
+    spec0[:, 640:] = 0
+    ovl = np.zeros((n, 512), np.int32)
+    pseq = np.zeros(n, np.int16); pshape = np.zeros(n, np.int16)
+    seq = np.zeros(n, np.uint8); shape = (np.arange(n) % 2).astype(np.uint8)
+    pcm = np.zeros((n, 1024), np.int16)
+    spec = spec0.copy()
+
+    def shard(t):
+        a, b = t * per_thread, (t + 1) * per_thread
+        p = oracle_lib._p
+        if kind == "reference":
+            ref.lib.ref_imdct_batch(per_thread, p(spec[a:b], P32), p(ovl[a:b], P32), p(pseq[a:b], P16),
+                                    p(pshape[a:b], P16), p(seq[a:b], PU8), p(shape[a:b], PU8), p(pcm[a:b], P16))
+        else:
+            orc.lib.xo_imdct_batch(per_thread, p(spec[a:b], P32), p(ovl[a:b], P32), p(pseq[a:b], P16),
+                                   p(pshape[a:b], P16), p(seq[a:b], PU8), p(shape[a:b], PU8), None,
+                                   p(pcm[a:b], P16), None, 0)
+
+    if kind == "reference":
+        ref.lib.ref_imdct_batch.restype = None
+        ref.lib.ref_imdct_batch.argtypes = [ctypes.c_int, P32, P32, P16, P16, PU8, PU8, P16]
+
+    def one_pass(nthreads):
+        if kind == "reference":
+            spec[:] = spec0           # the reference transforms its input in place
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=shard, args=(t,)) for t in range(nthreads)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        return time.perf_counter() - t0
+
+    one_pass(cores)                   # warm
+    t1 = min(one_pass(1) for _ in range(2))
+    passes, spent, best = 0, 0.0, 1e9
+    while spent < seconds_budget and passes < 2000:
+        dt = one_pass(cores)
+        best = min(best, dt)
+        spent += dt
+        passes += 1
+    frames = n / CH
+    return {"value": round(frames / best, 1), "unit": "frames/s", "cores": cores, "kind": kind,
+            "value_1core": round(per_thread / CH / t1, 1),
+            "sample": "%d stereo frames (%d channel-frames) per pass, %d passes, one %d-channel-frame shard per "
+                      "thread, same synthetic C2 input" % (frames, n, passes, per_thread)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--sets", type=int, default=4, help="independent 8192-stream batches cycled per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import libxaac_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert torch.cuda.is_available(), "bench.py needs a GPU; the product has no CPU path"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    stream = torch.cuda.Stream(device=dev)      # kernels AND timing events go on this one stream
+    torch.cuda.set_stream(stream)
+    ctx = libxaac_amd.XaacContext(local_rank, stream.cuda_stream)
+    batches = make_inputs(torch, dev, args.sets, rank)
+    for b in batches:                 # window shape alternates per frame; state follows
+        b["ics"][:, 1] = (torch.arange(b["ics"].shape[0], device=dev) // CH % 2).to(torch.uint8)
+
+    def step(i, ev=None):
+        b = batches[i % len(batches)]
+        if ev is not None:
+            ev[0].record(stream)
+        ctx.imdct_process_batch(b["spec"], b["ics"], b["overlap"], b["state"], None, b["pcm"], None,
+                                ch_fac=CH, pcm_mode=libxaac_amd.PCM_LC)
+        if ev is not None:
+            ev[1].record(stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, events[i])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
+
+    # the run stays honest: decode one more frame of set 0 and compare a slice with the oracle
+    checked = None
+    if rank == 0:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib
+            orc = oracle_lib.load_oracle()
+            b = batches[0]
+            k = 256
+            h = {n_: b[n_][:k].cpu().numpy() for n_ in ("spec", "ics", "overlap", "state")}
+            want = orc.imdct_batch(h["spec"], h["ics"], h["overlap"], h["state"], ch_fac=CH)
+            step(0)
+            torch.cuda.synchronize()
+            checked = bool(np.array_equal(b["pcm"][:k * 1024].cpu().numpy().reshape(k, 1024), want["pcm16"]) and
+                           np.array_equal(b["overlap"][:k].cpu().numpy(), want["overlap"]))
+        except Exception as e:  # the checker is optional for the measurement itself
+            checked = "unavailable: %s" % e
+
+    if rank == 0:
+        frames = FRAMES_PER_STEP * args.steps * world
+        alg_bytes = ALG_BYTES_PER_FRAME * FRAMES_PER_STEP
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "decoded audio frames/s (1024-spl IMDCT+overlap-add, AAC-LC stereo)",
+            "value": round(frames / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+            "data": "synthetic",
+            "config": {"workload": "C2: AAC-LC 48 kHz stereo, batch=8192 frames/step (16384 channel-frames), "
+                                   "ONLY_LONG 1024-pt IMDCT + window/overlap-add + PCM16, %d stream sets cycled"
+                                   % args.sets,
+                       "frames_per_step": FRAMES_PER_STEP, "channels": CH, "launch": ctx.last_launch(),
+                       "sharding": "streams split across ranks, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "xaac_imdct_ola_kernel", "kernel_ms": round(kern_ms, 5),
+                         "alg_bytes_per_launch": alg_bytes},
+            "bit_exact_vs_oracle": checked,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -92,6 +92,9 @@ typedef struct xaac_ctx xaac_ctx;
  * hipStream_t to launch on (NULL: the context creates and owns one). */
 int32_t xaac_create(xaac_ctx **ctx, int32_t device, void *hip_stream);
 int32_t xaac_destroy(xaac_ctx *ctx);
+/* Rebind the context to another hipStream_t; NULL here means the device's
+ * legacy null stream (unlike xaac_create, nothing is created). */
+int32_t xaac_set_stream(xaac_ctx *ctx, void *hip_stream);
 /* Block until everything queued on the context's stream has finished. */
 int32_t xaac_sync(xaac_ctx *ctx);
 

@@ -55,6 +55,13 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64 and owns the
+    # streams / device memory handed to the C ABI, so it must be the copy that
+    # libxaac_amd.so binds to -- import torch first whenever it is installed.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = library_path()
     if not os.path.exists(path):
         raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -64,10 +71,11 @@ def load_library():
     lib.xaac_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_void_p]
     lib.xaac_destroy.argtypes = [ctypes.c_void_p]
     lib.xaac_sync.argtypes = [ctypes.c_void_p]
+    lib.xaac_set_stream.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.xaac_imdct_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_ImdctBatch)]
     lib.xaac_imdct_process_batch_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(_ImdctBatch)]
     lib.xaac_last_launch.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int32)] * 3
-    for f in ("xaac_create", "xaac_destroy", "xaac_sync", "xaac_imdct_process_batch",
+    for f in ("xaac_create", "xaac_destroy", "xaac_sync", "xaac_set_stream", "xaac_imdct_process_batch",
               "xaac_imdct_process_batch_host", "xaac_last_launch"):
         getattr(lib, f).restype = ctypes.c_int32
     _lib = lib
@@ -105,13 +113,22 @@ class XaacContext:
     """One context per GPU / stream (xaac_create ... xaac_destroy)."""
 
     def __init__(self, device=0, stream_handle=None):
+        """stream_handle: a hipStream_t as an int (e.g. torch.cuda.Stream().cuda_stream; 0 = the
+        legacy null stream); None lets the library create and own a stream."""
         self._lib = load_library()
         h = ctypes.c_void_p()
-        rc = self._lib.xaac_create(ctypes.byref(h), int(device), ctypes.c_void_p(stream_handle or 0))
+        rc = self._lib.xaac_create(ctypes.byref(h), int(device), None)
         if rc != 0:
             raise XaacError(rc, "xaac_create")
         self._h = h
         self.device = device
+        if stream_handle is not None:
+            self.set_stream(stream_handle)
+
+    def set_stream(self, stream_handle):
+        rc = self._lib.xaac_set_stream(self._h, ctypes.c_void_p(int(stream_handle)))
+        if rc != 0:
+            raise XaacError(rc, "xaac_set_stream")
 
     def close(self):
         if getattr(self, "_h", None):

@@ -91,6 +91,14 @@ int32_t xaac_destroy(xaac_ctx *c) {
   return XAAC_OK;
 }
 
+int32_t xaac_set_stream(xaac_ctx *c, void *hip_stream) {
+  if (!c) return XAAC_FATAL_NULL_ARG;
+  if (c->owns_stream) (void)hipStreamDestroy(c->stream);
+  c->owns_stream = false;
+  c->stream = static_cast<hipStream_t>(hip_stream);
+  return XAAC_OK;
+}
+
 int32_t xaac_sync(xaac_ctx *c) {
   if (!c) return XAAC_FATAL_NULL_ARG;
   return hip_ok(hipStreamSynchronize(c->stream)) ? XAAC_OK : XAAC_FATAL_HIP;

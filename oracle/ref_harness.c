@@ -58,7 +58,7 @@
  * returns ics.qshift_adj */
 int ref_imdct_process(WORD32 *spec, WORD32 *overlap, WORD16 *prev_seq, WORD16 *prev_shape,
                       int seq, int shape, WORD32 *out, int ch_fac) {
-  static WORD32 scratch[2048];
+  static __thread WORD32 scratch[2048];
   ia_aac_dec_overlap_info oi;
   ia_ics_info_struct ics;
   ia_aac_dec_tables_struct tabs;
@@ -81,4 +81,20 @@ int ref_imdct_process(WORD32 *spec, WORD32 *overlap, WORD16 *prev_seq, WORD16 *p
   *prev_seq = oi.window_sequence;
   *prev_shape = oi.window_shape;
   return ics.qshift_adj;
+}
+
+/* n channel-frames in a C loop (for timing the reference as the CPU baseline):
+ * per channel c: spec[c][1024] (clobbered), overlap[c][512], prev_seq/prev_shape[c],
+ * seq/shape[c]; writes PCM16 at stride 1 per channel like ixheaacd_scale_adjust +
+ * round16 would (AAC-LC, limiter off).  Thread-safe across disjoint channel ranges. */
+void ref_imdct_batch(int n, WORD32 *spec, WORD32 *overlap, WORD16 *prev_seq, WORD16 *prev_shape,
+                     const UWORD8 *seq, const UWORD8 *shape, WORD16 *pcm) {
+  WORD32 out[1024];
+  int c, i;
+  for (c = 0; c < n; c++) {
+    int q = ref_imdct_process(spec + 1024 * (size_t)c, overlap + 512 * (size_t)c, prev_seq + c, prev_shape + c,
+                              seq[c], shape[c], out, 1);
+    if (pcm)
+      for (i = 0; i < 1024; i++) pcm[1024 * (size_t)c + i] = ixheaac_round16((WORD32)((UWORD32)out[i] << q));
+  }
 }
