@@ -42,25 +42,26 @@ FX_HD int32_t fx_sat64(int64_t v) {
 }
 FX_HD int32_t fx_add_sat(int32_t a, int32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  /* branch-free overflow test; same clamp as the 64-bit form */
-  int32_t s = fx_add(a, b);
-  int32_t ovf = (~(a ^ b)) & (a ^ s);
-  return ovf < 0 ? (a < 0 ? FX_MIN32 : FX_MAX32) : s;
+  return __builtin_elementwise_add_sat(a, b); /* v_add_i32 ... clamp: the same two-sided clamp */
 #else
   return fx_sat64((int64_t)a + (int64_t)b);
 #endif
 }
 FX_HD int32_t fx_sub_sat(int32_t a, int32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  int32_t d = fx_sub(a, b);
-  int32_t ovf = (a ^ b) & (a ^ d);
-  return ovf < 0 ? (a < 0 ? FX_MIN32 : FX_MAX32) : d;
+  return __builtin_elementwise_sub_sat(a, b); /* v_sub_i32 ... clamp */
 #else
   return fx_sat64((int64_t)a - (int64_t)b);
 #endif
 }
 /* basic_ops32.h:317-327 */
-FX_HD int32_t fx_neg_sat(int32_t a) { return a == FX_MIN32 ? FX_MAX32 : -a; }
+FX_HD int32_t fx_neg_sat(int32_t a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_elementwise_sub_sat(0, a);
+#else
+  return a == FX_MIN32 ? FX_MAX32 : -a;
+#endif
+}
 /* basic_ops32.h:295-307 */
 FX_HD int32_t fx_abs_sat(int32_t a) { return a == FX_MIN32 ? FX_MAX32 : (a < 0 ? -a : a); }
 /* basic_ops32.h:283-293 */

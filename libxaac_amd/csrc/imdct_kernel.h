@@ -11,6 +11,9 @@
 
 #define XAAC_IMDCT_WAVES 4                       /* independent waves per workgroup */
 #define XAAC_IMDCT_BLOCK (64 * XAAC_IMDCT_WAVES)
+#ifndef XAAC_IMDCT_MIN_WAVES_PER_SIMD
+#define XAAC_IMDCT_MIN_WAVES_PER_SIMD 4         /* register budget: <= 128 VGPRs */
+#endif
 #define XAAC_IMDCT_LDS_WIN_BYTES 4608            /* 2x1024 + 2x128 int16 windows */
 #define XAAC_IMDCT_LDS_WAVE_WORDS (1024 + 512)   /* exchange tile + old-overlap copy */
 #define XAAC_IMDCT_LDS_CONST_WORDS (1024 + 2 * 448) /* rotation pairs + pass-2/3 twiddles, lane-major */

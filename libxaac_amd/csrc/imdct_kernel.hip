@@ -37,6 +37,12 @@
 
 namespace {
 
+/* LDS-qualified element types: the out-of-line rare paths take these so that they
+   use ds_read/ds_write and not FLAT addressing (a flat base address that dips below
+   the LDS aperture before its immediate offset is added faults on gfx950). */
+typedef __attribute__((address_space(3))) int32_t lds_i32;
+typedef __attribute__((address_space(3))) int16_t lds_i16;
+
 struct cpx {
   int32_t re, im;
 };
@@ -240,9 +246,8 @@ __device__ __forceinline__ void long_transform(int32_t *buf, int lane, int e, co
 }
 
 /* EIGHT_SHORT: eight 128-sample transforms; lane = (window w, butterfly b) */
-__device__ __forceinline__ void short_transform(int32_t *buf, int lane, int e) {
+__device__ __forceinline__ void short_transform(lds_i32 *buf, int lane, int e) {
   cpx x[8], y[8];
-  int2 *Z = reinterpret_cast<int2 *>(buf);
   const int w = lane >> 3, b = lane & 7;
   const int sl = e < 0 ? -e : 0, sr = e < 0 ? 0 : e;
   int32_t rx[8], ry[8];
@@ -259,12 +264,14 @@ __device__ __forceinline__ void short_transform(int32_t *buf, int lane, int e) {
   }
   bfly8(x, y);
 #pragma unroll
-  for (int q = 0; q < 8; q++) Z[64 * w + 8 * b + q] = make_int2(y[q].re, y[q].im);
+  for (int q = 0; q < 8; q++) {
+    buf[2 * (64 * w + 8 * b + q)] = y[q].re;
+    buf[2 * (64 * w + 8 * b + q) + 1] = y[q].im;
+  }
   /* last pass (del = 8), column m = b, twiddles tw[8*m*k] */
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    int2 t = Z[64 * w + b + 8 * k];
-    x[k] = {t.x, t.y};
+    x[k] = {buf[2 * (64 * w + b + 8 * k)], buf[2 * (64 * w + b + 8 * k) + 1]};
   }
 #pragma unroll
   for (int k = 1; k < 8; k++) x[k] = twiddle(x[k], xaac_tab_fft_tw[8 * b * k]);
@@ -286,8 +293,8 @@ __device__ __forceinline__ void short_transform(int32_t *buf, int lane, int e) {
 __device__ __forceinline__ int32_t to_ovl(int32_t v, int q) { return fx_shr_rnd(v, 16 - q); }
 
 /* block.c:1193: n-point ola1; coef -> 2n block (upper half read), prev -> n old-overlap words */
-__device__ __forceinline__ void ola1(const int32_t *coef, const int32_t *prev, const Sink &sk, int obase,
-                                     const int16_t *win, int q, int n, int lane) {
+__device__ __forceinline__ void ola1(const lds_i32 *coef, const lds_i32 *prev, const Sink &sk, int obase,
+                                     const lds_i16 *win, int q, int n, int lane) {
   for (int i = lane; i < n; i += 64) {
     int16_t w1 = win[2 * n - 2 * i - 1], w2 = win[2 * n - 2 * i - 2];
     int32_t c = coef[2 * n - 1 - i], p = prev[i];
@@ -297,7 +304,7 @@ __device__ __forceinline__ void ola1(const int32_t *coef, const int32_t *prev, c
 }
 
 /* block.c:1220: value i (0..2n-1) of the short/short overlap */
-__device__ __forceinline__ int32_t ola2_value(const int32_t *coef, const int32_t *prev, const int16_t *win, int q,
+__device__ __forceinline__ int32_t ola2_value(const lds_i32 *coef, const lds_i32 *prev, const lds_i16 *win, int q,
                                               int n, int i) {
   int32_t a;
   if (i < n) {
@@ -311,8 +318,8 @@ __device__ __forceinline__ int32_t ola2_value(const int32_t *coef, const int32_t
 }
 
 /* lpfuncs.c:94: long block beside a short edge (start: edge on the left) */
-__device__ __forceinline__ void win_edge(const int32_t *y, const int32_t *ov, const Sink &sk, const int16_t *wl,
-                                         const int16_t *ws, int q, bool start, int lane) {
+__device__ __forceinline__ void win_edge(const lds_i32 *y, const lds_i32 *ov, const Sink &sk, const lds_i16 *wl,
+                                         const lds_i16 *ws, int q, bool start, int lane) {
   constexpr int u = 64;
   if (start) {
     for (int i = lane; i < 7 * u; i += 64) {
@@ -330,8 +337,8 @@ __device__ __forceinline__ void win_edge(const int32_t *y, const int32_t *ov, co
   }
   {
     const int i = lane;
-    const int16_t *wa = start ? wl + 14 * u : ws;
-    const int16_t *wb = start ? ws : wl + 14 * u;
+    const lds_i16 *wa = start ? wl + 14 * u : ws;
+    const lds_i16 *wb = start ? ws : wl + 14 * u;
     int32_t c = y[15 * u + i];
     int32_t p = start ? ov[8 * u - 1 - i] : ov[u - 1 - i];
     int16_t w1 = wa[2 * i], w2 = wa[2 * i + 1], w4 = wb[2 * i], w3 = wb[2 * i + 1];
@@ -343,9 +350,9 @@ __device__ __forceinline__ void win_edge(const int32_t *y, const int32_t *ov, co
 }
 
 /* lpfuncs.c:180-284: EIGHT_SHORT after a long-tailed frame; also yields new overlap[0..63] */
-__device__ __forceinline__ void short_after_long(const int32_t *y, const int32_t *ov, const Sink &sk,
-                                                 int32_t *ovl_out, const int16_t *wsc, const int16_t *wsp,
-                                                 const int16_t *wlp, int q, int lane) {
+__device__ __forceinline__ void short_after_long(const lds_i32 *y, const lds_i32 *ov, const Sink &sk,
+                                                 int32_t *ovl_out, const lds_i16 *wsc, const lds_i16 *wsp,
+                                                 const lds_i16 *wlp, int q, int lane) {
   constexpr int u = 64;
   for (int i = lane; i < 7 * u; i += 64) sk.put(i, nosh(ov[8 * u - 1 - i], fx_neg16(wlp[2 * i + 1])));
   const int i = lane;
@@ -355,9 +362,9 @@ __device__ __forceinline__ void short_after_long(const int32_t *y, const int32_t
                                nosh(ov[i], wlp[16 * u - 2 - 2 * i])));
   for (int b = 0; b < 4; b++) {
     int inc = 2 * u * b;
-    const int32_t *cur = y + u + inc;
-    const int32_t *pv = ov + u + inc;
-    const int16_t *wl = wlp + 2 * (7 * u - inc);
+    const lds_i32 *cur = y + u + inc;
+    const lds_i32 *pv = ov + u + inc;
+    const lds_i16 *wl = wlp + 2 * (7 * u - inc);
     int32_t c1 = cur[2 * u + i], c2 = cur[-1 - i];
     int16_t sh1 = wsc[2 * i + 1], sh2 = wsc[2 * i];
     int32_t a = fx_sub(mul16(c1, sh2), mul16(c2, sh1));
@@ -373,8 +380,8 @@ __device__ __forceinline__ void short_after_long(const int32_t *y, const int32_t
 }
 
 /* ONLY_LONG after a short edge, LONG_START, LONG_STOP (lpfuncs.c:489-655); returns qshift_adj */
-__device__ __noinline__ int long_transition_paths(const int32_t *y, const int32_t *ovs, Sink sk, int32_t *ovl,
-                                                  const int16_t *wl, const int16_t *ws, int q, int seq,
+__device__ __noinline__ int long_transition_paths(const lds_i32 *y, const lds_i32 *ovs, Sink sk, int32_t *ovl,
+                                                  const lds_i16 *wl, const lds_i16 *ws, int q, int seq,
                                                   bool prev_short_edge, int lane) {
   constexpr int u = 64;
   if (seq == XAAC_K_ONLY_LONG) { /* after LONG_START / EIGHT_SHORT */
@@ -405,21 +412,21 @@ __device__ __noinline__ int long_transition_paths(const int32_t *y, const int32_
 }
 
 /* EIGHT_SHORT (lpfuncs.c:657-798): transform + all its overlap handling; qshift_adj is always 2 */
-__device__ __noinline__ void eight_short_path(int32_t *buf, const int32_t *ovs, Sink sk, int32_t *ovl,
-                                              const int16_t *wl, const int16_t *ws, const int16_t *wsc,
+__device__ __noinline__ void eight_short_path(lds_i32 *buf, const lds_i32 *ovs, Sink sk, int32_t *ovl,
+                                              const lds_i16 *wl, const lds_i16 *ws, const lds_i16 *wsc,
                                               int headroom, bool prev_short_edge, int lane) {
   constexpr int u = 64;
   const int e = 5 - (headroom - 1);
   const int q = e + 2 + 8;
   short_transform(buf, lane, e);
-  const int32_t *y = buf;
+  const lds_i32 *y = buf;
   const int i = lane;
   if (prev_short_edge) {
     for (int n = lane; n < 7 * u; n += 64) sk.put(n, fx_shl_sat((int16_t)ovs[n], 15));
     ola1(y, ovs + 7 * u, sk, 7 * u, ws, q, u, lane);
     for (int b = 0; b < 3; b++) {
       /* ola1 against the (requantised) tail of the previous short window */
-      const int32_t *coef = y + 2 * u + 2 * u * b;
+      const lds_i32 *coef = y + 2 * u + 2 * u * b;
       int16_t w1 = wsc[2 * u - 2 * i - 1], w2 = wsc[2 * u - 2 * i - 2];
       int32_t c = coef[2 * u - 1 - i], pr = to_ovl(y[2 * u * b + i], q);
       sk.put(9 * u + 2 * u * b + u - 1 - i, fx_sub_sat(fx_shl_dir_sat_limit(mul16(c, w2), q), nosh(pr, w1)));
@@ -442,13 +449,60 @@ __device__ __noinline__ void eight_short_path(int32_t *buf, const int32_t *ovs, 
 }  // namespace
 
 /* ========================================================================= */
-__global__ __launch_bounds__(XAAC_IMDCT_BLOCK) void xaac_imdct_ola_kernel(XaacImdctParams p) {
+/* hot-path OLA (aac_imdct.c:506) for one group of four t's.  QPOS = (q_shift > 0)
+   selects the reference's two branches at compile time. */
+template <bool QPOS>
+__device__ __forceinline__ void ola_long_long4(const int32_t *y, const int16_t *wl, int t0, const int4 &old4, int q,
+                                               int32_t (&lo)[4], int32_t (&hi)[4], int4 &new4) {
+  const int4 vv = *reinterpret_cast<const int4 *>(y + 1020 - t0);       /* y[1023-t], j = 3..0 */
+  const int4 uu = *reinterpret_cast<const int4 *>(y + t0);              /* y[t]                */
+  const int4 ww = *reinterpret_cast<const int4 *>(wl + 2 * (508 - t0)); /* W32[511-t], j = 3..0 */
+  const int32_t vj[4] = {vv.w, vv.z, vv.y, vv.x};
+  const int32_t wj[4] = {ww.w, ww.z, ww.y, ww.x};
+  const int32_t oj[4] = {old4.x, old4.y, old4.z, old4.w};
+  const int32_t uj[4] = {uu.x, uu.y, uu.z, uu.w};
+  int32_t nv[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    int32_t a = fx_mul32xlo(vj[j], wj[j]);
+    int32_t b = fx_mul32xhi(fx_neg_sat(vj[j]), wj[j]);
+    int32_t o = oj[j];
+    if (QPOS) {
+      a = fx_shl_sat(a, q);
+      b = fx_shl_sat(b, q);
+    } else {
+      a = fx_shr(a, -q);
+      b = fx_shr(b, -q);
+      o = (int16_t)o; /* aac_imdct.c:679: this branch reads the overlap word as WORD16 */
+    }
+    lo[j] = fx_sub_sat(a, nosh(o, (int16_t)(wj[j] >> 16))); /* out[511-t] */
+    hi[j] = fx_sub_sat(b, nosh(o, (int16_t)wj[j]));         /* out[512+t] */
+    nv[j] = to_ovl(uj[j], q);
+  }
+  new4 = make_int4(nv[0], nv[1], nv[2], nv[3]);
+}
+
+__device__ __forceinline__ int32_t pack16(int16_t a, int16_t b) {
+  return (int32_t)((uint32_t)(uint16_t)a | ((uint32_t)(uint16_t)b << 16));
+}
+
+/* One work unit = one access unit = CF channel-frames handled back to back by
+   the same wave, so that for CF = 2 the PCM of both channels leaves as
+   interleaved 16-byte stores (channel 0 is parked in LDS meanwhile).
+   MODE = XAAC_PCM_LC / XAAC_PCM_SBR. */
+template <int CF, int MODE>
+__global__ __launch_bounds__(XAAC_IMDCT_BLOCK, XAAC_IMDCT_MIN_WAVES_PER_SIMD) void xaac_imdct_ola_kernel(
+    XaacImdctParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int16_t *s_win = reinterpret_cast<int16_t *>(smem); /* [long sine|long kbd|short sine|short kbd] */
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane_id = tid & 63;
+  /* wave index as a scalar: everything per-frame below (pointers, window sequence,
+     block exponent, branches) then lives in SGPRs and branches are s_cbranch, not exec masks */
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int32_t *s_const = reinterpret_cast<int32_t *>(smem + XAAC_IMDCT_LDS_WIN_BYTES);
   int32_t *buf = s_const + XAAC_IMDCT_LDS_CONST_WORDS + wave * XAAC_IMDCT_LDS_WAVE_WORDS;
-  int32_t *ovs = buf + 1024; /* old overlap copy for the rare paths */
+  int32_t *ovs = buf + 1024; /* 2 KB: old-overlap copy for the rare paths / parked channel-0 PCM */
+  int16_t *park = reinterpret_cast<int16_t *>(ovs);
 
   for (int i = tid; i < 1024; i += XAAC_IMDCT_BLOCK) {
     s_win[i] = xaac_tab_win_long_sine[i];
@@ -463,126 +517,168 @@ __global__ __launch_bounds__(XAAC_IMDCT_BLOCK) void xaac_imdct_ola_kernel(XaacIm
   __syncthreads();
 
   const int waves_total = gridDim.x * XAAC_IMDCT_WAVES;
-  for (int ch = blockIdx.x * XAAC_IMDCT_WAVES + wave; ch < p.n_ch; ch += waves_total) {
-    /* ---- loads: 4 KB spectrum + 2 KB overlap, 16 B per lane per instruction */
-    const int4 *sp = reinterpret_cast<const int4 *>(p.spec + (size_t)ch * 1024);
-    int32_t *ovl = p.overlap + (size_t)ch * 512;
-    int4 v[4], o4[2];
+  const int n_au = p.n_ch / CF;
+  for (int au = blockIdx.x * XAAC_IMDCT_WAVES + wave; au < n_au; au += waves_total) {
+    bool parked = false; /* CF == 2: channel 0's PCM sits in LDS waiting for channel 1 */
+#pragma unroll 1
+    for (int c = 0; c < CF; c++) {
+      const int ch = au * CF + c;
+      /* keep lane-derived LDS addresses out of loop-invariant registers: recomputing the
+         ~30 of them per frame is a few dozen VALU ops, holding them costs a wave of occupancy */
+      int lane = lane_id;
+      asm volatile("" : "+v"(lane));
+      /* ---- loads: 4 KB spectrum + 2 KB overlap, 16 B per lane per instruction */
+      const int4 *sp = reinterpret_cast<const int4 *>(p.spec + (size_t)ch * 1024);
+      int32_t *ovl = p.overlap + (size_t)ch * 512;
+      int4 v[4], o4[2];
 #pragma unroll
-    for (int r = 0; r < 4; r++) v[r] = sp[64 * r + lane];
-    o4[0] = reinterpret_cast<const int4 *>(ovl)[lane];
-    o4[1] = reinterpret_cast<const int4 *>(ovl)[64 + lane];
-    const int seq = p.ics[ch].window_sequence, shape = p.ics[ch].window_shape;
-    const int pseq = p.state[ch].window_sequence, pshape = p.state[ch].window_shape;
+      for (int r = 0; r < 4; r++) v[r] = sp[64 * r + lane];
+      const int ics_bits = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint16_t *>(p.ics + ch));
+      const int st_bits = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint16_t *>(p.state + ch));
+      const int seq = ics_bits & 0xff, shape = ics_bits >> 8;
+      const int pseq = st_bits & 0xff, pshape = st_bits >> 8;
 
-    /* block exponent: OR of abs_nrm over the frame (aac_tns.c:422) */
-    int32_t acc = 0;
+      /* block exponent: OR of abs_nrm over the frame (aac_tns.c:422) */
+      int32_t acc = 0;
 #pragma unroll
-    for (int r = 0; r < 4; r++)
-      acc |= fx_abs_nrm(v[r].x) | fx_abs_nrm(v[r].y) | fx_abs_nrm(v[r].z) | fx_abs_nrm(v[r].w);
-    const int headroom = fx_norm32(wave_or(acc));
+      for (int r = 0; r < 4; r++)
+        acc |= fx_abs_nrm(v[r].x) | fx_abs_nrm(v[r].y) | fx_abs_nrm(v[r].z) | fx_abs_nrm(v[r].w);
+      const int headroom = __builtin_amdgcn_readfirstlane(fx_norm32(wave_or(acc)));
 
-    stage_spec(buf, v, lane);
+      stage_spec(buf, v, lane);
+      /* old overlap: issued now, consumed after the transform (its latency hides under the FFT) */
+      o4[0] = reinterpret_cast<const int4 *>(ovl)[lane];
+      o4[1] = reinterpret_cast<const int4 *>(ovl)[64 + lane];
 
-    const bool prev_short_edge = (pseq == XAAC_K_LONG_START) || (pseq == XAAC_K_EIGHT_SHORT);
-    const int16_t *wl = s_win + 1024 * pshape;        /* previous shape, long */
-    const int16_t *ws = s_win + 2048 + 128 * pshape;  /* previous shape, short */
-    const int cf = p.ch_fac;
-    const size_t obase = (size_t)(ch / cf) * 1024 * cf + (ch % cf);
-    Sink sk;
-    sk.o32 = p.out32 ? p.out32 + obase : nullptr;
-    sk.p16 = p.pcm16 ? p.pcm16 + obase : nullptr;
-    sk.stride = cf;
-    sk.mode = p.pcm_mode;
-    sk.qadj = 2;
+      const bool prev_short_edge = (pseq == XAAC_K_LONG_START) || (pseq == XAAC_K_EIGHT_SHORT);
+      const bool hot = (seq == XAAC_K_ONLY_LONG) && !prev_short_edge;
+      const int16_t *wl = s_win + 1024 * pshape;       /* previous shape, long */
+      const int16_t *ws = s_win + 2048 + 128 * pshape; /* previous shape, short */
+      const size_t obase = (size_t)au * 1024 * CF + c;
+      Sink sk;
+      sk.o32 = p.out32 ? p.out32 + obase : nullptr;
+      sk.p16 = p.pcm16 ? p.pcm16 + obase : nullptr;
+      sk.stride = CF;
+      sk.mode = MODE;
+      sk.qadj = 2;
 
-    if (seq != XAAC_K_EIGHT_SHORT) {
-      const int e = 8 - (headroom - 1);
-      const int q = e + 2 + 5;
-      long_transform(buf, lane, e, wc);
-      const int32_t *y = buf;
+      /* CF == 2: channel 0 was parked but this channel cannot pair with it (rare path,
+         which also needs the parking area for the old overlap): flush channel 0 now */
+      if (CF == 2 && parked && !hot) {
+        for (int n = lane; n < 1024; n += 64) p.pcm16[obase - 1 + 2 * (size_t)n] = park[n];
+        parked = false;
+      }
 
-      if (seq == XAAC_K_ONLY_LONG && !prev_short_edge) {
-        /* ---- hot path (aac_imdct.c:506): lane owns t = 4l+j and 256+4l+j */
+      if (seq != XAAC_K_EIGHT_SHORT) {
+        const int e = 8 - (headroom - 1);
+        const int q = e + 2 + 5;
+        long_transform(buf, lane, e, wc);
+        const int32_t *y = buf;
+
+        if (hot) {
+          /* ---- hot path: lane owns t = 4l+j and 256+4l+j, i.e. outputs 508-t0.. and 512+t0.. */
 #pragma unroll
-        for (int g = 0; g < 2; g++) {
-          const int t0 = 256 * g + 4 * lane;
-          int4 vv = *reinterpret_cast<const int4 *>(y + 1020 - t0);         /* y[1023-t], j = 3..0 */
-          int4 uu = *reinterpret_cast<const int4 *>(y + t0);                /* y[t]               */
-          int4 ww = *reinterpret_cast<const int4 *>(wl + 2 * (508 - t0));   /* W32[511-t], j = 3..0 */
-          const int32_t vj[4] = {vv.w, vv.z, vv.y, vv.x};
-          const int32_t wj[4] = {ww.w, ww.z, ww.y, ww.x};
-          const int32_t oj[4] = {o4[g].x, o4[g].y, o4[g].z, o4[g].w};
-          const int32_t uj[4] = {uu.x, uu.y, uu.z, uu.w};
-          int32_t lo[4], hi[4], nv[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            int32_t a = fx_mul32xlo(vj[j], wj[j]);
-            int32_t b = fx_mul32xhi(fx_neg_sat(vj[j]), wj[j]);
-            int32_t o = oj[j];
-            if (q > 0) {
-              a = fx_shl_sat(a, q);
-              b = fx_shl_sat(b, q);
-            } else {
-              a = fx_shr(a, -q);
-              b = fx_shr(b, -q);
-              o = (int16_t)o; /* aac_imdct.c:679 */
-            }
-            lo[j] = fx_sub_sat(a, nosh(o, (int16_t)(wj[j] >> 16)));   /* out[511-t] */
-            hi[j] = fx_sub_sat(b, nosh(o, (int16_t)wj[j]));           /* out[512+t] */
-            nv[j] = to_ovl(uj[j], q);
-          }
-          reinterpret_cast<int4 *>(ovl)[64 * g + lane] = make_int4(nv[0], nv[1], nv[2], nv[3]);
-          if (cf == 1) {
+          for (int g = 0; g < 2; g++) {
+            const int t0 = 256 * g + 4 * lane;
+            int32_t lo[4], hi[4];
+            int4 nv;
+            if (q > 0)
+              ola_long_long4<true>(y, wl, t0, o4[g], q, lo, hi, nv);
+            else
+              ola_long_long4<false>(y, wl, t0, o4[g], q, lo, hi, nv);
+            reinterpret_cast<int4 *>(ovl)[64 * g + lane] = nv;
             if (sk.o32) {
-              *reinterpret_cast<int4 *>(sk.o32 + 508 - t0) = make_int4(lo[3], lo[2], lo[1], lo[0]);
-              *reinterpret_cast<int4 *>(sk.o32 + 512 + t0) = make_int4(hi[0], hi[1], hi[2], hi[3]);
+              if (CF == 1) {
+                *reinterpret_cast<int4 *>(sk.o32 + 508 - t0) = make_int4(lo[3], lo[2], lo[1], lo[0]);
+                *reinterpret_cast<int4 *>(sk.o32 + 512 + t0) = make_int4(hi[0], hi[1], hi[2], hi[3]);
+              } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                  sk.o32[CF * (511 - t0 - j)] = lo[j];
+                  sk.o32[CF * (512 + t0 + j)] = hi[j];
+                }
+              }
             }
             if (sk.p16) {
-              auto pk = [&](int32_t a, int32_t b) {
-                return (int32_t)((uint32_t)(uint16_t)sk.to_pcm(a) | ((uint32_t)(uint16_t)sk.to_pcm(b) << 16));
-              };
-              *reinterpret_cast<int2 *>(sk.p16 + 508 - t0) = make_int2(pk(lo[3], lo[2]), pk(lo[1], lo[0]));
-              *reinterpret_cast<int2 *>(sk.p16 + 512 + t0) = make_int2(pk(hi[0], hi[1]), pk(hi[2], hi[3]));
-            }
-          } else {
+              int16_t pl[4], ph[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-              sk.put(511 - t0 - j, lo[j]);
-              sk.put(512 + t0 + j, hi[j]);
+              for (int j = 0; j < 4; j++) {
+                pl[j] = sk.to_pcm(lo[j]);
+                ph[j] = sk.to_pcm(hi[j]);
+              }
+              if (CF == 1) {
+                *reinterpret_cast<int2 *>(sk.p16 + 508 - t0) = make_int2(pack16(pl[3], pl[2]), pack16(pl[1], pl[0]));
+                *reinterpret_cast<int2 *>(sk.p16 + 512 + t0) = make_int2(pack16(ph[0], ph[1]), pack16(ph[2], ph[3]));
+              } else if (c == 0) {
+                /* park: channel 1 (same lane, same samples) will interleave and store */
+                *reinterpret_cast<int2 *>(park + 508 - t0) = make_int2(pack16(pl[3], pl[2]), pack16(pl[1], pl[0]));
+                *reinterpret_cast<int2 *>(park + 512 + t0) = make_int2(pack16(ph[0], ph[1]), pack16(ph[2], ph[3]));
+              } else if (parked) {
+                const int2 a = *reinterpret_cast<const int2 *>(park + 508 - t0);
+                const int2 b = *reinterpret_cast<const int2 *>(park + 512 + t0);
+                const int16_t l0[4] = {(int16_t)a.x, (int16_t)(a.x >> 16), (int16_t)a.y, (int16_t)(a.y >> 16)};
+                const int16_t l1[4] = {(int16_t)b.x, (int16_t)(b.x >> 16), (int16_t)b.y, (int16_t)(b.y >> 16)};
+                int32_t *dst = reinterpret_cast<int32_t *>(p.pcm16 + (size_t)au * 2048); /* one dword per sample pair */
+                *reinterpret_cast<int4 *>(dst + 508 - t0) =
+                    make_int4(pack16(l0[0], pl[3]), pack16(l0[1], pl[2]), pack16(l0[2], pl[1]), pack16(l0[3], pl[0]));
+                *reinterpret_cast<int4 *>(dst + 512 + t0) =
+                    make_int4(pack16(l1[0], ph[0]), pack16(l1[1], ph[1]), pack16(l1[2], ph[2]), pack16(l1[3], ph[3]));
+              } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                  sk.p16[CF * (511 - t0 - j)] = pl[j];
+                  sk.p16[CF * (512 + t0 + j)] = ph[j];
+                }
+              }
             }
           }
+          parked = (CF == 2 && c == 0 && sk.p16 != nullptr);
+        } else {
+          /* rare long-window transitions: out of line so that their register
+             appetite does not set the occupancy of the hot path */
+#ifndef XAAC_HOT_ONLY /* (analysis builds drop the rare paths to read the hot loop's ISA) */
+          reinterpret_cast<int4 *>(ovs)[lane] = o4[0];
+          reinterpret_cast<int4 *>(ovs)[64 + lane] = o4[1];
+          sk.qadj = long_transition_paths((const lds_i32 *)buf, (const lds_i32 *)ovs, sk, ovl, (const lds_i16 *)wl,
+                                          (const lds_i16 *)ws, q, seq, prev_short_edge, lane);
+#endif
         }
       } else {
-        /* rare long-window transitions: out of line so that their register
-           appetite does not set the occupancy of the hot path */
+#ifndef XAAC_HOT_ONLY
         reinterpret_cast<int4 *>(ovs)[lane] = o4[0];
         reinterpret_cast<int4 *>(ovs)[64 + lane] = o4[1];
-        sk.qadj = long_transition_paths(buf, ovs, sk, ovl, wl, ws, q, seq, prev_short_edge, lane);
+        eight_short_path((lds_i32 *)buf, (const lds_i32 *)ovs, sk, ovl, (const lds_i16 *)wl, (const lds_i16 *)ws,
+                         (const lds_i16 *)(s_win + 2048 + 128 * shape), headroom, prev_short_edge, lane);
+#endif
       }
-    } else {
-      reinterpret_cast<int4 *>(ovs)[lane] = o4[0];
-      reinterpret_cast<int4 *>(ovs)[64 + lane] = o4[1];
-      eight_short_path(buf, ovs, sk, ovl, wl, ws, s_win + 2048 + 128 * shape, headroom, prev_short_edge, lane);
-    }
 
-    if (lane == 0) {
-      p.state[ch].window_sequence = (uint8_t)seq;
-      p.state[ch].window_shape = (uint8_t)shape;
-      if (p.qshift_adj) p.qshift_adj[ch] = (int8_t)sk.qadj;
+      if (lane == 0) {
+        p.state[ch].window_sequence = (uint8_t)seq;
+        p.state[ch].window_shape = (uint8_t)shape;
+        if (p.qshift_adj) p.qshift_adj[ch] = (int8_t)sk.qadj;
+      }
     }
   }
 }
 
+namespace {
+typedef void (*imdct_kernel_t)(XaacImdctParams);
+imdct_kernel_t pick_kernel(int ch_fac, int pcm_mode) {
+  if (ch_fac == 2) return pcm_mode ? xaac_imdct_ola_kernel<2, 1> : xaac_imdct_ola_kernel<2, 0>;
+  return pcm_mode ? xaac_imdct_ola_kernel<1, 1> : xaac_imdct_ola_kernel<1, 0>;
+}
+}  // namespace
+
 extern "C" hipError_t xaac_launch_imdct(const XaacImdctParams *p, int grid, hipStream_t stream) {
-  hipLaunchKernelGGL(xaac_imdct_ola_kernel, dim3(grid), dim3(XAAC_IMDCT_BLOCK), XAAC_IMDCT_LDS_BYTES, stream, *p);
+  hipLaunchKernelGGL(pick_kernel(p->ch_fac, p->pcm_mode), dim3(grid), dim3(XAAC_IMDCT_BLOCK), XAAC_IMDCT_LDS_BYTES,
+                     stream, *p);
   return hipGetLastError();
 }
 
 /* resident workgroups per CU for this kernel (registers + LDS), for sizing the persistent grid */
 extern "C" int xaac_imdct_blocks_per_cu(void) {
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, xaac_imdct_ola_kernel, XAAC_IMDCT_BLOCK,
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, xaac_imdct_ola_kernel<2, 0>, XAAC_IMDCT_BLOCK,
                                                    XAAC_IMDCT_LDS_BYTES) != hipSuccess || n < 1)
     n = 2;
   return n;
