@@ -39,6 +39,17 @@ FRAMES_PER_STEP = 8192          # stereo frames per batch (BASELINE configs[1])
 CH = 2
 ALG_BYTES_PER_FRAME = 20480     # R spec 2x4096 + ovl 2x2048, W pcm16 2x2048 + ovl 2x2048
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")   # written from the rocprofv3 --pmc passes
+
+
+def measured_traffic():
+    """HBM bytes per launch from the last committed PMC profile of this kernel (rocprofv3
+    FETCH_SIZE x2 + WRITE_SIZE, calibrated as MI355X_MICROARCH.md prescribes), or None."""
+    try:
+        with open(PMC_FILE) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
 
 
 def make_inputs(torch, device, sets, seed):
@@ -132,18 +143,13 @@ def main():
     import torch
     import libxaac_amd
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from libxaac_amd import dist as xdist
+    rank, local_rank, world = xdist.env_rank()
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     assert torch.cuda.is_available(), "bench.py needs a GPU; the product has no CPU path"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dist = xdist.init("nccl")       # RCCL; None at world 1
 
     stream = torch.cuda.Stream(device=dev)      # kernels AND timing events go on this one stream
     torch.cuda.set_stream(stream)
@@ -176,10 +182,7 @@ def main():
         step(args.warmup + i, events[i])
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = xdist.max_over_ranks(dist, elapsed, dev)
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
 
     # the run stays honest: decode one more frame of set 0 and compare a slice with the oracle
@@ -216,7 +219,9 @@ def main():
                        "frames_per_step": FRAMES_PER_STEP, "channels": CH, "launch": ctx.last_launch(),
                        "sharding": "streams split across ranks, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": (measured_traffic() or {}).get("bytes_per_launch"),
+                         "traffic_source": (measured_traffic() or {}).get("source"),
                          "kernel": "xaac_imdct_ola_kernel", "kernel_ms": round(kern_ms, 5),
                          "alg_bytes_per_launch": alg_bytes},
             "bit_exact_vs_oracle": checked,

@@ -11,7 +11,7 @@ import sys
 
 
 def short(name, n=70):
-    name = name.split("(")[0] if name.startswith("xaac") else name
+    name = name.split("(")[0] if "xaac" in name else name
     return name if len(name) <= n else name[:n - 3] + "..."
 
 
@@ -26,7 +26,7 @@ def stats(db):
         print("%-72s %6d %12.1f %10.2f %10.2f %10.2f %6.1f" % (short(r[0]), r[1], r[2] / 1e3, r[3] / 1e3,
                                                               r[4] / 1e3, r[5] / 1e3, 100.0 * r[2] / tot))
     for r in rows:
-        if r[0].startswith("xaac"):
+        if "xaac" in r[0]:
             print("\n%s: vgpr=%s agpr=%s sgpr=%s lds=%s B scratch=%s B grid=%s threads wg=%s" % (
                 short(r[0]), r[6], r[7], r[8], r[9], r[10], r[11], r[12]))
 
@@ -39,7 +39,7 @@ def pmc(dbs):
         print("# %s" % db)
         print("%-72s %-14s %6s %16s %10s" % ("kernel", "counter", "calls", "mean value", "avg_us"))
         for r in rows:
-            if r[0].startswith("xaac") or "copy" in r[0].lower():
+            if "xaac" in r[0] or "copy" in r[0].lower():
                 print("%-72s %-14s %6d %16.1f %10.2f" % (short(r[0]), r[1], r[2], r[3], r[4] / 1e3))
 
 
