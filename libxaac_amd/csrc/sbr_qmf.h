@@ -1,0 +1,361 @@
+/*
+ * sbr_qmf.h -- per-slot transforms of the SBR QMF banks (fixed-point "Path B"),
+ * written once as scalar host/device code: on the GPU one LANE runs one QMF
+ * slot (the transforms are 16/32-point FFT sized, there are 32 slots per
+ * channel-frame and thousands of channel-frames, so the batch is the parallel
+ * axis and no cross-lane exchange is needed); on the host the same code is the
+ * arithmetic core of the oracle (oracle/oracle_qmf.cpp), which pins it to the
+ * reference function by function.
+ *
+ * Reference map (decoder/...):
+ *   xq_radix4          generic/ixheaacd_qmf_dec_generic.c:1736  ixheaacd_radix4bfly
+ *   xq_postradix4/2    generic/...:1831 / :1934                 ixheaacd_postradixcompute4/2
+ *   xq_dct3_32         generic/...:63                           ixheaacd_dct3_32        (LP analysis)
+ *   xq_cos_sin_mod     generic/...:259                          ixheaacd_cos_sin_mod    (HQ analysis + synthesis)
+ *   xq_fwd_modulation  generic/...:468                          ixheaacd_fwd_modulation (HQ analysis)
+ *   xq_dct2_64_lp      generic/...:241 + ixheaacd_qmf_dec.c:72-215 (pretwdct2, fftposttw, posttwdct2)
+ *                      + generic/...:851 ixheaacd_inv_modulation_lp  (LP synthesis, one slot -> 128 ring samples)
+ *   xq_synth_hq_slot   generic/...:869 inv_emodulation + :1638 shiftrountine_with_rnd (HQ synthesis slot)
+ * The reference walks these arrays with post-incremented pointers that are also
+ * used as array bases; everything below is the same sequential dataflow written
+ * with explicit indices.  mul() is (a*b)>>16 with a 16-bit b; "w" ops wrap,
+ * "_sat" ops clamp, exactly as in fx.h.
+ */
+#ifndef XAAC_SBR_QMF_H
+#define XAAC_SBR_QMF_H
+
+#include "fx.h"
+
+#ifndef XQ_TABLES_DECLARED
+#define XQ_TABLES_DECLARED
+#if defined(__HIPCC__)
+#define XAAC_TAB_QUAL static __device__ const
+#include "tables_qmf.inc"
+#undef XAAC_TAB_QUAL
+#define XQ_T(name) xaac_qmf_##name
+#else
+#include "tables_qmf.inc"
+#define XQ_T(name) xaac_qmf_##name
+#endif
+#endif
+
+#if defined(__HIPCC__)
+#define XQ_UNROLL _Pragma("unroll")
+#else
+#define XQ_UNROLL
+#endif
+
+FX_HD int32_t xq_mul(int32_t a, int16_t b) { return fx_mul32x16(a, b); }
+
+/* radix-4 pass over interleaved complex x; twiddles (si1,co1,si2,co2,si3,co3) per column */
+FX_HD void xq_radix4(const int16_t *w, int32_t *x, int index1, int index) {
+  const int h2 = 2 * index, l1 = 4 * index, l2 = 6 * index;
+  XQ_UNROLL
+  for (int b = 0; b < index1; b++) {
+    XQ_UNROLL
+    for (int i = 0; i < index; i++) {
+      int32_t *p = x + 8 * index * b + 2 * i;
+      const int16_t si1 = w[6 * i], co1 = w[6 * i + 1], si2 = w[6 * i + 2], co2 = w[6 * i + 3], si3 = w[6 * i + 4],
+                    co3 = w[6 * i + 5];
+      int32_t xh0 = fx_add_sat(p[0], p[l1]), xl0 = fx_sub_sat(p[0], p[l1]);
+      int32_t xh20 = fx_add_sat(p[h2], p[l2]), xl20 = fx_sub_sat(p[h2], p[l2]);
+      int32_t xh1 = fx_add_sat(p[1], p[l1 + 1]), xl1 = fx_sub_sat(p[1], p[l1 + 1]);
+      int32_t xh21 = fx_add_sat(p[h2 + 1], p[l2 + 1]), xl21 = fx_sub_sat(p[h2 + 1], p[l2 + 1]);
+      int32_t xt0 = fx_sub_sat(xh0, xh20), yt0 = fx_sub_sat(xh1, xh21);
+      int32_t xt1 = fx_add_sat(xl0, xl21), xt2 = fx_sub_sat(xl0, xl21);
+      int32_t yt2 = fx_add_sat(xl1, xl20), yt1 = fx_sub_sat(xl1, xl20);
+      p[0] = fx_add_sat(xh0, xh20);
+      p[1] = fx_add_sat(xh1, xh21);
+      p[l2] = fx_shlw(fx_add(xq_mul(yt2, si3), xq_mul(xt2, co3)), 1);
+      p[l2 + 1] = fx_shlw(fx_sub(xq_mul(yt2, co3), xq_mul(xt2, si3)), 1);
+      p[l1] = fx_shlw(fx_add(xq_mul(yt0, si2), xq_mul(xt0, co2)), 1);
+      p[l1 + 1] = fx_shlw(fx_sub(xq_mul(yt0, co2), xq_mul(xt0, si2)), 1);
+      p[h2] = fx_shlw(fx_add(xq_mul(yt1, si1), xq_mul(xt1, co1)), 1);
+      p[h2 + 1] = fx_shlw(fx_sub(xq_mul(yt1, co1), xq_mul(xt1, si1)), 1);
+    }
+  }
+}
+
+/* final radix-4 (twiddle-free) stage + digit-reversed scatter, 16 complex points */
+FX_HD void xq_postradix4(int32_t *y, const int32_t *x) {
+  XQ_UNROLL
+  for (int k = 0; k < 2; k++) {
+    const int h = XQ_T(dig_rev_table4_16)[k] >> 2;
+    XQ_UNROLL
+    for (int half = 0; half < 2; half++) {
+      const int32_t *a = x + 16 * k + 8 * half;
+      int32_t *o = y + h + 2 * half;
+      int32_t xh0 = fx_add_sat(a[0], a[4]), xh1 = fx_add_sat(a[1], a[5]);
+      int32_t xl0 = fx_sub_sat(a[0], a[4]), xl1 = fx_sub_sat(a[1], a[5]);
+      int32_t yh0 = fx_add_sat(a[2], a[6]), yh1 = fx_add_sat(a[3], a[7]);
+      int32_t yl0 = fx_sub_sat(a[2], a[6]), yl1 = fx_sub_sat(a[3], a[7]);
+      o[0] = fx_add_sat(xh0, yh0);
+      o[1] = fx_add_sat(xh1, yh1);
+      o[8] = fx_add_sat(xl0, yl1);
+      o[9] = fx_sub_sat(xl1, yl0);
+      o[16] = fx_sub_sat(xh0, yh0);
+      o[17] = fx_sub_sat(xh1, yh1);
+      o[24] = fx_sub_sat(xl0, yl1);
+      o[25] = fx_add_sat(xl1, yl0);
+    }
+  }
+}
+
+/* final radix-2 stage + digit-reversed scatter, 32 complex points */
+FX_HD void xq_postradix2(int32_t *y, const int32_t *x) {
+  XQ_UNROLL
+  for (int k = 0; k < 2; k++) {
+    XQ_UNROLL
+    for (int i = 0; i < 2; i++) {
+      const int h = XQ_T(dig_rev_table2_32)[2 * k + i] >> 2;
+      XQ_UNROLL
+      for (int half = 0; half < 2; half++) {
+        const int32_t *a = x + 32 * k + 8 * i + 16 * half;
+        int32_t *o = y + h + 2 * half;
+        o[0] = fx_add_sat(a[0], a[2]);
+        o[1] = fx_add_sat(a[1], a[3]);
+        o[32] = fx_sub_sat(a[0], a[2]);
+        o[33] = fx_sub_sat(a[1], a[3]);
+        o[8] = fx_add_sat(a[4], a[6]);
+        o[9] = fx_add_sat(a[5], a[7]);
+        o[40] = fx_sub_sat(a[4], a[6]);
+        o[41] = fx_sub_sat(a[5], a[7]);
+      }
+    }
+  }
+}
+
+/* LP analysis: 64 window-add outputs in[] (clobbered) -> 32 real subband samples out[] */
+FX_HD void xq_dct3_32(int32_t *in, int32_t *out) {
+  const int16_t *tw = XQ_T(dct23_tw);
+  const int16_t *post = XQ_T(post_fft_tbl);
+  out[0] = in[48] >> 7;
+  out[1] = 0;
+  XQ_UNROLL
+  for (int n = 1; n < 16; n++) {
+    int32_t t0 = fx_add_sat(fx_shr(in[48 + n], 7), fx_shr(in[48 - n], 7));
+    int32_t t1 = fx_sub_sat(fx_shr(in[16 + n], 7), fx_shr(in[16 - n], 7));
+    int16_t re = tw[4 * n], im = tw[4 * n + 1];
+    out[2 * n] = fx_add(xq_mul(t0, re), xq_mul(t1, im));
+    out[2 * n + 1] = fx_add(fx_neg(xq_mul(t1, re)), xq_mul(t0, im));
+  }
+  {
+    int16_t re = tw[64], im = tw[65];
+    int32_t t = fx_sub_sat(fx_shr(in[32], 7), fx_shr(in[0], 7));
+    int32_t c2 = fx_add(xq_mul(t, re), xq_mul(t, im));
+    int32_t c3 = fx_add(fx_neg(xq_mul(t, re)), xq_mul(t, im));
+    int32_t a0 = out[0], a1 = out[1];
+    int32_t u0 = fx_sub(fx_neg(a1), c3), u1 = fx_sub(a0, c2);
+    out[0] = fx_add(fx_add(a0, c2), u0) >> 1;
+    out[1] = fx_add(fx_sub(a1, c3), u1) >> 1;
+  }
+  XQ_UNROLL
+  for (int n = 1; n <= 8; n++) {
+    int32_t a0 = out[2 * n], a1 = out[2 * n + 1], a3 = out[33 - 2 * n], a2 = out[32 - 2 * n];
+    int32_t t0 = fx_sub(a0, a2), t1 = fx_add(a0, a2), t2 = fx_add(a1, a3), t3 = fx_sub(a1, a3);
+    if (n < 8) {
+      int16_t re = post[16 - 2 * n], im = post[2 * n];
+      int32_t t4 = fx_add(xq_mul(t0, re), xq_mul(t2, im));
+      int32_t t5 = fx_add(fx_neg(xq_mul(t2, re)), xq_mul(t0, im));
+      t1 >>= 1;
+      t3 >>= 1;
+      out[2 * n] = fx_sub(t1, t4);
+      out[2 * n + 1] = fx_add(t3, t5);
+      out[33 - 2 * n] = fx_add(fx_neg(t3), t5);
+      out[32 - 2 * n] = fx_add(t1, t4);
+    } else {
+      int16_t re = (int16_t)(-post[0]), im = post[16];
+      int32_t t4 = fx_sub(xq_mul(t0, re), xq_mul(t2, im));
+      int32_t t5 = fx_add(xq_mul(t2, re), xq_mul(t0, im));
+      t1 >>= 1;
+      t3 >>= 1;
+      out[16] = fx_add(t1, t4);
+      out[17] = fx_add(t3, t5);
+    }
+  }
+  xq_radix4(XQ_T(w_16), out, 1, 4);
+  xq_postradix4(in, out);
+  out[0] = in[0];
+  out[2] = in[1];
+  XQ_UNROLL
+  for (int j = 0; j < 7; j++) {
+    out[1 + 4 * j] = in[3 + 2 * j];
+    out[3 + 4 * j] = in[2 + 2 * j];
+    out[30 - 4 * j] = in[19 + 2 * j];
+    out[28 - 4 * j] = in[18 + 2 * j];
+  }
+  out[29] = in[17];
+  out[31] = in[16];
+}
+
+/* complex modulation core shared by HQ analysis (M = 16) and HQ synthesis (M = 32):
+   s[0..2M-1] and s[64..64+2M-1] in place; t = 128 words of scratch */
+template <int M>
+FX_HD void xq_cos_sin_mod(int32_t *s, int32_t *t) {
+  const int16_t *tw = (M == 32) ? XQ_T(sin_cos_twiddle_l64) : XQ_T(sin_cos_twiddle_l32);
+  const int16_t *alt = (M == 32) ? XQ_T(alt_sin_twiddle_l64) : XQ_T(alt_sin_twiddle_l32);
+  XQ_UNROLL
+  for (int q = 0; q < M / 2; q++) {
+    {
+      int16_t wim = tw[4 * q], wre = tw[4 * q + 1];
+      int32_t re = s[2 * q], im = s[2 * M - 1 - 2 * q];
+      t[2 * q] = fx_add_sat(xq_mul(re, wre), xq_mul(im, wim));
+      t[2 * q + 1] = fx_sub_sat(xq_mul(im, wre), xq_mul(re, wim));
+      re = s[64 + 2 * q];
+      im = s[64 + 2 * M - 1 - 2 * q];
+      t[64 + 2 * q] = fx_sub_sat(xq_mul(im, wim), xq_mul(re, wre));
+      t[64 + 2 * q + 1] = fx_add_sat(xq_mul(re, wim), xq_mul(im, wre));
+    }
+    {
+      int16_t wim = tw[4 * q + 2], wre = tw[4 * q + 3];
+      int32_t re = s[2 * M - 2 - 2 * q], im = s[2 * q + 1];
+      t[2 * M - 1 - 2 * q] = fx_sub_sat(xq_mul(im, wre), xq_mul(re, wim));
+      t[2 * M - 2 - 2 * q] = fx_add_sat(xq_mul(re, wre), xq_mul(im, wim));
+      re = s[64 + 2 * M - 2 - 2 * q];
+      im = s[64 + 2 * q + 1];
+      t[64 + 2 * M - 1 - 2 * q] = fx_add_sat(xq_mul(re, wim), xq_mul(im, wre));
+      t[64 + 2 * M - 2 - 2 * q] = fx_sub_sat(xq_mul(im, wim), xq_mul(re, wre));
+    }
+  }
+  if (M == 32) {
+    XQ_UNROLL
+    for (int h = 0; h < 2; h++) {
+      xq_radix4(XQ_T(w_32), t + 64 * h, 1, 8);
+      xq_radix4(XQ_T(w_32) + 48, t + 64 * h, 4, 2);
+      xq_postradix2(s + 64 * h, t + 64 * h);
+    }
+  } else {
+    XQ_UNROLL
+    for (int h = 0; h < 2; h++) {
+      xq_radix4(XQ_T(w_16), t + 64 * h, 1, 4);
+      xq_postradix4(s + 64 * h, t + 64 * h);
+    }
+  }
+  /* post-rotation, in place and order-sensitive (each value is consumed before it is overwritten) */
+  int ps = 0, ps1 = 2 * M - 1, pa = 0;
+  int32_t re = s[ps1];
+  s[0] = s[0] >> 1;
+  ps = 1;
+  s[ps1] = fx_neg_sat(s[1] >> 1);
+  ps1--;
+  int16_t wim = alt[pa++], wre = alt[pa++];
+  int32_t im = s[ps1];
+  s[ps1--] = fx_add_sat(xq_mul(re, wre), xq_mul(im, wim));
+  s[ps++] = fx_sub_sat(xq_mul(im, wre), xq_mul(re, wim));
+  int ps2 = 64, ps12 = 64 + 2 * M - 1;
+  re = s[ps12];
+  s[ps12--] = fx_neg_sat(s[ps2] >> 1);
+  s[ps2] = s[ps2 + 1] >> 1;
+  ps2++;
+  im = s[ps12];
+  s[ps2++] = fx_neg_sat(fx_add_sat(xq_mul(re, wre), xq_mul(im, wim)));
+  s[ps12--] = fx_sub_sat(xq_mul(re, wim), xq_mul(im, wre));
+  XQ_UNROLL
+  for (int i = 0; i < M / 2 - 1; i++) {
+    int32_t im0 = s[ps], re0 = s[ps + 1], re2 = s[ps1];
+    s[ps++] = fx_add_sat(xq_mul(re0, wim), xq_mul(im0, wre));
+    s[ps1--] = fx_sub_sat(xq_mul(im0, wim), xq_mul(re0, wre));
+    int32_t im1 = s[ps2], re1 = s[ps2 + 1], re3 = s[ps12];
+    s[ps12--] = fx_neg_sat(fx_add_sat(xq_mul(re1, wim), xq_mul(im1, wre)));
+    s[ps2++] = fx_sub_sat(xq_mul(re1, wre), xq_mul(im1, wim));
+    wim = alt[pa++];
+    wre = alt[pa++];
+    im0 = s[ps1];
+    s[ps1--] = fx_add_sat(xq_mul(re2, wre), xq_mul(im0, wim));
+    s[ps++] = fx_sub_sat(xq_mul(im0, wre), xq_mul(re2, wim));
+    im1 = s[ps12];
+    s[ps2++] = fx_neg_sat(fx_add_sat(xq_mul(re3, wre), xq_mul(im1, wim)));
+    s[ps12--] = fx_sub_sat(xq_mul(re3, wim), xq_mul(im1, wre));
+  }
+}
+
+/* HQ analysis: 64 window-add outputs -> 32 complex subbands, s[0..31] real, s[64..95] imaginary;
+   nrot = usb - lsb of the analysis bank (bands that get the final phase rotation) */
+FX_HD void xq_fwd_modulation(const int32_t *in, int32_t *s, int32_t *t, int nrot) {
+  XQ_UNROLL
+  for (int i = 0; i < 32; i++) {
+    int32_t a = fx_shr(in[i], 4), b = fx_shr(in[63 - i], 4);
+    s[i] = fx_sub_sat(a, b);
+    s[64 + i] = fx_add_sat(a, b);
+  }
+  xq_cos_sin_mod<16>(s, t);
+  const int16_t *tc = XQ_T(t_cos_sin_l32);
+  XQ_UNROLL
+  for (int i = 0; i < 32; i++) {
+    if (i < nrot) {
+      int32_t re = s[i], im = s[64 + i];
+      int16_t c = tc[2 * i], sn = tc[2 * i + 1];
+      s[i] = fx_add_sat(fx_mul32x16_shl(re, c), fx_mul32x16_shl(im, sn));
+      s[64 + i] = fx_sub_sat(fx_mul32x16_shl(im, c), fx_mul32x16_shl(re, sn));
+    }
+  }
+}
+
+/* LP synthesis slot: 64 real subband samples x[] (clobbered), scratch X[64] ->
+   the 128 int16 samples b[0..127] that the reference writes at filter_states + drc_offset */
+FX_HD void xq_dct2_64_lp(int32_t *x, int32_t *X, int16_t *b) {
+  XQ_UNROLL
+  for (int n = 0; n < 32; n++) {
+    X[n] = x[2 * n];
+    X[63 - n] = x[2 * n + 1];
+  }
+  xq_radix4(XQ_T(w_32), X, 1, 8);
+  xq_radix4(XQ_T(w_32) + 48, X, 4, 2);
+  xq_postradix2(x, X);
+  {
+    const int16_t *post = XQ_T(post_fft_tbl);
+    x[0] = fx_shlw(x[0], 1);
+    x[1] = fx_shlw(x[1], 1);
+    XQ_UNROLL
+    for (int k = 1; k <= 16; k++) {
+      const int pf = 2 * k, pr = 65 - 2 * k;
+      int32_t t0 = x[pf], t1 = x[pf + 1], t3 = x[pr], t2 = x[pr - 1];
+      int32_t in2 = fx_sub_sat(t3, t1), in1 = fx_add_sat(t3, t1);
+      int32_t d = fx_sub_sat(t0, t2), sm = fx_add_sat(t0, t2);
+      int16_t re = post[k], im = post[16 - k];
+      int32_t v1 = fx_shlw(fx_sub(xq_mul(in1, re), xq_mul(d, im)), 1);
+      int32_t v2 = fx_shlw(fx_add(xq_mul(d, re), xq_mul(in1, im)), 1);
+      x[pf] = fx_add_sat(sm, v1);
+      x[pf + 1] = fx_add_sat(in2, v2);
+      x[pr] = fx_sub_sat(v2, in2);
+      x[pr - 1] = fx_sub_sat(sm, v1);
+    }
+  }
+  {
+    const int16_t *tw = XQ_T(dct23_tw);
+    int16_t *of = b + 32;
+    int32_t re0 = x[0], im0 = x[1];
+    int32_t half = fx_sat64(((int64_t)re0 + (int64_t)im0) >> 1);
+    of[0] = fx_round16(fx_shl(half, 4));
+    int32_t last = fx_sub_sat(re0, im0);
+    XQ_UNROLL
+    for (int n = 1; n < 32; n++) {
+      int32_t re = x[2 * n], im = x[2 * n + 1];
+      int16_t tr = tw[2 * n], ti = tw[2 * n + 1];
+      int32_t o_re = fx_sub_sat(xq_mul(re, tr), xq_mul(im, ti));
+      int32_t o_im = fx_add_sat(xq_mul(im, tr), xq_mul(re, ti));
+      int16_t r1 = fx_round16(fx_shl(o_re, 4)), i1 = fx_round16(fx_shl(o_im, 4));
+      of[n] = r1;
+      of[-n] = r1;
+      of[64 - n] = i1;
+      of[64 + n] = fx_neg16(i1);
+    }
+    int16_t r1 = fx_round16(fx_shl(xq_mul(last, tw[64]), 4));
+    of[32] = r1;
+    of[-32] = r1;
+    of[64] = 0; /* filter_states[3*M] = 0, generic:863 */
+  }
+}
+
+/* HQ synthesis slot: s[0..63] real, s[64..127] imaginary (clobbered), t scratch ->
+   128 int16 ring samples; shift = out_scale_factor + 1 (qmf_dec.c:1064) */
+FX_HD void xq_synth_hq_slot(int32_t *s, int32_t *t, int16_t *b, int shift) {
+  xq_cos_sin_mod<32>(s, t);
+  XQ_UNROLL
+  for (int c = 0; c < 64; c++) {
+    b[c] = fx_round16(fx_shl_sat(fx_sub_sat(s[64 + c], s[c]), shift));
+    b[64 + c] = fx_round16(fx_shl_sat(fx_add_sat(s[64 + 63 - c], s[63 - c]), shift));
+  }
+}
+
+#endif /* XAAC_SBR_QMF_H */

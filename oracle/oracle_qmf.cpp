@@ -1,0 +1,164 @@
+/*
+ * oracle/oracle_qmf.cpp -- TEST INFRASTRUCTURE ONLY (checker + CPU baseline).
+ *
+ * CPU restatement of the fixed-point SBR QMF banks ("Path B"): the 32-band analysis
+ * bank ixheaacd_cplx_anal_qmffilt (decoder/generic/ixheaacd_qmf_dec_generic.c:590)
+ * and the 64-band synthesis bank ixheaacd_cplx_synt_qmffilt
+ * (decoder/ixheaacd_qmf_dec.c:811), low-power (real, DCT) and HQ (complex) modes.
+ * The per-slot arithmetic is libxaac_amd/csrc/sbr_qmf.h (shared with the GPU
+ * kernels); this file adds the reference's ring-buffer state machines exactly as
+ * they evolve (filter-state rings, window phase, drc offset), so state can be
+ * compared word for word with the reference.
+ *
+ * Parity status: PINNED -- tests/test_qmf_oracle_vs_reference.py compares every
+ * exported piece (radix4bfly, postradixcompute2/4, dct3_32, cos_sin_mod,
+ * fwd_modulation, dct2_64 path, shiftrountine_with_rnd path) and the two complete
+ * banks, state included, with the compiled reference on seeded inputs.
+ */
+#include <stdint.h>
+#include <string.h>
+
+#include "../libxaac_amd/csrc/sbr_qmf.h"
+#include "oracle_qmf.h"
+
+extern "C" {
+
+/* ---- unit entry points (each mirrors one reference symbol) -------------------- */
+void xo_radix4(const int16_t *w, int32_t *x, int index1, int index) { xq_radix4(w, x, index1, index); }
+void xo_postradix4(int32_t *y, const int32_t *x) { xq_postradix4(y, x); }
+void xo_postradix2(int32_t *y, const int32_t *x) { xq_postradix2(y, x); }
+void xo_dct3_32(int32_t *in, int32_t *out) { xq_dct3_32(in, out); }
+void xo_cos_sin_mod(int32_t *s, int m) {
+  int32_t t[128];
+  if (m == 32)
+    xq_cos_sin_mod<32>(s, t);
+  else
+    xq_cos_sin_mod<16>(s, t);
+}
+void xo_fwd_modulation(const int32_t *in, int32_t *s, int nrot) {
+  int32_t t[128];
+  xq_fwd_modulation(in, s, t, nrot);
+}
+void xo_dct2_64_lp(int32_t *x, int16_t *b) {
+  int32_t X[64];
+  xq_dct2_64_lp(x, X, b);
+}
+void xo_synth_hq_slot(int32_t *s, int16_t *b, int shift) {
+  int32_t t[128];
+  xq_synth_hq_slot(s, t, b, shift);
+}
+
+/* ---- analysis bank -------------------------------------------------------------- */
+void xo_qmf_ana_init(xo_qmf_ana_state *st) { memset(st, 0, sizeof(*st)); }
+
+/* generic:528: 5-tap polyphase sums; never saturates (max sum|c| = 32757 < 65536) */
+static void ana_winadd(const int16_t *i1, const int16_t *i2, const int16_t *q1, const int16_t *q2, int32_t *o) {
+  for (int n = 0; n < 32; n++) {
+    int32_t a = 0, b = 0;
+    for (int j = 0; j < 5; j++) {
+      a = fx_add_sat(a, (int32_t)i1[n + 64 * j] * q1[2 * (n + 64 * j)]);
+      b = fx_add_sat(b, (int32_t)i2[n + 64 * j] * q2[2 * (n + 64 * j)]);
+    }
+    o[n] = a;
+    o[32 + n] = b;
+  }
+}
+
+/* One frame: 32 slots of 32 new samples.  qmf: slot s at qmf + s*slot_stride; LP writes 32 reals,
+   HQ writes 32 reals at +0 and 32 imaginaries at +64.  usb = analysis bank's usb (HQ rotation count). */
+void xo_qmf_analysis(const int16_t *pcm, int stride, xo_qmf_ana_state *st, int low_pow, int usb, int32_t *qmf,
+                     int slot_stride) {
+  const int16_t *c = xaac_qmf_qmf_c;
+  int f1 = st->phase, f2 = st->phase + 64; /* offsets into qmf_c (int16 units) */
+  int wr = st->wr;
+  int fp1 = 0, fp2 = 32;
+  for (int s = 0; s < 32; s++) {
+    int32_t z[64], t[128], sb[128];
+    for (int k = 0; k < 32; k++) st->ring[wr + 31 - k] = pcm[stride * (32 * s + k)];
+    ana_winadd(st->ring + fp1, st->ring + fp2, c + f1, c + f2, z);
+    wr -= 32;
+    if (wr < 0) wr = 288;
+    { int tmp = fp1; fp1 = fp2; fp2 = tmp; }
+    f1 += 64;
+    f2 += 64;
+    { int tmp = f1; f1 = f2; f2 = tmp; }
+    if (f2 > 640) {
+      f1 = 0;
+      f2 = 64;
+    }
+    int32_t *o = qmf + (size_t)s * slot_stride;
+    if (low_pow) {
+      xq_dct3_32(z, o);
+    } else {
+      xq_fwd_modulation(z, sb, t, usb);
+      memcpy(o, sb, 32 * sizeof(int32_t));
+      memcpy(o + 64, sb + 64, 32 * sizeof(int32_t));
+    }
+  }
+  st->phase = (int16_t)f1;
+  st->wr = (int16_t)wr;
+}
+
+/* ---- synthesis bank --------------------------------------------------------------- */
+void xo_qmf_syn_init(xo_qmf_syn_state *st) { memset(st, 0, sizeof(*st)); }
+
+/* env_calc.c:1099 on one sample */
+static inline int32_t adj(int32_t v, int shift) {
+  if (shift == 0) return v;
+  if (shift > 31) shift = 31;
+  if (shift < -31) shift = -31;
+  return shift > 0 ? fx_shlw(v, shift) : (v >> -shift);
+}
+
+/* One frame: 32 slots -> 2048 PCM16 at `stride`.  qmf rows as for analysis (64 reals, +64 imaginaries in HQ);
+   they are NOT modified here (the reference scales and transforms them in place).
+   sf = {lb_scale, ov_lb_scale, hb_scale, st_syn_scale}; no PS (active = 0). */
+void xo_qmf_synthesis(const int32_t *qmf, int slot_stride, const int16_t *sf, int lsb, int usb, int split,
+                      xo_qmf_syn_state *st, int low_pow, int16_t *pcm, int stride) {
+  const int lb_scale = sf[0], ov_lb_scale = sf[1], hb_scale = sf[2], st_syn = sf[3];
+  const int bias = low_pow ? 4 : 8; /* qmf_dec.c:906-933 */
+  const int ov_lb_shift = (st_syn - ov_lb_scale) - bias, lb_shift = (st_syn - lb_scale) - bias,
+            hb_shift = (st_syn - hb_scale) - bias;
+  const int out_scale = low_pow ? -(st_syn - 1) : -(st_syn - 3);
+  const int16_t *c = xaac_qmf_qmf_c;
+  int d = st->drc_offset, ph = st->phase;
+  int fp1 = 0, fp2 = 64;
+  for (int s = 0; s < 32; s++) {
+    int32_t x[128], t[128];
+    int16_t *b = st->ring + d;
+    const int32_t *row = qmf + (size_t)s * slot_stride;
+    const int nparts = low_pow ? 1 : 2;
+    for (int p = 0; p < nparts; p++)
+      for (int k = 0; k < 64; k++) {
+        int32_t v = row[64 * p + k];
+        if (k < lsb)
+          v = adj(v, s < split ? ov_lb_shift : lb_shift);
+        else if (k < usb)
+          v = adj(v, hb_shift);
+        x[64 * p + k] = v;
+      }
+    if (low_pow) {
+      xq_dct2_64_lp(x, t, b);
+    } else {
+      xq_synth_hq_slot(x, t, b, out_scale + 1);
+    }
+    /* generic:1508: 10-tap polyphase sum (cannot saturate: sum|c| = 57308), then the output shift */
+    const int shift = low_pow ? 2 : 1;
+    const int16_t *t1 = st->ring + fp1, *t2 = st->ring + fp2, *cf = c + ph;
+    for (int k = 0; k < 64; k++) {
+      int32_t acc = 0x8000 >> shift;
+      for (int m = 0; m < 5; m++) acc = fx_add_sat(acc, (int32_t)t1[256 * m + k] * cf[k + 128 * m]);
+      for (int m = 0; m < 5; m++) acc = fx_add_sat(acc, (int32_t)t2[128 + 256 * m + k] * cf[k + 64 + 128 * m]);
+      pcm[stride * (64 * s + k)] = (int16_t)(fx_shl_sat(acc, shift) >> 16);
+    }
+    d -= 128;
+    if (d < 0) d += 1280;
+    { int tmp = fp1; fp1 = fp2; fp2 = tmp; }
+    ph += 64;
+    if (ph == 640) ph = 0;
+  }
+  st->drc_offset = (int16_t)d;
+  st->phase = (int16_t)ph;
+}
+
+}  // extern "C"

@@ -98,3 +98,126 @@ void ref_imdct_batch(int n, WORD32 *spec, WORD32 *overlap, WORD16 *prev_seq, WOR
       for (i = 0; i < 1024; i++) pcm[1024 * (size_t)c + i] = ixheaac_round16((WORD32)((UWORD32)out[i] << q));
   }
 }
+
+/* ======================================================================================
+ * SBR QMF banks (fixed-point Path B).  Wrappers fill the reference's own structs and call
+ * its external symbols; tables are the reference's ROM (ixheaacd_aac_qmf_dec_tables).
+ * ====================================================================================== */
+#include "ixheaacd_qmf_dec.h"
+
+static ia_qmf_dec_tables_struct *ref_qmf_tabs(void) {
+  return (ia_qmf_dec_tables_struct *)&ixheaacd_aac_qmf_dec_tables;
+}
+
+void ref_radix4bfly(int which_w, int w_off, WORD32 *x, int index1, int index) {
+  const WORD16 *w = which_w == 32 ? ref_qmf_tabs()->w_32 : ref_qmf_tabs()->w_16;
+  ixheaacd_radix4bfly(w + w_off, x, index1, index);
+}
+void ref_postradix4(WORD32 *y, WORD32 *x) { ixheaacd_postradixcompute4(y, x, ref_qmf_tabs()->dig_rev_table4_16, 16); }
+void ref_postradix2(WORD32 *y, WORD32 *x) { ixheaacd_postradixcompute2(y, x, ref_qmf_tabs()->dig_rev_table2_32, 32); }
+void ref_dct3_32(WORD32 *in, WORD32 *out) {
+  ia_qmf_dec_tables_struct *t = ref_qmf_tabs();
+  ixheaacd_dct3_32(in, out, t->dct23_tw, t->post_fft_tbl, t->w_16, t->dig_rev_table4_16);
+}
+/* cos_sin_mod with the twiddle set the analysis (m=16) / synthesis (m=32) bank selects */
+void ref_cos_sin_mod(WORD32 *s, int m) {
+  ia_qmf_dec_tables_struct *t = ref_qmf_tabs();
+  ia_sbr_qmf_filter_bank_struct bank;
+  memset(&bank, 0, sizeof(bank));
+  bank.no_channels = 2 * m;
+  if (m == 32) {
+    bank.cos_twiddle = t->sbr_sin_cos_twiddle_l64;
+    bank.alt_sin_twiddle = t->sbr_alt_sin_twiddle_l64;
+    ixheaacd_cos_sin_mod(s, &bank, t->w_32, t->dig_rev_table2_32);
+  } else {
+    bank.cos_twiddle = t->sbr_sin_cos_twiddle_l32;
+    bank.alt_sin_twiddle = t->sbr_alt_sin_twiddle_l32;
+    ixheaacd_cos_sin_mod(s, &bank, t->w_16, t->dig_rev_table4_16);
+  }
+}
+/* LP synthesis slot: ixheaacd_inv_modulation_lp writes 128 samples at filter_states */
+void ref_inv_modulation_lp(WORD32 *x, WORD16 *b) {
+  ia_sbr_qmf_filter_bank_struct bank;
+  memset(&bank, 0, sizeof(bank));
+  bank.no_channels = 64;
+  ixheaacd_inv_modulation_lp(x, b, &bank, ref_qmf_tabs());
+}
+/* HQ synthesis slot: inv_emodulation + shiftrountine_with_rnd */
+void ref_synth_hq_slot(WORD32 *s, WORD16 *b, int shift) {
+  ia_qmf_dec_tables_struct *t = ref_qmf_tabs();
+  ia_sbr_qmf_filter_bank_struct bank;
+  memset(&bank, 0, sizeof(bank));
+  bank.no_channels = 64;
+  bank.cos_twiddle = t->sbr_sin_cos_twiddle_l64;
+  bank.alt_sin_twiddle = t->sbr_alt_sin_twiddle_l64;
+  ixheaacd_inv_emodulation(s, &bank, t);
+  ixheaacd_shiftrountine_with_rnd(s, s + 64, b, 64, shift);
+}
+
+/* One frame through ixheaacd_cplx_anal_qmffilt.  ring/wr/phase = anal_filter_states,
+ * core_samples_buffer - anal_filter_states, filter_pos - qmf_c.  qmf: slot s at qmf + s*slot_stride
+ * (real at +0, imaginary at +64 in HQ mode). */
+void ref_qmf_analysis(const WORD16 *pcm, int stride, WORD16 *ring, WORD16 *wr, WORD16 *phase, int low_pow,
+                      int usb, WORD32 *qmf, int slot_stride) {
+  ia_qmf_dec_tables_struct *t = ref_qmf_tabs();
+  ia_sbr_qmf_filter_bank_struct bank;
+  ia_sbr_scale_fact_struct sf;
+  WORD32 *re[32], *im[32];
+  int s;
+  memset(&bank, 0, sizeof(bank));
+  memset(&sf, 0, sizeof(sf));
+  bank.no_channels = 32;
+  bank.num_time_slots = 32;
+  bank.lsb = 0;
+  bank.usb = (WORD16)usb;
+  bank.anal_filter_states = ring;
+  bank.core_samples_buffer = ring + *wr;
+  bank.analy_win_coeff = t->qmf_c;
+  bank.filter_pos = t->qmf_c + *phase;
+  for (s = 0; s < 32; s++) {
+    re[s] = qmf + (size_t)s * slot_stride;
+    im[s] = re[s] + 64;
+  }
+  ixheaacd_cplx_anal_qmffilt(pcm, &sf, re, im, &bank, t, stride, low_pow, AOT_AAC_LC);
+  *wr = (WORD16)(bank.core_samples_buffer - ring);
+  *phase = (WORD16)(bank.filter_pos - t->qmf_c);
+}
+
+/* One frame through ixheaacd_cplx_synt_qmffilt (no PS: active = 0).  qmf is scaled and transformed
+ * in place by the reference.  sf = {lb_scale, ov_lb_scale, hb_scale, st_syn_scale}. */
+void ref_qmf_synthesis(WORD32 *qmf, int slot_stride, const WORD16 *sfv, int lsb, int usb, int split, WORD16 *ring,
+                       WORD16 *drc_offset, WORD16 *phase, int low_pow, WORD16 *pcm, int stride) {
+  ia_qmf_dec_tables_struct *t = ref_qmf_tabs();
+  ia_sbr_tables_struct tabs;
+  ia_sbr_qmf_filter_bank_struct bank;
+  ia_sbr_scale_fact_struct sf;
+  static __thread WORD32 copy_re[32][64], copy_im[32][64];
+  WORD32 *re[MAX_ENV_COLS], *im[MAX_ENV_COLS], *ore[MAX_ENV_COLS], *oim[MAX_ENV_COLS];
+  int s;
+  memset(&bank, 0, sizeof(bank));
+  memset(&sf, 0, sizeof(sf));
+  memset(&tabs, 0, sizeof(tabs));
+  tabs.qmf_dec_tables_ptr = t;
+  sf.lb_scale = sfv[0];
+  sf.ov_lb_scale = sfv[1];
+  sf.hb_scale = sfv[2];
+  sf.st_syn_scale = sfv[3];
+  bank.no_channels = 64;
+  bank.num_time_slots = 32;
+  bank.lsb = (WORD16)lsb;
+  bank.usb = (WORD16)usb;
+  bank.filter_states = ring;
+  bank.p_filter = t->qmf_c;
+  bank.filter_pos_syn = t->qmf_c + *phase;
+  bank.ixheaacd_drc_offset = *drc_offset;
+  for (s = 0; s < 32; s++) {
+    re[s] = qmf + (size_t)s * slot_stride;
+    im[s] = re[s] + 64;
+    ore[s] = copy_re[s];
+    oim[s] = copy_im[s];
+  }
+  ixheaacd_cplx_synt_qmffilt(re, im, split, ore, oim, &sf, pcm, &bank, NULL, 0, low_pow, &tabs, NULL, stride, 0, NULL,
+                             AOT_AAC_LC);
+  *drc_offset = bank.ixheaacd_drc_offset;
+  *phase = (WORD16)(bank.filter_pos_syn - t->qmf_c);
+}
