@@ -86,6 +86,52 @@ typedef struct xaac_imdct_batch {
   int32_t pcm_mode;           /* XAAC_PCM_LC or XAAC_PCM_SBR (used when pcm16 != NULL) */
 } xaac_imdct_batch;
 
+/* ---- SBR QMF banks (fixed-point "Path B") ---------------------------------------------
+ * xaac_qmf_analysis_batch  <-> ixheaacd_cplx_anal_qmffilt
+ *      decl decoder/ixheaacd_qmf_dec.h:74, def decoder/generic/ixheaacd_qmf_dec_generic.c:590,
+ *      call site decoder/ixheaacd_sbr_dec.c:1025
+ * xaac_qmf_synthesis_batch <-> ixheaacd_cplx_synt_qmffilt (no-PS branch)
+ *      def decoder/ixheaacd_qmf_dec.c:811, call site decoder/ixheaacd_sbr_dec.c:1273
+ * One frame (32 QMF slots) per channel per call, N channels per batch.  The persistent
+ * state is the reference's own (ia_sbr_qmf_filter_bank_struct, decoder/ixheaacd_qmf_dec.h:23-72)
+ * with pointers turned into offsets, so it can be copied to and from a reference decoder. */
+typedef struct xaac_qmf_ana_state {
+  int16_t ring[320]; /* anal_filter_states */
+  int16_t wr;        /* core_samples_buffer - anal_filter_states */
+  int16_t phase;     /* filter_pos - qmf_c */
+} xaac_qmf_ana_state;  /* zero-initialised for a new stream (sbrdec_initfuncs.c:1105-1122) */
+
+typedef struct xaac_qmf_syn_state {
+  int16_t ring[1280]; /* filter_states */
+  int16_t drc_offset; /* ixheaacd_drc_offset */
+  int16_t phase;      /* filter_pos_syn - qmf_c */
+} xaac_qmf_syn_state;  /* zero-initialised for a new stream (sbrdec_initfuncs.c:1175-1196) */
+
+typedef struct xaac_qmf_ana_batch {
+  int32_t n_ch;              /* channels in the batch */
+  int32_t ch_fac;            /* interleave stride of pcm: channel i reads sample n at
+                                (i/ch_fac)*1024*ch_fac + n*ch_fac + i%ch_fac */
+  int32_t low_pow;           /* 1: real-valued low-power bank (dct3_32), 0: complex HQ bank */
+  int32_t usb;               /* analysis bank usb (HQ: bands that get the final rotation) */
+  int32_t slot_stride;       /* words between consecutive slots in qmf (>= 32, >= 96 for HQ) */
+  const int16_t *pcm;        /* core-decoder PCM16, 1024 samples per channel */
+  xaac_qmf_ana_state *state; /* [n_ch] in/out */
+  int32_t *qmf;              /* [n_ch][32][slot_stride]: 32 real bands at +0, 32 imaginary at +64 (HQ) */
+} xaac_qmf_ana_batch;
+
+typedef struct xaac_qmf_syn_batch {
+  int32_t n_ch;
+  int32_t ch_fac;            /* interleave stride of the 2048-sample PCM output */
+  int32_t low_pow;
+  int32_t lsb, usb;          /* synthesis bank lsb / usb (region rescale, qmf_dec.c:937-953) */
+  int32_t split;             /* first slot of the current frame's low band (op_delay = 6) */
+  int32_t slot_stride;       /* >= 64 (LP) / >= 128 (HQ: imaginary row at +64) */
+  const int32_t *qmf;        /* [n_ch][32][slot_stride] (not modified) */
+  const int16_t *scale;      /* [n_ch][4]: lb_scale, ov_lb_scale, hb_scale, st_syn_scale */
+  xaac_qmf_syn_state *state; /* [n_ch] in/out */
+  int16_t *pcm;              /* 2048 samples per channel, interleaved at ch_fac */
+} xaac_qmf_syn_batch;
+
 typedef struct xaac_ctx xaac_ctx;
 
 /* Create a context bound to HIP device `device`.  `hip_stream` is a
@@ -103,6 +149,10 @@ int32_t xaac_imdct_process_batch(xaac_ctx *ctx, const xaac_imdct_batch *batch);
 /* Same with host buffers: copies in, runs, copies the outputs and state back,
  * synchronises.  PCIe-inclusive convenience path. */
 int32_t xaac_imdct_process_batch_host(xaac_ctx *ctx, const xaac_imdct_batch *batch);
+
+/* SBR QMF banks, device pointers, asynchronous on the context's stream. */
+int32_t xaac_qmf_analysis_batch(xaac_ctx *ctx, const xaac_qmf_ana_batch *batch);
+int32_t xaac_qmf_synthesis_batch(xaac_ctx *ctx, const xaac_qmf_syn_batch *batch);
 
 /* Launch geometry the library used for the last batch (for reports). */
 int32_t xaac_last_launch(xaac_ctx *ctx, int32_t *grid, int32_t *block, int32_t *lds_bytes);

@@ -47,6 +47,24 @@ class _ImdctBatch(ctypes.Structure):
                 ("pcm_mode", ctypes.c_int32)]
 
 
+class _QmfAnaBatch(ctypes.Structure):
+    # struct xaac_qmf_ana_batch
+    _fields_ = [("n_ch", ctypes.c_int32), ("ch_fac", ctypes.c_int32), ("low_pow", ctypes.c_int32),
+                ("usb", ctypes.c_int32), ("slot_stride", ctypes.c_int32), ("pcm", ctypes.c_void_p),
+                ("state", ctypes.c_void_p), ("qmf", ctypes.c_void_p)]
+
+
+class _QmfSynBatch(ctypes.Structure):
+    # struct xaac_qmf_syn_batch
+    _fields_ = [("n_ch", ctypes.c_int32), ("ch_fac", ctypes.c_int32), ("low_pow", ctypes.c_int32),
+                ("lsb", ctypes.c_int32), ("usb", ctypes.c_int32), ("split", ctypes.c_int32),
+                ("slot_stride", ctypes.c_int32), ("qmf", ctypes.c_void_p), ("scale", ctypes.c_void_p),
+                ("state", ctypes.c_void_p), ("pcm", ctypes.c_void_p)]
+
+
+QMF_ANA_STATE_WORDS = 322    # int16 words of struct xaac_qmf_ana_state: ring[320], wr, phase
+QMF_SYN_STATE_WORDS = 1282   # int16 words of struct xaac_qmf_syn_state: ring[1280], drc_offset, phase
+
 _lib = None
 
 
@@ -75,8 +93,11 @@ def load_library():
     lib.xaac_imdct_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_ImdctBatch)]
     lib.xaac_imdct_process_batch_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(_ImdctBatch)]
     lib.xaac_last_launch.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int32)] * 3
+    lib.xaac_qmf_analysis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_QmfAnaBatch)]
+    lib.xaac_qmf_synthesis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_QmfSynBatch)]
     for f in ("xaac_create", "xaac_destroy", "xaac_sync", "xaac_set_stream", "xaac_imdct_process_batch",
-              "xaac_imdct_process_batch_host", "xaac_last_launch"):
+              "xaac_imdct_process_batch_host", "xaac_last_launch", "xaac_qmf_analysis_batch",
+              "xaac_qmf_synthesis_batch"):
         getattr(lib, f).restype = ctypes.c_int32
     _lib = lib
     return lib
@@ -185,3 +206,37 @@ class XaacContext:
         rc = self._lib.xaac_imdct_process_batch_host(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_imdct_process_batch_host")
+
+    def qmf_analysis_batch(self, pcm, state, qmf, low_pow, usb=32, slot_stride=None, ch_fac=1):
+        """Batched ixheaacd_cplx_anal_qmffilt: one frame (1024 PCM16 -> 32 slots x 32 bands) per channel.
+        pcm int16[n_ch*1024] interleaved at ch_fac; state int16[n_ch, 322] in/out; qmf int32[n_ch, 32, slot_stride]
+        (real bands at +0, imaginary at +64 in HQ mode)."""
+        n_ch = state.shape[0]
+        if slot_stride is None:
+            slot_stride = 64 if low_pow else 128
+        b = _QmfAnaBatch()
+        b.n_ch, b.ch_fac, b.low_pow, b.usb, b.slot_stride = n_ch, int(ch_fac), int(bool(low_pow)), int(usb), slot_stride
+        b.pcm = _ptr(pcm, "int16", n_ch * 1024, device_ok=True)
+        b.state = _ptr(state, "int16", n_ch * QMF_ANA_STATE_WORDS, device_ok=True)
+        b.qmf = _ptr(qmf, "int32", n_ch * 32 * slot_stride, device_ok=True)
+        rc = self._lib.xaac_qmf_analysis_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_qmf_analysis_batch")
+
+    def qmf_synthesis_batch(self, qmf, scale, state, pcm, low_pow, lsb, usb, split=6, slot_stride=None, ch_fac=1):
+        """Batched ixheaacd_cplx_synt_qmffilt (no PS): 32 slots x 64 bands -> 2048 PCM16 per channel.
+        qmf int32[n_ch, 32, slot_stride]; scale int16[n_ch, 4] = lb_scale, ov_lb_scale, hb_scale, st_syn_scale;
+        state int16[n_ch, 1282] in/out; pcm int16[n_ch*2048] interleaved at ch_fac."""
+        n_ch = state.shape[0]
+        if slot_stride is None:
+            slot_stride = 64 if low_pow else 128
+        b = _QmfSynBatch()
+        b.n_ch, b.ch_fac, b.low_pow, b.lsb, b.usb, b.split = n_ch, int(ch_fac), int(bool(low_pow)), int(lsb), int(usb), int(split)
+        b.slot_stride = slot_stride
+        b.qmf = _ptr(qmf, "int32", n_ch * 32 * slot_stride, device_ok=True)
+        b.scale = _ptr(scale, "int16", n_ch * 4, device_ok=True)
+        b.state = _ptr(state, "int16", n_ch * QMF_SYN_STATE_WORDS, device_ok=True)
+        b.pcm = _ptr(pcm, "int16", n_ch * 2048, device_ok=True)
+        rc = self._lib.xaac_qmf_synthesis_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_qmf_synthesis_batch")

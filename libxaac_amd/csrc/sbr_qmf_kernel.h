@@ -1,0 +1,42 @@
+/* sbr_qmf_kernel.h -- launch interface of the SBR QMF kernels (internal). */
+#ifndef XAAC_SBR_QMF_KERNEL_H
+#define XAAC_SBR_QMF_KERNEL_H
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "../../include/xaac_amd.h"
+
+#define XAAC_QMF_WAVES 2                       /* waves per workgroup; each wave owns two channel-frames */
+#define XAAC_QMF_BLOCK (64 * XAAC_QMF_WAVES)
+/* analysis: 2 x 1312 int16 history (+pad) and a 64 x 65 int32 exchange tile */
+#define XAAC_QMF_ANA_LDS_PER_WAVE (2 * 1312 * 2 + 32 + 64 * 65 * 4)
+/* synthesis: max(row tile, ring-sample store) ; row tile 64 x (64|128)+1 words, store 2 x 41 x 128 int16 */
+#define XAAC_QMF_SYN_LDS_PER_WAVE_LP 20992
+#define XAAC_QMF_SYN_LDS_PER_WAVE_HQ (64 * 129 * 4)
+
+typedef struct XaacQmfAnaParams {
+  int32_t n_ch, ch_fac, low_pow, usb, slot_stride;
+  const int16_t *pcm;
+  xaac_qmf_ana_state *state;
+  int32_t *qmf;
+} XaacQmfAnaParams;
+
+typedef struct XaacQmfSynParams {
+  int32_t n_ch, ch_fac, low_pow, lsb, usb, split, slot_stride;
+  const int32_t *qmf;
+  const int16_t *scale;
+  xaac_qmf_syn_state *state;
+  int16_t *pcm;
+} XaacQmfSynParams;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+hipError_t xaac_launch_qmf_analysis(const XaacQmfAnaParams *p, int grid, hipStream_t stream);
+hipError_t xaac_launch_qmf_synthesis(const XaacQmfSynParams *p, int grid, hipStream_t stream);
+int xaac_qmf_blocks_per_cu(int which);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,303 @@
+/*
+ * sbr_qmf_kernel.hip -- gfx950 kernels for the fixed-point SBR QMF banks:
+ *   xaac_qmf_analysis_kernel   <->  ixheaacd_cplx_anal_qmffilt  (generic/ixheaacd_qmf_dec_generic.c:590)
+ *   xaac_qmf_synthesis_kernel  <->  ixheaacd_cplx_synt_qmffilt  (ixheaacd_qmf_dec.c:811, no-PS branch)
+ * low-power (real) and HQ (complex) modes, one frame = 32 slots per channel.
+ *
+ * MI355X mapping.  The reference runs the 32 slots of a frame one after another through
+ * pointer-rotated ring buffers.  Both banks are time-invariant polyphase FIRs around a
+ * per-slot transform, and neither window-add can saturate (sum|c| over the 5 analysis taps
+ * is 32757, over the 10 synthesis taps 57308 -> |acc| < 2^31), so the accumulation order
+ * is immaterial and every slot is independent given the frame's samples plus the history
+ * the ring holds:
+ *   analysis   z[s][m] = sum_{j<5}  x[32s+31 - (m+64j)] * c[2m+128j]
+ *   synthesis  y[s][k] = rnd + sum_{A<10} v[s-A][64(A&1)+k] * c[64A+k]
+ * (pairings derived by simulating the reference's pointer state machines; the ring layout
+ * itself is kept as the persistent state so it stays word-identical with the reference).
+ * One wave handles TWO channel-frames:
+ *   - window-add phases: lanes = the 64 polyphase outputs, loop over slots, history in LDS,
+ *     the lane's 5/10 coefficients held in registers;
+ *   - transform phase: ONE LANE = ONE SLOT (2 x 32 slots = 64 lanes) running the scalar
+ *     code of sbr_qmf.h on private registers -- the transforms are 16/32-point FFT sized,
+ *     the batch supplies the parallelism, no cross-lane traffic;
+ *   - rows move between the two layouts through a padded LDS tile (stride 65/129 words,
+ *     conflict-free both ways), HBM sees only coalesced row accesses.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sbr_qmf.h"
+#include "sbr_qmf_kernel.h"
+
+namespace {
+
+constexpr int kHist = 288 + 1024; /* analysis: time-ordered samples, oldest first */
+
+/* where the analysis ring keeps the sample of age a (0 = newest) when the next write goes to wr */
+__device__ __forceinline__ int ana_ring_pos(int wr, int a) {
+  int p = wr + 32 + a;
+  return p >= 320 ? p - 320 : p;
+}
+
+/* 32 steps of the window-phase bookkeeping of generic:698-722 (does not influence the samples) */
+__device__ __forceinline__ int ana_phase_after_frame(int phase) {
+  int f1 = phase, f2 = phase + 64;
+  for (int s = 0; s < 32; s++) {
+    f1 += 64;
+    f2 += 64;
+    int t = f1;
+    f1 = f2;
+    f2 = t;
+    if (f2 > 640) {
+      f1 = 0;
+      f2 = 64;
+    }
+  }
+  return f1;
+}
+
+/* env_calc.c:1099 */
+__device__ __forceinline__ int32_t adj_scale(int32_t v, int shift) {
+  if (shift > 31) shift = 31;
+  if (shift < -31) shift = -31;
+  return shift > 0 ? fx_shlw(v, shift) : (shift < 0 ? (v >> -shift) : v);
+}
+
+}  // namespace
+
+/* ===================================================================================== */
+template <bool LP>
+__global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_analysis_kernel(XaacQmfAnaParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char *wbase = smem + wave * XAAC_QMF_ANA_LDS_PER_WAVE;
+  int16_t *hist = reinterpret_cast<int16_t *>(wbase);            /* [2][kHist] */
+  int32_t *z = reinterpret_cast<int32_t *>(wbase + 2 * kHist * 2 + 32); /* [64][65] */
+
+  int32_t coef[5]; /* c[2m + 128 j] of this lane's polyphase branch m = lane */
+#pragma unroll
+  for (int j = 0; j < 5; j++) coef[j] = xaac_qmf_qmf_c[2 * lane + 128 * j];
+
+  const int n_pairs = (p.n_ch + 1) >> 1;
+  const int waves_total = gridDim.x * XAAC_QMF_WAVES;
+  for (int pair = blockIdx.x * XAAC_QMF_WAVES + wave; pair < n_pairs; pair += waves_total) {
+    /* ---- history + new samples, time ordered ------------------------------------------ */
+    for (int c = 0; c < 2; c++) {
+      const int ch = 2 * pair + c;
+      int16_t *h = hist + c * kHist;
+      if (ch < p.n_ch) {
+        const xaac_qmf_ana_state *st = p.state + ch;
+        const int wr = st->wr;
+        for (int a = lane; a < 288; a += 64) h[287 - a] = st->ring[ana_ring_pos(wr, a)];
+        const int cf = p.ch_fac;
+        const int16_t *src = p.pcm + (size_t)(ch / cf) * 1024 * cf + (ch % cf);
+        for (int i = lane; i < 1024; i += 64) h[288 + i] = src[(size_t)i * cf];
+      } else {
+        for (int i = lane; i < kHist; i += 64) h[i] = 0;
+      }
+    }
+    /* ---- window-add: lanes = polyphase branch m, loop over the 2 x 32 slots ------------- */
+    for (int r = 0; r < 64; r++) {
+      const int16_t *h = hist + (r >> 5) * kHist + 288 + 32 * (r & 31) + 31 - lane;
+      int32_t acc = 0;
+#pragma unroll
+      for (int j = 0; j < 5; j++) acc += (int32_t)h[-64 * j] * coef[j]; /* |acc| < 2^30: exact */
+      z[65 * r + lane] = acc;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    /* ---- per-slot transform: lane = slot ------------------------------------------------ */
+    {
+      int32_t in[64];
+#pragma unroll
+      for (int k = 0; k < 64; k++) in[k] = z[65 * lane + k];
+      if (LP) {
+        int32_t out[32];
+        xq_dct3_32(in, out);
+#pragma unroll
+        for (int k = 0; k < 32; k++) z[65 * lane + k] = out[k];
+      } else {
+        int32_t sb[128], t[128];
+        xq_fwd_modulation(in, sb, t, p.usb);
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+          z[65 * lane + k] = sb[k];
+          z[65 * lane + 32 + k] = sb[64 + k];
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    /* ---- rows out: coalesced, real bands at +0, imaginary (HQ) at +64 ---------------------- */
+    for (int r = 0; r < 64; r++) {
+      const int ch = 2 * pair + (r >> 5);
+      if (ch >= p.n_ch) break;
+      int32_t *row = p.qmf + ((size_t)ch * 32 + (r & 31)) * p.slot_stride;
+      if (LP) {
+        if (lane < 32) row[lane] = z[65 * r + lane];
+      } else {
+        row[(lane & 31) + 64 * (lane >> 5)] = z[65 * r + lane];
+      }
+    }
+    /* ---- state: the ring as the reference leaves it after 32 slots -------------------------- */
+    for (int c = 0; c < 2; c++) {
+      const int ch = 2 * pair + c;
+      if (ch >= p.n_ch) break;
+      xaac_qmf_ana_state *st = p.state + ch;
+      const int wr_new = (st->wr + 256) % 320;
+      const int ph_new = ana_phase_after_frame(st->phase);
+      const int16_t *h = hist + c * kHist;
+      for (int a = lane; a < 320; a += 64) st->ring[ana_ring_pos(wr_new, a)] = h[kHist - 1 - a];
+      if (lane == 0) {
+        st->wr = (int16_t)wr_new;
+        st->phase = (int16_t)ph_new;
+      }
+    }
+  }
+}
+
+/* ===================================================================================== */
+template <bool LP>
+__global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(XaacQmfSynParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ROW = LP ? 64 : 128;    /* words per slot row */
+  constexpr int RS = ROW + 1;           /* padded LDS row stride */
+  constexpr int VSLOTS = 9 + 32;        /* 9 slots of history + this frame */
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char *wbase = smem + wave * (LP ? XAAC_QMF_SYN_LDS_PER_WAVE_LP : XAAC_QMF_SYN_LDS_PER_WAVE_HQ);
+  int32_t *rows = reinterpret_cast<int32_t *>(wbase);  /* [64][RS] slot rows, later aliased by ... */
+  int16_t *v = reinterpret_cast<int16_t *>(wbase);     /* ... [2][VSLOTS][128] ring samples */
+
+  int32_t coef[10]; /* c[64 A + k], k = lane */
+#pragma unroll
+  for (int a = 0; a < 10; a++) coef[a] = xaac_qmf_qmf_c[64 * a + lane];
+
+  const int n_pairs = (p.n_ch + 1) >> 1;
+  const int waves_total = gridDim.x * XAAC_QMF_WAVES;
+  for (int pair = blockIdx.x * XAAC_QMF_WAVES + wave; pair < n_pairs; pair += waves_total) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    /* ---- slot rows in, coalesced --------------------------------------------------------------- */
+    for (int r = 0; r < 64; r++) {
+      const int ch = 2 * pair + (r >> 5);
+      if (ch < p.n_ch) {
+        const int32_t *row = p.qmf + ((size_t)ch * 32 + (r & 31)) * p.slot_stride;
+        for (int k = lane; k < ROW; k += 64) rows[RS * r + k] = row[k];
+      } else {
+        for (int k = lane; k < ROW; k += 64) rows[RS * r + k] = 0;
+      }
+    }
+    /* ---- per-slot: region rescale (qmf_dec.c:937-953) + inverse modulation; lane = slot ----------- */
+    int16_t b[128];
+    {
+      const int ch = 2 * pair + (lane >> 5);
+      const int chc = ch < p.n_ch ? ch : p.n_ch - 1;
+      const int16_t *sf = p.scale + 4 * chc; /* lb_scale, ov_lb_scale, hb_scale, st_syn_scale */
+      const int st_syn = sf[3];
+      const int bias = LP ? 4 : 8;
+      const int s = lane & 31;
+      const int lo_shift = (st_syn - (s < p.split ? sf[1] : sf[0])) - bias;
+      const int hb_shift = (st_syn - sf[2]) - bias;
+      int32_t x[ROW], t[ROW];
+#pragma unroll
+      for (int k = 0; k < ROW; k++) {
+        int32_t val = rows[RS * lane + k];
+        const int band = k & 63;
+        val = band < p.lsb ? adj_scale(val, lo_shift) : (band < p.usb ? adj_scale(val, hb_shift) : val);
+        x[k] = val;
+      }
+      if (LP)
+        xq_dct2_64_lp(x, t, b);
+      else
+        xq_synth_hq_slot(x, t, b, -(st_syn - 3) + 1);
+    }
+    /* all lanes hold their slot in registers now: the row tile may be overwritten (the tile is
+       re-used through an int16 view: keep the compiler from moving accesses across this point) */
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+      int16_t *dst = v + ((lane >> 5) * VSLOTS + 9 + (lane & 31)) * 128;
+#pragma unroll
+      for (int i = 0; i < 128; i += 2)
+        *reinterpret_cast<int32_t *>(dst + i) = (int32_t)((uint32_t)(uint16_t)b[i] | ((uint32_t)(uint16_t)b[i + 1] << 16));
+    }
+    for (int c = 0; c < 2; c++) {
+      const int ch = 2 * pair + c;
+      if (ch >= p.n_ch) break;
+      const xaac_qmf_syn_state *st = p.state + ch;
+      const int d = st->drc_offset;
+      for (int i = lane; i < 9 * 128; i += 64) {
+        const int A = 9 - (i >> 7); /* slot age relative to this frame's slot 0 */
+        int pos = d + 128 * A + (i & 127);
+        if (pos >= 1280) pos -= 1280;
+        v[(c * VSLOTS + (i >> 7)) * 128 + (i & 127)] = st->ring[pos];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    /* ---- window-add: lanes = output sample k of the slot, loop over slots ------------------------ */
+    for (int c = 0; c < 2; c++) {
+      const int ch = 2 * pair + c;
+      if (ch >= p.n_ch) break;
+      const int cf = p.ch_fac;
+      int16_t *dst = p.pcm + (size_t)(ch / cf) * 2048 * cf + (ch % cf);
+      const int shift = LP ? 2 : 1;
+      for (int s = 0; s < 32; s++) {
+        const int16_t *vs = v + (c * VSLOTS + 9 + s) * 128 + lane;
+        int32_t acc = 0x8000 >> shift;
+#pragma unroll
+        for (int A = 0; A < 10; A++) acc += (int32_t)vs[-128 * A + 64 * (A & 1)] * coef[A]; /* < 2^31: exact */
+        dst[(size_t)(64 * s + lane) * cf] = (int16_t)(fx_shl_sat(acc, shift) >> 16);
+      }
+    }
+    /* ---- state: ring blocks of the last 10 slots, drc offset, window phase --------------------------- */
+    for (int c = 0; c < 2; c++) {
+      const int ch = 2 * pair + c;
+      if (ch >= p.n_ch) break;
+      xaac_qmf_syn_state *st = p.state + ch;
+      const int d_new = (st->drc_offset + 1024) % 1280;
+      const int ph_new = (st->phase + 128) % 640;
+      for (int i = lane; i < 1280; i += 64) {
+        const int A = 1 + (i >> 7); /* age relative to the NEXT frame's slot 0: 1..10 */
+        int pos = d_new + 128 * A + (i & 127);
+        if (pos >= 1280) pos -= 1280;
+        if (pos >= 1280) pos -= 1280;
+        st->ring[pos] = v[(c * VSLOTS + 9 + 32 - A) * 128 + (i & 127)];
+      }
+      if (lane == 0) {
+        st->drc_offset = (int16_t)d_new;
+        st->phase = (int16_t)ph_new;
+      }
+    }
+  }
+}
+
+extern "C" hipError_t xaac_launch_qmf_analysis(const XaacQmfAnaParams *p, int grid, hipStream_t stream) {
+  if (p->low_pow)
+    hipLaunchKernelGGL(xaac_qmf_analysis_kernel<true>, dim3(grid), dim3(XAAC_QMF_BLOCK),
+                       XAAC_QMF_WAVES * XAAC_QMF_ANA_LDS_PER_WAVE, stream, *p);
+  else
+    hipLaunchKernelGGL(xaac_qmf_analysis_kernel<false>, dim3(grid), dim3(XAAC_QMF_BLOCK),
+                       XAAC_QMF_WAVES * XAAC_QMF_ANA_LDS_PER_WAVE, stream, *p);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t xaac_launch_qmf_synthesis(const XaacQmfSynParams *p, int grid, hipStream_t stream) {
+  if (p->low_pow)
+    hipLaunchKernelGGL(xaac_qmf_synthesis_kernel<true>, dim3(grid), dim3(XAAC_QMF_BLOCK),
+                       XAAC_QMF_WAVES * XAAC_QMF_SYN_LDS_PER_WAVE_LP, stream, *p);
+  else
+    hipLaunchKernelGGL(xaac_qmf_synthesis_kernel<false>, dim3(grid), dim3(XAAC_QMF_BLOCK),
+                       XAAC_QMF_WAVES * XAAC_QMF_SYN_LDS_PER_WAVE_HQ, stream, *p);
+  return hipGetLastError();
+}
+
+extern "C" int xaac_qmf_blocks_per_cu(int which) {
+  int n = 0;
+  hipError_t e;
+  switch (which) {
+    case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, xaac_qmf_analysis_kernel<true>, XAAC_QMF_BLOCK, XAAC_QMF_WAVES * XAAC_QMF_ANA_LDS_PER_WAVE); break;
+    case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, xaac_qmf_analysis_kernel<false>, XAAC_QMF_BLOCK, XAAC_QMF_WAVES * XAAC_QMF_ANA_LDS_PER_WAVE); break;
+    case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, xaac_qmf_synthesis_kernel<true>, XAAC_QMF_BLOCK, XAAC_QMF_WAVES * XAAC_QMF_SYN_LDS_PER_WAVE_LP); break;
+    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, xaac_qmf_synthesis_kernel<false>, XAAC_QMF_BLOCK, XAAC_QMF_WAVES * XAAC_QMF_SYN_LDS_PER_WAVE_HQ); break;
+  }
+  if (e != hipSuccess || n < 1) n = 1;
+  return n;
+}

@@ -13,6 +13,7 @@
 
 #include "../../include/xaac_amd.h"
 #include "imdct_kernel.h"
+#include "sbr_qmf_kernel.h"
 
 struct xaac_ctx {
   int device;
@@ -20,6 +21,7 @@ struct xaac_ctx {
   bool owns_stream;
   int num_cu;
   int blocks_per_cu;
+  int qmf_blocks_per_cu[4];
   int last_grid, last_block, last_lds;
 };
 
@@ -79,6 +81,7 @@ int32_t xaac_create(xaac_ctx **out, int32_t device, void *hip_stream) {
   }
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c->blocks_per_cu = xaac_imdct_blocks_per_cu();
+  for (int i = 0; i < 4; i++) c->qmf_blocks_per_cu[i] = xaac_qmf_blocks_per_cu(i);
   c->last_grid = c->last_block = c->last_lds = 0;
   *out = c;
   return XAAC_OK;
@@ -178,6 +181,49 @@ int32_t xaac_imdct_process_batch_host(xaac_ctx *c, const xaac_imdct_batch *hb) {
   (void)hipFree(d);
   if (rc != XAAC_OK) return rc;
   return (ok && synced) ? XAAC_OK : XAAC_FATAL_HIP;
+}
+
+static int qmf_grid(const xaac_ctx *c, int n_ch, int which) {
+  int pairs = (n_ch + 1) / 2;
+  int need = (pairs + XAAC_QMF_WAVES - 1) / XAAC_QMF_WAVES;
+  int resident = c->num_cu * c->qmf_blocks_per_cu[which];
+  int g = need < resident ? need : resident;
+  return g < 1 ? 1 : g;
+}
+
+int32_t xaac_qmf_analysis_batch(xaac_ctx *c, const xaac_qmf_ana_batch *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n_ch < 0 || (b->ch_fac != 1 && b->ch_fac != 2) || b->n_ch % b->ch_fac) return XAAC_FATAL_BAD_ARG;
+  if (b->slot_stride < (b->low_pow ? 32 : 96) || b->usb < 0 || b->usb > 32) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch == 0) return XAAC_OK;
+  if (!b->pcm || !b->state || !b->qmf) return XAAC_FATAL_NULL_ARG;
+  XaacQmfAnaParams p;
+  p.n_ch = b->n_ch; p.ch_fac = b->ch_fac; p.low_pow = b->low_pow ? 1 : 0; p.usb = b->usb;
+  p.slot_stride = b->slot_stride; p.pcm = b->pcm; p.state = b->state; p.qmf = b->qmf;
+  const int grid = qmf_grid(c, b->n_ch, p.low_pow ? 0 : 1);
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  if (!hip_ok(xaac_launch_qmf_analysis(&p, grid, c->stream))) return XAAC_FATAL_HIP;
+  c->last_grid = grid; c->last_block = XAAC_QMF_BLOCK; c->last_lds = XAAC_QMF_WAVES * XAAC_QMF_ANA_LDS_PER_WAVE;
+  return XAAC_OK;
+}
+
+int32_t xaac_qmf_synthesis_batch(xaac_ctx *c, const xaac_qmf_syn_batch *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n_ch < 0 || (b->ch_fac != 1 && b->ch_fac != 2) || b->n_ch % b->ch_fac) return XAAC_FATAL_BAD_ARG;
+  if (b->slot_stride < (b->low_pow ? 64 : 128)) return XAAC_FATAL_BAD_ARG;
+  if (b->lsb < 0 || b->usb < b->lsb || b->usb > 64 || b->split < 0 || b->split > 32) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch == 0) return XAAC_OK;
+  if (!b->qmf || !b->scale || !b->state || !b->pcm) return XAAC_FATAL_NULL_ARG;
+  XaacQmfSynParams p;
+  p.n_ch = b->n_ch; p.ch_fac = b->ch_fac; p.low_pow = b->low_pow ? 1 : 0; p.lsb = b->lsb; p.usb = b->usb;
+  p.split = b->split; p.slot_stride = b->slot_stride; p.qmf = b->qmf; p.scale = b->scale; p.state = b->state;
+  p.pcm = b->pcm;
+  const int grid = qmf_grid(c, b->n_ch, p.low_pow ? 2 : 3);
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  if (!hip_ok(xaac_launch_qmf_synthesis(&p, grid, c->stream))) return XAAC_FATAL_HIP;
+  c->last_grid = grid; c->last_block = XAAC_QMF_BLOCK;
+  c->last_lds = XAAC_QMF_WAVES * (p.low_pow ? XAAC_QMF_SYN_LDS_PER_WAVE_LP : XAAC_QMF_SYN_LDS_PER_WAVE_HQ);
+  return XAAC_OK;
 }
 
 int32_t xaac_last_launch(xaac_ctx *c, int32_t *grid, int32_t *block, int32_t *lds_bytes) {

@@ -61,6 +61,41 @@ class Oracle:
                 "overlap": ovl, "state": np.stack([pseq, pshape], 1).astype(np.uint8)}
 
 
+class QmfAnaState(ctypes.Structure):
+    _fields_ = [("ring", ctypes.c_int16 * 320), ("wr", ctypes.c_int16), ("phase", ctypes.c_int16)]
+
+
+class QmfSynState(ctypes.Structure):
+    _fields_ = [("ring", ctypes.c_int16 * 1280), ("drc_offset", ctypes.c_int16), ("phase", ctypes.c_int16)]
+
+
+def qmf_analysis_batch(orc, pcm, state, low_pow, usb, slot_stride, ch_fac=1):
+    """oracle over a batch with the C ABI's conventions; state int16[n,322] (updated copy returned)"""
+    n = state.shape[0]
+    state = np.array(state, np.int16)
+    qmf = np.zeros((n, 32, slot_stride), np.int32)
+    for i in range(n):
+        st = QmfAnaState.from_buffer(state[i])
+        src = pcm[(i // ch_fac) * 1024 * ch_fac + (i % ch_fac):]
+        orc.lib.xo_qmf_analysis(_p(np.ascontiguousarray(src), P16), ch_fac, ctypes.byref(st), int(low_pow), int(usb),
+                                _p(qmf[i], P32), slot_stride)
+    return qmf, state
+
+
+def qmf_synthesis_batch(orc, qmf, scale, state, low_pow, lsb, usb, split, ch_fac=1):
+    n = state.shape[0]
+    state = np.array(state, np.int16)
+    slot_stride = qmf.shape[2]
+    pcm = np.zeros(n * 2048, np.int16)
+    for i in range(n):
+        st = QmfSynState.from_buffer(state[i])
+        dst = pcm[(i // ch_fac) * 2048 * ch_fac + (i % ch_fac):]
+        orc.lib.xo_qmf_synthesis(_p(np.ascontiguousarray(qmf[i]), P32), slot_stride,
+                                 _p(np.ascontiguousarray(scale[i]), P16), int(lsb), int(usb), int(split),
+                                 ctypes.byref(st), int(low_pow), _p(dst, P16), ch_fac)
+    return pcm, state
+
+
 class Reference:
     def __init__(self, lib):
         self.lib = lib
