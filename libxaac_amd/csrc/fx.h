@@ -20,8 +20,10 @@
 
 #if defined(__HIPCC__)
 #define FX_HD __host__ __device__ __forceinline__
+#define FX_MEMBER __host__ __device__ __forceinline__
 #else
 #define FX_HD static inline
+#define FX_MEMBER inline
 #endif
 
 #define FX_MAX32 ((int32_t)0x7fffffff)
