@@ -42,9 +42,25 @@ class State(ctypes.Structure):
                 ("harm_flags_prev", I8 * 56)]
 
 
+def diff_state(a, b):
+    """list of (field, detail) where two State structs differ"""
+    out = []
+    for n, _ in State._fields_:
+        va, vb = getattr(a, n), getattr(b, n)
+        if hasattr(va, "__len__"):
+            xa, xb = np.ctypeslib.as_array(va).ravel(), np.ctypeslib.as_array(vb).ravel()
+            if not np.array_equal(xa, xb):
+                out.append((n, int(np.sum(xa != xb)), np.nonzero(xa != xb)[0][:6].tolist()))
+        elif va != vb:
+            out.append((n, va, vb))
+    return out
+
+
 def read_records(path, limit=None):
+    import gzip
     recs = []
-    with open(path, "rb") as f:
+    opener = gzip.open if str(path).endswith(".gz") else open
+    with opener(path, "rb") as f:
         while True:
             m = f.read(32)
             if len(m) < 32:
