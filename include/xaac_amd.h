@@ -30,6 +30,8 @@
 
 #include <stdint.h>
 
+#include "xaac_sbr.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -132,6 +134,24 @@ typedef struct xaac_qmf_syn_batch {
   int16_t *pcm;              /* 2048 samples per channel, interleaved at ch_fac */
 } xaac_qmf_syn_batch;
 
+/* ---- low-power SBR, whole channel-frame (HE-AACv1) ---------------------------------------
+ * xaac_sbr_lp_process_batch <-> ixheaacd_sbr_dec with low_pow_flag = 1
+ *      def decoder/ixheaacd_sbr_dec.c:662, call sites decoder/ixheaacd_sbrdecoder.c:877 / :943
+ * N independent channels, one frame each: core PCM16 (1024) + SBR side info -> 2048 PCM16, with the
+ * per-channel state of xaac_sbr_state carried in device memory.  Formats: xaac_sbr.h. */
+typedef struct xaac_sbr_lp_batch {
+  int32_t n_ch;
+  int32_t in_ch_fac, out_ch_fac;   /* interleave strides of pcm_in (1024/ch) and pcm_out (2048/ch) */
+  const int16_t *pcm_in;
+  const xaac_sbr_header *header;   /* [n_ch] (channels of one stream carry copies) */
+  const xaac_sbr_frame *frame;     /* [n_ch] */
+  xaac_sbr_state *state;           /* [n_ch] in/out */
+  int16_t *pcm_out;
+  int32_t *status;                 /* optional [n_ch]: 0, or -1 where the reference would have failed the frame */
+  void *workspace;                 /* device scratch, >= xaac_sbr_lp_workspace_bytes(n_ch) */
+  uint64_t workspace_bytes;
+} xaac_sbr_lp_batch;
+
 typedef struct xaac_ctx xaac_ctx;
 
 /* Create a context bound to HIP device `device`.  `hip_stream` is a
@@ -153,6 +173,10 @@ int32_t xaac_imdct_process_batch_host(xaac_ctx *ctx, const xaac_imdct_batch *bat
 /* SBR QMF banks, device pointers, asynchronous on the context's stream. */
 int32_t xaac_qmf_analysis_batch(xaac_ctx *ctx, const xaac_qmf_ana_batch *batch);
 int32_t xaac_qmf_synthesis_batch(xaac_ctx *ctx, const xaac_qmf_syn_batch *batch);
+
+/* Low-power SBR channel-frames (QMF analysis -> HF generation + envelope adjustment -> QMF synthesis). */
+uint64_t xaac_sbr_lp_workspace_bytes(int32_t n_ch);
+int32_t xaac_sbr_lp_process_batch(xaac_ctx *ctx, const xaac_sbr_lp_batch *batch);
 
 /* Launch geometry the library used for the last batch (for reports). */
 int32_t xaac_last_launch(xaac_ctx *ctx, int32_t *grid, int32_t *block, int32_t *lds_bytes);

@@ -62,6 +62,15 @@ class _QmfSynBatch(ctypes.Structure):
                 ("state", ctypes.c_void_p), ("pcm", ctypes.c_void_p)]
 
 
+class _SbrLpBatch(ctypes.Structure):
+    # struct xaac_sbr_lp_batch
+    _fields_ = [("n_ch", ctypes.c_int32), ("in_ch_fac", ctypes.c_int32), ("out_ch_fac", ctypes.c_int32),
+                ("pcm_in", ctypes.c_void_p), ("header", ctypes.c_void_p), ("frame", ctypes.c_void_p),
+                ("state", ctypes.c_void_p), ("pcm_out", ctypes.c_void_p), ("status", ctypes.c_void_p),
+                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_uint64)]
+
+
+SBR_HEADER_BYTES, SBR_FRAME_BYTES, SBR_STATE_BYTES = 336, 1072, 7300   # include/xaac_sbr.h
 QMF_ANA_STATE_WORDS = 322    # int16 words of struct xaac_qmf_ana_state: ring[320], wr, phase
 QMF_SYN_STATE_WORDS = 1282   # int16 words of struct xaac_qmf_syn_state: ring[1280], drc_offset, phase
 
@@ -95,6 +104,10 @@ def load_library():
     lib.xaac_last_launch.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int32)] * 3
     lib.xaac_qmf_analysis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_QmfAnaBatch)]
     lib.xaac_qmf_synthesis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_QmfSynBatch)]
+    lib.xaac_sbr_lp_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_SbrLpBatch)]
+    lib.xaac_sbr_lp_process_batch.restype = ctypes.c_int32
+    lib.xaac_sbr_lp_workspace_bytes.argtypes = [ctypes.c_int32]
+    lib.xaac_sbr_lp_workspace_bytes.restype = ctypes.c_uint64
     for f in ("xaac_create", "xaac_destroy", "xaac_sync", "xaac_set_stream", "xaac_imdct_process_batch",
               "xaac_imdct_process_batch_host", "xaac_last_launch", "xaac_qmf_analysis_batch",
               "xaac_qmf_synthesis_batch"):
@@ -240,3 +253,27 @@ class XaacContext:
         rc = self._lib.xaac_qmf_synthesis_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_qmf_synthesis_batch")
+
+    def sbr_lp_workspace_bytes(self, n_ch):
+        return int(self._lib.xaac_sbr_lp_workspace_bytes(int(n_ch)))
+
+    def sbr_lp_process_batch(self, pcm_in, header, frame, state, pcm_out, workspace, status=None, in_ch_fac=1,
+                             out_ch_fac=1):
+        """Batched ixheaacd_sbr_dec, low-power mode (HE-AACv1): one frame per channel.
+        pcm_in int16[n_ch*1024]; header/frame/state uint8[n_ch, SBR_*_BYTES] (structs of include/xaac_sbr.h,
+        state in/out); pcm_out int16[n_ch*2048]; workspace uint8[>= sbr_lp_workspace_bytes(n_ch)];
+        status optional int32[n_ch]."""
+        n_ch = state.shape[0]
+        b = _SbrLpBatch()
+        b.n_ch, b.in_ch_fac, b.out_ch_fac = n_ch, int(in_ch_fac), int(out_ch_fac)
+        b.pcm_in = _ptr(pcm_in, "int16", n_ch * 1024, device_ok=True)
+        b.header = _ptr(header, "uint8", n_ch * SBR_HEADER_BYTES, device_ok=True)
+        b.frame = _ptr(frame, "uint8", n_ch * SBR_FRAME_BYTES, device_ok=True)
+        b.state = _ptr(state, "uint8", n_ch * SBR_STATE_BYTES, device_ok=True)
+        b.pcm_out = _ptr(pcm_out, "int16", n_ch * 2048, device_ok=True)
+        b.status = _ptr(status, "int32", n_ch, allow_none=True, device_ok=True)
+        b.workspace = _ptr(workspace, "uint8", device_ok=True)
+        b.workspace_bytes = workspace.numel()
+        rc = self._lib.xaac_sbr_lp_process_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_sbr_lp_process_batch")

@@ -1,0 +1,30 @@
+/* sbr_core_kernel.h -- launch interface of the SBR core kernel (internal). */
+#ifndef XAAC_SBR_CORE_KERNEL_H
+#define XAAC_SBR_CORE_KERNEL_H
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "../../include/xaac_amd.h"
+
+#define XAAC_SBR_X_ROWS 40                       /* 2 LPC history rows + 6 overlap slots + 32 new slots */
+#define XAAC_SBR_X_WORDS (XAAC_SBR_X_ROWS * 64)  /* int32 words of one channel's QMF matrix */
+
+typedef struct XaacSbrCoreParams {
+  int32_t n_ch;
+  const xaac_sbr_header *header;
+  const xaac_sbr_frame *frame;
+  xaac_sbr_state *state;
+  int32_t *x;        /* [n_ch][XAAC_SBR_X_WORDS] */
+  int16_t *syn_par;  /* [n_ch][8]: lb, ov_lb, hb, st_syn scales, synthesis lsb, usb */
+  int32_t *status;   /* optional [n_ch] */
+} XaacSbrCoreParams;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+hipError_t xaac_launch_sbr_core_lp(const XaacSbrCoreParams *p, hipStream_t stream);
+#ifdef __cplusplus
+}
+#endif
+#endif

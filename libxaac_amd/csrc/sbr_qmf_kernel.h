@@ -15,8 +15,13 @@
 #define XAAC_QMF_SYN_LDS_PER_WAVE_LP 20992
 #define XAAC_QMF_SYN_LDS_PER_WAVE_HQ (64 * 129 * 4)
 
+/* state / qmf / scale are addressed with explicit per-channel strides so that the same kernels serve the
+   stand-alone QMF entry points (tight arrays) and the fused SBR path (fields inside xaac_sbr_state, rows
+   inside the per-channel 40 x 64 QMF matrix). */
 typedef struct XaacQmfAnaParams {
   int32_t n_ch, ch_fac, low_pow, usb, slot_stride;
+  int32_t state_stride;   /* bytes between consecutive channels' xaac_qmf_ana_state */
+  int32_t qmf_ch_stride;  /* words between consecutive channels' slot 0 */
   const int16_t *pcm;
   xaac_qmf_ana_state *state;
   int32_t *qmf;
@@ -24,6 +29,9 @@ typedef struct XaacQmfAnaParams {
 
 typedef struct XaacQmfSynParams {
   int32_t n_ch, ch_fac, low_pow, lsb, usb, split, slot_stride;
+  int32_t state_stride, qmf_ch_stride;
+  int32_t scale_stride;   /* int16 words between channels' {lb, ov_lb, hb, st_syn[, lsb, usb]} */
+  int32_t per_ch_bands;   /* 1: lsb/usb come from scale[4], scale[5] of each channel */
   const int32_t *qmf;
   const int16_t *scale;
   xaac_qmf_syn_state *state;

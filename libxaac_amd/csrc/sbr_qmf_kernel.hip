@@ -87,7 +87,8 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_analysis_kernel(XaacQ
       const int ch = 2 * pair + c;
       int16_t *h = hist + c * kHist;
       if (ch < p.n_ch) {
-        const xaac_qmf_ana_state *st = p.state + ch;
+        const xaac_qmf_ana_state *st = reinterpret_cast<const xaac_qmf_ana_state *>(
+            reinterpret_cast<const char *>(p.state) + (size_t)ch * p.state_stride);
         const int wr = st->wr;
         for (int a = lane; a < 288; a += 64) h[287 - a] = st->ring[ana_ring_pos(wr, a)];
         const int cf = p.ch_fac;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_analysis_kernel(XaacQ
     for (int r = 0; r < 64; r++) {
       const int ch = 2 * pair + (r >> 5);
       if (ch >= p.n_ch) break;
-      int32_t *row = p.qmf + ((size_t)ch * 32 + (r & 31)) * p.slot_stride;
+      int32_t *row = p.qmf + (size_t)ch * p.qmf_ch_stride + (size_t)(r & 31) * p.slot_stride;
       if (LP) {
         if (lane < 32) row[lane] = z[65 * r + lane];
       } else {
@@ -142,7 +143,8 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_analysis_kernel(XaacQ
     for (int c = 0; c < 2; c++) {
       const int ch = 2 * pair + c;
       if (ch >= p.n_ch) break;
-      xaac_qmf_ana_state *st = p.state + ch;
+      xaac_qmf_ana_state *st =
+          reinterpret_cast<xaac_qmf_ana_state *>(reinterpret_cast<char *>(p.state) + (size_t)ch * p.state_stride);
       const int wr_new = (st->wr + 256) % 320;
       const int ph_new = ana_phase_after_frame(st->phase);
       const int16_t *h = hist + c * kHist;
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
     for (int r = 0; r < 64; r++) {
       const int ch = 2 * pair + (r >> 5);
       if (ch < p.n_ch) {
-        const int32_t *row = p.qmf + ((size_t)ch * 32 + (r & 31)) * p.slot_stride;
+        const int32_t *row = p.qmf + (size_t)ch * p.qmf_ch_stride + (size_t)(r & 31) * p.slot_stride;
         for (int k = lane; k < ROW; k += 64) rows[RS * r + k] = row[k];
       } else {
         for (int k = lane; k < ROW; k += 64) rows[RS * r + k] = 0;
@@ -191,8 +193,9 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
     {
       const int ch = 2 * pair + (lane >> 5);
       const int chc = ch < p.n_ch ? ch : p.n_ch - 1;
-      const int16_t *sf = p.scale + 4 * chc; /* lb_scale, ov_lb_scale, hb_scale, st_syn_scale */
+      const int16_t *sf = p.scale + (size_t)p.scale_stride * chc; /* lb_scale, ov_lb_scale, hb_scale, st_syn_scale */
       const int st_syn = sf[3];
+      const int lsb = p.per_ch_bands ? sf[4] : p.lsb, usb = p.per_ch_bands ? sf[5] : p.usb;
       const int bias = LP ? 4 : 8;
       const int s = lane & 31;
       const int lo_shift = (st_syn - (s < p.split ? sf[1] : sf[0])) - bias;
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
       for (int k = 0; k < ROW; k++) {
         int32_t val = rows[RS * lane + k];
         const int band = k & 63;
-        val = band < p.lsb ? adj_scale(val, lo_shift) : (band < p.usb ? adj_scale(val, hb_shift) : val);
+        val = band < lsb ? adj_scale(val, lo_shift) : (band < usb ? adj_scale(val, hb_shift) : val);
         x[k] = val;
       }
       if (LP)
@@ -222,7 +225,8 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
     for (int c = 0; c < 2; c++) {
       const int ch = 2 * pair + c;
       if (ch >= p.n_ch) break;
-      const xaac_qmf_syn_state *st = p.state + ch;
+      const xaac_qmf_syn_state *st = reinterpret_cast<const xaac_qmf_syn_state *>(
+          reinterpret_cast<const char *>(p.state) + (size_t)ch * p.state_stride);
       const int d = st->drc_offset;
       for (int i = lane; i < 9 * 128; i += 64) {
         const int A = 9 - (i >> 7); /* slot age relative to this frame's slot 0 */
@@ -251,7 +255,8 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
     for (int c = 0; c < 2; c++) {
       const int ch = 2 * pair + c;
       if (ch >= p.n_ch) break;
-      xaac_qmf_syn_state *st = p.state + ch;
+      xaac_qmf_syn_state *st =
+          reinterpret_cast<xaac_qmf_syn_state *>(reinterpret_cast<char *>(p.state) + (size_t)ch * p.state_stride);
       const int d_new = (st->drc_offset + 1024) % 1280;
       const int ph_new = (st->phase + 128) % 640;
       for (int i = lane; i < 1280; i += 64) {

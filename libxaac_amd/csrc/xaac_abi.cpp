@@ -14,6 +14,8 @@
 #include "../../include/xaac_amd.h"
 #include "imdct_kernel.h"
 #include "sbr_qmf_kernel.h"
+#include "sbr_core_kernel.h"
+#include <cstddef>
 
 struct xaac_ctx {
   int device;
@@ -200,6 +202,7 @@ int32_t xaac_qmf_analysis_batch(xaac_ctx *c, const xaac_qmf_ana_batch *b) {
   XaacQmfAnaParams p;
   p.n_ch = b->n_ch; p.ch_fac = b->ch_fac; p.low_pow = b->low_pow ? 1 : 0; p.usb = b->usb;
   p.slot_stride = b->slot_stride; p.pcm = b->pcm; p.state = b->state; p.qmf = b->qmf;
+  p.state_stride = (int32_t)sizeof(xaac_qmf_ana_state); p.qmf_ch_stride = 32 * b->slot_stride;
   const int grid = qmf_grid(c, b->n_ch, p.low_pow ? 0 : 1);
   if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
   if (!hip_ok(xaac_launch_qmf_analysis(&p, grid, c->stream))) return XAAC_FATAL_HIP;
@@ -218,11 +221,57 @@ int32_t xaac_qmf_synthesis_batch(xaac_ctx *c, const xaac_qmf_syn_batch *b) {
   p.n_ch = b->n_ch; p.ch_fac = b->ch_fac; p.low_pow = b->low_pow ? 1 : 0; p.lsb = b->lsb; p.usb = b->usb;
   p.split = b->split; p.slot_stride = b->slot_stride; p.qmf = b->qmf; p.scale = b->scale; p.state = b->state;
   p.pcm = b->pcm;
+  p.state_stride = (int32_t)sizeof(xaac_qmf_syn_state); p.qmf_ch_stride = 32 * b->slot_stride;
+  p.scale_stride = 4; p.per_ch_bands = 0;
   const int grid = qmf_grid(c, b->n_ch, p.low_pow ? 2 : 3);
   if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
   if (!hip_ok(xaac_launch_qmf_synthesis(&p, grid, c->stream))) return XAAC_FATAL_HIP;
   c->last_grid = grid; c->last_block = XAAC_QMF_BLOCK;
   c->last_lds = XAAC_QMF_WAVES * (p.low_pow ? XAAC_QMF_SYN_LDS_PER_WAVE_LP : XAAC_QMF_SYN_LDS_PER_WAVE_HQ);
+  return XAAC_OK;
+}
+
+uint64_t xaac_sbr_lp_workspace_bytes(int32_t n_ch) {
+  if (n_ch < 0) return 0;
+  return (uint64_t)n_ch * (XAAC_SBR_X_WORDS * 4 + 8 * 2) + 256;
+}
+
+int32_t xaac_sbr_lp_process_batch(xaac_ctx *c, const xaac_sbr_lp_batch *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n_ch < 0) return XAAC_FATAL_BAD_ARG;
+  if ((b->in_ch_fac != 1 && b->in_ch_fac != 2) || (b->out_ch_fac != 1 && b->out_ch_fac != 2)) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch % b->in_ch_fac || b->n_ch % b->out_ch_fac) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch == 0) return XAAC_OK;
+  if (!b->pcm_in || !b->header || !b->frame || !b->state || !b->pcm_out || !b->workspace) return XAAC_FATAL_NULL_ARG;
+  if (b->workspace_bytes < xaac_sbr_lp_workspace_bytes(b->n_ch)) return XAAC_FATAL_BAD_ARG;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  int32_t *x = reinterpret_cast<int32_t *>(((uintptr_t)b->workspace + 255) & ~(uintptr_t)255);
+  int16_t *par = reinterpret_cast<int16_t *>(x + (size_t)b->n_ch * XAAC_SBR_X_WORDS);
+  char *st = reinterpret_cast<char *>(b->state);
+  /* 1. analysis bank: 32 new slots into rows 8..39 of each channel's matrix */
+  XaacQmfAnaParams pa;
+  pa.n_ch = b->n_ch; pa.ch_fac = b->in_ch_fac; pa.low_pow = 1; pa.usb = 32; pa.slot_stride = 64;
+  pa.state_stride = (int32_t)sizeof(xaac_sbr_state); pa.qmf_ch_stride = XAAC_SBR_X_WORDS;
+  pa.pcm = b->pcm_in;
+  pa.state = reinterpret_cast<xaac_qmf_ana_state *>(st + offsetof(xaac_sbr_state, ana_ring));
+  pa.qmf = x + (2 + 6) * 64;
+  if (!hip_ok(xaac_launch_qmf_analysis(&pa, qmf_grid(c, b->n_ch, 0), c->stream))) return XAAC_FATAL_HIP;
+  /* 2. everything between the banks */
+  XaacSbrCoreParams pc;
+  pc.n_ch = b->n_ch; pc.header = b->header; pc.frame = b->frame; pc.state = b->state; pc.x = x; pc.syn_par = par;
+  pc.status = b->status;
+  if (!hip_ok(xaac_launch_sbr_core_lp(&pc, c->stream))) return XAAC_FATAL_HIP;
+  /* 3. synthesis bank over rows 2..33 (the 6 delayed + first 26 new slots) */
+  XaacQmfSynParams ps;
+  ps.n_ch = b->n_ch; ps.ch_fac = b->out_ch_fac; ps.low_pow = 1; ps.lsb = 0; ps.usb = 0; ps.split = 6;
+  ps.slot_stride = 64; ps.state_stride = (int32_t)sizeof(xaac_sbr_state); ps.qmf_ch_stride = XAAC_SBR_X_WORDS;
+  ps.scale_stride = 8; ps.per_ch_bands = 1;
+  ps.qmf = x + 2 * 64; ps.scale = par;
+  ps.state = reinterpret_cast<xaac_qmf_syn_state *>(st + offsetof(xaac_sbr_state, syn_ring));
+  ps.pcm = b->pcm_out;
+  const int grid = qmf_grid(c, b->n_ch, 2);
+  if (!hip_ok(xaac_launch_qmf_synthesis(&ps, grid, c->stream))) return XAAC_FATAL_HIP;
+  c->last_grid = grid; c->last_block = XAAC_QMF_BLOCK; c->last_lds = XAAC_QMF_WAVES * XAAC_QMF_SYN_LDS_PER_WAVE_LP;
   return XAAC_OK;
 }
 

@@ -1,0 +1,101 @@
+"""Low-power SBR (HE-AACv1 channel-frames) on the GPU through the C ABI: against the committed records of the
+real reference, and against the oracle on long fuzzed chains with the state living on the device."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import sbr_capture as cap
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P16 = ctypes.POINTER(ctypes.c_int16)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import libxaac_amd
+    c = libxaac_amd.XaacContext(0, 0)
+    yield c
+    c.close()
+
+
+def gpu_run(ctx, headers, frames, states, pcm_in, in_ch_fac=1, out_ch_fac=1):
+    """lists of ctypes structs (+ pcm_in int16[n*1024]) -> (pcm_out, new states as bytes rows, status)"""
+    import torch
+    import libxaac_amd
+    n = len(states)
+    t = lambda objs: torch.from_numpy(np.frombuffer(b"".join(bytes(o) for o in objs), np.uint8).reshape(n, -1).copy()).cuda()
+    t_h, t_f, t_s = t(headers), t(frames), t(states)
+    out = torch.zeros(n * 2048, dtype=torch.int16, device="cuda")
+    status = torch.full((n,), 7, dtype=torch.int32, device="cuda")
+    ws = torch.zeros(ctx.sbr_lp_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    ctx.sbr_lp_process_batch(torch.from_numpy(np.ascontiguousarray(pcm_in)).cuda(), t_h, t_f, t_s, out, ws, status,
+                             in_ch_fac, out_ch_fac)
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), t_s.cpu().numpy(), status.cpu().numpy()
+
+
+def test_reference_records(ctx):
+    recs = cap.read_records(os.path.join(ROOT, "tests", "golden", "sbr_lp_records.bin.gz"))
+    n = len(recs)
+    pcm_in = np.concatenate([r["pcm_in"] for r in recs])
+    out, st, status = gpu_run(ctx, [r["header"] for r in recs], [r["frame"] for r in recs], [r["st0"] for r in recs],
+                              pcm_in)
+    for i, r in enumerate(recs):
+        assert status[i] == r["ret"]
+        assert np.array_equal(out[2048 * i:2048 * (i + 1)], r["pcm_out"][0]), ("pcm", i, r["call"])
+        got = cap.State.from_buffer_copy(st[i].tobytes())
+        assert not cap.diff_state(got, r["st1"]), (i, r["call"], cap.diff_state(got, r["st1"])[:3])
+
+
+def test_fuzzed_chain_vs_oracle_stereo_interleaved(ctx, oracle):
+    """a batch of 2 x 36 channels built from the golden records: 12 frames of fuzzed side info and random core PCM,
+    interleaved stereo in and out, state carried on the device; every frame must equal the oracle"""
+    recs = cap.read_records(os.path.join(ROOT, "tests", "golden", "sbr_lp_records.bin.gz"))
+    recs = recs[:72 - 72 % 2]
+    n = len(recs)
+    rng = np.random.default_rng(9)
+    states = [cap.State.from_buffer_copy(bytes(r["st0"])) for r in recs]
+    for step in range(12):
+        headers, frames = [], []
+        for r in recs:
+            h = cap.Header.from_buffer_copy(bytes(r["header"]))
+            f = cap.Frame.from_buffer_copy(bytes(r["frame"]))
+            for k in range(h.num_if_bands):
+                f.sbr_invf_mode[k] = int(rng.integers(0, 4))
+            h.limiter_gains = int(rng.integers(0, 4))
+            h.interpol_freq = int(rng.integers(0, 2))
+            if rng.integers(0, 3) == 0:
+                for k in range(h.num_sf_bands[1]):
+                    f.add_harmonics[k] = int(rng.integers(0, 4) == 0)
+            headers.append(h); frames.append(f)
+        amp = [30000, 3000, 200][step % 3]
+        pcm_planar = rng.integers(-amp, amp, (n, 1024)).astype(np.int16)
+        pcm_il = pcm_planar.reshape(n // 2, 2, 1024).transpose(0, 2, 1).reshape(-1)       # L R L R ...
+        out, st_bytes, status = gpu_run(ctx, headers, frames, states, pcm_il, in_ch_fac=2, out_ch_fac=2)
+        out_planar = out.reshape(n // 2, 2048, 2).transpose(0, 2, 1).reshape(n, 2048)
+        new_states = []
+        for i in range(n):
+            st = cap.State.from_buffer_copy(bytes(states[i]))
+            want = np.zeros(2048, np.int16)
+            pin = np.ascontiguousarray(pcm_planar[i])
+            rc = oracle.lib.xo_sbr_dec_lp(ctypes.byref(headers[i]), ctypes.byref(frames[i]), ctypes.byref(st),
+                                          pin.ctypes.data_as(P16), 1, want.ctypes.data_as(P16), 1)
+            assert status[i] == rc, (step, i)
+            assert np.array_equal(out_planar[i], want), ("pcm", step, i)
+            got = cap.State.from_buffer_copy(st_bytes[i].tobytes())
+            assert not cap.diff_state(got, st), (step, i, cap.diff_state(got, st)[:3])
+            new_states.append(st)
+        states = new_states
+
+
+def test_workspace_and_argument_checks(ctx):
+    import torch
+    import libxaac_amd
+    z = lambda n, dt=torch.uint8: torch.zeros(n, dtype=dt, device="cuda")
+    with pytest.raises(libxaac_amd.XaacError):     # workspace too small
+        ctx.sbr_lp_process_batch(z(2048, torch.int16), z((2, 336)), z((2, 1072)), z((2, 7300)), z(4096, torch.int16),
+                                 z(1000))
+    assert ctx.sbr_lp_workspace_bytes(16384) >= 16384 * 40 * 64 * 4
