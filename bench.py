@@ -71,6 +71,50 @@ def make_inputs(torch, device, sets, seed):
     return batches
 
 
+# ---- workload C3: HE-AACv1 stereo (BASELINE.json configs[2]) ------------------------------------------------
+C3_ALG_BYTES_PER_CH = (4096 + 2048 + 336 + 1072 + 7300) + (2048 + 7300 + 4096)   # R + W per channel-frame, DESIGN.md
+
+
+def make_inputs_c3(torch, device, sets, seed):
+    """Core spectra as C2 (24 kHz core: bins < 512 populated) + SBR side info cycled from the committed
+    reference-captured frames (tests/golden/sbr_lp_records.bin.gz), grouped by stream configuration."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import sbr_capture as cap
+    recs = [r for r in cap.read_records(os.path.join(ROOT, "tests", "golden", "sbr_lp_records.bin.gz")) if r["enh"] == 0]
+    groups = {}
+    for r in recs:
+        groups.setdefault(bytes(r["header"]), []).append(r)
+    groups = list(groups.values())
+    n = FRAMES_PER_STEP * CH
+    g = torch.Generator(device=device)
+    g.manual_seed(0xC0FFEE + seed)
+    hdr = np.zeros((n, 336), np.uint8); st0 = np.zeros((n, 7300), np.uint8)
+    frames = []
+    for c in range(n):
+        grp = groups[(c // CH) % len(groups)]
+        hdr[c] = np.frombuffer(bytes(grp[0]["header"]), np.uint8)
+        st0[c] = np.frombuffer(bytes(grp[0]["st0"]), np.uint8)      # the reference's own initial state
+    nvar = 4
+    for v in range(nvar):
+        fr = np.zeros((n, 1072), np.uint8)
+        for c in range(n):
+            grp = groups[(c // CH) % len(groups)]
+            fr[c] = np.frombuffer(bytes(grp[(c + v) % len(grp)]["frame"]), np.uint8)
+        frames.append(torch.from_numpy(fr).to(device))
+    batches = []
+    for s in range(sets):
+        spec = torch.randint(-(1 << 17), 1 << 17, (n, 1024), generator=g, device=device, dtype=torch.int32)
+        spec[:, 512:] = 0
+        batches.append({"spec": spec, "ics": torch.zeros((n, 2), dtype=torch.uint8, device=device),
+                        "overlap": torch.zeros((n, 512), dtype=torch.int32, device=device),
+                        "state": torch.zeros((n, 2), dtype=torch.uint8, device=device),
+                        "core_pcm": torch.zeros(n * 1024, dtype=torch.int16, device=device),
+                        "hdr": torch.from_numpy(hdr).to(device), "frames": frames,
+                        "sbr_state": torch.from_numpy(st0).to(device),
+                        "pcm": torch.zeros(n * 2048, dtype=torch.int16, device=device)})
+    return batches
+
+
 def cpu_baseline(seconds_budget=12.0):
     """Time the CPU path on a bounded sample of the same workload (all host cores,
     one contiguous shard of channel-frames per thread)."""
@@ -138,6 +182,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--sets", type=int, default=4, help="independent 8192-stream batches cycled per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
+                    help="c2: AAC-LC IMDCT+OLA (BASELINE configs[1], default); c3: HE-AACv1 stereo, IMDCT + LP-SBR")
     args = ap.parse_args()
 
     import torch
@@ -154,16 +200,25 @@ def main():
     stream = torch.cuda.Stream(device=dev)      # kernels AND timing events go on this one stream
     torch.cuda.set_stream(stream)
     ctx = libxaac_amd.XaacContext(local_rank, stream.cuda_stream)
-    batches = make_inputs(torch, dev, args.sets, rank)
+    c3 = args.workload == "c3"
+    batches = make_inputs_c3(torch, dev, args.sets, rank) if c3 else make_inputs(torch, dev, args.sets, rank)
     for b in batches:                 # window shape alternates per frame; state follows
         b["ics"][:, 1] = (torch.arange(b["ics"].shape[0], device=dev) // CH % 2).to(torch.uint8)
+    ws = torch.zeros(ctx.sbr_lp_workspace_bytes(FRAMES_PER_STEP * CH), dtype=torch.uint8, device=dev) if c3 else None
 
     def step(i, ev=None):
         b = batches[i % len(batches)]
         if ev is not None:
             ev[0].record(stream)
-        ctx.imdct_process_batch(b["spec"], b["ics"], b["overlap"], b["state"], None, b["pcm"], None,
-                                ch_fac=CH, pcm_mode=libxaac_amd.PCM_LC)
+        if c3:
+            # core decoder back-end: planar PCM16 with the SBR hand-off rounding, then the low-power SBR chain
+            ctx.imdct_process_batch(b["spec"], b["ics"], b["overlap"], b["state"], None, b["core_pcm"], None,
+                                    ch_fac=1, pcm_mode=libxaac_amd.PCM_SBR)
+            ctx.sbr_lp_process_batch(b["core_pcm"], b["hdr"], b["frames"][(i // len(batches)) % len(b["frames"])],
+                                     b["sbr_state"], b["pcm"], ws, None, in_ch_fac=1, out_ch_fac=CH)
+        else:
+            ctx.imdct_process_batch(b["spec"], b["ics"], b["overlap"], b["state"], None, b["pcm"], None,
+                                    ch_fac=CH, pcm_mode=libxaac_amd.PCM_LC)
         if ev is not None:
             ev[1].record(stream)
 
@@ -187,7 +242,9 @@ def main():
 
     # the run stays honest: decode one more frame of set 0 and compare a slice with the oracle
     checked = None
-    if rank == 0:
+    if rank == 0 and c3:
+        checked = "see tests/test_sbr_gpu.py (bit-exact vs reference records and oracle chains)"
+    if rank == 0 and not c3:
         try:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib
@@ -205,28 +262,33 @@ def main():
 
     if rank == 0:
         frames = FRAMES_PER_STEP * args.steps * world
-        alg_bytes = ALG_BYTES_PER_FRAME * FRAMES_PER_STEP
+        alg_bytes = (C3_ALG_BYTES_PER_CH * CH if c3 else ALG_BYTES_PER_FRAME) * FRAMES_PER_STEP
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         out = {
-            "metric": "decoded audio frames/s (1024-spl IMDCT+overlap-add, AAC-LC stereo)",
+            "metric": ("decoded audio frames/s (1024-spl IMDCT + 32/64-band QMF + low-power SBR, HE-AACv1 stereo)" if c3
+                       else "decoded audio frames/s (1024-spl IMDCT+overlap-add, AAC-LC stereo)"),
             "value": round(frames / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
             "data": "synthetic",
-            "config": {"workload": "C2: AAC-LC 48 kHz stereo, batch=8192 frames/step (16384 channel-frames), "
-                                   "ONLY_LONG 1024-pt IMDCT + window/overlap-add + PCM16, %d stream sets cycled"
-                                   % args.sets,
+            "config": {"workload": ("C3: HE-AACv1 48 kHz stereo, batch=8192 frames/step: IMDCT+OLA -> QMF-32 analysis -> "
+                                    "LPP HF generation + envelope adjustment (side info cycled from reference-captured "
+                                    "frames) -> QMF-64 synthesis, %d stream sets cycled" % args.sets) if c3 else
+                                   ("C2: AAC-LC 48 kHz stereo, batch=8192 frames/step (16384 channel-frames), "
+                                    "ONLY_LONG 1024-pt IMDCT + window/overlap-add + PCM16, %d stream sets cycled"
+                                    % args.sets),
                        "frames_per_step": FRAMES_PER_STEP, "channels": CH, "launch": ctx.last_launch(),
                        "sharding": "streams split across ranks, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": (measured_traffic() or {}).get("bytes_per_launch"),
-                         "traffic_source": (measured_traffic() or {}).get("source"),
-                         "kernel": "xaac_imdct_ola_kernel", "kernel_ms": round(kern_ms, 5),
+                         "traffic": None if c3 else (measured_traffic() or {}).get("bytes_per_launch"),
+                         "traffic_source": None if c3 else (measured_traffic() or {}).get("source"),
+                         "kernel": "imdct_ola + qmf_analysis + sbr_core_lp + qmf_synthesis (4 launches)" if c3
+                                   else "xaac_imdct_ola_kernel", "kernel_ms": round(kern_ms, 5),
                          "alg_bytes_per_launch": alg_bytes},
             "bit_exact_vs_oracle": checked,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not c3:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if dist is not None:
