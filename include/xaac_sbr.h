@@ -61,6 +61,26 @@ typedef struct xaac_sbr_frame {
   int16_t int_noise_floor[XAAC_SBR_MAX_NOISE_VALUES];
 } xaac_sbr_frame;
 
+/* The members of xaac_sbr_state behind the filterbank rings and the overlap slots -- the part the
+ * serial SBR core reads and writes.  Spelled as a macro so that the GPU core can keep a copy of
+ * exactly this tail in LDS (libxaac_amd/csrc/sbr_core_kernel.hip) without a second field list. */
+#define XAAC_SBR_STATE_TAIL_FIELDS                                                                         \
+  int32_t lpc_real[2][32], lpc_imag[2][32]; /* str_hf_generator.lpc_filt_states_* */                       \
+  int32_t bw_array_prev[XAAC_SBR_MAX_PATCHES];                                                             \
+  int16_t lb_scale, st_lb_scale, ov_lb_scale, hb_scale, ov_hb_scale, st_syn_scale, ps_scale, pad0_;        \
+  /* ia_sbr_prev_frame_data_struct members the path reads/writes */                                        \
+  int32_t prev_invf_mode[XAAC_SBR_MAX_NOISE_VALUES];                                                       \
+  int32_t prev_max_qmf_subband_aac;                                                                        \
+  int32_t prev_coupling_mode;                                                                              \
+  int16_t prev_end_position, prev_amp_res;                                                                 \
+  /* ia_sbr_calc_env_struct */                                                                             \
+  int16_t filt_buf_me[2 * XAAC_SBR_MAX_FREQ_COEFFS];                                                       \
+  int16_t filt_buf_noise_m[XAAC_SBR_MAX_FREQ_COEFFS];                                                      \
+  int32_t filt_buf_noise_e;                                                                                \
+  int32_t start_up;                                                                                        \
+  int16_t ph_index, tansient_env_prev, harm_index, pad1_;                                                  \
+  int8_t harm_flags_prev[XAAC_SBR_MAX_FREQ_COEFFS];
+
 /* Per-channel persistent state of ixheaacd_sbr_dec. */
 typedef struct xaac_sbr_state {
   /* analysis / synthesis banks: same layouts as xaac_qmf_ana_state / xaac_qmf_syn_state */
@@ -70,21 +90,7 @@ typedef struct xaac_sbr_state {
   int16_t syn_lsb, syn_usb;                   /* str_synthesis_qmf_bank.lsb / .usb */
   int16_t pad2_;
   int32_t overlap[6 * 64 * 2];                /* ptr_sbr_overlap_buf: 6 slots x 64 (LP) or x 128 (HQ) */
-  int32_t lpc_real[2][32], lpc_imag[2][32];   /* str_hf_generator.lpc_filt_states_* */
-  int32_t bw_array_prev[XAAC_SBR_MAX_PATCHES];
-  int16_t lb_scale, st_lb_scale, ov_lb_scale, hb_scale, ov_hb_scale, st_syn_scale, ps_scale, pad0_;
-  /* ia_sbr_prev_frame_data_struct members the path reads/writes */
-  int32_t prev_invf_mode[XAAC_SBR_MAX_NOISE_VALUES];
-  int32_t prev_max_qmf_subband_aac;
-  int32_t prev_coupling_mode;
-  int16_t prev_end_position, prev_amp_res;
-  /* ia_sbr_calc_env_struct */
-  int16_t filt_buf_me[2 * XAAC_SBR_MAX_FREQ_COEFFS];
-  int16_t filt_buf_noise_m[XAAC_SBR_MAX_FREQ_COEFFS];
-  int32_t filt_buf_noise_e;
-  int32_t start_up;
-  int16_t ph_index, tansient_env_prev, harm_index, pad1_;
-  int8_t harm_flags_prev[XAAC_SBR_MAX_FREQ_COEFFS];
+  XAAC_SBR_STATE_TAIL_FIELDS
 } xaac_sbr_state;
 
 #endif /* XAAC_SBR_H */

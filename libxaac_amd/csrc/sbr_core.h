@@ -1,11 +1,10 @@
 /*
- * sbr_core.h -- the serial "control and adjustment" part of the fixed-point SBR decoder for ONE
+ * sbr_core.h -- the "control and adjustment" part of the fixed-point SBR decoder for ONE
  * channel-frame, low-power (real-valued) mode: block-floating-point bookkeeping, LPP transposer
- * (HF generation) and envelope adjustment, as scalar host/device code.  On the GPU one LANE runs
- * one channel (channels are independent; the QMF matrix is stored channel-minor so that the
- * lanes' accesses coalesce); on the host the same code is the oracle's arithmetic
- * (oracle/oracle_sbr.cpp), which is pinned to the compiled reference on frames captured from
- * real HE-AAC streams.
+ * (HF generation) and envelope adjustment, as host/device code.  On the GPU one WAVE runs one
+ * channel-frame (see "execution context" below); on the host the same code, executed sequentially,
+ * is the oracle's arithmetic (oracle/oracle_sbr.cpp), which is pinned to the compiled reference on
+ * frames captured from real HE-AAC streams and on fuzzed side info.
  *
  * Reference map (decoder/...):
  *   xs_fix_mant_div / xs_mant_exp_sqrt / xs_fix_div      ixheaacd_basic_funcs.c:66 / :101 / :130
@@ -21,6 +20,9 @@
  *   xs_harm_zerotwo_lp / xs_harm_onethree_lp              ixheaacd_env_calc.c:1564 / :1617
  *   xs_adapt_noise_gain / xs_calc_sbrenvelope             ixheaacd_env_calc.c:479 / :692
  *   xs_sbr_core_lp                                        ixheaacd_sbr_dec.c:726-775, :1050-1245, :1283-1308
+ * Preconditions the reference's header parser guarantees (ixheaacd_freq_sca.c): band tables strictly
+ * increasing, sub_band_end <= 64, at most 56 adjusted bands, patch destinations disjoint and above
+ * the source range.
  * The reference keeps gains/energies as interleaved (mantissa, exponent) WORD16 pairs and
  * truncates through WORD16 assignments in many places; the pairs and every truncation are kept.
  */
@@ -135,45 +137,207 @@ FX_HD void xs_acc_me(int32_t *am, int32_t *ae, int32_t m, int32_t e) {
   }
 }
 
-/* ---- QMF matrix view: slot rows of 64 bands; rows -2,-1 are the LPC history --------------------- */
-template <class T>
-struct XsMat {
-  T *p;       /* element (slot, band) at p[((slot + 2) * 64 + band) * stride] */
-  int stride;
-  FX_MEMBER T &operator()(int slot, int band) const { return p[((slot + 2) * 64 + band) * stride]; }
+/* ---- execution context ------------------------------------------------------------------------------
+ * The same source runs two ways.  On the host (the oracle) lane = 0, n = 1: every lane loop is an
+ * ordinary loop and the code is a sequential restatement of the reference.  On the GPU ONE WAVE runs
+ * one channel-frame and is used as what it is -- a scalar processor with a 64-wide vector unit:
+ *   - XS_PAR / XS_LANES loops spread independent iterations (QMF bands) over the lanes;
+ *   - per-band quantities of the envelope adjuster (energies, gains, noise and sine levels, flags)
+ *     live in lane vectors (XsLv: element k in lane k, i.e. one VGPR), not in memory;
+ *   - the sequential parts of the algorithm (pseudo-float sums over a limiter band, the walks that
+ *     build alias groups / per-band metadata / aliasing degrees) run uniformly on all lanes, reading
+ *     lane-vector elements with v_readlane -- scalar-ALU code without memory latency;
+ *   - the QMF matrix, the state copy and the side info are in LDS, cx.sync() between a producer and a
+ *     consumer on another lane.
+ * cx.uni() marks a value as wave-uniform (readfirstlane) so loop control stays on the scalar unit. */
+struct XsCx {
+  int lane, n;
+  FX_MEMBER void sync() const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __syncthreads();
+#endif
+  }
+  FX_MEMBER int32_t wave_or(int32_t v) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
+#endif
+    return v;
+  }
+  FX_MEMBER int32_t wave_max(int32_t v) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int o = 32; o > 0; o >>= 1) {
+      int32_t t = __shfl_xor(v, o);
+      v = t > v ? t : v;
+    }
+#endif
+    return v;
+  }
+  FX_MEMBER int32_t uni(int32_t v) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_readfirstlane(v);
+#else
+    return v;
+#endif
+  }
+  /* first index >= b0 owned by this lane (index k is owned by lane k; ranges end at <= 64) */
+  FX_MEMBER int first(int b0) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return lane >= b0 ? lane : lane + 64;
+#else
+    return b0;
+#endif
+  }
 };
-typedef XsMat<int32_t> XsQmf;
+#ifndef XS_T
+#define XS_T(i) /* optional phase timer hook (tools/prof_sbr_core.py) */
+#endif
+#define XS_PAR(k, b0, b1) for (int k = (b0) + cx.lane; k < (b1); k += cx.n)
+#define XS_LANES(k, b0, b1) for (int k = cx.first(b0); k < (b1); k += cx.n) /* k on lane k; b1 <= 64 */
+#define XS_ONE if (cx.lane == 0)
+#if defined(__HIPCC__)
+#define XS_UNROLL4 _Pragma("unroll 4")
+#else
+#define XS_UNROLL4
+#endif
+
+/* Lane vector: 64 int32 elements, element k held by lane k (a VGPR) / a plain array in the oracle. */
+struct XsLv {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int32_t v;
+  FX_MEMBER int32_t &own(int) { return v; }
+  FX_MEMBER int32_t own(int) const { return v; }
+  FX_MEMBER int32_t get(int i) const { return __builtin_amdgcn_readlane(v, i); } /* i uniform */
+  FX_MEMBER void put(int i, int32_t val) { /* i, val uniform */
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    v = lane == i ? val : v;
+  }
+  FX_MEMBER void fill(int32_t val) { v = val; }
+  FX_MEMBER XsLv shifted(const XsCx &cx, int d) const { /* element k of the result = element k + d (0 outside) */
+    XsLv r;
+    const int s = cx.lane + d;
+    const int32_t t = __shfl(v, s & 63);
+    r.v = (s >= 0 && s < 64) ? t : 0;
+    return r;
+  }
+#else
+  int32_t a[64];
+  int32_t &own(int k) { return a[k & 63]; }
+  int32_t own(int k) const { return a[k & 63]; }
+  int32_t get(int i) const { return a[i & 63]; }
+  void put(int i, int32_t val) { a[i & 63] = val; }
+  void fill(int32_t val) {
+    for (int i = 0; i < 64; i++) a[i] = val;
+  }
+  XsLv shifted(const XsCx &, int d) const {
+    XsLv r;
+    for (int i = 0; i < 64; i++) r.a[i] = (i + d >= 0 && i + d < 64) ? a[i + d] : 0;
+    return r;
+  }
+#endif
+};
+
+/* (mantissa, exponent) pseudo-float packed into one lane-vector element */
+FX_HD int32_t xs_me(int16_t m, int16_t e) { return (int32_t)(((uint32_t)(uint16_t)e << 16) | (uint16_t)m); }
+FX_HD int16_t xs_m(int32_t v) { return (int16_t)v; }
+FX_HD int16_t xs_e(int32_t v) { return (int16_t)(v >> 16); }
+
+/* number of elements 0..k (inclusive) of s[0..n) whose mantissa is non-zero */
+FX_HD XsLv xs_prefix_nonzero_m(const XsCx &cx, const XsLv &s, int n) {
+  XsLv r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned long long mask = __ballot(cx.lane < n && xs_m(s.v) != 0);
+  r.v = __popcll(mask & ((2ull << cx.lane) - 1ull));
+#else
+  int c = 0;
+  for (int k = 0; k < 64; k++) {
+    if (k < n && xs_m(s.a[k]) != 0) c++;
+    r.a[k] = c;
+  }
+#endif
+  return r;
+}
+
+/* bit `bit` of elements 0..n-1 gathered into a 64-bit mask */
+FX_HD uint64_t xs_ballot(const XsCx &cx, const XsLv &p, int bit, int n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __ballot(cx.lane < n && (p.v & bit) != 0);
+#else
+  uint64_t m = 0;
+  for (int k = 0; k < 64 && k < n; k++)
+    if (p.a[k] & bit) m |= (uint64_t)1 << k;
+  return m;
+#endif
+}
+FX_HD int xs_clz64(uint64_t v) { return __builtin_clzll(v); } /* v != 0 */
+FX_HD int xs_ctz64(uint64_t v) { return __builtin_ctzll(v); } /* v != 0 */
+FX_HD uint64_t xs_mask_upto(int k) { return ((uint64_t)2 << k) - 1; } /* bits 0..k, k <= 63 */
+
+/* ---- QMF matrix view: slot rows of 64 bands; rows -2,-1 are the LPC history --------------------- */
+struct XsQmf {
+  int32_t *p; /* element (slot, band) at p[(slot + 2) * 64 + band] */
+  FX_MEMBER int32_t &operator()(int slot, int band) const { return p[(slot + 2) * 64 + band]; }
+};
+
+struct XsCov {
+  int32_t phi_11, phi_22, phi_01, phi_02, phi_12, d;
+};
+
+/* Per-channel-frame scratch in memory shared by the lanes (LDS on the GPU, stack in the oracle). */
+struct XsWork {
+  int32_t bw_array[XAAC_SBR_MAX_PATCHES];
+  int32_t fold_a[XS_MAXF + 8][2]; /* inputs of the sequential pseudo-float sums, per band */
+  int32_t fold_b[XS_MAXF + 8][4];
+  int16_t res_a[XS_MAXF + 8][4];  /* their results, per limiter band / per alias group (by first band) */
+  int16_t res_b[XS_MAXF + 8][2];
+  int16_t nrg_est[2 * XS_MAXF];   /* only the interpol_freq == 0 path goes through memory */
+};
+
+/* Per-band registers of the envelope adjuster.  est / e_orig / gain / noise / sine / meta: element c
+   is QMF band max_qmf_subband_aac + c; alias_red / sine_mapped / deg / deg1: element i is band
+   sub_band_start + i (deg1 is deg one band up).  Exactly the index conventions of the reference's
+   nrg_est[] ... arrays (env_calc.c:692), two int16 per entry there, one packed int32 here. */
+struct XsEnv {
+  XsLv est, e_orig, gain, noise, sine, meta, alias_red, sine_mapped, deg, deg1;
+};
 
 /* env_calc.c:1159 (real-valued): headroom of bands [b0,b1) x slots [s0,s1) */
-FX_HD int xs_headroom(const XsQmf &x, int b0, int b1, int s0, int s1) {
+FX_HD int xs_headroom(const XsCx &cx, const XsQmf &x, int b0, int b1, int s0, int s1) {
+  int32_t m = 1;
+  XS_PAR(k, b0, b1) {
+    XS_UNROLL4
+    for (int l = s0; l < s1; l++) m |= fx_abs_nrm(x(l, k));
+  }
+  return xs_pnorm32(cx.wave_or(m));
+}
+/* the same, sequential (for code that already runs one band group per lane) */
+FX_HD int xs_headroom_seq(const XsQmf &x, int b0, int b1, int s0, int s1) {
   int32_t m = 1;
   for (int l = s0; l < s1; l++)
     for (int k = b0; k < b1; k++) m |= fx_abs_nrm(x(l, k));
   return xs_pnorm32(m);
 }
 /* env_calc.c:1099 (real-valued) */
-FX_HD void xs_adjust(const XsQmf &x, int b0, int b1, int s0, int s1, int shift) {
+FX_HD void xs_adjust(const XsCx &cx, const XsQmf &x, int b0, int b1, int s0, int s1, int shift) {
   if (shift == 0) return;
   if (shift > 31) shift = 31;
   if (shift < -31) shift = -31;
-  for (int l = s0; l < s1; l++)
-    for (int k = b0; k < b1; k++) x(l, k) = shift > 0 ? fx_shlw(x(l, k), shift) : (x(l, k) >> -shift);
+  XS_PAR(k, b0, b1) {
+    XS_UNROLL4
+    for (int l = s0; l < s1; l++) x(l, k) = shift > 0 ? fx_shlw(x(l, k), shift) : (x(l, k) >> -shift);
+  }
 }
 
 /* ---- HF generator, low-power mode ------------------------------------------------------------------ */
-struct XsCov {
-  int32_t phi_11, phi_22, phi_01, phi_02, phi_12, d;
-};
-
 /* lpp_tran.c:271: real autocorrelation of band k over `len` (= 38) slots starting at row -2 */
 FX_HD void xs_covariance_lp(const XsQmf &x, int k, int len, XsCov *c) {
   int32_t p01 = 0, p02 = 0, p11 = 0;
   int row = -2;
-  int32_t t1 = fx_shr(x(row, k), 3), t2 = fx_shr(x(row + 1, k), 3), t3 = 0;
+  const int32_t first = fx_shr(x(-2, k), 3), second = fx_shr(x(-1, k), 3);
+  int32_t t1 = first, t2 = second, t3 = 0;
   row += 2;
   /* the reference walks three samples at a time; the running sums only depend on the sample order */
-  int n = len; /* number of lags accumulated: slots 2 .. len+1 relative to the start */
-  for (int j = 0; j < n; j++) {
+  XS_UNROLL4
+  for (int j = 0; j < len; j++) {
     t3 = fx_shr(x(row++, k), 3);
     p01 = fx_add(p01, xs_mul_hi16(t3, t2));
     p02 = fx_add(p02, xs_mul_hi16(t3, t1));
@@ -183,7 +347,6 @@ FX_HD void xs_covariance_lp(const XsQmf &x, int k, int len, XsCov *c) {
   }
   /* after the loop (t1, t2) are the last two samples; the reference's temp1/temp3 at that point */
   int32_t last1 = t2, last3 = t1;
-  int32_t first = fx_shr(x(-2, k), 3), second = fx_shr(x(-1, k), 3);
   int32_t p12 = fx_add(fx_sub(p01, xs_mul_hi16(last1, last3)), xs_mul_hi16(second, first));
   int32_t p22 = fx_add(fx_sub(p11, xs_mul_hi16(last3, last3)), xs_mul_hi16(first, first));
   int32_t mx = fx_abs_nrm(p01) | fx_abs_nrm(p02) | fx_abs_nrm(p12) | p11 | p22;
@@ -196,10 +359,10 @@ FX_HD void xs_covariance_lp(const XsQmf &x, int k, int len, XsCov *c) {
   c->d = fx_sub_sat(fx_mul32(c->phi_22, c->phi_11), fx_mul32(c->phi_12, c->phi_12));
 }
 
-/* sbrdec_lpfuncs.c:735 */
-FX_HD void xs_invfilt_level_emphasis(const int32_t *bw_prev, int n, const int32_t *mode, const int32_t *mode_prev,
-                                     int32_t *bw) {
-  for (int i = 0; i < n; i++) {
+/* sbrdec_lpfuncs.c:735 (at most 5 inverse-filtering bands: one per lane) */
+FX_HD void xs_invfilt_level_emphasis(const XsCx &cx, const int32_t *bw_prev, int n, const int32_t *mode,
+                                     const int32_t *mode_prev, int32_t *bw) {
+  XS_PAR(i, 0, n) {
     int32_t b = xaac_sbr_new_bw_table[4 * mode_prev[i] + mode[i]];
     int16_t w1, w2;
     if (b < bw_prev[i]) {
@@ -216,187 +379,230 @@ FX_HD void xs_invfilt_level_emphasis(const int32_t *bw_prev, int n, const int32_
   }
 }
 
-/* lpp_tran.c:629 + :665: LPC coefficients per low band, aliasing degrees, and the patch copy/filter.
-   start/stop: first_slot_offset and (num_columns + last_slot_offset) as in lpp_tran.c:861 */
-FX_HD void xs_filter1_lp(const xaac_sbr_header *h, const XsQmf &x, const XsCov *cov, const int32_t *bw_array,
-                         int16_t *degree_alias, int start_idx, int stop_idx, int max_qmf_subband, int start_patch,
-                         int stop_patch) {
-  int16_t k1, k1_below = 0, k1_below2 = 0;
-  int bw_index[XAAC_SBR_MAX_PATCHES] = {0, 0, 0, 0, 0, 0};
+/* lpp_tran.c:665, first half: prediction coefficients and reflection coefficient of one low band */
+FX_HD void xs_lpc_coeffs_lp(const XsCov *c, int16_t *alpha0_out, int16_t *alpha1_out, int16_t *k1_out) {
+  int16_t alpha0 = 0, alpha1 = 0, k1;
+  if (c->d != 0) {
+    int norm_d = fx_norm32(c->d);
+    int16_t inv_d = (int16_t)xs_fix_div(0x40000000, xs_shl(c->d, norm_d));
+    int32_t mod_d = c->d < 0 ? -c->d : c->d;
+    int32_t t = fx_sub_sat(fx_mul32(c->phi_01, c->phi_12), fx_mul32(c->phi_02, c->phi_11)) >> 2;
+    if ((t < 0 ? -t : t) < mod_d) alpha1 = (int16_t)(xs_shl(xs_mul32x16_shl_sat(t, inv_d), norm_d) >> 15);
+    t = fx_sub_sat(fx_mul32(c->phi_02, c->phi_12), fx_mul32(c->phi_01, c->phi_22)) >> 2;
+    if ((t < 0 ? -t : t) < mod_d) alpha0 = (int16_t)(xs_shl(xs_mul32x16_shl_sat(t, inv_d), norm_d) >> 15);
+  }
+  if (c->phi_11 == 0) {
+    k1 = 0;
+  } else if (fx_abs_sat(c->phi_01) >= c->phi_11) {
+    k1 = c->phi_01 < 0 ? (int16_t)0x7fff : (int16_t)-0x8000;
+  } else {
+    k1 = (int16_t)(-((int16_t)xs_fix_div(c->phi_01, c->phi_11)));
+  }
+  *alpha0_out = alpha0;
+  *alpha1_out = alpha1;
+  *k1_out = k1;
+}
+
+/* lpp_tran.c:665, aliasing degrees: a recurrence over the low bands (sequential, uniform) */
+FX_HD void xs_degree_alias_lp(const XsLv &k1v, XsLv &deg, int start_patch, int stop_patch) {
+  int16_t k1_below = 0, k1_below2 = 0;
   for (int lb = start_patch; lb < stop_patch; lb++) {
-    const XsCov *c = &cov[lb];
-    int16_t alpha0 = 0, alpha1 = 0;
-    if (c->d != 0) {
-      int norm_d = fx_norm32(c->d);
-      int16_t inv_d = (int16_t)xs_fix_div(0x40000000, xs_shl(c->d, norm_d));
-      int32_t mod_d = c->d < 0 ? -c->d : c->d;
-      int32_t t = fx_sub_sat(fx_mul32(c->phi_01, c->phi_12), fx_mul32(c->phi_02, c->phi_11)) >> 2;
-      if ((t < 0 ? -t : t) < mod_d) alpha1 = (int16_t)(xs_shl(xs_mul32x16_shl_sat(t, inv_d), norm_d) >> 15);
-      t = fx_sub_sat(fx_mul32(c->phi_02, c->phi_12), fx_mul32(c->phi_01, c->phi_22)) >> 2;
-      if ((t < 0 ? -t : t) < mod_d) alpha0 = (int16_t)(xs_shl(xs_mul32x16_shl_sat(t, inv_d), norm_d) >> 15);
-    }
-    if (c->phi_11 == 0) {
-      k1 = 0;
-    } else if (fx_abs_sat(c->phi_01) >= c->phi_11) {
-      k1 = c->phi_01 < 0 ? (int16_t)0x7fff : (int16_t)-0x8000;
-    } else {
-      k1 = (int16_t)(-((int16_t)xs_fix_div(c->phi_01, c->phi_11)));
-    }
+    const int16_t k1 = (int16_t)k1v.get(lb);
     if (lb > 1) {
-      int16_t deg = fx_sat16(0x7fff - (int32_t)xs_mult16_shl_sat(k1_below, k1_below));
-      degree_alias[lb] = 0;
+      const int16_t dg = fx_sat16(0x7fff - (int32_t)xs_mult16_shl_sat(k1_below, k1_below));
+      int32_t here = 0;
       if (((lb & 1) == 0) && (k1 < 0)) {
         if (k1_below < 0) {
-          degree_alias[lb] = 0x7fff;
-          if (k1_below2 > 0) degree_alias[lb - 1] = deg;
+          here = 0x7fff;
+          if (k1_below2 > 0) deg.put(lb - 1, dg);
         } else if (k1_below2 > 0) {
-          degree_alias[lb] = deg;
+          here = dg;
         }
       }
       if (((lb & 1) != 0) && (k1 > 0)) {
         if (k1_below > 0) {
-          degree_alias[lb] = 0x7fff;
-          if (k1_below2 < 0) degree_alias[lb - 1] = deg;
+          here = 0x7fff;
+          if (k1_below2 < 0) deg.put(lb - 1, dg);
         } else if (k1_below2 < 0) {
-          degree_alias[lb] = deg;
+          here = dg;
         }
       }
+      deg.put(lb, here);
     }
     k1_below2 = k1_below;
     k1_below = k1;
+  }
+}
 
-    for (int patch = 0; patch < h->num_patches; patch++) {
-      const xaac_sbr_patch *pp = &h->patch[patch];
-      int hb = xs_shl(lb + pp->dst_end_band, 8) >> 8;
-      if (lb < pp->src_start_band || lb >= pp->src_end_band || hb < max_qmf_subband) continue;
-      int bi = bw_index[patch];
-      while (hb >= h->bw_borders[bi]) bi++;
-      bw_index[patch] = bi;
-      int16_t bw = (int16_t)(bw_array[bi] >> 16);
-      int32_t a0 = xs_mult16x16_shl(bw, alpha0);
-      bw = xs_mult16_shl_sat(bw, bw);
-      int32_t a1 = xs_mult16x16_shl(bw, alpha1);
-      const int len = stop_idx - start_idx - 1;
-      if (bw > 0) {
-        /* lpp_tran.c:629: second-order FIR on the low band, two slots per step */
-        int r = start_idx - 2; /* row of sub_sig_x[start_idx] in slot coordinates */
-        int32_t prev2 = x(r, lb), prev1 = x(r + 1, lb);
-        int rl = r + 2, rh = start_idx;
-        for (int i = len; i >= 0; i -= 2) {
-          int32_t curr = x(rl++, lb);
-          int32_t t = xs_mul_hi16(prev2, a1);
-          x(rh++, hb) = fx_add_sat(curr >> 2, fx_shlw(fx_add(t, xs_mul_hi16(prev1, a0)), 1));
-          prev2 = x(rl++, lb);
-          t = xs_mul_hi16(prev1, a1);
-          x(rh++, hb) = fx_add_sat(prev2 >> 2, fx_shlw(fx_add(t, xs_mul_hi16(curr, a0)), 1));
-          prev1 = prev2;
-          prev2 = curr;
-        }
-      } else {
-        for (int i = 0; i <= len; i++) x(start_idx + i, hb) = x(start_idx + i, lb) >> 2;
+/* lpp_tran.c:629 + :665, second half: copy / inverse-filter low band lb into each patch's high band.
+   The reference advances a per-patch index into bw_borders as hb grows; hb grows with lb inside a
+   patch, so that index is the first border above hb. */
+FX_HD void xs_patch_band_lp(const xaac_sbr_header *h, const XsQmf &x, int lb, int16_t alpha0, int16_t alpha1,
+                            const int32_t *bw_array, int start_idx, int stop_idx, int max_qmf_subband) {
+  for (int patch = 0; patch < h->num_patches; patch++) {
+    const xaac_sbr_patch *pp = &h->patch[patch];
+    int hb = xs_shl(lb + pp->dst_end_band, 8) >> 8;
+    if (lb < pp->src_start_band || lb >= pp->src_end_band || hb < max_qmf_subband) continue;
+    int bi = 0;
+    while (hb >= h->bw_borders[bi]) bi++;
+    int16_t bw = (int16_t)(bw_array[bi] >> 16);
+    int32_t a0 = xs_mult16x16_shl(bw, alpha0);
+    bw = xs_mult16_shl_sat(bw, bw);
+    int32_t a1 = xs_mult16x16_shl(bw, alpha1);
+    const int len = stop_idx - start_idx - 1;
+    /* the reference produces two slots per step: an odd count runs one slot past stop_idx */
+    const int n_out = len >= 0 ? ((len >> 1) + 1) * 2 : 0;
+    if (bw > 0) {
+      /* lpp_tran.c:629: y[n] = x[n]/4 + 2 (a1 x[n-2] + a0 x[n-1]) */
+      int32_t xm2 = x(start_idx - 2, lb), xm1 = x(start_idx - 1, lb);
+      XS_UNROLL4
+      for (int i = 0; i < n_out; i++) {
+        const int32_t cur = x(start_idx + i, lb);
+        const int32_t t = xs_mul_hi16(xm2, a1);
+        x(start_idx + i, hb) = fx_add_sat(cur >> 2, fx_shlw(fx_add(t, xs_mul_hi16(xm1, a0)), 1));
+        xm2 = xm1;
+        xm1 = cur;
       }
+    } else {
+      XS_UNROLL4
+      for (int i = 0; i <= len; i++) x(start_idx + i, hb) = x(start_idx + i, lb) >> 2;
     }
   }
 }
 
-/* lpp_tran.c:843.  degree_alias[64] must be zeroed by the caller.  Writes bw_array_prev. */
-FX_HD void xs_low_pow_hf_generator(const xaac_sbr_header *h, xaac_sbr_state *st, const XsQmf &x, int16_t *degree_alias,
-                                   int start_idx, int last_slot_offset, int max_qmf_subband, const int32_t *invf_mode,
-                                   const int32_t *invf_mode_prev, int norm_max) {
-  int32_t bw_array[XAAC_SBR_MAX_PATCHES] = {0, 0, 0, 0, 0, 0};
-  XsCov cov[32];
-  const int num_patches = h->num_patches;
-  const int auto_corr_len = h->num_columns + 6;
-  const int stop_idx = h->num_columns + last_slot_offset;
-  xs_invfilt_level_emphasis(st->bw_array_prev, h->num_if_bands, invf_mode, invf_mode_prev, bw_array);
-  const int actual_stop = (int16_t)(h->patch[num_patches - 1].dst_start_band + h->patch[num_patches - 1].num_bands_in_patch);
+/* lpp_tran.c:843.  deg (64 aliasing degrees by QMF band) must be zeroed by the caller.  Writes
+   bw_array_prev. */
+template <class ST>
+FX_HD void xs_low_pow_hf_generator(const XsCx &cx, const xaac_sbr_header *h, ST *st, const XsQmf &x, XsWork *w,
+                                   XsLv &deg, int start_idx, int last_slot_offset, int max_qmf_subband,
+                                   const int32_t *invf_mode, const int32_t *invf_mode_prev, int norm_max) {
+  const int num_patches = cx.uni(h->num_patches);
+  const int auto_corr_len = cx.uni(h->num_columns) + 6;
+  const int stop_idx = cx.uni(h->num_columns) + last_slot_offset;
+  XS_PAR(i, 0, XAAC_SBR_MAX_PATCHES) w->bw_array[i] = 0;
+  cx.sync();
+  xs_invfilt_level_emphasis(cx, st->bw_array_prev, h->num_if_bands, invf_mode, invf_mode_prev, w->bw_array);
+  const int actual_stop = cx.uni(
+      (int16_t)(h->patch[num_patches - 1].dst_start_band + h->patch[num_patches - 1].num_bands_in_patch));
   {
     int len = 6;
     if (len > stop_idx) len = stop_idx;
-    for (int l = start_idx; l <= len - 1; l++)
-      for (int k = actual_stop; k < 64; k++) x(l, k) = 0;
-    if (actual_stop < 32)
-      for (int l = len; l <= stop_idx - 1; l++)
-        for (int k = actual_stop; k < 32; k++) x(l, k) = 0;
+    XS_PAR(k, actual_stop, 64)
+      for (int l = start_idx; l <= len - 1; l++) x(l, k) = 0;
+    if (actual_stop < 32) XS_PAR(k, actual_stop, 32)
+      for (int l = len; l <= stop_idx - 1; l++) x(l, k) = 0;
   }
-  int start_patch = h->start_patch - 2;
+  int start_patch = cx.uni(h->start_patch) - 2;
   if (start_patch < 1) start_patch = 1;
-  int stop_patch = h->patch[0].dst_start_band;
-  for (int i = 0; i < 2; i++)
-    for (int k = 0; k < stop_patch; k++) x(i - 2, k) = st->lpc_real[i][k];
-  for (int k = 0; k < 32; k++) cov[k] = XsCov{0, 0, 0, 0, 0, 0};
-  if (norm_max != 30)
-    for (int k = start_patch; k < stop_patch; k++) xs_covariance_lp(x, k, auto_corr_len, &cov[k]);
-  xs_filter1_lp(h, x, cov, bw_array, degree_alias, start_idx, stop_idx, max_qmf_subband, start_patch, stop_patch);
-  for (int lb = h->start_patch; lb < h->stop_patch; lb++) {
+  const int stop_patch = cx.uni(h->patch[0].dst_start_band);
+  XS_PAR(k, 0, stop_patch) {
+    x(-2, k) = st->lpc_real[0][k];
+    x(-1, k) = st->lpc_real[1][k];
+  }
+  cx.sync();
+  XS_T(12);
+  XsLv k1v, alpha;
+  k1v.fill(0);
+  alpha.fill(0);
+  XS_LANES(k, start_patch, stop_patch) {
+    XsCov c = {0, 0, 0, 0, 0, 0};
+    if (norm_max != 30) xs_covariance_lp(x, k, auto_corr_len, &c);
+    int16_t a0, a1, k1;
+    xs_lpc_coeffs_lp(&c, &a0, &a1, &k1);
+    alpha.own(k) = xs_me(a0, a1);
+    k1v.own(k) = k1;
+  }
+  XS_T(13);
+  xs_degree_alias_lp(k1v, deg, start_patch, stop_patch);
+  XS_T(14);
+  XS_LANES(lb, start_patch, stop_patch)
+    xs_patch_band_lp(h, x, lb, xs_m(alpha.own(lb)), xs_e(alpha.own(lb)), w->bw_array, start_idx, stop_idx,
+                     max_qmf_subband);
+  /* lpp_tran.c:905: the high bands inherit the aliasing degree of their source band (patch
+     destinations are disjoint and above the source range, so one shifted copy per patch) */
+  {
+    const int lb0 = cx.uni(h->start_patch), lb1 = cx.uni(h->stop_patch);
     for (int patch = 0; patch < num_patches; patch++) {
       const xaac_sbr_patch *pp = &h->patch[patch];
-      int hb = lb + pp->dst_end_band;
-      if (lb < pp->src_start_band || lb >= pp->src_end_band || hb >= 64) continue;
-      if (hb != pp->dst_start_band) degree_alias[hb] = degree_alias[lb];
+      const int off = cx.uni(pp->dst_end_band), s0 = cx.uni(pp->src_start_band), s1 = cx.uni(pp->src_end_band);
+      const int d0 = cx.uni(pp->dst_start_band);
+      const XsLv src = deg.shifted(cx, -off);
+      XS_LANES(hb, 0, 64) {
+        const int lb = hb - off;
+        if (lb >= lb0 && lb < lb1 && lb >= s0 && lb < s1 && hb != d0) deg.own(hb) = src.own(hb);
+      }
     }
   }
-  for (int i = 0; i < h->num_if_bands; i++) st->bw_array_prev[i] = bw_array[i];
+  XS_PAR(i, 0, h->num_if_bands) st->bw_array_prev[i] = w->bw_array[i];
+  cx.sync();
 }
 
 /* ---- envelope adjuster ------------------------------------------------------------------------------ */
-/* sbrdec_lpfuncs.c:529 */
-FX_HD void xs_map_sineflags(const int16_t *tbl_hi, int nsf, const uint8_t *add_harm, int8_t *flags_prev, int tr_env,
-                            int8_t *sine_mapped) {
-  const int low2 = tbl_hi[0] << 1;
-  for (int i = 0; i < XS_MAXF; i++) sine_mapped[i] = XAAC_SBR_MAX_ENVELOPES;
-  int8_t *fp = flags_prev;
+/* sbrdec_lpfuncs.c:529.  harm_flags_prev[j] pairs with sfb nsf-1-j; two sfbs can map to the same
+   band, the lower sfb (visited later by the reference) wins, hence the sequential stores. */
+template <class ST>
+FX_HD void xs_map_sineflags(const XsCx &cx, const int16_t *tbl_hi, int nsf, const uint8_t *add_harm, ST *st,
+                            int tr_env, XsLv &sine_mapped) {
+  const int low2 = cx.uni(tbl_hi[0]) << 1;
+  XsLv q, val;
+  q.fill(-1);
+  val.fill(0);
+  sine_mapped.fill(XAAC_SBR_MAX_ENVELOPES);
+  XS_LANES(i, 0, nsf) {
+    const int j = nsf - 1 - i;
+    const int old = st->harm_flags_prev[j];
+    st->harm_flags_prev[j] = (int8_t)add_harm[i];
+    if (add_harm[i]) q.own(i) = ((tbl_hi[i + 1] + tbl_hi[i]) - low2) >> 1;
+    val.own(i) = old ? 0 : (int8_t)tr_env;
+  }
   for (int i = nsf - 1; i >= 0; i--) {
-    int old = *fp;
-    *fp++ = (int8_t)add_harm[i];
-    if (add_harm[i]) {
-      int q = ((tbl_hi[i + 1] + tbl_hi[i]) - low2) >> 1;
-      sine_mapped[q] = old ? 0 : (int8_t)tr_env;
-    }
+    const int qq = q.get(i);
+    if (qq >= 0) sine_mapped.put(qq, val.get(i));
   }
 }
 
-/* env_calc.c:1211, low-power branch: per-band energy estimate over slots [s0,s1) */
-FX_HD void xs_energy_per_subband(const XsQmf &x, int s0, int s1, int b0, int b1, int frame_exp, int16_t *nrg_est) {
-  const int16_t inv_width = xaac_sbr_inv_int_table[s1 - s0];
+/* env_calc.c:1211, low-power branch: energy estimate of band k over slots [s0,s1) */
+FX_HD int32_t xs_energy_of_subband(const XsQmf &x, int s0, int s1, int k, int frame_exp2, int16_t inv_width) {
   const int n = s1 - s0;
-  frame_exp <<= 1;
-  for (int k = b0; k < b1; k++) {
-    int32_t mx = 1;
-    for (int l = 0; l < n; l++) {
-      int32_t v = fx_abs_nrm(x(s0 + l, k));
-      if (v > mx) mx = v;
-    }
-    int pre = xs_pnorm32(mx) - 3;
-    int32_t accu = 0;
-    int shift = 16 - pre;
-    for (int l = 0; l < n; l++) {
-      int16_t t = shift > 0 ? (int16_t)xs_sar(x(s0 + l, k), shift) : (int16_t)xs_shl(x(s0 + l, k), -shift);
-      accu = fx_add(accu, (int32_t)t * t);
-    }
-    if (accu != 0) {
-      shift = -xs_pnorm32(accu);
-      int16_t sum_m = (int16_t)xs_shr_dir_sat_limit(accu, 16 + shift);
-      *nrg_est++ = xs_mult16_shl_sat(sum_m, inv_width);
-      shift = shift - (pre << 1) + 1;
-      *nrg_est++ = (int16_t)(frame_exp + shift + 1);
-    } else {
-      *nrg_est++ = 0;
-      *nrg_est++ = 0;
-    }
+  int32_t mx = 1;
+  XS_UNROLL4
+  for (int l = 0; l < n; l++) {
+    int32_t v = fx_abs_nrm(x(s0 + l, k));
+    if (v > mx) mx = v;
   }
+  int pre = xs_pnorm32(mx) - 3;
+  int32_t accu = 0;
+  int shift = 16 - pre;
+  XS_UNROLL4
+  for (int l = 0; l < n; l++) {
+    int16_t t = shift > 0 ? (int16_t)xs_sar(x(s0 + l, k), shift) : (int16_t)xs_shl(x(s0 + l, k), -shift);
+    accu = fx_add(accu, (int32_t)t * t);
+  }
+  if (accu == 0) return 0;
+  shift = -xs_pnorm32(accu);
+  int16_t sum_m = (int16_t)xs_shr_dir_sat_limit(accu, 16 + shift);
+  sum_m = xs_mult16_shl_sat(sum_m, inv_width);
+  shift = shift - (pre << 1) + 1;
+  return xs_me(sum_m, (int16_t)(frame_exp2 + shift + 1));
+}
+FX_HD void xs_energy_per_subband(const XsCx &cx, const XsQmf &x, int s0, int s1, int b0, int b1, int frame_exp,
+                                 XsLv &est) {
+  const int16_t inv_width = xaac_sbr_inv_int_table[s1 - s0];
+  XS_LANES(c, 0, b1 - b0) est.own(c) = xs_energy_of_subband(x, s0, s1, b0 + c, frame_exp << 1, inv_width);
 }
 
-/* env_calc.c:1298, low-power branch */
-FX_HD void xs_energy_per_sfb(const XsQmf &x, int nsf, const int16_t *tbl, int s0, int s1, int max_sb, int frame_exp,
-                             int16_t *nrg_est) {
+/* env_calc.c:1298, low-power branch: one scale-factor band per lane.  The reference appends the
+   estimates of successive sfbs; they start at the first sfb at or above max_sb. */
+FX_HD void xs_energy_per_sfb(const XsCx &cx, const XsQmf &x, int nsf, const int16_t *tbl, int s0, int s1, int max_sb,
+                             int frame_exp, XsWork *w, XsLv &est) {
   const int16_t inv_width = xaac_sbr_inv_int_table[s1 - s0];
   frame_exp <<= 1;
-  for (int j = 0; j < nsf; j++) {
-    int li = tbl[j];
-    if (li < max_sb) continue;
-    int ui = tbl[j + 1];
-    int pre = xs_headroom(x, li, ui, s0, s1) - 4;
+  int j0 = 0;
+  while (j0 < nsf && cx.uni(tbl[j0]) < max_sb) j0++;
+  const int base = cx.uni(tbl[j0]);
+  XS_PAR(j, j0, nsf) {
+    const int li = tbl[j], ui = tbl[j + 1];
+    int pre = xs_headroom_seq(x, li, ui, s0, s1) - 4;
     int32_t accumulate = 0;
     for (int k = li; k < ui; k++) {
       int p1 = 16 - pre;
@@ -419,10 +625,14 @@ FX_HD void xs_energy_per_sfb(const XsQmf &x, int nsf, const int16_t *tbl, int s0
       sum_e = ((frame_exp + 11) - shift) - (pre << 1);
     }
     for (int k = li; k < ui; k++) {
-      *nrg_est++ = sum_m;
-      *nrg_est++ = (int16_t)sum_e;
+      w->nrg_est[2 * (k - base)] = sum_m;
+      w->nrg_est[2 * (k - base) + 1] = (int16_t)sum_e;
     }
   }
+  cx.sync();
+  const int count = j0 < nsf ? cx.uni(tbl[nsf]) - base : 0;
+  XS_LANES(c, 0, count) est.own(c) = xs_me(w->nrg_est[2 * c], w->nrg_est[2 * c + 1]);
+  cx.sync();
 }
 
 /* env_calc.c:1382 */
@@ -472,54 +682,90 @@ FX_HD void xs_subbandgain(int16_t e_orig_m, int16_t noise_m, int16_t est_m, int1
   }
 }
 
-/* env_calc.c:616 */
-FX_HD void xs_calc_subband_gains(const xaac_sbr_header *h, const xaac_sbr_frame *f, int freq_res,
-                                 const int16_t *noise_floor, int nsf, int mvalue, int env, const int8_t *sine_mapped,
-                                 int8_t *alias_red, int16_t *e_orig, int16_t *sine, const int16_t *est, int16_t *gain,
-                                 int16_t *noise_lvl, int noise_absc) {
-  const int16_t *tbl = freq_res ? h->freq_band_tbl_hi : h->freq_band_tbl_lo;
-  int ui_noise = h->freq_band_tbl_noise[1], nb = 0, c = 0;
-  const int sb_start = h->sub_band_start;
-  const int skip = f->max_qmf_subband_aac - sb_start;
-  const int8_t *sm = sine_mapped;
-  const int8_t *sm1 = sine_mapped + skip;
+/* env_calc.c:616 in two steps.  Step 1: for every QMF band covered by the envelope's frequency table
+   find its scale-factor band j, its noise-floor band nb and whether its sfb carries a sine in this
+   envelope, plus the alias-reduction flag.  The reference finds them walking the tables band by band;
+   with strictly increasing tables that start at the same band (ixheaacd_freq_sca.c builds them so)
+   the walk has a closed form per band -- j / nb = number of table borders at or below the band, the
+   sine flag = OR over the lanes of the same sfb, taken from two ballots -- so lane i does band
+   tbl[0] + i.  Step 2 (one band per lane): the three pseudo-float divisions of xs_subbandgain.
+   Returns the number of bands at or above max_qmf_subband_aac (elements of v.meta). */
+FX_HD int xs_subband_gain_meta(const XsCx &cx, const xaac_sbr_header *h, int max_qmf_subband_aac, const int16_t *tbl,
+                               int nsf, int env, XsEnv &v) {
+  XsLv tblv, noisev, jn, flags, ar, mt;
+  tblv.fill(0);
+  noisev.fill(0);
+  XS_LANES(i, 0, nsf + 1) tblv.own(i) = tbl[i];
+  XS_LANES(i, 0, XAAC_SBR_MAX_NOISE_COEFFS + 1) noisev.own(i) = h->freq_band_tbl_noise[i];
+  const int t0 = tblv.get(0);
+  int n = tblv.get(nsf) - t0;
+  if (n > 64) n = 64;
+  const int nnf = cx.uni(h->num_nf_bands);
+  jn.fill(0);
+  flags.fill(0);
+  XS_LANES(i, 0, n) {
+    const int k = t0 + i;
+    int j = 0, nb = 0;
+    XS_UNROLL4
+    for (int t = 1; t < nsf; t++) j += tblv.get(t) <= k;
+    for (int t = 1; t < nnf; t++) nb += noisev.get(t) <= k;
+    jn.own(i) = j | (nb << 8);
+  }
+  const XsLv jprev = jn.shifted(cx, -1);
+  XS_LANES(i, 0, n)
+    flags.own(i) = ((i == 0 || (jn.own(i) & 255) != (jprev.own(i) & 255)) ? 1 : 0) |
+                   ((env >= v.sine_mapped.own(i)) ? 2 : 0);
+  const uint64_t sfb_start = xs_ballot(cx, flags, 1, n), sine_here = xs_ballot(cx, flags, 2, n);
+  ar.fill(0);
+  mt.fill(0);
+  XS_LANES(i, 0, n) {
+    const int first = 63 - xs_clz64(sfb_start & xs_mask_upto(i)); /* bit 0 is always set */
+    const uint64_t above = sfb_start & ~xs_mask_upto(i);
+    const int end = above ? xs_ctz64(above) : n;
+    const uint64_t seg = (((uint64_t)1 << end) - 1) & ~(((uint64_t)1 << first) - 1);
+    const int present = (sine_here & seg) != 0;
+    ar.own(i) = !present;
+    mt.own(i) = jn.own(i) | (present << 16);
+  }
+  /* alias_red is indexed from sub_band_start, meta from max_qmf_subband_aac */
+  const int aoff = t0 - cx.uni(h->sub_band_start);
+  const XsLv ar_s = ar.shifted(cx, -aoff);
+  XS_LANES(e, aoff, aoff + n > 64 ? 64 : aoff + n) v.alias_red.own(e) = ar_s.own(e);
+  const int moff = max_qmf_subband_aac > t0 ? max_qmf_subband_aac - t0 : 0;
+  const XsLv mt_s = mt.shifted(cx, moff);
+  const int n_meta = n > moff ? n - moff : 0;
+  XS_LANES(c, 0, n_meta) v.meta.own(c) = mt_s.own(c);
+  return n_meta;
+}
+FX_HD void xs_calc_subband_gains(const XsCx &cx, const xaac_sbr_frame *f, const int16_t *noise_floor, int mvalue,
+                                 int env, int n_meta, int skip, XsEnv &v, int noise_absc) {
+  const XsLv sm1 = v.sine_mapped.shifted(cx, skip);
   const int16_t *env_sf = &f->int_env_sf_arr[mvalue];
-  int8_t *ar = &alias_red[tbl[0] - sb_start];
-  int16_t nm = (int16_t)(noise_floor[nb] & 0xffc0), ne = (int16_t)((noise_floor[nb] & 63) - 38);
-  for (int j = 0; j < nsf; j++) {
-    int li = tbl[j], ui = tbl[j + 1];
-    int16_t sf = *env_sf++;
-    int16_t ref_e = (int16_t)((sf & 63) - 16), ref_m = (int16_t)(sf & 0xffc0);
-    int present = 0;
-    for (int k = li; k < ui; k++)
-      if (env >= *sm++) present = 1;
-    for (int k = li; k < ui; k++) {
-      *ar++ = (int8_t)!present;
-      if (k >= ui_noise) {
-        nb++;
-        ui_noise = h->freq_band_tbl_noise[nb + 1];
-        nm = (int16_t)(noise_floor[nb] & 0xffc0);
-        ne = (int16_t)((noise_floor[nb] & 63) - 38);
-      }
-      if (k >= f->max_qmf_subband_aac) {
-        e_orig[2 * c] = ref_m;
-        e_orig[2 * c + 1] = ref_e;
-        sine[2 * c] = 0;
-        sine[2 * c + 1] = 0;
-        xs_subbandgain(ref_m, nm, est[2 * c], est[2 * c + 1], ne, ref_e, present, env >= sm1[c], noise_absc,
-                       &gain[2 * c], &noise_lvl[2 * c], &sine[2 * c]);
-        c++;
-      }
-    }
+  XS_LANES(c, 0, n_meta) {
+    const int meta = v.meta.own(c);
+    const int16_t sf = env_sf[meta & 255];
+    const int16_t nfl = noise_floor[(meta >> 8) & 255];
+    const int present = (meta >> 16) & 1;
+    const int16_t ref_e = (int16_t)((sf & 63) - 16), ref_m = (int16_t)(sf & 0xffc0);
+    const int16_t nm = (int16_t)(nfl & 0xffc0), ne = (int16_t)((nfl & 63) - 38);
+    int16_t g[2] = {0, 0}, nl[2] = {0, 0}, sn[2] = {0, 0};
+    const int32_t est = v.est.own(c);
+    xs_subbandgain(ref_m, nm, xs_m(est), xs_e(est), ne, ref_e, present, env >= sm1.own(c), noise_absc, g, nl, sn);
+    v.e_orig.own(c) = xs_me(ref_m, ref_e);
+    v.gain.own(c) = xs_me(g[0], g[1]);
+    v.noise.own(c) = xs_me(nl[0], nl[1]);
+    v.sine.own(c) = xs_me(sn[0], sn[1]);
   }
 }
 
-/* env_calc.c:1454 */
-FX_HD void xs_avggain(const int16_t *e_orig, const int16_t *est, int b0, int b1, int16_t *o_mant, int16_t *o_exp,
-                      int16_t *avg_m, int16_t *avg_e, int flag) {
+/* env_calc.c:1454: pseudo-float sums over bands [b0,b1) -- order dependent, hence sequential.
+   ab[k] = {(m,e) of the first operand, (m,e) of the second}, packed as xs_me. */
+FX_HD void xs_avggain(const int32_t (*ab)[2], int b0, int b1, int16_t *o_mant, int16_t *o_exp, int16_t *avg_m,
+                      int16_t *avg_e, int flag) {
   int32_t som = 0, soe = 0, sem = 0, see = 0;
   for (int k = b0; k < b1; k++) {
-    int16_t m = e_orig[2 * k], e = e_orig[2 * k + 1], m2 = est[2 * k], e2 = est[2 * k + 1];
+    const int32_t va = ab[k][0], vb = ab[k][1];
+    int16_t m = xs_m(va), e = xs_e(va), m2 = xs_m(vb), e2 = xs_e(vb);
     xs_acc_me(&som, &soe, m, e);
     if (flag) {
       m = (int16_t)(((int32_t)m * m2) >> 16);
@@ -558,17 +804,24 @@ FX_HD void xs_avggain(const int16_t *e_orig, const int16_t *est, int b0, int b1,
   *o_exp = so_e;
 }
 
-/* env_calc.c:229 */
-FX_HD void xs_noiselimiting(const xaac_sbr_header *h, int skip, const int16_t *e_orig, const int16_t *est,
-                            int16_t *gain, int16_t *noise_lvl, int16_t *sine, const int16_t *lim_tab, int noise_absc) {
+/* env_calc.c:229.  Two kinds of steps alternate: per-band ones (lane = band) and the order-dependent
+   pseudo-float sums over a limiter band (lane = limiter band, all limiter bands at once); they hand
+   their operands / results over through w->fold_* / w->res_*. */
+FX_HD void xs_noiselimiting(const XsCx &cx, const xaac_sbr_header *h, int skip, int n_bands, XsEnv &v, XsWork *w,
+                            const int16_t *lim_tab, int noise_absc) {
   const int16_t lim_m = lim_tab[0], lim_e = lim_tab[1];
-  for (int c = 0; c < h->num_lf_bands; c++) {
-    int b0 = 0, b1 = 0;
-    if (h->freq_band_tbl_lim[c] > skip) b0 = h->freq_band_tbl_lim[c] - skip;
-    if (h->freq_band_tbl_lim[c + 1] > skip) b1 = h->freq_band_tbl_lim[c + 1] - skip;
+  const int nlf = cx.uni(h->num_lf_bands);
+  XS_LANES(k, 0, n_bands) {
+    w->fold_a[k][0] = v.e_orig.own(k);
+    w->fold_a[k][1] = v.est.own(k);
+  }
+  cx.sync();
+  XS_PAR(c, 0, nlf) {
+    const int t_lo = h->freq_band_tbl_lim[c], t_hi = h->freq_band_tbl_lim[c + 1];
+    const int b0 = t_lo > skip ? t_lo - skip : 0, b1 = t_hi > skip ? t_hi - skip : 0;
     if (b0 >= b1) continue;
     int16_t so_m, so_e, mg_m, mg_e;
-    xs_avggain(e_orig, est, b0, b1, &so_m, &so_e, &mg_m, &mg_e, 0);
+    xs_avggain(w->fold_a, b0, b1, &so_m, &so_e, &mg_m, &mg_e, 0);
     int32_t mt = xs_mult16x16_shl(mg_m, lim_m);
     mg_e = (int16_t)(mg_e + lim_e);
     int tv = fx_norm32(mt);
@@ -578,26 +831,64 @@ FX_HD void xs_noiselimiting(const xaac_sbr_header *h, int skip, const int16_t *e
       mg_m = 0x3000;
       mg_e = 34;
     }
-    for (int k = b0; k < b1; k++) {
-      int16_t gm = gain[2 * k], ge = gain[2 * k + 1];
-      if (ge > mg_e || (ge == mg_e && gm > mg_m)) {
-        int16_t na_m;
-        int na_e = xs_fix_mant_div(mg_m, gm, &na_m);
-        na_e += (mg_e - ge) + 1;
-        noise_lvl[2 * k] = (int16_t)(fx_shl_dir_sat_limit(xs_mult16x16_shl(noise_lvl[2 * k], na_m), (int16_t)na_e) >> 16);
-        gain[2 * k] = mg_m;
-        gain[2 * k + 1] = mg_e;
-      }
+    w->res_a[c][0] = mg_m;
+    w->res_a[c][1] = mg_e;
+    w->res_a[c][2] = so_m;
+    w->res_a[c][3] = so_e;
+  }
+  cx.sync();
+  XS_T(16);
+  /* band k belongs to the limiter band with tbl_lim[c] <= k + skip < tbl_lim[c + 1] (the last such c, as
+     the reference's loop over c would apply them in order; the bands are disjoint) */
+  XsLv limv;
+  limv.fill(0);
+  XS_LANES(i, 0, nlf + 1) limv.own(i) = h->freq_band_tbl_lim[i];
+  XsLv mine;
+  mine.fill(-1);
+  XS_LANES(k, 0, n_bands) {
+    int c_of = -1;
+    for (int c = 0; c < nlf; c++) {
+      const int t_lo = limv.get(c), t_hi = limv.get(c + 1);
+      const int b0 = t_lo > skip ? t_lo - skip : 0, b1 = t_hi > skip ? t_hi - skip : 0;
+      if (k >= b0 && k < b1) c_of = c;
     }
+    mine.own(k) = c_of;
+    if (c_of < 0) continue;
+    const int16_t mg_m = w->res_a[c_of][0], mg_e = w->res_a[c_of][1];
+    int16_t gm = xs_m(v.gain.own(k)), ge = xs_e(v.gain.own(k));
+    if (ge > mg_e || (ge == mg_e && gm > mg_m)) {
+      int16_t na_m;
+      int na_e = xs_fix_mant_div(mg_m, gm, &na_m);
+      na_e += (mg_e - ge) + 1;
+      const int32_t nl = v.noise.own(k);
+      v.noise.own(k) =
+          xs_me((int16_t)(fx_shl_dir_sat_limit(xs_mult16x16_shl(xs_m(nl), na_m), (int16_t)na_e) >> 16), xs_e(nl));
+      gm = mg_m;
+      ge = mg_e;
+      v.gain.own(k) = xs_me(gm, ge);
+    }
+    w->fold_b[k][0] = ((int32_t)gm * xs_m(v.est.own(k))) >> 15;
+    w->fold_b[k][1] = ge + xs_e(v.est.own(k));
+    w->fold_b[k][2] = v.sine.own(k);
+    w->fold_b[k][3] = v.noise.own(k);
+  }
+  cx.sync();
+  XS_T(17);
+  XS_PAR(c, 0, nlf) {
+    const int t_lo = h->freq_band_tbl_lim[c], t_hi = h->freq_band_tbl_lim[c + 1];
+    const int b0 = t_lo > skip ? t_lo - skip : 0, b1 = t_hi > skip ? t_hi - skip : 0;
+    if (b0 >= b1) continue;
+    const int16_t so_m = w->res_a[c][2], so_e = w->res_a[c][3];
     int32_t am = 0, ae = 0;
     for (int k = b0; k < b1; k++) {
-      int32_t m = ((int32_t)gain[2 * k] * est[2 * k]) >> 15;
-      int32_t e = gain[2 * k + 1] + est[2 * k + 1];
-      xs_acc_me(&am, &ae, m, e);
-      if (sine[2 * k] != 0)
-        xs_acc_me(&am, &ae, sine[2 * k], sine[2 * k + 1]);
-      else if (noise_absc == 0)
-        xs_acc_me(&am, &ae, noise_lvl[2 * k], noise_lvl[2 * k + 1]);
+      xs_acc_me(&am, &ae, w->fold_b[k][0], w->fold_b[k][1]);
+      const int32_t sn = w->fold_b[k][2];
+      if (xs_m(sn) != 0) {
+        xs_acc_me(&am, &ae, xs_m(sn), xs_e(sn));
+      } else if (noise_absc == 0) {
+        const int32_t nl = w->fold_b[k][3];
+        xs_acc_me(&am, &ae, xs_m(nl), xs_e(nl));
+      }
     }
     int nv = 16 - fx_norm32(am);
     if (nv > 0) {
@@ -611,211 +902,262 @@ FX_HD void xs_noiselimiting(const xaac_sbr_header *h, int skip, const int16_t *e
       bg_m = 0x5061;
       bg_e = 2;
     }
-    for (int k = b0; k < b1; k++) {
-      gain[2 * k] = xs_mult16_shl(gain[2 * k], bg_m);
-      sine[2 * k] = xs_mult16_shl(sine[2 * k], bg_m);
-      noise_lvl[2 * k] = xs_mult16_shl(noise_lvl[2 * k], bg_m);
-      gain[2 * k + 1] = (int16_t)(gain[2 * k + 1] + bg_e);
-      sine[2 * k + 1] = (int16_t)(sine[2 * k + 1] + bg_e);
-      noise_lvl[2 * k + 1] = (int16_t)(noise_lvl[2 * k + 1] + bg_e);
-    }
+    w->res_b[c][0] = bg_m;
+    w->res_b[c][1] = (int16_t)bg_e;
   }
+  cx.sync();
+  XS_T(18);
+  XS_LANES(k, 0, n_bands) {
+    const int c_of = mine.own(k);
+    if (c_of < 0) continue;
+    const int16_t bg_m = w->res_b[c_of][0], bg_e = w->res_b[c_of][1];
+    const int32_t g = v.gain.own(k), sn = v.sine.own(k), nl = v.noise.own(k);
+    v.gain.own(k) = xs_me(xs_mult16_shl(xs_m(g), bg_m), (int16_t)(xs_e(g) + bg_e));
+    v.sine.own(k) = xs_me(xs_mult16_shl(xs_m(sn), bg_m), (int16_t)(xs_e(sn) + bg_e));
+    v.noise.own(k) = xs_me(xs_mult16_shl(xs_m(nl), bg_m), (int16_t)(xs_e(nl) + bg_e));
+  }
+  cx.sync();
+  XS_T(20);
 }
 
-/* env_calc.c:78 (low-power only) */
-FX_HD void xs_alias_reduction(const int16_t *deg, int16_t *gain, const int16_t *est, const int8_t *alias_red, int nsb) {
-  int16_t grp[XS_MAXF + 2];
-  int grouping = 0, i = 0;
-  for (int k = 0; k < nsb - 1; k++) {
-    if (deg[k + 1] != 0 && alias_red[k]) {
-      if (!grouping) {
-        grp[i++] = (int16_t)k;
-        grouping = 1;
-      } else if (grp[i - 1] + 3 == k) {
-        grp[i++] = (int16_t)(k + 1);
-        grouping = 0;
-      }
-    } else if (grouping) {
-      grouping = 0;
-      grp[i] = (int16_t)k;
-      if (alias_red[k]) grp[i] = (int16_t)(k + 1);
-      i++;
+/* env_calc.c:78 (low-power only), step 1: the groups of aliasing bands.  The reference walks the
+   bands with a little state machine: a run of bands with (deg[k+1] != 0 && alias_red[k]) is cut into
+   groups of four; a run that stops early closes its last group at the stopping band (inclusive when
+   that band still has alias_red set), a run that reaches the last band closes it at nsb.  As a
+   function of the two bit masks involved that is: a band starts a group iff its offset in its run is
+   a multiple of four; its group ends four bands up when the next three bands are still in the run,
+   else where the run stops.  Returns the mask of group-start bands; end.own(s) = end of the group
+   that starts at s. */
+FX_HD uint64_t xs_alias_groups(const XsCx &cx, const XsLv &deg1, const XsLv &alias_red, int nsb, XsLv &end) {
+  XsLv f;
+  f.fill(0);
+  XS_LANES(k, 0, 64)
+    f.own(k) = ((k < nsb - 1 && deg1.own(k) != 0 && alias_red.own(k)) ? 1 : 0) | (alias_red.own(k) ? 2 : 0);
+  const uint64_t in_run = xs_ballot(cx, f, 1, 64), red = xs_ballot(cx, f, 2, 64);
+  XsLv st;
+  st.fill(0);
+  XS_LANES(k, 0, 64) {
+    if (!((in_run >> k) & 1)) continue;
+    const uint64_t gaps_below = ~in_run & (xs_mask_upto(k) >> 1);
+    const int run_start = gaps_below ? 64 - xs_clz64(gaps_below) : 0;
+    if ((k - run_start) & 3) continue;
+    st.own(k) = 1;
+    int e;
+    if (((in_run >> k) & 15) == 15) {
+      e = k + 4;
+    } else {
+      const int z = k + xs_ctz64(~(in_run >> k)); /* first band at or above k outside the run */
+      if (z >= nsb - 1)
+        e = nsb;
+      else
+        e = ((red >> z) & 1) ? z + 1 : z;
     }
+    end.own(k) = e;
   }
-  if (grouping) grp[i++] = (int16_t)nsb;
-  const int ngroups = i >> 1;
-  for (int g = 0; g < ngroups; g++) {
-    const int b0 = grp[2 * g], b1 = grp[2 * g + 1];
+  return xs_ballot(cx, st, 1, 64);
+}
+/* step 2: equalise the gains inside each group (the lane of a group's first band does its sums) */
+FX_HD void xs_alias_reduction(const XsCx &cx, XsEnv &v, XsWork *w, uint64_t starts, const XsLv &end, int nsb) {
+  if (starts == 0) return;
+  XS_LANES(k, 0, nsb) {
+    w->fold_a[k][0] = v.est.own(k);
+    w->fold_a[k][1] = v.gain.own(k);
+  }
+  cx.sync();
+  XS_LANES(s, 0, nsb) {
+    if (!((starts >> s) & 1)) continue;
     int16_t amp_m, amp_e, gg_m, gg_e;
-    xs_avggain(est, gain, b0, b1, &amp_m, &amp_e, &gg_m, &gg_e, 1);
-    int32_t mod_m = 0, mod_e = 0;
-    for (int k = b0; k < b1; k++) {
-      int16_t alpha = deg[k];
-      if (k < nsb - 1 && deg[k + 1] > alpha) alpha = deg[k + 1];
-      int32_t gain_m = (int32_t)alpha * gg_m;
-      int16_t one_minus = (int16_t)(0x7fff - alpha);
-      int32_t tm = gain[2 * k], te = gain[2 * k + 1];
-      tm = ((int32_t)one_minus * tm) >> 15;
-      int32_t d = gg_e - te;
-      if (d >= 0) {
-        te = gg_e;
-        tm = fx_shr(tm, d);
-        tm = (gain_m >> 15) + tm;
-      } else {
-        tm = fx_shr(gain_m, 15 - d) + tm;
-      }
-      gain[2 * k] = (int16_t)tm;
-      gain[2 * k + 1] = (int16_t)te;
-      /* the reference multiplies the untruncated 32-bit tmp_gain_mant here (env_calc.c:182) */
-      int32_t pm = (int32_t)((uint32_t)tm * (uint32_t)(int32_t)est[2 * k]) >> 16;
-      int32_t pe = te + est[2 * k + 1] + 1;
-      xs_acc_me(&mod_m, &mod_e, pm, pe);
+    xs_avggain(w->fold_a, s, end.own(s), &amp_m, &amp_e, &gg_m, &gg_e, 1);
+    w->res_a[s][0] = amp_m;
+    w->res_a[s][1] = amp_e;
+    w->res_a[s][2] = gg_m;
+    w->res_a[s][3] = gg_e;
+    w->res_b[s][0] = (int16_t)end.own(s);
+  }
+  cx.sync();
+  XsLv mine;
+  mine.fill(-1);
+  XS_LANES(k, 0, nsb) {
+    const uint64_t below = starts & xs_mask_upto(k);
+    if (!below) continue;
+    const int s = 63 - xs_clz64(below);
+    if (k >= w->res_b[s][0]) continue;
+    mine.own(k) = s;
+    const int16_t gg_m = w->res_a[s][2], gg_e = w->res_a[s][3];
+    int16_t alpha = (int16_t)v.deg.own(k);
+    if (k < nsb - 1 && (int16_t)v.deg1.own(k) > alpha) alpha = (int16_t)v.deg1.own(k);
+    int32_t gain_m = (int32_t)alpha * gg_m;
+    int16_t one_minus = (int16_t)(0x7fff - alpha);
+    int32_t tm = xs_m(v.gain.own(k)), te = xs_e(v.gain.own(k));
+    tm = ((int32_t)one_minus * tm) >> 15;
+    int32_t d = gg_e - te;
+    if (d >= 0) {
+      te = gg_e;
+      tm = fx_shr(tm, d);
+      tm = (gain_m >> 15) + tm;
+    } else {
+      tm = fx_shr(gain_m, 15 - d) + tm;
     }
+    v.gain.own(k) = xs_me((int16_t)tm, (int16_t)te);
+    /* the reference multiplies the untruncated 32-bit tmp_gain_mant here (env_calc.c:182) */
+    w->fold_b[k][0] = (int32_t)((uint32_t)tm * (uint32_t)(int32_t)xs_m(v.est.own(k))) >> 16;
+    w->fold_b[k][1] = te + xs_e(v.est.own(k)) + 1;
+  }
+  cx.sync();
+  XS_LANES(s, 0, nsb) {
+    if (!((starts >> s) & 1)) continue;
+    int32_t mod_m = 0, mod_e = 0;
+    const int e = end.own(s);
+    for (int k = s; k < e; k++) xs_acc_me(&mod_m, &mod_e, w->fold_b[k][0], w->fold_b[k][1]);
     int nv = 16 - xs_pnorm32(mod_m);
     if (nv > 0) {
       mod_m >>= nv;
       mod_e += nv;
     }
     int16_t comp_m;
-    int comp_e = xs_fix_mant_div(amp_m, (int16_t)mod_m, &comp_m);
-    comp_e = (int16_t)(comp_e + amp_e - (int16_t)mod_e + 1 + 1);
-    for (int k = b0; k < b1; k++) {
-      gain[2 * k] = (int16_t)(((int32_t)gain[2 * k] * comp_m) >> 16);
-      gain[2 * k + 1] = (int16_t)(gain[2 * k + 1] + comp_e);
-    }
+    int comp_e = xs_fix_mant_div(w->res_a[s][0], (int16_t)mod_m, &comp_m);
+    comp_e = (int16_t)(comp_e + w->res_a[s][1] - (int16_t)mod_e + 1 + 1);
+    w->res_b[s][1] = comp_m;
+    w->res_a[s][3] = (int16_t)comp_e;
   }
+  cx.sync();
+  XS_LANES(k, 0, nsb) {
+    const int s = mine.own(k);
+    if (s < 0) continue;
+    const int16_t comp_m = w->res_b[s][1], comp_e = w->res_a[s][3];
+    const int32_t g2 = v.gain.own(k);
+    v.gain.own(k) = xs_me((int16_t)(((int32_t)xs_m(g2) * comp_m) >> 16), (int16_t)(xs_e(g2) + comp_e));
+  }
+  cx.sync();
 }
 
 /* env_calc.c:423 */
-FX_HD void xs_erg_to_amplitude_lp(int bands, int16_t noise_e, int16_t *sine, int16_t *gain, int16_t *noise_lvl) {
-  for (int k = 0; k < bands; k++) {
-    xs_mant_exp_sqrt(&sine[2 * k]);
-    xs_mant_exp_sqrt(&gain[2 * k]);
-    xs_mant_exp_sqrt(&noise_lvl[2 * k]);
-    int shift = (noise_e - noise_lvl[2 * k + 1]) - 4;
+FX_HD void xs_erg_to_amplitude_lp(const XsCx &cx, int bands, int16_t noise_e, XsEnv &v) {
+  XS_LANES(k, 0, bands) {
+    int16_t sn[2] = {xs_m(v.sine.own(k)), xs_e(v.sine.own(k))};
+    int16_t g[2] = {xs_m(v.gain.own(k)), xs_e(v.gain.own(k))};
+    int16_t nl[2] = {xs_m(v.noise.own(k)), xs_e(v.noise.own(k))};
+    xs_mant_exp_sqrt(sn);
+    xs_mant_exp_sqrt(g);
+    xs_mant_exp_sqrt(nl);
+    int shift = (noise_e - nl[1]) - 4;
     if (shift > 0)
-      noise_lvl[2 * k] = (int16_t)xs_sar(noise_lvl[2 * k], shift);
+      nl[0] = (int16_t)xs_sar(nl[0], shift);
     else
-      noise_lvl[2 * k] = (int16_t)xs_shl(noise_lvl[2 * k], -shift);
-    shift = sine[2 * k + 1] - noise_e;
+      nl[0] = (int16_t)xs_shl(nl[0], -shift);
+    shift = sn[1] - noise_e;
     if (shift > 0)
-      sine[2 * k] = xs_shl16_sat(sine[2 * k], (int16_t)shift);
+      sn[0] = xs_shl16_sat(sn[0], (int16_t)shift);
     else
-      sine[2 * k] = (int16_t)xs_sar(sine[2 * k], (int16_t)-shift);
+      sn[0] = (int16_t)xs_sar(sn[0], (int16_t)-shift);
+    v.sine.own(k) = xs_me(sn[0], sn[1]);
+    v.gain.own(k) = xs_me(g[0], g[1]);
+    v.noise.own(k) = xs_me(nl[0], nl[1]);
   }
 }
 
-/* env_calc.c:1017 */
-FX_HD void xs_equalize_filt_buf(int16_t *fb, int16_t *gain, int n) {
-  for (int b = 0; b < n; b++, fb += 2, gain += 2) {
-    int32_t fe = fb[1], ge = gain[1], fm = fb[0], gm = gain[0];
-    int32_t diff = ge - fe;
-    if (diff >= 0) {
-      fb[1] = (int16_t)ge;
-      fb[0] = (int16_t)xs_sar(fb[0], diff);
+/* env_calc.c:1017, one band */
+FX_HD void xs_equalize_filt_buf(int16_t *fb, int16_t *gain) {
+  int32_t fe = fb[1], ge = gain[1], fm = fb[0], gm = gain[0];
+  int32_t diff = ge - fe;
+  if (diff >= 0) {
+    fb[1] = (int16_t)ge;
+    fb[0] = (int16_t)xs_sar(fb[0], diff);
+  } else {
+    int32_t reserve = fx_norm32(fm) - 16;
+    if (diff + reserve >= 0) {
+      fb[0] = (int16_t)xs_shl(fm, -diff);
+      fb[1] = (int16_t)(fe + diff);
     } else {
-      int32_t reserve = fx_norm32(fm) - 16;
-      if (diff + reserve >= 0) {
-        fb[0] = (int16_t)xs_shl(fm, -diff);
-        fb[1] = (int16_t)(fe + diff);
-      } else {
-        fb[0] = (int16_t)xs_shl(fm, reserve);
-        fb[1] = (int16_t)(fe - reserve);
-        int32_t shift = -(reserve + diff);
-        gain[0] = (int16_t)xs_sar(gm, shift);
-        gain[1] = (int16_t)(gain[1] + shift);
-      }
+      fb[0] = (int16_t)xs_shl(fm, reserve);
+      fb[1] = (int16_t)(fe - reserve);
+      int32_t shift = -(reserve + diff);
+      gain[0] = (int16_t)xs_sar(gm, shift);
+      gain[1] = (int16_t)(gain[1] + shift);
     }
   }
 }
 
-/* env_calc.c:1080 */
-FX_HD void xs_noise_rescale(int16_t *p, int diff, int n, int step) {
-  if (diff > 0)
-    for (int k = 0; k < n; k++) p[k * step] = (int16_t)xs_sar(p[k * step], diff);
-  else if (diff < 0)
-    for (int k = 0; k < n; k++) p[k * step] = (int16_t)xs_shl(p[k * step], -diff);
+/* env_calc.c:1080, one value */
+FX_HD int16_t xs_noise_rescale(int16_t v, int diff) {
+  if (diff > 0) return (int16_t)xs_sar(v, diff);
+  if (diff < 0) return (int16_t)xs_shl(v, -diff);
+  return v;
 }
 
 #define XS_FACTOR ((int32_t)(0x010b0000 * 2))
 
-/* env_calc.c:1564: one slot, harmonic index 0 / 2 */
-FX_HD void xs_harm_zerotwo_lp(const XsQmf &x, int slot, int b0, const int16_t *gain, int scale_change,
-                              const int16_t *sine, const int32_t *rand_ph, const int16_t *noise_lvl, int nsb,
-                              int noise_absc, int harm_index) {
+/* The per-band constants of one envelope that the slot loop needs (registers) */
+struct XsBandAmp {
+  int16_t gm, ge;          /* gain */
+  int16_t sl, sl_prev, sl_next; /* sine level of this band and of its neighbours */
+  int16_t nl;              /* noise level */
+  int16_t tone_count;      /* bands 0..k carrying a sine */
+};
+
+/* env_calc.c:1564: one slot, harmonic index 0 / 2, band k of the adjusted range */
+FX_HD void xs_harm_zerotwo_lp(const XsQmf &x, int slot, int b0, int k, const XsBandAmp &a, int scale_change,
+                              int16_t rand_ph, int noise_absc, int harm_index) {
   scale_change -= 1;
-  for (int k = 0; k < nsb; k++) {
-    int32_t v = fx_mul32x16(x(slot, b0 + k), gain[2 * k]);
-    int shift = gain[2 * k + 1] - scale_change;
-    v = shift > 0 ? xs_shl(v, shift) : xs_sar(v, -shift);
-    int32_t sl = xs_shl(sine[2 * k], 16);
-    if (!noise_absc && sl == 0)
-      v = xs_mac16x16_shl_sat(v, (int16_t)(rand_ph[k] >> 16), noise_lvl[2 * k]);
-    else if (harm_index == 0)
-      v = fx_add_sat(v, sl);
-    else
-      v = fx_sub_sat(v, sl);
-    x(slot, b0 + k) = v;
-  }
+  int32_t v = fx_mul32x16(x(slot, b0 + k), a.gm);
+  int shift = a.ge - scale_change;
+  v = shift > 0 ? xs_shl(v, shift) : xs_sar(v, -shift);
+  int32_t sl = xs_shl(a.sl, 16);
+  if (!noise_absc && sl == 0)
+    v = xs_mac16x16_shl_sat(v, rand_ph, a.nl);
+  else if (harm_index == 0)
+    v = fx_add_sat(v, sl);
+  else
+    v = fx_sub_sat(v, sl);
+  x(slot, b0 + k) = v;
 }
 
-/* env_calc.c:1617: one slot, harmonic index 1 / 3 */
-FX_HD void xs_harm_onethree_lp(const XsQmf &x, int slot, int b0, const int16_t *gain, int scale_change,
-                               const int16_t *sine, const int32_t *rand_ph, const int16_t *noise_lvl, int nsb,
-                               int noise_absc, int freq_inv, int noise_e, int sb_start) {
-  int k = 0, tone_count = 0;
-  scale_change -= 1;
-  int32_t v = fx_mul32x16(x(slot, b0), gain[0]);
-  int shift = gain[1] - scale_change;
-  v = shift > 0 ? xs_shl(v, shift) : xs_sar(v, -shift);
-  int16_t sl = sine[0], sl_prev, sl_next = nsb > 1 ? sine[2] : (int16_t)0;
-  if (sine[0] != 0)
-    tone_count++;
-  else if (!noise_absc)
-    v = xs_mac16x16_shl_sat(v, (int16_t)(rand_ph[0] >> 16), noise_lvl[0]);
-  int32_t tm2 = fx_mul32x16(XS_FACTOR, sl_next);
-  int32_t tm = fx_mul32x16(XS_FACTOR, sl);
-  int16_t ne = (int16_t)noise_e;
-  tm = ne > 0 ? fx_shl(tm, ne) : fx_shr(tm, -ne);
-  if (freq_inv < 0) {
-    x(slot, b0 - 1) = fx_add_sat(x(slot, b0 - 1), tm);
-    v = fx_sub_sat(v, tm2);
-  } else {
-    x(slot, b0 - 1) = fx_sub_sat(x(slot, b0 - 1), tm);
-    v = fx_add_sat(v, tm2);
-  }
-  x(slot, b0) = v;
+/* env_calc.c:1617: one slot, harmonic index 1 / 3, band k of nsb.  The reference walks the bands
+   carrying three things along: the sine levels of the neighbours, a sign that alternates from band 1
+   on (freq_inv * (-1)^(k-1)), and the number of bands with a sine seen so far.  With those spelled
+   out every band is independent; band 0 also touches b0-1 and the last band b0+nsb, which no other
+   band writes. */
+FX_HD void xs_harm_onethree_lp(const XsQmf &x, int slot, int b0, int k, const XsBandAmp &a, int scale_change,
+                               int16_t rand_ph, int nsb, int noise_absc, int freq_inv, int noise_e, int sb_start) {
   const int nm1 = nsb - 1;
-  for (k = 1; k < nm1; k++) {
-    v = fx_mul32x16(x(slot, b0 + k), gain[2 * k]);
-    shift = gain[2 * k + 1] - scale_change;
+  scale_change -= 1;
+  int32_t v = fx_mul32x16(x(slot, b0 + k), a.gm);
+  const int shift = a.ge - scale_change;
+  const int16_t sl = a.sl;
+  if (k == 0) {
+    v = shift > 0 ? xs_shl(v, shift) : xs_sar(v, -shift);
+    const int16_t sl_next = nsb > 1 ? a.sl_next : (int16_t)0;
+    if (sl == 0 && !noise_absc) v = xs_mac16x16_shl_sat(v, rand_ph, a.nl);
+    int32_t tm2 = fx_mul32x16(XS_FACTOR, sl_next);
+    int32_t tm = fx_mul32x16(XS_FACTOR, sl);
+    int16_t ne = (int16_t)noise_e;
+    tm = ne > 0 ? fx_shl(tm, ne) : fx_shr(tm, -ne);
+    if (freq_inv < 0) {
+      x(slot, b0 - 1) = fx_add_sat(x(slot, b0 - 1), tm);
+      v = fx_sub_sat(v, tm2);
+    } else {
+      x(slot, b0 - 1) = fx_sub_sat(x(slot, b0 - 1), tm);
+      v = fx_add_sat(v, tm2);
+    }
+    x(slot, b0) = v;
+  } else if (k < nm1) {
     v = shift >= 0 ? xs_shl(v, shift) : xs_sar(v, -shift);
-    sl_prev = sl;
-    sl = sl_next;
-    if (sl != 0) tone_count++;
-    sl_next = sine[2 * (k + 1)];
-    if (!noise_absc && sl == 0) v = xs_mac16x16_shl_sat(v, (int16_t)(rand_ph[k] >> 16), noise_lvl[2 * k]);
-    if (tone_count <= 16) {
-      int32_t add = fx_mul32x16(XS_FACTOR, (int16_t)(sl_prev - sl_next));
-      v = fx_add_sat(v, (int32_t)((uint32_t)add * (uint32_t)freq_inv));
+    if (!noise_absc && sl == 0) v = xs_mac16x16_shl_sat(v, rand_ph, a.nl);
+    if (a.tone_count <= 16) {
+      int32_t add = fx_mul32x16(XS_FACTOR, (int16_t)(a.sl_prev - a.sl_next));
+      const int fi = (k & 1) ? freq_inv : -freq_inv;
+      v = fx_add_sat(v, (int32_t)((uint32_t)add * (uint32_t)fi));
     }
     x(slot, b0 + k) = v;
-    freq_inv = -freq_inv;
-  }
-  freq_inv = (freq_inv + 1) >> 1;
-  if (nm1 > 0) {
-    v = fx_mul32x16(x(slot, b0 + k), gain[2 * k]);
-    shift = gain[2 * k + 1] - scale_change;
+  } else { /* k == nm1 > 0 */
     v = shift > 0 ? xs_shl(v, shift) : xs_sar(v, -shift);
-    int32_t tms = fx_mul32x16(XS_FACTOR, sl);
-    sl = sl_next;
-    if (sl != 0)
-      tone_count++;
-    else if (!noise_absc)
-      v = xs_mac16x16_shl_sat(v, (int16_t)(rand_ph[k] >> 16), noise_lvl[2 * k]);
-    if (tone_count <= 16) {
-      tm2 = fx_mul32x16(XS_FACTOR, sl);
-      if (freq_inv) {
+    /* the sign after bands 1..nm1-1 have each flipped it, mapped to {0,1} */
+    const int fi = ((((nm1 & 1) ? freq_inv : -freq_inv)) + 1) >> 1;
+    int32_t tms = fx_mul32x16(XS_FACTOR, a.sl_prev);
+    if (sl == 0 && !noise_absc) v = xs_mac16x16_shl_sat(v, rand_ph, a.nl);
+    if (a.tone_count <= 16) {
+      int32_t tm2 = fx_mul32x16(XS_FACTOR, sl);
+      if (fi) {
         x(slot, b0 + k) = fx_add_sat(v, tms);
         if (k + sb_start < 62) x(slot, b0 + k + 1) = fx_sub_sat(x(slot, b0 + k + 1), tm2);
       } else {
@@ -828,242 +1170,331 @@ FX_HD void xs_harm_onethree_lp(const XsQmf &x, int slot, int b0, const int16_t *
   }
 }
 
-/* env_calc.c:479, low-power branch: apply gains / noise / sines to slots [s0,s1) */
-FX_HD void xs_adapt_noise_gain_lp(xaac_sbr_state *st, int noise_e, int nsb, int skip, int16_t *gain, int16_t *noise_lvl,
-                                  int16_t *sine, int s0, int s1, int input_e, int adj_e, int final_e, int sb_start,
-                                  int lb_scale, int noise_absc, const XsQmf &x) {
+/* env_calc.c:479, low-power branch: apply gains / noise / sines to slots [s0,s1).  The reference
+   loops slots outside, bands inside; a band only ever touches its own column of x (plus the two edge
+   columns noted above) and its own gain / noise / sine / filter-buffer entries, so the loops are
+   interchanged: each lane keeps its band's constants in registers and walks the slots. */
+template <class ST>
+FX_HD void xs_adapt_noise_gain_lp(const XsCx &cx, ST *st, XsEnv &v, const int16_t *rand_hi, int noise_e, int nsb, int skip, int s0, int s1,
+                                  int input_e, int adj_e, int final_e, int sb_start, int lb_scale, int noise_absc,
+                                  const XsQmf &x) {
   const int bands = nsb - skip;
-  if (st->start_up) {
-    st->start_up = 0;
-    st->filt_buf_noise_e = noise_e;
-    for (int k = 0; k < bands; k++) {
-      st->filt_buf_me[2 * (skip + k)] = gain[2 * k];
-      st->filt_buf_me[2 * (skip + k) + 1] = gain[2 * k + 1];
-      st->filt_buf_noise_m[skip + k] = noise_lvl[2 * k];
-    }
-  } else {
-    xs_equalize_filt_buf(&st->filt_buf_me[2 * skip], gain, bands);
-  }
-  for (int l = s0; l < s1; l++) {
-    int scale_change;
-    if (l < 32) {
-      scale_change = adj_e - input_e;
+  const int start_up = cx.uni(st->start_up);
+  const int ph0 = cx.uni(st->ph_index), harm0 = cx.uni(st->harm_index);
+  const int fb_noise_e0 = start_up ? noise_e : cx.uni(st->filt_buf_noise_e);
+  cx.sync(); /* everyone has read the scalars before they are updated */
+  XS_LANES(k, 0, bands) {
+    int16_t g[2] = {xs_m(v.gain.own(k)), xs_e(v.gain.own(k))};
+    if (start_up) {
+      st->filt_buf_me[2 * (skip + k)] = g[0];
+      st->filt_buf_me[2 * (skip + k) + 1] = g[1];
+      st->filt_buf_noise_m[skip + k] = xs_m(v.noise.own(k));
     } else {
-      scale_change = final_e - input_e;
-      if (l == 32 && s0 < 32) {
-        int diff = final_e - noise_e;
-        noise_e = final_e;
-        xs_noise_rescale(noise_lvl, diff, bands, 2);
+      xs_equalize_filt_buf(&st->filt_buf_me[2 * (skip + k)], g);
+      v.gain.own(k) = xs_me(g[0], g[1]);
+    }
+  }
+  cx.sync();
+  const XsLv tone = xs_prefix_nonzero_m(cx, v.sine, nsb);
+  const XsLv s_prev = v.sine.shifted(cx, -1), s_next = v.sine.shifted(cx, 1);
+  XS_T(21);
+  int fi0 = !(sb_start & 1);
+  fi0 = (fi0 << 1) - 1;
+  XS_LANES(k, 0, nsb) {
+    XsBandAmp a;
+    a.gm = xs_m(v.gain.own(k));
+    a.ge = xs_e(v.gain.own(k));
+    a.sl = xs_m(v.sine.own(k));
+    a.sl_prev = xs_m(s_prev.own(k));
+    a.sl_next = xs_m(s_next.own(k));
+    a.nl = xs_m(v.noise.own(k));
+    a.tone_count = (int16_t)tone.own(k);
+    int16_t fbn = st->filt_buf_noise_m[k];
+    int ne = noise_e, fbe = fb_noise_e0, ph = ph0, harm = harm0;
+    for (int l = s0; l < s1; l++) {
+      int scale_change;
+      if (l < 32) {
+        scale_change = adj_e - input_e;
+      } else {
+        scale_change = final_e - input_e;
+        if (l == 32 && s0 < 32) {
+          const int diff = final_e - ne;
+          ne = final_e;
+          if (k < bands) a.nl = xs_noise_rescale(a.nl, diff);
+        }
+      }
+      fbn = xs_noise_rescale(fbn, fbe - ne);
+      fbe = ne;
+      const int16_t rp = rand_hi[ph + 1 + k];
+      const int hi = harm;
+      ph = (ph + nsb) & 511;
+      harm = (harm + 1) & 3;
+      if (!(hi & 1)) {
+        xs_harm_zerotwo_lp(x, l, sb_start, k, a, scale_change, rp, noise_absc, hi);
+      } else {
+        xs_harm_onethree_lp(x, l, sb_start, k, a, scale_change, rp, nsb, noise_absc, hi == 3 ? -fi0 : fi0,
+                            (ne - 16) - lb_scale, sb_start);
       }
     }
-    xs_noise_rescale(st->filt_buf_noise_m, st->filt_buf_noise_e - noise_e, nsb, 1);
-    st->filt_buf_noise_e = noise_e;
-    const int index = st->ph_index, harm_index = st->harm_index;
-    const int32_t *rp = &xaac_sbr_rand_ph[index + 1];
-    st->ph_index = (int16_t)((index + nsb) & 511);
-    st->harm_index = (int16_t)((harm_index + 1) & 3);
-    if (!(harm_index & 1)) {
-      xs_harm_zerotwo_lp(x, l, sb_start, gain, scale_change, sine, rp, noise_lvl, nsb, noise_absc, harm_index);
-    } else {
-      int noise = (noise_e - 16) - lb_scale;
-      int fi = !(sb_start & 1);
-      fi = (fi << 1) - 1;
-      if (harm_index == 3) fi = -fi;
-      xs_harm_onethree_lp(x, l, sb_start, gain, scale_change, sine, rp, noise_lvl, nsb, noise_absc, fi, noise,
-                          sb_start);
-    }
+    st->filt_buf_noise_m[k] = fbn;
+    v.noise.own(k) = xs_me(a.nl, xs_e(v.noise.own(k)));
   }
-  for (int k = 0; k < bands; k++) {
-    st->filt_buf_me[2 * (skip + k)] = gain[2 * k];
-    st->filt_buf_noise_m[skip + k] = noise_lvl[2 * k];
+  cx.sync();
+  XS_T(22);
+  XS_LANES(k, 0, bands) {
+    st->filt_buf_me[2 * (skip + k)] = xs_m(v.gain.own(k));
+    st->filt_buf_noise_m[skip + k] = xs_m(v.noise.own(k));
   }
+  XS_ONE {
+    const int n = s1 > s0 ? s1 - s0 : 0;
+    int ne = noise_e;
+    if (s0 < 32 && s1 > 32) ne = final_e;
+    st->start_up = 0;
+    st->filt_buf_noise_e = n > 0 ? ne : fb_noise_e0;
+    st->ph_index = (int16_t)((ph0 + n * nsb) & 511);
+    st->harm_index = (int16_t)((harm0 + n) & 3);
+  }
+  cx.sync();
 }
 
-/* env_calc.c:692, low-power, AAC-LC/HE-AAC (not ELD), 1024-sample frames.  Returns 0 or -1. */
-FX_HD int xs_calc_sbrenvelope_lp(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st,
-                                 const XsQmf &x, const int16_t *deg_patched) {
-  const int num_env = f->num_env;
+/* env_calc.c:692, low-power, AAC-LC/HE-AAC (not ELD), 1024-sample frames.  deg64: aliasing degree per
+   QMF band from the HF generator.  Returns 0 or -1. */
+template <class ST>
+FX_HD int xs_calc_sbrenvelope_lp(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, ST *st,
+                                 const XsQmf &x, XsWork *w, const int16_t *rand_hi, const XsLv &deg64) {
+  const int num_env = cx.uni(f->num_env);
   const int16_t *border = f->border_vec;
   const int16_t *noise_floor = f->int_noise_floor;
-  const int sb_start = h->sub_band_start, sb_end = h->sub_band_end;
+  const int sb_start = cx.uni(h->sub_band_start), sb_end = cx.uni(h->sub_band_end);
+  const int max_sb = cx.uni(f->max_qmf_subband_aac);
   const int nsb = sb_end - sb_start;
-  const int skip = f->max_qmf_subband_aac - sb_start;
-  int16_t nrg_est[2 * XS_MAXF], nrg_gain[2 * XS_MAXF], noise_lvl[2 * XS_MAXF], nrg_sine[2 * XS_MAXF],
-      e_orig[2 * XS_MAXF];
-  int8_t sine_mapped[XS_MAXF], alias_red[64];
-  for (int i = 0; i < 2 * XS_MAXF; i++) nrg_est[i] = nrg_gain[i] = noise_lvl[i] = nrg_sine[i] = e_orig[i] = 0;
-  for (int i = 0; i < 64; i++) alias_red[i] = 0;
-  xs_map_sineflags(h->freq_band_tbl_hi, h->num_sf_bands[1], f->add_harmonics, st->harm_flags_prev, f->transient_env,
-                   sine_mapped);
+  const int skip = max_sb - sb_start;
+  const int transient_env = cx.uni(f->transient_env);
+  XsEnv v;
+  v.est.fill(0);
+  v.e_orig.fill(0);
+  v.gain.fill(0);
+  v.noise.fill(0);
+  v.sine.fill(0);
+  v.meta.fill(0);
+  v.alias_red.fill(0);
+  v.deg = deg64.shifted(cx, sb_start);
+  v.deg1 = deg64.shifted(cx, sb_start + 1);
+  xs_map_sineflags(cx, h->freq_band_tbl_hi, cx.uni(h->num_sf_bands[1]), f->add_harmonics, st, transient_env,
+                   v.sine_mapped);
   int adj_e;
   {
-    int first_band = (st->prev_max_qmf_subband_aac > f->max_qmf_subband_aac ? st->prev_max_qmf_subband_aac
-                                                                             : f->max_qmf_subband_aac) - sb_start;
-    int16_t max_noise = 0;
-    for (int i = first_band; i < nsb; i++)
+    const int prev_sb = cx.uni(st->prev_max_qmf_subband_aac);
+    const int first_band = (prev_sb > max_sb ? prev_sb : max_sb) - sb_start;
+    int32_t max_noise = 0;
+    XS_PAR(i, first_band, nsb)
       if (st->filt_buf_noise_m[i] > max_noise) max_noise = st->filt_buf_noise_m[i];
-    adj_e = (st->filt_buf_noise_e - fx_norm32(max_noise)) - 16;
+    max_noise = cx.wave_max(max_noise);
+    adj_e = (cx.uni(st->filt_buf_noise_e) - fx_norm32((int16_t)max_noise)) - 16;
   }
   int final_e = 0;
   {
-    const int16_t *p = f->int_env_sf_arr;
+    int base = 0;
     for (int i = 0; i < num_env; i++) {
-      int mx = 16 - 16; /* NRG_EXP_OFFSET - SHORT_BITS */
-      const int fr = f->freq_res[i];
-      for (int j = 0; j < h->num_sf_bands[fr]; j++) {
-        int t = *p++ & 63;
+      int32_t mx = 16 - 16; /* NRG_EXP_OFFSET - SHORT_BITS */
+      const int nsf = cx.uni(h->num_sf_bands[f->freq_res[i]]);
+      XS_PAR(j, 0, nsf) {
+        int t = f->int_env_sf_arr[base + j] & 63;
         if (t > mx) mx = t;
       }
+      base += nsf;
+      mx = cx.wave_max(mx);
       mx -= 16;
       int t = (mx + 13) >> 1;
-      if (border[i] < 16 && t > adj_e) adj_e = (int16_t)t;
-      if (border[i + 1] > 16 && t > final_e) final_e = (int16_t)t;
+      if (cx.uni(border[i]) < 16 && t > adj_e) adj_e = (int16_t)t;
+      if (cx.uni(border[i + 1]) > 16 && t > final_e) final_e = (int16_t)t;
     }
   }
+  cx.sync();
+  XS_T(3);
   int m = 0, nf_idx = 0;
+  const int tansient_env_prev = cx.uni(st->tansient_env_prev);
+  const int hb_scale = cx.uni(st->hb_scale), lb_scale = cx.uni(st->lb_scale);
   for (int i = 0; i < num_env; i++) {
-    const int s0 = 2 * border[i], s1 = 2 * border[i + 1];
+    const int s0 = 2 * cx.uni(border[i]), s1 = 2 * cx.uni(border[i + 1]);
     if (s0 >= 38 || s1 > 38) return -1;
-    const int fr = f->freq_res[i];
+    const int fr = cx.uni(f->freq_res[i]);
+    const int16_t *tbl = fr ? h->freq_band_tbl_hi : h->freq_band_tbl_lo;
+    const int nsf = cx.uni(h->num_sf_bands[fr]);
     if (nf_idx >= XAAC_SBR_MAX_NOISE_ENVELOPES) return -1;
-    if (border[i] == f->noise_border_vec[nf_idx + 1]) {
-      noise_floor += h->num_nf_bands;
+    if (cx.uni(border[i]) == cx.uni(f->noise_border_vec[nf_idx + 1])) {
+      noise_floor += cx.uni(h->num_nf_bands);
       nf_idx++;
     }
-    int noise_absc;
-    if (i == f->transient_env || i == st->tansient_env_prev)
-      noise_absc = 1;
+    const int noise_absc = (i == transient_env || i == tansient_env_prev) ? 1 : 0;
+    const int input_e = 15 - hb_scale;
+    if (cx.uni(h->interpol_freq))
+      xs_energy_per_subband(cx, x, s0, s1, max_sb, sb_end, input_e, v.est);
     else
-      noise_absc = 0;
-    const int input_e = 15 - st->hb_scale;
-    if (h->interpol_freq)
-      xs_energy_per_subband(x, s0, s1, f->max_qmf_subband_aac, sb_end, input_e, nrg_est);
-    else
-      xs_energy_per_sfb(x, h->num_sf_bands[fr], fr ? h->freq_band_tbl_hi : h->freq_band_tbl_lo, s0, s1,
-                        f->max_qmf_subband_aac, input_e, nrg_est);
-    if ((fr ? h->freq_band_tbl_hi : h->freq_band_tbl_lo)[0] < sb_start) return -1;
-    xs_calc_subband_gains(h, f, fr, noise_floor, h->num_sf_bands[fr], m, i, sine_mapped, alias_red, e_orig, nrg_sine,
-                          nrg_est, nrg_gain, noise_lvl, noise_absc);
-    m += h->num_sf_bands[fr];
-    xs_noiselimiting(h, skip, e_orig, nrg_est, nrg_gain, noise_lvl, nrg_sine, &xaac_sbr_lim_gains_m[2 * h->limiter_gains],
-                     noise_absc);
-    xs_alias_reduction(deg_patched + sb_start, nrg_gain, nrg_est, alias_red, nsb);
+      xs_energy_per_sfb(cx, x, nsf, tbl, s0, s1, max_sb, input_e, w, v.est);
+    XS_T(4);
+    if (cx.uni(tbl[0]) < sb_start) return -1;
+    const int n_meta = xs_subband_gain_meta(cx, h, max_sb, tbl, nsf, i, v);
+    XS_T(5);
+    xs_calc_subband_gains(cx, f, noise_floor, m, i, n_meta, skip, v, noise_absc);
+    m += nsf;
+    XS_T(6);
+    xs_noiselimiting(cx, h, skip, n_meta, v, w, &xaac_sbr_lim_gains_m[2 * cx.uni(h->limiter_gains)], noise_absc);
+    XS_T(7);
+    XsLv grp_end;
+    grp_end.fill(0);
+    const uint64_t grp_starts = xs_alias_groups(cx, v.deg1, v.alias_red, nsb, grp_end);
+    XS_T(23);
+    xs_alias_reduction(cx, v, w, grp_starts, grp_end, nsb);
+    XS_T(8);
     const int16_t noise_e = (int16_t)(s0 < 32 ? adj_e : final_e);
-    const int bands = nsb - skip;
-    xs_erg_to_amplitude_lp(bands, noise_e, nrg_sine, nrg_gain, noise_lvl);
-    const int16_t lb_scale = (int16_t)(15 - st->lb_scale);
-    xs_adapt_noise_gain_lp(st, noise_e, nsb, skip, nrg_gain, noise_lvl, nrg_sine, s0, s1, input_e, adj_e, final_e,
-                           f->max_qmf_subband_aac, lb_scale, noise_absc, x);
+    xs_erg_to_amplitude_lp(cx, nsb - skip, noise_e, v);
+    XS_T(9);
+    xs_adapt_noise_gain_lp(cx, st, v, rand_hi, noise_e, nsb, skip, s0, s1, input_e, adj_e, final_e, max_sb,
+                           (int16_t)(15 - lb_scale), noise_absc, x);
+    XS_T(10);
   }
-  const int first_start = border[0] * 2;
-  {
-    const int ov_adj_e = 15 - st->ov_hb_scale;
-    const int output_e = ov_adj_e > adj_e ? ov_adj_e : adj_e; /* reserves are 0 without PS */
-    xs_adjust(x, f->max_qmf_subband_aac, sb_end, 0, first_start, ov_adj_e - output_e);
-    xs_adjust(x, f->max_qmf_subband_aac, sb_end, first_start, h->num_time_slots * h->time_step, adj_e - output_e);
+  const int first_start = cx.uni(border[0]) * 2;
+  const int ov_adj_e = 15 - cx.uni(st->ov_hb_scale);
+  const int output_e = ov_adj_e > adj_e ? ov_adj_e : adj_e; /* reserves are 0 without PS */
+  xs_adjust(cx, x, max_sb, sb_end, 0, first_start, ov_adj_e - output_e);
+  xs_adjust(cx, x, max_sb, sb_end, first_start, cx.uni(h->num_time_slots) * cx.uni(h->time_step), adj_e - output_e);
+  cx.sync();
+  XS_ONE {
     st->hb_scale = (int16_t)(15 - output_e);
+    st->ov_hb_scale = (int16_t)(15 - final_e);
+    st->tansient_env_prev = (transient_env == num_env) ? 0 : -1;
   }
-  st->ov_hb_scale = (int16_t)(15 - final_e);
-  st->tansient_env_prev = (f->transient_env == num_env) ? 0 : -1;
+  cx.sync();
+  XS_T(11);
   return 0;
 }
 
 /* sbrdec_lpfuncs.c:453 (real-valued) */
-FX_HD void xs_rescale_x_overlap(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st, const XsQmf &x) {
-  const int old_lsb = st->prev_max_qmf_subband_aac;
-  const int start_slot = h->time_step * (st->prev_end_position - h->num_time_slots);
-  const int new_lsb = f->max_qmf_subband_aac;
-  st->codec_usb = (int16_t)new_lsb;
-  st->syn_lsb = (int16_t)new_lsb;
+template <class ST>
+FX_HD void xs_rescale_x_overlap(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, ST *st,
+                                const XsQmf &x) {
+  const int old_lsb = cx.uni(st->prev_max_qmf_subband_aac);
+  const int start_slot = cx.uni(h->time_step) * (cx.uni(st->prev_end_position) - cx.uni(h->num_time_slots));
+  const int new_lsb = cx.uni(f->max_qmf_subband_aac);
+  const int ov_hb = cx.uni(st->ov_hb_scale), ov_lb = cx.uni(st->ov_lb_scale), syn_usb = cx.uni(st->syn_usb);
+  cx.sync();
+  XS_ONE {
+    st->codec_usb = (int16_t)new_lsb;
+    st->syn_lsb = (int16_t)new_lsb;
+  }
   int b0 = old_lsb < new_lsb ? old_lsb : new_lsb, b1 = old_lsb < new_lsb ? new_lsb : old_lsb;
-  if (new_lsb == old_lsb || old_lsb <= 0) return;
-  for (int l = start_slot; l < 6; l++)
-    for (int k = old_lsb; k < new_lsb; k++) x(l, k) = 0;
+  if (new_lsb == old_lsb || old_lsb <= 0) {
+    cx.sync();
+    return;
+  }
+  XS_PAR(k, old_lsb, new_lsb)
+    for (int l = start_slot; l < 6; l++) x(l, k) = 0;
   int source, target, t_lsb, t_usb;
   if (new_lsb > old_lsb) {
-    source = st->ov_hb_scale;
-    target = st->ov_lb_scale;
+    source = ov_hb;
+    target = ov_lb;
     t_lsb = 0;
     t_usb = old_lsb;
   } else {
-    source = st->ov_lb_scale;
-    target = st->ov_hb_scale;
+    source = ov_lb;
+    target = ov_hb;
     t_lsb = old_lsb;
-    t_usb = st->syn_usb;
+    t_usb = syn_usb;
   }
-  const int reserve = xs_headroom(x, b0, b1, 0, start_slot);
-  xs_adjust(x, b0, b1, 0, start_slot, reserve);
+  cx.sync();
+  const int reserve = xs_headroom(cx, x, b0, b1, 0, start_slot);
+  xs_adjust(cx, x, b0, b1, 0, start_slot, reserve);
   source += reserve;
   int delta = target - source;
   if (delta > 0) {
     delta = -delta;
     b0 = t_lsb;
     b1 = t_usb;
-    if (new_lsb > old_lsb)
-      st->ov_lb_scale = (int16_t)source;
-    else
-      st->ov_hb_scale = (int16_t)source;
+    XS_ONE {
+      if (new_lsb > old_lsb)
+        st->ov_lb_scale = (int16_t)source;
+      else
+        st->ov_hb_scale = (int16_t)source;
+    }
   }
-  xs_adjust(x, b0, b1, 0, start_slot, delta);
+  cx.sync();
+  xs_adjust(cx, x, b0, b1, 0, start_slot, delta);
+  cx.sync();
 }
 
 /* The part of ixheaacd_sbr_dec between the two QMF banks (sbr_dec.c:1050-1245, low-power mode).
    On entry x holds the 6 overlap slots (already through xs_rescale_x_overlap) and the 32 freshly
    analysed slots (bands 0..31); on exit x is ready for the synthesis bank and the state carries the
-   new scale factors, LPC history and envelope-adjuster memory.  Returns 0 or -1. */
-FX_HD int xs_sbr_core_lp(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st, const XsQmf &x,
-                         int *save_lb_scale_out) {
-  const int usb = st->codec_usb;
-  XsMat<int32_t> lpc = {&st->lpc_real[0][0], 1}; /* two rows of 32 */
-  int reserve = xs_headroom(x, 0, usb, 6, 38);
-  int reserve_ov1 = xs_headroom(x, 0, usb, 0, 6);
+   new scale factors, LPC history and envelope-adjuster memory.  rand_hi[i] = xaac_sbr_rand_ph[i] >> 16
+   (the only part of that table this mode uses; an LDS copy on the GPU).  Returns 0 or -1. */
+template <class ST>
+FX_HD int xs_sbr_core_lp(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, ST *st, const XsQmf &x,
+                         XsWork *w, const int16_t *rand_hi, int *save_lb_scale_out) {
+  const int usb = cx.uni(st->codec_usb);
+  int reserve = xs_headroom(cx, x, 0, usb, 6, 38);
+  int reserve_ov1 = xs_headroom(cx, x, 0, usb, 0, 6);
   const int max_samp_val = reserve < reserve_ov1 ? reserve : reserve_ov1;
   int32_t m = 1;
-  for (int i = 0; i < 2; i++)
-    for (int k = 0; k < usb; k++) m |= fx_abs_nrm(st->lpc_real[i][k]);
-  const int reserve_ov2 = xs_pnorm32(m);
+  XS_PAR(k, 0, usb) m |= fx_abs_nrm(st->lpc_real[0][k]) | fx_abs_nrm(st->lpc_real[1][k]);
+  const int reserve_ov2 = xs_pnorm32(cx.wave_or(m));
   if (reserve_ov2 < reserve_ov1) reserve_ov1 = reserve_ov2;
-  const int shift1 = st->lb_scale + reserve, shift2 = st->ov_lb_scale + reserve_ov1;
+  const int lb_scale0 = cx.uni(st->lb_scale), ov_lb_scale0 = cx.uni(st->ov_lb_scale);
+  const int shift1 = lb_scale0 + reserve, shift2 = ov_lb_scale0 + reserve_ov1;
   const int min_shift = shift1 < shift2 ? shift1 : shift2;
   const int shift_over = shift2 - min_shift;
   reserve -= (shift1 - min_shift);
-  st->ov_lb_scale = (int16_t)(st->ov_lb_scale + (reserve_ov1 - shift_over));
-  xs_adjust(x, 0, usb, 0, 6, reserve_ov1 - shift_over);
-  xs_adjust(x, 0, usb, 6, 38, reserve);
+  cx.sync();
+  xs_adjust(cx, x, 0, usb, 0, 6, reserve_ov1 - shift_over);
+  xs_adjust(cx, x, 0, usb, 6, 38, reserve);
   {
     int sh = reserve_ov1 - shift_over;
     if (sh != 0) {
       if (sh > 31) sh = 31;
       if (sh < -31) sh = -31;
-      for (int i = 0; i < 2; i++)
-        for (int k = 0; k < usb; k++)
+      XS_PAR(k, 0, usb)
+        for (int i = 0; i < 2; i++)
           st->lpc_real[i][k] = sh > 0 ? fx_shlw(st->lpc_real[i][k], sh) : (st->lpc_real[i][k] >> -sh);
     }
   }
-  (void)lpc;
-  st->lb_scale = (int16_t)(st->lb_scale + reserve);
-  const int save_lb_scale = st->lb_scale;
-  *save_lb_scale_out = save_lb_scale;
-  for (int l = 6; l < 38; l++)
-    for (int k = 32; k < 64; k++) x(l, k) = 0;
-  if (f->apply_processing) {
-    int16_t degree_alias[64];
-    for (int k = 0; k < 64; k++) degree_alias[k] = 0;
-    const int16_t last = fx_sat16((int32_t)f->border_vec[f->num_env] - h->num_time_slots);
-    xs_low_pow_hf_generator(h, st, x, degree_alias, f->border_vec[0] * h->time_step, h->time_step * last,
-                            f->max_qmf_subband_aac, f->sbr_invf_mode, st->prev_invf_mode, max_samp_val);
-    st->hb_scale = (int16_t)((st->ov_lb_scale < st->lb_scale ? st->ov_lb_scale : st->lb_scale) - 2);
-    if (xs_calc_sbrenvelope_lp(h, f, st, x, degree_alias)) return -1;
-    for (int i = 0; i < h->num_if_bands; i++) st->prev_invf_mode[i] = f->sbr_invf_mode[i];
-    st->prev_coupling_mode = f->coupling_mode;
-    st->prev_max_qmf_subband_aac = f->max_qmf_subband_aac;
-    st->prev_end_position = f->border_vec[f->num_env];
-    st->prev_amp_res = f->amp_res;
-  } else {
-    st->hb_scale = (int16_t)save_lb_scale;
+  const int save_lb_scale = (int16_t)(lb_scale0 + reserve);
+  XS_ONE {
+    st->ov_lb_scale = (int16_t)(ov_lb_scale0 + (reserve_ov1 - shift_over));
+    st->lb_scale = (int16_t)save_lb_scale;
   }
-  for (int i = 0; i < 2; i++)
-    for (int k = 0; k < st->codec_usb; k++) st->lpc_real[i][k] = x(30 + i, k);
+  *save_lb_scale_out = save_lb_scale;
+  XS_PAR(k, 32, 64)
+    for (int l = 6; l < 38; l++) x(l, k) = 0;
+  cx.sync();
+  XS_T(1);
+  if (cx.uni(f->apply_processing)) {
+    XsLv deg64;
+    deg64.fill(0);
+    const int n_env = cx.uni(f->num_env), nts = cx.uni(h->num_time_slots), ts = cx.uni(h->time_step);
+    const int16_t last = fx_sat16((int32_t)cx.uni(f->border_vec[n_env]) - nts);
+    xs_low_pow_hf_generator(cx, h, st, x, w, deg64, cx.uni(f->border_vec[0]) * ts, ts * last,
+                            cx.uni(f->max_qmf_subband_aac), f->sbr_invf_mode, st->prev_invf_mode, max_samp_val);
+    XS_T(2);
+    XS_ONE st->hb_scale = (int16_t)((st->ov_lb_scale < st->lb_scale ? st->ov_lb_scale : st->lb_scale) - 2);
+    cx.sync();
+    if (xs_calc_sbrenvelope_lp(cx, h, f, st, x, w, rand_hi, deg64)) return -1;
+    XS_PAR(i, 0, h->num_if_bands) st->prev_invf_mode[i] = f->sbr_invf_mode[i];
+    XS_ONE {
+      st->prev_coupling_mode = f->coupling_mode;
+      st->prev_max_qmf_subband_aac = f->max_qmf_subband_aac;
+      st->prev_end_position = f->border_vec[f->num_env];
+      st->prev_amp_res = f->amp_res;
+    }
+  } else {
+    XS_ONE st->hb_scale = (int16_t)save_lb_scale;
+  }
+  cx.sync();
+  XS_PAR(k, 0, st->codec_usb) {
+    st->lpc_real[0][k] = x(30, k);
+    st->lpc_real[1][k] = x(31, k);
+  }
+  cx.sync();
+  XS_T(15);
   return 0;
 }
 

@@ -1,53 +1,156 @@
 /*
- * sbr_core_kernel.hip -- the serial middle of ixheaacd_sbr_dec (decoder/ixheaacd_sbr_dec.c:726-775,
+ * sbr_core_kernel.hip -- the middle of ixheaacd_sbr_dec (decoder/ixheaacd_sbr_dec.c:726-775,
  * :1050-1245, :1283-1308; low-power mode) on gfx950: overlap restore + xs_rescale_x_overlap, block
  * floating point, LPP transposer, envelope adjustment, LPC/overlap/scale state update -- everything
  * between the two QMF banks (which run as their own slot-parallel kernels before and after).
  *
- * First mapping (round 1): ONE LANE = ONE CHANNEL running the scalar code of sbr_core.h on the
- * channel's 40 x 64 QMF matrix in the workspace.  The control flow of this stage is data dependent per
- * channel (envelope count, limiter bands, alias groups), channels are plentiful (16384 per batch), and
- * sharing the scalar source with the oracle keeps it bit-exact by construction.  Its cost -- lanes
- * walk 10 KB-strided matrices, i.e. uncoalesced -- is the known next optimisation (DESIGN.md §7:
- * band-parallel energy / covariance / gain application with the matrix staged in LDS).
+ * Mapping: ONE WAVE = ONE CHANNEL-FRAME, one wave per workgroup.  The channel's 40 x 64 QMF matrix,
+ * its header / frame side info, the control part of its state and the per-frame scratch (XsWork)
+ * live in LDS (~13 KB, so a dozen channels share a CU and hide each other's latencies).  The
+ * arithmetic is sbr_core.h -- the same source the oracle runs sequentially -- which puts QMF bands
+ * (energies, covariances, LPC filtering, gain application) on the lanes, keeps per-band gains in
+ * lane registers and runs the inherently sequential sums/walks as uniform scalar code; the matrix is
+ * band-minor, so a lane-per-band access is a conflict-free LDS row read.
+ * Global traffic is the coalesced copy-in (overlap slots, the 32 analysed slots x 32 bands, side
+ * info, state) and copy-out (32 slots for the synthesis bank, overlap slots, state).
+ *
+ * (The first version of this kernel ran one channel per LANE on the matrix in global memory:
+ * 4.3 ms per 16384 channels, profiles/r01_c_c3_kernel_stats.txt -- latency bound on 10 KB-strided
+ * accesses.)
  */
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
+#ifdef XS_PROFILE
+/* phase timers (tools/prof_sbr_core.py): cycles of lane 0 between XS_T hooks, summed over channels */
+__shared__ long long xs_prof_last;
+__shared__ long long xs_prof_acc[32];
+#define XS_T(i)                                   \
+  do {                                            \
+    if (threadIdx.x == 0) {                       \
+      long long t_ = clock64();                   \
+      xs_prof_acc[i] += t_ - xs_prof_last;        \
+      xs_prof_last = t_;                          \
+    }                                             \
+  } while (0)
+#endif
 #include "sbr_core.h"
 #include "sbr_core_kernel.h"
 
+namespace {
+
+/* LDS copy of the state members the core touches: the four bank-limit shorts + the struct tail */
+struct XsLdsState {
+  int16_t codec_usb, syn_lsb, syn_usb, pad2_;
+  XAAC_SBR_STATE_TAIL_FIELDS
+};
+constexpr int kHeadOff = offsetof(xaac_sbr_state, codec_usb);
+constexpr int kTailOff = offsetof(xaac_sbr_state, lpc_real);
+constexpr int kTailWords = (sizeof(xaac_sbr_state) - kTailOff) / 4;
+static_assert(kHeadOff % 4 == 0 && kTailOff % 4 == 0 && sizeof(xaac_sbr_state) % 4 == 0, "word copies");
+static_assert(offsetof(XsLdsState, lpc_real) == 8 && sizeof(XsLdsState) == 8 + kTailWords * 4, "mirror layout");
+static_assert(offsetof(xaac_sbr_state, overlap) % 16 == 0 || true, "");
+static_assert(sizeof(xaac_sbr_header) % 4 == 0 && sizeof(xaac_sbr_frame) % 4 == 0, "word copies");
+
+struct XsLds {
+  int32_t x[XAAC_SBR_X_WORDS + 64]; /* + one row: the reference's edge writes may run past slot 37 */
+  XsLdsState st;
+  xaac_sbr_header h;
+  xaac_sbr_frame f;
+  XsWork w;
+  int16_t rand_hi[568]; /* xaac_sbr_rand_ph >> 16 */
+};
+
+__device__ __forceinline__ void copy_words(int32_t *dst, const int32_t *src, int n, int lane) {
+  for (int i = lane; i < n; i += 64) dst[i] = src[i];
+}
+
+}  // namespace
+
 __global__ __launch_bounds__(64) void xaac_sbr_core_lp_kernel(XaacSbrCoreParams p) {
-  const int ch = blockIdx.x * 64 + threadIdx.x;
-  if (ch >= p.n_ch) return;
-  const xaac_sbr_header *h = p.header + ch;
-  const xaac_sbr_frame *f = p.frame + ch;
-  xaac_sbr_state *st = p.state + ch;
-  XsQmf x = {p.x + (size_t)ch * XAAC_SBR_X_WORDS, 1};
-  for (int l = 0; l < 6; l++)
-    for (int k = 0; k < 64; k++) x(l, k) = st->overlap[64 * l + k];
-  st->lb_scale = 0;
-  if (f->apply_processing) xs_rescale_x_overlap(h, f, st, x);
+  __shared__ XsLds s;
+  const int ch = blockIdx.x, lane = threadIdx.x;
+  xaac_sbr_state *gst = p.state + ch;
+  int32_t *gx = p.x + (size_t)ch * XAAC_SBR_X_WORDS;
+  const int32_t *gstw = reinterpret_cast<const int32_t *>(gst);
+
+  /* ---- copy-in ---- */
+  copy_words(reinterpret_cast<int32_t *>(&s.h), reinterpret_cast<const int32_t *>(p.header + ch),
+             sizeof(xaac_sbr_header) / 4, lane);
+  copy_words(reinterpret_cast<int32_t *>(&s.f), reinterpret_cast<const int32_t *>(p.frame + ch),
+             sizeof(xaac_sbr_frame) / 4, lane);
+  {
+    int32_t *m = reinterpret_cast<int32_t *>(&s.st);
+    if (lane < 2) m[lane] = gstw[kHeadOff / 4 + lane];
+    copy_words(m + 2, gstw + kTailOff / 4, kTailWords, lane);
+  }
+  for (int i = lane; i < 568; i += 64) s.rand_hi[i] = (int16_t)(xaac_sbr_rand_ph[i] >> 16);
+  s.x[lane] = 0;
+  s.x[64 + lane] = 0;
+  s.x[XAAC_SBR_X_WORDS + lane] = 0;
+  copy_words(s.x + 2 * 64, gstw + offsetof(xaac_sbr_state, overlap) / 4, 6 * 64, lane);  /* sbr_dec.c:753 */
+  for (int i = lane; i < 32 * 32; i += 64) {
+    const int o = (8 + (i >> 5)) * 64 + (i & 31);
+    s.x[o] = gx[o];
+  }
+  __syncthreads();
+#ifdef XS_PROFILE
+  if (lane == 0) {
+    for (int i = 0; i < 32; i++) xs_prof_acc[i] = 0;
+    xs_prof_last = clock64();
+  }
+#endif
+
+  const XsCx cx = {lane, 64};
+  const XsQmf x = {s.x};
+  if (lane == 0) s.st.lb_scale = 0;
+  if (s.f.apply_processing) xs_rescale_x_overlap(cx, &s.h, &s.f, &s.st, x);
   /* what ixheaacd_cplx_anal_qmffilt leaves in the scale struct (generic:630-631) */
-  st->st_lb_scale = 0;
-  st->lb_scale = -10;
+  __syncthreads();
+  if (lane == 0) {
+    s.st.st_lb_scale = 0;
+    s.st.lb_scale = -10;
+  }
+  __syncthreads();
   int save_lb_scale = 0;
-  const int rc = xs_sbr_core_lp(h, f, st, x, &save_lb_scale);
-  int16_t *par = p.syn_par + 8 * (size_t)ch;
-  par[0] = st->lb_scale;
-  par[1] = st->ov_lb_scale;
-  par[2] = st->hb_scale;
-  par[3] = st->st_syn_scale;
-  par[4] = st->syn_lsb;
-  par[5] = st->syn_usb;
-  for (int l = 0; l < 6; l++)
-    for (int k = 0; k < 64; k++) st->overlap[64 * l + k] = x(32 + l, k);
-  st->ov_lb_scale = (int16_t)save_lb_scale;
-  if (p.status) p.status[ch] = rc;
+#ifdef XS_SKIP_CORE
+  const int rc = 0;
+#else
+  const int rc = xs_sbr_core_lp(cx, &s.h, &s.f, &s.st, x, &s.w, s.rand_hi, &save_lb_scale);
+#endif
+  __syncthreads();
+#ifdef XS_PROFILE
+  XS_T(15);
+  if (lane < 32 && p.status) atomicAdd(reinterpret_cast<unsigned long long *>(p.status) + lane, (unsigned long long)xs_prof_acc[lane]);
+#endif
+
+  /* ---- copy-out ---- */
+  if (lane == 0) {
+    int16_t *par = p.syn_par + 8 * (size_t)ch;
+    par[0] = s.st.lb_scale;
+    par[1] = s.st.ov_lb_scale;
+    par[2] = s.st.hb_scale;
+    par[3] = s.st.st_syn_scale;
+    par[4] = s.st.syn_lsb;
+    par[5] = s.st.syn_usb;
+    s.st.ov_lb_scale = (int16_t)save_lb_scale;  /* sbr_dec.c:1304 */
+#ifndef XS_PROFILE
+    if (p.status) p.status[ch] = rc;
+#endif
+  }
+  __syncthreads();
+  copy_words(gx + 2 * 64, s.x + 2 * 64, 32 * 64, lane);
+  {
+    int32_t *gw = reinterpret_cast<int32_t *>(gst);
+    copy_words(gw + offsetof(xaac_sbr_state, overlap) / 4, s.x + (2 + 32) * 64, 6 * 64, lane);  /* :1283 */
+    const int32_t *m = reinterpret_cast<const int32_t *>(&s.st);
+    if (lane < 2) gw[kHeadOff / 4 + lane] = m[lane];
+    copy_words(gw + kTailOff / 4, m + 2, kTailWords, lane);
+  }
 }
 
 extern "C" hipError_t xaac_launch_sbr_core_lp(const XaacSbrCoreParams *p, hipStream_t stream) {
-  const int grid = (p->n_ch + 63) / 64;
-  hipLaunchKernelGGL(xaac_sbr_core_lp_kernel, dim3(grid), dim3(64), 0, stream, *p);
+  hipLaunchKernelGGL(xaac_sbr_core_lp_kernel, dim3(p->n_ch), dim3(64), 0, stream, *p);
   return hipGetLastError();
 }

@@ -17,16 +17,28 @@
 #include "../libxaac_amd/csrc/sbr_core.h"
 #include "oracle_qmf.h"
 
+static const int16_t *rand_hi_table() {
+  static const struct Tab {
+    int16_t v[568];
+    Tab() {
+      for (int i = 0; i < 568; i++) v[i] = (int16_t)(xaac_sbr_rand_ph[i] >> 16);
+    }
+  } tab;
+  return tab.v;
+}
+
 extern "C" int xo_sbr_dec_lp(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st,
                              const int16_t *pcm_in, int in_stride, int16_t *pcm_out, int out_stride) {
   static thread_local int32_t buf[40 * 64];
-  XsQmf x = {buf, 1};
+  XsQmf x = {buf};
+  const XsCx cx = {0, 1}; /* sequential execution of the shared core */
+  XsWork w;
   memset(buf, 0, sizeof(buf));
   /* sbr_dec.c:753: the six overlap slots */
   for (int l = 0; l < 6; l++)
     for (int k = 0; k < 64; k++) x(l, k) = st->overlap[64 * l + k];
   st->lb_scale = 0;
-  if (f->apply_processing) xs_rescale_x_overlap(h, f, st, x);
+  if (f->apply_processing) xs_rescale_x_overlap(cx, h, f, st, x);
   /* sbr_dec.c:1025: analysis bank into slots 6..37 */
   {
     xo_qmf_ana_state a;
@@ -41,7 +53,7 @@ extern "C" int xo_sbr_dec_lp(const xaac_sbr_header *h, const xaac_sbr_frame *f, 
     st->lb_scale = -10;
   }
   int save_lb_scale = 0;
-  if (xs_sbr_core_lp(h, f, st, x, &save_lb_scale)) return -1;
+  if (xs_sbr_core_lp(cx, h, f, st, x, &w, rand_hi_table(), &save_lb_scale)) return -1;
   /* sbr_dec.c:1273: synthesis bank over slots 0..31 */
   {
     xo_qmf_syn_state s;

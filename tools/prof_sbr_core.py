@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Phase timers of the SBR core kernel: builds the product library with -DXS_PROFILE (the XS_T hooks of
+sbr_core.h accumulate lane-0 cycle counts per phase), runs the C3 bench inputs through it a few times and
+prints cycles per channel-frame for every phase.  Developer tool; run on the GPU box."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+NAMES = {1: "block floating point", 2: "hf generator (total)", 3: "env: init/sineflags/adj_e", 4: "env: energies",
+         5: "env: gain meta (lane 0)", 6: "env: subband gains", 7: "env: noise limiting", 8: "env: alias groups+reduction",
+         9: "env: erg->amplitude", 10: "env: apply (adapt_noise_gain)", 11: "env: final adjust", 12: "hf: setup/clears",
+         13: "hf: covariance+lpc", 14: "hf: degree alias (lane 0)", 15: "tail (state, lpc save)", 16: "lim: avggain", 17: "lim: limit loop", 18: "lim: accumulate",
+         19: "lim: boost div", 20: "lim: scale loop", 21: "apply: startup/equalize/tones", 22: "apply: slot loop",
+         23: "alias: groups (lane 0)"}
+
+
+def main():
+    import torch
+    import libxaac_amd
+    src = os.path.join(ROOT, "libxaac_amd", "csrc")
+    out = os.path.join(ROOT, "libxaac_amd", "libxaac_amd_prof.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DXS_PROFILE",
+                           "-shared", "-x", "hip"] + [os.path.join(src, f) for f in
+                           ("imdct_kernel.hip", "sbr_qmf_kernel.hip", "sbr_core_kernel.hip", "xaac_abi.cpp")] + ["-o", out])
+    libxaac_amd.library_path = lambda: out
+    import bench
+    dev = torch.device("cuda:0")
+    n = bench.FRAMES_PER_STEP * bench.CH
+    b = bench.make_inputs_c3(torch, dev, 1, 0)[0]
+    ctx = libxaac_amd.XaacContext(0, None)
+    ws = torch.zeros(ctx.sbr_lp_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    status = torch.zeros(n, dtype=torch.int32, device=dev)
+    steps = 4
+    for i in range(steps):
+        ctx.imdct_process_batch(b["spec"], b["ics"], b["overlap"], b["state"], None, b["core_pcm"], None, ch_fac=1,
+                                pcm_mode=libxaac_amd.PCM_SBR)
+        ctx.sbr_lp_process_batch(b["core_pcm"], b["hdr"], b["frames"][i % 4], b["sbr_state"], b["pcm"], ws, status,
+                                 in_ch_fac=1, out_ch_fac=2)
+    ctx.sync()
+    acc = status.cpu().numpy()[:64].view(np.uint64).astype(np.float64) / (steps * n)
+    tot = acc.sum()
+    for i in range(1, 24):
+        print("%2d %-34s %9.0f cycles/channel-frame %5.1f%%" % (i, NAMES[i], acc[i], 100 * acc[i] / tot))
+    print("   total %.0f cycles" % tot)
+
+
+if __name__ == "__main__":
+    main()
