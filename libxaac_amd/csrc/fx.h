@@ -77,9 +77,8 @@ FX_HD int32_t fx_shl(int32_t a, int b) {
 }
 /* basic_ops32.h:51-65: arithmetic, count mod 256, >=31 gives the sign */
 FX_HD int32_t fx_shr(int32_t a, int b) {
-  b &= 0xff;
-  if (b >= 31) return a < 0 ? -1 : 0;
-  return a >> b;
+  b &= 0xff; /* counts of 31 and more leave the sign, which is what a shift by 31 leaves */
+  return a >> (b < 31 ? b : 31);
 }
 /* basic_ops32.h:67-78 (0 <= b <= 31 on every path that reaches it) */
 FX_HD int32_t fx_shl_sat(int32_t a, int b) {

@@ -126,15 +126,14 @@ FX_HD int32_t xs_fix_div(int32_t op1, int32_t op2) {
   return ((op1 ^ op2) < 0) ? -q : q;
 }
 
-/* accumulate (m, e) into a running (am, ae) pseudo-float sum: the recurring idiom of env_calc.c */
+/* accumulate (m, e) into a running (am, ae) pseudo-float sum: the recurring idiom of env_calc.c
+   (if e >= ae the sum is shifted down to the new exponent, else the addend is).  Written without the
+   branch: shifting by 0 is the identity. */
 FX_HD void xs_acc_me(int32_t *am, int32_t *ae, int32_t m, int32_t e) {
-  int32_t d = e - *ae;
-  if (d >= 0) {
-    *am = m + fx_shr(*am, d);
-    *ae = e;
-  } else {
-    *am = fx_shr(m, -d) + *am;
-  }
+  const int32_t d = e - *ae;
+  const int32_t up = d > 0 ? d : 0, down = d < 0 ? -d : 0;
+  *am = fx_shr(m, down) + fx_shr(*am, up);
+  *ae = d >= 0 ? e : *ae;
 }
 
 /* ---- execution context ------------------------------------------------------------------------------
@@ -403,34 +402,47 @@ FX_HD void xs_lpc_coeffs_lp(const XsCov *c, int16_t *alpha0_out, int16_t *alpha1
   *k1_out = k1;
 }
 
-/* lpp_tran.c:665, aliasing degrees: a recurrence over the low bands (sequential, uniform) */
-FX_HD void xs_degree_alias_lp(const XsLv &k1v, XsLv &deg, int start_patch, int stop_patch) {
-  int16_t k1_below = 0, k1_below2 = 0;
-  for (int lb = start_patch; lb < stop_patch; lb++) {
-    const int16_t k1 = (int16_t)k1v.get(lb);
-    if (lb > 1) {
-      const int16_t dg = fx_sat16(0x7fff - (int32_t)xs_mult16_shl_sat(k1_below, k1_below));
-      int32_t here = 0;
-      if (((lb & 1) == 0) && (k1 < 0)) {
-        if (k1_below < 0) {
-          here = 0x7fff;
-          if (k1_below2 > 0) deg.put(lb - 1, dg);
-        } else if (k1_below2 > 0) {
-          here = dg;
-        }
-      }
-      if (((lb & 1) != 0) && (k1 > 0)) {
-        if (k1_below > 0) {
-          here = 0x7fff;
-          if (k1_below2 < 0) deg.put(lb - 1, dg);
-        } else if (k1_below2 < 0) {
-          here = dg;
-        }
-      }
-      deg.put(lb, here);
+/* lpp_tran.c:665, aliasing degrees.  The reference's loop over the low bands carries the reflection
+   coefficients of the two bands below along and, at band L, writes deg[L] and sometimes overwrites
+   deg[L-1].  Spelled out, the step at L only reads k1[L], k1[L-1], k1[L-2] (0 below start_patch), so
+   band lb's final value is what step lb+1 wrote over it, else what step lb wrote: one band per lane. */
+FX_HD void xs_degree_step(int L, int16_t a, int16_t b, int16_t c, int32_t *here, int32_t *below, int *below_set) {
+  const int16_t dg = fx_sat16(0x7fff - (int32_t)xs_mult16_shl_sat(b, b));
+  *here = 0;
+  *below_set = 0;
+  *below = dg;
+  if (((L & 1) == 0) && (a < 0)) {
+    if (b < 0) {
+      *here = 0x7fff;
+      if (c > 0) *below_set = 1;
+    } else if (c > 0) {
+      *here = dg;
     }
-    k1_below2 = k1_below;
-    k1_below = k1;
+  }
+  if (((L & 1) != 0) && (a > 0)) {
+    if (b > 0) {
+      *here = 0x7fff;
+      if (c < 0) *below_set = 1;
+    } else if (c < 0) {
+      *here = dg;
+    }
+  }
+}
+FX_HD void xs_degree_alias_lp(const XsCx &cx, const XsLv &k1v, XsLv &deg, int start_patch, int stop_patch) {
+  const XsLv km1 = k1v.shifted(cx, -1), km2 = k1v.shifted(cx, -2), kp1 = k1v.shifted(cx, 1);
+  XS_LANES(lb, 0, stop_patch) {
+    /* k1v is 0 outside [start_patch, stop_patch), which is what the reference's initial values are */
+    int32_t here = 0, below = 0, h2 = 0;
+    int set = 0, dummy = 0;
+    if (lb >= start_patch && lb > 1) {
+      xs_degree_step(lb, (int16_t)k1v.own(lb), (int16_t)km1.own(lb), (int16_t)km2.own(lb), &here, &h2, &dummy);
+      deg.own(lb) = here;
+    }
+    const int L = lb + 1;
+    if (L >= start_patch && L < stop_patch && L > 1) {
+      xs_degree_step(L, (int16_t)kp1.own(lb), (int16_t)k1v.own(lb), (int16_t)km1.own(lb), &h2, &below, &set);
+      if (set) deg.own(lb) = below;
+    }
   }
 }
 
@@ -513,7 +525,7 @@ FX_HD void xs_low_pow_hf_generator(const XsCx &cx, const xaac_sbr_header *h, ST 
     k1v.own(k) = k1;
   }
   XS_T(13);
-  xs_degree_alias_lp(k1v, deg, start_patch, stop_patch);
+  xs_degree_alias_lp(cx, k1v, deg, start_patch, stop_patch);
   XS_T(14);
   XS_LANES(lb, start_patch, stop_patch)
     xs_patch_band_lp(h, x, lb, xs_m(alpha.own(lb)), xs_e(alpha.own(lb)), w->bw_array, start_idx, stop_idx,
@@ -555,9 +567,14 @@ FX_HD void xs_map_sineflags(const XsCx &cx, const int16_t *tbl_hi, int nsf, cons
     if (add_harm[i]) q.own(i) = ((tbl_hi[i + 1] + tbl_hi[i]) - low2) >> 1;
     val.own(i) = old ? 0 : (int8_t)tr_env;
   }
-  for (int i = nsf - 1; i >= 0; i--) {
-    const int qq = q.get(i);
-    if (qq >= 0) sine_mapped.put(qq, val.get(i));
+  XsLv has;
+  has.fill(0);
+  XS_LANES(i, 0, nsf) has.own(i) = q.own(i) >= 0;
+  uint64_t todo = xs_ballot(cx, has, 1, nsf);
+  while (todo) { /* descending sfb order, as the reference stores them */
+    const int i = 63 - xs_clz64(todo);
+    todo &= ~((uint64_t)1 << i);
+    sine_mapped.put(q.get(i), val.get(i));
   }
 }
 
@@ -1087,97 +1104,21 @@ FX_HD int16_t xs_noise_rescale(int16_t v, int diff) {
 
 #define XS_FACTOR ((int32_t)(0x010b0000 * 2))
 
-/* The per-band constants of one envelope that the slot loop needs (registers) */
-struct XsBandAmp {
-  int16_t gm, ge;          /* gain */
-  int16_t sl, sl_prev, sl_next; /* sine level of this band and of its neighbours */
-  int16_t nl;              /* noise level */
-  int16_t tone_count;      /* bands 0..k carrying a sine */
-};
-
-/* env_calc.c:1564: one slot, harmonic index 0 / 2, band k of the adjusted range */
-FX_HD void xs_harm_zerotwo_lp(const XsQmf &x, int slot, int b0, int k, const XsBandAmp &a, int scale_change,
-                              int16_t rand_ph, int noise_absc, int harm_index) {
-  scale_change -= 1;
-  int32_t v = fx_mul32x16(x(slot, b0 + k), a.gm);
-  int shift = a.ge - scale_change;
-  v = shift > 0 ? xs_shl(v, shift) : xs_sar(v, -shift);
-  int32_t sl = xs_shl(a.sl, 16);
-  if (!noise_absc && sl == 0)
-    v = xs_mac16x16_shl_sat(v, rand_ph, a.nl);
-  else if (harm_index == 0)
-    v = fx_add_sat(v, sl);
-  else
-    v = fx_sub_sat(v, sl);
-  x(slot, b0 + k) = v;
-}
-
-/* env_calc.c:1617: one slot, harmonic index 1 / 3, band k of nsb.  The reference walks the bands
-   carrying three things along: the sine levels of the neighbours, a sign that alternates from band 1
-   on (freq_inv * (-1)^(k-1)), and the number of bands with a sine seen so far.  With those spelled
-   out every band is independent; band 0 also touches b0-1 and the last band b0+nsb, which no other
-   band writes. */
-FX_HD void xs_harm_onethree_lp(const XsQmf &x, int slot, int b0, int k, const XsBandAmp &a, int scale_change,
-                               int16_t rand_ph, int nsb, int noise_absc, int freq_inv, int noise_e, int sb_start) {
-  const int nm1 = nsb - 1;
-  scale_change -= 1;
-  int32_t v = fx_mul32x16(x(slot, b0 + k), a.gm);
-  const int shift = a.ge - scale_change;
-  const int16_t sl = a.sl;
-  if (k == 0) {
-    v = shift > 0 ? xs_shl(v, shift) : xs_sar(v, -shift);
-    const int16_t sl_next = nsb > 1 ? a.sl_next : (int16_t)0;
-    if (sl == 0 && !noise_absc) v = xs_mac16x16_shl_sat(v, rand_ph, a.nl);
-    int32_t tm2 = fx_mul32x16(XS_FACTOR, sl_next);
-    int32_t tm = fx_mul32x16(XS_FACTOR, sl);
-    int16_t ne = (int16_t)noise_e;
-    tm = ne > 0 ? fx_shl(tm, ne) : fx_shr(tm, -ne);
-    if (freq_inv < 0) {
-      x(slot, b0 - 1) = fx_add_sat(x(slot, b0 - 1), tm);
-      v = fx_sub_sat(v, tm2);
-    } else {
-      x(slot, b0 - 1) = fx_sub_sat(x(slot, b0 - 1), tm);
-      v = fx_add_sat(v, tm2);
-    }
-    x(slot, b0) = v;
-  } else if (k < nm1) {
-    v = shift >= 0 ? xs_shl(v, shift) : xs_sar(v, -shift);
-    if (!noise_absc && sl == 0) v = xs_mac16x16_shl_sat(v, rand_ph, a.nl);
-    if (a.tone_count <= 16) {
-      int32_t add = fx_mul32x16(XS_FACTOR, (int16_t)(a.sl_prev - a.sl_next));
-      const int fi = (k & 1) ? freq_inv : -freq_inv;
-      v = fx_add_sat(v, (int32_t)((uint32_t)add * (uint32_t)fi));
-    }
-    x(slot, b0 + k) = v;
-  } else { /* k == nm1 > 0 */
-    v = shift > 0 ? xs_shl(v, shift) : xs_sar(v, -shift);
-    /* the sign after bands 1..nm1-1 have each flipped it, mapped to {0,1} */
-    const int fi = ((((nm1 & 1) ? freq_inv : -freq_inv)) + 1) >> 1;
-    int32_t tms = fx_mul32x16(XS_FACTOR, a.sl_prev);
-    if (sl == 0 && !noise_absc) v = xs_mac16x16_shl_sat(v, rand_ph, a.nl);
-    if (a.tone_count <= 16) {
-      int32_t tm2 = fx_mul32x16(XS_FACTOR, sl);
-      if (fi) {
-        x(slot, b0 + k) = fx_add_sat(v, tms);
-        if (k + sb_start < 62) x(slot, b0 + k + 1) = fx_sub_sat(x(slot, b0 + k + 1), tm2);
-      } else {
-        x(slot, b0 + k) = fx_sub_sat(v, tms);
-        if (k + sb_start < 62) x(slot, b0 + k + 1) = fx_add_sat(x(slot, b0 + k + 1), tm2);
-      }
-    } else {
-      x(slot, b0 + k) = v;
-    }
-  }
-}
-
-/* env_calc.c:479, low-power branch: apply gains / noise / sines to slots [s0,s1).  The reference
-   loops slots outside, bands inside; a band only ever touches its own column of x (plus the two edge
-   columns noted above) and its own gain / noise / sine / filter-buffer entries, so the loops are
-   interchanged: each lane keeps its band's constants in registers and walks the slots. */
+/* env_calc.c:479 with :1564 (harmonic index 0 / 2) and :1617 (1 / 3), low-power branch: apply gains,
+   noise and sines to slots [s0,s1).
+   The reference loops slots outside, bands inside.  A band only ever touches its own column of x
+   and its own gain / noise / sine / filter-buffer entries -- except that in the odd-index slots band 0
+   also adds a sine tail to column b0-1 and the last band to column b0+nsb, which no band owns -- so
+   the loops are interchanged: each lane keeps its band's constants in registers and walks the slots.
+   The odd-index code of the reference walks the bands carrying along the neighbours' sine levels, a
+   sign that alternates from band 1 on (freq_inv * (-1)^(k-1)) and the number of sines seen so far;
+   spelled out per band, what is added to the gained sample is a per-envelope constant `term1` (its
+   negative when the harmonic index is 3).  Shifts by 0 are the identity in both directions, which
+   is why the reference's "> 0" / ">= 0" variants need no distinction. */
 template <class ST>
-FX_HD void xs_adapt_noise_gain_lp(const XsCx &cx, ST *st, XsEnv &v, const int16_t *rand_hi, int noise_e, int nsb, int skip, int s0, int s1,
-                                  int input_e, int adj_e, int final_e, int sb_start, int lb_scale, int noise_absc,
-                                  const XsQmf &x) {
+FX_HD void xs_adapt_noise_gain_lp(const XsCx &cx, ST *st, XsEnv &v, const int16_t *rand_hi, int noise_e, int nsb,
+                                  int skip, int s0, int s1, int input_e, int adj_e, int final_e, int sb_start,
+                                  int lb_scale, int noise_absc, const XsQmf &x) {
   const int bands = nsb - skip;
   const int start_up = cx.uni(st->start_up);
   const int ph0 = cx.uni(st->ph_index), harm0 = cx.uni(st->harm_index);
@@ -1198,17 +1139,41 @@ FX_HD void xs_adapt_noise_gain_lp(const XsCx &cx, ST *st, XsEnv &v, const int16_
   const XsLv tone = xs_prefix_nonzero_m(cx, v.sine, nsb);
   const XsLv s_prev = v.sine.shifted(cx, -1), s_next = v.sine.shifted(cx, 1);
   XS_T(21);
-  int fi0 = !(sb_start & 1);
+  const int nm1 = nsb - 1;
+  int fi0 = !(sb_start & 1); /* freq_inv for harmonic index 1; index 3 negates it */
   fi0 = (fi0 << 1) - 1;
   XS_LANES(k, 0, nsb) {
-    XsBandAmp a;
-    a.gm = xs_m(v.gain.own(k));
-    a.ge = xs_e(v.gain.own(k));
-    a.sl = xs_m(v.sine.own(k));
-    a.sl_prev = xs_m(s_prev.own(k));
-    a.sl_next = xs_m(s_next.own(k));
-    a.nl = xs_m(v.noise.own(k));
-    a.tone_count = (int16_t)tone.own(k);
+    const int16_t gm = xs_m(v.gain.own(k)), ge = xs_e(v.gain.own(k));
+    const int16_t sl = xs_m(v.sine.own(k)), sl_prev = xs_m(s_prev.own(k));
+    const int16_t sl_next = (k + 1 < nsb) ? xs_m(s_next.own(k)) : (int16_t)0;
+    int16_t nl = xs_m(v.noise.own(k));
+    const int with_noise = !noise_absc && sl == 0;
+    const int few_tones = tone.own(k) <= 16;
+    const int32_t sine32 = xs_shl(sl, 16);
+    /* odd harmonic index: what band k adds to its own sample when the index is 1 */
+    int32_t term1;
+    if (k == 0) {
+      term1 = fx_mul32x16(XS_FACTOR, sl_next);
+      if (fi0 < 0) term1 = -term1;
+    } else if (k < nm1) {
+      const int32_t add = fx_mul32x16(XS_FACTOR, (int16_t)(sl_prev - sl_next));
+      term1 = few_tones ? (((k & 1) ? fi0 : -fi0) < 0 ? -add : add) : 0;
+    } else {
+      const int32_t tms = fx_mul32x16(XS_FACTOR, sl_prev);
+      term1 = few_tones ? (((nm1 & 1) ? fi0 : -fi0) > 0 ? tms : -tms) : 0;
+    }
+    /* ... and what the two edge bands add to the column outside the range (index 1; sign as above) */
+    int32_t edge1 = 0;
+    int edge_col = -1;
+    if (k == 0) {
+      edge1 = fx_mul32x16(XS_FACTOR, sl); /* shifted by the slot's noise exponent below */
+      edge_col = sb_start - 1;
+    }
+    if (k == nm1 && nm1 > 0 && few_tones && k + sb_start < 62) {
+      const int32_t tm2 = fx_mul32x16(XS_FACTOR, sl);
+      edge1 = ((nm1 & 1) ? fi0 : -fi0) > 0 ? -tm2 : tm2;
+      edge_col = sb_start + k + 1;
+    }
     int16_t fbn = st->filt_buf_noise_m[k];
     int ne = noise_e, fbe = fb_noise_e0, ph = ph0, harm = harm0;
     for (int l = s0; l < s1; l++) {
@@ -1220,7 +1185,7 @@ FX_HD void xs_adapt_noise_gain_lp(const XsCx &cx, ST *st, XsEnv &v, const int16_
         if (l == 32 && s0 < 32) {
           const int diff = final_e - ne;
           ne = final_e;
-          if (k < bands) a.nl = xs_noise_rescale(a.nl, diff);
+          if (k < bands) nl = xs_noise_rescale(nl, diff);
         }
       }
       fbn = xs_noise_rescale(fbn, fbe - ne);
@@ -1229,15 +1194,33 @@ FX_HD void xs_adapt_noise_gain_lp(const XsCx &cx, ST *st, XsEnv &v, const int16_
       const int hi = harm;
       ph = (ph + nsb) & 511;
       harm = (harm + 1) & 3;
+      int32_t val = fx_mul32x16(x(l, sb_start + k), gm);
+      const int shift = ge - (scale_change - 1);
+      val = shift > 0 ? xs_shl(val, shift) : xs_sar(val, -shift);
       if (!(hi & 1)) {
-        xs_harm_zerotwo_lp(x, l, sb_start, k, a, scale_change, rp, noise_absc, hi);
+        if (with_noise)
+          val = xs_mac16x16_shl_sat(val, rp, nl);
+        else
+          val = hi == 0 ? fx_add_sat(val, sine32) : fx_sub_sat(val, sine32);
       } else {
-        xs_harm_onethree_lp(x, l, sb_start, k, a, scale_change, rp, nsb, noise_absc, hi == 3 ? -fi0 : fi0,
-                            (ne - 16) - lb_scale, sb_start);
+        if (with_noise) val = xs_mac16x16_shl_sat(val, rp, nl);
+        val = fx_add_sat(val, hi == 1 ? term1 : -term1);
+        if (edge_col >= 0) {
+          int32_t t = edge1;
+          const int neg = (hi == 1 ? fi0 : -fi0) < 0;
+          if (k == 0) { /* band 0's tail carries the noise exponent; freq_inv < 0 adds it, else subtracts */
+            const int16_t nexp = (int16_t)((ne - 16) - lb_scale);
+            t = nexp > 0 ? fx_shl(t, nexp) : fx_shr(t, -nexp);
+            x(l, edge_col) = neg ? fx_add_sat(x(l, edge_col), t) : fx_sub_sat(x(l, edge_col), t);
+          } else { /* edge1 holds the index-1 sign already */
+            x(l, edge_col) = hi == 1 ? fx_add_sat(x(l, edge_col), t) : fx_sub_sat(x(l, edge_col), t);
+          }
+        }
       }
+      x(l, sb_start + k) = val;
     }
     st->filt_buf_noise_m[k] = fbn;
-    v.noise.own(k) = xs_me(a.nl, xs_e(v.noise.own(k)));
+    v.noise.own(k) = xs_me(nl, xs_e(v.noise.own(k)));
   }
   cx.sync();
   XS_T(22);
