@@ -93,4 +93,40 @@ typedef struct xaac_sbr_state {
   XAAC_SBR_STATE_TAIL_FIELDS
 } xaac_sbr_state;
 
+/* ---- parametric stereo (HE-AACv2): ia_ps_dec_struct, decoder/ixheaacd_ps_dec.h:97-243 -------------------- */
+#define XAAC_PS_MAX_ENV 5       /* MAXIM_NUM_OF_PS_ENVLOPS */
+#define XAAC_PS_BANDS_FINE 34   /* NUM_BANDS_FINE */
+#define XAAC_PS_GROUPS 22       /* NO_IID_GROUPS: 10 hybrid + 12 QMF groups */
+
+/* Per-frame PS side info after ixheaacd_decode_ps_data (ixheaacd_ps_bitdec.c): the envelope borders and
+ * the IID / ICC indices already mapped to the 20-band resolution the fixed-point path works in. */
+typedef struct xaac_ps_frame {
+  int16_t iid_quant;                                   /* fine (1) or coarse (0) IID quantiser */
+  int16_t pad0_;
+  int16_t border_position[XAAC_PS_MAX_ENV + 2];
+  int16_t pad1_;
+  int16_t iid_par_table[XAAC_PS_MAX_ENV + 2][XAAC_PS_BANDS_FINE];
+  int16_t icc_par_table[XAAC_PS_MAX_ENV + 2][XAAC_PS_BANDS_FINE];
+} xaac_ps_frame;
+
+/* Per-stream persistent PS state + the right channel's synthesis bank. */
+typedef struct xaac_ps_state {
+  int16_t ser[5][3][64];        /* delay_buf_qmf_ser_re_im: all-pass links of the QMF bands (re,im pairs) */
+  int16_t ap[2][64];            /* delay_buf_qmf_ap_re_im */
+  int16_t ld[14][24];           /* delay_buf_qmf_ld_re_im: 14-slot delay, 12 bands */
+  int16_t sd[64];               /* delay_buf_qmf_sd_re_im: 1-slot delay (58 used; contiguous with ld) */
+  int16_t sub[2][32];           /* delay_buf_qmf_sub_re_im: hybrid sub-bands */
+  int16_t sub_ser[5][3][32];    /* delay_buf_qmf_sub_ser_re_im (contiguous with sub) */
+  int16_t idx_ser[3], sample_ser[3];
+  int16_t idx, idx_long;
+  int32_t peak_decay_diff[20], energy_prev[20], peak_decay_diff_prev[20]; /* contiguous, in this order */
+  int32_t hyb_buf[3][2][12];    /* str_hybrid.ptr_qmf_buf_re/_im: 12-slot history of QMF bands 0..2 */
+  int16_t h11_h12_vec[48], h21_h22_vec[48], H11_H12[48], H21_H22[48], delta_h11_h12[48], delta_h21_h22[48];
+  int16_t delay_buffer_scale, usb;
+  /* right channel: str_synthesis_qmf_bank + scale factors of pstr_sbr_channel[1] */
+  int16_t syn_ring_r[1280], syn_drc_offset_r, syn_phase_r;
+  int16_t syn_lsb_r, syn_usb_r;
+  int16_t st_syn_scale_r, lb_scale_r, ov_lb_scale_r, hb_scale_r;
+} xaac_ps_state;
+
 #endif /* XAAC_SBR_H */

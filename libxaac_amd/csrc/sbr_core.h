@@ -51,6 +51,7 @@ FX_HD int32_t xs_sar(int32_t v, int s) { return v >> (s & 31); }
 FX_HD int xs_pnorm32(int32_t a) { return fx_norm32(a); } /* non-negative arguments only */
 FX_HD int16_t xs_mult16_shl_sat(int16_t a, int16_t b) { return fx_sat16(((int32_t)a * b) >> 15); }
 FX_HD int16_t xs_mult16_shl(int16_t a, int16_t b) { return (int16_t)(((int32_t)a * b) >> 15); }
+FX_HD int16_t xs_mult16(int16_t a, int16_t b) { return (int16_t)(((int32_t)a * b) >> 16); }
 FX_HD int32_t xs_mult16x16_shl(int16_t a, int16_t b) { return fx_shl((int32_t)a * b, 1); }
 FX_HD int32_t xs_mac16x16_shl_sat(int32_t acc, int16_t b, int16_t c) {
   int32_t p = (int32_t)b * c;
@@ -271,11 +272,19 @@ FX_HD int xs_clz64(uint64_t v) { return __builtin_clzll(v); } /* v != 0 */
 FX_HD int xs_ctz64(uint64_t v) { return __builtin_ctzll(v); } /* v != 0 */
 FX_HD uint64_t xs_mask_upto(int k) { return ((uint64_t)2 << k) - 1; } /* bits 0..k, k <= 63 */
 
-/* ---- QMF matrix view: slot rows of 64 bands; rows -2,-1 are the LPC history --------------------- */
-struct XsQmf {
-  int32_t *p; /* element (slot, band) at p[(slot + 2) * 64 + band] */
-  FX_MEMBER int32_t &operator()(int slot, int band) const { return p[(slot + 2) * 64 + band]; }
+/* ---- QMF matrix view: rows -2,-1 are the LPC history, rows 0..37 the slots.  Low-power mode keeps 64
+   real values per slot; HQ mode keeps 64 real then 64 imaginary ones (the reference's slot-pointer
+   arrays over one scratch block, sbr_dec.c:752-766, have exactly these strides). */
+template <int HQ_>
+struct XsQmfT {
+  static constexpr int HQ = HQ_;
+  static constexpr int ROW = HQ_ ? 128 : 64;
+  int32_t *p;
+  FX_MEMBER int32_t &operator()(int slot, int band) const { return p[(slot + 2) * ROW + band]; }
+  FX_MEMBER int32_t &im(int slot, int band) const { return p[(slot + 2) * ROW + 64 + band]; }
 };
+typedef XsQmfT<0> XsQmf;
+typedef XsQmfT<1> XsQmfHq;
 
 struct XsCov {
   int32_t phi_11, phi_22, phi_01, phi_02, phi_12, d;
@@ -299,30 +308,42 @@ struct XsEnv {
   XsLv est, e_orig, gain, noise, sine, meta, alias_red, sine_mapped, deg, deg1;
 };
 
-/* env_calc.c:1159 (real-valued): headroom of bands [b0,b1) x slots [s0,s1) */
-FX_HD int xs_headroom(const XsCx &cx, const XsQmf &x, int b0, int b1, int s0, int s1) {
+/* env_calc.c:1159: headroom of bands [b0,b1) x slots [s0,s1) */
+template <class Q>
+FX_HD int xs_headroom(const XsCx &cx, const Q &x, int b0, int b1, int s0, int s1) {
   int32_t m = 1;
   XS_PAR(k, b0, b1) {
     XS_UNROLL4
-    for (int l = s0; l < s1; l++) m |= fx_abs_nrm(x(l, k));
+    for (int l = s0; l < s1; l++) {
+      m |= fx_abs_nrm(x(l, k));
+      if (Q::HQ) m |= fx_abs_nrm(x.im(l, k));
+    }
   }
   return xs_pnorm32(cx.wave_or(m));
 }
 /* the same, sequential (for code that already runs one band group per lane) */
-FX_HD int xs_headroom_seq(const XsQmf &x, int b0, int b1, int s0, int s1) {
+template <class Q>
+FX_HD int xs_headroom_seq(const Q &x, int b0, int b1, int s0, int s1) {
   int32_t m = 1;
   for (int l = s0; l < s1; l++)
-    for (int k = b0; k < b1; k++) m |= fx_abs_nrm(x(l, k));
+    for (int k = b0; k < b1; k++) {
+      m |= fx_abs_nrm(x(l, k));
+      if (Q::HQ) m |= fx_abs_nrm(x.im(l, k));
+    }
   return xs_pnorm32(m);
 }
-/* env_calc.c:1099 (real-valued) */
-FX_HD void xs_adjust(const XsCx &cx, const XsQmf &x, int b0, int b1, int s0, int s1, int shift) {
+/* env_calc.c:1099 */
+template <class Q>
+FX_HD void xs_adjust(const XsCx &cx, const Q &x, int b0, int b1, int s0, int s1, int shift) {
   if (shift == 0) return;
   if (shift > 31) shift = 31;
   if (shift < -31) shift = -31;
   XS_PAR(k, b0, b1) {
     XS_UNROLL4
-    for (int l = s0; l < s1; l++) x(l, k) = shift > 0 ? fx_shlw(x(l, k), shift) : (x(l, k) >> -shift);
+    for (int l = s0; l < s1; l++) {
+      x(l, k) = shift > 0 ? fx_shlw(x(l, k), shift) : (x(l, k) >> -shift);
+      if (Q::HQ) x.im(l, k) = shift > 0 ? fx_shlw(x.im(l, k), shift) : (x.im(l, k) >> -shift);
+    }
   }
 }
 
@@ -578,39 +599,50 @@ FX_HD void xs_map_sineflags(const XsCx &cx, const int16_t *tbl_hi, int nsf, cons
   }
 }
 
-/* env_calc.c:1211, low-power branch: energy estimate of band k over slots [s0,s1) */
-FX_HD int32_t xs_energy_of_subband(const XsQmf &x, int s0, int s1, int k, int frame_exp2, int16_t inv_width) {
+/* env_calc.c:1211: energy estimate of band k over slots [s0,s1) (HQ: real and imaginary parts) */
+template <class Q>
+FX_HD int32_t xs_energy_of_subband(const Q &x, int s0, int s1, int k, int frame_exp2, int16_t inv_width) {
   const int n = s1 - s0;
   int32_t mx = 1;
   XS_UNROLL4
   for (int l = 0; l < n; l++) {
     int32_t v = fx_abs_nrm(x(s0 + l, k));
     if (v > mx) mx = v;
+    if (Q::HQ) {
+      v = fx_abs_nrm(x.im(s0 + l, k));
+      if (v > mx) mx = v;
+    }
   }
-  int pre = xs_pnorm32(mx) - 3;
+  int pre = xs_pnorm32(mx) - (Q::HQ ? 4 : 3);
   int32_t accu = 0;
   int shift = 16 - pre;
   XS_UNROLL4
   for (int l = 0; l < n; l++) {
     int16_t t = shift > 0 ? (int16_t)xs_sar(x(s0 + l, k), shift) : (int16_t)xs_shl(x(s0 + l, k), -shift);
     accu = fx_add(accu, (int32_t)t * t);
+    if (Q::HQ) {
+      t = shift > 0 ? (int16_t)xs_sar(x.im(s0 + l, k), shift) : (int16_t)xs_shl(x.im(s0 + l, k), -shift);
+      accu = fx_add(accu, (int32_t)t * t);
+    }
   }
   if (accu == 0) return 0;
   shift = -xs_pnorm32(accu);
   int16_t sum_m = (int16_t)xs_shr_dir_sat_limit(accu, 16 + shift);
   sum_m = xs_mult16_shl_sat(sum_m, inv_width);
-  shift = shift - (pre << 1) + 1;
+  shift = shift - (pre << 1) + (Q::HQ ? 0 : 1);
   return xs_me(sum_m, (int16_t)(frame_exp2 + shift + 1));
 }
-FX_HD void xs_energy_per_subband(const XsCx &cx, const XsQmf &x, int s0, int s1, int b0, int b1, int frame_exp,
+template <class Q>
+FX_HD void xs_energy_per_subband(const XsCx &cx, const Q &x, int s0, int s1, int b0, int b1, int frame_exp,
                                  XsLv &est) {
   const int16_t inv_width = xaac_sbr_inv_int_table[s1 - s0];
   XS_LANES(c, 0, b1 - b0) est.own(c) = xs_energy_of_subband(x, s0, s1, b0 + c, frame_exp << 1, inv_width);
 }
 
-/* env_calc.c:1298, low-power branch: one scale-factor band per lane.  The reference appends the
-   estimates of successive sfbs; they start at the first sfb at or above max_sb. */
-FX_HD void xs_energy_per_sfb(const XsCx &cx, const XsQmf &x, int nsf, const int16_t *tbl, int s0, int s1, int max_sb,
+/* env_calc.c:1298: one scale-factor band per lane.  The reference appends the estimates of successive
+   sfbs; they start at the first sfb at or above max_sb. */
+template <class Q>
+FX_HD void xs_energy_per_sfb(const XsCx &cx, const Q &x, int nsf, const int16_t *tbl, int s0, int s1, int max_sb,
                              int frame_exp, XsWork *w, XsLv &est) {
   const int16_t inv_width = xaac_sbr_inv_int_table[s1 - s0];
   frame_exp <<= 1;
@@ -628,6 +660,10 @@ FX_HD void xs_energy_per_sfb(const XsCx &cx, const XsQmf &x, int nsf, const int1
       for (int l = s0; l < s1; l++) {
         int16_t t = (int16_t)fx_shr_dir(x(l, k), p1);
         line = fx_add_sat(line, (int32_t)t * t);
+        if (Q::HQ) {
+          t = (int16_t)fx_shr_dir(x.im(l, k), p1);
+          line = fx_add_sat(line, (int32_t)t * t);
+        }
       }
       accumulate = fx_add_sat(accumulate, fx_shr(line, 9));
     }
@@ -639,7 +675,7 @@ FX_HD void xs_energy_per_sfb(const XsCx &cx, const XsQmf &x, int nsf, const int1
     } else {
       sum_m = xs_mult16_shl_sat(sum_m, inv_width);
       sum_m = xs_mult16_shl_sat(sum_m, xaac_sbr_inv_int_table[ui - li]);
-      sum_e = ((frame_exp + 11) - shift) - (pre << 1);
+      sum_e = ((frame_exp + (Q::HQ ? 10 : 11)) - shift) - (pre << 1);
     }
     for (int k = li; k < ui; k++) {
       w->nrg_est[2 * (k - base)] = sum_m;
@@ -1240,11 +1276,333 @@ FX_HD void xs_adapt_noise_gain_lp(const XsCx &cx, ST *st, XsEnv &v, const int16_
   cx.sync();
 }
 
-/* env_calc.c:692, low-power, AAC-LC/HE-AAC (not ELD), 1024-sample frames.  deg64: aliasing degree per
-   QMF band from the HF generator.  Returns 0 or -1. */
+/* ---- HQ (complex) mode -------------------------------------------------------------------------- */
+/* env_calc.c:450 */
+FX_HD void xs_erg_to_amplitude_hq(const XsCx &cx, int bands, int16_t noise_e, XsEnv &v) {
+  XS_LANES(k, 0, bands) {
+    int16_t sn[2] = {xs_m(v.sine.own(k)), xs_e(v.sine.own(k))};
+    int16_t g[2] = {xs_m(v.gain.own(k)), xs_e(v.gain.own(k))};
+    int16_t nl[2] = {xs_m(v.noise.own(k)), xs_e(v.noise.own(k))};
+    xs_mant_exp_sqrt(sn);
+    xs_mant_exp_sqrt(g);
+    xs_mant_exp_sqrt(nl);
+    int shift = (noise_e - nl[1]) - 4;
+    if (shift > 0) {
+      if (shift > 31) shift = 31;
+      nl[0] = (int16_t)(nl[0] >> shift);
+    } else {
+      if (shift < -31) shift = -31;
+      nl[0] = (int16_t)xs_shl(nl[0], -shift);
+    }
+    v.sine.own(k) = xs_me(sn[0], sn[1]);
+    v.gain.own(k) = xs_me(g[0], g[1]);
+    v.noise.own(k) = xs_me(nl[0], nl[1]);
+  }
+}
+
+/* env_calc.c:479 (HQ branch) with ixheaacd_adj_timeslot (env_dec.c:845) and ixheaacd_harm_idx_zerotwo /
+   _onethree (env_calc.c:1759 / :1827): gain smoothing over the first slots of an envelope, then gain,
+   noise (complex random phase) or sine (real part for harmonic index 0/2, imaginary for 1/3, sign
+   alternating with the band) per band.  Bands are independent; lane i owns filter-buffer entry i and,
+   from skip on, band i - skip. */
 template <class ST>
-FX_HD int xs_calc_sbrenvelope_lp(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, ST *st,
-                                 const XsQmf &x, XsWork *w, const int16_t *rand_hi, const XsLv &deg64) {
+FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e, int nsb, int skip, int s0, int s1,
+                                  int input_e, int adj_e, int final_e, int sb_start, int noise_absc,
+                                  int smooth_length, const XsQmfHq &x) {
+  const int bands = nsb - skip;
+  const int start_up = cx.uni(st->start_up);
+  const int ph0 = cx.uni(st->ph_index), harm0 = cx.uni(st->harm_index);
+  const int fb_noise_e0 = start_up ? noise_e : cx.uni(st->filt_buf_noise_e);
+  cx.sync();
+  XS_LANES(k, 0, bands) {
+    int16_t g[2] = {xs_m(v.gain.own(k)), xs_e(v.gain.own(k))};
+    if (start_up) {
+      st->filt_buf_me[2 * (skip + k)] = g[0];
+      st->filt_buf_me[2 * (skip + k) + 1] = g[1];
+      st->filt_buf_noise_m[skip + k] = xs_m(v.noise.own(k));
+    } else {
+      xs_equalize_filt_buf(&st->filt_buf_me[2 * (skip + k)], g);
+      v.gain.own(k) = xs_me(g[0], g[1]);
+    }
+  }
+  cx.sync();
+  /* band values seen from the lane that owns filter-buffer entry i = skip + k */
+  const XsLv gain_i = v.gain.shifted(cx, -skip), noise_i = v.noise.shifted(cx, -skip),
+             sine_i = v.sine.shifted(cx, -skip);
+  XsLv noise_out;
+  noise_out.fill(0);
+  XS_LANES(i, 0, nsb) {
+    const int k = i - skip;
+    const int16_t gm = xs_m(gain_i.own(i)), ge = xs_e(gain_i.own(i));
+    const int16_t sm = xs_m(sine_i.own(i)), se = xs_e(sine_i.own(i));
+    int16_t nl = xs_m(noise_i.own(i));
+    int16_t fbm = st->filt_buf_me[2 * i], fbn = st->filt_buf_noise_m[i];
+    int ne = noise_e, fbe = fb_noise_e0, ph = ph0, harm = harm0;
+    for (int l = s0; l < s1; l++) {
+      int scale_change;
+      if (l < 32) {
+        scale_change = adj_e - input_e;
+      } else {
+        scale_change = final_e - input_e;
+        if (l == 32 && s0 < 32) {
+          const int diff = final_e - ne;
+          ne = final_e;
+          if (k >= 0) nl = xs_noise_rescale(nl, diff);
+        }
+      }
+      fbn = xs_noise_rescale(fbn, fbe - ne);
+      fbe = ne;
+      const int32_t rp = xaac_sbr_rand_ph[ph + 1 + (k >= 0 ? k : 0)];
+      const int hi = harm;
+      ph = (ph + bands) & 511;
+      harm = (harm + 1) & 3;
+      if (k < 0) continue;
+      const int16_t smooth = (l - s0) < smooth_length ? xaac_sbr_smooth_filter[l - s0] : (int16_t)0;
+      int16_t sg = gm, snz = nl;
+      if (smooth) {
+        const int16_t direct = fx_sat16(0x7fff - (int32_t)smooth);
+        const int16_t t = (int16_t)(xs_mult16(smooth, fbm) + xs_mult16(direct, gm));
+        const int16_t t1 = (int16_t)(xs_mult16(smooth, fbn) + xs_mult16(direct, nl));
+        fbm = (int16_t)(t << 1);
+        fbn = (int16_t)(t1 << 1);
+        sg = fbm;
+        snz = fbn;
+      }
+      const int16_t sc = (int16_t)((int16_t)scale_change - 1);
+      int32_t re = fx_mul32x16(x(l, sb_start + k), sg), im = fx_mul32x16(x.im(l, sb_start + k), sg);
+      const int shift = (int16_t)(ge - sc);
+      if (shift > 0) {
+        re = fx_shl(re, shift);
+        im = fx_shl(im, shift);
+      } else {
+        re = fx_shr(re, -shift);
+        im = fx_shr(im, -shift);
+      }
+      if (sm != 0) {
+        const int tmp = (int16_t)(se - (int16_t)(ne - 16));
+        int32_t sine_level;
+        if (!(hi & 1)) {
+          /* (sic) the non-positive case shifts by tmp, not -tmp (env_calc.c:1797) */
+          sine_level = tmp > 0 ? fx_shl(sm, tmp) : fx_shr(sm, tmp);
+          re = hi == 0 ? fx_add_sat(re, sine_level) : fx_sub_sat(re, sine_level);
+        } else {
+          sine_level = tmp > 0 ? fx_shl(sm, tmp) : fx_shr(sm, -tmp);
+          int fi = sb_start & 1;
+          if (hi == 1) fi = !fi;
+          if (k & 1) fi = !fi;
+          im = fi ? fx_add_sat(im, sine_level) : fx_sub_sat(im, sine_level);
+        }
+      } else if (!noise_absc) {
+        re = xs_mac16x16_shl_sat(re, (int16_t)(rp >> 16), snz);
+        im = xs_mac16x16_shl_sat(im, (int16_t)rp, snz);
+      }
+      x(l, sb_start + k) = re;
+      x.im(l, sb_start + k) = im;
+    }
+    st->filt_buf_me[2 * i] = fbm;
+    st->filt_buf_noise_m[i] = fbn;
+    noise_out.own(i) = nl;
+  }
+  cx.sync();
+  {
+    const XsLv nb = noise_out.shifted(cx, skip); /* back to band indexing */
+    XS_LANES(k, 0, bands) {
+      v.noise.own(k) = xs_me((int16_t)nb.own(k), xs_e(v.noise.own(k)));
+      st->filt_buf_me[2 * (skip + k)] = xs_m(v.gain.own(k)); /* env_calc.c:1060 */
+      st->filt_buf_noise_m[skip + k] = (int16_t)nb.own(k);
+    }
+  }
+  XS_ONE {
+    const int n = s1 > s0 ? s1 - s0 : 0;
+    int ne = noise_e;
+    if (s0 < 32 && s1 > 32) ne = final_e;
+    st->start_up = 0;
+    st->filt_buf_noise_e = n > 0 ? ne : fb_noise_e0;
+    st->ph_index = (int16_t)((ph0 + n * bands) & 511);
+    st->harm_index = (int16_t)((harm0 + n) & 3);
+  }
+  cx.sync();
+}
+
+/* lpp_tran.c:372: complex covariances of low band k over `slots` (= 38) slots starting at row 0, with the
+   two LPC history rows below.  All sums wrap, so their order is free: with M(a, b) = a * hi16(b) >> 16,
+   phi_01 = sum_{n=0}^{slots-1} x[n] conj(x[n-1]), phi_02 likewise with x[n-2], phi_11 = sum_{n=-1}^{slots-2}
+   |x[n]|^2, phi_12 = sum_{n=-1}^{slots-2} x[n] conj(x[n-1]), phi_22 = sum_{n=-2}^{slots-3} |x[n]|^2. */
+struct XsCovHq {
+  int32_t phi_11, phi_22, phi_01, phi_02, phi_12, phi_01_im, phi_02_im, phi_12_im;
+};
+FX_HD void xs_covariance_hq(const XsQmfHq &x, int k, int slots, XsCovHq *c) {
+  int32_t p01 = 0, p01i = 0, p02 = 0, p02i = 0, p11 = 0, p12 = 0, p12i = 0, p22 = 0;
+  int32_t r2 = fx_shr(x(-2, k), 3), i2 = fx_shr(x.im(-2, k), 3); /* x[n-2] */
+  int32_t r1 = fx_shr(x(-1, k), 3), i1 = fx_shr(x.im(-1, k), 3); /* x[n-1] */
+  p22 = fx_add(xs_mul_hi16(r2, r2), xs_mul_hi16(i2, i2));
+  p12 = fx_add(xs_mul_hi16(r1, r2), xs_mul_hi16(i1, i2));
+  p12i = fx_sub(xs_mul_hi16(i1, r2), xs_mul_hi16(r1, i2));
+  XS_UNROLL4
+  for (int n = 0; n < slots; n++) {
+    const int32_t r0 = fx_shr(x(n, k), 3), i0 = fx_shr(x.im(n, k), 3);
+    const int32_t t01 = fx_add(xs_mul_hi16(r0, r1), xs_mul_hi16(i0, i1));
+    const int32_t t01i = fx_sub(xs_mul_hi16(i0, r1), xs_mul_hi16(r0, i1));
+    const int32_t e1 = fx_add(xs_mul_hi16(r1, r1), xs_mul_hi16(i1, i1)); /* |x[n-1]|^2 */
+    p01 = fx_add(p01, t01);
+    p01i = fx_add(p01i, t01i);
+    p02 = fx_add(p02, fx_add(xs_mul_hi16(r0, r2), xs_mul_hi16(i0, i2)));
+    p02i = fx_add(p02i, fx_sub(xs_mul_hi16(i0, r2), xs_mul_hi16(r0, i2)));
+    p11 = fx_add(p11, e1);
+    if (n < slots - 1) { /* the shifted sums stop one sample earlier */
+      p12 = fx_add(p12, t01);
+      p12i = fx_add(p12i, t01i);
+      p22 = fx_add(p22, e1);
+    }
+    r2 = r1;
+    i2 = i1;
+    r1 = r0;
+    i1 = i0;
+  }
+  c->phi_11 = p11;
+  c->phi_22 = p22;
+  c->phi_01 = p01;
+  c->phi_02 = p02;
+  c->phi_12 = p12;
+  c->phi_01_im = p01i;
+  c->phi_02_im = p02i;
+  c->phi_12_im = p12i;
+}
+
+/* lpp_tran.c:1041-1201: complex prediction coefficients of one low band, with the reference's reset
+   rules.  a[0..3] = alpha0 re, alpha0 im, alpha1 re, alpha1 im. */
+FX_HD void xs_lpc_coeffs_hq(const XsCovHq *s, int16_t *a) {
+  int32_t mx = fx_abs_nrm(s->phi_01) | fx_abs_nrm(s->phi_02) | fx_abs_nrm(s->phi_12) | s->phi_11 | s->phi_22 |
+               fx_abs_nrm(s->phi_01_im) | fx_abs_nrm(s->phi_02_im) | fx_abs_nrm(s->phi_12_im);
+  const int q = xs_pnorm32(mx);
+  const int32_t p11 = xs_shl(s->phi_11, q), p22 = xs_shl(s->phi_22, q), p01 = xs_shl(s->phi_01, q),
+                p02 = xs_shl(s->phi_02, q), p12 = xs_shl(s->phi_12, q), p01i = xs_shl(s->phi_01_im, q),
+                p02i = xs_shl(s->phi_02_im, q), p12i = xs_shl(s->phi_12_im, q);
+  const int32_t d = fx_shlw(fx_sub_sat(fx_mul32(p11, p22), fx_add_sat(fx_mul32(p12, p12), fx_mul32(p12i, p12i))), 1);
+  int reset = 0;
+  int16_t a1r = 0, a1i = 0, a0r = 0, a0i = 0;
+  if (d != 0) {
+    const int norm_d = fx_norm32(d);
+    const int16_t inv_d = (int16_t)xs_fix_div(0x40000000, xs_shl(d, norm_d));
+    const int32_t mod_d = fx_abs_sat(d);
+    const int32_t tr = fx_sub_sat(fx_sub_sat(fx_mul32(p01, p12), fx_mul32(p01i, p12i)), fx_mul32(p02, p11)) >> 1;
+    const int32_t ti = fx_sub_sat(fx_add_sat(fx_mul32(p01i, p12), fx_mul32(p01, p12i)), fx_mul32(p02i, p11)) >> 1;
+    if (fx_abs_sat(tr) >= mod_d)
+      reset = 1;
+    else
+      a1r = (int16_t)(xs_shl(fx_mul32x16(tr, inv_d), norm_d + 1) >> 15);
+    if (fx_abs_sat(ti) >= mod_d)
+      reset = 1;
+    else
+      a1i = (int16_t)(xs_shl(fx_mul32x16(ti, inv_d), norm_d + 1) >> 15);
+  }
+  if (p11 != 0) {
+    const int norm = fx_norm32(p11);
+    const int16_t inv = (int16_t)xs_fix_div(0x40000000, xs_shl(p11, norm));
+    int32_t tr = fx_add_sat(fx_add(p01 >> 3, fx_mul32x16(p12, a1r)), fx_mul32x16(p12i, a1i));
+    int32_t ti = fx_sub_sat(fx_add(p01i >> 3, fx_mul32x16(p12, a1i)), fx_mul32x16(p12i, a1r));
+    tr = fx_shlw(tr, 1);
+    ti = fx_shlw(ti, 1);
+    if (fx_abs_sat(tr) >= p11)
+      reset = 1;
+    else
+      a0r = (int16_t)(xs_shl(fx_mul32x16(fx_sub_sat(0, tr), inv), norm + 1) >> 15);
+    if (fx_abs_sat(ti) >= p11)
+      reset = 1;
+    else
+      a0i = (int16_t)(xs_shl(fx_mul32x16(fx_sub_sat(0, ti), inv), norm + 1) >> 15);
+  }
+  if (fx_add_sat((int32_t)a0r * a0r, (int32_t)a0i * a0i) >= 0x40000000) reset = 1;
+  if (fx_add_sat((int32_t)a1r * a1r, (int32_t)a1i * a1i) >= 0x40000000) reset = 1;
+  if (reset) a0r = a0i = a1r = a1i = 0;
+  a[0] = a0r;
+  a[1] = a0i;
+  a[2] = a1r;
+  a[3] = a1i;
+}
+
+/* lpp_tran.c:102 + :1203-1250: copy / inverse-filter low band lb into each patch's high band */
+FX_HD void xs_patch_band_hq(const xaac_sbr_header *h, const XsQmfHq &x, int lb, const int16_t *alpha,
+                            const int32_t *bw_array, int start_idx, int stop_idx, int max_qmf_subband) {
+  for (int patch = 0; patch < h->num_patches; patch++) {
+    const xaac_sbr_patch *pp = &h->patch[patch];
+    const int hb = lb + pp->dst_end_band;
+    if (lb < pp->src_start_band || lb >= pp->src_end_band || hb < max_qmf_subband) continue;
+    int bi = 0; /* the reference's per-patch running index: first border above hb, capped (lpp_tran.c:1218) */
+    while (bi < XAAC_SBR_MAX_PATCHES - 1 && bi < XAAC_SBR_MAX_NOISE_VALUES && hb >= h->bw_borders[bi]) bi++;
+    int16_t bw = (int16_t)(bw_array[bi] >> 16);
+    const int16_t a0r = xs_mult16_shl_sat(bw, alpha[0]), a0i = xs_mult16_shl_sat(bw, alpha[1]);
+    bw = xs_mult16_shl_sat(bw, bw);
+    const int16_t a1r = xs_mult16_shl_sat(bw, alpha[2]), a1i = xs_mult16_shl_sat(bw, alpha[3]);
+    const int n = stop_idx - start_idx;
+    if (bw > 0) {
+      int32_t p2r = x(start_idx - 2, lb), p2i = x.im(start_idx - 2, lb);
+      int32_t p1r = x(start_idx - 1, lb), p1i = x.im(start_idx - 1, lb);
+      XS_UNROLL4
+      for (int i = 0; i < n; i++) {
+        const int32_t cr = x(start_idx + i, lb), ci = x.im(start_idx + i, lb);
+        int32_t acc = fx_sub(fx_add(fx_sub(fx_mul32x16(p1r, a0r), fx_mul32x16(p1i, a0i)), fx_mul32x16(p2r, a1r)),
+                             fx_mul32x16(p2i, a1i));
+        x(start_idx + i, hb) = fx_add(cr >> 2, fx_shlw(acc, 1));
+        acc = fx_add(fx_add_sat(fx_add_sat(fx_mul32x16(p1r, a0i), fx_mul32x16(p1i, a0r)), fx_mul32x16(p2r, a1i)),
+                     fx_mul32x16(p2i, a1r));
+        x.im(start_idx + i, hb) = fx_add(ci >> 2, fx_shlw(acc, 1));
+        p2r = p1r;
+        p2i = p1i;
+        p1r = cr;
+        p1i = ci;
+      }
+    } else {
+      for (int i = 0; i < n; i++) {
+        x(start_idx + i, hb) = x(start_idx + i, lb) >> 2;
+        x.im(start_idx + i, hb) = x.im(start_idx + i, lb) >> 2;
+      }
+    }
+  }
+}
+
+/* lpp_tran.c:956.  Writes bw_array_prev. */
+template <class ST>
+FX_HD void xs_hf_generator_hq(const XsCx &cx, const xaac_sbr_header *h, ST *st, const XsQmfHq &x, XsWork *w,
+                              int start_idx, int last_slot_offset, int max_qmf_subband, const int32_t *invf_mode,
+                              const int32_t *invf_mode_prev) {
+  const int num_patches = cx.uni(h->num_patches);
+  const int stop_idx = cx.uni(h->num_columns) + last_slot_offset;
+  XS_PAR(i, 0, XAAC_SBR_MAX_PATCHES) w->bw_array[i] = 0;
+  cx.sync();
+  xs_invfilt_level_emphasis(cx, st->bw_array_prev, h->num_if_bands, invf_mode, invf_mode_prev, w->bw_array);
+  const int actual_stop = cx.uni(
+      (int16_t)(h->patch[num_patches - 1].dst_start_band + h->patch[num_patches - 1].num_bands_in_patch));
+  XS_PAR(k, actual_stop, 64)
+    for (int l = start_idx; l < stop_idx; l++) {
+      x(l, k) = 0;
+      x.im(l, k) = 0;
+    }
+  const int start_patch = cx.uni(h->start_patch), stop_patch = cx.uni(h->stop_patch);
+  XS_PAR(k, start_patch, stop_patch) {
+    x(-2, k) = st->lpc_real[0][k];
+    x(-1, k) = st->lpc_real[1][k];
+    x.im(-2, k) = st->lpc_imag[0][k];
+    x.im(-1, k) = st->lpc_imag[1][k];
+  }
+  cx.sync();
+  XS_LANES(lb, start_patch, stop_patch) {
+    XsCovHq c;
+    xs_covariance_hq(x, lb, 38, &c); /* num_columns + 6 = 38 for 1024-sample frames (lpp_tran.c:1034) */
+    int16_t alpha[4];
+    xs_lpc_coeffs_hq(&c, alpha);
+    xs_patch_band_hq(h, x, lb, alpha, w->bw_array, start_idx, stop_idx, max_qmf_subband);
+  }
+  cx.sync();
+  XS_PAR(i, 0, h->num_if_bands) st->bw_array_prev[i] = w->bw_array[i];
+  cx.sync();
+}
+
+/* env_calc.c:692, AAC-LC/HE-AAC (not ELD), 1024-sample frames, low-power (Q = XsQmf) or HQ (XsQmfHq).
+   deg64: aliasing degree per QMF band from the low-power HF generator.  Returns 0 or -1. */
+template <class ST, class Q>
+FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, ST *st, const Q &x,
+                              XsWork *w, const int16_t *rand_hi, const XsLv &deg64) {
   const int num_env = cx.uni(f->num_env);
   const int16_t *border = f->border_vec;
   const int16_t *noise_floor = f->int_noise_floor;
@@ -1310,6 +1668,7 @@ FX_HD int xs_calc_sbrenvelope_lp(const XsCx &cx, const xaac_sbr_header *h, const
       nf_idx++;
     }
     const int noise_absc = (i == transient_env || i == tansient_env_prev) ? 1 : 0;
+    const int smooth_length = noise_absc ? 0 : ((1 - cx.uni(h->smoothing_mode)) << 2);
     const int input_e = 15 - hb_scale;
     if (cx.uni(h->interpol_freq))
       xs_energy_per_subband(cx, x, s0, s1, max_sb, sb_end, input_e, v.est);
@@ -1324,22 +1683,33 @@ FX_HD int xs_calc_sbrenvelope_lp(const XsCx &cx, const xaac_sbr_header *h, const
     XS_T(6);
     xs_noiselimiting(cx, h, skip, n_meta, v, w, &xaac_sbr_lim_gains_m[2 * cx.uni(h->limiter_gains)], noise_absc);
     XS_T(7);
-    XsLv grp_end;
-    grp_end.fill(0);
-    const uint64_t grp_starts = xs_alias_groups(cx, v.deg1, v.alias_red, nsb, grp_end);
-    XS_T(23);
-    xs_alias_reduction(cx, v, w, grp_starts, grp_end, nsb);
-    XS_T(8);
     const int16_t noise_e = (int16_t)(s0 < 32 ? adj_e : final_e);
-    xs_erg_to_amplitude_lp(cx, nsb - skip, noise_e, v);
-    XS_T(9);
-    xs_adapt_noise_gain_lp(cx, st, v, rand_hi, noise_e, nsb, skip, s0, s1, input_e, adj_e, final_e, max_sb,
-                           (int16_t)(15 - lb_scale), noise_absc, x);
+    if constexpr (!Q::HQ) {
+      XsLv grp_end;
+      grp_end.fill(0);
+      const uint64_t grp_starts = xs_alias_groups(cx, v.deg1, v.alias_red, nsb, grp_end);
+      XS_T(23);
+      xs_alias_reduction(cx, v, w, grp_starts, grp_end, nsb);
+      XS_T(8);
+      xs_erg_to_amplitude_lp(cx, nsb - skip, noise_e, v);
+      XS_T(9);
+      xs_adapt_noise_gain_lp(cx, st, v, rand_hi, noise_e, nsb, skip, s0, s1, input_e, adj_e, final_e, max_sb,
+                             (int16_t)(15 - lb_scale), noise_absc, x);
+    } else {
+      xs_erg_to_amplitude_hq(cx, nsb - skip, noise_e, v);
+      xs_adapt_noise_gain_hq(cx, st, v, noise_e, nsb, skip, s0, s1, input_e, adj_e, final_e, max_sb, noise_absc,
+                             smooth_length, x);
+    }
     XS_T(10);
   }
   const int first_start = cx.uni(border[0]) * 2;
   const int ov_adj_e = 15 - cx.uni(st->ov_hb_scale);
-  const int output_e = ov_adj_e > adj_e ? ov_adj_e : adj_e; /* reserves are 0 without PS */
+  int ov_reserve = 0, reserve = 0; /* env_calc.c:961: only taken for parametric stereo */
+  if (cx.uni(h->channel_mode) == 3) {
+    ov_reserve = xs_headroom(cx, x, max_sb, sb_end, 0, first_start);
+    reserve = xs_headroom(cx, x, max_sb, sb_end, first_start, 32);
+  }
+  const int output_e = (ov_adj_e - ov_reserve) > (adj_e - reserve) ? (ov_adj_e - ov_reserve) : (adj_e - reserve);
   xs_adjust(cx, x, max_sb, sb_end, 0, first_start, ov_adj_e - output_e);
   xs_adjust(cx, x, max_sb, sb_end, first_start, cx.uni(h->num_time_slots) * cx.uni(h->time_step), adj_e - output_e);
   cx.sync();
@@ -1354,9 +1724,9 @@ FX_HD int xs_calc_sbrenvelope_lp(const XsCx &cx, const xaac_sbr_header *h, const
 }
 
 /* sbrdec_lpfuncs.c:453 (real-valued) */
-template <class ST>
+template <class ST, class Q>
 FX_HD void xs_rescale_x_overlap(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, ST *st,
-                                const XsQmf &x) {
+                                const Q &x) {
   const int old_lsb = cx.uni(st->prev_max_qmf_subband_aac);
   const int start_slot = cx.uni(h->time_step) * (cx.uni(st->prev_end_position) - cx.uni(h->num_time_slots));
   const int new_lsb = cx.uni(f->max_qmf_subband_aac);
@@ -1372,7 +1742,10 @@ FX_HD void xs_rescale_x_overlap(const XsCx &cx, const xaac_sbr_header *h, const 
     return;
   }
   XS_PAR(k, old_lsb, new_lsb)
-    for (int l = start_slot; l < 6; l++) x(l, k) = 0;
+    for (int l = start_slot; l < 6; l++) {
+      x(l, k) = 0;
+      if (Q::HQ) x.im(l, k) = 0;
+    }
   int source, target, t_lsb, t_usb;
   if (new_lsb > old_lsb) {
     source = ov_hb;
@@ -1406,20 +1779,24 @@ FX_HD void xs_rescale_x_overlap(const XsCx &cx, const xaac_sbr_header *h, const 
   cx.sync();
 }
 
-/* The part of ixheaacd_sbr_dec between the two QMF banks (sbr_dec.c:1050-1245, low-power mode).
+/* The part of ixheaacd_sbr_dec between the two QMF banks (sbr_dec.c:1050-1245), low-power (Q = XsQmf) or
+   HQ (Q = XsQmfHq) mode.
    On entry x holds the 6 overlap slots (already through xs_rescale_x_overlap) and the 32 freshly
    analysed slots (bands 0..31); on exit x is ready for the synthesis bank and the state carries the
    new scale factors, LPC history and envelope-adjuster memory.  rand_hi[i] = xaac_sbr_rand_ph[i] >> 16
    (the only part of that table this mode uses; an LDS copy on the GPU).  Returns 0 or -1. */
-template <class ST>
-FX_HD int xs_sbr_core_lp(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, ST *st, const XsQmf &x,
-                         XsWork *w, const int16_t *rand_hi, int *save_lb_scale_out) {
+template <class ST, class Q>
+FX_HD int xs_sbr_core(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, ST *st, const Q &x, XsWork *w,
+                      const int16_t *rand_hi, int *save_lb_scale_out) {
   const int usb = cx.uni(st->codec_usb);
   int reserve = xs_headroom(cx, x, 0, usb, 6, 38);
   int reserve_ov1 = xs_headroom(cx, x, 0, usb, 0, 6);
   const int max_samp_val = reserve < reserve_ov1 ? reserve : reserve_ov1;
   int32_t m = 1;
-  XS_PAR(k, 0, usb) m |= fx_abs_nrm(st->lpc_real[0][k]) | fx_abs_nrm(st->lpc_real[1][k]);
+  XS_PAR(k, 0, usb) {
+    m |= fx_abs_nrm(st->lpc_real[0][k]) | fx_abs_nrm(st->lpc_real[1][k]);
+    if (Q::HQ) m |= fx_abs_nrm(st->lpc_imag[0][k]) | fx_abs_nrm(st->lpc_imag[1][k]);
+  }
   const int reserve_ov2 = xs_pnorm32(cx.wave_or(m));
   if (reserve_ov2 < reserve_ov1) reserve_ov1 = reserve_ov2;
   const int lb_scale0 = cx.uni(st->lb_scale), ov_lb_scale0 = cx.uni(st->ov_lb_scale);
@@ -1436,8 +1813,10 @@ FX_HD int xs_sbr_core_lp(const XsCx &cx, const xaac_sbr_header *h, const xaac_sb
       if (sh > 31) sh = 31;
       if (sh < -31) sh = -31;
       XS_PAR(k, 0, usb)
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < 2; i++) {
           st->lpc_real[i][k] = sh > 0 ? fx_shlw(st->lpc_real[i][k], sh) : (st->lpc_real[i][k] >> -sh);
+          if (Q::HQ) st->lpc_imag[i][k] = sh > 0 ? fx_shlw(st->lpc_imag[i][k], sh) : (st->lpc_imag[i][k] >> -sh);
+        }
     }
   }
   const int save_lb_scale = (int16_t)(lb_scale0 + reserve);
@@ -1447,7 +1826,10 @@ FX_HD int xs_sbr_core_lp(const XsCx &cx, const xaac_sbr_header *h, const xaac_sb
   }
   *save_lb_scale_out = save_lb_scale;
   XS_PAR(k, 32, 64)
-    for (int l = 6; l < 38; l++) x(l, k) = 0;
+    for (int l = 6; l < 38; l++) {
+      x(l, k) = 0;
+      if (Q::HQ) x.im(l, k) = 0;
+    }
   cx.sync();
   XS_T(1);
   if (cx.uni(f->apply_processing)) {
@@ -1455,12 +1837,16 @@ FX_HD int xs_sbr_core_lp(const XsCx &cx, const xaac_sbr_header *h, const xaac_sb
     deg64.fill(0);
     const int n_env = cx.uni(f->num_env), nts = cx.uni(h->num_time_slots), ts = cx.uni(h->time_step);
     const int16_t last = fx_sat16((int32_t)cx.uni(f->border_vec[n_env]) - nts);
-    xs_low_pow_hf_generator(cx, h, st, x, w, deg64, cx.uni(f->border_vec[0]) * ts, ts * last,
-                            cx.uni(f->max_qmf_subband_aac), f->sbr_invf_mode, st->prev_invf_mode, max_samp_val);
+    if constexpr (!Q::HQ)
+      xs_low_pow_hf_generator(cx, h, st, x, w, deg64, cx.uni(f->border_vec[0]) * ts, ts * last,
+                              cx.uni(f->max_qmf_subband_aac), f->sbr_invf_mode, st->prev_invf_mode, max_samp_val);
+    else
+      xs_hf_generator_hq(cx, h, st, x, w, cx.uni(f->border_vec[0]) * ts, ts * last, cx.uni(f->max_qmf_subband_aac),
+                         f->sbr_invf_mode, st->prev_invf_mode);
     XS_T(2);
     XS_ONE st->hb_scale = (int16_t)((st->ov_lb_scale < st->lb_scale ? st->ov_lb_scale : st->lb_scale) - 2);
     cx.sync();
-    if (xs_calc_sbrenvelope_lp(cx, h, f, st, x, w, rand_hi, deg64)) return -1;
+    if (xs_calc_sbrenvelope(cx, h, f, st, x, w, rand_hi, deg64)) return -1;
     XS_PAR(i, 0, h->num_if_bands) st->prev_invf_mode[i] = f->sbr_invf_mode[i];
     XS_ONE {
       st->prev_coupling_mode = f->coupling_mode;
@@ -1475,6 +1861,10 @@ FX_HD int xs_sbr_core_lp(const XsCx &cx, const xaac_sbr_header *h, const xaac_sb
   XS_PAR(k, 0, st->codec_usb) {
     st->lpc_real[0][k] = x(30, k);
     st->lpc_real[1][k] = x(31, k);
+    if (Q::HQ) {
+      st->lpc_imag[0][k] = x.im(30, k);
+      st->lpc_imag[1][k] = x.im(31, k);
+    }
   }
   cx.sync();
   XS_T(15);

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64) void xaac_sbr_core_lp_kernel(XaacSbrCoreParams 
 #ifdef XS_SKIP_CORE
   const int rc = 0;
 #else
-  const int rc = xs_sbr_core_lp(cx, &s.h, &s.f, &s.st, x, &s.w, s.rand_hi, &save_lb_scale);
+  const int rc = xs_sbr_core(cx, &s.h, &s.f, &s.st, x, &s.w, s.rand_hi, &save_lb_scale);
 #endif
   __syncthreads();
 #ifdef XS_PROFILE

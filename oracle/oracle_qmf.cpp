@@ -110,6 +110,38 @@ static inline int32_t adj(int32_t v, int shift) {
   return shift > 0 ? fx_shlw(v, shift) : (v >> -shift);
 }
 
+/* One slot of the synthesis bank: x = 64 reals (+ 64 imaginaries in HQ), already in the output scale of
+   the frame; transform into the ring, 10-tap polyphase sum, 64 PCM16 at `stride`; advances the ring
+   state.  `slot` is the slot's index in the frame (the two ring halves alternate with its parity). */
+void xo_qmf_synthesis_slot(const int32_t *x, xo_qmf_syn_state *st, int slot, int low_pow, int out_scale, int16_t *pcm,
+                           int stride) {
+  const int16_t *c = xaac_qmf_qmf_c;
+  int d = st->drc_offset, ph = st->phase;
+  const int fp1 = (slot & 1) ? 64 : 0, fp2 = (slot & 1) ? 0 : 64;
+  int32_t xin[128], t[128];
+  int16_t *b = st->ring + d;
+  for (int k = 0; k < (low_pow ? 64 : 128); k++) xin[k] = x[k];
+  if (low_pow)
+    xq_dct2_64_lp(xin, t, b);
+  else
+    xq_synth_hq_slot(xin, t, b, out_scale + 1);
+  /* generic:1508: 10-tap polyphase sum (cannot saturate: sum|c| = 57308), then the output shift */
+  const int shift = low_pow ? 2 : 1;
+  const int16_t *t1 = st->ring + fp1, *t2 = st->ring + fp2, *cf = c + ph;
+  for (int k = 0; k < 64; k++) {
+    int32_t acc = 0x8000 >> shift;
+    for (int m = 0; m < 5; m++) acc = fx_add_sat(acc, (int32_t)t1[256 * m + k] * cf[k + 128 * m]);
+    for (int m = 0; m < 5; m++) acc = fx_add_sat(acc, (int32_t)t2[128 + 256 * m + k] * cf[k + 64 + 128 * m]);
+    pcm[stride * k] = (int16_t)(fx_shl_sat(acc, shift) >> 16);
+  }
+  d -= 128;
+  if (d < 0) d += 1280;
+  ph += 64;
+  if (ph == 640) ph = 0;
+  st->drc_offset = (int16_t)d;
+  st->phase = (int16_t)ph;
+}
+
 /* One frame: 32 slots -> 2048 PCM16 at `stride`.  qmf rows as for analysis (64 reals, +64 imaginaries in HQ);
    they are NOT modified here (the reference scales and transforms them in place).
    sf = {lb_scale, ov_lb_scale, hb_scale, st_syn_scale}; no PS (active = 0). */
@@ -120,12 +152,8 @@ void xo_qmf_synthesis(const int32_t *qmf, int slot_stride, const int16_t *sf, in
   const int ov_lb_shift = (st_syn - ov_lb_scale) - bias, lb_shift = (st_syn - lb_scale) - bias,
             hb_shift = (st_syn - hb_scale) - bias;
   const int out_scale = low_pow ? -(st_syn - 1) : -(st_syn - 3);
-  const int16_t *c = xaac_qmf_qmf_c;
-  int d = st->drc_offset, ph = st->phase;
-  int fp1 = 0, fp2 = 64;
   for (int s = 0; s < 32; s++) {
-    int32_t x[128], t[128];
-    int16_t *b = st->ring + d;
+    int32_t x[128];
     const int32_t *row = qmf + (size_t)s * slot_stride;
     const int nparts = low_pow ? 1 : 2;
     for (int p = 0; p < nparts; p++)
@@ -137,28 +165,8 @@ void xo_qmf_synthesis(const int32_t *qmf, int slot_stride, const int16_t *sf, in
           v = adj(v, hb_shift);
         x[64 * p + k] = v;
       }
-    if (low_pow) {
-      xq_dct2_64_lp(x, t, b);
-    } else {
-      xq_synth_hq_slot(x, t, b, out_scale + 1);
-    }
-    /* generic:1508: 10-tap polyphase sum (cannot saturate: sum|c| = 57308), then the output shift */
-    const int shift = low_pow ? 2 : 1;
-    const int16_t *t1 = st->ring + fp1, *t2 = st->ring + fp2, *cf = c + ph;
-    for (int k = 0; k < 64; k++) {
-      int32_t acc = 0x8000 >> shift;
-      for (int m = 0; m < 5; m++) acc = fx_add_sat(acc, (int32_t)t1[256 * m + k] * cf[k + 128 * m]);
-      for (int m = 0; m < 5; m++) acc = fx_add_sat(acc, (int32_t)t2[128 + 256 * m + k] * cf[k + 64 + 128 * m]);
-      pcm[stride * (64 * s + k)] = (int16_t)(fx_shl_sat(acc, shift) >> 16);
-    }
-    d -= 128;
-    if (d < 0) d += 1280;
-    { int tmp = fp1; fp1 = fp2; fp2 = tmp; }
-    ph += 64;
-    if (ph == 640) ph = 0;
+    xo_qmf_synthesis_slot(x, st, s, low_pow, out_scale, pcm + (size_t)stride * 64 * s, stride);
   }
-  st->drc_offset = (int16_t)d;
-  st->phase = (int16_t)ph;
 }
 
 }  // extern "C"

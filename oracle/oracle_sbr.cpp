@@ -13,8 +13,13 @@
  */
 #include <stdint.h>
 #include <string.h>
+#ifdef XO_PS_DEBUG
+#include <stdio.h>
+#include <stdlib.h>
+#endif
 
 #include "../libxaac_amd/csrc/sbr_core.h"
+#include "../libxaac_amd/csrc/sbr_ps.h"
 #include "oracle_qmf.h"
 
 static const int16_t *rand_hi_table() {
@@ -53,7 +58,7 @@ extern "C" int xo_sbr_dec_lp(const xaac_sbr_header *h, const xaac_sbr_frame *f, 
     st->lb_scale = -10;
   }
   int save_lb_scale = 0;
-  if (xs_sbr_core_lp(cx, h, f, st, x, &w, rand_hi_table(), &save_lb_scale)) return -1;
+  if (xs_sbr_core(cx, h, f, st, x, &w, rand_hi_table(), &save_lb_scale)) return -1;
   /* sbr_dec.c:1273: synthesis bank over slots 0..31 */
   {
     xo_qmf_syn_state s;
@@ -69,6 +74,119 @@ extern "C" int xo_sbr_dec_lp(const xaac_sbr_header *h, const xaac_sbr_frame *f, 
   /* sbr_dec.c:1283-1308 */
   for (int l = 0; l < 6; l++)
     for (int k = 0; k < 64; k++) st->overlap[64 * l + k] = x(32 + l, k);
+  st->ov_lb_scale = (int16_t)save_lb_scale;
+  return 0;
+}
+
+static inline int32_t adj_word(int32_t v, int shift) { /* env_calc.c:1099 on one word */
+  if (shift == 0) return v;
+  if (shift > 31) shift = 31;
+  if (shift < -31) shift = -31;
+  return shift > 0 ? fx_shlw(v, shift) : (v >> -shift);
+}
+
+/* One frame of ixheaacd_sbr_dec in HQ (complex) mode: low_pow_flag = 0, i.e. HE-AAC mono and, with
+   pf / ps given and channel_mode = PS_STEREO, HE-AACv2 (sbr_dec.c:1246-1281: the left synthesis bank
+   runs the parametric-stereo tool slot by slot, the right one consumes what it leaves in the matrix).
+   pcm_out: left at [n * out_stride], right at [n * out_stride + 1]. */
+extern "C" int xo_sbr_dec_hq(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st,
+                             const xaac_ps_frame *pf, xaac_ps_state *ps, const int16_t *pcm_in, int in_stride,
+                             int16_t *pcm_out, int out_stride) {
+  static thread_local int32_t buf[41 * 128];
+  XsQmfHq x = {buf};
+  const XsCx cx = {0, 1};
+  XsWork w;
+  memset(buf, 0, sizeof(buf));
+  /* sbr_dec.c:753: twelve half-rows = six complex overlap slots */
+  memcpy(&x(0, 0), st->overlap, sizeof(int32_t) * 12 * 64);
+  st->lb_scale = 0;
+  if (f->apply_processing) xs_rescale_x_overlap(cx, h, f, st, x);
+  {
+    xo_qmf_ana_state a;
+    memcpy(a.ring, st->ana_ring, sizeof(a.ring));
+    a.wr = st->ana_wr;
+    a.phase = st->ana_phase;
+    xo_qmf_analysis(pcm_in, in_stride, &a, 0, st->codec_usb, &x(6, 0), 128);
+    memcpy(st->ana_ring, a.ring, sizeof(a.ring));
+    st->ana_wr = a.wr;
+    st->ana_phase = a.phase;
+    st->st_lb_scale = 0;
+    st->lb_scale = -8; /* generic:631 */
+  }
+  int save_lb_scale = 0;
+  if (xs_sbr_core(cx, h, f, st, x, &w, rand_hi_table(), &save_lb_scale)) return -1;
+  xo_qmf_syn_state s;
+  memcpy(s.ring, st->syn_ring, sizeof(s.ring));
+  s.drc_offset = st->syn_drc_offset;
+  s.phase = st->syn_phase;
+  if (f->apply_processing && h->channel_mode == 3 && pf && ps) {
+    const int ps_scale = xp_init_ps_scale(ps, st->lb_scale, st->ov_lb_scale, st->hb_scale);
+    st->ps_scale = (int16_t)ps_scale;
+    const int lsb = st->syn_lsb, usb = st->syn_usb, st_syn = st->st_syn_scale;
+    const int ov_lb_shift = ps_scale - st->ov_lb_scale, lb_shift = ps_scale - st->lb_scale,
+              hb_shift = ps_scale - st->hb_scale, common_shift = (st_syn - ps_scale) - 8;
+    for (int l = 0; l < 32; l++)
+      for (int k = 0; k < 64; k++) {
+        const int sh = k < lsb ? (l < 6 ? ov_lb_shift : lb_shift) : (k < usb ? hb_shift : 0);
+        x(l, k) = adj_word(x(l, k), sh);
+        x.im(l, k) = adj_word(x.im(l, k), sh);
+      }
+    int env = 0;
+    for (int l = 0; l < 32; l++) {
+      int32_t right[128];
+      XpHyb hy;
+      memset(&hy, 0, sizeof(hy));
+      if (l == pf->border_position[env]) {
+        xp_init_rot_env(ps, pf, env, usb);
+        env++;
+      }
+      const int shiftdelay = l < 32 - 6 ? 0 : (int16_t)(st->lb_scale - ps_scale); /* thumb_ps_dec.c:77 */
+      xp_hybrid_analysis(&x(l + 6, 0), ps, &hy, shiftdelay);
+      xp_decorrelation(ps, &hy, &x(l, 0), right);
+      xp_apply_rot(ps, &hy, &x(l, 0), right);
+#ifdef XO_PS_DEBUG
+      {
+        static FILE *df;
+        const char *dp = getenv("XO_PS_DUMP");
+        if (dp) {
+          int32_t sl = l;
+          if (!df) df = fopen(dp, "wb");
+          fwrite(&sl, 4, 1, df);
+          fwrite(&x(l, 0), 4, 128, df);
+          fwrite(right, 4, 128, df);
+          fflush(df);
+        }
+      }
+#endif
+      if (common_shift) /* generic:1610 */
+        for (int k = 0; k < 128; k++) {
+          int32_t *p = &x(l, 0) + k;
+          *p = common_shift < 0 ? fx_shr(*p, -common_shift > 31 ? 31 : -common_shift) : fx_shl_sat(*p, common_shift);
+        }
+      xo_qmf_synthesis_slot(&x(l, 0), &s, l, 0, -(st_syn - 3), pcm_out + (size_t)out_stride * 64 * l, out_stride);
+      memcpy(&x(l, 0), right, sizeof(right));
+    }
+    /* right channel: all three scales are ps_scale (sbr_dec.c:1261-1264) */
+    ps->lb_scale_r = ps->ov_lb_scale_r = ps->hb_scale_r = (int16_t)ps_scale;
+    xo_qmf_syn_state r;
+    memcpy(r.ring, ps->syn_ring_r, sizeof(r.ring));
+    r.drc_offset = ps->syn_drc_offset_r;
+    r.phase = ps->syn_phase_r;
+    const int16_t sf_r[4] = {(int16_t)ps_scale, (int16_t)ps_scale, (int16_t)ps_scale, ps->st_syn_scale_r};
+    xo_qmf_synthesis(&x(0, 0), 128, sf_r, ps->syn_lsb_r, ps->syn_usb_r, 6, &r, 0, pcm_out + 1, out_stride);
+    memcpy(ps->syn_ring_r, r.ring, sizeof(r.ring));
+    ps->syn_drc_offset_r = r.drc_offset;
+    ps->syn_phase_r = r.phase;
+  } else {
+    const int16_t sf[4] = {st->lb_scale, st->ov_lb_scale, st->hb_scale, st->st_syn_scale};
+    xo_qmf_synthesis(&x(0, 0), 128, sf, st->syn_lsb, st->syn_usb, 6, &s, 0, pcm_out, out_stride);
+  }
+  memcpy(st->syn_ring, s.ring, sizeof(s.ring));
+  st->syn_drc_offset = s.drc_offset;
+  st->syn_phase = s.phase;
+  /* sbr_dec.c:1283-1291 copies 6 * 64 words whatever the mode: in HQ that is the first three of the six
+     complex overlap slots -- the other three keep what they held (kept as is: it is the reference's output) */
+  memcpy(st->overlap, &x(32, 0), sizeof(int32_t) * 6 * 64);
   st->ov_lb_scale = (int16_t)save_lb_scale;
   return 0;
 }

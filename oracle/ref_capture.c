@@ -154,6 +154,56 @@ static void to_state(const ia_sbr_dec_struct *d, const ia_sbr_prev_frame_data_st
   memcpy(o->harm_flags_prev, e->harm_flags_prev, sizeof(o->harm_flags_prev));
 }
 
+static void to_ps_frame(const ia_ps_dec_struct *ps, xaac_ps_frame *o) {
+  memset(o, 0, sizeof(*o));
+  o->iid_quant = (int16_t)ps->iid_quant;
+  memcpy(o->border_position, ps->border_position, sizeof(o->border_position));
+  memcpy(o->iid_par_table, ps->iid_par_table, sizeof(o->iid_par_table));
+  memcpy(o->icc_par_table, ps->icc_par_table, sizeof(o->icc_par_table));
+}
+
+static void to_ps_state(const ia_ps_dec_struct *ps, const ia_sbr_qmf_filter_bank_struct *sr,
+                        const ia_sbr_scale_fact_struct *sf_r, xaac_ps_state *o) {
+  int i;
+  memset(o, 0, sizeof(*o));
+  memcpy(o->ser, ps->delay_buf_qmf_ser_re_im, sizeof(o->ser));
+  memcpy(o->ap, ps->delay_buf_qmf_ap_re_im, sizeof(o->ap));
+  memcpy(o->ld, ps->delay_buf_qmf_ld_re_im, sizeof(o->ld));
+  memcpy(o->sd, ps->delay_buf_qmf_sd_re_im, 58 * sizeof(WORD16));
+  memcpy(o->sub, ps->delay_buf_qmf_sub_re_im, sizeof(o->sub));
+  memcpy(o->sub_ser, ps->delay_buf_qmf_sub_ser_re_im, sizeof(o->sub_ser));
+  for (i = 0; i < 3; i++) {
+    o->idx_ser[i] = ps->delay_buf_idx_ser[i];
+    o->sample_ser[i] = ps->delay_sample_ser[i];
+  }
+  o->idx = ps->delay_buf_idx;
+  o->idx_long = ps->delay_buf_idx_long;
+  memcpy(o->peak_decay_diff, ps->peak_decay_diff, sizeof(o->peak_decay_diff));
+  memcpy(o->energy_prev, ps->energy_prev, sizeof(o->energy_prev));
+  memcpy(o->peak_decay_diff_prev, ps->peak_decay_diff_prev, sizeof(o->peak_decay_diff_prev));
+  for (i = 0; i < 3; i++) {
+    memcpy(o->hyb_buf[i][0], ps->str_hybrid.ptr_qmf_buf_re[i], 12 * sizeof(WORD32));
+    memcpy(o->hyb_buf[i][1], ps->str_hybrid.ptr_qmf_buf_im[i], 12 * sizeof(WORD32));
+  }
+  memcpy(o->h11_h12_vec, ps->h11_h12_vec, sizeof(o->h11_h12_vec));
+  memcpy(o->h21_h22_vec, ps->h21_h22_vec, sizeof(o->h21_h22_vec));
+  memcpy(o->H11_H12, ps->H11_H12, sizeof(o->H11_H12));
+  memcpy(o->H21_H22, ps->H21_H22, sizeof(o->H21_H22));
+  memcpy(o->delta_h11_h12, ps->delta_h11_h12, sizeof(o->delta_h11_h12));
+  memcpy(o->delta_h21_h22, ps->delta_h21_h22, sizeof(o->delta_h21_h22));
+  o->delay_buffer_scale = ps->delay_buffer_scale;
+  o->usb = ps->usb;
+  memcpy(o->syn_ring_r, sr->filter_states, sizeof(o->syn_ring_r));
+  o->syn_drc_offset_r = sr->ixheaacd_drc_offset;
+  o->syn_phase_r = (int16_t)(sr->filter_pos_syn - sr->p_filter);
+  o->syn_lsb_r = sr->lsb;
+  o->syn_usb_r = sr->usb;
+  o->st_syn_scale_r = sf_r->st_syn_scale;
+  o->lb_scale_r = sf_r->lb_scale;
+  o->ov_lb_scale_r = sf_r->ov_lb_scale;
+  o->hb_scale_r = sf_r->hb_scale;
+}
+
 WORD32 __real_ixheaacd_sbr_dec(ia_sbr_dec_struct *, WORD16 *, ia_sbr_header_data_struct *,
                                ia_sbr_frame_info_data_struct *, ia_sbr_prev_frame_data_struct *, ia_ps_dec_struct *,
                                ia_sbr_qmf_filter_bank_struct *, ia_sbr_scale_fact_struct *, FLAG, FLAG, WORD32 *,
@@ -170,6 +220,8 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
   static xaac_sbr_header hd;
   static xaac_sbr_frame fr;
   static xaac_sbr_state st0, st1;
+  static xaac_ps_frame psf;
+  static xaac_ps_state ps0, ps1;
   int16_t in[1024], outp[2][2048];
   int32_t meta[8];
   WORD32 ret;
@@ -181,10 +233,15 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
   to_header(h, d, &hd);
   to_frame(f, apply, &fr);
   to_state(d, p, low_pow, &st0);
+  if (ps_on) {
+    to_ps_frame(ps, &psf);
+    to_ps_state(ps, synth_r, sf_r, &ps0);
+  }
   for (i = 0; i < 1024; i++) in[i] = time_data[i * ch_fac];
   ret = __real_ixheaacd_sbr_dec(d, time_data, h, f, p, ps, synth_r, sf_r, apply, low_pow, work, tabs, common, ch_fac,
                                 pvc, drc_on, drc, aot, ldmps, self, mps, ec);
   to_state(d, p, low_pow, &st1);
+  if (ps_on) to_ps_state(ps, synth_r, sf_r, &ps1);
   for (i = 0; i < 2048; i++) {
     outp[0][i] = time_data[i * ch_fac];
     outp[1][i] = ps_on ? time_data[i * ch_fac + 1] : 0;
@@ -204,6 +261,69 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
   fwrite(in, sizeof(in), 1, g_out);
   fwrite(&st1, sizeof(st1), 1, g_out);
   fwrite(outp, sizeof(outp), 1, g_out);
+  if (ps_on) { /* HE-AACv2 records carry the PS side info and state as well */
+    fwrite(&psf, sizeof(psf), 1, g_out);
+    fwrite(&ps0, sizeof(ps0), 1, g_out);
+    fwrite(&ps1, sizeof(ps1), 1, g_out);
+  }
   fflush(g_out);
   return ret;
+}
+
+/* Debug aid: with $XAAC_PS_DUMP set, every ixheaacd_apply_ps call (thumb_ps_dec.c:69) appends
+   {slot, left re[64] im[64], right re[64] im[64]} after the call to that file. */
+VOID __real_ixheaacd_apply_ps(ia_ps_dec_struct *, WORD32 **, WORD32 **, WORD32 *, WORD32 *, ia_sbr_scale_fact_struct *,
+                              WORD16, ia_sbr_tables_struct *, WORD);
+VOID __wrap_ixheaacd_apply_ps(ia_ps_dec_struct *ps, WORD32 **lr, WORD32 **li, WORD32 *rr, WORD32 *ri,
+                              ia_sbr_scale_fact_struct *sf, WORD16 slot, ia_sbr_tables_struct *t, WORD no_col) {
+  static FILE *f;
+  const char *path = getenv("XAAC_PS_DUMP");
+  if (path && getenv("XAAC_PS_DUMP_PRE")) {
+    int32_t s = -1 - slot;
+    if (!f) f = fopen(path, "wb");
+    fwrite(&s, 4, 1, f);
+    fwrite(lr[0], 4, 64, f);
+    fwrite(li[0], 4, 64, f);
+    fwrite(rr, 4, 64, f);
+    fwrite(ri, 4, 64, f);
+  }
+  __real_ixheaacd_apply_ps(ps, lr, li, rr, ri, sf, slot, t, no_col);
+  if (path) {
+    int32_t s = slot;
+    if (!f) f = fopen(path, "wb");
+    fwrite(&s, 4, 1, f);
+    fwrite(lr[0], 4, 64, f);
+    fwrite(li[0], 4, 64, f);
+    fwrite(rr, 4, 64, f);
+    fwrite(ri, 4, 64, f);
+    fflush(f);
+  }
+}
+
+/* Debug aid: with $XAAC_SYN_DUMP set, every ixheaacd_cplx_synt_qmffilt call (qmf_dec.c:811) appends
+   {active, lb, ov_lb, hb, ps, st_syn scales, lsb, usb, 32 rows x (64 re | 64 im)} on entry. */
+VOID __real_ixheaacd_cplx_synt_qmffilt(WORD32 **, WORD32 **, WORD32, WORD32 **, WORD32 **, ia_sbr_scale_fact_struct *,
+                                       WORD16 *, ia_sbr_qmf_filter_bank_struct *, ia_ps_dec_struct *, FLAG, FLAG,
+                                       ia_sbr_tables_struct *, ixheaacd_misc_tables *, WORD32, FLAG, WORD32[][64],
+                                       WORD32);
+VOID __wrap_ixheaacd_cplx_synt_qmffilt(WORD32 **re, WORD32 **im, WORD32 split, WORD32 **ore, WORD32 **oim,
+                                       ia_sbr_scale_fact_struct *sf, WORD16 *out, ia_sbr_qmf_filter_bank_struct *bank,
+                                       ia_ps_dec_struct *ps, FLAG active, FLAG low_pow, ia_sbr_tables_struct *t,
+                                       ixheaacd_misc_tables *c, WORD32 ch_fac, FLAG drc_on, WORD32 drc[][64],
+                                       WORD32 aot) {
+  static FILE *f;
+  const char *path = getenv("XAAC_SYN_DUMP");
+  if (path && !low_pow) {
+    int32_t m[8] = {active, sf->lb_scale, sf->ov_lb_scale, sf->hb_scale, sf->ps_scale, sf->st_syn_scale, bank->lsb, bank->usb};
+    int i;
+    if (!f) f = fopen(path, "wb");
+    fwrite(m, 4, 8, f);
+    for (i = 0; i < 32; i++) {
+      fwrite(re[i], 4, 64, f);
+      fwrite(im[i], 4, 64, f);
+    }
+    fflush(f);
+  }
+  __real_ixheaacd_cplx_synt_qmffilt(re, im, split, ore, oim, sf, out, bank, ps, active, low_pow, t, c, ch_fac, drc_on, drc,
+                                    aot);
 }

@@ -54,9 +54,11 @@
 
 #include "xaac_sbr.h"
 
-/* low-power (HE-AACv1) channel-frame through the real ixheaacd_sbr_dec */
-int ref_sbr_dec_lp(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st, const int16_t *pcm_in,
-                   int in_stride, int16_t *pcm_out, int out_stride) {
+/* one channel-frame through the real ixheaacd_sbr_dec: low-power (HE-AACv1), HQ, or HQ + parametric stereo
+   (pf / ps given and channel_mode = PS_STEREO: right channel at pcm_out[n * out_stride + 1]) */
+static int run_sbr_dec(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st, const xaac_ps_frame *psf,
+                       xaac_ps_state *pss, int low_pow, const int16_t *pcm_in, int in_stride, int16_t *pcm_out,
+                       int out_stride) {
   static __thread ia_sbr_dec_struct d;
   static __thread ia_sbr_header_data_struct hd;
   static __thread ia_freq_band_data_struct fb;
@@ -65,7 +67,13 @@ int ref_sbr_dec_lp(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_s
   static __thread ia_sbr_tables_struct tabs;
   static __thread WORD64 frame_mem[(sizeof(ia_sbr_frame_info_data_struct) + 1024) / 8 + 2];
   static __thread WORD32 work[64 * 48 * 2 + 1024];
-  static __thread WORD32 overlap[6 * 64 * 2], lpc[2][32], copy_re[MAX_ENV_COLS][64];
+  static __thread WORD32 overlap[6 * 64 * 2], lpc[2][64], lpc_im[2][64], copy_re[MAX_ENV_COLS][64];
+  static __thread ia_ps_dec_struct psd;
+  static __thread ia_sbr_qmf_filter_bank_struct bank_r;
+  static __thread ia_sbr_scale_fact_struct sf_r;
+  static __thread WORD16 ps_ser[5][3][64], ps_ap[2][64], ps_ld_sd[14 * 24 + 64], syn_ring_r[1280];
+  static __thread WORD32 ps_hyb[64], ps_work[32], ps_hbuf[3][2][12], ps_peak[60], ps_temp[16];
+  const int use_ps = psf && pss && h->channel_mode == PS_STEREO;
   static __thread WORD16 time_data[2048 * 2];
   static __thread WORD16 ana_ring[320], syn_ring[1280], filt_me[2 * MAX_FREQ_COEFFS], filt_noise[MAX_FREQ_COEFFS];
   ia_sbr_frame_info_data_struct *fr = (ia_sbr_frame_info_data_struct *)frame_mem;
@@ -127,7 +135,12 @@ int ref_sbr_dec_lp(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_s
   memcpy(ana_ring, st->ana_ring, sizeof(ana_ring));
   memcpy(syn_ring, st->syn_ring, sizeof(syn_ring));
   memcpy(overlap, st->overlap, sizeof(overlap));
-  memcpy(lpc, st->lpc_real, sizeof(lpc));
+  memset(lpc, 0, sizeof(lpc));
+  memset(lpc_im, 0, sizeof(lpc_im));
+  for (i = 0; i < 2; i++) {
+    memcpy(lpc[i], st->lpc_real[i], 32 * sizeof(WORD32));
+    memcpy(lpc_im[i], st->lpc_imag[i], 32 * sizeof(WORD32));
+  }
   memcpy(filt_me, st->filt_buf_me, sizeof(filt_me));
   memcpy(filt_noise, st->filt_buf_noise_m, sizeof(filt_noise));
   d.ptr_sbr_overlap_buf = overlap;
@@ -150,6 +163,8 @@ int ref_sbr_dec_lp(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_s
   d.str_hf_generator.pstr_settings = &ts;
   d.str_hf_generator.lpc_filt_states_real[0] = lpc[0];
   d.str_hf_generator.lpc_filt_states_real[1] = lpc[1];
+  d.str_hf_generator.lpc_filt_states_imag[0] = lpc_im[0];
+  d.str_hf_generator.lpc_filt_states_imag[1] = lpc_im[1];
   memcpy(d.str_hf_generator.bw_array_prev, st->bw_array_prev, sizeof(st->bw_array_prev));
   d.str_sbr_scale_fact.lb_scale = st->lb_scale;
   d.str_sbr_scale_fact.st_lb_scale = st->st_lb_scale;
@@ -172,11 +187,115 @@ int ref_sbr_dec_lp(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_s
   pf.coupling_mode = st->prev_coupling_mode;
   pf.end_position = st->prev_end_position;
   pf.amp_res = st->prev_amp_res;
-  for (i = 0; i < 1024; i++) time_data[i] = pcm_in[(size_t)i * in_stride];
-  ret = ixheaacd_sbr_dec(&d, time_data, &hd, fr, &pf, NULL, NULL, NULL, f->apply_processing, 1, work, &tabs,
-                         (ixheaacd_misc_tables *)&ixheaacd_str_fft_n_transcendent_tables, 1, NULL, 0, NULL, AOT_SBR, 0,
-                         NULL, 0, 0);
-  for (i = 0; i < 2048; i++) pcm_out[(size_t)i * out_stride] = time_data[i];
+  for (i = 0; i < 1024; i++) time_data[i * (use_ps ? 2 : 1)] = pcm_in[(size_t)i * in_stride];
+  if (use_ps) { /* ia_ps_dec_struct over local copies of the boundary state (layout: sbrdec_initfuncs.c:976) */
+    memset(&psd, 0, sizeof(psd));
+    memset(&bank_r, 0, sizeof(bank_r));
+    memset(&sf_r, 0, sizeof(sf_r));
+    tabs.ps_tables_ptr = (ia_ps_tables_struct *)&ixheaacd_aac_dec_ps_tables;
+    memcpy(ps_ser, pss->ser, sizeof(ps_ser));
+    memcpy(ps_ap, pss->ap, sizeof(ps_ap));
+    memcpy(ps_ld_sd, pss->ld, sizeof(pss->ld));
+    memcpy(ps_ld_sd + 14 * 24, pss->sd, sizeof(pss->sd));
+    psd.delay_buf_qmf_ser_re_im = (VOID *)ps_ser;
+    psd.delay_buf_qmf_ap_re_im = (VOID *)ps_ap;
+    psd.delay_buf_qmf_ld_re_im = (VOID *)ps_ld_sd;
+    psd.delay_buf_qmf_sd_re_im = (VOID *)(ps_ld_sd + 14 * 24);
+    memcpy(psd.delay_buf_qmf_sub_re_im, pss->sub, sizeof(pss->sub));
+    memcpy(psd.delay_buf_qmf_sub_ser_re_im, pss->sub_ser, sizeof(pss->sub_ser));
+    for (i = 0; i < 3; i++) {
+      psd.delay_buf_idx_ser[i] = pss->idx_ser[i];
+      psd.delay_sample_ser[i] = pss->sample_ser[i];
+    }
+    psd.delay_buf_idx = pss->idx;
+    psd.delay_buf_idx_long = pss->idx_long;
+    memcpy(ps_peak, pss->peak_decay_diff, 20 * 4);
+    memcpy(ps_peak + 20, pss->energy_prev, 20 * 4);
+    memcpy(ps_peak + 40, pss->peak_decay_diff_prev, 20 * 4);
+    psd.peak_decay_diff = ps_peak;
+    psd.energy_prev = ps_peak + 20;
+    psd.peak_decay_diff_prev = ps_peak + 40;
+    memset(ps_hyb, 0, sizeof(ps_hyb));
+    psd.ptr_hyb_left_re = ps_hyb;
+    psd.ptr_hyb_left_im = ps_hyb + 16;
+    psd.ptr_hyb_right_re = ps_hyb + 32;
+    psd.ptr_hyb_right_im = ps_hyb + 48;
+    memcpy(ps_hbuf, pss->hyb_buf, sizeof(ps_hbuf));
+    psd.str_hybrid.ptr_resol = ixheaacd_aac_dec_ps_tables.hyb_resol;
+    psd.str_hybrid.ptr_qmf_buf = HYBRID_FILTER_LENGTH - 1;
+    psd.str_hybrid.ptr_temp_re = ps_temp;
+    psd.str_hybrid.ptr_temp_im = ps_temp + 8;
+    psd.str_hybrid.ptr_work_re = ps_work;
+    psd.str_hybrid.ptr_work_im = ps_work + 16;
+    for (i = 0; i < 3; i++) {
+      psd.str_hybrid.ptr_qmf_buf_re[i] = ps_hbuf[i][0];
+      psd.str_hybrid.ptr_qmf_buf_im[i] = ps_hbuf[i][1];
+    }
+    memcpy(psd.h11_h12_vec, pss->h11_h12_vec, sizeof(pss->h11_h12_vec));
+    memcpy(psd.h21_h22_vec, pss->h21_h22_vec, sizeof(pss->h21_h22_vec));
+    memcpy(psd.H11_H12, pss->H11_H12, sizeof(pss->H11_H12));
+    memcpy(psd.H21_H22, pss->H21_H22, sizeof(pss->H21_H22));
+    memcpy(psd.delta_h11_h12, pss->delta_h11_h12, sizeof(pss->delta_h11_h12));
+    memcpy(psd.delta_h21_h22, pss->delta_h21_h22, sizeof(pss->delta_h21_h22));
+    psd.delay_buffer_scale = pss->delay_buffer_scale;
+    psd.usb = pss->usb;
+    psd.iid_quant = psf->iid_quant;
+    memcpy(psd.border_position, psf->border_position, sizeof(psf->border_position));
+    memcpy(psd.iid_par_table, psf->iid_par_table, sizeof(psf->iid_par_table));
+    memcpy(psd.icc_par_table, psf->icc_par_table, sizeof(psf->icc_par_table));
+    memcpy(syn_ring_r, pss->syn_ring_r, sizeof(syn_ring_r));
+    bank_r.no_channels = 64;
+    bank_r.num_time_slots = 32;
+    bank_r.lsb = pss->syn_lsb_r;
+    bank_r.usb = pss->syn_usb_r;
+    bank_r.filter_states = syn_ring_r;
+    bank_r.p_filter = qt->qmf_c;
+    bank_r.filter_pos_syn = qt->qmf_c + pss->syn_phase_r;
+    bank_r.ixheaacd_drc_offset = pss->syn_drc_offset_r;
+    sf_r.st_syn_scale = pss->st_syn_scale_r;
+    sf_r.lb_scale = pss->lb_scale_r;
+    sf_r.ov_lb_scale = pss->ov_lb_scale_r;
+    sf_r.hb_scale = pss->hb_scale_r;
+  }
+  ret = ixheaacd_sbr_dec(&d, time_data, &hd, fr, &pf, use_ps ? &psd : NULL, use_ps ? &bank_r : NULL,
+                         use_ps ? &sf_r : NULL, f->apply_processing, low_pow, work, &tabs,
+                         (ixheaacd_misc_tables *)&ixheaacd_str_fft_n_transcendent_tables, use_ps ? 2 : 1, NULL, 0, NULL,
+                         use_ps ? AOT_PS : AOT_SBR, 0, NULL, 0, 0);
+  if (use_ps) {
+    for (i = 0; i < 2048; i++) {
+      pcm_out[(size_t)i * out_stride] = time_data[2 * i];
+      pcm_out[(size_t)i * out_stride + 1] = time_data[2 * i + 1];
+    }
+    memcpy(pss->ser, ps_ser, sizeof(ps_ser));
+    memcpy(pss->ap, ps_ap, sizeof(ps_ap));
+    memcpy(pss->ld, ps_ld_sd, sizeof(pss->ld));
+    memcpy(pss->sd, ps_ld_sd + 14 * 24, sizeof(pss->sd));
+    memcpy(pss->sub, psd.delay_buf_qmf_sub_re_im, sizeof(pss->sub));
+    memcpy(pss->sub_ser, psd.delay_buf_qmf_sub_ser_re_im, sizeof(pss->sub_ser));
+    for (i = 0; i < 3; i++) pss->idx_ser[i] = psd.delay_buf_idx_ser[i];
+    pss->idx = psd.delay_buf_idx;
+    pss->idx_long = psd.delay_buf_idx_long;
+    memcpy(pss->peak_decay_diff, ps_peak, 20 * 4);
+    memcpy(pss->energy_prev, ps_peak + 20, 20 * 4);
+    memcpy(pss->peak_decay_diff_prev, ps_peak + 40, 20 * 4);
+    memcpy(pss->hyb_buf, ps_hbuf, sizeof(ps_hbuf));
+    memcpy(pss->h11_h12_vec, psd.h11_h12_vec, sizeof(pss->h11_h12_vec));
+    memcpy(pss->h21_h22_vec, psd.h21_h22_vec, sizeof(pss->h21_h22_vec));
+    memcpy(pss->H11_H12, psd.H11_H12, sizeof(pss->H11_H12));
+    memcpy(pss->H21_H22, psd.H21_H22, sizeof(pss->H21_H22));
+    memcpy(pss->delta_h11_h12, psd.delta_h11_h12, sizeof(pss->delta_h11_h12));
+    memcpy(pss->delta_h21_h22, psd.delta_h21_h22, sizeof(pss->delta_h21_h22));
+    pss->delay_buffer_scale = psd.delay_buffer_scale;
+    pss->usb = psd.usb;
+    memcpy(pss->syn_ring_r, syn_ring_r, sizeof(syn_ring_r));
+    pss->syn_drc_offset_r = bank_r.ixheaacd_drc_offset;
+    pss->syn_phase_r = (int16_t)(bank_r.filter_pos_syn - qt->qmf_c);
+    pss->lb_scale_r = sf_r.lb_scale;
+    pss->ov_lb_scale_r = sf_r.ov_lb_scale;
+    pss->hb_scale_r = sf_r.hb_scale;
+  } else {
+    for (i = 0; i < 2048; i++) pcm_out[(size_t)i * out_stride] = time_data[i];
+  }
   /* state back */
   memcpy(st->ana_ring, ana_ring, sizeof(ana_ring));
   st->ana_wr = (int16_t)(d.str_codec_qmf_bank.core_samples_buffer - ana_ring);
@@ -187,8 +306,11 @@ int ref_sbr_dec_lp(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_s
   st->codec_usb = d.str_codec_qmf_bank.usb;
   st->syn_lsb = d.str_synthesis_qmf_bank.lsb;
   st->syn_usb = d.str_synthesis_qmf_bank.usb;
-  memcpy(st->overlap, overlap, sizeof(WORD32) * 6 * 64);
-  memcpy(st->lpc_real, lpc, sizeof(lpc));
+  memcpy(st->overlap, overlap, sizeof(overlap));
+  for (i = 0; i < 2; i++) {
+    memcpy(st->lpc_real[i], lpc[i], 32 * sizeof(WORD32));
+    memcpy(st->lpc_imag[i], lpc_im[i], 32 * sizeof(WORD32));
+  }
   memcpy(st->bw_array_prev, d.str_hf_generator.bw_array_prev, sizeof(st->bw_array_prev));
   st->lb_scale = d.str_sbr_scale_fact.lb_scale;
   st->st_lb_scale = d.str_sbr_scale_fact.st_lb_scale;
@@ -211,4 +333,14 @@ int ref_sbr_dec_lp(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_s
   st->harm_index = d.str_sbr_calc_env.harm_index;
   memcpy(st->harm_flags_prev, d.str_sbr_calc_env.harm_flags_prev, sizeof(st->harm_flags_prev));
   return ret;
+}
+
+int ref_sbr_dec_lp(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st, const int16_t *pcm_in,
+                   int in_stride, int16_t *pcm_out, int out_stride) {
+  return run_sbr_dec(h, f, st, NULL, NULL, 1, pcm_in, in_stride, pcm_out, out_stride);
+}
+
+int ref_sbr_dec_hq(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st, const xaac_ps_frame *pf,
+                   xaac_ps_state *ps, const int16_t *pcm_in, int in_stride, int16_t *pcm_out, int out_stride) {
+  return run_sbr_dec(h, f, st, pf, ps, 0, pcm_in, in_stride, pcm_out, out_stride);
 }

@@ -42,10 +42,26 @@ class State(ctypes.Structure):
                 ("harm_flags_prev", I8 * 56)]
 
 
+class PsFrame(ctypes.Structure):
+    _fields_ = [("iid_quant", I16), ("pad0_", I16), ("border_position", I16 * 7), ("pad1_", I16),
+                ("iid_par_table", (I16 * 34) * 7), ("icc_par_table", (I16 * 34) * 7)]
+
+
+class PsState(ctypes.Structure):
+    _fields_ = [("ser", ((I16 * 64) * 3) * 5), ("ap", (I16 * 64) * 2), ("ld", (I16 * 24) * 14), ("sd", I16 * 64),
+                ("sub", (I16 * 32) * 2), ("sub_ser", ((I16 * 32) * 3) * 5), ("idx_ser", I16 * 3), ("sample_ser", I16 * 3),
+                ("idx", I16), ("idx_long", I16), ("peak_decay_diff", I32 * 20), ("energy_prev", I32 * 20),
+                ("peak_decay_diff_prev", I32 * 20), ("hyb_buf", ((I32 * 12) * 2) * 3), ("h11_h12_vec", I16 * 48),
+                ("h21_h22_vec", I16 * 48), ("H11_H12", I16 * 48), ("H21_H22", I16 * 48), ("delta_h11_h12", I16 * 48),
+                ("delta_h21_h22", I16 * 48), ("delay_buffer_scale", I16), ("usb", I16), ("syn_ring_r", I16 * 1280),
+                ("syn_drc_offset_r", I16), ("syn_phase_r", I16), ("syn_lsb_r", I16), ("syn_usb_r", I16),
+                ("st_syn_scale_r", I16), ("lb_scale_r", I16), ("ov_lb_scale_r", I16), ("hb_scale_r", I16)]
+
+
 def diff_state(a, b):
     """list of (field, detail) where two State structs differ"""
     out = []
-    for n, _ in State._fields_:
+    for n, _ in type(a)._fields_:
         va, vb = getattr(a, n), getattr(b, n)
         if hasattr(va, "__len__"):
             xa, xb = np.ctypeslib.as_array(va).ravel(), np.ctypeslib.as_array(vb).ravel()
@@ -73,9 +89,14 @@ def read_records(path, limit=None):
             pcm_in = np.frombuffer(f.read(2048), np.int16).copy()
             st1 = State.from_buffer_copy(f.read(ctypes.sizeof(State)))
             pcm_out = np.frombuffer(f.read(8192), np.int16).reshape(2, 2048).copy()
-            recs.append(dict(call=int(meta[1]), low_pow=int(meta[2]), ch_fac=int(meta[3]), aot=int(meta[4]),
-                             ps=int(meta[5]), ret=int(meta[6]), enh=int(meta[7]), header=hd, frame=fr, st0=st0,
-                             st1=st1, pcm_in=pcm_in, pcm_out=pcm_out))
+            rec = dict(call=int(meta[1]), low_pow=int(meta[2]), ch_fac=int(meta[3]), aot=int(meta[4]),
+                       ps=int(meta[5]), ret=int(meta[6]), enh=int(meta[7]), header=hd, frame=fr, st0=st0,
+                       st1=st1, pcm_in=pcm_in, pcm_out=pcm_out)
+            if rec["ps"]:       # HE-AACv2 records carry the PS side info and state (oracle/ref_capture.c)
+                rec["ps_frame"] = PsFrame.from_buffer_copy(f.read(ctypes.sizeof(PsFrame)))
+                rec["ps0"] = PsState.from_buffer_copy(f.read(ctypes.sizeof(PsState)))
+                rec["ps1"] = PsState.from_buffer_copy(f.read(ctypes.sizeof(PsState)))
+            recs.append(rec)
             if limit and len(recs) >= limit:
                 break
     return recs

@@ -21,7 +21,7 @@ def captures(reference, tmp_path_factory):
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "xaacdec_capture")):
         pytest.skip("capture build of the reference decoder missing")
     d = tmp_path_factory.mktemp("streams")
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_test_streams.py"), str(d)],
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_test_streams.py"), str(d), "5"],
                           stdout=subprocess.DEVNULL)
     files = sorted(glob.glob(os.path.join(str(d), "*aot5*.cap")))
     assert len(files) >= 6

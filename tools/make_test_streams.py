@@ -49,13 +49,15 @@ def signals(seconds=4.0):
     return out
 
 
-def main(outdir):
+def main(outdir, only_aot=None):
     os.makedirs(outdir, exist_ok=True)
     made = []
     for name, x in signals().items():
         wav = os.path.join(outdir, name + ".wav")
         write_wav(wav, x)
         for aot, br in ((5, 32000), (5, 48000), (5, 64000), (29, 24000), (29, 32000)):
+            if only_aot is not None and aot != only_aot:
+                continue
             tag = "%s_aot%d_%dk" % (name, aot, br // 1000)
             aac = os.path.join(outdir, tag + ".aac")
             cap = os.path.join(outdir, tag + ".cap")
@@ -70,4 +72,4 @@ def main(outdir):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "/tmp/xaac_streams")
+    main(sys.argv[1] if len(sys.argv) > 1 else "/tmp/xaac_streams", int(sys.argv[2]) if len(sys.argv) > 2 else None)
