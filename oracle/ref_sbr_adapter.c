@@ -67,7 +67,7 @@ static int run_sbr_dec(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_s
   static __thread ia_sbr_tables_struct tabs;
   static __thread WORD64 frame_mem[(sizeof(ia_sbr_frame_info_data_struct) + 1024) / 8 + 2];
   static __thread WORD32 work[64 * 48 * 2 + 1024];
-  static __thread WORD32 overlap[6 * 64 * 2], lpc[2][64], lpc_im[2][64], copy_re[MAX_ENV_COLS][64];
+  static __thread WORD32 overlap[6 * 64 * 2], lpc_all[4][32], copy_re[MAX_ENV_COLS][64];
   static __thread ia_ps_dec_struct psd;
   static __thread ia_sbr_qmf_filter_bank_struct bank_r;
   static __thread ia_sbr_scale_fact_struct sf_r;
@@ -135,12 +135,10 @@ static int run_sbr_dec(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_s
   memcpy(ana_ring, st->ana_ring, sizeof(ana_ring));
   memcpy(syn_ring, st->syn_ring, sizeof(syn_ring));
   memcpy(overlap, st->overlap, sizeof(overlap));
-  memset(lpc, 0, sizeof(lpc));
-  memset(lpc_im, 0, sizeof(lpc_im));
-  for (i = 0; i < 2; i++) {
-    memcpy(lpc[i], st->lpc_real[i], 32 * sizeof(WORD32));
-    memcpy(lpc_im[i], st->lpc_imag[i], 32 * sizeof(WORD32));
-  }
+  /* rows of 32 words back to back, as ixheaacd_sbrdec_initfuncs.c:239-259 lays them out (the reference
+     indexes row 0 past its end in places and lands in row 1) */
+  memcpy(lpc_all[0], st->lpc_real, 2 * 32 * sizeof(WORD32));
+  memcpy(lpc_all[2], st->lpc_imag, 2 * 32 * sizeof(WORD32));
   memcpy(filt_me, st->filt_buf_me, sizeof(filt_me));
   memcpy(filt_noise, st->filt_buf_noise_m, sizeof(filt_noise));
   d.ptr_sbr_overlap_buf = overlap;
@@ -161,10 +159,10 @@ static int run_sbr_dec(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_s
   d.str_synthesis_qmf_bank.filter_pos_syn = qt->qmf_c + st->syn_phase;
   d.str_synthesis_qmf_bank.ixheaacd_drc_offset = st->syn_drc_offset;
   d.str_hf_generator.pstr_settings = &ts;
-  d.str_hf_generator.lpc_filt_states_real[0] = lpc[0];
-  d.str_hf_generator.lpc_filt_states_real[1] = lpc[1];
-  d.str_hf_generator.lpc_filt_states_imag[0] = lpc_im[0];
-  d.str_hf_generator.lpc_filt_states_imag[1] = lpc_im[1];
+  d.str_hf_generator.lpc_filt_states_real[0] = lpc_all[0];
+  d.str_hf_generator.lpc_filt_states_real[1] = lpc_all[1];
+  d.str_hf_generator.lpc_filt_states_imag[0] = lpc_all[2];
+  d.str_hf_generator.lpc_filt_states_imag[1] = lpc_all[3];
   memcpy(d.str_hf_generator.bw_array_prev, st->bw_array_prev, sizeof(st->bw_array_prev));
   d.str_sbr_scale_fact.lb_scale = st->lb_scale;
   d.str_sbr_scale_fact.st_lb_scale = st->st_lb_scale;
@@ -307,10 +305,8 @@ static int run_sbr_dec(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_s
   st->syn_lsb = d.str_synthesis_qmf_bank.lsb;
   st->syn_usb = d.str_synthesis_qmf_bank.usb;
   memcpy(st->overlap, overlap, sizeof(overlap));
-  for (i = 0; i < 2; i++) {
-    memcpy(st->lpc_real[i], lpc[i], 32 * sizeof(WORD32));
-    memcpy(st->lpc_imag[i], lpc_im[i], 32 * sizeof(WORD32));
-  }
+  memcpy(st->lpc_real, lpc_all[0], 2 * 32 * sizeof(WORD32));
+  memcpy(st->lpc_imag, lpc_all[2], 2 * 32 * sizeof(WORD32));
   memcpy(st->bw_array_prev, d.str_hf_generator.bw_array_prev, sizeof(st->bw_array_prev));
   st->lb_scale = d.str_sbr_scale_fact.lb_scale;
   st->st_lb_scale = d.str_sbr_scale_fact.st_lb_scale;
