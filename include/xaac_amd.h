@@ -152,6 +152,31 @@ typedef struct xaac_sbr_lp_batch {
   uint64_t workspace_bytes;
 } xaac_sbr_lp_batch;
 
+/* --- HQ (complex) SBR channel-frames, optionally with parametric stereo ---------------------------
+ * ref: the same ixheaacd_sbr_dec with low_pow_flag = 0 -- HE-AAC mono and, with PS side info, HE-AACv2
+ *      (decoder/ixheaacd_sbr_dec.c:1246-1281: the left channel's synthesis bank runs the PS tool, the
+ *      right channel's bank consumes what it leaves).
+ * N independent streams, one frame each: mono core PCM16 (1024) + SBR (+ PS) side info -> 2048 PCM16, or
+ * with PS 2048 L,R pairs.  With PS every stream's channel_mode must be PS_STEREO; a stream whose frame
+ * is not processed (apply_processing = 0) gets its mono output on the left and its right-channel
+ * buffer and bank untouched, as in the reference. */
+typedef struct xaac_sbr_hq_batch {
+  int32_t n_ch;                    /* streams */
+  int32_t in_ch_fac;               /* interleave stride of pcm_in (1024 per stream) */
+  int32_t out_ch_fac;              /* without PS: interleave stride of pcm_out; with PS the output is L,R pairs */
+  int32_t pad_;
+  const int16_t *pcm_in;
+  const xaac_sbr_header *header;   /* [n_ch] */
+  const xaac_sbr_frame *frame;     /* [n_ch] */
+  xaac_sbr_state *state;           /* [n_ch] in/out */
+  const xaac_ps_frame *ps_frame;   /* [n_ch], or NULL together with ps_state: no parametric stereo */
+  xaac_ps_state *ps_state;         /* [n_ch] in/out */
+  int16_t *pcm_out;                /* n_ch x 2048 (x 2 with PS) */
+  int32_t *status;                 /* optional [n_ch] */
+  void *workspace;                 /* device scratch, >= xaac_sbr_hq_workspace_bytes(n_ch, ps_frame != NULL) */
+  uint64_t workspace_bytes;
+} xaac_sbr_hq_batch;
+
 typedef struct xaac_ctx xaac_ctx;
 
 /* Create a context bound to HIP device `device`.  `hip_stream` is a
@@ -177,6 +202,11 @@ int32_t xaac_qmf_synthesis_batch(xaac_ctx *ctx, const xaac_qmf_syn_batch *batch)
 /* Low-power SBR channel-frames (QMF analysis -> HF generation + envelope adjustment -> QMF synthesis). */
 uint64_t xaac_sbr_lp_workspace_bytes(int32_t n_ch);
 int32_t xaac_sbr_lp_process_batch(xaac_ctx *ctx, const xaac_sbr_lp_batch *batch);
+
+/* HQ SBR stream-frames (complex QMF analysis -> LPP transposer + envelope adjustment -> [parametric
+ * stereo] -> complex QMF synthesis, once per output channel). */
+uint64_t xaac_sbr_hq_workspace_bytes(int32_t n_ch, int32_t with_ps);
+int32_t xaac_sbr_hq_process_batch(xaac_ctx *ctx, const xaac_sbr_hq_batch *batch);
 
 /* Launch geometry the library used for the last batch (for reports). */
 int32_t xaac_last_launch(xaac_ctx *ctx, int32_t *grid, int32_t *block, int32_t *lds_bytes);

@@ -109,20 +109,25 @@ typedef struct xaac_ps_frame {
   int16_t icc_par_table[XAAC_PS_MAX_ENV + 2][XAAC_PS_BANDS_FINE];
 } xaac_ps_frame;
 
+/* The PS tool's own part of xaac_ps_state, as a macro so that the GPU kernel can keep exactly these members in
+ * LDS (libxaac_amd/csrc/sbr_ps_kernel.hip) without a second field list. */
+#define XAAC_PS_STATE_HEAD_FIELDS                                                                           \
+  int16_t ser[5][3][64];     /* delay_buf_qmf_ser_re_im: all-pass links of the QMF bands (re,im pairs) */   \
+  int16_t ap[2][64];         /* delay_buf_qmf_ap_re_im */                                                   \
+  int16_t ld[14][24];        /* delay_buf_qmf_ld_re_im: 14-slot delay, 12 bands */                          \
+  int16_t sd[64];            /* delay_buf_qmf_sd_re_im: 1-slot delay (58 used; contiguous with ld) */       \
+  int16_t sub[2][32];        /* delay_buf_qmf_sub_re_im: hybrid sub-bands */                                \
+  int16_t sub_ser[5][3][32]; /* delay_buf_qmf_sub_ser_re_im (contiguous with sub) */                        \
+  int16_t idx_ser[3], sample_ser[3];                                                                        \
+  int16_t idx, idx_long;                                                                                    \
+  int32_t peak_decay_diff[20], energy_prev[20], peak_decay_diff_prev[20]; /* contiguous, in this order */   \
+  int32_t hyb_buf[3][2][12]; /* str_hybrid.ptr_qmf_buf_re/_im: 12-slot history of QMF bands 0..2 */         \
+  int16_t h11_h12_vec[48], h21_h22_vec[48], H11_H12[48], H21_H22[48], delta_h11_h12[48], delta_h21_h22[48]; \
+  int16_t delay_buffer_scale, usb;
+
 /* Per-stream persistent PS state + the right channel's synthesis bank. */
 typedef struct xaac_ps_state {
-  int16_t ser[5][3][64];        /* delay_buf_qmf_ser_re_im: all-pass links of the QMF bands (re,im pairs) */
-  int16_t ap[2][64];            /* delay_buf_qmf_ap_re_im */
-  int16_t ld[14][24];           /* delay_buf_qmf_ld_re_im: 14-slot delay, 12 bands */
-  int16_t sd[64];               /* delay_buf_qmf_sd_re_im: 1-slot delay (58 used; contiguous with ld) */
-  int16_t sub[2][32];           /* delay_buf_qmf_sub_re_im: hybrid sub-bands */
-  int16_t sub_ser[5][3][32];    /* delay_buf_qmf_sub_ser_re_im (contiguous with sub) */
-  int16_t idx_ser[3], sample_ser[3];
-  int16_t idx, idx_long;
-  int32_t peak_decay_diff[20], energy_prev[20], peak_decay_diff_prev[20]; /* contiguous, in this order */
-  int32_t hyb_buf[3][2][12];    /* str_hybrid.ptr_qmf_buf_re/_im: 12-slot history of QMF bands 0..2 */
-  int16_t h11_h12_vec[48], h21_h22_vec[48], H11_H12[48], H21_H22[48], delta_h11_h12[48], delta_h21_h22[48];
-  int16_t delay_buffer_scale, usb;
+  XAAC_PS_STATE_HEAD_FIELDS
   /* right channel: str_synthesis_qmf_bank + scale factors of pstr_sbr_channel[1] */
   int16_t syn_ring_r[1280], syn_drc_offset_r, syn_phase_r;
   int16_t syn_lsb_r, syn_usb_r;

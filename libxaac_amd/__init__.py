@@ -70,7 +70,17 @@ class _SbrLpBatch(ctypes.Structure):
                 ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_uint64)]
 
 
+class _SbrHqBatch(ctypes.Structure):
+    # struct xaac_sbr_hq_batch
+    _fields_ = [("n_ch", ctypes.c_int32), ("in_ch_fac", ctypes.c_int32), ("out_ch_fac", ctypes.c_int32),
+                ("pad_", ctypes.c_int32), ("pcm_in", ctypes.c_void_p), ("header", ctypes.c_void_p),
+                ("frame", ctypes.c_void_p), ("state", ctypes.c_void_p), ("ps_frame", ctypes.c_void_p),
+                ("ps_state", ctypes.c_void_p), ("pcm_out", ctypes.c_void_p), ("status", ctypes.c_void_p),
+                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_uint64)]
+
+
 SBR_HEADER_BYTES, SBR_FRAME_BYTES, SBR_STATE_BYTES = 336, 1072, 7300   # include/xaac_sbr.h
+PS_FRAME_BYTES, PS_STATE_BYTES = 972, 7764
 QMF_ANA_STATE_WORDS = 322    # int16 words of struct xaac_qmf_ana_state: ring[320], wr, phase
 QMF_SYN_STATE_WORDS = 1282   # int16 words of struct xaac_qmf_syn_state: ring[1280], drc_offset, phase
 
@@ -108,6 +118,10 @@ def load_library():
     lib.xaac_sbr_lp_process_batch.restype = ctypes.c_int32
     lib.xaac_sbr_lp_workspace_bytes.argtypes = [ctypes.c_int32]
     lib.xaac_sbr_lp_workspace_bytes.restype = ctypes.c_uint64
+    lib.xaac_sbr_hq_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_SbrHqBatch)]
+    lib.xaac_sbr_hq_process_batch.restype = ctypes.c_int32
+    lib.xaac_sbr_hq_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32]
+    lib.xaac_sbr_hq_workspace_bytes.restype = ctypes.c_uint64
     for f in ("xaac_create", "xaac_destroy", "xaac_sync", "xaac_set_stream", "xaac_imdct_process_batch",
               "xaac_imdct_process_batch_host", "xaac_last_launch", "xaac_qmf_analysis_batch",
               "xaac_qmf_synthesis_batch"):
@@ -253,6 +267,32 @@ class XaacContext:
         rc = self._lib.xaac_qmf_synthesis_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_qmf_synthesis_batch")
+
+    def sbr_hq_workspace_bytes(self, n_ch, with_ps=True):
+        return int(self._lib.xaac_sbr_hq_workspace_bytes(int(n_ch), int(bool(with_ps))))
+
+    def sbr_hq_process_batch(self, pcm_in, header, frame, state, pcm_out, workspace, ps_frame=None, ps_state=None,
+                             status=None, in_ch_fac=1, out_ch_fac=1):
+        """Batched ixheaacd_sbr_dec, HQ mode: one frame per stream.  With ps_frame / ps_state (uint8[n, PS_*_BYTES])
+        the parametric-stereo tool runs too (HE-AACv2) and pcm_out is int16[n*2048*2] of L,R pairs; without them
+        pcm_out is int16[n*2048] (HE-AAC mono, HQ)."""
+        n_ch = state.shape[0]
+        with_ps = ps_frame is not None
+        b = _SbrHqBatch()
+        b.n_ch, b.in_ch_fac, b.out_ch_fac = n_ch, int(in_ch_fac), int(out_ch_fac)
+        b.pcm_in = _ptr(pcm_in, "int16", n_ch * 1024, device_ok=True)
+        b.header = _ptr(header, "uint8", n_ch * SBR_HEADER_BYTES, device_ok=True)
+        b.frame = _ptr(frame, "uint8", n_ch * SBR_FRAME_BYTES, device_ok=True)
+        b.state = _ptr(state, "uint8", n_ch * SBR_STATE_BYTES, device_ok=True)
+        b.ps_frame = _ptr(ps_frame, "uint8", n_ch * PS_FRAME_BYTES, allow_none=True, device_ok=True)
+        b.ps_state = _ptr(ps_state, "uint8", n_ch * PS_STATE_BYTES, allow_none=True, device_ok=True)
+        b.pcm_out = _ptr(pcm_out, "int16", n_ch * 2048 * (2 if with_ps else 1), device_ok=True)
+        b.status = _ptr(status, "int32", n_ch, allow_none=True, device_ok=True)
+        b.workspace = _ptr(workspace, "uint8", device_ok=True)
+        b.workspace_bytes = workspace.numel()
+        rc = self._lib.xaac_sbr_hq_process_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_sbr_hq_process_batch")
 
     def sbr_lp_workspace_bytes(self, n_ch):
         return int(self._lib.xaac_sbr_lp_workspace_bytes(int(n_ch)))

@@ -24,6 +24,8 @@ typedef struct XaacSbrCoreParams {
 extern "C" {
 #endif
 hipError_t xaac_launch_sbr_core_lp(const XaacSbrCoreParams *p, hipStream_t stream);
+/* HQ: x rows are 128 words (64 real | 64 imaginary): [n_ch][2 * XAAC_SBR_X_WORDS] */
+hipError_t xaac_launch_sbr_core_hq(const XaacSbrCoreParams *p, hipStream_t stream);
 #ifdef __cplusplus
 }
 #endif

@@ -53,8 +53,9 @@ static_assert(offsetof(XsLdsState, lpc_real) == 8 && sizeof(XsLdsState) == 8 + k
 static_assert(offsetof(xaac_sbr_state, overlap) % 16 == 0 || true, "");
 static_assert(sizeof(xaac_sbr_header) % 4 == 0 && sizeof(xaac_sbr_frame) % 4 == 0, "word copies");
 
+template <int HQ>
 struct XsLds {
-  int32_t x[XAAC_SBR_X_WORDS + 64]; /* + one row: the reference's edge writes may run past slot 37 */
+  int32_t x[(HQ ? 2 : 1) * XAAC_SBR_X_WORDS + 128]; /* + one row: the reference's edge writes may run past slot 37 */
   XsLdsState st;
   xaac_sbr_header h;
   xaac_sbr_frame f;
@@ -68,11 +69,14 @@ __device__ __forceinline__ void copy_words(int32_t *dst, const int32_t *src, int
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void xaac_sbr_core_lp_kernel(XaacSbrCoreParams p) {
-  __shared__ XsLds s;
+/* HQ = 0: low-power mode, rows of 64 reals; HQ = 1: rows of 64 real | 64 imaginary (HE-AAC mono / v2) */
+template <int HQ>
+__global__ __launch_bounds__(64) void xaac_sbr_core_kernel(XaacSbrCoreParams p) {
+  __shared__ XsLds<HQ> s;
+  constexpr int ROW = HQ ? 128 : 64, XW = (HQ ? 2 : 1) * XAAC_SBR_X_WORDS;
   const int ch = blockIdx.x, lane = threadIdx.x;
   xaac_sbr_state *gst = p.state + ch;
-  int32_t *gx = p.x + (size_t)ch * XAAC_SBR_X_WORDS;
+  int32_t *gx = p.x + (size_t)ch * XW;
   const int32_t *gstw = reinterpret_cast<const int32_t *>(gst);
 
   /* ---- copy-in ---- */
@@ -86,12 +90,14 @@ __global__ __launch_bounds__(64) void xaac_sbr_core_lp_kernel(XaacSbrCoreParams 
     copy_words(m + 2, gstw + kTailOff / 4, kTailWords, lane);
   }
   for (int i = lane; i < 568; i += 64) s.rand_hi[i] = (int16_t)(xaac_sbr_rand_ph[i] >> 16);
-  s.x[lane] = 0;
-  s.x[64 + lane] = 0;
-  s.x[XAAC_SBR_X_WORDS + lane] = 0;
-  copy_words(s.x + 2 * 64, gstw + offsetof(xaac_sbr_state, overlap) / 4, 6 * 64, lane);  /* sbr_dec.c:753 */
-  for (int i = lane; i < 32 * 32; i += 64) {
-    const int o = (8 + (i >> 5)) * 64 + (i & 31);
+  for (int i = lane; i < 2 * ROW; i += 64) {
+    s.x[i] = 0;
+    s.x[XW + (i & 127)] = 0;
+  }
+  copy_words(s.x + 2 * ROW, gstw + offsetof(xaac_sbr_state, overlap) / 4, 6 * ROW, lane);  /* sbr_dec.c:753 */
+  for (int i = lane; i < 32 * 32 * (HQ ? 2 : 1); i += 64) { /* the analysed slots: bands 0..31 (re, im) */
+    const int row = HQ ? (i >> 6) : (i >> 5), col = HQ ? ((i & 31) + ((i & 32) ? 64 : 0)) : (i & 31);
+    const int o = (8 + row) * ROW + col;
     s.x[o] = gx[o];
   }
   __syncthreads();
@@ -103,14 +109,14 @@ __global__ __launch_bounds__(64) void xaac_sbr_core_lp_kernel(XaacSbrCoreParams 
 #endif
 
   const XsCx cx = {lane, 64};
-  const XsQmf x = {s.x};
+  const XsQmfT<HQ> x = {s.x};
   if (lane == 0) s.st.lb_scale = 0;
   if (s.f.apply_processing) xs_rescale_x_overlap(cx, &s.h, &s.f, &s.st, x);
   /* what ixheaacd_cplx_anal_qmffilt leaves in the scale struct (generic:630-631) */
   __syncthreads();
   if (lane == 0) {
     s.st.st_lb_scale = 0;
-    s.st.lb_scale = -10;
+    s.st.lb_scale = HQ ? -8 : -10;
   }
   __syncthreads();
   int save_lb_scale = 0;
@@ -134,16 +140,19 @@ __global__ __launch_bounds__(64) void xaac_sbr_core_lp_kernel(XaacSbrCoreParams 
     par[3] = s.st.st_syn_scale;
     par[4] = s.st.syn_lsb;
     par[5] = s.st.syn_usb;
+    par[6] = 0; /* channel active (the synthesis kernel skips channels flagged here) */
+    par[7] = 0;
     s.st.ov_lb_scale = (int16_t)save_lb_scale;  /* sbr_dec.c:1304 */
 #ifndef XS_PROFILE
     if (p.status) p.status[ch] = rc;
 #endif
   }
   __syncthreads();
-  copy_words(gx + 2 * 64, s.x + 2 * 64, 32 * 64, lane);
+  copy_words(gx + 2 * ROW, s.x + 2 * ROW, 38 * ROW, lane); /* slots 0..31 for synthesis (+ 32..37 for PS) */
   {
     int32_t *gw = reinterpret_cast<int32_t *>(gst);
-    copy_words(gw + offsetof(xaac_sbr_state, overlap) / 4, s.x + (2 + 32) * 64, 6 * 64, lane);  /* :1283 */
+    /* sbr_dec.c:1283-1291 copies 6 * 64 words in either mode: in HQ the first three of the six slots */
+    copy_words(gw + offsetof(xaac_sbr_state, overlap) / 4, s.x + (2 + 32) * ROW, 6 * 64, lane);
     const int32_t *m = reinterpret_cast<const int32_t *>(&s.st);
     if (lane < 2) gw[kHeadOff / 4 + lane] = m[lane];
     copy_words(gw + kTailOff / 4, m + 2, kTailWords, lane);
@@ -151,6 +160,11 @@ __global__ __launch_bounds__(64) void xaac_sbr_core_lp_kernel(XaacSbrCoreParams 
 }
 
 extern "C" hipError_t xaac_launch_sbr_core_lp(const XaacSbrCoreParams *p, hipStream_t stream) {
-  hipLaunchKernelGGL(xaac_sbr_core_lp_kernel, dim3(p->n_ch), dim3(64), 0, stream, *p);
+  hipLaunchKernelGGL(xaac_sbr_core_kernel<0>, dim3(p->n_ch), dim3(64), 0, stream, *p);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t xaac_launch_sbr_core_hq(const XaacSbrCoreParams *p, hipStream_t stream) {
+  hipLaunchKernelGGL(xaac_sbr_core_kernel<1>, dim3(p->n_ch), dim3(64), 0, stream, *p);
   return hipGetLastError();
 }

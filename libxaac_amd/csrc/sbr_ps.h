@@ -4,7 +4,9 @@
  * plain delays), 2x2 rotation with per-envelope interpolated coefficients, and the delay-line scaling
  * that keeps the PS state in step with the block-floating-point scale of the frame.  One QMF slot at a
  * time, as the reference does inside its synthesis loop (decoder/ixheaacd_qmf_dec.c:1015-1031).
- * Host/device scalar code; the oracle (oracle/oracle_sbr.cpp) runs exactly this.
+ * Host/device code in the execution model of sbr_core.h: on the GPU one wave runs one stream with the
+ * sub-bands / QMF bands / parameter groups on the lanes and the PS state in LDS; the oracle
+ * (oracle/oracle_sbr.cpp) runs exactly this source sequentially (lane count 1).
  *
  * Reference map (decoder/...):
  *   xp_filt_2ch / xp_filt_8ch / xp_hybrid_analysis     ixheaacd_hybrid.c:51 / :96 / :214
@@ -132,14 +134,16 @@ FX_HD void xp_filt_8ch(const int32_t *w_re, const int32_t *w_im, int32_t *h_re, 
   xp_fft8(cum, h_re, h_im);
 }
 
-/* hybrid.c:214: push one slot of QMF bands 0..2 (row = 64 real | 64 imaginary) into the 12-slot histories
-   and filter.  scale: right shift applied to the incoming sample (left if negative). */
-FX_HD void xp_hybrid_analysis(const int32_t *row, xaac_ps_state *ps, XpHyb *hy, int scale) {
-  int off = 0;
-  for (int band = 0; band < 3; band++) {
+/* hybrid.c:214: push one slot of QMF bands 0..2 into the 12-slot histories and filter (one band per lane).
+   in_re / in_im: bands 0..2 of the slot six ahead; scale: right shift applied to them (left if negative). */
+template <class PS>
+FX_HD void xp_hybrid_analysis(const XsCx &cx, const int32_t *in_re, const int32_t *in_im, PS *ps, XpHyb *hy,
+                              int scale) {
+  XS_PAR(band, 0, 3) {
+    const int off = band == 0 ? 0 : 4 + 2 * band;
     int32_t w_re[13], w_im[13];
     int32_t *b_re = ps->hyb_buf[band][0], *b_im = ps->hyb_buf[band][1];
-    int32_t t_re = row[band], t_im = row[band + 64];
+    int32_t t_re = in_re[band], t_im = in_im[band];
     if (scale < 0) {
       t_re = fx_shl(t_re, -scale);
       t_im = fx_shl(t_im, -scale);
@@ -154,19 +158,17 @@ FX_HD void xp_hybrid_analysis(const int32_t *row, xaac_ps_state *ps, XpHyb *hy, 
     w_re[12] = t_re;
     w_im[12] = t_im;
     for (int t = 0; t < 11; t++) {
-      b_re[t] = b_re[t + 1];
-      b_im[t] = b_im[t + 1];
+      b_re[t] = w_re[t + 1];
+      b_im[t] = w_im[t + 1];
     }
     b_re[11] = t_re;
     b_im[11] = t_im;
-    if (xaac_ps_hyb_resol[band] == 8) {
+    if (band == 0)
       xp_filt_8ch(w_re, w_im, &hy->l_re[off], &hy->l_im[off]);
-      off += 6;
-    } else {
+    else
       xp_filt_2ch(w_re, w_im, &hy->l_re[off], &hy->l_im[off]);
-      off += 2;
-    }
   }
+  cx.sync();
 }
 
 /* ps_dec.c:212 */
@@ -217,35 +219,40 @@ FX_HD void xp_allpass(int16_t *d0, int32_t new_re, int32_t new_im, const int16_t
   *out_im = in_im;
 }
 
+/* ps_dec.c:470-545: input power of transient-detector bin `bin` (20 bins: hybrid sub-bands, QMF bands 3..8,
+   then groups of QMF bands) */
+FX_HD int32_t xp_bin_power(int bin, const XpHyb *hy, const int32_t *l_re, const int32_t *l_im, int usb) {
+  if (bin < 2) {
+    const int a = bin == 0 ? 0 : 4, b = bin == 0 ? 5 : 1;
+    int32_t pw = xp_power(hy->l_re[a], hy->l_im[a]);
+    pw = fx_add_sat(pw, fx_mul32x16(hy->l_re[b], (int16_t)(hy->l_re[b] >> 16)));
+    return fx_add_sat(pw, fx_mul32x16(hy->l_im[b], (int16_t)(hy->l_im[b] >> 16)));
+  }
+  if (bin < 8) {
+    const int sb = xaac_ps_borders_group[bin + 2];
+    return xp_power(hy->l_re[sb], hy->l_im[sb]);
+  }
+  if (bin < 14) return xp_power(l_re[bin - 5], l_im[bin - 5]);
+  const int gr = bin + 2;
+  int32_t accu = 0;
+  int hi = xaac_ps_borders_group[gr + 1];
+  if (usb < hi) hi = usb;
+  for (int sb = xaac_ps_borders_group[gr]; sb < hi; sb++)
+    accu = fx_add_sat(accu, xp_power(l_re[sb], l_im[sb]) >> xaac_ps_group_shift[gr - 16]);
+  return accu;
+}
+
 /* ps_dec.c:450: decorrelated (right) signal of one slot.  left: the slot's QMF row (64 re | 64 im), right:
-   output row; hy: hybrid sub-bands of the slot (left in, right out). */
-FX_HD void xp_decorrelation(xaac_ps_state *ps, XpHyb *hy, const int32_t *left, int32_t *right) {
-  const int usb = ps->usb;
+   output row; hy: hybrid sub-bands of the slot (left in, right out); ratio: 21 shorts of scratch. */
+template <class PS>
+FX_HD void xp_decorrelation(const XsCx &cx, PS *ps, XpHyb *hy, const int32_t *left, int32_t *right, int16_t *ratio) {
+  const int usb = cx.uni(ps->usb);
+  const int idx = cx.uni(ps->idx), idx_long = cx.uni(ps->idx_long);
+  const int is0 = cx.uni(ps->idx_ser[0]), is1 = cx.uni(ps->idx_ser[1]), is2 = cx.uni(ps->idx_ser[2]);
   const int32_t *l_re = left, *l_im = left + 64;
   int32_t *r_re = right, *r_im = right + 64;
-  int32_t power[20];
-  int16_t ratio[21];
-  power[0] = fx_add_sat(xp_power(hy->l_re[0], hy->l_im[0]), 0);
-  power[0] = fx_add_sat(fx_add_sat(power[0], fx_mul32x16(hy->l_re[5], (int16_t)(hy->l_re[5] >> 16))),
-                        fx_mul32x16(hy->l_im[5], (int16_t)(hy->l_im[5] >> 16)));
-  power[1] = xp_power(hy->l_re[4], hy->l_im[4]);
-  power[1] = fx_add_sat(fx_add_sat(power[1], fx_mul32x16(hy->l_re[1], (int16_t)(hy->l_re[1] >> 16))),
-                        fx_mul32x16(hy->l_im[1], (int16_t)(hy->l_im[1] >> 16)));
-  for (int gr = 4; gr < 10; gr++) {
-    const int sb = xaac_ps_borders_group[gr];
-    power[gr - 2] = xp_power(hy->l_re[sb], hy->l_im[sb]);
-  }
-  for (int sb = 3; sb < 9; sb++) power[sb + 5] = xp_power(l_re[sb], l_im[sb]);
-  for (int gr = 16; gr < XAAC_PS_GROUPS; gr++) {
-    int32_t accu = 0;
-    int hi = xaac_ps_borders_group[gr + 1];
-    if (usb < hi) hi = usb;
-    for (int sb = xaac_ps_borders_group[gr]; sb < hi; sb++)
-      accu = fx_add_sat(accu, xp_power(l_re[sb], l_im[sb]) >> xaac_ps_group_shift[gr - 16]);
-    power[gr - 2] = accu;
-  }
-  for (int bin = 0; bin < 20; bin++) {
-    int32_t pw = fx_shl(power[bin], 1);
+  XS_PAR(bin, 0, 20) { /* transient detector: peak-decay against smoothed energy, per bin */
+    int32_t pw = fx_shl(xp_bin_power(bin, hy, l_re, l_im, usb), 1);
     if (pw < 0) pw = 0;
     int32_t pd = fx_mul32x16_shl(ps->peak_decay_diff[bin], 0x620a);
     if (pw > pd) pd = pw;
@@ -257,12 +264,13 @@ FX_HD void xp_decorrelation(xaac_ps_state *ps, XpHyb *hy, const int32_t *left, i
     peak_diff = fx_add_sat(peak_diff, peak_diff >> 1);
     ratio[bin] = peak_diff <= nrg ? (int16_t)0x7fff : (int16_t)xp_divide16_pos(nrg, peak_diff);
   }
-  /* hybrid sub-bands (ps_dec.c:236) */
-  for (int sb = 0; sb < 10; sb++) {
+  XS_ONE ratio[20] = 0;
+  cx.sync();
+  XS_PAR(sb, 0, 10) { /* hybrid sub-bands (ps_dec.c:236) */
     int16_t o_re, o_im;
-    xp_allpass(&ps->sub[ps->idx][2 * sb], hy->l_re[sb], hy->l_im[sb], &xaac_ps_frac_delay_phase_fac_qmf_sub_re_im[2 * sb],
-               &ps->sub_ser[ps->idx_ser[0]][0][2 * sb], &ps->sub_ser[ps->idx_ser[1]][1][2 * sb],
-               &ps->sub_ser[ps->idx_ser[2]][2][2 * sb], &xaac_ps_frac_delay_phase_fac_qmf_sub_ser_re_im[2 * sb],
+    xp_allpass(&ps->sub[idx][2 * sb], hy->l_re[sb], hy->l_im[sb], &xaac_ps_frac_delay_phase_fac_qmf_sub_re_im[2 * sb],
+               &ps->sub_ser[is0][0][2 * sb], &ps->sub_ser[is1][1][2 * sb], &ps->sub_ser[is2][2][2 * sb],
+               &xaac_ps_frac_delay_phase_fac_qmf_sub_ser_re_im[2 * sb],
                &xaac_ps_frac_delay_phase_fac_qmf_sub_ser_re_im[32 + 2 * sb],
                &xaac_ps_frac_delay_phase_fac_qmf_sub_ser_re_im[64 + 2 * sb], xaac_ps_rev_link_decay_ser[0],
                xaac_ps_rev_link_decay_ser[1], xaac_ps_rev_link_decay_ser[2], &o_re, &o_im);
@@ -270,56 +278,42 @@ FX_HD void xp_decorrelation(xaac_ps_state *ps, XpHyb *hy, const int32_t *left, i
     hy->r_re[sb] = xp_m16x16_shl(o_re, tr);
     hy->r_im[sb] = xp_m16x16_shl(o_im, tr);
   }
-  ratio[20] = 0;
-  /* QMF bands 3..22 (ps_dec.c:339) */
-  for (int sb = 3; sb < 23; sb++) {
-    int16_t o_re, o_im;
-    const int di = 9 + 3 * (sb - 3);
-    xp_allpass(&ps->ap[ps->idx][2 * sb], l_re[sb], l_im[sb], &xaac_ps_frac_delay_phase_fac_qmf_re_im[2 * sb],
-               &ps->ser[ps->idx_ser[0]][0][2 * sb], &ps->ser[ps->idx_ser[1]][1][2 * sb],
-               &ps->ser[ps->idx_ser[2]][2][2 * sb], &xaac_ps_frac_delay_phase_fac_qmf_ser_re_im[2 * sb],
-               &xaac_ps_frac_delay_phase_fac_qmf_ser_re_im[64 + 2 * sb],
-               &xaac_ps_frac_delay_phase_fac_qmf_ser_re_im[128 + 2 * sb], xaac_ps_decay_scale_factor[di],
-               xaac_ps_decay_scale_factor[di + 1], xaac_ps_decay_scale_factor[di + 2], &o_re, &o_im);
-    const int16_t tr = ratio[xaac_ps_delay_to_bin[sb]];
-    r_re[sb] = xp_m16x16_shl(o_re, tr);
-    r_im[sb] = xp_m16x16_shl(o_im, tr);
-  }
-  /* plain delays: 14 slots for bands 23..34, one slot above (ps_dec.c:602-648) */
-  {
-    int hi = xaac_ps_borders_group[21];
-    if (usb < hi) hi = usb;
-    int16_t *d = ps->ld[ps->idx_long];
-    for (int sb = xaac_ps_borders_group[20]; sb < hi; sb++, d += 2) {
+  XS_PAR(sb, 3, 64) {
+    if (sb < 23) { /* QMF bands 3..22: all-pass chain (ps_dec.c:339), whatever usb is */
+      int16_t o_re, o_im;
+      const int di = 9 + 3 * (sb - 3);
+      xp_allpass(&ps->ap[idx][2 * sb], l_re[sb], l_im[sb], &xaac_ps_frac_delay_phase_fac_qmf_re_im[2 * sb],
+                 &ps->ser[is0][0][2 * sb], &ps->ser[is1][1][2 * sb], &ps->ser[is2][2][2 * sb],
+                 &xaac_ps_frac_delay_phase_fac_qmf_ser_re_im[2 * sb],
+                 &xaac_ps_frac_delay_phase_fac_qmf_ser_re_im[64 + 2 * sb],
+                 &xaac_ps_frac_delay_phase_fac_qmf_ser_re_im[128 + 2 * sb], xaac_ps_decay_scale_factor[di],
+                 xaac_ps_decay_scale_factor[di + 1], xaac_ps_decay_scale_factor[di + 2], &o_re, &o_im);
+      const int16_t tr = ratio[xaac_ps_delay_to_bin[sb]];
+      r_re[sb] = xp_m16x16_shl(o_re, tr);
+      r_im[sb] = xp_m16x16_shl(o_im, tr);
+    } else if (sb < usb) { /* plain delays: 14 slots for bands 23..34, one slot above (ps_dec.c:602-648) */
+      int16_t *d = sb < 35 ? &ps->ld[idx_long][2 * (sb - 23)] : &ps->sd[2 * (sb - 35)];
+      const int16_t tr = ratio[sb < 35 ? 18 : 19];
       const int16_t dr = d[0], di = d[1];
       d[0] = fx_round16(l_re[sb]);
       d[1] = fx_round16(l_im[sb]);
-      r_re[sb] = xp_m16x16_shl(dr, ratio[18]);
-      r_im[sb] = xp_m16x16_shl(di, ratio[18]);
-    }
-    ps->idx_long = (int16_t)(ps->idx_long + 1);
-    if (ps->idx_long >= 14) ps->idx_long = 0;
-    hi = xaac_ps_borders_group[22];
-    if (usb < hi) hi = usb;
-    d = ps->sd;
-    for (int sb = xaac_ps_borders_group[21]; sb < hi; sb++, d += 2) {
-      const int16_t dr = d[0], di = d[1];
-      d[0] = fx_round16(l_re[sb]);
-      d[1] = fx_round16(l_im[sb]);
-      r_re[sb] = xp_m16x16_shl(dr, ratio[19]);
-      r_im[sb] = xp_m16x16_shl(di, ratio[19]);
+      r_re[sb] = xp_m16x16_shl(dr, tr);
+      r_im[sb] = xp_m16x16_shl(di, tr);
     }
   }
-  for (int sb = usb; sb < 64; sb++) {
+  cx.sync();
+  XS_PAR(sb, usb, 64) { /* after the filters: they run up to band 22 even when usb is lower */
     r_re[sb] = 0;
     r_im[sb] = 0;
   }
-  ps->idx = (int16_t)(ps->idx + 1);
-  if (ps->idx >= 2) ps->idx = 0;
-  for (int m = 0; m < 3; m++) {
-    ps->idx_ser[m] = (int16_t)(ps->idx_ser[m] + 1);
-    if (ps->idx_ser[m] >= ps->sample_ser[m]) ps->idx_ser[m] = 0;
+  XS_ONE {
+    ps->idx_long = (int16_t)(idx_long + 1 >= 14 ? 0 : idx_long + 1);
+    ps->idx = (int16_t)(idx + 1 >= 2 ? 0 : idx + 1);
+    ps->idx_ser[0] = (int16_t)(is0 + 1 >= ps->sample_ser[0] ? 0 : is0 + 1);
+    ps->idx_ser[1] = (int16_t)(is1 + 1 >= ps->sample_ser[1] ? 0 : is1 + 1);
+    ps->idx_ser[2] = (int16_t)(is2 + 1 >= ps->sample_ser[2] ? 0 : is2 + 1);
   }
+  cx.sync();
 }
 
 /* ps_dec.c:678 / :691: quarter-wave table lookups of the rotation angles */
@@ -338,31 +332,32 @@ FX_HD int16_t xp_sin512(int32_t phi_by_4) {
 }
 
 /* ps_dec.c:714: at an envelope border, the target mixing coefficients of every parameter group from the
-   IID / ICC indices, and the per-slot increments towards them */
-FX_HD void xp_init_rot_env(xaac_ps_state *ps, const xaac_ps_frame *pf, int env, int usb) {
+   IID / ICC indices, and the per-slot increments towards them (one group per lane) */
+template <class PS>
+FX_HD void xp_init_rot_env(const XsCx &cx, PS *ps, const xaac_ps_frame *pf, int env, int usb) {
   if (env == 0) {
-    const int usb_prev = ps->usb;
-    ps->usb = (int16_t)usb;
+    const int usb_prev = cx.uni(ps->usb);
+    cx.sync();
+    XS_ONE ps->usb = (int16_t)usb;
     if (usb > usb_prev && usb_prev) { /* clear the delay lines of the bands that just became active */
       const int ap_hi = usb < 23 ? usb : 23;
       if (ap_hi > usb_prev)
         for (int i = 0; i < 3; i++)
-          for (int j = 0; j < ps->sample_ser[i]; j++)
-            for (int k = 2 * usb_prev; k < 2 * ap_hi; k++) ps->ser[j][i][k] = 0;
+          for (int j = 0; j < cx.uni(ps->sample_ser[i]); j++) XS_PAR(k, 2 * usb_prev, 2 * ap_hi) ps->ser[j][i][k] = 0;
       const int ld_hi = usb < 35 ? usb : 35;
       if (ld_hi >= ap_hi && ld_hi <= 12)
-        for (int i = 0; i < 14; i++)
-          for (int k = 2 * ap_hi; k < 2 * ld_hi; k++) ps->ld[i][k] = 0;
-      if (usb >= ld_hi && usb <= 16)
-        for (int k = 2 * ld_hi; k < 2 * usb; k++) ps->sd[k] = 0;
+        for (int i = 0; i < 14; i++) XS_PAR(k, 2 * ap_hi, 2 * ld_hi) ps->ld[i][k] = 0;
+      if (usb >= ld_hi && usb <= 16) XS_PAR(k, 2 * ld_hi, 2 * usb) ps->sd[k] = 0;
     }
+    cx.sync();
   }
-  const int steps = pf->iid_quant ? 15 : 7;
-  const int16_t *sf = pf->iid_quant ? xaac_ps_scale_factors_fine : xaac_ps_scale_factors;
-  int16_t len = fx_sat16((int32_t)pf->border_position[env + 1] - pf->border_position[env]);
+  const int fine = cx.uni(pf->iid_quant);
+  const int steps = fine ? 15 : 7;
+  const int16_t *sf = fine ? xaac_ps_scale_factors_fine : xaac_ps_scale_factors;
+  int16_t len = fx_sat16((int32_t)cx.uni(pf->border_position[env + 1]) - cx.uni(pf->border_position[env]));
   if (len < 0) len = (int16_t)(len == -32768 ? 32767 : -len);
   const int16_t inv_len = xaac_sbr_inv_int_table[len];
-  for (int g = 0; g < XAAC_PS_GROUPS; g++) {
+  XS_PAR(g, 0, XAAC_PS_GROUPS) {
     const int bin = xaac_ps_group_to_bin[g];
     const int iid = pf->iid_par_table[env][bin], icc = pf->icc_par_table[env][bin];
     const int16_t c1 = sf[steps + iid], c2 = sf[steps - iid];
@@ -387,6 +382,7 @@ FX_HD void xp_init_rot_env(xaac_ps_state *ps, const xaac_ps_frame *pf, int env, 
     ps->h21_h22_vec[2 * g] = h21;
     ps->h21_h22_vec[2 * g + 1] = h22;
   }
+  cx.sync();
 }
 
 FX_HD void xp_rotate(int32_t *l, int32_t *r, int16_t h11, int16_t h12, int16_t h21, int16_t h22) {
@@ -398,102 +394,109 @@ FX_HD void xp_rotate(int32_t *l, int32_t *r, int16_t h11, int16_t h12, int16_t h
 
 /* ps_dec.c:856: advance the interpolated coefficients by one slot and mix left / decorrelated into the
    output pair, in the hybrid domain for QMF bands 0..2 (their sub-bands are then summed back) */
-FX_HD void xp_apply_rot(xaac_ps_state *ps, XpHyb *hy, int32_t *left, int32_t *right) {
-  const int usb = ps->usb;
-  for (int g = 0; g < XAAC_PS_GROUPS; g++) {
+template <class PS>
+FX_HD void xp_apply_rot(const XsCx &cx, PS *ps, XpHyb *hy, int32_t *left, int32_t *right) {
+  const int usb = cx.uni(ps->usb);
+  XS_PAR(g, 0, XAAC_PS_GROUPS) {
     ps->H11_H12[2 * g] = (int16_t)(ps->H11_H12[2 * g] + ps->delta_h11_h12[2 * g]);
     ps->H11_H12[2 * g + 1] = (int16_t)(ps->H11_H12[2 * g + 1] + ps->delta_h11_h12[2 * g + 1]);
     ps->H21_H22[2 * g] = (int16_t)(ps->H21_H22[2 * g] + ps->delta_h21_h22[2 * g]);
     ps->H21_H22[2 * g + 1] = (int16_t)(ps->H21_H22[2 * g + 1] + ps->delta_h21_h22[2 * g + 1]);
   }
-  for (int sb = 0; sb < 10; sb++) {
+  cx.sync();
+  XS_PAR(sb, 0, 10) {
     const int16_t h11 = ps->H11_H12[2 * sb], h12 = ps->H11_H12[2 * sb + 1], h21 = ps->H21_H22[2 * sb],
                   h22 = ps->H21_H22[2 * sb + 1];
     xp_rotate(&hy->l_re[sb], &hy->r_re[sb], h11, h12, h21, h22);
     xp_rotate(&hy->l_im[sb], &hy->r_im[sb], h11, h12, h21, h22);
   }
+  cx.sync();
   int32_t *l_re = left, *l_im = left + 64, *r_re = right, *r_im = right + 64;
-  int p = 0;
-  for (int band = 0; band < 3; band++) {
-    int n = xaac_ps_hyb_resol[band] < 6 ? xaac_ps_hyb_resol[band] : 6;
-    int32_t a = hy->l_re[p], b = hy->l_im[p], c = hy->r_re[p], d = hy->r_im[p];
-    for (int k = 1; k < n; k++) {
-      a = fx_add_sat(a, hy->l_re[p + k]);
-      b = fx_add_sat(b, hy->l_im[p + k]);
-      c = fx_add_sat(c, hy->r_re[p + k]);
-      d = fx_add_sat(d, hy->r_im[p + k]);
-    }
-    p += n;
-    l_re[band] = a;
-    l_im[band] = b;
-    r_re[band] = c;
-    r_im[band] = d;
-  }
-  for (int g = 10; g < XAAC_PS_GROUPS; g++) {
-    int hi = xaac_ps_borders_group[g + 1];
-    if (usb < hi) hi = usb;
-    const int16_t h11 = ps->H11_H12[2 * g], h12 = ps->H11_H12[2 * g + 1], h21 = ps->H21_H22[2 * g],
-                  h22 = ps->H21_H22[2 * g + 1];
-    for (int sb = xaac_ps_borders_group[g]; sb < hi; sb++) {
+  XS_PAR(sb, 0, usb > 3 ? usb : 3) {
+    if (sb < 3) { /* QMF bands 0..2: the sum of their hybrid sub-bands */
+      const int p = sb == 0 ? 0 : 4 + 2 * sb, n = sb == 0 ? 6 : 2;
+      int32_t a = hy->l_re[p], b = hy->l_im[p], c = hy->r_re[p], d = hy->r_im[p];
+      for (int k = 1; k < n; k++) {
+        a = fx_add_sat(a, hy->l_re[p + k]);
+        b = fx_add_sat(b, hy->l_im[p + k]);
+        c = fx_add_sat(c, hy->r_re[p + k]);
+        d = fx_add_sat(d, hy->r_im[p + k]);
+      }
+      l_re[sb] = a;
+      l_im[sb] = b;
+      r_re[sb] = c;
+      r_im[sb] = d;
+    } else { /* the band's parameter group: borders 3,4,...,9,11,14,18,23,35,64 */
+      int g = 10;
+      while (sb >= xaac_ps_borders_group[g + 1]) g++;
+      const int16_t h11 = ps->H11_H12[2 * g], h12 = ps->H11_H12[2 * g + 1], h21 = ps->H21_H22[2 * g],
+                    h22 = ps->H21_H22[2 * g + 1];
       xp_rotate(&l_re[sb], &r_re[sb], h11, h12, h21, h22);
       xp_rotate(&l_im[sb], &r_im[sb], h11, h12, h21, h22);
     }
   }
+  cx.sync();
 }
 
 /* ---- keeping the PS state in the frame's block-floating-point scale (ps_dec.c:134-210, thumb:101) ---- */
-FX_HD int32_t xp_or_abs16(const int16_t *p, int n, int32_t m) {
-  for (int i = 0; i < n; i++) m |= fx_abs_nrm(p[i]);
+FX_HD int32_t xp_or_abs16(const XsCx &cx, const int16_t *p, int n, int32_t m) {
+  XS_PAR(i, 0, n) m |= fx_abs_nrm(p[i]);
   return m;
 }
-FX_HD int xp_ps_headroom(const xaac_ps_state *ps) {
+template <class PS>
+FX_HD int xp_ps_headroom(const XsCx &cx, const PS *ps) {
   int32_t m = 0;
-  for (int i = 0; i < 2; i++) m = xp_or_abs16(&ps->ap[i][6], 40, m);
-  m = xp_or_abs16(&ps->ld[0][0], 2 * 14 * 12, m);
-  m = xp_or_abs16(ps->sd, 2 * 29, m);
-  m = xp_or_abs16(&ps->sub[0][0], 2 * 16 * 2, m);
+  for (int i = 0; i < 2; i++) m = xp_or_abs16(cx, &ps->ap[i][6], 40, m);
+  m = xp_or_abs16(cx, &ps->ld[0][0], 2 * 14 * 12, m);
+  m = xp_or_abs16(cx, ps->sd, 2 * 29, m);
+  m = xp_or_abs16(cx, &ps->sub[0][0], 2 * 16 * 2, m);
   for (int i = 0; i < 3; i++)
-    for (int j = 0; j < ps->sample_ser[i]; j++) m = xp_or_abs16(&ps->ser[j][i][6], 40, m);
-  m = xp_or_abs16(&ps->sub_ser[0][0][0], 2 * 3 * 5 * 16, m);
+    for (int j = 0; j < cx.uni(ps->sample_ser[i]); j++) m = xp_or_abs16(cx, &ps->ser[j][i][6], 40, m);
+  m = xp_or_abs16(cx, &ps->sub_ser[0][0][0], 2 * 3 * 5 * 16, m);
   m = (int32_t)((uint32_t)m << 16);
   const int32_t *h = &ps->hyb_buf[0][0][0];
-  for (int i = 0; i < 3 * 2 * 12; i++) m |= fx_abs_nrm(h[i]);
-  return xs_pnorm32(m);
+  XS_PAR(i, 0, 3 * 2 * 12) m |= fx_abs_nrm(h[i]);
+  return xs_pnorm32(cx.wave_or(m));
 }
-FX_HD void xp_scale16(int16_t *p, int n, int scale) { /* scale > 0: left, saturating; < 0: right */
+FX_HD void xp_scale16(const XsCx &cx, int16_t *p, int n, int scale) { /* scale > 0: left, saturating; < 0: right */
   if (scale > 0) {
     const int s = scale > 15 ? 15 : scale;
-    for (int i = 0; i < n; i++) p[i] = fx_sat16(xs_shl(p[i], s));
+    XS_PAR(i, 0, n) p[i] = fx_sat16(xs_shl(p[i], s));
   } else {
-    for (int i = 0; i < n; i++) p[i] = (int16_t)(p[i] >> (-scale > 31 ? 31 : -scale));
+    const int s = -scale > 31 ? 31 : -scale;
+    XS_PAR(i, 0, n) p[i] = (int16_t)(p[i] >> s);
   }
 }
-FX_HD void xp_scale32(int32_t *p, int n, int scale) {
+FX_HD void xp_scale32(const XsCx &cx, int32_t *p, int n, int scale) {
   if (scale > 0)
-    for (int i = 0; i < n; i++) p[i] = fx_shl_sat(p[i], scale);
+    XS_PAR(i, 0, n) p[i] = fx_shl_sat(p[i], scale);
   else
-    for (int i = 0; i < n; i++) p[i] = fx_shr(p[i], -scale);
+    XS_PAR(i, 0, n) p[i] = fx_shr(p[i], -scale);
 }
-FX_HD void xp_scale_states(xaac_ps_state *ps, int scale) {
+template <class PS>
+FX_HD void xp_scale_states(const XsCx &cx, PS *ps, int scale) {
   if (scale == 0) return;
-  for (int m = 0; m < 2; m++) xp_scale16(&ps->ap[m][6], 40, scale);
-  xp_scale16(&ps->ld[0][0], 2 * 14 * 12 + 2 * 29, scale); /* ld and sd are one block */
-  xp_scale16(&ps->sub[0][0], 2 * 16 * 2 + 2 * 3 * 5 * 16, scale); /* sub and sub_ser too */
+  for (int m = 0; m < 2; m++) xp_scale16(cx, &ps->ap[m][6], 40, scale);
+  xp_scale16(cx, &ps->ld[0][0], 2 * 14 * 12 + 2 * 29, scale);        /* ld and sd are one block */
+  xp_scale16(cx, &ps->sub[0][0], 2 * 16 * 2 + 2 * 3 * 5 * 16, scale); /* sub and sub_ser too */
   for (int i = 0; i < 3; i++)
-    for (int m = 0; m < ps->sample_ser[i]; m++) xp_scale16(&ps->ser[m][i][6], 40, scale);
-  xp_scale32(&ps->hyb_buf[0][0][0], 2 * 3 * 12, scale);
-  xp_scale32(ps->peak_decay_diff, 3 * 20, 2 * scale);
+    for (int m = 0; m < cx.uni(ps->sample_ser[i]); m++) xp_scale16(cx, &ps->ser[m][i][6], 40, scale);
+  xp_scale32(cx, &ps->hyb_buf[0][0][0], 2 * 3 * 12, scale);
+  xp_scale32(cx, ps->peak_decay_diff, 3 * 20, 2 * scale);
 }
 /* ps_dec.c:188: returns ps_scale */
-FX_HD int xp_init_ps_scale(xaac_ps_state *ps, int lb_scale, int ov_lb_scale, int hb_scale) {
-  const int reserve = xp_ps_headroom(ps);
-  ps->delay_buffer_scale = (int16_t)(ps->delay_buffer_scale + reserve);
+template <class PS>
+FX_HD int xp_init_ps_scale(const XsCx &cx, PS *ps, int lb_scale, int ov_lb_scale, int hb_scale) {
+  const int reserve = xp_ps_headroom(cx, ps);
+  const int dbs = (int16_t)(cx.uni(ps->delay_buffer_scale) + reserve);
   int16_t t = (int16_t)(lb_scale < ov_lb_scale ? lb_scale : ov_lb_scale);
   if (hb_scale < t) t = (int16_t)hb_scale;
-  if (ps->delay_buffer_scale < t) t = ps->delay_buffer_scale;
+  if (dbs < t) t = (int16_t)dbs;
   const int ps_scale = t - 1;
-  xp_scale_states(ps, (int16_t)((ps_scale - ps->delay_buffer_scale) + reserve));
-  ps->delay_buffer_scale = (int16_t)ps_scale;
+  cx.sync();
+  xp_scale_states(cx, ps, (int16_t)((ps_scale - dbs) + reserve));
+  XS_ONE ps->delay_buffer_scale = (int16_t)ps_scale;
+  cx.sync();
   return ps_scale;
 }
 

@@ -1,0 +1,137 @@
+/*
+ * sbr_ps_kernel.hip -- the parametric-stereo tool of HE-AACv2 on gfx950: what the reference runs inside the
+ * left channel's synthesis loop (decoder/ixheaacd_qmf_dec.c:1015-1031 with ixheaacd_thumb_ps_dec.c:69 and
+ * ixheaacd_ps_dec.c), pulled out in front of the two synthesis banks.
+ *
+ * Mapping: ONE WAVE = ONE STREAM.  The tool is a recursion over the 32 QMF slots of the frame (delay lines,
+ * transient detector, interpolated mixing matrix), so slots are walked in order; inside a slot the lanes are
+ * the hybrid sub-bands / QMF bands / transient bins / parameter groups (sbr_ps.h, the source the oracle runs
+ * sequentially).  The PS state (5.2 KB), the frame's side info and one slot of left/right samples live in LDS;
+ * the QMF matrix stays where the core kernel put it (L2-resident workspace), one 512-byte row in and two out
+ * per slot.  The kernel also does what ixheaacd_cplx_synt_qmffilt does around the tool -- bring the matrix to
+ * the PS scale (adjust_scale, qmf_dec.c:937), the hybrid look-ahead's scale (thumb:77), the common shift in
+ * front of the left bank (generic:1610) -- so that both synthesis launches find their input ready.
+ */
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "sbr_ps.h"
+#include "sbr_ps_kernel.h"
+
+namespace {
+
+struct XpLdsState {
+  XAAC_PS_STATE_HEAD_FIELDS
+};
+constexpr int kHeadWords = offsetof(xaac_ps_state, syn_ring_r) / 4;
+static_assert(offsetof(xaac_ps_state, syn_ring_r) % 4 == 0 && sizeof(XpLdsState) == kHeadWords * 4, "mirror layout");
+static_assert(sizeof(xaac_ps_frame) % 4 == 0, "word copies");
+
+struct XpLds {
+  XpLdsState ps;
+  xaac_ps_frame pf;
+  XpHyb hy;
+  int32_t left[128], right[128];
+  int32_t ahead[8]; /* bands 0..2 of the slot six ahead: re at [0..2], im at [4..6] */
+  int16_t ratio[24];
+};
+
+__device__ __forceinline__ int32_t adj_word(int32_t v, int shift) { /* env_calc.c:1099 on one word */
+  if (shift == 0) return v;
+  if (shift > 31) shift = 31;
+  if (shift < -31) shift = -31;
+  return shift > 0 ? fx_shlw(v, shift) : (v >> -shift);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void xaac_ps_kernel(XaacPsParams p) {
+  __shared__ XpLds s;
+  const int n = blockIdx.x, lane = threadIdx.x;
+  if (!(p.sbr_frame[n].apply_processing && p.header[n].channel_mode == 3)) { /* sbr_dec.c:1246: mono this frame */
+    if (lane == 0) {
+      p.par_l[8 * (size_t)n + 6] = 0;
+      p.par_r[8 * (size_t)n + 6] = 1;
+    }
+    return;
+  }
+  xaac_ps_state *gps = p.state + n;
+  int32_t *gx = p.x + (size_t)n * (40 * 128) + 2 * 128; /* slot 0 */
+  int32_t *gr = p.xr + (size_t)n * (32 * 128);
+  {
+    const int32_t *src = reinterpret_cast<const int32_t *>(gps);
+    int32_t *dst = reinterpret_cast<int32_t *>(&s.ps);
+    for (int i = lane; i < kHeadWords; i += 64) dst[i] = src[i];
+    const int32_t *fs = reinterpret_cast<const int32_t *>(p.frame + n);
+    int32_t *fd = reinterpret_cast<int32_t *>(&s.pf);
+    for (int i = lane; i < (int)(sizeof(xaac_ps_frame) / 4); i += 64) fd[i] = fs[i];
+  }
+  __syncthreads();
+  const XsCx cx = {lane, 64};
+  int16_t *par = p.par_l + 8 * (size_t)n;
+  const int lb_scale = par[0], ov_lb_scale = par[1], hb_scale = par[2], st_syn = par[3], lsb = par[4], usb = par[5];
+  const int ps_scale = xp_init_ps_scale(cx, &s.ps, lb_scale, ov_lb_scale, hb_scale); /* sbr_dec.c:1252 */
+  const int ov_lb_shift = ps_scale - ov_lb_scale, lb_shift = ps_scale - lb_scale, hb_shift = ps_scale - hb_scale;
+  const int common_shift = (st_syn - ps_scale) - 8;
+  /* what adjust_scale would do to this lane's band in slots < 6 / >= 6 (qmf_dec.c:937-953) */
+  const int sh_ov = lane < lsb ? ov_lb_shift : (lane < usb ? hb_shift : 0);
+  const int sh_lb = lane < lsb ? lb_shift : (lane < usb ? hb_shift : 0);
+  int env = 0;
+  for (int l = 0; l < 32; l++) {
+    {
+      const int sh = l < 6 ? sh_ov : sh_lb;
+      s.left[lane] = adj_word(gx[l * 128 + lane], sh);
+      s.left[64 + lane] = adj_word(gx[l * 128 + 64 + lane], sh);
+      if (lane < 3) { /* the hybrid bank looks six slots ahead; slots of the next frame are not rescaled */
+        const int la = l + 6;
+        const int sha = la < 32 ? sh_lb : 0;
+        s.ahead[lane] = adj_word(gx[la * 128 + lane], sha);
+        s.ahead[4 + lane] = adj_word(gx[la * 128 + 64 + lane], sha);
+      }
+    }
+    __syncthreads();
+    if (l == s.pf.border_position[env]) {
+      xp_init_rot_env(cx, &s.ps, &s.pf, env, usb);
+      env++;
+    }
+    const int shiftdelay = l < 32 - 6 ? 0 : (int16_t)(lb_scale - ps_scale); /* thumb_ps_dec.c:77 */
+    xp_hybrid_analysis(cx, s.ahead, s.ahead + 4, &s.ps, &s.hy, shiftdelay);
+    xp_decorrelation(cx, &s.ps, &s.hy, s.left, s.right, s.ratio);
+    xp_apply_rot(cx, &s.ps, &s.hy, s.left, s.right);
+    for (int k = lane; k < 128; k += 64) {
+      int32_t v = s.left[k];
+      if (common_shift < 0)
+        v = fx_shr(v, -common_shift > 31 ? 31 : -common_shift);
+      else if (common_shift > 0)
+        v = fx_shl_sat(v, common_shift);
+      gx[l * 128 + k] = v;
+      gr[l * 128 + k] = s.right[k];
+    }
+    __syncthreads();
+  }
+  /* ---- state and the two synthesis launches' parameters ---- */
+  {
+    int32_t *dst = reinterpret_cast<int32_t *>(gps);
+    const int32_t *src = reinterpret_cast<const int32_t *>(&s.ps);
+    for (int i = lane; i < kHeadWords; i += 64) dst[i] = src[i];
+  }
+  if (lane == 0) {
+    int16_t *pr = p.par_r + 8 * (size_t)n;
+    const int16_t ready = (int16_t)(st_syn - 8); /* makes the bank's own rescale a no-op: data is in place */
+    par[0] = par[1] = par[2] = ready;
+    pr[0] = pr[1] = pr[2] = (int16_t)ps_scale;
+    pr[3] = gps->st_syn_scale_r;
+    pr[4] = gps->syn_lsb_r;
+    pr[5] = gps->syn_usb_r;
+    pr[6] = 0;
+    par[6] = 0;
+    gps->lb_scale_r = gps->ov_lb_scale_r = gps->hb_scale_r = (int16_t)ps_scale; /* sbr_dec.c:1261-1264 */
+    p.sbr_state[n].ps_scale = (int16_t)ps_scale;
+  }
+}
+
+extern "C" hipError_t xaac_launch_ps(const XaacPsParams *p, hipStream_t stream) {
+  hipLaunchKernelGGL(xaac_ps_kernel, dim3(p->n), dim3(64), 0, stream, *p);
+  return hipGetLastError();
+}

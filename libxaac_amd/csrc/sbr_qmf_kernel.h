@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "../../include/xaac_amd.h"
+#include "../../include/xaac_sbr.h"
 
 #define XAAC_QMF_WAVES 2                       /* waves per workgroup; each wave owns two channel-frames */
 #define XAAC_QMF_BLOCK (64 * XAAC_QMF_WAVES)
@@ -25,6 +26,11 @@ typedef struct XaacQmfAnaParams {
   const int16_t *pcm;
   xaac_qmf_ana_state *state;
   int32_t *qmf;
+  /* fused SBR path, HQ mode: the band limit of the final rotation is per channel -- what
+     ixheaacd_rescale_x_overlap (sbrdec_lpfuncs.c:470) leaves in str_codec_qmf_bank.usb before the bank
+     runs: frame->max_qmf_subband_aac when the frame is processed, else the state's codec_usb (state then
+     points into xaac_sbr_state).  NULL: use `usb` for every channel. */
+  const xaac_sbr_frame *frame;
 } XaacQmfAnaParams;
 
 typedef struct XaacQmfSynParams {
@@ -36,6 +42,9 @@ typedef struct XaacQmfSynParams {
   const int16_t *scale;
   xaac_qmf_syn_state *state;
   int16_t *pcm;
+  /* output addressing: 0 -> the ch_fac interleave of the C ABI; else channel c's sample n goes to
+     pcm[c * pcm_ch_stride + n * pcm_sample_stride] (one launch per output channel of a PS stream) */
+  int32_t pcm_ch_stride, pcm_sample_stride;
 } XaacQmfSynParams;
 
 #ifdef __cplusplus

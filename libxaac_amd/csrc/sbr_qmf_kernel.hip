@@ -119,7 +119,17 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_analysis_kernel(XaacQ
         for (int k = 0; k < 32; k++) z[65 * lane + k] = out[k];
       } else {
         int32_t sb[128], t[128];
-        xq_fwd_modulation(in, sb, t, p.usb);
+        int nrot = p.usb;
+        if (p.frame) { /* lanes 0..31 are the slots of the pair's first channel, 32..63 of its second */
+          const int ch = 2 * pair + (lane >> 5);
+          if (ch < p.n_ch) {
+            const xaac_sbr_frame *f = p.frame + ch;
+            const xaac_sbr_state *sst = reinterpret_cast<const xaac_sbr_state *>(
+                reinterpret_cast<const char *>(p.state) + (size_t)ch * p.state_stride);
+            nrot = f->apply_processing ? f->max_qmf_subband_aac : sst->codec_usb;
+          }
+        }
+        xq_fwd_modulation(in, sb, t, nrot);
 #pragma unroll
         for (int k = 0; k < 32; k++) {
           z[65 * lane + k] = sb[k];
@@ -240,8 +250,10 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
     for (int c = 0; c < 2; c++) {
       const int ch = 2 * pair + c;
       if (ch >= p.n_ch) break;
-      const int cf = p.ch_fac;
-      int16_t *dst = p.pcm + (size_t)(ch / cf) * 2048 * cf + (ch % cf);
+      if (p.per_ch_bands && p.scale[(size_t)p.scale_stride * ch + 6]) continue; /* channel inactive this frame */
+      const int cf = p.pcm_sample_stride ? p.pcm_sample_stride : p.ch_fac;
+      int16_t *dst = p.pcm_sample_stride ? p.pcm + (size_t)ch * p.pcm_ch_stride
+                                         : p.pcm + (size_t)(ch / cf) * 2048 * cf + (ch % cf);
       const int shift = LP ? 2 : 1;
       for (int s = 0; s < 32; s++) {
         const int16_t *vs = v + (c * VSLOTS + 9 + s) * 128 + lane;
@@ -255,6 +267,7 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
     for (int c = 0; c < 2; c++) {
       const int ch = 2 * pair + c;
       if (ch >= p.n_ch) break;
+      if (p.per_ch_bands && p.scale[(size_t)p.scale_stride * ch + 6]) continue;
       xaac_qmf_syn_state *st =
           reinterpret_cast<xaac_qmf_syn_state *>(reinterpret_cast<char *>(p.state) + (size_t)ch * p.state_stride);
       const int d_new = (st->drc_offset + 1024) % 1280;

@@ -15,6 +15,7 @@
 #include "imdct_kernel.h"
 #include "sbr_qmf_kernel.h"
 #include "sbr_core_kernel.h"
+#include "sbr_ps_kernel.h"
 #include <cstddef>
 
 struct xaac_ctx {
@@ -199,7 +200,7 @@ int32_t xaac_qmf_analysis_batch(xaac_ctx *c, const xaac_qmf_ana_batch *b) {
   if (b->slot_stride < (b->low_pow ? 32 : 96) || b->usb < 0 || b->usb > 32) return XAAC_FATAL_BAD_ARG;
   if (b->n_ch == 0) return XAAC_OK;
   if (!b->pcm || !b->state || !b->qmf) return XAAC_FATAL_NULL_ARG;
-  XaacQmfAnaParams p;
+  XaacQmfAnaParams p = {};
   p.n_ch = b->n_ch; p.ch_fac = b->ch_fac; p.low_pow = b->low_pow ? 1 : 0; p.usb = b->usb;
   p.slot_stride = b->slot_stride; p.pcm = b->pcm; p.state = b->state; p.qmf = b->qmf;
   p.state_stride = (int32_t)sizeof(xaac_qmf_ana_state); p.qmf_ch_stride = 32 * b->slot_stride;
@@ -217,7 +218,7 @@ int32_t xaac_qmf_synthesis_batch(xaac_ctx *c, const xaac_qmf_syn_batch *b) {
   if (b->lsb < 0 || b->usb < b->lsb || b->usb > 64 || b->split < 0 || b->split > 32) return XAAC_FATAL_BAD_ARG;
   if (b->n_ch == 0) return XAAC_OK;
   if (!b->qmf || !b->scale || !b->state || !b->pcm) return XAAC_FATAL_NULL_ARG;
-  XaacQmfSynParams p;
+  XaacQmfSynParams p = {};
   p.n_ch = b->n_ch; p.ch_fac = b->ch_fac; p.low_pow = b->low_pow ? 1 : 0; p.lsb = b->lsb; p.usb = b->usb;
   p.split = b->split; p.slot_stride = b->slot_stride; p.qmf = b->qmf; p.scale = b->scale; p.state = b->state;
   p.pcm = b->pcm;
@@ -249,7 +250,7 @@ int32_t xaac_sbr_lp_process_batch(xaac_ctx *c, const xaac_sbr_lp_batch *b) {
   int16_t *par = reinterpret_cast<int16_t *>(x + (size_t)b->n_ch * XAAC_SBR_X_WORDS);
   char *st = reinterpret_cast<char *>(b->state);
   /* 1. analysis bank: 32 new slots into rows 8..39 of each channel's matrix */
-  XaacQmfAnaParams pa;
+  XaacQmfAnaParams pa = {};
   pa.n_ch = b->n_ch; pa.ch_fac = b->in_ch_fac; pa.low_pow = 1; pa.usb = 32; pa.slot_stride = 64;
   pa.state_stride = (int32_t)sizeof(xaac_sbr_state); pa.qmf_ch_stride = XAAC_SBR_X_WORDS;
   pa.pcm = b->pcm_in;
@@ -262,7 +263,7 @@ int32_t xaac_sbr_lp_process_batch(xaac_ctx *c, const xaac_sbr_lp_batch *b) {
   pc.status = b->status;
   if (!hip_ok(xaac_launch_sbr_core_lp(&pc, c->stream))) return XAAC_FATAL_HIP;
   /* 3. synthesis bank over rows 2..33 (the 6 delayed + first 26 new slots) */
-  XaacQmfSynParams ps;
+  XaacQmfSynParams ps = {};
   ps.n_ch = b->n_ch; ps.ch_fac = b->out_ch_fac; ps.low_pow = 1; ps.lsb = 0; ps.usb = 0; ps.split = 6;
   ps.slot_stride = 64; ps.state_stride = (int32_t)sizeof(xaac_sbr_state); ps.qmf_ch_stride = XAAC_SBR_X_WORDS;
   ps.scale_stride = 8; ps.per_ch_bands = 1;
@@ -272,6 +273,76 @@ int32_t xaac_sbr_lp_process_batch(xaac_ctx *c, const xaac_sbr_lp_batch *b) {
   const int grid = qmf_grid(c, b->n_ch, 2);
   if (!hip_ok(xaac_launch_qmf_synthesis(&ps, grid, c->stream))) return XAAC_FATAL_HIP;
   c->last_grid = grid; c->last_block = XAAC_QMF_BLOCK; c->last_lds = XAAC_QMF_WAVES * XAAC_QMF_SYN_LDS_PER_WAVE_LP;
+  return XAAC_OK;
+}
+
+uint64_t xaac_sbr_hq_workspace_bytes(int32_t n_ch, int32_t with_ps) {
+  if (n_ch < 0) return 0;
+  uint64_t per = 2 * XAAC_SBR_X_WORDS * 4 + 8 * 2;
+  if (with_ps) per += 32 * 128 * 4 + 8 * 2;
+  return (uint64_t)n_ch * per + 512;
+}
+
+int32_t xaac_sbr_hq_process_batch(xaac_ctx *c, const xaac_sbr_hq_batch *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n_ch < 0) return XAAC_FATAL_BAD_ARG;
+  const bool with_ps = b->ps_frame != nullptr;
+  if ((b->ps_frame == nullptr) != (b->ps_state == nullptr)) return XAAC_FATAL_BAD_ARG;
+  if (b->in_ch_fac != 1 && b->in_ch_fac != 2) return XAAC_FATAL_BAD_ARG;
+  if (!with_ps && b->out_ch_fac != 1 && b->out_ch_fac != 2) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch % b->in_ch_fac || (!with_ps && b->n_ch % b->out_ch_fac)) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch == 0) return XAAC_OK;
+  if (!b->pcm_in || !b->header || !b->frame || !b->state || !b->pcm_out || !b->workspace) return XAAC_FATAL_NULL_ARG;
+  if (b->workspace_bytes < xaac_sbr_hq_workspace_bytes(b->n_ch, with_ps)) return XAAC_FATAL_BAD_ARG;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  const size_t n = (size_t)b->n_ch;
+  const int xw = 2 * XAAC_SBR_X_WORDS; /* 40 rows of 64 real | 64 imaginary per stream */
+  int32_t *x = reinterpret_cast<int32_t *>(((uintptr_t)b->workspace + 255) & ~(uintptr_t)255);
+  int32_t *xr = x + n * xw;
+  int16_t *par_l = reinterpret_cast<int16_t *>(xr + (with_ps ? n * 32 * 128 : 0));
+  int16_t *par_r = par_l + n * 8;
+  char *st = reinterpret_cast<char *>(b->state);
+  /* 1. complex analysis bank: 32 new slots into rows 8..39 of each stream's matrix */
+  XaacQmfAnaParams pa = {};
+  pa.n_ch = b->n_ch; pa.ch_fac = b->in_ch_fac; pa.low_pow = 0; pa.usb = 32; pa.slot_stride = 128;
+  pa.state_stride = (int32_t)sizeof(xaac_sbr_state); pa.qmf_ch_stride = xw;
+  pa.pcm = b->pcm_in;
+  pa.state = reinterpret_cast<xaac_qmf_ana_state *>(st + offsetof(xaac_sbr_state, ana_ring));
+  pa.qmf = x + (2 + 6) * 128;
+  pa.frame = b->frame;
+  if (!hip_ok(xaac_launch_qmf_analysis(&pa, qmf_grid(c, b->n_ch, 1), c->stream))) return XAAC_FATAL_HIP;
+  /* 2. everything between the banks */
+  XaacSbrCoreParams pc;
+  pc.n_ch = b->n_ch; pc.header = b->header; pc.frame = b->frame; pc.state = b->state; pc.x = x; pc.syn_par = par_l;
+  pc.status = b->status;
+  if (!hip_ok(xaac_launch_sbr_core_hq(&pc, c->stream))) return XAAC_FATAL_HIP;
+  /* 3. parametric stereo: rows 2..33 become the left channel, xr the right one */
+  if (with_ps) {
+    XaacPsParams pp;
+    pp.n = b->n_ch; pp.x = x; pp.xr = xr; pp.header = b->header; pp.sbr_frame = b->frame; pp.frame = b->ps_frame;
+    pp.state = b->ps_state; pp.sbr_state = b->state; pp.par_l = par_l; pp.par_r = par_r;
+    if (!hip_ok(xaac_launch_ps(&pp, c->stream))) return XAAC_FATAL_HIP;
+  }
+  /* 4. synthesis bank(s) over the 6 delayed + first 26 new slots */
+  XaacQmfSynParams ps = {};
+  ps.n_ch = b->n_ch; ps.ch_fac = with_ps ? 1 : b->out_ch_fac; ps.low_pow = 0; ps.split = 6;
+  ps.slot_stride = 128; ps.state_stride = (int32_t)sizeof(xaac_sbr_state); ps.qmf_ch_stride = xw;
+  ps.scale_stride = 8; ps.per_ch_bands = 1;
+  ps.qmf = x + 2 * 128; ps.scale = par_l;
+  ps.state = reinterpret_cast<xaac_qmf_syn_state *>(st + offsetof(xaac_sbr_state, syn_ring));
+  ps.pcm = b->pcm_out;
+  if (with_ps) { ps.pcm_ch_stride = 2 * 2048; ps.pcm_sample_stride = 2; }
+  const int grid = qmf_grid(c, b->n_ch, 3);
+  if (!hip_ok(xaac_launch_qmf_synthesis(&ps, grid, c->stream))) return XAAC_FATAL_HIP;
+  if (with_ps) {
+    ps.state_stride = (int32_t)sizeof(xaac_ps_state); ps.qmf_ch_stride = 32 * 128;
+    ps.qmf = xr; ps.scale = par_r;
+    ps.state = reinterpret_cast<xaac_qmf_syn_state *>(reinterpret_cast<char *>(b->ps_state) +
+                                                      offsetof(xaac_ps_state, syn_ring_r));
+    ps.pcm = b->pcm_out + 1;
+    if (!hip_ok(xaac_launch_qmf_synthesis(&ps, grid, c->stream))) return XAAC_FATAL_HIP;
+  }
+  c->last_grid = grid; c->last_block = XAAC_QMF_BLOCK; c->last_lds = XAAC_QMF_WAVES * XAAC_QMF_SYN_LDS_PER_WAVE_HQ;
   return XAAC_OK;
 }
 

@@ -120,7 +120,7 @@ extern "C" int xo_sbr_dec_hq(const xaac_sbr_header *h, const xaac_sbr_frame *f, 
   s.drc_offset = st->syn_drc_offset;
   s.phase = st->syn_phase;
   if (f->apply_processing && h->channel_mode == 3 && pf && ps) {
-    const int ps_scale = xp_init_ps_scale(ps, st->lb_scale, st->ov_lb_scale, st->hb_scale);
+    const int ps_scale = xp_init_ps_scale(cx, ps, st->lb_scale, st->ov_lb_scale, st->hb_scale);
     st->ps_scale = (int16_t)ps_scale;
     const int lsb = st->syn_lsb, usb = st->syn_usb, st_syn = st->st_syn_scale;
     const int ov_lb_shift = ps_scale - st->ov_lb_scale, lb_shift = ps_scale - st->lb_scale,
@@ -136,14 +136,15 @@ extern "C" int xo_sbr_dec_hq(const xaac_sbr_header *h, const xaac_sbr_frame *f, 
       int32_t right[128];
       XpHyb hy;
       memset(&hy, 0, sizeof(hy));
+      int16_t ratio[21];
       if (l == pf->border_position[env]) {
-        xp_init_rot_env(ps, pf, env, usb);
+        xp_init_rot_env(cx, ps, pf, env, usb);
         env++;
       }
       const int shiftdelay = l < 32 - 6 ? 0 : (int16_t)(st->lb_scale - ps_scale); /* thumb_ps_dec.c:77 */
-      xp_hybrid_analysis(&x(l + 6, 0), ps, &hy, shiftdelay);
-      xp_decorrelation(ps, &hy, &x(l, 0), right);
-      xp_apply_rot(ps, &hy, &x(l, 0), right);
+      xp_hybrid_analysis(cx, &x(l + 6, 0), &x.im(l + 6, 0), ps, &hy, shiftdelay);
+      xp_decorrelation(cx, ps, &hy, &x(l, 0), right, ratio);
+      xp_apply_rot(cx, ps, &hy, &x(l, 0), right);
 #ifdef XO_PS_DEBUG
       {
         static FILE *df;

@@ -38,3 +38,28 @@ def test_oracle_reproduces_reference_records(oracle):
         kinds.add((r["frame"].num_env, r["header"].interpol_freq, max(r["frame"].sbr_invf_mode[:3]) > 0))
     # the fixture really covers multi-envelope frames, interpolation off and active inverse filtering
     assert {k[0] for k in kinds} >= {1, 3, 4} and any(k[1] == 0 for k in kinds) and any(k[2] for k in kinds)
+
+
+def test_hq_ps_oracle_reproduces_reference_records(oracle):
+    """HE-AACv2: HQ SBR + parametric stereo (tests/golden/sbr_hq_ps_records.bin.gz, tools/make_golden_sbr_hq.py)."""
+    assert (ctypes.sizeof(cap.PsFrame), ctypes.sizeof(cap.PsState)) == (972, 7764)
+    recs = cap.read_records(os.path.join(ROOT, "tests", "golden", "sbr_hq_ps_records.bin.gz"))
+    assert len(recs) >= 40
+    kinds = set()
+    for r in recs:
+        st = cap.State.from_buffer_copy(bytes(r["st0"]))
+        ps = cap.PsState.from_buffer_copy(bytes(r["ps0"]))
+        out = np.zeros(4096, np.int16)
+        pin = np.ascontiguousarray(r["pcm_in"])
+        rc = oracle.lib.xo_sbr_dec_hq(ctypes.byref(r["header"]), ctypes.byref(r["frame"]), ctypes.byref(st),
+                                      ctypes.byref(r["ps_frame"]), ctypes.byref(ps), pin.ctypes.data_as(P16), 1,
+                                      out.ctypes.data_as(P16), 2)
+        assert rc == r["ret"]
+        assert np.array_equal(out[0::2], r["pcm_out"][0]) and np.array_equal(out[1::2], r["pcm_out"][1]), r["call"]
+        assert not cap.diff_state(st, r["st1"]), (r["call"], cap.diff_state(st, r["st1"])[:3])
+        assert not cap.diff_state(ps, r["ps1"]), (r["call"], cap.diff_state(ps, r["ps1"])[:3])
+        kinds.add((r["header"].smoothing_mode, r["ps_frame"].iid_quant, max(r["frame"].sbr_invf_mode[:3]) > 0,
+                   r["header"].interpol_freq))
+    # gain smoothing on, fine IID quantiser, active inverse filtering, energies per scale-factor band all present
+    assert any(k[0] == 0 for k in kinds) and any(k[1] for k in kinds) and any(k[2] for k in kinds)
+    assert any(k[3] == 0 for k in kinds)

@@ -1,0 +1,147 @@
+"""HE-AACv2 on the GPU through the C ABI (HQ SBR + parametric stereo, xaac_sbr_hq_process_batch): against the
+committed records of the real reference, and against the oracle on fuzzed chains with the SBR and PS state living
+on the device."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import sbr_capture as cap
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P16 = ctypes.POINTER(ctypes.c_int16)
+GOLDEN = os.path.join(ROOT, "tests", "golden", "sbr_hq_ps_records.bin.gz")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import libxaac_amd
+    c = libxaac_amd.XaacContext(0, 0)
+    yield c
+    c.close()
+
+
+def gpu_run(ctx, headers, frames, states, ps_frames, ps_states, pcm_in):
+    import torch
+    n = len(states)
+    t = lambda objs: torch.from_numpy(np.frombuffer(b"".join(bytes(o) for o in objs), np.uint8).reshape(n, -1).copy()).cuda()
+    t_h, t_f, t_s = t(headers), t(frames), t(states)
+    with_ps = ps_frames is not None
+    t_pf, t_ps = (t(ps_frames), t(ps_states)) if with_ps else (None, None)
+    out = torch.zeros(n * 2048 * (2 if with_ps else 1), dtype=torch.int16, device="cuda")
+    status = torch.full((n,), 7, dtype=torch.int32, device="cuda")
+    ws = torch.zeros(ctx.sbr_hq_workspace_bytes(n, with_ps), dtype=torch.uint8, device="cuda")
+    ctx.sbr_hq_process_batch(torch.from_numpy(np.ascontiguousarray(pcm_in)).cuda(), t_h, t_f, t_s, out, ws, t_pf, t_ps,
+                             status)
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), t_s.cpu().numpy(), (t_ps.cpu().numpy() if with_ps else None), status.cpu().numpy()
+
+
+def test_reference_records(ctx):
+    recs = cap.read_records(GOLDEN)
+    pcm_in = np.concatenate([r["pcm_in"] for r in recs])
+    out, st, ps, status = gpu_run(ctx, [r["header"] for r in recs], [r["frame"] for r in recs], [r["st0"] for r in recs],
+                                  [r["ps_frame"] for r in recs], [r["ps0"] for r in recs], pcm_in)
+    for i, r in enumerate(recs):
+        assert status[i] == r["ret"]
+        o = out[4096 * i:4096 * (i + 1)]
+        assert np.array_equal(o[0::2], r["pcm_out"][0]), ("left", i, r["call"], int(np.sum(o[0::2] != r["pcm_out"][0])))
+        assert np.array_equal(o[1::2], r["pcm_out"][1]), ("right", i, r["call"], int(np.sum(o[1::2] != r["pcm_out"][1])))
+        got = cap.State.from_buffer_copy(st[i].tobytes())
+        assert not cap.diff_state(got, r["st1"]), (i, r["call"], cap.diff_state(got, r["st1"])[:3])
+        gps = cap.PsState.from_buffer_copy(ps[i].tobytes())
+        assert not cap.diff_state(gps, r["ps1"]), (i, r["call"], cap.diff_state(gps, r["ps1"])[:3])
+
+
+def _fuzz(rng, h, f, pf):
+    for k in range(h.num_if_bands):
+        f.sbr_invf_mode[k] = int(rng.integers(0, 4))
+    h.limiter_gains = int(rng.integers(0, 4))
+    h.interpol_freq = int(rng.integers(0, 2))
+    h.smoothing_mode = int(rng.integers(0, 2))
+    if rng.integers(0, 3) == 0:
+        for k in range(h.num_sf_bands[1]):
+            f.add_harmonics[k] = int(rng.integers(0, 4) == 0)
+    if pf is not None:
+        pf.iid_quant = int(rng.integers(0, 2))
+        nenv = int(rng.integers(1, 5))
+        borders = [0] + sorted(rng.choice(np.arange(1, 32), nenv - 1, replace=False).tolist()) + [32]
+        for e in range(7):
+            pf.border_position[e] = borders[e] if e < len(borders) else 0
+        lim = 15 if pf.iid_quant else 7
+        for e in range(nenv):
+            for b in range(20):
+                pf.iid_par_table[e][b] = int(rng.integers(-lim, lim + 1))
+                pf.icc_par_table[e][b] = int(rng.integers(0, 8))
+
+
+def test_fuzzed_chain_vs_oracle(ctx, oracle):
+    """48 streams built from the golden records: 10 frames of fuzzed SBR / PS side info and random core PCM, the
+    state carried on the device; every frame must equal the oracle.  One stream per step is left unprocessed
+    (apply_processing = 0): its right channel and PS state must stay untouched."""
+    recs = cap.read_records(GOLDEN)
+    n = len(recs)
+    rng = np.random.default_rng(19)
+    states = [cap.State.from_buffer_copy(bytes(r["st0"])) for r in recs]
+    pstates = [cap.PsState.from_buffer_copy(bytes(r["ps0"])) for r in recs]
+    for step in range(10):
+        headers, frames, pframes = [], [], []
+        for i, r in enumerate(recs):
+            h = cap.Header.from_buffer_copy(bytes(r["header"]))
+            f = cap.Frame.from_buffer_copy(bytes(r["frame"]))
+            pf = cap.PsFrame.from_buffer_copy(bytes(r["ps_frame"]))
+            _fuzz(rng, h, f, pf)
+            if i == step:
+                f.apply_processing = 0
+            headers.append(h); frames.append(f); pframes.append(pf)
+        amp = [30000, 3000, 200][step % 3]
+        pcm = rng.integers(-amp, amp, (n, 1024)).astype(np.int16)
+        out, st_bytes, ps_bytes, status = gpu_run(ctx, headers, frames, states, pframes, pstates, pcm.reshape(-1))
+        new_states, new_ps = [], []
+        for i in range(n):
+            so = cap.State.from_buffer_copy(bytes(states[i]))
+            po = cap.PsState.from_buffer_copy(bytes(pstates[i]))
+            ref_out = np.zeros(4096, np.int16)
+            rc = oracle.lib.xo_sbr_dec_hq(ctypes.byref(headers[i]), ctypes.byref(frames[i]), ctypes.byref(so),
+                                          ctypes.byref(pframes[i]), ctypes.byref(po), pcm[i].ctypes.data_as(P16), 1,
+                                          ref_out.ctypes.data_as(P16), 2)
+            o = out[4096 * i:4096 * (i + 1)]
+            assert status[i] == rc, (step, i)
+            assert np.array_equal(o[0::2], ref_out[0::2]), ("left", step, i, int(np.sum(o[0::2] != ref_out[0::2])))
+            if frames[i].apply_processing:
+                assert np.array_equal(o[1::2], ref_out[1::2]), ("right", step, i)
+            else:
+                assert not o[1::2].any()      # nothing written (the output tensor starts zeroed)
+            gs = cap.State.from_buffer_copy(st_bytes[i].tobytes())
+            gp = cap.PsState.from_buffer_copy(ps_bytes[i].tobytes())
+            assert not cap.diff_state(gs, so), (step, i, cap.diff_state(gs, so)[:3])
+            assert not cap.diff_state(gp, po), (step, i, cap.diff_state(gp, po)[:3])
+            new_states.append(gs); new_ps.append(gp)
+        states, pstates = new_states, new_ps
+
+
+def test_hq_mono_without_ps_vs_oracle(ctx, oracle):
+    """HQ SBR alone (HE-AAC mono in HQ mode): the same records run with channel_mode = mono and no PS buffers"""
+    recs = cap.read_records(GOLDEN)[:24]
+    n = len(recs)
+    rng = np.random.default_rng(23)
+    headers, frames, states = [], [], []
+    for r in recs:
+        h = cap.Header.from_buffer_copy(bytes(r["header"]))
+        f = cap.Frame.from_buffer_copy(bytes(r["frame"]))
+        _fuzz(rng, h, f, None)
+        h.channel_mode = 1
+        headers.append(h); frames.append(f); states.append(cap.State.from_buffer_copy(bytes(r["st0"])))
+    pcm = rng.integers(-20000, 20000, (n, 1024)).astype(np.int16)
+    out, st_bytes, _, status = gpu_run(ctx, headers, frames, states, None, None, pcm.reshape(-1))
+    for i in range(n):
+        so = cap.State.from_buffer_copy(bytes(states[i]))
+        ref_out = np.zeros(2048, np.int16)
+        rc = oracle.lib.xo_sbr_dec_hq(ctypes.byref(headers[i]), ctypes.byref(frames[i]), ctypes.byref(so), None, None,
+                                      pcm[i].ctypes.data_as(P16), 1, ref_out.ctypes.data_as(P16), 1)
+        assert status[i] == rc
+        assert np.array_equal(out[2048 * i:2048 * (i + 1)], ref_out), (i, int(np.sum(out[2048 * i:2048 * (i + 1)] != ref_out)))
+        gs = cap.State.from_buffer_copy(st_bytes[i].tobytes())
+        assert not cap.diff_state(gs, so), (i, cap.diff_state(gs, so)[:3])
