@@ -115,6 +115,100 @@ def make_inputs_c3(torch, device, sets, seed):
     return batches
 
 
+# ---- workload C4: HE-AACv2 mono + parametric stereo (BASELINE.json configs[3]) -----------------------------
+# R: spec 4096 + overlap 2048 + SBR header 336 / frame 1072 / state 7300 + PS frame 972 / state 7764;
+# W: overlap 2048 + SBR state 7300 + PS state 7764 + PCM16 L,R 8192 -- per stream and frame, DESIGN.md
+C4_ALG_BYTES_PER_STREAM = (4096 + 2048 + 336 + 1072 + 7300 + 972 + 7764) + (2048 + 7300 + 7764 + 8192)
+
+
+def make_inputs_c4(torch, device, sets, seed):
+    """One mono core channel per stream (24 kHz core: bins < 512 populated) + SBR and PS side info cycled from
+    the committed reference-captured HE-AACv2 frames (tests/golden/sbr_hq_ps_records.bin.gz)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import sbr_capture as cap
+    recs = [r for r in cap.read_records(os.path.join(ROOT, "tests", "golden", "sbr_hq_ps_records.bin.gz")) if r["enh"] == 0]
+    groups = {}
+    for r in recs:
+        groups.setdefault(bytes(r["header"]), []).append(r)
+    groups = list(groups.values())
+    n = FRAMES_PER_STEP
+    g = torch.Generator(device=device)
+    g.manual_seed(0xC0FFEE + seed)
+    rows = lambda key, size, pick: torch.from_numpy(np.stack(
+        [np.frombuffer(bytes(pick(groups[c % len(groups)], c)[key]), np.uint8) for c in range(n)])).to(device)
+    hdr = rows("header", 336, lambda grp, c: grp[0])
+    st0 = rows("st0", 7300, lambda grp, c: grp[0])
+    ps0 = rows("ps0", 7764, lambda grp, c: grp[0])
+    frames = [(rows("frame", 1072, lambda grp, c, v=v: grp[(c + v) % len(grp)]),
+               rows("ps_frame", 972, lambda grp, c, v=v: grp[(c + v) % len(grp)])) for v in range(4)]
+    batches = []
+    for s in range(sets):
+        spec = torch.randint(-(1 << 17), 1 << 17, (n, 1024), generator=g, device=device, dtype=torch.int32)
+        spec[:, 512:] = 0
+        batches.append({"spec": spec, "ics": torch.zeros((n, 2), dtype=torch.uint8, device=device),
+                        "overlap": torch.zeros((n, 512), dtype=torch.int32, device=device),
+                        "state": torch.zeros((n, 2), dtype=torch.uint8, device=device),
+                        "core_pcm": torch.zeros(n * 1024, dtype=torch.int16, device=device),
+                        "hdr": hdr, "frames": frames, "sbr_state": st0.clone(), "ps_state": ps0.clone(),
+                        "pcm": torch.zeros(n * 4096, dtype=torch.int16, device=device)})
+    return batches
+
+
+def cpu_baseline_sbr(workload, seconds_budget=10.0):
+    """CPU baseline of the SBR workloads: the compiled reference's own ixheaacd_sbr_dec driven through
+    oracle/ref_sbr_adapter.c (kind "reference") or, where oracle/_ref did not travel, the bit-exact restatement
+    (kind "port"), on the committed reference-captured frames, one chain of frames per thread, all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    import sbr_capture as cap
+    P16 = ctypes.POINTER(ctypes.c_int16)
+    hq = workload == "c4"
+    recs = [r for r in cap.read_records(os.path.join(ROOT, "tests", "golden",
+            "sbr_hq_ps_records.bin.gz" if hq else "sbr_lp_records.bin.gz")) if r["enh"] == 0]
+    ref = oracle_lib.load_reference()
+    fn_name = ("ref_sbr_dec_hq" if hq else "ref_sbr_dec_lp")
+    if ref is not None and hasattr(ref.lib, fn_name):
+        kind, fn = "reference", getattr(ref.lib, fn_name)
+    else:
+        kind, fn = "port", getattr(oracle_lib.load_oracle().lib, "xo_sbr_dec_hq" if hq else "xo_sbr_dec_lp")
+    cores = os.cpu_count() or 1
+    reps = 8
+
+    def chain(t, count):
+        out = np.zeros(4096, np.int16)
+        for k in range(count):
+            r = recs[(t + k) % len(recs)]
+            st = cap.State.from_buffer_copy(bytes(r["st0"]))
+            pin = r["pcm_in"]
+            if hq:
+                ps = cap.PsState.from_buffer_copy(bytes(r["ps0"]))
+                fn(ctypes.byref(r["header"]), ctypes.byref(r["frame"]), ctypes.byref(st), ctypes.byref(r["ps_frame"]),
+                   ctypes.byref(ps), pin.ctypes.data_as(P16), 1, out.ctypes.data_as(P16), 2)
+            else:
+                fn(ctypes.byref(r["header"]), ctypes.byref(r["frame"]), ctypes.byref(st), pin.ctypes.data_as(P16), 1,
+                   out.ctypes.data_as(P16), 1)
+
+    def one_pass(nthreads, count):
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=chain, args=(t, count)) for t in range(nthreads)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        return time.perf_counter() - t0
+
+    one_pass(cores, 2)
+    t1 = min(one_pass(1, reps) for _ in range(2))
+    best, spent, passes = 1e9, 0.0, 0
+    while spent < seconds_budget and passes < 200:
+        dt = one_pass(cores, reps)
+        best, spent, passes = min(best, dt), spent + dt, passes + 1
+    per_frame = 1.0 if hq else 0.5     # C3 counts stereo frames: two channel calls each
+    return {"value": round(cores * reps * per_frame / best, 1), "unit": "frames/s", "cores": cores, "kind": kind,
+            "value_1core": round(reps * per_frame / t1, 1),
+            "sample": "%d ixheaacd_sbr_dec calls per thread per pass on the committed reference-captured frames "
+                      "(python call overhead included), %d passes; SBR chain only, the core IMDCT is not in it"
+                      % (reps, passes)}
+
+
 def cpu_baseline(seconds_budget=12.0):
     """Time the CPU path on a bounded sample of the same workload (all host cores,
     one contiguous shard of channel-frames per thread)."""
@@ -182,8 +276,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--sets", type=int, default=4, help="independent 8192-stream batches cycled per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
-                    help="c2: AAC-LC IMDCT+OLA (BASELINE configs[1], default); c3: HE-AACv1 stereo, IMDCT + LP-SBR")
+    ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
+                    help="c2: AAC-LC IMDCT+OLA (BASELINE configs[1], default); c3: HE-AACv1 stereo, IMDCT + LP-SBR; "
+                         "c4: HE-AACv2, mono IMDCT + HQ-SBR + parametric stereo")
     args = ap.parse_args()
 
     import torch
@@ -200,11 +295,16 @@ def main():
     stream = torch.cuda.Stream(device=dev)      # kernels AND timing events go on this one stream
     torch.cuda.set_stream(stream)
     ctx = libxaac_amd.XaacContext(local_rank, stream.cuda_stream)
-    c3 = args.workload == "c3"
-    batches = make_inputs_c3(torch, dev, args.sets, rank) if c3 else make_inputs(torch, dev, args.sets, rank)
+    c3, c4 = args.workload == "c3", args.workload == "c4"
+    batches = (make_inputs_c3(torch, dev, args.sets, rank) if c3 else make_inputs_c4(torch, dev, args.sets, rank) if c4
+               else make_inputs(torch, dev, args.sets, rank))
     for b in batches:                 # window shape alternates per frame; state follows
-        b["ics"][:, 1] = (torch.arange(b["ics"].shape[0], device=dev) // CH % 2).to(torch.uint8)
-    ws = torch.zeros(ctx.sbr_lp_workspace_bytes(FRAMES_PER_STEP * CH), dtype=torch.uint8, device=dev) if c3 else None
+        b["ics"][:, 1] = (torch.arange(b["ics"].shape[0], device=dev) // (1 if c4 else CH) % 2).to(torch.uint8)
+    ws = None
+    if c3:
+        ws = torch.zeros(ctx.sbr_lp_workspace_bytes(FRAMES_PER_STEP * CH), dtype=torch.uint8, device=dev)
+    if c4:
+        ws = torch.zeros(ctx.sbr_hq_workspace_bytes(FRAMES_PER_STEP, True), dtype=torch.uint8, device=dev)
 
     def step(i, ev=None):
         b = batches[i % len(batches)]
@@ -216,6 +316,12 @@ def main():
                                     ch_fac=1, pcm_mode=libxaac_amd.PCM_SBR)
             ctx.sbr_lp_process_batch(b["core_pcm"], b["hdr"], b["frames"][(i // len(batches)) % len(b["frames"])],
                                      b["sbr_state"], b["pcm"], ws, None, in_ch_fac=1, out_ch_fac=CH)
+        elif c4:
+            # mono core back-end, then HQ SBR + parametric stereo -> L,R pairs
+            ctx.imdct_process_batch(b["spec"], b["ics"], b["overlap"], b["state"], None, b["core_pcm"], None,
+                                    ch_fac=1, pcm_mode=libxaac_amd.PCM_SBR)
+            fr, pfr = b["frames"][(i // len(batches)) % len(b["frames"])]
+            ctx.sbr_hq_process_batch(b["core_pcm"], b["hdr"], fr, b["sbr_state"], b["pcm"], ws, pfr, b["ps_state"])
         else:
             ctx.imdct_process_batch(b["spec"], b["ics"], b["overlap"], b["state"], None, b["pcm"], None,
                                     ch_fac=CH, pcm_mode=libxaac_amd.PCM_LC)
@@ -244,7 +350,9 @@ def main():
     checked = None
     if rank == 0 and c3:
         checked = "see tests/test_sbr_gpu.py (bit-exact vs reference records and oracle chains)"
-    if rank == 0 and not c3:
+    if rank == 0 and c4:
+        checked = "see tests/test_sbr_hq_gpu.py (bit-exact vs reference records and oracle chains)"
+    if rank == 0 and not (c3 or c4):
         try:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib
@@ -262,10 +370,12 @@ def main():
 
     if rank == 0:
         frames = FRAMES_PER_STEP * args.steps * world
-        alg_bytes = (C3_ALG_BYTES_PER_CH * CH if c3 else ALG_BYTES_PER_FRAME) * FRAMES_PER_STEP
+        alg_bytes = (C3_ALG_BYTES_PER_CH * CH if c3 else C4_ALG_BYTES_PER_STREAM if c4 else ALG_BYTES_PER_FRAME) * FRAMES_PER_STEP
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": ("decoded audio frames/s (1024-spl IMDCT + 32/64-band QMF + low-power SBR, HE-AACv1 stereo)" if c3
+                       else "decoded audio frames/s (1024-spl IMDCT + complex QMF + HQ SBR + parametric stereo, "
+                            "HE-AACv2)" if c4
                        else "decoded audio frames/s (1024-spl IMDCT+overlap-add, AAC-LC stereo)"),
             "value": round(frames / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -274,22 +384,27 @@ def main():
             "config": {"workload": ("C3: HE-AACv1 48 kHz stereo, batch=8192 frames/step: IMDCT+OLA -> QMF-32 analysis -> "
                                     "LPP HF generation + envelope adjustment (side info cycled from reference-captured "
                                     "frames) -> QMF-64 synthesis, %d stream sets cycled" % args.sets) if c3 else
+                                   ("C4: HE-AACv2 48 kHz, batch=8192 frames/step (one mono core channel each): IMDCT+OLA "
+                                    "-> complex QMF-32 analysis -> LPP transposer + envelope adjustment -> parametric "
+                                    "stereo -> two complex QMF-64 synthesis banks (SBR / PS side info cycled from "
+                                    "reference-captured frames), %d stream sets cycled" % args.sets) if c4 else
                                    ("C2: AAC-LC 48 kHz stereo, batch=8192 frames/step (16384 channel-frames), "
                                     "ONLY_LONG 1024-pt IMDCT + window/overlap-add + PCM16, %d stream sets cycled"
                                     % args.sets),
-                       "frames_per_step": FRAMES_PER_STEP, "channels": CH, "launch": ctx.last_launch(),
+                       "frames_per_step": FRAMES_PER_STEP, "channels": 1 if c4 else CH, "launch": ctx.last_launch(),
                        "sharding": "streams split across ranks, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None if c3 else (measured_traffic() or {}).get("bytes_per_launch"),
-                         "traffic_source": None if c3 else (measured_traffic() or {}).get("source"),
+                         "traffic": None if (c3 or c4) else (measured_traffic() or {}).get("bytes_per_launch"),
+                         "traffic_source": None if (c3 or c4) else (measured_traffic() or {}).get("source"),
                          "kernel": "imdct_ola + qmf_analysis + sbr_core_lp + qmf_synthesis (4 launches)" if c3
+                                   else "imdct_ola + qmf_analysis + sbr_core_hq + ps + 2 x qmf_synthesis (6 launches)" if c4
                                    else "xaac_imdct_ola_kernel", "kernel_ms": round(kern_ms, 5),
                          "alg_bytes_per_launch": alg_bytes},
             "bit_exact_vs_oracle": checked,
         }
-        if world == 1 and not args.no_cpu_baseline and not c3:
-            out["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_sbr(args.workload) if (c3 or c4) else cpu_baseline()
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
