@@ -28,7 +28,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def library_path():
-    return os.path.join(_HERE, "libxaac_amd.so")
+    # XAAC_AMD_LIBRARY: developer override to time an experimental build of the same library
+    return os.environ.get("XAAC_AMD_LIBRARY") or os.path.join(_HERE, "libxaac_amd.so")
 
 
 class XaacError(RuntimeError):

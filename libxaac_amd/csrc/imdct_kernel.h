@@ -9,7 +9,9 @@
 
 #include "../../include/xaac_amd.h"
 
+#ifndef XAAC_IMDCT_WAVES
 #define XAAC_IMDCT_WAVES 4                       /* independent waves per workgroup */
+#endif
 #define XAAC_IMDCT_BLOCK (64 * XAAC_IMDCT_WAVES)
 #ifndef XAAC_IMDCT_MIN_WAVES_PER_SIMD
 #define XAAC_IMDCT_MIN_WAVES_PER_SIMD 4         /* register budget: <= 128 VGPRs */

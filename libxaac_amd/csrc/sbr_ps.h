@@ -34,6 +34,8 @@
 #endif
 #endif
 
+typedef struct xaac_ps_tables_t XpTables; /* tables_ps.inc: on the GPU the kernel passes its LDS copy */
+
 /* hybrid sub-band samples of one slot: 10 sub-bands (6 of QMF band 0, 2 + 2 of bands 1, 2), left and right */
 struct XpHyb {
   int32_t l_re[16], l_im[16], r_re[16], r_im[16];
@@ -42,11 +44,11 @@ struct XpHyb {
 FX_HD int32_t xp_m16x16_shl(int16_t a, int16_t b) { return fx_shl((int32_t)a * b, 1); }
 
 /* hybrid.c:51: 2-channel real-coefficient filter on the 13-slot history w[0..12] */
-FX_HD void xp_filt_2ch(const int32_t *w_re, const int32_t *w_im, int32_t *h_re, int32_t *h_im) {
+FX_HD void xp_filt_2ch(const XpTables *T, const int32_t *w_re, const int32_t *w_im, int32_t *h_re, int32_t *h_im) {
   int32_t c_re = 0, c_im = 0;
   for (int t = 0; t < 6; t++) {
-    c_re = fx_add_sat(c_re, fx_mul32x16(w_re[1 + 2 * t], xaac_ps_p2_6[t]));
-    c_im = fx_add_sat(c_im, fx_mul32x16(w_im[1 + 2 * t], xaac_ps_p2_6[t]));
+    c_re = fx_add_sat(c_re, fx_mul32x16(w_re[1 + 2 * t], T->p2_6[t]));
+    c_im = fx_add_sat(c_im, fx_mul32x16(w_im[1 + 2 * t], T->p2_6[t]));
   }
   c_re = fx_shl(c_re, 1);
   c_im = fx_shl(c_im, 1);
@@ -99,9 +101,9 @@ FX_HD void xp_fft8(const int32_t *y, int32_t *re, int32_t *im) {
 }
 
 /* hybrid.c:96: 8-channel complex filter (13-tap prototype, symmetric: taps t and t+8 share a phase) */
-FX_HD void xp_filt_8ch(const int32_t *w_re, const int32_t *w_im, int32_t *h_re, int32_t *h_im) {
+FX_HD void xp_filt_8ch(const XpTables *T, const int32_t *w_re, const int32_t *w_im, int32_t *h_re, int32_t *h_im) {
   const int16_t tcos = 0x7642, tsin = 0x30fc, tcom = 0x5a82;
-  const int16_t *p = xaac_ps_p8_13;
+  const int16_t *p = T->p8_13;
   int32_t cum[16], re, im;
 #define XP_PAIR(t) /* taps t and t + 8 combined */                                                           \
   re = fx_shl(fx_add_sat(fx_mul32x16(w_re[t], p[t]), fx_mul32x16(w_re[(t) + 8], p[(t) + 8])), 1);           \
@@ -137,7 +139,7 @@ FX_HD void xp_filt_8ch(const int32_t *w_re, const int32_t *w_im, int32_t *h_re, 
 /* hybrid.c:214: push one slot of QMF bands 0..2 into the 12-slot histories and filter (one band per lane).
    in_re / in_im: bands 0..2 of the slot six ahead; scale: right shift applied to them (left if negative). */
 template <class PS>
-FX_HD void xp_hybrid_analysis(const XsCx &cx, const int32_t *in_re, const int32_t *in_im, PS *ps, XpHyb *hy,
+FX_HD void xp_hybrid_analysis(const XsCx &cx, const XpTables *T, const int32_t *in_re, const int32_t *in_im, PS *ps, XpHyb *hy,
                               int scale) {
   XS_PAR(band, 0, 3) {
     const int off = band == 0 ? 0 : 4 + 2 * band;
@@ -164,9 +166,9 @@ FX_HD void xp_hybrid_analysis(const XsCx &cx, const int32_t *in_re, const int32_
     b_re[11] = t_re;
     b_im[11] = t_im;
     if (band == 0)
-      xp_filt_8ch(w_re, w_im, &hy->l_re[off], &hy->l_im[off]);
+      xp_filt_8ch(T, w_re, w_im, &hy->l_re[off], &hy->l_im[off]);
     else
-      xp_filt_2ch(w_re, w_im, &hy->l_re[off], &hy->l_im[off]);
+      xp_filt_2ch(T, w_re, w_im, &hy->l_re[off], &hy->l_im[off]);
   }
   cx.sync();
 }
@@ -204,8 +206,9 @@ FX_HD void xp_allpass(int16_t *d0, int32_t new_re, int32_t new_im, const int16_t
   int16_t *ser[3] = {ser0, ser1, ser2};
   const int16_t *ph[3] = {ph0, ph1, ph2};
   const int16_t decay[3] = {decay0, decay1, decay2};
+  const int16_t s_re[3] = {ser0[0], ser1[0], ser2[0]}, s_im[3] = {ser0[1], ser1[1], ser2[1]}; /* distinct buffers */
   for (int m = 0; m < 3; m++) {
-    const int16_t sr = ser[m][0], si = ser[m][1];
+    const int16_t sr = s_re[m], si = s_im[m];
     int16_t t_re = (int16_t)(fx_sub_sat((int32_t)sr * ph[m][0], (int32_t)si * ph[m][1]) >> 15);
     int16_t t_im = (int16_t)(fx_add_sat((int32_t)sr * ph[m][1], (int32_t)si * ph[m][0]) >> 15);
     t_re = (int16_t)(t_re - xs_mult16_shl(in_re, decay[m]));
@@ -221,7 +224,7 @@ FX_HD void xp_allpass(int16_t *d0, int32_t new_re, int32_t new_im, const int16_t
 
 /* ps_dec.c:470-545: input power of transient-detector bin `bin` (20 bins: hybrid sub-bands, QMF bands 3..8,
    then groups of QMF bands) */
-FX_HD int32_t xp_bin_power(int bin, const XpHyb *hy, const int32_t *l_re, const int32_t *l_im, int usb) {
+FX_HD int32_t xp_bin_power(const XpTables *T, int bin, const XpHyb *hy, const int32_t *band_pw, int usb) {
   if (bin < 2) {
     const int a = bin == 0 ? 0 : 4, b = bin == 0 ? 5 : 1;
     int32_t pw = xp_power(hy->l_re[a], hy->l_im[a]);
@@ -229,30 +232,39 @@ FX_HD int32_t xp_bin_power(int bin, const XpHyb *hy, const int32_t *l_re, const 
     return fx_add_sat(pw, fx_mul32x16(hy->l_im[b], (int16_t)(hy->l_im[b] >> 16)));
   }
   if (bin < 8) {
-    const int sb = xaac_ps_borders_group[bin + 2];
+    const int sb = T->borders_group[bin + 2];
     return xp_power(hy->l_re[sb], hy->l_im[sb]);
   }
-  if (bin < 14) return xp_power(l_re[bin - 5], l_im[bin - 5]);
+  if (bin < 14) return band_pw[bin - 5];
   const int gr = bin + 2;
   int32_t accu = 0;
-  int hi = xaac_ps_borders_group[gr + 1];
+  int hi = T->borders_group[gr + 1];
   if (usb < hi) hi = usb;
-  for (int sb = xaac_ps_borders_group[gr]; sb < hi; sb++)
-    accu = fx_add_sat(accu, xp_power(l_re[sb], l_im[sb]) >> xaac_ps_group_shift[gr - 16]);
+  const int shift = T->group_shift[gr - 16];
+  int sb = T->borders_group[gr];
+  for (; sb + 4 <= hi; sb += 4) { /* same order of saturating adds; four loads in flight */
+    const int32_t a = band_pw[sb], b = band_pw[sb + 1], c = band_pw[sb + 2], d = band_pw[sb + 3];
+    accu = fx_add_sat(fx_add_sat(fx_add_sat(fx_add_sat(accu, a >> shift), b >> shift), c >> shift), d >> shift);
+  }
+  for (; sb < hi; sb++) accu = fx_add_sat(accu, band_pw[sb] >> shift);
   return accu;
 }
 
 /* ps_dec.c:450: decorrelated (right) signal of one slot.  left: the slot's QMF row (64 re | 64 im), right:
-   output row; hy: hybrid sub-bands of the slot (left in, right out); ratio: 21 shorts of scratch. */
+   output row; hy: hybrid sub-bands of the slot (left in, right out); ratio: 21 shorts, band_pw: 64 words of
+   scratch. */
 template <class PS>
-FX_HD void xp_decorrelation(const XsCx &cx, PS *ps, XpHyb *hy, const int32_t *left, int32_t *right, int16_t *ratio) {
+FX_HD void xp_decorrelation(const XsCx &cx, const XpTables *T, PS *ps, XpHyb *hy, const int32_t *left, int32_t *right,
+                            int16_t *ratio, int32_t *band_pw) {
   const int usb = cx.uni(ps->usb);
   const int idx = cx.uni(ps->idx), idx_long = cx.uni(ps->idx_long);
   const int is0 = cx.uni(ps->idx_ser[0]), is1 = cx.uni(ps->idx_ser[1]), is2 = cx.uni(ps->idx_ser[2]);
   const int32_t *l_re = left, *l_im = left + 64;
   int32_t *r_re = right, *r_im = right + 64;
+  XS_PAR(sb, 3, 64) band_pw[sb] = xp_power(l_re[sb], l_im[sb]); /* ps_dec.c:520-545, one QMF band per lane */
+  cx.sync();
   XS_PAR(bin, 0, 20) { /* transient detector: peak-decay against smoothed energy, per bin */
-    int32_t pw = fx_shl(xp_bin_power(bin, hy, l_re, l_im, usb), 1);
+    int32_t pw = fx_shl(xp_bin_power(T, bin, hy, band_pw, usb), 1);
     if (pw < 0) pw = 0;
     int32_t pd = fx_mul32x16_shl(ps->peak_decay_diff[bin], 0x620a);
     if (pw > pd) pd = pw;
@@ -266,31 +278,25 @@ FX_HD void xp_decorrelation(const XsCx &cx, PS *ps, XpHyb *hy, const int32_t *le
   }
   XS_ONE ratio[20] = 0;
   cx.sync();
-  XS_PAR(sb, 0, 10) { /* hybrid sub-bands (ps_dec.c:236) */
-    int16_t o_re, o_im;
-    xp_allpass(&ps->sub[idx][2 * sb], hy->l_re[sb], hy->l_im[sb], &xaac_ps_frac_delay_phase_fac_qmf_sub_re_im[2 * sb],
-               &ps->sub_ser[is0][0][2 * sb], &ps->sub_ser[is1][1][2 * sb], &ps->sub_ser[is2][2][2 * sb],
-               &xaac_ps_frac_delay_phase_fac_qmf_sub_ser_re_im[2 * sb],
-               &xaac_ps_frac_delay_phase_fac_qmf_sub_ser_re_im[32 + 2 * sb],
-               &xaac_ps_frac_delay_phase_fac_qmf_sub_ser_re_im[64 + 2 * sb], xaac_ps_rev_link_decay_ser[0],
-               xaac_ps_rev_link_decay_ser[1], xaac_ps_rev_link_decay_ser[2], &o_re, &o_im);
-    const int16_t tr = ratio[xaac_ps_hybrid_to_bin[sb]];
-    hy->r_re[sb] = xp_m16x16_shl(o_re, tr);
-    hy->r_im[sb] = xp_m16x16_shl(o_im, tr);
-  }
-  XS_PAR(sb, 3, 64) {
-    if (sb < 23) { /* QMF bands 3..22: all-pass chain (ps_dec.c:339), whatever usb is */
+  XS_PAR(u, 0, 10 + 61) { /* u = 0..9: hybrid sub-bands (ps_dec.c:236); above: QMF band u - 7 */
+    const int hyb = u < 10, sb = hyb ? u : u - 7;
+    if (sb < 23) { /* the thirty all-pass chains (QMF bands 3..22 whatever usb is, ps_dec.c:339): one code path */
       int16_t o_re, o_im;
       const int di = 9 + 3 * (sb - 3);
-      xp_allpass(&ps->ap[idx][2 * sb], l_re[sb], l_im[sb], &xaac_ps_frac_delay_phase_fac_qmf_re_im[2 * sb],
-                 &ps->ser[is0][0][2 * sb], &ps->ser[is1][1][2 * sb], &ps->ser[is2][2][2 * sb],
-                 &xaac_ps_frac_delay_phase_fac_qmf_ser_re_im[2 * sb],
-                 &xaac_ps_frac_delay_phase_fac_qmf_ser_re_im[64 + 2 * sb],
-                 &xaac_ps_frac_delay_phase_fac_qmf_ser_re_im[128 + 2 * sb], xaac_ps_decay_scale_factor[di],
-                 xaac_ps_decay_scale_factor[di + 1], xaac_ps_decay_scale_factor[di + 2], &o_re, &o_im);
-      const int16_t tr = ratio[xaac_ps_delay_to_bin[sb]];
-      r_re[sb] = xp_m16x16_shl(o_re, tr);
-      r_im[sb] = xp_m16x16_shl(o_im, tr);
+      int16_t *d0 = hyb ? &ps->sub[idx][2 * sb] : &ps->ap[idx][2 * sb];
+      int16_t *e0 = hyb ? &ps->sub_ser[is0][0][2 * sb] : &ps->ser[is0][0][2 * sb];
+      int16_t *e1 = hyb ? &ps->sub_ser[is1][1][2 * sb] : &ps->ser[is1][1][2 * sb];
+      int16_t *e2 = hyb ? &ps->sub_ser[is2][2][2 * sb] : &ps->ser[is2][2][2 * sb];
+      const int16_t *ph = hyb ? &T->frac_delay_phase_fac_qmf_sub_re_im[2 * sb] : &T->frac_delay_phase_fac_qmf_re_im[2 * sb];
+      const int16_t *pser = hyb ? &T->frac_delay_phase_fac_qmf_sub_ser_re_im[2 * sb] : &T->frac_delay_phase_fac_qmf_ser_re_im[2 * sb];
+      const int pstep = hyb ? 32 : 64;
+      xp_allpass(d0, hyb ? hy->l_re[sb] : l_re[sb], hyb ? hy->l_im[sb] : l_im[sb], ph, e0, e1, e2, pser, pser + pstep,
+                 pser + 2 * pstep, hyb ? T->rev_link_decay_ser[0] : T->decay_scale_factor[di],
+                 hyb ? T->rev_link_decay_ser[1] : T->decay_scale_factor[di + 1],
+                 hyb ? T->rev_link_decay_ser[2] : T->decay_scale_factor[di + 2], &o_re, &o_im);
+      const int16_t tr = ratio[hyb ? T->hybrid_to_bin[sb] : T->delay_to_bin[sb]];
+      *(hyb ? &hy->r_re[sb] : &r_re[sb]) = xp_m16x16_shl(o_re, tr);
+      *(hyb ? &hy->r_im[sb] : &r_im[sb]) = xp_m16x16_shl(o_im, tr);
     } else if (sb < usb) { /* plain delays: 14 slots for bands 23..34, one slot above (ps_dec.c:602-648) */
       int16_t *d = sb < 35 ? &ps->ld[idx_long][2 * (sb - 23)] : &ps->sd[2 * (sb - 35)];
       const int16_t tr = ratio[sb < 35 ? 18 : 19];
@@ -317,24 +323,24 @@ FX_HD void xp_decorrelation(const XsCx &cx, PS *ps, XpHyb *hy, const int32_t *le
 }
 
 /* ps_dec.c:678 / :691: quarter-wave table lookups of the rotation angles */
-FX_HD int16_t xp_cos512(int32_t phi_by_4) {
+FX_HD int16_t xp_cos512(const XpTables *T, int32_t phi_by_4) {
   int index = fx_round16(fx_abs_sat(phi_by_4)) & 0x3ff;
-  return index < 512 ? xaac_ps_trig_data[512 - index] : (int16_t)(-xaac_ps_trig_data[index - 512]);
+  return index < 512 ? T->trig_data[512 - index] : (int16_t)(-T->trig_data[index - 512]);
 }
-FX_HD int16_t xp_sin512(int32_t phi_by_4) {
+FX_HD int16_t xp_sin512(const XpTables *T, int32_t phi_by_4) {
   int index = fx_round16(phi_by_4);
   if (index < 0) {
     index = (-index) & 0x3ff;
-    return index < 512 ? (int16_t)(-xaac_ps_trig_data[index]) : (int16_t)(-xaac_ps_trig_data[1024 - index]);
+    return index < 512 ? (int16_t)(-T->trig_data[index]) : (int16_t)(-T->trig_data[1024 - index]);
   }
   index &= 0x3ff;
-  return index < 512 ? xaac_ps_trig_data[index] : xaac_ps_trig_data[1024 - index];
+  return index < 512 ? T->trig_data[index] : T->trig_data[1024 - index];
 }
 
 /* ps_dec.c:714: at an envelope border, the target mixing coefficients of every parameter group from the
    IID / ICC indices, and the per-slot increments towards them (one group per lane) */
 template <class PS>
-FX_HD void xp_init_rot_env(const XsCx &cx, PS *ps, const xaac_ps_frame *pf, int env, int usb) {
+FX_HD void xp_init_rot_env(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_frame *pf, int env, int usb) {
   if (env == 0) {
     const int usb_prev = cx.uni(ps->usb);
     cx.sync();
@@ -353,22 +359,22 @@ FX_HD void xp_init_rot_env(const XsCx &cx, PS *ps, const xaac_ps_frame *pf, int 
   }
   const int fine = cx.uni(pf->iid_quant);
   const int steps = fine ? 15 : 7;
-  const int16_t *sf = fine ? xaac_ps_scale_factors_fine : xaac_ps_scale_factors;
+  const int16_t *sf = fine ? T->scale_factors_fine : T->scale_factors;
   int16_t len = fx_sat16((int32_t)cx.uni(pf->border_position[env + 1]) - cx.uni(pf->border_position[env]));
   if (len < 0) len = (int16_t)(len == -32768 ? 32767 : -len);
   const int16_t inv_len = xaac_sbr_inv_int_table[len];
   XS_PAR(g, 0, XAAC_PS_GROUPS) {
-    const int bin = xaac_ps_group_to_bin[g];
+    const int bin = T->group_to_bin[g];
     const int iid = pf->iid_par_table[env][bin], icc = pf->icc_par_table[env][bin];
     const int16_t c1 = sf[steps + iid], c2 = sf[steps - iid];
     const int32_t beta =
-        fx_mul32x16_shl(xp_m16x16_shl(xaac_ps_alpha_values[icc], (int16_t)(c1 - c2)), 0x5a82);
-    const int32_t alpha = xs_shr_dir_sat_limit(xs_shl(xaac_ps_alpha_values[icc], 16), 1);
+        fx_mul32x16_shl(xp_m16x16_shl(T->alpha_values[icc], (int16_t)(c1 - c2)), 0x5a82);
+    const int32_t alpha = xs_shr_dir_sat_limit(xs_shl(T->alpha_values[icc], 16), 1);
     const int16_t bpa = fx_round16(fx_add_sat(beta, alpha)), bma = fx_round16(fx_sub_sat(beta, alpha));
     const int32_t rescale = (int32_t)(0x0517cc1b << 1);
     const int32_t ipa = fx_mul32x16(rescale, bpa), ima = fx_mul32x16(rescale, bma);
-    const int16_t h11 = xs_mult16_shl(xp_cos512(ipa), c2), h12 = xs_mult16_shl(xp_cos512(ima), c1);
-    const int16_t h21 = xs_mult16_shl(xp_sin512(ipa), c2), h22 = xs_mult16_shl(xp_sin512(ima), c1);
+    const int16_t h11 = xs_mult16_shl(xp_cos512(T, ipa), c2), h12 = xs_mult16_shl(xp_cos512(T, ima), c1);
+    const int16_t h21 = xs_mult16_shl(xp_sin512(T, ipa), c2), h22 = xs_mult16_shl(xp_sin512(T, ima), c1);
     ps->delta_h11_h12[2 * g] = xs_mult16_shl(inv_len, (int16_t)(h11 - ps->h11_h12_vec[2 * g]));
     ps->delta_h11_h12[2 * g + 1] = xs_mult16_shl(inv_len, (int16_t)(h12 - ps->h11_h12_vec[2 * g + 1]));
     ps->delta_h21_h22[2 * g] = xs_mult16_shl(inv_len, (int16_t)(h21 - ps->h21_h22_vec[2 * g]));
@@ -395,7 +401,7 @@ FX_HD void xp_rotate(int32_t *l, int32_t *r, int16_t h11, int16_t h12, int16_t h
 /* ps_dec.c:856: advance the interpolated coefficients by one slot and mix left / decorrelated into the
    output pair, in the hybrid domain for QMF bands 0..2 (their sub-bands are then summed back) */
 template <class PS>
-FX_HD void xp_apply_rot(const XsCx &cx, PS *ps, XpHyb *hy, int32_t *left, int32_t *right) {
+FX_HD void xp_apply_rot(const XsCx &cx, const XpTables *T, PS *ps, XpHyb *hy, int32_t *left, int32_t *right) {
   const int usb = cx.uni(ps->usb);
   XS_PAR(g, 0, XAAC_PS_GROUPS) {
     ps->H11_H12[2 * g] = (int16_t)(ps->H11_H12[2 * g] + ps->delta_h11_h12[2 * g]);
@@ -427,8 +433,7 @@ FX_HD void xp_apply_rot(const XsCx &cx, PS *ps, XpHyb *hy, int32_t *left, int32_
       r_re[sb] = c;
       r_im[sb] = d;
     } else { /* the band's parameter group: borders 3,4,...,9,11,14,18,23,35,64 */
-      int g = 10;
-      while (sb >= xaac_ps_borders_group[g + 1]) g++;
+      const int g = T->band_to_group[sb];
       const int16_t h11 = ps->H11_H12[2 * g], h12 = ps->H11_H12[2 * g + 1], h21 = ps->H21_H22[2 * g],
                     h22 = ps->H21_H22[2 * g + 1];
       xp_rotate(&l_re[sb], &r_re[sb], h11, h12, h21, h22);

@@ -16,6 +16,21 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#ifdef XS_PROFILE
+/* phase timers (tools/prof_sbr_core.py ps): cycles of lane 0 between XP_T hooks, summed over streams */
+__shared__ long long xp_prof_last;
+__shared__ long long xp_prof_acc[16];
+#define XP_T(i)                                   \
+  do {                                            \
+    if (threadIdx.x == 0) {                       \
+      long long t_ = clock64();                   \
+      xp_prof_acc[i] += t_ - xp_prof_last;        \
+      xp_prof_last = t_;                          \
+    }                                             \
+  } while (0)
+#else
+#define XP_T(i)
+#endif
 #include "sbr_ps.h"
 #include "sbr_ps_kernel.h"
 
@@ -35,7 +50,10 @@ struct XpLds {
   int32_t left[128], right[128];
   int32_t ahead[8]; /* bands 0..2 of the slot six ahead: re at [0..2], im at [4..6] */
   int16_t ratio[24];
+  int32_t band_pw[64];
+  XpTables tabs; /* the PS constants: a table lookup in global memory costs a slot-loop iteration its latency */
 };
+static_assert(sizeof(XpTables) % 4 == 0, "word copies");
 
 __device__ __forceinline__ int32_t adj_word(int32_t v, int shift) { /* env_calc.c:1099 on one word */
   if (shift == 0) return v;
@@ -66,8 +84,17 @@ __global__ __launch_bounds__(64) void xaac_ps_kernel(XaacPsParams p) {
     const int32_t *fs = reinterpret_cast<const int32_t *>(p.frame + n);
     int32_t *fd = reinterpret_cast<int32_t *>(&s.pf);
     for (int i = lane; i < (int)(sizeof(xaac_ps_frame) / 4); i += 64) fd[i] = fs[i];
+    const int32_t *ts = reinterpret_cast<const int32_t *>(&xaac_ps_tables);
+    int32_t *td = reinterpret_cast<int32_t *>(&s.tabs);
+    for (int i = lane; i < (int)(sizeof(XpTables) / 4); i += 64) td[i] = ts[i];
   }
   __syncthreads();
+#ifdef XS_PROFILE
+  if (lane == 0) {
+    for (int i = 0; i < 16; i++) xp_prof_acc[i] = 0;
+    xp_prof_last = clock64();
+  }
+#endif
   const XsCx cx = {lane, 64};
   int16_t *par = p.par_l + 8 * (size_t)n;
   const int lb_scale = par[0], ov_lb_scale = par[1], hb_scale = par[2], st_syn = par[3], lsb = par[4], usb = par[5];
@@ -78,27 +105,46 @@ __global__ __launch_bounds__(64) void xaac_ps_kernel(XaacPsParams p) {
   const int sh_ov = lane < lsb ? ov_lb_shift : (lane < usb ? hb_shift : 0);
   const int sh_lb = lane < lsb ? lb_shift : (lane < usb ? hb_shift : 0);
   int env = 0;
+  XP_T(1);
+  /* the next slot's row (and the look-ahead bands) are fetched while the current slot is processed */
+  int32_t n_re = gx[lane], n_im = gx[64 + lane], a_re = 0, a_im = 0;
+  if (lane < 3) {
+    a_re = gx[6 * 128 + lane];
+    a_im = gx[6 * 128 + 64 + lane];
+  }
   for (int l = 0; l < 32; l++) {
     {
       const int sh = l < 6 ? sh_ov : sh_lb;
-      s.left[lane] = adj_word(gx[l * 128 + lane], sh);
-      s.left[64 + lane] = adj_word(gx[l * 128 + 64 + lane], sh);
+      s.left[lane] = adj_word(n_re, sh);
+      s.left[64 + lane] = adj_word(n_im, sh);
       if (lane < 3) { /* the hybrid bank looks six slots ahead; slots of the next frame are not rescaled */
-        const int la = l + 6;
-        const int sha = la < 32 ? sh_lb : 0;
-        s.ahead[lane] = adj_word(gx[la * 128 + lane], sha);
-        s.ahead[4 + lane] = adj_word(gx[la * 128 + 64 + lane], sha);
+        const int sha = l + 6 < 32 ? sh_lb : 0;
+        s.ahead[lane] = adj_word(a_re, sha);
+        s.ahead[4 + lane] = adj_word(a_im, sha);
+      }
+      if (l + 1 < 32) {
+        n_re = gx[(l + 1) * 128 + lane];
+        n_im = gx[(l + 1) * 128 + 64 + lane];
+        if (lane < 3) {
+          a_re = gx[(l + 7) * 128 + lane];
+          a_im = gx[(l + 7) * 128 + 64 + lane];
+        }
       }
     }
     __syncthreads();
+    XP_T(2);
     if (l == s.pf.border_position[env]) {
-      xp_init_rot_env(cx, &s.ps, &s.pf, env, usb);
+      xp_init_rot_env(cx, &s.tabs, &s.ps, &s.pf, env, usb);
       env++;
     }
+    XP_T(3);
     const int shiftdelay = l < 32 - 6 ? 0 : (int16_t)(lb_scale - ps_scale); /* thumb_ps_dec.c:77 */
-    xp_hybrid_analysis(cx, s.ahead, s.ahead + 4, &s.ps, &s.hy, shiftdelay);
-    xp_decorrelation(cx, &s.ps, &s.hy, s.left, s.right, s.ratio);
-    xp_apply_rot(cx, &s.ps, &s.hy, s.left, s.right);
+    xp_hybrid_analysis(cx, &s.tabs, s.ahead, s.ahead + 4, &s.ps, &s.hy, shiftdelay);
+    XP_T(4);
+    xp_decorrelation(cx, &s.tabs, &s.ps, &s.hy, s.left, s.right, s.ratio, s.band_pw);
+    XP_T(5);
+    xp_apply_rot(cx, &s.tabs, &s.ps, &s.hy, s.left, s.right);
+    XP_T(6);
     for (int k = lane; k < 128; k += 64) {
       int32_t v = s.left[k];
       if (common_shift < 0)
@@ -109,6 +155,7 @@ __global__ __launch_bounds__(64) void xaac_ps_kernel(XaacPsParams p) {
       gr[l * 128 + k] = s.right[k];
     }
     __syncthreads();
+    XP_T(7);
   }
   /* ---- state and the two synthesis launches' parameters ---- */
   {
@@ -116,6 +163,11 @@ __global__ __launch_bounds__(64) void xaac_ps_kernel(XaacPsParams p) {
     const int32_t *src = reinterpret_cast<const int32_t *>(&s.ps);
     for (int i = lane; i < kHeadWords; i += 64) dst[i] = src[i];
   }
+#ifdef XS_PROFILE
+  XP_T(8);
+  __syncthreads();
+  if (lane < 16 && p.dbg) atomicAdd(reinterpret_cast<unsigned long long *>(p.dbg) + 32 + lane, (unsigned long long)xp_prof_acc[lane]);
+#endif
   if (lane == 0) {
     int16_t *pr = p.par_r + 8 * (size_t)n;
     const int16_t ready = (int16_t)(st_syn - 8); /* makes the bank's own rescale a no-op: data is in place */

@@ -320,7 +320,7 @@ int32_t xaac_sbr_hq_process_batch(xaac_ctx *c, const xaac_sbr_hq_batch *b) {
   if (with_ps) {
     XaacPsParams pp;
     pp.n = b->n_ch; pp.x = x; pp.xr = xr; pp.header = b->header; pp.sbr_frame = b->frame; pp.frame = b->ps_frame;
-    pp.state = b->ps_state; pp.sbr_state = b->state; pp.par_l = par_l; pp.par_r = par_r;
+    pp.state = b->ps_state; pp.sbr_state = b->state; pp.par_l = par_l; pp.par_r = par_r; pp.dbg = b->status;
     if (!hip_ok(xaac_launch_ps(&pp, c->stream))) return XAAC_FATAL_HIP;
   }
   /* 4. synthesis bank(s) over the 6 delayed + first 26 new slots */

@@ -137,14 +137,15 @@ extern "C" int xo_sbr_dec_hq(const xaac_sbr_header *h, const xaac_sbr_frame *f, 
       XpHyb hy;
       memset(&hy, 0, sizeof(hy));
       int16_t ratio[21];
+      int32_t band_pw[64];
       if (l == pf->border_position[env]) {
-        xp_init_rot_env(cx, ps, pf, env, usb);
+        xp_init_rot_env(cx, &xaac_ps_tables, ps, pf, env, usb);
         env++;
       }
       const int shiftdelay = l < 32 - 6 ? 0 : (int16_t)(st->lb_scale - ps_scale); /* thumb_ps_dec.c:77 */
-      xp_hybrid_analysis(cx, &x(l + 6, 0), &x.im(l + 6, 0), ps, &hy, shiftdelay);
-      xp_decorrelation(cx, ps, &hy, &x(l, 0), right, ratio);
-      xp_apply_rot(cx, ps, &hy, &x(l, 0), right);
+      xp_hybrid_analysis(cx, &xaac_ps_tables, &x(l + 6, 0), &x.im(l + 6, 0), ps, &hy, shiftdelay);
+      xp_decorrelation(cx, &xaac_ps_tables, ps, &hy, &x(l, 0), right, ratio, band_pw);
+      xp_apply_rot(cx, &xaac_ps_tables, ps, &hy, &x(l, 0), right);
 #ifdef XO_PS_DEBUG
       {
         static FILE *df;

@@ -18,6 +18,48 @@ NAMES = {1: "block floating point", 2: "hf generator (total)", 3: "env: init/sin
          23: "alias: groups (lane 0)"}
 
 
+PS_NAMES = {1: "copy-in, init_ps_scale", 2: "row loads", 3: "init_rot_env", 4: "hybrid analysis", 5: "decorrelation",
+            6: "rotation", 7: "row stores", 8: "state out"}
+
+
+def main_ps():
+    """same for the parametric-stereo kernel on the C4 bench inputs: python tools/prof_sbr_core.py ps"""
+    import torch
+    import libxaac_amd
+    src = os.path.join(ROOT, "libxaac_amd", "csrc")
+    out = os.path.join(ROOT, "libxaac_amd", "libxaac_amd_prof.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DXS_PROFILE",
+                           "-shared", "-x", "hip"] + [os.path.join(src, f) for f in
+                           ("imdct_kernel.hip", "sbr_qmf_kernel.hip", "sbr_core_kernel.hip", "sbr_ps_kernel.hip",
+                            "xaac_abi.cpp")] + ["-o", out])
+    libxaac_amd.library_path = lambda: out
+    import bench
+    dev = torch.device("cuda:0")
+    n = bench.FRAMES_PER_STEP
+    b = bench.make_inputs_c4(torch, dev, 1, 0)[0]
+    ctx = libxaac_amd.XaacContext(0, None)
+    ws = torch.zeros(ctx.sbr_hq_workspace_bytes(n, True), dtype=torch.uint8, device=dev)
+    status = torch.zeros(n, dtype=torch.int32, device=dev)
+    steps = 4
+    for i in range(steps):
+        ctx.imdct_process_batch(b["spec"], b["ics"], b["overlap"], b["state"], None, b["core_pcm"], None, ch_fac=1,
+                                pcm_mode=libxaac_amd.PCM_SBR)
+        fr, pfr = b["frames"][i % 4]
+        ctx.sbr_hq_process_batch(b["core_pcm"], b["hdr"], fr, b["sbr_state"], b["pcm"], ws, pfr, b["ps_state"], status)
+    ctx.sync()
+    raw = status.cpu().numpy()[:128].view(np.uint64).astype(np.float64) / (steps * n)
+    core, ps = raw[:32], raw[32:48]
+    print("HQ core kernel:")
+    for i in range(1, 24):
+        if core[i]:
+            print("%2d %-34s %9.0f cycles/channel-frame %5.1f%%" % (i, NAMES.get(i, "?"), core[i], 100 * core[i] / core.sum()))
+    print("   total %.0f cycles" % core.sum())
+    print("PS kernel:")
+    for i in range(1, 9):
+        print("%2d %-34s %9.0f cycles/stream-frame %5.1f%%" % (i, PS_NAMES[i], ps[i], 100 * ps[i] / ps.sum()))
+    print("   total %.0f cycles" % ps.sum())
+
+
 def main():
     import torch
     import libxaac_amd
@@ -25,7 +67,7 @@ def main():
     out = os.path.join(ROOT, "libxaac_amd", "libxaac_amd_prof.so")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DXS_PROFILE",
                            "-shared", "-x", "hip"] + [os.path.join(src, f) for f in
-                           ("imdct_kernel.hip", "sbr_qmf_kernel.hip", "sbr_core_kernel.hip", "xaac_abi.cpp")] + ["-o", out])
+                           ("imdct_kernel.hip", "sbr_qmf_kernel.hip", "sbr_core_kernel.hip", "sbr_ps_kernel.hip", "xaac_abi.cpp")] + ["-o", out])
     libxaac_amd.library_path = lambda: out
     import bench
     dev = torch.device("cuda:0")
@@ -49,4 +91,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main_ps() if len(sys.argv) > 1 and sys.argv[1] == "ps" else main()
