@@ -1788,6 +1788,9 @@ FX_HD void xs_rescale_x_overlap(const XsCx &cx, const xaac_sbr_header *h, const 
 template <class ST, class Q>
 FX_HD int xs_sbr_core(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, ST *st, const Q &x, XsWork *w,
                       const int16_t *rand_hi, int *save_lb_scale_out) {
+  /* the frame grid this implementation (and the reference's MAX_ENV_COLS buffers, sbr_dec.c:733-748) is laid
+     out for: 16 time slots of 2 QMF slots; anything else is refused like the reference refuses its own limits */
+  if (cx.uni(h->num_time_slots) * cx.uni(h->time_step) != 32 || cx.uni(h->num_columns) != 32) return -1;
   const int usb = cx.uni(st->codec_usb);
   int reserve = xs_headroom(cx, x, 0, usb, 6, 38);
   int reserve_ov1 = xs_headroom(cx, x, 0, usb, 0, 6);
