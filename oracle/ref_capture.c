@@ -10,199 +10,11 @@
  * that INTEGRATION.md describes.  No reference code is copied: it only reads the reference's
  * own structs through the reference's own headers.
  */
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-#include "ixheaacd_sbr_common.h"
-#include "ixheaac_type_def.h"
-#include "ixheaac_constants.h"
-#include "ixheaac_basic_ops32.h"
-#include "ixheaac_basic_ops16.h"
-#include "ixheaac_basic_ops40.h"
-#include "ixheaac_basic_ops.h"
-#include "ixheaac_basic_op.h"
-#include "ixheaacd_intrinsics.h"
-#include "ixheaacd_common_rom.h"
-#include "ixheaacd_sbrdecsettings.h"
-#include "ixheaacd_bitbuffer.h"
-#include "ixheaacd_defines.h"
-#include "ixheaacd_pns.h"
-#include "ixheaacd_aac_rom.h"
-#include "ixheaacd_pulsedata.h"
-#include "ixheaacd_drc_data_struct.h"
-#include "ixheaacd_lt_predict.h"
-#include "ixheaacd_cnst.h"
-#include "ixheaacd_ec_defines.h"
-#include "ixheaacd_ec_struct_def.h"
-#include "ixheaacd_channelinfo.h"
-#include "ixheaacd_drc_dec.h"
-#include "ixheaacd_sbrdecoder.h"
-#include "ixheaacd_definitions.h"
-#include "ixheaacd_error_codes.h"
-#include "ixheaacd_sbr_scale.h"
-#include "ixheaacd_lpp_tran.h"
-#include "ixheaacd_env_extr_part.h"
-#include "ixheaacd_sbr_rom.h"
-#include "ixheaacd_hybrid.h"
-#include "ixheaacd_ps_dec.h"
-#include "ixheaacd_env_extr.h"
-#include "ixheaacd_qmf_dec.h"
-#include "ixheaacd_env_calc.h"
-#include "ixheaac_sbr_const.h"
-#include "ixheaacd_pvc_dec.h"
-#include "ixheaacd_sbr_dec.h"
+#include "ref_convert.h"
 
-#include "xaac_sbr.h"
 
 static FILE *g_out;
 static int g_calls;
-
-static void to_header(const ia_sbr_header_data_struct *h, const ia_sbr_dec_struct *d, xaac_sbr_header *o) {
-  const ia_freq_band_data_struct *f = h->pstr_freq_band_data;
-  const ia_transposer_settings_struct *t = d->str_hf_generator.pstr_settings;
-  int i;
-  memset(o, 0, sizeof(*o));
-  o->num_time_slots = h->num_time_slots;
-  o->time_step = h->time_step;
-  o->channel_mode = (int16_t)h->channel_mode;
-  o->limiter_gains = h->limiter_gains;
-  o->interpol_freq = h->interpol_freq;
-  o->smoothing_mode = h->smoothing_mode;
-  o->num_sf_bands[0] = f->num_sf_bands[0];
-  o->num_sf_bands[1] = f->num_sf_bands[1];
-  o->num_nf_bands = f->num_nf_bands;
-  o->sub_band_start = f->sub_band_start;
-  o->sub_band_end = f->sub_band_end;
-  o->num_lf_bands = f->num_lf_bands;
-  o->num_if_bands = f->num_if_bands;
-  memcpy(o->freq_band_tbl_lim, f->freq_band_tbl_lim, sizeof(o->freq_band_tbl_lim));
-  memcpy(o->freq_band_tbl_lo, f->freq_band_tbl_lo, sizeof(o->freq_band_tbl_lo));
-  memcpy(o->freq_band_tbl_hi, f->freq_band_tbl_hi, sizeof(o->freq_band_tbl_hi));
-  memcpy(o->freq_band_tbl_noise, f->freq_band_tbl_noise, sizeof(o->freq_band_tbl_noise));
-  o->num_columns = t->num_columns;
-  o->num_patches = t->num_patches;
-  o->start_patch = t->start_patch;
-  o->stop_patch = t->stop_patch;
-  memcpy(o->bw_borders, t->bw_borders, sizeof(o->bw_borders));
-  for (i = 0; i < MAX_NUM_PATCHES; i++) memcpy(&o->patch[i], &t->str_patch_param[i], sizeof(xaac_sbr_patch));
-}
-
-static void to_frame(const ia_sbr_frame_info_data_struct *f, int apply, xaac_sbr_frame *o) {
-  const ia_frame_info_struct *fi = &f->str_frame_info_details;
-  int i;
-  memset(o, 0, sizeof(*o));
-  o->num_env = fi->num_env;
-  o->transient_env = fi->transient_env;
-  o->num_noise_env = fi->num_noise_env;
-  o->frame_class = fi->frame_class;
-  memcpy(o->border_vec, fi->border_vec, sizeof(o->border_vec));
-  memcpy(o->freq_res, fi->freq_res, sizeof(o->freq_res));
-  memcpy(o->noise_border_vec, fi->noise_border_vec, sizeof(o->noise_border_vec));
-  o->amp_res = f->amp_res;
-  o->apply_processing = (int16_t)apply;
-  o->coupling_mode = f->coupling_mode;
-  o->max_qmf_subband_aac = f->max_qmf_subband_aac;
-  memcpy(o->sbr_invf_mode, f->sbr_invf_mode, sizeof(o->sbr_invf_mode));
-  for (i = 0; i < MAX_FREQ_COEFFS; i++) o->add_harmonics[i] = (uint8_t)f->add_harmonics[i];
-  memcpy(o->int_env_sf_arr, f->int_env_sf_arr, sizeof(o->int_env_sf_arr));
-  memcpy(o->int_noise_floor, f->int_noise_floor, sizeof(o->int_noise_floor));
-}
-
-static void to_state(const ia_sbr_dec_struct *d, const ia_sbr_prev_frame_data_struct *p, int low_pow,
-                     xaac_sbr_state *o) {
-  const ia_sbr_qmf_filter_bank_struct *a = &d->str_codec_qmf_bank, *s = &d->str_synthesis_qmf_bank;
-  const ia_sbr_calc_env_struct *e = &d->str_sbr_calc_env;
-  const ia_qmf_dec_tables_struct *t = &ixheaacd_aac_qmf_dec_tables;
-  int i;
-  memset(o, 0, sizeof(*o));
-  memcpy(o->ana_ring, a->anal_filter_states, sizeof(o->ana_ring));
-  o->ana_wr = (int16_t)(a->core_samples_buffer - a->anal_filter_states);
-  o->ana_phase = (int16_t)(a->filter_pos - a->analy_win_coeff);
-  memcpy(o->syn_ring, s->filter_states, sizeof(o->syn_ring));
-  o->syn_drc_offset = s->ixheaacd_drc_offset;
-  o->syn_phase = (int16_t)(s->filter_pos_syn - s->p_filter);
-  o->codec_usb = a->usb;
-  o->syn_lsb = s->lsb;
-  o->syn_usb = s->usb;
-  (void)t;
-  memcpy(o->overlap, d->ptr_sbr_overlap_buf, sizeof(WORD32) * 64 * 6 * (low_pow ? 1 : 2));
-  for (i = 0; i < 2; i++) {
-    memcpy(o->lpc_real[i], d->str_hf_generator.lpc_filt_states_real[i], 32 * sizeof(WORD32));
-    if (!low_pow && d->str_hf_generator.lpc_filt_states_imag[i])
-      memcpy(o->lpc_imag[i], d->str_hf_generator.lpc_filt_states_imag[i], 32 * sizeof(WORD32));
-  }
-  memcpy(o->bw_array_prev, d->str_hf_generator.bw_array_prev, sizeof(o->bw_array_prev));
-  o->lb_scale = d->str_sbr_scale_fact.lb_scale;
-  o->st_lb_scale = d->str_sbr_scale_fact.st_lb_scale;
-  o->ov_lb_scale = d->str_sbr_scale_fact.ov_lb_scale;
-  o->hb_scale = d->str_sbr_scale_fact.hb_scale;
-  o->ov_hb_scale = d->str_sbr_scale_fact.ov_hb_scale;
-  o->st_syn_scale = d->str_sbr_scale_fact.st_syn_scale;
-  o->ps_scale = d->str_sbr_scale_fact.ps_scale;
-  memcpy(o->prev_invf_mode, p->sbr_invf_mode, sizeof(o->prev_invf_mode));
-  o->prev_max_qmf_subband_aac = p->max_qmf_subband_aac;
-  o->prev_coupling_mode = p->coupling_mode;
-  o->prev_end_position = p->end_position;
-  o->prev_amp_res = p->amp_res;
-  memcpy(o->filt_buf_me, e->filt_buf_me, sizeof(o->filt_buf_me));
-  memcpy(o->filt_buf_noise_m, e->filt_buf_noise_m, sizeof(o->filt_buf_noise_m));
-  o->filt_buf_noise_e = e->filt_buf_noise_e;
-  o->start_up = e->start_up;
-  o->ph_index = e->ph_index;
-  o->tansient_env_prev = e->tansient_env_prev;
-  o->harm_index = e->harm_index;
-  memcpy(o->harm_flags_prev, e->harm_flags_prev, sizeof(o->harm_flags_prev));
-}
-
-static void to_ps_frame(const ia_ps_dec_struct *ps, xaac_ps_frame *o) {
-  memset(o, 0, sizeof(*o));
-  o->iid_quant = (int16_t)ps->iid_quant;
-  memcpy(o->border_position, ps->border_position, sizeof(o->border_position));
-  memcpy(o->iid_par_table, ps->iid_par_table, sizeof(o->iid_par_table));
-  memcpy(o->icc_par_table, ps->icc_par_table, sizeof(o->icc_par_table));
-}
-
-static void to_ps_state(const ia_ps_dec_struct *ps, const ia_sbr_qmf_filter_bank_struct *sr,
-                        const ia_sbr_scale_fact_struct *sf_r, xaac_ps_state *o) {
-  int i;
-  memset(o, 0, sizeof(*o));
-  memcpy(o->ser, ps->delay_buf_qmf_ser_re_im, sizeof(o->ser));
-  memcpy(o->ap, ps->delay_buf_qmf_ap_re_im, sizeof(o->ap));
-  memcpy(o->ld, ps->delay_buf_qmf_ld_re_im, sizeof(o->ld));
-  memcpy(o->sd, ps->delay_buf_qmf_sd_re_im, 58 * sizeof(WORD16));
-  memcpy(o->sub, ps->delay_buf_qmf_sub_re_im, sizeof(o->sub));
-  memcpy(o->sub_ser, ps->delay_buf_qmf_sub_ser_re_im, sizeof(o->sub_ser));
-  for (i = 0; i < 3; i++) {
-    o->idx_ser[i] = ps->delay_buf_idx_ser[i];
-    o->sample_ser[i] = ps->delay_sample_ser[i];
-  }
-  o->idx = ps->delay_buf_idx;
-  o->idx_long = ps->delay_buf_idx_long;
-  memcpy(o->peak_decay_diff, ps->peak_decay_diff, sizeof(o->peak_decay_diff));
-  memcpy(o->energy_prev, ps->energy_prev, sizeof(o->energy_prev));
-  memcpy(o->peak_decay_diff_prev, ps->peak_decay_diff_prev, sizeof(o->peak_decay_diff_prev));
-  for (i = 0; i < 3; i++) {
-    memcpy(o->hyb_buf[i][0], ps->str_hybrid.ptr_qmf_buf_re[i], 12 * sizeof(WORD32));
-    memcpy(o->hyb_buf[i][1], ps->str_hybrid.ptr_qmf_buf_im[i], 12 * sizeof(WORD32));
-  }
-  memcpy(o->h11_h12_vec, ps->h11_h12_vec, sizeof(o->h11_h12_vec));
-  memcpy(o->h21_h22_vec, ps->h21_h22_vec, sizeof(o->h21_h22_vec));
-  memcpy(o->H11_H12, ps->H11_H12, sizeof(o->H11_H12));
-  memcpy(o->H21_H22, ps->H21_H22, sizeof(o->H21_H22));
-  memcpy(o->delta_h11_h12, ps->delta_h11_h12, sizeof(o->delta_h11_h12));
-  memcpy(o->delta_h21_h22, ps->delta_h21_h22, sizeof(o->delta_h21_h22));
-  o->delay_buffer_scale = ps->delay_buffer_scale;
-  o->usb = ps->usb;
-  memcpy(o->syn_ring_r, sr->filter_states, sizeof(o->syn_ring_r));
-  o->syn_drc_offset_r = sr->ixheaacd_drc_offset;
-  o->syn_phase_r = (int16_t)(sr->filter_pos_syn - sr->p_filter);
-  o->syn_lsb_r = sr->lsb;
-  o->syn_usb_r = sr->usb;
-  o->st_syn_scale_r = sf_r->st_syn_scale;
-  o->lb_scale_r = sf_r->lb_scale;
-  o->ov_lb_scale_r = sf_r->ov_lb_scale;
-  o->hb_scale_r = sf_r->hb_scale;
-}
 
 WORD32 __real_ixheaacd_sbr_dec(ia_sbr_dec_struct *, WORD16 *, ia_sbr_header_data_struct *,
                                ia_sbr_frame_info_data_struct *, ia_sbr_prev_frame_data_struct *, ia_ps_dec_struct *,

@@ -1,0 +1,42 @@
+"""The drop-in, end to end: the REAL reference decoder decodes whole .aac streams with its two frame-level seams
+(ixheaacd_imdct_process, ixheaacd_sbr_dec) diverted to libxaac_amd on the GPU (oracle/_ref/xaacdec_dropin, built
+from oracle/ref_dropin.c by oracle/Makefile.ref); the output file must be byte-identical to what the unmodified
+reference decoder (oracle/_ref/xaacdec) writes.  Needs the prebuilt oracle/_ref binaries next to the repo."""
+import glob
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+STREAMS = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "streams", "*.aac")))
+
+
+def _decode(binary, aac, out, extra=()):
+    p = subprocess.run([os.path.join(REF, binary), "-ifile:" + aac, "-ofile:" + out, "-esbr:0", *extra],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    return p.stderr.decode(errors="replace")
+
+
+@pytest.mark.parametrize("aac", STREAMS, ids=[os.path.basename(s) for s in STREAMS])
+def test_reference_decoder_with_gpu_back_end_is_byte_identical(aac, tmp_path):
+    if not (os.path.exists(os.path.join(REF, "xaacdec")) and os.path.exists(os.path.join(REF, "xaacdec_dropin"))):
+        pytest.skip("oracle/_ref/xaacdec[_dropin] missing (built by oracle/Makefile.ref where /root/reference exists)")
+    ref_wav, gpu_wav = str(tmp_path / "ref.wav"), str(tmp_path / "gpu.wav")
+    _decode("xaacdec", aac, ref_wav)
+    log = _decode("xaacdec_dropin", aac, gpu_wav)
+    m = re.search(r"(\d+) imdct_process and (\d+) sbr_dec calls ran on the GPU", log)
+    assert m, log[-400:]
+    n_imdct, n_sbr = int(m.group(1)), int(m.group(2))
+    assert n_imdct > 30
+    if "aot2_" not in aac:
+        assert n_sbr > 30
+    a, b = open(ref_wav, "rb").read(), open(gpu_wav, "rb").read()
+    assert len(a) > 100000 and a == b, (len(a), len(b), n_imdct, n_sbr)
+
+
+def test_streams_present():
+    assert len(STREAMS) >= 3

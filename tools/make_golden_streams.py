@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Build tests/golden/streams/*.aac: three short ADTS streams (AAC-LC stereo, HE-AACv1 stereo, HE-AACv2) encoded by
+the reference encoder (oracle/_ref/xaacenc) from a synthetic signal with clicks (short blocks, multi-envelope SBR
+frames), a harmonic stack (sinusoidal coding) and level steps.  Data fixtures for tests/test_dropin_gpu.py."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_test_streams as m  # noqa: E402
+
+ROOT = os.path.dirname(HERE)
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+def main():
+    out = os.path.join(ROOT, "tests", "golden", "streams")
+    os.makedirs(out, exist_ok=True)
+    sig = m.signals(seconds=1.6)
+    x = 0.5 * sig["clicks"] + 0.35 * sig["harmonic"] + 0.3 * sig["noise_sweep"]
+    wav = "/tmp/xaac_golden_mix.wav"
+    m.write_wav(wav, x)
+    for aot, br in ((2, 64000), (5, 48000), (29, 32000)):
+        aac = os.path.join(out, "mix_aot%d_%dk.aac" % (aot, br // 1000))
+        subprocess.run([os.path.join(REF, "xaacenc"), "-ifile:" + wav, "-ofile:" + aac, "-aot:%d" % aot, "-br:%d" % br,
+                        "-adts:1"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        print(aac, os.path.getsize(aac))
+
+
+if __name__ == "__main__":
+    main()
