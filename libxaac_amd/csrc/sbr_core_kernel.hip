@@ -63,8 +63,24 @@ struct XsLds {
   int16_t rand_hi[568]; /* xaac_sbr_rand_ph >> 16 */
 };
 
+/* global -> LDS (or back): eight loads are in flight before the first store, so a copy costs one memory
+   latency per 512 words instead of one per 64 */
 __device__ __forceinline__ void copy_words(int32_t *dst, const int32_t *src, int n, int lane) {
-  for (int i = lane; i < n; i += 64) dst[i] = src[i];
+  int i = lane;
+  for (; i + 64 * 7 < n; i += 64 * 8) {
+    int32_t t[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) t[j] = src[i + 64 * j];
+#pragma unroll
+    for (int j = 0; j < 8; j++) dst[i + 64 * j] = t[j];
+  }
+  int32_t t[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++)
+    if (i + 64 * j < n) t[j] = src[i + 64 * j];
+#pragma unroll
+  for (int j = 0; j < 8; j++)
+    if (i + 64 * j < n) dst[i + 64 * j] = t[j];
 }
 
 }  // namespace
@@ -95,10 +111,20 @@ __global__ __launch_bounds__(64) void xaac_sbr_core_kernel(XaacSbrCoreParams p) 
     s.x[XW + (i & 127)] = 0;
   }
   copy_words(s.x + 2 * ROW, gstw + offsetof(xaac_sbr_state, overlap) / 4, 6 * ROW, lane);  /* sbr_dec.c:753 */
-  for (int i = lane; i < 32 * 32 * (HQ ? 2 : 1); i += 64) { /* the analysed slots: bands 0..31 (re, im) */
-    const int row = HQ ? (i >> 6) : (i >> 5), col = HQ ? ((i & 31) + ((i & 32) ? 64 : 0)) : (i & 31);
-    const int o = (8 + row) * ROW + col;
-    s.x[o] = gx[o];
+  for (int i0 = lane; i0 < 32 * 32 * (HQ ? 2 : 1); i0 += 64 * 8) { /* the analysed slots: bands 0..31 (re, im) */
+    int32_t t[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int i = i0 + 64 * j;
+      const int row = HQ ? (i >> 6) : (i >> 5), col = HQ ? ((i & 31) + ((i & 32) ? 64 : 0)) : (i & 31);
+      t[j] = gx[(8 + row) * ROW + col];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int i = i0 + 64 * j;
+      const int row = HQ ? (i >> 6) : (i >> 5), col = HQ ? ((i & 31) + ((i & 32) ? 64 : 0)) : (i & 31);
+      s.x[(8 + row) * ROW + col] = t[j];
+    }
   }
   __syncthreads();
 #ifdef XS_PROFILE

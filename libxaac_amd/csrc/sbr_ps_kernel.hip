@@ -55,6 +55,19 @@ struct XpLds {
 };
 static_assert(sizeof(XpTables) % 4 == 0, "word copies");
 
+/* global -> LDS with eight loads in flight (see sbr_core_kernel.hip) */
+__device__ __forceinline__ void copy_words(int32_t *dst, const int32_t *src, int n, int lane) {
+  for (int i = lane; i < n; i += 64 * 8) {
+    int32_t t[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (i + 64 * j < n) t[j] = src[i + 64 * j];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (i + 64 * j < n) dst[i + 64 * j] = t[j];
+  }
+}
+
 __device__ __forceinline__ int32_t adj_word(int32_t v, int shift) { /* env_calc.c:1099 on one word */
   if (shift == 0) return v;
   if (shift > 31) shift = 31;
@@ -77,17 +90,11 @@ __global__ __launch_bounds__(64) void xaac_ps_kernel(XaacPsParams p) {
   xaac_ps_state *gps = p.state + n;
   int32_t *gx = p.x + (size_t)n * (40 * 128) + 2 * 128; /* slot 0 */
   int32_t *gr = p.xr + (size_t)n * (32 * 128);
-  {
-    const int32_t *src = reinterpret_cast<const int32_t *>(gps);
-    int32_t *dst = reinterpret_cast<int32_t *>(&s.ps);
-    for (int i = lane; i < kHeadWords; i += 64) dst[i] = src[i];
-    const int32_t *fs = reinterpret_cast<const int32_t *>(p.frame + n);
-    int32_t *fd = reinterpret_cast<int32_t *>(&s.pf);
-    for (int i = lane; i < (int)(sizeof(xaac_ps_frame) / 4); i += 64) fd[i] = fs[i];
-    const int32_t *ts = reinterpret_cast<const int32_t *>(&xaac_ps_tables);
-    int32_t *td = reinterpret_cast<int32_t *>(&s.tabs);
-    for (int i = lane; i < (int)(sizeof(XpTables) / 4); i += 64) td[i] = ts[i];
-  }
+  copy_words(reinterpret_cast<int32_t *>(&s.ps), reinterpret_cast<const int32_t *>(gps), kHeadWords, lane);
+  copy_words(reinterpret_cast<int32_t *>(&s.pf), reinterpret_cast<const int32_t *>(p.frame + n),
+             sizeof(xaac_ps_frame) / 4, lane);
+  copy_words(reinterpret_cast<int32_t *>(&s.tabs), reinterpret_cast<const int32_t *>(&xaac_ps_tables),
+             sizeof(XpTables) / 4, lane);
   __syncthreads();
 #ifdef XS_PROFILE
   if (lane == 0) {

@@ -45,6 +45,7 @@ typedef struct XaacQmfSynParams {
   /* output addressing: 0 -> the ch_fac interleave of the C ABI; else channel c's sample n goes to
      pcm[c * pcm_ch_stride + n * pcm_sample_stride] (one launch per output channel of a PS stream) */
   int32_t pcm_ch_stride, pcm_sample_stride;
+  int32_t *dbg; /* profiling builds (-DXS_PROFILE) only: cycle counters at dbg[64..], else unused */
 } XaacQmfSynParams;
 
 #ifdef __cplusplus

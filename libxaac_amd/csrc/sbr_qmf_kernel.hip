@@ -90,10 +90,24 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_analysis_kernel(XaacQ
         const xaac_qmf_ana_state *st = reinterpret_cast<const xaac_qmf_ana_state *>(
             reinterpret_cast<const char *>(p.state) + (size_t)ch * p.state_stride);
         const int wr = st->wr;
-        for (int a = lane; a < 288; a += 64) h[287 - a] = st->ring[ana_ring_pos(wr, a)];
         const int cf = p.ch_fac;
         const int16_t *src = p.pcm + (size_t)(ch / cf) * 1024 * cf + (ch % cf);
-        for (int i = lane; i < 1024; i += 64) h[288 + i] = src[(size_t)i * cf];
+        /* all loads of the channel (5 ring + 16 PCM per lane) in flight before the first LDS store */
+        int16_t hr[5], hp[16];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+          const int a = lane + 64 * j;
+          hr[j] = a < 288 ? st->ring[ana_ring_pos(wr, a)] : (int16_t)0;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) hp[j] = src[(size_t)(lane + 64 * j) * cf];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+          const int a = lane + 64 * j;
+          if (a < 288) h[287 - a] = hr[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) h[288 + lane + 64 * j] = hp[j];
       } else {
         for (int i = lane; i < kHist; i += 64) h[i] = 0;
       }
@@ -167,6 +181,20 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_analysis_kernel(XaacQ
   }
 }
 
+#ifdef XS_PROFILE
+/* phase timers of the synthesis kernel (tools/prof_sbr_core.py): cycles of each wave's lane 0 */
+#define XQ_T(i)                                                            \
+  do {                                                                     \
+    if (lane == 0) {                                                       \
+      long long t_ = clock64();                                            \
+      xq_acc[i] += t_ - xq_last;                                           \
+      xq_last = t_;                                                        \
+    }                                                                      \
+  } while (0)
+#else
+#define XQ_T(i)
+#endif
+
 /* ===================================================================================== */
 template <bool LP>
 __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(XaacQmfSynParams p) {
@@ -184,20 +212,33 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
 #pragma unroll
   for (int a = 0; a < 10; a++) coef[a] = xaac_qmf_qmf_c[64 * a + lane];
 
+#ifdef XS_PROFILE
+  long long xq_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xq_last = clock64();
+#endif
   const int n_pairs = (p.n_ch + 1) >> 1;
   const int waves_total = gridDim.x * XAAC_QMF_WAVES;
   for (int pair = blockIdx.x * XAAC_QMF_WAVES + wave; pair < n_pairs; pair += waves_total) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    XQ_T(0);
     /* ---- slot rows in, coalesced --------------------------------------------------------------- */
-    for (int r = 0; r < 64; r++) {
-      const int ch = 2 * pair + (r >> 5);
-      if (ch < p.n_ch) {
-        const int32_t *row = p.qmf + (size_t)ch * p.qmf_ch_stride + (size_t)(r & 31) * p.slot_stride;
-        for (int k = lane; k < ROW; k += 64) rows[RS * r + k] = row[k];
-      } else {
-        for (int k = lane; k < ROW; k += 64) rows[RS * r + k] = 0;
+    /* eight rows' loads are issued before the first is consumed: one HBM/L2 latency per group, not per row */
+    for (int r0 = 0; r0 < 64; r0 += 8) {
+      int32_t tmp[8][ROW / 64];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int r = r0 + j, ch = 2 * pair + (r >> 5);
+        const int32_t *row = p.qmf + (size_t)(ch < p.n_ch ? ch : 0) * p.qmf_ch_stride + (size_t)(r & 31) * p.slot_stride;
+#pragma unroll
+        for (int q = 0; q < ROW / 64; q++) tmp[j][q] = row[lane + 64 * q];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int r = r0 + j, ch = 2 * pair + (r >> 5);
+#pragma unroll
+        for (int q = 0; q < ROW / 64; q++) rows[RS * r + lane + 64 * q] = ch < p.n_ch ? tmp[j][q] : 0;
       }
     }
+    XQ_T(1);
     /* ---- per-slot: region rescale (qmf_dec.c:937-953) + inverse modulation; lane = slot ----------- */
     int16_t b[128];
     {
@@ -223,6 +264,7 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
       else
         xq_synth_hq_slot(x, t, b, -(st_syn - 3) + 1);
     }
+    XQ_T(2);
     /* all lanes hold their slot in registers now: the row tile may be overwritten (the tile is
        re-used through an int16 view: keep the compiler from moving accesses across this point) */
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -238,14 +280,23 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
       const xaac_qmf_syn_state *st = reinterpret_cast<const xaac_qmf_syn_state *>(
           reinterpret_cast<const char *>(p.state) + (size_t)ch * p.state_stride);
       const int d = st->drc_offset;
-      for (int i = lane; i < 9 * 128; i += 64) {
+      int16_t hist[18]; /* 9 slots x 128 samples over 64 lanes: all loads in flight together */
+#pragma unroll
+      for (int j = 0; j < 18; j++) {
+        const int i = lane + 64 * j;
         const int A = 9 - (i >> 7); /* slot age relative to this frame's slot 0 */
         int pos = d + 128 * A + (i & 127);
         if (pos >= 1280) pos -= 1280;
-        v[(c * VSLOTS + (i >> 7)) * 128 + (i & 127)] = st->ring[pos];
+        hist[j] = st->ring[pos];
+      }
+#pragma unroll
+      for (int j = 0; j < 18; j++) {
+        const int i = lane + 64 * j;
+        v[(c * VSLOTS + (i >> 7)) * 128 + (i & 127)] = hist[j];
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    XQ_T(3);
     /* ---- window-add: lanes = output sample k of the slot, loop over slots ------------------------ */
     for (int c = 0; c < 2; c++) {
       const int ch = 2 * pair + c;
@@ -263,6 +314,7 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
         dst[(size_t)(64 * s + lane) * cf] = (int16_t)(fx_shl_sat(acc, shift) >> 16);
       }
     }
+    XQ_T(4);
     /* ---- state: ring blocks of the last 10 slots, drc offset, window phase --------------------------- */
     for (int c = 0; c < 2; c++) {
       const int ch = 2 * pair + c;
@@ -284,7 +336,13 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
         st->phase = (int16_t)ph_new;
       }
     }
+    XQ_T(5);
   }
+#ifdef XS_PROFILE
+  if (lane == 0 && p.dbg)
+    for (int i = 0; i < 8; i++)
+      atomicAdd(reinterpret_cast<unsigned long long *>(p.dbg) + 64 + (LP ? 0 : 8) + i, (unsigned long long)xq_acc[i]);
+#endif
 }
 
 extern "C" hipError_t xaac_launch_qmf_analysis(const XaacQmfAnaParams *p, int grid, hipStream_t stream) {

@@ -267,7 +267,7 @@ int32_t xaac_sbr_lp_process_batch(xaac_ctx *c, const xaac_sbr_lp_batch *b) {
   ps.n_ch = b->n_ch; ps.ch_fac = b->out_ch_fac; ps.low_pow = 1; ps.lsb = 0; ps.usb = 0; ps.split = 6;
   ps.slot_stride = 64; ps.state_stride = (int32_t)sizeof(xaac_sbr_state); ps.qmf_ch_stride = XAAC_SBR_X_WORDS;
   ps.scale_stride = 8; ps.per_ch_bands = 1;
-  ps.qmf = x + 2 * 64; ps.scale = par;
+  ps.qmf = x + 2 * 64; ps.scale = par; ps.dbg = b->status;
   ps.state = reinterpret_cast<xaac_qmf_syn_state *>(st + offsetof(xaac_sbr_state, syn_ring));
   ps.pcm = b->pcm_out;
   const int grid = qmf_grid(c, b->n_ch, 2);
@@ -328,7 +328,7 @@ int32_t xaac_sbr_hq_process_batch(xaac_ctx *c, const xaac_sbr_hq_batch *b) {
   ps.n_ch = b->n_ch; ps.ch_fac = with_ps ? 1 : b->out_ch_fac; ps.low_pow = 0; ps.split = 6;
   ps.slot_stride = 128; ps.state_stride = (int32_t)sizeof(xaac_sbr_state); ps.qmf_ch_stride = xw;
   ps.scale_stride = 8; ps.per_ch_bands = 1;
-  ps.qmf = x + 2 * 128; ps.scale = par_l;
+  ps.qmf = x + 2 * 128; ps.scale = par_l; ps.dbg = b->status;
   ps.state = reinterpret_cast<xaac_qmf_syn_state *>(st + offsetof(xaac_sbr_state, syn_ring));
   ps.pcm = b->pcm_out;
   if (with_ps) { ps.pcm_ch_stride = 2 * 2048; ps.pcm_sample_stride = 2; }

@@ -54,6 +54,11 @@ def main_ps():
         if core[i]:
             print("%2d %-34s %9.0f cycles/channel-frame %5.1f%%" % (i, NAMES.get(i, "?"), core[i], 100 * core[i] / core.sum()))
     print("   total %.0f cycles" % core.sum())
+    syn = status.cpu().numpy()[128:160].view(np.uint64).astype(np.float64)[8:16] / (steps * n * 2)
+    print("HQ synthesis kernel (per channel-frame of a wave's pair; both launches):")
+    for i, nm in enumerate(["loop top", "rows in", "transform", "v store + ring load", "window-add", "state out"]):
+        print("%2d %-34s %9.0f cycles %5.1f%%" % (i, nm, syn[i], 100 * syn[i] / syn.sum()))
+    print("   total %.0f cycles" % syn.sum())
     print("PS kernel:")
     for i in range(1, 9):
         print("%2d %-34s %9.0f cycles/stream-frame %5.1f%%" % (i, PS_NAMES[i], ps[i], 100 * ps[i] / ps.sum()))
