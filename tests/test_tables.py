@@ -49,3 +49,30 @@ def test_tables_equal_reference_rom():
     mine = gen_tables.tables()
     for name, want in ref.items():
         assert np.array_equal(mine[name], want), name
+
+
+def _regenerated_equals_committed(tool, out_name, tmp_path):
+    """tools/gen_tables_{qmf,sbr,ps}.py read the constants out of the compiled reference's ROM image; the committed
+    .inc must be exactly what they produce today"""
+    import importlib
+    import os
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libxaacdec_ref.so")
+    if not os.path.exists(ref_so):
+        pytest.skip("oracle/_ref/libxaacdec_ref.so missing (built where /root/reference exists)")
+    mod = importlib.import_module(tool)
+    out = str(tmp_path / out_name)
+    mod.emit(mod.reference_tables(), out)
+    committed = os.path.join(ROOT, "libxaac_amd", "csrc", out_name)
+    assert open(out).read() == open(committed).read(), "%s is stale: rerun tools/%s.py" % (out_name, tool)
+
+
+def test_qmf_tables_equal_reference_rom(tmp_path):
+    _regenerated_equals_committed("gen_tables_qmf", "tables_qmf.inc", tmp_path)
+
+
+def test_sbr_tables_equal_reference_rom(tmp_path):
+    _regenerated_equals_committed("gen_tables_sbr", "tables_sbr.inc", tmp_path)
+
+
+def test_ps_tables_equal_reference_rom(tmp_path):
+    _regenerated_equals_committed("gen_tables_ps", "tables_ps.inc", tmp_path)
