@@ -157,56 +157,60 @@ def make_inputs_c4(torch, device, sets, seed):
 def cpu_baseline_sbr(workload, seconds_budget=10.0):
     """CPU baseline of the SBR workloads: the compiled reference's own ixheaacd_sbr_dec driven through
     oracle/ref_sbr_adapter.c (kind "reference") or, where oracle/_ref did not travel, the bit-exact restatement
-    (kind "port"), on the committed reference-captured frames, one chain of frames per thread, all host cores."""
+    (kind "port"), on the committed reference-captured frames: every host thread runs a C loop over its own shard
+    of channel-frames (arrays of the boundary structs, state reset per pass)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     import sbr_capture as cap
-    P16 = ctypes.POINTER(ctypes.c_int16)
     hq = workload == "c4"
     recs = [r for r in cap.read_records(os.path.join(ROOT, "tests", "golden",
             "sbr_hq_ps_records.bin.gz" if hq else "sbr_lp_records.bin.gz")) if r["enh"] == 0]
     ref = oracle_lib.load_reference()
-    fn_name = ("ref_sbr_dec_hq" if hq else "ref_sbr_dec_lp")
-    if ref is not None and hasattr(ref.lib, fn_name):
-        kind, fn = "reference", getattr(ref.lib, fn_name)
+    name = "sbr_dec_hq_batch" if hq else "sbr_dec_lp_batch"
+    if ref is not None and hasattr(ref.lib, "ref_" + name):
+        kind, fn = "reference", getattr(ref.lib, "ref_" + name)
     else:
-        kind, fn = "port", getattr(oracle_lib.load_oracle().lib, "xo_sbr_dec_hq" if hq else "xo_sbr_dec_lp")
+        kind, fn = "port", getattr(oracle_lib.load_oracle().lib, "xo_" + name)
+    fn.restype = ctypes.c_int
     cores = os.cpu_count() or 1
-    reps = 8
+    per_thread = 64                    # channel-frames per thread per pass
+    pick = [recs[i % len(recs)] for i in range(per_thread)]
+    blob = lambda key: b"".join(bytes(r[key]) for r in pick)
+    hdr, frm, st0 = blob("header"), blob("frame"), blob("st0")
+    pin = np.concatenate([r["pcm_in"] for r in pick]).astype(np.int16)
+    psf, ps0 = (blob("ps_frame"), blob("ps0")) if hq else (None, None)
 
-    def chain(t, count):
-        out = np.zeros(4096, np.int16)
-        for k in range(count):
-            r = recs[(t + k) % len(recs)]
-            st = cap.State.from_buffer_copy(bytes(r["st0"]))
-            pin = r["pcm_in"]
-            if hq:
-                ps = cap.PsState.from_buffer_copy(bytes(r["ps0"]))
-                fn(ctypes.byref(r["header"]), ctypes.byref(r["frame"]), ctypes.byref(st), ctypes.byref(r["ps_frame"]),
-                   ctypes.byref(ps), pin.ctypes.data_as(P16), 1, out.ctypes.data_as(P16), 2)
-            else:
-                fn(ctypes.byref(r["header"]), ctypes.byref(r["frame"]), ctypes.byref(st), pin.ctypes.data_as(P16), 1,
-                   out.ctypes.data_as(P16), 1)
+    def shard(_):
+        st = ctypes.create_string_buffer(st0, len(st0))
+        out = np.zeros(per_thread * (4096 if hq else 2048), np.int16)
+        if hq:
+            ps = ctypes.create_string_buffer(ps0, len(ps0))
+            fn(per_thread, hdr, frm, st, psf, ps, pin.ctypes.data, out.ctypes.data)
+        else:
+            fn(per_thread, hdr, frm, st, pin.ctypes.data, out.ctypes.data)
 
-    def one_pass(nthreads, count):
+    fn.argtypes = ([ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p,
+                    ctypes.c_void_p, ctypes.c_void_p] if hq else
+                   [ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p])
+
+    def one_pass(nthreads):
         t0 = time.perf_counter()
-        th = [threading.Thread(target=chain, args=(t, count)) for t in range(nthreads)]
+        th = [threading.Thread(target=shard, args=(t,)) for t in range(nthreads)]
         [t.start() for t in th]
         [t.join() for t in th]
         return time.perf_counter() - t0
 
-    one_pass(cores, 2)
-    t1 = min(one_pass(1, reps) for _ in range(2))
+    one_pass(cores)
+    t1 = min(one_pass(1) for _ in range(2))
     best, spent, passes = 1e9, 0.0, 0
-    while spent < seconds_budget and passes < 200:
-        dt = one_pass(cores, reps)
+    while spent < seconds_budget and passes < 400:
+        dt = one_pass(cores)
         best, spent, passes = min(best, dt), spent + dt, passes + 1
     per_frame = 1.0 if hq else 0.5     # C3 counts stereo frames: two channel calls each
-    return {"value": round(cores * reps * per_frame / best, 1), "unit": "frames/s", "cores": cores, "kind": kind,
-            "value_1core": round(reps * per_frame / t1, 1),
-            "sample": "%d ixheaacd_sbr_dec calls per thread per pass on the committed reference-captured frames "
-                      "(python call overhead included), %d passes; SBR chain only, the core IMDCT is not in it"
-                      % (reps, passes)}
+    return {"value": round(cores * per_thread * per_frame / best, 1), "unit": "frames/s", "cores": cores, "kind": kind,
+            "value_1core": round(per_thread * per_frame / t1, 1),
+            "sample": "%d ixheaacd_sbr_dec calls per thread per pass (C loop) on the committed reference-captured "
+                      "frames, %d passes; SBR chain only, the core IMDCT is not in it" % (per_thread, passes)}
 
 
 def cpu_baseline(seconds_budget=12.0):

@@ -192,3 +192,20 @@ extern "C" int xo_sbr_dec_hq(const xaac_sbr_header *h, const xaac_sbr_frame *f, 
   st->ov_lb_scale = (int16_t)save_lb_scale;
   return 0;
 }
+
+/* n independent channel-frames in a C loop (CPU baseline "port" when oracle/_ref did not travel) */
+extern "C" int xo_sbr_dec_lp_batch(int n, const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st,
+                                   const int16_t *pcm_in, int16_t *pcm_out) {
+  int bad = 0;
+  for (int i = 0; i < n; i++)
+    bad += xo_sbr_dec_lp(h + i, f + i, st + i, pcm_in + 1024 * (size_t)i, 1, pcm_out + 2048 * (size_t)i, 1) != 0;
+  return bad;
+}
+extern "C" int xo_sbr_dec_hq_batch(int n, const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st,
+                                   const xaac_ps_frame *pf, xaac_ps_state *ps, const int16_t *pcm_in, int16_t *pcm_out) {
+  int bad = 0;
+  for (int i = 0; i < n; i++)
+    bad += xo_sbr_dec_hq(h + i, f + i, st + i, pf ? pf + i : nullptr, ps ? ps + i : nullptr, pcm_in + 1024 * (size_t)i, 1,
+                         pcm_out + (pf ? 4096 : 2048) * (size_t)i, pf ? 2 : 1) != 0;
+  return bad;
+}

@@ -340,3 +340,23 @@ int ref_sbr_dec_hq(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_s
                    xaac_ps_state *ps, const int16_t *pcm_in, int in_stride, int16_t *pcm_out, int out_stride) {
   return run_sbr_dec(h, f, st, pf, ps, 0, pcm_in, in_stride, pcm_out, out_stride);
 }
+
+/* n independent channel-frames in a C loop (for timing the reference as the CPU baseline of the SBR
+   workloads, one shard of channels per host thread): arrays of the boundary structs, pcm_in n x 1024,
+   pcm_out n x 2048 (x 2 interleaved with PS).  Returns the number of failed frames. */
+int ref_sbr_dec_lp_batch(int n, const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st,
+                         const int16_t *pcm_in, int16_t *pcm_out) {
+  int i, bad = 0;
+  for (i = 0; i < n; i++)
+    bad += run_sbr_dec(h + i, f + i, st + i, NULL, NULL, 1, pcm_in + 1024 * (size_t)i, 1, pcm_out + 2048 * (size_t)i, 1) != 0;
+  return bad;
+}
+
+int ref_sbr_dec_hq_batch(int n, const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st,
+                         const xaac_ps_frame *pf, xaac_ps_state *ps, const int16_t *pcm_in, int16_t *pcm_out) {
+  int i, bad = 0;
+  for (i = 0; i < n; i++)
+    bad += run_sbr_dec(h + i, f + i, st + i, pf ? pf + i : NULL, ps ? ps + i : NULL, 0, pcm_in + 1024 * (size_t)i, 1,
+                       pcm_out + (pf ? 4096 : 2048) * (size_t)i, pf ? 2 : 1) != 0;
+  return bad;
+}
