@@ -173,7 +173,7 @@ def cpu_baseline_sbr(workload, seconds_budget=10.0):
         kind, fn = "port", getattr(oracle_lib.load_oracle().lib, "xo_" + name)
     fn.restype = ctypes.c_int
     cores = os.cpu_count() or 1
-    per_thread = 64                    # channel-frames per thread per pass
+    per_thread = 512                   # channel-frames per thread per pass (thread start-up amortised)
     pick = [recs[i % len(recs)] for i in range(per_thread)]
     blob = lambda key: b"".join(bytes(r[key]) for r in pick)
     hdr, frm, st0 = blob("header"), blob("frame"), blob("st0")
