@@ -177,6 +177,44 @@ typedef struct xaac_sbr_hq_batch {
   uint64_t workspace_bytes;
 } xaac_sbr_hq_batch;
 
+/* ---- peak limiter + PCM16 hand-off (the AAC-LC post stage) ---------------------------------
+ * xaac_peak_limiter_process_batch <-> ixheaacd_peak_limiter_process
+ *      def decoder/ixheaacd_peak_limiter.c:201-309, call site decoder/ixheaacd_api.c:3667, followed by the
+ *      round16 loop of api.c:3676-3681 (pcm16).  It consumes what xaac_imdct_process_batch leaves: the
+ *      interleaved WORD32 block (out32) and qshift_adj per channel.
+ * The state is ia_peak_limiter_struct (decoder/ixheaacd_peak_limiter_struct_def.h:31-51) with its two
+ * buffer pointers turned into arrays: max_buf = attack_time_samples window of channel-maximum magnitudes,
+ * delayed_input = the look-ahead delay line, attack_time_samples x num_channels interleaved. */
+#define XAAC_LIM_MAX_ATTACK 480 /* 5 ms at 96 kHz */
+#define XAAC_LIM_MAX_CH 8
+typedef struct xaac_limiter_state {
+  float attack_constant, release_constant;
+  uint32_t num_channels;        /* 1 .. XAAC_LIM_MAX_CH */
+  uint32_t attack_time_samples; /* 1 .. XAAC_LIM_MAX_ATTACK */
+  uint32_t limiter_on;
+  float gain_modified;
+  float min_gain;               /* out: smallest gain applied in the last frame */
+  uint32_t delayed_input_index;
+  double pre_smoothed_gain;
+  int32_t max_idx, cir_buf_pnt;
+  float max_buf[XAAC_LIM_MAX_ATTACK];
+  float delayed_input[XAAC_LIM_MAX_ATTACK * XAAC_LIM_MAX_CH];
+} xaac_limiter_state;
+
+typedef struct xaac_limiter_batch {
+  int32_t n_streams;
+  int32_t frame_len;          /* samples per channel, 1 .. 1024 */
+  int32_t *samples;           /* in/out [n_streams][frame_len][num_channels] WORD32 (stream s at s * stride) */
+  int64_t stride;             /* words between consecutive streams' blocks, >= frame_len * num_channels */
+  const int8_t *qshift_adj;   /* [n_streams][num_channels], each 0 .. 30 */
+  xaac_limiter_state *state;  /* [n_streams] in/out; num_channels must be the same in the whole batch */
+  int32_t num_channels;
+  int32_t pad_;
+  int16_t *pcm16;             /* optional [n_streams][frame_len][num_channels]: round16 of the result (dense) */
+  int32_t *status;            /* optional [n_streams]: 0, or -1 for a stream whose state does not fit the batch
+                                 (num_channels / attack_time_samples out of range): left untouched */
+} xaac_limiter_batch;
+
 typedef struct xaac_ctx xaac_ctx;
 
 /* Create a context bound to HIP device `device`.  `hip_stream` is a
@@ -207,6 +245,12 @@ int32_t xaac_sbr_lp_process_batch(xaac_ctx *ctx, const xaac_sbr_lp_batch *batch)
  * stereo] -> complex QMF synthesis, once per output channel). */
 uint64_t xaac_sbr_hq_workspace_bytes(int32_t n_ch, int32_t with_ps);
 int32_t xaac_sbr_hq_process_batch(xaac_ctx *ctx, const xaac_sbr_hq_batch *batch);
+
+/* ixheaacd_peak_limiter_init (peak_limiter.c:46-77) on a host-side state; returns the limiter delay in
+ * samples (attack_time_samples) or a fatal code when the rate / channel count does not fit the struct. */
+int32_t xaac_peak_limiter_init(xaac_limiter_state *state, uint32_t num_channels, uint32_t sample_rate);
+/* One frame of every stream through the limiter (device pointers, asynchronous). */
+int32_t xaac_peak_limiter_process_batch(xaac_ctx *ctx, const xaac_limiter_batch *batch);
 
 /* Launch geometry the library used for the last batch (for reports). */
 int32_t xaac_last_launch(xaac_ctx *ctx, int32_t *grid, int32_t *block, int32_t *lds_bytes);

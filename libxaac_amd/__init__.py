@@ -80,6 +80,29 @@ class _SbrHqBatch(ctypes.Structure):
                 ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_uint64)]
 
 
+class _LimiterBatch(ctypes.Structure):
+    # struct xaac_limiter_batch
+    _fields_ = [("n_streams", ctypes.c_int32), ("frame_len", ctypes.c_int32), ("samples", ctypes.c_void_p),
+                ("stride", ctypes.c_int64), ("qshift_adj", ctypes.c_void_p), ("state", ctypes.c_void_p),
+                ("num_channels", ctypes.c_int32), ("pad_", ctypes.c_int32), ("pcm16", ctypes.c_void_p),
+                ("status", ctypes.c_void_p)]
+
+
+LIM_MAX_ATTACK, LIM_MAX_CH = 480, 8
+
+
+class LimiterState(ctypes.Structure):
+    # struct xaac_limiter_state (ia_peak_limiter_struct with its buffers inline)
+    _fields_ = [("attack_constant", ctypes.c_float), ("release_constant", ctypes.c_float),
+                ("num_channels", ctypes.c_uint32), ("attack_time_samples", ctypes.c_uint32),
+                ("limiter_on", ctypes.c_uint32), ("gain_modified", ctypes.c_float), ("min_gain", ctypes.c_float),
+                ("delayed_input_index", ctypes.c_uint32), ("pre_smoothed_gain", ctypes.c_double),
+                ("max_idx", ctypes.c_int32), ("cir_buf_pnt", ctypes.c_int32),
+                ("max_buf", ctypes.c_float * LIM_MAX_ATTACK),
+                ("delayed_input", ctypes.c_float * (LIM_MAX_ATTACK * LIM_MAX_CH))]
+
+
+LIMITER_STATE_BYTES = ctypes.sizeof(LimiterState)   # 17328
 SBR_HEADER_BYTES, SBR_FRAME_BYTES, SBR_STATE_BYTES = 336, 1072, 7300   # include/xaac_sbr.h
 PS_FRAME_BYTES, PS_STATE_BYTES = 972, 7764
 QMF_ANA_STATE_WORDS = 322    # int16 words of struct xaac_qmf_ana_state: ring[320], wr, phase
@@ -123,6 +146,10 @@ def load_library():
     lib.xaac_sbr_hq_process_batch.restype = ctypes.c_int32
     lib.xaac_sbr_hq_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32]
     lib.xaac_sbr_hq_workspace_bytes.restype = ctypes.c_uint64
+    lib.xaac_peak_limiter_init.argtypes = [ctypes.POINTER(LimiterState), ctypes.c_uint32, ctypes.c_uint32]
+    lib.xaac_peak_limiter_init.restype = ctypes.c_int32
+    lib.xaac_peak_limiter_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_LimiterBatch)]
+    lib.xaac_peak_limiter_process_batch.restype = ctypes.c_int32
     for f in ("xaac_create", "xaac_destroy", "xaac_sync", "xaac_set_stream", "xaac_imdct_process_batch",
               "xaac_imdct_process_batch_host", "xaac_last_launch", "xaac_qmf_analysis_batch",
               "xaac_qmf_synthesis_batch"):
@@ -156,6 +183,15 @@ def _ptr(t, dtype_name, numel=None, allow_none=False, device_ok=None):
     if numel is not None and n != numel:
         raise ValueError("buffer has %d elements, expected %d" % (n, numel))
     return p
+
+
+def peak_limiter_init(num_channels, sample_rate):
+    """ixheaacd_peak_limiter_init: -> (LimiterState, delay in samples)"""
+    st = LimiterState()
+    rc = load_library().xaac_peak_limiter_init(ctypes.byref(st), int(num_channels), int(sample_rate))
+    if rc < 0:
+        raise XaacError(rc, "xaac_peak_limiter_init")
+    return st, rc
 
 
 class XaacContext:
@@ -294,6 +330,27 @@ class XaacContext:
         rc = self._lib.xaac_sbr_hq_process_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_sbr_hq_process_batch")
+
+    def peak_limiter_process_batch(self, samples, qshift_adj, state, num_channels, frame_len=1024, pcm16=None,
+                                   stride=None, status=None):
+        """Batched ixheaacd_peak_limiter_process (+ the round16 hand-off): one frame of every stream.
+        samples int32[n_streams * stride] in/out, frame_len x num_channels interleaved per stream (what
+        imdct_process_batch leaves in out32); qshift_adj int8[n_streams * num_channels]; state
+        uint8[n_streams, LIMITER_STATE_BYTES] in/out (peak_limiter_init() makes one); pcm16 optional
+        int16[n_streams * frame_len * num_channels]."""
+        n = state.shape[0]
+        if stride is None:
+            stride = frame_len * num_channels
+        b = _LimiterBatch()
+        b.n_streams, b.frame_len, b.num_channels, b.stride = n, int(frame_len), int(num_channels), int(stride)
+        b.samples = _ptr(samples, "int32", n * stride, device_ok=True)
+        b.qshift_adj = _ptr(qshift_adj, "int8", n * num_channels, device_ok=True)
+        b.state = _ptr(state, "uint8", n * LIMITER_STATE_BYTES, device_ok=True)
+        b.pcm16 = _ptr(pcm16, "int16", n * frame_len * num_channels, allow_none=True, device_ok=True)
+        b.status = _ptr(status, "int32", n, allow_none=True, device_ok=True)
+        rc = self._lib.xaac_peak_limiter_process_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_peak_limiter_process_batch")
 
     def sbr_lp_workspace_bytes(self, n_ch):
         return int(self._lib.xaac_sbr_lp_workspace_bytes(int(n_ch)))

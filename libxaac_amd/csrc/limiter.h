@@ -1,0 +1,90 @@
+/*
+ * limiter.h -- the arithmetic of ixheaacd_peak_limiter_process (decoder/ixheaacd_peak_limiter.c:201-309),
+ * one function per step of its sample loop, for host (oracle, sequential) and gfx950 (limiter_kernel.hip).
+ *
+ * The reference mixes float and double on purpose-or-not; every conversion below is where the C
+ * expression puts it (usual arithmetic conversions, FLT_EVAL_METHOD 0, no contraction -- both compilers
+ * get -ffp-contract=off for this code and the pragma below says it again).
+ */
+#ifndef XAAC_LIMITER_H
+#define XAAC_LIMITER_H
+
+#include <stdint.h>
+
+#include "../../include/xaac_amd.h"
+#include "fx.h"
+
+#define XL_THR_FIX 2147483647 /* PEAK_LIM_THR_FIX, peak_limiter_struct_def.h:28 */
+
+/* the gain recursion's carried values (peak_limiter.c:216-218) */
+struct XlGain {
+  float gain_modified;
+  double pre_smoothed_gain;
+};
+
+/* peak_limiter.c:227-228: tmp = (FLOAT32)MAX(tmp, fabs(sample * gain_t)) */
+FX_HD float xl_scaled(int32_t x, int qshift) {
+#pragma clang fp contract(off)
+  const float gain_t = (float)(int32_t)(1u << qshift);
+  return (float)x * gain_t;
+}
+FX_HD float xl_peak(float tmp, int32_t x, int qshift) {
+  float a = xl_scaled(x, qshift);
+  a = a < 0.0f ? -a : a; /* fabs; the double round trip is exact */
+  return tmp > a ? tmp : a;
+}
+
+/* peak_limiter.c:245-249: the target gain for the window maximum */
+FX_HD float xl_target_gain(float maximum) {
+#pragma clang fp contract(off)
+  const float thr = (float)XL_THR_FIX; /* WORD32 -> float in both the compare and the divide: 2^31 */
+  return maximum > thr ? thr / maximum : 1.0f;
+}
+
+/* peak_limiter.c:251-271: one step of the attack / release smoothing; returns the gain to apply */
+FX_HD float xl_gain_step(XlGain &g, float gain, float attack_constant, float release_constant) {
+#pragma clang fp contract(off)
+  double psg = g.pre_smoothed_gain;
+  float gm = g.gain_modified;
+  if ((double)gain < psg) {
+    const float cand = (gain - 0.1f * (float)psg) * 1.11111111f;
+    gm = gm > cand ? cand : gm; /* MIN(x, y) = x > y ? y : x */
+  } else {
+    gm = gain;
+  }
+  if ((double)gm < psg) {
+    psg = (double)attack_constant * (psg - (double)gm) + (double)gm;
+    psg = psg > (double)gain ? psg : (double)gain; /* MAX */
+  } else {
+    psg = (double)release_constant * (psg - (double)gm) + (double)gm;
+  }
+  g.pre_smoothed_gain = psg;
+  g.gain_modified = gm;
+  return (float)psg;
+}
+
+/* peak_limiter.c:272-281: delayed sample x gain -> WORD64 (truncation) -> clamp -> WORD32 */
+FX_HD int32_t xl_apply(float delayed, float gain) {
+#pragma clang fp contract(off)
+  const float t = delayed * gain;
+  int64_t v = (int64_t)t; /* |t| < 2^34 */
+  if (v > (int64_t)XL_THR_FIX) v = XL_THR_FIX;
+  else if (v < -(int64_t)XL_THR_FIX) v = -(int64_t)XL_THR_FIX;
+  return (int32_t)v;
+}
+
+/* peak_limiter.c:293 (limiter off and fully released: plain delay): (WORD32)float as x86's cvttss2si does it */
+FX_HD int32_t xl_passthrough(float delayed) {
+  if (!(delayed < 2147483648.0f && delayed >= -2147483648.0f)) return FX_MIN32;
+  return (int32_t)delayed;
+}
+
+/* peak_limiter.c:222: which branch the frame takes */
+FX_HD int xl_active(uint32_t limiter_on, double pre_smoothed_gain) {
+  return limiter_on != 0 || (float)pre_smoothed_gain != 0.0f;
+}
+
+/* api.c:3676-3681 */
+FX_HD int16_t xl_round16(int32_t v) { return fx_round16(v); }
+
+#endif /* XAAC_LIMITER_H */

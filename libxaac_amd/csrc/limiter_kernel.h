@@ -1,0 +1,28 @@
+/* limiter_kernel.h -- launch interface of the peak limiter kernel (internal). */
+#ifndef XAAC_LIMITER_KERNEL_H
+#define XAAC_LIMITER_KERNEL_H
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "../../include/xaac_amd.h"
+
+typedef struct XaacLimiterParams {
+  int32_t n_streams, frame_len, num_channels;
+  int32_t *samples;
+  int64_t stride;
+  const int8_t *qshift_adj;
+  xaac_limiter_state *state;
+  int16_t *pcm16;
+  int32_t *status;
+  long long *dbg; /* phase timers (profiling builds) */
+} XaacLimiterParams;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+hipError_t xaac_launch_limiter(const XaacLimiterParams *p, hipStream_t stream);
+#ifdef __cplusplus
+}
+#endif
+#endif

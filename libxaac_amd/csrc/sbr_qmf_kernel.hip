@@ -183,7 +183,8 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_analysis_kernel(XaacQ
 
 #ifdef XS_PROFILE
 /* phase timers of the synthesis kernel (tools/prof_sbr_core.py): cycles of each wave's lane 0 */
-#define XQ_T(i)                                                            \
+
+#define XQ_TIME(i)                                                            \
   do {                                                                     \
     if (lane == 0) {                                                       \
       long long t_ = clock64();                                            \
@@ -192,7 +193,8 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_analysis_kernel(XaacQ
     }                                                                      \
   } while (0)
 #else
-#define XQ_T(i)
+
+#define XQ_TIME(i)
 #endif
 
 /* ===================================================================================== */
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
   const int waves_total = gridDim.x * XAAC_QMF_WAVES;
   for (int pair = blockIdx.x * XAAC_QMF_WAVES + wave; pair < n_pairs; pair += waves_total) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    XQ_T(0);
+    XQ_TIME(0);
     /* ---- slot rows in, coalesced --------------------------------------------------------------- */
     /* eight rows' loads are issued before the first is consumed: one HBM/L2 latency per group, not per row */
     for (int r0 = 0; r0 < 64; r0 += 8) {
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
         for (int q = 0; q < ROW / 64; q++) rows[RS * r + lane + 64 * q] = ch < p.n_ch ? tmp[j][q] : 0;
       }
     }
-    XQ_T(1);
+    XQ_TIME(1);
     /* ---- per-slot: region rescale (qmf_dec.c:937-953) + inverse modulation; lane = slot ----------- */
     int16_t b[128];
     {
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
       else
         xq_synth_hq_slot(x, t, b, -(st_syn - 3) + 1);
     }
-    XQ_T(2);
+    XQ_TIME(2);
     /* all lanes hold their slot in registers now: the row tile may be overwritten (the tile is
        re-used through an int16 view: keep the compiler from moving accesses across this point) */
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    XQ_T(3);
+    XQ_TIME(3);
     /* ---- window-add: lanes = output sample k of the slot, loop over slots ------------------------ */
     for (int c = 0; c < 2; c++) {
       const int ch = 2 * pair + c;
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
         dst[(size_t)(64 * s + lane) * cf] = (int16_t)(fx_shl_sat(acc, shift) >> 16);
       }
     }
-    XQ_T(4);
+    XQ_TIME(4);
     /* ---- state: ring blocks of the last 10 slots, drc offset, window phase --------------------------- */
     for (int c = 0; c < 2; c++) {
       const int ch = 2 * pair + c;
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
         st->phase = (int16_t)ph_new;
       }
     }
-    XQ_T(5);
+    XQ_TIME(5);
   }
 #ifdef XS_PROFILE
   if (lane == 0 && p.dbg)

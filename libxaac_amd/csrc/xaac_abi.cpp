@@ -16,7 +16,10 @@
 #include "sbr_qmf_kernel.h"
 #include "sbr_core_kernel.h"
 #include "sbr_ps_kernel.h"
+#include "limiter_kernel.h"
+#include <cmath>
 #include <cstddef>
+#include <cstring>
 
 struct xaac_ctx {
   int device;
@@ -343,6 +346,41 @@ int32_t xaac_sbr_hq_process_batch(xaac_ctx *c, const xaac_sbr_hq_batch *b) {
     if (!hip_ok(xaac_launch_qmf_synthesis(&ps, grid, c->stream))) return XAAC_FATAL_HIP;
   }
   c->last_grid = grid; c->last_block = XAAC_QMF_BLOCK; c->last_lds = XAAC_QMF_WAVES * XAAC_QMF_SYN_LDS_PER_WAVE_HQ;
+  return XAAC_OK;
+}
+
+/* ixheaacd_peak_limiter_init, decoder/ixheaacd_peak_limiter.c:46-77 (host side: a stream's state is made once) */
+int32_t xaac_peak_limiter_init(xaac_limiter_state *s, uint32_t num_channels, uint32_t sample_rate) {
+  if (!s) return XAAC_FATAL_NULL_ARG;
+  const uint32_t attack = (uint32_t)(5.0f * sample_rate / 1000);
+  if (attack < 1 || attack > XAAC_LIM_MAX_ATTACK || num_channels < 1 || num_channels > XAAC_LIM_MAX_CH)
+    return XAAC_FATAL_BAD_ARG;
+  std::memset(s, 0, sizeof(*s));
+  s->attack_time_samples = attack;
+  s->attack_constant = (float)std::pow(0.1, 1.0 / (attack + 1));
+  s->release_constant = (float)std::pow(0.1, 1.0 / (50.0f * sample_rate / 1000 + 1));
+  s->num_channels = num_channels;
+  s->min_gain = 1.0f;
+  s->limiter_on = 1;
+  s->pre_smoothed_gain = 1.0f;
+  s->gain_modified = 1.0f;
+  return (int32_t)attack;
+}
+
+int32_t xaac_peak_limiter_process_batch(xaac_ctx *c, const xaac_limiter_batch *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n_streams < 0 || b->frame_len < 1 || b->frame_len > 1024) return XAAC_FATAL_BAD_ARG;
+  if (b->num_channels < 1 || b->num_channels > XAAC_LIM_MAX_CH) return XAAC_FATAL_BAD_ARG;
+  if (b->stride < (int64_t)b->frame_len * b->num_channels) return XAAC_FATAL_BAD_ARG;
+  if (b->n_streams == 0) return XAAC_OK;
+  if (!b->samples || !b->qshift_adj || !b->state) return XAAC_FATAL_NULL_ARG;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  XaacLimiterParams p = {};
+  p.n_streams = b->n_streams; p.frame_len = b->frame_len; p.num_channels = b->num_channels;
+  p.samples = b->samples; p.stride = b->stride; p.qshift_adj = b->qshift_adj; p.state = b->state;
+  p.pcm16 = b->pcm16; p.status = b->status;
+  if (!hip_ok(xaac_launch_limiter(&p, c->stream))) return XAAC_FATAL_HIP;
+  c->last_grid = b->n_streams; c->last_block = 64; c->last_lds = (XAAC_LIM_MAX_ATTACK + 1024) * 4;
   return XAAC_OK;
 }
 
