@@ -63,14 +63,17 @@ FX_HD float xl_gain_step(XlGain &g, float gain, float attack_constant, float rel
   return (float)psg;
 }
 
-/* peak_limiter.c:272-281: delayed sample x gain -> WORD64 (truncation) -> clamp -> WORD32 */
+/* peak_limiter.c:272-281: delayed sample x gain -> WORD64 (truncation) -> clamp to +-(2^31 - 1) -> WORD32.
+   |t| < 2^34, so the WORD64 never overflows; the same result without 64-bit conversions: floats at or above
+   2^31 clamp to 2^31 - 1, those at or below -2^31 to -(2^31 - 1) (so does -2^31 + anything truncated), the
+   rest convert exactly.  (The int conversion of an out-of-range value is never the selected operand.) */
 FX_HD int32_t xl_apply(float delayed, float gain) {
 #pragma clang fp contract(off)
   const float t = delayed * gain;
-  int64_t v = (int64_t)t; /* |t| < 2^34 */
-  if (v > (int64_t)XL_THR_FIX) v = XL_THR_FIX;
-  else if (v < -(int64_t)XL_THR_FIX) v = -(int64_t)XL_THR_FIX;
-  return (int32_t)v;
+  const float lo = t > -2147483648.0f ? t : -2147483648.0f;
+  int32_t v = t >= 2147483648.0f ? 0 : (int32_t)lo;
+  v = t >= 2147483648.0f ? XL_THR_FIX : v;
+  return v < -XL_THR_FIX ? -XL_THR_FIX : v;
 }
 
 /* peak_limiter.c:293 (limiter off and fully released: plain delay): (WORD32)float as x86's cvttss2si does it */

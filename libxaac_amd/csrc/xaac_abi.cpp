@@ -379,6 +379,7 @@ int32_t xaac_peak_limiter_process_batch(xaac_ctx *c, const xaac_limiter_batch *b
   p.n_streams = b->n_streams; p.frame_len = b->frame_len; p.num_channels = b->num_channels;
   p.samples = b->samples; p.stride = b->stride; p.qshift_adj = b->qshift_adj; p.state = b->state;
   p.pcm16 = b->pcm16; p.status = b->status;
+  p.dbg = reinterpret_cast<long long *>(b->status); /* phase timers of -DXL_PROFILE builds (tools/time_limiter.py) */
   if (!hip_ok(xaac_launch_limiter(&p, c->stream))) return XAAC_FATAL_HIP;
   c->last_grid = b->n_streams; c->last_block = 64; c->last_lds = (XAAC_LIM_MAX_ATTACK + 1024) * 4;
   return XAAC_OK;

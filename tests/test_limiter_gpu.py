@@ -120,6 +120,33 @@ def test_off_branch_and_misfit_state(ctx, oracle):
         assert bytes(sg2[i]) == bytes(sg[i])
 
 
+def test_state_with_stale_max_idx(ctx, oracle):
+    """a state whose max_idx does not point at the window's maximum cannot come out of init + process, but the
+    reference runs on it (it trusts the index): the kernel's per-sample walk has to give the same"""
+    import torch
+    init, _, batch = lc.bind(oracle.lib, "xo")
+    n, nch = 10, 2
+    rng = np.random.default_rng(21)
+    so = (lc.LimiterState * n)()
+    for i in range(n):
+        init(ctypes.byref(so[i]), nch, 48000)
+    sg = (lc.LimiterState * n)()
+    for frame in range(5):
+        if frame in (1, 3):
+            for i in range(n):
+                so[i].max_idx = (so[i].max_idx + 1 + 23 * i) % so[i].attack_time_samples
+        ctypes.memmove(sg, so, ctypes.sizeof(so))
+        x = np.concatenate([lc.signal(rng, lc.KINDS[(i + frame) % len(lc.KINDS)], 1024, nch) for i in range(n)])
+        q = rng.integers(1, 3, n * nch).astype(np.int8)
+        xo = x.copy()
+        po = np.zeros(n * 1024 * nch, np.int16)
+        batch(n, 1024, nch, xo.ctypes.data_as(lc.P32), 1024 * nch, q.ctypes.data_as(lc.P8), so, po.ctypes.data_as(lc.P16))
+        xg, pg, sg, status = run_gpu(ctx, torch, x, q, sg, nch, 1024)
+        assert np.array_equal(xg, xo) and np.array_equal(pg, po), frame
+        for i in range(n):
+            assert lc.state_view(sg[i]) == lc.state_view(so[i]), (frame, i)
+
+
 def test_imdct_to_limiter_chain(ctx, oracle):
     """the AAC-LC tail as the decoder runs it: IMDCT out32 + qshift_adj straight into the limiter, on the GPU"""
     import torch
