@@ -213,6 +213,8 @@ typedef struct xaac_limiter_batch {
   int16_t *pcm16;             /* optional [n_streams][frame_len][num_channels]: round16 of the result (dense) */
   int32_t *status;            /* optional [n_streams]: 0, or -1 for a stream whose state does not fit the batch
                                  (num_channels / attack_time_samples out of range): left untouched */
+  void *workspace;            /* device scratch, >= xaac_peak_limiter_workspace_bytes(n_streams) */
+  uint64_t workspace_bytes;
 } xaac_limiter_batch;
 
 typedef struct xaac_ctx xaac_ctx;
@@ -250,6 +252,7 @@ int32_t xaac_sbr_hq_process_batch(xaac_ctx *ctx, const xaac_sbr_hq_batch *batch)
  * samples (attack_time_samples) or a fatal code when the rate / channel count does not fit the struct. */
 int32_t xaac_peak_limiter_init(xaac_limiter_state *state, uint32_t num_channels, uint32_t sample_rate);
 /* One frame of every stream through the limiter (device pointers, asynchronous). */
+uint64_t xaac_peak_limiter_workspace_bytes(int32_t n_streams);
 int32_t xaac_peak_limiter_process_batch(xaac_ctx *ctx, const xaac_limiter_batch *batch);
 
 /* Launch geometry the library used for the last batch (for reports). */

@@ -85,7 +85,7 @@ class _LimiterBatch(ctypes.Structure):
     _fields_ = [("n_streams", ctypes.c_int32), ("frame_len", ctypes.c_int32), ("samples", ctypes.c_void_p),
                 ("stride", ctypes.c_int64), ("qshift_adj", ctypes.c_void_p), ("state", ctypes.c_void_p),
                 ("num_channels", ctypes.c_int32), ("pad_", ctypes.c_int32), ("pcm16", ctypes.c_void_p),
-                ("status", ctypes.c_void_p)]
+                ("status", ctypes.c_void_p), ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_uint64)]
 
 
 LIM_MAX_ATTACK, LIM_MAX_CH = 480, 8
@@ -150,6 +150,8 @@ def load_library():
     lib.xaac_peak_limiter_init.restype = ctypes.c_int32
     lib.xaac_peak_limiter_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_LimiterBatch)]
     lib.xaac_peak_limiter_process_batch.restype = ctypes.c_int32
+    lib.xaac_peak_limiter_workspace_bytes.argtypes = [ctypes.c_int32]
+    lib.xaac_peak_limiter_workspace_bytes.restype = ctypes.c_uint64
     for f in ("xaac_create", "xaac_destroy", "xaac_sync", "xaac_set_stream", "xaac_imdct_process_batch",
               "xaac_imdct_process_batch_host", "xaac_last_launch", "xaac_qmf_analysis_batch",
               "xaac_qmf_synthesis_batch"):
@@ -331,13 +333,16 @@ class XaacContext:
         if rc != 0:
             raise XaacError(rc, "xaac_sbr_hq_process_batch")
 
-    def peak_limiter_process_batch(self, samples, qshift_adj, state, num_channels, frame_len=1024, pcm16=None,
-                                   stride=None, status=None):
+    def peak_limiter_workspace_bytes(self, n_streams):
+        return int(self._lib.xaac_peak_limiter_workspace_bytes(int(n_streams)))
+
+    def peak_limiter_process_batch(self, samples, qshift_adj, state, num_channels, workspace, frame_len=1024,
+                                   pcm16=None, stride=None, status=None):
         """Batched ixheaacd_peak_limiter_process (+ the round16 hand-off): one frame of every stream.
         samples int32[n_streams * stride] in/out, frame_len x num_channels interleaved per stream (what
         imdct_process_batch leaves in out32); qshift_adj int8[n_streams * num_channels]; state
         uint8[n_streams, LIMITER_STATE_BYTES] in/out (peak_limiter_init() makes one); pcm16 optional
-        int16[n_streams * frame_len * num_channels]."""
+        int16[n_streams * frame_len * num_channels]; workspace uint8[>= peak_limiter_workspace_bytes(n_streams)]."""
         n = state.shape[0]
         if stride is None:
             stride = frame_len * num_channels
@@ -348,6 +353,8 @@ class XaacContext:
         b.state = _ptr(state, "uint8", n * LIMITER_STATE_BYTES, device_ok=True)
         b.pcm16 = _ptr(pcm16, "int16", n * frame_len * num_channels, allow_none=True, device_ok=True)
         b.status = _ptr(status, "int32", n, allow_none=True, device_ok=True)
+        b.workspace = _ptr(workspace, "uint8", device_ok=True)
+        b.workspace_bytes = workspace.numel()
         rc = self._lib.xaac_peak_limiter_process_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_peak_limiter_process_batch")

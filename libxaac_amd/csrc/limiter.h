@@ -41,26 +41,23 @@ FX_HD float xl_target_gain(float maximum) {
   return maximum > thr ? thr / maximum : 1.0f;
 }
 
-/* peak_limiter.c:251-271: one step of the attack / release smoothing; returns the gain to apply */
+/* peak_limiter.c:251-271: one step of the attack / release smoothing; returns the gain to apply.
+   Written as selects (both candidates of each branch are computed): the same values, and on the GPU one
+   straight dependency chain instead of four exec-mask regions. */
 FX_HD float xl_gain_step(XlGain &g, float gain, float attack_constant, float release_constant) {
 #pragma clang fp contract(off)
-  double psg = g.pre_smoothed_gain;
-  float gm = g.gain_modified;
-  if ((double)gain < psg) {
-    const float cand = (gain - 0.1f * (float)psg) * 1.11111111f;
-    gm = gm > cand ? cand : gm; /* MIN(x, y) = x > y ? y : x */
-  } else {
-    gm = gain;
-  }
-  if ((double)gm < psg) {
-    psg = (double)attack_constant * (psg - (double)gm) + (double)gm;
-    psg = psg > (double)gain ? psg : (double)gain; /* MAX */
-  } else {
-    psg = (double)release_constant * (psg - (double)gm) + (double)gm;
-  }
-  g.pre_smoothed_gain = psg;
+  const double psg = g.pre_smoothed_gain, gain_d = (double)gain;
+  const float cand = (gain - 0.1f * (float)psg) * 1.11111111f;
+  const float gm_min = g.gain_modified > cand ? cand : g.gain_modified; /* MIN(x, y) = x > y ? y : x */
+  const float gm = gain_d < psg ? gm_min : gain;
+  const double gm_d = (double)gm, diff = psg - gm_d;
+  double attack = (double)attack_constant * diff + gm_d;
+  attack = attack > gain_d ? attack : gain_d; /* MAX */
+  const double release = (double)release_constant * diff + gm_d;
+  const double next = gm_d < psg ? attack : release;
+  g.pre_smoothed_gain = next;
   g.gain_modified = gm;
-  return (float)psg;
+  return (float)next;
 }
 
 /* peak_limiter.c:272-281: delayed sample x gain -> WORD64 (truncation) -> clamp to +-(2^31 - 1) -> WORD32.

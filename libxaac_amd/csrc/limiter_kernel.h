@@ -15,6 +15,8 @@ typedef struct XaacLimiterParams {
   xaac_limiter_state *state;
   int16_t *pcm16;
   int32_t *status;
+  float *ws_gain;   /* [n_streams][1024]: target gains -> gains of the streams the recursion runs on */
+  int32_t *ws_flag; /* [n_streams][2]: finished by the front kernel?, first sample of the recursion */
   long long *dbg; /* phase timers (profiling builds) */
 } XaacLimiterParams;
 

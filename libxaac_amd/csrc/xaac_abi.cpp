@@ -367,21 +367,30 @@ int32_t xaac_peak_limiter_init(xaac_limiter_state *s, uint32_t num_channels, uin
   return (int32_t)attack;
 }
 
+/* target gains / gains of the streams whose smoothing recursion has to run (4 KB each) + two words of hand-over */
+uint64_t xaac_peak_limiter_workspace_bytes(int32_t n_streams) {
+  if (n_streams < 0) return 0;
+  return (uint64_t)n_streams * (1024 * sizeof(float) + 2 * sizeof(int32_t)) + 256;
+}
+
 int32_t xaac_peak_limiter_process_batch(xaac_ctx *c, const xaac_limiter_batch *b) {
   if (!c || !b) return XAAC_FATAL_NULL_ARG;
   if (b->n_streams < 0 || b->frame_len < 1 || b->frame_len > 1024) return XAAC_FATAL_BAD_ARG;
   if (b->num_channels < 1 || b->num_channels > XAAC_LIM_MAX_CH) return XAAC_FATAL_BAD_ARG;
   if (b->stride < (int64_t)b->frame_len * b->num_channels) return XAAC_FATAL_BAD_ARG;
   if (b->n_streams == 0) return XAAC_OK;
-  if (!b->samples || !b->qshift_adj || !b->state) return XAAC_FATAL_NULL_ARG;
+  if (!b->samples || !b->qshift_adj || !b->state || !b->workspace) return XAAC_FATAL_NULL_ARG;
+  if (b->workspace_bytes < xaac_peak_limiter_workspace_bytes(b->n_streams)) return XAAC_FATAL_BAD_ARG;
   if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
   XaacLimiterParams p = {};
+  p.ws_gain = reinterpret_cast<float *>(((uintptr_t)b->workspace + 255) & ~(uintptr_t)255);
+  p.ws_flag = reinterpret_cast<int32_t *>(p.ws_gain + (size_t)b->n_streams * 1024);
   p.n_streams = b->n_streams; p.frame_len = b->frame_len; p.num_channels = b->num_channels;
   p.samples = b->samples; p.stride = b->stride; p.qshift_adj = b->qshift_adj; p.state = b->state;
   p.pcm16 = b->pcm16; p.status = b->status;
   p.dbg = reinterpret_cast<long long *>(b->status); /* phase timers of -DXL_PROFILE builds (tools/time_limiter.py) */
   if (!hip_ok(xaac_launch_limiter(&p, c->stream))) return XAAC_FATAL_HIP;
-  c->last_grid = b->n_streams; c->last_block = 64; c->last_lds = (XAAC_LIM_MAX_ATTACK + 1024) * 4;
+  c->last_grid = b->n_streams; c->last_block = 64; c->last_lds = 2 * (XAAC_LIM_MAX_ATTACK + 1024) * 4 + 256;
   return XAAC_OK;
 }
 

@@ -39,7 +39,8 @@ def run_gpu(ctx, torch, x, q, states, nch, frame_len, stride=None):
     st = states_to_tensor(states, torch)
     pcm = torch.zeros(n * frame_len * nch, dtype=torch.int16, device="cuda")
     status = torch.full((n,), 77, dtype=torch.int32, device="cuda")
-    ctx.peak_limiter_process_batch(xs, qs, st, nch, frame_len=frame_len, pcm16=pcm, stride=stride, status=status)
+    ws = torch.zeros(ctx.peak_limiter_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    ctx.peak_limiter_process_batch(xs, qs, st, nch, ws, frame_len=frame_len, pcm16=pcm, stride=stride, status=status)
     ctx.sync()
     return xs.cpu().numpy(), pcm.cpu().numpy(), tensor_to_states(st, n), status.cpu().numpy()
 
@@ -158,6 +159,7 @@ def test_imdct_to_limiter_chain(ctx, oracle):
     for i in range(n_streams):
         init(ctypes.byref(so[i]), nch, 48000)
     st_g = states_to_tensor(so, torch)
+    ws = torch.zeros(ctx.peak_limiter_workspace_bytes(n_streams), dtype=torch.uint8, device="cuda")
     ovl_o = np.zeros((n, 512), np.int32)
     state_o = np.zeros((n, 2), np.uint8)
     ovl_g = torch.zeros(n, 512, dtype=torch.int32, device="cuda")
@@ -176,7 +178,7 @@ def test_imdct_to_limiter_chain(ctx, oracle):
         pcm = torch.zeros(n * 1024, dtype=torch.int16, device="cuda")
         ctx.imdct_process_batch(torch.from_numpy(spec).cuda(), torch.from_numpy(ics).cuda(), ovl_g, state_g, out32=out32,
                                 qshift_adj=qadj, ch_fac=nch)
-        ctx.peak_limiter_process_batch(out32, qadj, st_g, nch, pcm16=pcm)
+        ctx.peak_limiter_process_batch(out32, qadj, st_g, nch, ws, pcm16=pcm)
         ctx.sync()
         assert np.array_equal(out32.cpu().numpy(), x), frame
         assert np.array_equal(pcm.cpu().numpy(), po), frame

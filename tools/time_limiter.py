@@ -38,6 +38,7 @@ def main():
     raw = np.frombuffer(bytes(st0), np.uint8)
     q = torch.full((n * nch,), 2, dtype=torch.int8, device=dev)
     pcm = torch.zeros(n * 1024 * nch, dtype=torch.int16, device=dev)
+    ws = torch.zeros(ctx.peak_limiter_workspace_bytes(n), dtype=torch.uint8, device=dev)
     g = torch.Generator(device=dev)
     g.manual_seed(1)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -51,7 +52,7 @@ def main():
             x = (torch.randn(n * 1024 * nch, device=dev, generator=g) * std).clamp(-2.0 ** 31, 2.0 ** 31 - 256).to(torch.int32)
             torch.cuda.synchronize()
             ev[0].record(stream)
-            ctx.peak_limiter_process_batch(x, q, state, nch, pcm16=pcm, status=status)
+            ctx.peak_limiter_process_batch(x, q, state, nch, ws, pcm16=pcm, status=status)
             ev[1].record(stream)
             torch.cuda.synchronize()
             ts.append(ev[0].elapsed_time(ev[1]) * 1e3)
