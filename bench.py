@@ -52,7 +52,13 @@ def measured_traffic():
         return None
 
 
-def make_inputs(torch, device, sets, seed):
+# ---- workload C2L: C2 + the AAC-LC post stage (peak limiter + PCM16), SURVEY.md §8 row f2 ---------------------
+# per stereo frame: IMDCT R spec + ovl, W out32 + ovl; limiter R out32 + delay line + window, W out32 + PCM16 + both
+C2L_ALG_BYTES_PER_FRAME = (8192 + 4096) + (8192 + 4096) + (8192 + 1920 + 960) + (8192 + 4096 + 1920 + 960)
+C2L_LOUD_EVERY = 4              # every 4th stream is a hot master: its spectra decode to peaks above full scale
+
+
+def make_inputs(torch, device, sets, seed, limiter=False):
     """`sets` batches of 16384 channel-frames, generated on the device."""
     g = torch.Generator(device=device)
     g.manual_seed(0xC0FFEE + seed)
@@ -60,6 +66,9 @@ def make_inputs(torch, device, sets, seed):
     batches = []
     for s in range(sets):
         spec = torch.randint(-(1 << 17), 1 << 17, (n, 1024), generator=g, device=device, dtype=torch.int32)
+        if limiter:   # x16 on the hot streams: ~12 % of their samples leave the IMDCT above 2^31 (tools/amp_probe.py)
+            hot = (torch.arange(n, device=device) // CH) % C2L_LOUD_EVERY == C2L_LOUD_EVERY - 1
+            spec[hot] *= 16
         spec[:, 640:] = 0
         ics = torch.zeros((n, 2), dtype=torch.uint8, device=device)
         batches.append({
@@ -68,6 +77,14 @@ def make_inputs(torch, device, sets, seed):
             "state": torch.zeros((n, 2), dtype=torch.uint8, device=device),
             "pcm": torch.zeros(n * 1024, dtype=torch.int16, device=device),
         })
+        if limiter:
+            import libxaac_amd
+            st0, _ = libxaac_amd.peak_limiter_init(CH, 48000)
+            raw = np.frombuffer(bytes(st0), np.uint8)
+            batches[-1].update({
+                "out32": torch.zeros(n * 1024, dtype=torch.int32, device=device),
+                "qshift": torch.zeros(n, dtype=torch.int8, device=device),
+                "lim_state": torch.from_numpy(np.tile(raw, (FRAMES_PER_STEP, 1))).to(device)})
     return batches
 
 
@@ -213,9 +230,10 @@ def cpu_baseline_sbr(workload, seconds_budget=10.0):
                       "frames, %d passes; SBR chain only, the core IMDCT is not in it" % (per_thread, passes)}
 
 
-def cpu_baseline(seconds_budget=12.0):
+def cpu_baseline(seconds_budget=12.0, limiter=False):
     """Time the CPU path on a bounded sample of the same workload (all host cores,
-    one contiguous shard of channel-frames per thread)."""
+    one contiguous shard of channel-frames per thread).  limiter: each thread also runs the reference's
+    ixheaacd_peak_limiter_process + round16 over its shard's frames (workload C2L)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     P32, P16, PU8 = oracle_lib.P32, oracle_lib.P16, oracle_lib.PU8
@@ -234,6 +252,18 @@ def cpu_baseline(seconds_budget=12.0):
     pcm = np.zeros((n, 1024), np.int16)
     spec = spec0.copy()
 
+    if limiter:   # the limiter's cost does not depend on the signal (it is a per-sample loop either way)
+        import limiter_cases as lc
+        import libxaac_amd
+        lim_batch = lc.bind(ref.lib if kind == "reference" else orc.lib, "ref" if kind == "reference" else "xo")[2]
+        lim_state = (lc.LimiterState * (n // CH))()
+        st0, _ = libxaac_amd.peak_limiter_init(CH, 48000)
+        for i in range(n // CH):
+            ctypes.memmove(ctypes.byref(lim_state[i]), ctypes.byref(st0), ctypes.sizeof(st0))
+        lim_x = (rng.standard_normal(n * 1024) * 2.0 ** 27.5).clip(-2.0 ** 31, 2.0 ** 31 - 256).astype(np.int32)
+        lim_q = np.full(n, 2, np.int8)
+        lim_pcm = np.zeros(n * 1024, np.int16)
+
     def shard(t):
         a, b = t * per_thread, (t + 1) * per_thread
         p = oracle_lib._p
@@ -244,6 +274,10 @@ def cpu_baseline(seconds_budget=12.0):
             orc.lib.xo_imdct_batch(per_thread, p(spec[a:b], P32), p(ovl[a:b], P32), p(pseq[a:b], P16),
                                    p(pshape[a:b], P16), p(seq[a:b], PU8), p(shape[a:b], PU8), None,
                                    p(pcm[a:b], P16), None, 0)
+        if limiter:
+            lim_batch(per_thread // CH, 1024, CH, p(lim_x[a * 1024:b * 1024], P32), 1024 * CH, p(lim_q[a:b], oracle_lib.P8),
+                      ctypes.cast(ctypes.byref(lim_state, (a // CH) * ctypes.sizeof(lc.LimiterState)),
+                                  ctypes.POINTER(lc.LimiterState)), p(lim_pcm[a * 1024:b * 1024], P16))
 
     if kind == "reference":
         ref.lib.ref_imdct_batch.restype = None
@@ -270,7 +304,8 @@ def cpu_baseline(seconds_budget=12.0):
     return {"value": round(frames / best, 1), "unit": "frames/s", "cores": cores, "kind": kind,
             "value_1core": round(per_thread / CH / t1, 1),
             "sample": "%d stereo frames (%d channel-frames) per pass, %d passes, one %d-channel-frame shard per "
-                      "thread, same synthetic C2 input" % (frames, n, passes, per_thread)}
+                      "thread, same synthetic C2 input%s" % (frames, n, passes, per_thread,
+                                                             " + limiter/round16 per frame" if limiter else "")}
 
 
 def main():
@@ -280,9 +315,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--sets", type=int, default=4, help="independent 8192-stream batches cycled per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
-                    help="c2: AAC-LC IMDCT+OLA (BASELINE configs[1], default); c3: HE-AACv1 stereo, IMDCT + LP-SBR; "
-                         "c4: HE-AACv2, mono IMDCT + HQ-SBR + parametric stereo")
+    ap.add_argument("--workload", choices=["c2", "c2l", "c3", "c4"], default="c2",
+                    help="c2: AAC-LC IMDCT+OLA (BASELINE configs[1], default); c2l: c2 + peak limiter + PCM16 (the "
+                         "AAC-LC post stage); c3: HE-AACv1 stereo, IMDCT + LP-SBR; c4: HE-AACv2, mono IMDCT + HQ-SBR + "
+                         "parametric stereo")
     args = ap.parse_args()
 
     import torch
@@ -299,9 +335,9 @@ def main():
     stream = torch.cuda.Stream(device=dev)      # kernels AND timing events go on this one stream
     torch.cuda.set_stream(stream)
     ctx = libxaac_amd.XaacContext(local_rank, stream.cuda_stream)
-    c3, c4 = args.workload == "c3", args.workload == "c4"
+    c3, c4, c2l = args.workload == "c3", args.workload == "c4", args.workload == "c2l"
     batches = (make_inputs_c3(torch, dev, args.sets, rank) if c3 else make_inputs_c4(torch, dev, args.sets, rank) if c4
-               else make_inputs(torch, dev, args.sets, rank))
+               else make_inputs(torch, dev, args.sets, rank, limiter=c2l))
     for b in batches:                 # window shape alternates per frame; state follows
         b["ics"][:, 1] = (torch.arange(b["ics"].shape[0], device=dev) // (1 if c4 else CH) % 2).to(torch.uint8)
     ws = None
@@ -309,6 +345,8 @@ def main():
         ws = torch.zeros(ctx.sbr_lp_workspace_bytes(FRAMES_PER_STEP * CH), dtype=torch.uint8, device=dev)
     if c4:
         ws = torch.zeros(ctx.sbr_hq_workspace_bytes(FRAMES_PER_STEP, True), dtype=torch.uint8, device=dev)
+    if c2l:
+        ws = torch.zeros(ctx.peak_limiter_workspace_bytes(FRAMES_PER_STEP), dtype=torch.uint8, device=dev)
 
     def step(i, ev=None):
         b = batches[i % len(batches)]
@@ -326,6 +364,11 @@ def main():
                                     ch_fac=1, pcm_mode=libxaac_amd.PCM_SBR)
             fr, pfr = b["frames"][(i // len(batches)) % len(b["frames"])]
             ctx.sbr_hq_process_batch(b["core_pcm"], b["hdr"], fr, b["sbr_state"], b["pcm"], ws, pfr, b["ps_state"])
+        elif c2l:
+            # AAC-LC tail as api.c runs it: interleaved WORD32 block + qshift_adj -> limiter in place -> PCM16
+            ctx.imdct_process_batch(b["spec"], b["ics"], b["overlap"], b["state"], b["out32"], None, b["qshift"],
+                                    ch_fac=CH)
+            ctx.peak_limiter_process_batch(b["out32"], b["qshift"], b["lim_state"], CH, ws, pcm16=b["pcm"])
         else:
             ctx.imdct_process_batch(b["spec"], b["ics"], b["overlap"], b["state"], None, b["pcm"], None,
                                     ch_fac=CH, pcm_mode=libxaac_amd.PCM_LC)
@@ -356,7 +399,12 @@ def main():
         checked = "see tests/test_sbr_gpu.py (bit-exact vs reference records and oracle chains)"
     if rank == 0 and c4:
         checked = "see tests/test_sbr_hq_gpu.py (bit-exact vs reference records and oracle chains)"
-    if rank == 0 and not (c3 or c4):
+    if rank == 0 and c2l:
+        st = batches[0]["lim_state"].cpu().numpy()
+        mg = np.ascontiguousarray(st[:, 24:28]).view(np.float32).reshape(-1)
+        checked = ("see tests/test_limiter_gpu.py (bit-exact vs reference vectors and oracle chains); streams limiting "
+                   "in the last frame: %.1f %%" % (100.0 * float((mg < 1.0).mean())))
+    if rank == 0 and not (c3 or c4 or c2l):
         try:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib
@@ -374,16 +422,19 @@ def main():
 
     if rank == 0:
         frames = FRAMES_PER_STEP * args.steps * world
-        alg_bytes = (C3_ALG_BYTES_PER_CH * CH if c3 else C4_ALG_BYTES_PER_STREAM if c4 else ALG_BYTES_PER_FRAME) * FRAMES_PER_STEP
+        alg_bytes = (C3_ALG_BYTES_PER_CH * CH if c3 else C4_ALG_BYTES_PER_STREAM if c4 else
+                     C2L_ALG_BYTES_PER_FRAME if c2l else ALG_BYTES_PER_FRAME) * FRAMES_PER_STEP
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": ("decoded audio frames/s (1024-spl IMDCT + 32/64-band QMF + low-power SBR, HE-AACv1 stereo)" if c3
                        else "decoded audio frames/s (1024-spl IMDCT + complex QMF + HQ SBR + parametric stereo, "
                             "HE-AACv2)" if c4
-                       else "decoded audio frames/s (1024-spl IMDCT+overlap-add, AAC-LC stereo)"),
+                       else "decoded audio frames/s (1024-spl IMDCT+overlap-add + peak limiter + PCM16, AAC-LC stereo)"
+                       if c2l else "decoded audio frames/s (1024-spl IMDCT+overlap-add, AAC-LC stereo)"),
             "value": round(frames / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32 (+ f32/f64 gain smoothing)" if c2l else "int32",
             "data": "synthetic",
             "config": {"workload": ("C3: HE-AACv1 48 kHz stereo, batch=8192 frames/step: IMDCT+OLA -> QMF-32 analysis -> "
                                     "LPP HF generation + envelope adjustment (side info cycled from reference-captured "
@@ -392,6 +443,10 @@ def main():
                                     "-> complex QMF-32 analysis -> LPP transposer + envelope adjustment -> parametric "
                                     "stereo -> two complex QMF-64 synthesis banks (SBR / PS side info cycled from "
                                     "reference-captured frames), %d stream sets cycled" % args.sets) if c4 else
+                                   ("C2L: C2 + the AAC-LC post stage, batch=8192 frames/step: IMDCT + window/overlap-add "
+                                    "(WORD32 block + qshift_adj) -> peak limiter in place (5 ms look-ahead, attack / "
+                                    "release smoothing) -> PCM16; every %dth stream decodes above full scale, %d stream "
+                                    "sets cycled" % (C2L_LOUD_EVERY, args.sets)) if c2l else
                                    ("C2: AAC-LC 48 kHz stereo, batch=8192 frames/step (16384 channel-frames), "
                                     "ONLY_LONG 1024-pt IMDCT + window/overlap-add + PCM16, %d stream sets cycled"
                                     % args.sets),
@@ -399,16 +454,17 @@ def main():
                        "sharding": "streams split across ranks, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None if (c3 or c4) else (measured_traffic() or {}).get("bytes_per_launch"),
-                         "traffic_source": None if (c3 or c4) else (measured_traffic() or {}).get("source"),
+                         "traffic": None if (c3 or c4 or c2l) else (measured_traffic() or {}).get("bytes_per_launch"),
+                         "traffic_source": None if (c3 or c4 or c2l) else (measured_traffic() or {}).get("source"),
                          "kernel": "imdct_ola + qmf_analysis + sbr_core_lp + qmf_synthesis (4 launches)" if c3
                                    else "imdct_ola + qmf_analysis + sbr_core_hq + ps + 2 x qmf_synthesis (6 launches)" if c4
+                                   else "imdct_ola + limiter_front + limiter_gain + limiter_apply (4 launches)" if c2l
                                    else "xaac_imdct_ola_kernel", "kernel_ms": round(kern_ms, 5),
                          "alg_bytes_per_launch": alg_bytes},
             "bit_exact_vs_oracle": checked,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_sbr(args.workload) if (c3 or c4) else cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline_sbr(args.workload) if (c3 or c4) else cpu_baseline(limiter=c2l)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
