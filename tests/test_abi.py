@@ -50,3 +50,23 @@ def test_no_cpu_fallback_without_device():
     with pytest.raises(libxaac_amd.XaacError) as e:
         libxaac_amd.XaacContext(0)
     assert e.value.code == 0xFFFF8002
+
+
+def test_limiter_structs_match_header(tmp_path):
+    """the ctypes mirrors of the limiter boundary against what a C compiler makes of include/xaac_amd.h"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "xaac_amd.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(xaac_limiter_state), '
+                   'offsetof(xaac_limiter_state, pre_smoothed_gain), offsetof(xaac_limiter_state, max_buf), '
+                   'offsetof(xaac_limiter_state, delayed_input), sizeof(xaac_limiter_batch), '
+                   'offsetof(xaac_limiter_batch, stride), offsetof(xaac_limiter_batch, pcm16), '
+                   'offsetof(xaac_limiter_batch, workspace_bytes)); return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    S, B = libxaac_amd.LimiterState, libxaac_amd._LimiterBatch
+    assert got == [ctypes.sizeof(S), S.pre_smoothed_gain.offset, S.max_buf.offset, S.delayed_input.offset,
+                   ctypes.sizeof(B), B.stride.offset, B.pcm16.offset, B.workspace_bytes.offset]
+    assert libxaac_amd.LIMITER_STATE_BYTES == got[0]
