@@ -16,6 +16,7 @@
 #include "ixheaacd_block.h"
 #include "ixheaacd_aac_imdct.h"
 #include "ixheaacd_audioobjtypes.h"
+#include "ixheaacd_peak_limiter_struct_def.h"
 #include "xaac_amd.h"
 
 static xaac_ctx *g_ctx;
@@ -34,7 +35,7 @@ static struct {
   void *ws;
   uint64_t ws_bytes;
 } g;
-static long g_imdct_calls, g_sbr_calls;
+static long g_imdct_calls, g_sbr_calls, g_lim_calls;
 
 static void die(const char *what) {
   fprintf(stderr, "xaacdec_dropin: %s failed\n", what);
@@ -44,6 +45,7 @@ static void die(const char *what) {
 
 static void report(void) {
   fprintf(stderr, "xaacdec_dropin: %ld imdct_process and %ld sbr_dec calls ran on the GPU\n", g_imdct_calls, g_sbr_calls);
+  fprintf(stderr, "xaacdec_dropin: %ld peak_limiter_process calls ran on the GPU\n", g_lim_calls);
 }
 
 static void setup(void) {
@@ -212,4 +214,55 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
   }
   g_sbr_calls++;
   return 0;
+}
+
+/* ---- seam 3: ixheaacd_peak_limiter_process (AAC-LC post stage, decoder/ixheaacd_api.c:3667) ----------- */
+void ref_limiter_to_ref(ia_peak_limiter_struct *r, const xaac_limiter_state *s);
+void ref_limiter_from_ref(xaac_limiter_state *s, const ia_peak_limiter_struct *r);
+VOID __real_ixheaacd_peak_limiter_process(ia_peak_limiter_struct *, VOID *, UWORD32, UWORD8 *);
+
+VOID __wrap_ixheaacd_peak_limiter_process(ia_peak_limiter_struct *lim, VOID *samples, UWORD32 frame_len,
+                                          UWORD8 *qshift_adj) {
+  static xaac_limiter_state st;
+  static struct { int32_t *x; int8_t *q; xaac_limiter_state *st; void *ws; uint64_t ws_bytes; } d;
+  const UWORD32 nch = lim->num_channels;
+  xaac_limiter_batch b;
+  if (nch < 1 || nch > XAAC_LIM_MAX_CH || lim->attack_time_samples < 1 || lim->attack_time_samples > XAAC_LIM_MAX_ATTACK ||
+      frame_len < 1 || frame_len > 1024) { /* outside the boundary struct: stays on the CPU */
+    __real_ixheaacd_peak_limiter_process(lim, samples, frame_len, qshift_adj);
+    return;
+  }
+  setup();
+  if (!d.x) {
+    HIP(hipMalloc((void **)&d.x, 1024 * XAAC_LIM_MAX_CH * 4));
+    HIP(hipMalloc((void **)&d.q, 16));
+    HIP(hipMalloc((void **)&d.st, sizeof(xaac_limiter_state)));
+    d.ws_bytes = xaac_peak_limiter_workspace_bytes(1);
+    HIP(hipMalloc(&d.ws, d.ws_bytes));
+  }
+  memset(&st, 0, sizeof(st));
+  ref_limiter_from_ref(&st, lim);
+  HIP(hipMemcpy(d.x, samples, (size_t)frame_len * nch * 4, hipMemcpyHostToDevice));
+  HIP(hipMemcpy(d.q, qshift_adj, nch, hipMemcpyHostToDevice));
+  HIP(hipMemcpy(d.st, &st, sizeof(st), hipMemcpyHostToDevice));
+  memset(&b, 0, sizeof(b));
+  b.n_streams = 1; b.frame_len = (int32_t)frame_len; b.num_channels = (int32_t)nch;
+  b.samples = d.x; b.stride = (int64_t)frame_len * nch; b.qshift_adj = d.q; b.state = d.st;
+  b.workspace = d.ws; b.workspace_bytes = d.ws_bytes;
+  if (xaac_peak_limiter_process_batch(g_ctx, &b) != XAAC_OK || xaac_sync(g_ctx) != XAAC_OK) die("xaac_peak_limiter_process_batch");
+  HIP(hipMemcpy(samples, d.x, (size_t)frame_len * nch * 4, hipMemcpyDeviceToHost));
+  HIP(hipMemcpy(&st, d.st, sizeof(st), hipMemcpyDeviceToHost));
+  { /* the reference keeps its buffer pointers; only the contents come back */
+    FLOAT32 *max_buf = lim->max_buf, *delayed = lim->delayed_input;
+    const UWORD32 a = lim->attack_time_samples;
+    lim->gain_modified = st.gain_modified;
+    lim->pre_smoothed_gain = st.pre_smoothed_gain;
+    lim->delayed_input_index = st.delayed_input_index;
+    lim->min_gain = st.min_gain;
+    lim->max_idx = st.max_idx;
+    lim->cir_buf_pnt = st.cir_buf_pnt;
+    memcpy(max_buf, st.max_buf, a * sizeof(FLOAT32));
+    memcpy(delayed, st.delayed_input, (size_t)a * nch * sizeof(FLOAT32));
+  }
+  g_lim_calls++;
 }

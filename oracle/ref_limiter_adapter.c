@@ -20,7 +20,8 @@ WORD32 ixheaacd_peak_limiter_init(ia_peak_limiter_struct *peak_limiter, UWORD32 
 VOID ixheaacd_peak_limiter_process(ia_peak_limiter_struct *peak_limiter, VOID *samples, UWORD32 frame_len,
                                    UWORD8 *qshift_adj);
 
-static void to_ref(ia_peak_limiter_struct *r, const xaac_limiter_state *s) {
+/* boundary state -> the reference's struct (also used by oracle/ref_dropin.c) */
+void ref_limiter_to_ref(ia_peak_limiter_struct *r, const xaac_limiter_state *s) {
   const UWORD32 a = s->attack_time_samples, c = s->num_channels;
   memset(r, 0, sizeof(*r));
   r->max_buf = r->buffer;
@@ -42,7 +43,7 @@ static void to_ref(ia_peak_limiter_struct *r, const xaac_limiter_state *s) {
   memcpy(r->delayed_input, s->delayed_input, a * c * sizeof(FLOAT32));
 }
 
-static void from_ref(xaac_limiter_state *s, const ia_peak_limiter_struct *r) {
+void ref_limiter_from_ref(xaac_limiter_state *s, const ia_peak_limiter_struct *r) {
   const UWORD32 a = r->attack_time_samples, c = r->num_channels;
   s->attack_constant = r->attack_constant;
   s->release_constant = r->release_constant;
@@ -68,14 +69,14 @@ int32_t ref_peak_limiter_init(xaac_limiter_state *s, uint32_t num_channels, uint
   memset(s, 0, sizeof(*s));
   ixheaacd_peak_limiter_init(&r, num_channels, sample_rate, r.buffer, &delay);
   if (delay < 1 || delay > XAAC_LIM_MAX_ATTACK || num_channels > XAAC_LIM_MAX_CH) return -1;
-  from_ref(s, &r);
+  ref_limiter_from_ref(s, &r);
   return (int32_t)delay;
 }
 
 void ref_peak_limiter_process(xaac_limiter_state *s, int32_t *samples, uint32_t frame_len, const int8_t *qshift_adj) {
-  to_ref(&g_lim, s);
+  ref_limiter_to_ref(&g_lim, s);
   ixheaacd_peak_limiter_process(&g_lim, samples, frame_len, (UWORD8 *)qshift_adj);
-  from_ref(s, &g_lim);
+  ref_limiter_from_ref(s, &g_lim);
 }
 
 /* same shape as xo_peak_limiter_batch / the C ABI: limiter + the round16 loop of api.c:3676-3681 */
@@ -84,9 +85,9 @@ void ref_peak_limiter_batch(int32_t n_streams, int32_t frame_len, int32_t num_ch
   ia_peak_limiter_struct r;
   for (int32_t s = 0; s < n_streams; s++) {
     int32_t *x = samples + (int64_t)s * stride;
-    to_ref(&r, state + s);
+    ref_limiter_to_ref(&r, state + s);
     ixheaacd_peak_limiter_process(&r, x, (UWORD32)frame_len, (UWORD8 *)(qshift_adj + (int64_t)s * num_channels));
-    from_ref(state + s, &r);
+    ref_limiter_from_ref(state + s, &r);
     if (pcm16)
       for (int32_t i = 0; i < frame_len * num_channels; i++)
         pcm16[(int64_t)s * frame_len * num_channels + i] = ixheaac_round16(x[i]);

@@ -1,5 +1,5 @@
-"""The drop-in, end to end: the REAL reference decoder decodes whole .aac streams with its two frame-level seams
-(ixheaacd_imdct_process, ixheaacd_sbr_dec) diverted to libxaac_amd on the GPU (oracle/_ref/xaacdec_dropin, built
+"""The drop-in, end to end: the REAL reference decoder decodes whole .aac streams with its frame-level seams
+(ixheaacd_imdct_process, ixheaacd_sbr_dec, ixheaacd_peak_limiter_process) diverted to libxaac_amd on the GPU (oracle/_ref/xaacdec_dropin, built
 from oracle/ref_dropin.c by oracle/Makefile.ref); the output file must be byte-identical to what the unmodified
 reference decoder (oracle/_ref/xaacdec) writes.  Needs the prebuilt oracle/_ref binaries next to the repo."""
 import glob
@@ -34,6 +34,9 @@ def test_reference_decoder_with_gpu_back_end_is_byte_identical(aac, tmp_path):
     assert n_imdct > 30
     if "aot2_" not in aac:
         assert n_sbr > 30
+    else:   # plain AAC-LC with default flags: the peak limiter is on (api.c:3663-3669) and ran on the GPU too
+        m = re.search(r"(\d+) peak_limiter_process calls ran on the GPU", log)
+        assert m and int(m.group(1)) > 30, log[-400:]
     a, b = open(ref_wav, "rb").read(), open(gpu_wav, "rb").read()
     assert len(a) > 100000 and a == b, (len(a), len(b), n_imdct, n_sbr)
 
