@@ -124,6 +124,24 @@ __device__ __forceinline__ int32_t wave_or(int32_t v) {
   return v;
 }
 
+/* maximum of a non-negative value over the wave, in the VALU's data-parallel-primitive lanes (no LDS round
+   trips): butterfly inside each row of 16, then the row results ripple up; lane 63 holds the total */
+__device__ __forceinline__ int32_t wave_max_nonneg(int32_t v) {
+#define XAAC_DPP_MAX(ctrl, rows)                                                   \
+  {                                                                                \
+    const int32_t t_ = __builtin_amdgcn_update_dpp(v, v, ctrl, rows, 0xf, false);  \
+    v = t_ > v ? t_ : v;                                                           \
+  }
+  XAAC_DPP_MAX(0xB1, 0xf)  /* quad_perm [1,0,3,2] */
+  XAAC_DPP_MAX(0x4E, 0xf)  /* quad_perm [2,3,0,1] */
+  XAAC_DPP_MAX(0x141, 0xf) /* row_half_mirror */
+  XAAC_DPP_MAX(0x140, 0xf) /* row_mirror */
+  XAAC_DPP_MAX(0x142, 0xa) /* row_bcast15 into rows 1, 3 */
+  XAAC_DPP_MAX(0x143, 0xc) /* row_bcast31 into rows 2, 3 */
+#undef XAAC_DPP_MAX
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 /* 16-bit multiplier from an LDS / register window value */
 __device__ __forceinline__ int32_t mul16(int32_t a, int16_t w) { return fx_mul32x16(a, w); }
 __device__ __forceinline__ int32_t nosh(int32_t a, int16_t w) {
@@ -193,10 +211,15 @@ __device__ __forceinline__ void long_transform(int32_t *buf, int lane, int e, co
   for (int k = 0; k < 8; k++) {
     int c = lane + 64 * k;
     int32_t a = buf[c], b = buf[512 + 511 - c];
-    int32_t re = fx_add(fx_mulhi(a, wc.rx[64 * k + lane]), fx_mulhi(b, wc.ry[64 * k + lane]));
-    int32_t im = fx_sub(fx_mulhi(b, wc.rx[64 * k + lane]), fx_mulhi(a, wc.ry[64 * k + lane]));
-    x[k].re = scale_by_expo(re, sl, sr);
-    x[k].im = scale_by_expo(im, sl, sr);
+    x[k].re = fx_add(fx_mulhi(a, wc.rx[64 * k + lane]), fx_mulhi(b, wc.ry[64 * k + lane]));
+    x[k].im = fx_sub(fx_mulhi(b, wc.rx[64 * k + lane]), fx_mulhi(a, wc.ry[64 * k + lane]));
+  }
+  if (e < 0) { /* one of the two shift counts is 0 (the exponent is per frame: a scalar branch) */
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = {fx_shlw(x[k].re, sl), fx_shlw(x[k].im, sl)};
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = {x[k].re >> sr, x[k].im >> sr};
   }
   bfly8(x, y);
   {
@@ -451,7 +474,9 @@ __device__ __noinline__ void eight_short_path(lds_i32 *buf, const lds_i32 *ovs, 
 /* ========================================================================= */
 /* hot-path OLA (aac_imdct.c:506) for one group of four t's.  QPOS = (q_shift > 0)
    selects the reference's two branches at compile time. */
-template <bool QPOS>
+/* FAST: the wave has checked that no windowed value saturates in the left shift and that every old-overlap word
+   is within +-65535 (so overlap x window fits 32 bits: one v_mul_i32_i24 instead of a clamped 64-bit product) */
+template <bool QPOS, bool FAST>
 __device__ __forceinline__ void ola_long_long4(const int32_t *y, const int16_t *wl, int t0, const int4 &old4, int q,
                                                int32_t (&lo)[4], int32_t (&hi)[4], int4 &new4) {
   const int4 vv = *reinterpret_cast<const int4 *>(y + 1020 - t0);       /* y[1023-t], j = 3..0 */
@@ -465,18 +490,23 @@ __device__ __forceinline__ void ola_long_long4(const int32_t *y, const int16_t *
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     int32_t a = fx_mul32xlo(vj[j], wj[j]);
-    int32_t b = fx_mul32xhi(fx_neg_sat(vj[j]), wj[j]);
+    int32_t b = fx_mul32xhi(FAST ? fx_neg(vj[j]) : fx_neg_sat(vj[j]), wj[j]); /* FAST: |y| is far from MIN */
     int32_t o = oj[j];
     if (QPOS) {
-      a = fx_shl_sat(a, q);
-      b = fx_shl_sat(b, q);
+      a = FAST ? fx_shlw(a, q) : fx_shl_sat(a, q);
+      b = FAST ? fx_shlw(b, q) : fx_shl_sat(b, q);
     } else {
       a = fx_shr(a, -q);
       b = fx_shr(b, -q);
       o = (int16_t)o; /* aac_imdct.c:679: this branch reads the overlap word as WORD16 */
     }
-    lo[j] = fx_sub_sat(a, nosh(o, (int16_t)(wj[j] >> 16))); /* out[511-t] */
-    hi[j] = fx_sub_sat(b, nosh(o, (int16_t)wj[j]));         /* out[512+t] */
+    if (FAST || !QPOS) {
+      lo[j] = fx_sub_sat(a, __mul24(o, (int16_t)(wj[j] >> 16))); /* out[511-t] */
+      hi[j] = fx_sub_sat(b, __mul24(o, (int16_t)wj[j]));         /* out[512+t] */
+    } else {
+      lo[j] = fx_sub_sat(a, nosh(o, (int16_t)(wj[j] >> 16)));
+      hi[j] = fx_sub_sat(b, nosh(o, (int16_t)wj[j]));
+    }
     nv[j] = to_ovl(uj[j], q);
   }
   new4 = make_int4(nv[0], nv[1], nv[2], nv[3]);
@@ -538,12 +568,15 @@ __global__ __launch_bounds__(XAAC_IMDCT_BLOCK, XAAC_IMDCT_MIN_WAVES_PER_SIMD) vo
       const int seq = ics_bits & 0xff, shape = ics_bits >> 8;
       const int pseq = st_bits & 0xff, pshape = st_bits >> 8;
 
-      /* block exponent: OR of abs_nrm over the frame (aac_tns.c:422) */
-      int32_t acc = 0;
+      /* block exponent: norm32 of the OR of abs_nrm over the frame (aac_tns.c:422).  Only the OR's top bit
+         matters, and that is the top bit of max abs_nrm(x) = max(max x, ~min x) */
+      int32_t mx = v[0].x, mn = v[0].x;
 #pragma unroll
-      for (int r = 0; r < 4; r++)
-        acc |= fx_abs_nrm(v[r].x) | fx_abs_nrm(v[r].y) | fx_abs_nrm(v[r].z) | fx_abs_nrm(v[r].w);
-      const int headroom = __builtin_amdgcn_readfirstlane(fx_norm32(wave_or(acc)));
+      for (int r = 0; r < 4; r++) {
+        mx = max(max(mx, v[r].x), max(v[r].y, max(v[r].z, v[r].w)));
+        mn = min(min(mn, v[r].x), min(v[r].y, min(v[r].z, v[r].w)));
+      }
+      const int headroom = fx_norm32(wave_max_nonneg(max(mx, ~mn)));
 
       stage_spec(buf, v, lane);
       /* old overlap: issued now, consumed after the transform (its latency hides under the FFT) */
@@ -582,10 +615,22 @@ __global__ __launch_bounds__(XAAC_IMDCT_BLOCK, XAAC_IMDCT_MIN_WAVES_PER_SIMD) vo
             const int t0 = 256 * g + 4 * lane;
             int32_t lo[4], hi[4];
             int4 nv;
-            if (q > 0)
-              ola_long_long4<true>(y, wl, t0, o4[g], q, lo, hi, nv);
-            else
-              ola_long_long4<false>(y, wl, t0, o4[g], q, lo, hi, nv);
+            if (q > 0) {
+              /* |y * w >> 16| <= |y| / 2 + 1: with the block's largest |y[512..1023]| the shift cannot saturate when
+                 (max >> 1) + 1 <= MAX >> q; the old overlap must fit +-65535 for the 24-bit product */
+              const int4 vv = *reinterpret_cast<const int4 *>(y + 1020 - t0);
+              const int32_t ymx = max(max(vv.x, vv.y), max(vv.z, vv.w)), ymn = min(min(vv.x, vv.y), min(vv.z, vv.w));
+              const int32_t omx = max(max(o4[g].x, o4[g].y), max(o4[g].z, o4[g].w));
+              const int32_t omn = min(min(o4[g].x, o4[g].y), min(o4[g].z, o4[g].w));
+              const int32_t ylim = ((FX_MAX32 >> q) - 1) << 1;
+              const bool slow = ymx > ylim || ymn < -ylim || omx > 65535 || omn < -65535;
+              if (!__ballot(slow))
+                ola_long_long4<true, true>(y, wl, t0, o4[g], q, lo, hi, nv);
+              else
+                ola_long_long4<true, false>(y, wl, t0, o4[g], q, lo, hi, nv);
+            } else {
+              ola_long_long4<false, false>(y, wl, t0, o4[g], q, lo, hi, nv);
+            }
             reinterpret_cast<int4 *>(ovl)[64 * g + lane] = nv;
             if (sk.o32) {
               if (CF == 1) {
