@@ -18,7 +18,7 @@
 #endif
 #define XAAC_IMDCT_LDS_WIN_BYTES 4608            /* 2x1024 + 2x128 int16 windows */
 #define XAAC_IMDCT_LDS_WAVE_WORDS (1024 + 512)   /* exchange tile + old-overlap copy */
-#define XAAC_IMDCT_LDS_CONST_WORDS (1024 + 2 * 448) /* rotation pairs + pass-2/3 twiddles, lane-major */
+#define XAAC_IMDCT_LDS_CONST_WORDS (1024 + 4 * 448) /* rotation pairs + split pass-2/3 twiddles, lane-major */
 #define XAAC_IMDCT_LDS_BYTES \
   (XAAC_IMDCT_LDS_WIN_BYTES + 4 * (XAAC_IMDCT_LDS_CONST_WORDS + XAAC_IMDCT_WAVES * XAAC_IMDCT_LDS_WAVE_WORDS))
 

@@ -167,27 +167,40 @@ struct Sink {
 };
 
 /* ------------------------------------------------------------------------- */
-/* Lane-major constant tiles in LDS (filled once per workgroup): every read is
+/* Lane-major constant tiles in LDS (filled once per workgroup): every read is one 8-byte
    word [k*64 + lane] -> bank-conflict free, and keeps ~30 VGPRs free.
-     rx/ry[k][lane]  rotation pair of bin lane + 64k (n = 1024), pre-shifted << 16
-     tw2[k-1][lane]  pass-2 twiddle of column m = lane & 7 : tw[8*m*k]
-     tw3[k-1][lane]  pass-3 twiddle of column m = lane     : tw[m*k]           */
+     rot[k][lane]    rotation pair (X, Y) of bin lane + 64k (n = 1024), pre-shifted << 16
+     tw2[k-1][lane]  pass-2 twiddle of column m = lane & 7 : tw[8*m*k], split (cos << 16, -sin << 16)
+     tw3[k-1][lane]  pass-3 twiddle of column m = lane     : tw[m*k], split likewise
+   (split = ready for v_mul_hi_i32: nothing is shifted or masked per use) */
 struct ConstTiles {
-  const int32_t *rx, *ry, *tw2, *tw3;
+  const int2 *rot, *tw2, *tw3;
 };
 
+__device__ __forceinline__ int2 split_twiddle(int32_t w) {
+  return make_int2((int32_t)((uint32_t)w << 16), (int32_t)((uint32_t)w & 0xffff0000u));
+}
+
 __device__ __forceinline__ void fill_const_tiles(int32_t *base, int tid, int nthreads) {
+  int2 *b2 = reinterpret_cast<int2 *>(base);
   for (int i = tid; i < 512; i += nthreads) {
     int32_t X, Y;
     rot_pair((i & 63) + 64 * (i >> 6), 512, 1, X, Y);
-    base[i] = X;
-    base[512 + i] = Y;
+    b2[i] = make_int2(X, Y);
   }
   for (int i = tid; i < 448; i += nthreads) {
     int k = (i >> 6) + 1, l = i & 63;
-    base[1024 + i] = xaac_tab_fft_tw[8 * (l & 7) * k];
-    base[1024 + 448 + i] = xaac_tab_fft_tw[l * k];
+    b2[512 + i] = split_twiddle(xaac_tab_fft_tw[8 * (l & 7) * k]);
+    b2[512 + 448 + i] = split_twiddle(xaac_tab_fft_tw[l * k]);
   }
+}
+
+/* twiddle with a pre-split factor */
+__device__ __forceinline__ cpx twiddle2(cpx x, int2 w) {
+  cpx r;
+  r.re = fx_shlw(fx_sub(fx_mulhi(x.re, w.x), fx_mulhi(x.im, w.y)), 1);
+  r.im = fx_shlw(fx_add(fx_mulhi(x.re, w.y), fx_mulhi(x.im, w.x)), 1);
+  return r;
 }
 
 /* spec (16 words per lane, as 4 coalesced int4 rows) -> de-interleaved LDS tile:
@@ -211,8 +224,9 @@ __device__ __forceinline__ void long_transform(int32_t *buf, int lane, int e, co
   for (int k = 0; k < 8; k++) {
     int c = lane + 64 * k;
     int32_t a = buf[c], b = buf[512 + 511 - c];
-    x[k].re = fx_add(fx_mulhi(a, wc.rx[64 * k + lane]), fx_mulhi(b, wc.ry[64 * k + lane]));
-    x[k].im = fx_sub(fx_mulhi(b, wc.rx[64 * k + lane]), fx_mulhi(a, wc.ry[64 * k + lane]));
+    const int2 r = wc.rot[64 * k + lane];
+    x[k].re = fx_add(fx_mulhi(a, r.x), fx_mulhi(b, r.y));
+    x[k].im = fx_sub(fx_mulhi(b, r.x), fx_mulhi(a, r.y));
   }
   if (e < 0) { /* one of the two shift counts is 0 (the exponent is per frame: a scalar branch) */
 #pragma unroll
@@ -235,10 +249,9 @@ __device__ __forceinline__ void long_transform(int32_t *buf, int lane, int e, co
       int2 t = Z[phi(A, k, C)];
       x[k] = {t.x, t.y};
     }
+    if (C != 0) { /* one exec-mask region instead of fourteen selects */
 #pragma unroll
-    for (int k = 1; k < 8; k++) {
-      cpx t = twiddle(x[k], wc.tw2[64 * (k - 1) + lane]);
-      x[k] = (C == 0) ? x[k] : t;
+      for (int k = 1; k < 8; k++) x[k] = twiddle2(x[k], wc.tw2[64 * (k - 1) + lane]);
     }
     bfly8(x, y);
 #pragma unroll
@@ -253,7 +266,7 @@ __device__ __forceinline__ void long_transform(int32_t *buf, int lane, int e, co
       x[k] = {t.x, t.y};
     }
 #pragma unroll
-    for (int k = 1; k < 8; k++) x[k] = twiddle(x[k], wc.tw3[64 * (k - 1) + lane]);
+    for (int k = 1; k < 8; k++) x[k] = twiddle2(x[k], wc.tw3[64 * (k - 1) + lane]);
     bfly8(x, y);
   }
   /* post-rotation of bins 64q + lane (same rotation registers), +-50 cross term */
@@ -261,8 +274,9 @@ __device__ __forceinline__ void long_transform(int32_t *buf, int lane, int e, co
 #pragma unroll
   for (int q = 0; q < 8; q++) {
     int c = lane + 64 * q;
-    int32_t r = fx_add(fx_mulhi(y[q].re, wc.rx[64 * q + lane]), fx_mulhi(y[q].im, wc.ry[64 * q + lane]));
-    int32_t i = fx_sub(fx_mulhi(y[q].re, wc.ry[64 * q + lane]), fx_mulhi(y[q].im, wc.rx[64 * q + lane]));
+    const int2 w = wc.rot[64 * q + lane];
+    int32_t r = fx_add(fx_mulhi(y[q].re, w.x), fx_mulhi(y[q].im, w.y));
+    int32_t i = fx_sub(fx_mulhi(y[q].re, w.y), fx_mulhi(y[q].im, w.x));
     buf[2 * c] = fx_add(r, fx_mulhi(i, kAdjN));
     buf[1023 - 2 * c] = fx_add(i, fx_mulhi(r, kAdjP));
   }
@@ -543,7 +557,8 @@ __global__ __launch_bounds__(XAAC_IMDCT_BLOCK, XAAC_IMDCT_MIN_WAVES_PER_SIMD) vo
     s_win[2176 + i] = xaac_tab_win_short_kbd[i];
   }
   fill_const_tiles(s_const, tid, XAAC_IMDCT_BLOCK);
-  const ConstTiles wc = {s_const, s_const + 512, s_const + 1024, s_const + 1024 + 448};
+  const ConstTiles wc = {reinterpret_cast<const int2 *>(s_const), reinterpret_cast<const int2 *>(s_const) + 512,
+                         reinterpret_cast<const int2 *>(s_const) + 512 + 448};
   __syncthreads();
 
   const int waves_total = gridDim.x * XAAC_IMDCT_WAVES;

@@ -790,10 +790,10 @@ FX_HD int xs_subband_gain_meta(const XsCx &cx, const xaac_sbr_header *h, int max
   XS_LANES(c, 0, n_meta) v.meta.own(c) = mt_s.own(c);
   return n_meta;
 }
-FX_HD void xs_calc_subband_gains(const XsCx &cx, const xaac_sbr_frame *f, const int16_t *noise_floor, int mvalue,
+FX_HD void xs_calc_subband_gains(const XsCx &cx, const int16_t *env_sf_all, const int16_t *noise_floor, int mvalue,
                                  int env, int n_meta, int skip, XsEnv &v, int noise_absc) {
   const XsLv sm1 = v.sine_mapped.shifted(cx, skip);
-  const int16_t *env_sf = &f->int_env_sf_arr[mvalue];
+  const int16_t *env_sf = &env_sf_all[mvalue];
   XS_LANES(c, 0, n_meta) {
     const int meta = v.meta.own(c);
     const int16_t sf = env_sf[meta & 255];
@@ -1601,11 +1601,15 @@ FX_HD void xs_hf_generator_hq(const XsCx &cx, const xaac_sbr_header *h, ST *st, 
 /* env_calc.c:692, AAC-LC/HE-AAC (not ELD), 1024-sample frames, low-power (Q = XsQmf) or HQ (XsQmfHq).
    deg64: aliasing degree per QMF band from the low-power HF generator.  Returns 0 or -1. */
 template <class ST, class Q>
-FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, ST *st, const Q &x,
+/* env_sf_all / noise_floor_all: the frame's int_env_sf_arr and int_noise_floor.  They are handed in beside `f` so that
+   the GPU core keeps only the head of the frame struct in LDS (the 896-byte envelope array is read once per
+   envelope: it stays in global memory there) -- nothing below may reach them through `f`. */
+FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f,
+                              const int16_t *env_sf_all, const int16_t *noise_floor_all, ST *st, const Q &x,
                               XsWork *w, const int16_t *rand_hi, const XsLv &deg64) {
   const int num_env = cx.uni(f->num_env);
   const int16_t *border = f->border_vec;
-  const int16_t *noise_floor = f->int_noise_floor;
+  const int16_t *noise_floor = noise_floor_all;
   const int sb_start = cx.uni(h->sub_band_start), sb_end = cx.uni(h->sub_band_end);
   const int max_sb = cx.uni(f->max_qmf_subband_aac);
   const int nsb = sb_end - sb_start;
@@ -1640,7 +1644,7 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
       int32_t mx = 16 - 16; /* NRG_EXP_OFFSET - SHORT_BITS */
       const int nsf = cx.uni(h->num_sf_bands[f->freq_res[i]]);
       XS_PAR(j, 0, nsf) {
-        int t = f->int_env_sf_arr[base + j] & 63;
+        int t = env_sf_all[base + j] & 63;
         if (t > mx) mx = t;
       }
       base += nsf;
@@ -1678,7 +1682,7 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
     if (cx.uni(tbl[0]) < sb_start) return -1;
     const int n_meta = xs_subband_gain_meta(cx, h, max_sb, tbl, nsf, i, v);
     XS_T(5);
-    xs_calc_subband_gains(cx, f, noise_floor, m, i, n_meta, skip, v, noise_absc);
+    xs_calc_subband_gains(cx, env_sf_all, noise_floor, m, i, n_meta, skip, v, noise_absc);
     m += nsf;
     XS_T(6);
     xs_noiselimiting(cx, h, skip, n_meta, v, w, &xaac_sbr_lim_gains_m[2 * cx.uni(h->limiter_gains)], noise_absc);
@@ -1786,8 +1790,9 @@ FX_HD void xs_rescale_x_overlap(const XsCx &cx, const xaac_sbr_header *h, const 
    new scale factors, LPC history and envelope-adjuster memory.  rand_hi[i] = xaac_sbr_rand_ph[i] >> 16
    (the only part of that table this mode uses; an LDS copy on the GPU).  Returns 0 or -1. */
 template <class ST, class Q>
-FX_HD int xs_sbr_core(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, ST *st, const Q &x, XsWork *w,
-                      const int16_t *rand_hi, int *save_lb_scale_out) {
+FX_HD int xs_sbr_core(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, const int16_t *env_sf_all,
+                      const int16_t *noise_floor_all, ST *st, const Q &x, XsWork *w, const int16_t *rand_hi,
+                      int *save_lb_scale_out) {
   /* the frame grid this implementation (and the reference's MAX_ENV_COLS buffers, sbr_dec.c:733-748) is laid
      out for: 16 time slots of 2 QMF slots; anything else is refused like the reference refuses its own limits */
   if (cx.uni(h->num_time_slots) * cx.uni(h->time_step) != 32 || cx.uni(h->num_columns) != 32) return -1;
@@ -1849,7 +1854,7 @@ FX_HD int xs_sbr_core(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
     XS_T(2);
     XS_ONE st->hb_scale = (int16_t)((st->ov_lb_scale < st->lb_scale ? st->ov_lb_scale : st->lb_scale) - 2);
     cx.sync();
-    if (xs_calc_sbrenvelope(cx, h, f, st, x, w, rand_hi, deg64)) return -1;
+    if (xs_calc_sbrenvelope(cx, h, f, env_sf_all, noise_floor_all, st, x, w, rand_hi, deg64)) return -1;
     XS_PAR(i, 0, h->num_if_bands) st->prev_invf_mode[i] = f->sbr_invf_mode[i];
     XS_ONE {
       st->prev_coupling_mode = f->coupling_mode;

@@ -53,12 +53,20 @@ static_assert(offsetof(XsLdsState, lpc_real) == 8 && sizeof(XsLdsState) == 8 + k
 static_assert(offsetof(xaac_sbr_state, overlap) % 16 == 0 || true, "");
 static_assert(sizeof(xaac_sbr_header) % 4 == 0 && sizeof(xaac_sbr_frame) % 4 == 0, "word copies");
 
+/* of the frame side info only the head lives in LDS: the envelope scale factors (896 B) are read once per envelope
+   and stay in global memory, the noise floor gets its own twenty bytes (sbr_core.h hands both in beside `f`) */
+constexpr int kFrameHeadBytes = offsetof(xaac_sbr_frame, int_env_sf_arr);
+static_assert(kFrameHeadBytes % 4 == 0 && offsetof(xaac_sbr_frame, int_noise_floor) % 4 == 0, "word copies");
+static_assert(offsetof(xaac_sbr_frame, int_noise_floor) == kFrameHeadBytes + sizeof(((xaac_sbr_frame *)0)->int_env_sf_arr),
+              "nothing but the two arrays behind the head");
+
 template <int HQ>
 struct XsLds {
   int32_t x[(HQ ? 2 : 1) * XAAC_SBR_X_WORDS + 128]; /* + one row: the reference's edge writes may run past slot 37 */
   XsLdsState st;
   xaac_sbr_header h;
-  xaac_sbr_frame f;
+  int32_t f_head[kFrameHeadBytes / 4];
+  int32_t noise_floor[sizeof(((xaac_sbr_frame *)0)->int_noise_floor) / 4];
   XsWork w;
   int16_t rand_hi[568]; /* xaac_sbr_rand_ph >> 16 */
 };
@@ -98,8 +106,10 @@ __global__ __launch_bounds__(64) void xaac_sbr_core_kernel(XaacSbrCoreParams p) 
   /* ---- copy-in ---- */
   copy_words(reinterpret_cast<int32_t *>(&s.h), reinterpret_cast<const int32_t *>(p.header + ch),
              sizeof(xaac_sbr_header) / 4, lane);
-  copy_words(reinterpret_cast<int32_t *>(&s.f), reinterpret_cast<const int32_t *>(p.frame + ch),
-             sizeof(xaac_sbr_frame) / 4, lane);
+  copy_words(s.f_head, reinterpret_cast<const int32_t *>(p.frame + ch), kFrameHeadBytes / 4, lane);
+  if (lane < (int)(sizeof(s.noise_floor) / 4))
+    s.noise_floor[lane] = reinterpret_cast<const int32_t *>(p.frame[ch].int_noise_floor)[lane];
+  const xaac_sbr_frame *f = reinterpret_cast<const xaac_sbr_frame *>(s.f_head); /* head members only */
   {
     int32_t *m = reinterpret_cast<int32_t *>(&s.st);
     if (lane < 2) m[lane] = gstw[kHeadOff / 4 + lane];
@@ -137,7 +147,7 @@ __global__ __launch_bounds__(64) void xaac_sbr_core_kernel(XaacSbrCoreParams p) 
   const XsCx cx = {lane, 64};
   const XsQmfT<HQ> x = {s.x};
   if (lane == 0) s.st.lb_scale = 0;
-  if (s.f.apply_processing) xs_rescale_x_overlap(cx, &s.h, &s.f, &s.st, x);
+  if (f->apply_processing) xs_rescale_x_overlap(cx, &s.h, f, &s.st, x);
   /* what ixheaacd_cplx_anal_qmffilt leaves in the scale struct (generic:630-631) */
   __syncthreads();
   if (lane == 0) {
@@ -149,7 +159,8 @@ __global__ __launch_bounds__(64) void xaac_sbr_core_kernel(XaacSbrCoreParams p) 
 #ifdef XS_SKIP_CORE
   const int rc = 0;
 #else
-  const int rc = xs_sbr_core(cx, &s.h, &s.f, &s.st, x, &s.w, s.rand_hi, &save_lb_scale);
+  const int rc = xs_sbr_core(cx, &s.h, f, p.frame[ch].int_env_sf_arr, reinterpret_cast<const int16_t *>(s.noise_floor),
+                             &s.st, x, &s.w, s.rand_hi, &save_lb_scale);
 #endif
   __syncthreads();
 #ifdef XS_PROFILE

@@ -58,7 +58,7 @@ extern "C" int xo_sbr_dec_lp(const xaac_sbr_header *h, const xaac_sbr_frame *f, 
     st->lb_scale = -10;
   }
   int save_lb_scale = 0;
-  if (xs_sbr_core(cx, h, f, st, x, &w, rand_hi_table(), &save_lb_scale)) return -1;
+  if (xs_sbr_core(cx, h, f, f->int_env_sf_arr, f->int_noise_floor, st, x, &w, rand_hi_table(), &save_lb_scale)) return -1;
   /* sbr_dec.c:1273: synthesis bank over slots 0..31 */
   {
     xo_qmf_syn_state s;
@@ -114,7 +114,7 @@ extern "C" int xo_sbr_dec_hq(const xaac_sbr_header *h, const xaac_sbr_frame *f, 
     st->lb_scale = -8; /* generic:631 */
   }
   int save_lb_scale = 0;
-  if (xs_sbr_core(cx, h, f, st, x, &w, rand_hi_table(), &save_lb_scale)) return -1;
+  if (xs_sbr_core(cx, h, f, f->int_env_sf_arr, f->int_noise_floor, st, x, &w, rand_hi_table(), &save_lb_scale)) return -1;
   xo_qmf_syn_state s;
   memcpy(s.ring, st->syn_ring, sizeof(s.ring));
   s.drc_offset = st->syn_drc_offset;

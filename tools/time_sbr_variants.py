@@ -8,7 +8,7 @@ def build(tag, flags):
     src = os.path.join(ROOT, "libxaac_amd", "csrc")
     out = os.path.join(ROOT, "libxaac_amd", "libxaac_amd_%s.so" % tag)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip"]
-                          + flags + [os.path.join(src, f) for f in ("imdct_kernel.hip", "sbr_qmf_kernel.hip", "sbr_core_kernel.hip", "xaac_abi.cpp")] + ["-o", out])
+                          + flags + [os.path.join(src, f) for f in ("imdct_kernel.hip", "sbr_qmf_kernel.hip", "sbr_core_kernel.hip", "sbr_ps_kernel.hip", "limiter_kernel.hip", "xaac_abi.cpp")] + ["-o", out])
     return out
 
 def main():
