@@ -185,3 +185,43 @@ def test_imdct_to_limiter_chain(ctx, oracle):
     sg = tensor_to_states(st_g, n_streams)
     for i in range(n_streams):
         assert lc.state_view(sg[i]) == lc.state_view(so[i])
+
+
+def test_full_size_batch_and_empty_batch(ctx, oracle):
+    """8192 stereo streams (BASELINE's batch): a handful of distinct signals tiled over the batch, three frames with the
+    state on the GPU; every copy must equal the oracle's result for its signal.  Then the empty batch and bad arguments."""
+    import torch
+    import libxaac_amd
+    init, _, batch = lc.bind(oracle.lib, "xo")
+    n, m, nch = 8192, 2 * len(lc.KINDS), 2
+    rng = np.random.default_rng(77)
+    idx = (np.arange(n) * 3 + np.arange(n) // m) % m
+    so = (lc.LimiterState * m)()
+    for i in range(m):
+        init(ctypes.byref(so[i]), nch, 48000)
+    st = states_to_tensor(so, torch)[torch.from_numpy(idx).cuda()].contiguous()
+    ws = torch.zeros(ctx.peak_limiter_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    pcm = torch.zeros(n * 2048, dtype=torch.int16, device="cuda")
+    for frame in range(3):
+        x = np.stack([lc.signal(rng, lc.KINDS[(i + frame) % len(lc.KINDS)], 1024, nch) for i in range(m)])
+        q = rng.integers(1, 3, (m, nch)).astype(np.int8)
+        xo, po = x.reshape(-1).copy(), np.zeros(m * 2048, np.int16)
+        batch(m, 1024, nch, xo.ctypes.data_as(lc.P32), 2048, q.ctypes.data_as(lc.P8), so, po.ctypes.data_as(lc.P16))
+        xg = torch.from_numpy(np.ascontiguousarray(x[idx]).reshape(-1)).cuda()
+        ctx.peak_limiter_process_batch(xg, torch.from_numpy(np.ascontiguousarray(q[idx]).reshape(-1)).cuda(), st, nch, ws,
+                                       pcm16=pcm)
+        ctx.sync()
+        assert np.array_equal(xg.cpu().numpy().reshape(n, 2048), xo.reshape(m, 2048)[idx]), frame
+        assert np.array_equal(pcm.cpu().numpy().reshape(n, 2048), po.reshape(m, 2048)[idx]), frame
+    got = st.cpu().numpy()
+    for i in list(range(0, n, 641)) + [n - 1]:
+        g = lc.LimiterState.from_buffer_copy(got[i].tobytes())
+        assert lc.state_view(g) == lc.state_view(so[idx[i]]), i
+    # nothing to do / nothing sensible to do
+    empty = torch.zeros(0, dtype=torch.int32, device="cuda")
+    ctx.peak_limiter_process_batch(empty, torch.zeros(0, dtype=torch.int8, device="cuda"),
+                                   torch.zeros((0, libxaac_amd.LIMITER_STATE_BYTES), dtype=torch.uint8, device="cuda"), nch, ws)
+    with pytest.raises(libxaac_amd.XaacError):
+        ctx.peak_limiter_process_batch(xg, torch.zeros(n * 9, dtype=torch.int8, device="cuda"), st, 9, ws, stride=2048)
+    with pytest.raises(libxaac_amd.XaacError):
+        ctx.peak_limiter_process_batch(xg, torch.zeros(n * nch, dtype=torch.int8, device="cuda"), st, nch, ws[:1000])

@@ -99,3 +99,37 @@ def test_workspace_and_argument_checks(ctx):
         ctx.sbr_lp_process_batch(z(2048, torch.int16), z((2, 336)), z((2, 1072)), z((2, 7300)), z(4096, torch.int16),
                                  z(1000))
     assert ctx.sbr_lp_workspace_bytes(16384) >= 16384 * 40 * 64 * 4
+
+
+def test_full_size_batch_matches_reference_records(ctx):
+    """BASELINE's batch size (16384 channel-frames): the golden records tiled over the whole batch -- every copy, wherever
+    it lands in the grid, must come out exactly as the reference's record (outputs, state, status)"""
+    import torch
+    recs = cap.read_records(os.path.join(ROOT, "tests", "golden", "sbr_lp_records.bin.gz"))
+    m, n = len(recs), 16384
+    idx = (np.arange(n) * 7 + np.arange(n) // m) % m          # a shuffled tiling, so neighbours differ
+    row = lambda key: np.stack([np.frombuffer(bytes(r[key]), np.uint8) for r in recs])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a[idx])).cuda()
+    t_h, t_f, t_s = t(row("header")), t(row("frame")), t(row("st0"))
+    pcm_in = torch.from_numpy(np.ascontiguousarray(np.stack([r["pcm_in"] for r in recs])[idx]).reshape(-1)).cuda()
+    out = torch.zeros(n * 2048, dtype=torch.int16, device="cuda")
+    status = torch.full((n,), 7, dtype=torch.int32, device="cuda")
+    ws = torch.zeros(ctx.sbr_lp_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    ctx.sbr_lp_process_batch(pcm_in, t_h, t_f, t_s, out, ws, status)
+    torch.cuda.synchronize()
+    want_out = np.stack([r["pcm_out"][0] for r in recs])[idx]
+    want_st = np.stack([np.frombuffer(bytes(r["st1"]), np.uint8) for r in recs])
+    assert np.array_equal(out.cpu().numpy().reshape(n, 2048), want_out)
+    assert np.array_equal(status.cpu().numpy(), np.array([r["ret"] for r in recs], np.int32)[idx])
+    got_st = t_s.cpu().numpy()
+    for i in list(range(0, n, 997)) + [n - 1]:               # the state compare knows which bytes are don't-care
+        assert not cap.diff_state(cap.State.from_buffer_copy(got_st[i].tobytes()), recs[idx[i]]["st1"]), i
+    # and all copies of one record end in the same state bytes
+    first = {}
+    for i in range(n):
+        k = int(idx[i])
+        if k in first:
+            assert np.array_equal(got_st[i], got_st[first[k]]), (i, k)
+        else:
+            first[k] = i
+    assert want_st.shape[0] == m

@@ -145,3 +145,31 @@ def test_hq_mono_without_ps_vs_oracle(ctx, oracle):
         assert np.array_equal(out[2048 * i:2048 * (i + 1)], ref_out), (i, int(np.sum(out[2048 * i:2048 * (i + 1)] != ref_out)))
         gs = cap.State.from_buffer_copy(st_bytes[i].tobytes())
         assert not cap.diff_state(gs, so), (i, cap.diff_state(gs, so)[:3])
+
+
+def test_full_size_batch_matches_reference_records(ctx):
+    """BASELINE's batch size (8192 HE-AACv2 streams): the golden records tiled over the whole batch; every copy must
+    come out exactly as the reference's record (both channels, SBR and PS state)"""
+    import torch
+    recs = cap.read_records(GOLDEN)
+    m, n = len(recs), 8192
+    idx = (np.arange(n) * 5 + np.arange(n) // m) % m
+    row = lambda key: np.stack([np.frombuffer(bytes(r[key]), np.uint8) for r in recs])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a[idx])).cuda()
+    t_h, t_f, t_s, t_pf, t_ps = t(row("header")), t(row("frame")), t(row("st0")), t(row("ps_frame")), t(row("ps0"))
+    pcm_in = torch.from_numpy(np.ascontiguousarray(np.stack([r["pcm_in"] for r in recs])[idx]).reshape(-1)).cuda()
+    out = torch.zeros(n * 4096, dtype=torch.int16, device="cuda")
+    status = torch.full((n,), 7, dtype=torch.int32, device="cuda")
+    ws = torch.zeros(ctx.sbr_hq_workspace_bytes(n, True), dtype=torch.uint8, device="cuda")
+    ctx.sbr_hq_process_batch(pcm_in, t_h, t_f, t_s, out, ws, t_pf, t_ps, status)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(n, 2048, 2)
+    left = np.stack([r["pcm_out"][0] for r in recs])[idx]
+    right = np.stack([r["pcm_out"][1] for r in recs])[idx]
+    assert np.array_equal(got[:, :, 0], left) and np.array_equal(got[:, :, 1], right)
+    assert np.array_equal(status.cpu().numpy(), np.array([r["ret"] for r in recs], np.int32)[idx])
+    got_st, got_ps = t_s.cpu().numpy(), t_ps.cpu().numpy()
+    for i in list(range(0, n, 499)) + [n - 1]:
+        r = recs[idx[i]]
+        assert not cap.diff_state(cap.State.from_buffer_copy(got_st[i].tobytes()), r["st1"]), i
+        assert not cap.diff_state(cap.PsState.from_buffer_copy(got_ps[i].tobytes()), r["ps1"]), i
