@@ -48,7 +48,8 @@ struct XpLds {
   xaac_ps_frame pf;
   XpHyb hy;
   int32_t left[128], right[128];
-  int32_t ahead[8]; /* bands 0..2 of the slot six ahead: re at [0..2], im at [4..6] */
+  int32_t hyb_u[3][2][44];  /* hybrid filter input of QMF bands 0..2: 12 slots of history + this frame's 32 */
+  int32_t hyb_all[32][20];  /* hybrid sub-band samples of all 32 slots: re of sub-bands 0..9, then im */
   int16_t ratio[24];
   int32_t band_pw[64];
   XpTables tabs; /* the PS constants: a table lookup in global memory costs a slot-loop iteration its latency */
@@ -113,29 +114,71 @@ __global__ __launch_bounds__(64) void xaac_ps_kernel(XaacPsParams p) {
   const int sh_lb = lane < lsb ? lb_shift : (lane < usb ? hb_shift : 0);
   int env = 0;
   XP_T(1);
-  /* the next slot's row (and the look-ahead bands) are fetched while the current slot is processed */
-  int32_t n_re = gx[lane], n_im = gx[64 + lane], a_re = 0, a_im = 0;
-  if (lane < 3) {
-    a_re = gx[6 * 128 + lane];
-    a_im = gx[6 * 128 + 64 + lane];
+  /* ---- hybrid analysis of the whole frame (ixheaacd_hybrid_analysis, hybrid.c:214, is a 13-tap FIR on QMF bands
+     0..2 looking six slots ahead: no recursion, so all 32 slots are filtered at once, one slot per lane, instead of
+     three lanes per slot inside the slot loop).  Input of step l: row l + 6 as adjust_scale leaves it (slots of the
+     next frame are not rescaled), then the delay-buffer shift of thumb_ps_dec.c:77. */
+  if (lane < 32) {
+    const int shiftdelay = lane < 32 - 6 ? 0 : (int16_t)(lb_scale - ps_scale);
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      const int sha = lane + 6 < 32 ? (b < lsb ? lb_shift : (b < usb ? hb_shift : 0)) : 0;
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        int32_t v = adj_word(gx[(lane + 6) * 128 + 64 * c + b], sha);
+        v = shiftdelay < 0 ? fx_shl(v, -shiftdelay) : fx_shr(v, shiftdelay);
+        s.hyb_u[b][c][12 + lane] = v;
+      }
+    }
+  } else if (lane < 32 + 12) {
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      s.hyb_u[b][0][lane - 32] = s.ps.hyb_buf[b][0][lane - 32];
+      s.hyb_u[b][1][lane - 32] = s.ps.hyb_buf[b][1][lane - 32];
+    }
   }
+  __syncthreads();
+  if (lane < 32) { /* QMF band 0: eight-channel filter, six sub-bands */
+    int32_t re[8], im[8];
+    xp_filt_8ch(&s.tabs, &s.hyb_u[0][0][lane], &s.hyb_u[0][1][lane], re, im);
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      s.hyb_all[lane][k] = re[k];
+      s.hyb_all[lane][10 + k] = im[k];
+    }
+  }
+  { /* QMF bands 1 and 2: two sub-bands each */
+    const int b = 1 + (lane >> 5), l = lane & 31;
+    int32_t re[2], im[2];
+    xp_filt_2ch(&s.tabs, &s.hyb_u[b][0][l], &s.hyb_u[b][1][l], re, im);
+    s.hyb_all[l][4 + 2 * b] = re[0];
+    s.hyb_all[l][5 + 2 * b] = re[1];
+    s.hyb_all[l][14 + 2 * b] = im[0];
+    s.hyb_all[l][15 + 2 * b] = im[1];
+  }
+  if (lane < 12) {
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      s.ps.hyb_buf[b][0][lane] = s.hyb_u[b][0][32 + lane];
+      s.ps.hyb_buf[b][1][lane] = s.hyb_u[b][1][32 + lane];
+    }
+  }
+  __syncthreads();
+  XP_T(4);
+  /* the next slot's row is fetched while the current slot is processed */
+  int32_t n_re = gx[lane], n_im = gx[64 + lane];
   for (int l = 0; l < 32; l++) {
     {
       const int sh = l < 6 ? sh_ov : sh_lb;
       s.left[lane] = adj_word(n_re, sh);
       s.left[64 + lane] = adj_word(n_im, sh);
-      if (lane < 3) { /* the hybrid bank looks six slots ahead; slots of the next frame are not rescaled */
-        const int sha = l + 6 < 32 ? sh_lb : 0;
-        s.ahead[lane] = adj_word(a_re, sha);
-        s.ahead[4 + lane] = adj_word(a_im, sha);
+      if (lane < 10) {
+        s.hy.l_re[lane] = s.hyb_all[l][lane];
+        s.hy.l_im[lane] = s.hyb_all[l][10 + lane];
       }
       if (l + 1 < 32) {
         n_re = gx[(l + 1) * 128 + lane];
         n_im = gx[(l + 1) * 128 + 64 + lane];
-        if (lane < 3) {
-          a_re = gx[(l + 7) * 128 + lane];
-          a_im = gx[(l + 7) * 128 + 64 + lane];
-        }
       }
     }
     __syncthreads();
@@ -145,9 +188,6 @@ __global__ __launch_bounds__(64) void xaac_ps_kernel(XaacPsParams p) {
       env++;
     }
     XP_T(3);
-    const int shiftdelay = l < 32 - 6 ? 0 : (int16_t)(lb_scale - ps_scale); /* thumb_ps_dec.c:77 */
-    xp_hybrid_analysis(cx, &s.tabs, s.ahead, s.ahead + 4, &s.ps, &s.hy, shiftdelay);
-    XP_T(4);
     xp_decorrelation(cx, &s.tabs, &s.ps, &s.hy, s.left, s.right, s.ratio, s.band_pw);
     XP_T(5);
     xp_apply_rot(cx, &s.tabs, &s.ps, &s.hy, s.left, s.right);
