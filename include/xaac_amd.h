@@ -128,10 +128,12 @@ typedef struct xaac_qmf_syn_batch {
   int32_t lsb, usb;          /* synthesis bank lsb / usb (region rescale, qmf_dec.c:937-953) */
   int32_t split;             /* first slot of the current frame's low band (op_delay = 6) */
   int32_t slot_stride;       /* >= 64 (LP) / >= 128 (HQ: imaginary row at +64) */
+  int32_t down_sample;       /* 1: the down-sampled bank (32 channels, sbrdec_initfuncs.c:1165; -dsample or output rates
+                                above 48 kHz): bands 0..31 only, 1024 samples out, 640 ring samples in use */
   const int32_t *qmf;        /* [n_ch][32][slot_stride] (not modified) */
   const int16_t *scale;      /* [n_ch][4]: lb_scale, ov_lb_scale, hb_scale, st_syn_scale */
   xaac_qmf_syn_state *state; /* [n_ch] in/out */
-  int16_t *pcm;              /* 2048 samples per channel, interleaved at ch_fac */
+  int16_t *pcm;              /* 2048 (down_sample: 1024) samples per channel, interleaved at ch_fac */
 } xaac_qmf_syn_batch;
 
 /* ---- low-power SBR, whole channel-frame (HE-AACv1) ---------------------------------------
@@ -142,6 +144,7 @@ typedef struct xaac_qmf_syn_batch {
 typedef struct xaac_sbr_lp_batch {
   int32_t n_ch;
   int32_t in_ch_fac, out_ch_fac;   /* interleave strides of pcm_in (1024/ch) and pcm_out (2048/ch) */
+  int32_t down_sample;             /* 1: down-sampled synthesis bank, 1024 samples out per channel */
   const int16_t *pcm_in;
   const xaac_sbr_header *header;   /* [n_ch] (channels of one stream carry copies) */
   const xaac_sbr_frame *frame;     /* [n_ch] */
@@ -164,7 +167,8 @@ typedef struct xaac_sbr_hq_batch {
   int32_t n_ch;                    /* streams */
   int32_t in_ch_fac;               /* interleave stride of pcm_in (1024 per stream) */
   int32_t out_ch_fac;              /* without PS: interleave stride of pcm_out; with PS the output is L,R pairs */
-  int32_t pad_;
+  int32_t down_sample;             /* 1: down-sampled synthesis bank (1024 samples out); not together with PS -- the
+                                      reference itself hands the right bank half a slot there (qmf_dec.c:1117-1119) */
   const int16_t *pcm_in;
   const xaac_sbr_header *header;   /* [n_ch] */
   const xaac_sbr_frame *frame;     /* [n_ch] */

@@ -59,13 +59,15 @@ class _QmfSynBatch(ctypes.Structure):
     # struct xaac_qmf_syn_batch
     _fields_ = [("n_ch", ctypes.c_int32), ("ch_fac", ctypes.c_int32), ("low_pow", ctypes.c_int32),
                 ("lsb", ctypes.c_int32), ("usb", ctypes.c_int32), ("split", ctypes.c_int32),
-                ("slot_stride", ctypes.c_int32), ("qmf", ctypes.c_void_p), ("scale", ctypes.c_void_p),
+                ("slot_stride", ctypes.c_int32), ("down_sample", ctypes.c_int32), ("qmf", ctypes.c_void_p),
+                ("scale", ctypes.c_void_p),
                 ("state", ctypes.c_void_p), ("pcm", ctypes.c_void_p)]
 
 
 class _SbrLpBatch(ctypes.Structure):
     # struct xaac_sbr_lp_batch
     _fields_ = [("n_ch", ctypes.c_int32), ("in_ch_fac", ctypes.c_int32), ("out_ch_fac", ctypes.c_int32),
+                ("down_sample", ctypes.c_int32),
                 ("pcm_in", ctypes.c_void_p), ("header", ctypes.c_void_p), ("frame", ctypes.c_void_p),
                 ("state", ctypes.c_void_p), ("pcm_out", ctypes.c_void_p), ("status", ctypes.c_void_p),
                 ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_uint64)]
@@ -74,7 +76,7 @@ class _SbrLpBatch(ctypes.Structure):
 class _SbrHqBatch(ctypes.Structure):
     # struct xaac_sbr_hq_batch
     _fields_ = [("n_ch", ctypes.c_int32), ("in_ch_fac", ctypes.c_int32), ("out_ch_fac", ctypes.c_int32),
-                ("pad_", ctypes.c_int32), ("pcm_in", ctypes.c_void_p), ("header", ctypes.c_void_p),
+                ("down_sample", ctypes.c_int32), ("pcm_in", ctypes.c_void_p), ("header", ctypes.c_void_p),
                 ("frame", ctypes.c_void_p), ("state", ctypes.c_void_p), ("ps_frame", ctypes.c_void_p),
                 ("ps_state", ctypes.c_void_p), ("pcm_out", ctypes.c_void_p), ("status", ctypes.c_void_p),
                 ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_uint64)]
@@ -289,20 +291,23 @@ class XaacContext:
         if rc != 0:
             raise XaacError(rc, "xaac_qmf_analysis_batch")
 
-    def qmf_synthesis_batch(self, qmf, scale, state, pcm, low_pow, lsb, usb, split=6, slot_stride=None, ch_fac=1):
+    def qmf_synthesis_batch(self, qmf, scale, state, pcm, low_pow, lsb, usb, split=6, slot_stride=None, ch_fac=1,
+                            down_sample=False):
         """Batched ixheaacd_cplx_synt_qmffilt (no PS): 32 slots x 64 bands -> 2048 PCM16 per channel.
         qmf int32[n_ch, 32, slot_stride]; scale int16[n_ch, 4] = lb_scale, ov_lb_scale, hb_scale, st_syn_scale;
-        state int16[n_ch, 1282] in/out; pcm int16[n_ch*2048] interleaved at ch_fac."""
+        state int16[n_ch, 1282] in/out; pcm int16[n_ch*2048] interleaved at ch_fac.  down_sample: the 32-channel
+        bank (1024 samples per channel out)."""
         n_ch = state.shape[0]
         if slot_stride is None:
             slot_stride = 64 if low_pow else 128
         b = _QmfSynBatch()
         b.n_ch, b.ch_fac, b.low_pow, b.lsb, b.usb, b.split = n_ch, int(ch_fac), int(bool(low_pow)), int(lsb), int(usb), int(split)
         b.slot_stride = slot_stride
+        b.down_sample = int(bool(down_sample))
         b.qmf = _ptr(qmf, "int32", n_ch * 32 * slot_stride, device_ok=True)
         b.scale = _ptr(scale, "int16", n_ch * 4, device_ok=True)
         b.state = _ptr(state, "int16", n_ch * QMF_SYN_STATE_WORDS, device_ok=True)
-        b.pcm = _ptr(pcm, "int16", n_ch * 2048, device_ok=True)
+        b.pcm = _ptr(pcm, "int16", n_ch * (1024 if down_sample else 2048), device_ok=True)
         rc = self._lib.xaac_qmf_synthesis_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_qmf_synthesis_batch")
@@ -311,7 +316,7 @@ class XaacContext:
         return int(self._lib.xaac_sbr_hq_workspace_bytes(int(n_ch), int(bool(with_ps))))
 
     def sbr_hq_process_batch(self, pcm_in, header, frame, state, pcm_out, workspace, ps_frame=None, ps_state=None,
-                             status=None, in_ch_fac=1, out_ch_fac=1):
+                             status=None, in_ch_fac=1, out_ch_fac=1, down_sample=False):
         """Batched ixheaacd_sbr_dec, HQ mode: one frame per stream.  With ps_frame / ps_state (uint8[n, PS_*_BYTES])
         the parametric-stereo tool runs too (HE-AACv2) and pcm_out is int16[n*2048*2] of L,R pairs; without them
         pcm_out is int16[n*2048] (HE-AAC mono, HQ)."""
@@ -319,13 +324,14 @@ class XaacContext:
         with_ps = ps_frame is not None
         b = _SbrHqBatch()
         b.n_ch, b.in_ch_fac, b.out_ch_fac = n_ch, int(in_ch_fac), int(out_ch_fac)
+        b.down_sample = int(bool(down_sample))
         b.pcm_in = _ptr(pcm_in, "int16", n_ch * 1024, device_ok=True)
         b.header = _ptr(header, "uint8", n_ch * SBR_HEADER_BYTES, device_ok=True)
         b.frame = _ptr(frame, "uint8", n_ch * SBR_FRAME_BYTES, device_ok=True)
         b.state = _ptr(state, "uint8", n_ch * SBR_STATE_BYTES, device_ok=True)
         b.ps_frame = _ptr(ps_frame, "uint8", n_ch * PS_FRAME_BYTES, allow_none=True, device_ok=True)
         b.ps_state = _ptr(ps_state, "uint8", n_ch * PS_STATE_BYTES, allow_none=True, device_ok=True)
-        b.pcm_out = _ptr(pcm_out, "int16", n_ch * 2048 * (2 if with_ps else 1), device_ok=True)
+        b.pcm_out = _ptr(pcm_out, "int16", n_ch * (1024 if down_sample else 2048) * (2 if with_ps else 1), device_ok=True)
         b.status = _ptr(status, "int32", n_ch, allow_none=True, device_ok=True)
         b.workspace = _ptr(workspace, "uint8", device_ok=True)
         b.workspace_bytes = workspace.numel()
@@ -363,7 +369,7 @@ class XaacContext:
         return int(self._lib.xaac_sbr_lp_workspace_bytes(int(n_ch)))
 
     def sbr_lp_process_batch(self, pcm_in, header, frame, state, pcm_out, workspace, status=None, in_ch_fac=1,
-                             out_ch_fac=1):
+                             out_ch_fac=1, down_sample=False):
         """Batched ixheaacd_sbr_dec, low-power mode (HE-AACv1): one frame per channel.
         pcm_in int16[n_ch*1024]; header/frame/state uint8[n_ch, SBR_*_BYTES] (structs of include/xaac_sbr.h,
         state in/out); pcm_out int16[n_ch*2048]; workspace uint8[>= sbr_lp_workspace_bytes(n_ch)];
@@ -371,11 +377,12 @@ class XaacContext:
         n_ch = state.shape[0]
         b = _SbrLpBatch()
         b.n_ch, b.in_ch_fac, b.out_ch_fac = n_ch, int(in_ch_fac), int(out_ch_fac)
+        b.down_sample = int(bool(down_sample))
         b.pcm_in = _ptr(pcm_in, "int16", n_ch * 1024, device_ok=True)
         b.header = _ptr(header, "uint8", n_ch * SBR_HEADER_BYTES, device_ok=True)
         b.frame = _ptr(frame, "uint8", n_ch * SBR_FRAME_BYTES, device_ok=True)
         b.state = _ptr(state, "uint8", n_ch * SBR_STATE_BYTES, device_ok=True)
-        b.pcm_out = _ptr(pcm_out, "int16", n_ch * 2048, device_ok=True)
+        b.pcm_out = _ptr(pcm_out, "int16", n_ch * (1024 if down_sample else 2048), device_ok=True)
         b.status = _ptr(status, "int32", n_ch, allow_none=True, device_ok=True)
         b.workspace = _ptr(workspace, "uint8", device_ok=True)
         b.workspace_bytes = workspace.numel()

@@ -358,4 +358,74 @@ FX_HD void xq_synth_hq_slot(int32_t *s, int32_t *t, int16_t *b, int shift) {
   }
 }
 
+/* ---- down-sampled synthesis bank (32 channels: -dsample / output rates above 48 kHz, sbrdec_initfuncs.c:622,
+   :1165) -- the same two slot transforms at half the size ---------------------------------------------------- */
+
+/* LP slot, ixheaacd_dct2_32 (qmf_dec.c:341: pretwdct2_32 :89, radix-4 FFT-16, fftposttw_32 :213, posttwdct2_32 :263):
+   32 real subband samples x[] (clobbered), scratch X[32] -> the 64 int16 samples the reference writes at
+   filter_states + drc_offset (+ the zero at [3 M], generic:863) */
+FX_HD void xq_dct2_32_lp(int32_t *x, int32_t *X, int16_t *b) {
+  XQ_UNROLL
+  for (int n = 0; n < 16; n++) {
+    X[n] = x[2 * n];
+    X[31 - n] = x[2 * n + 1];
+  }
+  xq_radix4(XQ_T(w_16), X, 1, 4);
+  xq_postradix4(x, X);
+  {
+    const int16_t *post = XQ_T(post_fft_tbl);
+    x[0] = fx_shlw(x[0], 1);
+    x[1] = fx_shlw(x[1], 1);
+    XQ_UNROLL
+    for (int k = 1; k <= 8; k++) {
+      const int pf = 2 * k, pr = 33 - 2 * k;
+      int32_t t0 = x[pf], t1 = x[pf + 1], t3 = x[pr], t2 = x[pr - 1];
+      int32_t in2 = fx_sub_sat(t3, t1), in1 = fx_add_sat(t3, t1);
+      int32_t d = fx_sub_sat(t0, t2), sm = fx_add_sat(t0, t2);
+      int16_t re = post[2 * k], im = post[16 - 2 * k];
+      int32_t v1 = fx_shlw(fx_sub(xq_mul(in1, re), xq_mul(d, im)), 1);
+      int32_t v2 = fx_shlw(fx_add(xq_mul(d, re), xq_mul(in1, im)), 1);
+      x[pf] = fx_add_sat(sm, v1);
+      x[pf + 1] = fx_add_sat(in2, v2);
+      x[pr] = fx_sub_sat(v2, in2);
+      x[pr - 1] = fx_sub_sat(sm, v1);
+    }
+  }
+  {
+    const int16_t *tw = XQ_T(dct23_tw);
+    int16_t *of = b + 16;
+    int32_t re0 = x[0], im0 = x[1];
+    int32_t half = fx_sat64(((int64_t)re0 + (int64_t)im0) >> 1);
+    of[0] = fx_round16(fx_shl_sat(half, 4));
+    int32_t last = fx_sub_sat(re0, im0);
+    XQ_UNROLL
+    for (int n = 1; n < 16; n++) {
+      int32_t re = x[2 * n], im = x[2 * n + 1];
+      int16_t tr = tw[4 * n], ti = tw[4 * n + 1];
+      int32_t o_re = fx_sub_sat(xq_mul(re, tr), xq_mul(im, ti));
+      int32_t o_im = fx_add_sat(xq_mul(im, tr), xq_mul(re, ti));
+      int16_t r1 = fx_round16(fx_shl_sat(o_re, 4)), i1 = fx_round16(fx_shl_sat(o_im, 4));
+      of[n] = r1;
+      of[-n] = r1;
+      of[32 - n] = i1;
+      of[32 + n] = fx_neg16(i1);
+    }
+    int16_t r1 = fx_round16(fx_shl_sat(xq_mul(last, tw[64]), 4));
+    of[16] = r1;
+    of[-16] = r1;
+    of[32] = 0;
+  }
+}
+
+/* HQ slot: s[0..31] real, s[64..95] imaginary (clobbered), t scratch -> 64 int16 ring samples
+   (inv_emodulation generic:869 with w_16, shiftrountine_with_rnd generic:1638 at len 32) */
+FX_HD void xq_synth_hq_slot_ds(int32_t *s, int32_t *t, int16_t *b, int shift) {
+  xq_cos_sin_mod<16>(s, t);
+  XQ_UNROLL
+  for (int c = 0; c < 32; c++) {
+    b[c] = fx_round16(fx_shl_sat(fx_sub_sat(s[64 + c], s[c]), shift));
+    b[32 + c] = fx_round16(fx_shl_sat(fx_add_sat(s[64 + 31 - c], s[31 - c]), shift));
+  }
+}
+
 #endif /* XAAC_SBR_QMF_H */

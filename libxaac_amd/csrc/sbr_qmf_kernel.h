@@ -38,6 +38,7 @@ typedef struct XaacQmfSynParams {
   int32_t state_stride, qmf_ch_stride;
   int32_t scale_stride;   /* int16 words between channels' {lb, ov_lb, hb, st_syn[, lsb, usb]} */
   int32_t per_ch_bands;   /* 1: lsb/usb come from scale[4], scale[5] of each channel */
+  int32_t down_sample;    /* 1: the 32-channel bank (sbrdec_initfuncs.c:1165): 1024 samples out, 640-sample ring */
   const int32_t *qmf;
   const int16_t *scale;
   xaac_qmf_syn_state *state;

@@ -198,21 +198,25 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_analysis_kernel(XaacQ
 #endif
 
 /* ===================================================================================== */
-template <bool LP>
+/* DS: the down-sampled bank -- 32 channels: the same kernel with half-size slot blocks (NC) */
+template <bool LP, bool DS>
 __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(XaacQmfSynParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ROW = LP ? 64 : 128;    /* words per slot row */
   constexpr int RS = ROW + 1;           /* padded LDS row stride */
   constexpr int VSLOTS = 9 + 32;        /* 9 slots of history + this frame */
+  constexpr int NC = DS ? 32 : 64;      /* synthesis channels = output samples per slot */
+  constexpr int BLK = 2 * NC;           /* ring samples one slot adds */
+  constexpr int RING = 10 * BLK;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   char *wbase = smem + wave * (LP ? XAAC_QMF_SYN_LDS_PER_WAVE_LP : XAAC_QMF_SYN_LDS_PER_WAVE_HQ);
   int32_t *rows = reinterpret_cast<int32_t *>(wbase);  /* [64][RS] slot rows, later aliased by ... */
-  int16_t *v = reinterpret_cast<int16_t *>(wbase);     /* ... [2][VSLOTS][128] ring samples */
+  int16_t *v = reinterpret_cast<int16_t *>(wbase);     /* ... [2][VSLOTS][BLK] ring samples */
 
-  int32_t coef[10]; /* c[64 A + k], k = lane */
+  int32_t coef[10]; /* c[64 A + k], k = lane; down-sampled: every second one, k = lane & 31 (qmf_dec.c:749) */
 #pragma unroll
-  for (int a = 0; a < 10; a++) coef[a] = xaac_qmf_qmf_c[64 * a + lane];
+  for (int a = 0; a < 10; a++) coef[a] = xaac_qmf_qmf_c[64 * a + (DS ? 2 * (lane & 31) : lane)];
 
 #ifdef XS_PROFILE
   long long xq_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xq_last = clock64();
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
     }
     XQ_TIME(1);
     /* ---- per-slot: region rescale (qmf_dec.c:937-953) + inverse modulation; lane = slot ----------- */
-    int16_t b[128];
+    int16_t b[BLK];
     {
       const int ch = 2 * pair + (lane >> 5);
       const int chc = ch < p.n_ch ? ch : p.n_ch - 1;
@@ -256,24 +260,33 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
       int32_t x[ROW], t[ROW];
 #pragma unroll
       for (int k = 0; k < ROW; k++) {
-        int32_t val = rows[RS * lane + k];
         const int band = k & 63;
-        val = band < lsb ? adj_scale(val, lo_shift) : (band < usb ? adj_scale(val, hb_shift) : val);
-        x[k] = val;
+        if (band < NC) { /* the down-sampled bank transforms bands 0..31 only */
+          int32_t val = rows[RS * lane + k];
+          val = band < lsb ? adj_scale(val, lo_shift) : (band < usb ? adj_scale(val, hb_shift) : val);
+          x[k] = val;
+        }
       }
-      if (LP)
-        xq_dct2_64_lp(x, t, b);
-      else
-        xq_synth_hq_slot(x, t, b, -(st_syn - 3) + 1);
+      if (LP) {
+        if (DS)
+          xq_dct2_32_lp(x, t, b);
+        else
+          xq_dct2_64_lp(x, t, b);
+      } else {
+        if (DS)
+          xq_synth_hq_slot_ds(x, t, b, -(st_syn - 3) + 1);
+        else
+          xq_synth_hq_slot(x, t, b, -(st_syn - 3) + 1);
+      }
     }
     XQ_TIME(2);
     /* all lanes hold their slot in registers now: the row tile may be overwritten (the tile is
        re-used through an int16 view: keep the compiler from moving accesses across this point) */
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     {
-      int16_t *dst = v + ((lane >> 5) * VSLOTS + 9 + (lane & 31)) * 128;
+      int16_t *dst = v + ((lane >> 5) * VSLOTS + 9 + (lane & 31)) * BLK;
 #pragma unroll
-      for (int i = 0; i < 128; i += 2)
+      for (int i = 0; i < BLK; i += 2)
         *reinterpret_cast<int32_t *>(dst + i) = (int32_t)((uint32_t)(uint16_t)b[i] | ((uint32_t)(uint16_t)b[i + 1] << 16));
     }
     for (int c = 0; c < 2; c++) {
@@ -282,19 +295,20 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
       const xaac_qmf_syn_state *st = reinterpret_cast<const xaac_qmf_syn_state *>(
           reinterpret_cast<const char *>(p.state) + (size_t)ch * p.state_stride);
       const int d = st->drc_offset;
-      int16_t hist[18]; /* 9 slots x 128 samples over 64 lanes: all loads in flight together */
+      constexpr int HJ = 9 * BLK / 64;
+      int16_t hist[HJ]; /* 9 slots x BLK samples over 64 lanes: all loads in flight together */
 #pragma unroll
-      for (int j = 0; j < 18; j++) {
+      for (int j = 0; j < HJ; j++) {
         const int i = lane + 64 * j;
-        const int A = 9 - (i >> 7); /* slot age relative to this frame's slot 0 */
-        int pos = d + 128 * A + (i & 127);
-        if (pos >= 1280) pos -= 1280;
+        const int A = 9 - i / BLK; /* slot age relative to this frame's slot 0 */
+        int pos = d + BLK * A + i % BLK;
+        if (pos >= RING) pos -= RING;
         hist[j] = st->ring[pos];
       }
 #pragma unroll
-      for (int j = 0; j < 18; j++) {
+      for (int j = 0; j < HJ; j++) {
         const int i = lane + 64 * j;
-        v[(c * VSLOTS + (i >> 7)) * 128 + (i & 127)] = hist[j];
+        v[(c * VSLOTS + i / BLK) * BLK + i % BLK] = hist[j];
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -306,14 +320,16 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
       if (p.per_ch_bands && p.scale[(size_t)p.scale_stride * ch + 6]) continue; /* channel inactive this frame */
       const int cf = p.pcm_sample_stride ? p.pcm_sample_stride : p.ch_fac;
       int16_t *dst = p.pcm_sample_stride ? p.pcm + (size_t)ch * p.pcm_ch_stride
-                                         : p.pcm + (size_t)(ch / cf) * 2048 * cf + (ch % cf);
+                                         : p.pcm + (size_t)(ch / cf) * (32 * NC) * cf + (ch % cf);
       const int shift = LP ? 2 : 1;
-      for (int s = 0; s < 32; s++) {
-        const int16_t *vs = v + (c * VSLOTS + 9 + s) * 128 + lane;
+      /* a wave covers one slot of 64 samples, or two slots of 32 */
+      for (int s0 = 0; s0 < 32; s0 += 64 / NC) {
+        const int s = DS ? s0 + (lane >> 5) : s0, k = DS ? (lane & 31) : lane;
+        const int16_t *vs = v + (c * VSLOTS + 9 + s) * BLK + k;
         int32_t acc = 0x8000 >> shift;
 #pragma unroll
-        for (int A = 0; A < 10; A++) acc += (int32_t)vs[-128 * A + 64 * (A & 1)] * coef[A]; /* < 2^31: exact */
-        dst[(size_t)(64 * s + lane) * cf] = (int16_t)(fx_shl_sat(acc, shift) >> 16);
+        for (int A = 0; A < 10; A++) acc += (int32_t)vs[-BLK * A + NC * (A & 1)] * coef[A]; /* < 2^31: exact */
+        dst[(size_t)(NC * s + k) * cf] = (int16_t)(fx_shl_sat(acc, shift) >> 16);
       }
     }
     XQ_TIME(4);
@@ -324,14 +340,14 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
       if (p.per_ch_bands && p.scale[(size_t)p.scale_stride * ch + 6]) continue;
       xaac_qmf_syn_state *st =
           reinterpret_cast<xaac_qmf_syn_state *>(reinterpret_cast<char *>(p.state) + (size_t)ch * p.state_stride);
-      const int d_new = (st->drc_offset + 1024) % 1280;
+      const int d_new = (st->drc_offset + RING - (32 * BLK) % RING) % RING; /* 32 slots of BLK downwards */
       const int ph_new = (st->phase + 128) % 640;
-      for (int i = lane; i < 1280; i += 64) {
-        const int A = 1 + (i >> 7); /* age relative to the NEXT frame's slot 0: 1..10 */
-        int pos = d_new + 128 * A + (i & 127);
-        if (pos >= 1280) pos -= 1280;
-        if (pos >= 1280) pos -= 1280;
-        st->ring[pos] = v[(c * VSLOTS + 9 + 32 - A) * 128 + (i & 127)];
+      for (int i = lane; i < RING; i += 64) {
+        const int A = 1 + i / BLK; /* age relative to the NEXT frame's slot 0: 1..10 */
+        int pos = d_new + BLK * A + i % BLK;
+        if (pos >= RING) pos -= RING;
+        if (pos >= RING) pos -= RING;
+        st->ring[pos] = v[(c * VSLOTS + 9 + 32 - A) * BLK + i % BLK];
       }
       if (lane == 0) {
         st->drc_offset = (int16_t)d_new;
@@ -358,11 +374,17 @@ extern "C" hipError_t xaac_launch_qmf_analysis(const XaacQmfAnaParams *p, int gr
 }
 
 extern "C" hipError_t xaac_launch_qmf_synthesis(const XaacQmfSynParams *p, int grid, hipStream_t stream) {
-  if (p->low_pow)
-    hipLaunchKernelGGL(xaac_qmf_synthesis_kernel<true>, dim3(grid), dim3(XAAC_QMF_BLOCK),
+  if (p->low_pow && p->down_sample)
+    hipLaunchKernelGGL((xaac_qmf_synthesis_kernel<true, true>), dim3(grid), dim3(XAAC_QMF_BLOCK),
                        XAAC_QMF_WAVES * XAAC_QMF_SYN_LDS_PER_WAVE_LP, stream, *p);
+  else if (p->low_pow)
+    hipLaunchKernelGGL((xaac_qmf_synthesis_kernel<true, false>), dim3(grid), dim3(XAAC_QMF_BLOCK),
+                       XAAC_QMF_WAVES * XAAC_QMF_SYN_LDS_PER_WAVE_LP, stream, *p);
+  else if (p->down_sample)
+    hipLaunchKernelGGL((xaac_qmf_synthesis_kernel<false, true>), dim3(grid), dim3(XAAC_QMF_BLOCK),
+                       XAAC_QMF_WAVES * XAAC_QMF_SYN_LDS_PER_WAVE_HQ, stream, *p);
   else
-    hipLaunchKernelGGL(xaac_qmf_synthesis_kernel<false>, dim3(grid), dim3(XAAC_QMF_BLOCK),
+    hipLaunchKernelGGL((xaac_qmf_synthesis_kernel<false, false>), dim3(grid), dim3(XAAC_QMF_BLOCK),
                        XAAC_QMF_WAVES * XAAC_QMF_SYN_LDS_PER_WAVE_HQ, stream, *p);
   return hipGetLastError();
 }
@@ -373,8 +395,8 @@ extern "C" int xaac_qmf_blocks_per_cu(int which) {
   switch (which) {
     case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, xaac_qmf_analysis_kernel<true>, XAAC_QMF_BLOCK, XAAC_QMF_WAVES * XAAC_QMF_ANA_LDS_PER_WAVE); break;
     case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, xaac_qmf_analysis_kernel<false>, XAAC_QMF_BLOCK, XAAC_QMF_WAVES * XAAC_QMF_ANA_LDS_PER_WAVE); break;
-    case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, xaac_qmf_synthesis_kernel<true>, XAAC_QMF_BLOCK, XAAC_QMF_WAVES * XAAC_QMF_SYN_LDS_PER_WAVE_LP); break;
-    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, xaac_qmf_synthesis_kernel<false>, XAAC_QMF_BLOCK, XAAC_QMF_WAVES * XAAC_QMF_SYN_LDS_PER_WAVE_HQ); break;
+    case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (xaac_qmf_synthesis_kernel<true, false>), XAAC_QMF_BLOCK, XAAC_QMF_WAVES * XAAC_QMF_SYN_LDS_PER_WAVE_LP); break;
+    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (xaac_qmf_synthesis_kernel<false, false>), XAAC_QMF_BLOCK, XAAC_QMF_WAVES * XAAC_QMF_SYN_LDS_PER_WAVE_HQ); break;
   }
   if (e != hipSuccess || n < 1) n = 1;
   return n;

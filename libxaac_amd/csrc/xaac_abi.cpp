@@ -223,6 +223,7 @@ int32_t xaac_qmf_synthesis_batch(xaac_ctx *c, const xaac_qmf_syn_batch *b) {
   if (!b->qmf || !b->scale || !b->state || !b->pcm) return XAAC_FATAL_NULL_ARG;
   XaacQmfSynParams p = {};
   p.n_ch = b->n_ch; p.ch_fac = b->ch_fac; p.low_pow = b->low_pow ? 1 : 0; p.lsb = b->lsb; p.usb = b->usb;
+  p.down_sample = b->down_sample ? 1 : 0;
   p.split = b->split; p.slot_stride = b->slot_stride; p.qmf = b->qmf; p.scale = b->scale; p.state = b->state;
   p.pcm = b->pcm;
   p.state_stride = (int32_t)sizeof(xaac_qmf_syn_state); p.qmf_ch_stride = 32 * b->slot_stride;
@@ -268,6 +269,7 @@ int32_t xaac_sbr_lp_process_batch(xaac_ctx *c, const xaac_sbr_lp_batch *b) {
   /* 3. synthesis bank over rows 2..33 (the 6 delayed + first 26 new slots) */
   XaacQmfSynParams ps = {};
   ps.n_ch = b->n_ch; ps.ch_fac = b->out_ch_fac; ps.low_pow = 1; ps.lsb = 0; ps.usb = 0; ps.split = 6;
+  ps.down_sample = b->down_sample ? 1 : 0;
   ps.slot_stride = 64; ps.state_stride = (int32_t)sizeof(xaac_sbr_state); ps.qmf_ch_stride = XAAC_SBR_X_WORDS;
   ps.scale_stride = 8; ps.per_ch_bands = 1;
   ps.qmf = x + 2 * 64; ps.scale = par; ps.dbg = b->status;
@@ -293,6 +295,7 @@ int32_t xaac_sbr_hq_process_batch(xaac_ctx *c, const xaac_sbr_hq_batch *b) {
   if ((b->ps_frame == nullptr) != (b->ps_state == nullptr)) return XAAC_FATAL_BAD_ARG;
   if (b->in_ch_fac != 1 && b->in_ch_fac != 2) return XAAC_FATAL_BAD_ARG;
   if (!with_ps && b->out_ch_fac != 1 && b->out_ch_fac != 2) return XAAC_FATAL_BAD_ARG;
+  if (with_ps && b->down_sample) return XAAC_FATAL_BAD_ARG; /* see xaac_sbr_hq_batch.down_sample */
   if (b->n_ch % b->in_ch_fac || (!with_ps && b->n_ch % b->out_ch_fac)) return XAAC_FATAL_BAD_ARG;
   if (b->n_ch == 0) return XAAC_OK;
   if (!b->pcm_in || !b->header || !b->frame || !b->state || !b->pcm_out || !b->workspace) return XAAC_FATAL_NULL_ARG;
@@ -329,6 +332,7 @@ int32_t xaac_sbr_hq_process_batch(xaac_ctx *c, const xaac_sbr_hq_batch *b) {
   /* 4. synthesis bank(s) over the 6 delayed + first 26 new slots */
   XaacQmfSynParams ps = {};
   ps.n_ch = b->n_ch; ps.ch_fac = with_ps ? 1 : b->out_ch_fac; ps.low_pow = 0; ps.split = 6;
+  ps.down_sample = b->down_sample ? 1 : 0;
   ps.slot_stride = 128; ps.state_stride = (int32_t)sizeof(xaac_sbr_state); ps.qmf_ch_stride = xw;
   ps.scale_stride = 8; ps.per_ch_bands = 1;
   ps.qmf = x + 2 * 128; ps.scale = par_l; ps.dbg = b->status;

@@ -112,46 +112,64 @@ static inline int32_t adj(int32_t v, int shift) {
 
 /* One slot of the synthesis bank: x = 64 reals (+ 64 imaginaries in HQ), already in the output scale of
    the frame; transform into the ring, 10-tap polyphase sum, 64 PCM16 at `stride`; advances the ring
-   state.  `slot` is the slot's index in the frame (the two ring halves alternate with its parity). */
-void xo_qmf_synthesis_slot(const int32_t *x, xo_qmf_syn_state *st, int slot, int low_pow, int out_scale, int16_t *pcm,
-                           int stride) {
+   state.  `slot` is the slot's index in the frame (the two ring halves alternate with its parity).
+   ds: the down-sampled bank (32 channels, qmf_dec.c:749 ixheaacd_sbr_qmfsyn32_winadd): only bands 0..31 of
+   x are used, the ring is 640 samples, every second prototype coefficient, 32 PCM16 per slot. */
+void xo_qmf_synthesis_slot_n(const int32_t *x, xo_qmf_syn_state *st, int slot, int low_pow, int out_scale, int16_t *pcm,
+                             int stride, int ds) {
   const int16_t *c = xaac_qmf_qmf_c;
+  const int L = ds ? 32 : 64, ring = 20 * L;
   int d = st->drc_offset, ph = st->phase;
-  const int fp1 = (slot & 1) ? 64 : 0, fp2 = (slot & 1) ? 0 : 64;
+  const int fp1 = (slot & 1) ? L : 0, fp2 = (slot & 1) ? 0 : L;
   int32_t xin[128], t[128];
   int16_t *b = st->ring + d;
-  for (int k = 0; k < (low_pow ? 64 : 128); k++) xin[k] = x[k];
-  if (low_pow)
-    xq_dct2_64_lp(xin, t, b);
-  else
-    xq_synth_hq_slot(xin, t, b, out_scale + 1);
-  /* generic:1508: 10-tap polyphase sum (cannot saturate: sum|c| = 57308), then the output shift */
-  const int shift = low_pow ? 2 : 1;
+  for (int k = 0; k < L; k++) {
+    xin[k] = x[k];
+    if (!low_pow) xin[64 + k] = x[64 + k];
+  }
+  if (low_pow) {
+    if (ds)
+      xq_dct2_32_lp(xin, t, b);
+    else
+      xq_dct2_64_lp(xin, t, b);
+  } else {
+    if (ds)
+      xq_synth_hq_slot_ds(xin, t, b, out_scale + 1);
+    else
+      xq_synth_hq_slot(xin, t, b, out_scale + 1);
+  }
+  /* generic:1508 / qmf_dec.c:749: 10-tap polyphase sum (cannot saturate: sum|c| = 57308), then the output shift */
+  const int shift = low_pow ? 2 : 1, cs = ds ? 2 : 1;
   const int16_t *t1 = st->ring + fp1, *t2 = st->ring + fp2, *cf = c + ph;
-  for (int k = 0; k < 64; k++) {
+  for (int k = 0; k < L; k++) {
     int32_t acc = 0x8000 >> shift;
-    for (int m = 0; m < 5; m++) acc = fx_add_sat(acc, (int32_t)t1[256 * m + k] * cf[k + 128 * m]);
-    for (int m = 0; m < 5; m++) acc = fx_add_sat(acc, (int32_t)t2[128 + 256 * m + k] * cf[k + 64 + 128 * m]);
+    for (int m = 0; m < 5; m++) acc = fx_add_sat(acc, (int32_t)t1[4 * L * m + k] * cf[cs * (k + 2 * L * m)]);
+    for (int m = 0; m < 5; m++) acc = fx_add_sat(acc, (int32_t)t2[2 * L + 4 * L * m + k] * cf[cs * (k + L + 2 * L * m)]);
     pcm[stride * k] = (int16_t)(fx_shl_sat(acc, shift) >> 16);
   }
-  d -= 128;
-  if (d < 0) d += 1280;
+  d -= 2 * L;
+  if (d < 0) d += ring;
   ph += 64;
   if (ph == 640) ph = 0;
   st->drc_offset = (int16_t)d;
   st->phase = (int16_t)ph;
 }
+void xo_qmf_synthesis_slot(const int32_t *x, xo_qmf_syn_state *st, int slot, int low_pow, int out_scale, int16_t *pcm,
+                           int stride) {
+  xo_qmf_synthesis_slot_n(x, st, slot, low_pow, out_scale, pcm, stride, 0);
+}
 
-/* One frame: 32 slots -> 2048 PCM16 at `stride`.  qmf rows as for analysis (64 reals, +64 imaginaries in HQ);
-   they are NOT modified here (the reference scales and transforms them in place).
+/* One frame: 32 slots -> 2048 (ds: 1024) PCM16 at `stride`.  qmf rows as for analysis (64 reals, +64 imaginaries in
+   HQ); they are NOT modified here (the reference scales and transforms them in place).
    sf = {lb_scale, ov_lb_scale, hb_scale, st_syn_scale}; no PS (active = 0). */
-void xo_qmf_synthesis(const int32_t *qmf, int slot_stride, const int16_t *sf, int lsb, int usb, int split,
-                      xo_qmf_syn_state *st, int low_pow, int16_t *pcm, int stride) {
+void xo_qmf_synthesis_n(const int32_t *qmf, int slot_stride, const int16_t *sf, int lsb, int usb, int split,
+                        xo_qmf_syn_state *st, int low_pow, int16_t *pcm, int stride, int ds) {
   const int lb_scale = sf[0], ov_lb_scale = sf[1], hb_scale = sf[2], st_syn = sf[3];
   const int bias = low_pow ? 4 : 8; /* qmf_dec.c:906-933 */
   const int ov_lb_shift = (st_syn - ov_lb_scale) - bias, lb_shift = (st_syn - lb_scale) - bias,
             hb_shift = (st_syn - hb_scale) - bias;
   const int out_scale = low_pow ? -(st_syn - 1) : -(st_syn - 3);
+  const int L = ds ? 32 : 64;
   for (int s = 0; s < 32; s++) {
     int32_t x[128];
     const int32_t *row = qmf + (size_t)s * slot_stride;
@@ -165,8 +183,12 @@ void xo_qmf_synthesis(const int32_t *qmf, int slot_stride, const int16_t *sf, in
           v = adj(v, hb_shift);
         x[64 * p + k] = v;
       }
-    xo_qmf_synthesis_slot(x, st, s, low_pow, out_scale, pcm + (size_t)stride * 64 * s, stride);
+    xo_qmf_synthesis_slot_n(x, st, s, low_pow, out_scale, pcm + (size_t)stride * L * s, stride, ds);
   }
+}
+void xo_qmf_synthesis(const int32_t *qmf, int slot_stride, const int16_t *sf, int lsb, int usb, int split,
+                      xo_qmf_syn_state *st, int low_pow, int16_t *pcm, int stride) {
+  xo_qmf_synthesis_n(qmf, slot_stride, sf, lsb, usb, split, st, low_pow, pcm, stride, 0);
 }
 
 }  // extern "C"

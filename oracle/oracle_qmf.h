@@ -31,6 +31,10 @@ void xo_qmf_ana_init(xo_qmf_ana_state *st);
 void xo_qmf_analysis(const int16_t *pcm, int stride, xo_qmf_ana_state *st, int low_pow, int usb, int32_t *qmf,
                      int slot_stride);
 void xo_qmf_syn_init(xo_qmf_syn_state *st);
+void xo_qmf_synthesis_slot_n(const int32_t *x, xo_qmf_syn_state *st, int slot, int low_pow, int out_scale, int16_t *pcm,
+                             int stride, int ds);
+void xo_qmf_synthesis_n(const int32_t *qmf, int slot_stride, const int16_t *sf, int lsb, int usb, int split,
+                        xo_qmf_syn_state *st, int low_pow, int16_t *pcm, int stride, int ds);
 void xo_qmf_synthesis_slot(const int32_t *x, xo_qmf_syn_state *st, int slot, int low_pow, int out_scale, int16_t *pcm,
                            int stride);
 void xo_qmf_synthesis(const int32_t *qmf, int slot_stride, const int16_t *sf, int lsb, int usb, int split,

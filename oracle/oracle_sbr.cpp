@@ -32,6 +32,9 @@ static const int16_t *rand_hi_table() {
   return tab.v;
 }
 
+/* down-sampled synthesis bank (32 channels) for the call in flight: set by the *_ds entry points */
+static thread_local int g_ds = 0;
+
 extern "C" int xo_sbr_dec_lp(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st,
                              const int16_t *pcm_in, int in_stride, int16_t *pcm_out, int out_stride) {
   static thread_local int32_t buf[40 * 64];
@@ -66,7 +69,7 @@ extern "C" int xo_sbr_dec_lp(const xaac_sbr_header *h, const xaac_sbr_frame *f, 
     s.drc_offset = st->syn_drc_offset;
     s.phase = st->syn_phase;
     const int16_t sf[4] = {st->lb_scale, st->ov_lb_scale, st->hb_scale, st->st_syn_scale};
-    xo_qmf_synthesis(&x(0, 0), 64, sf, st->syn_lsb, st->syn_usb, 6, &s, 1, pcm_out, out_stride);
+    xo_qmf_synthesis_n(&x(0, 0), 64, sf, st->syn_lsb, st->syn_usb, 6, &s, 1, pcm_out, out_stride, g_ds);
     memcpy(st->syn_ring, s.ring, sizeof(s.ring));
     st->syn_drc_offset = s.drc_offset;
     st->syn_phase = s.phase;
@@ -165,7 +168,7 @@ extern "C" int xo_sbr_dec_hq(const xaac_sbr_header *h, const xaac_sbr_frame *f, 
           int32_t *p = &x(l, 0) + k;
           *p = common_shift < 0 ? fx_shr(*p, -common_shift > 31 ? 31 : -common_shift) : fx_shl_sat(*p, common_shift);
         }
-      xo_qmf_synthesis_slot(&x(l, 0), &s, l, 0, -(st_syn - 3), pcm_out + (size_t)out_stride * 64 * l, out_stride);
+      xo_qmf_synthesis_slot_n(&x(l, 0), &s, l, 0, -(st_syn - 3), pcm_out + (size_t)out_stride * (g_ds ? 32 : 64) * l, out_stride, g_ds);
       memcpy(&x(l, 0), right, sizeof(right));
     }
     /* right channel: all three scales are ps_scale (sbr_dec.c:1261-1264) */
@@ -175,13 +178,13 @@ extern "C" int xo_sbr_dec_hq(const xaac_sbr_header *h, const xaac_sbr_frame *f, 
     r.drc_offset = ps->syn_drc_offset_r;
     r.phase = ps->syn_phase_r;
     const int16_t sf_r[4] = {(int16_t)ps_scale, (int16_t)ps_scale, (int16_t)ps_scale, ps->st_syn_scale_r};
-    xo_qmf_synthesis(&x(0, 0), 128, sf_r, ps->syn_lsb_r, ps->syn_usb_r, 6, &r, 0, pcm_out + 1, out_stride);
+    xo_qmf_synthesis_n(&x(0, 0), 128, sf_r, ps->syn_lsb_r, ps->syn_usb_r, 6, &r, 0, pcm_out + 1, out_stride, g_ds);
     memcpy(ps->syn_ring_r, r.ring, sizeof(r.ring));
     ps->syn_drc_offset_r = r.drc_offset;
     ps->syn_phase_r = r.phase;
   } else {
     const int16_t sf[4] = {st->lb_scale, st->ov_lb_scale, st->hb_scale, st->st_syn_scale};
-    xo_qmf_synthesis(&x(0, 0), 128, sf, st->syn_lsb, st->syn_usb, 6, &s, 0, pcm_out, out_stride);
+    xo_qmf_synthesis_n(&x(0, 0), 128, sf, st->syn_lsb, st->syn_usb, 6, &s, 0, pcm_out, out_stride, g_ds);
   }
   memcpy(st->syn_ring, s.ring, sizeof(s.ring));
   st->syn_drc_offset = s.drc_offset;
@@ -208,4 +211,21 @@ extern "C" int xo_sbr_dec_hq_batch(int n, const xaac_sbr_header *h, const xaac_s
     bad += xo_sbr_dec_hq(h + i, f + i, st + i, pf ? pf + i : nullptr, ps ? ps + i : nullptr, pcm_in + 1024 * (size_t)i, 1,
                          pcm_out + (pf ? 4096 : 2048) * (size_t)i, pf ? 2 : 1) != 0;
   return bad;
+}
+
+/* the same two calls with the down-sampled synthesis bank (1024 output samples per channel) */
+extern "C" int xo_sbr_dec_lp_ds(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st,
+                                const int16_t *pcm_in, int in_stride, int16_t *pcm_out, int out_stride, int ds) {
+  g_ds = ds;
+  const int rc = xo_sbr_dec_lp(h, f, st, pcm_in, in_stride, pcm_out, out_stride);
+  g_ds = 0;
+  return rc;
+}
+extern "C" int xo_sbr_dec_hq_ds(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st,
+                                const xaac_ps_frame *pf, xaac_ps_state *ps, const int16_t *pcm_in, int in_stride,
+                                int16_t *pcm_out, int out_stride, int ds) {
+  g_ds = ds;
+  const int rc = xo_sbr_dec_hq(h, f, st, pf, ps, pcm_in, in_stride, pcm_out, out_stride);
+  g_ds = 0;
+  return rc;
 }

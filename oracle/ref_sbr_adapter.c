@@ -56,6 +56,7 @@
 
 /* one channel-frame through the real ixheaacd_sbr_dec: low-power (HE-AACv1), HQ, or HQ + parametric stereo
    (pf / ps given and channel_mode = PS_STEREO: right channel at pcm_out[n * out_stride + 1]) */
+static int g_down_sample; /* ref_sbr_set_down_sample() */
 static int run_sbr_dec(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st, const xaac_ps_frame *psf,
                        xaac_ps_state *pss, int low_pow, const int16_t *pcm_in, int in_stride, int16_t *pcm_out,
                        int out_stride) {
@@ -150,7 +151,7 @@ static int run_sbr_dec(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_s
   d.str_codec_qmf_bank.core_samples_buffer = ana_ring + st->ana_wr;
   d.str_codec_qmf_bank.analy_win_coeff = qt->qmf_c;
   d.str_codec_qmf_bank.filter_pos = qt->qmf_c + st->ana_phase;
-  d.str_synthesis_qmf_bank.no_channels = 64;
+  d.str_synthesis_qmf_bank.no_channels = g_down_sample ? 32 : 64;
   d.str_synthesis_qmf_bank.num_time_slots = 32;
   d.str_synthesis_qmf_bank.lsb = st->syn_lsb;
   d.str_synthesis_qmf_bank.usb = st->syn_usb;
@@ -242,7 +243,7 @@ static int run_sbr_dec(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_s
     memcpy(psd.iid_par_table, psf->iid_par_table, sizeof(psf->iid_par_table));
     memcpy(psd.icc_par_table, psf->icc_par_table, sizeof(psf->icc_par_table));
     memcpy(syn_ring_r, pss->syn_ring_r, sizeof(syn_ring_r));
-    bank_r.no_channels = 64;
+    bank_r.no_channels = g_down_sample ? 32 : 64;
     bank_r.num_time_slots = 32;
     bank_r.lsb = pss->syn_lsb_r;
     bank_r.usb = pss->syn_usb_r;
@@ -260,7 +261,7 @@ static int run_sbr_dec(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_s
                          (ixheaacd_misc_tables *)&ixheaacd_str_fft_n_transcendent_tables, use_ps ? 2 : 1, NULL, 0, NULL,
                          use_ps ? AOT_PS : AOT_SBR, 0, NULL, 0, 0);
   if (use_ps) {
-    for (i = 0; i < 2048; i++) {
+    for (i = 0; i < (g_down_sample ? 1024 : 2048); i++) {
       pcm_out[(size_t)i * out_stride] = time_data[2 * i];
       pcm_out[(size_t)i * out_stride + 1] = time_data[2 * i + 1];
     }
@@ -292,7 +293,7 @@ static int run_sbr_dec(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_s
     pss->ov_lb_scale_r = sf_r.ov_lb_scale;
     pss->hb_scale_r = sf_r.hb_scale;
   } else {
-    for (i = 0; i < 2048; i++) pcm_out[(size_t)i * out_stride] = time_data[i];
+    for (i = 0; i < (g_down_sample ? 1024 : 2048); i++) pcm_out[(size_t)i * out_stride] = time_data[i];
   }
   /* state back */
   memcpy(st->ana_ring, ana_ring, sizeof(ana_ring));
@@ -330,6 +331,9 @@ static int run_sbr_dec(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_s
   memcpy(st->harm_flags_prev, d.str_sbr_calc_env.harm_flags_prev, sizeof(st->harm_flags_prev));
   return ret;
 }
+
+/* the down-sampled synthesis bank (sbrdec_initfuncs.c:1165: 32 channels) for the following calls */
+void ref_sbr_set_down_sample(int on) { g_down_sample = on; }
 
 int ref_sbr_dec_lp(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st, const int16_t *pcm_in,
                    int in_stride, int16_t *pcm_out, int out_stride) {
