@@ -365,10 +365,11 @@ def main():
             fr, pfr = b["frames"][(i // len(batches)) % len(b["frames"])]
             ctx.sbr_hq_process_batch(b["core_pcm"], b["hdr"], fr, b["sbr_state"], b["pcm"], ws, pfr, b["ps_state"])
         elif c2l:
-            # AAC-LC tail as api.c runs it: interleaved WORD32 block + qshift_adj -> limiter in place -> PCM16
+            # AAC-LC tail as api.c runs it: WORD32 block + qshift_adj -> limiter in place -> interleaved PCM16.  The
+            # block stays planar between the two (16-byte stores from the IMDCT; the limiter interleaves on the way out)
             ctx.imdct_process_batch(b["spec"], b["ics"], b["overlap"], b["state"], b["out32"], None, b["qshift"],
-                                    ch_fac=CH)
-            ctx.peak_limiter_process_batch(b["out32"], b["qshift"], b["lim_state"], CH, ws, pcm16=b["pcm"])
+                                    ch_fac=1)
+            ctx.peak_limiter_process_batch(b["out32"], b["qshift"], b["lim_state"], CH, ws, pcm16=b["pcm"], planar=True)
         else:
             ctx.imdct_process_batch(b["spec"], b["ics"], b["overlap"], b["state"], None, b["pcm"], None,
                                     ch_fac=CH, pcm_mode=libxaac_amd.PCM_LC)

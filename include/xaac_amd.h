@@ -213,7 +213,8 @@ typedef struct xaac_limiter_batch {
   const int8_t *qshift_adj;   /* [n_streams][num_channels], each 0 .. 30 */
   xaac_limiter_state *state;  /* [n_streams] in/out; num_channels must be the same in the whole batch */
   int32_t num_channels;
-  int32_t pad_;
+  int32_t planar;             /* 1: samples is [n_streams][num_channels][frame_len] -- what xaac_imdct_process_batch writes
+                                 with ch_fac = 1 (16-byte stores) -- and stays so in place; pcm16 is interleaved either way */
   int16_t *pcm16;             /* optional [n_streams][frame_len][num_channels]: round16 of the result (dense) */
   int32_t *status;            /* optional [n_streams]: 0, or -1 for a stream whose state does not fit the batch
                                  (num_channels / attack_time_samples out of range): left untouched */

@@ -86,7 +86,7 @@ class _LimiterBatch(ctypes.Structure):
     # struct xaac_limiter_batch
     _fields_ = [("n_streams", ctypes.c_int32), ("frame_len", ctypes.c_int32), ("samples", ctypes.c_void_p),
                 ("stride", ctypes.c_int64), ("qshift_adj", ctypes.c_void_p), ("state", ctypes.c_void_p),
-                ("num_channels", ctypes.c_int32), ("pad_", ctypes.c_int32), ("pcm16", ctypes.c_void_p),
+                ("num_channels", ctypes.c_int32), ("planar", ctypes.c_int32), ("pcm16", ctypes.c_void_p),
                 ("status", ctypes.c_void_p), ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_uint64)]
 
 
@@ -343,7 +343,7 @@ class XaacContext:
         return int(self._lib.xaac_peak_limiter_workspace_bytes(int(n_streams)))
 
     def peak_limiter_process_batch(self, samples, qshift_adj, state, num_channels, workspace, frame_len=1024,
-                                   pcm16=None, stride=None, status=None):
+                                   pcm16=None, stride=None, status=None, planar=False):
         """Batched ixheaacd_peak_limiter_process (+ the round16 hand-off): one frame of every stream.
         samples int32[n_streams * stride] in/out, frame_len x num_channels interleaved per stream (what
         imdct_process_batch leaves in out32); qshift_adj int8[n_streams * num_channels]; state
@@ -354,6 +354,7 @@ class XaacContext:
             stride = frame_len * num_channels
         b = _LimiterBatch()
         b.n_streams, b.frame_len, b.num_channels, b.stride = n, int(frame_len), int(num_channels), int(stride)
+        b.planar = int(bool(planar))
         b.samples = _ptr(samples, "int32", n * stride, device_ok=True)
         b.qshift_adj = _ptr(qshift_adj, "int8", n * num_channels, device_ok=True)
         b.state = _ptr(state, "uint8", n * LIMITER_STATE_BYTES, device_ok=True)

@@ -9,6 +9,7 @@
 
 typedef struct XaacLimiterParams {
   int32_t n_streams, frame_len, num_channels;
+  int32_t planar; /* samples: [channel][frame_len] per stream instead of [frame_len][channel] */
   int32_t *samples;
   int64_t stride;
   const int8_t *qshift_adj;

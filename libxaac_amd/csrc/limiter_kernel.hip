@@ -126,6 +126,26 @@ __device__ __forceinline__ void st_(T *p, const T (&v)[N]) {
 }
 
 
+/* N channels of sample i of a stream's WORD32 block: interleaved [i][channel] (one access) or planar [channel][i] */
+template <int N>
+__device__ __forceinline__ void ld_block(const int32_t *x, int i, int j, int C, int L, bool planar, int32_t (&v)[N]) {
+  if (planar) {
+#pragma unroll
+    for (int c = 0; c < N; c++) v[c] = x[(j + c) * L + i];
+  } else {
+    ld<N>(x + i * C + j, v);
+  }
+}
+template <int N>
+__device__ __forceinline__ void st_block(int32_t *x, int i, int j, int C, int L, bool planar, const int32_t (&v)[N]) {
+  if (planar) {
+#pragma unroll
+    for (int c = 0; c < N; c++) x[(j + c) * L + i] = v[c];
+  } else {
+    st_<N>(x + i * C + j, v);
+  }
+}
+
 /* ---- step 6: gains from `gain_of(i)` applied to the delayed samples of stream s ---- */
 template <int CT, typename GainOf>
 __device__ __forceinline__ void apply_frame(const XaacLimiterParams &p, int s, int lane, bool active, GainOf gain_of) {
@@ -134,6 +154,7 @@ __device__ __forceinline__ void apply_frame(const XaacLimiterParams &p, int s, i
   const int8_t *qs = p.qshift_adj + (int64_t)s * p.num_channels;
   const int C = CT ? CT : p.num_channels, L = p.frame_len;
   const int A = (int)st->attack_time_samples, dii0 = (int)st->delayed_input_index;
+  const bool planar = p.planar != 0;
   constexpr int N = CT == 2 ? 2 : 1;
   const int end_pos = (dii0 + L) % A; /* delayed_input_index after the frame */
   float min_gain = 1.0f;
@@ -163,8 +184,8 @@ __device__ __forceinline__ void apply_frame(const XaacLimiterParams &p, int s, i
         for (int c = 0; c < N; c++) now[k][c] = before[k][c] = 0;
         gain[k] = 1.0f;
         if (i < L) {
-          ld<N>(x + i * C + j, now[k]);
-          if (i >= A) ld<N>(x + (i - A) * C + j, before[k]);
+          ld_block<N>(x, i, j, C, L, planar, now[k]);
+          if (i >= A) ld_block<N>(x, i - A, j, C, L, planar, before[k]);
           gain[k] = gain_of(i);
         }
       }
@@ -184,7 +205,7 @@ __device__ __forceinline__ void apply_frame(const XaacLimiterParams &p, int s, i
             keep[c] = xl_scaled(now[k][c], q[c]);
           }
           if (active) min_gain = gain[k] < min_gain ? gain[k] : min_gain;
-          st_<N>(x + i * C + j, v);
+          st_block<N>(x, i, j, C, L, planar, v);
           if (p.pcm16) st_<N>(p.pcm16 + ((int64_t)s * L + i) * C + j, v16);
           if (i >= L - A) { /* one of the frame's last attack_time_samples inputs: stays in the delay line */
             int pos = end_pos - (L - i);
@@ -247,7 +268,9 @@ __global__ __launch_bounds__(64) void xaac_limiter_front_kernel(XaacLimiterParam
     const int i = lane + 64 * k;
     float tmp = 0.0f;
     if (i < L) {
-      if (CT == 2) {
+      if (p.planar) {
+        for (int j = 0; j < C; j++) tmp = xl_peak(tmp, x[j * L + i], qs[j]);
+      } else if (CT == 2) {
         const int2 v = reinterpret_cast<const int2 *>(x)[i];
         tmp = xl_peak(xl_peak(tmp, v.x, qs[0]), v.y, qs[1]);
       } else {

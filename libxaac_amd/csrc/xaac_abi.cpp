@@ -390,6 +390,7 @@ int32_t xaac_peak_limiter_process_batch(xaac_ctx *c, const xaac_limiter_batch *b
   p.ws_gain = reinterpret_cast<float *>(((uintptr_t)b->workspace + 255) & ~(uintptr_t)255);
   p.ws_flag = reinterpret_cast<int32_t *>(p.ws_gain + (size_t)b->n_streams * 1024);
   p.n_streams = b->n_streams; p.frame_len = b->frame_len; p.num_channels = b->num_channels;
+  p.planar = b->planar ? 1 : 0;
   p.samples = b->samples; p.stride = b->stride; p.qshift_adj = b->qshift_adj; p.state = b->state;
   p.pcm16 = b->pcm16; p.status = b->status;
   p.dbg = reinterpret_cast<long long *>(b->status); /* phase timers of -DXL_PROFILE builds (tools/time_limiter.py) */

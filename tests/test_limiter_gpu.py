@@ -225,3 +225,35 @@ def test_full_size_batch_and_empty_batch(ctx, oracle):
         ctx.peak_limiter_process_batch(xg, torch.zeros(n * 9, dtype=torch.int8, device="cuda"), st, 9, ws, stride=2048)
     with pytest.raises(libxaac_amd.XaacError):
         ctx.peak_limiter_process_batch(xg, torch.zeros(n * nch, dtype=torch.int8, device="cuda"), st, nch, ws[:1000])
+
+
+@pytest.mark.parametrize("nch,frame_len", [(2, 1024), (1, 1024), (3, 600)])
+def test_planar_block_layout(ctx, oracle, nch, frame_len):
+    """planar = 1: the WORD32 block is [channel][frame_len] (what the IMDCT writes with ch_fac = 1); same results,
+    PCM16 interleaved as always"""
+    import torch
+    init, _, batch = lc.bind(oracle.lib, "xo")
+    n = 2 * len(lc.KINDS)
+    rng = np.random.default_rng(5 + nch)
+    so = (lc.LimiterState * n)()
+    for i in range(n):
+        init(ctypes.byref(so[i]), nch, 48000)
+    st = states_to_tensor(so, torch)
+    ws = torch.zeros(ctx.peak_limiter_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    pcm = torch.zeros(n * frame_len * nch, dtype=torch.int16, device="cuda")
+    for frame in range(4):
+        x = np.stack([lc.signal(rng, lc.KINDS[(i + frame) % len(lc.KINDS)], frame_len, nch) for i in range(n)])
+        q = rng.integers(1, 3, (n, nch)).astype(np.int8)
+        xo, po = x.reshape(-1).copy(), np.zeros(n * frame_len * nch, np.int16)
+        batch(n, frame_len, nch, xo.ctypes.data_as(lc.P32), frame_len * nch, q.ctypes.data_as(lc.P8), so, po.ctypes.data_as(lc.P16))
+        xp = np.ascontiguousarray(x.reshape(n, frame_len, nch).transpose(0, 2, 1))      # [stream][channel][sample]
+        xg = torch.from_numpy(xp.reshape(-1)).cuda()
+        ctx.peak_limiter_process_batch(xg, torch.from_numpy(q.reshape(-1)).cuda(), st, nch, ws, frame_len=frame_len, pcm16=pcm,
+                                       planar=True)
+        ctx.sync()
+        got = xg.cpu().numpy().reshape(n, nch, frame_len).transpose(0, 2, 1).reshape(-1)
+        assert np.array_equal(got, xo), frame
+        assert np.array_equal(pcm.cpu().numpy(), po), frame
+    sg = tensor_to_states(st, n)
+    for i in range(n):
+        assert lc.state_view(sg[i]) == lc.state_view(so[i]), i
