@@ -13,7 +13,7 @@
 /* analysis: 2 x 1312 int16 history (+pad) and a 64 x 65 int32 exchange tile */
 #define XAAC_QMF_ANA_LDS_PER_WAVE (2 * 1312 * 2 + 32 + 64 * 65 * 4)
 /* synthesis: max(row tile, ring-sample store) ; row tile 64 x (64|128)+1 words, store 2 x 41 x 128 int16 */
-#define XAAC_QMF_SYN_LDS_PER_WAVE_LP 20992
+#define XAAC_QMF_SYN_LDS_PER_WAVE_LP 21376 /* 2 channels x 41 slots x (128 + 2) ring samples, rounded up */
 #define XAAC_QMF_SYN_LDS_PER_WAVE_HQ (64 * 129 * 4)
 
 /* state / qmf / scale are addressed with explicit per-channel strides so that the same kernels serve the

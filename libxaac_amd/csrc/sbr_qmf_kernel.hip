@@ -208,11 +208,13 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
   constexpr int NC = DS ? 32 : 64;      /* synthesis channels = output samples per slot */
   constexpr int BLK = 2 * NC;           /* ring samples one slot adds */
   constexpr int RING = 10 * BLK;
+  constexpr int VROW = BLK + 2;         /* LDS stride of a slot's ring samples: odd in dwords, so that the 64 lanes
+                                           writing their slots (lane = slot) land in different banks */
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   char *wbase = smem + wave * (LP ? XAAC_QMF_SYN_LDS_PER_WAVE_LP : XAAC_QMF_SYN_LDS_PER_WAVE_HQ);
   int32_t *rows = reinterpret_cast<int32_t *>(wbase);  /* [64][RS] slot rows, later aliased by ... */
-  int16_t *v = reinterpret_cast<int16_t *>(wbase);     /* ... [2][VSLOTS][BLK] ring samples */
+  int16_t *v = reinterpret_cast<int16_t *>(wbase);     /* ... [2][VSLOTS][VROW] ring samples */
 
   int32_t coef[10]; /* c[64 A + k], k = lane; down-sampled: every second one, k = lane & 31 (qmf_dec.c:749) */
 #pragma unroll
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
        re-used through an int16 view: keep the compiler from moving accesses across this point) */
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     {
-      int16_t *dst = v + ((lane >> 5) * VSLOTS + 9 + (lane & 31)) * BLK;
+      int16_t *dst = v + ((lane >> 5) * VSLOTS + 9 + (lane & 31)) * VROW;
 #pragma unroll
       for (int i = 0; i < BLK; i += 2)
         *reinterpret_cast<int32_t *>(dst + i) = (int32_t)((uint32_t)(uint16_t)b[i] | ((uint32_t)(uint16_t)b[i + 1] << 16));
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
 #pragma unroll
       for (int j = 0; j < HJ; j++) {
         const int i = lane + 64 * j;
-        v[(c * VSLOTS + i / BLK) * BLK + i % BLK] = hist[j];
+        v[(c * VSLOTS + i / BLK) * VROW + i % BLK] = hist[j];
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -325,10 +327,10 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
       /* a wave covers one slot of 64 samples, or two slots of 32 */
       for (int s0 = 0; s0 < 32; s0 += 64 / NC) {
         const int s = DS ? s0 + (lane >> 5) : s0, k = DS ? (lane & 31) : lane;
-        const int16_t *vs = v + (c * VSLOTS + 9 + s) * BLK + k;
+        const int16_t *vs = v + (c * VSLOTS + 9 + s) * VROW + k;
         int32_t acc = 0x8000 >> shift;
 #pragma unroll
-        for (int A = 0; A < 10; A++) acc += (int32_t)vs[-BLK * A + NC * (A & 1)] * coef[A]; /* < 2^31: exact */
+        for (int A = 0; A < 10; A++) acc += (int32_t)vs[-VROW * A + NC * (A & 1)] * coef[A]; /* < 2^31: exact */
         dst[(size_t)(NC * s + k) * cf] = (int16_t)(fx_shl_sat(acc, shift) >> 16);
       }
     }
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
         int pos = d_new + BLK * A + i % BLK;
         if (pos >= RING) pos -= RING;
         if (pos >= RING) pos -= RING;
-        st->ring[pos] = v[(c * VSLOTS + 9 + 32 - A) * BLK + i % BLK];
+        st->ring[pos] = v[(c * VSLOTS + 9 + 32 - A) * VROW + i % BLK];
       }
       if (lane == 0) {
         st->drc_offset = (int16_t)d_new;
