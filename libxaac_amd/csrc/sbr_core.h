@@ -272,6 +272,45 @@ FX_HD int xs_clz64(uint64_t v) { return __builtin_clzll(v); } /* v != 0 */
 FX_HD int xs_ctz64(uint64_t v) { return __builtin_ctzll(v); } /* v != 0 */
 FX_HD uint64_t xs_mask_upto(int k) { return ((uint64_t)2 << k) - 1; } /* bits 0..k, k <= 63 */
 
+/* ---- the order-dependent pseudo-float sums, split into what is a recursion and what is not ------------------
+ * xs_acc_me over a sequence (m_1, e_1), (m_2, e_2), ... from (0, 0) leaves ae = E_n and am = F_n with
+ *     E_k = max(0, e_1 .. e_k),      F_k = (F_{k-1} >> (E_k - E_{k-1})) + (m_k >> (E_k - e_k)).
+ * The running exponents E_k are a prefix maximum -- associative, so a scan over the lanes --, the addends
+ * c_k = m_k >> (E_k - e_k) and the shifts d_k = E_k - E_{k-1} follow per element in parallel, and only
+ * F_k = (F_{k-1} >> d_k) + c_k stays sequential: two dependent operations per element instead of the dozen of
+ * the compare / select / shift / add form.  Exact: it is the same arithmetic in the same order. */
+
+/* inclusive prefix maximum over the lanes: element k = max of elements 0..k */
+FX_HD XsLv xs_prefix_max(const XsCx &cx, const XsLv &s) {
+  XsLv r = s;
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (int d = 1; d < 64; d <<= 1) {
+    const int32_t t = __shfl_up(r.v, d);
+    if (cx.lane >= d) r.v = t > r.v ? t : r.v;
+  }
+#else
+  for (int k = 1; k < 64; k++) r.a[k] = r.a[k - 1] > r.a[k] ? r.a[k - 1] : r.a[k];
+#endif
+  return r;
+}
+
+/* E before element k: max(0, e_j) over the elements j < k of k's segment.  seg: segment of each element, non-decreasing
+   along the lanes, -1 = not in a sum.  |e| < 2^14 (exponents of the envelope adjuster are within +-100). */
+FX_HD XsLv xs_seg_running_max(const XsCx &cx, const XsLv &seg, const XsLv &e, int n) {
+  XsLv key;
+  key.fill(0);
+  XS_LANES(k, 0, n) key.own(k) = seg.own(k) >= 0 ? ((seg.own(k) + 1) << 16) | ((e.own(k) + 0x4000) & 0xffff) : 0;
+  const XsLv before = xs_prefix_max(cx, key).shifted(cx, -1);
+  XsLv r;
+  r.fill(0);
+  XS_LANES(k, 0, n) {
+    const int32_t p = before.own(k);
+    const int32_t ep = (p & 0xffff) - 0x4000;
+    r.own(k) = ((p >> 16) == seg.own(k) + 1 && ep > 0) ? ep : 0;
+  }
+  return r;
+}
+
 /* ---- QMF matrix view: rows -2,-1 are the LPC history, rows 0..37 the slots.  Low-power mode keeps 64
    real values per slot; HQ mode keeps 64 real then 64 imaginary ones (the reference's slot-pointer
    arrays over one scratch block, sbr_dec.c:752-766, have exactly these strides). */
@@ -864,17 +903,68 @@ FX_HD void xs_noiselimiting(const XsCx &cx, const xaac_sbr_header *h, int skip, 
                             const int16_t *lim_tab, int noise_absc) {
   const int16_t lim_m = lim_tab[0], lim_e = lim_tab[1];
   const int nlf = cx.uni(h->num_lf_bands);
+  /* band k belongs to the limiter band with tbl_lim[c] <= k + skip < tbl_lim[c + 1] (the last such c, as
+     the reference's loop over c would apply them in order; the bands are disjoint and in band order) */
+  XsLv limv;
+  limv.fill(0);
+  XS_LANES(i, 0, nlf + 1) limv.own(i) = h->freq_band_tbl_lim[i];
+  XsLv mine;
+  mine.fill(-1);
   XS_LANES(k, 0, n_bands) {
-    w->fold_a[k][0] = v.e_orig.own(k);
-    w->fold_a[k][1] = v.est.own(k);
+    int c_of = -1;
+    for (int c = 0; c < nlf; c++) {
+      const int t_lo = limv.get(c), t_hi = limv.get(c + 1);
+      const int b0 = t_lo > skip ? t_lo - skip : 0, b1 = t_hi > skip ? t_hi - skip : 0;
+      if (k >= b0 && k < b1) c_of = c;
+    }
+    mine.own(k) = c_of;
+  }
+  /* env_calc.c:1454 (avggain, flag 0) per limiter band: sum of e_orig and sum of est -- addends and exponent steps of
+     both sums per band here, the two-operation recursions per limiter band below */
+  {
+    XsLv eo, ee;
+    eo.fill(0);
+    ee.fill(0);
+    XS_LANES(k, 0, n_bands) {
+      eo.own(k) = xs_e(v.e_orig.own(k));
+      ee.own(k) = xs_e(v.est.own(k));
+    }
+    const XsLv po = xs_seg_running_max(cx, mine, eo, n_bands), pe = xs_seg_running_max(cx, mine, ee, n_bands);
+    XS_LANES(k, 0, n_bands) {
+      const int Eo = eo.own(k) > po.own(k) ? eo.own(k) : po.own(k), Ee = ee.own(k) > pe.own(k) ? ee.own(k) : pe.own(k);
+      w->fold_b[k][0] = fx_shr(xs_m(v.e_orig.own(k)), Eo - eo.own(k));
+      w->fold_b[k][1] = fx_shr(xs_m(v.est.own(k)), Ee - ee.own(k));
+      w->fold_b[k][2] = ((Eo - po.own(k)) & 0xff) | (((Ee - pe.own(k)) & 0xff) << 8); /* shr32 masks its count so */
+      w->fold_b[k][3] = (Eo & 0xffff) | (int32_t)((uint32_t)Ee << 16);
+    }
   }
   cx.sync();
   XS_PAR(c, 0, nlf) {
     const int t_lo = h->freq_band_tbl_lim[c], t_hi = h->freq_band_tbl_lim[c + 1];
     const int b0 = t_lo > skip ? t_lo - skip : 0, b1 = t_hi > skip ? t_hi - skip : 0;
     if (b0 >= b1) continue;
-    int16_t so_m, so_e, mg_m, mg_e;
-    xs_avggain(w->fold_a, b0, b1, &so_m, &so_e, &mg_m, &mg_e, 0);
+    int32_t som = 0, sem = 0, last = 0;
+    XS_UNROLL4
+    for (int k = b0; k < b1; k++) {
+      const int32_t d = w->fold_b[k][2];
+      som = fx_shr(som, d & 255) + w->fold_b[k][0];
+      sem = fx_shr(sem, d >> 8) + w->fold_b[k][1];
+      last = w->fold_b[k][3];
+    }
+    int32_t soe = (int16_t)last, see = last >> 16;
+    int nv = 16 - xs_pnorm32(som);
+    if (nv > 0) {
+      som >>= nv;
+      soe += nv;
+    }
+    nv = 16 - xs_pnorm32(sem);
+    if (nv > 0) {
+      sem >>= nv;
+      see += nv;
+    }
+    const int16_t so_m = (int16_t)som, so_e = (int16_t)soe;
+    int16_t mg_m;
+    int16_t mg_e = (int16_t)(xs_fix_mant_div(so_m, (int16_t)sem, &mg_m) + (so_e - (int16_t)see) + 1);
     int32_t mt = xs_mult16x16_shl(mg_m, lim_m);
     mg_e = (int16_t)(mg_e + lim_e);
     int tv = fx_norm32(mt);
@@ -891,39 +981,53 @@ FX_HD void xs_noiselimiting(const XsCx &cx, const xaac_sbr_header *h, int skip, 
   }
   cx.sync();
   XS_T(16);
-  /* band k belongs to the limiter band with tbl_lim[c] <= k + skip < tbl_lim[c + 1] (the last such c, as
-     the reference's loop over c would apply them in order; the bands are disjoint) */
-  XsLv limv;
-  limv.fill(0);
-  XS_LANES(i, 0, nlf + 1) limv.own(i) = h->freq_band_tbl_lim[i];
-  XsLv mine;
-  mine.fill(-1);
-  XS_LANES(k, 0, n_bands) {
-    int c_of = -1;
-    for (int c = 0; c < nlf; c++) {
-      const int t_lo = limv.get(c), t_hi = limv.get(c + 1);
-      const int b0 = t_lo > skip ? t_lo - skip : 0, b1 = t_hi > skip ? t_hi - skip : 0;
-      if (k >= b0 && k < b1) c_of = c;
+  /* the gain limit per band; then the sum of what the limited gains, sines and noise deliver (env_calc.c:330-390):
+     up to two addends per band, in band order */
+  {
+    XsLv a_m, a_e, b_me, emax, with_b;
+    a_m.fill(0);
+    a_e.fill(0);
+    b_me.fill(0);
+    emax.fill(0);
+    with_b.fill(0);
+    XS_LANES(k, 0, n_bands) {
+      const int c_of = mine.own(k);
+      if (c_of < 0) continue;
+      const int16_t mg_m = w->res_a[c_of][0], mg_e = w->res_a[c_of][1];
+      int16_t gm = xs_m(v.gain.own(k)), ge = xs_e(v.gain.own(k));
+      if (ge > mg_e || (ge == mg_e && gm > mg_m)) {
+        int16_t na_m;
+        int na_e = xs_fix_mant_div(mg_m, gm, &na_m);
+        na_e += (mg_e - ge) + 1;
+        const int32_t nl = v.noise.own(k);
+        v.noise.own(k) =
+            xs_me((int16_t)(fx_shl_dir_sat_limit(xs_mult16x16_shl(xs_m(nl), na_m), (int16_t)na_e) >> 16), xs_e(nl));
+        gm = mg_m;
+        ge = mg_e;
+        v.gain.own(k) = xs_me(gm, ge);
+      }
+      a_m.own(k) = ((int32_t)gm * xs_m(v.est.own(k))) >> 15;
+      a_e.own(k) = ge + xs_e(v.est.own(k));
+      /* the second addend: the sine if there is one, else the noise unless it is absent (noise_absc) */
+      const int32_t sn = v.sine.own(k);
+      b_me.own(k) = xs_m(sn) != 0 ? sn : (noise_absc == 0 ? v.noise.own(k) : 0);
+      const bool has_b = xs_m(sn) != 0 || noise_absc == 0;
+      emax.own(k) = (has_b && xs_e(b_me.own(k)) > a_e.own(k)) ? xs_e(b_me.own(k)) : a_e.own(k);
+      with_b.own(k) = has_b ? 1 : 0;
     }
-    mine.own(k) = c_of;
-    if (c_of < 0) continue;
-    const int16_t mg_m = w->res_a[c_of][0], mg_e = w->res_a[c_of][1];
-    int16_t gm = xs_m(v.gain.own(k)), ge = xs_e(v.gain.own(k));
-    if (ge > mg_e || (ge == mg_e && gm > mg_m)) {
-      int16_t na_m;
-      int na_e = xs_fix_mant_div(mg_m, gm, &na_m);
-      na_e += (mg_e - ge) + 1;
-      const int32_t nl = v.noise.own(k);
-      v.noise.own(k) =
-          xs_me((int16_t)(fx_shl_dir_sat_limit(xs_mult16x16_shl(xs_m(nl), na_m), (int16_t)na_e) >> 16), xs_e(nl));
-      gm = mg_m;
-      ge = mg_e;
-      v.gain.own(k) = xs_me(gm, ge);
+    const XsLv pm = xs_seg_running_max(cx, mine, emax, n_bands);
+    XS_LANES(k, 0, n_bands) {
+      if (mine.own(k) < 0) continue;
+      const int has_b = with_b.own(k);
+      const int E0 = pm.own(k);
+      const int E1 = a_e.own(k) > E0 ? a_e.own(k) : E0;
+      const int eb = xs_e(b_me.own(k));
+      const int E2 = (has_b && eb > E1) ? eb : E1;
+      w->fold_b[k][0] = fx_shr(a_m.own(k), E1 - a_e.own(k));
+      w->fold_b[k][1] = has_b ? fx_shr(xs_m(b_me.own(k)), E2 - eb) : 0;
+      w->fold_b[k][2] = ((E1 - E0) & 0xff) | (((E2 - E1) & 0xff) << 8);
+      w->fold_b[k][3] = E2;
     }
-    w->fold_b[k][0] = ((int32_t)gm * xs_m(v.est.own(k))) >> 15;
-    w->fold_b[k][1] = ge + xs_e(v.est.own(k));
-    w->fold_b[k][2] = v.sine.own(k);
-    w->fold_b[k][3] = v.noise.own(k);
   }
   cx.sync();
   XS_T(17);
@@ -933,15 +1037,12 @@ FX_HD void xs_noiselimiting(const XsCx &cx, const xaac_sbr_header *h, int skip, 
     if (b0 >= b1) continue;
     const int16_t so_m = w->res_a[c][2], so_e = w->res_a[c][3];
     int32_t am = 0, ae = 0;
+    XS_UNROLL4
     for (int k = b0; k < b1; k++) {
-      xs_acc_me(&am, &ae, w->fold_b[k][0], w->fold_b[k][1]);
-      const int32_t sn = w->fold_b[k][2];
-      if (xs_m(sn) != 0) {
-        xs_acc_me(&am, &ae, xs_m(sn), xs_e(sn));
-      } else if (noise_absc == 0) {
-        const int32_t nl = w->fold_b[k][3];
-        xs_acc_me(&am, &ae, xs_m(nl), xs_e(nl));
-      }
+      const int32_t d = w->fold_b[k][2];
+      am = fx_shr(am, d & 255) + w->fold_b[k][0];
+      am = fx_shr(am, d >> 8) + w->fold_b[k][1];
+      ae = w->fold_b[k][3];
     }
     int nv = 16 - fx_norm32(am);
     if (nv > 0) {
