@@ -280,14 +280,25 @@ FX_HD uint64_t xs_mask_upto(int k) { return ((uint64_t)2 << k) - 1; } /* bits 0.
  * F_k = (F_{k-1} >> d_k) + c_k stays sequential: two dependent operations per element instead of the dozen of
  * the compare / select / shift / add form.  Exact: it is the same arithmetic in the same order. */
 
-/* inclusive prefix maximum over the lanes: element k = max of elements 0..k */
+/* inclusive prefix maximum over the lanes: element k = max of elements 0..k (elements >= 0) */
 FX_HD XsLv xs_prefix_max(const XsCx &cx, const XsLv &s) {
   XsLv r = s;
 #if defined(__HIP_DEVICE_COMPILE__)
-  for (int d = 1; d < 64; d <<= 1) {
-    const int32_t t = __shfl_up(r.v, d);
-    if (cx.lane >= d) r.v = t > r.v ? t : r.v;
+  /* elements are >= 0 (0 = nothing): the data-parallel-primitive shifts feed 0 into the lanes without a source.
+     Inside each row of 16 by shifts of 1, 2, 4, 8; then every row takes the last element of the rows below it. */
+#define XS_DPP_MAX(ctrl, rows)                                                      \
+  {                                                                                 \
+    const int32_t t_ = __builtin_amdgcn_update_dpp(0, r.v, ctrl, rows, 0xf, false); \
+    r.v = t_ > r.v ? t_ : r.v;                                                      \
   }
+  XS_DPP_MAX(0x111, 0xf) /* row_shr:1 */
+  XS_DPP_MAX(0x112, 0xf) /* row_shr:2 */
+  XS_DPP_MAX(0x114, 0xf) /* row_shr:4 */
+  XS_DPP_MAX(0x118, 0xf) /* row_shr:8 */
+  XS_DPP_MAX(0x142, 0xa) /* row_bcast:15 into rows 1 and 3 */
+  XS_DPP_MAX(0x143, 0xc) /* row_bcast:31 into rows 2 and 3 */
+#undef XS_DPP_MAX
+  (void)cx;
 #else
   for (int k = 1; k < 64; k++) r.a[k] = r.a[k - 1] > r.a[k] ? r.a[k - 1] : r.a[k];
 #endif
