@@ -157,18 +157,31 @@ struct XsCx {
     __syncthreads();
 #endif
   }
+  /* wave reductions of idempotent operations, in the VALU's data-parallel-primitive lanes (no LDS round trips):
+     butterfly inside each row of 16, then the row results ripple up; lane 63 ends with the total.  A lane without
+     a source keeps its own value, which idempotence makes harmless. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define XS_DPP_REDUCE(OP)                                                            \
+  {                                                                                  \
+    int32_t t_;                                                                      \
+    t_ = __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false); v = OP;  /* quad_perm [1,0,3,2] */ \
+    t_ = __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false); v = OP;  /* quad_perm [2,3,0,1] */ \
+    t_ = __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false); v = OP; /* row_half_mirror */      \
+    t_ = __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false); v = OP; /* row_mirror */           \
+    t_ = __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false); v = OP; /* row_bcast:15 */         \
+    t_ = __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false); v = OP; /* row_bcast:31 */         \
+    v = __builtin_amdgcn_readlane(v, 63);                                            \
+  }
+#endif
   FX_MEMBER int32_t wave_or(int32_t v) const {
 #if defined(__HIP_DEVICE_COMPILE__)
-    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
+    XS_DPP_REDUCE(v | t_)
 #endif
     return v;
   }
   FX_MEMBER int32_t wave_max(int32_t v) const {
 #if defined(__HIP_DEVICE_COMPILE__)
-    for (int o = 32; o > 0; o >>= 1) {
-      int32_t t = __shfl_xor(v, o);
-      v = t > v ? t : v;
-    }
+    XS_DPP_REDUCE(t_ > v ? t_ : v)
 #endif
     return v;
   }
