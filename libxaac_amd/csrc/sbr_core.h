@@ -1463,6 +1463,7 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
     int16_t nl = xs_m(noise_i.own(i));
     int16_t fbm = st->filt_buf_me[2 * i], fbn = st->filt_buf_noise_m[i];
     int ne = noise_e, fbe = fb_noise_e0, ph = ph0, harm = harm0;
+    int32_t rp_next = xaac_sbr_rand_ph[ph + 1 + (k >= 0 ? k : 0)]; /* fetched one slot ahead: the table is in global memory */
     for (int l = s0; l < s1; l++) {
       int scale_change;
       if (l < 32) {
@@ -1477,10 +1478,11 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
       }
       fbn = xs_noise_rescale(fbn, fbe - ne);
       fbe = ne;
-      const int32_t rp = xaac_sbr_rand_ph[ph + 1 + (k >= 0 ? k : 0)];
+      const int32_t rp = rp_next;
       const int hi = harm;
       ph = (ph + bands) & 511;
       harm = (harm + 1) & 3;
+      rp_next = xaac_sbr_rand_ph[ph + 1 + (k >= 0 ? k : 0)];
       if (k < 0) continue;
       const int16_t smooth = (l - s0) < smooth_length ? xaac_sbr_smooth_filter[l - s0] : (int16_t)0;
       int16_t sg = gm, snz = nl;
