@@ -75,6 +75,12 @@ FX_HD int32_t xs_shr_dir_sat_limit(int32_t a, int b) {
 }
 
 /* ---- pseudo-float helpers (ixheaacd_basic_funcs.c) ------------------------------------------- */
+/* The reciprocal and square-root tables sit on the serial paths of the envelope adjuster (one dependent lookup per
+   pseudo-float divide); the GPU core kernel points these at its LDS copies before including this file. */
+#ifndef XS_TAB_INV
+#define XS_TAB_INV(i) xaac_sbr_inv_table[i]
+#define XS_TAB_SQRT(i) xaac_sbr_sqrt_table[i]
+#endif
 FX_HD int xs_fix_mant_div(int16_t op1, int16_t op2, int16_t *res) {
   int pre = fx_norm32(op2) - 16, post;
   int idx = xs_sar(xs_shl(op2, pre), 16 - 3 - 8) & 511;
@@ -83,7 +89,7 @@ FX_HD int xs_fix_mant_div(int16_t op1, int16_t op2, int16_t *res) {
     *res = (int16_t)xs_shl(op1, post);
   } else {
     idx = (idx - 1) >> 1;
-    int32_t ratio = (int32_t)xaac_sbr_inv_table[idx] * op1;
+    int32_t ratio = (int32_t)XS_TAB_INV(idx) * op1;
     post = fx_norm32(ratio) - 1;
     *res = (int16_t)(xs_shl(ratio, post) >> 15);
   }
@@ -96,7 +102,7 @@ FX_HD void xs_mant_exp_sqrt(int16_t *me) {
     int pre = fx_norm32((int16_t)m) - 16;
     e -= pre;
     int idx = xs_sar(xs_shl(m, pre), 16 - 3 - 8) & 511;
-    rm = xaac_sbr_sqrt_table[idx >> 1];
+    rm = XS_TAB_SQRT(idx >> 1);
     if (e & 1) {
       rm = (rm * 0x5a82) >> 16;
       e += 3;

@@ -35,6 +35,12 @@ __shared__ long long xs_prof_acc[32];
     }                                             \
   } while (0)
 #endif
+/* LDS copies of the two tables behind every pseudo-float divide / square root (sbr_core.h: XS_TAB_*): a lookup in
+   global memory on those serial paths costs its latency each time */
+__shared__ int16_t xs_lds_inv_table[256];
+__shared__ int16_t xs_lds_sqrt_table[258];
+#define XS_TAB_INV(i) xs_lds_inv_table[i]
+#define XS_TAB_SQRT(i) xs_lds_sqrt_table[i]
 #include "sbr_core.h"
 #include "sbr_core_kernel.h"
 
@@ -68,7 +74,7 @@ struct XsLds {
   int32_t f_head[kFrameHeadBytes / 4];
   int32_t noise_floor[sizeof(((xaac_sbr_frame *)0)->int_noise_floor) / 4];
   XsWork w;
-  int16_t rand_hi[568]; /* xaac_sbr_rand_ph >> 16 */
+  int16_t rand_hi[HQ ? 4 : 568]; /* xaac_sbr_rand_ph >> 16 (the low-power slot loop; HQ reads the 32-bit table ahead) */
 };
 
 /* global -> LDS (or back): eight loads are in flight before the first store, so a copy costs one memory
@@ -115,7 +121,10 @@ __global__ __launch_bounds__(64) void xaac_sbr_core_kernel(XaacSbrCoreParams p) 
     if (lane < 2) m[lane] = gstw[kHeadOff / 4 + lane];
     copy_words(m + 2, gstw + kTailOff / 4, kTailWords, lane);
   }
-  for (int i = lane; i < 568; i += 64) s.rand_hi[i] = (int16_t)(xaac_sbr_rand_ph[i] >> 16);
+  if (!HQ)
+    for (int i = lane; i < 568; i += 64) s.rand_hi[i] = (int16_t)(xaac_sbr_rand_ph[i] >> 16);
+  for (int i = lane; i < 256; i += 64) xs_lds_inv_table[i] = xaac_sbr_inv_table[i];
+  for (int i = lane; i < 257; i += 64) xs_lds_sqrt_table[i] = xaac_sbr_sqrt_table[i];
   for (int i = lane; i < 2 * ROW; i += 64) {
     s.x[i] = 0;
     s.x[XW + (i & 127)] = 0;
