@@ -929,18 +929,17 @@ FX_HD void xs_avggain(const int32_t (*ab)[2], int b0, int b1, int16_t *o_mant, i
 /* env_calc.c:229.  Two kinds of steps alternate: per-band ones (lane = band) and the order-dependent
    pseudo-float sums over a limiter band (lane = limiter band, all limiter bands at once); they hand
    their operands / results over through w->fold_* / w->res_*. */
-FX_HD void xs_noiselimiting(const XsCx &cx, const xaac_sbr_header *h, int skip, int n_bands, XsEnv &v, XsWork *w,
-                            const int16_t *lim_tab, int noise_absc) {
-  const int16_t lim_m = lim_tab[0], lim_e = lim_tab[1];
+/* which limiter band each band k (band max_qmf_subband_aac + k) belongs to: tbl_lim[c] <= k + skip < tbl_lim[c + 1]
+   (the last such c, as the reference's loop over c would apply them in order; the bands are disjoint and in band
+   order); -1 outside.  The same for every envelope of a frame. */
+FX_HD XsLv xs_limiter_band_of(const XsCx &cx, const xaac_sbr_header *h, int skip) {
   const int nlf = cx.uni(h->num_lf_bands);
-  /* band k belongs to the limiter band with tbl_lim[c] <= k + skip < tbl_lim[c + 1] (the last such c, as
-     the reference's loop over c would apply them in order; the bands are disjoint and in band order) */
   XsLv limv;
   limv.fill(0);
   XS_LANES(i, 0, nlf + 1) limv.own(i) = h->freq_band_tbl_lim[i];
   XsLv mine;
   mine.fill(-1);
-  XS_LANES(k, 0, n_bands) {
+  XS_LANES(k, 0, 64) {
     int c_of = -1;
     for (int c = 0; c < nlf; c++) {
       const int t_lo = limv.get(c), t_hi = limv.get(c + 1);
@@ -949,6 +948,16 @@ FX_HD void xs_noiselimiting(const XsCx &cx, const xaac_sbr_header *h, int skip, 
     }
     mine.own(k) = c_of;
   }
+  return mine;
+}
+
+FX_HD void xs_noiselimiting(const XsCx &cx, const xaac_sbr_header *h, int skip, int n_bands, XsEnv &v, XsWork *w,
+                            const int16_t *lim_tab, int noise_absc, const XsLv &band_of) {
+  const int16_t lim_m = lim_tab[0], lim_e = lim_tab[1];
+  const int nlf = cx.uni(h->num_lf_bands);
+  XsLv mine;
+  mine.fill(-1);
+  XS_LANES(k, 0, n_bands) mine.own(k) = band_of.own(k);
   /* env_calc.c:1454 (avggain, flag 0) per limiter band: sum of e_orig and sum of est -- addends and exponent steps of
      both sums per band here, the two-operation recursions per limiter band below */
   {
@@ -1793,6 +1802,7 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
   int m = 0, nf_idx = 0;
   const int tansient_env_prev = cx.uni(st->tansient_env_prev);
   const int hb_scale = cx.uni(st->hb_scale), lb_scale = cx.uni(st->lb_scale);
+  const XsLv lim_of = xs_limiter_band_of(cx, h, skip);
   for (int i = 0; i < num_env; i++) {
     const int s0 = 2 * cx.uni(border[i]), s1 = 2 * cx.uni(border[i + 1]);
     if (s0 >= 38 || s1 > 38) return -1;
@@ -1818,7 +1828,7 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
     xs_calc_subband_gains(cx, env_sf_all, noise_floor, m, i, n_meta, skip, v, noise_absc);
     m += nsf;
     XS_T(6);
-    xs_noiselimiting(cx, h, skip, n_meta, v, w, &xaac_sbr_lim_gains_m[2 * cx.uni(h->limiter_gains)], noise_absc);
+    xs_noiselimiting(cx, h, skip, n_meta, v, w, &xaac_sbr_lim_gains_m[2 * cx.uni(h->limiter_gains)], noise_absc, lim_of);
     XS_T(7);
     const int16_t noise_e = (int16_t)(s0 < 32 ? adj_e : final_e);
     if constexpr (!Q::HQ) {
