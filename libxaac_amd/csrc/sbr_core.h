@@ -325,18 +325,18 @@ FX_HD XsLv xs_prefix_max(const XsCx &cx, const XsLv &s) {
 }
 
 /* E before element k: max(0, e_j) over the elements j < k of k's segment.  seg: segment of each element, non-decreasing
-   along the lanes, -1 = not in a sum.  |e| < 2^14 (exponents of the envelope adjuster are within +-100). */
+   along the lanes and below 2^10, -1 = not in a sum.  |e| < 2^19: any sum of two 16-bit exponents fits. */
 FX_HD XsLv xs_seg_running_max(const XsCx &cx, const XsLv &seg, const XsLv &e, int n) {
   XsLv key;
   key.fill(0);
-  XS_LANES(k, 0, n) key.own(k) = seg.own(k) >= 0 ? ((seg.own(k) + 1) << 16) | ((e.own(k) + 0x4000) & 0xffff) : 0;
+  XS_LANES(k, 0, n) key.own(k) = seg.own(k) >= 0 ? ((seg.own(k) + 1) << 20) | ((e.own(k) + 0x80000) & 0xfffff) : 0;
   const XsLv before = xs_prefix_max(cx, key).shifted(cx, -1);
   XsLv r;
   r.fill(0);
   XS_LANES(k, 0, n) {
     const int32_t p = before.own(k);
-    const int32_t ep = (p & 0xffff) - 0x4000;
-    r.own(k) = ((p >> 16) == seg.own(k) + 1 && ep > 0) ? ep : 0;
+    const int32_t ep = (p & 0xfffff) - 0x80000;
+    r.own(k) = ((p >> 20) == seg.own(k) + 1 && ep > 0) ? ep : 0;
   }
   return r;
 }
