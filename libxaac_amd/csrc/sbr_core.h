@@ -1926,6 +1926,45 @@ FX_HD void xs_rescale_x_overlap(const XsCx &cx, const xaac_sbr_header *h, const 
   cx.sync();
 }
 
+/* Side info the code can index with: every count within the capacity of its array, every band number within the
+   64-band grid.  The reference's parser guarantees (much tighter) ranges before ixheaacd_sbr_dec ever runs
+   (ixheaacd_env_extr.c, ixheaacd_freq_sca.c); the boundary takes the structs from a host it does not control, so a
+   frame outside these bounds is refused with -1 like the grid checks of sbr_dec.c:733-748 instead of being indexed.
+   A frame the reference decodes always passes. */
+FX_HD int xs_side_info_bad(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f) {
+  int bad = 0;
+  XS_ONE {
+    const auto in = [](int v, int lo, int hi) { return v < lo || v > hi; };
+    bad |= in(h->num_sf_bands[0], 0, XAAC_SBR_MAX_FREQ_COEFFS / 2) | in(h->num_sf_bands[1], 0, XAAC_SBR_MAX_FREQ_COEFFS);
+    bad |= in(h->num_nf_bands, 0, XAAC_SBR_MAX_NOISE_COEFFS) | in(h->num_lf_bands, 0, XAAC_SBR_MAX_LIMITERS);
+    bad |= in(h->num_if_bands, 0, XAAC_SBR_MAX_NOISE_VALUES) | in(h->limiter_gains, 0, 3);
+    bad |= in(h->sub_band_start, 0, 64) | in(h->sub_band_end, h->sub_band_start, 64);
+    bad |= in(h->num_patches, 0, XAAC_SBR_MAX_PATCHES) | in(h->start_patch, 0, 64) | in(h->stop_patch, 0, 64);
+    bad |= in(f->num_env, 0, XAAC_SBR_MAX_ENVELOPES) | in(f->num_noise_env, 0, XAAC_SBR_MAX_NOISE_ENVELOPES);
+    bad |= in(f->max_qmf_subband_aac, 0, 64) | in(f->transient_env, -1, XAAC_SBR_MAX_ENVELOPES);
+  }
+  /* the entries in use (what lies behind a count is the host's business) */
+  const int n_hi = h->num_sf_bands[1], n_lo = h->num_sf_bands[0], n_lim = h->num_lf_bands, n_nf = h->num_nf_bands;
+  const int n_if = h->num_if_bands, n_pat = h->num_patches, n_env = f->num_env, n_nenv = f->num_noise_env;
+  XS_PAR(i, 0, XAAC_SBR_MAX_FREQ_COEFFS + 1) {
+    if (i <= n_hi) bad |= (unsigned)h->freq_band_tbl_hi[i] > 64u;
+    if (i <= n_lo && i <= XAAC_SBR_MAX_FREQ_COEFFS / 2) bad |= (unsigned)h->freq_band_tbl_lo[i] > 64u;
+    if (i <= n_lim && i <= XAAC_SBR_MAX_LIMITERS) bad |= (unsigned)h->freq_band_tbl_lim[i] > 64u;
+    if (i <= n_nf && i <= XAAC_SBR_MAX_NOISE_COEFFS) bad |= (unsigned)h->freq_band_tbl_noise[i] > 64u;
+    if (i < n_if && i < XAAC_SBR_MAX_NOISE_VALUES) bad |= ((unsigned)h->bw_borders[i] > 64u) | ((unsigned)f->sbr_invf_mode[i] > 3u);
+    if (i < n_pat && i < XAAC_SBR_MAX_PATCHES) {
+      const xaac_sbr_patch *pp = &h->patch[i];
+      bad |= ((unsigned)pp->src_start_band > 64u) | ((unsigned)pp->src_end_band > 64u) | ((unsigned)pp->guard_start_band > 64u) |
+             ((unsigned)pp->dst_start_band > 64u) | ((unsigned)pp->dst_end_band > 64u) | ((unsigned)pp->num_bands_in_patch > 64u);
+    }
+    if (i <= n_env && i <= XAAC_SBR_MAX_ENVELOPES) bad |= (unsigned)f->border_vec[i] > 19u;
+    if (i < n_env && i < XAAC_SBR_MAX_ENVELOPES) bad |= (unsigned)f->freq_res[i] > 1u;
+    if (i <= n_nenv && i <= XAAC_SBR_MAX_NOISE_ENVELOPES) bad |= (unsigned)f->noise_border_vec[i] > 19u;
+  }
+  return cx.wave_or(bad) != 0;
+}
+
+
 /* The part of ixheaacd_sbr_dec between the two QMF banks (sbr_dec.c:1050-1245), low-power (Q = XsQmf) or
    HQ (Q = XsQmfHq) mode.
    On entry x holds the 6 overlap slots (already through xs_rescale_x_overlap) and the 32 freshly
@@ -1939,6 +1978,9 @@ FX_HD int xs_sbr_core(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
   /* the frame grid this implementation (and the reference's MAX_ENV_COLS buffers, sbr_dec.c:733-748) is laid
      out for: 16 time slots of 2 QMF slots; anything else is refused like the reference refuses its own limits */
   if (cx.uni(h->num_time_slots) * cx.uni(h->time_step) != 32 || cx.uni(h->num_columns) != 32) return -1;
+#if !defined(__HIP_DEVICE_COMPILE__) /* the GPU kernel has checked before it touched the overlap (sbr_core_kernel.hip) */
+  if (xs_side_info_bad(cx, h, f)) return -1;
+#endif
   const int usb = cx.uni(st->codec_usb);
   int reserve = xs_headroom(cx, x, 0, usb, 6, 38);
   int reserve_ov1 = xs_headroom(cx, x, 0, usb, 0, 6);

@@ -156,7 +156,8 @@ __global__ __launch_bounds__(64) void xaac_sbr_core_kernel(XaacSbrCoreParams p) 
   const XsCx cx = {lane, 64};
   const XsQmfT<HQ> x = {s.x};
   if (lane == 0) s.st.lb_scale = 0;
-  if (f->apply_processing) xs_rescale_x_overlap(cx, &s.h, f, &s.st, x);
+  const int refused = xs_side_info_bad(cx, &s.h, f); /* counts / band numbers past the structs' capacity */
+  if (f->apply_processing && !refused) xs_rescale_x_overlap(cx, &s.h, f, &s.st, x);
   /* what ixheaacd_cplx_anal_qmffilt leaves in the scale struct (generic:630-631) */
   __syncthreads();
   if (lane == 0) {
@@ -168,8 +169,9 @@ __global__ __launch_bounds__(64) void xaac_sbr_core_kernel(XaacSbrCoreParams p) 
 #ifdef XS_SKIP_CORE
   const int rc = 0;
 #else
-  const int rc = xs_sbr_core(cx, &s.h, f, p.frame[ch].int_env_sf_arr, reinterpret_cast<const int16_t *>(s.noise_floor),
-                             &s.st, x, &s.w, s.rand_hi, &save_lb_scale);
+  const int rc = refused ? -1
+                         : xs_sbr_core(cx, &s.h, f, p.frame[ch].int_env_sf_arr, reinterpret_cast<const int16_t *>(s.noise_floor),
+                                       &s.st, x, &s.w, s.rand_hi, &save_lb_scale);
 #endif
   __syncthreads();
 #ifdef XS_PROFILE

@@ -357,6 +357,7 @@ FX_HD void xp_init_rot_env(const XsCx &cx, const XpTables *T, PS *ps, const xaac
   const int16_t *sf = fine ? T->scale_factors_fine : T->scale_factors;
   int16_t len = fx_sat16((int32_t)cx.uni(pf->border_position[env + 1]) - cx.uni(pf->border_position[env]));
   if (len < 0) len = (int16_t)(len == -32768 ? 32767 : -len);
+  if (len > 48) len = 48; /* borders the parser cannot produce (ps_bitdec.c keeps them within 0..32): stay inside the table */
   const int16_t inv_len = xaac_sbr_inv_int_table[len];
   XS_PAR(g, 0, XAAC_PS_GROUPS) {
     const int bin = T->group_to_bin[g];

@@ -133,3 +133,33 @@ def test_full_size_batch_matches_reference_records(ctx):
         else:
             first[k] = i
     assert want_st.shape[0] == m
+
+
+def test_side_info_outside_the_structs_capacity_is_refused(ctx):
+    """a frame whose counts / band numbers would index past the boundary structs is answered with status -1 (the
+    reference's parser never produces one; the boundary does not trust its caller), its neighbours in the batch are
+    untouched by it"""
+    recs = cap.read_records(os.path.join(ROOT, "tests", "golden", "sbr_lp_records.bin.gz"))[:24]
+    rng = np.random.default_rng(4)
+    headers = [cap.Header.from_buffer_copy(bytes(r["header"])) for r in recs]
+    frames = [cap.Frame.from_buffer_copy(bytes(r["frame"])) for r in recs]
+    broken = {1: "num_env", 5: "tbl_hi", 9: "patch", 13: "garbage header", 17: "garbage frame", 21: "num_sf"}
+    frames[1].num_env = 9
+    headers[5].freq_band_tbl_hi[2] = 400
+    headers[9].num_patches = 6
+    headers[9].patch[5].src_start_band = -7
+    raw = bytearray(bytes(headers[13]))
+    raw[4:] = rng.integers(0, 256, len(raw) - 4, dtype=np.uint8).tobytes()     # keeps the 16 x 2 frame grid
+    headers[13] = cap.Header.from_buffer_copy(bytes(raw))
+    frames[17] = cap.Frame.from_buffer_copy(rng.integers(0, 256, ctypes.sizeof(cap.Frame), dtype=np.uint8).tobytes())
+    frames[17].apply_processing = 1
+    headers[21].num_sf_bands[1] = 60
+    pcm_in = np.concatenate([r["pcm_in"] for r in recs])
+    out, st, status = gpu_run(ctx, headers, frames, [r["st0"] for r in recs], pcm_in)
+    for i, r in enumerate(recs):
+        if i in broken:
+            assert status[i] == -1, (i, broken[i], status[i])
+        else:
+            assert status[i] == r["ret"]
+            assert np.array_equal(out[2048 * i:2048 * (i + 1)], r["pcm_out"][0]), i
+            assert not cap.diff_state(cap.State.from_buffer_copy(st[i].tobytes()), r["st1"]), i
