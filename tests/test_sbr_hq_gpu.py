@@ -173,3 +173,27 @@ def test_full_size_batch_matches_reference_records(ctx):
         r = recs[idx[i]]
         assert not cap.diff_state(cap.State.from_buffer_copy(got_st[i].tobytes()), r["st1"]), i
         assert not cap.diff_state(cap.PsState.from_buffer_copy(got_ps[i].tobytes()), r["ps1"]), i
+
+
+def test_malformed_side_info_does_not_disturb_the_batch(ctx):
+    """HE-AACv2 batch with one stream's SBR frame and another's PS frame filled with random bytes: the SBR one is
+    refused (status -1), the PS one runs on whatever the bytes say (its tables are indexed inside LDS only); every
+    other stream of the batch is bit-exact"""
+    recs = cap.read_records(GOLDEN)[:16]
+    rng = np.random.default_rng(8)
+    frames = [cap.Frame.from_buffer_copy(bytes(r["frame"])) for r in recs]
+    psf = [cap.PsFrame.from_buffer_copy(bytes(r["ps_frame"])) for r in recs]
+    frames[3] = cap.Frame.from_buffer_copy(rng.integers(0, 256, ctypes.sizeof(cap.Frame), dtype=np.uint8).tobytes())
+    frames[3].apply_processing = 1
+    psf[11] = cap.PsFrame.from_buffer_copy(rng.integers(0, 256, ctypes.sizeof(cap.PsFrame), dtype=np.uint8).tobytes())
+    pcm_in = np.concatenate([r["pcm_in"] for r in recs])
+    out, st, ps, status = gpu_run(ctx, [r["header"] for r in recs], frames, [r["st0"] for r in recs], psf,
+                                  [r["ps0"] for r in recs], pcm_in)
+    assert status[3] == -1
+    for i, r in enumerate(recs):
+        if i in (3, 11):
+            continue
+        o = out[4096 * i:4096 * (i + 1)]
+        assert status[i] == r["ret"]
+        assert np.array_equal(o[0::2], r["pcm_out"][0]) and np.array_equal(o[1::2], r["pcm_out"][1]), i
+        assert not cap.diff_state(cap.PsState.from_buffer_copy(ps[i].tobytes()), r["ps1"]), i
