@@ -86,6 +86,9 @@ typedef struct xaac_imdct_batch {
   int16_t *pcm16;             /* optional [n_ch*1024] PCM16 after the qshift_adj hand-off */
   int8_t *qshift_adj;         /* optional [n_ch] ics->qshift_adj as the reference sets it */
   int32_t pcm_mode;           /* XAAC_PCM_LC or XAAC_PCM_SBR (used when pcm16 != NULL) */
+  int32_t *status;            /* optional [n_ch]: XAAC_OK, or XAAC_FATAL_BAD_WINDOW_SEQ for a channel-frame whose
+                                 window_sequence > 3 / window_shape > 1 (in ics or in state) -- values the 2-bit / 1-bit
+                                 bitstream fields cannot carry; such a channel-frame is left untouched */
 } xaac_imdct_batch;
 
 /* ---- SBR QMF banks (fixed-point "Path B") ---------------------------------------------

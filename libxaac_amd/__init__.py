@@ -17,12 +17,13 @@ import os
 
 __all__ = [
     "ONLY_LONG_SEQUENCE", "LONG_START_SEQUENCE", "EIGHT_SHORT_SEQUENCE", "LONG_STOP_SEQUENCE",
-    "PCM_LC", "PCM_SBR", "XaacError", "XaacContext", "load_library", "library_path",
+    "PCM_LC", "PCM_SBR", "BAD_WINDOW_SEQ", "XaacError", "XaacContext", "load_library", "library_path",
 ]
 
 # decoder/ixheaacd_cnst.h:100-103
 ONLY_LONG_SEQUENCE, LONG_START_SEQUENCE, EIGHT_SHORT_SEQUENCE, LONG_STOP_SEQUENCE = 0, 1, 2, 3
 PCM_LC, PCM_SBR = 0, 1
+BAD_WINDOW_SEQ = -0x7FFC   # XAAC_FATAL_BAD_WINDOW_SEQ (0xFFFF8004) as the int32 a status word holds
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -45,7 +46,7 @@ class _ImdctBatch(ctypes.Structure):
     _fields_ = [("n_ch", ctypes.c_int32), ("ch_fac", ctypes.c_int32), ("spec", ctypes.c_void_p),
                 ("ics", ctypes.c_void_p), ("overlap", ctypes.c_void_p), ("state", ctypes.c_void_p),
                 ("out32", ctypes.c_void_p), ("pcm16", ctypes.c_void_p), ("qshift_adj", ctypes.c_void_p),
-                ("pcm_mode", ctypes.c_int32)]
+                ("pcm_mode", ctypes.c_int32), ("status", ctypes.c_void_p)]
 
 
 class _QmfAnaBatch(ctypes.Structure):
@@ -240,7 +241,7 @@ class XaacContext:
         self._lib.xaac_last_launch(self._h, ctypes.byref(g), ctypes.byref(b), ctypes.byref(l))
         return {"grid": g.value, "block": b.value, "lds_bytes": l.value}
 
-    def _batch(self, n_ch, spec, ics, overlap, state, out32, pcm16, qshift_adj, ch_fac, pcm_mode, on_device):
+    def _batch(self, n_ch, spec, ics, overlap, state, out32, pcm16, qshift_adj, ch_fac, pcm_mode, on_device, status=None):
         b = _ImdctBatch()
         b.n_ch, b.ch_fac, b.pcm_mode = int(n_ch), int(ch_fac), int(pcm_mode)
         b.spec = _ptr(spec, "int32", n_ch * 1024, device_ok=on_device)
@@ -250,27 +251,29 @@ class XaacContext:
         b.out32 = _ptr(out32, "int32", n_ch * 1024, allow_none=True, device_ok=on_device)
         b.pcm16 = _ptr(pcm16, "int16", n_ch * 1024, allow_none=True, device_ok=on_device)
         b.qshift_adj = _ptr(qshift_adj, "int8", n_ch, allow_none=True, device_ok=on_device)
+        b.status = _ptr(status, "int32", n_ch, allow_none=True, device_ok=on_device)
         return b
 
     def imdct_process_batch(self, spec, ics, overlap, state, out32=None, pcm16=None, qshift_adj=None,
-                            ch_fac=1, pcm_mode=PCM_LC):
+                            ch_fac=1, pcm_mode=PCM_LC, status=None):
         """Batched ixheaacd_imdct_process on device tensors (asynchronous).
 
         spec int32[N,1024]; ics uint8[N,2] = (window_sequence, window_shape);
         overlap int32[N,512] in/out; state uint8[N,2] in/out (previous
         window_sequence, window_shape); optional outputs out32 int32[N*1024],
-        pcm16 int16[N*1024] (interleaved at stride ch_fac), qshift_adj int8[N]."""
+        pcm16 int16[N*1024] (interleaved at stride ch_fac), qshift_adj int8[N], status int32[N] (0, or
+        BAD_WINDOW_SEQ for a channel-frame whose window bytes no bitstream can carry: left untouched)."""
         n_ch = spec.shape[0] if spec.dim() == 2 else spec.numel() // 1024
-        b = self._batch(n_ch, spec, ics, overlap, state, out32, pcm16, qshift_adj, ch_fac, pcm_mode, True)
+        b = self._batch(n_ch, spec, ics, overlap, state, out32, pcm16, qshift_adj, ch_fac, pcm_mode, True, status)
         rc = self._lib.xaac_imdct_process_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_imdct_process_batch")
 
     def imdct_process_batch_host(self, spec, ics, overlap, state, out32=None, pcm16=None, qshift_adj=None,
-                                 ch_fac=1, pcm_mode=PCM_LC):
+                                 ch_fac=1, pcm_mode=PCM_LC, status=None):
         """Same on host numpy arrays (copies over PCIe, synchronous)."""
         n_ch = spec.shape[0]
-        b = self._batch(n_ch, spec, ics, overlap, state, out32, pcm16, qshift_adj, ch_fac, pcm_mode, False)
+        b = self._batch(n_ch, spec, ics, overlap, state, out32, pcm16, qshift_adj, ch_fac, pcm_mode, False, status)
         rc = self._lib.xaac_imdct_process_batch_host(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_imdct_process_batch_host")

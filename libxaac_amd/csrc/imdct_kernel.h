@@ -35,6 +35,7 @@ typedef struct XaacImdctParams {
   int16_t *pcm16;
   int8_t *qshift_adj;
   int32_t pcm_mode;
+  int32_t *status;
 } XaacImdctParams;
 
 #ifdef __cplusplus

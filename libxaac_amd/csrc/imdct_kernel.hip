@@ -582,6 +582,18 @@ __global__ __launch_bounds__(XAAC_IMDCT_BLOCK, XAAC_IMDCT_MIN_WAVES_PER_SIMD) vo
       const int st_bits = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint16_t *>(p.state + ch));
       const int seq = ics_bits & 0xff, shape = ics_bits >> 8;
       const int pseq = st_bits & 0xff, pshape = st_bits >> 8;
+      /* window_sequence is a 2-bit, window_shape a 1-bit field of the bitstream (ixheaacd_channel.c:ics_info); values
+         beyond that cannot come from a parser and would index past the window tables: the channel-frame is refused
+         -- overlap, state and output untouched, XAAC_FATAL_BAD_WINDOW_SEQ in its status word -- and its neighbours
+         are not affected (scalar test: both words are wave-uniform) */
+      if (((ics_bits | st_bits) & ~0x0103) != 0) {
+        if (CF == 2 && parked) { /* channel 0 of this access unit is waiting in LDS: let it out alone */
+          for (int n = lane; n < 1024; n += 64) p.pcm16[(size_t)au * 2048 + 2 * (size_t)n] = park[n];
+          parked = false;
+        }
+        if (lane == 0 && p.status) p.status[ch] = XAAC_FATAL_BAD_WINDOW_SEQ;
+        continue;
+      }
 
       /* block exponent: norm32 of the OR of abs_nrm over the frame (aac_tns.c:422).  Only the OR's top bit
          matters, and that is the top bit of max abs_nrm(x) = max(max x, ~min x) */
@@ -716,6 +728,7 @@ __global__ __launch_bounds__(XAAC_IMDCT_BLOCK, XAAC_IMDCT_MIN_WAVES_PER_SIMD) vo
         p.state[ch].window_sequence = (uint8_t)seq;
         p.state[ch].window_shape = (uint8_t)shape;
         if (p.qshift_adj) p.qshift_adj[ch] = (int8_t)sk.qadj;
+        if (p.status) p.status[ch] = XAAC_OK;
       }
     }
   }

@@ -1931,10 +1931,18 @@ FX_HD void xs_rescale_x_overlap(const XsCx &cx, const xaac_sbr_header *h, const 
    (ixheaacd_env_extr.c, ixheaacd_freq_sca.c); the boundary takes the structs from a host it does not control, so a
    frame outside these bounds is refused with -1 like the grid checks of sbr_dec.c:733-748 instead of being indexed.
    A frame the reference decodes always passes. */
-FX_HD int xs_side_info_bad(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f) {
+template <class ST>
+FX_HD int xs_side_info_bad(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, const ST *st) {
   int bad = 0;
   XS_ONE {
-    const auto in = [](int v, int lo, int hi) { return v < lo || v > hi; };
+    const auto in = [](int v, int lo, int hi) -> int { return v < lo || v > hi; };
+    /* the frame grid this implementation (and the reference's MAX_ENV_COLS buffers, sbr_dec.c:733-748) is laid out
+       for: 16 time slots of 2 QMF slots, 32 columns -- decided here, before xs_rescale_x_overlap turns
+       time_step * (prev_end_position - num_time_slots) into a row index */
+    bad |= (h->num_time_slots != 16) | (h->time_step != 2) | (h->num_columns != 32);
+    /* state members that become row / band indices (a state is the host's to initialise: sbrdec_initfuncs.c) */
+    bad |= in(st->prev_end_position, 0, 19) | in(st->prev_max_qmf_subband_aac, 0, 64) | in(st->codec_usb, 0, 64);
+    bad |= in(st->syn_lsb, 0, 64) | in(st->syn_usb, 0, 64);
     bad |= in(h->num_sf_bands[0], 0, XAAC_SBR_MAX_FREQ_COEFFS / 2) | in(h->num_sf_bands[1], 0, XAAC_SBR_MAX_FREQ_COEFFS);
     bad |= in(h->num_nf_bands, 0, XAAC_SBR_MAX_NOISE_COEFFS) | in(h->num_lf_bands, 0, XAAC_SBR_MAX_LIMITERS);
     bad |= in(h->num_if_bands, 0, XAAC_SBR_MAX_NOISE_VALUES) | in(h->limiter_gains, 0, 3);
@@ -1978,9 +1986,7 @@ FX_HD int xs_sbr_core(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
   /* the frame grid this implementation (and the reference's MAX_ENV_COLS buffers, sbr_dec.c:733-748) is laid
      out for: 16 time slots of 2 QMF slots; anything else is refused like the reference refuses its own limits */
   if (cx.uni(h->num_time_slots) * cx.uni(h->time_step) != 32 || cx.uni(h->num_columns) != 32) return -1;
-#if !defined(__HIP_DEVICE_COMPILE__) /* the GPU kernel has checked before it touched the overlap (sbr_core_kernel.hip) */
-  if (xs_side_info_bad(cx, h, f)) return -1;
-#endif
+  /* xs_side_info_bad has been run by the caller, before xs_rescale_x_overlap touched the overlap slots */
   const int usb = cx.uni(st->codec_usb);
   int reserve = xs_headroom(cx, x, 0, usb, 6, 38);
   int reserve_ov1 = xs_headroom(cx, x, 0, usb, 0, 6);

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64) void xaac_sbr_core_kernel(XaacSbrCoreParams p) 
   const XsCx cx = {lane, 64};
   const XsQmfT<HQ> x = {s.x};
   if (lane == 0) s.st.lb_scale = 0;
-  const int refused = xs_side_info_bad(cx, &s.h, f); /* counts / band numbers past the structs' capacity */
+  const int refused = xs_side_info_bad(cx, &s.h, f, &s.st); /* counts / band numbers past the structs' capacity */
   if (f->apply_processing && !refused) xs_rescale_x_overlap(cx, &s.h, f, &s.st, x);
   /* what ixheaacd_cplx_anal_qmffilt leaves in the scale struct (generic:630-631) */
   __syncthreads();

@@ -332,6 +332,30 @@ FX_HD int16_t xp_sin512(const XpTables *T, int32_t phi_by_4) {
   return index < 512 ? T->trig_data[index] : T->trig_data[1024 - index];
 }
 
+/* The reference's parser (ixheaacd_ps_bitdec.c:98-300) hands over IID indices within +-7 (+-15 fine), ICC indices
+   0..7 and borders 0..32; the tool uses them as raw table indices.  A frame from anywhere else is brought into
+   those ranges before use (returns 1 if anything had to be changed: the caller reports status -1 for the stream). */
+FX_HD int xp_frame_sanitize(const XsCx &cx, xaac_ps_frame *pf) {
+  int bad = 0;
+  const int steps = cx.uni(pf->iid_quant) ? 15 : 7;
+  XS_PAR(i, 0, (XAAC_PS_MAX_ENV + 2) * XAAC_PS_BANDS_FINE) {
+    int16_t *iid = &pf->iid_par_table[0][0] + i, *icc = &pf->icc_par_table[0][0] + i;
+    const int a = *iid < -steps ? -steps : (*iid > steps ? steps : *iid);
+    const int c = *icc < 0 ? 0 : (*icc > 7 ? 7 : *icc);
+    bad |= (a != *iid) | (c != *icc);
+    *iid = (int16_t)a;
+    *icc = (int16_t)c;
+  }
+  XS_PAR(i, 0, XAAC_PS_MAX_ENV + 2) {
+    const int b = pf->border_position[i];
+    const int c = b < 0 ? 0 : (b > 32 ? 32 : b);
+    bad |= b != c;
+    pf->border_position[i] = (int16_t)c;
+  }
+  cx.sync();
+  return cx.wave_or(bad) != 0;
+}
+
 /* ps_dec.c:714: at an envelope border, the target mixing coefficients of every parameter group from the
    IID / ICC indices, and the per-slot increments towards them (one group per lane) */
 template <class PS>

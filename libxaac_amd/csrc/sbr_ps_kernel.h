@@ -22,6 +22,7 @@ typedef struct XaacPsParams {
                                  out: the same slots rewritten for the left synthesis launch */
   int16_t *par_r;             /* [n][8] out: scale / band parameters of the right synthesis launch;
                                  [6] = 1 where the stream has no PS this frame (bank and output left alone) */
+  int32_t *status;            /* optional [n]: -1 where PS side info had to be clamped into its tables */
   int32_t *dbg;               /* profiling builds (-DXS_PROFILE) only: 32 cycle counters, else unused */
 } XaacPsParams;
 

@@ -104,6 +104,7 @@ __global__ __launch_bounds__(64) void xaac_ps_kernel(XaacPsParams p) {
   }
 #endif
   const XsCx cx = {lane, 64};
+  const int ps_clamped = xp_frame_sanitize(cx, &s.pf); /* indices a parser cannot produce: contained, reported */
   int16_t *par = p.par_l + 8 * (size_t)n;
   const int lb_scale = par[0], ov_lb_scale = par[1], hb_scale = par[2], st_syn = par[3], lsb = par[4], usb = par[5];
   const int ps_scale = xp_init_ps_scale(cx, &s.ps, lb_scale, ov_lb_scale, hb_scale); /* sbr_dec.c:1252 */
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(64) void xaac_ps_kernel(XaacPsParams p) {
     }
     __syncthreads();
     XP_T(2);
-    if (l == s.pf.border_position[env]) {
+    if (env <= XAAC_PS_MAX_ENV && l == s.pf.border_position[env]) {
       xp_init_rot_env(cx, &s.tabs, &s.ps, &s.pf, env, usb);
       env++;
     }
@@ -227,6 +228,9 @@ __global__ __launch_bounds__(64) void xaac_ps_kernel(XaacPsParams p) {
     par[6] = 0;
     gps->lb_scale_r = gps->ov_lb_scale_r = gps->hb_scale_r = (int16_t)ps_scale; /* sbr_dec.c:1261-1264 */
     p.sbr_state[n].ps_scale = (int16_t)ps_scale;
+#ifndef XS_PROFILE
+    if (ps_clamped && p.status) p.status[n] = -1;
+#endif
   }
 }
 

@@ -31,6 +31,15 @@ struct xaac_ctx {
   int last_grid, last_block, last_lds;
 };
 
+/* Profiling builds (-DXS_PROFILE / -DXL_PROFILE, tools/prof_sbr_core.py, tools/time_limiter.py) collect 64-bit phase
+   counters in the caller's status buffer; it then has to hold 128 of them, which the tools' batches (>= 256
+   channels) do.  Regular builds never hand the kernels a counter buffer. */
+#if defined(XS_PROFILE) || defined(XL_PROFILE)
+#define XAAC_DBG_BUF(status, n) ((n) >= 256 ? (status) : nullptr)
+#else
+#define XAAC_DBG_BUF(status, n) static_cast<int32_t *>(nullptr)
+#endif
+
 namespace {
 
 inline bool hip_ok(hipError_t e) { return e == hipSuccess; }
@@ -129,6 +138,7 @@ int32_t xaac_imdct_process_batch(xaac_ctx *c, const xaac_imdct_batch *b) {
   p.pcm16 = b->pcm16;
   p.qshift_adj = b->qshift_adj;
   p.pcm_mode = b->pcm_mode;
+  p.status = b->status;
   int grid = pick_grid(c, b->n_ch);
   if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
   if (!hip_ok(xaac_launch_imdct(&p, grid, c->stream))) return XAAC_FATAL_HIP;
@@ -147,9 +157,9 @@ int32_t xaac_imdct_process_batch_host(xaac_ctx *c, const xaac_imdct_batch *hb) {
   if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
   const size_t sz_spec = n * 1024 * 4, sz_ics = n * sizeof(xaac_ics_info), sz_ovl = n * 512 * 4,
                sz_st = n * sizeof(xaac_ovl_state), sz_o32 = hb->out32 ? n * 1024 * 4 : 0,
-               sz_pcm = hb->pcm16 ? n * 1024 * 2 : 0, sz_q = hb->qshift_adj ? n : 0;
+               sz_pcm = hb->pcm16 ? n * 1024 * 2 : 0, sz_q = hb->qshift_adj ? n : 0, sz_stat = hb->status ? n * 4 : 0;
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  const size_t total = up(sz_spec) + up(sz_ics) + up(sz_ovl) + up(sz_st) + up(sz_o32) + up(sz_pcm) + up(sz_q);
+  const size_t total = up(sz_spec) + up(sz_ics) + up(sz_ovl) + up(sz_st) + up(sz_o32) + up(sz_pcm) + up(sz_q) + up(sz_stat);
   char *d = nullptr;
   if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d), total))) return XAAC_FATAL_HIP;
   char *cur = d;
@@ -160,7 +170,7 @@ int32_t xaac_imdct_process_batch_host(xaac_ctx *c, const xaac_imdct_batch *hb) {
   };
   xaac_imdct_batch db = *hb;
   char *d_spec = carve(sz_spec), *d_ics = carve(sz_ics), *d_ovl = carve(sz_ovl), *d_st = carve(sz_st);
-  char *d_o32 = carve(sz_o32), *d_pcm = carve(sz_pcm), *d_q = carve(sz_q);
+  char *d_o32 = carve(sz_o32), *d_pcm = carve(sz_pcm), *d_q = carve(sz_q), *d_stat = carve(sz_stat);
   db.spec = reinterpret_cast<const int32_t *>(d_spec);
   db.ics = reinterpret_cast<const xaac_ics_info *>(d_ics);
   db.overlap = reinterpret_cast<int32_t *>(d_ovl);
@@ -168,6 +178,7 @@ int32_t xaac_imdct_process_batch_host(xaac_ctx *c, const xaac_imdct_batch *hb) {
   db.out32 = hb->out32 ? reinterpret_cast<int32_t *>(d_o32) : nullptr;
   db.pcm16 = hb->pcm16 ? reinterpret_cast<int16_t *>(d_pcm) : nullptr;
   db.qshift_adj = hb->qshift_adj ? reinterpret_cast<int8_t *>(d_q) : nullptr;
+  db.status = hb->status ? reinterpret_cast<int32_t *>(d_stat) : nullptr;
   bool ok = hip_ok(hipMemcpyAsync(d_spec, hb->spec, sz_spec, hipMemcpyHostToDevice, c->stream)) &&
             hip_ok(hipMemcpyAsync(d_ics, hb->ics, sz_ics, hipMemcpyHostToDevice, c->stream)) &&
             hip_ok(hipMemcpyAsync(d_ovl, hb->overlap, sz_ovl, hipMemcpyHostToDevice, c->stream)) &&
@@ -182,6 +193,7 @@ int32_t xaac_imdct_process_batch_host(xaac_ctx *c, const xaac_imdct_batch *hb) {
     if (ok && sz_o32) ok = hip_ok(hipMemcpyAsync(hb->out32, d_o32, sz_o32, hipMemcpyDeviceToHost, c->stream));
     if (ok && sz_pcm) ok = hip_ok(hipMemcpyAsync(hb->pcm16, d_pcm, sz_pcm, hipMemcpyDeviceToHost, c->stream));
     if (ok && sz_q) ok = hip_ok(hipMemcpyAsync(hb->qshift_adj, d_q, sz_q, hipMemcpyDeviceToHost, c->stream));
+    if (ok && sz_stat) ok = hip_ok(hipMemcpyAsync(hb->status, d_stat, sz_stat, hipMemcpyDeviceToHost, c->stream));
   }
   bool synced = hip_ok(hipStreamSynchronize(c->stream));
   (void)hipFree(d);
@@ -272,7 +284,7 @@ int32_t xaac_sbr_lp_process_batch(xaac_ctx *c, const xaac_sbr_lp_batch *b) {
   ps.down_sample = b->down_sample ? 1 : 0;
   ps.slot_stride = 64; ps.state_stride = (int32_t)sizeof(xaac_sbr_state); ps.qmf_ch_stride = XAAC_SBR_X_WORDS;
   ps.scale_stride = 8; ps.per_ch_bands = 1;
-  ps.qmf = x + 2 * 64; ps.scale = par; ps.dbg = b->status;
+  ps.qmf = x + 2 * 64; ps.scale = par; ps.dbg = XAAC_DBG_BUF(b->status, b->n_ch);
   ps.state = reinterpret_cast<xaac_qmf_syn_state *>(st + offsetof(xaac_sbr_state, syn_ring));
   ps.pcm = b->pcm_out;
   const int grid = qmf_grid(c, b->n_ch, 2);
@@ -326,7 +338,7 @@ int32_t xaac_sbr_hq_process_batch(xaac_ctx *c, const xaac_sbr_hq_batch *b) {
   if (with_ps) {
     XaacPsParams pp;
     pp.n = b->n_ch; pp.x = x; pp.xr = xr; pp.header = b->header; pp.sbr_frame = b->frame; pp.frame = b->ps_frame;
-    pp.state = b->ps_state; pp.sbr_state = b->state; pp.par_l = par_l; pp.par_r = par_r; pp.dbg = b->status;
+    pp.state = b->ps_state; pp.sbr_state = b->state; pp.par_l = par_l; pp.par_r = par_r; pp.status = b->status; pp.dbg = XAAC_DBG_BUF(b->status, b->n_ch);
     if (!hip_ok(xaac_launch_ps(&pp, c->stream))) return XAAC_FATAL_HIP;
   }
   /* 4. synthesis bank(s) over the 6 delayed + first 26 new slots */
@@ -335,7 +347,7 @@ int32_t xaac_sbr_hq_process_batch(xaac_ctx *c, const xaac_sbr_hq_batch *b) {
   ps.down_sample = b->down_sample ? 1 : 0;
   ps.slot_stride = 128; ps.state_stride = (int32_t)sizeof(xaac_sbr_state); ps.qmf_ch_stride = xw;
   ps.scale_stride = 8; ps.per_ch_bands = 1;
-  ps.qmf = x + 2 * 128; ps.scale = par_l; ps.dbg = b->status;
+  ps.qmf = x + 2 * 128; ps.scale = par_l; ps.dbg = XAAC_DBG_BUF(b->status, b->n_ch);
   ps.state = reinterpret_cast<xaac_qmf_syn_state *>(st + offsetof(xaac_sbr_state, syn_ring));
   ps.pcm = b->pcm_out;
   if (with_ps) { ps.pcm_ch_stride = 2 * 2048; ps.pcm_sample_stride = 2; }
@@ -393,7 +405,7 @@ int32_t xaac_peak_limiter_process_batch(xaac_ctx *c, const xaac_limiter_batch *b
   p.planar = b->planar ? 1 : 0;
   p.samples = b->samples; p.stride = b->stride; p.qshift_adj = b->qshift_adj; p.state = b->state;
   p.pcm16 = b->pcm16; p.status = b->status;
-  p.dbg = reinterpret_cast<long long *>(b->status); /* phase timers of -DXL_PROFILE builds (tools/time_limiter.py) */
+  p.dbg = reinterpret_cast<long long *>(XAAC_DBG_BUF(b->status, b->n_streams)); /* phase timers of -DXL_PROFILE builds */
   if (!hip_ok(xaac_launch_limiter(&p, c->stream))) return XAAC_FATAL_HIP;
   c->last_grid = b->n_streams; c->last_block = 64; c->last_lds = 2 * (XAAC_LIM_MAX_ATTACK + 1024) * 4 + 256;
   return XAAC_OK;

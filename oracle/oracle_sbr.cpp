@@ -45,6 +45,7 @@ extern "C" int xo_sbr_dec_lp(const xaac_sbr_header *h, const xaac_sbr_frame *f, 
   /* sbr_dec.c:753: the six overlap slots */
   for (int l = 0; l < 6; l++)
     for (int k = 0; k < 64; k++) x(l, k) = st->overlap[64 * l + k];
+  if (xs_side_info_bad(cx, h, f, st)) return -1; /* refused before anything is touched, like sbr_dec.c:733-748 */
   st->lb_scale = 0;
   if (f->apply_processing) xs_rescale_x_overlap(cx, h, f, st, x);
   /* sbr_dec.c:1025: analysis bank into slots 6..37 */
@@ -102,6 +103,7 @@ extern "C" int xo_sbr_dec_hq(const xaac_sbr_header *h, const xaac_sbr_frame *f, 
   memset(buf, 0, sizeof(buf));
   /* sbr_dec.c:753: twelve half-rows = six complex overlap slots */
   memcpy(&x(0, 0), st->overlap, sizeof(int32_t) * 12 * 64);
+  if (xs_side_info_bad(cx, h, f, st)) return -1; /* refused before anything is touched, like sbr_dec.c:733-748 */
   st->lb_scale = 0;
   if (f->apply_processing) xs_rescale_x_overlap(cx, h, f, st, x);
   {
@@ -122,7 +124,12 @@ extern "C" int xo_sbr_dec_hq(const xaac_sbr_header *h, const xaac_sbr_frame *f, 
   memcpy(s.ring, st->syn_ring, sizeof(s.ring));
   s.drc_offset = st->syn_drc_offset;
   s.phase = st->syn_phase;
+  int ps_clamped = 0;
+  xaac_ps_frame pf_clean;
   if (f->apply_processing && h->channel_mode == 3 && pf && ps) {
+    pf_clean = *pf;
+    ps_clamped = xp_frame_sanitize(cx, &pf_clean);
+    pf = &pf_clean;
     const int ps_scale = xp_init_ps_scale(cx, ps, st->lb_scale, st->ov_lb_scale, st->hb_scale);
     st->ps_scale = (int16_t)ps_scale;
     const int lsb = st->syn_lsb, usb = st->syn_usb, st_syn = st->st_syn_scale;
@@ -141,7 +148,7 @@ extern "C" int xo_sbr_dec_hq(const xaac_sbr_header *h, const xaac_sbr_frame *f, 
       memset(&hy, 0, sizeof(hy));
       int16_t ratio[21];
       int32_t band_pw[64];
-      if (l == pf->border_position[env]) {
+      if (env <= XAAC_PS_MAX_ENV && l == pf->border_position[env]) {
         xp_init_rot_env(cx, &xaac_ps_tables, ps, pf, env, usb);
         env++;
       }
@@ -193,7 +200,7 @@ extern "C" int xo_sbr_dec_hq(const xaac_sbr_header *h, const xaac_sbr_frame *f, 
      complex overlap slots -- the other three keep what they held (kept as is: it is the reference's output) */
   memcpy(st->overlap, &x(32, 0), sizeof(int32_t) * 6 * 64);
   st->ov_lb_scale = (int16_t)save_lb_scale;
-  return 0;
+  return ps_clamped ? -1 : 0;
 }
 
 /* n independent channel-frames in a C loop (CPU baseline "port" when oracle/_ref did not travel) */

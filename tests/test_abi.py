@@ -38,9 +38,23 @@ def test_null_and_bad_arguments_are_fatal_codes():
     assert lib.xaac_imdct_process_batch(None, None) & 0x80000000
 
 
-def test_struct_layout_matches_header():
-    # 2 x int32 + 7 pointers + int32 (+ tail padding) on LP64
-    assert ctypes.sizeof(libxaac_amd._ImdctBatch) == 72
+def test_struct_layout_matches_header(tmp_path):
+    """every batch descriptor's ctypes mirror against what a C compiler makes of include/xaac_amd.h"""
+    import subprocess
+    pairs = [("xaac_imdct_batch", libxaac_amd._ImdctBatch, "status"), ("xaac_qmf_ana_batch", libxaac_amd._QmfAnaBatch, "qmf"),
+             ("xaac_qmf_syn_batch", libxaac_amd._QmfSynBatch, "pcm"), ("xaac_sbr_lp_batch", libxaac_amd._SbrLpBatch, "workspace_bytes"),
+             ("xaac_sbr_hq_batch", libxaac_amd._SbrHqBatch, "workspace_bytes")]
+    body = "".join('printf("%%zu %%zu\\n", sizeof(%s), offsetof(%s, %s));' % (c, c, last) for c, _, last in pairs)
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "xaac_amd.h"\nint main(void) { %s return 0; }\n' % body)
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    want = []
+    for _, cls, last in pairs:
+        want += [ctypes.sizeof(cls), getattr(cls, last).offset]
+    assert got == want
+    assert ctypes.sizeof(libxaac_amd._ImdctBatch) == 80   # 2 x int32 + 7 pointers + int32 (+ pad) + status pointer on LP64
 
 
 def test_no_cpu_fallback_without_device():

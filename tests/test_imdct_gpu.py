@@ -190,3 +190,51 @@ def test_bad_arguments_rejected(ctx):
     with pytest.raises((ValueError, TypeError)):
         ctx.imdct_process_batch(z(torch.int32, 2, 1024).cpu(), z(torch.uint8, 2, 2), z(torch.int32, 2, 512),
                                 z(torch.uint8, 2, 2))
+
+
+@pytest.mark.parametrize("ch_fac", [1, 2])
+@pytest.mark.parametrize("pcm_mode", [0, 1])
+def test_malformed_window_bytes_refused_neighbours_exact(ctx, oracle, ch_fac, pcm_mode):
+    """window_sequence > 3 / window_shape > 1 in ics or in the carried state cannot come from a bitstream (2-bit and
+    1-bit fields): such a channel-frame is refused with XAAC_FATAL_BAD_WINDOW_SEQ in its status word and left
+    untouched (overlap, state, output), every other channel-frame of the launch -- including the other channel of
+    the same access unit, whose PCM shares 16-byte stores with it -- stays bit-exact."""
+    import torch
+    import libxaac_amd
+    rng = np.random.default_rng(900 + 2 * ch_fac + pcm_mode)
+    n = 2 * 301
+    spec, ovl = oracle_lib.random_case(rng, n)
+    ics = np.stack([rng.integers(0, 4, n), rng.integers(0, 2, n)], 1).astype(np.uint8)
+    state = np.stack([rng.integers(0, 4, n), rng.integers(0, 2, n)], 1).astype(np.uint8)
+    ics[::3, 0] = 0    # plenty of hot-path frames so that the parked-channel pairing is exercised
+    state[::3, 0] = 0
+    bad = np.zeros(n, bool)
+    poison = [(5, "ics", 0, 4), (6, "ics", 1, 2), (40, "state", 0, 255), (41, "state", 1, 7), (100, "ics", 0, 128),
+              (101, "state", 1, 2), (n - 1, "ics", 1, 255), (n - 2, "state", 0, 4), (200, "ics", 0, 7), (203, "state", 0, 9)]
+    ics_p, state_p = ics.copy(), state.copy()
+    for i, where, col, val in poison:
+        (ics_p if where == "ics" else state_p)[i, col] = val
+        bad[i] = True
+    want = oracle.imdct_batch(spec, ics, ovl, state, ch_fac=ch_fac, pcm_mode=pcm_mode)   # the clean batch
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    t_ovl, t_state = d(ovl), d(state_p)
+    out32 = torch.full((n * 1024,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    pcm = torch.full((n * 1024,), 0x5A5A, dtype=torch.int16, device="cuda")
+    qadj = torch.full((n,), 99, dtype=torch.int8, device="cuda")
+    status = torch.full((n,), 77, dtype=torch.int32, device="cuda")
+    ctx.imdct_process_batch(d(spec), d(ics_p), t_ovl, t_state, out32, pcm, qadj, ch_fac=ch_fac, pcm_mode=pcm_mode,
+                            status=status)
+    torch.cuda.synchronize()
+    st = status.cpu().numpy()
+    assert (st[bad] == libxaac_amd.BAD_WINDOW_SEQ).all() and (st[~bad] == 0).all()
+    unint = lambda a: a.reshape(n // ch_fac, 1024, ch_fac).transpose(0, 2, 1).reshape(n, 1024)  # -> [channel-frame][sample]
+    g32, g16 = unint(out32.cpu().numpy()), unint(pcm.cpu().numpy())
+    w32, w16 = unint(want["out32"]), unint(want["pcm16"])
+    good = ~bad
+    assert np.array_equal(g32[good], w32[good]) and np.array_equal(g16[good], w16[good])
+    assert np.array_equal(t_ovl.cpu().numpy()[good], want["overlap"][good])
+    assert np.array_equal(t_state.cpu().numpy()[good], want["state"][good])
+    assert np.array_equal(qadj.cpu().numpy()[good], want["qshift_adj"][good])
+    # refused channel-frames: nothing written
+    assert (g32[bad] == 0x5A5A5A5A).all() and (g16[bad] == 0x5A5A).all() and (qadj.cpu().numpy()[bad] == 99).all()
+    assert np.array_equal(t_ovl.cpu().numpy()[bad], ovl[bad]) and np.array_equal(t_state.cpu().numpy()[bad], state_p[bad])

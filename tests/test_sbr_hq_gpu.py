@@ -175,10 +175,11 @@ def test_full_size_batch_matches_reference_records(ctx):
         assert not cap.diff_state(cap.PsState.from_buffer_copy(got_ps[i].tobytes()), r["ps1"]), i
 
 
-def test_malformed_side_info_does_not_disturb_the_batch(ctx):
+def test_malformed_side_info_does_not_disturb_the_batch(ctx, oracle):
     """HE-AACv2 batch with one stream's SBR frame and another's PS frame filled with random bytes: the SBR one is
-    refused (status -1), the PS one runs on whatever the bytes say (its tables are indexed inside LDS only); every
-    other stream of the batch is bit-exact"""
+    refused (status -1); the PS one has its indices clamped into the tables (xp_frame_sanitize, the same code in the
+    oracle), is reported with status -1 and decodes exactly as the oracle does; every other stream of the batch is
+    bit-exact"""
     recs = cap.read_records(GOLDEN)[:16]
     rng = np.random.default_rng(8)
     frames = [cap.Frame.from_buffer_copy(bytes(r["frame"])) for r in recs]
@@ -189,7 +190,15 @@ def test_malformed_side_info_does_not_disturb_the_batch(ctx):
     pcm_in = np.concatenate([r["pcm_in"] for r in recs])
     out, st, ps, status = gpu_run(ctx, [r["header"] for r in recs], frames, [r["st0"] for r in recs], psf,
                                   [r["ps0"] for r in recs], pcm_in)
-    assert status[3] == -1
+    assert status[3] == -1 and status[11] == -1
+    r = recs[11]
+    st = cap.State.from_buffer_copy(bytes(r["st0"])); pst = cap.PsState.from_buffer_copy(bytes(r["ps0"]))
+    ref = np.zeros(4096, np.int16)
+    rc = oracle.lib.xo_sbr_dec_hq(ctypes.byref(r["header"]), ctypes.byref(frames[11]), ctypes.byref(st),
+                                  ctypes.byref(psf[11]), ctypes.byref(pst), r["pcm_in"].ctypes.data_as(P16), 1,
+                                  ref.ctypes.data_as(P16), 2)
+    assert rc == -1 and np.array_equal(out[4096 * 11:4096 * 12], ref), "clamped PS frame: GPU and oracle agree"
+    assert not cap.diff_state(cap.PsState.from_buffer_copy(ps[11].tobytes()), pst)
     for i, r in enumerate(recs):
         if i in (3, 11):
             continue
