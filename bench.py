@@ -1,24 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- decoded audio frames/s of the MI355X transform back-end.
 
-Workload (BASELINE.json configs[1], SURVEY.md §8d "C2"): AAC-LC 48 kHz stereo,
-batch = 8192 frames per step = 16384 channel-frames through the 1024-sample
-IMDCT + window/overlap-add kernel with the fused PCM16 hand-off, stereo
-interleaved output.  Synthetic spectra (seeded, uniform in +-2^17 below bin 640,
-zero above; ONLY_LONG, window shape alternating per frame), overlap state
-carried in HBM.  Each rank owns `--sets` x 8192 independent streams and decodes
-one frame of 8192 of them per step, round-robin, so the working set (> 256 MiB)
-streams from HBM rather than from the Infinity Cache.
+Default workload = the configuration BASELINE.json's metric is quoted on (configs[3], SURVEY.md §8d "C4"):
+HE-AACv2 48 kHz, batch = 8192 streams per step, one frame each: mono 1024-sample IMDCT + window/overlap-add
+(PCM16 hand-off of the SBR case) -> complex 32-band QMF analysis -> LPP transposer + envelope adjustment
+(HQ SBR) -> parametric stereo (hybrid filterbank, decorrelation, rotation) -> two complex 64-band QMF
+synthesis banks -> 2048 L,R PCM16 pairs.  Synthetic core spectra (seeded, uniform in +-2^17 below bin 512),
+SBR / PS side info cycled from reference-captured HE-AACv2 frames (tests/golden/sbr_hq_ps_records.bin.gz), all
+per-stream state (IMDCT overlap, SBR, PS, filterbank rings) carried in HBM.  Each rank owns `--sets` x 8192
+independent streams and decodes one frame of 8192 of them per step, round-robin, so the working set streams from
+HBM rather than from the Infinity Cache.  With --gpus N every rank runs this on its own 8192 x sets streams
+(C5: weak scaling, streams sharded by rank, no data-path collective); after the timed region the ranks' PCM is
+gathered once over RCCL (the north star's "final interleaved gather") and that time is reported separately.
 
-A "step" = one pass of the hot path over one batch (one kernel launch).
-Inputs are resident in HBM before the timed region.  `value` = frames decoded by
-all ranks / wall time (max over ranks).  `roofline.achieved` = algorithmic bytes
-per launch (20480 B per stereo frame) / mean kernel duration from
-HIP events recorded on the launch stream.  `cpu_baseline` = the same workload on
-the host cores (the compiled reference when oracle/_ref travelled with the repo,
-else the bit-exact C restatement), bounded sample, rank 0 at N=1 only.
+A "step" = one pass of the hot path over one batch.  Inputs are resident in HBM before the timed region.
+`value` = frames decoded by all ranks / wall time (max over ranks).  `roofline.achieved` = algorithmic bytes per
+step / mean step duration from HIP events recorded on the launch stream.  Every run checks itself
+(outside the timed region): the status words of the last step must all be zero, and one more step of a
+256-stream slice is decoded by the oracle chain on the host from the same device state and compared word for
+word (`bit_exact_vs_oracle`).  `secondary` (N=1 only) = short runs of C2 (AAC-LC IMDCT, BASELINE configs[1]) and
+C3 (HE-AACv1, configs[2]) in the same process.  `cpu_baseline` = the same workload on the host cores (the
+compiled reference when oracle/_ref travelled with the repo, else the bit-exact restatement), bounded sample,
+rank 0 at N=1 only.
 
-  python bench.py --gpus 1 --steps 200 --warmup 20
+  python bench.py --gpus 1 --steps 100 --warmup 10
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       --master-port P bench.py --gpus N --steps K --warmup W
 """
@@ -42,14 +47,14 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")   # written from the rocprofv3 --pmc passes
 
 
-def measured_traffic():
-    """HBM bytes per launch from the last committed PMC profile of this kernel (rocprofv3
-    FETCH_SIZE x2 + WRITE_SIZE, calibrated as MI355X_MICROARCH.md prescribes), or None."""
+def measured_traffic(workload):
+    """HBM bytes per step from the last committed PMC profile of this workload's kernels (rocprofv3 FETCH_SIZE
+    x2 + WRITE_SIZE summed over the chain's launches, calibrated as MI355X_MICROARCH.md prescribes), or {}."""
     try:
         with open(PMC_FILE) as f:
-            return json.load(f)
+            return json.load(f).get(workload) or {}
     except (OSError, ValueError):
-        return None
+        return {}
 
 
 # ---- workload C2L: C2 + the AAC-LC post stage (peak limiter + PCM16), SURVEY.md §8 row f2 ---------------------
@@ -308,17 +313,215 @@ def cpu_baseline(seconds_budget=12.0, limiter=False):
                                                              " + limiter/round16 per frame" if limiter else "")}
 
 
+METRIC = {
+    "c2": "decoded audio frames/s (1024-spl IMDCT+overlap-add, AAC-LC stereo)",
+    "c2l": "decoded audio frames/s (1024-spl IMDCT+overlap-add + peak limiter + PCM16, AAC-LC stereo)",
+    "c3": "decoded audio frames/s (1024-spl IMDCT + 32/64-band QMF + low-power SBR, HE-AACv1 stereo)",
+    "c4": "decoded audio frames/s (1024-spl IMDCT + complex QMF + HQ SBR + parametric stereo, HE-AACv2)",
+}
+WORKLOAD = {
+    "c2": "C2: AAC-LC 48 kHz stereo, batch=8192 frames/step (16384 channel-frames), ONLY_LONG 1024-pt IMDCT + "
+          "window/overlap-add + PCM16, %d stream sets cycled",
+    "c2l": "C2L: C2 + the AAC-LC post stage, batch=8192 frames/step: IMDCT + window/overlap-add (WORD32 block + "
+           "qshift_adj) -> peak limiter in place (5 ms look-ahead, attack / release smoothing) -> PCM16; every "
+           + str(C2L_LOUD_EVERY) + "th stream decodes above full scale, %d stream sets cycled",
+    "c3": "C3: HE-AACv1 48 kHz stereo, batch=8192 frames/step: IMDCT+OLA -> QMF-32 analysis -> LPP HF generation + "
+          "envelope adjustment (side info cycled from reference-captured frames) -> QMF-64 synthesis, %d stream sets "
+          "cycled",
+    "c4": "C4: HE-AACv2 48 kHz, batch=8192 frames/step (one mono core channel each): IMDCT+OLA -> complex QMF-32 "
+          "analysis -> LPP transposer + envelope adjustment -> parametric stereo -> two complex QMF-64 synthesis banks "
+          "(SBR / PS side info cycled from reference-captured frames), %d stream sets cycled",
+}
+KERNELS = {
+    "c2": "xaac_imdct_ola_kernel",
+    "c2l": "imdct_ola + limiter_front + limiter_gain + limiter_apply (4 launches)",
+    "c3": "imdct_ola + qmf_analysis + sbr_core_lp + qmf_synthesis (4 launches)",
+    "c4": "imdct_ola + qmf_analysis + sbr_core_hq + ps + 2 x qmf_synthesis (6 launches)",
+}
+
+
+def alg_bytes_per_step(w):
+    return (C3_ALG_BYTES_PER_CH * CH if w == "c3" else C4_ALG_BYTES_PER_STREAM if w == "c4" else
+            C2L_ALG_BYTES_PER_FRAME if w == "c2l" else ALG_BYTES_PER_FRAME) * FRAMES_PER_STEP
+
+
+class Workload:
+    """Inputs, per-step launch sequence and the self-check of one of the four workloads on one rank."""
+
+    def __init__(self, w, torch, libxaac_amd, ctx, dev, stream, sets, seed):
+        self.w, self.torch, self.x, self.ctx, self.dev, self.stream = w, torch, libxaac_amd, ctx, dev, stream
+        c3, c4, c2l = w == "c3", w == "c4", w == "c2l"
+        self.batches = (make_inputs_c3(torch, dev, sets, seed) if c3 else make_inputs_c4(torch, dev, sets, seed) if c4
+                        else make_inputs(torch, dev, sets, seed, limiter=c2l))
+        for b in self.batches:            # window shape alternates per frame (SURVEY §8d); state follows
+            b["ics"][:, 1] = (torch.arange(b["ics"].shape[0], device=dev) // (1 if c4 else CH) % 2).to(torch.uint8)
+        n_units = FRAMES_PER_STEP * (1 if c4 else CH) if (c3 or c4) else FRAMES_PER_STEP
+        self.status = torch.zeros(n_units, dtype=torch.int32, device=dev) if (c3 or c4 or c2l) else None
+        self.imdct_status = torch.zeros(FRAMES_PER_STEP * (1 if c4 else CH), dtype=torch.int32, device=dev)
+        self.ws = self._workspace(FRAMES_PER_STEP)
+
+    def _workspace(self, frames):
+        t, ctx, w = self.torch, self.ctx, self.w
+        nbytes = (ctx.sbr_lp_workspace_bytes(frames * CH) if w == "c3" else ctx.sbr_hq_workspace_bytes(frames, True)
+                  if w == "c4" else ctx.peak_limiter_workspace_bytes(frames) if w == "c2l" else 0)
+        return t.zeros(nbytes, dtype=t.uint8, device=self.dev) if nbytes else None
+
+    def launch(self, b, frames_idx, k=None, ws=None, status=None, imdct_status=None):
+        """one frame of the first k streams of batch b (k = None: all of them)"""
+        ctx, x, w = self.ctx, self.x, self.w
+        ws = self.ws if ws is None else ws
+        status = self.status if status is None else status
+        imdct_status = self.imdct_status if imdct_status is None else imdct_status
+        cut = (lambda t, per: t) if k is None else (lambda t, per: t[:k * per])
+        if w == "c3":
+            # core decoder back-end: planar PCM16 with the SBR hand-off rounding, then the low-power SBR chain
+            ctx.imdct_process_batch(cut(b["spec"], CH), cut(b["ics"], CH), cut(b["overlap"], CH), cut(b["state"], CH), None,
+                                    cut(b["core_pcm"], CH * 1024), None, ch_fac=1, pcm_mode=x.PCM_SBR,
+                                    status=cut(imdct_status, CH))
+            ctx.sbr_lp_process_batch(cut(b["core_pcm"], CH * 1024), cut(b["hdr"], CH),
+                                     cut(b["frames"][frames_idx % len(b["frames"])], CH), cut(b["sbr_state"], CH),
+                                     cut(b["pcm"], CH * 2048), ws, cut(status, CH), in_ch_fac=1, out_ch_fac=CH)
+        elif w == "c4":
+            # mono core back-end, then HQ SBR + parametric stereo -> L,R pairs
+            ctx.imdct_process_batch(cut(b["spec"], 1), cut(b["ics"], 1), cut(b["overlap"], 1), cut(b["state"], 1), None,
+                                    cut(b["core_pcm"], 1024), None, ch_fac=1, pcm_mode=x.PCM_SBR,
+                                    status=cut(imdct_status, 1))
+            fr, pfr = b["frames"][frames_idx % len(b["frames"])]
+            ctx.sbr_hq_process_batch(cut(b["core_pcm"], 1024), cut(b["hdr"], 1), cut(fr, 1), cut(b["sbr_state"], 1),
+                                     cut(b["pcm"], 4096), ws, cut(pfr, 1), cut(b["ps_state"], 1), cut(status, 1))
+        elif w == "c2l":
+            # AAC-LC tail as api.c runs it: WORD32 block + qshift_adj -> limiter in place -> interleaved PCM16.  The
+            # block stays planar between the two (16-byte stores from the IMDCT; the limiter interleaves on the way out)
+            ctx.imdct_process_batch(cut(b["spec"], CH), cut(b["ics"], CH), cut(b["overlap"], CH), cut(b["state"], CH),
+                                    cut(b["out32"], CH * 1024), None, cut(b["qshift"], CH), ch_fac=1,
+                                    status=cut(imdct_status, CH))
+            ctx.peak_limiter_process_batch(cut(b["out32"], CH * 1024), cut(b["qshift"], CH), cut(b["lim_state"], 1), CH, ws,
+                                           pcm16=cut(b["pcm"], CH * 1024), planar=True, status=cut(status, 1))
+        else:
+            ctx.imdct_process_batch(cut(b["spec"], CH), cut(b["ics"], CH), cut(b["overlap"], CH), cut(b["state"], CH), None,
+                                    cut(b["pcm"], CH * 1024), None, ch_fac=CH, pcm_mode=x.PCM_LC,
+                                    status=cut(imdct_status, CH))
+
+    def step(self, i, ev=None):
+        b = self.batches[i % len(self.batches)]
+        if ev is not None:
+            ev[0].record(self.stream)
+        self.launch(b, i // len(self.batches))
+        if ev is not None:
+            ev[1].record(self.stream)
+
+    def run(self, steps, warmup, barrier):
+        torch = self.torch
+        for i in range(warmup):
+            self.step(i)
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            self.step(warmup + i, events[i])
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
+        self.next_step = warmup + steps
+        return elapsed, kern_ms
+
+    def refused(self):
+        """fraction of the last step's units the kernels refused (status != 0): must be zero for the timed work to
+        be the whole work"""
+        bad = 0.0
+        if self.status is not None:
+            bad = float((self.status != 0).float().mean().item())
+        return max(bad, float((self.imdct_status != 0).float().mean().item()))
+
+    def verify(self, k=256):
+        """Decode one more frame of the first k streams of the next batch twice from the same device state: by
+        the oracle chain on the host and by the GPU path on the slice; PCM, carried state and status must agree
+        word for word."""
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        torch, w = self.torch, self.w
+        orc = oracle_lib.load_oracle()
+        P16 = ctypes.POINTER(ctypes.c_int16)
+        i = self.next_step
+        b = self.batches[i % len(self.batches)]
+        fidx = i // len(self.batches)
+        cf = 1 if w == "c4" else CH
+        h = {n_: b[n_][:k * cf].cpu().numpy() for n_ in ("spec", "ics", "overlap", "state")}
+        torch.cuda.synchronize()
+        if w == "c2":
+            want = orc.imdct_batch(h["spec"], h["ics"], h["overlap"], h["state"], ch_fac=CH)
+            self.launch(b, fidx, k=k)
+            torch.cuda.synchronize()
+            return bool(np.array_equal(b["pcm"][:k * CH * 1024].cpu().numpy().reshape(k * CH, 1024), want["pcm16"]) and
+                        np.array_equal(b["overlap"][:k * CH].cpu().numpy(), want["overlap"]))
+        if w == "c2l":
+            import limiter_cases as lc
+            core = orc.imdct_batch(h["spec"], h["ics"], h["overlap"], h["state"], ch_fac=CH)   # interleaved WORD32 block
+            xs = np.ascontiguousarray(core["out32"].reshape(-1))
+            q = np.ascontiguousarray(core["qshift_adj"])
+            st_raw = np.ascontiguousarray(b["lim_state"][:k].cpu().numpy())
+            st = (lc.LimiterState * k).from_buffer_copy(st_raw.tobytes())
+            pcm = np.zeros(k * CH * 1024, np.int16)
+            lc.bind(orc.lib, "xo")[2](k, 1024, CH, xs.ctypes.data_as(lc.P32), 1024 * CH, q.ctypes.data_as(lc.P8), st,
+                                       pcm.ctypes.data_as(lc.P16))
+            ws = self._workspace(k)
+            self.launch(b, fidx, k=k, ws=ws)
+            torch.cuda.synchronize()
+            got_st = (lc.LimiterState * k).from_buffer_copy(b["lim_state"][:k].cpu().numpy().tobytes())
+            return bool(np.array_equal(b["pcm"][:k * CH * 1024].cpu().numpy(), pcm) and
+                        all(lc.state_view(got_st[j]) == lc.state_view(st[j]) for j in range(k)))
+        import sbr_capture as cap
+        core = orc.imdct_batch(h["spec"], h["ics"], h["overlap"], h["state"], pcm_mode=1)
+        n = k * cf
+        hdr = b["hdr"][:n].cpu().numpy()
+        st = np.ascontiguousarray(b["sbr_state"][:n].cpu().numpy())
+        frames = b["frames"][fidx % len(b["frames"])]
+        if w == "c4":
+            fr, pfr = frames[0][:n].cpu().numpy(), frames[1][:n].cpu().numpy()
+            ps = np.ascontiguousarray(b["ps_state"][:n].cpu().numpy())
+        else:
+            fr = frames[:n].cpu().numpy()
+        out = np.zeros(n * 2048 * (2 if w == "c4" else 1), np.int16)
+        rcs = np.zeros(n, np.int32)
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        for j in range(n):
+            pin = np.ascontiguousarray(core["pcm16"][j])
+            if w == "c4":
+                rcs[j] = orc.lib.xo_sbr_dec_hq(vp(hdr[j]), vp(fr[j]), vp(st[j]), vp(pfr[j]), vp(ps[j]), pin.ctypes.data_as(P16),
+                                               1, out[4096 * j:].ctypes.data_as(P16), 2)
+            else:
+                rcs[j] = orc.lib.xo_sbr_dec_lp(vp(hdr[j]), vp(fr[j]), vp(st[j]), pin.ctypes.data_as(P16), 1,
+                                               out[(j // CH) * 2048 * CH + (j % CH):].ctypes.data_as(P16), CH)
+        ws = self._workspace(k)
+        self.launch(b, fidx, k=k, ws=ws)
+        torch.cuda.synchronize()
+        ok = np.array_equal(self.status[:n].cpu().numpy(), rcs)
+        good = rcs == 0
+        per = 4096 if w == "c4" else 2048
+        g_pcm = b["pcm"][:n * per].cpu().numpy()
+        if w == "c4":
+            ok = ok and np.array_equal(g_pcm.reshape(n, per)[good], out.reshape(n, per)[good])
+            ok = ok and np.array_equal(b["ps_state"][:n].cpu().numpy()[good], ps[good])
+        else:
+            unint = lambda a: a.reshape(k, 2048, CH).transpose(0, 2, 1).reshape(n, 2048)
+            ok = ok and np.array_equal(unint(g_pcm)[good], unint(out)[good])
+        ok = ok and np.array_equal(b["sbr_state"][:n].cpu().numpy()[good], st[good])
+        ok = ok and np.array_equal(b["overlap"][:n].cpu().numpy(), core["overlap"])
+        return bool(ok)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--sets", type=int, default=4, help="independent 8192-stream batches cycled per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["c2", "c2l", "c3", "c4"], default="c2",
-                    help="c2: AAC-LC IMDCT+OLA (BASELINE configs[1], default); c2l: c2 + peak limiter + PCM16 (the "
-                         "AAC-LC post stage); c3: HE-AACv1 stereo, IMDCT + LP-SBR; c4: HE-AACv2, mono IMDCT + HQ-SBR + "
-                         "parametric stereo")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short C2 / C3 runs of the N=1 report")
+    ap.add_argument("--workload", choices=["c2", "c2l", "c3", "c4"], default="c4",
+                    help="c4 (default): HE-AACv2, mono IMDCT + HQ-SBR + parametric stereo -- the configuration the "
+                         "metric is quoted on, and C5 with --gpus N; c2: AAC-LC IMDCT+OLA (BASELINE configs[1]); c2l: c2 "
+                         "+ peak limiter + PCM16 (the AAC-LC post stage); c3: HE-AACv1 stereo, IMDCT + LP-SBR")
     args = ap.parse_args()
 
     import torch
@@ -331,141 +534,101 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = xdist.init("nccl")       # RCCL; None at world 1
+    if dist is not None:
+        assert dist.get_world_size() == args.gpus and dist.get_rank() == rank
 
     stream = torch.cuda.Stream(device=dev)      # kernels AND timing events go on this one stream
     torch.cuda.set_stream(stream)
     ctx = libxaac_amd.XaacContext(local_rank, stream.cuda_stream)
-    c3, c4, c2l = args.workload == "c3", args.workload == "c4", args.workload == "c2l"
-    batches = (make_inputs_c3(torch, dev, args.sets, rank) if c3 else make_inputs_c4(torch, dev, args.sets, rank) if c4
-               else make_inputs(torch, dev, args.sets, rank, limiter=c2l))
-    for b in batches:                 # window shape alternates per frame; state follows
-        b["ics"][:, 1] = (torch.arange(b["ics"].shape[0], device=dev) // (1 if c4 else CH) % 2).to(torch.uint8)
-    ws = None
-    if c3:
-        ws = torch.zeros(ctx.sbr_lp_workspace_bytes(FRAMES_PER_STEP * CH), dtype=torch.uint8, device=dev)
-    if c4:
-        ws = torch.zeros(ctx.sbr_hq_workspace_bytes(FRAMES_PER_STEP, True), dtype=torch.uint8, device=dev)
-    if c2l:
-        ws = torch.zeros(ctx.peak_limiter_workspace_bytes(FRAMES_PER_STEP), dtype=torch.uint8, device=dev)
-
-    def step(i, ev=None):
-        b = batches[i % len(batches)]
-        if ev is not None:
-            ev[0].record(stream)
-        if c3:
-            # core decoder back-end: planar PCM16 with the SBR hand-off rounding, then the low-power SBR chain
-            ctx.imdct_process_batch(b["spec"], b["ics"], b["overlap"], b["state"], None, b["core_pcm"], None,
-                                    ch_fac=1, pcm_mode=libxaac_amd.PCM_SBR)
-            ctx.sbr_lp_process_batch(b["core_pcm"], b["hdr"], b["frames"][(i // len(batches)) % len(b["frames"])],
-                                     b["sbr_state"], b["pcm"], ws, None, in_ch_fac=1, out_ch_fac=CH)
-        elif c4:
-            # mono core back-end, then HQ SBR + parametric stereo -> L,R pairs
-            ctx.imdct_process_batch(b["spec"], b["ics"], b["overlap"], b["state"], None, b["core_pcm"], None,
-                                    ch_fac=1, pcm_mode=libxaac_amd.PCM_SBR)
-            fr, pfr = b["frames"][(i // len(batches)) % len(b["frames"])]
-            ctx.sbr_hq_process_batch(b["core_pcm"], b["hdr"], fr, b["sbr_state"], b["pcm"], ws, pfr, b["ps_state"])
-        elif c2l:
-            # AAC-LC tail as api.c runs it: WORD32 block + qshift_adj -> limiter in place -> interleaved PCM16.  The
-            # block stays planar between the two (16-byte stores from the IMDCT; the limiter interleaves on the way out)
-            ctx.imdct_process_batch(b["spec"], b["ics"], b["overlap"], b["state"], b["out32"], None, b["qshift"],
-                                    ch_fac=1)
-            ctx.peak_limiter_process_batch(b["out32"], b["qshift"], b["lim_state"], CH, ws, pcm16=b["pcm"], planar=True)
-        else:
-            ctx.imdct_process_batch(b["spec"], b["ics"], b["overlap"], b["state"], None, b["pcm"], None,
-                                    ch_fac=CH, pcm_mode=libxaac_amd.PCM_LC)
-        if ev is not None:
-            ev[1].record(stream)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i, events[i])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = xdist.max_over_ranks(dist, elapsed, dev)
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
+    w = args.workload
+    job = Workload(w, torch, libxaac_amd, ctx, dev, stream, args.sets, rank)
+    own_elapsed, kern_ms = job.run(args.steps, args.warmup, barrier)
+    elapsed = xdist.max_over_ranks(dist, own_elapsed, dev)
+    refused = job.refused()
+    try:
+        checked = job.verify()
+    except Exception as e:  # the checker (oracle/) is test infrastructure: its absence must not hide the measurement
+        checked = "unavailable: %r" % (e,)
 
-    # the run stays honest: decode one more frame of set 0 and compare a slice with the oracle
-    checked = None
-    if rank == 0 and c3:
-        checked = "see tests/test_sbr_gpu.py (bit-exact vs reference records and oracle chains)"
-    if rank == 0 and c4:
-        checked = "see tests/test_sbr_hq_gpu.py (bit-exact vs reference records and oracle chains)"
-    if rank == 0 and c2l:
-        st = batches[0]["lim_state"].cpu().numpy()
-        mg = np.ascontiguousarray(st[:, 24:28]).view(np.float32).reshape(-1)
-        checked = ("see tests/test_limiter_gpu.py (bit-exact vs reference vectors and oracle chains); streams limiting "
-                   "in the last frame: %.1f %%" % (100.0 * float((mg < 1.0).mean())))
-    if rank == 0 and not (c3 or c4 or c2l):
-        try:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import oracle_lib
-            orc = oracle_lib.load_oracle()
-            b = batches[0]
-            k = 256
-            h = {n_: b[n_][:k].cpu().numpy() for n_ in ("spec", "ics", "overlap", "state")}
-            want = orc.imdct_batch(h["spec"], h["ics"], h["overlap"], h["state"], ch_fac=CH)
-            step(0)
-            torch.cuda.synchronize()
-            checked = bool(np.array_equal(b["pcm"][:k * 1024].cpu().numpy().reshape(k, 1024), want["pcm16"]) and
-                           np.array_equal(b["overlap"][:k].cpu().numpy(), want["overlap"]))
-        except Exception as e:  # the checker is optional for the measurement itself
-            checked = "unavailable: %s" % e
+    # the ranks' own rates (load balance of a SCALE run) and the final interleaved gather over RCCL/xGMI, once
+    per_rank, gather = None, None
+    if dist is not None:
+        t = torch.tensor([FRAMES_PER_STEP * args.steps / own_elapsed], dtype=torch.float64, device=dev)
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        per_rank = [round(float(p.item()), 1) for p in parts]
+        pcm = job.batches[0]["pcm"].view(FRAMES_PER_STEP, -1)
+        xdist.gather_pcm(dist, pcm[:64])          # warm the communicator
+        barrier()
+        t0 = time.perf_counter()
+        whole = xdist.gather_pcm(dist, pcm)
+        barrier()
+        gt = xdist.max_over_ranks(dist, time.perf_counter() - t0, dev)
+        lo = rank * FRAMES_PER_STEP
+        assert whole.shape[0] == world * FRAMES_PER_STEP and torch.equal(whole[lo:lo + FRAMES_PER_STEP], pcm)
+        gather = {"ms": round(gt * 1e3, 3), "bytes_per_rank": int(pcm.numel() * pcm.element_size()),
+                  "what": "dist.gather_pcm: all_gather of every rank's last PCM batch (all ranks receive all %d "
+                          "streams' frames), RCCL, after the timed region" % (world * FRAMES_PER_STEP),
+                  "GBps_in_per_rank": round((world - 1) * pcm.numel() * pcm.element_size() / gt / 1e9, 1)}
+        del whole
+
+    secondary = None
+    if world == 1 and not args.no_secondary and w == "c4":
+        secondary = {}
+        del job.batches, job.ws
+        torch.cuda.empty_cache()
+        for w2 in ("c2", "c3"):
+            j2 = Workload(w2, torch, libxaac_amd, ctx, dev, stream, args.sets, rank)
+            e2, k2 = j2.run(max(20, args.steps // 2), max(4, args.warmup // 2), barrier)
+            steps2 = max(20, args.steps // 2)
+            ab = alg_bytes_per_step(w2)
+            try:
+                ok2 = j2.verify()
+            except Exception as e:
+                ok2 = "unavailable: %r" % (e,)
+            secondary[w2] = {"metric": METRIC[w2], "value": round(FRAMES_PER_STEP * steps2 / e2, 1), "unit": "frames/s",
+                             "steps": steps2, "ms_per_step": round(e2 / steps2 * 1e3, 4), "kernel_ms": round(k2, 5),
+                             "roofline_frac": round(ab / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "alg_bytes_per_step": ab, "refused_frac": j2.refused(), "bit_exact_vs_oracle": ok2,
+                             "workload": WORKLOAD[w2] % args.sets}
+            del j2
+            torch.cuda.empty_cache()
 
     if rank == 0:
         frames = FRAMES_PER_STEP * args.steps * world
-        alg_bytes = (C3_ALG_BYTES_PER_CH * CH if c3 else C4_ALG_BYTES_PER_STREAM if c4 else
-                     C2L_ALG_BYTES_PER_FRAME if c2l else ALG_BYTES_PER_FRAME) * FRAMES_PER_STEP
+        alg_bytes = alg_bytes_per_step(w)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        pmc = measured_traffic(w)
         out = {
-            "metric": ("decoded audio frames/s (1024-spl IMDCT + 32/64-band QMF + low-power SBR, HE-AACv1 stereo)" if c3
-                       else "decoded audio frames/s (1024-spl IMDCT + complex QMF + HQ SBR + parametric stereo, "
-                            "HE-AACv2)" if c4
-                       else "decoded audio frames/s (1024-spl IMDCT+overlap-add + peak limiter + PCM16, AAC-LC stereo)"
-                       if c2l else "decoded audio frames/s (1024-spl IMDCT+overlap-add, AAC-LC stereo)"),
+            "metric": METRIC[w],
             "value": round(frames / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32 (+ f32/f64 gain smoothing)" if c2l else "int32",
+            "dtype": "int32 (+ f32/f64 gain smoothing)" if w == "c2l" else "int32",
             "data": "synthetic",
-            "config": {"workload": ("C3: HE-AACv1 48 kHz stereo, batch=8192 frames/step: IMDCT+OLA -> QMF-32 analysis -> "
-                                    "LPP HF generation + envelope adjustment (side info cycled from reference-captured "
-                                    "frames) -> QMF-64 synthesis, %d stream sets cycled" % args.sets) if c3 else
-                                   ("C4: HE-AACv2 48 kHz, batch=8192 frames/step (one mono core channel each): IMDCT+OLA "
-                                    "-> complex QMF-32 analysis -> LPP transposer + envelope adjustment -> parametric "
-                                    "stereo -> two complex QMF-64 synthesis banks (SBR / PS side info cycled from "
-                                    "reference-captured frames), %d stream sets cycled" % args.sets) if c4 else
-                                   ("C2L: C2 + the AAC-LC post stage, batch=8192 frames/step: IMDCT + window/overlap-add "
-                                    "(WORD32 block + qshift_adj) -> peak limiter in place (5 ms look-ahead, attack / "
-                                    "release smoothing) -> PCM16; every %dth stream decodes above full scale, %d stream "
-                                    "sets cycled" % (C2L_LOUD_EVERY, args.sets)) if c2l else
-                                   ("C2: AAC-LC 48 kHz stereo, batch=8192 frames/step (16384 channel-frames), "
-                                    "ONLY_LONG 1024-pt IMDCT + window/overlap-add + PCM16, %d stream sets cycled"
-                                    % args.sets),
-                       "frames_per_step": FRAMES_PER_STEP, "channels": 1 if c4 else CH, "launch": ctx.last_launch(),
-                       "sharding": "streams split across ranks, no data-path collective"},
+            "config": {"workload": WORKLOAD[w] % args.sets,
+                       "frames_per_step": FRAMES_PER_STEP, "channels": 1 if w == "c4" else CH, "launch": ctx.last_launch(),
+                       "sharding": "streams split across ranks (%d per rank), no data-path collective" % FRAMES_PER_STEP},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None if (c3 or c4 or c2l) else (measured_traffic() or {}).get("bytes_per_launch"),
-                         "traffic_source": None if (c3 or c4 or c2l) else (measured_traffic() or {}).get("source"),
-                         "kernel": "imdct_ola + qmf_analysis + sbr_core_lp + qmf_synthesis (4 launches)" if c3
-                                   else "imdct_ola + qmf_analysis + sbr_core_hq + ps + 2 x qmf_synthesis (6 launches)" if c4
-                                   else "imdct_ola + limiter_front + limiter_gain + limiter_apply (4 launches)" if c2l
-                                   else "xaac_imdct_ola_kernel", "kernel_ms": round(kern_ms, 5),
-                         "alg_bytes_per_launch": alg_bytes},
+                         "traffic": pmc.get("bytes_per_step"), "traffic_source": pmc.get("source"),
+                         "kernel": KERNELS[w], "kernel_ms": round(kern_ms, 5), "alg_bytes_per_launch": alg_bytes},
+            "refused_frac": refused,
             "bit_exact_vs_oracle": checked,
         }
+        if per_rank is not None:
+            out["per_rank_frames_per_s"] = per_rank
+            out["gather"] = gather
+        if secondary is not None:
+            out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_sbr(args.workload) if (c3 or c4) else cpu_baseline(limiter=c2l)
+            out["cpu_baseline"] = cpu_baseline_sbr(w) if w in ("c3", "c4") else cpu_baseline(limiter=(w == "c2l"))
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
