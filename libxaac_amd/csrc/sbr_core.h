@@ -1949,7 +1949,9 @@ FX_HD int xs_side_info_bad(const XsCx &cx, const xaac_sbr_header *h, const xaac_
     bad |= in(h->sub_band_start, 0, 64) | in(h->sub_band_end, h->sub_band_start, 64);
     bad |= in(h->num_patches, 0, XAAC_SBR_MAX_PATCHES) | in(h->start_patch, 0, 64) | in(h->stop_patch, 0, 64);
     bad |= in(f->num_env, 0, XAAC_SBR_MAX_ENVELOPES) | in(f->num_noise_env, 0, XAAC_SBR_MAX_NOISE_ENVELOPES);
-    bad |= in(f->max_qmf_subband_aac, 0, 64) | in(f->transient_env, -1, XAAC_SBR_MAX_ENVELOPES);
+    /* the reference sets max_qmf_subband_aac = sub_band_start (sbrdecoder.c:731); below it, skip_bands of env_calc.c:633 /
+       :764 would be negative and the per-band arrays would be read before their first element */
+    bad |= in(f->max_qmf_subband_aac, h->sub_band_start, 64) | in(f->transient_env, -1, XAAC_SBR_MAX_ENVELOPES);
   }
   /* the entries in use (what lies behind a count is the host's business) */
   const int n_hi = h->num_sf_bands[1], n_lo = h->num_sf_bands[0], n_lim = h->num_lf_bands, n_nf = h->num_nf_bands;

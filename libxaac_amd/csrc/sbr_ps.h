@@ -189,15 +189,16 @@ FX_HD int32_t xp_power(int32_t re, int32_t im) {
 
 /* one all-pass stage chain (ps_dec.c:262-321 / :377-437): in = delayed sample rotated by the band's
    fractional-delay phase; three serial links with per-link delay lines.  d0: the band's delay-line
-   entry {re, im}; ser[m]: its entry in link m's buffer at that link's read position. */
-FX_HD void xp_allpass(int16_t *d0, int32_t new_re, int32_t new_im, const int16_t *phase, int16_t *ser0, int16_t *ser1,
+   entry {re, im}; new_re16 / new_im16: the band's current sample rounded to 16 bits (what the delay line takes in);
+   ser[m]: its entry in link m's buffer at that link's read position. */
+FX_HD void xp_allpass(int16_t *d0, int16_t new_re16, int16_t new_im16, const int16_t *phase, int16_t *ser0, int16_t *ser1,
                       int16_t *ser2, const int16_t *ph0, const int16_t *ph1, const int16_t *ph2, int16_t decay0,
                       int16_t decay1, int16_t decay2, int16_t *out_re, int16_t *out_im) {
   const int16_t r0 = d0[0], i0 = d0[1];
   int16_t in_re = (int16_t)(fx_sub_sat((int32_t)r0 * phase[0], (int32_t)i0 * phase[1]) >> 15);
   int16_t in_im = (int16_t)(fx_add_sat((int32_t)r0 * phase[1], (int32_t)i0 * phase[0]) >> 15);
-  d0[0] = fx_round16(new_re);
-  d0[1] = fx_round16(new_im);
+  d0[0] = new_re16; /* round16 of the band's sample, ps_dec.c:268 */
+  d0[1] = new_im16;
   int16_t *ser[3] = {ser0, ser1, ser2};
   const int16_t *ph[3] = {ph0, ph1, ph2};
   const int16_t decay[3] = {decay0, decay1, decay2};
@@ -285,7 +286,7 @@ FX_HD void xp_decorrelation(const XsCx &cx, const XpTables *T, PS *ps, XpHyb *hy
       const int16_t *ph = hyb ? &T->frac_delay_phase_fac_qmf_sub_re_im[2 * sb] : &T->frac_delay_phase_fac_qmf_re_im[2 * sb];
       const int16_t *pser = hyb ? &T->frac_delay_phase_fac_qmf_sub_ser_re_im[2 * sb] : &T->frac_delay_phase_fac_qmf_ser_re_im[2 * sb];
       const int pstep = hyb ? 32 : 64;
-      xp_allpass(d0, hyb ? hy->l_re[sb] : l_re[sb], hyb ? hy->l_im[sb] : l_im[sb], ph, e0, e1, e2, pser, pser + pstep,
+      xp_allpass(d0, fx_round16(hyb ? hy->l_re[sb] : l_re[sb]), fx_round16(hyb ? hy->l_im[sb] : l_im[sb]), ph, e0, e1, e2, pser, pser + pstep,
                  pser + 2 * pstep, hyb ? T->rev_link_decay_ser[0] : T->decay_scale_factor[di],
                  hyb ? T->rev_link_decay_ser[1] : T->decay_scale_factor[di + 1],
                  hyb ? T->rev_link_decay_ser[2] : T->decay_scale_factor[di + 2], &o_re, &o_im);
@@ -359,6 +360,8 @@ FX_HD int xp_frame_sanitize(const XsCx &cx, xaac_ps_frame *pf) {
 /* ps_dec.c:714: at an envelope border, the target mixing coefficients of every parameter group from the
    IID / ICC indices, and the per-slot increments towards them (one group per lane) */
 template <class PS>
+FX_HD void xp_rot_env_coeffs(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_frame *pf, int env);
+template <class PS>
 FX_HD void xp_init_rot_env(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_frame *pf, int env, int usb) {
   if (env == 0) {
     const int usb_prev = cx.uni(ps->usb);
@@ -376,6 +379,12 @@ FX_HD void xp_init_rot_env(const XsCx &cx, const XpTables *T, PS *ps, const xaac
     }
     cx.sync();
   }
+  xp_rot_env_coeffs(cx, T, ps, pf, env);
+}
+
+/* the second half of ps_dec.c:714: target coefficients of envelope `env` and the per-slot increments towards them */
+template <class PS>
+FX_HD void xp_rot_env_coeffs(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_frame *pf, int env) {
   const int fine = cx.uni(pf->iid_quant);
   const int steps = fine ? 15 : 7;
   const int16_t *sf = fine ? T->scale_factors_fine : T->scale_factors;

@@ -18,8 +18,8 @@ NAMES = {1: "block floating point", 2: "hf generator (total)", 3: "env: init/sin
          23: "alias: groups (lane 0)"}
 
 
-PS_NAMES = {1: "copy-in, init_ps_scale", 2: "row loads", 3: "init_rot_env", 4: "hybrid analysis", 5: "decorrelation",
-            6: "rotation", 7: "row stores", 8: "state out"}
+PS_NAMES = {1: "sanitize, init_ps_scale", 2: "P1 hybrid analysis", 3: "P2 envelope walk", 4: "P3 band powers, inputs",
+            5: "P4 transient detector", 6: "P5 all-pass chains", 7: "P6 hybrid rotation", 8: "P7 delays, rotation, rows out"}
 
 
 def main_ps():
