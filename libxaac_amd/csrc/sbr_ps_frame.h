@@ -43,29 +43,44 @@
 
 #define XP_MAX_SEG (XAAC_PS_MAX_ENV + 2) /* the segment carried in from the last frame + one per border (env 0..5) */
 
+#if defined(__HIPCC__)
+#define XP_UNROLL _Pragma("unroll")
+#else
+#define XP_UNROLL
+#endif
+
 struct XpFrameWork {
-  union {                    /* three scratch areas that are never live together */
+  union {                    /* scratch areas that are never live together */
     int32_t hyb_u[3][2][44]; /* P1: hybrid filter input of QMF bands 0..2: 12 slots of history + this frame's 32 */
     int32_t gsum[8][56];     /* P3: addends of the group sums, bands 9..63 of eight slots */
-    int32_t low[32][12];     /* P6 -> P7: QMF bands 0..2 after hybrid synthesis: [band][l_re, l_im, r_re, r_im] */
+    int32_t peak[32][20];    /* P4: transient peak difference */
   };
-  int32_t hyb_l[32][20];     /* left hybrid sub-band samples of every slot: re 0..9 | im 10..19; rotated in place */
+  int32_t hyb_l[32][20];     /* left hybrid sub-band samples of every slot: re 0..9 | im 10..19 */
   union {
     int32_t binpw[32][20];   /* P3: bin powers; P4: smoothed energy ... */
     int16_t ratio[32][20];   /* ... compacted in place into the transient ratios (entry i lands inside entry i / 2) */
   };
-  union {
-    int32_t peak[32][20];    /* P4: transient peak difference */
-    int32_t hyb_r[32][20];   /* P6: right hybrid sub-band samples after the rotation */
-  };
-  uint32_t ap[32][30];       /* all-pass chains, 10 hybrid + QMF bands 3..22: rounded input pairs -> output pairs */
-  uint32_t dl[32][12];       /* rounded input pairs of QMF bands 23..34 (the 14-slot delay) */
+  uint32_t ap_h[32][10];     /* outputs of the hybrid sub-bands' all-pass chains (re, im pairs) */
   int16_t seg_h[XP_MAX_SEG][4][24]; /* per segment and group: H11, H12, H21, H22 before the segment's first slot */
   int16_t seg_d[XP_MAX_SEG][4][24]; /* per-slot increments */
-  int8_t seg_of_slot[32];
-  int8_t seg_start[8];
 };
 
+/* What a lane keeps for its QMF band from the moment the rows are fetched until they are written back: the band's 32
+   complex samples (the stream's whole QMF matrix is 64 registers per lane).  On the host the "lanes" are array
+   elements. */
+struct XpLaneRows {
+  int32_t re[32], im[32];
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+#define XP_LANE_ROWS(name) XpLaneRows name##_[1]
+#define XP_ROWS(name, lane) name##_[0]
+#else
+#define XP_LANE_ROWS(name) static thread_local XpLaneRows name##_[64]
+#define XP_ROWS(name, lane) name##_[lane]
+#endif
+
+FX_HD int xp_popc(uint32_t v) { return __builtin_popcount(v); }
+FX_HD int xp_clz(uint32_t v) { return __builtin_clz(v); } /* v != 0 */
 FX_HD uint32_t xp_pack16(int16_t lo, int16_t hi) { return (uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16); }
 FX_HD int16_t xp_lo16(uint32_t v) { return (int16_t)(v & 0xffffu); }
 FX_HD int16_t xp_hi16(uint32_t v) { return (int16_t)(v >> 16); }
@@ -95,6 +110,16 @@ FX_HD int32_t xp_bin_power_hyb(const XpTables *T, int bin, const int32_t *re, co
 template <class PS>
 FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_frame *pf, XpFrameWork *w, int32_t *xl,
                       int32_t *xr, int lb_scale, int ov_lb_scale, int hb_scale, int st_syn, int lsb, int usb) {
+  /* the lane's band, all 32 slots: 64 loads in flight while the state is scaled and the envelopes are walked */
+  XP_LANE_ROWS(rows);
+  XS_PAR(sb, 0, 64) {
+    XpLaneRows &rw = XP_ROWS(rows, sb);
+    XP_UNROLL
+    for (int l = 0; l < 32; l++) {
+      rw.re[l] = xl[l * 128 + sb];
+      rw.im[l] = xl[l * 128 + 64 + sb];
+    }
+  }
   const int ps_scale = xp_init_ps_scale(cx, ps, lb_scale, ov_lb_scale, hb_scale); /* sbr_dec.c:1252 */
   const int ov_lb_shift = ps_scale - ov_lb_scale, lb_shift = ps_scale - lb_scale, hb_shift = ps_scale - hb_scale;
   const int common_shift = (st_syn - ps_scale) - 8;
@@ -157,13 +182,14 @@ FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_f
     w->seg_d[0][2][g] = ps->delta_h21_h22[2 * g];
     w->seg_d[0][3][g] = ps->delta_h21_h22[2 * g + 1];
   }
-  XS_ONE w->seg_start[0] = 0;
   const int usb_prev = cx.uni(ps->usb);
+  uint32_t seg_mask = 0; /* bit l: a border was reached at slot l -- segment popcount(bits 0..l) starts there (a scalar) */
   int clear_slot = 32; /* first slot that runs with the new usb: the slot of border 0, if it is reached at all */
   {
-    int env = 0, cur = 0, nseg = 1;
+    int env = 0, nseg = 1;
+    int next = cx.uni(pf->border_position[0]); /* the border the counter is waiting for; 64 = none left */
     for (int l = 0; l < 32; l++) {
-      if (env <= XAAC_PS_MAX_ENV && l == cx.uni(pf->border_position[env])) {
+      if (l == next) {
         if (env == 0) clear_slot = l;
         cx.sync();
         xp_rot_env_coeffs(cx, T, ps, pf, env); /* ps->H.. = the old targets, ps->delta.., ps->h.._vec = the new ones */
@@ -177,37 +203,33 @@ FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_f
           w->seg_d[nseg][2][g] = ps->delta_h21_h22[2 * g];
           w->seg_d[nseg][3][g] = ps->delta_h21_h22[2 * g + 1];
         }
-        XS_ONE w->seg_start[nseg] = (int8_t)l;
-        cur = nseg++;
+        seg_mask |= 1u << l;
+        nseg++;
         env++;
+        next = env <= XAAC_PS_MAX_ENV ? cx.uni(pf->border_position[env]) : 64;
       }
-      XS_ONE w->seg_of_slot[l] = (int8_t)cur;
     }
   }
   cx.sync();
   XP_T(3);
 
-  /* ---- P3: band powers (ps_dec.c:520-545), the inputs of the all-pass chains and of the 14-slot delay.  A lane
-     walks its band through eight slots at a time: the sixteen row words are fetched together. */
+  /* ---- P3: band powers (ps_dec.c:520-545).  The lane's 64 row words arrive here (fetched at the top of the frame),
+     are brought to the PS scale and stay in registers. */
+  XP_UNROLL
   for (int c = 0; c < 4; c++) {
     XS_PAR(sb, 0, 64) {
-      int32_t rre[8], rim[8];
-      for (int ls = 0; ls < 8; ls++) {
-        rre[ls] = xl[(8 * c + ls) * 128 + sb];
-        rim[ls] = xl[(8 * c + ls) * 128 + 64 + sb];
-      }
+      XpLaneRows &rw = XP_ROWS(rows, sb);
       const int gsh = sb < 11 ? 0 : (sb < 18 ? 1 : (sb < 23 ? 2 : (sb < 35 ? 3 : 4))); /* group_shift of the band's group */
+      XP_UNROLL
       for (int ls = 0; ls < 8; ls++) {
         const int l = 8 * c + ls;
         const int usb_l = l >= clear_slot ? usb : usb_prev;
         const int sh = sb < lsb ? (l < 6 ? ov_lb_shift : lb_shift) : (sb < usb ? hb_shift : 0);
-        const int32_t re = xp_adj_word(rre[ls], sh), im = xp_adj_word(rim[ls], sh);
+        const int32_t re = xp_adj_word(rw.re[l], sh), im = xp_adj_word(rw.im[l], sh);
+        rw.re[l] = re;
+        rw.im[l] = im;
         if (sb >= 3) {
           const int32_t pw = xp_power(re, im);
-          if (sb < 23)
-            w->ap[l][10 + sb - 3] = xp_pack16(fx_round16(re), fx_round16(im));
-          else if (sb < 35)
-            w->dl[l][sb - 23] = xp_pack16(fx_round16(re), fx_round16(im));
           if (sb < 9)
             w->binpw[l][sb + 5] = pw;
           else
@@ -224,10 +246,6 @@ FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_f
       w->binpw[8 * c + ls][14 + g] = acc;
     }
     cx.sync();
-  }
-  XS_PAR(i, 0, 320) {
-    const int l = i / 10, u = i % 10;
-    w->ap[l][u] = xp_pack16(fx_round16(w->hyb_l[l][u]), fx_round16(w->hyb_l[l][10 + u]));
   }
   XS_PAR(i, 0, 256) {
     const int l = i >> 3, bin = i & 7;
@@ -272,191 +290,262 @@ FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_f
   cx.sync();
   XP_T(5);
 
-  /* ---- P5: the thirty all-pass chains (ps_dec.c:236 hybrid sub-bands, :339 QMF bands 3..22 whatever usb is) */
+  /* ---- P5 + P7, one walk over the slots per lane.
+     All-pass chains (ps_dec.c:236 hybrid sub-bands, :339 QMF bands 3..22 whatever usb is): the chain of QMF band sb
+     runs on lane sb -- its input is the lane's own row word, its output feeds the lane's own rotation --, the chains
+     of the ten hybrid sub-bands on lanes 32..41 (their outputs go to LDS for P6).  A chain's delay lines (a 2-slot
+     line and three links of 3, 4 and 5 slots) are loaded oldest-first into registers, shifted by renaming in the
+     unrolled loop, and stored back at the end: no LDS traffic inside the recursion.
+     Delays, rotation, output (ps_dec.c:602-648, :893-945, generic:1610): the 14-slot delay reads the lane's own
+     registers of slot l - 14, the 1-slot delay and the interpolated coefficients of the band's group stay in
+     registers too.  Bands 0..2 are written by P6. */
   {
-    int idx = cx.uni(ps->idx);
-    int is0 = cx.uni(ps->idx_ser[0]), is1 = cx.uni(ps->idx_ser[1]), is2 = cx.uni(ps->idx_ser[2]);
-    const int ss0 = cx.uni(ps->sample_ser[0]), ss1 = cx.uni(ps->sample_ser[1]), ss2 = cx.uni(ps->sample_ser[2]);
-    for (int l = 0; l < 32; l++) {
-      if (l == clear_slot && usb > usb_prev && usb_prev) { /* ps_dec.c:733-757: bands that just became active */
-        const int ap_hi = usb < 23 ? usb : 23;
-        cx.sync();
-        if (ap_hi > usb_prev)
-          for (int i = 0; i < 3; i++)
-            for (int j = 0; j < (i == 0 ? ss0 : (i == 1 ? ss1 : ss2)); j++)
-              XS_PAR(k, 2 * usb_prev, 2 * ap_hi) ps->ser[j][i][k] = 0;
-        cx.sync();
-      }
-      XS_PAR(u, 0, 30) {
-        const int hyb = u < 10, sb = hyb ? u : u - 7;
-        const int di = 9 + 3 * (sb - 3);
-        int16_t *d0 = hyb ? &ps->sub[idx][2 * sb] : &ps->ap[idx][2 * sb];
-        int16_t *e0 = hyb ? &ps->sub_ser[is0][0][2 * sb] : &ps->ser[is0][0][2 * sb];
-        int16_t *e1 = hyb ? &ps->sub_ser[is1][1][2 * sb] : &ps->ser[is1][1][2 * sb];
-        int16_t *e2 = hyb ? &ps->sub_ser[is2][2][2 * sb] : &ps->ser[is2][2][2 * sb];
-        const int16_t *ph = hyb ? &T->frac_delay_phase_fac_qmf_sub_re_im[2 * sb] : &T->frac_delay_phase_fac_qmf_re_im[2 * sb];
-        const int16_t *pser = hyb ? &T->frac_delay_phase_fac_qmf_sub_ser_re_im[2 * sb] : &T->frac_delay_phase_fac_qmf_ser_re_im[2 * sb];
-        const int pstep = hyb ? 32 : 64;
-        const uint32_t in = w->ap[l][u];
-        int16_t o_re, o_im;
-        xp_allpass(d0, xp_lo16(in), xp_hi16(in), ph, e0, e1, e2, pser, pser + pstep, pser + 2 * pstep,
-                   hyb ? T->rev_link_decay_ser[0] : T->decay_scale_factor[di],
-                   hyb ? T->rev_link_decay_ser[1] : T->decay_scale_factor[di + 1],
-                   hyb ? T->rev_link_decay_ser[2] : T->decay_scale_factor[di + 2], &o_re, &o_im);
-        w->ap[l][u] = xp_pack16(o_re, o_im);
-      }
-      idx = idx + 1 >= 2 ? 0 : idx + 1;
-      is0 = is0 + 1 >= ss0 ? 0 : is0 + 1;
-      is1 = is1 + 1 >= ss1 ? 0 : is1 + 1;
-      is2 = is2 + 1 >= ss2 ? 0 : is2 + 1;
-    }
-    cx.sync();
-    XS_ONE {
-      ps->idx = (int16_t)idx;
-      ps->idx_ser[0] = (int16_t)is0;
-      ps->idx_ser[1] = (int16_t)is1;
-      ps->idx_ser[2] = (int16_t)is2;
-    }
-  }
-  cx.sync();
-  XP_T(6);
-
-  /* ---- P6: rotation of the hybrid sub-bands (ps_dec.c:856, groups 0..9) and hybrid synthesis of QMF bands 0..2 */
-  XS_PAR(i, 0, 320) {
-    const int l = i / 10, sb = i % 10;
-    const int s = w->seg_of_slot[l], n = l - w->seg_start[s] + 1;
-    const int16_t h11 = (int16_t)(w->seg_h[s][0][sb] + n * w->seg_d[s][0][sb]);
-    const int16_t h12 = (int16_t)(w->seg_h[s][1][sb] + n * w->seg_d[s][1][sb]);
-    const int16_t h21 = (int16_t)(w->seg_h[s][2][sb] + n * w->seg_d[s][2][sb]);
-    const int16_t h22 = (int16_t)(w->seg_h[s][3][sb] + n * w->seg_d[s][3][sb]);
-    const int16_t tr = w->ratio[l][T->hybrid_to_bin[sb]];
-    const uint32_t o = w->ap[l][sb];
-    int32_t l_re = w->hyb_l[l][sb], l_im = w->hyb_l[l][10 + sb];
-    int32_t r_re = xp_m16x16_shl(xp_lo16(o), tr), r_im = xp_m16x16_shl(xp_hi16(o), tr);
-    xp_rotate(&l_re, &r_re, h11, h12, h21, h22);
-    xp_rotate(&l_im, &r_im, h11, h12, h21, h22);
-    w->hyb_l[l][sb] = l_re;
-    w->hyb_l[l][10 + sb] = l_im;
-    w->hyb_r[l][sb] = r_re;
-    w->hyb_r[l][10 + sb] = r_im;
-  }
-  cx.sync();
-  XS_PAR(i, 0, 384) {
-    const int l = i / 12, b = (i % 12) >> 2, c = i & 3;
-    const int p = b == 0 ? 0 : 4 + 2 * b, n = b == 0 ? 6 : 2;
-    const int32_t *src = (c < 2 ? &w->hyb_l[l][0] : &w->hyb_r[l][0]) + ((c & 1) ? 10 : 0) + p;
-    int32_t a = src[0];
-    for (int k = 1; k < n; k++) a = fx_add_sat(a, src[k]);
-    w->low[l][4 * b + c] = a;
-  }
-  cx.sync();
-  XP_T(7);
-
-  /* ---- P7: plain delays (ps_dec.c:602-648), rotation (ps_dec.c:893-945), the common shift in front of the left
-     bank (generic:1610).  A lane walks its band through the 32 slots (one row word pair in, two out per slot, eight
-     slots' words fetched together); what the slot loop keeps in the state between slots -- the interpolated
-     coefficients of the band's group, the 1-slot delay -- stays in the lane's registers. */
-  {
-    const int idx_long0 = cx.uni(ps->idx_long);
+    const int idx0 = cx.uni(ps->idx), idx_long0 = cx.uni(ps->idx_long);
+    const int is0 = cx.uni(ps->idx_ser[0]), is1 = cx.uni(ps->idx_ser[1]), is2 = cx.uni(ps->idx_ser[2]);
+    const int clear_lo = (usb > usb_prev && usb_prev) ? usb_prev : 64; /* ps_dec.c:733-757: bands that just became active */
+    const int clear_hi = usb < 23 ? usb : 23;
     XS_PAR(sb, 0, 64) {
-      const int g = T->band_to_group[sb];
-      int16_t h11 = 0, h12 = 0, h21 = 0, h22 = 0, d11 = 0, d12 = 0, d21 = 0, d22 = 0;
-      uint32_t prev = sb >= 35 ? xp_pack16(ps->sd[2 * (sb - 35)], ps->sd[2 * (sb - 35) + 1]) : 0u;
-      for (int c = 0; c < 4; c++) {
-        int32_t rre[8], rim[8];
-        for (int ls = 0; ls < 8; ls++) {
-          rre[ls] = xl[(8 * c + ls) * 128 + sb];
-          rim[ls] = xl[(8 * c + ls) * 128 + 64 + sb];
+      XpLaneRows &rw = XP_ROWS(rows, sb);
+      /* -- the lane's chain, if it has one */
+      const int qmf_chain = sb >= 3 && sb < 23, hyb_chain = sb >= 32 && sb < 42, chain = qmf_chain || hyb_chain;
+      const int csb = qmf_chain ? sb : (hyb_chain ? sb - 32 : 3);
+      const int di = 9 + 3 * (csb - 3);
+      const int16_t *ph = hyb_chain ? &T->frac_delay_phase_fac_qmf_sub_re_im[2 * csb] : &T->frac_delay_phase_fac_qmf_re_im[2 * csb];
+      const int16_t *pser = hyb_chain ? &T->frac_delay_phase_fac_qmf_sub_ser_re_im[2 * csb] : &T->frac_delay_phase_fac_qmf_ser_re_im[2 * csb];
+      const int pstep = hyb_chain ? 32 : 64;
+      const int16_t phase[2] = {ph[0], ph[1]};
+      const int16_t ps0[2] = {pser[0], pser[1]}, ps1[2] = {pser[pstep], pser[pstep + 1]},
+                    ps2[2] = {pser[2 * pstep], pser[2 * pstep + 1]};
+      const int16_t dec0 = hyb_chain ? T->rev_link_decay_ser[0] : T->decay_scale_factor[qmf_chain ? di : 9];
+      const int16_t dec1 = hyb_chain ? T->rev_link_decay_ser[1] : T->decay_scale_factor[qmf_chain ? di + 1 : 10];
+      const int16_t dec2 = hyb_chain ? T->rev_link_decay_ser[2] : T->decay_scale_factor[qmf_chain ? di + 2 : 11];
+      uint32_t d0[2] = {0, 0}, r0[3] = {0, 0, 0}, r1[4] = {0, 0, 0, 0}, r2[5] = {0, 0, 0, 0, 0}; /* oldest first */
+      if (chain) {
+        XP_UNROLL
+        for (int j = 0; j < 2; j++) {
+          const int16_t *q = hyb_chain ? &ps->sub[(idx0 + j) % 2][2 * csb] : &ps->ap[(idx0 + j) % 2][2 * csb];
+          d0[j] = xp_pack16(q[0], q[1]);
         }
-        for (int ls = 0; ls < 8; ls++) {
-          const int l = 8 * c + ls;
-          const int s = cx.uni(w->seg_of_slot[l]);
-          const int usb_l = l >= clear_slot ? usb : usb_prev;
-          if (l == cx.uni(w->seg_start[s])) { /* a border: this group's coefficients restart from the old targets */
-            h11 = w->seg_h[s][0][g]; h12 = w->seg_h[s][1][g]; h21 = w->seg_h[s][2][g]; h22 = w->seg_h[s][3][g];
-            d11 = w->seg_d[s][0][g]; d12 = w->seg_d[s][1][g]; d21 = w->seg_d[s][2][g]; d22 = w->seg_d[s][3][g];
+        XP_UNROLL
+        for (int j = 0; j < 3; j++) {
+          const int16_t *q = hyb_chain ? &ps->sub_ser[(is0 + j) % 3][0][2 * csb] : &ps->ser[(is0 + j) % 3][0][2 * csb];
+          r0[j] = xp_pack16(q[0], q[1]);
+        }
+        XP_UNROLL
+        for (int j = 0; j < 4; j++) {
+          const int16_t *q = hyb_chain ? &ps->sub_ser[(is1 + j) % 4][1][2 * csb] : &ps->ser[(is1 + j) % 4][1][2 * csb];
+          r1[j] = xp_pack16(q[0], q[1]);
+        }
+        XP_UNROLL
+        for (int j = 0; j < 5; j++) {
+          const int16_t *q = hyb_chain ? &ps->sub_ser[(is2 + j) % 5][2][2 * csb] : &ps->ser[(is2 + j) % 5][2][2 * csb];
+          r2[j] = xp_pack16(q[0], q[1]);
+        }
+      }
+      /* -- the lane's band */
+      const int g = T->band_to_group[sb];
+      const int bin_sb = sb < 23 ? T->delay_to_bin[sb] : (sb < 35 ? 18 : 19); /* the band's transient-detector bin */
+      /* segment 0 continues the last frame's interpolation */
+      int16_t h11 = w->seg_h[0][0][g], h12 = w->seg_h[0][1][g], h21 = w->seg_h[0][2][g], h22 = w->seg_h[0][3][g];
+      int16_t d11 = w->seg_d[0][0][g], d12 = w->seg_d[0][1][g], d21 = w->seg_d[0][2][g], d22 = w->seg_d[0][3][g];
+      uint32_t prev = sb >= 35 ? xp_pack16(ps->sd[2 * (sb - 35)], ps->sd[2 * (sb - 35) + 1]) : 0u;
+      /* What the next slot needs from LDS is fetched one slot ahead (nothing in the loop writes these arrays).  The loop
+         body is written without lane-dependent branches: every lane runs the chain arithmetic (on don't-care values
+         where it has no chain -- the rings then shift by register renaming, not by masked moves), band classes are
+         selects, only the stores are predicated. */
+      const int is_ap = sb < 23, is_d14 = sb >= 23 && sb < 35;
+      const int ldj = is_d14 ? 2 * (sb - 23) : 0;
+      int16_t tr_nx = w->ratio[0][bin_sb];
+      int32_t hre_nx = w->hyb_l[0][csb], him_nx = w->hyb_l[0][10 + csb];
+      uint32_t ld_nx = xp_pack16(ps->ld[idx_long0 % 14][ldj], ps->ld[idx_long0 % 14][ldj + 1]);
+      XP_UNROLL
+      for (int l = 0; l < 32; l++) {
+        const int usb_l = l >= clear_slot ? usb : usb_prev;
+        const int16_t tr = tr_nx;
+        const int32_t hre = hre_nx, him = him_nx;
+        const uint32_t ld_cur = ld_nx;
+        if (l + 1 < 32) {
+          tr_nx = w->ratio[l + 1][bin_sb];
+          hre_nx = w->hyb_l[l + 1][csb];
+          him_nx = w->hyb_l[l + 1][10 + csb];
+          if (l + 1 < 14) {
+            const int pn = (idx_long0 + l + 1) % 14;
+            ld_nx = xp_pack16(ps->ld[pn][ldj], ps->ld[pn][ldj + 1]);
           }
-          h11 = (int16_t)(h11 + d11); /* the interpolation advances whether or not the band is rotated */
-          h12 = (int16_t)(h12 + d12);
-          h21 = (int16_t)(h21 + d21);
-          h22 = (int16_t)(h22 + d22);
-          const int sh = sb < lsb ? (l < 6 ? ov_lb_shift : lb_shift) : (sb < usb ? hb_shift : 0);
-          int32_t re = xp_adj_word(rre[ls], sh), im = xp_adj_word(rim[ls], sh);
-          int32_t r_re = 0, r_im = 0;
-          if (sb < 3) {
-            re = w->low[l][4 * sb];
-            im = w->low[l][4 * sb + 1];
-            r_re = w->low[l][4 * sb + 2];
-            r_im = w->low[l][4 * sb + 3];
-          } else if (sb < usb_l) {
-            uint32_t o;
-            int16_t tr;
-            if (sb < 23) {
-              o = w->ap[l][10 + sb - 3];
-              tr = w->ratio[l][T->delay_to_bin[sb]];
-            } else if (sb < 35) { /* what slot l - 14 put in, if it ran with this band active; else the state */
-              const int pos = (idx_long0 + l) % 14;
-              o = (l >= 14 && sb < (l - 14 >= clear_slot ? usb : usb_prev))
-                      ? w->dl[l - 14][sb - 23]
-                      : xp_pack16(ps->ld[pos][2 * (sb - 23)], ps->ld[pos][2 * (sb - 23) + 1]);
-              tr = w->ratio[l][18];
-            } else {
-              o = prev;
-              tr = w->ratio[l][19];
-              prev = xp_pack16(fx_round16(re), fx_round16(im));
-            }
-            r_re = xp_m16x16_shl(xp_lo16(o), tr);
-            r_im = xp_m16x16_shl(xp_hi16(o), tr);
-            xp_rotate(&re, &r_re, h11, h12, h21, h22);
-            xp_rotate(&im, &r_im, h11, h12, h21, h22);
-          }
-          if (common_shift < 0) {
-            const int cs = -common_shift > 31 ? 31 : -common_shift;
-            re = fx_shr(re, cs);
-            im = fx_shr(im, cs);
-          } else if (common_shift > 0) {
-            re = fx_shl_sat(re, common_shift);
-            im = fx_shl_sat(im, common_shift);
-          }
+        }
+        const int16_t q_re = fx_round16(rw.re[l]), q_im = fx_round16(rw.im[l]);
+        const uint32_t q = xp_pack16(q_re, q_im);
+        /* the chain */
+        if (l == clear_slot) { /* (uniform) the three links' lines of the bands that just became active */
+          const int c = qmf_chain && sb >= clear_lo && sb < clear_hi;
+          XP_UNROLL
+          for (int j = 0; j < 3; j++) r0[j] = c ? 0u : r0[j];
+          XP_UNROLL
+          for (int j = 0; j < 4; j++) r1[j] = c ? 0u : r1[j];
+          XP_UNROLL
+          for (int j = 0; j < 5; j++) r2[j] = c ? 0u : r2[j];
+        }
+        const int16_t in_re = hyb_chain ? fx_round16(hre) : q_re, in_im = hyb_chain ? fx_round16(him) : q_im;
+        int16_t dv[2] = {xp_lo16(d0[0]), xp_hi16(d0[0])};
+        int16_t e0[2] = {xp_lo16(r0[0]), xp_hi16(r0[0])}, e1[2] = {xp_lo16(r1[0]), xp_hi16(r1[0])},
+                e2[2] = {xp_lo16(r2[0]), xp_hi16(r2[0])};
+        int16_t o_re, o_im;
+        xp_allpass(dv, in_re, in_im, phase, e0, e1, e2, ps0, ps1, ps2, dec0, dec1, dec2, &o_re, &o_im);
+        d0[0] = d0[1];
+        d0[1] = xp_pack16(dv[0], dv[1]);
+        r0[0] = r0[1]; r0[1] = r0[2];
+        r0[2] = xp_pack16(e0[0], e0[1]);
+        r1[0] = r1[1]; r1[1] = r1[2]; r1[2] = r1[3];
+        r1[3] = xp_pack16(e1[0], e1[1]);
+        r2[0] = r2[1]; r2[1] = r2[2]; r2[2] = r2[3]; r2[3] = r2[4];
+        r2[4] = xp_pack16(e2[0], e2[1]);
+        const uint32_t o_chain = xp_pack16(o_re, o_im);
+        if (hyb_chain) w->ap_h[l][csb] = o_chain;
+        /* the interpolated coefficients of the band's group */
+        if ((seg_mask >> l) & 1u) { /* (uniform) a border: they restart from the old targets */
+          const int s = xp_popc(seg_mask & (0xffffffffu >> (31 - l)));
+          h11 = w->seg_h[s][0][g]; h12 = w->seg_h[s][1][g]; h21 = w->seg_h[s][2][g]; h22 = w->seg_h[s][3][g];
+          d11 = w->seg_d[s][0][g]; d12 = w->seg_d[s][1][g]; d21 = w->seg_d[s][2][g]; d22 = w->seg_d[s][3][g];
+        }
+        h11 = (int16_t)(h11 + d11); /* the interpolation advances whether or not the band is rotated */
+        h12 = (int16_t)(h12 + d12);
+        h21 = (int16_t)(h21 + d21);
+        h22 = (int16_t)(h22 + d22);
+        /* the decorrelated sample of the band: all-pass output, or the input of 14 slots / 1 slot ago.  The 14-slot
+           line holds what slot l - 14 put in if that slot ran with the band active, else what the state held. */
+        const int active = sb < usb_l;
+        const int fed14 = l >= 14 && sb < (l - 14 >= clear_slot ? usb : usb_prev);
+        const uint32_t q14 = xp_pack16(fx_round16(rw.re[l >= 14 ? l - 14 : 0]), fx_round16(rw.im[l >= 14 ? l - 14 : 0]));
+        const uint32_t o14 = fed14 ? q14 : (l < 14 ? ld_cur : xp_pack16(ps->ld[(idx_long0 + l) % 14][ldj], ps->ld[(idx_long0 + l) % 14][ldj + 1]));
+        const uint32_t o = is_ap ? o_chain : (is_d14 ? o14 : prev);
+        prev = active ? q : prev;
+        int32_t re = rw.re[l], im = rw.im[l];
+        int32_t r_re = xp_m16x16_shl(xp_lo16(o), tr), r_im = xp_m16x16_shl(xp_hi16(o), tr);
+        xp_rotate(&re, &r_re, h11, h12, h21, h22);
+        xp_rotate(&im, &r_im, h11, h12, h21, h22);
+        re = active ? re : rw.re[l]; /* above usb: the left sample passes, the right one is zero */
+        im = active ? im : rw.im[l];
+        r_re = active ? r_re : 0;
+        r_im = active ? r_im : 0;
+        if (common_shift < 0) {
+          const int cs = -common_shift > 31 ? 31 : -common_shift;
+          re = fx_shr(re, cs);
+          im = fx_shr(im, cs);
+        } else if (common_shift > 0) {
+          re = fx_shl_sat(re, common_shift);
+          im = fx_shl_sat(im, common_shift);
+        }
+        if (sb >= 3) {
           xl[l * 128 + sb] = re;
           xl[l * 128 + 64 + sb] = im;
           xr[l * 128 + sb] = r_re;
           xr[l * 128 + 64 + sb] = r_im;
         }
       }
+      /* -- the delay lines as the slot loop leaves them */
+      if (chain) {
+        XP_UNROLL
+        for (int j = 0; j < 2; j++) {
+          int16_t *q = hyb_chain ? &ps->sub[(idx0 + j) % 2][2 * csb] : &ps->ap[(idx0 + j) % 2][2 * csb]; /* 32 slots: same phase */
+          q[0] = xp_lo16(d0[j]);
+          q[1] = xp_hi16(d0[j]);
+        }
+        XP_UNROLL
+        for (int j = 0; j < 3; j++) {
+          int16_t *q = hyb_chain ? &ps->sub_ser[(is0 + 32 + j) % 3][0][2 * csb] : &ps->ser[(is0 + 32 + j) % 3][0][2 * csb];
+          q[0] = xp_lo16(r0[j]);
+          q[1] = xp_hi16(r0[j]);
+        }
+        XP_UNROLL
+        for (int j = 0; j < 4; j++) {
+          int16_t *q = hyb_chain ? &ps->sub_ser[(is1 + 32 + j) % 4][1][2 * csb] : &ps->ser[(is1 + 32 + j) % 4][1][2 * csb];
+          q[0] = xp_lo16(r1[j]);
+          q[1] = xp_hi16(r1[j]);
+        }
+        XP_UNROLL
+        for (int j = 0; j < 5; j++) {
+          int16_t *q = hyb_chain ? &ps->sub_ser[(is2 + 32 + j) % 5][2][2 * csb] : &ps->ser[(is2 + 32 + j) % 5][2][2 * csb];
+          q[0] = xp_lo16(r2[j]);
+          q[1] = xp_hi16(r2[j]);
+        }
+      }
       if (sb >= 35) { /* the 1-slot delay line as the last slot leaves it */
         ps->sd[2 * (sb - 35)] = xp_lo16(prev);
         ps->sd[2 * (sb - 35) + 1] = xp_hi16(prev);
       }
-    }
-    cx.sync();
-    /* the delay lines as the slot loop leaves them: each position of the 14-slot ring holds the input of the last
-       slot that wrote it (a slot writes band sb only while sb < usb) */
-    XS_PAR(i, 0, 14 * 12) {
-      const int p = i / 12, j = i % 12, sb = 23 + j;
-      const int l0 = (p - idx_long0 % 14 + 14) % 14;
-      for (int l = l0 + 28; l >= 0; l -= 14) {
-        if (l < 32 && sb < (l >= clear_slot ? usb : usb_prev)) {
-          ps->ld[p][2 * j] = xp_lo16(w->dl[l][j]);
-          ps->ld[p][2 * j + 1] = xp_hi16(w->dl[l][j]);
-          break;
+      if (is_d14 && (clear_slot == 0 || usb == usb_prev)) { /* (the usual frame) one band limit: the last 14 slots' inputs */
+        if (sb < usb) {
+          XP_UNROLL
+          for (int j = 0; j < 14; j++) {
+            const int pos = (idx_long0 + 18 + j) % 14;
+            ps->ld[pos][ldj] = fx_round16(rw.re[18 + j]);
+            ps->ld[pos][ldj + 1] = fx_round16(rw.im[18 + j]);
+          }
+        }
+      } else if (is_d14) { /* each position of the 14-slot ring ends up with the input of the last slot that wrote it */
+        XP_UNROLL
+        for (int l = 0; l < 32; l++) {
+          const int pos = (idx_long0 + l) % 14;
+          if (sb < (l >= clear_slot ? usb : usb_prev)) {
+            ps->ld[pos][2 * (sb - 23)] = fx_round16(rw.re[l]);
+            ps->ld[pos][2 * (sb - 23) + 1] = fx_round16(rw.im[l]);
+          }
         }
       }
     }
-    const int s = cx.uni(w->seg_of_slot[31]), n = 32 - cx.uni(w->seg_start[s]);
+    cx.sync();
+    XS_ONE {
+      ps->idx = (int16_t)idx0; /* 32 slots later the 2-slot line is in the same phase */
+      ps->idx_ser[0] = (int16_t)((is0 + 32) % 3);
+      ps->idx_ser[1] = (int16_t)((is1 + 32) % 4);
+      ps->idx_ser[2] = (int16_t)((is2 + 32) % 5);
+      ps->idx_long = (int16_t)((idx_long0 + 32) % 14);
+      if (clear_slot < 32) ps->usb = (int16_t)usb;
+    }
+  }
+  cx.sync();
+  XP_T(6);
+
+  /* ---- P6: rotation of the hybrid sub-bands (ps_dec.c:856, groups 0..9) and hybrid synthesis of QMF bands 0..2
+     (the saturating sums of ps_dec.c:899-925, in sub-band order), one (slot, band, re | im) per lane */
+  XS_PAR(i, 0, 192) {
+    const int l = i / 6, b = (i % 6) >> 1, c = i & 1;
+    const int p = b == 0 ? 0 : 4 + 2 * b, n = b == 0 ? 6 : 2;
+    const uint32_t below = seg_mask & (0xffffffffu >> (31 - l));     /* borders at or before slot l */
+    const int s = xp_popc(below), nn = l - (below ? 31 - xp_clz(below) : 0) + 1; /* slots since the segment began */
+    int32_t acc_l = 0, acc_r = 0;
+    for (int k = 0; k < n; k++) {
+      const int sb = p + k;
+      const int16_t h11 = (int16_t)(w->seg_h[s][0][sb] + nn * w->seg_d[s][0][sb]);
+      const int16_t h12 = (int16_t)(w->seg_h[s][1][sb] + nn * w->seg_d[s][1][sb]);
+      const int16_t h21 = (int16_t)(w->seg_h[s][2][sb] + nn * w->seg_d[s][2][sb]);
+      const int16_t h22 = (int16_t)(w->seg_h[s][3][sb] + nn * w->seg_d[s][3][sb]);
+      const int16_t tr = w->ratio[l][T->hybrid_to_bin[sb]];
+      const uint32_t o = w->ap_h[l][sb];
+      int32_t lv = w->hyb_l[l][10 * c + sb];
+      int32_t rv = xp_m16x16_shl(c ? xp_hi16(o) : xp_lo16(o), tr);
+      xp_rotate(&lv, &rv, h11, h12, h21, h22);
+      acc_l = k == 0 ? lv : fx_add_sat(acc_l, lv);
+      acc_r = k == 0 ? rv : fx_add_sat(acc_r, rv);
+    }
+    if (common_shift < 0)
+      acc_l = fx_shr(acc_l, -common_shift > 31 ? 31 : -common_shift);
+    else if (common_shift > 0)
+      acc_l = fx_shl_sat(acc_l, common_shift);
+    xl[l * 128 + 64 * c + b] = acc_l;
+    xr[l * 128 + 64 * c + b] = acc_r;
+  }
+  {
+    const int s = xp_popc(seg_mask), n = 32 - (seg_mask ? 31 - xp_clz(seg_mask) : 0);
     XS_PAR(g, 0, XAAC_PS_GROUPS) {
       ps->H11_H12[2 * g] = (int16_t)(w->seg_h[s][0][g] + n * w->seg_d[s][0][g]);
       ps->H11_H12[2 * g + 1] = (int16_t)(w->seg_h[s][1][g] + n * w->seg_d[s][1][g]);
       ps->H21_H22[2 * g] = (int16_t)(w->seg_h[s][2][g] + n * w->seg_d[s][2][g]);
       ps->H21_H22[2 * g + 1] = (int16_t)(w->seg_h[s][3][g] + n * w->seg_d[s][3][g]);
     }
-    XS_ONE {
-      ps->idx_long = (int16_t)((idx_long0 + 32) % 14);
-      if (clear_slot < 32) ps->usb = (int16_t)usb;
-    }
   }
   cx.sync();
-  XP_T(8);
+  XP_T(7);
   return ps_scale;
 }
 

@@ -47,13 +47,16 @@ constexpr int kHeadWords = offsetof(xaac_ps_state, syn_ring_r) / 4;
 static_assert(offsetof(xaac_ps_state, syn_ring_r) % 4 == 0 && sizeof(XpLdsState) == kHeadWords * 4, "mirror layout");
 static_assert(sizeof(xaac_ps_frame) % 4 == 0, "word copies");
 
+/* the PS constants (a table lookup in global memory costs a serial phase its latency) without the last member, the
+   quarter-wave sine table of the envelope borders' coefficient set-up, which is read from global memory */
+constexpr int kTabBytes = offsetof(XpTables, trig_data);
 struct XpLds {
   XpLdsState ps;
   xaac_ps_frame pf;
   XpFrameWork w;
-  XpTables tabs; /* the PS constants: a table lookup in global memory costs a serial phase its latency */
+  int32_t tabs[(kTabBytes + 3) / 4];
 };
-static_assert(sizeof(XpTables) % 4 == 0, "word copies");
+static_assert(kTabBytes + sizeof(((XpTables *)0)->trig_data) <= sizeof(XpTables), "trig_data is the last member (the word copy may take its first entry along)");
 
 /* global -> LDS with eight loads in flight (see sbr_core_kernel.hip) */
 __device__ __forceinline__ void copy_words(int32_t *dst, const int32_t *src, int n, int lane) {
@@ -70,12 +73,12 @@ __device__ __forceinline__ void copy_words(int32_t *dst, const int32_t *src, int
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void xaac_ps_kernel(XaacPsParams p) {
+__global__ __launch_bounds__(64, 2) void xaac_ps_kernel(XaacPsParams p) {
   __shared__ XpLds s;
   const int lane = threadIdx.x;
   const XsCx cx = {lane, 64};
-  copy_words(reinterpret_cast<int32_t *>(&s.tabs), reinterpret_cast<const int32_t *>(&xaac_ps_tables),
-             sizeof(XpTables) / 4, lane);
+  copy_words(s.tabs, reinterpret_cast<const int32_t *>(&xaac_ps_tables), (kTabBytes + 3) / 4, lane);
+  const XpTables *tabs = reinterpret_cast<const XpTables *>(s.tabs);
 #ifdef XS_PROFILE
   if (lane == 0) {
     for (int i = 0; i < 16; i++) xp_prof_acc[i] = 0;
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(64) void xaac_ps_kernel(XaacPsParams p) {
     const int lb_scale = cx.uni(par[0]), ov_lb_scale = cx.uni(par[1]), hb_scale = cx.uni(par[2]), st_syn = cx.uni(par[3]);
     const int lsb = cx.uni(par[4]), usb = cx.uni(par[5]);
     const int ps_scale =
-        xp_ps_frame(cx, &s.tabs, &s.ps, &s.pf, &s.w, gx, gr, lb_scale, ov_lb_scale, hb_scale, st_syn, lsb, usb);
+        xp_ps_frame(cx, tabs, &s.ps, &s.pf, &s.w, gx, gr, lb_scale, ov_lb_scale, hb_scale, st_syn, lsb, usb);
     /* ---- state and the two synthesis launches' parameters ---- */
     __syncthreads();
     {
