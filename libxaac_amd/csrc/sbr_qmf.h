@@ -188,10 +188,14 @@ FX_HD void xq_dct3_32(int32_t *in, int32_t *out) {
   out[31] = in[16];
 }
 
-/* complex modulation core shared by HQ analysis (M = 16) and HQ synthesis (M = 32):
-   s[0..2M-1] and s[64..64+2M-1] in place; t = 128 words of scratch */
-template <int M>
-FX_HD void xq_cos_sin_mod(int32_t *s, int32_t *t) {
+/* complex modulation core shared by HQ analysis (M = 16) and HQ synthesis (M = 32), generic:259.  The reference
+   walks a "real" and an "imaginary" half (s[0..2M-1] and s[64..64+2M-1]) side by side through pre-rotation, an
+   M-point complex FFT and post-rotation; the halves never meet inside, so each is a function of its own 2M words
+   (H = 0: the first half, H = 1: the second; they differ in the signs of the two rotations).  s: the half's 2M
+   words in place, t: 2M words of scratch.  The GPU synthesis kernel runs the halves one after the other through a
+   half-size LDS tile. */
+template <int M, int H>
+FX_HD void xq_cos_sin_mod_half(int32_t *s, int32_t *t) {
   const int16_t *tw = (M == 32) ? XQ_T(sin_cos_twiddle_l64) : XQ_T(sin_cos_twiddle_l32);
   const int16_t *alt = (M == 32) ? XQ_T(alt_sin_twiddle_l64) : XQ_T(alt_sin_twiddle_l32);
   XQ_UNROLL
@@ -199,74 +203,84 @@ FX_HD void xq_cos_sin_mod(int32_t *s, int32_t *t) {
     {
       int16_t wim = tw[4 * q], wre = tw[4 * q + 1];
       int32_t re = s[2 * q], im = s[2 * M - 1 - 2 * q];
-      t[2 * q] = fx_add_sat(xq_mul(re, wre), xq_mul(im, wim));
-      t[2 * q + 1] = fx_sub_sat(xq_mul(im, wre), xq_mul(re, wim));
-      re = s[64 + 2 * q];
-      im = s[64 + 2 * M - 1 - 2 * q];
-      t[64 + 2 * q] = fx_sub_sat(xq_mul(im, wim), xq_mul(re, wre));
-      t[64 + 2 * q + 1] = fx_add_sat(xq_mul(re, wim), xq_mul(im, wre));
+      if (H == 0) {
+        t[2 * q] = fx_add_sat(xq_mul(re, wre), xq_mul(im, wim));
+        t[2 * q + 1] = fx_sub_sat(xq_mul(im, wre), xq_mul(re, wim));
+      } else {
+        t[2 * q] = fx_sub_sat(xq_mul(im, wim), xq_mul(re, wre));
+        t[2 * q + 1] = fx_add_sat(xq_mul(re, wim), xq_mul(im, wre));
+      }
     }
     {
       int16_t wim = tw[4 * q + 2], wre = tw[4 * q + 3];
       int32_t re = s[2 * M - 2 - 2 * q], im = s[2 * q + 1];
-      t[2 * M - 1 - 2 * q] = fx_sub_sat(xq_mul(im, wre), xq_mul(re, wim));
-      t[2 * M - 2 - 2 * q] = fx_add_sat(xq_mul(re, wre), xq_mul(im, wim));
-      re = s[64 + 2 * M - 2 - 2 * q];
-      im = s[64 + 2 * q + 1];
-      t[64 + 2 * M - 1 - 2 * q] = fx_add_sat(xq_mul(re, wim), xq_mul(im, wre));
-      t[64 + 2 * M - 2 - 2 * q] = fx_sub_sat(xq_mul(im, wim), xq_mul(re, wre));
+      if (H == 0) {
+        t[2 * M - 1 - 2 * q] = fx_sub_sat(xq_mul(im, wre), xq_mul(re, wim));
+        t[2 * M - 2 - 2 * q] = fx_add_sat(xq_mul(re, wre), xq_mul(im, wim));
+      } else {
+        t[2 * M - 1 - 2 * q] = fx_add_sat(xq_mul(re, wim), xq_mul(im, wre));
+        t[2 * M - 2 - 2 * q] = fx_sub_sat(xq_mul(im, wim), xq_mul(re, wre));
+      }
     }
   }
   if (M == 32) {
-    XQ_UNROLL
-    for (int h = 0; h < 2; h++) {
-      xq_radix4(XQ_T(w_32), t + 64 * h, 1, 8);
-      xq_radix4(XQ_T(w_32) + 48, t + 64 * h, 4, 2);
-      xq_postradix2(s + 64 * h, t + 64 * h);
-    }
+    xq_radix4(XQ_T(w_32), t, 1, 8);
+    xq_radix4(XQ_T(w_32) + 48, t, 4, 2);
+    xq_postradix2(s, t);
   } else {
-    XQ_UNROLL
-    for (int h = 0; h < 2; h++) {
-      xq_radix4(XQ_T(w_16), t + 64 * h, 1, 4);
-      xq_postradix4(s + 64 * h, t + 64 * h);
-    }
+    xq_radix4(XQ_T(w_16), t, 1, 4);
+    xq_postradix4(s, t);
   }
   /* post-rotation, in place and order-sensitive (each value is consumed before it is overwritten) */
-  int ps = 0, ps1 = 2 * M - 1, pa = 0;
-  int32_t re = s[ps1];
-  s[0] = s[0] >> 1;
-  ps = 1;
-  s[ps1] = fx_neg_sat(s[1] >> 1);
-  ps1--;
+  int lo = 0, hi = 2 * M - 1, pa = 0;
   int16_t wim = alt[pa++], wre = alt[pa++];
-  int32_t im = s[ps1];
-  s[ps1--] = fx_add_sat(xq_mul(re, wre), xq_mul(im, wim));
-  s[ps++] = fx_sub_sat(xq_mul(im, wre), xq_mul(re, wim));
-  int ps2 = 64, ps12 = 64 + 2 * M - 1;
-  re = s[ps12];
-  s[ps12--] = fx_neg_sat(s[ps2] >> 1);
-  s[ps2] = s[ps2 + 1] >> 1;
-  ps2++;
-  im = s[ps12];
-  s[ps2++] = fx_neg_sat(fx_add_sat(xq_mul(re, wre), xq_mul(im, wim)));
-  s[ps12--] = fx_sub_sat(xq_mul(re, wim), xq_mul(im, wre));
-  XQ_UNROLL
-  for (int i = 0; i < M / 2 - 1; i++) {
-    int32_t im0 = s[ps], re0 = s[ps + 1], re2 = s[ps1];
-    s[ps++] = fx_add_sat(xq_mul(re0, wim), xq_mul(im0, wre));
-    s[ps1--] = fx_sub_sat(xq_mul(im0, wim), xq_mul(re0, wre));
-    int32_t im1 = s[ps2], re1 = s[ps2 + 1], re3 = s[ps12];
-    s[ps12--] = fx_neg_sat(fx_add_sat(xq_mul(re1, wim), xq_mul(im1, wre)));
-    s[ps2++] = fx_sub_sat(xq_mul(re1, wre), xq_mul(im1, wim));
-    wim = alt[pa++];
-    wre = alt[pa++];
-    im0 = s[ps1];
-    s[ps1--] = fx_add_sat(xq_mul(re2, wre), xq_mul(im0, wim));
-    s[ps++] = fx_sub_sat(xq_mul(im0, wre), xq_mul(re2, wim));
-    im1 = s[ps12];
-    s[ps2++] = fx_neg_sat(fx_add_sat(xq_mul(re3, wre), xq_mul(im1, wim)));
-    s[ps12--] = fx_sub_sat(xq_mul(re3, wim), xq_mul(im1, wre));
+  if (H == 0) {
+    int32_t re = s[hi];
+    s[0] = s[0] >> 1;
+    lo = 1;
+    s[hi] = fx_neg_sat(s[1] >> 1);
+    hi--;
+    int32_t im = s[hi];
+    s[hi--] = fx_add_sat(xq_mul(re, wre), xq_mul(im, wim));
+    s[lo++] = fx_sub_sat(xq_mul(im, wre), xq_mul(re, wim));
+    XQ_UNROLL
+    for (int i = 0; i < M / 2 - 1; i++) {
+      int32_t im0 = s[lo], re0 = s[lo + 1], re2 = s[hi];
+      s[lo++] = fx_add_sat(xq_mul(re0, wim), xq_mul(im0, wre));
+      s[hi--] = fx_sub_sat(xq_mul(im0, wim), xq_mul(re0, wre));
+      wim = alt[pa++];
+      wre = alt[pa++];
+      im0 = s[hi];
+      s[hi--] = fx_add_sat(xq_mul(re2, wre), xq_mul(im0, wim));
+      s[lo++] = fx_sub_sat(xq_mul(im0, wre), xq_mul(re2, wim));
+    }
+  } else {
+    int32_t re = s[hi];
+    s[hi--] = fx_neg_sat(s[lo] >> 1);
+    s[lo] = s[lo + 1] >> 1;
+    lo++;
+    int32_t im = s[hi];
+    s[lo++] = fx_neg_sat(fx_add_sat(xq_mul(re, wre), xq_mul(im, wim)));
+    s[hi--] = fx_sub_sat(xq_mul(re, wim), xq_mul(im, wre));
+    XQ_UNROLL
+    for (int i = 0; i < M / 2 - 1; i++) {
+      int32_t im1 = s[lo], re1 = s[lo + 1], re3 = s[hi];
+      s[hi--] = fx_neg_sat(fx_add_sat(xq_mul(re1, wim), xq_mul(im1, wre)));
+      s[lo++] = fx_sub_sat(xq_mul(re1, wre), xq_mul(im1, wim));
+      wim = alt[pa++];
+      wre = alt[pa++];
+      im1 = s[hi];
+      s[lo++] = fx_neg_sat(fx_add_sat(xq_mul(re3, wre), xq_mul(im1, wim)));
+      s[hi--] = fx_sub_sat(xq_mul(re3, wim), xq_mul(im1, wre));
+    }
   }
+}
+
+/* both halves: s[0..2M-1] and s[64..64+2M-1] in place; t = 128 words of scratch */
+template <int M>
+FX_HD void xq_cos_sin_mod(int32_t *s, int32_t *t) {
+  xq_cos_sin_mod_half<M, 0>(s, t);
+  xq_cos_sin_mod_half<M, 1>(s + 64, t + 64);
 }
 
 /* HQ analysis: 64 window-add outputs -> 32 complex subbands, s[0..31] real, s[64..95] imaginary;

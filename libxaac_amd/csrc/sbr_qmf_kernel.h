@@ -49,9 +49,25 @@ typedef struct XaacQmfSynParams {
   int32_t *dbg; /* profiling builds (-DXS_PROFILE) only: cycle counters at dbg[64..], else unused */
 } XaacQmfSynParams;
 
+/* HE-AACv2: both complex synthesis banks of a stream in one wave (channel 0 = left, state in xaac_sbr_state; channel
+   1 = right, state in xaac_ps_state), output as interleaved L,R pairs.  scale[c] + 8 i: lb, ov_lb, hb, st_syn scales,
+   lsb, usb, and [6] != 0 where the channel is not synthesised this frame (bank and output samples left alone). */
+#define XAAC_QMF_SYN_PAIR_LDS 21376 /* 2 channels x 41 slots x (128 + 2) ring samples; the 64 x 65-word row tile fits inside */
+typedef struct XaacQmfSynPairParams {
+  int32_t n;       /* streams */
+  int32_t split;   /* first slot of the current frame's low band (op_delay = 6) */
+  const int32_t *qmf[2];
+  int32_t qmf_stride[2];    /* words between consecutive streams' slot 0 (rows of 64 re | 64 im) */
+  const int16_t *scale[2];
+  xaac_qmf_syn_state *state[2];
+  int32_t state_stride[2];  /* bytes */
+  int16_t *pcm;             /* [n][2048][2] */
+} XaacQmfSynPairParams;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+hipError_t xaac_launch_qmf_synthesis_pair(const XaacQmfSynPairParams *p, hipStream_t stream);
 hipError_t xaac_launch_qmf_analysis(const XaacQmfAnaParams *p, int grid, hipStream_t stream);
 hipError_t xaac_launch_qmf_synthesis(const XaacQmfSynParams *p, int grid, hipStream_t stream);
 int xaac_qmf_blocks_per_cu(int which);

@@ -365,6 +365,168 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
 #endif
 }
 
+/* ===================================================================================== */
+/* HE-AACv2: the left and the right complex synthesis bank of one stream in one wave (xaac_qmf_synthesis_kernel<false,
+   false> twice, with three changes of arrangement, none of arithmetic):
+   - the slot transform's two halves (sbr_qmf.h: xq_cos_sin_mod_half) run one after the other -- real parts of the 64
+     rows through the LDS tile, transform, imaginary parts through the same tile, transform, combine -- so the tile is
+     64 x 65 words instead of 64 x 129 and fits inside the ring-sample store: 21 KB of LDS per wave instead of 33, seven
+     waves per CU instead of four;
+   - the window-add works on sample pairs (one ds_read_b32 per tap and channel instead of two ds_read_u16), two slots
+     per wave pass, and since both channels of the stream are at hand the output leaves as interleaved L,R words: 8
+     contiguous bytes per lane, 512 per store instruction, instead of two launches' 2-byte stores at stride 4;
+   - ring history and ring state move as dwords (a slot's 128 ring samples are 128-sample aligned in the ring). */
+__global__ __launch_bounds__(64, 2) void xaac_qmf_synthesis_pair_kernel(XaacQmfSynPairParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RS = 65;              /* padded LDS row stride of a half row (64 words) */
+  constexpr int VSLOTS = 9 + 32;      /* 9 slots of history + this frame */
+  constexpr int VROW = 130;           /* int16 stride of a slot's 128 ring samples: 65 dwords, odd */
+  constexpr int RING = 1280;
+  const int lane = threadIdx.x;
+  int32_t *rows = reinterpret_cast<int32_t *>(smem); /* [64][RS], later aliased by ... */
+  int16_t *v = reinterpret_cast<int16_t *>(smem);    /* ... [2][VSLOTS][VROW] ring samples */
+  const int i = blockIdx.x;
+  const int ch = lane >> 5, slot = lane & 31; /* transform phase: lane = (channel, slot) */
+  const int16_t *sf = p.scale[ch] + 8 * (size_t)i;
+  const int st_syn = sf[3], lsb = sf[4], usb = sf[5];
+  const int lo_shift = (st_syn - (slot < p.split ? sf[1] : sf[0])) - 8, hb_shift = (st_syn - sf[2]) - 8;
+  const int inactive0 = __builtin_amdgcn_readfirstlane(p.scale[0][8 * (size_t)i + 6]);
+  const int inactive1 = __builtin_amdgcn_readfirstlane(p.scale[1][8 * (size_t)i + 6]);
+  {
+    int32_t s_re[64], x[64], t[64];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      /* ---- half rows in, coalesced: 64 words of each of the 64 rows (2 channels x 32 slots), XB loads in flight */
+      constexpr int XB = 16;
+      for (int r0 = 0; r0 < 64; r0 += XB) {
+        int32_t tmp[XB];
+#pragma unroll
+        for (int j = 0; j < XB; j++) {
+          const int r = r0 + j, c = r >> 5;
+          tmp[j] = (p.qmf[c] + (size_t)i * p.qmf_stride[c] + (size_t)(r & 31) * 128 + 64 * h)[lane];
+        }
+#pragma unroll
+        for (int j = 0; j < XB; j++) rows[RS * (r0 + j) + lane] = tmp[j];
+      }
+      __syncthreads();
+      /* ---- region rescale (qmf_dec.c:937-953), lane = slot */
+#pragma unroll
+      for (int k = 0; k < 64; k++) {
+        const int32_t val = rows[RS * lane + k];
+        x[k] = k < lsb ? adj_scale(val, lo_shift) : (k < usb ? adj_scale(val, hb_shift) : val);
+      }
+      __syncthreads(); /* the tile may be overwritten by the other half's rows / the ring samples */
+      if (h == 0) {
+        xq_cos_sin_mod_half<32, 0>(x, t);
+#pragma unroll
+        for (int k = 0; k < 64; k++) s_re[k] = x[k];
+      } else {
+        xq_cos_sin_mod_half<32, 1>(x, t);
+      }
+    }
+    /* inv_emodulation's last step + shiftrountine_with_rnd (generic:869, :1638): the slot's 128 ring samples, straight
+       into the ring-sample store (the row tile it aliases is dead: every lane has its slot in registers) */
+    const int shift = -(st_syn - 3) + 1;
+    int32_t *dst = reinterpret_cast<int32_t *>(v + (ch * VSLOTS + 9 + slot) * VROW);
+#pragma unroll
+    for (int c = 0; c < 64; c += 2) {
+      const int16_t b0 = fx_round16(fx_shl_sat(fx_sub_sat(x[c], s_re[c]), shift));
+      const int16_t b1 = fx_round16(fx_shl_sat(fx_sub_sat(x[c + 1], s_re[c + 1]), shift));
+      dst[c >> 1] = (int32_t)((uint32_t)(uint16_t)b0 | ((uint32_t)(uint16_t)b1 << 16));
+      const int16_t b2 = fx_round16(fx_shl_sat(fx_add_sat(x[63 - c], s_re[63 - c]), shift));
+      const int16_t b3 = fx_round16(fx_shl_sat(fx_add_sat(x[62 - c], s_re[62 - c]), shift));
+      dst[32 + (c >> 1)] = (int32_t)((uint32_t)(uint16_t)b2 | ((uint32_t)(uint16_t)b3 << 16));
+    }
+  }
+  /* ---- the 9 slots of history from the state -------------------------------------------------------------------- */
+  int d_old[2];
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    const xaac_qmf_syn_state *st = reinterpret_cast<const xaac_qmf_syn_state *>(
+        reinterpret_cast<const char *>(p.state[c]) + (size_t)i * p.state_stride[c]);
+    /* a slot's block of 128 samples sits 128-aligned in the ring (the offset moves by 128 per slot from 0) */
+    int d = __builtin_amdgcn_readfirstlane(st->drc_offset);
+    d = ((d % RING + RING) % RING) & ~127;
+    d_old[c] = d;
+    int32_t hist[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) { /* v row j = the slot of age 9 - j */
+      int pos = d + 128 * (9 - j);
+      if (pos >= RING) pos -= RING;
+      hist[j] = reinterpret_cast<const int32_t *>(st->ring + pos)[lane];
+    }
+#pragma unroll
+    for (int j = 0; j < 9; j++) reinterpret_cast<int32_t *>(v + (c * VSLOTS + j) * VROW)[lane] = hist[j];
+  }
+  __syncthreads();
+  /* ---- window-add: lane = (slot parity, sample pair), both channels; y[s][k] = rnd + sum_A v[s-A][64(A&1)+k] c[64A+k] */
+  {
+    const int par = lane >> 5, k2 = lane & 31;
+    int32_t cf0[10], cf1[10];
+#pragma unroll
+    for (int a = 0; a < 10; a++) {
+      cf0[a] = xaac_qmf_qmf_c[64 * a + 2 * k2];
+      cf1[a] = xaac_qmf_qmf_c[64 * a + 2 * k2 + 1];
+    }
+    int32_t *out = reinterpret_cast<int32_t *>(p.pcm) + (size_t)i * 2048; /* one word per L,R pair */
+    for (int s0 = 0; s0 < 32; s0 += 2) {
+      const int s = s0 + par;
+      int32_t acc[2][2] = {{0x4000, 0x4000}, {0x4000, 0x4000}};
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        const int16_t *vs = v + (c * VSLOTS + 9 + s) * VROW + 2 * k2;
+#pragma unroll
+        for (int A = 0; A < 10; A++) {
+          const int32_t wd = *reinterpret_cast<const int32_t *>(vs - VROW * A + 64 * (A & 1));
+          acc[c][0] += (int32_t)(int16_t)(wd & 0xffff) * cf0[A]; /* < 2^31: exact */
+          acc[c][1] += (wd >> 16) * cf1[A];
+        }
+      }
+      const uint32_t l0 = (uint32_t)(uint16_t)(fx_shl_sat(acc[0][0], 1) >> 16), l1 = (uint32_t)(uint16_t)(fx_shl_sat(acc[0][1], 1) >> 16);
+      const uint32_t r0 = (uint32_t)(uint16_t)(fx_shl_sat(acc[1][0], 1) >> 16), r1 = (uint32_t)(uint16_t)(fx_shl_sat(acc[1][1], 1) >> 16);
+      int32_t *o = out + 64 * s + 2 * k2;
+      if (!inactive0 && !inactive1) {
+        *reinterpret_cast<int2 *>(o) = make_int2((int32_t)(l0 | (r0 << 16)), (int32_t)(l1 | (r1 << 16)));
+      } else { /* one channel only: its samples alone (the other's are left as they are) */
+        int16_t *o16 = reinterpret_cast<int16_t *>(o);
+        if (!inactive0) {
+          o16[0] = (int16_t)l0;
+          o16[2] = (int16_t)l1;
+        }
+        if (!inactive1) {
+          o16[1] = (int16_t)r0;
+          o16[3] = (int16_t)r1;
+        }
+      }
+    }
+  }
+  /* ---- state: ring blocks of the last 10 slots, drc offset, window phase -------------------------------------- */
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    if (c == 0 ? inactive0 : inactive1) continue;
+    xaac_qmf_syn_state *st = reinterpret_cast<xaac_qmf_syn_state *>(reinterpret_cast<char *>(p.state[c]) +
+                                                                    (size_t)i * p.state_stride[c]);
+    const int d_new = (d_old[c] + RING - (32 * 128) % RING) % RING; /* 32 slots of 128 downwards */
+    const int ph_new = (st->phase + 128) % 640;
+#pragma unroll
+    for (int A = 1; A <= 10; A++) { /* age relative to the NEXT frame's slot 0 */
+      int pos = d_new + 128 * A;
+      if (pos >= RING) pos -= RING;
+      if (pos >= RING) pos -= RING;
+      reinterpret_cast<int32_t *>(st->ring + pos)[lane] = reinterpret_cast<const int32_t *>(v + (c * VSLOTS + 9 + 32 - A) * VROW)[lane];
+    }
+    if (lane == 0) {
+      st->drc_offset = (int16_t)d_new;
+      st->phase = (int16_t)ph_new;
+    }
+  }
+}
+
+extern "C" hipError_t xaac_launch_qmf_synthesis_pair(const XaacQmfSynPairParams *p, hipStream_t stream) {
+  hipLaunchKernelGGL(xaac_qmf_synthesis_pair_kernel, dim3(p->n), dim3(64), XAAC_QMF_SYN_PAIR_LDS, stream, *p);
+  return hipGetLastError();
+}
+
 extern "C" hipError_t xaac_launch_qmf_analysis(const XaacQmfAnaParams *p, int grid, hipStream_t stream) {
   if (p->low_pow)
     hipLaunchKernelGGL(xaac_qmf_analysis_kernel<true>, dim3(grid), dim3(XAAC_QMF_BLOCK),

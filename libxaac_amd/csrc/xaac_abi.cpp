@@ -342,6 +342,21 @@ int32_t xaac_sbr_hq_process_batch(xaac_ctx *c, const xaac_sbr_hq_batch *b) {
     if (!hip_ok(xaac_launch_ps(&pp, c->stream))) return XAAC_FATAL_HIP;
   }
   /* 4. synthesis bank(s) over the 6 delayed + first 26 new slots */
+  if (with_ps) { /* both banks of a stream in one wave, interleaved L,R out */
+    XaacQmfSynPairParams pq = {};
+    pq.n = b->n_ch; pq.split = 6;
+    pq.qmf[0] = x + 2 * 128; pq.qmf_stride[0] = xw; pq.scale[0] = par_l;
+    pq.state[0] = reinterpret_cast<xaac_qmf_syn_state *>(st + offsetof(xaac_sbr_state, syn_ring));
+    pq.state_stride[0] = (int32_t)sizeof(xaac_sbr_state);
+    pq.qmf[1] = xr; pq.qmf_stride[1] = 32 * 128; pq.scale[1] = par_r;
+    pq.state[1] = reinterpret_cast<xaac_qmf_syn_state *>(reinterpret_cast<char *>(b->ps_state) +
+                                                         offsetof(xaac_ps_state, syn_ring_r));
+    pq.state_stride[1] = (int32_t)sizeof(xaac_ps_state);
+    pq.pcm = b->pcm_out;
+    if (!hip_ok(xaac_launch_qmf_synthesis_pair(&pq, c->stream))) return XAAC_FATAL_HIP;
+    c->last_grid = b->n_ch; c->last_block = 64; c->last_lds = XAAC_QMF_SYN_PAIR_LDS;
+    return XAAC_OK;
+  }
   XaacQmfSynParams ps = {};
   ps.n_ch = b->n_ch; ps.ch_fac = with_ps ? 1 : b->out_ch_fac; ps.low_pow = 0; ps.split = 6;
   ps.down_sample = b->down_sample ? 1 : 0;
