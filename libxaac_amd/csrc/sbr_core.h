@@ -215,8 +215,10 @@ struct XsCx {
 #define XS_ONE if (cx.lane == 0)
 #if defined(__HIPCC__)
 #define XS_UNROLL4 _Pragma("unroll 4")
+#define XS_UNROLL8 _Pragma("unroll 8")
 #else
 #define XS_UNROLL4
+#define XS_UNROLL8
 #endif
 
 /* Lane vector: 64 int32 elements, element k held by lane k (a VGPR) / a plain array in the oracle. */
@@ -1478,8 +1480,16 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
     int16_t nl = xs_m(noise_i.own(i));
     int16_t fbm = st->filt_buf_me[2 * i], fbn = st->filt_buf_noise_m[i];
     int ne = noise_e, fbe = fb_noise_e0, ph = ph0, harm = harm0;
-    int32_t rp_next = xaac_sbr_rand_ph[ph + 1 + (k >= 0 ? k : 0)]; /* fetched one slot ahead: the table is in global memory */
-    for (int l = s0; l < s1; l++) {
+    /* the random-phase table is in global memory: eight slots' entries are fetched together, one memory latency per
+       eight slots instead of one per slot */
+    int32_t rp8[8];
+    for (int l0 = s0; l0 < s1; l0 += 8) {
+    XS_UNROLL8
+    for (int j = 0; j < 8; j++) rp8[j] = xaac_sbr_rand_ph[((ph + j * bands) & 511) + 1 + (k >= 0 ? k : 0)];
+    XS_UNROLL8
+    for (int j = 0; j < 8; j++) {
+      const int l = l0 + j;
+      if (l >= s1) break;
       int scale_change;
       if (l < 32) {
         scale_change = adj_e - input_e;
@@ -1493,11 +1503,10 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
       }
       fbn = xs_noise_rescale(fbn, fbe - ne);
       fbe = ne;
-      const int32_t rp = rp_next;
+      const int32_t rp = rp8[j];
       const int hi = harm;
       ph = (ph + bands) & 511;
       harm = (harm + 1) & 3;
-      rp_next = xaac_sbr_rand_ph[ph + 1 + (k >= 0 ? k : 0)];
       if (k < 0) continue;
       const int16_t smooth = (l - s0) < smooth_length ? xaac_sbr_smooth_filter[l - s0] : (int16_t)0;
       int16_t sg = gm, snz = nl;
@@ -1540,6 +1549,7 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
       }
       x(l, sb_start + k) = re;
       x.im(l, sb_start + k) = im;
+    }
     }
     st->filt_buf_me[2 * i] = fbm;
     st->filt_buf_noise_m[i] = fbn;
