@@ -45,8 +45,10 @@
 
 #if defined(__HIPCC__)
 #define XP_UNROLL _Pragma("unroll")
+#define XP_NOUNROLL _Pragma("nounroll")
 #else
 #define XP_UNROLL
+#define XP_NOUNROLL
 #endif
 
 struct XpFrameWork {
@@ -54,6 +56,7 @@ struct XpFrameWork {
     int32_t hyb_u[3][2][44]; /* P1: hybrid filter input of QMF bands 0..2: 12 slots of history + this frame's 32 */
     int32_t gsum[8][56];     /* P3: addends of the group sums, bands 9..63 of eight slots */
     int32_t peak[32][20];    /* P4: transient peak difference */
+    uint32_t dl[32][12];     /* P5/P7: rounded samples of QMF bands 23..34 (the 14-slot delay looks 14 slots back) */
   };
   int32_t hyb_l[32][20];     /* left hybrid sub-band samples of every slot: re 0..9 | im 10..19 */
   union {
@@ -64,20 +67,6 @@ struct XpFrameWork {
   int16_t seg_h[XP_MAX_SEG][4][24]; /* per segment and group: H11, H12, H21, H22 before the segment's first slot */
   int16_t seg_d[XP_MAX_SEG][4][24]; /* per-slot increments */
 };
-
-/* What a lane keeps for its QMF band from the moment the rows are fetched until they are written back: the band's 32
-   complex samples (the stream's whole QMF matrix is 64 registers per lane).  On the host the "lanes" are array
-   elements. */
-struct XpLaneRows {
-  int32_t re[32], im[32];
-};
-#if defined(__HIP_DEVICE_COMPILE__)
-#define XP_LANE_ROWS(name) XpLaneRows name##_[1]
-#define XP_ROWS(name, lane) name##_[0]
-#else
-#define XP_LANE_ROWS(name) static thread_local XpLaneRows name##_[64]
-#define XP_ROWS(name, lane) name##_[lane]
-#endif
 
 FX_HD int xp_popc(uint32_t v) { return __builtin_popcount(v); }
 FX_HD int xp_clz(uint32_t v) { return __builtin_clz(v); } /* v != 0 */
@@ -110,16 +99,6 @@ FX_HD int32_t xp_bin_power_hyb(const XpTables *T, int bin, const int32_t *re, co
 template <class PS>
 FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_frame *pf, XpFrameWork *w, int32_t *xl,
                       int32_t *xr, int lb_scale, int ov_lb_scale, int hb_scale, int st_syn, int lsb, int usb) {
-  /* the lane's band, all 32 slots: 64 loads in flight while the state is scaled and the envelopes are walked */
-  XP_LANE_ROWS(rows);
-  XS_PAR(sb, 0, 64) {
-    XpLaneRows &rw = XP_ROWS(rows, sb);
-    XP_UNROLL
-    for (int l = 0; l < 32; l++) {
-      rw.re[l] = xl[l * 128 + sb];
-      rw.im[l] = xl[l * 128 + 64 + sb];
-    }
-  }
   const int ps_scale = xp_init_ps_scale(cx, ps, lb_scale, ov_lb_scale, hb_scale); /* sbr_dec.c:1252 */
   const int ov_lb_shift = ps_scale - ov_lb_scale, lb_shift = ps_scale - lb_scale, hb_shift = ps_scale - hb_scale;
   const int common_shift = (st_syn - ps_scale) - 8;
@@ -213,39 +192,44 @@ FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_f
   cx.sync();
   XP_T(3);
 
-  /* ---- P3: band powers (ps_dec.c:520-545).  The lane's 64 row words arrive here (fetched at the top of the frame),
-     are brought to the PS scale and stay in registers. */
-  XP_UNROLL
-  for (int c = 0; c < 4; c++) {
-    XS_PAR(sb, 0, 64) {
-      XpLaneRows &rw = XP_ROWS(rows, sb);
-      const int gsh = sb < 11 ? 0 : (sb < 18 ? 1 : (sb < 23 ? 2 : (sb < 35 ? 3 : 4))); /* group_shift of the band's group */
-      XP_UNROLL
-      for (int ls = 0; ls < 8; ls++) {
-        const int l = 8 * c + ls;
-        const int usb_l = l >= clear_slot ? usb : usb_prev;
-        const int sh = sb < lsb ? (l < 6 ? ov_lb_shift : lb_shift) : (sb < usb ? hb_shift : 0);
-        const int32_t re = xp_adj_word(rw.re[l], sh), im = xp_adj_word(rw.im[l], sh);
-        rw.re[l] = re;
-        rw.im[l] = im;
-        if (sb >= 3) {
-          const int32_t pw = xp_power(re, im);
-          if (sb < 9)
-            w->binpw[l][sb + 5] = pw;
-          else
-            w->gsum[ls][sb - 9] = sb < usb_l ? (pw >> gsh) : 0;
+  /* ---- P3: band powers (ps_dec.c:520-545).  A lane walks its band through eight slots at a time: the sixteen row
+     words of the next eight are in flight while these are worked on. */
+  {
+    XP_NOUNROLL
+    for (int c = 0; c < 4; c++) {
+      XS_PAR(sb, 0, 64) {
+        int32_t rre[8], rim[8];
+        XP_UNROLL
+        for (int ls = 0; ls < 8; ls++) {
+          rre[ls] = xl[(8 * c + ls) * 128 + sb];
+          rim[ls] = xl[(8 * c + ls) * 128 + 64 + sb];
+        }
+        const int gsh = sb < 11 ? 0 : (sb < 18 ? 1 : (sb < 23 ? 2 : (sb < 35 ? 3 : 4))); /* group_shift of the band's group */
+        XP_UNROLL
+        for (int ls = 0; ls < 8; ls++) {
+          const int l = 8 * c + ls;
+          const int usb_l = l >= clear_slot ? usb : usb_prev;
+          const int sh = sb < lsb ? (l < 6 ? ov_lb_shift : lb_shift) : (sb < usb ? hb_shift : 0);
+          const int32_t re = xp_adj_word(rre[ls], sh), im = xp_adj_word(rim[ls], sh);
+          if (sb >= 3) {
+            const int32_t pw = xp_power(re, im);
+            if (sb < 9)
+              w->binpw[l][sb + 5] = pw;
+            else
+              w->gsum[ls][sb - 9] = sb < usb_l ? (pw >> gsh) : 0;
+          }
         }
       }
+      cx.sync();
+      XS_PAR(i, 0, 48) { /* bins 14..19 = sums over the groups [9,11) [11,14) [14,18) [18,23) [23,35) [35,64) */
+        const int ls = i / 6, g = i % 6;
+        const int b0 = T->borders_group[16 + g], b1 = T->borders_group[17 + g];
+        int32_t acc = 0;
+        for (int sb = b0; sb < b1; sb++) acc = fx_add_sat(acc, w->gsum[ls][sb - 9]);
+        w->binpw[8 * c + ls][14 + g] = acc;
+      }
+      cx.sync();
     }
-    cx.sync();
-    XS_PAR(i, 0, 48) { /* bins 14..19 = sums over the groups [9,11) [11,14) [14,18) [18,23) [23,35) [35,64) */
-      const int ls = i / 6, g = i % 6;
-      const int b0 = T->borders_group[16 + g], b1 = T->borders_group[17 + g];
-      int32_t acc = 0;
-      for (int sb = b0; sb < b1; sb++) acc = fx_add_sat(acc, w->gsum[ls][sb - 9]);
-      w->binpw[8 * c + ls][14 + g] = acc;
-    }
-    cx.sync();
   }
   XS_PAR(i, 0, 256) {
     const int l = i >> 3, bin = i & 7;
@@ -305,7 +289,6 @@ FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_f
     const int clear_lo = (usb > usb_prev && usb_prev) ? usb_prev : 64; /* ps_dec.c:733-757: bands that just became active */
     const int clear_hi = usb < 23 ? usb : 23;
     XS_PAR(sb, 0, 64) {
-      XpLaneRows &rw = XP_ROWS(rows, sb);
       /* -- the lane's chain, if it has one */
       const int qmf_chain = sb >= 3 && sb < 23, hyb_chain = sb >= 32 && sb < 42, chain = qmf_chain || hyb_chain;
       const int csb = qmf_chain ? sb : (hyb_chain ? sb - 32 : 3);
@@ -349,97 +332,121 @@ FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_f
       int16_t h11 = w->seg_h[0][0][g], h12 = w->seg_h[0][1][g], h21 = w->seg_h[0][2][g], h22 = w->seg_h[0][3][g];
       int16_t d11 = w->seg_d[0][0][g], d12 = w->seg_d[0][1][g], d21 = w->seg_d[0][2][g], d22 = w->seg_d[0][3][g];
       uint32_t prev = sb >= 35 ? xp_pack16(ps->sd[2 * (sb - 35)], ps->sd[2 * (sb - 35) + 1]) : 0u;
-      /* What the next slot needs from LDS is fetched one slot ahead (nothing in the loop writes these arrays).  The loop
-         body is written without lane-dependent branches: every lane runs the chain arithmetic (on don't-care values
-         where it has no chain -- the rings then shift by register renaming, not by masked moves), band classes are
-         selects, only the stores are predicated. */
+      /* The walk: four slots per pass of the loop (the delay lines of 2 and 4 slots are back in place after four
+         steps, the 3- and 5-slot ones cost a few moves), the next pass's eight row words and the next slot's LDS
+         operands in flight meanwhile.  The body has no lane-dependent branches: every lane runs the chain arithmetic
+         (on don't-care values where it has no chain), band classes are selects, only the stores are predicated. */
       const int is_ap = sb < 23, is_d14 = sb >= 23 && sb < 35;
-      const int ldj = is_d14 ? 2 * (sb - 23) : 0;
+      const int ldj = is_d14 ? 2 * (sb - 23) : 0, dlj = is_d14 ? sb - 23 : 0;
       int16_t tr_nx = w->ratio[0][bin_sb];
       int32_t hre_nx = w->hyb_l[0][csb], him_nx = w->hyb_l[0][10 + csb];
       uint32_t ld_nx = xp_pack16(ps->ld[idx_long0 % 14][ldj], ps->ld[idx_long0 % 14][ldj + 1]);
+      int32_t nre[4], nim[4];
       XP_UNROLL
-      for (int l = 0; l < 32; l++) {
-        const int usb_l = l >= clear_slot ? usb : usb_prev;
-        const int16_t tr = tr_nx;
-        const int32_t hre = hre_nx, him = him_nx;
-        const uint32_t ld_cur = ld_nx;
-        if (l + 1 < 32) {
-          tr_nx = w->ratio[l + 1][bin_sb];
-          hre_nx = w->hyb_l[l + 1][csb];
-          him_nx = w->hyb_l[l + 1][10 + csb];
-          if (l + 1 < 14) {
-            const int pn = (idx_long0 + l + 1) % 14;
-            ld_nx = xp_pack16(ps->ld[pn][ldj], ps->ld[pn][ldj + 1]);
+      for (int j = 0; j < 4; j++) {
+        nre[j] = xl[j * 128 + sb];
+        nim[j] = xl[j * 128 + 64 + sb];
+      }
+      XP_NOUNROLL
+      for (int l0 = 0; l0 < 32; l0 += 4) {
+        int32_t cre[4], cim[4];
+        XP_UNROLL
+        for (int j = 0; j < 4; j++) {
+          cre[j] = nre[j];
+          cim[j] = nim[j];
+        }
+        if (l0 + 4 < 32) {
+          XP_UNROLL
+          for (int j = 0; j < 4; j++) {
+            nre[j] = xl[(l0 + 4 + j) * 128 + sb];
+            nim[j] = xl[(l0 + 4 + j) * 128 + 64 + sb];
           }
         }
-        const int16_t q_re = fx_round16(rw.re[l]), q_im = fx_round16(rw.im[l]);
-        const uint32_t q = xp_pack16(q_re, q_im);
-        /* the chain */
-        if (l == clear_slot) { /* (uniform) the three links' lines of the bands that just became active */
-          const int c = qmf_chain && sb >= clear_lo && sb < clear_hi;
-          XP_UNROLL
-          for (int j = 0; j < 3; j++) r0[j] = c ? 0u : r0[j];
-          XP_UNROLL
-          for (int j = 0; j < 4; j++) r1[j] = c ? 0u : r1[j];
-          XP_UNROLL
-          for (int j = 0; j < 5; j++) r2[j] = c ? 0u : r2[j];
-        }
-        const int16_t in_re = hyb_chain ? fx_round16(hre) : q_re, in_im = hyb_chain ? fx_round16(him) : q_im;
-        int16_t dv[2] = {xp_lo16(d0[0]), xp_hi16(d0[0])};
-        int16_t e0[2] = {xp_lo16(r0[0]), xp_hi16(r0[0])}, e1[2] = {xp_lo16(r1[0]), xp_hi16(r1[0])},
-                e2[2] = {xp_lo16(r2[0]), xp_hi16(r2[0])};
-        int16_t o_re, o_im;
-        xp_allpass(dv, in_re, in_im, phase, e0, e1, e2, ps0, ps1, ps2, dec0, dec1, dec2, &o_re, &o_im);
-        d0[0] = d0[1];
-        d0[1] = xp_pack16(dv[0], dv[1]);
-        r0[0] = r0[1]; r0[1] = r0[2];
-        r0[2] = xp_pack16(e0[0], e0[1]);
-        r1[0] = r1[1]; r1[1] = r1[2]; r1[2] = r1[3];
-        r1[3] = xp_pack16(e1[0], e1[1]);
-        r2[0] = r2[1]; r2[1] = r2[2]; r2[2] = r2[3]; r2[3] = r2[4];
-        r2[4] = xp_pack16(e2[0], e2[1]);
-        const uint32_t o_chain = xp_pack16(o_re, o_im);
-        if (hyb_chain) w->ap_h[l][csb] = o_chain;
-        /* the interpolated coefficients of the band's group */
-        if ((seg_mask >> l) & 1u) { /* (uniform) a border: they restart from the old targets */
-          const int s = xp_popc(seg_mask & (0xffffffffu >> (31 - l)));
-          h11 = w->seg_h[s][0][g]; h12 = w->seg_h[s][1][g]; h21 = w->seg_h[s][2][g]; h22 = w->seg_h[s][3][g];
-          d11 = w->seg_d[s][0][g]; d12 = w->seg_d[s][1][g]; d21 = w->seg_d[s][2][g]; d22 = w->seg_d[s][3][g];
-        }
-        h11 = (int16_t)(h11 + d11); /* the interpolation advances whether or not the band is rotated */
-        h12 = (int16_t)(h12 + d12);
-        h21 = (int16_t)(h21 + d21);
-        h22 = (int16_t)(h22 + d22);
-        /* the decorrelated sample of the band: all-pass output, or the input of 14 slots / 1 slot ago.  The 14-slot
-           line holds what slot l - 14 put in if that slot ran with the band active, else what the state held. */
-        const int active = sb < usb_l;
-        const int fed14 = l >= 14 && sb < (l - 14 >= clear_slot ? usb : usb_prev);
-        const uint32_t q14 = xp_pack16(fx_round16(rw.re[l >= 14 ? l - 14 : 0]), fx_round16(rw.im[l >= 14 ? l - 14 : 0]));
-        const uint32_t o14 = fed14 ? q14 : (l < 14 ? ld_cur : xp_pack16(ps->ld[(idx_long0 + l) % 14][ldj], ps->ld[(idx_long0 + l) % 14][ldj + 1]));
-        const uint32_t o = is_ap ? o_chain : (is_d14 ? o14 : prev);
-        prev = active ? q : prev;
-        int32_t re = rw.re[l], im = rw.im[l];
-        int32_t r_re = xp_m16x16_shl(xp_lo16(o), tr), r_im = xp_m16x16_shl(xp_hi16(o), tr);
-        xp_rotate(&re, &r_re, h11, h12, h21, h22);
-        xp_rotate(&im, &r_im, h11, h12, h21, h22);
-        re = active ? re : rw.re[l]; /* above usb: the left sample passes, the right one is zero */
-        im = active ? im : rw.im[l];
-        r_re = active ? r_re : 0;
-        r_im = active ? r_im : 0;
-        if (common_shift < 0) {
-          const int cs = -common_shift > 31 ? 31 : -common_shift;
-          re = fx_shr(re, cs);
-          im = fx_shr(im, cs);
-        } else if (common_shift > 0) {
-          re = fx_shl_sat(re, common_shift);
-          im = fx_shl_sat(im, common_shift);
-        }
-        if (sb >= 3) {
-          xl[l * 128 + sb] = re;
-          xl[l * 128 + 64 + sb] = im;
-          xr[l * 128 + sb] = r_re;
-          xr[l * 128 + 64 + sb] = r_im;
+        XP_UNROLL
+        for (int j = 0; j < 4; j++) {
+          const int l = l0 + j;
+          const int usb_l = l >= clear_slot ? usb : usb_prev;
+          const int16_t tr = tr_nx;
+          const int32_t hre = hre_nx, him = him_nx;
+          const uint32_t ld_cur = ld_nx;
+          {
+            const int ln = l + 1 < 32 ? l + 1 : 31, pn = (idx_long0 + ln) % 14;
+            tr_nx = w->ratio[ln][bin_sb];
+            hre_nx = w->hyb_l[ln][csb];
+            him_nx = w->hyb_l[ln][10 + csb];
+            ld_nx = xp_pack16(ps->ld[pn][ldj], ps->ld[pn][ldj + 1]);
+          }
+          const int sh = sb < lsb ? (l < 6 ? ov_lb_shift : lb_shift) : (sb < usb ? hb_shift : 0);
+          const int32_t re0 = xp_adj_word(cre[j], sh), im0 = xp_adj_word(cim[j], sh);
+          const int16_t q_re = fx_round16(re0), q_im = fx_round16(im0);
+          const uint32_t q = xp_pack16(q_re, q_im);
+          /* the chain */
+          if (l == clear_slot) { /* (uniform) the three links' lines of the bands that just became active */
+            const int c = qmf_chain && sb >= clear_lo && sb < clear_hi;
+            XP_UNROLL
+            for (int m = 0; m < 3; m++) r0[m] = c ? 0u : r0[m];
+            XP_UNROLL
+            for (int m = 0; m < 4; m++) r1[m] = c ? 0u : r1[m];
+            XP_UNROLL
+            for (int m = 0; m < 5; m++) r2[m] = c ? 0u : r2[m];
+          }
+          const int16_t in_re = hyb_chain ? fx_round16(hre) : q_re, in_im = hyb_chain ? fx_round16(him) : q_im;
+          int16_t dv[2] = {xp_lo16(d0[0]), xp_hi16(d0[0])};
+          int16_t e0[2] = {xp_lo16(r0[0]), xp_hi16(r0[0])}, e1[2] = {xp_lo16(r1[0]), xp_hi16(r1[0])},
+                  e2[2] = {xp_lo16(r2[0]), xp_hi16(r2[0])};
+          int16_t o_re, o_im;
+          xp_allpass(dv, in_re, in_im, phase, e0, e1, e2, ps0, ps1, ps2, dec0, dec1, dec2, &o_re, &o_im);
+          d0[0] = d0[1];
+          d0[1] = xp_pack16(dv[0], dv[1]);
+          r0[0] = r0[1]; r0[1] = r0[2];
+          r0[2] = xp_pack16(e0[0], e0[1]);
+          r1[0] = r1[1]; r1[1] = r1[2]; r1[2] = r1[3];
+          r1[3] = xp_pack16(e1[0], e1[1]);
+          r2[0] = r2[1]; r2[1] = r2[2]; r2[2] = r2[3]; r2[3] = r2[4];
+          r2[4] = xp_pack16(e2[0], e2[1]);
+          const uint32_t o_chain = xp_pack16(o_re, o_im);
+          if (hyb_chain) w->ap_h[l][csb] = o_chain;
+          /* the interpolated coefficients of the band's group */
+          if ((seg_mask >> l) & 1u) { /* (uniform) a border: they restart from the old targets */
+            const int s = xp_popc(seg_mask & (0xffffffffu >> (31 - l)));
+            h11 = w->seg_h[s][0][g]; h12 = w->seg_h[s][1][g]; h21 = w->seg_h[s][2][g]; h22 = w->seg_h[s][3][g];
+            d11 = w->seg_d[s][0][g]; d12 = w->seg_d[s][1][g]; d21 = w->seg_d[s][2][g]; d22 = w->seg_d[s][3][g];
+          }
+          h11 = (int16_t)(h11 + d11); /* the interpolation advances whether or not the band is rotated */
+          h12 = (int16_t)(h12 + d12);
+          h21 = (int16_t)(h21 + d21);
+          h22 = (int16_t)(h22 + d22);
+          /* the decorrelated sample of the band: all-pass output, or the input of 14 slots / 1 slot ago.  The 14-slot
+             line holds what slot l - 14 put in if that slot ran with the band active, else what the state held. */
+          const int active = sb < usb_l;
+          const int fed14 = l >= 14 && sb < (l - 14 >= clear_slot ? usb : usb_prev);
+          const uint32_t o14 = fed14 ? w->dl[l >= 14 ? l - 14 : 0][dlj]
+                                     : (l < 14 ? ld_cur : xp_pack16(ps->ld[(idx_long0 + l) % 14][ldj], ps->ld[(idx_long0 + l) % 14][ldj + 1]));
+          const uint32_t o = is_ap ? o_chain : (is_d14 ? o14 : prev);
+          if (is_d14) w->dl[l][dlj] = q;
+          prev = active ? q : prev;
+          int32_t re = re0, im = im0;
+          int32_t r_re = xp_m16x16_shl(xp_lo16(o), tr), r_im = xp_m16x16_shl(xp_hi16(o), tr);
+          xp_rotate(&re, &r_re, h11, h12, h21, h22);
+          xp_rotate(&im, &r_im, h11, h12, h21, h22);
+          re = active ? re : re0; /* above usb: the left sample passes, the right one is zero */
+          im = active ? im : im0;
+          r_re = active ? r_re : 0;
+          r_im = active ? r_im : 0;
+          if (common_shift < 0) {
+            const int cs = -common_shift > 31 ? 31 : -common_shift;
+            re = fx_shr(re, cs);
+            im = fx_shr(im, cs);
+          } else if (common_shift > 0) {
+            re = fx_shl_sat(re, common_shift);
+            im = fx_shl_sat(im, common_shift);
+          }
+          if (sb >= 3) {
+            xl[l * 128 + sb] = re;
+            xl[l * 128 + 64 + sb] = im;
+            xr[l * 128 + sb] = r_re;
+            xr[l * 128 + 64 + sb] = r_im;
+          }
         }
       }
       /* -- the delay lines as the slot loop leaves them */
@@ -473,22 +480,12 @@ FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_f
         ps->sd[2 * (sb - 35)] = xp_lo16(prev);
         ps->sd[2 * (sb - 35) + 1] = xp_hi16(prev);
       }
-      if (is_d14 && (clear_slot == 0 || usb == usb_prev)) { /* (the usual frame) one band limit: the last 14 slots' inputs */
-        if (sb < usb) {
-          XP_UNROLL
-          for (int j = 0; j < 14; j++) {
-            const int pos = (idx_long0 + 18 + j) % 14;
-            ps->ld[pos][ldj] = fx_round16(rw.re[18 + j]);
-            ps->ld[pos][ldj + 1] = fx_round16(rw.im[18 + j]);
-          }
-        }
-      } else if (is_d14) { /* each position of the 14-slot ring ends up with the input of the last slot that wrote it */
-        XP_UNROLL
-        for (int l = 0; l < 32; l++) {
+      if (is_d14) { /* each position of the 14-slot ring ends up with the input of the last slot that wrote it */
+        for (int l = (clear_slot == 0 || usb == usb_prev) ? 18 : 0; l < 32; l++) {
           const int pos = (idx_long0 + l) % 14;
           if (sb < (l >= clear_slot ? usb : usb_prev)) {
-            ps->ld[pos][2 * (sb - 23)] = fx_round16(rw.re[l]);
-            ps->ld[pos][2 * (sb - 23) + 1] = fx_round16(rw.im[l]);
+            ps->ld[pos][ldj] = xp_lo16(w->dl[l][dlj]);
+            ps->ld[pos][ldj + 1] = xp_hi16(w->dl[l][dlj]);
           }
         }
       }
