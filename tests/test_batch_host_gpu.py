@@ -1,0 +1,74 @@
+"""The batched multi-stream host (oracle/ref_batch_host.c -> oracle/_ref/xaacdec_batch): N forked instances of the
+REAL reference command-line decoder, their frame-level seams (ixheaacd_imdct_process, ixheaacd_sbr_dec,
+ixheaacd_peak_limiter_process) served group-wise by ONE xaac_*_process_batch per rendezvous on the GPU, operands in
+page-locked staging arrays, one HIP stream per group.  Every instance's output file must be byte-identical to what the
+unmodified reference decoder writes for the same stream (AAC-LC with the limiter on, HE-AACv1, HE-AACv2, mixed in one
+run).  Needs the prebuilt oracle/_ref binaries next to the repo."""
+import glob
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+STREAMS = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "streams", "*.aac")))
+
+
+def _md5(path):
+    return hashlib.md5(open(path, "rb").read()).hexdigest()
+
+
+def _need():
+    if not all(os.path.exists(os.path.join(REF, b)) for b in ("xaacdec", "xaacdec_batch")):
+        pytest.skip("oracle/_ref/xaacdec[_batch] missing (built by oracle/Makefile.ref where /root/reference exists)")
+
+
+def run_batch(tmp_path, groups, timeout=900):
+    """groups: [(n, aac)] -> (summary dict, {group index: [wav paths]})"""
+    args = [os.path.join(REF, "xaacdec_batch"), "-esbr:0", "--"]
+    outs = {}
+    for k, (n, aac) in enumerate(groups):
+        prefix = str(tmp_path / ("g%d" % k))
+        args.append("%d:%s:%s" % (n, aac, prefix))
+        outs[k] = ["%s.%d.wav" % (prefix, i) for i in range(n)]
+    p = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-600:]
+    return json.loads(p.stdout.decode().strip().splitlines()[-1]), outs
+
+
+def reference_md5(tmp_path, aac):
+    ref = str(tmp_path / ("ref_" + os.path.basename(aac) + ".wav"))
+    subprocess.run([os.path.join(REF, "xaacdec"), "-ifile:" + aac, "-ofile:" + ref, "-esbr:0"], stdout=subprocess.DEVNULL,
+                   stderr=subprocess.DEVNULL, timeout=600, check=False)
+    return _md5(ref)
+
+
+def test_mixed_groups_every_instance_byte_identical(tmp_path):
+    """three groups (AAC-LC, HE-AACv1, HE-AACv2) of 24 instances each in one run: 72 decoders, three HIP streams"""
+    _need()
+    groups = [(24, s) for s in STREAMS]
+    summary, outs = run_batch(tmp_path, groups)
+    assert summary["failed"] == 0 and summary["streams"] == 72
+    for k, (n, aac) in enumerate(groups):
+        want = reference_md5(tmp_path, aac)
+        got = {_md5(w) for w in outs[k]}
+        assert got == {want}, (os.path.basename(aac), len(got))
+    c, b = summary["calls"], summary["batches"]
+    assert c["imdct"] > 0 and c["sbr_lp"] > 0 and c["sbr_ps"] > 0 and c["limiter"] > 0
+    # one batch per rendezvous: 24 calls of a kind share one xaac_*_process_batch
+    assert b["imdct"] * 24 == c["imdct"] and b["sbr_ps"] * 24 == c["sbr_ps"] and b["limiter"] * 24 == c["limiter"]
+
+
+def test_256_instances_of_the_he_aac_v2_stream(tmp_path):
+    """the verdict's size: >= 256 reference decoder instances, one xaac_sbr_hq_process_batch per frame-step"""
+    _need()
+    aac = [s for s in STREAMS if "aot29" in s][0]
+    summary, outs = run_batch(tmp_path, [(256, aac)])
+    assert summary["failed"] == 0
+    want = reference_md5(tmp_path, aac)
+    assert {_md5(w) for w in outs[0]} == {want}
+    assert summary["batches"]["sbr_ps"] * 256 == summary["calls"]["sbr_ps"]

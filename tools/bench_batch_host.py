@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""End-to-end throughput of the batched multi-stream host (oracle/_ref/xaacdec_batch): parse (the reference's own
+decoder instances on the host cores) + conversion + PCIe both ways + GPU, next to the same streams decoded by as many
+plain reference decoders (oracle/_ref/xaacdec) run in parallel on the same cores.  A 20 s HE-AACv2 stream is made on
+the spot with the reference encoder (oracle/_ref/xaacenc).  Prints one JSON line.  Run on the GPU box:
+    python tools/bench_batch_host.py [instances] [groups]"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import make_test_streams as mts  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    groups = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    seconds = 20.0
+    tmp = tempfile.mkdtemp(prefix="xaac_batch_")
+    x = mts.signals(seconds)["harmonic"]
+    wav, aac = os.path.join(tmp, "in.wav"), os.path.join(tmp, "in.aac")
+    mts.write_wav(wav, x)
+    subprocess.run([os.path.join(REF, "xaacenc"), "-ifile:" + wav, "-ofile:" + aac, "-aot:29", "-br:32000", "-adts:1"],
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+    frames_per_stream = int(seconds * 48000 / 2048)
+    per = n // groups
+    args = [os.path.join(REF, "xaacdec_batch"), "-esbr:0", "--"] + ["%d:%s:%s/g%d" % (per, aac, tmp, k) for k in range(groups)]
+    t0 = time.perf_counter()
+    p = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    wall = time.perf_counter() - t0
+    summary = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    frames = summary["calls"]["sbr_ps"] + summary["calls"]["sbr_hq"]
+    # the same number of plain reference decoders, all at once, on the same cores
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([os.path.join(REF, "xaacdec"), "-ifile:" + aac, "-ofile:%s/r%d.wav" % (tmp, i), "-esbr:0"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for i in range(per * groups)]
+    for q in procs:
+        q.wait()
+    wall_ref = time.perf_counter() - t0
+    same = open("%s/g0.0.wav" % tmp, "rb").read() == open("%s/r0.wav" % tmp, "rb").read()
+    print(json.dumps({"what": "HE-AACv2 48 kHz, %d decoder instances in %d groups, %.0f s stream each: reference parser "
+                              "instances + conversion + PCIe + GPU back-end, state shipped both ways per call" % (per * groups, groups, seconds),
+                      "frames": frames, "frames_expected_per_stream": frames_per_stream,
+                      "end_to_end_frames_per_s": round(frames / summary["seconds"], 1), "seconds": summary["seconds"],
+                      "wall_incl_fork": round(wall, 3), "pinned": summary["pinned"], "batches": summary["batches"],
+                      "cpu_only_reference_frames_per_s": round(frames / wall_ref, 1), "cores": os.cpu_count(),
+                      "output_identical": same}))
+
+
+if __name__ == "__main__":
+    main()
