@@ -157,12 +157,22 @@ struct Sink {
   int stride;
   int qadj;
   int mode;
+  /* The reference converts an interleaved stereo block for the SBR tool IN PLACE, channel by channel
+     (ixheaacd_allocate_sbr_scr, api.c:353-366): channel 0's WORD16 results land in the low halves of words 0..1023,
+     and the odd ones of those are channel 1's samples 0..511, not yet converted.  So channel 1's sample n < 512 is
+     converted with its low 16 bits replaced by channel 0's PCM sample 2 n + 1.  peer: channel 0's PCM of this access
+     unit (interleaved output, stride 2), set only for channel 1 of a stereo unit in XAAC_PCM_SBR mode. */
+  const int16_t *peer;
   __device__ __forceinline__ int16_t to_pcm(int32_t v) const {
     return fx_round16(mode ? fx_shl_sat(v, qadj) : fx_shlw(v, qadj));
   }
+  __device__ __forceinline__ int32_t in_place(int n, int32_t v) const {
+    if (peer && n < 512) v = (int32_t)(((uint32_t)v & 0xffff0000u) | (uint16_t)peer[2 * (2 * n + 1)]);
+    return v;
+  }
   __device__ __forceinline__ void put(int n, int32_t v) const {
     if (o32) o32[n * stride] = v;
-    if (p16) p16[n * stride] = to_pcm(v);
+    if (p16) p16[n * stride] = to_pcm(in_place(n, v));
   }
 };
 
@@ -621,12 +631,20 @@ __global__ __launch_bounds__(XAAC_IMDCT_BLOCK, XAAC_IMDCT_MIN_WAVES_PER_SIMD) vo
       sk.stride = CF;
       sk.mode = MODE;
       sk.qadj = 2;
+      sk.peer = nullptr;
 
       /* CF == 2: channel 0 was parked but this channel cannot pair with it (rare path,
          which also needs the parking area for the old overlap): flush channel 0 now */
       if (CF == 2 && parked && !hot) {
         for (int n = lane; n < 1024; n += 64) p.pcm16[obase - 1 + 2 * (size_t)n] = park[n];
         parked = false;
+      }
+      /* stereo + SBR hand-off, channel 1: the in-place conversion's view of channel 0 (see Sink).  Channel 0's PCM is in
+         LDS while it is parked, else in the output buffer, where this wave's own stores have to have landed first. */
+      const bool in_place1 = CF == 2 && MODE == XAAC_PCM_SBR && c == 1 && p.pcm16 != nullptr;
+      if (in_place1 && !parked) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sk.peer = p.pcm16 + (size_t)au * 2048;
       }
 
       if (seq != XAAC_K_EIGHT_SHORT) {
@@ -675,7 +693,13 @@ __global__ __launch_bounds__(XAAC_IMDCT_BLOCK, XAAC_IMDCT_MIN_WAVES_PER_SIMD) vo
               int16_t pl[4], ph[4];
 #pragma unroll
               for (int j = 0; j < 4; j++) {
-                pl[j] = sk.to_pcm(lo[j]);
+                int32_t lv = lo[j]; /* sample 511 - t0 - j: below 512, where channel 1 sees channel 0's halfwords */
+                if (in_place1) {
+                  const int m = 2 * (511 - t0 - j) + 1;
+                  const int16_t c0 = parked ? park[m] : sk.peer[2 * m];
+                  lv = (int32_t)(((uint32_t)lv & 0xffff0000u) | (uint16_t)c0);
+                }
+                pl[j] = sk.to_pcm(lv);
                 ph[j] = sk.to_pcm(hi[j]);
               }
               if (CF == 1) {

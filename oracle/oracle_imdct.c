@@ -396,6 +396,35 @@ void xo_pcm16(const int32_t *in, int in_stride, int16_t *pcm, int pcm_stride, in
   }
 }
 
+/* The same hand-off on an interleaved block of nch channels, IN PLACE like the reference does it: blk = [1024][nch]
+   WORD32, the WORD16 samples end up packed at the front of the same memory.
+   mode 0 (api.c:3676-3681 after ixheaacd_scale_adjust): sample-major, ascending -- every word is read before the
+          halfword that lands in it is written: nothing is lost.
+   mode 1 (ixheaacd_allocate_sbr_scr, api.c:353-366): CHANNEL-major -- the pass over channel 0 stores its WORD16
+          results into the low halves of words 0..1023, and the odd ones of those are channel 1's samples 0..511, not
+          yet converted: channel 1's first 512 samples are converted with their low 16 bits replaced by channel 0's
+          output sample 2 s + 1.  (Their top bits decide all but the rounding: an LSB now and then.)  Kept: it is what
+          the reference decoder feeds its SBR tool for a stereo stream. */
+void xo_pcm16_block(int32_t *blk, const int8_t *qadj, int nch, int mode, int16_t *out) {
+  int16_t *h = (int16_t *)blk; /* the reference's own aliasing (it is built with -fno-strict-aliasing, see Makefile.ref) */
+  if (mode == 0) {
+    for (int i = 0; i < 1024 * nch; i++) {
+      const int32_t v = fx_shlw(blk[i], qadj[i % nch]);
+      const int16_t r = fx_round16(v);
+      memcpy(&h[i], &r, 2);
+    }
+  } else {
+    for (int j = 0; j < nch; j++)
+      for (int i = 0; i < 1024; i++) {
+        int32_t v;
+        memcpy(&v, &blk[nch * i + j], 4);
+        const int16_t r = fx_round16(fx_shl_sat(v, qadj[j]));
+        memcpy(&h[nch * i + j], &r, 2);
+      }
+  }
+  memcpy(out, blk, sizeof(int16_t) * 1024 * (size_t)nch);
+}
+
 /* Batch driver used as the CPU baseline: nch independent channel-frames. */
 void xo_imdct_batch(int nch, const int32_t *spec, int32_t *ovl, int16_t *prev_seq, int16_t *prev_shape,
                     const uint8_t *seq, const uint8_t *shape, int32_t *out32, int16_t *pcm, int8_t *qadj,

@@ -99,6 +99,30 @@ void ref_imdct_batch(int n, WORD32 *spec, WORD32 *overlap, WORD16 *prev_seq, WOR
   }
 }
 
+/* ---- the WORD32 -> WORD16 hand-off behind the IMDCT, by the reference's own code ------------
+ * mode 1 (core -> SBR): ixheaacd_allocate_sbr_scr (api.c:337-370) converts the interleaved WORD32 block in place:
+ *        round16(shl32_sat(x, qshift_adj[ch])), the WORD16 samples packed at the front of the same buffer;
+ * mode 0 (AAC-LC, limiter off): ixheaacd_scale_adjust (peak_limiter.c:324), then the round16 loop of api.c:3676-3681
+ *        (that loop is inline in ixheaacd_dec_execute: it is restated here with the reference's ixheaac_round16).
+ * x: [1024][nch] interleaved WORD32 (clobbered), q: [nch], out: [1024][nch] WORD16. */
+/* (ia_sbr_scr_struct: ixheaacd_sbrdecoder.h, included above) */
+VOID ixheaacd_allocate_sbr_scr(ia_sbr_scr_struct *sbr_scratch_struct, VOID *base_scratch_ptr, VOID *output_ptr,
+                               WORD32 total_channels, WORD8 *p_qshift_arr, UWORD8 slot_pos, UWORD8 num_ch);
+VOID ixheaacd_scale_adjust(WORD32 *samples, UWORD32 frame_len, WORD8 *qshift_adj, WORD num_channels);
+
+void ref_pcm_handoff(WORD32 *x, WORD8 *q, int nch, int mode, WORD16 *out) {
+  int i;
+  if (mode == 1) {
+    ia_sbr_scr_struct scr;
+    static __thread WORD32 scratch[16];
+    ixheaacd_allocate_sbr_scr(&scr, scratch, x, nch, q, 0, (UWORD8)nch);
+    memcpy(out, x, sizeof(WORD16) * 1024 * (size_t)nch);
+  } else {
+    ixheaacd_scale_adjust(x, 1024, q, nch);
+    for (i = 0; i < 1024 * nch; i++) out[i] = ixheaac_round16(x[i]);
+  }
+}
+
 /* ======================================================================================
  * SBR QMF banks (fixed-point Path B).  Wrappers fill the reference's own structs and call
  * its external symbols; tables are the reference's ROM (ixheaacd_aac_qmf_dec_tables).

@@ -56,7 +56,15 @@ class Oracle:
                                 _p(shape, PU8), _p(out32, P32), _p(pcm, P16), _p(qadj, P8), int(pcm_mode))
         if ch_fac != 1:
             out32 = out32.reshape(n // ch_fac, ch_fac, 1024).transpose(0, 2, 1).reshape(n, 1024)
-            pcm = pcm.reshape(n // ch_fac, ch_fac, 1024).transpose(0, 2, 1).reshape(n, 1024)
+            # the interleaved block's PCM16 is made IN PLACE like the reference makes it (xo_pcm16_block): for
+            # stereo + the SBR hand-off that is not the per-channel conversion (oracle_imdct.c)
+            blk = np.ascontiguousarray(out32).copy()
+            pcm = np.zeros((n, 1024), np.int16)
+            self.lib.xo_pcm16_block.restype = None
+            for au in range(n // ch_fac):
+                self.lib.xo_pcm16_block(blk[au * ch_fac:].ctypes.data_as(ctypes.c_void_p),
+                                        np.ascontiguousarray(qadj[au * ch_fac:(au + 1) * ch_fac]).ctypes.data_as(ctypes.c_void_p),
+                                        ch_fac, int(pcm_mode), pcm[au * ch_fac:].ctypes.data_as(ctypes.c_void_p))
         return {"out32": np.ascontiguousarray(out32), "pcm16": np.ascontiguousarray(pcm), "qshift_adj": qadj,
                 "overlap": ovl, "state": np.stack([pseq, pshape], 1).astype(np.uint8)}
 

@@ -45,3 +45,34 @@ def test_oracle_batch_matches_single_calls(oracle):
             v = np.clip(v, -2 ** 31, 2 ** 31 - 1)
         want = (np.clip(v + 0x8000, -2 ** 31, 2 ** 31 - 1) >> 16).astype(np.int16)
         assert np.array_equal(pcm, want), mode
+
+
+def test_pcm_handoff_matches_the_references_own_code(oracle):
+    """row a8: both PCM16 hand-off flavours of the oracle against tests/golden/handoff_ref.npz, which
+    tools/make_golden_handoff.py made by calling ixheaacd_allocate_sbr_scr (api.c:337-370) and ixheaacd_scale_adjust +
+    ixheaac_round16 (peak_limiter.c:324, api.c:3676-3681) themselves"""
+    import ctypes
+    h = np.load(os.path.join(ROOT, "tests", "golden", "handoff_ref.npz"))
+    P32, P16 = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int16)
+    oracle.lib.xo_pcm16.restype = None
+    oracle.lib.xo_pcm16.argtypes = [P32, ctypes.c_int, P16, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    for mode, key in ((0, "mono_lc"), (1, "mono_sbr")):
+        for i in range(h["x"].shape[0]):
+            x = np.ascontiguousarray(h["x"][i])
+            out = np.zeros(1024, np.int16)
+            oracle.lib.xo_pcm16(x.ctypes.data_as(P32), 1, out.ctypes.data_as(P16), 1, 1024, int(h["q"][i]), mode)
+            assert np.array_equal(out, h[key][i]), (mode, i)
+    oracle.lib.xo_pcm16_block.restype = None
+    for mode, key in ((0, "stereo_lc"), (1, "stereo_sbr")):       # interleaved, in place like the reference
+        for p in range(h[key].shape[0]):
+            blk = np.ascontiguousarray(np.stack([h["x"][2 * p], h["x"][2 * p + 1]], 1))
+            q = np.ascontiguousarray(h["q"][2 * p:2 * p + 2])
+            out = np.zeros((1024, 2), np.int16)
+            oracle.lib.xo_pcm16_block(blk.ctypes.data_as(ctypes.c_void_p), q.ctypes.data_as(ctypes.c_void_p), 2, mode,
+                                      out.ctypes.data_as(ctypes.c_void_p))
+            assert np.array_equal(out, h[key][p]), (mode, p)
+    # and the in-place order matters: the stereo SBR hand-off is NOT the per-channel conversion (ch 1, samples < 512)
+    diff = sum(int(np.any(h["stereo_sbr"][p][:, 1] != h["mono_sbr"][2 * p + 1])) for p in range(h["stereo_sbr"].shape[0]))
+    same = all(np.array_equal(h["stereo_sbr"][p][:, 0], h["mono_sbr"][2 * p]) and
+               np.array_equal(h["stereo_sbr"][p][512:, 1], h["mono_sbr"][2 * p + 1][512:]) for p in range(h["stereo_sbr"].shape[0]))
+    assert same and diff > 0

@@ -231,10 +231,35 @@ def test_malformed_window_bytes_refused_neighbours_exact(ctx, oracle, ch_fac, pc
     g32, g16 = unint(out32.cpu().numpy()), unint(pcm.cpu().numpy())
     w32, w16 = unint(want["out32"]), unint(want["pcm16"])
     good = ~bad
-    assert np.array_equal(g32[good], w32[good]) and np.array_equal(g16[good], w16[good])
+    # stereo + the SBR hand-off converts the block in place like the reference: channel 1's first 512 PCM samples
+    # take their low bits from channel 0's PCM (imdct_kernel.hip, Sink) -- with channel 0 refused there is nothing
+    # defined to take; the WORD32 block, overlap and state of that channel 1 are still exact
+    pcm_ok = good.copy()
+    if ch_fac == 2 and pcm_mode == 1:
+        pcm_ok[1::2] &= ~bad[0::2]
+    assert np.array_equal(g32[good], w32[good]) and np.array_equal(g16[pcm_ok], w16[pcm_ok])
     assert np.array_equal(t_ovl.cpu().numpy()[good], want["overlap"][good])
     assert np.array_equal(t_state.cpu().numpy()[good], want["state"][good])
     assert np.array_equal(qadj.cpu().numpy()[good], want["qshift_adj"][good])
     # refused channel-frames: nothing written
     assert (g32[bad] == 0x5A5A5A5A).all() and (g16[bad] == 0x5A5A).all() and (qadj.cpu().numpy()[bad] == 99).all()
     assert np.array_equal(t_ovl.cpu().numpy()[bad], ovl[bad]) and np.array_equal(t_state.cpu().numpy()[bad], state_p[bad])
+
+
+@pytest.mark.parametrize("pcm_mode", [0, 1])
+def test_fused_pcm16_handoff_vs_reference_made_vectors(ctx, pcm_mode):
+    """row a8: the PCM16 the kernel writes behind the IMDCT (XAAC_PCM_LC / XAAC_PCM_SBR) against
+    tests/golden/handoff_ref.npz -- made by the reference's own ixheaacd_scale_adjust + round16 and
+    ixheaacd_allocate_sbr_scr on the reference's own IMDCT outputs -- planar and as interleaved stereo pairs"""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "imdct_ref.npz"))
+    h = np.load(os.path.join(ROOT, "tests", "golden", "handoff_ref.npz"))
+    n = g["spec"].shape[0]
+    ics = np.ascontiguousarray(g["meta"][:, 2:4])
+    state = np.ascontiguousarray(g["meta"][:, 0:2])
+    assert np.array_equal(h["x"][:n], g["out"]) and np.array_equal(h["q"][:n], g["qadj"])
+    r = run_gpu(ctx, g["spec"], ics, g["ovl"], state, ch_fac=1, pcm_mode=pcm_mode)
+    assert np.array_equal(r["pcm16"], (h["mono_sbr"] if pcm_mode else h["mono_lc"])[:n])
+    m = n & ~1
+    r = run_gpu(ctx, g["spec"][:m], ics[:m], g["ovl"][:m], state[:m], ch_fac=2, pcm_mode=pcm_mode)
+    want = (h["stereo_sbr"] if pcm_mode else h["stereo_lc"])[:m // 2]          # [pair][1024][2]
+    assert np.array_equal(r["pcm16"].reshape(m // 2, 1024, 2), want)

@@ -24,7 +24,11 @@ def main():
     groups = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     seconds = 20.0
     tmp = tempfile.mkdtemp(prefix="xaac_batch_")
-    x = mts.signals(seconds)["harmonic"]
+    t = np.arange(int(48000 * seconds)) / 48000.0
+    rng = np.random.default_rng(7)
+    tone = sum((0.3 / k) * np.sin(2 * np.pi * 440.0 * k * t + k) for k in range(1, 24)) * (0.6 + 0.4 * np.sin(2 * np.pi * 0.9 * t))
+    nz = rng.standard_normal(len(t)) * (0.03 + 0.15 * (np.floor(t * 2.5) % 2))
+    x = np.stack([0.5 * tone + nz, 0.5 * tone + 0.6 * nz[::-1]], 1)
     wav, aac = os.path.join(tmp, "in.wav"), os.path.join(tmp, "in.aac")
     mts.write_wav(wav, x)
     subprocess.run([os.path.join(REF, "xaacenc"), "-ifile:" + wav, "-ofile:" + aac, "-aot:29", "-br:32000", "-adts:1"],
