@@ -66,3 +66,60 @@ def test_two_rank_gloo_shard_and_gather(oracle):
     want = oracle.imdct_batch(spec, ics, ovl, st)["pcm16"]
     assert np.array_equal(pcm, want)
     assert t == 2.0                                  # max over ranks of (1.0, 2.0)
+
+
+def _c4_steps(lib, lo, hi, steps):
+    """the HE-AACv2 chain (oracle) on chains lo..hi-1 of tests/golden/sbr_chains.npz for `steps` frame-steps with the SBR
+    and PS state carried; returns the PCM of every step [steps, hi - lo, 4096] and the final states' bytes"""
+    import ctypes
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_golden_sbr_chains import chain_pcm
+    ch = np.load(os.path.join(ROOT, "tests", "golden", "sbr_chains.npz"))
+    P16 = ctypes.POINTER(ctypes.c_int16)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    st = np.ascontiguousarray(ch["hq_st0"][lo:hi]).copy()
+    ps = np.ascontiguousarray(ch["hq_ps0"][lo:hi]).copy()
+    out = np.zeros((steps, hi - lo, 4096), np.int16)
+    for s in range(steps):
+        for i, c in enumerate(range(lo, hi)):
+            pin = np.ascontiguousarray(chain_pcm(1, c, s))
+            h, f, pf = (np.ascontiguousarray(ch[k][c, s]) for k in ("hq_header", "hq_frame", "hq_ps_frame"))
+            rc = lib.xo_sbr_dec_hq(vp(h), vp(f), vp(st[i]), vp(pf), vp(ps[i]), pin.ctypes.data_as(P16), 1,
+                                   out[s, i].ctypes.data_as(P16), 2)
+            assert rc == 0
+    return out, st, ps
+
+
+def _worker_c4(rank, world, port, n_streams, steps, q):
+    import oracle_lib
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    dist = xdist.init("gloo")
+    assert dist.get_world_size() == world
+    lib = oracle_lib.load_oracle().lib
+    lo, hi = xdist.shard_range(n_streams, rank, world)     # this rank's streams: state stays with the rank
+    out, st, ps = _c4_steps(lib, lo, hi, steps)
+    dist.barrier()
+    gathered = [xdist.gather_pcm(dist, torch.from_numpy(out[s])).numpy() for s in range(steps)]
+    t = xdist.max_over_ranks(dist, 0.5 + rank, torch.device("cpu"))
+    if rank == 0:
+        q.put((np.stack(gathered), t))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_c4_chain_with_carried_state(oracle):
+    """C5 by construction: 2 ranks shard 23 HE-AACv2 streams (12 + 11), each decodes 3 frame-steps of its shard with
+    the SBR / PS state resident on the rank, the PCM of every step is gathered: identical to one process doing all"""
+    n, steps = 23, 3
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_c4, args=(r, 2, port, n, steps, q)) for r in range(2)]
+    [p.start() for p in procs]
+    pcm, t = q.get(timeout=300)
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    want, _, _ = _c4_steps(oracle.lib, 0, n, steps)
+    assert pcm.shape == want.shape and np.array_equal(pcm, want)
+    assert t == 1.5
