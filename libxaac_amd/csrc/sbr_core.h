@@ -213,8 +213,11 @@ struct XsCx {
 #define XS_PAR(k, b0, b1) for (int k = (b0) + cx.lane; k < (b1); k += cx.n)
 #define XS_LANES(k, b0, b1) for (int k = cx.first(b0); k < (b1); k += cx.n) /* k on lane k; b1 <= 64 */
 #define XS_ONE if (cx.lane == 0)
-#if defined(__HIPCC__)
+#if defined(__HIPCC__) && !defined(XS_NO_UNROLL)
 #define XS_UNROLL4 _Pragma("unroll 4")
+#define XS_UNROLL8 _Pragma("unroll 8")
+#elif defined(__HIPCC__)
+#define XS_UNROLL4 _Pragma("nounroll")
 #define XS_UNROLL8 _Pragma("unroll 8")
 #else
 #define XS_UNROLL4

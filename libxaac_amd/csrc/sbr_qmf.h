@@ -24,6 +24,7 @@
 #ifndef XAAC_SBR_QMF_H
 #define XAAC_SBR_QMF_H
 
+#include <stdint.h>
 #include "fx.h"
 
 #ifndef XQ_TABLES_DECLARED
@@ -39,6 +40,17 @@
 #endif
 #endif
 
+#ifndef XQ_ESBR_TABLES_DECLARED
+#define XQ_ESBR_TABLES_DECLARED
+#if defined(__HIPCC__)
+#define XAAC_TAB_QUAL static __device__ const
+#include "tables_qmf_esbr.inc"
+#undef XAAC_TAB_QUAL
+#else
+#include "tables_qmf_esbr.inc"
+#endif
+#endif
+
 #if defined(__HIPCC__)
 #define XQ_UNROLL _Pragma("unroll")
 #else
@@ -47,16 +59,54 @@
 
 FX_HD int32_t xq_mul(int32_t a, int16_t b) { return fx_mul32x16(a, b); }
 
+/* The reference has every transform below twice: with 16-bit twiddles and 32x16 products rounded down one by one (the
+   fixed-point "Path B" banks), and with 32-bit twiddles and full 64-bit products summed before the one shift (the
+   eSBR "Path A" banks: ixheaacd_esbr_radix4bfly generic:880, ixheaacd_esbr_cos_sin_mod :1163, ...).  The data flow is
+   the same, only the two-product primitives differ -- they are the policy W:
+     madd / msub   rotation: a wa +- b wb, saturating            (add32_sat of two >>16 products | add64 / sub64_sat, >>32)
+     badd / bsub   radix-4 butterfly output, then << 1, wrapping  (generic:1736 | generic:880: RADIXSHIFT = 1)         */
+struct XqW16 {
+  typedef int16_t T;
+  static FX_MEMBER int32_t madd(int32_t a, T wa, int32_t b, T wb) { return fx_add_sat(xq_mul(a, wa), xq_mul(b, wb)); }
+  static FX_MEMBER int32_t msub(int32_t a, T wa, int32_t b, T wb) { return fx_sub_sat(xq_mul(a, wa), xq_mul(b, wb)); }
+  static FX_MEMBER int32_t badd(int32_t a, T wa, int32_t b, T wb) { return fx_shlw(fx_add(xq_mul(a, wa), xq_mul(b, wb)), 1); }
+  static FX_MEMBER int32_t bsub(int32_t a, T wa, int32_t b, T wb) { return fx_shlw(fx_sub(xq_mul(a, wa), xq_mul(b, wb)), 1); }
+  static FX_MEMBER const T *w32() { return XQ_T(w_32); }
+  static FX_MEMBER const T *w16() { return XQ_T(w_16); }
+  template <int M> static FX_MEMBER const T *tw() { return M == 32 ? XQ_T(sin_cos_twiddle_l64) : XQ_T(sin_cos_twiddle_l32); }
+  template <int M> static FX_MEMBER const T *alt() { return M == 32 ? XQ_T(alt_sin_twiddle_l64) : XQ_T(alt_sin_twiddle_l32); }
+};
+FX_HD int64_t xq_sub64_sat(int64_t a, int64_t b) { /* basic_ops40.h:221 */
+  const int64_t d = (int64_t)((uint64_t)a - (uint64_t)b);
+  if (((a ^ b) & INT64_MIN) != 0 && ((d ^ a) & INT64_MIN) != 0) return a < 0 ? INT64_MIN : INT64_MAX;
+  return d;
+}
+FX_HD int64_t xq_add64(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); } /* basic_ops40.h:207 */
+struct XqW32 {
+  typedef int32_t T;
+  static FX_MEMBER int32_t madd(int32_t a, T wa, int32_t b, T wb) { return (int32_t)(xq_add64((int64_t)a * wa, (int64_t)b * wb) >> 32); }
+  static FX_MEMBER int32_t msub(int32_t a, T wa, int32_t b, T wb) { return (int32_t)(xq_sub64_sat((int64_t)a * wa, (int64_t)b * wb) >> 32); }
+  static FX_MEMBER int32_t badd(int32_t a, T wa, int32_t b, T wb) { return fx_shlw((int32_t)(xq_add64((int64_t)a * wa, (int64_t)b * wb) >> 32), 1); }
+  static FX_MEMBER int32_t bsub(int32_t a, T wa, int32_t b, T wb) {
+    return fx_shlw((int32_t)((int64_t)((uint64_t)((int64_t)a * wa) - (uint64_t)((int64_t)b * wb)) >> 32), 1);
+  }
+  static FX_MEMBER const T *w32() { return XQ_T(esbr_w_32); }
+  static FX_MEMBER const T *w16() { return XQ_T(esbr_w_16); }
+  template <int M> static FX_MEMBER const T *tw() { return M == 32 ? XQ_T(esbr_sin_cos_twiddle_l64) : XQ_T(esbr_sin_cos_twiddle_l32); }
+  template <int M> static FX_MEMBER const T *alt() { return M == 32 ? XQ_T(esbr_alt_sin_twiddle_l64) : XQ_T(esbr_alt_sin_twiddle_l32); }
+};
+
 /* radix-4 pass over interleaved complex x; twiddles (si1,co1,si2,co2,si3,co3) per column */
-FX_HD void xq_radix4(const int16_t *w, int32_t *x, int index1, int index) {
+template <class W = XqW16>
+FX_HD void xq_radix4(const typename W::T *w, int32_t *x, int index1, int index) {
   const int h2 = 2 * index, l1 = 4 * index, l2 = 6 * index;
   XQ_UNROLL
   for (int b = 0; b < index1; b++) {
     XQ_UNROLL
     for (int i = 0; i < index; i++) {
       int32_t *p = x + 8 * index * b + 2 * i;
-      const int16_t si1 = w[6 * i], co1 = w[6 * i + 1], si2 = w[6 * i + 2], co2 = w[6 * i + 3], si3 = w[6 * i + 4],
-                    co3 = w[6 * i + 5];
+      const typename W::T si1 = w[6 * i], co1 = w[6 * i + 1], si2 = w[6 * i + 2], co2 = w[6 * i + 3], si3 = w[6 * i + 4],
+                          co3 = w[6 * i + 5];
       int32_t xh0 = fx_add_sat(p[0], p[l1]), xl0 = fx_sub_sat(p[0], p[l1]);
       int32_t xh20 = fx_add_sat(p[h2], p[l2]), xl20 = fx_sub_sat(p[h2], p[l2]);
       int32_t xh1 = fx_add_sat(p[1], p[l1 + 1]), xl1 = fx_sub_sat(p[1], p[l1 + 1]);
@@ -66,12 +116,12 @@ FX_HD void xq_radix4(const int16_t *w, int32_t *x, int index1, int index) {
       int32_t yt2 = fx_add_sat(xl1, xl20), yt1 = fx_sub_sat(xl1, xl20);
       p[0] = fx_add_sat(xh0, xh20);
       p[1] = fx_add_sat(xh1, xh21);
-      p[l2] = fx_shlw(fx_add(xq_mul(yt2, si3), xq_mul(xt2, co3)), 1);
-      p[l2 + 1] = fx_shlw(fx_sub(xq_mul(yt2, co3), xq_mul(xt2, si3)), 1);
-      p[l1] = fx_shlw(fx_add(xq_mul(yt0, si2), xq_mul(xt0, co2)), 1);
-      p[l1 + 1] = fx_shlw(fx_sub(xq_mul(yt0, co2), xq_mul(xt0, si2)), 1);
-      p[h2] = fx_shlw(fx_add(xq_mul(yt1, si1), xq_mul(xt1, co1)), 1);
-      p[h2 + 1] = fx_shlw(fx_sub(xq_mul(yt1, co1), xq_mul(xt1, si1)), 1);
+      p[l2] = W::badd(yt2, si3, xt2, co3);
+      p[l2 + 1] = W::bsub(yt2, co3, xt2, si3);
+      p[l1] = W::badd(yt0, si2, xt0, co2);
+      p[l1 + 1] = W::bsub(yt0, co2, xt0, si2);
+      p[h2] = W::badd(yt1, si1, xt1, co1);
+      p[h2 + 1] = W::bsub(yt1, co1, xt1, si1);
     }
   }
 }
@@ -194,46 +244,47 @@ FX_HD void xq_dct3_32(int32_t *in, int32_t *out) {
    (H = 0: the first half, H = 1: the second; they differ in the signs of the two rotations).  s: the half's 2M
    words in place, t: 2M words of scratch.  The GPU synthesis kernel runs the halves one after the other through a
    half-size LDS tile. */
-template <int M, int H>
+template <int M, int H, class W = XqW16>
 FX_HD void xq_cos_sin_mod_half(int32_t *s, int32_t *t) {
-  const int16_t *tw = (M == 32) ? XQ_T(sin_cos_twiddle_l64) : XQ_T(sin_cos_twiddle_l32);
-  const int16_t *alt = (M == 32) ? XQ_T(alt_sin_twiddle_l64) : XQ_T(alt_sin_twiddle_l32);
+  typedef typename W::T WT;
+  const WT *tw = W::template tw<M>();
+  const WT *alt = W::template alt<M>();
   XQ_UNROLL
   for (int q = 0; q < M / 2; q++) {
     {
-      int16_t wim = tw[4 * q], wre = tw[4 * q + 1];
-      int32_t re = s[2 * q], im = s[2 * M - 1 - 2 * q];
+      const WT wim = tw[4 * q], wre = tw[4 * q + 1];
+      const int32_t re = s[2 * q], im = s[2 * M - 1 - 2 * q];
       if (H == 0) {
-        t[2 * q] = fx_add_sat(xq_mul(re, wre), xq_mul(im, wim));
-        t[2 * q + 1] = fx_sub_sat(xq_mul(im, wre), xq_mul(re, wim));
+        t[2 * q] = W::madd(re, wre, im, wim);
+        t[2 * q + 1] = W::msub(im, wre, re, wim);
       } else {
-        t[2 * q] = fx_sub_sat(xq_mul(im, wim), xq_mul(re, wre));
-        t[2 * q + 1] = fx_add_sat(xq_mul(re, wim), xq_mul(im, wre));
+        t[2 * q] = W::msub(im, wim, re, wre);
+        t[2 * q + 1] = W::madd(re, wim, im, wre);
       }
     }
     {
-      int16_t wim = tw[4 * q + 2], wre = tw[4 * q + 3];
-      int32_t re = s[2 * M - 2 - 2 * q], im = s[2 * q + 1];
+      const WT wim = tw[4 * q + 2], wre = tw[4 * q + 3];
+      const int32_t re = s[2 * M - 2 - 2 * q], im = s[2 * q + 1];
       if (H == 0) {
-        t[2 * M - 1 - 2 * q] = fx_sub_sat(xq_mul(im, wre), xq_mul(re, wim));
-        t[2 * M - 2 - 2 * q] = fx_add_sat(xq_mul(re, wre), xq_mul(im, wim));
+        t[2 * M - 1 - 2 * q] = W::msub(im, wre, re, wim);
+        t[2 * M - 2 - 2 * q] = W::madd(re, wre, im, wim);
       } else {
-        t[2 * M - 1 - 2 * q] = fx_add_sat(xq_mul(re, wim), xq_mul(im, wre));
-        t[2 * M - 2 - 2 * q] = fx_sub_sat(xq_mul(im, wim), xq_mul(re, wre));
+        t[2 * M - 1 - 2 * q] = W::madd(re, wim, im, wre);
+        t[2 * M - 2 - 2 * q] = W::msub(im, wim, re, wre);
       }
     }
   }
   if (M == 32) {
-    xq_radix4(XQ_T(w_32), t, 1, 8);
-    xq_radix4(XQ_T(w_32) + 48, t, 4, 2);
+    xq_radix4<W>(W::w32(), t, 1, 8);
+    xq_radix4<W>(W::w32() + 48, t, 4, 2);
     xq_postradix2(s, t);
   } else {
-    xq_radix4(XQ_T(w_16), t, 1, 4);
+    xq_radix4<W>(W::w16(), t, 1, 4);
     xq_postradix4(s, t);
   }
   /* post-rotation, in place and order-sensitive (each value is consumed before it is overwritten) */
   int lo = 0, hi = 2 * M - 1, pa = 0;
-  int16_t wim = alt[pa++], wre = alt[pa++];
+  WT wim = alt[pa++], wre = alt[pa++];
   if (H == 0) {
     int32_t re = s[hi];
     s[0] = s[0] >> 1;
@@ -241,18 +292,18 @@ FX_HD void xq_cos_sin_mod_half(int32_t *s, int32_t *t) {
     s[hi] = fx_neg_sat(s[1] >> 1);
     hi--;
     int32_t im = s[hi];
-    s[hi--] = fx_add_sat(xq_mul(re, wre), xq_mul(im, wim));
-    s[lo++] = fx_sub_sat(xq_mul(im, wre), xq_mul(re, wim));
+    s[hi--] = W::madd(re, wre, im, wim);
+    s[lo++] = W::msub(im, wre, re, wim);
     XQ_UNROLL
     for (int i = 0; i < M / 2 - 1; i++) {
       int32_t im0 = s[lo], re0 = s[lo + 1], re2 = s[hi];
-      s[lo++] = fx_add_sat(xq_mul(re0, wim), xq_mul(im0, wre));
-      s[hi--] = fx_sub_sat(xq_mul(im0, wim), xq_mul(re0, wre));
+      s[lo++] = W::madd(re0, wim, im0, wre);
+      s[hi--] = W::msub(im0, wim, re0, wre);
       wim = alt[pa++];
       wre = alt[pa++];
       im0 = s[hi];
-      s[hi--] = fx_add_sat(xq_mul(re2, wre), xq_mul(im0, wim));
-      s[lo++] = fx_sub_sat(xq_mul(im0, wre), xq_mul(re2, wim));
+      s[hi--] = W::madd(re2, wre, im0, wim);
+      s[lo++] = W::msub(im0, wre, re2, wim);
     }
   } else {
     int32_t re = s[hi];
@@ -260,27 +311,27 @@ FX_HD void xq_cos_sin_mod_half(int32_t *s, int32_t *t) {
     s[lo] = s[lo + 1] >> 1;
     lo++;
     int32_t im = s[hi];
-    s[lo++] = fx_neg_sat(fx_add_sat(xq_mul(re, wre), xq_mul(im, wim)));
-    s[hi--] = fx_sub_sat(xq_mul(re, wim), xq_mul(im, wre));
+    s[lo++] = fx_neg_sat(W::madd(re, wre, im, wim));
+    s[hi--] = W::msub(re, wim, im, wre);
     XQ_UNROLL
     for (int i = 0; i < M / 2 - 1; i++) {
       int32_t im1 = s[lo], re1 = s[lo + 1], re3 = s[hi];
-      s[hi--] = fx_neg_sat(fx_add_sat(xq_mul(re1, wim), xq_mul(im1, wre)));
-      s[lo++] = fx_sub_sat(xq_mul(re1, wre), xq_mul(im1, wim));
+      s[hi--] = fx_neg_sat(W::madd(re1, wim, im1, wre));
+      s[lo++] = W::msub(re1, wre, im1, wim);
       wim = alt[pa++];
       wre = alt[pa++];
       im1 = s[hi];
-      s[lo++] = fx_neg_sat(fx_add_sat(xq_mul(re3, wre), xq_mul(im1, wim)));
-      s[hi--] = fx_sub_sat(xq_mul(re3, wim), xq_mul(im1, wre));
+      s[lo++] = fx_neg_sat(W::madd(re3, wre, im1, wim));
+      s[hi--] = W::msub(re3, wim, im1, wre);
     }
   }
 }
 
 /* both halves: s[0..2M-1] and s[64..64+2M-1] in place; t = 128 words of scratch */
-template <int M>
+template <int M, class W = XqW16>
 FX_HD void xq_cos_sin_mod(int32_t *s, int32_t *t) {
-  xq_cos_sin_mod_half<M, 0>(s, t);
-  xq_cos_sin_mod_half<M, 1>(s + 64, t + 64);
+  xq_cos_sin_mod_half<M, 0, W>(s, t);
+  xq_cos_sin_mod_half<M, 1, W>(s + 64, t + 64);
 }
 
 /* HQ analysis: 64 window-add outputs -> 32 complex subbands, s[0..31] real, s[64..95] imaginary;
@@ -439,6 +490,38 @@ FX_HD void xq_synth_hq_slot_ds(int32_t *s, int32_t *t, int16_t *b, int shift) {
   for (int c = 0; c < 32; c++) {
     b[c] = fx_round16(fx_shl_sat(fx_sub_sat(s[64 + c], s[c]), shift));
     b[32 + c] = fx_round16(fx_shl_sat(fx_add_sat(s[64 + 31 - c], s[31 - c]), shift));
+  }
+}
+
+/* ---- eSBR ("Path A", -esbr:1) banks: the same slot transforms on 32-bit constants ------------------------------ */
+
+/* ixheaacd_esbr_fwd_modulation (generic:1463), 32 analysis channels: 64 window-add outputs -> 32 complex subbands,
+   s[0..31] real, s[64..95] imaginary.  The final rotation runs over usb - lsb = 32 bands (sbr_dec.c:239). */
+FX_HD void xq_esbr_fwd_modulation(const int32_t *in, int32_t *s, int32_t *t) {
+  XQ_UNROLL
+  for (int i = 0; i < 32; i++) {
+    const int32_t a = fx_shr(in[i], 4), b = fx_shr(in[63 - i], 4);
+    s[i] = fx_sub_sat(a, b);
+    s[64 + i] = fx_add_sat(a, b);
+  }
+  xq_cos_sin_mod<16, XqW32>(s, t);
+  const int32_t *tc = XQ_T(esbr_t_cos_sin_l32);
+  XQ_UNROLL
+  for (int i = 0; i < 32; i++) {
+    const int32_t re = s[i], im = s[64 + i], c = tc[2 * i], sn = tc[2 * i + 1];
+    s[i] = (int32_t)(xq_add64((int64_t)re * c, (int64_t)im * sn) >> 31);
+    s[64 + i] = (int32_t)(xq_sub64_sat((int64_t)im * c, (int64_t)re * sn) >> 31);
+  }
+}
+
+/* ixheaacd_esbr_inv_modulation (qmf_dec.c:733) + ixheaacd_shiftrountine_with_rnd_hq (generic:1704), 64 synthesis
+   channels: s[0..63] real, s[64..127] imaginary (clobbered) -> the slot's 128 WORD32 ring samples */
+FX_HD void xq_esbr_synth_slot(int32_t *s, int32_t *t, int32_t *b, int shift) {
+  xq_cos_sin_mod<32, XqW32>(s, t);
+  XQ_UNROLL
+  for (int c = 0; c < 64; c++) {
+    b[c] = fx_shl_sat(fx_sub_sat(s[64 + c], s[c]), shift);
+    b[64 + c] = fx_shl_sat(fx_add_sat(s[64 + 63 - c], s[63 - c]), shift);
   }
 }
 

@@ -192,3 +192,81 @@ void xo_qmf_synthesis(const int32_t *qmf, int slot_stride, const int16_t *sf, in
 }
 
 }  // extern "C"
+
+/* ======================================================================================================================
+ * eSBR ("Path A", -esbr:1) QMF banks, ring-faithful like the banks above: the reference's pointer state machines
+ * restated with explicit offsets; the slot transforms are sbr_qmf.h's (the same templates on 32-bit constants).
+ *   xo_esbr_analysis   ixheaacd_esbr_analysis_filt_block  decoder/ixheaacd_sbr_dec.c:185  (32 analysis channels)
+ *                      + ixheaacd_esbr_qmfanal32_winadd   decoder/ixheaacd_qmf_dec.c:537
+ *   xo_esbr_synthesis  the bank loop of ixheaacd_esbr_synthesis_filt_block  sbr_dec.c:572-656  (64 synthesis channels)
+ *                      + ixheaacd_esbr_qmfsyn64_winadd    generic/ixheaacd_qmf_dec_generic.c:1544
+ * The float <-> WORD32 conversions at the banks' edges are exact (multiplications / divisions by powers of two, one
+ * truncating cast), so the float outputs are bit-identical to the reference's, not merely close.
+ * ====================================================================================================================== */
+extern "C" {
+
+/* core: 1024 floats; ring: WORD32[320]; pos: where the next 32 samples go (state_new_samples_pos_low_32 - ring);
+   win_off: filter_pos_32 - esbr_qmf_c; re / im: [32][64] floats, bands 0..31 written */
+void xo_esbr_analysis(const float *core, int32_t *ring, int32_t *pos, int32_t *win_off, float *re, float *im) {
+  const int32_t *c = xaac_qmf_esbr_qmf_c;
+  int p = *pos, w1 = *win_off, w2 = *win_off + 64;
+  int f1 = 0, f2 = 32; /* the two ring halves the window-add starts from: reset per call, swapped per slot */
+  for (int s = 0; s < 32; s++) {
+    for (int z = 0; z < 32; z++) ring[p + 31 - z] = (int32_t)(core[32 * s + z] * 32768.0f);
+    int32_t anal[64], sb[128], t[128];
+    for (int n = 0; n < 32; n++) {
+      int64_t a1 = 0, a2 = 0;
+      for (int j = 0; j < 5; j++) a1 = xq_add64(a1, (int64_t)ring[f1 + n + 64 * j] * c[w1 + 2 * (n + 64 * j)]);
+      for (int j = 0; j < 5; j++) a2 = xq_add64(a2, (int64_t)ring[f2 + n + 64 * j] * c[w2 + 2 * (n + 64 * j)]);
+      anal[n] = (int32_t)(a1 >> 31);
+      anal[32 + n] = (int32_t)(a2 >> 31);
+    }
+    p -= 32;
+    if (p < 0) p = 10 * 32 - 32;
+    { const int tmp = f1; f1 = f2; f2 = tmp; }
+    w1 += 64;
+    w2 += 64;
+    { const int tmp = w1; w1 = w2; w2 = tmp; }
+    if (w2 > 64 * 10) { w1 = 0; w2 = 64; }
+    xq_esbr_fwd_modulation(anal, sb, t);
+    for (int z = 0; z < 32; z++) {
+      re[64 * s + z] = (float)sb[z] * (1.0f / 256.0f);
+      im[64 * s + z] = (float)sb[64 + z] * (1.0f / 256.0f);
+    }
+  }
+  *pos = p;
+  *win_off = w1;
+}
+
+/* re / im: [32][64] floats; ring: WORD32[1280]; drc_off: ixheaacd_drc_offset; filt_off: filter_pos_syn_32 - esbr_qmf_c;
+   out: 2048 floats */
+void xo_esbr_synthesis(const float *re, const float *im, int32_t *ring, int32_t *drc_off, int32_t *filt_off, float *out) {
+  const int32_t *c = xaac_qmf_esbr_qmf_c;
+  int d = *drc_off, fl = *filt_off;
+  int f1 = 0, f2 = 64, step = 64;
+  for (int s = 0; s < 32; s++) {
+    int32_t x[128], t[128];
+    for (int k = 0; k < 64; k++) {
+      x[k] = (int32_t)(re[64 * s + k] * 64);
+      x[64 + k] = (int32_t)(im[64 * s + k] * 64);
+    }
+    xq_esbr_synth_slot(x, t, ring + d, 5 + 1);
+    for (int k = 0; k < 64; k++) {
+      int64_t acc = 0;
+      for (int j = 0; j < 5; j++) acc = xq_add64(acc, (int64_t)ring[f1 + 256 * j + k] * c[fl + k + 128 * j]);
+      for (int j = 0; j < 5; j++) acc = xq_add64(acc, (int64_t)ring[f2 + 128 + 256 * j + k] * c[fl + k + 64 + 128 * j]);
+      out[64 * s + k] = (float)(int32_t)(acc >> 31) / 65536.0f;
+    }
+    f1 += step;
+    f2 -= step;
+    step = -step;
+    d -= 128;
+    if (d < 0) d += 1280;
+    fl += 64;
+    if (fl == 640) fl = 0;
+  }
+  *drc_off = d;
+  *filt_off = fl;
+}
+
+}  // extern "C"

@@ -364,3 +364,77 @@ int ref_sbr_dec_hq_batch(int n, const xaac_sbr_header *h, const xaac_sbr_frame *
                        pcm_out + (pf ? 4096 : 2048) * (size_t)i, pf ? 2 : 1) != 0;
   return bad;
 }
+
+/* ======================================================================================================================
+ * eSBR ("Path A", -esbr:1) QMF banks: the reference's own ixheaacd_esbr_analysis_filt_block (sbr_dec.c:185, 32 analysis
+ * channels) and the bank loop of ixheaacd_esbr_synthesis_filt_block (sbr_dec.c:447, 64 synthesis channels, no regrouping
+ * / PS / DRC), driven from plain arrays: the WORD32 ring, the ring / window positions as offsets.
+ * ====================================================================================================================== */
+VOID ixheaacd_esbr_analysis_filt_block(ia_sbr_dec_struct *ptr_sbr_dec, ia_sbr_tables_struct *sbr_tables_ptr, WORD32 op_delay);
+VOID ixheaacd_esbr_synthesis_filt_block(ia_sbr_dec_struct *ptr_sbr_dec, ia_sbr_header_data_struct *ptr_header_data,
+                                        ia_sbr_frame_info_data_struct *ptr_frame_data, WORD32 apply_processing,
+                                        FLOAT32 **qmf_buf_real, FLOAT32 **qmf_buf_imag, WORD32 stereo_config_idx,
+                                        ia_sbr_tables_struct *sbr_tables_ptr, WORD32 mps_sbr_flag, WORD32 ch_fac,
+                                        WORD32 ps_enable, WORD32 skip_re_grouping, ia_ps_dec_struct *ptr_ps_dec,
+                                        FLAG drc_on, WORD32 drc_sbr_factors[][64]);
+
+static ia_sbr_tables_struct *esbr_tabs(void) {
+  static ia_sbr_tables_struct t;
+  t.qmf_dec_tables_ptr = (ia_qmf_dec_tables_struct *)&ixheaacd_aac_qmf_dec_tables;
+  return &t;
+}
+
+/* core: 1024 float samples; ring: WORD32[320]; pos / win_off: state_new_samples_pos_low_32 and filter_pos_32 as offsets
+   from their bases; re / im: [32 slots][64] floats (bands 0..31 written) */
+void ref_esbr_analysis(const float *core, int32_t *ring, int32_t *pos, int32_t *win_off, float *re, float *im) {
+  static __thread ia_sbr_dec_struct d;
+  ia_qmf_dec_tables_struct *q = esbr_tabs()->qmf_dec_tables_ptr;
+  ia_sbr_qmf_filter_bank_struct *b = &d.str_codec_qmf_bank;
+  static __thread float in[1024];
+  memset(b, 0, sizeof(*b));
+  memcpy(in, core, sizeof(in));
+  b->no_channels = 32;
+  b->num_time_slots = 32;
+  b->anal_filter_states_32 = ring;
+  b->state_new_samples_pos_low_32 = ring + *pos;
+  b->analy_win_coeff_32 = q->esbr_qmf_c;
+  b->filter_pos_32 = q->esbr_qmf_c + *win_off;
+  b->esbr_cos_twiddle = q->esbr_sin_cos_twiddle_l32;
+  b->esbr_alt_sin_twiddle = q->esbr_alt_sin_twiddle_l32;
+  b->esbr_t_cos = q->esbr_t_cos_sin_l32;
+  b->lsb = 0;
+  d.time_sample_buf = in;
+  ixheaacd_esbr_analysis_filt_block(&d, esbr_tabs(), 0);
+  for (int s = 0; s < 32; s++) {
+    memcpy(re + 64 * s, d.qmf_buf_real[s], 64 * sizeof(float));
+    memcpy(im + 64 * s, d.qmf_buf_imag[s], 64 * sizeof(float));
+  }
+  *pos = (int32_t)(b->state_new_samples_pos_low_32 - ring);
+  *win_off = (int32_t)(b->filter_pos_32 - q->esbr_qmf_c);
+}
+
+/* re / im: [32 slots][64] floats; ring: WORD32[1280]; drc_off / filt_off: ixheaacd_drc_offset and filter_pos_syn_32 - esbr_qmf_c;
+   out: 2048 floats */
+void ref_esbr_synthesis(const float *re, const float *im, int32_t *ring, int32_t *drc_off, int32_t *filt_off, float *out) {
+  static __thread ia_sbr_dec_struct d;
+  static __thread ia_sbr_frame_info_data_struct fr;
+  static __thread float rows_re[32][64], rows_im[32][64], time[2048];
+  float *pr[32], *pi[32];
+  ia_qmf_dec_tables_struct *q = esbr_tabs()->qmf_dec_tables_ptr;
+  ia_sbr_qmf_filter_bank_struct *b = &d.str_synthesis_qmf_bank;
+  memset(b, 0, sizeof(*b));
+  memcpy(rows_re, re, sizeof(rows_re));
+  memcpy(rows_im, im, sizeof(rows_im));
+  for (int s = 0; s < 32; s++) { pr[s] = rows_re[s]; pi[s] = rows_im[s]; }
+  b->no_channels = 64;
+  b->filter_states_32 = ring;
+  b->ixheaacd_drc_offset = (WORD16)*drc_off;
+  b->p_filter_32 = q->esbr_qmf_c;
+  b->filter_pos_syn_32 = q->esbr_qmf_c + *filt_off;
+  d.str_codec_qmf_bank.num_time_slots = 32;
+  d.time_sample_buf = time;
+  ixheaacd_esbr_synthesis_filt_block(&d, NULL, &fr, 1, pr, pi, 0, esbr_tabs(), 0, 1, 0, 1, NULL, 0, NULL);
+  memcpy(out, time, sizeof(time));
+  *drc_off = b->ixheaacd_drc_offset;
+  *filt_off = (int32_t)(b->filter_pos_syn_32 - q->esbr_qmf_c);
+}

@@ -76,3 +76,21 @@ def test_sbr_tables_equal_reference_rom(tmp_path):
 
 def test_ps_tables_equal_reference_rom(tmp_path):
     _regenerated_equals_committed("gen_tables_ps", "tables_ps.inc", tmp_path)
+
+
+def test_esbr_qmf_tables_equal_reference_rom(tmp_path):
+    _regenerated_equals_committed("gen_tables_qmf_esbr", "tables_qmf_esbr.inc", tmp_path)
+
+
+def test_esbr_tables_are_the_q31_versions_of_the_q15_ones():
+    """independent of the ROM: the 32-bit eSBR constants are the 16-bit bank constants at 16 more fractional bits
+    (prototype filter, radix-4 twiddles, modulation twiddles), to rounding"""
+    def parse(path, prefix):
+        txt = open(os.path.join(ROOT, "libxaac_amd", "csrc", path)).read()
+        return {m.group(1): np.array([int(v) for v in m.group(3).replace("\n", " ").split(",") if v.strip()], np.int64)
+                for m in re.finditer(r"%s(\w+)\[(\d+)\] = \{([^}]*)\}" % prefix, txt)}
+    q15, q31 = parse("tables_qmf.inc", "xaac_qmf_"), parse("tables_qmf_esbr.inc", "xaac_qmf_esbr_")
+    for a, b in (("qmf_c", "qmf_c"), ("w_32", "w_32"), ("w_16", "w_16"), ("sin_cos_twiddle_l64", "sin_cos_twiddle_l64"),
+                 ("alt_sin_twiddle_l64", "alt_sin_twiddle_l64"), ("sin_cos_twiddle_l32", "sin_cos_twiddle_l32"),
+                 ("alt_sin_twiddle_l32", "alt_sin_twiddle_l32"), ("t_cos_sin_l32", "t_cos_sin_l32")):
+        assert np.max(np.abs(q31[b] / 65536.0 - q15[a])) <= 1.0, a
