@@ -225,6 +225,41 @@ typedef struct xaac_limiter_batch {
   uint64_t workspace_bytes;
 } xaac_limiter_batch;
 
+/* ---- eSBR ("Path A", the reference's default -esbr:1) QMF banks ---------------------------------------------------
+ * xaac_esbr_qmf_analysis_batch  <-> ixheaacd_esbr_analysis_filt_block
+ *      def decoder/ixheaacd_sbr_dec.c:185 (32 analysis channels: HE-AAC 2:1), call site sbr_dec.c:892
+ * xaac_esbr_qmf_synthesis_batch <-> the synthesis bank loop of ixheaacd_esbr_synthesis_filt_block
+ *      def decoder/ixheaacd_sbr_dec.c:447 (64 synthesis channels, :572-656: after regrouping / PS / DRC factors)
+ * Float at the edges, WORD32 inside (rings, 32-bit prototype filter and twiddles, 64-bit accumulation); every
+ * conversion is exact, so the results are bit-identical to the reference's.  The states are the reference's WORD32
+ * rings (ia_sbr_qmf_filter_bank_struct: anal_filter_states_32 / filter_states_32, decoder/ixheaacd_qmf_dec.h:54-58) with
+ * their pointers as offsets. */
+typedef struct xaac_esbr_ana_state {
+  int32_t ring[320];   /* anal_filter_states_32 */
+  int32_t pos;         /* state_new_samples_pos_low_32 - anal_filter_states_32 */
+  int32_t win_off;     /* filter_pos_32 - esbr_qmf_c */
+} xaac_esbr_ana_state; /* zero-initialised for a new stream (sbrdec_initfuncs.c:1108-1119) */
+
+typedef struct xaac_esbr_syn_state {
+  int32_t ring[1280];  /* filter_states_32 */
+  int32_t drc_offset;  /* ixheaacd_drc_offset */
+  int32_t filt_off;    /* filter_pos_syn_32 - esbr_qmf_c */
+} xaac_esbr_syn_state; /* zero-initialised for a new stream (sbrdec_initfuncs.c:1185-1202) */
+
+typedef struct xaac_esbr_ana_batch {
+  int32_t n_ch;
+  const float *core;           /* [n_ch][1024] core-decoder time samples (time_sample_buf) */
+  xaac_esbr_ana_state *state;  /* [n_ch] in/out */
+  float *qmf_re, *qmf_im;      /* [n_ch][32 slots][64]: bands 0..31 written (qmf_buf_real / _imag rows) */
+} xaac_esbr_ana_batch;
+
+typedef struct xaac_esbr_syn_batch {
+  int32_t n_ch;
+  const float *qmf_re, *qmf_im; /* [n_ch][32 slots][64] */
+  xaac_esbr_syn_state *state;   /* [n_ch] in/out */
+  float *out;                   /* [n_ch][2048] time samples */
+} xaac_esbr_syn_batch;
+
 typedef struct xaac_ctx xaac_ctx;
 
 /* Create a context bound to HIP device `device`.  `hip_stream` is a
@@ -246,6 +281,10 @@ int32_t xaac_imdct_process_batch_host(xaac_ctx *ctx, const xaac_imdct_batch *bat
 /* SBR QMF banks, device pointers, asynchronous on the context's stream. */
 int32_t xaac_qmf_analysis_batch(xaac_ctx *ctx, const xaac_qmf_ana_batch *batch);
 int32_t xaac_qmf_synthesis_batch(xaac_ctx *ctx, const xaac_qmf_syn_batch *batch);
+
+/* eSBR (Path A) QMF banks, device pointers, asynchronous on the context's stream. */
+int32_t xaac_esbr_qmf_analysis_batch(xaac_ctx *ctx, const xaac_esbr_ana_batch *batch);
+int32_t xaac_esbr_qmf_synthesis_batch(xaac_ctx *ctx, const xaac_esbr_syn_batch *batch);
 
 /* Low-power SBR channel-frames (QMF analysis -> HF generation + envelope adjustment -> QMF synthesis). */
 uint64_t xaac_sbr_lp_workspace_bytes(int32_t n_ch);

@@ -65,6 +65,22 @@ class _QmfSynBatch(ctypes.Structure):
                 ("state", ctypes.c_void_p), ("pcm", ctypes.c_void_p)]
 
 
+class _EsbrAnaBatch(ctypes.Structure):
+    # struct xaac_esbr_ana_batch
+    _fields_ = [("n_ch", ctypes.c_int32), ("core", ctypes.c_void_p), ("state", ctypes.c_void_p),
+                ("qmf_re", ctypes.c_void_p), ("qmf_im", ctypes.c_void_p)]
+
+
+class _EsbrSynBatch(ctypes.Structure):
+    # struct xaac_esbr_syn_batch
+    _fields_ = [("n_ch", ctypes.c_int32), ("qmf_re", ctypes.c_void_p), ("qmf_im", ctypes.c_void_p),
+                ("state", ctypes.c_void_p), ("out", ctypes.c_void_p)]
+
+
+ESBR_ANA_STATE_WORDS = 322   # struct xaac_esbr_ana_state: ring[320], pos, win_off (int32)
+ESBR_SYN_STATE_WORDS = 1282  # struct xaac_esbr_syn_state: ring[1280], drc_offset, filt_off (int32)
+
+
 class _SbrLpBatch(ctypes.Structure):
     # struct xaac_sbr_lp_batch
     _fields_ = [("n_ch", ctypes.c_int32), ("in_ch_fac", ctypes.c_int32), ("out_ch_fac", ctypes.c_int32),
@@ -141,6 +157,10 @@ def load_library():
     lib.xaac_last_launch.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int32)] * 3
     lib.xaac_qmf_analysis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_QmfAnaBatch)]
     lib.xaac_qmf_synthesis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_QmfSynBatch)]
+    lib.xaac_esbr_qmf_analysis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_EsbrAnaBatch)]
+    lib.xaac_esbr_qmf_analysis_batch.restype = ctypes.c_int32
+    lib.xaac_esbr_qmf_synthesis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_EsbrSynBatch)]
+    lib.xaac_esbr_qmf_synthesis_batch.restype = ctypes.c_int32
     lib.xaac_sbr_lp_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_SbrLpBatch)]
     lib.xaac_sbr_lp_process_batch.restype = ctypes.c_int32
     lib.xaac_sbr_lp_workspace_bytes.argtypes = [ctypes.c_int32]
@@ -314,6 +334,35 @@ class XaacContext:
         rc = self._lib.xaac_qmf_synthesis_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_qmf_synthesis_batch")
+
+    def esbr_qmf_analysis_batch(self, core, state, qmf_re, qmf_im):
+        """Batched ixheaacd_esbr_analysis_filt_block (eSBR / Path A, 32 channels): core float32[n_ch, 1024];
+        state int32[n_ch, 322] in/out (ring, pos, win_off); qmf_re / qmf_im float32[n_ch, 32, 64], bands 0..31 written."""
+        n_ch = state.shape[0]
+        b = _EsbrAnaBatch()
+        b.n_ch = n_ch
+        b.core = _ptr(core, "float32", n_ch * 1024, device_ok=True)
+        b.state = _ptr(state, "int32", n_ch * ESBR_ANA_STATE_WORDS, device_ok=True)
+        b.qmf_re = _ptr(qmf_re, "float32", n_ch * 2048, device_ok=True)
+        b.qmf_im = _ptr(qmf_im, "float32", n_ch * 2048, device_ok=True)
+        rc = self._lib.xaac_esbr_qmf_analysis_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_esbr_qmf_analysis_batch")
+
+    def esbr_qmf_synthesis_batch(self, qmf_re, qmf_im, state, out):
+        """Batched synthesis bank of ixheaacd_esbr_synthesis_filt_block (eSBR / Path A, 64 channels):
+        qmf_re / qmf_im float32[n_ch, 32, 64]; state int32[n_ch, 1282] in/out (ring, drc_offset, filt_off);
+        out float32[n_ch, 2048]."""
+        n_ch = state.shape[0]
+        b = _EsbrSynBatch()
+        b.n_ch = n_ch
+        b.qmf_re = _ptr(qmf_re, "float32", n_ch * 2048, device_ok=True)
+        b.qmf_im = _ptr(qmf_im, "float32", n_ch * 2048, device_ok=True)
+        b.state = _ptr(state, "int32", n_ch * ESBR_SYN_STATE_WORDS, device_ok=True)
+        b.out = _ptr(out, "float32", n_ch * 2048, device_ok=True)
+        rc = self._lib.xaac_esbr_qmf_synthesis_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_esbr_qmf_synthesis_batch")
 
     def sbr_hq_workspace_bytes(self, n_ch, with_ps=True):
         return int(self._lib.xaac_sbr_hq_workspace_bytes(int(n_ch), int(bool(with_ps))))

@@ -1,0 +1,35 @@
+/* esbr_qmf_kernel.h -- launch interface of the eSBR ("Path A") QMF bank kernels (internal). */
+#ifndef XAAC_ESBR_QMF_KERNEL_H
+#define XAAC_ESBR_QMF_KERNEL_H
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "../../include/xaac_amd.h"
+
+#define XAAC_ESBR_ANA_LDS (2 * 1312 * 4 + 64 * 65 * 4)         /* two channels' time-ordered history + the 64 x 65 exchange tile */
+#define XAAC_ESBR_SYN_LDS (2 * 41 * 129 * 4)                   /* ring samples of 2 channels x (9 + 32) slots; the row tile fits */
+
+typedef struct XaacEsbrAnaParams {
+  int32_t n_ch;
+  const float *core;            /* [n_ch][1024] */
+  xaac_esbr_ana_state *state;   /* [n_ch] */
+  float *qmf_re, *qmf_im;       /* [n_ch][32][64]; bands 0..31 written */
+} XaacEsbrAnaParams;
+
+typedef struct XaacEsbrSynParams {
+  int32_t n_ch;
+  const float *qmf_re, *qmf_im; /* [n_ch][32][64] */
+  xaac_esbr_syn_state *state;   /* [n_ch] */
+  float *out;                   /* [n_ch][2048] */
+} XaacEsbrSynParams;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+hipError_t xaac_launch_esbr_analysis(const XaacEsbrAnaParams *p, hipStream_t stream);
+hipError_t xaac_launch_esbr_synthesis(const XaacEsbrSynParams *p, hipStream_t stream);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,217 @@
+/*
+ * esbr_qmf_kernel.hip -- gfx950 kernels for the QMF banks of the reference's default SBR path ("Path A", -esbr:1):
+ *   xaac_esbr_analysis_kernel   <->  ixheaacd_esbr_analysis_filt_block   decoder/ixheaacd_sbr_dec.c:185 (32 channels)
+ *   xaac_esbr_synthesis_kernel  <->  the bank loop of ixheaacd_esbr_synthesis_filt_block   sbr_dec.c:572-656 (64 channels)
+ * These banks are float at their edges and integer inside: core samples x 2^15 -> WORD32, a 32-bit prototype filter with
+ * 64-bit accumulation, the transforms of sbr_qmf.h on 32-bit twiddles with 64-bit products, results x 2^-8 / x 2^-16 back
+ * to float.  Every conversion is exact, so the outputs are bit-identical to the reference's, like the fixed-point banks'.
+ *
+ * Mapping: the same as sbr_qmf_kernel.hip -- the banks are time-invariant polyphase FIRs around a per-slot transform, so
+ * every slot is independent given the frame's samples and the history the ring holds (the closed forms there carry over:
+ * the ring / window-phase state machines are the same, only the word size differs).  One wave = two channel-frames:
+ * window-add with lanes = polyphase outputs, transform with lane = slot, rows through a padded LDS tile, the WORD32 ring
+ * kept word-identical with the reference's as the persistent state.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sbr_qmf.h"
+#include "esbr_qmf_kernel.h"
+
+namespace {
+
+constexpr int kHist = 288 + 1024;
+
+__device__ __forceinline__ int ring_pos(int wr, int a) { /* where the ring keeps the sample of age a (0 = newest) */
+  int p = wr + 32 + a;
+  return p >= 320 ? p - 320 : p;
+}
+
+/* 32 steps of the window-pointer bookkeeping of sbr_dec.c:262-277 (it does not influence the samples) */
+__device__ __forceinline__ int win_after_frame(int w) {
+  int f1 = w, f2 = w + 64;
+  for (int s = 0; s < 32; s++) {
+    f1 += 64;
+    f2 += 64;
+    const int t = f1;
+    f1 = f2;
+    f2 = t;
+    if (f2 > 640) {
+      f1 = 0;
+      f2 = 64;
+    }
+  }
+  return f1;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void xaac_esbr_analysis_kernel(XaacEsbrAnaParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  int32_t *hist = reinterpret_cast<int32_t *>(smem);                 /* [2][kHist] time-ordered, oldest first */
+  int32_t *z = reinterpret_cast<int32_t *>(smem + 2 * kHist * 4);    /* [64][65] */
+  const int pair = blockIdx.x;
+  int32_t coef[5]; /* c[2 m + 128 j] of this lane's polyphase branch m = lane */
+#pragma unroll
+  for (int j = 0; j < 5; j++) coef[j] = xaac_qmf_esbr_qmf_c[2 * lane + 128 * j];
+  for (int c = 0; c < 2; c++) {
+    const int ch = 2 * pair + c;
+    int32_t *h = hist + c * kHist;
+    if (ch < p.n_ch) {
+      const xaac_esbr_ana_state *st = p.state + ch;
+      int wr = st->pos;
+      wr = ((wr % 320 + 320) % 320) & ~31; /* a block start (the position moves by 32 from 0) */
+      const float *src = p.core + (size_t)ch * 1024;
+      for (int a = lane; a < 288; a += 64) h[287 - a] = st->ring[ring_pos(wr, a)];
+      for (int i = lane; i < 1024; i += 64) h[288 + i] = (int32_t)(src[i] * 32768.0f); /* sbr_dec.c:248 */
+    } else {
+      for (int i = lane; i < kHist; i += 64) h[i] = 0;
+    }
+  }
+  __syncthreads();
+  /* window-add (ixheaacd_esbr_qmfanal32_winadd, qmf_dec.c:537): 64-bit sums, >> 31 */
+  for (int r = 0; r < 64; r++) {
+    const int32_t *h = hist + (r >> 5) * kHist + 288 + 32 * (r & 31) + 31 - lane;
+    int64_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) acc = xq_add64(acc, (int64_t)h[-64 * j] * coef[j]);
+    z[65 * r + lane] = (int32_t)(acc >> 31);
+  }
+  __syncthreads();
+  { /* per-slot transform, lane = slot */
+    int32_t in[64], sb[128], t[128];
+#pragma unroll
+    for (int k = 0; k < 64; k++) in[k] = z[65 * lane + k];
+    xq_esbr_fwd_modulation(in, sb, t);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+      z[65 * lane + k] = sb[k];
+      z[65 * lane + 32 + k] = sb[64 + k];
+    }
+  }
+  __syncthreads();
+  for (int r = 0; r < 64; r++) { /* rows out: 32 real and 32 imaginary bands per slot, x 1/256 (sbr_dec.c:285-290) */
+    const int ch = 2 * pair + (r >> 5);
+    if (ch >= p.n_ch) break;
+    const float v = (float)z[65 * r + lane] * (1.0f / 256.0f);
+    float *row = (lane < 32 ? p.qmf_re : p.qmf_im) + ((size_t)ch * 32 + (r & 31)) * 64;
+    row[lane & 31] = v;
+  }
+  for (int c = 0; c < 2; c++) { /* state: the ring as the reference leaves it after 32 slots */
+    const int ch = 2 * pair + c;
+    if (ch >= p.n_ch) break;
+    xaac_esbr_ana_state *st = p.state + ch;
+    int wr = st->pos;
+    wr = ((wr % 320 + 320) % 320) & ~31;
+    const int wr_new = (wr + 256) % 320;
+    const int w_new = win_after_frame(st->win_off);
+    const int32_t *h = hist + c * kHist;
+    __syncthreads();
+    for (int a = lane; a < 320; a += 64) st->ring[ring_pos(wr_new, a)] = h[kHist - 1 - a];
+    if (lane == 0) {
+      st->pos = wr_new;
+      st->win_off = w_new;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void xaac_esbr_synthesis_kernel(XaacEsbrSynParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RS = 129, VSLOTS = 41, VROW = 129, RING = 1280;
+  const int lane = threadIdx.x;
+  int32_t *rows = reinterpret_cast<int32_t *>(smem); /* [64][RS] slot rows (re 0..63 | im 64..127), aliased later by ... */
+  int32_t *v = reinterpret_cast<int32_t *>(smem);    /* ... [2][VSLOTS][VROW] ring samples */
+  const int pair = blockIdx.x;
+  int32_t coef[10]; /* c[64 A + k], k = lane */
+#pragma unroll
+  for (int a = 0; a < 10; a++) coef[a] = xaac_qmf_esbr_qmf_c[64 * a + lane];
+  for (int r0 = 0; r0 < 64; r0 += 8) { /* rows in: (WORD32)(x * 64), sbr_dec.c:592-595 */
+    float tr[8], ti[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int r = r0 + j, ch = 2 * pair + (r >> 5);
+      const size_t off = ((size_t)(ch < p.n_ch ? ch : 0) * 32 + (r & 31)) * 64 + lane;
+      tr[j] = p.qmf_re[off];
+      ti[j] = p.qmf_im[off];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int r = r0 + j, ch = 2 * pair + (r >> 5);
+      rows[RS * r + lane] = ch < p.n_ch ? (int32_t)(tr[j] * 64.0f) : 0;
+      rows[RS * r + 64 + lane] = ch < p.n_ch ? (int32_t)(ti[j] * 64.0f) : 0;
+    }
+  }
+  __syncthreads();
+  int32_t b[128];
+  {
+    int32_t x[128], t[128];
+#pragma unroll
+    for (int k = 0; k < 128; k++) x[k] = rows[RS * lane + k];
+    xq_esbr_synth_slot(x, t, b, 5 + 1); /* out_scalefactor + 1, sbr_dec.c:556 / :604 */
+  }
+  __syncthreads();
+  {
+    int32_t *dst = v + ((lane >> 5) * VSLOTS + 9 + (lane & 31)) * VROW;
+#pragma unroll
+    for (int k = 0; k < 128; k++) dst[k] = b[k];
+  }
+  int d_old[2];
+  for (int c = 0; c < 2; c++) { /* 9 slots of history from the ring */
+    const int ch = 2 * pair + c;
+    d_old[c] = 0;
+    if (ch >= p.n_ch) continue;
+    const xaac_esbr_syn_state *st = p.state + ch;
+    int d = st->drc_offset;
+    d = ((d % RING + RING) % RING) & ~127;
+    d_old[c] = d;
+    for (int i = lane; i < 9 * 128; i += 64) {
+      const int A = 9 - i / 128;
+      int pos = d + 128 * A + i % 128;
+      if (pos >= RING) pos -= RING;
+      v[(c * VSLOTS + i / 128) * VROW + i % 128] = st->ring[pos];
+    }
+  }
+  __syncthreads();
+  for (int c = 0; c < 2; c++) { /* window-add (ixheaacd_esbr_qmfsyn64_winadd, generic:1544), x 2^-16 to float */
+    const int ch = 2 * pair + c;
+    if (ch >= p.n_ch) break;
+    float *dst = p.out + (size_t)ch * 2048;
+    for (int s = 0; s < 32; s++) {
+      const int32_t *vs = v + (c * VSLOTS + 9 + s) * VROW + lane;
+      int64_t acc = 0;
+#pragma unroll
+      for (int A = 0; A < 10; A++) acc = xq_add64(acc, (int64_t)vs[-VROW * A + 64 * (A & 1)] * coef[A]);
+      dst[64 * s + lane] = (float)(int32_t)(acc >> 31) / 65536.0f;
+    }
+  }
+  for (int c = 0; c < 2; c++) { /* state: ring blocks of the last 10 slots, drc offset, window position */
+    const int ch = 2 * pair + c;
+    if (ch >= p.n_ch) break;
+    xaac_esbr_syn_state *st = p.state + ch;
+    const int d_new = (d_old[c] + RING - (32 * 128) % RING) % RING;
+    const int f_new = (st->filt_off + 32 * 64) % 640;
+    for (int i = lane; i < RING; i += 64) {
+      const int A = 1 + i / 128;
+      int pos = d_new + 128 * A + i % 128;
+      if (pos >= RING) pos -= RING;
+      if (pos >= RING) pos -= RING;
+      st->ring[pos] = v[(c * VSLOTS + 9 + 32 - A) * VROW + i % 128];
+    }
+    if (lane == 0) {
+      st->drc_offset = d_new;
+      st->filt_off = f_new;
+    }
+  }
+}
+
+extern "C" hipError_t xaac_launch_esbr_analysis(const XaacEsbrAnaParams *p, hipStream_t stream) {
+  hipLaunchKernelGGL(xaac_esbr_analysis_kernel, dim3((p->n_ch + 1) / 2), dim3(64), XAAC_ESBR_ANA_LDS, stream, *p);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t xaac_launch_esbr_synthesis(const XaacEsbrSynParams *p, hipStream_t stream) {
+  hipLaunchKernelGGL(xaac_esbr_synthesis_kernel, dim3((p->n_ch + 1) / 2), dim3(64), XAAC_ESBR_SYN_LDS, stream, *p);
+  return hipGetLastError();
+}

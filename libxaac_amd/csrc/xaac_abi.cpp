@@ -17,6 +17,7 @@
 #include "sbr_core_kernel.h"
 #include "sbr_ps_kernel.h"
 #include "limiter_kernel.h"
+#include "esbr_qmf_kernel.h"
 #include <cmath>
 #include <cstddef>
 #include <cstring>
@@ -245,6 +246,30 @@ int32_t xaac_qmf_synthesis_batch(xaac_ctx *c, const xaac_qmf_syn_batch *b) {
   if (!hip_ok(xaac_launch_qmf_synthesis(&p, grid, c->stream))) return XAAC_FATAL_HIP;
   c->last_grid = grid; c->last_block = XAAC_QMF_BLOCK;
   c->last_lds = XAAC_QMF_WAVES * (p.low_pow ? XAAC_QMF_SYN_LDS_PER_WAVE_LP : XAAC_QMF_SYN_LDS_PER_WAVE_HQ);
+  return XAAC_OK;
+}
+
+int32_t xaac_esbr_qmf_analysis_batch(xaac_ctx *c, const xaac_esbr_ana_batch *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n_ch < 0) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch == 0) return XAAC_OK;
+  if (!b->core || !b->state || !b->qmf_re || !b->qmf_im) return XAAC_FATAL_NULL_ARG;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  XaacEsbrAnaParams p = {b->n_ch, b->core, b->state, b->qmf_re, b->qmf_im};
+  if (!hip_ok(xaac_launch_esbr_analysis(&p, c->stream))) return XAAC_FATAL_HIP;
+  c->last_grid = (b->n_ch + 1) / 2; c->last_block = 64; c->last_lds = XAAC_ESBR_ANA_LDS;
+  return XAAC_OK;
+}
+
+int32_t xaac_esbr_qmf_synthesis_batch(xaac_ctx *c, const xaac_esbr_syn_batch *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n_ch < 0) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch == 0) return XAAC_OK;
+  if (!b->qmf_re || !b->qmf_im || !b->state || !b->out) return XAAC_FATAL_NULL_ARG;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  XaacEsbrSynParams p = {b->n_ch, b->qmf_re, b->qmf_im, b->state, b->out};
+  if (!hip_ok(xaac_launch_esbr_synthesis(&p, c->stream))) return XAAC_FATAL_HIP;
+  c->last_grid = (b->n_ch + 1) / 2; c->last_block = 64; c->last_lds = XAAC_ESBR_SYN_LDS;
   return XAAC_OK;
 }
 
