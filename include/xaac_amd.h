@@ -260,6 +260,29 @@ typedef struct xaac_esbr_syn_batch {
   float *out;                   /* [n_ch][2048] time samples */
 } xaac_esbr_syn_batch;
 
+/* ---- USAC frequency-domain IMDCT ------------------------------------------------------------------------------------
+ * xaac_usac_imdct_batch <-> ixheaacd_fd_frm_dec   def decoder/ixheaacd_imdct.c:596 (-> ixheaacd_fd_imdct_long :477,
+ *      ixheaacd_fd_imdct_short :336, ixheaacd_acelp_imdct :186, ixheaacd_complex_fft_p2_dec ixheaacd_fft.c:1412),
+ *      call site decoder/ixheaacd_ext_ch_ele.c:991, with the caller's float conversion and shape hand-over (:1008-1016).
+ * Scope: ccfl = 1024, FD frame after an FD frame (td_frame_prev = 0), no FAC data, no error concealment.  One frame of
+ * one channel per entry; the overlap is the reference's overlap_data_ptr row (Q14, un-windowed), so a channel can move
+ * between a reference decoder and this library at any frame boundary. */
+typedef struct xaac_usac_ics {
+  uint8_t window_sequence; /* 0 ONLY_LONG, 1 LONG_START, 2 EIGHT_SHORT, 3 LONG_STOP, 4 STOP_START (ixheaacd_cnst.h:100) */
+  uint8_t window_shape;    /* 0 sine, 1 KBD */
+} xaac_usac_ics;
+
+typedef struct xaac_usac_imdct_batch {
+  int32_t n_ch;
+  const int32_t *coef;       /* [n_ch][1024] coef_fix (not modified) */
+  const xaac_usac_ics *ics;  /* [n_ch] */
+  int32_t *overlap;          /* [n_ch][1024] in/out: overlap_data_ptr */
+  uint8_t *shape_prev;       /* [n_ch] in/out: window_shape_prev */
+  int32_t *out32;            /* optional [n_ch][1024]: output_data_ptr (Q15) */
+  float *time;               /* optional [n_ch][1024]: time_sample_vector (= out32 * 2^-15) */
+  int32_t *status;           /* optional [n_ch]: XAAC_OK or XAAC_FATAL_BAD_WINDOW_SEQ (channel-frame left untouched) */
+} xaac_usac_imdct_batch;
+
 typedef struct xaac_ctx xaac_ctx;
 
 /* Create a context bound to HIP device `device`.  `hip_stream` is a
@@ -281,6 +304,9 @@ int32_t xaac_imdct_process_batch_host(xaac_ctx *ctx, const xaac_imdct_batch *bat
 /* SBR QMF banks, device pointers, asynchronous on the context's stream. */
 int32_t xaac_qmf_analysis_batch(xaac_ctx *ctx, const xaac_qmf_ana_batch *batch);
 int32_t xaac_qmf_synthesis_batch(xaac_ctx *ctx, const xaac_qmf_syn_batch *batch);
+
+/* USAC FD IMDCT + windowing + overlap-add, device pointers, asynchronous on the context's stream. */
+int32_t xaac_usac_imdct_process_batch(xaac_ctx *ctx, const xaac_usac_imdct_batch *batch);
 
 /* eSBR (Path A) QMF banks, device pointers, asynchronous on the context's stream. */
 int32_t xaac_esbr_qmf_analysis_batch(xaac_ctx *ctx, const xaac_esbr_ana_batch *batch);

@@ -65,6 +65,13 @@ class _QmfSynBatch(ctypes.Structure):
                 ("state", ctypes.c_void_p), ("pcm", ctypes.c_void_p)]
 
 
+class _UsacImdctBatch(ctypes.Structure):
+    # struct xaac_usac_imdct_batch
+    _fields_ = [("n_ch", ctypes.c_int32), ("coef", ctypes.c_void_p), ("ics", ctypes.c_void_p),
+                ("overlap", ctypes.c_void_p), ("shape_prev", ctypes.c_void_p), ("out32", ctypes.c_void_p),
+                ("time", ctypes.c_void_p), ("status", ctypes.c_void_p)]
+
+
 class _EsbrAnaBatch(ctypes.Structure):
     # struct xaac_esbr_ana_batch
     _fields_ = [("n_ch", ctypes.c_int32), ("core", ctypes.c_void_p), ("state", ctypes.c_void_p),
@@ -157,6 +164,8 @@ def load_library():
     lib.xaac_last_launch.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int32)] * 3
     lib.xaac_qmf_analysis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_QmfAnaBatch)]
     lib.xaac_qmf_synthesis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_QmfSynBatch)]
+    lib.xaac_usac_imdct_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_UsacImdctBatch)]
+    lib.xaac_usac_imdct_process_batch.restype = ctypes.c_int32
     lib.xaac_esbr_qmf_analysis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_EsbrAnaBatch)]
     lib.xaac_esbr_qmf_analysis_batch.restype = ctypes.c_int32
     lib.xaac_esbr_qmf_synthesis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_EsbrSynBatch)]
@@ -334,6 +343,24 @@ class XaacContext:
         rc = self._lib.xaac_qmf_synthesis_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_qmf_synthesis_batch")
+
+    def usac_imdct_process_batch(self, coef, ics, overlap, shape_prev, out32=None, time=None, status=None):
+        """Batched ixheaacd_fd_frm_dec (USAC FD frame after an FD frame, ccfl 1024, no FAC): coef int32[n_ch, 1024];
+        ics uint8[n_ch, 2] (window_sequence 0..4, window_shape); overlap int32[n_ch, 1024] in/out; shape_prev uint8[n_ch]
+        in/out; out32 int32[n_ch, 1024] (Q15) and / or time float32[n_ch, 1024]; status int32[n_ch]."""
+        n_ch = overlap.shape[0]
+        b = _UsacImdctBatch()
+        b.n_ch = n_ch
+        b.coef = _ptr(coef, "int32", n_ch * 1024, device_ok=True)
+        b.ics = _ptr(ics, "uint8", n_ch * 2, device_ok=True)
+        b.overlap = _ptr(overlap, "int32", n_ch * 1024, device_ok=True)
+        b.shape_prev = _ptr(shape_prev, "uint8", n_ch, device_ok=True)
+        b.out32 = _ptr(out32, "int32", n_ch * 1024, allow_none=True, device_ok=True)
+        b.time = _ptr(time, "float32", n_ch * 1024, allow_none=True, device_ok=True)
+        b.status = _ptr(status, "int32", n_ch, allow_none=True, device_ok=True)
+        rc = self._lib.xaac_usac_imdct_process_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_usac_imdct_process_batch")
 
     def esbr_qmf_analysis_batch(self, core, state, qmf_re, qmf_im):
         """Batched ixheaacd_esbr_analysis_filt_block (eSBR / Path A, 32 channels): core float32[n_ch, 1024];

@@ -1,0 +1,31 @@
+/* usac_imdct_kernel.h -- launch interface of the USAC FD IMDCT kernel (internal). */
+#ifndef XAAC_USAC_IMDCT_KERNEL_H
+#define XAAC_USAC_IMDCT_KERNEL_H
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "../../include/xaac_amd.h"
+
+#define XAAC_USAC_WAVES_PER_WG 4
+#define XAAC_USAC_LDS (XAAC_USAC_WAVES_PER_WG * 2 * 1024 * 4)
+
+typedef struct XaacUsacImdctParams {
+  int32_t n_ch;
+  const int32_t *coef;
+  const xaac_usac_ics *ics;
+  int32_t *overlap;
+  uint8_t *shape_prev;
+  int32_t *out32;
+  float *time;
+  int32_t *status;
+} XaacUsacImdctParams;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+hipError_t xaac_launch_usac_imdct(const XaacUsacImdctParams *p, hipStream_t stream);
+#ifdef __cplusplus
+}
+#endif
+#endif

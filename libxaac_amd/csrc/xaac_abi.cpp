@@ -18,6 +18,7 @@
 #include "sbr_ps_kernel.h"
 #include "limiter_kernel.h"
 #include "esbr_qmf_kernel.h"
+#include "usac_imdct_kernel.h"
 #include <cmath>
 #include <cstddef>
 #include <cstring>
@@ -246,6 +247,20 @@ int32_t xaac_qmf_synthesis_batch(xaac_ctx *c, const xaac_qmf_syn_batch *b) {
   if (!hip_ok(xaac_launch_qmf_synthesis(&p, grid, c->stream))) return XAAC_FATAL_HIP;
   c->last_grid = grid; c->last_block = XAAC_QMF_BLOCK;
   c->last_lds = XAAC_QMF_WAVES * (p.low_pow ? XAAC_QMF_SYN_LDS_PER_WAVE_LP : XAAC_QMF_SYN_LDS_PER_WAVE_HQ);
+  return XAAC_OK;
+}
+
+int32_t xaac_usac_imdct_process_batch(xaac_ctx *c, const xaac_usac_imdct_batch *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n_ch < 0) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch == 0) return XAAC_OK;
+  if (!b->coef || !b->ics || !b->overlap || !b->shape_prev) return XAAC_FATAL_NULL_ARG;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  XaacUsacImdctParams p = {b->n_ch, b->coef, b->ics, b->overlap, b->shape_prev, b->out32, b->time, b->status};
+  if (!hip_ok(xaac_launch_usac_imdct(&p, c->stream))) return XAAC_FATAL_HIP;
+  c->last_grid = (b->n_ch + XAAC_USAC_WAVES_PER_WG - 1) / XAAC_USAC_WAVES_PER_WG;
+  c->last_block = 64 * XAAC_USAC_WAVES_PER_WG;
+  c->last_lds = XAAC_USAC_LDS;
   return XAAC_OK;
 }
 

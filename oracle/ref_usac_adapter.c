@@ -1,0 +1,61 @@
+/*
+ * oracle/ref_usac_adapter.c -- TEST INFRASTRUCTURE ONLY.
+ * Drives the real ixheaacd_fd_frm_dec (decoder/ixheaacd_imdct.c:596) for one channel-frame: fills the reference's own
+ * ia_usac_data_struct (the members the function reads: ixheaacd_main.h:69-191) and calls the reference's symbol.
+ * Contains no reference code.  The header list is what the struct's definition needs.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "ixheaac_type_def.h"
+#include "ixheaacd_interface.h"
+#include "ixheaacd_defines.h"
+#include "ixheaacd_aac_rom.h"
+#include "ixheaacd_bitbuffer.h"
+#include "ixheaacd_tns_usac.h"
+#include "ixheaacd_cnst.h"
+#include "ixheaacd_acelp_info.h"
+#include "ixheaacd_td_mdct.h"
+#include "ixheaacd_sbrdecsettings.h"
+#include "ixheaacd_info.h"
+#include "ixheaacd_sbr_common.h"
+#include "ixheaacd_drc_data_struct.h"
+#include "ixheaacd_drc_dec.h"
+#include "ixheaacd_sbrdecoder.h"
+#include "ixheaacd_mps_polyphase.h"
+#include "ixheaac_sbr_const.h"
+#include "ixheaacd_pulsedata.h"
+#include "ixheaacd_pns.h"
+#include "ixheaacd_lt_predict.h"
+#include "ixheaacd_ec_defines.h"
+#include "ixheaacd_ec_struct_def.h"
+#include "ixheaacd_main.h"
+
+WORD32 ixheaacd_fd_frm_dec(ia_usac_data_struct *usac_data, WORD32 i_ch);
+
+/* coef: 1024 lines in / out (the reference transforms coef_fix in place); overlap: 1024 words in / out; out: 1024 Q15
+   words; time: 1024 floats as the caller makes them (ixheaacd_ext_ch_ele.c:1008-1012) */
+int ref_usac_fd_imdct(WORD32 *coef, WORD32 *overlap, int seq, int shape, int shape_prev, WORD32 *out, FLOAT32 *time) {
+  static __thread ia_usac_data_struct *u;
+  int k, err;
+  if (!u) u = (ia_usac_data_struct *)calloc(1, sizeof(*u));
+  u->ccfl = 1024;
+  u->ec_flag = 0;
+  u->frame_ok = 1;
+  u->td_frame_prev[0] = 0;
+  u->fac_data_present[0] = 0;
+  u->window_sequence[0] = seq;
+  u->window_shape[0] = shape;
+  u->window_shape_prev[0] = shape_prev;
+  u->coef_fix[0] = u->arr_coef_fix[0];
+  u->str_tddec[0] = &u->arr_str_tddec[0];
+  memcpy(u->coef_fix[0], coef, sizeof(WORD32) * 1024);
+  memcpy(u->overlap_data_ptr[0], overlap, sizeof(WORD32) * 1024);
+  memset(u->output_data_ptr[0], 0, sizeof(WORD32) * 1024);
+  err = ixheaacd_fd_frm_dec(u, 0);
+  memcpy(coef, u->coef_fix[0], sizeof(WORD32) * 1024);
+  memcpy(overlap, u->overlap_data_ptr[0], sizeof(WORD32) * 1024);
+  memcpy(out, u->output_data_ptr[0], sizeof(WORD32) * 1024);
+  for (k = 0; k < 1024; k++) time[k] = (FLOAT32)((FLOAT32)out[k] * (FLOAT32)0.000030517578125) /* ONE_BY_TWO_POW_15, ext_ch_ele.c:146 */;
+  return err;
+}

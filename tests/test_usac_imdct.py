@@ -1,0 +1,125 @@
+"""USAC FD IMDCT against reference-made chains (tests/golden/usac_imdct_ref.npz, tools/make_golden_usac_imdct.py: the
+compiled reference's ixheaacd_fd_frm_dec with the overlap carried along window-sequence walks, all five sequences, both
+shapes, levels from silence to full scale).  CPU: the oracle reproduces every CRC.  GPU: xaac_usac_imdct_process_batch
+through the C ABI, all chains as one batch per frame step; a large random batch against the oracle; malformed side info
+is refused per channel-frame with the neighbours bit-exact."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from make_golden_usac_imdct import CHAINS, FRAMES, chain_coef, crc  # noqa: E402
+import test_usac_oracle_vs_reference as t  # noqa: E402
+
+GOLD = np.load(os.path.join(ROOT, "tests", "golden", "usac_imdct_ref.npz"))
+
+
+def _start_shape_prev(c):
+    return c & 1
+
+
+def test_oracle_matches_reference_chains(oracle):
+    for c in range(CHAINS):
+        ov = np.zeros(1024, np.int32)
+        shape_prev = _start_shape_prev(c)
+        for f in range(FRAMES):
+            seq, shape = (int(v) for v in GOLD["side"][c, f])
+            rc, _, ov, out = t.orc_call(oracle, chain_coef(c, f), ov, seq, shape, shape_prev)
+            assert rc == 0
+            assert (crc(out), crc(ov)) == tuple(int(v) for v in GOLD["crc"][c, f]), (c, f, seq)
+            shape_prev = shape
+        assert np.array_equal(out, GOLD["last"][c, 0]) and np.array_equal(ov, GOLD["last"][c, 1])
+
+
+@pytest.mark.gpu
+def test_gpu_reference_chains():
+    import torch
+    import libxaac_amd
+    dev = torch.device("cuda:0")
+    ctx = libxaac_amd.XaacContext(0, None)
+    n = CHAINS + 1  # + a copy of chain 0: the batch is not a multiple of the workgroup's four channel-frames
+    idx = list(range(CHAINS)) + [0]
+    ov = torch.zeros((n, 1024), dtype=torch.int32, device=dev)
+    sp = torch.tensor([_start_shape_prev(c) for c in idx], dtype=torch.uint8, device=dev)
+    out = torch.zeros((n, 1024), dtype=torch.int32, device=dev)
+    tm = torch.zeros((n, 1024), dtype=torch.float32, device=dev)
+    status = torch.full((n,), 7, dtype=torch.int32, device=dev)
+    for f in range(FRAMES):
+        coef = torch.from_numpy(np.stack([chain_coef(c, f) for c in idx])).to(dev)
+        ics = torch.from_numpy(np.stack([GOLD["side"][c, f] for c in idx])).to(dev)
+        ctx.usac_imdct_process_batch(coef, ics, ov, sp, out, tm, status)
+        ctx.sync()
+        o, v = out.cpu().numpy(), ov.cpu().numpy()
+        assert not status.cpu().numpy().any()
+        for c in range(CHAINS):
+            assert (crc(o[c]), crc(v[c])) == tuple(int(x) for x in GOLD["crc"][c, f]), (c, f, GOLD["side"][c, f])
+        assert np.array_equal(o[CHAINS], o[0]) and np.array_equal(v[CHAINS], v[0])
+        assert np.array_equal(tm.cpu().numpy(), o.astype(np.float32) * np.float32(2.0 ** -15))
+        assert np.array_equal(sp.cpu().numpy(), ics.cpu().numpy()[:, 1])
+    assert np.array_equal(o[:CHAINS], GOLD["last"][:, 0]) and np.array_equal(v[:CHAINS], GOLD["last"][:, 1])
+
+
+@pytest.mark.gpu
+def test_gpu_large_batch_vs_oracle(oracle):
+    import torch
+    import libxaac_amd
+    dev = torch.device("cuda:0")
+    ctx = libxaac_amd.XaacContext(0, None)
+    n = 4099
+    rng = np.random.default_rng(3)
+    ov_h = np.zeros((n, 1024), np.int32)
+    sp_h = rng.integers(0, 2, n).astype(np.uint8)
+    seq = rng.integers(0, 5, n)
+    ov = torch.from_numpy(ov_h).to(dev)
+    sp = torch.from_numpy(sp_h).to(dev)
+    out = torch.zeros((n, 1024), dtype=torch.int32, device=dev)
+    check = np.concatenate([np.arange(0, 40), rng.integers(0, n, 60), [n - 3, n - 2, n - 1]])
+    for f in range(3):
+        lvl = rng.integers(0, 27, (n, 1))
+        coef = (rng.integers(-2 ** 31, 2 ** 31, (n, 1024)) >> lvl).astype(np.int32)
+        coef[rng.integers(0, n, 50)] = 0
+        shape = rng.integers(0, 2, n).astype(np.uint8)
+        ics = np.stack([seq.astype(np.uint8), shape], 1)
+        ctx.usac_imdct_process_batch(torch.from_numpy(coef).to(dev), torch.from_numpy(ics).to(dev), ov, sp, out)
+        ctx.sync()
+        o, v = out.cpu().numpy(), ov.cpu().numpy()
+        for c in check:
+            rc, _, nov, xo = t.orc_call(oracle, coef[c], ov_h[c], int(seq[c]), int(shape[c]), int(sp_h[c]))
+            assert np.array_equal(xo, o[c]), (f, c, int(seq[c]))
+            assert np.array_equal(nov, v[c]), (f, c, int(seq[c]))
+        ov_h, sp_h = v.copy(), shape
+        seq = np.array([rng.choice(t.NEXT[int(s)]) for s in seq])
+    assert np.any(o)
+
+
+@pytest.mark.gpu
+def test_gpu_malformed_side_info_is_refused(oracle):
+    import torch
+    import libxaac_amd
+    dev = torch.device("cuda:0")
+    ctx = libxaac_amd.XaacContext(0, None)
+    n = 11
+    rng = np.random.default_rng(9)
+    coef = (rng.integers(-2 ** 31, 2 ** 31, (n, 1024)) >> 6).astype(np.int32)
+    ov_h = (rng.integers(-2 ** 31, 2 ** 31, (n, 1024)) >> 18).astype(np.int32)
+    ics = np.stack([rng.integers(0, 5, n), rng.integers(0, 2, n)], 1).astype(np.uint8)
+    sp_h = rng.integers(0, 2, n).astype(np.uint8)
+    ics[2, 0] = 5
+    ics[5, 1] = 2
+    sp_h[8] = 200
+    ov, sp = torch.from_numpy(ov_h).to(dev), torch.from_numpy(sp_h).to(dev)
+    out = torch.full((n, 1024), 77, dtype=torch.int32, device=dev)
+    status = torch.zeros(n, dtype=torch.int32, device=dev)
+    ctx.usac_imdct_process_batch(torch.from_numpy(coef).to(dev), torch.from_numpy(ics).to(dev), ov, sp, out, None, status)
+    ctx.sync()
+    st, o, v, s2 = status.cpu().numpy(), out.cpu().numpy(), ov.cpu().numpy(), sp.cpu().numpy()
+    for c in range(n):
+        if c in (2, 5, 8):
+            assert st[c] == libxaac_amd.BAD_WINDOW_SEQ
+            assert np.all(o[c] == 77) and np.array_equal(v[c], ov_h[c]) and s2[c] == sp_h[c]
+        else:
+            rc, _, nov, xo = t.orc_call(oracle, coef[c], ov_h[c], int(ics[c, 0]), int(ics[c, 1]), int(sp_h[c]))
+            assert st[c] == 0 and np.array_equal(xo, o[c]) and np.array_equal(nov, v[c]) and s2[c] == ics[c, 1]

@@ -1,0 +1,77 @@
+"""USAC frequency-domain IMDCT (ccfl 1024, no FAC, previous frame FD): the oracle (oracle/oracle_usac.cpp, arithmetic of
+libxaac_amd/csrc/usac_imdct.h) against the compiled reference's own ixheaacd_fd_frm_dec (decoder/ixheaacd_imdct.c:596,
+driven by oracle/ref_usac_adapter.c): Q15 output, new overlap and the in-place transformed coefficient buffer identical
+over chains of legal window-sequence walks with the overlap carried, all levels from silence to full scale."""
+import ctypes
+
+import numpy as np
+import pytest
+
+P32 = ctypes.POINTER(ctypes.c_int32)
+PF = ctypes.POINTER(ctypes.c_float)
+# legal successors (ISO/IEC 23003-3 window sequence transitions, FD only): after ONLY_LONG / LONG_STOP a frame starts
+# with a long slope, after LONG_START / EIGHT_SHORT / STOP_START with a short one
+NEXT = {0: (0, 1), 3: (0, 1), 1: (2, 3, 4), 2: (2, 3, 4), 4: (2, 3, 4)}
+
+
+def _p(a, t=P32):
+    return a.ctypes.data_as(t)
+
+
+def ref_call(ref, coef, ov, seq, shape, shape_prev):
+    fn = ref.lib.ref_usac_fd_imdct
+    fn.restype = ctypes.c_int
+    fn.argtypes = [P32, P32, ctypes.c_int, ctypes.c_int, ctypes.c_int, P32, PF]
+    c, o = coef.copy(), ov.copy()
+    out, tm = np.zeros(1024, np.int32), np.zeros(1024, np.float32)
+    rc = fn(_p(c), _p(o), seq, shape, shape_prev, _p(out), _p(tm, PF))
+    return rc, c, o, out, tm
+
+
+def orc_call(orc, coef, ov, seq, shape, shape_prev):
+    fn = orc.lib.xo_usac_fd_imdct
+    fn.restype = ctypes.c_int
+    fn.argtypes = [P32, P32, ctypes.c_int, ctypes.c_int, ctypes.c_int, P32]
+    c, o = coef.copy(), ov.copy()
+    out = np.zeros(1024, np.int32)
+    rc = fn(_p(c), _p(o), seq, shape, shape_prev, _p(out))
+    return rc, c, o, out
+
+
+def spectrum(rng, kind):
+    """1024 lines: noise at a random level, sparse tonal lines, silence, one full-scale line"""
+    if kind == 0:
+        return (rng.standard_normal(1024) * 2.0 ** rng.integers(2, 27)).astype(np.int64).clip(-2 ** 31, 2 ** 31 - 1).astype(np.int32)
+    if kind == 1:
+        x = np.zeros(1024, np.int32)
+        idx = rng.integers(0, 1024, 12)
+        x[idx] = rng.integers(-2 ** 28, 2 ** 28, 12)
+        return x
+    if kind == 2:
+        return np.zeros(1024, np.int32)
+    x = (rng.standard_normal(1024) * 50).astype(np.int32)
+    x[int(rng.integers(0, 1024))] = -2 ** 31 if rng.integers(0, 2) else 2 ** 31 - 1
+    return x
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_chain(oracle, reference, seed):
+    rng = np.random.default_rng(1000 + seed)
+    ov_r = np.zeros(1024, np.int32)
+    ov_o = np.zeros(1024, np.int32)
+    seq, shape_prev = 0, 0
+    seen = set()
+    for f in range(60):
+        shape = int(rng.integers(0, 2))
+        coef = spectrum(rng, int(rng.choice([0, 0, 0, 1, 2, 3])))
+        rc_r, c_r, ov_r, out_r, tm = ref_call(reference, coef, ov_r, seq, shape, shape_prev)
+        rc_o, c_o, ov_o, out_o = orc_call(oracle, coef, ov_o, seq, shape, shape_prev)
+        assert rc_r == 0 and rc_o == 0
+        assert np.array_equal(c_r, c_o), (f, seq, int(np.sum(c_r != c_o)))
+        assert np.array_equal(out_r, out_o), (f, seq, int(np.sum(out_r != out_o)))
+        assert np.array_equal(ov_r, ov_o), (f, seq, int(np.sum(ov_r != ov_o)))
+        assert np.array_equal(tm, out_r.astype(np.float32) * np.float32(2.0 ** -15))
+        seen.add(seq)
+        shape_prev = shape
+        seq = int(rng.choice(NEXT[seq]))
+    assert seen == {0, 1, 2, 3, 4}

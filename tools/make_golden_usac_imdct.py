@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Build tests/golden/usac_imdct_ref.npz: chains of the REAL ixheaacd_fd_frm_dec (decoder/ixheaacd_imdct.c:596; ccfl 1024,
+FD after FD, no FAC) run by the compiled reference (oracle/_ref/libref_harness.so through oracle/ref_usac_adapter.c) with
+the overlap carried from frame to frame along legal window-sequence walks.
+
+The 1024 spectral lines of a frame are NOT stored: tests regenerate them from (chain, frame) with chain_coef() below
+(integer arithmetic on a counter, no library RNG).  Stored per frame: window sequence, shape, CRC32 of the reference's
+Q15 output and of its overlap after the call; the last frame's output and overlap in full.  Data only; runs only where
+/root/reference is."""
+import os
+import sys
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+CHAINS, FRAMES = 24, 44
+NEXT = {0: (0, 1), 3: (0, 1), 1: (2, 3, 4), 2: (2, 3, 4), 4: (2, 3, 4)}
+
+
+def _mix(base, n):
+    z = (np.uint64(base) * np.uint64(4096) + np.arange(n, dtype=np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def chain_coef(chain, frame):
+    """1024 spectral lines: uniform noise at a level that walks with (chain, frame); every 5th frame sparse tonal lines,
+    every 11th silence, every 13th one full-scale line in low-level noise"""
+    z = _mix((1 << 30) | (chain << 12) | frame, 1024)
+    v = (z >> np.uint64(32)).astype(np.int64) - (1 << 31)            # 32-bit signed, uniform
+    level = (3 * chain + 5 * frame) % 27                             # right shift 0 .. 26
+    x = v >> level
+    if frame % 11 == 10:
+        x[:] = 0
+    elif frame % 5 == 4:
+        keep = (z & np.uint64(63)) == 0
+        x = np.where(keep, x, 0)
+    elif frame % 13 == 12:
+        x = v >> 25
+        x[int(z[0] & np.uint64(1023))] = -(1 << 31) if (int(z[1]) & 1) else (1 << 31) - 1
+    return x.astype(np.int32)
+
+
+def chain_side(chain, frame, seq):
+    """(shape, next window sequence) of the frame"""
+    z = _mix((2 << 30) | (chain << 12) | frame, 2)
+    nxt = NEXT[seq]
+    return int(z[0] & np.uint64(1)), int(nxt[int(z[1] >> np.uint64(8)) % len(nxt)])
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xffffffff
+
+
+def main():
+    import oracle_lib
+    import test_usac_oracle_vs_reference as t
+    ref = oracle_lib.load_reference()
+    side = np.zeros((CHAINS, FRAMES, 2), np.uint8)
+    crcs = np.zeros((CHAINS, FRAMES, 2), np.uint32)
+    last = np.zeros((CHAINS, 2, 1024), np.int32)
+    for c in range(CHAINS):
+        ov = np.zeros(1024, np.int32)
+        seq, shape_prev = (0, 1, 3, 4)[c % 4] if c >= 4 else 0, c & 1
+        for f in range(FRAMES):
+            shape, nxt = chain_side(c, f, seq)
+            rc, _, ov, out, _ = t.ref_call(ref, chain_coef(c, f), ov, seq, shape, shape_prev)
+            assert rc == 0
+            side[c, f] = seq, shape
+            crcs[c, f] = crc(out), crc(ov)
+            seq, shape_prev = nxt, shape
+        last[c, 0], last[c, 1] = out, ov
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "usac_imdct_ref.npz"), side=side, crc=crcs, last=last)
+    print("wrote", CHAINS, "chains x", FRAMES, "frames; sequences seen:", np.bincount(side[:, :, 0].ravel(), minlength=5))
+
+
+if __name__ == "__main__":
+    main()
