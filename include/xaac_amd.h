@@ -184,6 +184,23 @@ typedef struct xaac_sbr_hq_batch {
   uint64_t workspace_bytes;
 } xaac_sbr_hq_batch;
 
+/* ---- state hand-overs at a change of channel configuration ------------------------------------------------------
+ * xaac_sbr_state_handover <-> the two memcpy blocks of ixheaacd_sbr_dec_apply, decoder/ixheaacd_sbrdecoder.c:762-806:
+ * a stream that was mono (no PS) in the previous frame and carries parametric stereo now starts the right synthesis
+ * bank from the left one's filter states (:762-775); a stream that turns from mono to stereo starts channel 1 from
+ * channel 0's synthesis / analysis filter states, overlap buffer and their scale factors (:777-806).  The host calls it
+ * before the frame's xaac_sbr_*_process_batch for exactly the streams whose configuration changed. */
+#define XAAC_HANDOVER_PS_START 1
+#define XAAC_HANDOVER_STEREO_START 2
+typedef struct xaac_sbr_handover_batch {
+  int32_t n;                /* entries */
+  int32_t mode;             /* XAAC_HANDOVER_PS_START or XAAC_HANDOVER_STEREO_START */
+  const int32_t *src;       /* [n] device: index into state of the channel that was running (channel 0) */
+  const int32_t *dst;       /* [n] device: PS_START: index into ps_state; STEREO_START: index into state (channel 1) */
+  xaac_sbr_state *state;
+  xaac_ps_state *ps_state;  /* PS_START only */
+} xaac_sbr_handover_batch;
+
 /* ---- peak limiter + PCM16 hand-off (the AAC-LC post stage) ---------------------------------
  * xaac_peak_limiter_process_batch <-> ixheaacd_peak_limiter_process
  *      def decoder/ixheaacd_peak_limiter.c:201-309, call site decoder/ixheaacd_api.c:3667, followed by the
@@ -320,6 +337,9 @@ int32_t xaac_sbr_lp_process_batch(xaac_ctx *ctx, const xaac_sbr_lp_batch *batch)
  * stereo] -> complex QMF synthesis, once per output channel). */
 uint64_t xaac_sbr_hq_workspace_bytes(int32_t n_ch, int32_t with_ps);
 int32_t xaac_sbr_hq_process_batch(xaac_ctx *ctx, const xaac_sbr_hq_batch *batch);
+
+/* Channel-configuration hand-overs (device pointers, asynchronous). */
+int32_t xaac_sbr_state_handover(xaac_ctx *ctx, const xaac_sbr_handover_batch *batch);
 
 /* ixheaacd_peak_limiter_init (peak_limiter.c:46-77) on a host-side state; returns the limiter delay in
  * samples (attack_time_samples) or a fatal code when the rate / channel count does not fit the struct. */

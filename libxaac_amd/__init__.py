@@ -65,6 +65,15 @@ class _QmfSynBatch(ctypes.Structure):
                 ("state", ctypes.c_void_p), ("pcm", ctypes.c_void_p)]
 
 
+class _HandoverBatch(ctypes.Structure):
+    # struct xaac_sbr_handover_batch
+    _fields_ = [("n", ctypes.c_int32), ("mode", ctypes.c_int32), ("src", ctypes.c_void_p), ("dst", ctypes.c_void_p),
+                ("state", ctypes.c_void_p), ("ps_state", ctypes.c_void_p)]
+
+
+HANDOVER_PS_START, HANDOVER_STEREO_START = 1, 2
+
+
 class _UsacImdctBatch(ctypes.Structure):
     # struct xaac_usac_imdct_batch
     _fields_ = [("n_ch", ctypes.c_int32), ("coef", ctypes.c_void_p), ("ics", ctypes.c_void_p),
@@ -164,6 +173,8 @@ def load_library():
     lib.xaac_last_launch.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int32)] * 3
     lib.xaac_qmf_analysis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_QmfAnaBatch)]
     lib.xaac_qmf_synthesis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_QmfSynBatch)]
+    lib.xaac_sbr_state_handover.argtypes = [ctypes.c_void_p, ctypes.POINTER(_HandoverBatch)]
+    lib.xaac_sbr_state_handover.restype = ctypes.c_int32
     lib.xaac_usac_imdct_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_UsacImdctBatch)]
     lib.xaac_usac_imdct_process_batch.restype = ctypes.c_int32
     lib.xaac_esbr_qmf_analysis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_EsbrAnaBatch)]
@@ -343,6 +354,20 @@ class XaacContext:
         rc = self._lib.xaac_qmf_synthesis_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_qmf_synthesis_batch")
+
+    def sbr_state_handover(self, mode, src, dst, state, ps_state=None):
+        """ixheaacd_sbrdecoder.c:762-806 for the listed streams: mode HANDOVER_PS_START (dst indexes ps_state) or
+        HANDOVER_STEREO_START (dst indexes state); src / dst int32 device tensors; state / ps_state uint8 views of the
+        xaac_sbr_state / xaac_ps_state arrays."""
+        b = _HandoverBatch()
+        b.n, b.mode = int(src.numel()), int(mode)
+        b.src = _ptr(src, "int32", device_ok=True)
+        b.dst = _ptr(dst, "int32", b.n, device_ok=True)
+        b.state = _ptr(state, "uint8", device_ok=True)
+        b.ps_state = _ptr(ps_state, "uint8", allow_none=True, device_ok=True)
+        rc = self._lib.xaac_sbr_state_handover(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_sbr_state_handover")
 
     def usac_imdct_process_batch(self, coef, ics, overlap, shape_prev, out32=None, time=None, status=None):
         """Batched ixheaacd_fd_frm_dec (USAC FD frame after an FD frame, ccfl 1024, no FAC): coef int32[n_ch, 1024];

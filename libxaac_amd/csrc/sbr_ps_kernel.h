@@ -29,6 +29,7 @@ typedef struct XaacPsParams {
 #ifdef __cplusplus
 extern "C" {
 #endif
+hipError_t xaac_launch_sbr_handover(const xaac_sbr_handover_batch *b, hipStream_t stream);
 hipError_t xaac_launch_ps(const XaacPsParams *p, hipStream_t stream);
 #ifdef __cplusplus
 }

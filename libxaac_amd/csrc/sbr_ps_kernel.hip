@@ -139,6 +139,35 @@ __global__ __launch_bounds__(64, 2) void xaac_ps_kernel(XaacPsParams p) {
 #endif
 }
 
+/* ixheaacd_sbrdecoder.c:762-806: what channel 1 inherits from channel 0 when a mono stream turns into a parametric-stereo
+   or a stereo one.  Only the arrays and scale factors the reference copies move; channel 1 keeps its own ring positions
+   (the reference's pointers into the rings are not part of the copy).  One workgroup per entry. */
+__global__ __launch_bounds__(64) void xaac_sbr_handover_kernel(xaac_sbr_handover_batch b) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  const xaac_sbr_state *src = b.state + b.src[e];
+  if (b.mode == XAAC_HANDOVER_PS_START) {
+    xaac_ps_state *dst = b.ps_state + b.dst[e];
+    for (int i = lane; i < 1280; i += 64) dst->syn_ring_r[i] = src->syn_ring[i];
+    if (lane == 0) dst->st_syn_scale_r = src->st_syn_scale;
+  } else {
+    xaac_sbr_state *dst = b.state + b.dst[e];
+    for (int i = lane; i < 1280; i += 64) dst->syn_ring[i] = src->syn_ring[i];
+    for (int i = lane; i < 320; i += 64) dst->ana_ring[i] = src->ana_ring[i];
+    for (int i = lane; i < 6 * 64; i += 64) dst->overlap[i] = src->overlap[i]; /* MAX_OV_COLS * NO_SYNTHESIS_CHANNELS words */
+    if (lane == 0) {
+      dst->st_syn_scale = src->st_syn_scale;
+      dst->st_lb_scale = src->st_lb_scale;
+      dst->ov_lb_scale = src->ov_lb_scale;
+      dst->ov_hb_scale = src->ov_hb_scale;
+    }
+  }
+}
+
+extern "C" hipError_t xaac_launch_sbr_handover(const xaac_sbr_handover_batch *b, hipStream_t stream) {
+  hipLaunchKernelGGL(xaac_sbr_handover_kernel, dim3(b->n), dim3(64), 0, stream, *b);
+  return hipGetLastError();
+}
+
 extern "C" hipError_t xaac_launch_ps(const XaacPsParams *p, hipStream_t stream) {
   static int resident = 0; /* workgroups the chip holds at once (LDS-bound) */
   if (!resident) {

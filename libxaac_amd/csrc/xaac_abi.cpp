@@ -250,6 +250,16 @@ int32_t xaac_qmf_synthesis_batch(xaac_ctx *c, const xaac_qmf_syn_batch *b) {
   return XAAC_OK;
 }
 
+int32_t xaac_sbr_state_handover(xaac_ctx *c, const xaac_sbr_handover_batch *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n < 0 || (b->mode != XAAC_HANDOVER_PS_START && b->mode != XAAC_HANDOVER_STEREO_START)) return XAAC_FATAL_BAD_ARG;
+  if (b->n == 0) return XAAC_OK;
+  if (!b->src || !b->dst || !b->state || (b->mode == XAAC_HANDOVER_PS_START && !b->ps_state)) return XAAC_FATAL_NULL_ARG;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  if (!hip_ok(xaac_launch_sbr_handover(b, c->stream))) return XAAC_FATAL_HIP;
+  return XAAC_OK;
+}
+
 int32_t xaac_usac_imdct_process_batch(xaac_ctx *c, const xaac_usac_imdct_batch *b) {
   if (!c || !b) return XAAC_FATAL_NULL_ARG;
   if (b->n_ch < 0) return XAAC_FATAL_BAD_ARG;

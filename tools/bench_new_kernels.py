@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Kernel times of the round-2 additions outside the C4 chain -- the USAC FD IMDCT and the eSBR (Path A) QMF banks -- on
+resident synthetic batches, HIP-event timed on the library's stream; prints one JSON line per kernel with the achieved
+algorithmic GB/s against the 8 TB/s HBM roof.  Run on the GPU box: python tools/bench_new_kernels.py [n_ch]"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timed(torch, ctx, fn, steps=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    ctx.sync()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps * 1e3  # us
+
+
+def main():
+    import torch
+    import libxaac_amd
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+    dev = torch.device("cuda:0")
+    ctx = libxaac_amd.XaacContext(0, torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(0)
+    res = []
+    # USAC FD IMDCT: long frames and short frames
+    coef = torch.from_numpy((rng.integers(-2 ** 31, 2 ** 31, (n, 1024)) >> 8).astype(np.int32)).to(dev)
+    ov = torch.zeros((n, 1024), dtype=torch.int32, device=dev)
+    sp = torch.zeros(n, dtype=torch.uint8, device=dev)
+    out = torch.zeros((n, 1024), dtype=torch.int32, device=dev)
+    for name, seq in (("usac_imdct_long", 0), ("usac_imdct_short", 2)):
+        ics = torch.tensor([[seq, 1]] * n, dtype=torch.uint8, device=dev)
+        us = timed(torch, ctx, lambda: ctx.usac_imdct_process_batch(coef, ics, ov, sp, out))
+        res.append((name, us, n * 16384))
+    # eSBR banks
+    core = torch.from_numpy((rng.uniform(-1, 1, (n, 1024)) * 20000).astype(np.float32)).to(dev)
+    sa = torch.zeros((n, libxaac_amd.ESBR_ANA_STATE_WORDS), dtype=torch.int32, device=dev)
+    ss = torch.zeros((n, libxaac_amd.ESBR_SYN_STATE_WORDS), dtype=torch.int32, device=dev)
+    re = torch.zeros((n, 32, 64), dtype=torch.float32, device=dev)
+    im = torch.zeros((n, 32, 64), dtype=torch.float32, device=dev)
+    pcm = torch.zeros((n, 2048), dtype=torch.float32, device=dev)
+    us = timed(torch, ctx, lambda: ctx.esbr_qmf_analysis_batch(core, sa, re, im))
+    res.append(("esbr_qmf_analysis", us, n * (4096 + 2 * 1288 + 2 * 4096)))   # core in, ring in/out, 32 bands re+im out
+    us = timed(torch, ctx, lambda: ctx.esbr_qmf_synthesis_batch(re, im, ss, pcm))
+    res.append(("esbr_qmf_synthesis", us, n * (2 * 8192 + 2 * 5128 + 8192)))  # rows in, ring in/out, samples out
+    for name, us, bytes_ in res:
+        print(json.dumps({"kernel": name, "n_ch": n, "us": round(us, 1), "channel_frames_per_s": round(n / us * 1e6),
+                          "alg_GBps": round(bytes_ / us / 1e3, 1), "frac_of_8TBps": round(bytes_ / us / 1e3 / 8000, 4)}))
+
+
+if __name__ == "__main__":
+    main()
