@@ -1,0 +1,75 @@
+/*
+ * xaac_esbr.h -- boundary formats of the eSBR ("Path A", the reference's default -esbr:1) SBR tool for HE-AAC streams:
+ * what ixheaacd_sbr_dec's Path A branch (decoder/ixheaacd_sbr_dec.c:816-1009) reads beyond xaac_sbr_header /
+ * xaac_sbr_frame (xaac_sbr.h), and the per-channel state it keeps between frames.
+ * Scope: 2:1 SBR of AAC-LC cores (usac_flag = 0): no harmonic transposer, no PVC, no pre-flattening, no MPS.
+ */
+#ifndef XAAC_ESBR_H
+#define XAAC_ESBR_H
+
+#include <stdint.h>
+
+#include "xaac_amd.h"
+#include "xaac_sbr.h"
+
+#define XAAC_ESBR_HIST_ROWS 40 /* op_delay 6 + SBR_HF_ADJ_OFFSET 2 + codec_x_delay 32 rows of qmf_buf_real/_imag kept */
+#define XAAC_ESBR_OUT_HIST_ROWS 8 /* op_delay 6 + SBR_HF_ADJ_OFFSET 2 rows of sbr_qmf_out_real/_imag kept */
+#define XAAC_ESBR_ROWS (XAAC_ESBR_HIST_ROWS + 32)
+
+/* Per-frame side info: ia_sbr_header_data_struct / ia_freq_band_data_struct / ia_sbr_frame_info_data_struct members
+ * (decoder/ixheaacd_env_extr_part.h:33-100, ixheaacd_env_extr.h:54-120) the float path reads and the fixed path does not. */
+typedef struct xaac_esbr_side {
+  int32_t out_sampling_freq;                          /* header: out_sampling_freq */
+  int16_t limiter_bands;                              /* header: limiter_bands */
+  int16_t num_mf_bands;                               /* freq band data: num_mf_bands */
+  int16_t f_master_tbl[XAAC_SBR_MAX_FREQ_COEFFS + 1]; /* freq band data: f_master_tbl */
+  int16_t qmf_sb_prev;                                /* freq band data: qmf_sb_prev (sbr_dec.c:314) */
+  int16_t reset_flag;                                 /* frame: reset_flag */
+  int16_t pad0_;
+  int32_t sbr_invf_mode_prev[XAAC_SBR_MAX_NOISE_VALUES]; /* frame: sbr_invf_mode_prev (set by the parser, env_extr.c:834) */
+  int32_t inter_temp_shape_mode[XAAC_SBR_MAX_ENVELOPES]; /* frame: inter_temp_shape_mode (0 without inter-TES) */
+  float flt_env_sf_arr[XAAC_SBR_MAX_ENV_VALUES];      /* frame: flt_env_sf_arr */
+  float flt_noise_floor[XAAC_SBR_MAX_NOISE_VALUES];   /* frame: flt_noise_floor */
+} xaac_esbr_side;
+
+/* Per-channel persistent state of the Path A branch. */
+typedef struct xaac_esbr_state {
+  xaac_esbr_ana_state ana;                            /* str_codec_qmf_bank (32-bit rings) */
+  xaac_esbr_syn_state syn;                            /* str_synthesis_qmf_bank */
+  float qmf_re[XAAC_ESBR_HIST_ROWS][64], qmf_im[XAAC_ESBR_HIST_ROWS][64];         /* qmf_buf_real / _imag rows 0..39 */
+  float out_re[XAAC_ESBR_OUT_HIST_ROWS][64], out_im[XAAC_ESBR_OUT_HIST_ROWS][64]; /* sbr_qmf_out_real / _imag rows 0..7 */
+  float bw_array_prev[XAAC_SBR_MAX_PATCHES];          /* frame_data: bw_array_prev */
+  float e_gain[5][64], noise_buf[5][64];              /* frame_data: e_gain, noise_buf */
+  int32_t lim_table[4][13], gate_mode[4];             /* frame_data: lim_table, gate_mode (remade at a reset frame) */
+  int32_t harm_index, phase_index;
+  int32_t esbr_start_up;                              /* header: esbr_start_up; 1 for a new stream */
+  int32_t env_short_flag_prev;
+  int32_t patch_start_subband[XAAC_SBR_MAX_PATCHES + 1], num_patches; /* frame_data: patch_param */
+  int8_t harm_flag_prev[64];
+} xaac_esbr_state;
+
+typedef struct xaac_esbr_sbr_batch {
+  int32_t n_ch;
+  const float *core;               /* [n_ch][1024] time_sample_buf in */
+  const xaac_sbr_header *header;   /* [n_ch] */
+  const xaac_sbr_frame *frame;     /* [n_ch] (apply_processing, grid, invf modes, harmonics) */
+  const xaac_esbr_side *side;      /* [n_ch] */
+  xaac_esbr_state *state;          /* [n_ch] in/out */
+  float *out;                      /* [n_ch][2048] time_sample_buf out */
+  int32_t *status;                 /* optional [n_ch]: 0, or -1 where the reference returns an error */
+  void *workspace;                 /* device scratch >= xaac_esbr_workspace_bytes(n_ch) */
+  uint64_t workspace_bytes;
+} xaac_esbr_sbr_batch;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* One frame of every channel through the Path A branch of ixheaacd_sbr_dec (mono / stereo channels, no PS):
+ * history shift (sbr_dec.c:835-857), ixheaacd_esbr_analysis_filt_block, ixheaacd_generate_hf (sbrdec_lpfuncs.c:981),
+ * ixheaacd_sbr_env_calc (esbr_envcal.c:71), ixheaacd_esbr_synthesis_regrp + the synthesis bank (sbr_dec.c:297 / :447). */
+uint64_t xaac_esbr_workspace_bytes(int32_t n_ch);
+int32_t xaac_esbr_sbr_process_batch(xaac_ctx *ctx, const xaac_esbr_sbr_batch *batch);
+#ifdef __cplusplus
+}
+#endif
+#endif /* XAAC_ESBR_H */

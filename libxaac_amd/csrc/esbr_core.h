@@ -1,0 +1,550 @@
+/*
+ * esbr_core.h -- the float HF generator and envelope adjuster of the reference's default SBR path ("Path A", -esbr:1)
+ * for HE-AAC streams, shared by the gfx950 kernel (esbr_core_kernel.hip: one wave = one channel-frame, lane = QMF band)
+ * and, compiled for the host with one "lane", by the checker (oracle/oracle_esbr.cpp).
+ *
+ * Restates
+ *   ixheaacd_generate_hf            decoder/ixheaacd_sbrdec_lpfuncs.c:981   (LPP transposer: covariance :781, chirp :832)
+ *   ixheaacd_sbr_env_calc           decoder/ixheaacd_esbr_envcal.c:71       (ORIG_SBR branch :640-860)
+ *   ixheaacd_createlimiterbands     esbr_envcal.c:910,  ixheaacd_apply_inter_tes  esbr_envcal.c:1021
+ *   ixheaacd_esbr_synthesis_regrp   decoder/ixheaacd_sbr_dec.c:297 (stereo_config_idx <= 0)
+ * for usac_flag = 0: 2:1 SBR, no harmonic transposer, no PVC, no pre-flattening, no MPS.
+ *
+ * Float results depend on the order of every operation, so every expression keeps the reference's operand order and
+ * width (float unless the reference mixes in a double: the 1e-17 guard, the sqrt calls); sums over bands or slots run
+ * sequentially in the reference's order on whichever lane needs them.  Compiled with -ffp-contract=off on both sides.
+ */
+#ifndef XAAC_ESBR_CORE_H
+#define XAAC_ESBR_CORE_H
+
+#include <math.h>
+
+#include "../../include/xaac_esbr.h"
+#include "sbr_core.h" /* XsCx, XS_PAR, XS_ONE */
+
+#if defined(__HIPCC__)
+#define XAAC_TAB_QUAL static __device__ const
+#include "tables_esbr.inc"
+#undef XAAC_TAB_QUAL
+#else
+#include "tables_esbr.inc"
+#endif
+
+#pragma clang fp contract(off)
+
+/* a [rows][64] float matrix pair; row 0 is the reference's pointer + SBR_HF_ADJ_OFFSET */
+struct XeMat {
+  float *re, *im;
+  FX_MEMBER float &r(int l, int k) const { return re[l * 64 + k]; }
+  FX_MEMBER float &i(int l, int k) const { return im[l * 64 + k]; }
+};
+
+struct XeWork {
+  float alpha_r[64][2], alpha_i[64][2];
+  float bw_array[XAAC_SBR_MAX_PATCHES];
+  float nrg_est[64], nrg_ref[64], nrg_gain[64], noise_level[64], nrg_tone[64];
+  float pow_lo[80], pow_hi[80], tes_gain[80];
+  int32_t err;
+  int16_t src_band[64]; /* HF generator: source band of high band k2; -1: cleared; -2: not in a patch */
+  int8_t bw_idx[64];
+  int8_t harmonics[64];
+  int8_t sfb_first[64], sfb_len[64], flag[64], o_idx[64];
+  int16_t m_idx[64];
+};
+
+FX_HD double xe_sqrt(double v) { return sqrt(v); }
+
+/* ---- ixheaacd_createlimiterbands (b_patching_mode = 1): serial, integer, run at a reset frame ------------------- */
+FX_HD void xe_shellsort(int32_t *in, int n) { /* esbr_envcal.c:48: any sort gives the same array of integers */
+  for (int i = 1; i < n; i++) {
+    const int32_t v = in[i];
+    int j = i;
+    for (; j > 0 && in[j - 1] > v; j--) in[j] = in[j - 1];
+    in[j] = v;
+  }
+}
+FX_HD int xe_limiter_bands(const xaac_sbr_header *h, xaac_esbr_state *st) {
+  const int nb = h->num_sf_bands[0];
+  const int16_t *tbl = h->freq_band_tbl_lo;
+  const int sb_start = tbl[0], sb_end = tbl[nb];
+  const int num_patches = st->num_patches;
+  int32_t patch_borders[XAAC_SBR_MAX_PATCHES + 2], t[32 + XAAC_SBR_MAX_PATCHES + 1];
+  int i;
+  for (i = 0; i < num_patches; i++) patch_borders[i] = st->patch_start_subband[i] - sb_start;
+  patch_borders[i] = sb_end - sb_start;
+  st->lim_table[0][0] = tbl[0] - sb_start;
+  st->lim_table[0][1] = tbl[nb] - sb_start;
+  st->gate_mode[0] = 1;
+  for (i = 1; i < 4; i++) {
+    for (int k = 0; k <= nb; k++) t[k] = tbl[k] - sb_start;
+    for (int k = 1; k < num_patches; k++) t[nb + k] = patch_borders[k];
+    int gate = nb + num_patches - 1;
+    xe_shellsort(t, gate + 1);
+    for (int j = 1; j <= gate; j++) {
+      const int a = t[j] + sb_start, b = t[j - 1] + sb_start;
+      const bool close = a >= 1 && a <= 64 && b >= 1 && b <= 64 && ((xaac_esbr_lim_close[64 * (i - 1) + a - 1] >> (b - 1)) & 1);
+      if (!close) continue;
+      if (t[j] == t[j - 1]) {
+        t[j] = sb_end;
+        xe_shellsort(t, gate + 1);
+        gate--;
+        j--;
+        continue;
+      }
+      bool pb0 = false, pb1 = false;
+      for (int k = 0; k <= num_patches; k++) pb0 = pb0 || t[j - 1] == patch_borders[k];
+      for (int k = 0; k <= num_patches; k++) pb1 = pb1 || t[j] == patch_borders[k];
+      if (!pb1) {
+        t[j] = sb_end;
+        xe_shellsort(t, gate + 1);
+        gate--;
+        j--;
+      } else if (!pb0) {
+        t[j - 1] = sb_end;
+        xe_shellsort(t, gate + 1);
+        gate--;
+        j--;
+      }
+    }
+    if (gate > 12) return -1;
+    st->gate_mode[i] = gate;
+    for (int k = 0; k <= gate; k++) st->lim_table[i][k] = t[k];
+  }
+  return 0;
+}
+
+/* ---- ixheaacd_generate_hf ---------------------------------------------------------------------------------------- */
+FX_HD int xe_closest_entry(int goal, const int16_t *f, int n) { /* sbrdec_lpfuncs.c:263, direction 0 */
+  if (goal <= f[0]) return f[0];
+  if (goal >= f[n]) return f[n];
+  int idx = n;
+  while (f[idx] > goal) idx--;
+  return f[idx];
+}
+
+/* the patch map (header-level integers, sbrdec_lpfuncs.c:1122-1200): lane 0 */
+FX_HD void xe_build_patches(const xaac_sbr_header *h, const xaac_esbr_side *sd, xaac_esbr_state *st, XeWork *w) {
+  const int16_t *fm = sd->f_master_tbl;
+  const int nmf = sd->num_mf_bands;
+  const int lsb = fm[0], usb = fm[nmf], xover_offset = h->sub_band_start - fm[0];
+  const int16_t *invf_tbl = h->freq_band_tbl_noise + 1;
+  for (int k = 0; k < 64; k++) w->src_band[k] = -2;
+  int goal_sb = (int)(2.048e6f / (float)sd->out_sampling_freq + 0.5f);
+  if (goal_sb < fm[nmf]) {
+    int index = 0;
+    while (fm[index] < goal_sb) index++;
+    goal_sb = fm[index];
+  } else {
+    goal_sb = fm[nmf];
+  }
+  int source_start_band = xover_offset + 1, sb = lsb + xover_offset, patch = 0, flag_break = 0;
+  while (sb < usb) {
+    if (patch >= XAAC_SBR_MAX_PATCHES) {
+      w->err = -1;
+      return;
+    }
+    st->patch_start_subband[patch] = sb;
+    int num = goal_sb - sb, stride;
+    if (num >= lsb - source_start_band) {
+      stride = (sb - source_start_band) & ~1;
+      num = lsb - (sb - stride);
+      num = xe_closest_entry(sb + num, fm, nmf) - sb;
+    }
+    stride = (num + sb - lsb + 1) & ~1;
+    source_start_band = 1;
+    if (goal_sb - (sb + num) < 3) goal_sb = usb;
+    if (num < 3 && patch > 0 && sb + num == usb) {
+      for (int k2 = sb; k2 < sb + num; k2++) w->src_band[k2] = -1;
+      break;
+    }
+    if (num < 0 && flag_break == 1) break;
+    if (num < 0) {
+      flag_break = 1;
+      continue;
+    }
+    flag_break = 0;
+    for (int k2 = sb; k2 < sb + num; k2++) {
+      int bw_index = 0;
+      while (k2 >= invf_tbl[bw_index]) {
+        bw_index++;
+        if (bw_index >= XAAC_SBR_MAX_NOISE_COEFFS) {
+          w->err = -1;
+          return;
+        }
+      }
+      w->src_band[k2] = (int16_t)(k2 - stride);
+      w->bw_idx[k2] = (int8_t)bw_index;
+    }
+    sb += num;
+    patch++;
+  }
+  st->num_patches = patch;
+}
+
+FX_HD void xe_generate_hf(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
+                          xaac_esbr_state *st, XeWork *w, const XeMat &src, const XeMat &dst) {
+  const int start = 2 * f->border_vec[0], end = 32 + 2 * (f->border_vec[f->num_env] - 16);
+  const int lsb = sd->f_master_tbl[0], usb = sd->f_master_tbl[sd->num_mf_bands];
+  const int num_if = h->num_nf_bands;
+  XS_PAR(i, 0, XAAC_SBR_MAX_PATCHES) { /* chirp factors, :832 */
+    float bw = 0.0f;
+    if (i < num_if) {
+      const float tab[4][4] = {{0.00f, 0.60f, 0.90f, 0.98f}, {0.60f, 0.75f, 0.90f, 0.98f},
+                                      {0.00f, 0.75f, 0.90f, 0.98f}, {0.00f, 0.75f, 0.90f, 0.98f}}; /* :80 */
+      bw = tab[sd->sbr_invf_mode_prev[i] & 3][f->sbr_invf_mode[i] & 3];
+      if (bw < st->bw_array_prev[i]) bw = 0.75000f * bw + 0.25000f * st->bw_array_prev[i];
+      else bw = 0.90625f * bw + 0.09375f * st->bw_array_prev[i];
+      if (bw < 0.015625f) bw = 0;
+    }
+    w->bw_array[i] = bw;
+  }
+  XS_ONE {
+    w->err = 0;
+    xe_build_patches(h, sd, st, w);
+  }
+  XS_PAR(k, usb, 64)
+    for (int l = start; l < end; l++) {
+      dst.r(l, k) = 0.0f;
+      dst.i(l, k) = 0.0f;
+    }
+  XS_PAR(k, 0, 64) {
+    float a0r = 0, a0i = 0, a1r = 0, a1i = 0;
+    if (k >= 1 && k < lsb) { /* covariance over 38 slots from row -2 on, :781; prediction coefficients :1077-1120 */
+      float p01r = 0, p01i = 0, p02r = 0, p02i = 0, p11 = 0, p12r = 0, p12i = 0, p22 = 0;
+      float r2 = src.r(-2, k), i2 = src.i(-2, k), r1 = src.r(-1, k), i1 = src.i(-1, k);
+      for (int j = 0; j < 38; j++) {
+        const float r0 = src.r(j, k), i0 = src.i(j, k);
+        p01r += r0 * r1 + i0 * i1;
+        p01i += i0 * r1 - r0 * i1;
+        p02r += r0 * r2 + i0 * i2;
+        p02i += i0 * r2 - r0 * i2;
+        p11 += r1 * r1 + i1 * i1;
+        p12r += r1 * r2 + i1 * i2;
+        p12i += i1 * r2 - r1 * i2;
+        p22 += r2 * r2 + i2 * i2;
+        r2 = r1; i2 = i1;
+        r1 = r0; i1 = i0;
+      }
+      const float det = p11 * p22 - (p12r * p12r + p12i * p12i) * 0.999999f;
+      if (det != 0.0f) {
+        const float fac = 1.0f / det;
+        a1r = (p01r * p12r - p01i * p12i - p02r * p11) * fac;
+        a1i = (p01i * p12r + p01r * p12i - p02i * p11) * fac;
+      }
+      if (p11 != 0) {
+        const float fac = 1.0f / p11;
+        a0r = -(p01r + a1r * p12r + a1i * p12i) * fac;
+        a0i = -(p01i + a1i * p12r - a1r * p12i) * fac;
+      }
+      if (a0r * a0r + a0i * a0i >= 16.0f || a1r * a1r + a1i * a1i >= 16.0f) a0r = a0i = a1r = a1i = 0.0f;
+    }
+    w->alpha_r[k][0] = a0r; w->alpha_i[k][0] = a0i;
+    w->alpha_r[k][1] = a1r; w->alpha_i[k][1] = a1i;
+  }
+  cx.sync();
+  if (w->err) return;
+  XS_PAR(k2, 0, 64) {
+    const int k = w->src_band[k2];
+    if (k == -1) {
+      for (int l = start; l < end; l++) {
+        dst.r(l, k2) = 0.0f;
+        dst.i(l, k2) = 0.0f;
+      }
+    } else if (k >= 0) {
+      float bw = w->bw_array[w->bw_idx[k2]];
+      const float a0r = bw * w->alpha_r[k][0], a0i = bw * w->alpha_i[k][0];
+      bw *= bw;
+      const float a1r = bw * w->alpha_r[k][1], a1i = bw * w->alpha_i[k][1];
+      float r2 = src.r(start - 2, k), i2 = src.i(start - 2, k), r1 = src.r(start - 1, k), i1 = src.i(start - 1, k);
+      for (int l = start; l < end; l++) {
+        const float r0 = src.r(l, k), i0 = src.i(l, k);
+        float yr = r0 * 1.0f, yi = i0 * 1.0f;
+        if (bw > 0.0f) {
+          yr += (a0r * r1 - a0i * i1 + a1r * r2 - a1i * i2) * 1.0f;
+          yi += (a0i * r1 + a0r * i1 + a1i * r2 + a1r * i2) * 1.0f;
+        }
+        dst.r(l, k2) = yr;
+        dst.i(l, k2) = yi;
+        r2 = r1; i2 = i1;
+        r1 = r0; i1 = i0;
+      }
+    }
+  }
+  XS_PAR(i, 0, num_if) st->bw_array_prev[i] = w->bw_array[i];
+  cx.sync();
+}
+
+/* ---- ixheaacd_apply_inter_tes (gamma > 0 only; HE-AAC streams carry gamma 0) ---------------------------------------- */
+FX_HD void xe_inter_tes(const XsCx &cx, XeWork *w, const XeMat &low, const XeMat &x, int row0, int num_sample,
+                        int sb_start, int num_sb, int gamma_idx) {
+  const float gamma = xaac_esbr_q_gamma[gamma_idx & 3];
+  if (!(gamma > 0)) return;
+  const int sb_end = sb_start + num_sb;
+  XS_PAR(i, 0, num_sample) {
+    const int l = row0 + i;
+    for (int j = 0; j < sb_start; j++) {
+      x.r(l, j) = low.r(l, j);
+      x.i(l, j) = low.i(l, j);
+    }
+    float pl = 0.0f, ph = 0.0f;
+    for (int j = 0; j < sb_start; j++) {
+      pl += x.r(l, j) * x.r(l, j);
+      pl += x.i(l, j) * x.i(l, j);
+    }
+    for (int j = sb_start; j < sb_end; j++) {
+      ph += x.r(l, j) * x.r(l, j);
+      ph += x.i(l, j) * x.i(l, j);
+    }
+    w->pow_lo[i] = pl;
+    w->pow_hi[i] = ph;
+  }
+  cx.sync();
+  float tot_lo = 0.0f, tot_hi = 0.0f, tot_after = 1.0e-6f;
+  for (int i = 0; i < num_sample; i++) {
+    tot_lo += w->pow_lo[i];
+    tot_hi += w->pow_hi[i];
+  }
+  XS_PAR(i, 0, num_sample) {
+    float g = (float)xe_sqrt((double)(w->pow_lo[i] * (float)num_sample / (tot_lo + 1.0e-6f)));
+    g = (float)(1.0f + gamma * (g - 1.0f));
+    if (g < 0.2f) g = 0.2f;
+    w->tes_gain[i] = g;
+  }
+  cx.sync();
+  for (int i = 0; i < num_sample; i++) {
+    const float g = w->tes_gain[i];
+    tot_after += w->pow_hi[i] * (g * g);
+  }
+  const float gain_adj = (float)xe_sqrt((double)(tot_hi / tot_after));
+  XS_PAR(k, sb_start, sb_end)
+    for (int i = 0; i < num_sample; i++) {
+      const float g = w->tes_gain[i] * gain_adj;
+      x.r(row0 + i, k) *= g;
+      x.i(row0 + i, k) *= g;
+    }
+  cx.sync();
+}
+
+/* ---- ixheaacd_sbr_env_calc, ORIG_SBR ------------------------------------------------------------------------------- */
+FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
+                      xaac_esbr_state *st, XeWork *w, const XeMat &x /* sbr_qmf_out */, const XeMat &low /* qmf_buf */) {
+  const int sb_start = h->sub_band_start, num_sb = h->sub_band_end - h->sub_band_start;
+  const int num_env = f->num_env, trans_env = f->transient_env, num_nf = h->num_nf_bands;
+  const int smoothing_length = h->smoothing_mode ? 0 : 4, int_mode = h->interpol_freq;
+  const int lim_band = sd->limiter_bands & 3, lim_gains = h->limiter_gains & 3;
+  const double guard = 1e-17;
+  int phase_index = st->phase_index, harm_index = st->harm_index, start_up = st->esbr_start_up;
+  if (num_sb < 0 || num_sb > 64) return -1;
+  if (sd->reset_flag) {
+    start_up = 1;
+    phase_index = 0;
+    XS_ONE w->err = xe_limiter_bands(h, st);
+    cx.sync();
+    if (w->err) return -1;
+  }
+  XS_ONE {
+    w->err = 0;
+    for (int i = 0; i < 64; i++) w->harmonics[i] = 0;
+    for (int i = 0; i < h->num_sf_bands[1]; i++) {
+      const int li = h->freq_band_tbl_hi[i], ui = h->freq_band_tbl_hi[i + 1];
+      const int tmp = ((ui + li) - (sb_start << 1)) >> 1;
+      if (tmp >= 64 || tmp < 0) {
+        w->err = -1;
+        break;
+      }
+      w->harmonics[tmp] = (int8_t)f->add_harmonics[i];
+    }
+  }
+  cx.sync();
+  if (w->err) return -1;
+  int kk = 0, next = -1, m = 0;
+  for (int i = 0; i < num_env; i++) {
+    if (kk > XAAC_SBR_MAX_NOISE_ENVELOPES) return -1;
+    if (f->border_vec[i] == f->noise_border_vec[kk]) kk++, next++;
+    if (next < 0) return -1; /* the reference would read in front of flt_noise_floor */
+    const int noise_absc = (i == trans_env || i == st->env_short_flag_prev) ? 1 : 0;
+    const int smooth_length = noise_absc ? 0 : smoothing_length;
+    const float *filt = smooth_length ? xaac_esbr_fir_4 : xaac_esbr_fir_0;
+    const int res = f->freq_res[i] ? 1 : 0, nsf = h->num_sf_bands[res];
+    const int16_t *ftab = res ? h->freq_band_tbl_hi : h->freq_band_tbl_lo;
+    const int l0 = 2 * f->border_vec[i], l1 = 2 * f->border_vec[i + 1];
+    /* band -> scale-factor band / noise band map of this envelope (esbr_envcal.c:657-699), lane 0 */
+    XS_ONE {
+      int c = 0, o = 0;
+      for (int j = 0; j < nsf; j++) {
+        const int li = ftab[j], ui = ftab[j + 1];
+        int ui2 = h->freq_band_tbl_noise[o + 1], flag = 0;
+        for (int k = li; k < ui; k++) {
+          const int cc = c + (k - li);
+          if (cc < 64 && w->harmonics[cc] && (i >= trans_env || st->harm_flag_prev[(cc + sb_start) & 63])) flag = 1;
+        }
+        for (int k = 0; k < ui - li; k++) {
+          o = (k + li >= ui2) ? o + 1 : o;
+          if (o >= XAAC_SBR_MAX_NOISE_COEFFS || c >= 64) {
+            w->err = -1;
+            break;
+          }
+          ui2 = h->freq_band_tbl_noise[o + 1];
+          w->sfb_first[c] = (int8_t)(c - k);
+          w->sfb_len[c] = (int8_t)(ui - li);
+          w->flag[c] = (int8_t)flag;
+          w->o_idx[c] = (int8_t)o;
+          w->m_idx[c] = (int16_t)(m + j);
+          c++;
+        }
+        if (w->err) break;
+      }
+      if (c != num_sb) w->err = -1;
+    }
+    cx.sync();
+    if (w->err) return -1;
+    m += nsf;
+    XS_PAR(c, 0, num_sb) { /* band energies */
+      float nrg = 0;
+      const int k = sb_start + c;
+      if (l0 < l1) {
+        for (int l = l0; l < l1; l++) nrg += (x.r(l, k) * x.r(l, k)) + (x.i(l, k) * x.i(l, k));
+        nrg = nrg / (float)(l1 - l0);
+      }
+      w->nrg_est[c] = nrg;
+    }
+    cx.sync();
+    float g_gain[1], g_noise[1], g_tone[1]; /* this lane's band (one band per lane; the host walks them one by one) */
+    (void)g_gain; (void)g_noise; (void)g_tone;
+    XS_PAR(c, 0, num_sb) { /* gains, :690-722 */
+      float est = w->nrg_est[c];
+      if (!int_mode) {
+        float nrg = 0;
+        const int n = w->sfb_len[c], c0 = w->sfb_first[c];
+        for (int k = c0; k < c0 + n; k++) nrg += w->nrg_est[k];
+        est = nrg / (float)n;
+      }
+      const float ref = sd->flt_env_sf_arr[w->m_idx[c]];
+      const float nf = sd->flt_noise_floor[next * num_nf + w->o_idx[c]];
+      const double tmp = nf / (1 + nf + guard);
+      const bool tone_here = w->harmonics[c] && (i >= trans_env || st->harm_flag_prev[(c + sb_start) & 63]);
+      float gain, tone = 0;
+      if (w->flag[c]) {
+        gain = (float)xe_sqrt(ref * tmp / (est + 1));
+        if (tone_here) tone = (float)xe_sqrt(ref * tmp / fabs(nf + guard));
+      } else if (noise_absc) {
+        gain = (float)xe_sqrt(ref / (est + 1));
+      } else {
+        gain = (float)xe_sqrt(ref * tmp / ((est + 1) * fabs(nf + guard)));
+      }
+      w->nrg_ref[c] = ref;
+      w->nrg_gain[c] = gain;
+      w->nrg_tone[c] = tone;
+      w->noise_level[c] = (float)xe_sqrt(ref * tmp);
+      w->pow_lo[c] = est; /* the interpolated estimate, used from here on */
+    }
+    cx.sync();
+    XS_PAR(c, 0, num_sb) w->nrg_est[c] = w->pow_lo[c];
+    cx.sync();
+    XS_PAR(c, 0, st->gate_mode[lim_band]) { /* limiter, one limiter band per lane, :725-761 */
+      const int k0 = st->lim_table[lim_band][c], k1 = st->lim_table[lim_band][c + 1];
+      if (k0 >= 0 && k1 <= 64 && k0 <= k1) {
+        float p_ref = 0, p_est = 0;
+        for (int k = k0; k < k1; k++) {
+          p_ref += w->nrg_ref[k];
+          p_est += w->nrg_est[k];
+        }
+        const float avg_gain = (float)xe_sqrt((p_ref + 1e-12f) / (p_est + 1e-12f));
+        float g_max = avg_gain * xaac_esbr_g_lim_gains[lim_gains];
+        if (g_max > 1.0e5f) g_max = 1.0e5f;
+        for (int k = k0; k < k1; k++)
+          if (g_max <= w->nrg_gain[k]) {
+            w->noise_level[k] = (float)(w->noise_level[k] * (g_max / (w->nrg_gain[k] + guard)));
+            w->nrg_gain[k] = g_max;
+          }
+        float p_adj = 0;
+        for (int k = k0; k < k1; k++) {
+          p_adj += w->nrg_gain[k] * w->nrg_gain[k] * w->nrg_est[k];
+          if (w->nrg_tone[k]) p_adj += w->nrg_tone[k] * w->nrg_tone[k];
+          else if (!noise_absc) p_adj += w->noise_level[k] * w->noise_level[k];
+        }
+        float boost = (float)xe_sqrt((p_ref + 1e-12f) / (p_adj + 1e-12f));
+        boost = boost > 1.584893192f ? 1.584893192f : boost;
+        for (int k = k0; k < k1; k++) {
+          w->nrg_gain[k] *= boost;
+          w->noise_level[k] *= boost;
+          w->nrg_tone[k] *= boost;
+        }
+      }
+    }
+    cx.sync();
+    if (start_up) {
+      XS_PAR(k, 0, num_sb)
+        for (int n = 0; n < 4; n++) {
+          st->e_gain[n][k] = w->nrg_gain[k];
+          st->noise_buf[n][k] = w->noise_level[k];
+        }
+      start_up = 0;
+    }
+    XS_PAR(k, 0, 64) { /* apply: smoothed gain, noise; the two five-deep histories rotate once per slot, :771-817 */
+      float eg[5], nb[5];
+      for (int n = 0; n < 5; n++) {
+        eg[n] = st->e_gain[n][k];
+        nb[n] = st->noise_buf[n][k];
+      }
+      const bool active = k < num_sb;
+      const float gain = active ? w->nrg_gain[k] : 0.0f, nl = active ? w->noise_level[k] : 0.0f;
+      const bool no_noise = active && (w->nrg_tone[k] != 0 || noise_absc);
+      for (int l = l0; l < l1; l++) {
+        if (active) {
+          eg[4] = gain;
+          nb[4] = nl;
+          float sb_gain = 0, sb_noise = 0;
+          int c = 0;
+          for (int n = 4 - smooth_length; n <= 4; n++) {
+            sb_gain += eg[n] * filt[c];
+            sb_noise += nb[n] * filt[c++];
+          }
+          const int ph = (phase_index + (l - l0) * num_sb + k + 1) & 511;
+          if (no_noise) sb_noise = 0;
+          const int kk2 = sb_start + k;
+          x.r(l, kk2) = x.r(l, kk2) * sb_gain + sb_noise * xaac_esbr_random_phase[2 * ph];
+          x.i(l, kk2) = x.i(l, kk2) * sb_gain + sb_noise * xaac_esbr_random_phase[2 * ph + 1];
+        }
+        const float t0 = eg[0], t1 = nb[0];
+        for (int n = 0; n < 4; n++) {
+          eg[n] = eg[n + 1];
+          nb[n] = nb[n + 1];
+        }
+        eg[4] = t0;
+        nb[4] = t1;
+      }
+      for (int n = 0; n < 5; n++) {
+        st->e_gain[n][k] = eg[n];
+        st->noise_buf[n][k] = nb[n];
+      }
+    }
+    phase_index = (phase_index + (l1 > l0 ? (l1 - l0) * num_sb : 0)) & 511;
+    cx.sync();
+    xe_inter_tes(cx, w, low, x, l0, l1 - l0, sb_start, num_sb, sd->inter_temp_shape_mode[i]);
+    XS_PAR(k, 0, num_sb) { /* sinusoids, :833-850 */
+      const float tone = w->nrg_tone[k];
+      const int freq_inv = ((sb_start + k) & 1) ? -1 : 1;
+      int hi = harm_index;
+      const float hp[2][4] = {{1.0f, 0.0f, -1.0f, 0.0f}, {0.0f, 1.0f, 0.0f, -1.0f}};
+      for (int l = l0; l < l1; l++) {
+        x.r(l, sb_start + k) += tone * hp[0][hi];
+        x.i(l, sb_start + k) += tone * (float)freq_inv * hp[1][hi];
+        hi = (hi + 1) & 3;
+      }
+    }
+    if (l1 > l0) harm_index = (harm_index + (l1 - l0)) & 3;
+    cx.sync();
+  }
+  XS_PAR(k, 0, 64) if (k >= sb_start) st->harm_flag_prev[k] = w->harmonics[k - sb_start];
+  XS_ONE {
+    st->env_short_flag_prev = trans_env == num_env ? 0 : -1;
+    st->harm_index = harm_index;
+    st->phase_index = phase_index;
+    st->esbr_start_up = start_up;
+  }
+  cx.sync();
+  return 0;
+}
+
+#endif
