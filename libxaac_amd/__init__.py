@@ -65,6 +65,14 @@ class _QmfSynBatch(ctypes.Structure):
                 ("state", ctypes.c_void_p), ("pcm", ctypes.c_void_p)]
 
 
+class _EsbrSbrBatch(ctypes.Structure):
+    # struct xaac_esbr_sbr_batch (include/xaac_esbr.h)
+    _fields_ = [("n_ch", ctypes.c_int32), ("core", ctypes.c_void_p), ("header", ctypes.c_void_p),
+                ("frame", ctypes.c_void_p), ("side", ctypes.c_void_p), ("state", ctypes.c_void_p),
+                ("out", ctypes.c_void_p), ("status", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
+                ("workspace_bytes", ctypes.c_uint64)]
+
+
 class _HandoverBatch(ctypes.Structure):
     # struct xaac_sbr_handover_batch
     _fields_ = [("n", ctypes.c_int32), ("mode", ctypes.c_int32), ("src", ctypes.c_void_p), ("dst", ctypes.c_void_p),
@@ -173,6 +181,10 @@ def load_library():
     lib.xaac_last_launch.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int32)] * 3
     lib.xaac_qmf_analysis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_QmfAnaBatch)]
     lib.xaac_qmf_synthesis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_QmfSynBatch)]
+    lib.xaac_esbr_workspace_bytes.argtypes = [ctypes.c_int32]
+    lib.xaac_esbr_workspace_bytes.restype = ctypes.c_uint64
+    lib.xaac_esbr_sbr_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_EsbrSbrBatch)]
+    lib.xaac_esbr_sbr_process_batch.restype = ctypes.c_int32
     lib.xaac_sbr_state_handover.argtypes = [ctypes.c_void_p, ctypes.POINTER(_HandoverBatch)]
     lib.xaac_sbr_state_handover.restype = ctypes.c_int32
     lib.xaac_usac_imdct_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_UsacImdctBatch)]
@@ -354,6 +366,29 @@ class XaacContext:
         rc = self._lib.xaac_qmf_synthesis_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_qmf_synthesis_batch")
+
+    def esbr_workspace_bytes(self, n_ch):
+        return int(self._lib.xaac_esbr_workspace_bytes(int(n_ch)))
+
+    def esbr_sbr_process_batch(self, core, header, frame, side, state, out, workspace, status=None):
+        """One frame of every channel through the Path A (eSBR, -esbr:1) branch of ixheaacd_sbr_dec, mono / stereo
+        channels without PS: core float32[n_ch, 1024]; header / frame / side / state uint8 views of the xaac_sbr_header,
+        xaac_sbr_frame, xaac_esbr_side, xaac_esbr_state arrays; out float32[n_ch, 2048]."""
+        n_ch = out.shape[0]
+        b = _EsbrSbrBatch()
+        b.n_ch = n_ch
+        b.core = _ptr(core, "float32", n_ch * 1024, device_ok=True)
+        b.header = _ptr(header, "uint8", n_ch * SBR_HEADER_BYTES, device_ok=True)
+        b.frame = _ptr(frame, "uint8", n_ch * SBR_FRAME_BYTES, device_ok=True)
+        b.side = _ptr(side, "uint8", device_ok=True)
+        b.state = _ptr(state, "uint8", device_ok=True)
+        b.out = _ptr(out, "float32", n_ch * 2048, device_ok=True)
+        b.status = _ptr(status, "int32", n_ch, allow_none=True, device_ok=True)
+        b.workspace = _ptr(workspace, "uint8", device_ok=True)
+        b.workspace_bytes = workspace.numel()
+        rc = self._lib.xaac_esbr_sbr_process_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_esbr_sbr_process_batch")
 
     def sbr_state_handover(self, mode, src, dst, state, ps_state=None):
         """ixheaacd_sbrdecoder.c:762-806 for the listed streams: mode HANDOVER_PS_START (dst indexes ps_state) or

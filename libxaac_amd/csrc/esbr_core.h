@@ -113,6 +113,35 @@ FX_HD int xe_limiter_bands(const xaac_sbr_header *h, xaac_esbr_state *st) {
   return 0;
 }
 
+/* Side info that would index past the boundary structs or the 40-row history (no legal HE-AAC frame does): refused.
+   One lane's worth of integer checks; every lane computes the same answer. */
+FX_HD int xe_side_info_bad(const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd) {
+  int bad = 0;
+  bad |= f->num_env < 1 || f->num_env > XAAC_SBR_MAX_ENVELOPES;
+  bad |= f->num_noise_env < 1 || f->num_noise_env > XAAC_SBR_MAX_NOISE_ENVELOPES;
+  bad |= h->num_sf_bands[0] < 1 || h->num_sf_bands[0] > XAAC_SBR_MAX_FREQ_COEFFS / 2;
+  bad |= h->num_sf_bands[1] < 1 || h->num_sf_bands[1] > XAAC_SBR_MAX_FREQ_COEFFS;
+  bad |= h->num_nf_bands < 1 || h->num_nf_bands > XAAC_SBR_MAX_NOISE_COEFFS;
+  bad |= sd->num_mf_bands < 1 || sd->num_mf_bands > XAAC_SBR_MAX_FREQ_COEFFS;
+  bad |= h->sub_band_start < 1 || h->sub_band_start > 32 || h->sub_band_end < h->sub_band_start || h->sub_band_end > 64;
+  bad |= sd->qmf_sb_prev < 0 || sd->qmf_sb_prev > 32 || sd->out_sampling_freq < 8000;
+  if (bad) return 1;
+  for (int i = 0; i <= f->num_env; i++) bad |= f->border_vec[i] < 0 || f->border_vec[i] > 19;
+  bad |= f->border_vec[f->num_env] < 16; /* rows the synthesis regrouping needs (the reference always has them) */
+  for (int i = 0; i <= f->num_noise_env; i++) bad |= f->noise_border_vec[i] < 0 || f->noise_border_vec[i] > 19;
+  for (int i = 0; i <= h->num_sf_bands[0]; i++) bad |= h->freq_band_tbl_lo[i] < 1 || h->freq_band_tbl_lo[i] > 64;
+  for (int i = 0; i <= h->num_sf_bands[1]; i++) bad |= h->freq_band_tbl_hi[i] < 1 || h->freq_band_tbl_hi[i] > 64;
+  for (int i = 0; i < h->num_sf_bands[0]; i++) bad |= h->freq_band_tbl_lo[i] > h->freq_band_tbl_lo[i + 1];
+  for (int i = 0; i < h->num_sf_bands[1]; i++) bad |= h->freq_band_tbl_hi[i] > h->freq_band_tbl_hi[i + 1];
+  for (int i = 0; i <= h->num_nf_bands; i++) bad |= h->freq_band_tbl_noise[i] < 1 || h->freq_band_tbl_noise[i] > 64;
+  for (int i = 0; i <= sd->num_mf_bands; i++) bad |= sd->f_master_tbl[i] < 1 || sd->f_master_tbl[i] > 64;
+  for (int i = 0; i < sd->num_mf_bands; i++) bad |= sd->f_master_tbl[i] > sd->f_master_tbl[i + 1];
+  bad |= sd->f_master_tbl[0] > h->sub_band_start || sd->f_master_tbl[0] > 32;
+  bad |= h->freq_band_tbl_lo[0] != h->sub_band_start || h->freq_band_tbl_hi[0] != h->sub_band_start;
+  bad |= h->freq_band_tbl_lo[h->num_sf_bands[0]] != h->sub_band_end || h->freq_band_tbl_hi[h->num_sf_bands[1]] != h->sub_band_end;
+  return bad;
+}
+
 /* ---- ixheaacd_generate_hf ---------------------------------------------------------------------------------------- */
 FX_HD int xe_closest_entry(int goal, const int16_t *f, int n) { /* sbrdec_lpfuncs.c:263, direction 0 */
   if (goal <= f[0]) return f[0];
@@ -171,6 +200,10 @@ FX_HD void xe_build_patches(const xaac_sbr_header *h, const xaac_esbr_side *sd, 
           w->err = -1;
           return;
         }
+      }
+      if (k2 - stride < 0 || k2 >= 64) { /* a source band in front of the matrix: the reference would read there */
+        w->err = -1;
+        return;
       }
       w->src_band[k2] = (int16_t)(k2 - stride);
       w->bw_idx[k2] = (int8_t)bw_index;
@@ -441,9 +474,11 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
     cx.sync();
     XS_PAR(c, 0, num_sb) w->nrg_est[c] = w->pow_lo[c];
     cx.sync();
-    XS_PAR(c, 0, st->gate_mode[lim_band]) { /* limiter, one limiter band per lane, :725-761 */
-      const int k0 = st->lim_table[lim_band][c], k1 = st->lim_table[lim_band][c + 1];
-      if (k0 >= 0 && k1 <= 64 && k0 <= k1) {
+    XS_PAR(c, 0, (st->gate_mode[lim_band] < 12 ? st->gate_mode[lim_band] : 12)) { /* limiter, one limiter band per lane, :725-761 */
+      /* a table made for another header (a header change without the reset the parser raises with it) may reach past
+         this frame's bands, where the reference reads whatever its scratch holds; here such a band ends at the last band */
+      const int k0 = st->lim_table[lim_band][c], k1r = st->lim_table[lim_band][c + 1], k1 = k1r < num_sb ? k1r : num_sb;
+      if (k0 >= 0 && k0 <= k1) {
         float p_ref = 0, p_est = 0;
         for (int k = k0; k < k1; k++) {
           p_ref += w->nrg_ref[k];

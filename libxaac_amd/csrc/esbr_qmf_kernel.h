@@ -15,6 +15,7 @@ typedef struct XaacEsbrAnaParams {
   const float *core;            /* [n_ch][1024] */
   xaac_esbr_ana_state *state;   /* [n_ch] */
   float *qmf_re, *qmf_im;       /* [n_ch][32][64]; bands 0..31 written */
+  int32_t state_stride;         /* bytes between consecutive channels' states */
 } XaacEsbrAnaParams;
 
 typedef struct XaacEsbrSynParams {
@@ -22,6 +23,7 @@ typedef struct XaacEsbrSynParams {
   const float *qmf_re, *qmf_im; /* [n_ch][32][64] */
   xaac_esbr_syn_state *state;   /* [n_ch] */
   float *out;                   /* [n_ch][2048] */
+  int32_t state_stride;         /* bytes between consecutive channels' states */
 } XaacEsbrSynParams;
 
 #ifdef __cplusplus

@@ -59,12 +59,12 @@ __global__ __launch_bounds__(64) void xaac_esbr_analysis_kernel(XaacEsbrAnaParam
     const int ch = 2 * pair + c;
     int32_t *h = hist + c * kHist;
     if (ch < p.n_ch) {
-      const xaac_esbr_ana_state *st = p.state + ch;
+      const xaac_esbr_ana_state *st = reinterpret_cast<const xaac_esbr_ana_state *>(reinterpret_cast<const char *>(p.state) + (size_t)ch * p.state_stride);
       int wr = st->pos;
       wr = ((wr % 320 + 320) % 320) & ~31; /* a block start (the position moves by 32 from 0) */
       const float *src = p.core + (size_t)ch * 1024;
       for (int a = lane; a < 288; a += 64) h[287 - a] = st->ring[ring_pos(wr, a)];
-      for (int i = lane; i < 1024; i += 64) h[288 + i] = (int32_t)(src[i] * 32768.0f); /* sbr_dec.c:248 */
+      for (int i = lane; i < 1024; i += 64) h[288 + i] = fx_f2i_trunc(src[i] * 32768.0f); /* sbr_dec.c:248 */
     } else {
       for (int i = lane; i < kHist; i += 64) h[i] = 0;
     }
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64) void xaac_esbr_analysis_kernel(XaacEsbrAnaParam
   for (int c = 0; c < 2; c++) { /* state: the ring as the reference leaves it after 32 slots */
     const int ch = 2 * pair + c;
     if (ch >= p.n_ch) break;
-    xaac_esbr_ana_state *st = p.state + ch;
+    xaac_esbr_ana_state *st = reinterpret_cast<xaac_esbr_ana_state *>(reinterpret_cast<char *>(p.state) + (size_t)ch * p.state_stride);
     int wr = st->pos;
     wr = ((wr % 320 + 320) % 320) & ~31;
     const int wr_new = (wr + 256) % 320;
@@ -139,8 +139,8 @@ __global__ __launch_bounds__(64) void xaac_esbr_synthesis_kernel(XaacEsbrSynPara
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int r = r0 + j, ch = 2 * pair + (r >> 5);
-      rows[RS * r + lane] = ch < p.n_ch ? (int32_t)(tr[j] * 64.0f) : 0;
-      rows[RS * r + 64 + lane] = ch < p.n_ch ? (int32_t)(ti[j] * 64.0f) : 0;
+      rows[RS * r + lane] = ch < p.n_ch ? fx_f2i_trunc(tr[j] * 64.0f) : 0;
+      rows[RS * r + 64 + lane] = ch < p.n_ch ? fx_f2i_trunc(ti[j] * 64.0f) : 0;
     }
   }
   __syncthreads();
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64) void xaac_esbr_synthesis_kernel(XaacEsbrSynPara
     const int ch = 2 * pair + c;
     d_old[c] = 0;
     if (ch >= p.n_ch) continue;
-    const xaac_esbr_syn_state *st = p.state + ch;
+    const xaac_esbr_syn_state *st = reinterpret_cast<const xaac_esbr_syn_state *>(reinterpret_cast<const char *>(p.state) + (size_t)ch * p.state_stride);
     int d = st->drc_offset;
     d = ((d % RING + RING) % RING) & ~127;
     d_old[c] = d;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64) void xaac_esbr_synthesis_kernel(XaacEsbrSynPara
   for (int c = 0; c < 2; c++) { /* state: ring blocks of the last 10 slots, drc offset, window position */
     const int ch = 2 * pair + c;
     if (ch >= p.n_ch) break;
-    xaac_esbr_syn_state *st = p.state + ch;
+    xaac_esbr_syn_state *st = reinterpret_cast<xaac_esbr_syn_state *>(reinterpret_cast<char *>(p.state) + (size_t)ch * p.state_stride);
     const int d_new = (d_old[c] + RING - (32 * 128) % RING) % RING;
     const int f_new = (st->filt_off + 32 * 64) % 640;
     for (int i = lane; i < RING; i += 64) {

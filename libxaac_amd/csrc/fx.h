@@ -106,6 +106,11 @@ FX_HD int32_t fx_shl_dir_sat_limit(int32_t a, int b) {
 FX_HD int32_t fx_shl_dir(int32_t a, int b) { return b < 0 ? fx_shr(a, -b) : fx_shl(a, b); }
 FX_HD int32_t fx_shr_dir(int32_t a, int b) { return b < 0 ? fx_shl(a, -b) : fx_shr(a, b); }
 
+/* (WORD32)v of a float as the reference's x86-64 build computes it (cvttss2si): truncation, and the "integer
+   indefinite" 0x80000000 for NaN and for everything outside int32 -- where C leaves the conversion undefined and the
+   GPU's own conversion would saturate instead */
+FX_HD int32_t fx_f2i_trunc(float v) { return (v >= 2147483648.0f || v < -2147483648.0f || v != v) ? FX_MIN32 : (int32_t)v; }
+
 /* ---- norm -------------------------------------------------------------- */
 /* basic_ops32.h:236-255: redundant sign bits; 0 and -1 give 31 */
 FX_HD int fx_norm32(int32_t a) {

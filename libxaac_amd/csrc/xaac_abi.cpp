@@ -19,6 +19,7 @@
 #include "limiter_kernel.h"
 #include "esbr_qmf_kernel.h"
 #include "usac_imdct_kernel.h"
+#include "esbr_core_kernel.h"
 #include <cmath>
 #include <cstddef>
 #include <cstring>
@@ -250,6 +251,31 @@ int32_t xaac_qmf_synthesis_batch(xaac_ctx *c, const xaac_qmf_syn_batch *b) {
   return XAAC_OK;
 }
 
+uint64_t xaac_esbr_workspace_bytes(int32_t n_ch) { return n_ch > 0 ? (uint64_t)n_ch * XAAC_ESBR_WS_FLOATS * sizeof(float) : 0; }
+
+int32_t xaac_esbr_sbr_process_batch(xaac_ctx *c, const xaac_esbr_sbr_batch *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n_ch < 0) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch == 0) return XAAC_OK;
+  if (!b->core || !b->header || !b->frame || !b->side || !b->state || !b->out || !b->workspace) return XAAC_FATAL_NULL_ARG;
+  if (b->workspace_bytes < xaac_esbr_workspace_bytes(b->n_ch)) return XAAC_FATAL_BAD_ARG;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  const size_t n = (size_t)b->n_ch;
+  float *ws = static_cast<float *>(b->workspace);
+  float *ana_re = ws, *ana_im = ana_re + n * 2048;
+  float *out_re = ana_im + n * 2048, *out_im = out_re + n * XAAC_ESBR_OUT_ROWS * 64;
+  float *syn_re = out_im + n * XAAC_ESBR_OUT_ROWS * 64, *syn_im = syn_re + n * 2048;
+  /* the banks' states are the first two members of xaac_esbr_state: the bank kernels take them at its stride */
+  XaacEsbrAnaParams pa = {b->n_ch, b->core, &b->state->ana, ana_re, ana_im, (int32_t)sizeof(xaac_esbr_state)};
+  if (!hip_ok(xaac_launch_esbr_analysis(&pa, c->stream))) return XAAC_FATAL_HIP;
+  XaacEsbrCoreParams pc = {b->n_ch, b->header, b->frame, b->side, b->state, ana_re, ana_im, out_re, out_im, syn_re, syn_im, b->status};
+  if (!hip_ok(xaac_launch_esbr_core(&pc, c->stream))) return XAAC_FATAL_HIP;
+  XaacEsbrSynParams ps = {b->n_ch, syn_re, syn_im, &b->state->syn, b->out, (int32_t)sizeof(xaac_esbr_state)};
+  if (!hip_ok(xaac_launch_esbr_synthesis(&ps, c->stream))) return XAAC_FATAL_HIP;
+  c->last_grid = b->n_ch; c->last_block = 64; c->last_lds = 0;
+  return XAAC_OK;
+}
+
 int32_t xaac_sbr_state_handover(xaac_ctx *c, const xaac_sbr_handover_batch *b) {
   if (!c || !b) return XAAC_FATAL_NULL_ARG;
   if (b->n < 0 || (b->mode != XAAC_HANDOVER_PS_START && b->mode != XAAC_HANDOVER_STEREO_START)) return XAAC_FATAL_BAD_ARG;
@@ -280,7 +306,7 @@ int32_t xaac_esbr_qmf_analysis_batch(xaac_ctx *c, const xaac_esbr_ana_batch *b) 
   if (b->n_ch == 0) return XAAC_OK;
   if (!b->core || !b->state || !b->qmf_re || !b->qmf_im) return XAAC_FATAL_NULL_ARG;
   if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
-  XaacEsbrAnaParams p = {b->n_ch, b->core, b->state, b->qmf_re, b->qmf_im};
+  XaacEsbrAnaParams p = {b->n_ch, b->core, b->state, b->qmf_re, b->qmf_im, (int32_t)sizeof(xaac_esbr_ana_state)};
   if (!hip_ok(xaac_launch_esbr_analysis(&p, c->stream))) return XAAC_FATAL_HIP;
   c->last_grid = (b->n_ch + 1) / 2; c->last_block = 64; c->last_lds = XAAC_ESBR_ANA_LDS;
   return XAAC_OK;
@@ -292,7 +318,7 @@ int32_t xaac_esbr_qmf_synthesis_batch(xaac_ctx *c, const xaac_esbr_syn_batch *b)
   if (b->n_ch == 0) return XAAC_OK;
   if (!b->qmf_re || !b->qmf_im || !b->state || !b->out) return XAAC_FATAL_NULL_ARG;
   if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
-  XaacEsbrSynParams p = {b->n_ch, b->qmf_re, b->qmf_im, b->state, b->out};
+  XaacEsbrSynParams p = {b->n_ch, b->qmf_re, b->qmf_im, b->state, b->out, (int32_t)sizeof(xaac_esbr_syn_state)};
   if (!hip_ok(xaac_launch_esbr_synthesis(&p, c->stream))) return XAAC_FATAL_HIP;
   c->last_grid = (b->n_ch + 1) / 2; c->last_block = 64; c->last_lds = XAAC_ESBR_SYN_LDS;
   return XAAC_OK;

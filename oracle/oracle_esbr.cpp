@@ -42,9 +42,8 @@ int xo_esbr_sbr_frame(const float *core, const xaac_sbr_header *h, const xaac_sb
   memcpy(ore, st->out_re, sizeof(st->out_re));
   memcpy(oim, st->out_im, sizeof(st->out_im));
   xo_esbr_analysis(core, st->ana.ring, &st->ana.pos, &st->ana.win_off, &qre[XAAC_ESBR_HIST_ROWS][0], &qim[XAAC_ESBR_HIST_ROWS][0]);
-  if (f->apply_processing) {
-    rc = xo_esbr_hf_env(h, f, sd, st, &qre[0][0], &qim[0][0], &ore[0][0], &oim[0][0]);
-    if (rc) return rc;
+  if (f->apply_processing) { /* a refused or failed frame still runs the banks and the history shift, like the kernel */
+    rc = xe_side_info_bad(h, f, sd) ? -1 : xo_esbr_hf_env(h, f, sd, st, &qre[0][0], &qim[0][0], &ore[0][0], &oim[0][0]);
   } else {
     memset(ore, 0, sizeof(ore));
     memset(oim, 0, sizeof(oim));
@@ -64,6 +63,6 @@ int xo_esbr_sbr_frame(const float *core, const xaac_sbr_header *h, const xaac_sb
   memcpy(st->qmf_im, qim + 32, sizeof(st->qmf_im));
   memcpy(st->out_re, ore + 32, sizeof(st->out_re));
   memcpy(st->out_im, oim + 32, sizeof(st->out_im));
-  return 0;
+  return rc;
 }
 }

@@ -212,7 +212,7 @@ void xo_esbr_analysis(const float *core, int32_t *ring, int32_t *pos, int32_t *w
   int p = *pos, w1 = *win_off, w2 = *win_off + 64;
   int f1 = 0, f2 = 32; /* the two ring halves the window-add starts from: reset per call, swapped per slot */
   for (int s = 0; s < 32; s++) {
-    for (int z = 0; z < 32; z++) ring[p + 31 - z] = (int32_t)(core[32 * s + z] * 32768.0f);
+    for (int z = 0; z < 32; z++) ring[p + 31 - z] = fx_f2i_trunc(core[32 * s + z] * 32768.0f);
     int32_t anal[64], sb[128], t[128];
     for (int n = 0; n < 32; n++) {
       int64_t a1 = 0, a2 = 0;
@@ -247,8 +247,8 @@ void xo_esbr_synthesis(const float *re, const float *im, int32_t *ring, int32_t 
   for (int s = 0; s < 32; s++) {
     int32_t x[128], t[128];
     for (int k = 0; k < 64; k++) {
-      x[k] = (int32_t)(re[64 * s + k] * 64);
-      x[64 + k] = (int32_t)(im[64 * s + k] * 64);
+      x[k] = fx_f2i_trunc(re[64 * s + k] * 64);
+      x[64 + k] = fx_f2i_trunc(im[64 * s + k] * 64);
     }
     xq_esbr_synth_slot(x, t, ring + d, 5 + 1);
     for (int k = 0; k < 64; k++) {

@@ -68,6 +68,7 @@ def run_chain(oracle, reference, recs, seed, xover_extra=0, tes=False, n_frames=
     rng = np.random.default_rng(seed)
     st_r, st_o = new_state(), new_state()
     prev_modes = [0] * 10
+    prev_tables = None
     start = int(rng.integers(0, max(1, len(recs) - n_frames)))
     done = 0
     for n, rec in enumerate(recs[start:start + n_frames]):
@@ -83,6 +84,10 @@ def run_chain(oracle, reference, recs, seed, xover_extra=0, tes=False, n_frames=
             for i in range(h.num_sf_bands[1]):
                 f.add_harmonics[i] = int(rng.integers(0, 5) == 0)
         sd = make_side(rng, h, f, prev_modes, n, xover_extra, tes)
+        tables = bytes(h)[12:]                        # a new header comes with a reset (the parser raises reset_flag)
+        if prev_tables != tables:
+            sd.reset_flag = 1
+        prev_tables = tables
         qre, qim = qmf_matrices(rng, float(2.0 ** rng.integers(0, 16)))
         outs = []
         for fn, st in ((ref_fn, st_r), (orc_fn, st_o)):

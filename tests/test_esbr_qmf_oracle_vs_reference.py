@@ -38,7 +38,7 @@ def syn(fn, re, im, ring, drc, filt):
     return out, d.value, f.value
 
 
-@pytest.mark.parametrize("amp", [1.0, 0.05, 1e-4, 0.999])
+@pytest.mark.parametrize("amp", [1.0, 0.05, 1e-4, 0.999, 2e6])  # the last: (WORD32) of values outside int32
 def test_analysis_chain(oracle, reference, amp):
     ra, _ = _bind(reference.lib, "ref")
     oa, _ = _bind(oracle.lib, "xo")
@@ -59,7 +59,7 @@ def test_analysis_chain(oracle, reference, amp):
         assert np.any(rr[:, :32] != 0) and not np.any(rr[:, 32:])
 
 
-@pytest.mark.parametrize("amp", [1.0, 30.0, 1e-3, 4000.0])
+@pytest.mark.parametrize("amp", [1.0, 30.0, 1e-3, 4000.0, 3e8])  # the last: (WORD32) of values outside int32
 def test_synthesis_chain(oracle, reference, amp):
     _, rs = _bind(reference.lib, "ref")
     _, os_ = _bind(oracle.lib, "xo")
