@@ -124,7 +124,7 @@ FX_HD int xe_side_info_bad(const xaac_sbr_header *h, const xaac_sbr_frame *f, co
   bad |= h->num_nf_bands < 1 || h->num_nf_bands > XAAC_SBR_MAX_NOISE_COEFFS;
   bad |= sd->num_mf_bands < 1 || sd->num_mf_bands > XAAC_SBR_MAX_FREQ_COEFFS;
   bad |= h->sub_band_start < 1 || h->sub_band_start > 32 || h->sub_band_end < h->sub_band_start || h->sub_band_end > 64;
-  bad |= sd->qmf_sb_prev < 0 || sd->qmf_sb_prev > 32 || sd->out_sampling_freq < 8000;
+  bad |= sd->qmf_sb_prev < 0 || sd->qmf_sb_prev > 64 || sd->out_sampling_freq < 8000; /* 64: no SBR frame before this one */
   if (bad) return 1;
   for (int i = 0; i <= f->num_env; i++) bad |= f->border_vec[i] < 0 || f->border_vec[i] > 19;
   bad |= f->border_vec[f->num_env] < 16; /* rows the synthesis regrouping needs (the reference always has them) */
@@ -304,6 +304,26 @@ FX_HD void xe_generate_hf(const XsCx &cx, const xaac_sbr_header *h, const xaac_s
     }
   }
   XS_PAR(i, 0, num_if) st->bw_array_prev[i] = w->bw_array[i];
+  cx.sync();
+}
+
+/* sbr_dec.c:866-872: with the harmonic-transposer flag set -- which the reference sets for every non-USAC stream it
+   decodes with eSBR on (sbrdecoder.c:399-403) -- rows 2..7 of the shifted qmf_buf lose what lies above the previous
+   frame's cross-over band.  The reference's memset counts BYTES where it means floats: (64 - qmf_sb_prev) bytes from band
+   qmf_sb_prev on, i.e. a quarter of the bands, and for a count that is not a multiple of four the low bytes of one more
+   float.  Restated to the byte.  (Nothing reads these cells unless the cross-over band moves up between frames.) */
+FX_HD void xe_hbe_history_clear(const XsCx &cx, xaac_esbr_state *st, int qmf_sb_prev) {
+  const int bytes = 64 - qmf_sb_prev, full = bytes >> 2, rem = bytes & 3;
+  XS_PAR(k, 0, 64) {
+    if (k >= qmf_sb_prev && k < qmf_sb_prev + full + (rem ? 1 : 0)) {
+      const uint32_t keep = k < qmf_sb_prev + full ? 0u : ~((1u << (8 * rem)) - 1u);
+      for (int r = 2; r < 8; r++) {
+        uint32_t *a = reinterpret_cast<uint32_t *>(&st->qmf_re[r][k]), *b = reinterpret_cast<uint32_t *>(&st->qmf_im[r][k]);
+        *a &= keep;
+        *b &= keep;
+      }
+    }
+  }
   cx.sync();
 }
 

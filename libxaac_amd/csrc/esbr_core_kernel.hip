@@ -35,6 +35,7 @@ __global__ __launch_bounds__(64) void xaac_esbr_core_kernel(XaacEsbrCoreParams p
     oim[i] = hist ? (&st->out_im[0][0])[i] : 0.0f;
   }
   __syncthreads();
+  if (sd->qmf_sb_prev >= 0 && sd->qmf_sb_prev <= 64) xe_hbe_history_clear(cx, st, sd->qmf_sb_prev);
   const XeMat src = {&st->qmf_re[0][0] + 128, &st->qmf_im[0][0] + 128}, dst = {ore + 128, oim + 128};
   if (apply && rc == 0) {
     xe_generate_hf(cx, h, f, sd, st, &w, src, dst);

@@ -33,6 +33,10 @@ int xo_esbr_sbr_frame(const float *core, const xaac_sbr_header *h, const xaac_sb
   static thread_local float qre[XAAC_ESBR_ROWS][64], qim[XAAC_ESBR_ROWS][64], ore[42][64], oim[42][64];
   static thread_local float rre[32][64], rim[32][64];
   int rc = 0;
+  if (sd->qmf_sb_prev >= 0 && sd->qmf_sb_prev <= 64) {
+    const XsCx cx = {0, 1};
+    xe_hbe_history_clear(cx, st, sd->qmf_sb_prev);
+  }
   memcpy(qre, st->qmf_re, sizeof(st->qmf_re));
   memcpy(qim, st->qmf_im, sizeof(st->qmf_im));
   memset(qre + XAAC_ESBR_HIST_ROWS, 0, sizeof(float) * 32 * 64);

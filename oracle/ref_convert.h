@@ -280,4 +280,81 @@ static void from_ps_state(const xaac_ps_state *o, ia_ps_dec_struct *ps, ia_sbr_q
   sf_r->hb_scale = o->hb_scale_r;
 }
 
-#endif /* XAAC_REF_CONVERT_H */
+/* ---- Path A (eSBR): include/xaac_esbr.h <-> the members ixheaacd_sbr_dec's enh_sbr branch works on ----------------- */
+#include "xaac_esbr.h"
+
+static void to_esbr_side(const ia_sbr_header_data_struct *h, const ia_sbr_frame_info_data_struct *f, xaac_esbr_side *o) {
+  const ia_freq_band_data_struct *fb = h->pstr_freq_band_data;
+  int i;
+  memset(o, 0, sizeof(*o));
+  o->out_sampling_freq = h->out_sampling_freq;
+  o->limiter_bands = h->limiter_bands;
+  o->num_mf_bands = fb->num_mf_bands;
+  memcpy(o->f_master_tbl, fb->f_master_tbl, sizeof(o->f_master_tbl));
+  o->qmf_sb_prev = fb->qmf_sb_prev;
+  o->reset_flag = (int16_t)f->reset_flag;
+  for (i = 0; i < XAAC_SBR_MAX_NOISE_VALUES; i++) o->sbr_invf_mode_prev[i] = f->sbr_invf_mode_prev[i];
+  for (i = 0; i < XAAC_SBR_MAX_ENVELOPES; i++) o->inter_temp_shape_mode[i] = f->inter_temp_shape_mode[i];
+  memcpy(o->flt_env_sf_arr, f->flt_env_sf_arr, sizeof(o->flt_env_sf_arr));
+  memcpy(o->flt_noise_floor, f->flt_noise_floor, sizeof(o->flt_noise_floor));
+}
+
+/* the state as the call finds it: this library's rows 0.. are the rows the reference is about to move down from row 32 */
+static void to_esbr_state(const ia_sbr_dec_struct *d, const ia_sbr_header_data_struct *h,
+                          const ia_sbr_frame_info_data_struct *f, xaac_esbr_state *o) {
+  const ia_sbr_qmf_filter_bank_struct *a = &d->str_codec_qmf_bank, *s = &d->str_synthesis_qmf_bank;
+  int i;
+  memset(o, 0, sizeof(*o));
+  memcpy(o->ana.ring, a->anal_filter_states_32, sizeof(o->ana.ring));
+  o->ana.pos = (int32_t)(a->state_new_samples_pos_low_32 - a->anal_filter_states_32);
+  o->ana.win_off = (int32_t)(a->filter_pos_32 - a->analy_win_coeff_32);
+  memcpy(o->syn.ring, s->filter_states_32, sizeof(o->syn.ring));
+  o->syn.drc_offset = s->ixheaacd_drc_offset;
+  o->syn.filt_off = (int32_t)(s->filter_pos_syn_32 - s->p_filter_32);
+  memcpy(o->qmf_re, d->qmf_buf_real[32], sizeof(o->qmf_re));
+  memcpy(o->qmf_im, d->qmf_buf_imag[32], sizeof(o->qmf_im));
+  memcpy(o->out_re, d->sbr_qmf_out_real[32], sizeof(o->out_re));
+  memcpy(o->out_im, d->sbr_qmf_out_imag[32], sizeof(o->out_im));
+  memcpy(o->bw_array_prev, f->bw_array_prev, sizeof(o->bw_array_prev));
+  memcpy(o->e_gain, f->e_gain, sizeof(o->e_gain));
+  memcpy(o->noise_buf, f->noise_buf, sizeof(o->noise_buf));
+  memcpy(o->lim_table, f->lim_table, sizeof(o->lim_table));
+  memcpy(o->gate_mode, f->gate_mode, sizeof(o->gate_mode));
+  o->harm_index = f->harm_index;
+  o->phase_index = f->phase_index;
+  o->esbr_start_up = h->esbr_start_up;
+  o->env_short_flag_prev = f->env_short_flag_prev;
+  o->num_patches = f->patch_param.num_patches;
+  for (i = 0; i <= XAAC_SBR_MAX_PATCHES; i++) o->patch_start_subband[i] = f->patch_param.start_subband[i];
+  memcpy(o->harm_flag_prev, f->harm_flag_prev, sizeof(o->harm_flag_prev));
+}
+
+static void from_esbr_state(const xaac_esbr_state *o, ia_sbr_dec_struct *d, ia_sbr_header_data_struct *h,
+                            ia_sbr_frame_info_data_struct *f) {
+  ia_sbr_qmf_filter_bank_struct *a = &d->str_codec_qmf_bank, *s = &d->str_synthesis_qmf_bank;
+  int i;
+  memcpy(a->anal_filter_states_32, o->ana.ring, sizeof(o->ana.ring));
+  a->state_new_samples_pos_low_32 = a->anal_filter_states_32 + o->ana.pos;
+  a->filter_pos_32 = a->analy_win_coeff_32 + o->ana.win_off;
+  memcpy(s->filter_states_32, o->syn.ring, sizeof(o->syn.ring));
+  s->ixheaacd_drc_offset = o->syn.drc_offset;
+  s->filter_pos_syn_32 = (WORD32 *)s->p_filter_32 + o->syn.filt_off;
+  memcpy(d->qmf_buf_real[32], o->qmf_re, sizeof(o->qmf_re));
+  memcpy(d->qmf_buf_imag[32], o->qmf_im, sizeof(o->qmf_im));
+  memcpy(d->sbr_qmf_out_real[32], o->out_re, sizeof(o->out_re));
+  memcpy(d->sbr_qmf_out_imag[32], o->out_im, sizeof(o->out_im));
+  memcpy(f->bw_array_prev, o->bw_array_prev, sizeof(o->bw_array_prev));
+  memcpy(f->e_gain, o->e_gain, sizeof(o->e_gain));
+  memcpy(f->noise_buf, o->noise_buf, sizeof(o->noise_buf));
+  memcpy(f->lim_table, o->lim_table, sizeof(o->lim_table));
+  memcpy(f->gate_mode, o->gate_mode, sizeof(o->gate_mode));
+  f->harm_index = o->harm_index;
+  f->phase_index = o->phase_index;
+  h->esbr_start_up = o->esbr_start_up;
+  f->env_short_flag_prev = o->env_short_flag_prev;
+  f->patch_param.num_patches = o->num_patches;
+  for (i = 0; i <= XAAC_SBR_MAX_PATCHES; i++) f->patch_param.start_subband[i] = o->patch_start_subband[i];
+  memcpy(f->harm_flag_prev, o->harm_flag_prev, sizeof(o->harm_flag_prev));
+}
+
+#endif

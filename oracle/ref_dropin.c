@@ -34,8 +34,12 @@ static struct {
   int32_t *status;
   void *ws;
   uint64_t ws_bytes;
+  float *core, *time;          /* Path A: time_sample_buf in / out */
+  xaac_esbr_side *side;
+  xaac_esbr_state *estate;
+  void *ews;
 } g;
-static long g_imdct_calls, g_sbr_calls, g_lim_calls;
+static long g_imdct_calls, g_sbr_calls, g_lim_calls, g_esbr_calls;
 
 static void die(const char *what) {
   fprintf(stderr, "xaacdec_dropin: %s failed\n", what);
@@ -46,6 +50,7 @@ static void die(const char *what) {
 static void report(void) {
   fprintf(stderr, "xaacdec_dropin: %ld imdct_process and %ld sbr_dec calls ran on the GPU\n", g_imdct_calls, g_sbr_calls);
   fprintf(stderr, "xaacdec_dropin: %ld peak_limiter_process calls ran on the GPU\n", g_lim_calls);
+  fprintf(stderr, "xaacdec_dropin: %ld sbr_dec calls took the eSBR (Path A) branch on the GPU\n", g_esbr_calls);
 }
 
 static void setup(void) {
@@ -70,7 +75,19 @@ static void setup(void) {
   b = xaac_sbr_hq_workspace_bytes(1, 1);
   g.ws_bytes = a > b ? a : b;
   HIP(hipMalloc(&g.ws, g.ws_bytes));
+  HIP(hipMalloc((void **)&g.core, 4096));
+  HIP(hipMalloc((void **)&g.time, 8192));
+  HIP(hipMalloc((void **)&g.side, sizeof(xaac_esbr_side)));
+  HIP(hipMalloc((void **)&g.estate, sizeof(xaac_esbr_state)));
+  HIP(hipMalloc(&g.ews, xaac_esbr_workspace_bytes(1)));
   atexit(report);
+}
+
+/* developer aid: the numeric code behind the command-line tool's "error unlisted" */
+int __real_ixheaacd_error_handler(void *info, char *context, int code);
+int __wrap_ixheaacd_error_handler(void *info, char *context, int code) {
+  if (code && getenv("XAAC_DROPIN_DEBUG")) fprintf(stderr, "xaacdec_dropin: error code 0x%08x\n", (unsigned)code);
+  return __real_ixheaacd_error_handler(info, context, code);
 }
 
 /* ---- seam 1: ixheaacd_imdct_process (core AAC back-end, 1024-sample frames) ------------------------- */
@@ -86,7 +103,7 @@ VOID __wrap_ixheaacd_imdct_process(ia_aac_dec_overlap_info *oi, WORD32 *spec, ia
   static int32_t tmp[1024];
   int8_t q;
   int i;
-  if (ics->frame_length != 1024 || ld_mps_present || object_type == AOT_ER_AAC_LD || object_type == AOT_ER_AAC_ELD) {
+  if (getenv("XAAC_DROPIN_PASS_IMDCT") || ics->frame_length != 1024 || ld_mps_present || object_type == AOT_ER_AAC_LD || object_type == AOT_ER_AAC_ELD) {
     __real_ixheaacd_imdct_process(oi, spec, ics, out, ch_fac, scratch, tabs, object_type, ld_mps_present, slot_element);
     return;
   }
@@ -114,6 +131,20 @@ VOID __wrap_ixheaacd_imdct_process(ia_aac_dec_overlap_info *oi, WORD32 *spec, ia
   HIP(hipMemcpy(oi->ptr_overlap_buf, g.overlap, 2048, hipMemcpyDeviceToHost));
   HIP(hipMemcpy(&hs, g.ovl_state, sizeof(hs), hipMemcpyDeviceToHost));
   HIP(hipMemcpy(&q, g.qadj, 1, hipMemcpyDeviceToHost));
+  if (getenv("XAAC_DROPIN_CHECK")) { /* developer aid: the reference's own function beside the GPU's answer */
+    static int32_t ovl_gpu[512];
+    int bad_out = 0, bad_ovl = 0;
+    HIP(hipMemcpy(ovl_gpu, g.overlap, 2048, hipMemcpyDeviceToHost));
+    __real_ixheaacd_imdct_process(oi, spec, ics, out, ch_fac, scratch, tabs, object_type, ld_mps_present, slot_element);
+    for (i = 0; i < 1024; i++) bad_out += ((WORD32 *)out)[i * ch_fac] != tmp[i];
+    for (i = 0; i < 512; i++) bad_ovl += oi->ptr_overlap_buf[i] != ovl_gpu[i];
+    if (bad_out || bad_ovl || ics->qshift_adj != q)
+      fprintf(stderr, "xaacdec_dropin: imdct call %ld differs: out %d overlap %d q %d/%d (seq %d shape %d prev %d %d ch_fac %d)\n",
+              g_imdct_calls, bad_out, bad_ovl, (int)ics->qshift_adj, (int)q, hi.window_sequence, hi.window_shape,
+              hs.window_sequence, hs.window_shape, (int)ch_fac);
+    g_imdct_calls++;
+    return;
+  }
   for (i = 0; i < 1024; i++) ((WORD32 *)out)[i * ch_fac] = tmp[i];
   oi->window_sequence = hs.window_sequence;
   oi->window_shape = hs.window_shape;
@@ -145,11 +176,82 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
   const int with_ps = !low_pow && ps && h->channel_mode == PS_STEREO;
   const int ps_on = with_ps && apply;
   int i, rc;
-  /* outside the path this library covers (float eSBR, LD/ELD, DRC inside the bank, MPS): the reference's own code */
+  /* the reference's default path (-esbr:1) on HE-AAC mono / stereo channels: Path A on the GPU.  (For such streams the
+     reference also runs its QMF harmonic transposer every frame -- hbe_flag is forced on, sbrdecoder.c:399-403 -- but
+     with sbr_patching_mode 1 nothing reads what it produces: ixheaacd_generate_hf takes the LPP branch.)  Everything the branch
+     at sbr_dec.c:816-1009 does for such a channel -- history shift, analysis, HF generator, envelope adjuster,
+     regrouping, synthesis -- is one xaac_esbr_sbr_process_batch call; the state lives in the reference's structs
+     between calls (to_esbr_state / from_esbr_state) */
+  if (h->enh_sbr && aot != AOT_ER_AAC_ELD && aot != AOT_ER_AAC_LD && !h->usac_flag && h->hbe_flag && f->sbr_patching_mode == 1 &&
+      !h->enh_sbr_ps &&
+      h->channel_mode != PS_STEREO && !drc_on && !ldmps && !mps && !f->mps_sbr_flag && f->sbr_mode != PVC_SBR &&
+      h->sbr_ratio_idx != SBR_UPSAMPLE_IDX_4_1 && !h->pre_proc_flag && h->num_time_slots == 16 &&
+      d->str_codec_qmf_bank.no_channels == 32 && d->str_synthesis_qmf_bank.no_channels == 64 && !getenv("XAAC_DROPIN_NO_ESBR")) {
+    static xaac_esbr_side sd;
+    static xaac_esbr_state est;
+    xaac_esbr_sbr_batch b;
+    const ia_qmf_dec_tables_struct *q = tabs->qmf_dec_tables_ptr;
+    setup();
+    /* the pointer re-basing ixheaacd_esbr_synthesis_filt_block does on entry (sbr_dec.c:578-580) */
+    d->str_synthesis_qmf_bank.filter_pos_syn_32 += q->esbr_qmf_c - d->str_synthesis_qmf_bank.p_filter_32;
+    d->str_synthesis_qmf_bank.p_filter_32 = q->esbr_qmf_c;
+    to_header(h, d, &hd);
+    to_frame(f, apply, &fr);
+    to_esbr_side(h, f, &sd);
+    to_esbr_state(d, h, f, &est);
+    HIP(hipMemcpy(g.hdr, &hd, sizeof(hd), hipMemcpyHostToDevice));
+    HIP(hipMemcpy(g.frame, &fr, sizeof(fr), hipMemcpyHostToDevice));
+    HIP(hipMemcpy(g.side, &sd, sizeof(sd), hipMemcpyHostToDevice));
+    HIP(hipMemcpy(g.estate, &est, sizeof(est), hipMemcpyHostToDevice));
+    HIP(hipMemcpy(g.core, d->time_sample_buf, 4096, hipMemcpyHostToDevice));
+    memset(&b, 0, sizeof(b));
+    b.n_ch = 1;
+    b.core = g.core;
+    b.header = g.hdr;
+    b.frame = g.frame;
+    b.side = g.side;
+    b.state = g.estate;
+    b.out = g.time;
+    b.status = g.status;
+    b.workspace = g.ews;
+    b.workspace_bytes = xaac_esbr_workspace_bytes(1);
+    if (xaac_esbr_sbr_process_batch(g_ctx, &b) != XAAC_OK || xaac_sync(g_ctx) != XAAC_OK) die("xaac_esbr_sbr_process_batch");
+    HIP(hipMemcpy(&status, g.status, 4, hipMemcpyDeviceToHost));
+    if (status && getenv("XAAC_DROPIN_DEBUG")) {
+      fprintf(stderr, "xaacdec_dropin: eSBR frame refused: apply %d num_env %d noise_env %d borders %d %d %d nsf %d %d nnf %d nmf %d "
+              "sb %d %d qsp %d fs %d fm0 %d lo0 %d hi0 %d loN %d hiN %d\n", fr.apply_processing, fr.num_env, fr.num_noise_env,
+              fr.border_vec[0], fr.border_vec[1], fr.border_vec[fr.num_env], hd.num_sf_bands[0], hd.num_sf_bands[1], hd.num_nf_bands,
+              sd.num_mf_bands, hd.sub_band_start, hd.sub_band_end, sd.qmf_sb_prev, sd.out_sampling_freq, sd.f_master_tbl[0],
+              hd.freq_band_tbl_lo[0], hd.freq_band_tbl_hi[0], hd.freq_band_tbl_lo[hd.num_sf_bands[0]], hd.freq_band_tbl_hi[hd.num_sf_bands[1]]);
+    }
+    if (status) return status;
+    HIP(hipMemcpy(&est, g.estate, sizeof(est), hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(d->time_sample_buf, g.time, 8192, hipMemcpyDeviceToHost));
+    from_esbr_state(&est, d, h, f);
+    /* what the branch leaves behind for the parser and the next call (sbr_dec.c:962-966, :657, :1006) */
+    d->band_count = h->pstr_freq_band_data->sub_band_end;
+    f->reset_flag = 0;
+    f->prev_sbr_mode = f->sbr_mode;
+    g_esbr_calls++;
+    return 0;
+  }
+  if (h->enh_sbr && getenv("XAAC_DROPIN_DEBUG")) {
+    static int once;
+    if (once++ < 6)
+      fprintf(stderr, "xaacdec_dropin: eSBR call not taken: aot %d usac %d hbe %d enh_ps %d chmode %d drc %d ldmps %d mps %d mps_sbr %d "
+              "sbr_mode %d ratio %d preproc %d slots %d ana %d syn %d patching %d\n", (int)aot, (int)h->usac_flag, (int)h->hbe_flag,
+              (int)h->enh_sbr_ps, (int)h->channel_mode, (int)drc_on, (int)ldmps, (int)mps, (int)f->mps_sbr_flag, (int)f->sbr_mode,
+              (int)h->sbr_ratio_idx, (int)h->pre_proc_flag, (int)h->num_time_slots, (int)d->str_codec_qmf_bank.no_channels,
+              (int)d->str_synthesis_qmf_bank.no_channels, (int)f->sbr_patching_mode);
+  }
+  /* outside the paths this library covers (USAC / PS / HBE eSBR, LD/ELD, DRC inside the bank, MPS): the reference's own code */
   if (h->enh_sbr || aot == AOT_ER_AAC_ELD || aot == AOT_ER_AAC_LD || drc_on || ldmps || mps ||
-      h->num_time_slots * h->time_step != 32)
-    return __real_ixheaacd_sbr_dec(d, time_data, h, f, p, ps, synth_r, sf_r, apply, low_pow, work, tabs, common, ch_fac,
-                                   pvc, drc_on, drc, aot, ldmps, self, mps, ec);
+      h->num_time_slots * h->time_step != 32) {
+    rc = __real_ixheaacd_sbr_dec(d, time_data, h, f, p, ps, synth_r, sf_r, apply, low_pow, work, tabs, common, ch_fac,
+                                 pvc, drc_on, drc, aot, ldmps, self, mps, ec);
+    if (rc && getenv("XAAC_DROPIN_DEBUG")) fprintf(stderr, "xaacdec_dropin: the reference's own ixheaacd_sbr_dec returned %d\n", rc);
+    return rc;
+  }
   setup();
   to_header(h, d, &hd);
   to_frame(f, apply, &fr);

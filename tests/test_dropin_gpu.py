@@ -15,8 +15,8 @@ REF = os.path.join(ROOT, "oracle", "_ref")
 STREAMS = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "streams", "*.aac")))
 
 
-def _decode(binary, aac, out, extra=()):
-    p = subprocess.run([os.path.join(REF, binary), "-ifile:" + aac, "-ofile:" + out, "-esbr:0", *extra],
+def _decode(binary, aac, out, extra=("-esbr:0",), env=None):
+    p = subprocess.run([os.path.join(REF, binary), "-ifile:" + aac, "-ofile:" + out, *extra], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     return p.stderr.decode(errors="replace")
 
@@ -39,6 +39,26 @@ def test_reference_decoder_with_gpu_back_end_is_byte_identical(aac, tmp_path):
         assert m and int(m.group(1)) > 30, log[-400:]
     a, b = open(ref_wav, "rb").read(), open(gpu_wav, "rb").read()
     assert len(a) > 100000 and a == b, (len(a), len(b), n_imdct, n_sbr)
+
+
+@pytest.mark.parametrize("aac", [s for s in STREAMS if "aot5_" in s], ids=lambda s: os.path.basename(s))
+def test_default_flags_he_aac_takes_the_esbr_path_on_the_gpu(aac, tmp_path):
+    """HE-AAC v1 with the reference's DEFAULT flags (-esbr:1): ixheaacd_sbr_dec's Path A branch -- 32-bit analysis bank,
+    float HF generator and envelope adjuster, 64-band synthesis -- runs on the GPU (xaac_esbr_sbr_process_batch) and the
+    decoded file is byte-identical to the unmodified reference decoder's."""
+    if not (os.path.exists(os.path.join(REF, "xaacdec")) and os.path.exists(os.path.join(REF, "xaacdec_dropin"))):
+        pytest.skip("oracle/_ref/xaacdec[_dropin] missing (built by oracle/Makefile.ref where /root/reference exists)")
+    ref_wav, gpu_wav = str(tmp_path / "ref.wav"), str(tmp_path / "gpu.wav")
+    _decode("xaacdec", aac, ref_wav, extra=())
+    log = _decode("xaacdec_dropin", aac, gpu_wav, extra=())
+    m = re.search(r"(\d+) sbr_dec calls took the eSBR \(Path A\) branch on the GPU", log)
+    assert m and int(m.group(1)) > 30, log[-600:]
+    a, b = open(ref_wav, "rb").read(), open(gpu_wav, "rb").read()
+    assert len(a) > 100000 and a == b, (len(a), len(b), int(m.group(1)))
+    # and it is a different decode from the fixed-point path the other tests pin
+    fix_wav = str(tmp_path / "fix.wav")
+    _decode("xaacdec", aac, fix_wav)
+    assert open(fix_wav, "rb").read() != a
 
 
 def test_streams_present():

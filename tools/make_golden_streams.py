@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build tests/golden/streams/*.aac: three short ADTS streams (AAC-LC stereo, HE-AACv1 stereo, HE-AACv2) encoded by
+"""Build tests/golden/streams/*.aac: four short ADTS streams (AAC-LC stereo, HE-AACv1 stereo and mono, HE-AACv2) encoded by
 the reference encoder (oracle/_ref/xaacenc) from a synthetic signal with clicks (short blocks, multi-envelope SBR
 frames), a harmonic stack (sinusoidal coding) and level steps.  Data fixtures for tests/test_dropin_gpu.py."""
 import os
@@ -28,6 +28,13 @@ def main():
         subprocess.run([os.path.join(REF, "xaacenc"), "-ifile:" + wav, "-ofile:" + aac, "-aot:%d" % aot, "-br:%d" % br,
                         "-adts:1"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
         print(aac, os.path.getsize(aac))
+    # a mono HE-AAC stream: the single-channel-element flavour of the SBR paths (one ixheaacd_sbr_dec call per frame)
+    wav = "/tmp/xaac_golden_mono.wav"
+    m.write_wav(wav, x[:, :1])
+    aac = os.path.join(out, "mono_aot5_32k.aac")
+    subprocess.run([os.path.join(REF, "xaacenc"), "-ifile:" + wav, "-ofile:" + aac, "-aot:5", "-br:32000", "-adts:1"],
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    print(aac, os.path.getsize(aac))
 
 
 if __name__ == "__main__":
