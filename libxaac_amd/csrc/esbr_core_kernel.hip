@@ -6,7 +6,9 @@
  * Mapping: one wave = one channel-frame, lane = QMF band.  The path works 38 slots behind the analysis bank (op_delay 6 +
  * the 32 slots the reference reserves for its harmonic transposer), so the HF generator reads the channel's 40-row
  * history straight from its state; this frame's analysis rows only enter the history at the end.  sbr_qmf_out lives in a
- * 42-row global scratch (L2-resident while the wave works on it), the per-band vectors in LDS.
+ * 42-row global scratch (L2-resident while the wave works on it), the per-band vectors in LDS: the stages are chains of
+ * short dependent loops, so what the kernel needs is many resident waves -- with the matrix in LDS (21.5 KB, 6 waves per
+ * CU) the same code measured 1.35x slower than with 4 KB of LDS and 24 waves per CU reading the matrix through L2.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -19,46 +19,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PF = ctypes.POINTER(ctypes.c_float)
 
 
-def _debug_dump(oracle, ws, n, ch, h, f, sd, st):
-    """where the kernel's sbr_qmf_out scratch differs from the oracle's (developer aid, XAAC_DEBUG_ESBR=1)"""
-    w = ws.cpu().numpy().view(np.float32)
-    o0 = 2 * n * 2048
-    g_re = w[o0 + ch * 42 * 64: o0 + (ch + 1) * 42 * 64].reshape(42, 64)
-    fn = oracle.lib.xo_esbr_hf_env
-    fn.restype = ctypes.c_int
-    fn.argtypes = [ctypes.c_void_p] * 4 + [PF] * 4
-    qre = np.zeros((72, 64), np.float32); qim = np.zeros((72, 64), np.float32)
-    qre[:40] = np.ctypeslib.as_array(st.qmf_re); qim[:40] = np.ctypeslib.as_array(st.qmf_im)
-    ore = np.zeros((72, 64), np.float32); oim = np.zeros((72, 64), np.float32)
-    ore[:8] = np.ctypeslib.as_array(st.out_re); oim[:8] = np.ctypeslib.as_array(st.out_im)
-    fn(ctypes.byref(h), ctypes.byref(f), ctypes.byref(sd), ctypes.byref(st), qre.ctypes.data_as(PF), qim.ctypes.data_as(PF),
-       ore.ctypes.data_as(PF), oim.ctypes.data_as(PF))
-    o1 = o0 + n * 42 * 64
-    g_im = w[o1 + ch * 42 * 64: o1 + (ch + 1) * 42 * 64].reshape(42, 64)
-    di = np.argwhere(oim[:42].view(np.uint32) != g_im.view(np.uint32))
-    print("DEBUG im differing", len(di), di[:8].tolist(), [(float(oim[r, k]), float(g_im[r, k])) for r, k in di[:4]])
-    o2 = o1 + n * 42 * 64
-    g_sre = w[o2 + ch * 2048: o2 + (ch + 1) * 2048].reshape(32, 64)
-    stop = 2 * f.border_vec[0]
-    want = np.zeros((32, 64), np.float32)
-    for i in range(32):
-        xo = sd.qmf_sb_prev if i < stop else h.sub_band_start
-        want[i, :xo] = qre[2 + i, :xo]
-        want[i, xo:] = ore[2 + i, xo:]
-    dr = np.argwhere(want.view(np.uint32) != g_sre.view(np.uint32))
-    print("DEBUG regrouped re differing", len(dr), dr[:8].tolist(), [(float(want[r, k]), float(g_sre[r, k])) for r, k in dr[:4]])
-    d = np.argwhere(ore[:42].view(np.uint32) != g_re.view(np.uint32))
-    print("DEBUG ch", ch, "sb", h.sub_band_start, h.sub_band_end, "num_env", f.num_env, [f.border_vec[i] for i in range(f.num_env + 1)],
-          "reset", sd.reset_flag, "interp", h.interpol_freq, "smooth", h.smoothing_mode, "limb", sd.limiter_bands, "trans", f.transient_env)
-    print("DEBUG differing cells", len(d), "rows", sorted(set(d[:, 0].tolist()))[:40], "bands", sorted(set(d[:, 1].tolist())))
-    print("DEBUG patches", st.num_patches, list(st.patch_start_subband), "noise tbl", list(h.freq_band_tbl_noise), "lim", list(st.lim_table[sd.limiter_bands]),
-          "gate", list(st.gate_mode), "fmaster", list(sd.f_master_tbl)[:sd.num_mf_bands + 1], "fs", sd.out_sampling_freq)
-    print("DEBUG harm", [i for i in range(h.num_sf_bands[1]) if f.add_harmonics[i]], "hi", list(h.freq_band_tbl_hi)[:h.num_sf_bands[1] + 1],
-          "res", list(f.freq_res)[:f.num_env], "invf", list(f.sbr_invf_mode)[:5], list(sd.sbr_invf_mode_prev)[:5], "limg", h.limiter_gains)
-    for r, k in d[:6]:
-        print("DEBUG", r, k, ore[r, k], g_re[r, k])
-
-
 @pytest.mark.gpu
 def test_chain_vs_oracle(oracle):
     import torch
@@ -108,7 +68,6 @@ def test_chain_vs_oracle(oracle):
         o_g, s_g, rc_g = out.cpu().numpy(), st_g.cpu().numpy(), status.cpu().numpy()
         for ch in range(n):
             o = np.zeros(2048, np.float32)
-            st_before = EsbrState.from_buffer_copy(bytes(st_o[ch]))
             rc = fn(core[ch].ctypes.data_as(PF), ctypes.byref(hs[ch]), ctypes.byref(fs[ch]), ctypes.byref(sds[ch]),
                     ctypes.byref(st_o[ch]), o.ctypes.data_as(PF))
             assert rc == rc_g[ch], (fr, ch, rc, rc_g[ch])
@@ -118,8 +77,6 @@ def test_chain_vs_oracle(oracle):
                 continue
             assert rc == 0
             bad = np.nonzero(o.view(np.uint32) != o_g[ch].view(np.uint32))[0]
-            if bad.size and os.environ.get("XAAC_DEBUG_ESBR"):
-                _debug_dump(oracle, ws, n, ch, hs[ch], fs[ch], sds[ch], st_before)
             assert bad.size == 0, (fr, ch, bad[:5], o[bad[:3]], o_g[ch][bad[:3]])
             if not np.array_equal(np.frombuffer(bytes(st_o[ch]), np.uint8), s_g[ch]):
                 g = EsbrState.from_buffer_copy(s_g[ch].tobytes())

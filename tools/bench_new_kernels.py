@@ -53,6 +53,29 @@ def main():
     res.append(("esbr_qmf_analysis", us, n * (4096 + 2 * 1288 + 2 * 4096)))   # core in, ring in/out, 32 bands re+im out
     us = timed(torch, ctx, lambda: ctx.esbr_qmf_synthesis_batch(re, im, ss, pcm))
     res.append(("esbr_qmf_synthesis", us, n * (2 * 8192 + 2 * 5128 + 8192)))  # rows in, ring in/out, samples out
+    # the whole Path A chain (analysis -> HF generator + envelope adjuster -> synthesis) on side info walked from the
+    # captured HE-AAC streams, 64 distinct channel set-ups tiled over the batch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes
+    import sbr_capture as c
+    from esbr_structs import new_state
+    from test_esbr_core_oracle_vs_reference import make_side
+    recs = [r for r in c.read_records(os.path.join(ROOT, "tests", "golden", "sbr_lp_records.bin.gz")) if r["frame"].apply_processing][:64]
+    hs, fs, sds = [], [], []
+    for r in recs:
+        h, f = c.Header.from_buffer_copy(bytes(r["header"])), c.Frame.from_buffer_copy(bytes(r["frame"]))
+        sd = make_side(rng, h, f, [0] * 10, 0, 0, False)
+        sd.reset_flag = 1
+        hs.append(np.frombuffer(bytes(h), np.uint8)), fs.append(np.frombuffer(bytes(f), np.uint8)), sds.append(np.frombuffer(bytes(sd), np.uint8))
+    tile = lambda xs: torch.from_numpy(np.stack([xs[i % len(xs)] for i in range(n)])).to(dev)
+    hd, fr, sd = tile(hs), tile(fs), tile(sds)
+    st = torch.from_numpy(np.stack([np.frombuffer(bytes(new_state()), np.uint8)] * n)).to(dev)
+    ws = torch.zeros(ctx.esbr_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    status = torch.zeros(n, dtype=torch.int32, device=dev)
+    us = timed(torch, ctx, lambda: ctx.esbr_sbr_process_batch(core, hd, fr, sd, st, pcm, ws, status))
+    assert not status.cpu().numpy().any()
+    # algorithmic bytes per channel-frame: 4 KB core in, 8 KB out, state in + out (its history rows dominate)
+    res.append(("esbr_sbr_chain(3 kernels)", us, n * (4096 + 8192 + 2 * st.shape[1])))
     for name, us, bytes_ in res:
         print(json.dumps({"kernel": name, "n_ch": n, "us": round(us, 1), "channel_frames_per_s": round(n / us * 1e6),
                           "alg_GBps": round(bytes_ / us / 1e3, 1), "frac_of_8TBps": round(bytes_ / us / 1e3 / 8000, 4)}))
