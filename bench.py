@@ -336,7 +336,7 @@ KERNELS = {
     "c2": "xaac_imdct_ola_kernel",
     "c2l": "imdct_ola + limiter_front + limiter_gain + limiter_apply (4 launches)",
     "c3": "imdct_ola + qmf_analysis + sbr_core_lp + qmf_synthesis (4 launches)",
-    "c4": "imdct_ola + qmf_analysis + sbr_core_hq + ps + 2 x qmf_synthesis (6 launches)",
+    "c4": "imdct_ola + qmf_analysis + sbr_core_hq + ps + qmf_synthesis_pair (5 launches)",
 }
 
 
