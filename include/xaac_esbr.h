@@ -2,7 +2,8 @@
  * xaac_esbr.h -- boundary formats of the eSBR ("Path A", the reference's default -esbr:1) SBR tool for HE-AAC streams:
  * what ixheaacd_sbr_dec's Path A branch (decoder/ixheaacd_sbr_dec.c:816-1009) reads beyond xaac_sbr_header /
  * xaac_sbr_frame (xaac_sbr.h), and the per-channel state it keeps between frames.
- * Scope: 2:1 SBR of AAC-LC cores (usac_flag = 0): no harmonic transposer, no PVC, no pre-flattening, no MPS.
+ * Scope: 2:1 SBR of AAC-LC cores (usac_flag = 0), with or without parametric stereo: no harmonic transposer, no PVC, no
+ * pre-flattening, no MPS.
  */
 #ifndef XAAC_ESBR_H
 #define XAAC_ESBR_H
@@ -48,6 +49,22 @@ typedef struct xaac_esbr_state {
   int8_t harm_flag_prev[64];
 } xaac_esbr_state;
 
+/* Per-stream persistent state of the float parametric-stereo tool (ia_ps_dec_struct's float members,
+ * decoder/ixheaacd_ps_dec.h:162-237, 20-band configuration) + the right channel's synthesis bank. */
+typedef struct xaac_esbr_ps_state {
+  float hyb_hist_re[3][12], hyb_hist_im[3][12];       /* hyb_qmf_buf_re_20 / _im_20: 12 slots of QMF bands 0..2 */
+  float qmf_delay_re[14][64], qmf_delay_im[14][64];   /* qmf_delay_buf_re / _im */
+  float sub_delay_re[2][12], sub_delay_im[2][12];     /* sub_qmf_delay_buf_re / _im (rows 0..1, 12 hybrid sub-bands) */
+  float ser_qmf_re[3][5][64], ser_qmf_im[3][5][64];   /* ser_qmf_delay_buf_re / _im */
+  float ser_sub_re[3][5][12], ser_sub_im[3][5][12];   /* ser_sub_qmf_dealy_buf_re / _im */
+  float h_prev[8][20];                                /* h11_re h12_re h21_re h22_re h11_im h12_im h21_im h22_im _prev;
+                                                         h11_re / h12_re start at 1.0 (ps_dec_flt.c:349-352) */
+  float peak_decay_fast[20], prev_nrg[20], prev_peak_diff[20];
+  int32_t delay_buf_idx, delay_buf_idx_ser[3];
+  int32_t delay_qmf_idx[64];                          /* delay_qmf_delay_buf_idx */
+  xaac_esbr_syn_state syn_r;                          /* pstr_sbr_channel[1]: str_synthesis_qmf_bank */
+} xaac_esbr_ps_state;
+
 typedef struct xaac_esbr_sbr_batch {
   int32_t n_ch;
   const float *core;               /* [n_ch][1024] time_sample_buf in */
@@ -55,7 +72,10 @@ typedef struct xaac_esbr_sbr_batch {
   const xaac_sbr_frame *frame;     /* [n_ch] (apply_processing, grid, invf modes, harmonics) */
   const xaac_esbr_side *side;      /* [n_ch] */
   xaac_esbr_state *state;          /* [n_ch] in/out */
-  float *out;                      /* [n_ch][2048] time_sample_buf out */
+  float *out;                      /* [n_ch][2048] time_sample_buf out (left channel with PS) */
+  const xaac_ps_frame *ps_frame;   /* [n_ch], or NULL together with ps_state / out_r: no parametric stereo */
+  xaac_esbr_ps_state *ps_state;    /* [n_ch] in/out */
+  float *out_r;                    /* [n_ch][2048] right channel (ps_dec->time_sample_buf[1]) */
   int32_t *status;                 /* optional [n_ch]: 0, or -1 where the reference returns an error */
   void *workspace;                 /* device scratch >= xaac_esbr_workspace_bytes(n_ch) */
   uint64_t workspace_bytes;
@@ -64,7 +84,8 @@ typedef struct xaac_esbr_sbr_batch {
 #ifdef __cplusplus
 extern "C" {
 #endif
-/* One frame of every channel through the Path A branch of ixheaacd_sbr_dec (mono / stereo channels, no PS):
+/* One frame of every channel through the Path A branch of ixheaacd_sbr_dec (mono / stereo channels; with ps_* set:
+ * HE-AACv2 streams, ixheaacd_esbr_apply_ps ps_dec_flt.c:389 between regrouping and the two synthesis banks):
  * history shift (sbr_dec.c:835-857), ixheaacd_esbr_analysis_filt_block, ixheaacd_generate_hf (sbrdec_lpfuncs.c:981),
  * ixheaacd_sbr_env_calc (esbr_envcal.c:71), ixheaacd_esbr_synthesis_regrp + the synthesis bank (sbr_dec.c:297 / :447). */
 uint64_t xaac_esbr_workspace_bytes(int32_t n_ch);

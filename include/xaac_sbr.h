@@ -102,9 +102,11 @@ typedef struct xaac_sbr_state {
  * the IID / ICC indices already mapped to the 20-band resolution the fixed-point path works in. */
 typedef struct xaac_ps_frame {
   int16_t iid_quant;                                   /* fine (1) or coarse (0) IID quantiser */
-  int16_t pad0_;
+  int16_t freq_res_ipd;                                /* = iid_mode 0..2 (ps_bitdec: freq_res_ipd); read by the float tool
+                                                          of the eSBR path only (xaac_esbr.h), ignored by the fixed-point one */
   int16_t border_position[XAAC_PS_MAX_ENV + 2];
-  int16_t pad1_;
+  int16_t num_env;                                     /* ps_dec->num_env after ixheaacd_decode_ps_data (1..5; border 0 is
+                                                          0, border num_env is 32); read by the float tool only */
   int16_t iid_par_table[XAAC_PS_MAX_ENV + 2][XAAC_PS_BANDS_FINE];
   int16_t icc_par_table[XAAC_PS_MAX_ENV + 2][XAAC_PS_BANDS_FINE];
 } xaac_ps_frame;

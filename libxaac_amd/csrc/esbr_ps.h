@@ -1,0 +1,352 @@
+/*
+ * esbr_ps.h -- the float parametric-stereo tool of the reference's default SBR path (ixheaacd_esbr_apply_ps,
+ * decoder/ixheaacd_ps_dec_flt.c:389: hybrid analysis :119 / :75, decorrelation :510, rotation :841, hybrid synthesis
+ * :203), shared by the gfx950 kernel (esbr_ps_kernel.hip: one wave = one stream-frame) and, compiled for the host with
+ * one "lane", by the checker (oracle/oracle_esbr.cpp).
+ *
+ * What the reference's AAC parser can hand this tool is narrower than the tool: ixheaacd_read_ps_data forces the
+ * 20-band configuration and the plain (non-PCA) mixing rule (sbrdec_lpfuncs.c:636-637), nothing ever writes the IPD / OPD
+ * index maps, and the tool is created with ps_mode 0.  This restatement covers exactly that: 20 bands; the mixing
+ * matrix from the table tools/gen_tables_esbr_ps.py makes with the C library's cos / sin; the phase step with all
+ * indices zero, which leaves h_re * 1.0f and h_im = h_re * 0.0f (a signed zero) below the IPD band limit.
+ *
+ * Float results depend on the order of every operation: expressions keep the reference's operand order, sums run in its
+ * order (the powers of a bin accumulate group by group, sub-band by sub-band), the mixing matrix is stepped slot by slot.
+ */
+#ifndef XAAC_ESBR_PS_H
+#define XAAC_ESBR_PS_H
+
+#include "esbr_core.h"
+
+#if defined(__HIPCC__)
+#define XAAC_TAB_QUAL static __device__ const
+#include "tables_esbr_ps.inc"
+#undef XAAC_TAB_QUAL
+#else
+#include "tables_esbr_ps.inc"
+#endif
+
+#pragma clang fp contract(off)
+
+struct XfWork {
+  float hl_re[32][12], hl_im[32][12], hr_re[32][12], hr_im[32][12]; /* hyb_left_* / hyb_right_*: 12 hybrid sub-bands */
+  float pw[32][20], tr[32][20];                                     /* pow_arr, trans_ratio_arr */
+  float hv[8][20];                                                  /* h11_re_vec ... h22_im_vec of the envelope */
+};
+
+#define XF_NEG 0x1000 /* NEGATE_IPD_MASK */
+
+/* one all-pass chain step (ps_dec_flt.c:693-716): in = the delayed, phase-rotated sample; returns the chain's output */
+FX_HD void xf_allpass(float &r_r0, float &i_r0, float *ser_re, float *ser_im /* [3] current ring cells */,
+                      const float *pf_re, const float *pf_im /* [3] */, float decay) {
+  for (int m = 0; m < 3; m++) {
+    const float real0 = ser_re[m], imag0 = ser_im[m];
+    float real = real0 * pf_re[m] - imag0 * pf_im[m];
+    float imag = real0 * pf_im[m] + imag0 * pf_re[m];
+    real += -decay * xaac_eps_all_pass_link_decay_ser[m] * r_r0;
+    imag += -decay * xaac_eps_all_pass_link_decay_ser[m] * i_r0;
+    ser_re[m] = r_r0 + decay * xaac_eps_all_pass_link_decay_ser[m] * real;
+    ser_im[m] = i_r0 + decay * xaac_eps_all_pass_link_decay_ser[m] * imag;
+    r_r0 = real;
+    i_r0 = imag;
+  }
+}
+
+/* L: the left matrix, rows 0..37 (rows 32..37: bands 0..4 of the next frame's first slots, sbr_dec.c:487-505); R: the
+   right matrix, rows 0..31.  usb = sub_band_end. */
+FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_state *ps, XfWork *w, const XeMat &L,
+                       const XeMat &R, int usb) {
+  const int num_env = pf->num_env;
+  const int k0 = pf->border_position[0], k1 = pf->border_position[num_env];
+  const int32_t *gb = xaac_eps_group_borders_20_tbl, *gmap = xaac_eps_bin_group_map_20;
+  /* bands above the SBR range start from silence (ps_dec_flt.c:427-438) */
+  XS_PAR(sb, usb < 0 ? 0 : usb, 64) {
+    for (int i = 0; i < 3; i++)
+      for (int k = 0; k < 5; k++) { /* delay_sample_ser = 3, 4, 5 */
+        if (k < 3 + i) {
+          ps->ser_qmf_re[i][k][sb] = 0;
+          ps->ser_qmf_im[i][k][sb] = 0;
+        }
+      }
+    for (int k = 0; k < 14; k++) {
+      ps->qmf_delay_re[k][sb] = 0;
+      ps->qmf_delay_im[k][sb] = 0;
+    }
+  }
+  /* hybrid analysis of QMF bands 0..2 (8 + 2 + 2 sub-bands), lane = slot; the 12-slot history is the filter's past */
+  XS_PAR(i, 0, 32) {
+    int ch_offset = 0;
+    for (int band = 0; band < 3; band++) {
+      float wr[13], wi[13];
+      for (int n = 0; n < 13; n++) {
+        const int j = n + i; /* index into the reference's work buffer: 12 history slots, then rows 6.. of L */
+        wr[n] = j < 12 ? ps->hyb_hist_re[band][j] : L.r(j - 12 + 6, band);
+        wi[n] = j < 12 ? ps->hyb_hist_im[band][j] : L.i(j - 12 + 6, band);
+      }
+      if (band == 0) {
+        for (int q = 0; q < 8; q++) {
+          float real = 0, imag = 0;
+          for (int n = 0; n < 13; n++) {
+            const float c = xaac_eps_cos_sin_mod_8channel[26 * q + 2 * n], s = xaac_eps_cos_sin_mod_8channel[26 * q + 2 * n + 1];
+            real += xaac_eps_p8_13_20[n] * (wr[n] * c - wi[n] * s);
+            imag += xaac_eps_p8_13_20[n] * (wi[n] * c + wr[n] * s);
+          }
+          w->hl_re[i][ch_offset + q] = real;
+          w->hl_im[i][ch_offset + q] = imag;
+        }
+        ch_offset += 8;
+      } else {
+        for (int q = 0; q < 2; q++) {
+          float real = 0, imag = 0;
+          for (int n = 0; n < 13; n++) {
+            const float c = xaac_eps_cos_mod_2channel[13 * q + n];
+            real += xaac_eps_p2_13_20[n] * (wr[n] * c);
+            imag += xaac_eps_p2_13_20[n] * (wi[n] * c);
+          }
+          w->hl_re[i][ch_offset + q] = real;
+          w->hl_im[i][ch_offset + q] = imag;
+        }
+        ch_offset += 2;
+      }
+    }
+    /* ps_dec_flt.c:446-459 */
+    w->hl_re[i][3] += w->hl_re[i][4];
+    w->hl_im[i][3] += w->hl_im[i][4];
+    w->hl_re[i][4] = 0.;
+    w->hl_im[i][4] = 0.;
+    w->hl_re[i][2] += w->hl_re[i][5];
+    w->hl_im[i][2] += w->hl_im[i][5];
+    w->hl_re[i][5] = 0.;
+    w->hl_im[i][5] = 0.;
+    for (int q = 0; q < 12; q++) {
+      w->hr_re[i][q] = 0;
+      w->hr_im[i][q] = 0;
+    }
+  }
+  cx.sync();
+  XS_PAR(j, 0, 36) { /* the next frame's history: the last 12 work slots = rows 26..37 of L */
+    const int band = j / 12, n = j % 12;
+    ps->hyb_hist_re[band][n] = L.r(26 + n, band);
+    ps->hyb_hist_im[band][n] = L.i(26 + n, band);
+  }
+  /* band powers per parameter bin (:606-632), lane = slot; a bin's sum runs group by group, sub-band by sub-band */
+  XS_PAR(k, 0, 32) {
+    for (int bin = 0; bin < 20; bin++) w->pw[k][bin] = 0;
+    if (k >= k0 && k < k1) {
+      for (int gr = 0; gr < 22; gr++) {
+        const int bin = gmap[gr] & ~XF_NEG;
+        if (gr < 10) {
+          const int sb = gb[gr];
+          const float a = w->hl_re[k][sb], b = w->hl_im[k][sb];
+          w->pw[k][bin] += a * a + b * b;
+        } else {
+          for (int sb = gb[gr]; sb < gb[gr + 1]; sb++) {
+            const float a = L.r(k, sb), b = L.i(k, sb);
+            w->pw[k][bin] += a * a + b * b;
+          }
+        }
+      }
+    }
+  }
+  cx.sync();
+  /* transient detector (:634-659), lane = bin, a recursion over the slots */
+  XS_PAR(bin, 0, 20) {
+    float peak = ps->peak_decay_fast[bin], pdiff = ps->prev_peak_diff[bin], nrg = ps->prev_nrg[bin];
+    for (int k = k0; k < k1; k++) {
+      const float q = 1.5f, p = w->pw[k][bin];
+      peak *= 0.765928338364649f;
+      if (peak < p) peak = p;
+      float d = pdiff;
+      d += (1.0f - 0.75f) * (peak - p - pdiff);
+      pdiff = d;
+      float e = nrg;
+      e += (1.0f - 0.75f) * (p - nrg);
+      nrg = e;
+      w->tr[k][bin] = q * d <= e ? 1.0f : e / (q * d);
+    }
+    ps->peak_decay_fast[bin] = peak;
+    ps->prev_peak_diff[bin] = pdiff;
+    ps->prev_nrg[bin] = nrg;
+  }
+  cx.sync();
+  /* decorrelation: all-pass chains on the hybrid sub-bands and QMF bands 3..22, plain delays above (:667-827); every
+     sub-band is its own recursion over the slots.  Lanes 0..9: hybrid groups; then lanes = QMF bands 3..63. */
+  const int l_delay0 = ps->delay_buf_idx;
+  const int ser0[3] = {ps->delay_buf_idx_ser[0], ps->delay_buf_idx_ser[1], ps->delay_buf_idx_ser[2]};
+  int l_delay_end = l_delay0, ser_end[3] = {ser0[0], ser0[1], ser0[2]};
+  XS_PAR(gr, 0, 10) {
+    const int sb = gb[gr], bin = gmap[gr] & ~XF_NEG;
+    int l_delay = l_delay0, ls[3] = {ser0[0], ser0[1], ser0[2]};
+    const float pr = xaac_eps_frac_delay_phase_fac_qmf_sub_re_20[sb], pi = xaac_eps_frac_delay_phase_fac_qmf_sub_im_20[sb];
+    for (int k = k0; k < k1; k++) {
+      const float in_re = w->hl_re[k][sb], in_im = w->hl_im[k][sb];
+      const float real0 = ps->sub_delay_re[l_delay][sb], imag0 = ps->sub_delay_im[l_delay][sb];
+      ps->sub_delay_re[l_delay][sb] = in_re;
+      ps->sub_delay_im[l_delay][sb] = in_im;
+      float r_r0 = real0 * pr - imag0 * pi, i_r0 = real0 * pi + imag0 * pr;
+      float sr[3], si[3];
+      for (int m = 0; m < 3; m++) {
+        sr[m] = ps->ser_sub_re[m][ls[m]][sb];
+        si[m] = ps->ser_sub_im[m][ls[m]][sb];
+      }
+      xf_allpass(r_r0, i_r0, sr, si, &xaac_eps_frac_delay_phase_fac_ser_qmf_sub_re_20[3 * sb],
+                 &xaac_eps_frac_delay_phase_fac_ser_qmf_sub_im_20[3 * sb], 1.0f);
+      for (int m = 0; m < 3; m++) {
+        ps->ser_sub_re[m][ls[m]][sb] = sr[m];
+        ps->ser_sub_im[m][ls[m]][sb] = si[m];
+      }
+      const float t = w->tr[k][bin];
+      w->hr_re[k][sb] = t * r_r0;
+      w->hr_im[k][sb] = t * i_r0;
+      if (++l_delay >= 2) l_delay = 0;
+      for (int m = 0; m < 3; m++)
+        if (++ls[m] >= 3 + m) ls[m] = 0;
+    }
+  }
+  XS_PAR(sb, 3, 64) {
+    int gr = 10;
+    while (gr < 21 && sb >= gb[gr + 1]) gr++;
+    const int bin = gmap[gr] & ~XF_NEG;
+    float decay = sb <= 3 ? 1.0f : 1.0f + 3.0f * 0.05f - 0.05f * (float)sb;
+    decay = decay > 0.0f ? decay : 0.0f;
+    int l_delay = l_delay0, ls[3] = {ser0[0], ser0[1], ser0[2]};
+    int di = ps->delay_qmf_idx[sb];
+    const int dn = xaac_eps_qmf_delay_idx_tbl[sb];
+    const bool plain = sb >= 23;
+    const float pr = xaac_eps_qmf_fract_delay_phase_factor_re[sb], pi = xaac_eps_qmf_fract_delay_phase_factor_im[sb];
+    for (int k = k0; k < k1; k++) {
+      const float in_re = L.r(k, sb), in_im = L.i(k, sb);
+      float r_r0, i_r0;
+      if (plain) {
+        r_r0 = ps->qmf_delay_re[di][sb];
+        i_r0 = ps->qmf_delay_im[di][sb];
+        ps->qmf_delay_re[di][sb] = in_re;
+        ps->qmf_delay_im[di][sb] = in_im;
+      } else {
+        const float real0 = ps->qmf_delay_re[l_delay][sb], imag0 = ps->qmf_delay_im[l_delay][sb];
+        ps->qmf_delay_re[l_delay][sb] = in_re;
+        ps->qmf_delay_im[l_delay][sb] = in_im;
+        r_r0 = real0 * pr - imag0 * pi;
+        i_r0 = real0 * pi + imag0 * pr;
+        float sr[3], si[3];
+        for (int m = 0; m < 3; m++) {
+          sr[m] = ps->ser_qmf_re[m][ls[m]][sb];
+          si[m] = ps->ser_qmf_im[m][ls[m]][sb];
+        }
+        xf_allpass(r_r0, i_r0, sr, si, &xaac_eps_qmf_ser_fract_delay_phase_factor_re[3 * sb],
+                   &xaac_eps_qmf_ser_fract_delay_phase_factor_im[3 * sb], decay);
+        for (int m = 0; m < 3; m++) {
+          ps->ser_qmf_re[m][ls[m]][sb] = sr[m];
+          ps->ser_qmf_im[m][ls[m]][sb] = si[m];
+        }
+      }
+      const float t = w->tr[k][bin];
+      R.r(k, sb) = t * r_r0;
+      R.i(k, sb) = t * i_r0;
+      if (++l_delay >= 2) l_delay = 0;
+      if (plain && ++di >= dn) di = 0;
+      for (int m = 0; m < 3; m++)
+        if (++ls[m] >= 3 + m) ls[m] = 0;
+    }
+    ps->delay_qmf_idx[sb] = di;
+  }
+  for (int k = k0; k < k1; k++) { /* where the shared ring positions end up (:829-832) */
+    if (++l_delay_end >= 2) l_delay_end = 0;
+    for (int m = 0; m < 3; m++)
+      if (++ser_end[m] >= 3 + m) ser_end[m] = 0;
+  }
+  cx.sync();
+  XS_ONE {
+    ps->delay_buf_idx = l_delay_end;
+    for (int m = 0; m < 3; m++) ps->delay_buf_idx_ser[m] = ser_end[m];
+  }
+  /* rotation (:841-1224): per envelope the target matrix of every bin, then every sub-band steps its matrix slot by slot */
+  const int ipd_bins = xaac_eps_ipd_bins_tbl[pf->freq_res_ipd < 0 ? 0 : (pf->freq_res_ipd > 2 ? 2 : pf->freq_res_ipd)];
+  const int steps = pf->iid_quant ? 15 : 7;
+  for (int env = 0; env < num_env; env++) {
+    XS_PAR(bin, 0, 20) {
+      int iid = pf->iid_par_table[env][bin], icc = pf->icc_par_table[env][bin];
+      iid = iid < -steps ? -steps : (iid > steps ? steps : iid);
+      icc = icc < 0 ? 0 : (icc > 7 ? 7 : icc);
+      const float *m = &xaac_eps_mix[(((pf->iid_quant ? 1 : 0) * 61 + iid + 30) * 8 + icc) * 4];
+      float hr[4] = {m[0], m[1], m[2], m[3]}, hi[4];
+      if (bin >= ipd_bins) {
+        hi[0] = hi[1] = hi[2] = hi[3] = 0.0f;
+      } else { /* the phase step with every IPD / OPD index zero: cos 1, sin 0 (:970-1004) */
+        for (int j = 0; j < 4; j++) {
+          hi[j] = hr[j] * 0.0f;
+          hr[j] *= 1.0f;
+        }
+      }
+      for (int j = 0; j < 4; j++) {
+        w->hv[j][bin] = hr[j];
+        w->hv[4 + j][bin] = hi[j];
+      }
+    }
+    cx.sync();
+    const int e0 = pf->border_position[env], e1 = pf->border_position[env + 1], len = e1 - e0;
+    XS_PAR(u, 0, 10 + 61) { /* units: 10 hybrid groups, then QMF bands 3..63 */
+      int gr, sb;
+      if (u < 10) {
+        gr = u;
+        sb = gb[gr];
+      } else {
+        sb = u - 10 + 3;
+        gr = 10;
+        while (gr < 21 && sb >= gb[gr + 1]) gr++;
+      }
+      const int bin = gmap[gr] & ~XF_NEG;
+      const bool neg = (gmap[gr] & XF_NEG) != 0;
+      float H[8], d[8];
+      for (int j = 0; j < 8; j++) {
+        const float prev = ps->h_prev[j][bin], cur = w->hv[j][bin];
+        const float Hp = (j >= 4 && neg) ? -prev : prev, hc = (j >= 4 && neg) ? -cur : cur;
+        H[j] = Hp;
+        d[j] = (hc - Hp) / (float)len;
+      }
+      for (int i = e0; i < e1; i++) {
+        for (int j = 0; j < 8; j++) H[j] += d[j];
+        /* H[0..3] = H11r H12r H21r H22r, H[4..7] = H11i H12i H21i H22i */
+        float lre, lim, rre, rim;
+        if (u < 10) {
+          lre = w->hl_re[i][sb]; lim = w->hl_im[i][sb]; rre = w->hr_re[i][sb]; rim = w->hr_im[i][sb];
+        } else {
+          lre = L.r(i, sb); lim = L.i(i, sb); rre = R.r(i, sb); rim = R.i(i, sb);
+        }
+        const float o_lre = H[0] * lre - H[4] * lim + H[2] * rre - H[6] * rim;
+        const float o_lim = H[4] * lre + H[0] * lim + H[6] * rre + H[2] * rim;
+        const float o_rre = H[1] * lre - H[5] * lim + H[3] * rre - H[7] * rim;
+        const float o_rim = H[5] * lre + H[1] * lim + H[7] * rre + H[3] * rim;
+        if (u < 10) {
+          w->hl_re[i][sb] = o_lre; w->hl_im[i][sb] = o_lim; w->hr_re[i][sb] = o_rre; w->hr_im[i][sb] = o_rim;
+        } else {
+          L.r(i, sb) = o_lre; L.i(i, sb) = o_lim; R.r(i, sb) = o_rre; R.i(i, sb) = o_rim;
+        }
+      }
+    }
+    cx.sync();
+    XS_PAR(bin, 0, 20)
+      for (int j = 0; j < 8; j++) ps->h_prev[j][bin] = w->hv[j][bin];
+    cx.sync();
+  }
+  /* hybrid synthesis (:203-227): QMF bands 0..2 of both channels */
+  XS_PAR(n, 0, 32) {
+    int ch = 0;
+    for (int band = 0; band < 3; band++) {
+      const int res = band == 0 ? 8 : 2;
+      float lr = 0, li = 0, rr = 0, ri = 0;
+      for (int k = 0; k < res; k++) {
+        lr += w->hl_re[n][ch + k];
+        li += w->hl_im[n][ch + k];
+        rr += w->hr_re[n][ch + k];
+        ri += w->hr_im[n][ch + k];
+      }
+      L.r(n, band) = lr; L.i(n, band) = li;
+      R.r(n, band) = rr; R.i(n, band) = ri;
+      ch += res;
+    }
+  }
+  cx.sync();
+}
+
+#endif

@@ -9,7 +9,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#include "../libxaac_amd/csrc/esbr_core.h"
+#include "../libxaac_amd/csrc/esbr_ps.h"
 
 extern "C" {
 void xo_esbr_analysis(const float *core, int32_t *ring, int32_t *pos, int32_t *win_off, float *re, float *im);
@@ -25,6 +25,15 @@ int xo_esbr_hf_env(const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac
   xe_generate_hf(cx, h, f, sd, st, &w, src, dst);
   if (w.err) return -1;
   return xe_env_calc(cx, h, f, sd, st, &w, dst, src);
+}
+
+/* the float parametric-stereo tool alone: l_* [38][64], r_* [32][64] */
+int xo_esbr_apply_ps(const xaac_ps_frame *pf, xaac_esbr_ps_state *st, float *l_re, float *l_im, float *r_re, float *r_im, int usb) {
+  static thread_local XfWork w;
+  const XsCx cx = {0, 1};
+  const XeMat L = {l_re, l_im}, R = {r_re, r_im};
+  xf_apply_ps(cx, pf, st, &w, L, R, usb);
+  return 0;
 }
 
 /* one frame of one channel: core 1024 floats in, out 2048 floats */

@@ -154,6 +154,8 @@ static void to_state(const ia_sbr_dec_struct *d, const ia_sbr_prev_frame_data_st
 static void to_ps_frame(const ia_ps_dec_struct *ps, xaac_ps_frame *o) {
   memset(o, 0, sizeof(*o));
   o->iid_quant = (int16_t)ps->iid_quant;
+  o->freq_res_ipd = (int16_t)ps->freq_res_ipd;
+  o->num_env = ps->num_env;
   memcpy(o->border_position, ps->border_position, sizeof(o->border_position));
   memcpy(o->iid_par_table, ps->iid_par_table, sizeof(o->iid_par_table));
   memcpy(o->icc_par_table, ps->icc_par_table, sizeof(o->icc_par_table));

@@ -100,3 +100,120 @@ int ref_esbr_hf_env(const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaa
   for (i = 0; i <= XAAC_SBR_MAX_PATCHES; i++) st->patch_start_subband[i] = fd.patch_param.start_subband[i];
   return rc ? -1 : 0;
 }
+
+/* ---- float parametric stereo (ixheaacd_esbr_apply_ps, decoder/ixheaacd_ps_dec_flt.c:389) ---------------------------- */
+/* the float members of the reference's PS ROM (ixheaacd_sbr_rom.h:193-236) by name, for tools/gen_tables_esbr_ps.py */
+const void *ref_ps_flt_table(const char *name, int *count, int *is_float) {
+  const ia_ps_tables_struct *t = &ixheaacd_aac_dec_ps_tables;
+#define T(member, flt)                                                          \
+  if (!strcmp(name, #member)) {                                                 \
+    *count = (int)(sizeof(t->member) / 4);                                      \
+    *is_float = flt;                                                            \
+    return t->member;                                                           \
+  }
+  T(qmf_fract_delay_phase_factor_im, 1) T(qmf_fract_delay_phase_factor_re, 1)
+  T(frac_delay_phase_fac_qmf_sub_im_20, 1) T(frac_delay_phase_fac_qmf_sub_re_20, 1)
+  T(qmf_ser_fract_delay_phase_factor_im, 1) T(qmf_ser_fract_delay_phase_factor_re, 1)
+  T(frac_delay_phase_fac_ser_qmf_sub_im_20, 1) T(frac_delay_phase_fac_ser_qmf_sub_re_20, 1)
+  T(scale_factors_flt, 1) T(scale_factors_fine_flt, 1) T(alphas, 1) T(all_pass_link_decay_ser, 1)
+  T(p8_13_20, 1) T(p2_13_20, 1) T(cos_mod_2channel, 1) T(cos_sin_mod_8channel, 1)
+  T(qmf_delay_idx_tbl, 0) T(group_borders_20_tbl, 0) T(bin_group_map_20, 0) T(ipd_bins_tbl, 0)
+#undef T
+  if (!strcmp(name, "band_res_hyb20")) { /* WORD16[3] */
+    static int32_t w[3];
+    w[0] = t->band_res_hyb20[0]; w[1] = t->band_res_hyb20[1]; w[2] = t->band_res_hyb20[2];
+    *count = 3;
+    *is_float = 0;
+    return w;
+  }
+  return NULL;
+}
+
+/* the real ixheaacd_esbr_apply_ps on the caller's matrices: l_* [38][64] (rows 32..37: the six look-ahead rows),
+   r_* [32][64]; state in / out in the boundary format */
+int ref_esbr_apply_ps(const xaac_ps_frame *pf, xaac_esbr_ps_state *st, float *l_re, float *l_im, float *r_re, float *r_im, int usb) {
+  static __thread ia_ps_dec_struct ps;
+  ia_ps_tables_struct *tabs = (ia_ps_tables_struct *)&ixheaacd_aac_dec_ps_tables;
+  float *plr[38], *pli[38], *prr[38], *pri[38];
+  static __thread float r_pad_re[38][64], r_pad_im[38][64];
+  int i, j, m, k;
+  memset(&ps, 0, sizeof(ps));
+  ixheaacd_create_ps_esbr_dec(&ps, tabs, 64, 32, 0);
+  ps.delay_sample_ser[0] = 3; ps.delay_sample_ser[1] = 4; ps.delay_sample_ser[2] = 5; /* rev_link_delay_ser, initfuncs.c:1054 */
+  ps.num_env = pf->num_env;
+  ps.iid_quant = pf->iid_quant;
+  ps.freq_res_ipd = pf->freq_res_ipd;
+  memcpy(ps.border_position, pf->border_position, sizeof(ps.border_position));
+  memcpy(ps.iid_par_table, pf->iid_par_table, sizeof(ps.iid_par_table));
+  memcpy(ps.icc_par_table, pf->icc_par_table, sizeof(ps.icc_par_table));
+  for (i = 0; i < 3; i++)
+    for (j = 0; j < 12; j++) {
+      ps.hyb_qmf_buf_re_20[i][j] = st->hyb_hist_re[i][j];
+      ps.hyb_qmf_buf_im_20[i][j] = st->hyb_hist_im[i][j];
+    }
+  memcpy(ps.qmf_delay_buf_re, st->qmf_delay_re, sizeof(st->qmf_delay_re));
+  memcpy(ps.qmf_delay_buf_im, st->qmf_delay_im, sizeof(st->qmf_delay_im));
+  for (i = 0; i < 2; i++)
+    for (j = 0; j < 12; j++) {
+      ps.sub_qmf_delay_buf_re[i][j] = st->sub_delay_re[i][j];
+      ps.sub_qmf_delay_buf_im[i][j] = st->sub_delay_im[i][j];
+    }
+  memcpy(ps.ser_qmf_delay_buf_re, st->ser_qmf_re, sizeof(st->ser_qmf_re));
+  memcpy(ps.ser_qmf_delay_buf_im, st->ser_qmf_im, sizeof(st->ser_qmf_im));
+  for (m = 0; m < 3; m++)
+    for (k = 0; k < 5; k++)
+      for (j = 0; j < 12; j++) {
+        ps.ser_sub_qmf_dealy_buf_re[m][k][j] = st->ser_sub_re[m][k][j];
+        ps.ser_sub_qmf_dealy_buf_im[m][k][j] = st->ser_sub_im[m][k][j];
+      }
+  for (j = 0; j < 20; j++) {
+    ps.h11_re_prev[j] = st->h_prev[0][j]; ps.h12_re_prev[j] = st->h_prev[1][j];
+    ps.h21_re_prev[j] = st->h_prev[2][j]; ps.h22_re_prev[j] = st->h_prev[3][j];
+    ps.h11_im_prev[j] = st->h_prev[4][j]; ps.h12_im_prev[j] = st->h_prev[5][j];
+    ps.h21_im_prev[j] = st->h_prev[6][j]; ps.h22_im_prev[j] = st->h_prev[7][j];
+    ps.peak_decay_fast_bin[j] = st->peak_decay_fast[j];
+    ps.prev_nrg_bin[j] = st->prev_nrg[j];
+    ps.prev_peak_diff_bin[j] = st->prev_peak_diff[j];
+  }
+  ps.delay_buf_idx = (WORD16)st->delay_buf_idx;
+  for (m = 0; m < 3; m++) ps.delay_buf_idx_ser[m] = (WORD16)st->delay_buf_idx_ser[m];
+  for (j = 0; j < 64; j++) ps.delay_qmf_delay_buf_idx[j] = st->delay_qmf_idx[j];
+  for (i = 0; i < 38; i++) {
+    plr[i] = l_re + 64 * i; pli[i] = l_im + 64 * i;
+    prr[i] = i < 32 ? r_re + 64 * i : r_pad_re[i]; pri[i] = i < 32 ? r_im + 64 * i : r_pad_im[i];
+  }
+  ixheaacd_esbr_apply_ps(&ps, plr, pli, prr, pri, usb, tabs, 16);
+  for (i = 0; i < 3; i++)
+    for (j = 0; j < 12; j++) {
+      st->hyb_hist_re[i][j] = ps.hyb_qmf_buf_re_20[i][j];
+      st->hyb_hist_im[i][j] = ps.hyb_qmf_buf_im_20[i][j];
+    }
+  memcpy(st->qmf_delay_re, ps.qmf_delay_buf_re, sizeof(st->qmf_delay_re));
+  memcpy(st->qmf_delay_im, ps.qmf_delay_buf_im, sizeof(st->qmf_delay_im));
+  for (i = 0; i < 2; i++)
+    for (j = 0; j < 12; j++) {
+      st->sub_delay_re[i][j] = ps.sub_qmf_delay_buf_re[i][j];
+      st->sub_delay_im[i][j] = ps.sub_qmf_delay_buf_im[i][j];
+    }
+  memcpy(st->ser_qmf_re, ps.ser_qmf_delay_buf_re, sizeof(st->ser_qmf_re));
+  memcpy(st->ser_qmf_im, ps.ser_qmf_delay_buf_im, sizeof(st->ser_qmf_im));
+  for (m = 0; m < 3; m++)
+    for (k = 0; k < 5; k++)
+      for (j = 0; j < 12; j++) {
+        st->ser_sub_re[m][k][j] = ps.ser_sub_qmf_dealy_buf_re[m][k][j];
+        st->ser_sub_im[m][k][j] = ps.ser_sub_qmf_dealy_buf_im[m][k][j];
+      }
+  for (j = 0; j < 20; j++) {
+    st->h_prev[0][j] = ps.h11_re_prev[j]; st->h_prev[1][j] = ps.h12_re_prev[j];
+    st->h_prev[2][j] = ps.h21_re_prev[j]; st->h_prev[3][j] = ps.h22_re_prev[j];
+    st->h_prev[4][j] = ps.h11_im_prev[j]; st->h_prev[5][j] = ps.h12_im_prev[j];
+    st->h_prev[6][j] = ps.h21_im_prev[j]; st->h_prev[7][j] = ps.h22_im_prev[j];
+    st->peak_decay_fast[j] = ps.peak_decay_fast_bin[j];
+    st->prev_nrg[j] = ps.prev_nrg_bin[j];
+    st->prev_peak_diff[j] = ps.prev_peak_diff_bin[j];
+  }
+  st->delay_buf_idx = ps.delay_buf_idx;
+  for (m = 0; m < 3; m++) st->delay_buf_idx_ser[m] = ps.delay_buf_idx_ser[m];
+  for (j = 0; j < 64; j++) st->delay_qmf_idx[j] = ps.delay_qmf_delay_buf_idx[j];
+  return 0;
+}

@@ -31,3 +31,20 @@ def new_state():
     st = EsbrState()
     st.esbr_start_up = 1
     return st
+
+
+class EsbrPsState(ctypes.Structure):
+    _fields_ = [("hyb_hist_re", (F32 * 12) * 3), ("hyb_hist_im", (F32 * 12) * 3), ("qmf_delay_re", (F32 * 64) * 14),
+                ("qmf_delay_im", (F32 * 64) * 14), ("sub_delay_re", (F32 * 12) * 2), ("sub_delay_im", (F32 * 12) * 2),
+                ("ser_qmf_re", ((F32 * 64) * 5) * 3), ("ser_qmf_im", ((F32 * 64) * 5) * 3),
+                ("ser_sub_re", ((F32 * 12) * 5) * 3), ("ser_sub_im", ((F32 * 12) * 5) * 3), ("h_prev", (F32 * 20) * 8),
+                ("peak_decay_fast", F32 * 20), ("prev_nrg", F32 * 20), ("prev_peak_diff", F32 * 20),
+                ("delay_buf_idx", I32), ("delay_buf_idx_ser", I32 * 3), ("delay_qmf_idx", I32 * 64), ("syn_r", EsbrSyn)]
+
+
+def new_ps_state():
+    st = EsbrPsState()
+    for j in range(20):
+        st.h_prev[0][j] = 1.0
+        st.h_prev[1][j] = 1.0
+    return st

@@ -43,7 +43,7 @@ class State(ctypes.Structure):
 
 
 class PsFrame(ctypes.Structure):
-    _fields_ = [("iid_quant", I16), ("pad0_", I16), ("border_position", I16 * 7), ("pad1_", I16),
+    _fields_ = [("iid_quant", I16), ("freq_res_ipd", I16), ("border_position", I16 * 7), ("num_env", I16),
                 ("iid_par_table", (I16 * 34) * 7), ("icc_par_table", (I16 * 34) * 7)]
 
 
