@@ -69,7 +69,8 @@ class _EsbrSbrBatch(ctypes.Structure):
     # struct xaac_esbr_sbr_batch (include/xaac_esbr.h)
     _fields_ = [("n_ch", ctypes.c_int32), ("core", ctypes.c_void_p), ("header", ctypes.c_void_p),
                 ("frame", ctypes.c_void_p), ("side", ctypes.c_void_p), ("state", ctypes.c_void_p),
-                ("out", ctypes.c_void_p), ("status", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
+                ("out", ctypes.c_void_p), ("ps_frame", ctypes.c_void_p), ("ps_state", ctypes.c_void_p),
+                ("out_r", ctypes.c_void_p), ("status", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
                 ("workspace_bytes", ctypes.c_uint64)]
 
 
@@ -370,10 +371,12 @@ class XaacContext:
     def esbr_workspace_bytes(self, n_ch):
         return int(self._lib.xaac_esbr_workspace_bytes(int(n_ch)))
 
-    def esbr_sbr_process_batch(self, core, header, frame, side, state, out, workspace, status=None):
+    def esbr_sbr_process_batch(self, core, header, frame, side, state, out, workspace, status=None, ps_frame=None,
+                               ps_state=None, out_r=None):
         """One frame of every channel through the Path A (eSBR, -esbr:1) branch of ixheaacd_sbr_dec, mono / stereo
         channels without PS: core float32[n_ch, 1024]; header / frame / side / state uint8 views of the xaac_sbr_header,
-        xaac_sbr_frame, xaac_esbr_side, xaac_esbr_state arrays; out float32[n_ch, 2048]."""
+        xaac_sbr_frame, xaac_esbr_side, xaac_esbr_state arrays; out float32[n_ch, 2048].  With ps_frame / ps_state (uint8
+        views of xaac_ps_frame / xaac_esbr_ps_state arrays) / out_r: HE-AACv2 streams, float parametric stereo, out = left."""
         n_ch = out.shape[0]
         b = _EsbrSbrBatch()
         b.n_ch = n_ch
@@ -383,6 +386,9 @@ class XaacContext:
         b.side = _ptr(side, "uint8", device_ok=True)
         b.state = _ptr(state, "uint8", device_ok=True)
         b.out = _ptr(out, "float32", n_ch * 2048, device_ok=True)
+        b.ps_frame = _ptr(ps_frame, "uint8", n_ch * PS_FRAME_BYTES, allow_none=True, device_ok=True)
+        b.ps_state = _ptr(ps_state, "uint8", allow_none=True, device_ok=True)
+        b.out_r = _ptr(out_r, "float32", n_ch * 2048, allow_none=True, device_ok=True)
         b.status = _ptr(status, "int32", n_ch, allow_none=True, device_ok=True)
         b.workspace = _ptr(workspace, "uint8", device_ok=True)
         b.workspace_bytes = workspace.numel()

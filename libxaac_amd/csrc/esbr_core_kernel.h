@@ -8,7 +8,8 @@
 #include "../../include/xaac_esbr.h"
 
 #define XAAC_ESBR_OUT_ROWS 42                                   /* 8 history + 32 + 2 rows a VARVAR frame can reach */
-#define XAAC_ESBR_WS_FLOATS (2 * 2048 + 2 * XAAC_ESBR_OUT_ROWS * 64 + 2 * 2048) /* analysis rows, sbr_qmf_out, regrouped rows */
+#define XAAC_ESBR_L_ROWS 38                                     /* 32 regrouped rows + the 6 look-ahead rows of the PS hybrid filter */
+#define XAAC_ESBR_WS_FLOATS (2 * 2048 + 2 * XAAC_ESBR_OUT_ROWS * 64 + 2 * XAAC_ESBR_L_ROWS * 64 + 2 * 2048) /* analysis rows, sbr_qmf_out, left rows, right rows */
 
 typedef struct XaacEsbrCoreParams {
   int32_t n_ch;
@@ -18,7 +19,9 @@ typedef struct XaacEsbrCoreParams {
   xaac_esbr_state *state;
   const float *ana_re, *ana_im; /* [n_ch][32][64] this frame's analysis rows */
   float *out_re, *out_im;       /* [n_ch][42][64] scratch: sbr_qmf_out */
-  float *syn_re, *syn_im;       /* [n_ch][32][64] regrouped rows for the synthesis bank */
+  float *syn_re, *syn_im;       /* [n_ch][38][64] regrouped rows for the synthesis bank (+ rows 32..37, bands 0..4, with PS) */
+
+  int32_t with_ps;
   int32_t *status;
 } XaacEsbrCoreParams;
 
@@ -26,6 +29,18 @@ typedef struct XaacEsbrCoreParams {
 extern "C" {
 #endif
 hipError_t xaac_launch_esbr_core(const XaacEsbrCoreParams *p, hipStream_t stream);
+
+typedef struct XaacEsbrPsParams {
+  int32_t n;
+  const xaac_sbr_header *header;  /* sub_band_end */
+  const xaac_sbr_frame *frame;    /* apply_processing */
+  const xaac_ps_frame *ps_frame;
+  xaac_esbr_ps_state *ps_state;
+  float *l_re, *l_im;             /* [n][38][64] in: regrouped rows; out: the left channel's rows 0..31 */
+  float *r_re, *r_im;             /* [n][32][64] out: the right channel */
+  int32_t *status;                /* -1 is written where the side info is outside the tool's tables */
+} XaacEsbrPsParams;
+hipError_t xaac_launch_esbr_ps(const XaacEsbrPsParams *p, hipStream_t stream);
 #ifdef __cplusplus
 }
 #endif

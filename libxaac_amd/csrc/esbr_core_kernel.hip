@@ -25,7 +25,7 @@ __global__ __launch_bounds__(64) void xaac_esbr_core_kernel(XaacEsbrCoreParams p
   const xaac_esbr_side *sd = p.side + ch;
   xaac_esbr_state *st = p.state + ch;
   float *ore = p.out_re + (size_t)ch * XAAC_ESBR_OUT_ROWS * 64, *oim = p.out_im + (size_t)ch * XAAC_ESBR_OUT_ROWS * 64;
-  float *rre = p.syn_re + (size_t)ch * 2048, *rim = p.syn_im + (size_t)ch * 2048;
+  float *rre = p.syn_re + (size_t)ch * XAAC_ESBR_L_ROWS * 64, *rim = p.syn_im + (size_t)ch * XAAC_ESBR_L_ROWS * 64;
   const float *are = p.ana_re + (size_t)ch * 2048, *aim = p.ana_im + (size_t)ch * 2048;
   const int apply = f->apply_processing != 0;
   int rc = 0;
@@ -53,6 +53,11 @@ __global__ __launch_bounds__(64) void xaac_esbr_core_kernel(XaacEsbrCoreParams p
       rim[64 * i + lane] = lane < xo ? st->qmf_im[2 + i][lane] : oim[64 * (2 + i) + lane];
     }
   }
+  if (p.with_ps) /* the six look-ahead rows of the PS hybrid filter: bands 0..4 of qmf_buf rows 34..39 (sbr_dec.c:487-505) */
+    for (int i = 32; i < 38; i++) {
+      rre[64 * i + lane] = lane < 5 ? st->qmf_re[2 + i][lane] : 0.0f;
+      rim[64 * i + lane] = lane < 5 ? st->qmf_im[2 + i][lane] : 0.0f;
+    }
   __syncthreads();
   /* histories: rows 32.. of this frame's buffers become rows 0.. of the next frame's (sbr_dec.c:835-857) */
   {

@@ -1,0 +1,48 @@
+/*
+ * esbr_ps_kernel.hip -- gfx950 kernel for the float parametric-stereo tool of the reference's default SBR path
+ * (ixheaacd_esbr_apply_ps, decoder/ixheaacd_ps_dec_flt.c:389, between the regrouping and the two synthesis banks of
+ * ixheaacd_esbr_synthesis_filt_block, sbr_dec.c:447); arithmetic in esbr_ps.h.
+ *
+ * Mapping: one wave = one stream-frame.  Hybrid analysis / synthesis and the band powers with lane = slot, the transient
+ * detector with lane = parameter bin, the decorrelator and the rotation with lane = hybrid sub-band or QMF band (each a
+ * recursion over the 32 slots: all-pass rings, delays, a mixing matrix stepped slot by slot).  Hybrid sub-band signals,
+ * powers and transient ratios live in LDS (11.6 KB), the two 64-band matrices and the 16 KB of delay-line state in global
+ * memory (L2-resident while the wave works on them).
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "esbr_ps.h"
+#include "esbr_core_kernel.h"
+
+__global__ __launch_bounds__(64) void xaac_esbr_ps_kernel(XaacEsbrPsParams p) {
+  __shared__ XfWork w;
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const XsCx cx = {lane, 64};
+  const xaac_ps_frame *pf = p.ps_frame + n;
+  float *lre = p.l_re + (size_t)n * XAAC_ESBR_L_ROWS * 64, *lim = p.l_im + (size_t)n * XAAC_ESBR_L_ROWS * 64;
+  float *rre = p.r_re + (size_t)n * 2048, *rim = p.r_im + (size_t)n * 2048;
+  const XeMat L = {lre, lim}, R = {rre, rim};
+  bool bad = pf->num_env < 1 || pf->num_env > XAAC_PS_MAX_ENV || pf->border_position[0] < 0;
+  if (!bad)
+    for (int e = 0; e < pf->num_env; e++) bad |= pf->border_position[e] > pf->border_position[e + 1] || pf->border_position[e + 1] > 32;
+  if (p.frame[n].apply_processing && !bad) {
+    for (int i = 0; i < 32; i++) { /* QMF bands 0..2 of the right channel come from the hybrid synthesis; clear the rest of the row set */
+      rre[64 * i + lane] = 0.0f;
+      rim[64 * i + lane] = 0.0f;
+    }
+    __syncthreads();
+    xf_apply_ps(cx, pf, p.ps_state + n, &w, L, R, p.header[n].sub_band_end);
+  } else { /* no SBR processing this frame: the right channel is the left one (sbr_dec.c:516-523) */
+    for (int i = 0; i < 32; i++) {
+      rre[64 * i + lane] = lre[64 * i + lane];
+      rim[64 * i + lane] = lim[64 * i + lane];
+    }
+    if (lane == 0 && bad && p.frame[n].apply_processing && p.status) p.status[n] = -1;
+  }
+}
+
+extern "C" hipError_t xaac_launch_esbr_ps(const XaacEsbrPsParams *p, hipStream_t stream) {
+  hipLaunchKernelGGL(xaac_esbr_ps_kernel, dim3(p->n), dim3(64), 0, stream, *p);
+  return hipGetLastError();
+}

@@ -24,6 +24,7 @@ typedef struct XaacEsbrSynParams {
   xaac_esbr_syn_state *state;   /* [n_ch] */
   float *out;                   /* [n_ch][2048] */
   int32_t state_stride;         /* bytes between consecutive channels' states */
+  int32_t in_stride;            /* floats between consecutive channels' row blocks (>= 2048) */
 } XaacEsbrSynParams;
 
 #ifdef __cplusplus

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64) void xaac_esbr_synthesis_kernel(XaacEsbrSynPara
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int r = r0 + j, ch = 2 * pair + (r >> 5);
-      const size_t off = ((size_t)(ch < p.n_ch ? ch : 0) * 32 + (r & 31)) * 64 + lane;
+      const size_t off = (size_t)(ch < p.n_ch ? ch : 0) * p.in_stride + (size_t)(r & 31) * 64 + lane;
       tr[j] = p.qmf_re[off];
       ti[j] = p.qmf_im[off];
     }

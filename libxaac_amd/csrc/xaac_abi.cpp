@@ -258,20 +258,32 @@ int32_t xaac_esbr_sbr_process_batch(xaac_ctx *c, const xaac_esbr_sbr_batch *b) {
   if (b->n_ch < 0) return XAAC_FATAL_BAD_ARG;
   if (b->n_ch == 0) return XAAC_OK;
   if (!b->core || !b->header || !b->frame || !b->side || !b->state || !b->out || !b->workspace) return XAAC_FATAL_NULL_ARG;
+  const bool with_ps = b->ps_frame != nullptr;
+  if (with_ps != (b->ps_state != nullptr) || with_ps != (b->out_r != nullptr)) return XAAC_FATAL_BAD_ARG;
   if (b->workspace_bytes < xaac_esbr_workspace_bytes(b->n_ch)) return XAAC_FATAL_BAD_ARG;
   if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
   const size_t n = (size_t)b->n_ch;
   float *ws = static_cast<float *>(b->workspace);
   float *ana_re = ws, *ana_im = ana_re + n * 2048;
   float *out_re = ana_im + n * 2048, *out_im = out_re + n * XAAC_ESBR_OUT_ROWS * 64;
-  float *syn_re = out_im + n * XAAC_ESBR_OUT_ROWS * 64, *syn_im = syn_re + n * 2048;
-  /* the banks' states are the first two members of xaac_esbr_state: the bank kernels take them at its stride */
+  float *syn_re = out_im + n * XAAC_ESBR_OUT_ROWS * 64, *syn_im = syn_re + n * XAAC_ESBR_L_ROWS * 64;
+  float *r_re = syn_im + n * XAAC_ESBR_L_ROWS * 64, *r_im = r_re + n * 2048;
+  /* the banks' states are members of xaac_esbr_state / xaac_esbr_ps_state: the bank kernels take them at that stride */
   XaacEsbrAnaParams pa = {b->n_ch, b->core, &b->state->ana, ana_re, ana_im, (int32_t)sizeof(xaac_esbr_state)};
   if (!hip_ok(xaac_launch_esbr_analysis(&pa, c->stream))) return XAAC_FATAL_HIP;
-  XaacEsbrCoreParams pc = {b->n_ch, b->header, b->frame, b->side, b->state, ana_re, ana_im, out_re, out_im, syn_re, syn_im, b->status};
+  XaacEsbrCoreParams pc = {b->n_ch, b->header, b->frame, b->side, b->state, ana_re, ana_im, out_re, out_im, syn_re, syn_im,
+                           with_ps ? 1 : 0, b->status};
   if (!hip_ok(xaac_launch_esbr_core(&pc, c->stream))) return XAAC_FATAL_HIP;
-  XaacEsbrSynParams ps = {b->n_ch, syn_re, syn_im, &b->state->syn, b->out, (int32_t)sizeof(xaac_esbr_state)};
+  if (with_ps) {
+    XaacEsbrPsParams pp = {b->n_ch, b->header, b->frame, b->ps_frame, b->ps_state, syn_re, syn_im, r_re, r_im, b->status};
+    if (!hip_ok(xaac_launch_esbr_ps(&pp, c->stream))) return XAAC_FATAL_HIP;
+  }
+  XaacEsbrSynParams ps = {b->n_ch, syn_re, syn_im, &b->state->syn, b->out, (int32_t)sizeof(xaac_esbr_state), XAAC_ESBR_L_ROWS * 64};
   if (!hip_ok(xaac_launch_esbr_synthesis(&ps, c->stream))) return XAAC_FATAL_HIP;
+  if (with_ps) {
+    XaacEsbrSynParams pr = {b->n_ch, r_re, r_im, &b->ps_state->syn_r, b->out_r, (int32_t)sizeof(xaac_esbr_ps_state), 2048};
+    if (!hip_ok(xaac_launch_esbr_synthesis(&pr, c->stream))) return XAAC_FATAL_HIP;
+  }
   c->last_grid = b->n_ch; c->last_block = 64; c->last_lds = 0;
   return XAAC_OK;
 }
@@ -318,7 +330,7 @@ int32_t xaac_esbr_qmf_synthesis_batch(xaac_ctx *c, const xaac_esbr_syn_batch *b)
   if (b->n_ch == 0) return XAAC_OK;
   if (!b->qmf_re || !b->qmf_im || !b->state || !b->out) return XAAC_FATAL_NULL_ARG;
   if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
-  XaacEsbrSynParams p = {b->n_ch, b->qmf_re, b->qmf_im, b->state, b->out, (int32_t)sizeof(xaac_esbr_syn_state)};
+  XaacEsbrSynParams p = {b->n_ch, b->qmf_re, b->qmf_im, b->state, b->out, (int32_t)sizeof(xaac_esbr_syn_state), 2048};
   if (!hip_ok(xaac_launch_esbr_synthesis(&p, c->stream))) return XAAC_FATAL_HIP;
   c->last_grid = (b->n_ch + 1) / 2; c->last_block = 64; c->last_lds = XAAC_ESBR_SYN_LDS;
   return XAAC_OK;

@@ -37,10 +37,19 @@ int xo_esbr_apply_ps(const xaac_ps_frame *pf, xaac_esbr_ps_state *st, float *l_r
 }
 
 /* one frame of one channel: core 1024 floats in, out 2048 floats */
+int xo_esbr_sbr_frame_ps(const float *core, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
+                         xaac_esbr_state *st, const xaac_ps_frame *pf, xaac_esbr_ps_state *pst, float *out, float *out_r);
+
 int xo_esbr_sbr_frame(const float *core, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
                       xaac_esbr_state *st, float *out) {
+  return xo_esbr_sbr_frame_ps(core, h, f, sd, st, nullptr, nullptr, out, nullptr);
+}
+
+/* ... and of one HE-AACv2 stream when pf / pst / out_r are given: float PS between regrouping and two synthesis banks */
+int xo_esbr_sbr_frame_ps(const float *core, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
+                         xaac_esbr_state *st, const xaac_ps_frame *pf, xaac_esbr_ps_state *pst, float *out, float *out_r) {
   static thread_local float qre[XAAC_ESBR_ROWS][64], qim[XAAC_ESBR_ROWS][64], ore[42][64], oim[42][64];
-  static thread_local float rre[32][64], rim[32][64];
+  static thread_local float rre[38][64], rim[38][64], xre[32][64], xim[32][64];
   int rc = 0;
   if (sd->qmf_sb_prev >= 0 && sd->qmf_sb_prev <= 64) {
     const XsCx cx = {0, 1};
@@ -70,6 +79,26 @@ int xo_esbr_sbr_frame(const float *core, const xaac_sbr_header *h, const xaac_sb
         rim[i][k] = k < xo ? qim[2 + i][k] : oim[2 + i][k];
       }
     }
+  }
+  if (pf) {
+    for (int i = 32; i < 38; i++) /* sbr_dec.c:487-505 */
+      for (int k = 0; k < 64; k++) {
+        rre[i][k] = k < 5 ? qre[2 + i][k] : 0.0f;
+        rim[i][k] = k < 5 ? qim[2 + i][k] : 0.0f;
+      }
+    bool bad = pf->num_env < 1 || pf->num_env > XAAC_PS_MAX_ENV || pf->border_position[0] < 0;
+    if (!bad)
+      for (int e = 0; e < pf->num_env; e++) bad |= pf->border_position[e] > pf->border_position[e + 1] || pf->border_position[e + 1] > 32;
+    if (f->apply_processing && !bad) {
+      memset(xre, 0, sizeof(xre));
+      memset(xim, 0, sizeof(xim));
+      xo_esbr_apply_ps(pf, pst, &rre[0][0], &rim[0][0], &xre[0][0], &xim[0][0], h->sub_band_end);
+    } else {
+      memcpy(xre, rre, sizeof(xre));
+      memcpy(xim, rim, sizeof(xim));
+      if (bad && f->apply_processing) rc = -1;
+    }
+    xo_esbr_synthesis(&xre[0][0], &xim[0][0], pst->syn_r.ring, &pst->syn_r.drc_offset, &pst->syn_r.filt_off, out_r);
   }
   xo_esbr_synthesis(&rre[0][0], &rim[0][0], st->syn.ring, &st->syn.drc_offset, &st->syn.filt_off, out);
   memcpy(st->qmf_re, qre + 32, sizeof(st->qmf_re));

@@ -82,3 +82,65 @@ def test_chain_vs_oracle(oracle):
                 g = EsbrState.from_buffer_copy(s_g[ch].tobytes())
                 raise AssertionError((fr, ch, [x for x in c.diff_state(st_o[ch], g) if x[0] not in ("ana", "syn")]))
         assert np.any(o_g != 0)
+
+
+@pytest.mark.gpu
+def test_ps_chain_vs_oracle(oracle):
+    """HE-AACv2 streams: the same chain with the float parametric-stereo tool between regrouping and two synthesis banks
+    (xaac_esbr_sbr_process_batch with ps_frame / ps_state / out_r); the oracle's float PS is pinned to the reference by
+    tests/test_esbr_ps_oracle_vs_reference.py.  Both output channels and both states as raw words."""
+    import torch
+    import libxaac_amd
+    from esbr_structs import EsbrPsState, new_ps_state
+    from test_esbr_ps_oracle_vs_reference import fuzz_ps_frame
+    fn = oracle.lib.xo_esbr_sbr_frame_ps
+    fn.restype = ctypes.c_int
+    fn.argtypes = [PF] + [ctypes.c_void_p] * 6 + [PF, PF]
+    recs = [r for r in c.read_records(os.path.join(ROOT, "tests", "golden", "sbr_hq_ps_records.bin.gz")) if r["ps"]]
+    dev = torch.device("cuda:0")
+    ctx = libxaac_amd.XaacContext(0, None)
+    n, frames = 21, 10
+    rng = np.random.default_rng(99)
+    offs = rng.integers(0, len(recs) - frames, n)
+    st_o, ps_o = [new_state() for _ in range(n)], [new_ps_state() for _ in range(n)]
+    pack = lambda xs: torch.from_numpy(np.stack([np.frombuffer(bytes(x), np.uint8) for x in xs])).to(dev)
+    st_g, ps_g = pack(st_o), pack(ps_o)
+    ws = torch.zeros(ctx.esbr_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    out_l = torch.zeros((n, 2048), dtype=torch.float32, device=dev)
+    out_r = torch.zeros((n, 2048), dtype=torch.float32, device=dev)
+    status = torch.zeros(n, dtype=torch.int32, device=dev)
+    prev_modes, prev_tables = [[0] * 10 for _ in range(n)], [None] * n
+    for fr in range(frames):
+        hs, fs, sds, pfs = [], [], [], []
+        core = (rng.uniform(-1, 1, (n, 1024)) * rng.choice([30000.0, 1500.0, 40.0], (n, 1))).astype(np.float32)
+        for ch in range(n):
+            rec = recs[offs[ch] + fr]
+            h, f = c.Header.from_buffer_copy(bytes(rec["header"])), c.Frame.from_buffer_copy(bytes(rec["frame"]))
+            if fr == 5 and ch % 4 == 0:
+                f.apply_processing = 0
+            sd = make_side(rng, h, f, prev_modes[ch], fr, 0, False)
+            tables = bytes(h)[12:]
+            if prev_tables[ch] != tables:
+                sd.reset_flag = 1
+            prev_tables[ch] = tables
+            pf = fuzz_ps_frame(rng, c.PsFrame.from_buffer_copy(bytes(rec["ps_frame"])), ch % 3)
+            hs.append(h), fs.append(f), sds.append(sd), pfs.append(pf)
+            prev_modes[ch] = [f.sbr_invf_mode[i] for i in range(10)]
+        ctx.esbr_sbr_process_batch(torch.from_numpy(core).to(dev), pack(hs), pack(fs), pack(sds), st_g, out_l, ws, status,
+                                   pack(pfs), ps_g, out_r)
+        ctx.sync()
+        l_g, r_g, s_g, p_g = out_l.cpu().numpy(), out_r.cpu().numpy(), st_g.cpu().numpy(), ps_g.cpu().numpy()
+        assert not status.cpu().numpy().any()
+        for ch in range(n):
+            ol, orr = np.zeros(2048, np.float32), np.zeros(2048, np.float32)
+            rc = fn(core[ch].ctypes.data_as(PF), ctypes.byref(hs[ch]), ctypes.byref(fs[ch]), ctypes.byref(sds[ch]),
+                    ctypes.byref(st_o[ch]), ctypes.byref(pfs[ch]), ctypes.byref(ps_o[ch]), ol.ctypes.data_as(PF),
+                    orr.ctypes.data_as(PF))
+            assert rc == 0
+            for nm, a, b in (("left", ol, l_g[ch]), ("right", orr, r_g[ch])):
+                bad = np.nonzero(a.view(np.uint32) != b.view(np.uint32))[0]
+                assert bad.size == 0, (fr, ch, nm, len(bad), bad[:5], a[bad[:3]], b[bad[:3]])
+            assert np.array_equal(np.frombuffer(bytes(st_o[ch]), np.uint8), s_g[ch]), (fr, ch)
+            if not np.array_equal(np.frombuffer(bytes(ps_o[ch]), np.uint8), p_g[ch]):
+                raise AssertionError((fr, ch, c.diff_state(ps_o[ch], EsbrPsState.from_buffer_copy(p_g[ch].tobytes()))))
+        assert np.any(r_g != 0) and np.any(l_g != r_g)

@@ -31,7 +31,7 @@ def main_ps():
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DXS_PROFILE",
                            "-shared", "-x", "hip"] + [os.path.join(src, f) for f in
                            ("imdct_kernel.hip", "sbr_qmf_kernel.hip", "sbr_core_kernel.hip", "sbr_ps_kernel.hip",
-                            "limiter_kernel.hip", "esbr_qmf_kernel.hip", "usac_imdct_kernel.hip", "esbr_core_kernel.hip", "xaac_abi.cpp")] + ["-o", out])
+                            "limiter_kernel.hip", "esbr_qmf_kernel.hip", "usac_imdct_kernel.hip", "esbr_core_kernel.hip", "esbr_ps_kernel.hip", "xaac_abi.cpp")] + ["-o", out])
     libxaac_amd.library_path = lambda: out
     import bench
     dev = torch.device("cuda:0")
@@ -72,7 +72,7 @@ def main():
     out = os.path.join(ROOT, "libxaac_amd", "libxaac_amd_prof.so")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DXS_PROFILE",
                            "-shared", "-x", "hip"] + [os.path.join(src, f) for f in
-                           ("imdct_kernel.hip", "sbr_qmf_kernel.hip", "sbr_core_kernel.hip", "sbr_ps_kernel.hip", "limiter_kernel.hip", "esbr_qmf_kernel.hip", "usac_imdct_kernel.hip", "esbr_core_kernel.hip", "xaac_abi.cpp")] + ["-o", out])
+                           ("imdct_kernel.hip", "sbr_qmf_kernel.hip", "sbr_core_kernel.hip", "sbr_ps_kernel.hip", "limiter_kernel.hip", "esbr_qmf_kernel.hip", "usac_imdct_kernel.hip", "esbr_core_kernel.hip", "esbr_ps_kernel.hip", "xaac_abi.cpp")] + ["-o", out])
     libxaac_amd.library_path = lambda: out
     import bench
     dev = torch.device("cuda:0")
