@@ -359,4 +359,83 @@ static void from_esbr_state(const xaac_esbr_state *o, ia_sbr_dec_struct *d, ia_s
   memcpy(f->harm_flag_prev, o->harm_flag_prev, sizeof(o->harm_flag_prev));
 }
 
+static void to_esbr_ps_state(const ia_ps_dec_struct *ps, const ia_sbr_qmf_filter_bank_struct *sr, xaac_esbr_ps_state *o) {
+  int i, j, m, k;
+  memset(o, 0, sizeof(*o));
+  for (i = 0; i < 3; i++)
+    for (j = 0; j < 12; j++) {
+      o->hyb_hist_re[i][j] = ps->hyb_qmf_buf_re_20[i][j];
+      o->hyb_hist_im[i][j] = ps->hyb_qmf_buf_im_20[i][j];
+    }
+  memcpy(o->qmf_delay_re, ps->qmf_delay_buf_re, sizeof(o->qmf_delay_re));
+  memcpy(o->qmf_delay_im, ps->qmf_delay_buf_im, sizeof(o->qmf_delay_im));
+  for (i = 0; i < 2; i++)
+    for (j = 0; j < 12; j++) {
+      o->sub_delay_re[i][j] = ps->sub_qmf_delay_buf_re[i][j];
+      o->sub_delay_im[i][j] = ps->sub_qmf_delay_buf_im[i][j];
+    }
+  memcpy(o->ser_qmf_re, ps->ser_qmf_delay_buf_re, sizeof(o->ser_qmf_re));
+  memcpy(o->ser_qmf_im, ps->ser_qmf_delay_buf_im, sizeof(o->ser_qmf_im));
+  for (m = 0; m < 3; m++)
+    for (k = 0; k < 5; k++)
+      for (j = 0; j < 12; j++) {
+        o->ser_sub_re[m][k][j] = ps->ser_sub_qmf_dealy_buf_re[m][k][j];
+        o->ser_sub_im[m][k][j] = ps->ser_sub_qmf_dealy_buf_im[m][k][j];
+      }
+  for (j = 0; j < 20; j++) {
+    o->h_prev[0][j] = ps->h11_re_prev[j]; o->h_prev[1][j] = ps->h12_re_prev[j];
+    o->h_prev[2][j] = ps->h21_re_prev[j]; o->h_prev[3][j] = ps->h22_re_prev[j];
+    o->h_prev[4][j] = ps->h11_im_prev[j]; o->h_prev[5][j] = ps->h12_im_prev[j];
+    o->h_prev[6][j] = ps->h21_im_prev[j]; o->h_prev[7][j] = ps->h22_im_prev[j];
+    o->peak_decay_fast[j] = ps->peak_decay_fast_bin[j];
+    o->prev_nrg[j] = ps->prev_nrg_bin[j];
+    o->prev_peak_diff[j] = ps->prev_peak_diff_bin[j];
+  }
+  o->delay_buf_idx = ps->delay_buf_idx;
+  for (m = 0; m < 3; m++) o->delay_buf_idx_ser[m] = ps->delay_buf_idx_ser[m];
+  for (j = 0; j < 64; j++) o->delay_qmf_idx[j] = ps->delay_qmf_delay_buf_idx[j];
+  memcpy(o->syn_r.ring, sr->filter_states_32, sizeof(o->syn_r.ring));
+  o->syn_r.drc_offset = sr->ixheaacd_drc_offset;
+  o->syn_r.filt_off = (int32_t)(sr->filter_pos_syn_32 - sr->p_filter_32);
+}
+
+static void from_esbr_ps_state(const xaac_esbr_ps_state *o, ia_ps_dec_struct *ps, ia_sbr_qmf_filter_bank_struct *sr) {
+  int i, j, m, k;
+  for (i = 0; i < 3; i++)
+    for (j = 0; j < 12; j++) {
+      ps->hyb_qmf_buf_re_20[i][j] = o->hyb_hist_re[i][j];
+      ps->hyb_qmf_buf_im_20[i][j] = o->hyb_hist_im[i][j];
+    }
+  memcpy(ps->qmf_delay_buf_re, o->qmf_delay_re, sizeof(o->qmf_delay_re));
+  memcpy(ps->qmf_delay_buf_im, o->qmf_delay_im, sizeof(o->qmf_delay_im));
+  for (i = 0; i < 2; i++)
+    for (j = 0; j < 12; j++) {
+      ps->sub_qmf_delay_buf_re[i][j] = o->sub_delay_re[i][j];
+      ps->sub_qmf_delay_buf_im[i][j] = o->sub_delay_im[i][j];
+    }
+  memcpy(ps->ser_qmf_delay_buf_re, o->ser_qmf_re, sizeof(o->ser_qmf_re));
+  memcpy(ps->ser_qmf_delay_buf_im, o->ser_qmf_im, sizeof(o->ser_qmf_im));
+  for (m = 0; m < 3; m++)
+    for (k = 0; k < 5; k++)
+      for (j = 0; j < 12; j++) {
+        ps->ser_sub_qmf_dealy_buf_re[m][k][j] = o->ser_sub_re[m][k][j];
+        ps->ser_sub_qmf_dealy_buf_im[m][k][j] = o->ser_sub_im[m][k][j];
+      }
+  for (j = 0; j < 20; j++) {
+    ps->h11_re_prev[j] = o->h_prev[0][j]; ps->h12_re_prev[j] = o->h_prev[1][j];
+    ps->h21_re_prev[j] = o->h_prev[2][j]; ps->h22_re_prev[j] = o->h_prev[3][j];
+    ps->h11_im_prev[j] = o->h_prev[4][j]; ps->h12_im_prev[j] = o->h_prev[5][j];
+    ps->h21_im_prev[j] = o->h_prev[6][j]; ps->h22_im_prev[j] = o->h_prev[7][j];
+    ps->peak_decay_fast_bin[j] = o->peak_decay_fast[j];
+    ps->prev_nrg_bin[j] = o->prev_nrg[j];
+    ps->prev_peak_diff_bin[j] = o->prev_peak_diff[j];
+  }
+  ps->delay_buf_idx = (WORD16)o->delay_buf_idx;
+  for (m = 0; m < 3; m++) ps->delay_buf_idx_ser[m] = (WORD16)o->delay_buf_idx_ser[m];
+  for (j = 0; j < 64; j++) ps->delay_qmf_delay_buf_idx[j] = o->delay_qmf_idx[j];
+  memcpy(sr->filter_states_32, o->syn_r.ring, sizeof(o->syn_r.ring));
+  sr->ixheaacd_drc_offset = o->syn_r.drc_offset;
+  sr->filter_pos_syn_32 = (WORD32 *)sr->p_filter_32 + o->syn_r.filt_off;
+}
+
 #endif

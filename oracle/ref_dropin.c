@@ -34,7 +34,8 @@ static struct {
   int32_t *status;
   void *ws;
   uint64_t ws_bytes;
-  float *core, *time;          /* Path A: time_sample_buf in / out */
+  float *core, *time, *time_r; /* Path A: time_sample_buf in / out (left, right) */
+  xaac_esbr_ps_state *epss;
   xaac_esbr_side *side;
   xaac_esbr_state *estate;
   void *ews;
@@ -77,6 +78,8 @@ static void setup(void) {
   HIP(hipMalloc(&g.ws, g.ws_bytes));
   HIP(hipMalloc((void **)&g.core, 4096));
   HIP(hipMalloc((void **)&g.time, 8192));
+  HIP(hipMalloc((void **)&g.time_r, 8192));
+  HIP(hipMalloc((void **)&g.epss, sizeof(xaac_esbr_ps_state)));
   HIP(hipMalloc((void **)&g.side, sizeof(xaac_esbr_side)));
   HIP(hipMalloc((void **)&g.estate, sizeof(xaac_esbr_state)));
   HIP(hipMalloc(&g.ews, xaac_esbr_workspace_bytes(1)));
@@ -183,15 +186,22 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
      regrouping, synthesis -- is one xaac_esbr_sbr_process_batch call; the state lives in the reference's structs
      between calls (to_esbr_state / from_esbr_state) */
   if (h->enh_sbr && aot != AOT_ER_AAC_ELD && aot != AOT_ER_AAC_LD && !h->usac_flag && h->hbe_flag && f->sbr_patching_mode == 1 &&
-      !h->enh_sbr_ps &&
-      h->channel_mode != PS_STEREO && !drc_on && !ldmps && !mps && !f->mps_sbr_flag && f->sbr_mode != PVC_SBR &&
+      (h->channel_mode == PS_STEREO ? (ps != NULL && synth_r != NULL && !ps->use_34_st_bands && !ps->use_pca_rot_flg && ps->ps_mode == 0)
+                                    : !h->enh_sbr_ps) &&
+      !drc_on && !ldmps && !mps && !f->mps_sbr_flag && f->sbr_mode != PVC_SBR &&
       h->sbr_ratio_idx != SBR_UPSAMPLE_IDX_4_1 && !h->pre_proc_flag && h->num_time_slots == 16 &&
       d->str_codec_qmf_bank.no_channels == 32 && d->str_synthesis_qmf_bank.no_channels == 64 && !getenv("XAAC_DROPIN_NO_ESBR")) {
     static xaac_esbr_side sd;
     static xaac_esbr_state est;
+    static xaac_esbr_ps_state epss;
     xaac_esbr_sbr_batch b;
     const ia_qmf_dec_tables_struct *q = tabs->qmf_dec_tables_ptr;
+    const int eps = h->channel_mode == PS_STEREO;
     setup();
+    if (eps) { /* the same re-basing for the right channel's bank */
+      synth_r->filter_pos_syn_32 += q->esbr_qmf_c - synth_r->p_filter_32;
+      synth_r->p_filter_32 = q->esbr_qmf_c;
+    }
     /* the pointer re-basing ixheaacd_esbr_synthesis_filt_block does on entry (sbr_dec.c:578-580) */
     d->str_synthesis_qmf_bank.filter_pos_syn_32 += q->esbr_qmf_c - d->str_synthesis_qmf_bank.p_filter_32;
     d->str_synthesis_qmf_bank.p_filter_32 = q->esbr_qmf_c;
@@ -212,6 +222,15 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     b.side = g.side;
     b.state = g.estate;
     b.out = g.time;
+    if (eps) {
+      to_ps_frame(ps, &psf);
+      to_esbr_ps_state(ps, synth_r, &epss);
+      HIP(hipMemcpy(g.psf, &psf, sizeof(psf), hipMemcpyHostToDevice));
+      HIP(hipMemcpy(g.epss, &epss, sizeof(epss), hipMemcpyHostToDevice));
+      b.ps_frame = g.psf;
+      b.ps_state = g.epss;
+      b.out_r = g.time_r;
+    }
     b.status = g.status;
     b.workspace = g.ews;
     b.workspace_bytes = xaac_esbr_workspace_bytes(1);
@@ -228,6 +247,13 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     HIP(hipMemcpy(&est, g.estate, sizeof(est), hipMemcpyDeviceToHost));
     HIP(hipMemcpy(d->time_sample_buf, g.time, 8192, hipMemcpyDeviceToHost));
     from_esbr_state(&est, d, h, f);
+    if (eps) { /* right channel out, PS state back, and what the second synthesis call leaves in channel 1's frame data */
+      HIP(hipMemcpy(&epss, g.epss, sizeof(epss), hipMemcpyDeviceToHost));
+      HIP(hipMemcpy(ps->time_sample_buf[1], g.time_r, 8192, hipMemcpyDeviceToHost));
+      from_esbr_ps_state(&epss, ps, synth_r);
+      ps->use_34_st_bands_prev = ps->use_34_st_bands;
+      ((ia_sbr_frame_info_data_struct *)((ia_handle_sbr_dec_inst_struct)self)->frame_buffer[1])->reset_flag = 0;
+    }
     /* what the branch leaves behind for the parser and the next call (sbr_dec.c:962-966, :657, :1006) */
     d->band_count = h->pstr_freq_band_data->sub_band_end;
     f->reset_flag = 0;

@@ -41,11 +41,11 @@ def test_reference_decoder_with_gpu_back_end_is_byte_identical(aac, tmp_path):
     assert len(a) > 100000 and a == b, (len(a), len(b), n_imdct, n_sbr)
 
 
-@pytest.mark.parametrize("aac", [s for s in STREAMS if "aot5_" in s], ids=lambda s: os.path.basename(s))
+@pytest.mark.parametrize("aac", [s for s in STREAMS if "aot5_" in s or "aot29_" in s], ids=lambda s: os.path.basename(s))
 def test_default_flags_he_aac_takes_the_esbr_path_on_the_gpu(aac, tmp_path):
-    """HE-AAC v1 with the reference's DEFAULT flags (-esbr:1): ixheaacd_sbr_dec's Path A branch -- 32-bit analysis bank,
-    float HF generator and envelope adjuster, 64-band synthesis -- runs on the GPU (xaac_esbr_sbr_process_batch) and the
-    decoded file is byte-identical to the unmodified reference decoder's."""
+    """HE-AAC v1 and v2 with the reference's DEFAULT flags (-esbr:1): ixheaacd_sbr_dec's Path A branch -- 32-bit analysis
+    bank, float HF generator and envelope adjuster, [float parametric stereo,] 64-band synthesis bank(s) -- runs on the GPU
+    (xaac_esbr_sbr_process_batch) and the decoded file is byte-identical to the unmodified reference decoder's."""
     if not (os.path.exists(os.path.join(REF, "xaacdec")) and os.path.exists(os.path.join(REF, "xaacdec_dropin"))):
         pytest.skip("oracle/_ref/xaacdec[_dropin] missing (built by oracle/Makefile.ref where /root/reference exists)")
     ref_wav, gpu_wav = str(tmp_path / "ref.wav"), str(tmp_path / "gpu.wav")

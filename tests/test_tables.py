@@ -86,6 +86,15 @@ def test_usac_tables_equal_reference_rom(tmp_path):
     _regenerated_equals_committed("gen_tables_usac", "tables_usac.inc", tmp_path)
 
 
+def test_esbr_float_tables_equal_reference_rom(tmp_path):
+    _regenerated_equals_committed("gen_tables_esbr", "tables_esbr.inc", tmp_path)
+
+
+def test_esbr_ps_tables_equal_reference_rom_and_libm(tmp_path):
+    """ROM members as exact float literals + the mixing-matrix table re-derived with this machine's C library"""
+    _regenerated_equals_committed("gen_tables_esbr_ps", "tables_esbr_ps.inc", tmp_path)
+
+
 def test_esbr_tables_are_the_q31_versions_of_the_q15_ones():
     """independent of the ROM: the 32-bit eSBR constants are the 16-bit bank constants at 16 more fractional bits
     (prototype filter, radix-4 twiddles, modulation twiddles), to rounding"""
