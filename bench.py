@@ -18,7 +18,8 @@ A "step" = one pass of the hot path over one batch.  Inputs are resident in HBM 
 step / mean step duration from HIP events recorded on the launch stream.  Every run checks itself
 (outside the timed region): the status words of the last step must all be zero, and one more step of a
 256-stream slice is decoded by the oracle chain on the host from the same device state and compared word for
-word (`bit_exact_vs_oracle`).  `secondary` (N=1 only) = short runs of C2 (AAC-LC IMDCT, BASELINE configs[1]) and
+word (`bit_exact_vs_oracle`).  `secondary` (N=1 only) = short runs of C2 (AAC-LC IMDCT, BASELINE configs[1]), C4A (the
+same HE-AACv2 streams through the reference's default float eSBR path) and
 C3 (HE-AACv1, configs[2]) in the same process.  `cpu_baseline` = the same workload on the host cores (the
 compiled reference when oracle/_ref travelled with the repo, else the bit-exact restatement), bounded sample,
 rank 0 at N=1 only.
@@ -174,6 +175,79 @@ def make_inputs_c4(torch, device, sets, seed):
                         "hdr": hdr, "frames": frames, "sbr_state": st0.clone(), "ps_state": ps0.clone(),
                         "pcm": torch.zeros(n * 4096, dtype=torch.int16, device=device)})
     return batches
+
+
+def secondary_esbr(torch, libxaac_amd, ctx, dev, steps, warmup):
+    """The same HE-AACv2 streams through the reference's DEFAULT SBR path (-esbr:1, "Path A": 32-bit-ring QMF banks, float
+    LPP transposer / envelope adjuster / parametric stereo): xaac_esbr_sbr_process_batch on float core
+    samples, 8192 streams per step, side info tiled from 64 reference-captured HE-AACv2 frames with synthetic float
+    envelope data.  One frame step of the 64 distinct set-ups is compared word for word with the oracle chain."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import sbr_capture as cap
+    from esbr_structs import new_state, new_ps_state
+    from test_esbr_core_oracle_vs_reference import make_side
+    from test_esbr_ps_oracle_vs_reference import fuzz_ps_frame
+    n = FRAMES_PER_STEP
+    rng = np.random.default_rng(7)
+    recs = [r for r in cap.read_records(os.path.join(ROOT, "tests", "golden", "sbr_hq_ps_records.bin.gz"))
+            if r["ps"] and r["frame"].apply_processing][:64]
+    hs, fs, sds, pfs = [], [], [], []
+    for r in recs:
+        h, f = cap.Header.from_buffer_copy(bytes(r["header"])), cap.Frame.from_buffer_copy(bytes(r["frame"]))
+        sd = make_side(rng, h, f, [0] * 10, 0, 0, False)
+        sd.reset_flag = 1
+        hs.append(h), fs.append(f), sds.append(sd)
+        pfs.append(fuzz_ps_frame(rng, cap.PsFrame.from_buffer_copy(bytes(r["ps_frame"])), 0))
+    tile = lambda xs: torch.from_numpy(np.stack([np.frombuffer(bytes(xs[i % len(xs)]), np.uint8) for i in range(n)])).to(dev)
+    hd, fr, sd, pf = tile(hs), tile(fs), tile(sds), tile(pfs)
+    st0 = torch.from_numpy(np.stack([np.frombuffer(bytes(new_state()), np.uint8)] * n)).to(dev)
+    ps0 = torch.from_numpy(np.stack([np.frombuffer(bytes(new_ps_state()), np.uint8)] * n)).to(dev)
+    st, pst = st0.clone(), ps0.clone()
+    core_h = (rng.uniform(-1, 1, (n, 1024)) * 12000.0).astype(np.float32)
+    core = torch.from_numpy(core_h).to(dev)
+    ws = torch.zeros(ctx.esbr_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    out_l = torch.zeros((n, 2048), dtype=torch.float32, device=dev)
+    out_r = torch.zeros((n, 2048), dtype=torch.float32, device=dev)
+    status = torch.zeros(n, dtype=torch.int32, device=dev)
+    run = lambda: ctx.esbr_sbr_process_batch(core, hd, fr, sd, st, out_l, ws, status, pf, pst, out_r)
+    run()
+    ctx.sync()
+    refused = float(status.cpu().numpy().astype(bool).mean())
+    try:  # the first step (fresh states) against the oracle, the 64 distinct set-ups
+        import oracle_lib
+        fn = oracle_lib.load_oracle().lib.xo_esbr_sbr_frame_ps
+        fn.restype = ctypes.c_int
+        PF = ctypes.POINTER(ctypes.c_float)
+        fn.argtypes = [PF] + [ctypes.c_void_p] * 6 + [PF, PF]
+        lg, rg = out_l[:64].cpu().numpy(), out_r[:64].cpu().numpy()
+        ok = True
+        for i in range(len(recs)):
+            a, b = np.zeros(2048, np.float32), np.zeros(2048, np.float32)
+            so, po = new_state(), new_ps_state()
+            fn(core_h[i].ctypes.data_as(PF), ctypes.byref(hs[i]), ctypes.byref(fs[i]), ctypes.byref(sds[i]), ctypes.byref(so),
+               ctypes.byref(pfs[i]), ctypes.byref(po), a.ctypes.data_as(PF), b.ctypes.data_as(PF))
+            ok = ok and np.array_equal(a.view(np.uint32), lg[i].view(np.uint32)) and np.array_equal(b.view(np.uint32), rg[i].view(np.uint32))
+        ok = bool(ok)
+    except Exception as e:
+        ok = "unavailable: %r" % (e,)
+    for _ in range(warmup):
+        run()
+    ctx.sync()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    ab = n * (4096 + 2 * 8192 + 2 * st.shape[1] + 2 * pst.shape[1] + pf.shape[1] + hd.shape[1] + fr.shape[1] + sd.shape[1])
+    return {"metric": "decoded audio frames/s (32-bit-ring QMF + float eSBR + float PS: the reference's default -esbr:1 path, HE-AACv2)",
+            "value": round(n / ms * 1e3, 1), "unit": "frames/s", "steps": steps, "ms_per_step": round(ms, 4),
+            "roofline_frac": round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "alg_bytes_per_step": int(ab), "dtype": "f32 / int64",
+            "refused_frac": refused, "bit_exact_vs_oracle": ok,
+            "workload": "C4A: HE-AACv2 48 kHz, batch=%d streams/step, float core samples in: eSBR analysis -> float HF "
+                        "generator + envelope adjuster -> float parametric stereo -> two eSBR synthesis banks (5 launches); "
+                        "states carried from step to step" % n}
 
 
 def cpu_baseline_sbr(workload, seconds_budget=10.0):
@@ -599,6 +673,11 @@ def main():
                              "workload": WORKLOAD[w2] % args.sets}
             del j2
             torch.cuda.empty_cache()
+        try:
+            secondary["c4_esbr"] = secondary_esbr(torch, libxaac_amd, ctx, dev, max(10, args.steps // 5), 2)
+        except Exception as e:  # never lose the headline line over the extra entry
+            secondary["c4_esbr"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
 
     if rank == 0:
         frames = FRAMES_PER_STEP * args.steps * world

@@ -76,6 +76,25 @@ def main():
     assert not status.cpu().numpy().any()
     # algorithmic bytes per channel-frame: 4 KB core in, 8 KB out, state in + out (its history rows dominate)
     res.append(("esbr_sbr_chain(3 kernels)", us, n * (4096 + 8192 + 2 * st.shape[1])))
+    # the same chain for HE-AACv2 streams: + float parametric stereo and the second synthesis bank
+    from esbr_structs import new_ps_state
+    from test_esbr_ps_oracle_vs_reference import fuzz_ps_frame
+    precs = [r for r in c.read_records(os.path.join(ROOT, "tests", "golden", "sbr_hq_ps_records.bin.gz")) if r["ps"] and r["frame"].apply_processing][:64]
+    hs, fs, sds, pfs = [], [], [], []
+    for r in precs:
+        h, f = c.Header.from_buffer_copy(bytes(r["header"])), c.Frame.from_buffer_copy(bytes(r["frame"]))
+        sd = make_side(rng, h, f, [0] * 10, 0, 0, False)
+        sd.reset_flag = 1
+        pf = fuzz_ps_frame(rng, c.PsFrame.from_buffer_copy(bytes(r["ps_frame"])), 0)
+        for x, lst in ((h, hs), (f, fs), (sd, sds), (pf, pfs)):
+            lst.append(np.frombuffer(bytes(x), np.uint8))
+    hd, fr, sd, pf = tile(hs), tile(fs), tile(sds), tile(pfs)
+    st = torch.from_numpy(np.stack([np.frombuffer(bytes(new_state()), np.uint8)] * n)).to(dev)
+    pst = torch.from_numpy(np.stack([np.frombuffer(bytes(new_ps_state()), np.uint8)] * n)).to(dev)
+    pcm_r = torch.zeros((n, 2048), dtype=torch.float32, device=dev)
+    us = timed(torch, ctx, lambda: ctx.esbr_sbr_process_batch(core, hd, fr, sd, st, pcm, ws, status, pf, pst, pcm_r))
+    assert not status.cpu().numpy().any()
+    res.append(("esbr_sbr_ps_chain(5 kernels)", us, n * (4096 + 2 * 8192 + 2 * st.shape[1] + 2 * pst.shape[1] + pf.shape[1])))
     for name, us, bytes_ in res:
         print(json.dumps({"kernel": name, "n_ch": n, "us": round(us, 1), "channel_frames_per_s": round(n / us * 1e6),
                           "alg_GBps": round(bytes_ / us / 1e3, 1), "frac_of_8TBps": round(bytes_ / us / 1e3 / 8000, 4)}))
