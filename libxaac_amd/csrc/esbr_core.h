@@ -39,6 +39,34 @@ struct XeMat {
   FX_MEMBER float &i(int l, int k) const { return im[l * 64 + k]; }
 };
 
+/* Column walks fetch / write back XE_CH rows in one burst, so that a stage costs one memory latency per XE_CH rows
+   instead of one per row (the compiler may not move a load across an earlier store of the same matrix by itself).  The
+   order of the arithmetic is untouched. */
+#define XE_CH 8
+#if defined(__HIPCC__)
+#define XE_UNROLL _Pragma("unroll")
+#define XE_NOUNROLL _Pragma("nounroll")
+#else
+#define XE_UNROLL
+#define XE_NOUNROLL
+#endif
+FX_HD void xe_rows_load(const XeMat &m, int k, int r0, int r1, float *cr, float *ci) { /* rows r0 .. min(r0 + XE_CH, r1) - 1 */
+  XE_UNROLL
+  for (int j = 0; j < XE_CH; j++)
+    if (r0 + j < r1) {
+      cr[j] = m.r(r0 + j, k);
+      ci[j] = m.i(r0 + j, k);
+    }
+}
+FX_HD void xe_rows_store(const XeMat &m, int k, int r0, int r1, const float *cr, const float *ci) {
+  XE_UNROLL
+  for (int j = 0; j < XE_CH; j++)
+    if (r0 + j < r1) {
+      m.r(r0 + j, k) = cr[j];
+      m.i(r0 + j, k) = ci[j];
+    }
+}
+
 struct XeWork {
   float alpha_r[64][2], alpha_i[64][2];
   float bw_array[XAAC_SBR_MAX_PATCHES];
@@ -245,8 +273,13 @@ FX_HD void xe_generate_hf(const XsCx &cx, const xaac_sbr_header *h, const xaac_s
     if (k >= 1 && k < lsb) { /* covariance over 38 slots from row -2 on, :781; prediction coefficients :1077-1120 */
       float p01r = 0, p01i = 0, p02r = 0, p02i = 0, p11 = 0, p12r = 0, p12i = 0, p22 = 0;
       float r2 = src.r(-2, k), i2 = src.i(-2, k), r1 = src.r(-1, k), i1 = src.i(-1, k);
-      for (int j = 0; j < 38; j++) {
-        const float r0 = src.r(j, k), i0 = src.i(j, k);
+      XE_NOUNROLL
+      for (int j0 = 0; j0 < 38; j0 += XE_CH) {
+        float cr[XE_CH], ci[XE_CH];
+        xe_rows_load(src, k, j0, 38, cr, ci);
+        XE_UNROLL
+        for (int jj = 0; jj < XE_CH; jj++) if (j0 + jj < 38) {
+        const float r0 = cr[jj], i0 = ci[jj];
         p01r += r0 * r1 + i0 * i1;
         p01i += i0 * r1 - r0 * i1;
         p02r += r0 * r2 + i0 * i2;
@@ -257,6 +290,7 @@ FX_HD void xe_generate_hf(const XsCx &cx, const xaac_sbr_header *h, const xaac_s
         p22 += r2 * r2 + i2 * i2;
         r2 = r1; i2 = i1;
         r1 = r0; i1 = i0;
+        }
       }
       const float det = p11 * p22 - (p12r * p12r + p12i * p12i) * 0.999999f;
       if (det != 0.0f) {
@@ -278,7 +312,8 @@ FX_HD void xe_generate_hf(const XsCx &cx, const xaac_sbr_header *h, const xaac_s
   if (w->err) return;
   XS_PAR(k2, 0, 64) {
     const int k = w->src_band[k2];
-    if (k == -1) {
+    if (k == -1 || (k == -2 && k2 >= h->sub_band_start && k2 < usb)) { /* (a band the patch loop left out keeps stale data
+                                                                         in the reference; here it is silent) */
       for (int l = start; l < end; l++) {
         dst.r(l, k2) = 0.0f;
         dst.i(l, k2) = 0.0f;
@@ -289,17 +324,25 @@ FX_HD void xe_generate_hf(const XsCx &cx, const xaac_sbr_header *h, const xaac_s
       bw *= bw;
       const float a1r = bw * w->alpha_r[k][1], a1i = bw * w->alpha_i[k][1];
       float r2 = src.r(start - 2, k), i2 = src.i(start - 2, k), r1 = src.r(start - 1, k), i1 = src.i(start - 1, k);
-      for (int l = start; l < end; l++) {
-        const float r0 = src.r(l, k), i0 = src.i(l, k);
-        float yr = r0 * 1.0f, yi = i0 * 1.0f;
-        if (bw > 0.0f) {
-          yr += (a0r * r1 - a0i * i1 + a1r * r2 - a1i * i2) * 1.0f;
-          yi += (a0i * r1 + a0r * i1 + a1i * r2 + a1r * i2) * 1.0f;
-        }
-        dst.r(l, k2) = yr;
-        dst.i(l, k2) = yi;
-        r2 = r1; i2 = i1;
-        r1 = r0; i1 = i0;
+      XE_NOUNROLL
+      for (int l0 = start; l0 < end; l0 += XE_CH) {
+        float cr[XE_CH], ci[XE_CH];
+        xe_rows_load(src, k, l0, end, cr, ci);
+        XE_UNROLL
+        for (int j = 0; j < XE_CH; j++)
+          if (l0 + j < end) {
+            const float r0 = cr[j], i0 = ci[j];
+            float yr = r0 * 1.0f, yi = i0 * 1.0f;
+            if (bw > 0.0f) {
+              yr += (a0r * r1 - a0i * i1 + a1r * r2 - a1i * i2) * 1.0f;
+              yi += (a0i * r1 + a0r * i1 + a1i * r2 + a1r * i2) * 1.0f;
+            }
+            cr[j] = yr;
+            ci[j] = yi;
+            r2 = r1; i2 = i1;
+            r1 = r0; i1 = i0;
+          }
+        xe_rows_store(dst, k2, l0, end, cr, ci);
       }
     }
   }
@@ -456,14 +499,19 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
       float nrg = 0;
       const int k = sb_start + c;
       if (l0 < l1) {
-        for (int l = l0; l < l1; l++) nrg += (x.r(l, k) * x.r(l, k)) + (x.i(l, k) * x.i(l, k));
+        XE_NOUNROLL
+        for (int j0 = l0; j0 < l1; j0 += XE_CH) {
+          float cr[XE_CH], ci[XE_CH];
+          xe_rows_load(x, k, j0, l1, cr, ci);
+          XE_UNROLL
+          for (int j = 0; j < XE_CH; j++)
+            if (j0 + j < l1) nrg += (cr[j] * cr[j]) + (ci[j] * ci[j]);
+        }
         nrg = nrg / (float)(l1 - l0);
       }
       w->nrg_est[c] = nrg;
     }
     cx.sync();
-    float g_gain[1], g_noise[1], g_tone[1]; /* this lane's band (one band per lane; the host walks them one by one) */
-    (void)g_gain; (void)g_noise; (void)g_tone;
     XS_PAR(c, 0, num_sb) { /* gains, :690-722 */
       float est = w->nrg_est[c];
       if (!int_mode) {
@@ -536,6 +584,7 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
         }
       start_up = 0;
     }
+    const bool tes = xaac_esbr_q_gamma[sd->inter_temp_shape_mode[i] & 3] > 0; /* inter-TES works across bands: through memory */
     XS_PAR(k, 0, 64) { /* apply: smoothed gain, noise; the two five-deep histories rotate once per slot, :771-817 */
       float eg[5], nb[5];
       for (int n = 0; n < 5; n++) {
@@ -545,29 +594,46 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
       const bool active = k < num_sb;
       const float gain = active ? w->nrg_gain[k] : 0.0f, nl = active ? w->noise_level[k] : 0.0f;
       const bool no_noise = active && (w->nrg_tone[k] != 0 || noise_absc);
-      for (int l = l0; l < l1; l++) {
-        if (active) {
-          eg[4] = gain;
-          nb[4] = nl;
-          float sb_gain = 0, sb_noise = 0;
-          int c = 0;
-          for (int n = 4 - smooth_length; n <= 4; n++) {
-            sb_gain += eg[n] * filt[c];
-            sb_noise += nb[n] * filt[c++];
+      const int kk2 = sb_start + k;
+      const float tone = active ? w->nrg_tone[k] : 0.0f;
+      const int freq_inv = (kk2 & 1) ? -1 : 1;
+      const float hp[2][4] = {{1.0f, 0.0f, -1.0f, 0.0f}, {0.0f, 1.0f, 0.0f, -1.0f}};
+      XE_NOUNROLL
+      for (int j0 = l0; j0 < l1; j0 += XE_CH) {
+        float cr[XE_CH], ci[XE_CH];
+        if (active) xe_rows_load(x, kk2, j0, l1, cr, ci);
+        XE_UNROLL
+        for (int jj = 0; jj < XE_CH; jj++)
+          if (j0 + jj < l1) {
+            const int j = j0 + jj - l0;
+            if (active) {
+              eg[4] = gain;
+              nb[4] = nl;
+              float sb_gain = 0, sb_noise = 0;
+              int c = 0;
+              for (int n = 4 - smooth_length; n <= 4; n++) {
+                sb_gain += eg[n] * filt[c];
+                sb_noise += nb[n] * filt[c++];
+              }
+              const int ph = (phase_index + j * num_sb + k + 1) & 511;
+              if (no_noise) sb_noise = 0;
+              cr[jj] = cr[jj] * sb_gain + sb_noise * xaac_esbr_random_phase[2 * ph];
+              ci[jj] = ci[jj] * sb_gain + sb_noise * xaac_esbr_random_phase[2 * ph + 1];
+              if (!tes) { /* sinusoids, :833-850 (behind the inter-TES shaping when that is active: below) */
+                const int hi = (harm_index + j) & 3;
+                cr[jj] += tone * hp[0][hi];
+                ci[jj] += tone * (float)freq_inv * hp[1][hi];
+              }
+            }
+            const float t0 = eg[0], t1 = nb[0];
+            for (int n = 0; n < 4; n++) {
+              eg[n] = eg[n + 1];
+              nb[n] = nb[n + 1];
+            }
+            eg[4] = t0;
+            nb[4] = t1;
           }
-          const int ph = (phase_index + (l - l0) * num_sb + k + 1) & 511;
-          if (no_noise) sb_noise = 0;
-          const int kk2 = sb_start + k;
-          x.r(l, kk2) = x.r(l, kk2) * sb_gain + sb_noise * xaac_esbr_random_phase[2 * ph];
-          x.i(l, kk2) = x.i(l, kk2) * sb_gain + sb_noise * xaac_esbr_random_phase[2 * ph + 1];
-        }
-        const float t0 = eg[0], t1 = nb[0];
-        for (int n = 0; n < 4; n++) {
-          eg[n] = eg[n + 1];
-          nb[n] = nb[n + 1];
-        }
-        eg[4] = t0;
-        nb[4] = t1;
+        if (active) xe_rows_store(x, kk2, j0, l1, cr, ci);
       }
       for (int n = 0; n < 5; n++) {
         st->e_gain[n][k] = eg[n];
@@ -576,16 +642,18 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
     }
     phase_index = (phase_index + (l1 > l0 ? (l1 - l0) * num_sb : 0)) & 511;
     cx.sync();
-    xe_inter_tes(cx, w, low, x, l0, l1 - l0, sb_start, num_sb, sd->inter_temp_shape_mode[i]);
-    XS_PAR(k, 0, num_sb) { /* sinusoids, :833-850 */
-      const float tone = w->nrg_tone[k];
-      const int freq_inv = ((sb_start + k) & 1) ? -1 : 1;
-      int hi = harm_index;
-      const float hp[2][4] = {{1.0f, 0.0f, -1.0f, 0.0f}, {0.0f, 1.0f, 0.0f, -1.0f}};
-      for (int l = l0; l < l1; l++) {
-        x.r(l, sb_start + k) += tone * hp[0][hi];
-        x.i(l, sb_start + k) += tone * (float)freq_inv * hp[1][hi];
-        hi = (hi + 1) & 3;
+    if (tes) {
+      xe_inter_tes(cx, w, low, x, l0, l1 - l0, sb_start, num_sb, sd->inter_temp_shape_mode[i]);
+      XS_PAR(k, 0, num_sb) { /* sinusoids, :833-850 */
+        const float tone = w->nrg_tone[k];
+        const int freq_inv = ((sb_start + k) & 1) ? -1 : 1;
+        int hi = harm_index;
+        const float hp[2][4] = {{1.0f, 0.0f, -1.0f, 0.0f}, {0.0f, 1.0f, 0.0f, -1.0f}};
+        for (int l = l0; l < l1; l++) {
+          x.r(l, sb_start + k) += tone * hp[0][hi];
+          x.i(l, sb_start + k) += tone * (float)freq_inv * hp[1][hi];
+          hi = (hi + 1) & 3;
+        }
       }
     }
     if (l1 > l0) harm_index = (harm_index + (l1 - l0)) & 3;

@@ -6,9 +6,10 @@
  * Mapping: one wave = one channel-frame, lane = QMF band.  The path works 38 slots behind the analysis bank (op_delay 6 +
  * the 32 slots the reference reserves for its harmonic transposer), so the HF generator reads the channel's 40-row
  * history straight from its state; this frame's analysis rows only enter the history at the end.  sbr_qmf_out lives in a
- * 42-row global scratch (L2-resident while the wave works on it), the per-band vectors in LDS: the stages are chains of
- * short dependent loops, so what the kernel needs is many resident waves -- with the matrix in LDS (21.5 KB, 6 waves per
- * CU) the same code measured 1.35x slower than with 4 KB of LDS and 24 waves per CU reading the matrix through L2.
+ * 42-row global scratch (L2-resident while the wave works on it), side info and per-band vectors in LDS.  The stages are
+ * chains of short dependent loops, so the kernel needs many resident waves AND few exposed memory latencies: column walks
+ * move eight rows per burst (esbr_core.h: XE_CH), the copies eight rows per burst, the side info is staged in LDS for the
+ * scalar table walks.  With the matrix in LDS (21.5 KB, 6 waves per CU) the same code measured 1.4x slower, twice.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -16,13 +17,39 @@
 #include "esbr_core.h"
 #include "esbr_core_kernel.h"
 
-__global__ __launch_bounds__(64) void xaac_esbr_core_kernel(XaacEsbrCoreParams p) {
+#ifdef XE_PROFILE /* tools/prof_esbr_core.py: lane-0 cycle counts per stage, summed into the status words */
+#define XE_T(i)                                                                                   \
+  do {                                                                                            \
+    if (threadIdx.x == 0) {                                                                       \
+      const long long now_ = clock64();                                                           \
+      atomicAdd(reinterpret_cast<unsigned long long *>(p.status) + (i), (unsigned long long)(now_ - t_last_)); \
+      t_last_ = now_;                                                                             \
+    }                                                                                             \
+  } while (0)
+#else
+#define XE_T(i)
+#endif
+
+__global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParams p) { /* 168 VGPRs: 12 waves per CU (measured best of 8 / 12 / 16) */
+#ifdef XE_PROFILE
+  long long t_last_ = clock64();
+#endif
   __shared__ XeWork w;
   const int ch = blockIdx.x, lane = threadIdx.x;
   const XsCx cx = {lane, 64};
-  const xaac_sbr_header *h = p.header + ch;
-  const xaac_sbr_frame *f = p.frame + ch;
-  const xaac_esbr_side *sd = p.side + ch;
+  /* the side info is walked by scalar, data-dependent code (band tables, patch construction): from LDS, not from global */
+  __shared__ xaac_sbr_header sh;
+  __shared__ xaac_sbr_frame sf;
+  __shared__ xaac_esbr_side ssd;
+  static_assert(sizeof(xaac_sbr_header) % 4 == 0 && sizeof(xaac_sbr_frame) % 4 == 0 && sizeof(xaac_esbr_side) % 4 == 0, "word copies");
+  for (int i = lane; i < (int)(sizeof(sh) / 4); i += 64) reinterpret_cast<int32_t *>(&sh)[i] = reinterpret_cast<const int32_t *>(p.header + ch)[i];
+  for (int i = lane; i < (int)(sizeof(sf) / 4); i += 64) reinterpret_cast<int32_t *>(&sf)[i] = reinterpret_cast<const int32_t *>(p.frame + ch)[i];
+  for (int i = lane; i < (int)(sizeof(ssd) / 4); i += 64) reinterpret_cast<int32_t *>(&ssd)[i] = reinterpret_cast<const int32_t *>(p.side + ch)[i];
+  __syncthreads();
+  const xaac_sbr_header *h = &sh;
+  const xaac_sbr_frame *f = &sf;
+  const xaac_esbr_side *sd = &ssd;
+  XE_T(0);
   xaac_esbr_state *st = p.state + ch;
   float *ore = p.out_re + (size_t)ch * XAAC_ESBR_OUT_ROWS * 64, *oim = p.out_im + (size_t)ch * XAAC_ESBR_OUT_ROWS * 64;
   float *rre = p.syn_re + (size_t)ch * XAAC_ESBR_L_ROWS * 64, *rim = p.syn_im + (size_t)ch * XAAC_ESBR_L_ROWS * 64;
@@ -30,27 +57,53 @@ __global__ __launch_bounds__(64) void xaac_esbr_core_kernel(XaacEsbrCoreParams p
   const int apply = f->apply_processing != 0;
   int rc = 0;
   if (apply && xe_side_info_bad(h, f, sd)) rc = -1;
-  /* sbr_qmf_out: 8 rows of history, the rest cleared (the stages write every cell that is read later) */
-  for (int i = lane; i < XAAC_ESBR_OUT_ROWS * 64; i += 64) {
-    const bool hist = apply && i < XAAC_ESBR_OUT_HIST_ROWS * 64;
-    ore[i] = hist ? (&st->out_re[0][0])[i] : 0.0f;
-    oim[i] = hist ? (&st->out_im[0][0])[i] : 0.0f;
+  /* sbr_qmf_out: 8 rows of history; the stages write every cell of rows 8..31 that is read later, so those are cleared
+     only for a frame without SBR processing (the reference zeroes the whole buffer then, sbr_dec.c:956-961) */
+  {
+    float t0[8], t1[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      t0[r] = apply ? st->out_re[r][lane] : 0.0f;
+      t1[r] = apply ? st->out_im[r][lane] : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      ore[64 * r + lane] = t0[r];
+      oim[64 * r + lane] = t1[r];
+    }
+    /* rows 32.. become the next frame's history: cleared, the stages fill what they reach */
+    for (int i = ((!apply || rc) ? 8 : 32) * 64 + lane; i < XAAC_ESBR_OUT_ROWS * 64; i += 64) {
+      ore[i] = 0.0f;
+      oim[i] = 0.0f;
+    }
   }
   __syncthreads();
   if (sd->qmf_sb_prev >= 0 && sd->qmf_sb_prev <= 64) xe_hbe_history_clear(cx, st, sd->qmf_sb_prev);
+  XE_T(1);
   const XeMat src = {&st->qmf_re[0][0] + 128, &st->qmf_im[0][0] + 128}, dst = {ore + 128, oim + 128};
   if (apply && rc == 0) {
     xe_generate_hf(cx, h, f, sd, st, &w, src, dst);
     __syncthreads();
+    XE_T(2);
     rc = w.err ? -1 : xe_env_calc(cx, h, f, sd, st, &w, dst, src);
   }
   __syncthreads();
+  XE_T(3);
   {
     const int stop = apply ? 2 * f->border_vec[0] : 0;
-    for (int i = 0; i < 32; i++) { /* regrouping, sbr_dec.c:365-395 */
-      const int xo = i < stop ? sd->qmf_sb_prev : h->sub_band_start;
-      rre[64 * i + lane] = lane < xo ? st->qmf_re[2 + i][lane] : ore[64 * (2 + i) + lane];
-      rim[64 * i + lane] = lane < xo ? st->qmf_im[2 + i][lane] : oim[64 * (2 + i) + lane];
+    for (int i0 = 0; i0 < 32; i0 += 8) { /* regrouping, sbr_dec.c:365-395; eight rows in flight */
+      float a[8], b[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int i = i0 + j, xo = i < stop ? sd->qmf_sb_prev : h->sub_band_start;
+        a[j] = lane < xo ? st->qmf_re[2 + i][lane] : ore[64 * (2 + i) + lane];
+        b[j] = lane < xo ? st->qmf_im[2 + i][lane] : oim[64 * (2 + i) + lane];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        rre[64 * (i0 + j) + lane] = a[j];
+        rim[64 * (i0 + j) + lane] = b[j];
+      }
     }
   }
   if (p.with_ps) /* the six look-ahead rows of the PS hybrid filter: bands 0..4 of qmf_buf rows 34..39 (sbr_dec.c:487-505) */
@@ -59,6 +112,7 @@ __global__ __launch_bounds__(64) void xaac_esbr_core_kernel(XaacEsbrCoreParams p
       rim[64 * i + lane] = lane < 5 ? st->qmf_im[2 + i][lane] : 0.0f;
     }
   __syncthreads();
+  XE_T(4);
   /* histories: rows 32.. of this frame's buffers become rows 0.. of the next frame's (sbr_dec.c:835-857) */
   {
     float t0[8], t1[8];
@@ -72,16 +126,35 @@ __global__ __launch_bounds__(64) void xaac_esbr_core_kernel(XaacEsbrCoreParams p
       st->qmf_re[r][lane] = t0[r];
       st->qmf_im[r][lane] = t1[r];
     }
-    for (int r = 0; r < 32; r++) {
-      st->qmf_re[8 + r][lane] = lane < 32 ? are[64 * r + lane] : 0.0f;
-      st->qmf_im[8 + r][lane] = lane < 32 ? aim[64 * r + lane] : 0.0f;
+    for (int r0 = 0; r0 < 32; r0 += 8) {
+      float a[8], b[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        a[j] = lane < 32 ? are[64 * (r0 + j) + lane] : 0.0f;
+        b[j] = lane < 32 ? aim[64 * (r0 + j) + lane] : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        st->qmf_re[8 + r0 + j][lane] = a[j];
+        st->qmf_im[8 + r0 + j][lane] = b[j];
+      }
     }
+#pragma unroll
     for (int r = 0; r < 8; r++) {
-      st->out_re[r][lane] = ore[64 * (32 + r) + lane];
-      st->out_im[r][lane] = oim[64 * (32 + r) + lane];
+      t0[r] = ore[64 * (32 + r) + lane];
+      t1[r] = oim[64 * (32 + r) + lane];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      st->out_re[r][lane] = t0[r];
+      st->out_im[r][lane] = t1[r];
     }
   }
+#ifdef XE_PROFILE
+  XE_T(5);
+#else
   if (lane == 0 && p.status) p.status[ch] = rc;
+#endif
 }
 
 extern "C" hipError_t xaac_launch_esbr_core(const XaacEsbrCoreParams *p, hipStream_t stream) {
