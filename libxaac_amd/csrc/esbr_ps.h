@@ -214,39 +214,48 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
     const int dn = xaac_eps_qmf_delay_idx_tbl[sb];
     const bool plain = sb >= 23;
     const float pr = xaac_eps_qmf_fract_delay_phase_factor_re[sb], pi = xaac_eps_qmf_fract_delay_phase_factor_im[sb];
-    for (int k = k0; k < k1; k++) {
-      const float in_re = L.r(k, sb), in_im = L.i(k, sb);
-      float r_r0, i_r0;
-      if (plain) {
-        r_r0 = ps->qmf_delay_re[di][sb];
-        i_r0 = ps->qmf_delay_im[di][sb];
-        ps->qmf_delay_re[di][sb] = in_re;
-        ps->qmf_delay_im[di][sb] = in_im;
-      } else {
-        const float real0 = ps->qmf_delay_re[l_delay][sb], imag0 = ps->qmf_delay_im[l_delay][sb];
-        ps->qmf_delay_re[l_delay][sb] = in_re;
-        ps->qmf_delay_im[l_delay][sb] = in_im;
-        r_r0 = real0 * pr - imag0 * pi;
-        i_r0 = real0 * pi + imag0 * pr;
-        float sr[3], si[3];
-        for (int m = 0; m < 3; m++) {
-          sr[m] = ps->ser_qmf_re[m][ls[m]][sb];
-          si[m] = ps->ser_qmf_im[m][ls[m]][sb];
+    XE_NOUNROLL
+    for (int kc = k0; kc < k1; kc += XE_CH) { /* eight input rows in, eight output rows out per burst */
+      float cr[XE_CH], ci[XE_CH];
+      xe_rows_load(L, sb, kc, k1, cr, ci);
+      XE_UNROLL
+      for (int jj = 0; jj < XE_CH; jj++)
+        if (kc + jj < k1) {
+          const int k = kc + jj;
+          const float in_re = cr[jj], in_im = ci[jj];
+          float r_r0, i_r0;
+          if (plain) {
+            r_r0 = ps->qmf_delay_re[di][sb];
+            i_r0 = ps->qmf_delay_im[di][sb];
+            ps->qmf_delay_re[di][sb] = in_re;
+            ps->qmf_delay_im[di][sb] = in_im;
+          } else {
+            const float real0 = ps->qmf_delay_re[l_delay][sb], imag0 = ps->qmf_delay_im[l_delay][sb];
+            ps->qmf_delay_re[l_delay][sb] = in_re;
+            ps->qmf_delay_im[l_delay][sb] = in_im;
+            r_r0 = real0 * pr - imag0 * pi;
+            i_r0 = real0 * pi + imag0 * pr;
+            float sr[3], si[3];
+            for (int m = 0; m < 3; m++) {
+              sr[m] = ps->ser_qmf_re[m][ls[m]][sb];
+              si[m] = ps->ser_qmf_im[m][ls[m]][sb];
+            }
+            xf_allpass(r_r0, i_r0, sr, si, &xaac_eps_qmf_ser_fract_delay_phase_factor_re[3 * sb],
+                       &xaac_eps_qmf_ser_fract_delay_phase_factor_im[3 * sb], decay);
+            for (int m = 0; m < 3; m++) {
+              ps->ser_qmf_re[m][ls[m]][sb] = sr[m];
+              ps->ser_qmf_im[m][ls[m]][sb] = si[m];
+            }
+          }
+          const float t = w->tr[k][bin];
+          cr[jj] = t * r_r0;
+          ci[jj] = t * i_r0;
+          if (++l_delay >= 2) l_delay = 0;
+          if (plain && ++di >= dn) di = 0;
+          for (int m = 0; m < 3; m++)
+            if (++ls[m] >= 3 + m) ls[m] = 0;
         }
-        xf_allpass(r_r0, i_r0, sr, si, &xaac_eps_qmf_ser_fract_delay_phase_factor_re[3 * sb],
-                   &xaac_eps_qmf_ser_fract_delay_phase_factor_im[3 * sb], decay);
-        for (int m = 0; m < 3; m++) {
-          ps->ser_qmf_re[m][ls[m]][sb] = sr[m];
-          ps->ser_qmf_im[m][ls[m]][sb] = si[m];
-        }
-      }
-      const float t = w->tr[k][bin];
-      R.r(k, sb) = t * r_r0;
-      R.i(k, sb) = t * i_r0;
-      if (++l_delay >= 2) l_delay = 0;
-      if (plain && ++di >= dn) di = 0;
-      for (int m = 0; m < 3; m++)
-        if (++ls[m] >= 3 + m) ls[m] = 0;
+      xe_rows_store(R, sb, kc, k1, cr, ci);
     }
     ps->delay_qmf_idx[sb] = di;
   }
@@ -304,23 +313,38 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
         H[j] = Hp;
         d[j] = (hc - Hp) / (float)len;
       }
-      for (int i = e0; i < e1; i++) {
-        for (int j = 0; j < 8; j++) H[j] += d[j];
-        /* H[0..3] = H11r H12r H21r H22r, H[4..7] = H11i H12i H21i H22i */
-        float lre, lim, rre, rim;
-        if (u < 10) {
-          lre = w->hl_re[i][sb]; lim = w->hl_im[i][sb]; rre = w->hr_re[i][sb]; rim = w->hr_im[i][sb];
-        } else {
-          lre = L.r(i, sb); lim = L.i(i, sb); rre = R.r(i, sb); rim = R.i(i, sb);
+      XE_NOUNROLL
+      for (int ic = e0; ic < e1; ic += XE_CH) {
+        float lr[XE_CH], li[XE_CH], rr[XE_CH], ri[XE_CH];
+        if (u >= 10) {
+          xe_rows_load(L, sb, ic, e1, lr, li);
+          xe_rows_load(R, sb, ic, e1, rr, ri);
         }
-        const float o_lre = H[0] * lre - H[4] * lim + H[2] * rre - H[6] * rim;
-        const float o_lim = H[4] * lre + H[0] * lim + H[6] * rre + H[2] * rim;
-        const float o_rre = H[1] * lre - H[5] * lim + H[3] * rre - H[7] * rim;
-        const float o_rim = H[5] * lre + H[1] * lim + H[7] * rre + H[3] * rim;
-        if (u < 10) {
-          w->hl_re[i][sb] = o_lre; w->hl_im[i][sb] = o_lim; w->hr_re[i][sb] = o_rre; w->hr_im[i][sb] = o_rim;
-        } else {
-          L.r(i, sb) = o_lre; L.i(i, sb) = o_lim; R.r(i, sb) = o_rre; R.i(i, sb) = o_rim;
+        XE_UNROLL
+        for (int jj = 0; jj < XE_CH; jj++)
+          if (ic + jj < e1) {
+            const int i = ic + jj;
+            for (int j = 0; j < 8; j++) H[j] += d[j];
+            /* H[0..3] = H11r H12r H21r H22r, H[4..7] = H11i H12i H21i H22i */
+            float lre, lim, rre, rim;
+            if (u < 10) {
+              lre = w->hl_re[i][sb]; lim = w->hl_im[i][sb]; rre = w->hr_re[i][sb]; rim = w->hr_im[i][sb];
+            } else {
+              lre = lr[jj]; lim = li[jj]; rre = rr[jj]; rim = ri[jj];
+            }
+            const float o_lre = H[0] * lre - H[4] * lim + H[2] * rre - H[6] * rim;
+            const float o_lim = H[4] * lre + H[0] * lim + H[6] * rre + H[2] * rim;
+            const float o_rre = H[1] * lre - H[5] * lim + H[3] * rre - H[7] * rim;
+            const float o_rim = H[5] * lre + H[1] * lim + H[7] * rre + H[3] * rim;
+            if (u < 10) {
+              w->hl_re[i][sb] = o_lre; w->hl_im[i][sb] = o_lim; w->hr_re[i][sb] = o_rre; w->hr_im[i][sb] = o_rim;
+            } else {
+              lr[jj] = o_lre; li[jj] = o_lim; rr[jj] = o_rre; ri[jj] = o_rim;
+            }
+          }
+        if (u >= 10) {
+          xe_rows_store(L, sb, ic, e1, lr, li);
+          xe_rows_store(R, sb, ic, e1, rr, ri);
         }
       }
     }
