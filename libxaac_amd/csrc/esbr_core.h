@@ -275,7 +275,7 @@ FX_HD void xe_generate_hf(const XsCx &cx, const xaac_sbr_header *h, const xaac_s
       float r2 = src.r(-2, k), i2 = src.i(-2, k), r1 = src.r(-1, k), i1 = src.i(-1, k);
       XE_NOUNROLL
       for (int j0 = 0; j0 < 38; j0 += XE_CH) {
-        float cr[XE_CH], ci[XE_CH];
+        float cr[XE_CH] = {0}, ci[XE_CH] = {0};
         xe_rows_load(src, k, j0, 38, cr, ci);
         XE_UNROLL
         for (int jj = 0; jj < XE_CH; jj++) if (j0 + jj < 38) {
@@ -326,7 +326,7 @@ FX_HD void xe_generate_hf(const XsCx &cx, const xaac_sbr_header *h, const xaac_s
       float r2 = src.r(start - 2, k), i2 = src.i(start - 2, k), r1 = src.r(start - 1, k), i1 = src.i(start - 1, k);
       XE_NOUNROLL
       for (int l0 = start; l0 < end; l0 += XE_CH) {
-        float cr[XE_CH], ci[XE_CH];
+        float cr[XE_CH] = {0}, ci[XE_CH] = {0};
         xe_rows_load(src, k, l0, end, cr, ci);
         XE_UNROLL
         for (int j = 0; j < XE_CH; j++)
@@ -501,7 +501,7 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
       if (l0 < l1) {
         XE_NOUNROLL
         for (int j0 = l0; j0 < l1; j0 += XE_CH) {
-          float cr[XE_CH], ci[XE_CH];
+          float cr[XE_CH] = {0}, ci[XE_CH] = {0};
           xe_rows_load(x, k, j0, l1, cr, ci);
           XE_UNROLL
           for (int j = 0; j < XE_CH; j++)
@@ -600,7 +600,7 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
       const float hp[2][4] = {{1.0f, 0.0f, -1.0f, 0.0f}, {0.0f, 1.0f, 0.0f, -1.0f}};
       XE_NOUNROLL
       for (int j0 = l0; j0 < l1; j0 += XE_CH) {
-        float cr[XE_CH], ci[XE_CH];
+        float cr[XE_CH] = {0}, ci[XE_CH] = {0};
         if (active) xe_rows_load(x, kk2, j0, l1, cr, ci);
         XE_UNROLL
         for (int jj = 0; jj < XE_CH; jj++)

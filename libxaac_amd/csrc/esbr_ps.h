@@ -174,34 +174,56 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
   const int l_delay0 = ps->delay_buf_idx;
   const int ser0[3] = {ps->delay_buf_idx_ser[0], ps->delay_buf_idx_ser[1], ps->delay_buf_idx_ser[2]};
   int l_delay_end = l_delay0, ser_end[3] = {ser0[0], ser0[1], ser0[2]};
+  /* The rings are walked as shift registers: a lane fetches its delay line and its three all-pass rings in time order
+     (oldest first) before the slot loop, shifts them in registers, and writes them back in time order behind the position
+     the loop ends at -- the same cells, the same values, one memory round trip instead of one per slot. */
   XS_PAR(gr, 0, 10) {
     const int sb = gb[gr], bin = gmap[gr] & ~XF_NEG;
-    int l_delay = l_delay0, ls[3] = {ser0[0], ser0[1], ser0[2]};
     const float pr = xaac_eps_frac_delay_phase_fac_qmf_sub_re_20[sb], pi = xaac_eps_frac_delay_phase_fac_qmf_sub_im_20[sb];
-    for (int k = k0; k < k1; k++) {
-      const float in_re = w->hl_re[k][sb], in_im = w->hl_im[k][sb];
-      const float real0 = ps->sub_delay_re[l_delay][sb], imag0 = ps->sub_delay_im[l_delay][sb];
-      ps->sub_delay_re[l_delay][sb] = in_re;
-      ps->sub_delay_im[l_delay][sb] = in_im;
-      float r_r0 = real0 * pr - imag0 * pi, i_r0 = real0 * pi + imag0 * pr;
-      float sr[3], si[3];
-      for (int m = 0; m < 3; m++) {
-        sr[m] = ps->ser_sub_re[m][ls[m]][sb];
-        si[m] = ps->ser_sub_im[m][ls[m]][sb];
+    float dre[2], dim[2], sre[3][5] = {{0}}, sim[3][5] = {{0}};
+    for (int j = 0; j < 2; j++) {
+      const int idx = (l_delay0 + j) & 1;
+      dre[j] = ps->sub_delay_re[idx][sb];
+      dim[j] = ps->sub_delay_im[idx][sb];
+    }
+    for (int m = 0; m < 3; m++)
+      for (int j = 0; j < 3 + m; j++) {
+        const int idx = (ser0[m] + j) % (3 + m);
+        sre[m][j] = ps->ser_sub_re[m][idx][sb];
+        sim[m][j] = ps->ser_sub_im[m][idx][sb];
       }
+    for (int k = k0; k < k1; k++) {
+      const float real0 = dre[0], imag0 = dim[0];
+      dre[0] = dre[1]; dim[0] = dim[1];
+      dre[1] = w->hl_re[k][sb]; dim[1] = w->hl_im[k][sb];
+      float r_r0 = real0 * pr - imag0 * pi, i_r0 = real0 * pi + imag0 * pr;
+      float sr[3] = {sre[0][0], sre[1][0], sre[2][0]}, si[3] = {sim[0][0], sim[1][0], sim[2][0]};
       xf_allpass(r_r0, i_r0, sr, si, &xaac_eps_frac_delay_phase_fac_ser_qmf_sub_re_20[3 * sb],
                  &xaac_eps_frac_delay_phase_fac_ser_qmf_sub_im_20[3 * sb], 1.0f);
       for (int m = 0; m < 3; m++) {
-        ps->ser_sub_re[m][ls[m]][sb] = sr[m];
-        ps->ser_sub_im[m][ls[m]][sb] = si[m];
+        for (int j = 0; j < 2 + m; j++) {
+          sre[m][j] = sre[m][j + 1];
+          sim[m][j] = sim[m][j + 1];
+        }
+        sre[m][2 + m] = sr[m];
+        sim[m][2 + m] = si[m];
       }
       const float t = w->tr[k][bin];
       w->hr_re[k][sb] = t * r_r0;
       w->hr_im[k][sb] = t * i_r0;
-      if (++l_delay >= 2) l_delay = 0;
-      for (int m = 0; m < 3; m++)
-        if (++ls[m] >= 3 + m) ls[m] = 0;
     }
+    const int cnt = k1 > k0 ? k1 - k0 : 0;
+    for (int j = 0; j < 2; j++) {
+      const int idx = (l_delay0 + cnt + j) & 1;
+      ps->sub_delay_re[idx][sb] = dre[j];
+      ps->sub_delay_im[idx][sb] = dim[j];
+    }
+    for (int m = 0; m < 3; m++)
+      for (int j = 0; j < 3 + m; j++) {
+        const int idx = (ser0[m] + cnt + j) % (3 + m);
+        ps->ser_sub_re[m][idx][sb] = sre[m][j];
+        ps->ser_sub_im[m][idx][sb] = sim[m][j];
+      }
   }
   XS_PAR(sb, 3, 64) {
     int gr = 10;
@@ -209,55 +231,87 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
     const int bin = gmap[gr] & ~XF_NEG;
     float decay = sb <= 3 ? 1.0f : 1.0f + 3.0f * 0.05f - 0.05f * (float)sb;
     decay = decay > 0.0f ? decay : 0.0f;
-    int l_delay = l_delay0, ls[3] = {ser0[0], ser0[1], ser0[2]};
-    int di = ps->delay_qmf_idx[sb];
-    const int dn = xaac_eps_qmf_delay_idx_tbl[sb];
     const bool plain = sb >= 23;
+    const int dl = plain ? xaac_eps_qmf_delay_idx_tbl[sb] : 2; /* 14, 1 or 2 cells of qmf_delay_buf belong to this band */
+    const int pos = plain ? ps->delay_qmf_idx[sb] : l_delay0;
     const float pr = xaac_eps_qmf_fract_delay_phase_factor_re[sb], pi = xaac_eps_qmf_fract_delay_phase_factor_im[sb];
+    float dre[14] = {0}, dim[14] = {0}, sre[3][5] = {{0}}, sim[3][5] = {{0}};
+    XE_UNROLL
+    for (int j = 0; j < 14; j++)
+      if (j < dl) {
+        int idx = pos + j;
+        if (idx >= dl) idx -= dl;
+        dre[j] = ps->qmf_delay_re[idx][sb];
+        dim[j] = ps->qmf_delay_im[idx][sb];
+      }
+    if (!plain)
+      for (int m = 0; m < 3; m++)
+        for (int j = 0; j < 3 + m; j++) {
+          const int idx = (ser0[m] + j) % (3 + m);
+          sre[m][j] = ps->ser_qmf_re[m][idx][sb];
+          sim[m][j] = ps->ser_qmf_im[m][idx][sb];
+        }
     XE_NOUNROLL
     for (int kc = k0; kc < k1; kc += XE_CH) { /* eight input rows in, eight output rows out per burst */
-      float cr[XE_CH], ci[XE_CH];
+      float cr[XE_CH] = {0}, ci[XE_CH] = {0};
       xe_rows_load(L, sb, kc, k1, cr, ci);
       XE_UNROLL
       for (int jj = 0; jj < XE_CH; jj++)
         if (kc + jj < k1) {
           const int k = kc + jj;
           const float in_re = cr[jj], in_im = ci[jj];
+          const float real0 = dre[0], imag0 = dim[0];
+          XE_UNROLL
+          for (int j = 0; j < 13; j++) {
+            dre[j] = dre[j + 1];
+            dim[j] = dim[j + 1];
+          }
+          if (dl == 14) { dre[13] = in_re; dim[13] = in_im; }
+          else if (dl == 2) { dre[1] = in_re; dim[1] = in_im; }
+          else { dre[0] = in_re; dim[0] = in_im; }
           float r_r0, i_r0;
           if (plain) {
-            r_r0 = ps->qmf_delay_re[di][sb];
-            i_r0 = ps->qmf_delay_im[di][sb];
-            ps->qmf_delay_re[di][sb] = in_re;
-            ps->qmf_delay_im[di][sb] = in_im;
+            r_r0 = real0;
+            i_r0 = imag0;
           } else {
-            const float real0 = ps->qmf_delay_re[l_delay][sb], imag0 = ps->qmf_delay_im[l_delay][sb];
-            ps->qmf_delay_re[l_delay][sb] = in_re;
-            ps->qmf_delay_im[l_delay][sb] = in_im;
             r_r0 = real0 * pr - imag0 * pi;
             i_r0 = real0 * pi + imag0 * pr;
-            float sr[3], si[3];
-            for (int m = 0; m < 3; m++) {
-              sr[m] = ps->ser_qmf_re[m][ls[m]][sb];
-              si[m] = ps->ser_qmf_im[m][ls[m]][sb];
-            }
+            float sr[3] = {sre[0][0], sre[1][0], sre[2][0]}, si[3] = {sim[0][0], sim[1][0], sim[2][0]};
             xf_allpass(r_r0, i_r0, sr, si, &xaac_eps_qmf_ser_fract_delay_phase_factor_re[3 * sb],
                        &xaac_eps_qmf_ser_fract_delay_phase_factor_im[3 * sb], decay);
             for (int m = 0; m < 3; m++) {
-              ps->ser_qmf_re[m][ls[m]][sb] = sr[m];
-              ps->ser_qmf_im[m][ls[m]][sb] = si[m];
+              for (int j = 0; j < 2 + m; j++) {
+                sre[m][j] = sre[m][j + 1];
+                sim[m][j] = sim[m][j + 1];
+              }
+              sre[m][2 + m] = sr[m];
+              sim[m][2 + m] = si[m];
             }
           }
           const float t = w->tr[k][bin];
           cr[jj] = t * r_r0;
           ci[jj] = t * i_r0;
-          if (++l_delay >= 2) l_delay = 0;
-          if (plain && ++di >= dn) di = 0;
-          for (int m = 0; m < 3; m++)
-            if (++ls[m] >= 3 + m) ls[m] = 0;
         }
       xe_rows_store(R, sb, kc, k1, cr, ci);
     }
-    ps->delay_qmf_idx[sb] = di;
+    const int cnt = k1 > k0 ? k1 - k0 : 0;
+    const int pos_end = (pos + cnt) % dl;
+    XE_UNROLL
+    for (int j = 0; j < 14; j++)
+      if (j < dl) {
+        int idx = pos_end + j;
+        if (idx >= dl) idx -= dl;
+        ps->qmf_delay_re[idx][sb] = dre[j];
+        ps->qmf_delay_im[idx][sb] = dim[j];
+      }
+    if (!plain)
+      for (int m = 0; m < 3; m++)
+        for (int j = 0; j < 3 + m; j++) {
+          const int idx = (ser0[m] + cnt + j) % (3 + m);
+          ps->ser_qmf_re[m][idx][sb] = sre[m][j];
+          ps->ser_qmf_im[m][idx][sb] = sim[m][j];
+        }
+    if (plain) ps->delay_qmf_idx[sb] = pos_end;
   }
   for (int k = k0; k < k1; k++) { /* where the shared ring positions end up (:829-832) */
     if (++l_delay_end >= 2) l_delay_end = 0;
@@ -315,7 +369,7 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
       }
       XE_NOUNROLL
       for (int ic = e0; ic < e1; ic += XE_CH) {
-        float lr[XE_CH], li[XE_CH], rr[XE_CH], ri[XE_CH];
+        float lr[XE_CH] = {0}, li[XE_CH] = {0}, rr[XE_CH] = {0}, ri[XE_CH] = {0};
         if (u >= 10) {
           xe_rows_load(L, sb, ic, e1, lr, li);
           xe_rows_load(R, sb, ic, e1, rr, ri);

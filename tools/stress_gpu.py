@@ -17,6 +17,9 @@ import test_imdct_gpu as ti  # noqa: E402
 import test_limiter_gpu as tl  # noqa: E402
 import test_sbr_gpu as ts  # noqa: E402
 import test_sbr_hq_gpu as th  # noqa: E402
+import test_esbr_sbr_gpu as te  # noqa: E402
+import test_usac_imdct as tu  # noqa: E402
+import test_esbr_qmf as tq  # noqa: E402
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 oracle = oracle_lib.load_oracle()
@@ -38,6 +41,10 @@ for r in range(1, rounds + 1):
         ("limiter chains 8k", lambda: tl.test_chains_vs_oracle(ctx, oracle, 1, 8000, 1024)),
         ("limiter stale idx", lambda: tl.test_state_with_stale_max_idx(ctx, oracle)),
         ("limiter planar", lambda: tl.test_planar_block_layout(ctx, oracle, 2, 1024)),
+        ("eSBR chain (Path A)", lambda: te.test_chain_vs_oracle(oracle)),
+        ("eSBR + float PS chain", lambda: te.test_ps_chain_vs_oracle(oracle)),
+        ("eSBR banks", lambda: tq.test_gpu_analysis_then_synthesis_vs_oracle(oracle)),
+        ("USAC IMDCT batch", lambda: tu.test_gpu_large_batch_vs_oracle(oracle)),
     ]
     for name, job in jobs:
         try:
