@@ -49,12 +49,20 @@ def main():
         q.wait()
     wall_ref = time.perf_counter() - t0
     same = open("%s/g0.0.wav" % tmp, "rb").read() == open("%s/r0.wav" % tmp, "rb").read()
+    # ... and with the reference's default flags (-esbr:1: its float eSBR path, the harmonic transposer running idle)
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([os.path.join(REF, "xaacdec"), "-ifile:" + aac, "-ofile:%s/d%d.wav" % (tmp, i)],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for i in range(per * groups)]
+    for q in procs:
+        q.wait()
+    wall_def = time.perf_counter() - t0
     print(json.dumps({"what": "HE-AACv2 48 kHz, %d decoder instances in %d groups, %.0f s stream each: reference parser "
                               "instances + conversion + PCIe + GPU back-end, state shipped both ways per call" % (per * groups, groups, seconds),
                       "frames": frames, "frames_expected_per_stream": frames_per_stream,
                       "end_to_end_frames_per_s": round(frames / summary["seconds"], 1), "seconds": summary["seconds"],
                       "wall_incl_fork": round(wall, 3), "pinned": summary["pinned"], "batches": summary["batches"],
-                      "cpu_only_reference_frames_per_s": round(frames / wall_ref, 1), "cores": os.cpu_count(),
+                      "cpu_only_reference_frames_per_s": round(frames / wall_ref, 1),
+                      "cpu_only_reference_default_flags_frames_per_s": round(frames / wall_def, 1), "cores": os.cpu_count(),
                       "output_identical": same}))
 
 
