@@ -3,6 +3,7 @@ include/xaac_amd.h declares; argument errors follow the reference's error-code
 convention.  No compute calls here."""
 import ctypes
 import os
+import sys
 import re
 
 import pytest
@@ -55,6 +56,30 @@ def test_struct_layout_matches_header(tmp_path):
         want += [ctypes.sizeof(cls), getattr(cls, last).offset]
     assert got == want
     assert ctypes.sizeof(libxaac_amd._ImdctBatch) == 80   # 2 x int32 + 7 pointers + int32 (+ pad) + status pointer on LP64
+
+
+def test_round2_struct_layouts_match_headers(tmp_path):
+    """the round-2 descriptors and states (eSBR / Path A, float PS, USAC IMDCT, hand-over): ctypes mirrors of the binding
+    and of tests/esbr_structs.py against what a C compiler makes of include/xaac_amd.h and include/xaac_esbr.h"""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import esbr_structs as es
+    pairs = [("xaac_esbr_ana_batch", libxaac_amd._EsbrAnaBatch, "qmf_im"), ("xaac_esbr_syn_batch", libxaac_amd._EsbrSynBatch, "out"),
+             ("xaac_usac_imdct_batch", libxaac_amd._UsacImdctBatch, "status"), ("xaac_sbr_handover_batch", libxaac_amd._HandoverBatch, "ps_state"),
+             ("xaac_esbr_sbr_batch", libxaac_amd._EsbrSbrBatch, "workspace_bytes"), ("xaac_esbr_side", es.EsbrSide, "flt_noise_floor"),
+             ("xaac_esbr_state", es.EsbrState, "harm_flag_prev"), ("xaac_esbr_ps_state", es.EsbrPsState, "syn_r"),
+             ("xaac_esbr_ana_state", es.EsbrAna, "win_off"), ("xaac_esbr_syn_state", es.EsbrSyn, "filt_off")]
+    body = "".join('printf("%%zu %%zu\\n", sizeof(%s), offsetof(%s, %s));' % (c, c, last) for c, _, last in pairs)
+    src = tmp_path / "layout2.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "xaac_esbr.h"\nint main(void) { %s return 0; }\n' % body)
+    exe = tmp_path / "layout2"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    want = []
+    for _, cls, last in pairs:
+        want += [ctypes.sizeof(cls), getattr(cls, last).offset]
+    assert got == want
+    assert ctypes.sizeof(es.EsbrAna) == 4 * libxaac_amd.ESBR_ANA_STATE_WORDS and ctypes.sizeof(es.EsbrSyn) == 4 * libxaac_amd.ESBR_SYN_STATE_WORDS
 
 
 def test_no_cpu_fallback_without_device():
