@@ -53,7 +53,7 @@
 int ref_cli_main(int argc, char **argv); /* the reference's test/decoder/ixheaacd_main.c: main, renamed at compile time */
 void ref_limiter_from_ref(xaac_limiter_state *s, const ia_peak_limiter_struct *r);
 
-enum { REQ_NONE = 0, REQ_IMDCT, REQ_SBR_LP, REQ_SBR_HQ, REQ_SBR_PS, REQ_LIM };
+enum { REQ_NONE = 0, REQ_IMDCT, REQ_SBR_LP, REQ_SBR_HQ, REQ_SBR_PS, REQ_ESBR, REQ_ESBR_PS, REQ_LIM, REQ_KINDS };
 #define LIM_MAX_CH 2 /* the streams this host is run on are mono / stereo (wider ones stay on the CPU path) */
 
 /* per-instance control word + semaphore */
@@ -61,7 +61,7 @@ typedef struct {
   sem_t done;
   volatile int req;   /* REQ_* while the instance waits */
   volatile int lim_nch, lim_len;
-  long calls[6];
+  long calls[REQ_KINDS];
 } inst_t;
 
 /* one group's staging arrays (all in one shared mapping); n = instances */
@@ -82,6 +82,11 @@ typedef struct {
   xaac_ps_state *pss;
   int16_t *pin, *pout;
   int32_t *status;
+  /* SBR, the reference's default float path (eSBR) */
+  xaac_esbr_side *esd;
+  xaac_esbr_state *est;
+  xaac_esbr_ps_state *eps;
+  float *ecore, *etime, *etime_r;
   /* limiter */
   int32_t *lx;
   int8_t *lq;
@@ -107,8 +112,9 @@ static void *carve(char **cur, size_t bytes) {
 static size_t group_bytes(int n) {
   size_t per = 4096 + 2048 + 4096 + 8 + 8 + 8 + sizeof(xaac_sbr_header) + sizeof(xaac_sbr_frame) + sizeof(xaac_sbr_state) +
                sizeof(xaac_ps_frame) + sizeof(xaac_ps_state) + 2048 + 8192 + 4 + 1024 * LIM_MAX_CH * 4 + 8 +
-               sizeof(xaac_limiter_state) + sizeof(inst_t);
-  return (size_t)n * per + 64 * 256;
+               sizeof(xaac_limiter_state) + sizeof(inst_t) + sizeof(xaac_esbr_side) + sizeof(xaac_esbr_state) +
+               sizeof(xaac_esbr_ps_state) + 4096 + 8192 + 8192;
+  return (size_t)n * per + 96 * 256;
 }
 
 static void group_layout(group_t *g, int n, char *base) {
@@ -132,6 +138,12 @@ static void group_layout(group_t *g, int n, char *base) {
   g->lx = carve(&cur, (size_t)n * 1024 * LIM_MAX_CH * 4);
   g->lq = carve(&cur, (size_t)n * LIM_MAX_CH);
   g->lst = carve(&cur, sizeof(xaac_limiter_state) * n);
+  g->esd = carve(&cur, sizeof(xaac_esbr_side) * n);
+  g->est = carve(&cur, sizeof(xaac_esbr_state) * n);
+  g->eps = carve(&cur, sizeof(xaac_esbr_ps_state) * n);
+  g->ecore = carve(&cur, (size_t)n * 4096);
+  g->etime = carve(&cur, (size_t)n * 8192);
+  g->etime_r = carve(&cur, (size_t)n * 8192);
 }
 
 /* ---- child side: post the request, sleep until the parent has the results in the staging row ------------------- */
@@ -189,6 +201,46 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
   const int i = my_idx;
   const int with_ps = !low_pow && ps && h->channel_mode == PS_STEREO;
   const int ps_on = with_ps && apply;
+  /* the reference's default flags: the eSBR branch (sbr_dec.c:816-1009) of an HE-AAC channel / HE-AACv2 stream, as in
+     oracle/ref_dropin.c */
+  if (g && h->enh_sbr && aot != AOT_ER_AAC_ELD && aot != AOT_ER_AAC_LD && !h->usac_flag && h->hbe_flag && f->sbr_patching_mode == 1 &&
+      (h->channel_mode == PS_STEREO ? (ps != NULL && synth_r != NULL && !ps->use_34_st_bands && !ps->use_pca_rot_flg && ps->ps_mode == 0)
+                                    : !h->enh_sbr_ps) &&
+      !drc_on && !ldmps && !mps && !f->mps_sbr_flag && f->sbr_mode != PVC_SBR && h->sbr_ratio_idx != SBR_UPSAMPLE_IDX_4_1 &&
+      !h->pre_proc_flag && h->num_time_slots == 16 && d->str_codec_qmf_bank.no_channels == 32 &&
+      d->str_synthesis_qmf_bank.no_channels == 64) {
+    const ia_qmf_dec_tables_struct *q = tabs->qmf_dec_tables_ptr;
+    const int eps = h->channel_mode == PS_STEREO;
+    d->str_synthesis_qmf_bank.filter_pos_syn_32 += q->esbr_qmf_c - d->str_synthesis_qmf_bank.p_filter_32;
+    d->str_synthesis_qmf_bank.p_filter_32 = q->esbr_qmf_c;
+    if (eps) {
+      synth_r->filter_pos_syn_32 += q->esbr_qmf_c - synth_r->p_filter_32;
+      synth_r->p_filter_32 = q->esbr_qmf_c;
+    }
+    to_header(h, d, &g->hdr[i]);
+    to_frame(f, apply, &g->frm[i]);
+    to_esbr_side(h, f, &g->esd[i]);
+    to_esbr_state(d, h, f, &g->est[i]);
+    memcpy(g->ecore + 1024 * (size_t)i, d->time_sample_buf, 4096);
+    if (eps) {
+      to_ps_frame(ps, &g->psf[i]);
+      to_esbr_ps_state(ps, synth_r, &g->eps[i]);
+    }
+    rendezvous(eps ? REQ_ESBR_PS : REQ_ESBR);
+    if (g->status[i]) return g->status[i];
+    memcpy(d->time_sample_buf, g->etime + 2048 * (size_t)i, 8192);
+    from_esbr_state(&g->est[i], d, h, f);
+    if (eps) {
+      memcpy(ps->time_sample_buf[1], g->etime_r + 2048 * (size_t)i, 8192);
+      from_esbr_ps_state(&g->eps[i], ps, synth_r);
+      ps->use_34_st_bands_prev = ps->use_34_st_bands;
+      ((ia_sbr_frame_info_data_struct *)((ia_handle_sbr_dec_inst_struct)self)->frame_buffer[1])->reset_flag = 0;
+    }
+    d->band_count = h->pstr_freq_band_data->sub_band_end;
+    f->reset_flag = 0;
+    f->prev_sbr_mode = f->sbr_mode;
+    return 0;
+  }
   if (!g || h->enh_sbr || aot == AOT_ER_AAC_ELD || aot == AOT_ER_AAC_LD || drc_on || ldmps || mps ||
       h->num_time_slots * h->time_step != 32)
     return __real_ixheaacd_sbr_dec(d, time_data, h, f, p, ps, synth_r, sf_r, apply, low_pow, work, tabs, common, ch_fac,
@@ -280,9 +332,9 @@ static void die(const char *what) {
    streams of a group differ) */
 static void launch_group(group_t *g, gpu_group_t *gg, long *batches) {
   const size_t n = (size_t)g->n;
-  int kinds[8] = {0};
+  int kinds[REQ_KINDS] = {0};
   for (int i = 0; i < g->n; i++) kinds[g->inst[i].req]++;
-  for (int req = REQ_IMDCT; req <= REQ_LIM; req++) {
+  for (int req = REQ_IMDCT; req < REQ_KINDS; req++) {
     if (!kinds[req]) continue;
     /* rows that are not part of this batch (instances that have finished, or wait with another kind of request) are
        processed along harmlessly: their rows hold stale but well-formed operands and nobody reads the results */
@@ -306,6 +358,20 @@ static void launch_group(group_t *g, gpu_group_t *gg, long *batches) {
       b.qshift_adj = gg->d.lq; b.state = gg->d.lst; b.workspace = gg->ws; b.workspace_bytes = gg->ws_bytes;
       if (xaac_peak_limiter_process_batch(gg->ctx, &b) != XAAC_OK) die("xaac_peak_limiter_process_batch");
       D2H(lx, n * 1024 * LIM_MAX_CH * 4); D2H(lst, n * sizeof(xaac_limiter_state));
+    } else if (req == REQ_ESBR || req == REQ_ESBR_PS) {
+      xaac_esbr_sbr_batch b;
+      memset(&b, 0, sizeof(b));
+      H2D(hdr, n * sizeof(xaac_sbr_header)); H2D(frm, n * sizeof(xaac_sbr_frame)); H2D(esd, n * sizeof(xaac_esbr_side));
+      H2D(est, n * sizeof(xaac_esbr_state)); H2D(ecore, n * 4096);
+      b.n_ch = g->n; b.core = gg->d.ecore; b.header = gg->d.hdr; b.frame = gg->d.frm; b.side = gg->d.esd; b.state = gg->d.est;
+      b.out = gg->d.etime; b.status = gg->d.status; b.workspace = gg->ws; b.workspace_bytes = gg->ws_bytes;
+      if (req == REQ_ESBR_PS) {
+        H2D(psf, n * sizeof(xaac_ps_frame)); H2D(eps, n * sizeof(xaac_esbr_ps_state));
+        b.ps_frame = gg->d.psf; b.ps_state = gg->d.eps; b.out_r = gg->d.etime_r;
+      }
+      if (xaac_esbr_sbr_process_batch(gg->ctx, &b) != XAAC_OK) die("xaac_esbr_sbr_process_batch");
+      D2H(etime, n * 8192); D2H(est, n * sizeof(xaac_esbr_state)); D2H(status, n * 4);
+      if (req == REQ_ESBR_PS) { D2H(etime_r, n * 8192); D2H(eps, n * sizeof(xaac_esbr_ps_state)); }
     } else {
       H2D(hdr, n * sizeof(xaac_sbr_header)); H2D(frm, n * sizeof(xaac_sbr_frame)); H2D(sst, n * sizeof(xaac_sbr_state));
       H2D(pin, n * 2048);
@@ -437,9 +503,10 @@ int main(int argc, char **argv) {
     uint64_t a = xaac_sbr_lp_workspace_bytes(gn[k]), b = xaac_sbr_hq_workspace_bytes(gn[k], 1),
              c = xaac_peak_limiter_workspace_bytes(gn[k]);
     gg[k].ws_bytes = a > b ? (a > c ? a : c) : (b > c ? b : c);
+    if (xaac_esbr_workspace_bytes(gn[k]) > gg[k].ws_bytes) gg[k].ws_bytes = xaac_esbr_workspace_bytes(gn[k]);
     HIP(hipMalloc(&gg[k].ws, gg[k].ws_bytes));
   }
-  long batches[8] = {0};
+  long batches[REQ_KINDS] = {0};
   for (;;) {
     int alive = 0, progressed = 0;
     for (int k = 0; k < n_groups; k++) {
@@ -484,15 +551,16 @@ int main(int argc, char **argv) {
     waitpid(pids[i], &st, 0);
     failed += !(WIFEXITED(st) && WEXITSTATUS(st) == 0);
   }
-  long calls[8] = {0};
+  long calls[REQ_KINDS] = {0};
   for (int k = 0; k < n_groups; k++)
     for (int i = 0; i < gn[k]; i++)
-      for (int r = 0; r < 6; r++) calls[r] += g_grp[k].inst[i].calls[r];
+      for (int r = 0; r < REQ_KINDS; r++) calls[r] += g_grp[k].inst[i].calls[r];
   printf("{\"streams\": %d, \"groups\": %d, \"failed\": %d, \"pinned\": %d, \"seconds\": %.6f, "
-         "\"calls\": {\"imdct\": %ld, \"sbr_lp\": %ld, \"sbr_hq\": %ld, \"sbr_ps\": %ld, \"limiter\": %ld}, "
-         "\"batches\": {\"imdct\": %ld, \"sbr_lp\": %ld, \"sbr_hq\": %ld, \"sbr_ps\": %ld, \"limiter\": %ld}}\n",
+         "\"calls\": {\"imdct\": %ld, \"sbr_lp\": %ld, \"sbr_hq\": %ld, \"sbr_ps\": %ld, \"limiter\": %ld, \"esbr\": %ld, \"esbr_ps\": %ld}, "
+         "\"batches\": {\"imdct\": %ld, \"sbr_lp\": %ld, \"sbr_hq\": %ld, \"sbr_ps\": %ld, \"limiter\": %ld, \"esbr\": %ld, \"esbr_ps\": %ld}}\n",
          total, n_groups, failed, pinned, (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec), calls[REQ_IMDCT],
-         calls[REQ_SBR_LP], calls[REQ_SBR_HQ], calls[REQ_SBR_PS], calls[REQ_LIM], batches[REQ_IMDCT], batches[REQ_SBR_LP],
-         batches[REQ_SBR_HQ], batches[REQ_SBR_PS], batches[REQ_LIM]);
+         calls[REQ_SBR_LP], calls[REQ_SBR_HQ], calls[REQ_SBR_PS], calls[REQ_LIM], calls[REQ_ESBR], calls[REQ_ESBR_PS],
+         batches[REQ_IMDCT], batches[REQ_SBR_LP], batches[REQ_SBR_HQ], batches[REQ_SBR_PS], batches[REQ_LIM], batches[REQ_ESBR],
+         batches[REQ_ESBR_PS]);
   return failed ? 1 : 0;
 }

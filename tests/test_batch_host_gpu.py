@@ -27,9 +27,9 @@ def _need():
         pytest.skip("oracle/_ref/xaacdec[_batch] missing (built by oracle/Makefile.ref where /root/reference exists)")
 
 
-def run_batch(tmp_path, groups, timeout=900):
+def run_batch(tmp_path, groups, timeout=900, flags=("-esbr:0",)):
     """groups: [(n, aac)] -> (summary dict, {group index: [wav paths]})"""
-    args = [os.path.join(REF, "xaacdec_batch"), "-esbr:0", "--"]
+    args = [os.path.join(REF, "xaacdec_batch"), *flags, "--"]
     outs = {}
     for k, (n, aac) in enumerate(groups):
         prefix = str(tmp_path / ("g%d" % k))
@@ -40,9 +40,9 @@ def run_batch(tmp_path, groups, timeout=900):
     return json.loads(p.stdout.decode().strip().splitlines()[-1]), outs
 
 
-def reference_md5(tmp_path, aac):
+def reference_md5(tmp_path, aac, flags=("-esbr:0",)):
     ref = str(tmp_path / ("ref_" + os.path.basename(aac) + ".wav"))
-    subprocess.run([os.path.join(REF, "xaacdec"), "-ifile:" + aac, "-ofile:" + ref, "-esbr:0"], stdout=subprocess.DEVNULL,
+    subprocess.run([os.path.join(REF, "xaacdec"), "-ifile:" + aac, "-ofile:" + ref, *flags], stdout=subprocess.DEVNULL,
                    stderr=subprocess.DEVNULL, timeout=600, check=False)
     return _md5(ref)
 
@@ -73,3 +73,20 @@ def test_256_instances_of_the_he_aac_v2_stream(tmp_path):
     want = reference_md5(tmp_path, aac)
     assert {_md5(w) for w in outs[0]} == {want}
     assert summary["batches"]["sbr_ps"] * 256 == summary["calls"]["sbr_ps"]
+
+
+def test_default_flags_mixed_groups_every_instance_byte_identical(tmp_path):
+    """the same with the reference's DEFAULT flags (-esbr:1): the SBR calls of the HE-AAC groups go through the float
+    eSBR chain (xaac_esbr_sbr_process_batch, with float parametric stereo for the HE-AACv2 group), one batch per
+    rendezvous; every instance's file byte-identical to the plain reference decoder's default-flags output"""
+    _need()
+    groups = [(32, s) for s in STREAMS]
+    summary, outs = run_batch(tmp_path, groups, flags=())
+    assert summary["failed"] == 0 and summary["streams"] == 32 * len(groups)
+    for k, (n, aac) in enumerate(groups):
+        want = reference_md5(tmp_path, aac, flags=())
+        got = {_md5(w) for w in outs[k]}
+        assert got == {want}, (os.path.basename(aac), len(got))
+    c, b = summary["calls"], summary["batches"]
+    assert c["esbr"] > 0 and c["esbr_ps"] > 0 and c["sbr_lp"] == 0 and c["sbr_ps"] == 0
+    assert b["esbr_ps"] * 32 == c["esbr_ps"]

@@ -49,6 +49,11 @@ def main():
         q.wait()
     wall_ref = time.perf_counter() - t0
     same = open("%s/g0.0.wav" % tmp, "rb").read() == open("%s/r0.wav" % tmp, "rb").read()
+    # the batched host again with the reference's DEFAULT flags: the SBR seam goes through the float eSBR chain
+    args_d = [os.path.join(REF, "xaacdec_batch"), "--"] + ["%d:%s:%s/e%d" % (per, aac, tmp, k) for k in range(groups)]
+    pd = subprocess.run(args_d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    sd = json.loads(pd.stdout.decode().strip().splitlines()[-1])
+    frames_d = sd["calls"]["esbr_ps"] + sd["calls"]["esbr"]
     # ... and with the reference's default flags (-esbr:1: its float eSBR path, the harmonic transposer running idle)
     t0 = time.perf_counter()
     procs = [subprocess.Popen([os.path.join(REF, "xaacdec"), "-ifile:" + aac, "-ofile:%s/d%d.wav" % (tmp, i)],
@@ -62,7 +67,10 @@ def main():
                       "end_to_end_frames_per_s": round(frames / summary["seconds"], 1), "seconds": summary["seconds"],
                       "wall_incl_fork": round(wall, 3), "pinned": summary["pinned"], "batches": summary["batches"],
                       "cpu_only_reference_frames_per_s": round(frames / wall_ref, 1),
-                      "cpu_only_reference_default_flags_frames_per_s": round(frames / wall_def, 1), "cores": os.cpu_count(),
+                      "cpu_only_reference_default_flags_frames_per_s": round(frames / wall_def, 1),
+                      "default_flags_end_to_end_frames_per_s": round(frames_d / sd["seconds"], 1), "default_flags_batches": sd["batches"],
+                      "default_flags_output_identical": open("%s/e0.0.wav" % tmp, "rb").read() == open("%s/d0.wav" % tmp, "rb").read(),
+                      "cores": os.cpu_count(),
                       "output_identical": same}))
 
 
