@@ -8,7 +8,7 @@
 #include "../../include/xaac_amd.h"
 
 #define XAAC_ESBR_ANA_LDS (2 * 1312 * 4 + 64 * 65 * 4)         /* two channels' time-ordered history + the 64 x 65 exchange tile */
-#define XAAC_ESBR_SYN_LDS (2 * 41 * 129 * 4)                   /* ring samples of 2 channels x (9 + 32) slots; the row tile fits */
+#define XAAC_ESBR_SYN_LDS (41 * 129 * 4)                       /* ring samples of one channel x (9 + 32) slots; the half-row tile fits */
 
 typedef struct XaacEsbrAnaParams {
   int32_t n_ch;

@@ -119,90 +119,97 @@ __global__ __launch_bounds__(64) void xaac_esbr_analysis_kernel(XaacEsbrAnaParam
 
 __global__ __launch_bounds__(64) void xaac_esbr_synthesis_kernel(XaacEsbrSynParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int RS = 129, VSLOTS = 41, VROW = 129, RING = 1280;
+  constexpr int HS = 65, VSLOTS = 41, VROW = 129, RING = 1280;
   const int lane = threadIdx.x;
-  int32_t *rows = reinterpret_cast<int32_t *>(smem); /* [64][RS] slot rows (re 0..63 | im 64..127), aliased later by ... */
-  int32_t *v = reinterpret_cast<int32_t *>(smem);    /* ... [2][VSLOTS][VROW] ring samples */
+  int32_t *rows = reinterpret_cast<int32_t *>(smem); /* [64][HS] half rows of the 64 slots, aliased later by ... */
+  int32_t *v = reinterpret_cast<int32_t *>(smem);    /* ... [VSLOTS][VROW] ring samples of one channel at a time */
   const int pair = blockIdx.x;
   int32_t coef[10]; /* c[64 A + k], k = lane */
 #pragma unroll
   for (int a = 0; a < 10; a++) coef[a] = xaac_qmf_esbr_qmf_c[64 * a + lane];
-  for (int r0 = 0; r0 < 64; r0 += 8) { /* rows in: (WORD32)(x * 64), sbr_dec.c:592-595 */
-    float tr[8], ti[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int r = r0 + j, ch = 2 * pair + (r >> 5);
-      const size_t off = (size_t)(ch < p.n_ch ? ch : 0) * p.in_stride + (size_t)(r & 31) * 64 + lane;
-      tr[j] = p.qmf_re[off];
-      ti[j] = p.qmf_im[off];
-    }
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int r = r0 + j, ch = 2 * pair + (r >> 5);
-      rows[RS * r + lane] = ch < p.n_ch ? fx_f2i_trunc(tr[j] * 64.0f) : 0;
-      rows[RS * r + 64 + lane] = ch < p.n_ch ? fx_f2i_trunc(ti[j] * 64.0f) : 0;
-    }
-  }
-  __syncthreads();
   int32_t b[128];
   {
+    /* rows in, (WORD32)(x * 64) (sbr_dec.c:592-595), through a [64][65] tile: the real parts, then the imaginary parts */
     int32_t x[128], t[128];
 #pragma unroll
-    for (int k = 0; k < 128; k++) x[k] = rows[RS * lane + k];
+    for (int half = 0; half < 2; half++) {
+      const float *src = half ? p.qmf_im : p.qmf_re;
+      for (int r0 = 0; r0 < 64; r0 += 8) {
+        float tr[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int r = r0 + j, ch = 2 * pair + (r >> 5);
+          tr[j] = src[(size_t)(ch < p.n_ch ? ch : 0) * p.in_stride + (size_t)(r & 31) * 64 + lane];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int r = r0 + j, ch = 2 * pair + (r >> 5);
+          rows[HS * r + lane] = ch < p.n_ch ? fx_f2i_trunc(tr[j] * 64.0f) : 0;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 64; k++) x[64 * half + k] = rows[HS * lane + k];
+      __syncthreads();
+    }
     xq_esbr_synth_slot(x, t, b, 5 + 1); /* out_scalefactor + 1, sbr_dec.c:556 / :604 */
   }
-  __syncthreads();
-  {
-    int32_t *dst = v + ((lane >> 5) * VSLOTS + 9 + (lane & 31)) * VROW;
-#pragma unroll
-    for (int k = 0; k < 128; k++) dst[k] = b[k];
-  }
-  int d_old[2];
-  for (int c = 0; c < 2; c++) { /* 9 slots of history from the ring */
+  for (int c = 0; c < 2; c++) { /* one channel's ring samples in LDS at a time */
     const int ch = 2 * pair + c;
-    d_old[c] = 0;
-    if (ch >= p.n_ch) continue;
-    const xaac_esbr_syn_state *st = reinterpret_cast<const xaac_esbr_syn_state *>(reinterpret_cast<const char *>(p.state) + (size_t)ch * p.state_stride);
+    if (ch >= p.n_ch) break; /* (uniform) */
+    xaac_esbr_syn_state *st = reinterpret_cast<xaac_esbr_syn_state *>(reinterpret_cast<char *>(p.state) + (size_t)ch * p.state_stride);
+    if ((lane >> 5) == c) {
+      int32_t *dst = v + (9 + (lane & 31)) * VROW;
+#pragma unroll
+      for (int k = 0; k < 128; k++) dst[k] = b[k];
+    }
     int d = st->drc_offset;
     d = ((d % RING + RING) % RING) & ~127;
-    d_old[c] = d;
-    for (int i = lane; i < 9 * 128; i += 64) {
-      const int A = 9 - i / 128;
-      int pos = d + 128 * A + i % 128;
-      if (pos >= RING) pos -= RING;
-      v[(c * VSLOTS + i / 128) * VROW + i % 128] = st->ring[pos];
-    }
-  }
-  __syncthreads();
-  for (int c = 0; c < 2; c++) { /* window-add (ixheaacd_esbr_qmfsyn64_winadd, generic:1544), x 2^-16 to float */
-    const int ch = 2 * pair + c;
-    if (ch >= p.n_ch) break;
-    float *dst = p.out + (size_t)ch * 2048;
-    for (int s = 0; s < 32; s++) {
-      const int32_t *vs = v + (c * VSLOTS + 9 + s) * VROW + lane;
-      int64_t acc = 0;
+    const int f_old = st->filt_off;
+    for (int i0 = lane; i0 < 9 * 128; i0 += 64 * 6) { /* 9 slots of history from the ring, six loads in flight */
+      int32_t tv[6];
 #pragma unroll
-      for (int A = 0; A < 10; A++) acc = xq_add64(acc, (int64_t)vs[-VROW * A + 64 * (A & 1)] * coef[A]);
-      dst[64 * s + lane] = (float)(int32_t)(acc >> 31) / 65536.0f;
+      for (int j = 0; j < 6; j++) {
+        const int i = i0 + 64 * j;
+        if (i < 9 * 128) {
+          const int A = 9 - i / 128;
+          int pos = d + 128 * A + i % 128;
+          if (pos >= RING) pos -= RING;
+          tv[j] = st->ring[pos];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        const int i = i0 + 64 * j;
+        if (i < 9 * 128) v[(i / 128) * VROW + i % 128] = tv[j];
+      }
     }
-  }
-  for (int c = 0; c < 2; c++) { /* state: ring blocks of the last 10 slots, drc offset, window position */
-    const int ch = 2 * pair + c;
-    if (ch >= p.n_ch) break;
-    xaac_esbr_syn_state *st = reinterpret_cast<xaac_esbr_syn_state *>(reinterpret_cast<char *>(p.state) + (size_t)ch * p.state_stride);
-    const int d_new = (d_old[c] + RING - (32 * 128) % RING) % RING;
-    const int f_new = (st->filt_off + 32 * 64) % 640;
-    for (int i = lane; i < RING; i += 64) {
-      const int A = 1 + i / 128;
-      int pos = d_new + 128 * A + i % 128;
-      if (pos >= RING) pos -= RING;
-      if (pos >= RING) pos -= RING;
-      st->ring[pos] = v[(c * VSLOTS + 9 + 32 - A) * VROW + i % 128];
+    __syncthreads();
+    { /* window-add (ixheaacd_esbr_qmfsyn64_winadd, generic:1544), x 2^-16 to float */
+      float *dst = p.out + (size_t)ch * 2048;
+      for (int s = 0; s < 32; s++) {
+        const int32_t *vs = v + (9 + s) * VROW + lane;
+        int64_t acc = 0;
+#pragma unroll
+        for (int A = 0; A < 10; A++) acc = xq_add64(acc, (int64_t)vs[-VROW * A + 64 * (A & 1)] * coef[A]);
+        dst[64 * s + lane] = (float)(int32_t)(acc >> 31) / 65536.0f;
+      }
     }
-    if (lane == 0) {
-      st->drc_offset = d_new;
-      st->filt_off = f_new;
+    { /* state: ring blocks of the last 10 slots, drc offset, window position */
+      const int d_new = (d + RING - (32 * 128) % RING) % RING;
+      for (int i = lane; i < RING; i += 64) {
+        const int A = 1 + i / 128;
+        int pos = d_new + 128 * A + i % 128;
+        if (pos >= RING) pos -= RING;
+        if (pos >= RING) pos -= RING;
+        st->ring[pos] = v[(9 + 32 - A) * VROW + i % 128];
+      }
+      if (lane == 0) {
+        st->drc_offset = d_new;
+        st->filt_off = (f_old + 32 * 64) % 640;
+      }
     }
+    __syncthreads();
   }
 }
 
