@@ -32,6 +32,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef XE_T
+#define XE_T(i) /* optional stage timer hook (tools/prof_esbr_core.py) */
+#endif
+
 /* a [rows][64] float matrix pair; row 0 is the reference's pointer + SBR_HF_ADJ_OFFSET */
 struct XeMat {
   float *re, *im;
@@ -493,6 +497,7 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
       if (c != num_sb) w->err = -1;
     }
     cx.sync();
+    XE_T(6);
     if (w->err) return -1;
     m += nsf;
     XS_PAR(c, 0, num_sb) { /* band energies */
@@ -512,6 +517,7 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
       w->nrg_est[c] = nrg;
     }
     cx.sync();
+    XE_T(7);
     XS_PAR(c, 0, num_sb) { /* gains, :690-722 */
       float est = w->nrg_est[c];
       if (!int_mode) {
@@ -542,6 +548,7 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
     cx.sync();
     XS_PAR(c, 0, num_sb) w->nrg_est[c] = w->pow_lo[c];
     cx.sync();
+    XE_T(8);
     XS_PAR(c, 0, (st->gate_mode[lim_band] < 12 ? st->gate_mode[lim_band] : 12)) { /* limiter, one limiter band per lane, :725-761 */
       /* a table made for another header (a header change without the reset the parser raises with it) may reach past
          this frame's bands, where the reference reads whatever its scratch holds; here such a band ends at the last band */
@@ -576,6 +583,7 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
       }
     }
     cx.sync();
+    XE_T(9);
     if (start_up) {
       XS_PAR(k, 0, num_sb)
         for (int n = 0; n < 4; n++) {
@@ -642,6 +650,7 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
     }
     phase_index = (phase_index + (l1 > l0 ? (l1 - l0) * num_sb : 0)) & 511;
     cx.sync();
+    XE_T(10);
     if (tes) {
       xe_inter_tes(cx, w, low, x, l0, l1 - l0, sb_start, num_sb, sd->inter_temp_shape_mode[i]);
       XS_PAR(k, 0, num_sb) { /* sinusoids, :833-850 */

@@ -14,25 +14,27 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifdef XE_PROFILE /* tools/prof_esbr_core.py: cycles of lane 0 between XE_T hooks, summed over channel-frames */
+__shared__ long long xe_prof_last;
+__shared__ long long xe_prof_acc[16];
+#define XE_T(i)                            \
+  do {                                     \
+    if (threadIdx.x == 0) {                \
+      const long long t_ = clock64();      \
+      xe_prof_acc[i] += t_ - xe_prof_last; \
+      xe_prof_last = t_;                   \
+    }                                      \
+  } while (0)
+#endif
 #include "esbr_core.h"
 #include "esbr_core_kernel.h"
 
-#ifdef XE_PROFILE /* tools/prof_esbr_core.py: lane-0 cycle counts per stage, summed into the status words */
-#define XE_T(i)                                                                                   \
-  do {                                                                                            \
-    if (threadIdx.x == 0) {                                                                       \
-      const long long now_ = clock64();                                                           \
-      atomicAdd(reinterpret_cast<unsigned long long *>(p.status) + (i), (unsigned long long)(now_ - t_last_)); \
-      t_last_ = now_;                                                                             \
-    }                                                                                             \
-  } while (0)
-#else
-#define XE_T(i)
-#endif
-
 __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParams p) { /* 168 VGPRs: 12 waves per CU (measured best of 8 / 12 / 16) */
 #ifdef XE_PROFILE
-  long long t_last_ = clock64();
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 16; i++) xe_prof_acc[i] = 0;
+    xe_prof_last = clock64();
+  }
 #endif
   __shared__ XeWork w;
   const int ch = blockIdx.x, lane = threadIdx.x;
@@ -152,6 +154,7 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
   }
 #ifdef XE_PROFILE
   XE_T(5);
+  if (lane < 16) atomicAdd(reinterpret_cast<unsigned long long *>(p.status) + lane, (unsigned long long)xe_prof_acc[lane]);
 #else
   if (lane == 0 && p.status) p.status[ch] = rc;
 #endif

@@ -11,7 +11,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-NAMES = ["side info to LDS", "history clear + sbr_qmf_out init", "generate_hf", "env_calc", "regroup (+PS rows)", "history shift"]
+NAMES = ["side info to LDS", "history clear + sbr_qmf_out init", "generate_hf", "env_calc: rest (reset, harmonics map, tail)", "regroup (+PS rows)",
+         "history shift", "env: band map (lane 0)", "env: energies", "env: gains", "env: limiter", "env: apply + sinusoids"]
 
 
 def main():
@@ -44,11 +45,17 @@ def main():
     pcm = torch.zeros((n, 2048), dtype=torch.float32, device=dev)
     ws = torch.zeros(ctx.esbr_workspace_bytes(n), dtype=torch.uint8, device=dev)
     status = torch.zeros(n, dtype=torch.int32, device=dev)
+    import esbr_structs
+    ctx.esbr_sbr_process_batch(core, hd, fr, sd, st, pcm, ws, status)   # first frame: reset flag set, limiter tables built
+    ctx.sync()
+    status.zero_()
+    off = esbr_structs.EsbrSide.reset_flag.offset
+    sd.view(n, -1)[:, off:off + 2] = 0
     steps = 4
     for _ in range(steps):
         ctx.esbr_sbr_process_batch(core, hd, fr, sd, st, pcm, ws, status)
     ctx.sync()
-    acc = status.cpu().numpy()[:16].view(np.uint64).astype(np.float64)[:6] / (steps * n)
+    acc = status.cpu().numpy()[:32].view(np.uint64).astype(np.float64)[:11] / (steps * n)
     for nm, v in zip(NAMES, acc):
         print("%-36s %9.0f cycles/channel-frame %5.1f%%" % (nm, v, 100 * v / acc.sum()))
     print("total %.0f cycles" % acc.sum())
