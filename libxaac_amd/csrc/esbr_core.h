@@ -35,6 +35,9 @@
 #ifndef XE_T
 #define XE_T(i) /* optional stage timer hook (tools/prof_esbr_core.py) */
 #endif
+#ifndef XE_RANDOM_PHASE
+#define XE_RANDOM_PHASE(i) xaac_esbr_random_phase[i] /* the kernel reads its LDS copy */
+#endif
 
 /* a [rows][64] float matrix pair; row 0 is the reference's pointer + SBR_HF_ADJ_OFFSET */
 struct XeMat {
@@ -76,11 +79,12 @@ struct XeWork {
   float bw_array[XAAC_SBR_MAX_PATCHES];
   float nrg_est[64], nrg_ref[64], nrg_gain[64], noise_level[64], nrg_tone[64];
   float pow_lo[80], pow_hi[80], tes_gain[80];
+  float lim_pref[13], lim_gmax[13];
   int32_t err;
   int16_t src_band[64]; /* HF generator: source band of high band k2; -1: cleared; -2: not in a patch */
   int8_t bw_idx[64];
   int8_t harmonics[64];
-  int8_t sfb_first[64], sfb_len[64], flag[64], o_idx[64];
+  int8_t sfb_first[64], sfb_len[64], flag[64], o_idx[64], lim_of[64];
   int16_t m_idx[64];
 };
 
@@ -166,6 +170,8 @@ FX_HD int xe_side_info_bad(const xaac_sbr_header *h, const xaac_sbr_frame *f, co
   for (int i = 0; i < h->num_sf_bands[0]; i++) bad |= h->freq_band_tbl_lo[i] > h->freq_band_tbl_lo[i + 1];
   for (int i = 0; i < h->num_sf_bands[1]; i++) bad |= h->freq_band_tbl_hi[i] > h->freq_band_tbl_hi[i + 1];
   for (int i = 0; i <= h->num_nf_bands; i++) bad |= h->freq_band_tbl_noise[i] < 1 || h->freq_band_tbl_noise[i] > 64;
+  for (int i = 0; i < h->num_nf_bands; i++) bad |= h->freq_band_tbl_noise[i] >= h->freq_band_tbl_noise[i + 1];
+  bad |= h->freq_band_tbl_noise[0] != h->sub_band_start || h->freq_band_tbl_noise[h->num_nf_bands] != h->sub_band_end;
   for (int i = 0; i <= sd->num_mf_bands; i++) bad |= sd->f_master_tbl[i] < 1 || sd->f_master_tbl[i] > 64;
   for (int i = 0; i < sd->num_mf_bands; i++) bad |= sd->f_master_tbl[i] > sd->f_master_tbl[i + 1];
   bad |= sd->f_master_tbl[0] > h->sub_band_start || sd->f_master_tbl[0] > 32;
@@ -188,7 +194,6 @@ FX_HD void xe_build_patches(const xaac_sbr_header *h, const xaac_esbr_side *sd, 
   const int16_t *fm = sd->f_master_tbl;
   const int nmf = sd->num_mf_bands;
   const int lsb = fm[0], usb = fm[nmf], xover_offset = h->sub_band_start - fm[0];
-  const int16_t *invf_tbl = h->freq_band_tbl_noise + 1;
   for (int k = 0; k < 64; k++) w->src_band[k] = -2;
   int goal_sb = (int)(2.048e6f / (float)sd->out_sampling_freq + 0.5f);
   if (goal_sb < fm[nmf]) {
@@ -224,26 +229,28 @@ FX_HD void xe_build_patches(const xaac_sbr_header *h, const xaac_esbr_side *sd, 
       continue;
     }
     flag_break = 0;
-    for (int k2 = sb; k2 < sb + num; k2++) {
-      int bw_index = 0;
-      while (k2 >= invf_tbl[bw_index]) {
-        bw_index++;
-        if (bw_index >= XAAC_SBR_MAX_NOISE_COEFFS) {
-          w->err = -1;
-          return;
-        }
-      }
-      if (k2 - stride < 0 || k2 >= 64) { /* a source band in front of the matrix: the reference would read there */
-        w->err = -1;
-        return;
-      }
-      w->src_band[k2] = (int16_t)(k2 - stride);
-      w->bw_idx[k2] = (int8_t)bw_index;
+    if (sb - stride < 0 || sb + num > 64) { /* a source band in front of the matrix: the reference would read there */
+      w->err = -1;
+      return;
     }
+    for (int k2 = sb; k2 < sb + num; k2++) w->src_band[k2] = (int16_t)(k2 - stride);
     sb += num;
     patch++;
   }
   st->num_patches = patch;
+}
+
+/* the inverse-filtering band of a patched band (sbrdec_lpfuncs.c:1201-1218), every lane for its own band */
+FX_HD void xe_patch_bw_index(const XsCx &cx, const xaac_sbr_header *h, XeWork *w) {
+  const int16_t *invf_tbl = h->freq_band_tbl_noise + 1;
+  XS_PAR(k2, 0, 64) {
+    if (w->src_band[k2] >= 0) {
+      int bw_index = 0;
+      while (bw_index < XAAC_SBR_MAX_NOISE_COEFFS && k2 >= invf_tbl[bw_index]) bw_index++;
+      if (bw_index >= XAAC_SBR_MAX_NOISE_COEFFS) w->err = -1;
+      else w->bw_idx[k2] = (int8_t)bw_index;
+    }
+  }
 }
 
 FX_HD void xe_generate_hf(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
@@ -312,6 +319,9 @@ FX_HD void xe_generate_hf(const XsCx &cx, const xaac_sbr_header *h, const xaac_s
     w->alpha_r[k][0] = a0r; w->alpha_i[k][0] = a0i;
     w->alpha_r[k][1] = a1r; w->alpha_i[k][1] = a1i;
   }
+  cx.sync();
+  if (w->err) return;
+  xe_patch_bw_index(cx, h, w);
   cx.sync();
   if (w->err) return;
   XS_PAR(k2, 0, 64) {
@@ -468,33 +478,26 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
     const int res = f->freq_res[i] ? 1 : 0, nsf = h->num_sf_bands[res];
     const int16_t *ftab = res ? h->freq_band_tbl_hi : h->freq_band_tbl_lo;
     const int l0 = 2 * f->border_vec[i], l1 = 2 * f->border_vec[i + 1];
-    /* band -> scale-factor band / noise band map of this envelope (esbr_envcal.c:657-699), lane 0 */
-    XS_ONE {
-      int c = 0, o = 0;
-      for (int j = 0; j < nsf; j++) {
-        const int li = ftab[j], ui = ftab[j + 1];
-        int ui2 = h->freq_band_tbl_noise[o + 1], flag = 0;
-        for (int k = li; k < ui; k++) {
-          const int cc = c + (k - li);
-          if (cc < 64 && w->harmonics[cc] && (i >= trans_env || st->harm_flag_prev[(cc + sb_start) & 63])) flag = 1;
-        }
-        for (int k = 0; k < ui - li; k++) {
-          o = (k + li >= ui2) ? o + 1 : o;
-          if (o >= XAAC_SBR_MAX_NOISE_COEFFS || c >= 64) {
-            w->err = -1;
-            break;
-          }
-          ui2 = h->freq_band_tbl_noise[o + 1];
-          w->sfb_first[c] = (int8_t)(c - k);
-          w->sfb_len[c] = (int8_t)(ui - li);
-          w->flag[c] = (int8_t)flag;
-          w->o_idx[c] = (int8_t)o;
-          w->m_idx[c] = (int16_t)(m + j);
-          c++;
-        }
-        if (w->err) break;
+    /* band -> scale-factor band / noise band map of this envelope (esbr_envcal.c:657-699).  The reference walks the bands
+       once, stepping its noise-band counter whenever a band reaches the next noise border; with the strictly increasing
+       tables xe_side_info_bad insists on, that counter is the number of inner noise borders at or below the band, so
+       every lane finds its own band's entries. */
+    XS_PAR(c, 0, num_sb) {
+      const int kabs = sb_start + c;
+      int j = 0;
+      while (j < nsf - 1 && kabs >= ftab[j + 1]) j++;
+      const int li = ftab[j], ui = ftab[j + 1];
+      int flag = 0, o = 0;
+      for (int k = li; k < ui; k++) {
+        const int cc = k - sb_start;
+        if (w->harmonics[cc & 63] && (i >= trans_env || st->harm_flag_prev[k & 63])) flag = 1;
       }
-      if (c != num_sb) w->err = -1;
+      for (int q = 1; q < num_nf; q++) o += kabs >= h->freq_band_tbl_noise[q];
+      w->sfb_first[c] = (int8_t)(li - sb_start);
+      w->sfb_len[c] = (int8_t)(ui - li);
+      w->flag[c] = (int8_t)flag;
+      w->o_idx[c] = (int8_t)o;
+      w->m_idx[c] = (int16_t)(m + j);
     }
     cx.sync();
     XE_T(6);
@@ -549,37 +552,71 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
     XS_PAR(c, 0, num_sb) w->nrg_est[c] = w->pow_lo[c];
     cx.sync();
     XE_T(8);
-    XS_PAR(c, 0, (st->gate_mode[lim_band] < 12 ? st->gate_mode[lim_band] : 12)) { /* limiter, one limiter band per lane, :725-761 */
-      /* a table made for another header (a header change without the reset the parser raises with it) may reach past
-         this frame's bands, where the reference reads whatever its scratch holds; here such a band ends at the last band */
+    /* limiter (:725-761).  Per limiter band the reference runs three sums over its bands in band order -- those stay
+       sequential, one limiter band per lane -- with element-wise work between them, which goes to one band per lane.
+       (A table made for another header -- a header change without the reset the parser raises with it -- may reach past
+       this frame's bands, where the reference reads whatever its scratch holds; here such a band ends at the last band.) */
+    const int n_lim = st->gate_mode[lim_band] < 12 ? st->gate_mode[lim_band] : 12;
+    XS_PAR(c, 0, n_lim) {
       const int k0 = st->lim_table[lim_band][c], k1r = st->lim_table[lim_band][c + 1], k1 = k1r < num_sb ? k1r : num_sb;
+      float p_ref = 0, p_est = 0, g_max = 0;
       if (k0 >= 0 && k0 <= k1) {
-        float p_ref = 0, p_est = 0;
         for (int k = k0; k < k1; k++) {
           p_ref += w->nrg_ref[k];
           p_est += w->nrg_est[k];
         }
         const float avg_gain = (float)xe_sqrt((p_ref + 1e-12f) / (p_est + 1e-12f));
-        float g_max = avg_gain * xaac_esbr_g_lim_gains[lim_gains];
+        g_max = avg_gain * xaac_esbr_g_lim_gains[lim_gains];
         if (g_max > 1.0e5f) g_max = 1.0e5f;
-        for (int k = k0; k < k1; k++)
-          if (g_max <= w->nrg_gain[k]) {
-            w->noise_level[k] = (float)(w->noise_level[k] * (g_max / (w->nrg_gain[k] + guard)));
-            w->nrg_gain[k] = g_max;
-          }
+      }
+      w->lim_pref[c] = p_ref;
+      w->lim_gmax[c] = g_max;
+    }
+    cx.sync();
+    XS_PAR(k, 0, num_sb) {
+      int lb = -1;
+      for (int c = 0; c < n_lim; c++) {
+        const int k0 = st->lim_table[lim_band][c], k1r = st->lim_table[lim_band][c + 1], k1 = k1r < num_sb ? k1r : num_sb;
+        if (lb < 0 && k0 >= 0 && k >= k0 && k < k1) lb = c;
+      }
+      w->lim_of[k] = (int8_t)lb;
+      float ta = 0.0f, tb = 0.0f;
+      if (lb >= 0) {
+        const float g_max = w->lim_gmax[lb];
+        if (g_max <= w->nrg_gain[k]) {
+          w->noise_level[k] = (float)(w->noise_level[k] * (g_max / (w->nrg_gain[k] + guard)));
+          w->nrg_gain[k] = g_max;
+        }
+        ta = w->nrg_gain[k] * w->nrg_gain[k] * w->nrg_est[k];
+        if (w->nrg_tone[k]) tb = w->nrg_tone[k] * w->nrg_tone[k];
+        else if (!noise_absc) tb = w->noise_level[k] * w->noise_level[k];
+      }
+      w->pow_hi[k] = ta;   /* the two terms the band adds to its limiter band's adjusted power, in this order; an absent */
+      w->tes_gain[k] = tb; /* second term is +0, which leaves the non-negative running sum as it is */
+    }
+    cx.sync();
+    XS_PAR(c, 0, n_lim) {
+      const int k0 = st->lim_table[lim_band][c], k1r = st->lim_table[lim_band][c + 1], k1 = k1r < num_sb ? k1r : num_sb;
+      float boost = 1.0f;
+      if (k0 >= 0 && k0 <= k1) {
         float p_adj = 0;
         for (int k = k0; k < k1; k++) {
-          p_adj += w->nrg_gain[k] * w->nrg_gain[k] * w->nrg_est[k];
-          if (w->nrg_tone[k]) p_adj += w->nrg_tone[k] * w->nrg_tone[k];
-          else if (!noise_absc) p_adj += w->noise_level[k] * w->noise_level[k];
+          p_adj += w->pow_hi[k];
+          p_adj += w->tes_gain[k];
         }
-        float boost = (float)xe_sqrt((p_ref + 1e-12f) / (p_adj + 1e-12f));
+        boost = (float)xe_sqrt((w->lim_pref[c] + 1e-12f) / (p_adj + 1e-12f));
         boost = boost > 1.584893192f ? 1.584893192f : boost;
-        for (int k = k0; k < k1; k++) {
-          w->nrg_gain[k] *= boost;
-          w->noise_level[k] *= boost;
-          w->nrg_tone[k] *= boost;
-        }
+      }
+      w->lim_gmax[c] = boost;
+    }
+    cx.sync();
+    XS_PAR(k, 0, num_sb) {
+      const int lb = w->lim_of[k];
+      if (lb >= 0) {
+        const float boost = w->lim_gmax[lb];
+        w->nrg_gain[k] *= boost;
+        w->noise_level[k] *= boost;
+        w->nrg_tone[k] *= boost;
       }
     }
     cx.sync();
@@ -625,8 +662,8 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
               }
               const int ph = (phase_index + j * num_sb + k + 1) & 511;
               if (no_noise) sb_noise = 0;
-              cr[jj] = cr[jj] * sb_gain + sb_noise * xaac_esbr_random_phase[2 * ph];
-              ci[jj] = ci[jj] * sb_gain + sb_noise * xaac_esbr_random_phase[2 * ph + 1];
+              cr[jj] = cr[jj] * sb_gain + sb_noise * XE_RANDOM_PHASE(2 * ph);
+              ci[jj] = ci[jj] * sb_gain + sb_noise * XE_RANDOM_PHASE(2 * ph + 1);
               if (!tes) { /* sinusoids, :833-850 (behind the inter-TES shaping when that is active: below) */
                 const int hi = (harm_index + j) & 3;
                 cr[jj] += tone * hp[0][hi];

@@ -26,8 +26,26 @@ __shared__ long long xe_prof_acc[16];
     }                                      \
   } while (0)
 #endif
+/* LDS copy of the 512 random phases the noise substitution looks up per band and slot */
+__shared__ float xe_lds_random_phase[1024];
+#define XE_RANDOM_PHASE(i) xe_lds_random_phase[i]
 #include "esbr_core.h"
 #include "esbr_core_kernel.h"
+
+namespace {
+/* global -> LDS: eight loads are in flight before the first store */
+__device__ __forceinline__ void xe_copy_words(int32_t *dst, const int32_t *src, int n, int lane) {
+  for (int i = lane; i < n; i += 64 * 8) {
+    int32_t t[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (i + 64 * j < n) t[j] = src[i + 64 * j];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (i + 64 * j < n) dst[i + 64 * j] = t[j];
+  }
+}
+}  // namespace
 
 __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParams p) { /* 168 VGPRs: 12 waves per CU (measured best of 8 / 12 / 16) */
 #ifdef XE_PROFILE
@@ -44,9 +62,10 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
   __shared__ xaac_sbr_frame sf;
   __shared__ xaac_esbr_side ssd;
   static_assert(sizeof(xaac_sbr_header) % 4 == 0 && sizeof(xaac_sbr_frame) % 4 == 0 && sizeof(xaac_esbr_side) % 4 == 0, "word copies");
-  for (int i = lane; i < (int)(sizeof(sh) / 4); i += 64) reinterpret_cast<int32_t *>(&sh)[i] = reinterpret_cast<const int32_t *>(p.header + ch)[i];
-  for (int i = lane; i < (int)(sizeof(sf) / 4); i += 64) reinterpret_cast<int32_t *>(&sf)[i] = reinterpret_cast<const int32_t *>(p.frame + ch)[i];
-  for (int i = lane; i < (int)(sizeof(ssd) / 4); i += 64) reinterpret_cast<int32_t *>(&ssd)[i] = reinterpret_cast<const int32_t *>(p.side + ch)[i];
+  xe_copy_words(reinterpret_cast<int32_t *>(&sh), reinterpret_cast<const int32_t *>(p.header + ch), sizeof(sh) / 4, lane);
+  xe_copy_words(reinterpret_cast<int32_t *>(&sf), reinterpret_cast<const int32_t *>(p.frame + ch), sizeof(sf) / 4, lane);
+  xe_copy_words(reinterpret_cast<int32_t *>(&ssd), reinterpret_cast<const int32_t *>(p.side + ch), sizeof(ssd) / 4, lane);
+  xe_copy_words(reinterpret_cast<int32_t *>(xe_lds_random_phase), reinterpret_cast<const int32_t *>(xaac_esbr_random_phase), 1024, lane);
   __syncthreads();
   const xaac_sbr_header *h = &sh;
   const xaac_sbr_frame *f = &sf;
