@@ -38,15 +38,15 @@ struct XfWork {
 
 /* one all-pass chain step (ps_dec_flt.c:693-716): in = the delayed, phase-rotated sample; returns the chain's output */
 FX_HD void xf_allpass(float &r_r0, float &i_r0, float *ser_re, float *ser_im /* [3] current ring cells */,
-                      const float *pf_re, const float *pf_im /* [3] */, float decay) {
+                      const float *pf_re, const float *pf_im /* [3] */, float decay, const float *link /* [3] */) {
   for (int m = 0; m < 3; m++) {
     const float real0 = ser_re[m], imag0 = ser_im[m];
     float real = real0 * pf_re[m] - imag0 * pf_im[m];
     float imag = real0 * pf_im[m] + imag0 * pf_re[m];
-    real += -decay * xaac_eps_all_pass_link_decay_ser[m] * r_r0;
-    imag += -decay * xaac_eps_all_pass_link_decay_ser[m] * i_r0;
-    ser_re[m] = r_r0 + decay * xaac_eps_all_pass_link_decay_ser[m] * real;
-    ser_im[m] = i_r0 + decay * xaac_eps_all_pass_link_decay_ser[m] * imag;
+    real += -decay * link[m] * r_r0;
+    imag += -decay * link[m] * i_r0;
+    ser_re[m] = r_r0 + decay * link[m] * real;
+    ser_im[m] = i_r0 + decay * link[m] * imag;
     r_r0 = real;
     i_r0 = imag;
   }
@@ -73,6 +73,7 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
       ps->qmf_delay_im[k][sb] = 0;
     }
   }
+  XE_T(0);
   /* hybrid analysis of QMF bands 0..2 (8 + 2 + 2 sub-bands), lane = slot; the 12-slot history is the filter's past */
   XS_PAR(i, 0, 32) {
     int ch_offset = 0;
@@ -129,6 +130,7 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
     ps->hyb_hist_re[band][n] = L.r(26 + n, band);
     ps->hyb_hist_im[band][n] = L.i(26 + n, band);
   }
+  XE_T(1);
   /* band powers per parameter bin (:606-632), lane = slot; a bin's sum runs group by group, sub-band by sub-band */
   XS_PAR(k, 0, 32) {
     for (int bin = 0; bin < 20; bin++) w->pw[k][bin] = 0;
@@ -149,6 +151,7 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
     }
   }
   cx.sync();
+  XE_T(2);
   /* transient detector (:634-659), lane = bin, a recursion over the slots */
   XS_PAR(bin, 0, 20) {
     float peak = ps->peak_decay_fast[bin], pdiff = ps->prev_peak_diff[bin], nrg = ps->prev_nrg[bin];
@@ -169,6 +172,7 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
     ps->prev_nrg[bin] = nrg;
   }
   cx.sync();
+  XE_T(3);
   /* decorrelation: all-pass chains on the hybrid sub-bands and QMF bands 3..22, plain delays above (:667-827); every
      sub-band is its own recursion over the slots.  Lanes 0..9: hybrid groups; then lanes = QMF bands 3..63. */
   const int l_delay0 = ps->delay_buf_idx;
@@ -180,6 +184,12 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
   XS_PAR(gr, 0, 10) {
     const int sb = gb[gr], bin = gmap[gr] & ~XF_NEG;
     const float pr = xaac_eps_frac_delay_phase_fac_qmf_sub_re_20[sb], pi = xaac_eps_frac_delay_phase_fac_qmf_sub_im_20[sb];
+    float pfr[3], pfi[3], link[3]; /* loop constants in registers */
+    for (int m = 0; m < 3; m++) {
+      pfr[m] = xaac_eps_frac_delay_phase_fac_ser_qmf_sub_re_20[3 * sb + m];
+      pfi[m] = xaac_eps_frac_delay_phase_fac_ser_qmf_sub_im_20[3 * sb + m];
+      link[m] = xaac_eps_all_pass_link_decay_ser[m];
+    }
     float dre[2], dim[2], sre[3][5] = {{0}}, sim[3][5] = {{0}};
     for (int j = 0; j < 2; j++) {
       const int idx = (l_delay0 + j) & 1;
@@ -198,8 +208,7 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
       dre[1] = w->hl_re[k][sb]; dim[1] = w->hl_im[k][sb];
       float r_r0 = real0 * pr - imag0 * pi, i_r0 = real0 * pi + imag0 * pr;
       float sr[3] = {sre[0][0], sre[1][0], sre[2][0]}, si[3] = {sim[0][0], sim[1][0], sim[2][0]};
-      xf_allpass(r_r0, i_r0, sr, si, &xaac_eps_frac_delay_phase_fac_ser_qmf_sub_re_20[3 * sb],
-                 &xaac_eps_frac_delay_phase_fac_ser_qmf_sub_im_20[3 * sb], 1.0f);
+      xf_allpass(r_r0, i_r0, sr, si, pfr, pfi, 1.0f, link);
       for (int m = 0; m < 3; m++) {
         for (int j = 0; j < 2 + m; j++) {
           sre[m][j] = sre[m][j + 1];
@@ -225,6 +234,7 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
         ps->ser_sub_im[m][idx][sb] = sim[m][j];
       }
   }
+  XE_T(4);
   XS_PAR(sb, 3, 64) {
     int gr = 10;
     while (gr < 21 && sb >= gb[gr + 1]) gr++;
@@ -235,6 +245,12 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
     const int dl = plain ? xaac_eps_qmf_delay_idx_tbl[sb] : 2; /* 14, 1 or 2 cells of qmf_delay_buf belong to this band */
     const int pos = plain ? ps->delay_qmf_idx[sb] : l_delay0;
     const float pr = xaac_eps_qmf_fract_delay_phase_factor_re[sb], pi = xaac_eps_qmf_fract_delay_phase_factor_im[sb];
+    float pfr[3], pfi[3], link[3]; /* loop constants in registers */
+    for (int m = 0; m < 3; m++) {
+      pfr[m] = xaac_eps_qmf_ser_fract_delay_phase_factor_re[3 * sb + m];
+      pfi[m] = xaac_eps_qmf_ser_fract_delay_phase_factor_im[3 * sb + m];
+      link[m] = xaac_eps_all_pass_link_decay_ser[m];
+    }
     float dre[14] = {0}, dim[14] = {0}, sre[3][5] = {{0}}, sim[3][5] = {{0}};
     XE_UNROLL
     for (int j = 0; j < 14; j++)
@@ -277,8 +293,7 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
             r_r0 = real0 * pr - imag0 * pi;
             i_r0 = real0 * pi + imag0 * pr;
             float sr[3] = {sre[0][0], sre[1][0], sre[2][0]}, si[3] = {sim[0][0], sim[1][0], sim[2][0]};
-            xf_allpass(r_r0, i_r0, sr, si, &xaac_eps_qmf_ser_fract_delay_phase_factor_re[3 * sb],
-                       &xaac_eps_qmf_ser_fract_delay_phase_factor_im[3 * sb], decay);
+            xf_allpass(r_r0, i_r0, sr, si, pfr, pfi, decay, link);
             for (int m = 0; m < 3; m++) {
               for (int j = 0; j < 2 + m; j++) {
                 sre[m][j] = sre[m][j + 1];
@@ -313,6 +328,7 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
         }
     if (plain) ps->delay_qmf_idx[sb] = pos_end;
   }
+  XE_T(5);
   for (int k = k0; k < k1; k++) { /* where the shared ring positions end up (:829-832) */
     if (++l_delay_end >= 2) l_delay_end = 0;
     for (int m = 0; m < 3; m++)
@@ -348,7 +364,9 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
     }
     cx.sync();
     const int e0 = pf->border_position[env], e1 = pf->border_position[env + 1], len = e1 - e0;
-    XS_PAR(u, 0, 10 + 61) { /* units: 10 hybrid groups, then QMF bands 3..63 */
+    XS_PAR(v, 0, 61 + 10) { /* units: QMF bands 3..63, then the 10 hybrid groups (the lanes' second pass holds hybrid
+                               units only, whose data is in LDS) */
+      const int u = v < 61 ? v + 10 : v - 61;
       int gr, sb;
       if (u < 10) {
         gr = u;
@@ -407,6 +425,7 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
       for (int j = 0; j < 8; j++) ps->h_prev[j][bin] = w->hv[j][bin];
     cx.sync();
   }
+  XE_T(6);
   /* hybrid synthesis (:203-227): QMF bands 0..2 of both channels */
   XS_PAR(n, 0, 32) {
     int ch = 0;
@@ -425,6 +444,7 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
     }
   }
   cx.sync();
+  XE_T(7);
 }
 
 #endif

@@ -12,13 +12,32 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifdef XE_PROFILE /* tools/prof_esbr_core.py ps: cycles of lane 0 between XE_T hooks, summed over stream-frames */
+__shared__ long long xe_prof_last;
+__shared__ long long xe_prof_acc[16];
+#define XE_T(i)                            \
+  do {                                     \
+    if (threadIdx.x == 0) {                \
+      const long long t_ = clock64();      \
+      xe_prof_acc[i] += t_ - xe_prof_last; \
+      xe_prof_last = t_;                   \
+    }                                      \
+  } while (0)
+#endif
 #include "esbr_ps.h"
 #include "esbr_core_kernel.h"
 
-__global__ __launch_bounds__(64) void xaac_esbr_ps_kernel(XaacEsbrPsParams p) {
+__global__ __launch_bounds__(64, 3) void xaac_esbr_ps_kernel(XaacEsbrPsParams p) {
   __shared__ XfWork w;
   const int n = blockIdx.x, lane = threadIdx.x;
   const XsCx cx = {lane, 64};
+#ifdef XE_PROFILE
+  if (lane == 0) {
+    for (int i = 0; i < 16; i++) xe_prof_acc[i] = 0;
+    xe_prof_last = clock64();
+  }
+  __syncthreads();
+#endif
   const xaac_ps_frame *pf = p.ps_frame + n;
   float *lre = p.l_re + (size_t)n * XAAC_ESBR_L_ROWS * 64, *lim = p.l_im + (size_t)n * XAAC_ESBR_L_ROWS * 64;
   float *rre = p.r_re + (size_t)n * 2048, *rim = p.r_im + (size_t)n * 2048;
@@ -33,6 +52,9 @@ __global__ __launch_bounds__(64) void xaac_esbr_ps_kernel(XaacEsbrPsParams p) {
     }
     __syncthreads();
     xf_apply_ps(cx, pf, p.ps_state + n, &w, L, R, p.header[n].sub_band_end);
+#ifdef XE_PROFILE
+    if (lane < 16) atomicAdd(reinterpret_cast<unsigned long long *>(p.status) + 16 + lane, (unsigned long long)xe_prof_acc[lane]);
+#endif
   } else { /* no SBR processing this frame: the right channel is the left one (sbr_dec.c:516-523) */
     for (int i = 0; i < 32; i++) {
       rre[64 * i + lane] = lre[64 * i + lane];

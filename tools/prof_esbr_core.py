@@ -15,6 +15,43 @@ NAMES = ["side info to LDS", "history clear + sbr_qmf_out init", "generate_hf", 
          "history shift", "env: band map (lane 0)", "env: energies", "env: gains", "env: limiter", "env: apply + sinusoids"]
 
 
+PS_NAMES = ["state clear above the SBR range", "hybrid analysis + history", "band powers", "transient detector",
+            "decorrelator, hybrid sub-bands", "decorrelator, QMF bands", "rotation (all envelopes)", "hybrid synthesis"]
+
+
+def main_ps(torch, libxaac_amd, ctx, dev, n, rng, c, make_side, core, pcm, ws, status):
+    """python tools/prof_esbr_core.py ps: the float parametric-stereo kernel's stages on HE-AACv2 side info"""
+    from esbr_structs import new_state, new_ps_state, EsbrSide
+    from test_esbr_ps_oracle_vs_reference import fuzz_ps_frame
+    recs = [r for r in c.read_records(os.path.join(ROOT, "tests", "golden", "sbr_hq_ps_records.bin.gz")) if r["ps"] and r["frame"].apply_processing][:64]
+    hs, fs, sds, pfs = [], [], [], []
+    for r in recs:
+        h, f = c.Header.from_buffer_copy(bytes(r["header"])), c.Frame.from_buffer_copy(bytes(r["frame"]))
+        sd = make_side(rng, h, f, [0] * 10, 0, 0, False)
+        sd.reset_flag = 1
+        pf = fuzz_ps_frame(rng, c.PsFrame.from_buffer_copy(bytes(r["ps_frame"])), 0)
+        for x, lst in ((h, hs), (f, fs), (sd, sds), (pf, pfs)):
+            lst.append(np.frombuffer(bytes(x), np.uint8))
+    tile = lambda xs: torch.from_numpy(np.stack([xs[i % len(xs)] for i in range(n)])).to(dev)
+    hd, fr, sd, pf = tile(hs), tile(fs), tile(sds), tile(pfs)
+    st = torch.from_numpy(np.stack([np.frombuffer(bytes(new_state()), np.uint8)] * n)).to(dev)
+    pst = torch.from_numpy(np.stack([np.frombuffer(bytes(new_ps_state()), np.uint8)] * n)).to(dev)
+    pcm_r = torch.zeros_like(pcm)
+    ctx.esbr_sbr_process_batch(core, hd, fr, sd, st, pcm, ws, status, pf, pst, pcm_r)
+    ctx.sync()
+    status.zero_()
+    off = EsbrSide.reset_flag.offset
+    sd.view(n, -1)[:, off:off + 2] = 0
+    steps = 4
+    for _ in range(steps):
+        ctx.esbr_sbr_process_batch(core, hd, fr, sd, st, pcm, ws, status, pf, pst, pcm_r)
+    ctx.sync()
+    acc = status.cpu().numpy()[:64].view(np.uint64).astype(np.float64)[16:24] / (steps * n)
+    for nm, v in zip(PS_NAMES, acc):
+        print("%-36s %9.0f cycles/stream-frame %5.1f%%" % (nm, v, 100 * v / acc.sum()))
+    print("total %.0f cycles" % acc.sum())
+
+
 def main():
     import torch
     import libxaac_amd
@@ -45,6 +82,8 @@ def main():
     pcm = torch.zeros((n, 2048), dtype=torch.float32, device=dev)
     ws = torch.zeros(ctx.esbr_workspace_bytes(n), dtype=torch.uint8, device=dev)
     status = torch.zeros(n, dtype=torch.int32, device=dev)
+    if len(sys.argv) > 1 and sys.argv[1] == "ps":
+        return main_ps(torch, libxaac_amd, ctx, dev, n, rng, c, make_side, core, pcm, ws, status)
     import esbr_structs
     ctx.esbr_sbr_process_batch(core, hd, fr, sd, st, pcm, ws, status)   # first frame: reset flag set, limiter tables built
     ctx.sync()
