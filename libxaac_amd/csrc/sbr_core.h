@@ -216,12 +216,15 @@ struct XsCx {
 #if defined(__HIPCC__) && !defined(XS_NO_UNROLL)
 #define XS_UNROLL4 _Pragma("unroll 4")
 #define XS_UNROLL8 _Pragma("unroll 8")
+#define XS_UNROLL _Pragma("unroll")
 #elif defined(__HIPCC__)
 #define XS_UNROLL4 _Pragma("nounroll")
 #define XS_UNROLL8 _Pragma("unroll 8")
+#define XS_UNROLL _Pragma("unroll")
 #else
 #define XS_UNROLL4
 #define XS_UNROLL8
+#define XS_UNROLL
 #endif
 
 /* Lane vector: 64 int32 elements, element k held by lane k (a VGPR) / a plain array in the oracle. */
@@ -243,6 +246,11 @@ struct XsLv {
     r.v = (s >= 0 && s < 64) ? t : 0;
     return r;
   }
+  FX_MEMBER XsLv gather(const XsLv &idx) const { /* element k of the result = element idx[k] (all lanes take part) */
+    XsLv r;
+    r.v = __shfl(v, idx.v & 63);
+    return r;
+  }
 #else
   int32_t a[64];
   int32_t &own(int k) { return a[k & 63]; }
@@ -255,6 +263,11 @@ struct XsLv {
   XsLv shifted(const XsCx &, int d) const {
     XsLv r;
     for (int i = 0; i < 64; i++) r.a[i] = (i + d >= 0 && i + d < 64) ? a[i + d] : 0;
+    return r;
+  }
+  XsLv gather(const XsLv &idx) const {
+    XsLv r;
+    for (int i = 0; i < 64; i++) r.a[i] = a[idx.a[i] & 63];
     return r;
   }
 #endif
@@ -382,16 +395,16 @@ struct XsEnv {
   XsLv est, e_orig, gain, noise, sine, meta, alias_red, sine_mapped, deg, deg1;
 };
 
-/* env_calc.c:1159: headroom of bands [b0,b1) x slots [s0,s1) */
+/* env_calc.c:1159: headroom of bands [b0,b1) x slots [s0,s1).  In a complex matrix the real and the imaginary
+   columns of the range are spread over the lanes side by side (a range of up to 32 bands fills the wave). */
 template <class Q>
 FX_HD int xs_headroom(const XsCx &cx, const Q &x, int b0, int b1, int s0, int s1) {
   int32_t m = 1;
-  XS_PAR(k, b0, b1) {
+  const int nb = b1 > b0 ? b1 - b0 : 0;
+  XS_PAR(c, 0, Q::HQ ? 2 * nb : nb) {
+    const int col = c < nb ? b0 + c : 64 + b0 + (c - nb);
     XS_UNROLL4
-    for (int l = s0; l < s1; l++) {
-      m |= fx_abs_nrm(x(l, k));
-      if (Q::HQ) m |= fx_abs_nrm(x.im(l, k));
-    }
+    for (int l = s0; l < s1; l++) m |= fx_abs_nrm(x(l, col));
   }
   return xs_pnorm32(cx.wave_or(m));
 }
@@ -412,12 +425,11 @@ FX_HD void xs_adjust(const XsCx &cx, const Q &x, int b0, int b1, int s0, int s1,
   if (shift == 0) return;
   if (shift > 31) shift = 31;
   if (shift < -31) shift = -31;
-  XS_PAR(k, b0, b1) {
+  const int nb = b1 > b0 ? b1 - b0 : 0;
+  XS_PAR(c, 0, Q::HQ ? 2 * nb : nb) {
+    const int col = c < nb ? b0 + c : 64 + b0 + (c - nb); /* real and imaginary columns side by side */
     XS_UNROLL4
-    for (int l = s0; l < s1; l++) {
-      x(l, k) = shift > 0 ? fx_shlw(x(l, k), shift) : (x(l, k) >> -shift);
-      if (Q::HQ) x.im(l, k) = shift > 0 ? fx_shlw(x.im(l, k), shift) : (x.im(l, k) >> -shift);
-    }
+    for (int l = s0; l < s1; l++) x(l, col) = shift > 0 ? fx_shlw(x(l, col), shift) : (x(l, col) >> -shift);
   }
 }
 
@@ -1445,6 +1457,51 @@ FX_HD void xs_erg_to_amplitude_hq(const XsCx &cx, int bands, int16_t noise_e, Xs
   }
 }
 
+/* N slots of one band inside a segment of constant scale (xs_adapt_noise_gain_hq, step 2): the per-slot body of
+   ixheaacd_harm_idx_zerotwo / _onethree with the gain, noise level and sine levels of the segment.  ph / harm
+   advance by N slots. */
+struct XsApplyHq {
+  int32_t sl_even, sl_odd;
+  int shift, col, step, kk;
+  int16_t sg, snz;
+  bool tone, noise, fi, live;
+};
+template <int N>
+FX_HD void xs_apply_slots_hq(const XsQmfHq &x, const XsApplyHq &a, int l, int &ph, int &harm) {
+  int32_t rp[N], xr[N], xi[N];
+  XS_UNROLL
+  for (int j = 0; j < N; j++) rp[j] = xaac_sbr_rand_ph[((ph + j * a.step) & 511) + 1 + a.kk];
+  XS_UNROLL
+  for (int j = 0; j < N; j++) {
+    xr[j] = x(l + j, a.col);
+    xi[j] = x.im(l + j, a.col);
+  }
+  XS_UNROLL
+  for (int j = 0; j < N; j++) {
+    int32_t re = fx_mul32x16(xr[j], a.sg), im = fx_mul32x16(xi[j], a.sg);
+    re = a.shift > 0 ? fx_shl(re, a.shift) : fx_shr(re, -a.shift);
+    im = a.shift > 0 ? fx_shl(im, a.shift) : fx_shr(im, -a.shift);
+    const int hi = (harm + j) & 3;
+    const bool odd = (hi & 1) != 0;
+    const bool plus = a.fi != (hi == 1);
+    const int32_t re_t = odd ? re : (hi == 0 ? fx_add_sat(re, a.sl_even) : fx_sub_sat(re, a.sl_even));
+    const int32_t im_t = odd ? (plus ? fx_add_sat(im, a.sl_odd) : fx_sub_sat(im, a.sl_odd)) : im;
+    const int32_t re_n = xs_mac16x16_shl_sat(re, (int16_t)(rp[j] >> 16), a.snz);
+    const int32_t im_n = xs_mac16x16_shl_sat(im, (int16_t)rp[j], a.snz);
+    xr[j] = a.tone ? re_t : (a.noise ? re_n : re);
+    xi[j] = a.tone ? im_t : (a.noise ? im_n : im);
+  }
+  if (a.live) {
+    XS_UNROLL
+    for (int j = 0; j < N; j++) {
+      x(l + j, a.col) = xr[j];
+      x.im(l + j, a.col) = xi[j];
+    }
+  }
+  ph = (ph + N * a.step) & 511;
+  harm = (harm + N) & 3;
+}
+
 /* env_calc.c:479 (HQ branch) with ixheaacd_adj_timeslot (env_dec.c:845) and ixheaacd_harm_idx_zerotwo /
    _onethree (env_calc.c:1759 / :1827): gain smoothing over the first slots of an envelope, then gain,
    noise (complex random phase) or sine (real part for harmonic index 0/2, imaginary for 1/3, sign
@@ -1476,6 +1533,7 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
              sine_i = v.sine.shifted(cx, -skip);
   XsLv noise_out;
   noise_out.fill(0);
+  XS_T(21);
   XS_LANES(i, 0, nsb) {
     const int k = i - skip;
     const int16_t gm = xs_m(gain_i.own(i)), ge = xs_e(gain_i.own(i));
@@ -1483,16 +1541,11 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
     int16_t nl = xs_m(noise_i.own(i));
     int16_t fbm = st->filt_buf_me[2 * i], fbn = st->filt_buf_noise_m[i];
     int ne = noise_e, fbe = fb_noise_e0, ph = ph0, harm = harm0;
-    /* the random-phase table is in global memory: eight slots' entries are fetched together, one memory latency per
-       eight slots instead of one per slot */
-    int32_t rp8[8];
-    for (int l0 = s0; l0 < s1; l0 += 8) {
-    XS_UNROLL8
-    for (int j = 0; j < 8; j++) rp8[j] = xaac_sbr_rand_ph[((ph + j * bands) & 511) + 1 + (k >= 0 ? k : 0)];
-    XS_UNROLL8
-    for (int j = 0; j < 8; j++) {
-      const int l = l0 + j;
-      if (l >= s1) break;
+    const int col = sb_start + (k >= 0 ? k : 0), kk = k >= 0 ? k : 0;
+    /* 1. the envelope's first slots while the gains are smoothed (at most four; the reference's slot body as it is) */
+    int l = s0;
+    int n_smooth = s1 - s0 < smooth_length ? s1 - s0 : smooth_length;
+    for (; n_smooth > 0; n_smooth--, l++) {
       int scale_change;
       if (l < 32) {
         scale_change = adj_e - input_e;
@@ -1506,12 +1559,12 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
       }
       fbn = xs_noise_rescale(fbn, fbe - ne);
       fbe = ne;
-      const int32_t rp = rp8[j];
+      const int32_t rp = xaac_sbr_rand_ph[(ph & 511) + 1 + kk];
       const int hi = harm;
       ph = (ph + bands) & 511;
       harm = (harm + 1) & 3;
       if (k < 0) continue;
-      const int16_t smooth = (l - s0) < smooth_length ? xaac_sbr_smooth_filter[l - s0] : (int16_t)0;
+      const int16_t smooth = xaac_sbr_smooth_filter[l - s0];
       int16_t sg = gm, snz = nl;
       if (smooth) {
         const int16_t direct = fx_sat16(0x7fff - (int32_t)smooth);
@@ -1523,7 +1576,7 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
         snz = fbn;
       }
       const int16_t sc = (int16_t)((int16_t)scale_change - 1);
-      int32_t re = fx_mul32x16(x(l, sb_start + k), sg), im = fx_mul32x16(x.im(l, sb_start + k), sg);
+      int32_t re = fx_mul32x16(x(l, col), sg), im = fx_mul32x16(x.im(l, col), sg);
       const int shift = (int16_t)(ge - sc);
       if (shift > 0) {
         re = fx_shl(re, shift);
@@ -1550,15 +1603,61 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
         re = xs_mac16x16_shl_sat(re, (int16_t)(rp >> 16), snz);
         im = xs_mac16x16_shl_sat(im, (int16_t)rp, snz);
       }
-      x(l, sb_start + k) = re;
-      x.im(l, sb_start + k) = im;
+      x(l, col) = re;
+      x.im(l, col) = im;
     }
+    /* 2. the rest in at most two segments, slots below 32 and from 32 on: inside a segment every per-slot quantity
+       but the random phase and the harmonic index is a constant of the band, so the slots go in bursts of eight
+       (rows and random phases fetched together, no control flow between the slots) */
+    while (l < s1) {
+      const int seg_end = (l < 32 && s1 > 32) ? 32 : s1;
+      int scale_change;
+      if (l < 32) {
+        scale_change = adj_e - input_e;
+      } else {
+        scale_change = final_e - input_e;
+        if (l == 32 && s0 < 32) {
+          const int diff = final_e - ne;
+          ne = final_e;
+          if (k >= 0) nl = xs_noise_rescale(nl, diff);
+        }
+      }
+      fbn = xs_noise_rescale(fbn, fbe - ne); /* a no-op in the segment's later slots */
+      fbe = ne;
+      XsApplyHq a;
+      a.sg = gm;
+      a.snz = nl;
+      a.shift = (int16_t)(ge - (int16_t)((int16_t)scale_change - 1));
+      const int tmp = (int16_t)(se - (int16_t)(ne - 16));
+      a.sl_even = tmp > 0 ? fx_shl(sm, tmp) : fx_shr(sm, tmp); /* (sic), as above */
+      a.sl_odd = tmp > 0 ? fx_shl(sm, tmp) : fx_shr(sm, -tmp);
+      a.tone = k >= 0 && sm != 0;
+      a.noise = k >= 0 && sm == 0 && !noise_absc;
+      a.fi = ((sb_start ^ kk) & 1) != 0;
+      a.live = k >= 0;
+      a.col = col;
+      a.step = bands;
+      a.kk = kk;
+      for (; l + 8 <= seg_end; l += 8) xs_apply_slots_hq<8>(x, a, l, ph, harm);
+      if (l + 4 <= seg_end) {
+        xs_apply_slots_hq<4>(x, a, l, ph, harm);
+        l += 4;
+      }
+      if (l + 2 <= seg_end) {
+        xs_apply_slots_hq<2>(x, a, l, ph, harm);
+        l += 2;
+      }
+      if (l < seg_end) {
+        xs_apply_slots_hq<1>(x, a, l, ph, harm);
+        l += 1;
+      }
     }
     st->filt_buf_me[2 * i] = fbm;
     st->filt_buf_noise_m[i] = fbn;
     noise_out.own(i) = nl;
   }
   cx.sync();
+  XS_T(22);
   {
     const XsLv nb = noise_out.shifted(cx, skip); /* back to band indexing */
     XS_LANES(k, 0, bands) {
@@ -1676,42 +1775,40 @@ FX_HD void xs_lpc_coeffs_hq(const XsCovHq *s, int16_t *a) {
   a[3] = a1i;
 }
 
-/* lpp_tran.c:102 + :1203-1250: copy / inverse-filter low band lb into each patch's high band */
-FX_HD void xs_patch_band_hq(const xaac_sbr_header *h, const XsQmfHq &x, int lb, const int16_t *alpha,
-                            const int32_t *bw_array, int start_idx, int stop_idx, int max_qmf_subband) {
-  for (int patch = 0; patch < h->num_patches; patch++) {
-    const xaac_sbr_patch *pp = &h->patch[patch];
-    const int hb = lb + pp->dst_end_band;
-    if (lb < pp->src_start_band || lb >= pp->src_end_band || hb < max_qmf_subband) continue;
-    int bi = 0; /* the reference's per-patch running index: first border above hb, capped (lpp_tran.c:1218) */
-    while (bi < XAAC_SBR_MAX_PATCHES - 1 && bi < XAAC_SBR_MAX_NOISE_VALUES && hb >= h->bw_borders[bi]) bi++;
-    int16_t bw = (int16_t)(bw_array[bi] >> 16);
-    const int16_t a0r = xs_mult16_shl_sat(bw, alpha[0]), a0i = xs_mult16_shl_sat(bw, alpha[1]);
-    bw = xs_mult16_shl_sat(bw, bw);
-    const int16_t a1r = xs_mult16_shl_sat(bw, alpha[2]), a1i = xs_mult16_shl_sat(bw, alpha[3]);
-    const int n = stop_idx - start_idx;
-    if (bw > 0) {
-      int32_t p2r = x(start_idx - 2, lb), p2i = x.im(start_idx - 2, lb);
-      int32_t p1r = x(start_idx - 1, lb), p1i = x.im(start_idx - 1, lb);
-      XS_UNROLL4
-      for (int i = 0; i < n; i++) {
-        const int32_t cr = x(start_idx + i, lb), ci = x.im(start_idx + i, lb);
-        int32_t acc = fx_sub(fx_add(fx_sub(fx_mul32x16(p1r, a0r), fx_mul32x16(p1i, a0i)), fx_mul32x16(p2r, a1r)),
-                             fx_mul32x16(p2i, a1i));
-        x(start_idx + i, hb) = fx_add(cr >> 2, fx_shlw(acc, 1));
-        acc = fx_add(fx_add_sat(fx_add_sat(fx_mul32x16(p1r, a0i), fx_mul32x16(p1i, a0r)), fx_mul32x16(p2r, a1i)),
-                     fx_mul32x16(p2i, a1r));
-        x.im(start_idx + i, hb) = fx_add(ci >> 2, fx_shlw(acc, 1));
-        p2r = p1r;
-        p2i = p1i;
-        p1r = cr;
-        p1i = ci;
-      }
-    } else {
-      for (int i = 0; i < n; i++) {
-        x(start_idx + i, hb) = x(start_idx + i, lb) >> 2;
-        x.im(start_idx + i, hb) = x.im(start_idx + i, lb) >> 2;
-      }
+/* lpp_tran.c:102 + :1203-1250: copy / inverse-filter low band lb into high band hb of patch `patch`.  The reference
+   walks the low bands and, inside, the patches; every (low band, patch) pair writes its own high band, so here the
+   pairs are spread over the lanes by their high band (xs_hf_generator_hq). */
+FX_HD void xs_patch_band_hq(const xaac_sbr_header *h, const XsQmfHq &x, int lb, int hb, const int16_t *alpha,
+                            const int32_t *bw_array, int start_idx, int stop_idx) {
+  int bi = 0; /* the reference's per-patch running index: first border above hb, capped (lpp_tran.c:1218) */
+  while (bi < XAAC_SBR_MAX_PATCHES - 1 && bi < XAAC_SBR_MAX_NOISE_VALUES && hb >= h->bw_borders[bi]) bi++;
+  int16_t bw = (int16_t)(bw_array[bi] >> 16);
+  const int16_t a0r = xs_mult16_shl_sat(bw, alpha[0]), a0i = xs_mult16_shl_sat(bw, alpha[1]);
+  bw = xs_mult16_shl_sat(bw, bw);
+  const int16_t a1r = xs_mult16_shl_sat(bw, alpha[2]), a1i = xs_mult16_shl_sat(bw, alpha[3]);
+  const int n = stop_idx - start_idx;
+  if (bw > 0) {
+    int32_t p2r = x(start_idx - 2, lb), p2i = x.im(start_idx - 2, lb);
+    int32_t p1r = x(start_idx - 1, lb), p1i = x.im(start_idx - 1, lb);
+    XS_UNROLL4
+    for (int i = 0; i < n; i++) {
+      const int32_t cr = x(start_idx + i, lb), ci = x.im(start_idx + i, lb);
+      int32_t acc = fx_sub(fx_add(fx_sub(fx_mul32x16(p1r, a0r), fx_mul32x16(p1i, a0i)), fx_mul32x16(p2r, a1r)),
+                           fx_mul32x16(p2i, a1i));
+      x(start_idx + i, hb) = fx_add(cr >> 2, fx_shlw(acc, 1));
+      acc = fx_add(fx_add_sat(fx_add_sat(fx_mul32x16(p1r, a0i), fx_mul32x16(p1i, a0r)), fx_mul32x16(p2r, a1i)),
+                   fx_mul32x16(p2i, a1r));
+      x.im(start_idx + i, hb) = fx_add(ci >> 2, fx_shlw(acc, 1));
+      p2r = p1r;
+      p2i = p1i;
+      p1r = cr;
+      p1i = ci;
+    }
+  } else {
+    XS_UNROLL4
+    for (int i = 0; i < n; i++) {
+      x(start_idx + i, hb) = x(start_idx + i, lb) >> 2;
+      x.im(start_idx + i, hb) = x.im(start_idx + i, lb) >> 2;
     }
   }
 }
@@ -1741,12 +1838,37 @@ FX_HD void xs_hf_generator_hq(const XsCx &cx, const xaac_sbr_header *h, ST *st, 
     x.im(-1, k) = st->lpc_imag[1][k];
   }
   cx.sync();
+  XsLv al01, al23, src;
+  al01.fill(0);
+  al23.fill(0);
   XS_LANES(lb, start_patch, stop_patch) {
     XsCovHq c;
     xs_covariance_hq(x, lb, 38, &c); /* num_columns + 6 = 38 for 1024-sample frames (lpp_tran.c:1034) */
     int16_t alpha[4];
     xs_lpc_coeffs_hq(&c, alpha);
-    xs_patch_band_hq(h, x, lb, alpha, w->bw_array, start_idx, stop_idx, max_qmf_subband);
+    al01.own(lb) = xs_me(alpha[0], alpha[1]);
+    al23.own(lb) = xs_me(alpha[2], alpha[3]);
+  }
+  /* the low band behind each high band: the reference's loops (low bands outside, patches inside) leave the pair with
+     the largest low band, the later patch among equals; target bands past 63 are refused by xs_side_info_bad */
+  XS_LANES(hb, 0, 64) {
+    int best = -1;
+    for (int patch = 0; patch < num_patches; patch++) {
+      const xaac_sbr_patch *pp = &h->patch[patch];
+      const int lb = hb - pp->dst_end_band;
+      if (lb < pp->src_start_band || lb >= pp->src_end_band || lb < start_patch || lb >= stop_patch) continue;
+      if (hb < max_qmf_subband) continue;
+      if (lb >= best) best = lb;
+    }
+    src.own(hb) = best;
+  }
+  const XsLv a01 = al01.gather(src), a23 = al23.gather(src);
+  XS_LANES(hb, 0, 64) {
+    const int lb = src.own(hb);
+    if (lb >= 0) {
+      const int16_t alpha[4] = {xs_m(a01.own(hb)), xs_e(a01.own(hb)), xs_m(a23.own(hb)), xs_e(a23.own(hb))};
+      xs_patch_band_hq(h, x, lb, hb, alpha, w->bw_array, start_idx, stop_idx);
+    }
   }
   cx.sync();
   XS_PAR(i, 0, h->num_if_bands) st->bw_array_prev[i] = w->bw_array[i];
@@ -1979,6 +2101,8 @@ FX_HD int xs_side_info_bad(const XsCx &cx, const xaac_sbr_header *h, const xaac_
       const xaac_sbr_patch *pp = &h->patch[i];
       bad |= ((unsigned)pp->src_start_band > 64u) | ((unsigned)pp->src_end_band > 64u) | ((unsigned)pp->guard_start_band > 64u) |
              ((unsigned)pp->dst_start_band > 64u) | ((unsigned)pp->dst_end_band > 64u) | ((unsigned)pp->num_bands_in_patch > 64u);
+      /* a patch's high bands (low band + dst_end_band, the reference's name for the offset) stay inside the row */
+      bad |= pp->src_end_band > pp->src_start_band && pp->src_end_band + pp->dst_end_band > 64;
     }
     if (i <= n_env && i <= XAAC_SBR_MAX_ENVELOPES) bad |= (unsigned)f->border_vec[i] > 19u;
     if (i < n_env && i < XAAC_SBR_MAX_ENVELOPES) bad |= (unsigned)f->freq_res[i] > 1u;
@@ -2039,11 +2163,10 @@ FX_HD int xs_sbr_core(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
     st->lb_scale = (int16_t)save_lb_scale;
   }
   *save_lb_scale_out = save_lb_scale;
-  XS_PAR(k, 32, 64)
-    for (int l = 6; l < 38; l++) {
-      x(l, k) = 0;
-      if (Q::HQ) x.im(l, k) = 0;
-    }
+  XS_PAR(c, 0, Q::HQ ? 64 : 32) {
+    const int col = c < 32 ? 32 + c : 64 + c; /* bands 32..63, real | imaginary */
+    for (int l = 6; l < 38; l++) x(l, col) = 0;
+  }
   cx.sync();
   XS_T(1);
   if (cx.uni(f->apply_processing)) {
