@@ -246,6 +246,16 @@ struct XsLv {
     r.v = (s >= 0 && s < 64) ? t : 0;
     return r;
   }
+  /* element k of the result = wrapping sum of the elements congruent to k mod w (w = 16, 32 or 64) */
+  FX_MEMBER XsLv fold(int w) const {
+    XsLv r;
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    int32_t t = v;
+    if (w <= 32) t = (int32_t)((uint32_t)t + (uint32_t)__shfl(t, (lane + 32) & 63));
+    if (w <= 16) t = (int32_t)((uint32_t)t + (uint32_t)__shfl(t, (lane + 16) & 63));
+    r.v = t;
+    return r;
+  }
   FX_MEMBER XsLv gather(const XsLv &idx) const { /* element k of the result = element idx[k] (all lanes take part) */
     XsLv r;
     r.v = __shfl(v, idx.v & 63);
@@ -268,6 +278,15 @@ struct XsLv {
   XsLv gather(const XsLv &idx) const {
     XsLv r;
     for (int i = 0; i < 64; i++) r.a[i] = a[idx.a[i] & 63];
+    return r;
+  }
+  XsLv fold(int w) const {
+    XsLv r;
+    for (int i = 0; i < 64; i++) {
+      uint32_t t = 0;
+      for (int j = i % w; j < 64; j += w) t += (uint32_t)a[j];
+      r.a[i] = (int32_t)t;
+    }
     return r;
   }
 #endif
@@ -1462,12 +1481,12 @@ FX_HD void xs_erg_to_amplitude_hq(const XsCx &cx, int bands, int16_t noise_e, Xs
    advance by N slots. */
 struct XsApplyHq {
   int32_t sl_even, sl_odd;
-  int shift, col, step, kk;
+  int ls, rs, keep, col, step, kk, harm_lane; /* ls / rs / keep: the segment's shift, see xs_adapt_noise_gain_hq */
   int16_t sg, snz;
   bool tone, noise, fi, live;
 };
 template <int N>
-FX_HD void xs_apply_slots_hq(const XsQmfHq &x, const XsApplyHq &a, int l, int &ph, int &harm) {
+FX_HD void xs_apply_slots_hq(const XsQmfHq &x, XsApplyHq &a, int l, int &ph, int &harm) {
   int32_t rp[N], xr[N], xi[N];
   XS_UNROLL
   for (int j = 0; j < N; j++) rp[j] = xaac_sbr_rand_ph[((ph + j * a.step) & 511) + 1 + a.kk];
@@ -1479,13 +1498,16 @@ FX_HD void xs_apply_slots_hq(const XsQmfHq &x, const XsApplyHq &a, int l, int &p
   XS_UNROLL
   for (int j = 0; j < N; j++) {
     int32_t re = fx_mul32x16(xr[j], a.sg), im = fx_mul32x16(xi[j], a.sg);
-    re = a.shift > 0 ? fx_shl(re, a.shift) : fx_shr(re, -a.shift);
-    im = a.shift > 0 ? fx_shl(im, a.shift) : fx_shr(im, -a.shift);
-    const int hi = (harm + j) & 3;
-    const bool odd = (hi & 1) != 0;
+    re = (fx_shlw(re, a.ls) >> a.rs) & a.keep; /* = shift > 0 ? fx_shl(re, shift) : fx_shr(re, -shift) */
+    im = (fx_shlw(im, a.ls) >> a.rs) & a.keep;
+    /* a.harm_lane is the harmonic index as a per-lane value (the same in every lane): the four cases become lane
+       selects instead of scalar branches between the slots */
+    const int hi = (a.harm_lane + j) & 3;
     const bool plus = a.fi != (hi == 1);
-    const int32_t re_t = odd ? re : (hi == 0 ? fx_add_sat(re, a.sl_even) : fx_sub_sat(re, a.sl_even));
-    const int32_t im_t = odd ? (plus ? fx_add_sat(im, a.sl_odd) : fx_sub_sat(im, a.sl_odd)) : im;
+    const int32_t re_a = fx_add_sat(re, a.sl_even), re_s = fx_sub_sat(re, a.sl_even);
+    const int32_t im_a = fx_add_sat(im, a.sl_odd), im_s = fx_sub_sat(im, a.sl_odd);
+    const int32_t re_t = hi == 0 ? re_a : (hi == 2 ? re_s : re);
+    const int32_t im_t = (hi & 1) ? (plus ? im_a : im_s) : im;
     const int32_t re_n = xs_mac16x16_shl_sat(re, (int16_t)(rp[j] >> 16), a.snz);
     const int32_t im_n = xs_mac16x16_shl_sat(im, (int16_t)rp[j], a.snz);
     xr[j] = a.tone ? re_t : (a.noise ? re_n : re);
@@ -1500,6 +1522,7 @@ FX_HD void xs_apply_slots_hq(const XsQmfHq &x, const XsApplyHq &a, int l, int &p
   }
   ph = (ph + N * a.step) & 511;
   harm = (harm + N) & 3;
+  a.harm_lane = (a.harm_lane + N) & 3;
 }
 
 /* env_calc.c:479 (HQ branch) with ixheaacd_adj_timeslot (env_dec.c:845) and ixheaacd_harm_idx_zerotwo /
@@ -1541,6 +1564,7 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
     int16_t nl = xs_m(noise_i.own(i));
     int16_t fbm = st->filt_buf_me[2 * i], fbn = st->filt_buf_noise_m[i];
     int ne = noise_e, fbe = fb_noise_e0, ph = ph0, harm = harm0;
+    const int harm_lane0 = st->harm_index; /* = harm0, but a per-lane value on the GPU (see xs_apply_slots_hq) */
     const int col = sb_start + (k >= 0 ? k : 0), kk = k >= 0 ? k : 0;
     /* 1. the envelope's first slots while the gains are smoothed (at most four; the reference's slot body as it is) */
     int l = s0;
@@ -1627,7 +1651,14 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
       XsApplyHq a;
       a.sg = gm;
       a.snz = nl;
-      a.shift = (int16_t)(ge - (int16_t)((int16_t)scale_change - 1));
+      {
+        /* fx_shl / fx_shr take their count mod 256; a left shift by more than 31 leaves 0, a right one the sign */
+        const int shift = (int16_t)(ge - (int16_t)((int16_t)scale_change - 1));
+        const int b = (shift > 0 ? shift : -shift) & 0xff;
+        a.ls = shift > 0 && b <= 31 ? b : 0;
+        a.rs = shift > 0 ? 0 : (b < 31 ? b : 31);
+        a.keep = shift > 0 && b > 31 ? 0 : -1;
+      }
       const int tmp = (int16_t)(se - (int16_t)(ne - 16));
       a.sl_even = tmp > 0 ? fx_shl(sm, tmp) : fx_shr(sm, tmp); /* (sic), as above */
       a.sl_odd = tmp > 0 ? fx_shl(sm, tmp) : fx_shr(sm, -tmp);
@@ -1638,6 +1669,7 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
       a.col = col;
       a.step = bands;
       a.kk = kk;
+      a.harm_lane = (harm_lane0 + (l - s0)) & 3;
       for (; l + 8 <= seg_end; l += 8) xs_apply_slots_hq<8>(x, a, l, ph, harm);
       if (l + 4 <= seg_end) {
         xs_apply_slots_hq<4>(x, a, l, ph, harm);
@@ -1685,15 +1717,18 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
 struct XsCovHq {
   int32_t phi_11, phi_22, phi_01, phi_02, phi_12, phi_01_im, phi_02_im, phi_12_im;
 };
-FX_HD void xs_covariance_hq(const XsQmfHq &x, int k, int slots, XsCovHq *c) {
+/* the terms of slots [n0, n1) only; `first` adds the terms that precede slot 0 (the caller sums the parts) */
+FX_HD void xs_covariance_hq(const XsQmfHq &x, int k, int n0, int n1, int slots, bool first, XsCovHq *c) {
   int32_t p01 = 0, p01i = 0, p02 = 0, p02i = 0, p11 = 0, p12 = 0, p12i = 0, p22 = 0;
-  int32_t r2 = fx_shr(x(-2, k), 3), i2 = fx_shr(x.im(-2, k), 3); /* x[n-2] */
-  int32_t r1 = fx_shr(x(-1, k), 3), i1 = fx_shr(x.im(-1, k), 3); /* x[n-1] */
-  p22 = fx_add(xs_mul_hi16(r2, r2), xs_mul_hi16(i2, i2));
-  p12 = fx_add(xs_mul_hi16(r1, r2), xs_mul_hi16(i1, i2));
-  p12i = fx_sub(xs_mul_hi16(i1, r2), xs_mul_hi16(r1, i2));
+  int32_t r2 = fx_shr(x(n0 - 2, k), 3), i2 = fx_shr(x.im(n0 - 2, k), 3); /* x[n-2] */
+  int32_t r1 = fx_shr(x(n0 - 1, k), 3), i1 = fx_shr(x.im(n0 - 1, k), 3); /* x[n-1] */
+  if (first) {
+    p22 = fx_add(xs_mul_hi16(r2, r2), xs_mul_hi16(i2, i2));
+    p12 = fx_add(xs_mul_hi16(r1, r2), xs_mul_hi16(i1, i2));
+    p12i = fx_sub(xs_mul_hi16(i1, r2), xs_mul_hi16(r1, i2));
+  }
   XS_UNROLL4
-  for (int n = 0; n < slots; n++) {
+  for (int n = n0; n < n1; n++) {
     const int32_t r0 = fx_shr(x(n, k), 3), i0 = fx_shr(x.im(n, k), 3);
     const int32_t t01 = fx_add(xs_mul_hi16(r0, r1), xs_mul_hi16(i0, i1));
     const int32_t t01i = fx_sub(xs_mul_hi16(i0, r1), xs_mul_hi16(r0, i1));
@@ -1825,11 +1860,14 @@ FX_HD void xs_hf_generator_hq(const XsCx &cx, const xaac_sbr_header *h, ST *st, 
   xs_invfilt_level_emphasis(cx, st->bw_array_prev, h->num_if_bands, invf_mode, invf_mode_prev, w->bw_array);
   const int actual_stop = cx.uni(
       (int16_t)(h->patch[num_patches - 1].dst_start_band + h->patch[num_patches - 1].num_bands_in_patch));
-  XS_PAR(k, actual_stop, 64)
-    for (int l = start_idx; l < stop_idx; l++) {
-      x(l, k) = 0;
-      x.im(l, k) = 0;
+  {
+    const int nz = actual_stop < 64 ? 64 - actual_stop : 0; /* real and imaginary columns side by side */
+    XS_PAR(c, 0, 2 * nz) {
+      const int col = c < nz ? actual_stop + c : 64 + actual_stop + (c - nz);
+      XS_UNROLL4
+      for (int l = start_idx; l < stop_idx; l++) x(l, col) = 0;
     }
+  }
   const int start_patch = cx.uni(h->start_patch), stop_patch = cx.uni(h->stop_patch);
   XS_PAR(k, start_patch, stop_patch) {
     x(-2, k) = st->lpc_real[0][k];
@@ -1838,17 +1876,49 @@ FX_HD void xs_hf_generator_hq(const XsCx &cx, const xaac_sbr_header *h, ST *st, 
     x.im(-1, k) = st->lpc_imag[1][k];
   }
   cx.sync();
+  XS_T(12);
   XsLv al01, al23, src;
   al01.fill(0);
   al23.fill(0);
+  /* covariances over num_columns + 6 = 38 slots (lpp_tran.c:1034).  All eight sums wrap, so the slots are dealt out
+     to the 64 / w lane groups of w lanes (lane = group * w + low band) and the groups' parts added up. */
+  const int cw = stop_patch <= 16 ? 16 : (stop_patch <= 32 ? 32 : 64), cper = (38 * cw + 63) / 64;
+  XsLv cv[8];
+  for (int i = 0; i < 8; i++) cv[i].fill(0);
+  XS_LANES(c, 0, 64) {
+    const int lb = c & (cw - 1), g = c / cw;
+    const int n0 = g * cper, n1 = n0 + cper < 38 ? n0 + cper : 38;
+    if (lb >= start_patch && lb < stop_patch && n0 < n1) {
+      XsCovHq part;
+      xs_covariance_hq(x, lb, n0, n1, 38, g == 0, &part);
+      cv[0].own(c) = part.phi_11;
+      cv[1].own(c) = part.phi_22;
+      cv[2].own(c) = part.phi_01;
+      cv[3].own(c) = part.phi_02;
+      cv[4].own(c) = part.phi_12;
+      cv[5].own(c) = part.phi_01_im;
+      cv[6].own(c) = part.phi_02_im;
+      cv[7].own(c) = part.phi_12_im;
+    }
+  }
+  if (cw < 64)
+    for (int i = 0; i < 8; i++) cv[i] = cv[i].fold(cw);
   XS_LANES(lb, start_patch, stop_patch) {
     XsCovHq c;
-    xs_covariance_hq(x, lb, 38, &c); /* num_columns + 6 = 38 for 1024-sample frames (lpp_tran.c:1034) */
+    c.phi_11 = cv[0].own(lb);
+    c.phi_22 = cv[1].own(lb);
+    c.phi_01 = cv[2].own(lb);
+    c.phi_02 = cv[3].own(lb);
+    c.phi_12 = cv[4].own(lb);
+    c.phi_01_im = cv[5].own(lb);
+    c.phi_02_im = cv[6].own(lb);
+    c.phi_12_im = cv[7].own(lb);
     int16_t alpha[4];
     xs_lpc_coeffs_hq(&c, alpha);
     al01.own(lb) = xs_me(alpha[0], alpha[1]);
     al23.own(lb) = xs_me(alpha[2], alpha[3]);
   }
+  XS_T(13);
   /* the low band behind each high band: the reference's loops (low bands outside, patches inside) leave the pair with
      the largest low band, the later patch among equals; target bands past 63 are refused by xs_side_info_bad */
   XS_LANES(hb, 0, 64) {
@@ -1871,6 +1941,7 @@ FX_HD void xs_hf_generator_hq(const XsCx &cx, const xaac_sbr_header *h, ST *st, 
     }
   }
   cx.sync();
+  XS_T(14);
   XS_PAR(i, 0, h->num_if_bands) st->bw_array_prev[i] = w->bw_array[i];
   cx.sync();
 }

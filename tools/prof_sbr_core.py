@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 NAMES = {1: "block floating point", 2: "hf generator (total)", 3: "env: init/sineflags/adj_e", 4: "env: energies",
          5: "env: gain meta (lane 0)", 6: "env: subband gains", 7: "env: noise limiting", 8: "env: alias groups+reduction",
          9: "env: erg->amplitude", 10: "env: apply (adapt_noise_gain)", 11: "env: final adjust", 12: "hf: setup/clears",
-         13: "hf: covariance+lpc", 14: "hf: degree alias (lane 0)", 15: "tail (state, lpc save)", 16: "lim: avggain", 17: "lim: limit loop", 18: "lim: accumulate",
+         13: "hf: covariance+lpc", 14: "hf: degree alias (LP) / patches (HQ)", 15: "tail (state, lpc save)", 16: "lim: avggain", 17: "lim: limit loop", 18: "lim: accumulate",
          19: "lim: boost div", 20: "lim: scale loop", 21: "apply: startup/equalize/tones", 22: "apply: slot loop",
          23: "alias: groups (lane 0)"}
 
