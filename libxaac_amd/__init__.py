@@ -96,6 +96,20 @@ class _EsbrAnaBatch(ctypes.Structure):
                 ("qmf_re", ctypes.c_void_p), ("qmf_im", ctypes.c_void_p)]
 
 
+class _HbeSynthBatch(ctypes.Structure):
+    # struct xaac_hbe_synth_batch
+    _fields_ = [("n_ch", ctypes.c_int32), ("num_columns", ctypes.c_int32), ("qmf_re", ctypes.c_void_p),
+                ("qmf_im", ctypes.c_void_p), ("state", ctypes.c_void_p), ("status", ctypes.c_void_p)]
+
+
+class _HbeAnalBatch(ctypes.Structure):
+    # struct xaac_hbe_anal_batch
+    _fields_ = [("n_ch", ctypes.c_int32), ("state", ctypes.c_void_p), ("status", ctypes.c_void_p)]
+
+
+HBE_STATE_BYTES = 4 * (1088 + 1280 + 640 + 32 * 128 + 64 * 128 + 12)   # struct xaac_hbe_state
+
+
 class _EsbrSynBatch(ctypes.Structure):
     # struct xaac_esbr_syn_batch
     _fields_ = [("n_ch", ctypes.c_int32), ("qmf_re", ctypes.c_void_p), ("qmf_im", ctypes.c_void_p),
@@ -190,6 +204,10 @@ def load_library():
     lib.xaac_sbr_state_handover.restype = ctypes.c_int32
     lib.xaac_usac_imdct_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_UsacImdctBatch)]
     lib.xaac_usac_imdct_process_batch.restype = ctypes.c_int32
+    lib.xaac_hbe_real_synth_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_HbeSynthBatch)]
+    lib.xaac_hbe_real_synth_batch.restype = ctypes.c_int32
+    lib.xaac_hbe_cplx_anal_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_HbeAnalBatch)]
+    lib.xaac_hbe_cplx_anal_batch.restype = ctypes.c_int32
     lib.xaac_esbr_qmf_analysis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_EsbrAnaBatch)]
     lib.xaac_esbr_qmf_analysis_batch.restype = ctypes.c_int32
     lib.xaac_esbr_qmf_synthesis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_EsbrSynBatch)]
@@ -427,6 +445,33 @@ class XaacContext:
         rc = self._lib.xaac_usac_imdct_process_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_usac_imdct_process_batch")
+
+    def hbe_real_synth_batch(self, qmf_re, qmf_im, state, status=None, num_columns=32):
+        """Batched ixheaacd_real_synth_filt (the harmonic transposer's real synthesis bank): qmf_re / qmf_im
+        float32[n_ch, num_columns, 64]; state uint8[n_ch, HBE_STATE_BYTES] in/out (struct xaac_hbe_state);
+        status int32[n_ch] or None."""
+        n_ch = state.shape[0]
+        b = _HbeSynthBatch()
+        b.n_ch, b.num_columns = n_ch, num_columns
+        b.qmf_re = _ptr(qmf_re, "float32", n_ch * num_columns * 64, device_ok=True)
+        b.qmf_im = _ptr(qmf_im, "float32", n_ch * num_columns * 64, device_ok=True)
+        b.state = _ptr(state, "uint8", n_ch * HBE_STATE_BYTES, device_ok=True)
+        b.status = _ptr(status, "int32", n_ch, device_ok=True) if status is not None else None
+        rc = self._lib.xaac_hbe_real_synth_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_hbe_real_synth_batch")
+
+    def hbe_cplx_anal_batch(self, state, status=None):
+        """Batched ixheaacd_complex_anal_filt (the harmonic transposer's complex analysis bank): state
+        uint8[n_ch, HBE_STATE_BYTES] in/out; status int32[n_ch] or None."""
+        n_ch = state.shape[0]
+        b = _HbeAnalBatch()
+        b.n_ch = n_ch
+        b.state = _ptr(state, "uint8", n_ch * HBE_STATE_BYTES, device_ok=True)
+        b.status = _ptr(status, "int32", n_ch, device_ok=True) if status is not None else None
+        rc = self._lib.xaac_hbe_cplx_anal_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_hbe_cplx_anal_batch")
 
     def esbr_qmf_analysis_batch(self, core, state, qmf_re, qmf_im):
         """Batched ixheaacd_esbr_analysis_filt_block (eSBR / Path A, 32 channels): core float32[n_ch, 1024];

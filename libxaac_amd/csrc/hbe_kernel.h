@@ -1,0 +1,34 @@
+/* hbe_kernel.h -- launch interface of the harmonic transposer's polyphase bank kernels (internal). */
+#ifndef XAAC_HBE_KERNEL_H
+#define XAAC_HBE_KERNEL_H
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "../../include/xaac_hbe.h"
+
+#define XAAC_HBE_SYN_LDS ((41 * 40 + 32 * 265) * 4) /* v of 9 + 32 columns; 32 lanes' transform scratch (odd stride) */
+#define XAAC_HBE_ANA_LDS ((16 * 80 + 16 * 80 + 16 * 513) * 4) /* u and results of 16 columns; 16 lanes' scratch */
+
+typedef struct XaacHbeSynParams {
+  int32_t n_ch, num_columns;
+  const float *qmf_re, *qmf_im; /* [n_ch][num_columns][64] */
+  xaac_hbe_state *state;        /* [n_ch] */
+  int32_t *status;              /* [n_ch] or NULL */
+} XaacHbeSynParams;
+
+typedef struct XaacHbeAnaParams {
+  int32_t n_ch;
+  xaac_hbe_state *state;
+  int32_t *status;
+} XaacHbeAnaParams;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+hipError_t xaac_launch_hbe_synth(const XaacHbeSynParams *p, hipStream_t stream);
+hipError_t xaac_launch_hbe_anal(const XaacHbeAnaParams *p, hipStream_t stream);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,368 @@
+/*
+ * hbe_poly.h -- the two polyphase banks of the QMF-domain harmonic transposer as host/device code: the real-valued
+ * synthesis bank that turns the core band's QMF columns back into a sub-sampled time signal
+ * (ixheaacd_real_synth_filt, decoder/ixheaacd_esbr_polyphase.c:157-274) and the complex analysis bank of twice the
+ * size that follows it (ixheaacd_complex_anal_filt, :48-155), with the float FFTs they call
+ * (common/ixheaac_esbr_fft.c).  Included by the oracle (oracle/oracle_hbe.cpp, sequential) and by the kernels
+ * (hbe_kernel.hip); both are compiled without floating-point contraction, every expression keeps the reference's
+ * operand order and width (FLOAT32 throughout).
+ *
+ * Both banks are written column by column in the reference (a delay line shifted per column).  Here a column's work is
+ * a pure function of the frame's input and of the previous frame's delay line, so the columns of a frame are
+ * independent:
+ *   synthesis  column idx: v[idx][0 .. 2S) = transform of the column's S modulated inputs (xh_synth_column);
+ *              output sample i = sum over the ten window blocks j of v[idx - j][(j odd ? S : 0) + i] * window[S j + i]
+ *              in the order j = 0..9 (xh_synth_out); v of the nine columns before the frame is the delay line.
+ *   analysis   column idx: u[i] = sum over five window blocks of the time signal (xh_anal_u), then the modulation
+ *              transform (xh_anal_column).
+ */
+#ifndef XAAC_HBE_POLY_H
+#define XAAC_HBE_POLY_H
+
+#include <stdint.h>
+
+#include "../../include/xaac_hbe.h"
+#include "fx.h"
+
+#if defined(__HIPCC__)
+#define XAAC_TAB_QUAL static __device__ const
+#include "tables_hbe.inc"
+#undef XAAC_TAB_QUAL
+#else
+#include "tables_hbe.inc"
+#endif
+
+#pragma clang fp contract(off)
+
+/* ---- tables per bank size (hbe_trans.c:71-100, :127-170) -------------------------------------------------------- */
+FX_HD bool xh_size_ok(int s) { return s == 4 || s == 8 || s == 12 || s == 16 || s == 20; }
+FX_HD const float *xh_window(int len) { /* ixheaacd_map_prot_filter */
+  switch (len) {
+    case 8: return xaac_hbe_window + 40;
+    case 12: return xaac_hbe_window + 120;
+    case 16: return xaac_hbe_window + 240;
+    case 20: return xaac_hbe_window + 400;
+    case 24: return xaac_hbe_window + 600;
+    case 32: return xaac_hbe_window + 840;
+    case 40: return xaac_hbe_window + 1160;
+    default: return xaac_hbe_window;
+  }
+}
+FX_HD const float *xh_synth_cos(int s) {
+  switch (s) {
+    case 8: return xaac_hbe_synth_cos_8;
+    case 12: return xaac_hbe_synth_cos_12;
+    case 16: return xaac_hbe_synth_cos_16;
+    case 20: return xaac_hbe_synth_cos_20;
+    default: return xaac_hbe_synth_cos_4;
+  }
+}
+FX_HD const float *xh_analy_cs(int s) { /* the analysis bank has 2 s channels */
+  switch (s) {
+    case 8: return xaac_hbe_analy_cs_16;
+    case 12: return xaac_hbe_analy_cs_24;
+    case 16: return xaac_hbe_analy_cs_32;
+    case 20: return xaac_hbe_analy_cs_40;
+    default: return xaac_hbe_analy_cs_8;
+  }
+}
+
+/* ---- the float FFTs (common/ixheaac_esbr_fft.c) ------------------------------------------------------------------ */
+/* tw[j] = cos, tw[j + 257] = sin of 2 pi j / 1024 (ixheaac_twiddle_table_fft_float) */
+FX_HD void xh_rot_a(float &r, float &i, float c, float s) { /* esbr_fft.c:186-188 */
+  const float t = (r * c) + (i * s);
+  i = -(r * s) + i * c;
+  r = t;
+}
+FX_HD void xh_rot_b(float &r, float &i, float w_lo, float w_hi) { /* :284-286: (w_hi, w_lo) = table entries [.. + 1], [.. - 256] */
+  const float t = (r * w_hi) - (i * w_lo);
+  i = (r * w_lo) + (i * w_hi);
+  r = t;
+}
+FX_HD void xh_rot_c(float &r, float &i, float c, float s) { /* :435-437 */
+  const float t = -(r * c) - (i * s);
+  i = -(r * s) + i * c;
+  r = t;
+}
+/* the radix-4 butterfly of every pass (esbr_fft.c:122-138; alt: the last twiddle quadrant's form, :446-449).  v = x0r,
+   x0i, x1r, x1i, x2r, x2i, x3r, x3i on entry, the reference's store order on return: x0, x2, x1, (x3i, x3r). */
+FX_HD void xh_bfly4(float *v, bool alt) {
+  float x0r = v[0], x0i = v[1], x1r = v[2], x1i = v[3], x2r = v[4], x2i = v[5], x3r = v[6], x3i = v[7];
+  x0r = x0r + x2r;
+  x0i = x0i + x2i;
+  x2r = x0r - (x2r * 2);
+  x2i = x0i - (x2i * 2);
+  x1r = x1r + x3r;
+  if (!alt) {
+    x1i = x1i + x3i;
+    x3r = x1r - (x3r * 2);
+    x3i = x1i - (x3i * 2);
+  } else {
+    x1i = x1i - x3i;
+    x3r = x1r - (x3r * 2);
+    x3i = x1i + (x3i * 2);
+  }
+  x0r = x0r + x1r;
+  x0i = x0i + x1i;
+  x1r = x0r - (x1r * 2);
+  x1i = x0i - (x1i * 2);
+  x2r = x2r - x3i;
+  x2i = x2i + x3r;
+  x3i = x2r + (x3i * 2);
+  x3r = x2i - (x3r * 2);
+  v[0] = x0r; v[1] = x0i;
+  v[2] = x2r; v[3] = x2i;
+  v[4] = x1r; v[5] = x1i;
+  v[6] = x3i; v[7] = x3r;
+}
+FX_HD unsigned xh_dig_rev(unsigned i, int m) { /* DIG_REV, esbr_fft.c:28-35 */
+  unsigned v = i;
+  v = ((v & 0x33333333u) << 2) | ((v & ~0x33333333u) >> 2);
+  v = ((v & 0x0F0F0F0Fu) << 4) | ((v & ~0x0F0F0F0Fu) >> 4);
+  v = ((v & 0x00FF00FFu) << 8) | ((v & ~0x00FF00FFu) >> 8);
+  return v >> m;
+}
+FX_HD int xh_log2(int n) { return n == 8 ? 3 : (n == 16 ? 4 : (n == 32 ? 5 : 6)); } /* n = 8, 16, 32, 64 */
+
+/* ixheaac_real_synth_fft_p2 (:42) / ixheaac_cmplx_anal_fft_p2 (:537) for n = 8, 16, 32 or 64 points: x -> y (2 n
+   floats).  real: x holds n/2 real samples (the upper half of the reference's input is zero and never read). */
+FX_HD void xh_fft_p2(const float *x, float *y, int n, bool real) {
+  const int lg = xh_log2(n), rev_shift = 15 - lg; /* norm32(n) + 1 - 16 */
+  const bool odd = (lg & 1) != 0;                 /* not a power of four: a radix-2 pass at the end */
+  for (int b = 0; b < n / 4; b++) {
+    unsigned h2 = xh_dig_rev((unsigned)(4 * b), rev_shift);
+    if (odd) h2 = (h2 + 1) & ~1u;
+    float *o = y + 8 * b;
+    if (real) {
+      const float *inp = x + (h2 >> 1);
+      float x0r = inp[0], x1r = inp[n >> 2], x2r = inp[2 * (n >> 2)], x3r = inp[3 * (n >> 2)];
+      x0r = x0r + x2r;
+      x2r = x0r - (x2r * 2);
+      x1r = x1r + x3r;
+      x3r = x1r - (x3r * 2);
+      x0r = x0r + x1r;
+      x1r = x0r - (x1r * 2);
+      o[0] = x0r; o[1] = 0;
+      o[2] = x2r; o[3] = x3r;
+      o[4] = x1r; o[5] = 0;
+      o[6] = x2r; o[7] = -x3r;
+    } else {
+      const float *inp = x + h2;
+      float v[8];
+      for (int q = 0; q < 4; q++) {
+        v[2 * q] = inp[q * (n >> 1)];
+        v[2 * q + 1] = inp[q * (n >> 1) + 1];
+      }
+      xh_bfly4(v, false);
+      for (int q = 0; q < 8; q++) o[q] = v[q];
+    }
+  }
+  const float *tw = xaac_hbe_fft_tw;
+  int del = 4;
+  for (int pass = (lg >> 1) - 1; pass > 0; pass--, del <<= 2) {
+    for (int b = 0; b < n / 4; b++) {
+      const int jj = b % del, k = b / del; /* twiddle column, group */
+      const int p0 = 4 * del * k + jj;     /* complex index of the first leg; the others del apart */
+      float v[8];
+      for (int q = 0; q < 4; q++) {
+        v[2 * q] = y[2 * (p0 + q * del)];
+        v[2 * q + 1] = y[2 * (p0 + q * del) + 1];
+      }
+      bool alt = false;
+      if (jj) {
+        const int j = jj * (256 / del); /* nodespacing * jj; nodespacing * del = 256 in every pass */
+        xh_rot_a(v[2], v[3], tw[j], tw[j + 257]);
+        if (j <= 128) xh_rot_a(v[4], v[5], tw[2 * j], tw[2 * j + 257]);
+        else xh_rot_b(v[4], v[5], tw[2 * j - 256], tw[2 * j + 1]);
+        if (j <= 85) xh_rot_a(v[6], v[7], tw[3 * j], tw[3 * j + 257]);
+        else if (j <= 170) xh_rot_b(v[6], v[7], tw[3 * j - 256], tw[3 * j + 1]);
+        else {
+          xh_rot_c(v[6], v[7], tw[3 * j - 512], tw[3 * j - 512 + 257]);
+          alt = true;
+        }
+      }
+      xh_bfly4(v, alt);
+      for (int q = 0; q < 4; q++) {
+        y[2 * (p0 + q * del)] = v[2 * q];
+        y[2 * (p0 + q * del) + 1] = v[2 * q + 1];
+      }
+    }
+  }
+  if (odd) { /* :484-534: del = n / 2 */
+    const int ns = 2 * (256 / del) * 1; /* nodespacing after the passes, doubled */
+    for (int m = 0; m < del; m++) {
+      const int t = (m % (del / 2)) * ns;
+      const float w1 = tw[t], w4 = tw[t + 257];
+      const float x0r = y[2 * m], x0i = y[2 * m + 1];
+      float x1r = y[2 * (m + del)], x1i = y[2 * (m + del) + 1];
+      if (m < del / 2) {
+        xh_rot_a(x1r, x1i, w1, w4);
+      } else {
+        const float tmp = (x1r * w4) - (x1i * w1);
+        x1i = (x1r * w1) + (x1i * w4);
+        x1r = tmp;
+      }
+      y[2 * (m + del)] = x0r - x1r;
+      y[2 * (m + del) + 1] = x0i - x1i;
+      y[2 * m] = x0r + x1r;
+      y[2 * m + 1] = x0i + x1i;
+    }
+  }
+}
+
+FX_HD void xh_fft3(const float *inp, float *op) { /* ixheaac_aac_ld_dec_fft_3_float, esbr_fft.c:1048 */
+  const float sinmu = -0.866025403784439f;
+  const float temp_real = inp[0] + inp[2], temp_imag = inp[1] + inp[3];
+  const float add_r = inp[2] + inp[4], add_i = inp[3] + inp[5];
+  const float sub_r = inp[2] - inp[4], sub_i = inp[3] - inp[5];
+  const float p1 = add_r / 2.0f, p4 = add_i / 2.0f, p2 = sub_i * sinmu, p3 = sub_r * sinmu;
+  const float temp = inp[0] - p1;
+  op[0] = temp_real + inp[4];
+  op[1] = temp_imag + inp[5];
+  op[2] = temp + p2;
+  op[3] = (inp[1] - p3) - p4;
+  op[4] = temp - p2;
+  op[5] = (inp[1] + p3) - p4;
+}
+
+/* ixheaac_real_synth_fft_p3 (:1084, n = 24: x = 12 real samples + 12 zeros) and ixheaac_cmplx_anal_fft_p3 (:1148,
+   n = 48 complex points): three interleaved power-of-two transforms, twiddles, 3-point transforms.  x_out: 2 n floats;
+   w: 4 n floats of scratch. */
+FX_HD void xh_fft_p3(const float *x_in, float *x_out, float *w, int n, bool real) {
+  const int m = n / 3; /* 8 or 16 points per sub-transform */
+  float *xs = w, *ys = w + 2 * m, *x = w + 4 * m, *y = x + 2 * n;
+  for (int i = 0; i < 3; i++) {
+    if (real)
+      for (int j = 0; j < m; j++) xs[j] = x_in[3 * j + i];
+    else
+      for (int j = 0; j < m; j++) {
+        xs[2 * j] = x_in[6 * j + 2 * i];
+        xs[2 * j + 1] = x_in[6 * j + 2 * i + 1];
+      }
+    xh_fft_p2(xs, ys, m, real);
+    for (int j = 0; j < m; j++) {
+      x[6 * j + 2 * i] = ys[2 * j];
+      x[6 * j + 2 * i + 1] = ys[2 * j + 1];
+    }
+  }
+  const float *wr = real ? xaac_hbe_tw24 : xaac_hbe_tw48;
+  for (int g = 0; g < m; g++)
+    for (int q = 1; q < 3; q++) {
+      float *p = x + 6 * g + 2 * q;
+      const float c = wr[4 * g + 2 * (q - 1)], s = wr[4 * g + 2 * (q - 1) + 1];
+      const float tmp = (p[0] * c + p[1] * s);
+      p[1] = (-p[0] * s + p[1] * c);
+      p[0] = tmp;
+    }
+  for (int g = 0; g < m; g++) xh_fft3(x + 6 * g, y + 6 * g);
+  for (int g = 0; g < m; g++)
+    for (int q = 0; q < 3; q++) {
+      x_out[2 * m * q + 2 * g] = y[6 * g + 2 * q];
+      x_out[2 * m * q + 2 * g + 1] = y[6 * g + 2 * q + 1];
+    }
+}
+#define XH_FFT_SCRATCH 512 /* floats: the callers' arrays (<= 256) and xh_fft_p3's w (4 n + 4 m <= 256) */
+#define XH_SYNTH_SCRATCH 264 /* what xh_synth_column uses of it */
+
+/* ---- the real synthesis bank ------------------------------------------------------------------------------------- */
+/* One column: re / im = the column's 64 QMF bands; v[0 .. 2 s) = what the reference writes to the front of its delay
+   line (esbr_polyphase.c:186-247).  w: XH_FFT_SCRATCH floats. */
+FX_HD void xh_synth_column(const float *re, const float *im, int s, int k_start, float *v, float *w) {
+  const float *ct = xaac_hbe_cos_trans_qmf + k_start * 32; /* :166-168 */
+  float *xin = w, *u = w + 40, *fw = w + 40 + 96;
+  for (int k = 0; k < s; k++) {
+    xin[k] = (ct[2 * k] * re[k_start + k] + ct[2 * k + 1] * im[k_start + k]);
+    xin[s + k] = 0; /* :192 */
+  }
+  const float *tab = xh_synth_cos(s);
+  if (s == 20) {
+    /* :199-221: 31 dot products; entries l and s - l (l <= s), l and 3 s - l (negated, l > s) -- written in the
+       reference's order so that the later store wins where they overlap */
+    for (int l = 0; l <= 3 * s / 2; l++) {
+      float accu = 0.0f;
+      for (int k = 0; k < s; k++) accu += xin[k] * tab[l * s + k];
+      if (l <= s) {
+        v[l] = accu;
+        v[s - l] = accu;
+      } else if (l < 3 * s / 2) {
+        v[l] = accu;
+        v[3 * s - l] = -accu;
+      } else {
+        v[3 * s / 2] = accu;
+      }
+    }
+  } else {
+    if (s == 12) xh_fft_p3(xin, u, fw, 2 * s, true);
+    else xh_fft_p2(xin, u, 2 * s, true);
+    const int kmax = s / 2;
+    for (int k = 0; k < 2 * s; k++) { /* :233-246: the first 3 s / 2 results go to v[s / 2 ..], the rest to v[0 ..] */
+      float tmp = (u[2 * k] * tab[2 * k]);
+      tmp -= (u[2 * k + 1] * tab[2 * k + 1]);
+      v[k < kmax + s ? kmax + k : k - (kmax + s)] = tmp;
+    }
+  }
+}
+/* Output sample i of column idx (:249-268).  vv(c, t): element t of column c's v, c = -9 .. num_columns - 1 (the
+   negative ones from the delay line: xh_synth_hist). */
+template <class VV>
+FX_HD float xh_synth_out(const VV &vv, int s, int idx, int i) {
+  const float *win = xh_window(s);
+  float accu = 0.0f;
+  for (int j = 0; j < 10; j++) accu = accu + vv(idx - j, (j & 1) ? s + i : i) * win[s * j + i];
+  return accu;
+}
+/* element t of column c < 0 in the delay line as the previous frame left it: block -1 - c */
+FX_HD float xh_synth_hist(const float *synth_buf, int s, int c, int t) { return synth_buf[2 * s * (-1 - c) + t]; }
+
+/* ---- the complex analysis bank ----------------------------------------------------------------------------------- */
+/* Sample n of the delay line at column idx (esbr_polyphase.c:92-98): block m = n / A holds column idx - m's A new
+   samples, reversed; columns before the frame come from analy_buf (block -1 - c of the previous frame). */
+FX_HD float xh_anal_x(const float *input_buf, const float *analy_buf, int a, int idx, int n) {
+  const int c = idx - n / a, i = n % a;
+  return c >= 0 ? input_buf[(c + 1) * a - i] : analy_buf[(-1 - c) * a + i];
+}
+FX_HD float xh_anal_u(const float *input_buf, const float *analy_buf, int a, int idx, int i) { /* :100-109 */
+  const float *win = xh_window(a);
+  float accu = 0.0f;
+  for (int j = 0; j < 5; j++) {
+    const int n = i + j * 2 * a;
+    accu = accu + xh_anal_x(input_buf, analy_buf, a, idx, n) * win[n];
+  }
+  return accu;
+}
+/* One column: u[0 .. 2 a) -> a complex sub-band samples out[0 .. 2 a) (:110-152).  u is overwritten; w: XH_FFT_SCRATCH. */
+FX_HD void xh_anal_column(float *u, int a, float *out, float *w) {
+  const float *tab = xh_analy_cs(a / 2);
+  if (a == 40) {
+    for (int i = 1; i < a; i++) {
+      const float t1 = u[i] + u[2 * a - i], t2 = u[i] - u[2 * a - i];
+      u[i] = t1;
+      u[2 * a - i] = t2;
+    }
+    for (int k = 0; k < a; k++) {
+      float accu_r = u[a], accu_i = (k & 1) ? u[0] : -u[0];
+      for (int l = 1; l < a; l++) {
+        accu_r = accu_r + u[l] * tab[2 * a * k + 2 * l];
+        accu_i = accu_i + u[2 * a - l] * tab[2 * a * k + 2 * l + 1];
+      }
+      out[2 * k] = accu_r;
+      out[2 * k + 1] = accu_i;
+    }
+  } else {
+    float *u_in = w, *u_out = w + 128, *fw = w + 256;
+    for (int k = 0; k < 2 * a; k++) {
+      u_in[2 * k] = (tab[2 * k] * u[k]);
+      u_in[2 * k + 1] = (tab[2 * k + 1] * u[k]);
+    }
+    if (a == 24) xh_fft_p3(u_in, u_out, fw, 2 * a, false);
+    else xh_fft_p2(u_in, u_out, 2 * a, false);
+    for (int k = 0; k < a / 2; k++) {
+      out[4 * k + 1] = -u_out[4 * k];
+      out[4 * k] = u_out[4 * k + 1];
+      out[4 * k + 3] = u_out[4 * k + 2];
+      out[4 * k + 2] = -u_out[4 * k + 3];
+    }
+  }
+}
+
+#endif /* XAAC_HBE_POLY_H */

@@ -20,6 +20,7 @@
 #include "esbr_qmf_kernel.h"
 #include "usac_imdct_kernel.h"
 #include "esbr_core_kernel.h"
+#include "hbe_kernel.h"
 #include <cmath>
 #include <cstddef>
 #include <cstring>
@@ -333,6 +334,30 @@ int32_t xaac_esbr_qmf_synthesis_batch(xaac_ctx *c, const xaac_esbr_syn_batch *b)
   XaacEsbrSynParams p = {b->n_ch, b->qmf_re, b->qmf_im, b->state, b->out, (int32_t)sizeof(xaac_esbr_syn_state), 2048};
   if (!hip_ok(xaac_launch_esbr_synthesis(&p, c->stream))) return XAAC_FATAL_HIP;
   c->last_grid = (b->n_ch + 1) / 2; c->last_block = 64; c->last_lds = XAAC_ESBR_SYN_LDS;
+  return XAAC_OK;
+}
+
+int32_t xaac_hbe_real_synth_batch(xaac_ctx *c, const xaac_hbe_synth_batch *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n_ch < 0 || b->num_columns < 0 || b->num_columns > XAAC_HBE_NO_BINS) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch == 0 || b->num_columns == 0) return XAAC_OK;
+  if (!b->qmf_re || !b->qmf_im || !b->state) return XAAC_FATAL_NULL_ARG;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  XaacHbeSynParams p = {b->n_ch, b->num_columns, b->qmf_re, b->qmf_im, b->state, b->status};
+  if (!hip_ok(xaac_launch_hbe_synth(&p, c->stream))) return XAAC_FATAL_HIP;
+  c->last_grid = b->n_ch; c->last_block = 64; c->last_lds = XAAC_HBE_SYN_LDS;
+  return XAAC_OK;
+}
+
+int32_t xaac_hbe_cplx_anal_batch(xaac_ctx *c, const xaac_hbe_anal_batch *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n_ch < 0) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch == 0) return XAAC_OK;
+  if (!b->state) return XAAC_FATAL_NULL_ARG;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  XaacHbeAnaParams p = {b->n_ch, b->state, b->status};
+  if (!hip_ok(xaac_launch_hbe_anal(&p, c->stream))) return XAAC_FATAL_HIP;
+  c->last_grid = b->n_ch; c->last_block = 64; c->last_lds = XAAC_HBE_ANA_LDS;
   return XAAC_OK;
 }
 

@@ -1,0 +1,91 @@
+/*
+ * oracle/ref_hbe_adapter.c -- TEST INFRASTRUCTURE ONLY.
+ * Drives the reference's harmonic-transposer banks -- ixheaacd_real_synth_filt / ixheaacd_complex_anal_filt
+ * (decoder/ixheaacd_esbr_polyphase.c:157 / :48) -- on a transposer instance the reference initialises itself
+ * (ixheaacd_esbr_hbe_data_init, sbrdec_initfuncs.c:86; ixheaacd_qmf_hbe_data_reinit, hbe_trans.c:102), loaded from and
+ * stored back to the boundary struct of include/xaac_hbe.h.  Contains no reference code.
+ */
+#include "ref_convert.h"
+#include "ixheaacd_qmf_poly.h"
+#include "xaac_hbe.h"
+
+VOID ixheaacd_esbr_hbe_data_init(ia_esbr_hbe_txposer_struct *pstr_esbr_hbe_txposer, const WORD32 num_aac_samples,
+                                 WORD32 samp_fac_4_flag, const WORD32 num_out_samples, VOID *persistent_hbe_mem,
+                                 WORD32 *total_persistant);
+
+static __thread ia_esbr_hbe_txposer_struct hbe_t;
+static __thread double hbe_mem[(80 * 1024) / 8];
+
+/* a transposer for 1024-sample cores at 2:1, its frequency tables reduced to the two borders reinit reads the bank
+   parameters from; returns 0 when the parameters it derives are the ones in st */
+static int hbe_load(const xaac_hbe_state *st) {
+  WORD32 used = 0;
+  int i;
+  WORD16 lo[2], hi[2], nsf[2] = {1, 1};
+  WORD16 *tab[2];
+  ixheaacd_esbr_hbe_data_init(&hbe_t, 1024, 0, 2048, hbe_mem, &used);
+  if (used > (WORD32)sizeof(hbe_mem)) return -3;
+  lo[0] = hi[0] = (WORD16)st->start_band;
+  lo[1] = hi[1] = (WORD16)st->end_band;
+  tab[0] = lo;
+  tab[1] = hi;
+  if (ixheaacd_qmf_hbe_data_reinit(&hbe_t, tab, nsf, 0)) return -1;
+  if (hbe_t.synth_size != st->synth_size || hbe_t.k_start != st->k_start) return -2;
+  memcpy(hbe_t.ptr_input_buf, st->input_buf, sizeof(st->input_buf));
+  memcpy(hbe_t.synth_buf, st->synth_buf, sizeof(st->synth_buf));
+  memcpy(hbe_t.analy_buf, st->analy_buf, sizeof(st->analy_buf));
+  for (i = 0; i < XAAC_HBE_NO_BINS; i++) memcpy(hbe_t.qmf_in_buf[i], st->qmf_in_buf[i], sizeof(st->qmf_in_buf[i]));
+  for (i = 0; i < 2 * XAAC_HBE_NO_BINS; i++) memcpy(hbe_t.qmf_out_buf[i], st->qmf_out_buf[i], sizeof(st->qmf_out_buf[i]));
+  for (i = 0; i < 6; i++) hbe_t.x_over_qmf[i] = st->x_over_qmf[i];
+  hbe_t.max_stretch = st->max_stretch;
+  return 0;
+}
+
+static void hbe_store(xaac_hbe_state *st) {
+  int i;
+  memcpy(st->input_buf, hbe_t.ptr_input_buf, sizeof(st->input_buf));
+  memcpy(st->synth_buf, hbe_t.synth_buf, sizeof(st->synth_buf));
+  memcpy(st->analy_buf, hbe_t.analy_buf, sizeof(st->analy_buf));
+  for (i = 0; i < XAAC_HBE_NO_BINS; i++) memcpy(st->qmf_in_buf[i], hbe_t.qmf_in_buf[i], sizeof(st->qmf_in_buf[i]));
+  for (i = 0; i < 2 * XAAC_HBE_NO_BINS; i++) memcpy(st->qmf_out_buf[i], hbe_t.qmf_out_buf[i], sizeof(st->qmf_out_buf[i]));
+}
+
+/* what ixheaacd_qmf_hbe_data_reinit derives from an SBR header's frequency tables */
+int ref_hbe_reinit(const int16_t *tbl_lo, int n_lo, const int16_t *tbl_hi, int n_hi, xaac_hbe_state *st) {
+  WORD32 used = 0;
+  int i;
+  WORD16 lo[64], hi[64], nsf[2];
+  WORD16 *tab[2];
+  if (n_lo < 0 || n_lo > 62 || n_hi < 0 || n_hi > 62) return -1;
+  ixheaacd_esbr_hbe_data_init(&hbe_t, 1024, 0, 2048, hbe_mem, &used);
+  for (i = 0; i <= n_lo; i++) lo[i] = tbl_lo[i];
+  for (i = 0; i <= n_hi; i++) hi[i] = tbl_hi[i];
+  nsf[0] = (WORD16)n_lo;
+  nsf[1] = (WORD16)n_hi;
+  tab[0] = lo;
+  tab[1] = hi;
+  if (ixheaacd_qmf_hbe_data_reinit(&hbe_t, tab, nsf, 0)) return -1;
+  st->synth_size = hbe_t.synth_size;
+  st->k_start = hbe_t.k_start;
+  st->start_band = hbe_t.start_band;
+  st->end_band = hbe_t.end_band;
+  for (i = 0; i < 6; i++) st->x_over_qmf[i] = hbe_t.x_over_qmf[i];
+  st->max_stretch = hbe_t.max_stretch;
+  return 0;
+}
+
+int ref_hbe_real_synth(xaac_hbe_state *st, const float *qmf_re, const float *qmf_im, int num_columns) {
+  int rc = hbe_load(st);
+  if (rc) return rc;
+  rc = ixheaacd_real_synth_filt(&hbe_t, num_columns, (FLOAT32(*)[64])qmf_re, (FLOAT32(*)[64])qmf_im);
+  hbe_store(st);
+  return rc;
+}
+
+int ref_hbe_cplx_anal(xaac_hbe_state *st) {
+  int rc = hbe_load(st);
+  if (rc) return rc;
+  rc = ixheaacd_complex_anal_filt(&hbe_t);
+  hbe_store(st);
+  return rc;
+}

@@ -1,0 +1,25 @@
+"""ctypes mirror of include/xaac_hbe.h (checked against the header's layout by tests/test_abi.py)."""
+import ctypes
+
+F, I32 = ctypes.c_float, ctypes.c_int32
+NO_BINS = 32
+
+
+class HbeState(ctypes.Structure):
+    _fields_ = [("input_buf", F * (1024 + 64)), ("synth_buf", F * 1280), ("analy_buf", F * 640),
+                ("qmf_in_buf", (F * 128) * NO_BINS), ("qmf_out_buf", (F * 128) * (2 * NO_BINS)),
+                ("synth_size", I32), ("k_start", I32), ("start_band", I32), ("end_band", I32),
+                ("x_over_qmf", I32 * 6), ("max_stretch", I32), ("pad_", I32)]
+
+
+K_START = [0, 0, 0, 0, 0, 0, 0, 2, 2, 2, 4, 4, 4, 4, 4, 6, 6, 6, 8, 8, 8, 8, 8, 10, 10, 10, 12, 12, 12, 12, 12, 12, 12]
+
+
+def new_state(start_band, end_band=None):
+    """a fresh stream's state with the bank parameters of hbe_trans.c:107-112 for a start band"""
+    st = HbeState()
+    st.start_band = start_band
+    st.end_band = min(64, 2 * start_band + 8) if end_band is None else end_band
+    st.synth_size = 4 * ((start_band + 4) // 8 + 1)
+    st.k_start = K_START[start_band]
+    return st

@@ -14,15 +14,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_functions():
-    txt = open(os.path.join(ROOT, "include", "xaac_amd.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(xaac_[a-z0-9_]+)\s*\(", txt)))
+    names = set()
+    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):  # every header of the boundary
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(xaac_[a-z0-9_]+)\s*\(", txt))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
     lib = libxaac_amd.load_library()
     names = _declared_functions()
-    assert "xaac_imdct_process_batch" in names and "xaac_create" in names
+    assert "xaac_imdct_process_batch" in names and "xaac_create" in names and "xaac_hbe_cplx_anal_batch" in names
     for n in names:
         assert hasattr(lib, n), n
 
@@ -80,6 +83,26 @@ def test_round2_struct_layouts_match_headers(tmp_path):
         want += [ctypes.sizeof(cls), getattr(cls, last).offset]
     assert got == want
     assert ctypes.sizeof(es.EsbrAna) == 4 * libxaac_amd.ESBR_ANA_STATE_WORDS and ctypes.sizeof(es.EsbrSyn) == 4 * libxaac_amd.ESBR_SYN_STATE_WORDS
+
+
+def test_hbe_struct_layouts_match_header(tmp_path):
+    """the harmonic transposer's state and batch descriptors against include/xaac_hbe.h"""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hbe_structs as hs
+    pairs = [("xaac_hbe_state", hs.HbeState, "max_stretch"), ("xaac_hbe_synth_batch", libxaac_amd._HbeSynthBatch, "status"),
+             ("xaac_hbe_anal_batch", libxaac_amd._HbeAnalBatch, "status")]
+    body = "".join('printf("%%zu %%zu\\n", sizeof(%s), offsetof(%s, %s));' % (c, c, last) for c, _, last in pairs)
+    src = tmp_path / "layout3.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "xaac_hbe.h"\nint main(void) { %s return 0; }\n' % body)
+    exe = tmp_path / "layout3"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    want = []
+    for _, cls, last in pairs:
+        want += [ctypes.sizeof(cls), getattr(cls, last).offset]
+    assert got == want
+    assert ctypes.sizeof(hs.HbeState) == libxaac_amd.HBE_STATE_BYTES
 
 
 def test_no_cpu_fallback_without_device():

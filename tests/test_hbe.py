@@ -1,0 +1,105 @@
+"""The harmonic transposer's polyphase banks against reference-made chains (tests/golden/hbe_ref.npz,
+tools/make_golden_hbe.py: the compiled reference's ixheaacd_real_synth_filt / ixheaacd_complex_anal_filt on its own
+transposer instance, delay lines carried, one chain per bank size).  CPU: the oracle (oracle/oracle_hbe.cpp)
+reproduces every state CRC.  GPU: xaac_hbe_real_synth_batch / xaac_hbe_cplx_anal_batch through the C ABI with all
+chains (and a second, shifted copy of each) as one batch: every state bit-identical to the reference's CRCs and to the
+oracle's state on extra random frames."""
+import ctypes
+import os
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from make_golden_hbe import START_BANDS, FRAMES, chain_input, shift_input, run  # noqa: E402
+from hbe_structs import HbeState, new_state  # noqa: E402
+
+GOLD = np.load(os.path.join(ROOT, "tests", "golden", "hbe_ref.npz"))
+PF = ctypes.POINTER(ctypes.c_float)
+
+
+def test_oracle_matches_reference_chains(oracle):
+    crcs, last_time, last_rows = run(oracle.lib, "xo")
+    assert np.array_equal(crcs, GOLD["crc"])
+    assert np.array_equal(last_time.view(np.uint32), GOLD["last_time"].view(np.uint32))
+    assert np.array_equal(last_rows.view(np.uint32), GOLD["last_rows"].view(np.uint32))
+
+
+def test_parameters_outside_the_tables_are_refused(oracle):
+    syn = oracle.lib.xo_hbe_real_synth
+    syn.restype, syn.argtypes = ctypes.c_int, [ctypes.POINTER(HbeState), PF, PF, ctypes.c_int]
+    z = np.zeros((32, 64), np.float32)
+    for size, ks in ((24, 0), (0, 0), (8, -1), (20, 60)):
+        st = new_state(9)
+        st.synth_size, st.k_start = size, ks
+        assert syn(ctypes.byref(st), z.ctypes.data_as(PF), z.ctypes.data_as(PF), 32) == -1
+
+
+def _states_tensor(torch, dev, states):
+    return torch.from_numpy(np.stack([np.frombuffer(bytes(s), np.uint8) for s in states])).to(dev)
+
+
+@pytest.mark.gpu
+def test_gpu_chains_match_reference_and_oracle(oracle):
+    import torch
+    import libxaac_amd
+    dev = torch.device("cuda:0")
+    ctx = libxaac_amd.XaacContext(0, None)
+    nchain = len(START_BANDS)
+    # channels 0..4: the golden chains; 5..9: the same chains one frame late (mixed delay-line contents in one batch);
+    # 10: parameters outside the tables
+    sbs = START_BANDS + START_BANDS + [9]
+    n = len(sbs)
+    host = [new_state(sb) for sb in sbs]
+    host[-1].synth_size = 24
+    state = _states_tensor(torch, dev, host)
+    status = torch.full((n,), 7, dtype=torch.int32, device=dev)
+    off_in = HbeState.input_buf.offset
+    osyn, oana = oracle.lib.xo_hbe_real_synth, oracle.lib.xo_hbe_cplx_anal
+    osyn.restype, osyn.argtypes = ctypes.c_int, [ctypes.POINTER(HbeState), PF, PF, ctypes.c_int]
+    oana.restype, oana.argtypes = ctypes.c_int, [ctypes.POINTER(HbeState)]
+    rng = np.random.default_rng(9)
+    for f in range(FRAMES + 3):
+        re, im = np.zeros((n, 32, 64), np.float32), np.zeros((n, 32, 64), np.float32)
+        for c in range(nchain):
+            if f < FRAMES:
+                re[c], im[c] = chain_input(c, f)
+            else:
+                re[c] = (rng.standard_normal((32, 64)) * 2.0 ** rng.integers(-8, 20)).astype(np.float32)
+                im[c] = (rng.standard_normal((32, 64)) * 100).astype(np.float32)
+            if f >= 1:
+                re[nchain + c], im[nchain + c] = chain_input(c, f - 1) if f - 1 < FRAMES else (re[c] * 0.5, im[c] * 2)
+        # the apply function's shift of the time signal (hbe_trans.c:235-238), as the host of these two calls does it
+        sv = state.view(n, -1)
+        fl = sv[:, off_in:off_in + 4 * 1088].contiguous().view(torch.float32).view(n, 1088)
+        for c, st in enumerate(host):
+            s = st.synth_size
+            if s <= 20:
+                fl[c, :s] = fl[c, 32 * s:33 * s].clone()
+        sv[:, off_in:off_in + 4 * 1088] = fl.view(torch.uint8).view(n, -1)
+        ctx.hbe_real_synth_batch(torch.from_numpy(re).to(dev), torch.from_numpy(im).to(dev), state, status)
+        ctx.sync()
+        got_syn = state.cpu().numpy()
+        ctx.hbe_cplx_anal_batch(state, status)
+        ctx.sync()
+        got_ana = state.cpu().numpy()
+        assert status.cpu().tolist() == [0] * (n - 1) + [-1]
+        for c in range(n - 1):
+            shift_input(host[c])
+            assert osyn(ctypes.byref(host[c]), re[c].ctypes.data_as(PF), im[c].ctypes.data_as(PF), 32) == 0
+            assert np.array_equal(np.frombuffer(bytes(host[c]), np.uint8), got_syn[c]), ("synthesis", f, c)
+            assert oana(ctypes.byref(host[c])) == 0
+            d = np.nonzero(np.frombuffer(bytes(host[c]), np.uint8) != got_ana[c])[0]
+            assert d.size == 0, ("analysis", f, c, d[:4])
+        if f < FRAMES:
+            for c in range(nchain):
+                assert zlib.crc32(got_syn[c].tobytes()) & 0xffffffff == int(GOLD["crc"][c, f, 0]), (f, c)
+                assert zlib.crc32(got_ana[c].tobytes()) & 0xffffffff == int(GOLD["crc"][c, f, 1]), (f, c)
+        if f >= 1 and f - 1 < FRAMES:
+            for c in range(nchain):
+                assert zlib.crc32(got_ana[nchain + c].tobytes()) & 0xffffffff == int(GOLD["crc"][c, f - 1, 1]), (f, c)
+    # the refused channel's state is untouched
+    assert np.array_equal(got_ana[-1], np.frombuffer(bytes(host[-1]), np.uint8))

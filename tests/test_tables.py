@@ -90,6 +90,10 @@ def test_esbr_float_tables_equal_reference_rom(tmp_path):
     _regenerated_equals_committed("gen_tables_esbr", "tables_esbr.inc", tmp_path)
 
 
+def test_hbe_tables_equal_reference_rom(tmp_path):
+    _regenerated_equals_committed("gen_tables_hbe", "tables_hbe.inc", tmp_path)
+
+
 def test_esbr_ps_tables_equal_reference_rom_and_libm(tmp_path):
     """ROM members as exact float literals + the mixing-matrix table re-derived with this machine's C library"""
     _regenerated_equals_committed("gen_tables_esbr_ps", "tables_esbr_ps.inc", tmp_path)
