@@ -102,6 +102,13 @@ class _HbeSynthBatch(ctypes.Structure):
                 ("qmf_im", ctypes.c_void_p), ("state", ctypes.c_void_p), ("status", ctypes.c_void_p)]
 
 
+class _HbeApplyBatch(ctypes.Structure):
+    # struct xaac_hbe_apply_batch_desc
+    _fields_ = [("n_ch", ctypes.c_int32), ("qmf_re", ctypes.c_void_p), ("qmf_im", ctypes.c_void_p),
+                ("pitch_in_bins", ctypes.c_void_p), ("state", ctypes.c_void_p), ("pv_re", ctypes.c_void_p),
+                ("pv_im", ctypes.c_void_p), ("status", ctypes.c_void_p)]
+
+
 class _HbeAnalBatch(ctypes.Structure):
     # struct xaac_hbe_anal_batch
     _fields_ = [("n_ch", ctypes.c_int32), ("state", ctypes.c_void_p), ("status", ctypes.c_void_p)]
@@ -206,6 +213,8 @@ def load_library():
     lib.xaac_usac_imdct_process_batch.restype = ctypes.c_int32
     lib.xaac_hbe_real_synth_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_HbeSynthBatch)]
     lib.xaac_hbe_real_synth_batch.restype = ctypes.c_int32
+    lib.xaac_hbe_apply_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_HbeApplyBatch)]
+    lib.xaac_hbe_apply_batch.restype = ctypes.c_int32
     lib.xaac_hbe_cplx_anal_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_HbeAnalBatch)]
     lib.xaac_hbe_cplx_anal_batch.restype = ctypes.c_int32
     lib.xaac_esbr_qmf_analysis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_EsbrAnaBatch)]
@@ -460,6 +469,24 @@ class XaacContext:
         rc = self._lib.xaac_hbe_real_synth_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_hbe_real_synth_batch")
+
+    def hbe_apply_batch(self, qmf_re, qmf_im, state, pv_re, pv_im, status=None, pitch_in_bins=None):
+        """Batched ixheaacd_qmf_hbe_apply (the QMF-domain harmonic transposer, frames without a pitch): qmf_re / qmf_im
+        float32[n_ch, 32, 64]; state uint8[n_ch, HBE_STATE_BYTES] in/out; pv_re / pv_im float32[n_ch, 32, 64] (bands
+        start_band..end_band-1 written); status int32[n_ch] or None; pitch_in_bins int32[n_ch] or None."""
+        n_ch = state.shape[0]
+        b = _HbeApplyBatch()
+        b.n_ch = n_ch
+        b.qmf_re = _ptr(qmf_re, "float32", n_ch * 2048, device_ok=True)
+        b.qmf_im = _ptr(qmf_im, "float32", n_ch * 2048, device_ok=True)
+        b.pitch_in_bins = _ptr(pitch_in_bins, "int32", n_ch, device_ok=True) if pitch_in_bins is not None else None
+        b.state = _ptr(state, "uint8", n_ch * HBE_STATE_BYTES, device_ok=True)
+        b.pv_re = _ptr(pv_re, "float32", n_ch * 2048, device_ok=True)
+        b.pv_im = _ptr(pv_im, "float32", n_ch * 2048, device_ok=True)
+        b.status = _ptr(status, "int32", n_ch, device_ok=True) if status is not None else None
+        rc = self._lib.xaac_hbe_apply_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_hbe_apply_batch")
 
     def hbe_cplx_anal_batch(self, state, status=None):
         """Batched ixheaacd_complex_anal_filt (the harmonic transposer's complex analysis bank): state

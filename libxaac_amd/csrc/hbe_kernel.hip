@@ -2,7 +2,9 @@
  * hbe_kernel.hip -- the polyphase banks of the QMF-domain harmonic transposer on gfx950:
  *   xaac_hbe_synth_kernel  <-> ixheaacd_real_synth_filt    (decoder/ixheaacd_esbr_polyphase.c:157-274)
  *   xaac_hbe_anal_kernel   <-> ixheaacd_complex_anal_filt  (decoder/ixheaacd_esbr_polyphase.c:48-155)
- * The arithmetic is hbe_poly.h (the oracle runs the same source sequentially).
+ *   xaac_hbe_post_kernel   <-> ixheaacd_hbe_post_anal_process without a pitch + the output stage of
+ *                              ixheaacd_qmf_hbe_apply (decoder/ixheaacd_hbe_trans.c:1549-1571, :262-295)
+ * The arithmetic is hbe_poly.h / hbe_trans.h (the oracle runs the same source sequentially).
  *
  * Mapping: one wave = one channel-frame.  The reference shifts a delay line per QMF column; here a column's transform
  * depends only on the column's input (hbe_poly.h), so the columns' transforms run side by side (lane = column, its
@@ -13,7 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "hbe_poly.h"
+#include "hbe_trans.h"
 #include "hbe_kernel.h"
 
 __global__ __launch_bounds__(64) void xaac_hbe_synth_kernel(XaacHbeSynParams p) {
@@ -23,12 +25,22 @@ __global__ __launch_bounds__(64) void xaac_hbe_synth_kernel(XaacHbeSynParams p) 
   const int ch = blockIdx.x, lane = threadIdx.x;
   xaac_hbe_state *st = p.state + ch;
   const int s = st->synth_size, ks = st->k_start, nc = p.num_columns;
-  const bool bad = !xh_size_ok(s) || ks < 0 || ks + s > 64 || ks * 32 + 2 * s > 7 * 64 || nc < 0 || nc > 32;
+  const bool bad = p.apply ? !xh_apply_params_ok(st, p.pitch ? p.pitch[ch] : 0)
+                           : (!xh_size_ok(s) || ks < 0 || ks + s > 64 || ks * 32 + 2 * s > 7 * 64 || nc < 0 || nc > 32);
   if (lane == 0 && p.status) p.status[ch] = bad ? -1 : 0;
   if (bad) return;
+  /* apply mode, hbe_trans.c:235-248: the last synth_size samples of the previous frame's time signal move to the
+     front; while the reference's FFT pointers are unset it re-initialises, which clears both delay lines */
+  const bool cleared = p.apply && !st->fft_ready;
+  float carry = 0.0f;
+  if (p.apply && lane < s) carry = st->input_buf[nc * s + lane];
+  if (cleared) {
+    for (int e = lane; e < 640; e += 64) st->analy_buf[e] = 0.0f;
+    for (int e = 20 * s + lane; e < 1280; e += 64) st->synth_buf[e] = 0.0f;
+  }
   for (int e = lane; e < 9 * 2 * s; e += 64) {
     const int c = -1 - e / (2 * s), t = e % (2 * s);
-    vv[c + 9][t] = xh_synth_hist(st->synth_buf, s, c, t);
+    vv[c + 9][t] = cleared ? 0.0f : xh_synth_hist(st->synth_buf, s, c, t);
   }
   if (lane < nc)
     xh_synth_column(p.qmf_re + ((size_t)ch * nc + lane) * 64, p.qmf_im + ((size_t)ch * nc + lane) * 64, s, ks, vv[lane + 9],
@@ -36,6 +48,7 @@ __global__ __launch_bounds__(64) void xaac_hbe_synth_kernel(XaacHbeSynParams p) 
   __syncthreads();
   const auto at = [&](int c, int t) { return vv[c + 9][t]; };
   for (int o = lane; o < nc * s; o += 64) st->input_buf[s + o] = xh_synth_out(at, s, o / s, o % s);
+  if (p.apply && lane < s) st->input_buf[lane] = carry;
   for (int e = lane; e < 20 * s; e += 64) {
     const int c = nc - 1 - e / (2 * s);
     st->synth_buf[e] = vv[c + 9][e % (2 * s)]; /* nc >= 1: columns nc - 10 .. nc - 1 >= -9 */
@@ -50,10 +63,12 @@ __global__ __launch_bounds__(64) void xaac_hbe_anal_kernel(XaacHbeAnaParams p) {
   const int ch = blockIdx.x, lane = threadIdx.x;
   xaac_hbe_state *st = p.state + ch;
   const int s = st->synth_size, ks = st->k_start, a = 2 * s;
-  const bool bad = !xh_size_ok(s) || ks < 0 || 4 * ks + 2 * a > 128;
-  if (lane == 0 && p.status) p.status[ch] = bad ? -1 : 0;
+  const bool bad = p.apply ? !xh_apply_params_ok(st, p.pitch ? p.pitch[ch] : 0) : (!xh_size_ok(s) || ks < 0 || 4 * ks + 2 * a > 128);
+  if (lane == 0 && p.status && !p.apply) p.status[ch] = bad ? -1 : 0;
   if (bad) return;
   constexpr int NCOL = XAAC_HBE_NO_BINS / 2;
+  if (p.apply) /* hbe_trans.c:254-258: rows 16..27 become rows 0..11 (rows 12..27 are written below, after the barrier) */
+    for (int e = lane; e < (XAAC_HBE_OPER_WIN_LEN - 1) * 128; e += 64) st->qmf_in_buf[e >> 7][e & 127] = st->qmf_in_buf[(e >> 7) + NCOL][e & 127];
   for (int e = lane; e < NCOL * 2 * a; e += 64) u[e / (2 * a)][e % (2 * a)] = xh_anal_u(st->input_buf, st->analy_buf, a, e / (2 * a), e % (2 * a));
   /* the delay line the last column leaves (read before anything of it is overwritten) */
   float nb[7];
@@ -76,6 +91,58 @@ __global__ __launch_bounds__(64) void xaac_hbe_anal_kernel(XaacHbeAnaParams p) {
   }
 }
 
+/* 256 threads per channel.  Tiles of 16 output bands: thread (band, column) computes the column's block of products into
+   LDS; then thread per complex element (row, band) moves the previous frame's upper rows down (rows 0..31 first, the
+   rows they come from afterwards), adds the blocks that reach it in column order, and rotates rows 0..31 of the SBR
+   range into the output (hbe_trans.c:262-295). */
+__global__ __launch_bounds__(XAAC_HBE_POST_THREADS) void xaac_hbe_post_kernel(XaacHbePostParams p) {
+  extern __shared__ float lds[];
+  float(*blk)[20] = reinterpret_cast<float(*)[20]>(lds); /* [16 bands x 16 columns][<= 10 complex] */
+  const int ch = blockIdx.x, tid = threadIdx.x;
+  xaac_hbe_state *st = p.state + ch;
+  if (!xh_apply_params_ok(st, p.pitch ? p.pitch[ch] : 0)) return;
+  const int ms = st->max_stretch, sb0 = st->start_band, sb1 = st->end_band;
+  int32_t xo[4];
+  for (int q = 0; q < 4; q++) xo[q] = st->x_over_qmf[q];
+  float *pv_re = p.pv_re + (size_t)ch * 2048, *pv_im = p.pv_im + (size_t)ch * 2048;
+  const auto in = [&](int row, int band) {
+    const float2 v = *reinterpret_cast<const float2 *>(&st->qmf_in_buf[row][2 * band]);
+    const XhC c = {v.x, v.y};
+    return c;
+  };
+  for (int tile = 0; tile < 4; tile++) {
+    {
+      const int qb = 16 * tile + (tid >> 4), i = tid & 15;
+      const int f = xh_band_factor(xo, ms, qb);
+      if (f == 2) xh_prod2_block(in, qb, i, blk[tid]);
+      else if (f == 3) xh_prod3_block(in, qb, i, blk[tid]);
+      else if (f == 4) xh_prod4_block(in, qb, i, blk[tid]);
+    }
+    __syncthreads();
+    for (int half = 0; half < 2; half++) {
+      for (int e = tid; e < 32 * 16; e += XAAC_HBE_POST_THREADS) {
+        const int r = 32 * half + (e >> 4), bt = e & 15, qb = 16 * tile + bt;
+        float2 *dst = reinterpret_cast<float2 *>(&st->qmf_out_buf[r][2 * qb]);
+        float2 v = make_float2(0.0f, 0.0f);
+        if (!half) v = *reinterpret_cast<const float2 *>(&st->qmf_out_buf[r + 32][2 * qb]);
+        const int f = xh_band_factor(xo, ms, qb);
+        if (f) {
+          const auto bk = [&](int i) { return (const float *)blk[16 * bt + i]; };
+          v.x = xh_prod_gather(v.x, f, r, 0, bk);
+          v.y = xh_prod_gather(v.y, f, r, 1, bk);
+        }
+        *dst = v;
+        if (!half && qb >= sb0 && qb < sb1) {
+          pv_re[64 * r + qb] = (float)(v.x * xaac_hbe_pv_cos[qb] - v.y * xaac_hbe_pv_sin[qb]);
+          pv_im[64 * r + qb] = (float)(v.x * xaac_hbe_pv_sin[qb] + v.y * xaac_hbe_pv_cos[qb]);
+        }
+      }
+      __syncthreads(); /* rows 32..63 are overwritten only after every row below has taken its start value from them */
+    }
+  }
+  if (tid == 0 && !st->fft_ready && st->synth_size != 20) st->fft_ready = 1;
+}
+
 extern "C" hipError_t xaac_launch_hbe_synth(const XaacHbeSynParams *p, hipStream_t stream) {
   hipLaunchKernelGGL(xaac_hbe_synth_kernel, dim3(p->n_ch), dim3(64), XAAC_HBE_SYN_LDS, stream, *p);
   return hipGetLastError();
@@ -83,5 +150,10 @@ extern "C" hipError_t xaac_launch_hbe_synth(const XaacHbeSynParams *p, hipStream
 
 extern "C" hipError_t xaac_launch_hbe_anal(const XaacHbeAnaParams *p, hipStream_t stream) {
   hipLaunchKernelGGL(xaac_hbe_anal_kernel, dim3(p->n_ch), dim3(64), XAAC_HBE_ANA_LDS, stream, *p);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t xaac_launch_hbe_post(const XaacHbePostParams *p, hipStream_t stream) {
+  hipLaunchKernelGGL(xaac_hbe_post_kernel, dim3(p->n_ch), dim3(XAAC_HBE_POST_THREADS), XAAC_HBE_POST_LDS, stream, *p);
   return hipGetLastError();
 }

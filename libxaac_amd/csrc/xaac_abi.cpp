@@ -343,7 +343,7 @@ int32_t xaac_hbe_real_synth_batch(xaac_ctx *c, const xaac_hbe_synth_batch *b) {
   if (b->n_ch == 0 || b->num_columns == 0) return XAAC_OK;
   if (!b->qmf_re || !b->qmf_im || !b->state) return XAAC_FATAL_NULL_ARG;
   if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
-  XaacHbeSynParams p = {b->n_ch, b->num_columns, b->qmf_re, b->qmf_im, b->state, b->status};
+  XaacHbeSynParams p = {b->n_ch, b->num_columns, b->qmf_re, b->qmf_im, b->state, b->status, nullptr, 0};
   if (!hip_ok(xaac_launch_hbe_synth(&p, c->stream))) return XAAC_FATAL_HIP;
   c->last_grid = b->n_ch; c->last_block = 64; c->last_lds = XAAC_HBE_SYN_LDS;
   return XAAC_OK;
@@ -355,9 +355,27 @@ int32_t xaac_hbe_cplx_anal_batch(xaac_ctx *c, const xaac_hbe_anal_batch *b) {
   if (b->n_ch == 0) return XAAC_OK;
   if (!b->state) return XAAC_FATAL_NULL_ARG;
   if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
-  XaacHbeAnaParams p = {b->n_ch, b->state, b->status};
+  XaacHbeAnaParams p = {b->n_ch, b->state, b->status, nullptr, 0};
   if (!hip_ok(xaac_launch_hbe_anal(&p, c->stream))) return XAAC_FATAL_HIP;
   c->last_grid = b->n_ch; c->last_block = 64; c->last_lds = XAAC_HBE_ANA_LDS;
+  return XAAC_OK;
+}
+
+int32_t xaac_hbe_apply_batch(xaac_ctx *c, const xaac_hbe_apply_batch_desc *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n_ch < 0) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch == 0) return XAAC_OK;
+  if (!b->qmf_re || !b->qmf_im || !b->state || !b->pv_re || !b->pv_im) return XAAC_FATAL_NULL_ARG;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  /* three launches on the context's stream: synthesis bank (with the frame's shift / re-initialisation and the
+     parameter check that sets status), analysis bank, products + output rows */
+  XaacHbeSynParams ps = {b->n_ch, XAAC_HBE_NO_BINS, b->qmf_re, b->qmf_im, b->state, b->status, b->pitch_in_bins, 1};
+  if (!hip_ok(xaac_launch_hbe_synth(&ps, c->stream))) return XAAC_FATAL_HIP;
+  XaacHbeAnaParams pa = {b->n_ch, b->state, b->status, b->pitch_in_bins, 1};
+  if (!hip_ok(xaac_launch_hbe_anal(&pa, c->stream))) return XAAC_FATAL_HIP;
+  XaacHbePostParams pp = {b->n_ch, b->state, b->pitch_in_bins, b->pv_re, b->pv_im};
+  if (!hip_ok(xaac_launch_hbe_post(&pp, c->stream))) return XAAC_FATAL_HIP;
+  c->last_grid = b->n_ch; c->last_block = XAAC_HBE_POST_THREADS; c->last_lds = XAAC_HBE_POST_LDS;
   return XAAC_OK;
 }
 

@@ -6,7 +6,7 @@
  */
 #include <string.h>
 
-#include "../libxaac_amd/csrc/hbe_poly.h"
+#include "../libxaac_amd/csrc/hbe_trans.h"
 
 extern "C" {
 
@@ -43,6 +43,54 @@ int xo_hbe_cplx_anal(xaac_hbe_state *st) {
   for (int n = 0; n < 10 * a; n++) nb[n] = xh_anal_x(st->input_buf, st->analy_buf, a, XAAC_HBE_NO_BINS / 2 - 1, n);
   memcpy(st->analy_buf, nb, sizeof(float) * 10 * a);
   return 0;
+}
+
+/* ixheaacd_qmf_hbe_apply (hbe_trans.c:224-296), frames without a pitch.  pv_re / pv_im: [32][64], bands start_band ..
+   end_band - 1 written.  Returns 0, or -1 (nothing touched) for parameters xh_apply_params_ok refuses. */
+int xo_hbe_apply(xaac_hbe_state *st, const float *qmf_re, const float *qmf_im, int pitch_in_bins, float *pv_re, float *pv_im) {
+  if (!xh_apply_params_ok(st, pitch_in_bins)) return -1;
+  const int s = st->synth_size, nb = XAAC_HBE_NO_BINS;
+  if (!st->fft_ready) { /* the reference re-initialises while its FFT pointers are unset (:240-248) */
+    memset(st->synth_buf, 0, sizeof(st->synth_buf));
+    memset(st->analy_buf, 0, sizeof(st->analy_buf));
+    if (s != 20) st->fft_ready = 1;
+  }
+  memcpy(st->input_buf, st->input_buf + nb * s, sizeof(float) * s); /* :235-238 */
+  xo_hbe_real_synth(st, qmf_re, qmf_im, nb);
+  for (int i = 0; i < XAAC_HBE_OPER_WIN_LEN - 1; i++) memcpy(st->qmf_in_buf[i], st->qmf_in_buf[i + nb / 2], sizeof(st->qmf_in_buf[i]));
+  xo_hbe_cplx_anal(st);
+  for (int i = 0; i < nb; i++) memcpy(st->qmf_out_buf[i], st->qmf_out_buf[i + nb], sizeof(st->qmf_out_buf[i]));
+  for (int i = nb; i < 2 * nb; i++) memset(st->qmf_out_buf[i], 0, sizeof(st->qmf_out_buf[i]));
+  const auto in = [&](int row, int band) {
+    const XhC v = {st->qmf_in_buf[row][2 * band], st->qmf_in_buf[row][2 * band + 1]};
+    return v;
+  };
+  for (int qb = 0; qb < 64; qb++) {
+    const int f = xh_band_factor(st->x_over_qmf, st->max_stretch, qb);
+    if (!f) continue;
+    float blk[16][20];
+    for (int i = 0; i < nb / 2; i++) {
+      if (f == 2) xh_prod2_block(in, qb, i, blk[i]);
+      else if (f == 3) xh_prod3_block(in, qb, i, blk[i]);
+      else xh_prod4_block(in, qb, i, blk[i]);
+    }
+    const auto bk = [&](int i) { return (const float *)blk[i]; };
+    for (int r = 0; r < 2 * nb; r++)
+      for (int c = 0; c < 2; c++) st->qmf_out_buf[r][2 * qb + c] = xh_prod_gather(st->qmf_out_buf[r][2 * qb + c], f, r, c, bk);
+  }
+  for (int i = 0; i < nb; i++)
+    for (int b = st->start_band; b < st->end_band; b++) { /* :281-294 */
+      const float o_r = st->qmf_out_buf[i][2 * b], o_i = st->qmf_out_buf[i][2 * b + 1];
+      pv_re[64 * i + b] = (float)(o_r * xaac_hbe_pv_cos[b] - o_i * xaac_hbe_pv_sin[b]);
+      pv_im[64 * i + b] = (float)(o_r * xaac_hbe_pv_sin[b] + o_i * xaac_hbe_pv_cos[b]);
+    }
+  return 0;
+}
+
+/* xh_cbrt against the C library's cbrt (tests/test_hbe_oracle_vs_reference.py): 1 if bit-identical on x */
+int xo_hbe_cbrt_equals_libm(double x) {
+  const double a = xh_cbrt(x), b = cbrt(x);
+  return memcmp(&a, &b, sizeof(a)) == 0;
 }
 
 }  // extern "C"

@@ -71,6 +71,7 @@ int ref_hbe_reinit(const int16_t *tbl_lo, int n_lo, const int16_t *tbl_hi, int n
   st->end_band = hbe_t.end_band;
   for (i = 0; i < 6; i++) st->x_over_qmf[i] = hbe_t.x_over_qmf[i];
   st->max_stretch = hbe_t.max_stretch;
+  st->fft_ready = 0;
   return 0;
 }
 
@@ -87,5 +88,57 @@ int ref_hbe_cplx_anal(xaac_hbe_state *st) {
   if (rc) return rc;
   rc = ixheaacd_complex_anal_filt(&hbe_t);
   hbe_store(st);
+  return rc;
+}
+
+void ixheaac_real_synth_fft_p2(FLOAT32 *ptr_x, FLOAT32 *ptr_y, WORD32 npoints);
+void ixheaac_cmplx_anal_fft_p2(FLOAT32 *ptr_x, FLOAT32 *ptr_y, WORD32 npoints);
+
+/* ixheaacd_qmf_hbe_apply (hbe_trans.c:224) on the frequency tables the state's parameters were derived from.
+   pv_re / pv_im: [32][64].  -2: the tables do not give the state's parameters. */
+int ref_hbe_apply(xaac_hbe_state *st, const int16_t *tbl_lo, int n_lo, const int16_t *tbl_hi, int n_hi, const float *qmf_re,
+                  const float *qmf_im, int pitch_in_bins, float *pv_re, float *pv_im) {
+  static __thread ia_freq_band_data_struct fb;
+  static __thread ia_sbr_header_data_struct hd;
+  WORD32 used = 0;
+  int i, rc;
+  WORD16 nsf[2];
+  if (n_lo < 0 || n_lo > MAX_FREQ_COEFFS / 2 || n_hi < 0 || n_hi > MAX_FREQ_COEFFS) return -1;
+  memset(&fb, 0, sizeof(fb));
+  memset(&hd, 0, sizeof(hd));
+  for (i = 0; i <= n_lo; i++) fb.freq_band_tbl_lo[i] = tbl_lo[i];
+  for (i = 0; i <= n_hi; i++) fb.freq_band_tbl_hi[i] = tbl_hi[i];
+  fb.freq_band_table[0] = fb.freq_band_tbl_lo;
+  fb.freq_band_table[1] = fb.freq_band_tbl_hi;
+  fb.num_sf_bands[0] = (WORD16)n_lo;
+  fb.num_sf_bands[1] = (WORD16)n_hi;
+  nsf[0] = (WORD16)n_lo;
+  nsf[1] = (WORD16)n_hi;
+  hd.pstr_freq_band_data = &fb;
+  hd.is_usf_4 = 0;
+  ixheaacd_esbr_hbe_data_init(&hbe_t, 1024, 0, 2048, hbe_mem, &used);
+  hbe_t.max_stretch = st->max_stretch; /* reinit leaves it alone when four patches fit below the end band */
+  if (ixheaacd_qmf_hbe_data_reinit(&hbe_t, fb.freq_band_table, nsf, 0)) return -1;
+  if (hbe_t.synth_size != st->synth_size || hbe_t.k_start != st->k_start || hbe_t.start_band != st->start_band ||
+      hbe_t.end_band != st->end_band || hbe_t.max_stretch != st->max_stretch)
+    return -2;
+  for (i = 0; i < 6; i++)
+    if (hbe_t.x_over_qmf[i] != st->x_over_qmf[i]) return -2;
+  memcpy(hbe_t.ptr_input_buf, st->input_buf, sizeof(st->input_buf));
+  memcpy(hbe_t.synth_buf, st->synth_buf, sizeof(st->synth_buf));
+  memcpy(hbe_t.analy_buf, st->analy_buf, sizeof(st->analy_buf));
+  for (i = 0; i < XAAC_HBE_NO_BINS; i++) memcpy(hbe_t.qmf_in_buf[i], st->qmf_in_buf[i], sizeof(st->qmf_in_buf[i]));
+  for (i = 0; i < 2 * XAAC_HBE_NO_BINS; i++) memcpy(hbe_t.qmf_out_buf[i], st->qmf_out_buf[i], sizeof(st->qmf_out_buf[i]));
+  if (!st->fft_ready) {
+    hbe_t.ixheaacd_real_synth_fft = NULL;
+    hbe_t.ixheaacd_cmplx_anal_fft = NULL;
+  } else if (hbe_t.ixheaacd_cmplx_anal_fft == NULL) { /* size 20 configured after another size: the old pointers stay */
+    hbe_t.ixheaacd_real_synth_fft = &ixheaac_real_synth_fft_p2;
+    hbe_t.ixheaacd_cmplx_anal_fft = &ixheaac_cmplx_anal_fft_p2;
+  }
+  rc = ixheaacd_qmf_hbe_apply(&hbe_t, (FLOAT32(*)[64])qmf_re, (FLOAT32(*)[64])qmf_im, XAAC_HBE_NO_BINS, (FLOAT32(*)[64])pv_re,
+                              (FLOAT32(*)[64])pv_im, pitch_in_bins, &hd);
+  hbe_store(st);
+  st->fft_ready = hbe_t.ixheaacd_cmplx_anal_fft != NULL;
   return rc;
 }

@@ -9,7 +9,7 @@ class HbeState(ctypes.Structure):
     _fields_ = [("input_buf", F * (1024 + 64)), ("synth_buf", F * 1280), ("analy_buf", F * 640),
                 ("qmf_in_buf", (F * 128) * NO_BINS), ("qmf_out_buf", (F * 128) * (2 * NO_BINS)),
                 ("synth_size", I32), ("k_start", I32), ("start_band", I32), ("end_band", I32),
-                ("x_over_qmf", I32 * 6), ("max_stretch", I32), ("pad_", I32)]
+                ("x_over_qmf", I32 * 6), ("max_stretch", I32), ("fft_ready", I32)]
 
 
 K_START = [0, 0, 0, 0, 0, 0, 0, 2, 2, 2, 4, 4, 4, 4, 4, 6, 6, 6, 8, 8, 8, 8, 8, 10, 10, 10, 12, 12, 12, 12, 12, 12, 12]

@@ -103,3 +103,82 @@ def test_gpu_chains_match_reference_and_oracle(oracle):
                 assert zlib.crc32(got_ana[nchain + c].tobytes()) & 0xffffffff == int(GOLD["crc"][c, f - 1, 1]), (f, c)
     # the refused channel's state is untouched
     assert np.array_equal(got_ana[-1], np.frombuffer(bytes(host[-1]), np.uint8))
+
+
+from make_golden_hbe import APPLY_FRAMES, apply_input, state_from_params  # noqa: E402
+
+
+def _oracle_apply(oracle):
+    fn = oracle.lib.xo_hbe_apply
+    fn.restype, fn.argtypes = ctypes.c_int, [ctypes.POINTER(HbeState), PF, PF, ctypes.c_int, PF, PF]
+    return fn
+
+
+def _crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xffffffff
+
+
+def test_oracle_apply_matches_reference_chains(oracle):
+    """ixheaacd_qmf_hbe_apply chains made by the reference (state and output-row CRCs per frame): the oracle's
+    xo_hbe_apply reproduces all of them from the stored bank parameters"""
+    fn = _oracle_apply(oracle)
+    for c, par in enumerate(GOLD["apply_params"]):
+        st = state_from_params(par)
+        for f in range(APPLY_FRAMES):
+            re, im = apply_input(c, f)
+            pv = np.full((2, 32, 64), 7.5, np.float32)
+            assert fn(ctypes.byref(st), re.ctypes.data_as(PF), im.ctypes.data_as(PF), 0, pv[0].ctypes.data_as(PF), pv[1].ctypes.data_as(PF)) == 0
+            assert (_crc(bytes(st)), _crc(pv[0]), _crc(pv[1])) == tuple(int(v) for v in GOLD["apply_crc"][c, f]), (c, f)
+        assert np.array_equal(pv.view(np.uint32), GOLD["apply_last_pv"][c].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_gpu_apply_matches_reference_and_oracle(oracle):
+    import torch
+    import libxaac_amd
+    dev = torch.device("cuda:0")
+    ctx = libxaac_amd.XaacContext(0, None)
+    fn = _oracle_apply(oracle)
+    pars = GOLD["apply_params"]
+    nchain = len(pars)
+    # channels 0..5: the golden chains; 6..11: the same one frame late, after a silent frame (whose analysis rows hold
+    # negative zeros: against the oracle only); 12: a pitch that selects the cross products
+    # (refused); 13: a cross-over band outside the row (refused)
+    host = [state_from_params(p) for p in pars] + [state_from_params(p) for p in pars] + [state_from_params(pars[1]), state_from_params(pars[1])]
+    host[-1].x_over_qmf[1] = 70
+    n = len(host)
+    pitch_np = np.zeros(n, np.int32)
+    pitch_np[nchain * 2] = 14
+    pitch = torch.from_numpy(pitch_np).to(dev)
+    state = _states_tensor(torch, dev, host)
+    untouched = [bytes(host[-2]), bytes(host[-1])]
+    status = torch.full((n,), 7, dtype=torch.int32, device=dev)
+    rng = np.random.default_rng(10)
+    for f in range(APPLY_FRAMES + 3):
+        re, im = np.zeros((n, 32, 64), np.float32), np.zeros((n, 32, 64), np.float32)
+        for c in range(nchain):
+            if f < APPLY_FRAMES:
+                re[c], im[c] = apply_input(c, f)
+            else:
+                re[c] = (rng.standard_normal((32, 64)) * 2.0 ** rng.integers(-4, 16)).astype(np.float32)
+                im[c] = (rng.standard_normal((32, 64)) * 300).astype(np.float32)
+            if 1 <= f <= APPLY_FRAMES:
+                re[nchain + c], im[nchain + c] = apply_input(c, f - 1)
+        re[-2:], im[-2:] = re[:2], im[:2]
+        pv_re = torch.full((n, 32, 64), 7.5, dtype=torch.float32, device=dev)
+        pv_im = torch.full((n, 32, 64), 7.5, dtype=torch.float32, device=dev)
+        ctx.hbe_apply_batch(torch.from_numpy(re).to(dev), torch.from_numpy(im).to(dev), state, pv_re, pv_im, status, pitch)
+        ctx.sync()
+        got, g_re, g_im = state.cpu().numpy(), pv_re.cpu().numpy(), pv_im.cpu().numpy()
+        assert status.cpu().tolist() == [0] * (2 * nchain) + [-1, -1]
+        for c in range(2 * nchain):
+            pv = np.full((2, 32, 64), 7.5, np.float32)
+            assert fn(ctypes.byref(host[c]), re[c].ctypes.data_as(PF), im[c].ctypes.data_as(PF), 0, pv[0].ctypes.data_as(PF), pv[1].ctypes.data_as(PF)) == 0
+            d = np.nonzero(np.frombuffer(bytes(host[c]), np.uint8) != got[c])[0]
+            assert d.size == 0, ("state", f, c, d[:4])
+            assert np.array_equal(pv[0].view(np.uint32), g_re[c].view(np.uint32)) and np.array_equal(pv[1].view(np.uint32), g_im[c].view(np.uint32)), ("rows", f, c)
+        if f < APPLY_FRAMES:
+            for c in range(nchain):
+                assert (_crc(got[c]), _crc(g_re[c]), _crc(g_im[c])) == tuple(int(v) for v in GOLD["apply_crc"][c, f]), (f, c)
+        assert [bytes(got[-2]), bytes(got[-1])] == untouched
+        assert np.all(g_re[-2:] == 7.5) and np.all(g_im[-2:] == 7.5)

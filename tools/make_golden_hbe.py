@@ -63,8 +63,80 @@ def run(lib, prefix):
     return crcs, last_time, last_rows
 
 
+P16 = ctypes.POINTER(ctypes.c_int16)
+APPLY_FRAMES = 5
+
+
+def apply_tables():
+    """(lo, hi) frequency-band tables of the apply chains: one per bank size with all three stretch factors in use
+    where four patches fit, and the two table pairs of the committed HE-AAC stream headers"""
+    out = []
+    for sb, end, width in ((2, 7, 1), (9, 31, 2), (14, 47, 3), (22, 64, 3), (30, 64, 2)):
+        hi = list(range(sb, end, width)) + [end]
+        lo = hi[::2] if (len(hi) - 1) % 2 == 0 else [hi[0]] + hi[1::2]
+        out.append((np.array(lo, np.int16), np.array(hi, np.int16)))
+    out.append((np.array([15, 17, 19, 21, 23, 26, 29, 33, 37, 41], np.int16),
+                np.array([15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 26, 27, 29, 31, 33, 35, 37, 39, 41], np.int16)))
+    return out
+
+
+def apply_input(chain, frame):
+    rng = np.random.default_rng(88000 + 100 * chain + frame)
+    a = 2.0 ** rng.integers(2, 14)
+    re = (rng.standard_normal((32, 64)) * a).astype(np.float32)
+    im = (rng.standard_normal((32, 64)) * a).astype(np.float32)
+    if frame == 2:
+        re[:], im[:] = 0, 0
+    return re, im
+
+
+def apply_state(ref_lib, lo, hi):
+    fn = ref_lib.ref_hbe_reinit
+    fn.restype, fn.argtypes = ctypes.c_int, [P16, ctypes.c_int, P16, ctypes.c_int, ctypes.POINTER(HbeState)]
+    st = HbeState()
+    assert fn(lo.ctypes.data_as(P16), len(lo) - 1, hi.ctypes.data_as(P16), len(hi) - 1, ctypes.byref(st)) == 0
+    return st
+
+
+def apply_params(st):
+    return [st.synth_size, st.k_start, st.start_band, st.end_band] + list(st.x_over_qmf) + [st.max_stretch]
+
+
+def state_from_params(par):
+    st = HbeState()
+    st.synth_size, st.k_start, st.start_band, st.end_band = [int(v) for v in par[:4]]
+    for q in range(6):
+        st.x_over_qmf[q] = int(par[4 + q])
+    st.max_stretch = int(par[10])
+    return st
+
+
+def run_apply_reference(ref_lib):
+    fn = ref_lib.ref_hbe_apply
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.POINTER(HbeState), P16, ctypes.c_int, P16, ctypes.c_int, PF, PF, ctypes.c_int, PF, PF]
+    tabs = apply_tables()
+    crcs = np.zeros((len(tabs), APPLY_FRAMES, 3), np.uint32)
+    params = np.zeros((len(tabs), 11), np.int32)
+    last_pv = np.zeros((len(tabs), 2, 32, 64), np.float32)
+    for c, (lo, hi) in enumerate(tabs):
+        st = apply_state(ref_lib, lo, hi)
+        params[c] = apply_params(st)
+        for f in range(APPLY_FRAMES):
+            re, im = apply_input(c, f)
+            pv = np.full((2, 32, 64), 7.5, np.float32)
+            assert fn(ctypes.byref(st), lo.ctypes.data_as(P16), len(lo) - 1, hi.ctypes.data_as(P16), len(hi) - 1,
+                      re.ctypes.data_as(PF), im.ctypes.data_as(PF), 0, pv[0].ctypes.data_as(PF), pv[1].ctypes.data_as(PF)) == 0
+            crcs[c, f] = [crc(st), zlib.crc32(pv[0].tobytes()) & 0xffffffff, zlib.crc32(pv[1].tobytes()) & 0xffffffff]
+        last_pv[c] = pv
+    return crcs, params, last_pv
+
+
 if __name__ == "__main__":
     ref = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_harness.so"))
     crcs, last_time, last_rows = run(ref, "ref")
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "hbe_ref.npz"), crc=crcs, last_time=last_time, last_rows=last_rows)
+    acrc, apar, apv = run_apply_reference(ref)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "hbe_ref.npz"), crc=crcs, last_time=last_time, last_rows=last_rows,
+                        apply_crc=acrc, apply_params=apar, apply_last_pv=apv)
+    print("apply chains", len(apar), "params", apar.tolist())
     print("chains", len(START_BANDS), "frames", FRAMES, "crc[0]", crcs[0].tolist())
