@@ -10,6 +10,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def timed(torch, ctx, fn, steps=20, warmup=3):
@@ -104,6 +106,22 @@ def main():
     us = timed(torch, ctx, lambda: ctx.esbr_sbr_process_batch(core, hd, fr, sd, st, pcm, ws, status, pf, pst, pcm_r))
     assert not status.cpu().numpy().any()
     res.append(("esbr_sbr_ps_chain(5 kernels)", us, n * (4096 + 2 * 8192 + 2 * st.shape[1] + 2 * pst.shape[1] + pf.shape[1])))
+    # the QMF-domain harmonic transposer (ixheaacd_qmf_hbe_apply without a pitch): the stream headers' bank (synth_size
+    # 12, stretch factors 2 and 3) and the largest bank with all three factors; algorithmic bytes: 2 x 8 KB rows in,
+    # 2 x 8 KB rows out, the state's delay lines and row buffers in + out
+    from make_golden_hbe import state_from_params
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    nh = min(n, 8192)
+    for label, par in (("hbe_apply(size 12, x2 x3)", [12, 6, 15, 41, 15, 29, 41, 0, 0, 0, 3]),
+                       ("hbe_apply(size 8, x2 x3 x4)", [8, 2, 9, 31, 9, 15, 27, 31, 0, 0, 4])):
+        hst = torch.from_numpy(np.stack([np.frombuffer(bytes(state_from_params(par)), np.uint8)] * nh)).to(dev)
+        qre = torch.from_numpy((rng.standard_normal((nh, 32, 64)) * 1000).astype(np.float32)).to(dev)
+        qim = torch.from_numpy((rng.standard_normal((nh, 32, 64)) * 1000).astype(np.float32)).to(dev)
+        pvr, pvi = torch.zeros_like(qre), torch.zeros_like(qre)
+        hstat = torch.zeros(nh, dtype=torch.int32, device=dev)
+        us = timed(torch, ctx, lambda: ctx.hbe_apply_batch(qre, qim, hst, pvr, pvi, hstat))
+        assert not hstat.cpu().numpy().any()
+        res.append((label, us * n / nh, n * (4 * 8192 + 2 * libxaac_amd.HBE_STATE_BYTES)))
     for name, us, bytes_ in res:
         print(json.dumps({"kernel": name, "n_ch": n, "us": round(us, 1), "channel_frames_per_s": round(n / us * 1e6),
                           "alg_GBps": round(bytes_ / us / 1e3, 1), "frac_of_8TBps": round(bytes_ / us / 1e3 / 8000, 4)}))
