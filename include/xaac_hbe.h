@@ -6,7 +6,7 @@
  *
  *   xaac_hbe_real_synth_batch  <-> ixheaacd_real_synth_filt     (esbr_polyphase.c:157-274)
  *   xaac_hbe_cplx_anal_batch   <-> ixheaacd_complex_anal_filt   (esbr_polyphase.c:48-155)
- *   xaac_hbe_apply_batch       <-> ixheaacd_qmf_hbe_apply       (hbe_trans.c:224-296), frames without a pitch
+ *   xaac_hbe_apply_batch       <-> ixheaacd_qmf_hbe_apply       (hbe_trans.c:224-296)
  *
  * Scope: the QMF transposer (esbr_hq = 0) at 2:1 SBR of 1024-sample cores: no_bins = 32 QMF columns per frame, bank
  * sizes synth_size = 4, 8, 12, 16, 20 (hbe_trans.c:111-112).  The DFT transposer's bank (esbr_polyphase.c:276) is not
@@ -53,8 +53,8 @@ typedef struct xaac_hbe_apply_batch_desc {
   const int32_t *pitch_in_bins; /* [n_ch] or NULL (all 0): frame data pitch_in_bins */
   xaac_hbe_state *state;        /* [n_ch] in/out */
   float *pv_re, *pv_im;         /* [n_ch][32][64]: ph_vocod_qmf_real / _imag rows; bands start_band..end_band-1 written */
-  int32_t *status;              /* [n_ch] or NULL: 0, or -1 (parameters outside the tables, a pitch that selects the
-                                   cross products): such a channel's state and output are left alone */
+  int32_t *status;              /* [n_ch] or NULL: 0, or -1 (parameters outside the tables or rows): such a channel's state
+                                   and output are left alone */
 } xaac_hbe_apply_batch_desc;
 
 typedef struct xaac_hbe_anal_batch {
@@ -72,9 +72,9 @@ int32_t xaac_hbe_real_synth_batch(xaac_ctx *ctx, const xaac_hbe_synth_batch *bat
 /* ixheaacd_complex_anal_filt for n_ch channels: no_bins / 2 columns of 2 * synth_size complex sub-band samples */
 int32_t xaac_hbe_cplx_anal_batch(xaac_ctx *ctx, const xaac_hbe_anal_batch *batch);
 
-/* ixheaacd_qmf_hbe_apply (hbe_trans.c:224-296) for n_ch channels, frames without a pitch (pitch_in_bins * 1/12 < 1):
-   time-signal shift, synthesis bank, analysis bank, stretch-by-2/3/4 products into qmf_out_buf, rotation of the
-   frame's 32 output rows into pv_re / pv_im.  fft_ready mirrors whether the reference's transposer has its FFT
+/* ixheaacd_qmf_hbe_apply (hbe_trans.c:224-296) for n_ch channels: time-signal shift, synthesis bank, analysis bank,
+   stretch-by-2/3/4 products into qmf_out_buf (with the pitch-adaptive cross products when pitch_in_bins / 12 >= 1),
+   rotation of the frame's 32 output rows into pv_re / pv_im.  fft_ready mirrors whether the reference's transposer has its FFT
    pointers: while it has not (a new stream; always for synth_size 20, whose case sets none, hbe_trans.c:159-164) the
    reference re-initialises on every call and so clears both delay lines first (:240-248, :124, :174). */
 int32_t xaac_hbe_apply_batch(xaac_ctx *ctx, const xaac_hbe_apply_batch_desc *batch);

@@ -29,7 +29,7 @@ typedef struct XaacHbeAnaParams {
 } XaacHbeAnaParams;
 
 #define XAAC_HBE_POST_THREADS 256
-#define XAAC_HBE_POST_LDS (256 * 20 * 4) /* the blocks of 16 bands x 16 columns */
+#define XAAC_HBE_POST_LDS (256 * 25 * 4) /* the blocks (+ cross terms) of 16 bands x 16 columns */
 typedef struct XaacHbePostParams {
   int32_t n_ch;
   xaac_hbe_state *state;

@@ -2,7 +2,7 @@
  * hbe_kernel.hip -- the polyphase banks of the QMF-domain harmonic transposer on gfx950:
  *   xaac_hbe_synth_kernel  <-> ixheaacd_real_synth_filt    (decoder/ixheaacd_esbr_polyphase.c:157-274)
  *   xaac_hbe_anal_kernel   <-> ixheaacd_complex_anal_filt  (decoder/ixheaacd_esbr_polyphase.c:48-155)
- *   xaac_hbe_post_kernel   <-> ixheaacd_hbe_post_anal_process without a pitch + the output stage of
+ *   xaac_hbe_post_kernel   <-> ixheaacd_hbe_post_anal_process + the output stage of
  *                              ixheaacd_qmf_hbe_apply (decoder/ixheaacd_hbe_trans.c:1549-1571, :262-295)
  * The arithmetic is hbe_poly.h / hbe_trans.h (the oracle runs the same source sequentially).
  *
@@ -97,10 +97,11 @@ __global__ __launch_bounds__(64) void xaac_hbe_anal_kernel(XaacHbeAnaParams p) {
    range into the output (hbe_trans.c:262-295). */
 __global__ __launch_bounds__(XAAC_HBE_POST_THREADS) void xaac_hbe_post_kernel(XaacHbePostParams p) {
   extern __shared__ float lds[];
-  float(*blk)[20] = reinterpret_cast<float(*)[20]>(lds); /* [16 bands x 16 columns][<= 10 complex] */
+  float(*blk)[XH_BLK] = reinterpret_cast<float(*)[XH_BLK]>(lds); /* [16 bands x 16 columns]: xh_column_block */
   const int ch = blockIdx.x, tid = threadIdx.x;
   xaac_hbe_state *st = p.state + ch;
-  if (!xh_apply_params_ok(st, p.pitch ? p.pitch[ch] : 0)) return;
+  const int pitch = p.pitch ? p.pitch[ch] : 0;
+  if (!xh_apply_params_ok(st, pitch)) return;
   const int ms = st->max_stretch, sb0 = st->start_band, sb1 = st->end_band;
   int32_t xo[4];
   for (int q = 0; q < 4; q++) xo[q] = st->x_over_qmf[q];
@@ -110,13 +111,13 @@ __global__ __launch_bounds__(XAAC_HBE_POST_THREADS) void xaac_hbe_post_kernel(Xa
     const XhC c = {v.x, v.y};
     return c;
   };
+  const float *in_flat = &st->qmf_in_buf[0][0];
+  const auto inf = [&](int row, int idx) { return in_flat[128 * row + idx]; };
   for (int tile = 0; tile < 4; tile++) {
     {
       const int qb = 16 * tile + (tid >> 4), i = tid & 15;
       const int f = xh_band_factor(xo, ms, qb);
-      if (f == 2) xh_prod2_block(in, qb, i, blk[tid]);
-      else if (f == 3) xh_prod3_block(in, qb, i, blk[tid]);
-      else if (f == 4) xh_prod4_block(in, qb, i, blk[tid]);
+      if (f) xh_column_block(in, inf, f, qb, i, pitch, blk[tid]);
     }
     __syncthreads();
     for (int half = 0; half < 2; half++) {

@@ -1,7 +1,7 @@
 /*
  * hbe_trans.h -- the QMF-domain harmonic transposer between its two banks (hbe_poly.h) as host/device code: the
- * stretch-by-2 / 3 / 4 products of ixheaacd_hbe_post_anal_process without a pitch (decoder/ixheaacd_hbe_trans.c:
- * 1549-1571 with :298-372, :753-794, :796-1027, :1029-1082) and the frame bookkeeping of ixheaacd_qmf_hbe_apply
+ * stretch-by-2 / 3 / 4 products of ixheaacd_hbe_post_anal_process (decoder/ixheaacd_hbe_trans.c:1549-1606 with
+ * :298-372, :753-794, :796-1027, :1029-1082; the variants with a pitch below) and the frame bookkeeping of ixheaacd_qmf_hbe_apply
  * (:224-296).  Included by the oracle (oracle/oracle_hbe.cpp) and by hbe_kernel.hip; no contraction, the reference's
  * operand order and width (FLOAT32, with the FLOAT64 bases and libm calls where the reference has them).
  *
@@ -10,8 +10,12 @@
  * (xh_prod2_block, xh_prod3_block, xh_prod4_block); a row's element then adds the blocks that reach it in the order of
  * the columns (xh_prod_gather).  Bands of the three stretch factors are disjoint.
  *
- * Not built: the pitch-adaptive cross products (ixheaacd_hbe_post_anal_xprod2/3/4, :1084-1547: frames with
- * pitch_in_bins * 0.08333333333333 >= 1 are refused), the 4:1 system, the DFT transposer.
+ * With a pitch (pitch_in_bins / 12 >= 1, :1572-1603) every column adds, after its block, one cross product of two
+ * sub-bands a pitch apart to the two rows 2 i + 5 and 2 i + 6 (ixheaacd_hbe_post_anal_xprod2, :1084-1247, and
+ * ixheaacd_hbe_xprod_proc_3 / _4, :374-567 / :569-751): xh_xprod2/3/4 compute the two terms, the gather adds them
+ * behind the column's block.
+ *
+ * Not built: the 4:1 system, the DFT transposer.
  */
 #ifndef XAAC_HBE_TRANS_H
 #define XAAC_HBE_TRANS_H
@@ -193,6 +197,231 @@ FX_HD void xh_prod3_block(const In &in, int qb, int i, float *blk) {
   }
 }
 
+/* ---- the pitch-adaptive cross products ---------------------------------------------------------------------------- */
+/* inf(row, idx): word idx of qmf_in_buf row `row` with the reference's flat addressing -- the candidate sub-bands of a
+   cross product may lie before a row's first or behind its last pair, and the reference reads the neighbouring row
+   there before it rejects the candidate (rows are contiguous in its memory as they are in xaac_hbe_state). */
+FX_HD void xh_cpow(float &r, float &i, int n) { /* n - 1 further multiplications by the start value (:509-514) */
+  const float temp_r = r, temp_i = i;
+  for (int idx = 0; idx < n - 1; idx++) {
+    const float tmp = r;
+    r = r * temp_r - i * temp_i;
+    i = tmp * temp_i + i * temp_r;
+  }
+}
+/* Stretch by 2 (:1124-1240).  cross[0..3] = the terms of rows 2 i + 5 and 2 i + 6; returns whether there is one. */
+template <class Inf>
+FX_HD bool xh_xprod2(const Inf &inf, int qb, int i, float p, int pitch_idx, float *cross) {
+  const double temp_fac = (2.0 * qb + 1 - p) * 0.5;
+  const int n1 = ((int)(temp_fac)) << 1, n2 = ((int)(temp_fac + p)) << 1;
+  const int row = i + XH_ZERO_BAND;
+  const float mag_zero_band = inf(row, 2 * qb) * inf(row, 2 * qb) + inf(row, 2 * qb + 1) * inf(row, 2 * qb + 1);
+  const float mag_n1_band = inf(row, n1) * inf(row, n1) + inf(row, n1 + 1) * inf(row, n1 + 1);
+  const float mag_n2_band = inf(row, n2) * inf(row, n2) + inf(row, n2 + 1) * inf(row, n2 + 1);
+  const float temp = mag_n1_band < mag_n2_band ? mag_n1_band : mag_n2_band;
+  float max_mag_value = 0;
+  int max_n1 = 0, max_n2 = 0;
+  if (temp > 0) {
+    max_mag_value = temp;
+    max_n1 = n1;
+    max_n2 = n2;
+  }
+  if (!(max_mag_value > mag_zero_band && max_n1 >= 0 && max_n2 < 128)) return false;
+  const XhC z = xh_norm2(inf(row, max_n1), inf(row, max_n1 + 1)); /* mid_trans_fac = 1: no further power */
+  XhC y[2];
+  for (int k = 0; k < 2; k++) y[k] = xh_norm2(inf(row - 1 + k, max_n2), inf(row - 1 + k, max_n2 + 1));
+  const float cs0 = xaac_hbe_xprod_cs_2[(pitch_idx << 1) + 0], cs1 = xaac_hbe_xprod_cs_2[(pitch_idx << 1) + 1];
+  const float mag_cmplx_gain = 1.666666667f;
+  float temp_r = y[0].r * z.r - y[0].i * z.i, temp_i = y[0].r * z.i + y[0].i * z.r;
+  const float tmp_r1 = (float)(cs0 * temp_r - cs1 * temp_i);
+  temp_i = (float)(cs0 * temp_i + cs1 * temp_r);
+  cross[0] = (float)(mag_cmplx_gain * tmp_r1);
+  cross[1] = (float)(mag_cmplx_gain * temp_i);
+  temp_r = y[1].r * z.r - y[1].i * z.i;
+  temp_i = y[1].r * z.i + y[1].i * z.r;
+  cross[2] = (float)(mag_cmplx_gain * temp_r);
+  cross[3] = (float)(mag_cmplx_gain * temp_i);
+  return true;
+}
+/* the common tail of ixheaacd_hbe_xprod_proc_3 / _4: powers, product, rotation of the first term, gain */
+FX_HD void xh_xprod_tail(float zr, float zi, float *yr, float *yi, int mid_trans_fac, int max_trans_fac, float cos_theta,
+                         float sin_theta, float gain, float *cross) {
+  xh_cpow(zr, zi, mid_trans_fac);
+  for (int k = 0; k < 2; k++) xh_cpow(yr[k], yi[k], max_trans_fac);
+  float o_r[2], o_i[2];
+  for (int k = 0; k < 2; k++) {
+    o_r[k] = yr[k] * zr - yi[k] * zi;
+    o_i[k] = yr[k] * zi + yi[k] * zr;
+  }
+  const float temp_r = o_r[0], temp_i = o_i[0];
+  o_r[0] = (float)(cos_theta * temp_r - sin_theta * temp_i);
+  o_i[0] = (float)(cos_theta * temp_i + sin_theta * temp_r);
+  for (int k = 0; k < 2; k++) {
+    cross[2 * k] = (float)(gain * o_r[k]);
+    cross[2 * k + 1] = (float)(gain * o_i[k]);
+  }
+}
+/* Stretch by 3 (ixheaacd_hbe_xprod_proc_3, :374-567) */
+template <class Inf>
+FX_HD bool xh_xprod3(const Inf &inf, int qb, int i, float p, int pitch_idx, float *cross) {
+  const int inp = 2 * qb / 3, row = i + XH_ZERO_BAND;
+  const float mag_zero_band = inf(row, 2 * inp) * inf(row, 2 * inp) + inf(row, 2 * inp + 1) * inf(row, 2 * inp + 1);
+  float max_mag_value = 0;
+  int max_n1 = 0, max_n2 = 0, max_trans_fac = 0;
+  for (int tr = 1; tr < 3; tr++) {
+    const double temp_fac = (2.0f * qb + 1 - tr * p) * 0.3333334;
+    const int n1 = (int)(temp_fac), n2 = (int)(temp_fac + p);
+    const float mag_n1_band = inf(row, 2 * n1) * inf(row, 2 * n1) + inf(row, 2 * n1 + 1) * inf(row, 2 * n1 + 1);
+    const float mag_n2_band = inf(row, 2 * n2) * inf(row, 2 * n2) + inf(row, 2 * n2 + 1) * inf(row, 2 * n2 + 1);
+    const float temp = mag_n1_band < mag_n2_band ? mag_n1_band : mag_n2_band;
+    if (temp > max_mag_value) {
+      max_mag_value = temp;
+      max_trans_fac = tr;
+      max_n1 = n1;
+      max_n2 = n2;
+    }
+  }
+  if (!(max_mag_value > mag_zero_band && max_n1 >= 0 && max_n2 < 64)) return false;
+  int mid_trans_fac = 3 - max_trans_fac;
+  float d1, d2;
+  int nz, ny; /* the sub-band of the zero-band factor, the sub-band of the two-row vector */
+  if (max_trans_fac == 1) {
+    d1 = 0;
+    d2 = 1.5;
+    nz = max_n1;
+    ny = max_n2;
+  } else {
+    d1 = 1.5;
+    d2 = 0;
+    mid_trans_fac = max_trans_fac;
+    max_trans_fac = 3 - max_trans_fac;
+    nz = max_n2;
+    ny = max_n1;
+  }
+  float zr = inf(row, 2 * nz), zi = inf(row, 2 * nz + 1);
+  const int idx = ((ny & 3) + 1) & 3;
+  const float c0r = xaac_hbe_interp_coeff[2 * idx], c0i = xaac_hbe_interp_coeff[2 * idx + 1];
+  const float c1r = c0r, c1i = -c0i;
+  float yr[2], yi[2];
+  yr[1] = inf(row, 2 * ny);
+  yi[1] = inf(row, 2 * ny + 1);
+  float temp_r = inf(row - 2, 2 * ny), temp_i = inf(row - 2, 2 * ny + 1);
+  yr[0] = c1r * temp_r - c1i * temp_i;
+  yi[0] = c1i * temp_r + c1r * temp_i;
+  temp_r = inf(row - 1, 2 * ny);
+  temp_i = inf(row - 1, 2 * ny + 1);
+  yr[0] += c0r * temp_r - c0i * temp_i;
+  yi[0] += c0i * temp_r + c0r * temp_i;
+  {
+    const XhC z = xh_norm3(zr, zi);
+    zr = z.r;
+    zi = z.i;
+    for (int k = 0; k < 2; k++) {
+      const XhC y = xh_norm3(yr[k], yi[k]);
+      yr[k] = y.r;
+      yi[k] = y.i;
+    }
+  }
+  const float cos_theta = xaac_hbe_xprod_cs_3[(pitch_idx << 1) + 0];
+  float sin_theta = xaac_hbe_xprod_cs_3[(pitch_idx << 1) + 1];
+  if (d2 < d1) sin_theta = -sin_theta;
+  xh_xprod_tail(zr, zi, yr, yi, mid_trans_fac, max_trans_fac, cos_theta, sin_theta, 1.8856f, cross);
+  return true;
+}
+/* Stretch by 4 (ixheaacd_hbe_xprod_proc_4, :569-751); n1 / n2 are word indices here as in the reference */
+template <class Inf>
+FX_HD bool xh_xprod4(const Inf &inf, int qb, int i, float p, int pitch_idx, float *cross) {
+  const int inp = qb >> 1, row = i + XH_ZERO_BAND;
+  const float mag_zero_band = inf(row, 2 * inp) * inf(row, 2 * inp) + inf(row, 2 * inp + 1) * inf(row, 2 * inp + 1);
+  float max_mag_value = 0;
+  int max_n1 = 0, max_n2 = 0, max_trans_fac = 0;
+  for (int tr = 1; tr < 4; tr++) {
+    const double temp_fac = (2.0 * qb + 1 - tr * p) * 0.25;
+    const int n1 = ((int)(temp_fac)) << 1, n2 = ((int)(temp_fac + p)) << 1;
+    const float mag_n1_band = inf(row, n1) * inf(row, n1) + inf(row, n1 + 1) * inf(row, n1 + 1);
+    const float mag_n2_band = inf(row, n2) * inf(row, n2) + inf(row, n2 + 1) * inf(row, n2 + 1);
+    const float temp = mag_n1_band < mag_n2_band ? mag_n1_band : mag_n2_band;
+    if (temp > max_mag_value) {
+      max_mag_value = temp;
+      max_trans_fac = tr;
+      max_n1 = n1;
+      max_n2 = n2;
+    }
+  }
+  if (!(max_mag_value > mag_zero_band && max_n1 >= 0 && max_n2 < 128)) return false;
+  int mid_trans_fac = 4 - max_trans_fac;
+  float d1, d2, zr, zi, yr[2], yi[2];
+  if (max_trans_fac == 1) {
+    d1 = 0;
+    d2 = 2;
+    zr = inf(row, max_n1);
+    zi = inf(row, max_n1 + 1);
+    for (int k = 0; k < 2; k++) {
+      yr[k] = inf(row + 2 * (k - 1), max_n2);
+      yi[k] = inf(row + 2 * (k - 1), max_n2 + 1);
+    }
+  } else if (max_trans_fac == 2) {
+    d1 = 0;
+    d2 = 1;
+    zr = inf(row, max_n1);
+    zi = inf(row, max_n1 + 1);
+    for (int k = 0; k < 2; k++) {
+      yr[k] = inf(row + (k - 1), max_n2);
+      yi[k] = inf(row + (k - 1), max_n2 + 1);
+    }
+  } else {
+    d1 = 2;
+    d2 = 0;
+    mid_trans_fac = max_trans_fac;
+    max_trans_fac = 4 - max_trans_fac;
+    zr = inf(row, max_n2);
+    zi = inf(row, max_n2 + 1);
+    for (int k = 0; k < 2; k++) {
+      yr[k] = inf(row + 2 * (k - 1), max_n1);
+      yi[k] = inf(row + 2 * (k - 1), max_n1 + 1);
+    }
+  }
+  {
+    const XhC z = xh_norm4(zr, zi);
+    zr = z.r;
+    zi = z.i;
+    for (int k = 0; k < 2; k++) {
+      const XhC y = xh_norm4(yr[k], yi[k]);
+      yr[k] = y.r;
+      yi[k] = y.i;
+    }
+  }
+  float cos_theta, sin_theta;
+  if (d2 == 1) {
+    cos_theta = xaac_hbe_xprod_cs_4_1[(pitch_idx << 1) + 0];
+    sin_theta = xaac_hbe_xprod_cs_4_1[(pitch_idx << 1) + 1];
+  } else {
+    cos_theta = xaac_hbe_xprod_cs_4[(pitch_idx << 1) + 0];
+    sin_theta = xaac_hbe_xprod_cs_4[(pitch_idx << 1) + 1];
+    if (d2 < d1) sin_theta = -sin_theta;
+  }
+  xh_xprod_tail(zr, zi, yr, yi, mid_trans_fac, max_trans_fac, cos_theta, sin_theta, 2.0f, cross);
+  return true;
+}
+/* the pitch in sub-bands and whether the frame takes the cross products (:1558-1562) */
+FX_HD float xh_pitch(int pitch_in_bins) { return (float)(pitch_in_bins * 0.08333333333333); }
+#define XH_BLK 25 /* floats per (band, column): <= 10 complex products, two cross terms, whether they exist */
+/* a column's whole contribution to band qb: blk[0..19] the block, blk[20..23] the cross terms, blk[24] != 0 with them */
+template <class In, class Inf>
+FX_HD void xh_column_block(const In &in, const Inf &inf, int factor, int qb, int i, int pitch_in_bins, float *blk) {
+  if (factor == 2) xh_prod2_block(in, qb, i, blk);
+  else if (factor == 3) xh_prod3_block(in, qb, i, blk);
+  else xh_prod4_block(in, qb, i, blk);
+  const float p = xh_pitch(pitch_in_bins);
+  bool has = false;
+  if (!(p < 1.0f)) {
+    if (factor == 2) has = xh_xprod2(inf, qb, i, p, pitch_in_bins, blk + 20);
+    else if (factor == 3) has = xh_xprod3(inf, qb, i, p, pitch_in_bins, blk + 20);
+    else has = xh_xprod4(inf, qb, i, p, pitch_in_bins, blk + 20);
+  }
+  blk[24] = has ? 1.0f : 0.0f;
+}
+
 /* which stretch factor writes output band qb (0: none), from x_over_qmf and max_stretch (:1562-1580) */
 FX_HD int xh_band_factor(const int32_t *xo, int max_stretch, int qb) {
   if (2 <= max_stretch && qb >= xo[0] && qb < xo[1]) return 2;
@@ -210,19 +439,22 @@ FX_HD float xh_prod_gather(float start, int factor, int r, int comp, const Blk &
   const int len = xh_block_len(factor), r0 = xh_block_row0(factor);
   float acc = start;
   for (int i = 0; i < XAAC_HBE_NO_BINS / 2; i++) {
+    const float *b = blk(i);
     const int k = r - r0 - 2 * i;
-    if (k >= 0 && k < len) acc += blk(i)[2 * k + comp];
+    if (k >= 0 && k < len) acc += b[2 * k + comp];
+    const int kc = r - (2 * i + XH_ZERO_BAND - 1); /* the cross terms follow the column's block (:1118-1240) */
+    if ((kc == 0 || kc == 1) && b[24] != 0.0f) acc += b[20 + 2 * kc + comp];
   }
   return acc;
 }
 
-/* the frame's parameters are usable: bank sizes in the tables, cross-over bands inside the rows, a pitch below the
-   cross-product threshold (:1558-1562), the reference's own x_over_qmf[2] > 1 condition (:1573) */
+/* the frame's parameters are usable: bank sizes in the tables, cross-over bands inside the rows, a pitch inside its
+   seven bits, the reference's own x_over_qmf[2] > 1 condition (:1573) */
 FX_HD bool xh_apply_params_ok(const xaac_hbe_state *st, int pitch_in_bins) {
   const int s = st->synth_size, ks = st->k_start;
   if (!xh_size_ok(s) || ks < 0 || ks + s > 64 || ks * 32 + 2 * s > 7 * 64 || 4 * ks + 4 * s > 128) return false;
   if (st->start_band < 0 || st->end_band > 64 || st->max_stretch < 0 || st->max_stretch > 4) return false;
-  if ((float)(pitch_in_bins * 0.08333333333333) >= 1.0f || pitch_in_bins < 0) return false;
+  if (pitch_in_bins < 0 || pitch_in_bins > 127) return false;
   for (int q = 0; q < st->max_stretch && q < 4; q++) {
     if (st->x_over_qmf[q] < 0 || st->x_over_qmf[q] > 64) return false;
     if (q && st->x_over_qmf[q] < st->x_over_qmf[q - 1]) return false;

@@ -45,7 +45,15 @@ int xo_hbe_cplx_anal(xaac_hbe_state *st) {
   return 0;
 }
 
-/* ixheaacd_qmf_hbe_apply (hbe_trans.c:224-296), frames without a pitch.  pv_re / pv_im: [32][64], bands start_band ..
+/* test coverage: how many (band, column) pairs took a cross product, per stretch factor, since the last reset */
+static long xo_hbe_cross_taken[3];
+long xo_hbe_cross_count(int factor, int reset) {
+  const long v = xo_hbe_cross_taken[factor - 2];
+  if (reset) xo_hbe_cross_taken[factor - 2] = 0;
+  return v;
+}
+
+/* ixheaacd_qmf_hbe_apply (hbe_trans.c:224-296).  pv_re / pv_im: [32][64], bands start_band ..
    end_band - 1 written.  Returns 0, or -1 (nothing touched) for parameters xh_apply_params_ok refuses. */
 int xo_hbe_apply(xaac_hbe_state *st, const float *qmf_re, const float *qmf_im, int pitch_in_bins, float *pv_re, float *pv_im) {
   if (!xh_apply_params_ok(st, pitch_in_bins)) return -1;
@@ -65,14 +73,14 @@ int xo_hbe_apply(xaac_hbe_state *st, const float *qmf_re, const float *qmf_im, i
     const XhC v = {st->qmf_in_buf[row][2 * band], st->qmf_in_buf[row][2 * band + 1]};
     return v;
   };
+  const auto inf = [&](int row, int idx) { return (&st->qmf_in_buf[0][0])[128 * row + idx]; };
   for (int qb = 0; qb < 64; qb++) {
     const int f = xh_band_factor(st->x_over_qmf, st->max_stretch, qb);
     if (!f) continue;
-    float blk[16][20];
+    float blk[16][XH_BLK];
     for (int i = 0; i < nb / 2; i++) {
-      if (f == 2) xh_prod2_block(in, qb, i, blk[i]);
-      else if (f == 3) xh_prod3_block(in, qb, i, blk[i]);
-      else xh_prod4_block(in, qb, i, blk[i]);
+      xh_column_block(in, inf, f, qb, i, pitch_in_bins, blk[i]);
+      if (blk[i][24] != 0.0f) xo_hbe_cross_taken[f - 2]++;
     }
     const auto bk = [&](int i) { return (const float *)blk[i]; };
     for (int r = 0; r < 2 * nb; r++)

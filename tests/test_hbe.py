@@ -105,7 +105,7 @@ def test_gpu_chains_match_reference_and_oracle(oracle):
     assert np.array_equal(got_ana[-1], np.frombuffer(bytes(host[-1]), np.uint8))
 
 
-from make_golden_hbe import APPLY_FRAMES, apply_input, state_from_params  # noqa: E402
+from make_golden_hbe import APPLY_FRAMES, APPLY_PITCH, apply_input, state_from_params  # noqa: E402
 
 
 def _oracle_apply(oracle):
@@ -127,7 +127,7 @@ def test_oracle_apply_matches_reference_chains(oracle):
         for f in range(APPLY_FRAMES):
             re, im = apply_input(c, f)
             pv = np.full((2, 32, 64), 7.5, np.float32)
-            assert fn(ctypes.byref(st), re.ctypes.data_as(PF), im.ctypes.data_as(PF), 0, pv[0].ctypes.data_as(PF), pv[1].ctypes.data_as(PF)) == 0
+            assert fn(ctypes.byref(st), re.ctypes.data_as(PF), im.ctypes.data_as(PF), APPLY_PITCH[c], pv[0].ctypes.data_as(PF), pv[1].ctypes.data_as(PF)) == 0
             assert (_crc(bytes(st)), _crc(pv[0]), _crc(pv[1])) == tuple(int(v) for v in GOLD["apply_crc"][c, f]), (c, f)
         assert np.array_equal(pv.view(np.uint32), GOLD["apply_last_pv"][c].view(np.uint32))
 
@@ -141,14 +141,13 @@ def test_gpu_apply_matches_reference_and_oracle(oracle):
     fn = _oracle_apply(oracle)
     pars = GOLD["apply_params"]
     nchain = len(pars)
-    # channels 0..5: the golden chains; 6..11: the same one frame late, after a silent frame (whose analysis rows hold
-    # negative zeros: against the oracle only); 12: a pitch that selects the cross products
-    # (refused); 13: a cross-over band outside the row (refused)
+    # channels 0..8: the golden chains (the last three with a pitch: cross products); 9..17: the same one frame late,
+    # after a silent frame (whose analysis rows hold negative zeros: against the oracle only); 18: a pitch outside its
+    # seven bits (refused); 19: a cross-over band outside the row (refused)
     host = [state_from_params(p) for p in pars] + [state_from_params(p) for p in pars] + [state_from_params(pars[1]), state_from_params(pars[1])]
     host[-1].x_over_qmf[1] = 70
     n = len(host)
-    pitch_np = np.zeros(n, np.int32)
-    pitch_np[nchain * 2] = 14
+    pitch_np = np.array(APPLY_PITCH + APPLY_PITCH + [200, 0], np.int32)
     pitch = torch.from_numpy(pitch_np).to(dev)
     state = _states_tensor(torch, dev, host)
     untouched = [bytes(host[-2]), bytes(host[-1])]
@@ -160,8 +159,9 @@ def test_gpu_apply_matches_reference_and_oracle(oracle):
             if f < APPLY_FRAMES:
                 re[c], im[c] = apply_input(c, f)
             else:
-                re[c] = (rng.standard_normal((32, 64)) * 2.0 ** rng.integers(-4, 16)).astype(np.float32)
-                im[c] = (rng.standard_normal((32, 64)) * 300).astype(np.float32)
+                re[c], im[c] = apply_input(c, 0)
+                re[c] += (rng.standard_normal((32, 64)) * 2.0 ** rng.integers(-4, 8)).astype(np.float32)
+                im[c] *= np.float32(0.5)
             if 1 <= f <= APPLY_FRAMES:
                 re[nchain + c], im[nchain + c] = apply_input(c, f - 1)
         re[-2:], im[-2:] = re[:2], im[:2]
@@ -173,7 +173,7 @@ def test_gpu_apply_matches_reference_and_oracle(oracle):
         assert status.cpu().tolist() == [0] * (2 * nchain) + [-1, -1]
         for c in range(2 * nchain):
             pv = np.full((2, 32, 64), 7.5, np.float32)
-            assert fn(ctypes.byref(host[c]), re[c].ctypes.data_as(PF), im[c].ctypes.data_as(PF), 0, pv[0].ctypes.data_as(PF), pv[1].ctypes.data_as(PF)) == 0
+            assert fn(ctypes.byref(host[c]), re[c].ctypes.data_as(PF), im[c].ctypes.data_as(PF), int(pitch_np[c]), pv[0].ctypes.data_as(PF), pv[1].ctypes.data_as(PF)) == 0
             d = np.nonzero(np.frombuffer(bytes(host[c]), np.uint8) != got[c])[0]
             assert d.size == 0, ("state", f, c, d[:4])
             assert np.array_equal(pv[0].view(np.uint32), g_re[c].view(np.uint32)) and np.array_equal(pv[1].view(np.uint32), g_im[c].view(np.uint32)), ("rows", f, c)

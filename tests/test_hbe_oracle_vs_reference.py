@@ -147,6 +147,46 @@ def test_apply_chain_every_bank_size(oracle, reference, kind):
     assert st.fft_ready == (0 if kind == 4 else 1)  # size 20 never gets its FFT pointers: re-initialised every frame
 
 
+@pytest.mark.parametrize("kind,pitch", [(0, 12), (1, 12), (1, 13), (1, 40), (2, 25), (2, 127), (3, 64), (4, 96), (1, 11)])
+def test_apply_chain_with_a_pitch(oracle, reference, kind, pitch):
+    """pitch_in_bins / 12 >= 1 selects the cross-product variants (hbe_trans.c:1572-1603); 11 stays below"""
+    lo, hi = freq_tables(kind)
+    _apply_chain(oracle, reference, lo, hi, 1200 + 10 * kind + pitch, frames=5, pitch=pitch)
+
+
+def test_apply_chain_with_a_pitch_on_tonal_input(oracle, reference):
+    """tones a pitch apart: the cross products are actually taken (the candidate pair is stronger than the band itself)"""
+    oa, ra, ri = _apply_fns(oracle, reference)
+    lo, hi = freq_tables(1)
+    rng = np.random.default_rng(77)
+    cnt = oracle.lib.xo_hbe_cross_count
+    cnt.restype, cnt.argtypes = ctypes.c_long, [ctypes.c_int, ctypes.c_int]
+    for f in (2, 3, 4):
+        cnt(f, 1)
+    for pitch in (24, 36, 60):
+        so, sr = HbeState(), HbeState()
+        for st in (so, sr):
+            assert ri(lo.ctypes.data_as(P16), len(lo) - 1, hi.ctypes.data_as(P16), len(hi) - 1, ctypes.byref(st)) == 0
+        for frame in range(4):
+            re = (rng.standard_normal((32, 64)) * 3).astype(np.float32)
+            im = (rng.standard_normal((32, 64)) * 3).astype(np.float32)
+            for k in range(1, 9, 2):  # strong core-band tones: the analysis bank spreads them over pairs of sub-bands
+                ph = rng.uniform(0, 6.28)
+                re[:, k] += (4000 * np.cos(ph + 0.9 * k * np.arange(32))).astype(np.float32)
+                im[:, k] += (4000 * np.sin(ph + 0.9 * k * np.arange(32))).astype(np.float32)
+            po = [np.full((32, 64), 7.5, np.float32) for _ in range(2)]
+            pr = [np.full((32, 64), 7.5, np.float32) for _ in range(2)]
+            assert oa(ctypes.byref(so), _p(re), _p(im), pitch, _p(po[0]), _p(po[1])) == 0
+            assert ra(ctypes.byref(sr), lo.ctypes.data_as(P16), len(lo) - 1, hi.ctypes.data_as(P16), len(hi) - 1, _p(re), _p(im),
+                      pitch, _p(pr[0]), _p(pr[1])) == 0
+            assert np.array_equal(bits(so), bits(sr)), (pitch, frame)
+            assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(po, pr))
+    cnt = oracle.lib.xo_hbe_cross_count
+    cnt.restype, cnt.argtypes = ctypes.c_long, [ctypes.c_int, ctypes.c_int]
+    taken = [cnt(f, 1) for f in (2, 3, 4)]
+    assert all(t > 50 for t in taken), taken   # every stretch factor's cross product ran on many (band, column) pairs
+
+
 def test_apply_chain_on_stream_headers(oracle, reference):
     tabs = record_tables()
     assert tabs
@@ -174,7 +214,7 @@ def test_apply_refuses_pitch_frames_and_bad_parameters(oracle, reference):
     assert ri(lo.ctypes.data_as(P16), len(lo) - 1, hi.ctypes.data_as(P16), len(hi) - 1, ctypes.byref(st)) == 0
     z = np.zeros((32, 64), np.float32)
     before = bytes(st)
-    assert oa(ctypes.byref(st), _p(z), _p(z), 12, _p(z.copy()), _p(z.copy())) == -1   # 12 / 12 >= 1: cross products
+    assert oa(ctypes.byref(st), _p(z), _p(z), 128, _p(z.copy()), _p(z.copy())) == -1   # a pitch has seven bits
     st.x_over_qmf[1] = 70
     assert oa(ctypes.byref(st), _p(z), _p(z), 0, _p(z.copy()), _p(z.copy())) == -1
     st.x_over_qmf[1] = 20

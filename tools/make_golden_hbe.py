@@ -77,7 +77,11 @@ def apply_tables():
         out.append((np.array(lo, np.int16), np.array(hi, np.int16)))
     out.append((np.array([15, 17, 19, 21, 23, 26, 29, 33, 37, 41], np.int16),
                 np.array([15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 26, 27, 29, 31, 33, 35, 37, 39, 41], np.int16)))
+    out += [out[1], out[2], out[5]]  # three more chains with a pitch (APPLY_PITCH): the cross-product variants
     return out
+
+
+APPLY_PITCH = [0, 0, 0, 0, 0, 0, 24, 60, 13]
 
 
 def apply_input(chain, frame):
@@ -87,6 +91,13 @@ def apply_input(chain, frame):
     im = (rng.standard_normal((32, 64)) * a).astype(np.float32)
     if frame == 2:
         re[:], im[:] = 0, 0
+    if chain >= 6 and frame != 2:  # the pitch chains: core-band tones, so that cross products are taken
+        re *= np.float32(1e-3)
+        im *= np.float32(1e-3)
+        for k in range(1, 9, 2):
+            ph = rng.uniform(0, 6.28)
+            re[:, k] += (a * np.cos(ph + 0.9 * k * np.arange(32))).astype(np.float32)
+            im[:, k] += (a * np.sin(ph + 0.9 * k * np.arange(32))).astype(np.float32)
     return re, im
 
 
@@ -126,7 +137,7 @@ def run_apply_reference(ref_lib):
             re, im = apply_input(c, f)
             pv = np.full((2, 32, 64), 7.5, np.float32)
             assert fn(ctypes.byref(st), lo.ctypes.data_as(P16), len(lo) - 1, hi.ctypes.data_as(P16), len(hi) - 1,
-                      re.ctypes.data_as(PF), im.ctypes.data_as(PF), 0, pv[0].ctypes.data_as(PF), pv[1].ctypes.data_as(PF)) == 0
+                      re.ctypes.data_as(PF), im.ctypes.data_as(PF), APPLY_PITCH[c], pv[0].ctypes.data_as(PF), pv[1].ctypes.data_as(PF)) == 0
             crcs[c, f] = [crc(st), zlib.crc32(pv[0].tobytes()) & 0xffffffff, zlib.crc32(pv[1].tobytes()) & 0xffffffff]
         last_pv[c] = pv
     return crcs, params, last_pv
