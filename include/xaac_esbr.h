@@ -2,8 +2,8 @@
  * xaac_esbr.h -- boundary formats of the eSBR ("Path A", the reference's default -esbr:1) SBR tool for HE-AAC streams:
  * what ixheaacd_sbr_dec's Path A branch (decoder/ixheaacd_sbr_dec.c:816-1009) reads beyond xaac_sbr_header /
  * xaac_sbr_frame (xaac_sbr.h), and the per-channel state it keeps between frames.
- * Scope: 2:1 SBR of AAC-LC cores (usac_flag = 0), with or without parametric stereo: no harmonic transposer, no PVC, no
- * pre-flattening, no MPS.
+ * Scope: 2:1 SBR of AAC-LC cores (usac_flag = 0), with or without parametric stereo, LPP or harmonic patching (the QMF
+ * transposer of xaac_hbe.h): no PVC, no pre-flattening of LPP patches, no MPS.
  */
 #ifndef XAAC_ESBR_H
 #define XAAC_ESBR_H
@@ -12,6 +12,7 @@
 
 #include "xaac_amd.h"
 #include "xaac_sbr.h"
+#include "xaac_hbe.h"
 
 #define XAAC_ESBR_HIST_ROWS 40 /* op_delay 6 + SBR_HF_ADJ_OFFSET 2 + codec_x_delay 32 rows of qmf_buf_real/_imag kept */
 #define XAAC_ESBR_OUT_HIST_ROWS 8 /* op_delay 6 + SBR_HF_ADJ_OFFSET 2 rows of sbr_qmf_out_real/_imag kept */
@@ -26,11 +27,13 @@ typedef struct xaac_esbr_side {
   int16_t f_master_tbl[XAAC_SBR_MAX_FREQ_COEFFS + 1]; /* freq band data: f_master_tbl */
   int16_t qmf_sb_prev;                                /* freq band data: qmf_sb_prev (sbr_dec.c:314) */
   int16_t reset_flag;                                 /* frame: reset_flag */
-  int16_t pad0_;
+  int16_t harmonic_sbr;                               /* frame: sbr_patching_mode == 0 (ENHSBR payload, env_extr.c:610): the HF
+                                                         generator takes the harmonic transposer's output, not LPP patches */
   int32_t sbr_invf_mode_prev[XAAC_SBR_MAX_NOISE_VALUES]; /* frame: sbr_invf_mode_prev (set by the parser, env_extr.c:834) */
   int32_t inter_temp_shape_mode[XAAC_SBR_MAX_ENVELOPES]; /* frame: inter_temp_shape_mode (0 without inter-TES) */
   float flt_env_sf_arr[XAAC_SBR_MAX_ENV_VALUES];      /* frame: flt_env_sf_arr */
   float flt_noise_floor[XAAC_SBR_MAX_NOISE_VALUES];   /* frame: flt_noise_floor */
+  int32_t pitch_in_bins;                              /* frame: pitch_in_bins (0 unless the ENHSBR payload carries one) */
 } xaac_esbr_side;
 
 /* Per-channel persistent state of the Path A branch. */
@@ -47,6 +50,9 @@ typedef struct xaac_esbr_state {
   int32_t env_short_flag_prev;
   int32_t patch_start_subband[XAAC_SBR_MAX_PATCHES + 1], num_patches; /* frame_data: patch_param */
   int8_t harm_flag_prev[64];
+  int32_t prev_sbr_patching_mode;                     /* frame_data: prev_sbr_patching_mode (0 for a new stream) */
+  float ph_re[XAAC_ESBR_OUT_HIST_ROWS][64], ph_im[XAAC_ESBR_OUT_HIST_ROWS][64]; /* ph_vocod_qmf_real / _imag rows 0..7 after
+                                                         the frame's shift (sbr_dec.c:859-868): the transposer's last rows */
 } xaac_esbr_state;
 
 /* Per-stream persistent state of the float parametric-stereo tool (ia_ps_dec_struct's float members,
@@ -79,6 +85,9 @@ typedef struct xaac_esbr_sbr_batch {
   int32_t *status;                 /* optional [n_ch]: 0, or -1 where the reference returns an error */
   void *workspace;                 /* device scratch >= xaac_esbr_workspace_bytes(n_ch) */
   uint64_t workspace_bytes;
+  xaac_hbe_state *hbe_state;        /* [n_ch] in/out, or NULL: the QMF harmonic transposer (xaac_hbe.h) of every channel,
+                                       run on each processed frame as the reference does for non-USAC streams
+                                       (sbr_dec.c:882-909).  Without it a frame with harmonic_sbr set is refused. */
 } xaac_esbr_sbr_batch;
 
 #ifdef __cplusplus

@@ -71,7 +71,7 @@ class _EsbrSbrBatch(ctypes.Structure):
                 ("frame", ctypes.c_void_p), ("side", ctypes.c_void_p), ("state", ctypes.c_void_p),
                 ("out", ctypes.c_void_p), ("ps_frame", ctypes.c_void_p), ("ps_state", ctypes.c_void_p),
                 ("out_r", ctypes.c_void_p), ("status", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
-                ("workspace_bytes", ctypes.c_uint64)]
+                ("workspace_bytes", ctypes.c_uint64), ("hbe_state", ctypes.c_void_p)]
 
 
 class _HandoverBatch(ctypes.Structure):
@@ -399,11 +399,13 @@ class XaacContext:
         return int(self._lib.xaac_esbr_workspace_bytes(int(n_ch)))
 
     def esbr_sbr_process_batch(self, core, header, frame, side, state, out, workspace, status=None, ps_frame=None,
-                               ps_state=None, out_r=None):
+                               ps_state=None, out_r=None, hbe_state=None):
         """One frame of every channel through the Path A (eSBR, -esbr:1) branch of ixheaacd_sbr_dec, mono / stereo
         channels without PS: core float32[n_ch, 1024]; header / frame / side / state uint8 views of the xaac_sbr_header,
         xaac_sbr_frame, xaac_esbr_side, xaac_esbr_state arrays; out float32[n_ch, 2048].  With ps_frame / ps_state (uint8
-        views of xaac_ps_frame / xaac_esbr_ps_state arrays) / out_r: HE-AACv2 streams, float parametric stereo, out = left."""
+        views of xaac_ps_frame / xaac_esbr_ps_state arrays) / out_r: HE-AACv2 streams, float parametric stereo, out = left.
+        hbe_state (uint8[n_ch, HBE_STATE_BYTES]): the harmonic transposer runs on every frame and frames with harmonic_sbr
+        set take its output."""
         n_ch = out.shape[0]
         b = _EsbrSbrBatch()
         b.n_ch = n_ch
@@ -419,6 +421,7 @@ class XaacContext:
         b.status = _ptr(status, "int32", n_ch, allow_none=True, device_ok=True)
         b.workspace = _ptr(workspace, "uint8", device_ok=True)
         b.workspace_bytes = workspace.numel()
+        b.hbe_state = _ptr(hbe_state, "uint8", n_ch * HBE_STATE_BYTES, allow_none=True, device_ok=True)
         rc = self._lib.xaac_esbr_sbr_process_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_esbr_sbr_process_batch")

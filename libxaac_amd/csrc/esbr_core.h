@@ -99,14 +99,24 @@ FX_HD void xe_shellsort(int32_t *in, int n) { /* esbr_envcal.c:48: any sort give
     in[j] = v;
   }
 }
-FX_HD int xe_limiter_bands(const xaac_sbr_header *h, xaac_esbr_state *st) {
+/* x_over_qmf: the harmonic transposer's cross-over bands, or NULL; with harmonic patching they are the patch borders
+   (esbr_envcal.c:929-941) */
+FX_HD int xe_limiter_bands(const xaac_sbr_header *h, xaac_esbr_state *st, int harmonic, const int32_t *x_over_qmf) {
   const int nb = h->num_sf_bands[0];
   const int16_t *tbl = h->freq_band_tbl_lo;
   const int sb_start = tbl[0], sb_end = tbl[nb];
-  const int num_patches = st->num_patches;
+  int num_patches = st->num_patches;
   int32_t patch_borders[XAAC_SBR_MAX_PATCHES + 2], t[32 + XAAC_SBR_MAX_PATCHES + 1];
   int i;
-  for (i = 0; i < num_patches; i++) patch_borders[i] = st->patch_start_subband[i] - sb_start;
+  if (harmonic && x_over_qmf) {
+    num_patches = 0;
+    for (i = 1; i < 4; i++)
+      if (x_over_qmf[i] != 0) num_patches++;
+    for (i = 0; i < num_patches; i++) patch_borders[i] = x_over_qmf[i] - sb_start;
+  } else {
+    if (num_patches < 0 || num_patches > XAAC_SBR_MAX_PATCHES) return -1;
+    for (i = 0; i < num_patches; i++) patch_borders[i] = st->patch_start_subband[i] - sb_start;
+  }
   patch_borders[i] = sb_end - sb_start;
   st->lim_table[0][0] = tbl[0] - sb_start;
   st->lim_table[0][1] = tbl[nb] - sb_start;
@@ -253,8 +263,105 @@ FX_HD void xe_patch_bw_index(const XsCx &cx, const xaac_sbr_header *h, XeWork *w
   }
 }
 
+/* covariance of band k over 38 slots from row -2 on (ixheaacd_esbr_calc_co_variance, sbrdec_lpfuncs.c:781) and the
+   second-order prediction coefficients of :1077-1120 */
+FX_HD void xe_covar_alpha(const XeMat &src, int k, float &a0r, float &a0i, float &a1r, float &a1i) {
+  a0r = a0i = a1r = a1i = 0;
+  float p01r = 0, p01i = 0, p02r = 0, p02i = 0, p11 = 0, p12r = 0, p12i = 0, p22 = 0;
+  float r2 = src.r(-2, k), i2 = src.i(-2, k), r1 = src.r(-1, k), i1 = src.i(-1, k);
+  XE_NOUNROLL
+  for (int j0 = 0; j0 < 38; j0 += XE_CH) {
+    float cr[XE_CH] = {0}, ci[XE_CH] = {0};
+    xe_rows_load(src, k, j0, 38, cr, ci);
+    XE_UNROLL
+    for (int jj = 0; jj < XE_CH; jj++) if (j0 + jj < 38) {
+    const float r0 = cr[jj], i0 = ci[jj];
+    p01r += r0 * r1 + i0 * i1;
+    p01i += i0 * r1 - r0 * i1;
+    p02r += r0 * r2 + i0 * i2;
+    p02i += i0 * r2 - r0 * i2;
+    p11 += r1 * r1 + i1 * i1;
+    p12r += r1 * r2 + i1 * i2;
+    p12i += i1 * r2 - r1 * i2;
+    p22 += r2 * r2 + i2 * i2;
+    r2 = r1; i2 = i1;
+    r1 = r0; i1 = i0;
+    }
+  }
+  const float det = p11 * p22 - (p12r * p12r + p12i * p12i) * 0.999999f;
+  if (det != 0.0f) {
+    const float fac = 1.0f / det;
+    a1r = (p01r * p12r - p01i * p12i - p02r * p11) * fac;
+    a1i = (p01i * p12r + p01r * p12i - p02i * p11) * fac;
+  }
+  if (p11 != 0) {
+    const float fac = 1.0f / p11;
+    a0r = -(p01r + a1r * p12r + a1i * p12i) * fac;
+    a0i = -(p01i + a1i * p12r - a1r * p12i) * fac;
+  }
+  if (a0r * a0r + a0i * a0i >= 16.0f || a1r * a1r + a1i * a1i >= 16.0f) a0r = a0i = a1r = a1i = 0.0f;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define XE_NOINLINE __attribute__((noinline)) /* rare paths stay out of the hot kernel's register budget */
+#else
+#define XE_NOINLINE
+#endif
+/* sbrdec_lpfuncs.c:1251-1352, harmonic patching: every high band is the transposer's band, inverse-filtered with its own
+   prediction coefficients */
+XE_NOINLINE FX_HD void xe_harmonic_patch(const XsCx &cx, const xaac_sbr_header *h, xaac_esbr_state *st, XeWork *w,
+                                         const XeMat &dst, const XeMat &ph, int start, int end, int usb, int num_if) {
+  /* sbrdec_lpfuncs.c:1251-1344: every high band is the transposer's band, inverse-filtered with its own prediction
+     coefficients; the chirp factor by the noise-floor band the band lies in (a running index in the reference, which
+     gives up at the table's fifth entry) */
+  cx.sync();
+  if (w->err) return;
+  XS_PAR(k2, h->sub_band_start, usb) {
+    float c0r, c0i, c1r, c1i;
+    xe_covar_alpha(ph, k2, c0r, c0i, c1r, c1i);
+    int bw_index = 0;
+    while (bw_index < 5 && k2 >= h->freq_band_tbl_noise[1 + bw_index]) bw_index++;
+    if (bw_index >= 5) {
+      w->err = -1;
+    } else {
+      float bw = w->bw_array[bw_index];
+      const float a0r = bw * c0r, a0i = bw * c0i;
+      bw *= bw;
+      const float a1r = bw * c1r, a1i = bw * c1i;
+      float r2 = ph.r(start - 2, k2), i2 = ph.i(start - 2, k2), r1 = ph.r(start - 1, k2), i1 = ph.i(start - 1, k2);
+      XE_NOUNROLL
+      for (int l0 = start; l0 < end; l0 += XE_CH) {
+        float cr[XE_CH] = {0}, ci[XE_CH] = {0};
+        xe_rows_load(ph, k2, l0, end, cr, ci);
+        XE_UNROLL
+        for (int j = 0; j < XE_CH; j++)
+          if (l0 + j < end) {
+            const float r0 = cr[j], i0 = ci[j];
+            float yr = r0, yi = i0;
+            if (bw > 0.0f) {
+              yr += ((a0r * r1 - a0i * i1) + (a1r * r2 - a1i * i2));
+              yi += ((a0i * r1 + a0r * i1) + (a1i * r2 + a1r * i2));
+            }
+            cr[j] = yr;
+            ci[j] = yi;
+            r2 = r1; i2 = i1;
+            r1 = r0; i1 = i0;
+          }
+        xe_rows_store(dst, k2, l0, end, cr, ci);
+      }
+    }
+  }
+  cx.sync();
+  if (w->err) return;
+  XS_ONE st->num_patches = 1; /* :1345-1352: patch = 1 on this path */
+  XS_PAR(i, 0, num_if) st->bw_array_prev[i] = w->bw_array[i];
+  cx.sync();
+  return;
+}
+
 FX_HD void xe_generate_hf(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
-                          xaac_esbr_state *st, XeWork *w, const XeMat &src, const XeMat &dst) {
+                          xaac_esbr_state *st, XeWork *w, const XeMat &src, const XeMat &dst,
+                          const XeMat *ph = nullptr /* ph_vocod_qmf rows (row 0 = the reference's + 2), harmonic patching */) {
   const int start = 2 * f->border_vec[0], end = 32 + 2 * (f->border_vec[f->num_env] - 16);
   const int lsb = sd->f_master_tbl[0], usb = sd->f_master_tbl[sd->num_mf_bands];
   const int num_if = h->num_nf_bands;
@@ -272,50 +379,21 @@ FX_HD void xe_generate_hf(const XsCx &cx, const xaac_sbr_header *h, const xaac_s
   }
   XS_ONE {
     w->err = 0;
-    xe_build_patches(h, sd, st, w);
+    if (!sd->harmonic_sbr) xe_build_patches(h, sd, st, w);
+    else if (!ph) w->err = -1; /* no transposer behind this channel */
   }
   XS_PAR(k, usb, 64)
     for (int l = start; l < end; l++) {
       dst.r(l, k) = 0.0f;
       dst.i(l, k) = 0.0f;
     }
+  if (sd->harmonic_sbr) {
+    xe_harmonic_patch(cx, h, st, w, dst, *ph, start, end, usb, num_if);
+    return;
+  }
   XS_PAR(k, 0, 64) {
     float a0r = 0, a0i = 0, a1r = 0, a1i = 0;
-    if (k >= 1 && k < lsb) { /* covariance over 38 slots from row -2 on, :781; prediction coefficients :1077-1120 */
-      float p01r = 0, p01i = 0, p02r = 0, p02i = 0, p11 = 0, p12r = 0, p12i = 0, p22 = 0;
-      float r2 = src.r(-2, k), i2 = src.i(-2, k), r1 = src.r(-1, k), i1 = src.i(-1, k);
-      XE_NOUNROLL
-      for (int j0 = 0; j0 < 38; j0 += XE_CH) {
-        float cr[XE_CH] = {0}, ci[XE_CH] = {0};
-        xe_rows_load(src, k, j0, 38, cr, ci);
-        XE_UNROLL
-        for (int jj = 0; jj < XE_CH; jj++) if (j0 + jj < 38) {
-        const float r0 = cr[jj], i0 = ci[jj];
-        p01r += r0 * r1 + i0 * i1;
-        p01i += i0 * r1 - r0 * i1;
-        p02r += r0 * r2 + i0 * i2;
-        p02i += i0 * r2 - r0 * i2;
-        p11 += r1 * r1 + i1 * i1;
-        p12r += r1 * r2 + i1 * i2;
-        p12i += i1 * r2 - r1 * i2;
-        p22 += r2 * r2 + i2 * i2;
-        r2 = r1; i2 = i1;
-        r1 = r0; i1 = i0;
-        }
-      }
-      const float det = p11 * p22 - (p12r * p12r + p12i * p12i) * 0.999999f;
-      if (det != 0.0f) {
-        const float fac = 1.0f / det;
-        a1r = (p01r * p12r - p01i * p12i - p02r * p11) * fac;
-        a1i = (p01i * p12r + p01r * p12i - p02i * p11) * fac;
-      }
-      if (p11 != 0) {
-        const float fac = 1.0f / p11;
-        a0r = -(p01r + a1r * p12r + a1i * p12i) * fac;
-        a0i = -(p01i + a1i * p12r - a1r * p12i) * fac;
-      }
-      if (a0r * a0r + a0i * a0i >= 16.0f || a1r * a1r + a1i * a1i >= 16.0f) a0r = a0i = a1r = a1i = 0.0f;
-    }
+    if (k >= 1 && k < lsb) xe_covar_alpha(src, k, a0r, a0i, a1r, a1i);
     w->alpha_r[k][0] = a0r; w->alpha_i[k][0] = a0i;
     w->alpha_r[k][1] = a1r; w->alpha_i[k][1] = a1i;
   }
@@ -437,7 +515,8 @@ FX_HD void xe_inter_tes(const XsCx &cx, XeWork *w, const XeMat &low, const XeMat
 
 /* ---- ixheaacd_sbr_env_calc, ORIG_SBR ------------------------------------------------------------------------------- */
 FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
-                      xaac_esbr_state *st, XeWork *w, const XeMat &x /* sbr_qmf_out */, const XeMat &low /* qmf_buf */) {
+                      xaac_esbr_state *st, XeWork *w, const XeMat &x /* sbr_qmf_out */, const XeMat &low /* qmf_buf */,
+                      const int32_t *x_over_qmf = nullptr /* the transposer's, where the host tracks one */) {
   const int sb_start = h->sub_band_start, num_sb = h->sub_band_end - h->sub_band_start;
   const int num_env = f->num_env, trans_env = f->transient_env, num_nf = h->num_nf_bands;
   const int smoothing_length = h->smoothing_mode ? 0 : 4, int_mode = h->interpol_freq;
@@ -448,9 +527,22 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
   if (sd->reset_flag) {
     start_up = 1;
     phase_index = 0;
-    XS_ONE w->err = xe_limiter_bands(h, st);
+    XS_ONE w->err = xe_limiter_bands(h, st, sd->harmonic_sbr != 0, x_over_qmf);
     cx.sync();
     if (w->err) return -1;
+  }
+  {
+    const int mode = sd->harmonic_sbr ? 0 : 1; /* sbr_patching_mode; esbr_envcal.c:181-190 */
+    const int changed = mode != st->prev_sbr_patching_mode;
+    cx.sync();
+    if (changed) {
+      XS_ONE {
+        w->err = xe_limiter_bands(h, st, sd->harmonic_sbr != 0, x_over_qmf);
+        if (!w->err) st->prev_sbr_patching_mode = mode;
+      }
+      cx.sync();
+      if (w->err) return -1;
+    }
   }
   XS_ONE {
     w->err = 0;

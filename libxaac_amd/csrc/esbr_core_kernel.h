@@ -9,7 +9,8 @@
 
 #define XAAC_ESBR_OUT_ROWS 42                                   /* 8 history + 32 + 2 rows a VARVAR frame can reach */
 #define XAAC_ESBR_L_ROWS 38                                     /* 32 regrouped rows + the 6 look-ahead rows of the PS hybrid filter */
-#define XAAC_ESBR_WS_FLOATS (2 * 2048 + 2 * XAAC_ESBR_OUT_ROWS * 64 + 2 * XAAC_ESBR_L_ROWS * 64 + 2 * 2048) /* analysis rows, sbr_qmf_out, left rows, right rows */
+#define XAAC_ESBR_PH_ROWS 40                                    /* ph_vocod_qmf: 8 history rows + the transposer's 32 */
+#define XAAC_ESBR_WS_FLOATS (2 * 2048 + 2 * XAAC_ESBR_OUT_ROWS * 64 + 2 * XAAC_ESBR_L_ROWS * 64 + 2 * 2048 + 2 * XAAC_ESBR_PH_ROWS * 64) /* analysis rows, sbr_qmf_out, left rows, right rows, transposer rows */
 
 typedef struct XaacEsbrCoreParams {
   int32_t n_ch;
@@ -23,6 +24,8 @@ typedef struct XaacEsbrCoreParams {
 
   int32_t with_ps;
   int32_t *status;
+  const xaac_hbe_state *hbe;    /* [n_ch] or NULL: the channels' harmonic transposers, already run on this frame */
+  float *ph_re, *ph_im;         /* [n_ch][40][64] scratch: ph_vocod_qmf (rows 8..39 written by the transposer) */
 } XaacEsbrCoreParams;
 
 #ifdef __cplusplus

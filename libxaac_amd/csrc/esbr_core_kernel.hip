@@ -30,6 +30,7 @@ __shared__ long long xe_prof_acc[16];
 __shared__ float xe_lds_random_phase[1024];
 #define XE_RANDOM_PHASE(i) xe_lds_random_phase[i]
 #include "esbr_core.h"
+#include "hbe_trans.h" /* xh_apply_params_ok */
 #include "esbr_core_kernel.h"
 
 namespace {
@@ -102,11 +103,40 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
   if (sd->qmf_sb_prev >= 0 && sd->qmf_sb_prev <= 64) xe_hbe_history_clear(cx, st, sd->qmf_sb_prev);
   XE_T(1);
   const XeMat src = {&st->qmf_re[0][0] + 128, &st->qmf_im[0][0] + 128}, dst = {ore + 128, oim + 128};
+  /* the harmonic transposer's rows (sbr_dec.c:859-868): its launches wrote rows 8..39 of the scratch matrix for this frame
+     if the channel has one with usable parameters; rows 0..7 are the previous frame's last rows */
+  float *phr = p.ph_re + (size_t)ch * XAAC_ESBR_PH_ROWS * 64, *phi = p.ph_im + (size_t)ch * XAAC_ESBR_PH_ROWS * 64;
+  const bool have_ph = p.hbe && apply && xh_apply_params_ok(p.hbe + ch, sd->pitch_in_bins);
+  if (have_ph) {
+    float t0[8], t1[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      t0[r] = st->ph_re[r][lane];
+      t1[r] = st->ph_im[r][lane];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      phr[64 * r + lane] = t0[r];
+      phi[64 * r + lane] = t1[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      t0[r] = phr[64 * (32 + r) + lane];
+      t1[r] = phi[64 * (32 + r) + lane];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      st->ph_re[r][lane] = t0[r];
+      st->ph_im[r][lane] = t1[r];
+    }
+    __syncthreads();
+  }
+  const XeMat ph = {phr + 128, phi + 128};
   if (apply && rc == 0) {
-    xe_generate_hf(cx, h, f, sd, st, &w, src, dst);
+    xe_generate_hf(cx, h, f, sd, st, &w, src, dst, have_ph ? &ph : nullptr);
     __syncthreads();
     XE_T(2);
-    rc = w.err ? -1 : xe_env_calc(cx, h, f, sd, st, &w, dst, src);
+    rc = w.err ? -1 : xe_env_calc(cx, h, f, sd, st, &w, dst, src, have_ph ? p.hbe[ch].x_over_qmf : nullptr);
   }
   __syncthreads();
   XE_T(3);

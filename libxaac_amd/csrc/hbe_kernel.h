@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
+#include "../../include/xaac_esbr.h"
 #include "../../include/xaac_hbe.h"
 
 #define XAAC_HBE_SYN_LDS ((41 * 40 + 32 * 265) * 4) /* v of 9 + 32 columns; 32 lanes' transform scratch (odd stride) */
@@ -18,6 +19,11 @@ typedef struct XaacHbeSynParams {
   const int32_t *pitch;         /* apply mode: [n_ch] or NULL */
   int32_t apply;                /* 1: as the first step of ixheaacd_qmf_hbe_apply (time-signal shift, the re-initialisation
                                    while fft_ready is 0, the frame's parameter check) */
+  /* inside the Path A chain (xaac_esbr_sbr_process_batch): the pitch comes from the side info and a channel whose
+     frame has no SBR processing is skipped (sbr_dec.c:882); NULL elsewhere */
+  const xaac_sbr_frame *frame;
+  const xaac_esbr_side *side;
+  int32_t in_stride;            /* floats between consecutive channels' qmf rows (2048 unless the chain hands in its own) */
 } XaacHbeSynParams;
 
 typedef struct XaacHbeAnaParams {
@@ -26,6 +32,8 @@ typedef struct XaacHbeAnaParams {
   int32_t *status;
   const int32_t *pitch;
   int32_t apply;                /* 1: second step of the apply chain (qmf_in_buf rows moved down first) */
+  const xaac_sbr_frame *frame;  /* as in XaacHbeSynParams */
+  const xaac_esbr_side *side;
 } XaacHbeAnaParams;
 
 #define XAAC_HBE_POST_THREADS 256
@@ -35,6 +43,11 @@ typedef struct XaacHbePostParams {
   xaac_hbe_state *state;
   const int32_t *pitch;
   float *pv_re, *pv_im;         /* [n_ch][32][64] */
+  const xaac_sbr_frame *frame;  /* as in XaacHbeSynParams */
+  const xaac_esbr_side *side;
+  int32_t pv_stride;            /* floats between consecutive channels' output rows (2048 standalone) */
+  int32_t zero_outside;         /* 1: bands outside start_band .. end_band - 1 of the 32 rows are written as zeros (the chain's
+                                   scratch rows; the reference leaves whatever its buffer held) */
 } XaacHbePostParams;
 
 #ifdef __cplusplus

@@ -18,14 +18,23 @@
 #include "hbe_trans.h"
 #include "hbe_kernel.h"
 
+namespace {
+/* the frame's pitch and whether the channel takes part (inside the Path A chain both come from the side info / frame) */
+__device__ __forceinline__ int hbe_pitch(const int32_t *pitch, const xaac_esbr_side *side, int ch) {
+  return side ? side[ch].pitch_in_bins : (pitch ? pitch[ch] : 0);
+}
+__device__ __forceinline__ bool hbe_skip(const xaac_sbr_frame *frame, int ch) { return frame && !frame[ch].apply_processing; }
+}  // namespace
+
 __global__ __launch_bounds__(64) void xaac_hbe_synth_kernel(XaacHbeSynParams p) {
   extern __shared__ float lds[];
   float(*vv)[40] = reinterpret_cast<float(*)[40]>(lds); /* [9 + 32][2 s <= 40] */
   float *scr = lds + 41 * 40;
   const int ch = blockIdx.x, lane = threadIdx.x;
   xaac_hbe_state *st = p.state + ch;
+  if (hbe_skip(p.frame, ch)) return;
   const int s = st->synth_size, ks = st->k_start, nc = p.num_columns;
-  const bool bad = p.apply ? !xh_apply_params_ok(st, p.pitch ? p.pitch[ch] : 0)
+  const bool bad = p.apply ? !xh_apply_params_ok(st, hbe_pitch(p.pitch, p.side, ch))
                            : (!xh_size_ok(s) || ks < 0 || ks + s > 64 || ks * 32 + 2 * s > 7 * 64 || nc < 0 || nc > 32);
   if (lane == 0 && p.status) p.status[ch] = bad ? -1 : 0;
   if (bad) return;
@@ -43,8 +52,8 @@ __global__ __launch_bounds__(64) void xaac_hbe_synth_kernel(XaacHbeSynParams p) 
     vv[c + 9][t] = cleared ? 0.0f : xh_synth_hist(st->synth_buf, s, c, t);
   }
   if (lane < nc)
-    xh_synth_column(p.qmf_re + ((size_t)ch * nc + lane) * 64, p.qmf_im + ((size_t)ch * nc + lane) * 64, s, ks, vv[lane + 9],
-                    scr + lane * 265);
+    xh_synth_column(p.qmf_re + (size_t)ch * p.in_stride + lane * 64, p.qmf_im + (size_t)ch * p.in_stride + lane * 64, s, ks,
+                    vv[lane + 9], scr + lane * 265);
   __syncthreads();
   const auto at = [&](int c, int t) { return vv[c + 9][t]; };
   for (int o = lane; o < nc * s; o += 64) st->input_buf[s + o] = xh_synth_out(at, s, o / s, o % s);
@@ -62,8 +71,9 @@ __global__ __launch_bounds__(64) void xaac_hbe_anal_kernel(XaacHbeAnaParams p) {
   float *scr = lds + 16 * 80 + 16 * 80;
   const int ch = blockIdx.x, lane = threadIdx.x;
   xaac_hbe_state *st = p.state + ch;
+  if (hbe_skip(p.frame, ch)) return;
   const int s = st->synth_size, ks = st->k_start, a = 2 * s;
-  const bool bad = p.apply ? !xh_apply_params_ok(st, p.pitch ? p.pitch[ch] : 0) : (!xh_size_ok(s) || ks < 0 || 4 * ks + 2 * a > 128);
+  const bool bad = p.apply ? !xh_apply_params_ok(st, hbe_pitch(p.pitch, p.side, ch)) : (!xh_size_ok(s) || ks < 0 || 4 * ks + 2 * a > 128);
   if (lane == 0 && p.status && !p.apply) p.status[ch] = bad ? -1 : 0;
   if (bad) return;
   constexpr int NCOL = XAAC_HBE_NO_BINS / 2;
@@ -100,12 +110,13 @@ __global__ __launch_bounds__(XAAC_HBE_POST_THREADS) void xaac_hbe_post_kernel(Xa
   float(*blk)[XH_BLK] = reinterpret_cast<float(*)[XH_BLK]>(lds); /* [16 bands x 16 columns]: xh_column_block */
   const int ch = blockIdx.x, tid = threadIdx.x;
   xaac_hbe_state *st = p.state + ch;
-  const int pitch = p.pitch ? p.pitch[ch] : 0;
+  if (hbe_skip(p.frame, ch)) return;
+  const int pitch = hbe_pitch(p.pitch, p.side, ch);
   if (!xh_apply_params_ok(st, pitch)) return;
   const int ms = st->max_stretch, sb0 = st->start_band, sb1 = st->end_band;
   int32_t xo[4];
   for (int q = 0; q < 4; q++) xo[q] = st->x_over_qmf[q];
-  float *pv_re = p.pv_re + (size_t)ch * 2048, *pv_im = p.pv_im + (size_t)ch * 2048;
+  float *pv_re = p.pv_re + (size_t)ch * p.pv_stride, *pv_im = p.pv_im + (size_t)ch * p.pv_stride;
   const auto in = [&](int row, int band) {
     const float2 v = *reinterpret_cast<const float2 *>(&st->qmf_in_buf[row][2 * band]);
     const XhC c = {v.x, v.y};
@@ -136,6 +147,9 @@ __global__ __launch_bounds__(XAAC_HBE_POST_THREADS) void xaac_hbe_post_kernel(Xa
         if (!half && qb >= sb0 && qb < sb1) {
           pv_re[64 * r + qb] = (float)(v.x * xaac_hbe_pv_cos[qb] - v.y * xaac_hbe_pv_sin[qb]);
           pv_im[64 * r + qb] = (float)(v.x * xaac_hbe_pv_sin[qb] + v.y * xaac_hbe_pv_cos[qb]);
+        } else if (!half && p.zero_outside) {
+          pv_re[64 * r + qb] = 0.0f;
+          pv_im[64 * r + qb] = 0.0f;
         }
       }
       __syncthreads(); /* rows 32..63 are overwritten only after every row below has taken its start value from them */

@@ -17,14 +17,21 @@ void xo_esbr_synthesis(const float *re, const float *im, int32_t *ring, int32_t 
 
 /* the two float stages alone, on the reference's own buffers: qmf / out = qmf_buf_real.. / sbr_qmf_out_real.. as
    [rows][64] arrays starting at the reference's row 0 (the stages work from row SBR_HF_ADJ_OFFSET = 2) */
-int xo_esbr_hf_env(const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd, xaac_esbr_state *st,
-                   float *qmf_re, float *qmf_im, float *out_re, float *out_im) {
+/* ph_re / ph_im: the harmonic transposer's rows [40][64] from the reference's row 0, and its cross-over bands, or NULL */
+int xo_esbr_hf_env_h(const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd, xaac_esbr_state *st,
+                     float *qmf_re, float *qmf_im, float *out_re, float *out_im, float *ph_re, float *ph_im,
+                     const int32_t *x_over_qmf) {
   static thread_local XeWork w;
   const XsCx cx = {0, 1};
   const XeMat src = {qmf_re + 128, qmf_im + 128}, dst = {out_re + 128, out_im + 128};
-  xe_generate_hf(cx, h, f, sd, st, &w, src, dst);
+  const XeMat ph = {ph_re ? ph_re + 128 : nullptr, ph_im ? ph_im + 128 : nullptr};
+  xe_generate_hf(cx, h, f, sd, st, &w, src, dst, ph_re ? &ph : nullptr);
   if (w.err) return -1;
-  return xe_env_calc(cx, h, f, sd, st, &w, dst, src);
+  return xe_env_calc(cx, h, f, sd, st, &w, dst, src, ph_re ? x_over_qmf : nullptr);
+}
+int xo_esbr_hf_env(const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd, xaac_esbr_state *st,
+                   float *qmf_re, float *qmf_im, float *out_re, float *out_im) {
+  return xo_esbr_hf_env_h(h, f, sd, st, qmf_re, qmf_im, out_re, out_im, nullptr, nullptr, nullptr);
 }
 
 /* the float parametric-stereo tool alone: l_* [38][64], r_* [32][64] */
@@ -39,6 +46,10 @@ int xo_esbr_apply_ps(const xaac_ps_frame *pf, xaac_esbr_ps_state *st, float *l_r
 /* one frame of one channel: core 1024 floats in, out 2048 floats */
 int xo_esbr_sbr_frame_ps(const float *core, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
                          xaac_esbr_state *st, const xaac_ps_frame *pf, xaac_esbr_ps_state *pst, float *out, float *out_r);
+int xo_esbr_sbr_frame_hbe(const float *core, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
+                          xaac_esbr_state *st, const xaac_ps_frame *pf, xaac_esbr_ps_state *pst, float *out, float *out_r,
+                          xaac_hbe_state *hst);
+int xo_hbe_apply(xaac_hbe_state *st, const float *qmf_re, const float *qmf_im, int pitch_in_bins, float *pv_re, float *pv_im);
 
 int xo_esbr_sbr_frame(const float *core, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
                       xaac_esbr_state *st, float *out) {
@@ -48,6 +59,15 @@ int xo_esbr_sbr_frame(const float *core, const xaac_sbr_header *h, const xaac_sb
 /* ... and of one HE-AACv2 stream when pf / pst / out_r are given: float PS between regrouping and two synthesis banks */
 int xo_esbr_sbr_frame_ps(const float *core, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
                          xaac_esbr_state *st, const xaac_ps_frame *pf, xaac_esbr_ps_state *pst, float *out, float *out_r) {
+  return xo_esbr_sbr_frame_hbe(core, h, f, sd, st, pf, pst, out, out_r, nullptr);
+}
+
+/* ... with the channel's harmonic transposer (hst, or NULL): it runs on every processed frame (sbr_dec.c:882-909) and a
+   frame with harmonic_sbr set takes the HF generator's input from it */
+int xo_esbr_sbr_frame_hbe(const float *core, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
+                          xaac_esbr_state *st, const xaac_ps_frame *pf, xaac_esbr_ps_state *pst, float *out, float *out_r,
+                          xaac_hbe_state *hst) {
+  static thread_local float phr[40][64], phi[40][64];
   static thread_local float qre[XAAC_ESBR_ROWS][64], qim[XAAC_ESBR_ROWS][64], ore[42][64], oim[42][64];
   static thread_local float rre[38][64], rim[38][64], xre[32][64], xim[32][64];
   int rc = 0;
@@ -64,8 +84,23 @@ int xo_esbr_sbr_frame_ps(const float *core, const xaac_sbr_header *h, const xaac
   memcpy(ore, st->out_re, sizeof(st->out_re));
   memcpy(oim, st->out_im, sizeof(st->out_im));
   xo_esbr_analysis(core, st->ana.ring, &st->ana.pos, &st->ana.win_off, &qre[XAAC_ESBR_HIST_ROWS][0], &qim[XAAC_ESBR_HIST_ROWS][0]);
+  bool have_ph = false;
+  if (hst && f->apply_processing) { /* sbr_dec.c:882-909: the frame's 32 new analysis rows through the transposer */
+    memcpy(phr, st->ph_re, sizeof(st->ph_re));
+    memcpy(phi, st->ph_im, sizeof(st->ph_im));
+    memset(phr + 8, 0, sizeof(float) * 32 * 64);
+    memset(phi + 8, 0, sizeof(float) * 32 * 64);
+    have_ph = xo_hbe_apply(hst, &qre[XAAC_ESBR_HIST_ROWS][0], &qim[XAAC_ESBR_HIST_ROWS][0], sd->pitch_in_bins, &phr[8][0], &phi[8][0]) == 0;
+    if (have_ph) {
+      memcpy(st->ph_re, phr + 32, sizeof(st->ph_re));
+      memcpy(st->ph_im, phi + 32, sizeof(st->ph_im));
+    }
+  }
   if (f->apply_processing) { /* a refused or failed frame still runs the banks and the history shift, like the kernel */
-    rc = xe_side_info_bad(h, f, sd) ? -1 : xo_esbr_hf_env(h, f, sd, st, &qre[0][0], &qim[0][0], &ore[0][0], &oim[0][0]);
+    rc = xe_side_info_bad(h, f, sd) ? -1
+                                    : xo_esbr_hf_env_h(h, f, sd, st, &qre[0][0], &qim[0][0], &ore[0][0], &oim[0][0],
+                                                       have_ph ? &phr[0][0] : nullptr, have_ph ? &phi[0][0] : nullptr,
+                                                       hst ? hst->x_over_qmf : nullptr);
   } else {
     memset(ore, 0, sizeof(ore));
     memset(oim, 0, sizeof(oim));

@@ -9,8 +9,11 @@
 #include "ref_convert.h"
 #include "xaac_esbr.h"
 
-int ref_esbr_hf_env(const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd, xaac_esbr_state *st,
-                    float *qmf_re, float *qmf_im, float *out_re, float *out_im) {
+/* ph_re / ph_im: the transposer's rows ([40][64], row 2 = the reference's + SBR_HF_ADJ_OFFSET) and its cross-over bands,
+   or NULL (then hbe_flag is 0 as for a USAC stream without harmonic SBR) */
+int ref_esbr_hf_env_h(const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd, xaac_esbr_state *st,
+                      float *qmf_re, float *qmf_im, float *out_re, float *out_im, float *ph_re, float *ph_im,
+                      const int32_t *x_over_qmf) {
   static __thread ia_freq_band_data_struct fb;
   static __thread ia_sbr_header_data_struct hd;
   static __thread ia_sbr_frame_info_data_struct fd;
@@ -64,8 +67,10 @@ int ref_esbr_hf_env(const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaa
   for (i = 0; i < XAAC_SBR_MAX_ENV_VALUES; i++) fd.flt_env_sf_arr[i] = sd->flt_env_sf_arr[i];
   for (i = 0; i < XAAC_SBR_MAX_ENVELOPES; i++) fd.inter_temp_shape_mode[i] = sd->inter_temp_shape_mode[i];
   fd.env_short_flag_prev = st->env_short_flag_prev;
-  fd.sbr_patching_mode = 1;
-  fd.prev_sbr_patching_mode = 1;
+  fd.sbr_patching_mode = sd->harmonic_sbr ? 0 : 1;
+  fd.prev_sbr_patching_mode = st->prev_sbr_patching_mode;
+  fd.pitch_in_bins = sd->pitch_in_bins;
+  hd.hbe_flag = ph_re != NULL;
   fd.sbr_mode = ORIG_SBR;
   fd.prev_sbr_mode = ORIG_SBR;
   fd.reset_flag = sd->reset_flag;
@@ -80,11 +85,18 @@ int ref_esbr_hf_env(const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaa
   fd.patch_param.num_patches = st->num_patches;
   for (i = 0; i <= XAAC_SBR_MAX_PATCHES; i++) fd.patch_param.start_subband[i] = st->patch_start_subband[i];
 
-  rc = ixheaacd_generate_hf((FLOAT32(*)[64])(qmf_re + 128), (FLOAT32(*)[64])(qmf_im + 128), NULL, NULL,
+  rc = ixheaacd_generate_hf((FLOAT32(*)[64])(qmf_re + 128), (FLOAT32(*)[64])(qmf_im + 128),
+                            ph_re ? (FLOAT32(*)[64])(ph_re + 128) : NULL, ph_im ? (FLOAT32(*)[64])(ph_im + 128) : NULL,
                             (FLOAT32(*)[64])(out_re + 128), (FLOAT32(*)[64])(out_im + 128), &fd, &hd, 0, 32, 0);
-  if (rc == 0)
+  if (rc == 0) {
+    WORD32 xo[MAX_NUM_PATCHES] = {0};
+    if (x_over_qmf)
+      for (i = 0; i < MAX_NUM_PATCHES; i++) xo[i] = x_over_qmf[i];
     rc = ixheaacd_sbr_env_calc(&fd, (FLOAT32(*)[64])(out_re + 128), (FLOAT32(*)[64])(out_im + 128),
-                               (FLOAT32(*)[64])(qmf_re + 128), (FLOAT32(*)[64])(qmf_im + 128), NULL, scratch, env_out, 0, 0);
+                               (FLOAT32(*)[64])(qmf_re + 128), (FLOAT32(*)[64])(qmf_im + 128),
+                               (hd.hbe_flag && x_over_qmf) ? xo : NULL, scratch, env_out, 0, 0);
+  }
+  st->prev_sbr_patching_mode = fd.prev_sbr_patching_mode;
 
   st->env_short_flag_prev = fd.env_short_flag_prev;
   st->harm_index = fd.harm_index;
@@ -99,6 +111,11 @@ int ref_esbr_hf_env(const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaa
   st->num_patches = fd.patch_param.num_patches;
   for (i = 0; i <= XAAC_SBR_MAX_PATCHES; i++) st->patch_start_subband[i] = fd.patch_param.start_subband[i];
   return rc ? -1 : 0;
+}
+
+int ref_esbr_hf_env(const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd, xaac_esbr_state *st,
+                    float *qmf_re, float *qmf_im, float *out_re, float *out_im) {
+  return ref_esbr_hf_env_h(h, f, sd, st, qmf_re, qmf_im, out_re, out_im, NULL, NULL, NULL);
 }
 
 /* ---- float parametric stereo (ixheaacd_esbr_apply_ps, decoder/ixheaacd_ps_dec_flt.c:389) ---------------------------- */

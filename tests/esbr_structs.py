@@ -6,8 +6,8 @@ I8, I16, I32, F32 = ctypes.c_int8, ctypes.c_int16, ctypes.c_int32, ctypes.c_floa
 
 class EsbrSide(ctypes.Structure):
     _fields_ = [("out_sampling_freq", I32), ("limiter_bands", I16), ("num_mf_bands", I16), ("f_master_tbl", I16 * 57),
-                ("qmf_sb_prev", I16), ("reset_flag", I16), ("pad0_", I16), ("sbr_invf_mode_prev", I32 * 10),
-                ("inter_temp_shape_mode", I32 * 8), ("flt_env_sf_arr", F32 * 448), ("flt_noise_floor", F32 * 10)]
+                ("qmf_sb_prev", I16), ("reset_flag", I16), ("harmonic_sbr", I16), ("sbr_invf_mode_prev", I32 * 10),
+                ("inter_temp_shape_mode", I32 * 8), ("flt_env_sf_arr", F32 * 448), ("flt_noise_floor", F32 * 10), ("pitch_in_bins", I32)]
 
 
 class EsbrAna(ctypes.Structure):
@@ -24,7 +24,8 @@ class EsbrState(ctypes.Structure):
                 ("e_gain", (F32 * 64) * 5), ("noise_buf", (F32 * 64) * 5), ("lim_table", (I32 * 13) * 4),
                 ("gate_mode", I32 * 4), ("harm_index", I32), ("phase_index", I32), ("esbr_start_up", I32),
                 ("env_short_flag_prev", I32), ("patch_start_subband", I32 * 7), ("num_patches", I32),
-                ("harm_flag_prev", I8 * 64)]
+                ("harm_flag_prev", I8 * 64), ("prev_sbr_patching_mode", I32), ("ph_re", (F32 * 64) * 8),
+                ("ph_im", (F32 * 64) * 8)]
 
 
 def new_state():

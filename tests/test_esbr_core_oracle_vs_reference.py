@@ -63,7 +63,18 @@ def state_words(st):
     return np.frombuffer(bytes(st), np.uint32)
 
 
-def run_chain(oracle, reference, recs, seed, xover_extra=0, tes=False, n_frames=40):
+def bind_h(lib, name):
+    fn = getattr(lib, name)
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p] * 4 + [PF] * 6 + [ctypes.POINTER(ctypes.c_int32)]
+    return fn
+
+
+def run_chain(oracle, reference, recs, seed, xover_extra=0, tes=False, n_frames=40, harmonic=False):
+    """harmonic: the HF generator's harmonic branch (sbr_patching_mode 0: the input is the transposer's rows, here random
+    ones) on most frames, LPP patching on the others, so that the limiter bands are remade at every change"""
+    if harmonic:
+        ref_h, orc_h = bind_h(reference.lib, "ref_esbr_hf_env_h"), bind_h(oracle.lib, "xo_esbr_hf_env_h")
     ref_fn, orc_fn = bind(reference.lib, "ref_esbr_hf_env"), bind(oracle.lib, "xo_esbr_hf_env")
     rng = np.random.default_rng(seed)
     st_r, st_o = new_state(), new_state()
@@ -90,11 +101,25 @@ def run_chain(oracle, reference, recs, seed, xover_extra=0, tes=False, n_frames=
         prev_tables = tables
         qre, qim = qmf_matrices(rng, float(2.0 ** rng.integers(0, 16)))
         outs = []
-        for fn, st in ((ref_fn, st_r), (orc_fn, st_o)):
+        if harmonic:
+            sd.harmonic_sbr = int(rng.integers(0, 4) != 0)
+            sd.pitch_in_bins = int(rng.integers(0, 128))
+            lvl = float(2.0 ** rng.integers(0, 16))
+            ph = [(rng.standard_normal((40, 64)) * lvl).astype(np.float32) for _ in range(2)]
+            ph[0][:, 40] += np.float32(lvl * 6) * np.cos(np.arange(40) * 1.1).astype(np.float32)
+            sb = h.sub_band_start
+            xo = (ctypes.c_int32 * 6)(sb, min(64, 2 * sb), min(64, 3 * sb) if rng.integers(0, 2) else 0, 0, 0, 0)
+        for fn, st in (((ref_h if harmonic else ref_fn), st_r), ((orc_h if harmonic else orc_fn), st_o)):
             ore, oim = np.zeros((72, 64), np.float32), np.zeros((72, 64), np.float32)
             a, b = qre.copy(), qim.copy()
-            rc = fn(ctypes.byref(h), ctypes.byref(f), ctypes.byref(sd), ctypes.byref(st), a.ctypes.data_as(PF),
-                    b.ctypes.data_as(PF), ore.ctypes.data_as(PF), oim.ctypes.data_as(PF))
+            if harmonic:
+                pa, pb = ph[0].copy(), ph[1].copy()
+                rc = fn(ctypes.byref(h), ctypes.byref(f), ctypes.byref(sd), ctypes.byref(st), a.ctypes.data_as(PF),
+                        b.ctypes.data_as(PF), ore.ctypes.data_as(PF), oim.ctypes.data_as(PF), pa.ctypes.data_as(PF),
+                        pb.ctypes.data_as(PF), xo)
+            else:
+                rc = fn(ctypes.byref(h), ctypes.byref(f), ctypes.byref(sd), ctypes.byref(st), a.ctypes.data_as(PF),
+                        b.ctypes.data_as(PF), ore.ctypes.data_as(PF), oim.ctypes.data_as(PF))
             outs.append((rc, ore, oim, a, b))
         (rc_r, ore_r, oim_r, a_r, b_r), (rc_o, ore_o, oim_o, a_o, b_o) = outs
         assert rc_r == rc_o, (n, rc_r, rc_o)
@@ -128,6 +153,11 @@ def test_hf_env_chain(oracle, reference, recs, seed):
 @pytest.mark.parametrize("seed", range(3))
 def test_hf_env_chain_with_xover_offset(oracle, reference, recs, seed):
     run_chain(oracle, reference, recs, 200 + seed, xover_extra=1 + seed)
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_hf_env_chain_with_harmonic_patching(oracle, reference, recs, seed):
+    run_chain(oracle, reference, recs, 400 + seed, harmonic=True, tes=seed == 4)
 
 
 @pytest.mark.parametrize("seed", range(3))

@@ -144,3 +144,91 @@ def test_ps_chain_vs_oracle(oracle):
             if not np.array_equal(np.frombuffer(bytes(ps_o[ch]), np.uint8), p_g[ch]):
                 raise AssertionError((fr, ch, c.diff_state(ps_o[ch], EsbrPsState.from_buffer_copy(p_g[ch].tobytes()))))
         assert np.any(r_g != 0) and np.any(l_g != r_g)
+
+
+@pytest.mark.gpu
+def test_chain_with_harmonic_transposer_vs_oracle(oracle, reference):
+    """the chain with every channel's QMF harmonic transposer (hbe_state): it runs on every processed frame; frames with
+    harmonic_sbr take the HF generator's input from it (with and without a pitch), others patch by LPP; the modes
+    alternate within a stream.  Output samples, the eSBR state and the transposer's state identical to the oracle's
+    xo_esbr_sbr_frame_hbe (its stages pinned to the reference by tests/test_esbr_core_oracle_vs_reference.py and
+    tests/test_hbe_oracle_vs_reference.py)."""
+    import torch
+    import libxaac_amd
+    from hbe_structs import HbeState
+    fn = oracle.lib.xo_esbr_sbr_frame_hbe
+    fn.restype = ctypes.c_int
+    fn.argtypes = [PF] + [ctypes.c_void_p] * 6 + [PF, PF, ctypes.c_void_p]
+    ri = reference.lib.ref_hbe_reinit
+    P16 = ctypes.POINTER(ctypes.c_int16)
+    ri.restype, ri.argtypes = ctypes.c_int, [P16, ctypes.c_int, P16, ctypes.c_int, ctypes.POINTER(HbeState)]
+    recs = [r for r in c.read_records(os.path.join(ROOT, "tests", "golden", "sbr_lp_records.bin.gz"))]
+    dev = torch.device("cuda:0")
+    ctx = libxaac_amd.XaacContext(0, None)
+    n, frames = 21, 10
+    rng = np.random.default_rng(91)
+    offs = rng.integers(0, len(recs) - frames, n)
+    st_o = [new_state() for _ in range(n)]
+    hb_o = [HbeState() for _ in range(n)]
+    st_g = torch.from_numpy(np.stack([np.frombuffer(bytes(s), np.uint8) for s in st_o])).to(dev)
+    hb_g = None
+    ws = torch.zeros(ctx.esbr_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    out = torch.zeros((n, 2048), dtype=torch.float32, device=dev)
+    status = torch.zeros(n, dtype=torch.int32, device=dev)
+    prev_modes = [[0] * 10 for _ in range(n)]
+    prev_tables = [None] * n
+    harmonic_frames = 0
+    for fr in range(frames):
+        hs, fs, sds = [], [], []
+        core = (rng.uniform(-1, 1, (n, 1024)) * rng.choice([30000.0, 2000.0, 50.0], (n, 1))).astype(np.float32)
+        core += (8000 * np.sin(np.arange(1024) * rng.uniform(0.05, 0.6, (n, 1)))).astype(np.float32)
+        for ch in range(n):
+            rec = recs[offs[ch] + fr]
+            h, f = c.Header.from_buffer_copy(bytes(rec["header"])), c.Frame.from_buffer_copy(bytes(rec["frame"]))
+            if fr == 4 and ch % 5 == 0:
+                f.apply_processing = 0
+            sd = make_side(rng, h, f, prev_modes[ch], fr, 0, False)
+            tables = bytes(h)[12:]
+            if prev_tables[ch] != tables:   # a header reset: the host re-derives the transposer's parameters (hbe_trans.c:102)
+                sd.reset_flag = 1
+                lo = np.array(h.freq_band_tbl_lo[:h.num_sf_bands[0] + 1], np.int16)
+                hi = np.array(h.freq_band_tbl_hi[:h.num_sf_bands[1] + 1], np.int16)
+                fresh = HbeState()
+                fresh.max_stretch = hb_o[ch].max_stretch
+                assert ri(lo.ctypes.data_as(P16), len(lo) - 1, hi.ctypes.data_as(P16), len(hi) - 1, ctypes.byref(fresh)) == 0
+                keep = hb_o[ch]
+                for name in ("synth_size", "k_start", "start_band", "end_band", "max_stretch"):
+                    setattr(keep, name, getattr(fresh, name))
+                for q in range(6):
+                    keep.x_over_qmf[q] = fresh.x_over_qmf[q]
+                ctypes.memset(ctypes.addressof(keep) + HbeState.synth_buf.offset, 0, 4 * 1280)   # reinit clears both lines
+                ctypes.memset(ctypes.addressof(keep) + HbeState.analy_buf.offset, 0, 4 * 640)
+                keep.fft_ready = 1 if (keep.synth_size != 20 or keep.fft_ready) else 0
+                if hb_g is not None:
+                    hb_g[ch] = torch.from_numpy(np.frombuffer(bytes(keep), np.uint8).copy()).to(dev)
+            prev_tables[ch] = tables
+            sd.harmonic_sbr = int(ch % 3 != 0 and rng.integers(0, 4) != 0)
+            sd.pitch_in_bins = int(rng.choice([0, 0, 14, 30, 77])) if sd.harmonic_sbr else 0
+            harmonic_frames += sd.harmonic_sbr and f.apply_processing
+            hs.append(h), fs.append(f), sds.append(sd)
+            prev_modes[ch] = [f.sbr_invf_mode[i] for i in range(10)]
+        if hb_g is None:
+            hb_g = torch.from_numpy(np.stack([np.frombuffer(bytes(s), np.uint8) for s in hb_o])).to(dev)
+        pack = lambda xs: torch.from_numpy(np.stack([np.frombuffer(bytes(x), np.uint8) for x in xs])).to(dev)
+        ctx.esbr_sbr_process_batch(torch.from_numpy(core).to(dev), pack(hs), pack(fs), pack(sds), st_g, out, ws, status,
+                                   hbe_state=hb_g)
+        ctx.sync()
+        o_g, s_g, h_g, rc_g = out.cpu().numpy(), st_g.cpu().numpy(), hb_g.cpu().numpy(), status.cpu().numpy()
+        for ch in range(n):
+            o = np.zeros(2048, np.float32)
+            rc = fn(core[ch].ctypes.data_as(PF), ctypes.byref(hs[ch]), ctypes.byref(fs[ch]), ctypes.byref(sds[ch]),
+                    ctypes.byref(st_o[ch]), None, None, o.ctypes.data_as(PF), None, ctypes.byref(hb_o[ch]))
+            assert (rc, rc_g[ch]) == (0, 0), (fr, ch, rc, rc_g[ch])
+            bad = np.nonzero(o.view(np.uint32) != o_g[ch].view(np.uint32))[0]
+            assert bad.size == 0, (fr, ch, sds[ch].harmonic_sbr, bad[:5], o[bad[:3]], o_g[ch][bad[:3]])
+            if not np.array_equal(np.frombuffer(bytes(st_o[ch]), np.uint8), s_g[ch]):
+                g = EsbrState.from_buffer_copy(s_g[ch].tobytes())
+                raise AssertionError((fr, ch, [x[0] for x in c.diff_state(st_o[ch], g) if x[0] not in ("ana", "syn")]))
+            d = np.nonzero(np.frombuffer(bytes(hb_o[ch]), np.uint8) != h_g[ch])[0]
+            assert d.size == 0, ("transposer state", fr, ch, d[:4])
+    assert harmonic_frames > 40
