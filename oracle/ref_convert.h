@@ -299,6 +299,8 @@ static void to_esbr_side(const ia_sbr_header_data_struct *h, const ia_sbr_frame_
   for (i = 0; i < XAAC_SBR_MAX_ENVELOPES; i++) o->inter_temp_shape_mode[i] = f->inter_temp_shape_mode[i];
   memcpy(o->flt_env_sf_arr, f->flt_env_sf_arr, sizeof(o->flt_env_sf_arr));
   memcpy(o->flt_noise_floor, f->flt_noise_floor, sizeof(o->flt_noise_floor));
+  o->harmonic_sbr = f->sbr_patching_mode == 0;
+  o->pitch_in_bins = f->pitch_in_bins;
 }
 
 /* the state as the call finds it: this library's rows 0.. are the rows the reference is about to move down from row 32 */
@@ -329,6 +331,9 @@ static void to_esbr_state(const ia_sbr_dec_struct *d, const ia_sbr_header_data_s
   o->num_patches = f->patch_param.num_patches;
   for (i = 0; i <= XAAC_SBR_MAX_PATCHES; i++) o->patch_start_subband[i] = f->patch_param.start_subband[i];
   memcpy(o->harm_flag_prev, f->harm_flag_prev, sizeof(o->harm_flag_prev));
+  o->prev_sbr_patching_mode = f->prev_sbr_patching_mode;
+  memcpy(o->ph_re, d->ph_vocod_qmf_real[32], sizeof(o->ph_re));
+  memcpy(o->ph_im, d->ph_vocod_qmf_imag[32], sizeof(o->ph_im));
 }
 
 static void from_esbr_state(const xaac_esbr_state *o, ia_sbr_dec_struct *d, ia_sbr_header_data_struct *h,
@@ -357,6 +362,42 @@ static void from_esbr_state(const xaac_esbr_state *o, ia_sbr_dec_struct *d, ia_s
   f->patch_param.num_patches = o->num_patches;
   for (i = 0; i <= XAAC_SBR_MAX_PATCHES; i++) f->patch_param.start_subband[i] = o->patch_start_subband[i];
   memcpy(f->harm_flag_prev, o->harm_flag_prev, sizeof(o->harm_flag_prev));
+  f->prev_sbr_patching_mode = o->prev_sbr_patching_mode;
+  memcpy(d->ph_vocod_qmf_real[32], o->ph_re, sizeof(o->ph_re));
+  memcpy(d->ph_vocod_qmf_imag[32], o->ph_im, sizeof(o->ph_im));
+}
+
+/* the QMF harmonic transposer (ia_esbr_hbe_txposer_struct, ixheaacd_sbr_dec.h:30-100) <-> xaac_hbe_state */
+static void to_hbe_state(const ia_esbr_hbe_txposer_struct *t, xaac_hbe_state *o) {
+  int i;
+  memset(o, 0, sizeof(*o));
+  memcpy(o->input_buf, t->ptr_input_buf, sizeof(o->input_buf));
+  memcpy(o->synth_buf, t->synth_buf, sizeof(o->synth_buf));
+  memcpy(o->analy_buf, t->analy_buf, sizeof(o->analy_buf));
+  for (i = 0; i < XAAC_HBE_NO_BINS; i++) memcpy(o->qmf_in_buf[i], t->qmf_in_buf[i], sizeof(o->qmf_in_buf[i]));
+  for (i = 0; i < 2 * XAAC_HBE_NO_BINS; i++) memcpy(o->qmf_out_buf[i], t->qmf_out_buf[i], sizeof(o->qmf_out_buf[i]));
+  o->synth_size = t->synth_size;
+  o->k_start = t->k_start;
+  o->start_band = t->start_band;
+  o->end_band = t->end_band;
+  for (i = 0; i < 6; i++) o->x_over_qmf[i] = t->x_over_qmf[i];
+  o->max_stretch = t->max_stretch;
+  o->fft_ready = t->ixheaacd_cmplx_anal_fft != NULL;
+}
+
+/* hd: the header whose tables the reference's own re-initialisation inside ixheaacd_qmf_hbe_apply would have used
+   (hbe_trans.c:240-248) -- run here when this library's call made the transposer's FFTs "ready", so that the
+   reference's struct gets its function and table pointers */
+static void from_hbe_state(const xaac_hbe_state *o, ia_esbr_hbe_txposer_struct *t, ia_sbr_header_data_struct *hd) {
+  int i;
+  if (o->fft_ready && t->ixheaacd_cmplx_anal_fft == NULL)
+    ixheaacd_qmf_hbe_data_reinit(t, hd->pstr_freq_band_data->freq_band_table, hd->pstr_freq_band_data->num_sf_bands,
+                                 hd->is_usf_4);
+  memcpy(t->ptr_input_buf, o->input_buf, sizeof(o->input_buf));
+  memcpy(t->synth_buf, o->synth_buf, sizeof(o->synth_buf));
+  memcpy(t->analy_buf, o->analy_buf, sizeof(o->analy_buf));
+  for (i = 0; i < XAAC_HBE_NO_BINS; i++) memcpy(t->qmf_in_buf[i], o->qmf_in_buf[i], sizeof(o->qmf_in_buf[i]));
+  for (i = 0; i < 2 * XAAC_HBE_NO_BINS; i++) memcpy(t->qmf_out_buf[i], o->qmf_out_buf[i], sizeof(o->qmf_out_buf[i]));
 }
 
 static void to_esbr_ps_state(const ia_ps_dec_struct *ps, const ia_sbr_qmf_filter_bank_struct *sr, xaac_esbr_ps_state *o) {

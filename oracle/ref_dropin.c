@@ -38,9 +38,10 @@ static struct {
   xaac_esbr_ps_state *epss;
   xaac_esbr_side *side;
   xaac_esbr_state *estate;
+  xaac_hbe_state *hbe;         /* Path A: the channel's QMF harmonic transposer */
   void *ews;
 } g;
-static long g_imdct_calls, g_sbr_calls, g_lim_calls, g_esbr_calls;
+static long g_imdct_calls, g_sbr_calls, g_lim_calls, g_esbr_calls, g_esbr_harm_calls;
 
 static void die(const char *what) {
   fprintf(stderr, "xaacdec_dropin: %s failed\n", what);
@@ -52,6 +53,7 @@ static void report(void) {
   fprintf(stderr, "xaacdec_dropin: %ld imdct_process and %ld sbr_dec calls ran on the GPU\n", g_imdct_calls, g_sbr_calls);
   fprintf(stderr, "xaacdec_dropin: %ld peak_limiter_process calls ran on the GPU\n", g_lim_calls);
   fprintf(stderr, "xaacdec_dropin: %ld sbr_dec calls took the eSBR (Path A) branch on the GPU\n", g_esbr_calls);
+  fprintf(stderr, "xaacdec_dropin: %ld of them with harmonic patching (the QMF transposer's output)\n", g_esbr_harm_calls);
 }
 
 static void setup(void) {
@@ -82,6 +84,7 @@ static void setup(void) {
   HIP(hipMalloc((void **)&g.epss, sizeof(xaac_esbr_ps_state)));
   HIP(hipMalloc((void **)&g.side, sizeof(xaac_esbr_side)));
   HIP(hipMalloc((void **)&g.estate, sizeof(xaac_esbr_state)));
+  HIP(hipMalloc((void **)&g.hbe, sizeof(xaac_hbe_state)));
   HIP(hipMalloc(&g.ews, xaac_esbr_workspace_bytes(1)));
   atexit(report);
 }
@@ -181,19 +184,21 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
   int i, rc;
   /* the reference's default path (-esbr:1) on HE-AAC mono / stereo channels: Path A on the GPU.  (For such streams the
      reference also runs its QMF harmonic transposer every frame -- hbe_flag is forced on, sbrdecoder.c:399-403 -- but
-     with sbr_patching_mode 1 nothing reads what it produces: ixheaacd_generate_hf takes the LPP branch.)  Everything the branch
+     with sbr_patching_mode 1 nothing reads what it produces: ixheaacd_generate_hf takes the LPP branch; the chain runs it
+     too, see below.)  Everything the branch
      at sbr_dec.c:816-1009 does for such a channel -- history shift, analysis, HF generator, envelope adjuster,
      regrouping, synthesis -- is one xaac_esbr_sbr_process_batch call; the state lives in the reference's structs
      between calls (to_esbr_state / from_esbr_state) */
-  if (h->enh_sbr && aot != AOT_ER_AAC_ELD && aot != AOT_ER_AAC_LD && !h->usac_flag && h->hbe_flag && f->sbr_patching_mode == 1 &&
+  if (h->enh_sbr && aot != AOT_ER_AAC_ELD && aot != AOT_ER_AAC_LD && !h->usac_flag && h->hbe_flag && d->p_hbe_txposer != NULL && !h->esbr_hq &&
       (h->channel_mode == PS_STEREO ? (ps != NULL && synth_r != NULL && !ps->use_34_st_bands && !ps->use_pca_rot_flg && ps->ps_mode == 0)
                                     : !h->enh_sbr_ps) &&
       !drc_on && !ldmps && !mps && !f->mps_sbr_flag && f->sbr_mode != PVC_SBR &&
-      h->sbr_ratio_idx != SBR_UPSAMPLE_IDX_4_1 && !h->pre_proc_flag && h->num_time_slots == 16 &&
+      h->sbr_ratio_idx != SBR_UPSAMPLE_IDX_4_1 && (!h->pre_proc_flag || f->sbr_patching_mode == 0) && h->num_time_slots == 16 &&
       d->str_codec_qmf_bank.no_channels == 32 && d->str_synthesis_qmf_bank.no_channels == 64 && !getenv("XAAC_DROPIN_NO_ESBR")) {
     static xaac_esbr_side sd;
     static xaac_esbr_state est;
     static xaac_esbr_ps_state epss;
+    static xaac_hbe_state hbs;
     xaac_esbr_sbr_batch b;
     const ia_qmf_dec_tables_struct *q = tabs->qmf_dec_tables_ptr;
     const int eps = h->channel_mode == PS_STEREO;
@@ -213,6 +218,11 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     HIP(hipMemcpy(g.frame, &fr, sizeof(fr), hipMemcpyHostToDevice));
     HIP(hipMemcpy(g.side, &sd, sizeof(sd), hipMemcpyHostToDevice));
     HIP(hipMemcpy(g.estate, &est, sizeof(est), hipMemcpyHostToDevice));
+    /* the channel's harmonic transposer: the reference runs it on every processed frame of such a stream
+       (sbr_dec.c:882-909) and frames with sbr_patching_mode 0 (ENHSBR payload) take the HF generator's input from it;
+       pre-flattening (pre_proc_flag) only acts on LPP patches (sbrdec_lpfuncs.c:1220), so it is moot for those frames */
+    to_hbe_state(d->p_hbe_txposer, &hbs);
+    HIP(hipMemcpy(g.hbe, &hbs, sizeof(hbs), hipMemcpyHostToDevice));
     HIP(hipMemcpy(g.core, d->time_sample_buf, 4096, hipMemcpyHostToDevice));
     memset(&b, 0, sizeof(b));
     b.n_ch = 1;
@@ -234,6 +244,7 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     b.status = g.status;
     b.workspace = g.ews;
     b.workspace_bytes = xaac_esbr_workspace_bytes(1);
+    b.hbe_state = g.hbe;
     if (xaac_esbr_sbr_process_batch(g_ctx, &b) != XAAC_OK || xaac_sync(g_ctx) != XAAC_OK) die("xaac_esbr_sbr_process_batch");
     HIP(hipMemcpy(&status, g.status, 4, hipMemcpyDeviceToHost));
     if (status && getenv("XAAC_DROPIN_DEBUG")) {
@@ -247,6 +258,10 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     HIP(hipMemcpy(&est, g.estate, sizeof(est), hipMemcpyDeviceToHost));
     HIP(hipMemcpy(d->time_sample_buf, g.time, 8192, hipMemcpyDeviceToHost));
     from_esbr_state(&est, d, h, f);
+    if (apply) {
+      HIP(hipMemcpy(&hbs, g.hbe, sizeof(hbs), hipMemcpyDeviceToHost));
+      from_hbe_state(&hbs, d->p_hbe_txposer, h);
+    }
     if (eps) { /* right channel out, PS state back, and what the second synthesis call leaves in channel 1's frame data */
       HIP(hipMemcpy(&epss, g.epss, sizeof(epss), hipMemcpyDeviceToHost));
       HIP(hipMemcpy(ps->time_sample_buf[1], g.time_r, 8192, hipMemcpyDeviceToHost));
@@ -259,6 +274,7 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     f->reset_flag = 0;
     f->prev_sbr_mode = f->sbr_mode;
     g_esbr_calls++;
+    if (apply && f->sbr_patching_mode == 0) g_esbr_harm_calls++;
     return 0;
   }
   if (h->enh_sbr && getenv("XAAC_DROPIN_DEBUG")) {

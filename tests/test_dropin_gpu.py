@@ -55,6 +55,9 @@ def test_default_flags_he_aac_takes_the_esbr_path_on_the_gpu(aac, tmp_path):
     assert m and int(m.group(1)) > 30, log[-600:]
     a, b = open(ref_wav, "rb").read(), open(gpu_wav, "rb").read()
     assert len(a) > 100000 and a == b, (len(a), len(b), int(m.group(1)))
+    mh = re.search(r"(\d+) of them with harmonic patching", log)
+    if "harm_" in aac:   # encoded with -harmonic_sbr:1: sbr_patching_mode 0 frames, the HF generator fed by the QMF transposer
+        assert mh and int(mh.group(1)) > 30, log[-600:]
     # and it is a different decode from the fixed-point path the other tests pin
     fix_wav = str(tmp_path / "fix.wav")
     _decode("xaacdec", aac, fix_wav)

@@ -28,6 +28,11 @@ def main():
         subprocess.run([os.path.join(REF, "xaacenc"), "-ifile:" + wav, "-ofile:" + aac, "-aot:%d" % aot, "-br:%d" % br,
                         "-adts:1"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
         print(aac, os.path.getsize(aac))
+    # HE-AAC with the eSBR extension payload: harmonic SBR (sbr_patching_mode 0 frames) and inter-TES
+    aac = os.path.join(out, "harm_aot5_48k.aac")
+    subprocess.run([os.path.join(REF, "xaacenc"), "-ifile:" + wav, "-ofile:" + aac, "-aot:5", "-br:48000", "-adts:1", "-esbr:1",
+                    "-harmonic_sbr:1", "-inter_tes_enc:1"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    print(aac, os.path.getsize(aac))
     # a mono HE-AAC stream: the single-channel-element flavour of the SBR paths (one ixheaacd_sbr_dec call per frame)
     wav = "/tmp/xaac_golden_mono.wav"
     m.write_wav(wav, x[:, :1])
