@@ -86,6 +86,7 @@ typedef struct {
   xaac_esbr_side *esd;
   xaac_esbr_state *est;
   xaac_esbr_ps_state *eps;
+  xaac_hbe_state *ehb; /* the channels' QMF harmonic transposers (run on every processed frame, as the reference does) */
   float *ecore, *etime, *etime_r;
   /* limiter */
   int32_t *lx;
@@ -113,7 +114,7 @@ static size_t group_bytes(int n) {
   size_t per = 4096 + 2048 + 4096 + 8 + 8 + 8 + sizeof(xaac_sbr_header) + sizeof(xaac_sbr_frame) + sizeof(xaac_sbr_state) +
                sizeof(xaac_ps_frame) + sizeof(xaac_ps_state) + 2048 + 8192 + 4 + 1024 * LIM_MAX_CH * 4 + 8 +
                sizeof(xaac_limiter_state) + sizeof(inst_t) + sizeof(xaac_esbr_side) + sizeof(xaac_esbr_state) +
-               sizeof(xaac_esbr_ps_state) + 4096 + 8192 + 8192;
+               sizeof(xaac_esbr_ps_state) + sizeof(xaac_hbe_state) + 4096 + 8192 + 8192;
   return (size_t)n * per + 96 * 256;
 }
 
@@ -141,6 +142,7 @@ static void group_layout(group_t *g, int n, char *base) {
   g->esd = carve(&cur, sizeof(xaac_esbr_side) * n);
   g->est = carve(&cur, sizeof(xaac_esbr_state) * n);
   g->eps = carve(&cur, sizeof(xaac_esbr_ps_state) * n);
+  g->ehb = carve(&cur, sizeof(xaac_hbe_state) * n);
   g->ecore = carve(&cur, (size_t)n * 4096);
   g->etime = carve(&cur, (size_t)n * 8192);
   g->etime_r = carve(&cur, (size_t)n * 8192);
@@ -203,11 +205,11 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
   const int ps_on = with_ps && apply;
   /* the reference's default flags: the eSBR branch (sbr_dec.c:816-1009) of an HE-AAC channel / HE-AACv2 stream, as in
      oracle/ref_dropin.c */
-  if (g && h->enh_sbr && aot != AOT_ER_AAC_ELD && aot != AOT_ER_AAC_LD && !h->usac_flag && h->hbe_flag && f->sbr_patching_mode == 1 &&
+  if (g && h->enh_sbr && aot != AOT_ER_AAC_ELD && aot != AOT_ER_AAC_LD && !h->usac_flag && h->hbe_flag && d->p_hbe_txposer != NULL && !h->esbr_hq &&
       (h->channel_mode == PS_STEREO ? (ps != NULL && synth_r != NULL && !ps->use_34_st_bands && !ps->use_pca_rot_flg && ps->ps_mode == 0)
                                     : !h->enh_sbr_ps) &&
       !drc_on && !ldmps && !mps && !f->mps_sbr_flag && f->sbr_mode != PVC_SBR && h->sbr_ratio_idx != SBR_UPSAMPLE_IDX_4_1 &&
-      !h->pre_proc_flag && h->num_time_slots == 16 && d->str_codec_qmf_bank.no_channels == 32 &&
+      (!h->pre_proc_flag || f->sbr_patching_mode == 0) && h->num_time_slots == 16 && d->str_codec_qmf_bank.no_channels == 32 &&
       d->str_synthesis_qmf_bank.no_channels == 64) {
     const ia_qmf_dec_tables_struct *q = tabs->qmf_dec_tables_ptr;
     const int eps = h->channel_mode == PS_STEREO;
@@ -221,6 +223,7 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     to_frame(f, apply, &g->frm[i]);
     to_esbr_side(h, f, &g->esd[i]);
     to_esbr_state(d, h, f, &g->est[i]);
+    to_hbe_state(d->p_hbe_txposer, &g->ehb[i]);
     memcpy(g->ecore + 1024 * (size_t)i, d->time_sample_buf, 4096);
     if (eps) {
       to_ps_frame(ps, &g->psf[i]);
@@ -230,6 +233,7 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     if (g->status[i]) return g->status[i];
     memcpy(d->time_sample_buf, g->etime + 2048 * (size_t)i, 8192);
     from_esbr_state(&g->est[i], d, h, f);
+    if (apply) from_hbe_state(&g->ehb[i], d->p_hbe_txposer, h);
     if (eps) {
       memcpy(ps->time_sample_buf[1], g->etime_r + 2048 * (size_t)i, 8192);
       from_esbr_ps_state(&g->eps[i], ps, synth_r);
@@ -362,15 +366,16 @@ static void launch_group(group_t *g, gpu_group_t *gg, long *batches) {
       xaac_esbr_sbr_batch b;
       memset(&b, 0, sizeof(b));
       H2D(hdr, n * sizeof(xaac_sbr_header)); H2D(frm, n * sizeof(xaac_sbr_frame)); H2D(esd, n * sizeof(xaac_esbr_side));
-      H2D(est, n * sizeof(xaac_esbr_state)); H2D(ecore, n * 4096);
+      H2D(est, n * sizeof(xaac_esbr_state)); H2D(ehb, n * sizeof(xaac_hbe_state)); H2D(ecore, n * 4096);
       b.n_ch = g->n; b.core = gg->d.ecore; b.header = gg->d.hdr; b.frame = gg->d.frm; b.side = gg->d.esd; b.state = gg->d.est;
       b.out = gg->d.etime; b.status = gg->d.status; b.workspace = gg->ws; b.workspace_bytes = gg->ws_bytes;
+      b.hbe_state = gg->d.ehb;
       if (req == REQ_ESBR_PS) {
         H2D(psf, n * sizeof(xaac_ps_frame)); H2D(eps, n * sizeof(xaac_esbr_ps_state));
         b.ps_frame = gg->d.psf; b.ps_state = gg->d.eps; b.out_r = gg->d.etime_r;
       }
       if (xaac_esbr_sbr_process_batch(gg->ctx, &b) != XAAC_OK) die("xaac_esbr_sbr_process_batch");
-      D2H(etime, n * 8192); D2H(est, n * sizeof(xaac_esbr_state)); D2H(status, n * 4);
+      D2H(etime, n * 8192); D2H(est, n * sizeof(xaac_esbr_state)); D2H(ehb, n * sizeof(xaac_hbe_state)); D2H(status, n * 4);
       if (req == REQ_ESBR_PS) { D2H(etime_r, n * 8192); D2H(eps, n * sizeof(xaac_esbr_ps_state)); }
     } else {
       H2D(hdr, n * sizeof(xaac_sbr_header)); H2D(frm, n * sizeof(xaac_sbr_frame)); H2D(sst, n * sizeof(xaac_sbr_state));
