@@ -8,8 +8,8 @@
 #include "../../include/xaac_esbr.h"
 #include "../../include/xaac_hbe.h"
 
-#define XAAC_HBE_SYN_LDS ((41 * 40 + 32 * 265) * 4) /* v of 9 + 32 columns; 32 lanes' transform scratch (odd stride) */
-#define XAAC_HBE_ANA_LDS ((16 * 80 + 16 * 80 + 16 * 513) * 4) /* u and results of 16 columns; 16 lanes' scratch */
+#define XAAC_HBE_SYN_LDS (41 * 40 * 4) /* v of 9 + 32 columns */
+#define XAAC_HBE_ANA_LDS ((16 * 80 + 16 * 80) * 4) /* u and results of 16 columns (the transforms' scratch is private) */
 
 typedef struct XaacHbeSynParams {
   int32_t n_ch, num_columns;
@@ -37,7 +37,7 @@ typedef struct XaacHbeAnaParams {
 } XaacHbeAnaParams;
 
 #define XAAC_HBE_POST_THREADS 256
-#define XAAC_HBE_POST_LDS (256 * 25 * 4) /* the blocks (+ cross terms) of 16 bands x 16 columns */
+#define XAAC_HBE_POST_LDS (256 * 25 * 4 + 5 * 16 * 32 * 8) /* the blocks (+ cross terms) of 16 bands x 16 columns; five planes of normalised samples */
 typedef struct XaacHbePostParams {
   int32_t n_ch;
   xaac_hbe_state *state;

@@ -8,7 +8,7 @@
  *
  * Mapping: one wave = one channel-frame.  The reference shifts a delay line per QMF column; here a column's transform
  * depends only on the column's input (hbe_poly.h), so the columns' transforms run side by side (lane = column, its
- * arrays in a private LDS strip with an odd stride), and the windowed sums -- 32 x synth_size outputs of ten products
+ * work arrays private), and the windowed sums -- 32 x synth_size outputs of ten products
  * each, 16 x 4 synth_size of five -- are spread over all lanes with coalesced stores.  The delay lines are rewritten
  * once per frame from the last columns instead of shifted per column.
  */
@@ -29,7 +29,6 @@ __device__ __forceinline__ bool hbe_skip(const xaac_sbr_frame *frame, int ch) { 
 __global__ __launch_bounds__(64) void xaac_hbe_synth_kernel(XaacHbeSynParams p) {
   extern __shared__ float lds[];
   float(*vv)[40] = reinterpret_cast<float(*)[40]>(lds); /* [9 + 32][2 s <= 40] */
-  float *scr = lds + 41 * 40;
   const int ch = blockIdx.x, lane = threadIdx.x;
   xaac_hbe_state *st = p.state + ch;
   if (hbe_skip(p.frame, ch)) return;
@@ -51,9 +50,11 @@ __global__ __launch_bounds__(64) void xaac_hbe_synth_kernel(XaacHbeSynParams p) 
     const int c = -1 - e / (2 * s), t = e % (2 * s);
     vv[c + 9][t] = cleared ? 0.0f : xh_synth_hist(st->synth_buf, s, c, t);
   }
-  if (lane < nc)
+  if (lane < nc) {
+    float w[XH_SYNTH_SCRATCH]; /* private: see the analysis kernel */
     xh_synth_column(p.qmf_re + (size_t)ch * p.in_stride + lane * 64, p.qmf_im + (size_t)ch * p.in_stride + lane * 64, s, ks,
-                    vv[lane + 9], scr + lane * 265);
+                    vv[lane + 9], w);
+  }
   __syncthreads();
   const auto at = [&](int c, int t) { return vv[c + 9][t]; };
   for (int o = lane; o < nc * s; o += 64) st->input_buf[s + o] = xh_synth_out(at, s, o / s, o % s);
@@ -68,7 +69,6 @@ __global__ __launch_bounds__(64) void xaac_hbe_anal_kernel(XaacHbeAnaParams p) {
   extern __shared__ float lds[];
   float(*u)[80] = reinterpret_cast<float(*)[80]>(lds);            /* [16][2 a <= 80] */
   float(*res)[80] = reinterpret_cast<float(*)[80]>(lds + 16 * 80); /* [16][2 a <= 80] */
-  float *scr = lds + 16 * 80 + 16 * 80;
   const int ch = blockIdx.x, lane = threadIdx.x;
   xaac_hbe_state *st = p.state + ch;
   if (hbe_skip(p.frame, ch)) return;
@@ -88,7 +88,10 @@ __global__ __launch_bounds__(64) void xaac_hbe_anal_kernel(XaacHbeAnaParams p) {
     nb[q] = n < 10 * a ? xh_anal_x(st->input_buf, st->analy_buf, a, NCOL - 1, n) : 0.0f;
   }
   __syncthreads();
-  if (lane < NCOL) xh_anal_column(u[lane], a, res[lane], scr + lane * 513);
+  if (lane < NCOL) {
+    float w[XH_FFT_SCRATCH]; /* private (scratch memory): in LDS these strips would leave three waves per CU */
+    xh_anal_column(u[lane], a, res[lane], w);
+  }
   __syncthreads();
   for (int e = lane; e < NCOL * 128; e += 64) {
     const int idx = e >> 7, w = (e & 127) - 4 * ks;
@@ -101,13 +104,26 @@ __global__ __launch_bounds__(64) void xaac_hbe_anal_kernel(XaacHbeAnaParams p) {
   }
 }
 
-/* 256 threads per channel.  Tiles of 16 output bands: thread (band, column) computes the column's block of products into
-   LDS; then thread per complex element (row, band) moves the previous frame's upper rows down (rows 0..31 first, the
-   rows they come from afterwards), adds the blocks that reach it in column order, and rotates rows 0..31 of the SBR
-   range into the output (hbe_trans.c:262-295). */
+/* 256 threads per channel.  Tiles of 16 output bands.  Per tile: (1) the normalised samples the tile's products read --
+   a function of (row, input band) alone, each used by up to ten columns -- are computed once into LDS (five planes:
+   fourth-root, 3/4-power and cube-root normalisations, the cube-root-normalised interpolated points in their two
+   summation orders); (2) thread (band, column) forms the column's block of products (+ cross terms) in LDS; (3) thread
+   per complex element (row, band) moves the previous frame's upper rows down (rows 0..31 first, the rows they come from
+   afterwards), adds the blocks that reach it in column order, and rotates rows 0..31 of the SBR range into the output
+   (hbe_trans.c:262-295). */
+namespace {
+enum { HP_N2, HP_N4, HP_N3A, HP_N3B1, HP_N3B2, HP_PLANES };
+constexpr int HP_SLOTS = 16; /* input bands per plane and tile (plane_base .. + 15) */
+__device__ __forceinline__ int hp_base(int plane, int tile) { /* the lowest input band a tile's products can read */
+  return plane == HP_N2 ? 16 * tile : (plane == HP_N4 ? (8 * tile > 0 ? 8 * tile - 1 : 0) : (32 * tile) / 3);
+}
+}  // namespace
+
 __global__ __launch_bounds__(XAAC_HBE_POST_THREADS) void xaac_hbe_post_kernel(XaacHbePostParams p) {
   extern __shared__ float lds[];
   float(*blk)[XH_BLK] = reinterpret_cast<float(*)[XH_BLK]>(lds); /* [16 bands x 16 columns]: xh_column_block */
+  float2(*nv)[HP_SLOTS][32] = reinterpret_cast<float2(*)[HP_SLOTS][32]>(lds + 256 * XH_BLK); /* [plane][slot][row] */
+  __shared__ unsigned need[HP_PLANES]; /* bit s: slot s of the plane is read by this tile */
   const int ch = blockIdx.x, tid = threadIdx.x;
   xaac_hbe_state *st = p.state + ch;
   if (hbe_skip(p.frame, ch)) return;
@@ -125,10 +141,69 @@ __global__ __launch_bounds__(XAAC_HBE_POST_THREADS) void xaac_hbe_post_kernel(Xa
   const float *in_flat = &st->qmf_in_buf[0][0];
   const auto inf = [&](int row, int idx) { return in_flat[128 * row + idx]; };
   for (int tile = 0; tile < 4; tile++) {
+    /* (1) which normalised samples the tile reads, then those samples */
+    if (tid < HP_PLANES) need[tid] = 0;
+    __syncthreads();
+    if (tid < 16) {
+      const int qb = 16 * tile + tid, f = xh_band_factor(xo, ms, qb);
+      if (f == 2) {
+        atomicOr(&need[HP_N2], 1u << (qb - hp_base(HP_N2, tile)));
+      } else if (f == 4) {
+        const int inp = qb >> 1, ip = (qb & 1) ? inp + 1 : inp - 1, b = hp_base(HP_N4, tile);
+        atomicOr(&need[HP_N4], (1u << (inp - b)) | (1u << (ip - b)));
+      } else if (f == 3) {
+        const int inp = (2 * qb) / 3, rem = 2 * qb - 3 * inp, b = hp_base(HP_N3A, tile);
+        if (rem == 2) {
+          atomicOr(&need[HP_N3A], 3u << (inp - b));
+          atomicOr(&need[HP_N3B2], 3u << (inp - b));
+        } else {
+          atomicOr(&need[HP_N3A], 1u << (inp - b));
+          atomicOr(&need[HP_N3B1], 1u << (inp - b));
+        }
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < HP_PLANES * HP_SLOTS * 32; e += XAAC_HBE_POST_THREADS) {
+      const int plane = e / (HP_SLOTS * 32), slot = (e / 32) % HP_SLOTS, row = e % 32;
+      if (!((need[plane] >> slot) & 1)) continue;
+      const int band = hp_base(plane, tile) + slot;
+      XhC v = {0.0f, 0.0f};
+      if (plane == HP_N2) {
+        const XhC x = in(row, band);
+        v = xh_norm2(x.r, x.i);
+      } else if (plane == HP_N4) {
+        const XhC x = in(row, band);
+        v = xh_norm4(x.r, x.i);
+      } else if (plane == HP_N3A) {
+        const XhC x = in(row, band);
+        v = xh_norm3(x.r, x.i);
+      } else if (row < 30) { /* the interpolated point behind `row` reads rows row + 1, row + 2 (used: row <= 24) */
+        const XhC x = xh_interp3(in, band, row, plane == HP_N3B2);
+        v = xh_norm3(x.r, x.i);
+      }
+      nv[plane][slot][row] = make_float2(v.r, v.i);
+    }
+    __syncthreads();
+    /* (2) the columns' blocks */
     {
       const int qb = 16 * tile + (tid >> 4), i = tid & 15;
       const int f = xh_band_factor(xo, ms, qb);
-      if (f) xh_column_block(in, inf, f, qb, i, pitch, blk[tid]);
+      const auto cached = [&](int plane, int band, int row) {
+        const float2 v = nv[plane][band - hp_base(plane, tile)][row];
+        const XhC c = {v.x, v.y};
+        return c;
+      };
+      if (f == 2) {
+        xh_prod2_block_n([&](int row) { return cached(HP_N2, qb, row); }, i, blk[tid]);
+      } else if (f == 4) {
+        const int inp = qb >> 1, ip = (qb & 1) ? inp + 1 : inp - 1;
+        xh_prod4_block_n([&](int row) { return cached(HP_N4, inp, row); }, [&](int row) { return cached(HP_N4, ip, row); }, i, blk[tid]);
+      } else if (f == 3) {
+        const int inp = (2 * qb) / 3, rem = 2 * qb - 3 * inp;
+        xh_prod3_block_n([&](int sel, int row) { return cached(HP_N3A, inp + sel, row); },
+                         [&](int sel, int row) { return cached(rem == 2 ? HP_N3B2 : HP_N3B1, inp + sel, row); }, rem, i, blk[tid]);
+      }
+      if (f) xh_column_cross(inf, f, qb, i, pitch, blk[tid]);
     }
     __syncthreads();
     for (int half = 0; half < 2; half++) {

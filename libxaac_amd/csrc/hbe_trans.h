@@ -93,25 +93,30 @@ FX_HD XhC xh_norm3(float x_r, float x_i) {
   return y;
 }
 
-/* in(row, band): (re, im) of qmf_in_buf[row][2 band ..] */
-/* Stretch by 2 (:753-794): the ten products column i adds to rows 1 + 2 i .. of band qb; blk[2 k ..] = product k. */
-template <class In>
-FX_HD void xh_prod2_block(const In &in, int qb, int i, float *blk) {
-  const XhC z0 = in(XH_ZERO_BAND + i, qb);
-  const XhC z = xh_norm2(z0.r, z0.i);
+/* in(row, band): (re, im) of qmf_in_buf[row][2 band ..].
+   The products work on normalised samples; a normalised sample is a function of (row, input band) alone, so the
+   *_n forms take accessors for them (the kernel computes each once per frame and keeps it in LDS, the plain forms
+   normalise on the fly). */
+/* Stretch by 2 (:753-794): the ten products column i adds to rows 1 + 2 i .. of band qb; blk[2 k ..] = product k.
+   n2(row) = xh_norm2 of the band's sample in `row`. */
+template <class N2>
+FX_HD void xh_prod2_block_n(const N2 &n2, int i, float *blk) {
+  const XhC z = n2(XH_ZERO_BAND + i);
   for (int k = 0; k < 10; k++) {
-    const XhC n0 = in(1 + i + k, qb);
-    const XhC n = xh_norm2(n0.r, n0.i);
+    const XhC n = n2(1 + i + k);
     blk[2 * k] = ((n.r * z.r - n.i * z.i) * 0.3333333f);
     blk[2 * k + 1] = ((n.r * z.i + n.i * z.r) * 0.3333333f);
   }
 }
-/* Stretch by 4 (:1029-1082): six products, rows 3 + 2 i .. */
 template <class In>
-FX_HD void xh_prod4_block(const In &in, int qb, int i, float *blk) {
-  const int inp = qb >> 1, ip = (qb & 1) ? inp + 1 : inp - 1;
-  const XhC z0 = in(XH_ZERO_BAND + i, inp);
-  const XhC z = xh_norm4(z0.r, z0.i);
+FX_HD void xh_prod2_block(const In &in, int qb, int i, float *blk) {
+  xh_prod2_block_n([&](int row) { const XhC v = in(row, qb); return xh_norm2(v.r, v.i); }, i, blk);
+}
+/* Stretch by 4 (:1029-1082): six products, rows 3 + 2 i ..; nz(row) / nn(row) = xh_norm4 of band qb >> 1 / of its
+   neighbour (above for odd qb, below for even) */
+template <class NZ, class NN>
+FX_HD void xh_prod4_block_n(const NZ &nz, const NN &nn, int i, float *blk) {
+  const XhC z = nz(XH_ZERO_BAND + i);
   const float temp_r = z.r, temp_i = z.i;
   float zr = z.r, zi = z.i;
   const float temp = zr * zr - zi * zi;
@@ -119,38 +124,50 @@ FX_HD void xh_prod4_block(const In &in, int qb, int i, float *blk) {
   zr = temp_r * temp - temp_i * zi;
   zi = temp_r * zi + temp_i * temp;
   for (int k = 0; k < 6; k++) {
-    const XhC n0 = in(i + 2 * k, ip);
-    const XhC n = xh_norm4(n0.r, n0.i);
+    const XhC n = nn(i + 2 * k);
     blk[2 * k] = ((n.r * zr - n.i * zi) * 0.6666667f);
     blk[2 * k + 1] = ((n.r * zi + n.i * zr) * 0.6666667f);
   }
 }
-/* Stretch by 3 (:796-1027): eight products, rows 2 + 2 i ..; the eight inputs alternate between a sample (rows i + 3 m)
-   and a point interpolated from the two rows behind it, normalised by the cube root. */
 template <class In>
-FX_HD void xh_prod3_block(const In &in, int qb, int i, float *blk) {
-  const int inp = (2 * qb) / 3, rem = 2 * qb - 3 * inp;
-  float sel[8], sel1[8]; /* ixheaac_sel_case rows (esbr_rom.c:3128) */
-  {
-    const float t[5][8] = {{1, -1, 1, 1, 1, 1, -1, 1}, {1, 1, -1, 1, 1, -1, 1, 1}, {-1, 1, -1, -1, -1, -1, 1, -1},
-                           {-1, -1, 1, -1, -1, 1, -1, -1}, {1, -1, 1, 1, 1, 1, -1, 1}};
-    for (int q = 0; q < 8; q++) {
-      sel[q] = t[(inp + 1) & 3][q];
-      sel1[q] = t[((inp + 1) & 3) + 1][q];
-    }
+FX_HD void xh_prod4_block(const In &in, int qb, int i, float *blk) {
+  const int inp = qb >> 1, ip = (qb & 1) ? inp + 1 : inp - 1;
+  xh_prod4_block_n([&](int row) { const XhC v = in(row, inp); return xh_norm4(v.r, v.i); },
+                   [&](int row) { const XhC v = in(row, ip); return xh_norm4(v.r, v.i); }, i, blk);
+}
+/* Stretch by 3 (:796-1027): eight products, rows 2 + 2 i ..; the eight inputs alternate between a sample (rows i + 3 m)
+   and a point interpolated from the two rows behind it, both normalised by the cube root.
+   xh_interp3: the interpolated point of input band b behind row r, before normalisation; the reference adds its four
+   terms in one order where the output band reads one input band (2 qb mod 3 < 2, :842-851) and in another where it
+   reads two (:902-925). */
+template <class In>
+FX_HD XhC xh_interp3(const In &in, int band, int r, bool two_band_order) {
+  const float t[5][8] = {{1, -1, 1, 1, 1, 1, -1, 1}, {1, 1, -1, 1, 1, -1, 1, 1}, {-1, 1, -1, -1, -1, -1, 1, -1},
+                         {-1, -1, 1, -1, -1, 1, -1, -1}, {1, -1, 1, 1, 1, 1, -1, 1}}; /* ixheaac_sel_case (esbr_rom.c:3128) */
+  const float *sel = t[(band + 1) & 3]; /* the second band of a pair takes the next row, which is this formula again */
+  const XhC b = in(r + 2, band), c = in(r + 1, band);
+  float tr = sel[0] * b.r + sel[1] * b.i, ti = sel[2] * b.r + sel[3] * b.i;
+  if (two_band_order) {
+    tr = tr + sel[4] * c.r + sel[5] * c.i;
+    ti = ti + sel[6] * c.r + sel[7] * c.i;
+  } else {
+    tr += sel[4] * c.r + sel[5] * c.i;
+    ti += sel[6] * c.r + sel[7] * c.i;
   }
+  tr *= 0.3984033437f;
+  ti *= 0.3984033437f;
+  const XhC y = {tr, ti};
+  return y;
+}
+/* na(band_sel, row) = xh_norm3 of the sample, nb(band_sel, row) = xh_norm3 of xh_interp3 behind row; band_sel 0: input
+   band 2 qb / 3, 1: the band above it (read when 2 qb mod 3 == 2) */
+template <class NA, class NB>
+FX_HD void xh_prod3_block_n(const NA &na, const NB &nb, int rem, int i, float *blk) {
   if (rem == 0 || rem == 1) {
     XhC vec[8];
     for (int m = 0; m < 4; m++) {
-      const XhC a = in(i + 3 * m, inp), b = in(i + 3 * m + 2, inp), c = in(i + 3 * m + 1, inp);
-      vec[2 * m] = xh_norm3(a.r, a.i);
-      float temp_r1 = sel[0] * b.r + sel[1] * b.i;
-      float temp_i1 = sel[2] * b.r + sel[3] * b.i;
-      temp_r1 += sel[4] * c.r + sel[5] * c.i;
-      temp_i1 += sel[6] * c.r + sel[7] * c.i;
-      temp_r1 *= 0.3984033437f;
-      temp_i1 *= 0.3984033437f;
-      vec[2 * m + 1] = xh_norm3(temp_r1, temp_i1);
+      vec[2 * m] = na(0, i + 3 * m);
+      vec[2 * m + 1] = nb(0, i + 3 * m);
     }
     const float tr = vec[XH_ZERO_BAND - 2].r, ti = vec[XH_ZERO_BAND - 2].i;
     const float zr = tr * tr - ti * ti, zi = tr * ti + ti * tr;
@@ -162,25 +179,10 @@ FX_HD void xh_prod3_block(const In &in, int qb, int i, float *blk) {
   } else {
     XhC vec[8], cap[8];
     for (int m = 0; m < 4; m++) {
-      const XhC a = in(i + 3 * m, inp), a1 = in(i + 3 * m, inp + 1);
-      vec[2 * m] = xh_norm3(a1.r, a1.i);
-      cap[2 * m] = xh_norm3(a.r, a.i);
-      const XhC b = in(i + 3 * m + 2, inp), c = in(i + 3 * m + 1, inp);
-      float temp_r1 = sel[0] * b.r + sel[1] * b.i;
-      float temp_i1 = sel[2] * b.r + sel[3] * b.i;
-      float tmp_cr = temp_r1 + sel[4] * c.r + sel[5] * c.i;
-      float tmp_ci = temp_i1 + sel[6] * c.r + sel[7] * c.i;
-      const XhC b1 = in(i + 3 * m + 2, inp + 1), c1 = in(i + 3 * m + 1, inp + 1);
-      temp_r1 = sel1[0] * b1.r + sel1[1] * b1.i;
-      temp_i1 = sel1[2] * b1.r + sel1[3] * b1.i;
-      float tmp_vr = temp_r1 + sel1[4] * c1.r + sel1[5] * c1.i;
-      float tmp_vi = temp_i1 + sel1[6] * c1.r + sel1[7] * c1.i;
-      tmp_cr *= 0.3984033437f;
-      tmp_ci *= 0.3984033437f;
-      tmp_vr *= 0.3984033437f;
-      tmp_vi *= 0.3984033437f;
-      vec[2 * m + 1] = xh_norm3(tmp_vr, tmp_vi);
-      cap[2 * m + 1] = xh_norm3(tmp_cr, tmp_ci);
+      vec[2 * m] = na(1, i + 3 * m);
+      cap[2 * m] = na(0, i + 3 * m);
+      vec[2 * m + 1] = nb(1, i + 3 * m);
+      cap[2 * m + 1] = nb(0, i + 3 * m);
     }
     float tr = cap[XH_ZERO_BAND - 2].r, ti = cap[XH_ZERO_BAND - 2].i;
     const float tr1 = vec[XH_ZERO_BAND - 2].r, ti1 = vec[XH_ZERO_BAND - 2].i;
@@ -195,6 +197,13 @@ FX_HD void xh_prod3_block(const In &in, int qb, int i, float *blk) {
       blk[2 * k + 1] = (pi * 0.23570225f);
     }
   }
+}
+template <class In>
+FX_HD void xh_prod3_block(const In &in, int qb, int i, float *blk) {
+  const int inp = (2 * qb) / 3, rem = 2 * qb - 3 * inp;
+  xh_prod3_block_n([&](int sel, int row) { const XhC v = in(row, inp + sel); return xh_norm3(v.r, v.i); },
+                   [&](int sel, int row) { const XhC v = xh_interp3(in, inp + sel, row, rem == 2); return xh_norm3(v.r, v.i); },
+                   rem, i, blk);
 }
 
 /* ---- the pitch-adaptive cross products ---------------------------------------------------------------------------- */
@@ -407,11 +416,9 @@ FX_HD bool xh_xprod4(const Inf &inf, int qb, int i, float p, int pitch_idx, floa
 FX_HD float xh_pitch(int pitch_in_bins) { return (float)(pitch_in_bins * 0.08333333333333); }
 #define XH_BLK 25 /* floats per (band, column): <= 10 complex products, two cross terms, whether they exist */
 /* a column's whole contribution to band qb: blk[0..19] the block, blk[20..23] the cross terms, blk[24] != 0 with them */
-template <class In, class Inf>
-FX_HD void xh_column_block(const In &in, const Inf &inf, int factor, int qb, int i, int pitch_in_bins, float *blk) {
-  if (factor == 2) xh_prod2_block(in, qb, i, blk);
-  else if (factor == 3) xh_prod3_block(in, qb, i, blk);
-  else xh_prod4_block(in, qb, i, blk);
+/* the cross terms of a column: blk[20..23], blk[24] != 0 with them */
+template <class Inf>
+FX_HD void xh_column_cross(const Inf &inf, int factor, int qb, int i, int pitch_in_bins, float *blk) {
   const float p = xh_pitch(pitch_in_bins);
   bool has = false;
   if (!(p < 1.0f)) {
@@ -421,7 +428,13 @@ FX_HD void xh_column_block(const In &in, const Inf &inf, int factor, int qb, int
   }
   blk[24] = has ? 1.0f : 0.0f;
 }
-
+template <class In, class Inf>
+FX_HD void xh_column_block(const In &in, const Inf &inf, int factor, int qb, int i, int pitch_in_bins, float *blk) {
+  if (factor == 2) xh_prod2_block(in, qb, i, blk);
+  else if (factor == 3) xh_prod3_block(in, qb, i, blk);
+  else xh_prod4_block(in, qb, i, blk);
+  xh_column_cross(inf, factor, qb, i, pitch_in_bins, blk);
+}
 /* which stretch factor writes output band qb (0: none), from x_over_qmf and max_stretch (:1562-1580) */
 FX_HD int xh_band_factor(const int32_t *xo, int max_stretch, int qb) {
   if (2 <= max_stretch && qb >= xo[0] && qb < xo[1]) return 2;
@@ -438,7 +451,11 @@ template <class Blk>
 FX_HD float xh_prod_gather(float start, int factor, int r, int comp, const Blk &blk) {
   const int len = xh_block_len(factor), r0 = xh_block_row0(factor);
   float acc = start;
-  for (int i = 0; i < XAAC_HBE_NO_BINS / 2; i++) {
+  /* only columns with 0 <= r - r0 - 2 i < len reach the row (the cross terms' column (r - 5) / 2 is one of them) */
+  int i_lo = (r - r0 - len + 2) >> 1, i_hi = (r - r0) >> 1;
+  if (i_lo < 0) i_lo = 0;
+  if (i_hi > XAAC_HBE_NO_BINS / 2 - 1) i_hi = XAAC_HBE_NO_BINS / 2 - 1;
+  for (int i = i_lo; i <= i_hi; i++) {
     const float *b = blk(i);
     const int k = r - r0 - 2 * i;
     if (k >= 0 && k < len) acc += b[2 * k + comp];
