@@ -359,6 +359,9 @@ XE_NOINLINE FX_HD void xe_harmonic_patch(const XsCx &cx, const xaac_sbr_header *
   return;
 }
 
+/* HARM = false: a build without the harmonic branch (the kernel variant for batches without transposers: a frame with
+   harmonic_sbr set is refused there) */
+template <bool HARM = true>
 FX_HD void xe_generate_hf(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
                           xaac_esbr_state *st, XeWork *w, const XeMat &src, const XeMat &dst,
                           const XeMat *ph = nullptr /* ph_vocod_qmf rows (row 0 = the reference's + 2), harmonic patching */) {
@@ -380,16 +383,20 @@ FX_HD void xe_generate_hf(const XsCx &cx, const xaac_sbr_header *h, const xaac_s
   XS_ONE {
     w->err = 0;
     if (!sd->harmonic_sbr) xe_build_patches(h, sd, st, w);
-    else if (!ph) w->err = -1; /* no transposer behind this channel */
+    else if (!HARM || !ph) w->err = -1; /* no transposer behind this channel */
   }
   XS_PAR(k, usb, 64)
     for (int l = start; l < end; l++) {
       dst.r(l, k) = 0.0f;
       dst.i(l, k) = 0.0f;
     }
-  if (sd->harmonic_sbr) {
-    xe_harmonic_patch(cx, h, st, w, dst, *ph, start, end, usb, num_if);
-    return;
+  if constexpr (HARM) {
+    if (sd->harmonic_sbr) {
+      cx.sync();
+      if (w->err) return;
+      xe_harmonic_patch(cx, h, st, w, dst, *ph, start, end, usb, num_if);
+      return;
+    }
   }
   XS_PAR(k, 0, 64) {
     float a0r = 0, a0i = 0, a1r = 0, a1i = 0;

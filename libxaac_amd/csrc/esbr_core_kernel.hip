@@ -48,6 +48,8 @@ __device__ __forceinline__ void xe_copy_words(int32_t *dst, const int32_t *src, 
 }
 }  // namespace
 
+/* HARM: with the harmonic transposer's rows (batches that hand in hbe_state); the other variant carries none of that code */
+template <bool HARM>
 __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParams p) { /* 168 VGPRs: 12 waves per CU (measured best of 8 / 12 / 16) */
 #ifdef XE_PROFILE
   if (threadIdx.x == 0) {
@@ -106,8 +108,9 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
   /* the harmonic transposer's rows (sbr_dec.c:859-868): its launches wrote rows 8..39 of the scratch matrix for this frame
      if the channel has one with usable parameters; rows 0..7 are the previous frame's last rows */
   float *phr = p.ph_re + (size_t)ch * XAAC_ESBR_PH_ROWS * 64, *phi = p.ph_im + (size_t)ch * XAAC_ESBR_PH_ROWS * 64;
-  const bool have_ph = p.hbe && apply && xh_apply_params_ok(p.hbe + ch, sd->pitch_in_bins);
-  if (have_ph) {
+  bool have_ph = false;
+  if constexpr (HARM) have_ph = p.hbe && apply && xh_apply_params_ok(p.hbe + ch, sd->pitch_in_bins);
+  if (HARM && have_ph) {
     float t0[8], t1[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
@@ -133,10 +136,10 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
   }
   const XeMat ph = {phr + 128, phi + 128};
   if (apply && rc == 0) {
-    xe_generate_hf(cx, h, f, sd, st, &w, src, dst, have_ph ? &ph : nullptr);
+    xe_generate_hf<HARM>(cx, h, f, sd, st, &w, src, dst, have_ph ? &ph : nullptr);
     __syncthreads();
     XE_T(2);
-    rc = w.err ? -1 : xe_env_calc(cx, h, f, sd, st, &w, dst, src, have_ph ? p.hbe[ch].x_over_qmf : nullptr);
+    rc = w.err ? -1 : xe_env_calc(cx, h, f, sd, st, &w, dst, src, (HARM && have_ph) ? p.hbe[ch].x_over_qmf : nullptr);
   }
   __syncthreads();
   XE_T(3);
@@ -210,6 +213,7 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
 }
 
 extern "C" hipError_t xaac_launch_esbr_core(const XaacEsbrCoreParams *p, hipStream_t stream) {
-  hipLaunchKernelGGL(xaac_esbr_core_kernel, dim3(p->n_ch), dim3(64), 0, stream, *p);
+  if (p->hbe) hipLaunchKernelGGL(xaac_esbr_core_kernel<true>, dim3(p->n_ch), dim3(64), 0, stream, *p);
+  else hipLaunchKernelGGL(xaac_esbr_core_kernel<false>, dim3(p->n_ch), dim3(64), 0, stream, *p);
   return hipGetLastError();
 }

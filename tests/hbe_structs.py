@@ -23,3 +23,33 @@ def new_state(start_band, end_band=None):
     st.synth_size = 4 * ((start_band + 4) // 8 + 1)
     st.k_start = K_START[start_band]
     return st
+
+
+def state_from_tables(lo, hi, prev_max_stretch=0):
+    """what ixheaacd_qmf_hbe_data_reinit (hbe_trans.c:102-222) derives from an SBR header's low / high resolution
+    frequency-band tables for 2:1 SBR of a 1024-sample core, on a fresh transposer (tests/test_hbe_oracle_vs_reference.py
+    checks it against the reference's function)"""
+    lo, hi = [int(v) for v in lo], [int(v) for v in hi]
+    n_lo, n_hi = len(lo) - 1, len(hi) - 1
+    st = HbeState()
+    st.start_band, st.end_band = lo[0], lo[n_lo]
+    st.synth_size = 4 * ((st.start_band + 4) // 8 + 1)
+    st.k_start = K_START[st.start_band]
+    st.max_stretch = prev_max_stretch
+    sfb = 0
+    for patch in range(1, 5):
+        while sfb <= n_lo and lo[sfb] <= patch * st.start_band:
+            sfb += 1
+        if sfb <= n_lo:
+            if patch * st.start_band - lo[sfb - 1] <= 3:
+                st.x_over_qmf[patch - 1] = lo[sfb - 1]
+            else:
+                s2 = 0
+                while s2 <= n_hi and hi[s2] <= patch * st.start_band:
+                    s2 += 1
+                st.x_over_qmf[patch - 1] = hi[s2 - 1]
+        else:
+            st.x_over_qmf[patch - 1] = st.end_band
+            st.max_stretch = min(patch, 4)
+            break
+    return st

@@ -187,6 +187,30 @@ def test_apply_chain_with_a_pitch_on_tonal_input(oracle, reference):
     assert all(t > 50 for t in taken), taken   # every stretch factor's cross product ran on many (band, column) pairs
 
 
+def test_python_restatement_of_the_parameter_derivation(reference):
+    """tests/hbe_structs.state_from_tables (used where the reference is not at hand: bench.py) == ref_hbe_reinit"""
+    from hbe_structs import state_from_tables
+    fn = reference.lib.ref_hbe_reinit
+    fn.restype, fn.argtypes = ctypes.c_int, [P16, ctypes.c_int, P16, ctypes.c_int, ctypes.POINTER(HbeState)]
+    rng = np.random.default_rng(5)
+    tabs = record_tables() + [freq_tables(k) for k in range(5)]
+    for _ in range(200):
+        sb = int(rng.integers(1, 33))
+        hi = [sb]
+        while hi[-1] < 64 and len(hi) < 40 and rng.integers(0, 12):
+            hi.append(min(64, hi[-1] + int(rng.integers(1, 5))))
+        if len(hi) < 2:
+            hi.append(min(64, sb + 2))
+        lo = hi[::2] if (len(hi) - 1) % 2 == 0 else [hi[0]] + hi[1::2]
+        tabs.append((np.array(lo, np.int16), np.array(hi, np.int16)))
+    for lo, hi in tabs:
+        st = HbeState()
+        assert fn(lo.ctypes.data_as(P16), len(lo) - 1, hi.ctypes.data_as(P16), len(hi) - 1, ctypes.byref(st)) == 0
+        mine = state_from_tables(lo, hi)
+        got = (st.synth_size, st.k_start, st.start_band, st.end_band, list(st.x_over_qmf), st.max_stretch)
+        assert got == (mine.synth_size, mine.k_start, mine.start_band, mine.end_band, list(mine.x_over_qmf), mine.max_stretch), (lo, hi)
+
+
 def test_apply_chain_on_stream_headers(oracle, reference):
     tabs = record_tables()
     assert tabs
