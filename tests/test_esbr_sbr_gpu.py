@@ -147,7 +147,7 @@ def test_ps_chain_vs_oracle(oracle):
 
 
 @pytest.mark.gpu
-def test_chain_with_harmonic_transposer_vs_oracle(oracle, reference):
+def test_chain_with_harmonic_transposer_vs_oracle(oracle):
     """the chain with every channel's QMF harmonic transposer (hbe_state): it runs on every processed frame; frames with
     harmonic_sbr take the HF generator's input from it (with and without a pitch), others patch by LPP; the modes
     alternate within a stream.  Output samples, the eSBR state and the transposer's state identical to the oracle's
@@ -155,13 +155,10 @@ def test_chain_with_harmonic_transposer_vs_oracle(oracle, reference):
     tests/test_hbe_oracle_vs_reference.py)."""
     import torch
     import libxaac_amd
-    from hbe_structs import HbeState
+    from hbe_structs import HbeState, state_from_tables
     fn = oracle.lib.xo_esbr_sbr_frame_hbe
     fn.restype = ctypes.c_int
     fn.argtypes = [PF] + [ctypes.c_void_p] * 6 + [PF, PF, ctypes.c_void_p]
-    ri = reference.lib.ref_hbe_reinit
-    P16 = ctypes.POINTER(ctypes.c_int16)
-    ri.restype, ri.argtypes = ctypes.c_int, [P16, ctypes.c_int, P16, ctypes.c_int, ctypes.POINTER(HbeState)]
     recs = [r for r in c.read_records(os.path.join(ROOT, "tests", "golden", "sbr_lp_records.bin.gz"))]
     dev = torch.device("cuda:0")
     ctx = libxaac_amd.XaacContext(0, None)
@@ -191,11 +188,8 @@ def test_chain_with_harmonic_transposer_vs_oracle(oracle, reference):
             tables = bytes(h)[12:]
             if prev_tables[ch] != tables:   # a header reset: the host re-derives the transposer's parameters (hbe_trans.c:102)
                 sd.reset_flag = 1
-                lo = np.array(h.freq_band_tbl_lo[:h.num_sf_bands[0] + 1], np.int16)
-                hi = np.array(h.freq_band_tbl_hi[:h.num_sf_bands[1] + 1], np.int16)
-                fresh = HbeState()
-                fresh.max_stretch = hb_o[ch].max_stretch
-                assert ri(lo.ctypes.data_as(P16), len(lo) - 1, hi.ctypes.data_as(P16), len(hi) - 1, ctypes.byref(fresh)) == 0
+                fresh = state_from_tables(h.freq_band_tbl_lo[:h.num_sf_bands[0] + 1], h.freq_band_tbl_hi[:h.num_sf_bands[1] + 1],
+                                          hb_o[ch].max_stretch)   # pinned on the reference's function (test_hbe_oracle_vs_reference.py)
                 keep = hb_o[ch]
                 for name in ("synth_size", "k_start", "start_band", "end_band", "max_stretch"):
                     setattr(keep, name, getattr(fresh, name))

@@ -45,6 +45,7 @@ for r in range(1, rounds + 1):
         ("eSBR + float PS chain", lambda: te.test_ps_chain_vs_oracle(oracle)),
         ("eSBR banks", lambda: tq.test_gpu_analysis_then_synthesis_vs_oracle(oracle)),
         ("USAC IMDCT batch", lambda: tu.test_gpu_large_batch_vs_oracle(oracle)),
+        ("eSBR chain with harmonic SBR", lambda: te.test_chain_with_harmonic_transposer_vs_oracle(oracle)),
     ]
     for name, job in jobs:
         try:
