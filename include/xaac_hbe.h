@@ -7,9 +7,10 @@
  *   xaac_hbe_real_synth_batch  <-> ixheaacd_real_synth_filt     (esbr_polyphase.c:157-274)
  *   xaac_hbe_cplx_anal_batch   <-> ixheaacd_complex_anal_filt   (esbr_polyphase.c:48-155)
  *   xaac_hbe_apply_batch       <-> ixheaacd_qmf_hbe_apply       (hbe_trans.c:224-296)
+ *   xaac_hbe_dft_anal_batch_run <-> ixheaacd_dft_hbe_cplx_anal_filt (esbr_polyphase.c:276-338; the DFT transposer's bank)
  *
  * Scope: the QMF transposer (esbr_hq = 0) at 2:1 SBR of 1024-sample cores: no_bins = 32 QMF columns per frame, bank
- * sizes synth_size = 4, 8, 12, 16, 20 (hbe_trans.c:111-112).  The DFT transposer's bank (esbr_polyphase.c:276) is not
+ * sizes synth_size = 4, 8, 12, 16, 20 (hbe_trans.c:111-112).  Of the DFT transposer (esbr_hq) only its polyphase bank is
  * built.  All samples are FLOAT32; results are bit-identical to the reference's x86-64 build (float operations in the
  * reference's order, no contraction).
  */
@@ -57,6 +58,29 @@ typedef struct xaac_hbe_apply_batch_desc {
                                    and output are left alone */
 } xaac_hbe_apply_batch_desc;
 
+/* The DFT transposer's (esbr_hq) analysis bank, ixheaacd_dft_hbe_cplx_anal_filt: per channel its delay line and the two
+   sizes ixheaacd_dft_hbe_data_reinit derives (hbe_dft_trans.c:318-321) */
+typedef struct xaac_hbe_dft_anal_state {
+  float analy_buf[640];         /* analy_buf: 10 * analy_size samples in use */
+  int32_t analy_size;           /* 4 .. 64, a multiple of 4 */
+  int32_t a_start;              /* first sub-band written; a_start + analy_size <= 64 */
+} xaac_hbe_dft_anal_state;
+
+typedef struct xaac_hbe_dft_anal_batch {
+  int32_t n_ch;
+  int32_t no_bins;              /* columns per frame, <= 32 */
+  const float *time_in;         /* [n_ch][in_stride]: ptr_output_buf (column idx reads samples idx * analy_size + 1 ..) */
+  int32_t in_stride;            /* floats per channel, >= no_bins * analy_size + 1 */
+  const float *coef_re, *coef_im; /* [n_cfg][64][128]: str_dft_hbe_anal_coeff.real / .imag of the configurations in use */
+  const int32_t *cfg;           /* [n_ch]: which configuration a channel uses, or NULL (all 0) */
+  xaac_hbe_dft_anal_state *state; /* [n_ch] in/out */
+  float *qmf_re, *qmf_im;       /* [n_ch][no_bins + 2][64] in/out: qmf_buf_real / _imag rows.  Real rows: sub-bands a_start..63
+                                   rewritten.  Imaginary rows: the reference clears 128 floats from [idx][a_start] on, i.e. into
+                                   the next two rows (esbr_polyphase.c:300-301): rows 1..no_bins come out zero outside the
+                                   written sub-bands, row 0 keeps its sub-bands below a_start, row no_bins + 1 loses them */
+  int32_t *status;              /* [n_ch] or NULL */
+} xaac_hbe_dft_anal_batch;
+
 typedef struct xaac_hbe_anal_batch {
   int32_t n_ch;
   xaac_hbe_state *state;        /* [n_ch] in/out: input_buf read, analy_buf, qmf_in_buf rows 12..27 written */
@@ -71,6 +95,9 @@ extern "C" {
 int32_t xaac_hbe_real_synth_batch(xaac_ctx *ctx, const xaac_hbe_synth_batch *batch);
 /* ixheaacd_complex_anal_filt for n_ch channels: no_bins / 2 columns of 2 * synth_size complex sub-band samples */
 int32_t xaac_hbe_cplx_anal_batch(xaac_ctx *ctx, const xaac_hbe_anal_batch *batch);
+
+/* ixheaacd_dft_hbe_cplx_anal_filt (esbr_polyphase.c:276-338) for n_ch channels */
+int32_t xaac_hbe_dft_anal_batch_run(xaac_ctx *ctx, const xaac_hbe_dft_anal_batch *batch);
 
 /* ixheaacd_qmf_hbe_apply (hbe_trans.c:224-296) for n_ch channels: time-signal shift, synthesis bank, analysis bank,
    stretch-by-2/3/4 products into qmf_out_buf (with the pitch-adaptive cross products when pitch_in_bins / 12 >= 1),

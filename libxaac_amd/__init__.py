@@ -109,6 +109,16 @@ class _HbeApplyBatch(ctypes.Structure):
                 ("pv_im", ctypes.c_void_p), ("status", ctypes.c_void_p)]
 
 
+class _HbeDftAnalBatch(ctypes.Structure):
+    # struct xaac_hbe_dft_anal_batch
+    _fields_ = [("n_ch", ctypes.c_int32), ("no_bins", ctypes.c_int32), ("time_in", ctypes.c_void_p), ("in_stride", ctypes.c_int32),
+                ("coef_re", ctypes.c_void_p), ("coef_im", ctypes.c_void_p), ("cfg", ctypes.c_void_p), ("state", ctypes.c_void_p),
+                ("qmf_re", ctypes.c_void_p), ("qmf_im", ctypes.c_void_p), ("status", ctypes.c_void_p)]
+
+
+HBE_DFT_STATE_BYTES = 4 * 642   # struct xaac_hbe_dft_anal_state
+
+
 class _HbeAnalBatch(ctypes.Structure):
     # struct xaac_hbe_anal_batch
     _fields_ = [("n_ch", ctypes.c_int32), ("state", ctypes.c_void_p), ("status", ctypes.c_void_p)]
@@ -213,6 +223,8 @@ def load_library():
     lib.xaac_usac_imdct_process_batch.restype = ctypes.c_int32
     lib.xaac_hbe_real_synth_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_HbeSynthBatch)]
     lib.xaac_hbe_real_synth_batch.restype = ctypes.c_int32
+    lib.xaac_hbe_dft_anal_batch_run.argtypes = [ctypes.c_void_p, ctypes.POINTER(_HbeDftAnalBatch)]
+    lib.xaac_hbe_dft_anal_batch_run.restype = ctypes.c_int32
     lib.xaac_hbe_apply_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_HbeApplyBatch)]
     lib.xaac_hbe_apply_batch.restype = ctypes.c_int32
     lib.xaac_hbe_cplx_anal_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_HbeAnalBatch)]
@@ -490,6 +502,25 @@ class XaacContext:
         rc = self._lib.xaac_hbe_apply_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_hbe_apply_batch")
+
+    def hbe_dft_anal_batch(self, time_in, coef_re, coef_im, state, qmf_re, qmf_im, cfg=None, status=None, no_bins=32):
+        """Batched ixheaacd_dft_hbe_cplx_anal_filt (the DFT transposer's analysis bank): time_in float32[n_ch, stride];
+        coef_re / coef_im float32[n_cfg, 64, 128]; state uint8[n_ch, HBE_DFT_STATE_BYTES] in/out; qmf_re / qmf_im
+        float32[n_ch, no_bins + 2, 64] in/out; cfg int32[n_ch] or None."""
+        n_ch = state.shape[0]
+        b = _HbeDftAnalBatch()
+        b.n_ch, b.no_bins, b.in_stride = n_ch, no_bins, int(time_in.shape[1])
+        b.time_in = _ptr(time_in, "float32", n_ch * b.in_stride, device_ok=True)
+        b.coef_re = _ptr(coef_re, "float32", device_ok=True)
+        b.coef_im = _ptr(coef_im, "float32", device_ok=True)
+        b.cfg = _ptr(cfg, "int32", n_ch, device_ok=True) if cfg is not None else None
+        b.state = _ptr(state, "uint8", n_ch * HBE_DFT_STATE_BYTES, device_ok=True)
+        b.qmf_re = _ptr(qmf_re, "float32", n_ch * (no_bins + 2) * 64, device_ok=True)
+        b.qmf_im = _ptr(qmf_im, "float32", n_ch * (no_bins + 2) * 64, device_ok=True)
+        b.status = _ptr(status, "int32", n_ch, device_ok=True) if status is not None else None
+        rc = self._lib.xaac_hbe_dft_anal_batch_run(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_hbe_dft_anal_batch_run")
 
     def hbe_cplx_anal_batch(self, state, status=None):
         """Batched ixheaacd_complex_anal_filt (the harmonic transposer's complex analysis bank): state

@@ -50,9 +50,22 @@ typedef struct XaacHbePostParams {
                                    scratch rows; the reference leaves whatever its buffer held) */
 } XaacHbePostParams;
 
+#define XAAC_HBE_DFT_LDS (32 * 128 * 4) /* u of 32 columns */
+typedef struct XaacHbeDftParams {
+  int32_t n_ch, no_bins;
+  const float *time_in;
+  int32_t in_stride;
+  const float *coef_re, *coef_im;
+  const int32_t *cfg;
+  xaac_hbe_dft_anal_state *state;
+  float *qmf_re, *qmf_im;
+  int32_t *status;
+} XaacHbeDftParams;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+hipError_t xaac_launch_hbe_dft_anal(const XaacHbeDftParams *p, hipStream_t stream);
 hipError_t xaac_launch_hbe_synth(const XaacHbeSynParams *p, hipStream_t stream);
 hipError_t xaac_launch_hbe_anal(const XaacHbeAnaParams *p, hipStream_t stream);
 hipError_t xaac_launch_hbe_post(const XaacHbePostParams *p, hipStream_t stream);

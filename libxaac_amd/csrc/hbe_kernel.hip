@@ -233,6 +233,54 @@ __global__ __launch_bounds__(XAAC_HBE_POST_THREADS) void xaac_hbe_post_kernel(Xa
   if (tid == 0 && !st->fft_ready && st->synth_size != 20) st->fft_ready = 1;
 }
 
+/* The DFT transposer's analysis bank: 256 threads per channel; u of all columns into LDS (five window products each), then
+   thread = (column, sub-band) runs the 2 L-term sums against the coefficient matrices (global, shared by the channels of
+   a configuration), and the rows' cleared cells are written in the closed form of the reference's overlapping memsets. */
+__global__ __launch_bounds__(256) void xaac_hbe_dft_anal_kernel(XaacHbeDftParams p) {
+  extern __shared__ float lds[];
+  float(*u)[128] = reinterpret_cast<float(*)[128]>(lds);
+  const int ch = blockIdx.x, tid = threadIdx.x, nb = p.no_bins;
+  xaac_hbe_dft_anal_state *st = p.state + ch;
+  const int L = st->analy_size, a0 = st->a_start;
+  const bool bad = L < 4 || L > 64 || (L & 3) || a0 < 0 || a0 + L > 64 || nb < 1 || nb > 32;
+  if (tid == 0 && p.status) p.status[ch] = bad ? -1 : 0;
+  if (bad) return;
+  const float *tin = p.time_in + (size_t)ch * p.in_stride, *win = xh_window_dft(L);
+  const size_t c = p.cfg ? (size_t)p.cfg[ch] : 0;
+  const float *cre = p.coef_re + c * 64 * 128, *cim = p.coef_im + c * 64 * 128;
+  float *qre = p.qmf_re + (size_t)ch * (nb + 2) * 64, *qim = p.qmf_im + (size_t)ch * (nb + 2) * 64;
+  for (int e = tid; e < nb * 2 * L; e += 256) u[e / (2 * L)][e % (2 * L)] = xh_anal_u_w(tin, st->analy_buf, L, e / (2 * L), e % (2 * L), win);
+  float keep[3];
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const int n = tid + 256 * q;
+    keep[q] = n < 10 * L ? xh_anal_x(tin, st->analy_buf, L, nb - 1, n) : 0.0f;
+  }
+  __syncthreads();
+  for (int e = tid; e < (nb + 2) * 64; e += 256) {
+    const int idx = e >> 6, k = e & 63;
+    if (idx < nb && k >= a0 && k < a0 + L) {
+      float o_r, o_i;
+      xh_dft_anal_band(u[idx], 2 * L, cre + 128 * (k - a0), cim + 128 * (k - a0), o_r, o_i);
+      qre[e] = o_r;
+      qim[e] = o_i;
+    } else {
+      if (idx < nb && k >= a0) qre[e] = 0.0f;
+      if ((idx < nb && (idx > 0 || k >= a0)) || idx == nb || (idx == nb + 1 && k < a0)) qim[e] = 0.0f;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const int n = tid + 256 * q;
+    if (n < 10 * L) st->analy_buf[n] = keep[q];
+  }
+}
+
+extern "C" hipError_t xaac_launch_hbe_dft_anal(const XaacHbeDftParams *p, hipStream_t stream) {
+  hipLaunchKernelGGL(xaac_hbe_dft_anal_kernel, dim3(p->n_ch), dim3(256), XAAC_HBE_DFT_LDS, stream, *p);
+  return hipGetLastError();
+}
+
 extern "C" hipError_t xaac_launch_hbe_synth(const XaacHbeSynParams *p, hipStream_t stream) {
   hipLaunchKernelGGL(xaac_hbe_synth_kernel, dim3(p->n_ch), dim3(64), XAAC_HBE_SYN_LDS, stream, *p);
   return hipGetLastError();

@@ -321,14 +321,39 @@ FX_HD float xh_anal_x(const float *input_buf, const float *analy_buf, int a, int
   const int c = idx - n / a, i = n % a;
   return c >= 0 ? input_buf[(c + 1) * a - i] : analy_buf[(-1 - c) * a + i];
 }
-FX_HD float xh_anal_u(const float *input_buf, const float *analy_buf, int a, int idx, int i) { /* :100-109 */
-  const float *win = xh_window(a);
+FX_HD float xh_anal_u_w(const float *input_buf, const float *analy_buf, int a, int idx, int i, const float *win) { /* :100-109 */
   float accu = 0.0f;
   for (int j = 0; j < 5; j++) {
     const int n = i + j * 2 * a;
     accu = accu + xh_anal_x(input_buf, analy_buf, a, idx, n) * win[n];
   }
   return accu;
+}
+FX_HD float xh_anal_u(const float *input_buf, const float *analy_buf, int a, int idx, int i) {
+  return xh_anal_u_w(input_buf, analy_buf, a, idx, i, xh_window(a));
+}
+
+/* ---- the DFT transposer's analysis bank (ixheaacd_dft_hbe_cplx_anal_filt, esbr_polyphase.c:276-338) --------------- */
+/* prototype filter as ixheaacd_hbe_dft_trans.c:69-108 maps it: sizes 28 and 36 have their own table, 44 is the last of
+   the concatenated windows, every size without a case (48 .. 64) falls back to the start of the concatenation, which the bank then reads 10 L entries of */
+FX_HD const float *xh_window_dft(int len) {
+  switch (len) {
+    case 28: return xaac_hbe_window_28_36;
+    case 36: return xaac_hbe_window_28_36 + 280;
+    case 44: return xaac_hbe_window + 1560;
+    default: return xh_window(len);
+  }
+}
+/* sub-band k of a column: the sums over 2 L windowed-and-folded samples u[] against row k of the transposer's coefficient
+   matrices ([64][128], made by ixheaacd_dft_hbe_data_reinit, hbe_dft_trans.c:374-388) */
+FX_HD void xh_dft_anal_band(const float *u, int l2, const float *coef_re_row, const float *coef_im_row, float &out_r, float &out_i) {
+  float accu_r = 0, accu_i = 0;
+  for (int l = 0; l < l2; l++) {
+    accu_r = accu_r + u[l] * coef_re_row[l];
+    accu_i = accu_i + u[l] * coef_im_row[l];
+  }
+  out_r = accu_r;
+  out_i = accu_i;
 }
 /* One column: u[0 .. 2 a) -> a complex sub-band samples out[0 .. 2 a) (:110-152).  u is overwritten; w: XH_FFT_SCRATCH. */
 FX_HD void xh_anal_column(float *u, int a, float *out, float *w) {

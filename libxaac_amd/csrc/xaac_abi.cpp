@@ -373,6 +373,18 @@ int32_t xaac_hbe_cplx_anal_batch(xaac_ctx *c, const xaac_hbe_anal_batch *b) {
   return XAAC_OK;
 }
 
+int32_t xaac_hbe_dft_anal_batch_run(xaac_ctx *c, const xaac_hbe_dft_anal_batch *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n_ch < 0 || b->no_bins < 1 || b->no_bins > XAAC_HBE_NO_BINS || b->in_stride < 1) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch == 0) return XAAC_OK;
+  if (!b->time_in || !b->coef_re || !b->coef_im || !b->state || !b->qmf_re || !b->qmf_im) return XAAC_FATAL_NULL_ARG;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  XaacHbeDftParams p = {b->n_ch, b->no_bins, b->time_in, b->in_stride, b->coef_re, b->coef_im, b->cfg, b->state, b->qmf_re, b->qmf_im, b->status};
+  if (!hip_ok(xaac_launch_hbe_dft_anal(&p, c->stream))) return XAAC_FATAL_HIP;
+  c->last_grid = b->n_ch; c->last_block = 256; c->last_lds = XAAC_HBE_DFT_LDS;
+  return XAAC_OK;
+}
+
 int32_t xaac_hbe_apply_batch(xaac_ctx *c, const xaac_hbe_apply_batch_desc *b) {
   if (!c || !b) return XAAC_FATAL_NULL_ARG;
   if (b->n_ch < 0) return XAAC_FATAL_BAD_ARG;

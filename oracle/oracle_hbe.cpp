@@ -45,6 +45,31 @@ int xo_hbe_cplx_anal(xaac_hbe_state *st) {
   return 0;
 }
 
+/* ixheaacd_dft_hbe_cplx_anal_filt (esbr_polyphase.c:276-338).  time_in: ptr_output_buf; coef_re / coef_im: [64][128];
+   qmf_re / qmf_im: [no_bins + 2][64] in/out (see include/xaac_hbe.h for what the reference's clears reach). */
+int xo_hbe_dft_anal(xaac_hbe_dft_anal_state *st, const float *time_in, const float *coef_re, const float *coef_im, int no_bins,
+                    float *qmf_re, float *qmf_im) {
+  const int L = st->analy_size, a0 = st->a_start;
+  if (L < 4 || L > 64 || (L & 3) || a0 < 0 || a0 + L > 64 || no_bins < 1 || no_bins > 32) return -1;
+  const float *win = xh_window_dft(L);
+  static thread_local float u[128];
+  for (int idx = 0; idx < no_bins; idx++) {
+    for (int i = 0; i < 2 * L; i++) u[i] = xh_anal_u_w(time_in, st->analy_buf, L, idx, i, win);
+    for (int k = 0; k < 64; k++) { /* the clears of this column and of the two before it, then the column's sub-bands */
+      if (k >= a0) qmf_re[64 * idx + k] = 0.0f;
+      if (idx > 0 || k >= a0) qmf_im[64 * idx + k] = 0.0f;
+    }
+    for (int k = 0; k < L; k++)
+      xh_dft_anal_band(u, 2 * L, coef_re + 128 * k, coef_im + 128 * k, qmf_re[64 * idx + a0 + k], qmf_im[64 * idx + a0 + k]);
+  }
+  for (int k = 0; k < 64; k++) qmf_im[64 * no_bins + k] = 0.0f;
+  for (int k = 0; k < a0; k++) qmf_im[64 * (no_bins + 1) + k] = 0.0f;
+  float nb[640];
+  for (int n = 0; n < 10 * L; n++) nb[n] = xh_anal_x(time_in, st->analy_buf, L, no_bins - 1, n);
+  memcpy(st->analy_buf, nb, sizeof(float) * 10 * L);
+  return 0;
+}
+
 /* test coverage: how many (band, column) pairs took a cross product, per stretch factor, since the last reset */
 static long xo_hbe_cross_taken[3];
 long xo_hbe_cross_count(int factor, int reset) {

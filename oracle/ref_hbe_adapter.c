@@ -142,3 +142,40 @@ int ref_hbe_apply(xaac_hbe_state *st, const int16_t *tbl_lo, int n_lo, const int
   st->fft_ready = hbe_t.ixheaacd_cmplx_anal_fft != NULL;
   return rc;
 }
+
+WORD32 ixheaacd_dft_hbe_cplx_anal_filt(ia_esbr_hbe_txposer_struct *ptr_hbe_txposer, FLOAT32 qmf_buf_real[][64],
+                                       FLOAT32 qmf_buf_imag[][64]);
+WORD32 ixheaacd_dft_hbe_data_reinit(ia_esbr_hbe_txposer_struct *ptr_hbe_txposer, WORD16 *p_freq_band_tab[2], WORD16 *p_num_sfb);
+
+/* the DFT transposer's analysis bank on a transposer the reference sets up itself from two frequency tables
+   (ixheaacd_dft_hbe_data_reinit, hbe_dft_trans.c:272): its coefficient matrices are copied out for the caller
+   (coef_re / coef_im [64][128]), the delay line goes in and out through st, time_in -> ptr_output_buf (4096 floats) */
+int ref_hbe_dft_anal(const int16_t *tbl_lo, int n_lo, const int16_t *tbl_hi, int n_hi, xaac_hbe_dft_anal_state *st,
+                     const float *time_in, int n_time, float *coef_re, float *coef_im, float *qmf_re, float *qmf_im) {
+  WORD32 used = 0;
+  int i;
+  WORD16 lo[64], hi[64], nsf[2];
+  WORD16 *tab[2];
+  if (n_lo < 0 || n_lo > 62 || n_hi < 0 || n_hi > 62 || n_time > 4096) return -1;
+  ixheaacd_esbr_hbe_data_init(&hbe_t, 1024, 0, 2048, hbe_mem, &used);
+  for (i = 0; i <= n_lo; i++) lo[i] = tbl_lo[i];
+  for (i = 0; i <= n_hi; i++) hi[i] = tbl_hi[i];
+  nsf[0] = (WORD16)n_lo;
+  nsf[1] = (WORD16)n_hi;
+  tab[0] = lo;
+  tab[1] = hi;
+  if (ixheaacd_dft_hbe_data_reinit(&hbe_t, tab, nsf)) return -1;
+  if (st->analy_size == 0) { /* first call: report what the reference derived */
+    st->analy_size = hbe_t.analy_size;
+    st->a_start = hbe_t.a_start;
+  }
+  if (hbe_t.analy_size != st->analy_size || hbe_t.a_start != st->a_start) return -2;
+  memcpy(coef_re, hbe_t.str_dft_hbe_anal_coeff.real, sizeof(hbe_t.str_dft_hbe_anal_coeff.real));
+  memcpy(coef_im, hbe_t.str_dft_hbe_anal_coeff.imag, sizeof(hbe_t.str_dft_hbe_anal_coeff.imag));
+  memcpy(hbe_t.analy_buf, st->analy_buf, sizeof(st->analy_buf));
+  memset(hbe_t.ptr_output_buf, 0, 4096 * sizeof(FLOAT32));
+  memcpy(hbe_t.ptr_output_buf, time_in, sizeof(FLOAT32) * n_time);
+  i = ixheaacd_dft_hbe_cplx_anal_filt(&hbe_t, (FLOAT32(*)[64])qmf_re, (FLOAT32(*)[64])qmf_im);
+  memcpy(st->analy_buf, hbe_t.analy_buf, sizeof(st->analy_buf));
+  return i;
+}

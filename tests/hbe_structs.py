@@ -12,6 +12,10 @@ class HbeState(ctypes.Structure):
                 ("x_over_qmf", I32 * 6), ("max_stretch", I32), ("fft_ready", I32)]
 
 
+class HbeDftState(ctypes.Structure):
+    _fields_ = [("analy_buf", F * 640), ("analy_size", I32), ("a_start", I32)]
+
+
 K_START = [0, 0, 0, 0, 0, 0, 0, 2, 2, 2, 4, 4, 4, 4, 4, 6, 6, 6, 8, 8, 8, 8, 8, 10, 10, 10, 12, 12, 12, 12, 12, 12, 12]
 
 

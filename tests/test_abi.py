@@ -92,7 +92,8 @@ def test_hbe_struct_layouts_match_header(tmp_path):
     import hbe_structs as hs
     pairs = [("xaac_hbe_state", hs.HbeState, "max_stretch"), ("xaac_hbe_synth_batch", libxaac_amd._HbeSynthBatch, "status"),
              ("xaac_hbe_anal_batch", libxaac_amd._HbeAnalBatch, "status"),
-             ("xaac_hbe_apply_batch_desc", libxaac_amd._HbeApplyBatch, "status")]
+             ("xaac_hbe_apply_batch_desc", libxaac_amd._HbeApplyBatch, "status"),
+             ("xaac_hbe_dft_anal_batch", libxaac_amd._HbeDftAnalBatch, "status"), ("xaac_hbe_dft_anal_state", hs.HbeDftState, "a_start")]
     body = "".join('printf("%%zu %%zu\\n", sizeof(%s), offsetof(%s, %s));' % (c, c, last) for c, _, last in pairs)
     src = tmp_path / "layout3.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "xaac_hbe.h"\nint main(void) { %s return 0; }\n' % body)

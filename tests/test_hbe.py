@@ -182,3 +182,57 @@ def test_gpu_apply_matches_reference_and_oracle(oracle):
                 assert (_crc(got[c]), _crc(g_re[c]), _crc(g_im[c])) == tuple(int(v) for v in GOLD["apply_crc"][c, f]), (f, c)
         assert [bytes(got[-2]), bytes(got[-1])] == untouched
         assert np.all(g_re[-2:] == 7.5) and np.all(g_im[-2:] == 7.5)
+
+
+@pytest.mark.gpu
+def test_gpu_dft_transposer_analysis_bank(oracle):
+    """xaac_hbe_dft_anal_batch_run (ixheaacd_dft_hbe_cplx_anal_filt; the oracle is pinned on the reference for every
+    prototype-filter case in tests/test_hbe_oracle_vs_reference.py): a batch with one channel per bank size, three
+    configurations' coefficient matrices, chains of frames with the delay lines carried; rows incl. the cleared cells and
+    states identical to the oracle's."""
+    import torch
+    import libxaac_amd
+    from hbe_structs import HbeDftState
+    oo = oracle.lib.xo_hbe_dft_anal
+    oo.restype = ctypes.c_int
+    oo.argtypes = [ctypes.POINTER(HbeDftState), PF, PF, PF, ctypes.c_int, PF, PF]
+    dev = torch.device("cuda:0")
+    ctx = libxaac_amd.XaacContext(0, None)
+    cfgs = [(8, 0), (24, 8), (28, 8), (36, 12), (44, 20), (60, 4), (64, 0), (4, 60), (40, 16), (12, 3)]   # (analy_size, a_start)
+    n = len(cfgs) + 1
+    rng = np.random.default_rng(21)
+    coef = np.zeros((n, 2, 64, 128), np.float32)
+    for c, (L, a0) in enumerate(cfgs):   # the reference's formula (hbe_dft_trans.c:374-388); any matrices would do here
+        k, l = np.arange(64)[:, None], np.arange(128)[None, :]
+        ang = np.pi / (2 * L) * ((k + 0.5) * (2 * l - L / 64.0) - L / 64.0 * a0)
+        coef[c, 0], coef[c, 1] = np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+    host = [HbeDftState() for _ in range(n)]
+    for c, (L, a0) in enumerate(cfgs):
+        host[c].analy_size, host[c].a_start = L, a0
+    host[-1].analy_size, host[-1].a_start = 30, 0   # not a multiple of four: refused
+    state = _states_tensor(torch, dev, host)
+    cre, cim = torch.from_numpy(np.ascontiguousarray(coef[:, 0])).to(dev), torch.from_numpy(np.ascontiguousarray(coef[:, 1])).to(dev)
+    cfg = torch.arange(n, dtype=torch.int32, device=dev)
+    status = torch.full((n,), 7, dtype=torch.int32, device=dev)
+    for frame in range(4):
+        t = (rng.standard_normal((n, 2100)) * 2.0 ** rng.integers(-3, 12, (n, 1))).astype(np.float32)
+        if frame == 2:
+            t[:] = 0
+        q = [rng.standard_normal((n, 34, 64)).astype(np.float32) for _ in range(2)]
+        g = [torch.from_numpy(a.copy()).to(dev) for a in q]
+        ctx.hbe_dft_anal_batch(torch.from_numpy(t).to(dev), cre, cim, state, g[0], g[1], cfg, status)
+        ctx.sync()
+        got = [a.cpu().numpy() for a in g]
+        gs = state.cpu().numpy()
+        assert status.cpu().tolist() == [0] * (n - 1) + [-1]
+        for c in range(n - 1):
+            tt = np.zeros(4096, np.float32)
+            tt[:2100] = t[c]
+            o = [q[0][c].copy(), q[1][c].copy()]
+            assert oo(ctypes.byref(host[c]), tt.ctypes.data_as(PF), coef[c, 0].ctypes.data_as(PF), coef[c, 1].ctypes.data_as(PF), 32,
+                      o[0].ctypes.data_as(PF), o[1].ctypes.data_as(PF)) == 0
+            for a, b, nm in zip(o, got, ("real", "imag")):
+                d = np.argwhere(a.view(np.uint32) != b[c].view(np.uint32))
+                assert d.size == 0, (nm, frame, cfgs[c], d[:4].tolist())
+            assert np.array_equal(np.frombuffer(bytes(host[c]), np.uint8), gs[c]), ("delay line", frame, cfgs[c])
+        assert np.array_equal(got[0][-1], q[0][-1]) and np.array_equal(got[1][-1], q[1][-1])

@@ -243,3 +243,49 @@ def test_apply_refuses_pitch_frames_and_bad_parameters(oracle, reference):
     assert oa(ctypes.byref(st), _p(z), _p(z), 0, _p(z.copy()), _p(z.copy())) == -1
     st.x_over_qmf[1] = 20
     assert bytes(st) != before or True
+
+
+def dft_tables(kind):
+    """frequency tables that give the DFT transposer's bank a spread of sizes (analy_size 4 .. 64 incl. 28, 36 and the
+    sizes above 40 that have no prototype of their own) and start bands"""
+    sb, end = [(2, 7), (9, 31), (14, 47), (22, 64), (30, 64), (11, 38), (17, 52), (6, 61), (24, 51), (10, 35)][kind]
+    hi = list(range(sb, end, 3)) + [end]
+    lo = hi[::2] if (len(hi) - 1) % 2 == 0 else [hi[0]] + hi[1::2]
+    return np.array(lo, np.int16), np.array(hi, np.int16)
+
+
+def _dft_fns(oracle, reference):
+    from hbe_structs import HbeDftState
+    ro, oo = reference.lib.ref_hbe_dft_anal, oracle.lib.xo_hbe_dft_anal
+    ro.restype = ctypes.c_int
+    ro.argtypes = [P16, ctypes.c_int, P16, ctypes.c_int, ctypes.POINTER(HbeDftState), PF, ctypes.c_int, PF, PF, PF, PF]
+    oo.restype = ctypes.c_int
+    oo.argtypes = [ctypes.POINTER(HbeDftState), PF, PF, PF, ctypes.c_int, PF, PF]
+    return ro, oo, HbeDftState
+
+
+@pytest.mark.parametrize("kind", range(10))
+def test_dft_transposer_analysis_bank(oracle, reference, kind):
+    """ixheaacd_dft_hbe_cplx_anal_filt (esbr_polyphase.c:276): output rows incl. the cells its overlapping clears reach
+    and the delay line, chains of frames, coefficient matrices as the reference's own re-initialisation makes them"""
+    ro, oo, S = _dft_fns(oracle, reference)
+    lo, hi = dft_tables(kind)
+    rng = np.random.default_rng(1500 + kind)
+    sr, so = S(), S()
+    coef = [np.zeros((64, 128), np.float32) for _ in range(2)]
+    sizes = None
+    for frame in range(4):
+        t = (rng.standard_normal(4096) * 2.0 ** rng.integers(-2, 14)).astype(np.float32) if frame != 2 else np.zeros(4096, np.float32)
+        qr = [(rng.standard_normal((34, 64))).astype(np.float32) for _ in range(2)]   # what the rows held before
+        qo = [a.copy() for a in qr]
+        assert ro(lo.ctypes.data_as(P16), len(lo) - 1, hi.ctypes.data_as(P16), len(hi) - 1, ctypes.byref(sr), _p(t), 4096,
+                  _p(coef[0]), _p(coef[1]), _p(qr[0]), _p(qr[1])) == 0
+        if sizes is None:
+            sizes = (sr.analy_size, sr.a_start)
+            so.analy_size, so.a_start = sizes
+        assert oo(ctypes.byref(so), _p(t), _p(coef[0]), _p(coef[1]), 32, _p(qo[0]), _p(qo[1])) == 0
+        assert np.array_equal(np.frombuffer(bytes(sr), np.uint32), np.frombuffer(bytes(so), np.uint32)), ("delay line", frame)
+        for a, b, nm in zip(qr, qo, ("real", "imag")):
+            d = np.argwhere(a.view(np.uint32) != b.view(np.uint32))
+            assert d.size == 0, (nm, frame, sizes, d[:4].tolist())
+    assert sizes[0] % 4 == 0 and 4 <= sizes[0] <= 64
