@@ -184,6 +184,57 @@ def test_gpu_apply_matches_reference_and_oracle(oracle):
         assert np.all(g_re[-2:] == 7.5) and np.all(g_im[-2:] == 7.5)
 
 
+def _dft_oracle(oracle):
+    from hbe_structs import HbeDftState
+    oo = oracle.lib.xo_hbe_dft_anal
+    oo.restype = ctypes.c_int
+    oo.argtypes = [ctypes.POINTER(HbeDftState), PF, PF, PF, ctypes.c_int, PF, PF]
+    return oo, HbeDftState
+
+
+def test_oracle_dft_bank_matches_reference_chains(oracle):
+    """reference-made chains of the DFT transposer's analysis bank (its own coefficient matrices stored with them)"""
+    from make_golden_hbe import DFT_FRAMES, dft_input
+    oo, S = _dft_oracle(oracle)
+    for c, (L, a0) in enumerate(GOLD["dft_sizes"]):
+        st = S()
+        st.analy_size, st.a_start = int(L), int(a0)
+        cre, cim = np.ascontiguousarray(GOLD["dft_coef"][c, 0]), np.ascontiguousarray(GOLD["dft_coef"][c, 1])
+        for f in range(DFT_FRAMES):
+            t, q = dft_input(c, f)
+            assert oo(ctypes.byref(st), t.ctypes.data_as(PF), cre.ctypes.data_as(PF), cim.ctypes.data_as(PF), 32,
+                      q[0].ctypes.data_as(PF), q[1].ctypes.data_as(PF)) == 0
+            assert (_crc(bytes(st)), _crc(q[0]), _crc(q[1])) == tuple(int(v) for v in GOLD["dft_crc"][c, f]), (c, f)
+
+
+@pytest.mark.gpu
+def test_gpu_dft_bank_matches_reference_chains():
+    import torch
+    import libxaac_amd
+    from hbe_structs import HbeDftState
+    from make_golden_hbe import DFT_FRAMES, dft_input
+    dev = torch.device("cuda:0")
+    ctx = libxaac_amd.XaacContext(0, None)
+    n = len(GOLD["dft_sizes"])
+    host = [HbeDftState() for _ in range(n)]
+    for c, (L, a0) in enumerate(GOLD["dft_sizes"]):
+        host[c].analy_size, host[c].a_start = int(L), int(a0)
+    state = _states_tensor(torch, dev, host)
+    cre = torch.from_numpy(np.ascontiguousarray(GOLD["dft_coef"][:, 0])).to(dev)
+    cim = torch.from_numpy(np.ascontiguousarray(GOLD["dft_coef"][:, 1])).to(dev)
+    cfg = torch.arange(n, dtype=torch.int32, device=dev)
+    for f in range(DFT_FRAMES):
+        ins = [dft_input(c, f) for c in range(n)]
+        t = torch.from_numpy(np.stack([i[0] for i in ins])).to(dev)
+        qr = torch.from_numpy(np.stack([i[1][0] for i in ins])).to(dev)
+        qi = torch.from_numpy(np.stack([i[1][1] for i in ins])).to(dev)
+        ctx.hbe_dft_anal_batch(t, cre, cim, state, qr, qi, cfg)
+        ctx.sync()
+        s, a, b = state.cpu().numpy(), qr.cpu().numpy(), qi.cpu().numpy()
+        for c in range(n):
+            assert (_crc(s[c]), _crc(a[c]), _crc(b[c])) == tuple(int(v) for v in GOLD["dft_crc"][c, f]), (c, f)
+
+
 @pytest.mark.gpu
 def test_gpu_dft_transposer_analysis_bank(oracle):
     """xaac_hbe_dft_anal_batch_run (ixheaacd_dft_hbe_cplx_anal_filt; the oracle is pinned on the reference for every
@@ -192,10 +243,7 @@ def test_gpu_dft_transposer_analysis_bank(oracle):
     states identical to the oracle's."""
     import torch
     import libxaac_amd
-    from hbe_structs import HbeDftState
-    oo = oracle.lib.xo_hbe_dft_anal
-    oo.restype = ctypes.c_int
-    oo.argtypes = [ctypes.POINTER(HbeDftState), PF, PF, PF, ctypes.c_int, PF, PF]
+    oo, HbeDftState = _dft_oracle(oracle)
     dev = torch.device("cuda:0")
     ctx = libxaac_amd.XaacContext(0, None)
     cfgs = [(8, 0), (24, 8), (28, 8), (36, 12), (44, 20), (60, 4), (64, 0), (4, 60), (40, 16), (12, 3)]   # (analy_size, a_start)

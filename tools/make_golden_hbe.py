@@ -143,11 +143,54 @@ def run_apply_reference(ref_lib):
     return crcs, params, last_pv
 
 
+DFT_TABLES = [(9, 31), (10, 35), (22, 64), (6, 61)]   # analy_size 24, 28, 44, 60
+DFT_FRAMES = 3
+
+
+def dft_tables(kind):
+    sb, end = DFT_TABLES[kind]
+    hi = list(range(sb, end, 3)) + [end]
+    lo = hi[::2] if (len(hi) - 1) % 2 == 0 else [hi[0]] + hi[1::2]
+    return np.array(lo, np.int16), np.array(hi, np.int16)
+
+
+def dft_input(chain, frame):
+    """(time signal float32[4096], rows before the call float32[2][34][64])"""
+    rng = np.random.default_rng(99000 + 100 * chain + frame)
+    t = (rng.standard_normal(4096) * 2.0 ** rng.integers(0, 12)).astype(np.float32)
+    return t, rng.standard_normal((2, 34, 64)).astype(np.float32)
+
+
+def run_dft_reference(ref_lib):
+    """the DFT transposer's analysis bank on the reference's own coefficient matrices: per chain the sizes it derives, its
+    matrices (as float16-exact? no: float32, stored), and per frame the CRCs of delay line + both row blocks"""
+    from hbe_structs import HbeDftState
+    fn = ref_lib.ref_hbe_dft_anal
+    fn.restype = ctypes.c_int
+    fn.argtypes = [P16, ctypes.c_int, P16, ctypes.c_int, ctypes.POINTER(HbeDftState), PF, ctypes.c_int, PF, PF, PF, PF]
+    n = len(DFT_TABLES)
+    sizes = np.zeros((n, 2), np.int32)
+    coef = np.zeros((n, 2, 64, 128), np.float32)
+    crcs = np.zeros((n, DFT_FRAMES, 3), np.uint32)
+    for c in range(n):
+        lo, hi = dft_tables(c)
+        st = HbeDftState()
+        for f in range(DFT_FRAMES):
+            t, q = dft_input(c, f)
+            assert fn(lo.ctypes.data_as(P16), len(lo) - 1, hi.ctypes.data_as(P16), len(hi) - 1, ctypes.byref(st), t.ctypes.data_as(PF), 4096,
+                      coef[c, 0].ctypes.data_as(PF), coef[c, 1].ctypes.data_as(PF), q[0].ctypes.data_as(PF), q[1].ctypes.data_as(PF)) == 0
+            crcs[c, f] = [zlib.crc32(bytes(st)) & 0xffffffff, zlib.crc32(q[0].tobytes()) & 0xffffffff, zlib.crc32(q[1].tobytes()) & 0xffffffff]
+        sizes[c] = [st.analy_size, st.a_start]
+    return sizes, coef, crcs
+
+
 if __name__ == "__main__":
     ref = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_harness.so"))
     crcs, last_time, last_rows = run(ref, "ref")
     acrc, apar, apv = run_apply_reference(ref)
+    dsz, dcoef, dcrc = run_dft_reference(ref)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "hbe_ref.npz"), crc=crcs, last_time=last_time, last_rows=last_rows,
-                        apply_crc=acrc, apply_params=apar, apply_last_pv=apv)
+                        apply_crc=acrc, apply_params=apar, apply_last_pv=apv, dft_sizes=dsz, dft_coef=dcoef, dft_crc=dcrc)
+    print("dft chains", dsz.tolist())
     print("apply chains", len(apar), "params", apar.tolist())
     print("chains", len(START_BANDS), "frames", FRAMES, "crc[0]", crcs[0].tolist())
