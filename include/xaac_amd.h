@@ -106,6 +106,29 @@ typedef struct xaac_qmf_ana_state {
   int16_t phase;     /* filter_pos - qmf_c */
 } xaac_qmf_ana_state;  /* zero-initialised for a new stream (sbrdec_initfuncs.c:1105-1122) */
 
+/* The LD / ELD flavour of the complex analysis bank (ixheaacd_cplx_anal_qmffilt with AOT_ER_AAC_LD / _ELD,
+ * generic/ixheaacd_qmf_dec_generic.c:590-741: low-delay prototype qmf_c_eld3, ixheaacd_sbr_qmfanal32_winadd_eld
+ * qmf_dec.c:484-535, ELD post-modulation twiddles): the reference keeps four rotating pointers between frames. */
+typedef struct xaac_qmf_ana_eld_state {
+  int16_t ring[320]; /* anal_filter_states */
+  int16_t wr;        /* core_samples_buffer - anal_filter_states */
+  int16_t f1;        /* filter_pos - qmf_c_eld3 */
+  int16_t f2;        /* filter_2 - qmf_c_eld3 */
+  int16_t fp;        /* fp1_anal - anal_filter_states (0 or 32; fp2_anal is the other) */
+} xaac_qmf_ana_eld_state; /* a new stream: ring zero, {0, 0, 32, 0} (sbrdec_initfuncs.c:1122-1148) */
+
+typedef struct xaac_qmf_ana_eld_batch {
+  int32_t n_ch;
+  int32_t n_slots;           /* QMF slots per frame: 16 (512-sample frames) or 15 (480) */
+  int32_t usb;               /* bands that get the post-modulation rotation (qmf_bank->usb; lsb is 0) */
+  int32_t slot_stride;       /* words between consecutive slots in qmf (>= 96: imaginary bands at +64) */
+  const int16_t *pcm;        /* [n_ch][32 * n_slots] core-decoder PCM16, planar */
+  xaac_qmf_ana_eld_state *state; /* [n_ch] in/out */
+  int32_t *qmf;              /* [n_ch][n_slots][slot_stride]: 32 real bands at +0, 32 imaginary at +64 */
+  int32_t *status;           /* [n_ch] or NULL: 0, or -1 for a state whose four pointers are not one of the ten phases the
+                                bank can be in (such a channel is left alone) */
+} xaac_qmf_ana_eld_batch;
+
 typedef struct xaac_qmf_syn_state {
   int16_t ring[1280]; /* filter_states */
   int16_t drc_offset; /* ixheaacd_drc_offset */
@@ -327,6 +350,8 @@ int32_t xaac_usac_imdct_process_batch(xaac_ctx *ctx, const xaac_usac_imdct_batch
 
 /* eSBR (Path A) QMF banks, device pointers, asynchronous on the context's stream. */
 int32_t xaac_esbr_qmf_analysis_batch(xaac_ctx *ctx, const xaac_esbr_ana_batch *batch);
+/* ixheaacd_cplx_anal_qmffilt for AAC-LD / ELD cores (complex bank, 16 or 15 slots per frame) */
+int32_t xaac_qmf_analysis_eld_batch(xaac_ctx *ctx, const xaac_qmf_ana_eld_batch *batch);
 int32_t xaac_esbr_qmf_synthesis_batch(xaac_ctx *ctx, const xaac_esbr_syn_batch *batch);
 
 /* Low-power SBR channel-frames (QMF analysis -> HF generation + envelope adjustment -> QMF synthesis). */

@@ -90,6 +90,15 @@ class _UsacImdctBatch(ctypes.Structure):
                 ("time", ctypes.c_void_p), ("status", ctypes.c_void_p)]
 
 
+class _QmfAnaEldBatch(ctypes.Structure):
+    # struct xaac_qmf_ana_eld_batch
+    _fields_ = [("n_ch", ctypes.c_int32), ("n_slots", ctypes.c_int32), ("usb", ctypes.c_int32), ("slot_stride", ctypes.c_int32),
+                ("pcm", ctypes.c_void_p), ("state", ctypes.c_void_p), ("qmf", ctypes.c_void_p), ("status", ctypes.c_void_p)]
+
+
+QMF_ANA_ELD_STATE_WORDS = 324   # struct xaac_qmf_ana_eld_state: ring[320], wr, f1, f2, fp (int16)
+
+
 class _EsbrAnaBatch(ctypes.Structure):
     # struct xaac_esbr_ana_batch
     _fields_ = [("n_ch", ctypes.c_int32), ("core", ctypes.c_void_p), ("state", ctypes.c_void_p),
@@ -229,6 +238,8 @@ def load_library():
     lib.xaac_hbe_apply_batch.restype = ctypes.c_int32
     lib.xaac_hbe_cplx_anal_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_HbeAnalBatch)]
     lib.xaac_hbe_cplx_anal_batch.restype = ctypes.c_int32
+    lib.xaac_qmf_analysis_eld_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_QmfAnaEldBatch)]
+    lib.xaac_qmf_analysis_eld_batch.restype = ctypes.c_int32
     lib.xaac_esbr_qmf_analysis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_EsbrAnaBatch)]
     lib.xaac_esbr_qmf_analysis_batch.restype = ctypes.c_int32
     lib.xaac_esbr_qmf_synthesis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_EsbrSynBatch)]
@@ -533,6 +544,20 @@ class XaacContext:
         rc = self._lib.xaac_hbe_cplx_anal_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_hbe_cplx_anal_batch")
+
+    def qmf_analysis_eld_batch(self, pcm, state, qmf, n_slots, usb, status=None):
+        """Batched LD / ELD complex analysis bank: pcm int16[n_ch, 32 * n_slots]; state int16[n_ch, 324] in/out (ring, wr,
+        f1, f2, fp; a new stream: zeros with f2 = 32); qmf int32[n_ch, n_slots, slot_stride >= 96]."""
+        n_ch = state.shape[0]
+        b = _QmfAnaEldBatch()
+        b.n_ch, b.n_slots, b.usb, b.slot_stride = n_ch, n_slots, usb, int(qmf.shape[2])
+        b.pcm = _ptr(pcm, "int16", n_ch * 32 * n_slots, device_ok=True)
+        b.state = _ptr(state, "int16", n_ch * QMF_ANA_ELD_STATE_WORDS, device_ok=True)
+        b.qmf = _ptr(qmf, "int32", n_ch * n_slots * b.slot_stride, device_ok=True)
+        b.status = _ptr(status, "int32", n_ch, device_ok=True) if status is not None else None
+        rc = self._lib.xaac_qmf_analysis_eld_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_qmf_analysis_eld_batch")
 
     def esbr_qmf_analysis_batch(self, core, state, qmf_re, qmf_im):
         """Batched ixheaacd_esbr_analysis_filt_block (eSBR / Path A, 32 channels): core float32[n_ch, 1024];

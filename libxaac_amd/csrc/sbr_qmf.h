@@ -40,6 +40,17 @@
 #endif
 #endif
 
+#ifndef XQ_ELD_TABLES_DECLARED
+#define XQ_ELD_TABLES_DECLARED
+#if defined(__HIPCC__)
+#define XAAC_TAB_QUAL static __device__ const
+#include "tables_qmf_eld.inc"
+#undef XAAC_TAB_QUAL
+#else
+#include "tables_qmf_eld.inc"
+#endif
+#endif
+
 #ifndef XQ_ESBR_TABLES_DECLARED
 #define XQ_ESBR_TABLES_DECLARED
 #if defined(__HIPCC__)
@@ -336,7 +347,8 @@ FX_HD void xq_cos_sin_mod(int32_t *s, int32_t *t) {
 
 /* HQ analysis: 64 window-add outputs -> 32 complex subbands, s[0..31] real, s[64..95] imaginary;
    nrot = usb - lsb of the analysis bank (bands that get the final phase rotation) */
-FX_HD void xq_fwd_modulation(const int32_t *in, int32_t *s, int32_t *t, int nrot) {
+/* eld: the LD / ELD bank's post-modulation twiddles (ixheaacd_sbr_t_cos_sin_l32_eld, generic:650-656) */
+FX_HD void xq_fwd_modulation(const int32_t *in, int32_t *s, int32_t *t, int nrot, bool eld = false) {
   XQ_UNROLL
   for (int i = 0; i < 32; i++) {
     int32_t a = fx_shr(in[i], 4), b = fx_shr(in[63 - i], 4);
@@ -344,7 +356,7 @@ FX_HD void xq_fwd_modulation(const int32_t *in, int32_t *s, int32_t *t, int nrot
     s[64 + i] = fx_add_sat(a, b);
   }
   xq_cos_sin_mod<16>(s, t);
-  const int16_t *tc = XQ_T(t_cos_sin_l32);
+  const int16_t *tc = eld ? xaac_qmf_eld_t_cos_sin_l32 : XQ_T(t_cos_sin_l32);
   XQ_UNROLL
   for (int i = 0; i < 32; i++) {
     if (i < nrot) {

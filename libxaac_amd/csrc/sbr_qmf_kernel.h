@@ -69,6 +69,8 @@ extern "C" {
 #endif
 hipError_t xaac_launch_qmf_synthesis_pair(const XaacQmfSynPairParams *p, hipStream_t stream);
 hipError_t xaac_launch_qmf_analysis(const XaacQmfAnaParams *p, int grid, hipStream_t stream);
+#define XAAC_QMF_ELD_LDS (4 * (288 + 512) * 2 + 64 * 65 * 4) /* four channels' time-ordered history + the exchange tile */
+hipError_t xaac_launch_qmf_analysis_eld(const xaac_qmf_ana_eld_batch *p, hipStream_t stream);
 hipError_t xaac_launch_qmf_synthesis(const XaacQmfSynParams *p, int grid, hipStream_t stream);
 int xaac_qmf_blocks_per_cu(int which);
 #ifdef __cplusplus

@@ -527,6 +527,101 @@ extern "C" hipError_t xaac_launch_qmf_synthesis_pair(const XaacQmfSynPairParams 
   return hipGetLastError();
 }
 
+/* ===================================================================================== */
+/* The LD / ELD flavour of the complex analysis bank.  qmf_c_eld3 is periodic in the 320 taps of the low-delay prototype and
+   the reference's four pointers (ring write position, two filter offsets, the ring half fp1 starts in) rotate together
+   through ten phases, so the window-add is again time invariant (derived by simulating the pointer state machine of
+   generic:662-741, checked against the literal oracle):
+     z[s][m] = sum_{j<5} x[32 s + 31 - (m + 64 j)] * c3[m + 64 j],  m = 0..63
+   (sum |c3| over a branch <= 18982: the saturating adds of qmf_dec.c:484-535 cannot clip).  One wave = FOUR channel-frames
+   of 16 (or 15) slots: window-add with lanes = the 64 branches, then one lane = one slot for the transform. */
+namespace {
+__device__ __forceinline__ int eld_phase(const xaac_qmf_ana_eld_state *st) { /* 0..9, or -1 for pointers out of step */
+  const int wr = st->wr;
+  if (wr < 0 || wr > 288 || (wr & 31)) return -1;
+  const int t = ((320 - wr) / 32) % 10;
+  const int f1 = (t & 1) ? 32 * (t + 1) : 32 * t, f2 = (t & 1) ? 32 * t : 32 * t + 32;
+  return (st->f1 == f1 && st->f2 == f2 && st->fp == 32 * (t & 1)) ? t : -1;
+}
+}  // namespace
+
+__global__ __launch_bounds__(64) void xaac_qmf_analysis_eld_kernel(xaac_qmf_ana_eld_batch p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int H = 288 + 512;
+  int16_t *hist = reinterpret_cast<int16_t *>(smem);              /* [4][H], oldest first */
+  int32_t *z = reinterpret_cast<int32_t *>(smem + 4 * H * 2);     /* [64][65] */
+  const int lane = threadIdx.x, ns = p.n_slots, quad = blockIdx.x;
+  int32_t coef[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) coef[j] = xaac_qmf_eld_c3[lane + 64 * j];
+  int phase[4];
+  for (int c = 0; c < 4; c++) {
+    const int ch = 4 * quad + c;
+    int16_t *h = hist + c * H;
+    phase[c] = -1;
+    if (ch < p.n_ch) phase[c] = eld_phase(p.state + ch);
+    if (phase[c] >= 0) {
+      const xaac_qmf_ana_eld_state *st = p.state + ch;
+      const int wr = st->wr;
+      for (int a = lane; a < 288; a += 64) h[287 - a] = st->ring[ana_ring_pos(wr, a)];
+      const int16_t *src = p.pcm + (size_t)ch * 32 * ns;
+      for (int i = lane; i < 32 * ns; i += 64) h[288 + i] = src[i];
+    } else {
+      for (int i = lane; i < H; i += 64) h[i] = 0;
+    }
+    if (lane == 0 && p.status && ch < p.n_ch) p.status[ch] = phase[c] >= 0 ? 0 : -1;
+  }
+  __syncthreads();
+  for (int r = 0; r < 64; r++) { /* row r = channel r / 16, slot r % 16 */
+    const int s = r & 15;
+    int32_t acc = 0;
+    if (s < ns) {
+      const int16_t *h = hist + (r >> 4) * H + 288 + 32 * s + 31 - lane;
+#pragma unroll
+      for (int j = 0; j < 5; j++) acc += (int32_t)h[-64 * j] * coef[j];
+    }
+    z[65 * r + lane] = acc;
+  }
+  __syncthreads();
+  {
+    int32_t in[64], sb[128], t[128];
+#pragma unroll
+    for (int k = 0; k < 64; k++) in[k] = z[65 * lane + k];
+    xq_fwd_modulation(in, sb, t, p.usb, true);
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+      z[65 * lane + k] = sb[k];
+      z[65 * lane + 32 + k] = sb[64 + k];
+    }
+  }
+  __syncthreads();
+  for (int r = 0; r < 64; r++) {
+    const int c = r >> 4, s = r & 15, ch = 4 * quad + c;
+    if (ch >= p.n_ch || phase[c] < 0 || s >= ns) continue;
+    int32_t *row = p.qmf + ((size_t)ch * ns + s) * p.slot_stride;
+    row[(lane & 31) + 64 * (lane >> 5)] = z[65 * r + lane];
+  }
+  for (int c = 0; c < 4; c++) { /* the ring and the pointers as the reference leaves them after n_slots slots */
+    const int ch = 4 * quad + c;
+    if (ch >= p.n_ch || phase[c] < 0) continue;
+    xaac_qmf_ana_eld_state *st = p.state + ch;
+    const int t = (phase[c] + ns) % 10, wr_new = (320 - 32 * t) % 320;
+    const int16_t *h = hist + c * H + 288 + 32 * ns; /* one past the newest sample */
+    for (int a = lane; a < 320; a += 64) st->ring[ana_ring_pos(wr_new, a)] = h[-1 - a];
+    if (lane == 0) {
+      st->wr = (int16_t)wr_new;
+      st->f1 = (int16_t)((t & 1) ? 32 * (t + 1) : 32 * t);
+      st->f2 = (int16_t)((t & 1) ? 32 * t : 32 * t + 32);
+      st->fp = (int16_t)(32 * (t & 1));
+    }
+  }
+}
+
+extern "C" hipError_t xaac_launch_qmf_analysis_eld(const xaac_qmf_ana_eld_batch *p, hipStream_t stream) {
+  hipLaunchKernelGGL(xaac_qmf_analysis_eld_kernel, dim3((p->n_ch + 3) / 4), dim3(64), XAAC_QMF_ELD_LDS, stream, *p);
+  return hipGetLastError();
+}
+
 extern "C" hipError_t xaac_launch_qmf_analysis(const XaacQmfAnaParams *p, int grid, hipStream_t stream) {
   if (p->low_pow)
     hipLaunchKernelGGL(xaac_qmf_analysis_kernel<true>, dim3(grid), dim3(XAAC_QMF_BLOCK),

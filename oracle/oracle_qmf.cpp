@@ -100,6 +100,47 @@ void xo_qmf_analysis(const int16_t *pcm, int stride, xo_qmf_ana_state *st, int l
 }
 
 /* ---- synthesis bank --------------------------------------------------------------- */
+/* The LD / ELD flavour of the complex analysis bank (ixheaacd_cplx_anal_qmffilt with AOT_ER_AAC_ELD, generic:590-741, and
+   ixheaacd_sbr_qmfanal32_winadd_eld, qmf_dec.c:484-535), literally: the reference's rotating pointers as offsets.
+   st: ring[320], wr, f1 (filter_pos), f2 (filter_2), fp (fp1_anal: 0 or 32; fp2_anal is the other half).  n_slots = 16
+   (512-sample frames) or 15 (480).  qmf: [n_slots][slot_stride], real bands at +0, imaginary at +64. */
+void xo_qmf_analysis_eld(const int16_t *pcm, int stride, int16_t *ring, int16_t *state4, int n_slots, int usb, int32_t *qmf,
+                         int slot_stride) {
+  const int16_t *c = xaac_qmf_eld_c3; /* one period of qmf_c_eld3: the ROM's second copy continues it */
+  int wr = state4[0], f1 = state4[1], f2 = state4[2], fp1 = state4[3], fp2 = 32 - state4[3];
+  for (int s = 0; s < n_slots; s++) {
+    int32_t z[64], t[128], sb[128];
+    for (int k = 0; k < 32; k++) ring[wr + 31 - k] = pcm[stride * (32 * s + k)];
+    for (int n = 0; n < 32; n++) { /* winadd_eld: five taps 64 apart, coefficient index = sample index + the filter offset */
+      int32_t a1 = 0, a2 = 0;
+      for (int j = 0; j < 5; j++) {
+        a1 = fx_add_sat(a1, (int32_t)ring[fp1 + n + 64 * j] * c[(f1 + n + 64 * j) % 320]);
+        a2 = fx_add_sat(a2, (int32_t)ring[fp2 + n + 64 * j] * c[(f2 + n + 64 * j) % 320]);
+      }
+      z[n] = a1;
+      z[n + 32] = a2;
+    }
+    wr -= 32;
+    if (wr < 0) wr = 288;
+    { int tmp = fp1; fp1 = fp2; fp2 = tmp; }
+    f1 += 32;
+    f2 += 32;
+    { int tmp = f1; f1 = f2; f2 = tmp; }
+    if (f2 > 320) {
+      f1 = 0;
+      f2 = 32;
+    }
+    xq_fwd_modulation(z, sb, t, usb, true);
+    int32_t *o = qmf + (size_t)s * slot_stride;
+    memcpy(o, sb, 32 * sizeof(int32_t));
+    memcpy(o + 64, sb + 64, 32 * sizeof(int32_t));
+  }
+  state4[0] = (int16_t)wr;
+  state4[1] = (int16_t)f1;
+  state4[2] = (int16_t)f2;
+  state4[3] = (int16_t)fp1;
+}
+
 void xo_qmf_syn_init(xo_qmf_syn_state *st) { memset(st, 0, sizeof(*st)); }
 
 /* env_calc.c:1099 on one sample */

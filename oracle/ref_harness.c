@@ -207,6 +207,39 @@ void ref_qmf_analysis(const WORD16 *pcm, int stride, WORD16 *ring, WORD16 *wr, W
   *phase = (WORD16)(bank.filter_pos - t->qmf_c);
 }
 
+/* the LD / ELD flavour: state4 = {core_samples_buffer, filter_pos, filter_2, fp1_anal} as offsets; a new stream starts
+   with {0, 0, 32, 0} (sbrdec_initfuncs.c:1122-1148) */
+void ref_qmf_analysis_eld(const WORD16 *pcm, int stride, WORD16 *ring, WORD16 *state4, int n_slots, int usb, WORD32 *qmf,
+                          int slot_stride) {
+  ia_qmf_dec_tables_struct *t = ref_qmf_tabs();
+  ia_sbr_qmf_filter_bank_struct bank;
+  ia_sbr_scale_fact_struct sf;
+  WORD32 *re[32], *im[32];
+  int s;
+  memset(&bank, 0, sizeof(bank));
+  memset(&sf, 0, sizeof(sf));
+  bank.no_channels = 32;
+  bank.num_time_slots = (WORD16)n_slots;
+  bank.lsb = 0;
+  bank.usb = (WORD16)usb;
+  bank.anal_filter_states = ring;
+  bank.core_samples_buffer = ring + state4[0];
+  bank.analy_win_coeff = t->qmf_c_eld3;
+  bank.filter_pos = t->qmf_c_eld3 + state4[1];
+  bank.filter_2 = t->qmf_c_eld3 + state4[2];
+  bank.fp1_anal = ring + state4[3];
+  bank.fp2_anal = ring + (32 - state4[3]);
+  for (s = 0; s < 32; s++) {
+    re[s] = qmf + (size_t)s * slot_stride;
+    im[s] = re[s] + 64;
+  }
+  ixheaacd_cplx_anal_qmffilt(pcm, &sf, re, im, &bank, t, stride, 0, AOT_ER_AAC_ELD);
+  state4[0] = (WORD16)(bank.core_samples_buffer - ring);
+  state4[1] = (WORD16)(bank.filter_pos - t->qmf_c_eld3);
+  state4[2] = (WORD16)(bank.filter_2 - t->qmf_c_eld3);
+  state4[3] = (WORD16)(bank.fp1_anal - ring);
+}
+
 /* One frame through ixheaacd_cplx_synt_qmffilt (no PS: active = 0).  qmf is scaled and transformed
  * in place by the reference.  sf = {lb_scale, ov_lb_scale, hb_scale, st_syn_scale}. */
 void ref_qmf_synthesis(WORD32 *qmf, int slot_stride, const WORD16 *sfv, int lsb, int usb, int split, WORD16 *ring,

@@ -90,6 +90,10 @@ def test_esbr_float_tables_equal_reference_rom(tmp_path):
     _regenerated_equals_committed("gen_tables_esbr", "tables_esbr.inc", tmp_path)
 
 
+def test_eld_qmf_tables_equal_reference_rom(tmp_path):
+    _regenerated_equals_committed("gen_tables_qmf_eld", "tables_qmf_eld.inc", tmp_path)
+
+
 def test_hbe_tables_equal_reference_rom(tmp_path):
     _regenerated_equals_committed("gen_tables_hbe", "tables_hbe.inc", tmp_path)
 
