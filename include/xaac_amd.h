@@ -129,6 +129,29 @@ typedef struct xaac_qmf_ana_eld_batch {
                                 bank can be in (such a channel is left alone) */
 } xaac_qmf_ana_eld_batch;
 
+/* ... and of the complex synthesis bank (ixheaacd_cplx_synt_qmffilt with AOT_ER_AAC_LD / _ELD, decoder/ixheaacd_qmf_dec.c:
+ * 811-1135: pre-twiddle :788, 64-channel inverse modulation, ixheaacd_shiftrountine_with_rnd_eld generic:1672, the
+ * 10-tap window-add on qmf_c_eld with output shift 2), no parametric stereo, no DRC */
+typedef struct xaac_qmf_syn_eld_state {
+  int16_t ring[1280]; /* filter_states */
+  int16_t drc_offset; /* ixheaacd_drc_offset */
+  int16_t phase;      /* filter_pos_syn - qmf_c_eld */
+  int16_t fp;         /* fp1_syn - filter_states (0 or 64) */
+  int16_t sixty4;     /* sixty4 (64 or -64; fp2_syn = fp1_syn + sixty4) */
+} xaac_qmf_syn_eld_state; /* a new stream: ring zero, {0, 0, 0, 64} (sbrdec_initfuncs.c:1181-1209) */
+
+typedef struct xaac_qmf_syn_eld_batch {
+  int32_t n_ch;
+  int32_t n_slots;           /* 16 or 15 */
+  int32_t lsb, usb, split;   /* region rescale as in xaac_qmf_syn_batch (qmf_dec.c:937-953) */
+  int32_t slot_stride;       /* >= 128: imaginary row at +64 */
+  const int32_t *qmf;        /* [n_ch][n_slots][slot_stride] (not modified) */
+  const int16_t *scale;      /* [n_ch][4]: lb_scale, ov_lb_scale, hb_scale, st_syn_scale */
+  xaac_qmf_syn_eld_state *state; /* [n_ch] in/out */
+  int16_t *pcm;              /* [n_ch][64 * n_slots] planar */
+  int32_t *status;           /* [n_ch] or NULL: -1 for a state outside the bank's ten phases (left alone) */
+} xaac_qmf_syn_eld_batch;
+
 typedef struct xaac_qmf_syn_state {
   int16_t ring[1280]; /* filter_states */
   int16_t drc_offset; /* ixheaacd_drc_offset */
@@ -352,6 +375,8 @@ int32_t xaac_usac_imdct_process_batch(xaac_ctx *ctx, const xaac_usac_imdct_batch
 int32_t xaac_esbr_qmf_analysis_batch(xaac_ctx *ctx, const xaac_esbr_ana_batch *batch);
 /* ixheaacd_cplx_anal_qmffilt for AAC-LD / ELD cores (complex bank, 16 or 15 slots per frame) */
 int32_t xaac_qmf_analysis_eld_batch(xaac_ctx *ctx, const xaac_qmf_ana_eld_batch *batch);
+/* ixheaacd_cplx_synt_qmffilt for AAC-LD / ELD (complex bank, 64 channels, 16 or 15 slots per frame) */
+int32_t xaac_qmf_synthesis_eld_batch(xaac_ctx *ctx, const xaac_qmf_syn_eld_batch *batch);
 int32_t xaac_esbr_qmf_synthesis_batch(xaac_ctx *ctx, const xaac_esbr_syn_batch *batch);
 
 /* Low-power SBR channel-frames (QMF analysis -> HF generation + envelope adjustment -> QMF synthesis). */

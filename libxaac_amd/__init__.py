@@ -99,6 +99,16 @@ class _QmfAnaEldBatch(ctypes.Structure):
 QMF_ANA_ELD_STATE_WORDS = 324   # struct xaac_qmf_ana_eld_state: ring[320], wr, f1, f2, fp (int16)
 
 
+class _QmfSynEldBatch(ctypes.Structure):
+    # struct xaac_qmf_syn_eld_batch
+    _fields_ = [("n_ch", ctypes.c_int32), ("n_slots", ctypes.c_int32), ("lsb", ctypes.c_int32), ("usb", ctypes.c_int32),
+                ("split", ctypes.c_int32), ("slot_stride", ctypes.c_int32), ("qmf", ctypes.c_void_p), ("scale", ctypes.c_void_p),
+                ("state", ctypes.c_void_p), ("pcm", ctypes.c_void_p), ("status", ctypes.c_void_p)]
+
+
+QMF_SYN_ELD_STATE_WORDS = 1284   # struct xaac_qmf_syn_eld_state: ring[1280], drc_offset, phase, fp, sixty4 (int16)
+
+
 class _EsbrAnaBatch(ctypes.Structure):
     # struct xaac_esbr_ana_batch
     _fields_ = [("n_ch", ctypes.c_int32), ("core", ctypes.c_void_p), ("state", ctypes.c_void_p),
@@ -240,6 +250,8 @@ def load_library():
     lib.xaac_hbe_cplx_anal_batch.restype = ctypes.c_int32
     lib.xaac_qmf_analysis_eld_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_QmfAnaEldBatch)]
     lib.xaac_qmf_analysis_eld_batch.restype = ctypes.c_int32
+    lib.xaac_qmf_synthesis_eld_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_QmfSynEldBatch)]
+    lib.xaac_qmf_synthesis_eld_batch.restype = ctypes.c_int32
     lib.xaac_esbr_qmf_analysis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_EsbrAnaBatch)]
     lib.xaac_esbr_qmf_analysis_batch.restype = ctypes.c_int32
     lib.xaac_esbr_qmf_synthesis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_EsbrSynBatch)]
@@ -558,6 +570,22 @@ class XaacContext:
         rc = self._lib.xaac_qmf_analysis_eld_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_qmf_analysis_eld_batch")
+
+    def qmf_synthesis_eld_batch(self, qmf, scale, state, pcm, n_slots, lsb, usb, split, status=None):
+        """Batched LD / ELD complex synthesis bank: qmf int32[n_ch, n_slots, slot_stride >= 128]; scale int16[n_ch, 4] (lb,
+        ov_lb, hb, st_syn); state int16[n_ch, 1284] in/out (ring, drc_offset, phase, fp, sixty4; a new stream: zeros with
+        sixty4 = 64); pcm int16[n_ch, 64 * n_slots]."""
+        n_ch = state.shape[0]
+        b = _QmfSynEldBatch()
+        b.n_ch, b.n_slots, b.lsb, b.usb, b.split, b.slot_stride = n_ch, n_slots, lsb, usb, split, int(qmf.shape[2])
+        b.qmf = _ptr(qmf, "int32", n_ch * n_slots * b.slot_stride, device_ok=True)
+        b.scale = _ptr(scale, "int16", n_ch * 4, device_ok=True)
+        b.state = _ptr(state, "int16", n_ch * QMF_SYN_ELD_STATE_WORDS, device_ok=True)
+        b.pcm = _ptr(pcm, "int16", n_ch * 64 * n_slots, device_ok=True)
+        b.status = _ptr(status, "int32", n_ch, device_ok=True) if status is not None else None
+        rc = self._lib.xaac_qmf_synthesis_eld_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_qmf_synthesis_eld_batch")
 
     def esbr_qmf_analysis_batch(self, core, state, qmf_re, qmf_im):
         """Batched ixheaacd_esbr_analysis_filt_block (eSBR / Path A, 32 channels): core float32[n_ch, 1024];

@@ -435,6 +435,28 @@ FX_HD void xq_synth_hq_slot(int32_t *s, int32_t *t, int16_t *b, int shift) {
   }
 }
 
+/* LD / ELD synthesis slot (qmf_dec.c:1043-1066 with AOT_ER_AAC_ELD): ixheaacd_sbr_pre_twiddle (:788, bands 0..62),
+   the 64-channel inverse modulation, ixheaacd_shiftrountine_with_rnd_eld (generic:1672) -> the 128 ring samples b[] */
+FX_HD int32_t xq_mul32x16_shl_sat(int32_t a, int16_t b) { /* basic_ops40.h:56 */
+  return (a == (int32_t)0x80000000 && b == (int16_t)0x8000) ? (int32_t)0x7fffffff : fx_mul32x16_shl(a, b);
+}
+FX_HD void xq_synth_eld_slot(int32_t *s, int32_t *t, int16_t *b, int shift) {
+  const int16_t *tw = xaac_qmf_eld_synth_cos_sin_l32;
+  XQ_UNROLL
+  for (int k = 0; k < 63; k++) {
+    const int32_t x_re = s[k], x_im = s[64 + k];
+    const int16_t c = tw[2 * k], sn = tw[2 * k + 1];
+    s[k] = fx_add_sat(fx_mul32x16_shl(x_re, c), xq_mul32x16_shl_sat(x_im, sn));
+    s[64 + k] = fx_sub_sat(fx_mul32x16_shl(x_im, c), fx_mul32x16_shl(x_re, sn));
+  }
+  xq_cos_sin_mod<32>(s, t);
+  XQ_UNROLL
+  for (int c = 0; c < 64; c++) { /* b[c] <- re - im of band c; b[64 + c] <- -(im + re) of band 63 - c */
+    b[c] = fx_round16(fx_shl_sat(fx_sub_sat(s[c], s[64 + c]), shift));
+    b[64 + c] = fx_round16(fx_shl_sat(fx_neg_sat(fx_add_sat(s[64 + 63 - c], s[63 - c])), shift));
+  }
+}
+
 /* ---- down-sampled synthesis bank (32 channels: -dsample / output rates above 48 kHz, sbrdec_initfuncs.c:622,
    :1165) -- the same two slot transforms at half the size ---------------------------------------------------- */
 

@@ -71,6 +71,8 @@ hipError_t xaac_launch_qmf_synthesis_pair(const XaacQmfSynPairParams *p, hipStre
 hipError_t xaac_launch_qmf_analysis(const XaacQmfAnaParams *p, int grid, hipStream_t stream);
 #define XAAC_QMF_ELD_LDS (4 * (288 + 512) * 2 + 64 * 65 * 4) /* four channels' time-ordered history + the exchange tile */
 hipError_t xaac_launch_qmf_analysis_eld(const xaac_qmf_ana_eld_batch *p, hipStream_t stream);
+#define XAAC_QMF_ELD_SYN_LDS (4 * 25 * 130 * 2) /* four channels x (9 + 16) slots of ring samples, padded rows */
+hipError_t xaac_launch_qmf_synthesis_eld(const xaac_qmf_syn_eld_batch *p, hipStream_t stream);
 hipError_t xaac_launch_qmf_synthesis(const XaacQmfSynParams *p, int grid, hipStream_t stream);
 int xaac_qmf_blocks_per_cu(int which);
 #ifdef __cplusplus

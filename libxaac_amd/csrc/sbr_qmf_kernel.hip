@@ -617,6 +617,101 @@ __global__ __launch_bounds__(64) void xaac_qmf_analysis_eld_kernel(xaac_qmf_ana_
   }
 }
 
+/* The LD / ELD synthesis bank.  As for the AAC bank the pointer rotation nets out (simulated; the oracle is the literal
+   form): y[s][k] = rnd + sum_{A<10} v[s-A][64 (A&1) + k] * c[64 A + k] on qmf_c_eld (sum |c| <= 27506: no clipping before
+   the final saturating shift), v[s] = the 128 ring samples slot s writes.  One wave = four channel-frames: lane =
+   (channel, slot) for the slot transforms, then lanes = the 64 outputs of a row.  Ten phases of the four state words. */
+namespace {
+__device__ __forceinline__ int eld_syn_phase(const xaac_qmf_syn_eld_state *st) {
+  const int d = st->drc_offset;
+  if (d < 0 || d > 1152 || (d & 127)) return -1;
+  const int t = ((1280 - d) / 128) % 10;
+  return (st->phase == 64 * t && st->fp == 64 * (t & 1) && st->sixty4 == ((t & 1) ? -64 : 64)) ? t : -1;
+}
+}  // namespace
+
+__global__ __launch_bounds__(64) void xaac_qmf_synthesis_eld_kernel(xaac_qmf_syn_eld_batch p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int VR = 130, VS = 25; /* padded row (int16), rows per channel: 9 of history + up to 16 slots */
+  int16_t *v = reinterpret_cast<int16_t *>(smem); /* [4][VS][VR] */
+  const int lane = threadIdx.x, ns = p.n_slots, quad = blockIdx.x;
+  int32_t coef[10];
+#pragma unroll
+  for (int a = 0; a < 10; a++) coef[a] = xaac_qmf_eld_c[64 * a + lane];
+  int phase[4];
+  for (int c = 0; c < 4; c++) {
+    const int ch = 4 * quad + c;
+    phase[c] = ch < p.n_ch ? eld_syn_phase(p.state + ch) : -1;
+    if (lane == 0 && p.status && ch < p.n_ch) p.status[ch] = phase[c] >= 0 ? 0 : -1;
+    int16_t *vc = v + c * VS * VR;
+    if (phase[c] >= 0) {
+      const xaac_qmf_syn_eld_state *st = p.state + ch;
+      const int d0 = st->drc_offset;
+      for (int e = lane; e < 9 * 128; e += 64) { /* slot -A (A = 1..9) lives 128 A behind the write offset */
+        const int a = 1 + e / 128, o = e % 128;
+        vc[(9 - a) * VR + o] = st->ring[(d0 + 128 * a + o) % 1280];
+      }
+    } else {
+      for (int e = lane; e < 9 * VR; e += 64) vc[e] = 0;
+    }
+  }
+  {
+    const int c = lane >> 4, s = lane & 15, ch = 4 * quad + c;
+    if (phase[c] >= 0 && s < ns) {
+      const int16_t *sf = p.scale + 4 * (size_t)ch;
+      const int st_syn = sf[3];
+      const int ov_lb_shift = (st_syn - sf[1]) - 7, lb_shift = (st_syn - sf[0]) - 7, hb_shift = (st_syn - sf[2]) - 7;
+      const int32_t *row = p.qmf + ((size_t)ch * ns + s) * p.slot_stride;
+      int32_t x[128], t[128];
+      int16_t b[128];
+#pragma unroll
+      for (int k = 0; k < 128; k++) {
+        const int band = k & 63;
+        int32_t val = row[k];
+        if (band < p.lsb) val = adj_scale(val, s < p.split ? ov_lb_shift : lb_shift);
+        else if (band < p.usb) val = adj_scale(val, hb_shift);
+        x[k] = val;
+      }
+      xq_synth_eld_slot(x, t, b, -(st_syn - 3));
+      int16_t *dst = v + (c * VS + 9 + s) * VR;
+#pragma unroll
+      for (int k = 0; k < 128; k++) dst[k] = b[k];
+    }
+  }
+  __syncthreads();
+  for (int r = 0; r < 64; r++) {
+    const int c = r >> 4, s = r & 15, ch = 4 * quad + c;
+    if (phase[c] < 0 || s >= ns) continue;
+    const int16_t *vc = v + c * VS * VR;
+    int32_t acc = 0x8000 >> 2;
+#pragma unroll
+    for (int a = 0; a < 10; a++) acc += (int32_t)vc[(9 + s - a) * VR + 64 * (a & 1) + lane] * coef[a];
+    p.pcm[((size_t)ch * ns + s) * 64 + lane] = (int16_t)(fx_shl_sat(acc, 2) >> 16);
+  }
+  for (int c = 0; c < 4; c++) { /* the ring = the last ten slots' samples at the offsets the reference wrote them to */
+    const int ch = 4 * quad + c;
+    if (phase[c] < 0) continue;
+    xaac_qmf_syn_eld_state *st = p.state + ch;
+    const int d0 = st->drc_offset, t = (phase[c] + ns) % 10;
+    const int16_t *vc = v + c * VS * VR;
+    for (int e = lane; e < 1280; e += 64) {
+      const int a = e / 128, o = e % 128, s = ns - 1 - a; /* slot s was written at d0 - 128 s */
+      st->ring[((d0 - 128 * s) % 1280 + 1280) % 1280 + o] = vc[(9 + s) * VR + o];
+    }
+    if (lane == 0) {
+      st->drc_offset = (int16_t)((1280 - 128 * t) % 1280);
+      st->phase = (int16_t)(64 * t);
+      st->fp = (int16_t)(64 * (t & 1));
+      st->sixty4 = (int16_t)((t & 1) ? -64 : 64);
+    }
+  }
+}
+
+extern "C" hipError_t xaac_launch_qmf_synthesis_eld(const xaac_qmf_syn_eld_batch *p, hipStream_t stream) {
+  hipLaunchKernelGGL(xaac_qmf_synthesis_eld_kernel, dim3((p->n_ch + 3) / 4), dim3(64), XAAC_QMF_ELD_SYN_LDS, stream, *p);
+  return hipGetLastError();
+}
+
 extern "C" hipError_t xaac_launch_qmf_analysis_eld(const xaac_qmf_ana_eld_batch *p, hipStream_t stream) {
   hipLaunchKernelGGL(xaac_qmf_analysis_eld_kernel, dim3((p->n_ch + 3) / 4), dim3(64), XAAC_QMF_ELD_LDS, stream, *p);
   return hipGetLastError();

@@ -241,6 +241,18 @@ int32_t xaac_qmf_analysis_eld_batch(xaac_ctx *c, const xaac_qmf_ana_eld_batch *b
   return XAAC_OK;
 }
 
+int32_t xaac_qmf_synthesis_eld_batch(xaac_ctx *c, const xaac_qmf_syn_eld_batch *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n_ch < 0 || (b->n_slots != 16 && b->n_slots != 15) || b->slot_stride < 128) return XAAC_FATAL_BAD_ARG;
+  if (b->lsb < 0 || b->usb < b->lsb || b->usb > 64 || b->split < 0 || b->split > b->n_slots) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch == 0) return XAAC_OK;
+  if (!b->qmf || !b->scale || !b->state || !b->pcm) return XAAC_FATAL_NULL_ARG;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  if (!hip_ok(xaac_launch_qmf_synthesis_eld(b, c->stream))) return XAAC_FATAL_HIP;
+  c->last_grid = (b->n_ch + 3) / 4; c->last_block = 64; c->last_lds = XAAC_QMF_ELD_SYN_LDS;
+  return XAAC_OK;
+}
+
 int32_t xaac_qmf_synthesis_batch(xaac_ctx *c, const xaac_qmf_syn_batch *b) {
   if (!c || !b) return XAAC_FATAL_NULL_ARG;
   if (b->n_ch < 0 || (b->ch_fac != 1 && b->ch_fac != 2) || b->n_ch % b->ch_fac) return XAAC_FATAL_BAD_ARG;

@@ -143,13 +143,59 @@ void xo_qmf_analysis_eld(const int16_t *pcm, int stride, int16_t *ring, int16_t 
 
 void xo_qmf_syn_init(xo_qmf_syn_state *st) { memset(st, 0, sizeof(*st)); }
 
-/* env_calc.c:1099 on one sample */
 static inline int32_t adj(int32_t v, int shift) {
   if (shift == 0) return v;
   if (shift > 31) shift = 31;
   if (shift < -31) shift = -31;
   return shift > 0 ? fx_shlw(v, shift) : (v >> -shift);
 }
+
+/* The LD / ELD flavour of the complex synthesis bank (ixheaacd_cplx_synt_qmffilt with AOT_ER_AAC_ELD, qmf_dec.c:811-1135,
+   no PS, no DRC), literally.  ring: filter_states[1280]; state4 = {ixheaacd_drc_offset, filter_pos_syn - qmf_c_eld,
+   fp1_syn - filter_states (0 or 64), sixty4 (64 or -64)}; a new stream: {0, 0, 0, 64}.  qmf rows are not modified.
+   sf = {lb_scale, ov_lb_scale, hb_scale, st_syn_scale}.  pcm: 64 * n_slots samples at `stride`. */
+void xo_qmf_synthesis_eld(const int32_t *qmf, int slot_stride, const int16_t *sf, int lsb, int usb, int split, int16_t *ring,
+                          int16_t *state4, int n_slots, int16_t *pcm, int stride) {
+  const int lb_scale = sf[0], ov_lb_scale = sf[1], hb_scale = sf[2], st_syn = sf[3];
+  const int ov_lb_shift = (st_syn - ov_lb_scale) - 7, lb_shift = (st_syn - lb_scale) - 7, hb_shift = (st_syn - hb_scale) - 7; /* :925-928 */
+  const int out_scale = -(st_syn - 3);
+  int d = state4[0], ph = state4[1], fp1 = state4[2], sixty4 = state4[3], fp2 = fp1 + sixty4;
+  const int16_t *c = xaac_qmf_eld_c;
+  for (int s = 0; s < n_slots; s++) {
+    int32_t x[128], t[128];
+    const int32_t *row = qmf + (size_t)s * slot_stride;
+    for (int p = 0; p < 2; p++)
+      for (int k = 0; k < 64; k++) {
+        int32_t v = row[64 * p + k];
+        if (k < lsb)
+          v = adj(v, s < split ? ov_lb_shift : lb_shift);
+        else if (k < usb)
+          v = adj(v, hb_shift);
+        x[64 * p + k] = v;
+      }
+    xq_synth_eld_slot(x, t, ring + d, out_scale); /* temp_out_scale_fac = out_scale_factor + 1 - 1 (:1054-1058) */
+    const int16_t *t1 = ring + fp1, *t2 = ring + fp2, *cf = c + ph;
+    for (int k = 0; k < 64; k++) { /* ixheaacd_sbr_qmfsyn64_winadd with shift 2 (:1091-1097) */
+      int32_t acc = 0x8000 >> 2;
+      for (int m = 0; m < 5; m++) acc = fx_add_sat(acc, (int32_t)t1[256 * m + k] * cf[k + 128 * m]);
+      for (int m = 0; m < 5; m++) acc = fx_add_sat(acc, (int32_t)t2[128 + 256 * m + k] * cf[k + 64 + 128 * m]);
+      pcm[(size_t)stride * (64 * s + k)] = (int16_t)(fx_shl_sat(acc, 2) >> 16);
+    }
+    fp1 += sixty4;
+    fp2 -= sixty4;
+    sixty4 = -sixty4;
+    d -= 128;
+    if (d < 0) d += 1280;
+    ph += 64;
+    if (ph == 640) ph = 0;
+  }
+  state4[0] = (int16_t)d;
+  state4[1] = (int16_t)ph;
+  state4[2] = (int16_t)fp1;
+  state4[3] = (int16_t)sixty4;
+}
+
+/* env_calc.c:1099 on one sample */
 
 /* One slot of the synthesis bank: x = 64 reals (+ 64 imaginaries in HQ), already in the output scale of
    the frame; transform into the ring, 10-tap polyphase sum, 64 PCM16 at `stride`; advances the ring

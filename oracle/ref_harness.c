@@ -278,3 +278,47 @@ void ref_qmf_synthesis(WORD32 *qmf, int slot_stride, const WORD16 *sfv, int lsb,
   *drc_offset = bank.ixheaacd_drc_offset;
   *phase = (WORD16)(bank.filter_pos_syn - t->qmf_c);
 }
+
+/* the LD / ELD flavour (AOT_ER_AAC_ELD): state4 = {ixheaacd_drc_offset, filter_pos_syn - qmf_c_eld, fp1_syn - ring, sixty4};
+   a new stream: {0, 0, 0, 64} (sbrdec_initfuncs.c:1181-1209).  qmf is scaled and transformed in place by the reference. */
+void ref_qmf_synthesis_eld(WORD32 *qmf, int slot_stride, const WORD16 *sfv, int lsb, int usb, int split, WORD16 *ring,
+                           WORD16 *state4, int n_slots, WORD16 *pcm, int stride) {
+  ia_qmf_dec_tables_struct *t = ref_qmf_tabs();
+  ia_sbr_tables_struct tabs;
+  ia_sbr_qmf_filter_bank_struct bank;
+  ia_sbr_scale_fact_struct sf;
+  static __thread WORD32 copy_re[32][64], copy_im[32][64];
+  WORD32 *re[MAX_ENV_COLS], *im[MAX_ENV_COLS], *ore[MAX_ENV_COLS], *oim[MAX_ENV_COLS];
+  int s;
+  memset(&bank, 0, sizeof(bank));
+  memset(&sf, 0, sizeof(sf));
+  memset(&tabs, 0, sizeof(tabs));
+  tabs.qmf_dec_tables_ptr = t;
+  sf.lb_scale = sfv[0];
+  sf.ov_lb_scale = sfv[1];
+  sf.hb_scale = sfv[2];
+  sf.st_syn_scale = sfv[3];
+  bank.no_channels = 64;
+  bank.num_time_slots = (WORD16)n_slots;
+  bank.lsb = (WORD16)lsb;
+  bank.usb = (WORD16)usb;
+  bank.filter_states = ring;
+  bank.p_filter = t->qmf_c_eld;
+  bank.filter_pos_syn = t->qmf_c_eld + state4[1];
+  bank.ixheaacd_drc_offset = state4[0];
+  bank.fp1_syn = ring + state4[2];
+  bank.sixty4 = state4[3];
+  bank.fp2_syn = bank.fp1_syn + bank.sixty4;
+  for (s = 0; s < 32; s++) {
+    re[s] = qmf + (size_t)s * slot_stride;
+    im[s] = re[s] + 64;
+    ore[s] = copy_re[s];
+    oim[s] = copy_im[s];
+  }
+  ixheaacd_cplx_synt_qmffilt(re, im, split, ore, oim, &sf, pcm, &bank, NULL, 0, 0, &tabs, NULL, stride, 0, NULL,
+                             AOT_ER_AAC_ELD);
+  state4[0] = bank.ixheaacd_drc_offset;
+  state4[1] = (WORD16)(bank.filter_pos_syn - t->qmf_c_eld);
+  state4[2] = (WORD16)(bank.fp1_syn - ring);
+  state4[3] = (WORD16)bank.sixty4;
+}

@@ -36,3 +36,37 @@ def test_eld_analysis_chain(oracle, reference, n_slots):
         assert np.array_equal(qr, qo), frame
         assert np.array_equal(ring_r, ring_o) and np.array_equal(st_r, st_o), (frame, st_r, st_o)
     assert st_r[0] != 0 or n_slots == 16
+
+
+def bind_syn(lib, name):
+    fn = getattr(lib, name)
+    fn.restype = None
+    fn.argtypes = [P32, ctypes.c_int, P16, ctypes.c_int, ctypes.c_int, ctypes.c_int, P16, P16, ctypes.c_int, P16, ctypes.c_int]
+    return fn
+
+
+@pytest.mark.parametrize("n_slots", [16, 15])
+def test_eld_synthesis_chain(oracle, reference, n_slots):
+    """ixheaacd_cplx_synt_qmffilt with AOT_ER_AAC_ELD (pre-twiddle, 64-channel inverse modulation, the ELD rounding
+    routine, 10-tap window-add on qmf_c_eld with output shift 2, fp / sixty4 carried between frames): PCM, ring and the
+    four state words identical over chains of frames, region scales varied, levels up to clipping"""
+    rf, of = bind_syn(reference.lib, "ref_qmf_synthesis_eld"), bind_syn(oracle.lib, "xo_qmf_synthesis_eld")
+    rng = np.random.default_rng(70 + n_slots)
+    ring_r, ring_o = np.zeros(1280, np.int16), np.zeros(1280, np.int16)
+    st_r, st_o = np.array([0, 0, 0, 64], np.int16), np.array([0, 0, 0, 64], np.int16)
+    for frame in range(21):
+        level = 2.0 ** rng.integers(8, 30)
+        q = (rng.standard_normal((n_slots, 128)) * level).clip(-2 ** 31, 2 ** 31 - 1).astype(np.int32)
+        if frame % 6 == 5:
+            q[:] = 2 ** 31 - 1 if frame % 2 else -2 ** 31
+        sf = np.array([rng.integers(-12, 4), rng.integers(-12, 4), rng.integers(-12, 4), rng.integers(-10, 2)], np.int16)
+        lsb = int(rng.integers(0, 40))
+        usb = int(rng.integers(lsb, 65))
+        split = int(rng.integers(0, n_slots + 1))
+        pr, po = np.zeros(64 * n_slots, np.int16), np.zeros(64 * n_slots, np.int16)
+        for fn, ring, st, pcm in ((rf, ring_r, st_r, pr), (of, ring_o, st_o, po)):
+            qq = q.copy()
+            fn(qq.ctypes.data_as(P32), 128, sf.ctypes.data_as(P16), lsb, usb, split, ring.ctypes.data_as(P16), st.ctypes.data_as(P16),
+               n_slots, pcm.ctypes.data_as(P16), 1)
+        assert np.array_equal(pr, po), (frame, np.nonzero(pr != po)[0][:5])
+        assert np.array_equal(ring_r, ring_o) and np.array_equal(st_r, st_o), (frame, st_r, st_o)
