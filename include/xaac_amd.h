@@ -363,6 +363,11 @@ int32_t xaac_imdct_process_batch(xaac_ctx *ctx, const xaac_imdct_batch *batch);
 /* Same with host buffers: copies in, runs, copies the outputs and state back,
  * synchronises.  PCIe-inclusive convenience path. */
 int32_t xaac_imdct_process_batch_host(xaac_ctx *ctx, const xaac_imdct_batch *batch);
+/* ixheaacd_imdct_process with ics->frame_length == 960 (the 960-line profile of DAB+ / DRM: ixheaacd_mdct_960 and eight
+ * ixheaacd_inverse_transform_960, decoder/ixheaacd_aac_imdct.c:1672 / :1624, the 960- and 120-sample windows, the 960
+ * branches of lpfuncs.c:347-802).  The same descriptor with 960 for 1024 and 480 for 512: spec [n_ch][960], overlap
+ * [n_ch][480], out32 / pcm16 [n_ch * 960] interleaved at ch_fac; pcm16 is the plain hand-off of pcm_mode per sample. */
+int32_t xaac_imdct960_process_batch(xaac_ctx *ctx, const xaac_imdct_batch *batch);
 
 /* SBR QMF banks, device pointers, asynchronous on the context's stream. */
 int32_t xaac_qmf_analysis_batch(xaac_ctx *ctx, const xaac_qmf_ana_batch *batch);

@@ -229,6 +229,8 @@ def load_library():
     lib.xaac_set_stream.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.xaac_imdct_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_ImdctBatch)]
     lib.xaac_imdct_process_batch_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(_ImdctBatch)]
+    lib.xaac_imdct960_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_ImdctBatch)]
+    lib.xaac_imdct960_process_batch.restype = ctypes.c_int32
     lib.xaac_last_launch.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int32)] * 3
     lib.xaac_qmf_analysis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_QmfAnaBatch)]
     lib.xaac_qmf_synthesis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_QmfSynBatch)]
@@ -356,15 +358,16 @@ class XaacContext:
         self._lib.xaac_last_launch(self._h, ctypes.byref(g), ctypes.byref(b), ctypes.byref(l))
         return {"grid": g.value, "block": b.value, "lds_bytes": l.value}
 
-    def _batch(self, n_ch, spec, ics, overlap, state, out32, pcm16, qshift_adj, ch_fac, pcm_mode, on_device, status=None):
+    def _batch(self, n_ch, spec, ics, overlap, state, out32, pcm16, qshift_adj, ch_fac, pcm_mode, on_device, status=None,
+               frame=1024):
         b = _ImdctBatch()
         b.n_ch, b.ch_fac, b.pcm_mode = int(n_ch), int(ch_fac), int(pcm_mode)
-        b.spec = _ptr(spec, "int32", n_ch * 1024, device_ok=on_device)
+        b.spec = _ptr(spec, "int32", n_ch * frame, device_ok=on_device)
         b.ics = _ptr(ics, "uint8", n_ch * 2, device_ok=on_device)
-        b.overlap = _ptr(overlap, "int32", n_ch * 512, device_ok=on_device)
+        b.overlap = _ptr(overlap, "int32", n_ch * frame // 2, device_ok=on_device)
         b.state = _ptr(state, "uint8", n_ch * 2, device_ok=on_device)
-        b.out32 = _ptr(out32, "int32", n_ch * 1024, allow_none=True, device_ok=on_device)
-        b.pcm16 = _ptr(pcm16, "int16", n_ch * 1024, allow_none=True, device_ok=on_device)
+        b.out32 = _ptr(out32, "int32", n_ch * frame, allow_none=True, device_ok=on_device)
+        b.pcm16 = _ptr(pcm16, "int16", n_ch * frame, allow_none=True, device_ok=on_device)
         b.qshift_adj = _ptr(qshift_adj, "int8", n_ch, allow_none=True, device_ok=on_device)
         b.status = _ptr(status, "int32", n_ch, allow_none=True, device_ok=on_device)
         return b
@@ -383,6 +386,16 @@ class XaacContext:
         rc = self._lib.xaac_imdct_process_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_imdct_process_batch")
+
+    def imdct960_process_batch(self, spec, ics, overlap, state, out32=None, pcm16=None, qshift_adj=None, ch_fac=1,
+                               pcm_mode=PCM_LC, status=None):
+        """Batched ixheaacd_imdct_process for frame_length 960 on device tensors (asynchronous): spec int32[N,960],
+        overlap int32[N,480] in/out, out32 / pcm16 [N*960]; everything else as imdct_process_batch."""
+        n_ch = spec.shape[0]
+        b = self._batch(n_ch, spec, ics, overlap, state, out32, pcm16, qshift_adj, ch_fac, pcm_mode, True, status, frame=960)
+        rc = self._lib.xaac_imdct960_process_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_imdct960_process_batch")
 
     def imdct_process_batch_host(self, spec, ics, overlap, state, out32=None, pcm16=None, qshift_adj=None,
                                  ch_fac=1, pcm_mode=PCM_LC, status=None):

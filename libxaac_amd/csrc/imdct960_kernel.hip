@@ -1,0 +1,67 @@
+/*
+ * imdct960_kernel.hip -- gfx950 kernel for the 960-line AAC IMDCT + windowing + overlap-add (frame_length 960 of
+ * ixheaacd_imdct_process, decoder/ixheaacd_lpfuncs.c:347-802); stages and arithmetic in imdct960.h.
+ *
+ * Mapping: one wave = one channel-frame, four per workgroup (they share nothing, so only wave-level barriers).  The 960
+ * lines and the 480 old overlap words are read once, coalesced, into LDS (the block exponent is an OR over the wave on
+ * the way); every stage of imdct960.h then spreads its independent items over the 64 lanes between two 3.75 KB LDS
+ * arrays: pre twiddle in the prime-factor input order, 15 x 32-point (three passes of 120 items), 32 x 15-point as
+ * 96 five-point + 160 three-point items, post twiddle with the 17476 scale, windowing / overlap-add straight to global
+ * memory.  HBM traffic = 3.75 KB lines + 1.9 KB overlap in, 3.75 KB samples + 1.9 KB overlap out per channel-frame.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "imdct960.h"
+#include "imdct960_kernel.h"
+
+namespace {
+__device__ __forceinline__ int32_t wave_or(int32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+  return v;
+}
+}  // namespace
+
+__global__ __launch_bounds__(64 * XAAC_I960_WAVES_PER_WG) void xaac_imdct960_kernel(xaac_imdct_batch p) {
+  extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nl = 64;
+  const int ch = blockIdx.x * XAAC_I960_WAVES_PER_WG + wave;
+  if (ch >= p.n_ch) return;
+  int32_t *y = smem + wave * (960 + 960 + 480), *a = y + 960, *old = a + 960;
+  const int seq = p.ics[ch].window_sequence, shape = p.ics[ch].window_shape;
+  const int pseq = p.state[ch].window_sequence, pshape = p.state[ch].window_shape;
+  if (seq > 3 || shape > 1 || pseq > 3 || pshape > 1) { /* values the bitstream fields cannot carry: left untouched */
+    if (lane == 0 && p.status) p.status[ch] = XAAC_FATAL_BAD_WINDOW_SEQ;
+    return;
+  }
+  const int32_t *spec = p.spec + (size_t)ch * 960;
+  int32_t *gov = p.overlap + (size_t)ch * 480;
+  int32_t acc = 0;
+  X9_FOR(i, 960) {
+    const int32_t v = spec[i];
+    a[i] = v;
+    acc |= fx_abs_nrm(v);
+  }
+  X9_FOR(i, 480) old[i] = gov[i];
+  const int headroom = fx_norm32(wave_or(acc));
+  x9_sync();
+  const bool edge = pseq == X9_LONG_START || pseq == X9_EIGHT_SHORT;
+  const size_t unit = (size_t)(ch / p.ch_fac) * 960 * p.ch_fac + ch % p.ch_fac;
+  const X9Sink sk = {p.out32 ? p.out32 + unit : nullptr, p.pcm16 ? p.pcm16 + unit : nullptr, p.ch_fac, x9_qshift_adj(seq, edge),
+                     p.pcm_mode};
+  /* the lines sit in the work array: the pre twiddle is their only reader and ends before anything is written there */
+  x9_imdct_process(a, old, gov, y, a, headroom, seq, shape, pseq, pshape, sk, lane, nl);
+  if (lane == 0) {
+    p.state[ch].window_sequence = (uint8_t)seq; /* lpfuncs.c:800-801 */
+    p.state[ch].window_shape = (uint8_t)shape;
+    if (p.qshift_adj) p.qshift_adj[ch] = (int8_t)sk.qadj;
+    if (p.status) p.status[ch] = XAAC_OK;
+  }
+}
+
+extern "C" hipError_t xaac_launch_imdct960(const xaac_imdct_batch *p, hipStream_t stream) {
+  const int wgs = (p->n_ch + XAAC_I960_WAVES_PER_WG - 1) / XAAC_I960_WAVES_PER_WG;
+  hipLaunchKernelGGL(xaac_imdct960_kernel, dim3(wgs), dim3(64 * XAAC_I960_WAVES_PER_WG), XAAC_I960_LDS, stream, *p);
+  return hipGetLastError();
+}

@@ -19,6 +19,7 @@
 #include "limiter_kernel.h"
 #include "esbr_qmf_kernel.h"
 #include "usac_imdct_kernel.h"
+#include "imdct960_kernel.h"
 #include "esbr_core_kernel.h"
 #include "hbe_kernel.h"
 #include <cmath>
@@ -149,6 +150,19 @@ int32_t xaac_imdct_process_batch(xaac_ctx *c, const xaac_imdct_batch *b) {
   c->last_grid = grid;
   c->last_block = XAAC_IMDCT_BLOCK;
   c->last_lds = XAAC_IMDCT_LDS_BYTES;
+  return XAAC_OK;
+}
+
+int32_t xaac_imdct960_process_batch(xaac_ctx *c, const xaac_imdct_batch *b) {
+  if (!c) return XAAC_FATAL_NULL_ARG;
+  int32_t rc = check_batch(b);
+  if (rc != XAAC_OK) return rc;
+  if (b->n_ch == 0) return XAAC_OK;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  if (!hip_ok(xaac_launch_imdct960(b, c->stream))) return XAAC_FATAL_HIP;
+  c->last_grid = (b->n_ch + XAAC_I960_WAVES_PER_WG - 1) / XAAC_I960_WAVES_PER_WG;
+  c->last_block = 64 * XAAC_I960_WAVES_PER_WG;
+  c->last_lds = XAAC_I960_LDS;
   return XAAC_OK;
 }
 

@@ -83,6 +83,36 @@ int ref_imdct_process(WORD32 *spec, WORD32 *overlap, WORD16 *prev_seq, WORD16 *p
   return ics.qshift_adj;
 }
 
+/* The same for frame_length 960 (lpfuncs.c's 960 branches: ixheaacd_mdct_960 / ixheaacd_inverse_transform_960, the 960- and
+ * 120-sample windows as aacdecoder.c:210-227 selects them): spec[1024] (960 used, clobbered), overlap[512] (480 used),
+ * out[960 * ch_fac]. */
+int ref_imdct960_process(WORD32 *spec, WORD32 *overlap, WORD16 *prev_seq, WORD16 *prev_shape, int seq, int shape,
+                         WORD32 *out, int ch_fac) {
+  static __thread WORD32 scratch[2048];
+  ia_aac_dec_overlap_info oi;
+  ia_ics_info_struct ics;
+  ia_aac_dec_tables_struct tabs;
+  ia_aac_dec_imdct_tables_struct *rom = (ia_aac_dec_imdct_tables_struct *)&ixheaacd_imdct_tables;
+  memset(&oi, 0, sizeof(oi));
+  memset(&ics, 0, sizeof(ics));
+  memset(&tabs, 0, sizeof(tabs));
+  tabs.pstr_imdct_tables = rom;
+  oi.ptr_long_window[0] = rom->only_long_window_sine_960;
+  oi.ptr_short_window[0] = rom->only_short_window_sine_120;
+  oi.ptr_long_window[1] = rom->only_long_window_kbd_960;
+  oi.ptr_short_window[1] = rom->only_short_window_kbd_120;
+  oi.window_shape = *prev_shape;
+  oi.window_sequence = *prev_seq;
+  oi.ptr_overlap_buf = overlap;
+  ics.window_sequence = (WORD16)seq;
+  ics.window_shape = (WORD16)shape;
+  ics.frame_length = 960;
+  ixheaacd_imdct_process(&oi, spec, &ics, out, (WORD16)ch_fac, scratch, &tabs, AOT_AAC_LC, 0, 0);
+  *prev_seq = oi.window_sequence;
+  *prev_shape = oi.window_shape;
+  return ics.qshift_adj;
+}
+
 /* n channel-frames in a C loop (for timing the reference as the CPU baseline):
  * per channel c: spec[c][1024] (clobbered), overlap[c][512], prev_seq/prev_shape[c],
  * seq/shape[c]; writes PCM16 at stride 1 per channel like ixheaacd_scale_adjust +
