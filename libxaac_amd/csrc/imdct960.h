@@ -222,10 +222,13 @@ FX_HD int x9_long_transform(const int32_t *spec, int32_t *y, int32_t *a, int e, 
   x9_sync();
   /* 32 x 15 points (:1975): three 5-point transforms on inputs 64 words apart in the reference's order ... */
   X9_FOR(t, 96) {
-    const int j = t / 3, g = t % 3;
+    const int j = t & 31, g = t >> 5;
     X9Cx in[5], out[5];
 #pragma unroll
-    for (int m = 0; m < 5; m++) in[m] = x9_ld(a, j + 32 * ((5 * g + 3 * m) % 15));
+    for (int m = 0; m < 5; m++) {
+      const int k = 5 * g + 3 * m; /* (5 g + 3 m) mod 15 */
+      in[m] = x9_ld(a, j + 32 * (k >= 15 ? k - 15 : k));
+    }
     x9_fft5<false>(in, out);
 #pragma unroll
     for (int m = 0; m < 5; m++) x9_st(y, 15 * j + 5 * g + m, out[m]);
@@ -233,7 +236,7 @@ FX_HD int x9_long_transform(const int32_t *spec, int32_t *y, int32_t *a, int e, 
   x9_sync();
   /* ... then five 3-point ones, results through re_arr_tab_sml_480 */
   X9_FOR(t, 160) {
-    const int j = t / 5, i = t % 5;
+    const int j = t & 31, i = t >> 5;
     X9Cx out[3];
     x9_fft3(x9_ld(y, 15 * j + i), x9_ld(y, 15 * j + 5 + i), x9_ld(y, 15 * j + 10 + i), out);
 #pragma unroll
@@ -250,8 +253,8 @@ FX_HD int x9_short_transform(const int32_t *spec, int32_t *y, int32_t *a, int e,
   const int sh = 4 - e;
   /* pre twiddle through re_arr_tab_4 (:2262) */
   X9_FOR(t, 480) {
-    const int w = t / 60, n = t % 60;
-    x9_st(y, t, x9_pre_twiddle<false>(spec + 120 * w, xaac_i960_arr_4[n], sh));
+    const int w = t & 7, n = t >> 3;
+    x9_st(y, 60 * w + n, x9_pre_twiddle<false>(spec + 120 * w, xaac_i960_arr_4[n], sh));
   }
   x9_sync();
   /* fifteen 4-point transforms per block (:2266-2316) */
@@ -269,33 +272,33 @@ FX_HD int x9_short_transform(const int32_t *spec, int32_t *y, int32_t *a, int e,
     x9_st(a, 4 * t + 3, n3);
   }
   x9_sync();
-  /* four 15-point transforms per block (:2334): inputs through re_arr_tab_15_4 and re_arr_tab_5; 5-point stage */
+  /* four 15-point transforms per block (:2334): inputs through re_arr_tab_15_4 and re_arr_tab_5 (composed by the table
+     generator); 5-point stage */
   X9_FOR(t, 96) {
-    const int w = t / 12, b = (t / 3) & 3, g = t % 3;
+    const int wb = t & 31, g = t >> 5; /* wb = 4 w + b: 15-point transform wb starts at complex 15 wb */
+    const int32_t *src = a + 2 * 60 * (wb >> 2);
     X9Cx in[5], out[5];
 #pragma unroll
-    for (int m = 0; m < 5; m++) in[m] = x9_ld(a, 60 * w + xaac_i960_arr_15_4[15 * b + xaac_i960_arr_5[5 * g + m]]);
+    for (int m = 0; m < 5; m++) in[m] = x9_ld(src, xaac_i960_arr_15_4_5[15 * (wb & 3) + 5 * g + m]);
     x9_fft5<true>(in, out);
 #pragma unroll
-    for (int m = 0; m < 5; m++) x9_st(y, 60 * w + 15 * b + 5 * g + m, out[m]);
+    for (int m = 0; m < 5; m++) x9_st(y, 15 * wb + 5 * g + m, out[m]);
   }
   x9_sync();
   /* 3-point stage through re_arr_tab_3 */
   X9_FOR(t, 160) {
-    const int w = t / 20, b = (t / 5) & 3, g = t % 5;
-    const int32_t *src = y + 2 * (60 * w + 15 * b);
+    const int wb = t & 31, g = t >> 5;
+    const int32_t *src = y + 2 * 15 * wb;
     X9Cx out[3];
     x9_fft3(x9_ld(src, xaac_i960_arr_3[3 * g]), x9_ld(src, xaac_i960_arr_3[3 * g + 1]), x9_ld(src, xaac_i960_arr_3[3 * g + 2]), out);
 #pragma unroll
-    for (int m = 0; m < 3; m++) x9_st(a, 60 * w + 15 * b + 3 * g + m, out[m]);
+    for (int m = 0; m < 3; m++) x9_st(a, 15 * wb + 3 * g + m, out[m]);
   }
   x9_sync();
-  /* post twiddle reading through re_arr_tab_sml and re_arr_tab_120 (:2362, :2331) */
+  /* post twiddle reading through re_arr_tab_sml and re_arr_tab_120 (:2362, :2331; the two composed by the table generator) */
   X9_FOR(t, 240) {
-    const int w = t / 30, k = t % 30;
-    const int n0 = xaac_i960_arr_120[k], n1 = xaac_i960_arr_120[59 - k];
-    const X9Cx lo = x9_ld(a, 60 * w + 15 * (n0 / 15) + xaac_i960_arr_sml[n0 % 15]);
-    const X9Cx hi = x9_ld(a, 60 * w + 15 * (n1 / 15) + xaac_i960_arr_sml[n1 % 15]);
+    const int w = t & 7, k = t >> 3;
+    const X9Cx lo = x9_ld(a, 60 * w + xaac_i960_arr_120_sml[k]), hi = x9_ld(a, 60 * w + xaac_i960_arr_120_sml[59 - k]);
     x9_post_twiddle<false>(lo, hi, k, y + 120 * w);
   }
   x9_sync();
@@ -389,8 +392,8 @@ FX_HD void x9_short_after_long(const int32_t *y, const int32_t *ov, const X9Sink
     sk.put(8 * u + i, fx_sub_sat(fx_shl_dir_sat_limit(fx_mul32x16(fx_neg_sat(y[2 * u - 1 - i]), wsp[2 * u - 2 * i - 1]), q),
                                  fx_mul32x16_nosh_sat(ov[i], wlp[16 * u - 2 - 2 * i])));
   }
-  X9_FOR(t, 4 * u) {
-    const int b = t / u, i = t % u, inc = 2 * u * b;
+  for (int b = 0; b < 4; b++) X9_FOR(i, u) {
+    const int inc = 2 * u * b;
     const int32_t *cur = y + u + inc;
     const int32_t *pv = ov + u + inc;
     const int16_t *wl = wlp + 2 * (7 * u - inc);
@@ -459,8 +462,7 @@ FX_HD void x9_imdct_process(const int32_t *spec, const int32_t *ov_old, int32_t 
     if (prev_short_edge) {
       X9_FOR(i, 7 * u) sk.put(i, fx_shl_sat((int32_t)(int16_t)ov_old[i], 15)); /* lpfuncs.c:325 */
       x9_ola1(y, ov_old + 7 * u, sk, 7 * u, ws, q, u, lane, nl);
-      X9_FOR(t, 3 * u) { /* ola1 against the (requantised) tail of the previous short window */
-        const int b = t / u, i = t % u;
+      for (int b = 0; b < 3; b++) X9_FOR(i, u) { /* ola1 against the (requantised) tail of the previous short window */
         const int32_t *coef = y + 2 * u + 2 * u * b;
         const int16_t w1 = wsc[2 * u - 2 * i - 1], w2 = wsc[2 * u - 2 * i - 2];
         const int32_t c = coef[2 * u - 1 - i], pr = x9_to_ovl(y[2 * u * b + i], q);
@@ -476,10 +478,8 @@ FX_HD void x9_imdct_process(const int32_t *spec, const int32_t *ov_old, int32_t 
     } else {
       x9_short_after_long(y, ov_old, sk, ovl_new, wsc, ws, wl, q, lane, nl);
     }
-    X9_FOR(t, 6 * u) {
-      const int b = t / (2 * u), i = t % (2 * u);
-      ovl_new[u + 2 * u * b + i] = x9_ola2_value(y + 10 * u + 2 * u * b, y + 8 * u + 2 * u * b, wsc, q, u, i);
-    }
+    for (int b = 0; b < 3; b++)
+      X9_FOR(i, 2 * u) ovl_new[u + 2 * u * b + i] = x9_ola2_value(y + 10 * u + 2 * u * b, y + 8 * u + 2 * u * b, wsc, q, u, i);
     X9_FOR(i, u) ovl_new[7 * u + i] = x9_to_ovl(y[14 * u + i], q);
   }
 }

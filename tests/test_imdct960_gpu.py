@@ -132,3 +132,33 @@ def test_refused_window_bytes_and_full_batch(oracle):
     ok[[7, 8, 9]] = False
     assert np.array_equal(got[ok], want32[ok]) and np.all(got[~ok] == 3)
     assert np.array_equal(d_ovl.cpu().numpy(), ho) and np.array_equal(d_state.cpu().numpy(), hs)
+
+
+@pytest.mark.gpu
+def test_reference_made_chains():
+    """tests/golden/imdct960_ref.npz: 32 chains x 40 frames made by the compiled reference (tools/make_golden_imdct960.py),
+    all chains as one batch per frame step with overlap and state on the device: every frame's output and overlap CRC"""
+    import os
+    import sys
+    import torch
+    import libxaac_amd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from make_golden_imdct960 import CHAINS, FRAMES, chain_spec, crc
+    gold = np.load(os.path.join(root, "tests", "golden", "imdct960_ref.npz"))
+    dev = torch.device("cuda:0")
+    ctx = libxaac_amd.XaacContext(0, None)
+    d_ovl = torch.zeros((CHAINS, 480), dtype=torch.int32, device=dev)
+    d_state = torch.zeros((CHAINS, 2), dtype=torch.uint8, device=dev)
+    for f in range(FRAMES):
+        spec = np.stack([chain_spec(c, f) for c in range(CHAINS)])
+        ics = np.ascontiguousarray(gold["side"][:, f, :2]).astype(np.uint8)
+        out32 = torch.zeros(CHAINS * 960, dtype=torch.int32, device=dev)
+        qadj = torch.zeros(CHAINS, dtype=torch.int8, device=dev)
+        ctx.imdct960_process_batch(torch.from_numpy(spec).to(dev), torch.from_numpy(ics).to(dev), d_ovl, d_state, out32, None, qadj)
+        ctx.sync()
+        got, ov = out32.cpu().numpy().reshape(CHAINS, 960), d_ovl.cpu().numpy()
+        assert np.array_equal(qadj.cpu().numpy(), gold["side"][:, f, 2])
+        for c in range(CHAINS):
+            assert (crc(got[c]), crc(ov[c])) == tuple(int(v) for v in gold["crc"][c, f]), (c, f)
+    assert np.array_equal(got, gold["last"][:, 0]) and np.array_equal(ov, gold["last"][:, 1, :480])

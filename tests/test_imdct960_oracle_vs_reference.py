@@ -88,3 +88,26 @@ def test_legal_walk_with_state(oracle, reference, seed):
         assert np.array_equal(so, spec)
         assert qr == qo and np.array_equal(outr, outo), (frame, seq)
         assert np.array_equal(ovl_r[:480], ovl_o), (frame, seq)
+
+
+def test_oracle_on_reference_made_chains(oracle):
+    """tests/golden/imdct960_ref.npz (tools/make_golden_imdct960.py: the compiled reference along legal walks): the
+    restatement reproduces every frame's output and overlap CRC; this one needs no reference at run time"""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from make_golden_imdct960 import CHAINS, FRAMES, chain_spec, crc
+    gold = np.load(os.path.join(root, "tests", "golden", "imdct960_ref.npz"))
+    of = bind(oracle.lib, "xo_imdct960_process")
+    for c in range(CHAINS):
+        ov = np.zeros(480, np.int32)
+        ps, pw = np.zeros(1, np.int16), np.zeros(1, np.int16)
+        for f in range(FRAMES):
+            seq, shape, q = (int(v) for v in gold["side"][c, f])
+            spec = chain_spec(c, f)
+            out = np.zeros(960, np.int32)
+            got = of(spec.ctypes.data_as(P32), ov.ctypes.data_as(P32), ps.ctypes.data_as(P16), pw.ctypes.data_as(P16), seq, shape,
+                     out.ctypes.data_as(P32), 1)
+            assert got == q and (crc(out), crc(ov)) == tuple(int(v) for v in gold["crc"][c, f]), (c, f, seq)
+        assert np.array_equal(out, gold["last"][c, 0]) and np.array_equal(ov, gold["last"][c, 1, :480])

@@ -94,6 +94,10 @@ def test_eld_qmf_tables_equal_reference_rom(tmp_path):
     _regenerated_equals_committed("gen_tables_qmf_eld", "tables_qmf_eld.inc", tmp_path)
 
 
+def test_imdct960_tables_equal_reference_rom(tmp_path):
+    _regenerated_equals_committed("gen_tables_imdct960", "tables_imdct960.inc", tmp_path)
+
+
 def test_hbe_tables_equal_reference_rom(tmp_path):
     _regenerated_equals_committed("gen_tables_hbe", "tables_hbe.inc", tmp_path)
 

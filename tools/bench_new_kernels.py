@@ -44,6 +44,15 @@ def main():
         ics = torch.tensor([[seq, 1]] * n, dtype=torch.uint8, device=dev)
         us = timed(torch, ctx, lambda: ctx.usac_imdct_process_batch(coef, ics, ov, sp, out))
         res.append((name, us, n * 16384))
+    # 960-line AAC IMDCT: 3840 B lines + 1920 B overlap in, 3840 B samples + 1920 B overlap out per channel-frame
+    spec9 = torch.from_numpy(rng.integers(-2 ** 17, 2 ** 17, (n, 960)).astype(np.int32)).to(dev)
+    ov9 = torch.zeros((n, 480), dtype=torch.int32, device=dev)
+    out9 = torch.zeros(n * 960, dtype=torch.int32, device=dev)
+    for name, seq in (("imdct960_long", 0), ("imdct960_short", 2)):
+        ics9 = torch.tensor([[seq, 1]] * n, dtype=torch.uint8, device=dev)
+        st9 = torch.tensor([[seq, 1]] * n, dtype=torch.uint8, device=dev)
+        us = timed(torch, ctx, lambda: ctx.imdct960_process_batch(spec9, ics9, ov9, st9, out9))
+        res.append((name, us, n * 11520))
     # eSBR banks
     core = torch.from_numpy((rng.uniform(-1, 1, (n, 1024)) * 20000).astype(np.float32)).to(dev)
     sa = torch.zeros((n, libxaac_amd.ESBR_ANA_STATE_WORDS), dtype=torch.int32, device=dev)
