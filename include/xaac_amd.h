@@ -91,6 +91,26 @@ typedef struct xaac_imdct_batch {
                                  bitstream fields cannot carry; such a channel-frame is left untouched */
 } xaac_imdct_batch;
 
+/* ---- AAC-LD / AAC-ELD IMDCT ------------------------------------------------------------
+ * xaac_imdct_ld_process_batch <-> ixheaacd_imdct_process with ics->frame_length 512 or 480 and object_type AOT_ER_AAC_LD (23)
+ * or AOT_ER_AAC_ELD (39) (decoder/ixheaacd_lpfuncs.c:385-409, :456-486): ixheaacd_inverse_transform_512 / ixheaacd_mdct_480_ld
+ * (aac_imdct.c:1761 / :1707), then ixheaacd_lap1_512_480 (block.c:1140) for LD or the sign / copy step and
+ * ixheaacd_eld_dec_windowing (lpfuncs.c:804) for ELD.  ONLY_LONG frames (the two profiles have no others); PCM16 out, which
+ * is what the reference writes here (qshift_adj = -2); ld_mps_present = 0, slot_element = 0. */
+typedef struct xaac_imdct_ld_batch {
+  int32_t n_ch;                 /* channel-frames; a multiple of ch_fac */
+  int32_t ch_fac;               /* output interleave stride, 1 or 2 */
+  int32_t frame_length;         /* 512 or 480 */
+  int32_t eld;                  /* 0: AAC-LD (sine / low-overlap window by the PREVIOUS frame's shape), 1: AAC-ELD */
+  const int32_t *spec;          /* [n_ch][frame_length] (not modified) */
+  const uint8_t *window_shape;  /* [n_ch] ics->window_shape of this frame */
+  int32_t *overlap;             /* in/out: LD [n_ch][frame_length / 2], ELD [n_ch][3 * frame_length] (ptr_overlap_buf; zero for a
+                                   new stream; ELD never writes its last frame_length / 4 words) */
+  uint8_t *shape_prev;          /* [n_ch] in/out: ia_aac_dec_overlap_info.window_shape */
+  int16_t *pcm16;               /* [n_ch * frame_length], channel-frame i at (i / ch_fac) * frame_length * ch_fac + i % ch_fac, stride ch_fac */
+  int32_t *status;              /* [n_ch] or NULL: XAAC_OK, or XAAC_FATAL_BAD_WINDOW_SEQ for a shape byte > 1 (left untouched) */
+} xaac_imdct_ld_batch;
+
 /* ---- SBR QMF banks (fixed-point "Path B") ---------------------------------------------
  * xaac_qmf_analysis_batch  <-> ixheaacd_cplx_anal_qmffilt
  *      decl decoder/ixheaacd_qmf_dec.h:74, def decoder/generic/ixheaacd_qmf_dec_generic.c:590,
@@ -368,6 +388,8 @@ int32_t xaac_imdct_process_batch_host(xaac_ctx *ctx, const xaac_imdct_batch *bat
  * branches of lpfuncs.c:347-802).  The same descriptor with 960 for 1024 and 480 for 512: spec [n_ch][960], overlap
  * [n_ch][480], out32 / pcm16 [n_ch * 960] interleaved at ch_fac; pcm16 is the plain hand-off of pcm_mode per sample. */
 int32_t xaac_imdct960_process_batch(xaac_ctx *ctx, const xaac_imdct_batch *batch);
+/* ixheaacd_imdct_process for AAC-LD / AAC-ELD frames (512 or 480 lines), device pointers, asynchronous */
+int32_t xaac_imdct_ld_process_batch(xaac_ctx *ctx, const xaac_imdct_ld_batch *batch);
 
 /* SBR QMF banks, device pointers, asynchronous on the context's stream. */
 int32_t xaac_qmf_analysis_batch(xaac_ctx *ctx, const xaac_qmf_ana_batch *batch);

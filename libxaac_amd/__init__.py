@@ -99,6 +99,13 @@ class _QmfAnaEldBatch(ctypes.Structure):
 QMF_ANA_ELD_STATE_WORDS = 324   # struct xaac_qmf_ana_eld_state: ring[320], wr, f1, f2, fp (int16)
 
 
+class _ImdctLdBatch(ctypes.Structure):
+    # struct xaac_imdct_ld_batch
+    _fields_ = [("n_ch", ctypes.c_int32), ("ch_fac", ctypes.c_int32), ("frame_length", ctypes.c_int32), ("eld", ctypes.c_int32),
+                ("spec", ctypes.c_void_p), ("window_shape", ctypes.c_void_p), ("overlap", ctypes.c_void_p),
+                ("shape_prev", ctypes.c_void_p), ("pcm16", ctypes.c_void_p), ("status", ctypes.c_void_p)]
+
+
 class _QmfSynEldBatch(ctypes.Structure):
     # struct xaac_qmf_syn_eld_batch
     _fields_ = [("n_ch", ctypes.c_int32), ("n_slots", ctypes.c_int32), ("lsb", ctypes.c_int32), ("usb", ctypes.c_int32),
@@ -231,6 +238,8 @@ def load_library():
     lib.xaac_imdct_process_batch_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(_ImdctBatch)]
     lib.xaac_imdct960_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_ImdctBatch)]
     lib.xaac_imdct960_process_batch.restype = ctypes.c_int32
+    lib.xaac_imdct_ld_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_ImdctLdBatch)]
+    lib.xaac_imdct_ld_process_batch.restype = ctypes.c_int32
     lib.xaac_last_launch.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int32)] * 3
     lib.xaac_qmf_analysis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_QmfAnaBatch)]
     lib.xaac_qmf_synthesis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_QmfSynBatch)]
@@ -396,6 +405,23 @@ class XaacContext:
         rc = self._lib.xaac_imdct960_process_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_imdct960_process_batch")
+
+    def imdct_ld_process_batch(self, spec, window_shape, overlap, shape_prev, pcm16, frame_length, eld, ch_fac=1, status=None):
+        """Batched ixheaacd_imdct_process for AAC-LD (eld = 0) / AAC-ELD (eld = 1) frames on device tensors: spec
+        int32[N, frame_length] (512 or 480), window_shape uint8[N], overlap int32[N, frame_length / 2] (LD) or
+        [N, 3 * frame_length] (ELD) in/out, shape_prev uint8[N] in/out, pcm16 int16[N * frame_length] at stride ch_fac."""
+        n_ch = spec.shape[0]
+        b = _ImdctLdBatch()
+        b.n_ch, b.ch_fac, b.frame_length, b.eld = n_ch, int(ch_fac), int(frame_length), int(eld)
+        b.spec = _ptr(spec, "int32", n_ch * frame_length, device_ok=True)
+        b.window_shape = _ptr(window_shape, "uint8", n_ch, device_ok=True)
+        b.overlap = _ptr(overlap, "int32", n_ch * (3 * frame_length if eld else frame_length // 2), device_ok=True)
+        b.shape_prev = _ptr(shape_prev, "uint8", n_ch, device_ok=True)
+        b.pcm16 = _ptr(pcm16, "int16", n_ch * frame_length, device_ok=True)
+        b.status = _ptr(status, "int32", n_ch, allow_none=True, device_ok=True)
+        rc = self._lib.xaac_imdct_ld_process_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_imdct_ld_process_batch")
 
     def imdct_process_batch_host(self, spec, ics, overlap, state, out32=None, pcm16=None, qshift_adj=None,
                                  ch_fac=1, pcm_mode=PCM_LC, status=None):

@@ -1,0 +1,72 @@
+/*
+ * imdct_ld_kernel.hip -- gfx950 kernels for the 512 / 480-line AAC-LD and AAC-ELD IMDCT + windowing + overlap-add (the
+ * frame_length 512 / 480 branches of ixheaacd_imdct_process, decoder/ixheaacd_lpfuncs.c:385-486, :804-1010); stages and
+ * arithmetic in imdct_ld.h.
+ *
+ * Mapping as for the 960-line kernel: one wave = one channel-frame, four per workgroup; lines and old overlap read once
+ * into LDS with the block exponent as a wave OR; the 256-point transform is four passes of 64 butterflies (one per lane),
+ * the 15 x 16 one five short stages; ELD's four-fold output is never materialised (the window stage reads the 2 F
+ * transform outputs with the sign / copy map of lpfuncs.c:401-408); PCM16 and the new overlap go straight to global memory.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "imdct_ld.h"
+#include "imdct_ld_kernel.h"
+
+namespace {
+__device__ __forceinline__ int32_t wave_or(int32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+  return v;
+}
+}  // namespace
+
+template <int F, bool ELD>
+__global__ __launch_bounds__(64 * XAAC_LD_WAVES_PER_WG) void xaac_imdct_ld_kernel(xaac_imdct_ld_batch p) {
+  extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+  constexpr int NOV = ELD ? 3 * F : F / 2, PER_WAVE = 1024 + 512 + NOV;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nl = 64;
+  const int ch = blockIdx.x * XAAC_LD_WAVES_PER_WG + wave;
+  if (ch >= p.n_ch) return;
+  int32_t *a = smem + wave * PER_WAVE, *b = a + 1024, *old = b + 512;
+  const int shape = p.window_shape[ch], shape_prev = p.shape_prev[ch];
+  if (shape > 1 || shape_prev > 1) { /* values the one-bit field cannot carry: left untouched */
+    if (lane == 0 && p.status) p.status[ch] = XAAC_FATAL_BAD_WINDOW_SEQ;
+    return;
+  }
+  const int32_t *spec = p.spec + (size_t)ch * F;
+  int32_t *gov = p.overlap + (size_t)ch * NOV;
+  int32_t acc = 0;
+  X9_FOR(i, F) { /* the lines wait in the upper half of a: the pre twiddle is their only reader */
+    const int32_t v = spec[i];
+    a[512 + i] = v;
+    acc |= fx_abs_nrm(v);
+  }
+  X9_FOR(i, NOV) old[i] = gov[i];
+  const int e = fx_norm32(wave_or(acc)) - 1;
+  x9_sync();
+  const int q = xl_transform<F, ELD>(a + 512, a, b, e, lane, nl);
+  int16_t *pcm = p.pcm16 + (size_t)(ch / p.ch_fac) * F * p.ch_fac + ch % p.ch_fac;
+  if (ELD)
+    xl_eld_overlap_add<F>(a, old, gov, pcm, p.ch_fac, q, lane, nl);
+  else
+    xl_ld_overlap_add<F>(a, old, gov, pcm, p.ch_fac, q, shape_prev, lane, nl);
+  if (lane == 0) {
+    p.shape_prev[ch] = (uint8_t)shape; /* lpfuncs.c:800 */
+    if (p.status) p.status[ch] = XAAC_OK;
+  }
+}
+
+extern "C" hipError_t xaac_launch_imdct_ld(const xaac_imdct_ld_batch *p, hipStream_t stream) {
+  const dim3 grid((p->n_ch + XAAC_LD_WAVES_PER_WG - 1) / XAAC_LD_WAVES_PER_WG), block(64 * XAAC_LD_WAVES_PER_WG);
+  const size_t lds = XAAC_LD_LDS(p->frame_length, p->eld);
+  if (p->frame_length == 512) {
+    if (p->eld) hipLaunchKernelGGL((xaac_imdct_ld_kernel<512, true>), grid, block, lds, stream, *p);
+    else hipLaunchKernelGGL((xaac_imdct_ld_kernel<512, false>), grid, block, lds, stream, *p);
+  } else {
+    if (p->eld) hipLaunchKernelGGL((xaac_imdct_ld_kernel<480, true>), grid, block, lds, stream, *p);
+    else hipLaunchKernelGGL((xaac_imdct_ld_kernel<480, false>), grid, block, lds, stream, *p);
+  }
+  return hipGetLastError();
+}

@@ -20,6 +20,7 @@
 #include "esbr_qmf_kernel.h"
 #include "usac_imdct_kernel.h"
 #include "imdct960_kernel.h"
+#include "imdct_ld_kernel.h"
 #include "esbr_core_kernel.h"
 #include "hbe_kernel.h"
 #include <cmath>
@@ -163,6 +164,20 @@ int32_t xaac_imdct960_process_batch(xaac_ctx *c, const xaac_imdct_batch *b) {
   c->last_grid = (b->n_ch + XAAC_I960_WAVES_PER_WG - 1) / XAAC_I960_WAVES_PER_WG;
   c->last_block = 64 * XAAC_I960_WAVES_PER_WG;
   c->last_lds = XAAC_I960_LDS;
+  return XAAC_OK;
+}
+
+int32_t xaac_imdct_ld_process_batch(xaac_ctx *c, const xaac_imdct_ld_batch *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n_ch < 0 || (b->ch_fac != 1 && b->ch_fac != 2) || b->n_ch % b->ch_fac) return XAAC_FATAL_BAD_ARG;
+  if ((b->frame_length != 512 && b->frame_length != 480) || (b->eld != 0 && b->eld != 1)) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch == 0) return XAAC_OK;
+  if (!b->spec || !b->window_shape || !b->overlap || !b->shape_prev || !b->pcm16) return XAAC_FATAL_NULL_ARG;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  if (!hip_ok(xaac_launch_imdct_ld(b, c->stream))) return XAAC_FATAL_HIP;
+  c->last_grid = (b->n_ch + XAAC_LD_WAVES_PER_WG - 1) / XAAC_LD_WAVES_PER_WG;
+  c->last_block = 64 * XAAC_LD_WAVES_PER_WG;
+  c->last_lds = XAAC_LD_LDS(b->frame_length, b->eld);
   return XAAC_OK;
 }
 

@@ -113,6 +113,40 @@ int ref_imdct960_process(WORD32 *spec, WORD32 *overlap, WORD16 *prev_seq, WORD16
   return ics.qshift_adj;
 }
 
+/* AAC-LD / ELD: frame_length 512 or 480, object_type AOT_ER_AAC_LD (23) or AOT_ER_AAC_ELD (39), ONLY_LONG frames; windows as
+ * aacdecoder.c:236-277 selects them.  spec[2048] (frame_length lines in, clobbered: ELD works in 4 x frame_length words),
+ * overlap[2048] in/out (LD: frame_length / 2 words, ELD: 3 x frame_length), out16[frame_length * ch_fac] PCM16. */
+int ref_imdct_ld_process(WORD32 *spec, WORD32 *overlap, WORD16 *prev_shape, int shape, int frame_length, int aot,
+                         WORD16 *out16, int ch_fac) {
+  static __thread WORD32 scratch[4096];
+  ia_aac_dec_overlap_info oi;
+  ia_ics_info_struct ics;
+  ia_aac_dec_tables_struct tabs;
+  ia_aac_dec_imdct_tables_struct *rom = (ia_aac_dec_imdct_tables_struct *)&ixheaacd_imdct_tables;
+  memset(&oi, 0, sizeof(oi));
+  memset(&ics, 0, sizeof(ics));
+  memset(&tabs, 0, sizeof(tabs));
+  tabs.pstr_imdct_tables = rom;
+  if (aot == AOT_ER_AAC_ELD) {
+    oi.ptr_long_window[0] = oi.ptr_long_window[1] =
+        frame_length == 512 ? (WORD16 *)rom->window_sine_512_eld : (WORD16 *)rom->window_sine_480_eld;
+  } else {
+    oi.ptr_long_window[0] = frame_length == 512 ? (WORD16 *)rom->window_sine_512 : (WORD16 *)rom->window_sine_480;
+    oi.ptr_long_window[1] = frame_length == 512 ? (WORD16 *)rom->low_overlap_win : (WORD16 *)rom->low_overlap_win_480;
+  }
+  oi.ptr_short_window[0] = rom->only_short_window_sine;
+  oi.ptr_short_window[1] = rom->only_short_window_kbd;
+  oi.window_shape = *prev_shape;
+  oi.window_sequence = 0;
+  oi.ptr_overlap_buf = overlap;
+  ics.window_sequence = 0;
+  ics.window_shape = (WORD16)shape;
+  ics.frame_length = (WORD16)frame_length;
+  ixheaacd_imdct_process(&oi, spec, &ics, out16, (WORD16)ch_fac, scratch, &tabs, aot, 0, 0);
+  *prev_shape = oi.window_shape;
+  return ics.qshift_adj;
+}
+
 /* n channel-frames in a C loop (for timing the reference as the CPU baseline):
  * per channel c: spec[c][1024] (clobbered), overlap[c][512], prev_seq/prev_shape[c],
  * seq/shape[c]; writes PCM16 at stride 1 per channel like ixheaacd_scale_adjust +

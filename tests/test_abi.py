@@ -109,14 +109,16 @@ def test_hbe_struct_layouts_match_header(tmp_path):
     src2.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "xaac_amd.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", '
                     'sizeof(xaac_qmf_ana_eld_state), offsetof(xaac_qmf_ana_eld_state, fp), sizeof(xaac_qmf_ana_eld_batch), '
                     'offsetof(xaac_qmf_ana_eld_batch, status), sizeof(xaac_qmf_syn_eld_state), offsetof(xaac_qmf_syn_eld_state, sixty4), '
-                    'sizeof(xaac_qmf_syn_eld_batch), offsetof(xaac_qmf_syn_eld_batch, status)); return 0; }\n')
+                    'sizeof(xaac_qmf_syn_eld_batch), offsetof(xaac_qmf_syn_eld_batch, status)); '
+                    'printf("%zu %zu %zu\\n", sizeof(xaac_imdct_ld_batch), offsetof(xaac_imdct_ld_batch, spec), offsetof(xaac_imdct_ld_batch, status)); return 0; }\n')
     exe2 = tmp_path / "layout4"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src2), "-o", str(exe2)])
     B = libxaac_amd._QmfAnaEldBatch
     S = libxaac_amd._QmfSynEldBatch
     assert [int(v) for v in subprocess.check_output([str(exe2)]).split()] == [
         2 * libxaac_amd.QMF_ANA_ELD_STATE_WORDS, 646, ctypes.sizeof(B), B.status.offset,
-        2 * libxaac_amd.QMF_SYN_ELD_STATE_WORDS, 2566, ctypes.sizeof(S), S.status.offset]
+        2 * libxaac_amd.QMF_SYN_ELD_STATE_WORDS, 2566, ctypes.sizeof(S), S.status.offset,
+        ctypes.sizeof(libxaac_amd._ImdctLdBatch), libxaac_amd._ImdctLdBatch.spec.offset, libxaac_amd._ImdctLdBatch.status.offset]
 
 
 def test_no_cpu_fallback_without_device():

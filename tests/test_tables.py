@@ -98,6 +98,10 @@ def test_imdct960_tables_equal_reference_rom(tmp_path):
     _regenerated_equals_committed("gen_tables_imdct960", "tables_imdct960.inc", tmp_path)
 
 
+def test_imdct_ld_tables_equal_reference_rom(tmp_path):
+    _regenerated_equals_committed("gen_tables_imdct_ld", "tables_imdct_ld.inc", tmp_path)
+
+
 def test_hbe_tables_equal_reference_rom(tmp_path):
     _regenerated_equals_committed("gen_tables_hbe", "tables_hbe.inc", tmp_path)
 

@@ -53,6 +53,17 @@ def main():
         st9 = torch.tensor([[seq, 1]] * n, dtype=torch.uint8, device=dev)
         us = timed(torch, ctx, lambda: ctx.imdct960_process_batch(spec9, ics9, ov9, st9, out9))
         res.append((name, us, n * 11520))
+    # AAC-LD / ELD IMDCT: lines + overlap in, PCM16 + overlap out (LD: F/2 words of overlap, ELD: 3 F in, 2.75 F out)
+    for fl in (512, 480):
+        for eld in (0, 1):
+            nov = 3 * fl if eld else fl // 2
+            specl = torch.from_numpy(rng.integers(-2 ** 17, 2 ** 17, (n, fl)).astype(np.int32)).to(dev)
+            ovl = torch.zeros((n, nov), dtype=torch.int32, device=dev)
+            shp = torch.zeros(n, dtype=torch.uint8, device=dev)
+            spv = torch.zeros(n, dtype=torch.uint8, device=dev)
+            pcml = torch.zeros(n * fl, dtype=torch.int16, device=dev)
+            us = timed(torch, ctx, lambda: ctx.imdct_ld_process_batch(specl, shp, ovl, spv, pcml, fl, eld))
+            res.append(("imdct_%s_%d" % ("eld" if eld else "ld", fl), us, n * (4 * fl + 2 * fl + (4 * nov + 11 * fl if eld else 8 * nov))))
     # eSBR banks
     core = torch.from_numpy((rng.uniform(-1, 1, (n, 1024)) * 20000).astype(np.float32)).to(dev)
     sa = torch.zeros((n, libxaac_amd.ESBR_ANA_STATE_WORDS), dtype=torch.int32, device=dev)
