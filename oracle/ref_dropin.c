@@ -41,7 +41,8 @@ static struct {
   xaac_hbe_state *hbe;         /* Path A: the channel's QMF harmonic transposer */
   void *ews;
 } g;
-static long g_imdct_calls, g_sbr_calls, g_lim_calls, g_esbr_calls, g_esbr_harm_calls;
+static long g_imdct_calls, g_sbr_calls, g_lim_calls, g_esbr_calls, g_esbr_harm_calls, g_imdct960_calls, g_imdct_ld_calls;
+static struct { int32_t *overlap; int16_t *pcm; uint8_t *shape; } gl; /* AAC-LD / ELD: 3 x 512 overlap words, 512 samples, 2 bytes */
 
 static void die(const char *what) {
   fprintf(stderr, "xaacdec_dropin: %s failed\n", what);
@@ -51,6 +52,8 @@ static void die(const char *what) {
 
 static void report(void) {
   fprintf(stderr, "xaacdec_dropin: %ld imdct_process and %ld sbr_dec calls ran on the GPU\n", g_imdct_calls, g_sbr_calls);
+  fprintf(stderr, "xaacdec_dropin: %ld imdct_process calls of 960-line frames and %ld of AAC-LD / ELD frames ran on the GPU\n",
+          g_imdct960_calls, g_imdct_ld_calls);
   fprintf(stderr, "xaacdec_dropin: %ld peak_limiter_process calls ran on the GPU\n", g_lim_calls);
   fprintf(stderr, "xaacdec_dropin: %ld sbr_dec calls took the eSBR (Path A) branch on the GPU\n", g_esbr_calls);
   fprintf(stderr, "xaacdec_dropin: %ld of them with harmonic patching (the QMF transposer's output)\n", g_esbr_harm_calls);
@@ -86,6 +89,9 @@ static void setup(void) {
   HIP(hipMalloc((void **)&g.estate, sizeof(xaac_esbr_state)));
   HIP(hipMalloc((void **)&g.hbe, sizeof(xaac_hbe_state)));
   HIP(hipMalloc(&g.ews, xaac_esbr_workspace_bytes(1)));
+  HIP(hipMalloc((void **)&gl.overlap, 3 * 512 * 4));
+  HIP(hipMalloc((void **)&gl.pcm, 512 * 2));
+  HIP(hipMalloc((void **)&gl.shape, 2));
   atexit(report);
 }
 
@@ -109,11 +115,77 @@ VOID __wrap_ixheaacd_imdct_process(ia_aac_dec_overlap_info *oi, WORD32 *spec, ia
   static int32_t tmp[1024];
   int8_t q;
   int i;
-  if (getenv("XAAC_DROPIN_PASS_IMDCT") || ics->frame_length != 1024 || ld_mps_present || object_type == AOT_ER_AAC_LD || object_type == AOT_ER_AAC_ELD) {
+  const int ld = object_type == AOT_ER_AAC_LD || object_type == AOT_ER_AAC_ELD;
+  if (!getenv("XAAC_DROPIN_PASS_IMDCT") && ld && !ld_mps_present && (ics->frame_length == 512 || ics->frame_length == 480) &&
+      ics->window_sequence == ONLY_LONG_SEQUENCE && oi->window_sequence == ONLY_LONG_SEQUENCE) {
+    /* AAC-LD / AAC-ELD: lpfuncs.c:385-486 through xaac_imdct_ld_process_batch; PCM16 comes back (out_samples - slot_element) */
+    const int fl = ics->frame_length, eld = object_type == AOT_ER_AAC_ELD, nov = eld ? 3 * fl : fl / 2;
+    static int16_t pcm[512];
+    xaac_imdct_ld_batch lb;
+    uint8_t sh[2];
+    WORD16 *o16 = (WORD16 *)out - slot_element;
+    setup();
+    sh[0] = (uint8_t)ics->window_shape;
+    sh[1] = (uint8_t)oi->window_shape;
+    HIP(hipMemcpy(g.spec, spec, 4 * fl, hipMemcpyHostToDevice));
+    HIP(hipMemcpy(gl.overlap, oi->ptr_overlap_buf, 4 * nov, hipMemcpyHostToDevice));
+    HIP(hipMemcpy(gl.shape, sh, 2, hipMemcpyHostToDevice));
+    memset(&lb, 0, sizeof(lb));
+    lb.n_ch = 1;
+    lb.ch_fac = 1;
+    lb.frame_length = fl;
+    lb.eld = eld;
+    lb.spec = g.spec;
+    lb.window_shape = gl.shape;
+    lb.overlap = gl.overlap;
+    lb.shape_prev = gl.shape + 1;
+    lb.pcm16 = gl.pcm;
+    if (xaac_imdct_ld_process_batch(g_ctx, &lb) != XAAC_OK || xaac_sync(g_ctx) != XAAC_OK) die("xaac_imdct_ld_process_batch");
+    HIP(hipMemcpy(pcm, gl.pcm, 2 * fl, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(oi->ptr_overlap_buf, gl.overlap, 4 * nov, hipMemcpyDeviceToHost));
+    for (i = 0; i < fl; i++) o16[i * ch_fac] = pcm[i];
+    oi->window_shape = ics->window_shape; /* lpfuncs.c:800-801 */
+    oi->window_sequence = ics->window_sequence;
+    ics->qshift_adj = -2;
+    g_imdct_ld_calls++;
+    return;
+  }
+  if (getenv("XAAC_DROPIN_PASS_IMDCT") || (ics->frame_length != 1024 && ics->frame_length != 960) || ld_mps_present || ld) {
     __real_ixheaacd_imdct_process(oi, spec, ics, out, ch_fac, scratch, tabs, object_type, ld_mps_present, slot_element);
     return;
   }
   setup();
+  if (ics->frame_length == 960) { /* the 960-line profile: the same descriptor with 960 / 480 */
+    hi.window_sequence = (uint8_t)ics->window_sequence;
+    hi.window_shape = (uint8_t)ics->window_shape;
+    hs.window_sequence = (uint8_t)oi->window_sequence;
+    hs.window_shape = (uint8_t)oi->window_shape;
+    HIP(hipMemcpy(g.spec, spec, 3840, hipMemcpyHostToDevice));
+    HIP(hipMemcpy(g.overlap, oi->ptr_overlap_buf, 1920, hipMemcpyHostToDevice));
+    HIP(hipMemcpy(g.ics, &hi, sizeof(hi), hipMemcpyHostToDevice));
+    HIP(hipMemcpy(g.ovl_state, &hs, sizeof(hs), hipMemcpyHostToDevice));
+    memset(&b, 0, sizeof(b));
+    b.n_ch = 1;
+    b.ch_fac = 1;
+    b.spec = g.spec;
+    b.ics = g.ics;
+    b.overlap = g.overlap;
+    b.state = g.ovl_state;
+    b.out32 = g.out32;
+    b.qshift_adj = g.qadj;
+    b.pcm_mode = XAAC_PCM_LC;
+    if (xaac_imdct960_process_batch(g_ctx, &b) != XAAC_OK || xaac_sync(g_ctx) != XAAC_OK) die("xaac_imdct960_process_batch");
+    HIP(hipMemcpy(tmp, g.out32, 3840, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(oi->ptr_overlap_buf, g.overlap, 1920, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(&hs, g.ovl_state, sizeof(hs), hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(&q, g.qadj, 1, hipMemcpyDeviceToHost));
+    for (i = 0; i < 960; i++) ((WORD32 *)out)[i * ch_fac] = tmp[i];
+    oi->window_sequence = hs.window_sequence;
+    oi->window_shape = hs.window_shape;
+    ics->qshift_adj = q;
+    g_imdct960_calls++;
+    return;
+  }
   hi.window_sequence = (uint8_t)ics->window_sequence;
   hi.window_shape = (uint8_t)ics->window_shape;
   hs.window_sequence = (uint8_t)oi->window_sequence;

@@ -66,3 +66,28 @@ def test_default_flags_he_aac_takes_the_esbr_path_on_the_gpu(aac, tmp_path):
 
 def test_streams_present():
     assert len(STREAMS) >= 3
+
+
+STREAMS_LD = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "streams_ld", "*.aac")))
+
+
+@pytest.mark.parametrize("aac", STREAMS_LD, ids=[os.path.basename(s) for s in STREAMS_LD])
+@pytest.mark.parametrize("flags", [("-esbr:0",), ()], ids=["esbr0", "default"])
+def test_other_frame_lengths_through_the_gpu(aac, flags, tmp_path):
+    """AAC-LC with 960-line frames, AAC-LD and AAC-ELD with 512- and 480-line frames (made by the reference encoder,
+    tools/make_golden_streams.py): the real reference decoder with ixheaacd_imdct_process served by
+    xaac_imdct960_process_batch / xaac_imdct_ld_process_batch writes the same bytes as the unmodified one (the ELD streams'
+    low-delay SBR stays the reference's code)."""
+    if not (os.path.exists(os.path.join(REF, "xaacdec")) and os.path.exists(os.path.join(REF, "xaacdec_dropin"))):
+        pytest.skip("oracle/_ref/xaacdec[_dropin] missing (built by oracle/Makefile.ref where /root/reference exists)")
+    meta = aac[:-4] + ".txt"
+    extra = tuple(flags) + (("-mp4:1", "-imeta:" + meta) if os.path.exists(meta) else ())
+    ref_wav, gpu_wav = str(tmp_path / "ref.wav"), str(tmp_path / "gpu.wav")
+    _decode("xaacdec", aac, ref_wav, extra=extra)
+    log = _decode("xaacdec_dropin", aac, gpu_wav, extra=extra)
+    m = re.search(r"(\d+) imdct_process calls of 960-line frames and (\d+) of AAC-LD / ELD frames ran on the GPU", log)
+    assert m, log[-600:]
+    n960, nld = int(m.group(1)), int(m.group(2))
+    assert (n960 > 100 and nld == 0) if "lc960" in aac else (nld > 100 and n960 == 0), (n960, nld)
+    a, b = open(ref_wav, "rb").read(), open(gpu_wav, "rb").read()
+    assert len(a) > 100000 and a == b, (len(a), len(b), n960, nld)

@@ -40,6 +40,20 @@ def main():
     subprocess.run([os.path.join(REF, "xaacenc"), "-ifile:" + wav, "-ofile:" + aac, "-aot:5", "-br:32000", "-adts:1"],
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
     print(aac, os.path.getsize(aac))
+    # the other frame lengths (tests/golden/streams_ld: kept apart from the 1024-line streams the batched host tests walk):
+    # AAC-LC with 960-line frames, AAC-LD and AAC-ELD with 512- and 480-line frames: raw access units behind an
+    # AudioSpecificConfig (ADTS cannot signal the frame length) + the encoder's frame-size list, which the reference's test
+    # decoder reads with -mp4:1 -imeta:
+    out_ld = os.path.join(ROOT, "tests", "golden", "streams_ld")
+    os.makedirs(out_ld, exist_ok=True)
+    wav = "/tmp/xaac_golden_mix.wav"
+    for name, args in (("lc960", ["-aot:2", "-br:64000", "-framesize:960"]), ("ld512", ["-aot:23", "-br:64000", "-framesize:512"]),
+                       ("ld480", ["-aot:23", "-br:64000", "-framesize:480"]), ("eld512", ["-aot:39", "-br:64000", "-framesize:512"]),
+                       ("eld480", ["-aot:39", "-br:64000", "-framesize:480"])):
+        aac = os.path.join(out_ld, name + ".aac")
+        subprocess.run([os.path.join(REF, "xaacenc"), "-ifile:" + wav, "-ofile:" + aac] + args, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, check=True)
+        print(aac, os.path.getsize(aac))
 
 
 if __name__ == "__main__":
