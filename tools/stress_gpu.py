@@ -20,6 +20,9 @@ import test_sbr_hq_gpu as th  # noqa: E402
 import test_esbr_sbr_gpu as te  # noqa: E402
 import test_usac_imdct as tu  # noqa: E402
 import test_esbr_qmf as tq  # noqa: E402
+import test_imdct960_gpu as t9  # noqa: E402
+import test_imdct_ld_gpu as tld  # noqa: E402
+import test_qmf_eld_gpu as teld  # noqa: E402
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 oracle = oracle_lib.load_oracle()
@@ -46,6 +49,14 @@ for r in range(1, rounds + 1):
         ("eSBR banks", lambda: tq.test_gpu_analysis_then_synthesis_vs_oracle(oracle)),
         ("USAC IMDCT batch", lambda: tu.test_gpu_large_batch_vs_oracle(oracle)),
         ("eSBR chain with harmonic SBR", lambda: te.test_chain_with_harmonic_transposer_vs_oracle(oracle)),
+        ("960-line IMDCT, every transition", lambda: t9.test_every_transition_vs_oracle(oracle, 0)),
+        ("960-line IMDCT, stereo walk", lambda: t9.test_stereo_walk_with_state_on_device(oracle)),
+        ("LD IMDCT 512", lambda: tld.test_stereo_chains_vs_oracle(oracle, 512, 0)),
+        ("ELD IMDCT 512", lambda: tld.test_stereo_chains_vs_oracle(oracle, 512, 1)),
+        ("LD IMDCT 480", lambda: tld.test_stereo_chains_vs_oracle(oracle, 480, 0)),
+        ("ELD IMDCT 480", lambda: tld.test_stereo_chains_vs_oracle(oracle, 480, 1)),
+        ("ELD analysis bank", lambda: teld.test_eld_analysis_chain_vs_oracle(oracle, 15)),
+        ("ELD synthesis bank", lambda: teld.test_eld_synthesis_chain_vs_oracle(oracle, 16)),
     ]
     for name, job in jobs:
         try:
