@@ -147,6 +147,23 @@ int ref_imdct_ld_process(WORD32 *spec, WORD32 *overlap, WORD16 *prev_shape, int 
   return ics.qshift_adj;
 }
 
+/* C loops over n channel-frames for timing the reference as the CPU baseline of the 960-line and LD / ELD rows
+ * (ONLY_LONG frames; buffers at the reference's own strides: spec 2048 words, overlap 2048 words per channel) */
+void ref_imdct960_loop(int n, WORD32 *spec, WORD32 *overlap, WORD32 *out) {
+  int c;
+  for (c = 0; c < n; c++) {
+    WORD16 ps = 0, pw = 0;
+    ref_imdct960_process(spec + 2048 * (size_t)c, overlap + 2048 * (size_t)c, &ps, &pw, 0, 0, out, 1);
+  }
+}
+void ref_imdct_ld_loop(int n, WORD32 *spec, WORD32 *overlap, int frame_length, int aot, WORD16 *out16) {
+  int c;
+  for (c = 0; c < n; c++) {
+    WORD16 pw = 0;
+    ref_imdct_ld_process(spec + 2048 * (size_t)c, overlap + 2048 * (size_t)c, &pw, 0, frame_length, aot, out16, 1);
+  }
+}
+
 /* n channel-frames in a C loop (for timing the reference as the CPU baseline):
  * per channel c: spec[c][1024] (clobbered), overlap[c][512], prev_seq/prev_shape[c],
  * seq/shape[c]; writes PCM16 at stride 1 per channel like ixheaacd_scale_adjust +

@@ -142,9 +142,47 @@ def main():
         us = timed(torch, ctx, lambda: ctx.hbe_apply_batch(qre, qim, hst, pvr, pvi, hstat))
         assert not hstat.cpu().numpy().any()
         res.append((label, us * n / nh, n * (4 * 8192 + 2 * libxaac_amd.HBE_STATE_BYTES)))
+    cpu = reference_cpu_rates()
     for name, us, bytes_ in res:
-        print(json.dumps({"kernel": name, "n_ch": n, "us": round(us, 1), "channel_frames_per_s": round(n / us * 1e6),
-                          "alg_GBps": round(bytes_ / us / 1e3, 1), "frac_of_8TBps": round(bytes_ / us / 1e3 / 8000, 4)}))
+        line = {"kernel": name, "n_ch": n, "us": round(us, 1), "channel_frames_per_s": round(n / us * 1e6),
+                "alg_GBps": round(bytes_ / us / 1e3, 1), "frac_of_8TBps": round(bytes_ / us / 1e3 / 8000, 4)}
+        if name in cpu:
+            line["cpu_reference_one_core_channel_frames_per_s"] = round(cpu[name])
+        print(json.dumps(line))
+
+
+def reference_cpu_rates(m=4000):
+    """the compiled reference's own functions (oracle/_ref/libref_harness.so, C loops in oracle/ref_harness.c) on one host
+    core over m channel-frames of the same kind of input: the CPU baseline of the 960-line and LD / ELD IMDCT rows"""
+    import ctypes
+    import time
+    so = os.path.join(ROOT, "oracle", "_ref", "libref_harness.so")
+    if not os.path.exists(so):
+        return {}
+    lib = ctypes.CDLL(so)
+    rng = np.random.default_rng(1)
+    P32, P16 = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int16)
+    out = {}
+    base = np.zeros((m, 2048), np.int32)
+    ov = np.zeros((m, 2048), np.int32)
+    o32, o16 = np.zeros(1024, np.int32), np.zeros(1024, np.int16)
+    for name, fl, call in (("imdct960_long", 960, lambda s: lib.ref_imdct960_loop(m, s.ctypes.data_as(P32), ov.ctypes.data_as(P32), o32.ctypes.data_as(P32))),
+                           ("imdct_ld_512", 512, lambda s: lib.ref_imdct_ld_loop(m, s.ctypes.data_as(P32), ov.ctypes.data_as(P32), 512, 23, o16.ctypes.data_as(P16))),
+                           ("imdct_eld_512", 512, lambda s: lib.ref_imdct_ld_loop(m, s.ctypes.data_as(P32), ov.ctypes.data_as(P32), 512, 39, o16.ctypes.data_as(P16))),
+                           ("imdct_ld_480", 480, lambda s: lib.ref_imdct_ld_loop(m, s.ctypes.data_as(P32), ov.ctypes.data_as(P32), 480, 23, o16.ctypes.data_as(P16))),
+                           ("imdct_eld_480", 480, lambda s: lib.ref_imdct_ld_loop(m, s.ctypes.data_as(P32), ov.ctypes.data_as(P32), 480, 39, o16.ctypes.data_as(P16)))):
+        if not hasattr(lib, "ref_imdct960_loop"):
+            return {}
+        best = 1e9
+        for _ in range(3):
+            spec = base.copy()
+            spec[:, :fl] = rng.integers(-2 ** 17, 2 ** 17, (m, fl))
+            ov[:] = 0
+            t0 = time.perf_counter()
+            call(spec)
+            best = min(best, time.perf_counter() - t0)
+        out[name] = m / best
+    return out
 
 
 if __name__ == "__main__":
