@@ -41,6 +41,7 @@ static struct {
   xaac_hbe_state *hbe;         /* Path A: the channel's QMF harmonic transposer */
   void *ews;
 } g;
+static long g_eld_ana_calls, g_eld_syn_calls;
 static long g_imdct_calls, g_sbr_calls, g_lim_calls, g_esbr_calls, g_esbr_harm_calls, g_imdct960_calls, g_imdct_ld_calls;
 static struct { int32_t *overlap; int16_t *pcm; uint8_t *shape; } gl; /* AAC-LD / ELD: 3 x 512 overlap words, 512 samples, 2 bytes */
 
@@ -54,6 +55,7 @@ static void report(void) {
   fprintf(stderr, "xaacdec_dropin: %ld imdct_process and %ld sbr_dec calls ran on the GPU\n", g_imdct_calls, g_sbr_calls);
   fprintf(stderr, "xaacdec_dropin: %ld imdct_process calls of 960-line frames and %ld of AAC-LD / ELD frames ran on the GPU\n",
           g_imdct960_calls, g_imdct_ld_calls);
+  fprintf(stderr, "xaacdec_dropin: %ld LD / ELD analysis-bank and %ld synthesis-bank calls ran on the GPU\n", g_eld_ana_calls, g_eld_syn_calls);
   fprintf(stderr, "xaacdec_dropin: %ld peak_limiter_process calls ran on the GPU\n", g_lim_calls);
   fprintf(stderr, "xaacdec_dropin: %ld sbr_dec calls took the eSBR (Path A) branch on the GPU\n", g_esbr_calls);
   fprintf(stderr, "xaacdec_dropin: %ld of them with harmonic patching (the QMF transposer's output)\n", g_esbr_harm_calls);
@@ -228,6 +230,184 @@ VOID __wrap_ixheaacd_imdct_process(ia_aac_dec_overlap_info *oi, WORD32 *spec, ia
   oi->window_shape = hs.window_shape;
   ics->qshift_adj = q;
   g_imdct_calls++;
+}
+
+/* ---- the LD / ELD complex QMF banks inside ixheaacd_sbr_dec (which stays the reference's for these profiles) ----------
+ * ixheaacd_cplx_anal_qmffilt (generic:590) and ixheaacd_cplx_synt_qmffilt (qmf_dec.c:811) with AOT_ER_AAC_LD / _ELD: bank
+ * state pointers <-> offsets, rows gathered to [slot][re 64 | im 64] and scattered back. */
+VOID __real_ixheaacd_cplx_anal_qmffilt(const WORD16 *, ia_sbr_scale_fact_struct *, WORD32 **, WORD32 **,
+                                       ia_sbr_qmf_filter_bank_struct *, ia_qmf_dec_tables_struct *, WORD32, WORD32, WORD);
+VOID __wrap_ixheaacd_cplx_anal_qmffilt(const WORD16 *time, ia_sbr_scale_fact_struct *sf, WORD32 **qre, WORD32 **qim,
+                                       ia_sbr_qmf_filter_bank_struct *bank, ia_qmf_dec_tables_struct *t, WORD32 ch_fac,
+                                       WORD32 low_pow_flag, WORD aot) {
+  static int16_t *d_pcm;
+  static int32_t *d_qmf, *d_status;
+  static xaac_qmf_ana_eld_state *d_st;
+  static int32_t rows[16][128];
+  static int16_t pcm[512];
+  xaac_qmf_ana_eld_state st;
+  xaac_qmf_ana_eld_batch b;
+  int32_t status;
+  const int ns = bank->num_time_slots;
+  int i, k;
+  if (getenv("XAAC_DROPIN_PASS_ELD_BANKS") || (aot != AOT_ER_AAC_ELD && aot != AOT_ER_AAC_LD) || low_pow_flag ||
+      bank->no_channels != 32 || (ns != 16 && ns != 15)) {
+    __real_ixheaacd_cplx_anal_qmffilt(time, sf, qre, qim, bank, t, ch_fac, low_pow_flag, aot);
+    return;
+  }
+  setup();
+  if (!d_pcm) {
+    HIP(hipMalloc((void **)&d_pcm, sizeof(pcm)));
+    HIP(hipMalloc((void **)&d_qmf, sizeof(rows)));
+    HIP(hipMalloc((void **)&d_st, sizeof(st)));
+    HIP(hipMalloc((void **)&d_status, 4));
+  }
+  /* what the function does to the bank and the scale factors besides the filtering (generic:609-651) */
+  bank->filter_pos += t->qmf_c_eld3 - bank->analy_win_coeff;
+  bank->analy_win_coeff = t->qmf_c_eld3;
+  sf->st_lb_scale = 0;
+  sf->lb_scale = -9;
+  bank->cos_twiddle = (WORD16 *)t->sbr_sin_cos_twiddle_l32;
+  bank->alt_sin_twiddle = (WORD16 *)t->sbr_alt_sin_twiddle_l32;
+  bank->t_cos = (WORD16 *)t->ixheaacd_sbr_t_cos_sin_l32_eld;
+  memcpy(st.ring, bank->anal_filter_states, sizeof(st.ring));
+  st.wr = (int16_t)(bank->core_samples_buffer - bank->anal_filter_states);
+  st.f1 = (int16_t)(bank->filter_pos - t->qmf_c_eld3);
+  st.f2 = (int16_t)(bank->filter_2 - t->qmf_c_eld3);
+  st.fp = (int16_t)(bank->fp1_anal - bank->anal_filter_states);
+  for (i = 0; i < 32 * ns; i++) pcm[i] = time[i * ch_fac];
+  for (i = 0; i < ns; i++)
+    for (k = 0; k < 64; k++) {
+      rows[i][k] = qre[i][k];
+      rows[i][64 + k] = qim[i][k];
+    }
+  HIP(hipMemcpy(d_pcm, pcm, 2 * 32 * ns, hipMemcpyHostToDevice));
+  HIP(hipMemcpy(d_qmf, rows, 512 * ns, hipMemcpyHostToDevice));
+  HIP(hipMemcpy(d_st, &st, sizeof(st), hipMemcpyHostToDevice));
+  memset(&b, 0, sizeof(b));
+  b.n_ch = 1;
+  b.n_slots = ns;
+  b.usb = bank->usb;
+  b.slot_stride = 128;
+  b.pcm = d_pcm;
+  b.state = d_st;
+  b.qmf = d_qmf;
+  b.status = d_status;
+  if (xaac_qmf_analysis_eld_batch(g_ctx, &b) != XAAC_OK || xaac_sync(g_ctx) != XAAC_OK) die("xaac_qmf_analysis_eld_batch");
+  HIP(hipMemcpy(&status, d_status, 4, hipMemcpyDeviceToHost));
+  if (status) die("xaac_qmf_analysis_eld_batch: bank state outside the ten phases");
+  HIP(hipMemcpy(rows, d_qmf, 512 * ns, hipMemcpyDeviceToHost));
+  HIP(hipMemcpy(&st, d_st, sizeof(st), hipMemcpyDeviceToHost));
+  for (i = 0; i < ns; i++)
+    for (k = 0; k < 64; k++) {
+      qre[i][k] = rows[i][k];
+      qim[i][k] = rows[i][64 + k];
+    }
+  memcpy(bank->anal_filter_states, st.ring, sizeof(st.ring));
+  bank->core_samples_buffer = bank->anal_filter_states + st.wr;
+  bank->filter_pos = t->qmf_c_eld3 + st.f1;
+  bank->filter_2 = t->qmf_c_eld3 + st.f2;
+  bank->fp1_anal = bank->anal_filter_states + st.fp;
+  bank->fp2_anal = bank->anal_filter_states + (32 - st.fp);
+  g_eld_ana_calls++;
+}
+
+extern VOID (*ixheaacd_adjust_scale)(WORD32 **, WORD32 **, WORD32, WORD32, WORD32, WORD32, WORD32, FLAG); /* function_selector.h:100 */
+VOID __real_ixheaacd_cplx_synt_qmffilt(WORD32 **, WORD32 **, WORD32, WORD32 **, WORD32 **, ia_sbr_scale_fact_struct *, WORD16 *,
+                                       ia_sbr_qmf_filter_bank_struct *, ia_ps_dec_struct *, FLAG, FLAG, ia_sbr_tables_struct *,
+                                       ixheaacd_misc_tables *, WORD32, FLAG, WORD32 (*)[64], WORD32);
+VOID __wrap_ixheaacd_cplx_synt_qmffilt(WORD32 **qre, WORD32 **qim, WORD32 split, WORD32 **ore, WORD32 **oim,
+                                       ia_sbr_scale_fact_struct *sf, WORD16 *time_out, ia_sbr_qmf_filter_bank_struct *bank,
+                                       ia_ps_dec_struct *ps, FLAG active, FLAG low_pow_flag, ia_sbr_tables_struct *tabs,
+                                       ixheaacd_misc_tables *misc, WORD32 ch_fac, FLAG drc_on, WORD32 drc[][64], WORD32 aot) {
+  static int32_t *d_qmf, *d_status;
+  static int16_t *d_scale, *d_pcm;
+  static xaac_qmf_syn_eld_state *d_st;
+  static int32_t rows[16][128];
+  static int16_t pcm[1024];
+  xaac_qmf_syn_eld_state st;
+  xaac_qmf_syn_eld_batch b;
+  int16_t scale[4];
+  int32_t status;
+  const int ns = bank->num_time_slots;
+  ia_qmf_dec_tables_struct *t = tabs->qmf_dec_tables_ptr;
+  int i, k;
+  if (getenv("XAAC_DROPIN_PASS_ELD_BANKS") || (aot != AOT_ER_AAC_ELD && aot != AOT_ER_AAC_LD) || low_pow_flag || active ||
+      drc_on || bank->no_channels != 64 || (ns != 16 && ns != 15)) {
+    __real_ixheaacd_cplx_synt_qmffilt(qre, qim, split, ore, oim, sf, time_out, bank, ps, active, low_pow_flag, tabs, misc, ch_fac,
+                                      drc_on, drc, aot);
+    return;
+  }
+  setup();
+  if (!d_qmf) {
+    HIP(hipMalloc((void **)&d_qmf, sizeof(rows)));
+    HIP(hipMalloc((void **)&d_scale, 8));
+    HIP(hipMalloc((void **)&d_pcm, sizeof(pcm)));
+    HIP(hipMalloc((void **)&d_st, sizeof(st)));
+    HIP(hipMalloc((void **)&d_status, 4));
+  }
+  bank->cos_twiddle = (WORD16 *)t->sbr_sin_cos_twiddle_l64; /* qmf_dec.c:862-875 */
+  bank->alt_sin_twiddle = (WORD16 *)t->sbr_alt_sin_twiddle_l64;
+  bank->filter_pos_syn += t->qmf_c_eld - bank->p_filter;
+  bank->p_filter = t->qmf_c_eld;
+  memcpy(st.ring, bank->filter_states, sizeof(st.ring));
+  st.drc_offset = (int16_t)bank->ixheaacd_drc_offset;
+  st.phase = (int16_t)(bank->filter_pos_syn - t->qmf_c_eld);
+  st.fp = (int16_t)(bank->fp1_syn - bank->filter_states);
+  st.sixty4 = (int16_t)bank->sixty4;
+  scale[0] = sf->lb_scale;
+  scale[1] = sf->ov_lb_scale;
+  scale[2] = sf->hb_scale;
+  scale[3] = sf->st_syn_scale;
+  for (i = 0; i < ns; i++)
+    for (k = 0; k < 64; k++) {
+      rows[i][k] = qre[i][k];
+      rows[i][64 + k] = qim[i][k];
+    }
+  HIP(hipMemcpy(d_qmf, rows, 512 * ns, hipMemcpyHostToDevice));
+  HIP(hipMemcpy(d_scale, scale, 8, hipMemcpyHostToDevice));
+  HIP(hipMemcpy(d_st, &st, sizeof(st), hipMemcpyHostToDevice));
+  memset(&b, 0, sizeof(b));
+  b.n_ch = 1;
+  b.n_slots = ns;
+  b.lsb = bank->lsb;
+  b.usb = bank->usb;
+  b.split = split;
+  b.slot_stride = 128;
+  b.qmf = d_qmf;
+  b.scale = d_scale;
+  b.state = d_st;
+  b.pcm = d_pcm;
+  b.status = d_status;
+  if (xaac_qmf_synthesis_eld_batch(g_ctx, &b) != XAAC_OK || xaac_sync(g_ctx) != XAAC_OK) die("xaac_qmf_synthesis_eld_batch");
+  HIP(hipMemcpy(&status, d_status, 4, hipMemcpyDeviceToHost));
+  if (status) die("xaac_qmf_synthesis_eld_batch: bank state outside the ten phases");
+  HIP(hipMemcpy(pcm, d_pcm, 2 * 64 * ns, hipMemcpyDeviceToHost));
+  HIP(hipMemcpy(&st, d_st, sizeof(st), hipMemcpyDeviceToHost));
+  for (i = 0; i < 64 * ns; i++) time_out[i * ch_fac] = pcm[i];
+  memcpy(bank->filter_states, st.ring, sizeof(st.ring));
+  bank->ixheaacd_drc_offset = st.drc_offset;
+  bank->filter_pos_syn = t->qmf_c_eld + st.phase;
+  bank->fp1_syn = bank->filter_states + st.fp;
+  bank->sixty4 = st.sixty4;
+  bank->fp2_syn = bank->fp1_syn + bank->sixty4;
+  { /* the one thing the kernel leaves to the host: the reference rescales the matrix in place (qmf_dec.c:937-953) and hands the
+       rescaled rows on (:966-976); the reference's own function does it here */
+    const int st_syn = sf->st_syn_scale, ov = st_syn - sf->ov_lb_scale - 7, lb = st_syn - sf->lb_scale - 7, hb = st_syn - sf->hb_scale - 7;
+    if (ov == lb) {
+      (*ixheaacd_adjust_scale)(qre, qim, 0, bank->lsb, 0, ns, ov, 0);
+    } else {
+      (*ixheaacd_adjust_scale)(qre, qim, 0, bank->lsb, 0, split, ov, 0);
+      (*ixheaacd_adjust_scale)(qre, qim, 0, bank->lsb, split, ns, lb, 0);
+    }
+    (*ixheaacd_adjust_scale)(qre, qim, bank->lsb, bank->usb, 0, ns, hb, 0);
+    for (i = 0; i < ns; i++)
+      for (k = 0; k < 64; k++) {
+        ore[i][k] = qre[i][k];
+        oim[i][k] = qim[i][k];
+      }
+  }
+  g_eld_syn_calls++;
 }
 
 /* ---- seam 2: ixheaacd_sbr_dec (fixed-point Path B: low-power, HQ, HQ + parametric stereo) ------------ */
