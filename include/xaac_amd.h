@@ -170,6 +170,9 @@ typedef struct xaac_qmf_syn_eld_batch {
   xaac_qmf_syn_eld_state *state; /* [n_ch] in/out */
   int16_t *pcm;              /* [n_ch][64 * n_slots] planar */
   int32_t *status;           /* [n_ch] or NULL: -1 for a state outside the bank's ten phases (left alone) */
+  int32_t *qmf_scaled;       /* optional [n_ch][n_slots][slot_stride], words 0..127 of a slot: the region-rescaled matrix, which the
+                                reference makes in place of its input and hands on through qmf_real_out / qmf_imag_out
+                                (qmf_dec.c:937-976; its input rows are work space afterwards) */
 } xaac_qmf_syn_eld_batch;
 
 typedef struct xaac_qmf_syn_state {

@@ -110,7 +110,7 @@ class _QmfSynEldBatch(ctypes.Structure):
     # struct xaac_qmf_syn_eld_batch
     _fields_ = [("n_ch", ctypes.c_int32), ("n_slots", ctypes.c_int32), ("lsb", ctypes.c_int32), ("usb", ctypes.c_int32),
                 ("split", ctypes.c_int32), ("slot_stride", ctypes.c_int32), ("qmf", ctypes.c_void_p), ("scale", ctypes.c_void_p),
-                ("state", ctypes.c_void_p), ("pcm", ctypes.c_void_p), ("status", ctypes.c_void_p)]
+                ("state", ctypes.c_void_p), ("pcm", ctypes.c_void_p), ("status", ctypes.c_void_p), ("qmf_scaled", ctypes.c_void_p)]
 
 
 QMF_SYN_ELD_STATE_WORDS = 1284   # struct xaac_qmf_syn_eld_state: ring[1280], drc_offset, phase, fp, sixty4 (int16)
@@ -610,7 +610,7 @@ class XaacContext:
         if rc != 0:
             raise XaacError(rc, "xaac_qmf_analysis_eld_batch")
 
-    def qmf_synthesis_eld_batch(self, qmf, scale, state, pcm, n_slots, lsb, usb, split, status=None):
+    def qmf_synthesis_eld_batch(self, qmf, scale, state, pcm, n_slots, lsb, usb, split, status=None, qmf_scaled=None):
         """Batched LD / ELD complex synthesis bank: qmf int32[n_ch, n_slots, slot_stride >= 128]; scale int16[n_ch, 4] (lb,
         ov_lb, hb, st_syn); state int16[n_ch, 1284] in/out (ring, drc_offset, phase, fp, sixty4; a new stream: zeros with
         sixty4 = 64); pcm int16[n_ch, 64 * n_slots]."""
@@ -622,6 +622,7 @@ class XaacContext:
         b.state = _ptr(state, "int16", n_ch * QMF_SYN_ELD_STATE_WORDS, device_ok=True)
         b.pcm = _ptr(pcm, "int16", n_ch * 64 * n_slots, device_ok=True)
         b.status = _ptr(status, "int32", n_ch, device_ok=True) if status is not None else None
+        b.qmf_scaled = _ptr(qmf_scaled, "int32", n_ch * n_slots * b.slot_stride, allow_none=True, device_ok=True)
         rc = self._lib.xaac_qmf_synthesis_eld_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_qmf_synthesis_eld_batch")

@@ -672,6 +672,11 @@ __global__ __launch_bounds__(64) void xaac_qmf_synthesis_eld_kernel(xaac_qmf_syn
         else if (band < p.usb) val = adj_scale(val, hb_shift);
         x[k] = val;
       }
+      if (p.qmf_scaled) {
+        int32_t *srow = p.qmf_scaled + ((size_t)ch * ns + s) * p.slot_stride;
+#pragma unroll
+        for (int k = 0; k < 128; k++) srow[k] = x[k];
+      }
       xq_synth_eld_slot(x, t, b, -(st_syn - 3));
       int16_t *dst = v + (c * VS + 9 + s) * VR;
 #pragma unroll

@@ -154,6 +154,22 @@ static inline int32_t adj(int32_t v, int shift) {
    no PS, no DRC), literally.  ring: filter_states[1280]; state4 = {ixheaacd_drc_offset, filter_pos_syn - qmf_c_eld,
    fp1_syn - filter_states (0 or 64), sixty4 (64 or -64)}; a new stream: {0, 0, 0, 64}.  qmf rows are not modified.
    sf = {lb_scale, ov_lb_scale, hb_scale, st_syn_scale}.  pcm: 64 * n_slots samples at `stride`. */
+/* the region rescale alone (qmf_dec.c:925-953 with the LD / ELD shifts): what the reference leaves in place of its input */
+void xo_qmf_eld_region_scale(const int32_t *qmf, int slot_stride, const int16_t *sf, int lsb, int usb, int split, int n_slots,
+                             int32_t *out) {
+  const int st_syn = sf[3], ov_lb_shift = (st_syn - sf[1]) - 7, lb_shift = (st_syn - sf[0]) - 7, hb_shift = (st_syn - sf[2]) - 7;
+  for (int s = 0; s < n_slots; s++)
+    for (int p = 0; p < 2; p++)
+      for (int k = 0; k < 64; k++) {
+        int32_t v = qmf[(size_t)s * slot_stride + 64 * p + k];
+        if (k < lsb)
+          v = adj(v, s < split ? ov_lb_shift : lb_shift);
+        else if (k < usb)
+          v = adj(v, hb_shift);
+        out[(size_t)s * slot_stride + 64 * p + k] = v;
+      }
+}
+
 void xo_qmf_synthesis_eld(const int32_t *qmf, int slot_stride, const int16_t *sf, int lsb, int usb, int split, int16_t *ring,
                           int16_t *state4, int n_slots, int16_t *pcm, int stride) {
   const int lb_scale = sf[0], ov_lb_scale = sf[1], hb_scale = sf[2], st_syn = sf[3];

@@ -312,7 +312,6 @@ VOID __wrap_ixheaacd_cplx_anal_qmffilt(const WORD16 *time, ia_sbr_scale_fact_str
   g_eld_ana_calls++;
 }
 
-extern VOID (*ixheaacd_adjust_scale)(WORD32 **, WORD32 **, WORD32, WORD32, WORD32, WORD32, WORD32, FLAG); /* function_selector.h:100 */
 VOID __real_ixheaacd_cplx_synt_qmffilt(WORD32 **, WORD32 **, WORD32, WORD32 **, WORD32 **, ia_sbr_scale_fact_struct *, WORD16 *,
                                        ia_sbr_qmf_filter_bank_struct *, ia_ps_dec_struct *, FLAG, FLAG, ia_sbr_tables_struct *,
                                        ixheaacd_misc_tables *, WORD32, FLAG, WORD32 (*)[64], WORD32);
@@ -320,7 +319,7 @@ VOID __wrap_ixheaacd_cplx_synt_qmffilt(WORD32 **qre, WORD32 **qim, WORD32 split,
                                        ia_sbr_scale_fact_struct *sf, WORD16 *time_out, ia_sbr_qmf_filter_bank_struct *bank,
                                        ia_ps_dec_struct *ps, FLAG active, FLAG low_pow_flag, ia_sbr_tables_struct *tabs,
                                        ixheaacd_misc_tables *misc, WORD32 ch_fac, FLAG drc_on, WORD32 drc[][64], WORD32 aot) {
-  static int32_t *d_qmf, *d_status;
+  static int32_t *d_qmf, *d_status, *d_scaled;
   static int16_t *d_scale, *d_pcm;
   static xaac_qmf_syn_eld_state *d_st;
   static int32_t rows[16][128];
@@ -341,6 +340,7 @@ VOID __wrap_ixheaacd_cplx_synt_qmffilt(WORD32 **qre, WORD32 **qim, WORD32 split,
   setup();
   if (!d_qmf) {
     HIP(hipMalloc((void **)&d_qmf, sizeof(rows)));
+    HIP(hipMalloc((void **)&d_scaled, sizeof(rows)));
     HIP(hipMalloc((void **)&d_scale, 8));
     HIP(hipMalloc((void **)&d_pcm, sizeof(pcm)));
     HIP(hipMalloc((void **)&d_st, sizeof(st)));
@@ -379,6 +379,7 @@ VOID __wrap_ixheaacd_cplx_synt_qmffilt(WORD32 **qre, WORD32 **qim, WORD32 split,
   b.state = d_st;
   b.pcm = d_pcm;
   b.status = d_status;
+  b.qmf_scaled = d_scaled;
   if (xaac_qmf_synthesis_eld_batch(g_ctx, &b) != XAAC_OK || xaac_sync(g_ctx) != XAAC_OK) die("xaac_qmf_synthesis_eld_batch");
   HIP(hipMemcpy(&status, d_status, 4, hipMemcpyDeviceToHost));
   if (status) die("xaac_qmf_synthesis_eld_batch: bank state outside the ten phases");
@@ -391,22 +392,14 @@ VOID __wrap_ixheaacd_cplx_synt_qmffilt(WORD32 **qre, WORD32 **qim, WORD32 split,
   bank->fp1_syn = bank->filter_states + st.fp;
   bank->sixty4 = st.sixty4;
   bank->fp2_syn = bank->fp1_syn + bank->sixty4;
-  { /* the one thing the kernel leaves to the host: the reference rescales the matrix in place (qmf_dec.c:937-953) and hands the
-       rescaled rows on (:966-976); the reference's own function does it here */
-    const int st_syn = sf->st_syn_scale, ov = st_syn - sf->ov_lb_scale - 7, lb = st_syn - sf->lb_scale - 7, hb = st_syn - sf->hb_scale - 7;
-    if (ov == lb) {
-      (*ixheaacd_adjust_scale)(qre, qim, 0, bank->lsb, 0, ns, ov, 0);
-    } else {
-      (*ixheaacd_adjust_scale)(qre, qim, 0, bank->lsb, 0, split, ov, 0);
-      (*ixheaacd_adjust_scale)(qre, qim, 0, bank->lsb, split, ns, lb, 0);
+  /* the reference rescales the matrix in place (qmf_dec.c:937-953), hands the rescaled rows on (:966-976) and then uses its input
+     rows as work space: the kernel's optional qmf_scaled output serves both */
+  HIP(hipMemcpy(rows, d_scaled, 512 * ns, hipMemcpyDeviceToHost));
+  for (i = 0; i < ns; i++)
+    for (k = 0; k < 64; k++) {
+      qre[i][k] = ore[i][k] = rows[i][k];
+      qim[i][k] = oim[i][k] = rows[i][64 + k];
     }
-    (*ixheaacd_adjust_scale)(qre, qim, bank->lsb, bank->usb, 0, ns, hb, 0);
-    for (i = 0; i < ns; i++)
-      for (k = 0; k < 64; k++) {
-        ore[i][k] = qre[i][k];
-        oim[i][k] = qim[i][k];
-      }
-  }
   g_eld_syn_calls++;
 }
 

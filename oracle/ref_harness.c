@@ -362,13 +362,24 @@ void ref_qmf_synthesis(WORD32 *qmf, int slot_stride, const WORD16 *sfv, int lsb,
 
 /* the LD / ELD flavour (AOT_ER_AAC_ELD): state4 = {ixheaacd_drc_offset, filter_pos_syn - qmf_c_eld, fp1_syn - ring, sixty4};
    a new stream: {0, 0, 0, 64} (sbrdec_initfuncs.c:1181-1209).  qmf is scaled and transformed in place by the reference. */
+/* the rows the LD / ELD synthesis bank hands on through qmf_real_out / qmf_imag_out (qmf_dec.c:966-976): the region-rescaled
+   matrix (its in-place input rows are work space after the call) */
+static __thread WORD32 eld_out_re[32][64], eld_out_im[32][64];
+void ref_qmf_synthesis_eld_handed_on(WORD32 *dst, int n_slots, int slot_stride) {
+  int s, k;
+  for (s = 0; s < n_slots; s++)
+    for (k = 0; k < 64; k++) {
+      dst[(size_t)s * slot_stride + k] = eld_out_re[s][k];
+      dst[(size_t)s * slot_stride + 64 + k] = eld_out_im[s][k];
+    }
+}
+
 void ref_qmf_synthesis_eld(WORD32 *qmf, int slot_stride, const WORD16 *sfv, int lsb, int usb, int split, WORD16 *ring,
                            WORD16 *state4, int n_slots, WORD16 *pcm, int stride) {
   ia_qmf_dec_tables_struct *t = ref_qmf_tabs();
   ia_sbr_tables_struct tabs;
   ia_sbr_qmf_filter_bank_struct bank;
   ia_sbr_scale_fact_struct sf;
-  static __thread WORD32 copy_re[32][64], copy_im[32][64];
   WORD32 *re[MAX_ENV_COLS], *im[MAX_ENV_COLS], *ore[MAX_ENV_COLS], *oim[MAX_ENV_COLS];
   int s;
   memset(&bank, 0, sizeof(bank));
@@ -393,8 +404,8 @@ void ref_qmf_synthesis_eld(WORD32 *qmf, int slot_stride, const WORD16 *sfv, int 
   for (s = 0; s < 32; s++) {
     re[s] = qmf + (size_t)s * slot_stride;
     im[s] = re[s] + 64;
-    ore[s] = copy_re[s];
-    oim[s] = copy_im[s];
+    ore[s] = eld_out_re[s];
+    oim[s] = eld_out_im[s];
   }
   ixheaacd_cplx_synt_qmffilt(re, im, split, ore, oim, &sf, pcm, &bank, NULL, 0, 0, &tabs, NULL, stride, 0, NULL,
                              AOT_ER_AAC_ELD);

@@ -96,8 +96,19 @@ def test_eld_synthesis_chain_vs_oracle(oracle, n_slots):
         split = int(rng.integers(0, n_slots + 1))
         pcm = torch.full((n, 64 * n_slots), 5, dtype=torch.int16, device=dev)
         qd = torch.from_numpy(q).to(dev)
-        ctx.qmf_synthesis_eld_batch(qd, torch.from_numpy(sf).to(dev), state, pcm, n_slots, lsb, usb, split, status)
+        scaled = torch.full((n, n_slots, 128), 9, dtype=torch.int32, device=dev)
+        ctx.qmf_synthesis_eld_batch(qd, torch.from_numpy(sf).to(dev), state, pcm, n_slots, lsb, usb, split, status, scaled)
         ctx.sync()
+        rs = oracle.lib.xo_qmf_eld_region_scale
+        rs.restype = None
+        rs.argtypes = [P32, ctypes.c_int, P16, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, P32]
+        gsc = scaled.cpu().numpy()
+        for ch in range(n - 1):
+            want_sc = np.zeros((n_slots, 128), np.int32)
+            rs(np.ascontiguousarray(q[ch]).ctypes.data_as(P32), 128, np.ascontiguousarray(sf[ch]).ctypes.data_as(P16), lsb, usb, split, n_slots,
+               want_sc.ctypes.data_as(P32))
+            assert np.array_equal(gsc[ch], want_sc), (frame, ch)
+        assert np.all(gsc[n - 1] == 9)
         assert np.array_equal(qd.cpu().numpy(), q)
         got, gs = pcm.cpu().numpy(), state.cpu().numpy()
         assert status.cpu().tolist() == [0] * (n - 1) + [-1]

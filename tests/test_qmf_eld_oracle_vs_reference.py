@@ -64,9 +64,24 @@ def test_eld_synthesis_chain(oracle, reference, n_slots):
         usb = int(rng.integers(lsb, 65))
         split = int(rng.integers(0, n_slots + 1))
         pr, po = np.zeros(64 * n_slots, np.int16), np.zeros(64 * n_slots, np.int16)
+        left = {}
         for fn, ring, st, pcm in ((rf, ring_r, st_r, pr), (of, ring_o, st_o, po)):
             qq = q.copy()
             fn(qq.ctypes.data_as(P32), 128, sf.ctypes.data_as(P16), lsb, usb, split, ring.ctypes.data_as(P16), st.ctypes.data_as(P16),
                n_slots, pcm.ctypes.data_as(P16), 1)
+            left[fn is rf] = qq
+        # the reference rescales its input in place, hands the rescaled rows on through qmf_real_out / qmf_imag_out and then uses
+        # the input rows as work space; the restatement's region scale alone reproduces what is handed on
+        handed = np.zeros_like(q)
+        ho = reference.lib.ref_qmf_synthesis_eld_handed_on
+        ho.restype = None
+        ho.argtypes = [P32, ctypes.c_int, ctypes.c_int]
+        ho(handed.ctypes.data_as(P32), n_slots, 128)
+        scaled = np.zeros_like(q)
+        rs = oracle.lib.xo_qmf_eld_region_scale
+        rs.restype = None
+        rs.argtypes = [P32, ctypes.c_int, P16, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, P32]
+        rs(q.ctypes.data_as(P32), 128, sf.ctypes.data_as(P16), lsb, usb, split, n_slots, scaled.ctypes.data_as(P32))
+        assert np.array_equal(handed, scaled) and np.array_equal(left[False], q), frame
         assert np.array_equal(pr, po), (frame, np.nonzero(pr != po)[0][:5])
         assert np.array_equal(ring_r, ring_o) and np.array_equal(st_r, st_o), (frame, st_r, st_o)
