@@ -424,13 +424,18 @@ FX_HD int x9_qshift_adj(int seq, bool prev_short_edge) {
 /* The frame: spec[960] -> samples through sk, new overlap into ovl_new[480] (may be the place ov_old was loaded from: ov_old
    is a private copy).  y, a: 960 words of work space each.  headroom = norm32 over the frame's lines (aac_tns.c:422). */
 FX_HD void x9_imdct_process(const int32_t *spec, const int32_t *ov_old, int32_t *ovl_new, int32_t *y, int32_t *a, int headroom,
-                            int seq, int shape, int pseq, int pshape, const X9Sink &sk, int lane, int nl) {
+                            int seq, int shape, int pseq, int pshape, const X9Sink &sk, int lane, int nl, bool ov_into_a = false) {
   constexpr int u = X9_U;
   const bool prev_short_edge = pseq == X9_LONG_START || pseq == X9_EIGHT_SHORT;
   const int16_t *wl = x9_long_win(pshape), *ws = x9_short_win(pshape);
   const int e = headroom - 1;
   if (seq != X9_EIGHT_SHORT) {
     const int q = x9_long_transform(spec, y, a, e, lane, nl);
+    if (ov_into_a) { /* the work array is free now: the old overlap moves there before the new one overwrites its source */
+      X9_FOR(i, 8 * u) a[i] = ov_old[i];
+      x9_sync();
+      ov_old = a;
+    }
     if (seq == X9_ONLY_LONG) {
       if (!prev_short_edge) {
         x9_ola1(y, ov_old, sk, 0, wl, q, 8 * u, lane, nl); /* lpfuncs.c:444-452 */
@@ -459,6 +464,11 @@ FX_HD void x9_imdct_process(const int32_t *spec, const int32_t *ov_old, int32_t 
   } else {
     const int16_t *wsc = x9_short_win(shape);
     const int q = x9_short_transform(spec, y, a, e, lane, nl);
+    if (ov_into_a) {
+      X9_FOR(i, 8 * u) a[i] = ov_old[i];
+      x9_sync();
+      ov_old = a;
+    }
     if (prev_short_edge) {
       X9_FOR(i, 7 * u) sk.put(i, fx_shl_sat((int32_t)(int16_t)ov_old[i], 15)); /* lpfuncs.c:325 */
       x9_ola1(y, ov_old + 7 * u, sk, 7 * u, ws, q, u, lane, nl);

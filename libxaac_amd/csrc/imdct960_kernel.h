@@ -8,7 +8,7 @@
 #include "../../include/xaac_amd.h"
 
 #define XAAC_I960_WAVES_PER_WG 4
-#define XAAC_I960_LDS (XAAC_I960_WAVES_PER_WG * (960 + 960 + 480) * 4)
+#define XAAC_I960_LDS (XAAC_I960_WAVES_PER_WG * (960 + 960) * 4)
 
 #ifdef __cplusplus
 extern "C" {

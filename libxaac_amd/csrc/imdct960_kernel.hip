@@ -4,8 +4,8 @@
  *
  * Mapping: one wave = one channel-frame, four per workgroup (they share nothing, so only wave-level barriers).  The 960
  * lines and the 480 old overlap words are read once, coalesced, into LDS (the block exponent is an OR over the wave on
- * the way); every stage of imdct960.h then spreads its independent items over the 64 lanes between two 3.75 KB LDS
- * arrays: pre twiddle in the prime-factor input order, 15 x 32-point (three passes of 120 items), 32 x 15-point as
+ * the way, the old overlap moves into the free work array after the transform); every stage of imdct960.h then spreads its
+ * independent items over the 64 lanes between two 3.75 KB LDS arrays: pre twiddle in the prime-factor input order, 15 x 32-point (three passes of 120 items), 32 x 15-point as
  * 96 five-point + 160 three-point items, post twiddle with the 17476 scale, windowing / overlap-add straight to global
  * memory.  HBM traffic = 3.75 KB lines + 1.9 KB overlap in, 3.75 KB samples + 1.9 KB overlap out per channel-frame.
  */
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64 * XAAC_I960_WAVES_PER_WG) void xaac_imdct960_ker
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nl = 64;
   const int ch = blockIdx.x * XAAC_I960_WAVES_PER_WG + wave;
   if (ch >= p.n_ch) return;
-  int32_t *y = smem + wave * (960 + 960 + 480), *a = y + 960, *old = a + 960;
+  int32_t *y = smem + wave * (960 + 960), *a = y + 960;
   const int seq = p.ics[ch].window_sequence, shape = p.ics[ch].window_shape;
   const int pseq = p.state[ch].window_sequence, pshape = p.state[ch].window_shape;
   if (seq > 3 || shape > 1 || pseq > 3 || pshape > 1) { /* values the bitstream fields cannot carry: left untouched */
@@ -43,7 +43,6 @@ __global__ __launch_bounds__(64 * XAAC_I960_WAVES_PER_WG) void xaac_imdct960_ker
     a[i] = v;
     acc |= fx_abs_nrm(v);
   }
-  X9_FOR(i, 480) old[i] = gov[i];
   const int headroom = fx_norm32(wave_or(acc));
   x9_sync();
   const bool edge = pseq == X9_LONG_START || pseq == X9_EIGHT_SHORT;
@@ -51,7 +50,7 @@ __global__ __launch_bounds__(64 * XAAC_I960_WAVES_PER_WG) void xaac_imdct960_ker
   const X9Sink sk = {p.out32 ? p.out32 + unit : nullptr, p.pcm16 ? p.pcm16 + unit : nullptr, p.ch_fac, x9_qshift_adj(seq, edge),
                      p.pcm_mode};
   /* the lines sit in the work array: the pre twiddle is their only reader and ends before anything is written there */
-  x9_imdct_process(a, old, gov, y, a, headroom, seq, shape, pseq, pshape, sk, lane, nl);
+  x9_imdct_process(a, gov, gov, y, a, headroom, seq, shape, pseq, pshape, sk, lane, nl, true);
   if (lane == 0) {
     p.state[ch].window_sequence = (uint8_t)seq; /* lpfuncs.c:800-801 */
     p.state[ch].window_shape = (uint8_t)shape;

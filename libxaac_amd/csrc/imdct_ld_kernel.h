@@ -8,8 +8,9 @@
 #include "../../include/xaac_amd.h"
 
 #define XAAC_LD_WAVES_PER_WG 4
-/* per wave: the transform's two arrays (1024 + 512 words) and the old overlap (ELD: 3 x frame_length, LD: frame_length / 2) */
-#define XAAC_LD_LDS(frame_length, eld) (XAAC_LD_WAVES_PER_WG * (1024 + 512 + ((eld) ? 3 * (frame_length) : (frame_length) / 2)) * 4)
+/* per wave: the transform's two arrays (1024 + 512 words); LD's frame_length / 2 old overlap words move into the second one
+   once the transform is done, ELD's 3 x frame_length are read where they lie */
+#define XAAC_LD_LDS(frame_length, eld) (XAAC_LD_WAVES_PER_WG * (1024 + 512) * 4)
 
 #ifdef __cplusplus
 extern "C" {

@@ -25,11 +25,11 @@ __device__ __forceinline__ int32_t wave_or(int32_t v) {
 template <int F, bool ELD>
 __global__ __launch_bounds__(64 * XAAC_LD_WAVES_PER_WG) void xaac_imdct_ld_kernel(xaac_imdct_ld_batch p) {
   extern __shared__ __attribute__((aligned(16))) int32_t smem[];
-  constexpr int NOV = ELD ? 3 * F : F / 2, PER_WAVE = 1024 + 512 + NOV;
+  constexpr int NOV = ELD ? 3 * F : F / 2, PER_WAVE = 1024 + 512;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nl = 64;
   const int ch = blockIdx.x * XAAC_LD_WAVES_PER_WG + wave;
   if (ch >= p.n_ch) return;
-  int32_t *a = smem + wave * PER_WAVE, *b = a + 1024, *old = b + 512;
+  int32_t *a = smem + wave * PER_WAVE, *b = a + 1024;
   const int shape = p.window_shape[ch], shape_prev = p.shape_prev[ch];
   if (shape > 1 || shape_prev > 1) { /* values the one-bit field cannot carry: left untouched */
     if (lane == 0 && p.status) p.status[ch] = XAAC_FATAL_BAD_WINDOW_SEQ;
@@ -43,15 +43,19 @@ __global__ __launch_bounds__(64 * XAAC_LD_WAVES_PER_WG) void xaac_imdct_ld_kerne
     a[512 + i] = v;
     acc |= fx_abs_nrm(v);
   }
-  X9_FOR(i, NOV) old[i] = gov[i];
   const int e = fx_norm32(wave_or(acc)) - 1;
   x9_sync();
   const int q = xl_transform<F, ELD>(a + 512, a, b, e, lane, nl);
   int16_t *pcm = p.pcm16 + (size_t)(ch / p.ch_fac) * F * p.ch_fac + ch % p.ch_fac;
-  if (ELD)
-    xl_eld_overlap_add<F>(a, old, gov, pcm, p.ch_fac, q, lane, nl);
-  else
-    xl_ld_overlap_add<F>(a, old, gov, pcm, p.ch_fac, q, shape_prev, lane, nl);
+  if (ELD) {
+    /* the 3 F old overlap words are read where they lie: output n reads word n, new word k reads word F + k, which is only
+       overwritten F / 64 iterations later (program order within the wave: each iteration's store consumes its own load) */
+    xl_eld_overlap_add<F>(a, gov, gov, pcm, p.ch_fac, q, lane, nl);
+  } else { /* LD: the F / 2 old overlap words move into the free work array before the new ones overwrite their source */
+    X9_FOR(i, NOV) b[i] = gov[i];
+    x9_sync();
+    xl_ld_overlap_add<F>(a, b, gov, pcm, p.ch_fac, q, shape_prev, lane, nl);
+  }
   if (lane == 0) {
     p.shape_prev[ch] = (uint8_t)shape; /* lpfuncs.c:800 */
     if (p.status) p.status[ch] = XAAC_OK;
