@@ -18,7 +18,7 @@ A "step" = one pass of the hot path over one batch.  Inputs are resident in HBM 
 step / mean step duration from HIP events recorded on the launch stream.  Every run checks itself
 (outside the timed region): the status words of the last step must all be zero, and one more step of a
 256-stream slice is decoded by the oracle chain on the host from the same device state and compared word for
-word (`bit_exact_vs_oracle`).  `secondary` (N=1 only) = short runs of C2 (AAC-LC IMDCT, BASELINE configs[1]), C4A (the
+word (`bit_exact_vs_oracle`).  `secondary` (N=1 only; `f4_transforms` = the USAC / 960-line / LD / ELD IMDCT kernels) = short runs of C2 (AAC-LC IMDCT, BASELINE configs[1]), C4A (the
 same HE-AACv2 streams through the reference's default float eSBR path) and
 C3 (HE-AACv1, configs[2]) in the same process.  `cpu_baseline` = the same workload on the host cores (the
 compiled reference when oracle/_ref travelled with the repo, else the bit-exact restatement), bounded sample,
@@ -175,6 +175,53 @@ def make_inputs_c4(torch, device, sets, seed):
                         "hdr": hdr, "frames": frames, "sbr_state": st0.clone(), "ps_state": ps0.clone(),
                         "pcm": torch.zeros(n * 4096, dtype=torch.int16, device=device)})
     return batches
+
+
+def secondary_f4(torch, libxaac_amd, ctx, dev, n=16384, launches=20):
+    """SURVEY.md row f4's transforms outside the C4 chain -- USAC FD, 960-line, AAC-LD and AAC-ELD IMDCT -- on resident synthetic
+    batches of n channel-frames: microseconds per launch (wall clock around `launches` back-to-back launches on the
+    library's stream) and the fraction of the HBM roof their algorithmic bytes reach.  Parity: tests/test_usac_imdct.py,
+    tests/test_imdct960_gpu.py, tests/test_imdct_ld_gpu.py."""
+    import numpy as np
+    rng = np.random.default_rng(4)
+    out = {}
+
+    def timed(name, fn, alg_bytes):
+        for _ in range(3):
+            fn()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(launches):
+            fn()
+        ctx.sync()
+        us = (time.perf_counter() - t0) / launches * 1e6
+        out[name] = {"us_per_launch": round(us, 1), "channel_frames_per_s": round(n / us * 1e6),
+                     "roofline_frac": round(alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    spec = torch.from_numpy(rng.integers(-2 ** 17, 2 ** 17, (n, 1024)).astype(np.int32)).to(dev)
+    z8 = lambda *shape: torch.zeros(shape, dtype=torch.uint8, device=dev)
+    ov = torch.zeros((n, 1024), dtype=torch.int32, device=dev)
+    o32 = torch.zeros((n, 1024), dtype=torch.int32, device=dev)
+    ics_u = torch.tensor([[0, 1]] * n, dtype=torch.uint8, device=dev)
+    sp_u = z8(n)
+    timed("usac_fd_1024", lambda: ctx.usac_imdct_process_batch(spec, ics_u, ov, sp_u, o32), n * 16384)
+    spec9 = spec[:, :960].contiguous()
+    ov9 = torch.zeros((n, 480), dtype=torch.int32, device=dev)
+    out9 = torch.zeros(n * 960, dtype=torch.int32, device=dev)
+    ics9, st9 = z8(n, 2), z8(n, 2)
+    timed("aac_960", lambda: ctx.imdct960_process_batch(spec9, ics9, ov9, st9, out9), n * 11520)
+    for fl in (512, 480):
+        for eld in (0, 1):
+            nov = 3 * fl if eld else fl // 2
+            sl = spec[:, :fl].contiguous()
+            ol = torch.zeros((n, nov), dtype=torch.int32, device=dev)
+            shp, spv = z8(n), z8(n)
+            pcm = torch.zeros(n * fl, dtype=torch.int16, device=dev)
+            timed("%s_%d" % ("aac_eld" if eld else "aac_ld", fl),
+                  lambda sl=sl, ol=ol, shp=shp, spv=spv, pcm=pcm, fl=fl, eld=eld: ctx.imdct_ld_process_batch(sl, shp, ol, spv, pcm, fl, eld),
+                  n * (4 * fl + 2 * fl + (4 * nov + 11 * fl if eld else 8 * nov)))
+    out["n_channel_frames"] = n
+    return out
 
 
 def secondary_esbr(torch, libxaac_amd, ctx, dev, steps, warmup):
@@ -698,6 +745,11 @@ def main():
             secondary["c4_esbr"] = secondary_esbr(torch, libxaac_amd, ctx, dev, max(10, args.steps // 5), 2)
         except Exception as e:  # never lose the headline line over the extra entry
             secondary["c4_esbr"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+        try:
+            secondary["f4_transforms"] = secondary_f4(torch, libxaac_amd, ctx, dev)
+        except Exception as e:
+            secondary["f4_transforms"] = {"error": repr(e)}
         torch.cuda.empty_cache()
 
     if rank == 0:
