@@ -168,16 +168,21 @@ FX_HD int xl_transform(const int32_t *spec, int32_t *a, int32_t *b, int e, int l
     x9_sync();
     X9_FOR(t, 64) xl_fft_bfly(b, 16 * (t >> 2) + (t & 3), 4, xaac_ld_w_256 + 480 + 6 * (t & 3));
     x9_sync();
-    X9_FOR(t, 64) xl_fft_last<256>(b, a, t);
-    x9_sync();
-    /* a holds the 256 transform outputs and is where the post twiddle writes its F (LD) or 2 F (ELD) words: through b */
-    X9_FOR(j, 256) {
-      const X9Cx x = x9_ld(a, j);
-      b[2 * j] = x.r;
-      b[2 * j + 1] = x.i;
+    if (!ELD) { /* LD writes F words: the transform's outputs go to the upper half of a, the post twiddle fills the lower */
+      X9_FOR(t, 64) xl_fft_last<256>(b, a + 512, t);
+      x9_sync();
+      X9_FOR(j, 256) xl_post_twiddle<512, ELD>(x9_ld(a + 512, j), j, a);
+    } else { /* ELD writes all 2 F words of a: the 256 transform outputs pass through b */
+      X9_FOR(t, 64) xl_fft_last<256>(b, a, t);
+      x9_sync();
+      X9_FOR(j, 256) {
+        const X9Cx x = x9_ld(a, j);
+        b[2 * j] = x.r;
+        b[2 * j + 1] = x.i;
+      }
+      x9_sync();
+      X9_FOR(j, 256) xl_post_twiddle<512, ELD>(x9_ld(b, j), j, a);
     }
-    x9_sync();
-    X9_FOR(j, 256) xl_post_twiddle<512, ELD>(x9_ld(b, j), j, a);
     x9_sync();
     return 15 - e;
   } else {
