@@ -366,164 +366,200 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
 }
 
 /* ===================================================================================== */
-/* HE-AACv2: the left and the right complex synthesis bank of one stream in one wave (xaac_qmf_synthesis_kernel<false,
-   false> twice, with three changes of arrangement, none of arithmetic):
-   - the slot transform's two halves (sbr_qmf.h: xq_cos_sin_mod_half) run one after the other -- real parts of the 64
-     rows through the LDS tile, transform, imaginary parts through the same tile, transform, combine -- so the tile is
-     64 x 65 words instead of 64 x 129 and fits inside the ring-sample store: 21 KB of LDS per wave instead of 33, seven
-     waves per CU instead of four;
-   - the window-add works on sample pairs (one ds_read_b32 per tap and channel instead of two ds_read_u16), two slots
-     per wave pass, and since both channels of the stream are at hand the output leaves as interleaved L,R words: 8
-     contiguous bytes per lane, 512 per store instruction, instead of two launches' 2-byte stores at stride 4;
-   - ring history and ring state move as dwords (a slot's 128 ring samples are 128-sample aligned in the ring). */
-__global__ __launch_bounds__(64, 2) void xaac_qmf_synthesis_pair_kernel(XaacQmfSynPairParams p) {
+/* HE-AACv2: the left and the right complex synthesis bank of one stream in one 128-thread workgroup
+   (xaac_qmf_synthesis_kernel<false, false> twice; the arithmetic is sbr_qmf.h's, only the arrangement differs):
+   - the slot transform's two independent halves (sbr_qmf.h: xq_cos_sin_mod_half) run on the workgroup's two waves:
+     wave h takes words 64 h .. 64 h + 63 of all 64 rows (2 channels x 32 slots, lane = (channel, slot)) through its own
+     64 x 65-word LDS tile and transforms them with H = h.  A wave's code is uniform, a lane holds 2 x 64 words (no
+     spill; the one-wave version kept three 64-word arrays and spilled 82 registers), and the halves meet through the
+     tiles: wave 0 forms the ring samples b[0..63] of every slot, wave 1 b[64..127];
+   - the region rescale (qmf_dec.c:937-953) happens on the way into the tile, where lane = band: the shift of a band is
+     a lane constant per channel and slot range;
+   - ring samples are stored as the pairs the window-add consumes: E[s][k] = (v[s][k], v[s-1][64+k]), so that
+       y[s][k] = rnd + sum_{j<5} v[s-2j][k] c[128j+k] + v[s-2j-1][64+k] c[128j+64+k]
+     is five v_dot2_i32_i16 on five ds_read_b32 (the sums cannot overflow: sum |c| = 57308, see the file header).  Each
+     wave window-adds 16 slots of both channels, lane = sample, and stores interleaved L,R words;
+   - the ring state keeps the reference's layout (2-byte accesses in and out).
+   A state whose drc_offset is not one of the reference's (a multiple of 128 below 1280) is refused: status -1, nothing
+   written for that stream. */
+namespace {
+__device__ __forceinline__ int32_t pair_rescale(int32_t v, int shl, int shr) { return (int32_t)((uint32_t)v << shl) >> shr; }
+typedef short xq_short2 __attribute__((ext_vector_type(2)));
+}  // namespace
+
+__global__ __launch_bounds__(128) void xaac_qmf_synthesis_pair_kernel(XaacQmfSynPairParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int RS = 65;              /* padded LDS row stride of a half row (64 words) */
-  constexpr int VSLOTS = 9 + 32;      /* 9 slots of history + this frame */
-  constexpr int VROW = 130;           /* int16 stride of a slot's 128 ring samples: 65 dwords, odd */
+  constexpr int RS = 65;          /* padded LDS row stride (dwords) of tiles and pair rows */
+  constexpr int EROWS = 9 + 32 + 1; /* pair rows of a channel: slots -9 .. 32 */
   constexpr int RING = 1280;
-  const int lane = threadIdx.x;
-  int32_t *rows = reinterpret_cast<int32_t *>(smem); /* [64][RS], later aliased by ... */
-  int16_t *v = reinterpret_cast<int16_t *>(smem);    /* ... [2][VSLOTS][VROW] ring samples */
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int32_t *tile_own = reinterpret_cast<int32_t *>(smem) + w * 64 * RS;
+  const int32_t *tile_oth = reinterpret_cast<const int32_t *>(smem) + (1 - w) * 64 * RS;
+  int32_t *E = reinterpret_cast<int32_t *>(smem); /* [2][EROWS][RS], aliases the tiles once they are dead */
   const int i = blockIdx.x;
-  const int ch = lane >> 5, slot = lane & 31; /* transform phase: lane = (channel, slot) */
-  const int16_t *sf = p.scale[ch] + 8 * (size_t)i;
-  const int st_syn = sf[3], lsb = sf[4], usb = sf[5];
-  const int lo_shift = (st_syn - (slot < p.split ? sf[1] : sf[0])) - 8, hb_shift = (st_syn - sf[2]) - 8;
   const int inactive0 = __builtin_amdgcn_readfirstlane(p.scale[0][8 * (size_t)i + 6]);
   const int inactive1 = __builtin_amdgcn_readfirstlane(p.scale[1][8 * (size_t)i + 6]);
+  /* this wave's channel for history / state: channel w */
+  xaac_qmf_syn_state *st_w = reinterpret_cast<xaac_qmf_syn_state *>(reinterpret_cast<char *>(p.state[w]) + (size_t)i * p.state_stride[w]);
+  const int d_old = __builtin_amdgcn_readfirstlane(st_w->drc_offset);
   {
-    int32_t s_re[64], x[64], t[64];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      /* ---- half rows in, coalesced: 64 words of each of the 64 rows (2 channels x 32 slots), XB loads in flight */
-      constexpr int XB = 16;
-      for (int r0 = 0; r0 < 64; r0 += XB) {
-        int32_t tmp[XB];
-#pragma unroll
-        for (int j = 0; j < XB; j++) {
-          const int r = r0 + j, c = r >> 5;
-          tmp[j] = (p.qmf[c] + (size_t)i * p.qmf_stride[c] + (size_t)(r & 31) * 128 + 64 * h)[lane];
-        }
-#pragma unroll
-        for (int j = 0; j < XB; j++) rows[RS * (r0 + j) + lane] = tmp[j];
-      }
-      __syncthreads();
-      /* ---- region rescale (qmf_dec.c:937-953), lane = slot */
-#pragma unroll
-      for (int k = 0; k < 64; k++) {
-        const int32_t val = rows[RS * lane + k];
-        x[k] = k < lsb ? adj_scale(val, lo_shift) : (k < usb ? adj_scale(val, hb_shift) : val);
-      }
-      __syncthreads(); /* the tile may be overwritten by the other half's rows / the ring samples */
-      if (h == 0) {
-        xq_cos_sin_mod_half<32, 0>(x, t);
-#pragma unroll
-        for (int k = 0; k < 64; k++) s_re[k] = x[k];
-      } else {
-        xq_cos_sin_mod_half<32, 1>(x, t);
-      }
-    }
-    /* inv_emodulation's last step + shiftrountine_with_rnd (generic:869, :1638): the slot's 128 ring samples, straight
-       into the ring-sample store (the row tile it aliases is dead: every lane has its slot in registers) */
-    const int shift = -(st_syn - 3) + 1;
-    int32_t *dst = reinterpret_cast<int32_t *>(v + (ch * VSLOTS + 9 + slot) * VROW);
-#pragma unroll
-    for (int c = 0; c < 64; c += 2) {
-      const int16_t b0 = fx_round16(fx_shl_sat(fx_sub_sat(x[c], s_re[c]), shift));
-      const int16_t b1 = fx_round16(fx_shl_sat(fx_sub_sat(x[c + 1], s_re[c + 1]), shift));
-      dst[c >> 1] = (int32_t)((uint32_t)(uint16_t)b0 | ((uint32_t)(uint16_t)b1 << 16));
-      const int16_t b2 = fx_round16(fx_shl_sat(fx_add_sat(x[63 - c], s_re[63 - c]), shift));
-      const int16_t b3 = fx_round16(fx_shl_sat(fx_add_sat(x[62 - c], s_re[62 - c]), shift));
-      dst[32 + (c >> 1)] = (int32_t)((uint32_t)(uint16_t)b2 | ((uint32_t)(uint16_t)b3 << 16));
+    const xaac_qmf_syn_state *st_o = reinterpret_cast<const xaac_qmf_syn_state *>(reinterpret_cast<const char *>(p.state[1 - w]) + (size_t)i * p.state_stride[1 - w]);
+    const int d_oth = __builtin_amdgcn_readfirstlane(st_o->drc_offset);
+    if (((d_old | d_oth) & 127) != 0 || d_old < 0 || d_old >= RING || d_oth < 0 || d_oth >= RING) {
+      if (threadIdx.x == 0 && p.status) p.status[i] = -1;
+      return; /* uniform over the workgroup */
     }
   }
-  /* ---- the 9 slots of history from the state -------------------------------------------------------------------- */
-  int d_old[2];
+  /* ---- phase A: half rows in (lane = band), rescaled, through the tile to lane = (channel, slot) --------------- */
+  int32_t x[64];
+  {
+    int shl[2][2], shr[2][2]; /* [channel][slot < split] for band = 64 w' + lane -> the band is lane (both halves: re | im of band lane) */
 #pragma unroll
-  for (int c = 0; c < 2; c++) {
-    const xaac_qmf_syn_state *st = reinterpret_cast<const xaac_qmf_syn_state *>(
-        reinterpret_cast<const char *>(p.state[c]) + (size_t)i * p.state_stride[c]);
-    /* a slot's block of 128 samples sits 128-aligned in the ring (the offset moves by 128 per slot from 0) */
-    int d = __builtin_amdgcn_readfirstlane(st->drc_offset);
-    d = ((d % RING + RING) % RING) & ~127;
-    d_old[c] = d;
-    int32_t hist[9];
+    for (int c = 0; c < 2; c++) {
+      const int16_t *sf = p.scale[c] + 8 * (size_t)i;
+      const int st_syn = sf[3], lsb = sf[4], usb = sf[5];
 #pragma unroll
-    for (int j = 0; j < 9; j++) { /* v row j = the slot of age 9 - j */
-      int pos = d + 128 * (9 - j);
-      if (pos >= RING) pos -= RING;
-      hist[j] = reinterpret_cast<const int32_t *>(st->ring + pos)[lane];
+      for (int ov = 0; ov < 2; ov++) {
+        int sh = lane < lsb ? (st_syn - sf[ov]) - 8 : (lane < usb ? (st_syn - sf[2]) - 8 : 0);
+        sh = sh > 31 ? 31 : (sh < -31 ? -31 : sh); /* env_calc.c:1099 */
+        shl[c][ov] = sh > 0 ? sh : 0;
+        shr[c][ov] = sh < 0 ? -sh : 0;
+      }
     }
+    constexpr int XB = 32;
 #pragma unroll
-    for (int j = 0; j < 9; j++) reinterpret_cast<int32_t *>(v + (c * VSLOTS + j) * VROW)[lane] = hist[j];
+    for (int r0 = 0; r0 < 64; r0 += XB) {
+      int32_t tmp[XB];
+#pragma unroll
+      for (int j = 0; j < XB; j++) {
+        const int r = r0 + j, c = r >> 5;
+        tmp[j] = (p.qmf[c] + (size_t)i * p.qmf_stride[c] + (size_t)(r & 31) * 128 + 64 * w)[lane];
+      }
+#pragma unroll
+      for (int j = 0; j < XB; j++) {
+        const int r = r0 + j, c = r >> 5;
+        const bool ov = (r & 31) < p.split;
+        tile_own[RS * r + lane] = pair_rescale(tmp[j], ov ? shl[c][1] : shl[c][0], ov ? shr[c][1] : shr[c][0]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the tile is this wave's own: no barrier */
+#pragma unroll
+    for (int k = 0; k < 64; k++) x[k] = tile_own[RS * lane + k];
+  }
+  {
+    int32_t t[64];
+    if (w == 0)
+      xq_cos_sin_mod_half<32, 0>(x, t);
+    else
+      xq_cos_sin_mod_half<32, 1>(x, t);
+  }
+  /* ---- phase B: the halves meet.  inv_emodulation's last step + shiftrountine_with_rnd (generic:869, :1638) --- */
+#pragma unroll
+  for (int k = 0; k < 64; k++) tile_own[RS * lane + k] = x[k]; /* a lane's row is read and written by that lane only */
+  /* this wave's channel: 9 slots of history from the ring, in flight across the exchange */
+  int16_t h_lo[9], h_hi[9];
+#pragma unroll
+  for (int A = 1; A <= 9; A++) {
+    int pos = d_old + 128 * A;
+    if (pos >= RING) pos -= RING;
+    h_lo[A - 1] = st_w->ring[pos + lane];
+    h_hi[A - 1] = st_w->ring[pos + 64 + lane];
   }
   __syncthreads();
-  /* ---- window-add: lane = (slot parity, sample pair), both channels; y[s][k] = rnd + sum_A v[s-A][64(A&1)+k] c[64A+k] */
+  int32_t o[64];
+#pragma unroll
+  for (int k = 0; k < 64; k++) o[k] = tile_oth[RS * lane + k];
+  __syncthreads(); /* both tiles are dead: the pair rows may overwrite them */
   {
-    const int par = lane >> 5, k2 = lane & 31;
-    int32_t cf0[10], cf1[10];
+    const int ch = lane >> 5, slot = lane & 31;
+    const int shift = -(p.scale[ch][8 * (size_t)i + 3] - 3) + 1;
+    const int32_t hi = FX_MAX32 >> shift, lo = FX_MIN32 >> shift;
+    /* round16(shl_sat(a, b)) == round16(clamp(a, MIN >> b, MAX >> b) << b): the clamped value's top 17 bits decide */
+    int16_t *row = reinterpret_cast<int16_t *>(E + (ch * EROWS + 9 + slot) * RS);
+    if (w == 0) { /* x = real half, o = imaginary half: b[c] -> low half of E[slot][c] */
 #pragma unroll
-    for (int a = 0; a < 10; a++) {
-      cf0[a] = xaac_qmf_qmf_c[64 * a + 2 * k2];
-      cf1[a] = xaac_qmf_qmf_c[64 * a + 2 * k2 + 1];
-    }
-    int32_t *out = reinterpret_cast<int32_t *>(p.pcm) + (size_t)i * 2048; /* one word per L,R pair */
-    for (int s0 = 0; s0 < 32; s0 += 2) {
-      const int s = s0 + par;
-      int32_t acc[2][2] = {{0x4000, 0x4000}, {0x4000, 0x4000}};
-#pragma unroll
-      for (int c = 0; c < 2; c++) {
-        const int16_t *vs = v + (c * VSLOTS + 9 + s) * VROW + 2 * k2;
-#pragma unroll
-        for (int A = 0; A < 10; A++) {
-          const int32_t wd = *reinterpret_cast<const int32_t *>(vs - VROW * A + 64 * (A & 1));
-          acc[c][0] += (int32_t)(int16_t)(wd & 0xffff) * cf0[A]; /* < 2^31: exact */
-          acc[c][1] += (wd >> 16) * cf1[A];
-        }
+      for (int c = 0; c < 64; c++) {
+        int32_t a = fx_sub_sat(o[c], x[c]);
+        a = a > hi ? hi : (a < lo ? lo : a);
+        row[2 * c] = fx_round16(fx_shlw(a, shift));
       }
-      const uint32_t l0 = (uint32_t)(uint16_t)(fx_shl_sat(acc[0][0], 1) >> 16), l1 = (uint32_t)(uint16_t)(fx_shl_sat(acc[0][1], 1) >> 16);
-      const uint32_t r0 = (uint32_t)(uint16_t)(fx_shl_sat(acc[1][0], 1) >> 16), r1 = (uint32_t)(uint16_t)(fx_shl_sat(acc[1][1], 1) >> 16);
-      int32_t *o = out + 64 * s + 2 * k2;
+    } else { /* x = imaginary half, o = real half: b[64 + c] -> high half of E[slot + 1][c] */
+#pragma unroll
+      for (int c = 0; c < 64; c++) {
+        int32_t a = fx_add_sat(x[63 - c], o[63 - c]);
+        a = a > hi ? hi : (a < lo ? lo : a);
+        row[2 * RS + 2 * c + 1] = fx_round16(fx_shlw(a, shift));
+      }
+    }
+    int16_t *hrow = reinterpret_cast<int16_t *>(E + (w * EROWS) * RS);
+#pragma unroll
+    for (int A = 1; A <= 9; A++) { /* slot -A: row 9 - A low halves, row 10 - A high halves */
+      hrow[(9 - A) * 2 * RS + 2 * lane] = h_lo[A - 1];
+      hrow[(10 - A) * 2 * RS + 2 * lane + 1] = h_hi[A - 1];
+    }
+  }
+  __syncthreads();
+  /* ---- phase C: window-add, wave w = slots 16 w .. 16 w + 15 of both channels, lane = sample k ----------------- */
+  {
+    xq_short2 cp[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      cp[j].x = xaac_qmf_qmf_c[128 * j + lane];
+      cp[j].y = xaac_qmf_qmf_c[128 * j + 64 + lane];
+    }
+    int32_t e[2][24]; /* E[16 w - 8 .. 16 w + 15][lane] */
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int q = 0; q < 24; q++) e[c][q] = E[(c * EROWS + 9 + 16 * w - 8 + q) * RS + lane];
+    int32_t *out = reinterpret_cast<int32_t *>(p.pcm) + (size_t)i * 2048 + 1024 * w + lane; /* one word per L,R pair */
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+      int32_t acc[2] = {0x4000, 0x4000};
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int j = 0; j < 5; j++) acc[c] = __builtin_amdgcn_sdot2(__builtin_bit_cast(xq_short2, e[c][8 + s - 2 * j]), cp[j], acc[c], false);
+      const uint32_t l = (uint32_t)(uint16_t)(fx_add_sat(acc[0], acc[0]) >> 16), r = (uint32_t)(uint16_t)(fx_add_sat(acc[1], acc[1]) >> 16);
       if (!inactive0 && !inactive1) {
-        *reinterpret_cast<int2 *>(o) = make_int2((int32_t)(l0 | (r0 << 16)), (int32_t)(l1 | (r1 << 16)));
+        out[64 * s] = (int32_t)(l | (r << 16));
       } else { /* one channel only: its samples alone (the other's are left as they are) */
-        int16_t *o16 = reinterpret_cast<int16_t *>(o);
-        if (!inactive0) {
-          o16[0] = (int16_t)l0;
-          o16[2] = (int16_t)l1;
-        }
-        if (!inactive1) {
-          o16[1] = (int16_t)r0;
-          o16[3] = (int16_t)r1;
-        }
+        int16_t *o16 = reinterpret_cast<int16_t *>(out + 64 * s);
+        if (!inactive0) o16[0] = (int16_t)l;
+        if (!inactive1) o16[1] = (int16_t)r;
       }
     }
   }
-  /* ---- state: ring blocks of the last 10 slots, drc offset, window phase -------------------------------------- */
+  /* ---- state of channel w: ring blocks of the last 10 slots, drc offset, window phase --------------------------- */
+  if (w == 0 ? inactive0 : inactive1) return;
+  {
+    const int d_new = (d_old + RING - (32 * 128) % RING) % RING; /* 32 slots of 128 downwards */
+    const int ph_new = (st_w->phase + 128) % 640;
+    const int16_t *hrow = reinterpret_cast<const int16_t *>(E + (w * EROWS) * RS);
+    int16_t v_lo[10], v_hi[10];
 #pragma unroll
-  for (int c = 0; c < 2; c++) {
-    if (c == 0 ? inactive0 : inactive1) continue;
-    xaac_qmf_syn_state *st = reinterpret_cast<xaac_qmf_syn_state *>(reinterpret_cast<char *>(p.state[c]) +
-                                                                    (size_t)i * p.state_stride[c]);
-    const int d_new = (d_old[c] + RING - (32 * 128) % RING) % RING; /* 32 slots of 128 downwards */
-    const int ph_new = (st->phase + 128) % 640;
+    for (int A = 1; A <= 10; A++) { /* age relative to the NEXT frame's slot 0: slot 32 - A */
+      v_lo[A - 1] = hrow[(9 + 32 - A) * 2 * RS + 2 * lane];
+      v_hi[A - 1] = hrow[(10 + 32 - A) * 2 * RS + 2 * lane + 1];
+    }
 #pragma unroll
-    for (int A = 1; A <= 10; A++) { /* age relative to the NEXT frame's slot 0 */
+    for (int A = 1; A <= 10; A++) {
       int pos = d_new + 128 * A;
       if (pos >= RING) pos -= RING;
       if (pos >= RING) pos -= RING;
-      reinterpret_cast<int32_t *>(st->ring + pos)[lane] = reinterpret_cast<const int32_t *>(v + (c * VSLOTS + 9 + 32 - A) * VROW)[lane];
+      st_w->ring[pos + lane] = v_lo[A - 1];
+      st_w->ring[pos + 64 + lane] = v_hi[A - 1];
     }
     if (lane == 0) {
-      st->drc_offset = (int16_t)d_new;
-      st->phase = (int16_t)ph_new;
+      st_w->drc_offset = (int16_t)d_new;
+      st_w->phase = (int16_t)ph_new;
     }
   }
 }
 
 extern "C" hipError_t xaac_launch_qmf_synthesis_pair(const XaacQmfSynPairParams *p, hipStream_t stream) {
-  hipLaunchKernelGGL(xaac_qmf_synthesis_pair_kernel, dim3(p->n), dim3(64), XAAC_QMF_SYN_PAIR_LDS, stream, *p);
+  hipLaunchKernelGGL(xaac_qmf_synthesis_pair_kernel, dim3(p->n), dim3(128), XAAC_QMF_SYN_PAIR_LDS, stream, *p);
   return hipGetLastError();
 }
 

@@ -559,30 +559,21 @@ int32_t xaac_sbr_hq_process_batch(xaac_ctx *c, const xaac_sbr_hq_batch *b) {
     pq.state[1] = reinterpret_cast<xaac_qmf_syn_state *>(reinterpret_cast<char *>(b->ps_state) +
                                                          offsetof(xaac_ps_state, syn_ring_r));
     pq.state_stride[1] = (int32_t)sizeof(xaac_ps_state);
-    pq.pcm = b->pcm_out;
+    pq.pcm = b->pcm_out; pq.status = b->status;
     if (!hip_ok(xaac_launch_qmf_synthesis_pair(&pq, c->stream))) return XAAC_FATAL_HIP;
-    c->last_grid = b->n_ch; c->last_block = 64; c->last_lds = XAAC_QMF_SYN_PAIR_LDS;
+    c->last_grid = b->n_ch; c->last_block = 128; c->last_lds = XAAC_QMF_SYN_PAIR_LDS;
     return XAAC_OK;
   }
   XaacQmfSynParams ps = {};
-  ps.n_ch = b->n_ch; ps.ch_fac = with_ps ? 1 : b->out_ch_fac; ps.low_pow = 0; ps.split = 6;
+  ps.n_ch = b->n_ch; ps.ch_fac = b->out_ch_fac; ps.low_pow = 0; ps.split = 6;
   ps.down_sample = b->down_sample ? 1 : 0;
   ps.slot_stride = 128; ps.state_stride = (int32_t)sizeof(xaac_sbr_state); ps.qmf_ch_stride = xw;
   ps.scale_stride = 8; ps.per_ch_bands = 1;
   ps.qmf = x + 2 * 128; ps.scale = par_l; ps.dbg = XAAC_DBG_BUF(b->status, b->n_ch);
   ps.state = reinterpret_cast<xaac_qmf_syn_state *>(st + offsetof(xaac_sbr_state, syn_ring));
   ps.pcm = b->pcm_out;
-  if (with_ps) { ps.pcm_ch_stride = 2 * 2048; ps.pcm_sample_stride = 2; }
   const int grid = qmf_grid(c, b->n_ch, 3);
   if (!hip_ok(xaac_launch_qmf_synthesis(&ps, grid, c->stream))) return XAAC_FATAL_HIP;
-  if (with_ps) {
-    ps.state_stride = (int32_t)sizeof(xaac_ps_state); ps.qmf_ch_stride = 32 * 128;
-    ps.qmf = xr; ps.scale = par_r;
-    ps.state = reinterpret_cast<xaac_qmf_syn_state *>(reinterpret_cast<char *>(b->ps_state) +
-                                                      offsetof(xaac_ps_state, syn_ring_r));
-    ps.pcm = b->pcm_out + 1;
-    if (!hip_ok(xaac_launch_qmf_synthesis(&ps, grid, c->stream))) return XAAC_FATAL_HIP;
-  }
   c->last_grid = grid; c->last_block = XAAC_QMF_BLOCK; c->last_lds = XAAC_QMF_WAVES * XAAC_QMF_SYN_LDS_PER_WAVE_HQ;
   return XAAC_OK;
 }
