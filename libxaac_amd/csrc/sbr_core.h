@@ -213,8 +213,13 @@ struct XsCx {
 #define XS_PAR(k, b0, b1) for (int k = (b0) + cx.lane; k < (b1); k += cx.n)
 #define XS_LANES(k, b0, b1) for (int k = cx.first(b0); k < (b1); k += cx.n) /* k on lane k; b1 <= 64 */
 #define XS_ONE if (cx.lane == 0)
+#ifndef XS_SLOT_UNROLL
+#define XS_SLOT_UNROLL 4 /* slots whose LDS reads are in flight together in the column walks */
+#endif
+#define XS_PRAGMA_(x) _Pragma(#x)
+#define XS_PRAGMA(x) XS_PRAGMA_(x)
 #if defined(__HIPCC__) && !defined(XS_NO_UNROLL)
-#define XS_UNROLL4 _Pragma("unroll 4")
+#define XS_UNROLL4 XS_PRAGMA(unroll XS_SLOT_UNROLL)
 #define XS_UNROLL8 _Pragma("unroll 8")
 #define XS_UNROLL _Pragma("unroll")
 #elif defined(__HIPCC__)
@@ -381,13 +386,18 @@ FX_HD XsLv xs_seg_running_max(const XsCx &cx, const XsLv &seg, const XsLv &e, in
 /* ---- QMF matrix view: rows -2,-1 are the LPC history, rows 0..37 the slots.  Low-power mode keeps 64
    real values per slot; HQ mode keeps 64 real then 64 imaginary ones (the reference's slot-pointer
    arrays over one scratch block, sbr_dec.c:752-766, have exactly these strides). */
-template <int HQ_>
+/* NB_: bands a row holds.  64 is the reference's layout; the GPU core kernel keeps rows of NB_ < 64 bands (less LDS,
+   more resident waves) for streams that provably touch no band at or above NB_ and sends the others through the
+   64-band instantiation (sbr_core_kernel.hip: "narrow rows"). */
+template <int HQ_, int NB_ = 64>
 struct XsQmfT {
   static constexpr int HQ = HQ_;
-  static constexpr int ROW = HQ_ ? 128 : 64;
+  static constexpr int NB = NB_;
+  static constexpr int IM = NB_;                    /* offset of a row's imaginary columns */
+  static constexpr int ROW = HQ_ ? 2 * NB_ : NB_;
   int32_t *p;
   FX_MEMBER int32_t &operator()(int slot, int band) const { return p[(slot + 2) * ROW + band]; }
-  FX_MEMBER int32_t &im(int slot, int band) const { return p[(slot + 2) * ROW + 64 + band]; }
+  FX_MEMBER int32_t &im(int slot, int band) const { return p[(slot + 2) * ROW + IM + band]; }
 };
 typedef XsQmfT<0> XsQmf;
 typedef XsQmfT<1> XsQmfHq;
@@ -399,11 +409,13 @@ struct XsCov {
 /* Per-channel-frame scratch in memory shared by the lanes (LDS on the GPU, stack in the oracle). */
 struct XsWork {
   int32_t bw_array[XAAC_SBR_MAX_PATCHES];
-  int32_t fold_a[XS_MAXF + 8][2]; /* inputs of the sequential pseudo-float sums, per band */
+  union { /* never live together: nrg_est is consumed into the est lane vector before the alias reduction starts */
+    int32_t fold_a[XS_MAXF + 8][2]; /* inputs of the sequential pseudo-float sums, per band */
+    int16_t nrg_est[2 * XS_MAXF];   /* only the interpol_freq == 0 path goes through memory */
+  };
   int32_t fold_b[XS_MAXF + 8][4];
   int16_t res_a[XS_MAXF + 8][4];  /* their results, per limiter band / per alias group (by first band) */
   int16_t res_b[XS_MAXF + 8][2];
-  int16_t nrg_est[2 * XS_MAXF];   /* only the interpol_freq == 0 path goes through memory */
 };
 
 /* Per-band registers of the envelope adjuster.  est / e_orig / gain / noise / sine / meta: element c
@@ -421,7 +433,7 @@ FX_HD int xs_headroom(const XsCx &cx, const Q &x, int b0, int b1, int s0, int s1
   int32_t m = 1;
   const int nb = b1 > b0 ? b1 - b0 : 0;
   XS_PAR(c, 0, Q::HQ ? 2 * nb : nb) {
-    const int col = c < nb ? b0 + c : 64 + b0 + (c - nb);
+    const int col = c < nb ? b0 + c : Q::IM + b0 + (c - nb);
     XS_UNROLL4
     for (int l = s0; l < s1; l++) m |= fx_abs_nrm(x(l, col));
   }
@@ -446,7 +458,7 @@ FX_HD void xs_adjust(const XsCx &cx, const Q &x, int b0, int b1, int s0, int s1,
   if (shift < -31) shift = -31;
   const int nb = b1 > b0 ? b1 - b0 : 0;
   XS_PAR(c, 0, Q::HQ ? 2 * nb : nb) {
-    const int col = c < nb ? b0 + c : 64 + b0 + (c - nb); /* real and imaginary columns side by side */
+    const int col = c < nb ? b0 + c : Q::IM + b0 + (c - nb); /* real and imaginary columns side by side */
     XS_UNROLL4
     for (int l = s0; l < s1; l++) x(l, col) = shift > 0 ? fx_shlw(x(l, col), shift) : (x(l, col) >> -shift);
   }
@@ -895,13 +907,28 @@ FX_HD int xs_subband_gain_meta(const XsCx &cx, const xaac_sbr_header *h, int max
   XS_LANES(c, 0, n_meta) v.meta.own(c) = mt_s.own(c);
   return n_meta;
 }
-FX_HD void xs_calc_subband_gains(const XsCx &cx, const int16_t *env_sf_all, const int16_t *noise_floor, int mvalue,
-                                 int env, int n_meta, int skip, XsEnv &v, int noise_absc) {
+/* one of the frame's per-envelope lane vectors, by a run-time envelope number */
+FX_HD XsLv xs_pick_env(const XsLv *v, int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  XsLv r = v[0];
+  XS_UNROLL
+  for (int k = 1; k < XAAC_SBR_MAX_ENVELOPES; k++) r.v = i == k ? v[k].v : r.v;
+  return r;
+#else
+  return v[i];
+#endif
+}
+/* env_sf: the envelope's scale factors, element j = scale-factor band j */
+FX_HD void xs_calc_subband_gains(const XsCx &cx, const XsLv &env_sf, const int16_t *noise_floor, int env, int n_meta,
+                                 int skip, XsEnv &v, int noise_absc) {
   const XsLv sm1 = v.sine_mapped.shifted(cx, skip);
-  const int16_t *env_sf = &env_sf_all[mvalue];
+  XsLv jv;
+  jv.fill(0);
+  XS_LANES(c, 0, n_meta) jv.own(c) = v.meta.own(c) & 255;
+  const XsLv sfg = env_sf.gather(jv);
   XS_LANES(c, 0, n_meta) {
     const int meta = v.meta.own(c);
-    const int16_t sf = env_sf[meta & 255];
+    const int16_t sf = (int16_t)sfg.own(c);
     const int16_t nfl = noise_floor[(meta >> 8) & 255];
     const int present = (meta >> 16) & 1;
     const int16_t ref_e = (int16_t)((sf & 63) - 16), ref_m = (int16_t)(sf & 0xffc0);
@@ -1485,8 +1512,8 @@ struct XsApplyHq {
   int16_t sg, snz;
   bool tone, noise, fi, live;
 };
-template <int N>
-FX_HD void xs_apply_slots_hq(const XsQmfHq &x, XsApplyHq &a, int l, int &ph, int &harm) {
+template <int N, class Q>
+FX_HD void xs_apply_slots_hq(const Q &x, XsApplyHq &a, int l, int &ph, int &harm) {
   int32_t rp[N], xr[N], xi[N];
   XS_UNROLL
   for (int j = 0; j < N; j++) rp[j] = xaac_sbr_rand_ph[((ph + j * a.step) & 511) + 1 + a.kk];
@@ -1530,10 +1557,10 @@ FX_HD void xs_apply_slots_hq(const XsQmfHq &x, XsApplyHq &a, int l, int &ph, int
    noise (complex random phase) or sine (real part for harmonic index 0/2, imaginary for 1/3, sign
    alternating with the band) per band.  Bands are independent; lane i owns filter-buffer entry i and,
    from skip on, band i - skip. */
-template <class ST>
+template <class ST, class Q>
 FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e, int nsb, int skip, int s0, int s1,
                                   int input_e, int adj_e, int final_e, int sb_start, int noise_absc,
-                                  int smooth_length, const XsQmfHq &x) {
+                                  int smooth_length, const Q &x) {
   const int bands = nsb - skip;
   const int start_up = cx.uni(st->start_up);
   const int ph0 = cx.uni(st->ph_index), harm0 = cx.uni(st->harm_index);
@@ -1718,7 +1745,8 @@ struct XsCovHq {
   int32_t phi_11, phi_22, phi_01, phi_02, phi_12, phi_01_im, phi_02_im, phi_12_im;
 };
 /* the terms of slots [n0, n1) only; `first` adds the terms that precede slot 0 (the caller sums the parts) */
-FX_HD void xs_covariance_hq(const XsQmfHq &x, int k, int n0, int n1, int slots, bool first, XsCovHq *c) {
+template <class Q>
+FX_HD void xs_covariance_hq(const Q &x, int k, int n0, int n1, int slots, bool first, XsCovHq *c) {
   int32_t p01 = 0, p01i = 0, p02 = 0, p02i = 0, p11 = 0, p12 = 0, p12i = 0, p22 = 0;
   int32_t r2 = fx_shr(x(n0 - 2, k), 3), i2 = fx_shr(x.im(n0 - 2, k), 3); /* x[n-2] */
   int32_t r1 = fx_shr(x(n0 - 1, k), 3), i1 = fx_shr(x.im(n0 - 1, k), 3); /* x[n-1] */
@@ -1813,7 +1841,8 @@ FX_HD void xs_lpc_coeffs_hq(const XsCovHq *s, int16_t *a) {
 /* lpp_tran.c:102 + :1203-1250: copy / inverse-filter low band lb into high band hb of patch `patch`.  The reference
    walks the low bands and, inside, the patches; every (low band, patch) pair writes its own high band, so here the
    pairs are spread over the lanes by their high band (xs_hf_generator_hq). */
-FX_HD void xs_patch_band_hq(const xaac_sbr_header *h, const XsQmfHq &x, int lb, int hb, const int16_t *alpha,
+template <class Q>
+FX_HD void xs_patch_band_hq(const xaac_sbr_header *h, const Q &x, int lb, int hb, const int16_t *alpha,
                             const int32_t *bw_array, int start_idx, int stop_idx) {
   int bi = 0; /* the reference's per-patch running index: first border above hb, capped (lpp_tran.c:1218) */
   while (bi < XAAC_SBR_MAX_PATCHES - 1 && bi < XAAC_SBR_MAX_NOISE_VALUES && hb >= h->bw_borders[bi]) bi++;
@@ -1849,8 +1878,8 @@ FX_HD void xs_patch_band_hq(const xaac_sbr_header *h, const XsQmfHq &x, int lb, 
 }
 
 /* lpp_tran.c:956.  Writes bw_array_prev. */
-template <class ST>
-FX_HD void xs_hf_generator_hq(const XsCx &cx, const xaac_sbr_header *h, ST *st, const XsQmfHq &x, XsWork *w,
+template <class ST, class Q>
+FX_HD void xs_hf_generator_hq(const XsCx &cx, const xaac_sbr_header *h, ST *st, const Q &x, XsWork *w,
                               int start_idx, int last_slot_offset, int max_qmf_subband, const int32_t *invf_mode,
                               const int32_t *invf_mode_prev) {
   const int num_patches = cx.uni(h->num_patches);
@@ -1861,9 +1890,9 @@ FX_HD void xs_hf_generator_hq(const XsCx &cx, const xaac_sbr_header *h, ST *st, 
   const int actual_stop = cx.uni(
       (int16_t)(h->patch[num_patches - 1].dst_start_band + h->patch[num_patches - 1].num_bands_in_patch));
   {
-    const int nz = actual_stop < 64 ? 64 - actual_stop : 0; /* real and imaginary columns side by side */
+    const int nz = actual_stop < Q::NB ? Q::NB - actual_stop : 0; /* real and imaginary columns side by side */
     XS_PAR(c, 0, 2 * nz) {
-      const int col = c < nz ? actual_stop + c : 64 + actual_stop + (c - nz);
+      const int col = c < nz ? actual_stop + c : Q::IM + actual_stop + (c - nz);
       XS_UNROLL4
       for (int l = start_idx; l < stop_idx; l++) x(l, col) = 0;
     }
@@ -1985,17 +2014,33 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
     max_noise = cx.wave_max(max_noise);
     adj_e = (cx.uni(st->filt_buf_noise_e) - fx_norm32((int16_t)max_noise)) - 16;
   }
-  int final_e = 0;
+  /* the envelopes' scale factors as lane vectors (element j = scale-factor band j; at most 56 per envelope): on the
+     GPU the frame's array stays in global memory, and fetching every envelope's run here puts all the loads in flight
+     together instead of paying a memory latency per envelope, twice */
+  XsLv sfv[XAAC_SBR_MAX_ENVELOPES];
   {
     int base = 0;
-    for (int i = 0; i < num_env; i++) {
+    XS_UNROLL
+    for (int i = 0; i < XAAC_SBR_MAX_ENVELOPES; i++) {
+      sfv[i].fill(0);
+      if (i < num_env) {
+        const int nsf = cx.uni(h->num_sf_bands[f->freq_res[i]]);
+        XS_LANES(j, 0, nsf) sfv[i].own(j) = env_sf_all[base + j];
+        base += nsf;
+      }
+    }
+  }
+  int final_e = 0;
+  {
+    XS_UNROLL
+    for (int i = 0; i < XAAC_SBR_MAX_ENVELOPES; i++) {
+      if (i >= num_env) break;
       int32_t mx = 16 - 16; /* NRG_EXP_OFFSET - SHORT_BITS */
       const int nsf = cx.uni(h->num_sf_bands[f->freq_res[i]]);
-      XS_PAR(j, 0, nsf) {
-        int t = env_sf_all[base + j] & 63;
+      XS_LANES(j, 0, nsf) {
+        int t = sfv[i].own(j) & 63;
         if (t > mx) mx = t;
       }
-      base += nsf;
       mx = cx.wave_max(mx);
       mx -= 16;
       int t = (mx + 13) >> 1;
@@ -2031,7 +2076,7 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
     if (cx.uni(tbl[0]) < sb_start) return -1;
     const int n_meta = xs_subband_gain_meta(cx, h, max_sb, tbl, nsf, i, v);
     XS_T(5);
-    xs_calc_subband_gains(cx, env_sf_all, noise_floor, m, i, n_meta, skip, v, noise_absc);
+    xs_calc_subband_gains(cx, xs_pick_env(sfv, i), noise_floor, i, n_meta, skip, v, noise_absc);
     m += nsf;
     XS_T(6);
     xs_noiselimiting(cx, h, skip, n_meta, v, w, &xaac_sbr_lim_gains_m[2 * cx.uni(h->limiter_gains)], noise_absc, lim_of);
@@ -2234,8 +2279,8 @@ FX_HD int xs_sbr_core(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
     st->lb_scale = (int16_t)save_lb_scale;
   }
   *save_lb_scale_out = save_lb_scale;
-  XS_PAR(c, 0, Q::HQ ? 64 : 32) {
-    const int col = c < 32 ? 32 + c : 64 + c; /* bands 32..63, real | imaginary */
+  XS_PAR(c, 0, (Q::HQ ? 2 : 1) * (Q::NB - 32)) {
+    const int col = c < Q::NB - 32 ? 32 + c : Q::IM + 32 + (c - (Q::NB - 32)); /* bands 32 and up, real | imaginary */
     for (int l = 6; l < 38; l++) x(l, col) = 0;
   }
   cx.sync();

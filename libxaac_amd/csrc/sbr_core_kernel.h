@@ -9,6 +9,7 @@
 
 #define XAAC_SBR_X_ROWS 40                       /* 2 LPC history rows + 6 overlap slots + 32 new slots */
 #define XAAC_SBR_X_WORDS (XAAC_SBR_X_ROWS * 64)  /* int32 words of one channel's QMF matrix */
+#define XAAC_SBR_NARROW_BANDS 48                 /* bands per LDS row of the HQ core's narrow-row kernel */
 
 typedef struct XaacSbrCoreParams {
   int32_t n_ch;
@@ -18,6 +19,9 @@ typedef struct XaacSbrCoreParams {
   int32_t *x;        /* [n_ch][XAAC_SBR_X_WORDS] */
   int16_t *syn_par;  /* [n_ch][8]: lb, ov_lb, hb, st_syn scales, synthesis lsb, usb */
   int32_t *status;   /* optional [n_ch] */
+  /* HQ only, optional (both or neither): [n_ch] stream numbers + one counter.  With them the launch runs the narrow-row
+     kernel first and the streams it cannot take through the 64-band rows afterwards (sbr_core_kernel.hip) */
+  int32_t *defer_list, *defer_count;
 } XaacSbrCoreParams;
 
 #ifdef __cplusplus

@@ -66,15 +66,25 @@ static_assert(kFrameHeadBytes % 4 == 0 && offsetof(xaac_sbr_frame, int_noise_flo
 static_assert(offsetof(xaac_sbr_frame, int_noise_floor) == kFrameHeadBytes + sizeof(((xaac_sbr_frame *)0)->int_env_sf_arr),
               "nothing but the two arrays behind the head");
 
-template <int HQ>
+/* NB: bands a matrix row holds in LDS ("narrow rows").  The reference's rows have 64 bands; an SBR range that ends at
+   band 48 or below (sub_band_end, patches, tables, bank limits, nothing left above in the overlap slots) never touches
+   the rest, and 40 x 2 x 48 words instead of 40 x 2 x 64 let eight waves share a CU's LDS instead of six -- the kernel
+   is latency bound, its throughput follows the number of resident waves (profiles/r03_b_core_occupancy.txt).  A stream
+   that does not qualify is appended to a list and runs through the 64-band instantiation in a second, list-driven
+   launch: same code, same results. */
+template <int HQ, int NB>
 struct XsLds {
-  int32_t x[(HQ ? 2 : 1) * XAAC_SBR_X_WORDS + 128]; /* + one row: the reference's edge writes may run past slot 37 */
+  typedef XsQmfT<HQ, NB> Q;
+  int32_t x[XAAC_SBR_X_ROWS * Q::ROW + (HQ ? 0 : 128)]; /* LP: + rows the reference's edge writes may run into past slot 37 */
   XsLdsState st;
   xaac_sbr_header h;
   int32_t f_head[kFrameHeadBytes / 4];
   int32_t noise_floor[sizeof(((xaac_sbr_frame *)0)->int_noise_floor) / 4];
   XsWork w;
   int16_t rand_hi[HQ ? 4 : 568]; /* xaac_sbr_rand_ph >> 16 (the low-power slot loop; HQ reads the 32-bit table ahead) */
+#ifdef XS_LDS_PAD
+  char occupancy_probe[XS_LDS_PAD]; /* developer experiment: fewer resident waves */
+#endif
 };
 
 /* global -> LDS (or back): eight loads are in flight before the first store, so a copy costs one memory
@@ -97,52 +107,80 @@ __device__ __forceinline__ void copy_words(int32_t *dst, const int32_t *src, int
     if (i + 64 * j < n) dst[i + 64 * j] = t[j];
 }
 
-}  // namespace
+/* word i of a run of matrix rows as global memory lays them out (HQ: 64 real | 64 imaginary per row, LP: 64 real) ->
+   its place in the LDS rows of NB bands, or -1 for a band the narrow rows do not hold */
+template <int HQ, int NB>
+__device__ __forceinline__ int lds_word(int i) {
+  constexpr int ROWG = HQ ? 128 : 64, ROW = XsQmfT<HQ, NB>::ROW;
+  if (NB == 64) return i;
+  const int row = i / ROWG, gc = i % ROWG, band = gc & 63, part = gc >> 6;
+  return band < NB ? row * ROW + part * NB + band : -1;
+}
 
-/* HQ = 0: low-power mode, rows of 64 reals; HQ = 1: rows of 64 real | 64 imaginary (HE-AAC mono / v2) */
-template <int HQ>
-__global__ __launch_bounds__(64) void xaac_sbr_core_kernel(XaacSbrCoreParams p) {
-  __shared__ XsLds<HQ> s;
-  constexpr int ROW = HQ ? 128 : 64, XW = (HQ ? 2 : 1) * XAAC_SBR_X_WORDS;
-  const int ch = blockIdx.x, lane = threadIdx.x;
+/* one channel-frame; returns false when the stream has to go through the 64-band rows (nothing written then) */
+template <int HQ, int NB>
+__device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int ch, XsLds<HQ, NB> &s, const int lane) {
+  typedef XsQmfT<HQ, NB> Q;
+  constexpr int ROW = Q::ROW, ROWG = HQ ? 128 : 64, XWG = (HQ ? 2 : 1) * XAAC_SBR_X_WORDS;
   xaac_sbr_state *gst = p.state + ch;
-  int32_t *gx = p.x + (size_t)ch * XW;
+  int32_t *gx = p.x + (size_t)ch * XWG;
   const int32_t *gstw = reinterpret_cast<const int32_t *>(gst);
 
-  /* ---- copy-in ---- */
-  copy_words(reinterpret_cast<int32_t *>(&s.h), reinterpret_cast<const int32_t *>(p.header + ch),
-             sizeof(xaac_sbr_header) / 4, lane);
-  copy_words(s.f_head, reinterpret_cast<const int32_t *>(p.frame + ch), kFrameHeadBytes / 4, lane);
-  if (lane < (int)(sizeof(s.noise_floor) / 4))
-    s.noise_floor[lane] = reinterpret_cast<const int32_t *>(p.frame[ch].int_noise_floor)[lane];
-  const xaac_sbr_frame *f = reinterpret_cast<const xaac_sbr_frame *>(s.f_head); /* head members only */
+  /* ---- copy-in: every global load of the channel-frame is issued before the first LDS store, so the wave pays one
+     memory latency here, not one per piece (the kernel is latency bound: a wave's lifetime is its cost) ---- */
+  constexpr int NH = (sizeof(xaac_sbr_header) / 4 + 63) / 64, NF = (kFrameHeadBytes / 4 + 63) / 64;
+  constexpr int NT = (kTailWords + 63) / 64, NOV = 6 * ROWG / 64, NAS = 32 * 32 * (HQ ? 2 : 1) / 64;
+  constexpr int NNF = sizeof(s.noise_floor) / 4;
+  static_assert(NOV * 64 == 6 * ROWG && NF == 1, "whole rows of lanes");
+  int32_t r_h[NH], r_f, r_nf = 0, r_hd = 0, r_t[NT], r_ov[NOV], r_an[NAS];
   {
-    int32_t *m = reinterpret_cast<int32_t *>(&s.st);
-    if (lane < 2) m[lane] = gstw[kHeadOff / 4 + lane];
-    copy_words(m + 2, gstw + kTailOff / 4, kTailWords, lane);
-  }
-  if (!HQ)
-    for (int i = lane; i < 568; i += 64) s.rand_hi[i] = (int16_t)(xaac_sbr_rand_ph[i] >> 16);
-  for (int i = lane; i < 256; i += 64) xs_lds_inv_table[i] = xaac_sbr_inv_table[i];
-  for (int i = lane; i < 257; i += 64) xs_lds_sqrt_table[i] = xaac_sbr_sqrt_table[i];
-  for (int i = lane; i < 2 * ROW; i += 64) {
-    s.x[i] = 0;
-    s.x[XW + (i & 127)] = 0;
-  }
-  copy_words(s.x + 2 * ROW, gstw + offsetof(xaac_sbr_state, overlap) / 4, 6 * ROW, lane);  /* sbr_dec.c:753 */
-  for (int i0 = lane; i0 < 32 * 32 * (HQ ? 2 : 1); i0 += 64 * 8) { /* the analysed slots: bands 0..31 (re, im) */
-    int32_t t[8];
+    const int32_t *gh = reinterpret_cast<const int32_t *>(p.header + ch), *gf = reinterpret_cast<const int32_t *>(p.frame + ch);
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int i = i0 + 64 * j;
+    for (int j = 0; j < NH; j++) r_h[j] = lane + 64 * j < (int)(sizeof(xaac_sbr_header) / 4) ? gh[lane + 64 * j] : 0;
+    r_f = lane < kFrameHeadBytes / 4 ? gf[lane] : 0;
+    if (lane < NNF) r_nf = reinterpret_cast<const int32_t *>(p.frame[ch].int_noise_floor)[lane];
+    if (lane < 2) r_hd = gstw[kHeadOff / 4 + lane];
+#pragma unroll
+    for (int j = 0; j < NT; j++) r_t[j] = lane + 64 * j < kTailWords ? gstw[kTailOff / 4 + lane + 64 * j] : 0;
+    const int32_t *gov = gstw + offsetof(xaac_sbr_state, overlap) / 4; /* sbr_dec.c:753 */
+#pragma unroll
+    for (int j = 0; j < NOV; j++) r_ov[j] = gov[lane + 64 * j];
+#pragma unroll
+    for (int j = 0; j < NAS; j++) { /* the analysed slots: bands 0..31 (re, im) */
+      const int i = lane + 64 * j;
       const int row = HQ ? (i >> 6) : (i >> 5), col = HQ ? ((i & 31) + ((i & 32) ? 64 : 0)) : (i & 31);
-      t[j] = gx[(8 + row) * ROW + col];
+      r_an[j] = gx[(8 + row) * ROWG + col];
+    }
+  }
+  const xaac_sbr_frame *f = reinterpret_cast<const xaac_sbr_frame *>(s.f_head); /* head members only */
+  int32_t above = 0; /* OR of the overlap words in bands the narrow rows do not hold */
+  {
+#pragma unroll
+    for (int j = 0; j < NH; j++)
+      if (lane + 64 * j < (int)(sizeof(xaac_sbr_header) / 4)) reinterpret_cast<int32_t *>(&s.h)[lane + 64 * j] = r_h[j];
+    if (lane < kFrameHeadBytes / 4) s.f_head[lane] = r_f;
+    if (lane < NNF) s.noise_floor[lane] = r_nf;
+    int32_t *m = reinterpret_cast<int32_t *>(&s.st);
+    if (lane < 2) m[lane] = r_hd;
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+      if (lane + 64 * j < kTailWords) m[2 + lane + 64 * j] = r_t[j];
+    for (int i = lane; i < 2 * ROW; i += 64) s.x[i] = 0;
+    if (!HQ)
+      for (int i = lane; i < 128; i += 64) s.x[XAAC_SBR_X_ROWS * ROW + i] = 0;
+#pragma unroll
+    for (int j = 0; j < NOV; j++) {
+      const int d = lds_word<HQ, NB>(lane + 64 * j);
+      if (d >= 0)
+        s.x[2 * ROW + d] = r_ov[j];
+      else
+        above |= r_ov[j];
     }
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int i = i0 + 64 * j;
-      const int row = HQ ? (i >> 6) : (i >> 5), col = HQ ? ((i & 31) + ((i & 32) ? 64 : 0)) : (i & 31);
-      s.x[(8 + row) * ROW + col] = t[j];
+    for (int j = 0; j < NAS; j++) {
+      const int i = lane + 64 * j;
+      const int row = HQ ? (i >> 6) : (i >> 5), col = HQ ? ((i & 31) + ((i & 32) ? Q::IM : 0)) : (i & 31);
+      s.x[(8 + row) * ROW + col] = r_an[j];
     }
   }
   __syncthreads();
@@ -154,9 +192,34 @@ __global__ __launch_bounds__(64) void xaac_sbr_core_kernel(XaacSbrCoreParams p) 
 #endif
 
   const XsCx cx = {lane, 64};
-  const XsQmfT<HQ> x = {s.x};
+  const Q x = {s.x};
   if (lane == 0) s.st.lb_scale = 0;
   const int refused = xs_side_info_bad(cx, &s.h, f, &s.st); /* counts / band numbers past the structs' capacity */
+  if (NB < 64) {
+    /* every band number this frame can turn into a column: the SBR range and its tables, the patches' targets, the
+       bank limits xs_rescale_x_overlap walks between (all within 0..64 once xs_side_info_bad has passed) */
+    int32_t top = 0;
+    if (!refused) {
+      top = s.h.sub_band_end;
+      const int32_t lim[5] = {s.st.syn_usb, s.st.syn_lsb, s.st.codec_usb, s.st.prev_max_qmf_subband_aac, f->max_qmf_subband_aac};
+      for (int i = 0; i < 5; i++) top = lim[i] > top ? lim[i] : top;
+      if (lane <= s.h.num_sf_bands[1] && s.h.freq_band_tbl_hi[lane] > top) top = s.h.freq_band_tbl_hi[lane];
+      if (lane <= s.h.num_sf_bands[0] && s.h.freq_band_tbl_lo[lane] > top) top = s.h.freq_band_tbl_lo[lane];
+      if (lane < s.h.num_patches) {
+        const xaac_sbr_patch *pp = &s.h.patch[lane];
+        const int a = pp->src_end_band + pp->dst_end_band, b = pp->dst_start_band + pp->num_bands_in_patch;
+        top = a > top ? a : top;
+        top = b > top ? b : top;
+      }
+    }
+    if (cx.wave_max(top) > NB || cx.wave_or(above) != 0) return false;
+  }
+  if (refused) { /* the matrix goes on as it came; what the analysis bank does not write is defined as 0 */
+    for (int i = lane; i < 32 * (HQ ? 2 : 1) * (NB - 32); i += 64) {
+      const int row = i / ((HQ ? 2 : 1) * (NB - 32)), c = i % ((HQ ? 2 : 1) * (NB - 32));
+      s.x[(8 + row) * ROW + (c < NB - 32 ? 32 + c : Q::IM + 32 + (c - (NB - 32)))] = 0;
+    }
+  }
   if (f->apply_processing && !refused) xs_rescale_x_overlap(cx, &s.h, f, &s.st, x);
   /* what ixheaacd_cplx_anal_qmffilt leaves in the scale struct (generic:630-631) */
   __syncthreads();
@@ -196,23 +259,88 @@ __global__ __launch_bounds__(64) void xaac_sbr_core_kernel(XaacSbrCoreParams p) 
 #endif
   }
   __syncthreads();
-  copy_words(gx + 2 * ROW, s.x + 2 * ROW, 38 * ROW, lane); /* slots 0..31 for synthesis (+ 32..37 for PS) */
+  /* slots 0..31 for synthesis (+ 32..37 for PS); bands the narrow rows do not hold are 0 */
+  for (int i0 = lane; i0 < 38 * ROWG; i0 += 64 * 8) {
+    int32_t t[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (i0 + 64 * j < 38 * ROWG) {
+        const int d = lds_word<HQ, NB>(i0 + 64 * j);
+        t[j] = d >= 0 ? s.x[2 * ROW + d] : 0;
+      }
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (i0 + 64 * j < 38 * ROWG) gx[2 * ROWG + i0 + 64 * j] = t[j];
+  }
   {
     int32_t *gw = reinterpret_cast<int32_t *>(gst);
     /* sbr_dec.c:1283-1291 copies 6 * 64 words in either mode: in HQ the first three of the six slots */
-    copy_words(gw + offsetof(xaac_sbr_state, overlap) / 4, s.x + (2 + 32) * ROW, 6 * 64, lane);
+    for (int i = lane; i < 6 * 64; i += 64) {
+      const int d = lds_word<HQ, NB>(i);
+      gw[offsetof(xaac_sbr_state, overlap) / 4 + i] = d >= 0 ? s.x[(2 + 32) * ROW + d] : 0;
+    }
     const int32_t *m = reinterpret_cast<const int32_t *>(&s.st);
     if (lane < 2) gw[kHeadOff / 4 + lane] = m[lane];
     copy_words(gw + kTailOff / 4, m + 2, kTailWords, lane);
   }
+  return true;
+}
+
+__device__ __forceinline__ void stage_tables(int lane, int16_t *rand_hi, bool lp) {
+  int16_t ti[4], ts[5];
+#pragma unroll
+  for (int j = 0; j < 4; j++) ti[j] = xaac_sbr_inv_table[lane + 64 * j];
+#pragma unroll
+  for (int j = 0; j < 5; j++) ts[j] = lane + 64 * j < 257 ? xaac_sbr_sqrt_table[lane + 64 * j] : (int16_t)0;
+  if (lp)
+    for (int i = lane; i < 568; i += 64) rand_hi[i] = (int16_t)(xaac_sbr_rand_ph[i] >> 16);
+#pragma unroll
+  for (int j = 0; j < 4; j++) xs_lds_inv_table[lane + 64 * j] = ti[j];
+#pragma unroll
+  for (int j = 0; j < 5; j++)
+    if (lane + 64 * j < 257) xs_lds_sqrt_table[lane + 64 * j] = ts[j];
+}
+
+}  // namespace
+
+/* HQ = 0: low-power mode, rows of 64 reals; HQ = 1: rows of NB real | NB imaginary (HE-AAC mono / v2).
+   One channel-frame per workgroup; with NB < 64 a stream that needs the full rows is appended to p.defer_list. */
+template <int HQ, int NB>
+__global__ __launch_bounds__(64) void xaac_sbr_core_kernel(XaacSbrCoreParams p) {
+  __shared__ XsLds<HQ, NB> s;
+  const int ch = blockIdx.x, lane = threadIdx.x;
+  stage_tables(lane, s.rand_hi, !HQ);
+  if (!core_one<HQ, NB>(p, ch, s, lane) && lane == 0) p.defer_list[atomicAdd(p.defer_count, 1)] = ch;
+}
+
+/* the streams of p.defer_list through the 64-band rows: a small grid walks the list (usually empty) */
+template <int HQ>
+__global__ __launch_bounds__(64) void xaac_sbr_core_list_kernel(XaacSbrCoreParams p) {
+  __shared__ XsLds<HQ, 64> s;
+  const int lane = threadIdx.x;
+  const int n = *p.defer_count;
+  if ((int)blockIdx.x >= n) return;
+  stage_tables(lane, s.rand_hi, !HQ);
+  for (int j = blockIdx.x; j < n; j += gridDim.x) {
+    __syncthreads();
+    core_one<HQ, 64>(p, p.defer_list[j], s, lane);
+  }
 }
 
 extern "C" hipError_t xaac_launch_sbr_core_lp(const XaacSbrCoreParams *p, hipStream_t stream) {
-  hipLaunchKernelGGL(xaac_sbr_core_kernel<0>, dim3(p->n_ch), dim3(64), 0, stream, *p);
+  hipLaunchKernelGGL((xaac_sbr_core_kernel<0, 64>), dim3(p->n_ch), dim3(64), 0, stream, *p);
   return hipGetLastError();
 }
 
 extern "C" hipError_t xaac_launch_sbr_core_hq(const XaacSbrCoreParams *p, hipStream_t stream) {
-  hipLaunchKernelGGL(xaac_sbr_core_kernel<1>, dim3(p->n_ch), dim3(64), 0, stream, *p);
+  if (!p->defer_list || !p->defer_count) {
+    hipLaunchKernelGGL((xaac_sbr_core_kernel<1, 64>), dim3(p->n_ch), dim3(64), 0, stream, *p);
+    return hipGetLastError();
+  }
+  hipError_t e = hipMemsetAsync(p->defer_count, 0, sizeof(int32_t), stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((xaac_sbr_core_kernel<1, XAAC_SBR_NARROW_BANDS>), dim3(p->n_ch), dim3(64), 0, stream, *p);
+  const int grid = p->n_ch < 1024 ? p->n_ch : 1024;
+  hipLaunchKernelGGL((xaac_sbr_core_list_kernel<1>), dim3(grid), dim3(64), 0, stream, *p);
   return hipGetLastError();
 }

@@ -481,7 +481,7 @@ int32_t xaac_sbr_lp_process_batch(xaac_ctx *c, const xaac_sbr_lp_batch *b) {
   pa.qmf = x + (2 + 6) * 64;
   if (!hip_ok(xaac_launch_qmf_analysis(&pa, qmf_grid(c, b->n_ch, 0), c->stream))) return XAAC_FATAL_HIP;
   /* 2. everything between the banks */
-  XaacSbrCoreParams pc;
+  XaacSbrCoreParams pc = {};
   pc.n_ch = b->n_ch; pc.header = b->header; pc.frame = b->frame; pc.state = b->state; pc.x = x; pc.syn_par = par;
   pc.status = b->status;
   if (!hip_ok(xaac_launch_sbr_core_lp(&pc, c->stream))) return XAAC_FATAL_HIP;
@@ -502,9 +502,9 @@ int32_t xaac_sbr_lp_process_batch(xaac_ctx *c, const xaac_sbr_lp_batch *b) {
 
 uint64_t xaac_sbr_hq_workspace_bytes(int32_t n_ch, int32_t with_ps) {
   if (n_ch < 0) return 0;
-  uint64_t per = 2 * XAAC_SBR_X_WORDS * 4 + 8 * 2;
+  uint64_t per = 2 * XAAC_SBR_X_WORDS * 4 + 8 * 2 + 4; /* matrix, synthesis parameters, an entry of the core's stream list */
   if (with_ps) per += 32 * 128 * 4 + 8 * 2;
-  return (uint64_t)n_ch * per + 512;
+  return (uint64_t)n_ch * per + 512 + 64;
 }
 
 int32_t xaac_sbr_hq_process_batch(xaac_ctx *c, const xaac_sbr_hq_batch *b) {
@@ -537,9 +537,11 @@ int32_t xaac_sbr_hq_process_batch(xaac_ctx *c, const xaac_sbr_hq_batch *b) {
   pa.frame = b->frame;
   if (!hip_ok(xaac_launch_qmf_analysis(&pa, qmf_grid(c, b->n_ch, 1), c->stream))) return XAAC_FATAL_HIP;
   /* 2. everything between the banks */
-  XaacSbrCoreParams pc;
+  XaacSbrCoreParams pc = {};
   pc.n_ch = b->n_ch; pc.header = b->header; pc.frame = b->frame; pc.state = b->state; pc.x = x; pc.syn_par = par_l;
   pc.status = b->status;
+  pc.defer_count = reinterpret_cast<int32_t *>(((uintptr_t)(par_l + n * 8 * (with_ps ? 2 : 1)) + 63) & ~(uintptr_t)63);
+  pc.defer_list = pc.defer_count + 1;
   if (!hip_ok(xaac_launch_sbr_core_hq(&pc, c->stream))) return XAAC_FATAL_HIP;
   /* 3. parametric stereo: rows 2..33 become the left channel, xr the right one */
   if (with_ps) {

@@ -22,16 +22,19 @@ PS_NAMES = {1: "sanitize, init_ps_scale", 2: "P1 hybrid analysis", 3: "P2 envelo
             5: "P4 transient detector", 6: "P5 all-pass chains", 7: "P6 hybrid rotation", 8: "P7 delays, rotation, rows out"}
 
 
+def build_prof(src, out):
+    """the product library with the XS_T / XP_T timer hooks compiled in (its own object directory)"""
+    subprocess.check_call(["make", "-s", "-C", src, "OUT=" + out, "OBJD=" + os.path.join(src, "build_prof"),
+                           "EXTRA=-DXS_PROFILE"])
+
+
 def main_ps():
     """same for the parametric-stereo kernel on the C4 bench inputs: python tools/prof_sbr_core.py ps"""
     import torch
     import libxaac_amd
     src = os.path.join(ROOT, "libxaac_amd", "csrc")
     out = os.path.join(ROOT, "libxaac_amd", "libxaac_amd_prof.so")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DXS_PROFILE",
-                           "-shared", "-x", "hip"] + [os.path.join(src, f) for f in
-                           ("imdct_kernel.hip", "sbr_qmf_kernel.hip", "sbr_core_kernel.hip", "sbr_ps_kernel.hip",
-                            "limiter_kernel.hip", "esbr_qmf_kernel.hip", "usac_imdct_kernel.hip", "esbr_core_kernel.hip", "esbr_ps_kernel.hip", "xaac_abi.cpp")] + ["-o", out])
+    build_prof(src, out)
     libxaac_amd.library_path = lambda: out
     import bench
     dev = torch.device("cuda:0")
@@ -54,11 +57,6 @@ def main_ps():
         if core[i]:
             print("%2d %-34s %9.0f cycles/channel-frame %5.1f%%" % (i, NAMES.get(i, "?"), core[i], 100 * core[i] / core.sum()))
     print("   total %.0f cycles" % core.sum())
-    syn = status.cpu().numpy()[128:160].view(np.uint64).astype(np.float64)[8:16] / (steps * n * 2)
-    print("HQ synthesis kernel (per channel-frame of a wave's pair; both launches):")
-    for i, nm in enumerate(["loop top", "rows in", "transform", "v store + ring load", "window-add", "state out"]):
-        print("%2d %-34s %9.0f cycles %5.1f%%" % (i, nm, syn[i], 100 * syn[i] / syn.sum()))
-    print("   total %.0f cycles" % syn.sum())
     print("PS kernel:")
     for i in range(1, 9):
         print("%2d %-34s %9.0f cycles/stream-frame %5.1f%%" % (i, PS_NAMES[i], ps[i], 100 * ps[i] / ps.sum()))
@@ -70,9 +68,7 @@ def main():
     import libxaac_amd
     src = os.path.join(ROOT, "libxaac_amd", "csrc")
     out = os.path.join(ROOT, "libxaac_amd", "libxaac_amd_prof.so")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DXS_PROFILE",
-                           "-shared", "-x", "hip"] + [os.path.join(src, f) for f in
-                           ("imdct_kernel.hip", "sbr_qmf_kernel.hip", "sbr_core_kernel.hip", "sbr_ps_kernel.hip", "limiter_kernel.hip", "esbr_qmf_kernel.hip", "usac_imdct_kernel.hip", "esbr_core_kernel.hip", "esbr_ps_kernel.hip", "xaac_abi.cpp")] + ["-o", out])
+    build_prof(src, out)
     libxaac_amd.library_path = lambda: out
     import bench
     dev = torch.device("cuda:0")
