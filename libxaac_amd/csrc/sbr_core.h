@@ -81,6 +81,9 @@ FX_HD int32_t xs_shr_dir_sat_limit(int32_t a, int b) {
 #define XS_TAB_INV(i) xaac_sbr_inv_table[i]
 #define XS_TAB_SQRT(i) xaac_sbr_sqrt_table[i]
 #endif
+#ifndef XS_TAB_RAND
+#define XS_TAB_RAND(i) xaac_sbr_rand_ph[i] /* the HQ slot loop's complex random phases (the GPU core kernel: an LDS copy) */
+#endif
 FX_HD int xs_fix_mant_div(int16_t op1, int16_t op2, int16_t *res) {
   int pre = fx_norm32(op2) - 16, post;
   int idx = xs_sar(xs_shl(op2, pre), 16 - 3 - 8) & 511;
@@ -160,7 +163,17 @@ struct XsCx {
   int lane, n;
   FX_MEMBER void sync() const {
 #if defined(__HIP_DEVICE_COMPILE__)
+#if defined(XS_SYNC_WAVE_LDS)
+    /* the fixed-point core kernel: a channel-frame is ONE wave and everything it shares between lanes is in LDS, whose
+       operations a wave sees in program order -- so producer and consumer only have to stay in order in the compiler.
+       No s_barrier (the workgroup's other waves run other channel-frames) and, unlike __syncthreads(), no wait for the
+       global loads that are deliberately in flight across these points */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
     __syncthreads();
+#endif
 #endif
   }
   /* wave reductions of idempotent operations, in the VALU's data-parallel-primitive lanes (no LDS round trips):
@@ -1516,7 +1529,7 @@ template <int N, class Q>
 FX_HD void xs_apply_slots_hq(const Q &x, XsApplyHq &a, int l, int &ph, int &harm) {
   int32_t rp[N], xr[N], xi[N];
   XS_UNROLL
-  for (int j = 0; j < N; j++) rp[j] = xaac_sbr_rand_ph[((ph + j * a.step) & 511) + 1 + a.kk];
+  for (int j = 0; j < N; j++) rp[j] = XS_TAB_RAND(((ph + j * a.step) & 511) + 1 + a.kk);
   XS_UNROLL
   for (int j = 0; j < N; j++) {
     xr[j] = x(l + j, a.col);
@@ -1610,7 +1623,7 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
       }
       fbn = xs_noise_rescale(fbn, fbe - ne);
       fbe = ne;
-      const int32_t rp = xaac_sbr_rand_ph[(ph & 511) + 1 + kk];
+      const int32_t rp = XS_TAB_RAND((ph & 511) + 1 + kk);
       const int hi = harm;
       ph = (ph + bands) & 511;
       harm = (harm + 1) & 3;

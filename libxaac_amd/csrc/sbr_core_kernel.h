@@ -10,6 +10,7 @@
 #define XAAC_SBR_X_ROWS 40                       /* 2 LPC history rows + 6 overlap slots + 32 new slots */
 #define XAAC_SBR_X_WORDS (XAAC_SBR_X_ROWS * 64)  /* int32 words of one channel's QMF matrix */
 #define XAAC_SBR_NARROW_BANDS 48                 /* bands per LDS row of the HQ core's narrow-row kernel */
+#define XAAC_SBR_CORE_HQ_WAVES 4                 /* its waves per workgroup (they share the lookup tables in LDS) */
 
 typedef struct XaacSbrCoreParams {
   int32_t n_ch;
@@ -22,6 +23,8 @@ typedef struct XaacSbrCoreParams {
   /* HQ only, optional (both or neither): [n_ch] stream numbers + one counter.  With them the launch runs the narrow-row
      kernel first and the streams it cannot take through the 64-band rows afterwards (sbr_core_kernel.hip) */
   int32_t *defer_list, *defer_count;
+  int32_t *work_counter; /* = defer_count + 1: the persistent waves' next channel-frame */
+  int32_t num_cu;        /* compute units of the device (grid of the persistent launch) */
 } XaacSbrCoreParams;
 
 #ifdef __cplusplus

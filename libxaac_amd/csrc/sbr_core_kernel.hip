@@ -39,12 +39,24 @@ __shared__ long long xs_prof_acc[32];
    global memory on those serial paths costs its latency each time */
 __shared__ int16_t xs_lds_inv_table[256];
 __shared__ int16_t xs_lds_sqrt_table[258];
+/* the slot loops' random phases: the 32-bit table for the HQ one (sbr_core.h: XS_TAB_RAND), its high halves for the
+   low-power one -- a kernel only allocates the one it references.  All three tables are shared by a workgroup's waves */
+__shared__ int32_t xs_lds_rand_ph[568];
+__shared__ int16_t xs_lds_rand_hi[568];
+#define XS_TAB_RAND(i) xs_lds_rand_ph[i]
+#define XS_SYNC_WAVE_LDS 1 /* XsCx::sync(): wave-level, LDS only (see sbr_core.h) */
 #define XS_TAB_INV(i) xs_lds_inv_table[i]
 #define XS_TAB_SQRT(i) xs_lds_sqrt_table[i]
 #include "sbr_core.h"
 #include "sbr_core_kernel.h"
 
 namespace {
+
+__device__ __forceinline__ void xs_wave_sync() { /* = XsCx::sync() */
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 /* LDS copy of the state members the core touches: the four bank-limit shorts + the struct tail */
 struct XsLdsState {
@@ -81,7 +93,6 @@ struct XsLds {
   int32_t f_head[kFrameHeadBytes / 4];
   int32_t noise_floor[sizeof(((xaac_sbr_frame *)0)->int_noise_floor) / 4];
   XsWork w;
-  int16_t rand_hi[HQ ? 4 : 568]; /* xaac_sbr_rand_ph >> 16 (the low-power slot loop; HQ reads the 32-bit table ahead) */
 #ifdef XS_LDS_PAD
   char occupancy_probe[XS_LDS_PAD]; /* developer experiment: fewer resident waves */
 #endif
@@ -183,7 +194,7 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
       s.x[(8 + row) * ROW + col] = r_an[j];
     }
   }
-  __syncthreads();
+  xs_wave_sync();
 #ifdef XS_PROFILE
   if (lane == 0) {
     for (int i = 0; i < 32; i++) xs_prof_acc[i] = 0;
@@ -222,21 +233,21 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
   }
   if (f->apply_processing && !refused) xs_rescale_x_overlap(cx, &s.h, f, &s.st, x);
   /* what ixheaacd_cplx_anal_qmffilt leaves in the scale struct (generic:630-631) */
-  __syncthreads();
+  xs_wave_sync();
   if (lane == 0) {
     s.st.st_lb_scale = 0;
     s.st.lb_scale = HQ ? -8 : -10;
   }
-  __syncthreads();
+  xs_wave_sync();
   int save_lb_scale = 0;
 #ifdef XS_SKIP_CORE
   const int rc = 0;
 #else
   const int rc = refused ? -1
                          : xs_sbr_core(cx, &s.h, f, p.frame[ch].int_env_sf_arr, reinterpret_cast<const int16_t *>(s.noise_floor),
-                                       &s.st, x, &s.w, s.rand_hi, &save_lb_scale);
+                                       &s.st, x, &s.w, HQ ? nullptr : xs_lds_rand_hi, &save_lb_scale);
 #endif
-  __syncthreads();
+  xs_wave_sync();
 #ifdef XS_PROFILE
   XS_T(15);
   if (lane < 32 && p.status) atomicAdd(reinterpret_cast<unsigned long long *>(p.status) + lane, (unsigned long long)xs_prof_acc[lane]);
@@ -258,7 +269,7 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
     if (p.status) p.status[ch] = rc;
 #endif
   }
-  __syncthreads();
+  xs_wave_sync();
   /* slots 0..31 for synthesis (+ 32..37 for PS); bands the narrow rows do not hold are 0 */
   for (int i0 = lane; i0 < 38 * ROWG; i0 += 64 * 8) {
     int32_t t[8];
@@ -286,31 +297,58 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
   return true;
 }
 
-__device__ __forceinline__ void stage_tables(int lane, int16_t *rand_hi, bool lp) {
-  int16_t ti[4], ts[5];
+/* the workgroup's tables, staged by all its threads (loads first, then the LDS stores) */
+template <int HQ, int THREADS>
+__device__ __forceinline__ void stage_tables(int tid) {
+  constexpr int NR = (568 + THREADS - 1) / THREADS, NI = (256 + THREADS - 1) / THREADS, NS = (257 + THREADS - 1) / THREADS;
+  int32_t tr[NR];
+  int16_t ti[NI], ts[NS];
 #pragma unroll
-  for (int j = 0; j < 4; j++) ti[j] = xaac_sbr_inv_table[lane + 64 * j];
+  for (int j = 0; j < NR; j++) tr[j] = tid + THREADS * j < 568 ? xaac_sbr_rand_ph[tid + THREADS * j] : 0;
 #pragma unroll
-  for (int j = 0; j < 5; j++) ts[j] = lane + 64 * j < 257 ? xaac_sbr_sqrt_table[lane + 64 * j] : (int16_t)0;
-  if (lp)
-    for (int i = lane; i < 568; i += 64) rand_hi[i] = (int16_t)(xaac_sbr_rand_ph[i] >> 16);
+  for (int j = 0; j < NI; j++) ti[j] = tid + THREADS * j < 256 ? xaac_sbr_inv_table[tid + THREADS * j] : (int16_t)0;
 #pragma unroll
-  for (int j = 0; j < 4; j++) xs_lds_inv_table[lane + 64 * j] = ti[j];
+  for (int j = 0; j < NS; j++) ts[j] = tid + THREADS * j < 257 ? xaac_sbr_sqrt_table[tid + THREADS * j] : (int16_t)0;
 #pragma unroll
-  for (int j = 0; j < 5; j++)
-    if (lane + 64 * j < 257) xs_lds_sqrt_table[lane + 64 * j] = ts[j];
+  for (int j = 0; j < NR; j++)
+    if (tid + THREADS * j < 568) {
+      if (HQ)
+        xs_lds_rand_ph[tid + THREADS * j] = tr[j];
+      else
+        xs_lds_rand_hi[tid + THREADS * j] = (int16_t)(tr[j] >> 16);
+    }
+#pragma unroll
+  for (int j = 0; j < NI; j++)
+    if (tid + THREADS * j < 256) xs_lds_inv_table[tid + THREADS * j] = ti[j];
+#pragma unroll
+  for (int j = 0; j < NS; j++)
+    if (tid + THREADS * j < 257) xs_lds_sqrt_table[tid + THREADS * j] = ts[j];
 }
 
 }  // namespace
 
 /* HQ = 0: low-power mode, rows of 64 reals; HQ = 1: rows of NB real | NB imaginary (HE-AAC mono / v2).
-   One channel-frame per workgroup; with NB < 64 a stream that needs the full rows is appended to p.defer_list. */
-template <int HQ, int NB>
-__global__ __launch_bounds__(64) void xaac_sbr_core_kernel(XaacSbrCoreParams p) {
-  __shared__ XsLds<HQ, NB> s;
-  const int ch = blockIdx.x, lane = threadIdx.x;
-  stage_tables(lane, s.rand_hi, !HQ);
-  if (!core_one<HQ, NB>(p, ch, s, lane) && lane == 0) p.defer_list[atomicAdd(p.defer_count, 1)] = ch;
+   WAVES waves per workgroup share the tables; every wave takes channel-frames off a work counter until none is left
+   (p.work_counter, zeroed by the launch; without one: workgroup i's wave w takes channel WAVES i + w).  With NB < 64 a
+   stream that needs the full rows is appended to p.defer_list. */
+template <int HQ, int NB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void xaac_sbr_core_kernel(XaacSbrCoreParams p) {
+  __shared__ XsLds<HQ, NB> s[WAVES];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  stage_tables<HQ, 64 * WAVES>(threadIdx.x);
+  __syncthreads();
+  for (bool first = true;; first = false) { /* one call site: one copy of the core in the kernel's code */
+    int ch = 0;
+    if (p.work_counter) {
+      if (lane == 0) ch = atomicAdd(p.work_counter, 1);
+      ch = __builtin_amdgcn_readfirstlane(ch);
+    } else {
+      ch = first ? (int)blockIdx.x * WAVES + wave : p.n_ch;
+    }
+    if (ch >= p.n_ch) break;
+    if (!core_one<HQ, NB>(p, ch, s[wave], lane) && lane == 0) p.defer_list[atomicAdd(p.defer_count, 1)] = ch;
+    xs_wave_sync();
+  }
 }
 
 /* the streams of p.defer_list through the 64-band rows: a small grid walks the list (usually empty) */
@@ -320,27 +358,35 @@ __global__ __launch_bounds__(64) void xaac_sbr_core_list_kernel(XaacSbrCoreParam
   const int lane = threadIdx.x;
   const int n = *p.defer_count;
   if ((int)blockIdx.x >= n) return;
-  stage_tables(lane, s.rand_hi, !HQ);
+  stage_tables<HQ, 64>(lane);
   for (int j = blockIdx.x; j < n; j += gridDim.x) {
-    __syncthreads();
+    xs_wave_sync();
     core_one<HQ, 64>(p, p.defer_list[j], s, lane);
   }
 }
 
 extern "C" hipError_t xaac_launch_sbr_core_lp(const XaacSbrCoreParams *p, hipStream_t stream) {
-  hipLaunchKernelGGL((xaac_sbr_core_kernel<0, 64>), dim3(p->n_ch), dim3(64), 0, stream, *p);
+  XaacSbrCoreParams q = *p;
+  q.work_counter = nullptr;
+  hipLaunchKernelGGL((xaac_sbr_core_kernel<0, 64, 1>), dim3(p->n_ch), dim3(64), 0, stream, q);
   return hipGetLastError();
 }
 
 extern "C" hipError_t xaac_launch_sbr_core_hq(const XaacSbrCoreParams *p, hipStream_t stream) {
-  if (!p->defer_list || !p->defer_count) {
-    hipLaunchKernelGGL((xaac_sbr_core_kernel<1, 64>), dim3(p->n_ch), dim3(64), 0, stream, *p);
+  if (!p->defer_list || !p->defer_count || !p->work_counter) {
+    XaacSbrCoreParams q = *p;
+    q.work_counter = nullptr;
+    hipLaunchKernelGGL((xaac_sbr_core_kernel<1, 64, 1>), dim3(p->n_ch), dim3(64), 0, stream, q);
     return hipGetLastError();
   }
-  hipError_t e = hipMemsetAsync(p->defer_count, 0, sizeof(int32_t), stream);
+  /* defer_count and work_counter are neighbours */
+  hipError_t e = hipMemsetAsync(p->defer_count, 0, 2 * sizeof(int32_t), stream);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((xaac_sbr_core_kernel<1, XAAC_SBR_NARROW_BANDS>), dim3(p->n_ch), dim3(64), 0, stream, *p);
-  const int grid = p->n_ch < 1024 ? p->n_ch : 1024;
+  constexpr int W = XAAC_SBR_CORE_HQ_WAVES;
+  const int resident = 2 * (p->num_cu > 0 ? p->num_cu : 256), need = (p->n_ch + W - 1) / W;
+  hipLaunchKernelGGL((xaac_sbr_core_kernel<1, XAAC_SBR_NARROW_BANDS, W>), dim3(need < resident ? need : resident), dim3(64 * W), 0,
+                     stream, *p);
+  const int grid = p->n_ch < 256 ? p->n_ch : 256;
   hipLaunchKernelGGL((xaac_sbr_core_list_kernel<1>), dim3(grid), dim3(64), 0, stream, *p);
   return hipGetLastError();
 }

@@ -504,7 +504,7 @@ uint64_t xaac_sbr_hq_workspace_bytes(int32_t n_ch, int32_t with_ps) {
   if (n_ch < 0) return 0;
   uint64_t per = 2 * XAAC_SBR_X_WORDS * 4 + 8 * 2 + 4; /* matrix, synthesis parameters, an entry of the core's stream list */
   if (with_ps) per += 32 * 128 * 4 + 8 * 2;
-  return (uint64_t)n_ch * per + 512 + 64;
+  return (uint64_t)n_ch * per + 512 + 128;
 }
 
 int32_t xaac_sbr_hq_process_batch(xaac_ctx *c, const xaac_sbr_hq_batch *b) {
@@ -541,7 +541,7 @@ int32_t xaac_sbr_hq_process_batch(xaac_ctx *c, const xaac_sbr_hq_batch *b) {
   pc.n_ch = b->n_ch; pc.header = b->header; pc.frame = b->frame; pc.state = b->state; pc.x = x; pc.syn_par = par_l;
   pc.status = b->status;
   pc.defer_count = reinterpret_cast<int32_t *>(((uintptr_t)(par_l + n * 8 * (with_ps ? 2 : 1)) + 63) & ~(uintptr_t)63);
-  pc.defer_list = pc.defer_count + 1;
+  pc.work_counter = pc.defer_count + 1; pc.defer_list = pc.defer_count + 2; pc.num_cu = c->num_cu;
   if (!hip_ok(xaac_launch_sbr_core_hq(&pc, c->stream))) return XAAC_FATAL_HIP;
   /* 3. parametric stereo: rows 2..33 become the left channel, xr the right one */
   if (with_ps) {

@@ -206,3 +206,36 @@ def test_malformed_side_info_does_not_disturb_the_batch(ctx, oracle):
         assert status[i] == r["ret"]
         assert np.array_equal(o[0::2], r["pcm_out"][0]) and np.array_equal(o[1::2], r["pcm_out"][1]), i
         assert not cap.diff_state(cap.PsState.from_buffer_copy(ps[i].tobytes()), r["ps1"]), i
+
+
+def test_streams_outside_the_narrow_rows_take_the_list_kernel(ctx, oracle):
+    """The HQ core keeps 48-band rows in LDS and sends streams that touch a higher band through a second, list-driven
+    launch with the reference's 64-band rows (sbr_core_kernel.hip).  Every third stream here carries overlap words above
+    band 48 (left there by a previous frame with a wider SBR range) and one more has its synthesis bank limit up there;
+    all must still equal the oracle, frame after frame, next to streams that stay on the narrow path."""
+    recs = cap.read_records(GOLDEN)
+    n = len(recs)
+    rng = np.random.default_rng(23)
+    states = [cap.State.from_buffer_copy(bytes(r["st0"])) for r in recs]
+    pstates = [cap.PsState.from_buffer_copy(bytes(r["ps0"])) for r in recs]
+    for i in range(0, n, 3):
+        ov = np.frombuffer(states[i], dtype=np.int32, count=6 * 128, offset=cap.State.overlap.offset).reshape(6, 2, 64)
+        ov[:, :, 48 + (i % 16):] = rng.integers(-2000, 2000, ov[:, :, 48 + (i % 16):].shape)
+    states[1].syn_usb = 52
+    for step in range(3):
+        headers = [cap.Header.from_buffer_copy(bytes(r["header"])) for r in recs]
+        frames = [cap.Frame.from_buffer_copy(bytes(r["frame"])) for r in recs]
+        pframes = [cap.PsFrame.from_buffer_copy(bytes(r["ps_frame"])) for r in recs]
+        pcm = rng.integers(-9000, 9000, (n, 1024)).astype(np.int16)
+        out, st_bytes, ps_bytes, status = gpu_run(ctx, headers, frames, states, pframes, pstates, pcm.reshape(-1))
+        for i in range(n):
+            ref_out = np.zeros(4096, np.int16)
+            rc = oracle.lib.xo_sbr_dec_hq(ctypes.byref(headers[i]), ctypes.byref(frames[i]), ctypes.byref(states[i]),
+                                          ctypes.byref(pframes[i]), ctypes.byref(pstates[i]), pcm[i].ctypes.data_as(P16), 1,
+                                          ref_out.ctypes.data_as(P16), 2)
+            assert status[i] == rc, (step, i)
+            assert np.array_equal(out[4096 * i:4096 * (i + 1)], ref_out), (step, i)
+            gs = cap.State.from_buffer_copy(st_bytes[i].tobytes())
+            gp = cap.PsState.from_buffer_copy(ps_bytes[i].tobytes())
+            assert not cap.diff_state(gs, states[i]), (step, i, cap.diff_state(gs, states[i])[:3])
+            assert not cap.diff_state(gp, pstates[i]), (step, i, cap.diff_state(gp, pstates[i])[:3])
