@@ -25,6 +25,7 @@ typedef struct XaacSbrCoreParams {
   int32_t *defer_list, *defer_count;
   int32_t *work_counter; /* = defer_count + 1: the persistent waves' next channel-frame */
   int32_t num_cu;        /* compute units of the device (grid of the persistent launch) */
+  int32_t counters_zeroed; /* 1: an earlier launch on the stream has cleared defer_count / work_counter */
 } XaacSbrCoreParams;
 
 #ifdef __cplusplus

@@ -380,13 +380,15 @@ extern "C" hipError_t xaac_launch_sbr_core_hq(const XaacSbrCoreParams *p, hipStr
     return hipGetLastError();
   }
   /* defer_count and work_counter are neighbours */
-  hipError_t e = hipMemsetAsync(p->defer_count, 0, 2 * sizeof(int32_t), stream);
-  if (e != hipSuccess) return e;
+  if (!p->counters_zeroed) {
+    hipError_t e = hipMemsetAsync(p->defer_count, 0, 2 * sizeof(int32_t), stream);
+    if (e != hipSuccess) return e;
+  }
   constexpr int W = XAAC_SBR_CORE_HQ_WAVES;
   const int resident = 2 * (p->num_cu > 0 ? p->num_cu : 256), need = (p->n_ch + W - 1) / W;
   hipLaunchKernelGGL((xaac_sbr_core_kernel<1, XAAC_SBR_NARROW_BANDS, W>), dim3(need < resident ? need : resident), dim3(64 * W), 0,
                      stream, *p);
-  const int grid = p->n_ch < 256 ? p->n_ch : 256;
+  const int grid = p->n_ch < 64 ? p->n_ch : 64;
   hipLaunchKernelGGL((xaac_sbr_core_list_kernel<1>), dim3(grid), dim3(64), 0, stream, *p);
   return hipGetLastError();
 }

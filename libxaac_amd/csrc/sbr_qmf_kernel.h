@@ -31,6 +31,7 @@ typedef struct XaacQmfAnaParams {
      runs: frame->max_qmf_subband_aac when the frame is processed, else the state's codec_usb (state then
      points into xaac_sbr_state).  NULL: use `usb` for every channel. */
   const xaac_sbr_frame *frame;
+  int32_t *zero_words; /* optional: two words the HQ kernel clears for the launch behind it (the SBR core's counters) */
 } XaacQmfAnaParams;
 
 typedef struct XaacQmfSynParams {

@@ -181,6 +181,149 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_analysis_kernel(XaacQ
   }
 }
 
+/* ===================================================================================== */
+/* The complex (HQ) analysis bank, two channels per 128-thread workgroup.  Same arithmetic as xaac_qmf_analysis_kernel<false>
+   (sbr_qmf.h: xq_fwd_modulation), arranged like the synthesis pair kernel below:
+   - wave w window-adds channel w: lane = polyphase branch m, and since z[s][m] = sum_j u[s - 2j] c[2m + 128j] with
+     u[k] = x[32k + 31 - m], the lane keeps its forty u in registers -- one LDS read per slot instead of five;
+   - the slot transform's two independent halves (xq_cos_sin_mod_half<16, H>) run on the two waves, lane = (channel,
+     slot) on both: wave 0 takes the difference terms (real parts), wave 1 the sums (imaginary parts), 32 words per
+     lane instead of the 64 + 128 + 128 of the whole transform; they meet through two 64 x 33-word tiles for the final
+     rotation (wave 0 forms the real outputs, wave 1 the imaginary ones) and for the way out (lane = band);
+   - 22 KB of LDS per workgroup: seven workgroups (14 waves) per CU where the one-wave-per-pair kernel had six waves. */
+__global__ __launch_bounds__(128) void xaac_qmf_analysis_hq_kernel(XaacQmfAnaParams p) {
+  __shared__ int16_t hist[2][kHist];
+  __shared__ int32_t tile[2 * 64 * 33]; /* the 64 x 65 window-add tile, then the two 64 x 33 half tiles */
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.x;
+  const int chw = 2 * pair + w; /* the channel this wave loads, window-adds and writes */
+  const bool live = chw < p.n_ch;
+  if (p.zero_words && blockIdx.x == 0 && threadIdx.x < 2) p.zero_words[threadIdx.x] = 0;
+  xaac_qmf_ana_state *st = reinterpret_cast<xaac_qmf_ana_state *>(reinterpret_cast<char *>(p.state) + (size_t)(live ? chw : 0) * p.state_stride);
+  int wr = 0;
+  /* ---- history + new samples of channel w, time ordered ---- */
+  {
+    int16_t *h = hist[w];
+    if (live) {
+      wr = st->wr;
+      const int cf = p.ch_fac;
+      const int16_t *src = p.pcm + (size_t)(chw / cf) * 1024 * cf + (chw % cf);
+      int16_t hr[5], hp[16];
+#pragma unroll
+      for (int j = 0; j < 5; j++) {
+        const int a = lane + 64 * j;
+        hr[j] = a < 288 ? st->ring[ana_ring_pos(wr, a)] : (int16_t)0;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; j++) hp[j] = src[(size_t)(lane + 64 * j) * cf];
+#pragma unroll
+      for (int j = 0; j < 5; j++) {
+        const int a = lane + 64 * j;
+        if (a < 288) h[287 - a] = hr[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 16; j++) h[288 + lane + 64 * j] = hp[j];
+    } else {
+      for (int i = lane; i < kHist; i += 64) h[i] = 0;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* hist[w] is this wave's own */
+  /* ---- window-add of channel w: lane = polyphase branch m ---- */
+  {
+    int32_t coef[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) coef[j] = xaac_qmf_qmf_c[2 * lane + 128 * j];
+    const int16_t *h = hist[w] + 288 + 31 - lane;
+    int32_t u[40]; /* u[8 + k] = x[32 k + 31 - m], k = -8 .. 31 */
+#pragma unroll
+    for (int k = 0; k < 40; k++) u[k] = h[32 * (k - 8)];
+#pragma unroll
+    for (int sl = 0; sl < 32; sl++) {
+      int32_t acc = 0;
+#pragma unroll
+      for (int j = 0; j < 5; j++) acc += u[8 + sl - 2 * j] * coef[j]; /* |acc| < 2^30: exact */
+      tile[65 * (32 * w + sl) + lane] = acc;
+    }
+  }
+  __syncthreads();
+  /* ---- the halves: lane = (channel, slot) ---- */
+  int32_t s[32];
+  {
+    int32_t in[64];
+#pragma unroll
+    for (int k = 0; k < 64; k++) in[k] = tile[65 * lane + k];
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+      const int32_t a = fx_shr(in[i], 4), b = fx_shr(in[63 - i], 4);
+      s[i] = w == 0 ? fx_sub_sat(a, b) : fx_add_sat(a, b);
+    }
+  }
+  __syncthreads(); /* the window-add tile is dead */
+  {
+    int32_t t[32];
+    if (w == 0)
+      xq_cos_sin_mod_half<16, 0>(s, t);
+    else
+      xq_cos_sin_mod_half<16, 1>(s, t);
+  }
+  int32_t *mine = tile + w * (64 * 33);
+  const int32_t *other = tile + (1 - w) * (64 * 33);
+#pragma unroll
+  for (int k = 0; k < 32; k++) mine[33 * lane + k] = s[k];
+  __syncthreads();
+  {
+    int32_t o[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) o[k] = other[33 * lane + k];
+    int nrot = p.usb;
+    if (p.frame) { /* lanes 0..31 are the slots of the pair's first channel, 32..63 of its second */
+      const int ch = 2 * pair + (lane >> 5);
+      if (ch < p.n_ch) {
+        const xaac_sbr_frame *f = p.frame + ch;
+        const xaac_sbr_state *sst = reinterpret_cast<const xaac_sbr_state *>(
+            reinterpret_cast<const char *>(p.state) + (size_t)ch * p.state_stride);
+        nrot = f->apply_processing ? f->max_qmf_subband_aac : sst->codec_usb;
+      }
+    }
+    const int16_t *tc = XQ_T(t_cos_sin_l32);
+#pragma unroll
+    for (int i = 0; i < 32; i++) { /* generic:650-656: own = real (wave 0) / imaginary (wave 1) part, o = the other */
+      const int16_t c = tc[2 * i], sn = tc[2 * i + 1];
+      const int32_t pa = fx_mul32x16_shl(s[i], c), pb = fx_mul32x16_shl(o[i], sn);
+      const int32_t r = w == 0 ? fx_add_sat(pa, pb) : fx_sub_sat(pa, pb);
+      s[i] = i < nrot ? r : s[i];
+    }
+  }
+  __syncthreads(); /* both waves have read the other's half */
+#pragma unroll
+  for (int k = 0; k < 32; k++) mine[33 * lane + k] = s[k];
+  __syncthreads();
+  if (!live) return;
+  /* ---- channel w's rows out: lane = (part, band), real bands at +0, imaginary at +64 ---- */
+  {
+    int32_t *row = p.qmf + (size_t)chw * p.qmf_ch_stride + (lane & 31) + 64 * (lane >> 5);
+    const int32_t *src = tile + (lane >> 5) * (64 * 33) + 33 * (32 * w) + (lane & 31);
+#pragma unroll 8
+    for (int r = 0; r < 32; r++) row[(size_t)r * p.slot_stride] = src[33 * r];
+  }
+  /* ---- state: the ring as the reference leaves it after 32 slots ---- */
+  {
+    const int wr_new = (wr + 256) % 320;
+    const int ph_new = ana_phase_after_frame(st->phase);
+    const int16_t *h = hist[w];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const int a = lane + 64 * j;
+      st->ring[ana_ring_pos(wr_new, a)] = h[kHist - 1 - a];
+    }
+    if (lane == 0) {
+      st->wr = (int16_t)wr_new;
+      st->phase = (int16_t)ph_new;
+    }
+  }
+}
+
 #ifdef XS_PROFILE
 /* phase timers of the synthesis kernel (tools/prof_sbr_core.py): cycles of each wave's lane 0 */
 
@@ -762,9 +905,8 @@ extern "C" hipError_t xaac_launch_qmf_analysis(const XaacQmfAnaParams *p, int gr
   if (p->low_pow)
     hipLaunchKernelGGL(xaac_qmf_analysis_kernel<true>, dim3(grid), dim3(XAAC_QMF_BLOCK),
                        XAAC_QMF_WAVES * XAAC_QMF_ANA_LDS_PER_WAVE, stream, *p);
-  else
-    hipLaunchKernelGGL(xaac_qmf_analysis_kernel<false>, dim3(grid), dim3(XAAC_QMF_BLOCK),
-                       XAAC_QMF_WAVES * XAAC_QMF_ANA_LDS_PER_WAVE, stream, *p);
+  else /* two channels per workgroup, not persistent: `grid` (sized for the low-power kernel) does not apply */
+    hipLaunchKernelGGL(xaac_qmf_analysis_hq_kernel, dim3((p->n_ch + 1) / 2), dim3(128), 0, stream, *p);
   return hipGetLastError();
 }
 

@@ -535,13 +535,17 @@ int32_t xaac_sbr_hq_process_batch(xaac_ctx *c, const xaac_sbr_hq_batch *b) {
   pa.state = reinterpret_cast<xaac_qmf_ana_state *>(st + offsetof(xaac_sbr_state, ana_ring));
   pa.qmf = x + (2 + 6) * 128;
   pa.frame = b->frame;
+  /* the core's two counters (streams deferred to the 64-band rows, next stream of the persistent waves) sit behind the
+     synthesis parameters; the analysis launch clears them on its way */
+  int32_t *counters = reinterpret_cast<int32_t *>(((uintptr_t)(par_l + n * 8 * (with_ps ? 2 : 1)) + 63) & ~(uintptr_t)63);
+  pa.zero_words = counters;
   if (!hip_ok(xaac_launch_qmf_analysis(&pa, qmf_grid(c, b->n_ch, 1), c->stream))) return XAAC_FATAL_HIP;
   /* 2. everything between the banks */
   XaacSbrCoreParams pc = {};
   pc.n_ch = b->n_ch; pc.header = b->header; pc.frame = b->frame; pc.state = b->state; pc.x = x; pc.syn_par = par_l;
   pc.status = b->status;
-  pc.defer_count = reinterpret_cast<int32_t *>(((uintptr_t)(par_l + n * 8 * (with_ps ? 2 : 1)) + 63) & ~(uintptr_t)63);
-  pc.work_counter = pc.defer_count + 1; pc.defer_list = pc.defer_count + 2; pc.num_cu = c->num_cu;
+  pc.defer_count = counters; pc.work_counter = counters + 1; pc.defer_list = counters + 2; pc.num_cu = c->num_cu;
+  pc.counters_zeroed = 1;
   if (!hip_ok(xaac_launch_sbr_core_hq(&pc, c->stream))) return XAAC_FATAL_HIP;
   /* 3. parametric stereo: rows 2..33 become the left channel, xr the right one */
   if (with_ps) {
