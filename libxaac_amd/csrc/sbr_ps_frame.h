@@ -99,6 +99,25 @@ FX_HD int32_t xp_bin_power_hyb(const XpTables *T, int bin, const int32_t *re, co
 template <class PS>
 FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_frame *pf, XpFrameWork *w, int32_t *xl,
                       int32_t *xr, int lb_scale, int ov_lb_scale, int hb_scale, int st_syn, int lsb, int usb) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  /* The matrix rows this frame reads before anything rewrites them, fetched now: P1's look-ahead words of QMF bands
+     0..2 (lane = slot) and P3's 32 slots of the lane's band.  Issued ahead of the state rescale and the hybrid
+     filters, their memory latency is covered instead of being paid once per phase and per group of eight slots. */
+  int32_t p1v[3][2], p3re[32], p3im[32];
+  {
+    const int l1 = cx.lane & 31;
+    XP_UNROLL
+    for (int b = 0; b < 3; b++) {
+      p1v[b][0] = xl[(l1 + 6) * 128 + b];
+      p1v[b][1] = xl[(l1 + 6) * 128 + 64 + b];
+    }
+    XP_UNROLL
+    for (int l = 0; l < 32; l++) {
+      p3re[l] = xl[l * 128 + cx.lane];
+      p3im[l] = xl[l * 128 + 64 + cx.lane];
+    }
+  }
+#endif
   const int ps_scale = xp_init_ps_scale(cx, ps, lb_scale, ov_lb_scale, hb_scale); /* sbr_dec.c:1252 */
   const int ov_lb_shift = ps_scale - ov_lb_scale, lb_shift = ps_scale - lb_scale, hb_shift = ps_scale - hb_scale;
   const int common_shift = (st_syn - ps_scale) - 8;
@@ -112,7 +131,11 @@ FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_f
     for (int b = 0; b < 3; b++) {
       const int sha = l + 6 < 32 ? (b < lsb ? lb_shift : (b < usb ? hb_shift : 0)) : 0;
       for (int c = 0; c < 2; c++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        int32_t v = xp_adj_word(p1v[b][c], sha); /* lane = slot l */
+#else
         int32_t v = xp_adj_word(xl[(l + 6) * 128 + 64 * c + b], sha);
+#endif
         v = shiftdelay < 0 ? fx_shl(v, -shiftdelay) : fx_shr(v, shiftdelay);
         w->hyb_u[b][c][12 + l] = v;
       }
@@ -195,14 +218,19 @@ FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_f
   /* ---- P3: band powers (ps_dec.c:520-545).  A lane walks its band through eight slots at a time: the sixteen row
      words of the next eight are in flight while these are worked on. */
   {
-    XP_NOUNROLL
+    XP_UNROLL
     for (int c = 0; c < 4; c++) {
       XS_PAR(sb, 0, 64) {
         int32_t rre[8], rim[8];
         XP_UNROLL
         for (int ls = 0; ls < 8; ls++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+          rre[ls] = p3re[8 * c + ls]; /* lane = band sb */
+          rim[ls] = p3im[8 * c + ls];
+#else
           rre[ls] = xl[(8 * c + ls) * 128 + sb];
           rim[ls] = xl[(8 * c + ls) * 128 + 64 + sb];
+#endif
         }
         const int gsh = sb < 11 ? 0 : (sb < 18 ? 1 : (sb < 23 ? 2 : (sb < 35 ? 3 : 4))); /* group_shift of the band's group */
         XP_UNROLL

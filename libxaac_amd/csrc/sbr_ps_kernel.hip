@@ -96,9 +96,21 @@ __global__ __launch_bounds__(64, 2) void xaac_ps_kernel(XaacPsParams p) {
     int32_t *gx = p.x + (size_t)n * (40 * 128) + 2 * 128; /* slot 0 */
     int32_t *gr = p.xr + (size_t)n * (32 * 128);
     __syncthreads(); /* the previous stream's state has left the LDS copy */
-    copy_words(reinterpret_cast<int32_t *>(&s.ps), reinterpret_cast<const int32_t *>(gps), kHeadWords, lane);
-    copy_words(reinterpret_cast<int32_t *>(&s.pf), reinterpret_cast<const int32_t *>(p.frame + n),
-               sizeof(xaac_ps_frame) / 4, lane);
+    { /* state and side info: all loads in flight before the first LDS store (one memory latency, not one per batch) */
+      constexpr int NS = (kHeadWords + 63) / 64, NF = (sizeof(xaac_ps_frame) / 4 + 63) / 64;
+      int32_t rs[NS], rf[NF];
+      const int32_t *gs = reinterpret_cast<const int32_t *>(gps), *gf = reinterpret_cast<const int32_t *>(p.frame + n);
+#pragma unroll
+      for (int j = 0; j < NS; j++) rs[j] = lane + 64 * j < kHeadWords ? gs[lane + 64 * j] : 0;
+#pragma unroll
+      for (int j = 0; j < NF; j++) rf[j] = lane + 64 * j < (int)(sizeof(xaac_ps_frame) / 4) ? gf[lane + 64 * j] : 0;
+#pragma unroll
+      for (int j = 0; j < NS; j++)
+        if (lane + 64 * j < kHeadWords) reinterpret_cast<int32_t *>(&s.ps)[lane + 64 * j] = rs[j];
+#pragma unroll
+      for (int j = 0; j < NF; j++)
+        if (lane + 64 * j < (int)(sizeof(xaac_ps_frame) / 4)) reinterpret_cast<int32_t *>(&s.pf)[lane + 64 * j] = rf[j];
+    }
     __syncthreads();
 #ifdef XS_PROFILE
     if (lane == 0) xp_prof_last = clock64();

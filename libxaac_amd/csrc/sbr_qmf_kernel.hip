@@ -570,7 +570,7 @@ __global__ __launch_bounds__(128) void xaac_qmf_synthesis_pair_kernel(XaacQmfSyn
         shr[c][ov] = sh < 0 ? -sh : 0;
       }
     }
-    constexpr int XB = 32;
+    constexpr int XB = 64; /* all 64 half rows in flight: one memory latency */
 #pragma unroll
     for (int r0 = 0; r0 < 64; r0 += XB) {
       int32_t tmp[XB];
