@@ -35,6 +35,9 @@ __shared__ long long xp_prof_acc[16];
 #else
 #define XP_T(i)
 #endif
+/* XsCx::sync(): a stream-frame is one wave and what its lanes share is in LDS (matrix words are only ever read back by
+   the lane that wrote them), so producer / consumer order inside the wave is all it takes -- see sbr_core.h */
+#define XS_SYNC_WAVE_LDS 1
 #include "sbr_ps_frame.h"
 #include "sbr_ps_kernel.h"
 
@@ -50,13 +53,25 @@ static_assert(sizeof(xaac_ps_frame) % 4 == 0, "word copies");
 /* the PS constants (a table lookup in global memory costs a serial phase its latency) without the last member, the
    quarter-wave sine table of the envelope borders' coefficient set-up, which is read from global memory */
 constexpr int kTabBytes = offsetof(XpTables, trig_data);
+#ifndef XP_WAVES
+#define XP_WAVES 4
+#endif
+#ifndef XP_WAVES_PER_EU
+#define XP_WAVES_PER_EU 2
+#endif
+constexpr int kPsWaves = XP_WAVES; /* waves (stream-frames in flight) per workgroup: they share the tables' LDS copy */
 struct XpLds {
   XpLdsState ps;
   xaac_ps_frame pf;
   XpFrameWork w;
-  int32_t tabs[(kTabBytes + 3) / 4];
 };
 static_assert(kTabBytes + sizeof(((XpTables *)0)->trig_data) <= sizeof(XpTables), "trig_data is the last member (the word copy may take its first entry along)");
+
+__device__ __forceinline__ void xp_wave_sync() { /* = XsCx::sync() */
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 /* global -> LDS with eight loads in flight (see sbr_core_kernel.hip) */
 __device__ __forceinline__ void copy_words(int32_t *dst, const int32_t *src, int n, int lane) {
@@ -73,18 +88,21 @@ __device__ __forceinline__ void copy_words(int32_t *dst, const int32_t *src, int
 
 }  // namespace
 
-__global__ __launch_bounds__(64, 2) void xaac_ps_kernel(XaacPsParams p) {
-  __shared__ XpLds s;
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(64 * kPsWaves, XP_WAVES_PER_EU) void xaac_ps_kernel(XaacPsParams p) {
+  __shared__ XpLds sw[kPsWaves];
+  __shared__ int32_t s_tabs[(kTabBytes + 3) / 4];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  XpLds &s = sw[wave];
   const XsCx cx = {lane, 64};
-  copy_words(s.tabs, reinterpret_cast<const int32_t *>(&xaac_ps_tables), (kTabBytes + 3) / 4, lane);
-  const XpTables *tabs = reinterpret_cast<const XpTables *>(s.tabs);
+  for (int i = threadIdx.x; i < (kTabBytes + 3) / 4; i += 64 * kPsWaves) s_tabs[i] = reinterpret_cast<const int32_t *>(&xaac_ps_tables)[i];
+  __syncthreads(); /* the only workgroup barrier: from here on the waves run their own streams */
+  const XpTables *tabs = reinterpret_cast<const XpTables *>(s_tabs);
 #ifdef XS_PROFILE
-  if (lane == 0) {
+  if (threadIdx.x == 0) {
     for (int i = 0; i < 16; i++) xp_prof_acc[i] = 0;
   }
 #endif
-  for (int n = blockIdx.x; n < p.n; n += gridDim.x) {
+  for (int n = blockIdx.x * kPsWaves + wave; n < p.n; n += gridDim.x * kPsWaves) {
     if (!(p.sbr_frame[n].apply_processing && p.header[n].channel_mode == 3)) { /* sbr_dec.c:1246: mono this frame */
       if (lane == 0) {
         p.par_l[8 * (size_t)n + 6] = 0;
@@ -95,7 +113,7 @@ __global__ __launch_bounds__(64, 2) void xaac_ps_kernel(XaacPsParams p) {
     xaac_ps_state *gps = p.state + n;
     int32_t *gx = p.x + (size_t)n * (40 * 128) + 2 * 128; /* slot 0 */
     int32_t *gr = p.xr + (size_t)n * (32 * 128);
-    __syncthreads(); /* the previous stream's state has left the LDS copy */
+    xp_wave_sync(); /* the previous stream's state has left the LDS copy */
     { /* state and side info: all loads in flight before the first LDS store (one memory latency, not one per batch) */
       constexpr int NS = (kHeadWords + 63) / 64, NF = (sizeof(xaac_ps_frame) / 4 + 63) / 64;
       int32_t rs[NS], rf[NF];
@@ -111,9 +129,9 @@ __global__ __launch_bounds__(64, 2) void xaac_ps_kernel(XaacPsParams p) {
       for (int j = 0; j < NF; j++)
         if (lane + 64 * j < (int)(sizeof(xaac_ps_frame) / 4)) reinterpret_cast<int32_t *>(&s.pf)[lane + 64 * j] = rf[j];
     }
-    __syncthreads();
+    xp_wave_sync();
 #ifdef XS_PROFILE
-    if (lane == 0) xp_prof_last = clock64();
+    if (threadIdx.x == 0) xp_prof_last = clock64();
 #endif
     const int ps_clamped = xp_frame_sanitize(cx, &s.pf); /* indices a parser cannot produce: contained, reported */
     int16_t *par = p.par_l + 8 * (size_t)n;
@@ -122,7 +140,7 @@ __global__ __launch_bounds__(64, 2) void xaac_ps_kernel(XaacPsParams p) {
     const int ps_scale =
         xp_ps_frame(cx, tabs, &s.ps, &s.pf, &s.w, gx, gr, lb_scale, ov_lb_scale, hb_scale, st_syn, lsb, usb);
     /* ---- state and the two synthesis launches' parameters ---- */
-    __syncthreads();
+    xp_wave_sync();
     {
       int32_t *dst = reinterpret_cast<int32_t *>(gps);
       const int32_t *src = reinterpret_cast<const int32_t *>(&s.ps);
@@ -147,7 +165,7 @@ __global__ __launch_bounds__(64, 2) void xaac_ps_kernel(XaacPsParams p) {
   }
 #ifdef XS_PROFILE
   __syncthreads();
-  if (lane < 16 && p.dbg) atomicAdd(reinterpret_cast<unsigned long long *>(p.dbg) + 32 + lane, (unsigned long long)xp_prof_acc[lane]);
+  if (threadIdx.x < 16 && p.dbg) atomicAdd(reinterpret_cast<unsigned long long *>(p.dbg) + 32 + lane, (unsigned long long)xp_prof_acc[lane]);
 #endif
 }
 
@@ -185,11 +203,11 @@ extern "C" hipError_t xaac_launch_ps(const XaacPsParams *p, hipStream_t stream) 
   if (!resident) {
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, xaac_ps_kernel, 64, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, xaac_ps_kernel, 64 * kPsWaves, 0) != hipSuccess || per_cu < 1) per_cu = 2;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
     resident = per_cu * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
   }
-  const int grid = p->n < resident ? p->n : resident;
-  hipLaunchKernelGGL(xaac_ps_kernel, dim3(grid), dim3(64), 0, stream, *p);
+  const int need = (p->n + kPsWaves - 1) / kPsWaves, grid = need < resident ? need : resident;
+  hipLaunchKernelGGL(xaac_ps_kernel, dim3(grid), dim3(64 * kPsWaves), 0, stream, *p);
   return hipGetLastError();
 }
