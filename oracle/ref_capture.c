@@ -11,6 +11,7 @@
  * own structs through the reference's own headers.
  */
 #include "ref_convert.h"
+#include "ixheaacd_audioobjtypes.h"
 
 
 static FILE *g_out;
@@ -21,6 +22,252 @@ WORD32 __real_ixheaacd_sbr_dec(ia_sbr_dec_struct *, WORD16 *, ia_sbr_header_data
                                ia_sbr_qmf_filter_bank_struct *, ia_sbr_scale_fact_struct *, FLAG, FLAG, WORD32 *,
                                ia_sbr_tables_struct *, ixheaacd_misc_tables *, WORD, ia_pvc_data_struct *, FLAG,
                                WORD32[][64], WORD32, WORD32, VOID *, WORD32, WORD32);
+
+/* ---- reference-made chains of the Path A (eSBR) branch, tools/make_golden_esbr_chains.py --------------------------
+   With $XAAC_ESBR_CHAIN_FILE set, every ixheaacd_sbr_dec call that takes the eSBR branch (the condition of
+   oracle/ref_dropin.c) is turned into a chain step: the reference's own live side info is fuzzed in place within the
+   ranges a bitstream can carry ($XAAC_ESBR_CHAIN_SEED; 0 = left as parsed), the float core input is replaced by a
+   counter-based synthetic frame (the same integer generator the tests use), the REAL function runs on the reference's
+   own carried state, and the step is written out in the boundary formats: header / frame / side / PS frame, the
+   return code, CRC32s of both outputs and of the states after the call (full states only before a chain's first
+   step).  A chain = one channel (one ia_sbr_dec_struct) of one decoder run. */
+static uint32_t crc32_buf(const void *p, size_t n) {
+  static uint32_t tab[256];
+  const uint8_t *b = (const uint8_t *)p;
+  uint32_t c = 0xffffffffu;
+  size_t i;
+  if (!tab[1]) {
+    uint32_t k, j;
+    for (k = 0; k < 256; k++) {
+      uint32_t v = k;
+      for (j = 0; j < 8; j++) v = (v & 1) ? 0xedb88320u ^ (v >> 1) : v >> 1;
+      tab[k] = v;
+    }
+  }
+  for (i = 0; i < n; i++) c = tab[(c ^ b[i]) & 255] ^ (c >> 8);
+  return c ^ 0xffffffffu;
+}
+static uint64_t g_rng;
+static uint32_t rnd(uint32_t n) { /* splitmix64 */
+  uint64_t z = (g_rng += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)((z >> 20) % n);
+}
+/* tests/ regenerate this: 1024 core samples of (chain, step) -- tools/make_golden_sbr_chains.py: chain_pcm(kind = 2) */
+static void chain_core(int run, int chain, int step, float *dst) {
+  static const int amps[6] = {30000, 3000, 12000, 200, 800, 32767};
+  const uint64_t c = (uint64_t)(run * 32 + chain);
+  const uint64_t base = (((uint64_t)2 << 40) | (c << 20) | (uint64_t)step) * 1024u;
+  int i;
+  for (i = 0; i < 1024; i++) {
+    uint64_t z = (base + (uint64_t)i + 1u) * 0x9E3779B97F4A7C15ull;
+    int64_t v;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    v = (int64_t)(z >> 40) - (1 << 23);
+    dst[i] = (float)(int16_t)((v * amps[(c + (uint64_t)step) % 6]) >> 23);
+  }
+}
+static int esbr_path(const ia_sbr_dec_struct *d, const ia_sbr_header_data_struct *h, const ia_sbr_frame_info_data_struct *f,
+                     const ia_ps_dec_struct *ps, const ia_sbr_qmf_filter_bank_struct *synth_r, FLAG drc_on, WORD32 aot,
+                     WORD32 ldmps, WORD32 mps) {
+  return h->enh_sbr && aot != AOT_ER_AAC_ELD && aot != AOT_ER_AAC_LD && !h->usac_flag && h->hbe_flag && d->p_hbe_txposer != NULL &&
+         !h->esbr_hq &&
+         (h->channel_mode == PS_STEREO ? (ps != NULL && synth_r != NULL && !ps->use_34_st_bands && !ps->use_pca_rot_flg && ps->ps_mode == 0)
+                                       : !h->enh_sbr_ps) &&
+         !drc_on && !ldmps && !mps && !f->mps_sbr_flag && f->sbr_mode != PVC_SBR && h->sbr_ratio_idx != SBR_UPSAMPLE_IDX_4_1 &&
+         !h->pre_proc_flag && h->num_time_slots == 16 && d->str_codec_qmf_bank.no_channels == 32 &&
+         d->str_synthesis_qmf_bank.no_channels == 64;
+}
+static WORD32 esbr_chain_call(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_header_data_struct *h,
+                              ia_sbr_frame_info_data_struct *f, ia_sbr_prev_frame_data_struct *p, ia_ps_dec_struct *ps,
+                              ia_sbr_qmf_filter_bank_struct *synth_r, ia_sbr_scale_fact_struct *sf_r, FLAG apply, FLAG low_pow,
+                              WORD32 *work, ia_sbr_tables_struct *tabs, ixheaacd_misc_tables *common, WORD ch_fac,
+                              ia_pvc_data_struct *pvc, FLAG drc_on, WORD32 drc[][64], WORD32 aot, WORD32 ldmps, VOID *self,
+                              WORD32 mps, WORD32 ec) {
+  static FILE *out;
+  static ia_sbr_dec_struct *chains[32]; /* chain -> channel; a channel's newest chain is the live one */
+  static int steps[32], n_chains, run, seed;
+  static uint32_t last_crc[32][3];
+  static xaac_sbr_header hd;
+  static xaac_sbr_frame fr;
+  static xaac_esbr_side sd;
+  static xaac_esbr_state est;
+  static xaac_esbr_ps_state epss;
+  static xaac_hbe_state hbs;
+  static xaac_ps_frame psf;
+  const ia_qmf_dec_tables_struct *q = tabs->qmf_dec_tables_ptr;
+  const int eps = h->channel_mode == PS_STEREO;
+  int32_t meta[16];
+  WORD32 ret;
+  int c, i, first;
+  if (!out) {
+    out = fopen(getenv("XAAC_ESBR_CHAIN_FILE"), "wb");
+    seed = getenv("XAAC_ESBR_CHAIN_SEED") ? atoi(getenv("XAAC_ESBR_CHAIN_SEED")) : 0;
+    run = getenv("XAAC_ESBR_CHAIN_RUN") ? atoi(getenv("XAAC_ESBR_CHAIN_RUN")) : 0;
+    g_rng = 0x1234567ull * (uint64_t)(seed + 1);
+  }
+  /* the pointer re-basing the branch does on entry (sbr_dec.c:578-580), so that the recorded offsets are the call's */
+  if (eps) {
+    synth_r->filter_pos_syn_32 += q->esbr_qmf_c - synth_r->p_filter_32;
+    synth_r->p_filter_32 = q->esbr_qmf_c;
+  }
+  d->str_synthesis_qmf_bank.filter_pos_syn_32 += q->esbr_qmf_c - d->str_synthesis_qmf_bank.p_filter_32;
+  d->str_synthesis_qmf_bank.p_filter_32 = q->esbr_qmf_c;
+  to_esbr_state(d, h, f, &est);
+  to_hbe_state(d->p_hbe_txposer, &hbs);
+  if (eps) to_esbr_ps_state(ps, synth_r, &epss);
+  for (c = n_chains - 1; c >= 0 && chains[c] != d; c--) {}
+  /* the decoder's own layers may touch the state between two calls (sync-state changes, header resets re-create the
+     banks and the transposer): a chain only lasts while the state found equals the state left */
+  if (c >= 0 && (last_crc[c][0] != crc32_buf(&est, sizeof(est)) || last_crc[c][1] != crc32_buf(&hbs, sizeof(hbs)) ||
+                 (eps && last_crc[c][2] != crc32_buf(&epss, sizeof(epss))))) {
+    if (getenv("XAAC_ESBR_CHAIN_DEBUG")) {
+      static xaac_esbr_state keep[32];
+      fprintf(stderr, "chain %d breaks after %d steps: est %d hbs %d eps %d\n", c, steps[c], last_crc[c][0] != crc32_buf(&est, sizeof(est)),
+              last_crc[c][1] != crc32_buf(&hbs, sizeof(hbs)), eps && last_crc[c][2] != crc32_buf(&epss, sizeof(epss)));
+    }
+    c = -1;
+  }
+  if (c < 0) {
+    if (n_chains == 32) return __real_ixheaacd_sbr_dec(d, time_data, h, f, p, ps, synth_r, sf_r, apply, low_pow, work, tabs, common,
+                                                       ch_fac, pvc, drc_on, drc, aot, ldmps, self, mps, ec);
+    c = n_chains++;
+    chains[c] = d;
+  }
+  first = steps[c] == 0 || getenv("XAAC_ESBR_CHAIN_FULL") != NULL;
+  /* -- reference-side fuzz: only what a bitstream can say, on the reference's own structs; the fuzzed members are put
+     back after the call (the parser decodes the next frame's PS indices and header fields relative to its own) -- */
+  static ia_sbr_header_data_struct h_keep;
+  static ia_sbr_frame_info_data_struct f_keep;
+  static ia_ps_dec_struct ps_keep;
+  h_keep = *h;
+  f_keep = *f;
+  if (eps) ps_keep = *ps;
+  if (seed && apply) {
+    const ia_freq_band_data_struct *fb = h->pstr_freq_band_data;
+    if (rnd(3) == 0) h->limiter_gains = (WORD16)rnd(4);
+    if (rnd(3) == 0) h->interpol_freq = (WORD16)rnd(2);
+    if (rnd(3) == 0) h->smoothing_mode = (WORD16)rnd(2);
+    if (rnd(4) == 0) h->limiter_bands = (WORD16)rnd(4);
+    if (rnd(2) == 0)
+      for (i = 0; i < fb->num_if_bands; i++) f->sbr_invf_mode[i] = (WORD32)rnd(4);
+    i = (int)rnd(4);
+    if (i == 0)
+      for (i = 0; i < fb->num_sf_bands[1]; i++) f->add_harmonics[i] = rnd(4) == 0;
+    else if (i == 1)
+      for (i = 0; i < fb->num_sf_bands[1]; i++) f->add_harmonics[i] = 0;
+    if (rnd(3) == 0)
+      for (i = 0; i < f->str_frame_info_details.num_env; i++) f->inter_temp_shape_mode[i] = (WORD32)rnd(2);
+    if (rnd(4) != 0) { /* harmonic patching on / off, with and without a pitch (env_extr.c:610-632: 7 bits) */
+      f->sbr_patching_mode = (WORD32)rnd(2);
+      f->pitch_in_bins = f->sbr_patching_mode == 0 && rnd(2) ? (WORD32)rnd(128) : 0;
+    }
+    if (steps[c] > 2 && rnd(9) == 0) f->reset_flag = 1;
+    if (eps && rnd(3) != 0) { /* PS: quantiser, 1..4 envelopes with random borders, random IID / ICC indices */
+      int nenv = 1 + (int)rnd(4), lim, b, e;
+      int bord[6] = {0, 0, 0, 0, 0, 0};
+      ps->iid_quant = (FLAG)rnd(2);
+      lim = ps->iid_quant ? 15 : 7;
+      for (e = 1; e < nenv; e++) { /* strictly increasing borders in 1..31 */
+        int lo = bord[e - 1] + 1, hi = 31 - (nenv - 1 - e);
+        bord[e] = lo + (int)rnd((uint32_t)(hi - lo + 1));
+      }
+      bord[nenv] = 32;
+      ps->num_env = (WORD16)nenv;
+      for (e = 0; e <= nenv; e++) ps->border_position[e] = (WORD16)bord[e];
+      for (e = 0; e < nenv; e++)
+        for (b = 0; b < 34; b++) {
+          ps->iid_par_table[e][b] = (WORD16)((int)rnd((uint32_t)(2 * lim + 1)) - lim);
+          ps->icc_par_table[e][b] = (WORD16)rnd(8);
+        }
+    }
+  }
+  chain_core(run, c, steps[c], d->time_sample_buf);
+  to_header(h, d, &hd);
+  to_frame(f, apply, &fr);
+  to_esbr_side(h, f, &sd);
+  memset(&psf, 0, sizeof(psf));
+  if (eps) to_ps_frame(ps, &psf);
+  memset(meta, 0, sizeof(meta));
+  meta[0] = 0x58414332; /* "XAC2" */
+  meta[1] = c;
+  meta[2] = steps[c];
+  meta[3] = eps;
+  meta[4] = first;
+  meta[5] = apply;
+  fwrite(meta, 4, 6, out);
+  if (first) { /* the states the chain starts from */
+    fwrite(&est, sizeof(est), 1, out);
+    fwrite(&hbs, sizeof(hbs), 1, out);
+    if (eps) fwrite(&epss, sizeof(epss), 1, out);
+  }
+  fwrite(&hd, sizeof(hd), 1, out);
+  fwrite(&fr, sizeof(fr), 1, out);
+  fwrite(&sd, sizeof(sd), 1, out);
+  fwrite(&psf, sizeof(psf), 1, out);
+  ret = __real_ixheaacd_sbr_dec(d, time_data, h, f, p, ps, synth_r, sf_r, apply, low_pow, work, tabs, common, ch_fac, pvc,
+                                drc_on, drc, aot, ldmps, self, mps, ec);
+  to_esbr_state(d, h, f, &est);
+  to_hbe_state(d->p_hbe_txposer, &hbs);
+  if (seed && apply) {
+    h->limiter_gains = h_keep.limiter_gains;
+    h->interpol_freq = h_keep.interpol_freq;
+    h->smoothing_mode = h_keep.smoothing_mode;
+    h->limiter_bands = h_keep.limiter_bands;
+    memcpy(f->sbr_invf_mode, f_keep.sbr_invf_mode, sizeof(f->sbr_invf_mode));
+    memcpy(f->add_harmonics, f_keep.add_harmonics, sizeof(f->add_harmonics));
+    memcpy(f->inter_temp_shape_mode, f_keep.inter_temp_shape_mode, sizeof(f->inter_temp_shape_mode));
+    f->sbr_patching_mode = f_keep.sbr_patching_mode;
+    f->pitch_in_bins = f_keep.pitch_in_bins;
+    if (eps) {
+      ps->iid_quant = ps_keep.iid_quant;
+      ps->num_env = ps_keep.num_env;
+      memcpy(ps->border_position, ps_keep.border_position, sizeof(ps->border_position));
+      memcpy(ps->iid_par_table, ps_keep.iid_par_table, sizeof(ps->iid_par_table));
+      memcpy(ps->icc_par_table, ps_keep.icc_par_table, sizeof(ps->icc_par_table));
+    }
+  }
+  meta[0] = ret;
+  meta[1] = (int32_t)crc32_buf(eps ? ps->time_sample_buf[0] : d->time_sample_buf, 2048 * sizeof(float));
+  meta[2] = (eps && apply) ? (int32_t)crc32_buf(ps->time_sample_buf[1], 2048 * sizeof(float)) : 0;
+  last_crc[c][0] = crc32_buf(&est, sizeof(est)); /* continuity is judged on the whole state */
+  { /* The CRC the tests compare: sbr_qmf_out entries no later call can read are left out.  The reference's 64-row output
+       matrix keeps whatever earlier frames left above the rows this frame produced (rows from 2 + 2 * border_vec[num_env]
+       on) and below the cross-over band, where the synthesis takes the low band from qmf_buf (sbr_dec.c:365-395); a
+       frame-by-frame implementation that rebuilds the matrix from its eight carried rows has zeros there. */
+    static xaac_esbr_state canon;
+    const int kx = h->pstr_freq_band_data->sub_band_start;
+    const int nenv = f->str_frame_info_details.num_env;
+    int keep = apply ? 2 + 2 * f->str_frame_info_details.border_vec[nenv] - 32 : XAAC_ESBR_OUT_HIST_ROWS, r, k;
+    canon = est;
+    for (r = 0; r < XAAC_ESBR_OUT_HIST_ROWS; r++)
+      for (k = 0; k < 64; k++)
+        if (r >= keep || k < kx) canon.out_re[r][k] = canon.out_im[r][k] = 0.0f;
+    meta[3] = (int32_t)crc32_buf(&canon, sizeof(canon));
+  }
+  meta[4] = (int32_t)crc32_buf(&hbs, sizeof(hbs));
+  meta[5] = 0;
+  if (eps) {
+    to_esbr_ps_state(ps, synth_r, &epss);
+    meta[5] = (int32_t)crc32_buf(&epss, sizeof(epss));
+  }
+  last_crc[c][1] = (uint32_t)meta[4];
+  last_crc[c][2] = (uint32_t)meta[5];
+  fwrite(meta, 4, 6, out);
+  if (getenv("XAAC_ESBR_CHAIN_FULL")) { /* debugging aid: the whole states after the call */
+    fwrite(&est, sizeof(est), 1, out);
+    fwrite(&hbs, sizeof(hbs), 1, out);
+    if (eps) fwrite(&epss, sizeof(epss), 1, out);
+    fwrite(eps ? ps->time_sample_buf[0] : d->time_sample_buf, 4, 2048, out);
+  }
+  fflush(out);
+  steps[c]++;
+  return ret;
+}
 
 WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_header_data_struct *h,
                                ia_sbr_frame_info_data_struct *f, ia_sbr_prev_frame_data_struct *p,
@@ -38,6 +285,9 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
   int32_t meta[8];
   WORD32 ret;
   int i, ps_on = (apply && h->channel_mode == PS_STEREO);
+  if (getenv("XAAC_ESBR_CHAIN_FILE") && esbr_path(d, h, f, ps, synth_r, drc_on, aot, ldmps, mps))
+    return esbr_chain_call(d, time_data, h, f, p, ps, synth_r, sf_r, apply, low_pow, work, tabs, common, ch_fac, pvc, drc_on, drc,
+                           aot, ldmps, self, mps, ec);
   if (!g_out) {
     const char *path = getenv("XAAC_CAPTURE_FILE");
     g_out = fopen(path ? path : "/tmp/xaac_capture.bin", "wb");

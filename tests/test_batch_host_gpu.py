@@ -24,7 +24,7 @@ def _md5(path):
 
 def _need():
     if not all(os.path.exists(os.path.join(REF, b)) for b in ("xaacdec", "xaacdec_batch")):
-        pytest.skip("oracle/_ref/xaacdec[_batch] missing (built by oracle/Makefile.ref where /root/reference exists)")
+        pytest.fail("oracle/_ref/xaacdec[_batch] missing: the reference binaries (built by oracle/Makefile.ref where /root/reference exists, git-ignored) did not travel with the snapshot -- the batched-host evidence must not vanish silently")
 
 
 def run_batch(tmp_path, groups, timeout=900, flags=("-esbr:0",)):

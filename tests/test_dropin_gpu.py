@@ -24,7 +24,7 @@ def _decode(binary, aac, out, extra=("-esbr:0",), env=None):
 @pytest.mark.parametrize("aac", STREAMS, ids=[os.path.basename(s) for s in STREAMS])
 def test_reference_decoder_with_gpu_back_end_is_byte_identical(aac, tmp_path):
     if not (os.path.exists(os.path.join(REF, "xaacdec")) and os.path.exists(os.path.join(REF, "xaacdec_dropin"))):
-        pytest.skip("oracle/_ref/xaacdec[_dropin] missing (built by oracle/Makefile.ref where /root/reference exists)")
+        pytest.fail("oracle/_ref/xaacdec[_dropin] missing: the reference binaries (built by oracle/Makefile.ref where /root/reference exists, git-ignored) did not travel with the snapshot -- the drop-in evidence must not vanish silently")
     ref_wav, gpu_wav = str(tmp_path / "ref.wav"), str(tmp_path / "gpu.wav")
     _decode("xaacdec", aac, ref_wav)
     log = _decode("xaacdec_dropin", aac, gpu_wav)
@@ -47,7 +47,7 @@ def test_default_flags_he_aac_takes_the_esbr_path_on_the_gpu(aac, tmp_path):
     bank, float HF generator and envelope adjuster, [float parametric stereo,] 64-band synthesis bank(s) -- runs on the GPU
     (xaac_esbr_sbr_process_batch) and the decoded file is byte-identical to the unmodified reference decoder's."""
     if not (os.path.exists(os.path.join(REF, "xaacdec")) and os.path.exists(os.path.join(REF, "xaacdec_dropin"))):
-        pytest.skip("oracle/_ref/xaacdec[_dropin] missing (built by oracle/Makefile.ref where /root/reference exists)")
+        pytest.fail("oracle/_ref/xaacdec[_dropin] missing: the reference binaries (built by oracle/Makefile.ref where /root/reference exists, git-ignored) did not travel with the snapshot -- the drop-in evidence must not vanish silently")
     ref_wav, gpu_wav = str(tmp_path / "ref.wav"), str(tmp_path / "gpu.wav")
     _decode("xaacdec", aac, ref_wav, extra=())
     log = _decode("xaacdec_dropin", aac, gpu_wav, extra=())
@@ -80,7 +80,7 @@ def test_other_frame_lengths_through_the_gpu(aac, flags, tmp_path):
     low-delay SBR (the reference's code) the two complex QMF banks are diverted to xaac_qmf_analysis_eld_batch /
     xaac_qmf_synthesis_eld_batch."""
     if not (os.path.exists(os.path.join(REF, "xaacdec")) and os.path.exists(os.path.join(REF, "xaacdec_dropin"))):
-        pytest.skip("oracle/_ref/xaacdec[_dropin] missing (built by oracle/Makefile.ref where /root/reference exists)")
+        pytest.fail("oracle/_ref/xaacdec[_dropin] missing: the reference binaries (built by oracle/Makefile.ref where /root/reference exists, git-ignored) did not travel with the snapshot -- the drop-in evidence must not vanish silently")
     meta = aac[:-4] + ".txt"
     extra = tuple(flags) + (("-mp4:1", "-imeta:" + meta) if os.path.exists(meta) else ())
     ref_wav, gpu_wav = str(tmp_path / "ref.wav"), str(tmp_path / "gpu.wav")

@@ -1,0 +1,140 @@
+"""tests/golden/esbr_chains.npz: 1451 calls of the REAL ixheaacd_sbr_dec taking its eSBR branch ("Path A": the reference's
+default -esbr:1 path for HE-AAC / HE-AACv2), made by tools/make_golden_esbr_chains.py as 48 chains (one channel of one run
+of the reference decoder over a committed stream) with reference-side fuzz of the live side info -- limiter gains and
+bands, interpolation, smoothing, inverse-filter modes, added harmonics, inter-TES, harmonic patching with and without a
+pitch, reset frames, PS quantiser / 1-4 envelopes / IID / ICC -- and the state carried by the reference itself.  Stored
+per step: side info in the boundary formats, the return code, CRC32s of out / out_r and of the eSBR, transposer and PS
+states after the call; the float core input is regenerated here (counter-based integer generator).
+  * CPU: the oracle's whole-frame function walks every chain (its own state carried) and must reproduce every CRC;
+  * GPU (-m gpu): xaac_esbr_sbr_process_batch walks all chains as one batch with the three states resident on the device:
+    the device builds of the float HF generator, envelope adjuster, float PS and transposer-in-chain meet reference data
+    directly (the float words, not +-1 LSB), not via the oracle."""
+import ctypes
+import os
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from make_golden_esbr_chains import chain_core  # noqa: E402  (the generator's own input function: data, not reference code)
+
+PF = ctypes.POINTER(ctypes.c_float)
+CH = np.load(os.path.join(ROOT, "tests", "golden", "esbr_chains.npz"))
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xffffffff
+
+
+def vp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def state_crc(st, header, frame, apply):
+    """CRC32 of an xaac_esbr_state without the sbr_qmf_out history entries no later call can read (rows from the frame's
+    last border on, bands below the cross-over): the reference's persistent 64-row matrix holds stale values there, a
+    frame-by-frame implementation zeros -- oracle/ref_capture.c masks the same entries before its CRC"""
+    from esbr_structs import EsbrState
+    import sbr_capture as cap
+    h = cap.Header.from_buffer_copy(header.tobytes())
+    f = cap.Frame.from_buffer_copy(frame.tobytes())
+    keep = 2 + 2 * f.border_vec[f.num_env] - 32 if apply else 8
+    b = np.array(st, copy=True)
+    for name in ("out_re", "out_im"):
+        fld = getattr(EsbrState, name)
+        m = b[fld.offset:fld.offset + fld.size].view(np.float32).reshape(8, 64)
+        m[max(keep, 0):, :] = 0
+        m[:, :h.sub_band_start] = 0
+    return crc(b)
+
+
+def steps_of_chains():
+    sc, si = CH["step_chain"], CH["step_idx"]
+    order = [np.nonzero(sc == c)[0] for c in range(len(CH["chain_len"]))]
+    for c, rows in enumerate(order):
+        assert np.array_equal(si[rows], np.arange(len(rows))) and len(rows) == CH["chain_len"][c]
+    return order
+
+
+def test_fixture_is_what_it_says():
+    assert CH["ret"].size >= 1000 and not CH["ret"].any()
+    from esbr_structs import EsbrSide
+    harm = CH["side"].view(np.int16)[:, EsbrSide.harmonic_sbr.offset // 2]
+    pitch = CH["side"].view(np.int32)[:, EsbrSide.pitch_in_bins.offset // 4]
+    proc = CH["apply"] != 0
+    assert (harm[proc] != 0).sum() > 300 and ((harm != 0) & (pitch != 0) & proc).sum() > 100
+    assert (CH["chain_ps"] != 0).sum() >= 4
+
+
+def test_oracle_walks_the_reference_chains(oracle):
+    fn = oracle.lib.xo_esbr_sbr_frame_hbe
+    fn.restype = ctypes.c_int
+    fn.argtypes = [PF] + [ctypes.c_void_p] * 6 + [PF, PF, ctypes.c_void_p]
+    for c, rows in enumerate(steps_of_chains()):
+        run, cid, eps = int(CH["chain_run"][c]), int(CH["chain_id"][c]), bool(CH["chain_ps"][c])
+        st, hb, ps = CH["est0"][c].copy(), CH["hbs0"][c].copy(), CH["eps0"][c].copy()
+        for s, r in enumerate(rows):
+            core = np.ascontiguousarray(chain_core(run, cid, s))
+            out, out_r = np.zeros(2048, np.float32), np.zeros(2048, np.float32)
+            h, f, sd, pf = (np.ascontiguousarray(CH[k][r]) for k in ("header", "frame", "side", "ps_frame"))
+            rc = fn(core.ctypes.data_as(PF), vp(h), vp(f), vp(sd), vp(st), vp(pf) if eps else None, vp(ps) if eps else None,
+                    out.ctypes.data_as(PF), out_r.ctypes.data_as(PF) if eps else None, vp(hb))
+            want = CH["crc"][r]
+            assert rc == CH["ret"][r], (c, s)
+            assert crc(out) == want[0], ("out", c, s)
+            if eps and CH["apply"][r]:
+                assert crc(out_r) == want[1], ("out_r", c, s)
+            assert state_crc(st, h, f, CH["apply"][r]) == want[2], ("state", c, s)
+            assert crc(hb) == want[3], ("transposer state", c, s)
+            if eps:
+                assert crc(ps) == want[4], ("ps state", c, s)
+
+
+@pytest.mark.gpu
+def test_gpu_walks_the_reference_chains():
+    import torch
+    import libxaac_amd
+    ctx = libxaac_amd.XaacContext(0, 0)
+    dev = torch.device("cuda:0")
+    order = steps_of_chains()
+    for with_ps in (False, True):      # the PS streams form their own batch (ps_frame / ps_state / out_r are per launch)
+        chains = [c for c in range(len(order)) if bool(CH["chain_ps"][c]) == with_ps]
+        n = len(chains)
+        t_st = torch.from_numpy(np.ascontiguousarray(CH["est0"][chains])).to(dev)
+        t_hb = torch.from_numpy(np.ascontiguousarray(CH["hbs0"][chains])).to(dev)
+        t_ps = torch.from_numpy(np.ascontiguousarray(CH["eps0"][chains])).to(dev) if with_ps else None
+        for s in range(max(len(order[c]) for c in chains)):
+            act = [i for i, c in enumerate(chains) if s < len(order[c])]      # chains that still have a step s
+            rows = [order[chains[i]][s] for i in act]
+            m = len(act)
+            idx = torch.tensor(act, device=dev)
+            core = torch.from_numpy(np.stack([chain_core(int(CH["chain_run"][chains[i]]), int(CH["chain_id"][chains[i]]), s) for i in act])).to(dev)
+            g = lambda k: torch.from_numpy(np.ascontiguousarray(CH[k][rows])).to(dev)
+            st, hb = t_st[idx].contiguous(), t_hb[idx].contiguous()
+            ps = t_ps[idx].contiguous() if with_ps else None
+            out = torch.zeros((m, 2048), dtype=torch.float32, device=dev)
+            out_r = torch.zeros((m, 2048), dtype=torch.float32, device=dev) if with_ps else None
+            status = torch.full((m,), 7, dtype=torch.int32, device=dev)
+            ws = torch.zeros(ctx.esbr_workspace_bytes(m), dtype=torch.uint8, device=dev)
+            ctx.esbr_sbr_process_batch(core, g("header"), g("frame"), g("side"), st, out, ws, status,
+                                       ps_frame=g("ps_frame") if with_ps else None, ps_state=ps, out_r=out_r, hbe_state=hb)
+            ctx.sync()
+            t_st[idx], t_hb[idx] = st, hb
+            if with_ps:
+                t_ps[idx] = ps
+            assert np.array_equal(status.cpu().numpy(), CH["ret"][rows]), s
+            o, orr = out.cpu().numpy(), (out_r.cpu().numpy() if with_ps else None)
+            stn, hbn, psn = st.cpu().numpy(), hb.cpu().numpy(), (ps.cpu().numpy() if with_ps else None)
+            for j, r in enumerate(rows):
+                want = CH["crc"][r]
+                assert crc(o[j]) == want[0], ("out", chains[act[j]], s)
+                if with_ps and CH["apply"][r]:
+                    assert crc(orr[j]) == want[1], ("out_r", chains[act[j]], s)
+                assert state_crc(stn[j], CH["header"][r], CH["frame"][r], CH["apply"][r]) == want[2], ("state", chains[act[j]], s)
+                assert crc(hbn[j]) == want[3], ("transposer state", chains[act[j]], s)
+                if with_ps:
+                    assert crc(psn[j]) == want[4], ("ps state", chains[act[j]], s)
+    ctx.close()

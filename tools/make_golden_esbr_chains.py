@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Build tests/golden/esbr_chains.npz: >= 1000 steps of the REAL ixheaacd_sbr_dec taking its eSBR branch ("Path A",
+sbr_dec.c:816-1009: analysis with 32-bit rings, QMF harmonic transposer, float HF generator + envelope adjuster, float
+parametric stereo, synthesis) as CHAINS whose state the reference carries itself.
+
+oracle/_ref/xaacdec_capture (oracle/ref_capture.c: esbr_chain_call) decodes the committed HE-AAC streams several times;
+at every eSBR call it fuzzes the reference's own live side info within what a bitstream can say (limiter gains / bands,
+interpolation, smoothing, inverse-filter modes, added harmonics, inter-TES, harmonic patching with and without a pitch,
+resets, PS quantiser / 1-4 envelopes / IID / ICC indices), replaces the core input by a counter-based synthetic frame
+(chain_core() below regenerates it: nothing is stored), runs the real function and writes the step in the boundary
+formats of include/xaac_esbr.h: side info, return code, CRC32s of out / out_r and of the three states after the call.
+A chain = one channel of one decoder run.  Data only; runs only where /root/reference exists."""
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from make_golden_sbr_chains import chain_pcm  # noqa: E402
+
+# (harm_aot5_48k.aac is left to tests/test_dropin_gpu.py: the reference's outer layers re-initialise that stream's banks and
+# transposer between almost all calls, so it yields chains of one or two steps; harmonic patching and inter-TES come
+# from the fuzz here)
+STREAMS = ("mix_aot5_48k", "mono_aot5_32k", "mix_aot29_32k")
+PASSES = 10           # decoder runs per stream; pass 0 is unfuzzed
+
+
+def chain_core(run, chain, step):
+    """the float core frame of (run, chain-in-run, step): the integers of chain_pcm(kind 2) as floats"""
+    return chain_pcm(2, run * 32 + chain, step).astype(np.float32)
+
+
+def sizes():
+    import ctypes
+    import esbr_structs as es
+    import hbe_structs as hs
+    import sbr_capture as c
+    return dict(hd=ctypes.sizeof(c.Header), fr=ctypes.sizeof(c.Frame), sd=ctypes.sizeof(es.EsbrSide), psf=ctypes.sizeof(c.PsFrame),
+                est=ctypes.sizeof(es.EsbrState), hbs=ctypes.sizeof(hs.HbeState), eps=ctypes.sizeof(es.EsbrPsState))
+
+
+def parse(path, run, z):
+    b = open(path, "rb").read()
+    o, recs = 0, []
+    while o < len(b):
+        magic, chain, step, eps, first, apply = struct.unpack_from("<6i", b, o)
+        assert magic == 0x58414332, hex(magic)
+        o += 24
+        r = dict(run=run, chain=chain, step=step, eps=eps, first=first, apply=apply)
+        if first:
+            r["est0"] = b[o:o + z["est"]]; o += z["est"]
+            r["hbs0"] = b[o:o + z["hbs"]]; o += z["hbs"]
+            if eps:
+                r["eps0"] = b[o:o + z["eps"]]; o += z["eps"]
+        for k in ("hd", "fr", "sd", "psf"):
+            r[k] = b[o:o + z[k]]; o += z[k]
+        r["ret"], *crcs = struct.unpack_from("<i5I", b, o)
+        r["crc"] = crcs
+        o += 24
+        recs.append(r)
+    return recs
+
+
+def main():
+    z = sizes()
+    cap = os.path.join(ROOT, "oracle", "_ref", "xaacdec_capture")
+    recs = []
+    run = 0
+    for p in range(PASSES):
+        for s in STREAMS:
+            tmp = "/tmp/xaac_esbr_chain_%d.bin" % run
+            env = dict(os.environ, XAAC_ESBR_CHAIN_FILE=tmp, XAAC_ESBR_CHAIN_SEED=str(0 if p == 0 else 100 * p + run),
+                       XAAC_ESBR_CHAIN_RUN=str(run))
+            subprocess.run([cap, "-ifile:" + os.path.join(ROOT, "tests", "golden", "streams", s + ".aac"), "-ofile:/tmp/xaac_esbr_chain.wav"],
+                           env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            recs += parse(tmp, run, z)
+            os.remove(tmp)
+            run += 1
+    chains = sorted({(r["run"], r["chain"]) for r in recs})
+    cidx = {c: i for i, c in enumerate(chains)}
+    n, nc = len(recs), len(chains)
+    u8 = lambda x, size: np.frombuffer(x, np.uint8) if x is not None else np.zeros(size, np.uint8)
+    d = {
+        "chain_run": np.array([c[0] for c in chains], np.int32), "chain_id": np.array([c[1] for c in chains], np.int32),
+        "chain_ps": np.zeros(nc, np.int32), "chain_len": np.zeros(nc, np.int32),
+        "est0": np.zeros((nc, z["est"]), np.uint8), "hbs0": np.zeros((nc, z["hbs"]), np.uint8), "eps0": np.zeros((nc, z["eps"]), np.uint8),
+        "step_chain": np.array([cidx[(r["run"], r["chain"])] for r in recs], np.int32),
+        "step_idx": np.array([r["step"] for r in recs], np.int32), "apply": np.array([r["apply"] for r in recs], np.int32),
+        "ret": np.array([r["ret"] for r in recs], np.int32), "crc": np.array([r["crc"] for r in recs], np.uint32),
+        "header": np.stack([u8(r["hd"], 0) for r in recs]), "frame": np.stack([u8(r["fr"], 0) for r in recs]),
+        "side": np.stack([u8(r["sd"], 0) for r in recs]), "ps_frame": np.stack([u8(r["psf"], 0) for r in recs]),
+    }
+    for r in recs:
+        i = cidx[(r["run"], r["chain"])]
+        d["chain_len"][i] += 1
+        d["chain_ps"][i] = r["eps"]
+        if r["first"]:
+            d["est0"][i] = u8(r["est0"], 0)
+            d["hbs0"][i] = u8(r["hbs0"], 0)
+            if r["eps"]:
+                d["eps0"][i] = u8(r["eps0"], 0)
+    dst = os.path.join(ROOT, "tests", "golden", "esbr_chains.npz")
+    np.savez_compressed(dst, **d)
+    from esbr_structs import EsbrSide
+    harm = sum(1 for r in recs if r["apply"] and np.frombuffer(r["sd"], np.int16)[EsbrSide.harmonic_sbr.offset // 2] != 0)
+    print(dst, os.path.getsize(dst), "bytes;", n, "steps in", nc, "chains;", int(d["ret"].astype(bool).sum()), "steps returned an error;",
+          int(d["apply"].sum()), "processed;", harm, "with harmonic patching")
+
+
+if __name__ == "__main__":
+    main()
