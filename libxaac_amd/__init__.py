@@ -159,6 +159,7 @@ class _EsbrSynBatch(ctypes.Structure):
                 ("state", ctypes.c_void_p), ("out", ctypes.c_void_p)]
 
 
+ESBR_SIDE_BYTES, ESBR_STATE_BYTES, ESBR_PS_STATE_BYTES = 2036, 38012, 23048   # include/xaac_esbr.h (tests/test_abi.py checks them)
 ESBR_ANA_STATE_WORDS = 322   # struct xaac_esbr_ana_state: ring[320], pos, win_off (int32)
 ESBR_SYN_STATE_WORDS = 1282  # struct xaac_esbr_syn_state: ring[1280], drc_offset, filt_off (int32)
 
@@ -486,11 +487,11 @@ class XaacContext:
         b.core = _ptr(core, "float32", n_ch * 1024, device_ok=True)
         b.header = _ptr(header, "uint8", n_ch * SBR_HEADER_BYTES, device_ok=True)
         b.frame = _ptr(frame, "uint8", n_ch * SBR_FRAME_BYTES, device_ok=True)
-        b.side = _ptr(side, "uint8", device_ok=True)
-        b.state = _ptr(state, "uint8", device_ok=True)
+        b.side = _ptr(side, "uint8", n_ch * ESBR_SIDE_BYTES, device_ok=True)
+        b.state = _ptr(state, "uint8", n_ch * ESBR_STATE_BYTES, device_ok=True)
         b.out = _ptr(out, "float32", n_ch * 2048, device_ok=True)
         b.ps_frame = _ptr(ps_frame, "uint8", n_ch * PS_FRAME_BYTES, allow_none=True, device_ok=True)
-        b.ps_state = _ptr(ps_state, "uint8", allow_none=True, device_ok=True)
+        b.ps_state = _ptr(ps_state, "uint8", n_ch * ESBR_PS_STATE_BYTES, allow_none=True, device_ok=True)
         b.out_r = _ptr(out_r, "float32", n_ch * 2048, allow_none=True, device_ok=True)
         b.status = _ptr(status, "int32", n_ch, allow_none=True, device_ok=True)
         b.workspace = _ptr(workspace, "uint8", device_ok=True)

@@ -73,7 +73,7 @@ int32_t check_batch(const xaac_imdct_batch *b) {
 
 extern "C" {
 
-const char *xaac_version(void) { return "libxaac_amd 0.1 gfx950"; }
+const char *xaac_version(void) { return "libxaac_amd 0.3 gfx950"; }
 
 int32_t xaac_create(xaac_ctx **out, int32_t device, void *hip_stream) {
   if (!out) return XAAC_FATAL_NULL_ARG;
@@ -158,6 +158,10 @@ int32_t xaac_imdct960_process_batch(xaac_ctx *c, const xaac_imdct_batch *b) {
   if (!c) return XAAC_FATAL_NULL_ARG;
   int32_t rc = check_batch(b);
   if (rc != XAAC_OK) return rc;
+  /* the core -> SBR hand-off of a stereo element converts in place, channel after channel (api.c:353-366): channel 1's
+     first samples take their low halves from channel 0's PCM.  The 1024-line kernel reproduces that; this one converts
+     sample by sample, so the combination is refused rather than answered with different low bits */
+  if (b->pcm16 && b->pcm_mode == XAAC_PCM_SBR && b->ch_fac == 2) return XAAC_FATAL_BAD_ARG;
   if (b->n_ch == 0) return XAAC_OK;
   if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
   if (!hip_ok(xaac_launch_imdct960(b, c->stream))) return XAAC_FATAL_HIP;

@@ -83,6 +83,8 @@ def test_round2_struct_layouts_match_headers(tmp_path):
         want += [ctypes.sizeof(cls), getattr(cls, last).offset]
     assert got == want
     assert ctypes.sizeof(es.EsbrAna) == 4 * libxaac_amd.ESBR_ANA_STATE_WORDS and ctypes.sizeof(es.EsbrSyn) == 4 * libxaac_amd.ESBR_SYN_STATE_WORDS
+    assert (ctypes.sizeof(es.EsbrSide), ctypes.sizeof(es.EsbrState), ctypes.sizeof(es.EsbrPsState)) == \
+        (libxaac_amd.ESBR_SIDE_BYTES, libxaac_amd.ESBR_STATE_BYTES, libxaac_amd.ESBR_PS_STATE_BYTES)
 
 
 def test_hbe_struct_layouts_match_header(tmp_path):
