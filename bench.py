@@ -701,24 +701,9 @@ def main():
     # the ranks' own rates (load balance of a SCALE run) and the final interleaved gather over RCCL/xGMI, once
     per_rank, gather = None, None
     if dist is not None:
-        t = torch.tensor([FRAMES_PER_STEP * args.steps / own_elapsed], dtype=torch.float64, device=dev)
-        parts = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(parts, t)
-        per_rank = [round(float(p.item()), 1) for p in parts]
         pcm = job.batches[0]["pcm"].view(FRAMES_PER_STEP, -1)
-        xdist.gather_pcm(dist, pcm[:64])          # warm the communicator
-        barrier()
-        t0 = time.perf_counter()
-        whole = xdist.gather_pcm(dist, pcm)
-        barrier()
-        gt = xdist.max_over_ranks(dist, time.perf_counter() - t0, dev)
-        lo = rank * FRAMES_PER_STEP
-        assert whole.shape[0] == world * FRAMES_PER_STEP and torch.equal(whole[lo:lo + FRAMES_PER_STEP], pcm)
-        gather = {"ms": round(gt * 1e3, 3), "bytes_per_rank": int(pcm.numel() * pcm.element_size()),
-                  "what": "dist.gather_pcm: all_gather of every rank's last PCM batch (all ranks receive all %d "
-                          "streams' frames), RCCL, after the timed region" % (world * FRAMES_PER_STEP),
-                  "GBps_in_per_rank": round((world - 1) * pcm.numel() * pcm.element_size() / gt / 1e9, 1)}
-        del whole
+        per_rank, gather = xdist.post_run_report(dist, pcm, FRAMES_PER_STEP * args.steps / own_elapsed, dev, barrier)
+        assert gather["ok"] is not False, "the gathered PCM differs from the ranks' shards"
 
     secondary = None
     if world == 1 and not args.no_secondary and w == "c4":

@@ -100,10 +100,16 @@ def _worker_c4(rank, world, port, n_streams, steps, q):
     lo, hi = xdist.shard_range(n_streams, rank, world)     # this rank's streams: state stays with the rank
     out, st, ps = _c4_steps(lib, lo, hi, steps)
     dist.barrier()
-    gathered = [xdist.gather_pcm(dist, torch.from_numpy(out[s])).numpy() for s in range(steps)]
+    gathered = [xdist.gather_pcm(dist, torch.from_numpy(out[s])) for s in range(steps)]   # the whole batch on rank 0, None elsewhere
+    assert all((g is None) == (rank != 0) for g in gathered)
     t = xdist.max_over_ranks(dist, 0.5 + rank, torch.device("cpu"))
+    # the code bench.py --gpus N runs behind its timed region (per-rank rates, the timed and checked gather), equal shards
+    m = hi - lo if n_streams % world == 0 else min(xdist.shard_range(n_streams, r, world)[1] - xdist.shard_range(n_streams, r, world)[0] for r in range(world))
+    per_rank, info = xdist.post_run_report(dist, torch.from_numpy(out[-1][:m]), 1000.0 * (rank + 1), torch.device("cpu"))
+    assert per_rank == [1000.0 * (r + 1) for r in range(world)] and info["bytes_per_rank"] == out[-1][:m].nbytes
+    assert info["ok"] is (True if rank == 0 else None)
     if rank == 0:
-        q.put((np.stack(gathered), t))
+        q.put((np.stack([g.numpy() for g in gathered]), t))
     dist.barrier()
     dist.destroy_process_group()
 
