@@ -45,17 +45,47 @@ FRAMES_PER_STEP = 8192          # stereo frames per batch (BASELINE configs[1])
 CH = 2
 ALG_BYTES_PER_FRAME = 20480     # R spec 2x4096 + ovl 2x2048, W pcm16 2x2048 + ovl 2x2048
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
-PMC_FILE = os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")   # written from the rocprofv3 --pmc passes
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_latest.json")       # tools/pmc_to_json.py, from the rocprofv3 --pmc passes
+PMC_FILE_C2 = os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")   # round-1 C2 counters (that kernel has not changed)
+VALU_CYCLES_PER_WAVE_INSTR = 4.4   # measured: tools/ubench/valu_rate.hip, profiles/r01_m_c2_sq_detail.txt (v_mul_hi_i32 = a shift)
+SIMDS, CLOCK_GHZ = 1024, 2.4       # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md peak engine clock
 
 
 def measured_traffic(workload):
     """HBM bytes per step from the last committed PMC profile of this workload's kernels (rocprofv3 FETCH_SIZE
     x2 + WRITE_SIZE summed over the chain's launches, calibrated as MI355X_MICROARCH.md prescribes), or {}."""
     try:
-        with open(PMC_FILE) as f:
+        if workload == "c4":
+            with open(PMC_FILE) as f:
+                d = json.load(f)
+            return {"bytes_per_step": d["c4"]["bytes_per_step"], "source": d["source"]}
+        with open(PMC_FILE_C2) as f:
             return json.load(f).get(workload) or {}
-    except (OSError, ValueError):
+    except (OSError, ValueError, KeyError):
         return {}
+
+
+def valu_roofline(workload, kernel_ms):
+    """The chain's other bound: wave-instructions issued per step from the committed SQ counters, the time
+    the chip's 1024 SIMDs need to issue them at the measured 4.4 cycles per wave64 instruction, and how much of the
+    measured kernel time that is.  None without counters for the workload."""
+    if workload != "c4":
+        return None
+    try:
+        with open(PMC_FILE) as f:
+            d = json.load(f)
+        c = d["c4"]
+    except (OSError, ValueError, KeyError):
+        return None
+    to_ms = lambda n: n / SIMDS * VALU_CYCLES_PER_WAVE_INSTR / (CLOCK_GHZ * 1e9) * 1e3
+    floor_valu, floor_all = to_ms(c["valu_wave_instr"]), to_ms(c["valu_wave_instr"] + c["salu_wave_instr"] + c["lds_wave_instr"])
+    return {"valu_wave_instr": c["valu_wave_instr"], "salu_wave_instr": c["salu_wave_instr"], "lds_wave_instr": c["lds_wave_instr"],
+            "cycles_per_wave_instr": VALU_CYCLES_PER_WAVE_INSTR, "simds": SIMDS, "clock_ghz": CLOCK_GHZ,
+            "issue_floor_ms_valu": round(floor_valu, 4), "issue_floor_ms_all": round(floor_all, 4),
+            "issue_frac": round(floor_all / kernel_ms, 3) if kernel_ms else None,
+            "active_lanes_per_valu_instr": {k: v.get("active_lanes") for k, v in d["kernels"].items() if "active_lanes" in v},
+            "note": "integer VALU issue, not HBM, bounds this chain: 32-bit multiplies issue at the same 4.4 cycles per "
+                    "wave instruction as adds and shifts; issue_frac = floor over measured kernel time", "source": d["source"]}
 
 
 # ---- workload C2L: C2 + the AAC-LC post stage (peak limiter + PCM16), SURVEY.md §8 row f2 ---------------------
@@ -478,7 +508,7 @@ KERNELS = {
     "c2": "xaac_imdct_ola_kernel",
     "c2l": "imdct_ola + limiter_front + limiter_gain + limiter_apply (4 launches)",
     "c3": "imdct_ola + qmf_analysis + sbr_core_lp + qmf_synthesis (4 launches)",
-    "c4": "imdct_ola + qmf_analysis + sbr_core_hq + ps + qmf_synthesis_pair (5 launches)",
+    "c4": "imdct_ola + qmf_analysis_hq + sbr_core_hq (narrow rows; + its list launch) + ps + qmf_synthesis_pair (6 launches)",
 }
 
 
@@ -755,7 +785,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": pmc.get("bytes_per_step"), "traffic_source": pmc.get("source"),
-                         "kernel": KERNELS[w], "kernel_ms": round(kern_ms, 5), "alg_bytes_per_launch": alg_bytes},
+                         "kernel": KERNELS[w], "kernel_ms": round(kern_ms, 5), "alg_bytes_per_launch": alg_bytes,
+                         "valu": valu_roofline(w, kern_ms)},
             "refused_frac": refused,
             "bit_exact_vs_oracle": checked,
         }
