@@ -350,7 +350,8 @@ typedef struct xaac_esbr_syn_batch {
  * xaac_usac_imdct_batch <-> ixheaacd_fd_frm_dec   def decoder/ixheaacd_imdct.c:596 (-> ixheaacd_fd_imdct_long :477,
  *      ixheaacd_fd_imdct_short :336, ixheaacd_acelp_imdct :186, ixheaacd_complex_fft_p2_dec ixheaacd_fft.c:1412),
  *      call site decoder/ixheaacd_ext_ch_ele.c:991, with the caller's float conversion and shape hand-over (:1008-1016).
- * Scope: ccfl = 1024, FD frame after an FD frame (td_frame_prev = 0), no FAC data, no error concealment.  One frame of
+ * Scope: ccfl = 1024 or 768 (the 768 / 96-line transforms run three power-of-two transforms and ixheaacd_complex_fft_p3's
+ * three-point stage, ixheaacd_fft.c:2531), FD frame after an FD frame (td_frame_prev = 0), no FAC data, no error concealment.  One frame of
  * one channel per entry; the overlap is the reference's overlap_data_ptr row (Q14, un-windowed), so a channel can move
  * between a reference decoder and this library at any frame boundary. */
 typedef struct xaac_usac_ics {
@@ -360,12 +361,13 @@ typedef struct xaac_usac_ics {
 
 typedef struct xaac_usac_imdct_batch {
   int32_t n_ch;
-  const int32_t *coef;       /* [n_ch][1024] coef_fix (not modified) */
+  int32_t ccfl;              /* usac_data->ccfl: 1024 (also for 0: descriptors made before the member existed) or 768 */
+  const int32_t *coef;       /* [n_ch][ccfl] coef_fix (not modified) */
   const xaac_usac_ics *ics;  /* [n_ch] */
-  int32_t *overlap;          /* [n_ch][1024] in/out: overlap_data_ptr */
+  int32_t *overlap;          /* [n_ch][ccfl] in/out: overlap_data_ptr */
   uint8_t *shape_prev;       /* [n_ch] in/out: window_shape_prev */
-  int32_t *out32;            /* optional [n_ch][1024]: output_data_ptr (Q15) */
-  float *time;               /* optional [n_ch][1024]: time_sample_vector (= out32 * 2^-15) */
+  int32_t *out32;            /* optional [n_ch][ccfl]: output_data_ptr (Q15) */
+  float *time;               /* optional [n_ch][ccfl]: time_sample_vector (= out32 * 2^-15) */
   int32_t *status;           /* optional [n_ch]: XAAC_OK or XAAC_FATAL_BAD_WINDOW_SEQ (channel-frame left untouched) */
 } xaac_usac_imdct_batch;
 

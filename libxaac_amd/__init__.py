@@ -85,7 +85,7 @@ HANDOVER_PS_START, HANDOVER_STEREO_START = 1, 2
 
 class _UsacImdctBatch(ctypes.Structure):
     # struct xaac_usac_imdct_batch
-    _fields_ = [("n_ch", ctypes.c_int32), ("coef", ctypes.c_void_p), ("ics", ctypes.c_void_p),
+    _fields_ = [("n_ch", ctypes.c_int32), ("ccfl", ctypes.c_int32), ("coef", ctypes.c_void_p), ("ics", ctypes.c_void_p),
                 ("overlap", ctypes.c_void_p), ("shape_prev", ctypes.c_void_p), ("out32", ctypes.c_void_p),
                 ("time", ctypes.c_void_p), ("status", ctypes.c_void_p)]
 
@@ -515,19 +515,19 @@ class XaacContext:
         if rc != 0:
             raise XaacError(rc, "xaac_sbr_state_handover")
 
-    def usac_imdct_process_batch(self, coef, ics, overlap, shape_prev, out32=None, time=None, status=None):
-        """Batched ixheaacd_fd_frm_dec (USAC FD frame after an FD frame, ccfl 1024, no FAC): coef int32[n_ch, 1024];
-        ics uint8[n_ch, 2] (window_sequence 0..4, window_shape); overlap int32[n_ch, 1024] in/out; shape_prev uint8[n_ch]
-        in/out; out32 int32[n_ch, 1024] (Q15) and / or time float32[n_ch, 1024]; status int32[n_ch]."""
+    def usac_imdct_process_batch(self, coef, ics, overlap, shape_prev, out32=None, time=None, status=None, ccfl=1024):
+        """Batched ixheaacd_fd_frm_dec (USAC FD frame after an FD frame, ccfl 1024 or 768, no FAC): coef int32[n_ch, ccfl];
+        ics uint8[n_ch, 2] (window_sequence 0..4, window_shape); overlap int32[n_ch, ccfl] in/out; shape_prev uint8[n_ch]
+        in/out; out32 int32[n_ch, ccfl] (Q15) and / or time float32[n_ch, ccfl]; status int32[n_ch]."""
         n_ch = overlap.shape[0]
         b = _UsacImdctBatch()
-        b.n_ch = n_ch
-        b.coef = _ptr(coef, "int32", n_ch * 1024, device_ok=True)
+        b.n_ch, b.ccfl = n_ch, int(ccfl)
+        b.coef = _ptr(coef, "int32", n_ch * ccfl, device_ok=True)
         b.ics = _ptr(ics, "uint8", n_ch * 2, device_ok=True)
-        b.overlap = _ptr(overlap, "int32", n_ch * 1024, device_ok=True)
+        b.overlap = _ptr(overlap, "int32", n_ch * ccfl, device_ok=True)
         b.shape_prev = _ptr(shape_prev, "uint8", n_ch, device_ok=True)
-        b.out32 = _ptr(out32, "int32", n_ch * 1024, allow_none=True, device_ok=True)
-        b.time = _ptr(time, "float32", n_ch * 1024, allow_none=True, device_ok=True)
+        b.out32 = _ptr(out32, "int32", n_ch * ccfl, allow_none=True, device_ok=True)
+        b.time = _ptr(time, "float32", n_ch * ccfl, allow_none=True, device_ok=True)
         b.status = _ptr(status, "int32", n_ch, allow_none=True, device_ok=True)
         rc = self._lib.xaac_usac_imdct_process_batch(self._h, ctypes.byref(b))
         if rc != 0:

@@ -1,5 +1,5 @@
 /*
- * usac_imdct.h -- the USAC frequency-domain IMDCT (ccfl = 1024, no FAC, previous frame FD), shared by the gfx950 kernel
+ * usac_imdct.h -- the USAC frequency-domain IMDCT (ccfl = 1024 or 768), shared by the gfx950 kernel
  * (usac_imdct_kernel.hip) and, compiled for the host, by the checker (oracle/oracle_usac.cpp).
  *
  * Restates, as per-index functions (every butterfly of a pass and every output sample is independent, so a caller may
@@ -7,6 +7,7 @@
  *   ixheaacd_fd_imdct_long / _short       decoder/ixheaacd_imdct.c:477 / :336
  *   ixheaacd_acelp_imdct, _fft_based_imdct, pre / post twiddle      ixheaacd_imdct.c:186 / :149 / :111 / :129
  *   ixheaacd_complex_fft_p2_dec (fft_mode = 1 branch)               ixheaacd_fft.c:1412, :1966-2484
+ *   ixheaacd_complex_fft_p3 (fft_mode = 1), ixheaacd_complex_3point_fft   ixheaacd_fft.c:2531 / :2493  (ccfl 768)
  *   ixheaacd_windowing_long1 / _long3 / _short2 / _short3 / _short4, _scale_down(_adj)   ixheaacd_basic_ops.c:77-660
  * Arithmetic: saturating adds / subtractions and (a*b)>>31 products clamped to 32 bits inside the FFT, truncating
  * (a*b)>>32 products in the twiddles, (a*b)>>31 wrapped to 32 bits in the windows -- bit for bit the reference's.
@@ -105,17 +106,21 @@ FX_HD unsigned xu_dig_rev(unsigned i, int m) {
 /* N = 512 or 64 complex points.  The transform of one block is:
  *   xu_fft_first<N>(x, y, b)      b = 0 .. N/4-1     x: N interleaved (re, im) words, already divided; y: the same size
  *   for del = 4, 16, (64):  xu_fft_pass<N>(y, del, b)   b = 0 .. N/4-1
- *   N == 512:               xu_fft_last512(y, b)        b = 0 .. 255
+ *   N == 512 / 128:         xu_fft_last<N>(y, b)        b = 0 .. N/2-1
  * with a barrier between passes.  Input division: xu_fft_in_shift<N>(); the exponent the reference reports:
  * xu_fft_out_shift<N>(). */
-template <int N> FX_HD constexpr int xu_fft_in_shift() { return N == 512 ? 6 : 5; }   /* fft.c:1438-1441 */
-template <int N> FX_HD constexpr int xu_fft_out_shift() { return N == 512 ? 7 : 5; }  /* + 1 for the radix-2 pass, :2410 */
+/* N = 512, 128, 64 or 16 complex points (the power-of-two transforms; 128 and 16 are the thirds of the 384- and 48-point
+   ones).  fft.c:1432-1441: the input division; +1 in the reported exponent for the radix-2 pass (:2426) */
+template <int N> FX_HD constexpr int xu_log2() { return N == 512 ? 9 : (N == 128 ? 7 : (N == 64 ? 6 : 4)); }
+template <int N> FX_HD constexpr bool xu_not_pow4() { return (xu_log2<N>() & 1) != 0; }
+template <int N> FX_HD constexpr int xu_fft_in_shift() { return xu_not_pow4<N>() ? (xu_log2<N>() + 3) / 2 : (xu_log2<N>() + 4) / 2; }
+template <int N> FX_HD constexpr int xu_fft_out_shift() { return xu_fft_in_shift<N>() + (xu_not_pow4<N>() ? 1 : 0); }
 
-template <int N, class Mem>
-FX_HD void xu_fft_first(const Mem &x, const Mem &y, int b) {
-  constexpr int rev_shift = N == 512 ? 6 : 9; /* norm32(N) + 1 - 16 */
+template <int N, class MemIn, class Mem>
+FX_HD void xu_fft_first(const MemIn &x, const Mem &y, int b) {
+  constexpr int rev_shift = 15 - xu_log2<N>(); /* norm32(N) + 1 - 16 */
   unsigned h2 = xu_dig_rev((unsigned)(4 * b), rev_shift);
-  if (N == 512) h2 = (h2 + 1) & ~1u;
+  if (xu_not_pow4<N>()) h2 = (h2 + 1) & ~1u;
   XuCx v[4];
   for (int q = 0; q < 4; q++) {
     v[q].r = x[h2 + q * (N / 2)];
@@ -158,85 +163,140 @@ FX_HD void xu_fft_pass(const Mem &y, int del, int b) {
   }
 }
 
-/* the radix-2 pass of the 512-point transform (fft.c:2407-2470) */
-template <class Mem>
-FX_HD void xu_fft_last512(const Mem &y, int b) {
-  const int j = b & 127, p = b;
-  const int32_t h = xaac_usac_fft_tw[4 * j], l = xaac_usac_fft_tw[4 * j + 1];
-  XuCx a = {y[2 * p], y[2 * p + 1]}, c = {y[2 * (p + 256)], y[2 * (p + 256) + 1]};
-  c = b < 128 ? xu_rot0(c, h, l) : xu_rot1(c, h, l);
-  y[2 * (p + 256)] = fx_sub(xu_div_pow2(a.r, 1), xu_div_pow2(c.r, 1));
-  y[2 * (p + 256) + 1] = fx_sub(xu_div_pow2(a.i, 1), xu_div_pow2(c.i, 1));
+/* the radix-2 pass of the 512- and 128-point transforms (fft.c:2423-2484): legs N/2 apart, twiddle step 2048 / N words */
+template <int N, class Mem>
+FX_HD void xu_fft_last(const Mem &y, int b) {
+  const int j = b & (N / 4 - 1), p = b;
+  const int32_t h = xaac_usac_fft_tw[(2048 / N) * j], l = xaac_usac_fft_tw[(2048 / N) * j + 1];
+  XuCx a = {y[2 * p], y[2 * p + 1]}, c = {y[2 * (p + N / 2)], y[2 * (p + N / 2) + 1]};
+  c = b < N / 4 ? xu_rot0(c, h, l) : xu_rot1(c, h, l);
+  y[2 * (p + N / 2)] = fx_sub(xu_div_pow2(a.r, 1), xu_div_pow2(c.r, 1));
+  y[2 * (p + N / 2) + 1] = fx_sub(xu_div_pow2(a.i, 1), xu_div_pow2(c.i, 1));
   y[2 * p] = fx_add(xu_div_pow2(a.r, 1), xu_div_pow2(c.r, 1));
   y[2 * p + 1] = fx_add(xu_div_pow2(a.i, 1), xu_div_pow2(c.i, 1));
 }
 
-/* pre twiddle of line pair i of an N-point block (imdct.c:111-127): x = the 2N spectral lines of the block; writes the
-   FFT's divided input */
+/* ---- ccfl 768: the 384- and 48-point transforms = 3 x (128 | 16) points + a three-point stage (fft.c:2531) ----------
+ * NT = 3 M points: sub-sequence s (s = 0, 1, 2) holds the points 3 j + s; each goes through the M-point transform above
+ * (its own input division, fft.c:1443); then, per group g = 0 .. M-1 (the s-th result of each third):
+ *   halve (:2575), rotate the second and third by the table (fft_mode = 1 branch, :2619-2641), three-point butterfly
+ *   (:2493), and the results are points g, M + g, 2 M + g of the output (:2651-2659). */
+FX_HD int32_t xu_mul32_shl(int32_t a, int32_t b) { return fx_shlw(fx_mulhi(a, b), 1); } /* ixheaac_mult32_shl */
+template <int M>
+FX_HD void xu_p3_group(XuCx x0, XuCx x1, XuCx x2, int g, XuCx *out /* [3]: points g, M + g, 2 M + g */) {
+  const int base = g * 3 * (128 / M);
+  x0.r >>= 1; x0.i >>= 1; x1.r >>= 1; x1.i >>= 1; x2.r >>= 1; x2.i >>= 1;
+  {
+    const int32_t wr = xaac_usac_tw3_r[base + 1], wi = xaac_usac_tw3_i[base + 1];
+    const int32_t t = fx_add_sat(xu_mul_sat(x1.r, wr), xu_mul_sat(x1.i, wi));
+    x1.i = fx_sub_sat(xu_mul_sat(x1.i, wr), xu_mul_sat(x1.r, wi));
+    x1.r = t;
+  }
+  {
+    const int32_t wr = xaac_usac_tw3_r[base + 2], wi = xaac_usac_tw3_i[base + 2];
+    const int32_t t = fx_add_sat(xu_mul_sat(x2.r, wr), xu_mul_sat(x2.i, wi));
+    x2.i = fx_sub_sat(xu_mul_sat(x2.i, wr), xu_mul_sat(x2.r, wi));
+    x2.r = t;
+  }
+  const int32_t sinmu = -1859775393; /* sign_dir = fft_mode = 1 */
+  const int32_t temp_real = fx_add_sat(x0.r, x1.r), temp_imag = fx_add_sat(x0.i, x1.i);
+  const int32_t add_r = fx_add_sat(x1.r, x2.r), add_i = fx_add_sat(x1.i, x2.i);
+  const int32_t sub_r = fx_sub_sat(x1.r, x2.r), sub_i = fx_sub_sat(x1.i, x2.i);
+  const int32_t p1 = add_r >> 1, p4 = add_i >> 1, p2 = xu_mul32_shl(sub_i, sinmu), p3 = xu_mul32_shl(sub_r, sinmu);
+  const int32_t temp = fx_sub(x0.r, p1);
+  out[0].r = fx_add_sat(temp_real, x2.r);
+  out[0].i = fx_add_sat(temp_imag, x2.i);
+  out[1].r = fx_add_sat(temp, p2);
+  out[1].i = fx_sub_sat(fx_sub_sat(x0.i, p3), p4);
+  out[2].r = fx_sub_sat(temp, p2);
+  out[2].i = fx_sub_sat(fx_add_sat(x0.i, p3), p4);
+}
+/* ixheaacd_acelp_imdct's prescale of a block whose length is not a power of two (imdct.c:197-202) */
+FX_HD int32_t xu_third_twice(int32_t v) { return fx_shlw(v / 3, 1); }
+
+/* N = complex points of a block's transform (2 N lines): 512 / 64 (ccfl 1024), 384 / 48 (ccfl 768) */
+template <int N> FX_HD const int32_t *xu_pre_cos() {
+  return N == 512 ? xaac_usac_pre_cos_512 : (N == 384 ? xaac_usac_pre_cos_384 : (N == 64 ? xaac_usac_pre_cos_64 : xaac_usac_pre_cos_48));
+}
+template <int N> FX_HD const int32_t *xu_pre_sin() {
+  return N == 512 ? xaac_usac_pre_sin_512 : (N == 384 ? xaac_usac_pre_sin_384 : (N == 64 ? xaac_usac_pre_sin_64 : xaac_usac_pre_sin_48));
+}
+/* the power-of-two transform a block's points go through: itself, or its thirds */
+template <int N> FX_HD constexpr int xu_sub_points() { return N == 384 ? 128 : (N == 48 ? 16 : N); }
+/* pre twiddle of line pair i of an N-point block (imdct.c:111-127): xa = x[2i], xb = x[2N-1-2i] of the block's 2N lines
+   (for ccfl 768 after the prescale); the result is already divided as the (sub-)transform's input (fft.c:1443) */
 template <int N>
-FX_HD XuCx xu_pre_twiddle(int32_t xa /* x[2i] */, int32_t xb /* x[2N-1-2i] */, int i) {
-  const int32_t c = (N == 512 ? xaac_usac_pre_cos_512 : xaac_usac_pre_cos_64)[i];
-  const int32_t s = (N == 512 ? xaac_usac_pre_sin_512 : xaac_usac_pre_sin_64)[i];
+FX_HD XuCx xu_pre_twiddle(int32_t xa, int32_t xb, int i) {
+  const int32_t c = xu_pre_cos<N>()[i], s = xu_pre_sin<N>()[i];
   XuCx y;
   y.r = fx_sub(fx_mulhi(fx_neg_sat(xa), c), fx_mulhi(xb, s));
   y.i = fx_sub(fx_mulhi(xb, c), fx_mulhi(xa, s));
-  y.r = xu_div_pow2(y.r, xu_fft_in_shift<N>());
-  y.i = xu_div_pow2(y.i, xu_fft_in_shift<N>());
+  y.r = xu_div_pow2(y.r, xu_fft_in_shift<xu_sub_points<N>()>());
+  y.i = xu_div_pow2(y.i, xu_fft_in_shift<xu_sub_points<N>()>());
   return y;
 }
 /* post twiddle (imdct.c:129-147): -> the new x[2i] (.r) and x[2N-1-2i] (.i) */
 template <int N>
 FX_HD XuCx xu_post_twiddle(XuCx v, int i) {
-  const int32_t c = (N == 512 ? xaac_usac_pre_cos_512 : xaac_usac_pre_cos_64)[i];
-  const int32_t s = (N == 512 ? xaac_usac_pre_sin_512 : xaac_usac_pre_sin_64)[i];
+  const int32_t c = xu_pre_cos<N>()[i], s = xu_pre_sin<N>()[i];
   XuCx y;
   y.r = fx_neg(fx_sub(fx_mulhi(v.r, c), fx_mulhi(v.i, s)));
   y.i = fx_neg(fx_add(fx_mulhi(v.i, c), fx_mulhi(v.r, s)));
   return y;
 }
 
-/* exponent after ixheaacd_acelp_imdct (imdct.c:186-208): *qshift -= (shift_out - log2(N2)) + 2, N2 = lines per block */
-template <int N> FX_HD constexpr int xu_imdct_q_gain() { return (N == 512 ? 10 : 7) - xu_fft_out_shift<N>() - 2; }
+/* what ixheaacd_acelp_imdct adds to the exponent (imdct.c:186-208): *qshift -= preshift' with
+   preshift' = (reported FFT shift - preshift) + 2, preshift = log2 of the block's power-of-two part (+ 1 with the
+   prescale by 2 / 3); power-of-two blocks: fft.c:2489; three-way ones: :2573 (shift by the third's size, + 1) */
+template <int N> FX_HD constexpr int xu_imdct_q_gain() {
+  return N == 512 ? 10 - 7 - 2 : (N == 64 ? 7 - 5 - 2 : (N == 384 ? 9 - (6 + 1) - 2 : /* 48 */ 6 - (4 + 1) - 2));
+}
 
 /* ixheaacd_normalize with the count the second renormalisation can reach (imdct.c:94-100, :517): max_shift - 1 is -1
    when the transform's peak already fills the word -- a negative shift count, undefined in C; here: count & 31 */
 FX_HD int32_t xu_normalize(int32_t v, int shift) { return fx_shlw(v, shift & 31); }
 
-FX_HD const int32_t *xu_window(int len, int shape) { /* ixheaacd_calc_window for the two lengths of ccfl 1024 */
-  if (len == 1024) return shape ? xaac_usac_kbd_win_1024 : xaac_usac_sine_win_1024;
-  return shape ? xaac_usac_kbd_win_128 : xaac_usac_sine_win_128;
+FX_HD const int32_t *xu_window(int len, int shape) { /* ixheaacd_calc_window (ixheaacd_Windowing.c:29) */
+  switch (len) {
+    case 1024: return shape ? xaac_usac_kbd_win_1024 : xaac_usac_sine_win_1024;
+    case 768: return shape ? xaac_usac_kbd_win_768 : xaac_usac_sine_win_768;
+    case 128: return shape ? xaac_usac_kbd_win_128 : xaac_usac_sine_win_128;
+    default: return shape ? xaac_usac_kbd_win_96 : xaac_usac_sine_win_96;
+  }
 }
 
-/* ---- long blocks: output sample i (0..1023) of the frame, before the final rescale ----------------------------------
- * x: the 1024 transform outputs after the second renormalisation; ov: the overlap (Q14); shiftp: their exponent.
- * ONLY_LONG / LONG_START: windowing_long1 (basic_ops.c:77); LONG_STOP / STOP_START: windowing_long3 (:298), no FAC. */
-template <class Mem, class Ov>
+/* ---- long blocks: output sample i (0 .. L-1) of the frame, before the final rescale; L = ccfl -----------------------
+ * x: the L transform outputs after the second renormalisation; ov: the overlap (Q14); shiftp: their exponent.
+ * ONLY_LONG / LONG_START: windowing_long1 (basic_ops.c:77); LONG_STOP / STOP_START: windowing_long3 (:298), no FAC:
+ * flat part of (L - L/8) / 2 samples, then the L/8-sample slope of the previous shape's short window. */
+template <int L, class Mem, class Ov>
 FX_HD int32_t xu_long_sample(const Mem &x, const Ov &ov, int i, int shiftp, bool stop_like, int shape_prev) {
+  constexpr int H = L / 2, S = L / 8, F = (L - S) / 2; /* half frame, short block, n_flat_ls */
   const int d = shiftp - XU_SHIFT_OLAP; /* > 0: the transform side is shifted down; <= 0: the overlap side */
   if (!stop_like) {
-    const int32_t *w = xu_window(1024, shape_prev);
-    const int m = i < 512 ? i : 1023 - i;             /* the loop index of basic_ops.c:85 */
-    const int32_t src1 = x[512 + m];
-    const int32_t t = i < 512 ? xu_mul_sh1(src1, w[m]) : xu_mul_sh1(fx_neg_sat(src1), w[1023 - m]);
-    const int32_t o = i < 512 ? xu_mul_sh1(ov[m], w[1023 - m]) : xu_mul_sh1(ov[1023 - m], w[m]);
+    const int32_t *w = xu_window(L, shape_prev);
+    const int m = i < H ? i : L - 1 - i;              /* the loop index of basic_ops.c:85 */
+    const int32_t src1 = x[H + m];
+    const int32_t t = i < H ? xu_mul_sh1(src1, w[m]) : xu_mul_sh1(fx_neg_sat(src1), w[L - 1 - m]);
+    const int32_t o = i < H ? xu_mul_sh1(ov[m], w[L - 1 - m]) : xu_mul_sh1(ov[L - 1 - m], w[m]);
     return d > 0 ? fx_add_sat(t >> d, o) : fx_add_sat(t, o >> -d);
   }
-  const int32_t *w = xu_window(128, shape_prev);
-  if (i < 448) return d > 0 ? ov[i] : (ov[i] >> -d);
-  if (i < 576) {
-    const int32_t src = i < 512 ? x[512 + i] : fx_neg_sat(x[512 + 1023 - i]);
-    const int32_t t = xu_mul_sh1(src, w[i - 448]), o = xu_mul_sh1(ov[i], w[127 - (i - 448)]);
+  const int32_t *w = xu_window(S, shape_prev);
+  if (i < F) return d > 0 ? ov[i] : (ov[i] >> -d);
+  if (i < F + S) {
+    const int32_t src = i < H ? x[H + i] : fx_neg_sat(x[H + L - 1 - i]);
+    const int32_t t = xu_mul_sh1(src, w[i - F]), o = xu_mul_sh1(ov[i], w[S - 1 - (i - F)]);
     return d > 0 ? fx_add_sat(t >> d, o) : fx_add_sat(t, o >> -d);
   }
-  const int32_t v = fx_neg_sat(x[512 + 1023 - i]);
+  const int32_t v = fx_neg_sat(x[H + L - 1 - i]);
   return d > 0 ? (v >> d) : v;
 }
 FX_HD int xu_long_output_q(int shiftp) { return shiftp > XU_SHIFT_OLAP ? XU_SHIFT_OLAP : shiftp; }
 /* the new overlap, sample i (imdct.c:563-576: both branches shift right) */
-template <class Mem>
+template <int L, class Mem>
 FX_HD int32_t xu_long_overlap(const Mem &x, int i, int shiftp) {
   const int d = shiftp > XU_SHIFT_OLAP ? shiftp - XU_SHIFT_OLAP : XU_SHIFT_OLAP - shiftp;
-  const int m = i >= 512 ? i - 512 : 511 - i;
+  const int m = i >= L / 2 ? i - L / 2 : L / 2 - 1 - i;
   return fx_neg_sat(x[m]) >> d;
 }
 /* ixheaacd_scale_down_adj(.., output_q, 15) (basic_ops.c:640): the frame's Q15 output */
@@ -246,31 +306,32 @@ FX_HD int32_t xu_scale_adj(int32_t v, int output_q) {
 /* ixheaacd_scale_down (basic_ops.c:622) */
 FX_HD int32_t xu_scale(int32_t v, int from_q, int to_q) { return from_q > to_q ? (v >> (from_q - to_q)) : fx_shl_sat(v, to_q - from_q); }
 
-/* ---- EIGHT_SHORT frames: sample p (0..2047) of the reference's overlap_data_buf after the eight windowed blocks ------
- * x: the 8 x 128 transform outputs after the renormalisation, ov: the old overlap (Q14), both read-only, so every p is
+/* ---- EIGHT_SHORT frames: sample p (0 .. 2L-1) of the reference's overlap_data_buf after the eight windowed blocks ------
+ * x: the 8 x L/8 transform outputs after the renormalisation, ov: the old overlap (Q14), both read-only, so every p is
  * independent.  Restates windowing_short2 (block 0 against the old overlap under the previous shape's window, which also
  * clears the overlap behind it), _short3 (block 0's tail), _short4 x 7 (basic_ops.c:430-620) as what each position ends
- * up holding: positions 448 + 128 k + t hold head(k, t) + tail(k - 1, t); the last tail is left unwindowed for the next
- * frame; the first 448 positions are the old overlap at the output exponent. */
-template <class Mem, class Ov>
+ * up holding: with S = L/8, F = (L - S) / 2 positions F + S k + t hold head(k, t) + tail(k - 1, t); the last tail is left
+ * unwindowed for the next frame; the first F positions are the old overlap at the output exponent. */
+template <int L, class Mem, class Ov>
 FX_HD int32_t xu_short_sample(const Mem &x, const Ov &ov, int p, int shiftp, int shape, int shape_prev) {
+  constexpr int S = L / 8, F = (L - S) / 2;
   const int dd = shiftp > XU_SHIFT_OLAP ? shiftp - XU_SHIFT_OLAP : 0; /* transform side down ... */
   const int od = shiftp < XU_SHIFT_OLAP ? XU_SHIFT_OLAP - shiftp : 0; /* ... or overlap side down */
-  if (p < 448) return ov[p] >> od; /* ixheaacd_scale_down(.., shift_olap, output_q), imdct.c:448 */
-  if (p >= 1600) return 0;
-  const int k = (p - 448) >> 7, t = (p - 448) & 127;
-  const int32_t *w = xu_window(128, shape);
+  if (p < F) return ov[p] >> od; /* ixheaacd_scale_down(.., shift_olap, output_q), imdct.c:448 */
+  if (p >= F + 9 * S) return 0;
+  const int k = (p - F) / S, t = (p - F) % S;
+  const int32_t *w = xu_window(S, shape);
   int32_t head = 0, tail = 0;
   if (k < 8) {
-    const int32_t *wh = k == 0 ? xu_window(128, shape_prev) : w;
-    const int32_t v = t < 64 ? x[128 * k + 64 + t] : fx_neg_sat(x[128 * k + 191 - t]);
+    const int32_t *wh = k == 0 ? xu_window(S, shape_prev) : w;
+    const int32_t v = t < S / 2 ? x[S * k + S / 2 + t] : fx_neg_sat(x[S * k + S + S / 2 - 1 - t]);
     head = xu_mul_sh1(v, wh[t]) >> dd;
   }
   if (k == 0) {
-    tail = xu_mul_sh1(ov[p], xu_window(128, shape_prev)[127 - t]) >> od;
+    tail = xu_mul_sh1(ov[p], xu_window(S, shape_prev)[S - 1 - t]) >> od;
   } else {
-    const int32_t v = fx_neg_sat(x[128 * (k - 1) + (t < 64 ? 63 - t : t - 64)]);
-    tail = k == 8 ? (v >> dd) : (xu_mul_sh1(v, w[127 - t]) >> dd);
+    const int32_t v = fx_neg_sat(x[S * (k - 1) + (t < S / 2 ? S / 2 - 1 - t : t - S / 2)]);
+    tail = k == 8 ? (v >> dd) : (xu_mul_sh1(v, w[S - 1 - t]) >> dd);
   }
   return k == 8 ? tail : fx_add_sat(head, tail);
 }

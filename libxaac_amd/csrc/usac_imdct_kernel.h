@@ -11,7 +11,7 @@
 #define XAAC_USAC_LDS (XAAC_USAC_WAVES_PER_WG * 2 * 1024 * 4)
 
 typedef struct XaacUsacImdctParams {
-  int32_t n_ch;
+  int32_t n_ch, ccfl; /* ccfl: 1024 or 768 */
   const int32_t *coef;
   const xaac_usac_ics *ics;
   int32_t *overlap;

@@ -1,6 +1,6 @@
 /*
  * usac_imdct_kernel.hip -- gfx950 kernel for the USAC frequency-domain IMDCT + windowing + overlap-add of
- * ixheaacd_fd_frm_dec (decoder/ixheaacd_imdct.c:596: ccfl 1024, no FAC, previous frame FD), arithmetic in usac_imdct.h.
+ * ixheaacd_fd_frm_dec (decoder/ixheaacd_imdct.c:596: ccfl 1024 or 768, no FAC, previous frame FD), arithmetic in usac_imdct.h.
  *
  * Mapping: one wave = one channel-frame, four per workgroup (they share nothing).  The 1024 lines are read once, strided
  * so that lane i holds the pairs (x[2i], x[2N-1-2i]) its pre twiddle needs; the block exponent is a wave max.  The
@@ -39,20 +39,31 @@ __device__ __forceinline__ int32_t wave_max(int32_t v) {
 
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 
-/* N = 512: one transform of 1024 lines; N = 64: eight of 128 lines side by side */
-template <int N>
+struct LdsStrided { /* words of the sub-sequence T j + s of an interleaved (re, im) array */
+  int32_t *p;
+  int T, s;
+  __device__ __forceinline__ int32_t &operator[](int w) const { return p[2 * (T * (w >> 1) + s) + (w & 1)]; }
+};
+
+/* L = ccfl (1024 or 768).  !SHORT: one transform of L lines (N = L/2 complex points); SHORT: eight of L/8 lines side by
+   side (N = L/16).  For ccfl 768 a block's points go through three M-point transforms (M = 128 | 16) and the
+   three-point stage (usac_imdct.h); every pass is spread over the lanes: L/8 radix-4 butterflies per pass either way. */
+template <int L, bool SHORT>
 __device__ __forceinline__ int transform(const int32_t *coef, int32_t *A, int32_t *B, int lane, int shiftp) {
-  constexpr int NB = 512 / N;                 /* blocks */
-  int32_t xa[8], xb[8];
+  constexpr int N = SHORT ? L / 16 : L / 2;   /* complex points per block */
+  constexpr int M = xu_sub_points<N>();       /* ... of the power-of-two transform they go through */
+  constexpr int T = N / M;                    /* 1, or 3 thirds */
+  constexpr int PP = L / 128;                 /* line pairs (= points) per lane */
+  int32_t xa[PP], xb[PP];
 #pragma unroll
-  for (int m = 0; m < 8; m++) {
-    const int blk = N == 512 ? 0 : m, i = N == 512 ? lane + 64 * m : lane;
+  for (int m = 0; m < PP; m++) {
+    const int q = lane + 64 * m, blk = q / N, i = q % N;
     xa[m] = coef[2 * N * blk + 2 * i];
     xb[m] = coef[2 * N * blk + 2 * N - 1 - 2 * i];
   }
   int32_t mx = 0;
 #pragma unroll
-  for (int m = 0; m < 8; m++) {
+  for (int m = 0; m < PP; m++) {
     const int32_t a = fx_abs_sat(xa[m]), b = fx_abs_sat(xb[m]);
     mx = a > mx ? a : mx;
     mx = b > mx ? b : mx;
@@ -60,61 +71,146 @@ __device__ __forceinline__ int transform(const int32_t *coef, int32_t *A, int32_
   int s = fx_norm32(wave_max(mx));
   shiftp += s + 6 + xu_imdct_q_gain<N>();
 #pragma unroll
-  for (int m = 0; m < 8; m++) {
-    const int blk = N == 512 ? 0 : m, i = N == 512 ? lane + 64 * m : lane;
-    const XuCx v = xu_pre_twiddle<N>(fx_shlw(xa[m], s), fx_shlw(xb[m], s), i);
+  for (int m = 0; m < PP; m++) {
+    const int q = lane + 64 * m, blk = q / N, i = q % N;
+    int32_t a = fx_shlw(xa[m], s), b = fx_shlw(xb[m], s);
+    if (T == 3) { /* ixheaacd_acelp_imdct's prescale of the 768- and 96-line blocks */
+      a = xu_third_twice(a);
+      b = xu_third_twice(b);
+    }
+    const XuCx v = xu_pre_twiddle<N>(a, b, i);
     *reinterpret_cast<int2 *>(A + 2 * N * blk + 2 * i) = make_int2(v.r, v.i);
   }
   wave_sync();
+  constexpr int NBF = L / 8; /* radix-4 butterflies per pass over all blocks and thirds */
 #pragma unroll
   for (int m = 0; m < 2; m++) {
-    const int b = lane + 64 * m, blk = N == 512 ? 0 : b / (N / 4), bb = N == 512 ? b : b % (N / 4);
-    const Lds a = {A + 2 * N * blk}, y = {B + 2 * N * blk};
-    xu_fft_first<N>(a, y, bb);
+    const int b = lane + 64 * m;
+    if (b < NBF) {
+      const int unit = b / (M / 4), bb = b % (M / 4), blk = unit / T, th = unit % T;
+      const LdsStrided a = {A + 2 * N * blk, T, th};
+      const Lds y = {B + 2 * N * blk + 2 * M * th};
+      xu_fft_first<M>(a, y, bb);
+    }
   }
   wave_sync();
 #pragma unroll
-  for (int del = 4; del < N / 2; del *= 4) {
+  for (int del = 4; del < M / 2; del *= 4) {
 #pragma unroll
     for (int m = 0; m < 2; m++) {
-      const int b = lane + 64 * m, blk = N == 512 ? 0 : b / (N / 4), bb = N == 512 ? b : b % (N / 4);
-      const Lds y = {B + 2 * N * blk};
-      xu_fft_pass<N>(y, del, bb);
+      const int b = lane + 64 * m;
+      if (b < NBF) {
+        const int unit = b / (M / 4), bb = b % (M / 4), blk = unit / T, th = unit % T;
+        const Lds y = {B + 2 * N * blk + 2 * M * th};
+        xu_fft_pass<M>(y, del, bb);
+      }
     }
     wave_sync();
   }
-  if (N == 512) {
-    const Lds y = {B};
+  if (xu_not_pow4<M>()) { /* long frames only: one transform, or its three thirds */
 #pragma unroll
-    for (int m = 0; m < 4; m++) xu_fft_last512(y, lane + 64 * m);
+    for (int m = 0; m < 4; m++) {
+      const int b = lane + 64 * m;
+      if (b < T * (M / 2)) {
+        const Lds y = {B + 2 * M * (b / (M / 2))};
+        xu_fft_last<M>(y, b % (M / 2));
+      }
+    }
     wave_sync();
   }
-  /* post twiddle; second block exponent; the renormalised lines go to A in natural order */
+  /* (three-point stage;) post twiddle; second block exponent; the renormalised lines go to A in natural order */
   mx = 0;
+  if (T == 1) {
 #pragma unroll
-  for (int m = 0; m < 8; m++) {
-    const int blk = N == 512 ? 0 : m, i = N == 512 ? lane + 64 * m : lane;
-    const int2 t = *reinterpret_cast<const int2 *>(B + 2 * N * blk + 2 * i);
-    const XuCx in = {t.x, t.y};
-    const XuCx v = xu_post_twiddle<N>(in, i);
-    xa[m] = v.r;
-    xb[m] = v.i;
-    const int32_t a = fx_abs_sat(v.r), b = fx_abs_sat(v.i);
+    for (int m = 0; m < PP; m++) {
+      const int q = lane + 64 * m, blk = q / N, i = q % N;
+      const int2 t = *reinterpret_cast<const int2 *>(B + 2 * N * blk + 2 * i);
+      const XuCx in = {t.x, t.y};
+      const XuCx v = xu_post_twiddle<N>(in, i);
+      xa[m] = v.r;
+      xb[m] = v.i;
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < PP / 3; m++) { /* a lane's groups: g of block blk -> points g, M + g, 2 M + g */
+      const int q = lane + 64 * m, blk = q / M, g = q % M;
+      const int32_t *y = B + 2 * N * blk;
+      const int2 t0 = *reinterpret_cast<const int2 *>(y + 2 * g), t1 = *reinterpret_cast<const int2 *>(y + 2 * M + 2 * g),
+                 t2 = *reinterpret_cast<const int2 *>(y + 4 * M + 2 * g);
+      const XuCx x0 = {t0.x, t0.y}, x1 = {t1.x, t1.y}, x2 = {t2.x, t2.y};
+      XuCx o[3];
+      xu_p3_group<M>(x0, x1, x2, g, o);
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const XuCx v = xu_post_twiddle<N>(o[k], k * M + g);
+        xa[3 * m + k] = v.r;
+        xb[3 * m + k] = v.i;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < PP; m++) {
+    const int32_t a = fx_abs_sat(xa[m]), b = fx_abs_sat(xb[m]);
     mx = a > mx ? a : mx;
     mx = b > mx ? b : mx;
   }
   s = fx_norm32(wave_max(mx));
 #pragma unroll
-  for (int m = 0; m < 8; m++) {
-    const int blk = N == 512 ? 0 : m, i = N == 512 ? lane + 64 * m : lane;
+  for (int m = 0; m < PP; m++) {
+    int blk, i;
+    if (T == 1) {
+      const int q = lane + 64 * m;
+      blk = q / N;
+      i = q % N;
+    } else {
+      const int q = lane + 64 * (m / 3);
+      blk = q / M;
+      i = (m % 3) * M + q % M;
+    }
     A[2 * N * blk + 2 * i] = xu_normalize(xa[m], s - 1);
     A[2 * N * blk + 2 * N - 1 - 2 * i] = xu_normalize(xb[m], s - 1);
   }
   wave_sync();
   shiftp += s - 1;
   if (shiftp - XU_SHIFT_OLAP > 31) shiftp = 31 + XU_SHIFT_OLAP;
-  (void)NB;
   return shiftp;
+}
+
+/* one channel-frame of L = ccfl lines */
+template <int L>
+__device__ __forceinline__ void frame(const XaacUsacImdctParams &p, int ch, int32_t *A, int32_t *B, int lane, int seq, int shape,
+                                      int shape_prev) {
+  const int32_t *coef = p.coef + (size_t)ch * L;
+  int32_t *gov = p.overlap + (size_t)ch * L;
+  const int shiftp = seq == 2 ? transform<L, true>(coef, A, B, lane, 0) : transform<L, false>(coef, A, B, lane, 0);
+  const int oq = xu_long_output_q(shiftp);
+  const Lds x = {A};
+  const Glb ov = {gov};
+  constexpr int SP = L / 64; /* samples per lane */
+  int32_t out[SP], nov[SP];
+  if (seq != 2) {
+    const bool stop_like = seq == 3 || seq == 4;
+#pragma unroll
+    for (int m = 0; m < SP; m++) {
+      const int i = lane + 64 * m;
+      out[m] = xu_scale_adj(xu_long_sample<L>(x, ov, i, shiftp, stop_like, shape_prev), oq);
+      nov[m] = xu_long_overlap<L>(x, i, shiftp);
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < SP; m++) {
+      const int i = lane + 64 * m;
+      out[m] = xu_scale(xu_short_sample<L>(x, ov, i, shiftp, shape, shape_prev), oq, 15);
+      nov[m] = xu_scale(xu_short_sample<L>(x, ov, L + i, shiftp, shape, shape_prev), oq, XU_SHIFT_OLAP);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < SP; m++) {
+    const int i = lane + 64 * m;
+    gov[i] = nov[m];
+    if (p.out32) p.out32[(size_t)ch * L + i] = out[m];
+    if (p.time) p.time[(size_t)ch * L + i] = (float)out[m] * 0.000030517578125f; /* ext_ch_ele.c:1008-1012 */
+  }
 }
 
 }  // namespace
@@ -130,36 +226,10 @@ __global__ __launch_bounds__(64 * XAAC_USAC_WAVES_PER_WG) void xaac_usac_imdct_k
     if (lane == 0 && p.status) p.status[ch] = XAAC_FATAL_BAD_WINDOW_SEQ;
     return;
   }
-  const int32_t *coef = p.coef + (size_t)ch * 1024;
-  int32_t *gov = p.overlap + (size_t)ch * 1024;
-  const int shiftp = seq == 2 ? transform<64>(coef, A, B, lane, 0) : transform<512>(coef, A, B, lane, 0);
-  const int oq = xu_long_output_q(shiftp);
-  const Lds x = {A};
-  const Glb ov = {gov};
-  int32_t out[16], nov[16];
-  if (seq != 2) {
-    const bool stop_like = seq == 3 || seq == 4;
-#pragma unroll
-    for (int m = 0; m < 16; m++) {
-      const int i = lane + 64 * m;
-      out[m] = xu_scale_adj(xu_long_sample(x, ov, i, shiftp, stop_like, shape_prev), oq);
-      nov[m] = xu_long_overlap(x, i, shiftp);
-    }
-  } else {
-#pragma unroll
-    for (int m = 0; m < 16; m++) {
-      const int i = lane + 64 * m;
-      out[m] = xu_scale(xu_short_sample(x, ov, i, shiftp, shape, shape_prev), oq, 15);
-      nov[m] = xu_scale(xu_short_sample(x, ov, 1024 + i, shiftp, shape, shape_prev), oq, XU_SHIFT_OLAP);
-    }
-  }
-#pragma unroll
-  for (int m = 0; m < 16; m++) {
-    const int i = lane + 64 * m;
-    gov[i] = nov[m];
-    if (p.out32) p.out32[(size_t)ch * 1024 + i] = out[m];
-    if (p.time) p.time[(size_t)ch * 1024 + i] = (float)out[m] * 0.000030517578125f; /* ext_ch_ele.c:1008-1012 */
-  }
+  if (p.ccfl == 768)
+    frame<768>(p, ch, A, B, lane, seq, shape, shape_prev);
+  else
+    frame<1024>(p, ch, A, B, lane, seq, shape, shape_prev);
   if (lane == 0) {
     p.shape_prev[ch] = (uint8_t)shape; /* ext_ch_ele.c:1015 */
     if (p.status) p.status[ch] = XAAC_OK;

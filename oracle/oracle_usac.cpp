@@ -1,6 +1,6 @@
 /*
  * oracle_usac.cpp -- TEST INFRASTRUCTURE: CPU restatement of the USAC frequency-domain IMDCT of one channel-frame
- * (ixheaacd_fd_frm_dec with ccfl = 1024, no FAC, previous frame FD: decoder/ixheaacd_imdct.c:596 -> :477 / :336).
+ * (ixheaacd_fd_frm_dec with ccfl = 1024 or 768, no FAC, previous frame FD: decoder/ixheaacd_imdct.c:596 -> :477 / :336).
  * The arithmetic is libxaac_amd/csrc/usac_imdct.h compiled for the host and run as plain sequential loops; pinned
  * against the compiled reference by tests/test_usac_oracle_vs_reference.py (oracle/ref_harness.c: ref_usac_fd_imdct).
  * Only tests/, __graft_entry__.smoke() and bench.py's checker legs may use it.
@@ -24,20 +24,52 @@ int max_shift(const int32_t *x, int n) { /* imdct.c:82-92 */
   return fx_norm32(m);
 }
 
+struct Strided { /* words of the sub-sequence 3 j + s of an interleaved (re, im) array */
+  int32_t *p;
+  int s;
+  int32_t &operator[](int w) const { return p[2 * (3 * (w >> 1) + s) + (w & 1)]; }
+};
+
+template <int M, class In>
+void fft_pow2(const In &in, int32_t *y) { /* ixheaacd_complex_fft_p2_dec, fft_mode 1, on M already divided points */
+  const Mem my = {y};
+  for (int b = 0; b < M / 4; b++) xu_fft_first<M>(in, my, b);
+  for (int del = 4; del < M / 2; del *= 4)
+    for (int b = 0; b < M / 4; b++) xu_fft_pass<M>(my, del, b);
+  if (xu_not_pow4<M>())
+    for (int b = 0; b < M / 2; b++) xu_fft_last<M>(my, b);
+}
+
 template <int N>
 void transform(int32_t *blk) { /* ixheaacd_acelp_imdct on 2N lines in place */
+  constexpr int M = xu_sub_points<N>();
   int32_t a[2 * N], y[2 * N];
+  if (M != N)
+    for (int i = 0; i < 2 * N; i++) blk[i] = xu_third_twice(blk[i]);
   for (int i = 0; i < N; i++) {
     const XuCx v = xu_pre_twiddle<N>(blk[2 * i], blk[2 * N - 1 - 2 * i], i);
     a[2 * i] = v.r;
     a[2 * i + 1] = v.i;
   }
-  const Mem ma = {a}, my = {y};
-  for (int b = 0; b < N / 4; b++) xu_fft_first<N>(ma, my, b);
-  for (int del = 4; del < N / 2; del *= 4)
-    for (int b = 0; b < N / 4; b++) xu_fft_pass<N>(my, del, b);
-  if (N == 512)
-    for (int b = 0; b < 256; b++) xu_fft_last512(my, b);
+  if (M == N) {
+    const Mem ma = {a};
+    fft_pow2<M>(ma, y);
+  } else {
+    for (int s = 0; s < 3; s++) {
+      const Strided in = {a, s};
+      fft_pow2<M>(in, y + 2 * M * s);
+    }
+    for (int g = 0; g < M; g++) {
+      XuCx o[3];
+      const XuCx x0 = {y[2 * g], y[2 * g + 1]}, x1 = {y[2 * M + 2 * g], y[2 * M + 2 * g + 1]}, x2 = {y[4 * M + 2 * g], y[4 * M + 2 * g + 1]};
+      xu_p3_group<M>(x0, x1, x2, g, o);
+      for (int q = 0; q < 3; q++) {
+        a[2 * (q * M + g)] = o[q].r;
+        a[2 * (q * M + g) + 1] = o[q].i;
+      }
+    }
+    memcpy(y, a, sizeof(a));
+  }
   for (int i = 0; i < N; i++) {
     const XuCx in = {y[2 * i], y[2 * i + 1]};
     const XuCx v = xu_post_twiddle<N>(in, i);
@@ -46,40 +78,51 @@ void transform(int32_t *blk) { /* ixheaacd_acelp_imdct on 2N lines in place */
   }
 }
 
-}  // namespace
-
-extern "C" {
-
-/* coef: 1024 lines (left as the reference leaves coef_fix: normalised and transformed in place); overlap: 1024 words in /
-   out; seq 0..4 (ixheaacd_cnst.h:100-104); shape / shape_prev 0 sine, 1 KBD; out: 1024 words in Q15.  Returns 0. */
-int xo_usac_fd_imdct(int32_t *coef, int32_t *overlap, int seq, int shape, int shape_prev, int32_t *out) {
-  int s = max_shift(coef, 1024);
-  for (int i = 0; i < 1024; i++) coef[i] = fx_shlw(coef[i], s);
+template <int L>
+int fd_imdct(int32_t *coef, int32_t *overlap, int seq, int shape, int shape_prev, int32_t *out) {
+  int s = max_shift(coef, L);
+  for (int i = 0; i < L; i++) coef[i] = fx_shlw(coef[i], s);
   int shiftp = s + 6;
   if (seq != 2) {
-    transform<512>(coef);
-    shiftp += xu_imdct_q_gain<512>();
+    transform<L / 2>(coef);
+    shiftp += xu_imdct_q_gain<L / 2>();
   } else {
-    for (int k = 0; k < 8; k++) transform<64>(coef + 128 * k);
-    shiftp += xu_imdct_q_gain<64>();
+    for (int k = 0; k < 8; k++) transform<L / 16>(coef + (L / 8) * k);
+    shiftp += xu_imdct_q_gain<L / 16>();
   }
-  s = max_shift(coef, 1024);
-  for (int i = 0; i < 1024; i++) coef[i] = xu_normalize(coef[i], s - 1);
+  s = max_shift(coef, L);
+  for (int i = 0; i < L; i++) coef[i] = xu_normalize(coef[i], s - 1);
   shiftp += s - 1;
   if (shiftp - XU_SHIFT_OLAP > 31) shiftp = 31 + XU_SHIFT_OLAP;
   const Mem x = {coef}, ov = {overlap};
   const int oq = xu_long_output_q(shiftp);
-  int32_t nov[1024];
+  int32_t nov[L];
   if (seq != 2) {
     const bool stop_like = seq == 3 || seq == 4;
-    for (int i = 0; i < 1024; i++) out[i] = xu_scale_adj(xu_long_sample(x, ov, i, shiftp, stop_like, shape_prev), oq);
-    for (int i = 0; i < 1024; i++) nov[i] = xu_long_overlap(x, i, shiftp);
+    for (int i = 0; i < L; i++) out[i] = xu_scale_adj(xu_long_sample<L>(x, ov, i, shiftp, stop_like, shape_prev), oq);
+    for (int i = 0; i < L; i++) nov[i] = xu_long_overlap<L>(x, i, shiftp);
   } else {
-    for (int i = 0; i < 1024; i++) out[i] = xu_scale(xu_short_sample(x, ov, i, shiftp, shape, shape_prev), oq, 15);
-    for (int i = 0; i < 1024; i++) nov[i] = xu_scale(xu_short_sample(x, ov, 1024 + i, shiftp, shape, shape_prev), oq, XU_SHIFT_OLAP);
+    for (int i = 0; i < L; i++) out[i] = xu_scale(xu_short_sample<L>(x, ov, i, shiftp, shape, shape_prev), oq, 15);
+    for (int i = 0; i < L; i++) nov[i] = xu_scale(xu_short_sample<L>(x, ov, L + i, shiftp, shape, shape_prev), oq, XU_SHIFT_OLAP);
   }
   memcpy(overlap, nov, sizeof(nov));
   return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* coef: ccfl lines (left as the reference leaves coef_fix: normalised and transformed in place); overlap: ccfl words in /
+   out; seq 0..4 (ixheaacd_cnst.h:100-104); shape / shape_prev 0 sine, 1 KBD; out: ccfl words in Q15.  ccfl 1024 or 768.
+   Returns 0, -1 for another ccfl. */
+int xo_usac_fd_imdct_ccfl(int32_t *coef, int32_t *overlap, int ccfl, int seq, int shape, int shape_prev, int32_t *out) {
+  if (ccfl == 1024) return fd_imdct<1024>(coef, overlap, seq, shape, shape_prev, out);
+  if (ccfl == 768) return fd_imdct<768>(coef, overlap, seq, shape, shape_prev, out);
+  return -1;
+}
+int xo_usac_fd_imdct(int32_t *coef, int32_t *overlap, int seq, int shape, int shape_prev, int32_t *out) {
+  return fd_imdct<1024>(coef, overlap, seq, shape, shape_prev, out);
 }
 
 }  // extern "C"

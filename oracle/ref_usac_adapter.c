@@ -33,13 +33,13 @@
 
 WORD32 ixheaacd_fd_frm_dec(ia_usac_data_struct *usac_data, WORD32 i_ch);
 
-/* coef: 1024 lines in / out (the reference transforms coef_fix in place); overlap: 1024 words in / out; out: 1024 Q15
-   words; time: 1024 floats as the caller makes them (ixheaacd_ext_ch_ele.c:1008-1012) */
-int ref_usac_fd_imdct(WORD32 *coef, WORD32 *overlap, int seq, int shape, int shape_prev, WORD32 *out, FLOAT32 *time) {
+/* coef: ccfl lines in / out (the reference transforms coef_fix in place); overlap: ccfl words in / out; out: ccfl Q15
+   words; time: ccfl floats as the caller makes them (ixheaacd_ext_ch_ele.c:1008-1012).  ccfl 1024 or 768. */
+int ref_usac_fd_imdct_ccfl(WORD32 *coef, WORD32 *overlap, int ccfl, int seq, int shape, int shape_prev, WORD32 *out, FLOAT32 *time) {
   static __thread ia_usac_data_struct *u;
   int k, err;
   if (!u) u = (ia_usac_data_struct *)calloc(1, sizeof(*u));
-  u->ccfl = 1024;
+  u->ccfl = ccfl;
   u->ec_flag = 0;
   u->frame_ok = 1;
   u->td_frame_prev[0] = 0;
@@ -49,13 +49,16 @@ int ref_usac_fd_imdct(WORD32 *coef, WORD32 *overlap, int seq, int shape, int sha
   u->window_shape_prev[0] = shape_prev;
   u->coef_fix[0] = u->arr_coef_fix[0];
   u->str_tddec[0] = &u->arr_str_tddec[0];
-  memcpy(u->coef_fix[0], coef, sizeof(WORD32) * 1024);
-  memcpy(u->overlap_data_ptr[0], overlap, sizeof(WORD32) * 1024);
-  memset(u->output_data_ptr[0], 0, sizeof(WORD32) * 1024);
+  memcpy(u->coef_fix[0], coef, sizeof(WORD32) * ccfl);
+  memcpy(u->overlap_data_ptr[0], overlap, sizeof(WORD32) * ccfl);
+  memset(u->output_data_ptr[0], 0, sizeof(WORD32) * ccfl);
   err = ixheaacd_fd_frm_dec(u, 0);
-  memcpy(coef, u->coef_fix[0], sizeof(WORD32) * 1024);
-  memcpy(overlap, u->overlap_data_ptr[0], sizeof(WORD32) * 1024);
-  memcpy(out, u->output_data_ptr[0], sizeof(WORD32) * 1024);
-  for (k = 0; k < 1024; k++) time[k] = (FLOAT32)((FLOAT32)out[k] * (FLOAT32)0.000030517578125) /* ONE_BY_TWO_POW_15, ext_ch_ele.c:146 */;
+  memcpy(coef, u->coef_fix[0], sizeof(WORD32) * ccfl);
+  memcpy(overlap, u->overlap_data_ptr[0], sizeof(WORD32) * ccfl);
+  memcpy(out, u->output_data_ptr[0], sizeof(WORD32) * ccfl);
+  for (k = 0; k < ccfl; k++) time[k] = (FLOAT32)((FLOAT32)out[k] * (FLOAT32)0.000030517578125) /* ONE_BY_TWO_POW_15, ext_ch_ele.c:146 */;
   return err;
+}
+int ref_usac_fd_imdct(WORD32 *coef, WORD32 *overlap, int seq, int shape, int shape_prev, WORD32 *out, FLOAT32 *time) {
+  return ref_usac_fd_imdct_ccfl(coef, overlap, 1024, seq, shape, shape_prev, out, time);
 }

@@ -11,7 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-from make_golden_usac_imdct import CHAINS, FRAMES, chain_coef, crc  # noqa: E402
+from make_golden_usac_imdct import CHAINS, CHAINS_768, FRAMES, FRAMES_768, chain_coef, crc  # noqa: E402
 import test_usac_oracle_vs_reference as t  # noqa: E402
 
 GOLD = np.load(os.path.join(ROOT, "tests", "golden", "usac_imdct_ref.npz"))
@@ -21,69 +21,79 @@ def _start_shape_prev(c):
     return c & 1
 
 
-def test_oracle_matches_reference_chains(oracle):
-    for c in range(CHAINS):
-        ov = np.zeros(1024, np.int32)
+def _fixture(ccfl):
+    return (CHAINS, FRAMES, "") if ccfl == 1024 else (CHAINS_768, FRAMES_768, "768")
+
+
+@pytest.mark.parametrize("ccfl", [1024, 768])
+def test_oracle_matches_reference_chains(oracle, ccfl):
+    chains, frames, key = _fixture(ccfl)
+    assert chains * frames >= 500
+    for c in range(chains):
+        ov = np.zeros(ccfl, np.int32)
         shape_prev = _start_shape_prev(c)
-        for f in range(FRAMES):
-            seq, shape = (int(v) for v in GOLD["side"][c, f])
-            rc, _, ov, out = t.orc_call(oracle, chain_coef(c, f), ov, seq, shape, shape_prev)
+        for f in range(frames):
+            seq, shape = (int(v) for v in GOLD["side" + key][c, f])
+            rc, _, ov, out = t.orc_call(oracle, chain_coef(c, f, ccfl), ov, seq, shape, shape_prev)
             assert rc == 0
-            assert (crc(out), crc(ov)) == tuple(int(v) for v in GOLD["crc"][c, f]), (c, f, seq)
+            assert (crc(out), crc(ov)) == tuple(int(v) for v in GOLD["crc" + key][c, f]), (c, f, seq)
             shape_prev = shape
-        assert np.array_equal(out, GOLD["last"][c, 0]) and np.array_equal(ov, GOLD["last"][c, 1])
+        assert np.array_equal(out, GOLD["last" + key][c, 0]) and np.array_equal(ov, GOLD["last" + key][c, 1])
 
 
 @pytest.mark.gpu
-def test_gpu_reference_chains():
+@pytest.mark.parametrize("ccfl", [1024, 768])
+def test_gpu_reference_chains(ccfl):
     import torch
     import libxaac_amd
     dev = torch.device("cuda:0")
     ctx = libxaac_amd.XaacContext(0, None)
-    n = CHAINS + 1  # + a copy of chain 0: the batch is not a multiple of the workgroup's four channel-frames
-    idx = list(range(CHAINS)) + [0]
-    ov = torch.zeros((n, 1024), dtype=torch.int32, device=dev)
+    chains, frames, key = _fixture(ccfl)
+    n = chains + 1  # + a copy of chain 0: the batch is not a multiple of the workgroup's four channel-frames
+    idx = list(range(chains)) + [0]
+    ov = torch.zeros((n, ccfl), dtype=torch.int32, device=dev)
     sp = torch.tensor([_start_shape_prev(c) for c in idx], dtype=torch.uint8, device=dev)
-    out = torch.zeros((n, 1024), dtype=torch.int32, device=dev)
-    tm = torch.zeros((n, 1024), dtype=torch.float32, device=dev)
+    out = torch.zeros((n, ccfl), dtype=torch.int32, device=dev)
+    tm = torch.zeros((n, ccfl), dtype=torch.float32, device=dev)
     status = torch.full((n,), 7, dtype=torch.int32, device=dev)
-    for f in range(FRAMES):
-        coef = torch.from_numpy(np.stack([chain_coef(c, f) for c in idx])).to(dev)
-        ics = torch.from_numpy(np.stack([GOLD["side"][c, f] for c in idx])).to(dev)
-        ctx.usac_imdct_process_batch(coef, ics, ov, sp, out, tm, status)
+    for f in range(frames):
+        coef = torch.from_numpy(np.stack([chain_coef(c, f, ccfl) for c in idx])).to(dev)
+        ics = torch.from_numpy(np.stack([GOLD["side" + key][c, f] for c in idx])).to(dev)
+        ctx.usac_imdct_process_batch(coef, ics, ov, sp, out, tm, status, ccfl=ccfl)
         ctx.sync()
         o, v = out.cpu().numpy(), ov.cpu().numpy()
         assert not status.cpu().numpy().any()
-        for c in range(CHAINS):
-            assert (crc(o[c]), crc(v[c])) == tuple(int(x) for x in GOLD["crc"][c, f]), (c, f, GOLD["side"][c, f])
-        assert np.array_equal(o[CHAINS], o[0]) and np.array_equal(v[CHAINS], v[0])
+        for c in range(chains):
+            assert (crc(o[c]), crc(v[c])) == tuple(int(x) for x in GOLD["crc" + key][c, f]), (c, f, GOLD["side" + key][c, f])
+        assert np.array_equal(o[chains], o[0]) and np.array_equal(v[chains], v[0])
         assert np.array_equal(tm.cpu().numpy(), o.astype(np.float32) * np.float32(2.0 ** -15))
         assert np.array_equal(sp.cpu().numpy(), ics.cpu().numpy()[:, 1])
-    assert np.array_equal(o[:CHAINS], GOLD["last"][:, 0]) and np.array_equal(v[:CHAINS], GOLD["last"][:, 1])
+    assert np.array_equal(o[:chains], GOLD["last" + key][:, 0]) and np.array_equal(v[:chains], GOLD["last" + key][:, 1])
 
 
 @pytest.mark.gpu
-def test_gpu_large_batch_vs_oracle(oracle):
+@pytest.mark.parametrize("L", [1024, 768])
+def test_gpu_large_batch_vs_oracle(oracle, L):
     import torch
     import libxaac_amd
     dev = torch.device("cuda:0")
     ctx = libxaac_amd.XaacContext(0, None)
     n = 4099
     rng = np.random.default_rng(3)
-    ov_h = np.zeros((n, 1024), np.int32)
+    ov_h = np.zeros((n, L), np.int32)
     sp_h = rng.integers(0, 2, n).astype(np.uint8)
     seq = rng.integers(0, 5, n)
     ov = torch.from_numpy(ov_h).to(dev)
     sp = torch.from_numpy(sp_h).to(dev)
-    out = torch.zeros((n, 1024), dtype=torch.int32, device=dev)
+    out = torch.zeros((n, L), dtype=torch.int32, device=dev)
     check = np.concatenate([np.arange(0, 40), rng.integers(0, n, 60), [n - 3, n - 2, n - 1]])
     for f in range(3):
         lvl = rng.integers(0, 27, (n, 1))
-        coef = (rng.integers(-2 ** 31, 2 ** 31, (n, 1024)) >> lvl).astype(np.int32)
+        coef = (rng.integers(-2 ** 31, 2 ** 31, (n, L)) >> lvl).astype(np.int32)
         coef[rng.integers(0, n, 50)] = 0
         shape = rng.integers(0, 2, n).astype(np.uint8)
         ics = np.stack([seq.astype(np.uint8), shape], 1)
-        ctx.usac_imdct_process_batch(torch.from_numpy(coef).to(dev), torch.from_numpy(ics).to(dev), ov, sp, out)
+        ctx.usac_imdct_process_batch(torch.from_numpy(coef).to(dev), torch.from_numpy(ics).to(dev), ov, sp, out, ccfl=L)
         ctx.sync()
         o, v = out.cpu().numpy(), ov.cpu().numpy()
         for c in check:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Build tests/golden/usac_imdct_ref.npz: chains of the REAL ixheaacd_fd_frm_dec (decoder/ixheaacd_imdct.c:596; ccfl 1024,
-FD after FD, no FAC) run by the compiled reference (oracle/_ref/libref_harness.so through oracle/ref_usac_adapter.c) with
+"""Build tests/golden/usac_imdct_ref.npz: chains of the REAL ixheaacd_fd_frm_dec (decoder/ixheaacd_imdct.c:596; ccfl 1024
+and 768, FD after FD, no FAC) run by the compiled reference (oracle/_ref/libref_harness.so through oracle/ref_usac_adapter.c) with
 the overlap carried from frame to frame along legal window-sequence walks.
 
 The 1024 spectral lines of a frame are NOT stored: tests regenerate them from (chain, frame) with chain_coef() below
@@ -27,10 +27,13 @@ def _mix(base, n):
     return z ^ (z >> np.uint64(31))
 
 
-def chain_coef(chain, frame):
-    """1024 spectral lines: uniform noise at a level that walks with (chain, frame); every 5th frame sparse tonal lines,
-    every 11th silence, every 13th one full-scale line in low-level noise"""
-    z = _mix((1 << 30) | (chain << 12) | frame, 1024)
+CHAINS_768, FRAMES_768 = 16, 40
+
+
+def chain_coef(chain, frame, ccfl=1024):
+    """ccfl spectral lines: uniform noise at a level that walks with (chain, frame); every 5th frame sparse tonal lines,
+    every 11th silence, every 13th one full-scale line in low-level noise (ccfl 768: its own counter range)"""
+    z = _mix((1 << 30) | (chain << 12) | frame | ((1 << 24) if ccfl == 768 else 0), ccfl)
     v = (z >> np.uint64(32)).astype(np.int64) - (1 << 31)            # 32-bit signed, uniform
     level = (3 * chain + 5 * frame) % 27                             # right shift 0 .. 26
     x = v >> level
@@ -41,7 +44,7 @@ def chain_coef(chain, frame):
         x = np.where(keep, x, 0)
     elif frame % 13 == 12:
         x = v >> 25
-        x[int(z[0] & np.uint64(1023))] = -(1 << 31) if (int(z[1]) & 1) else (1 << 31) - 1
+        x[int(z[0] & np.uint64(1023)) % ccfl] = -(1 << 31) if (int(z[1]) & 1) else (1 << 31) - 1
     return x.astype(np.int32)
 
 
@@ -74,8 +77,25 @@ def main():
             crcs[c, f] = crc(out), crc(ov)
             seq, shape_prev = nxt, shape
         last[c, 0], last[c, 1] = out, ov
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "usac_imdct_ref.npz"), side=side, crc=crcs, last=last)
-    print("wrote", CHAINS, "chains x", FRAMES, "frames; sequences seen:", np.bincount(side[:, :, 0].ravel(), minlength=5))
+    # ccfl 768 (768- / 96-line transforms = 3 x radix-4 + ixheaacd_complex_fft_p3's three-point stage, the 768 / 96 windows)
+    side8 = np.zeros((CHAINS_768, FRAMES_768, 2), np.uint8)
+    crcs8 = np.zeros((CHAINS_768, FRAMES_768, 2), np.uint32)
+    last8 = np.zeros((CHAINS_768, 2, 768), np.int32)
+    for c in range(CHAINS_768):
+        ov = np.zeros(768, np.int32)
+        seq, shape_prev = (0, 1, 3, 4)[c % 4] if c >= 4 else 0, c & 1
+        for f in range(FRAMES_768):
+            shape, nxt = chain_side(c + 64, f, seq)
+            rc, _, ov, out, _ = t.ref_call(ref, chain_coef(c, f, 768), ov, seq, shape, shape_prev)
+            assert rc == 0
+            side8[c, f] = seq, shape
+            crcs8[c, f] = crc(out), crc(ov)
+            seq, shape_prev = nxt, shape
+        last8[c, 0], last8[c, 1] = out, ov
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "usac_imdct_ref.npz"), side=side, crc=crcs, last=last, side768=side8,
+                        crc768=crcs8, last768=last8)
+    print("wrote", CHAINS, "chains x", FRAMES, "frames; sequences seen:", np.bincount(side[:, :, 0].ravel(), minlength=5),
+          "and", CHAINS_768, "x", FRAMES_768, "of 768 lines:", np.bincount(side8[:, :, 0].ravel(), minlength=5))
 
 
 if __name__ == "__main__":
