@@ -351,13 +351,19 @@ typedef struct xaac_esbr_syn_batch {
  *      ixheaacd_fd_imdct_short :336, ixheaacd_acelp_imdct :186, ixheaacd_complex_fft_p2_dec ixheaacd_fft.c:1412),
  *      call site decoder/ixheaacd_ext_ch_ele.c:991, with the caller's float conversion and shape hand-over (:1008-1016).
  * Scope: ccfl = 1024 or 768 (the 768 / 96-line transforms run three power-of-two transforms and ixheaacd_complex_fft_p3's
- * three-point stage, ixheaacd_fft.c:2531), FD frame after an FD frame (td_frame_prev = 0), no FAC data, no error concealment.  One frame of
+ * three-point stage, ixheaacd_fft.c:2531); FD frames after FD frames and after LPD frames (td_frame_prev, FAC signal handed in:
+ * see lpd_flags / fac below); no error concealment.  One frame of
  * one channel per entry; the overlap is the reference's overlap_data_ptr row (Q14, un-windowed), so a channel can move
  * between a reference decoder and this library at any frame boundary. */
 typedef struct xaac_usac_ics {
   uint8_t window_sequence; /* 0 ONLY_LONG, 1 LONG_START, 2 EIGHT_SHORT, 3 LONG_STOP, 4 STOP_START (ixheaacd_cnst.h:100) */
   uint8_t window_shape;    /* 0 sine, 1 KBD */
 } xaac_usac_ics;
+
+typedef struct xaac_usac_fac {
+  int32_t q;                 /* fac_q */
+  int32_t data[256];         /* fac_idata[0 .. 2 lfac), lfac <= FAC_LENGTH = 128 */
+} xaac_usac_fac;
 
 typedef struct xaac_usac_imdct_batch {
   int32_t n_ch;
@@ -368,7 +374,17 @@ typedef struct xaac_usac_imdct_batch {
   uint8_t *shape_prev;       /* [n_ch] in/out: window_shape_prev */
   int32_t *out32;            /* optional [n_ch][ccfl]: output_data_ptr (Q15) */
   float *time;               /* optional [n_ch][ccfl]: time_sample_vector (= out32 * 2^-15) */
-  int32_t *status;           /* optional [n_ch]: XAAC_OK or XAAC_FATAL_BAD_WINDOW_SEQ (channel-frame left untouched) */
+  int32_t *status;           /* optional [n_ch]: XAAC_OK or XAAC_FATAL_BAD_WINDOW_SEQ / _BAD_ARG (channel-frame left untouched) */
+  /* LPD -> FD transitions (ixheaacd_fd_frm_dec :618-640).  lpd_flags, optional [n_ch]: bit 0 = usac_data->td_frame_prev
+     (the slope behind an LPD frame is 2 lfac samples long, lfac = ccfl / 16 for EIGHT_SHORT, ccfl / 8 else), bit 1 =
+     usac_data->fac_data_present.  fac, optional [n_ch]: the forward-aliasing-cancellation signal of the channels with bit
+     1 set, as ixheaacd_cal_fac_data (:210) leaves it for the windowing -- fac_idata[0 .. 2 lfac) and its exponent: it is
+     made from the LPD decoder's state (previous LPC filter, ACELP zero-input response), which stays on the host.
+     Behind an LPD frame out32 / time are what the reference holds once ixheaacd_lpd_bpf_fix -- the LPD decoder's bass
+     post filter, also LPD state -- has been the identity (Q15 -> float -> Q15 as imdct.c:459-470 does around it): the
+     host applies its filter to `time` and converts back. */
+  const uint8_t *lpd_flags;
+  const struct xaac_usac_fac *fac;
 } xaac_usac_imdct_batch;
 
 typedef struct xaac_ctx xaac_ctx;

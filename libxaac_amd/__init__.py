@@ -87,7 +87,7 @@ class _UsacImdctBatch(ctypes.Structure):
     # struct xaac_usac_imdct_batch
     _fields_ = [("n_ch", ctypes.c_int32), ("ccfl", ctypes.c_int32), ("coef", ctypes.c_void_p), ("ics", ctypes.c_void_p),
                 ("overlap", ctypes.c_void_p), ("shape_prev", ctypes.c_void_p), ("out32", ctypes.c_void_p),
-                ("time", ctypes.c_void_p), ("status", ctypes.c_void_p)]
+                ("time", ctypes.c_void_p), ("status", ctypes.c_void_p), ("lpd_flags", ctypes.c_void_p), ("fac", ctypes.c_void_p)]
 
 
 class _QmfAnaEldBatch(ctypes.Structure):
@@ -515,7 +515,8 @@ class XaacContext:
         if rc != 0:
             raise XaacError(rc, "xaac_sbr_state_handover")
 
-    def usac_imdct_process_batch(self, coef, ics, overlap, shape_prev, out32=None, time=None, status=None, ccfl=1024):
+    def usac_imdct_process_batch(self, coef, ics, overlap, shape_prev, out32=None, time=None, status=None, ccfl=1024,
+                                 lpd_flags=None, fac=None):
         """Batched ixheaacd_fd_frm_dec (USAC FD frame after an FD frame, ccfl 1024 or 768, no FAC): coef int32[n_ch, ccfl];
         ics uint8[n_ch, 2] (window_sequence 0..4, window_shape); overlap int32[n_ch, ccfl] in/out; shape_prev uint8[n_ch]
         in/out; out32 int32[n_ch, ccfl] (Q15) and / or time float32[n_ch, ccfl]; status int32[n_ch]."""
@@ -529,6 +530,10 @@ class XaacContext:
         b.out32 = _ptr(out32, "int32", n_ch * ccfl, allow_none=True, device_ok=True)
         b.time = _ptr(time, "float32", n_ch * ccfl, allow_none=True, device_ok=True)
         b.status = _ptr(status, "int32", n_ch, allow_none=True, device_ok=True)
+        # LPD -> FD transitions: lpd_flags uint8[n_ch] (bit 0 td_frame_prev, bit 1 fac_data_present), fac int32[n_ch, 257]
+        # (struct xaac_usac_fac: q, data[256])
+        b.lpd_flags = _ptr(lpd_flags, "uint8", n_ch, allow_none=True, device_ok=True)
+        b.fac = _ptr(fac, "int32", n_ch * 257, allow_none=True, device_ok=True)
         rc = self._lib.xaac_usac_imdct_process_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_usac_imdct_process_batch")

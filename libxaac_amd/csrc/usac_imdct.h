@@ -261,19 +261,38 @@ FX_HD const int32_t *xu_window(int len, int shape) { /* ixheaacd_calc_window (ix
     case 1024: return shape ? xaac_usac_kbd_win_1024 : xaac_usac_sine_win_1024;
     case 768: return shape ? xaac_usac_kbd_win_768 : xaac_usac_sine_win_768;
     case 128: return shape ? xaac_usac_kbd_win_128 : xaac_usac_sine_win_128;
+    case 256: return xaac_usac_sine_win_256; /* no KBD window of this length: xu_lpd_window_missing() */
+    case 192: return shape ? xaac_usac_kbd_win_192 : xaac_usac_sine_win_192;
     default: return shape ? xaac_usac_kbd_win_96 : xaac_usac_sine_win_96;
   }
+}
+
+/* ---- the frame behind an LPD frame (td_frame_prev) and forward-aliasing cancellation (fac_data_present) ---------------
+ * ixheaacd_fd_frm_dec (imdct.c:618-633): behind a time-domain frame the left slope is 2 lfac samples long with
+ * lfac = ccfl / 16 (EIGHT_SHORT) or ccfl / 8 (other sequences); otherwise it is the short window's.  FAC data, when
+ * present, is the 2 lfac-sample signal ixheaacd_cal_fac_data leaves in fac_idata (with its exponent fac_q): computed by
+ * the LPD decoder's side (LPC synthesis of the transmitted FAC spectrum + the ACELP zero-input response) and handed in. */
+struct XuLpd {
+  int td_prev, fac;     /* usac_data->td_frame_prev, ->fac_data_present */
+  int fac_q;            /* exponent of the FAC signal */
+};
+template <int L> FX_HD constexpr int xu_lfac(bool td_prev, bool eight_short) { return td_prev ? (eight_short ? L / 16 : L / 8) : 128; /* FAC_LENGTH */ }
+/* ixheaacd_calc_window fails for a KBD window of 256 taps (ixheaacd_Windowing.c:63-104): ccfl 1024, LONG_STOP / STOP_START
+   behind an LPD frame with window_shape_prev = 1 */
+template <int L> FX_HD bool xu_lpd_window_missing(bool td_prev, int seq, int shape_prev) {
+  return L == 1024 && td_prev && (seq == 3 || seq == 4) && shape_prev == 1;
 }
 
 /* ---- long blocks: output sample i (0 .. L-1) of the frame, before the final rescale; L = ccfl -----------------------
  * x: the L transform outputs after the second renormalisation; ov: the overlap (Q14); shiftp: their exponent.
  * ONLY_LONG / LONG_START: windowing_long1 (basic_ops.c:77); LONG_STOP / STOP_START: windowing_long3 (:298), no FAC:
  * flat part of (L - L/8) / 2 samples, then the L/8-sample slope of the previous shape's short window. */
-template <int L, class Mem, class Ov>
-FX_HD int32_t xu_long_sample(const Mem &x, const Ov &ov, int i, int shiftp, bool stop_like, int shape_prev) {
-  constexpr int H = L / 2, S = L / 8, F = (L - S) / 2; /* half frame, short block, n_flat_ls */
-  const int d = shiftp - XU_SHIFT_OLAP; /* > 0: the transform side is shifted down; <= 0: the overlap side */
-  if (!stop_like) {
+template <int L, class Mem, class Ov, class Fac>
+FX_HD int32_t xu_long_sample_lpd(const Mem &x, const Ov &ov, const Fac &fac, int i, int shiftp, bool stop_like, int shape_prev,
+                                 const XuLpd &lp) {
+  constexpr int H = L / 2;
+  if (!stop_like) { /* windowing_long1: the whole frame under the previous shape's long window */
+    const int d = shiftp - XU_SHIFT_OLAP; /* > 0: the transform side is shifted down; <= 0: the overlap side */
     const int32_t *w = xu_window(L, shape_prev);
     const int m = i < H ? i : L - 1 - i;              /* the loop index of basic_ops.c:85 */
     const int32_t src1 = x[H + m];
@@ -281,15 +300,48 @@ FX_HD int32_t xu_long_sample(const Mem &x, const Ov &ov, int i, int shiftp, bool
     const int32_t o = i < H ? xu_mul_sh1(ov[m], w[L - 1 - m]) : xu_mul_sh1(ov[L - 1 - m], w[m]);
     return d > 0 ? fx_add_sat(t >> d, o) : fx_add_sat(t, o >> -d);
   }
-  const int32_t *w = xu_window(S, shape_prev);
-  if (i < F) return d > 0 ? ov[i] : (ov[i] >> -d);
-  if (i < F + S) {
-    const int32_t src = i < H ? x[H + i] : fx_neg_sat(x[H + L - 1 - i]);
-    const int32_t t = xu_mul_sh1(src, w[i - F]), o = xu_mul_sh1(ov[i], w[S - 1 - (i - F)]);
-    return d > 0 ? fx_add_sat(t >> d, o) : fx_add_sat(t, o >> -d);
+  /* LONG_STOP / STOP_START: flat part F, slope of W samples under the previous shape's window of that length */
+  const int lfac = xu_lfac<L>(lp.td_prev != 0, false);
+  const int W = lp.td_prev ? 2 * lfac : L / 8, F = (L - W) / 2;
+  const int32_t *w = xu_window(W, shape_prev);
+  if (!lp.fac) { /* windowing_long3 (basic_ops.c:298) */
+    const int d = shiftp - XU_SHIFT_OLAP;
+    if (i < F) return d > 0 ? ov[i] : (ov[i] >> -d);
+    if (i < F + W) {
+      const int32_t src = i < H ? x[H + i] : fx_neg_sat(x[H + L - 1 - i]);
+      const int32_t t = xu_mul_sh1(src, w[i - F]), o = xu_mul_sh1(ov[i], w[W - 1 - (i - F)]);
+      return d > 0 ? fx_add_sat(t >> d, o) : fx_add_sat(t, o >> -d);
+    }
+    const int32_t v = fx_neg_sat(x[H + L - 1 - i]);
+    return d > 0 ? (v >> d) : v;
   }
-  const int32_t v = fx_neg_sat(x[H + L - 1 - i]);
-  return d > 0 ? (v >> d) : v;
+  /* windowing_long2 (basic_ops.c:121): the old overlap up to F + lfac, the second half of the slope, the FAC signal over
+     [F + lfac, F + 3 lfac); every term comes down to q = the smallest of the three exponents (the four branches of the
+     reference are this rule; a shift by 0 is the identity) */
+  int q = shiftp < XU_SHIFT_OLAP ? shiftp : XU_SHIFT_OLAP;
+  q = lp.fac_q < q ? lp.fac_q : q;
+  const int dx = shiftp - q, dov = XU_SHIFT_OLAP - q, df = lp.fac_q - q;
+  if (i < F + lfac) return ov[i] >> dov;
+  const int32_t v = fx_neg_sat(x[H + L - 1 - i]);     /* i >= F + lfac = L / 2 */
+  if (i < F + W) return fx_add_sat(xu_mul_sh1(v, w[i - F]) >> dx, fac[i - F - lfac] >> df);
+  if (i < F + 3 * lfac) return fx_add_sat(v >> dx, fac[i - F - lfac] >> df);
+  return v >> dx;
+}
+/* the exponent xu_long_sample_lpd's value has */
+FX_HD int xu_long_output_q_lpd(int shiftp, bool stop_like, const XuLpd &lp) {
+  int q = shiftp > XU_SHIFT_OLAP ? XU_SHIFT_OLAP : shiftp;
+  if (stop_like && lp.fac && lp.fac_q < q) q = lp.fac_q;
+  return q;
+}
+/* imdct.c:459-470: p_out_buffer = (FLOAT32)out * 2^-15; [bass post filter]; out = (WORD32)(p_out_buffer * 32768) */
+FX_HD int32_t xu_float_round_trip(int32_t v) { return fx_f2i_trunc(((float)v * 0.000030517578125f) * 32768.0f); }
+struct XuNoFac {
+  FX_MEMBER int32_t operator[](int) const { return 0; }
+};
+template <int L, class Mem, class Ov>
+FX_HD int32_t xu_long_sample(const Mem &x, const Ov &ov, int i, int shiftp, bool stop_like, int shape_prev) {
+  const XuLpd none = {0, 0, 0};
+  return xu_long_sample_lpd<L>(x, ov, XuNoFac(), i, shiftp, stop_like, shape_prev, none);
 }
 FX_HD int xu_long_output_q(int shiftp) { return shiftp > XU_SHIFT_OLAP ? XU_SHIFT_OLAP : shiftp; }
 /* the new overlap, sample i (imdct.c:563-576: both branches shift right) */
@@ -312,28 +364,52 @@ FX_HD int32_t xu_scale(int32_t v, int from_q, int to_q) { return from_q > to_q ?
  * clears the overlap behind it), _short3 (block 0's tail), _short4 x 7 (basic_ops.c:430-620) as what each position ends
  * up holding: with S = L/8, F = (L - S) / 2 positions F + S k + t hold head(k, t) + tail(k - 1, t); the last tail is left
  * unwindowed for the next frame; the first F positions are the old overlap at the output exponent. */
-template <int L, class Mem, class Ov>
-FX_HD int32_t xu_short_sample(const Mem &x, const Ov &ov, int p, int shiftp, int shape, int shape_prev) {
-  constexpr int S = L / 8, F = (L - S) / 2;
+template <int L, class Mem, class Ov, class Fac>
+FX_HD int32_t xu_short_sample_lpd(const Mem &x, const Ov &ov, const Fac &fac, int p, int shiftp, int shape, int shape_prev,
+                                  const XuLpd &lp) {
+  constexpr int S = L / 8, F = (L - S) / 2; /* behind an LPD frame lfac = L / 16: the same flat part and slope length */
   const int dd = shiftp > XU_SHIFT_OLAP ? shiftp - XU_SHIFT_OLAP : 0; /* transform side down ... */
   const int od = shiftp < XU_SHIFT_OLAP ? XU_SHIFT_OLAP - shiftp : 0; /* ... or overlap side down */
+  const int lfac = xu_lfac<L>(lp.td_prev != 0, true);
   if (p < F) return ov[p] >> od; /* ixheaacd_scale_down(.., shift_olap, output_q), imdct.c:448 */
   if (p >= F + 9 * S) return 0;
   const int k = (p - F) / S, t = (p - F) % S;
   const int32_t *w = xu_window(S, shape);
-  int32_t head = 0, tail = 0;
-  if (k < 8) {
-    const int32_t *wh = k == 0 ? xu_window(S, shape_prev) : w;
-    const int32_t v = t < S / 2 ? x[S * k + S / 2 + t] : fx_neg_sat(x[S * k + S + S / 2 - 1 - t]);
-    head = xu_mul_sh1(v, wh[t]) >> dd;
-  }
-  if (k == 0) {
-    tail = xu_mul_sh1(ov[p], xu_window(S, shape_prev)[S - 1 - t]) >> od;
+  int32_t v;
+  if (lp.fac && k == 0) {
+    /* windowing_short1 (basic_ops.c:373): up to lfac the old overlap alone, then block 0's falling half under the
+       previous window WITHOUT the old overlap (and nothing where lfac reaches past the block) */
+    if (t < lfac) v = ov[p] >> od;
+    else v = xu_mul_sh1(fx_neg_sat(x[S + S / 2 - 1 - t]), xu_window(S, shape_prev)[t]) >> dd;
   } else {
-    const int32_t v = fx_neg_sat(x[S * (k - 1) + (t < S / 2 ? S / 2 - 1 - t : t - S / 2)]);
-    tail = k == 8 ? (v >> dd) : (xu_mul_sh1(v, w[S - 1 - t]) >> dd);
+    int32_t head = 0, tail = 0;
+    if (k < 8) {
+      const int32_t *wh = k == 0 ? xu_window(S, shape_prev) : w;
+      const int32_t hv = t < S / 2 ? x[S * k + S / 2 + t] : fx_neg_sat(x[S * k + S + S / 2 - 1 - t]);
+      head = xu_mul_sh1(hv, wh[t]) >> dd;
+    }
+    if (k == 0) {
+      tail = xu_mul_sh1(ov[p], xu_window(S, shape_prev)[S - 1 - t]) >> od;
+    } else {
+      const int32_t tv = fx_neg_sat(x[S * (k - 1) + (t < S / 2 ? S / 2 - 1 - t : t - S / 2)]);
+      tail = k == 8 ? (tv >> dd) : (xu_mul_sh1(tv, w[S - 1 - t]) >> dd);
+      /* with FAC windowing_short1 clears the old overlap only up to 2 F + lfac (it clears n_flat_ls + lfac words from the
+         block on): what lies between there and 2 F + S is still in place when a later block's tail is added onto it */
+      if (lp.fac && p >= 2 * F + lfac && p < 2 * F + S) tail = fx_add_sat(tail, ov[p] >> od);
+    }
+    v = k == 8 ? tail : fx_add_sat(head, tail);
   }
-  return k == 8 ? tail : fx_add_sat(head, tail);
+  if (lp.fac && p >= F + lfac && p < F + 3 * lfac) { /* ixheaacd_combine_fac (basic_ops.c:56) */
+    const int oq = shiftp > XU_SHIFT_OLAP ? XU_SHIFT_OLAP : shiftp;
+    const int32_t f = fac[p - F - lfac];
+    v = fx_add_sat(v, lp.fac_q > oq ? (f >> (lp.fac_q - oq)) : fx_shl_sat(f, oq - lp.fac_q));
+  }
+  return v;
+}
+template <int L, class Mem, class Ov>
+FX_HD int32_t xu_short_sample(const Mem &x, const Ov &ov, int p, int shiftp, int shape, int shape_prev) {
+  const XuLpd none = {0, 0, 0};
+  return xu_short_sample_lpd<L>(x, ov, XuNoFac(), p, shiftp, shape, shape_prev, none);
 }
 
 #endif

@@ -19,6 +19,8 @@ typedef struct XaacUsacImdctParams {
   int32_t *out32;
   float *time;
   int32_t *status;
+  const uint8_t *lpd_flags;  /* optional [n_ch]: bit 0 td_frame_prev, bit 1 fac_data_present */
+  const xaac_usac_fac *fac;  /* optional [n_ch] */
 } XaacUsacImdctParams;
 
 #ifdef __cplusplus

@@ -1,6 +1,6 @@
 /*
  * usac_imdct_kernel.hip -- gfx950 kernel for the USAC frequency-domain IMDCT + windowing + overlap-add of
- * ixheaacd_fd_frm_dec (decoder/ixheaacd_imdct.c:596: ccfl 1024 or 768, no FAC, previous frame FD), arithmetic in usac_imdct.h.
+ * ixheaacd_fd_frm_dec (decoder/ixheaacd_imdct.c:596: ccfl 1024 or 768; behind an FD or an LPD frame, with or without the FAC signal), arithmetic in usac_imdct.h.
  *
  * Mapping: one wave = one channel-frame, four per workgroup (they share nothing).  The 1024 lines are read once, strided
  * so that lane i holds the pairs (x[2i], x[2N-1-2i]) its pre twiddle needs; the block exponent is a wave max.  The
@@ -176,41 +176,50 @@ __device__ __forceinline__ int transform(const int32_t *coef, int32_t *A, int32_
   return shiftp;
 }
 
-/* one channel-frame of L = ccfl lines */
+/* one channel-frame of L = ccfl lines; returns XAAC_OK or the status of a refused frame (nothing written then) */
 template <int L>
-__device__ __forceinline__ void frame(const XaacUsacImdctParams &p, int ch, int32_t *A, int32_t *B, int lane, int seq, int shape,
-                                      int shape_prev) {
+__device__ __forceinline__ int frame(const XaacUsacImdctParams &p, int ch, int32_t *A, int32_t *B, int lane, int seq, int shape,
+                                     int shape_prev) {
+  const int flags = p.lpd_flags ? p.lpd_flags[ch] : 0;
+  const XuLpd lp = {flags & 1, (flags >> 1) & 1, (p.fac && (flags & 2)) ? p.fac[ch].q : 0};
+  /* FAC data only ever follows an LPD frame and needs its signal; ccfl 1024 has no 256-tap KBD window (calc_window fails) */
+  if (lp.fac && (!lp.td_prev || !p.fac)) return XAAC_FATAL_BAD_ARG;
+  if (xu_lpd_window_missing<L>(lp.td_prev != 0, seq, shape_prev)) return XAAC_FATAL_BAD_WINDOW_SEQ;
   const int32_t *coef = p.coef + (size_t)ch * L;
   int32_t *gov = p.overlap + (size_t)ch * L;
   const int shiftp = seq == 2 ? transform<L, true>(coef, A, B, lane, 0) : transform<L, false>(coef, A, B, lane, 0);
-  const int oq = xu_long_output_q(shiftp);
   const Lds x = {A};
   const Glb ov = {gov};
+  const Glb fac = {lp.fac ? p.fac[ch].data : gov};
   constexpr int SP = L / 64; /* samples per lane */
   int32_t out[SP], nov[SP];
   if (seq != 2) {
     const bool stop_like = seq == 3 || seq == 4;
+    const int oq = xu_long_output_q_lpd(shiftp, stop_like, lp);
 #pragma unroll
     for (int m = 0; m < SP; m++) {
       const int i = lane + 64 * m;
-      out[m] = xu_scale_adj(xu_long_sample<L>(x, ov, i, shiftp, stop_like, shape_prev), oq);
+      out[m] = xu_scale_adj(xu_long_sample_lpd<L>(x, ov, fac, i, shiftp, stop_like, shape_prev, lp), oq);
       nov[m] = xu_long_overlap<L>(x, i, shiftp);
     }
   } else {
+    const int oq = xu_long_output_q(shiftp);
 #pragma unroll
     for (int m = 0; m < SP; m++) {
       const int i = lane + 64 * m;
-      out[m] = xu_scale(xu_short_sample<L>(x, ov, i, shiftp, shape, shape_prev), oq, 15);
-      nov[m] = xu_scale(xu_short_sample<L>(x, ov, L + i, shiftp, shape, shape_prev), oq, XU_SHIFT_OLAP);
+      out[m] = xu_scale(xu_short_sample_lpd<L>(x, ov, fac, i, shiftp, shape, shape_prev, lp), oq, 15);
+      nov[m] = xu_scale(xu_short_sample_lpd<L>(x, ov, fac, L + i, shiftp, shape, shape_prev, lp), oq, XU_SHIFT_OLAP);
     }
   }
 #pragma unroll
   for (int m = 0; m < SP; m++) {
     const int i = lane + 64 * m;
+    if (lp.td_prev) out[m] = xu_float_round_trip(out[m]); /* imdct.c:459-470 around the LPD decoder's post filter */
     gov[i] = nov[m];
     if (p.out32) p.out32[(size_t)ch * L + i] = out[m];
     if (p.time) p.time[(size_t)ch * L + i] = (float)out[m] * 0.000030517578125f; /* ext_ch_ele.c:1008-1012 */
   }
+  return XAAC_OK;
 }
 
 }  // namespace
@@ -226,13 +235,10 @@ __global__ __launch_bounds__(64 * XAAC_USAC_WAVES_PER_WG) void xaac_usac_imdct_k
     if (lane == 0 && p.status) p.status[ch] = XAAC_FATAL_BAD_WINDOW_SEQ;
     return;
   }
-  if (p.ccfl == 768)
-    frame<768>(p, ch, A, B, lane, seq, shape, shape_prev);
-  else
-    frame<1024>(p, ch, A, B, lane, seq, shape, shape_prev);
+  const int rc = p.ccfl == 768 ? frame<768>(p, ch, A, B, lane, seq, shape, shape_prev) : frame<1024>(p, ch, A, B, lane, seq, shape, shape_prev);
   if (lane == 0) {
-    p.shape_prev[ch] = (uint8_t)shape; /* ext_ch_ele.c:1015 */
-    if (p.status) p.status[ch] = XAAC_OK;
+    if (rc == XAAC_OK) p.shape_prev[ch] = (uint8_t)shape; /* ext_ch_ele.c:1015 */
+    if (p.status) p.status[ch] = rc;
   }
 }
 

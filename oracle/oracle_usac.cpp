@@ -79,7 +79,10 @@ void transform(int32_t *blk) { /* ixheaacd_acelp_imdct on 2N lines in place */
 }
 
 template <int L>
-int fd_imdct(int32_t *coef, int32_t *overlap, int seq, int shape, int shape_prev, int32_t *out) {
+int fd_imdct(int32_t *coef, int32_t *overlap, int seq, int shape, int shape_prev, int32_t *out, int td_prev = 0, int fac_present = 0,
+             const int32_t *fac = nullptr, int fac_q = 0) {
+  if (fac_present && (!td_prev || !fac)) return -1; /* FAC data only ever follows an LPD frame */
+  if (xu_lpd_window_missing<L>(td_prev != 0, seq, shape_prev)) return -1; /* ixheaacd_calc_window fails (imdct.c:542) */
   int s = max_shift(coef, L);
   for (int i = 0; i < L; i++) coef[i] = fx_shlw(coef[i], s);
   int shiftp = s + 6;
@@ -95,16 +98,30 @@ int fd_imdct(int32_t *coef, int32_t *overlap, int seq, int shape, int shape_prev
   shiftp += s - 1;
   if (shiftp - XU_SHIFT_OLAP > 31) shiftp = 31 + XU_SHIFT_OLAP;
   const Mem x = {coef}, ov = {overlap};
-  const int oq = xu_long_output_q(shiftp);
+  const XuLpd lp = {td_prev, fac_present, fac_q};
+  const Mem fc = {const_cast<int32_t *>(fac)};
   int32_t nov[L];
   if (seq != 2) {
     const bool stop_like = seq == 3 || seq == 4;
-    for (int i = 0; i < L; i++) out[i] = xu_scale_adj(xu_long_sample<L>(x, ov, i, shiftp, stop_like, shape_prev), oq);
+    const int oq = xu_long_output_q_lpd(shiftp, stop_like, lp);
+    for (int i = 0; i < L; i++) {
+      const int32_t v = fac_present ? xu_long_sample_lpd<L>(x, ov, fc, i, shiftp, stop_like, shape_prev, lp)
+                                    : xu_long_sample_lpd<L>(x, ov, XuNoFac(), i, shiftp, stop_like, shape_prev, lp);
+      out[i] = xu_scale_adj(v, oq);
+    }
     for (int i = 0; i < L; i++) nov[i] = xu_long_overlap<L>(x, i, shiftp);
   } else {
-    for (int i = 0; i < L; i++) out[i] = xu_scale(xu_short_sample<L>(x, ov, i, shiftp, shape, shape_prev), oq, 15);
-    for (int i = 0; i < L; i++) nov[i] = xu_scale(xu_short_sample<L>(x, ov, L + i, shiftp, shape, shape_prev), oq, XU_SHIFT_OLAP);
+    const int oq = xu_long_output_q(shiftp);
+    for (int p = 0; p < 2 * L; p++) {
+      const int32_t v = fac_present ? xu_short_sample_lpd<L>(x, ov, fc, p, shiftp, shape, shape_prev, lp)
+                                    : xu_short_sample_lpd<L>(x, ov, XuNoFac(), p, shiftp, shape, shape_prev, lp);
+      if (p < L) out[p] = xu_scale(v, oq, 15);
+      else nov[p - L] = xu_scale(v, oq, XU_SHIFT_OLAP);
+    }
   }
+  if (td_prev) /* imdct.c:459-470 / :581-592 around the LPD decoder's bass post filter, which stays with the LPD decoder:
+                  Q15 -> float -> (filter) -> Q15 */
+    for (int i = 0; i < L; i++) out[i] = xu_float_round_trip(out[i]);
   memcpy(overlap, nov, sizeof(nov));
   return 0;
 }
@@ -119,6 +136,13 @@ extern "C" {
 int xo_usac_fd_imdct_ccfl(int32_t *coef, int32_t *overlap, int ccfl, int seq, int shape, int shape_prev, int32_t *out) {
   if (ccfl == 1024) return fd_imdct<1024>(coef, overlap, seq, shape, shape_prev, out);
   if (ccfl == 768) return fd_imdct<768>(coef, overlap, seq, shape, shape_prev, out);
+  return -1;
+}
+/* ... behind an LPD frame (td_prev) and / or with the 2 lfac-sample FAC signal and its exponent (fac != NULL) */
+int xo_usac_fd_imdct_lpd(int32_t *coef, int32_t *overlap, int ccfl, int seq, int shape, int shape_prev, int td_prev,
+                         const int32_t *fac, int fac_q, int32_t *out) {
+  if (ccfl == 1024) return fd_imdct<1024>(coef, overlap, seq, shape, shape_prev, out, td_prev, fac != nullptr, fac, fac_q);
+  if (ccfl == 768) return fd_imdct<768>(coef, overlap, seq, shape, shape_prev, out, td_prev, fac != nullptr, fac, fac_q);
   return -1;
 }
 int xo_usac_fd_imdct(int32_t *coef, int32_t *overlap, int seq, int shape, int shape_prev, int32_t *out) {

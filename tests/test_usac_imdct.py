@@ -133,3 +133,85 @@ def test_gpu_malformed_side_info_is_refused(oracle):
         else:
             rc, _, nov, xo = t.orc_call(oracle, coef[c], ov_h[c], int(ics[c, 0]), int(ics[c, 1]), int(sp_h[c]))
             assert st[c] == 0 and np.array_equal(xo, o[c]) and np.array_equal(nov, v[c]) and s2[c] == ics[c, 1]
+
+
+# ---- LPD -> FD transitions: tests/golden/usac_lpd_ref.npz (tools/make_golden_usac_imdct.py: make_lpd) -------------------------
+from make_golden_usac_imdct import LPD_CHAINS, LPD_FRAMES  # noqa: E402
+
+LPD = np.load(os.path.join(ROOT, "tests", "golden", "usac_lpd_ref.npz"))
+
+
+@pytest.mark.parametrize("ccfl", [1024, 768])
+def test_oracle_matches_reference_lpd_chains(oracle, ccfl):
+    """544 reference-made frames per frame length, a third of them behind an LPD frame (slope of 2 lfac samples, Q15 -> float ->
+    Q15 around the LPD decoder's post filter), two in three of those with the reference's own FAC signal"""
+    k = str(ccfl)
+    assert LPD["side" + k][:, :, 2].sum() > 150 and LPD["side" + k][:, :, 3].sum() > 100
+    for c in range(LPD_CHAINS):
+        ov = np.zeros(ccfl, np.int32)
+        shape_prev = c & 1
+        for f in range(LPD_FRAMES):
+            seq, shape, td, fac = (int(v) for v in LPD["side" + k][c, f])
+            if td:
+                shape_prev = 0
+            sig = np.ascontiguousarray(LPD["fac" + k][c, f]) if fac else None
+            rc, _, ov, out = t.orc_call_lpd(oracle, chain_coef(c + 32, f, ccfl), ov, seq, shape, shape_prev, td, sig, int(LPD["fac_q" + k][c, f]))
+            assert rc == 0
+            assert (crc(out), crc(ov)) == tuple(int(v) for v in LPD["crc" + k][c, f]), (c, f, seq, td, fac)
+            shape_prev = shape
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ccfl", [1024, 768])
+def test_gpu_reference_lpd_chains(ccfl):
+    import torch
+    import libxaac_amd
+    dev = torch.device("cuda:0")
+    ctx = libxaac_amd.XaacContext(0, None)
+    k = str(ccfl)
+    n = LPD_CHAINS
+    ov = torch.zeros((n, ccfl), dtype=torch.int32, device=dev)
+    sp = torch.tensor([c & 1 for c in range(n)], dtype=torch.uint8, device=dev)
+    out = torch.zeros((n, ccfl), dtype=torch.int32, device=dev)
+    tm = torch.zeros((n, ccfl), dtype=torch.float32, device=dev)
+    status = torch.full((n,), 7, dtype=torch.int32, device=dev)
+    for f in range(LPD_FRAMES):
+        side = LPD["side" + k][:, f]
+        coef = torch.from_numpy(np.stack([chain_coef(c + 32, f, ccfl) for c in range(n)])).to(dev)
+        ics = torch.from_numpy(np.ascontiguousarray(side[:, :2])).to(dev)
+        flags = torch.from_numpy((side[:, 2] | (side[:, 3] << 1)).astype(np.uint8)).to(dev)
+        fac = torch.from_numpy(np.concatenate([LPD["fac_q" + k][:, f, None], LPD["fac" + k][:, f]], 1).astype(np.int32)).to(dev)
+        sp[torch.from_numpy(side[:, 2] != 0).to(dev)] = 0      # the shape an LPD frame leaves behind
+        ctx.usac_imdct_process_batch(coef, ics, ov, sp, out, tm, status, ccfl=ccfl, lpd_flags=flags, fac=fac)
+        ctx.sync()
+        o, v = out.cpu().numpy(), ov.cpu().numpy()
+        assert not status.cpu().numpy().any()
+        for c in range(n):
+            assert (crc(o[c]), crc(v[c])) == tuple(int(x) for x in LPD["crc" + k][c, f]), (c, f, side[c])
+        assert np.array_equal(tm.cpu().numpy(), o.astype(np.float32) * np.float32(2.0 ** -15))
+
+
+@pytest.mark.gpu
+def test_gpu_fac_without_lpd_frame_is_refused():
+    import torch
+    import libxaac_amd
+    dev = torch.device("cuda:0")
+    ctx = libxaac_amd.XaacContext(0, None)
+    n = 5
+    rng = np.random.default_rng(4)
+    coef = torch.from_numpy((rng.integers(-2 ** 31, 2 ** 31, (n, 1024)) >> 8).astype(np.int32)).to(dev)
+    ov_h = (rng.integers(-2 ** 31, 2 ** 31, (n, 1024)) >> 18).astype(np.int32)
+    ov, sp = torch.from_numpy(ov_h).to(dev), torch.tensor([0, 0, 1, 0, 0], dtype=torch.uint8, device=dev)
+    ics = torch.tensor([[3, 0], [3, 0], [3, 0], [2, 1], [0, 0]], dtype=torch.uint8, device=dev)
+    flags = torch.tensor([2, 3, 1, 1, 0], dtype=torch.uint8, device=dev)   # FAC without LPD; fine; LPD + KBD 256: no window; fine; fine
+    fac = torch.zeros((n, 257), dtype=torch.int32, device=dev)
+    out = torch.full((n, 1024), 77, dtype=torch.int32, device=dev)
+    status = torch.zeros(n, dtype=torch.int32, device=dev)
+    ctx.usac_imdct_process_batch(coef, ics, ov, sp, out, None, status, lpd_flags=flags, fac=fac)
+    ctx.sync()
+    st, o, v = status.cpu().numpy(), out.cpu().numpy(), ov.cpu().numpy()
+    assert st[0] < 0 and st[0] != libxaac_amd.BAD_WINDOW_SEQ      # XAAC_FATAL_BAD_ARG
+    assert st[2] == libxaac_amd.BAD_WINDOW_SEQ and list(st[[1, 3, 4]]) == [0, 0, 0]
+    for c in (0, 2):
+        assert np.all(o[c] == 77) and np.array_equal(v[c], ov_h[c])
+    assert np.any(o[1] != 77) and np.any(o[3] != 77)

@@ -78,3 +78,74 @@ def test_chain(oracle, reference, seed, ccfl):
         shape_prev = shape
         seq = int(rng.choice(NEXT[seq]))
     assert seen == {0, 1, 2, 3, 4}
+
+
+# ---- the frame behind an LPD frame (td_frame_prev) and forward-aliasing cancellation -----------------------------------------
+def lpd_side(rng, ccfl, seq, fac):
+    """LPD-side inputs of ixheaacd_cal_fac_data in plausible ranges: gain index + quantised FAC lines, the previous LPC
+    filter, the ACELP zero-input response"""
+    fac_data = np.zeros(129, np.int32)
+    lpc = np.zeros(17, np.float32)
+    zir = np.zeros(257, np.float32)
+    if fac:
+        fac_data[0] = rng.integers(0, 120)
+        fac_data[1:] = rng.integers(-40, 41, 128) * (rng.integers(0, 4, 128) == 0)
+        lpc[0] = 1.0
+        lpc[1:] = (rng.standard_normal(16) * 0.4 * 0.8 ** np.arange(16)).astype(np.float32)
+        zir[:] = (rng.standard_normal(257) * 10.0 ** rng.integers(0, 4)).astype(np.float32)
+    return fac_data, lpc, zir
+
+
+def ref_call_lpd(ref, coef, ov, seq, shape, shape_prev, td_prev, fac_present, side):
+    n = len(coef)
+    fn = ref.lib.ref_usac_fd_imdct_lpd
+    fn.restype = ctypes.c_int
+    fn.argtypes = [P32, P32] + [ctypes.c_int] * 6 + [P32, PF, PF, P32, P32, P32]
+    c, o = coef.copy(), ov.copy()
+    out, fac_out, fq = np.zeros(n, np.int32), np.zeros(256, np.int32), np.zeros(1, np.int32)
+    rc = fn(_p(c), _p(o), n, seq, shape, shape_prev, td_prev, fac_present, _p(side[0]), _p(side[1], PF), _p(side[2], PF), _p(out),
+            _p(fac_out), _p(fq))
+    return rc, c, o, out, fac_out, int(fq[0])
+
+
+def orc_call_lpd(orc, coef, ov, seq, shape, shape_prev, td_prev, fac, fac_q):
+    n = len(coef)
+    fn = orc.lib.xo_usac_fd_imdct_lpd
+    fn.restype = ctypes.c_int
+    fn.argtypes = [P32, P32] + [ctypes.c_int] * 5 + [P32, ctypes.c_int, P32]
+    c, o = coef.copy(), ov.copy()
+    out = np.zeros(n, np.int32)
+    rc = fn(_p(c), _p(o), n, seq, shape, shape_prev, td_prev, _p(fac) if fac is not None else None, fac_q, _p(out))
+    return rc, c, o, out
+
+
+@pytest.mark.parametrize("ccfl", [1024, 768])
+@pytest.mark.parametrize("seed", range(5))
+def test_chain_with_lpd_transitions(oracle, reference, seed, ccfl):
+    """walks in which every third frame or so follows an LPD frame: the slope of 2 lfac samples (lfac = ccfl / 16 for
+    EIGHT_SHORT, ccfl / 8 else), with and without the FAC signal (the reference's own ixheaacd_cal_fac_data output, handed to
+    the oracle as the boundary hands it to the library), the float round trip around the LPD decoder's post filter"""
+    rng = np.random.default_rng(5000 + seed + ccfl)
+    ov_r = np.zeros(ccfl, np.int32)
+    ov_o = np.zeros(ccfl, np.int32)
+    seq, shape_prev, n_td = 0, 0, 0
+    seen = set()
+    for f in range(70):
+        shape = int(rng.integers(0, 2))
+        td_prev = int(rng.integers(0, 3) == 0)
+        if td_prev:      # the frame behind an LPD frame opens with a short slope; the LPD frame's shape counts as sine
+            n_td += 1
+            seq, shape_prev = (2, 3, 4)[n_td % 3], 0
+        fac = int(td_prev and (n_td // 3) % 2 == 0)
+        side = lpd_side(rng, ccfl, seq, fac)
+        coef = spectrum(rng, int(rng.choice([0, 0, 0, 1, 2, 3])), ccfl)
+        rc_r, c_r, ov_r, out_r, fac_sig, fac_q = ref_call_lpd(reference, coef, ov_r, seq, shape, shape_prev, td_prev, fac, side)
+        rc_o, c_o, ov_o, out_o = orc_call_lpd(oracle, coef, ov_o, seq, shape, shape_prev, td_prev, fac_sig if fac else None, fac_q)
+        assert rc_r == 0 and rc_o == 0, (f, rc_r, rc_o)
+        assert np.array_equal(c_r, c_o), (f, seq, int(np.sum(c_r != c_o)))
+        assert np.array_equal(out_r, out_o), (f, seq, td_prev, fac, int(np.sum(out_r != out_o)), np.nonzero(out_r != out_o)[0][:6])
+        assert np.array_equal(ov_r, ov_o), (f, seq, td_prev, fac, int(np.sum(ov_r != ov_o)), np.nonzero(ov_r != ov_o)[0][:6])
+        seen.add((seq, td_prev, fac))
+        shape_prev = shape
+        seq = int(rng.choice(NEXT[seq]))
+    assert {(2, 1, 1), (3, 1, 1), (4, 1, 1), (2, 1, 0), (3, 1, 0), (4, 1, 0)} <= seen

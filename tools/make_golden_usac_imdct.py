@@ -96,6 +96,55 @@ def main():
                         crc768=crcs8, last768=last8)
     print("wrote", CHAINS, "chains x", FRAMES, "frames; sequences seen:", np.bincount(side[:, :, 0].ravel(), minlength=5),
           "and", CHAINS_768, "x", FRAMES_768, "of 768 lines:", np.bincount(side8[:, :, 0].ravel(), minlength=5))
+    make_lpd(ref, t)
+
+
+LPD_CHAINS, LPD_FRAMES = 16, 34     # per ccfl: 544 frames, about a third of them behind an LPD frame
+
+
+def lpd_plan(ccfl, chain, frame, seq):
+    """(window sequence, shape, td_frame_prev, fac_data_present, next sequence) of a frame of the LPD walks: every third frame
+    or so follows an LPD frame (then it opens with a short slope and the previous shape counts as sine), two in three of
+    those carry FAC data"""
+    z = _mix((3 << 30) | ((ccfl == 768) << 24) | (chain << 12) | frame, 4)
+    td = int(z[0] >> np.uint64(11)) % 3 == 0 and frame > 0
+    if td:
+        seq = (2, 3, 4)[int(z[1] >> np.uint64(9)) % 3]
+    fac = td and int(z[2] >> np.uint64(13)) % 3 != 0
+    nxt = NEXT[seq]
+    return seq, int(z[3] & np.uint64(1)), int(td), int(fac), int(nxt[int(z[3] >> np.uint64(8)) % len(nxt)])
+
+
+def make_lpd(ref, t):
+    """tests/golden/usac_lpd_ref.npz: the REAL ixheaacd_fd_frm_dec on walks with LPD -> FD transitions.  The FAC signal of a
+    frame is the reference's own ixheaacd_cal_fac_data output for LPD-side inputs drawn here (they are not stored; the
+    signal and its exponent are: the boundary takes exactly those from the host)."""
+    rng = np.random.default_rng(77)
+    d = {}
+    for ccfl in (1024, 768):
+        side = np.zeros((LPD_CHAINS, LPD_FRAMES, 4), np.uint8)
+        crcs = np.zeros((LPD_CHAINS, LPD_FRAMES, 2), np.uint32)
+        facq = np.zeros((LPD_CHAINS, LPD_FRAMES), np.int32)
+        facs = np.zeros((LPD_CHAINS, LPD_FRAMES, 256), np.int32)
+        for c in range(LPD_CHAINS):
+            ov = np.zeros(ccfl, np.int32)
+            seq, shape_prev = 0, c & 1
+            for f in range(LPD_FRAMES):
+                seq, shape, td, fac, nxt = lpd_plan(ccfl, c, f, seq)
+                if td:
+                    shape_prev = 0
+                rc, _, ov, out, sig, q = t.ref_call_lpd(ref, chain_coef(c + 32, f, ccfl), ov, seq, shape, shape_prev, td, fac,
+                                                        t.lpd_side(rng, ccfl, seq, fac))
+                assert rc == 0, (ccfl, c, f, rc)
+                side[c, f] = seq, shape, td, fac
+                crcs[c, f] = crc(out), crc(ov)
+                if fac:
+                    facq[c, f], facs[c, f] = q, sig
+                seq, shape_prev = nxt, shape
+        k = str(ccfl)
+        d.update({"side" + k: side, "crc" + k: crcs, "fac_q" + k: facq, "fac" + k: facs})
+        print("ccfl", ccfl, ":", LPD_CHAINS * LPD_FRAMES, "frames,", int(side[:, :, 2].sum()), "behind an LPD frame,", int(side[:, :, 3].sum()), "with FAC")
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "usac_lpd_ref.npz"), **d)
 
 
 if __name__ == "__main__":
