@@ -389,3 +389,48 @@ VOID __wrap_ixheaacd_cplx_synt_qmffilt(WORD32 **re, WORD32 **im, WORD32 split, W
   __real_ixheaacd_cplx_synt_qmffilt(re, im, split, ore, oim, sf, out, bank, ps, active, low_pow, t, c, ch_fac, drc_on, drc,
                                     aot);
 }
+
+/* ---- the AAC core's spectra, for the parser of libxaac_amd/host (tests/test_parser_*.py) ---------------------------------
+   With $XAAC_SPEC_DUMP set: every ixheaacd_channel_pair_process call (channel.c:602) appends, per channel, the spectrum as
+   the Huffman decoder + inverse quantiser + scale factors left it {1, channel, window_sequence, window_shape, max_sfb,
+   num_window_groups, 1024 words}; every ixheaacd_imdct_process call (lpfuncs.c:347) appends the spectrum it is given
+   {2, ch_fac, window_sequence, window_shape, max_sfb, frame_length, 1024 words} -- after M/S, intensity, PNS and TNS. */
+#include "ixheaacd_block.h"
+#include "ixheaacd_channel.h"
+static FILE *g_spec;
+static FILE *spec_file(void) {
+  const char *path = getenv("XAAC_SPEC_DUMP");
+  if (path && !g_spec) g_spec = fopen(path, "wb");
+  return g_spec;
+}
+IA_ERRORCODE __real_ixheaacd_channel_pair_process(ia_aac_dec_channel_info_struct *[], WORD32, ia_aac_dec_tables_struct *, WORD32, WORD32,
+                                                  WORD32, WORD32, WORD32 *, WORD32 *, void *);
+IA_ERRORCODE __wrap_ixheaacd_channel_pair_process(ia_aac_dec_channel_info_struct *ci[], WORD32 num_ch, ia_aac_dec_tables_struct *tabs,
+                                                  WORD32 total_channels, WORD32 object_type, WORD32 a, WORD32 b, WORD32 *in_data,
+                                                  WORD32 *out_data, void *self) {
+  FILE *f = spec_file();
+  if (f) {
+    int c;
+    for (c = 0; c < num_ch; c++) {
+      int32_t m[6] = {1, c, ci[c]->str_ics_info.window_sequence, ci[c]->str_ics_info.window_shape, ci[c]->str_ics_info.max_sfb,
+                      ci[c]->str_ics_info.num_window_groups};
+      fwrite(m, 4, 6, f);
+      fwrite(ci[c]->ptr_spec_coeff, 4, 1024, f);
+    }
+  }
+  return __real_ixheaacd_channel_pair_process(ci, num_ch, tabs, total_channels, object_type, a, b, in_data, out_data, self);
+}
+VOID __real_ixheaacd_imdct_process(ia_aac_dec_overlap_info *, WORD32 *, ia_ics_info_struct *, VOID *, const WORD16, WORD32 *,
+                                   ia_aac_dec_tables_struct *, WORD32, WORD32, WORD);
+VOID __wrap_ixheaacd_imdct_process(ia_aac_dec_overlap_info *oi, WORD32 *spec, ia_ics_info_struct *ics, VOID *out, const WORD16 ch_fac,
+                                   WORD32 *scratch, ia_aac_dec_tables_struct *tabs, WORD32 object_type, WORD32 ld_mps_present,
+                                   WORD slot_element) {
+  FILE *f = spec_file();
+  if (f) {
+    int32_t m[6] = {2, ch_fac, ics->window_sequence, ics->window_shape, ics->max_sfb, ics->frame_length};
+    fwrite(m, 4, 6, f);
+    fwrite(spec, 4, 1024, f);
+    fflush(f);
+  }
+  __real_ixheaacd_imdct_process(oi, spec, ics, out, ch_fac, scratch, tabs, object_type, ld_mps_present, slot_element);
+}
