@@ -1,0 +1,79 @@
+/*
+ * xaac_parse.h -- C ABI of the host-side bitstream front end (libxaac_amd/libxaac_host.so): ADTS framing and the
+ * AAC-LC / SBR / PS syntax, decoded on the CPU into exactly the frame-level inputs the GPU entry points of xaac_amd.h
+ * take (xaac_imdct_batch spectra and window info; xaac_sbr_header / xaac_sbr_frame / xaac_ps_frame side info).
+ * It replaces, for real streams, what a reference decoder instance does between its input buffer and those seams:
+ *   ixheaacd_adtsframe                  decoder/ixheaacd_headerdecode.c:316
+ *   ixheaacd_aacdec_decodeframe         decoder/ixheaacd_aacdecoder.c:100   (element loop :362-647)
+ *   ixheaacd_individual_ch_stream       decoder/ixheaacd_channel.c:481, ixheaacd_channel_pair_process :602
+ *   ixheaacd_check_for_sbr_payload      decoder/ixheaacd_aacpluscheck.c:59
+ *   ixheaacd_sbr_read_sce / _cpe        decoder/ixheaacd_env_extr.c, ixheaacd_dec_sbrdata decoder/ixheaacd_env_dec.c
+ *   ixheaacd_read_ps_data / ixheaacd_decode_ps_data   decoder/ixheaacd_ps_bitdec.c
+ * No reference code runs in the process.  CPU only: no GPU or torch dependency.
+ */
+#ifndef XAAC_PARSE_H
+#define XAAC_PARSE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XAAC_PARSE_OK 0
+#define XAAC_PARSE_NEED_DATA 1        /* fewer bytes than one whole ADTS frame */
+#define XAAC_PARSE_ERR_SYNC -10       /* no ADTS sync word at the given position */
+#define XAAC_PARSE_ERR_HEADER -11     /* profile other than AAC-LC, layer != 0, sampling index > 11, frame length < 8 */
+#define XAAC_PARSE_ERR_BITS -1        /* the frame ran out of bits */
+#define XAAC_PARSE_ERR_SYNTAX -2      /* a value the syntax forbids */
+#define XAAC_PARSE_ERR_UNSUPPORTED -3 /* outside this front end's scope (see libxaac_amd/host/aac_core.h) */
+#define XAAC_PARSE_ERR_ESCAPE -4      /* spectral escape value beyond the inverse quantiser's range */
+
+#define XAAC_TOOL_MS 1
+#define XAAC_TOOL_INTENSITY 2
+#define XAAC_TOOL_PNS 4
+#define XAAC_TOOL_TNS 8
+#define XAAC_TOOL_PULSE 16
+#define XAAC_TOOL_SHORT 32
+#define XAAC_TOOL_ESCAPE 64
+
+typedef struct xaac_adts_header {
+  int32_t id, layer, protection_absent, profile; /* profile = 2 bit field + 1, as the reference counts it */
+  int32_t sr_index, sampling_rate, channel_config, frame_bytes, raw_blocks, header_bytes;
+} xaac_adts_header;
+
+/* one decoded AAC-LC core frame: what ixheaacd_imdct_process (decoder/ixheaacd_lpfuncs.c:347) is handed per channel */
+typedef struct xaac_core_frame {
+  int32_t n_ch;            /* 1 (SCE) or 2 (CPE) */
+  int32_t element_id;      /* 0 SCE, 1 CPE, 3 LFE */
+  int32_t common_window;
+  int32_t sbr_ext_type;    /* 0: no SBR payload; 13 SBR_EXTENSION, 14 SBR_EXTENSION_CRC */
+  int32_t sbr_bytes;       /* bytes of sbr[] (first byte = the 4 bits behind the extension type) */
+  int32_t tools;           /* which tools the frame used: XAAC_TOOL_* bits (informative; tests assert coverage with it) */
+  struct {
+    int16_t window_sequence, window_shape, max_sfb, num_window_groups;
+  } ics[2];
+  int32_t spec[2][1024];   /* spectral lines in the reference's Q-format; short frames: 8 x 128, window by window */
+  uint8_t sbr[272];
+} xaac_core_frame;
+
+typedef struct xaac_parser xaac_parser;
+
+int32_t xaac_parser_create(xaac_parser **p);
+void xaac_parser_destroy(xaac_parser *p);
+
+/* The ADTS header at data[0 .. n): XAAC_PARSE_OK, _NEED_DATA (n < 7 / 9), _ERR_SYNC or _ERR_HEADER. */
+int32_t xaac_adts_parse_header(const uint8_t *data, size_t n, xaac_adts_header *h);
+
+/* Decodes the ADTS frame at data[0 .. n) (one raw_data_block) into `out`.  stage 2: spectra as the IMDCT takes them;
+   stage 1: as they are before the M/S, intensity, PNS and TNS tools (the entry of ixheaacd_channel_pair_process).
+   *consumed = the frame's length.  The parser keeps what outlives a frame (PNS random seed, SBR / PS decoding state). */
+int32_t xaac_parse_adts_frame(xaac_parser *p, const uint8_t *data, size_t n, int32_t stage, xaac_core_frame *out,
+                              size_t *consumed);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* XAAC_PARSE_H */

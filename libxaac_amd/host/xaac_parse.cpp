@@ -1,0 +1,106 @@
+/*
+ * xaac_parse.cpp -- C ABI of the host-side bitstream front end (include/xaac_parse.h): ADTS framing around the AAC-LC
+ * syntax decoder of aac_core.cpp.
+ */
+#include "../../include/xaac_parse.h"
+
+#include <new>
+#include <string.h>
+
+#include "aac_core.h"
+
+static const int32_t k_sample_rate[12] = {96000, 88200, 64000, 48000, 44100, 32000, 24000, 22050, 16000, 12000, 11025, 8000};
+
+struct xaac_parser {
+  int sr_index;
+  XhCoreState core;
+  XhElement el;
+};
+
+extern "C" {
+
+int32_t xaac_parser_create(xaac_parser **p) {
+  if (!p) return XAAC_PARSE_ERR_SYNTAX;
+  xaac_parser *q = new (std::nothrow) xaac_parser;
+  if (!q) return XAAC_PARSE_ERR_UNSUPPORTED;
+  memset(static_cast<void *>(q), 0, sizeof(*q));
+  q->sr_index = -1;
+  *p = q;
+  return XAAC_PARSE_OK;
+}
+
+void xaac_parser_destroy(xaac_parser *p) { delete p; }
+
+int32_t xaac_adts_parse_header(const uint8_t *data, size_t n, xaac_adts_header *h) { /* headerdecode.c:316-368, :838-849 */
+  if (n < 7) return XAAC_PARSE_NEED_DATA;
+  XhBits br(data, n);
+  if (br.get(12) != 0xfff) return XAAC_PARSE_ERR_SYNC;
+  h->id = br.get1();
+  h->layer = (int32_t)br.get(2);
+  h->protection_absent = br.get1();
+  h->profile = (int32_t)br.get(2) + 1;
+  h->sr_index = (int32_t)br.get(4);
+  br.get(1); /* private_bit */
+  h->channel_config = (int32_t)br.get(3);
+  br.get(4); /* original_copy, home, copyright_identification_bit, copyright_identification_start */
+  h->frame_bytes = (int32_t)br.get(13);
+  br.get(11); /* adts_buffer_fullness */
+  h->raw_blocks = (int32_t)br.get(2);
+  h->header_bytes = h->protection_absent ? 7 : 9 + 2 * h->raw_blocks;
+  if (h->profile != 2 || h->sr_index > 11 || h->layer != 0 || h->frame_bytes < 8) return XAAC_PARSE_ERR_HEADER;
+  h->sampling_rate = k_sample_rate[h->sr_index];
+  if (n < (size_t)h->header_bytes) return XAAC_PARSE_NEED_DATA;
+  return XAAC_PARSE_OK;
+}
+
+int32_t xaac_parse_adts_frame(xaac_parser *p, const uint8_t *data, size_t n, int32_t stage, xaac_core_frame *out,
+                              size_t *consumed) {
+  xaac_adts_header h;
+  const int32_t e = xaac_adts_parse_header(data, n, &h);
+  if (e) return e;
+  if (n < (size_t)h.frame_bytes) return XAAC_PARSE_NEED_DATA;
+  if (h.raw_blocks != 0 || h.frame_bytes < h.header_bytes) return XAAC_PARSE_ERR_UNSUPPORTED;
+  if (consumed) *consumed = (size_t)h.frame_bytes;
+  if (p->sr_index != h.sr_index) {
+    const int32_t seed = p->sr_index < 0 ? 0 : p->core.pns_seed;
+    if (xh_core_init(&p->core, h.sr_index)) return XAAC_PARSE_ERR_HEADER;
+    p->core.pns_seed = seed;
+    p->sr_index = h.sr_index;
+  }
+  XhBits br(data + h.header_bytes, (size_t)(h.frame_bytes - h.header_bytes));
+  const int r = xh_parse_raw_data_block(&p->core, &br, &p->el, stage);
+  if (r) return r;
+  const XhElement &el = p->el;
+  out->n_ch = el.n_ch;
+  out->element_id = el.id;
+  out->common_window = el.common_window;
+  out->sbr_ext_type = el.sbr_ext_type;
+  out->sbr_bytes = el.sbr_bytes;
+  memcpy(out->sbr, el.sbr, sizeof(out->sbr));
+  out->tools = 0;
+  for (int g = 0; g < 8; g++)
+    for (int sfb = 0; sfb < 64; sfb++)
+      if (el.ms_used[g][sfb]) out->tools |= XAAC_TOOL_MS;
+  for (int c = 0; c < el.n_ch; c++) {
+    const XhChannel &ch = el.ch[c];
+    if (ch.pns_active) out->tools |= XAAC_TOOL_PNS;
+    if (ch.tns.present) out->tools |= XAAC_TOOL_TNS;
+    if (ch.pulse.present) out->tools |= XAAC_TOOL_PULSE;
+    if (ch.ics.window_sequence == XH_EIGHT_SHORT) out->tools |= XAAC_TOOL_SHORT;
+    for (int g = 0; g < ch.ics.num_groups; g++)
+      for (int sfb = 0; sfb < ch.ics.max_sfb; sfb++) {
+        if (ch.cb[16 * g + sfb] >= XH_INTENSITY_HCB2) out->tools |= XAAC_TOOL_INTENSITY;
+        if (ch.cb[16 * g + sfb] == XH_ESC_HCB) out->tools |= XAAC_TOOL_ESCAPE;
+      }
+  }
+  for (int c = 0; c < el.n_ch; c++) {
+    out->ics[c].window_sequence = (int16_t)el.ch[c].ics.window_sequence;
+    out->ics[c].window_shape = (int16_t)el.ch[c].ics.window_shape;
+    out->ics[c].max_sfb = (int16_t)el.ch[c].ics.max_sfb;
+    out->ics[c].num_window_groups = (int16_t)el.ch[c].ics.num_groups;
+    memcpy(out->spec[c], const_cast<XhElement &>(el).ch[c].spec(), sizeof(out->spec[c]));
+  }
+  return XAAC_PARSE_OK;
+}
+
+}  // extern "C"

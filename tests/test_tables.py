@@ -51,7 +51,7 @@ def test_tables_equal_reference_rom():
         assert np.array_equal(mine[name], want), name
 
 
-def _regenerated_equals_committed(tool, out_name, tmp_path):
+def _regenerated_equals_committed(tool, out_name, tmp_path, where="csrc"):
     """tools/gen_tables_{qmf,sbr,ps}.py read the constants out of the compiled reference's ROM image; the committed
     .inc must be exactly what they produce today"""
     import importlib
@@ -62,7 +62,7 @@ def _regenerated_equals_committed(tool, out_name, tmp_path):
     mod = importlib.import_module(tool)
     out = str(tmp_path / out_name)
     mod.emit(mod.reference_tables(), out)
-    committed = os.path.join(ROOT, "libxaac_amd", "csrc", out_name)
+    committed = os.path.join(ROOT, "libxaac_amd", where, out_name)
     assert open(out).read() == open(committed).read(), "%s is stale: rerun tools/%s.py" % (out_name, tool)
 
 
@@ -123,3 +123,9 @@ def test_esbr_tables_are_the_q31_versions_of_the_q15_ones():
                  ("alt_sin_twiddle_l64", "alt_sin_twiddle_l64"), ("sin_cos_twiddle_l32", "sin_cos_twiddle_l32"),
                  ("alt_sin_twiddle_l32", "alt_sin_twiddle_l32"), ("t_cos_sin_l32", "t_cos_sin_l32")):
         assert np.max(np.abs(q31[b] / 65536.0 - q15[a])) <= 1.0, a
+
+
+def test_aac_syntax_tables_equal_reference_rom(tmp_path):
+    """the host parser's code books (every code word listed by probing the reference's own lookup), inverse quantiser, gains,
+    TNS and band tables"""
+    _regenerated_equals_committed("gen_tables_aac", "tables_aac.inc", tmp_path, where="host")
