@@ -17,6 +17,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "xaac_sbr.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -58,6 +60,25 @@ typedef struct xaac_core_frame {
   uint8_t sbr[272];
 } xaac_core_frame;
 
+/* the SBR (+ PS) side info of the frame, decoded as the reference's -esbr:0 path decodes it (ixheaacd_applysbr,
+   decoder/ixheaacd_sbrdecoder.c:313-760), and what the frame asks of the host beside handing the side info on */
+typedef struct xaac_sbr_side {
+  int32_t apply;          /* sync_state == SBR_ACTIVE: frame[].apply_processing = 1 */
+  int32_t reset;          /* ixheaacd_sbr_dec_reset ran (sbrdecoder.c:103-252): before this frame's GPU call set, in the
+                             xaac_sbr_state of channels 0 .. reset_channels-1: ph_index = 0, filt_buf_noise_e = 0,
+                             start_up = 1, bw_array_prev = 0, syn_lsb = codec_usb = header.sub_band_start,
+                             syn_usb = header.sub_band_end */
+  int32_t reset_channels;
+  int32_t upsampling;     /* ixheaacd_prepare_upsamp ran (:254): syn_lsb = codec_usb = 32, syn_usb = 64 in those channels */
+  int32_t stereo;         /* channel pair: frame[0] and frame[1] are both in use */
+  int32_t ps;             /* header.channel_mode == PS_STEREO: ps_frame is valid, the output has two channels */
+  int32_t ps_start;       /* first PS frame behind mono frames: xaac_sbr_state_handover(XAAC_HANDOVER_PS_START) first (:762) */
+  int32_t frame_ok;       /* the payload parsed and its length / CRC checked out */
+  xaac_sbr_header header; /* one per stream: the channels of a pair share it */
+  xaac_sbr_frame frame[2];
+  xaac_ps_frame ps_frame;
+} xaac_sbr_side;
+
 typedef struct xaac_parser xaac_parser;
 
 int32_t xaac_parser_create(xaac_parser **p);
@@ -71,6 +92,12 @@ int32_t xaac_adts_parse_header(const uint8_t *data, size_t n, xaac_adts_header *
    *consumed = the frame's length.  The parser keeps what outlives a frame (PNS random seed, SBR / PS decoding state). */
 int32_t xaac_parse_adts_frame(xaac_parser *p, const uint8_t *data, size_t n, int32_t stage, xaac_core_frame *out,
                               size_t *consumed);
+
+/* The SBR / PS side info of the frame xaac_parse_adts_frame decoded last (its payload is in the parser; a frame without
+   one counts as a frame whose SBR data is missing, as in the reference).  ps_enable: parametric stereo allowed (mono
+   streams).  The first call fixes the stream's SBR configuration (output rate = twice the core rate).  Returns
+   XAAC_PARSE_OK, or XAAC_PARSE_ERR_SYNTAX where the reference returns a fatal error from ixheaacd_applysbr. */
+int32_t xaac_parse_sbr_side(xaac_parser *p, int32_t ps_enable, xaac_sbr_side *side);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include "aac_core.h"
+#include "sbr_side.h"
 
 static const int32_t k_sample_rate[12] = {96000, 88200, 64000, 48000, 44100, 32000, 24000, 22050, 16000, 12000, 11025, 8000};
 
@@ -15,6 +16,8 @@ struct xaac_parser {
   int sr_index;
   XhCoreState core;
   XhElement el;
+  int sbr_ready, sampling_rate;
+  XsDecoder sbr;
 };
 
 extern "C" {
@@ -66,6 +69,7 @@ int32_t xaac_parse_adts_frame(xaac_parser *p, const uint8_t *data, size_t n, int
     if (xh_core_init(&p->core, h.sr_index)) return XAAC_PARSE_ERR_HEADER;
     p->core.pns_seed = seed;
     p->sr_index = h.sr_index;
+    p->sampling_rate = h.sampling_rate;
   }
   XhBits br(data + h.header_bytes, (size_t)(h.frame_bytes - h.header_bytes));
   const int r = xh_parse_raw_data_block(&p->core, &br, &p->el, stage);
@@ -100,6 +104,21 @@ int32_t xaac_parse_adts_frame(xaac_parser *p, const uint8_t *data, size_t n, int
     out->ics[c].num_window_groups = (int16_t)el.ch[c].ics.num_groups;
     memcpy(out->spec[c], const_cast<XhElement &>(el).ch[c].spec(), sizeof(out->spec[c]));
   }
+  return XAAC_PARSE_OK;
+}
+
+int32_t xaac_parse_sbr_side(xaac_parser *p, int32_t ps_enable, xaac_sbr_side *side) {
+  if (!p || !side || p->sr_index < 0 || p->el.n_ch < 1) return XAAC_PARSE_ERR_SYNTAX;
+  if (!p->sbr_ready) {
+    xs_init(&p->sbr, p->sampling_rate, p->el.n_ch, ps_enable && p->el.n_ch == 1);
+    p->sbr_ready = 1;
+  }
+  XsFrameResult r;
+  if (xs_decode_frame(&p->sbr, p->el.sbr, p->el.sbr_bytes, p->el.sbr_ext_type, &side->header, side->frame, &side->ps_frame, &r))
+    return XAAC_PARSE_ERR_SYNTAX;
+  xs_frame_done(&p->sbr, &r); /* what the frame's ixheaacd_sbr_dec leaves for the next frame's delta decoding */
+  side->apply = r.apply, side->reset = r.reset, side->reset_channels = r.reset_channels, side->upsampling = r.upsampling;
+  side->stereo = r.stereo, side->ps = r.ps, side->ps_start = r.ps_start, side->frame_ok = r.frame_ok;
   return XAAC_PARSE_OK;
 }
 

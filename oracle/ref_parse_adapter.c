@@ -67,3 +67,67 @@ void ref_aac_huff_probe(int cb, unsigned word, int *index, int *len) {
   *index = i;
   *len = l;
 }
+
+/* ---- SBR / PS side info ROM (decoder/ixheaacd_sbr_rom.h:118-240, ixheaacd_common_rom.h:30) ---------------------------- */
+#include "ixheaac_constants.h"
+#include "ixheaacd_sbr_common.h"
+#include "ixheaacd_bitbuffer.h"
+#include "ixheaacd_sbrdecsettings.h"
+#include "ixheaacd_common_rom.h"
+#include "ixheaacd_sbr_scale.h"
+#include "ixheaacd_lpp_tran.h"
+#include "ixheaacd_env_extr_part.h"
+#include "ixheaacd_sbr_rom.h"
+
+typedef const UWORD16 *ia_huffman_data_type; /* decoder/ixheaacd_env_extr.h:36 */
+WORD32 ixheaacd_ssc_huff_dec(ia_huffman_data_type t_huff, ia_bit_buf_struct *it_bit_buff);
+
+/* one lookup in SBR code book `table` (order of k_sbr below): index and length */
+void ref_sbr_huff_probe(int table, unsigned word, int *index, int *len) {
+  const ia_env_extr_tables_struct *t = &ixheaacd_aac_dec_env_extr_tables;
+  const WORD16 *inp[10] = {t->ixheaacd_t_huffman_env_1_5db_inp_table,     t->ixheaacd_f_huffman_env_1_5db_inp_table,
+                           t->ixheaacd_t_huffman_env_3_0db_inp_table,     t->ixheaacd_f_huffman_env_3_0db_inp_table,
+                           t->ixheaacd_t_huffman_env_bal_1_5db_inp_table, t->ixheaacd_f_huffman_env_bal_1_5db_inp_table,
+                           t->ixheaacd_t_huffman_env_bal_3_0db_inp_table, t->ixheaacd_f_huffman_env_bal_3_0db_inp_table,
+                           t->ixheaacd_t_huffman_noise_3_0db_inp_table,   t->ixheaacd_t_huffman_noise_bal_3_0db_inp_table};
+  const WORD32 *idx[10] = {t->ixheaacd_t_huffman_env_1_5db_idx_table,     t->ixheaacd_f_huffman_env_1_5db_idx_table,
+                           t->ixheaacd_t_huffman_env_3_0db_idx_table,     t->ixheaacd_f_huffman_env_3_0db_idx_table,
+                           t->ixheaacd_t_huffman_env_bal_1_5db_idx_table, t->ixheaacd_f_huffman_env_bal_1_5db_idx_table,
+                           t->ixheaacd_t_huffman_env_bal_3_0db_idx_table, t->ixheaacd_f_huffman_env_bal_3_0db_idx_table,
+                           t->ixheaacd_t_huffman_noise_3_0db_idx_table,   t->ixheaacd_t_huffman_noise_bal_3_0db_idx_table};
+  WORD16 i = 0, l = 0;
+  ixheaacd_huffman_decode((WORD32)word, &i, &l, (const UWORD16 *)inp[table], (const UWORD32 *)idx[table]);
+  *index = i;
+  *len = l;
+}
+
+/* one value of PS code book `table` (0 iid_df, 1 iid_dt, 2 iid_df_fine, 3 iid_dt_fine, 4 icc_df, 5 icc_dt) read from the 32
+   bits in `word` by the reference's own tree walk (env_extr.c:325): the value it returns and the bits it took */
+void ref_ps_huff_probe(int table, unsigned word, int *value, int *len) {
+  const ia_ps_tables_struct *t = &ixheaacd_aac_dec_ps_tables;
+  const WORD16 *tab[6] = {t->huff_iid_df, t->huff_iid_dt, t->huff_iid_df_fine, t->huff_iid_dt_fine, t->huff_icc_df, t->huff_icc_dt};
+  UWORD8 bytes[8] = {(UWORD8)(word >> 24), (UWORD8)(word >> 16), (UWORD8)(word >> 8), (UWORD8)word, 0, 0, 0, 0};
+  ia_bit_buf_struct bb;
+  memset(&bb, 0, sizeof(bb));
+  ixheaacd_create_init_bit_buf(&bb, bytes, 8);
+  const WORD32 before = bb.cnt_bits;
+  *value = ixheaacd_ssc_huff_dec((ia_huffman_data_type)tab[table], &bb);
+  *len = before - bb.cnt_bits;
+}
+
+/* the FIXFIX frame grids (sbr_frame_info1_2_4_16, used by env_extr.c:1763) flattened to 24 int16 per entry:
+   frame_class, num_env, transient_env, num_noise_env, border_vec[9], freq_res[8], noise_border_vec[3]; and log2 table */
+int ref_sbr_frame_info(int entry, short *out) {
+  const ia_frame_info_struct *f = &ixheaacd_aac_dec_env_extr_tables.sbr_frame_info1_2_4_16[entry];
+  int i, n = 0;
+  if (entry < 0 || entry >= 7) return -1;
+  out[n++] = f->frame_class, out[n++] = f->num_env, out[n++] = f->transient_env, out[n++] = f->num_noise_env;
+  for (i = 0; i < MAX_ENVELOPES + 1; i++) out[n++] = f->border_vec[i];
+  for (i = 0; i < MAX_ENVELOPES; i++) out[n++] = f->freq_res[i];
+  for (i = 0; i < MAX_NOISE_ENVELOPES + 1; i++) out[n++] = f->noise_border_vec[i];
+  return n;
+}
+const short *ref_log_dual_is_table(int *count) {
+  *count = LOG_2_TABLE_SIZE;
+  return ixheaacd_str_fft_n_transcendent_tables.log_dual_is_table;
+}

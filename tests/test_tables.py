@@ -129,3 +129,8 @@ def test_aac_syntax_tables_equal_reference_rom(tmp_path):
     """the host parser's code books (every code word listed by probing the reference's own lookup), inverse quantiser, gains,
     TNS and band tables"""
     _regenerated_equals_committed("gen_tables_aac", "tables_aac.inc", tmp_path, where="host")
+
+
+def test_sbr_side_info_tables_equal_reference_rom(tmp_path):
+    """the host parser's SBR / PS code books, FIXFIX grids and log2 table"""
+    _regenerated_equals_committed("gen_tables_sbr_side", "tables_sbr_side.inc", tmp_path, where="host")
