@@ -99,6 +99,20 @@ int32_t xaac_parse_adts_frame(xaac_parser *p, const uint8_t *data, size_t n, int
    XAAC_PARSE_OK, or XAAC_PARSE_ERR_SYNTAX where the reference returns a fatal error from ixheaacd_applysbr. */
 int32_t xaac_parse_sbr_side(xaac_parser *p, int32_t ps_enable, xaac_sbr_side *side);
 
+/* ---- the states of a new stream, and the frame-level state changes of ixheaacd_applysbr -------------------------------
+ * Host-side helpers on HOST copies of the boundary structs (the host writes them to the device once per stream, and on
+ * the rare frames with side->reset / side->upsampling reads the stream's state back, applies the change, writes it again). */
+/* ixheaacd_init_sbr for one channel: decoder/ixheaacd_sbrdec_initfuncs.c:1133-1135 (bank scales), :1235-1238 (scale
+   factors), :870-898 (envelope calculator, previous-frame data) */
+void xaac_sbr_state_init(xaac_sbr_state *s);
+/* ... and the parametric stereo tool with the right channel's bank: :1050-1059 */
+void xaac_ps_state_init(xaac_ps_state *s);
+/* what ixheaacd_sbr_dec_reset (sbrdecoder.c:103-252) and ixheaacd_prepare_upsamp (:254-276) do to one channel's state
+   for this frame's side info; channel = 0 or 1 (no-op beyond side->reset_channels / for frames without either) */
+void xaac_sbr_state_apply_side(xaac_sbr_state *s, const xaac_sbr_side *side, int32_t channel);
+/* the same for the right channel's synthesis bank kept in the PS state (channel 1 of a mono + PS stream) */
+void xaac_ps_state_apply_side(xaac_ps_state *s, const xaac_sbr_side *side);
+
 #ifdef __cplusplus
 }
 #endif

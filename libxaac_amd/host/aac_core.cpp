@@ -259,6 +259,7 @@ int read_sections(XhBits *br, XhChannel *c) { /* longblock.c:62-153 */
       }
       len += incr;
       sfb += len;
+      if (br->overrun) return XH_ERR_BITS; /* zeros behind the end of the frame would make sections of length 0 for ever */
       if (sfb > ics.max_sfb) return XH_ERR_SYNTAX;
       if (sect_cb == XH_ESC_HCB + 1) return XH_ERR_SYNTAX;
       for (int i = sfb - len; i < sfb; i++) cb[i] = (uint8_t)sect_cb;

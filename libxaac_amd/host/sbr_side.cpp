@@ -247,6 +247,7 @@ int master_table(XsHeader *h) { /* :232-502 (upsampling factor 2) */
       if (h->alter_scale) nb1 = (int32_t)(((int64_t)nb1 * 0x6276) >> 15);
       nb1 = ((nb1 + 0x1000) >> 13) << 1;
       if (nb0 < 1 || nb1 < 1) return -1;
+      if (nb1 > 50 || nb0 + nb1 > XAAC_SBR_MAX_FREQ_COEFFS) return -1; /* beyond the reference's own arrays (vec_dk, f_master_tbl) */
       calc_bands(dk0, k0, k1, nb0);
       shellsort(dk0, nb0);
       f[0] = k0;
@@ -268,6 +269,7 @@ int master_table(XsHeader *h) { /* :232-502 (upsampling factor 2) */
       int32_t nb0 = bands * (xh_log_dual_is[k2] - xh_log_dual_is[k0]);
       nb0 = ((nb0 + 0x1000) >> 13) << 1;
       if (nb0 < 1) return -1;
+      if (nb0 > 50) return -1;
       calc_bands(dk0, k0, k2, nb0);
       shellsort(dk0, nb0);
       if (dk0[0] == 0) return -1;

@@ -122,4 +122,47 @@ int32_t xaac_parse_sbr_side(xaac_parser *p, int32_t ps_enable, xaac_sbr_side *si
   return XAAC_PARSE_OK;
 }
 
+void xaac_sbr_state_init(xaac_sbr_state *s) {
+  memset(s, 0, sizeof(*s));
+  s->ov_lb_scale = s->hb_scale = s->ov_hb_scale = 31;
+  s->st_syn_scale = -6;
+  s->prev_end_position = 16;
+  s->start_up = 1;
+  s->tansient_env_prev = -1;
+}
+
+void xaac_ps_state_init(xaac_ps_state *s) {
+  memset(s, 0, sizeof(*s));
+  s->sample_ser[0] = 3, s->sample_ser[1] = 4, s->sample_ser[2] = 5; /* rev_link_delay_ser */
+  memset(s->h11_h12_vec, 0xff, sizeof(s->h11_h12_vec));
+  s->st_syn_scale_r = -6;
+  s->ov_lb_scale_r = s->hb_scale_r = 31;
+}
+
+void xaac_sbr_state_apply_side(xaac_sbr_state *s, const xaac_sbr_side *side, int32_t channel) {
+  if (side->reset && channel < side->reset_channels) {
+    s->ph_index = 0;
+    s->filt_buf_noise_e = 0;
+    s->start_up = 1;
+    s->syn_lsb = s->codec_usb = side->header.sub_band_start;
+    s->syn_usb = side->header.sub_band_end;
+    memset(s->bw_array_prev, 0, sizeof(s->bw_array_prev));
+  }
+  if (side->upsampling) {
+    s->syn_lsb = s->codec_usb = 32;
+    s->syn_usb = 64;
+  }
+}
+
+void xaac_ps_state_apply_side(xaac_ps_state *s, const xaac_sbr_side *side) {
+  if (side->reset && side->reset_channels > 1) {
+    s->syn_lsb_r = side->header.sub_band_start;
+    s->syn_usb_r = side->header.sub_band_end;
+  }
+  if (side->upsampling) {
+    s->syn_lsb_r = 32;
+    s->syn_usb_r = 64;
+  }
+}
+
 }  // extern "C"

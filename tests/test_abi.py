@@ -3,6 +3,7 @@ include/xaac_amd.h declares; argument errors follow the reference's error-code
 convention.  No compute calls here."""
 import ctypes
 import os
+import subprocess
 import sys
 import re
 
@@ -13,9 +14,14 @@ import libxaac_amd
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_functions():
+HOST_HEADERS = ("xaac_parse.h",)  # the CPU front end's boundary: libxaac_amd/libxaac_host.so
+
+
+def _declared_functions(host=False):
     names = set()
     for h in sorted(os.listdir(os.path.join(ROOT, "include"))):  # every header of the boundary
+        if (h in HOST_HEADERS) != host:
+            continue
         txt = open(os.path.join(ROOT, "include", h)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         names |= set(re.findall(r"\b(xaac_[a-z0-9_]+)\s*\(", txt))
@@ -28,6 +34,31 @@ def test_library_exports_every_declared_symbol():
     assert "xaac_imdct_process_batch" in names and "xaac_create" in names and "xaac_hbe_cplx_anal_batch" in names
     for n in names:
         assert hasattr(lib, n), n
+
+
+def test_host_library_exports_every_declared_symbol():
+    """include/xaac_parse.h <-> libxaac_amd/libxaac_host.so (CPU only: loads and parses without a GPU)"""
+    from libxaac_amd import decoder
+    lib = decoder.load_host_library()
+    names = _declared_functions(host=True)
+    assert "xaac_parse_adts_frame" in names and "xaac_parse_sbr_side" in names and "xaac_sbr_state_init" in names
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_host_struct_layouts_match_header(tmp_path):
+    """the ctypes mirrors of libxaac_amd/decoder.py against what a C compiler makes of include/xaac_parse.h"""
+    from libxaac_amd import decoder
+    src, exe = tmp_path / "h.c", tmp_path / "h"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "xaac_parse.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", '
+                   'sizeof(xaac_adts_header), sizeof(xaac_core_frame), offsetof(xaac_core_frame, spec), offsetof(xaac_core_frame, sbr), '
+                   'sizeof(xaac_sbr_side), offsetof(xaac_sbr_side, frame), offsetof(xaac_sbr_side, ps_frame)); return 0; }\n')
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    want = [ctypes.sizeof(decoder.AdtsHeader), ctypes.sizeof(decoder.CoreFrame), decoder.CoreFrame.spec.offset,
+            decoder.CoreFrame.sbr.offset, ctypes.sizeof(decoder.SbrSide), decoder.SbrSide.frame.offset,
+            decoder.SbrSide.ps_frame.offset]
+    assert got == want
 
 
 def test_version_string():

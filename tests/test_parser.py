@@ -1,0 +1,168 @@
+"""The host-side bitstream front end (libxaac_amd/host -> libxaac_host.so, include/xaac_parse.h) on the committed ADTS streams:
+  * against committed CRCs of what the REAL reference decoder holds frame by frame (tests/golden/parser_ref.npz, made by
+    tools/make_golden_parser.py): spectra before the tools and at the IMDCT, window info, SBR header / frame / PS structs;
+  * live against oracle/_ref/xaacdec_capture where it exists (this container and the GPU box), with the differing words named;
+  * damaged input: truncations, bit flips and random bytes come back as error codes (never a crash or a hang).
+CPU only."""
+import ctypes
+import os
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from libxaac_amd import decoder  # noqa: E402
+
+STREAMS = os.path.join(ROOT, "tests", "golden", "streams")
+NAMES = ["mix_aot2_64k", "mix_aot5_48k", "mono_aot5_32k", "harm_aot5_48k", "mix_aot29_32k"]
+CAPTURE = os.path.join(ROOT, "oracle", "_ref", "xaacdec_capture")
+
+
+def crc(b):
+    return zlib.crc32(bytes(b)) & 0xffffffff
+
+
+def stream(name):
+    return open(os.path.join(STREAMS, name + ".aac"), "rb").read()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_spectra_and_side_info_equal_the_references(name):
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "parser_ref.npz"))
+    core = gold[name + "_core"]
+    before = decoder.parse_stream(stream(name), stage=1)
+    after = decoder.parse_stream(stream(name), stage=2)
+    assert len(before) == len(after) == core.shape[0]
+    for f, ((s1, ics, _, _), (s2, _, _, side)) in enumerate(zip(before, after)):
+        for c in range(core.shape[1]):
+            assert tuple(int(v) for v in ics[c, :3]) == tuple(int(v) for v in core[f, c, 2:5]), (f, c)
+            assert crc(s1[c].tobytes()) == core[f, c, 0], "frame %d channel %d: spectrum before the tools" % (f, c)
+            assert crc(s2[c].tobytes()) == core[f, c, 1], "frame %d channel %d: spectrum at the IMDCT" % (f, c)
+        if name + "_sbr" in gold:
+            sbr = gold[name + "_sbr"]
+            for c in range(sbr.shape[1]):
+                assert crc(side.header) == sbr[f, c, 0], "frame %d: SBR header tables" % f
+                assert crc(side.frame[c]) == sbr[f, c, 1], "frame %d channel %d: SBR frame data" % (f, c)
+                if sbr[f, c, 2]:
+                    assert side.ps and crc(side.ps_frame) == sbr[f, c, 2], "frame %d: PS frame" % f
+        else:
+            assert side is None
+
+
+def test_the_streams_exercise_the_tools():
+    """what the committed streams cover, so that a pass above means something: M/S, TNS, short blocks, escapes, SBR with and
+    without coupling, every frame class, PS; (intensity, PNS and pulse data are not in these streams: tests/test_parser_synth.py)"""
+    tools = 0
+    classes, coupling, ps_frames, concealed = set(), set(), 0, 0
+    for name in NAMES:
+        for _, _, t, side in decoder.parse_stream(stream(name)):
+            tools |= t
+            if side is not None and side.apply:
+                import sbr_capture as sc
+                fr = sc.Frame.from_buffer_copy(bytes(side.frame[0]))
+                classes.add(fr.frame_class)
+                coupling.add(fr.coupling_mode)
+                ps_frames += bool(side.ps)
+                concealed += not side.frame_ok
+    for bit in (decoder.TOOL_MS, decoder.TOOL_TNS, decoder.TOOL_SHORT, decoder.TOOL_ESCAPE):
+        assert tools & bit, bit
+    assert classes == {0, 1, 2, 3} and coupling >= {0, 1} and ps_frames >= 30 and concealed >= 5
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_live_against_the_reference_decoder(name, tmp_path):
+    """the same comparison word for word against a fresh run of the reference (oracle/_ref/xaacdec_capture -esbr:0)"""
+    if not os.path.exists(CAPTURE):
+        pytest.skip("oracle/_ref/xaacdec_capture missing (built where /root/reference exists)")
+    import make_golden_parser as mg
+    import sbr_capture as sc
+    raw, recs = mg.capture(name, str(tmp_path))
+    t1, t2 = raw[raw[:, 0] == 1], raw[raw[:, 0] == 2]
+    frames1, frames2 = decoder.parse_stream(stream(name), stage=1), decoder.parse_stream(stream(name), stage=2)
+    n_ch = frames1[0][0].shape[0]
+    t1, t2, recs = t1[n_ch:], t2[n_ch:], recs[n_ch:]
+    assert len(t1) == len(frames1) * n_ch
+    for f in range(len(frames1)):
+        for c in range(n_ch):
+            k = f * n_ch + c
+            assert np.array_equal(frames1[f][0][c], t1[k, 6:]), (f, c, np.nonzero(frames1[f][0][c] != t1[k, 6:])[0][:8])
+            assert np.array_equal(frames2[f][0][c], t2[k, 6:]), (f, c, np.nonzero(frames2[f][0][c] != t2[k, 6:])[0][:8])
+            if recs:
+                side = frames2[f][3]
+                assert bytes(side.header) == bytes(recs[k]["header"]), (f, c)
+                assert bytes(side.frame[c]) == bytes(recs[k]["frame"]), (f, c)
+                assert bool(side.ps) == bool(recs[k]["ps"])
+                if recs[k]["ps"]:
+                    assert bytes(side.ps_frame) == bytes(recs[k]["ps_frame"]), f
+    assert sc is not None
+
+
+def test_adts_header_fields():
+    lib = decoder.load_host_library()
+    d = stream("mix_aot5_48k")
+    h = decoder.AdtsHeader()
+    assert lib.xaac_adts_parse_header(d, len(d), ctypes.byref(h)) == 0
+    assert (h.profile, h.layer, h.sampling_rate, h.channel_config, h.raw_blocks) == (2, 0, 24000, 2, 0)
+    assert h.header_bytes == (7 if h.protection_absent else 9) and 8 <= h.frame_bytes <= len(d)
+    assert lib.xaac_adts_parse_header(d, 3, ctypes.byref(h)) == 1                       # XAAC_PARSE_NEED_DATA
+    assert lib.xaac_adts_parse_header(b"\x00" * 16, 16, ctypes.byref(h)) == -10         # XAAC_PARSE_ERR_SYNC
+    bad = bytearray(d[:16])
+    bad[2] = (bad[2] & 0x3f) | 0xc0                                                     # profile 4: not AAC-LC
+    assert lib.xaac_adts_parse_header(bytes(bad), 16, ctypes.byref(h)) == -11           # XAAC_PARSE_ERR_HEADER
+
+
+FUZZ = r"""
+import ctypes, sys
+import numpy as np
+sys.path.insert(0, %r)
+from libxaac_amd import decoder
+lib = decoder.load_host_library()
+data = open(%r, 'rb').read()
+rng = np.random.default_rng(%d)
+hdr = decoder.AdtsHeader()
+pos, frames = 0, []
+while pos + 7 < len(data) and lib.xaac_adts_parse_header(data[pos:pos + 16], 16, ctypes.byref(hdr)) == 0:
+    frames.append(data[pos:pos + hdr.frame_bytes])
+    pos += hdr.frame_bytes
+codes = {}
+core, side, used = decoder.CoreFrame(), decoder.SbrSide(), ctypes.c_size_t()
+for trial in range(%d):
+    p = ctypes.c_void_p()
+    lib.xaac_parser_create(ctypes.byref(p))
+    for f in frames[:12]:
+        b = bytearray(f)
+        kind = trial %% 4
+        if kind == 0:                                  # a few flipped bits behind the header
+            for _ in range(int(rng.integers(1, 6))):
+                b[int(rng.integers(7, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:                                # payload replaced by random bytes
+            b[7:] = rng.integers(0, 256, len(b) - 7, dtype=np.uint8).tobytes()
+        elif kind == 2:                                # truncated (the header still announces the full length)
+            b = b[:int(rng.integers(8, len(b)))]
+        else:                                          # a run of ones / zeros
+            at = int(rng.integers(7, len(b) - 1))
+            b[at:at + 40] = bytes([0xff if trial & 4 else 0]) * len(b[at:at + 40])
+        rc = lib.xaac_parse_adts_frame(p, bytes(b), len(b), 2, ctypes.byref(core), ctypes.byref(used))
+        codes[rc] = codes.get(rc, 0) + 1
+        if rc == 0:
+            rc2 = lib.xaac_parse_sbr_side(p, 1, ctypes.byref(side))
+            codes[100 + rc2] = codes.get(100 + rc2, 0) + 1
+    lib.xaac_parser_destroy(p)
+print(sorted(codes.items()))
+"""
+
+
+@pytest.mark.parametrize("name", ["mix_aot2_64k", "mix_aot5_48k", "mix_aot29_32k"])
+def test_damaged_frames_come_back_as_error_codes(name):
+    """in a child process, so that a crash or a hang of the parser is a test failure and not the end of the test run"""
+    code = FUZZ % (ROOT, os.path.join(STREAMS, name + ".aac"), 1234, 160)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    codes = dict(eval(r.stdout.strip().splitlines()[-1]))
+    assert all(k in (0, 1, -1, -2, -3, -4, 100, 98) for k in codes), codes     # 98 = 100 + XAAC_PARSE_ERR_SYNTAX
+    assert sum(v for k, v in codes.items() if k < 0) > 50, codes                # the damage is noticed, mostly
