@@ -99,6 +99,35 @@ int32_t xaac_parse_adts_frame(xaac_parser *p, const uint8_t *data, size_t n, int
    XAAC_PARSE_OK, or XAAC_PARSE_ERR_SYNTAX where the reference returns a fatal error from ixheaacd_applysbr. */
 int32_t xaac_parse_sbr_side(xaac_parser *p, int32_t ps_enable, xaac_sbr_side *side);
 
+/* ---- one frame of N streams at once ----------------------------------------------------------------------------------
+ * What a batched host runs per step: every stream's next ADTS frame parsed (core, and SBR / PS side info when with_sbr)
+ * on a team of CPU threads, the results written straight into the host staging arrays -- pinned, in the layouts the GPU
+ * entry points take -- that one cudaMemcpyAsync per array then moves.  Streams are independent, so is their parsing. */
+typedef struct xaac_parse_batch {
+  int32_t n_streams;
+  int32_t n_ch;               /* core channels of every stream (1 or 2) */
+  int32_t with_sbr;           /* also decode the SBR / PS side info (ps_enable as in xaac_parse_sbr_side) */
+  int32_t ps_enable;
+  int32_t stage;              /* as in xaac_parse_adts_frame */
+  int32_t threads;            /* worker threads, <= 0: as many as the machine has */
+  xaac_parser *const *parser; /* [n_streams] */
+  const uint8_t *const *data; /* [n_streams] the frame's first byte */
+  const uint64_t *bytes;      /* [n_streams] bytes available there */
+  int32_t *spec;              /* [n_streams][n_ch][1024] */
+  uint8_t *ics;               /* [n_streams][n_ch][2]: window_sequence, window_shape (xaac_ics_info) */
+  xaac_sbr_header *header;    /* with_sbr: [n_streams][n_ch] (the channels of a pair get copies) */
+  xaac_sbr_frame *frame;      /* with_sbr: [n_streams][n_ch] */
+  xaac_ps_frame *ps_frame;    /* with_sbr, optional: [n_streams] */
+  int32_t *flags;             /* with_sbr: [n_streams][8] = apply, reset, reset_channels, upsampling, stereo, ps, ps_start,
+                                 frame_ok of xaac_sbr_side */
+  int32_t *tools;             /* optional [n_streams] */
+  uint64_t *consumed;         /* [n_streams] frame length (0 where status != 0) */
+  int32_t *status;            /* [n_streams] XAAC_PARSE_OK / _NEED_DATA / error: such a stream's rows are left as they were */
+} xaac_parse_batch;
+
+/* returns the number of streams whose status is XAAC_PARSE_OK, or a negative XAAC_PARSE_ERR_* for a bad descriptor */
+int32_t xaac_parse_batch_run(const xaac_parse_batch *b);
+
 /* ---- the states of a new stream, and the frame-level state changes of ixheaacd_applysbr -------------------------------
  * Host-side helpers on HOST copies of the boundary structs (the host writes them to the device once per stream, and on
  * the rare frames with side->reset / side->upsampling reads the stream's state back, applies the change, writes it again). */

@@ -156,151 +156,233 @@ def parse_stream(data, stage=2):
     return out
 
 
+class _ParseBatch(ctypes.Structure):
+    # struct xaac_parse_batch
+    _fields_ = [(n, ctypes.c_int32) for n in ("n_streams", "n_ch", "with_sbr", "ps_enable", "stage", "threads")] + \
+               [(n, ctypes.c_void_p) for n in ("parser", "data", "bytes", "spec", "ics", "header", "frame", "ps_frame", "flags",
+                                               "tools", "consumed", "status")]
+
+
+F_APPLY, F_RESET, F_RESET_CHANNELS, F_UPSAMPLING, F_STEREO, F_PS, F_PS_START, F_FRAME_OK = range(8)
+
+
+class BatchParser:
+    """N ADTS streams of one kind through the host front end in lock step: xaac_parse_batch_run parses one frame of every
+    stream on a team of CPU threads, straight into the (pinned) staging arrays handed to step()."""
+
+    def __init__(self, streams, threads=0, stage=2):
+        self.lib = load_host_library()
+        self.lib.xaac_parse_batch_run.argtypes = [ctypes.c_void_p]
+        self.n = n = len(streams)
+        self.length = np.array([len(d) for d in streams], np.uint64)
+        self.start = np.concatenate([[0], np.cumsum(self.length)[:-1]]).astype(np.uint64)
+        self.blob = np.frombuffer(b"".join(bytes(d) for d in streams) + b"\0" * 16, np.uint8).copy()
+        self.base = self.blob.ctypes.data
+        self.pos = np.zeros(n, np.uint64)
+        self.parsers = (ctypes.c_void_p * n)()
+        for i in range(n):
+            h = ctypes.c_void_p()
+            if self.lib.xaac_parser_create(ctypes.byref(h)):
+                raise RuntimeError("xaac_parser_create failed")
+            self.parsers[i] = h
+        self.threads, self.stage = int(threads), int(stage)
+        self.consumed, self.status = np.zeros(n, np.uint64), np.zeros(n, np.int32)
+        self.tools = np.zeros(n, np.int32)
+        self.frames = np.zeros(n, np.int64)
+        hdr = AdtsHeader()
+        rc = self.lib.xaac_adts_parse_header(bytes(streams[0][:16]), min(16, len(streams[0])), ctypes.byref(hdr))
+        if rc:
+            raise ParseError(rc, 0)
+        self.core_rate, self.n_ch = hdr.sampling_rate, (2 if hdr.channel_config == 2 else 1)
+        # the initialisation pass over frame 0 (api.c:2097): nothing of it is kept but the PNS seed
+        spec, ics = np.zeros((n, self.n_ch, 1024), np.int32), np.zeros((n, self.n_ch, 2), np.uint8)
+        self._run(spec, ics, None, None, None, None, with_sbr=False, advance=False)
+        if np.any(self.status != 0):
+            raise ParseError(int(self.status[np.nonzero(self.status)[0][0]]), 0)
+        core = CoreFrame()
+        used = ctypes.c_size_t()
+        probe = ctypes.c_void_p()
+        self.lib.xaac_parser_create(ctypes.byref(probe))
+        self.lib.xaac_parse_adts_frame(probe, bytes(streams[0]), len(streams[0]), 2, ctypes.byref(core), ctypes.byref(used))
+        self.lib.xaac_parser_destroy(probe)
+        self.sbr = bool(core.sbr_bytes > 0 or self.core_rate <= 24000)
+
+    def close(self):
+        for i in range(self.n):
+            if self.parsers[i]:
+                self.lib.xaac_parser_destroy(self.parsers[i])
+                self.parsers[i] = None
+
+    def _run(self, spec, ics, hdr, frm, psf, flags, with_sbr, advance=True):
+        n = self.n
+        left = self.length - self.pos
+        ptrs = (np.uint64(self.base) + self.start + self.pos).astype(np.uint64)
+        b = _ParseBatch()
+        b.n_streams, b.n_ch, b.with_sbr, b.ps_enable, b.stage, b.threads = n, self.n_ch, int(with_sbr), 1, self.stage, self.threads
+        b.parser, b.data, b.bytes = ctypes.addressof(self.parsers), ptrs.ctypes.data, left.ctypes.data
+        ptr = lambda t: None if t is None else (t.data_ptr() if hasattr(t, "data_ptr") else t.ctypes.data)
+        b.spec, b.ics, b.header, b.frame, b.ps_frame, b.flags = ptr(spec), ptr(ics), ptr(hdr), ptr(frm), ptr(psf), ptr(flags)
+        b.tools, b.consumed, b.status = self.tools.ctypes.data, self.consumed.ctypes.data, self.status.ctypes.data
+        ok = self.lib.xaac_parse_batch_run(ctypes.byref(b))
+        if ok < 0:
+            raise RuntimeError("xaac_parse_batch_run: %d" % ok)
+        if advance:
+            self.pos += self.consumed
+            self.frames += (self.status == 0)
+        return ok
+
+    def step(self, spec, ics, hdr=None, frm=None, psf=None, flags=None):
+        """parses the next frame of every stream into the staging arrays; -> bool[n]: which streams delivered a frame
+        (the others are at their end: their rows are left as they were)"""
+        self._run(spec, ics, hdr, frm, psf, flags, with_sbr=self.sbr)
+        bad = (self.status != 0) & (self.status != 1)
+        if np.any(bad):
+            i = int(np.nonzero(bad)[0][0])
+            raise ParseError(int(self.status[i]), int(self.frames[i]))
+        return self.status == 0
+
+
 def _struct_bytes(fn, size):
     raw = (ctypes.c_uint8 * size)()
     fn(raw)
     return np.frombuffer(raw, np.uint8).copy()
 
 
-def decode_streams(streams, ctx=None, device="cuda:0"):
+def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True, timing=None):
     """Decodes N ADTS streams of the same kind (all AAC-LC stereo, all HE-AAC stereo, or all HE-AAC / HE-AACv2 mono) in
-    lock step: per step one frame of every stream is parsed on the CPU and the whole batch runs through the GPU entry
-    points.  -> (list of int16 [samples, 2] arrays, output sampling rate).  Streams that end early drop out of the batch."""
+    lock step: per step one frame of every stream is parsed on CPU threads into pinned staging arrays, copied to the GPU
+    (spectra + window info, SBR / PS side info: nothing else crosses the bus on the way in), run through the GPU entry
+    points against the streams' device-resident states, and the PCM copied back.
+    -> (list of int16 [samples, 2] arrays, output sampling rate).  keep_pcm False: the PCM still comes back to the host
+    every step but is not collected (throughput measurements); timing: a dict that receives seconds per stage."""
+    import time
     import torch
     lib = load_host_library()
     dev = torch.device(device)
     own = ctx is None
     if own:   # the context launches on torch's current stream, so that its kernels and torch's copies stay in order
         ctx = XaacContext(dev.index or 0, torch.cuda.current_stream(dev).cuda_stream)
-    ps = [StreamParser(d) for d in streams]
-    n = len(ps)
-    n_ch, sbr, rate = ps[0].n_ch, ps[0].sbr, ps[0].core_rate
-    for p in ps:
-        if (p.n_ch, p.sbr, p.core_rate) != (n_ch, sbr, rate):
-            raise ValueError("decode_streams takes streams of one kind")
+    bp = BatchParser(streams, threads=threads)
+    n, n_ch, sbr, rate = bp.n, bp.n_ch, bp.sbr, bp.core_rate
     nc = n * n_ch
+    t_parse = t_gpu = 0.0
 
     def dz(*shape, dtype=torch.uint8):
         return torch.zeros(*shape, dtype=dtype, device=dev)
 
+    def pinned(*shape, dtype=torch.uint8):
+        return torch.zeros(*shape, dtype=dtype).pin_memory()
+
     overlap, ovl_state = dz(nc, 512, dtype=torch.int32), dz(nc, 2)
-    spec_h = torch.zeros(nc, 1024, dtype=torch.int32).pin_memory()
-    ics_h = torch.zeros(nc, 2, dtype=torch.uint8).pin_memory()
+    spec_h, ics_h = pinned(nc, 1024, dtype=torch.int32), pinned(nc, 2)
     spec_d, ics_d = dz(nc, 1024, dtype=torch.int32), dz(nc, 2)
     out = [[] for _ in range(n)]
+    hdr_h = frm_h = psf_h = flags = None
     if not sbr:
+        if n_ch != 2:
+            raise NotImplementedError("mono AAC-LC without SBR")
         # AAC-LC: IMDCT -> WORD32 + qshift_adj -> peak limiter -> round16 (api.c:3662-3692)
         out32, qadj = dz(n * 1024 * 2, dtype=torch.int32), dz(n * 2, dtype=torch.int8)
         lim0, delay = peak_limiter_init(2, rate)
         lim = torch.from_numpy(np.tile(np.frombuffer(bytes(lim0), np.uint8), (n, 1)).copy()).to(dev)
         ws = dz(max(ctx.peak_limiter_workspace_bytes(n), 16))
         pcm = dz(n * 1024 * 2, dtype=torch.int16)
+        pcm_h = pinned(n * 1024 * 2, dtype=torch.int16)
     else:
-        sbr_state0 = _struct_bytes(lib.xaac_sbr_state_init, SBR_STATE_BYTES)
-        state = torch.from_numpy(np.tile(sbr_state0, (nc, 1)).copy()).to(dev)
+        state = torch.from_numpy(np.tile(_struct_bytes(lib.xaac_sbr_state_init, SBR_STATE_BYTES), (nc, 1)).copy()).to(dev)
         core16 = dz(nc * 1024, dtype=torch.int16)
-        hdr_h = torch.zeros(nc, SBR_HEADER_BYTES, dtype=torch.uint8).pin_memory()
-        frm_h = torch.zeros(nc, SBR_FRAME_BYTES, dtype=torch.uint8).pin_memory()
+        hdr_h, frm_h = pinned(nc, SBR_HEADER_BYTES), pinned(nc, SBR_FRAME_BYTES)
         hdr_d, frm_d = dz(nc, SBR_HEADER_BYTES), dz(nc, SBR_FRAME_BYTES)
+        flags = np.zeros((n, 8), np.int32)
         status = dz(nc, dtype=torch.int32)
+        pcm_h = pinned(n * 2048 * 2, dtype=torch.int16)
         if n_ch == 2:
             ws = dz(ctx.sbr_lp_workspace_bytes(nc))
             pcm = dz(nc * 2048, dtype=torch.int16)
         else:
-            ps_state0 = _struct_bytes(lib.xaac_ps_state_init, PS_STATE_BYTES)
-            ps_state = torch.from_numpy(np.tile(ps_state0, (n, 1)).copy()).to(dev)
-            psf_h = torch.zeros(n, PS_FRAME_BYTES, dtype=torch.uint8).pin_memory()
-            psf_d = dz(n, PS_FRAME_BYTES)
+            ps_state = torch.from_numpy(np.tile(_struct_bytes(lib.xaac_ps_state_init, PS_STATE_BYTES), (n, 1)).copy()).to(dev)
+            psf_h, psf_d = pinned(n, PS_FRAME_BYTES), dz(n, PS_FRAME_BYTES)
             ws = dz(ctx.sbr_hq_workspace_bytes(n, True))
-            pcm_ps, pcm_mono = dz(n * 2048 * 2, dtype=torch.int16), dz(n * 2048, dtype=torch.int16)
-    alive = list(range(n))
+            pcm = dz(n * 2048 * 2, dtype=torch.int16)
+            pcm_mono = dz(n * 2048, dtype=torch.int16)
     first = True
-    while alive:
-        alive = [i for i in alive if ps[i].next()]
-        if not alive:
+    while True:
+        t0 = time.perf_counter()
+        got = bp.step(spec_h, ics_h, hdr_h, frm_h, psf_h, flags)
+        t_parse += time.perf_counter() - t0
+        if not got.any():
             break
-        if len(alive) != n:
-            # the batch shrinks only at stream ends: simplest correct handling is to finish the others one by one
-            raise NotImplementedError("streams of different lengths: decode them in separate calls")
-        for i in alive:
-            c = ps[i].core
-            spec_h[i * n_ch:(i + 1) * n_ch] = torch.from_numpy(np.ctypeslib.as_array(c.spec)[:n_ch])
-            ics_np = np.ctypeslib.as_array(c.ics)[:n_ch, :2].astype(np.uint8)
-            ics_h[i * n_ch:(i + 1) * n_ch] = torch.from_numpy(ics_np)
+        t0 = time.perf_counter()
         spec_d.copy_(spec_h, non_blocking=True)
         ics_d.copy_(ics_h, non_blocking=True)
         if not sbr:
-            ctx.imdct_process_batch(spec_d, ics_d, overlap, ovl_state, out32=out32, qshift_adj=qadj, ch_fac=n_ch)
-            if n_ch == 1:
-                raise NotImplementedError("mono AAC-LC without SBR")
+            ctx.imdct_process_batch(spec_d, ics_d, overlap, ovl_state, out32=out32, qshift_adj=qadj, ch_fac=2)
             ctx.peak_limiter_process_batch(out32, qadj, lim, 2, ws, pcm16=pcm)
+            pcm_h.copy_(pcm, non_blocking=True)
             ctx.sync()
-            block = pcm.cpu().numpy().reshape(n, 1024, 2)
-            for i in range(n):
-                out[i].append(block[i, delay:] if first else block[i])
+            if keep_pcm:
+                block = pcm_h.numpy().reshape(n, 1024, 2)
+                for i in np.nonzero(got)[0]:
+                    out[i].append(block[i, delay:].copy() if first else block[i].copy())
         else:
             ctx.imdct_process_batch(spec_d, ics_d, overlap, ovl_state, pcm16=core16, ch_fac=n_ch, pcm_mode=PCM_SBR)
-            sides = [ps[i].side for i in alive]
             # frames that reset the SBR decoder or fall back to plain up-sampling change a few words of the resident state
-            touched = [i for i in alive if ps[i].side.reset or ps[i].side.upsampling]
-            if touched:
-                ctx.sync()
-                st_h = state.cpu().numpy()
-                ps_h = ps_state.cpu().numpy() if n_ch == 1 else None
-                for i in touched:
+            touched = np.nonzero(got & ((flags[:, F_RESET] != 0) | (flags[:, F_UPSAMPLING] != 0)))[0]
+            if touched.size:
+                rows = torch.from_numpy((touched[:, None] * n_ch + np.arange(n_ch)[None, :]).ravel()).to(dev)
+                st_h = state.index_select(0, rows).cpu().numpy()
+                side = SbrSide()
+                if n_ch == 1:
+                    prow = torch.from_numpy(touched).to(dev)
+                    ps_h = ps_state.index_select(0, prow).cpu().numpy()
+                for k, i in enumerate(touched):
+                    for name, v in zip(("apply", "reset", "reset_channels", "upsampling", "stereo", "ps", "ps_start", "frame_ok"),
+                                       flags[i]):
+                        setattr(side, name, int(v))
+                    ctypes.memmove(ctypes.addressof(side) + SbrSide.header.offset, hdr_h[i * n_ch].numpy().ctypes.data,
+                                   SBR_HEADER_BYTES)
                     for c in range(n_ch):
-                        row = np.ascontiguousarray(st_h[i * n_ch + c])
-                        lib.xaac_sbr_state_apply_side(row.ctypes.data, ctypes.byref(ps[i].side), c)
-                        st_h[i * n_ch + c] = row
+                        row = np.ascontiguousarray(st_h[k * n_ch + c])
+                        lib.xaac_sbr_state_apply_side(row.ctypes.data, ctypes.byref(side), c)
+                        st_h[k * n_ch + c] = row
                     if n_ch == 1:
-                        row = np.ascontiguousarray(ps_h[i])
-                        lib.xaac_ps_state_apply_side(row.ctypes.data, ctypes.byref(ps[i].side))
-                        ps_h[i] = row
-                state.copy_(torch.from_numpy(st_h))
+                        row = np.ascontiguousarray(ps_h[k])
+                        lib.xaac_ps_state_apply_side(row.ctypes.data, ctypes.byref(side))
+                        ps_h[k] = row
+                state.index_copy_(0, rows, torch.from_numpy(st_h).to(dev))
                 if n_ch == 1:
-                    ps_state.copy_(torch.from_numpy(ps_h))
-            for k, i in enumerate(alive):
-                s = sides[k]
-                hdr_np = np.frombuffer(bytes(s.header), np.uint8)
-                for c in range(n_ch):
-                    hdr_h[i * n_ch + c] = torch.from_numpy(hdr_np.copy())
-                    frm_h[i * n_ch + c] = torch.from_numpy(np.frombuffer(bytes(s.frame[c]), np.uint8).copy())
-                if n_ch == 1:
-                    psf_h[i] = torch.from_numpy(np.frombuffer(bytes(s.ps_frame), np.uint8).copy())
+                    ps_state.index_copy_(0, prow, torch.from_numpy(ps_h).to(dev))
             hdr_d.copy_(hdr_h, non_blocking=True)
             frm_d.copy_(frm_h, non_blocking=True)
             if n_ch == 2:
                 ctx.sbr_lp_process_batch(core16, hdr_d, frm_d, state, pcm, ws, status=status, in_ch_fac=2, out_ch_fac=2)
-                ctx.sync()
-                block = pcm.cpu().numpy().reshape(n, 2048, 2)
-                for i in range(n):
-                    out[i].append(block[i].copy())
+                pcm_h.copy_(pcm, non_blocking=True)
             else:
-                with_ps = [bool(ps[i].side.ps) for i in alive]
-                if any(with_ps) != all(with_ps):
+                with_ps = flags[got, F_PS] != 0
+                if with_ps.any() != with_ps.all():
                     raise NotImplementedError("a batch mixing PS and non-PS frames")
-                if all(with_ps):
-                    starts = [i for i in alive if ps[i].side.ps_start]
-                    if starts:
-                        idx = torch.tensor(starts, dtype=torch.int32, device=dev)
+                if with_ps.all():
+                    starts = np.nonzero(got & (flags[:, F_PS_START] != 0))[0]
+                    if starts.size:
+                        idx = torch.from_numpy(starts.astype(np.int32)).to(dev)
                         ctx.sbr_state_handover(HANDOVER_PS_START, idx, idx, state, ps_state)
                     psf_d.copy_(psf_h, non_blocking=True)
-                    ctx.sbr_hq_process_batch(core16, hdr_d, frm_d, state, pcm_ps, ws, ps_frame=psf_d, ps_state=ps_state,
-                                             status=status)
-                    ctx.sync()
-                    block = pcm_ps.cpu().numpy().reshape(n, 2048, 2)
-                    for i in range(n):
-                        out[i].append(block[i].copy())
+                    ctx.sbr_hq_process_batch(core16, hdr_d, frm_d, state, pcm, ws, ps_frame=psf_d, ps_state=ps_state, status=status)
+                    pcm_h.copy_(pcm, non_blocking=True)
                 else:
                     ctx.sbr_hq_process_batch(core16, hdr_d, frm_d, state, pcm_mono, ws, status=status)
-                    ctx.sync()
-                    block = pcm_mono.cpu().numpy().reshape(n, 2048)
-                    for i in range(n):
-                        out[i].append(np.repeat(block[i][:, None], 2, axis=1))   # mono duplicated to stereo (api.c:3639)
-            if int(status.min().item()) < 0:
+                    # mono duplicated to stereo (api.c:3639-3660)
+                    pcm_h.copy_(pcm_mono.view(n, 2048, 1).expand(n, 2048, 2).reshape(-1), non_blocking=True)
+            bad = int(status.min().item())    # also the step's synchronisation point
+            if bad < 0:
                 raise RuntimeError("the SBR kernels refused a frame")
+            if keep_pcm:
+                block = pcm_h.numpy().reshape(n, 2048, 2)
+                for i in np.nonzero(got)[0]:
+                    out[i].append(block[i].copy())
+        t_gpu += time.perf_counter() - t0
         first = False
-    if not sbr:
+    if not sbr and keep_pcm:
         # the limiter's delay line holds the last attack_time_samples samples: api.c:2824-2866
         ctx.sync()
         lim_h = lim.cpu().numpy()
@@ -308,12 +390,13 @@ def decode_streams(streams, ctx=None, device="cuda:0"):
             st = LimiterState.from_buffer_copy(lim_h[i].tobytes())
             att, idx = st.attack_time_samples, st.delayed_input_index
             d = np.ctypeslib.as_array(st.delayed_input)[:att * 2].reshape(att, 2)
-            tail = np.concatenate([d[idx:], d[:idx]]).astype(np.float64)
-            v = tail.astype(np.int64)                         # (WORD32) of the float, then round16
+            v = np.concatenate([d[idx:], d[:idx]]).astype(np.int64)      # (WORD32) of the float, then round16
             v = np.clip(v + 0x8000, -(1 << 31), (1 << 31) - 1) >> 16
             out[i].append(v.astype(np.int16))
-    for p in ps:
-        p.close()
+    frames = int(bp.frames.sum())
+    bp.close()
     if own:
         ctx.close()
+    if timing is not None:
+        timing.update(parse_s=t_parse, gpu_s=t_gpu, frames=frames)
     return [np.concatenate(o) if o else np.zeros((0, 2), np.int16) for o in out], rate * (2 if sbr else 1)

@@ -25,7 +25,7 @@ struct Book {
   uint16_t lut[1024]; /* the first ten bits -> entry (length <= 10), or 0xffff */
 };
 Book g_book[12];
-bool g_books_ready = false;
+
 
 #define XH_BOOK(k) {xh_hcb##k##_code, xh_hcb##k##_len, xh_hcb##k##_idx, (int)(sizeof(xh_hcb##k##_len)), {0}}
 
@@ -42,7 +42,7 @@ void build_books() {
         for (uint32_t j = 0; j < count; j++) k.lut[first + j] = (uint16_t)e;
       }
   }
-  g_books_ready = true;
+
 }
 
 /* one code word at the reader's position: its index in the book's value order */
@@ -704,7 +704,8 @@ int skip_pce(XhBits *br) { /* program_config_element: read over it (ISO/IEC 1449
 }  // namespace
 
 int xh_core_init(XhCoreState *st, int sr_index) {
-  if (!g_books_ready) build_books();
+  static const bool books_built = (build_books(), true); /* once, also when the first callers are parser threads */
+  (void)books_built;
   if (sr_index < 0 || sr_index > 11) return XH_ERR_UNSUPPORTED;
   /* initfuncs.c:222-300: which width table a sampling frequency index takes */
   static const int8_t *const long_tab[12] = {xh_sfb_96_1024, xh_sfb_96_1024, xh_sfb_64_1024, xh_sfb_48_1024,

@@ -8,6 +8,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include <string.h>
 
 struct XhBits {
   const uint8_t *p;
@@ -20,7 +21,13 @@ struct XhBits {
   uint32_t peek32() const {
     const size_t byte = pos >> 3;
     const size_t total = n_bits >> 3;
-    uint64_t w = 0;
+    uint64_t w;
+    if (byte + 8 <= total) { /* eight bytes at once, most significant first */
+      memcpy(&w, p + byte, 8);
+      w = __builtin_bswap64(w);
+      return (uint32_t)((w << (pos & 7)) >> 32);
+    }
+    w = 0;
     for (size_t k = 0; k < 5; k++) w = (w << 8) | (byte + k < total ? p[byte + k] : 0);
     return (uint32_t)(w >> (8 - (pos & 7)));
   }

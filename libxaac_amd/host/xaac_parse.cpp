@@ -5,6 +5,7 @@
 #include "../../include/xaac_parse.h"
 
 #include <new>
+#include <omp.h>
 #include <string.h>
 
 #include "aac_core.h"
@@ -18,6 +19,7 @@ struct xaac_parser {
   XhElement el;
   int sbr_ready, sampling_rate;
   XsDecoder sbr;
+  xaac_sbr_side side_scratch;
 };
 
 extern "C" {
@@ -56,8 +58,28 @@ int32_t xaac_adts_parse_header(const uint8_t *data, size_t n, xaac_adts_header *
   return XAAC_PARSE_OK;
 }
 
-int32_t xaac_parse_adts_frame(xaac_parser *p, const uint8_t *data, size_t n, int32_t stage, xaac_core_frame *out,
-                              size_t *consumed) {
+static int32_t tools_of(const XhElement &el) {
+  int32_t tools = 0;
+  for (int g = 0; g < 8; g++)
+    for (int sfb = 0; sfb < 64; sfb++)
+      if (el.ms_used[g][sfb]) tools |= XAAC_TOOL_MS;
+  for (int c = 0; c < el.n_ch; c++) {
+    const XhChannel &ch = el.ch[c];
+    if (ch.pns_active) tools |= XAAC_TOOL_PNS;
+    if (ch.tns.present) tools |= XAAC_TOOL_TNS;
+    if (ch.pulse.present) tools |= XAAC_TOOL_PULSE;
+    if (ch.ics.window_sequence == XH_EIGHT_SHORT) tools |= XAAC_TOOL_SHORT;
+    for (int g = 0; g < ch.ics.num_groups; g++)
+      for (int sfb = 0; sfb < ch.ics.max_sfb; sfb++) {
+        if (ch.cb[16 * g + sfb] >= XH_INTENSITY_HCB2) tools |= XAAC_TOOL_INTENSITY;
+        if (ch.cb[16 * g + sfb] == XH_ESC_HCB) tools |= XAAC_TOOL_ESCAPE;
+      }
+  }
+  return tools;
+}
+
+/* the frame at data[0 .. n) into p->el */
+static int32_t parse_frame(xaac_parser *p, const uint8_t *data, size_t n, int32_t stage, size_t *consumed) {
   xaac_adts_header h;
   const int32_t e = xaac_adts_parse_header(data, n, &h);
   if (e) return e;
@@ -72,7 +94,12 @@ int32_t xaac_parse_adts_frame(xaac_parser *p, const uint8_t *data, size_t n, int
     p->sampling_rate = h.sampling_rate;
   }
   XhBits br(data + h.header_bytes, (size_t)(h.frame_bytes - h.header_bytes));
-  const int r = xh_parse_raw_data_block(&p->core, &br, &p->el, stage);
+  return xh_parse_raw_data_block(&p->core, &br, &p->el, stage);
+}
+
+int32_t xaac_parse_adts_frame(xaac_parser *p, const uint8_t *data, size_t n, int32_t stage, xaac_core_frame *out,
+                              size_t *consumed) {
+  const int32_t r = parse_frame(p, data, n, stage, consumed);
   if (r) return r;
   const XhElement &el = p->el;
   out->n_ch = el.n_ch;
@@ -81,22 +108,7 @@ int32_t xaac_parse_adts_frame(xaac_parser *p, const uint8_t *data, size_t n, int
   out->sbr_ext_type = el.sbr_ext_type;
   out->sbr_bytes = el.sbr_bytes;
   memcpy(out->sbr, el.sbr, sizeof(out->sbr));
-  out->tools = 0;
-  for (int g = 0; g < 8; g++)
-    for (int sfb = 0; sfb < 64; sfb++)
-      if (el.ms_used[g][sfb]) out->tools |= XAAC_TOOL_MS;
-  for (int c = 0; c < el.n_ch; c++) {
-    const XhChannel &ch = el.ch[c];
-    if (ch.pns_active) out->tools |= XAAC_TOOL_PNS;
-    if (ch.tns.present) out->tools |= XAAC_TOOL_TNS;
-    if (ch.pulse.present) out->tools |= XAAC_TOOL_PULSE;
-    if (ch.ics.window_sequence == XH_EIGHT_SHORT) out->tools |= XAAC_TOOL_SHORT;
-    for (int g = 0; g < ch.ics.num_groups; g++)
-      for (int sfb = 0; sfb < ch.ics.max_sfb; sfb++) {
-        if (ch.cb[16 * g + sfb] >= XH_INTENSITY_HCB2) out->tools |= XAAC_TOOL_INTENSITY;
-        if (ch.cb[16 * g + sfb] == XH_ESC_HCB) out->tools |= XAAC_TOOL_ESCAPE;
-      }
-  }
+  out->tools = tools_of(el);
   for (int c = 0; c < el.n_ch; c++) {
     out->ics[c].window_sequence = (int16_t)el.ch[c].ics.window_sequence;
     out->ics[c].window_shape = (int16_t)el.ch[c].ics.window_shape;
@@ -120,6 +132,50 @@ int32_t xaac_parse_sbr_side(xaac_parser *p, int32_t ps_enable, xaac_sbr_side *si
   side->apply = r.apply, side->reset = r.reset, side->reset_channels = r.reset_channels, side->upsampling = r.upsampling;
   side->stereo = r.stereo, side->ps = r.ps, side->ps_start = r.ps_start, side->frame_ok = r.frame_ok;
   return XAAC_PARSE_OK;
+}
+
+int32_t xaac_parse_batch_run(const xaac_parse_batch *b) {
+  if (!b || b->n_streams < 0 || (b->n_ch != 1 && b->n_ch != 2) || !b->parser || !b->data || !b->bytes || !b->spec || !b->ics ||
+      !b->consumed || !b->status || (b->with_sbr && (!b->header || !b->frame || !b->flags)))
+    return XAAC_PARSE_ERR_SYNTAX;
+  const int n_ch = b->n_ch;
+  int ok = 0;
+  int threads = b->threads > 0 ? b->threads : omp_get_max_threads();
+  if (threads > b->n_streams) threads = b->n_streams > 0 ? b->n_streams : 1;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(+ : ok)
+  for (int i = 0; i < b->n_streams; i++) {
+    xaac_parser *p = b->parser[i];
+    size_t used = 0;
+    b->consumed[i] = 0;
+    int32_t r = parse_frame(p, b->data[i], (size_t)b->bytes[i], b->stage, &used);
+    if (r == 0 && p->el.n_ch != n_ch) r = XAAC_PARSE_ERR_UNSUPPORTED;
+    xaac_sbr_side *side = nullptr;
+    if (r == 0 && b->with_sbr) {
+      side = &p->side_scratch;
+      r = xaac_parse_sbr_side(p, b->ps_enable, side);
+    }
+    b->status[i] = r;
+    if (r) continue;
+    ok++;
+    b->consumed[i] = used;
+    if (b->tools) b->tools[i] = tools_of(p->el);
+    for (int c = 0; c < n_ch; c++) {
+      memcpy(b->spec + ((size_t)i * n_ch + c) * 1024, p->el.ch[c].spec(), 1024 * sizeof(int32_t));
+      b->ics[((size_t)i * n_ch + c) * 2 + 0] = (uint8_t)p->el.ch[c].ics.window_sequence;
+      b->ics[((size_t)i * n_ch + c) * 2 + 1] = (uint8_t)p->el.ch[c].ics.window_shape;
+      if (side) {
+        b->header[(size_t)i * n_ch + c] = side->header;
+        b->frame[(size_t)i * n_ch + c] = side->frame[c];
+      }
+    }
+    if (side) {
+      if (b->ps_frame) b->ps_frame[i] = side->ps_frame;
+      int32_t *f = b->flags + (size_t)i * 8;
+      f[0] = side->apply, f[1] = side->reset, f[2] = side->reset_channels, f[3] = side->upsampling;
+      f[4] = side->stereo, f[5] = side->ps, f[6] = side->ps_start, f[7] = side->frame_ok;
+    }
+  }
+  return ok;
 }
 
 void xaac_sbr_state_init(xaac_sbr_state *s) {
