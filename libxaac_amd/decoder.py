@@ -82,9 +82,9 @@ class ParseError(RuntimeError):
 
 
 class StreamParser:
-    """One ADTS stream through the host front end, frame by frame, the way the reference's decoder walks it: the first
-    frame is decoded once while the decoder initialises (ixheaacd_dec_init, api.c:2097: only the PNS random seed
-    survives that pass) and then again as the first output frame."""
+    """One ADTS stream through the host front end, frame by frame.  (The reference decodes the first frame twice, once
+    while it initialises -- ixheaacd_dec_init, api.c:2097 -- and again as the first output frame; every state is set up
+    afresh in between, api.c:2141-2170, so nothing of the first pass shows and one pass is all that is needed here.)"""
 
     def __init__(self, data, with_sbr=None, stage=2):
         self.lib = load_host_library()
@@ -100,8 +100,10 @@ class StreamParser:
         if rc:
             raise ParseError(rc, 0)
         self.core_rate = hdr.sampling_rate
-        rc = self.lib.xaac_parse_adts_frame(self.h, self.buf, len(self.data), stage, ctypes.byref(self.core),
-                                            ctypes.byref(self.used))      # the initialisation pass over frame 0
+        probe = ctypes.c_void_p()           # a look at frame 0 with a parser of its own: channels, SBR payload or not
+        self.lib.xaac_parser_create(ctypes.byref(probe))
+        rc = self.lib.xaac_parse_adts_frame(probe, self.buf, len(self.data), 1, ctypes.byref(self.core), ctypes.byref(self.used))
+        self.lib.xaac_parser_destroy(probe)
         if rc:
             raise ParseError(rc, 0)
         self.n_ch = self.core.n_ch
@@ -194,17 +196,14 @@ class BatchParser:
         if rc:
             raise ParseError(rc, 0)
         self.core_rate, self.n_ch = hdr.sampling_rate, (2 if hdr.channel_config == 2 else 1)
-        # the initialisation pass over frame 0 (api.c:2097): nothing of it is kept but the PNS seed
-        spec, ics = np.zeros((n, self.n_ch, 1024), np.int32), np.zeros((n, self.n_ch, 2), np.uint8)
-        self._run(spec, ics, None, None, None, None, with_sbr=False, advance=False)
-        if np.any(self.status != 0):
-            raise ParseError(int(self.status[np.nonzero(self.status)[0][0]]), 0)
         core = CoreFrame()
         used = ctypes.c_size_t()
         probe = ctypes.c_void_p()
         self.lib.xaac_parser_create(ctypes.byref(probe))
-        self.lib.xaac_parse_adts_frame(probe, bytes(streams[0]), len(streams[0]), 2, ctypes.byref(core), ctypes.byref(used))
+        rc = self.lib.xaac_parse_adts_frame(probe, bytes(streams[0]), len(streams[0]), 1, ctypes.byref(core), ctypes.byref(used))
         self.lib.xaac_parser_destroy(probe)
+        if rc:
+            raise ParseError(rc, 0)
         self.sbr = bool(core.sbr_bytes > 0 or self.core_rate <= 24000)
 
     def close(self):
@@ -248,13 +247,15 @@ def _struct_bytes(fn, size):
     return np.frombuffer(raw, np.uint8).copy()
 
 
-def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True, timing=None):
+def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True, timing=None, overlap=True):
     """Decodes N ADTS streams of the same kind (all AAC-LC stereo, all HE-AAC stereo, or all HE-AAC / HE-AACv2 mono) in
     lock step: per step one frame of every stream is parsed on CPU threads into pinned staging arrays, copied to the GPU
     (spectra + window info, SBR / PS side info: nothing else crosses the bus on the way in), run through the GPU entry
     points against the streams' device-resident states, and the PCM copied back.
     -> (list of int16 [samples, 2] arrays, output sampling rate).  keep_pcm False: the PCM still comes back to the host
-    every step but is not collected (throughput measurements); timing: a dict that receives seconds per stage."""
+    every step but is not collected (throughput measurements); timing: a dict that receives seconds per stage.
+    overlap: the host parses step k + 1 (a second set of staging arrays, a helper thread: the parser calls release the GIL)
+    while the GPU works on step k."""
     import time
     import torch
     lib = load_host_library()
@@ -273,11 +274,28 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
     def pinned(*shape, dtype=torch.uint8):
         return torch.zeros(*shape, dtype=dtype).pin_memory()
 
-    overlap, ovl_state = dz(nc, 512, dtype=torch.int32), dz(nc, 2)
-    spec_h, ics_h = pinned(nc, 1024, dtype=torch.int32), pinned(nc, 2)
+    ovl, ovl_state = dz(nc, 512, dtype=torch.int32), dz(nc, 2)
     spec_d, ics_d = dz(nc, 1024, dtype=torch.int32), dz(nc, 2)
     out = [[] for _ in range(n)]
-    hdr_h = frm_h = psf_h = flags = None
+
+    class Staging:    # what one step's parse leaves for the GPU: pinned host arrays
+        def __init__(self):
+            self.spec, self.ics = pinned(nc, 1024, dtype=torch.int32), pinned(nc, 2)
+            self.hdr = self.frm = self.psf = self.flags = None
+            if sbr:
+                self.hdr, self.frm = pinned(nc, SBR_HEADER_BYTES), pinned(nc, SBR_FRAME_BYTES)
+                self.flags = np.zeros((n, 8), np.int32)
+                if n_ch == 1:
+                    self.psf = pinned(n, PS_FRAME_BYTES)
+            self.got, self.seconds = None, 0.0
+
+        def parse(self):
+            t0 = time.perf_counter()
+            self.got = bp.step(self.spec, self.ics, self.hdr, self.frm, self.psf, self.flags)
+            self.seconds = time.perf_counter() - t0
+            return self
+
+    sets = [Staging(), Staging()] if overlap else [Staging()]
     if not sbr:
         if n_ch != 2:
             raise NotImplementedError("mono AAC-LC without SBR")
@@ -291,9 +309,7 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
     else:
         state = torch.from_numpy(np.tile(_struct_bytes(lib.xaac_sbr_state_init, SBR_STATE_BYTES), (nc, 1)).copy()).to(dev)
         core16 = dz(nc * 1024, dtype=torch.int16)
-        hdr_h, frm_h = pinned(nc, SBR_HEADER_BYTES), pinned(nc, SBR_FRAME_BYTES)
         hdr_d, frm_d = dz(nc, SBR_HEADER_BYTES), dz(nc, SBR_FRAME_BYTES)
-        flags = np.zeros((n, 8), np.int32)
         status = dz(nc, dtype=torch.int32)
         pcm_h = pinned(n * 2048 * 2, dtype=torch.int16)
         if n_ch == 2:
@@ -301,22 +317,34 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
             pcm = dz(nc * 2048, dtype=torch.int16)
         else:
             ps_state = torch.from_numpy(np.tile(_struct_bytes(lib.xaac_ps_state_init, PS_STATE_BYTES), (n, 1)).copy()).to(dev)
-            psf_h, psf_d = pinned(n, PS_FRAME_BYTES), dz(n, PS_FRAME_BYTES)
+            psf_d = dz(n, PS_FRAME_BYTES)
             ws = dz(ctx.sbr_hq_workspace_bytes(n, True))
             pcm = dz(n * 2048 * 2, dtype=torch.int16)
             pcm_mono = dz(n * 2048, dtype=torch.int16)
     first = True
+    pool = None
+    if overlap:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(1)
+        pending = pool.submit(sets[0].parse)
+    which = 0
+    t_steps = time.perf_counter()
     while True:
-        t0 = time.perf_counter()
-        got = bp.step(spec_h, ics_h, hdr_h, frm_h, psf_h, flags)
-        t_parse += time.perf_counter() - t0
+        cur = pending.result() if overlap else sets[0].parse()
+        t_parse += cur.seconds
+        got = cur.got
         if not got.any():
             break
+        if overlap:    # the next step's frames are parsed while the GPU works on this one's
+            which ^= 1
+            pending = pool.submit(sets[which].parse)
+        spec_h, ics_h, hdr_h, frm_h, psf_h, flags = cur.spec, cur.ics, cur.hdr, cur.frm, cur.psf, cur.flags
+        overlap_buf = ovl
         t0 = time.perf_counter()
         spec_d.copy_(spec_h, non_blocking=True)
         ics_d.copy_(ics_h, non_blocking=True)
         if not sbr:
-            ctx.imdct_process_batch(spec_d, ics_d, overlap, ovl_state, out32=out32, qshift_adj=qadj, ch_fac=2)
+            ctx.imdct_process_batch(spec_d, ics_d, overlap_buf, ovl_state, out32=out32, qshift_adj=qadj, ch_fac=2)
             ctx.peak_limiter_process_batch(out32, qadj, lim, 2, ws, pcm16=pcm)
             pcm_h.copy_(pcm, non_blocking=True)
             ctx.sync()
@@ -325,7 +353,7 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
                 for i in np.nonzero(got)[0]:
                     out[i].append(block[i, delay:].copy() if first else block[i].copy())
         else:
-            ctx.imdct_process_batch(spec_d, ics_d, overlap, ovl_state, pcm16=core16, ch_fac=n_ch, pcm_mode=PCM_SBR)
+            ctx.imdct_process_batch(spec_d, ics_d, overlap_buf, ovl_state, pcm16=core16, ch_fac=n_ch, pcm_mode=PCM_SBR)
             # frames that reset the SBR decoder or fall back to plain up-sampling change a few words of the resident state
             touched = np.nonzero(got & ((flags[:, F_RESET] != 0) | (flags[:, F_UPSAMPLING] != 0)))[0]
             if touched.size:
@@ -382,6 +410,9 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
                     out[i].append(block[i].copy())
         t_gpu += time.perf_counter() - t0
         first = False
+    t_steps = time.perf_counter() - t_steps
+    if pool is not None:
+        pool.shutdown()
     if not sbr and keep_pcm:
         # the limiter's delay line holds the last attack_time_samples samples: api.c:2824-2866
         ctx.sync()
@@ -390,13 +421,15 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
             st = LimiterState.from_buffer_copy(lim_h[i].tobytes())
             att, idx = st.attack_time_samples, st.delayed_input_index
             d = np.ctypeslib.as_array(st.delayed_input)[:att * 2].reshape(att, 2)
-            v = np.concatenate([d[idx:], d[:idx]]).astype(np.int64)      # (WORD32) of the float, then round16
-            v = np.clip(v + 0x8000, -(1 << 31), (1 << 31) - 1) >> 16
+            tail = np.concatenate([d[idx:], d[:idx]]).astype(np.float64)
+            inside = (tail > -2147483649.0) & (tail < 2147483648.0)      # (WORD32) of a float as x86 converts it: what does
+            v = np.where(inside, np.trunc(np.where(inside, tail, 0.0)), -2147483648.0).astype(np.int64)   # not fit is INT_MIN
+            v = np.clip(v + 0x8000, -(1 << 31), (1 << 31) - 1) >> 16   # round16
             out[i].append(v.astype(np.int16))
     frames = int(bp.frames.sum())
     bp.close()
     if own:
         ctx.close()
     if timing is not None:
-        timing.update(parse_s=t_parse, gpu_s=t_gpu, frames=frames)
+        timing.update(parse_s=t_parse, gpu_s=t_gpu, steps_s=t_steps, frames=frames)
     return [np.concatenate(o) if o else np.zeros((0, 2), np.int16) for o in out], rate * (2 if sbr else 1)

@@ -788,9 +788,8 @@ int xh_parse_raw_data_block(XhCoreState *st, XhBits *br, XhElement *el, int stag
             }
             intensity_stereo(st, el);
           }
-          int32_t corr_seed[8 * 16];
           for (int c = 0; c < el->n_ch; c++) {
-            pns(st, el, c, corr_seed);
+            pns(st, el, c, st->pns_corr_seed);
             if (el->ch[c].tns.present) tns(st, &el->ch[c]);
           }
         }

@@ -70,6 +70,10 @@ struct XhCoreState {
   const int8_t *width_long, *width_short;
   int num_swb_long, num_swb_short;
   int32_t pns_seed;        /* pstr_pns_rand_vec_data->current_seed: starts at 0, runs on from frame to frame */
+  int32_t pns_corr_seed[8 * 16]; /* pstr_pns_corr_info->random_vector: the left channel's seed of a band whose noise the M/S
+                                    flag correlates; a right channel that substitutes noise in such a band where the left one
+                                    does not finds the value an earlier frame left (the reference keeps it in scratch memory
+                                    that AAC-LC decoding does not reuse in between) */
 };
 
 struct XhElement {

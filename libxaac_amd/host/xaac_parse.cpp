@@ -87,9 +87,12 @@ static int32_t parse_frame(xaac_parser *p, const uint8_t *data, size_t n, int32_
   if (h.raw_blocks != 0 || h.frame_bytes < h.header_bytes) return XAAC_PARSE_ERR_UNSUPPORTED;
   if (consumed) *consumed = (size_t)h.frame_bytes;
   if (p->sr_index != h.sr_index) {
-    const int32_t seed = p->sr_index < 0 ? 0 : p->core.pns_seed;
+    const XhCoreState keep = p->core;
     if (xh_core_init(&p->core, h.sr_index)) return XAAC_PARSE_ERR_HEADER;
-    p->core.pns_seed = seed;
+    if (p->sr_index >= 0) { /* a change of sampling rate in mid-stream: the noise generator runs on */
+      p->core.pns_seed = keep.pns_seed;
+      memcpy(p->core.pns_corr_seed, keep.pns_corr_seed, sizeof(keep.pns_corr_seed));
+    }
     p->sr_index = h.sr_index;
     p->sampling_rate = h.sampling_rate;
   }

@@ -13,7 +13,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STREAMS = os.path.join(ROOT, "tests", "golden", "streams")
 XAACDEC = os.path.join(ROOT, "oracle", "_ref", "xaacdec")
-NAMES = ["mix_aot2_64k", "mix_aot5_48k", "mono_aot5_32k", "harm_aot5_48k", "mix_aot29_32k"]
+NAMES = ["mix_aot2_64k", "mix_aot5_48k", "mono_aot5_32k", "harm_aot5_48k", "mix_aot29_32k", "synth_lc_a", "synth_lc_b"]
+GOLD_ORDER = ["mix_aot2_64k", "mix_aot5_48k", "mono_aot5_32k", "harm_aot5_48k", "mix_aot29_32k", "synth_lc_a", "synth_lc_b",
+              "synth_lc_mono"]      # tools/make_golden_parser.py NAMES
 
 pytestmark = pytest.mark.gpu
 
@@ -44,7 +46,8 @@ def test_stream_equals_reference_decoder(name, tmp_path):
 def test_streams_against_committed_crcs():
     from libxaac_amd import decoder
     gold = np.load(os.path.join(ROOT, "tests", "golden", "decoder_ref.npz"))
-    for k, name in enumerate(NAMES):
+    for name in NAMES:
+        k = GOLD_ORDER.index(name)
         data = open(os.path.join(STREAMS, name + ".aac"), "rb").read()
         got, rate = decoder.decode_streams([data])
         assert (len(got[0]), rate) == (int(gold["samples"][k]), int(gold["rate"][k])), name

@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from libxaac_amd import decoder  # noqa: E402
 
 STREAMS = os.path.join(ROOT, "tests", "golden", "streams")
-NAMES = ["mix_aot2_64k", "mix_aot5_48k", "mono_aot5_32k", "harm_aot5_48k", "mix_aot29_32k"]
+NAMES = ["mix_aot2_64k", "mix_aot5_48k", "mono_aot5_32k", "harm_aot5_48k", "mix_aot29_32k", "synth_lc_a", "synth_lc_b", "synth_lc_mono"]
 CAPTURE = os.path.join(ROOT, "oracle", "_ref", "xaacdec_capture")
 
 
@@ -56,7 +56,8 @@ def test_spectra_and_side_info_equal_the_references(name):
 
 def test_the_streams_exercise_the_tools():
     """what the committed streams cover, so that a pass above means something: M/S, TNS, short blocks, escapes, SBR with and
-    without coupling, every frame class, PS; (intensity, PNS and pulse data are not in these streams: tests/test_parser_synth.py)"""
+    without coupling, every frame class, PS; intensity stereo, PNS and pulse data through the generated streams
+    (tools/make_synth_streams.py: the reference's encoder does not use them)"""
     tools = 0
     classes, coupling, ps_frames, concealed = set(), set(), 0, 0
     for name in NAMES:
@@ -69,7 +70,8 @@ def test_the_streams_exercise_the_tools():
                 coupling.add(fr.coupling_mode)
                 ps_frames += bool(side.ps)
                 concealed += not side.frame_ok
-    for bit in (decoder.TOOL_MS, decoder.TOOL_TNS, decoder.TOOL_SHORT, decoder.TOOL_ESCAPE):
+    for bit in (decoder.TOOL_MS, decoder.TOOL_TNS, decoder.TOOL_SHORT, decoder.TOOL_ESCAPE, decoder.TOOL_INTENSITY,
+                decoder.TOOL_PNS, decoder.TOOL_PULSE):
         assert tools & bit, bit
     assert classes == {0, 1, 2, 3} and coupling >= {0, 1} and ps_frames >= 30 and concealed >= 5
 
