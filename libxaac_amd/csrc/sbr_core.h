@@ -925,7 +925,11 @@ FX_HD XsLv xs_pick_env(const XsLv *v, int i) {
 #if defined(__HIP_DEVICE_COMPILE__)
   XsLv r = v[0];
   XS_UNROLL
-  for (int k = 1; k < XAAC_SBR_MAX_ENVELOPES; k++) r.v = i == k ? v[k].v : r.v;
+  for (int k = 1; k < XAAC_SBR_MAX_ENVELOPES; k++) {
+    int32_t t = v[k].v;
+    asm volatile("" : "+v"(t)); /* keeps the chain a chain of selects: folded into v[i] it would put the array in scratch */
+    r.v = i == k ? t : r.v;
+  }
   return r;
 #else
   return v[i];
