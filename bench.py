@@ -279,11 +279,24 @@ def secondary_end_to_end(copies=4096):
         if best is None or timing["steps_s"] < best["steps_s"]:
             best = timing
     parser = max(bench_decoder.parser_only(decoder, data, copies, t) for t in (0, 64))
+    native = None
+    cli = os.path.join(ROOT, "libxaac_amd", "xaacdec_amd")
+    if os.path.exists(cli):   # the same loop without Python: libxaac_amd/host/xaacdec_amd.cpp (HIP runtime + the two libraries)
+        import subprocess
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            r = subprocess.run([cli, "-ifile:" + os.path.join(ROOT, "tests", "golden", "streams", name + ".aac"),
+                                "-ofile:" + os.path.join(tmp, "o.wav"), "-copies:%d" % copies], capture_output=True, text=True, timeout=300)
+            if r.returncode == 0:
+                j = json.loads(r.stdout.strip().splitlines()[-1])
+                native = {"frames_per_s_after_first_step": j["frames_per_s_after_first_step"], "frames_per_s_whole_run": j["frames_per_s"],
+                          "wall_s": j["wall_s"]}
     return {"metric": "HE-AACv2 ADTS streams decoded end to end (own host parser + GPU, PCIe inclusive)",
             "value": round(best["frames"] / best["steps_s"], 1), "unit": "frames/s", "streams": copies, "frames": best["frames"],
             "parse_s": round(best["parse_s"], 4), "gpu_and_copies_s": round(best["gpu_s"], 4), "wall_s": round(best["steps_s"], 4),
             "parser_only_frames_per_s": round(parser, 1), "host_threads": os.cpu_count(),
-            "pcm_equals_reference_decoder": exact, "stream": name + ".aac", "output_rate_hz": rate}
+            "pcm_equals_reference_decoder": exact, "stream": name + ".aac", "output_rate_hz": rate,
+            "native_cli": native}
 
 
 def secondary_esbr(torch, libxaac_amd, ctx, dev, steps, warmup):

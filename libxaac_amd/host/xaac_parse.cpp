@@ -4,8 +4,13 @@
  */
 #include "../../include/xaac_parse.h"
 
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <new>
-#include <omp.h>
+#include <thread>
+#include <vector>
 #include <string.h>
 
 #include "aac_core.h"
@@ -21,6 +26,79 @@ struct xaac_parser {
   XsDecoder sbr;
   xaac_sbr_side side_scratch;
 };
+
+/* A small persistent team for xaac_parse_batch_run: workers sleep on a condition variable between calls (a host that also
+   drives a GPU must not have its cores spun on by idle parser threads), take items in chunks from a shared counter, and the
+   caller works along.  One batch call at a time (calls from several threads are serialised). */
+namespace {
+class Team {
+ public:
+  void run(int items, int threads, const std::function<void(int)> &fn) {
+    std::lock_guard<std::mutex> serial(call_);
+    if (threads < 1) threads = 1;
+    grow(threads - 1);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = &fn, items_ = items, next_.store(0), active_ = threads - 1, pending_ = threads - 1, generation_++;
+    }
+    if (threads > 1) wake_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+  ~Team() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      quit_ = true;
+    }
+    wake_.notify_all();
+    for (auto &t : workers_) t.join();
+  }
+
+ private:
+  void work() {
+    for (;;) {
+      const int first = next_.fetch_add(kChunk);
+      if (first >= items_) return;
+      const int last = first + kChunk < items_ ? first + kChunk : items_;
+      for (int i = first; i < last; i++) (*fn_)(i);
+    }
+  }
+  void grow(int n) {
+    while ((int)workers_.size() < n) {
+      const int id = (int)workers_.size();
+      workers_.emplace_back([this, id] {
+        uint64_t seen = 0;
+        for (;;) {
+          {
+            std::unique_lock<std::mutex> lk(mu_);
+            wake_.wait(lk, [&] { return quit_ || (generation_ != seen && id < active_); });
+            if (quit_) return;
+            seen = generation_;
+          }
+          work();
+          std::lock_guard<std::mutex> lk(mu_);
+          if (--pending_ == 0) done_.notify_all();
+        }
+      });
+    }
+  }
+  static constexpr int kChunk = 4;
+  std::mutex call_, mu_;
+  std::condition_variable wake_, done_;
+  std::vector<std::thread> workers_;
+  const std::function<void(int)> *fn_ = nullptr;
+  std::atomic<int> next_{0};
+  int items_ = 0, active_ = 0, pending_ = 0;
+  uint64_t generation_ = 0;
+  bool quit_ = false;
+};
+Team &team() {
+  static Team t;
+  return t;
+}
+}  // namespace
 
 extern "C" {
 
@@ -142,11 +220,13 @@ int32_t xaac_parse_batch_run(const xaac_parse_batch *b) {
       !b->consumed || !b->status || (b->with_sbr && (!b->header || !b->frame || !b->flags)))
     return XAAC_PARSE_ERR_SYNTAX;
   const int n_ch = b->n_ch;
-  int ok = 0;
-  int threads = b->threads > 0 ? b->threads : omp_get_max_threads();
-  if (threads > b->n_streams) threads = b->n_streams > 0 ? b->n_streams : 1;
-#pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(+ : ok)
-  for (int i = 0; i < b->n_streams; i++) {
+  std::atomic<int> ok{0};
+  /* default: one thread per physical core as far as the machine tells (half its hardware threads), at most 64 -- beyond
+     that the staging arrays' memory traffic, not the parsing, sets the pace */
+  int hw = (int)std::thread::hardware_concurrency();
+  int threads = b->threads > 0 ? b->threads : (hw >= 4 ? (hw / 2 > 64 ? 64 : hw / 2) : (hw > 0 ? hw : 1));
+  if (threads > (b->n_streams + 3) / 4) threads = b->n_streams > 0 ? (b->n_streams + 3) / 4 : 1;
+  team().run(b->n_streams, threads, [&](int i) {
     xaac_parser *p = b->parser[i];
     size_t used = 0;
     b->consumed[i] = 0;
@@ -158,7 +238,7 @@ int32_t xaac_parse_batch_run(const xaac_parse_batch *b) {
       r = xaac_parse_sbr_side(p, b->ps_enable, side);
     }
     b->status[i] = r;
-    if (r) continue;
+    if (r) return;
     ok++;
     b->consumed[i] = used;
     if (b->tools) b->tools[i] = tools_of(p->el);
@@ -177,8 +257,8 @@ int32_t xaac_parse_batch_run(const xaac_parse_batch *b) {
       f[0] = side->apply, f[1] = side->reset, f[2] = side->reset_channels, f[3] = side->upsampling;
       f[4] = side->stereo, f[5] = side->ps, f[6] = side->ps_start, f[7] = side->frame_ok;
     }
-  }
-  return ok;
+  });
+  return ok.load();
 }
 
 void xaac_sbr_state_init(xaac_sbr_state *s) {

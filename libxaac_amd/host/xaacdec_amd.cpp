@@ -1,0 +1,412 @@
+/*
+ * xaacdec_amd.cpp -- the native command line decoder of this repo: ADTS AAC-LC / HE-AAC / HE-AACv2 in, 16-bit WAV out, as
+ * `xaacdec -esbr:0` (test/decoder/ixheaacd_main.c over decoder/ixheaacd_api.c:2624-3788) decodes it, with the repo's own
+ * host front end (include/xaac_parse.h, CPU threads) in front of the GPU entry points of include/xaac_amd.h and every
+ * stream's state resident in device memory.  No reference code, no Python, no torch: HIP runtime + the two libraries.
+ *
+ *   xaacdec_amd -ifile:<in.aac> -ofile:<out.wav> [-copies:<N>] [-verify] [-threads:<T>] [-quiet]
+ *
+ * -copies:N decodes N instances of the stream in one lock-step batch (the first one's PCM is written; with -verify all N are
+ * compared with it word for word) and prints the end-to-end rate: the shape a serving host has, with one input here for brevity.
+ * libxaac_amd/decoder.py is the same loop in Python (used by the tests for its ease of inspection).
+ */
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <mutex>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/xaac_amd.h"
+#include "../../include/xaac_parse.h"
+
+namespace {
+
+[[noreturn]] void die(const char *what, long code = 0) {
+  fprintf(stderr, "xaacdec_amd: %s failed (%ld)\n", what, code);
+  exit(2);
+}
+#define HIP(x)                         \
+  do {                                 \
+    hipError_t e_ = (x);               \
+    if (e_ != hipSuccess) die(#x, e_); \
+  } while (0)
+#define XA(x)                 \
+  do {                        \
+    int32_t e_ = (x);         \
+    if (e_ != 0) die(#x, e_); \
+  } while (0)
+
+template <class T>
+T *dev(size_t n) {
+  void *p = nullptr;
+  HIP(hipMalloc(&p, n * sizeof(T) ? n * sizeof(T) : 16));
+  HIP(hipMemset(p, 0, n * sizeof(T) ? n * sizeof(T) : 16));
+  return static_cast<T *>(p);
+}
+template <class T>
+T *pinned(size_t n) {
+  void *p = nullptr;
+  HIP(hipHostMalloc(&p, n * sizeof(T) ? n * sizeof(T) : 16, hipHostMallocDefault));
+  memset(p, 0, n * sizeof(T) ? n * sizeof(T) : 16);
+  return static_cast<T *>(p);
+}
+
+struct Staging { /* what one step's parse leaves for the GPU */
+  int32_t *spec;
+  uint8_t *ics;
+  xaac_sbr_header *header;
+  xaac_sbr_frame *frame;
+  xaac_ps_frame *ps;
+  std::vector<int32_t> flags, status;
+  std::vector<uint64_t> consumed;
+  int delivered;
+};
+
+void write_wav(const std::string &path, const std::vector<int16_t> &pcm, int channels, int rate) {
+  FILE *f = fopen(path.c_str(), "wb");
+  if (!f) die("fopen(output)");
+  const uint32_t data = (uint32_t)(pcm.size() * 2), riff = 36 + data, fmt = 16, byte_rate = (uint32_t)(rate * channels * 2);
+  const uint16_t pcm_tag = 1, ch = (uint16_t)channels, align = (uint16_t)(channels * 2), bits = 16;
+  const uint32_t sr = (uint32_t)rate;
+  fwrite("RIFF", 1, 4, f), fwrite(&riff, 4, 1, f), fwrite("WAVEfmt ", 1, 8, f), fwrite(&fmt, 4, 1, f);
+  fwrite(&pcm_tag, 2, 1, f), fwrite(&ch, 2, 1, f), fwrite(&sr, 4, 1, f), fwrite(&byte_rate, 4, 1, f);
+  fwrite(&align, 2, 1, f), fwrite(&bits, 2, 1, f), fwrite("data", 1, 4, f), fwrite(&data, 4, 1, f);
+  fwrite(pcm.data(), 2, pcm.size(), f);
+  fclose(f);
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  std::string in, out;
+  int copies = 1, threads = 0, quiet = 0, verify = 0, profile = 0;
+  for (int i = 1; i < argc; i++) {
+    const std::string a = argv[i];
+    if (a.rfind("-ifile:", 0) == 0) in = a.substr(7);
+    else if (a.rfind("-ofile:", 0) == 0) out = a.substr(7);
+    else if (a.rfind("-copies:", 0) == 0) copies = atoi(a.c_str() + 8);
+    else if (a.rfind("-threads:", 0) == 0) threads = atoi(a.c_str() + 9);
+    else if (a == "-quiet") quiet = 1;
+    else if (a == "-verify") verify = 1;
+    else if (a == "-profile") profile = 1; /* synchronise behind every phase of a step and report the seconds spent in each */
+    else if (a.rfind("-esbr:", 0) == 0 && a != "-esbr:0") die("only the -esbr:0 interpretation of the SBR payload is built");
+  }
+  if (in.empty() || out.empty() || copies < 1) {
+    fprintf(stderr, "usage: xaacdec_amd -ifile:<in.aac> -ofile:<out.wav> [-copies:N] [-threads:T] [-quiet]\n");
+    return 1;
+  }
+  std::vector<uint8_t> data;
+  {
+    FILE *f = fopen(in.c_str(), "rb");
+    if (!f) die("fopen(input)");
+    fseek(f, 0, SEEK_END);
+    const long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    data.resize((size_t)n + 16);
+    if (fread(data.data(), 1, (size_t)n, f) != (size_t)n) die("fread");
+    fclose(f);
+    data.resize((size_t)n);
+  }
+  /* a look at frame 0: channels, SBR or not (api.c:2160: payload in the first frame, or a core rate of 24 kHz and below) */
+  xaac_adts_header hdr;
+  if (xaac_adts_parse_header(data.data(), data.size(), &hdr)) die("ADTS header");
+  int n_ch, sbr;
+  {
+    xaac_parser *probe = nullptr;
+    XA(xaac_parser_create(&probe));
+    std::vector<xaac_core_frame> cf(1);
+    size_t used = 0;
+    const int32_t rc = xaac_parse_adts_frame(probe, data.data(), data.size(), 1, cf.data(), &used);
+    if (rc) die("first frame", rc);
+    n_ch = cf[0].n_ch;
+    sbr = cf[0].sbr_bytes > 0 || hdr.sampling_rate <= 24000;
+    xaac_parser_destroy(probe);
+  }
+  if (!sbr && n_ch != 2) die("mono AAC-LC without SBR is not built");
+  const int N = copies, NC = N * n_ch, rate = hdr.sampling_rate, out_rate = sbr ? 2 * rate : rate, per = sbr ? 2048 : 1024;
+
+  xaac_ctx *ctx = nullptr;
+  hipStream_t stream;
+  HIP(hipSetDevice(0));
+  HIP(hipStreamCreate(&stream));
+  XA(xaac_create(&ctx, 0, stream));
+  std::vector<xaac_parser *> parser((size_t)N);
+  for (auto &p : parser) XA(xaac_parser_create(&p));
+  std::vector<const uint8_t *> ptr((size_t)N);
+  std::vector<uint64_t> left((size_t)N), pos((size_t)N, 0);
+
+  /* device-resident state and per-step device buffers */
+  int32_t *d_overlap = dev<int32_t>((size_t)NC * 512), *d_spec = dev<int32_t>((size_t)NC * 1024);
+  xaac_ovl_state *d_ovl = dev<xaac_ovl_state>((size_t)NC);
+  xaac_ics_info *d_ics = dev<xaac_ics_info>((size_t)NC);
+  int16_t *d_pcm = dev<int16_t>((size_t)N * per * 2), *h_pcm = pinned<int16_t>((size_t)N * per * 2);
+  int32_t *d_status = dev<int32_t>((size_t)NC), *h_status = pinned<int32_t>((size_t)NC);
+  /* AAC-LC */
+  int32_t *d_out32 = nullptr;
+  int8_t *d_qadj = nullptr;
+  xaac_limiter_state *d_lim = nullptr;
+  int delay = 0;
+  /* SBR */
+  int16_t *d_core = nullptr, *d_mono = nullptr;
+  xaac_sbr_header *d_header = nullptr;
+  xaac_sbr_frame *d_frame = nullptr;
+  xaac_sbr_state *d_state = nullptr;
+  xaac_ps_frame *d_psf = nullptr;
+  xaac_ps_state *d_ps_state = nullptr;
+  int32_t *d_idx = nullptr;
+  void *d_ws = nullptr;
+  uint64_t ws_bytes = 0;
+  if (!sbr) {
+    d_out32 = dev<int32_t>((size_t)N * 2048);
+    d_qadj = dev<int8_t>((size_t)N * 2);
+    d_lim = dev<xaac_limiter_state>((size_t)N);
+    xaac_limiter_state l0;
+    delay = xaac_peak_limiter_init(&l0, 2, (uint32_t)rate);
+    if (delay < 0) die("xaac_peak_limiter_init", delay);
+    for (int i = 0; i < N; i++) HIP(hipMemcpy(d_lim + i, &l0, sizeof(l0), hipMemcpyHostToDevice));
+    ws_bytes = xaac_peak_limiter_workspace_bytes(N);
+  } else {
+    d_core = dev<int16_t>((size_t)NC * 1024);
+    d_header = dev<xaac_sbr_header>((size_t)NC);
+    d_frame = dev<xaac_sbr_frame>((size_t)NC);
+    d_state = dev<xaac_sbr_state>((size_t)NC);
+    xaac_sbr_state s0;
+    xaac_sbr_state_init(&s0);
+    for (int i = 0; i < NC; i++) HIP(hipMemcpy(d_state + i, &s0, sizeof(s0), hipMemcpyHostToDevice));
+    if (n_ch == 1) {
+      d_psf = dev<xaac_ps_frame>((size_t)N);
+      d_ps_state = dev<xaac_ps_state>((size_t)N);
+      d_mono = dev<int16_t>((size_t)N * 2048);
+      d_idx = dev<int32_t>((size_t)N);
+      xaac_ps_state p0;
+      xaac_ps_state_init(&p0);
+      for (int i = 0; i < N; i++) HIP(hipMemcpy(d_ps_state + i, &p0, sizeof(p0), hipMemcpyHostToDevice));
+      ws_bytes = xaac_sbr_hq_workspace_bytes(N, 1);
+    } else {
+      ws_bytes = xaac_sbr_lp_workspace_bytes(NC);
+    }
+  }
+  HIP(hipMalloc(&d_ws, ws_bytes ? ws_bytes : 16));
+
+  Staging st[2];
+  for (auto &s : st) {
+    s.spec = pinned<int32_t>((size_t)NC * 1024);
+    s.ics = pinned<uint8_t>((size_t)NC * 2);
+    s.header = sbr ? pinned<xaac_sbr_header>((size_t)NC) : nullptr;
+    s.frame = sbr ? pinned<xaac_sbr_frame>((size_t)NC) : nullptr;
+    s.ps = (sbr && n_ch == 1) ? pinned<xaac_ps_frame>((size_t)N) : nullptr;
+    s.flags.assign((size_t)N * 8, 0), s.status.assign((size_t)N, 0), s.consumed.assign((size_t)N, 0);
+    s.delivered = 0;
+  }
+  double parse_s = 0;
+  auto parse = [&](Staging *s) { /* the next frame of every stream into one staging set */
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < N; i++) ptr[(size_t)i] = data.data() + pos[(size_t)i], left[(size_t)i] = data.size() - pos[(size_t)i];
+    xaac_parse_batch b;
+    memset(&b, 0, sizeof(b));
+    b.n_streams = N, b.n_ch = n_ch, b.with_sbr = sbr, b.ps_enable = 1, b.stage = 2, b.threads = threads;
+    b.parser = parser.data(), b.data = ptr.data(), b.bytes = left.data();
+    b.spec = s->spec, b.ics = s->ics, b.header = s->header, b.frame = s->frame, b.ps_frame = s->ps;
+    b.flags = s->flags.data(), b.consumed = s->consumed.data(), b.status = s->status.data();
+    const int ok = xaac_parse_batch_run(&b);
+    if (ok < 0) die("xaac_parse_batch_run", ok);
+    for (int i = 0; i < N; i++) {
+      if (s->status[(size_t)i] < 0) die("a frame does not parse", s->status[(size_t)i]);
+      pos[(size_t)i] += s->consumed[(size_t)i];
+    }
+    s->delivered = ok;
+    parse_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  };
+
+  double phase_s[4] = {0, 0, 0, 0}; /* -profile: copies up, kernels, copies down, host work on the PCM */
+  auto t_phase = std::chrono::steady_clock::now();
+  auto lap = [&](int k) {
+    if (!profile) return;
+    HIP(hipStreamSynchronize(stream));
+    const auto now = std::chrono::steady_clock::now();
+    phase_s[k] += std::chrono::duration<double>(now - t_phase).count();
+    t_phase = now;
+  };
+  std::vector<int16_t> pcm; /* stream 0's output */
+  long frames = 0, mismatched = 0;
+  bool first = true;
+  const auto t_all = std::chrono::steady_clock::now();
+  auto t_first = t_all;
+  /* one helper thread for the whole run: it parses the next staging set when told to, the main thread waits for `done` */
+  std::mutex mu;
+  std::condition_variable cv;
+  int job = 0, done = -1;
+  bool quit = false;
+  std::thread worker([&] {
+    for (int expect = 0;; expect++) {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return quit || job > expect; });
+      if (quit) return;
+      lk.unlock();
+      parse(&st[expect & 1]);
+      lk.lock();
+      done = expect;
+      cv.notify_all();
+    }
+  });
+  auto start_parse = [&] {
+    std::lock_guard<std::mutex> lk(mu);
+    job++;
+    cv.notify_all();
+  };
+  auto wait_parse = [&](int step) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return done >= step; });
+  };
+  start_parse();
+  for (int step = 0;; step++) {
+    const int which = step & 1;
+    wait_parse(step);
+    Staging &s = st[which];
+    if (s.delivered == 0) break;
+    if (s.delivered != N) die("streams of different lengths in one batch");
+    start_parse(); /* the next step's frames are parsed while the GPU works on this one's */
+    t_phase = std::chrono::steady_clock::now();
+    HIP(hipMemcpyAsync(d_spec, s.spec, (size_t)NC * 4096, hipMemcpyHostToDevice, stream));
+    HIP(hipMemcpyAsync(d_ics, s.ics, (size_t)NC * 2, hipMemcpyHostToDevice, stream));
+    lap(0);
+    xaac_imdct_batch ib;
+    memset(&ib, 0, sizeof(ib));
+    ib.n_ch = NC, ib.ch_fac = n_ch, ib.spec = d_spec, ib.ics = d_ics, ib.overlap = d_overlap, ib.state = d_ovl;
+    if (!sbr) { /* AAC-LC: IMDCT -> limiter -> round16 (api.c:3662-3692) */
+      ib.out32 = d_out32, ib.qshift_adj = d_qadj;
+      XA(xaac_imdct_process_batch(ctx, &ib));
+      xaac_limiter_batch lb;
+      memset(&lb, 0, sizeof(lb));
+      lb.n_streams = N, lb.frame_len = 1024, lb.samples = d_out32, lb.stride = 2048, lb.qshift_adj = d_qadj, lb.state = d_lim;
+      lb.num_channels = 2, lb.pcm16 = d_pcm, lb.workspace = d_ws, lb.workspace_bytes = ws_bytes;
+      XA(xaac_peak_limiter_process_batch(ctx, &lb));
+    } else {
+      ib.pcm16 = d_core, ib.pcm_mode = XAAC_PCM_SBR;
+      XA(xaac_imdct_process_batch(ctx, &ib));
+      for (int i = 0; i < N; i++) { /* rare: frames that reset the SBR decoder or fall back to plain up-sampling */
+        const int32_t *f = &s.flags[(size_t)i * 8];
+        if (!f[1] && !f[3]) continue;
+        xaac_sbr_side side;
+        memset(&side, 0, sizeof(side));
+        side.reset = f[1], side.reset_channels = f[2], side.upsampling = f[3], side.header = s.header[(size_t)i * n_ch];
+        HIP(hipStreamSynchronize(stream));
+        for (int c = 0; c < n_ch; c++) {
+          xaac_sbr_state t;
+          HIP(hipMemcpy(&t, d_state + (size_t)i * n_ch + c, sizeof(t), hipMemcpyDeviceToHost));
+          xaac_sbr_state_apply_side(&t, &side, c);
+          HIP(hipMemcpy(d_state + (size_t)i * n_ch + c, &t, sizeof(t), hipMemcpyHostToDevice));
+        }
+        if (n_ch == 1) {
+          xaac_ps_state t;
+          HIP(hipMemcpy(&t, d_ps_state + i, sizeof(t), hipMemcpyDeviceToHost));
+          xaac_ps_state_apply_side(&t, &side);
+          HIP(hipMemcpy(d_ps_state + i, &t, sizeof(t), hipMemcpyHostToDevice));
+        }
+      }
+      HIP(hipMemcpyAsync(d_header, s.header, (size_t)NC * sizeof(xaac_sbr_header), hipMemcpyHostToDevice, stream));
+      HIP(hipMemcpyAsync(d_frame, s.frame, (size_t)NC * sizeof(xaac_sbr_frame), hipMemcpyHostToDevice, stream));
+      if (n_ch == 2) {
+        xaac_sbr_lp_batch b;
+        memset(&b, 0, sizeof(b));
+        b.n_ch = NC, b.in_ch_fac = 2, b.out_ch_fac = 2, b.pcm_in = d_core, b.header = d_header, b.frame = d_frame;
+        b.state = d_state, b.pcm_out = d_pcm, b.status = d_status, b.workspace = d_ws, b.workspace_bytes = ws_bytes;
+        XA(xaac_sbr_lp_process_batch(ctx, &b));
+      } else {
+        int with_ps = 0, starts = 0;
+        std::vector<int32_t> idx;
+        for (int i = 0; i < N; i++) {
+          with_ps += s.flags[(size_t)i * 8 + 5] != 0;
+          if (s.flags[(size_t)i * 8 + 6]) idx.push_back(i), starts++;
+        }
+        if (with_ps != 0 && with_ps != N) die("a batch mixing PS and non-PS frames");
+        xaac_sbr_hq_batch b;
+        memset(&b, 0, sizeof(b));
+        b.n_ch = N, b.in_ch_fac = 1, b.out_ch_fac = 1, b.pcm_in = d_core, b.header = d_header, b.frame = d_frame;
+        b.state = d_state, b.status = d_status, b.workspace = d_ws, b.workspace_bytes = ws_bytes;
+        if (with_ps) {
+          if (starts) { /* the right bank starts from the left one's filter states (sbrdecoder.c:762-775) */
+            HIP(hipMemcpyAsync(d_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, stream));
+            HIP(hipStreamSynchronize(stream));
+            xaac_sbr_handover_batch hb;
+            memset(&hb, 0, sizeof(hb));
+            hb.n = starts, hb.mode = XAAC_HANDOVER_PS_START, hb.src = d_idx, hb.dst = d_idx, hb.state = d_state, hb.ps_state = d_ps_state;
+            XA(xaac_sbr_state_handover(ctx, &hb));
+          }
+          HIP(hipMemcpyAsync(d_psf, s.ps, (size_t)N * sizeof(xaac_ps_frame), hipMemcpyHostToDevice, stream));
+          b.ps_frame = d_psf, b.ps_state = d_ps_state, b.pcm_out = d_pcm;
+        } else {
+          b.pcm_out = d_mono;
+        }
+        XA(xaac_sbr_hq_process_batch(ctx, &b));
+        lap(1);
+        if (!with_ps) HIP(hipMemcpyAsync(h_pcm, d_mono, (size_t)N * 2048 * 2, hipMemcpyDeviceToHost, stream));
+        else HIP(hipMemcpyAsync(h_pcm, d_pcm, (size_t)N * 4096 * 2, hipMemcpyDeviceToHost, stream));
+        HIP(hipMemcpyAsync(h_status, d_status, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
+        HIP(hipStreamSynchronize(stream));
+        for (int i = 0; i < N; i++)
+          if (h_status[i] < 0) die("the SBR kernels refused a frame", i);
+        if (!with_ps) { /* mono duplicated to stereo (api.c:3639-3660), from the back so that it can be done in place */
+          for (long k = (long)N * 2048 - 1; k >= 0; k--) h_pcm[2 * k] = h_pcm[2 * k + 1] = h_pcm[k];
+        }
+      }
+    }
+    if (!(sbr && n_ch == 1)) {
+      lap(1);
+      HIP(hipMemcpyAsync(h_pcm, d_pcm, (size_t)N * per * 2 * 2, hipMemcpyDeviceToHost, stream));
+      if (sbr) HIP(hipMemcpyAsync(h_status, d_status, (size_t)NC * 4, hipMemcpyDeviceToHost, stream));
+      HIP(hipStreamSynchronize(stream));
+      if (sbr)
+        for (int i = 0; i < NC; i++)
+          if (h_status[i] < 0) die("the SBR kernels refused a frame", i);
+    }
+    lap(2);
+    const size_t skip = (!sbr && first) ? (size_t)delay * 2 : 0; /* the limiter's delay is cut from the first frame */
+    pcm.insert(pcm.end(), h_pcm + skip, h_pcm + (size_t)per * 2);
+    for (int i = 1; verify && i < N; i++) mismatched += memcmp(h_pcm, h_pcm + (size_t)i * per * 2, (size_t)per * 4) != 0;
+    frames += N;
+    if (first) t_first = std::chrono::steady_clock::now(); /* the first step also loads the kernels' code objects */
+    first = false;
+    lap(3);
+  }
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    quit = true;
+    cv.notify_all();
+  }
+  worker.join();
+  const auto t_end = std::chrono::steady_clock::now();
+  const double wall = std::chrono::duration<double>(t_end - t_all).count();
+  const double steady = std::chrono::duration<double>(t_end - t_first).count();
+  if (!sbr) { /* the limiter's delay line holds the last attack_time_samples samples: api.c:2824-2866 */
+    static xaac_limiter_state l;
+    HIP(hipMemcpy(&l, d_lim, sizeof(l), hipMemcpyDeviceToHost));
+    const uint32_t att = l.attack_time_samples, at = l.delayed_input_index;
+    for (uint32_t k = 0; k < att; k++)
+      for (int c = 0; c < 2; c++) {
+        const float v = l.delayed_input[(size_t)((at + k) % att) * 2 + c];
+        const int64_t w = (v >= 2147483648.0f || v < -2147483648.0f || v != v) ? INT32_MIN : (int64_t)v; /* (WORD32)v as x86 has it */
+        int64_t r = w + 0x8000;
+        if (r > INT32_MAX) r = INT32_MAX;
+        pcm.push_back((int16_t)(r >> 16));
+      }
+  }
+  write_wav(out, pcm, 2, out_rate);
+  if (!quiet)
+    printf("{\"frames\": %ld, \"streams\": %d, \"wall_s\": %.4f, \"parse_s\": %.4f, \"frames_per_s\": %.1f, "
+           "\"frames_per_s_after_first_step\": %.1f, \"mismatched_copies\": %ld, \"samples\": %zu, \"rate\": %d, \"sbr\": %d, "
+           "\"channels\": %d}\n",
+           frames, N, wall, parse_s, frames / wall, frames > N && steady > 0 ? (frames - N) / steady : 0.0, mismatched,
+           pcm.size() / 2, out_rate, sbr, n_ch);
+  if (profile)
+    printf("{\"h2d_s\": %.4f, \"kernels_s\": %.4f, \"d2h_s\": %.4f, \"host_pcm_s\": %.4f}\n", phase_s[0], phase_s[1], phase_s[2], phase_s[3]);
+  return mismatched ? 3 : 0;
+}

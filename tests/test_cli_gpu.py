@@ -1,0 +1,54 @@
+"""libxaac_amd/xaacdec_amd, the native command line decoder (host front end + GPU back end, HIP runtime only: no Python, no
+torch, no reference code in the process), on the committed ADTS streams: its WAV payload must equal what the reference
+decoder writes (`oracle/_ref/xaacdec -esbr:0`, and the committed CRCs of that), also when it decodes a batch of copies."""
+import json
+import os
+import subprocess
+import wave
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STREAMS = os.path.join(ROOT, "tests", "golden", "streams")
+CLI = os.path.join(ROOT, "libxaac_amd", "xaacdec_amd")
+GOLD_ORDER = ["mix_aot2_64k", "mix_aot5_48k", "mono_aot5_32k", "harm_aot5_48k", "mix_aot29_32k", "synth_lc_a", "synth_lc_b",
+              "synth_lc_mono"]      # tools/make_golden_parser.py NAMES
+NAMES = GOLD_ORDER[:7]
+
+pytestmark = pytest.mark.gpu
+
+
+def run(name, tmp_path, *flags):
+    assert os.path.exists(CLI), "libxaac_amd/xaacdec_amd is not built (make -C libxaac_amd/host)"
+    out = str(tmp_path / (name + ".wav"))
+    p = subprocess.run([CLI, "-ifile:" + os.path.join(STREAMS, name + ".aac"), "-ofile:" + out, *flags], capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-500:]
+    with wave.open(out) as w:
+        assert (w.getsampwidth(), w.getnchannels()) == (2, 2)
+        return w.readframes(w.getnframes()), w.getframerate(), json.loads(p.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_wav_equals_the_reference_decoders(name, tmp_path):
+    pcm, rate, info = run(name, tmp_path)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "decoder_ref.npz"))
+    k = GOLD_ORDER.index(name)
+    assert (len(pcm) // 4, rate) == (int(gold["samples"][k]), int(gold["rate"][k]))
+    assert zlib.crc32(pcm) & 0xffffffff == int(gold["crc"][k])
+    ref = os.path.join(ROOT, "oracle", "_ref", "xaacdec")
+    if not os.path.exists(ref):
+        pytest.fail("oracle/_ref/xaacdec missing: the reference binary did not travel with the snapshot")
+    want = str(tmp_path / "ref.wav")
+    subprocess.run([ref, "-ifile:" + os.path.join(STREAMS, name + ".aac"), "-ofile:" + want, "-esbr:0"], check=True, capture_output=True)
+    with wave.open(want) as w:
+        assert w.readframes(w.getnframes()) == pcm
+
+
+@pytest.mark.parametrize("name", ["mix_aot29_32k", "mix_aot5_48k", "mix_aot2_64k"])
+def test_a_batch_of_copies(name, tmp_path):
+    one, _, _ = run(name, tmp_path)
+    many, _, info = run(name, tmp_path, "-copies:64", "-verify")
+    assert many == one and info["streams"] == 64 and info["mismatched_copies"] == 0
