@@ -252,7 +252,7 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
     lock step: per step one frame of every stream is parsed on CPU threads into pinned staging arrays, copied to the GPU
     (spectra + window info, SBR / PS side info: nothing else crosses the bus on the way in), run through the GPU entry
     points against the streams' device-resident states, and the PCM copied back.
-    -> (list of int16 [samples, 2] arrays, output sampling rate).  keep_pcm False: the PCM still comes back to the host
+    -> (list of int16 [samples, channels] arrays, output sampling rate).  keep_pcm False: the PCM still comes back to the host
     every step but is not collected (throughput measurements); timing: a dict that receives seconds per stage.
     overlap: the host parses step k + 1 (a second set of staging arrays, a helper thread: the parser calls release the GIL)
     while the GPU works on step k."""
@@ -274,6 +274,7 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
     def pinned(*shape, dtype=torch.uint8):
         return torch.zeros(*shape, dtype=dtype).pin_memory()
 
+    out_ch = 2 if sbr else n_ch     # SBR streams come out in stereo (PS, or the mono column twice); AAC-LC as coded
     ovl, ovl_state = dz(nc, 512, dtype=torch.int32), dz(nc, 2)
     spec_d, ics_d = dz(nc, 1024, dtype=torch.int32), dz(nc, 2)
     out = [[] for _ in range(n)]
@@ -297,15 +298,13 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
 
     sets = [Staging(), Staging()] if overlap else [Staging()]
     if not sbr:
-        if n_ch != 2:
-            raise NotImplementedError("mono AAC-LC without SBR")
         # AAC-LC: IMDCT -> WORD32 + qshift_adj -> peak limiter -> round16 (api.c:3662-3692)
-        out32, qadj = dz(n * 1024 * 2, dtype=torch.int32), dz(n * 2, dtype=torch.int8)
-        lim0, delay = peak_limiter_init(2, rate)
+        out32, qadj = dz(n * 1024 * n_ch, dtype=torch.int32), dz(n * n_ch, dtype=torch.int8)
+        lim0, delay = peak_limiter_init(n_ch, rate)
         lim = torch.from_numpy(np.tile(np.frombuffer(bytes(lim0), np.uint8), (n, 1)).copy()).to(dev)
         ws = dz(max(ctx.peak_limiter_workspace_bytes(n), 16))
-        pcm = dz(n * 1024 * 2, dtype=torch.int16)
-        pcm_h = pinned(n * 1024 * 2, dtype=torch.int16)
+        pcm = dz(n * 1024 * n_ch, dtype=torch.int16)
+        pcm_h = pinned(n * 1024 * n_ch, dtype=torch.int16)
     else:
         state = torch.from_numpy(np.tile(_struct_bytes(lib.xaac_sbr_state_init, SBR_STATE_BYTES), (nc, 1)).copy()).to(dev)
         core16 = dz(nc * 1024, dtype=torch.int16)
@@ -344,12 +343,12 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
         spec_d.copy_(spec_h, non_blocking=True)
         ics_d.copy_(ics_h, non_blocking=True)
         if not sbr:
-            ctx.imdct_process_batch(spec_d, ics_d, overlap_buf, ovl_state, out32=out32, qshift_adj=qadj, ch_fac=2)
-            ctx.peak_limiter_process_batch(out32, qadj, lim, 2, ws, pcm16=pcm)
+            ctx.imdct_process_batch(spec_d, ics_d, overlap_buf, ovl_state, out32=out32, qshift_adj=qadj, ch_fac=n_ch)
+            ctx.peak_limiter_process_batch(out32, qadj, lim, n_ch, ws, pcm16=pcm)
             pcm_h.copy_(pcm, non_blocking=True)
             ctx.sync()
             if keep_pcm:
-                block = pcm_h.numpy().reshape(n, 1024, 2)
+                block = pcm_h.numpy().reshape(n, 1024, n_ch)
                 for i in np.nonzero(got)[0]:
                     out[i].append(block[i, delay:].copy() if first else block[i].copy())
         else:
@@ -420,7 +419,7 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
         for i in range(n):
             st = LimiterState.from_buffer_copy(lim_h[i].tobytes())
             att, idx = st.attack_time_samples, st.delayed_input_index
-            d = np.ctypeslib.as_array(st.delayed_input)[:att * 2].reshape(att, 2)
+            d = np.ctypeslib.as_array(st.delayed_input)[:att * n_ch].reshape(att, n_ch)
             tail = np.concatenate([d[idx:], d[:idx]]).astype(np.float64)
             inside = (tail > -2147483649.0) & (tail < 2147483648.0)      # (WORD32) of a float as x86 converts it: what does
             v = np.where(inside, np.trunc(np.where(inside, tail, 0.0)), -2147483648.0).astype(np.int64)   # not fit is INT_MIN
@@ -432,4 +431,4 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
         ctx.close()
     if timing is not None:
         timing.update(parse_s=t_parse, gpu_s=t_gpu, steps_s=t_steps, frames=frames)
-    return [np.concatenate(o) if o else np.zeros((0, 2), np.int16) for o in out], rate * (2 if sbr else 1)
+    return [np.concatenate(o) if o else np.zeros((0, out_ch), np.int16) for o in out], rate * (2 if sbr else 1)

@@ -130,8 +130,8 @@ int main(int argc, char **argv) {
     sbr = cf[0].sbr_bytes > 0 || hdr.sampling_rate <= 24000;
     xaac_parser_destroy(probe);
   }
-  if (!sbr && n_ch != 2) die("mono AAC-LC without SBR is not built");
-  const int N = copies, NC = N * n_ch, rate = hdr.sampling_rate, out_rate = sbr ? 2 * rate : rate, per = sbr ? 2048 : 1024;
+  const int out_ch = sbr ? 2 : n_ch; /* SBR streams come out in stereo (PS, or the mono column twice); AAC-LC as coded */
+  const int N = copies, NC = N * n_ch, NCD = NC, rate = hdr.sampling_rate, out_rate = sbr ? 2 * rate : rate, per = sbr ? 2048 : 1024;
 
   xaac_ctx *ctx = nullptr;
   hipStream_t stream;
@@ -144,10 +144,10 @@ int main(int argc, char **argv) {
   std::vector<uint64_t> left((size_t)N), pos((size_t)N, 0);
 
   /* device-resident state and per-step device buffers */
-  int32_t *d_overlap = dev<int32_t>((size_t)NC * 512), *d_spec = dev<int32_t>((size_t)NC * 1024);
-  xaac_ovl_state *d_ovl = dev<xaac_ovl_state>((size_t)NC);
-  xaac_ics_info *d_ics = dev<xaac_ics_info>((size_t)NC);
-  int16_t *d_pcm = dev<int16_t>((size_t)N * per * 2), *h_pcm = pinned<int16_t>((size_t)N * per * 2);
+  int32_t *d_overlap = dev<int32_t>((size_t)NCD * 512), *d_spec = dev<int32_t>((size_t)NCD * 1024);
+  xaac_ovl_state *d_ovl = dev<xaac_ovl_state>((size_t)NCD);
+  xaac_ics_info *d_ics = dev<xaac_ics_info>((size_t)NCD);
+  int16_t *d_pcm = dev<int16_t>((size_t)N * per * out_ch), *h_pcm = pinned<int16_t>((size_t)N * per * 2);
   int32_t *d_status = dev<int32_t>((size_t)NC), *h_status = pinned<int32_t>((size_t)NC);
   /* AAC-LC */
   int32_t *d_out32 = nullptr;
@@ -165,11 +165,11 @@ int main(int argc, char **argv) {
   void *d_ws = nullptr;
   uint64_t ws_bytes = 0;
   if (!sbr) {
-    d_out32 = dev<int32_t>((size_t)N * 2048);
-    d_qadj = dev<int8_t>((size_t)N * 2);
+    d_out32 = dev<int32_t>((size_t)N * 1024 * n_ch);
+    d_qadj = dev<int8_t>((size_t)N * n_ch);
     d_lim = dev<xaac_limiter_state>((size_t)N);
     xaac_limiter_state l0;
-    delay = xaac_peak_limiter_init(&l0, 2, (uint32_t)rate);
+    delay = xaac_peak_limiter_init(&l0, (uint32_t)n_ch, (uint32_t)rate);
     if (delay < 0) die("xaac_peak_limiter_init", delay);
     for (int i = 0; i < N; i++) HIP(hipMemcpy(d_lim + i, &l0, sizeof(l0), hipMemcpyHostToDevice));
     ws_bytes = xaac_peak_limiter_workspace_bytes(N);
@@ -280,14 +280,14 @@ int main(int argc, char **argv) {
     lap(0);
     xaac_imdct_batch ib;
     memset(&ib, 0, sizeof(ib));
-    ib.n_ch = NC, ib.ch_fac = n_ch, ib.spec = d_spec, ib.ics = d_ics, ib.overlap = d_overlap, ib.state = d_ovl;
+    ib.n_ch = NCD, ib.ch_fac = n_ch, ib.spec = d_spec, ib.ics = d_ics, ib.overlap = d_overlap, ib.state = d_ovl;
     if (!sbr) { /* AAC-LC: IMDCT -> limiter -> round16 (api.c:3662-3692) */
       ib.out32 = d_out32, ib.qshift_adj = d_qadj;
       XA(xaac_imdct_process_batch(ctx, &ib));
       xaac_limiter_batch lb;
       memset(&lb, 0, sizeof(lb));
-      lb.n_streams = N, lb.frame_len = 1024, lb.samples = d_out32, lb.stride = 2048, lb.qshift_adj = d_qadj, lb.state = d_lim;
-      lb.num_channels = 2, lb.pcm16 = d_pcm, lb.workspace = d_ws, lb.workspace_bytes = ws_bytes;
+      lb.n_streams = N, lb.frame_len = 1024, lb.samples = d_out32, lb.stride = 1024 * n_ch, lb.qshift_adj = d_qadj, lb.state = d_lim;
+      lb.num_channels = n_ch, lb.pcm16 = d_pcm, lb.workspace = d_ws, lb.workspace_bytes = ws_bytes;
       XA(xaac_peak_limiter_process_batch(ctx, &lb));
     } else {
       ib.pcm16 = d_core, ib.pcm_mode = XAAC_PCM_SBR;
@@ -361,7 +361,7 @@ int main(int argc, char **argv) {
     }
     if (!(sbr && n_ch == 1)) {
       lap(1);
-      HIP(hipMemcpyAsync(h_pcm, d_pcm, (size_t)N * per * 2 * 2, hipMemcpyDeviceToHost, stream));
+      HIP(hipMemcpyAsync(h_pcm, d_pcm, (size_t)N * per * out_ch * 2, hipMemcpyDeviceToHost, stream));
       if (sbr) HIP(hipMemcpyAsync(h_status, d_status, (size_t)NC * 4, hipMemcpyDeviceToHost, stream));
       HIP(hipStreamSynchronize(stream));
       if (sbr)
@@ -369,9 +369,10 @@ int main(int argc, char **argv) {
           if (h_status[i] < 0) die("the SBR kernels refused a frame", i);
     }
     lap(2);
-    const size_t skip = (!sbr && first) ? (size_t)delay * 2 : 0; /* the limiter's delay is cut from the first frame */
-    pcm.insert(pcm.end(), h_pcm + skip, h_pcm + (size_t)per * 2);
-    for (int i = 1; verify && i < N; i++) mismatched += memcmp(h_pcm, h_pcm + (size_t)i * per * 2, (size_t)per * 4) != 0;
+    const size_t skip = (!sbr && first) ? (size_t)delay * out_ch : 0; /* the limiter's delay is cut from the first frame */
+    pcm.insert(pcm.end(), h_pcm + skip, h_pcm + (size_t)per * out_ch);
+    for (int i = 1; verify && i < N; i++)
+      mismatched += memcmp(h_pcm, h_pcm + (size_t)i * per * out_ch, (size_t)per * out_ch * 2) != 0;
     frames += N;
     if (first) t_first = std::chrono::steady_clock::now(); /* the first step also loads the kernels' code objects */
     first = false;
@@ -391,21 +392,21 @@ int main(int argc, char **argv) {
     HIP(hipMemcpy(&l, d_lim, sizeof(l), hipMemcpyDeviceToHost));
     const uint32_t att = l.attack_time_samples, at = l.delayed_input_index;
     for (uint32_t k = 0; k < att; k++)
-      for (int c = 0; c < 2; c++) {
-        const float v = l.delayed_input[(size_t)((at + k) % att) * 2 + c];
+      for (int c = 0; c < n_ch; c++) {
+        const float v = l.delayed_input[(size_t)((at + k) % att) * n_ch + c];
         const int64_t w = (v >= 2147483648.0f || v < -2147483648.0f || v != v) ? INT32_MIN : (int64_t)v; /* (WORD32)v as x86 has it */
         int64_t r = w + 0x8000;
         if (r > INT32_MAX) r = INT32_MAX;
         pcm.push_back((int16_t)(r >> 16));
       }
   }
-  write_wav(out, pcm, 2, out_rate);
+  write_wav(out, pcm, out_ch, out_rate);
   if (!quiet)
     printf("{\"frames\": %ld, \"streams\": %d, \"wall_s\": %.4f, \"parse_s\": %.4f, \"frames_per_s\": %.1f, "
            "\"frames_per_s_after_first_step\": %.1f, \"mismatched_copies\": %ld, \"samples\": %zu, \"rate\": %d, \"sbr\": %d, "
            "\"channels\": %d}\n",
            frames, N, wall, parse_s, frames / wall, frames > N && steady > 0 ? (frames - N) / steady : 0.0, mismatched,
-           pcm.size() / 2, out_rate, sbr, n_ch);
+           pcm.size() / out_ch, out_rate, sbr, n_ch);
   if (profile)
     printf("{\"h2d_s\": %.4f, \"kernels_s\": %.4f, \"d2h_s\": %.4f, \"host_pcm_s\": %.4f}\n", phase_s[0], phase_s[1], phase_s[2], phase_s[3]);
   return mismatched ? 3 : 0;

@@ -13,7 +13,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STREAMS = os.path.join(ROOT, "tests", "golden", "streams")
 XAACDEC = os.path.join(ROOT, "oracle", "_ref", "xaacdec")
-NAMES = ["mix_aot2_64k", "mix_aot5_48k", "mono_aot5_32k", "harm_aot5_48k", "mix_aot29_32k", "synth_lc_a", "synth_lc_b"]
+NAMES = ["mix_aot2_64k", "mix_aot5_48k", "mono_aot5_32k", "harm_aot5_48k", "mix_aot29_32k", "synth_lc_a", "synth_lc_b", "synth_lc_mono"]
 GOLD_ORDER = ["mix_aot2_64k", "mix_aot5_48k", "mono_aot5_32k", "harm_aot5_48k", "mix_aot29_32k", "synth_lc_a", "synth_lc_b",
               "synth_lc_mono"]      # tools/make_golden_parser.py NAMES
 
