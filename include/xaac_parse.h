@@ -99,6 +99,10 @@ int32_t xaac_parse_adts_frame(xaac_parser *p, const uint8_t *data, size_t n, int
    XAAC_PARSE_OK, or XAAC_PARSE_ERR_SYNTAX where the reference returns a fatal error from ixheaacd_applysbr. */
 int32_t xaac_parse_sbr_side(xaac_parser *p, int32_t ps_enable, xaac_sbr_side *side);
 
+/* The inverse quantiser of spectral magnitudes, |q|^(4/3) in Q13, exactly as the reference computes it (table up to 128, its
+   linear interpolation beyond, decoder/ixheaacd_channel.c:1055-1093; _ERR_ESCAPE past 8191 + 32).  Exposed for tests. */
+int32_t xaac_inverse_quant(int32_t magnitude, int32_t *out);
+
 /* ---- one frame of N streams at once ----------------------------------------------------------------------------------
  * What a batched host runs per step: every stream's next ADTS frame parsed (core, and SBR / PS side info when with_sbr)
  * on a team of CPU threads, the results written straight into the host staging arrays -- pinned, in the layouts the GPU

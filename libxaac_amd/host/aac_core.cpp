@@ -74,7 +74,10 @@ inline int32_t pow43(int32_t q, int *err) {
   const int shift = q < 1024 ? 3 : 6;
   const int32_t q1 = q >> shift;
   const int16_t interp = (int16_t)(q - (q1 << shift));
-  int32_t t = (xh_pow43_q13[q1 + 1] - xh_pow43_q13[q1]) * (int32_t)interp;
+  /* magnitudes 8192 .. 8223 make q1 + 1 = 129: the reference reads the word behind its 129-entry table, which is the first
+     scale-factor gain of the same ROM struct (ixheaacd_aac_rom.h:26-27) */
+  const int32_t upper = q1 + 1 <= 128 ? xh_pow43_q13[q1 + 1] : xh_scale_tab[0];
+  int32_t t = (upper - xh_pow43_q13[q1]) * (int32_t)interp;
   t = fx_add(t, fx_shlw(xh_pow43_q13[q1], shift));
   return fx_shlw(t, shift == 3 ? 1 : 2);
 }
@@ -702,6 +705,8 @@ int skip_pce(XhBits *br) { /* program_config_element: read over it (ISO/IEC 1449
 }
 
 }  // namespace
+
+int32_t xh_inverse_quant(int32_t magnitude, int *err) { return pow43(magnitude, err); }
 
 int xh_core_init(XhCoreState *st, int sr_index) {
   static const bool books_built = (build_books(), true); /* once, also when the first callers are parser threads */

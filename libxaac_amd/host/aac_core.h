@@ -88,6 +88,10 @@ struct XhElement {
   uint8_t sbr[272];
 };
 
+/* |q|^(4/3) in Q13 of a quantised magnitude as the reference computes it (table, then its interpolation: channel.c:1055);
+   *err is set beyond 8191 + 32 */
+int32_t xh_inverse_quant(int32_t magnitude, int *err);
+
 /* sr_index 0 .. 11; returns 0 or XH_ERR_UNSUPPORTED */
 int xh_core_init(XhCoreState *st, int sr_index);
 

@@ -215,6 +215,13 @@ int32_t xaac_parse_sbr_side(xaac_parser *p, int32_t ps_enable, xaac_sbr_side *si
   return XAAC_PARSE_OK;
 }
 
+int32_t xaac_inverse_quant(int32_t magnitude, int32_t *out) {
+  int err = 0;
+  if (magnitude < 0 || !out) return XAAC_PARSE_ERR_SYNTAX;
+  *out = xh_inverse_quant(magnitude, &err);
+  return err ? XAAC_PARSE_ERR_ESCAPE : XAAC_PARSE_OK;
+}
+
 int32_t xaac_parse_batch_run(const xaac_parse_batch *b) {
   if (!b || b->n_streams < 0 || (b->n_ch != 1 && b->n_ch != 2) || !b->parser || !b->data || !b->bytes || !b->spec || !b->ics ||
       !b->consumed || !b->status || (b->with_sbr && (!b->header || !b->frame || !b->flags)))

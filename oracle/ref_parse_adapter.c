@@ -68,6 +68,15 @@ void ref_aac_huff_probe(int cb, unsigned word, int *index, int *len) {
   *len = l;
 }
 
+/* the reference's inverse quantiser of escape magnitudes (decoder/ixheaacd_channel.c:1055); returns its error code */
+WORD32 ixheaacd_inv_quant(WORD32 *px_quant, WORD32 *ixheaacd_pow_table_Q13);
+int ref_inv_quant(int q, int *out) {
+  WORD32 v = q;
+  const int rc = ixheaacd_inv_quant(&v, (WORD32 *)ixheaacd_aac_block_tables.ixheaacd_pow_table_Q13);
+  *out = v;
+  return rc;
+}
+
 /* ---- SBR / PS side info ROM (decoder/ixheaacd_sbr_rom.h:118-240, ixheaacd_common_rom.h:30) ---------------------------- */
 #include "ixheaac_constants.h"
 #include "ixheaacd_sbr_common.h"

@@ -1,0 +1,84 @@
+/*
+ * tests/fuzz/fuzz_parser.cpp -- TEST INFRASTRUCTURE: the host front end (libxaac_amd/host/*.cpp, compiled into this binary
+ * with -fsanitize=address,undefined by tests/test_parser_sanitized.py) fed damaged ADTS streams: bit flips anywhere, bit
+ * flips inside the SBR payload only (the core stays decodable, so the SBR / PS reader sees the damage), random payloads,
+ * truncations, runs of ones / zeros, frames spliced from two places.  Any out-of-bounds access, signed overflow outside
+ * -fwrapv, misaligned access or leak ends the process with a report; the test requires a clean exit.
+ *   fuzz_parser <stream.aac> <seed> <rounds>
+ */
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/xaac_parse.h"
+
+static uint64_t g_state;
+static uint32_t rnd(uint32_t n) { /* splitmix64 */
+  uint64_t z = (g_state += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return (uint32_t)((z ^ (z >> 31)) % n);
+}
+
+int main(int argc, char **argv) {
+  if (argc < 4) return 2;
+  FILE *f = fopen(argv[1], "rb");
+  if (!f) return 2;
+  std::vector<uint8_t> data(1 << 20);
+  data.resize(fread(data.data(), 1, data.size(), f));
+  fclose(f);
+  g_state = strtoull(argv[2], nullptr, 10);
+  const int rounds = atoi(argv[3]);
+  std::vector<std::vector<uint8_t>> frames;
+  for (size_t pos = 0; pos + 7 < data.size();) {
+    xaac_adts_header h;
+    if (xaac_adts_parse_header(data.data() + pos, data.size() - pos, &h) || pos + (size_t)h.frame_bytes > data.size()) break;
+    frames.emplace_back(data.begin() + (long)pos, data.begin() + (long)pos + h.frame_bytes);
+    pos += (size_t)h.frame_bytes;
+  }
+  if (frames.size() < 4) return 2;
+  long ok = 0, bad = 0, sbr_ok = 0, sbr_bad = 0;
+  static xaac_core_frame core;
+  static xaac_sbr_side side;
+  for (int r = 0; r < rounds; r++) {
+    xaac_parser *p = nullptr;
+    if (xaac_parser_create(&p)) return 2;
+    const int kind = r % 6;
+    for (size_t k = 0; k < frames.size() && k < 24; k++) {
+      std::vector<uint8_t> b = frames[k];
+      const size_t n = b.size();
+      if (kind == 0) {
+        for (uint32_t j = rnd(6) + 1; j; j--) b[7 + rnd((uint32_t)n - 7)] ^= (uint8_t)(1u << rnd(8));
+      } else if (kind == 1) { /* damage behind the core data only: the tail of the frame is where the fill elements sit */
+        const size_t from = n - 1 - rnd((uint32_t)(n / 3));
+        for (uint32_t j = rnd(8) + 1; j; j--) b[from + rnd((uint32_t)(n - from))] ^= (uint8_t)(1u << rnd(8));
+      } else if (kind == 2) {
+        for (size_t j = 7; j < n; j++) b[j] = (uint8_t)rnd(256);
+      } else if (kind == 3) {
+        b.resize(8 + rnd((uint32_t)n - 8));
+      } else if (kind == 4) {
+        const size_t at = 7 + rnd((uint32_t)n - 8);
+        for (size_t j = at; j < n && j < at + 48; j++) b[j] = (r & 8) ? 0xff : 0;
+      } else { /* the head of this frame, the tail of another */
+        const std::vector<uint8_t> &o = frames[rnd((uint32_t)frames.size())];
+        const size_t cut = 7 + rnd((uint32_t)n - 7);
+        for (size_t j = cut; j < n; j++) b[j] = o[j % o.size()];
+      }
+      size_t used = 0;
+      const int32_t rc = xaac_parse_adts_frame(p, b.data(), b.size(), 2, &core, &used);
+      if (rc == 0) {
+        ok++;
+        const int32_t rs = xaac_parse_sbr_side(p, 1, &side);
+        if (rs == 0) sbr_ok++;
+        else sbr_bad++;
+      } else {
+        bad++;
+      }
+    }
+    xaac_parser_destroy(p);
+  }
+  printf("frames parsed %ld, refused %ld; SBR side info decoded %ld, refused %ld\n", ok, bad, sbr_ok, sbr_bad);
+  return 0;
+}

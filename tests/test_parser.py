@@ -168,3 +168,22 @@ def test_damaged_frames_come_back_as_error_codes(name):
     codes = dict(eval(r.stdout.strip().splitlines()[-1]))
     assert all(k in (0, 1, -1, -2, -3, -4, 100, 98) for k in codes), codes     # 98 = 100 + XAAC_PARSE_ERR_SYNTAX
     assert sum(v for k, v in codes.items() if k < 0) > 50, codes                # the damage is noticed, mostly
+
+
+def test_inverse_quantiser_equals_the_references_for_every_magnitude():
+    """table entries, both interpolation ranges, the magnitudes 8192 .. 8223 whose interpolation reads one word past the
+    reference's table (into the next member of its ROM struct), and the error beyond"""
+    harness = os.path.join(ROOT, "oracle", "_ref", "libref_harness.so")
+    if not os.path.exists(harness):
+        pytest.skip("oracle/_ref/libref_harness.so missing (built where /root/reference exists)")
+    ref, lib = ctypes.CDLL(harness), decoder.load_host_library()
+    a, b = ctypes.c_int(), ctypes.c_int32()
+    for q in range(129, 8300):
+        rc_ref = ref.ref_inv_quant(q, ctypes.byref(a))
+        rc = lib.xaac_inverse_quant(q, ctypes.byref(b))
+        assert (rc != 0) == (rc_ref != 0), q
+        if rc == 0:
+            assert a.value == b.value, q
+    for q in range(0, 129):       # the table itself
+        assert lib.xaac_inverse_quant(q, ctypes.byref(b)) == 0
+        assert abs(b.value - round(q ** (4.0 / 3.0) * 8192)) <= 1, q

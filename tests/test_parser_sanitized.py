@@ -1,0 +1,29 @@
+"""The host front end under AddressSanitizer + UndefinedBehaviorSanitizer on damaged streams: tests/fuzz/fuzz_parser.cpp is
+compiled together with libxaac_amd/host/*.cpp (-fsanitize=address,undefined -fno-sanitize-recover) and run over the committed
+streams with several kinds of damage.  The parser is the one component that reads untrusted bytes; a memory error here would
+be a memory error in a serving host.  CPU only."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "libxaac_amd", "host")
+
+
+@pytest.fixture(scope="module")
+def fuzzer(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("fuzz") / "fuzz_parser")
+    srcs = [os.path.join(ROOT, "tests", "fuzz", "fuzz_parser.cpp")] + [os.path.join(HOST, f) for f in ("xaac_parse.cpp", "aac_core.cpp", "sbr_side.cpp")]
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fwrapv", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-fno-omit-frame-pointer", *srcs, "-o", exe, "-lpthread"])
+    return exe
+
+
+@pytest.mark.parametrize("name", ["mix_aot2_64k", "mix_aot5_48k", "mono_aot5_32k", "mix_aot29_32k", "synth_lc_a"])
+def test_damaged_streams_are_memory_safe(fuzzer, name):
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    p = subprocess.run([fuzzer, os.path.join(ROOT, "tests", "golden", "streams", name + ".aac"), "4242", "240"], capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert p.returncode == 0, (p.stdout[-300:], p.stderr[-3000:])
+    assert "frames parsed" in p.stdout
