@@ -291,12 +291,31 @@ def secondary_end_to_end(copies=4096):
                 j = json.loads(r.stdout.strip().splitlines()[-1])
                 native = {"frames_per_s_after_first_step": j["frames_per_s_after_first_step"], "frames_per_s_whole_run": j["frames_per_s"],
                           "wall_s": j["wall_s"]}
+    # the reference decoder itself on this machine's cores, end to end on the same stream (repeated into a longer file so
+    # that process start-up does not count): P processes of oracle/_ref/xaacdec -esbr:0 side by side
+    ref_cpu = None
+    xaacdec = os.path.join(ROOT, "oracle", "_ref", "xaacdec")
+    if os.path.exists(xaacdec):
+        import subprocess
+        import tempfile
+        procs, reps = min(os.cpu_count() or 1, 128), 60
+        with tempfile.TemporaryDirectory() as tmp:
+            long_aac = os.path.join(tmp, "long.aac")
+            open(long_aac, "wb").write(data * reps)
+            t0 = time.perf_counter()
+            ps = [subprocess.Popen([xaacdec, "-ifile:" + long_aac, "-ofile:" + os.path.join(tmp, "o%d.wav" % i), "-esbr:0"],
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for i in range(procs)]
+            ok = all(p.wait() == 0 for p in ps)
+            dt = time.perf_counter() - t0
+        if ok:
+            ref_cpu = {"value": round(procs * reps * 38 / dt, 1), "unit": "frames/s", "processes": procs, "kind": "reference",
+                       "sample": "%d processes of oracle/_ref/xaacdec -esbr:0, each on the stream repeated %d times (%d frames)" % (procs, reps, reps * 38)}
     return {"metric": "HE-AACv2 ADTS streams decoded end to end (own host parser + GPU, PCIe inclusive)",
             "value": round(best["frames"] / best["steps_s"], 1), "unit": "frames/s", "streams": copies, "frames": best["frames"],
             "parse_s": round(best["parse_s"], 4), "gpu_and_copies_s": round(best["gpu_s"], 4), "wall_s": round(best["steps_s"], 4),
             "parser_only_frames_per_s": round(parser, 1), "host_threads": os.cpu_count(),
             "pcm_equals_reference_decoder": exact, "stream": name + ".aac", "output_rate_hz": rate,
-            "native_cli": native}
+            "native_cli": native, "reference_decoder_on_host_cores": ref_cpu}
 
 
 def secondary_esbr(torch, libxaac_amd, ctx, dev, steps, warmup):
