@@ -17,6 +17,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "xaac_esbr.h"
 #include "xaac_sbr.h"
 
 #ifdef __cplusplus
@@ -99,6 +100,15 @@ int32_t xaac_parse_adts_frame(xaac_parser *p, const uint8_t *data, size_t n, int
    XAAC_PARSE_OK, or XAAC_PARSE_ERR_SYNTAX where the reference returns a fatal error from ixheaacd_applysbr. */
 int32_t xaac_parse_sbr_side(xaac_parser *p, int32_t ps_enable, xaac_sbr_side *side);
 
+/* The reference's default interpretation of the SBR payload (-esbr:1, "Path A": decoder/ixheaacd_sbrdecoder.c:479-493 the
+   payload runs one frame late; the ENHSBR extension element with patching mode / pitch, env_extr.c:595-714; scale factors
+   and noise floors handed to the float tools, env_dec.c:52-72, :586-626) instead of the -esbr:0 one.  To be chosen before
+   the stream's first xaac_parse_sbr_side call; esbr 0 / 1. */
+int32_t xaac_parser_set_esbr(xaac_parser *p, int32_t esbr);
+/* ... and for such a stream, after xaac_parse_sbr_side: the xaac_esbr_side of channel 0 / 1 of the frame (what
+   xaac_esbr_sbr_process_batch takes beside header and frame) */
+int32_t xaac_parse_esbr_side(xaac_parser *p, int32_t channel, xaac_esbr_side *side);
+
 /* The inverse quantiser of spectral magnitudes, |q|^(4/3) in Q13, exactly as the reference computes it (table up to 128, its
    linear interpolation beyond, decoder/ixheaacd_channel.c:1055-1093; _ERR_ESCAPE past 8191 + 32).  Exposed for tests. */
 int32_t xaac_inverse_quant(int32_t magnitude, int32_t *out);
@@ -127,6 +137,7 @@ typedef struct xaac_parse_batch {
   int32_t *tools;             /* optional [n_streams] */
   uint64_t *consumed;         /* [n_streams] frame length (0 where status != 0) */
   int32_t *status;            /* [n_streams] XAAC_PARSE_OK / _NEED_DATA / error: such a stream's rows are left as they were */
+  xaac_esbr_side *esbr_side;  /* with_sbr, parsers in xaac_parser_set_esbr(1) mode, optional: [n_streams][n_ch] */
 } xaac_parse_batch;
 
 /* returns the number of streams whose status is XAAC_PARSE_OK, or a negative XAAC_PARSE_ERR_* for a bad descriptor */
@@ -140,6 +151,17 @@ int32_t xaac_parse_batch_run(const xaac_parse_batch *b);
 void xaac_sbr_state_init(xaac_sbr_state *s);
 /* ... and the parametric stereo tool with the right channel's bank: :1050-1059 */
 void xaac_ps_state_init(xaac_ps_state *s);
+/* the Path A (-esbr:1) states of a new stream: zeros but esbr_start_up = 1 (sbrdec_initfuncs.c:1018) and the PS mixing
+   matrix's h11 / h12 real parts = 1.0 (ps_dec_flt.c:349-352); the transposer's parameters are zero until the first reset */
+void xaac_esbr_state_init(xaac_esbr_state *s);
+void xaac_esbr_ps_state_init(xaac_esbr_ps_state *s);
+void xaac_hbe_state_init(xaac_hbe_state *s);
+/* ixheaacd_qmf_hbe_data_reinit (decoder/ixheaacd_hbe_trans.c:102-222) as ixheaacd_sbr_dec_reset calls it for a 2:1 stream
+   with 1024-line core frames: the bank size, first band, band range and cross-over bands of the QMF transposer from the
+   header's band tables; clears the two banks' delay lines.  Returns 0, or -1 where the reference returns an error.
+   (The reset's two transposer runs over the rows the channel holds, sbrdecoder.c:196-236, are the caller's:
+   xaac_hbe_apply_batch on the device-resident state.) */
+int32_t xaac_hbe_state_reinit(xaac_hbe_state *s, const xaac_sbr_header *header);
 /* what ixheaacd_sbr_dec_reset (sbrdecoder.c:103-252) and ixheaacd_prepare_upsamp (:254-276) do to one channel's state
    for this frame's side info; channel = 0 or 1 (no-op beyond side->reset_channels / for frames without either) */
 void xaac_sbr_state_apply_side(xaac_sbr_state *s, const xaac_sbr_side *side, int32_t channel);

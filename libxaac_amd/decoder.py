@@ -14,8 +14,9 @@ import os
 
 import numpy as np
 
-from . import (LIMITER_STATE_BYTES, PCM_LC, PCM_SBR, PS_FRAME_BYTES, PS_STATE_BYTES, SBR_FRAME_BYTES, SBR_HEADER_BYTES,
-               SBR_STATE_BYTES, LimiterState, XaacContext, peak_limiter_init)
+from . import (ESBR_PS_STATE_BYTES, ESBR_SIDE_BYTES, ESBR_STATE_BYTES, HBE_STATE_BYTES, LIMITER_STATE_BYTES, PCM_LC, PCM_SBR,
+               PS_FRAME_BYTES, PS_STATE_BYTES, SBR_FRAME_BYTES, SBR_HEADER_BYTES, SBR_STATE_BYTES, LimiterState, XaacContext,
+               peak_limiter_init)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _host = None
@@ -64,9 +65,13 @@ def load_host_library():
         lib.xaac_parse_adts_frame.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32,
                                               ctypes.POINTER(CoreFrame), ctypes.POINTER(ctypes.c_size_t)]
         lib.xaac_parse_sbr_side.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(SbrSide)]
-        for fn in ("xaac_sbr_state_init", "xaac_ps_state_init"):
+        for fn in ("xaac_sbr_state_init", "xaac_ps_state_init", "xaac_esbr_state_init", "xaac_esbr_ps_state_init",
+                   "xaac_hbe_state_init"):
             getattr(lib, fn).argtypes = [ctypes.c_void_p]
             getattr(lib, fn).restype = None
+        lib.xaac_parser_set_esbr.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+        lib.xaac_parse_esbr_side.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+        lib.xaac_hbe_state_reinit.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.xaac_sbr_state_apply_side.argtypes = [ctypes.c_void_p, ctypes.POINTER(SbrSide), ctypes.c_int32]
         lib.xaac_sbr_state_apply_side.restype = None
         lib.xaac_ps_state_apply_side.argtypes = [ctypes.c_void_p, ctypes.POINTER(SbrSide)]
@@ -86,15 +91,19 @@ class StreamParser:
     while it initialises -- ixheaacd_dec_init, api.c:2097 -- and again as the first output frame; every state is set up
     afresh in between, api.c:2141-2170, so nothing of the first pass shows and one pass is all that is needed here.)"""
 
-    def __init__(self, data, with_sbr=None, stage=2):
+    def __init__(self, data, with_sbr=None, stage=2, esbr=False):
         self.lib = load_host_library()
+        self.esbr = bool(esbr)     # the reference's default -esbr:1 reading of the SBR payload (xaac_parser_set_esbr)
         self.data = bytes(data)
         self.buf = (ctypes.c_uint8 * len(self.data)).from_buffer_copy(self.data)
         self.h = ctypes.c_void_p()
         if self.lib.xaac_parser_create(ctypes.byref(self.h)):
             raise RuntimeError("xaac_parser_create failed")
+        if self.esbr and self.lib.xaac_parser_set_esbr(self.h, 1):
+            raise RuntimeError("xaac_parser_set_esbr failed")
         self.pos, self.frame_no, self.stage = 0, 0, stage
         self.core, self.side, self.used = CoreFrame(), SbrSide(), ctypes.c_size_t()
+        self.esbr_side = [(ctypes.c_uint8 * ESBR_SIDE_BYTES)(), (ctypes.c_uint8 * ESBR_SIDE_BYTES)()]
         hdr = AdtsHeader()
         rc = self.lib.xaac_adts_parse_header(self.buf, len(self.data), ctypes.byref(hdr))
         if rc:
@@ -137,13 +146,18 @@ class StreamParser:
             rc = self.lib.xaac_parse_sbr_side(self.h, 1, ctypes.byref(self.side))
             if rc:
                 raise ParseError(rc, self.frame_no)
+            if self.esbr:
+                for c in range(self.core.n_ch):
+                    if self.lib.xaac_parse_esbr_side(self.h, c, self.esbr_side[c]):
+                        raise ParseError(-2, self.frame_no)
         self.frame_no += 1
         return True
 
 
-def parse_stream(data, stage=2):
-    """the CPU half alone: [(spec int32[n_ch, 1024], ics int16[n_ch, 4], tools, side or None)] of every frame"""
-    p = StreamParser(data, stage=stage)
+def parse_stream(data, stage=2, esbr=False):
+    """the CPU half alone: [(spec int32[n_ch, 1024], ics int16[n_ch, 4], tools, side or None)] of every frame; esbr: the
+    -esbr:1 reading of the SBR payload, and a fifth member [xaac_esbr_side bytes per channel]"""
+    p = StreamParser(data, stage=stage, esbr=esbr)
     out = []
     while p.next():
         n = p.core.n_ch
@@ -153,7 +167,10 @@ def parse_stream(data, stage=2):
         if p.sbr:
             side = SbrSide()
             ctypes.memmove(ctypes.byref(side), ctypes.byref(p.side), ctypes.sizeof(SbrSide))
-        out.append((spec, ics, int(p.core.tools), side))
+        if esbr:
+            out.append((spec, ics, int(p.core.tools), side, [bytes(p.esbr_side[c]) for c in range(n)] if p.sbr else None))
+        else:
+            out.append((spec, ics, int(p.core.tools), side))
     p.close()
     return out
 
@@ -162,7 +179,7 @@ class _ParseBatch(ctypes.Structure):
     # struct xaac_parse_batch
     _fields_ = [(n, ctypes.c_int32) for n in ("n_streams", "n_ch", "with_sbr", "ps_enable", "stage", "threads")] + \
                [(n, ctypes.c_void_p) for n in ("parser", "data", "bytes", "spec", "ics", "header", "frame", "ps_frame", "flags",
-                                               "tools", "consumed", "status")]
+                                               "tools", "consumed", "status", "esbr_side")]
 
 
 F_APPLY, F_RESET, F_RESET_CHANNELS, F_UPSAMPLING, F_STEREO, F_PS, F_PS_START, F_FRAME_OK = range(8)
@@ -172,9 +189,10 @@ class BatchParser:
     """N ADTS streams of one kind through the host front end in lock step: xaac_parse_batch_run parses one frame of every
     stream on a team of CPU threads, straight into the (pinned) staging arrays handed to step()."""
 
-    def __init__(self, streams, threads=0, stage=2):
+    def __init__(self, streams, threads=0, stage=2, esbr=False):
         self.lib = load_host_library()
         self.lib.xaac_parse_batch_run.argtypes = [ctypes.c_void_p]
+        self.esbr = bool(esbr)
         self.n = n = len(streams)
         self.length = np.array([len(d) for d in streams], np.uint64)
         self.start = np.concatenate([[0], np.cumsum(self.length)[:-1]]).astype(np.uint64)
@@ -186,6 +204,8 @@ class BatchParser:
             h = ctypes.c_void_p()
             if self.lib.xaac_parser_create(ctypes.byref(h)):
                 raise RuntimeError("xaac_parser_create failed")
+            if self.esbr:
+                self.lib.xaac_parser_set_esbr(h, 1)
             self.parsers[i] = h
         self.threads, self.stage = int(threads), int(stage)
         self.consumed, self.status = np.zeros(n, np.uint64), np.zeros(n, np.int32)
@@ -212,7 +232,7 @@ class BatchParser:
                 self.lib.xaac_parser_destroy(self.parsers[i])
                 self.parsers[i] = None
 
-    def _run(self, spec, ics, hdr, frm, psf, flags, with_sbr, advance=True):
+    def _run(self, spec, ics, hdr, frm, psf, flags, with_sbr, advance=True, eside=None):
         n = self.n
         left = self.length - self.pos
         ptrs = (np.uint64(self.base) + self.start + self.pos).astype(np.uint64)
@@ -222,6 +242,7 @@ class BatchParser:
         ptr = lambda t: None if t is None else (t.data_ptr() if hasattr(t, "data_ptr") else t.ctypes.data)
         b.spec, b.ics, b.header, b.frame, b.ps_frame, b.flags = ptr(spec), ptr(ics), ptr(hdr), ptr(frm), ptr(psf), ptr(flags)
         b.tools, b.consumed, b.status = self.tools.ctypes.data, self.consumed.ctypes.data, self.status.ctypes.data
+        b.esbr_side = ptr(eside)
         ok = self.lib.xaac_parse_batch_run(ctypes.byref(b))
         if ok < 0:
             raise RuntimeError("xaac_parse_batch_run: %d" % ok)
@@ -230,10 +251,10 @@ class BatchParser:
             self.frames += (self.status == 0)
         return ok
 
-    def step(self, spec, ics, hdr=None, frm=None, psf=None, flags=None):
+    def step(self, spec, ics, hdr=None, frm=None, psf=None, flags=None, eside=None):
         """parses the next frame of every stream into the staging arrays; -> bool[n]: which streams delivered a frame
         (the others are at their end: their rows are left as they were)"""
-        self._run(spec, ics, hdr, frm, psf, flags, with_sbr=self.sbr)
+        self._run(spec, ics, hdr, frm, psf, flags, with_sbr=self.sbr, eside=eside)
         bad = (self.status != 0) & (self.status != 1)
         if np.any(bad):
             i = int(np.nonzero(bad)[0][0])

@@ -649,14 +649,21 @@ void read_deltas(XsFrameData *f, XhBits *br, const Book &hcb_t, const Book &hcb_
                  int start_bits, int start_bits_bal, int is_noise, int lav) {
   const int16_t *dir = is_noise ? f->dir_noise : f->dir_env;
   int16_t *sf = is_noise ? f->noise_floor : f->env_sf;
+  float *sff = is_noise ? f->flt_noise_floor : f->flt_env_sf;
   const int bal = f->coupling_mode == XS_COUPLING_BAL;
   const int bits = bal ? start_bits_bal : start_bits, shift = bal ? comp : 0;
   int offset = 0;
   for (int j = 0; j < num_env; j++) {
     const int d = dir[j];
-    if (d == DIR_FREQ) sf[offset] = (int16_t)(br->get(bits) << shift);
+    if (d == DIR_FREQ) {
+      sf[offset] = (int16_t)(br->get(bits) << shift);
+      sff[offset] = sf[offset];
+    }
     const Book &h = d == DIR_FREQ ? hcb_f : hcb_t;
-    for (int i = 1 - d; i < no_band[j]; i++) sf[offset + i] = (int16_t)((huff(h, br) - lav) * (1 << comp));
+    for (int i = 1 - d; i < no_band[j]; i++) {
+      sf[offset + i] = (int16_t)((huff(h, br) - lav) * (1 << comp));
+      sff[offset + i] = sf[offset + i];
+    }
     offset += no_band[j];
   }
 }
@@ -758,16 +765,55 @@ int read_ps(XsPs *ps, XhBits *br, int bits_left) {
   return (int)(br->pos - at);
 }
 
-/* :716-795: extended data (PS); returns -1 for the fatal error, 0 otherwise.  ps == NULL: the reference stops reading. */
-int read_extension(XsHeader *h, XsPs *ps, XhBits *br) {
+/* :595-714: the ENHSBR extension of one element: patching mode, over-sampling flag, pitch; returns the bits it took */
+int read_enh(XhBits *br, XsFrameData *f, int cpe) {
+  int bits = 1;
+  br->get(1); /* pre-flattening flag: a USAC tool, read and not used for AAC-LC cores */
+  auto one = [&](XsFrameData *a, XsFrameData *b) {
+    const int mode = br->get1();
+    bits += 1;
+    int over = 0, pitch = 0;
+    if (mode == 0) {
+      over = br->get1();
+      bits += 2;
+      if (br->get1()) {
+        pitch = (int)br->get(7);
+        bits += 7;
+      }
+    }
+    a->patching_mode = mode, a->over_sampling = over, a->pitch_in_bins = pitch;
+    if (b) b->patching_mode = mode, b->over_sampling = over, b->pitch_in_bins = pitch;
+  };
+  if (!cpe) {
+    one(&f[0], nullptr);
+  } else if (f[0].coupling_mode) {
+    one(&f[0], &f[1]);
+  } else {
+    one(&f[0], nullptr);
+    one(&f[1], nullptr);
+  }
+  if (bits < 6) {
+    br->get(6 - bits);
+    bits = 6;
+  }
+  return bits;
+}
+
+/* :716-795: extended data (PS, ENHSBR); returns -1 for the fatal error, 0 otherwise.  ps == NULL: the reference stops
+   reading at a PS element.  enh: the eSBR interpretation (the ENHSBR element is read; otherwise it is skipped) */
+int read_extension(XsHeader *h, XsPs *ps, XhBits *br, XsFrameData *f = nullptr, int cpe = 0, int enh = 0) {
   if (!br->get1()) return 0;
   int cnt = (int)br->get(4);
   if (cnt == 15) cnt += (int)br->get(8);
   int left = cnt << 3, ps_read = 0;
   while (left > 7) {
     int id = (int)br->get(2);
-    if (id == 3) id = -1; /* EXTENSION_ID_ENHSBR_CODING without the eSBR tools */
+    if (id == 3 && !enh) id = -1; /* EXTENSION_ID_ENHSBR_CODING without the eSBR tools */
     left -= 2;
+    if (id == 3) {
+      left -= read_enh(br, f, cpe);
+      continue;
+    }
     if (id == 2) { /* EXTENSION_ID_PS_CODING */
       if (!ps) return 0;
       if (!ps_read) {
@@ -792,23 +838,26 @@ int read_extension(XsHeader *h, XsPs *ps, XhBits *br) {
 }
 
 /* :860-975; returns frame_status (1 ok, 0 bad) or -1 (fatal) */
-int read_sce(XsHeader *h, XsFrameData *f, XsPs *ps, XhBits *br) {
+int read_sce(XsHeader *h, XsFrameData *f, XsPs *ps, XhBits *br, int enh) {
   f->coupling_mode = XS_COUPLING_OFF;
   if (br->get1()) br->get(4);
   if (!read_grid(br, &f->fi)) return 0;
   if (!validate_grid(&f->fi)) return 0;
   read_dtdf(f, br);
   if (f->dir_env[0] == DIR_FREQ) h->err_flag = 0;
-  for (int i = 0; i < h->num_if_bands; i++) f->invf_mode[i] = (int32_t)br->get(2);
+  for (int i = 0; i < h->num_if_bands; i++) {
+    f->invf_mode_prev[i] = f->invf_mode[i];
+    f->invf_mode[i] = (int32_t)br->get(2);
+  }
   if (!read_envelopes(h, f, br)) return 0;
   read_noise(h, f, br);
   read_sines(h, f, br);
-  if (read_extension(h, ps, br) < 0) return -1;
+  if (read_extension(h, ps, br, f, 0, enh) < 0) return -1;
   return 1;
 }
 
 /* :977-1229 */
-int read_cpe(XsHeader *h, XsFrameData *f, XhBits *br) {
+int read_cpe(XsHeader *h, XsFrameData *f, XhBits *br, int enh) {
   if (br->get1()) br->get(8);
   if (h->channel_mode != XS_SBR_STEREO) {
     h->sync_state = XS_UPSAMPLING;
@@ -830,8 +879,12 @@ int read_cpe(XsHeader *h, XsFrameData *f, XhBits *br) {
   read_dtdf(&f[1], br);
   if (f[0].dir_env[0] == DIR_FREQ && f[1].dir_env[0] == DIR_FREQ) h->err_flag = 0;
   for (int k = 0; k < num_ch; k++)
-    for (int i = 0; i < h->num_if_bands; i++) f[k].invf_mode[i] = (int32_t)br->get(2);
+    for (int i = 0; i < h->num_if_bands; i++) {
+      f[k].invf_mode_prev[i] = f[k].invf_mode[i];
+      f[k].invf_mode[i] = (int32_t)br->get(2);
+    }
   if (coupling) {
+    memcpy(f[1].invf_mode_prev, f[1].invf_mode, sizeof(int32_t) * (size_t)h->num_if_bands);
     memcpy(f[1].invf_mode, f[0].invf_mode, sizeof(int32_t) * (size_t)h->num_if_bands);
     if (!read_envelopes(h, &f[0], br)) return 0;
     read_noise(h, &f[0], br);
@@ -844,7 +897,7 @@ int read_cpe(XsHeader *h, XsFrameData *f, XhBits *br) {
   read_noise(h, &f[1], br);
   read_sines(h, &f[0], br);
   read_sines(h, &f[1], br);
-  if (read_extension(h, nullptr, br) < 0) return -1;
+  if (read_extension(h, nullptr, br, f, 1, enh) < 0) return -1;
   return 1;
 }
 
@@ -967,13 +1020,18 @@ int timing_compensate(const XsHeader *h, XsFrameData *f, const XsPrevData *p) { 
   return 0;
 }
 
-int decode_envelope(XsHeader *h, XsFrameData *f, XsPrevData *p0, XsPrevData *p1) { /* :727-843 (no concealment option) */
+int decode_envelope(XsHeader *h, XsFrameData *f, XsPrevData *p0, XsPrevData *p1, int enh) { /* :727-843 (no concealment option) */
   int t = p0->end_position - kTimeSlots;
   if (t < 0) return -1;
   t = f->fi.border_vec[0] - t;
   if (!h->err_flag_prev && !h->err_flag && t != 0) {
     if (f->dir_env[0] == DIR_TIME) h->err_flag = 1;
     else h->err_flag_prev = 1;
+  }
+  if (enh) { /* usac_flag | enh_sbr: no concealment, no timing compensation, no range check, no dequantisation (:759-842) */
+    delta_decode_env(h, f, p0);
+    for (int i = 0; i < f->num_env_sfac; i++) f->flt_env_sf[i] = (float)f->env_sf[i];
+    return 0;
   }
   if (h->err_flag) {
     lean_concealment(h, f, p0);
@@ -1009,7 +1067,7 @@ int decode_envelope(XsHeader *h, XsFrameData *f, XsPrevData *p0, XsPrevData *p1)
       if (bad) {
         h->err_flag = 1;
         memcpy(p0->sfb_nrg_prev, saved, sizeof(saved));
-        return decode_envelope(h, f, p0, p1);
+        return decode_envelope(h, f, p0, p1, enh);
       }
     }
   }
@@ -1026,7 +1084,7 @@ int decode_envelope(XsHeader *h, XsFrameData *f, XsPrevData *p0, XsPrevData *p1)
   return 0;
 }
 
-int decode_noise(const XsHeader *h, XsFrameData *f, XsPrevData *p) { /* :396-494 */
+int decode_noise(const XsHeader *h, XsFrameData *f, XsPrevData *p, int enh) { /* :396-494 */
   const int nb = h->num_nf_bands, ne = f->fi.num_noise_env;
   int16_t *nf = f->noise_floor;
   if (f->dir_noise[0] == DIR_FREQ) {
@@ -1048,8 +1106,11 @@ int decode_noise(const XsHeader *h, XsFrameData *f, XsPrevData *p) { /* :396-494
   const int offset = nb * (ne - 1);
   if (offset < 0 || offset >= XAAC_SBR_MAX_NOISE_VALUES) return -1;
   memcpy(p->prev_noise_level, nf + offset, sizeof(int16_t) * (size_t)nb);
-  if (f->coupling_mode != XS_COUPLING_BAL)
-    for (int i = 0; i < nb * ne; i++) nf[i] = (int16_t)(0x4000 + ((6 + 1 + kNoiseExpOffset - nf[i]) & kMaskExp));
+  if (enh || f->coupling_mode != XS_COUPLING_BAL)
+    for (int i = 0; i < nb * ne; i++) {
+      f->flt_noise_floor[i] = (float)nf[i]; /* the float tools' copy: the limited level itself (:471-476) */
+      nf[i] = (int16_t)(0x4000 + ((6 + 1 + kNoiseExpOffset - nf[i]) & kMaskExp));
+    }
   return 0;
 }
 
@@ -1082,17 +1143,51 @@ void dequant_coupled(const XsHeader *h, XsFrameData *l, XsFrameData *r) { /* :51
   }
 }
 
+/* the float tools' scale factors: :52-72 (one channel) and :586-626 (a coupled pair) */
+void dequant_float(const XsHeader *h, XsFrameData *f) {
+  const float a = f->amp_res ? 1.0f : 0.5f;
+  for (int i = 0; i < f->num_env_sfac; i++) f->flt_env_sf[i] = (float)(pow(2, f->flt_env_sf[i] * a) * 64);
+  const int n = h->num_nf_bands * f->fi.num_noise_env;
+  for (int i = 0; i < n; i++) {
+    float t = f->flt_noise_floor[i];
+    t = 6.0f - t;
+    f->flt_noise_floor[i] = (float)pow(2.0f, t);
+  }
+}
+void dequant_float_coupled(const XsHeader *h, XsFrameData *l, XsFrameData *r) {
+  static const float pan_offset[2] = {24.0f, 12.0f}, a_arr[2] = {0.5f, 1.0f};
+  const int amp = l->amp_res;
+  const float a = a_arr[amp];
+  for (int i = 0; i < l->num_env_sfac; i++) {
+    const float tl = l->flt_env_sf[i], tr = r->flt_env_sf[i];
+    l->flt_env_sf[i] = (float)(64 * (pow(2, tl * a + 1) / (1 + pow(2, (pan_offset[amp] - tr) * a))));
+    r->flt_env_sf[i] = (float)(64 * (pow(2, tl * a + 1) / (1 + pow(2, (tr - pan_offset[amp]) * a))));
+  }
+  const int n = h->num_nf_bands * r->fi.num_noise_env;
+  for (int i = 0; i < n; i++) {
+    const float tl = l->flt_noise_floor[i], tr = r->flt_noise_floor[i];
+    l->flt_noise_floor[i] = (float)(pow(2, 6.0f - tl + 1) / (1 + pow(2, pan_offset[1] - tr)));
+    r->flt_noise_floor[i] = (float)(pow(2, 6.0f - tl + 1) / (1 + pow(2, tr - pan_offset[1])));
+  }
+}
+
 int decode_sbr_data(XsDecoder *d, int two) { /* ixheaacd_dec_sbrdata :628-725 */
   XsHeader *h = &d->hdr;
-  if (decode_envelope(h, &d->fd[0], &d->prev[0], &d->prev[1])) return -1;
-  if (decode_noise(h, &d->fd[0], &d->prev[0])) return -1;
+  const int enh = d->enh;
+  if (decode_envelope(h, &d->fd[0], &d->prev[0], &d->prev[1], enh)) return -1;
+  if (decode_noise(h, &d->fd[0], &d->prev[0], enh)) return -1;
+  if (enh && !d->fd[0].coupling_mode) dequant_float(h, &d->fd[0]);
   if (two) {
     const int err = h->err_flag;
-    if (decode_envelope(h, &d->fd[1], &d->prev[1], &d->prev[0])) return -1;
-    if (decode_noise(h, &d->fd[1], &d->prev[1])) return -1;
-    if (!err && h->err_flag)
-      if (decode_envelope(h, &d->fd[0], &d->prev[0], &d->prev[1])) return -1;
-    if (d->fd[0].coupling_mode) dequant_coupled(h, &d->fd[0], &d->fd[1]);
+    if (decode_envelope(h, &d->fd[1], &d->prev[1], &d->prev[0], enh)) return -1;
+    if (decode_noise(h, &d->fd[1], &d->prev[1], enh)) return -1;
+    if (enh && !d->fd[1].coupling_mode) dequant_float(h, &d->fd[1]);
+    if (!enh && !err && h->err_flag)
+      if (decode_envelope(h, &d->fd[0], &d->prev[0], &d->prev[1], enh)) return -1;
+    if (d->fd[0].coupling_mode) {
+      dequant_coupled(h, &d->fd[0], &d->fd[1]);
+      if (enh) dequant_float_coupled(h, &d->fd[0], &d->fd[1]);
+    }
   }
   return 0;
 }
@@ -1278,10 +1373,17 @@ void export_frame(const XsFrameData *f, int apply, xaac_sbr_frame *o) { /* to_fr
 
 }  // namespace
 
-void xs_init(XsDecoder *d, int core_sampling_rate, int core_channels, int ps_enable) {
+void xs_init(XsDecoder *d, int core_sampling_rate, int core_channels, int ps_enable, int enh) {
   memset(d, 0, sizeof(*d));
   d->core_channels = core_channels;
   d->ps_enable = ps_enable;
+  d->enh = enh;
+  d->qmf_sb_prev = 64;
+  { /* str_sbr_default_header (ixheaacd_sbr_rom.c:2008-2030), copied into a new stream's header (sbrdec_initfuncs.c:556) */
+    XsHeader *h = &d->hdr;
+    h->amp_res = 1, h->start_freq = 15, h->stop_freq = 6, h->xover_band = 0, h->freq_scale = 2, h->alter_scale = 1, h->noise_bands = 2;
+    h->limiter_bands = 2, h->limiter_gains = 2, h->interpol_freq = 1, h->smoothing_mode = 1;
+  }
   d->hdr.out_sampling_freq = 2 * core_sampling_rate;
   d->hdr.sync_state = XS_NOT_INITIALIZED;
   for (int c = 0; c < 2; c++) d->prev[c].end_position = kTimeSlots; /* sbrdec_initfuncs.c:884-898 */
@@ -1299,10 +1401,20 @@ int xs_decode_frame(XsDecoder *d, const uint8_t *payload, int bytes, int ext_typ
   const int initial_sync = h->sync_state;
   h->err_flag_prev = h->err_flag;
   const int lr1 = d->ps_enable ? 2 : num_channels;
+  uint8_t late[sizeof(d->prev_payload)];
+  int skip_element = 0;
   if (bytes == 0) {
     frame_status = 0;
     h->sync_state = XS_UPSAMPLING;
-  } else {
+  } else if (d->enh) { /* the payload decoded now is the previous frame's; this one waits (sbrdecoder.c:479-493) */
+    const int nb = d->prev_bytes, nt = d->prev_ext_type;
+    memcpy(late, d->prev_payload, sizeof(late));
+    memcpy(d->prev_payload, payload, (size_t)bytes);
+    d->prev_bytes = bytes, d->prev_ext_type = ext_type;
+    payload = late, bytes = nb, ext_type = nt;
+    if (bytes == 0) skip_element = 1; /* `continue`: nothing of the element is looked at */
+  }
+  if (bytes != 0) {
     XhBits br(payload, (size_t)bytes);
     stereo = num_channels == 2; /* the payload of a CPE (the element types follow the core channels in this scope) */
     br.get(4);                  /* the nibble behind the extension type (sbrdecoder.c:495) */
@@ -1316,6 +1428,10 @@ int xs_decode_frame(XsDecoder *d, const uint8_t *payload, int bytes, int ext_typ
       if (header_flag == SBR_RESET) {
         err = calc_freq_tables(h);
         if (!err) {
+          for (int lr = 0; lr < lr1; lr++) {
+            d->fd[lr].reset_flag = 1;
+            if (h->sync_state == XS_NOT_INITIALIZED) d->fd[lr].patching_mode = 1, d->fd[lr].over_sampling = 0, d->fd[lr].pitch_in_bins = 0;
+          }
           int e2 = reset_hf_generator(h);
           if (e2 < 0) return -1;
           err |= e2;
@@ -1331,8 +1447,8 @@ int xs_decode_frame(XsDecoder *d, const uint8_t *payload, int bytes, int ext_typ
       if (err) return -1;
     }
     if (frame_status && h->sync_state == XS_ACTIVE) {
-      if (stereo) frame_status = read_cpe(h, d->fd, &br);
-      else frame_status = read_sce(h, &d->fd[0], d->ps_enable ? &d->ps : nullptr, &br);
+      if (stereo) frame_status = read_cpe(h, d->fd, &br, d->enh);
+      else frame_status = read_sce(h, &d->fd[0], d->ps_enable ? &d->ps : nullptr, &br, d->enh);
       if (frame_status < 0) return -1;
       const int read = (int)br.pos;
       if (read > (bytes << 3) || read < (bytes << 3) - 8) frame_status = 0;
@@ -1356,6 +1472,7 @@ int xs_decode_frame(XsDecoder *d, const uint8_t *payload, int bytes, int ext_typ
     if (stereo) d->fd[1].max_qmf_subband_aac = h->sub_band_start;
   }
   if (initial_sync == XS_NOT_INITIALIZED && h->err_flag) h->sync_state = XS_NOT_INITIALIZED;
+  (void)skip_element;
   res->apply = h->sync_state == XS_ACTIVE;
   res->stereo = stereo;
   res->ps = h->channel_mode == XS_PS_STEREO;
@@ -1376,7 +1493,33 @@ int xs_decode_frame(XsDecoder *d, const uint8_t *payload, int bytes, int ext_typ
   return 0;
 }
 
+int xs_hbe_k_start(int start_band) { return start_band >= 0 && start_band <= 32 ? xh_start_subband2kl[start_band] : -1; }
+
+void xs_export_esbr_side(const XsDecoder *d, int c, xaac_esbr_side *o) { /* oracle/ref_convert.h: to_esbr_side */
+  const XsHeader *h = &d->hdr;
+  const XsFrameData *f = &d->fd[c];
+  memset(o, 0, sizeof(*o));
+  o->out_sampling_freq = h->out_sampling_freq;
+  o->limiter_bands = (int16_t)h->limiter_bands;
+  o->num_mf_bands = h->num_mf_bands;
+  memcpy(o->f_master_tbl, h->f_master, sizeof(o->f_master_tbl));
+  o->qmf_sb_prev = (int16_t)d->qmf_sb_prev_frame;
+  o->reset_flag = (int16_t)f->reset_flag_frame;
+  o->harmonic_sbr = f->patching_mode == 0;
+  memcpy(o->sbr_invf_mode_prev, f->invf_mode_prev, sizeof(o->sbr_invf_mode_prev));
+  memcpy(o->flt_env_sf_arr, f->flt_env_sf, sizeof(o->flt_env_sf_arr));
+  memcpy(o->flt_noise_floor, f->flt_noise_floor, sizeof(o->flt_noise_floor));
+  o->pitch_in_bins = f->pitch_in_bins;
+}
+
 void xs_frame_done(XsDecoder *d, const XsFrameResult *res) {
+  /* qmf_sb_prev follows the start band behind the frame's ixheaacd_sbr_dec calls (sbrdecoder.c:915-990, the calls with a DRC
+     handle): channel 0 of a mono stream, channel 1 of a pair (both write the one table the channels share) */
+  d->qmf_sb_prev_frame = d->qmf_sb_prev;
+  for (int c = 0; c < 2; c++) d->fd[c].reset_flag_frame = d->fd[c].reset_flag;
+  if (d->enh) /* the float synthesis stage takes the flag down behind every frame (sbr_dec.c:659) */
+    for (int c = 0; c < (d->core_channels == 2 ? 2 : 1); c++) d->fd[c].reset_flag = 0;
+  if (d->enh && res->apply && (d->core_channels != 2 || res->stereo)) d->qmf_sb_prev = d->hdr.sub_band_start;
   if (!res->apply) return;
   const int n = (res->stereo && d->core_channels == 2) ? 2 : 1;
   for (int c = 0; c < n; c++) {

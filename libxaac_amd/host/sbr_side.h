@@ -14,6 +14,7 @@
 
 #include <stdint.h>
 
+#include "../../include/xaac_esbr.h"
 #include "../../include/xaac_sbr.h"
 #include "bits.h"
 
@@ -36,6 +37,11 @@ struct XsFrameData { /* the members of ia_sbr_frame_info_data_struct this path u
   uint8_t add_harmonics[XAAC_SBR_MAX_FREQ_COEFFS];
   int16_t env_sf[XAAC_SBR_MAX_ENV_VALUES];
   int16_t noise_floor[XAAC_SBR_MAX_NOISE_VALUES];
+  /* the eSBR interpretation (-esbr:1, enh_sbr): float copies the float tools read, and what the ENHSBR extension carries */
+  float flt_env_sf[XAAC_SBR_MAX_ENV_VALUES], flt_noise_floor[XAAC_SBR_MAX_NOISE_VALUES];
+  float prev_noise_level_flt[XAAC_SBR_MAX_NOISE_COEFFS]; /* ia_sbr_frame_info_data_struct::prev_noise_level */
+  int32_t invf_mode_prev[XAAC_SBR_MAX_NOISE_VALUES];
+  int32_t patching_mode, over_sampling, pitch_in_bins, reset_flag, reset_flag_frame;
 };
 
 struct XsPrevData { /* ia_sbr_prev_frame_data_struct */
@@ -68,6 +74,11 @@ struct XsPs { /* the members of ia_ps_dec_struct the payload decoder keeps */
 
 struct XsDecoder { /* one stream */
   int core_channels, ps_enable;
+  int enh;                 /* the reference's default -esbr:1: payloads run one frame late, ENHSBR extension, float dequantisation */
+  int qmf_sb_prev;         /* pstr_freq_band_data->qmf_sb_prev (sbrdec_initfuncs.c:649, sbrdecoder.c:892-986) */
+  int qmf_sb_prev_frame;   /* ... as the frame decoded last found it */
+  int prev_bytes, prev_ext_type;
+  uint8_t prev_payload[272];
   XsHeader hdr;
   XsFrameData fd[2];
   XsPrevData prev[2];
@@ -89,7 +100,13 @@ struct XsFrameResult {
 };
 
 /* a new stream: core sampling rate (the SBR range runs at twice that), core channels, PS allowed */
-void xs_init(XsDecoder *d, int core_sampling_rate, int core_channels, int ps_enable);
+void xs_init(XsDecoder *d, int core_sampling_rate, int core_channels, int ps_enable, int enh = 0);
+
+/* enh streams: the members of xaac_esbr_side of channel c for the frame xs_decode_frame decoded last */
+void xs_export_esbr_side(const XsDecoder *d, int c, xaac_esbr_side *o);
+
+/* the QMF transposer's first synthesis band for SBR start band b (0 .. 32): ixheaac_start_subband2kL_tbl */
+int xs_hbe_k_start(int start_band);
 
 /* One frame.  payload / bytes / ext_type: XhElement::sbr etc. (bytes = 0: no SBR payload in this frame).
    Fills header, frame[0 .. 1], ps_frame and res.  Returns 0, or a negative value where the reference would have

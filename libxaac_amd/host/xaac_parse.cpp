@@ -22,7 +22,7 @@ struct xaac_parser {
   int sr_index;
   XhCoreState core;
   XhElement el;
-  int sbr_ready, sampling_rate;
+  int sbr_ready, sampling_rate, esbr;
   XsDecoder sbr;
   xaac_sbr_side side_scratch;
 };
@@ -203,7 +203,7 @@ int32_t xaac_parse_adts_frame(xaac_parser *p, const uint8_t *data, size_t n, int
 int32_t xaac_parse_sbr_side(xaac_parser *p, int32_t ps_enable, xaac_sbr_side *side) {
   if (!p || !side || p->sr_index < 0 || p->el.n_ch < 1) return XAAC_PARSE_ERR_SYNTAX;
   if (!p->sbr_ready) {
-    xs_init(&p->sbr, p->sampling_rate, p->el.n_ch, ps_enable && p->el.n_ch == 1);
+    xs_init(&p->sbr, p->sampling_rate, p->el.n_ch, ps_enable && p->el.n_ch == 1, p->esbr);
     p->sbr_ready = 1;
   }
   XsFrameResult r;
@@ -212,6 +212,18 @@ int32_t xaac_parse_sbr_side(xaac_parser *p, int32_t ps_enable, xaac_sbr_side *si
   xs_frame_done(&p->sbr, &r); /* what the frame's ixheaacd_sbr_dec leaves for the next frame's delta decoding */
   side->apply = r.apply, side->reset = r.reset, side->reset_channels = r.reset_channels, side->upsampling = r.upsampling;
   side->stereo = r.stereo, side->ps = r.ps, side->ps_start = r.ps_start, side->frame_ok = r.frame_ok;
+  return XAAC_PARSE_OK;
+}
+
+int32_t xaac_parser_set_esbr(xaac_parser *p, int32_t esbr) {
+  if (!p || p->sbr_ready || (esbr != 0 && esbr != 1)) return XAAC_PARSE_ERR_SYNTAX;
+  p->esbr = esbr;
+  return XAAC_PARSE_OK;
+}
+
+int32_t xaac_parse_esbr_side(xaac_parser *p, int32_t channel, xaac_esbr_side *side) {
+  if (!p || !side || !p->sbr_ready || !p->esbr || channel < 0 || channel > 1) return XAAC_PARSE_ERR_SYNTAX;
+  xs_export_esbr_side(&p->sbr, channel, side);
   return XAAC_PARSE_OK;
 }
 
@@ -258,6 +270,8 @@ int32_t xaac_parse_batch_run(const xaac_parse_batch *b) {
         b->frame[(size_t)i * n_ch + c] = side->frame[c];
       }
     }
+    if (side && b->esbr_side && p->esbr)
+      for (int c = 0; c < n_ch; c++) xs_export_esbr_side(&p->sbr, c, b->esbr_side + (size_t)i * n_ch + c);
     if (side) {
       if (b->ps_frame) b->ps_frame[i] = side->ps_frame;
       int32_t *f = b->flags + (size_t)i * 8;
@@ -283,6 +297,51 @@ void xaac_ps_state_init(xaac_ps_state *s) {
   memset(s->h11_h12_vec, 0xff, sizeof(s->h11_h12_vec));
   s->st_syn_scale_r = -6;
   s->ov_lb_scale_r = s->hb_scale_r = 31;
+}
+
+void xaac_esbr_state_init(xaac_esbr_state *s) {
+  memset(s, 0, sizeof(*s));
+  s->esbr_start_up = 1;
+}
+
+void xaac_esbr_ps_state_init(xaac_esbr_ps_state *s) {
+  memset(s, 0, sizeof(*s));
+  for (int b = 0; b < 20; b++) s->h_prev[0][b] = s->h_prev[1][b] = 1.0f;
+}
+
+void xaac_hbe_state_init(xaac_hbe_state *s) { memset(s, 0, sizeof(*s)); }
+
+int32_t xaac_hbe_state_reinit(xaac_hbe_state *s, const xaac_sbr_header *h) {
+  const int n_lo = h->num_sf_bands[0], n_hi = h->num_sf_bands[1];
+  if (n_lo < 0 || n_lo > XAAC_SBR_MAX_FREQ_COEFFS / 2 || n_hi < 0 || n_hi > XAAC_SBR_MAX_FREQ_COEFFS) return -1;
+  const int16_t *lo = h->freq_band_tbl_lo, *hi = h->freq_band_tbl_hi;
+  if (lo[0] < 0 || lo[0] > 32) return -1;
+  s->start_band = lo[0];
+  s->end_band = lo[n_lo];
+  s->synth_size = 4 * ((s->start_band + 4) / 8 + 1);
+  s->k_start = xs_hbe_k_start(s->start_band);
+  memset(s->synth_buf, 0, sizeof(s->synth_buf));
+  memset(s->analy_buf, 0, sizeof(s->analy_buf));
+  s->fft_ready = s->synth_size != 20; /* the one bank size the reference sets no FFT for (hbe_trans.c:164-169) */
+  memset(s->x_over_qmf, 0, sizeof(s->x_over_qmf));
+  int sfb = 0;
+  for (int patch = 1; patch <= 4; patch++) { /* MAX_STRETCH */
+    while (sfb <= n_lo && lo[sfb] <= patch * s->start_band) sfb++;
+    if (sfb <= n_lo) {
+      if (sfb > 0 && patch * s->start_band - lo[sfb - 1] <= 3) {
+        s->x_over_qmf[patch - 1] = lo[sfb - 1];
+      } else {
+        int k = 0;
+        while (k <= n_hi && hi[k] <= patch * s->start_band) k++;
+        s->x_over_qmf[patch - 1] = k > 0 ? hi[k - 1] : 0;
+      }
+    } else {
+      s->x_over_qmf[patch - 1] = s->end_band;
+      s->max_stretch = patch < 4 ? patch : 4;
+      break;
+    }
+  }
+  return s->k_start < 0 ? -1 : 0;
 }
 
 void xaac_sbr_state_apply_side(xaac_sbr_state *s, const xaac_sbr_side *side, int32_t channel) {

@@ -285,6 +285,51 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
   int32_t meta[8];
   WORD32 ret;
   int i, ps_on = (apply && h->channel_mode == PS_STEREO);
+  if (getenv("XAAC_ESBR_SIDE_FILE")) { /* the side info of every call as the boundary structs hold it, eSBR members included:
+       {"XAE1", call, PS on, apply, enh_sbr, ch_fac, low_pow, 0} header frame esbr_side ps_frame hbe parameters[11]
+       (for the host front end's -esbr:1 mode: tests/test_parser_esbr.py) */
+    static FILE *fs;
+    static xaac_esbr_side es;
+    static xaac_hbe_state hb;
+    int32_t m[8] = {0x58414531, g_calls++, ps_on, apply, h->enh_sbr, ch_fac, low_pow, 0}, par[11];
+    if (!fs) fs = fopen(getenv("XAAC_ESBR_SIDE_FILE"), "wb");
+    to_header(h, d, &hd);
+    to_frame(f, apply, &fr);
+    to_esbr_side(h, f, &es);
+    memset(&psf, 0, sizeof(psf));
+    if (ps_on) to_ps_frame(ps, &psf);
+    memset(par, 0, sizeof(par));
+    if (d->p_hbe_txposer) {
+      to_hbe_state(d->p_hbe_txposer, &hb);
+      par[0] = hb.synth_size, par[1] = hb.k_start, par[2] = hb.start_band, par[3] = hb.end_band;
+      for (i = 0; i < 6; i++) par[4 + i] = hb.x_over_qmf[i];
+      par[10] = hb.max_stretch;
+    }
+    fwrite(m, sizeof(m), 1, fs), fwrite(&hd, sizeof(hd), 1, fs), fwrite(&fr, sizeof(fr), 1, fs), fwrite(&es, sizeof(es), 1, fs);
+    fwrite(&psf, sizeof(psf), 1, fs), fwrite(par, sizeof(par), 1, fs);
+    fflush(fs);
+    if (getenv("XAAC_ESBR_INIT_FILE") && m[1] < 2) { /* what the first calls find in the Path A state: a new stream's values
+         (esbr state, hbe state, esbr PS state: the checker of xaac_esbr_stream_init) */
+      static xaac_esbr_state est;
+      static xaac_esbr_ps_state epss;
+      const ia_qmf_dec_tables_struct *q = tabs->qmf_dec_tables_ptr;
+      FILE *fi = fopen(getenv("XAAC_ESBR_INIT_FILE"), m[1] ? "ab" : "wb");
+      d->str_synthesis_qmf_bank.filter_pos_syn_32 += q->esbr_qmf_c - d->str_synthesis_qmf_bank.p_filter_32;
+      d->str_synthesis_qmf_bank.p_filter_32 = q->esbr_qmf_c;
+      to_esbr_state(d, h, f, &est);
+      memset(&hb, 0, sizeof(hb)), memset(&epss, 0, sizeof(epss));
+      if (d->p_hbe_txposer) to_hbe_state(d->p_hbe_txposer, &hb);
+      if (ps && synth_r) {
+        synth_r->filter_pos_syn_32 += q->esbr_qmf_c - synth_r->p_filter_32;
+        synth_r->p_filter_32 = q->esbr_qmf_c;
+        to_esbr_ps_state(ps, synth_r, &epss);
+      }
+      fwrite(&est, sizeof(est), 1, fi), fwrite(&hb, sizeof(hb), 1, fi), fwrite(&epss, sizeof(epss), 1, fi);
+      fclose(fi);
+    }
+    return __real_ixheaacd_sbr_dec(d, time_data, h, f, p, ps, synth_r, sf_r, apply, low_pow, work, tabs, common, ch_fac, pvc, drc_on,
+                                   drc, aot, ldmps, self, mps, ec);
+  }
   if (getenv("XAAC_ESBR_CHAIN_FILE") && esbr_path(d, h, f, ps, synth_r, drc_on, aot, ldmps, mps))
     return esbr_chain_call(d, time_data, h, f, p, ps, synth_r, sf_r, apply, low_pow, work, tabs, common, ch_fac, pvc, drc_on, drc,
                            aot, ldmps, self, mps, ec);
