@@ -3,7 +3,7 @@
  * what ixheaacd_sbr_dec's Path A branch (decoder/ixheaacd_sbr_dec.c:816-1009) reads beyond xaac_sbr_header /
  * xaac_sbr_frame (xaac_sbr.h), and the per-channel state it keeps between frames.
  * Scope: 2:1 SBR of AAC-LC cores (usac_flag = 0), with or without parametric stereo, LPP or harmonic patching (the QMF
- * transposer of xaac_hbe.h): no PVC, no pre-flattening of LPP patches, no MPS.
+ * transposer of xaac_hbe.h), pre-flattening of LPP patches: no PVC, no MPS.
  */
 #ifndef XAAC_ESBR_H
 #define XAAC_ESBR_H
@@ -18,6 +18,8 @@
 #define XAAC_ESBR_OUT_HIST_ROWS 8 /* op_delay 6 + SBR_HF_ADJ_OFFSET 2 rows of sbr_qmf_out_real/_imag kept */
 #define XAAC_ESBR_ROWS (XAAC_ESBR_HIST_ROWS + 32)
 
+enum { XAAC_ESBR_HARMONIC = 1, XAAC_ESBR_PRE_FLATTEN = 2 }; /* bits of xaac_esbr_side::harmonic_sbr */
+
 /* Per-frame side info: ia_sbr_header_data_struct / ia_freq_band_data_struct / ia_sbr_frame_info_data_struct members
  * (decoder/ixheaacd_env_extr_part.h:33-100, ixheaacd_env_extr.h:54-120) the float path reads and the fixed path does not. */
 typedef struct xaac_esbr_side {
@@ -27,8 +29,10 @@ typedef struct xaac_esbr_side {
   int16_t f_master_tbl[XAAC_SBR_MAX_FREQ_COEFFS + 1]; /* freq band data: f_master_tbl */
   int16_t qmf_sb_prev;                                /* freq band data: qmf_sb_prev (sbr_dec.c:314) */
   int16_t reset_flag;                                 /* frame: reset_flag */
-  int16_t harmonic_sbr;                               /* frame: sbr_patching_mode == 0 (ENHSBR payload, env_extr.c:610): the HF
-                                                         generator takes the harmonic transposer's output, not LPP patches */
+  int16_t harmonic_sbr;                               /* what the frame's ENHSBR payload asks of the HF generator (env_extr.c:595-714):
+                                                         XAAC_ESBR_HARMONIC: sbr_patching_mode == 0, it takes the harmonic
+                                                         transposer's output, not LPP patches; XAAC_ESBR_PRE_FLATTEN: header
+                                                         pre_proc_flag, LPP patches are pre-flattened (sbrdec_lpfuncs.c:928) */
   int32_t sbr_invf_mode_prev[XAAC_SBR_MAX_NOISE_VALUES]; /* frame: sbr_invf_mode_prev (set by the parser, env_extr.c:834) */
   int32_t inter_temp_shape_mode[XAAC_SBR_MAX_ENVELOPES]; /* frame: inter_temp_shape_mode (0 without inter-TES) */
   float flt_env_sf_arr[XAAC_SBR_MAX_ENV_VALUES];      /* frame: flt_env_sf_arr */

@@ -89,6 +89,8 @@ struct XeWork {
 };
 
 FX_HD double xe_sqrt(double v) { return sqrt(v); }
+FX_HD double xe_log10(double v) { return log10(v); }
+FX_HD double xe_pow10(double v) { return pow(10.0, v); }
 
 /* ---- ixheaacd_createlimiterbands (b_patching_mode = 1): serial, integer, run at a reset frame ------------------- */
 FX_HD void xe_shellsort(int32_t *in, int n) { /* esbr_envcal.c:48: any sort gives the same array of integers */
@@ -359,6 +361,85 @@ XE_NOINLINE FX_HD void xe_harmonic_patch(const XsCx &cx, const xaac_sbr_header *
   return;
 }
 
+/* ixheaacd_pre_processing (sbrdec_lpfuncs.c:928-979): the pre-flattening of LPP patches a frame's ENHSBR element asks for
+   (bs_sbr_preprocessing; env_extr.c:602).  The low band's envelope in dB per QMF band over the frame's slots, a cubic fitted
+   to it over the band index (ixheaacd_polyfit :898, normal equations solved by ixheaacd_gausssolve :850 with partial
+   pivoting -- all in single precision, restated operation by operation), and per band the gain that brings the fitted
+   curve to the mean level.  Gains -> w->nrg_gain[0 .. num_bands); w->nrg_est, w->alpha_r are scratch here. */
+XE_NOINLINE FX_HD void xe_pre_flatten(const XsCx &cx, XeWork *w, const XeMat &src, int num_bands, int start, int end) {
+  float *low_env = w->nrg_est, *gain = w->nrg_gain;
+  float *a = &w->alpha_r[0][0], *b = a + 16, *v = b + 4, *p = v + 7, *mean = p + 4; /* a[4][4] b[4] v[7] p[4] mean */
+  XS_PAR(k, 0, 64) {
+    float e = 0.0f;
+    if (k < num_bands && num_bands != 0 && end != start) {
+      float temp = 0.0f;
+      for (int i = start; i < end; i++) temp += src.r(i, k) * src.r(i, k) + src.i(i, k) * src.i(i, k);
+      temp /= (float)(end - start);
+      e = (float)(10 * xe_log10((double)(temp + 1)));
+    }
+    low_env[k] = e;
+  }
+  cx.sync();
+  XS_ONE {
+    float m = 0.0f;
+    if (num_bands != 0 && end != start) {
+      for (int k = 0; k < num_bands; k++) m = m + low_env[k];
+      m /= (float)num_bands;
+    }
+    *mean = m;
+    for (int i = 0; i < 20; i++) a[i] = 0.0f; /* a and b */
+    for (int k = 0; k < num_bands; k++) {
+      v[0] = 1.0f;
+      for (int i = 1; i <= 6; i++) v[i] = (float)k * v[i - 1];
+      for (int i = 0; i <= 3; i++) {
+        b[i] += v[3 - i] * low_env[k];
+        for (int j = 0; j <= 3; j++) a[4 * i + j] += v[6 - i - j];
+      }
+    }
+    for (int i = 0; i < 4; i++) {
+      int imax = i;
+      for (int k = i + 1; k < 4; k++)
+        if (fabsf(a[4 * k + i]) > fabsf(a[4 * imax + i])) imax = k;
+      if (imax != i) {
+        float t = b[imax];
+        b[imax] = b[i];
+        b[i] = t;
+        for (int j = i; j < 4; j++) {
+          t = a[4 * imax + j];
+          a[4 * imax + j] = a[4 * i + j];
+          a[4 * i + j] = t;
+        }
+      }
+      const float d = a[4 * i + i];
+      b[i] /= d;
+      for (int j = i; j < 4; j++) a[4 * i + j] /= d;
+      for (int k = i + 1; k < 4; k++) {
+        const float t = a[4 * k + i];
+        b[k] -= t * b[i];
+        for (int j = i + 1; j < 4; j++) a[4 * k + j] -= t * a[4 * i + j];
+      }
+    }
+    for (int i = 3; i >= 0; i--) {
+      p[i] = b[i];
+      for (int j = i + 1; j < 4; j++) p[i] -= a[4 * i + j] * p[j];
+    }
+  }
+  cx.sync();
+  XS_PAR(k, 0, 64) {
+    if (k < num_bands) {
+      float x = (float)k;
+      float slope = p[3];
+      slope = slope + p[2] * x;
+      x = x * x;
+      slope = slope + p[1] * x;
+      x = x * (float)k;
+      slope = slope + p[0] * x;
+      gain[k] = (float)xe_pow10((double)((*mean - slope) / 20.0f));
+    }
+  }
+  cx.sync();
+}
+
 /* HARM = false: a build without the harmonic branch (the kernel variant for batches without transposers: a frame with
    harmonic_sbr set is refused there) */
 template <bool HARM = true>
@@ -382,7 +463,7 @@ FX_HD void xe_generate_hf(const XsCx &cx, const xaac_sbr_header *h, const xaac_s
   }
   XS_ONE {
     w->err = 0;
-    if (!sd->harmonic_sbr) xe_build_patches(h, sd, st, w);
+    if (!(sd->harmonic_sbr & XAAC_ESBR_HARMONIC)) xe_build_patches(h, sd, st, w);
     else if (!HARM || !ph) w->err = -1; /* no transposer behind this channel */
   }
   XS_PAR(k, usb, 64)
@@ -391,12 +472,17 @@ FX_HD void xe_generate_hf(const XsCx &cx, const xaac_sbr_header *h, const xaac_s
       dst.i(l, k) = 0.0f;
     }
   if constexpr (HARM) {
-    if (sd->harmonic_sbr) {
+    if (sd->harmonic_sbr & XAAC_ESBR_HARMONIC) {
       cx.sync();
       if (w->err) return;
       xe_harmonic_patch(cx, h, st, w, dst, *ph, start, end, usb, num_if);
       return;
     }
+  }
+  const bool flatten = (sd->harmonic_sbr & XAAC_ESBR_PRE_FLATTEN) != 0;
+  if (flatten) {
+    cx.sync();
+    xe_pre_flatten(cx, w, src, lsb, start, end); /* (before the prediction coefficients, whose arrays it borrows) */
   }
   XS_PAR(k, 0, 64) {
     float a0r = 0, a0i = 0, a1r = 0, a1i = 0;
@@ -423,6 +509,7 @@ FX_HD void xe_generate_hf(const XsCx &cx, const xaac_sbr_header *h, const xaac_s
       bw *= bw;
       const float a1r = bw * w->alpha_r[k][1], a1i = bw * w->alpha_i[k][1];
       float r2 = src.r(start - 2, k), i2 = src.i(start - 2, k), r1 = src.r(start - 1, k), i1 = src.i(start - 1, k);
+      const float gain = flatten ? w->nrg_gain[k] : 1.0f; /* :1220-1224 */
       XE_NOUNROLL
       for (int l0 = start; l0 < end; l0 += XE_CH) {
         float cr[XE_CH] = {0}, ci[XE_CH] = {0};
@@ -431,10 +518,10 @@ FX_HD void xe_generate_hf(const XsCx &cx, const xaac_sbr_header *h, const xaac_s
         for (int j = 0; j < XE_CH; j++)
           if (l0 + j < end) {
             const float r0 = cr[j], i0 = ci[j];
-            float yr = r0 * 1.0f, yi = i0 * 1.0f;
+            float yr = r0 * gain, yi = i0 * gain;
             if (bw > 0.0f) {
-              yr += (a0r * r1 - a0i * i1 + a1r * r2 - a1i * i2) * 1.0f;
-              yi += (a0i * r1 + a0r * i1 + a1i * r2 + a1r * i2) * 1.0f;
+              yr += (a0r * r1 - a0i * i1 + a1r * r2 - a1i * i2) * gain;
+              yi += (a0i * r1 + a0r * i1 + a1i * r2 + a1r * i2) * gain;
             }
             cr[j] = yr;
             ci[j] = yi;
@@ -534,17 +621,17 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
   if (sd->reset_flag) {
     start_up = 1;
     phase_index = 0;
-    XS_ONE w->err = xe_limiter_bands(h, st, sd->harmonic_sbr != 0, x_over_qmf);
+    XS_ONE w->err = xe_limiter_bands(h, st, (sd->harmonic_sbr & XAAC_ESBR_HARMONIC) != 0, x_over_qmf);
     cx.sync();
     if (w->err) return -1;
   }
   {
-    const int mode = sd->harmonic_sbr ? 0 : 1; /* sbr_patching_mode; esbr_envcal.c:181-190 */
+    const int mode = (sd->harmonic_sbr & XAAC_ESBR_HARMONIC) ? 0 : 1; /* sbr_patching_mode; esbr_envcal.c:181-190 */
     const int changed = mode != st->prev_sbr_patching_mode;
     cx.sync();
     if (changed) {
       XS_ONE {
-        w->err = xe_limiter_bands(h, st, sd->harmonic_sbr != 0, x_over_qmf);
+        w->err = xe_limiter_bands(h, st, (sd->harmonic_sbr & XAAC_ESBR_HARMONIC) != 0, x_over_qmf);
         if (!w->err) st->prev_sbr_patching_mode = mode;
       }
       cx.sync();

@@ -268,7 +268,13 @@ def _struct_bytes(fn, size):
     return np.frombuffer(raw, np.uint8).copy()
 
 
-def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True, timing=None, overlap=True):
+# float offsets of members of struct xaac_esbr_state (include/xaac_esbr.h; tests/test_parser_esbr.py checks them against the
+# ctypes mirror of the header): qmf_re / qmf_im rows, and the transposer's last rows ph_re / ph_im
+_ES_QMF_RE, _ES_QMF_IM, _ES_PH_RE, _ES_PH_IM = 1604, 4164, 8479, 8991
+
+
+def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True, timing=None, overlap=True, esbr=False,
+                   _trace=None):
     """Decodes N ADTS streams of the same kind (all AAC-LC stereo, all HE-AAC stereo, or all HE-AAC / HE-AACv2 mono) in
     lock step: per step one frame of every stream is parsed on CPU threads into pinned staging arrays, copied to the GPU
     (spectra + window info, SBR / PS side info: nothing else crosses the bus on the way in), run through the GPU entry
@@ -276,7 +282,13 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
     -> (list of int16 [samples, channels] arrays, output sampling rate).  keep_pcm False: the PCM still comes back to the host
     every step but is not collected (throughput measurements); timing: a dict that receives seconds per stage.
     overlap: the host parses step k + 1 (a second set of staging arrays, a helper thread: the parser calls release the GIL)
-    while the GPU works on step k."""
+    while the GPU works on step k.
+    esbr: decode SBR streams the way the reference does with its default flags (-esbr:1, "Path A": the float eSBR tools of
+    xaac_esbr_sbr_process_batch with the QMF harmonic transposer and float parametric stereo; the SBR payload runs one
+    frame late, and the reference's command line decoder does not write the first frame's output,
+    test/decoder/ixheaacd_main.c:2181-2186) instead of -esbr:0.  AAC-LC streams decode
+    the same either way.  A stream whose SBR header changes after its first one is not supported in this mode (the
+    reset-time transposer runs, sbrdecoder.c:196-236, would need rows of the QMF history the device state does not keep)."""
     import time
     import torch
     lib = load_host_library()
@@ -284,8 +296,9 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
     own = ctx is None
     if own:   # the context launches on torch's current stream, so that its kernels and torch's copies stay in order
         ctx = XaacContext(dev.index or 0, torch.cuda.current_stream(dev).cuda_stream)
-    bp = BatchParser(streams, threads=threads)
+    bp = BatchParser(streams, threads=threads, esbr=esbr)
     n, n_ch, sbr, rate = bp.n, bp.n_ch, bp.sbr, bp.core_rate
+    esbr = bool(esbr) and sbr
     nc = n * n_ch
     t_parse = t_gpu = 0.0
 
@@ -303,7 +316,9 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
     class Staging:    # what one step's parse leaves for the GPU: pinned host arrays
         def __init__(self):
             self.spec, self.ics = pinned(nc, 1024, dtype=torch.int32), pinned(nc, 2)
-            self.hdr = self.frm = self.psf = self.flags = None
+            self.hdr = self.frm = self.psf = self.flags = self.eside = None
+            if esbr:
+                self.eside = pinned(nc, ESBR_SIDE_BYTES)
             if sbr:
                 self.hdr, self.frm = pinned(nc, SBR_HEADER_BYTES), pinned(nc, SBR_FRAME_BYTES)
                 self.flags = np.zeros((n, 8), np.int32)
@@ -313,7 +328,7 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
 
         def parse(self):
             t0 = time.perf_counter()
-            self.got = bp.step(self.spec, self.ics, self.hdr, self.frm, self.psf, self.flags)
+            self.got = bp.step(self.spec, self.ics, self.hdr, self.frm, self.psf, self.flags, self.eside)
             self.seconds = time.perf_counter() - t0
             return self
 
@@ -326,6 +341,22 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
         ws = dz(max(ctx.peak_limiter_workspace_bytes(n), 16))
         pcm = dz(n * 1024 * n_ch, dtype=torch.int16)
         pcm_h = pinned(n * 1024 * n_ch, dtype=torch.int16)
+    elif esbr:
+        # Path A: IMDCT (16-bit core PCM, one plane per channel) -> float -> the eSBR chain -> saturate / truncate to 16 bit
+        # (ixheaacd_samples_sat, decode_main.c:82-107); every state member stays on the device
+        state = torch.from_numpy(np.tile(_struct_bytes(lib.xaac_esbr_state_init, ESBR_STATE_BYTES), (nc, 1)).copy()).to(dev)
+        hbe = dz(nc, HBE_STATE_BYTES)
+        core16 = dz(nc * 1024, dtype=torch.int16)
+        hdr_d, frm_d, eside_d = dz(nc, SBR_HEADER_BYTES), dz(nc, SBR_FRAME_BYTES), dz(nc, ESBR_SIDE_BYTES)
+        status = dz(nc, dtype=torch.int32)
+        ws = dz(ctx.esbr_workspace_bytes(nc))
+        out_l, out_r = dz(nc, 2048, dtype=torch.float32), None
+        pcm_h = pinned(n * 2048 * 2, dtype=torch.int16)
+        if n_ch == 1:
+            ps_state = torch.from_numpy(np.tile(_struct_bytes(lib.xaac_esbr_ps_state_init, ESBR_PS_STATE_BYTES), (n, 1)).copy()).to(dev)
+            psf_d = dz(n, PS_FRAME_BYTES)
+            out_r = dz(n, 2048, dtype=torch.float32)
+        reset_seen = np.zeros(n, bool)
     else:
         state = torch.from_numpy(np.tile(_struct_bytes(lib.xaac_sbr_state_init, SBR_STATE_BYTES), (nc, 1)).copy()).to(dev)
         core16 = dz(nc * 1024, dtype=torch.int16)
@@ -372,6 +403,69 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
                 block = pcm_h.numpy().reshape(n, 1024, n_ch)
                 for i in np.nonzero(got)[0]:
                     out[i].append(block[i, delay:].copy() if first else block[i].copy())
+        elif esbr:
+            # (interleaved as the reference holds it: its in-place 32 -> 16 bit conversion of a pair leaves traces of channel
+            # 0 in channel 1, api.c:353-366, which the IMDCT's PCM_SBR hand-off restates for ch_fac 2)
+            ctx.imdct_process_batch(spec_d, ics_d, overlap_buf, ovl_state, pcm16=core16, ch_fac=n_ch, pcm_mode=PCM_SBR)
+            hdr_d.copy_(hdr_h, non_blocking=True)
+            frm_d.copy_(frm_h, non_blocking=True)
+            eside_d.copy_(cur.eside, non_blocking=True)
+            touched = np.nonzero(got & (flags[:, F_RESET] != 0))[0]
+            if touched.size:
+                # ixheaacd_sbr_dec_reset for Path A (sbrdecoder.c:175-236): new transposer parameters from the header's band
+                # tables, then two transposer runs over rows 8..39 and 24..55 of the QMF history.  At a stream's first
+                # reset the rows before 32 are zero and 32..55 are rows 0..23 of the state's history.
+                if reset_seen[touched].any():
+                    raise NotImplementedError("-esbr:1 decoding of a stream whose SBR header changes after the first")
+                reset_seen[touched] = True
+                k = touched.size * n_ch
+                rows_h = (touched[:, None] * n_ch + np.arange(n_ch)[None, :]).ravel()
+                hb_h = np.zeros((k, HBE_STATE_BYTES), np.uint8)
+                for j, r in enumerate(rows_h):
+                    if lib.xaac_hbe_state_reinit(hb_h[j].ctypes.data, hdr_h[int(r)].numpy().ctypes.data):
+                        raise RuntimeError("the QMF transposer refused the SBR band tables of stream %d" % (r // n_ch))
+                rows = torch.from_numpy(rows_h).to(dev)
+                hb = torch.from_numpy(hb_h).to(dev)
+                st32 = state.view(torch.float32)
+                q_re, q_im = dz(k, 32, 64, dtype=torch.float32), dz(k, 32, 64, dtype=torch.float32)
+                pv_re, pv_im = dz(k, 32, 64, dtype=torch.float32), dz(k, 32, 64, dtype=torch.float32)
+                rst = dz(k, dtype=torch.int32)
+                ctx.hbe_apply_batch(q_re, q_im, hb, pv_re, pv_im, status=rst)
+                hist = st32.index_select(0, rows)
+                q_re[:, 16:] = hist[:, _ES_QMF_RE + 8 * 64:_ES_QMF_RE + 24 * 64].view(k, 16, 64)
+                q_im[:, 16:] = hist[:, _ES_QMF_IM + 8 * 64:_ES_QMF_IM + 24 * 64].view(k, 16, 64)
+                pv_re.zero_(), pv_im.zero_()
+                ctx.hbe_apply_batch(q_re, q_im, hb, pv_re, pv_im, status=rst)
+                hist[:, _ES_PH_RE:_ES_PH_RE + 512] = pv_re[:, 24:].reshape(k, 512)
+                hist[:, _ES_PH_IM:_ES_PH_IM + 512] = pv_im[:, 24:].reshape(k, 512)
+                st32.index_copy_(0, rows, hist)
+                hbe.index_copy_(0, rows, hb)
+            core = core16.view(n, 1024, n_ch).transpose(1, 2).to(torch.float32).contiguous().view(nc, 1024)
+            if _trace is not None:   # debugging: the device states in front of the chain call
+                _trace(dict(state=state, hbe=hbe, ps_state=ps_state if n_ch == 1 else None, core=core, side=eside_d, header=hdr_d,
+                            frame=frm_d))
+            with_ps = (flags[got, F_PS] != 0) if n_ch == 1 else np.zeros(1, bool)
+            if with_ps.any() != with_ps.all():
+                raise NotImplementedError("a batch mixing PS and non-PS frames")
+            if with_ps.all():
+                psf_d.copy_(psf_h, non_blocking=True)
+                ctx.esbr_sbr_process_batch(core, hdr_d, frm_d, eside_d, state, out_l, ws, status=status, ps_frame=psf_d,
+                                           ps_state=ps_state, out_r=out_r, hbe_state=hbe)
+                both = torch.stack((out_l, out_r), dim=2)                                   # [n, 2048, 2]
+            elif n_ch == 1:
+                ctx.esbr_sbr_process_batch(core, hdr_d, frm_d, eside_d, state, out_l, ws, status=status, hbe_state=hbe)
+                both = out_l.view(n, 2048, 1).expand(n, 2048, 2)                            # mono twice (api.c:3639-3660)
+            else:
+                ctx.esbr_sbr_process_batch(core, hdr_d, frm_d, eside_d, state, out_l, ws, status=status, hbe_state=hbe)
+                both = out_l.view(n, 2, 2048).transpose(1, 2)
+            pcm_h.copy_(both.clamp(-32768.0, 32767.0).to(torch.int16).reshape(-1), non_blocking=True)
+            bad = int(status.min().item())    # also the step's synchronisation point
+            if bad < 0:
+                raise RuntimeError("the eSBR kernels refused a frame")
+            if keep_pcm and not first:        # the first frame's output is not written in this mode
+                block = pcm_h.numpy().reshape(n, 2048, 2)
+                for i in np.nonzero(got)[0]:
+                    out[i].append(block[i].copy())
         else:
             ctx.imdct_process_batch(spec_d, ics_d, overlap_buf, ovl_state, pcm16=core16, ch_fac=n_ch, pcm_mode=PCM_SBR)
             # frames that reset the SBR decoder or fall back to plain up-sampling change a few words of the resident state

@@ -766,9 +766,9 @@ int read_ps(XsPs *ps, XhBits *br, int bits_left) {
 }
 
 /* :595-714: the ENHSBR extension of one element: patching mode, over-sampling flag, pitch; returns the bits it took */
-int read_enh(XhBits *br, XsFrameData *f, int cpe) {
+int read_enh(XhBits *br, XsFrameData *f, int cpe, int *pre_flatten) {
   int bits = 1;
-  br->get(1); /* pre-flattening flag: a USAC tool, read and not used for AAC-LC cores */
+  *pre_flatten = br->get1(); /* header pre_proc_flag: stays until the next ENHSBR element (:602) */
   auto one = [&](XsFrameData *a, XsFrameData *b) {
     const int mode = br->get1();
     bits += 1;
@@ -811,7 +811,7 @@ int read_extension(XsHeader *h, XsPs *ps, XhBits *br, XsFrameData *f = nullptr, 
     if (id == 3 && !enh) id = -1; /* EXTENSION_ID_ENHSBR_CODING without the eSBR tools */
     left -= 2;
     if (id == 3) {
-      left -= read_enh(br, f, cpe);
+      left -= read_enh(br, f, cpe, &h->pre_flatten);
       continue;
     }
     if (id == 2) { /* EXTENSION_ID_PS_CODING */
@@ -1430,7 +1430,8 @@ int xs_decode_frame(XsDecoder *d, const uint8_t *payload, int bytes, int ext_typ
         if (!err) {
           for (int lr = 0; lr < lr1; lr++) {
             d->fd[lr].reset_flag = 1;
-            if (h->sync_state == XS_NOT_INITIALIZED) d->fd[lr].patching_mode = 1, d->fd[lr].over_sampling = 0, d->fd[lr].pitch_in_bins = 0;
+            if (h->sync_state == XS_NOT_INITIALIZED)
+              d->fd[lr].patching_mode = 1, d->fd[lr].over_sampling = 0, d->fd[lr].pitch_in_bins = 0, h->pre_flatten = 0;
           }
           int e2 = reset_hf_generator(h);
           if (e2 < 0) return -1;
@@ -1505,7 +1506,7 @@ void xs_export_esbr_side(const XsDecoder *d, int c, xaac_esbr_side *o) { /* orac
   memcpy(o->f_master_tbl, h->f_master, sizeof(o->f_master_tbl));
   o->qmf_sb_prev = (int16_t)d->qmf_sb_prev_frame;
   o->reset_flag = (int16_t)f->reset_flag_frame;
-  o->harmonic_sbr = f->patching_mode == 0;
+  o->harmonic_sbr = (int16_t)((f->patching_mode == 0 ? XAAC_ESBR_HARMONIC : 0) | (h->pre_flatten ? XAAC_ESBR_PRE_FLATTEN : 0));
   memcpy(o->sbr_invf_mode_prev, f->invf_mode_prev, sizeof(o->sbr_invf_mode_prev));
   memcpy(o->flt_env_sf_arr, f->flt_env_sf, sizeof(o->flt_env_sf_arr));
   memcpy(o->flt_noise_floor, f->flt_noise_floor, sizeof(o->flt_noise_floor));

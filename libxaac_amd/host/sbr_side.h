@@ -55,6 +55,7 @@ struct XsHeader { /* ia_sbr_header_data_struct + ia_freq_band_data_struct + ia_t
   int channel_mode, amp_res, start_freq, stop_freq, xover_band, freq_scale, alter_scale, noise_bands;
   int limiter_bands, limiter_gains, interpol_freq, smoothing_mode;
   int out_sampling_freq;
+  int pre_flatten;         /* pre_proc_flag: the last ENHSBR element asked for pre-flattened LPP patches (env_extr.c:602) */
   int16_t num_sf_bands[2], num_nf_bands, num_mf_bands, sub_band_start, sub_band_end, num_lf_bands, num_if_bands;
   int16_t f_master[XAAC_SBR_MAX_FREQ_COEFFS + 1];
   int16_t tbl_lim[XAAC_SBR_MAX_LIMITERS + 1], tbl_lo[XAAC_SBR_MAX_FREQ_COEFFS / 2 + 1], tbl_hi[XAAC_SBR_MAX_FREQ_COEFFS + 1];

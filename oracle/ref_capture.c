@@ -79,7 +79,7 @@ static int esbr_path(const ia_sbr_dec_struct *d, const ia_sbr_header_data_struct
          (h->channel_mode == PS_STEREO ? (ps != NULL && synth_r != NULL && !ps->use_34_st_bands && !ps->use_pca_rot_flg && ps->ps_mode == 0)
                                        : !h->enh_sbr_ps) &&
          !drc_on && !ldmps && !mps && !f->mps_sbr_flag && f->sbr_mode != PVC_SBR && h->sbr_ratio_idx != SBR_UPSAMPLE_IDX_4_1 &&
-         !h->pre_proc_flag && h->num_time_slots == 16 && d->str_codec_qmf_bank.no_channels == 32 &&
+         h->num_time_slots == 16 && d->str_codec_qmf_bank.no_channels == 32 &&
          d->str_synthesis_qmf_bank.no_channels == 64;
 }
 static WORD32 esbr_chain_call(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_header_data_struct *h,
@@ -166,6 +166,7 @@ static WORD32 esbr_chain_call(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_he
       f->sbr_patching_mode = (WORD32)rnd(2);
       f->pitch_in_bins = f->sbr_patching_mode == 0 && rnd(2) ? (WORD32)rnd(128) : 0;
     }
+    if (rnd(3) == 0) h->pre_proc_flag = (WORD16)rnd(2); /* the ENHSBR element's pre-flattening flag (env_extr.c:602) */
     if (steps[c] > 2 && rnd(9) == 0) f->reset_flag = 1;
     if (eps && rnd(3) != 0) { /* PS: quantiser, 1..4 envelopes with random borders, random IID / ICC indices */
       int nenv = 1 + (int)rnd(4), lim, b, e;
@@ -308,7 +309,7 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     fwrite(m, sizeof(m), 1, fs), fwrite(&hd, sizeof(hd), 1, fs), fwrite(&fr, sizeof(fr), 1, fs), fwrite(&es, sizeof(es), 1, fs);
     fwrite(&psf, sizeof(psf), 1, fs), fwrite(par, sizeof(par), 1, fs);
     fflush(fs);
-    if (getenv("XAAC_ESBR_INIT_FILE") && m[1] < 2) { /* what the first calls find in the Path A state: a new stream's values
+    if (getenv("XAAC_ESBR_INIT_FILE") && (m[1] < 2 || getenv("XAAC_ESBR_INIT_ALL"))) { /* _ALL: every call (debugging) */ /* what the first calls find in the Path A state: a new stream's values
          (esbr state, hbe state, esbr PS state: the checker of xaac_esbr_stream_init) */
       static xaac_esbr_state est;
       static xaac_esbr_ps_state epss;
@@ -325,6 +326,7 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
         to_esbr_ps_state(ps, synth_r, &epss);
       }
       fwrite(&est, sizeof(est), 1, fi), fwrite(&hb, sizeof(hb), 1, fi), fwrite(&epss, sizeof(epss), 1, fi);
+      if (getenv("XAAC_ESBR_INIT_ALL")) fwrite(d->time_sample_buf, sizeof(FLOAT32), 1024, fi); /* ... and the core input */
       fclose(fi);
     }
     return __real_ixheaacd_sbr_dec(d, time_data, h, f, p, ps, synth_r, sf_r, apply, low_pow, work, tabs, common, ch_fac, pvc, drc_on,

@@ -299,7 +299,7 @@ static void to_esbr_side(const ia_sbr_header_data_struct *h, const ia_sbr_frame_
   for (i = 0; i < XAAC_SBR_MAX_ENVELOPES; i++) o->inter_temp_shape_mode[i] = f->inter_temp_shape_mode[i];
   memcpy(o->flt_env_sf_arr, f->flt_env_sf_arr, sizeof(o->flt_env_sf_arr));
   memcpy(o->flt_noise_floor, f->flt_noise_floor, sizeof(o->flt_noise_floor));
-  o->harmonic_sbr = f->sbr_patching_mode == 0;
+  o->harmonic_sbr = (int16_t)((f->sbr_patching_mode == 0 ? XAAC_ESBR_HARMONIC : 0) | (h->pre_proc_flag ? XAAC_ESBR_PRE_FLATTEN : 0));
   o->pitch_in_bins = f->pitch_in_bins;
 }
 

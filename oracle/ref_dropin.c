@@ -438,7 +438,7 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
       (h->channel_mode == PS_STEREO ? (ps != NULL && synth_r != NULL && !ps->use_34_st_bands && !ps->use_pca_rot_flg && ps->ps_mode == 0)
                                     : !h->enh_sbr_ps) &&
       !drc_on && !ldmps && !mps && !f->mps_sbr_flag && f->sbr_mode != PVC_SBR &&
-      h->sbr_ratio_idx != SBR_UPSAMPLE_IDX_4_1 && (!h->pre_proc_flag || f->sbr_patching_mode == 0) && h->num_time_slots == 16 &&
+      h->sbr_ratio_idx != SBR_UPSAMPLE_IDX_4_1 && h->num_time_slots == 16 &&
       d->str_codec_qmf_bank.no_channels == 32 && d->str_synthesis_qmf_bank.no_channels == 64 && !getenv("XAAC_DROPIN_NO_ESBR")) {
     static xaac_esbr_side sd;
     static xaac_esbr_state est;

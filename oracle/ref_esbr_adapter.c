@@ -67,7 +67,8 @@ int ref_esbr_hf_env_h(const xaac_sbr_header *h, const xaac_sbr_frame *f, const x
   for (i = 0; i < XAAC_SBR_MAX_ENV_VALUES; i++) fd.flt_env_sf_arr[i] = sd->flt_env_sf_arr[i];
   for (i = 0; i < XAAC_SBR_MAX_ENVELOPES; i++) fd.inter_temp_shape_mode[i] = sd->inter_temp_shape_mode[i];
   fd.env_short_flag_prev = st->env_short_flag_prev;
-  fd.sbr_patching_mode = sd->harmonic_sbr ? 0 : 1;
+  fd.sbr_patching_mode = (sd->harmonic_sbr & XAAC_ESBR_HARMONIC) ? 0 : 1;
+  hd.pre_proc_flag = (sd->harmonic_sbr & XAAC_ESBR_PRE_FLATTEN) != 0;
   fd.prev_sbr_patching_mode = st->prev_sbr_patching_mode;
   fd.pitch_in_bins = sd->pitch_in_bins;
   hd.hbe_flag = ph_re != NULL;

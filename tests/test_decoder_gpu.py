@@ -20,11 +20,11 @@ GOLD_ORDER = ["mix_aot2_64k", "mix_aot5_48k", "mono_aot5_32k", "harm_aot5_48k", 
 pytestmark = pytest.mark.gpu
 
 
-def reference_pcm(name, tmp_path):
+def reference_pcm(name, tmp_path, flags=("-esbr:0",)):
     if not os.path.exists(XAACDEC):
         pytest.fail("oracle/_ref/xaacdec missing: run __graft_entry__.build() where /root/reference exists")
     out = str(tmp_path / (name + ".wav"))
-    subprocess.run([XAACDEC, "-ifile:" + os.path.join(STREAMS, name + ".aac"), "-ofile:" + out, "-esbr:0"], check=True,
+    subprocess.run([XAACDEC, "-ifile:" + os.path.join(STREAMS, name + ".aac"), "-ofile:" + out] + list(flags), check=True,
                    capture_output=True)
     with wave.open(out) as w:
         assert w.getsampwidth() == 2
@@ -41,6 +41,31 @@ def test_stream_equals_reference_decoder(name, tmp_path):
     assert got[0].shape == want.shape, (got[0].shape, want.shape)
     bad = np.nonzero(np.any(got[0] != want, axis=1))[0]
     assert bad.size == 0, "first differing sample %d of %d" % (bad[0], len(want))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_stream_equals_reference_decoder_with_its_default_flags(name, tmp_path):
+    """-esbr:1, the reference's default: SBR streams through Path A (float eSBR tools, QMF transposer, float PS)"""
+    from libxaac_amd import decoder
+    want, rate = reference_pcm(name, tmp_path, flags=())
+    data = open(os.path.join(STREAMS, name + ".aac"), "rb").read()
+    got, got_rate = decoder.decode_streams([data], esbr=True)
+    assert got_rate == rate
+    assert got[0].shape == want.shape, (got[0].shape, want.shape)
+    bad = np.nonzero(np.any(got[0] != want, axis=1))[0]
+    assert bad.size == 0, "first differing sample %d of %d" % (bad[0], len(want))
+
+
+def test_esbr_streams_against_committed_crcs_and_in_batches():
+    from libxaac_amd import decoder
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "decoder_ref.npz"))
+    for name in ("mix_aot5_48k", "mono_aot5_32k", "harm_aot5_48k", "mix_aot29_32k"):
+        k = GOLD_ORDER.index(name)
+        data = open(os.path.join(STREAMS, name + ".aac"), "rb").read()
+        got, rate = decoder.decode_streams([data] * 3, esbr=True)
+        for g in got:
+            assert (len(g), rate) == (int(gold["samples_esbr"][k]), int(gold["rate"][k])), name
+            assert zlib.crc32(np.ascontiguousarray(g).tobytes()) & 0xffffffff == int(gold["crc_esbr"][k]), name
 
 
 def test_streams_against_committed_crcs():

@@ -65,7 +65,8 @@ def test_fixture_is_what_it_says():
     harm = CH["side"].view(np.int16)[:, EsbrSide.harmonic_sbr.offset // 2]
     pitch = CH["side"].view(np.int32)[:, EsbrSide.pitch_in_bins.offset // 4]
     proc = CH["apply"] != 0
-    assert (harm[proc] != 0).sum() > 300 and ((harm != 0) & (pitch != 0) & proc).sum() > 100
+    assert ((harm[proc] & 1) != 0).sum() > 300 and (((harm & 1) != 0) & (pitch != 0) & proc).sum() > 100
+    assert (harm[proc] == 2).sum() > 300     # XAAC_ESBR_PRE_FLATTEN on frames with LPP patches
     assert (CH["chain_ps"] != 0).sum() >= 4
 
 

@@ -81,7 +81,7 @@ def run_chain(oracle, reference, recs, seed, xover_extra=0, tes=False, n_frames=
     prev_modes = [0] * 10
     prev_tables = None
     start = int(rng.integers(0, max(1, len(recs) - n_frames)))
-    done = 0
+    done = flattened = 0
     for n, rec in enumerate(recs[start:start + n_frames]):
         h, f = c.Header.from_buffer_copy(bytes(rec["header"])), c.Frame.from_buffer_copy(bytes(rec["frame"]))
         if not f.apply_processing:
@@ -109,6 +109,9 @@ def run_chain(oracle, reference, recs, seed, xover_extra=0, tes=False, n_frames=
             ph[0][:, 40] += np.float32(lvl * 6) * np.cos(np.arange(40) * 1.1).astype(np.float32)
             sb = h.sub_band_start
             xo = (ctypes.c_int32 * 6)(sb, min(64, 2 * sb), min(64, 3 * sb) if rng.integers(0, 2) else 0, 0, 0, 0)
+        if rng.integers(0, 3) == 0:                   # the ENHSBR element's pre-flattening flag (acts on LPP patches)
+            sd.harmonic_sbr |= 2
+            flattened += int(not (sd.harmonic_sbr & 1) and f.apply_processing != 0)
         for fn, st in (((ref_h if harmonic else ref_fn), st_r), ((orc_h if harmonic else orc_fn), st_o)):
             ore, oim = np.zeros((72, 64), np.float32), np.zeros((72, 64), np.float32)
             a, b = qre.copy(), qim.copy()
@@ -136,7 +139,7 @@ def run_chain(oracle, reference, recs, seed, xover_extra=0, tes=False, n_frames=
         assert np.any(ore_r[2:34, h.sub_band_start:h.sub_band_end] != 0)
         prev_modes = [f.sbr_invf_mode[i] for i in range(10)]
         done += 1
-    assert done >= n_frames // 2
+    assert done >= n_frames // 2 and (flattened > 0 or harmonic)
 
 
 @pytest.fixture(scope="module")

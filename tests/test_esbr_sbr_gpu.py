@@ -203,7 +203,9 @@ def test_chain_with_harmonic_transposer_vs_oracle(oracle):
             prev_tables[ch] = tables
             sd.harmonic_sbr = int(ch % 3 != 0 and rng.integers(0, 4) != 0)
             sd.pitch_in_bins = int(rng.choice([0, 0, 14, 30, 77])) if sd.harmonic_sbr else 0
-            harmonic_frames += sd.harmonic_sbr and f.apply_processing
+            if rng.integers(0, 3) == 0:
+                sd.harmonic_sbr |= 2     # XAAC_ESBR_PRE_FLATTEN: LPP patches of this frame are pre-flattened
+            harmonic_frames += (sd.harmonic_sbr & 1) and f.apply_processing
             hs.append(h), fs.append(f), sds.append(sd)
             prev_modes[ch] = [f.sbr_invf_mode[i] for i in range(10)]
         if hb_g is None:

@@ -5,7 +5,7 @@ parametric stereo, synthesis) as CHAINS whose state the reference carries itself
 
 oracle/_ref/xaacdec_capture (oracle/ref_capture.c: esbr_chain_call) decodes the committed HE-AAC streams several times;
 at every eSBR call it fuzzes the reference's own live side info within what a bitstream can say (limiter gains / bands,
-interpolation, smoothing, inverse-filter modes, added harmonics, inter-TES, harmonic patching with and without a pitch,
+pre-flattening, interpolation, smoothing, inverse-filter modes, added harmonics, inter-TES, harmonic patching with and without a pitch,
 resets, PS quantiser / 1-4 envelopes / IID / ICC indices), replaces the core input by a counter-based synthetic frame
 (chain_core() below regenerates it: nothing is stored), runs the real function and writes the step in the boundary
 formats of include/xaac_esbr.h: side info, return code, CRC32s of out / out_r and of the three states after the call.
@@ -22,10 +22,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from make_golden_sbr_chains import chain_pcm  # noqa: E402
 
-# (harm_aot5_48k.aac is left to tests/test_dropin_gpu.py: the reference's outer layers re-initialise that stream's banks and
-# transposer between almost all calls, so it yields chains of one or two steps; harmonic patching and inter-TES come
-# from the fuzz here)
-STREAMS = ("mix_aot5_48k", "mono_aot5_32k", "mix_aot29_32k")
+# (harm_aot5_48k.aac carries ENHSBR elements of its own: harmonic patching and pre-flattened LPP frames; the fuzz adds them
+# to the other streams, with inter-TES)
+STREAMS = ("mix_aot5_48k", "mono_aot5_32k", "mix_aot29_32k", "harm_aot5_48k")
 PASSES = 10           # decoder runs per stream; pass 0 is unfuzzed
 
 
@@ -107,8 +106,9 @@ def main():
     np.savez_compressed(dst, **d)
     from esbr_structs import EsbrSide
     harm = sum(1 for r in recs if r["apply"] and np.frombuffer(r["sd"], np.int16)[EsbrSide.harmonic_sbr.offset // 2] != 0)
+    flat = sum(1 for r in recs if r["apply"] and np.frombuffer(r["sd"], np.int16)[EsbrSide.harmonic_sbr.offset // 2] == 2)
     print(dst, os.path.getsize(dst), "bytes;", n, "steps in", nc, "chains;", int(d["ret"].astype(bool).sum()), "steps returned an error;",
-          int(d["apply"].sum()), "processed;", harm, "with harmonic patching")
+          int(d["apply"].sum()), "processed;", harm, "with harmonic patching or the pre-flattening flag;", flat, "with pre-flattened LPP patches")
 
 
 if __name__ == "__main__":
