@@ -103,12 +103,14 @@ FX_HD void xe_shellsort(int32_t *in, int n) { /* esbr_envcal.c:48: any sort give
 }
 /* x_over_qmf: the harmonic transposer's cross-over bands, or NULL; with harmonic patching they are the patch borders
    (esbr_envcal.c:929-941) */
-FX_HD int xe_limiter_bands(const xaac_sbr_header *h, xaac_esbr_state *st, int harmonic, const int32_t *x_over_qmf) {
+/* tmp: 48 words of work space (the sorted band list and the patch borders: indexed at run time, so in the caller's
+   shared memory, not in a lane's registers) */
+FX_HD int xe_limiter_bands(const xaac_sbr_header *h, xaac_esbr_state *st, int harmonic, const int32_t *x_over_qmf, int32_t *tmp) {
   const int nb = h->num_sf_bands[0];
   const int16_t *tbl = h->freq_band_tbl_lo;
   const int sb_start = tbl[0], sb_end = tbl[nb];
   int num_patches = st->num_patches;
-  int32_t patch_borders[XAAC_SBR_MAX_PATCHES + 2], t[32 + XAAC_SBR_MAX_PATCHES + 1];
+  int32_t *patch_borders = tmp /* [XAAC_SBR_MAX_PATCHES + 2] */, *t = tmp + XAAC_SBR_MAX_PATCHES + 2 /* [32 + XAAC_SBR_MAX_PATCHES + 1] */;
   int i;
   if (harmonic && x_over_qmf) {
     num_patches = 0;
@@ -311,8 +313,9 @@ FX_HD void xe_covar_alpha(const XeMat &src, int k, float &a0r, float &a0i, float
 #endif
 /* sbrdec_lpfuncs.c:1251-1352, harmonic patching: every high band is the transposer's band, inverse-filtered with its own
    prediction coefficients */
-XE_NOINLINE FX_HD void xe_harmonic_patch(const XsCx &cx, const xaac_sbr_header *h, xaac_esbr_state *st, XeWork *w,
-                                         const XeMat &dst, const XeMat &ph, int start, int end, int usb, int num_if) {
+XE_NOINLINE FX_HD void xe_harmonic_patch(const XsCx cx, const xaac_sbr_header *h, xaac_esbr_state *st, XeWork *w,
+                                         const XeMat dst, const XeMat ph, int start, int end, int usb, int num_if) {
+  /* (cx, dst, ph by value: a reference to a caller's object would put it on the stack of this out-of-line call) */
   /* sbrdec_lpfuncs.c:1251-1344: every high band is the transposer's band, inverse-filtered with its own prediction
      coefficients; the chirp factor by the noise-floor band the band lies in (a running index in the reference, which
      gives up at the table's fifth entry) */
@@ -366,7 +369,7 @@ XE_NOINLINE FX_HD void xe_harmonic_patch(const XsCx &cx, const xaac_sbr_header *
    to it over the band index (ixheaacd_polyfit :898, normal equations solved by ixheaacd_gausssolve :850 with partial
    pivoting -- all in single precision, restated operation by operation), and per band the gain that brings the fitted
    curve to the mean level.  Gains -> w->nrg_gain[0 .. num_bands); w->nrg_est, w->alpha_r are scratch here. */
-XE_NOINLINE FX_HD void xe_pre_flatten(const XsCx &cx, XeWork *w, const XeMat &src, int num_bands, int start, int end) {
+XE_NOINLINE FX_HD void xe_pre_flatten(const XsCx cx, XeWork *w, const XeMat src, int num_bands, int start, int end) {
   float *low_env = w->nrg_est, *gain = w->nrg_gain;
   float *a = &w->alpha_r[0][0], *b = a + 16, *v = b + 4, *p = v + 7, *mean = p + 4; /* a[4][4] b[4] v[7] p[4] mean */
   XS_PAR(k, 0, 64) {
@@ -621,7 +624,7 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
   if (sd->reset_flag) {
     start_up = 1;
     phase_index = 0;
-    XS_ONE w->err = xe_limiter_bands(h, st, (sd->harmonic_sbr & XAAC_ESBR_HARMONIC) != 0, x_over_qmf);
+    XS_ONE w->err = xe_limiter_bands(h, st, (sd->harmonic_sbr & XAAC_ESBR_HARMONIC) != 0, x_over_qmf, reinterpret_cast<int32_t *>(w->pow_lo));
     cx.sync();
     if (w->err) return -1;
   }
@@ -631,7 +634,7 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
     cx.sync();
     if (changed) {
       XS_ONE {
-        w->err = xe_limiter_bands(h, st, (sd->harmonic_sbr & XAAC_ESBR_HARMONIC) != 0, x_over_qmf);
+        w->err = xe_limiter_bands(h, st, (sd->harmonic_sbr & XAAC_ESBR_HARMONIC) != 0, x_over_qmf, reinterpret_cast<int32_t *>(w->pow_lo));
         if (!w->err) st->prev_sbr_patching_mode = mode;
       }
       cx.sync();

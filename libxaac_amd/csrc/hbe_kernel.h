@@ -8,33 +8,30 @@
 #include "../../include/xaac_esbr.h"
 #include "../../include/xaac_hbe.h"
 
-#define XAAC_HBE_SYN_LDS (41 * 40 * 4) /* v of 9 + 32 columns */
-#define XAAC_HBE_ANA_LDS ((16 * 80 + 16 * 80) * 4) /* u and results of 16 columns (the transforms' scratch is private) */
+/* the two polyphase banks (hbe_kernel.hip: xaac_hbe_banks_kernel) */
+#define XAAC_HBE_BANKS_THREADS 256
+#define XAAC_HBE_PHASE_SYNTH 1
+#define XAAC_HBE_PHASE_ANAL 2
+#define XAAC_HBE_T_FLOATS 660 /* the time signal of 32 + 1 columns of at most 20 samples */
+/* LDS: T, then the larger of the synthesis phase's (v of 9 + 32 columns, the columns' inputs, transform work space) and the
+   analysis phase's (u and results of 16 columns, transform work space) */
+#define XAAC_HBE_BANKS_LDS ((XAAC_HBE_T_FLOATS + (2 * 16 * 80 + 16 * 192 > 41 * 40 + 32 * 20 + 32 * 96 ? 2 * 16 * 80 + 16 * 192 : 41 * 40 + 32 * 20 + 32 * 96)) * 4)
 
-typedef struct XaacHbeSynParams {
-  int32_t n_ch, num_columns;
-  const float *qmf_re, *qmf_im; /* [n_ch][num_columns][64] */
+typedef struct XaacHbeBanksParams {
+  int32_t n_ch, num_columns;    /* num_columns: of the synthesis phase (32 in the apply chain) */
+  const float *qmf_re, *qmf_im; /* [n_ch][num_columns][64] (synthesis phase) */
   xaac_hbe_state *state;        /* [n_ch] */
   int32_t *status;              /* [n_ch] or NULL */
   const int32_t *pitch;         /* apply mode: [n_ch] or NULL */
-  int32_t apply;                /* 1: as the first step of ixheaacd_qmf_hbe_apply (time-signal shift, the re-initialisation
-                                   while fft_ready is 0, the frame's parameter check) */
+  int32_t apply;                /* 1: as the first steps of ixheaacd_qmf_hbe_apply (time-signal shift, the re-initialisation
+                                   while fft_ready is 0, the frame's parameter check, qmf_in_buf rows moved down) */
   /* inside the Path A chain (xaac_esbr_sbr_process_batch): the pitch comes from the side info and a channel whose
      frame has no SBR processing is skipped (sbr_dec.c:882); NULL elsewhere */
   const xaac_sbr_frame *frame;
   const xaac_esbr_side *side;
   int32_t in_stride;            /* floats between consecutive channels' qmf rows (2048 unless the chain hands in its own) */
-} XaacHbeSynParams;
-
-typedef struct XaacHbeAnaParams {
-  int32_t n_ch;
-  xaac_hbe_state *state;
-  int32_t *status;
-  const int32_t *pitch;
-  int32_t apply;                /* 1: second step of the apply chain (qmf_in_buf rows moved down first) */
-  const xaac_sbr_frame *frame;  /* as in XaacHbeSynParams */
-  const xaac_esbr_side *side;
-} XaacHbeAnaParams;
+  int32_t phases;               /* XAAC_HBE_PHASE_SYNTH | XAAC_HBE_PHASE_ANAL */
+} XaacHbeBanksParams;
 
 #define XAAC_HBE_POST_THREADS 256
 #define XAAC_HBE_POST_LDS (256 * 25 * 4 + 5 * 16 * 32 * 8) /* the blocks (+ cross terms) of 16 bands x 16 columns; five planes of normalised samples */
@@ -43,7 +40,7 @@ typedef struct XaacHbePostParams {
   xaac_hbe_state *state;
   const int32_t *pitch;
   float *pv_re, *pv_im;         /* [n_ch][32][64] */
-  const xaac_sbr_frame *frame;  /* as in XaacHbeSynParams */
+  const xaac_sbr_frame *frame;  /* as in XaacHbeBanksParams */
   const xaac_esbr_side *side;
   int32_t pv_stride;            /* floats between consecutive channels' output rows (2048 standalone) */
   int32_t zero_outside;         /* 1: bands outside start_band .. end_band - 1 of the 32 rows are written as zeros (the chain's
@@ -66,8 +63,7 @@ typedef struct XaacHbeDftParams {
 extern "C" {
 #endif
 hipError_t xaac_launch_hbe_dft_anal(const XaacHbeDftParams *p, hipStream_t stream);
-hipError_t xaac_launch_hbe_synth(const XaacHbeSynParams *p, hipStream_t stream);
-hipError_t xaac_launch_hbe_anal(const XaacHbeAnaParams *p, hipStream_t stream);
+hipError_t xaac_launch_hbe_banks(const XaacHbeBanksParams *p, hipStream_t stream);
 hipError_t xaac_launch_hbe_post(const XaacHbePostParams *p, hipStream_t stream);
 #ifdef __cplusplus
 }

@@ -26,81 +26,120 @@ __device__ __forceinline__ int hbe_pitch(const int32_t *pitch, const xaac_esbr_s
 __device__ __forceinline__ bool hbe_skip(const xaac_sbr_frame *frame, int ch) { return frame && !frame[ch].apply_processing; }
 }  // namespace
 
-__global__ __launch_bounds__(64) void xaac_hbe_synth_kernel(XaacHbeSynParams p) {
-  extern __shared__ float lds[];
-  float(*vv)[40] = reinterpret_cast<float(*)[40]>(lds); /* [9 + 32][2 s <= 40] */
-  const int ch = blockIdx.x, lane = threadIdx.x;
-  xaac_hbe_state *st = p.state + ch;
-  if (hbe_skip(p.frame, ch)) return;
-  const int s = st->synth_size, ks = st->k_start, nc = p.num_columns;
-  const bool bad = p.apply ? !xh_apply_params_ok(st, hbe_pitch(p.pitch, p.side, ch))
-                           : (!xh_size_ok(s) || ks < 0 || ks + s > 64 || ks * 32 + 2 * s > 7 * 64 || nc < 0 || nc > 32);
-  if (lane == 0 && p.status) p.status[ch] = bad ? -1 : 0;
-  if (bad) return;
-  /* apply mode, hbe_trans.c:235-248: the last synth_size samples of the previous frame's time signal move to the
-     front; while the reference's FFT pointers are unset it re-initialises, which clears both delay lines */
-  const bool cleared = p.apply && !st->fft_ready;
-  float carry = 0.0f;
-  if (p.apply && lane < s) carry = st->input_buf[nc * s + lane];
-  if (cleared) {
-    for (int e = lane; e < 640; e += 64) st->analy_buf[e] = 0.0f;
-    for (int e = 20 * s + lane; e < 1280; e += 64) st->synth_buf[e] = 0.0f;
-  }
-  for (int e = lane; e < 9 * 2 * s; e += 64) {
-    const int c = -1 - e / (2 * s), t = e % (2 * s);
-    vv[c + 9][t] = cleared ? 0.0f : xh_synth_hist(st->synth_buf, s, c, t);
-  }
-  if (lane < nc) {
-    float w[XH_SYNTH_SCRATCH]; /* private: see the analysis kernel */
-    xh_synth_column(p.qmf_re + (size_t)ch * p.in_stride + lane * 64, p.qmf_im + (size_t)ch * p.in_stride + lane * 64, s, ks,
-                    vv[lane + 9], w);
-  }
-  __syncthreads();
-  const auto at = [&](int c, int t) { return vv[c + 9][t]; };
-  for (int o = lane; o < nc * s; o += 64) st->input_buf[s + o] = xh_synth_out(at, s, o / s, o % s);
-  if (p.apply && lane < s) st->input_buf[lane] = carry;
-  for (int e = lane; e < 20 * s; e += 64) {
-    const int c = nc - 1 - e / (2 * s);
-    st->synth_buf[e] = vv[c + 9][e % (2 * s)]; /* nc >= 1: columns nc - 10 .. nc - 1 >= -9 */
-  }
-}
+namespace {
+struct XhWaveTeam { /* the channel's workgroup as the team of hbe_poly.h's cooperative routines */
+  int lane, n;
+  __device__ __forceinline__ void sync() const { __syncthreads(); }
+};
+}  // namespace
 
-__global__ __launch_bounds__(64) void xaac_hbe_anal_kernel(XaacHbeAnaParams p) {
-  extern __shared__ float lds[];
-  float(*u)[80] = reinterpret_cast<float(*)[80]>(lds);            /* [16][2 a <= 80] */
-  float(*res)[80] = reinterpret_cast<float(*)[80]>(lds + 16 * 80); /* [16][2 a <= 80] */
-  const int ch = blockIdx.x, lane = threadIdx.x;
-  xaac_hbe_state *st = p.state + ch;
-  if (hbe_skip(p.frame, ch)) return;
-  const int s = st->synth_size, ks = st->k_start, a = 2 * s;
-  const bool bad = p.apply ? !xh_apply_params_ok(st, hbe_pitch(p.pitch, p.side, ch)) : (!xh_size_ok(s) || ks < 0 || 4 * ks + 2 * a > 128);
-  if (lane == 0 && p.status && !p.apply) p.status[ch] = bad ? -1 : 0;
-  if (bad) return;
+/* Both banks of one channel-frame in one launch (phases: XAAC_HBE_PHASE_SYNTH | XAAC_HBE_PHASE_ANAL): the synthesis bank's
+   time signal stays in LDS for the analysis bank behind it (and goes to the state, which keeps it for the next frame).
+   The columns' transforms run as team routines over LDS arrays -- (column, butterfly) units spread over the lanes,
+   a barrier per pass -- instead of one column per lane in private (scratch) memory. */
+/* (the bank size as a template parameter: every index split below divides by it or its double) */
+template <int S>
+__device__ __forceinline__ void xaac_hbe_banks_body(const XaacHbeBanksParams &p, xaac_hbe_state *st, int ch, int lane, float *lds) {
+  float *T = lds;                 /* [(32 + 1) * s <= 660]: input_buf as the analysis bank reads it */
+  float *R = lds + XAAC_HBE_T_FLOATS;
+  const bool synth = (p.phases & XAAC_HBE_PHASE_SYNTH) != 0, anal = (p.phases & XAAC_HBE_PHASE_ANAL) != 0;
+  constexpr int s = S, a = 2 * S;
+  const int ks = st->k_start, nc = p.num_columns;
+  constexpr int NT = XAAC_HBE_BANKS_THREADS;
+  const XhWaveTeam cx = {lane, NT};
+  if (synth) {
+    float(*vv)[40] = reinterpret_cast<float(*)[40]>(R); /* [9 + 32][2 s <= 40] */
+    float *xin = R + 41 * 40;                            /* [32][20] */
+    float *work = xin + 32 * 20;                         /* [32][96] */
+    /* apply mode, hbe_trans.c:235-248: the last synth_size samples of the previous frame's time signal move to the
+       front; while the reference's FFT pointers are unset it re-initialises, which clears both delay lines */
+    const bool cleared = p.apply && !st->fft_ready;
+    float front = 0.0f;
+    if (lane < s) front = st->input_buf[p.apply ? nc * s + lane : lane];
+    if (cleared) {
+      for (int e = lane; e < 640; e += NT) st->analy_buf[e] = 0.0f;
+      for (int e = 20 * s + lane; e < 1280; e += NT) st->synth_buf[e] = 0.0f;
+    }
+    for (int e = lane; e < 9 * 2 * s; e += NT) {
+      const int c = -1 - e / (2 * s), t = e % (2 * s);
+      vv[c + 9][t] = cleared ? 0.0f : xh_synth_hist(st->synth_buf, s, c, t);
+    }
+    const float *qre = p.qmf_re + (size_t)ch * p.in_stride, *qim = p.qmf_im + (size_t)ch * p.in_stride;
+    for (int e = lane; e < nc * s; e += NT) {
+      const int c = e / s, k = e % s;
+      xin[20 * c + k] = xh_synth_xin(qre + 64 * c, qim + 64 * c, ks, k);
+    }
+    __syncthreads();
+    xh_synth_team(cx, [&](int c, int k) { return xin[20 * c + k]; }, [&](int c) { return vv[c + 9]; }, nc, s, work);
+    const auto at = [&](int c, int t) { return vv[c + 9][t]; };
+    for (int o = lane; o < nc * s; o += NT) {
+      const float y = xh_synth_out(at, s, o / s, o % s);
+      st->input_buf[s + o] = y;
+      T[s + o] = y;
+    }
+    if (lane < s) {
+      if (p.apply) st->input_buf[lane] = front;
+      T[lane] = front;
+    }
+    for (int e = lane; e < 20 * s; e += NT) {
+      const int c = nc - 1 - e / (2 * s);
+      st->synth_buf[e] = vv[c + 9][e % (2 * s)]; /* nc >= 1: columns nc - 10 .. nc - 1 >= -9 */
+    }
+    __syncthreads(); /* T complete; the clears of analy_buf above visible to the lanes that read it below */
+  }
+  if (!anal) return;
   constexpr int NCOL = XAAC_HBE_NO_BINS / 2;
-  if (p.apply) /* hbe_trans.c:254-258: rows 16..27 become rows 0..11 (rows 12..27 are written below, after the barrier) */
-    for (int e = lane; e < (XAAC_HBE_OPER_WIN_LEN - 1) * 128; e += 64) st->qmf_in_buf[e >> 7][e & 127] = st->qmf_in_buf[(e >> 7) + NCOL][e & 127];
-  for (int e = lane; e < NCOL * 2 * a; e += 64) u[e / (2 * a)][e % (2 * a)] = xh_anal_u(st->input_buf, st->analy_buf, a, e / (2 * a), e % (2 * a));
+  float(*u)[80] = reinterpret_cast<float(*)[80]>(R);              /* [16][2 a <= 80] */
+  float(*res)[80] = reinterpret_cast<float(*)[80]>(R + 16 * 80);  /* [16][2 a <= 80] */
+  float *work = R + 2 * 16 * 80;                                  /* [16][192] */
+  if (!synth) {
+    for (int e = lane; e <= NCOL * a; e += NT) T[e] = st->input_buf[e];
+    __syncthreads();
+  }
+  if (p.apply) /* hbe_trans.c:254-258: rows 16..27 become rows 0..11 (rows 12..27 are written below) */
+    for (int e = lane; e < (XAAC_HBE_OPER_WIN_LEN - 1) * 128; e += NT) st->qmf_in_buf[e >> 7][e & 127] = st->qmf_in_buf[(e >> 7) + NCOL][e & 127];
+  for (int e = lane; e < NCOL * 2 * a; e += NT) u[e / (2 * a)][e % (2 * a)] = xh_anal_u(T, st->analy_buf, a, e / (2 * a), e % (2 * a));
   /* the delay line the last column leaves (read before anything of it is overwritten) */
-  float nb[7];
+  constexpr int NB = (10 * a + NT - 1) / NT;
+  float nb[NB];
 #pragma unroll
-  for (int q = 0; q < 7; q++) {
-    const int n = lane + 64 * q;
-    nb[q] = n < 10 * a ? xh_anal_x(st->input_buf, st->analy_buf, a, NCOL - 1, n) : 0.0f;
+  for (int q = 0; q < NB; q++) {
+    const int n = lane + NT * q;
+    nb[q] = n < 10 * a ? xh_anal_x(T, st->analy_buf, a, NCOL - 1, n) : 0.0f;
   }
   __syncthreads();
-  if (lane < NCOL) {
-    float w[XH_FFT_SCRATCH]; /* private (scratch memory): in LDS these strips would leave three waves per CU */
-    xh_anal_column(u[lane], a, res[lane], w);
-  }
-  __syncthreads();
-  for (int e = lane; e < NCOL * 128; e += 64) {
+  xh_anal_team(cx, &u[0][0], 80, [&](int c) { return res[c]; }, NCOL, a, work);
+  for (int e = lane; e < NCOL * 128; e += NT) {
     const int idx = e >> 7, w = (e & 127) - 4 * ks;
     st->qmf_in_buf[idx + XAAC_HBE_OPER_WIN_LEN - 1][e & 127] = (w >= 0 && w < 2 * a) ? res[idx][w] : 0.0f;
   }
 #pragma unroll
-  for (int q = 0; q < 7; q++) {
-    const int n = lane + 64 * q;
+  for (int q = 0; q < NB; q++) {
+    const int n = lane + NT * q;
     if (n < 10 * a) st->analy_buf[n] = nb[q];
+  }
+}
+
+__global__ __launch_bounds__(XAAC_HBE_BANKS_THREADS) void xaac_hbe_banks_kernel(XaacHbeBanksParams p) {
+  extern __shared__ float lds[];
+  const int ch = blockIdx.x, lane = threadIdx.x;
+  xaac_hbe_state *st = p.state + ch;
+  if (hbe_skip(p.frame, ch)) return;
+  const bool synth = (p.phases & XAAC_HBE_PHASE_SYNTH) != 0, anal = (p.phases & XAAC_HBE_PHASE_ANAL) != 0;
+  const int s = st->synth_size, ks = st->k_start, nc = p.num_columns, a = 2 * s;
+  bool bad;
+  if (p.apply) bad = !xh_apply_params_ok(st, hbe_pitch(p.pitch, p.side, ch));
+  else
+    bad = !xh_size_ok(s) || ks < 0 || (synth && (ks + s > 64 || ks * 32 + 2 * s > 7 * 64 || nc < 0 || nc > 32)) ||
+          (anal && 4 * ks + 2 * a > 128);
+  if (lane == 0 && p.status && (synth || !p.apply)) p.status[ch] = bad ? -1 : 0;
+  if (bad) return;
+  switch (s) {
+    case 4: xaac_hbe_banks_body<4>(p, st, ch, lane, lds); break;
+    case 8: xaac_hbe_banks_body<8>(p, st, ch, lane, lds); break;
+    case 12: xaac_hbe_banks_body<12>(p, st, ch, lane, lds); break;
+    case 16: xaac_hbe_banks_body<16>(p, st, ch, lane, lds); break;
+    default: xaac_hbe_banks_body<20>(p, st, ch, lane, lds); break;
   }
 }
 
@@ -281,13 +320,8 @@ extern "C" hipError_t xaac_launch_hbe_dft_anal(const XaacHbeDftParams *p, hipStr
   return hipGetLastError();
 }
 
-extern "C" hipError_t xaac_launch_hbe_synth(const XaacHbeSynParams *p, hipStream_t stream) {
-  hipLaunchKernelGGL(xaac_hbe_synth_kernel, dim3(p->n_ch), dim3(64), XAAC_HBE_SYN_LDS, stream, *p);
-  return hipGetLastError();
-}
-
-extern "C" hipError_t xaac_launch_hbe_anal(const XaacHbeAnaParams *p, hipStream_t stream) {
-  hipLaunchKernelGGL(xaac_hbe_anal_kernel, dim3(p->n_ch), dim3(64), XAAC_HBE_ANA_LDS, stream, *p);
+extern "C" hipError_t xaac_launch_hbe_banks(const XaacHbeBanksParams *p, hipStream_t stream) {
+  hipLaunchKernelGGL(xaac_hbe_banks_kernel, dim3(p->n_ch), dim3(XAAC_HBE_BANKS_THREADS), XAAC_HBE_BANKS_LDS, stream, *p);
   return hipGetLastError();
 }
 

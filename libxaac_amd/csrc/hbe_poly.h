@@ -124,18 +124,29 @@ FX_HD unsigned xh_dig_rev(unsigned i, int m) { /* DIG_REV, esbr_fft.c:28-35 */
 }
 FX_HD int xh_log2(int n) { return n == 8 ? 3 : (n == 16 ? 4 : (n == 32 ? 5 : 6)); } /* n = 8, 16, 32, 64 */
 
-/* ixheaac_real_synth_fft_p2 (:42) / ixheaac_cmplx_anal_fft_p2 (:537) for n = 8, 16, 32 or 64 points: x -> y (2 n
-   floats).  real: x holds n/2 real samples (the upper half of the reference's input is zero and never read). */
-FX_HD void xh_fft_p2(const float *x, float *y, int n, bool real) {
+/* a "team" of one: the sequential run of the cooperative routines below (the oracle, and single columns) */
+struct XhSeq {
+  int lane, n;
+  FX_MEMBER void sync() const {}
+};
+
+/* ixheaac_real_synth_fft_p2 (:42) / ixheaac_cmplx_anal_fft_p2 (:537) for n = 8, 16, 32 or 64 points, `units` transforms
+   side by side on a team of lanes (CX: lane, n, sync(); a pass's butterflies touch disjoint elements, so spreading
+   them over lanes changes no operation): unit t's input through `in` (real: in(t, e) = sample e, e < n, the upper half
+   zero; complex: in(t, 2 c) / in(t, 2 c + 1) = real / imaginary part of point c), output y + t * ys (2 n floats). */
+template <class CX, class IN>
+FX_HD void xh_fft_p2_team(const CX &cx, const IN &in, float *y, int ys, int units, int n, bool real) {
   const int lg = xh_log2(n), rev_shift = 15 - lg; /* norm32(n) + 1 - 16 */
   const bool odd = (lg & 1) != 0;                 /* not a power of four: a radix-2 pass at the end */
-  for (int b = 0; b < n / 4; b++) {
+  const int q4 = n / 4;
+  for (int e = cx.lane; e < units * q4; e += cx.n) {
+    const int t = e / q4, b = e % q4;
     unsigned h2 = xh_dig_rev((unsigned)(4 * b), rev_shift);
     if (odd) h2 = (h2 + 1) & ~1u;
-    float *o = y + 8 * b;
+    float *o = y + (size_t)t * ys + 8 * b;
     if (real) {
-      const float *inp = x + (h2 >> 1);
-      float x0r = inp[0], x1r = inp[n >> 2], x2r = inp[2 * (n >> 2)], x3r = inp[3 * (n >> 2)];
+      const int i0 = (int)(h2 >> 1);
+      float x0r = in(t, i0), x1r = in(t, i0 + (n >> 2)), x2r = in(t, i0 + 2 * (n >> 2)), x3r = in(t, i0 + 3 * (n >> 2));
       x0r = x0r + x2r;
       x2r = x0r - (x2r * 2);
       x1r = x1r + x3r;
@@ -147,26 +158,28 @@ FX_HD void xh_fft_p2(const float *x, float *y, int n, bool real) {
       o[4] = x1r; o[5] = 0;
       o[6] = x2r; o[7] = -x3r;
     } else {
-      const float *inp = x + h2;
       float v[8];
       for (int q = 0; q < 4; q++) {
-        v[2 * q] = inp[q * (n >> 1)];
-        v[2 * q + 1] = inp[q * (n >> 1) + 1];
+        v[2 * q] = in(t, (int)h2 + q * (n >> 1));
+        v[2 * q + 1] = in(t, (int)h2 + q * (n >> 1) + 1);
       }
       xh_bfly4(v, false);
       for (int q = 0; q < 8; q++) o[q] = v[q];
     }
   }
+  cx.sync();
   const float *tw = xaac_hbe_fft_tw;
   int del = 4;
   for (int pass = (lg >> 1) - 1; pass > 0; pass--, del <<= 2) {
-    for (int b = 0; b < n / 4; b++) {
+    for (int e = cx.lane; e < units * q4; e += cx.n) {
+      const int t = e / q4, b = e % q4;
+      float *yt = y + (size_t)t * ys;
       const int jj = b % del, k = b / del; /* twiddle column, group */
       const int p0 = 4 * del * k + jj;     /* complex index of the first leg; the others del apart */
       float v[8];
       for (int q = 0; q < 4; q++) {
-        v[2 * q] = y[2 * (p0 + q * del)];
-        v[2 * q + 1] = y[2 * (p0 + q * del) + 1];
+        v[2 * q] = yt[2 * (p0 + q * del)];
+        v[2 * q + 1] = yt[2 * (p0 + q * del) + 1];
       }
       bool alt = false;
       if (jj) {
@@ -183,18 +196,21 @@ FX_HD void xh_fft_p2(const float *x, float *y, int n, bool real) {
       }
       xh_bfly4(v, alt);
       for (int q = 0; q < 4; q++) {
-        y[2 * (p0 + q * del)] = v[2 * q];
-        y[2 * (p0 + q * del) + 1] = v[2 * q + 1];
+        yt[2 * (p0 + q * del)] = v[2 * q];
+        yt[2 * (p0 + q * del) + 1] = v[2 * q + 1];
       }
     }
+    cx.sync();
   }
   if (odd) { /* :484-534: del = n / 2 */
     const int ns = 2 * (256 / del) * 1; /* nodespacing after the passes, doubled */
-    for (int m = 0; m < del; m++) {
-      const int t = (m % (del / 2)) * ns;
-      const float w1 = tw[t], w4 = tw[t + 257];
-      const float x0r = y[2 * m], x0i = y[2 * m + 1];
-      float x1r = y[2 * (m + del)], x1i = y[2 * (m + del) + 1];
+    for (int e = cx.lane; e < units * del; e += cx.n) {
+      const int t = e / del, m = e % del;
+      float *yt = y + (size_t)t * ys;
+      const int tt = (m % (del / 2)) * ns;
+      const float w1 = tw[tt], w4 = tw[tt + 257];
+      const float x0r = yt[2 * m], x0i = yt[2 * m + 1];
+      float x1r = yt[2 * (m + del)], x1i = yt[2 * (m + del) + 1];
       if (m < del / 2) {
         xh_rot_a(x1r, x1i, w1, w4);
       } else {
@@ -202,11 +218,12 @@ FX_HD void xh_fft_p2(const float *x, float *y, int n, bool real) {
         x1i = (x1r * w1) + (x1i * w4);
         x1r = tmp;
       }
-      y[2 * (m + del)] = x0r - x1r;
-      y[2 * (m + del) + 1] = x0i - x1i;
-      y[2 * m] = x0r + x1r;
-      y[2 * m + 1] = x0i + x1i;
+      yt[2 * (m + del)] = x0r - x1r;
+      yt[2 * (m + del) + 1] = x0i - x1i;
+      yt[2 * m] = x0r + x1r;
+      yt[2 * m + 1] = x0i + x1i;
     }
+    cx.sync();
   }
 }
 
@@ -225,82 +242,105 @@ FX_HD void xh_fft3(const float *inp, float *op) { /* ixheaac_aac_ld_dec_fft_3_fl
   op[5] = (inp[1] + p3) - p4;
 }
 
-/* ixheaac_real_synth_fft_p3 (:1084, n = 24: x = 12 real samples + 12 zeros) and ixheaac_cmplx_anal_fft_p3 (:1148,
-   n = 48 complex points): three interleaved power-of-two transforms, twiddles, 3-point transforms.  x_out: 2 n floats;
-   w: 4 n floats of scratch. */
-FX_HD void xh_fft_p3(const float *x_in, float *x_out, float *w, int n, bool real) {
+/* ixheaac_real_synth_fft_p3 (:1084, n = 24: 12 real samples + 12 zeros) and ixheaac_cmplx_anal_fft_p3 (:1148, n = 48
+   complex points), `cols` of them side by side: three interleaved power-of-two transforms per column (3 cols units of
+   xh_fft_p2_team into ysub, 2 n floats per column), then per (column, g) the two twiddles, the 3-point transform and the
+   reference's output order -- the arrays the reference passes between these steps hold nothing another g reads.
+   in as above (of the n-point transform); out + c * os: 2 n floats. */
+template <class CX, class IN>
+FX_HD void xh_fft_p3_team(const CX &cx, const IN &in, float *ysub, float *out, int os, int cols, int n, bool real) {
   const int m = n / 3; /* 8 or 16 points per sub-transform */
-  float *xs = w, *ys = w + 2 * m, *x = w + 4 * m, *y = x + 2 * n;
-  for (int i = 0; i < 3; i++) {
-    if (real)
-      for (int j = 0; j < m; j++) xs[j] = x_in[3 * j + i];
-    else
-      for (int j = 0; j < m; j++) {
-        xs[2 * j] = x_in[6 * j + 2 * i];
-        xs[2 * j + 1] = x_in[6 * j + 2 * i + 1];
-      }
-    xh_fft_p2(xs, ys, m, real);
-    for (int j = 0; j < m; j++) {
-      x[6 * j + 2 * i] = ys[2 * j];
-      x[6 * j + 2 * i + 1] = ys[2 * j + 1];
+  const auto sub_in = [&](int t, int e) { /* unit t = 3 column + i: point j of it is point 3 j + i of the column */
+    const int c = t / 3, i = t % 3;
+    return real ? in(c, 3 * e + i) : in(c, 6 * (e >> 1) + 2 * i + (e & 1));
+  };
+  xh_fft_p2_team(cx, sub_in, ysub, 2 * m, 3 * cols, m, real);
+  const float *wr = real ? xaac_hbe_tw24 : xaac_hbe_tw48;
+  for (int e = cx.lane; e < cols * m; e += cx.n) {
+    const int c = e / m, g = e % m;
+    const float *ys = ysub + (size_t)c * 6 * m;
+    float x[6], y[6];
+    for (int q = 0; q < 3; q++) {
+      x[2 * q] = ys[2 * m * q + 2 * g];
+      x[2 * q + 1] = ys[2 * m * q + 2 * g + 1];
+    }
+    for (int q = 1; q < 3; q++) {
+      const float cw = wr[4 * g + 2 * (q - 1)], sw = wr[4 * g + 2 * (q - 1) + 1];
+      const float tmp = (x[2 * q] * cw + x[2 * q + 1] * sw);
+      x[2 * q + 1] = (-x[2 * q] * sw + x[2 * q + 1] * cw);
+      x[2 * q] = tmp;
+    }
+    xh_fft3(x, y);
+    float *o = out + (size_t)c * os;
+    for (int q = 0; q < 3; q++) {
+      o[2 * m * q + 2 * g] = y[2 * q];
+      o[2 * m * q + 2 * g + 1] = y[2 * q + 1];
     }
   }
-  const float *wr = real ? xaac_hbe_tw24 : xaac_hbe_tw48;
-  for (int g = 0; g < m; g++)
-    for (int q = 1; q < 3; q++) {
-      float *p = x + 6 * g + 2 * q;
-      const float c = wr[4 * g + 2 * (q - 1)], s = wr[4 * g + 2 * (q - 1) + 1];
-      const float tmp = (p[0] * c + p[1] * s);
-      p[1] = (-p[0] * s + p[1] * c);
-      p[0] = tmp;
-    }
-  for (int g = 0; g < m; g++) xh_fft3(x + 6 * g, y + 6 * g);
-  for (int g = 0; g < m; g++)
-    for (int q = 0; q < 3; q++) {
-      x_out[2 * m * q + 2 * g] = y[6 * g + 2 * q];
-      x_out[2 * m * q + 2 * g + 1] = y[6 * g + 2 * q + 1];
-    }
+  cx.sync();
 }
-#define XH_FFT_SCRATCH 512 /* floats: the callers' arrays (<= 256) and xh_fft_p3's w (4 n + 4 m <= 256) */
-#define XH_SYNTH_SCRATCH 264 /* what xh_synth_column uses of it */
+#define XH_FFT_SCRATCH 512 /* floats the single-column wrappers below take as work space */
+#define XH_SYNTH_SCRATCH 264
 
 /* ---- the real synthesis bank ------------------------------------------------------------------------------------- */
-/* One column: re / im = the column's 64 QMF bands; v[0 .. 2 s) = what the reference writes to the front of its delay
-   line (esbr_polyphase.c:186-247).  w: XH_FFT_SCRATCH floats. */
-FX_HD void xh_synth_column(const float *re, const float *im, int s, int k_start, float *v, float *w) {
-  const float *ct = xaac_hbe_cos_trans_qmf + k_start * 32; /* :166-168 */
-  float *xin = w, *u = w + 40, *fw = w + 40 + 96;
-  for (int k = 0; k < s; k++) {
-    xin[k] = (ct[2 * k] * re[k_start + k] + ct[2 * k + 1] * im[k_start + k]);
-    xin[s + k] = 0; /* :192 */
-  }
+/* `cols` columns side by side (esbr_polyphase.c:186-247): xin(c, k) = the column's k-th modulated input, k < s
+   (xh_synth_xin); v(c) = where column c's 2 s values go (what the reference writes to the front of its delay line);
+   work: cols * 128 floats (transform output, and the sub-transforms of the 24-point case). */
+FX_HD float xh_synth_xin(const float *re, const float *im, int k_start, int k) { /* :166-168, :189-191 */
+  const float *ct = xaac_hbe_cos_trans_qmf + k_start * 32;
+  return (ct[2 * k] * re[k_start + k] + ct[2 * k + 1] * im[k_start + k]);
+}
+template <class CX, class XIN, class VOUT>
+FX_HD void xh_synth_team(const CX &cx, const XIN &xin, const VOUT &v, int cols, int s, float *work) {
   const float *tab = xh_synth_cos(s);
   if (s == 20) {
-    /* :199-221: 31 dot products; entries l and s - l (l <= s), l and 3 s - l (negated, l > s) -- written in the
-       reference's order so that the later store wins where they overlap */
-    for (int l = 0; l <= 3 * s / 2; l++) {
+    /* :199-221: 31 dot products.  l <= s writes entries l and s - l, l > s entries l and 3 s - l (negated).  In the
+       reference's serial order the stores of l > s / 2 land on top of those of s - l, so of l = 0 .. s only l >= s / 2
+       leave anything: v[s - l] and v[l] (once for l = s / 2).  One l per lane, the overwritten stores left out. */
+    for (int e = cx.lane; e < cols * (3 * s / 2 + 1); e += cx.n) {
+      const int c = e / (3 * s / 2 + 1), l = e % (3 * s / 2 + 1);
       float accu = 0.0f;
-      for (int k = 0; k < s; k++) accu += xin[k] * tab[l * s + k];
+      for (int k = 0; k < s; k++) accu += xin(c, k) * tab[l * s + k];
+      float *vc = v(c);
       if (l <= s) {
-        v[l] = accu;
-        v[s - l] = accu;
+        if (l >= s / 2) {
+          vc[l] = accu;
+          vc[s - l] = accu;
+        }
       } else if (l < 3 * s / 2) {
-        v[l] = accu;
-        v[3 * s - l] = -accu;
+        vc[l] = accu;
+        vc[3 * s - l] = -accu;
       } else {
-        v[3 * s / 2] = accu;
+        vc[3 * s / 2] = accu;
       }
     }
-  } else {
-    if (s == 12) xh_fft_p3(xin, u, fw, 2 * s, true);
-    else xh_fft_p2(xin, u, 2 * s, true);
-    const int kmax = s / 2;
-    for (int k = 0; k < 2 * s; k++) { /* :233-246: the first 3 s / 2 results go to v[s / 2 ..], the rest to v[0 ..] */
-      float tmp = (u[2 * k] * tab[2 * k]);
-      tmp -= (u[2 * k + 1] * tab[2 * k + 1]);
-      v[k < kmax + s ? kmax + k : k - (kmax + s)] = tmp;
-    }
+    cx.sync();
+    return;
   }
+  const int n = 2 * s;
+  const auto in = [&](int c, int e) { return e < s ? xin(c, e) : 0.0f; }; /* :192 */
+  float *u = work;
+  int us = 2 * n;
+  if (s == 12) {
+    u = work + (size_t)cols * 2 * n;
+    xh_fft_p3_team(cx, in, work, u, us, cols, n, true);
+  } else {
+    xh_fft_p2_team(cx, in, u, us, cols, n, true);
+  }
+  const int kmax = s / 2;
+  for (int e = cx.lane; e < cols * n; e += cx.n) { /* :233-246: the first 3 s / 2 results go to v[s / 2 ..], the rest to v[0 ..] */
+    const int c = e / n, k = e % n;
+    const float *uc = u + (size_t)c * us;
+    float tmp = (uc[2 * k] * tab[2 * k]);
+    tmp -= (uc[2 * k + 1] * tab[2 * k + 1]);
+    v(c)[k < kmax + s ? kmax + k : k - (kmax + s)] = tmp;
+  }
+  cx.sync();
+}
+/* One column: re / im = the column's 64 QMF bands; v[0 .. 2 s); w: XH_FFT_SCRATCH floats. */
+FX_HD void xh_synth_column(const float *re, const float *im, int s, int k_start, float *v, float *w) {
+  const XhSeq cx = {0, 1};
+  xh_synth_team(cx, [&](int, int k) { return xh_synth_xin(re, im, k_start, k); }, [&](int) { return v; }, 1, s, w);
 }
 /* Output sample i of column idx (:249-268).  vv(c, t): element t of column c's v, c = -9 .. num_columns - 1 (the
    negative ones from the delay line: xh_synth_hist). */
@@ -355,39 +395,60 @@ FX_HD void xh_dft_anal_band(const float *u, int l2, const float *coef_re_row, co
   out_r = accu_r;
   out_i = accu_i;
 }
-/* One column: u[0 .. 2 a) -> a complex sub-band samples out[0 .. 2 a) (:110-152).  u is overwritten; w: XH_FFT_SCRATCH. */
-FX_HD void xh_anal_column(float *u, int a, float *out, float *w) {
+/* `cols` columns side by side (:110-152): u + c * us = the column's 2 a windowed sums (overwritten when a = 40);
+   out(c) = where its a complex sub-band samples (2 a floats) go; work: cols * 256 floats (a = 40: none). */
+template <class CX, class OUT>
+FX_HD void xh_anal_team(const CX &cx, float *u, int us, const OUT &out, int cols, int a, float *work) {
   const float *tab = xh_analy_cs(a / 2);
   if (a == 40) {
-    for (int i = 1; i < a; i++) {
-      const float t1 = u[i] + u[2 * a - i], t2 = u[i] - u[2 * a - i];
-      u[i] = t1;
-      u[2 * a - i] = t2;
+    for (int e = cx.lane; e < cols * (a - 1); e += cx.n) {
+      float *uc = u + (size_t)(e / (a - 1)) * us;
+      const int i = 1 + e % (a - 1);
+      const float t1 = uc[i] + uc[2 * a - i], t2 = uc[i] - uc[2 * a - i];
+      uc[i] = t1;
+      uc[2 * a - i] = t2;
     }
-    for (int k = 0; k < a; k++) {
-      float accu_r = u[a], accu_i = (k & 1) ? u[0] : -u[0];
+    cx.sync();
+    for (int e = cx.lane; e < cols * a; e += cx.n) {
+      const int c = e / a, k = e % a;
+      const float *uc = u + (size_t)c * us;
+      float accu_r = uc[a], accu_i = (k & 1) ? uc[0] : -uc[0];
       for (int l = 1; l < a; l++) {
-        accu_r = accu_r + u[l] * tab[2 * a * k + 2 * l];
-        accu_i = accu_i + u[2 * a - l] * tab[2 * a * k + 2 * l + 1];
+        accu_r = accu_r + uc[l] * tab[2 * a * k + 2 * l];
+        accu_i = accu_i + uc[2 * a - l] * tab[2 * a * k + 2 * l + 1];
       }
-      out[2 * k] = accu_r;
-      out[2 * k + 1] = accu_i;
+      float *o = out(c);
+      o[2 * k] = accu_r;
+      o[2 * k + 1] = accu_i;
     }
-  } else {
-    float *u_in = w, *u_out = w + 128, *fw = w + 256;
-    for (int k = 0; k < 2 * a; k++) {
-      u_in[2 * k] = (tab[2 * k] * u[k]);
-      u_in[2 * k + 1] = (tab[2 * k + 1] * u[k]);
-    }
-    if (a == 24) xh_fft_p3(u_in, u_out, fw, 2 * a, false);
-    else xh_fft_p2(u_in, u_out, 2 * a, false);
-    for (int k = 0; k < a / 2; k++) {
-      out[4 * k + 1] = -u_out[4 * k];
-      out[4 * k] = u_out[4 * k + 1];
-      out[4 * k + 3] = u_out[4 * k + 2];
-      out[4 * k + 2] = -u_out[4 * k + 3];
-    }
+    cx.sync();
+    return;
   }
+  const int n = 2 * a;
+  const auto in = [&](int c, int e) { return (tab[e] * u[(size_t)c * us + (e >> 1)]); }; /* u_in[2 k] , [2 k + 1] = tab * u[k] */
+  float *y = work;
+  const int ys = 2 * n;
+  if (a == 24) {
+    y = work + (size_t)cols * 2 * n;
+    xh_fft_p3_team(cx, in, work, y, ys, cols, n, false);
+  } else {
+    xh_fft_p2_team(cx, in, y, ys, cols, n, false);
+  }
+  for (int e = cx.lane; e < cols * (a / 2); e += cx.n) {
+    const int c = e / (a / 2), k = e % (a / 2);
+    const float *yc = y + (size_t)c * ys;
+    float *o = out(c);
+    o[4 * k + 1] = -yc[4 * k];
+    o[4 * k] = yc[4 * k + 1];
+    o[4 * k + 3] = yc[4 * k + 2];
+    o[4 * k + 2] = -yc[4 * k + 3];
+  }
+  cx.sync();
+}
+/* One column: u[0 .. 2 a) -> out[0 .. 2 a).  u is overwritten; w: XH_FFT_SCRATCH floats. */
+FX_HD void xh_anal_column(float *u, int a, float *out, float *w) {
+  const XhSeq cx = {0, 1};
+  xh_anal_team(cx, u, 0, [&](int) { return out; }, 1, a, w);
 }
 
 #endif /* XAAC_HBE_POLY_H */

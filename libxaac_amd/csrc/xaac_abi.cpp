@@ -330,12 +330,11 @@ int32_t xaac_esbr_sbr_process_batch(xaac_ctx *c, const xaac_esbr_sbr_batch *b) {
   XaacEsbrAnaParams pa = {b->n_ch, b->core, &b->state->ana, ana_re, ana_im, (int32_t)sizeof(xaac_esbr_state)};
   if (!hip_ok(xaac_launch_esbr_analysis(&pa, c->stream))) return XAAC_FATAL_HIP;
   if (b->hbe_state) {
-    /* sbr_dec.c:882-909: the frame's new analysis rows through the channel's harmonic transposer (three launches),
+    /* sbr_dec.c:882-909: the frame's new analysis rows through the channel's harmonic transposer (two launches),
        its 32 output rows into rows 8..39 of the ph scratch matrix; channels without SBR processing are skipped */
-    XaacHbeSynParams hs = {b->n_ch, XAAC_HBE_NO_BINS, ana_re, ana_im, b->hbe_state, nullptr, nullptr, 1, b->frame, b->side, 2048};
-    if (!hip_ok(xaac_launch_hbe_synth(&hs, c->stream))) return XAAC_FATAL_HIP;
-    XaacHbeAnaParams ha = {b->n_ch, b->hbe_state, nullptr, nullptr, 1, b->frame, b->side};
-    if (!hip_ok(xaac_launch_hbe_anal(&ha, c->stream))) return XAAC_FATAL_HIP;
+    XaacHbeBanksParams hs = {b->n_ch, XAAC_HBE_NO_BINS, ana_re, ana_im, b->hbe_state, nullptr, nullptr, 1, b->frame, b->side, 2048,
+                             XAAC_HBE_PHASE_SYNTH | XAAC_HBE_PHASE_ANAL};
+    if (!hip_ok(xaac_launch_hbe_banks(&hs, c->stream))) return XAAC_FATAL_HIP;
     XaacHbePostParams hp = {b->n_ch, b->hbe_state, nullptr, ph_re + 8 * 64, ph_im + 8 * 64, b->frame, b->side,
                             XAAC_ESBR_PH_ROWS * 64, 1};
     if (!hip_ok(xaac_launch_hbe_post(&hp, c->stream))) return XAAC_FATAL_HIP;
@@ -413,9 +412,10 @@ int32_t xaac_hbe_real_synth_batch(xaac_ctx *c, const xaac_hbe_synth_batch *b) {
   if (b->n_ch == 0 || b->num_columns == 0) return XAAC_OK;
   if (!b->qmf_re || !b->qmf_im || !b->state) return XAAC_FATAL_NULL_ARG;
   if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
-  XaacHbeSynParams p = {b->n_ch, b->num_columns, b->qmf_re, b->qmf_im, b->state, b->status, nullptr, 0, nullptr, nullptr, b->num_columns * 64};
-  if (!hip_ok(xaac_launch_hbe_synth(&p, c->stream))) return XAAC_FATAL_HIP;
-  c->last_grid = b->n_ch; c->last_block = 64; c->last_lds = XAAC_HBE_SYN_LDS;
+  XaacHbeBanksParams p = {b->n_ch, b->num_columns, b->qmf_re, b->qmf_im, b->state, b->status, nullptr, 0, nullptr, nullptr,
+                          b->num_columns * 64, XAAC_HBE_PHASE_SYNTH};
+  if (!hip_ok(xaac_launch_hbe_banks(&p, c->stream))) return XAAC_FATAL_HIP;
+  c->last_grid = b->n_ch; c->last_block = XAAC_HBE_BANKS_THREADS; c->last_lds = XAAC_HBE_BANKS_LDS;
   return XAAC_OK;
 }
 
@@ -425,9 +425,9 @@ int32_t xaac_hbe_cplx_anal_batch(xaac_ctx *c, const xaac_hbe_anal_batch *b) {
   if (b->n_ch == 0) return XAAC_OK;
   if (!b->state) return XAAC_FATAL_NULL_ARG;
   if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
-  XaacHbeAnaParams p = {b->n_ch, b->state, b->status, nullptr, 0, nullptr, nullptr};
-  if (!hip_ok(xaac_launch_hbe_anal(&p, c->stream))) return XAAC_FATAL_HIP;
-  c->last_grid = b->n_ch; c->last_block = 64; c->last_lds = XAAC_HBE_ANA_LDS;
+  XaacHbeBanksParams p = {b->n_ch, 0, nullptr, nullptr, b->state, b->status, nullptr, 0, nullptr, nullptr, 0, XAAC_HBE_PHASE_ANAL};
+  if (!hip_ok(xaac_launch_hbe_banks(&p, c->stream))) return XAAC_FATAL_HIP;
+  c->last_grid = b->n_ch; c->last_block = XAAC_HBE_BANKS_THREADS; c->last_lds = XAAC_HBE_BANKS_LDS;
   return XAAC_OK;
 }
 
@@ -449,12 +449,11 @@ int32_t xaac_hbe_apply_batch(xaac_ctx *c, const xaac_hbe_apply_batch_desc *b) {
   if (b->n_ch == 0) return XAAC_OK;
   if (!b->qmf_re || !b->qmf_im || !b->state || !b->pv_re || !b->pv_im) return XAAC_FATAL_NULL_ARG;
   if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
-  /* three launches on the context's stream: synthesis bank (with the frame's shift / re-initialisation and the
-     parameter check that sets status), analysis bank, products + output rows */
-  XaacHbeSynParams ps = {b->n_ch, XAAC_HBE_NO_BINS, b->qmf_re, b->qmf_im, b->state, b->status, b->pitch_in_bins, 1, nullptr, nullptr, 2048};
-  if (!hip_ok(xaac_launch_hbe_synth(&ps, c->stream))) return XAAC_FATAL_HIP;
-  XaacHbeAnaParams pa = {b->n_ch, b->state, b->status, b->pitch_in_bins, 1, nullptr, nullptr};
-  if (!hip_ok(xaac_launch_hbe_anal(&pa, c->stream))) return XAAC_FATAL_HIP;
+  /* two launches on the context's stream: the two polyphase banks (with the frame's shift / re-initialisation and the
+     parameter check that sets status), then products + output rows */
+  XaacHbeBanksParams ps = {b->n_ch, XAAC_HBE_NO_BINS, b->qmf_re, b->qmf_im, b->state, b->status, b->pitch_in_bins, 1, nullptr, nullptr, 2048,
+                           XAAC_HBE_PHASE_SYNTH | XAAC_HBE_PHASE_ANAL};
+  if (!hip_ok(xaac_launch_hbe_banks(&ps, c->stream))) return XAAC_FATAL_HIP;
   XaacHbePostParams pp = {b->n_ch, b->state, b->pitch_in_bins, b->pv_re, b->pv_im, nullptr, nullptr, 2048, 0};
   if (!hip_ok(xaac_launch_hbe_post(&pp, c->stream))) return XAAC_FATAL_HIP;
   c->last_grid = b->n_ch; c->last_block = XAAC_HBE_POST_THREADS; c->last_lds = XAAC_HBE_POST_LDS;

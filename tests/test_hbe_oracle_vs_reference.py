@@ -18,7 +18,13 @@ def _p(a):
 
 
 def bits(st):
-    return np.frombuffer(bytes(st), np.uint32)
+    """the state's words; every NaN as one value (which operand's NaN an addition hands on -- sign and payload -- is the
+    compiler's choice of operand order on either side, not the algorithm's)"""
+    w = np.frombuffer(bytes(st), np.uint32).copy()
+    n_float = (ctypes.sizeof(HbeState) - 12 * 4) // 4            # the float arrays in front of the twelve integers
+    f = w[:n_float].view(np.float32)
+    w[:n_float][np.isnan(f)] = 0x7fc00000
+    return w
 
 
 def qmf_columns(rng, kind):
