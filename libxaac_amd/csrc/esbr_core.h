@@ -88,6 +88,9 @@ struct XeWork {
   int16_t m_idx[64];
 };
 
+struct XeTrue { static constexpr bool value = true; };
+struct XeFalse { static constexpr bool value = false; };
+
 FX_HD double xe_sqrt(double v) { return sqrt(v); }
 FX_HD double xe_log10(double v) { return log10(v); }
 FX_HD double xe_pow10(double v) { return pow(10.0, v); }
@@ -512,27 +515,33 @@ FX_HD void xe_generate_hf(const XsCx &cx, const xaac_sbr_header *h, const xaac_s
       bw *= bw;
       const float a1r = bw * w->alpha_r[k][1], a1i = bw * w->alpha_i[k][1];
       float r2 = src.r(start - 2, k), i2 = src.i(start - 2, k), r1 = src.r(start - 1, k), i1 = src.i(start - 1, k);
-      const float gain = flatten ? w->nrg_gain[k] : 1.0f; /* :1220-1224 */
-      XE_NOUNROLL
-      for (int l0 = start; l0 < end; l0 += XE_CH) {
-        float cr[XE_CH] = {0}, ci[XE_CH] = {0};
-        xe_rows_load(src, k, l0, end, cr, ci);
-        XE_UNROLL
-        for (int j = 0; j < XE_CH; j++)
-          if (l0 + j < end) {
-            const float r0 = cr[j], i0 = ci[j];
-            float yr = r0 * gain, yi = i0 * gain;
-            if (bw > 0.0f) {
-              yr += (a0r * r1 - a0i * i1 + a1r * r2 - a1i * i2) * gain;
-              yi += (a0i * r1 + a0r * i1 + a1i * r2 + a1r * i2) * gain;
+      /* :1220-1247; the gain of a pre-flattened frame as its own copy of the loop: the usual frame multiplies by
+         nothing (x * 1.0f = x exactly, so leaving the products out changes no value) */
+      const auto run = [&](auto fl) {
+        const float gain = decltype(fl)::value ? w->nrg_gain[k] : 1.0f;
+        XE_NOUNROLL
+        for (int l0 = start; l0 < end; l0 += XE_CH) {
+          float cr[XE_CH] = {0}, ci[XE_CH] = {0};
+          xe_rows_load(src, k, l0, end, cr, ci);
+          XE_UNROLL
+          for (int j = 0; j < XE_CH; j++)
+            if (l0 + j < end) {
+              const float r0 = cr[j], i0 = ci[j];
+              float yr = r0 * gain, yi = i0 * gain;
+              if (bw > 0.0f) {
+                yr += (a0r * r1 - a0i * i1 + a1r * r2 - a1i * i2) * gain;
+                yi += (a0i * r1 + a0r * i1 + a1i * r2 + a1r * i2) * gain;
+              }
+              cr[j] = yr;
+              ci[j] = yi;
+              r2 = r1; i2 = i1;
+              r1 = r0; i1 = i0;
             }
-            cr[j] = yr;
-            ci[j] = yi;
-            r2 = r1; i2 = i1;
-            r1 = r0; i1 = i0;
-          }
-        xe_rows_store(dst, k2, l0, end, cr, ci);
-      }
+          xe_rows_store(dst, k2, l0, end, cr, ci);
+        }
+      };
+      if (flatten) run(XeTrue{});
+      else run(XeFalse{});
     }
   }
   XS_PAR(i, 0, num_if) st->bw_array_prev[i] = w->bw_array[i];
