@@ -4,4 +4,4 @@ import sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
 print("%-70s %6s %12s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "%"))
 for name, calls, total, avg, pct in c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
-    print("%-70s %6d %12.1f %10.2f %6.1f" % (name[:70], calls, total / 1e3, avg / 1e3, pct))
+    print("%-70s %6d %12.1f %10.2f %6.1f" % (name[:70], calls, total, avg, pct))
