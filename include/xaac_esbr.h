@@ -94,9 +94,30 @@ typedef struct xaac_esbr_sbr_batch {
                                        (sbr_dec.c:882-909).  Without it a frame with harmonic_sbr set is refused. */
 } xaac_esbr_sbr_batch;
 
+/* The hand-offs on either side of the branch in ixheaacd_dec_execute: the core decoder's PCM16 (after the 32 -> 16 bit
+ * conversion of xaac_imdct_process_batch's XAAC_PCM_SBR mode, channels of an element interleaved) as floats, one plane per
+ * channel (decoder/ixheaacd_api.c:3385-3432); and the branch's float output as 16-bit PCM, saturated to [-32768, 32767] and
+ * truncated towards zero, two channels interleaved (ixheaacd_samples_sat, decoder/ixheaacd_decode_main.c:82-107; a mono
+ * channel that the API then duplicates, api.c:3639-3660: left == right). */
+typedef struct xaac_esbr_core_in_batch {
+  int32_t n_ch;                    /* channel-frames in total, a multiple of ch_fac */
+  int32_t ch_fac;                  /* 1 or 2: channels interleaved in pcm */
+  const int16_t *pcm;              /* [n_ch / ch_fac][1024][ch_fac] */
+  float *core;                     /* [n_ch][1024] */
+} xaac_esbr_core_in_batch;
+
+typedef struct xaac_esbr_pcm_out_batch {
+  int32_t n;                       /* streams */
+  int32_t stride;                  /* floats between consecutive streams' planes in left / right (>= 2048) */
+  const float *left, *right;       /* stream i's planes: left + i * stride, right + i * stride; 2048 samples each */
+  int16_t *pcm;                    /* [n][2048][2] */
+} xaac_esbr_pcm_out_batch;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+int32_t xaac_esbr_core_from_pcm16_batch(xaac_ctx *ctx, const xaac_esbr_core_in_batch *batch);
+int32_t xaac_esbr_pcm16_from_float_batch(xaac_ctx *ctx, const xaac_esbr_pcm_out_batch *batch);
 /* One frame of every channel through the Path A branch of ixheaacd_sbr_dec (mono / stereo channels; with ps_* set:
  * HE-AACv2 streams, ixheaacd_esbr_apply_ps ps_dec_flt.c:389 between regrouping and the two synthesis banks):
  * history shift (sbr_dec.c:835-857), ixheaacd_esbr_analysis_filt_block, ixheaacd_generate_hf (sbrdec_lpfuncs.c:981),

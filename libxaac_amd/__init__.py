@@ -74,6 +74,17 @@ class _EsbrSbrBatch(ctypes.Structure):
                 ("workspace_bytes", ctypes.c_uint64), ("hbe_state", ctypes.c_void_p)]
 
 
+class _EsbrCoreInBatch(ctypes.Structure):
+    # struct xaac_esbr_core_in_batch
+    _fields_ = [("n_ch", ctypes.c_int32), ("ch_fac", ctypes.c_int32), ("pcm", ctypes.c_void_p), ("core", ctypes.c_void_p)]
+
+
+class _EsbrPcmOutBatch(ctypes.Structure):
+    # struct xaac_esbr_pcm_out_batch
+    _fields_ = [("n", ctypes.c_int32), ("stride", ctypes.c_int32), ("left", ctypes.c_void_p), ("right", ctypes.c_void_p),
+                ("pcm", ctypes.c_void_p)]
+
+
 class _HandoverBatch(ctypes.Structure):
     # struct xaac_sbr_handover_batch
     _fields_ = [("n", ctypes.c_int32), ("mode", ctypes.c_int32), ("src", ctypes.c_void_p), ("dst", ctypes.c_void_p),
@@ -500,6 +511,30 @@ class XaacContext:
         rc = self._lib.xaac_esbr_sbr_process_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_esbr_sbr_process_batch")
+
+    def esbr_core_from_pcm16(self, pcm, core, ch_fac=1):
+        """the core decoder's PCM16 (int16[n_ch * 1024], channels of an element interleaved at ch_fac) as float planes
+        core float32[n_ch, 1024] (api.c:3385-3432)"""
+        b = _EsbrCoreInBatch()
+        b.n_ch, b.ch_fac = int(core.shape[0]), int(ch_fac)
+        b.pcm = _ptr(pcm, "int16", b.n_ch * 1024, device_ok=True)
+        b.core = _ptr(core, "float32", b.n_ch * 1024, device_ok=True)
+        rc = self._lib.xaac_esbr_core_from_pcm16_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_esbr_core_from_pcm16_batch")
+
+    def esbr_pcm16_from_float(self, left, right, pcm, stride=2048):
+        """ixheaacd_samples_sat for two channels: stream i's float planes left / right (device tensors; element offset
+        i * stride) -> pcm int16[n * 2048 * 2]; left is right for a duplicated mono channel"""
+        n = pcm.numel() // 4096
+        b = _EsbrPcmOutBatch()
+        b.n, b.stride = int(n), int(stride)
+        b.left = _ptr(left, "float32", device_ok=True)
+        b.right = _ptr(right, "float32", device_ok=True)
+        b.pcm = _ptr(pcm, "int16", n * 4096, device_ok=True)
+        rc = self._lib.xaac_esbr_pcm16_from_float_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_esbr_pcm16_from_float_batch")
 
     def sbr_state_handover(self, mode, src, dst, state, ps_state=None):
         """ixheaacd_sbrdecoder.c:762-806 for the listed streams: mode HANDOVER_PS_START (dst indexes ps_state) or

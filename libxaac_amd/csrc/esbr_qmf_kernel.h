@@ -27,9 +27,23 @@ typedef struct XaacEsbrSynParams {
   int32_t in_stride;            /* floats between consecutive channels' row blocks (>= 2048) */
 } XaacEsbrSynParams;
 
+typedef struct XaacEsbrCoreInParams {
+  int32_t n_ch, ch_fac;         /* n_ch: channel-frames in total (a multiple of ch_fac) */
+  const int16_t *pcm;           /* [n_ch / ch_fac][1024][ch_fac] */
+  float *core;                  /* [n_ch][1024] */
+} XaacEsbrCoreInParams;
+
+typedef struct XaacEsbrPcmOutParams {
+  int32_t n, stride;            /* streams; floats between consecutive streams' planes */
+  const float *left, *right;
+  int16_t *pcm;                 /* [n][2048][2] */
+} XaacEsbrPcmOutParams;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+hipError_t xaac_launch_esbr_core_from_pcm16(const XaacEsbrCoreInParams *p, hipStream_t stream);
+hipError_t xaac_launch_esbr_pcm16_from_float(const XaacEsbrPcmOutParams *p, hipStream_t stream);
 hipError_t xaac_launch_esbr_analysis(const XaacEsbrAnaParams *p, hipStream_t stream);
 hipError_t xaac_launch_esbr_synthesis(const XaacEsbrSynParams *p, hipStream_t stream);
 #ifdef __cplusplus

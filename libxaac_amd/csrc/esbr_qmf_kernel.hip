@@ -213,6 +213,43 @@ __global__ __launch_bounds__(64) void xaac_esbr_synthesis_kernel(XaacEsbrSynPara
   }
 }
 
+/* The two hand-offs around the Path A branch (decoder/ixheaacd_api.c:3385-3432, decoder/ixheaacd_decode_main.c:82-107): the
+   core decoder's 16-bit PCM (channels interleaved) as floats, one plane per channel; and the branch's float output as 16-bit
+   PCM, saturated and truncated towards zero, two channels interleaved.  One thread per output sample pair / sample. */
+__global__ __launch_bounds__(256) void xaac_esbr_core_from_pcm16_kernel(XaacEsbrCoreInParams p) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; /* element of pcm: ((element * 1024 + k) * ch_fac + c) */
+  if (e >= (size_t)p.n_ch * 1024) return;
+  const int cf = p.ch_fac;
+  const size_t el = e / ((size_t)1024 * cf), r = e % ((size_t)1024 * cf);
+  const int k = (int)(r / cf), c = (int)(r % cf);
+  p.core[(el * cf + c) * 1024 + k] = (float)p.pcm[e];
+}
+__global__ __launch_bounds__(256) void xaac_esbr_pcm16_from_float_kernel(XaacEsbrPcmOutParams p) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; /* (stream, sample) */
+  if (e >= (size_t)p.n * 2048) return;
+  const size_t i = e >> 11, k = e & 2047;
+  const auto sat = [](float v) { /* decode_main.c:96-104 */
+    if (v > 32767.0f) v = 32767.0f;
+    else if (v < -32768.0f) v = -32768.0f;
+    return (int16_t)v;
+  };
+  short2 o;
+  o.x = sat(p.left[i * p.stride + k]);
+  o.y = sat(p.right[i * p.stride + k]);
+  reinterpret_cast<short2 *>(p.pcm)[e] = o;
+}
+
+extern "C" hipError_t xaac_launch_esbr_core_from_pcm16(const XaacEsbrCoreInParams *p, hipStream_t stream) {
+  const size_t total = (size_t)p->n_ch * 1024;
+  hipLaunchKernelGGL(xaac_esbr_core_from_pcm16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, *p);
+  return hipGetLastError();
+}
+extern "C" hipError_t xaac_launch_esbr_pcm16_from_float(const XaacEsbrPcmOutParams *p, hipStream_t stream) {
+  const size_t total = (size_t)p->n * 2048;
+  hipLaunchKernelGGL(xaac_esbr_pcm16_from_float_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, *p);
+  return hipGetLastError();
+}
+
 extern "C" hipError_t xaac_launch_esbr_analysis(const XaacEsbrAnaParams *p, hipStream_t stream) {
   hipLaunchKernelGGL(xaac_esbr_analysis_kernel, dim3((p->n_ch + 1) / 2), dim3(64), XAAC_ESBR_ANA_LDS, stream, *p);
   return hipGetLastError();

@@ -356,6 +356,28 @@ int32_t xaac_esbr_sbr_process_batch(xaac_ctx *c, const xaac_esbr_sbr_batch *b) {
   return XAAC_OK;
 }
 
+int32_t xaac_esbr_core_from_pcm16_batch(xaac_ctx *c, const xaac_esbr_core_in_batch *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n_ch < 0 || (b->ch_fac != 1 && b->ch_fac != 2) || b->n_ch % b->ch_fac) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch == 0) return XAAC_OK;
+  if (!b->pcm || !b->core) return XAAC_FATAL_NULL_ARG;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  XaacEsbrCoreInParams p = {b->n_ch, b->ch_fac, b->pcm, b->core};
+  if (!hip_ok(xaac_launch_esbr_core_from_pcm16(&p, c->stream))) return XAAC_FATAL_HIP;
+  return XAAC_OK;
+}
+
+int32_t xaac_esbr_pcm16_from_float_batch(xaac_ctx *c, const xaac_esbr_pcm_out_batch *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n < 0 || b->stride < 2048) return XAAC_FATAL_BAD_ARG;
+  if (b->n == 0) return XAAC_OK;
+  if (!b->left || !b->right || !b->pcm) return XAAC_FATAL_NULL_ARG;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  XaacEsbrPcmOutParams p = {b->n, b->stride, b->left, b->right, b->pcm};
+  if (!hip_ok(xaac_launch_esbr_pcm16_from_float(&p, c->stream))) return XAAC_FATAL_HIP;
+  return XAAC_OK;
+}
+
 int32_t xaac_sbr_state_handover(xaac_ctx *c, const xaac_sbr_handover_batch *b) {
   if (!c || !b) return XAAC_FATAL_NULL_ARG;
   if (b->n < 0 || (b->mode != XAAC_HANDOVER_PS_START && b->mode != XAAC_HANDOVER_STEREO_START)) return XAAC_FATAL_BAD_ARG;

@@ -342,8 +342,8 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
         pcm = dz(n * 1024 * n_ch, dtype=torch.int16)
         pcm_h = pinned(n * 1024 * n_ch, dtype=torch.int16)
     elif esbr:
-        # Path A: IMDCT (16-bit core PCM, one plane per channel) -> float -> the eSBR chain -> saturate / truncate to 16 bit
-        # (ixheaacd_samples_sat, decode_main.c:82-107); every state member stays on the device
+        # Path A: IMDCT (16-bit core PCM) -> xaac_esbr_core_from_pcm16_batch -> the eSBR chain -> xaac_esbr_pcm16_from_float_batch
+        # (saturate / truncate to 16 bit: ixheaacd_samples_sat, decode_main.c:82-107); every state member stays on the device
         state = torch.from_numpy(np.tile(_struct_bytes(lib.xaac_esbr_state_init, ESBR_STATE_BYTES), (nc, 1)).copy()).to(dev)
         hbe = dz(nc, HBE_STATE_BYTES)
         core16 = dz(nc * 1024, dtype=torch.int16)
@@ -351,6 +351,8 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
         status = dz(nc, dtype=torch.int32)
         ws = dz(ctx.esbr_workspace_bytes(nc))
         out_l, out_r = dz(nc, 2048, dtype=torch.float32), None
+        core = dz(nc, 1024, dtype=torch.float32)
+        pcm = dz(n * 2048 * 2, dtype=torch.int16)
         pcm_h = pinned(n * 2048 * 2, dtype=torch.int16)
         if n_ch == 1:
             ps_state = torch.from_numpy(np.tile(_struct_bytes(lib.xaac_esbr_ps_state_init, ESBR_PS_STATE_BYTES), (n, 1)).copy()).to(dev)
@@ -440,7 +442,7 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
                 hist[:, _ES_PH_IM:_ES_PH_IM + 512] = pv_im[:, 24:].reshape(k, 512)
                 st32.index_copy_(0, rows, hist)
                 hbe.index_copy_(0, rows, hb)
-            core = core16.view(n, 1024, n_ch).transpose(1, 2).to(torch.float32).contiguous().view(nc, 1024)
+            ctx.esbr_core_from_pcm16(core16, core, ch_fac=n_ch)
             if _trace is not None:   # debugging: the device states in front of the chain call
                 _trace(dict(state=state, hbe=hbe, ps_state=ps_state if n_ch == 1 else None, core=core, side=eside_d, header=hdr_d,
                             frame=frm_d))
@@ -451,14 +453,14 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
                 psf_d.copy_(psf_h, non_blocking=True)
                 ctx.esbr_sbr_process_batch(core, hdr_d, frm_d, eside_d, state, out_l, ws, status=status, ps_frame=psf_d,
                                            ps_state=ps_state, out_r=out_r, hbe_state=hbe)
-                both = torch.stack((out_l, out_r), dim=2)                                   # [n, 2048, 2]
+                ctx.esbr_pcm16_from_float(out_l, out_r, pcm)
             elif n_ch == 1:
                 ctx.esbr_sbr_process_batch(core, hdr_d, frm_d, eside_d, state, out_l, ws, status=status, hbe_state=hbe)
-                both = out_l.view(n, 2048, 1).expand(n, 2048, 2)                            # mono twice (api.c:3639-3660)
+                ctx.esbr_pcm16_from_float(out_l, out_l, pcm)                                # mono twice (api.c:3639-3660)
             else:
                 ctx.esbr_sbr_process_batch(core, hdr_d, frm_d, eside_d, state, out_l, ws, status=status, hbe_state=hbe)
-                both = out_l.view(n, 2, 2048).transpose(1, 2)
-            pcm_h.copy_(both.clamp(-32768.0, 32767.0).to(torch.int16).reshape(-1), non_blocking=True)
+                ctx.esbr_pcm16_from_float(out_l, out_l[1:], pcm, stride=4096)
+            pcm_h.copy_(pcm, non_blocking=True)
             bad = int(status.min().item())    # also the step's synchronisation point
             if bad < 0:
                 raise RuntimeError("the eSBR kernels refused a frame")
