@@ -1,10 +1,11 @@
 /*
  * xaacdec_amd.cpp -- the native command line decoder of this repo: ADTS AAC-LC / HE-AAC / HE-AACv2 in, 16-bit WAV out, as
- * `xaacdec -esbr:0` (test/decoder/ixheaacd_main.c over decoder/ixheaacd_api.c:2624-3788) decodes it, with the repo's own
+ * `xaacdec` (test/decoder/ixheaacd_main.c over decoder/ixheaacd_api.c:2624-3788) decodes it -- with the reference's default
+ * -esbr:1 (SBR streams through the float eSBR tools, "Path A") or with -esbr:0 (the fixed-point SBR tools) -- with the repo's own
  * host front end (include/xaac_parse.h, CPU threads) in front of the GPU entry points of include/xaac_amd.h and every
  * stream's state resident in device memory.  No reference code, no Python, no torch: HIP runtime + the two libraries.
  *
- *   xaacdec_amd -ifile:<in.aac> -ofile:<out.wav> [-copies:<N>] [-verify] [-threads:<T>] [-quiet]
+ *   xaacdec_amd -ifile:<in.aac> -ofile:<out.wav> [-esbr:<0|1>] [-copies:<N>] [-verify] [-threads:<T>] [-quiet]
  *
  * -copies:N decodes N instances of the stream in one lock-step batch (the first one's PCM is written; with -verify all N are
  * compared with it word for word) and prints the end-to-end rate: the shape a serving host has, with one input here for brevity.
@@ -16,6 +17,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <mutex>
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -25,6 +27,7 @@
 #include <vector>
 
 #include "../../include/xaac_amd.h"
+#include "../../include/xaac_esbr.h"
 #include "../../include/xaac_parse.h"
 
 namespace {
@@ -65,6 +68,7 @@ struct Staging { /* what one step's parse leaves for the GPU */
   xaac_sbr_header *header;
   xaac_sbr_frame *frame;
   xaac_ps_frame *ps;
+  xaac_esbr_side *eside;
   std::vector<int32_t> flags, status;
   std::vector<uint64_t> consumed;
   int delivered;
@@ -87,7 +91,7 @@ void write_wav(const std::string &path, const std::vector<int16_t> &pcm, int cha
 
 int main(int argc, char **argv) {
   std::string in, out;
-  int copies = 1, threads = 0, quiet = 0, verify = 0, profile = 0;
+  int copies = 1, threads = 0, quiet = 0, verify = 0, profile = 0, esbr = 1;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
     if (a.rfind("-ifile:", 0) == 0) in = a.substr(7);
@@ -97,10 +101,12 @@ int main(int argc, char **argv) {
     else if (a == "-quiet") quiet = 1;
     else if (a == "-verify") verify = 1;
     else if (a == "-profile") profile = 1; /* synchronise behind every phase of a step and report the seconds spent in each */
-    else if (a.rfind("-esbr:", 0) == 0 && a != "-esbr:0") die("only the -esbr:0 interpretation of the SBR payload is built");
+    else if (a == "-esbr:0") esbr = 0;
+    else if (a == "-esbr:1") esbr = 1;
+    else if (a.rfind("-esbr", 0) == 0) die("-esbr:0 or -esbr:1");
   }
   if (in.empty() || out.empty() || copies < 1) {
-    fprintf(stderr, "usage: xaacdec_amd -ifile:<in.aac> -ofile:<out.wav> [-copies:N] [-threads:T] [-quiet]\n");
+    fprintf(stderr, "usage: xaacdec_amd -ifile:<in.aac> -ofile:<out.wav> [-esbr:0|1] [-copies:N] [-threads:T] [-quiet]\n");
     return 1;
   }
   std::vector<uint8_t> data;
@@ -130,6 +136,7 @@ int main(int argc, char **argv) {
     sbr = cf[0].sbr_bytes > 0 || hdr.sampling_rate <= 24000;
     xaac_parser_destroy(probe);
   }
+  if (!sbr) esbr = 0; /* AAC-LC streams decode the same either way */
   const int out_ch = sbr ? 2 : n_ch; /* SBR streams come out in stereo (PS, or the mono column twice); AAC-LC as coded */
   const int N = copies, NC = N * n_ch, NCD = NC, rate = hdr.sampling_rate, out_rate = sbr ? 2 * rate : rate, per = sbr ? 2048 : 1024;
 
@@ -139,7 +146,10 @@ int main(int argc, char **argv) {
   HIP(hipStreamCreate(&stream));
   XA(xaac_create(&ctx, 0, stream));
   std::vector<xaac_parser *> parser((size_t)N);
-  for (auto &p : parser) XA(xaac_parser_create(&p));
+  for (auto &p : parser) {
+    XA(xaac_parser_create(&p));
+    if (esbr) XA(xaac_parser_set_esbr(p, 1));
+  }
   std::vector<const uint8_t *> ptr((size_t)N);
   std::vector<uint64_t> left((size_t)N), pos((size_t)N, 0);
 
@@ -162,6 +172,13 @@ int main(int argc, char **argv) {
   xaac_ps_frame *d_psf = nullptr;
   xaac_ps_state *d_ps_state = nullptr;
   int32_t *d_idx = nullptr;
+  /* Path A (-esbr:1) */
+  xaac_esbr_side *d_eside = nullptr;
+  xaac_esbr_state *d_estate = nullptr;
+  xaac_hbe_state *d_hbe = nullptr;
+  xaac_esbr_ps_state *d_eps = nullptr;
+  float *d_fcore = nullptr, *d_out_l = nullptr, *d_out_r = nullptr, *d_q = nullptr, *d_pv = nullptr;
+  bool reset_seen = false;
   void *d_ws = nullptr;
   uint64_t ws_bytes = 0;
   if (!sbr) {
@@ -173,6 +190,27 @@ int main(int argc, char **argv) {
     if (delay < 0) die("xaac_peak_limiter_init", delay);
     for (int i = 0; i < N; i++) HIP(hipMemcpy(d_lim + i, &l0, sizeof(l0), hipMemcpyHostToDevice));
     ws_bytes = xaac_peak_limiter_workspace_bytes(N);
+  } else if (esbr) {
+    d_core = dev<int16_t>((size_t)NC * 1024);
+    d_header = dev<xaac_sbr_header>((size_t)NC);
+    d_frame = dev<xaac_sbr_frame>((size_t)NC);
+    d_eside = dev<xaac_esbr_side>((size_t)NC);
+    d_estate = dev<xaac_esbr_state>((size_t)NC);
+    d_hbe = dev<xaac_hbe_state>((size_t)NC); /* all zero for a new stream */
+    d_fcore = dev<float>((size_t)NC * 1024);
+    d_out_l = dev<float>((size_t)NC * 2048);
+    static xaac_esbr_state e0;
+    xaac_esbr_state_init(&e0);
+    for (int i = 0; i < NC; i++) HIP(hipMemcpy(d_estate + i, &e0, sizeof(e0), hipMemcpyHostToDevice));
+    if (n_ch == 1) {
+      d_psf = dev<xaac_ps_frame>((size_t)N);
+      d_eps = dev<xaac_esbr_ps_state>((size_t)N);
+      d_out_r = dev<float>((size_t)N * 2048);
+      static xaac_esbr_ps_state p0;
+      xaac_esbr_ps_state_init(&p0);
+      for (int i = 0; i < N; i++) HIP(hipMemcpy(d_eps + i, &p0, sizeof(p0), hipMemcpyHostToDevice));
+    }
+    ws_bytes = xaac_esbr_workspace_bytes(NC);
   } else {
     d_core = dev<int16_t>((size_t)NC * 1024);
     d_header = dev<xaac_sbr_header>((size_t)NC);
@@ -203,6 +241,7 @@ int main(int argc, char **argv) {
     s.header = sbr ? pinned<xaac_sbr_header>((size_t)NC) : nullptr;
     s.frame = sbr ? pinned<xaac_sbr_frame>((size_t)NC) : nullptr;
     s.ps = (sbr && n_ch == 1) ? pinned<xaac_ps_frame>((size_t)N) : nullptr;
+    s.eside = esbr ? pinned<xaac_esbr_side>((size_t)NC) : nullptr;
     s.flags.assign((size_t)N * 8, 0), s.status.assign((size_t)N, 0), s.consumed.assign((size_t)N, 0);
     s.delivered = 0;
   }
@@ -215,7 +254,7 @@ int main(int argc, char **argv) {
     b.n_streams = N, b.n_ch = n_ch, b.with_sbr = sbr, b.ps_enable = 1, b.stage = 2, b.threads = threads;
     b.parser = parser.data(), b.data = ptr.data(), b.bytes = left.data();
     b.spec = s->spec, b.ics = s->ics, b.header = s->header, b.frame = s->frame, b.ps_frame = s->ps;
-    b.flags = s->flags.data(), b.consumed = s->consumed.data(), b.status = s->status.data();
+    b.flags = s->flags.data(), b.consumed = s->consumed.data(), b.status = s->status.data(), b.esbr_side = s->eside;
     const int ok = xaac_parse_batch_run(&b);
     if (ok < 0) die("xaac_parse_batch_run", ok);
     for (int i = 0; i < N; i++) {
@@ -289,6 +328,65 @@ int main(int argc, char **argv) {
       lb.n_streams = N, lb.frame_len = 1024, lb.samples = d_out32, lb.stride = 1024 * n_ch, lb.qshift_adj = d_qadj, lb.state = d_lim;
       lb.num_channels = n_ch, lb.pcm16 = d_pcm, lb.workspace = d_ws, lb.workspace_bytes = ws_bytes;
       XA(xaac_peak_limiter_process_batch(ctx, &lb));
+    } else if (esbr) { /* Path A: IMDCT -> float planes -> eSBR chain (+ transposer, float PS) -> samples_sat */
+      ib.pcm16 = d_core, ib.pcm_mode = XAAC_PCM_SBR;
+      XA(xaac_imdct_process_batch(ctx, &ib));
+      int resets = 0, with_ps = 0;
+      for (int i = 0; i < N; i++) resets += s.flags[(size_t)i * 8 + 1] != 0, with_ps += s.flags[(size_t)i * 8 + 5] != 0;
+      if ((resets != 0 && resets != N) || (with_ps != 0 && with_ps != N)) die("a batch mixing kinds of frames");
+      if (resets) {
+        /* ixheaacd_sbr_dec_reset for Path A (sbrdecoder.c:175-236): the transposer's parameters from the new band tables, then
+           its two runs over rows 8..39 and 24..55 of the QMF history -- at a stream's first reset the rows in front of the
+           state's history are zero and rows 32..55 are its rows 0..23 */
+        if (reset_seen) die("-esbr:1 decoding of a stream whose SBR header changes after the first is not built");
+        reset_seen = true;
+        static xaac_hbe_state h0;
+        constexpr size_t kTail = sizeof(xaac_hbe_state) - offsetof(xaac_hbe_state, synth_size); /* the integers behind the (still zero) buffers */
+        std::vector<uint8_t> tail((size_t)NC * kTail);
+        for (int i = 0; i < NC; i++) {
+          xaac_hbe_state_init(&h0);
+          if (xaac_hbe_state_reinit(&h0, &s.header[(size_t)i])) die("the QMF transposer refused the SBR band tables");
+          memcpy(&tail[(size_t)i * kTail], &h0.synth_size, kTail);
+        }
+        HIP(hipMemcpy2D(&d_hbe[0].synth_size, sizeof(xaac_hbe_state), tail.data(), kTail, kTail, (size_t)NC, hipMemcpyHostToDevice));
+        if (!d_q) d_q = dev<float>((size_t)NC * 2 * 2048), d_pv = dev<float>((size_t)NC * 2 * 2048);
+        float *q_re = d_q, *q_im = d_q + (size_t)NC * 2048, *pv_re = d_pv, *pv_im = d_pv + (size_t)NC * 2048;
+        xaac_hbe_apply_batch_desc hb;
+        memset(&hb, 0, sizeof(hb));
+        hb.n_ch = NC, hb.qmf_re = q_re, hb.qmf_im = q_im, hb.state = d_hbe, hb.pv_re = pv_re, hb.pv_im = pv_im, hb.status = d_status;
+        HIP(hipMemsetAsync(d_q, 0, (size_t)NC * 2 * 2048 * 4, stream));
+        HIP(hipMemsetAsync(d_pv, 0, (size_t)NC * 2 * 2048 * 4, stream));
+        XA(xaac_hbe_apply_batch(ctx, &hb));
+        HIP(hipMemcpy2DAsync(q_re + 16 * 64, 2048 * 4, &d_estate[0].qmf_re[8][0], sizeof(xaac_esbr_state), 16 * 64 * 4, (size_t)NC,
+                             hipMemcpyDeviceToDevice, stream));
+        HIP(hipMemcpy2DAsync(q_im + 16 * 64, 2048 * 4, &d_estate[0].qmf_im[8][0], sizeof(xaac_esbr_state), 16 * 64 * 4, (size_t)NC,
+                             hipMemcpyDeviceToDevice, stream));
+        HIP(hipMemsetAsync(d_pv, 0, (size_t)NC * 2 * 2048 * 4, stream));
+        XA(xaac_hbe_apply_batch(ctx, &hb));
+        HIP(hipMemcpy2DAsync(&d_estate[0].ph_re[0][0], sizeof(xaac_esbr_state), pv_re + 24 * 64, 2048 * 4, 8 * 64 * 4, (size_t)NC,
+                             hipMemcpyDeviceToDevice, stream));
+        HIP(hipMemcpy2DAsync(&d_estate[0].ph_im[0][0], sizeof(xaac_esbr_state), pv_im + 24 * 64, 2048 * 4, 8 * 64 * 4, (size_t)NC,
+                             hipMemcpyDeviceToDevice, stream));
+      }
+      HIP(hipMemcpyAsync(d_header, s.header, (size_t)NC * sizeof(xaac_sbr_header), hipMemcpyHostToDevice, stream));
+      HIP(hipMemcpyAsync(d_frame, s.frame, (size_t)NC * sizeof(xaac_sbr_frame), hipMemcpyHostToDevice, stream));
+      HIP(hipMemcpyAsync(d_eside, s.eside, (size_t)NC * sizeof(xaac_esbr_side), hipMemcpyHostToDevice, stream));
+      xaac_esbr_core_in_batch cb = {NC, n_ch, d_core, d_fcore};
+      XA(xaac_esbr_core_from_pcm16_batch(ctx, &cb));
+      xaac_esbr_sbr_batch b;
+      memset(&b, 0, sizeof(b));
+      b.n_ch = NC, b.core = d_fcore, b.header = d_header, b.frame = d_frame, b.side = d_eside, b.state = d_estate, b.out = d_out_l;
+      b.status = d_status, b.workspace = d_ws, b.workspace_bytes = ws_bytes, b.hbe_state = d_hbe;
+      xaac_esbr_pcm_out_batch ob = {N, 2048, d_out_l, d_out_l, d_pcm}; /* a mono channel twice (api.c:3639-3660) */
+      if (with_ps) {
+        HIP(hipMemcpyAsync(d_psf, s.ps, (size_t)N * sizeof(xaac_ps_frame), hipMemcpyHostToDevice, stream));
+        b.ps_frame = d_psf, b.ps_state = d_eps, b.out_r = d_out_r;
+        ob.right = d_out_r;
+      } else if (n_ch == 2) {
+        ob.stride = 4096, ob.right = d_out_l + 2048;
+      }
+      XA(xaac_esbr_sbr_process_batch(ctx, &b));
+      XA(xaac_esbr_pcm16_from_float_batch(ctx, &ob));
     } else {
       ib.pcm16 = d_core, ib.pcm_mode = XAAC_PCM_SBR;
       XA(xaac_imdct_process_batch(ctx, &ib));
@@ -359,7 +457,7 @@ int main(int argc, char **argv) {
         }
       }
     }
-    if (!(sbr && n_ch == 1)) {
+    if (!(sbr && n_ch == 1 && !esbr)) {
       lap(1);
       HIP(hipMemcpyAsync(h_pcm, d_pcm, (size_t)N * per * out_ch * 2, hipMemcpyDeviceToHost, stream));
       if (sbr) HIP(hipMemcpyAsync(h_status, d_status, (size_t)NC * 4, hipMemcpyDeviceToHost, stream));
@@ -370,7 +468,9 @@ int main(int argc, char **argv) {
     }
     lap(2);
     const size_t skip = (!sbr && first) ? (size_t)delay * out_ch : 0; /* the limiter's delay is cut from the first frame */
-    pcm.insert(pcm.end(), h_pcm + skip, h_pcm + (size_t)per * out_ch);
+    /* (with -esbr:1 the reference's command line decoder does not write an SBR stream's first frame:
+       test/decoder/ixheaacd_main.c:2181-2186) */
+    if (!(esbr && first)) pcm.insert(pcm.end(), h_pcm + skip, h_pcm + (size_t)per * out_ch);
     for (int i = 1; verify && i < N; i++)
       mismatched += memcmp(h_pcm, h_pcm + (size_t)i * per * out_ch, (size_t)per * out_ch * 2) != 0;
     frames += N;
@@ -404,9 +504,9 @@ int main(int argc, char **argv) {
   if (!quiet)
     printf("{\"frames\": %ld, \"streams\": %d, \"wall_s\": %.4f, \"parse_s\": %.4f, \"frames_per_s\": %.1f, "
            "\"frames_per_s_after_first_step\": %.1f, \"mismatched_copies\": %ld, \"samples\": %zu, \"rate\": %d, \"sbr\": %d, "
-           "\"channels\": %d}\n",
+           "\"channels\": %d, \"esbr\": %d}\n",
            frames, N, wall, parse_s, frames / wall, frames > N && steady > 0 ? (frames - N) / steady : 0.0, mismatched,
-           pcm.size() / out_ch, out_rate, sbr, n_ch);
+           pcm.size() / out_ch, out_rate, sbr, n_ch, esbr);
   if (profile)
     printf("{\"h2d_s\": %.4f, \"kernels_s\": %.4f, \"d2h_s\": %.4f, \"host_pcm_s\": %.4f}\n", phase_s[0], phase_s[1], phase_s[2], phase_s[3]);
   return mismatched ? 3 : 0;

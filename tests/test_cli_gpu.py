@@ -1,6 +1,7 @@
 """libxaac_amd/xaacdec_amd, the native command line decoder (host front end + GPU back end, HIP runtime only: no Python, no
 torch, no reference code in the process), on the committed ADTS streams: its WAV payload must equal what the reference
-decoder writes (`oracle/_ref/xaacdec -esbr:0`, and the committed CRCs of that), also when it decodes a batch of copies."""
+decoder writes, with the same flags -- none (the reference's default -esbr:1: SBR streams through Path A) and -esbr:0 -- live
+against `oracle/_ref/xaacdec` and against the committed CRCs of its output, also when it decodes a batch of copies."""
 import json
 import os
 import subprocess
@@ -31,24 +32,27 @@ def run(name, tmp_path, *flags):
         return w.readframes(w.getnframes()), w.getframerate(), json.loads(p.stdout.strip().splitlines()[-1]), w.getnchannels()
 
 
+@pytest.mark.parametrize("flags", [(), ("-esbr:0",)], ids=["default", "esbr0"])
 @pytest.mark.parametrize("name", NAMES)
-def test_wav_equals_the_reference_decoders(name, tmp_path):
-    pcm, rate, info, channels = run(name, tmp_path)
+def test_wav_equals_the_reference_decoders(name, flags, tmp_path):
+    pcm, rate, info, channels = run(name, tmp_path, *flags)
     gold = np.load(os.path.join(ROOT, "tests", "golden", "decoder_ref.npz"))
     k = GOLD_ORDER.index(name)
-    assert (len(pcm) // (2 * channels), rate) == (int(gold["samples"][k]), int(gold["rate"][k]))
-    assert zlib.crc32(pcm) & 0xffffffff == int(gold["crc"][k])
+    samples, crc = ("samples", "crc") if flags else ("samples_esbr", "crc_esbr")
+    assert (len(pcm) // (2 * channels), rate) == (int(gold[samples][k]), int(gold["rate"][k]))
+    assert zlib.crc32(pcm) & 0xffffffff == int(gold[crc][k])
     ref = os.path.join(ROOT, "oracle", "_ref", "xaacdec")
     if not os.path.exists(ref):
         pytest.fail("oracle/_ref/xaacdec missing: the reference binary did not travel with the snapshot")
     want = str(tmp_path / "ref.wav")
-    subprocess.run([ref, "-ifile:" + os.path.join(STREAMS, name + ".aac"), "-ofile:" + want, "-esbr:0"], check=True, capture_output=True)
+    subprocess.run([ref, "-ifile:" + os.path.join(STREAMS, name + ".aac"), "-ofile:" + want, *flags], check=True, capture_output=True)
     with wave.open(want) as w:
         assert w.getnchannels() == channels and w.readframes(w.getnframes()) == pcm
 
 
+@pytest.mark.parametrize("flags", [(), ("-esbr:0",)], ids=["default", "esbr0"])
 @pytest.mark.parametrize("name", ["mix_aot29_32k", "mix_aot5_48k", "mix_aot2_64k"])
-def test_a_batch_of_copies(name, tmp_path):
-    one, _, _, _ = run(name, tmp_path)
-    many, _, info, _ = run(name, tmp_path, "-copies:64", "-verify")
+def test_a_batch_of_copies(name, flags, tmp_path):
+    one, _, _, _ = run(name, tmp_path, *flags)
+    many, _, info, _ = run(name, tmp_path, "-copies:64", "-verify", *flags)
     assert many == one and info["streams"] == 64 and info["mismatched_copies"] == 0
