@@ -47,7 +47,7 @@ class SbrSide(ctypes.Structure):
 
 
 def host_library_path():
-    return os.path.join(_HERE, "libxaac_host.so")
+    return os.environ.get("XAAC_HOST_LIBRARY") or os.path.join(_HERE, "libxaac_host.so")
 
 
 def load_host_library():

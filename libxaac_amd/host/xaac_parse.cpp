@@ -5,13 +5,16 @@
 #include "../../include/xaac_parse.h"
 
 #include <atomic>
-#include <condition_variable>
 #include <functional>
 #include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
+#include <limits.h>
+#include <linux/futex.h>
 #include <string.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include "aac_core.h"
 #include "sbr_side.h"
@@ -27,39 +30,55 @@ struct xaac_parser {
   xaac_sbr_side side_scratch;
 };
 
-/* A small persistent team for xaac_parse_batch_run: workers sleep on a condition variable between calls (a host that also
-   drives a GPU must not have its cores spun on by idle parser threads), take items in chunks from a shared counter, and the
-   caller works along.  One batch call at a time (calls from several threads are serialised). */
+/* A small persistent team for xaac_parse_batch_run.  Workers wait for the next call on a generation counter: a short spin
+   (batches of a running decoder follow each other within microseconds), then asleep in the kernel on a futex -- a host
+   that also drives a GPU must not have its cores spun on by idle parser threads, and a wake-up must not pass a mutex
+   from thread to thread (with a condition variable the team's wake-up alone cost more than the parsing from 128 threads
+   on).  Items are taken in chunks from a shared counter and the caller works along.  One batch call at a time (calls
+   from several threads are serialised). */
 namespace {
+inline void futex_wait(std::atomic<uint32_t> *a, uint32_t expected) {
+  syscall(SYS_futex, reinterpret_cast<uint32_t *>(a), FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0);
+}
+inline void futex_wake_all(std::atomic<uint32_t> *a) {
+  syscall(SYS_futex, reinterpret_cast<uint32_t *>(a), FUTEX_WAKE_PRIVATE, INT32_MAX, nullptr, nullptr, 0);
+}
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#endif
+}
 class Team {
  public:
   void run(int items, int threads, const std::function<void(int)> &fn) {
     std::lock_guard<std::mutex> serial(call_);
     if (threads < 1) threads = 1;
     grow(threads - 1);
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      fn_ = &fn, items_ = items, next_.store(0), active_ = threads - 1, pending_ = threads - 1, generation_++;
-    }
-    if (threads > 1) wake_.notify_all();
+    fn_ = &fn, items_ = items, active_ = threads - 1;
+    next_.store(0, std::memory_order_relaxed);
+    pending_.store((uint32_t)(threads - 1), std::memory_order_relaxed);
+    generation_.fetch_add(1, std::memory_order_release); /* publishes the job */
+    if (threads > 1) futex_wake_all(&generation_);
     work();
-    std::unique_lock<std::mutex> lk(mu_);
-    done_.wait(lk, [&] { return pending_ == 0; });
+    for (int spin = 0;;) { /* the workers that took part */
+      const uint32_t p = pending_.load(std::memory_order_acquire);
+      if (p == 0) break;
+      if (++spin < kSpin) cpu_relax();
+      else futex_wait(&pending_, p);
+    }
     fn_ = nullptr;
   }
   ~Team() {
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      quit_ = true;
-    }
-    wake_.notify_all();
+    quit_.store(true, std::memory_order_release);
+    generation_.fetch_add(1, std::memory_order_release);
+    futex_wake_all(&generation_);
     for (auto &t : workers_) t.join();
   }
 
  private:
   void work() {
     for (;;) {
-      const int first = next_.fetch_add(kChunk);
+      const int first = next_.fetch_add(kChunk, std::memory_order_relaxed);
       if (first >= items_) return;
       const int last = first + kChunk < items_ ? first + kChunk : items_;
       for (int i = first; i < last; i++) (*fn_)(i);
@@ -68,31 +87,35 @@ class Team {
   void grow(int n) {
     while ((int)workers_.size() < n) {
       const int id = (int)workers_.size();
-      workers_.emplace_back([this, id] {
-        uint64_t seen = 0;
+      const uint32_t born = generation_.load(std::memory_order_acquire);
+      workers_.emplace_back([this, id, born] {
+        uint32_t seen = born;
         for (;;) {
-          {
-            std::unique_lock<std::mutex> lk(mu_);
-            wake_.wait(lk, [&] { return quit_ || (generation_ != seen && id < active_); });
-            if (quit_) return;
-            seen = generation_;
+          uint32_t g;
+          for (int spin = 0;;) {
+            g = generation_.load(std::memory_order_acquire);
+            if (g != seen) break;
+            if (++spin < kSpin) cpu_relax();
+            else futex_wait(&generation_, seen);
           }
+          if (quit_.load(std::memory_order_acquire)) return;
+          seen = g;
+          if (id >= active_) continue; /* this call uses fewer threads than the team has */
           work();
-          std::lock_guard<std::mutex> lk(mu_);
-          if (--pending_ == 0) done_.notify_all();
+          if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) futex_wake_all(&pending_);
         }
       });
     }
   }
   static constexpr int kChunk = 4;
-  std::mutex call_, mu_;
-  std::condition_variable wake_, done_;
+  static constexpr int kSpin = 4000; /* a few tens of microseconds */
+  std::mutex call_;
   std::vector<std::thread> workers_;
   const std::function<void(int)> *fn_ = nullptr;
   std::atomic<int> next_{0};
-  int items_ = 0, active_ = 0, pending_ = 0;
-  uint64_t generation_ = 0;
-  bool quit_ = false;
+  std::atomic<uint32_t> generation_{0}, pending_{0};
+  std::atomic<bool> quit_{false};
+  int items_ = 0, active_ = 0;
 };
 Team &team() {
   static Team t;
@@ -240,10 +263,11 @@ int32_t xaac_parse_batch_run(const xaac_parse_batch *b) {
     return XAAC_PARSE_ERR_SYNTAX;
   const int n_ch = b->n_ch;
   std::atomic<int> ok{0};
-  /* default: one thread per physical core as far as the machine tells (half its hardware threads), at most 64 -- beyond
-     that the staging arrays' memory traffic, not the parsing, sets the pace */
+  /* default: half the machine's hardware threads, at most 48 -- measured on a 2 x 64-core host (tools/bench_parser_scaling.py):
+     3 - 4 x 10^6 HE-AACv2 frames/s at 32 .. 48 threads, less from 64 on (4096 streams x 20 KB of parser state are a
+     latency-bound walk through memory that the second socket's threads only slow down) */
   int hw = (int)std::thread::hardware_concurrency();
-  int threads = b->threads > 0 ? b->threads : (hw >= 4 ? (hw / 2 > 64 ? 64 : hw / 2) : (hw > 0 ? hw : 1));
+  int threads = b->threads > 0 ? b->threads : (hw >= 4 ? (hw / 2 > 48 ? 48 : hw / 2) : (hw > 0 ? hw : 1));
   if (threads > (b->n_streams + 3) / 4) threads = b->n_streams > 0 ? (b->n_streams + 3) / 4 : 1;
   team().run(b->n_streams, threads, [&](int i) {
     xaac_parser *p = b->parser[i];
