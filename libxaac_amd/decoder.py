@@ -116,8 +116,9 @@ class StreamParser:
         if rc:
             raise ParseError(rc, 0)
         self.n_ch = self.core.n_ch
-        # an SBR decoder exists for streams that carry SBR data or run at 24 kHz and below (implicit signalling, api.c:2160)
-        self.sbr = bool(self.core.sbr_bytes > 0 or self.core_rate <= 24000) if with_sbr is None else bool(with_sbr)
+        # the SBR tools run for the frames that carry an SBR payload (api.c:3369-3373: a stream at 24 kHz and below gets an SBR
+        # decoder object by implicit signalling, api.c:2160, but without payloads it is never called: plain AAC-LC output)
+        self.sbr = bool(self.core.sbr_bytes > 0) if with_sbr is None else bool(with_sbr)
 
     def close(self):
         if self.h:
@@ -224,7 +225,7 @@ class BatchParser:
         self.lib.xaac_parser_destroy(probe)
         if rc:
             raise ParseError(rc, 0)
-        self.sbr = bool(core.sbr_bytes > 0 or self.core_rate <= 24000)
+        self.sbr = bool(core.sbr_bytes > 0)
 
     def close(self):
         for i in range(self.n):

@@ -121,7 +121,8 @@ int main(int argc, char **argv) {
     fclose(f);
     data.resize((size_t)n);
   }
-  /* a look at frame 0: channels, SBR or not (api.c:2160: payload in the first frame, or a core rate of 24 kHz and below) */
+  /* a look at frame 0: channels, SBR or not (api.c:3369-3373: the SBR tools run for frames with an SBR payload; a stream at
+     24 kHz and below has an SBR decoder object by implicit signalling, api.c:2160, which is never called without payloads) */
   xaac_adts_header hdr;
   if (xaac_adts_parse_header(data.data(), data.size(), &hdr)) die("ADTS header");
   int n_ch, sbr;
@@ -133,7 +134,7 @@ int main(int argc, char **argv) {
     const int32_t rc = xaac_parse_adts_frame(probe, data.data(), data.size(), 1, cf.data(), &used);
     if (rc) die("first frame", rc);
     n_ch = cf[0].n_ch;
-    sbr = cf[0].sbr_bytes > 0 || hdr.sampling_rate <= 24000;
+    sbr = cf[0].sbr_bytes > 0;
     xaac_parser_destroy(probe);
   }
   if (!sbr) esbr = 0; /* AAC-LC streams decode the same either way */

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STREAMS = os.path.join(ROOT, "tests", "golden", "streams")
 CLI = os.path.join(ROOT, "libxaac_amd", "xaacdec_amd")
 GOLD_ORDER = ["mix_aot2_64k", "mix_aot5_48k", "mono_aot5_32k", "harm_aot5_48k", "mix_aot29_32k", "synth_lc_a", "synth_lc_b",
-              "synth_lc_mono"]      # tools/make_golden_parser.py NAMES
+              "synth_lc_mono", "lc_aot2_16k_mono", "he_aot5_44k"]      # tools/make_golden_parser.py NAMES
 NAMES = GOLD_ORDER
 
 pytestmark = pytest.mark.gpu

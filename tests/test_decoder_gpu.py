@@ -13,9 +13,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STREAMS = os.path.join(ROOT, "tests", "golden", "streams")
 XAACDEC = os.path.join(ROOT, "oracle", "_ref", "xaacdec")
-NAMES = ["mix_aot2_64k", "mix_aot5_48k", "mono_aot5_32k", "harm_aot5_48k", "mix_aot29_32k", "synth_lc_a", "synth_lc_b", "synth_lc_mono"]
+NAMES = ["mix_aot2_64k", "mix_aot5_48k", "mono_aot5_32k", "harm_aot5_48k", "mix_aot29_32k", "synth_lc_a", "synth_lc_b", "synth_lc_mono", "lc_aot2_16k_mono", "he_aot5_44k"]
 GOLD_ORDER = ["mix_aot2_64k", "mix_aot5_48k", "mono_aot5_32k", "harm_aot5_48k", "mix_aot29_32k", "synth_lc_a", "synth_lc_b",
-              "synth_lc_mono"]      # tools/make_golden_parser.py NAMES
+              "synth_lc_mono", "lc_aot2_16k_mono", "he_aot5_44k"]      # tools/make_golden_parser.py NAMES
 
 pytestmark = pytest.mark.gpu
 
@@ -59,7 +59,7 @@ def test_stream_equals_reference_decoder_with_its_default_flags(name, tmp_path):
 def test_esbr_streams_against_committed_crcs_and_in_batches():
     from libxaac_amd import decoder
     gold = np.load(os.path.join(ROOT, "tests", "golden", "decoder_ref.npz"))
-    for name in ("mix_aot5_48k", "mono_aot5_32k", "harm_aot5_48k", "mix_aot29_32k"):
+    for name in ("mix_aot5_48k", "mono_aot5_32k", "harm_aot5_48k", "mix_aot29_32k", "he_aot5_44k"):
         k = GOLD_ORDER.index(name)
         data = open(os.path.join(STREAMS, name + ".aac"), "rb").read()
         got, rate = decoder.decode_streams([data] * 3, esbr=True)

@@ -22,7 +22,7 @@ from esbr_structs import EsbrPsState, EsbrState  # noqa: E402
 from hbe_structs import HbeState  # noqa: E402
 
 STREAMS = os.path.join(ROOT, "tests", "golden", "streams")
-NAMES = ["mix_aot5_48k", "mono_aot5_32k", "harm_aot5_48k", "mix_aot29_32k"]
+NAMES = ["mix_aot5_48k", "mono_aot5_32k", "harm_aot5_48k", "mix_aot29_32k", "he_aot5_44k"]
 CAPTURE = os.path.join(ROOT, "oracle", "_ref", "xaacdec_capture")
 
 

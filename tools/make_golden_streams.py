@@ -40,6 +40,20 @@ def main():
     subprocess.run([os.path.join(REF, "xaacenc"), "-ifile:" + wav, "-ofile:" + aac, "-aot:5", "-br:32000", "-adts:1"],
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
     print(aac, os.path.getsize(aac))
+    # other sampling rates (other scale factor band tables, SBR frequency tables and core / SBR rate pairs): AAC-LC mono at
+    # 16 kHz -- a rate at which the reference creates an SBR decoder by implicit signalling and, without payloads, never calls
+    # it -- and HE-AAC stereo at 44.1 kHz; the same samples played at those rates (the encoder only sees numbers)
+    import wave
+    for name, fs, ch, args in (("lc_aot2_16k_mono", 16000, 1, ["-aot:2", "-br:32000"]), ("he_aot5_44k", 44100, 2, ["-aot:5", "-br:48000"])):
+        wav = "/tmp/xaac_golden_%d.wav" % fs
+        pcm = np.clip(np.round(x[:, :ch] * 32767.0), -32768, 32767).astype(np.int16)
+        with wave.open(wav, "wb") as w:
+            w.setnchannels(ch), w.setsampwidth(2), w.setframerate(fs)
+            w.writeframes(pcm.tobytes())
+        aac = os.path.join(out, name + ".aac")
+        subprocess.run([os.path.join(REF, "xaacenc"), "-ifile:" + wav, "-ofile:" + aac, "-adts:1"] + args, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, check=True)
+        print(aac, os.path.getsize(aac))
     # the other frame lengths (tests/golden/streams_ld: kept apart from the 1024-line streams the batched host tests walk):
     # AAC-LC with 960-line frames, AAC-LD and AAC-ELD with 512- and 480-line frames: raw access units behind an
     # AudioSpecificConfig (ADTS cannot signal the frame length) + the encoder's frame-size list, which the reference's test

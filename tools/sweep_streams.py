@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Parity sweep beyond the committed streams (GPU box; oracle/_ref must have travelled): the reference encoder makes ADTS
+streams at several sampling rates, bit rates, channel counts and object types from the synthetic test signal; every stream
+is decoded by the reference (`xaacdec`, default flags and -esbr:0) and by the repo's native decoder
+(libxaac_amd/xaacdec_amd, same flags); the WAV payloads must be identical.  Prints one line per (stream, flag)."""
+import os
+import subprocess
+import sys
+import wave
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import make_test_streams as m  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+CLI = os.path.join(ROOT, "libxaac_amd", "xaacdec_amd")
+TMP = os.environ.get("SWEEP_TMP", "/tmp/xaac_sweep")
+
+
+def payload(path):
+    with wave.open(path) as w:
+        return w.getnchannels(), w.getframerate(), w.readframes(w.getnframes())
+
+
+def main():
+    os.makedirs(TMP, exist_ok=True)
+    sig = m.signals(seconds=1.6)
+    x48 = 0.5 * sig["clicks"] + 0.35 * sig["harmonic"] + 0.3 * sig["noise_sweep"]
+    cases = []
+    for fs in (16000, 22050, 24000, 32000, 44100, 48000):
+        # the same samples played at another rate: the encoder only sees numbers
+        for ch in (1, 2):
+            wav = os.path.join(TMP, "in_%d_%d.wav" % (fs, ch))
+            pcm = np.clip(np.round(x48[:, :ch] * 32767.0), -32768, 32767).astype(np.int16)
+            with wave.open(wav, "wb") as w:
+                w.setnchannels(ch); w.setsampwidth(2); w.setframerate(fs)
+                w.writeframes(pcm.tobytes())
+            for aot, brs in ((2, (32000, 96000)), (5, (24000, 48000)), (29, (18000, 32000))):
+                if aot == 29 and ch != 2:
+                    continue       # parametric stereo codes a stereo input
+                if aot != 2 and fs < 32000:
+                    continue       # SBR at twice a low core rate: the encoder's supported range
+                for br in brs:
+                    cases.append((fs, ch, aot, br, wav))
+    bad = total = 0
+    for fs, ch, aot, br, wav in cases:
+        name = "s%d_c%d_a%d_b%d" % (fs, ch, aot, br)
+        aac = os.path.join(TMP, name + ".aac")
+        r = subprocess.run([os.path.join(REF, "xaacenc"), "-ifile:" + wav, "-ofile:" + aac, "-aot:%d" % aot, "-br:%d" % br, "-adts:1"],
+                           capture_output=True)
+        if r.returncode or not os.path.exists(aac) or os.path.getsize(aac) < 100:
+            print(name, "encoder refused")
+            continue
+        for flags in ((), ("-esbr:0",)):
+            a, b = os.path.join(TMP, "ref.wav"), os.path.join(TMP, "own.wav")
+            for f in (a, b):
+                if os.path.exists(f):
+                    os.remove(f)
+            r1 = subprocess.run([os.path.join(REF, "xaacdec"), "-ifile:" + aac, "-ofile:" + a, *flags], capture_output=True)
+            r2 = subprocess.run([CLI, "-ifile:" + aac, "-ofile:" + b, "-quiet", *flags], capture_output=True, text=True)
+            total += 1
+            if r1.returncode or not os.path.exists(a):
+                print(name, flags, "reference decoder failed")
+                continue
+            if r2.returncode or not os.path.exists(b):
+                print(name, flags, "OWN DECODER FAILED:", r2.stderr.strip()[-200:])
+                bad += 1
+                continue
+            pa, pb = payload(a), payload(b)
+            if pa == pb:
+                print(name, flags, "identical", pa[0], "ch", pa[1], "Hz", len(pa[2]) // (2 * pa[0]), "samples")
+            else:
+                bad += 1
+                if pa[:2] != pb[:2] or len(pa[2]) != len(pb[2]):
+                    print(name, flags, "DIFFERENT SHAPE", pa[:2], len(pa[2]), pb[:2], len(pb[2]))
+                else:
+                    x = np.frombuffer(pa[2], np.int16).reshape(-1, pa[0]); y = np.frombuffer(pb[2], np.int16).reshape(-1, pa[0])
+                    d = np.nonzero(np.any(x != y, axis=1))[0]
+                    print(name, flags, "DIFFERENT", d.size, "samples, first", int(d[0]), "max", int(np.abs(x.astype(int) - y).max()))
+    print("cases", total, "bad", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
