@@ -26,7 +26,7 @@ def payload(path):
 
 def main():
     os.makedirs(TMP, exist_ok=True)
-    sig = m.signals(seconds=1.6)
+    sig = m.signals(seconds=float(os.environ.get("SWEEP_SECONDS", "1.6")))   # (multiples of 0.8 s)
     x48 = 0.5 * sig["clicks"] + 0.35 * sig["harmonic"] + 0.3 * sig["noise_sweep"]
     cases = []
     for fs in (16000, 22050, 24000, 32000, 44100, 48000):
@@ -44,9 +44,23 @@ def main():
                     continue       # SBR at twice a low core rate: the encoder's supported range
                 for br in brs:
                     cases.append((fs, ch, aot, br, wav))
+    # other material at one rate: digital silence, full-scale noise (the peak limiter at work, escape codes, saturating float
+    # samples on Path A), a lone click train; stereo
+    rng = np.random.default_rng(3)
+    n = x48.shape[0]
+    extra = {"silence": np.zeros((n, 2)), "loud": np.clip(rng.standard_normal((n, 2)) * 0.9, -1.0, 1.0),
+             "clicks": np.clip(1.9 * sig["clicks"], -1.0, 1.0)}
+    for label, x in extra.items():
+        wav = os.path.join(TMP, "in_%s.wav" % label)
+        pcm = np.clip(np.round(x * 32767.0), -32768, 32767).astype(np.int16)
+        with wave.open(wav, "wb") as w:
+            w.setnchannels(2); w.setsampwidth(2); w.setframerate(44100)
+            w.writeframes(pcm.tobytes())
+        for aot, br in ((2, 64000), (5, 32000), (29, 24000)):
+            cases.append((label, 2, aot, br, wav))
     bad = total = 0
     for fs, ch, aot, br, wav in cases:
-        name = "s%d_c%d_a%d_b%d" % (fs, ch, aot, br)
+        name = "s%s_c%d_a%d_b%d" % (fs, ch, aot, br)
         aac = os.path.join(TMP, name + ".aac")
         r = subprocess.run([os.path.join(REF, "xaacenc"), "-ifile:" + wav, "-ofile:" + aac, "-aot:%d" % aot, "-br:%d" % br, "-adts:1"],
                            capture_output=True)
