@@ -34,7 +34,8 @@ typedef struct XaacHbeBanksParams {
 } XaacHbeBanksParams;
 
 #define XAAC_HBE_POST_THREADS 256
-#define XAAC_HBE_POST_LDS (256 * 25 * 4 + 5 * 16 * 32 * 8) /* the blocks (+ cross terms) of 16 bands x 16 columns; five planes of normalised samples */
+#define XAAC_HBE_POST_BLK_ROWS (17 * 15 + 16) /* block (band bt, column i) in row 17 bt + i */
+#define XAAC_HBE_POST_LDS (XAAC_HBE_POST_BLK_ROWS * 25 * 4 + 5 * 16 * 32 * 8) /* the blocks (+ cross terms) of 16 bands x 16 columns; five planes of normalised samples */
 typedef struct XaacHbePostParams {
   int32_t n_ch;
   xaac_hbe_state *state;

@@ -18,6 +18,27 @@
 #include "hbe_trans.h"
 #include "hbe_kernel.h"
 
+#ifdef XE_PROFILE /* tools/prof_hbe_post.py: thread 0's cycles between the hooks of the products kernel, summed over channels */
+__device__ unsigned long long xh_prof_total[8];
+#define XH_T(i)                                                       \
+  do {                                                                \
+    if (threadIdx.x == 0) {                                           \
+      const long long t_ = clock64();                                 \
+      atomicAdd(&xh_prof_total[i], (unsigned long long)(t_ - xh_t0)); \
+      xh_t0 = t_;                                                     \
+    }                                                                 \
+  } while (0)
+extern "C" hipError_t xaac_debug_hbe_prof(unsigned long long *out, int clear) {
+  if (clear) {
+    unsigned long long z[8] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(xh_prof_total), z, sizeof(z));
+  }
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(xh_prof_total), 8 * sizeof(unsigned long long));
+}
+#else
+#define XH_T(i)
+#endif
+
 namespace {
 /* the frame's pitch and whether the channel takes part (inside the Path A chain both come from the side info / frame) */
 __device__ __forceinline__ int hbe_pitch(const int32_t *pitch, const xaac_esbr_side *side, int ch) {
@@ -160,8 +181,10 @@ __device__ __forceinline__ int hp_base(int plane, int tile) { /* the lowest inpu
 
 __global__ __launch_bounds__(XAAC_HBE_POST_THREADS) void xaac_hbe_post_kernel(XaacHbePostParams p) {
   extern __shared__ float lds[];
-  float(*blk)[XH_BLK] = reinterpret_cast<float(*)[XH_BLK]>(lds); /* [16 bands x 16 columns]: xh_column_block */
-  float2(*nv)[HP_SLOTS][32] = reinterpret_cast<float2(*)[HP_SLOTS][32]>(lds + 256 * XH_BLK); /* [plane][slot][row] */
+  /* [16 bands x 16 columns]: xh_column_block of (band bt, column i) in row 17 bt + i -- the skew spreads the gather's reads,
+     whose lanes differ in bt, over the LDS banks (rows 16 bt + i put all sixteen bands on two banks) */
+  float(*blk)[XH_BLK] = reinterpret_cast<float(*)[XH_BLK]>(lds);
+  float2(*nv)[HP_SLOTS][32] = reinterpret_cast<float2(*)[HP_SLOTS][32]>(lds + XAAC_HBE_POST_BLK_ROWS * XH_BLK); /* [plane][slot][row] */
   __shared__ unsigned need[HP_PLANES]; /* bit s: slot s of the plane is read by this tile */
   const int ch = blockIdx.x, tid = threadIdx.x;
   xaac_hbe_state *st = p.state + ch;
@@ -179,7 +202,18 @@ __global__ __launch_bounds__(XAAC_HBE_POST_THREADS) void xaac_hbe_post_kernel(Xa
   };
   const float *in_flat = &st->qmf_in_buf[0][0];
   const auto inf = [&](int row, int idx) { return in_flat[128 * row + idx]; };
+#ifdef XE_PROFILE
+  long long xh_t0 = clock64();
+#endif
   for (int tile = 0; tile < 4; tile++) {
+    /* the previous frame's upper rows of this tile's bands -- the start values of rows 0..31 in (3) -- are on their way
+       from memory while (1) and (2) compute */
+    float2 upper[(32 * 16) / XAAC_HBE_POST_THREADS];
+#pragma unroll
+    for (int q = 0; q < (32 * 16) / XAAC_HBE_POST_THREADS; q++) {
+      const int e = tid + q * XAAC_HBE_POST_THREADS;
+      upper[q] = *reinterpret_cast<const float2 *>(&st->qmf_out_buf[32 + (e >> 4)][2 * (16 * tile + (e & 15))]);
+    }
     /* (1) which normalised samples the tile reads, then those samples */
     if (tid < HP_PLANES) need[tid] = 0;
     __syncthreads();
@@ -202,30 +236,53 @@ __global__ __launch_bounds__(XAAC_HBE_POST_THREADS) void xaac_hbe_post_kernel(Xa
       }
     }
     __syncthreads();
-    for (int e = tid; e < HP_PLANES * HP_SLOTS * 32; e += XAAC_HBE_POST_THREADS) {
-      const int plane = e / (HP_SLOTS * 32), slot = (e / 32) % HP_SLOTS, row = e % 32;
+    /* thread's entries e = tid + 256 q: two per plane (q >> 1); every input sample they read is requested before the
+       first one is used (one memory latency for the phase instead of one per entry) */
+    static_assert(HP_SLOTS * 32 == 2 * XAAC_HBE_POST_THREADS, "two entries per plane and thread");
+    float2 xa[2 * HP_PLANES], xb[4];
+    bool on[2 * HP_PLANES];
+#pragma unroll
+    for (int q = 0; q < 2 * HP_PLANES; q++) {
+      const int plane = q >> 1, e = tid + (q & 1) * XAAC_HBE_POST_THREADS, slot = e >> 5, row = e & 31;
+      const int band = hp_base(plane, tile) + slot;
+      on[q] = ((need[plane] >> slot) & 1) != 0 && (plane < HP_N3B1 || row < 30);
+      xa[q] = make_float2(0.0f, 0.0f);
+      if (plane >= HP_N3B1) xb[q - 2 * HP_N3B1] = make_float2(0.0f, 0.0f);
+      if (on[q]) {
+        if (plane < HP_N3B1) {
+          xa[q] = *reinterpret_cast<const float2 *>(&st->qmf_in_buf[row][2 * band]);
+        } else { /* the interpolated point behind `row` reads rows row + 1, row + 2 (used: row <= 24) */
+          xa[q] = *reinterpret_cast<const float2 *>(&st->qmf_in_buf[row + 2][2 * band]);
+          xb[q - 2 * HP_N3B1] = *reinterpret_cast<const float2 *>(&st->qmf_in_buf[row + 1][2 * band]);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2 * HP_PLANES; q++) {
+      const int plane = q >> 1, e = tid + (q & 1) * XAAC_HBE_POST_THREADS, slot = e >> 5, row = e & 31;
       if (!((need[plane] >> slot) & 1)) continue;
       const int band = hp_base(plane, tile) + slot;
       XhC v = {0.0f, 0.0f};
       if (plane == HP_N2) {
-        const XhC x = in(row, band);
-        v = xh_norm2(x.r, x.i);
+        v = xh_norm2(xa[q].x, xa[q].y);
       } else if (plane == HP_N4) {
-        const XhC x = in(row, band);
-        v = xh_norm4(x.r, x.i);
+        v = xh_norm4(xa[q].x, xa[q].y);
       } else if (plane == HP_N3A) {
-        const XhC x = in(row, band);
-        v = xh_norm3(x.r, x.i);
-      } else if (row < 30) { /* the interpolated point behind `row` reads rows row + 1, row + 2 (used: row <= 24) */
-        const XhC x = xh_interp3(in, band, row, plane == HP_N3B2);
+        v = xh_norm3(xa[q].x, xa[q].y);
+      } else if (on[q]) {
+        const float2 r2 = xa[q], r1 = xb[q - 2 * HP_N3B1 < 0 ? 0 : q - 2 * HP_N3B1];
+        const XhC x = xh_interp3([&](int rr, int) { const XhC c = rr == row + 2 ? XhC{r2.x, r2.y} : XhC{r1.x, r1.y}; return c; }, band, row,
+                                 plane == HP_N3B2);
         v = xh_norm3(x.r, x.i);
       }
       nv[plane][slot][row] = make_float2(v.r, v.i);
     }
     __syncthreads();
+    XH_T(0);
     /* (2) the columns' blocks */
     {
       const int qb = 16 * tile + (tid >> 4), i = tid & 15;
+      float *mine = blk[17 * (tid >> 4) + i];
       const int f = xh_band_factor(xo, ms, qb);
       const auto cached = [&](int plane, int band, int row) {
         const float2 v = nv[plane][band - hp_base(plane, tile)][row];
@@ -233,27 +290,30 @@ __global__ __launch_bounds__(XAAC_HBE_POST_THREADS) void xaac_hbe_post_kernel(Xa
         return c;
       };
       if (f == 2) {
-        xh_prod2_block_n([&](int row) { return cached(HP_N2, qb, row); }, i, blk[tid]);
+        xh_prod2_block_n([&](int row) { return cached(HP_N2, qb, row); }, i, mine);
       } else if (f == 4) {
         const int inp = qb >> 1, ip = (qb & 1) ? inp + 1 : inp - 1;
-        xh_prod4_block_n([&](int row) { return cached(HP_N4, inp, row); }, [&](int row) { return cached(HP_N4, ip, row); }, i, blk[tid]);
+        xh_prod4_block_n([&](int row) { return cached(HP_N4, inp, row); }, [&](int row) { return cached(HP_N4, ip, row); }, i, mine);
       } else if (f == 3) {
         const int inp = (2 * qb) / 3, rem = 2 * qb - 3 * inp;
         xh_prod3_block_n([&](int sel, int row) { return cached(HP_N3A, inp + sel, row); },
-                         [&](int sel, int row) { return cached(rem == 2 ? HP_N3B2 : HP_N3B1, inp + sel, row); }, rem, i, blk[tid]);
+                         [&](int sel, int row) { return cached(rem == 2 ? HP_N3B2 : HP_N3B1, inp + sel, row); }, rem, i, mine);
       }
-      if (f) xh_column_cross(inf, f, qb, i, pitch, blk[tid]);
+      if (f) xh_column_cross(inf, f, qb, i, pitch, mine);
     }
     __syncthreads();
+    XH_T(1);
     for (int half = 0; half < 2; half++) {
-      for (int e = tid; e < 32 * 16; e += XAAC_HBE_POST_THREADS) {
+#pragma unroll
+      for (int q = 0; q < (32 * 16) / XAAC_HBE_POST_THREADS; q++) {
+        const int e = tid + q * XAAC_HBE_POST_THREADS;
         const int r = 32 * half + (e >> 4), bt = e & 15, qb = 16 * tile + bt;
         float2 *dst = reinterpret_cast<float2 *>(&st->qmf_out_buf[r][2 * qb]);
         float2 v = make_float2(0.0f, 0.0f);
-        if (!half) v = *reinterpret_cast<const float2 *>(&st->qmf_out_buf[r + 32][2 * qb]);
+        if (!half) v = upper[q];
         const int f = xh_band_factor(xo, ms, qb);
         if (f) {
-          const auto bk = [&](int i) { return (const float *)blk[16 * bt + i]; };
+          const auto bk = [&](int i) { return (const float *)blk[17 * bt + i]; };
           v.x = xh_prod_gather(v.x, f, r, 0, bk);
           v.y = xh_prod_gather(v.y, f, r, 1, bk);
         }
@@ -267,6 +327,7 @@ __global__ __launch_bounds__(XAAC_HBE_POST_THREADS) void xaac_hbe_post_kernel(Xa
         }
       }
       __syncthreads(); /* rows 32..63 are overwritten only after every row below has taken its start value from them */
+      XH_T(2 + half);
     }
   }
   if (tid == 0 && !st->fft_ready && st->synth_size != 20) st->fft_ready = 1;
