@@ -158,15 +158,26 @@ int main(int argc, char **argv) {
   int32_t *d_overlap = dev<int32_t>((size_t)NCD * 512), *d_spec = dev<int32_t>((size_t)NCD * 1024);
   xaac_ovl_state *d_ovl = dev<xaac_ovl_state>((size_t)NCD);
   xaac_ics_info *d_ics = dev<xaac_ics_info>((size_t)NCD);
-  int16_t *d_pcm = dev<int16_t>((size_t)N * per * out_ch), *h_pcm = pinned<int16_t>((size_t)N * per * 2);
-  int32_t *d_status = dev<int32_t>((size_t)NC), *h_status = pinned<int32_t>((size_t)NC);
+  /* PCM and status of a step in two sets: the copy down of step k (a second stream) runs beside the copies up and the kernels
+     of step k + 1 */
+  int16_t *d_pcm2[2], *h_pcm2[2], *d_mono2[2] = {nullptr, nullptr};
+  int32_t *d_status2[2], *h_status2[2];
+  hipStream_t down;
+  hipEvent_t ev_kernels[2], ev_down[2];
+  HIP(hipStreamCreate(&down));
+  for (int k = 0; k < 2; k++) {
+    d_pcm2[k] = dev<int16_t>((size_t)N * per * out_ch), h_pcm2[k] = pinned<int16_t>((size_t)N * per * 2);
+    d_status2[k] = dev<int32_t>((size_t)NC), h_status2[k] = pinned<int32_t>((size_t)NC);
+    HIP(hipEventCreateWithFlags(&ev_kernels[k], hipEventDisableTiming));
+    HIP(hipEventCreateWithFlags(&ev_down[k], hipEventDisableTiming));
+  }
   /* AAC-LC */
   int32_t *d_out32 = nullptr;
   int8_t *d_qadj = nullptr;
   xaac_limiter_state *d_lim = nullptr;
   int delay = 0;
   /* SBR */
-  int16_t *d_core = nullptr, *d_mono = nullptr;
+  int16_t *d_core = nullptr;
   xaac_sbr_header *d_header = nullptr;
   xaac_sbr_frame *d_frame = nullptr;
   xaac_sbr_state *d_state = nullptr;
@@ -223,7 +234,7 @@ int main(int argc, char **argv) {
     if (n_ch == 1) {
       d_psf = dev<xaac_ps_frame>((size_t)N);
       d_ps_state = dev<xaac_ps_state>((size_t)N);
-      d_mono = dev<int16_t>((size_t)N * 2048);
+      d_mono2[0] = dev<int16_t>((size_t)N * 2048), d_mono2[1] = dev<int16_t>((size_t)N * 2048);
       d_idx = dev<int32_t>((size_t)N);
       xaac_ps_state p0;
       xaac_ps_state_init(&p0);
@@ -235,7 +246,7 @@ int main(int argc, char **argv) {
   }
   HIP(hipMalloc(&d_ws, ws_bytes ? ws_bytes : 16));
 
-  Staging st[2];
+  Staging st[3]; /* parse of step k + 1 | copies up and kernels of step k | copy down of step k - 1 */
   for (auto &s : st) {
     s.spec = pinned<int32_t>((size_t)NC * 1024);
     s.ics = pinned<uint8_t>((size_t)NC * 2);
@@ -291,7 +302,7 @@ int main(int argc, char **argv) {
       cv.wait(lk, [&] { return quit || job > expect; });
       if (quit) return;
       lk.unlock();
-      parse(&st[expect & 1]);
+      parse(&st[expect % 3]);
       lk.lock();
       done = expect;
       cv.notify_all();
@@ -306,12 +317,42 @@ int main(int argc, char **argv) {
     std::unique_lock<std::mutex> lk(mu);
     cv.wait(lk, [&] { return done >= step; });
   };
+  /* what a step leaves for the host once its copy down has arrived */
+  struct Pending {
+    bool valid, mono_twice, first;
+    int slot;
+  } pending = {false, false, false, 0};
+  auto consume = [&]() {
+    if (!pending.valid) return;
+    HIP(hipEventSynchronize(ev_down[pending.slot]));
+    int16_t *h_pcm = h_pcm2[pending.slot];
+    const int32_t *h_status = h_status2[pending.slot];
+    if (sbr)
+      for (int i = 0; i < (pending.mono_twice || (n_ch == 1 && !esbr) ? N : NC); i++)
+        if (h_status[i] < 0) die("the SBR kernels refused a frame", i);
+    if (pending.mono_twice) /* mono duplicated to stereo (api.c:3639-3660), from the back so that it can be done in place */
+      for (long k = (long)N * 2048 - 1; k >= 0; k--) h_pcm[2 * k] = h_pcm[2 * k + 1] = h_pcm[k];
+    lap(2);
+    const size_t skip = (!sbr && pending.first) ? (size_t)delay * out_ch : 0; /* the limiter's delay is cut from the first frame */
+    /* (with -esbr:1 the reference's command line decoder does not write an SBR stream's first frame:
+       test/decoder/ixheaacd_main.c:2181-2186) */
+    if (!(esbr && pending.first)) pcm.insert(pcm.end(), h_pcm + skip, h_pcm + (size_t)per * out_ch);
+    for (int i = 1; verify && i < N; i++)
+      mismatched += memcmp(h_pcm, h_pcm + (size_t)i * per * out_ch, (size_t)per * out_ch * 2) != 0;
+    frames += N;
+    if (pending.first) t_first = std::chrono::steady_clock::now(); /* the first step also loads the kernels' code objects */
+    pending.valid = false;
+    lap(3);
+  };
   start_parse();
   for (int step = 0;; step++) {
-    const int which = step & 1;
+    const int which = step % 3, slot = step & 1;
     wait_parse(step);
     Staging &s = st[which];
     if (s.delivered == 0) break;
+    int16_t *d_pcm = d_pcm2[slot], *d_mono = d_mono2[slot];
+    int32_t *d_status = d_status2[slot];
+    bool mono_twice = false;
     if (s.delivered != N) die("streams of different lengths in one batch");
     start_parse(); /* the next step's frames are parsed while the GPU works on this one's */
     t_phase = std::chrono::steady_clock::now();
@@ -446,39 +487,22 @@ int main(int argc, char **argv) {
           b.pcm_out = d_mono;
         }
         XA(xaac_sbr_hq_process_batch(ctx, &b));
-        lap(1);
-        if (!with_ps) HIP(hipMemcpyAsync(h_pcm, d_mono, (size_t)N * 2048 * 2, hipMemcpyDeviceToHost, stream));
-        else HIP(hipMemcpyAsync(h_pcm, d_pcm, (size_t)N * 4096 * 2, hipMemcpyDeviceToHost, stream));
-        HIP(hipMemcpyAsync(h_status, d_status, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
-        HIP(hipStreamSynchronize(stream));
-        for (int i = 0; i < N; i++)
-          if (h_status[i] < 0) die("the SBR kernels refused a frame", i);
-        if (!with_ps) { /* mono duplicated to stereo (api.c:3639-3660), from the back so that it can be done in place */
-          for (long k = (long)N * 2048 - 1; k >= 0; k--) h_pcm[2 * k] = h_pcm[2 * k + 1] = h_pcm[k];
-        }
+        mono_twice = !with_ps;
       }
     }
-    if (!(sbr && n_ch == 1 && !esbr)) {
-      lap(1);
-      HIP(hipMemcpyAsync(h_pcm, d_pcm, (size_t)N * per * out_ch * 2, hipMemcpyDeviceToHost, stream));
-      if (sbr) HIP(hipMemcpyAsync(h_status, d_status, (size_t)NC * 4, hipMemcpyDeviceToHost, stream));
-      HIP(hipStreamSynchronize(stream));
-      if (sbr)
-        for (int i = 0; i < NC; i++)
-          if (h_status[i] < 0) die("the SBR kernels refused a frame", i);
-    }
-    lap(2);
-    const size_t skip = (!sbr && first) ? (size_t)delay * out_ch : 0; /* the limiter's delay is cut from the first frame */
-    /* (with -esbr:1 the reference's command line decoder does not write an SBR stream's first frame:
-       test/decoder/ixheaacd_main.c:2181-2186) */
-    if (!(esbr && first)) pcm.insert(pcm.end(), h_pcm + skip, h_pcm + (size_t)per * out_ch);
-    for (int i = 1; verify && i < N; i++)
-      mismatched += memcmp(h_pcm, h_pcm + (size_t)i * per * out_ch, (size_t)per * out_ch * 2) != 0;
-    frames += N;
-    if (first) t_first = std::chrono::steady_clock::now(); /* the first step also loads the kernels' code objects */
+    lap(1);
+    HIP(hipEventRecord(ev_kernels[slot], stream));
+    HIP(hipStreamWaitEvent(down, ev_kernels[slot], 0));
+    if (mono_twice) HIP(hipMemcpyAsync(h_pcm2[slot], d_mono, (size_t)N * 2048 * 2, hipMemcpyDeviceToHost, down));
+    else HIP(hipMemcpyAsync(h_pcm2[slot], d_pcm, (size_t)N * per * out_ch * 2, hipMemcpyDeviceToHost, down));
+    if (sbr) HIP(hipMemcpyAsync(h_status2[slot], d_status, (size_t)NC * 4, hipMemcpyDeviceToHost, down));
+    HIP(hipEventRecord(ev_down[slot], down));
+    consume(); /* the step before this one: its PCM has been on its way while this step's work was queued */
+    pending = {true, mono_twice, first, slot};
+    if (profile) consume(); /* phase timing wants one step at a time */
     first = false;
-    lap(3);
   }
+  consume();
   {
     std::lock_guard<std::mutex> lk(mu);
     quit = true;
