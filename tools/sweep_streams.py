@@ -29,7 +29,8 @@ def main():
     sig = m.signals(seconds=float(os.environ.get("SWEEP_SECONDS", "1.6")))   # (multiples of 0.8 s)
     x48 = 0.5 * sig["clicks"] + 0.35 * sig["harmonic"] + 0.3 * sig["noise_sweep"]
     cases = []
-    for fs in (16000, 22050, 24000, 32000, 44100, 48000):
+    rates = tuple(int(v) for v in os.environ["SWEEP_RATES"].split(",")) if os.environ.get("SWEEP_RATES") else (16000, 22050, 24000, 32000, 44100, 48000)
+    for fs in rates:
         # the same samples played at another rate: the encoder only sees numbers
         for ch in (1, 2):
             wav = os.path.join(TMP, "in_%d_%d.wav" % (fs, ch))
