@@ -333,15 +333,17 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
             self.seconds = time.perf_counter() - t0
             return self
 
-    sets = [Staging(), Staging()] if overlap else [Staging()]
+    # three staging sets: the parse of step k + 1 | the copies up and kernels of step k | the copy down of step k - 1
+    sets = [Staging(), Staging(), Staging()] if overlap else [Staging()]
     if not sbr:
         # AAC-LC: IMDCT -> WORD32 + qshift_adj -> peak limiter -> round16 (api.c:3662-3692)
         out32, qadj = dz(n * 1024 * n_ch, dtype=torch.int32), dz(n * n_ch, dtype=torch.int8)
         lim0, delay = peak_limiter_init(n_ch, rate)
         lim = torch.from_numpy(np.tile(np.frombuffer(bytes(lim0), np.uint8), (n, 1)).copy()).to(dev)
         ws = dz(max(ctx.peak_limiter_workspace_bytes(n), 16))
-        pcm = dz(n * 1024 * n_ch, dtype=torch.int16)
-        pcm_h = pinned(n * 1024 * n_ch, dtype=torch.int16)
+        pcm2 = [dz(n * 1024 * n_ch, dtype=torch.int16) for _ in range(2)]
+        pcm_h2 = [pinned(n * 1024 * n_ch, dtype=torch.int16) for _ in range(2)]
+        status2 = status_h2 = None
     elif esbr:
         # Path A: IMDCT (16-bit core PCM) -> xaac_esbr_core_from_pcm16_batch -> the eSBR chain -> xaac_esbr_pcm16_from_float_batch
         # (saturate / truncate to 16 bit: ixheaacd_samples_sat, decode_main.c:82-107); every state member stays on the device
@@ -349,12 +351,13 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
         hbe = dz(nc, HBE_STATE_BYTES)
         core16 = dz(nc * 1024, dtype=torch.int16)
         hdr_d, frm_d, eside_d = dz(nc, SBR_HEADER_BYTES), dz(nc, SBR_FRAME_BYTES), dz(nc, ESBR_SIDE_BYTES)
-        status = dz(nc, dtype=torch.int32)
+        status2 = [dz(nc, dtype=torch.int32) for _ in range(2)]
+        status_h2 = [pinned(nc, dtype=torch.int32) for _ in range(2)]
         ws = dz(ctx.esbr_workspace_bytes(nc))
         out_l, out_r = dz(nc, 2048, dtype=torch.float32), None
         core = dz(nc, 1024, dtype=torch.float32)
-        pcm = dz(n * 2048 * 2, dtype=torch.int16)
-        pcm_h = pinned(n * 2048 * 2, dtype=torch.int16)
+        pcm2 = [dz(n * 2048 * 2, dtype=torch.int16) for _ in range(2)]
+        pcm_h2 = [pinned(n * 2048 * 2, dtype=torch.int16) for _ in range(2)]
         if n_ch == 1:
             ps_state = torch.from_numpy(np.tile(_struct_bytes(lib.xaac_esbr_ps_state_init, ESBR_PS_STATE_BYTES), (n, 1)).copy()).to(dev)
             psf_d = dz(n, PS_FRAME_BYTES)
@@ -364,16 +367,16 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
         state = torch.from_numpy(np.tile(_struct_bytes(lib.xaac_sbr_state_init, SBR_STATE_BYTES), (nc, 1)).copy()).to(dev)
         core16 = dz(nc * 1024, dtype=torch.int16)
         hdr_d, frm_d = dz(nc, SBR_HEADER_BYTES), dz(nc, SBR_FRAME_BYTES)
-        status = dz(nc, dtype=torch.int32)
-        pcm_h = pinned(n * 2048 * 2, dtype=torch.int16)
+        status2 = [dz(nc, dtype=torch.int32) for _ in range(2)]
+        status_h2 = [pinned(nc, dtype=torch.int32) for _ in range(2)]
+        pcm_h2 = [pinned(n * 2048 * 2, dtype=torch.int16) for _ in range(2)]
+        pcm2 = [dz(n * 2048 * 2, dtype=torch.int16) for _ in range(2)]
         if n_ch == 2:
             ws = dz(ctx.sbr_lp_workspace_bytes(nc))
-            pcm = dz(nc * 2048, dtype=torch.int16)
         else:
             ps_state = torch.from_numpy(np.tile(_struct_bytes(lib.xaac_ps_state_init, PS_STATE_BYTES), (n, 1)).copy()).to(dev)
             psf_d = dz(n, PS_FRAME_BYTES)
             ws = dz(ctx.sbr_hq_workspace_bytes(n, True))
-            pcm = dz(n * 2048 * 2, dtype=torch.int16)
             pcm_mono = dz(n * 2048, dtype=torch.int16)
     first = True
     pool = None
@@ -382,6 +385,42 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
         pool = ThreadPoolExecutor(1)
         pending = pool.submit(sets[0].parse)
     which = 0
+    # The copy down of step k runs on a second stream beside the copies up and kernels of step k + 1 (two PCM / status sets);
+    # the host takes a step's PCM one step later.
+    main_stream, down = torch.cuda.current_stream(dev), torch.cuda.Stream(dev)
+    done = [torch.cuda.Event(), torch.cuda.Event()]
+    waiting = None    # (slot, got, shape, cut, drop) of the step whose PCM is on its way
+
+    def consume():
+        nonlocal waiting
+        if waiting is None:
+            return
+        slot_, got_, shape_, cut_, drop_ = waiting
+        waiting = None
+        done[slot_].synchronize()
+        if status_h2 is not None and int(status_h2[slot_].min()) < 0:
+            raise RuntimeError("the SBR kernels refused a frame")
+        if keep_pcm and not drop_:
+            block = pcm_h2[slot_].numpy().reshape(shape_)
+            for i in np.nonzero(got_)[0]:
+                out[i].append(block[i, cut_:].copy())
+
+    def hand_down(slot_, got_, shape_, cut_=0, drop_=False):
+        nonlocal waiting
+        ev = torch.cuda.Event()
+        ev.record(main_stream)
+        with torch.cuda.stream(down):
+            down.wait_event(ev)
+            pcm_h2[slot_].copy_(pcm2[slot_], non_blocking=True)
+            if status2 is not None:
+                status_h2[slot_].copy_(status2[slot_], non_blocking=True)
+            done[slot_].record(down)
+        consume()
+        waiting = (slot_, got_, shape_, cut_, drop_)
+        if not overlap:   # one staging set: its copies up must be over before the next parse writes it
+            consume()
+
+    step_no = 0
     t_steps = time.perf_counter()
     while True:
         cur = pending.result() if overlap else sets[0].parse()
@@ -390,8 +429,12 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
         if not got.any():
             break
         if overlap:    # the next step's frames are parsed while the GPU works on this one's
-            which ^= 1
+            which = (which + 1) % 3
             pending = pool.submit(sets[which].parse)
+        slot = step_no & 1
+        step_no += 1
+        pcm = pcm2[slot]
+        status = status2[slot] if status2 is not None else None
         spec_h, ics_h, hdr_h, frm_h, psf_h, flags = cur.spec, cur.ics, cur.hdr, cur.frm, cur.psf, cur.flags
         overlap_buf = ovl
         t0 = time.perf_counter()
@@ -400,12 +443,7 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
         if not sbr:
             ctx.imdct_process_batch(spec_d, ics_d, overlap_buf, ovl_state, out32=out32, qshift_adj=qadj, ch_fac=n_ch)
             ctx.peak_limiter_process_batch(out32, qadj, lim, n_ch, ws, pcm16=pcm)
-            pcm_h.copy_(pcm, non_blocking=True)
-            ctx.sync()
-            if keep_pcm:
-                block = pcm_h.numpy().reshape(n, 1024, n_ch)
-                for i in np.nonzero(got)[0]:
-                    out[i].append(block[i, delay:].copy() if first else block[i].copy())
+            hand_down(slot, got, (n, 1024, n_ch), cut_=delay if first else 0)   # the limiter's delay is cut from the first frame
         elif esbr:
             # (interleaved as the reference holds it: its in-place 32 -> 16 bit conversion of a pair leaves traces of channel
             # 0 in channel 1, api.c:353-366, which the IMDCT's PCM_SBR hand-off restates for ch_fac 2)
@@ -461,14 +499,7 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
             else:
                 ctx.esbr_sbr_process_batch(core, hdr_d, frm_d, eside_d, state, out_l, ws, status=status, hbe_state=hbe)
                 ctx.esbr_pcm16_from_float(out_l, out_l[1:], pcm, stride=4096)
-            pcm_h.copy_(pcm, non_blocking=True)
-            bad = int(status.min().item())    # also the step's synchronisation point
-            if bad < 0:
-                raise RuntimeError("the eSBR kernels refused a frame")
-            if keep_pcm and not first:        # the first frame's output is not written in this mode
-                block = pcm_h.numpy().reshape(n, 2048, 2)
-                for i in np.nonzero(got)[0]:
-                    out[i].append(block[i].copy())
+            hand_down(slot, got, (n, 2048, 2), drop_=first)      # the first frame's output is not written in this mode
         else:
             ctx.imdct_process_batch(spec_d, ics_d, overlap_buf, ovl_state, pcm16=core16, ch_fac=n_ch, pcm_mode=PCM_SBR)
             # frames that reset the SBR decoder or fall back to plain up-sampling change a few words of the resident state
@@ -501,7 +532,6 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
             frm_d.copy_(frm_h, non_blocking=True)
             if n_ch == 2:
                 ctx.sbr_lp_process_batch(core16, hdr_d, frm_d, state, pcm, ws, status=status, in_ch_fac=2, out_ch_fac=2)
-                pcm_h.copy_(pcm, non_blocking=True)
             else:
                 with_ps = flags[got, F_PS] != 0
                 if with_ps.any() != with_ps.all():
@@ -513,20 +543,14 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
                         ctx.sbr_state_handover(HANDOVER_PS_START, idx, idx, state, ps_state)
                     psf_d.copy_(psf_h, non_blocking=True)
                     ctx.sbr_hq_process_batch(core16, hdr_d, frm_d, state, pcm, ws, ps_frame=psf_d, ps_state=ps_state, status=status)
-                    pcm_h.copy_(pcm, non_blocking=True)
                 else:
                     ctx.sbr_hq_process_batch(core16, hdr_d, frm_d, state, pcm_mono, ws, status=status)
                     # mono duplicated to stereo (api.c:3639-3660)
-                    pcm_h.copy_(pcm_mono.view(n, 2048, 1).expand(n, 2048, 2).reshape(-1), non_blocking=True)
-            bad = int(status.min().item())    # also the step's synchronisation point
-            if bad < 0:
-                raise RuntimeError("the SBR kernels refused a frame")
-            if keep_pcm:
-                block = pcm_h.numpy().reshape(n, 2048, 2)
-                for i in np.nonzero(got)[0]:
-                    out[i].append(block[i].copy())
+                    pcm.view(n, 2048, 2).copy_(pcm_mono.view(n, 2048, 1).expand(n, 2048, 2))
+            hand_down(slot, got, (n, 2048, 2))
         t_gpu += time.perf_counter() - t0
         first = False
+    consume()
     t_steps = time.perf_counter() - t_steps
     if pool is not None:
         pool.shutdown()
