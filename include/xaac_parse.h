@@ -108,6 +108,9 @@ int32_t xaac_parser_set_esbr(xaac_parser *p, int32_t esbr);
 /* ... and for such a stream, after xaac_parse_sbr_side: the xaac_esbr_side of channel 0 / 1 of the frame (what
    xaac_esbr_sbr_process_batch takes beside header and frame) */
 int32_t xaac_parse_esbr_side(xaac_parser *p, int32_t channel, xaac_esbr_side *side);
+/* ... and for a frame with side.reset: the pitch_in_bins that ixheaacd_sbr_dec_reset hands to its two transposer runs (the
+   first channel's, from the payload before this frame's: sbrdecoder.c:547-550) */
+int32_t xaac_parse_reset_pitch(xaac_parser *p, int32_t *pitch_in_bins);
 
 /* The inverse quantiser of spectral magnitudes, |q|^(4/3) in Q13, exactly as the reference computes it (table up to 128, its
    linear interpolation beyond, decoder/ixheaacd_channel.c:1055-1093; _ERR_ESCAPE past 8191 + 32).  Exposed for tests. */
@@ -138,6 +141,7 @@ typedef struct xaac_parse_batch {
   uint64_t *consumed;         /* [n_streams] frame length (0 where status != 0) */
   int32_t *status;            /* [n_streams] XAAC_PARSE_OK / _NEED_DATA / error: such a stream's rows are left as they were */
   xaac_esbr_side *esbr_side;  /* with_sbr, parsers in xaac_parser_set_esbr(1) mode, optional: [n_streams][n_ch] */
+  int32_t *reset_pitch;       /* ... optional: [n_streams], written for frames with flags[1] (reset): xaac_parse_reset_pitch */
 } xaac_parse_batch;
 
 /* returns the number of streams whose status is XAAC_PARSE_OK, or a negative XAAC_PARSE_ERR_* for a bad descriptor */
@@ -158,7 +162,9 @@ void xaac_esbr_ps_state_init(xaac_esbr_ps_state *s);
 void xaac_hbe_state_init(xaac_hbe_state *s);
 /* ixheaacd_qmf_hbe_data_reinit (decoder/ixheaacd_hbe_trans.c:102-222) as ixheaacd_sbr_dec_reset calls it for a 2:1 stream
    with 1024-line core frames: the bank size, first band, band range and cross-over bands of the QMF transposer from the
-   header's band tables; clears the two banks' delay lines.  Returns 0, or -1 where the reference returns an error.
+   header's band tables; clears the two banks' delay lines.  `s` is the channel's state as it is (a new stream's, or the one a
+   header before this one left: max_stretch and fft_ready carry over where the reference leaves them alone).  Returns 0, or
+   -1 where the reference returns an error.
    (The reset's two transposer runs over the rows the channel holds, sbrdecoder.c:196-236, are the caller's:
    xaac_hbe_apply_batch on the device-resident state.) */
 int32_t xaac_hbe_state_reinit(xaac_hbe_state *s, const xaac_sbr_header *header);

@@ -72,6 +72,7 @@ def load_host_library():
         lib.xaac_parser_set_esbr.argtypes = [ctypes.c_void_p, ctypes.c_int32]
         lib.xaac_parse_esbr_side.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
         lib.xaac_hbe_state_reinit.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.xaac_parse_reset_pitch.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]
         lib.xaac_sbr_state_apply_side.argtypes = [ctypes.c_void_p, ctypes.POINTER(SbrSide), ctypes.c_int32]
         lib.xaac_sbr_state_apply_side.restype = None
         lib.xaac_ps_state_apply_side.argtypes = [ctypes.c_void_p, ctypes.POINTER(SbrSide)]
@@ -180,7 +181,7 @@ class _ParseBatch(ctypes.Structure):
     # struct xaac_parse_batch
     _fields_ = [(n, ctypes.c_int32) for n in ("n_streams", "n_ch", "with_sbr", "ps_enable", "stage", "threads")] + \
                [(n, ctypes.c_void_p) for n in ("parser", "data", "bytes", "spec", "ics", "header", "frame", "ps_frame", "flags",
-                                               "tools", "consumed", "status", "esbr_side")]
+                                               "tools", "consumed", "status", "esbr_side", "reset_pitch")]
 
 
 F_APPLY, F_RESET, F_RESET_CHANNELS, F_UPSAMPLING, F_STEREO, F_PS, F_PS_START, F_FRAME_OK = range(8)
@@ -211,6 +212,7 @@ class BatchParser:
         self.threads, self.stage = int(threads), int(stage)
         self.consumed, self.status = np.zeros(n, np.uint64), np.zeros(n, np.int32)
         self.tools = np.zeros(n, np.int32)
+        self.reset_pitch = np.zeros(n, np.int32)   # at frames with a reset flag: xaac_parse_reset_pitch
         self.frames = np.zeros(n, np.int64)
         hdr = AdtsHeader()
         rc = self.lib.xaac_adts_parse_header(bytes(streams[0][:16]), min(16, len(streams[0])), ctypes.byref(hdr))
@@ -244,6 +246,7 @@ class BatchParser:
         b.spec, b.ics, b.header, b.frame, b.ps_frame, b.flags = ptr(spec), ptr(ics), ptr(hdr), ptr(frm), ptr(psf), ptr(flags)
         b.tools, b.consumed, b.status = self.tools.ctypes.data, self.consumed.ctypes.data, self.status.ctypes.data
         b.esbr_side = ptr(eside)
+        b.reset_pitch = self.reset_pitch.ctypes.data
         ok = self.lib.xaac_parse_batch_run(ctypes.byref(b))
         if ok < 0:
             raise RuntimeError("xaac_parse_batch_run: %d" % ok)
@@ -288,8 +291,9 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
     xaac_esbr_sbr_process_batch with the QMF harmonic transposer and float parametric stereo; the SBR payload runs one
     frame late, and the reference's command line decoder does not write the first frame's output,
     test/decoder/ixheaacd_main.c:2181-2186) instead of -esbr:0.  AAC-LC streams decode
-    the same either way.  A stream whose SBR header changes after its first one is not supported in this mode (the
-    reset-time transposer runs, sbrdecoder.c:196-236, would need rows of the QMF history the device state does not keep)."""
+    the same either way.  SBR header changes in the middle of a stream are followed as the reference follows them (the
+    reset-time transposer runs, sbrdecoder.c:196-236, read 24 rows of the QMF history of the frame before: kept beside the
+    state)."""
     import time
     import torch
     lib = load_host_library()
@@ -330,6 +334,7 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
         def parse(self):
             t0 = time.perf_counter()
             self.got = bp.step(self.spec, self.ics, self.hdr, self.frm, self.psf, self.flags, self.eside)
+            self.reset_pitch = bp.reset_pitch.copy()
             self.seconds = time.perf_counter() - t0
             return self
 
@@ -362,7 +367,8 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
             ps_state = torch.from_numpy(np.tile(_struct_bytes(lib.xaac_esbr_ps_state_init, ESBR_PS_STATE_BYTES), (n, 1)).copy()).to(dev)
             psf_d = dz(n, PS_FRAME_BYTES)
             out_r = dz(n, 2048, dtype=torch.float32)
-        reset_seen = np.zeros(n, bool)
+        older = dz(nc, 2, 24 * 64, dtype=torch.float32)   # rows 8..31 of the QMF history as the frame before found them
+        hbe_tail = np.zeros((nc, 48), np.uint8)            # the transposers' integers (struct xaac_hbe_state from synth_size on)
     else:
         state = torch.from_numpy(np.tile(_struct_bytes(lib.xaac_sbr_state_init, SBR_STATE_BYTES), (nc, 1)).copy()).to(dev)
         core16 = dz(nc * 1024, dtype=torch.int16)
@@ -454,33 +460,47 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
             touched = np.nonzero(got & (flags[:, F_RESET] != 0))[0]
             if touched.size:
                 # ixheaacd_sbr_dec_reset for Path A (sbrdecoder.c:175-236): new transposer parameters from the header's band
-                # tables, then two transposer runs over rows 8..39 and 24..55 of the QMF history.  At a stream's first
-                # reset the rows before 32 are zero and 32..55 are rows 0..23 of the state's history.
-                if reset_seen[touched].any():
-                    raise NotImplementedError("-esbr:1 decoding of a stream whose SBR header changes after the first")
-                reset_seen[touched] = True
+                # tables (its two delay lines cleared), then two transposer runs over rows 8..39 and 40..71 of the QMF buffer
+                # as the frame before left it: rows 8..31 are what that frame found as rows 8..31 of its history (`older`),
+                # rows 32..71 are the state's history (the codec bank's num_time_slots is 32 here).  The second run's last eight output rows become the
+                # state's ph rows (bands outside the transposer's range keep what they held).
                 k = touched.size * n_ch
                 rows_h = (touched[:, None] * n_ch + np.arange(n_ch)[None, :]).ravel()
-                hb_h = np.zeros((k, HBE_STATE_BYTES), np.uint8)
-                for j, r in enumerate(rows_h):
-                    if lib.xaac_hbe_state_reinit(hb_h[j].ctypes.data, hdr_h[int(r)].numpy().ctypes.data):
-                        raise RuntimeError("the QMF transposer refused the SBR band tables of stream %d" % (r // n_ch))
                 rows = torch.from_numpy(rows_h).to(dev)
-                hb = torch.from_numpy(hb_h).to(dev)
+                hb = hbe.index_select(0, rows)
+                tail_off = HBE_STATE_BYTES - 48
+                one = np.zeros(HBE_STATE_BYTES, np.uint8)
+                for j, r in enumerate(rows_h):
+                    one[tail_off:] = hbe_tail[r]
+                    if lib.xaac_hbe_state_reinit(one.ctypes.data, hdr_h[int(r)].numpy().ctypes.data):
+                        raise RuntimeError("the QMF transposer refused the SBR band tables of stream %d" % (r // n_ch))
+                    hbe_tail[r] = one[tail_off:]
+                hb[:, tail_off:] = torch.from_numpy(hbe_tail[rows_h]).to(dev)
+                hb32 = hb.view(torch.float32)
+                hb32[:, 1088:1088 + 1280 + 640] = 0.0          # synth_buf, analy_buf (behind input_buf[1024 + 64])
+                pitch = torch.from_numpy(np.repeat(cur.reset_pitch[touched], n_ch).astype(np.int32)).to(dev)
                 st32 = state.view(torch.float32)
+                hist, old = st32.index_select(0, rows), older.index_select(0, rows)
                 q_re, q_im = dz(k, 32, 64, dtype=torch.float32), dz(k, 32, 64, dtype=torch.float32)
                 pv_re, pv_im = dz(k, 32, 64, dtype=torch.float32), dz(k, 32, 64, dtype=torch.float32)
                 rst = dz(k, dtype=torch.int32)
-                ctx.hbe_apply_batch(q_re, q_im, hb, pv_re, pv_im, status=rst)
-                hist = st32.index_select(0, rows)
-                q_re[:, 16:] = hist[:, _ES_QMF_RE + 8 * 64:_ES_QMF_RE + 24 * 64].view(k, 16, 64)
-                q_im[:, 16:] = hist[:, _ES_QMF_IM + 8 * 64:_ES_QMF_IM + 24 * 64].view(k, 16, 64)
-                pv_re.zero_(), pv_im.zero_()
-                ctx.hbe_apply_batch(q_re, q_im, hb, pv_re, pv_im, status=rst)
+                q_re[:, :24] = old[:, 0].view(k, 24, 64)
+                q_im[:, :24] = old[:, 1].view(k, 24, 64)
+                q_re[:, 24:] = hist[:, _ES_QMF_RE:_ES_QMF_RE + 8 * 64].view(k, 8, 64)
+                q_im[:, 24:] = hist[:, _ES_QMF_IM:_ES_QMF_IM + 8 * 64].view(k, 8, 64)
+                ctx.hbe_apply_batch(q_re, q_im, hb, pv_re, pv_im, status=rst, pitch_in_bins=pitch)
+                q_re[:] = hist[:, _ES_QMF_RE + 8 * 64:_ES_QMF_RE + 40 * 64].view(k, 32, 64)
+                q_im[:] = hist[:, _ES_QMF_IM + 8 * 64:_ES_QMF_IM + 40 * 64].view(k, 32, 64)
+                pv_re[:, 24:] = hist[:, _ES_PH_RE:_ES_PH_RE + 512].view(k, 8, 64)
+                pv_im[:, 24:] = hist[:, _ES_PH_IM:_ES_PH_IM + 512].view(k, 8, 64)
+                ctx.hbe_apply_batch(q_re, q_im, hb, pv_re, pv_im, status=rst, pitch_in_bins=pitch)
                 hist[:, _ES_PH_RE:_ES_PH_RE + 512] = pv_re[:, 24:].reshape(k, 512)
                 hist[:, _ES_PH_IM:_ES_PH_IM + 512] = pv_im[:, 24:].reshape(k, 512)
                 st32.index_copy_(0, rows, hist)
                 hbe.index_copy_(0, rows, hb)
+            st32 = state.view(torch.float32)
+            older[:, 0] = st32[:, _ES_QMF_RE + 8 * 64:_ES_QMF_RE + 32 * 64]   # for the reset a later frame may bring
+            older[:, 1] = st32[:, _ES_QMF_IM + 8 * 64:_ES_QMF_IM + 32 * 64]
             ctx.esbr_core_from_pcm16(core16, core, ch_fac=n_ch)
             if _trace is not None:   # debugging: the device states in front of the chain call
                 _trace(dict(state=state, hbe=hbe, ps_state=ps_state if n_ch == 1 else None, core=core, side=eside_d, header=hdr_d,

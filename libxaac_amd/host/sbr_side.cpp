@@ -1439,6 +1439,8 @@ int xs_decode_frame(XsDecoder *d, const uint8_t *payload, int bytes, int ext_typ
           derive_lim_bands(h);
           res->reset = 1;
           res->reset_channels = lr1;
+          d->reset_pitch = d->fd[0].pitch_in_bins; /* what ixheaacd_sbr_dec_reset is handed: the element's first channel's
+                                                      pitch of the payload before this one (sbrdecoder.c:547-550) */
         }
         if (err == 0) h->sync_state = XS_ACTIVE;
       }

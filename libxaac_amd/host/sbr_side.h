@@ -78,6 +78,7 @@ struct XsDecoder { /* one stream */
   int enh;                 /* the reference's default -esbr:1: payloads run one frame late, ENHSBR extension, float dequantisation */
   int qmf_sb_prev;         /* pstr_freq_band_data->qmf_sb_prev (sbrdec_initfuncs.c:649, sbrdecoder.c:892-986) */
   int qmf_sb_prev_frame;   /* ... as the frame decoded last found it */
+  int reset_pitch;         /* at a frame with res.reset: pitch_in_bins the reset's transposer runs take */
   int prev_bytes, prev_ext_type;
   uint8_t prev_payload[272];
   XsHeader hdr;

@@ -250,6 +250,12 @@ int32_t xaac_parse_esbr_side(xaac_parser *p, int32_t channel, xaac_esbr_side *si
   return XAAC_PARSE_OK;
 }
 
+int32_t xaac_parse_reset_pitch(xaac_parser *p, int32_t *pitch_in_bins) {
+  if (!p || !pitch_in_bins || !p->sbr_ready) return XAAC_PARSE_ERR_SYNTAX;
+  *pitch_in_bins = p->sbr.reset_pitch;
+  return XAAC_PARSE_OK;
+}
+
 int32_t xaac_inverse_quant(int32_t magnitude, int32_t *out) {
   int err = 0;
   if (magnitude < 0 || !out) return XAAC_PARSE_ERR_SYNTAX;
@@ -294,6 +300,7 @@ int32_t xaac_parse_batch_run(const xaac_parse_batch *b) {
         b->frame[(size_t)i * n_ch + c] = side->frame[c];
       }
     }
+    if (side && b->reset_pitch && side->reset) b->reset_pitch[i] = p->sbr.reset_pitch;
     if (side && b->esbr_side && p->esbr)
       for (int c = 0; c < n_ch; c++) xs_export_esbr_side(&p->sbr, c, b->esbr_side + (size_t)i * n_ch + c);
     if (side) {
@@ -346,7 +353,8 @@ int32_t xaac_hbe_state_reinit(xaac_hbe_state *s, const xaac_sbr_header *h) {
   s->k_start = xs_hbe_k_start(s->start_band);
   memset(s->synth_buf, 0, sizeof(s->synth_buf));
   memset(s->analy_buf, 0, sizeof(s->analy_buf));
-  s->fft_ready = s->synth_size != 20; /* the one bank size the reference sets no FFT for (hbe_trans.c:164-169) */
+  if (s->synth_size != 20) s->fft_ready = 1; /* the one bank size the reference sets no FFT pointers for keeps what a bank
+                                                before it left (hbe_trans.c:164-169) */
   memset(s->x_over_qmf, 0, sizeof(s->x_over_qmf));
   int sfb = 0;
   for (int patch = 1; patch <= 4; patch++) { /* MAX_STRETCH */

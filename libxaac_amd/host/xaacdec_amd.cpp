@@ -69,7 +69,7 @@ struct Staging { /* what one step's parse leaves for the GPU */
   xaac_sbr_frame *frame;
   xaac_ps_frame *ps;
   xaac_esbr_side *eside;
-  std::vector<int32_t> flags, status;
+  std::vector<int32_t> flags, status, reset_pitch;
   std::vector<uint64_t> consumed;
   int delivered;
 };
@@ -190,7 +190,7 @@ int main(int argc, char **argv) {
   xaac_hbe_state *d_hbe = nullptr;
   xaac_esbr_ps_state *d_eps = nullptr;
   float *d_fcore = nullptr, *d_out_l = nullptr, *d_out_r = nullptr, *d_q = nullptr, *d_pv = nullptr;
-  bool reset_seen = false;
+  float *d_older = nullptr; /* [2][NC][24][64]: rows 8..31 of the QMF history as the frame before found them (see the reset) */
   void *d_ws = nullptr;
   uint64_t ws_bytes = 0;
   if (!sbr) {
@@ -211,6 +211,7 @@ int main(int argc, char **argv) {
     d_hbe = dev<xaac_hbe_state>((size_t)NC); /* all zero for a new stream */
     d_fcore = dev<float>((size_t)NC * 1024);
     d_out_l = dev<float>((size_t)NC * 2048);
+    d_older = dev<float>((size_t)2 * NC * 24 * 64);
     static xaac_esbr_state e0;
     xaac_esbr_state_init(&e0);
     for (int i = 0; i < NC; i++) HIP(hipMemcpy(d_estate + i, &e0, sizeof(e0), hipMemcpyHostToDevice));
@@ -254,7 +255,7 @@ int main(int argc, char **argv) {
     s.frame = sbr ? pinned<xaac_sbr_frame>((size_t)NC) : nullptr;
     s.ps = (sbr && n_ch == 1) ? pinned<xaac_ps_frame>((size_t)N) : nullptr;
     s.eside = esbr ? pinned<xaac_esbr_side>((size_t)NC) : nullptr;
-    s.flags.assign((size_t)N * 8, 0), s.status.assign((size_t)N, 0), s.consumed.assign((size_t)N, 0);
+    s.flags.assign((size_t)N * 8, 0), s.status.assign((size_t)N, 0), s.consumed.assign((size_t)N, 0), s.reset_pitch.assign((size_t)N, 0);
     s.delivered = 0;
   }
   double parse_s = 0;
@@ -267,6 +268,7 @@ int main(int argc, char **argv) {
     b.parser = parser.data(), b.data = ptr.data(), b.bytes = left.data();
     b.spec = s->spec, b.ics = s->ics, b.header = s->header, b.frame = s->frame, b.ps_frame = s->ps;
     b.flags = s->flags.data(), b.consumed = s->consumed.data(), b.status = s->status.data(), b.esbr_side = s->eside;
+    b.reset_pitch = s->reset_pitch.data();
     const int ok = xaac_parse_batch_run(&b);
     if (ok < 0) die("xaac_parse_batch_run", ok);
     for (int i = 0; i < N; i++) {
@@ -376,40 +378,61 @@ int main(int argc, char **argv) {
       int resets = 0, with_ps = 0;
       for (int i = 0; i < N; i++) resets += s.flags[(size_t)i * 8 + 1] != 0, with_ps += s.flags[(size_t)i * 8 + 5] != 0;
       if ((resets != 0 && resets != N) || (with_ps != 0 && with_ps != N)) die("a batch mixing kinds of frames");
+      const size_t row = 64 * sizeof(float), st_pitch = sizeof(xaac_esbr_state), q_pitch = 2048 * sizeof(float);
+      float *older_re = d_older, *older_im = d_older + (size_t)NC * 24 * 64;
       if (resets) {
-        /* ixheaacd_sbr_dec_reset for Path A (sbrdecoder.c:175-236): the transposer's parameters from the new band tables, then
-           its two runs over rows 8..39 and 24..55 of the QMF history -- at a stream's first reset the rows in front of the
-           state's history are zero and rows 32..55 are its rows 0..23 */
-        if (reset_seen) die("-esbr:1 decoding of a stream whose SBR header changes after the first is not built");
-        reset_seen = true;
+        /* ixheaacd_sbr_dec_reset for Path A (sbrdecoder.c:175-236): the transposer's parameters from the new band tables (its
+           two delay lines cleared, hbe_trans.c:102-222), then its two runs over rows 8..39 and 40..71 of the QMF buffer (the codec bank's num_time_slots is 32) as the
+           frame before left it: rows 8..31 are what that frame found as its history rows 8..31 (d_older), rows 32..71 are
+           the state's history.  The second run's last eight output rows are the state's ph rows (bands outside
+           the transposer's range keep what they held). */
         static xaac_hbe_state h0;
-        constexpr size_t kTail = sizeof(xaac_hbe_state) - offsetof(xaac_hbe_state, synth_size); /* the integers behind the (still zero) buffers */
-        std::vector<uint8_t> tail((size_t)NC * kTail);
+        constexpr size_t kTail = sizeof(xaac_hbe_state) - offsetof(xaac_hbe_state, synth_size); /* the integers behind the buffers */
+        static std::vector<uint8_t> tail; /* every channel's, kept between resets: some survive one (max_stretch, fft_ready) */
+        if (tail.empty()) tail.assign((size_t)NC * kTail, 0);
         for (int i = 0; i < NC; i++) {
           xaac_hbe_state_init(&h0);
+          memcpy(&h0.synth_size, &tail[(size_t)i * kTail], kTail);
           if (xaac_hbe_state_reinit(&h0, &s.header[(size_t)i])) die("the QMF transposer refused the SBR band tables");
           memcpy(&tail[(size_t)i * kTail], &h0.synth_size, kTail);
         }
+        HIP(hipStreamSynchronize(stream));
         HIP(hipMemcpy2D(&d_hbe[0].synth_size, sizeof(xaac_hbe_state), tail.data(), kTail, kTail, (size_t)NC, hipMemcpyHostToDevice));
+        HIP(hipMemset2DAsync(&d_hbe[0].synth_buf[0], sizeof(xaac_hbe_state), 0, sizeof(h0.synth_buf), (size_t)NC, stream));
+        HIP(hipMemset2DAsync(&d_hbe[0].analy_buf[0], sizeof(xaac_hbe_state), 0, sizeof(h0.analy_buf), (size_t)NC, stream));
         if (!d_q) d_q = dev<float>((size_t)NC * 2 * 2048), d_pv = dev<float>((size_t)NC * 2 * 2048);
         float *q_re = d_q, *q_im = d_q + (size_t)NC * 2048, *pv_re = d_pv, *pv_im = d_pv + (size_t)NC * 2048;
         xaac_hbe_apply_batch_desc hb;
         memset(&hb, 0, sizeof(hb));
         hb.n_ch = NC, hb.qmf_re = q_re, hb.qmf_im = q_im, hb.state = d_hbe, hb.pv_re = pv_re, hb.pv_im = pv_im, hb.status = d_status;
-        HIP(hipMemsetAsync(d_q, 0, (size_t)NC * 2 * 2048 * 4, stream));
-        HIP(hipMemsetAsync(d_pv, 0, (size_t)NC * 2 * 2048 * 4, stream));
+        {
+          std::vector<int32_t> pitch((size_t)NC);
+          for (int i = 0; i < NC; i++) pitch[(size_t)i] = s.reset_pitch[(size_t)(i / n_ch)];
+          if (!d_idx) d_idx = dev<int32_t>((size_t)NC);
+          HIP(hipMemcpy(d_idx, pitch.data(), (size_t)NC * 4, hipMemcpyHostToDevice));
+          hb.pitch_in_bins = d_idx;
+        }
+        const auto copy_rows = [&](float *dst, size_t dpitch, const float *src, size_t spitch, int rows) {
+          HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, rows * row, (size_t)NC, hipMemcpyDeviceToDevice, stream));
+        };
+        /* run 1: buffer rows 8..39 */
+        copy_rows(q_re, q_pitch, older_re, 24 * row, 24);
+        copy_rows(q_im, q_pitch, older_im, 24 * row, 24);
+        copy_rows(q_re + 24 * 64, q_pitch, &d_estate[0].qmf_re[0][0], st_pitch, 8);
+        copy_rows(q_im + 24 * 64, q_pitch, &d_estate[0].qmf_im[0][0], st_pitch, 8);
         XA(xaac_hbe_apply_batch(ctx, &hb));
-        HIP(hipMemcpy2DAsync(q_re + 16 * 64, 2048 * 4, &d_estate[0].qmf_re[8][0], sizeof(xaac_esbr_state), 16 * 64 * 4, (size_t)NC,
-                             hipMemcpyDeviceToDevice, stream));
-        HIP(hipMemcpy2DAsync(q_im + 16 * 64, 2048 * 4, &d_estate[0].qmf_im[8][0], sizeof(xaac_esbr_state), 16 * 64 * 4, (size_t)NC,
-                             hipMemcpyDeviceToDevice, stream));
-        HIP(hipMemsetAsync(d_pv, 0, (size_t)NC * 2 * 2048 * 4, stream));
+        /* run 2: buffer rows 40..71; its output rows 24..31 start from the state's ph rows */
+        copy_rows(q_re, q_pitch, &d_estate[0].qmf_re[8][0], st_pitch, 32);
+        copy_rows(q_im, q_pitch, &d_estate[0].qmf_im[8][0], st_pitch, 32);
+        copy_rows(pv_re + 24 * 64, q_pitch, &d_estate[0].ph_re[0][0], st_pitch, 8);
+        copy_rows(pv_im + 24 * 64, q_pitch, &d_estate[0].ph_im[0][0], st_pitch, 8);
         XA(xaac_hbe_apply_batch(ctx, &hb));
-        HIP(hipMemcpy2DAsync(&d_estate[0].ph_re[0][0], sizeof(xaac_esbr_state), pv_re + 24 * 64, 2048 * 4, 8 * 64 * 4, (size_t)NC,
-                             hipMemcpyDeviceToDevice, stream));
-        HIP(hipMemcpy2DAsync(&d_estate[0].ph_im[0][0], sizeof(xaac_esbr_state), pv_im + 24 * 64, 2048 * 4, 8 * 64 * 4, (size_t)NC,
-                             hipMemcpyDeviceToDevice, stream));
+        copy_rows(&d_estate[0].ph_re[0][0], st_pitch, pv_re + 24 * 64, q_pitch, 8);
+        copy_rows(&d_estate[0].ph_im[0][0], st_pitch, pv_im + 24 * 64, q_pitch, 8);
       }
+      /* what this frame finds as rows 8..31 of its history: the frame behind it may need them at a reset */
+      HIP(hipMemcpy2DAsync(older_re, 24 * row, &d_estate[0].qmf_re[8][0], st_pitch, 24 * row, (size_t)NC, hipMemcpyDeviceToDevice, stream));
+      HIP(hipMemcpy2DAsync(older_im, 24 * row, &d_estate[0].qmf_im[8][0], st_pitch, 24 * row, (size_t)NC, hipMemcpyDeviceToDevice, stream));
       HIP(hipMemcpyAsync(d_header, s.header, (size_t)NC * sizeof(xaac_sbr_header), hipMemcpyHostToDevice, stream));
       HIP(hipMemcpyAsync(d_frame, s.frame, (size_t)NC * sizeof(xaac_sbr_frame), hipMemcpyHostToDevice, stream));
       HIP(hipMemcpyAsync(d_eside, s.eside, (size_t)NC * sizeof(xaac_esbr_side), hipMemcpyHostToDevice, stream));

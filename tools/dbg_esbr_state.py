@@ -9,7 +9,7 @@ from libxaac_amd import decoder, ESBR_STATE_BYTES, HBE_STATE_BYTES, ESBR_PS_STAT
 from esbr_structs import EsbrState
 from hbe_structs import HbeState
 name = sys.argv[1]
-src = os.path.join(ROOT, "tests/golden/streams", name + ".aac")
+src = name if os.path.exists(name) else os.path.join(ROOT, "tests/golden/streams", name + ".aac")
 subprocess.run([os.path.join(ROOT, "oracle/_ref/xaacdec_capture"), "-ifile:" + src, "-ofile:/tmp/o.wav"], check=True, capture_output=True,
                env=dict(os.environ, XAAC_ESBR_SIDE_FILE="/tmp/side.bin", XAAC_ESBR_INIT_FILE="/tmp/init.bin", XAAC_ESBR_INIT_ALL="1"))
 raw = open("/tmp/init.bin", "rb").read()
@@ -44,6 +44,7 @@ def trace(t):
     k = step[0]; step[0] += 1
     st = t["state"].cpu().numpy(); hb = t["hbe"].cpu().numpy()
     nch = st.shape[0]
+    if k < int(os.environ.get("DBG_FIRST", "0")): return
     for c in range(nch):
         call = nch + k * nch + c           # the initialisation pass comes first
         if call >= calls: return
@@ -59,5 +60,5 @@ def trace(t):
         bad = np.nonzero(core != ref_core)[0]
         if bad.size: print("frame", k, "ch", c, "core differs at", bad.size, "first", bad[:6].tolist(), core[bad[:6]].tolist(), ref_core[bad[:6]].tolist())
         if nb: print("frame", k, "ch", c, "members differing", nb)
-    if k > 6: raise SystemExit
+    if k > int(os.environ.get("DBG_LAST", "6")): raise SystemExit
 decoder.decode_streams([open(src, "rb").read()], esbr=True, overlap=False, _trace=trace)
