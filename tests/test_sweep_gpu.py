@@ -27,9 +27,9 @@ def test_streams_made_on_the_spot_decode_like_the_reference(tmp_path):
 
 def test_spliced_streams_with_sbr_header_changes_in_the_middle(tmp_path):
     """tools/splice_check.py: streams of different bit rates (different SBR ranges: a new SBR header, i.e. a reset of the SBR
-    decoder, at every splice) joined frame-wise, with and without ENHSBR elements; the native decoder and decode_streams
+    decoder, at every splice) joined frame-wise, with and without ENHSBR elements, and mono HE-AAC joined with HE-AACv2 (parametric stereo starting and stopping); the native decoder and decode_streams
     against the reference with both flag settings (Path A: the reset-time transposer runs on device rows)."""
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "splice_check.py")], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, SWEEP_TMP=str(tmp_path)))
     lines = p.stdout.strip().splitlines()
-    assert lines and lines[-1] == "bad 0" and sum("identical" in l for l in lines) == 12, p.stdout[-1200:] + p.stderr[-600:]
+    assert lines and lines[-1] == "bad 0" and sum("identical" in l for l in lines) == 16, p.stdout[-1200:] + p.stderr[-600:]

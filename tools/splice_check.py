@@ -25,10 +25,15 @@ def payload(path):
         return w.getnchannels(), w.getframerate(), w.readframes(w.getnframes())
 bad = 0
 HARM = ("-esbr:1", "-harmonic_sbr:1", "-inter_tes_enc:1")   # ENHSBR elements: harmonic patching (the transposer's output is read), pre-flattening
-for ch, aot, brs, extra in ((2, 5, (24000, 64000, 32000), ()), (1, 5, (16000, 40000), ()), (2, 29, (18000, 40000, 24000), ()),
-                           (2, 2, (48000, 128000), ()), (2, 5, (48000, 32000, 64000), HARM), (1, 5, (32000, 20000), HARM)):
-    parts = [enc("p%d_%d_%d_%d" % (ch, aot, br, len(extra)), ch, aot, br, extra) for br in brs]
-    spliced = os.path.join(TMP, "splice_%d_%d_%d.aac" % (ch, aot, len(extra)))
+CASES = [("2 5", [(2, 5, br, ()) for br in (24000, 64000, 32000)]), ("1 5", [(1, 5, br, ()) for br in (16000, 40000)]),
+         ("2 29", [(2, 29, br, ()) for br in (18000, 40000, 24000)]), ("2 2", [(2, 2, br, ()) for br in (48000, 128000)]),
+         ("2 5 harmonic", [(2, 5, br, HARM) for br in (48000, 32000, 64000)]), ("1 5 harmonic", [(1, 5, br, HARM) for br in (32000, 20000)]),
+         # parametric stereo appearing and disappearing on a mono core
+         ("mono + ps + mono", [(1, 5, 24000, ()), (2, 29, 24000, ()), (1, 5, 32000, ())]), ("ps + mono", [(2, 29, 32000, ()), (1, 5, 24000, ())])]
+for label, plist in CASES:
+    ch, aot = label, ""
+    parts = [enc("p%d_%d_%d_%d" % (c, a, br, len(extra)), c, a, br, extra) for c, a, br, extra in plist]
+    spliced = os.path.join(TMP, "splice_%s.aac" % label.replace(" ", "_").replace("+", "p"))
     open(spliced, "wb").write(b"".join(parts))
     for flags in (("-esbr:0",), ()):
         a, b = os.path.join(TMP, "ref.wav"), os.path.join(TMP, "own.wav")
