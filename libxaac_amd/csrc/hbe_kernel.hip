@@ -195,11 +195,6 @@ __global__ __launch_bounds__(XAAC_HBE_POST_THREADS) void xaac_hbe_post_kernel(Xa
   int32_t xo[4];
   for (int q = 0; q < 4; q++) xo[q] = st->x_over_qmf[q];
   float *pv_re = p.pv_re + (size_t)ch * p.pv_stride, *pv_im = p.pv_im + (size_t)ch * p.pv_stride;
-  const auto in = [&](int row, int band) {
-    const float2 v = *reinterpret_cast<const float2 *>(&st->qmf_in_buf[row][2 * band]);
-    const XhC c = {v.x, v.y};
-    return c;
-  };
   const float *in_flat = &st->qmf_in_buf[0][0];
   const auto inf = [&](int row, int idx) { return in_flat[128 * row + idx]; };
 #ifdef XE_PROFILE

@@ -2067,7 +2067,7 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
   }
   cx.sync();
   XS_T(3);
-  int m = 0, nf_idx = 0;
+  int nf_idx = 0;
   const int tansient_env_prev = cx.uni(st->tansient_env_prev);
   const int hb_scale = cx.uni(st->hb_scale), lb_scale = cx.uni(st->lb_scale);
   const XsLv lim_of = xs_limiter_band_of(cx, h, skip);
@@ -2094,7 +2094,6 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
     const int n_meta = xs_subband_gain_meta(cx, h, max_sb, tbl, nsf, i, v);
     XS_T(5);
     xs_calc_subband_gains(cx, xs_pick_env(sfv, i), noise_floor, i, n_meta, skip, v, noise_absc);
-    m += nsf;
     XS_T(6);
     xs_noiselimiting(cx, h, skip, n_meta, v, w, &xaac_sbr_lim_gains_m[2 * cx.uni(h->limiter_gains)], noise_absc, lim_of);
     XS_T(7);
