@@ -4,6 +4,8 @@
  * flips inside the SBR payload only (the core stays decodable, so the SBR / PS reader sees the damage), random payloads,
  * truncations, runs of ones / zeros, frames spliced from two places.  Any out-of-bounds access, signed overflow outside
  * -fwrapv, misaligned access or leak ends the process with a report; the test requires a clean exit.
+ * Every other round runs the parser in its -esbr:1 mode (payload one frame late, ENHSBR element, float scale factors) and reads
+ * the eSBR side info, the reset pitch and the transposer parameters a reset derives from the (possibly damaged) band tables.
  *   fuzz_parser <stream.aac> <seed> <rounds>
  */
 #include <cstdint>
@@ -45,7 +47,11 @@ int main(int argc, char **argv) {
   for (int r = 0; r < rounds; r++) {
     xaac_parser *p = nullptr;
     if (xaac_parser_create(&p)) return 2;
-    const int kind = r % 6;
+    const int kind = r % 6, esbr = (r / 6) & 1;
+    if (esbr && xaac_parser_set_esbr(p, 1)) return 2;
+    static xaac_esbr_side es;
+    static xaac_hbe_state hb;
+    xaac_hbe_state_init(&hb);
     for (size_t k = 0; k < frames.size() && k < 24; k++) {
       std::vector<uint8_t> b = frames[k];
       const size_t n = b.size();
@@ -73,6 +79,14 @@ int main(int argc, char **argv) {
         const int32_t rs = xaac_parse_sbr_side(p, 1, &side);
         if (rs == 0) sbr_ok++;
         else sbr_bad++;
+        if (rs == 0 && esbr) {
+          int32_t pitch = 0;
+          for (int c = 0; c < core.n_ch; c++) xaac_parse_esbr_side(p, c, &es);
+          if (side.reset) {
+            xaac_parse_reset_pitch(p, &pitch);
+            xaac_hbe_state_reinit(&hb, &side.header);
+          }
+        }
       } else {
         bad++;
       }

@@ -20,7 +20,7 @@ def fuzzer(tmp_path_factory):
     return exe
 
 
-@pytest.mark.parametrize("name", ["mix_aot2_64k", "mix_aot5_48k", "mono_aot5_32k", "mix_aot29_32k", "synth_lc_a"])
+@pytest.mark.parametrize("name", ["mix_aot2_64k", "mix_aot5_48k", "mono_aot5_32k", "mix_aot29_32k", "synth_lc_a", "harm_aot5_48k"])
 def test_damaged_streams_are_memory_safe(fuzzer, name):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     p = subprocess.run([fuzzer, os.path.join(ROOT, "tests", "golden", "streams", name + ".aac"), "4242", "240"], capture_output=True,

@@ -47,7 +47,8 @@ for r in range(1, rounds + 1):
         ("eSBR chain (Path A)", lambda: te.test_chain_vs_oracle(oracle)),
         ("eSBR + float PS chain", lambda: te.test_ps_chain_vs_oracle(oracle)),
         ("eSBR banks", lambda: tq.test_gpu_analysis_then_synthesis_vs_oracle(oracle)),
-        ("USAC IMDCT batch", lambda: tu.test_gpu_large_batch_vs_oracle(oracle)),
+        ("USAC IMDCT batch 1024", lambda: tu.test_gpu_large_batch_vs_oracle(oracle, 1024)),
+        ("USAC IMDCT batch 768", lambda: tu.test_gpu_large_batch_vs_oracle(oracle, 768)),
         ("eSBR chain with harmonic SBR", lambda: te.test_chain_with_harmonic_transposer_vs_oracle(oracle)),
         ("960-line IMDCT, every transition", lambda: t9.test_every_transition_vs_oracle(oracle, 0)),
         ("960-line IMDCT, stereo walk", lambda: t9.test_stereo_walk_with_state_on_device(oracle)),
