@@ -28,6 +28,14 @@ def main():
     os.makedirs(TMP, exist_ok=True)
     sig = m.signals(seconds=float(os.environ.get("SWEEP_SECONDS", "1.6")))   # (multiples of 0.8 s)
     x48 = 0.5 * sig["clicks"] + 0.35 * sig["harmonic"] + 0.3 * sig["noise_sweep"]
+    variant = int(os.environ.get("SWEEP_VARIANT", "0"))   # other mixes of the same ingredients: weights, time offsets, polarity
+    if variant:
+        vr = np.random.default_rng(1000 + variant)
+        w = vr.uniform(0.05, 0.9, 3)
+        x48 = sum(wk * np.roll(sig[k], int(vr.integers(0, 48000)), axis=0) * vr.choice([-1.0, 1.0]) for wk, k in zip(w, ("clicks", "harmonic", "noise_sweep")))
+        x48 = x48 + vr.uniform(0.0, 0.2) * vr.standard_normal(x48.shape)
+        x48[:, 1] = vr.uniform(0.2, 1.0) * x48[:, 1] + vr.uniform(0.0, 0.5) * np.roll(x48[:, 0], int(vr.integers(1, 400)))
+        x48 = np.clip(x48 / max(1.0, np.abs(x48).max() / 0.98), -1.0, 1.0)
     cases = []
     rates = tuple(int(v) for v in os.environ["SWEEP_RATES"].split(",")) if os.environ.get("SWEEP_RATES") else (16000, 22050, 24000, 32000, 44100, 48000)
     for fs in rates:
@@ -45,6 +53,8 @@ def main():
                     continue       # SBR at twice a low core rate: the encoder's supported range
                 for br in brs:
                     cases.append((fs, ch, aot, br, wav))
+                    if aot == 5:   # ... and with ENHSBR elements: harmonic patching, pre-flattening, inter-TES
+                        cases.append((fs, ch, aot, br, wav, ("-esbr:1", "-harmonic_sbr:1", "-inter_tes_enc:1")))
     # other material at one rate: digital silence, full-scale noise (the peak limiter at work, escape codes, saturating float
     # samples on Path A), a lone click train; stereo
     rng = np.random.default_rng(3)
@@ -60,10 +70,11 @@ def main():
         for aot, br in ((2, 64000), (5, 32000), (29, 24000)):
             cases.append((label, 2, aot, br, wav))
     bad = total = 0
-    for fs, ch, aot, br, wav in cases:
-        name = "s%s_c%d_a%d_b%d" % (fs, ch, aot, br)
+    for fs, ch, aot, br, wav, *enc_extra in cases:
+        enc_extra = enc_extra[0] if enc_extra else ()
+        name = "s%s_c%d_a%d_b%d%s" % (fs, ch, aot, br, "_enh" if enc_extra else "")
         aac = os.path.join(TMP, name + ".aac")
-        r = subprocess.run([os.path.join(REF, "xaacenc"), "-ifile:" + wav, "-ofile:" + aac, "-aot:%d" % aot, "-br:%d" % br, "-adts:1"],
+        r = subprocess.run([os.path.join(REF, "xaacenc"), "-ifile:" + wav, "-ofile:" + aac, "-aot:%d" % aot, "-br:%d" % br, "-adts:1", *enc_extra],
                            capture_output=True)
         if r.returncode or not os.path.exists(aac) or os.path.getsize(aac) < 100:
             print(name, "encoder refused")
