@@ -6,9 +6,12 @@
  * stream's state resident in device memory.  No reference code, no Python, no torch: HIP runtime + the two libraries.
  *
  *   xaacdec_amd -ifile:<in.aac> -ofile:<out.wav> [-esbr:<0|1>] [-copies:<N>] [-verify] [-threads:<T>] [-quiet]
+ *   xaacdec_amd -ilist:<file with one input path per line> -odir:<directory> [-esbr:<0|1>] [-threads:<T>] [-quiet]
  *
  * -copies:N decodes N instances of the stream in one lock-step batch (the first one's PCM is written; with -verify all N are
  * compared with it word for word) and prints the end-to-end rate: the shape a serving host has, with one input here for brevity.
+ * -ilist decodes different streams of one kind (sampling rate, channels, SBR / PS or not) in one batch, each to <odir>/<name>.wav;
+ * a stream that ends drops out of the steps, the others go on.
  * libxaac_amd/decoder.py is the same loop in Python (used by the tests for its ease of inspection).
  */
 #include <hip/hip_runtime_api.h>
@@ -90,12 +93,14 @@ void write_wav(const std::string &path, const std::vector<int16_t> &pcm, int cha
 }  // namespace
 
 int main(int argc, char **argv) {
-  std::string in, out;
+  std::string in, out, ilist, odir;
   int copies = 1, threads = 0, quiet = 0, verify = 0, profile = 0, esbr = 1;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
     if (a.rfind("-ifile:", 0) == 0) in = a.substr(7);
     else if (a.rfind("-ofile:", 0) == 0) out = a.substr(7);
+    else if (a.rfind("-ilist:", 0) == 0) ilist = a.substr(7);
+    else if (a.rfind("-odir:", 0) == 0) odir = a.substr(6);
     else if (a.rfind("-copies:", 0) == 0) copies = atoi(a.c_str() + 8);
     else if (a.rfind("-threads:", 0) == 0) threads = atoi(a.c_str() + 9);
     else if (a == "-quiet") quiet = 1;
@@ -105,22 +110,39 @@ int main(int argc, char **argv) {
     else if (a == "-esbr:1") esbr = 1;
     else if (a.rfind("-esbr", 0) == 0) die("-esbr:0 or -esbr:1");
   }
-  if (in.empty() || out.empty() || copies < 1) {
+  std::vector<std::string> inputs;
+  if (!ilist.empty()) {
+    FILE *f = fopen(ilist.c_str(), "r");
+    if (!f) die("fopen(-ilist)");
+    char line[4096];
+    while (fgets(line, sizeof(line), f)) {
+      std::string sline(line);
+      while (!sline.empty() && (sline.back() == '\n' || sline.back() == '\r' || sline.back() == ' ')) sline.pop_back();
+      if (!sline.empty()) inputs.push_back(sline);
+    }
+    fclose(f);
+    if (inputs.empty() || odir.empty()) die("-ilist needs paths and -odir");
+    copies = 1, verify = 0;
+  } else if (!in.empty()) {
+    inputs.push_back(in);
+  }
+  if (inputs.empty() || (ilist.empty() && out.empty()) || copies < 1) {
     fprintf(stderr, "usage: xaacdec_amd -ifile:<in.aac> -ofile:<out.wav> [-esbr:0|1] [-copies:N] [-threads:T] [-quiet]\n");
     return 1;
   }
-  std::vector<uint8_t> data;
-  {
-    FILE *f = fopen(in.c_str(), "rb");
+  std::vector<std::vector<uint8_t>> datas(inputs.size());
+  for (size_t k = 0; k < inputs.size(); k++) {
+    FILE *f = fopen(inputs[k].c_str(), "rb");
     if (!f) die("fopen(input)");
     fseek(f, 0, SEEK_END);
     const long n = ftell(f);
     fseek(f, 0, SEEK_SET);
-    data.resize((size_t)n + 16);
-    if (fread(data.data(), 1, (size_t)n, f) != (size_t)n) die("fread");
+    datas[k].resize((size_t)n + 16);
+    if (fread(datas[k].data(), 1, (size_t)n, f) != (size_t)n) die("fread");
     fclose(f);
-    data.resize((size_t)n);
+    datas[k].resize((size_t)n);
   }
+  const std::vector<uint8_t> &data = datas[0];
   /* a look at frame 0: channels, SBR or not (api.c:3369-3373: the SBR tools run for frames with an SBR payload; a stream at
      24 kHz and below has an SBR decoder object by implicit signalling, api.c:2160, which is never called without payloads) */
   xaac_adts_header hdr;
@@ -136,10 +158,19 @@ int main(int argc, char **argv) {
     n_ch = cf[0].n_ch;
     sbr = cf[0].sbr_bytes > 0;
     xaac_parser_destroy(probe);
+    for (size_t k = 1; k < datas.size(); k++) { /* -ilist: one kind of stream per batch */
+      xaac_adts_header h2;
+      if (xaac_adts_parse_header(datas[k].data(), datas[k].size(), &h2)) die("ADTS header");
+      XA(xaac_parser_create(&probe));
+      if (xaac_parse_adts_frame(probe, datas[k].data(), datas[k].size(), 1, cf.data(), &used)) die("first frame");
+      if (h2.sampling_rate != hdr.sampling_rate || cf[0].n_ch != n_ch || (cf[0].sbr_bytes > 0) != (sbr != 0))
+        die("-ilist: streams of different kinds (sampling rate, channels, SBR) in one batch");
+      xaac_parser_destroy(probe);
+    }
   }
   if (!sbr) esbr = 0; /* AAC-LC streams decode the same either way */
   const int out_ch = sbr ? 2 : n_ch; /* SBR streams come out in stereo (PS, or the mono column twice); AAC-LC as coded */
-  const int N = copies, NC = N * n_ch, NCD = NC, rate = hdr.sampling_rate, out_rate = sbr ? 2 * rate : rate, per = sbr ? 2048 : 1024;
+  const int N = ilist.empty() ? copies : (int)datas.size(), NC = N * n_ch, NCD = NC, rate = hdr.sampling_rate, out_rate = sbr ? 2 * rate : rate, per = sbr ? 2048 : 1024;
 
   xaac_ctx *ctx = nullptr;
   hipStream_t stream;
@@ -261,7 +292,10 @@ int main(int argc, char **argv) {
   double parse_s = 0;
   auto parse = [&](Staging *s) { /* the next frame of every stream into one staging set */
     const auto t0 = std::chrono::steady_clock::now();
-    for (int i = 0; i < N; i++) ptr[(size_t)i] = data.data() + pos[(size_t)i], left[(size_t)i] = data.size() - pos[(size_t)i];
+    for (int i = 0; i < N; i++) {
+      const std::vector<uint8_t> &d = datas[datas.size() > 1 ? (size_t)i : 0];
+      ptr[(size_t)i] = d.data() + pos[(size_t)i], left[(size_t)i] = d.size() - pos[(size_t)i];
+    }
     xaac_parse_batch b;
     memset(&b, 0, sizeof(b));
     b.n_streams = N, b.n_ch = n_ch, b.with_sbr = sbr, b.ps_enable = 1, b.stage = 2, b.threads = threads;
@@ -288,7 +322,12 @@ int main(int argc, char **argv) {
     phase_s[k] += std::chrono::duration<double>(now - t_phase).count();
     t_phase = now;
   };
-  std::vector<int16_t> pcm; /* stream 0's output */
+  const bool list_mode = !ilist.empty();
+  std::vector<std::vector<int16_t>> pcms((size_t)(list_mode ? N : 1)); /* every stream's output (-ilist), or stream 0's */
+  std::vector<int16_t> &pcm = pcms[0];
+  std::vector<char> ended((size_t)N, 0);
+  std::vector<xaac_limiter_state> lim_at_end; /* -ilist, AAC-LC: the limiter state a stream leaves behind its last frame */
+  if (list_mode && !sbr) lim_at_end.resize((size_t)N);
   long frames = 0, mismatched = 0;
   bool first = true;
   const auto t_all = std::chrono::steady_clock::now();
@@ -322,8 +361,8 @@ int main(int argc, char **argv) {
   /* what a step leaves for the host once its copy down has arrived */
   struct Pending {
     bool valid, mono_twice, first;
-    int slot;
-  } pending = {false, false, false, 0};
+    int slot, which;
+  } pending = {false, false, false, 0, 0};
   auto consume = [&]() {
     if (!pending.valid) return;
     HIP(hipEventSynchronize(ev_down[pending.slot]));
@@ -338,10 +377,13 @@ int main(int argc, char **argv) {
     const size_t skip = (!sbr && pending.first) ? (size_t)delay * out_ch : 0; /* the limiter's delay is cut from the first frame */
     /* (with -esbr:1 the reference's command line decoder does not write an SBR stream's first frame:
        test/decoder/ixheaacd_main.c:2181-2186) */
-    if (!(esbr && pending.first)) pcm.insert(pcm.end(), h_pcm + skip, h_pcm + (size_t)per * out_ch);
+    const std::vector<int32_t> &alive = st[pending.which].status; /* 0: the stream delivered a frame in that step */
+    if (!(esbr && pending.first))
+      for (size_t i = 0; i < pcms.size(); i++)
+        if (alive[i] == 0) pcms[i].insert(pcms[i].end(), h_pcm + i * per * out_ch + skip, h_pcm + (i + 1) * per * out_ch);
     for (int i = 1; verify && i < N; i++)
       mismatched += memcmp(h_pcm, h_pcm + (size_t)i * per * out_ch, (size_t)per * out_ch * 2) != 0;
-    frames += N;
+    frames += st[pending.which].delivered;
     if (pending.first) t_first = std::chrono::steady_clock::now(); /* the first step also loads the kernels' code objects */
     pending.valid = false;
     lap(3);
@@ -355,7 +397,14 @@ int main(int argc, char **argv) {
     int16_t *d_pcm = d_pcm2[slot], *d_mono = d_mono2[slot];
     int32_t *d_status = d_status2[slot];
     bool mono_twice = false;
-    if (s.delivered != N) die("streams of different lengths in one batch");
+    if (s.delivered != N) {
+      if (!list_mode) die("streams of different lengths in one batch");
+      for (int i = 0; i < N; i++)
+        if (s.status[(size_t)i] != 0 && !ended[(size_t)i]) { /* this stream is over: the other rows go on, its own run idle */
+          ended[(size_t)i] = 1;
+          if (!sbr) HIP(hipMemcpy(&lim_at_end[(size_t)i], d_lim + i, sizeof(xaac_limiter_state), hipMemcpyDeviceToHost)); /* (waits for the step before) */
+        }
+    }
     start_parse(); /* the next step's frames are parsed while the GPU works on this one's */
     t_phase = std::chrono::steady_clock::now();
     HIP(hipMemcpyAsync(d_spec, s.spec, (size_t)NC * 4096, hipMemcpyHostToDevice, stream));
@@ -376,8 +425,9 @@ int main(int argc, char **argv) {
       ib.pcm16 = d_core, ib.pcm_mode = XAAC_PCM_SBR;
       XA(xaac_imdct_process_batch(ctx, &ib));
       int resets = 0, with_ps = 0;
-      for (int i = 0; i < N; i++) resets += s.flags[(size_t)i * 8 + 1] != 0, with_ps += s.flags[(size_t)i * 8 + 5] != 0;
-      if ((resets != 0 && resets != N) || (with_ps != 0 && with_ps != N)) die("a batch mixing kinds of frames");
+      for (int i = 0; i < N; i++)
+        if (s.status[(size_t)i] == 0) resets += s.flags[(size_t)i * 8 + 1] != 0, with_ps += s.flags[(size_t)i * 8 + 5] != 0;
+      if ((resets != 0 && resets != s.delivered) || (with_ps != 0 && with_ps != s.delivered)) die("a batch mixing kinds of frames");
       const size_t row = 64 * sizeof(float), st_pitch = sizeof(xaac_esbr_state), q_pitch = 2048 * sizeof(float);
       float *older_re = d_older, *older_im = d_older + (size_t)NC * 24 * 64;
       if (resets) {
@@ -457,7 +507,7 @@ int main(int argc, char **argv) {
       XA(xaac_imdct_process_batch(ctx, &ib));
       for (int i = 0; i < N; i++) { /* rare: frames that reset the SBR decoder or fall back to plain up-sampling */
         const int32_t *f = &s.flags[(size_t)i * 8];
-        if (!f[1] && !f[3]) continue;
+        if (s.status[(size_t)i] != 0 || (!f[1] && !f[3])) continue; /* (a stream that is over keeps its last frame's flags) */
         xaac_sbr_side side;
         memset(&side, 0, sizeof(side));
         side.reset = f[1], side.reset_channels = f[2], side.upsampling = f[3], side.header = s.header[(size_t)i * n_ch];
@@ -487,10 +537,10 @@ int main(int argc, char **argv) {
         int with_ps = 0, starts = 0;
         std::vector<int32_t> idx;
         for (int i = 0; i < N; i++) {
-          with_ps += s.flags[(size_t)i * 8 + 5] != 0;
-          if (s.flags[(size_t)i * 8 + 6]) idx.push_back(i), starts++;
+          with_ps += s.status[(size_t)i] == 0 && s.flags[(size_t)i * 8 + 5] != 0;
+          if (s.status[(size_t)i] == 0 && s.flags[(size_t)i * 8 + 6]) idx.push_back(i), starts++;
         }
-        if (with_ps != 0 && with_ps != N) die("a batch mixing PS and non-PS frames");
+        if (with_ps != 0 && with_ps != s.delivered) die("a batch mixing PS and non-PS frames");
         xaac_sbr_hq_batch b;
         memset(&b, 0, sizeof(b));
         b.n_ch = N, b.in_ch_fac = 1, b.out_ch_fac = 1, b.pcm_in = d_core, b.header = d_header, b.frame = d_frame;
@@ -521,7 +571,7 @@ int main(int argc, char **argv) {
     if (sbr) HIP(hipMemcpyAsync(h_status2[slot], d_status, (size_t)NC * 4, hipMemcpyDeviceToHost, down));
     HIP(hipEventRecord(ev_down[slot], down));
     consume(); /* the step before this one: its PCM has been on its way while this step's work was queued */
-    pending = {true, mono_twice, first, slot};
+    pending = {true, mono_twice, first, slot, which};
     if (profile) consume(); /* phase timing wants one step at a time */
     first = false;
   }
@@ -537,17 +587,30 @@ int main(int argc, char **argv) {
   const double steady = std::chrono::duration<double>(t_end - t_first).count();
   if (!sbr) { /* the limiter's delay line holds the last attack_time_samples samples: api.c:2824-2866 */
     static xaac_limiter_state l;
-    HIP(hipMemcpy(&l, d_lim, sizeof(l), hipMemcpyDeviceToHost));
-    const uint32_t att = l.attack_time_samples, at = l.delayed_input_index;
-    for (uint32_t k = 0; k < att; k++)
-      for (int c = 0; c < n_ch; c++) {
-        const float v = l.delayed_input[(size_t)((at + k) % att) * n_ch + c];
-        const int64_t w = (v >= 2147483648.0f || v < -2147483648.0f || v != v) ? INT32_MIN : (int64_t)v; /* (WORD32)v as x86 has it */
-        int64_t r = w + 0x8000;
-        if (r > INT32_MAX) r = INT32_MAX;
-        pcm.push_back((int16_t)(r >> 16));
-      }
+    for (size_t i = 0; i < pcms.size(); i++) {
+      if (list_mode && ended[i]) l = lim_at_end[i];
+      else HIP(hipMemcpy(&l, d_lim + i, sizeof(l), hipMemcpyDeviceToHost));
+      const uint32_t att = l.attack_time_samples, at = l.delayed_input_index;
+      for (uint32_t k = 0; k < att; k++)
+        for (int c = 0; c < n_ch; c++) {
+          const float v = l.delayed_input[(size_t)((at + k) % att) * n_ch + c];
+          const int64_t w = (v >= 2147483648.0f || v < -2147483648.0f || v != v) ? INT32_MIN : (int64_t)v; /* (WORD32)v as x86 has it */
+          int64_t r = w + 0x8000;
+          if (r > INT32_MAX) r = INT32_MAX;
+          pcms[i].push_back((int16_t)(r >> 16));
+        }
+    }
   }
+  if (list_mode) {
+    for (size_t i = 0; i < pcms.size(); i++) {
+      std::string base = inputs[i];
+      const size_t slash = base.find_last_of('/');
+      if (slash != std::string::npos) base = base.substr(slash + 1);
+      const size_t dot = base.find_last_of('.');
+      if (dot != std::string::npos) base = base.substr(0, dot);
+      write_wav(odir + "/" + base + ".wav", pcms[i], out_ch, out_rate);
+    }
+  } else
   write_wav(out, pcm, out_ch, out_rate);
   if (!quiet)
     printf("{\"frames\": %ld, \"streams\": %d, \"wall_s\": %.4f, \"parse_s\": %.4f, \"frames_per_s\": %.1f, "

@@ -56,3 +56,25 @@ def test_a_batch_of_copies(name, flags, tmp_path):
     one, _, _, _ = run(name, tmp_path, *flags)
     many, _, info, _ = run(name, tmp_path, "-copies:64", "-verify", *flags)
     assert many == one and info["streams"] == 64 and info["mismatched_copies"] == 0
+
+
+@pytest.mark.parametrize("flags", [(), ("-esbr:0",)], ids=["default", "esbr0"])
+@pytest.mark.parametrize("names", [("synth_lc_a", "mix_aot2_64k", "synth_lc_b"), ("mix_aot5_48k", "harm_aot5_48k"),
+                                   ("mix_aot29_32k",)], ids=["lc", "he", "hev2"])
+def test_a_list_of_different_streams_in_one_batch(names, flags, tmp_path):
+    """-ilist: streams of one kind but different content and length decoded in lock step, each to its own WAV; a stream that
+    ends drops out (the AAC-LC limiter's delay line is taken where the stream ends)"""
+    lst = tmp_path / "list.txt"
+    lst.write_text("\n".join(os.path.join(STREAMS, n + ".aac") for n in names) + "\n")
+    out = tmp_path / "out"
+    out.mkdir()
+    p = subprocess.run([CLI, "-ilist:" + str(lst), "-odir:" + str(out), *flags], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-500:]
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "decoder_ref.npz"))
+    for n in names:
+        k = GOLD_ORDER.index(n)
+        with wave.open(str(out / (n + ".wav"))) as w:
+            pcm = w.readframes(w.getnframes())
+            samples, crc = ("samples", "crc") if flags else ("samples_esbr", "crc_esbr")
+            assert (w.getnframes(), w.getframerate()) == (int(gold[samples][k]), int(gold["rate"][k])), n
+            assert zlib.crc32(pcm) & 0xffffffff == int(gold[crc][k]), n
