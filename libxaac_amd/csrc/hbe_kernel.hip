@@ -298,32 +298,31 @@ __global__ __launch_bounds__(XAAC_HBE_POST_THREADS) void xaac_hbe_post_kernel(Xa
     }
     __syncthreads();
     XH_T(1);
-    for (int half = 0; half < 2; half++) {
+    /* (3) rows r and r + 32 of the thread's band: the old upper row (fetched above) moves down and takes the blocks that
+       reach it, the new upper row starts from zero; the lower row is rotated into the output */
 #pragma unroll
-      for (int q = 0; q < (32 * 16) / XAAC_HBE_POST_THREADS; q++) {
-        const int e = tid + q * XAAC_HBE_POST_THREADS;
-        const int r = 32 * half + (e >> 4), bt = e & 15, qb = 16 * tile + bt;
-        float2 *dst = reinterpret_cast<float2 *>(&st->qmf_out_buf[r][2 * qb]);
-        float2 v = make_float2(0.0f, 0.0f);
-        if (!half) v = upper[q];
-        const int f = xh_band_factor(xo, ms, qb);
-        if (f) {
-          const auto bk = [&](int i) { return (const float *)blk[17 * bt + i]; };
-          v.x = xh_prod_gather(v.x, f, r, 0, bk);
-          v.y = xh_prod_gather(v.y, f, r, 1, bk);
-        }
-        *dst = v;
-        if (!half && qb >= sb0 && qb < sb1) {
-          pv_re[64 * r + qb] = (float)(v.x * xaac_hbe_pv_cos[qb] - v.y * xaac_hbe_pv_sin[qb]);
-          pv_im[64 * r + qb] = (float)(v.x * xaac_hbe_pv_sin[qb] + v.y * xaac_hbe_pv_cos[qb]);
-        } else if (!half && p.zero_outside) {
-          pv_re[64 * r + qb] = 0.0f;
-          pv_im[64 * r + qb] = 0.0f;
-        }
+    for (int q = 0; q < (32 * 16) / XAAC_HBE_POST_THREADS; q++) {
+      const int e = tid + q * XAAC_HBE_POST_THREADS;
+      const int r = e >> 4, bt = e & 15, qb = 16 * tile + bt;
+      float2 lo = upper[q], hi = make_float2(0.0f, 0.0f);
+      const int f = xh_band_factor(xo, ms, qb);
+      if (f) {
+        const auto bk = [&](int i) { return (const float *)blk[17 * bt + i]; };
+        xh_prod_gather2(lo.x, lo.y, f, r, bk);
+        xh_prod_gather2(hi.x, hi.y, f, r + 32, bk);
       }
-      __syncthreads(); /* rows 32..63 are overwritten only after every row below has taken its start value from them */
-      XH_T(2 + half);
+      *reinterpret_cast<float2 *>(&st->qmf_out_buf[r][2 * qb]) = lo;
+      *reinterpret_cast<float2 *>(&st->qmf_out_buf[r + 32][2 * qb]) = hi;
+      if (qb >= sb0 && qb < sb1) {
+        pv_re[64 * r + qb] = (float)(lo.x * xaac_hbe_pv_cos[qb] - lo.y * xaac_hbe_pv_sin[qb]);
+        pv_im[64 * r + qb] = (float)(lo.x * xaac_hbe_pv_sin[qb] + lo.y * xaac_hbe_pv_cos[qb]);
+      } else if (p.zero_outside) {
+        pv_re[64 * r + qb] = 0.0f;
+        pv_im[64 * r + qb] = 0.0f;
+      }
     }
+    __syncthreads(); /* the next tile rewrites the planes and the blocks */
+    XH_T(2);
   }
   if (tid == 0 && !st->fft_ready && st->synth_size != 20) st->fft_ready = 1;
 }

@@ -465,6 +465,28 @@ FX_HD float xh_prod_gather(float start, int factor, int r, int comp, const Blk &
   return acc;
 }
 
+/* both components of an element in one walk over the columns (each component's additions in the order of xh_prod_gather) */
+template <class Blk>
+FX_HD void xh_prod_gather2(float &re, float &im, int factor, int r, const Blk &blk) {
+  const int len = xh_block_len(factor), r0 = xh_block_row0(factor);
+  int i_lo = (r - r0 - len + 2) >> 1, i_hi = (r - r0) >> 1;
+  if (i_lo < 0) i_lo = 0;
+  if (i_hi > XAAC_HBE_NO_BINS / 2 - 1) i_hi = XAAC_HBE_NO_BINS / 2 - 1;
+  for (int i = i_lo; i <= i_hi; i++) {
+    const float *b = blk(i);
+    const int k = r - r0 - 2 * i;
+    if (k >= 0 && k < len) {
+      re += b[2 * k];
+      im += b[2 * k + 1];
+    }
+    const int kc = r - (2 * i + XH_ZERO_BAND - 1); /* the cross terms follow the column's block (:1118-1240) */
+    if ((kc == 0 || kc == 1) && b[24] != 0.0f) {
+      re += b[20 + 2 * kc];
+      im += b[20 + 2 * kc + 1];
+    }
+  }
+}
+
 /* the frame's parameters are usable: bank sizes in the tables, cross-over bands inside the rows, a pitch inside its
    seven bits, the reference's own x_over_qmf[2] > 1 condition (:1573) */
 FX_HD bool xh_apply_params_ok(const xaac_hbe_state *st, int pitch_in_bins) {
