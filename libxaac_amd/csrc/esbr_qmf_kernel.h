@@ -7,7 +7,7 @@
 
 #include "../../include/xaac_amd.h"
 
-#define XAAC_ESBR_ANA_LDS (2 * 1312 * 4 + 64 * 65 * 4)         /* two channels' time-ordered history + the 64 x 65 exchange tile */
+#define XAAC_ESBR_ANA_LDS (64 * 65 * 4)                        /* two channels' time-ordered history (2 x 1312 words), then the 64 x 65 exchange tile in its place */
 #define XAAC_ESBR_SYN_LDS (41 * 129 * 4)                       /* ring samples of one channel x (9 + 32) slots; the half-row tile fits */
 
 typedef struct XaacEsbrAnaParams {

@@ -50,7 +50,8 @@ __global__ __launch_bounds__(64) void xaac_esbr_analysis_kernel(XaacEsbrAnaParam
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
   int32_t *hist = reinterpret_cast<int32_t *>(smem);                 /* [2][kHist] time-ordered, oldest first */
-  int32_t *z = reinterpret_cast<int32_t *>(smem + 2 * kHist * 4);    /* [64][65] */
+  int32_t *z = reinterpret_cast<int32_t *>(smem);                    /* [64][65]: the exchange tile takes the history's place once
+                                                                        the window-add has read it and the rings are written */
   const int pair = blockIdx.x;
   int32_t coef[5]; /* c[2 m + 128 j] of this lane's polyphase branch m = lane */
 #pragma unroll
@@ -71,13 +72,38 @@ __global__ __launch_bounds__(64) void xaac_esbr_analysis_kernel(XaacEsbrAnaParam
   }
   __syncthreads();
   /* window-add (ixheaacd_esbr_qmfanal32_winadd, qmf_dec.c:537): 64-bit sums, >> 31 */
+  int32_t wa[64]; /* this lane's polyphase branch of all 64 slots */
+#pragma unroll
   for (int r = 0; r < 64; r++) {
     const int32_t *h = hist + (r >> 5) * kHist + 288 + 32 * (r & 31) + 31 - lane;
     int64_t acc = 0;
 #pragma unroll
     for (int j = 0; j < 5; j++) acc = xq_add64(acc, (int64_t)h[-64 * j] * coef[j]);
-    z[65 * r + lane] = (int32_t)(acc >> 31);
+    wa[r] = (int32_t)(acc >> 31);
   }
+  for (int c = 0; c < 2; c++) { /* state: the ring as the reference leaves it after 32 slots (the history's last 320 samples) */
+    const int ch = 2 * pair + c;
+    if (ch >= p.n_ch) break;
+    xaac_esbr_ana_state *st = reinterpret_cast<xaac_esbr_ana_state *>(reinterpret_cast<char *>(p.state) + (size_t)ch * p.state_stride);
+    int wr = st->pos;
+    wr = ((wr % 320 + 320) % 320) & ~31;
+    const int wr_new = (wr + 256) % 320;
+    const int w_new = win_after_frame(st->win_off);
+    const int32_t *h = hist + c * kHist;
+    int32_t keep[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) keep[j] = h[kHist - 1 - (lane + 64 * j)];
+    __syncthreads(); /* every lane has read the old ring positions in the copy-in above */
+#pragma unroll
+    for (int j = 0; j < 5; j++) st->ring[ring_pos(wr_new, lane + 64 * j)] = keep[j];
+    if (lane == 0) {
+      st->pos = wr_new;
+      st->win_off = w_new;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 64; r++) z[65 * r + lane] = wa[r];
   __syncthreads();
   { /* per-slot transform, lane = slot */
     int32_t in[64], sb[128], t[128];
@@ -98,22 +124,6 @@ __global__ __launch_bounds__(64) void xaac_esbr_analysis_kernel(XaacEsbrAnaParam
     const float v = (float)z[65 * r + lane] * (1.0f / 256.0f);
     float *row = (lane < 32 ? p.qmf_re : p.qmf_im) + ((size_t)ch * 32 + (r & 31)) * 64;
     row[lane & 31] = v;
-  }
-  for (int c = 0; c < 2; c++) { /* state: the ring as the reference leaves it after 32 slots */
-    const int ch = 2 * pair + c;
-    if (ch >= p.n_ch) break;
-    xaac_esbr_ana_state *st = reinterpret_cast<xaac_esbr_ana_state *>(reinterpret_cast<char *>(p.state) + (size_t)ch * p.state_stride);
-    int wr = st->pos;
-    wr = ((wr % 320 + 320) % 320) & ~31;
-    const int wr_new = (wr + 256) % 320;
-    const int w_new = win_after_frame(st->win_off);
-    const int32_t *h = hist + c * kHist;
-    __syncthreads();
-    for (int a = lane; a < 320; a += 64) st->ring[ring_pos(wr_new, a)] = h[kHist - 1 - a];
-    if (lane == 0) {
-      st->pos = wr_new;
-      st->win_off = w_new;
-    }
   }
 }
 
