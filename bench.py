@@ -407,11 +407,13 @@ def secondary_esbr(torch, libxaac_amd, ctx, dev, steps, warmup):
     ms = e0.elapsed_time(e1) / steps
     ab = n * (4096 + 2 * 8192 + 2 * st.shape[1] + 2 * pst.shape[1] + pf.shape[1] + hd.shape[1] + fr.shape[1] + sd.shape[1])
     # the same with every stream's QMF harmonic transposer tracked, as the reference runs it on each frame of such a stream
-    # (its output is only read by frames with harmonic SBR): three more launches per step
+    # (its output is only read by frames with harmonic SBR): two more launches per step
     from hbe_structs import state_from_tables
     hbs = [state_from_tables(h.freq_band_tbl_lo[:h.num_sf_bands[0] + 1], h.freq_band_tbl_hi[:h.num_sf_bands[1] + 1]) for h in hs]
     hb = tile(hbs)
-    run_h = lambda: ctx.esbr_sbr_process_batch(core, hd, fr, sd, st, out_l, ws, status, pf, pst, out_r, hbe_state=hb)
+    smax = max(int(x.synth_size) for x in hbs)   # the host knows its streams' bank sizes (xaac_hbe_state_reinit): the hint of the ABI
+    run_h = lambda: ctx.esbr_sbr_process_batch(core, hd, fr, sd, st, out_l, ws, status, pf, pst, out_r, hbe_state=hb,
+                                               hbe_max_synth_size=8 if smax <= 8 else 0)
     for _ in range(max(warmup, 2)):
         run_h()
     ctx.sync()

@@ -92,6 +92,10 @@ typedef struct xaac_esbr_sbr_batch {
   xaac_hbe_state *hbe_state;        /* [n_ch] in/out, or NULL: the QMF harmonic transposer (xaac_hbe.h) of every channel,
                                        run on each processed frame as the reference does for non-USAC streams
                                        (sbr_dec.c:882-909).  Without it a frame with harmonic_sbr set is refused. */
+  int32_t hbe_max_synth_size;       /* optional hint: 4 or 8 = no transposer of the batch has a larger bank (xaac_hbe_state::
+                                       synth_size, known to the host from xaac_hbe_state_reinit): the banks kernel then takes less
+                                       LDS per channel and more channels run per CU; a channel with a larger bank is refused
+                                       (status -1).  0: any size. */
 } xaac_esbr_sbr_batch;
 
 /* The hand-offs on either side of the branch in ixheaacd_dec_execute: the core decoder's PCM16 (after the 32 -> 16 bit

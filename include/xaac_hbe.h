@@ -56,6 +56,7 @@ typedef struct xaac_hbe_apply_batch_desc {
   float *pv_re, *pv_im;         /* [n_ch][32][64]: ph_vocod_qmf_real / _imag rows; bands start_band..end_band-1 written */
   int32_t *status;              /* [n_ch] or NULL: 0, or -1 (parameters outside the tables or rows): such a channel's state
                                    and output are left alone */
+  int32_t max_synth_size;       /* optional hint as xaac_esbr_sbr_batch::hbe_max_synth_size: 4, 8, or 0 = any */
 } xaac_hbe_apply_batch_desc;
 
 /* The DFT transposer's (esbr_hq) analysis bank, ixheaacd_dft_hbe_cplx_anal_filt: per channel its delay line and the two

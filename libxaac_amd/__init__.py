@@ -71,7 +71,7 @@ class _EsbrSbrBatch(ctypes.Structure):
                 ("frame", ctypes.c_void_p), ("side", ctypes.c_void_p), ("state", ctypes.c_void_p),
                 ("out", ctypes.c_void_p), ("ps_frame", ctypes.c_void_p), ("ps_state", ctypes.c_void_p),
                 ("out_r", ctypes.c_void_p), ("status", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
-                ("workspace_bytes", ctypes.c_uint64), ("hbe_state", ctypes.c_void_p)]
+                ("workspace_bytes", ctypes.c_uint64), ("hbe_state", ctypes.c_void_p), ("hbe_max_synth_size", ctypes.c_int32)]
 
 
 class _EsbrCoreInBatch(ctypes.Structure):
@@ -143,7 +143,7 @@ class _HbeApplyBatch(ctypes.Structure):
     # struct xaac_hbe_apply_batch_desc
     _fields_ = [("n_ch", ctypes.c_int32), ("qmf_re", ctypes.c_void_p), ("qmf_im", ctypes.c_void_p),
                 ("pitch_in_bins", ctypes.c_void_p), ("state", ctypes.c_void_p), ("pv_re", ctypes.c_void_p),
-                ("pv_im", ctypes.c_void_p), ("status", ctypes.c_void_p)]
+                ("pv_im", ctypes.c_void_p), ("status", ctypes.c_void_p), ("max_synth_size", ctypes.c_int32)]
 
 
 class _HbeDftAnalBatch(ctypes.Structure):
@@ -485,7 +485,7 @@ class XaacContext:
         return int(self._lib.xaac_esbr_workspace_bytes(int(n_ch)))
 
     def esbr_sbr_process_batch(self, core, header, frame, side, state, out, workspace, status=None, ps_frame=None,
-                               ps_state=None, out_r=None, hbe_state=None):
+                               ps_state=None, out_r=None, hbe_state=None, hbe_max_synth_size=0):
         """One frame of every channel through the Path A (eSBR, -esbr:1) branch of ixheaacd_sbr_dec, mono / stereo
         channels without PS: core float32[n_ch, 1024]; header / frame / side / state uint8 views of the xaac_sbr_header,
         xaac_sbr_frame, xaac_esbr_side, xaac_esbr_state arrays; out float32[n_ch, 2048].  With ps_frame / ps_state (uint8
@@ -508,6 +508,7 @@ class XaacContext:
         b.workspace = _ptr(workspace, "uint8", device_ok=True)
         b.workspace_bytes = workspace.numel()
         b.hbe_state = _ptr(hbe_state, "uint8", n_ch * HBE_STATE_BYTES, allow_none=True, device_ok=True)
+        b.hbe_max_synth_size = int(hbe_max_synth_size)   # 4 / 8: no larger transposer bank in the batch (less LDS per channel); 0: any
         rc = self._lib.xaac_esbr_sbr_process_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_esbr_sbr_process_batch")
@@ -588,7 +589,7 @@ class XaacContext:
         if rc != 0:
             raise XaacError(rc, "xaac_hbe_real_synth_batch")
 
-    def hbe_apply_batch(self, qmf_re, qmf_im, state, pv_re, pv_im, status=None, pitch_in_bins=None):
+    def hbe_apply_batch(self, qmf_re, qmf_im, state, pv_re, pv_im, status=None, pitch_in_bins=None, max_synth_size=0):
         """Batched ixheaacd_qmf_hbe_apply (the QMF-domain harmonic transposer, frames without a pitch): qmf_re / qmf_im
         float32[n_ch, 32, 64]; state uint8[n_ch, HBE_STATE_BYTES] in/out; pv_re / pv_im float32[n_ch, 32, 64] (bands
         start_band..end_band-1 written); status int32[n_ch] or None; pitch_in_bins int32[n_ch] or None."""
@@ -602,6 +603,7 @@ class XaacContext:
         b.pv_re = _ptr(pv_re, "float32", n_ch * 2048, device_ok=True)
         b.pv_im = _ptr(pv_im, "float32", n_ch * 2048, device_ok=True)
         b.status = _ptr(status, "int32", n_ch, device_ok=True) if status is not None else None
+        b.max_synth_size = int(max_synth_size)
         rc = self._lib.xaac_hbe_apply_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_hbe_apply_batch")

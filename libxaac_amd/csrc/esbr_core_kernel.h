@@ -26,6 +26,7 @@ typedef struct XaacEsbrCoreParams {
   int32_t *status;
   const xaac_hbe_state *hbe;    /* [n_ch] or NULL: the channels' harmonic transposers, already run on this frame */
   float *ph_re, *ph_im;         /* [n_ch][40][64] scratch: ph_vocod_qmf (rows 8..39 written by the transposer) */
+  int32_t hbe_lds_synth_size;   /* the transposer launches' LDS hint (hbe_kernel.h): a channel whose bank is larger was not run */
 } XaacEsbrCoreParams;
 
 #ifdef __cplusplus

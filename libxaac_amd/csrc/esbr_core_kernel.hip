@@ -31,6 +31,7 @@ __shared__ float xe_lds_random_phase[1024];
 #define XE_RANDOM_PHASE(i) xe_lds_random_phase[i]
 #include "esbr_core.h"
 #include "hbe_trans.h" /* xh_apply_params_ok */
+#include "hbe_kernel.h" /* XAAC_HBE_LDS_OK */
 #include "esbr_core_kernel.h"
 
 namespace {
@@ -109,7 +110,10 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
      if the channel has one with usable parameters; rows 0..7 are the previous frame's last rows */
   float *phr = p.ph_re + (size_t)ch * XAAC_ESBR_PH_ROWS * 64, *phi = p.ph_im + (size_t)ch * XAAC_ESBR_PH_ROWS * 64;
   bool have_ph = false;
-  if constexpr (HARM) have_ph = p.hbe && apply && xh_apply_params_ok(p.hbe + ch, sd->pitch_in_bins);
+  if constexpr (HARM) {
+    have_ph = p.hbe && apply && xh_apply_params_ok(p.hbe + ch, sd->pitch_in_bins);
+    if (have_ph && !XAAC_HBE_LDS_OK(p.hbe[ch].synth_size, p.hbe_lds_synth_size)) have_ph = false, rc = -1; /* the host's hint was wrong */
+  }
   if (HARM && have_ph) {
     float t0[8], t1[8];
 #pragma unroll

@@ -12,10 +12,21 @@
 #define XAAC_HBE_BANKS_THREADS 256
 #define XAAC_HBE_PHASE_SYNTH 1
 #define XAAC_HBE_PHASE_ANAL 2
-#define XAAC_HBE_T_FLOATS 660 /* the time signal of 32 + 1 columns of at most 20 samples */
-/* LDS: T, then the larger of the synthesis phase's (v of 9 + 32 columns, the columns' inputs, transform work space) and the
-   analysis phase's (u and results of 16 columns, transform work space) */
-#define XAAC_HBE_BANKS_LDS ((XAAC_HBE_T_FLOATS + (2 * 16 * 80 + 16 * 192 > 41 * 40 + 32 * 20 + 32 * 96 ? 2 * 16 * 80 + 16 * 192 : 41 * 40 + 32 * 20 + 32 * 96)) * 4)
+/* LDS floats of a channel of bank size s: the time signal of 32 + 1 columns, then the larger of the synthesis phase's (v of 9 + 32
+   columns, the columns' inputs, transform work space: none for the size-20 matrix, 96 per column for the 24-point transforms) and
+   the analysis phase's (u and results of 16 columns, work space: none / 192 per column for the 48-point transforms) */
+#define XAAC_HBE_MAX2(a, b) ((a) > (b) ? (a) : (b))
+#define XAAC_HBE_BANKS_LDS_FLOATS(s)                                                                                    \
+  (33 * (s) + XAAC_HBE_MAX2(41 * 2 * (s) + 32 * (s) + ((s) == 20 ? 0 : ((s) == 12 ? 32 * 96 : 32 * 4 * (s))),          \
+                            2 * 16 * 4 * (s) + ((s) == 20 ? 0 : ((s) == 12 ? 16 * 192 : 16 * 8 * (s)))))
+/* ... of a launch whose largest bank is hint (4 .. 20; anything else: the largest need of all sizes, size 12's) */
+#define XAAC_HBE_BANKS_LDS_FLOATS_FOR(hint)                                                                             \
+  ((hint) == 4 ? XAAC_HBE_BANKS_LDS_FLOATS(4)                                                                           \
+               : ((hint) == 8 ? XAAC_HBE_MAX2(XAAC_HBE_BANKS_LDS_FLOATS(8), XAAC_HBE_BANKS_LDS_FLOATS(4)) : XAAC_HBE_BANKS_LDS_FLOATS(12)))
+#define XAAC_HBE_BANKS_LDS (XAAC_HBE_BANKS_LDS_FLOATS(12) * 4)
+/* a channel of bank size s fits the LDS a launch with this hint takes (the banks kernel, the products kernel and the core
+   kernel of the chain all leave a channel that does not alone: status -1) */
+#define XAAC_HBE_LDS_OK(s, hint) (XAAC_HBE_BANKS_LDS_FLOATS(s) <= XAAC_HBE_BANKS_LDS_FLOATS_FOR(hint))
 
 typedef struct XaacHbeBanksParams {
   int32_t n_ch, num_columns;    /* num_columns: of the synthesis phase (32 in the apply chain) */
@@ -31,6 +42,8 @@ typedef struct XaacHbeBanksParams {
   const xaac_esbr_side *side;
   int32_t in_stride;            /* floats between consecutive channels' qmf rows (2048 unless the chain hands in its own) */
   int32_t phases;               /* XAAC_HBE_PHASE_SYNTH | XAAC_HBE_PHASE_ANAL */
+  int32_t lds_synth_size;       /* 4 or 8: no channel of the batch has a larger bank (less LDS per workgroup, more of them per
+                                   CU; a channel that does is refused); anything else: sized for every bank */
 } XaacHbeBanksParams;
 
 #define XAAC_HBE_POST_THREADS 256
@@ -46,6 +59,7 @@ typedef struct XaacHbePostParams {
   int32_t pv_stride;            /* floats between consecutive channels' output rows (2048 standalone) */
   int32_t zero_outside;         /* 1: bands outside start_band .. end_band - 1 of the 32 rows are written as zeros (the chain's
                                    scratch rows; the reference leaves whatever its buffer held) */
+  int32_t lds_synth_size;       /* as XaacHbeBanksParams: a channel the banks kernel refused for its size is left alone here too */
 } XaacHbePostParams;
 
 #define XAAC_HBE_DFT_LDS (32 * 128 * 4) /* u of 32 columns */

@@ -62,16 +62,16 @@ struct XhWaveTeam { /* the channel's workgroup as the team of hbe_poly.h's coope
 template <int S>
 __device__ __forceinline__ void xaac_hbe_banks_body(const XaacHbeBanksParams &p, xaac_hbe_state *st, int ch, int lane, float *lds) {
   float *T = lds;                 /* [(32 + 1) * s <= 660]: input_buf as the analysis bank reads it */
-  float *R = lds + XAAC_HBE_T_FLOATS;
+  float *R = lds + 33 * S; /* (the layout is the bank size's own: XAAC_HBE_BANKS_LDS_FLOATS(S)) */
   const bool synth = (p.phases & XAAC_HBE_PHASE_SYNTH) != 0, anal = (p.phases & XAAC_HBE_PHASE_ANAL) != 0;
   constexpr int s = S, a = 2 * S;
   const int ks = st->k_start, nc = p.num_columns;
   constexpr int NT = XAAC_HBE_BANKS_THREADS;
   const XhWaveTeam cx = {lane, NT};
   if (synth) {
-    float(*vv)[40] = reinterpret_cast<float(*)[40]>(R); /* [9 + 32][2 s <= 40] */
-    float *xin = R + 41 * 40;                            /* [32][20] */
-    float *work = xin + 32 * 20;                         /* [32][96] */
+    float(*vv)[2 * S] = reinterpret_cast<float(*)[2 * S]>(R); /* [9 + 32][2 s] */
+    float *xin = R + 41 * 2 * S;                               /* [32][s] */
+    float *work = xin + 32 * S;                                /* [32][4 s], [32][96] for the 24-point transforms */
     /* apply mode, hbe_trans.c:235-248: the last synth_size samples of the previous frame's time signal move to the
        front; while the reference's FFT pointers are unset it re-initialises, which clears both delay lines */
     const bool cleared = p.apply && !st->fft_ready;
@@ -88,10 +88,10 @@ __device__ __forceinline__ void xaac_hbe_banks_body(const XaacHbeBanksParams &p,
     const float *qre = p.qmf_re + (size_t)ch * p.in_stride, *qim = p.qmf_im + (size_t)ch * p.in_stride;
     for (int e = lane; e < nc * s; e += NT) {
       const int c = e / s, k = e % s;
-      xin[20 * c + k] = xh_synth_xin(qre + 64 * c, qim + 64 * c, ks, k);
+      xin[S * c + k] = xh_synth_xin(qre + 64 * c, qim + 64 * c, ks, k);
     }
     __syncthreads();
-    xh_synth_team(cx, [&](int c, int k) { return xin[20 * c + k]; }, [&](int c) { return vv[c + 9]; }, nc, s, work);
+    xh_synth_team(cx, [&](int c, int k) { return xin[S * c + k]; }, [&](int c) { return vv[c + 9]; }, nc, s, work);
     const auto at = [&](int c, int t) { return vv[c + 9][t]; };
     for (int o = lane; o < nc * s; o += NT) {
       const float y = xh_synth_out(at, s, o / s, o % s);
@@ -110,9 +110,9 @@ __device__ __forceinline__ void xaac_hbe_banks_body(const XaacHbeBanksParams &p,
   }
   if (!anal) return;
   constexpr int NCOL = XAAC_HBE_NO_BINS / 2;
-  float(*u)[80] = reinterpret_cast<float(*)[80]>(R);              /* [16][2 a <= 80] */
-  float(*res)[80] = reinterpret_cast<float(*)[80]>(R + 16 * 80);  /* [16][2 a <= 80] */
-  float *work = R + 2 * 16 * 80;                                  /* [16][192] */
+  float(*u)[2 * a] = reinterpret_cast<float(*)[2 * a]>(R);                  /* [16][2 a] */
+  float(*res)[2 * a] = reinterpret_cast<float(*)[2 * a]>(R + 16 * 2 * a);    /* [16][2 a] */
+  float *work = R + 2 * 16 * 2 * a;                                          /* [16][4 a], [16][192] for the 48-point transforms */
   if (!synth) {
     for (int e = lane; e <= NCOL * a; e += NT) T[e] = st->input_buf[e];
     __syncthreads();
@@ -129,7 +129,7 @@ __device__ __forceinline__ void xaac_hbe_banks_body(const XaacHbeBanksParams &p,
     nb[q] = n < 10 * a ? xh_anal_x(T, st->analy_buf, a, NCOL - 1, n) : 0.0f;
   }
   __syncthreads();
-  xh_anal_team(cx, &u[0][0], 80, [&](int c) { return res[c]; }, NCOL, a, work);
+  xh_anal_team(cx, &u[0][0], 2 * a, [&](int c) { return res[c]; }, NCOL, a, work);
   for (int e = lane; e < NCOL * 128; e += NT) {
     const int idx = e >> 7, w = (e & 127) - 4 * ks;
     st->qmf_in_buf[idx + XAAC_HBE_OPER_WIN_LEN - 1][e & 127] = (w >= 0 && w < 2 * a) ? res[idx][w] : 0.0f;
@@ -153,6 +153,8 @@ __global__ __launch_bounds__(XAAC_HBE_BANKS_THREADS) void xaac_hbe_banks_kernel(
   else
     bad = !xh_size_ok(s) || ks < 0 || (synth && (ks + s > 64 || ks * 32 + 2 * s > 7 * 64 || nc < 0 || nc > 32)) ||
           (anal && 4 * ks + 2 * a > 128);
+  /* the launch's LDS was sized for p.lds_synth_size (the largest bank the host expects; 0: any): a larger bank is refused */
+  bad = bad || !XAAC_HBE_LDS_OK(s, p.lds_synth_size);
   if (lane == 0 && p.status && (synth || !p.apply)) p.status[ch] = bad ? -1 : 0;
   if (bad) return;
   switch (s) {
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(XAAC_HBE_POST_THREADS) void xaac_hbe_post_kernel(Xa
   xaac_hbe_state *st = p.state + ch;
   if (hbe_skip(p.frame, ch)) return;
   const int pitch = hbe_pitch(p.pitch, p.side, ch);
-  if (!xh_apply_params_ok(st, pitch)) return;
+  if (!xh_apply_params_ok(st, pitch) || !XAAC_HBE_LDS_OK(st->synth_size, p.lds_synth_size)) return;
   const int ms = st->max_stretch, sb0 = st->start_band, sb1 = st->end_band;
   int32_t xo[4];
   for (int q = 0; q < 4; q++) xo[q] = st->x_over_qmf[q];
@@ -376,7 +378,8 @@ extern "C" hipError_t xaac_launch_hbe_dft_anal(const XaacHbeDftParams *p, hipStr
 }
 
 extern "C" hipError_t xaac_launch_hbe_banks(const XaacHbeBanksParams *p, hipStream_t stream) {
-  hipLaunchKernelGGL(xaac_hbe_banks_kernel, dim3(p->n_ch), dim3(XAAC_HBE_BANKS_THREADS), XAAC_HBE_BANKS_LDS, stream, *p);
+  hipLaunchKernelGGL(xaac_hbe_banks_kernel, dim3(p->n_ch), dim3(XAAC_HBE_BANKS_THREADS),
+                     (size_t)XAAC_HBE_BANKS_LDS_FLOATS_FOR(p->lds_synth_size) * 4, stream, *p);
   return hipGetLastError();
 }
 

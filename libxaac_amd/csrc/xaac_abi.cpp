@@ -333,14 +333,14 @@ int32_t xaac_esbr_sbr_process_batch(xaac_ctx *c, const xaac_esbr_sbr_batch *b) {
     /* sbr_dec.c:882-909: the frame's new analysis rows through the channel's harmonic transposer (two launches),
        its 32 output rows into rows 8..39 of the ph scratch matrix; channels without SBR processing are skipped */
     XaacHbeBanksParams hs = {b->n_ch, XAAC_HBE_NO_BINS, ana_re, ana_im, b->hbe_state, nullptr, nullptr, 1, b->frame, b->side, 2048,
-                             XAAC_HBE_PHASE_SYNTH | XAAC_HBE_PHASE_ANAL};
+                             XAAC_HBE_PHASE_SYNTH | XAAC_HBE_PHASE_ANAL, b->hbe_max_synth_size};
     if (!hip_ok(xaac_launch_hbe_banks(&hs, c->stream))) return XAAC_FATAL_HIP;
     XaacHbePostParams hp = {b->n_ch, b->hbe_state, nullptr, ph_re + 8 * 64, ph_im + 8 * 64, b->frame, b->side,
-                            XAAC_ESBR_PH_ROWS * 64, 1};
+                            XAAC_ESBR_PH_ROWS * 64, 1, b->hbe_max_synth_size};
     if (!hip_ok(xaac_launch_hbe_post(&hp, c->stream))) return XAAC_FATAL_HIP;
   }
   XaacEsbrCoreParams pc = {b->n_ch, b->header, b->frame, b->side, b->state, ana_re, ana_im, out_re, out_im, syn_re, syn_im,
-                           with_ps ? 1 : 0, b->status, b->hbe_state, ph_re, ph_im};
+                           with_ps ? 1 : 0, b->status, b->hbe_state, ph_re, ph_im, b->hbe_max_synth_size};
   if (!hip_ok(xaac_launch_esbr_core(&pc, c->stream))) return XAAC_FATAL_HIP;
   if (with_ps) {
     XaacEsbrPsParams pp = {b->n_ch, b->header, b->frame, b->ps_frame, b->ps_state, syn_re, syn_im, r_re, r_im, b->status};
@@ -474,9 +474,9 @@ int32_t xaac_hbe_apply_batch(xaac_ctx *c, const xaac_hbe_apply_batch_desc *b) {
   /* two launches on the context's stream: the two polyphase banks (with the frame's shift / re-initialisation and the
      parameter check that sets status), then products + output rows */
   XaacHbeBanksParams ps = {b->n_ch, XAAC_HBE_NO_BINS, b->qmf_re, b->qmf_im, b->state, b->status, b->pitch_in_bins, 1, nullptr, nullptr, 2048,
-                           XAAC_HBE_PHASE_SYNTH | XAAC_HBE_PHASE_ANAL};
+                           XAAC_HBE_PHASE_SYNTH | XAAC_HBE_PHASE_ANAL, b->max_synth_size};
   if (!hip_ok(xaac_launch_hbe_banks(&ps, c->stream))) return XAAC_FATAL_HIP;
-  XaacHbePostParams pp = {b->n_ch, b->state, b->pitch_in_bins, b->pv_re, b->pv_im, nullptr, nullptr, 2048, 0};
+  XaacHbePostParams pp = {b->n_ch, b->state, b->pitch_in_bins, b->pv_re, b->pv_im, nullptr, nullptr, 2048, 0, b->max_synth_size};
   if (!hip_ok(xaac_launch_hbe_post(&pp, c->stream))) return XAAC_FATAL_HIP;
   c->last_grid = b->n_ch; c->last_block = XAAC_HBE_POST_THREADS; c->last_lds = XAAC_HBE_POST_LDS;
   return XAAC_OK;

@@ -369,6 +369,9 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
             out_r = dz(n, 2048, dtype=torch.float32)
         older = dz(nc, 2, 24 * 64, dtype=torch.float32)   # rows 8..31 of the QMF history as the frame before found them
         hbe_tail = np.zeros((nc, 48), np.uint8)            # the transposers' integers (struct xaac_hbe_state from synth_size on)
+
+        def hbe_hint():   # the largest transposer bank of the batch, as the ABI's LDS hint takes it (8, or 0 = any)
+            return 8 if int(hbe_tail.view(np.int32)[:, 0].max()) <= 8 else 0
     else:
         state = torch.from_numpy(np.tile(_struct_bytes(lib.xaac_sbr_state_init, SBR_STATE_BYTES), (nc, 1)).copy()).to(dev)
         core16 = dz(nc * 1024, dtype=torch.int16)
@@ -488,12 +491,12 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
                 q_im[:, :24] = old[:, 1].view(k, 24, 64)
                 q_re[:, 24:] = hist[:, _ES_QMF_RE:_ES_QMF_RE + 8 * 64].view(k, 8, 64)
                 q_im[:, 24:] = hist[:, _ES_QMF_IM:_ES_QMF_IM + 8 * 64].view(k, 8, 64)
-                ctx.hbe_apply_batch(q_re, q_im, hb, pv_re, pv_im, status=rst, pitch_in_bins=pitch)
+                ctx.hbe_apply_batch(q_re, q_im, hb, pv_re, pv_im, status=rst, pitch_in_bins=pitch, max_synth_size=hbe_hint())
                 q_re[:] = hist[:, _ES_QMF_RE + 8 * 64:_ES_QMF_RE + 40 * 64].view(k, 32, 64)
                 q_im[:] = hist[:, _ES_QMF_IM + 8 * 64:_ES_QMF_IM + 40 * 64].view(k, 32, 64)
                 pv_re[:, 24:] = hist[:, _ES_PH_RE:_ES_PH_RE + 512].view(k, 8, 64)
                 pv_im[:, 24:] = hist[:, _ES_PH_IM:_ES_PH_IM + 512].view(k, 8, 64)
-                ctx.hbe_apply_batch(q_re, q_im, hb, pv_re, pv_im, status=rst, pitch_in_bins=pitch)
+                ctx.hbe_apply_batch(q_re, q_im, hb, pv_re, pv_im, status=rst, pitch_in_bins=pitch, max_synth_size=hbe_hint())
                 hist[:, _ES_PH_RE:_ES_PH_RE + 512] = pv_re[:, 24:].reshape(k, 512)
                 hist[:, _ES_PH_IM:_ES_PH_IM + 512] = pv_im[:, 24:].reshape(k, 512)
                 st32.index_copy_(0, rows, hist)
@@ -511,13 +514,13 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
             if with_ps.all():
                 psf_d.copy_(psf_h, non_blocking=True)
                 ctx.esbr_sbr_process_batch(core, hdr_d, frm_d, eside_d, state, out_l, ws, status=status, ps_frame=psf_d,
-                                           ps_state=ps_state, out_r=out_r, hbe_state=hbe)
+                                           ps_state=ps_state, out_r=out_r, hbe_state=hbe, hbe_max_synth_size=hbe_hint())
                 ctx.esbr_pcm16_from_float(out_l, out_r, pcm)
             elif n_ch == 1:
-                ctx.esbr_sbr_process_batch(core, hdr_d, frm_d, eside_d, state, out_l, ws, status=status, hbe_state=hbe)
+                ctx.esbr_sbr_process_batch(core, hdr_d, frm_d, eside_d, state, out_l, ws, status=status, hbe_state=hbe, hbe_max_synth_size=hbe_hint())
                 ctx.esbr_pcm16_from_float(out_l, out_l, pcm)                                # mono twice (api.c:3639-3660)
             else:
-                ctx.esbr_sbr_process_batch(core, hdr_d, frm_d, eside_d, state, out_l, ws, status=status, hbe_state=hbe)
+                ctx.esbr_sbr_process_batch(core, hdr_d, frm_d, eside_d, state, out_l, ws, status=status, hbe_state=hbe, hbe_max_synth_size=hbe_hint())
                 ctx.esbr_pcm16_from_float(out_l, out_l[1:], pcm, stride=4096)
             hand_down(slot, got, (n, 2048, 2), drop_=first)      # the first frame's output is not written in this mode
         else:

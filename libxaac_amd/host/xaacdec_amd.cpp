@@ -221,6 +221,13 @@ int main(int argc, char **argv) {
   xaac_hbe_state *d_hbe = nullptr;
   xaac_esbr_ps_state *d_eps = nullptr;
   float *d_fcore = nullptr, *d_out_l = nullptr, *d_out_r = nullptr, *d_q = nullptr, *d_pv = nullptr;
+  std::vector<uint8_t> hbe_tail; /* every channel's transposer integers, kept between resets: some survive one (max_stretch, fft_ready) */
+  const auto hbe_hint = [&]() { /* the largest bank of the batch, as the ABI's LDS hint takes it: 8, or 0 = any */
+    int32_t smax = 0, v;
+    constexpr size_t kTail = sizeof(xaac_hbe_state) - offsetof(xaac_hbe_state, synth_size);
+    for (size_t i = 0; i * kTail < hbe_tail.size(); i++) memcpy(&v, &hbe_tail[i * kTail], 4), smax = v > smax ? v : smax;
+    return smax <= 8 ? 8 : 0;
+  };
   float *d_older = nullptr; /* [2][NC][24][64]: rows 8..31 of the QMF history as the frame before found them (see the reset) */
   void *d_ws = nullptr;
   uint64_t ws_bytes = 0;
@@ -438,8 +445,8 @@ int main(int argc, char **argv) {
            the transposer's range keep what they held). */
         static xaac_hbe_state h0;
         constexpr size_t kTail = sizeof(xaac_hbe_state) - offsetof(xaac_hbe_state, synth_size); /* the integers behind the buffers */
-        static std::vector<uint8_t> tail; /* every channel's, kept between resets: some survive one (max_stretch, fft_ready) */
-        if (tail.empty()) tail.assign((size_t)NC * kTail, 0);
+        if (hbe_tail.empty()) hbe_tail.assign((size_t)NC * kTail, 0);
+        std::vector<uint8_t> &tail = hbe_tail;
         for (int i = 0; i < NC; i++) {
           xaac_hbe_state_init(&h0);
           memcpy(&h0.synth_size, &tail[(size_t)i * kTail], kTail);
@@ -455,6 +462,7 @@ int main(int argc, char **argv) {
         xaac_hbe_apply_batch_desc hb;
         memset(&hb, 0, sizeof(hb));
         hb.n_ch = NC, hb.qmf_re = q_re, hb.qmf_im = q_im, hb.state = d_hbe, hb.pv_re = pv_re, hb.pv_im = pv_im, hb.status = d_status;
+        hb.max_synth_size = hbe_hint();
         {
           std::vector<int32_t> pitch((size_t)NC);
           for (int i = 0; i < NC; i++) pitch[(size_t)i] = s.reset_pitch[(size_t)(i / n_ch)];
@@ -492,6 +500,7 @@ int main(int argc, char **argv) {
       memset(&b, 0, sizeof(b));
       b.n_ch = NC, b.core = d_fcore, b.header = d_header, b.frame = d_frame, b.side = d_eside, b.state = d_estate, b.out = d_out_l;
       b.status = d_status, b.workspace = d_ws, b.workspace_bytes = ws_bytes, b.hbe_state = d_hbe;
+      b.hbe_max_synth_size = hbe_hint();
       xaac_esbr_pcm_out_batch ob = {N, 2048, d_out_l, d_out_l, d_pcm}; /* a mono channel twice (api.c:3639-3660) */
       if (with_ps) {
         HIP(hipMemcpyAsync(d_psf, s.ps, (size_t)N * sizeof(xaac_ps_frame), hipMemcpyHostToDevice, stream));

@@ -228,3 +228,16 @@ def test_chain_with_harmonic_transposer_vs_oracle(oracle):
             d = np.nonzero(np.frombuffer(bytes(hb_o[ch]), np.uint8) != h_g[ch])[0]
             assert d.size == 0, ("transposer state", fr, ch, d[:4])
     assert harmonic_frames > 40
+    # a wrong bank-size hint (xaac_esbr_sbr_batch::hbe_max_synth_size): channels with a larger bank come back with status -1
+    # and their transposer state as it was; the others run
+    sizes = [s.synth_size for s in hb_o]
+    assert max(sizes) > 8
+    before = hb_g.clone()
+    ctx.esbr_sbr_process_batch(torch.from_numpy(core).to(dev), pack(hs), pack(fs), pack(sds), st_g, out, ws, status,
+                               hbe_state=hb_g, hbe_max_synth_size=8)
+    ctx.sync()
+    rc_g, same = status.cpu().numpy(), (hb_g == before).all(dim=1).cpu().numpy()
+    for ch in range(n):
+        refused = sizes[ch] > 8 and fs[ch].apply_processing != 0
+        assert rc_g[ch] == (-1 if refused else 0), (ch, sizes[ch], rc_g[ch])
+        assert not refused or same[ch]

@@ -284,3 +284,36 @@ def test_gpu_dft_transposer_analysis_bank(oracle):
                 assert d.size == 0, (nm, frame, cfgs[c], d[:4].tolist())
             assert np.array_equal(np.frombuffer(bytes(host[c]), np.uint8), gs[c]), ("delay line", frame, cfgs[c])
         assert np.array_equal(got[0][-1], q[0][-1]) and np.array_equal(got[1][-1], q[1][-1])
+
+
+@pytest.mark.gpu
+def test_gpu_apply_with_the_bank_size_hint(oracle):
+    """xaac_hbe_apply_batch_desc::max_synth_size = 8 (less LDS per channel in the banks kernel): the same words as without the
+    hint for banks of size 4 and 8; a channel with a larger bank is refused with status -1 and left alone"""
+    import torch
+    import libxaac_amd
+    dev = torch.device("cuda:0")
+    ctx = libxaac_amd.XaacContext(0, None)
+    pars = [[8, 2, 9, 31, 9, 15, 27, 31, 0, 0, 4], [4, 0, 3, 20, 3, 6, 9, 12, 0, 0, 4], [8, 4, 11, 33, 11, 22, 33, 0, 0, 0, 3],
+            [12, 6, 15, 41, 15, 29, 41, 0, 0, 0, 3]]
+    host = [state_from_params(p) for p in pars]
+    n = len(host)
+    rng = np.random.default_rng(77)
+    a, b = _states_tensor(torch, dev, host), _states_tensor(torch, dev, host)
+    big = bytes(host[3])
+    for f in range(3):
+        re = torch.from_numpy((rng.standard_normal((n, 32, 64)) * 900).astype(np.float32)).to(dev)
+        im = torch.from_numpy((rng.standard_normal((n, 32, 64)) * 900).astype(np.float32)).to(dev)
+        outs = []
+        for st, hint in ((a, 0), (b, 8)):
+            pvr, pvi = torch.zeros_like(re), torch.zeros_like(re)
+            status = torch.full((n,), 7, dtype=torch.int32, device=dev)
+            ctx.hbe_apply_batch(re, im, st, pvr, pvi, status, max_synth_size=hint)
+            ctx.sync()
+            outs.append((pvr.cpu().numpy(), pvi.cpu().numpy(), status.cpu().numpy()))
+        assert outs[0][2].tolist() == [0, 0, 0, 0] and outs[1][2].tolist() == [0, 0, 0, -1]
+        for k in range(2):
+            assert np.array_equal(outs[0][k][:3].view(np.uint32), outs[1][k][:3].view(np.uint32))
+        sa, sb = a.cpu().numpy(), b.cpu().numpy()
+        assert np.array_equal(sa[:3], sb[:3]) and sb[3].tobytes() == big
+    ctx.close()
