@@ -156,6 +156,16 @@ class _HbeDftAnalBatch(ctypes.Structure):
 HBE_DFT_STATE_BYTES = 4 * 642   # struct xaac_hbe_dft_anal_state
 
 
+class _PvcBatch(ctypes.Structure):
+    # struct xaac_pvc_batch (include/xaac_pvc.h)
+    _fields_ = [("n_ch", ctypes.c_int32), ("frame", ctypes.c_void_p), ("qmf_re", ctypes.c_void_p), ("qmf_im", ctypes.c_void_p),
+                ("qmf_stride", ctypes.c_int32), ("state", ctypes.c_void_p), ("out", ctypes.c_void_p), ("status", ctypes.c_void_p)]
+
+
+PVC_FRAME_BYTES = 40    # struct xaac_pvc_frame
+PVC_STATE_BYTES = 188   # struct xaac_pvc_state
+
+
 class _HbeAnalBatch(ctypes.Structure):
     # struct xaac_hbe_anal_batch
     _fields_ = [("n_ch", ctypes.c_int32), ("state", ctypes.c_void_p), ("status", ctypes.c_void_p)]
@@ -267,6 +277,8 @@ def load_library():
     lib.xaac_hbe_real_synth_batch.restype = ctypes.c_int32
     lib.xaac_hbe_dft_anal_batch_run.argtypes = [ctypes.c_void_p, ctypes.POINTER(_HbeDftAnalBatch)]
     lib.xaac_hbe_dft_anal_batch_run.restype = ctypes.c_int32
+    lib.xaac_pvc_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_PvcBatch)]
+    lib.xaac_pvc_process_batch.restype = ctypes.c_int32
     lib.xaac_hbe_apply_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_HbeApplyBatch)]
     lib.xaac_hbe_apply_batch.restype = ctypes.c_int32
     lib.xaac_hbe_cplx_anal_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_HbeAnalBatch)]
@@ -626,6 +638,23 @@ class XaacContext:
         rc = self._lib.xaac_hbe_dft_anal_batch_run(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_hbe_dft_anal_batch_run")
+
+    def pvc_process_batch(self, frame, qmf_re, qmf_im, state, out, status=None):
+        """Batched PVC envelope decoder (ixheaacd_qmf_enrg_calc + ixheaacd_pvc_process): frame uint8[n_ch, PVC_FRAME_BYTES];
+        qmf_re / qmf_im float32[n_ch, >= 64, 64] (row 2 of the QMF buffers onwards); state uint8[n_ch, PVC_STATE_BYTES]
+        in/out; out float32[n_ch, 16, 64]; status int32[n_ch] or None."""
+        n_ch = state.shape[0]
+        b = _PvcBatch()
+        b.n_ch, b.qmf_stride = n_ch, int(qmf_re.shape[1]) * int(qmf_re.shape[2])
+        b.frame = _ptr(frame, "uint8", n_ch * PVC_FRAME_BYTES, device_ok=True)
+        b.qmf_re = _ptr(qmf_re, "float32", n_ch * b.qmf_stride, device_ok=True)
+        b.qmf_im = _ptr(qmf_im, "float32", n_ch * b.qmf_stride, device_ok=True)
+        b.state = _ptr(state, "uint8", n_ch * PVC_STATE_BYTES, device_ok=True)
+        b.out = _ptr(out, "float32", n_ch * 16 * 64, device_ok=True)
+        b.status = _ptr(status, "int32", n_ch, device_ok=True) if status is not None else None
+        rc = self._lib.xaac_pvc_process_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_pvc_process_batch")
 
     def hbe_cplx_anal_batch(self, state, status=None):
         """Batched ixheaacd_complex_anal_filt (the harmonic transposer's complex analysis bank): state

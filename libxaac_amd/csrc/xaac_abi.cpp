@@ -23,6 +23,7 @@
 #include "imdct_ld_kernel.h"
 #include "esbr_core_kernel.h"
 #include "hbe_kernel.h"
+#include "pvc_kernel.h"
 #include <cmath>
 #include <cstddef>
 #include <cstring>
@@ -462,6 +463,18 @@ int32_t xaac_hbe_dft_anal_batch_run(xaac_ctx *c, const xaac_hbe_dft_anal_batch *
   XaacHbeDftParams p = {b->n_ch, b->no_bins, b->time_in, b->in_stride, b->coef_re, b->coef_im, b->cfg, b->state, b->qmf_re, b->qmf_im, b->status};
   if (!hip_ok(xaac_launch_hbe_dft_anal(&p, c->stream))) return XAAC_FATAL_HIP;
   c->last_grid = b->n_ch; c->last_block = 256; c->last_lds = XAAC_HBE_DFT_LDS;
+  return XAAC_OK;
+}
+
+int32_t xaac_pvc_process_batch(xaac_ctx *c, const xaac_pvc_batch *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n_ch < 0 || b->qmf_stride < 64 * 64) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch == 0) return XAAC_OK;
+  if (!b->frame || !b->qmf_re || !b->qmf_im || !b->state || !b->out) return XAAC_FATAL_NULL_ARG;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  XaacPvcParams p = {b->n_ch, b->frame, b->qmf_re, b->qmf_im, b->qmf_stride, b->state, b->out, b->status};
+  if (!hip_ok(xaac_launch_pvc(&p, c->stream))) return XAAC_FATAL_HIP;
+  c->last_grid = b->n_ch; c->last_block = 64; c->last_lds = (int32_t)(sizeof(float) * (31 * 3 + 16 * 3 + 16 * 8) + sizeof(xaac_pvc_frame));
   return XAAC_OK;
 }
 

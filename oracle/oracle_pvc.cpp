@@ -1,0 +1,13 @@
+/*
+ * oracle_pvc.cpp -- TEST INFRASTRUCTURE: the sequential CPU run of libxaac_amd/csrc/pvc.h (the PVC envelope decoder,
+ * decoder/ixheaacd_pred_vec_block.c:30-240 + ixheaacd_qmf_enrg_calc, ixheaacd_sbr_dec.c:80-129).  Pinned bit for bit against
+ * the compiled reference by tests/test_pvc.py (oracle/ref_pvc_adapter.c).  Only tests/, __graft_entry__.smoke() and
+ * bench.py's checker legs may use it.
+ */
+#include "../libxaac_amd/csrc/pvc.h"
+
+extern "C" int xo_pvc_process(const xaac_pvc_frame *f, const float *qmf_re, const float *qmf_im, xaac_pvc_state *st, float *out) {
+  static thread_local XpWork w;
+  const XpCx cx = {0, 1};
+  return xp_process(cx, &w, f, qmf_re, qmf_im, st, out);
+}

@@ -181,3 +181,22 @@ def test_limiter_structs_match_header(tmp_path):
     assert got == [ctypes.sizeof(S), S.pre_smoothed_gain.offset, S.max_buf.offset, S.delayed_input.offset,
                    ctypes.sizeof(B), B.stride.offset, B.pcm16.offset, B.workspace_bytes.offset]
     assert libxaac_amd.LIMITER_STATE_BYTES == got[0]
+
+
+def test_pvc_struct_layouts_match_header(tmp_path):
+    """the PVC decoder's frame, state and batch descriptor against include/xaac_pvc.h"""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pvc_structs as ps
+    pairs = [("xaac_pvc_frame", ps.PvcFrame, "pvc_id"), ("xaac_pvc_state", ps.PvcState, "prev_pvc_rate"), ("xaac_pvc_batch", libxaac_amd._PvcBatch, "status")]
+    body = "".join('printf("%%zu %%zu\\n", sizeof(%s), offsetof(%s, %s));' % (c, c, last) for c, _, last in pairs)
+    src = tmp_path / "layout_pvc.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "xaac_pvc.h"\nint main(void) { %s return 0; }\n' % body)
+    exe = tmp_path / "layout_pvc"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    want = []
+    for _, cls, last in pairs:
+        want += [ctypes.sizeof(cls), getattr(cls, last).offset]
+    assert got == want
+    assert (ctypes.sizeof(ps.PvcFrame), ctypes.sizeof(ps.PvcState)) == (libxaac_amd.PVC_FRAME_BYTES, libxaac_amd.PVC_STATE_BYTES)

@@ -106,6 +106,10 @@ def test_hbe_tables_equal_reference_rom(tmp_path):
     _regenerated_equals_committed("gen_tables_hbe", "tables_hbe.inc", tmp_path)
 
 
+def test_pvc_tables_equal_reference_rom(tmp_path):
+    _regenerated_equals_committed("gen_tables_pvc", "tables_pvc.inc", tmp_path)
+
+
 def test_esbr_ps_tables_equal_reference_rom_and_libm(tmp_path):
     """ROM members as exact float literals + the mixing-matrix table re-derived with this machine's C library"""
     _regenerated_equals_committed("gen_tables_esbr_ps", "tables_esbr_ps.inc", tmp_path)
