@@ -38,6 +38,7 @@ struct XpCx { /* the team working on one channel: lane of n, sync() between phas
 
 struct XpWork { /* shared between the lanes (LDS on the device) */
   float esg[2 * XAAC_PVC_SLOTS - 1][XAAC_PVC_NB_LOW]; /* ia_pvc_data_struct::esg */
+  float fresh[XAAC_PVC_SLOTS][XAAC_PVC_NB_LOW];       /* the frame's own rows before the restart rule */
   float smooth[XAAC_PVC_SLOTS][XAAC_PVC_NB_LOW];      /* smooth_esg_arr */
   float high[XAAC_PVC_SLOTS][8];                      /* 10 ^ (sbr_range_esg_arr / 10) */
 };
@@ -80,7 +81,6 @@ FX_HD int xp_process(const XpCx cx, XpWork *w, const xaac_pvc_frame *f, const fl
   const int first = f->first_bnd_idx, first_slot = f->first_pvc_timeslot;
   const bool restart = st->prev_pvc_flg == 0 || first * rate != st->prev_first_bnd_idx * st->prev_pvc_rate; /* :94-97 */
   /* ixheaacd_pvc_qmf_grouping (:62): the frame's 16 x 3 grouped energies in dB, behind the 15 rows of history */
-  XP_PAR(i, 0, (XAAC_PVC_SLOTS - 1) * XAAC_PVC_NB_LOW) w->esg[i / 3][i % 3] = st->esg[i / 3][i % 3];
   XP_PAR(i, 0, XAAC_PVC_SLOTS * XAAC_PVC_NB_LOW) {
     const int t = i / 3, ksg = i % 3, start = first - lbw * XAAC_PVC_NB_LOW + lbw * ksg;
     float esg = 0.1f; /* PVC_ESG_MIN_VAL */
@@ -89,13 +89,16 @@ FX_HD int xp_process(const XpCx cx, XpWork *w, const xaac_pvc_frame *f, const fl
       for (int ib = start; ib < start + lbw; ib++) esg += xp_slot_energy(re, im, rate, f->low_power, t, ib);
       esg = esg / (float)lbw;
     }
-    w->esg[t + XAAC_PVC_SLOTS - 1][ksg] = esg > 0.1f ? 10 * ((float)log10((double)esg)) : -10.0f;
+    w->fresh[t][ksg] = esg > 0.1f ? 10 * ((float)log10((double)esg)) : -10.0f;
   }
   cx.sync();
-  if (restart) { /* the history takes the first PVC slot's values (:98-104) */
-    XP_PAR(i, 0, (XAAC_PVC_SLOTS - 1 + first_slot) * XAAC_PVC_NB_LOW) w->esg[i / 3][i % 3] = w->esg[XAAC_PVC_SLOTS - 1 + first_slot][i % 3];
-    cx.sync(); /* (the source row is not among the rows written) */
+  /* rows 0 .. 14: the history -- or, at a restart, like every row in front of the first PVC slot's, that slot's values (:98-104) */
+  const int fill = restart ? XAAC_PVC_SLOTS - 1 + first_slot : 0;
+  XP_PAR(i, 0, (2 * XAAC_PVC_SLOTS - 1) * XAAC_PVC_NB_LOW) {
+    const int r = i / 3, c = i % 3;
+    w->esg[r][c] = r < fill ? w->fresh[first_slot][c] : (r < XAAC_PVC_SLOTS - 1 ? st->esg[r][c] : w->fresh[r - (XAAC_PVC_SLOTS - 1)][c]);
   }
+  cx.sync();
   /* ixheaacd_pvc_time_smoothing (:109): taps from the slot itself back */
   XP_PAR(i, 0, XAAC_PVC_SLOTS * XAAC_PVC_NB_LOW) {
     const int t = i / 3, ksg = i % 3;

@@ -474,7 +474,7 @@ int32_t xaac_pvc_process_batch(xaac_ctx *c, const xaac_pvc_batch *b) {
   if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
   XaacPvcParams p = {b->n_ch, b->frame, b->qmf_re, b->qmf_im, b->qmf_stride, b->state, b->out, b->status};
   if (!hip_ok(xaac_launch_pvc(&p, c->stream))) return XAAC_FATAL_HIP;
-  c->last_grid = b->n_ch; c->last_block = 64; c->last_lds = (int32_t)(sizeof(float) * (31 * 3 + 16 * 3 + 16 * 8) + sizeof(xaac_pvc_frame));
+  c->last_grid = b->n_ch; c->last_block = 64; c->last_lds = (int32_t)(sizeof(float) * (31 * 3 + 16 * 3 + 16 * 3 + 16 * 8) + sizeof(xaac_pvc_frame));
   return XAAC_OK;
 }
 

@@ -96,7 +96,7 @@ def _gpu_walk(chains, n_frames):
         ctx.sync()
         o, s, rc = out.cpu().numpy(), state.cpu().numpy(), status.cpu().numpy()
         for k in range(n):
-            res[k, fr] = (rc[k] & 0xffffffff, ps.crc(o[k]), ps.crc(s[k]))
+            res[k, fr] = (int(rc[k]) & 0xffffffff, ps.crc(o[k]), ps.crc(s[k]))
     ctx.close()
     return res
 
