@@ -251,6 +251,14 @@ def secondary_f4(torch, libxaac_amd, ctx, dev, n=16384, launches=20):
                   lambda sl=sl, ol=ol, shp=shp, spv=spv, pcm=pcm, fl=fl, eld=eld: ctx.imdct_ld_process_batch(sl, shp, ol, spv, pcm, fl, eld),
                   n * (4 * fl + 2 * fl + (4 * nov + 11 * fl if eld else 8 * nov)))
     out["n_channel_frames"] = n
+    # the PVC envelope decoder (tests/test_pvc.py): 2:1 frames at start band 12, the QMF rows of one stream-frame per channel
+    fr = np.zeros((n, libxaac_amd.PVC_FRAME_BYTES), np.uint8)
+    fr[:, 0], fr[:, 2], fr[:, 4] = 1 + (np.arange(n) & 1), 2, 12           # pvc_mode, pvc_rate, first_bnd_idx
+    fr[:, 8:40:2] = rng.integers(0, 128, (n, 16)).astype(np.uint8)        # pvc_id (little-endian uint16)
+    pv_f = torch.from_numpy(fr).to(dev)
+    pv_q = torch.randn((2048, 64, 64), dtype=torch.float32, device=dev).mul_(900.0).repeat(n // 2048, 1, 1)
+    pv_st, pv_out = z8(n, libxaac_amd.PVC_STATE_BYTES), torch.zeros((n, 16, 64), dtype=torch.float32, device=dev)
+    timed("esbr_pvc", lambda: ctx.pvc_process_batch(pv_f, pv_q, pv_q, pv_st, pv_out), n * (32 * 16 * 2 * 4 + 228 + 4096 + 188))
     return out
 
 
