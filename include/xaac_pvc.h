@@ -49,7 +49,8 @@ typedef struct xaac_pvc_batch {
   const xaac_pvc_frame *frame;  /* [n_ch] */
   const float *qmf_re, *qmf_im; /* [n_ch][qmf_stride]: row SBR_HF_ADJ_OFFSET (= 2) of qmf_buf_real / _imag onwards, 64 floats per
                                    row; 32 rows (pvc_rate 2) or 64 rows (pvc_rate 4) are read, sub-bands 0..31 / 0..15 */
-  int32_t qmf_stride;           /* floats per channel, >= 64 * 64 */
+  int32_t qmf_stride;           /* floats from one channel's row 2 to the next channel's, >= 32 * 64 (the rows read must exist:
+                                   32 of them for pvc_rate 2, 64 for pvc_rate 4) */
   xaac_pvc_state *state;        /* [n_ch] in/out */
   float *out;                   /* [n_ch][16][64]: pvc_dec_out_buf (sub-bands below first_bnd_idx: zero) */
   int32_t *status;              /* [n_ch] or NULL: 0, -1 = parameters outside the reference's tables (nothing written) */

@@ -468,7 +468,7 @@ int32_t xaac_hbe_dft_anal_batch_run(xaac_ctx *c, const xaac_hbe_dft_anal_batch *
 
 int32_t xaac_pvc_process_batch(xaac_ctx *c, const xaac_pvc_batch *b) {
   if (!c || !b) return XAAC_FATAL_NULL_ARG;
-  if (b->n_ch < 0 || b->qmf_stride < 64 * 64) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch < 0 || b->qmf_stride < 32 * 64) return XAAC_FATAL_BAD_ARG;
   if (b->n_ch == 0) return XAAC_OK;
   if (!b->frame || !b->qmf_re || !b->qmf_im || !b->state || !b->out) return XAAC_FATAL_NULL_ARG;
   if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
