@@ -442,11 +442,77 @@ def secondary_esbr(torch, libxaac_amd, ctx, dev, steps, warmup):
                         "states carried from step to step" % n}
 
 
+def usable_cores():
+    """Host cores this process may really use: the scheduler affinity mask cut by the cgroup CPU quota (v2 cpu.max or
+    v1 cfs_quota_us / cfs_period_us) when there is one.  Returns (workers, {"affinity":, "cgroup_quota":, "os_cpu_count":})."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = float(f.read()), float(g.read())
+                quota = None if q <= 0 else q / per
+        except (OSError, ValueError):
+            pass
+    workers = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return workers, {"affinity": aff, "cgroup_quota": None if quota is None else round(quota, 2), "os_cpu_count": os.cpu_count()}
+
+
+def timed_team(work, workers, seconds_budget, reset=None, max_passes=400):
+    """Run work(t) on `workers` host threads at once (work = one ctypes call into a C loop: the GIL is released for its
+    whole length) and time only the span between a common start line and the last thread's end: threads are created and
+    every buffer is allocated BEFORE the clock starts; reset() (untimed) puts the inputs back between passes.  Returns
+    (best seconds per pass, passes)."""
+    best, spent, passes = 1e9, 0.0, 0
+    while (spent < seconds_budget and passes < max_passes) or passes < 2:
+        if reset is not None:
+            reset()
+        go = threading.Barrier(workers + 1)
+        ends = [0.0] * workers
+
+        def run(t):
+            go.wait()
+            work(t)
+            ends[t] = time.perf_counter()
+
+        th = [threading.Thread(target=run, args=(t,)) for t in range(workers)]
+        [t.start() for t in th]
+        go.wait()
+        t0 = time.perf_counter()
+        [t.join() for t in th]
+        dt = max(ends) - t0
+        best, spent, passes = min(best, dt), spent + dt, passes + 1
+    return best, passes
+
+
+def baseline_report(value, value_1, workers, info, kind, sample):
+    """`cores` = the worker threads actually run; `scaling` = all-workers rate / one-worker rate, printed so that a reader
+    sees whether the box really gave that many cores (a quota the cgroup files do not show, SMT siblings, memory
+    bandwidth).  When the two disagree by more than 2 x the line says so instead of letting `cores` stand alone."""
+    scaling = value / value_1 if value_1 else None
+    out = {"value": round(value, 1), "unit": "frames/s", "cores": workers, "usable_cores": workers, "kind": kind,
+           "value_1core": round(value_1, 1), "scaling": None if scaling is None else round(scaling, 2), "host": info,
+           "sample": sample}
+    if scaling is not None and scaling < 0.5 * workers:
+        out["cores_note"] = ("%d worker threads ran (affinity mask / cgroup quota) but together they reached only %.1f x one "
+                             "worker: the lease gives fewer physical cores than it lists (SMT siblings, a hidden quota) or the "
+                             "pass is memory-bound; read `value` against `scaling`, not against `cores`" % (workers, scaling))
+    return out
+
+
 def cpu_baseline_sbr(workload, seconds_budget=10.0):
     """CPU baseline of the SBR workloads: the compiled reference's own ixheaacd_sbr_dec driven through
     oracle/ref_sbr_adapter.c (kind "reference") or, where oracle/_ref did not travel, the bit-exact restatement
-    (kind "port"), on the committed reference-captured frames: every host thread runs a C loop over its own shard
-    of channel-frames (arrays of the boundary structs, state reset per pass)."""
+    (kind "port"), on the committed reference-captured frames: every worker thread runs ONE C loop over its own shard
+    of 1024-4096 channel-frames (arrays of the boundary structs); state and output buffers are allocated, and the state reset,
+    outside the timed span."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     import sbr_capture as cap
@@ -460,50 +526,45 @@ def cpu_baseline_sbr(workload, seconds_budget=10.0):
     else:
         kind, fn = "port", getattr(oracle_lib.load_oracle().lib, "xo_" + name)
     fn.restype = ctypes.c_int
-    cores = os.cpu_count() or 1
-    per_thread = 512                   # channel-frames per thread per pass (thread start-up amortised)
+    workers, info = usable_cores()
+    per_thread = max(1024, min(4096, 262144 // workers))   # channel-frames per worker per pass (23 KB of state + PCM each)
     pick = [recs[i % len(recs)] for i in range(per_thread)]
     blob = lambda key: b"".join(bytes(r[key]) for r in pick)
     hdr, frm, st0 = blob("header"), blob("frame"), blob("st0")
     pin = np.concatenate([r["pcm_in"] for r in pick]).astype(np.int16)
     psf, ps0 = (blob("ps_frame"), blob("ps0")) if hq else (None, None)
-
-    def shard(_):
-        st = ctypes.create_string_buffer(st0, len(st0))
-        out = np.zeros(per_thread * (4096 if hq else 2048), np.int16)
-        if hq:
-            ps = ctypes.create_string_buffer(ps0, len(ps0))
-            fn(per_thread, hdr, frm, st, psf, ps, pin.ctypes.data, out.ctypes.data)
-        else:
-            fn(per_thread, hdr, frm, st, pin.ctypes.data, out.ctypes.data)
-
     fn.argtypes = ([ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p,
                     ctypes.c_void_p, ctypes.c_void_p] if hq else
                    [ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p])
+    st = [ctypes.create_string_buffer(st0, len(st0)) for _ in range(workers)]
+    ps = [ctypes.create_string_buffer(ps0, len(ps0)) for _ in range(workers)] if hq else None
+    out = [np.zeros(per_thread * (4096 if hq else 2048), np.int16) for _ in range(workers)]
 
-    def one_pass(nthreads):
-        t0 = time.perf_counter()
-        th = [threading.Thread(target=shard, args=(t,)) for t in range(nthreads)]
-        [t.start() for t in th]
-        [t.join() for t in th]
-        return time.perf_counter() - t0
+    def reset():
+        for t in range(workers):
+            ctypes.memmove(st[t], st0, len(st0))
+            if hq:
+                ctypes.memmove(ps[t], ps0, len(ps0))
 
-    one_pass(cores)
-    t1 = min(one_pass(1) for _ in range(2))
-    best, spent, passes = 1e9, 0.0, 0
-    while spent < seconds_budget and passes < 400:
-        dt = one_pass(cores)
-        best, spent, passes = min(best, dt), spent + dt, passes + 1
+    def work(t):
+        if hq:
+            fn(per_thread, hdr, frm, st[t], psf, ps[t], pin.ctypes.data, out[t].ctypes.data)
+        else:
+            fn(per_thread, hdr, frm, st[t], pin.ctypes.data, out[t].ctypes.data)
+
+    timed_team(work, workers, 0.0, reset, max_passes=1)          # warm: pages touched, tables in cache
+    t1, _ = timed_team(work, 1, 0.0, reset, max_passes=2)
+    best, passes = timed_team(work, workers, seconds_budget, reset)
     per_frame = 1.0 if hq else 0.5     # C3 counts stereo frames: two channel calls each
-    return {"value": round(cores * per_thread * per_frame / best, 1), "unit": "frames/s", "cores": cores, "kind": kind,
-            "value_1core": round(per_thread * per_frame / t1, 1),
-            "sample": "%d ixheaacd_sbr_dec calls per thread per pass (C loop) on the committed reference-captured "
-                      "frames, %d passes; SBR chain only, the core IMDCT is not in it" % (per_thread, passes)}
+    return baseline_report(workers * per_thread * per_frame / best, per_thread * per_frame / t1, workers, info, kind,
+                           "%d ixheaacd_sbr_dec calls per worker per pass (one C loop per worker, buffers allocated and state "
+                           "reset outside the timed span) on the committed reference-captured frames, %d passes; SBR chain "
+                           "only, the core IMDCT is not in it" % (per_thread, passes))
 
 
 def cpu_baseline(seconds_budget=12.0, limiter=False):
-    """Time the CPU path on a bounded sample of the same workload (all host cores,
-    one contiguous shard of channel-frames per thread).  limiter: each thread also runs the reference's
+    """Time the CPU path on a bounded sample of the same workload (every usable host core,
+    one contiguous shard of channel-frames per worker).  limiter: each worker also runs the reference's
     ixheaacd_peak_limiter_process + round16 over its shard's frames (workload C2L)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
@@ -511,12 +572,13 @@ def cpu_baseline(seconds_budget=12.0, limiter=False):
     ref = oracle_lib.load_reference()
     kind = "reference" if ref is not None and hasattr(ref.lib, "ref_imdct_batch") else "port"
     orc = oracle_lib.load_oracle()
-    cores = os.cpu_count() or 1
-    per_thread = max(256, min(2048, 131072 // cores))   # channel-frames per thread per pass
+    workers, info = usable_cores()
+    per_thread = max(1024, min(4096, 262144 // workers))   # channel-frames per worker per pass
     rng = np.random.default_rng(0xC0FFEE)
-    n = per_thread * cores
-    spec0 = rng.integers(-(1 << 17), 1 << 17, (n, 1024)).astype(np.int32)
-    spec0[:, 640:] = 0
+    n = per_thread * workers
+    base = rng.integers(-(1 << 17), 1 << 17, (per_thread, 1024)).astype(np.int32)
+    base[:, 640:] = 0
+    spec0 = np.tile(base, (workers, 1))
     ovl = np.zeros((n, 512), np.int32)
     pseq = np.zeros(n, np.int16); pshape = np.zeros(n, np.int16)
     seq = np.zeros(n, np.uint8); shape = (np.arange(n) % 2).astype(np.uint8)
@@ -535,7 +597,7 @@ def cpu_baseline(seconds_budget=12.0, limiter=False):
         lim_q = np.full(n, 2, np.int8)
         lim_pcm = np.zeros(n * 1024, np.int16)
 
-    def shard(t):
+    def work(t):
         a, b = t * per_thread, (t + 1) * per_thread
         p = oracle_lib._p
         if kind == "reference":
@@ -554,29 +616,17 @@ def cpu_baseline(seconds_budget=12.0, limiter=False):
         ref.lib.ref_imdct_batch.restype = None
         ref.lib.ref_imdct_batch.argtypes = [ctypes.c_int, P32, P32, P16, P16, PU8, PU8, P16]
 
-    def one_pass(nthreads):
+    def reset():
         if kind == "reference":
             spec[:] = spec0           # the reference transforms its input in place
-        t0 = time.perf_counter()
-        th = [threading.Thread(target=shard, args=(t,)) for t in range(nthreads)]
-        [t.start() for t in th]
-        [t.join() for t in th]
-        return time.perf_counter() - t0
 
-    one_pass(cores)                   # warm
-    t1 = min(one_pass(1) for _ in range(2))
-    passes, spent, best = 0, 0.0, 1e9
-    while spent < seconds_budget and passes < 2000:
-        dt = one_pass(cores)
-        best = min(best, dt)
-        spent += dt
-        passes += 1
-    frames = n / CH
-    return {"value": round(frames / best, 1), "unit": "frames/s", "cores": cores, "kind": kind,
-            "value_1core": round(per_thread / CH / t1, 1),
-            "sample": "%d stereo frames (%d channel-frames) per pass, %d passes, one %d-channel-frame shard per "
-                      "thread, same synthetic C2 input%s" % (frames, n, passes, per_thread,
-                                                             " + limiter/round16 per frame" if limiter else "")}
+    timed_team(work, workers, 0.0, reset, max_passes=1)           # warm
+    t1, _ = timed_team(work, 1, 0.0, reset, max_passes=2)
+    best, passes = timed_team(work, workers, seconds_budget, reset, max_passes=2000)
+    return baseline_report(n / CH / best, per_thread / CH / t1, workers, info, kind,
+                           "%d stereo frames (%d channel-frames) per pass, %d passes, one %d-channel-frame shard per "
+                           "worker thread (buffers allocated, input restored outside the timed span), same synthetic C2 input%s"
+                           % (n // CH, n, passes, per_thread, " + limiter/round16 per frame" if limiter else ""))
 
 
 METRIC = {
@@ -776,6 +826,53 @@ class Workload:
         return bool(ok)
 
 
+def need_gpus(torch, n):
+    """the product has no CPU path: say what is missing instead of failing somewhere inside a launch"""
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        sys.exit("bench.py needs %d GPU%s on this node (found %d); the product has no CPU path" % (n, "s" if n > 1 else "", have))
+
+
+def self_launch(n, launch_check):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks ourselves, the way the driver's own command line
+    does (one process per GPU, rendezvous on 127.0.0.1), and hand back the launcher's exit code.  The device count is
+    checked first so that a box without N GPUs says so."""
+    import socket
+    import subprocess
+    if not launch_check:
+        import torch
+        need_gpus(torch, n)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(torch, xdist, rank, world):
+    """--launch-check: everything a multi-rank run does around its timed region except the decode, on host tensors over
+    gloo: rendezvous, barrier, max-over-ranks, per-rank report and the gather of a per-rank PCM-shaped pattern into rank 0."""
+    dist = xdist.init("gloo")
+    dev = torch.device("cpu")
+    barrier = dist.barrier if dist is not None else (lambda: None)
+    barrier()
+    elapsed = xdist.max_over_ranks(dist, 1.0 + rank, dev)
+    pcm = (torch.arange(64 * 4096, dtype=torch.int32).view(64, 4096) * (rank + 3) % 65521 - 32760).to(torch.int16)
+    per_rank, gather = (None, None) if dist is None else xdist.post_run_report(dist, pcm, 1000.0 + rank, dev, barrier)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "metric": None, "value": None, "n_gpus": world, "max_over_ranks_s": elapsed,
+                          "per_rank_frames_per_s": per_rank, "gather": gather,
+                          "note": "launcher / rendezvous / gather check on host tensors (gloo); not a measurement"}))
+    if dist is not None:
+        assert gather["ok"] is not False
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -788,15 +885,25 @@ def main():
                     help="c4 (default): HE-AACv2, mono IMDCT + HQ-SBR + parametric stereo -- the configuration the "
                          "metric is quoted on, and C5 with --gpus N; c2: AAC-LC IMDCT+OLA (BASELINE configs[1]); c2l: c2 "
                          "+ peak limiter + PCM16 (the AAC-LC post stage); c3: HE-AACv1 stereo, IMDCT + LP-SBR")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="no decode, no GPU: start the N ranks exactly as a real run does, rendezvous over gloo and run the "
+                         "post-run report (per-rank rates + the PCM gather) on host tensors; prints a line that is NOT a "
+                         "measurement (tests/test_dist_cpu.py)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, args.launch_check))
 
     import torch
     import libxaac_amd
 
     from libxaac_amd import dist as xdist
     rank, local_rank, world = xdist.env_rank()
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    assert torch.cuda.is_available(), "bench.py needs a GPU; the product has no CPU path"
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher's WORLD_SIZE is %d" % (args.gpus, world))
+    if args.launch_check:
+        return launch_check(torch, xdist, rank, world)
+    need_gpus(torch, max(args.gpus, local_rank + 1))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = xdist.init("nccl")       # RCCL; None at world 1

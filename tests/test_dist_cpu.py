@@ -129,3 +129,45 @@ def test_two_rank_gloo_c4_chain_with_carried_state(oracle):
     want, _, _ = _c4_steps(oracle.lib, 0, n, steps)
     assert pcm.shape == want.shape and np.array_equal(pcm, want)
     assert t == 1.5
+
+
+def _bench(*argv, env=None, timeout=300):
+    import subprocess
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=e, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+@pytest.mark.skipif(torch.cuda.is_available() and torch.cuda.device_count() >= 2, reason="box has the GPUs: the run would start")
+def test_bench_gpus_2_without_a_launcher_stops_at_the_device_count():
+    """`python bench.py --gpus 2` (the driver's bare form) must not die at a world-size assert: with no launcher it starts
+    its own ranks, and on a box without two GPUs the only complaint is the missing devices"""
+    r = _bench("--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0
+    assert "needs 2 GPUs" in r.stderr and "AssertionError" not in r.stderr and "nproc-per-node" not in r.stderr
+
+
+@pytest.mark.skipif(torch.cuda.is_available() and torch.cuda.device_count() >= 2, reason="box has the GPUs: the run would start")
+def test_bench_rank_under_a_launcher_stops_at_the_device_count():
+    """a rank started the driver's way (torchrun environment) on a box without its GPU says so"""
+    r = _bench("--gpus", "2", "--steps", "1", "--warmup", "0",
+               env=dict(RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533"))
+    assert r.returncode != 0 and "needs 2 GPUs" in r.stderr
+
+
+def test_bench_world_size_mismatch_is_reported():
+    r = _bench("--gpus", "4", env=dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2"))
+    assert r.returncode != 0 and "WORLD_SIZE is 2" in r.stderr
+
+
+def test_bench_self_launch_two_ranks_rendezvous_and_gather():
+    """the same launcher path with --launch-check: bench.py starts two ranks through torch.distributed.run, they meet over
+    gloo on 127.0.0.1 and run dist.post_run_report; rank 0's line carries what an N > 1 line carries"""
+    import json
+    r = _bench("--gpus", "2", "--launch-check")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["launch_check"] is True and line["n_gpus"] == 2 and line["value"] is None
+    assert line["max_over_ranks_s"] == 2.0 and line["per_rank_frames_per_s"] == [1000.0, 1001.0]
+    assert line["gather"]["ok"] is True and line["gather"]["bytes_per_rank"] == 64 * 4096 * 2
