@@ -361,7 +361,8 @@ typedef struct xaac_usac_ics {
 } xaac_usac_ics;
 
 typedef struct xaac_usac_fac {
-  int32_t q;                 /* fac_q */
+  int32_t q;                 /* fac_q; a frame for which it would drive one of the windowing's shift counts outside 0..31
+                                (given the frame's own transform exponent) is refused with XAAC_FATAL_BAD_ARG */
   int32_t data[256];         /* fac_idata[0 .. 2 lfac), lfac <= FAC_LENGTH = 128 */
 } xaac_usac_fac;
 

@@ -50,7 +50,9 @@ typedef struct xaac_pvc_batch {
   const float *qmf_re, *qmf_im; /* [n_ch][qmf_stride]: row SBR_HF_ADJ_OFFSET (= 2) of qmf_buf_real / _imag onwards, 64 floats per
                                    row; 32 rows (pvc_rate 2) or 64 rows (pvc_rate 4) are read, sub-bands 0..31 / 0..15 */
   int32_t qmf_stride;           /* floats from one channel's row 2 to the next channel's, >= 32 * 64 (the rows read must exist:
-                                   32 of them for pvc_rate 2, 64 for pvc_rate 4) */
+                                   32 of them for pvc_rate 2, 64 for pvc_rate 4: a pvc_rate 4 frame in a batch whose stride
+                                   is below 64 * 64 is refused with status -1, and so is a pvc_rate 4 frame with
+                                   first_bnd_idx > 16 -- the reference fills energies of sub-bands 0..15 only there) */
   xaac_pvc_state *state;        /* [n_ch] in/out */
   float *out;                   /* [n_ch][16][64]: pvc_dec_out_buf (sub-bands below first_bnd_idx: zero) */
   int32_t *status;              /* [n_ch] or NULL: 0, -1 = parameters outside the reference's tables (nothing written) */

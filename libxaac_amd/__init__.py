@@ -641,10 +641,13 @@ class XaacContext:
 
     def pvc_process_batch(self, frame, qmf_re, qmf_im, state, out, status=None):
         """Batched PVC envelope decoder (ixheaacd_qmf_enrg_calc + ixheaacd_pvc_process): frame uint8[n_ch, PVC_FRAME_BYTES];
-        qmf_re / qmf_im float32[n_ch, >= 64, 64] (row 2 of the QMF buffers onwards); state uint8[n_ch, PVC_STATE_BYTES]
+        qmf_re / qmf_im float32[n_ch, rows, 64] (row 2 of the QMF buffers onwards; rows >= 32, and >= 64 for batches that hold
+        pvc_rate 4 frames: on fewer rows such a frame is refused with status -1); state uint8[n_ch, PVC_STATE_BYTES]
         in/out; out float32[n_ch, 16, 64]; status int32[n_ch] or None."""
         n_ch = state.shape[0]
         b = _PvcBatch()
+        if qmf_re.dim() != 3 or qmf_re.shape[2] != 64 or qmf_re.shape[1] < 32 or tuple(qmf_im.shape) != tuple(qmf_re.shape):
+            raise ValueError("qmf_re / qmf_im must be [n_ch, rows >= 32, 64] and alike")
         b.n_ch, b.qmf_stride = n_ch, int(qmf_re.shape[1]) * int(qmf_re.shape[2])
         b.frame = _ptr(frame, "uint8", n_ch * PVC_FRAME_BYTES, device_ok=True)
         b.qmf_re = _ptr(qmf_re, "float32", n_ch * b.qmf_stride, device_ok=True)

@@ -44,10 +44,13 @@ struct XpWork { /* shared between the lanes (LDS on the device) */
 };
 
 /* the frame's parameters are inside what the reference's loops and tables cover (the reference itself does not look) */
-FX_HD bool xp_frame_ok(const xaac_pvc_frame *f) {
+FX_HD bool xp_frame_ok(const xaac_pvc_frame *f, size_t qmf_stride) {
   if (f->pvc_mode != 1 && f->pvc_mode != 2) return false;       /* pred_vec_block.c:218: returns -1 */
   if (f->pvc_rate != 2 && f->pvc_rate != 4) return false;        /* 8 / pvc_rate, 12 / pvc_rate */
   if (f->first_bnd_idx < 0 || f->first_bnd_idx > 32) return false; /* the low groups end below it, inside a 32-band row */
+  /* 4:1: ixheaacd_qmf_enrg_calc (sbr_dec.c:83-107) fills bands 0..15 of a row only -- above them the reference reads what an
+     earlier frame left, which is not a function of this frame -- and it reads 64 QMF rows, not 32 */
+  if (f->pvc_rate == 4 && (f->first_bnd_idx > 16 || qmf_stride < (size_t)64 * 64)) return false;
   if (f->first_pvc_timeslot < 0 || f->first_pvc_timeslot > XAAC_PVC_SLOTS - 1) return false;
   for (int t = 0; t < XAAC_PVC_SLOTS; t++)
     if (f->pvc_id[t] >= 128) return false;                       /* code book 2 has 128 entries */
@@ -68,9 +71,9 @@ FX_HD float xp_slot_energy(const float *re, const float *im, int rate, int low_p
 }
 
 /* One channel's frame.  re / im: row 2 of the channel's QMF buffers; out: [16][64].  Returns 0 or -1 (nothing written). */
-FX_HD int xp_process(const XpCx cx, XpWork *w, const xaac_pvc_frame *f, const float *re, const float *im, xaac_pvc_state *st,
-                     float *out) {
-  if (!xp_frame_ok(f)) return -1;
+FX_HD int xp_process(const XpCx cx, XpWork *w, const xaac_pvc_frame *f, const float *re, const float *im, size_t qmf_stride,
+                     xaac_pvc_state *st, float *out) {
+  if (!xp_frame_ok(f, qmf_stride)) return -1;
   const int rate = f->pvc_rate, mode1 = f->pvc_mode == 1;
   const int nb_high = mode1 ? 8 : 6, per_grp = (mode1 ? 8 : 12) / rate, lbw = 8 / rate;
   const int nts = mode1 ? (f->ns_mode ? 4 : 16) : (f->ns_mode ? 3 : 12);

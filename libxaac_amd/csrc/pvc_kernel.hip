@@ -22,7 +22,7 @@ __global__ __launch_bounds__(64) void xaac_pvc_kernel(XaacPvcParams p) {
   __syncthreads();
   const XpCx cx = {(int)threadIdx.x, 64};
   const size_t o = (size_t)ch * p.qmf_stride;
-  const int rc = xp_process(cx, &w, &f, p.qmf_re + o, p.qmf_im + o, p.state + ch, p.out + (size_t)ch * XAAC_PVC_SLOTS * 64);
+  const int rc = xp_process(cx, &w, &f, p.qmf_re + o, p.qmf_im + o, (size_t)p.qmf_stride, p.state + ch, p.out + (size_t)ch * XAAC_PVC_SLOTS * 64);
   if (p.status && threadIdx.x == 0) p.status[ch] = rc;
 }
 

@@ -283,6 +283,22 @@ template <int L> FX_HD bool xu_lpd_window_missing(bool td_prev, int seq, int sha
   return L == 1024 && td_prev && (seq == 3 || seq == 4) && shape_prev == 1;
 }
 
+/* fac_q comes from the caller (ixheaacd_cal_fac_data's *q_fac = qshift1 - preshift, imdct.c:325): every shift count the FAC
+   windowing forms from it and the frame's transform exponent must lie in 0..31 -- outside, the reference's own C shifts are
+   undefined, and a CPU and a GPU would silently disagree.  Such a frame is refused (XAAC_FATAL_BAD_ARG, nothing written).
+   x_zero: the transform's output is all zeros (a silent frame: shiftp sits at its cap of 31 + XU_SHIFT_OLAP and the
+   transform side's count may pass 31 -- shifting zeros, which every machine answers with zero; the reference-made chains
+   hold such frames). */
+FX_HD bool xu_fac_q_ok(int shiftp, bool x_zero, bool eight_short, int fac_q) {
+  if (eight_short) { /* ixheaacd_combine_fac (basic_ops.c:56) at the short path's output exponent */
+    const int d = fac_q - (shiftp > XU_SHIFT_OLAP ? XU_SHIFT_OLAP : shiftp);
+    return d >= -31 && d <= 31;
+  }
+  int q = shiftp < XU_SHIFT_OLAP ? shiftp : XU_SHIFT_OLAP; /* windowing_long2 (basic_ops.c:121) + ixheaacd_scale_down_adj */
+  q = fac_q < q ? fac_q : q;
+  return (x_zero || shiftp - q <= 31) && XU_SHIFT_OLAP - q <= 31 && fac_q - q <= 31 && 15 - q <= 31;
+}
+
 /* ---- long blocks: output sample i (0 .. L-1) of the frame, before the final rescale; L = ccfl -----------------------
  * x: the L transform outputs after the second renormalisation; ov: the overlap (Q14); shiftp: their exponent.
  * ONLY_LONG / LONG_START: windowing_long1 (basic_ops.c:77); LONG_STOP / STOP_START: windowing_long3 (:298), no FAC:

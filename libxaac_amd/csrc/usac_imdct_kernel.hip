@@ -49,7 +49,7 @@ struct LdsStrided { /* words of the sub-sequence T j + s of an interleaved (re, 
    side (N = L/16).  For ccfl 768 a block's points go through three M-point transforms (M = 128 | 16) and the
    three-point stage (usac_imdct.h); every pass is spread over the lanes: L/8 radix-4 butterflies per pass either way. */
 template <int L, bool SHORT>
-__device__ __forceinline__ int transform(const int32_t *coef, int32_t *A, int32_t *B, int lane, int shiftp) {
+__device__ __forceinline__ int transform(const int32_t *coef, int32_t *A, int32_t *B, int lane, int shiftp, bool &all_zero) {
   constexpr int N = SHORT ? L / 16 : L / 2;   /* complex points per block */
   constexpr int M = xu_sub_points<N>();       /* ... of the power-of-two transform they go through */
   constexpr int T = N / M;                    /* 1, or 3 thirds */
@@ -171,6 +171,7 @@ __device__ __forceinline__ int transform(const int32_t *coef, int32_t *A, int32_
     A[2 * N * blk + 2 * N - 1 - 2 * i] = xu_normalize(xb[m], s - 1);
   }
   wave_sync();
+  all_zero = s == 31; /* fx_norm32 of a block maximum of 0 */
   shiftp += s - 1;
   if (shiftp - XU_SHIFT_OLAP > 31) shiftp = 31 + XU_SHIFT_OLAP;
   return shiftp;
@@ -187,7 +188,9 @@ __device__ __forceinline__ int frame(const XaacUsacImdctParams &p, int ch, int32
   if (xu_lpd_window_missing<L>(lp.td_prev != 0, seq, shape_prev)) return XAAC_FATAL_BAD_WINDOW_SEQ;
   const int32_t *coef = p.coef + (size_t)ch * L;
   int32_t *gov = p.overlap + (size_t)ch * L;
-  const int shiftp = seq == 2 ? transform<L, true>(coef, A, B, lane, 0) : transform<L, false>(coef, A, B, lane, 0);
+  bool all_zero;
+  const int shiftp = seq == 2 ? transform<L, true>(coef, A, B, lane, 0, all_zero) : transform<L, false>(coef, A, B, lane, 0, all_zero);
+  if (lp.fac && (seq == 2 || seq == 3 || seq == 4) && !xu_fac_q_ok(shiftp, all_zero, seq == 2, lp.fac_q)) return XAAC_FATAL_BAD_ARG;
   const Lds x = {A};
   const Glb ov = {gov};
   const Glb fac = {lp.fac ? p.fac[ch].data : gov};

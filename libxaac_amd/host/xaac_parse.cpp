@@ -54,13 +54,16 @@ class Team {
     std::lock_guard<std::mutex> serial(call_);
     if (threads < 1) threads = 1;
     grow(threads - 1);
+    /* Every worker of the team -- not only the `threads - 1` that take items -- acknowledges every generation through
+       pending_: a worker reads fn_ / items_ / active_ only between seeing the new generation and its decrement, and run()
+       does not return (so the next run() cannot rewrite those fields, nor the caller's lambda die) before all decrements. */
     fn_ = &fn, items_ = items, active_ = threads - 1;
     next_.store(0, std::memory_order_relaxed);
-    pending_.store((uint32_t)(threads - 1), std::memory_order_relaxed);
+    pending_.store((uint32_t)workers_.size(), std::memory_order_relaxed);
     generation_.fetch_add(1, std::memory_order_release); /* publishes the job */
-    if (threads > 1) futex_wake_all(&generation_);
+    if (!workers_.empty()) futex_wake_all(&generation_);
     work();
-    for (int spin = 0;;) { /* the workers that took part */
+    for (int spin = 0;;) { /* every worker has seen this generation and is done with the job's fields */
       const uint32_t p = pending_.load(std::memory_order_acquire);
       if (p == 0) break;
       if (++spin < kSpin) cpu_relax();
@@ -100,8 +103,7 @@ class Team {
           }
           if (quit_.load(std::memory_order_acquire)) return;
           seen = g;
-          if (id >= active_) continue; /* this call uses fewer threads than the team has */
-          work();
+          if (id < active_) work(); /* else: this call uses fewer threads than the team has; acknowledge only */
           if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) futex_wake_all(&pending_);
         }
       });

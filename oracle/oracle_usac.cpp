@@ -97,6 +97,7 @@ int fd_imdct(int32_t *coef, int32_t *overlap, int seq, int shape, int shape_prev
   for (int i = 0; i < L; i++) coef[i] = xu_normalize(coef[i], s - 1);
   shiftp += s - 1;
   if (shiftp - XU_SHIFT_OLAP > 31) shiftp = 31 + XU_SHIFT_OLAP;
+  if (fac_present && (seq == 2 || seq == 3 || seq == 4) && !xu_fac_q_ok(shiftp, s == 31, seq == 2, fac_q)) return -1;
   const Mem x = {coef}, ov = {overlap};
   const XuLpd lp = {td_prev, fac_present, fac_q};
   const Mem fc = {const_cast<int32_t *>(fac)};

@@ -27,3 +27,22 @@ def test_damaged_streams_are_memory_safe(fuzzer, name):
                        text=True, timeout=600, env=env)
     assert p.returncode == 0, (p.stdout[-300:], p.stderr[-3000:])
     assert "frames parsed" in p.stdout
+
+
+@pytest.fixture(scope="module")
+def tsan_team(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("tsan") / "tsan_team")
+    srcs = [os.path.join(ROOT, "tests", "fuzz", "tsan_team.cpp")] + [os.path.join(HOST, f) for f in ("xaac_parse.cpp", "aac_core.cpp", "sbr_side.cpp")]
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fwrapv", "-fsanitize=thread", *srcs, "-o", exe, "-lpthread"])
+    return exe
+
+
+def test_worker_team_is_race_free_when_thread_counts_alternate(tsan_team):
+    """xaac_parse_batch_run's futex team under ThreadSanitizer: two callers, thread counts 1..8 alternating from call to
+    call, streams dropping out; the version whose idle workers skipped the pending_ handshake is reported here"""
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66")
+    for _ in range(3):
+        p = subprocess.run([tsan_team, os.path.join(ROOT, "tests", "golden", "streams", "mono_aot5_32k.aac"), "30"],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0 and "ThreadSanitizer" not in p.stderr, (p.stdout[-300:], p.stderr[-3000:])
+        assert "equal to the single-threaded pass" in p.stdout

@@ -57,10 +57,12 @@ def test_parameters_outside_the_tables_are_refused(oracle, reference):
     fo, fr = ps.bind(oracle.lib, "xo_pvc_process"), ps.bind(reference.lib, "ref_pvc_process")
     f, re, im, _ = ps.chain(1, 1)[0]
     for name, value in (("pvc_mode", 0), ("pvc_mode", 3), ("pvc_rate", 3), ("pvc_rate", 0), ("first_bnd_idx", 33), ("first_bnd_idx", -1),
-                        ("first_pvc_timeslot", 16), ("pvc_id", 128)):
+                        ("first_pvc_timeslot", 16), ("pvc_id", 128), ("first_bnd_idx@4:1", 17), ("first_bnd_idx@4:1", 32)):
         g = ps.PvcFrame.from_buffer_copy(bytes(f))
         if name == "pvc_id":
             g.pvc_id[9] = value
+        elif name == "first_bnd_idx@4:1":   # the reference's energy rows hold sub-bands 0..15 only at 4:1 (sbr_dec.c:83-107)
+            g.pvc_rate, g.first_bnd_idx = 4, value
         else:
             setattr(g, name, value)
         st = ps.PvcState()
@@ -125,3 +127,46 @@ def test_gpu_batch_vs_oracle_and_refusals(oracle):
     res = _gpu_walk(chains, frames)
     bad = np.argwhere(res != want)
     assert bad.size == 0, (len(bad), bad[:4].tolist())
+
+
+@pytest.mark.gpu
+def test_gpu_refuses_4_to_1_frames_on_32_row_buffers(oracle):
+    """a pvc_rate 4 frame reads 64 QMF rows: in a batch whose channels are 32 rows apart it is refused (status -1, nothing
+    written) instead of reading the next channel's rows -- or, for the last channel, past the allocation; the 2:1 frames of
+    the same batch decode as before"""
+    import torch
+    import libxaac_amd
+    fn = ps.bind(oracle.lib, "xo_pvc_process")
+    dev = torch.device("cuda:0")
+    ctx = libxaac_amd.XaacContext(0, None)
+    items = []
+    seed = 100
+    while len(items) < 24:
+        f, re, im, _ = ps.chain(seed, 1)[0]
+        seed += 1
+        items.append((f, re, im))
+    rates = np.array([i[0].pvc_rate for i in items])
+    assert (rates == 4).sum() >= 3 and (rates == 2).sum() >= 3 and items[-1][0].pvc_rate in (2, 4)
+    if rates[-1] != 4:                      # the last channel is the one that would leave the allocation
+        k4 = int(np.argwhere(rates == 4)[0][0])
+        items[-1], items[k4] = items[k4], items[-1]
+        rates = np.array([i[0].pvc_rate for i in items])
+    n = len(items)
+    frame = torch.from_numpy(np.stack([np.frombuffer(bytes(i[0]), np.uint8) for i in items])).to(dev)
+    re = torch.from_numpy(np.stack([i[1][:32] for i in items])).to(dev)      # [n, 32, 64]
+    im = torch.from_numpy(np.stack([i[2][:32] for i in items])).to(dev)
+    state = torch.zeros((n, libxaac_amd.PVC_STATE_BYTES), dtype=torch.uint8, device=dev)
+    out = torch.full((n, 16, 64), -7.0, dtype=torch.float32, device=dev)
+    status = torch.full((n,), 5, dtype=torch.int32, device=dev)
+    ctx.pvc_process_batch(frame, re, im, state, out, status)
+    ctx.sync()
+    o, s, rc = out.cpu().numpy(), state.cpu().numpy(), status.cpu().numpy()
+    assert np.array_equal(rc, np.where(rates == 4, -1, 0))
+    assert np.all(o[rates == 4] == -7.0) and not s[rates == 4].any()
+    for k in np.argwhere(rates == 2)[:, 0]:
+        st = ps.PvcState()
+        want = np.zeros((16, 64), np.float32)
+        assert fn(ctypes.byref(items[k][0]), items[k][1].ctypes.data_as(ps.PF), items[k][2].ctypes.data_as(ps.PF), ctypes.byref(st),
+                  want.ctypes.data_as(ps.PF)) == 0
+        assert np.array_equal(o[k].view(np.uint32), want.view(np.uint32)) and bytes(s[k]) == bytes(st)
+    ctx.close()

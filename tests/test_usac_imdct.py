@@ -192,19 +192,25 @@ def test_gpu_reference_lpd_chains(ccfl):
 
 
 @pytest.mark.gpu
-def test_gpu_fac_without_lpd_frame_is_refused():
+def test_gpu_fac_without_lpd_frame_is_refused(oracle):
+    import ctypes
     import torch
     import libxaac_amd
     dev = torch.device("cuda:0")
     ctx = libxaac_amd.XaacContext(0, None)
-    n = 5
+    n = 8
     rng = np.random.default_rng(4)
-    coef = torch.from_numpy((rng.integers(-2 ** 31, 2 ** 31, (n, 1024)) >> 8).astype(np.int32)).to(dev)
+    coef_h = (rng.integers(-2 ** 31, 2 ** 31, (n, 1024)) >> 8).astype(np.int32)
+    coef = torch.from_numpy(coef_h).to(dev)
     ov_h = (rng.integers(-2 ** 31, 2 ** 31, (n, 1024)) >> 18).astype(np.int32)
-    ov, sp = torch.from_numpy(ov_h).to(dev), torch.tensor([0, 0, 1, 0, 0], dtype=torch.uint8, device=dev)
-    ics = torch.tensor([[3, 0], [3, 0], [3, 0], [2, 1], [0, 0]], dtype=torch.uint8, device=dev)
-    flags = torch.tensor([2, 3, 1, 1, 0], dtype=torch.uint8, device=dev)   # FAC without LPD; fine; LPD + KBD 256: no window; fine; fine
-    fac = torch.zeros((n, 257), dtype=torch.int32, device=dev)
+    ov, sp = torch.from_numpy(ov_h).to(dev), torch.tensor([0, 0, 1, 0, 0, 0, 0, 0], dtype=torch.uint8, device=dev)
+    ics_h = np.array([[3, 0], [3, 0], [3, 0], [2, 1], [0, 0], [3, 0], [2, 0], [4, 1]], np.uint8)
+    ics = torch.from_numpy(ics_h).to(dev)
+    # FAC without LPD; fine; LPD + KBD 256: no window; fine; fine; then three frames whose fac.q would make a shift count leave 0..31
+    flags = torch.tensor([2, 3, 1, 1, 0, 3, 3, 3], dtype=torch.uint8, device=dev)
+    fac_h = np.zeros((n, 257), np.int32)
+    fac_h[5, 0], fac_h[6, 0], fac_h[7, 0] = 60, -40, -18
+    fac = torch.from_numpy(fac_h).to(dev)
     out = torch.full((n, 1024), 77, dtype=torch.int32, device=dev)
     status = torch.zeros(n, dtype=torch.int32, device=dev)
     ctx.usac_imdct_process_batch(coef, ics, ov, sp, out, None, status, lpd_flags=flags, fac=fac)
@@ -212,6 +218,15 @@ def test_gpu_fac_without_lpd_frame_is_refused():
     st, o, v = status.cpu().numpy(), out.cpu().numpy(), ov.cpu().numpy()
     assert st[0] < 0 and st[0] != libxaac_amd.BAD_WINDOW_SEQ      # XAAC_FATAL_BAD_ARG
     assert st[2] == libxaac_amd.BAD_WINDOW_SEQ and list(st[[1, 3, 4]]) == [0, 0, 0]
-    for c in (0, 2):
+    assert list(st[5:8]) == [st[0]] * 3                            # fac.q outside what the windowing can shift by
+    for c in (0, 2, 5, 6, 7):
         assert np.all(o[c] == 77) and np.array_equal(v[c], ov_h[c])
     assert np.any(o[1] != 77) and np.any(o[3] != 77)
+    # the oracle refuses the same three
+    P32 = ctypes.POINTER(ctypes.c_int32)
+    for c in (5, 6, 7):
+        cf, vv, oo = coef_h[c].copy(), ov_h[c].copy(), np.zeros(1024, np.int32)
+        fd = np.ascontiguousarray(fac_h[c, 1:])
+        assert oracle.lib.xo_usac_fd_imdct_lpd(cf.ctypes.data_as(P32), vv.ctypes.data_as(P32), 1024, int(ics_h[c, 0]), int(ics_h[c, 1]), 0, 1,
+                                               fd.ctypes.data_as(P32), int(fac_h[c, 0]), oo.ctypes.data_as(P32)) == -1
+        assert np.array_equal(vv, ov_h[c])
