@@ -281,24 +281,24 @@ struct XsLv {
   }
 #else
   int32_t a[64];
-  int32_t &own(int k) { return a[k & 63]; }
-  int32_t own(int k) const { return a[k & 63]; }
-  int32_t get(int i) const { return a[i & 63]; }
-  void put(int i, int32_t val) { a[i & 63] = val; }
-  void fill(int32_t val) {
+  FX_MEMBER int32_t &own(int k) { return a[k & 63]; }
+  FX_MEMBER int32_t own(int k) const { return a[k & 63]; }
+  FX_MEMBER int32_t get(int i) const { return a[i & 63]; }
+  FX_MEMBER void put(int i, int32_t val) { a[i & 63] = val; }
+  FX_MEMBER void fill(int32_t val) {
     for (int i = 0; i < 64; i++) a[i] = val;
   }
-  XsLv shifted(const XsCx &, int d) const {
+  FX_MEMBER XsLv shifted(const XsCx &, int d) const {
     XsLv r;
     for (int i = 0; i < 64; i++) r.a[i] = (i + d >= 0 && i + d < 64) ? a[i + d] : 0;
     return r;
   }
-  XsLv gather(const XsLv &idx) const {
+  FX_MEMBER XsLv gather(const XsLv &idx) const {
     XsLv r;
     for (int i = 0; i < 64; i++) r.a[i] = a[idx.a[i] & 63];
     return r;
   }
-  XsLv fold(int w) const {
+  FX_MEMBER XsLv fold(int w) const {
     XsLv r;
     for (int i = 0; i < 64; i++) {
       uint32_t t = 0;
@@ -474,6 +474,28 @@ FX_HD void xs_adjust(const XsCx &cx, const Q &x, int b0, int b1, int s0, int s1,
     const int col = c < nb ? b0 + c : Q::IM + b0 + (c - nb); /* real and imaginary columns side by side */
     XS_UNROLL4
     for (int l = s0; l < s1; l++) x(l, col) = shift > 0 ? fx_shlw(x(l, col), shift) : (x(l, col) >> -shift);
+  }
+}
+
+/* zero bands [b0,b1) x slots [s0,s1) (real and imaginary parts) */
+template <class Q>
+FX_HD void xs_clear(const XsCx &cx, const Q &x, int b0, int b1, int s0, int s1) {
+  const int nb = b1 > b0 ? b1 - b0 : 0;
+  XS_PAR(c, 0, Q::HQ ? 2 * nb : nb) {
+    const int col = c < nb ? b0 + c : Q::IM + b0 + (c - nb);
+    for (int l = s0; l < s1; l++) x(l, col) = 0;
+  }
+}
+/* sbr_dec.c:1221-1236: the last two slots of the low bands are the next frame's LPC history */
+template <class ST, class Q>
+FX_HD void xs_lpc_save(const XsCx &cx, ST *st, const Q &x, int usb) {
+  XS_PAR(k, 0, usb) {
+    st->lpc_real[0][k] = x(30, k);
+    st->lpc_real[1][k] = x(31, k);
+    if (Q::HQ) {
+      st->lpc_imag[0][k] = x.im(30, k);
+      st->lpc_imag[1][k] = x.im(31, k);
+    }
   }
 }
 
@@ -2155,11 +2177,7 @@ FX_HD void xs_rescale_x_overlap(const XsCx &cx, const xaac_sbr_header *h, const 
     cx.sync();
     return;
   }
-  XS_PAR(k, old_lsb, new_lsb)
-    for (int l = start_slot; l < 6; l++) {
-      x(l, k) = 0;
-      if (Q::HQ) x.im(l, k) = 0;
-    }
+  xs_clear(cx, x, old_lsb, new_lsb, start_slot, 6);
   int source, target, t_lsb, t_usb;
   if (new_lsb > old_lsb) {
     source = ov_hb;
@@ -2295,10 +2313,7 @@ FX_HD int xs_sbr_core(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
     st->lb_scale = (int16_t)save_lb_scale;
   }
   *save_lb_scale_out = save_lb_scale;
-  XS_PAR(c, 0, (Q::HQ ? 2 : 1) * (Q::NB - 32)) {
-    const int col = c < Q::NB - 32 ? 32 + c : Q::IM + 32 + (c - (Q::NB - 32)); /* bands 32 and up, real | imaginary */
-    for (int l = 6; l < 38; l++) x(l, col) = 0;
-  }
+  xs_clear(cx, x, 32, Q::NB, 6, 38); /* bands 32 and up of the analysed slots */
   cx.sync();
   XS_T(1);
   if (cx.uni(f->apply_processing)) {
@@ -2327,14 +2342,7 @@ FX_HD int xs_sbr_core(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
     XS_ONE st->hb_scale = (int16_t)save_lb_scale;
   }
   cx.sync();
-  XS_PAR(k, 0, st->codec_usb) {
-    st->lpc_real[0][k] = x(30, k);
-    st->lpc_real[1][k] = x(31, k);
-    if (Q::HQ) {
-      st->lpc_imag[0][k] = x.im(30, k);
-      st->lpc_imag[1][k] = x.im(31, k);
-    }
-  }
+  xs_lpc_save(cx, st, x, cx.uni(st->codec_usb));
   cx.sync();
   XS_T(15);
   return 0;
