@@ -48,7 +48,6 @@ __shared__ int16_t xs_lds_rand_hi[568];
 #define XS_TAB_INV(i) xs_lds_inv_table[i]
 #define XS_TAB_SQRT(i) xs_lds_sqrt_table[i]
 #include "sbr_core.h"
-#include "sbr_core_reg.h"
 #include "sbr_core_kernel.h"
 
 namespace {
@@ -298,118 +297,6 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
   return true;
 }
 
-/* ---- the HQ core with the matrix in registers (sbr_core_reg.h): lane = band owns its column of 40 rows ----------------
-   LDS holds only the side info, the state tail and the adjuster's scratch (6 KB per wave); the matrix comes from global
-   memory straight into the lanes' registers (coalesced 256-byte rows: 64 real | 64 imaginary words per slot) and leaves
-   the same way.  Returns false for a frame the register form does not take (nothing written: the list launch runs it). */
-struct XsLdsReg {
-  XsLdsState st;
-  xaac_sbr_header h;
-  int32_t f_head[kFrameHeadBytes / 4];
-  int32_t noise_floor[sizeof(((xaac_sbr_frame *)0)->int_noise_floor) / 4];
-  XsWork w;
-};
-
-__device__ __forceinline__ bool core_one_reg(const XaacSbrCoreParams &p, const int ch, XsLdsReg &s, const int lane) {
-  constexpr int ROWG = 128, XWG = 2 * XAAC_SBR_X_WORDS;
-  xaac_sbr_state *gst = p.state + ch;
-  int32_t *gx = p.x + (size_t)ch * XWG;
-  const int32_t *gstw = reinterpret_cast<const int32_t *>(gst);
-  constexpr int NH = (sizeof(xaac_sbr_header) / 4 + 63) / 64, NF = (kFrameHeadBytes / 4 + 63) / 64;
-  constexpr int NT = (kTailWords + 63) / 64, NNF = sizeof(s.noise_floor) / 4;
-  static_assert(NF == 1, "the frame head fits one word per lane");
-  XsQmfReg x;
-  {
-    /* every global load of the channel-frame in flight before the first use: one memory latency */
-    int32_t r_h[NH], r_f, r_nf = 0, r_hd = 0, r_t[NT];
-    const int32_t *gh = reinterpret_cast<const int32_t *>(p.header + ch), *gf = reinterpret_cast<const int32_t *>(p.frame + ch);
-#pragma unroll
-    for (int j = 0; j < NH; j++) r_h[j] = lane + 64 * j < (int)(sizeof(xaac_sbr_header) / 4) ? gh[lane + 64 * j] : 0;
-    r_f = lane < kFrameHeadBytes / 4 ? gf[lane] : 0;
-    if (lane < NNF) r_nf = reinterpret_cast<const int32_t *>(p.frame[ch].int_noise_floor)[lane];
-    if (lane < 2) r_hd = gstw[kHeadOff / 4 + lane];
-#pragma unroll
-    for (int j = 0; j < NT; j++) r_t[j] = lane + 64 * j < kTailWords ? gstw[kTailOff / 4 + lane + 64 * j] : 0;
-    const int32_t *gov = gstw + offsetof(xaac_sbr_state, overlap) / 4; /* sbr_dec.c:753: six complex slots */
-    x.re[0].fill(0); x.im[0].fill(0); x.re[1].fill(0); x.im[1].fill(0);
-#pragma unroll
-    for (int l = 0; l < 6; l++) {
-      x.re[2 + l].own(lane) = gov[ROWG * l + lane];
-      x.im[2 + l].own(lane) = gov[ROWG * l + 64 + lane];
-    }
-#pragma unroll
-    for (int l = 6; l < 38; l++) { /* the analysed slots: bands 0..31; what lies above in the row is not defined */
-      x.re[2 + l].fill(0);
-      x.im[2 + l].fill(0);
-      if (lane < 32) {
-        x.re[2 + l].own(lane) = gx[(2 + l) * ROWG + lane];
-        x.im[2 + l].own(lane) = gx[(2 + l) * ROWG + 64 + lane];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < NH; j++)
-      if (lane + 64 * j < (int)(sizeof(xaac_sbr_header) / 4)) reinterpret_cast<int32_t *>(&s.h)[lane + 64 * j] = r_h[j];
-    if (lane < kFrameHeadBytes / 4) s.f_head[lane] = r_f;
-    if (lane < NNF) s.noise_floor[lane] = r_nf;
-    int32_t *m = reinterpret_cast<int32_t *>(&s.st);
-    if (lane < 2) m[lane] = r_hd;
-#pragma unroll
-    for (int j = 0; j < NT; j++)
-      if (lane + 64 * j < kTailWords) m[2 + lane + 64 * j] = r_t[j];
-  }
-  const xaac_sbr_frame *f = reinterpret_cast<const xaac_sbr_frame *>(s.f_head); /* head members only */
-  xs_wave_sync();
-  if (!xs_reg_core_takes(&s.h)) return false;
-  const XsCx cx = {lane, 64};
-  if (lane == 0) s.st.lb_scale = 0;
-  const int refused = xs_side_info_bad(cx, &s.h, f, &s.st);
-  if (f->apply_processing && !refused) xs_rescale_x_overlap(cx, &s.h, f, &s.st, x);
-  xs_wave_sync();
-  if (lane == 0) {
-    s.st.st_lb_scale = 0;
-    s.st.lb_scale = -8; /* what ixheaacd_cplx_anal_qmffilt leaves in the scale struct (generic:630-631) */
-  }
-  xs_wave_sync();
-  int save_lb_scale = 0;
-  const int rc = refused ? -1
-                         : xs_sbr_core(cx, &s.h, f, p.frame[ch].int_env_sf_arr, reinterpret_cast<const int16_t *>(s.noise_floor),
-                                       &s.st, x, &s.w, nullptr, &save_lb_scale);
-  xs_wave_sync();
-  /* ---- copy-out ---- */
-  if (lane == 0) {
-    int16_t *par = p.syn_par + 8 * (size_t)ch;
-    par[0] = s.st.lb_scale;
-    par[1] = s.st.ov_lb_scale;
-    par[2] = s.st.hb_scale;
-    par[3] = s.st.st_syn_scale;
-    par[4] = s.st.syn_lsb;
-    par[5] = s.st.syn_usb;
-    par[6] = 0; /* channel active (the synthesis kernel skips channels flagged here) */
-    par[7] = 0;
-    s.st.ov_lb_scale = (int16_t)save_lb_scale; /* sbr_dec.c:1304 */
-    if (p.status) p.status[ch] = rc;
-  }
-  xs_wave_sync();
-#pragma unroll
-  for (int l = 0; l < 38; l++) { /* slots 0..31 for synthesis (+ 32..37 for PS) */
-    gx[(2 + l) * ROWG + lane] = x.re[2 + l].own(lane);
-    gx[(2 + l) * ROWG + 64 + lane] = x.im[2 + l].own(lane);
-  }
-  {
-    int32_t *gw = reinterpret_cast<int32_t *>(gst);
-    /* sbr_dec.c:1283-1291 copies 6 * 64 words in either mode: in HQ the first three of the six slots */
-#pragma unroll
-    for (int l = 0; l < 3; l++) {
-      gw[offsetof(xaac_sbr_state, overlap) / 4 + ROWG * l + lane] = x.re[34 + l].own(lane);
-      gw[offsetof(xaac_sbr_state, overlap) / 4 + ROWG * l + 64 + lane] = x.im[34 + l].own(lane);
-    }
-    const int32_t *m = reinterpret_cast<const int32_t *>(&s.st);
-    if (lane < 2) gw[kHeadOff / 4 + lane] = m[lane];
-    copy_words(gw + kTailOff / 4, m + 2, kTailWords, lane);
-  }
-  return true;
-}
-
 /* the workgroup's tables, staged by all its threads (loads first, then the LDS stores) */
 template <int HQ, int THREADS>
 __device__ __forceinline__ void stage_tables(int tid) {
@@ -464,29 +351,6 @@ __global__ __launch_bounds__(64 * WAVES) void xaac_sbr_core_kernel(XaacSbrCorePa
   }
 }
 
-#ifndef XS_REG_WAVES_PER_EU
-#define XS_REG_WAVES_PER_EU 2 /* waves per SIMD the register allocation is held to */
-#endif
-/* HQ, matrix in registers: WAVES persistent waves per workgroup on the work counter; a frame the register form does not
-   take is appended to p.defer_list */
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES, XS_REG_WAVES_PER_EU) void xaac_sbr_core_reg_kernel(XaacSbrCoreParams p) {
-  __shared__ XsLdsReg s[WAVES];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  stage_tables<1, 64 * WAVES>(threadIdx.x);
-  __syncthreads();
-  for (;;) {
-    int ch = 0;
-    if (lane == 0) ch = atomicAdd(p.work_counter, 1);
-    ch = __builtin_amdgcn_readfirstlane(ch);
-    if (ch >= p.n_ch) break;
-    int ln = lane;
-    asm volatile("" : "+v"(ln)); /* lane-derived values are recomputed per stream instead of living across the whole loop */
-    if (!core_one_reg(p, ch, s[wave], ln) && lane == 0) p.defer_list[atomicAdd(p.defer_count, 1)] = ch;
-    xs_wave_sync();
-  }
-}
-
 /* the streams of p.defer_list through the 64-band rows: a small grid walks the list (usually empty) */
 template <int HQ>
 __global__ __launch_bounds__(64) void xaac_sbr_core_list_kernel(XaacSbrCoreParams p) {
@@ -521,11 +385,9 @@ extern "C" hipError_t xaac_launch_sbr_core_hq(const XaacSbrCoreParams *p, hipStr
     if (e != hipSuccess) return e;
   }
   constexpr int W = XAAC_SBR_CORE_HQ_WAVES;
-  static int per_cu = 0; /* workgroups of the register kernel a CU holds (VGPR-bound) */
-  if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, xaac_sbr_core_reg_kernel<W>, 64 * W, 0) != hipSuccess || per_cu < 1))
-    per_cu = 2;
-  const int resident = per_cu * (p->num_cu > 0 ? p->num_cu : 256), need = (p->n_ch + W - 1) / W;
-  hipLaunchKernelGGL((xaac_sbr_core_reg_kernel<W>), dim3(need < resident ? need : resident), dim3(64 * W), 0, stream, *p);
+  const int resident = 2 * (p->num_cu > 0 ? p->num_cu : 256), need = (p->n_ch + W - 1) / W;
+  hipLaunchKernelGGL((xaac_sbr_core_kernel<1, XAAC_SBR_NARROW_BANDS, W>), dim3(need < resident ? need : resident), dim3(64 * W), 0,
+                     stream, *p);
   const int grid = p->n_ch < 64 ? p->n_ch : 64;
   hipLaunchKernelGGL((xaac_sbr_core_list_kernel<1>), dim3(grid), dim3(64), 0, stream, *p);
   return hipGetLastError();

@@ -53,7 +53,7 @@ typedef struct XaacQmfSynParams {
 /* HE-AACv2: both complex synthesis banks of a stream in one wave (channel 0 = left, state in xaac_sbr_state; channel
    1 = right, state in xaac_ps_state), output as interleaved L,R pairs.  scale[c] + 8 i: lb, ov_lb, hb, st_syn scales,
    lsb, usb, and [6] != 0 where the channel is not synthesised this frame (bank and output samples left alone). */
-#define XAAC_QMF_SYN_PAIR_LDS (2 * 64 * 65 * 4) /* two 64 x 65-word half-row tiles (one per wave); the 2 x 42 x 65 pair rows alias them */
+#define XAAC_QMF_SYN_PAIR_LDS (2 * 42 * 65 * 4) /* the 2 x 42 x 65 pair rows; the two 32 x 65-word half-row tiles (one per wave, one channel at a time) alias them */
 typedef struct XaacQmfSynPairParams {
   int32_t n;       /* streams */
   int32_t split;   /* first slot of the current frame's low band (op_delay = 6) */

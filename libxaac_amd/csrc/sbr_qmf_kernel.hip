@@ -537,9 +537,13 @@ __global__ __launch_bounds__(128) void xaac_qmf_synthesis_pair_kernel(XaacQmfSyn
   constexpr int RING = 1280;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int32_t *tile_own = reinterpret_cast<int32_t *>(smem) + w * 64 * RS;
-  const int32_t *tile_oth = reinterpret_cast<const int32_t *>(smem) + (1 - w) * 64 * RS;
+  /* a wave's tile holds the 32 half rows of ONE channel at a time (the lanes of channel 0, then those of channel 1, go
+     through it): 2 x 8.3 KB instead of 2 x 16.6 KB, so that the pair rows (21.8 KB) set the workgroup's LDS and six
+     workgroups -- three waves per SIMD, what the 154 VGPRs allow -- share a CU instead of four */
+  int32_t *tile_own = reinterpret_cast<int32_t *>(smem) + w * 32 * RS;
+  const int32_t *tile_oth = reinterpret_cast<const int32_t *>(smem) + (1 - w) * 32 * RS;
   int32_t *E = reinterpret_cast<int32_t *>(smem); /* [2][EROWS][RS], aliases the tiles once they are dead */
+  const int lch = lane >> 5, lrow = lane & 31; /* the lane's (channel, slot) */
   const int i = blockIdx.x;
   const int inactive0 = __builtin_amdgcn_readfirstlane(p.scale[0][8 * (size_t)i + 6]);
   const int inactive1 = __builtin_amdgcn_readfirstlane(p.scale[1][8 * (size_t)i + 6]);
@@ -570,25 +574,26 @@ __global__ __launch_bounds__(128) void xaac_qmf_synthesis_pair_kernel(XaacQmfSyn
         shr[c][ov] = sh < 0 ? -sh : 0;
       }
     }
-    constexpr int XB = 64; /* all 64 half rows in flight: one memory latency */
+    int32_t tmp[64]; /* all 64 half rows in flight: one memory latency */
 #pragma unroll
-    for (int r0 = 0; r0 < 64; r0 += XB) {
-      int32_t tmp[XB];
-#pragma unroll
-      for (int j = 0; j < XB; j++) {
-        const int r = r0 + j, c = r >> 5;
-        tmp[j] = (p.qmf[c] + (size_t)i * p.qmf_stride[c] + (size_t)(r & 31) * 128 + 64 * w)[lane];
-      }
-#pragma unroll
-      for (int j = 0; j < XB; j++) {
-        const int r = r0 + j, c = r >> 5;
-        const bool ov = (r & 31) < p.split;
-        tile_own[RS * r + lane] = pair_rescale(tmp[j], ov ? shl[c][1] : shl[c][0], ov ? shr[c][1] : shr[c][0]);
-      }
+    for (int r = 0; r < 64; r++) {
+      const int c = r >> 5;
+      tmp[r] = (p.qmf[c] + (size_t)i * p.qmf_stride[c] + (size_t)(r & 31) * 128 + 64 * w)[lane];
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the tile is this wave's own: no barrier */
 #pragma unroll
-    for (int k = 0; k < 64; k++) x[k] = tile_own[RS * lane + k];
+    for (int c = 0; c < 2; c++) {
+#pragma unroll
+      for (int j = 0; j < 32; j++) {
+        const bool ov = j < p.split;
+        tile_own[RS * j + lane] = pair_rescale(tmp[32 * c + j], ov ? shl[c][1] : shl[c][0], ov ? shr[c][1] : shr[c][0]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the tile is this wave's own: no barrier */
+      if (lch == c) {
+#pragma unroll
+        for (int k = 0; k < 64; k++) x[k] = tile_own[RS * lrow + k];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* channel 0's reads are done before channel 1's rows land */
+    }
   }
   {
     int32_t t[64];
@@ -598,8 +603,6 @@ __global__ __launch_bounds__(128) void xaac_qmf_synthesis_pair_kernel(XaacQmfSyn
       xq_cos_sin_mod_half<32, 1>(x, t);
   }
   /* ---- phase B: the halves meet.  inv_emodulation's last step + shiftrountine_with_rnd (generic:869, :1638) --- */
-#pragma unroll
-  for (int k = 0; k < 64; k++) tile_own[RS * lane + k] = x[k]; /* a lane's row is read and written by that lane only */
   /* this wave's channel: 9 slots of history from the ring, in flight across the exchange */
   int16_t h_lo[9], h_hi[9];
 #pragma unroll
@@ -609,11 +612,20 @@ __global__ __launch_bounds__(128) void xaac_qmf_synthesis_pair_kernel(XaacQmfSyn
     h_lo[A - 1] = st_w->ring[pos + lane];
     h_hi[A - 1] = st_w->ring[pos + 64 + lane];
   }
-  __syncthreads();
   int32_t o[64];
 #pragma unroll
-  for (int k = 0; k < 64; k++) o[k] = tile_oth[RS * lane + k];
-  __syncthreads(); /* both tiles are dead: the pair rows may overwrite them */
+  for (int c = 0; c < 2; c++) { /* the lanes of channel c hand their half over through the (half-size) tiles */
+    if (lch == c) {
+#pragma unroll
+      for (int k = 0; k < 64; k++) tile_own[RS * lrow + k] = x[k];
+    }
+    __syncthreads();
+    if (lch == c) {
+#pragma unroll
+      for (int k = 0; k < 64; k++) o[k] = tile_oth[RS * lrow + k];
+    }
+    __syncthreads(); /* after the second round both tiles are dead: the pair rows may overwrite them */
+  }
   {
     const int ch = lane >> 5, slot = lane & 31;
     const int shift = -(p.scale[ch][8 * (size_t)i + 3] - 3) + 1;

@@ -19,7 +19,6 @@
 #endif
 
 #include "../libxaac_amd/csrc/sbr_core.h"
-#include "../libxaac_amd/csrc/sbr_core_reg.h"
 #include "../libxaac_amd/csrc/sbr_ps.h"
 #include "../libxaac_amd/csrc/sbr_ps_frame.h"
 #include "oracle_qmf.h"
@@ -39,26 +38,6 @@ static thread_local int g_ds = 0;
 /* 1: run the parametric-stereo tool through the product's frame-at-once arrangement (sbr_ps_frame.h, lane count 1)
    instead of the slot loop below -- tests/test_ps_frame_cpu.py checks the two against each other on the host */
 static thread_local int g_ps_phased = 0;
-/* 1: run the HQ core on the product's register-matrix arrangement (sbr_core_reg.h: lane = band owns its column; on the
-   host the 64 "lanes" run one after the other) instead of the matrix in memory -- tests/test_core_reg_cpu.py checks the
-   two against each other on the host.  Frames the register form does not take (xs_reg_core_takes) stay on the memory form,
-   as in the kernel. */
-static thread_local int g_core_reg = 0;
-
-static void to_reg(const XsQmfHq &x, XsQmfReg &r) {
-  for (int row = 0; row < XS_REG_ROWS; row++)
-    for (int k = 0; k < 64; k++) {
-      r.re[row].own(k) = x(row - 2, k);
-      r.im[row].own(k) = x.im(row - 2, k);
-    }
-}
-static void from_reg(const XsQmfReg &r, const XsQmfHq &x) {
-  for (int row = 0; row < XS_REG_ROWS; row++)
-    for (int k = 0; k < 64; k++) {
-      x(row - 2, k) = r.re[row].own(k);
-      x.im(row - 2, k) = r.im[row].own(k);
-    }
-}
 
 extern "C" int xo_sbr_dec_lp(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st,
                              const int16_t *pcm_in, int in_stride, int16_t *pcm_out, int out_stride) {
@@ -130,17 +109,7 @@ extern "C" int xo_sbr_dec_hq(const xaac_sbr_header *h, const xaac_sbr_frame *f, 
   memcpy(&x(0, 0), st->overlap, sizeof(int32_t) * 12 * 64);
   if (xs_side_info_bad(cx, h, f, st)) return -1; /* refused before anything is touched, like sbr_dec.c:733-748 */
   st->lb_scale = 0;
-  const bool reg = g_core_reg && xs_reg_core_takes(h);
-  static thread_local XsQmfReg xreg;
-  if (f->apply_processing) {
-    if (reg) {
-      to_reg(x, xreg);
-      xs_rescale_x_overlap(cx, h, f, st, xreg);
-      from_reg(xreg, x);
-    } else {
-      xs_rescale_x_overlap(cx, h, f, st, x);
-    }
-  }
+  if (f->apply_processing) xs_rescale_x_overlap(cx, h, f, st, x);
   {
     xo_qmf_ana_state a;
     memcpy(a.ring, st->ana_ring, sizeof(a.ring));
@@ -154,14 +123,7 @@ extern "C" int xo_sbr_dec_hq(const xaac_sbr_header *h, const xaac_sbr_frame *f, 
     st->lb_scale = -8; /* generic:631 */
   }
   int save_lb_scale = 0;
-  if (reg) {
-    to_reg(x, xreg);
-    const int rc = xs_sbr_core(cx, h, f, f->int_env_sf_arr, f->int_noise_floor, st, xreg, &w, rand_hi_table(), &save_lb_scale);
-    from_reg(xreg, x);
-    if (rc) return -1;
-  } else if (xs_sbr_core(cx, h, f, f->int_env_sf_arr, f->int_noise_floor, st, x, &w, rand_hi_table(), &save_lb_scale)) {
-    return -1;
-  }
+  if (xs_sbr_core(cx, h, f, f->int_env_sf_arr, f->int_noise_floor, st, x, &w, rand_hi_table(), &save_lb_scale)) return -1;
   xo_qmf_syn_state s;
   memcpy(s.ring, st->syn_ring, sizeof(s.ring));
   s.drc_offset = st->syn_drc_offset;
@@ -290,19 +252,6 @@ extern "C" int xo_sbr_dec_hq_phased(const xaac_sbr_header *h, const xaac_sbr_fra
                                     int16_t *pcm_out, int out_stride) {
   g_ps_phased = 1;
   const int rc = xo_sbr_dec_hq(h, f, st, pf, ps, pcm_in, in_stride, pcm_out, out_stride);
-  g_ps_phased = 0;
-  return rc;
-}
-
-/* xo_sbr_dec_hq with the core on the register-matrix arrangement (sbr_core_reg.h) and the phased PS tool: the product's
-   kernels' source, run on the host */
-extern "C" int xo_sbr_dec_hq_reg(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st,
-                                 const xaac_ps_frame *pf, xaac_ps_state *ps, const int16_t *pcm_in, int in_stride,
-                                 int16_t *pcm_out, int out_stride) {
-  g_core_reg = 1;
-  g_ps_phased = 1;
-  const int rc = xo_sbr_dec_hq(h, f, st, pf, ps, pcm_in, in_stride, pcm_out, out_stride);
-  g_core_reg = 0;
   g_ps_phased = 0;
   return rc;
 }
