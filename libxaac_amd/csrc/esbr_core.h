@@ -21,6 +21,7 @@
 
 #include "../../include/xaac_esbr.h"
 #include "sbr_core.h" /* XsCx, XS_PAR, XS_ONE */
+#include "fx_libm.h"
 
 #if defined(__HIPCC__)
 #define XAAC_TAB_QUAL static __device__ const
@@ -92,8 +93,6 @@ struct XeTrue { static constexpr bool value = true; };
 struct XeFalse { static constexpr bool value = false; };
 
 FX_HD double xe_sqrt(double v) { return sqrt(v); }
-FX_HD double xe_log10(double v) { return log10(v); }
-FX_HD double xe_pow10(double v) { return pow(10.0, v); }
 
 /* ---- ixheaacd_createlimiterbands (b_patching_mode = 1): serial, integer, run at a reset frame ------------------- */
 FX_HD void xe_shellsort(int32_t *in, int n) { /* esbr_envcal.c:48: any sort gives the same array of integers */
@@ -381,7 +380,7 @@ XE_NOINLINE FX_HD void xe_pre_flatten(const XsCx cx, XeWork *w, const XeMat src,
       float temp = 0.0f;
       for (int i = start; i < end; i++) temp += src.r(i, k) * src.r(i, k) + src.i(i, k) * src.i(i, k);
       temp /= (float)(end - start);
-      e = (float)(10 * xe_log10((double)(temp + 1)));
+      e = xm_10log10f_of(temp + 1);
     }
     low_env[k] = e;
   }
@@ -440,7 +439,7 @@ XE_NOINLINE FX_HD void xe_pre_flatten(const XsCx cx, XeWork *w, const XeMat src,
       slope = slope + p[1] * x;
       x = x * (float)k;
       slope = slope + p[0] * x;
-      gain[k] = (float)xe_pow10((double)((*mean - slope) / 20.0f));
+      gain[k] = xm_pow10f_of((*mean - slope) / 20.0f);
     }
   }
   cx.sync();

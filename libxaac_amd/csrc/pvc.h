@@ -15,6 +15,7 @@
 
 #include "../../include/xaac_pvc.h"
 #include "fx.h"
+#include "fx_libm.h"
 
 #if defined(__HIPCC__)
 #define XAAC_TAB_QUAL static __device__ const
@@ -92,7 +93,7 @@ FX_HD int xp_process(const XpCx cx, XpWork *w, const xaac_pvc_frame *f, const fl
       for (int ib = start; ib < start + lbw; ib++) esg += xp_slot_energy(re, im, rate, f->low_power, t, ib);
       esg = esg / (float)lbw;
     }
-    w->fresh[t][ksg] = esg > 0.1f ? 10 * ((float)log10((double)esg)) : -10.0f;
+    w->fresh[t][ksg] = esg > 0.1f ? 10 * xm_log10f_of(esg) : -10.0f;
   }
   cx.sync();
   /* rows 0 .. 14: the history -- or, at a restart, like every row in front of the first PVC slot's, that slot's values (:98-104) */
@@ -119,7 +120,7 @@ FX_HD int xp_process(const XpCx cx, XpWork *w, const xaac_pvc_frame *f, const fl
       const float c = (float)tab1[(grp * XAAC_PVC_NB_LOW + kb) * nb_high + ksg] * q[kb];
       r += c * w->smooth[t][kb];
     }
-    w->high[t][ksg] = (float)pow(10.0, r / 10.0);
+    w->high[t][ksg] = xm_pow10_tenth(r);
   }
   cx.sync();
   /* ixheaacd_pvc_sb_parsing (:30): group g starts at first + g * per_grp; every group but the first runs on to band 63 when
