@@ -56,14 +56,15 @@ struct XpFrameWork {
     int32_t hyb_u[3][2][44]; /* P1: hybrid filter input of QMF bands 0..2: 12 slots of history + this frame's 32 */
     int32_t gsum[8][56];     /* P3: addends of the group sums, bands 9..63 of eight slots */
     int32_t peak[32][20];    /* P4: transient peak difference */
-    uint32_t dl[32][12];     /* P5/P7: rounded samples of QMF bands 23..34 (the 14-slot delay looks 14 slots back) */
+    uint32_t dl[32][13];     /* P5/P7: rounded samples of QMF bands 23..34 (the 14-slot delay looks 14 slots back); column
+                                12 takes the other lanes' stores, so that the store needs no predicate */
   };
   int32_t hyb_l[32][20];     /* left hybrid sub-band samples of every slot: re 0..9 | im 10..19 */
   union {
     int32_t binpw[32][20];   /* P3: bin powers; P4: smoothed energy ... */
     int16_t ratio[32][20];   /* ... compacted in place into the transient ratios (entry i lands inside entry i / 2) */
   };
-  uint32_t ap_h[32][10];     /* outputs of the hybrid sub-bands' all-pass chains (re, im pairs) */
+  uint32_t ap_h[32][11];     /* outputs of the hybrid sub-bands' all-pass chains (re, im pairs); column 10: the other lanes' */
   int16_t seg_h[XP_MAX_SEG][4][24]; /* per segment and group: H11, H12, H21, H22 before the segment's first slot */
   int16_t seg_d[XP_MAX_SEG][4][24]; /* per-slot increments */
 };
@@ -365,7 +366,7 @@ FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_f
          operands in flight meanwhile.  The body has no lane-dependent branches: every lane runs the chain arithmetic
          (on don't-care values where it has no chain), band classes are selects, only the stores are predicated. */
       const int is_ap = sb < 23, is_d14 = sb >= 23 && sb < 35;
-      const int ldj = is_d14 ? 2 * (sb - 23) : 0, dlj = is_d14 ? sb - 23 : 0;
+      const int ldj = is_d14 ? 2 * (sb - 23) : 0, dlj = is_d14 ? sb - 23 : 12, apj = hyb_chain ? csb : 10;
       int16_t tr_nx = w->ratio[0][bin_sb];
       int32_t hre_nx = w->hyb_l[0][csb], him_nx = w->hyb_l[0][10 + csb];
       uint32_t ld_nx = xp_pack16(ps->ld[idx_long0 % 14][ldj], ps->ld[idx_long0 % 14][ldj + 1]);
@@ -433,7 +434,7 @@ FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_f
           r2[0] = r2[1]; r2[1] = r2[2]; r2[2] = r2[3]; r2[3] = r2[4];
           r2[4] = xp_pack16(e2[0], e2[1]);
           const uint32_t o_chain = xp_pack16(o_re, o_im);
-          if (hyb_chain) w->ap_h[l][csb] = o_chain;
+          w->ap_h[l][apj] = o_chain; /* lanes without a hybrid chain write the spare column */
           /* the interpolated coefficients of the band's group */
           if ((seg_mask >> l) & 1u) { /* (uniform) a border: they restart from the old targets */
             const int s = xp_popc(seg_mask & (0xffffffffu >> (31 - l)));
@@ -448,10 +449,13 @@ FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_f
              line holds what slot l - 14 put in if that slot ran with the band active, else what the state held. */
           const int active = sb < usb_l;
           const int fed14 = l >= 14 && sb < (l - 14 >= clear_slot ? usb : usb_prev);
-          const uint32_t o14 = fed14 ? w->dl[l >= 14 ? l - 14 : 0][dlj]
-                                     : (l < 14 ? ld_cur : xp_pack16(ps->ld[(idx_long0 + l) % 14][ldj], ps->ld[(idx_long0 + l) % 14][ldj + 1]));
+          /* (both candidates are read by every lane -- a lane without a delay line reads entries it does not use -- and
+             the value is a select: no predicated region inside the walk) */
+          const uint32_t o14_new = w->dl[l >= 14 ? l - 14 : 0][dlj];
+          const uint32_t o14_old = l < 14 ? ld_cur : xp_pack16(ps->ld[(idx_long0 + l) % 14][ldj], ps->ld[(idx_long0 + l) % 14][ldj + 1]);
+          const uint32_t o14 = fed14 ? o14_new : o14_old;
           const uint32_t o = is_ap ? o_chain : (is_d14 ? o14 : prev);
-          if (is_d14) w->dl[l][dlj] = q;
+          w->dl[l][dlj] = q; /* lanes without a 14-slot line write the spare column */
           prev = active ? q : prev;
           int32_t re = re0, im = im0;
           int32_t r_re = xp_m16x16_shl(xp_lo16(o), tr), r_im = xp_m16x16_shl(xp_hi16(o), tr);
