@@ -75,6 +75,51 @@ FX_HD uint32_t xp_pack16(int16_t lo, int16_t hi) { return (uint32_t)(uint16_t)lo
 FX_HD int16_t xp_lo16(uint32_t v) { return (int16_t)(v & 0xffffu); }
 FX_HD int16_t xp_hi16(uint32_t v) { return (int16_t)(v >> 16); }
 
+/* a.lo * b.lo + a.hi * b.hi of two packed pairs of int16, wrapping: one v_dot2_i32_i16 on the GPU */
+FX_HD int32_t xp_dot2(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef short xp_short2 __attribute__((ext_vector_type(2)));
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(xp_short2, a), __builtin_bit_cast(xp_short2, b), 0, false);
+#else
+  return (int32_t)((uint32_t)((int32_t)xp_lo16(a) * xp_lo16(b)) + (uint32_t)((int32_t)xp_hi16(a) * xp_hi16(b)));
+#endif
+}
+/* a complex 16-bit rotation factor (re, im) as the two pairs the products of xp_allpass take: (re, -im) gives the real
+   part, (im, re) the imaginary one.  The PS tables hold no -32768 (tests/test_tables.py), so -im is a short and the sum of
+   two products of a sample and a factor stays below 2^31: the reference's saturating add / subtract never saturates
+   there, and the wrapping dot product is the same number. */
+struct XpPhase {
+  uint32_t re_pair, im_pair;
+};
+FX_HD XpPhase xp_phase_pairs(int16_t re, int16_t im) {
+  XpPhase p;
+  p.re_pair = xp_pack16(re, (int16_t)-im);
+  p.im_pair = xp_pack16(im, re);
+  return p;
+}
+/* xp_allpass (sbr_ps.h, ps_dec.c:236 / :339) on packed (re, im) pairs: d0 = the 2-slot line's oldest entry (replaced by the
+   new sample), e0 / e1 / e2 = the three links' entries at their read positions (replaced); returns the chain's output pair */
+FX_HD uint32_t xp_allpass_packed(uint32_t &d0, uint32_t new_pair, const XpPhase &ph, uint32_t &e0, uint32_t &e1, uint32_t &e2,
+                                 const XpPhase &p0, const XpPhase &p1, const XpPhase &p2, int16_t decay0, int16_t decay1,
+                                 int16_t decay2) {
+  int16_t in_re = (int16_t)(xp_dot2(d0, ph.re_pair) >> 15), in_im = (int16_t)(xp_dot2(d0, ph.im_pair) >> 15);
+  d0 = new_pair;
+  uint32_t *e[3] = {&e0, &e1, &e2};
+  const XpPhase *pp[3] = {&p0, &p1, &p2};
+  const int16_t decay[3] = {decay0, decay1, decay2};
+  XP_UNROLL
+  for (int m = 0; m < 3; m++) {
+    const uint32_t s = *e[m];
+    int16_t t_re = (int16_t)(xp_dot2(s, pp[m]->re_pair) >> 15), t_im = (int16_t)(xp_dot2(s, pp[m]->im_pair) >> 15);
+    t_re = (int16_t)(t_re - xs_mult16_shl(in_re, decay[m]));
+    t_im = (int16_t)(t_im - xs_mult16_shl(in_im, decay[m]));
+    *e[m] = xp_pack16((int16_t)(in_re + xs_mult16_shl(t_re, decay[m])), (int16_t)(in_im + xs_mult16_shl(t_im, decay[m])));
+    in_re = t_re;
+    in_im = t_im;
+  }
+  return xp_pack16(in_re, in_im);
+}
+
 FX_HD int32_t xp_adj_word(int32_t v, int shift) { /* env_calc.c:1099 on one word */
   if (shift == 0) return v;
   if (shift > 31) shift = 31;
@@ -325,9 +370,9 @@ FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_f
       const int16_t *ph = hyb_chain ? &T->frac_delay_phase_fac_qmf_sub_re_im[2 * csb] : &T->frac_delay_phase_fac_qmf_re_im[2 * csb];
       const int16_t *pser = hyb_chain ? &T->frac_delay_phase_fac_qmf_sub_ser_re_im[2 * csb] : &T->frac_delay_phase_fac_qmf_ser_re_im[2 * csb];
       const int pstep = hyb_chain ? 32 : 64;
-      const int16_t phase[2] = {ph[0], ph[1]};
-      const int16_t ps0[2] = {pser[0], pser[1]}, ps1[2] = {pser[pstep], pser[pstep + 1]},
-                    ps2[2] = {pser[2 * pstep], pser[2 * pstep + 1]};
+      const XpPhase phase = xp_phase_pairs(ph[0], ph[1]);
+      const XpPhase ps0 = xp_phase_pairs(pser[0], pser[1]), ps1 = xp_phase_pairs(pser[pstep], pser[pstep + 1]),
+                    ps2 = xp_phase_pairs(pser[2 * pstep], pser[2 * pstep + 1]);
       const int16_t dec0 = hyb_chain ? T->rev_link_decay_ser[0] : T->decay_scale_factor[qmf_chain ? di : 9];
       const int16_t dec1 = hyb_chain ? T->rev_link_decay_ser[1] : T->decay_scale_factor[qmf_chain ? di + 1 : 10];
       const int16_t dec2 = hyb_chain ? T->rev_link_decay_ser[2] : T->decay_scale_factor[qmf_chain ? di + 2 : 11];
@@ -419,21 +464,17 @@ FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_f
             XP_UNROLL
             for (int m = 0; m < 5; m++) r2[m] = c ? 0u : r2[m];
           }
-          const int16_t in_re = hyb_chain ? fx_round16(hre) : q_re, in_im = hyb_chain ? fx_round16(him) : q_im;
-          int16_t dv[2] = {xp_lo16(d0[0]), xp_hi16(d0[0])};
-          int16_t e0[2] = {xp_lo16(r0[0]), xp_hi16(r0[0])}, e1[2] = {xp_lo16(r1[0]), xp_hi16(r1[0])},
-                  e2[2] = {xp_lo16(r2[0]), xp_hi16(r2[0])};
-          int16_t o_re, o_im;
-          xp_allpass(dv, in_re, in_im, phase, e0, e1, e2, ps0, ps1, ps2, dec0, dec1, dec2, &o_re, &o_im);
+          const uint32_t in_pair = hyb_chain ? xp_pack16(fx_round16(hre), fx_round16(him)) : q;
+          uint32_t dv = d0[0], e0 = r0[0], e1 = r1[0], e2 = r2[0];
+          const uint32_t o_chain = xp_allpass_packed(dv, in_pair, phase, e0, e1, e2, ps0, ps1, ps2, dec0, dec1, dec2);
           d0[0] = d0[1];
-          d0[1] = xp_pack16(dv[0], dv[1]);
+          d0[1] = dv;
           r0[0] = r0[1]; r0[1] = r0[2];
-          r0[2] = xp_pack16(e0[0], e0[1]);
+          r0[2] = e0;
           r1[0] = r1[1]; r1[1] = r1[2]; r1[2] = r1[3];
-          r1[3] = xp_pack16(e1[0], e1[1]);
+          r1[3] = e1;
           r2[0] = r2[1]; r2[1] = r2[2]; r2[2] = r2[3]; r2[3] = r2[4];
-          r2[4] = xp_pack16(e2[0], e2[1]);
-          const uint32_t o_chain = xp_pack16(o_re, o_im);
+          r2[4] = e2;
           w->ap_h[l][apj] = o_chain; /* lanes without a hybrid chain write the spare column */
           /* the interpolated coefficients of the band's group */
           if ((seg_mask >> l) & 1u) { /* (uniform) a border: they restart from the old targets */

@@ -138,3 +138,15 @@ def test_aac_syntax_tables_equal_reference_rom(tmp_path):
 def test_sbr_side_info_tables_equal_reference_rom(tmp_path):
     """the host parser's SBR / PS code books, FIXFIX grids and log2 table"""
     _regenerated_equals_committed("gen_tables_sbr_side", "tables_sbr_side.inc", tmp_path, where="host")
+
+
+def test_ps_rotation_factors_hold_no_minus_one():
+    """sbr_ps_frame.h's packed all-pass (xp_allpass_packed) negates the imaginary parts of the fractional-delay phase factors
+    into shorts and relies on two sample x factor products never summing to 2^31: true as long as no factor is -32768"""
+    import re
+    src = open(os.path.join(ROOT, "libxaac_amd", "csrc", "tables_ps.inc")).read()
+    for name in ("frac_delay_phase_fac_qmf_re_im", "frac_delay_phase_fac_qmf_sub_re_im", "frac_delay_phase_fac_qmf_ser_re_im",
+                 "frac_delay_phase_fac_qmf_sub_ser_re_im"):
+        body = re.search(r"/\* %s \*/ \{(.*?)\}" % name, src, re.S).group(1)
+        vals = [int(v) for v in re.findall(r"-?\d+", body)]
+        assert len(vals) >= 32 and min(vals) > -32768 and max(vals) <= 32767, name
