@@ -1326,6 +1326,356 @@ FX_HD void xs_alias_reduction(const XsCx &cx, XsEnv &v, XsWork *w, uint64_t star
   cx.sync();
 }
 
+/* ---- two envelopes side by side (HQ mode) ----------------------------------------------------------------------------
+ * The gain mathematics of an envelope -- xs_subband_gain_meta, xs_calc_subband_gains, xs_noiselimiting,
+ * xs_erg_to_amplitude_hq -- only reads the envelope's energy estimates and side info: nothing of it depends on the envelope
+ * before.  A frame's SBR range is at most 32 bands wide in every stream the reference's tables produce at 48 kHz and below
+ * (26 - 27 bands in the bench's streams), so the chain above leaves more than half of the wave idle and runs once per
+ * envelope, 2.9 times per frame in the bench's transient-heavy material.  Here element c of envelope q (q = 0, 1) of a pass
+ * lives on lane 32 q + c and the chain runs once per PAIR of envelopes; what differs between the two (frequency resolution,
+ * noise-floor row, scale factors, the "no noise" flag of a transient envelope, the envelope number the sine flags are held
+ * against, the noise exponent) is a per-lane select.  Same operations in the same order per element -- the sums over a
+ * limiter band are the same recursions, on two lane groups.  The slots of the two envelopes are then adjusted one after the
+ * other (xs_adapt_noise_gain_hq: the filter buffers chain the envelopes).
+ * Taken when the frame is the regular case (xs_pack_frame_ok); every other frame runs the one-envelope chain. */
+#define XS_PK 32
+struct XsPass {       /* the (wave-uniform) per-envelope values of a pass */
+  int n;              /* envelopes in the pass: 1 or 2 */
+  int env[2], fr[2], nf_off[2], noise_absc[2], noise_e[2];
+};
+FX_HD int xs_qsel(int q, const int *v) { return q ? v[1] : v[0]; }
+
+/* xs_energy_per_subband (env_calc.c:1211, complex matrix) for a pass: element (q, c) = band b0 + c over envelope q's slots
+   [s0[q], s1[q]).  Both envelopes walk their slots together; a lane whose envelope is the shorter one re-reads its last
+   slot (harmless for the maximum) and adds nothing. */
+template <class Q>
+FX_HD void xs_energy_per_subband_pk(const XsCx &cx, const Q &x, const XsPass &ps, const int *s0, const int *s1, int b0,
+                                    int nb, int frame_exp, XsLv &est) {
+  const int n0 = s1[0] - s0[0], n1 = ps.n > 1 ? s1[1] - s0[1] : 0, nmax = n0 > n1 ? n0 : n1;
+  const int frame_exp2 = frame_exp << 1;
+  XS_LANES(l, 0, 64) {
+    const int q = l / XS_PK, c = l & (XS_PK - 1);
+    int32_t e = 0;
+    if (q < ps.n && c < nb) {
+      const int first = xs_qsel(q, s0), n = q ? n1 : n0, k = b0 + c;
+      const int16_t inv_width = xaac_sbr_inv_int_table[n];
+      int32_t mx = 1;
+      XS_UNROLL4
+      for (int j = 0; j < nmax; j++) {
+        const int row = first + (j < n ? j : n - 1);
+        int32_t a = fx_abs_nrm(x(row, k));
+        if (a > mx) mx = a;
+        a = fx_abs_nrm(x.im(row, k));
+        if (a > mx) mx = a;
+      }
+      const int pre = xs_pnorm32(mx) - 4;
+      int32_t accu = 0;
+      int shift = 16 - pre;
+      XS_UNROLL4
+      for (int j = 0; j < nmax; j++) {
+        const int row = first + (j < n ? j : n - 1);
+        int16_t t = shift > 0 ? (int16_t)xs_sar(x(row, k), shift) : (int16_t)xs_shl(x(row, k), -shift);
+        accu = fx_add(accu, j < n ? (int32_t)t * t : 0);
+        t = shift > 0 ? (int16_t)xs_sar(x.im(row, k), shift) : (int16_t)xs_shl(x.im(row, k), -shift);
+        accu = fx_add(accu, j < n ? (int32_t)t * t : 0);
+      }
+      if (accu != 0) {
+        shift = -xs_pnorm32(accu);
+        int16_t sum_m = (int16_t)xs_shr_dir_sat_limit(accu, 16 + shift);
+        sum_m = xs_mult16_shl_sat(sum_m, inv_width);
+        shift = shift - (pre << 1);
+        e = xs_me(sum_m, (int16_t)(frame_exp2 + shift + 1));
+      }
+    }
+    est.own(l) = e;
+  }
+}
+
+/* per frame: for each band of the SBR range (element i = band sub_band_start + i) its scale-factor band under the high- and
+   the low-resolution table and its noise-floor band (the table walks of xs_subband_gain_meta, once per frame instead of
+   once per envelope): j | nb << 8 */
+FX_HD void xs_band_maps(const XsCx &cx, const xaac_sbr_header *h, int nsb, XsLv &jn_hi, XsLv &jn_lo) {
+  XsLv thi, tlo, noisev;
+  thi.fill(0);
+  tlo.fill(0);
+  noisev.fill(0);
+  const int nhi = cx.uni(h->num_sf_bands[1]), nlo = cx.uni(h->num_sf_bands[0]), nnf = cx.uni(h->num_nf_bands);
+  XS_LANES(i, 0, nhi + 1) thi.own(i) = h->freq_band_tbl_hi[i];
+  XS_LANES(i, 0, nlo + 1) tlo.own(i) = h->freq_band_tbl_lo[i];
+  XS_LANES(i, 0, XAAC_SBR_MAX_NOISE_COEFFS + 1) noisev.own(i) = h->freq_band_tbl_noise[i];
+  const int t0 = thi.get(0);
+  jn_hi.fill(0);
+  jn_lo.fill(0);
+  XS_LANES(i, 0, nsb) {
+    const int k = t0 + i;
+    int jh = 0, jl = 0, nb = 0;
+    XS_UNROLL4
+    for (int t = 1; t < nhi; t++) jh += thi.get(t) <= k;
+    for (int t = 1; t < nlo; t++) jl += tlo.get(t) <= k;
+    for (int t = 1; t < nnf; t++) nb += noisev.get(t) <= k;
+    jn_hi.own(i) = jh | (nb << 8);
+    jn_lo.own(i) = jl | (nb << 8);
+  }
+}
+
+/* xs_subband_gain_meta for a pass.  jn_*: xs_band_maps; fills v.meta (element (q, c): band max_qmf_subband_aac + c of
+   envelope q).  skip = max_qmf_subband_aac - sub_band_start, nsb = sub_band_end - sub_band_start <= 32. */
+FX_HD void xs_subband_gain_meta_pk(const XsCx &cx, const XsPass &ps, const XsLv &jn_hi, const XsLv &jn_lo, int nsb, int skip,
+                                   XsEnv &v) {
+  XsLv idx, flags;
+  idx.fill(0);
+  XS_LANES(l, 0, 64) idx.own(l) = l & (XS_PK - 1);
+  const XsLv gh = jn_hi.gather(idx), gl = jn_lo.gather(idx), sm = v.sine_mapped.gather(idx);
+  XsLv jn;
+  jn.fill(0);
+  flags.fill(0);
+  XS_LANES(l, 0, 64) {
+    const int q = l / XS_PK, i = l & (XS_PK - 1);
+    if (q < ps.n && i < nsb) jn.own(l) = xs_qsel(q, ps.fr) ? gh.own(l) : gl.own(l);
+  }
+  const XsLv jprev = jn.shifted(cx, -1);
+  XS_LANES(l, 0, 64) {
+    const int q = l / XS_PK, i = l & (XS_PK - 1);
+    if (q < ps.n && i < nsb)
+      flags.own(l) = ((i == 0 || (jn.own(l) & 255) != (jprev.own(l) & 255)) ? 1 : 0) | ((xs_qsel(q, ps.env) >= sm.own(l)) ? 2 : 0) | 4;
+  }
+  const uint64_t sfb_start = xs_ballot(cx, flags, 1, 64), sine_here = xs_ballot(cx, flags, 2, 64);
+  XsLv mt;
+  mt.fill(0);
+  XS_LANES(l, 0, 64) {
+    const int q = l / XS_PK, i = l & (XS_PK - 1);
+    if (q < ps.n && i < nsb) {
+      const uint64_t st_q = (sfb_start >> (XS_PK * q)) & 0xffffffffull, sn_q = (sine_here >> (XS_PK * q)) & 0xffffffffull;
+      const int first = 63 - xs_clz64(st_q & xs_mask_upto(i)); /* bit 0 is always set */
+      const uint64_t above = st_q & ~xs_mask_upto(i);
+      const int end = above ? xs_ctz64(above) : nsb;
+      const uint64_t seg = (((uint64_t)1 << end) - 1) & ~(((uint64_t)1 << first) - 1);
+      const int present = (sn_q & seg) != 0;
+      mt.own(l) = jn.own(l) | (present << 16);
+    }
+  }
+  /* meta is indexed from max_qmf_subband_aac: element (q, c) = band (q, c + skip) */
+  XsLv src;
+  src.fill(0);
+  XS_LANES(l, 0, 64) src.own(l) = (l & (XS_PK - 1)) + skip < XS_PK ? l + skip : l;
+  const XsLv mt_s = mt.gather(src);
+  XS_LANES(l, 0, 64) {
+    const int c = l & (XS_PK - 1);
+    v.meta.own(l) = (c + skip < nsb) ? mt_s.own(l) : 0;
+  }
+}
+
+/* xs_calc_subband_gains for a pass: sf_a / sf_b = the two envelopes' scale factors (element j = scale-factor band j) */
+FX_HD void xs_calc_subband_gains_pk(const XsCx &cx, const XsPass &ps, const XsLv &sf_a, const XsLv &sf_b,
+                                    const int16_t *noise_floor_all, int bands, int skip, XsEnv &v) {
+  XsLv idx, jv;
+  idx.fill(0);
+  jv.fill(0);
+  XS_LANES(l, 0, 64) {
+    idx.own(l) = ((l & (XS_PK - 1)) + skip) & 63;
+    jv.own(l) = v.meta.own(l) & 255;
+  }
+  const XsLv sm1 = v.sine_mapped.gather(idx); /* element (q, c) = sine_mapped[c + skip] */
+  const XsLv ga = sf_a.gather(jv), gb = sf_b.gather(jv);
+  XS_LANES(l, 0, 64) {
+    const int q = l / XS_PK, c = l & (XS_PK - 1);
+    if (q < ps.n && c < bands) {
+      const int meta = v.meta.own(l);
+      const int16_t sf = (int16_t)(q ? gb.own(l) : ga.own(l));
+      const int16_t nfl = noise_floor_all[xs_qsel(q, ps.nf_off) + ((meta >> 8) & 255)];
+      const int present = (meta >> 16) & 1;
+      const int16_t ref_e = (int16_t)((sf & 63) - 16), ref_m = (int16_t)(sf & 0xffc0);
+      const int16_t nm = (int16_t)(nfl & 0xffc0), ne = (int16_t)((nfl & 63) - 38);
+      int16_t g[2] = {0, 0}, nl[2] = {0, 0}, sn[2] = {0, 0};
+      const int32_t est = v.est.own(l);
+      const int mapped = c + skip < 64 ? (xs_qsel(q, ps.env) >= sm1.own(l)) : (xs_qsel(q, ps.env) >= 0);
+      xs_subbandgain(ref_m, nm, xs_m(est), xs_e(est), ne, ref_e, present, mapped, xs_qsel(q, ps.noise_absc), g, nl, sn);
+      v.e_orig.own(l) = xs_me(ref_m, ref_e);
+      v.gain.own(l) = xs_me(g[0], g[1]);
+      v.noise.own(l) = xs_me(nl[0], nl[1]);
+      v.sine.own(l) = xs_me(sn[0], sn[1]);
+    }
+  }
+}
+
+/* xs_noiselimiting for a pass.  band_of: xs_limiter_band_of (element c = band max_qmf_subband_aac + c).  The limiter bands
+   of envelope q are the recursion lanes 16 q .. 16 q + nlf - 1 and use rows 16 q + c of res_a / res_b; a band's operands sit
+   in row 32 q + c of fold_b. */
+FX_HD void xs_noiselimiting_pk(const XsCx &cx, const xaac_sbr_header *h, const XsPass &ps, int skip, int bands, XsEnv &v,
+                               XsWork *w, const int16_t *lim_tab, const XsLv &band_of) {
+  const int16_t lim_m = lim_tab[0], lim_e = lim_tab[1];
+  const int nlf = cx.uni(h->num_lf_bands);
+  XsLv idx, mine, key;
+  idx.fill(0);
+  XS_LANES(l, 0, 64) idx.own(l) = l & (XS_PK - 1);
+  const XsLv bo = band_of.gather(idx);
+  mine.fill(-1);
+  key.fill(-1);
+  XS_LANES(l, 0, 64) {
+    const int q = l / XS_PK, c = l & (XS_PK - 1);
+    if (q < ps.n && c < bands) {
+      mine.own(l) = bo.own(l);
+      key.own(l) = bo.own(l) < 0 ? -1 : 16 * q + bo.own(l);
+    }
+  }
+  {
+    XsLv eo, ee;
+    eo.fill(0);
+    ee.fill(0);
+    XS_LANES(l, 0, 64) {
+      eo.own(l) = xs_e(v.e_orig.own(l));
+      ee.own(l) = xs_e(v.est.own(l));
+    }
+    const XsLv po = xs_seg_running_max(cx, key, eo, 64), pe = xs_seg_running_max(cx, key, ee, 64);
+    XS_LANES(l, 0, 64) {
+      const int Eo = eo.own(l) > po.own(l) ? eo.own(l) : po.own(l), Ee = ee.own(l) > pe.own(l) ? ee.own(l) : pe.own(l);
+      w->fold_b[l][0] = fx_shr(xs_m(v.e_orig.own(l)), Eo - eo.own(l));
+      w->fold_b[l][1] = fx_shr(xs_m(v.est.own(l)), Ee - ee.own(l));
+      w->fold_b[l][2] = ((Eo - po.own(l)) & 0xff) | (((Ee - pe.own(l)) & 0xff) << 8);
+      w->fold_b[l][3] = (Eo & 0xffff) | (int32_t)((uint32_t)Ee << 16);
+    }
+  }
+  cx.sync();
+  XS_LANES(r, 0, 32) {
+    const int q = r >> 4, c = r & 15;
+    if (q < ps.n && c < nlf) {
+      const int t_lo = h->freq_band_tbl_lim[c], t_hi = h->freq_band_tbl_lim[c + 1];
+      int b0 = t_lo > skip ? t_lo - skip : 0, b1 = t_hi > skip ? t_hi - skip : 0;
+      if (b1 > bands) b1 = bands; /* (the bands of the pass: xs_pack_frame_ok has checked that the table ends there) */
+      if (b0 < b1) {
+        int32_t som = 0, sem = 0, last = 0;
+        XS_UNROLL4
+        for (int k = b0; k < b1; k++) {
+          const int32_t d = w->fold_b[XS_PK * q + k][2];
+          som = fx_shr(som, d & 255) + w->fold_b[XS_PK * q + k][0];
+          sem = fx_shr(sem, d >> 8) + w->fold_b[XS_PK * q + k][1];
+          last = w->fold_b[XS_PK * q + k][3];
+        }
+        int32_t soe = (int16_t)last, see = last >> 16;
+        int nv = 16 - xs_pnorm32(som);
+        if (nv > 0) {
+          som >>= nv;
+          soe += nv;
+        }
+        nv = 16 - xs_pnorm32(sem);
+        if (nv > 0) {
+          sem >>= nv;
+          see += nv;
+        }
+        const int16_t so_m = (int16_t)som, so_e = (int16_t)soe;
+        int16_t mg_m;
+        int16_t mg_e = (int16_t)(xs_fix_mant_div(so_m, (int16_t)sem, &mg_m) + (so_e - (int16_t)see) + 1);
+        int32_t mt = xs_mult16x16_shl(mg_m, lim_m);
+        mg_e = (int16_t)(mg_e + lim_e);
+        int tv = fx_norm32(mt);
+        mg_e = (int16_t)(mg_e - tv);
+        mg_m = (int16_t)(xs_shl(mt, tv) >> 16);
+        if (mg_e >= 34) {
+          mg_m = 0x3000;
+          mg_e = 34;
+        }
+        w->res_a[r][0] = mg_m;
+        w->res_a[r][1] = mg_e;
+        w->res_a[r][2] = so_m;
+        w->res_a[r][3] = so_e;
+      }
+    }
+  }
+  cx.sync();
+  {
+    XsLv a_m, a_e, b_me, emax, with_b;
+    a_m.fill(0);
+    a_e.fill(0);
+    b_me.fill(0);
+    emax.fill(0);
+    with_b.fill(0);
+    XS_LANES(l, 0, 64) {
+      const int c_of = mine.own(l);
+      if (c_of < 0) continue;
+      const int q = l / XS_PK, noise_absc = xs_qsel(q, ps.noise_absc);
+      const int16_t mg_m = w->res_a[16 * q + c_of][0], mg_e = w->res_a[16 * q + c_of][1];
+      int16_t gm = xs_m(v.gain.own(l)), ge = xs_e(v.gain.own(l));
+      if (ge > mg_e || (ge == mg_e && gm > mg_m)) {
+        int16_t na_m;
+        int na_e = xs_fix_mant_div(mg_m, gm, &na_m);
+        na_e += (mg_e - ge) + 1;
+        const int32_t nl = v.noise.own(l);
+        v.noise.own(l) =
+            xs_me((int16_t)(fx_shl_dir_sat_limit(xs_mult16x16_shl(xs_m(nl), na_m), (int16_t)na_e) >> 16), xs_e(nl));
+        gm = mg_m;
+        ge = mg_e;
+        v.gain.own(l) = xs_me(gm, ge);
+      }
+      a_m.own(l) = ((int32_t)gm * xs_m(v.est.own(l))) >> 15;
+      a_e.own(l) = ge + xs_e(v.est.own(l));
+      const int32_t sn = v.sine.own(l);
+      b_me.own(l) = xs_m(sn) != 0 ? sn : (noise_absc == 0 ? v.noise.own(l) : 0);
+      const bool has_b = xs_m(sn) != 0 || noise_absc == 0;
+      emax.own(l) = (has_b && xs_e(b_me.own(l)) > a_e.own(l)) ? xs_e(b_me.own(l)) : a_e.own(l);
+      with_b.own(l) = has_b ? 1 : 0;
+    }
+    const XsLv pm = xs_seg_running_max(cx, key, emax, 64);
+    XS_LANES(l, 0, 64) {
+      if (mine.own(l) < 0) continue;
+      const int has_b = with_b.own(l);
+      const int E0 = pm.own(l);
+      const int E1 = a_e.own(l) > E0 ? a_e.own(l) : E0;
+      const int eb = xs_e(b_me.own(l));
+      const int E2 = (has_b && eb > E1) ? eb : E1;
+      w->fold_b[l][0] = fx_shr(a_m.own(l), E1 - a_e.own(l));
+      w->fold_b[l][1] = has_b ? fx_shr(xs_m(b_me.own(l)), E2 - eb) : 0;
+      w->fold_b[l][2] = ((E1 - E0) & 0xff) | (((E2 - E1) & 0xff) << 8);
+      w->fold_b[l][3] = E2;
+    }
+  }
+  cx.sync();
+  XS_LANES(r, 0, 32) {
+    const int q = r >> 4, c = r & 15;
+    if (q < ps.n && c < nlf) {
+      const int t_lo = h->freq_band_tbl_lim[c], t_hi = h->freq_band_tbl_lim[c + 1];
+      int b0 = t_lo > skip ? t_lo - skip : 0, b1 = t_hi > skip ? t_hi - skip : 0;
+      if (b1 > bands) b1 = bands;
+      if (b0 < b1) {
+        const int16_t so_m = w->res_a[r][2], so_e = w->res_a[r][3];
+        int32_t am = 0, ae = 0;
+        XS_UNROLL4
+        for (int k = b0; k < b1; k++) {
+          const int32_t d = w->fold_b[XS_PK * q + k][2];
+          am = fx_shr(am, d & 255) + w->fold_b[XS_PK * q + k][0];
+          am = fx_shr(am, d >> 8) + w->fold_b[XS_PK * q + k][1];
+          ae = w->fold_b[XS_PK * q + k][3];
+        }
+        int nv = 16 - fx_norm32(am);
+        if (nv > 0) {
+          am >>= nv;
+          ae += nv;
+        }
+        int16_t bg_m;
+        int bg_e = xs_fix_mant_div(so_m, (int16_t)am, &bg_m);
+        bg_e = (int16_t)(bg_e + (so_e - (int16_t)ae) + 1);
+        if (bg_e > 2 || (bg_e == 2 && bg_m > 0x5061)) {
+          bg_m = 0x5061;
+          bg_e = 2;
+        }
+        w->res_b[r][0] = bg_m;
+        w->res_b[r][1] = (int16_t)bg_e;
+      }
+    }
+  }
+  cx.sync();
+  XS_LANES(l, 0, 64) {
+    const int c_of = mine.own(l);
+    if (c_of < 0) continue;
+    const int q = l / XS_PK;
+    const int16_t bg_m = w->res_b[16 * q + c_of][0], bg_e = w->res_b[16 * q + c_of][1];
+    const int32_t g = v.gain.own(l), sn = v.sine.own(l), nl = v.noise.own(l);
+    v.gain.own(l) = xs_me(xs_mult16_shl(xs_m(g), bg_m), (int16_t)(xs_e(g) + bg_e));
+    v.sine.own(l) = xs_me(xs_mult16_shl(xs_m(sn), bg_m), (int16_t)(xs_e(sn) + bg_e));
+    v.noise.own(l) = xs_me(xs_mult16_shl(xs_m(nl), bg_m), (int16_t)(xs_e(nl) + bg_e));
+  }
+  cx.sync();
+}
+
 /* env_calc.c:423 */
 FX_HD void xs_erg_to_amplitude_lp(const XsCx &cx, int bands, int16_t noise_e, XsEnv &v) {
   XS_LANES(k, 0, bands) {
@@ -1540,6 +1890,47 @@ FX_HD void xs_erg_to_amplitude_hq(const XsCx &cx, int bands, int16_t noise_e, Xs
     v.gain.own(k) = xs_me(g[0], g[1]);
     v.noise.own(k) = xs_me(nl[0], nl[1]);
   }
+}
+
+/* xs_erg_to_amplitude_hq for a pass (see "two envelopes side by side") */
+FX_HD void xs_erg_to_amplitude_hq_pk(const XsCx &cx, const XsPass &ps, int bands, XsEnv &v) {
+  XS_LANES(l, 0, 64) {
+    const int q = l / XS_PK, c = l & (XS_PK - 1);
+    if (q < ps.n && c < bands) {
+      const int noise_e = (int16_t)xs_qsel(q, ps.noise_e);
+      int16_t sn[2] = {xs_m(v.sine.own(l)), xs_e(v.sine.own(l))};
+      int16_t g[2] = {xs_m(v.gain.own(l)), xs_e(v.gain.own(l))};
+      int16_t nl[2] = {xs_m(v.noise.own(l)), xs_e(v.noise.own(l))};
+      xs_mant_exp_sqrt(sn);
+      xs_mant_exp_sqrt(g);
+      xs_mant_exp_sqrt(nl);
+      int shift = (noise_e - nl[1]) - 4;
+      if (shift > 0) {
+        if (shift > 31) shift = 31;
+        nl[0] = (int16_t)(nl[0] >> shift);
+      } else {
+        if (shift < -31) shift = -31;
+        nl[0] = (int16_t)xs_shl(nl[0], -shift);
+      }
+      v.sine.own(l) = xs_me(sn[0], sn[1]);
+      v.gain.own(l) = xs_me(g[0], g[1]);
+      v.noise.own(l) = xs_me(nl[0], nl[1]);
+    }
+  }
+}
+
+/* the regular frame the two-envelope chain is written for: energies per QMF band (interpol_freq), both frequency tables
+   spanning exactly the SBR range of at most 32 bands, the limiter table inside it.  Every frame the reference's own tables
+   (ixheaacd_freq_sca.c) describe at these widths passes; anything else runs the one-envelope chain. */
+FX_HD bool xs_pack_frame_ok(const XsCx &cx, const xaac_sbr_header *h) {
+  const int nhi = cx.uni(h->num_sf_bands[1]), nlo = cx.uni(h->num_sf_bands[0]), nlf = cx.uni(h->num_lf_bands);
+  const int sb_start = cx.uni(h->sub_band_start), sb_end = cx.uni(h->sub_band_end), nsb = sb_end - sb_start;
+  if (!cx.uni(h->interpol_freq) || nhi < 1 || nlo < 1 || nsb < 1 || nsb > XS_PK) return false;
+  if (cx.uni(h->freq_band_tbl_hi[0]) != sb_start || cx.uni(h->freq_band_tbl_lo[0]) != sb_start) return false;
+  if (cx.uni(h->freq_band_tbl_hi[nhi]) != sb_end || cx.uni(h->freq_band_tbl_lo[nlo]) != sb_end) return false;
+  int32_t bad = 0;
+  XS_LANES(c, 0, nlf + 1) bad |= h->freq_band_tbl_lim[c] > nsb;
+  return cx.wave_or(bad) == 0;
 }
 
 /* N slots of one band inside a segment of constant scale (xs_adapt_noise_gain_hq, step 2): the per-slot body of
@@ -2093,7 +2484,83 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
   const int tansient_env_prev = cx.uni(st->tansient_env_prev);
   const int hb_scale = cx.uni(st->hb_scale), lb_scale = cx.uni(st->lb_scale);
   const XsLv lim_of = xs_limiter_band_of(cx, h, skip);
-  for (int i = 0; i < num_env; i++) {
+  bool packed = false;
+  if constexpr (Q::HQ) packed = xs_pack_frame_ok(cx, h);
+  if constexpr (Q::HQ) if (packed) {
+    /* two envelopes per pass of the gain mathematics (see "two envelopes side by side") */
+    XsLv jn_hi, jn_lo;
+    xs_band_maps(cx, h, nsb, jn_hi, jn_lo);
+    const int bands = nsb - skip, input_e = 15 - hb_scale, nnf = cx.uni(h->num_nf_bands);
+    const int16_t *lim_tab = &xaac_sbr_lim_gains_m[2 * cx.uni(h->limiter_gains)];
+    int nf_off = 0;
+    for (int i = 0; i < num_env;) {
+      XsPass ps;
+      int s0[2], s1[2];
+      /* envelope i: the reference's checks, in its order */
+      s0[0] = 2 * cx.uni(border[i]);
+      s1[0] = 2 * cx.uni(border[i + 1]);
+      if (s0[0] >= 38 || s1[0] > 38) return -1;
+      if (nf_idx >= XAAC_SBR_MAX_NOISE_ENVELOPES) return -1;
+      if (cx.uni(border[i]) == cx.uni(f->noise_border_vec[nf_idx + 1])) {
+        nf_off += nnf;
+        nf_idx++;
+      }
+      ps.n = 1;
+      ps.env[0] = i;
+      ps.fr[0] = cx.uni(f->freq_res[i]);
+      ps.nf_off[0] = nf_off;
+      ps.noise_absc[0] = (i == transient_env || i == tansient_env_prev) ? 1 : 0;
+      ps.noise_e[0] = (int16_t)(s0[0] < 32 ? adj_e : final_e);
+      ps.env[1] = ps.fr[1] = ps.nf_off[1] = ps.noise_absc[1] = ps.noise_e[1] = 0;
+      s0[1] = s1[1] = 0;
+      /* envelope i + 1 rides along if it is a regular one behind envelope i: it would pass the same checks, and its slots lie
+         behind i's (its energies must not see i's adjusted slots before the reference would) */
+      if (i + 1 < num_env) {
+        const int t0 = 2 * cx.uni(border[i + 1]), t1 = 2 * cx.uni(border[i + 2]);
+        int nf2 = nf_idx, off2 = nf_off;
+        bool ok = !(t0 >= 38 || t1 > 38) && nf2 < XAAC_SBR_MAX_NOISE_ENVELOPES && s0[0] < s1[0] && s1[0] <= t0 && t0 < t1;
+        if (ok) {
+          if (cx.uni(border[i + 1]) == cx.uni(f->noise_border_vec[nf2 + 1])) {
+            off2 += nnf;
+            nf2++;
+          }
+          ps.n = 2;
+          s0[1] = t0;
+          s1[1] = t1;
+          ps.env[1] = i + 1;
+          ps.fr[1] = cx.uni(f->freq_res[i + 1]);
+          ps.nf_off[1] = off2;
+          ps.noise_absc[1] = (i + 1 == transient_env || i + 1 == tansient_env_prev) ? 1 : 0;
+          ps.noise_e[1] = (int16_t)(t0 < 32 ? adj_e : final_e);
+          nf_idx = nf2;
+          nf_off = off2;
+        }
+      }
+      /* energies: each envelope's own slots, side by side in v.est */
+      xs_energy_per_subband_pk(cx, x, ps, s0, s1, max_sb, bands, input_e, v.est);
+      XS_T(4);
+      xs_subband_gain_meta_pk(cx, ps, jn_hi, jn_lo, nsb, skip, v);
+      XS_T(5);
+      xs_calc_subband_gains_pk(cx, ps, xs_pick_env(sfv, ps.env[0]), xs_pick_env(sfv, ps.env[1]), noise_floor_all, bands, skip, v);
+      XS_T(6);
+      xs_noiselimiting_pk(cx, h, ps, skip, bands, v, w, lim_tab, lim_of);
+      XS_T(7);
+      xs_erg_to_amplitude_hq_pk(cx, ps, bands, v);
+      /* the envelopes' slots, one envelope after the other */
+      for (int q = 0; q < ps.n; q++) {
+        XsEnv vq;
+        vq.gain = q ? v.gain.shifted(cx, XS_PK) : v.gain;
+        vq.noise = q ? v.noise.shifted(cx, XS_PK) : v.noise;
+        vq.sine = q ? v.sine.shifted(cx, XS_PK) : v.sine;
+        const int smooth_length = ps.noise_absc[q] ? 0 : ((1 - cx.uni(h->smoothing_mode)) << 2);
+        xs_adapt_noise_gain_hq(cx, st, vq, ps.noise_e[q], nsb, skip, s0[q], s1[q], input_e, adj_e, final_e, max_sb,
+                               ps.noise_absc[q], smooth_length, x);
+      }
+      XS_T(10);
+      i += ps.n;
+    }
+  }
+  for (int i = packed ? num_env : 0; i < num_env; i++) {
     const int s0 = 2 * cx.uni(border[i]), s1 = 2 * cx.uni(border[i + 1]);
     if (s0 >= 38 || s1 > 38) return -1;
     const int fr = cx.uni(f->freq_res[i]);
