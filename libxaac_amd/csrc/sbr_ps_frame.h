@@ -120,11 +120,14 @@ FX_HD uint32_t xp_allpass_packed(uint32_t &d0, uint32_t new_pair, const XpPhase 
   return xp_pack16(in_re, in_im);
 }
 
-FX_HD int32_t xp_adj_word(int32_t v, int shift) { /* env_calc.c:1099 on one word */
-  if (shift == 0) return v;
+/* env_calc.c:1099 on one word, without a branch: a left count and a right count of which at most one is not zero (a shift
+   by zero is the identity either way).  Inside the slot walks the counts are lane constants; as three-way branches per word
+   the same thing cost a dozen scalar instructions around two vector ones. */
+FX_HD int32_t xp_adj_word(int32_t v, int shift) {
   if (shift > 31) shift = 31;
   if (shift < -31) shift = -31;
-  return shift > 0 ? fx_shlw(v, shift) : (v >> -shift);
+  const int shl = shift > 0 ? shift : 0, shr = shift < 0 ? -shift : 0;
+  return (int32_t)((uint32_t)v << shl) >> shr;
 }
 
 /* ps_dec.c:470-519: the eight transient-detector bins that live in the hybrid domain */
