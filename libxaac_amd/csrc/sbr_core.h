@@ -768,12 +768,14 @@ FX_HD int32_t xs_energy_of_subband(const Q &x, int s0, int s1, int k, int frame_
   int pre = xs_pnorm32(mx) - (Q::HQ ? 4 : 3);
   int32_t accu = 0;
   int shift = 16 - pre;
+  /* shift > 0 ? xs_sar(v, shift) : xs_shl(v, -shift) without the branch: one of the two counts is zero */
+  const int e_shr = shift > 0 ? shift & 31 : 0, e_shl = shift > 0 ? 0 : (-shift) & 31;
   XS_UNROLL4
   for (int l = 0; l < n; l++) {
-    int16_t t = shift > 0 ? (int16_t)xs_sar(x(s0 + l, k), shift) : (int16_t)xs_shl(x(s0 + l, k), -shift);
+    int16_t t = (int16_t)((int32_t)((uint32_t)x(s0 + l, k) << e_shl) >> e_shr);
     accu = fx_add(accu, (int32_t)t * t);
     if (Q::HQ) {
-      t = shift > 0 ? (int16_t)xs_sar(x.im(s0 + l, k), shift) : (int16_t)xs_shl(x.im(s0 + l, k), -shift);
+      t = (int16_t)((int32_t)((uint32_t)x.im(s0 + l, k) << e_shl) >> e_shr);
       accu = fx_add(accu, (int32_t)t * t);
     }
   }
@@ -1371,12 +1373,13 @@ FX_HD void xs_energy_per_subband_pk(const XsCx &cx, const Q &x, const XsPass &ps
       const int pre = xs_pnorm32(mx) - 4;
       int32_t accu = 0;
       int shift = 16 - pre;
+      const int e_shr = shift > 0 ? shift & 31 : 0, e_shl = shift > 0 ? 0 : (-shift) & 31;
       XS_UNROLL4
       for (int j = 0; j < nmax; j++) {
         const int row = first + (j < n ? j : n - 1);
-        int16_t t = shift > 0 ? (int16_t)xs_sar(x(row, k), shift) : (int16_t)xs_shl(x(row, k), -shift);
+        int16_t t = (int16_t)((int32_t)((uint32_t)x(row, k) << e_shl) >> e_shr);
         accu = fx_add(accu, j < n ? (int32_t)t * t : 0);
-        t = shift > 0 ? (int16_t)xs_sar(x.im(row, k), shift) : (int16_t)xs_shl(x.im(row, k), -shift);
+        t = (int16_t)((int32_t)((uint32_t)x.im(row, k) << e_shl) >> e_shr);
         accu = fx_add(accu, j < n ? (int32_t)t * t : 0);
       }
       if (accu != 0) {
@@ -2281,29 +2284,26 @@ FX_HD void xs_patch_band_hq(const xaac_sbr_header *h, const Q &x, int lb, int hb
   bw = xs_mult16_shl_sat(bw, bw);
   const int16_t a1r = xs_mult16_shl_sat(bw, alpha[2]), a1i = xs_mult16_shl_sat(bw, alpha[3]);
   const int n = stop_idx - start_idx;
-  if (bw > 0) {
-    int32_t p2r = x(start_idx - 2, lb), p2i = x.im(start_idx - 2, lb);
-    int32_t p1r = x(start_idx - 1, lb), p1i = x.im(start_idx - 1, lb);
-    XS_UNROLL4
-    for (int i = 0; i < n; i++) {
-      const int32_t cr = x(start_idx + i, lb), ci = x.im(start_idx + i, lb);
-      int32_t acc = fx_sub(fx_add(fx_sub(fx_mul32x16(p1r, a0r), fx_mul32x16(p1i, a0i)), fx_mul32x16(p2r, a1r)),
-                           fx_mul32x16(p2i, a1i));
-      x(start_idx + i, hb) = fx_add(cr >> 2, fx_shlw(acc, 1));
-      acc = fx_add(fx_add_sat(fx_add_sat(fx_mul32x16(p1r, a0i), fx_mul32x16(p1i, a0r)), fx_mul32x16(p2r, a1i)),
-                   fx_mul32x16(p2i, a1r));
-      x.im(start_idx + i, hb) = fx_add(ci >> 2, fx_shlw(acc, 1));
-      p2r = p1r;
-      p2i = p1i;
-      p1r = cr;
-      p1i = ci;
-    }
-  } else {
-    XS_UNROLL4
-    for (int i = 0; i < n; i++) {
-      x(start_idx + i, hb) = x(start_idx + i, lb) >> 2;
-      x.im(start_idx + i, hb) = x.im(start_idx + i, lb) >> 2;
-    }
+  /* where the chirp factor is not positive the reference copies x >> 2 (lpp_tran.c:1239-1248): that is this filter with
+     all four coefficients at zero -- its sums are zero then --, so every lane walks the one loop */
+  const bool filt = bw > 0;
+  const int16_t c0r = filt ? a0r : (int16_t)0, c0i = filt ? a0i : (int16_t)0, c1r = filt ? a1r : (int16_t)0,
+                c1i = filt ? a1i : (int16_t)0;
+  int32_t p2r = x(start_idx - 2, lb), p2i = x.im(start_idx - 2, lb);
+  int32_t p1r = x(start_idx - 1, lb), p1i = x.im(start_idx - 1, lb);
+  XS_UNROLL4
+  for (int i = 0; i < n; i++) {
+    const int32_t cr = x(start_idx + i, lb), ci = x.im(start_idx + i, lb);
+    int32_t acc = fx_sub(fx_add(fx_sub(fx_mul32x16(p1r, c0r), fx_mul32x16(p1i, c0i)), fx_mul32x16(p2r, c1r)),
+                         fx_mul32x16(p2i, c1i));
+    x(start_idx + i, hb) = fx_add(cr >> 2, fx_shlw(acc, 1));
+    acc = fx_add(fx_add_sat(fx_add_sat(fx_mul32x16(p1r, c0i), fx_mul32x16(p1i, c0r)), fx_mul32x16(p2r, c1i)),
+                 fx_mul32x16(p2i, c1r));
+    x.im(start_idx + i, hb) = fx_add(ci >> 2, fx_shlw(acc, 1));
+    p2r = p1r;
+    p2i = p1i;
+    p1r = cr;
+    p1i = ci;
   }
 }
 

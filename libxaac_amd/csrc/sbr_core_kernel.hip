@@ -118,16 +118,6 @@ __device__ __forceinline__ void copy_words(int32_t *dst, const int32_t *src, int
     if (i + 64 * j < n) dst[i + 64 * j] = t[j];
 }
 
-/* word i of a run of matrix rows as global memory lays them out (HQ: 64 real | 64 imaginary per row, LP: 64 real) ->
-   its place in the LDS rows of NB bands, or -1 for a band the narrow rows do not hold */
-template <int HQ, int NB>
-__device__ __forceinline__ int lds_word(int i) {
-  constexpr int ROWG = HQ ? 128 : 64, ROW = XsQmfT<HQ, NB>::ROW;
-  if (NB == 64) return i;
-  const int row = i / ROWG, gc = i % ROWG, band = gc & 63, part = gc >> 6;
-  return band < NB ? row * ROW + part * NB + band : -1;
-}
-
 /* one channel-frame; returns false when the stream has to go through the 64-band rows (nothing written then) */
 template <int HQ, int NB>
 __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int ch, XsLds<HQ, NB> &s, const int lane) {
@@ -179,11 +169,13 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
     for (int i = lane; i < 2 * ROW; i += 64) s.x[i] = 0;
     if (!HQ)
       for (int i = lane; i < 128; i += 64) s.x[XAAC_SBR_X_ROWS * ROW + i] = 0;
+    /* a run of 64 words of a global row is one part (real | imaginary) of one slot with band = lane (HQ), or one slot
+       (LP): the LDS place follows from j and the lane with one predicate, band < NB */
 #pragma unroll
     for (int j = 0; j < NOV; j++) {
-      const int d = lds_word<HQ, NB>(lane + 64 * j);
-      if (d >= 0)
-        s.x[2 * ROW + d] = r_ov[j];
+      const int row = HQ ? j >> 1 : j, part = HQ ? j & 1 : 0;
+      if (NB == 64 || lane < NB)
+        s.x[(2 + row) * ROW + part * NB + lane] = r_ov[j];
       else
         above |= r_ov[j];
     }
@@ -271,24 +263,33 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
   }
   xs_wave_sync();
   /* slots 0..31 for synthesis (+ 32..37 for PS); bands the narrow rows do not hold are 0 */
-  for (int i0 = lane; i0 < 38 * ROWG; i0 += 64 * 8) {
-    int32_t t[8];
+  {
+    constexpr int NW = 38 * ROWG / 64; /* runs of 64 words: (slot, part) with band = lane */
+    const bool held = NB == 64 || lane < NB;
 #pragma unroll
-    for (int j = 0; j < 8; j++)
-      if (i0 + 64 * j < 38 * ROWG) {
-        const int d = lds_word<HQ, NB>(i0 + 64 * j);
-        t[j] = d >= 0 ? s.x[2 * ROW + d] : 0;
-      }
+    for (int j0 = 0; j0 < NW; j0 += 8) {
+      int32_t t[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++)
-      if (i0 + 64 * j < 38 * ROWG) gx[2 * ROWG + i0 + 64 * j] = t[j];
+      for (int j = 0; j < 8; j++)
+        if (j0 + j < NW) {
+          const int row = HQ ? (j0 + j) >> 1 : j0 + j, part = HQ ? (j0 + j) & 1 : 0;
+          t[j] = 0;
+          if (held) t[j] = s.x[(2 + row) * ROW + part * NB + lane];
+        }
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        if (j0 + j < NW) gx[2 * ROWG + 64 * (j0 + j) + lane] = t[j];
+    }
   }
   {
     int32_t *gw = reinterpret_cast<int32_t *>(gst);
     /* sbr_dec.c:1283-1291 copies 6 * 64 words in either mode: in HQ the first three of the six slots */
-    for (int i = lane; i < 6 * 64; i += 64) {
-      const int d = lds_word<HQ, NB>(i);
-      gw[offsetof(xaac_sbr_state, overlap) / 4 + i] = d >= 0 ? s.x[(2 + 32) * ROW + d] : 0;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      const int row = HQ ? j >> 1 : j, part = HQ ? j & 1 : 0;
+      int32_t t = 0;
+      if (NB == 64 || lane < NB) t = s.x[(2 + 32 + row) * ROW + part * NB + lane];
+      gw[offsetof(xaac_sbr_state, overlap) / 4 + 64 * j + lane] = t;
     }
     const int32_t *m = reinterpret_cast<const int32_t *>(&s.st);
     if (lane < 2) gw[kHeadOff / 4 + lane] = m[lane];
