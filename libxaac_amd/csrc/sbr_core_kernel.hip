@@ -171,13 +171,15 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
       for (int i = lane; i < 128; i += 64) s.x[XAAC_SBR_X_ROWS * ROW + i] = 0;
     /* a run of 64 words of a global row is one part (real | imaginary) of one slot with band = lane (HQ), or one slot
        (LP): the LDS place follows from j and the lane with one predicate, band < NB */
+    const bool held = NB == 64 || lane < NB;
 #pragma unroll
-    for (int j = 0; j < NOV; j++) {
-      const int row = HQ ? j >> 1 : j, part = HQ ? j & 1 : 0;
-      if (NB == 64 || lane < NB)
+    for (int j = 0; j < NOV; j++) above |= held ? 0 : r_ov[j];
+    if (held) { /* one predicated region for the twelve stores */
+#pragma unroll
+      for (int j = 0; j < NOV; j++) {
+        const int row = HQ ? j >> 1 : j, part = HQ ? j & 1 : 0;
         s.x[(2 + row) * ROW + part * NB + lane] = r_ov[j];
-      else
-        above |= r_ov[j];
+      }
     }
 #pragma unroll
     for (int j = 0; j < NAS; j++) {
@@ -266,6 +268,7 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
   {
     constexpr int NW = 38 * ROWG / 64; /* runs of 64 words: (slot, part) with band = lane */
     const bool held = NB == 64 || lane < NB;
+    const int lane_h = held ? lane : 0; /* every lane reads (a select, not a predicated region per word) */
 #pragma unroll
     for (int j0 = 0; j0 < NW; j0 += 8) {
       int32_t t[8];
@@ -273,8 +276,8 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
       for (int j = 0; j < 8; j++)
         if (j0 + j < NW) {
           const int row = HQ ? (j0 + j) >> 1 : j0 + j, part = HQ ? (j0 + j) & 1 : 0;
-          t[j] = 0;
-          if (held) t[j] = s.x[(2 + row) * ROW + part * NB + lane];
+          const int32_t v = s.x[(2 + row) * ROW + part * NB + lane_h];
+          t[j] = held ? v : 0;
         }
 #pragma unroll
       for (int j = 0; j < 8; j++)
@@ -287,9 +290,9 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
 #pragma unroll
     for (int j = 0; j < 6; j++) {
       const int row = HQ ? j >> 1 : j, part = HQ ? j & 1 : 0;
-      int32_t t = 0;
-      if (NB == 64 || lane < NB) t = s.x[(2 + 32 + row) * ROW + part * NB + lane];
-      gw[offsetof(xaac_sbr_state, overlap) / 4 + 64 * j + lane] = t;
+      const bool held = NB == 64 || lane < NB;
+      const int32_t v = s.x[(2 + 32 + row) * ROW + part * NB + (held ? lane : 0)];
+      gw[offsetof(xaac_sbr_state, overlap) / 4 + 64 * j + lane] = held ? v : 0;
     }
     const int32_t *m = reinterpret_cast<const int32_t *>(&s.st);
     if (lane < 2) gw[kHeadOff / 4 + lane] = m[lane];
