@@ -282,19 +282,20 @@ FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_f
 #endif
         }
         const int gsh = sb < 11 ? 0 : (sb < 18 ? 1 : (sb < 23 ? 2 : (sb < 35 ? 3 : 4))); /* group_shift of the band's group */
+        /* where the band's power goes: bands 3..8 are bins of their own, bands 9.. addends of the group sums, bands 0..2
+           (whose bins come from the hybrid sub-bands) write the spare column 55 of gsum -- one store per slot through a
+           lane pointer and a lane stride instead of a tree of predicated regions */
+        const bool own_bin = sb >= 3 && sb < 9;
+        int32_t *dst = sb < 3 ? &w->gsum[0][55] : (own_bin ? &w->binpw[8 * c][sb + 5] : &w->gsum[0][sb - 9]);
+        const int dstride = own_bin ? 20 : 56;
         XP_UNROLL
         for (int ls = 0; ls < 8; ls++) {
           const int l = 8 * c + ls;
           const int usb_l = l >= clear_slot ? usb : usb_prev;
           const int sh = sb < lsb ? (l < 6 ? ov_lb_shift : lb_shift) : (sb < usb ? hb_shift : 0);
           const int32_t re = xp_adj_word(rre[ls], sh), im = xp_adj_word(rim[ls], sh);
-          if (sb >= 3) {
-            const int32_t pw = xp_power(re, im);
-            if (sb < 9)
-              w->binpw[l][sb + 5] = pw;
-            else
-              w->gsum[ls][sb - 9] = sb < usb_l ? (pw >> gsh) : 0;
-          }
+          const int32_t pw = xp_power(re, im);
+          dst[ls * dstride] = own_bin ? pw : (sb < usb_l ? (pw >> gsh) : 0);
         }
       }
       cx.sync();
