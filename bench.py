@@ -356,7 +356,7 @@ def secondary_end_to_end(copies=4096):
 
 def secondary_esbr(torch, libxaac_amd, ctx, dev, steps, warmup):
     """The same HE-AACv2 streams through the reference's DEFAULT SBR path (-esbr:1, "Path A": 32-bit-ring QMF banks, float
-    LPP transposer / envelope adjuster / parametric stereo): xaac_esbr_sbr_process_batch on float core
+    LPP transposer / envelope adjuster / parametric stereo; docs/NOTEBOOK.md 5f): xaac_esbr_sbr_process_batch on float core
     samples, 8192 streams per step, side info tiled from 64 reference-captured HE-AACv2 frames with synthetic float
     envelope data.  One frame step of the 64 distinct set-ups is compared word for word with the oracle chain."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -423,7 +423,7 @@ def secondary_esbr(torch, libxaac_amd, ctx, dev, steps, warmup):
     ms = e0.elapsed_time(e1) / steps
     ab = n * (4096 + 2 * 8192 + 2 * st.shape[1] + 2 * pst.shape[1] + pf.shape[1] + hd.shape[1] + fr.shape[1] + sd.shape[1])
     # the same with every stream's QMF harmonic transposer tracked, as the reference runs it on each frame of such a stream
-    # (its output is only read by frames with harmonic SBR): two more launches per step
+    # (docs/NOTEBOOK.md 5h; its output is only read by frames with harmonic SBR): two more launches per step
     from hbe_structs import state_from_tables
     hbs = [state_from_tables(h.freq_band_tbl_lo[:h.num_sf_bands[0] + 1], h.freq_band_tbl_hi[:h.num_sf_bands[1] + 1]) for h in hs]
     hb = tile(hbs)

@@ -11,7 +11,7 @@
  * overlap_out_copy (lpfuncs.c:94-345), over_lap_add1/2 (block.c:1193-1240) and
  * the WORD32->WORD16 hand-off (api.c:353-366 / peak_limiter.c:324 + api.c:3676).
  *
- * MI355X mapping:
+ * MI355X mapping (docs/NOTEBOOK.md §3-4):
  *   - persistent grid; a 256-thread workgroup = 4 independent waves, each wave
  *     loops over channel-frames (no __syncthreads in the loop, LDS regions are
  *     private to a wave, a wave's DS ops retire in order).

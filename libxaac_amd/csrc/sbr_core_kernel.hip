@@ -81,7 +81,7 @@ static_assert(offsetof(xaac_sbr_frame, int_noise_floor) == kFrameHeadBytes + siz
 /* NB: bands a matrix row holds in LDS ("narrow rows").  The reference's rows have 64 bands; an SBR range that ends at
    band 48 or below (sub_band_end, patches, tables, bank limits, nothing left above in the overlap slots) never touches
    the rest, and 40 x 2 x 48 words instead of 40 x 2 x 64 let eight waves share a CU's LDS instead of six -- the kernel
-   is latency bound, its throughput follows the number of resident waves (profiles/r03_b_core_occupancy.txt).  A stream
+   is latency bound, its throughput follows the number of resident waves (measured with padded LDS: 4, 5, 6 waves per CU gave 528, 483, 348 us, docs/NOTEBOOK.md 5k).  A stream
    that does not qualify is appended to a list and runs through the 64-band instantiation in a second, list-driven
    launch: same code, same results. */
 template <int HQ, int NB>

@@ -1,4 +1,4 @@
-"""Multi-GPU plumbing for the stream-sharded path (DESIGN.md §6): one process per
+"""Multi-GPU plumbing for the stream-sharded path (DESIGN.md §7): one process per
 GPU, contiguous stream ranges per rank, no data-path collective.  torch.distributed
 (backend "nccl" = RCCL on ROCm, "gloo" in the CPU tests) is used only for the
 barrier, the max-over-ranks timing and the optional final PCM gather."""

@@ -273,7 +273,7 @@ int32_t xaac_parse_batch_run(const xaac_parse_batch *b) {
   std::atomic<int> ok{0};
   /* default: half the machine's hardware threads, at most 48 -- measured on a 2 x 64-core host (tools/bench_parser_scaling.py):
      3 - 4 x 10^6 HE-AACv2 frames/s at 32 .. 48 threads, less from 64 on (4096 streams x 20 KB of parser state are a
-     latency-bound walk through memory that the second socket's threads only slow down) */
+     latency-bound walk through memory that the second socket's threads only slow down; docs/NOTEBOOK.md 5l) */
   int hw = (int)std::thread::hardware_concurrency();
   int threads = b->threads > 0 ? b->threads : (hw >= 4 ? (hw / 2 > 48 ? 48 : hw / 2) : (hw > 0 ? hw : 1));
   if (threads > (b->n_streams + 3) / 4) threads = b->n_streams > 0 ? (b->n_streams + 3) / 4 : 1;
