@@ -2391,12 +2391,36 @@ FX_HD void xs_hf_generator_hq(const XsCx &cx, const xaac_sbr_header *h, ST *st, 
     }
     src.own(hb) = best;
   }
-  const XsLv a01 = al01.gather(src), a23 = al23.gather(src);
-  XS_LANES(hb, 0, 64) {
-    const int lb = src.own(hb);
-    if (lb >= 0) {
-      const int16_t alpha[4] = {xs_m(a01.own(hb)), xs_e(a01.own(hb)), xs_m(a23.own(hb)), xs_e(a23.own(hb))};
-      xs_patch_band_hq(h, x, lb, hb, alpha, w->bw_array, start_idx, stop_idx);
+  /* The patch filter is a FIR over the low band's column (it reads x[n-1], x[n-2] of the SOURCE), so a high band's slots can
+     be dealt out: when the patched bands fit 32 lanes (they lie at or above max_qmf_subband), lane 32 g + c takes half g of
+     band max_qmf_subband + c's slots -- twice the lanes busy, half the walk. */
+  int32_t wide = 0;
+  XS_LANES(hb, 0, 64) wide |= src.own(hb) >= 0 && (hb < max_qmf_subband || hb >= max_qmf_subband + 32);
+  if (cx.wave_or(wide) == 0 && max_qmf_subband >= 0 && stop_idx - start_idx >= 8) {
+    XsLv idx;
+    idx.fill(0);
+    XS_LANES(l, 0, 64) idx.own(l) = (max_qmf_subband + (l & 31)) & 63;
+    const XsLv src2 = src.gather(idx);
+    XsLv srcc;
+    srcc.fill(0);
+    XS_LANES(l, 0, 64) srcc.own(l) = (max_qmf_subband + (l & 31) < 64) ? src2.own(l) : -1;
+    const XsLv b01 = al01.gather(srcc), b23 = al23.gather(srcc);
+    const int mid = start_idx + ((stop_idx - start_idx + 1) >> 1);
+    XS_LANES(l, 0, 64) {
+      const int lb = srcc.own(l), hb = max_qmf_subband + (l & 31);
+      if (lb >= 0) {
+        const int16_t alpha[4] = {xs_m(b01.own(l)), xs_e(b01.own(l)), xs_m(b23.own(l)), xs_e(b23.own(l))};
+        xs_patch_band_hq(h, x, lb, hb, alpha, w->bw_array, l < 32 ? start_idx : mid, l < 32 ? mid : stop_idx);
+      }
+    }
+  } else {
+    const XsLv a01 = al01.gather(src), a23 = al23.gather(src);
+    XS_LANES(hb, 0, 64) {
+      const int lb = src.own(hb);
+      if (lb >= 0) {
+        const int16_t alpha[4] = {xs_m(a01.own(hb)), xs_e(a01.own(hb)), xs_m(a23.own(hb)), xs_e(a23.own(hb))};
+        xs_patch_band_hq(h, x, lb, hb, alpha, w->bw_array, start_idx, stop_idx);
+      }
     }
   }
   cx.sync();
