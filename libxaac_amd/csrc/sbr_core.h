@@ -2012,16 +2012,29 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
   }
   cx.sync();
   /* band values seen from the lane that owns filter-buffer entry i = skip + k */
-  const XsLv gain_i = v.gain.shifted(cx, -skip), noise_i = v.noise.shifted(cx, -skip),
-             sine_i = v.sine.shifted(cx, -skip);
+  XsLv gain_i = v.gain.shifted(cx, -skip), noise_i = v.noise.shifted(cx, -skip), sine_i = v.sine.shifted(cx, -skip);
+  /* With at most 32 entries the two halves of the wave share the walk: lane 32 g + i takes half g of every segment's slots
+     of entry i (a slot's result depends on its number only -- random phase, harmonic index -- once the smoothed start is
+     over; the smoothed slots, a recursion, stay with g = 0, and so does everything that is written to the state). */
+  const bool two = nsb <= 32;
+  if (two) {
+    XsLv idx;
+    idx.fill(0);
+    XS_LANES(l, 0, 64) idx.own(l) = l & 31;
+    gain_i = gain_i.gather(idx);
+    noise_i = noise_i.gather(idx);
+    sine_i = sine_i.gather(idx);
+  }
   XsLv noise_out;
   noise_out.fill(0);
   XS_T(21);
-  XS_LANES(i, 0, nsb) {
+  XS_LANES(li, 0, two ? 64 : nsb) {
+    const int g = two ? li >> 5 : 0, i = two ? li & 31 : li;
+    if (i >= nsb) continue;
     const int k = i - skip;
-    const int16_t gm = xs_m(gain_i.own(i)), ge = xs_e(gain_i.own(i));
-    const int16_t sm = xs_m(sine_i.own(i)), se = xs_e(sine_i.own(i));
-    int16_t nl = xs_m(noise_i.own(i));
+    const int16_t gm = xs_m(gain_i.own(li)), ge = xs_e(gain_i.own(li));
+    const int16_t sm = xs_m(sine_i.own(li)), se = xs_e(sine_i.own(li));
+    int16_t nl = xs_m(noise_i.own(li));
     int16_t fbm = st->filt_buf_me[2 * i], fbn = st->filt_buf_noise_m[i];
     int ne = noise_e, fbe = fb_noise_e0, ph = ph0, harm = harm0;
     const int harm_lane0 = st->harm_index; /* = harm0, but a per-lane value on the GPU (see xs_apply_slots_hq) */
@@ -2087,8 +2100,10 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
         re = xs_mac16x16_shl_sat(re, (int16_t)(rp >> 16), snz);
         im = xs_mac16x16_shl_sat(im, (int16_t)rp, snz);
       }
-      x(l, col) = re;
-      x.im(l, col) = im;
+      if (g == 0) {
+        x(l, col) = re;
+        x.im(l, col) = im;
+      }
     }
     /* 2. the rest in at most two segments, slots below 32 and from 32 on: inside a segment every per-slot quantity
        but the random phase and the harmonic index is a constant of the band, so the slots go in bursts of eight
@@ -2129,24 +2144,33 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
       a.col = col;
       a.step = bands;
       a.kk = kk;
-      a.harm_lane = (harm_lane0 + (l - s0)) & 3;
-      for (; l + 8 <= seg_end; l += 8) xs_apply_slots_hq<8>(x, a, l, ph, harm);
-      if (l + 4 <= seg_end) {
-        xs_apply_slots_hq<4>(x, a, l, ph, harm);
-        l += 4;
+      /* this lane's share of the segment's slots [l, seg_end) */
+      const int count = seg_end - l, half = two ? (count + 1) >> 1 : count;
+      int lg = g ? l + half : l, phg = g ? (ph + half * bands) & 511 : ph, harmg = g ? (harm + half) & 3 : harm;
+      const int end_g = g ? seg_end : l + half;
+      a.harm_lane = (harm_lane0 + (lg - s0)) & 3;
+      for (; lg + 8 <= end_g; lg += 8) xs_apply_slots_hq<8>(x, a, lg, phg, harmg);
+      if (lg + 4 <= end_g) {
+        xs_apply_slots_hq<4>(x, a, lg, phg, harmg);
+        lg += 4;
       }
-      if (l + 2 <= seg_end) {
-        xs_apply_slots_hq<2>(x, a, l, ph, harm);
-        l += 2;
+      if (lg + 2 <= end_g) {
+        xs_apply_slots_hq<2>(x, a, lg, phg, harmg);
+        lg += 2;
       }
-      if (l < seg_end) {
-        xs_apply_slots_hq<1>(x, a, l, ph, harm);
-        l += 1;
+      if (lg < end_g) {
+        xs_apply_slots_hq<1>(x, a, lg, phg, harmg);
+        lg += 1;
       }
+      ph = (ph + count * bands) & 511;
+      harm = (harm + count) & 3;
+      l = seg_end;
     }
-    st->filt_buf_me[2 * i] = fbm;
-    st->filt_buf_noise_m[i] = fbn;
-    noise_out.own(i) = nl;
+    if (g == 0) {
+      st->filt_buf_me[2 * i] = fbm;
+      st->filt_buf_noise_m[i] = fbn;
+      noise_out.own(li) = nl;
+    }
   }
   cx.sync();
   XS_T(22);
