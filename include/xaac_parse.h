@@ -126,7 +126,8 @@ typedef struct xaac_parse_batch {
   int32_t with_sbr;           /* also decode the SBR / PS side info (ps_enable as in xaac_parse_sbr_side) */
   int32_t ps_enable;
   int32_t stage;              /* as in xaac_parse_adts_frame */
-  int32_t threads;            /* worker threads (the caller counts as one), <= 0: half the hardware threads, at most 48 */
+  int32_t threads;            /* worker threads (the caller counts as one), <= 0: half the hardware threads, at most 48 and at most
+                                 twice what the scheduler affinity and the cgroup CPU quota grant the process */
   xaac_parser *const *parser; /* [n_streams] */
   const uint8_t *const *data; /* [n_streams] the frame's first byte */
   const uint64_t *bytes;      /* [n_streams] bytes available there */

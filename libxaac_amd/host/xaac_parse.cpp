@@ -11,6 +11,9 @@
 #include <thread>
 #include <vector>
 #include <limits.h>
+#include <sched.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <linux/futex.h>
 #include <string.h>
 #include <sys/syscall.h>
@@ -47,6 +50,34 @@ inline void cpu_relax() {
 #if defined(__x86_64__) || defined(__i386__)
   __builtin_ia32_pause();
 #endif
+}
+/* CPUs this process can run on at once: the scheduler affinity mask, cut by the cgroup CPU quota (v2 cpu.max, v1
+   cpu.cfs_quota_us / cpu.cfs_period_us) when there is one; 0 = unknown */
+int usable_cpus() {
+  int n = 0;
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+  double quota = 0;
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[32] = {0};
+    long long period = 0;
+    if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) quota = atof(q) / (double)period;
+    fclose(f);
+  } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+    long long qv = 0, period = 0;
+    if (fscanf(g, "%lld", &qv) == 1 && qv > 0) {
+      if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+        if (fscanf(h, "%lld", &period) == 1 && period > 0) quota = (double)qv / (double)period;
+        fclose(h);
+      }
+    }
+    fclose(g);
+  }
+  if (quota > 0) {
+    const int q = (int)(quota + 0.5) < 1 ? 1 : (int)(quota + 0.5);
+    if (n == 0 || q < n) n = q;
+  }
+  return n;
 }
 class Team {
  public:
@@ -274,8 +305,13 @@ int32_t xaac_parse_batch_run(const xaac_parse_batch *b) {
   /* default: half the machine's hardware threads, at most 48 -- measured on a 2 x 64-core host (tools/bench_parser_scaling.py):
      3 - 4 x 10^6 HE-AACv2 frames/s at 32 .. 48 threads, less from 64 on (4096 streams x 20 KB of parser state are a
      latency-bound walk through memory that the second socket's threads only slow down; docs/NOTEBOOK.md 5l) */
+  static const int usable = usable_cpus(); /* what the process may really use: a container lists 256 CPUs and grants 16 */
   int hw = (int)std::thread::hardware_concurrency();
   int threads = b->threads > 0 ? b->threads : (hw >= 4 ? (hw / 2 > 48 ? 48 : hw / 2) : (hw > 0 ? hw : 1));
+  /* ... and at most twice what the process is granted: measured on a box that lists 256 CPUs and grants 16
+     (tools/bench_parser_scaling.py, 4096 HE-AACv2 streams): 16 threads 1.9, 32 threads 2.9, 48 threads 1.6, 96 threads
+     0.85 x 10^6 frames/s -- the workers wait on memory, so some oversubscription pays; spinning ones beyond it steal time */
+  if (b->threads <= 0 && usable > 0 && threads > 2 * usable) threads = 2 * usable;
   if (threads > (b->n_streams + 3) / 4) threads = b->n_streams > 0 ? (b->n_streams + 3) / 4 : 1;
   team().run(b->n_streams, threads, [&](int i) {
     xaac_parser *p = b->parser[i];
