@@ -460,6 +460,9 @@ FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_f
           const uint32_t q = xp_pack16(q_re, q_im);
           /* the chain */
           if (l == clear_slot) { /* (uniform) the three links' lines of the bands that just became active */
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile(""); /* keeps this a scalar branch taken once per frame: as twelve selects it ran in every slot */
+#endif
             const int c = qmf_chain && sb >= clear_lo && sb < clear_hi;
             XP_UNROLL
             for (int m = 0; m < 3; m++) r0[m] = c ? 0u : r0[m];
