@@ -303,7 +303,19 @@ FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_f
         const int ls = i / 6, g = i % 6;
         const int b0 = T->borders_group[16 + g], b1 = T->borders_group[17 + g];
         int32_t acc = 0;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(XP_OLD_GSUM)
+        /* the same saturating adds in the same order, eight addends fetched at a time (a group has up to 29: one LDS
+           latency per eight instead of one per addend; slots past the group's end re-read its last word and add zero) */
+        for (int sb = b0; sb < b1; sb += 8) {
+          int32_t t[8];
+          XP_UNROLL
+          for (int j = 0; j < 8; j++) t[j] = w->gsum[ls][(sb + j < b1 ? sb + j : b1 - 1) - 9];
+          XP_UNROLL
+          for (int j = 0; j < 8; j++) acc = fx_add_sat(acc, sb + j < b1 ? t[j] : 0);
+        }
+#else
         for (int sb = b0; sb < b1; sb++) acc = fx_add_sat(acc, w->gsum[ls][sb - 9]);
+#endif
         w->binpw[8 * c + ls][14 + g] = acc;
       }
       cx.sync();
