@@ -2533,7 +2533,9 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
   const int hb_scale = cx.uni(st->hb_scale), lb_scale = cx.uni(st->lb_scale);
   const XsLv lim_of = xs_limiter_band_of(cx, h, skip);
   bool packed = false;
+#ifndef XS_NO_ENV_PAIRS /* (a checker build runs every frame through the one-envelope chain: tests/test_env_pairs_cpu.py) */
   if constexpr (Q::HQ) packed = xs_pack_frame_ok(cx, h);
+#endif
   if constexpr (Q::HQ) if (packed) {
     /* two envelopes per pass of the gain mathematics (see "two envelopes side by side") */
     XsLv jn_hi, jn_lo;
