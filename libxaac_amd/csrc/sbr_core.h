@@ -2543,21 +2543,30 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
     const int bands = nsb - skip, input_e = 15 - hb_scale, nnf = cx.uni(h->num_nf_bands);
     const int16_t *lim_tab = &xaac_sbr_lim_gains_m[2 * cx.uni(h->limiter_gains)];
     int nf_off = 0;
+    /* the frame's borders, resolutions and noise borders as lane vectors: a scalar of the pass loop is then a v_readlane,
+       not an LDS round trip (with the wave stalled on it) each */
+    XsLv bordv, resv, nbordv;
+    bordv.fill(0);
+    resv.fill(0);
+    nbordv.fill(0);
+    XS_LANES(j, 0, XAAC_SBR_MAX_ENVELOPES + 1) bordv.own(j) = border[j];
+    XS_LANES(j, 0, XAAC_SBR_MAX_ENVELOPES) resv.own(j) = f->freq_res[j];
+    XS_LANES(j, 0, XAAC_SBR_MAX_NOISE_ENVELOPES + 1) nbordv.own(j) = f->noise_border_vec[j];
     for (int i = 0; i < num_env;) {
       XsPass ps;
       int s0[2], s1[2];
       /* envelope i: the reference's checks, in its order */
-      s0[0] = 2 * cx.uni(border[i]);
-      s1[0] = 2 * cx.uni(border[i + 1]);
+      s0[0] = 2 * bordv.get(i);
+      s1[0] = 2 * bordv.get(i + 1);
       if (s0[0] >= 38 || s1[0] > 38) return -1;
       if (nf_idx >= XAAC_SBR_MAX_NOISE_ENVELOPES) return -1;
-      if (cx.uni(border[i]) == cx.uni(f->noise_border_vec[nf_idx + 1])) {
+      if (bordv.get(i) == nbordv.get(nf_idx + 1)) {
         nf_off += nnf;
         nf_idx++;
       }
       ps.n = 1;
       ps.env[0] = i;
-      ps.fr[0] = cx.uni(f->freq_res[i]);
+      ps.fr[0] = resv.get(i);
       ps.nf_off[0] = nf_off;
       ps.noise_absc[0] = (i == transient_env || i == tansient_env_prev) ? 1 : 0;
       ps.noise_e[0] = (int16_t)(s0[0] < 32 ? adj_e : final_e);
@@ -2566,11 +2575,11 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
       /* envelope i + 1 rides along if it is a regular one behind envelope i: it would pass the same checks, and its slots lie
          behind i's (its energies must not see i's adjusted slots before the reference would) */
       if (i + 1 < num_env) {
-        const int t0 = 2 * cx.uni(border[i + 1]), t1 = 2 * cx.uni(border[i + 2]);
+        const int t0 = 2 * bordv.get(i + 1), t1 = 2 * bordv.get(i + 2);
         int nf2 = nf_idx, off2 = nf_off;
         bool ok = !(t0 >= 38 || t1 > 38) && nf2 < XAAC_SBR_MAX_NOISE_ENVELOPES && s0[0] < s1[0] && s1[0] <= t0 && t0 < t1;
         if (ok) {
-          if (cx.uni(border[i + 1]) == cx.uni(f->noise_border_vec[nf2 + 1])) {
+          if (bordv.get(i + 1) == nbordv.get(nf2 + 1)) {
             off2 += nnf;
             nf2++;
           }
@@ -2578,7 +2587,7 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
           s0[1] = t0;
           s1[1] = t1;
           ps.env[1] = i + 1;
-          ps.fr[1] = cx.uni(f->freq_res[i + 1]);
+          ps.fr[1] = resv.get(i + 1);
           ps.nf_off[1] = off2;
           ps.noise_absc[1] = (i + 1 == transient_env || i + 1 == tansient_env_prev) ? 1 : 0;
           ps.noise_e[1] = (int16_t)(t0 < 32 ? adj_e : final_e);
