@@ -948,6 +948,25 @@ def main():
     secondary = None
     if world == 1 and not args.no_secondary and w == "c4":
         secondary = {}
+        try:   # what a caller with smaller batches gets: the same six launches per step on the first k streams
+            sweep = {}
+            for k in (256, 1024, 4096):
+                ws_k = job._workspace(k)
+                for i in range(4):
+                    job.launch(job.batches[i % len(job.batches)], 0, k=k, ws=ws_k)
+                barrier()
+                t0 = time.perf_counter()
+                for i in range(40):
+                    job.launch(job.batches[i % len(job.batches)], i // len(job.batches), k=k, ws=ws_k)
+                barrier()
+                dt = (time.perf_counter() - t0) / 40
+                sweep[str(k)] = {"ms_per_step": round(dt * 1e3, 4), "frames_per_s": round(k / dt, 1)}
+            sweep["note"] = ("C4 chain on the first k streams of the batches (six launches per step, no HIP graph): launch latency "
+                             "shows below a few thousand streams; the kernels are persistent or one workgroup per stream, so a small "
+                             "batch leaves most of the chip idle")
+            secondary["c4_batch_sweep"] = sweep
+        except Exception as e:
+            secondary["c4_batch_sweep"] = {"error": repr(e)}
         del job.batches, job.ws
         torch.cuda.empty_cache()
         for w2 in ("c2", "c3"):
