@@ -40,6 +40,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this driver needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise); read at runtime start-up,
+# so it is set before torch is imported, whichever way the ranks were started
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 FRAMES_PER_STEP = 8192          # stereo frames per batch (BASELINE configs[1])
 CH = 2
@@ -925,7 +928,7 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])   # the rank's own GPU, said explicitly
         torch.cuda.synchronize()
 
     w = args.workload
