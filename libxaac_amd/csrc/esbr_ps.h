@@ -364,8 +364,10 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
     }
     cx.sync();
     const int e0 = pf->border_position[env], e1 = pf->border_position[env + 1], len = e1 - e0;
-    XS_PAR(v, 0, 61 + 10) { /* units: QMF bands 3..63, then the 10 hybrid groups (the lanes' second pass holds hybrid
-                               units only, whose data is in LDS) */
+    /* units: QMF bands 3..63 and the 10 hybrid groups = 71 for 64 lanes.  The first 64 (bands 3..63, hybrid groups 0..2)
+       walk the envelope's slots one lane each; the other seven hybrid groups, whose data is in LDS, are dealt out over 63
+       lanes below -- nine lanes per group, a ninth of the slots each -- instead of a second pass with seven lanes busy */
+    XS_PAR(v, 0, 64) {
       const int u = v < 61 ? v + 10 : v - 61;
       int gr, sb;
       if (u < 10) {
@@ -417,6 +419,41 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
         if (u >= 10) {
           xe_rows_store(L, sb, ic, e1, lr, li);
           xe_rows_store(R, sb, ic, e1, rr, ri);
+        }
+      }
+    }
+    {
+      /* hybrid groups 3..9: lane 9 (gr - 3) + c takes slots e0 + c per .. of the envelope.  The matrix of a slot is the sum
+         H_prev + d + d + ... in single precision, so a lane first steps through the slots in front of its own (the same
+         additions in the same order; eight adds per slot against the forty-odd operations of a rotated slot) */
+      const int per = len > 0 ? (len + 8) / 9 : 0;
+      XS_PAR(t, 0, 63) {
+        const int gr = 3 + t / 9, c = t % 9, sb = gb[gr];
+        const int bin = gmap[gr] & ~XF_NEG;
+        const bool neg = (gmap[gr] & XF_NEG) != 0;
+        const int i0 = e0 + c * per, i1 = i0 + per < e1 ? i0 + per : e1;
+        if (i0 < i1) {
+          float H[8], d[8];
+          for (int j = 0; j < 8; j++) {
+            const float prev = ps->h_prev[j][bin], cur = w->hv[j][bin];
+            const float Hp = (j >= 4 && neg) ? -prev : prev, hc = (j >= 4 && neg) ? -cur : cur;
+            H[j] = Hp;
+            d[j] = (hc - Hp) / (float)len;
+          }
+          for (int i = e0; i < i0; i++)
+            for (int j = 0; j < 8; j++) H[j] += d[j];
+          for (int i = i0; i < i1; i++) {
+            for (int j = 0; j < 8; j++) H[j] += d[j];
+            const float lre = w->hl_re[i][sb], lim = w->hl_im[i][sb], rre = w->hr_re[i][sb], rim = w->hr_im[i][sb];
+            const float o_lre = H[0] * lre - H[4] * lim + H[2] * rre - H[6] * rim;
+            const float o_lim = H[4] * lre + H[0] * lim + H[6] * rre + H[2] * rim;
+            const float o_rre = H[1] * lre - H[5] * lim + H[3] * rre - H[7] * rim;
+            const float o_rim = H[5] * lre + H[1] * lim + H[7] * rre + H[3] * rim;
+            w->hl_re[i][sb] = o_lre;
+            w->hl_im[i][sb] = o_lim;
+            w->hr_re[i][sb] = o_rre;
+            w->hr_im[i][sb] = o_rim;
+          }
         }
       }
     }
