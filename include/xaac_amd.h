@@ -270,6 +270,23 @@ typedef struct xaac_sbr_handover_batch {
   xaac_ps_state *ps_state;  /* PS_START only */
 } xaac_sbr_handover_batch;
 
+/* ---- what a header change does to the resident state --------------------------------------------------------------
+ * xaac_sbr_state_apply_side_batch <-> the words of the channel state that ixheaacd_sbr_dec_reset
+ * (decoder/ixheaacd_sbrdecoder.c:103-252) and ixheaacd_prepare_upsamp (:254-276) rewrite, for every stream of the batch
+ * whose frame carries the reset or the up-sampling flag -- on the device-resident arrays, so that a step in which every
+ * stream resets (the first frame of a batch) costs one launch instead of a round trip of every state over the bus.
+ * The same words as the host-side xaac_sbr_state_apply_side / xaac_ps_state_apply_side (include/xaac_parse.h) write.
+ * Call it before the frame's xaac_sbr_*_process_batch, with that call's header array. */
+typedef struct xaac_sbr_apply_side_batch {
+  int32_t n_streams;
+  int32_t ch_fac;                 /* channels per stream, 1 or 2: channel c of stream i is entry i * ch_fac + c */
+  const xaac_sbr_header *header;  /* [n_streams * ch_fac] device: this frame's headers (sub_band_start / sub_band_end) */
+  const int32_t *flags;           /* [n_streams][8] device: the parser's flag rows (xaac_parse_batch: [1] reset, [2]
+                                     reset_channels, [3] upsampling); all zero for a stream without a frame */
+  xaac_sbr_state *state;          /* [n_streams * ch_fac] device, in / out */
+  xaac_ps_state *ps_state;        /* optional [n_streams] device (mono + PS streams: the right channel's bank), in / out */
+} xaac_sbr_apply_side_batch;
+
 /* ---- peak limiter + PCM16 hand-off (the AAC-LC post stage) ---------------------------------
  * xaac_peak_limiter_process_batch <-> ixheaacd_peak_limiter_process
  *      def decoder/ixheaacd_peak_limiter.c:201-309, call site decoder/ixheaacd_api.c:3667, followed by the
@@ -439,6 +456,7 @@ int32_t xaac_sbr_hq_process_batch(xaac_ctx *ctx, const xaac_sbr_hq_batch *batch)
 
 /* Channel-configuration hand-overs (device pointers, asynchronous). */
 int32_t xaac_sbr_state_handover(xaac_ctx *ctx, const xaac_sbr_handover_batch *batch);
+int32_t xaac_sbr_state_apply_side_batch(xaac_ctx *ctx, const xaac_sbr_apply_side_batch *batch);
 
 /* ixheaacd_peak_limiter_init (peak_limiter.c:46-77) on a host-side state; returns the limiter delay in
  * samples (attack_time_samples) or a fatal code when the rate / channel count does not fit the struct. */

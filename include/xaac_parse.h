@@ -147,6 +147,15 @@ typedef struct xaac_parse_batch {
 
 /* returns the number of streams whose status is XAAC_PARSE_OK, or a negative XAAC_PARSE_ERR_* for a bad descriptor */
 int32_t xaac_parse_batch_run(const xaac_parse_batch *b);
+/* The same call in two halves, for a host whose calling thread has other work meanwhile (queueing the copies and launches
+   of the step before): _start hands the batch to the worker team (all `threads` of them team threads: the caller does not
+   parse along) and returns at once; _wait blocks until every stream is parsed and returns what _run would have.  The
+   descriptor is copied; the arrays it points to belong to the team until _wait returns.  One batch in flight per process:
+   every _start needs its _wait (on any thread) before the next _start or _run gets the team; _wait without a _start returns
+   XAAC_PARSE_ERR_SYNTAX.  busy_seconds (optional): how long the team parsed, from _start until its last thread ran out of
+   streams -- what the caller overlapped, or waited for. */
+int32_t xaac_parse_batch_start(const xaac_parse_batch *b);
+int32_t xaac_parse_batch_wait(double *busy_seconds);
 
 /* ---- the states of a new stream, and the frame-level state changes of ixheaacd_applysbr -------------------------------
  * Host-side helpers on HOST copies of the boundary structs (the host writes them to the device once per stream, and on

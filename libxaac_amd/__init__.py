@@ -93,6 +93,12 @@ class _HandoverBatch(ctypes.Structure):
 
 HANDOVER_PS_START, HANDOVER_STEREO_START = 1, 2
 
+class _ApplySideBatch(ctypes.Structure):
+    # struct xaac_sbr_apply_side_batch
+    _fields_ = [("n_streams", ctypes.c_int32), ("ch_fac", ctypes.c_int32), ("header", ctypes.c_void_p), ("flags", ctypes.c_void_p),
+                ("state", ctypes.c_void_p), ("ps_state", ctypes.c_void_p)]
+
+
 
 class _UsacImdctBatch(ctypes.Structure):
     # struct xaac_usac_imdct_batch
@@ -271,6 +277,8 @@ def load_library():
     lib.xaac_esbr_sbr_process_batch.restype = ctypes.c_int32
     lib.xaac_sbr_state_handover.argtypes = [ctypes.c_void_p, ctypes.POINTER(_HandoverBatch)]
     lib.xaac_sbr_state_handover.restype = ctypes.c_int32
+    lib.xaac_sbr_state_apply_side_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_ApplySideBatch)]
+    lib.xaac_sbr_state_apply_side_batch.restype = ctypes.c_int32
     lib.xaac_usac_imdct_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_UsacImdctBatch)]
     lib.xaac_usac_imdct_process_batch.restype = ctypes.c_int32
     lib.xaac_hbe_real_synth_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_HbeSynthBatch)]
@@ -562,6 +570,20 @@ class XaacContext:
         rc = self._lib.xaac_sbr_state_handover(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_sbr_state_handover")
+
+    def sbr_state_apply_side_batch(self, header, flags, state, ch_fac, ps_state=None):
+        """ixheaacd_sbr_dec_reset / ixheaacd_prepare_upsamp (sbrdecoder.c:103-276) on the resident states of the streams whose
+        flag rows say so: header uint8[n * ch_fac, SBR_HEADER_BYTES] (this frame's), flags int32[n, 8] (the parser's rows;
+        zero for streams without a frame), state / ps_state the uint8 views of the xaac_sbr_state / xaac_ps_state arrays."""
+        b = _ApplySideBatch()
+        b.n_streams, b.ch_fac = int(flags.shape[0]), int(ch_fac)
+        b.header = _ptr(header, "uint8", b.n_streams * b.ch_fac * SBR_HEADER_BYTES, device_ok=True)
+        b.flags = _ptr(flags, "int32", b.n_streams * 8, device_ok=True)
+        b.state = _ptr(state, "uint8", b.n_streams * b.ch_fac * SBR_STATE_BYTES, device_ok=True)
+        b.ps_state = _ptr(ps_state, "uint8", allow_none=True, device_ok=True)
+        rc = self._lib.xaac_sbr_state_apply_side_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_sbr_state_apply_side_batch")
 
     def usac_imdct_process_batch(self, coef, ics, overlap, shape_prev, out32=None, time=None, status=None, ccfl=1024,
                                  lpd_flags=None, fac=None):

@@ -30,6 +30,7 @@ typedef struct XaacPsParams {
 extern "C" {
 #endif
 hipError_t xaac_launch_sbr_handover(const xaac_sbr_handover_batch *b, hipStream_t stream);
+hipError_t xaac_launch_sbr_apply_side(const xaac_sbr_apply_side_batch *b, hipStream_t stream);
 hipError_t xaac_launch_ps(const XaacPsParams *p, hipStream_t stream);
 #ifdef __cplusplus
 }

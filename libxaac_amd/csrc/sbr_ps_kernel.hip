@@ -193,6 +193,49 @@ __global__ __launch_bounds__(64) void xaac_sbr_handover_kernel(xaac_sbr_handover
   }
 }
 
+/* sbrdecoder.c:103-252 (ixheaacd_sbr_dec_reset) and :254-276 (ixheaacd_prepare_upsamp): the state words a frame with the
+   reset / up-sampling flag rewrites -- the same as libxaac_amd/host/xaac_parse.cpp: xaac_sbr_state_apply_side and
+   xaac_ps_state_apply_side.  One thread per channel. */
+__global__ __launch_bounds__(256) void xaac_sbr_apply_side_kernel(xaac_sbr_apply_side_batch b) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= b.n_streams * b.ch_fac) return;
+  const int i = e / b.ch_fac, c = e % b.ch_fac;
+  const int32_t *f = b.flags + 8 * (size_t)i;
+  const int reset = f[1], reset_channels = f[2], upsampling = f[3];
+  if (!reset && !upsampling) return;
+  xaac_sbr_state *s = b.state + e;
+  const xaac_sbr_header *h = b.header + (size_t)i * b.ch_fac; /* the stream's header (channel 0's copy, as the host one reads) */
+  if (reset && c < reset_channels) {
+    s->ph_index = 0;
+    s->filt_buf_noise_e = 0;
+    s->start_up = 1;
+    s->syn_lsb = s->codec_usb = h->sub_band_start;
+    s->syn_usb = h->sub_band_end;
+    for (int k = 0; k < XAAC_SBR_MAX_PATCHES; k++) s->bw_array_prev[k] = 0;
+  }
+  if (upsampling) {
+    s->syn_lsb = s->codec_usb = 32;
+    s->syn_usb = 64;
+  }
+  if (b.ps_state && c == 0) {
+    xaac_ps_state *ps = b.ps_state + i;
+    if (reset && reset_channels > 1) {
+      ps->syn_lsb_r = h->sub_band_start;
+      ps->syn_usb_r = h->sub_band_end;
+    }
+    if (upsampling) {
+      ps->syn_lsb_r = 32;
+      ps->syn_usb_r = 64;
+    }
+  }
+}
+
+extern "C" hipError_t xaac_launch_sbr_apply_side(const xaac_sbr_apply_side_batch *b, hipStream_t stream) {
+  const int n = b->n_streams * b->ch_fac;
+  hipLaunchKernelGGL(xaac_sbr_apply_side_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, *b);
+  return hipGetLastError();
+}
+
 extern "C" hipError_t xaac_launch_sbr_handover(const xaac_sbr_handover_batch *b, hipStream_t stream) {
   hipLaunchKernelGGL(xaac_sbr_handover_kernel, dim3(b->n), dim3(64), 0, stream, *b);
   return hipGetLastError();

@@ -389,6 +389,16 @@ int32_t xaac_sbr_state_handover(xaac_ctx *c, const xaac_sbr_handover_batch *b) {
   return XAAC_OK;
 }
 
+int32_t xaac_sbr_state_apply_side_batch(xaac_ctx *c, const xaac_sbr_apply_side_batch *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n_streams < 0 || (b->ch_fac != 1 && b->ch_fac != 2)) return XAAC_FATAL_BAD_ARG;
+  if (b->n_streams == 0) return XAAC_OK;
+  if (!b->header || !b->flags || !b->state) return XAAC_FATAL_NULL_ARG;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  if (!hip_ok(xaac_launch_sbr_apply_side(b, c->stream))) return XAAC_FATAL_HIP;
+  return XAAC_OK;
+}
+
 int32_t xaac_usac_imdct_process_batch(xaac_ctx *c, const xaac_usac_imdct_batch *b) {
   if (!c || !b) return XAAC_FATAL_NULL_ARG;
   if (b->n_ch < 0) return XAAC_FATAL_BAD_ARG;

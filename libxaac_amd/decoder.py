@@ -194,6 +194,8 @@ class BatchParser:
     def __init__(self, streams, threads=0, stage=2, esbr=False):
         self.lib = load_host_library()
         self.lib.xaac_parse_batch_run.argtypes = [ctypes.c_void_p]
+        self.lib.xaac_parse_batch_start.argtypes = [ctypes.c_void_p]
+        self.lib.xaac_parse_batch_wait.argtypes = [ctypes.c_void_p]
         self.esbr = bool(esbr)
         self.n = n = len(streams)
         self.length = np.array([len(d) for d in streams], np.uint64)
@@ -230,23 +232,42 @@ class BatchParser:
         self.sbr = bool(core.sbr_bytes > 0)
 
     def close(self):
+        if getattr(self, "_in_flight", False):   # (a caller that gave up between start_step() and wait_step(): the team must get its batch back)
+            self.lib.xaac_parse_batch_wait(None)
+            self._in_flight = False
         for i in range(self.n):
             if self.parsers[i]:
                 self.lib.xaac_parser_destroy(self.parsers[i])
                 self.parsers[i] = None
 
-    def _run(self, spec, ics, hdr, frm, psf, flags, with_sbr, advance=True, eside=None):
+    def _descriptor(self, spec, ics, hdr, frm, psf, flags, with_sbr, eside=None):
         n = self.n
-        left = self.length - self.pos
-        ptrs = (np.uint64(self.base) + self.start + self.pos).astype(np.uint64)
+        # (kept on the object: the library reads them until the call -- or, for start_step(), the wait_step() -- is over)
+        self._left = self.length - self.pos
+        self._ptrs = (np.uint64(self.base) + self.start + self.pos).astype(np.uint64)
         b = _ParseBatch()
         b.n_streams, b.n_ch, b.with_sbr, b.ps_enable, b.stage, b.threads = n, self.n_ch, int(with_sbr), 1, self.stage, self.threads
-        b.parser, b.data, b.bytes = ctypes.addressof(self.parsers), ptrs.ctypes.data, left.ctypes.data
+        b.parser, b.data, b.bytes = ctypes.addressof(self.parsers), self._ptrs.ctypes.data, self._left.ctypes.data
         ptr = lambda t: None if t is None else (t.data_ptr() if hasattr(t, "data_ptr") else t.ctypes.data)
         b.spec, b.ics, b.header, b.frame, b.ps_frame, b.flags = ptr(spec), ptr(ics), ptr(hdr), ptr(frm), ptr(psf), ptr(flags)
         b.tools, b.consumed, b.status = self.tools.ctypes.data, self.consumed.ctypes.data, self.status.ctypes.data
         b.esbr_side = ptr(eside)
         b.reset_pitch = self.reset_pitch.ctypes.data
+        return b
+
+    def _advance(self, ok):
+        if ok < 0:
+            raise RuntimeError("xaac_parse_batch: %d" % ok)
+        self.pos += self.consumed
+        self.frames += (self.status == 0)
+        bad = (self.status != 0) & (self.status != 1)
+        if np.any(bad):
+            i = int(np.nonzero(bad)[0][0])
+            raise ParseError(int(self.status[i]), int(self.frames[i]))
+        return self.status == 0
+
+    def _run(self, spec, ics, hdr, frm, psf, flags, with_sbr, advance=True, eside=None):
+        b = self._descriptor(spec, ics, hdr, frm, psf, flags, with_sbr, eside)
         ok = self.lib.xaac_parse_batch_run(ctypes.byref(b))
         if ok < 0:
             raise RuntimeError("xaac_parse_batch_run: %d" % ok)
@@ -258,12 +279,24 @@ class BatchParser:
     def step(self, spec, ics, hdr=None, frm=None, psf=None, flags=None, eside=None):
         """parses the next frame of every stream into the staging arrays; -> bool[n]: which streams delivered a frame
         (the others are at their end: their rows are left as they were)"""
-        self._run(spec, ics, hdr, frm, psf, flags, with_sbr=self.sbr, eside=eside)
-        bad = (self.status != 0) & (self.status != 1)
-        if np.any(bad):
-            i = int(np.nonzero(bad)[0][0])
-            raise ParseError(int(self.status[i]), int(self.frames[i]))
-        return self.status == 0
+        b = self._descriptor(spec, ics, hdr, frm, psf, flags, self.sbr, eside)
+        return self._advance(self.lib.xaac_parse_batch_run(ctypes.byref(b)))
+
+    def start_step(self, spec, ics, hdr=None, frm=None, psf=None, flags=None, eside=None):
+        """step() in two halves (xaac_parse_batch_start / _wait): the library's worker team parses while the caller does
+        something else; the staging arrays are the team's until wait_step() returns."""
+        b = self._descriptor(spec, ics, hdr, frm, psf, flags, self.sbr, eside)
+        rc = self.lib.xaac_parse_batch_start(ctypes.byref(b))
+        if rc:
+            raise RuntimeError("xaac_parse_batch_start: %d" % rc)
+        self._in_flight = True
+
+    def wait_step(self):
+        """-> (bool[n] as step(), seconds the team parsed)"""
+        busy = ctypes.c_double(0.0)
+        ok = self.lib.xaac_parse_batch_wait(ctypes.byref(busy))
+        self._in_flight = False
+        return self._advance(ok), busy.value
 
 
 def _struct_bytes(fn, size):
@@ -285,8 +318,8 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
     points against the streams' device-resident states, and the PCM copied back.
     -> (list of int16 [samples, channels] arrays, output sampling rate).  keep_pcm False: the PCM still comes back to the host
     every step but is not collected (throughput measurements); timing: a dict that receives seconds per stage.
-    overlap: the host parses step k + 1 (a second set of staging arrays, a helper thread: the parser calls release the GIL)
-    while the GPU works on step k.
+    overlap: the host parses step k + 1 (further sets of staging arrays; the parser library's own threads,
+    xaac_parse_batch_start / _wait) while this thread queues step k on the GPU.
     esbr: decode SBR streams the way the reference does with its default flags (-esbr:1, "Path A": the float eSBR tools of
     xaac_esbr_sbr_process_batch with the QMF harmonic transposer and float parametric stereo; the SBR payload runs one
     frame late, and the reference's command line decoder does not write the first frame's output,
@@ -305,7 +338,7 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
     n, n_ch, sbr, rate = bp.n, bp.n_ch, bp.sbr, bp.core_rate
     esbr = bool(esbr) and sbr
     nc = n * n_ch
-    t_parse = t_gpu = 0.0
+    t_parse = t_gpu = t_wait_parse = t_wait_down = 0.0
 
     def dz(*shape, dtype=torch.uint8):
         return torch.zeros(*shape, dtype=dtype, device=dev)
@@ -327,6 +360,7 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
             if sbr:
                 self.hdr, self.frm = pinned(nc, SBR_HEADER_BYTES), pinned(nc, SBR_FRAME_BYTES)
                 self.flags = np.zeros((n, 8), np.int32)
+                self.flags_pin = pinned(n, 8, dtype=torch.int32)   # the rows as they go up for xaac_sbr_state_apply_side_batch
                 if n_ch == 1:
                     self.psf = pinned(n, PS_FRAME_BYTES)
             self.got, self.seconds = None, 0.0
@@ -336,6 +370,15 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
             self.got = bp.step(self.spec, self.ics, self.hdr, self.frm, self.psf, self.flags, self.eside)
             self.reset_pitch = bp.reset_pitch.copy()
             self.seconds = time.perf_counter() - t0
+            return self
+
+        def begin(self):    # the library's team parses into this set while the caller queues the step before on the GPU
+            bp.start_step(self.spec, self.ics, self.hdr, self.frm, self.psf, self.flags, self.eside)
+            return self
+
+        def end(self):
+            self.got, self.seconds = bp.wait_step()
+            self.reset_pitch = bp.reset_pitch.copy()
             return self
 
     # three staging sets: the parse of step k + 1 | the copies up and kernels of step k | the copy down of step k - 1
@@ -376,6 +419,7 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
         state = torch.from_numpy(np.tile(_struct_bytes(lib.xaac_sbr_state_init, SBR_STATE_BYTES), (nc, 1)).copy()).to(dev)
         core16 = dz(nc * 1024, dtype=torch.int16)
         hdr_d, frm_d = dz(nc, SBR_HEADER_BYTES), dz(nc, SBR_FRAME_BYTES)
+        flags_d = dz(n, 8, dtype=torch.int32)
         status2 = [dz(nc, dtype=torch.int32) for _ in range(2)]
         status_h2 = [pinned(nc, dtype=torch.int32) for _ in range(2)]
         pcm_h2 = [pinned(n * 2048 * 2, dtype=torch.int16) for _ in range(2)]
@@ -388,11 +432,11 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
             ws = dz(ctx.sbr_hq_workspace_bytes(n, True))
             pcm_mono = dz(n * 2048, dtype=torch.int16)
     first = True
-    pool = None
     if overlap:
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(1)
-        pending = pool.submit(sets[0].parse)
+        # (the parse of the next step runs on the parser library's own threads, xaac_parse_batch_start / _wait: a Python helper
+        # thread would have to win the interpreter lock from this one, which gives it up only for microseconds at a time
+        # while it queues copies and launches -- measured, its parse began when this thread blocked on the result)
+        pending = sets[0].begin()
     which = 0
     # The copy down of step k runs on a second stream beside the copies up and kernels of step k + 1 (two PCM / status sets);
     # the host takes a step's PCM one step later.
@@ -401,12 +445,14 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
     waiting = None    # (slot, got, shape, cut, drop) of the step whose PCM is on its way
 
     def consume():
-        nonlocal waiting
+        nonlocal waiting, t_wait_down
         if waiting is None:
             return
         slot_, got_, shape_, cut_, drop_ = waiting
         waiting = None
+        t_c = time.perf_counter()
         done[slot_].synchronize()
+        t_wait_down += time.perf_counter() - t_c
         if status_h2 is not None and int(status_h2[slot_].min()) < 0:
             raise RuntimeError("the SBR kernels refused a frame")
         if keep_pcm and not drop_:
@@ -431,152 +477,136 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
 
     step_no = 0
     t_steps = time.perf_counter()
-    while True:
-        cur = pending.result() if overlap else sets[0].parse()
-        t_parse += cur.seconds
-        got = cur.got
-        if not got.any():
-            break
-        if overlap:    # the next step's frames are parsed while the GPU works on this one's
-            which = (which + 1) % 3
-            pending = pool.submit(sets[which].parse)
-        slot = step_no & 1
-        step_no += 1
-        pcm = pcm2[slot]
-        status = status2[slot] if status2 is not None else None
-        spec_h, ics_h, hdr_h, frm_h, psf_h, flags = cur.spec, cur.ics, cur.hdr, cur.frm, cur.psf, cur.flags
-        overlap_buf = ovl
-        t0 = time.perf_counter()
-        spec_d.copy_(spec_h, non_blocking=True)
-        ics_d.copy_(ics_h, non_blocking=True)
-        if not sbr:
-            ctx.imdct_process_batch(spec_d, ics_d, overlap_buf, ovl_state, out32=out32, qshift_adj=qadj, ch_fac=n_ch)
-            ctx.peak_limiter_process_batch(out32, qadj, lim, n_ch, ws, pcm16=pcm)
-            hand_down(slot, got, (n, 1024, n_ch), cut_=delay if first else 0)   # the limiter's delay is cut from the first frame
-        elif esbr:
-            # (interleaved as the reference holds it: its in-place 32 -> 16 bit conversion of a pair leaves traces of channel
-            # 0 in channel 1, api.c:353-366, which the IMDCT's PCM_SBR hand-off restates for ch_fac 2)
-            ctx.imdct_process_batch(spec_d, ics_d, overlap_buf, ovl_state, pcm16=core16, ch_fac=n_ch, pcm_mode=PCM_SBR)
-            hdr_d.copy_(hdr_h, non_blocking=True)
-            frm_d.copy_(frm_h, non_blocking=True)
-            eside_d.copy_(cur.eside, non_blocking=True)
-            touched = np.nonzero(got & (flags[:, F_RESET] != 0))[0]
-            if touched.size:
-                # ixheaacd_sbr_dec_reset for Path A (sbrdecoder.c:175-236): new transposer parameters from the header's band
-                # tables (its two delay lines cleared), then two transposer runs over rows 8..39 and 40..71 of the QMF buffer
-                # as the frame before left it: rows 8..31 are what that frame found as rows 8..31 of its history (`older`),
-                # rows 32..71 are the state's history (the codec bank's num_time_slots is 32 here).  The second run's last eight output rows become the
-                # state's ph rows (bands outside the transposer's range keep what they held).
-                k = touched.size * n_ch
-                rows_h = (touched[:, None] * n_ch + np.arange(n_ch)[None, :]).ravel()
-                rows = torch.from_numpy(rows_h).to(dev)
-                hb = hbe.index_select(0, rows)
-                tail_off = HBE_STATE_BYTES - 48
-                one = np.zeros(HBE_STATE_BYTES, np.uint8)
-                for j, r in enumerate(rows_h):
-                    one[tail_off:] = hbe_tail[r]
-                    if lib.xaac_hbe_state_reinit(one.ctypes.data, hdr_h[int(r)].numpy().ctypes.data):
-                        raise RuntimeError("the QMF transposer refused the SBR band tables of stream %d" % (r // n_ch))
-                    hbe_tail[r] = one[tail_off:]
-                hb[:, tail_off:] = torch.from_numpy(hbe_tail[rows_h]).to(dev)
-                hb32 = hb.view(torch.float32)
-                hb32[:, 1088:1088 + 1280 + 640] = 0.0          # synth_buf, analy_buf (behind input_buf[1024 + 64])
-                pitch = torch.from_numpy(np.repeat(cur.reset_pitch[touched], n_ch).astype(np.int32)).to(dev)
+    try:
+        while True:
+            t_w = time.perf_counter()
+            cur = pending.end() if overlap else sets[0].parse()
+            t_wait_parse += time.perf_counter() - t_w
+            t_parse += cur.seconds
+            got = cur.got
+            if not got.any():
+                break
+            if overlap:    # the next step's frames are parsed while the GPU works on this one's
+                which = (which + 1) % 3
+                pending = sets[which].begin()
+            slot = step_no & 1
+            step_no += 1
+            pcm = pcm2[slot]
+            status = status2[slot] if status2 is not None else None
+            spec_h, ics_h, hdr_h, frm_h, psf_h, flags = cur.spec, cur.ics, cur.hdr, cur.frm, cur.psf, cur.flags
+            overlap_buf = ovl
+            t0 = time.perf_counter()
+            spec_d.copy_(spec_h, non_blocking=True)
+            ics_d.copy_(ics_h, non_blocking=True)
+            if not sbr:
+                ctx.imdct_process_batch(spec_d, ics_d, overlap_buf, ovl_state, out32=out32, qshift_adj=qadj, ch_fac=n_ch)
+                ctx.peak_limiter_process_batch(out32, qadj, lim, n_ch, ws, pcm16=pcm)
+                hand_down(slot, got, (n, 1024, n_ch), cut_=delay if first else 0)   # the limiter's delay is cut from the first frame
+            elif esbr:
+                # (interleaved as the reference holds it: its in-place 32 -> 16 bit conversion of a pair leaves traces of channel
+                # 0 in channel 1, api.c:353-366, which the IMDCT's PCM_SBR hand-off restates for ch_fac 2)
+                ctx.imdct_process_batch(spec_d, ics_d, overlap_buf, ovl_state, pcm16=core16, ch_fac=n_ch, pcm_mode=PCM_SBR)
+                hdr_d.copy_(hdr_h, non_blocking=True)
+                frm_d.copy_(frm_h, non_blocking=True)
+                eside_d.copy_(cur.eside, non_blocking=True)
+                touched = np.nonzero(got & (flags[:, F_RESET] != 0))[0]
+                if touched.size:
+                    # ixheaacd_sbr_dec_reset for Path A (sbrdecoder.c:175-236): new transposer parameters from the header's band
+                    # tables (its two delay lines cleared), then two transposer runs over rows 8..39 and 40..71 of the QMF buffer
+                    # as the frame before left it: rows 8..31 are what that frame found as rows 8..31 of its history (`older`),
+                    # rows 32..71 are the state's history (the codec bank's num_time_slots is 32 here).  The second run's last eight output rows become the
+                    # state's ph rows (bands outside the transposer's range keep what they held).
+                    k = touched.size * n_ch
+                    rows_h = (touched[:, None] * n_ch + np.arange(n_ch)[None, :]).ravel()
+                    rows = torch.from_numpy(rows_h).to(dev)
+                    hb = hbe.index_select(0, rows)
+                    tail_off = HBE_STATE_BYTES - 48
+                    one = np.zeros(HBE_STATE_BYTES, np.uint8)
+                    for j, r in enumerate(rows_h):
+                        one[tail_off:] = hbe_tail[r]
+                        if lib.xaac_hbe_state_reinit(one.ctypes.data, hdr_h[int(r)].numpy().ctypes.data):
+                            raise RuntimeError("the QMF transposer refused the SBR band tables of stream %d" % (r // n_ch))
+                        hbe_tail[r] = one[tail_off:]
+                    hb[:, tail_off:] = torch.from_numpy(hbe_tail[rows_h]).to(dev)
+                    hb32 = hb.view(torch.float32)
+                    hb32[:, 1088:1088 + 1280 + 640] = 0.0          # synth_buf, analy_buf (behind input_buf[1024 + 64])
+                    pitch = torch.from_numpy(np.repeat(cur.reset_pitch[touched], n_ch).astype(np.int32)).to(dev)
+                    st32 = state.view(torch.float32)
+                    hist, old = st32.index_select(0, rows), older.index_select(0, rows)
+                    q_re, q_im = dz(k, 32, 64, dtype=torch.float32), dz(k, 32, 64, dtype=torch.float32)
+                    pv_re, pv_im = dz(k, 32, 64, dtype=torch.float32), dz(k, 32, 64, dtype=torch.float32)
+                    rst = dz(k, dtype=torch.int32)
+                    q_re[:, :24] = old[:, 0].view(k, 24, 64)
+                    q_im[:, :24] = old[:, 1].view(k, 24, 64)
+                    q_re[:, 24:] = hist[:, _ES_QMF_RE:_ES_QMF_RE + 8 * 64].view(k, 8, 64)
+                    q_im[:, 24:] = hist[:, _ES_QMF_IM:_ES_QMF_IM + 8 * 64].view(k, 8, 64)
+                    ctx.hbe_apply_batch(q_re, q_im, hb, pv_re, pv_im, status=rst, pitch_in_bins=pitch, max_synth_size=hbe_hint())
+                    q_re[:] = hist[:, _ES_QMF_RE + 8 * 64:_ES_QMF_RE + 40 * 64].view(k, 32, 64)
+                    q_im[:] = hist[:, _ES_QMF_IM + 8 * 64:_ES_QMF_IM + 40 * 64].view(k, 32, 64)
+                    pv_re[:, 24:] = hist[:, _ES_PH_RE:_ES_PH_RE + 512].view(k, 8, 64)
+                    pv_im[:, 24:] = hist[:, _ES_PH_IM:_ES_PH_IM + 512].view(k, 8, 64)
+                    ctx.hbe_apply_batch(q_re, q_im, hb, pv_re, pv_im, status=rst, pitch_in_bins=pitch, max_synth_size=hbe_hint())
+                    hist[:, _ES_PH_RE:_ES_PH_RE + 512] = pv_re[:, 24:].reshape(k, 512)
+                    hist[:, _ES_PH_IM:_ES_PH_IM + 512] = pv_im[:, 24:].reshape(k, 512)
+                    st32.index_copy_(0, rows, hist)
+                    hbe.index_copy_(0, rows, hb)
                 st32 = state.view(torch.float32)
-                hist, old = st32.index_select(0, rows), older.index_select(0, rows)
-                q_re, q_im = dz(k, 32, 64, dtype=torch.float32), dz(k, 32, 64, dtype=torch.float32)
-                pv_re, pv_im = dz(k, 32, 64, dtype=torch.float32), dz(k, 32, 64, dtype=torch.float32)
-                rst = dz(k, dtype=torch.int32)
-                q_re[:, :24] = old[:, 0].view(k, 24, 64)
-                q_im[:, :24] = old[:, 1].view(k, 24, 64)
-                q_re[:, 24:] = hist[:, _ES_QMF_RE:_ES_QMF_RE + 8 * 64].view(k, 8, 64)
-                q_im[:, 24:] = hist[:, _ES_QMF_IM:_ES_QMF_IM + 8 * 64].view(k, 8, 64)
-                ctx.hbe_apply_batch(q_re, q_im, hb, pv_re, pv_im, status=rst, pitch_in_bins=pitch, max_synth_size=hbe_hint())
-                q_re[:] = hist[:, _ES_QMF_RE + 8 * 64:_ES_QMF_RE + 40 * 64].view(k, 32, 64)
-                q_im[:] = hist[:, _ES_QMF_IM + 8 * 64:_ES_QMF_IM + 40 * 64].view(k, 32, 64)
-                pv_re[:, 24:] = hist[:, _ES_PH_RE:_ES_PH_RE + 512].view(k, 8, 64)
-                pv_im[:, 24:] = hist[:, _ES_PH_IM:_ES_PH_IM + 512].view(k, 8, 64)
-                ctx.hbe_apply_batch(q_re, q_im, hb, pv_re, pv_im, status=rst, pitch_in_bins=pitch, max_synth_size=hbe_hint())
-                hist[:, _ES_PH_RE:_ES_PH_RE + 512] = pv_re[:, 24:].reshape(k, 512)
-                hist[:, _ES_PH_IM:_ES_PH_IM + 512] = pv_im[:, 24:].reshape(k, 512)
-                st32.index_copy_(0, rows, hist)
-                hbe.index_copy_(0, rows, hb)
-            st32 = state.view(torch.float32)
-            older[:, 0] = st32[:, _ES_QMF_RE + 8 * 64:_ES_QMF_RE + 32 * 64]   # for the reset a later frame may bring
-            older[:, 1] = st32[:, _ES_QMF_IM + 8 * 64:_ES_QMF_IM + 32 * 64]
-            ctx.esbr_core_from_pcm16(core16, core, ch_fac=n_ch)
-            if _trace is not None:   # debugging: the device states in front of the chain call
-                _trace(dict(state=state, hbe=hbe, ps_state=ps_state if n_ch == 1 else None, core=core, side=eside_d, header=hdr_d,
-                            frame=frm_d))
-            with_ps = (flags[got, F_PS] != 0) if n_ch == 1 else np.zeros(1, bool)
-            if with_ps.any() != with_ps.all():
-                raise NotImplementedError("a batch mixing PS and non-PS frames")
-            if with_ps.all():
-                psf_d.copy_(psf_h, non_blocking=True)
-                ctx.esbr_sbr_process_batch(core, hdr_d, frm_d, eside_d, state, out_l, ws, status=status, ps_frame=psf_d,
-                                           ps_state=ps_state, out_r=out_r, hbe_state=hbe, hbe_max_synth_size=hbe_hint())
-                ctx.esbr_pcm16_from_float(out_l, out_r, pcm)
-            elif n_ch == 1:
-                ctx.esbr_sbr_process_batch(core, hdr_d, frm_d, eside_d, state, out_l, ws, status=status, hbe_state=hbe, hbe_max_synth_size=hbe_hint())
-                ctx.esbr_pcm16_from_float(out_l, out_l, pcm)                                # mono twice (api.c:3639-3660)
-            else:
-                ctx.esbr_sbr_process_batch(core, hdr_d, frm_d, eside_d, state, out_l, ws, status=status, hbe_state=hbe, hbe_max_synth_size=hbe_hint())
-                ctx.esbr_pcm16_from_float(out_l, out_l[1:], pcm, stride=4096)
-            hand_down(slot, got, (n, 2048, 2), drop_=first)      # the first frame's output is not written in this mode
-        else:
-            ctx.imdct_process_batch(spec_d, ics_d, overlap_buf, ovl_state, pcm16=core16, ch_fac=n_ch, pcm_mode=PCM_SBR)
-            # frames that reset the SBR decoder or fall back to plain up-sampling change a few words of the resident state
-            touched = np.nonzero(got & ((flags[:, F_RESET] != 0) | (flags[:, F_UPSAMPLING] != 0)))[0]
-            if touched.size:
-                rows = torch.from_numpy((touched[:, None] * n_ch + np.arange(n_ch)[None, :]).ravel()).to(dev)
-                st_h = state.index_select(0, rows).cpu().numpy()
-                side = SbrSide()
-                if n_ch == 1:
-                    prow = torch.from_numpy(touched).to(dev)
-                    ps_h = ps_state.index_select(0, prow).cpu().numpy()
-                for k, i in enumerate(touched):
-                    for name, v in zip(("apply", "reset", "reset_channels", "upsampling", "stereo", "ps", "ps_start", "frame_ok"),
-                                       flags[i]):
-                        setattr(side, name, int(v))
-                    ctypes.memmove(ctypes.addressof(side) + SbrSide.header.offset, hdr_h[i * n_ch].numpy().ctypes.data,
-                                   SBR_HEADER_BYTES)
-                    for c in range(n_ch):
-                        row = np.ascontiguousarray(st_h[k * n_ch + c])
-                        lib.xaac_sbr_state_apply_side(row.ctypes.data, ctypes.byref(side), c)
-                        st_h[k * n_ch + c] = row
-                    if n_ch == 1:
-                        row = np.ascontiguousarray(ps_h[k])
-                        lib.xaac_ps_state_apply_side(row.ctypes.data, ctypes.byref(side))
-                        ps_h[k] = row
-                state.index_copy_(0, rows, torch.from_numpy(st_h).to(dev))
-                if n_ch == 1:
-                    ps_state.index_copy_(0, prow, torch.from_numpy(ps_h).to(dev))
-            hdr_d.copy_(hdr_h, non_blocking=True)
-            frm_d.copy_(frm_h, non_blocking=True)
-            if n_ch == 2:
-                ctx.sbr_lp_process_batch(core16, hdr_d, frm_d, state, pcm, ws, status=status, in_ch_fac=2, out_ch_fac=2)
-            else:
-                with_ps = flags[got, F_PS] != 0
+                older[:, 0] = st32[:, _ES_QMF_RE + 8 * 64:_ES_QMF_RE + 32 * 64]   # for the reset a later frame may bring
+                older[:, 1] = st32[:, _ES_QMF_IM + 8 * 64:_ES_QMF_IM + 32 * 64]
+                ctx.esbr_core_from_pcm16(core16, core, ch_fac=n_ch)
+                if _trace is not None:   # debugging: the device states in front of the chain call
+                    _trace(dict(state=state, hbe=hbe, ps_state=ps_state if n_ch == 1 else None, core=core, side=eside_d, header=hdr_d,
+                                frame=frm_d))
+                with_ps = (flags[got, F_PS] != 0) if n_ch == 1 else np.zeros(1, bool)
                 if with_ps.any() != with_ps.all():
                     raise NotImplementedError("a batch mixing PS and non-PS frames")
                 if with_ps.all():
-                    starts = np.nonzero(got & (flags[:, F_PS_START] != 0))[0]
-                    if starts.size:
-                        idx = torch.from_numpy(starts.astype(np.int32)).to(dev)
-                        ctx.sbr_state_handover(HANDOVER_PS_START, idx, idx, state, ps_state)
                     psf_d.copy_(psf_h, non_blocking=True)
-                    ctx.sbr_hq_process_batch(core16, hdr_d, frm_d, state, pcm, ws, ps_frame=psf_d, ps_state=ps_state, status=status)
+                    ctx.esbr_sbr_process_batch(core, hdr_d, frm_d, eside_d, state, out_l, ws, status=status, ps_frame=psf_d,
+                                               ps_state=ps_state, out_r=out_r, hbe_state=hbe, hbe_max_synth_size=hbe_hint())
+                    ctx.esbr_pcm16_from_float(out_l, out_r, pcm)
+                elif n_ch == 1:
+                    ctx.esbr_sbr_process_batch(core, hdr_d, frm_d, eside_d, state, out_l, ws, status=status, hbe_state=hbe, hbe_max_synth_size=hbe_hint())
+                    ctx.esbr_pcm16_from_float(out_l, out_l, pcm)                                # mono twice (api.c:3639-3660)
                 else:
-                    ctx.sbr_hq_process_batch(core16, hdr_d, frm_d, state, pcm_mono, ws, status=status)
-                    # mono duplicated to stereo (api.c:3639-3660)
-                    pcm.view(n, 2048, 2).copy_(pcm_mono.view(n, 2048, 1).expand(n, 2048, 2))
-            hand_down(slot, got, (n, 2048, 2))
-        t_gpu += time.perf_counter() - t0
-        first = False
+                    ctx.esbr_sbr_process_batch(core, hdr_d, frm_d, eside_d, state, out_l, ws, status=status, hbe_state=hbe, hbe_max_synth_size=hbe_hint())
+                    ctx.esbr_pcm16_from_float(out_l, out_l[1:], pcm, stride=4096)
+                hand_down(slot, got, (n, 2048, 2), drop_=first)      # the first frame's output is not written in this mode
+            else:
+                ctx.imdct_process_batch(spec_d, ics_d, overlap_buf, ovl_state, pcm16=core16, ch_fac=n_ch, pcm_mode=PCM_SBR)
+                hdr_d.copy_(hdr_h, non_blocking=True)
+                frm_d.copy_(frm_h, non_blocking=True)
+                # frames that reset the SBR decoder or fall back to plain up-sampling change a few words of the resident state:
+                # on the device, from the flag rows (streams without a frame: zero rows)
+                if (got & ((flags[:, F_RESET] != 0) | (flags[:, F_UPSAMPLING] != 0))).any():
+                    cur.flags_pin.copy_(torch.from_numpy(flags * got[:, None].astype(np.int32)))
+                    flags_d.copy_(cur.flags_pin, non_blocking=True)
+                    ctx.sbr_state_apply_side_batch(hdr_d, flags_d, state, n_ch, ps_state=ps_state if n_ch == 1 else None)
+                if n_ch == 2:
+                    ctx.sbr_lp_process_batch(core16, hdr_d, frm_d, state, pcm, ws, status=status, in_ch_fac=2, out_ch_fac=2)
+                else:
+                    with_ps = flags[got, F_PS] != 0
+                    if with_ps.any() != with_ps.all():
+                        raise NotImplementedError("a batch mixing PS and non-PS frames")
+                    if with_ps.all():
+                        starts = np.nonzero(got & (flags[:, F_PS_START] != 0))[0]
+                        if starts.size:
+                            idx = torch.from_numpy(starts.astype(np.int32)).to(dev)
+                            ctx.sbr_state_handover(HANDOVER_PS_START, idx, idx, state, ps_state)
+                        psf_d.copy_(psf_h, non_blocking=True)
+                        ctx.sbr_hq_process_batch(core16, hdr_d, frm_d, state, pcm, ws, ps_frame=psf_d, ps_state=ps_state, status=status)
+                    else:
+                        ctx.sbr_hq_process_batch(core16, hdr_d, frm_d, state, pcm_mono, ws, status=status)
+                        # mono duplicated to stereo (api.c:3639-3660)
+                        pcm.view(n, 2048, 2).copy_(pcm_mono.view(n, 2048, 1).expand(n, 2048, 2))
+                hand_down(slot, got, (n, 2048, 2))
+            t_gpu += time.perf_counter() - t0
+            first = False
+    except BaseException:
+        bp.close()   # (also takes back a batch the parser team still holds)
+        raise
     consume()
     t_steps = time.perf_counter() - t_steps
-    if pool is not None:
-        pool.shutdown()
     if not sbr and keep_pcm:
         # the limiter's delay line holds the last attack_time_samples samples: api.c:2824-2866
         ctx.sync()
@@ -595,5 +625,7 @@ def decode_streams(streams, ctx=None, device="cuda:0", threads=0, keep_pcm=True,
     if own:
         ctx.close()
     if timing is not None:
-        timing.update(parse_s=t_parse, gpu_s=t_gpu, steps_s=t_steps, frames=frames)
+        # parse_s: inside the parser calls; wait_parse_s: what the loop waited for them; gpu_s: the loop's GPU section (enqueue
+        # + wait_down_s, the wait for the previous step's PCM)
+        timing.update(parse_s=t_parse, gpu_s=t_gpu, steps_s=t_steps, frames=frames, wait_parse_s=t_wait_parse, wait_down_s=t_wait_down)
     return [np.concatenate(o) if o else np.zeros((0, out_ch), np.int16) for o in out], rate * (2 if sbr else 1)

@@ -5,6 +5,7 @@
 #include "../../include/xaac_parse.h"
 
 #include <atomic>
+#include <chrono>
 #include <functional>
 #include <mutex>
 #include <new>
@@ -81,19 +82,38 @@ int usable_cpus() {
 }
 class Team {
  public:
-  void run(int items, int threads, const std::function<void(int)> &fn) {
-    std::lock_guard<std::mutex> serial(call_);
+  /* One job at a time: acquire() ... release() bracket it (a binary semaphore on a futex word rather than a mutex, because
+     the asynchronous pair xaac_parse_batch_start / _wait may take and give it back on different threads). */
+  void acquire() {
+    for (;;) {
+      uint32_t free_word = 0;
+      if (busy_.compare_exchange_strong(free_word, 1, std::memory_order_acquire)) return;
+      futex_wait(&busy_, 1);
+    }
+  }
+  void release() {
+    busy_.store(0, std::memory_order_release);
+    futex_wake_all(&busy_);
+  }
+  /* between acquire() and release(): hands `items` to `threads` threads -- the team's workers, and the caller itself as one
+     of them if it is going to call join(true) */
+  void launch(int items, int threads, std::function<void(int)> fn, bool caller_works) {
     if (threads < 1) threads = 1;
-    grow(threads - 1);
-    /* Every worker of the team -- not only the `threads - 1` that take items -- acknowledges every generation through
-       pending_: a worker reads fn_ / items_ / active_ only between seeing the new generation and its decrement, and run()
-       does not return (so the next run() cannot rewrite those fields, nor the caller's lambda die) before all decrements. */
-    fn_ = &fn, items_ = items, active_ = threads - 1;
+    const int helpers = caller_works ? threads - 1 : threads;
+    grow(helpers);
+    /* Every worker of the team -- not only the `helpers` that take items -- acknowledges every generation through
+       pending_: a worker reads fn_ / items_ / active_ only between seeing the new generation and its decrement, and join()
+       does not return (so the next launch() cannot rewrite those fields) before all decrements. */
+    fn_ = std::move(fn), items_ = items, active_ = helpers;
+    t_launch_ = std::chrono::steady_clock::now();
     next_.store(0, std::memory_order_relaxed);
+    busy_ns_.store(0, std::memory_order_relaxed);
     pending_.store((uint32_t)workers_.size(), std::memory_order_relaxed);
     generation_.fetch_add(1, std::memory_order_release); /* publishes the job */
     if (!workers_.empty()) futex_wake_all(&generation_);
-    work();
+  }
+  void join(bool caller_works) {
+    if (caller_works) work();
     for (int spin = 0;;) { /* every worker has seen this generation and is done with the job's fields */
       const uint32_t p = pending_.load(std::memory_order_acquire);
       if (p == 0) break;
@@ -102,6 +122,8 @@ class Team {
     }
     fn_ = nullptr;
   }
+  /* after join(): from launch() until the last helper ran out of items */
+  double helpers_busy_seconds() const { return 1e-9 * (double)busy_ns_.load(std::memory_order_relaxed); }
   ~Team() {
     quit_.store(true, std::memory_order_release);
     generation_.fetch_add(1, std::memory_order_release);
@@ -115,7 +137,7 @@ class Team {
       const int first = next_.fetch_add(kChunk, std::memory_order_relaxed);
       if (first >= items_) return;
       const int last = first + kChunk < items_ ? first + kChunk : items_;
-      for (int i = first; i < last; i++) (*fn_)(i);
+      for (int i = first; i < last; i++) fn_(i);
     }
   }
   void grow(int n) {
@@ -134,7 +156,13 @@ class Team {
           }
           if (quit_.load(std::memory_order_acquire)) return;
           seen = g;
-          if (id < active_) work(); /* else: this call uses fewer threads than the team has; acknowledge only */
+          if (id < active_) { /* else: this call uses fewer threads than the team has; acknowledge only */
+            work();
+            const int64_t t = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_launch_).count();
+            int64_t seen_t = busy_ns_.load(std::memory_order_relaxed);
+            while (t > seen_t && !busy_ns_.compare_exchange_weak(seen_t, t, std::memory_order_relaxed)) {
+            }
+          }
           if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) futex_wake_all(&pending_);
         }
       });
@@ -142,12 +170,13 @@ class Team {
   }
   static constexpr int kChunk = 4;
   static constexpr int kSpin = 4000; /* a few tens of microseconds */
-  std::mutex call_;
   std::vector<std::thread> workers_;
-  const std::function<void(int)> *fn_ = nullptr;
+  std::function<void(int)> fn_;
   std::atomic<int> next_{0};
-  std::atomic<uint32_t> generation_{0}, pending_{0};
+  std::atomic<uint32_t> generation_{0}, pending_{0}, busy_{0};
   std::atomic<bool> quit_{false};
+  std::atomic<int64_t> busy_ns_{0};
+  std::chrono::steady_clock::time_point t_launch_;
   int items_ = 0, active_ = 0;
 };
 Team &team() {
@@ -296,12 +325,58 @@ int32_t xaac_inverse_quant(int32_t magnitude, int32_t *out) {
   return err ? XAAC_PARSE_ERR_ESCAPE : XAAC_PARSE_OK;
 }
 
-int32_t xaac_parse_batch_run(const xaac_parse_batch *b) {
-  if (!b || b->n_streams < 0 || (b->n_ch != 1 && b->n_ch != 2) || !b->parser || !b->data || !b->bytes || !b->spec || !b->ics ||
-      !b->consumed || !b->status || (b->with_sbr && (!b->header || !b->frame || !b->flags)))
-    return XAAC_PARSE_ERR_SYNTAX;
-  const int n_ch = b->n_ch;
+namespace {
+/* the batch the team is working on (covered by the team's acquire() ... release()) */
+struct BatchJob {
+  xaac_parse_batch b;
   std::atomic<int> ok{0};
+  std::atomic<bool> in_flight{false}; /* an xaac_parse_batch_start whose _wait has not come yet */
+};
+BatchJob g_job;
+
+void parse_item(const xaac_parse_batch *b, int i, std::atomic<int> *ok) {
+  const int n_ch = b->n_ch;
+  xaac_parser *p = b->parser[i];
+  size_t used = 0;
+  b->consumed[i] = 0;
+  int32_t r = parse_frame(p, b->data[i], (size_t)b->bytes[i], b->stage, &used);
+  if (r == 0 && p->el.n_ch != n_ch) r = XAAC_PARSE_ERR_UNSUPPORTED;
+  xaac_sbr_side *side = nullptr;
+  if (r == 0 && b->with_sbr) {
+    side = &p->side_scratch;
+    r = xaac_parse_sbr_side(p, b->ps_enable, side);
+  }
+  b->status[i] = r;
+  if (r) return;
+  (*ok)++;
+  b->consumed[i] = used;
+  if (b->tools) b->tools[i] = tools_of(p->el);
+  for (int c = 0; c < n_ch; c++) {
+    memcpy(b->spec + ((size_t)i * n_ch + c) * 1024, p->el.ch[c].spec(), 1024 * sizeof(int32_t));
+    b->ics[((size_t)i * n_ch + c) * 2 + 0] = (uint8_t)p->el.ch[c].ics.window_sequence;
+    b->ics[((size_t)i * n_ch + c) * 2 + 1] = (uint8_t)p->el.ch[c].ics.window_shape;
+    if (side) {
+      b->header[(size_t)i * n_ch + c] = side->header;
+      b->frame[(size_t)i * n_ch + c] = side->frame[c];
+    }
+  }
+  if (side && b->reset_pitch && side->reset) b->reset_pitch[i] = p->sbr.reset_pitch;
+  if (side && b->esbr_side && p->esbr)
+    for (int c = 0; c < n_ch; c++) xs_export_esbr_side(&p->sbr, c, b->esbr_side + (size_t)i * n_ch + c);
+  if (side) {
+    if (b->ps_frame) b->ps_frame[i] = side->ps_frame;
+    int32_t *f = b->flags + (size_t)i * 8;
+    f[0] = side->apply, f[1] = side->reset, f[2] = side->reset_channels, f[3] = side->upsampling;
+    f[4] = side->stereo, f[5] = side->ps, f[6] = side->ps_start, f[7] = side->frame_ok;
+  }
+}
+
+bool batch_ok(const xaac_parse_batch *b) {
+  return b && b->n_streams >= 0 && (b->n_ch == 1 || b->n_ch == 2) && b->parser && b->data && b->bytes && b->spec && b->ics &&
+         b->consumed && b->status && (!b->with_sbr || (b->header && b->frame && b->flags));
+}
+
+int batch_threads(const xaac_parse_batch *b) {
   /* default: half the machine's hardware threads, at most 48 -- measured on a 2 x 64-core host (tools/bench_parser_scaling.py):
      3 - 4 x 10^6 HE-AACv2 frames/s at 32 .. 48 threads, less from 64 on (4096 streams x 20 KB of parser state are a
      latency-bound walk through memory that the second socket's threads only slow down; docs/NOTEBOOK.md 5l) */
@@ -313,42 +388,41 @@ int32_t xaac_parse_batch_run(const xaac_parse_batch *b) {
      0.85 x 10^6 frames/s -- the workers wait on memory, so some oversubscription pays; spinning ones beyond it steal time */
   if (b->threads <= 0 && usable > 0 && threads > 2 * usable) threads = 2 * usable;
   if (threads > (b->n_streams + 3) / 4) threads = b->n_streams > 0 ? (b->n_streams + 3) / 4 : 1;
-  team().run(b->n_streams, threads, [&](int i) {
-    xaac_parser *p = b->parser[i];
-    size_t used = 0;
-    b->consumed[i] = 0;
-    int32_t r = parse_frame(p, b->data[i], (size_t)b->bytes[i], b->stage, &used);
-    if (r == 0 && p->el.n_ch != n_ch) r = XAAC_PARSE_ERR_UNSUPPORTED;
-    xaac_sbr_side *side = nullptr;
-    if (r == 0 && b->with_sbr) {
-      side = &p->side_scratch;
-      r = xaac_parse_sbr_side(p, b->ps_enable, side);
-    }
-    b->status[i] = r;
-    if (r) return;
-    ok++;
-    b->consumed[i] = used;
-    if (b->tools) b->tools[i] = tools_of(p->el);
-    for (int c = 0; c < n_ch; c++) {
-      memcpy(b->spec + ((size_t)i * n_ch + c) * 1024, p->el.ch[c].spec(), 1024 * sizeof(int32_t));
-      b->ics[((size_t)i * n_ch + c) * 2 + 0] = (uint8_t)p->el.ch[c].ics.window_sequence;
-      b->ics[((size_t)i * n_ch + c) * 2 + 1] = (uint8_t)p->el.ch[c].ics.window_shape;
-      if (side) {
-        b->header[(size_t)i * n_ch + c] = side->header;
-        b->frame[(size_t)i * n_ch + c] = side->frame[c];
-      }
-    }
-    if (side && b->reset_pitch && side->reset) b->reset_pitch[i] = p->sbr.reset_pitch;
-    if (side && b->esbr_side && p->esbr)
-      for (int c = 0; c < n_ch; c++) xs_export_esbr_side(&p->sbr, c, b->esbr_side + (size_t)i * n_ch + c);
-    if (side) {
-      if (b->ps_frame) b->ps_frame[i] = side->ps_frame;
-      int32_t *f = b->flags + (size_t)i * 8;
-      f[0] = side->apply, f[1] = side->reset, f[2] = side->reset_channels, f[3] = side->upsampling;
-      f[4] = side->stereo, f[5] = side->ps, f[6] = side->ps_start, f[7] = side->frame_ok;
-    }
-  });
-  return ok.load();
+  return threads;
+}
+
+/* takes the team, hands it the batch (a copy of the descriptor: the caller's may go out of scope before the team is done) */
+void batch_launch(const xaac_parse_batch *b, bool caller_works) {
+  team().acquire();
+  g_job.b = *b;
+  g_job.ok.store(0, std::memory_order_relaxed);
+  team().launch(b->n_streams, batch_threads(b), [](int i) { parse_item(&g_job.b, i, &g_job.ok); }, caller_works);
+}
+}  // namespace
+
+int32_t xaac_parse_batch_run(const xaac_parse_batch *b) {
+  if (!batch_ok(b)) return XAAC_PARSE_ERR_SYNTAX;
+  batch_launch(b, true);
+  team().join(true);
+  const int ok = g_job.ok.load();
+  team().release();
+  return ok;
+}
+
+int32_t xaac_parse_batch_start(const xaac_parse_batch *b) {
+  if (!batch_ok(b)) return XAAC_PARSE_ERR_SYNTAX;
+  batch_launch(b, false);
+  g_job.in_flight.store(true, std::memory_order_release);
+  return XAAC_PARSE_OK;
+}
+
+int32_t xaac_parse_batch_wait(double *busy_seconds) {
+  if (!g_job.in_flight.exchange(false, std::memory_order_acq_rel)) return XAAC_PARSE_ERR_SYNTAX; /* nothing was started */
+  team().join(false);
+  const int ok = g_job.ok.load();
+  if (busy_seconds) *busy_seconds = team().helpers_busy_seconds();
+  team().release();
+  return ok;
 }
 
 void xaac_sbr_state_init(xaac_sbr_state *s) {

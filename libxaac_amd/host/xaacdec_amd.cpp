@@ -215,6 +215,7 @@ int main(int argc, char **argv) {
   xaac_ps_frame *d_psf = nullptr;
   xaac_ps_state *d_ps_state = nullptr;
   int32_t *d_idx = nullptr;
+  int32_t *d_flags = nullptr, *h_flags = nullptr; /* the parser's flag rows as xaac_sbr_state_apply_side_batch takes them */
   /* Path A (-esbr:1) */
   xaac_esbr_side *d_eside = nullptr;
   xaac_esbr_state *d_estate = nullptr;
@@ -269,7 +270,11 @@ int main(int argc, char **argv) {
     d_state = dev<xaac_sbr_state>((size_t)NC);
     xaac_sbr_state s0;
     xaac_sbr_state_init(&s0);
-    for (int i = 0; i < NC; i++) HIP(hipMemcpy(d_state + i, &s0, sizeof(s0), hipMemcpyHostToDevice));
+    {
+      std::vector<xaac_sbr_state> all((size_t)NC, s0);
+      HIP(hipMemcpy(d_state, all.data(), all.size() * sizeof(s0), hipMemcpyHostToDevice));
+    }
+    d_flags = dev<int32_t>((size_t)N * 8), h_flags = pinned<int32_t>((size_t)N * 8);
     if (n_ch == 1) {
       d_psf = dev<xaac_ps_frame>((size_t)N);
       d_ps_state = dev<xaac_ps_state>((size_t)N);
@@ -277,7 +282,10 @@ int main(int argc, char **argv) {
       d_idx = dev<int32_t>((size_t)N);
       xaac_ps_state p0;
       xaac_ps_state_init(&p0);
-      for (int i = 0; i < N; i++) HIP(hipMemcpy(d_ps_state + i, &p0, sizeof(p0), hipMemcpyHostToDevice));
+      {
+        std::vector<xaac_ps_state> all((size_t)N, p0);
+        HIP(hipMemcpy(d_ps_state, all.data(), all.size() * sizeof(p0), hipMemcpyHostToDevice));
+      }
       ws_bytes = xaac_sbr_hq_workspace_bytes(N, 1);
     } else {
       ws_bytes = xaac_sbr_lp_workspace_bytes(NC);
@@ -514,28 +522,27 @@ int main(int argc, char **argv) {
     } else {
       ib.pcm16 = d_core, ib.pcm_mode = XAAC_PCM_SBR;
       XA(xaac_imdct_process_batch(ctx, &ib));
-      for (int i = 0; i < N; i++) { /* rare: frames that reset the SBR decoder or fall back to plain up-sampling */
-        const int32_t *f = &s.flags[(size_t)i * 8];
-        if (s.status[(size_t)i] != 0 || (!f[1] && !f[3])) continue; /* (a stream that is over keeps its last frame's flags) */
-        xaac_sbr_side side;
-        memset(&side, 0, sizeof(side));
-        side.reset = f[1], side.reset_channels = f[2], side.upsampling = f[3], side.header = s.header[(size_t)i * n_ch];
-        HIP(hipStreamSynchronize(stream));
-        for (int c = 0; c < n_ch; c++) {
-          xaac_sbr_state t;
-          HIP(hipMemcpy(&t, d_state + (size_t)i * n_ch + c, sizeof(t), hipMemcpyDeviceToHost));
-          xaac_sbr_state_apply_side(&t, &side, c);
-          HIP(hipMemcpy(d_state + (size_t)i * n_ch + c, &t, sizeof(t), hipMemcpyHostToDevice));
-        }
-        if (n_ch == 1) {
-          xaac_ps_state t;
-          HIP(hipMemcpy(&t, d_ps_state + i, sizeof(t), hipMemcpyDeviceToHost));
-          xaac_ps_state_apply_side(&t, &side);
-          HIP(hipMemcpy(d_ps_state + i, &t, sizeof(t), hipMemcpyHostToDevice));
-        }
-      }
       HIP(hipMemcpyAsync(d_header, s.header, (size_t)NC * sizeof(xaac_sbr_header), hipMemcpyHostToDevice, stream));
       HIP(hipMemcpyAsync(d_frame, s.frame, (size_t)NC * sizeof(xaac_sbr_frame), hipMemcpyHostToDevice, stream));
+      { /* frames that reset the SBR decoder or fall back to plain up-sampling rewrite a few words of the resident state: on
+           the device, from the flag rows (a stream that is over keeps its last frame's flags: its row goes up as zeros) */
+        bool any = false;
+        for (int i = 0; i < N; i++) {
+          const int32_t *f = &s.flags[(size_t)i * 8];
+          const bool live = s.status[(size_t)i] == 0;
+          for (int k = 0; k < 8; k++) h_flags[(size_t)i * 8 + k] = live ? f[k] : 0;
+          any = any || (live && (f[1] || f[3]));
+        }
+        if (any) {
+          HIP(hipStreamSynchronize(stream)); /* (h_flags is one buffer: the step before may still be reading it) */
+          HIP(hipMemcpyAsync(d_flags, h_flags, (size_t)N * 8 * 4, hipMemcpyHostToDevice, stream));
+          xaac_sbr_apply_side_batch ab;
+          memset(&ab, 0, sizeof(ab));
+          ab.n_streams = N, ab.ch_fac = n_ch, ab.header = d_header, ab.flags = d_flags, ab.state = d_state;
+          ab.ps_state = n_ch == 1 ? d_ps_state : nullptr;
+          XA(xaac_sbr_state_apply_side_batch(ctx, &ab));
+        }
+      }
       if (n_ch == 2) {
         xaac_sbr_lp_batch b;
         memset(&b, 0, sizeof(b));

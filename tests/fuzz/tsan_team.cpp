@@ -3,7 +3,9 @@
  * is run many times back to back with the thread count alternating between calls (1, 7, 2, 8, 3, ...) and stream counts that
  * change the clamp `threads <= (n_streams + 3) / 4`, from two caller threads at once: a worker that is idle in one call
  * must never read the next call's job fields under the old generation, parse a stream twice, or touch the caller's
- * (stack-allocated) job after the call returned.  Results are compared with a single-threaded pass of the same frames.
+ * (stack-allocated) job after the call returned.  Every third call goes through xaac_parse_batch_start / _wait instead (the
+ * descriptor freed in between, the wait on another thread every other time).  Results are compared with a single-threaded
+ * pass of the same frames.
  *   tsan_team <stream.aac> <calls>
  */
 #include <cstdint>
@@ -52,7 +54,23 @@ static int run_caller(const std::vector<uint8_t> &file, int n_streams, int calls
     b.parser = s.parser.data(), b.data = s.data.data(), b.bytes = s.bytes.data(), b.spec = s.spec.data(), b.ics = s.ics.data();
     b.header = s.header.data(), b.frame = s.frame.data(), b.flags = s.flags.data(), b.consumed = s.consumed.data();
     b.status = s.status.data();
-    const int ok = xaac_parse_batch_run(&b);
+    int ok;
+    if (first_threads > 0 && c % 3 == 1) { /* the two-halves form: the descriptor dies between the halves, the waiter may be another thread */
+      xaac_parse_batch *tmp = new xaac_parse_batch(b);
+      if (xaac_parse_batch_start(tmp)) return 1;
+      memset(tmp, 0xee, sizeof(*tmp));
+      delete tmp;
+      double busy = -1.0;
+      if (c % 2) {
+        std::thread waiter([&] { ok = xaac_parse_batch_wait(&busy); });
+        waiter.join();
+      } else {
+        ok = xaac_parse_batch_wait(&busy);
+      }
+      if (busy < 0.0) return 1;
+    } else {
+      ok = xaac_parse_batch_run(&b);
+    }
     if (ok != live) {
       fprintf(stderr, "call %d: %d of %d streams parsed\n", c, ok, live);
       return 1;

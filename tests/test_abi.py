@@ -100,6 +100,7 @@ def test_round2_struct_layouts_match_headers(tmp_path):
     import esbr_structs as es
     pairs = [("xaac_esbr_ana_batch", libxaac_amd._EsbrAnaBatch, "qmf_im"), ("xaac_esbr_syn_batch", libxaac_amd._EsbrSynBatch, "out"),
              ("xaac_usac_imdct_batch", libxaac_amd._UsacImdctBatch, "status"), ("xaac_sbr_handover_batch", libxaac_amd._HandoverBatch, "ps_state"),
+             ("xaac_sbr_apply_side_batch", libxaac_amd._ApplySideBatch, "ps_state"),
              ("xaac_esbr_sbr_batch", libxaac_amd._EsbrSbrBatch, "hbe_state"), ("xaac_esbr_side", es.EsbrSide, "pitch_in_bins"),
              ("xaac_esbr_state", es.EsbrState, "ph_im"), ("xaac_esbr_ps_state", es.EsbrPsState, "syn_r"),
              ("xaac_esbr_ana_state", es.EsbrAna, "win_off"), ("xaac_esbr_syn_state", es.EsbrSyn, "filt_off")]

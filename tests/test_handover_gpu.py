@@ -52,3 +52,52 @@ def test_handover(mode):
     assert np.array_equal(st.cpu().numpy(), want_st)
     assert np.array_equal(ps.cpu().numpy(), want_ps)
     assert not np.array_equal(want_st, st0) or mode == "ps"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ch_fac", [1, 2])
+def test_apply_side_batch_equals_the_host_functions(ch_fac):
+    """xaac_sbr_state_apply_side_batch (the words ixheaacd_sbr_dec_reset / ixheaacd_prepare_upsamp rewrite, sbrdecoder.c:103-276,
+    on the resident arrays) against the host library's xaac_sbr_state_apply_side / xaac_ps_state_apply_side on copies of the
+    same random states: every flag combination, streams without a flag untouched."""
+    import torch
+    import libxaac_amd
+    from libxaac_amd import decoder
+    lib = decoder.load_host_library()
+    dev = torch.device("cuda:0")
+    ctx = libxaac_amd.XaacContext(0, None)
+    rng = np.random.default_rng(11 + ch_fac)
+    n = 300   # more than one 256-thread workgroup of channels
+    nc = n * ch_fac
+    sb, pb, hb = libxaac_amd.SBR_STATE_BYTES, libxaac_amd.PS_STATE_BYTES, libxaac_amd.SBR_HEADER_BYTES
+    st0 = rng.integers(0, 256, (nc, sb), dtype=np.uint8)
+    ps0 = rng.integers(0, 256, (n, pb), dtype=np.uint8)
+    hdr = rng.integers(0, 256, (nc, hb), dtype=np.uint8)
+    flags = np.zeros((n, 8), np.int32)
+    flags[:, 1] = rng.integers(0, 2, n)          # reset
+    flags[:, 2] = rng.integers(0, 3, n)          # reset_channels 0..2
+    flags[:, 3] = rng.integers(0, 4, n) == 0     # upsampling
+    flags[:, 0], flags[:, 4:] = 1, rng.integers(0, 2, (n, 4))
+    st, ps = torch.from_numpy(st0).to(dev), torch.from_numpy(ps0).to(dev)
+    ctx.sbr_state_apply_side_batch(torch.from_numpy(hdr).to(dev), torch.from_numpy(flags).to(dev), st, ch_fac,
+                                   ps_state=ps if ch_fac == 1 else None)
+    ctx.sync()
+    want_st, want_ps = st0.copy(), ps0.copy()
+    side = decoder.SbrSide()
+    for i in range(n):
+        for name, v in zip(("apply", "reset", "reset_channels", "upsampling", "stereo", "ps", "ps_start", "frame_ok"), flags[i]):
+            setattr(side, name, int(v))
+        ctypes.memmove(ctypes.addressof(side) + decoder.SbrSide.header.offset, hdr[i * ch_fac].ctypes.data, hb)
+        for ch in range(ch_fac):
+            row = np.ascontiguousarray(want_st[i * ch_fac + ch])
+            lib.xaac_sbr_state_apply_side(row.ctypes.data, ctypes.byref(side), ch)
+            want_st[i * ch_fac + ch] = row
+        if ch_fac == 1:
+            row = np.ascontiguousarray(want_ps[i])
+            lib.xaac_ps_state_apply_side(row.ctypes.data, ctypes.byref(side))
+            want_ps[i] = row
+    assert np.array_equal(st.cpu().numpy(), want_st)
+    assert np.array_equal(ps.cpu().numpy(), want_ps)
+    assert not np.array_equal(want_st, st0) and (ch_fac == 2 or not np.array_equal(want_ps, ps0))
+    quiet = (flags[:, 1] == 0) & (flags[:, 3] == 0)
+    assert quiet.any() and np.array_equal(want_st.reshape(n, -1)[quiet], st0.reshape(n, -1)[quiet])
