@@ -9,6 +9,7 @@
  */
 #include "aac_core.h"
 
+#include <stddef.h>
 #include <string.h>
 
 #include "../csrc/fx.h"
@@ -17,17 +18,41 @@
 namespace {
 
 /* ---- code books --------------------------------------------------------------------------------------------------- */
+/* what the first ten bits of a spectral code word decide, if they hold all of it: its length, the two or four quantised
+   values (signed books: with their sign; unsigned books: magnitudes, `nsign` sign bits follow the code word, one per
+   non-zero value in line order).  len 0: a longer code word, or a pair of book 11 with an escape -- the general path. */
+struct FastEntry {
+  int8_t v[4];
+  uint8_t len, nsign;
+};
 struct Book {
   const uint32_t *code;
   const uint8_t *len;
   const uint16_t *idx;
   int n;
   uint16_t lut[1024]; /* the first ten bits -> entry (length <= 10), or 0xffff */
+  FastEntry fast[1024];
 };
 Book g_book[12];
+int32_t g_deq[33]; /* deq_long(q, 0) for q = -16 .. 16 at [q + 16] */
 
+#define XH_BOOK(k) {xh_hcb##k##_code, xh_hcb##k##_len, xh_hcb##k##_idx, (int)(sizeof(xh_hcb##k##_len)), {0}, {{{0}, 0, 0}}}
 
-#define XH_BOOK(k) {xh_hcb##k##_code, xh_hcb##k##_len, xh_hcb##k##_idx, (int)(sizeof(xh_hcb##k##_len)), {0}}
+/* the values of value-order index idx of spectral book cb (block.c:129-1130: quads base 3, pairs base 9 / 8 / 13 / 17) */
+inline int unpack_values(int cb, int idx, int *v) {
+  if (cb <= 4) {
+    v[0] = idx / 27, idx -= v[0] * 27;
+    v[1] = idx / 9, idx -= v[1] * 9;
+    v[2] = idx / 3, v[3] = idx - v[2] * 3;
+    if (cb <= 2)
+      for (int j = 0; j < 4; j++) v[j] -= 1;
+    return 4;
+  }
+  const int mod = cb <= 6 ? 9 : (cb <= 8 ? 8 : (cb <= 10 ? 13 : 17));
+  v[0] = idx / mod, v[1] = idx % mod;
+  if (cb <= 6) v[0] -= 4, v[1] -= 4;
+  return 2;
+}
 
 void build_books() {
   static const Book init[12] = {XH_BOOK(0), XH_BOOK(1), XH_BOOK(2), XH_BOOK(3), XH_BOOK(4),  XH_BOOK(5),
@@ -41,8 +66,24 @@ void build_books() {
         const uint32_t first = k.code[e] >> 22, count = 1u << (10 - k.len[e]);
         for (uint32_t j = 0; j < count; j++) k.lut[first + j] = (uint16_t)e;
       }
+    if (b == 0) continue; /* the scale factor book has no value tuples */
+    const bool is_signed = b == 1 || b == 2 || b == 5 || b == 6;
+    for (int i = 0; i < 1024; i++) {
+      FastEntry &f = k.fast[i];
+      f = FastEntry{{0, 0, 0, 0}, 0, 0};
+      const int e = k.lut[i];
+      if (e == 0xffff) continue;
+      int v[4] = {0, 0, 0, 0};
+      const int n = unpack_values(b, k.idx[e], v);
+      int nz = 0, esc = 0;
+      for (int j = 0; j < n; j++) nz += v[j] != 0, esc += (b == 11 && v[j] == 16);
+      if (esc) continue;
+      for (int j = 0; j < n; j++) f.v[j] = (int8_t)v[j];
+      f.len = k.len[e];
+      f.nsign = is_signed ? 0 : (uint8_t)nz;
+    }
   }
-
+  for (int q = -16; q <= 16; q++) g_deq[q + 16] = q <= 0 ? -xh_pow43_q13[-q] : xh_pow43_q13[q];
 }
 
 /* one code word at the reader's position: its index in the book's value order */
@@ -97,55 +138,76 @@ inline int32_t escape(XhBits *br) {
    (block.c:404-417, :674-686, :728-742, :932-978): zero and negative values come out negated */
 inline int32_t deq_long(int32_t q, int t) { return q <= 0 ? -xh_pow43_q13[t - q] : xh_pow43_q13[q + t]; }
 
-/* the lines of one section of a long block (ixheaacd_huffman_dec_word2): width lines at x, pulse amplitudes at pulse */
-int spectral_long(XhBits *br, int cb, int width, int32_t *x, const uint8_t *pulse) {
-  const Book &k = g_book[cb];
-  int err = 0;
-  if (cb <= 4) {
-    for (int i = 0; i < width; i += 4) {
-      int idx = huff(k, br);
-      int v[4];
-      v[0] = idx / 27, idx -= v[0] * 27;
-      v[1] = idx / 9, idx -= v[1] * 9;
-      v[2] = idx / 3, v[3] = idx - v[2] * 3;
-      for (int j = 0; j < 4; j++) {
-        int q = v[j];
-        if (cb <= 2) q -= 1;
-        else if (q && br->get1()) q = -q;
-        x[i + j] = deq_long(q, pulse[i + j]);
-      }
+/* one code word of a long block's section the general way: any length, escapes (block.c:129-1130) */
+inline void spectral_long_word(XhBits *br, const Book &k, int cb, int32_t *x, const uint8_t *pulse, int *err) {
+  static const uint8_t no_pulse[4] = {0, 0, 0, 0};
+  if (!pulse) pulse = no_pulse;
+  const int idx = huff(k, br);
+  int v[4];
+  const int n = unpack_values(cb, idx, v);
+  if (cb <= 10) {
+    const bool is_signed = cb <= 2 || cb == 5 || cb == 6;
+    for (int j = 0; j < n; j++) {
+      int q = v[j];
+      if (!is_signed && q && br->get1()) q = -q;
+      x[j] = deq_long(q, pulse[j]);
     }
-  } else if (cb <= 10) {
-    const int mod = cb <= 6 ? 9 : (cb <= 8 ? 8 : 13);
-    for (int i = 0; i < width; i += 2) {
-      const int idx = huff(k, br);
-      int v[2] = {idx / mod, idx % mod};
-      for (int j = 0; j < 2; j++) {
-        int q = v[j];
-        if (cb <= 6) q -= 4;
-        else if (q && br->get1()) q = -q;
-        x[i + j] = deq_long(q, pulse[i + j]);
-      }
-    }
-  } else {
-    for (int i = 0; i < width; i += 2) {
-      const int idx = huff(k, br);
-      int v[2] = {idx / 17, idx % 17};
-      int neg[2] = {0, 0};
-      for (int j = 0; j < 2; j++)
-        if (v[j]) neg[j] = br->get1();
-      for (int j = 0; j < 2; j++) {
-        if (v[j] == 16) {
-          const int32_t m = escape(br) + pulse[i + j];
-          const int32_t p = pow43(m, &err);
-          x[i + j] = neg[j] ? fx_neg(p) : p;
-        } else {
-          x[i + j] = deq_long(neg[j] ? -v[j] : v[j], pulse[i + j]);
-        }
-      }
+    return;
+  }
+  int neg[2] = {0, 0};
+  for (int j = 0; j < 2; j++)
+    if (v[j]) neg[j] = br->get1();
+  for (int j = 0; j < 2; j++) {
+    if (v[j] == 16) {
+      const int32_t m = escape(br) + pulse[j];
+      const int32_t p = pow43(m, err);
+      x[j] = neg[j] ? fx_neg(p) : p;
+    } else {
+      x[j] = deq_long(neg[j] ? -v[j] : v[j], pulse[j]);
     }
   }
+}
+
+/* the lines of one section of a long block (ixheaacd_huffman_dec_word2): width lines at x, pulse amplitudes at pulse (or
+   none).  N values per code word; UNS: an unsigned book, sign bits behind the code word.  Code words of up to ten bits take
+   the book's combined table -- length, values and the number of sign bits from one look-up, the signs from the same
+   32-bit window -- with the bit position in a register; the rest goes the general way. */
+template <int N, bool UNS>
+int spectral_long_section(XhBits *br, int cb, int width, int32_t *x, const uint8_t *pulse) {
+  const Book &k = g_book[cb];
+  int err = 0;
+  size_t pos = br->pos;
+  for (int i = 0; i < width; i += N) {
+    const uint32_t w = br->peek32_at(pos);
+    const FastEntry f = k.fast[w >> 22];
+    if (f.len) {
+      uint32_t sb = w << f.len; /* the sign bits, the first one on top */
+      pos += (size_t)f.len + f.nsign;
+      for (int j = 0; j < N; j++) {
+        int q = f.v[j];
+        if (UNS) {
+          const uint32_t nz = q != 0;
+          q = ((sb >> 31) & nz) ? -q : q;
+          sb <<= nz;
+        }
+        x[i + j] = pulse ? deq_long(q, pulse[i + j]) : g_deq[q + 16];
+      }
+    } else {
+      br->pos = pos;
+      spectral_long_word(br, k, cb, x + i, pulse ? pulse + i : nullptr, &err);
+      pos = br->pos;
+    }
+  }
+  br->pos = pos;
+  if (pos > br->n_bits) br->overrun = true;
   return err ? XH_ERR_ESCAPE : 0;
+}
+
+int spectral_long(XhBits *br, int cb, int width, int32_t *x, const uint8_t *pulse) {
+  if (cb <= 2) return spectral_long_section<4, false>(br, cb, width, x, pulse);
+  if (cb <= 4) return spectral_long_section<4, true>(br, cb, width, x, pulse);
+  if (cb <= 6) return spectral_long_section<2, false>(br, cb, width, x, pulse);
+  return spectral_long_section<2, true>(br, cb, width, x, pulse);
 }
 
 /* the lines of bands start .. stop-1 of one window group of a short frame (ixheaacd_decode_huffman): per band, per
@@ -357,11 +419,11 @@ int read_tns(XhBits *br, XhChannel *c) { /* channel.c:961-1053 */
 int read_spectrum(const XhCoreState *st, XhBits *br, XhChannel *c) { /* channel.c:749-905 */
   const XhIcs &ics = c->ics;
   int32_t *spec = c->spec();
-  memset(c->spec_mem, 0, sizeof(c->spec_mem));
+  memset(c->spec_mem, 0, XH_SPEC_WORDS * sizeof(int32_t));
   if (ics.window_sequence != XH_EIGHT_SHORT) {
     uint8_t pulse[1024];
-    memset(pulse, 0, sizeof(pulse));
     if (c->pulse.present) { /* channel.c:727-747 */
+      memset(pulse, 0, sizeof(pulse));
       int k = st->swb_long[c->pulse.start_band];
       for (int i = 0; i <= c->pulse.number; i++) {
         k += c->pulse.offset[i];
@@ -373,7 +435,7 @@ int read_spectrum(const XhCoreState *st, XhBits *br, XhChannel *c) { /* channel.
       while (sfb < ics.max_sfb && c->cb[sfb] == cb) sfb++;
       const int lo = st->swb_long[start], width = st->swb_long[sfb] - lo;
       if (cb > XH_ZERO_HCB && cb < XH_NOISE_HCB) {
-        const int e = spectral_long(br, cb, width, spec + lo, pulse + lo);
+        const int e = spectral_long(br, cb, width, spec + lo, c->pulse.present ? pulse + lo : nullptr);
         if (e) return e;
       } else if (c->pulse.present) { /* a pulse on a line without spectral data: block.c:115-127, negated */
         for (int i = 0; i < width; i++) spec[lo + i] = -xh_pow43_q13[pulse[lo + i]];
@@ -608,10 +670,59 @@ void parcor_to_lpc(const int16_t *parcor, int16_t *lpc, int16_t *scale, int orde
   }
 }
 
+/* One output of the all-pole filter: acc = sum over j = m .. 1 of mul32x16(s[i - j], lpc[j]), added up with saturation in
+   that order (aac_tns.c:371-420).  If the magnitudes of the products add up to less than 2^31 no partial sum can leave
+   the 32-bit range, the saturating chain is the plain sum and the order does not matter.  With L = sum |lpc[j]| and
+   every state so far at most `quiet` = (2^31 - 1 - order) * 2^16 / L in magnitude that holds for sure
+   (|floor(s * l / 2^16)| <= |s| |l| / 2^16 + 1): the case for every stream with the headroom the reference's scaling
+   leaves (four bits), and it turns a chain of `order` dependent clamped adds per line into independent multiply-adds.
+   From the first state beyond `quiet` on the chain is run as written. */
+inline int32_t tns_acc_chain(const int32_t *h, const int16_t *lpc, int m) {
+  int32_t acc = 0;
+  for (int j = m; j > 0; j--) acc = fx_add_sat(acc, fx_mul32x16(h[-j], lpc[j]));
+  return acc;
+}
+template <int M>
+inline int32_t tns_acc_plain(const int32_t *h, const int16_t *lpc, int m_runtime) {
+  const int m = M ? M : m_runtime;
+  int64_t sum = 0;
+  for (int j = 1; j <= m; j++) sum += ((int64_t)h[-j] * lpc[j]) >> 16; /* = fx_mul32x16, exactly */
+  return (int32_t)sum;
+}
+inline uint32_t tns_mag(int32_t v) { return v < 0 ? 0u - (uint32_t)v : (uint32_t)v; }
+
+/* lines from .. n-1; returns the first line it did not do (n, or where a state left the quiet range) */
+template <int M>
+inline int tns_ar_run(int32_t *x, int from, int n, int inc, const int16_t *lpc, int order, int shift_value, int scale_spec,
+                      int32_t *hist, uint32_t quiet, uint32_t *loudest) {
+  x += (ptrdiff_t)from * inc;
+  uint32_t top = *loudest;
+  int i = from;
+  for (; i < n && top <= quiet; i++) {
+    const int32_t y0 = fx_shl_sat(*x, scale_spec);
+    const int32_t acc = tns_acc_plain<M>(hist + i, lpc, i < order ? i : order);
+    /* y = sub_sat(y0, shl_sat(acc, 1)), state = shl_sat(y, shift_value): line i + 1 waits for this state, so the three
+       clamps are first assumed idle (plain 64-bit arithmetic, checked beside the chain) and only redone if one was not */
+    const int64_t t64 = 2 * (int64_t)acc, y64 = (int64_t)y0 - t64, s64 = (int64_t)((uint64_t)y64 << shift_value);
+    int32_t y = (int32_t)y64, s = (int32_t)s64; /* the reference's state[0]: state[j] of step i is hist[i - 1 - j] */
+    if (__builtin_expect(t64 != (int32_t)t64 || y64 != (int32_t)y64 || s64 != (int32_t)s64, 0)) {
+      y = fx_sub_sat(y0, fx_shl_sat(acc, 1));
+      s = fx_shl_sat(y, shift_value);
+    }
+    hist[i] = s;
+    const uint32_t a = tns_mag(s);
+    top = a > top ? a : top;
+    *x = y >> scale_spec;
+    x += inc;
+  }
+  *loudest = top;
+  return i;
+}
+
 void tns_ar_filter(int32_t *x, int size, int inc, int16_t *lpc, int order, int shift_value, int scale_spec) {
   /* aac_tns.c:371-420: the order is rounded up to a multiple of four with zero coefficients, and the first `order`
      lines are filtered whether the region has that many or not */
-  int32_t state[32 + 4 + 1];
+  int32_t hist[1024 + 64];
   if (order & 3) {
     int i;
     for (i = order + 1; i < (order & ~3) + 4; i++) lpc[i] = 0;
@@ -623,15 +734,27 @@ void tns_ar_filter(int32_t *x, int size, int inc, int16_t *lpc, int order, int s
     }
   }
   const int n = size > order ? size : order;
-  for (int i = 0; i < n; i++) {
-    int32_t y = fx_shl_sat(*x, scale_spec);
-    int32_t acc = 0;
-    for (int j = i < order ? i : order; j > 0; j--) {
-      acc = fx_add_sat(acc, fx_mul32x16(state[j - 1], lpc[j]));
-      state[j] = state[j - 1];
+  int64_t l1 = 0;
+  for (int j = 1; j <= order; j++) l1 += lpc[j] < 0 ? -(int64_t)lpc[j] : lpc[j];
+  const int64_t q = l1 ? (((int64_t)FX_MAX32 - order) << 16) / l1 : (int64_t)0xffffffff;
+  const uint32_t quiet = q > (int64_t)0xffffffff ? 0xffffffffu : (uint32_t)q;
+  uint32_t loudest = 0;
+  const int lead = order < n ? order : n;
+  int i = tns_ar_run<0>(x, 0, lead, inc, lpc, order, shift_value, scale_spec, hist, quiet, &loudest); /* fewer than `order` states yet */
+  if (i == lead) {
+    switch (order) {
+      case 4: i = tns_ar_run<4>(x, lead, n, inc, lpc, order, shift_value, scale_spec, hist, quiet, &loudest); break;
+      case 8: i = tns_ar_run<8>(x, lead, n, inc, lpc, order, shift_value, scale_spec, hist, quiet, &loudest); break;
+      case 12: i = tns_ar_run<12>(x, lead, n, inc, lpc, order, shift_value, scale_spec, hist, quiet, &loudest); break;
+      default: i = tns_ar_run<0>(x, lead, n, inc, lpc, order, shift_value, scale_spec, hist, quiet, &loudest); break;
     }
+  }
+  x += (ptrdiff_t)i * inc;
+  for (; i < n; i++) { /* a state beyond the quiet range: the chain as the reference runs it */
+    int32_t y = fx_shl_sat(*x, scale_spec);
+    const int32_t acc = tns_acc_chain(hist + i, lpc, i < order ? i : order);
     y = fx_sub_sat(y, fx_shl_sat(acc, 1));
-    state[0] = fx_shl_sat(y, shift_value);
+    hist[i] = fx_shl_sat(y, shift_value);
     *x = y >> scale_spec;
     x += inc;
   }

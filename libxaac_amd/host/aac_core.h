@@ -59,9 +59,12 @@ struct XhChannel {
   int pns_active;
   int16_t noise_energy;
   uint8_t pns_used[8 * 16];
-  int32_t spec_mem[1024 + 2 * XH_SPEC_SLACK];
+  /* the frame's lines: XH_SPEC_WORDS words of the CALLER's (set before xh_parse_raw_data_block; a parser that keeps one
+     such buffer per thread instead of one per stream has 8 KB less state to drag through the caches per frame) */
+  int32_t *spec_mem;
   int32_t *spec() { return spec_mem + XH_SPEC_SLACK; }
 };
+#define XH_SPEC_WORDS (1024 + 2 * XH_SPEC_SLACK)
 
 /* what is constant between ADTS headers of one stream, and the little state that outlives a frame */
 struct XhCoreState {
@@ -95,7 +98,8 @@ int32_t xh_inverse_quant(int32_t magnitude, int *err);
 /* sr_index 0 .. 11; returns 0 or XH_ERR_UNSUPPORTED */
 int xh_core_init(XhCoreState *st, int sr_index);
 
-/* Parses one raw_data_block at the reader's position (up to and including ID_END and the byte alignment), dequantises,
+/* Parses one raw_data_block at the reader's position (up to and including ID_END and the byte alignment) into the line
+   buffers el->ch[c].spec_mem point to, dequantises,
    applies the scale factors and the tools (M/S, intensity, PNS, TNS): el->ch[c].spec() are the lines the IMDCT takes.
    `stage`: 2 = everything; 1 = stop before the tools (spectra as at the entry of ixheaacd_channel_pair_process).
    Returns 0 or a negative XH_ERR_*. */

@@ -18,7 +18,9 @@ struct XhBits {
   XhBits(const uint8_t *data, size_t bytes) : p(data), n_bits(bytes * 8), pos(0), overrun(false) {}
 
   /* the next 32 bits, first bit in the MSB, without consuming them */
-  uint32_t peek32() const {
+  uint32_t peek32() const { return peek32_at(pos); }
+  /* ... at any bit position (decoding loops that keep the position in a register and hand it back with `pos = ...`) */
+  uint32_t peek32_at(size_t pos) const {
     const size_t byte = pos >> 3;
     const size_t total = n_bits >> 3;
     uint64_t w;

@@ -31,7 +31,6 @@ struct xaac_parser {
   XhElement el;
   int sbr_ready, sampling_rate, esbr;
   XsDecoder sbr;
-  xaac_sbr_side side_scratch;
 };
 
 /* A small persistent team for xaac_parse_batch_run.  Workers wait for the next call on a generation counter: a short spin
@@ -223,9 +222,10 @@ int32_t xaac_adts_parse_header(const uint8_t *data, size_t n, xaac_adts_header *
 
 static int32_t tools_of(const XhElement &el) {
   int32_t tools = 0;
-  for (int g = 0; g < 8; g++)
-    for (int sfb = 0; sfb < 64; sfb++)
-      if (el.ms_used[g][sfb]) tools |= XAAC_TOOL_MS;
+  if (el.n_ch == 2 && el.common_window) /* (ms_used is cleared per element and written inside these bounds only) */
+    for (int g = 0; g < el.ch[0].ics.num_groups; g++)
+      for (int sfb = 0; sfb < el.ch[0].ics.max_sfb; sfb++)
+        if (el.ms_used[g][sfb]) tools |= XAAC_TOOL_MS;
   for (int c = 0; c < el.n_ch; c++) {
     const XhChannel &ch = el.ch[c];
     if (ch.pns_active) tools |= XAAC_TOOL_PNS;
@@ -260,6 +260,10 @@ static int32_t parse_frame(xaac_parser *p, const uint8_t *data, size_t n, int32_
     p->sampling_rate = h.sampling_rate;
   }
   XhBits br(data + h.header_bytes, (size_t)(h.frame_bytes - h.header_bytes));
+  /* the frame's lines live in a buffer of the calling thread until the caller has copied them out (both entry points do,
+     before they return): nothing of a stream outlives the frame there */
+  static thread_local int32_t lines[2][XH_SPEC_WORDS];
+  p->el.ch[0].spec_mem = lines[0], p->el.ch[1].spec_mem = lines[1];
   return xh_parse_raw_data_block(&p->core, &br, &p->el, stage);
 }
 
@@ -343,7 +347,8 @@ void parse_item(const xaac_parse_batch *b, int i, std::atomic<int> *ok) {
   if (r == 0 && p->el.n_ch != n_ch) r = XAAC_PARSE_ERR_UNSUPPORTED;
   xaac_sbr_side *side = nullptr;
   if (r == 0 && b->with_sbr) {
-    side = &p->side_scratch;
+    static thread_local xaac_sbr_side side_of_thread; /* copied into the batch's arrays below */
+    side = &side_of_thread;
     r = xaac_parse_sbr_side(p, b->ps_enable, side);
   }
   b->status[i] = r;

@@ -46,3 +46,15 @@ def test_worker_team_is_race_free_when_thread_counts_alternate(tsan_team):
                            capture_output=True, text=True, timeout=600, env=env)
         assert p.returncode == 0 and "ThreadSanitizer" not in p.stderr, (p.stdout[-300:], p.stderr[-3000:])
         assert "equal to the single-threaded pass" in p.stdout
+
+
+def test_tns_filter_and_code_word_tables_equal_their_plain_forms(tmp_path):
+    """tests/fuzz/tns_filter_check.cpp: the parser's TNS filter (clamp-free multiply-adds inside a proven-quiet range, the
+    reference's saturating chain outside it) against the chain as ixheaacd_aac_tns.c:371-420 runs it, on quiet and on
+    saturating regions; and every entry of the combined spectral code word tables against the general decode (ASan + UBSan)"""
+    exe = str(tmp_path / "tns_filter_check")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fwrapv", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           os.path.join(ROOT, "tests", "fuzz", "tns_filter_check.cpp"), "-o", exe])
+    p = subprocess.run([exe, "20000"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-300:], p.stderr[-3000:])
+    assert "equal to the chain" in p.stdout and "(0 saturated" not in p.stdout
