@@ -176,13 +176,41 @@ template <int N, bool UNS>
 int spectral_long_section(XhBits *br, int cb, int width, int32_t *x, const uint8_t *pulse) {
   const Book &k = g_book[cb];
   int err = 0;
-  size_t pos = br->pos;
+  /* a 64-bit reservoir, the next bit on top: refilled four bytes at a time while the frame has eight left from the fill
+     position on, else (the last bytes of a frame) this section goes through the reader's own window */
+  const uint8_t *const base = br->p;
+  const size_t total = br->n_bits >> 3;
+  size_t pos = br->pos, fill = (pos >> 3) + 8; /* `fill`: the first byte not in the reservoir */
+  uint64_t buf = 0;
+  int have = 0; /* valid bits in buf */
+  bool fast = (pos >> 3) + 8 <= total;
+  if (fast) {
+    uint64_t w;
+    memcpy(&w, base + (pos >> 3), 8);
+    buf = __builtin_bswap64(w) << (pos & 7);
+    have = 64 - (int)(pos & 7);
+  }
   for (int i = 0; i < width; i += N) {
-    const uint32_t w = br->peek32_at(pos);
+    uint32_t w;
+    if (fast) {
+      if (have < 32) {
+        if (fill + 4 <= total) {
+          uint32_t t;
+          memcpy(&t, base + fill, 4);
+          buf |= (uint64_t)__builtin_bswap32(t) << (32 - have);
+          have += 32, fill += 4;
+        } else {
+          fast = false;
+        }
+      }
+    }
+    w = fast ? (uint32_t)(buf >> 32) : br->peek32_at(pos);
     const FastEntry f = k.fast[w >> 22];
     if (f.len) {
       uint32_t sb = w << f.len; /* the sign bits, the first one on top */
-      pos += (size_t)f.len + f.nsign;
+      const int used = f.len + f.nsign;
+      pos += (size_t)used;
+      buf <<= used, have -= used;
       for (int j = 0; j < N; j++) {
         int q = f.v[j];
         if (UNS) {
@@ -196,6 +224,14 @@ int spectral_long_section(XhBits *br, int cb, int width, int32_t *x, const uint8
       br->pos = pos;
       spectral_long_word(br, k, cb, x + i, pulse ? pulse + i : nullptr, &err);
       pos = br->pos;
+      fast = (pos >> 3) + 8 <= total; /* the reservoir starts over behind the long code word */
+      if (fast) {
+        uint64_t t;
+        memcpy(&t, base + (pos >> 3), 8);
+        buf = __builtin_bswap64(t) << (pos & 7);
+        have = 64 - (int)(pos & 7);
+        fill = (pos >> 3) + 8;
+      }
     }
   }
   br->pos = pos;
