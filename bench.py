@@ -908,6 +908,9 @@ def main():
 
     import torch
     import libxaac_amd
+    # torch sizes its CPU pool by the CPUs the machine lists; on a box that lists 256 and grants 16 the pool's spinning threads
+    # would eat the cgroup quota the host-side legs (cpu_baseline, end_to_end) are measured in
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), usable_cores()[0])))
 
     from libxaac_amd import dist as xdist
     rank, local_rank, world = xdist.env_rank()

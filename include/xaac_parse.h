@@ -143,6 +143,12 @@ typedef struct xaac_parse_batch {
   int32_t *status;            /* [n_streams] XAAC_PARSE_OK / _NEED_DATA / error: such a stream's rows are left as they were */
   xaac_esbr_side *esbr_side;  /* with_sbr, parsers in xaac_parser_set_esbr(1) mode, optional: [n_streams][n_ch] */
   int32_t *reset_pitch;       /* ... optional: [n_streams], written for frames with flags[1] (reset): xaac_parse_reset_pitch */
+  uint64_t *pos;              /* optional [n_streams], in / out: the library keeps the streams' read positions -- stream i's frame
+                                 starts at data[i] + pos[i] with bytes[i] - pos[i] bytes available, and pos[i] moves on by the
+                                 frame's length where status is XAAC_PARSE_OK.  A host that leaves data / bytes as the whole
+                                 streams can then issue the next step's call without touching its arrays in between.
+                                 (Appended in round 4: a descriptor built for the older layout must be zero-initialised at the
+                                 new size.) */
 } xaac_parse_batch;
 
 /* returns the number of streams whose status is XAAC_PARSE_OK, or a negative XAAC_PARSE_ERR_* for a bad descriptor */

@@ -181,7 +181,7 @@ class _ParseBatch(ctypes.Structure):
     # struct xaac_parse_batch
     _fields_ = [(n, ctypes.c_int32) for n in ("n_streams", "n_ch", "with_sbr", "ps_enable", "stage", "threads")] + \
                [(n, ctypes.c_void_p) for n in ("parser", "data", "bytes", "spec", "ics", "header", "frame", "ps_frame", "flags",
-                                               "tools", "consumed", "status", "esbr_side", "reset_pitch")]
+                                               "tools", "consumed", "status", "esbr_side", "reset_pitch", "pos")]
 
 
 F_APPLY, F_RESET, F_RESET_CHANNELS, F_UPSAMPLING, F_STEREO, F_PS, F_PS_START, F_FRAME_OK = range(8)
@@ -245,6 +245,7 @@ class BatchParser:
         self.blob = np.frombuffer(b"".join(bytes(d) for d in streams) + b"\0" * 16, np.uint8).copy()
         self.base = self.blob.ctypes.data
         self.pos = np.zeros(n, np.uint64)
+        self._ptrs = (np.uint64(self.base) + self.start).astype(np.uint64)   # every stream's first byte
         self.parsers = (ctypes.c_void_p * n)()
         for i in range(n):
             h = ctypes.c_void_p()
@@ -255,7 +256,6 @@ class BatchParser:
             self.parsers[i] = h
         self.threads, self.stage = int(threads), int(stage)
         self.consumed, self.status = np.zeros(n, np.uint64), np.zeros(n, np.int32)
-        self.tools = np.zeros(n, np.int32)
         self.reset_pitch = np.zeros(n, np.int32)   # at frames with a reset flag: xaac_parse_reset_pitch
         self.frames = np.zeros(n, np.int64)
         hdr = AdtsHeader()
@@ -282,41 +282,33 @@ class BatchParser:
                 self.lib.xaac_parser_destroy(self.parsers[i])
                 self.parsers[i] = None
 
-    def _descriptor(self, spec, ics, hdr, frm, psf, flags, with_sbr, eside=None):
-        n = self.n
-        # (kept on the object: the library reads them until the call -- or, for start_step(), the wait_step() -- is over)
-        self._left = self.length - self.pos
-        self._ptrs = (np.uint64(self.base) + self.start + self.pos).astype(np.uint64)
+    def _descriptor(self, spec, ics, hdr, frm, psf, flags, with_sbr, eside=None, status=None, reset_pitch=None):
+        # data / bytes are the whole streams and stay as they are; the library moves self.pos (xaac_parse_batch::pos), so a
+        # call costs this thread the filling of the descriptor and nothing per stream
         b = _ParseBatch()
-        b.n_streams, b.n_ch, b.with_sbr, b.ps_enable, b.stage, b.threads = n, self.n_ch, int(with_sbr), 1, self.stage, self.threads
-        b.parser, b.data, b.bytes = ctypes.addressof(self.parsers), self._ptrs.ctypes.data, self._left.ctypes.data
+        b.n_streams, b.n_ch, b.with_sbr, b.ps_enable, b.stage, b.threads = self.n, self.n_ch, int(with_sbr), 1, self.stage, self.threads
+        b.parser, b.data, b.bytes = ctypes.addressof(self.parsers), self._ptrs.ctypes.data, self.length.ctypes.data
         ptr = lambda t: None if t is None else (t.data_ptr() if hasattr(t, "data_ptr") else t.ctypes.data)
         b.spec, b.ics, b.header, b.frame, b.ps_frame, b.flags = ptr(spec), ptr(ics), ptr(hdr), ptr(frm), ptr(psf), ptr(flags)
-        b.tools, b.consumed, b.status = self.tools.ctypes.data, self.consumed.ctypes.data, self.status.ctypes.data
+        b.tools, b.consumed = None, self.consumed.ctypes.data   # (which tools a frame used: nobody downstream asks)
+        b.status = (self.status if status is None else status).ctypes.data
         b.esbr_side = ptr(eside)
-        b.reset_pitch = self.reset_pitch.ctypes.data
+        b.reset_pitch = (self.reset_pitch if reset_pitch is None else reset_pitch).ctypes.data
+        b.pos = self.pos.ctypes.data
         return b
 
-    def _advance(self, ok):
+    def _advance(self, ok, status=None):
         if ok < 0:
             raise RuntimeError("xaac_parse_batch: %d" % ok)
-        self.pos += self.consumed
-        self.frames += (self.status == 0)
-        bad = (self.status != 0) & (self.status != 1)
-        if np.any(bad):
-            i = int(np.nonzero(bad)[0][0])
-            raise ParseError(int(self.status[i]), int(self.frames[i]))
-        return self.status == 0
-
-    def _run(self, spec, ics, hdr, frm, psf, flags, with_sbr, advance=True, eside=None):
-        b = self._descriptor(spec, ics, hdr, frm, psf, flags, with_sbr, eside)
-        ok = self.lib.xaac_parse_batch_run(ctypes.byref(b))
-        if ok < 0:
-            raise RuntimeError("xaac_parse_batch_run: %d" % ok)
-        if advance:
-            self.pos += self.consumed
-            self.frames += (self.status == 0)
-        return ok
+        status = self.status if status is None else status
+        good = status == 0
+        self.frames += good
+        if ok != self.n:
+            bad = ~good & (status != 1)
+            if np.any(bad):
+                i = int(np.nonzero(bad)[0][0])
+                raise ParseError(int(status[i]), int(self.frames[i]))
+        return good
 
     def step(self, spec, ics, hdr=None, frm=None, psf=None, flags=None, eside=None):
         """parses the next frame of every stream into the staging arrays; -> bool[n]: which streams delivered a frame
@@ -324,21 +316,30 @@ class BatchParser:
         b = self._descriptor(spec, ics, hdr, frm, psf, flags, self.sbr, eside)
         return self._advance(self.lib.xaac_parse_batch_run(ctypes.byref(b)))
 
-    def start_step(self, spec, ics, hdr=None, frm=None, psf=None, flags=None, eside=None):
+    def start_step(self, spec, ics, hdr=None, frm=None, psf=None, flags=None, eside=None, status=None, reset_pitch=None):
         """step() in two halves (xaac_parse_batch_start / _wait): the library's worker team parses while the caller does
-        something else; the staging arrays are the team's until wait_step() returns."""
-        b = self._descriptor(spec, ics, hdr, frm, psf, flags, self.sbr, eside)
+        something else; the staging arrays are the team's until wait_step() returns.  status / reset_pitch: the caller's own
+        int32[n] arrays for this step's results (a caller that starts the next step before it has looked at this one's)."""
+        self._status_in_flight = status
+        b = self._descriptor(spec, ics, hdr, frm, psf, flags, self.sbr, eside, status, reset_pitch)
         rc = self.lib.xaac_parse_batch_start(ctypes.byref(b))
         if rc:
             raise RuntimeError("xaac_parse_batch_start: %d" % rc)
         self._in_flight = True
 
-    def wait_step(self):
-        """-> (bool[n] as step(), seconds the team parsed)"""
+    def wait_step(self, check=True):
+        """-> (bool[n] as step(), seconds the team parsed); check False: (parsed-ok count, seconds) -- the caller looks at its
+        status array itself (finish_step) after it has started the next step"""
         busy = ctypes.c_double(0.0)
         ok = self.lib.xaac_parse_batch_wait(ctypes.byref(busy))
         self._in_flight = False
-        return self._advance(ok), busy.value
+        if not check:
+            return ok, busy.value
+        return self._advance(ok, self._status_in_flight), busy.value
+
+    def finish_step(self, ok, status):
+        """what wait_step(check=True) does behind the library call, for a step waited for with check=False"""
+        return self._advance(ok, status)
 
 
 def _struct_bytes(fn, size):
@@ -413,6 +414,7 @@ def _decode_streams(streams, ctx, device, threads, keep_pcm, timing, overlap, es
                 if n_ch == 1:
                     self.psf = pinned(n, PS_FRAME_BYTES)
             self.got, self.seconds = None, 0.0
+            self.status, self.reset_pitch = np.zeros(n, np.int32), np.zeros(n, np.int32)   # this set's own (begin / end / finish)
 
         def parse(self):
             t0 = time.perf_counter()
@@ -422,12 +424,16 @@ def _decode_streams(streams, ctx, device, threads, keep_pcm, timing, overlap, es
             return self
 
         def begin(self):    # the library's team parses into this set while the caller queues the step before on the GPU
-            bp.start_step(self.spec, self.ics, self.hdr, self.frm, self.psf, self.flags, self.eside)
+            bp.start_step(self.spec, self.ics, self.hdr, self.frm, self.psf, self.flags, self.eside, status=self.status,
+                          reset_pitch=self.reset_pitch)
             return self
 
-        def end(self):
-            self.got, self.seconds = bp.wait_step()
-            self.reset_pitch = bp.reset_pitch.copy()
+        def end(self):      # back from the team; the results are looked at in finish(), once the next set is on its way
+            self.ok, self.seconds = bp.wait_step(check=False)
+            return self
+
+        def finish(self):
+            self.got = bp.finish_step(self.ok, self.status)
             return self
 
     # three staging sets: the parse of step k + 1 | the copies up and kernels of step k | the copy down of step k - 1
@@ -531,13 +537,16 @@ def _decode_streams(streams, ctx, device, threads, keep_pcm, timing, overlap, es
             t_w = time.perf_counter()
             cur = pending.end() if overlap else sets[0].parse()
             t_wait_parse += time.perf_counter() - t_w
+            if overlap:    # the next step's frames are parsed while this thread looks at this step's and queues them on the GPU
+                which = (which + 1) % 3
+                pending = sets[which].begin()
+                cur.finish()
             t_parse += cur.seconds
             got = cur.got
             if not got.any():
+                if overlap:
+                    pending.end()   # (every stream is over: that call found nothing to parse)
                 break
-            if overlap:    # the next step's frames are parsed while the GPU works on this one's
-                which = (which + 1) % 3
-                pending = sets[which].begin()
             slot = step_no & 1
             step_no += 1
             pcm = pcm2[slot]

@@ -477,8 +477,10 @@ int read_spectrum(const XhCoreState *st, XhBits *br, XhChannel *c) { /* channel.
         for (int i = 0; i < width; i++) spec[lo + i] = -xh_pow43_q13[pulse[lo + i]];
       }
     }
+    /* (bands without spectral data -- code book 0, noise, intensity -- hold zeros, and zeros they stay whatever the gain) */
     for (int sfb = 0, lo = 0; sfb < ics.max_sfb; lo += st->width_long[sfb], sfb++)
-      apply_scale_factor(c->sf[sfb], spec + lo, st->width_long[sfb]);
+      if ((c->cb[sfb] > XH_ZERO_HCB && c->cb[sfb] < XH_NOISE_HCB) || c->pulse.present)
+        apply_scale_factor(c->sf[sfb], spec + lo, st->width_long[sfb]);
   } else {
     int win = 0;
     for (int g = 0; g < ics.num_groups; g++) {
@@ -917,7 +919,9 @@ int xh_parse_raw_data_block(XhCoreState *st, XhBits *br, XhElement *el, int stag
           el->ch[c].pns_active = 0;
           el->ch[c].noise_energy = 0;
           memset(el->ch[c].pns_used, 0, sizeof(el->ch[c].pns_used));
-          memset(&el->ch[c].tns, 0, sizeof(el->ch[c].tns));
+          /* (a filter's fields are written by read_tns before tns() reads them: n_filt says how many are valid) */
+          el->ch[c].tns.present = 0;
+          memset(el->ch[c].tns.n_filt, 0, sizeof(el->ch[c].tns.n_filt));
         }
         if (id == XH_ID_CPE) {
           el->common_window = br->get1();

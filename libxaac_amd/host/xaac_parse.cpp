@@ -343,7 +343,8 @@ void parse_item(const xaac_parse_batch *b, int i, std::atomic<int> *ok) {
   xaac_parser *p = b->parser[i];
   size_t used = 0;
   b->consumed[i] = 0;
-  int32_t r = parse_frame(p, b->data[i], (size_t)b->bytes[i], b->stage, &used);
+  const uint64_t at = b->pos ? (b->pos[i] < b->bytes[i] ? b->pos[i] : b->bytes[i]) : 0;
+  int32_t r = parse_frame(p, b->data[i] + at, (size_t)(b->bytes[i] - at), b->stage, &used);
   if (r == 0 && p->el.n_ch != n_ch) r = XAAC_PARSE_ERR_UNSUPPORTED;
   xaac_sbr_side *side = nullptr;
   if (r == 0 && b->with_sbr) {
@@ -355,6 +356,7 @@ void parse_item(const xaac_parse_batch *b, int i, std::atomic<int> *ok) {
   if (r) return;
   (*ok)++;
   b->consumed[i] = used;
+  if (b->pos) b->pos[i] = at + used;
   if (b->tools) b->tools[i] = tools_of(p->el);
   for (int c = 0; c < n_ch; c++) {
     memcpy(b->spec + ((size_t)i * n_ch + c) * 1024, p->el.ch[c].spec(), 1024 * sizeof(int32_t));

@@ -184,6 +184,8 @@ int main(int argc, char **argv) {
   }
   std::vector<const uint8_t *> ptr((size_t)N);
   std::vector<uint64_t> left((size_t)N), pos((size_t)N, 0);
+  const bool list_mode = !ilist.empty();
+  std::vector<char> broken((size_t)N, 0); /* -ilist: a stream whose frame did not parse is treated as over from there on */
 
   /* device-resident state and per-step device buffers */
   int32_t *d_overlap = dev<int32_t>((size_t)NCD * 512), *d_spec = dev<int32_t>((size_t)NCD * 1024);
@@ -309,7 +311,7 @@ int main(int argc, char **argv) {
     const auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < N; i++) {
       const std::vector<uint8_t> &d = datas[datas.size() > 1 ? (size_t)i : 0];
-      ptr[(size_t)i] = d.data() + pos[(size_t)i], left[(size_t)i] = d.size() - pos[(size_t)i];
+      ptr[(size_t)i] = d.data() + pos[(size_t)i], left[(size_t)i] = broken[(size_t)i] ? 0 : d.size() - pos[(size_t)i];
     }
     xaac_parse_batch b;
     memset(&b, 0, sizeof(b));
@@ -321,7 +323,15 @@ int main(int argc, char **argv) {
     const int ok = xaac_parse_batch_run(&b);
     if (ok < 0) die("xaac_parse_batch_run", ok);
     for (int i = 0; i < N; i++) {
-      if (s->status[(size_t)i] < 0) die("a frame does not parse", s->status[(size_t)i]);
+      if (s->status[(size_t)i] < 0) {
+        /* one file of a list with trailing bytes or damage must not take the other streams' output along: that stream ends
+           here (what it delivered so far is written), the batch goes on */
+        if (!list_mode) die("a frame does not parse", s->status[(size_t)i]);
+        fprintf(stderr, "xaacdec_amd: stream %d: a frame does not parse (%d) at byte %llu: the stream ends here\n", i, s->status[(size_t)i],
+                (unsigned long long)pos[(size_t)i]);
+        broken[(size_t)i] = 1;
+        s->status[(size_t)i] = XAAC_PARSE_NEED_DATA;
+      }
       pos[(size_t)i] += s->consumed[(size_t)i];
     }
     s->delivered = ok;
@@ -337,7 +347,6 @@ int main(int argc, char **argv) {
     phase_s[k] += std::chrono::duration<double>(now - t_phase).count();
     t_phase = now;
   };
-  const bool list_mode = !ilist.empty();
   std::vector<std::vector<int16_t>> pcms((size_t)(list_mode ? N : 1)); /* every stream's output (-ilist), or stream 0's */
   std::vector<int16_t> &pcm = pcms[0];
   std::vector<char> ended((size_t)N, 0);
@@ -383,16 +392,18 @@ int main(int argc, char **argv) {
     HIP(hipEventSynchronize(ev_down[pending.slot]));
     int16_t *h_pcm = h_pcm2[pending.slot];
     const int32_t *h_status = h_status2[pending.slot];
-    if (sbr)
-      for (int i = 0; i < (pending.mono_twice || (n_ch == 1 && !esbr) ? N : NC); i++)
-        if (h_status[i] < 0) die("the SBR kernels refused a frame", i);
+    const std::vector<int32_t> &alive = st[pending.which].status; /* 0: the stream delivered a frame in that step */
+    if (sbr) { /* (rows of streams that are over re-run their last staging rows: what the kernels say about those is not looked at) */
+      const int rows = (pending.mono_twice || (n_ch == 1 && !esbr)) ? N : NC;
+      for (int i = 0; i < rows; i++)
+        if (h_status[i] < 0 && alive[(size_t)(rows == N ? i : i / n_ch)] == 0) die("the SBR kernels refused a frame", i);
+    }
     if (pending.mono_twice) /* mono duplicated to stereo (api.c:3639-3660), from the back so that it can be done in place */
       for (long k = (long)N * 2048 - 1; k >= 0; k--) h_pcm[2 * k] = h_pcm[2 * k + 1] = h_pcm[k];
     lap(2);
     const size_t skip = (!sbr && pending.first) ? (size_t)delay * out_ch : 0; /* the limiter's delay is cut from the first frame */
     /* (with -esbr:1 the reference's command line decoder does not write an SBR stream's first frame:
        test/decoder/ixheaacd_main.c:2181-2186) */
-    const std::vector<int32_t> &alive = st[pending.which].status; /* 0: the stream delivered a frame in that step */
     if (!(esbr && pending.first))
       for (size_t i = 0; i < pcms.size(); i++)
         if (alive[i] == 0) pcms[i].insert(pcms[i].end(), h_pcm + i * per * out_ch + skip, h_pcm + (i + 1) * per * out_ch);

@@ -78,3 +78,30 @@ def test_a_list_of_different_streams_in_one_batch(names, flags, tmp_path):
             samples, crc = ("samples", "crc") if flags else ("samples_esbr", "crc_esbr")
             assert (w.getnframes(), w.getframerate()) == (int(gold[samples][k]), int(gold["rate"][k])), n
             assert zlib.crc32(pcm) & 0xffffffff == int(gold[crc][k]), n
+
+
+@pytest.mark.gpu
+def test_a_damaged_stream_of_a_list_ends_alone(tmp_path):
+    """-ilist: one file with garbage behind its 20th frame -- that stream ends there (its 20 frames are written), the other
+    streams of the batch come out as if it had not been in the list"""
+    good = open(os.path.join(STREAMS, "mix_aot29_32k.aac"), "rb").read()
+    pos = 0
+    for _ in range(20):   # ADTS: the frame length is 13 bits from bit 30 of the header
+        pos += ((good[pos + 3] & 3) << 11) | (good[pos + 4] << 3) | (good[pos + 5] >> 5)
+    bad = tmp_path / "damaged.aac"
+    bad.write_bytes(good[:pos] + bytes(range(7, 200)))
+    lst = tmp_path / "list.txt"
+    lst.write_text(os.path.join(STREAMS, "mix_aot29_32k.aac") + "\n" + str(bad) + "\n")
+    out = tmp_path / "out"
+    out.mkdir()
+    p = subprocess.run([CLI, "-ilist:" + str(lst), "-odir:" + str(out), "-esbr:0"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-500:]
+    assert "the stream ends here" in p.stderr
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "decoder_ref.npz"))
+    k = GOLD_ORDER.index("mix_aot29_32k")
+    with wave.open(str(out / "mix_aot29_32k.wav")) as w:
+        whole = w.readframes(w.getnframes())
+        assert w.getnframes() == int(gold["samples"][k]) and zlib.crc32(whole) & 0xffffffff == int(gold["crc"][k])
+    with wave.open(str(out / "damaged.wav")) as w:
+        part = w.readframes(w.getnframes())
+        assert w.getnframes() == 20 * 2048 and part == whole[:len(part)]

@@ -14,7 +14,7 @@ def main():
     copies = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     data = open(os.path.join(ROOT, "tests", "golden", "streams", "mix_aot29_32k.aac"), "rb").read()
     decoder.decode_streams([data] * 8)
-    for threads in (0, 8, 16, 24, 32):
+    for threads in [int(t) for t in os.environ.get("XAAC_TRACE_THREADS", "0,8,16,24,32").split(",")]:
         best = None
         for _ in range(3):
             t = {}
