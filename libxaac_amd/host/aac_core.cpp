@@ -986,7 +986,13 @@ int xh_parse_raw_data_block(XhCoreState *st, XhBits *br, XhElement *el, int stag
             el->sbr_ext_type = type;
             el->sbr_bytes = count;
             el->sbr[0] = (uint8_t)br->get(4);
-            for (int i = 1; i < count; i++) el->sbr[i] = (uint8_t)br->get(8);
+            int i = 1;
+            for (; i + 4 <= count; i += 4) { /* four payload bytes per look (they sit at any bit offset) */
+              const uint32_t w = br->peek32();
+              el->sbr[i] = (uint8_t)(w >> 24), el->sbr[i + 1] = (uint8_t)(w >> 16), el->sbr[i + 2] = (uint8_t)(w >> 8), el->sbr[i + 3] = (uint8_t)w;
+              br->skip(32);
+            }
+            for (; i < count; i++) el->sbr[i] = (uint8_t)br->get(8);
           } else {
             br->get(4);
             br->skip(8 * (size_t)(count - 1));

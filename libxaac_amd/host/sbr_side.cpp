@@ -26,22 +26,40 @@ struct Book {
   const uint8_t *len;
   const int16_t *val;
   int n;
+  uint16_t lut[1024]; /* the first ten bits -> entry (code words of up to ten bits), or 0xffff: built by build_luts() */
 };
-#define XS_BOOK(name) {xh_##name##_code, xh_##name##_len, xh_##name##_val, (int)sizeof(xh_##name##_len)}
-const Book k_env_t_15 = XS_BOOK(sbr_env_t_15), k_env_f_15 = XS_BOOK(sbr_env_f_15), k_env_t_30 = XS_BOOK(sbr_env_t_30),
-           k_env_f_30 = XS_BOOK(sbr_env_f_30), k_bal_t_15 = XS_BOOK(sbr_bal_t_15), k_bal_f_15 = XS_BOOK(sbr_bal_f_15),
-           k_bal_t_30 = XS_BOOK(sbr_bal_t_30), k_bal_f_30 = XS_BOOK(sbr_bal_f_30), k_noise_t_30 = XS_BOOK(sbr_noise_t_30),
-           k_noise_bal_t_30 = XS_BOOK(sbr_noise_bal_t_30);
-const Book k_ps[6] = {XS_BOOK(ps_iid_df), XS_BOOK(ps_iid_dt), XS_BOOK(ps_iid_df_fine),
-                      XS_BOOK(ps_iid_dt_fine), XS_BOOK(ps_icc_df), XS_BOOK(ps_icc_dt)};
+#define XS_BOOK(name) {xh_##name##_code, xh_##name##_len, xh_##name##_val, (int)sizeof(xh_##name##_len), {0}}
+Book k_env_t_15 = XS_BOOK(sbr_env_t_15), k_env_f_15 = XS_BOOK(sbr_env_f_15), k_env_t_30 = XS_BOOK(sbr_env_t_30),
+     k_env_f_30 = XS_BOOK(sbr_env_f_30), k_bal_t_15 = XS_BOOK(sbr_bal_t_15), k_bal_f_15 = XS_BOOK(sbr_bal_f_15),
+     k_bal_t_30 = XS_BOOK(sbr_bal_t_30), k_bal_f_30 = XS_BOOK(sbr_bal_f_30), k_noise_t_30 = XS_BOOK(sbr_noise_t_30),
+     k_noise_bal_t_30 = XS_BOOK(sbr_noise_bal_t_30);
+Book k_ps[6] = {XS_BOOK(ps_iid_df), XS_BOOK(ps_iid_dt), XS_BOOK(ps_iid_df_fine),
+                XS_BOOK(ps_iid_dt_fine), XS_BOOK(ps_icc_df), XS_BOOK(ps_icc_dt)};
 
-inline int huff(const Book &k, XhBits *br) { /* sorted code words: the last one not above the window is the prefix */
+void build_luts() { /* once, from xs_init (also when the first callers are parser threads: a function-local static) */
+  Book *all[16] = {&k_env_t_15, &k_env_f_15, &k_env_t_30, &k_env_f_30, &k_bal_t_15, &k_bal_f_15, &k_bal_t_30, &k_bal_f_30,
+                   &k_noise_t_30, &k_noise_bal_t_30, &k_ps[0], &k_ps[1], &k_ps[2], &k_ps[3], &k_ps[4], &k_ps[5]};
+  for (Book *k : all) {
+    for (int i = 0; i < 1024; i++) k->lut[i] = 0xffff;
+    for (int e = 0; e < k->n; e++)
+      if (k->len[e] <= 10) {
+        const uint32_t first = k->code[e] >> 22, count = 1u << (10 - k->len[e]);
+        for (uint32_t j = 0; j < count; j++) k->lut[first + j] = (uint16_t)e;
+      }
+  }
+}
+
+inline int huff(const Book &k, XhBits *br) {
   const uint32_t w = br->peek32();
-  int lo = 0, hi = k.n - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (k.code[mid] <= w) lo = mid;
-    else hi = mid - 1;
+  int lo = k.lut[w >> 22];
+  if (lo == 0xffff) { /* a longer code word.  They are sorted: the last one not above the window is the prefix */
+    lo = 0;
+    int hi = k.n - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (k.code[mid] <= w) lo = mid;
+      else hi = mid - 1;
+    }
   }
   br->skip(k.len[lo]);
   return k.val[lo];
@@ -1374,6 +1392,8 @@ void export_frame(const XsFrameData *f, int apply, xaac_sbr_frame *o) { /* to_fr
 }  // namespace
 
 void xs_init(XsDecoder *d, int core_sampling_rate, int core_channels, int ps_enable, int enh) {
+  static const bool luts_built = (build_luts(), true);
+  (void)luts_built;
   memset(d, 0, sizeof(*d));
   d->core_channels = core_channels;
   d->ps_enable = ps_enable;
