@@ -209,6 +209,52 @@ def usable_cores():
     return aff if quota is None else max(1, min(aff, int(quota + 0.5)))
 
 
+def gpu_numa_cpus(device_index):
+    """CPUs of the NUMA node the GPU hangs off (hipDeviceGetPCIBusId -> /sys/bus/pci/devices/<id>/numa_node -> the node's
+    cpulist), cut by what the process may run on; None where that cannot be read (no sysfs, a single node, node -1)"""
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) != 0:
+            return None
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % buf.value.decode().lower()).read())
+        if node < 0:
+            return None
+        cpus = []
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus += range(int(a), int(b or a) + 1)
+        cpus = sorted(set(cpus) & os.sched_getaffinity(0))
+        return cpus or None
+    except (OSError, ValueError, AttributeError):
+        return None
+
+
+class _NearGpu:
+    """While pinned staging memory is allocated and first touched: the calling thread on the GPU's NUMA node, so that the
+    pages land there.  With the staging on the other socket the bus carries one direction at full rate but both at once
+    (a step's spectra going up beside the PCM of the step before coming down) at 38 GiB/s in total instead of 63 (measured
+    on a two-socket MI355X host with 64 MiB copies)."""
+
+    def __init__(self, device_index):
+        self.cpus = gpu_numa_cpus(device_index)
+
+    def __enter__(self):
+        self.before = None
+        if self.cpus:
+            try:
+                self.before = os.sched_getaffinity(0)
+                os.sched_setaffinity(0, self.cpus)
+            except OSError:
+                self.before = None
+        return self
+
+    def __exit__(self, *exc):
+        if self.before is not None:
+            os.sched_setaffinity(0, self.before)
+        return False
+
+
 class _TorchCpuThreads:
     """For the length of a decode: torch's intra-op CPU pool no larger than the cores the process is granted.  torch sizes
     the pool by the CPUs the machine lists; in a container that lists 256 and grants 16, one parallel fill of a staging
@@ -391,14 +437,19 @@ def _decode_streams(streams, ctx, device, threads, keep_pcm, timing, overlap, es
     def dz(*shape, dtype=torch.uint8):
         return torch.zeros(*shape, dtype=dtype, device=dev)
 
+    near_gpu = _NearGpu(dev.index or 0)
+
     def pinned(*shape, dtype=torch.uint8):
-        t = torch.empty(*shape, dtype=dtype, pin_memory=True)
-        t.numpy().fill(0)      # (numpy: one thread; torch.zeros would wake the whole intra-op pool for it)
+        with near_gpu:         # allocated and first touched on the GPU's NUMA node
+            t = torch.empty(*shape, dtype=dtype, pin_memory=True)
+            t.numpy().fill(0)  # (numpy: one thread; torch.zeros would wake the whole intra-op pool for it)
         return t
 
     out_ch = 2 if sbr else n_ch     # SBR streams come out in stereo (PS, or the mono column twice); AAC-LC as coded
     ovl, ovl_state = dz(nc, 512, dtype=torch.int32), dz(nc, 2)
-    spec_d, ics_d = dz(nc, 1024, dtype=torch.int32), dz(nc, 2)
+    # two sets of device input arrays: step k + 1 is copied up (its own stream) while step k's kernels read theirs
+    spec_d2, ics_d2 = [dz(nc, 1024, dtype=torch.int32) for _ in range(2)], [dz(nc, 2) for _ in range(2)]
+    hdr_d2 = frm_d2 = eside_d2 = psf_d2 = flags_d2 = None
     out = [[] for _ in range(n)]
 
     class Staging:    # what one step's parse leaves for the GPU: pinned host arrays
@@ -414,9 +465,13 @@ def _decode_streams(streams, ctx, device, threads, keep_pcm, timing, overlap, es
                 if n_ch == 1:
                     self.psf = pinned(n, PS_FRAME_BYTES)
             self.got, self.seconds = None, 0.0
+            self.sent = torch.cuda.Event()   # this set's copies up are over (before the parser may write it again)
+            self.sent_once = False
             self.status, self.reset_pitch = np.zeros(n, np.int32), np.zeros(n, np.int32)   # this set's own (begin / end / finish)
 
         def parse(self):
+            if self.sent_once:
+                self.sent.synchronize()   # one staging set: its copies up must be over before it is written again
             t0 = time.perf_counter()
             self.got = bp.step(self.spec, self.ics, self.hdr, self.frm, self.psf, self.flags, self.eside)
             self.reset_pitch = bp.reset_pitch.copy()
@@ -424,6 +479,8 @@ def _decode_streams(streams, ctx, device, threads, keep_pcm, timing, overlap, es
             return self
 
         def begin(self):    # the library's team parses into this set while the caller queues the step before on the GPU
+            if self.sent_once:
+                self.sent.synchronize()   # (three steps ago: long over)
             bp.start_step(self.spec, self.ics, self.hdr, self.frm, self.psf, self.flags, self.eside, status=self.status,
                           reset_pitch=self.reset_pitch)
             return self
@@ -453,7 +510,8 @@ def _decode_streams(streams, ctx, device, threads, keep_pcm, timing, overlap, es
         state = torch.from_numpy(np.tile(_struct_bytes(lib.xaac_esbr_state_init, ESBR_STATE_BYTES), (nc, 1)).copy()).to(dev)
         hbe = dz(nc, HBE_STATE_BYTES)
         core16 = dz(nc * 1024, dtype=torch.int16)
-        hdr_d, frm_d, eside_d = dz(nc, SBR_HEADER_BYTES), dz(nc, SBR_FRAME_BYTES), dz(nc, ESBR_SIDE_BYTES)
+        hdr_d2, frm_d2 = [dz(nc, SBR_HEADER_BYTES) for _ in range(2)], [dz(nc, SBR_FRAME_BYTES) for _ in range(2)]
+        eside_d2 = [dz(nc, ESBR_SIDE_BYTES) for _ in range(2)]
         status2 = [dz(nc, dtype=torch.int32) for _ in range(2)]
         status_h2 = [pinned(nc, dtype=torch.int32) for _ in range(2)]
         ws = dz(ctx.esbr_workspace_bytes(nc))
@@ -463,7 +521,7 @@ def _decode_streams(streams, ctx, device, threads, keep_pcm, timing, overlap, es
         pcm_h2 = [pinned(n * 2048 * 2, dtype=torch.int16) for _ in range(2)]
         if n_ch == 1:
             ps_state = torch.from_numpy(np.tile(_struct_bytes(lib.xaac_esbr_ps_state_init, ESBR_PS_STATE_BYTES), (n, 1)).copy()).to(dev)
-            psf_d = dz(n, PS_FRAME_BYTES)
+            psf_d2 = [dz(n, PS_FRAME_BYTES) for _ in range(2)]
             out_r = dz(n, 2048, dtype=torch.float32)
         older = dz(nc, 2, 24 * 64, dtype=torch.float32)   # rows 8..31 of the QMF history as the frame before found them
         hbe_tail = np.zeros((nc, 48), np.uint8)            # the transposers' integers (struct xaac_hbe_state from synth_size on)
@@ -473,8 +531,8 @@ def _decode_streams(streams, ctx, device, threads, keep_pcm, timing, overlap, es
     else:
         state = torch.from_numpy(np.tile(_struct_bytes(lib.xaac_sbr_state_init, SBR_STATE_BYTES), (nc, 1)).copy()).to(dev)
         core16 = dz(nc * 1024, dtype=torch.int16)
-        hdr_d, frm_d = dz(nc, SBR_HEADER_BYTES), dz(nc, SBR_FRAME_BYTES)
-        flags_d = dz(n, 8, dtype=torch.int32)
+        hdr_d2, frm_d2 = [dz(nc, SBR_HEADER_BYTES) for _ in range(2)], [dz(nc, SBR_FRAME_BYTES) for _ in range(2)]
+        flags_d2 = [dz(n, 8, dtype=torch.int32) for _ in range(2)]
         status2 = [dz(nc, dtype=torch.int32) for _ in range(2)]
         status_h2 = [pinned(nc, dtype=torch.int32) for _ in range(2)]
         pcm_h2 = [pinned(n * 2048 * 2, dtype=torch.int16) for _ in range(2)]
@@ -483,7 +541,7 @@ def _decode_streams(streams, ctx, device, threads, keep_pcm, timing, overlap, es
             ws = dz(ctx.sbr_lp_workspace_bytes(nc))
         else:
             ps_state = torch.from_numpy(np.tile(_struct_bytes(lib.xaac_ps_state_init, PS_STATE_BYTES), (n, 1)).copy()).to(dev)
-            psf_d = dz(n, PS_FRAME_BYTES)
+            psf_d2 = [dz(n, PS_FRAME_BYTES) for _ in range(2)]
             ws = dz(ctx.sbr_hq_workspace_bytes(n, True))
             pcm_mono = dz(n * 2048, dtype=torch.int16)
     first = True
@@ -495,8 +553,9 @@ def _decode_streams(streams, ctx, device, threads, keep_pcm, timing, overlap, es
     which = 0
     # The copy down of step k runs on a second stream beside the copies up and kernels of step k + 1 (two PCM / status sets);
     # the host takes a step's PCM one step later.
-    main_stream, down = torch.cuda.current_stream(dev), torch.cuda.Stream(dev)
+    main_stream, down, up = torch.cuda.current_stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
     done = [torch.cuda.Event(), torch.cuda.Event()]
+    computed = [torch.cuda.Event(), torch.cuda.Event()]
     waiting = None    # (slot, got, shape, cut, drop) of the step whose PCM is on its way
 
     def consume():
@@ -517,8 +576,8 @@ def _decode_streams(streams, ctx, device, threads, keep_pcm, timing, overlap, es
 
     def hand_down(slot_, got_, shape_, cut_=0, drop_=False):
         nonlocal waiting
-        ev = torch.cuda.Event()
-        ev.record(main_stream)
+        ev = computed[slot_]
+        ev.record(main_stream)   # this step's kernels are queued: its input set may be refilled, its PCM may go down
         with torch.cuda.stream(down):
             down.wait_event(ev)
             pcm_h2[slot_].copy_(pcm2[slot_], non_blocking=True)
@@ -554,8 +613,30 @@ def _decode_streams(streams, ctx, device, threads, keep_pcm, timing, overlap, es
             spec_h, ics_h, hdr_h, frm_h, psf_h, flags = cur.spec, cur.ics, cur.hdr, cur.frm, cur.psf, cur.flags
             overlap_buf = ovl
             t0 = time.perf_counter()
-            spec_d.copy_(spec_h, non_blocking=True)
-            ics_d.copy_(ics_h, non_blocking=True)
+            pick = lambda two: None if two is None else two[slot]
+            spec_d, ics_d, hdr_d, frm_d, eside_d, psf_d, flags_d = (pick(spec_d2), pick(ics_d2), pick(hdr_d2), pick(frm_d2),
+                                                                    pick(eside_d2), pick(psf_d2), pick(flags_d2))
+            ps_frames = bool(sbr and n_ch == 1 and (flags[got, F_PS] != 0).all())
+            side_words = bool(sbr and not esbr and (got & ((flags[:, F_RESET] != 0) | (flags[:, F_UPSAMPLING] != 0))).any())
+            if side_words:   # xaac_sbr_state_apply_side_batch's flag rows (streams without a frame: zero rows)
+                cur.flags_pin.numpy()[:] = flags * got[:, None].astype(np.int32)
+            with torch.cuda.stream(up):   # everything this step sends up, beside the kernels of the step before
+                if step_no > 2:
+                    up.wait_event(computed[slot])   # (the kernels that read this input set two steps ago)
+                spec_d.copy_(spec_h, non_blocking=True)
+                ics_d.copy_(ics_h, non_blocking=True)
+                if sbr:
+                    hdr_d.copy_(hdr_h, non_blocking=True)
+                    frm_d.copy_(frm_h, non_blocking=True)
+                    if esbr:
+                        eside_d.copy_(cur.eside, non_blocking=True)
+                    if ps_frames:
+                        psf_d.copy_(psf_h, non_blocking=True)
+                    if side_words:
+                        flags_d.copy_(cur.flags_pin, non_blocking=True)
+                cur.sent.record(up)
+            cur.sent_once = True
+            main_stream.wait_event(cur.sent)
             if not sbr:
                 ctx.imdct_process_batch(spec_d, ics_d, overlap_buf, ovl_state, out32=out32, qshift_adj=qadj, ch_fac=n_ch)
                 ctx.peak_limiter_process_batch(out32, qadj, lim, n_ch, ws, pcm16=pcm)
@@ -564,9 +645,6 @@ def _decode_streams(streams, ctx, device, threads, keep_pcm, timing, overlap, es
                 # (interleaved as the reference holds it: its in-place 32 -> 16 bit conversion of a pair leaves traces of channel
                 # 0 in channel 1, api.c:353-366, which the IMDCT's PCM_SBR hand-off restates for ch_fac 2)
                 ctx.imdct_process_batch(spec_d, ics_d, overlap_buf, ovl_state, pcm16=core16, ch_fac=n_ch, pcm_mode=PCM_SBR)
-                hdr_d.copy_(hdr_h, non_blocking=True)
-                frm_d.copy_(frm_h, non_blocking=True)
-                eside_d.copy_(cur.eside, non_blocking=True)
                 touched = np.nonzero(got & (flags[:, F_RESET] != 0))[0]
                 if touched.size:
                     # ixheaacd_sbr_dec_reset for Path A (sbrdecoder.c:175-236): new transposer parameters from the header's band
@@ -619,7 +697,6 @@ def _decode_streams(streams, ctx, device, threads, keep_pcm, timing, overlap, es
                 if with_ps.any() != with_ps.all():
                     raise NotImplementedError("a batch mixing PS and non-PS frames")
                 if with_ps.all():
-                    psf_d.copy_(psf_h, non_blocking=True)
                     ctx.esbr_sbr_process_batch(core, hdr_d, frm_d, eside_d, state, out_l, ws, status=status, ps_frame=psf_d,
                                                ps_state=ps_state, out_r=out_r, hbe_state=hbe, hbe_max_synth_size=hbe_hint())
                     ctx.esbr_pcm16_from_float(out_l, out_r, pcm)
@@ -632,13 +709,9 @@ def _decode_streams(streams, ctx, device, threads, keep_pcm, timing, overlap, es
                 hand_down(slot, got, (n, 2048, 2), drop_=first)      # the first frame's output is not written in this mode
             else:
                 ctx.imdct_process_batch(spec_d, ics_d, overlap_buf, ovl_state, pcm16=core16, ch_fac=n_ch, pcm_mode=PCM_SBR)
-                hdr_d.copy_(hdr_h, non_blocking=True)
-                frm_d.copy_(frm_h, non_blocking=True)
                 # frames that reset the SBR decoder or fall back to plain up-sampling change a few words of the resident state:
-                # on the device, from the flag rows (streams without a frame: zero rows)
-                if (got & ((flags[:, F_RESET] != 0) | (flags[:, F_UPSAMPLING] != 0))).any():
-                    cur.flags_pin.numpy()[:] = flags * got[:, None].astype(np.int32)
-                    flags_d.copy_(cur.flags_pin, non_blocking=True)
+                # on the device, from the flag rows
+                if side_words:
                     ctx.sbr_state_apply_side_batch(hdr_d, flags_d, state, n_ch, ps_state=ps_state if n_ch == 1 else None)
                 if n_ch == 2:
                     ctx.sbr_lp_process_batch(core16, hdr_d, frm_d, state, pcm, ws, status=status, in_ch_fac=2, out_ch_fac=2)
@@ -651,7 +724,6 @@ def _decode_streams(streams, ctx, device, threads, keep_pcm, timing, overlap, es
                         if starts.size:
                             idx = torch.from_numpy(starts.astype(np.int32)).to(dev)
                             ctx.sbr_state_handover(HANDOVER_PS_START, idx, idx, state, ps_state)
-                        psf_d.copy_(psf_h, non_blocking=True)
                         ctx.sbr_hq_process_batch(core16, hdr_d, frm_d, state, pcm, ws, ps_frame=psf_d, ps_state=ps_state, status=status)
                     else:
                         ctx.sbr_hq_process_batch(core16, hdr_d, frm_d, state, pcm_mono, ws, status=status)
