@@ -557,10 +557,17 @@ FX_HD void xe_hbe_history_clear(const XsCx &cx, xaac_esbr_state *st, int qmf_sb_
   XS_PAR(k, 0, 64) {
     if (k >= qmf_sb_prev && k < qmf_sb_prev + full + (rem ? 1 : 0)) {
       const uint32_t keep = k < qmf_sb_prev + full ? 0u : ~((1u << (8 * rem)) - 1u);
-      for (int r = 2; r < 8; r++) {
-        uint32_t *a = reinterpret_cast<uint32_t *>(&st->qmf_re[r][k]), *b = reinterpret_cast<uint32_t *>(&st->qmf_im[r][k]);
-        *a &= keep;
-        *b &= keep;
+      uint32_t va[6], vb[6]; /* the twelve words in flight together (as twelve read-modify-writes through pointers the
+                                compiler cannot tell apart they were twelve memory round trips in a row) */
+      XE_UNROLL
+      for (int r = 0; r < 6; r++) {
+        va[r] = keep ? *reinterpret_cast<const uint32_t *>(&st->qmf_re[2 + r][k]) : 0u;
+        vb[r] = keep ? *reinterpret_cast<const uint32_t *>(&st->qmf_im[2 + r][k]) : 0u;
+      }
+      XE_UNROLL
+      for (int r = 0; r < 6; r++) {
+        *reinterpret_cast<uint32_t *>(&st->qmf_re[2 + r][k]) = va[r] & keep;
+        *reinterpret_cast<uint32_t *>(&st->qmf_im[2 + r][k]) = vb[r] & keep;
       }
     }
   }

@@ -66,16 +66,44 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
   __shared__ xaac_sbr_frame sf;
   __shared__ xaac_esbr_side ssd;
   static_assert(sizeof(xaac_sbr_header) % 4 == 0 && sizeof(xaac_sbr_frame) % 4 == 0 && sizeof(xaac_esbr_side) % 4 == 0, "word copies");
-  xe_copy_words(reinterpret_cast<int32_t *>(&sh), reinterpret_cast<const int32_t *>(p.header + ch), sizeof(sh) / 4, lane);
-  xe_copy_words(reinterpret_cast<int32_t *>(&sf), reinterpret_cast<const int32_t *>(p.frame + ch), sizeof(sf) / 4, lane);
-  xe_copy_words(reinterpret_cast<int32_t *>(&ssd), reinterpret_cast<const int32_t *>(p.side + ch), sizeof(ssd) / 4, lane);
-  xe_copy_words(reinterpret_cast<int32_t *>(xe_lds_random_phase), reinterpret_cast<const int32_t *>(xaac_esbr_random_phase), 1024, lane);
+  xaac_esbr_state *st = p.state + ch;
+  float hist_re[8], hist_im[8]; /* sbr_qmf_out's eight rows of history: fetched with the side info, stored below */
+  { /* header, frame, side info and the random-phase table: every load in flight before the first LDS store -- one memory
+       latency for the lot (as four copies one behind the other they were four, and the history rows a fifth) */
+    constexpr int NH = (sizeof(sh) / 4 + 63) / 64, NF = (sizeof(sf) / 4 + 63) / 64, NS = (sizeof(ssd) / 4 + 63) / 64, NR = 1024 / 64;
+    const int32_t *gh = reinterpret_cast<const int32_t *>(p.header + ch), *gf = reinterpret_cast<const int32_t *>(p.frame + ch);
+    const int32_t *gs = reinterpret_cast<const int32_t *>(p.side + ch), *gr = reinterpret_cast<const int32_t *>(xaac_esbr_random_phase);
+    int32_t th[NH], tf[NF], ts[NS], tr[NR];
+#pragma unroll
+    for (int j = 0; j < NH; j++) th[j] = lane + 64 * j < (int)(sizeof(sh) / 4) ? gh[lane + 64 * j] : 0;
+#pragma unroll
+    for (int j = 0; j < NF; j++) tf[j] = lane + 64 * j < (int)(sizeof(sf) / 4) ? gf[lane + 64 * j] : 0;
+#pragma unroll
+    for (int j = 0; j < NS; j++) ts[j] = lane + 64 * j < (int)(sizeof(ssd) / 4) ? gs[lane + 64 * j] : 0;
+#pragma unroll
+    for (int j = 0; j < NR; j++) tr[j] = gr[lane + 64 * j];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      hist_re[r] = st->out_re[r][lane];
+      hist_im[r] = st->out_im[r][lane];
+    }
+#pragma unroll
+    for (int j = 0; j < NH; j++)
+      if (lane + 64 * j < (int)(sizeof(sh) / 4)) reinterpret_cast<int32_t *>(&sh)[lane + 64 * j] = th[j];
+#pragma unroll
+    for (int j = 0; j < NF; j++)
+      if (lane + 64 * j < (int)(sizeof(sf) / 4)) reinterpret_cast<int32_t *>(&sf)[lane + 64 * j] = tf[j];
+#pragma unroll
+    for (int j = 0; j < NS; j++)
+      if (lane + 64 * j < (int)(sizeof(ssd) / 4)) reinterpret_cast<int32_t *>(&ssd)[lane + 64 * j] = ts[j];
+#pragma unroll
+    for (int j = 0; j < NR; j++) reinterpret_cast<int32_t *>(xe_lds_random_phase)[lane + 64 * j] = tr[j];
+  }
   __syncthreads();
   const xaac_sbr_header *h = &sh;
   const xaac_sbr_frame *f = &sf;
   const xaac_esbr_side *sd = &ssd;
   XE_T(0);
-  xaac_esbr_state *st = p.state + ch;
   float *ore = p.out_re + (size_t)ch * XAAC_ESBR_OUT_ROWS * 64, *oim = p.out_im + (size_t)ch * XAAC_ESBR_OUT_ROWS * 64;
   float *rre = p.syn_re + (size_t)ch * XAAC_ESBR_L_ROWS * 64, *rim = p.syn_im + (size_t)ch * XAAC_ESBR_L_ROWS * 64;
   const float *are = p.ana_re + (size_t)ch * 2048, *aim = p.ana_im + (size_t)ch * 2048;
@@ -85,16 +113,10 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
   /* sbr_qmf_out: 8 rows of history; the stages write every cell of rows 8..31 that is read later, so those are cleared
      only for a frame without SBR processing (the reference zeroes the whole buffer then, sbr_dec.c:956-961) */
   {
-    float t0[8], t1[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-      t0[r] = apply ? st->out_re[r][lane] : 0.0f;
-      t1[r] = apply ? st->out_im[r][lane] : 0.0f;
-    }
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-      ore[64 * r + lane] = t0[r];
-      oim[64 * r + lane] = t1[r];
+      ore[64 * r + lane] = apply ? hist_re[r] : 0.0f;
+      oim[64 * r + lane] = apply ? hist_im[r] : 0.0f;
     }
     /* rows 32.. become the next frame's history: cleared, the stages fill what they reach */
     for (int i = ((!apply || rc) ? 8 : 32) * 64 + lane; i < XAAC_ESBR_OUT_ROWS * 64; i += 64) {
@@ -149,16 +171,17 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
   XE_T(3);
   {
     const int stop = apply ? 2 * f->border_vec[0] : 0;
-    for (int i0 = 0; i0 < 32; i0 += 8) { /* regrouping, sbr_dec.c:365-395; eight rows in flight */
-      float a[8], b[8];
+    const int xo_prev = sd->qmf_sb_prev, xo_now = h->sub_band_start;
+    for (int i0 = 0; i0 < 32; i0 += 16) { /* regrouping, sbr_dec.c:365-395; sixteen rows (32 words a lane) in flight */
+      float a[16], b[16];
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int i = i0 + j, xo = i < stop ? sd->qmf_sb_prev : h->sub_band_start;
+      for (int j = 0; j < 16; j++) {
+        const int i = i0 + j, xo = i < stop ? xo_prev : xo_now;
         a[j] = lane < xo ? st->qmf_re[2 + i][lane] : ore[64 * (2 + i) + lane];
         b[j] = lane < xo ? st->qmf_im[2 + i][lane] : oim[64 * (2 + i) + lane];
       }
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
+      for (int j = 0; j < 16; j++) {
         rre[64 * (i0 + j) + lane] = a[j];
         rim[64 * (i0 + j) + lane] = b[j];
       }
@@ -171,41 +194,44 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
     }
   __syncthreads();
   XE_T(4);
-  /* histories: rows 32.. of this frame's buffers become rows 0.. of the next frame's (sbr_dec.c:835-857) */
+  /* histories: rows 32.. of this frame's buffers become rows 0.. of the next frame's (sbr_dec.c:835-857).  Loads of one
+     batch all in flight: the two 8-row tails first, then the analysis bank's 32 new rows sixteen at a time */
   {
-    float t0[8], t1[8];
+    float t0[8], t1[8], u0[8], u1[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
       t0[r] = st->qmf_re[32 + r][lane];
       t1[r] = st->qmf_im[32 + r][lane];
+      u0[r] = ore[64 * (32 + r) + lane];
+      u1[r] = oim[64 * (32 + r) + lane];
+    }
+    float a[16], b[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      a[j] = lane < 32 ? are[64 * j + lane] : 0.0f;
+      b[j] = lane < 32 ? aim[64 * j + lane] : 0.0f;
     }
 #pragma unroll
     for (int r = 0; r < 8; r++) {
       st->qmf_re[r][lane] = t0[r];
       st->qmf_im[r][lane] = t1[r];
-    }
-    for (int r0 = 0; r0 < 32; r0 += 8) {
-      float a[8], b[8];
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        a[j] = lane < 32 ? are[64 * (r0 + j) + lane] : 0.0f;
-        b[j] = lane < 32 ? aim[64 * (r0 + j) + lane] : 0.0f;
-      }
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        st->qmf_re[8 + r0 + j][lane] = a[j];
-        st->qmf_im[8 + r0 + j][lane] = b[j];
-      }
+      st->out_re[r][lane] = u0[r];
+      st->out_im[r][lane] = u1[r];
     }
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-      t0[r] = ore[64 * (32 + r) + lane];
-      t1[r] = oim[64 * (32 + r) + lane];
+    for (int j = 0; j < 16; j++) {
+      st->qmf_re[8 + j][lane] = a[j];
+      st->qmf_im[8 + j][lane] = b[j];
     }
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-      st->out_re[r][lane] = t0[r];
-      st->out_im[r][lane] = t1[r];
+    for (int j = 0; j < 16; j++) {
+      a[j] = lane < 32 ? are[64 * (16 + j) + lane] : 0.0f;
+      b[j] = lane < 32 ? aim[64 * (16 + j) + lane] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      st->qmf_re[24 + j][lane] = a[j];
+      st->qmf_im[24 + j][lane] = b[j];
     }
   }
 #ifdef XE_PROFILE
