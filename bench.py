@@ -297,7 +297,10 @@ def secondary_end_to_end(copies=4096):
         decoder.decode_streams([data] * copies, keep_pcm=False, timing=timing)
         if best is None or timing["steps_s"] < best["steps_s"]:
             best = timing
-    parser = max(bench_decoder.parser_only(decoder, data, copies, t) for t in (0, 64))
+    parser = 0.0
+    for _ in range(3):   # (a pause in front of each try: the decode runs above have used up the cgroup's CPU quota of their periods)
+        time.sleep(0.25)
+        parser = max(parser, bench_decoder.parser_only(decoder, data, copies, 0))
     # the same streams decoded the way the reference does with its default flags (-esbr:1: float eSBR tools, the QMF harmonic
     # transposer on every frame, float PS; decode_streams(esbr=True)), checked against the CRC of `xaacdec`'s PCM
     pcm_e, _ = decoder.decode_streams([data] * 4, esbr=True)
