@@ -561,13 +561,15 @@ FX_HD void xe_hbe_history_clear(const XsCx &cx, xaac_esbr_state *st, int qmf_sb_
                                 compiler cannot tell apart they were twelve memory round trips in a row) */
       XE_UNROLL
       for (int r = 0; r < 6; r++) {
-        va[r] = keep ? *reinterpret_cast<const uint32_t *>(&st->qmf_re[2 + r][k]) : 0u;
-        vb[r] = keep ? *reinterpret_cast<const uint32_t *>(&st->qmf_im[2 + r][k]) : 0u;
+        memcpy(&va[r], &st->qmf_re[2 + r][k], 4);
+        memcpy(&vb[r], &st->qmf_im[2 + r][k], 4);
       }
       XE_UNROLL
       for (int r = 0; r < 6; r++) {
-        *reinterpret_cast<uint32_t *>(&st->qmf_re[2 + r][k]) = va[r] & keep;
-        *reinterpret_cast<uint32_t *>(&st->qmf_im[2 + r][k]) = vb[r] & keep;
+        va[r] &= keep;
+        vb[r] &= keep;
+        memcpy(&st->qmf_re[2 + r][k], &va[r], 4);
+        memcpy(&st->qmf_im[2 + r][k], &vb[r], 4);
       }
     }
   }

@@ -30,7 +30,13 @@
 
 struct XfWork {
   float hl_re[32][12], hl_im[32][12], hr_re[32][12], hr_im[32][12]; /* hyb_left_* / hyb_right_*: 12 hybrid sub-bands */
-  float pw[32][20], tr[32][20];                                     /* pow_arr, trans_ratio_arr */
+  union {
+    float pw[32][20];                                               /* pow_arr */
+    float hin[2][3][44];                                            /* before the band powers: the hybrid filters' work buffer
+                                                                       (re | im) of QMF bands 0..2: 12 slots of history, then
+                                                                       rows 6..37 of the left matrix */
+  };
+  float tr[32][20];                                                 /* trans_ratio_arr */
   float hv[8][20];                                                  /* h11_re_vec ... h22_im_vec of the envelope */
 };
 
@@ -74,42 +80,52 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
     }
   }
   XE_T(0);
-  /* hybrid analysis of QMF bands 0..2 (8 + 2 + 2 sub-bands), lane = slot; the 12-slot history is the filter's past */
-  XS_PAR(i, 0, 32) {
-    int ch_offset = 0;
-    for (int band = 0; band < 3; band++) {
-      float wr[13], wi[13];
-      for (int n = 0; n < 13; n++) {
-        const int j = n + i; /* index into the reference's work buffer: 12 history slots, then rows 6.. of L */
-        wr[n] = j < 12 ? ps->hyb_hist_re[band][j] : L.r(j - 12 + 6, band);
-        wi[n] = j < 12 ? ps->hyb_hist_im[band][j] : L.i(j - 12 + 6, band);
-      }
-      if (band == 0) {
-        for (int q = 0; q < 8; q++) {
-          float real = 0, imag = 0;
-          for (int n = 0; n < 13; n++) {
-            const float c = xaac_eps_cos_sin_mod_8channel[26 * q + 2 * n], s = xaac_eps_cos_sin_mod_8channel[26 * q + 2 * n + 1];
-            real += xaac_eps_p8_13_20[n] * (wr[n] * c - wi[n] * s);
-            imag += xaac_eps_p8_13_20[n] * (wi[n] * c + wr[n] * s);
-          }
-          w->hl_re[i][ch_offset + q] = real;
-          w->hl_im[i][ch_offset + q] = imag;
+  /* hybrid analysis of QMF bands 0..2 (8 + 2 + 2 sub-bands); the 12-slot history is the filter's past.  The three columns
+     are staged once (a lane per (band, row): as 78 column gathers per slot-lane they were 78 uncoalesced loads each), then a
+     lane takes a slot and half of the sub-bands: band 0's channels 0..3 and band 1, or channels 4..7 and band 2. */
+  XS_PAR(e, 0, 96) {
+    const int band = e >> 5, r = e & 31;
+    w->hin[0][band][12 + r] = L.r(6 + r, band);
+    w->hin[1][band][12 + r] = L.i(6 + r, band);
+  }
+  XS_PAR(j, 0, 36) {
+    const int band = j / 12, n = j % 12;
+    w->hin[0][band][n] = ps->hyb_hist_re[band][n];
+    w->hin[1][band][n] = ps->hyb_hist_im[band][n];
+  }
+  cx.sync();
+  XS_PAR(e, 0, 64) {
+    const int i = e & 31, half = e >> 5;
+    {
+      const float *wr = &w->hin[0][0][i], *wi = &w->hin[1][0][i];
+      for (int q = 4 * half; q < 4 * half + 4; q++) {
+        float real = 0, imag = 0;
+        for (int n = 0; n < 13; n++) {
+          const float c = xaac_eps_cos_sin_mod_8channel[26 * q + 2 * n], sn = xaac_eps_cos_sin_mod_8channel[26 * q + 2 * n + 1];
+          real += xaac_eps_p8_13_20[n] * (wr[n] * c - wi[n] * sn);
+          imag += xaac_eps_p8_13_20[n] * (wi[n] * c + wr[n] * sn);
         }
-        ch_offset += 8;
-      } else {
-        for (int q = 0; q < 2; q++) {
-          float real = 0, imag = 0;
-          for (int n = 0; n < 13; n++) {
-            const float c = xaac_eps_cos_mod_2channel[13 * q + n];
-            real += xaac_eps_p2_13_20[n] * (wr[n] * c);
-            imag += xaac_eps_p2_13_20[n] * (wi[n] * c);
-          }
-          w->hl_re[i][ch_offset + q] = real;
-          w->hl_im[i][ch_offset + q] = imag;
-        }
-        ch_offset += 2;
+        w->hl_re[i][q] = real;
+        w->hl_im[i][q] = imag;
       }
     }
+    {
+      const int band = 1 + half, ch_offset = 8 + 2 * half;
+      const float *wr = &w->hin[0][band][i], *wi = &w->hin[1][band][i];
+      for (int q = 0; q < 2; q++) {
+        float real = 0, imag = 0;
+        for (int n = 0; n < 13; n++) {
+          const float c = xaac_eps_cos_mod_2channel[13 * q + n];
+          real += xaac_eps_p2_13_20[n] * (wr[n] * c);
+          imag += xaac_eps_p2_13_20[n] * (wi[n] * c);
+        }
+        w->hl_re[i][ch_offset + q] = real;
+        w->hl_im[i][ch_offset + q] = imag;
+      }
+    }
+  }
+  cx.sync();
+  XS_PAR(i, 0, 32) {
     /* ps_dec_flt.c:446-459 */
     w->hl_re[i][3] += w->hl_re[i][4];
     w->hl_im[i][3] += w->hl_im[i][4];
@@ -124,12 +140,12 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
       w->hr_im[i][q] = 0;
     }
   }
-  cx.sync();
   XS_PAR(j, 0, 36) { /* the next frame's history: the last 12 work slots = rows 26..37 of L */
     const int band = j / 12, n = j % 12;
-    ps->hyb_hist_re[band][n] = L.r(26 + n, band);
-    ps->hyb_hist_im[band][n] = L.i(26 + n, band);
+    ps->hyb_hist_re[band][n] = w->hin[0][band][32 + n];
+    ps->hyb_hist_im[band][n] = w->hin[1][band][32 + n];
   }
+  cx.sync(); /* (the band powers below take the work buffer's place) */
   XE_T(1);
   /* band powers per parameter bin (:606-632), lane = slot; a bin's sum runs group by group, sub-band by sub-band */
   XS_PAR(k, 0, 32) {
