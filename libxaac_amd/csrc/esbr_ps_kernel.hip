@@ -46,10 +46,15 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_ps_kernel(XaacEsbrPsParams p)
   if (!bad)
     for (int e = 0; e < pf->num_env; e++) bad |= pf->border_position[e] > pf->border_position[e + 1] || pf->border_position[e + 1] > 32;
   if (p.frame[n].apply_processing && !bad) {
-    for (int i = 0; i < 32; i++) { /* QMF bands 0..2 of the right channel come from the hybrid synthesis; clear the rest of the row set */
-      rre[64 * i + lane] = 0.0f;
-      rim[64 * i + lane] = 0.0f;
-    }
+    /* The right channel's rows: inside the frame's PS range [border 0, last border) the decorrelator writes every band from 3
+       up and the hybrid synthesis bands 0..2 of every row, so only rows outside the range (none, for the borders 0 and 32 an
+       encoder sends) have to be cleared -- not 16 KB of zeros per stream that the same kernel then overwrites */
+    const int k0 = pf->border_position[0], k1 = pf->border_position[pf->num_env];
+    for (int i = 0; i < 32; i++)
+      if (i < k0 || i >= k1) { /* (uniform) */
+        rre[64 * i + lane] = 0.0f;
+        rim[64 * i + lane] = 0.0f;
+      }
     __syncthreads();
     xf_apply_ps(cx, pf, p.ps_state + n, &w, L, R, p.header[n].sub_band_end);
 #ifdef XE_PROFILE
