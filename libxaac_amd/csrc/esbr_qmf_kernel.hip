@@ -127,77 +127,116 @@ __global__ __launch_bounds__(64) void xaac_esbr_analysis_kernel(XaacEsbrAnaParam
   }
 }
 
-__global__ __launch_bounds__(64) void xaac_esbr_synthesis_kernel(XaacEsbrSynParams p) {
+/* Two waves per channel pair, as in xaac_qmf_synthesis_pair_kernel (sbr_qmf_kernel.hip): the slot transform's two independent
+   halves (sbr_qmf.h: xq_cos_sin_mod_half) run on the workgroup's two waves -- wave h takes the real (h = 0) or imaginary
+   (h = 1) half rows of all 64 rows (2 channels x 32 slots, lane = (channel, slot)) through its own half-size tile, a lane
+   holds 2 x 64 words instead of three 128-word arrays (243 VGPRs and two waves per SIMD in the one-wave version) -- and
+   the halves meet through the tiles: wave 0 forms the ring samples b[0..63] of every slot, wave 1 b[64..127].  The
+   window-add of a channel is split by slots (wave h: slots 16 h .. 16 h + 15, lane = sample), history and state by words. */
+#ifndef XE_SYN_MIN_WAVES
+#define XE_SYN_MIN_WAVES 2
+#endif
+__global__ __launch_bounds__(128, XE_SYN_MIN_WAVES) void xaac_esbr_synthesis_kernel(XaacEsbrSynParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int HS = 65, VSLOTS = 41, VROW = 129, RING = 1280;
-  const int lane = threadIdx.x;
-  int32_t *rows = reinterpret_cast<int32_t *>(smem); /* [64][HS] half rows of the 64 slots, aliased later by ... */
-  int32_t *v = reinterpret_cast<int32_t *>(smem);    /* ... [VSLOTS][VROW] ring samples of one channel at a time */
-  const int pair = blockIdx.x;
+  constexpr int RS = 65, VSLOTS = 41, VROW = 129, RING = 1280;
+  static_assert(2 * 32 * RS <= VSLOTS * VROW, "the tiles fit where the ring samples go");
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int32_t *tile_own = reinterpret_cast<int32_t *>(smem) + w * 32 * RS;
+  const int32_t *tile_oth = reinterpret_cast<const int32_t *>(smem) + (1 - w) * 32 * RS;
+  int32_t *v = reinterpret_cast<int32_t *>(smem); /* [VSLOTS][VROW] ring samples of one channel at a time, once the tiles are dead */
+  const int pair = blockIdx.x, lch = lane >> 5, lrow = lane & 31;
   int32_t coef[10]; /* c[64 A + k], k = lane */
 #pragma unroll
   for (int a = 0; a < 10; a++) coef[a] = xaac_qmf_esbr_qmf_c[64 * a + lane];
-  int32_t b[128];
+  int32_t x[64];
+  { /* half rows in (lane = band), (WORD32)(x * 64) (sbr_dec.c:592-595), through the tile to lane = (channel, slot) */
+    const float *src = w ? p.qmf_im : p.qmf_re;
+    float tmp[64]; /* all 64 half rows in flight: one memory latency */
+#pragma unroll
+    for (int r = 0; r < 64; r++) {
+      const int ch = 2 * pair + (r >> 5);
+      tmp[r] = src[(size_t)(ch < p.n_ch ? ch : 0) * p.in_stride + (size_t)(r & 31) * 64 + lane];
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const bool live = 2 * pair + c < p.n_ch;
+#pragma unroll
+      for (int j = 0; j < 32; j++) tile_own[RS * j + lane] = live ? fx_f2i_trunc(tmp[32 * c + j] * 64.0f) : 0;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the tile is this wave's own: no barrier */
+      if (lch == c) {
+#pragma unroll
+        for (int k = 0; k < 64; k++) x[k] = tile_own[RS * lrow + k];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* channel 0's reads are done before channel 1's rows land */
+    }
+  }
   {
-    /* rows in, (WORD32)(x * 64) (sbr_dec.c:592-595), through a [64][65] tile: the real parts, then the imaginary parts */
-    int32_t x[128], t[128];
+    int32_t t[64];
+    if (w == 0)
+      xq_cos_sin_mod_half<32, 0, XqW32>(x, t);
+    else
+      xq_cos_sin_mod_half<32, 1, XqW32>(x, t);
+  }
+  {
+    int32_t o[64];
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-      const float *src = half ? p.qmf_im : p.qmf_re;
-      for (int r0 = 0; r0 < 64; r0 += 8) {
-        float tr[8];
+    for (int c = 0; c < 2; c++) { /* the lanes of channel c hand their half over through the tiles */
+      if (lch == c) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const int r = r0 + j, ch = 2 * pair + (r >> 5);
-          tr[j] = src[(size_t)(ch < p.n_ch ? ch : 0) * p.in_stride + (size_t)(r & 31) * 64 + lane];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const int r = r0 + j, ch = 2 * pair + (r >> 5);
-          rows[HS * r + lane] = ch < p.n_ch ? fx_f2i_trunc(tr[j] * 64.0f) : 0;
-        }
+        for (int k = 0; k < 64; k++) tile_own[RS * lrow + k] = x[k];
       }
       __syncthreads();
+      if (lch == c) {
 #pragma unroll
-      for (int k = 0; k < 64; k++) x[64 * half + k] = rows[HS * lane + k];
-      __syncthreads();
+        for (int k = 0; k < 64; k++) o[k] = tile_oth[RS * lrow + k];
+      }
+      __syncthreads(); /* after the second round both tiles are dead: the ring samples may overwrite them */
     }
-    xq_esbr_synth_slot(x, t, b, 5 + 1); /* out_scalefactor + 1, sbr_dec.c:556 / :604 */
+    /* ixheaacd_esbr_inv_modulation's last step + ixheaacd_shiftrountine_with_rnd_hq (qmf_dec.c:733, generic:1704), shift =
+       out_scalefactor + 1 = 6 (sbr_dec.c:556 / :604): this wave's 64 of the slot's 128 ring samples, in place in x */
+    if (w == 0) { /* x = real half s[c], o = imaginary half s[64 + c]: b[c] */
+#pragma unroll
+      for (int c = 0; c < 64; c++) x[c] = fx_shl_sat(fx_sub_sat(o[c], x[c]), 6);
+    } else { /* x = imaginary half, o = real half: b[64 + c] = s[64 + 63 - c] + s[63 - c] */
+#pragma unroll
+      for (int c = 0; c < 32; c++) {
+        const int32_t lo = fx_shl_sat(fx_add_sat(x[63 - c], o[63 - c]), 6), hi = fx_shl_sat(fx_add_sat(x[c], o[c]), 6);
+        x[c] = lo;
+        x[63 - c] = hi;
+      }
+    }
   }
   for (int c = 0; c < 2; c++) { /* one channel's ring samples in LDS at a time */
     const int ch = 2 * pair + c;
     if (ch >= p.n_ch) break; /* (uniform) */
     xaac_esbr_syn_state *st = reinterpret_cast<xaac_esbr_syn_state *>(reinterpret_cast<char *>(p.state) + (size_t)ch * p.state_stride);
-    if ((lane >> 5) == c) {
-      int32_t *dst = v + (9 + (lane & 31)) * VROW;
+    if (lch == c) {
+      int32_t *dst = v + (9 + lrow) * VROW + 64 * w;
 #pragma unroll
-      for (int k = 0; k < 128; k++) dst[k] = b[k];
+      for (int k = 0; k < 64; k++) dst[k] = x[k];
     }
     int d = st->drc_offset;
     d = ((d % RING + RING) % RING) & ~127;
     const int f_old = st->filt_off;
-    for (int i0 = lane; i0 < 9 * 128; i0 += 64 * 6) { /* 9 slots of history from the ring, six loads in flight */
-      int32_t tv[6];
+    { /* 9 slots of history from the ring: 1152 words over 128 threads, nine loads in flight */
+      int32_t tv[9];
 #pragma unroll
-      for (int j = 0; j < 6; j++) {
-        const int i = i0 + 64 * j;
-        if (i < 9 * 128) {
-          const int A = 9 - i / 128;
-          int pos = d + 128 * A + i % 128;
-          if (pos >= RING) pos -= RING;
-          tv[j] = st->ring[pos];
-        }
+      for (int j = 0; j < 9; j++) {
+        const int i = (int)threadIdx.x + 128 * j; /* = 128 j + word */
+        int pos = d + 128 * (9 - j) + (int)threadIdx.x;
+        if (pos >= RING) pos -= RING;
+        tv[j] = st->ring[pos];
+        (void)i;
       }
 #pragma unroll
-      for (int j = 0; j < 6; j++) {
-        const int i = i0 + 64 * j;
-        if (i < 9 * 128) v[(i / 128) * VROW + i % 128] = tv[j];
-      }
+      for (int j = 0; j < 9; j++) v[j * VROW + (int)threadIdx.x] = tv[j];
     }
     __syncthreads();
-    { /* window-add (ixheaacd_esbr_qmfsyn64_winadd, generic:1544), x 2^-16 to float */
+    { /* window-add (ixheaacd_esbr_qmfsyn64_winadd, generic:1544), x 2^-16 to float: wave w takes slots 16 w .. 16 w + 15 */
       float *dst = p.out + (size_t)ch * 2048;
-      for (int s = 0; s < 32; s++) {
+#pragma unroll 4
+      for (int s = 16 * w; s < 16 * w + 16; s++) {
         const int32_t *vs = v + (9 + s) * VROW + lane;
         int64_t acc = 0;
 #pragma unroll
@@ -205,21 +244,24 @@ __global__ __launch_bounds__(64) void xaac_esbr_synthesis_kernel(XaacEsbrSynPara
         dst[64 * s + lane] = (float)(int32_t)(acc >> 31) / 65536.0f;
       }
     }
-    { /* state: ring blocks of the last 10 slots, drc offset, window position */
+    { /* state: ring blocks of the last 10 slots (1280 words over 128 threads), drc offset, window position */
       const int d_new = (d + RING - (32 * 128) % RING) % RING;
-      for (int i = lane; i < RING; i += 64) {
-        const int A = 1 + i / 128;
-        int pos = d_new + 128 * A + i % 128;
+      int32_t tv[10];
+#pragma unroll
+      for (int j = 0; j < 10; j++) tv[j] = v[(9 + 32 - (1 + j)) * VROW + (int)threadIdx.x]; /* age A = 1 + j relative to the next frame's slot 0 */
+#pragma unroll
+      for (int j = 0; j < 10; j++) {
+        int pos = d_new + 128 * (1 + j) + (int)threadIdx.x;
         if (pos >= RING) pos -= RING;
         if (pos >= RING) pos -= RING;
-        st->ring[pos] = v[(9 + 32 - A) * VROW + i % 128];
+        st->ring[pos] = tv[j];
       }
-      if (lane == 0) {
+      if (threadIdx.x == 0) {
         st->drc_offset = d_new;
         st->filt_off = (f_old + 32 * 64) % 640;
       }
     }
-    __syncthreads();
+    __syncthreads(); /* channel 1's samples take the place of channel 0's */
   }
 }
 
@@ -266,6 +308,6 @@ extern "C" hipError_t xaac_launch_esbr_analysis(const XaacEsbrAnaParams *p, hipS
 }
 
 extern "C" hipError_t xaac_launch_esbr_synthesis(const XaacEsbrSynParams *p, hipStream_t stream) {
-  hipLaunchKernelGGL(xaac_esbr_synthesis_kernel, dim3((p->n_ch + 1) / 2), dim3(64), XAAC_ESBR_SYN_LDS, stream, *p);
+  hipLaunchKernelGGL(xaac_esbr_synthesis_kernel, dim3((p->n_ch + 1) / 2), dim3(128), XAAC_ESBR_SYN_LDS, stream, *p);
   return hipGetLastError();
 }
