@@ -87,6 +87,9 @@ struct XeWork {
   int8_t harmonics[64];
   int8_t sfb_first[64], sfb_len[64], flag[64], o_idx[64], lim_of[64];
   int16_t m_idx[64];
+  /* copies of state members the envelope loop reads band by band (from global memory each read was a memory latency) */
+  int32_t lim_tab[13];
+  int8_t harm_prev[64];
 };
 
 struct XeTrue { static constexpr bool value = true; };
@@ -658,6 +661,8 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
       if (w->err) return -1;
     }
   }
+  XS_PAR(k, 0, 64) w->harm_prev[k] = st->harm_flag_prev[k];
+  XS_PAR(c, 0, 13) w->lim_tab[c] = st->lim_table[lim_band][c]; /* (as the reset above may just have made it) */
   XS_ONE {
     w->err = 0;
     for (int i = 0; i < 64; i++) w->harmonics[i] = 0;
@@ -696,7 +701,7 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
       int flag = 0, o = 0;
       for (int k = li; k < ui; k++) {
         const int cc = k - sb_start;
-        if (w->harmonics[cc & 63] && (i >= trans_env || st->harm_flag_prev[k & 63])) flag = 1;
+        if (w->harmonics[cc & 63] && (i >= trans_env || w->harm_prev[k & 63])) flag = 1;
       }
       for (int q = 1; q < num_nf; q++) o += kabs >= h->freq_band_tbl_noise[q];
       w->sfb_first[c] = (int8_t)(li - sb_start);
@@ -738,7 +743,7 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
       const float ref = sd->flt_env_sf_arr[w->m_idx[c]];
       const float nf = sd->flt_noise_floor[next * num_nf + w->o_idx[c]];
       const double tmp = nf / (1 + nf + guard);
-      const bool tone_here = w->harmonics[c] && (i >= trans_env || st->harm_flag_prev[(c + sb_start) & 63]);
+      const bool tone_here = w->harmonics[c] && (i >= trans_env || w->harm_prev[(c + sb_start) & 63]);
       float gain, tone = 0;
       if (w->flag[c]) {
         gain = (float)xe_sqrt(ref * tmp / (est + 1));
@@ -764,7 +769,7 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
        this frame's bands, where the reference reads whatever its scratch holds; here such a band ends at the last band.) */
     const int n_lim = st->gate_mode[lim_band] < 12 ? st->gate_mode[lim_band] : 12;
     XS_PAR(c, 0, n_lim) {
-      const int k0 = st->lim_table[lim_band][c], k1r = st->lim_table[lim_band][c + 1], k1 = k1r < num_sb ? k1r : num_sb;
+      const int k0 = w->lim_tab[c], k1r = w->lim_tab[c + 1], k1 = k1r < num_sb ? k1r : num_sb;
       float p_ref = 0, p_est = 0, g_max = 0;
       if (k0 >= 0 && k0 <= k1) {
         for (int k = k0; k < k1; k++) {
@@ -782,7 +787,7 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
     XS_PAR(k, 0, num_sb) {
       int lb = -1;
       for (int c = 0; c < n_lim; c++) {
-        const int k0 = st->lim_table[lim_band][c], k1r = st->lim_table[lim_band][c + 1], k1 = k1r < num_sb ? k1r : num_sb;
+        const int k0 = w->lim_tab[c], k1r = w->lim_tab[c + 1], k1 = k1r < num_sb ? k1r : num_sb;
         if (lb < 0 && k0 >= 0 && k >= k0 && k < k1) lb = c;
       }
       w->lim_of[k] = (int8_t)lb;
@@ -802,7 +807,7 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
     }
     cx.sync();
     XS_PAR(c, 0, n_lim) {
-      const int k0 = st->lim_table[lim_band][c], k1r = st->lim_table[lim_band][c + 1], k1 = k1r < num_sb ? k1r : num_sb;
+      const int k0 = w->lim_tab[c], k1r = w->lim_tab[c + 1], k1 = k1r < num_sb ? k1r : num_sb;
       float boost = 1.0f;
       if (k0 >= 0 && k0 <= k1) {
         float p_adj = 0;
