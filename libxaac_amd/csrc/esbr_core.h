@@ -50,7 +50,9 @@ struct XeMat {
 /* Column walks fetch / write back XE_CH rows in one burst, so that a stage costs one memory latency per XE_CH rows
    instead of one per row (the compiler may not move a load across an earlier store of the same matrix by itself).  The
    order of the arithmetic is untouched. */
+#ifndef XE_CH
 #define XE_CH 8
+#endif
 #if defined(__HIPCC__)
 #define XE_UNROLL _Pragma("unroll")
 #define XE_NOUNROLL _Pragma("nounroll")

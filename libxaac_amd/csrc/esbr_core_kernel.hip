@@ -29,6 +29,9 @@ __shared__ long long xe_prof_acc[16];
 /* LDS copy of the 512 random phases the noise substitution looks up per band and slot */
 __shared__ float xe_lds_random_phase[1024];
 #define XE_RANDOM_PHASE(i) xe_lds_random_phase[i]
+/* rows a column walk keeps in flight (esbr_core.h: XE_CH): twelve measured best for this kernel (8: 413 us, 12: 398, 16: 440 with
+   70 spills); the float PS kernel stays at eight (twelve: 320 -> 350 us) */
+#define XE_CH 12
 #include "esbr_core.h"
 #include "hbe_trans.h" /* xh_apply_params_ok */
 #include "hbe_kernel.h" /* XAAC_HBE_LDS_OK */
