@@ -319,13 +319,13 @@ FX_HD void xp_decorrelation(const XsCx &cx, const XpTables *T, PS *ps, XpHyb *hy
 }
 
 /* ps_dec.c:678 / :691: quarter-wave table lookups of the rotation angles */
-FX_HD int16_t xp_cos512(const XpTables *, int32_t phi_by_4) { /* the table itself: T may be a copy without trig_data */
-  const int16_t *trig = xaac_ps_tables.trig_data;
+FX_HD int16_t xp_cos512(const XpTables *T, int32_t phi_by_4) {
+  const int16_t *trig = T->trig_data;
   int index = fx_round16(fx_abs_sat(phi_by_4)) & 0x3ff;
   return index < 512 ? trig[512 - index] : (int16_t)(-trig[index - 512]);
 }
-FX_HD int16_t xp_sin512(const XpTables *, int32_t phi_by_4) {
-  const int16_t *trig = xaac_ps_tables.trig_data;
+FX_HD int16_t xp_sin512(const XpTables *T, int32_t phi_by_4) {
+  const int16_t *trig = T->trig_data;
   int index = fx_round16(phi_by_4);
   if (index < 0) {
     index = (-index) & 0x3ff;

@@ -50,9 +50,10 @@ constexpr int kHeadWords = offsetof(xaac_ps_state, syn_ring_r) / 4;
 static_assert(offsetof(xaac_ps_state, syn_ring_r) % 4 == 0 && sizeof(XpLdsState) == kHeadWords * 4, "mirror layout");
 static_assert(sizeof(xaac_ps_frame) % 4 == 0, "word copies");
 
-/* the PS constants (a table lookup in global memory costs a serial phase its latency) without the last member, the
-   quarter-wave sine table of the envelope borders' coefficient set-up, which is read from global memory */
-constexpr int kTabBytes = offsetof(XpTables, trig_data);
+/* the PS constants, all of them (a table lookup in global memory costs a serial phase its latency; the quarter-wave sine table
+   of the envelope borders' coefficient set-up stayed in global memory until the LDS budget was counted: 2 x (4 x 17.9 KB +
+   2.4 KB) = 148 KB per CU) */
+constexpr int kTabBytes = (int)sizeof(XpTables);
 #ifndef XP_WAVES
 #define XP_WAVES 4
 #endif
@@ -65,7 +66,6 @@ struct XpLds {
   xaac_ps_frame pf;
   XpFrameWork w;
 };
-static_assert(kTabBytes + sizeof(((XpTables *)0)->trig_data) <= sizeof(XpTables), "trig_data is the last member (the word copy may take its first entry along)");
 
 __device__ __forceinline__ void xp_wave_sync() { /* = XsCx::sync() */
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
