@@ -103,40 +103,44 @@ __global__ __launch_bounds__(64 * kPsWaves, XP_WAVES_PER_EU) void xaac_ps_kernel
   }
 #endif
   for (int n = blockIdx.x * kPsWaves + wave; n < p.n; n += gridDim.x * kPsWaves) {
-    if (!(p.sbr_frame[n].apply_processing && p.header[n].channel_mode == 3)) { /* sbr_dec.c:1246: mono this frame */
+    xaac_ps_state *gps = p.state + n;
+    int32_t *gx = p.x + (size_t)n * (40 * 128) + 2 * 128; /* slot 0 */
+    int32_t *gr = p.xr + (size_t)n * (32 * 128);
+    int16_t *par = p.par_l + 8 * (size_t)n;
+    /* Everything the stream's set-up reads from global memory in flight together: the two words that say whether this is a PS
+       frame at all, state, side info and the six scale parameters the core left (as a chain -- flags, then state, then
+       parameters -- a stream paid three memory latencies before its first instruction of work) */
+    constexpr int NS = (kHeadWords + 63) / 64, NF = (sizeof(xaac_ps_frame) / 4 + 63) / 64;
+    int32_t rs[NS], rf[NF];
+    const int32_t *gs = reinterpret_cast<const int32_t *>(gps), *gf = reinterpret_cast<const int32_t *>(p.frame + n);
+    const int apply_v = p.sbr_frame[n].apply_processing, mode_v = p.header[n].channel_mode;
+    const int par_v = lane < 6 ? par[lane] : 0;
+#pragma unroll
+    for (int j = 0; j < NS; j++) rs[j] = lane + 64 * j < kHeadWords ? gs[lane + 64 * j] : 0;
+#pragma unroll
+    for (int j = 0; j < NF; j++) rf[j] = lane + 64 * j < (int)(sizeof(xaac_ps_frame) / 4) ? gf[lane + 64 * j] : 0;
+    if (!(__builtin_amdgcn_readfirstlane(apply_v) && __builtin_amdgcn_readfirstlane(mode_v) == 3)) { /* sbr_dec.c:1246: mono this frame */
       if (lane == 0) {
         p.par_l[8 * (size_t)n + 6] = 0;
         p.par_r[8 * (size_t)n + 6] = 1;
       }
       continue;
     }
-    xaac_ps_state *gps = p.state + n;
-    int32_t *gx = p.x + (size_t)n * (40 * 128) + 2 * 128; /* slot 0 */
-    int32_t *gr = p.xr + (size_t)n * (32 * 128);
     xp_wave_sync(); /* the previous stream's state has left the LDS copy */
-    { /* state and side info: all loads in flight before the first LDS store (one memory latency, not one per batch) */
-      constexpr int NS = (kHeadWords + 63) / 64, NF = (sizeof(xaac_ps_frame) / 4 + 63) / 64;
-      int32_t rs[NS], rf[NF];
-      const int32_t *gs = reinterpret_cast<const int32_t *>(gps), *gf = reinterpret_cast<const int32_t *>(p.frame + n);
 #pragma unroll
-      for (int j = 0; j < NS; j++) rs[j] = lane + 64 * j < kHeadWords ? gs[lane + 64 * j] : 0;
+    for (int j = 0; j < NS; j++)
+      if (lane + 64 * j < kHeadWords) reinterpret_cast<int32_t *>(&s.ps)[lane + 64 * j] = rs[j];
 #pragma unroll
-      for (int j = 0; j < NF; j++) rf[j] = lane + 64 * j < (int)(sizeof(xaac_ps_frame) / 4) ? gf[lane + 64 * j] : 0;
-#pragma unroll
-      for (int j = 0; j < NS; j++)
-        if (lane + 64 * j < kHeadWords) reinterpret_cast<int32_t *>(&s.ps)[lane + 64 * j] = rs[j];
-#pragma unroll
-      for (int j = 0; j < NF; j++)
-        if (lane + 64 * j < (int)(sizeof(xaac_ps_frame) / 4)) reinterpret_cast<int32_t *>(&s.pf)[lane + 64 * j] = rf[j];
-    }
+    for (int j = 0; j < NF; j++)
+      if (lane + 64 * j < (int)(sizeof(xaac_ps_frame) / 4)) reinterpret_cast<int32_t *>(&s.pf)[lane + 64 * j] = rf[j];
     xp_wave_sync();
 #ifdef XS_PROFILE
     if (threadIdx.x == 0) xp_prof_last = clock64();
 #endif
     const int ps_clamped = xp_frame_sanitize(cx, &s.pf); /* indices a parser cannot produce: contained, reported */
-    int16_t *par = p.par_l + 8 * (size_t)n;
-    const int lb_scale = cx.uni(par[0]), ov_lb_scale = cx.uni(par[1]), hb_scale = cx.uni(par[2]), st_syn = cx.uni(par[3]);
-    const int lsb = cx.uni(par[4]), usb = cx.uni(par[5]);
+    const int lb_scale = __builtin_amdgcn_readlane(par_v, 0), ov_lb_scale = __builtin_amdgcn_readlane(par_v, 1);
+    const int hb_scale = __builtin_amdgcn_readlane(par_v, 2), st_syn = __builtin_amdgcn_readlane(par_v, 3);
+    const int lsb = __builtin_amdgcn_readlane(par_v, 4), usb = __builtin_amdgcn_readlane(par_v, 5);
     const int ps_scale =
         xp_ps_frame(cx, tabs, &s.ps, &s.pf, &s.w, gx, gr, lb_scale, ov_lb_scale, hb_scale, st_syn, lsb, usb);
     /* ---- state and the two synthesis launches' parameters ---- */
