@@ -500,6 +500,7 @@ def _decode_streams(streams, ctx, device, threads, keep_pcm, timing, overlap, es
         out32, qadj = dz(n * 1024 * n_ch, dtype=torch.int32), dz(n * n_ch, dtype=torch.int8)
         lim0, delay = peak_limiter_init(n_ch, rate)
         lim = torch.from_numpy(np.tile(np.frombuffer(bytes(lim0), np.uint8), (n, 1)).copy()).to(dev)
+        lim_at_end, lim_taken = {}, np.zeros(n, bool)
         ws = dz(max(ctx.peak_limiter_workspace_bytes(n), 16))
         pcm2 = [dz(n * 1024 * n_ch, dtype=torch.int16) for _ in range(2)]
         pcm_h2 = [pinned(n * 1024 * n_ch, dtype=torch.int16) for _ in range(2)]
@@ -638,6 +639,11 @@ def _decode_streams(streams, ctx, device, threads, keep_pcm, timing, overlap, es
             cur.sent_once = True
             main_stream.wait_event(cur.sent)
             if not sbr:
+                # a stream that ended with the step before: its limiter state as its last frame left it (the rows of ended
+                # streams go on running idle through the kernels; the delay line flushed behind a stream is the one it ended on)
+                for i in np.nonzero(~got & ~lim_taken)[0]:
+                    lim_at_end[int(i)] = lim[int(i)].cpu().numpy()     # (waits for the kernels of the step before)
+                    lim_taken[i] = True
                 ctx.imdct_process_batch(spec_d, ics_d, overlap_buf, ovl_state, out32=out32, qshift_adj=qadj, ch_fac=n_ch)
                 ctx.peak_limiter_process_batch(out32, qadj, lim, n_ch, ws, pcm16=pcm)
                 hand_down(slot, got, (n, 1024, n_ch), cut_=delay if first else 0)   # the limiter's delay is cut from the first frame
@@ -742,7 +748,7 @@ def _decode_streams(streams, ctx, device, threads, keep_pcm, timing, overlap, es
         ctx.sync()
         lim_h = lim.cpu().numpy()
         for i in range(n):
-            st = LimiterState.from_buffer_copy(lim_h[i].tobytes())
+            st = LimiterState.from_buffer_copy((lim_at_end[i] if i in lim_at_end else lim_h[i]).tobytes())
             att, idx = st.attack_time_samples, st.delayed_input_index
             d = np.ctypeslib.as_array(st.delayed_input)[:att * n_ch].reshape(att, n_ch)
             tail = np.concatenate([d[idx:], d[:idx]]).astype(np.float64)

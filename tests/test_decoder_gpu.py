@@ -106,5 +106,30 @@ def test_streams_of_different_lengths_share_a_batch():
         assert np.array_equal(got[0], full[0])
         if per_frame == 2048:
             assert np.array_equal(got[1], full[0][:10 * 2048]) and np.array_equal(got[2], full[0][:21 * 2048])
-        else:   # AAC-LC: the limiter's delay line is flushed behind the last frame, so only the common part is compared
-            assert np.array_equal(got[1][:9 * 1024], full[0][:9 * 1024]) and len(got[1]) == 10 * 1024
+        else:   # AAC-LC: the limiter's delay line is flushed behind the stream's last frame: a cut stream ends like the cut
+            alone_1, _ = decoder.decode_streams([data[:cuts[9]]])   # stream decoded alone
+            alone_2, _ = decoder.decode_streams([data[:cuts[20]]])
+            assert np.array_equal(got[1], alone_1[0]) and np.array_equal(got[2], alone_2[0]) and len(got[1]) == 10 * 1024
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("esbr", [False, True], ids=["esbr0", "default"])
+def test_the_pipelined_loop_equals_the_plain_one(esbr):
+    """overlap=True (the parser library's own threads parse step k + 1, copies up on their own stream into two sets of device
+    inputs, copy down of step k - 1 beside both) against overlap=False (parse, copy, run, copy, one after the other) on batches
+    with streams of different lengths, and a thread count that does not divide the batch"""
+    from libxaac_amd import decoder
+    for name in ("mix_aot29_32k", "mix_aot5_48k", "mix_aot2_64k"):
+        data = open(os.path.join(STREAMS, name + ".aac"), "rb").read()
+        lens, pos = [], 0
+        while pos + 7 <= len(data):
+            n = ((data[pos + 3] & 3) << 11) | (data[pos + 4] << 3) | (data[pos + 5] >> 5)
+            lens.append(n)
+            pos += n
+        batch = [data, data[:sum(lens[:12])], data, data[:sum(lens[:3])], data]
+        plain, rate_a = decoder.decode_streams(batch, overlap=False, esbr=esbr, threads=3)
+        piped, rate_b = decoder.decode_streams(batch, overlap=True, esbr=esbr, threads=3)
+        assert rate_a == rate_b
+        for a, b in zip(plain, piped):
+            assert np.array_equal(a, b), name
+        assert len(plain[1]) < len(plain[0]) and len(plain[3]) < len(plain[1])
