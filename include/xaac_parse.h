@@ -149,6 +149,12 @@ typedef struct xaac_parse_batch {
                                  streams can then issue the next step's call without touching its arrays in between.
                                  (Appended in round 4: a descriptor built for the older layout must be zero-initialised at the
                                  new size.) */
+  int32_t frames;             /* 0 or 1: one frame per stream and call.  T > 1 (needs pos): up to T consecutive frames of every
+                                 stream per call -- a stream's parser state and bytes are fetched once for T frames -- with every
+                                 output array T times as long, step t's rows behind step t - 1's (spec [T][n_streams][n_ch][1024],
+                                 status [T][n_streams], flags [T][n_streams][8], ...; consumed [n_streams] = the bytes of all its
+                                 frames).  A stream that runs out or fails at step t has that status word in steps t .. T - 1.
+                                 The call then returns the number of frames parsed. */
 } xaac_parse_batch;
 
 /* returns the number of streams whose status is XAAC_PARSE_OK, or a negative XAAC_PARSE_ERR_* for a bad descriptor */

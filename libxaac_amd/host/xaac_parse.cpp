@@ -338,11 +338,12 @@ struct BatchJob {
 };
 BatchJob g_job;
 
-void parse_item(const xaac_parse_batch *b, int i, std::atomic<int> *ok) {
+/* frame t (of the call's b->frames) of stream i; the arrays of step t lie one step's array behind those of step t - 1 */
+int32_t parse_one(const xaac_parse_batch *b, int i, int t, std::atomic<int> *ok) {
   const int n_ch = b->n_ch;
+  const size_t S = (size_t)b->n_streams * (size_t)t, SC = S * (size_t)n_ch; /* streams / channels in front of this step's rows */
   xaac_parser *p = b->parser[i];
   size_t used = 0;
-  b->consumed[i] = 0;
   const uint64_t at = b->pos ? (b->pos[i] < b->bytes[i] ? b->pos[i] : b->bytes[i]) : 0;
   int32_t r = parse_frame(p, b->data[i] + at, (size_t)(b->bytes[i] - at), b->stage, &used);
   if (r == 0 && p->el.n_ch != n_ch) r = XAAC_PARSE_ERR_UNSUPPORTED;
@@ -352,35 +353,51 @@ void parse_item(const xaac_parse_batch *b, int i, std::atomic<int> *ok) {
     side = &side_of_thread;
     r = xaac_parse_sbr_side(p, b->ps_enable, side);
   }
-  b->status[i] = r;
-  if (r) return;
+  b->status[S + i] = r;
+  if (r) return r;
   (*ok)++;
-  b->consumed[i] = used;
+  b->consumed[i] += used;
   if (b->pos) b->pos[i] = at + used;
-  if (b->tools) b->tools[i] = tools_of(p->el);
+  if (b->tools) b->tools[S + i] = tools_of(p->el);
   for (int c = 0; c < n_ch; c++) {
-    memcpy(b->spec + ((size_t)i * n_ch + c) * 1024, p->el.ch[c].spec(), 1024 * sizeof(int32_t));
-    b->ics[((size_t)i * n_ch + c) * 2 + 0] = (uint8_t)p->el.ch[c].ics.window_sequence;
-    b->ics[((size_t)i * n_ch + c) * 2 + 1] = (uint8_t)p->el.ch[c].ics.window_shape;
+    const size_t row = SC + (size_t)i * n_ch + c;
+    memcpy(b->spec + row * 1024, p->el.ch[c].spec(), 1024 * sizeof(int32_t));
+    b->ics[row * 2 + 0] = (uint8_t)p->el.ch[c].ics.window_sequence;
+    b->ics[row * 2 + 1] = (uint8_t)p->el.ch[c].ics.window_shape;
     if (side) {
-      b->header[(size_t)i * n_ch + c] = side->header;
-      b->frame[(size_t)i * n_ch + c] = side->frame[c];
+      b->header[row] = side->header;
+      b->frame[row] = side->frame[c];
     }
   }
-  if (side && b->reset_pitch && side->reset) b->reset_pitch[i] = p->sbr.reset_pitch;
+  if (side && b->reset_pitch && side->reset) b->reset_pitch[S + i] = p->sbr.reset_pitch;
   if (side && b->esbr_side && p->esbr)
-    for (int c = 0; c < n_ch; c++) xs_export_esbr_side(&p->sbr, c, b->esbr_side + (size_t)i * n_ch + c);
+    for (int c = 0; c < n_ch; c++) xs_export_esbr_side(&p->sbr, c, b->esbr_side + SC + (size_t)i * n_ch + c);
   if (side) {
-    if (b->ps_frame) b->ps_frame[i] = side->ps_frame;
-    int32_t *f = b->flags + (size_t)i * 8;
+    if (b->ps_frame) b->ps_frame[S + i] = side->ps_frame;
+    int32_t *f = b->flags + (S + i) * 8;
     f[0] = side->apply, f[1] = side->reset, f[2] = side->reset_channels, f[3] = side->upsampling;
     f[4] = side->stereo, f[5] = side->ps, f[6] = side->ps_start, f[7] = side->frame_ok;
+  }
+  return 0;
+}
+
+/* one stream's frames of the call, one behind the other while its parser state and its bytes are in this core's caches */
+void parse_item(const xaac_parse_batch *b, int i, std::atomic<int> *ok) {
+  const int frames = b->frames > 1 ? b->frames : 1;
+  b->consumed[i] = 0;
+  for (int t = 0; t < frames; t++) {
+    const int32_t r = parse_one(b, i, t, ok);
+    if (r) { /* the stream stops here for this call: the later steps carry the same word */
+      for (int u = t + 1; u < frames; u++) b->status[(size_t)b->n_streams * u + i] = r;
+      return;
+    }
   }
 }
 
 bool batch_ok(const xaac_parse_batch *b) {
   return b && b->n_streams >= 0 && (b->n_ch == 1 || b->n_ch == 2) && b->parser && b->data && b->bytes && b->spec && b->ics &&
-         b->consumed && b->status && (!b->with_sbr || (b->header && b->frame && b->flags));
+         b->consumed && b->status && (!b->with_sbr || (b->header && b->frame && b->flags)) && b->frames >= 0 &&
+         (b->frames <= 1 || b->pos); /* several frames per call: the positions are the library's */
 }
 
 int batch_threads(const xaac_parse_batch *b) {

@@ -201,12 +201,13 @@ def _frame_lengths(data):
 
 
 @pytest.mark.parametrize("name", ["mix_aot29_32k", "mix_aot5_48k", "mix_aot2_64k"])
-@pytest.mark.parametrize("halves", [False, True], ids=["run", "start_wait"])
-def test_batch_parser_equals_the_single_stream_parser(name, halves):
-    """xaac_parse_batch_run and its two-halves form (xaac_parse_batch_start / _wait, read positions kept by the library,
-    the caller's own status array per step) over streams of different lengths in one batch -- whole, cut behind frame 9, cut in
-    the middle of frame 5 -- against xaac_parse_adts_frame / xaac_parse_sbr_side stream by stream: spectra, window info, SBR
-    header / frame / PS structs, flags, and which streams deliver a frame in which step."""
+@pytest.mark.parametrize("mode", ["run", "start_wait", "three_frames_per_call"])
+def test_batch_parser_equals_the_single_stream_parser(name, mode):
+    """xaac_parse_batch_run, its two-halves form (xaac_parse_batch_start / _wait, read positions kept by the library, the
+    caller's own status array per step) and the form with several frames of every stream per call (xaac_parse_batch::frames)
+    over streams of different lengths in one batch -- whole, cut behind frame 9, cut in the middle of frame 5 -- against
+    xaac_parse_adts_frame / xaac_parse_sbr_side stream by stream: spectra, window info, SBR header / frame / PS structs, flags,
+    and which streams deliver a frame in which step."""
     from libxaac_amd import PS_FRAME_BYTES, SBR_FRAME_BYTES, SBR_HEADER_BYTES
     whole = stream(name)
     lens = _frame_lengths(whole)
@@ -216,47 +217,52 @@ def test_batch_parser_equals_the_single_stream_parser(name, halves):
     bp = decoder.BatchParser(datas, threads=3)
     n, n_ch = bp.n, bp.n_ch
     nc = n * n_ch
-    two = lambda *shape, dtype=np.uint8: [np.zeros(shape, dtype) for _ in range(2)]
+    T = 3 if mode == "three_frames_per_call" else 1
+    two = lambda *shape, dtype=np.uint8: [np.zeros((T,) + shape, dtype) for _ in range(2)]
     spec, ics = two(nc, 1024, dtype=np.int32), two(nc, 2)
     hdr, frm, psf = two(nc, SBR_HEADER_BYTES), two(nc, SBR_FRAME_BYTES), two(n, PS_FRAME_BYTES)
     flags, status, pitch = two(n, 8, dtype=np.int32), two(n, dtype=np.int32), two(n, dtype=np.int32)
     args = lambda s: (spec[s], ics[s], hdr[s] if bp.sbr else None, frm[s] if bp.sbr else None,
                       psf[s] if bp.sbr and n_ch == 1 else None, flags[s] if bp.sbr else None)
-    step = 0
-    if halves:
-        bp.start_step(*args(0), status=status[0], reset_pitch=pitch[0])
-    while True:
-        s = step & 1
-        if halves:   # as decode_streams does: wait, start the next step into the other set, then look at this one
+    step, call = 0, 0
+    if mode != "run":
+        bp.start_step(*args(0), status=status[0], reset_pitch=pitch[0], frames=T)
+    done = False
+    while not done:
+        s = call & 1
+        if mode != "run":   # as decode_streams does: wait, start the next call into the other set, then look at this one
             ok, busy = bp.wait_step(check=False)
             assert busy >= 0.0
-            bp.start_step(*args(1 - s), status=status[1 - s], reset_pitch=pitch[1 - s])
-            got = bp.finish_step(ok, status[s])
+            bp.start_step(*args(1 - s), status=status[1 - s], reset_pitch=pitch[1 - s], frames=T)
+            gots = [bp.finish_step(ok if T == 1 else None, status[s][t]) for t in range(T)]
         else:
-            got = bp.step(*args(s))
-        assert list(got) == [step < len(w) for w in want], step
-        if not got.any():
-            break
-        for i in np.nonzero(got)[0]:
-            w_spec, w_ics, _, w_side = want[i][step][:4]
-            for c in range(n_ch):
-                assert np.array_equal(spec[s][i * n_ch + c], w_spec[c]), (step, i, c)
-                assert list(ics[s][i * n_ch + c]) == [int(w_ics[c][0]), int(w_ics[c][1])]
-            if bp.sbr:
-                raw = bytes(w_side)
-                off = decoder.SbrSide.header.offset
-                assert bytes(hdr[s][i * n_ch]) == raw[off:off + SBR_HEADER_BYTES], (step, i)
-                off = decoder.SbrSide.frame.offset
+            gots = [bp.step(*(a if a is None else a[0] for a in args(s)))]
+        call += 1
+        for t, got in enumerate(gots):
+            assert list(got) == [step < len(w) for w in want], step
+            if not got.any():
+                done = True
+                break
+            for i in np.nonzero(got)[0]:
+                w_spec, w_ics, _, w_side = want[i][step][:4]
                 for c in range(n_ch):
-                    assert bytes(frm[s][i * n_ch + c]) == raw[off + c * SBR_FRAME_BYTES:off + (c + 1) * SBR_FRAME_BYTES], (step, i, c)
-                if n_ch == 1:
-                    off = decoder.SbrSide.ps_frame.offset
-                    assert bytes(psf[s][i]) == raw[off:off + PS_FRAME_BYTES], (step, i)
-                assert list(flags[s][i]) == [w_side.apply, w_side.reset, w_side.reset_channels, w_side.upsampling, w_side.stereo,
-                                             w_side.ps, w_side.ps_start, w_side.frame_ok]
-        step += 1
+                    assert np.array_equal(spec[s][t][i * n_ch + c], w_spec[c]), (step, i, c)
+                    assert list(ics[s][t][i * n_ch + c]) == [int(w_ics[c][0]), int(w_ics[c][1])]
+                if bp.sbr:
+                    raw = bytes(w_side)
+                    off = decoder.SbrSide.header.offset
+                    assert bytes(hdr[s][t][i * n_ch]) == raw[off:off + SBR_HEADER_BYTES], (step, i)
+                    off = decoder.SbrSide.frame.offset
+                    for c in range(n_ch):
+                        assert bytes(frm[s][t][i * n_ch + c]) == raw[off + c * SBR_FRAME_BYTES:off + (c + 1) * SBR_FRAME_BYTES], (step, i, c)
+                    if n_ch == 1:
+                        off = decoder.SbrSide.ps_frame.offset
+                        assert bytes(psf[s][t][i]) == raw[off:off + PS_FRAME_BYTES], (step, i)
+                    assert list(flags[s][t][i]) == [w_side.apply, w_side.reset, w_side.reset_channels, w_side.upsampling,
+                                                    w_side.stereo, w_side.ps, w_side.ps_start, w_side.frame_ok]
+            step += 1
     assert step == len(lens) and list(bp.frames) == [len(w) for w in want]
-    if halves:
-        ok, _ = bp.wait_step(check=False)   # the step started behind the last one: nothing left to parse
+    if mode != "run":
+        ok, _ = bp.wait_step(check=False)   # the call started behind the last one: nothing left to parse
         assert ok == 0
     bp.close()
