@@ -155,6 +155,10 @@ typedef struct xaac_parse_batch {
                                  status [T][n_streams], flags [T][n_streams][8], ...; consumed [n_streams] = the bytes of all its
                                  frames).  A stream that runs out or fails at step t has that status word in steps t .. T - 1.
                                  The call then returns the number of frames parsed. */
+  int32_t *lines;             /* optional [frames][n_streams], out: for a delivered frame the number of leading spectral lines
+                                 (a multiple of 16, the larger of the stream's channels) behind which every line is zero -- what
+                                 a host needs to send up of the frame's rows (AAC + SBR streams code the lower half of the
+                                 spectrum or less) */
 } xaac_parse_batch;
 
 /* returns the number of streams whose status is XAAC_PARSE_OK, or a negative XAAC_PARSE_ERR_* for a bad descriptor */

@@ -369,6 +369,21 @@ int32_t parse_one(const xaac_parse_batch *b, int i, int t, std::atomic<int> *ok)
       b->frame[row] = side->frame[c];
     }
   }
+  if (b->lines) {
+    int top = 0;
+    for (int c = 0; c < n_ch; c++) {
+      const int32_t *x = p->el.ch[c].spec();
+      int blk = 1024 / 16;
+      for (; blk > top; blk--) { /* the topmost block of 16 lines with a non-zero word */
+        const int32_t *q = x + 16 * (blk - 1);
+        int32_t any = 0;
+        for (int k = 0; k < 16; k++) any |= q[k];
+        if (any) break;
+      }
+      top = blk > top ? blk : top;
+    }
+    b->lines[S + i] = 16 * top;
+  }
   if (side && b->reset_pitch && side->reset) b->reset_pitch[S + i] = p->sbr.reset_pitch;
   if (side && b->esbr_side && p->esbr)
     for (int c = 0; c < n_ch; c++) xs_export_esbr_side(&p->sbr, c, b->esbr_side + SC + (size_t)i * n_ch + c);

@@ -222,18 +222,19 @@ def test_batch_parser_equals_the_single_stream_parser(name, mode):
     spec, ics = two(nc, 1024, dtype=np.int32), two(nc, 2)
     hdr, frm, psf = two(nc, SBR_HEADER_BYTES), two(nc, SBR_FRAME_BYTES), two(n, PS_FRAME_BYTES)
     flags, status, pitch = two(n, 8, dtype=np.int32), two(n, dtype=np.int32), two(n, dtype=np.int32)
+    lin = two(n, dtype=np.int32)
     args = lambda s: (spec[s], ics[s], hdr[s] if bp.sbr else None, frm[s] if bp.sbr else None,
                       psf[s] if bp.sbr and n_ch == 1 else None, flags[s] if bp.sbr else None)
     step, call = 0, 0
     if mode != "run":
-        bp.start_step(*args(0), status=status[0], reset_pitch=pitch[0], frames=T)
+        bp.start_step(*args(0), status=status[0], reset_pitch=pitch[0], frames=T, lines=lin[0])
     done = False
     while not done:
         s = call & 1
         if mode != "run":   # as decode_streams does: wait, start the next call into the other set, then look at this one
             ok, busy = bp.wait_step(check=False)
             assert busy >= 0.0
-            bp.start_step(*args(1 - s), status=status[1 - s], reset_pitch=pitch[1 - s], frames=T)
+            bp.start_step(*args(1 - s), status=status[1 - s], reset_pitch=pitch[1 - s], frames=T, lines=lin[1 - s])
             gots = [bp.finish_step(ok if T == 1 else None, status[s][t]) for t in range(T)]
         else:
             gots = [bp.step(*(a if a is None else a[0] for a in args(s)))]
@@ -248,6 +249,10 @@ def test_batch_parser_equals_the_single_stream_parser(name, mode):
                 for c in range(n_ch):
                     assert np.array_equal(spec[s][t][i * n_ch + c], w_spec[c]), (step, i, c)
                     assert list(ics[s][t][i * n_ch + c]) == [int(w_ics[c][0]), int(w_ics[c][1])]
+                if mode != "run":   # xaac_parse_batch::lines: nothing but zeros behind them, a non-zero word in their last 16
+                    L = int(lin[s][t][i])
+                    rows = spec[s][t][i * n_ch:(i + 1) * n_ch]
+                    assert L % 16 == 0 and 0 <= L <= 1024 and not rows[:, L:].any() and (L == 0 or rows[:, L - 16:L].any())
                 if bp.sbr:
                     raw = bytes(w_side)
                     off = decoder.SbrSide.header.offset
