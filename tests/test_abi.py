@@ -201,3 +201,19 @@ def test_pvc_struct_layouts_match_header(tmp_path):
         want += [ctypes.sizeof(cls), getattr(cls, last).offset]
     assert got == want
     assert (ctypes.sizeof(ps.PvcFrame), ctypes.sizeof(ps.PvcState)) == (libxaac_amd.PVC_FRAME_BYTES, libxaac_amd.PVC_STATE_BYTES)
+
+
+def test_parse_batch_descriptor_matches_header(tmp_path):
+    """libxaac_amd/decoder.py's mirror of struct xaac_parse_batch (members appended in round 4: pos, frames, lines) against what
+    a C compiler makes of include/xaac_parse.h"""
+    import subprocess
+    from libxaac_amd import decoder
+    src = tmp_path / "pb.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "xaac_parse.h"\nint main(void) { printf("%zu %zu %zu %zu %zu\\n", '
+                   'sizeof(xaac_parse_batch), offsetof(xaac_parse_batch, parser), offsetof(xaac_parse_batch, pos), '
+                   'offsetof(xaac_parse_batch, frames), offsetof(xaac_parse_batch, lines)); return 0; }\n')
+    exe = tmp_path / "pb"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    P = decoder._ParseBatch
+    assert got == [ctypes.sizeof(P), P.parser.offset, P.pos.offset, P.frames.offset, P.lines.offset]
