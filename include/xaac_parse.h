@@ -194,6 +194,12 @@ void xaac_hbe_state_init(xaac_hbe_state *s);
    (The reset's two transposer runs over the rows the channel holds, sbrdecoder.c:196-236, are the caller's:
    xaac_hbe_apply_batch on the device-resident state.) */
 int32_t xaac_hbe_state_reinit(xaac_hbe_state *s, const xaac_sbr_header *header);
+/* ... for n channels at once, on the states' integer tails alone (everything from synth_size on: the members the re-initialisation
+   computes; a batched host keeps them beside the device-resident states and clears the two delay lines on the device):
+   tails [n][XAAC_HBE_TAIL_BYTES] in / out, headers [n].  Returns -1, or the index of the first channel whose band tables the
+   reference would refuse (the tails behind it are left as they were). */
+#define XAAC_HBE_TAIL_BYTES (sizeof(xaac_hbe_state) - offsetof(xaac_hbe_state, synth_size))
+int32_t xaac_hbe_state_reinit_tails(uint8_t *tails, const xaac_sbr_header *headers, int32_t n);
 /* what ixheaacd_sbr_dec_reset (sbrdecoder.c:103-252) and ixheaacd_prepare_upsamp (:254-276) do to one channel's state
    for this frame's side info; channel = 0 or 1 (no-op beyond side->reset_channels / for frames without either) */
 void xaac_sbr_state_apply_side(xaac_sbr_state *s, const xaac_sbr_side *side, int32_t channel);

@@ -72,6 +72,8 @@ def load_host_library():
         lib.xaac_parser_set_esbr.argtypes = [ctypes.c_void_p, ctypes.c_int32]
         lib.xaac_parse_esbr_side.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
         lib.xaac_hbe_state_reinit.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.xaac_hbe_state_reinit_tails.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
+        lib.xaac_hbe_state_reinit_tails.restype = ctypes.c_int32
         lib.xaac_parse_reset_pitch.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]
         lib.xaac_sbr_state_apply_side.argtypes = [ctypes.c_void_p, ctypes.POINTER(SbrSide), ctypes.c_int32]
         lib.xaac_sbr_state_apply_side.restype = None
@@ -706,13 +708,13 @@ def _decode_streams(streams, ctx, device, threads, keep_pcm, timing, overlap, es
                     rows = torch.from_numpy(rows_h).to(dev)
                     hb = hbe.index_select(0, rows)
                     tail_off = HBE_STATE_BYTES - 48
-                    one = np.zeros(HBE_STATE_BYTES, np.uint8)
-                    for j, r in enumerate(rows_h):
-                        one[tail_off:] = hbe_tail[r]
-                        if lib.xaac_hbe_state_reinit(one.ctypes.data, hdr_h[int(r)].numpy().ctypes.data):
-                            raise RuntimeError("the QMF transposer refused the SBR band tables of stream %d" % (r // n_ch))
-                        hbe_tail[r] = one[tail_off:]
-                    hb[:, tail_off:] = torch.from_numpy(hbe_tail[rows_h]).to(dev)
+                    tails = np.ascontiguousarray(hbe_tail[rows_h])            # (one call for all of them: every stream's first
+                    heads = np.ascontiguousarray(hdr_h.numpy()[rows_h])       #  frame is a reset frame)
+                    bad = lib.xaac_hbe_state_reinit_tails(tails.ctypes.data, heads.ctypes.data, len(rows_h))
+                    if bad >= 0:
+                        raise RuntimeError("the QMF transposer refused the SBR band tables of stream %d" % (rows_h[bad] // n_ch))
+                    hbe_tail[rows_h] = tails
+                    hb[:, tail_off:] = torch.from_numpy(tails).to(dev)
                     hb32 = hb.view(torch.float32)
                     hb32[:, 1088:1088 + 1280 + 640] = 0.0          # synth_buf, analy_buf (behind input_buf[1024 + 64])
                     pitch = torch.from_numpy(np.repeat(cur.reset_pitch[touched], n_ch).astype(np.int32)).to(dev)

@@ -527,6 +527,17 @@ int32_t xaac_hbe_state_reinit(xaac_hbe_state *s, const xaac_sbr_header *h) {
   return s->k_start < 0 ? -1 : 0;
 }
 
+int32_t xaac_hbe_state_reinit_tails(uint8_t *tails, const xaac_sbr_header *headers, int32_t n) {
+  static thread_local xaac_hbe_state tmp; /* only its tail matters: the buffers the re-initialisation clears are the caller's */
+  uint8_t *tail = reinterpret_cast<uint8_t *>(&tmp) + offsetof(xaac_hbe_state, synth_size);
+  for (int32_t i = 0; i < n; i++) {
+    memcpy(tail, tails + (size_t)i * XAAC_HBE_TAIL_BYTES, XAAC_HBE_TAIL_BYTES);
+    if (xaac_hbe_state_reinit(&tmp, headers + i)) return i;
+    memcpy(tails + (size_t)i * XAAC_HBE_TAIL_BYTES, tail, XAAC_HBE_TAIL_BYTES);
+  }
+  return -1;
+}
+
 void xaac_sbr_state_apply_side(xaac_sbr_state *s, const xaac_sbr_side *side, int32_t channel) {
   if (side->reset && channel < side->reset_channels) {
     s->ph_index = 0;

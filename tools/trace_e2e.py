@@ -18,7 +18,7 @@ def main():
         best = None
         for _ in range(3):
             t = {}
-            decoder.decode_streams([data] * copies, keep_pcm=False, timing=t, threads=threads)
+            decoder.decode_streams([data] * copies, keep_pcm=False, timing=t, threads=threads, esbr=bool(int(os.environ.get("XAAC_TRACE_ESBR", "0"))))
             if best is None or t["steps_s"] < best["steps_s"]:
                 best = t
         best = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in best.items()}
