@@ -14,16 +14,27 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def parser_only(decoder, data, n, threads):
+def parser_only(decoder, data, n, threads, frames_per_call=4):
+    """the host parser alone, the way decode_streams drives it: xaac_parse_batch_start / _wait with frames_per_call frames of
+    every stream per call (plain host arrays; nothing is copied anywhere)"""
     bp = decoder.BatchParser([data] * n, threads=threads)
     from libxaac_amd import PS_FRAME_BYTES, SBR_FRAME_BYTES, SBR_HEADER_BYTES
-    nc = n * bp.n_ch
-    spec, ics = np.zeros((nc, 1024), np.int32), np.zeros((nc, 2), np.uint8)
-    hdr, frm = np.zeros((nc, SBR_HEADER_BYTES), np.uint8), np.zeros((nc, SBR_FRAME_BYTES), np.uint8)
-    psf, flags = np.zeros((n, PS_FRAME_BYTES), np.uint8), np.zeros((n, 8), np.int32)
+    nc, T = n * bp.n_ch, int(frames_per_call)
+    spec, ics = np.zeros((T, nc, 1024), np.int32), np.zeros((T, nc, 2), np.uint8)
+    hdr, frm = np.zeros((T, nc, SBR_HEADER_BYTES), np.uint8), np.zeros((T, nc, SBR_FRAME_BYTES), np.uint8)
+    psf, flags = np.zeros((T, n, PS_FRAME_BYTES), np.uint8), np.zeros((T, n, 8), np.int32)
+    status, pitch = np.zeros((T, n), np.int32), np.zeros((T, n), np.int32)
+    sbr = bp.sbr
     t0 = time.perf_counter()
-    while bp.step(spec, ics, hdr, frm, psf, flags).any():
-        pass
+    while True:
+        bp.start_step(spec, ics, hdr if sbr else None, frm if sbr else None, psf if sbr and bp.n_ch == 1 else None,
+                      flags if sbr else None, status=status, reset_pitch=pitch, frames=T)
+        bp.wait_step(check=False)
+        live = False
+        for t in range(T):
+            live = bool(bp.finish_step(None, status[t]).any()) or live
+        if not live:
+            break
     dt = time.perf_counter() - t0
     frames = int(bp.frames.sum())
     bp.close()
