@@ -92,6 +92,7 @@ struct XeWork {
   /* copies of state members the envelope loop reads band by band (from global memory each read was a memory latency) */
   int32_t lim_tab[13];
   int8_t harm_prev[64];
+  int8_t own_tone[64]; /* per envelope: band c carries a sinusoid that counts in this envelope */
 };
 
 struct XeTrue { static constexpr bool value = true; };
@@ -665,18 +666,17 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
   }
   XS_PAR(k, 0, 64) w->harm_prev[k] = st->harm_flag_prev[k];
   XS_PAR(c, 0, 13) w->lim_tab[c] = st->lim_table[lim_band][c]; /* (as the reset above may just have made it) */
-  XS_ONE {
-    w->err = 0;
-    for (int i = 0; i < 64; i++) w->harmonics[i] = 0;
-    for (int i = 0; i < h->num_sf_bands[1]; i++) {
-      const int li = h->freq_band_tbl_hi[i], ui = h->freq_band_tbl_hi[i + 1];
-      const int tmp = ((ui + li) - (sb_start << 1)) >> 1;
-      if (tmp >= 64 || tmp < 0) {
-        w->err = -1;
-        break;
-      }
-      w->harmonics[tmp] = (int8_t)f->add_harmonics[i];
-    }
+  /* the sinusoids' bands (esbr_envcal.c:640-655): a scale-factor band's flag goes to its centre band; the centres of a strictly
+     increasing table are distinct, so the bands scatter their flags side by side (on lane 0 this loop was fifty LDS round
+     trips one behind the other; a centre outside 0..63 fails the frame either way) */
+  XS_PAR(i, 0, 64) w->harmonics[i] = 0;
+  XS_ONE w->err = 0;
+  cx.sync();
+  XS_PAR(i, 0, h->num_sf_bands[1]) {
+    const int li = h->freq_band_tbl_hi[i], ui = h->freq_band_tbl_hi[i + 1];
+    const int tmp = ((ui + li) - (sb_start << 1)) >> 1;
+    if (tmp >= 64 || tmp < 0) w->err = -1;
+    else w->harmonics[tmp] = (int8_t)f->add_harmonics[i];
   }
   cx.sync();
   if (w->err) return -1;
@@ -695,16 +695,15 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
        once, stepping its noise-band counter whenever a band reaches the next noise border; with the strictly increasing
        tables xe_side_info_bad insists on, that counter is the number of inner noise borders at or below the band, so
        every lane finds its own band's entries. */
+    XS_PAR(cc, 0, 64) w->own_tone[cc] = (int8_t)(w->harmonics[cc] && (i >= trans_env || w->harm_prev[(cc + sb_start) & 63]));
+    cx.sync();
     XS_PAR(c, 0, num_sb) {
       const int kabs = sb_start + c;
-      int j = 0;
-      while (j < nsf - 1 && kabs >= ftab[j + 1]) j++;
+      int j = 0; /* (a count over the increasing table instead of a search: the loads do not wait for one another) */
+      for (int q = 1; q < nsf; q++) j += kabs >= ftab[q];
       const int li = ftab[j], ui = ftab[j + 1];
       int flag = 0, o = 0;
-      for (int k = li; k < ui; k++) {
-        const int cc = k - sb_start;
-        if (w->harmonics[cc & 63] && (i >= trans_env || w->harm_prev[k & 63])) flag = 1;
-      }
+      for (int k = li; k < ui; k++) flag |= w->own_tone[(k - sb_start) & 63];
       for (int q = 1; q < num_nf; q++) o += kabs >= h->freq_band_tbl_noise[q];
       w->sfb_first[c] = (int8_t)(li - sb_start);
       w->sfb_len[c] = (int8_t)(ui - li);
