@@ -35,12 +35,16 @@ struct XfWork {
     float hin[2][3][44];                                            /* before the band powers: the hybrid filters' work buffer
                                                                        (re | im) of QMF bands 0..2: 12 slots of history, then
                                                                        rows 6..37 of the left matrix */
+    float hv[XAAC_PS_MAX_ENV][8][20];                               /* behind the transient detector: h11_re_vec ... h22_im_vec
+                                                                       of every envelope */
   };
   float tr[32][20];                                                 /* trans_ratio_arr */
-  float hv[8][20];                                                  /* h11_re_vec ... h22_im_vec of the envelope */
 };
 
 #define XF_NEG 0x1000 /* NEGATE_IPD_MASK */
+#ifndef XF_WALK_CH
+#define XF_WALK_CH 4 /* rows in flight in the decorrelation + rotation walk (four arrays of them beside the chains' state) */
+#endif
 
 /* one all-pass chain step (ps_dec_flt.c:693-716): in = the delayed, phase-rotated sample; returns the chain's output */
 FX_HD void xf_allpass(float &r_r0, float &i_r0, float *ser_re, float *ser_im /* [3] current ring cells */,
@@ -251,10 +255,41 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
       }
   }
   XE_T(4);
+  /* the envelopes' target matrices (:841-1004), all of them before the walks below: bin -> h11, h12, h21, h22 (re | im) */
+  const int ipd_bins = xaac_eps_ipd_bins_tbl[pf->freq_res_ipd < 0 ? 0 : (pf->freq_res_ipd > 2 ? 2 : pf->freq_res_ipd)];
+  const int steps = pf->iid_quant ? 15 : 7;
+  if (num_env > XAAC_PS_MAX_ENV) return; /* (the kernel and the oracle's entry check the frame before they call) */
+  XS_PAR(e, 0, 20 * num_env) {
+    const int env = e / 20, bin = e % 20;
+    int iid = pf->iid_par_table[env][bin], icc = pf->icc_par_table[env][bin];
+    iid = iid < -steps ? -steps : (iid > steps ? steps : iid);
+    icc = icc < 0 ? 0 : (icc > 7 ? 7 : icc);
+    const float *m = &xaac_eps_mix[(((pf->iid_quant ? 1 : 0) * 61 + iid + 30) * 8 + icc) * 4];
+    float hr[4] = {m[0], m[1], m[2], m[3]}, hi[4];
+    if (bin >= ipd_bins) {
+      hi[0] = hi[1] = hi[2] = hi[3] = 0.0f;
+    } else { /* the phase step with every IPD / OPD index zero: cos 1, sin 0 (:970-1004) */
+      for (int j = 0; j < 4; j++) {
+        hi[j] = hr[j] * 0.0f;
+        hr[j] *= 1.0f;
+      }
+    }
+    for (int j = 0; j < 4; j++) {
+      w->hv[env][j][bin] = hr[j];
+      w->hv[env][4 + j][bin] = hi[j];
+    }
+  }
+  cx.sync();
+  /* QMF bands 3..63: decorrelation (all-pass chain or plain delay, :667-827) and the rotation by the interpolated matrix
+     (:1006-1224) in one walk over the slots -- the decorrelated sample goes from the chain into the rotation in a register.  (As
+     two passes the right channel's rows were written, read back and written again, and the left channel's read twice: 48 KB
+     per stream-frame through memory for nothing.)  An envelope's matrix starts from the previous envelope's target (the
+     state's, for the first) and steps by a constant per slot. */
   XS_PAR(sb, 3, 64) {
     int gr = 10;
     while (gr < 21 && sb >= gb[gr + 1]) gr++;
     const int bin = gmap[gr] & ~XF_NEG;
+    const bool neg = (gmap[gr] & XF_NEG) != 0;
     float decay = sb <= 3 ? 1.0f : 1.0f + 3.0f * 0.05f - 0.05f * (float)sb;
     decay = decay > 0.0f ? decay : 0.0f;
     const bool plain = sb >= 23;
@@ -283,47 +318,78 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
           sre[m][j] = ps->ser_qmf_re[m][idx][sb];
           sim[m][j] = ps->ser_qmf_im[m][idx][sb];
         }
-    XE_NOUNROLL
-    for (int kc = k0; kc < k1; kc += XE_CH) { /* eight input rows in, eight output rows out per burst */
-      float cr[XE_CH] = {0}, ci[XE_CH] = {0};
-      xe_rows_load(L, sb, kc, k1, cr, ci);
-      XE_UNROLL
-      for (int jj = 0; jj < XE_CH; jj++)
-        if (kc + jj < k1) {
-          const int k = kc + jj;
-          const float in_re = cr[jj], in_im = ci[jj];
-          const float real0 = dre[0], imag0 = dim[0];
-          XE_UNROLL
-          for (int j = 0; j < 13; j++) {
-            dre[j] = dre[j + 1];
-            dim[j] = dim[j + 1];
+    float Hprev[8];
+    for (int j = 0; j < 8; j++) Hprev[j] = ps->h_prev[j][bin];
+    for (int env = 0; env < num_env; env++) {
+      const int e0 = pf->border_position[env], e1 = pf->border_position[env + 1], len = e1 - e0;
+      float H[8], d[8];
+      for (int j = 0; j < 8; j++) {
+        const float prev = Hprev[j], cur = w->hv[env][j][bin];
+        const float Hp = (j >= 4 && neg) ? -prev : prev, hc = (j >= 4 && neg) ? -cur : cur;
+        H[j] = Hp;
+        d[j] = (hc - Hp) / (float)len;
+        Hprev[j] = cur;
+      }
+      XE_NOUNROLL
+      for (int kc = e0; kc < e1; kc += XF_WALK_CH) { /* XF_WALK_CH rows of the left channel in, as many of both channels out per burst */
+        float lr[XF_WALK_CH] = {0}, li[XF_WALK_CH] = {0}, rr[XF_WALK_CH] = {0}, ri[XF_WALK_CH] = {0};
+        XE_UNROLL
+        for (int jj = 0; jj < XF_WALK_CH; jj++)
+          if (kc + jj < e1) {
+            lr[jj] = L.r(kc + jj, sb);
+            li[jj] = L.i(kc + jj, sb);
           }
-          if (dl == 14) { dre[13] = in_re; dim[13] = in_im; }
-          else if (dl == 2) { dre[1] = in_re; dim[1] = in_im; }
-          else { dre[0] = in_re; dim[0] = in_im; }
-          float r_r0, i_r0;
-          if (plain) {
-            r_r0 = real0;
-            i_r0 = imag0;
-          } else {
-            r_r0 = real0 * pr - imag0 * pi;
-            i_r0 = real0 * pi + imag0 * pr;
-            float sr[3] = {sre[0][0], sre[1][0], sre[2][0]}, si[3] = {sim[0][0], sim[1][0], sim[2][0]};
-            xf_allpass(r_r0, i_r0, sr, si, pfr, pfi, decay, link);
-            for (int m = 0; m < 3; m++) {
-              for (int j = 0; j < 2 + m; j++) {
-                sre[m][j] = sre[m][j + 1];
-                sim[m][j] = sim[m][j + 1];
-              }
-              sre[m][2 + m] = sr[m];
-              sim[m][2 + m] = si[m];
+        XE_UNROLL
+        for (int jj = 0; jj < XF_WALK_CH; jj++)
+          if (kc + jj < e1) {
+            const int k = kc + jj;
+            const float in_re = lr[jj], in_im = li[jj];
+            const float real0 = dre[0], imag0 = dim[0];
+            XE_UNROLL
+            for (int j = 0; j < 13; j++) {
+              dre[j] = dre[j + 1];
+              dim[j] = dim[j + 1];
             }
+            if (dl == 14) { dre[13] = in_re; dim[13] = in_im; }
+            else if (dl == 2) { dre[1] = in_re; dim[1] = in_im; }
+            else { dre[0] = in_re; dim[0] = in_im; }
+            float r_r0, i_r0;
+            if (plain) {
+              r_r0 = real0;
+              i_r0 = imag0;
+            } else {
+              r_r0 = real0 * pr - imag0 * pi;
+              i_r0 = real0 * pi + imag0 * pr;
+              float sr[3] = {sre[0][0], sre[1][0], sre[2][0]}, si[3] = {sim[0][0], sim[1][0], sim[2][0]};
+              xf_allpass(r_r0, i_r0, sr, si, pfr, pfi, decay, link);
+              for (int m = 0; m < 3; m++) {
+                for (int j = 0; j < 2 + m; j++) {
+                  sre[m][j] = sre[m][j + 1];
+                  sim[m][j] = sim[m][j + 1];
+                }
+                sre[m][2 + m] = sr[m];
+                sim[m][2 + m] = si[m];
+              }
+            }
+            const float t = w->tr[k][bin];
+            const float rre = t * r_r0, rim = t * i_r0; /* the right channel's sample in front of the rotation */
+            for (int j = 0; j < 8; j++) H[j] += d[j];
+            /* H[0..3] = H11r H12r H21r H22r, H[4..7] = H11i H12i H21i H22i */
+            const float lre = in_re, lim = in_im;
+            lr[jj] = H[0] * lre - H[4] * lim + H[2] * rre - H[6] * rim;
+            li[jj] = H[4] * lre + H[0] * lim + H[6] * rre + H[2] * rim;
+            rr[jj] = H[1] * lre - H[5] * lim + H[3] * rre - H[7] * rim;
+            ri[jj] = H[5] * lre + H[1] * lim + H[7] * rre + H[3] * rim;
           }
-          const float t = w->tr[k][bin];
-          cr[jj] = t * r_r0;
-          ci[jj] = t * i_r0;
-        }
-      xe_rows_store(R, sb, kc, k1, cr, ci);
+        XE_UNROLL
+        for (int jj = 0; jj < XF_WALK_CH; jj++)
+          if (kc + jj < e1) {
+            L.r(kc + jj, sb) = lr[jj];
+            L.i(kc + jj, sb) = li[jj];
+            R.r(kc + jj, sb) = rr[jj];
+            R.i(kc + jj, sb) = ri[jj];
+          }
+      }
     }
     const int cnt = k1 > k0 ? k1 - k0 : 0;
     const int pos_end = (pos + cnt) % dl;
@@ -355,129 +421,47 @@ FX_HD void xf_apply_ps(const XsCx &cx, const xaac_ps_frame *pf, xaac_esbr_ps_sta
     ps->delay_buf_idx = l_delay_end;
     for (int m = 0; m < 3; m++) ps->delay_buf_idx_ser[m] = ser_end[m];
   }
-  /* rotation (:841-1224): per envelope the target matrix of every bin, then every sub-band steps its matrix slot by slot */
-  const int ipd_bins = xaac_eps_ipd_bins_tbl[pf->freq_res_ipd < 0 ? 0 : (pf->freq_res_ipd > 2 ? 2 : pf->freq_res_ipd)];
-  const int steps = pf->iid_quant ? 15 : 7;
+  /* rotation of the ten hybrid groups, whose samples are in LDS: six lanes per group, a sixth of an envelope's slots each.
+     The matrix of a slot is the sum H_prev + d + d + ... in single precision, so a lane first steps through the slots in front
+     of its own (the same additions in the same order; eight adds per slot against the forty-odd operations of a rotated slot) */
   for (int env = 0; env < num_env; env++) {
-    XS_PAR(bin, 0, 20) {
-      int iid = pf->iid_par_table[env][bin], icc = pf->icc_par_table[env][bin];
-      iid = iid < -steps ? -steps : (iid > steps ? steps : iid);
-      icc = icc < 0 ? 0 : (icc > 7 ? 7 : icc);
-      const float *m = &xaac_eps_mix[(((pf->iid_quant ? 1 : 0) * 61 + iid + 30) * 8 + icc) * 4];
-      float hr[4] = {m[0], m[1], m[2], m[3]}, hi[4];
-      if (bin >= ipd_bins) {
-        hi[0] = hi[1] = hi[2] = hi[3] = 0.0f;
-      } else { /* the phase step with every IPD / OPD index zero: cos 1, sin 0 (:970-1004) */
-        for (int j = 0; j < 4; j++) {
-          hi[j] = hr[j] * 0.0f;
-          hr[j] *= 1.0f;
-        }
-      }
-      for (int j = 0; j < 4; j++) {
-        w->hv[j][bin] = hr[j];
-        w->hv[4 + j][bin] = hi[j];
-      }
-    }
-    cx.sync();
     const int e0 = pf->border_position[env], e1 = pf->border_position[env + 1], len = e1 - e0;
-    /* units: QMF bands 3..63 and the 10 hybrid groups = 71 for 64 lanes.  The first 64 (bands 3..63, hybrid groups 0..2)
-       walk the envelope's slots one lane each; the other seven hybrid groups, whose data is in LDS, are dealt out over 63
-       lanes below -- nine lanes per group, a ninth of the slots each -- instead of a second pass with seven lanes busy */
-    XS_PAR(v, 0, 64) {
-      const int u = v < 61 ? v + 10 : v - 61;
-      int gr, sb;
-      if (u < 10) {
-        gr = u;
-        sb = gb[gr];
-      } else {
-        sb = u - 10 + 3;
-        gr = 10;
-        while (gr < 21 && sb >= gb[gr + 1]) gr++;
-      }
+    const int per = len > 0 ? (len + 5) / 6 : 0;
+    XS_PAR(t, 0, 60) {
+      const int gr = t / 6, c = t % 6, sb = gb[gr];
       const int bin = gmap[gr] & ~XF_NEG;
       const bool neg = (gmap[gr] & XF_NEG) != 0;
-      float H[8], d[8];
-      for (int j = 0; j < 8; j++) {
-        const float prev = ps->h_prev[j][bin], cur = w->hv[j][bin];
-        const float Hp = (j >= 4 && neg) ? -prev : prev, hc = (j >= 4 && neg) ? -cur : cur;
-        H[j] = Hp;
-        d[j] = (hc - Hp) / (float)len;
-      }
-      XE_NOUNROLL
-      for (int ic = e0; ic < e1; ic += XE_CH) {
-        float lr[XE_CH] = {0}, li[XE_CH] = {0}, rr[XE_CH] = {0}, ri[XE_CH] = {0};
-        if (u >= 10) {
-          xe_rows_load(L, sb, ic, e1, lr, li);
-          xe_rows_load(R, sb, ic, e1, rr, ri);
+      const int i0 = e0 + c * per, i1 = i0 + per < e1 ? i0 + per : e1;
+      if (i0 < i1) {
+        float H[8], d[8];
+        for (int j = 0; j < 8; j++) {
+          const float prev = env ? w->hv[env - 1][j][bin] : ps->h_prev[j][bin], cur = w->hv[env][j][bin];
+          const float Hp = (j >= 4 && neg) ? -prev : prev, hc = (j >= 4 && neg) ? -cur : cur;
+          H[j] = Hp;
+          d[j] = (hc - Hp) / (float)len;
         }
-        XE_UNROLL
-        for (int jj = 0; jj < XE_CH; jj++)
-          if (ic + jj < e1) {
-            const int i = ic + jj;
-            for (int j = 0; j < 8; j++) H[j] += d[j];
-            /* H[0..3] = H11r H12r H21r H22r, H[4..7] = H11i H12i H21i H22i */
-            float lre, lim, rre, rim;
-            if (u < 10) {
-              lre = w->hl_re[i][sb]; lim = w->hl_im[i][sb]; rre = w->hr_re[i][sb]; rim = w->hr_im[i][sb];
-            } else {
-              lre = lr[jj]; lim = li[jj]; rre = rr[jj]; rim = ri[jj];
-            }
-            const float o_lre = H[0] * lre - H[4] * lim + H[2] * rre - H[6] * rim;
-            const float o_lim = H[4] * lre + H[0] * lim + H[6] * rre + H[2] * rim;
-            const float o_rre = H[1] * lre - H[5] * lim + H[3] * rre - H[7] * rim;
-            const float o_rim = H[5] * lre + H[1] * lim + H[7] * rre + H[3] * rim;
-            if (u < 10) {
-              w->hl_re[i][sb] = o_lre; w->hl_im[i][sb] = o_lim; w->hr_re[i][sb] = o_rre; w->hr_im[i][sb] = o_rim;
-            } else {
-              lr[jj] = o_lre; li[jj] = o_lim; rr[jj] = o_rre; ri[jj] = o_rim;
-            }
-          }
-        if (u >= 10) {
-          xe_rows_store(L, sb, ic, e1, lr, li);
-          xe_rows_store(R, sb, ic, e1, rr, ri);
+        for (int i = e0; i < i0; i++)
+          for (int j = 0; j < 8; j++) H[j] += d[j];
+        for (int i = i0; i < i1; i++) {
+          for (int j = 0; j < 8; j++) H[j] += d[j];
+          const float lre = w->hl_re[i][sb], lim = w->hl_im[i][sb], rre = w->hr_re[i][sb], rim = w->hr_im[i][sb];
+          const float o_lre = H[0] * lre - H[4] * lim + H[2] * rre - H[6] * rim;
+          const float o_lim = H[4] * lre + H[0] * lim + H[6] * rre + H[2] * rim;
+          const float o_rre = H[1] * lre - H[5] * lim + H[3] * rre - H[7] * rim;
+          const float o_rim = H[5] * lre + H[1] * lim + H[7] * rre + H[3] * rim;
+          w->hl_re[i][sb] = o_lre;
+          w->hl_im[i][sb] = o_lim;
+          w->hr_re[i][sb] = o_rre;
+          w->hr_im[i][sb] = o_rim;
         }
       }
     }
-    {
-      /* hybrid groups 3..9: lane 9 (gr - 3) + c takes slots e0 + c per .. of the envelope.  The matrix of a slot is the sum
-         H_prev + d + d + ... in single precision, so a lane first steps through the slots in front of its own (the same
-         additions in the same order; eight adds per slot against the forty-odd operations of a rotated slot) */
-      const int per = len > 0 ? (len + 8) / 9 : 0;
-      XS_PAR(t, 0, 63) {
-        const int gr = 3 + t / 9, c = t % 9, sb = gb[gr];
-        const int bin = gmap[gr] & ~XF_NEG;
-        const bool neg = (gmap[gr] & XF_NEG) != 0;
-        const int i0 = e0 + c * per, i1 = i0 + per < e1 ? i0 + per : e1;
-        if (i0 < i1) {
-          float H[8], d[8];
-          for (int j = 0; j < 8; j++) {
-            const float prev = ps->h_prev[j][bin], cur = w->hv[j][bin];
-            const float Hp = (j >= 4 && neg) ? -prev : prev, hc = (j >= 4 && neg) ? -cur : cur;
-            H[j] = Hp;
-            d[j] = (hc - Hp) / (float)len;
-          }
-          for (int i = e0; i < i0; i++)
-            for (int j = 0; j < 8; j++) H[j] += d[j];
-          for (int i = i0; i < i1; i++) {
-            for (int j = 0; j < 8; j++) H[j] += d[j];
-            const float lre = w->hl_re[i][sb], lim = w->hl_im[i][sb], rre = w->hr_re[i][sb], rim = w->hr_im[i][sb];
-            const float o_lre = H[0] * lre - H[4] * lim + H[2] * rre - H[6] * rim;
-            const float o_lim = H[4] * lre + H[0] * lim + H[6] * rre + H[2] * rim;
-            const float o_rre = H[1] * lre - H[5] * lim + H[3] * rre - H[7] * rim;
-            const float o_rim = H[5] * lre + H[1] * lim + H[7] * rre + H[3] * rim;
-            w->hl_re[i][sb] = o_lre;
-            w->hl_im[i][sb] = o_lim;
-            w->hr_re[i][sb] = o_rre;
-            w->hr_im[i][sb] = o_rim;
-          }
-        }
-      }
-    }
-    cx.sync();
-    XS_PAR(bin, 0, 20)
-      for (int j = 0; j < 8; j++) ps->h_prev[j][bin] = w->hv[j][bin];
-    cx.sync();
   }
+  cx.sync();
+  if (num_env > 0)
+    XS_PAR(bin, 0, 20)
+      for (int j = 0; j < 8; j++) ps->h_prev[j][bin] = w->hv[num_env - 1][j][bin];
+  cx.sync();
   XE_T(6);
   /* hybrid synthesis (:203-227): QMF bands 0..2 of both channels */
   XS_PAR(n, 0, 32) {
