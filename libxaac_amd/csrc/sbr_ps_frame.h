@@ -331,8 +331,12 @@ FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_f
   /* ---- P4: transient detector (ps_dec.c:547-590): peak decay against smoothed energy, per bin */
   XS_PAR(bin, 0, 20) {
     int32_t pd = ps->peak_decay_diff[bin], pdp = ps->peak_decay_diff_prev[bin], nrg = ps->energy_prev[bin];
+    int32_t pin[32]; /* the bin's 32 powers first: the recursion below then waits for no LDS load */
+    XP_UNROLL
+    for (int l = 0; l < 32; l++) pin[l] = w->binpw[l][bin];
+    XP_UNROLL
     for (int l = 0; l < 32; l++) {
-      int32_t pw = fx_shl(w->binpw[l][bin], 1);
+      int32_t pw = fx_shl(pin[l], 1);
       if (pw < 0) pw = 0;
       pd = fx_mul32x16_shl(pd, 0x620a);
       if (pw > pd) pd = pw;
