@@ -1807,17 +1807,18 @@ FX_HD void xs_adapt_noise_gain_lp(const XsCx &cx, ST *st, XsEnv &v, const int16_
     }
     int16_t fbn = st->filt_buf_noise_m[k];
     int ne = noise_e, fbe = fb_noise_e0, ph = ph0, harm = harm0;
+    /* the gain's shift of a slot, ge - (scale_change - 1) with one of two scale changes, as a (left, right) pair of counts of
+       which one is zero: lane constants, so that the slot loop has no branch on the lane's exponent (xs_shl / xs_sar take
+       their counts modulo 32) */
+    const int sh_a = ge - ((adj_e - input_e) - 1), sh_b = ge - ((final_e - input_e) - 1);
+    const int shl_a = sh_a > 0 ? (sh_a & 31) : 0, shr_a = sh_a > 0 ? 0 : ((-sh_a) & 31);
+    const int shl_b = sh_b > 0 ? (sh_b & 31) : 0, shr_b = sh_b > 0 ? 0 : ((-sh_b) & 31);
     for (int l = s0; l < s1; l++) {
-      int scale_change;
-      if (l < 32) {
-        scale_change = adj_e - input_e;
-      } else {
-        scale_change = final_e - input_e;
-        if (l == 32 && s0 < 32) {
-          const int diff = final_e - ne;
-          ne = final_e;
-          if (k < bands) nl = xs_noise_rescale(nl, diff);
-        }
+      if (l == 32 && s0 < 32) { /* (uniform) */
+        const int diff = final_e - ne;
+        ne = final_e;
+        const int16_t nl2 = xs_noise_rescale(nl, diff);
+        nl = k < bands ? nl2 : nl;
       }
       fbn = xs_noise_rescale(fbn, fbe - ne);
       fbe = ne;
@@ -1826,15 +1827,13 @@ FX_HD void xs_adapt_noise_gain_lp(const XsCx &cx, ST *st, XsEnv &v, const int16_
       ph = (ph + nsb) & 511;
       harm = (harm + 1) & 3;
       int32_t val = fx_mul32x16(x(l, sb_start + k), gm);
-      const int shift = ge - (scale_change - 1);
-      val = shift > 0 ? xs_shl(val, shift) : xs_sar(val, -shift);
+      val = (int32_t)((uint32_t)val << (l < 32 ? shl_a : shl_b)) >> (l < 32 ? shr_a : shr_b);
+      const int32_t noisy = xs_mac16x16_shl_sat(val, rp, nl); /* (every lane: a select below, not a branch per lane) */
       if (!(hi & 1)) {
-        if (with_noise)
-          val = xs_mac16x16_shl_sat(val, rp, nl);
-        else
-          val = hi == 0 ? fx_add_sat(val, sine32) : fx_sub_sat(val, sine32);
+        const int32_t toned = hi == 0 ? fx_add_sat(val, sine32) : fx_sub_sat(val, sine32);
+        val = with_noise ? noisy : toned;
       } else {
-        if (with_noise) val = xs_mac16x16_shl_sat(val, rp, nl);
+        val = with_noise ? noisy : val;
         val = fx_add_sat(val, hi == 1 ? term1 : -term1);
         if (edge_col >= 0) {
           int32_t t = edge1;
