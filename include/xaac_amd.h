@@ -416,6 +416,9 @@ int32_t xaac_destroy(xaac_ctx *ctx);
 int32_t xaac_set_stream(xaac_ctx *ctx, void *hip_stream);
 /* Block until everything queued on the context's stream has finished. */
 int32_t xaac_sync(xaac_ctx *ctx);
+/* Loads every kernel's code object onto the context's device now (the HIP runtime otherwise does that at a module's first launch:
+   some 20 ms inside the first batch a process decodes).  Optional; no reference counterpart. */
+int32_t xaac_warm_up(xaac_ctx *ctx);
 
 /* Enqueue one IMDCT + overlap-add pass over the batch (asynchronous). */
 int32_t xaac_imdct_process_batch(xaac_ctx *ctx, const xaac_imdct_batch *batch);

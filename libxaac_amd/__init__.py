@@ -261,6 +261,8 @@ def load_library():
     lib.xaac_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_void_p]
     lib.xaac_destroy.argtypes = [ctypes.c_void_p]
     lib.xaac_sync.argtypes = [ctypes.c_void_p]
+    lib.xaac_warm_up.argtypes = [ctypes.c_void_p]
+    lib.xaac_warm_up.restype = ctypes.c_int32
     lib.xaac_set_stream.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.xaac_imdct_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_ImdctBatch)]
     lib.xaac_imdct_process_batch_host.argtypes = [ctypes.c_void_p, ctypes.POINTER(_ImdctBatch)]
@@ -393,6 +395,12 @@ class XaacContext:
         rc = self._lib.xaac_sync(self._h)
         if rc != 0:
             raise XaacError(rc, "xaac_sync")
+
+    def warm_up(self):
+        """every kernel's code object onto the device now (otherwise: at each module's first launch)"""
+        rc = self._lib.xaac_warm_up(self._h)
+        if rc != 0:
+            raise XaacError(rc, "xaac_warm_up")
 
     def last_launch(self):
         g, b, l = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()

@@ -250,3 +250,9 @@ extern "C" hipError_t xaac_launch_esbr_core(const XaacEsbrCoreParams *p, hipStre
   else hipLaunchKernelGGL(xaac_esbr_core_kernel<false>, dim3(p->n_ch), dim3(64), 0, stream, *p);
   return hipGetLastError();
 }
+
+/* xaac_warm_up (xaac_abi.cpp): asking for a kernel's attributes puts this translation unit's code object on the device */
+extern "C" hipError_t xaac_warm_esbr_core(void) {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&xaac_esbr_core_kernel<false>));
+}

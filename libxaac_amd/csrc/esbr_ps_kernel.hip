@@ -73,3 +73,9 @@ extern "C" hipError_t xaac_launch_esbr_ps(const XaacEsbrPsParams *p, hipStream_t
   hipLaunchKernelGGL(xaac_esbr_ps_kernel, dim3(p->n), dim3(64), 0, stream, *p);
   return hipGetLastError();
 }
+
+/* xaac_warm_up (xaac_abi.cpp): asking for a kernel's attributes puts this translation unit's code object on the device */
+extern "C" hipError_t xaac_warm_esbr_ps(void) {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&xaac_esbr_ps_kernel));
+}

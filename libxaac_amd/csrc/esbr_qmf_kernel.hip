@@ -311,3 +311,9 @@ extern "C" hipError_t xaac_launch_esbr_synthesis(const XaacEsbrSynParams *p, hip
   hipLaunchKernelGGL(xaac_esbr_synthesis_kernel, dim3((p->n_ch + 1) / 2), dim3(128), XAAC_ESBR_SYN_LDS, stream, *p);
   return hipGetLastError();
 }
+
+/* xaac_warm_up (xaac_abi.cpp): asking for a kernel's attributes puts this translation unit's code object on the device */
+extern "C" hipError_t xaac_warm_esbr_qmf(void) {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&xaac_esbr_synthesis_kernel));
+}

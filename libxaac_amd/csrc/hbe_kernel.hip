@@ -387,3 +387,9 @@ extern "C" hipError_t xaac_launch_hbe_post(const XaacHbePostParams *p, hipStream
   hipLaunchKernelGGL(xaac_hbe_post_kernel, dim3(p->n_ch), dim3(XAAC_HBE_POST_THREADS), XAAC_HBE_POST_LDS, stream, *p);
   return hipGetLastError();
 }
+
+/* xaac_warm_up (xaac_abi.cpp): asking for a kernel's attributes puts this translation unit's code object on the device */
+extern "C" hipError_t xaac_warm_hbe(void) {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&xaac_hbe_post_kernel));
+}

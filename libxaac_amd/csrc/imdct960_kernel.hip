@@ -64,3 +64,9 @@ extern "C" hipError_t xaac_launch_imdct960(const xaac_imdct_batch *p, hipStream_
   hipLaunchKernelGGL(xaac_imdct960_kernel, dim3(wgs), dim3(64 * XAAC_I960_WAVES_PER_WG), XAAC_I960_LDS, stream, *p);
   return hipGetLastError();
 }
+
+/* xaac_warm_up (xaac_abi.cpp): asking for a kernel's attributes puts this translation unit's code object on the device */
+extern "C" hipError_t xaac_warm_imdct960(void) {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&xaac_imdct960_kernel));
+}

@@ -780,3 +780,9 @@ extern "C" int xaac_imdct_blocks_per_cu(void) {
     n = 2;
   return n;
 }
+
+/* xaac_warm_up (xaac_abi.cpp): asking for a kernel's attributes puts this translation unit's code object on the device */
+extern "C" hipError_t xaac_warm_imdct(void) {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(pick_kernel(1, XAAC_PCM_SBR)));
+}

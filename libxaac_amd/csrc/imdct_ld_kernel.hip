@@ -74,3 +74,9 @@ extern "C" hipError_t xaac_launch_imdct_ld(const xaac_imdct_ld_batch *p, hipStre
   }
   return hipGetLastError();
 }
+
+/* xaac_warm_up (xaac_abi.cpp): asking for a kernel's attributes puts this translation unit's code object on the device */
+extern "C" hipError_t xaac_warm_imdct_ld(void) {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&xaac_imdct_ld_kernel<512, false>));
+}

@@ -541,3 +541,9 @@ extern "C" hipError_t xaac_launch_limiter(const XaacLimiterParams *p, hipStream_
     hipLaunchKernelGGL(xaac_limiter_apply_kernel<0>, grid, block, 0, stream, *p);
   return hipGetLastError();
 }
+
+/* xaac_warm_up (xaac_abi.cpp): asking for a kernel's attributes puts this translation unit's code object on the device */
+extern "C" hipError_t xaac_warm_limiter(void) {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&xaac_limiter_gain_kernel));
+}

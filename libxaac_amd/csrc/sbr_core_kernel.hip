@@ -396,3 +396,9 @@ extern "C" hipError_t xaac_launch_sbr_core_hq(const XaacSbrCoreParams *p, hipStr
   hipLaunchKernelGGL((xaac_sbr_core_list_kernel<1>), dim3(grid), dim3(64), 0, stream, *p);
   return hipGetLastError();
 }
+
+/* xaac_warm_up (xaac_abi.cpp): asking for a kernel's attributes puts this translation unit's code object on the device */
+extern "C" hipError_t xaac_warm_sbr_core(void) {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&xaac_sbr_core_kernel<1, XAAC_SBR_NARROW_BANDS, XAAC_SBR_CORE_HQ_WAVES>));
+}

@@ -258,3 +258,9 @@ extern "C" hipError_t xaac_launch_ps(const XaacPsParams *p, hipStream_t stream) 
   hipLaunchKernelGGL(xaac_ps_kernel, dim3(grid), dim3(64 * kPsWaves), 0, stream, *p);
   return hipGetLastError();
 }
+
+/* xaac_warm_up (xaac_abi.cpp): asking for a kernel's attributes puts this translation unit's code object on the device */
+extern "C" hipError_t xaac_warm_sbr_ps(void) {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&xaac_ps_kernel));
+}

@@ -957,3 +957,9 @@ extern "C" int xaac_qmf_blocks_per_cu(int which) {
   if (e != hipSuccess || n < 1) n = 1;
   return n;
 }
+
+/* xaac_warm_up (xaac_abi.cpp): asking for a kernel's attributes puts this translation unit's code object on the device */
+extern "C" hipError_t xaac_warm_sbr_qmf(void) {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&xaac_qmf_synthesis_pair_kernel));
+}

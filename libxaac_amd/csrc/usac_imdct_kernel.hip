@@ -250,3 +250,9 @@ extern "C" hipError_t xaac_launch_usac_imdct(const XaacUsacImdctParams *p, hipSt
   hipLaunchKernelGGL(xaac_usac_imdct_kernel, dim3(wgs), dim3(64 * XAAC_USAC_WAVES_PER_WG), XAAC_USAC_LDS, stream, *p);
   return hipGetLastError();
 }
+
+/* xaac_warm_up (xaac_abi.cpp): asking for a kernel's attributes puts this translation unit's code object on the device */
+extern "C" hipError_t xaac_warm_usac_imdct(void) {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&xaac_usac_imdct_kernel));
+}

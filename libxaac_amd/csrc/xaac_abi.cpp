@@ -124,6 +124,23 @@ int32_t xaac_set_stream(xaac_ctx *c, void *hip_stream) {
   return XAAC_OK;
 }
 
+extern "C" {
+hipError_t xaac_warm_imdct(void), xaac_warm_sbr_qmf(void), xaac_warm_sbr_core(void), xaac_warm_sbr_ps(void), xaac_warm_limiter(void),
+    xaac_warm_esbr_qmf(void), xaac_warm_esbr_core(void), xaac_warm_esbr_ps(void), xaac_warm_hbe(void), xaac_warm_usac_imdct(void),
+    xaac_warm_imdct960(void), xaac_warm_imdct_ld(void), xaac_warm_pvc(void);
+}
+
+int32_t xaac_warm_up(xaac_ctx *c) {
+  if (!c) return XAAC_FATAL_NULL_ARG;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  hipError_t (*const hooks[])(void) = {xaac_warm_imdct,     xaac_warm_sbr_qmf,   xaac_warm_sbr_core, xaac_warm_sbr_ps,     xaac_warm_limiter,
+                                       xaac_warm_esbr_qmf,  xaac_warm_esbr_core, xaac_warm_esbr_ps,  xaac_warm_hbe,        xaac_warm_usac_imdct,
+                                       xaac_warm_imdct960,  xaac_warm_imdct_ld,  xaac_warm_pvc};
+  for (auto h : hooks)
+    if (!hip_ok(h())) return XAAC_FATAL_HIP;
+  return XAAC_OK;
+}
+
 int32_t xaac_sync(xaac_ctx *c) {
   if (!c) return XAAC_FATAL_NULL_ARG;
   return hip_ok(hipStreamSynchronize(c->stream)) ? XAAC_OK : XAAC_FATAL_HIP;

@@ -227,6 +227,7 @@ int main(int argc, char **argv) {
   HIP(hipSetDevice(0));
   HIP(hipStreamCreate(&stream));
   XA(xaac_create(&ctx, 0, stream));
+  XA(xaac_warm_up(ctx)); /* the kernels' code objects are on the device before the first batch (and the run's clock) */
   std::vector<xaac_parser *> parser((size_t)N);
   for (auto &p : parser) {
     XA(xaac_parser_create(&p));
