@@ -372,7 +372,11 @@ __global__ __launch_bounds__(64) void xaac_sbr_core_list_kernel(XaacSbrCoreParam
 extern "C" hipError_t xaac_launch_sbr_core_lp(const XaacSbrCoreParams *p, hipStream_t stream) {
   XaacSbrCoreParams q = *p;
   q.work_counter = nullptr;
-  hipLaunchKernelGGL((xaac_sbr_core_kernel<0, 64, 1>), dim3(p->n_ch), dim3(64), 0, stream, q);
+#ifndef XS_LP_WAVES
+#define XS_LP_WAVES 2 /* measured: 1: 457 us, 2: 410 (30 KB of LDS per workgroup: ten waves per CU instead of nine), 3: 454 */
+#endif
+  constexpr int W = XS_LP_WAVES; /* waves (channel-frames) per workgroup: they share one staging of the tables */
+  hipLaunchKernelGGL((xaac_sbr_core_kernel<0, 64, W>), dim3((p->n_ch + W - 1) / W), dim3(64 * W), 0, stream, q);
   return hipGetLastError();
 }
 
