@@ -372,18 +372,22 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     XQ_TIME(0);
     /* ---- slot rows in, coalesced --------------------------------------------------------------- */
-    /* eight rows' loads are issued before the first is consumed: one HBM/L2 latency per group, not per row */
-    for (int r0 = 0; r0 < 64; r0 += 8) {
-      int32_t tmp[8][ROW / 64];
+    /* a group of rows' loads is issued before the first is consumed: one HBM/L2 latency per group, not per row */
+#ifndef XQ_SYN_GROUP_LP
+#define XQ_SYN_GROUP_LP 16 /* measured on the LP chain: 8: 141 us, 16: 129, 32: 129, 64: 132 */
+#endif
+    constexpr int G = LP ? XQ_SYN_GROUP_LP : 8;
+    for (int r0 = 0; r0 < 64; r0 += G) {
+      int32_t tmp[G][ROW / 64];
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
+      for (int j = 0; j < G; j++) {
         const int r = r0 + j, ch = 2 * pair + (r >> 5);
         const int32_t *row = p.qmf + (size_t)(ch < p.n_ch ? ch : 0) * p.qmf_ch_stride + (size_t)(r & 31) * p.slot_stride;
 #pragma unroll
         for (int q = 0; q < ROW / 64; q++) tmp[j][q] = row[lane + 64 * q];
       }
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
+      for (int j = 0; j < G; j++) {
         const int r = r0 + j, ch = 2 * pair + (r >> 5);
 #pragma unroll
         for (int q = 0; q < ROW / 64; q++) rows[RS * r + lane + 64 * q] = ch < p.n_ch ? tmp[j][q] : 0;
