@@ -83,33 +83,42 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_analysis_kernel(XaacQ
   const int waves_total = gridDim.x * XAAC_QMF_WAVES;
   for (int pair = blockIdx.x * XAAC_QMF_WAVES + wave; pair < n_pairs; pair += waves_total) {
     /* ---- history + new samples, time ordered ------------------------------------------ */
-    for (int c = 0; c < 2; c++) {
-      const int ch = 2 * pair + c;
-      int16_t *h = hist + c * kHist;
-      if (ch < p.n_ch) {
-        const xaac_qmf_ana_state *st = reinterpret_cast<const xaac_qmf_ana_state *>(
-            reinterpret_cast<const char *>(p.state) + (size_t)ch * p.state_stride);
-        const int wr = st->wr;
-        const int cf = p.ch_fac;
-        const int16_t *src = p.pcm + (size_t)(ch / cf) * 1024 * cf + (ch % cf);
-        /* all loads of the channel (5 ring + 16 PCM per lane) in flight before the first LDS store */
-        int16_t hr[5], hp[16];
+    {
+      /* all loads of both channels (5 ring + 16 PCM per lane and channel) in flight before the first LDS store */
+      int16_t hr[2][5], hp[2][16];
 #pragma unroll
-        for (int j = 0; j < 5; j++) {
-          const int a = lane + 64 * j;
-          hr[j] = a < 288 ? st->ring[ana_ring_pos(wr, a)] : (int16_t)0;
+      for (int c = 0; c < 2; c++) {
+        const int ch = 2 * pair + c;
+        if (ch < p.n_ch) { /* (uniform) */
+          const xaac_qmf_ana_state *st = reinterpret_cast<const xaac_qmf_ana_state *>(
+              reinterpret_cast<const char *>(p.state) + (size_t)ch * p.state_stride);
+          const int wr = st->wr;
+          const int cf = p.ch_fac;
+          const int16_t *src = p.pcm + (size_t)(ch / cf) * 1024 * cf + (ch % cf);
+#pragma unroll
+          for (int j = 0; j < 5; j++) {
+            const int a = lane + 64 * j;
+            hr[c][j] = a < 288 ? st->ring[ana_ring_pos(wr, a)] : (int16_t)0;
+          }
+#pragma unroll
+          for (int j = 0; j < 16; j++) hp[c][j] = src[(size_t)(lane + 64 * j) * cf];
         }
+      }
 #pragma unroll
-        for (int j = 0; j < 16; j++) hp[j] = src[(size_t)(lane + 64 * j) * cf];
+      for (int c = 0; c < 2; c++) {
+        const int ch = 2 * pair + c;
+        int16_t *h = hist + c * kHist;
+        if (ch < p.n_ch) {
 #pragma unroll
-        for (int j = 0; j < 5; j++) {
-          const int a = lane + 64 * j;
-          if (a < 288) h[287 - a] = hr[j];
+          for (int j = 0; j < 5; j++) {
+            const int a = lane + 64 * j;
+            if (a < 288) h[287 - a] = hr[c][j];
+          }
+#pragma unroll
+          for (int j = 0; j < 16; j++) h[288 + lane + 64 * j] = hp[c][j];
+        } else {
+          for (int i = lane; i < kHist; i += 64) h[i] = 0;
         }
-#pragma unroll
-        for (int j = 0; j < 16; j++) h[288 + lane + 64 * j] = hp[j];
-      } else {
-        for (int i = lane; i < kHist; i += 64) h[i] = 0;
       }
     }
     /* ---- window-add: lanes = polyphase branch m, loop over the 2 x 32 slots ------------- */
