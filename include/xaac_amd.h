@@ -385,7 +385,11 @@ typedef struct xaac_usac_fac {
 
 typedef struct xaac_usac_imdct_batch {
   int32_t n_ch;
-  int32_t ccfl;              /* usac_data->ccfl: 1024 (also for 0: descriptors made before the member existed) or 768 */
+  int32_t ccfl;              /* usac_data->ccfl: 1024 or 768; 0 = 1024.  (Added in round 3 where LP64 had four bytes of padding in
+                                front of `coef`: the struct's size and the other members' offsets did not change, and a caller
+                                built against the older header reads as ccfl 0 if it zero-initialised the descriptor, as the
+                                samples in INTEGRATION.md do; one that did not has to be recompiled.  Members added since are
+                                appended at the end of their structs.) */
   const int32_t *coef;       /* [n_ch][ccfl] coef_fix (not modified) */
   const xaac_usac_ics *ics;  /* [n_ch] */
   int32_t *overlap;          /* [n_ch][ccfl] in/out: overlap_data_ptr */
