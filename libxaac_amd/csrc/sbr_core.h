@@ -81,6 +81,14 @@ FX_HD int32_t xs_shr_dir_sat_limit(int32_t a, int b) {
 #define XS_TAB_INV(i) xaac_sbr_inv_table[i]
 #define XS_TAB_SQRT(i) xaac_sbr_sqrt_table[i]
 #endif
+/* the four small tables (limiter gains, smoothing filter, 1 / n, chirp targets): the GPU core kernel points these at LDS copies
+   too -- as global tables each lookup was a memory latency in the middle of a serial stretch */
+#ifndef XS_TAB_LIMG
+#define XS_TAB_LIMG(i) xaac_sbr_lim_gains_m[i]
+#define XS_TAB_SMOOTH(i) xaac_sbr_smooth_filter[i]
+#define XS_TAB_INVINT(i) xaac_sbr_inv_int_table[i]
+#define XS_TAB_NEWBW(i) xaac_sbr_new_bw_table[i]
+#endif
 #ifndef XS_TAB_RAND
 #define XS_TAB_RAND(i) xaac_sbr_rand_ph[i] /* the HQ slot loop's complex random phases (the GPU core kernel: an LDS copy) */
 #endif
@@ -228,6 +236,13 @@ struct XsCx {
 #define XS_ONE if (cx.lane == 0)
 #ifndef XS_SLOT_UNROLL
 #define XS_SLOT_UNROLL 4 /* slots whose LDS reads are in flight together in the column walks */
+#endif
+/* XS_KEEP(v): the value is what it is, here (device: an empty asm the optimiser cannot look through -- keeps a batch of loads
+   a batch; host: nothing) */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define XS_KEEP(v) asm volatile("" : "+v"(v))
+#else
+#define XS_KEEP(v)
 #endif
 #define XS_PRAGMA_(x) _Pragma(#x)
 #define XS_PRAGMA(x) XS_PRAGMA_(x)
@@ -535,7 +550,7 @@ FX_HD void xs_covariance_lp(const XsQmf &x, int k, int len, XsCov *c) {
 FX_HD void xs_invfilt_level_emphasis(const XsCx &cx, const int32_t *bw_prev, int n, const int32_t *mode,
                                      const int32_t *mode_prev, int32_t *bw) {
   XS_PAR(i, 0, n) {
-    int32_t b = xaac_sbr_new_bw_table[4 * mode_prev[i] + mode[i]];
+    int32_t b = XS_TAB_NEWBW(4 * mode_prev[i] + mode[i]);
     int16_t w1, w2;
     if (b < bw_prev[i]) {
       w1 = 0x6000;
@@ -789,7 +804,7 @@ FX_HD int32_t xs_energy_of_subband(const Q &x, int s0, int s1, int k, int frame_
 template <class Q>
 FX_HD void xs_energy_per_subband(const XsCx &cx, const Q &x, int s0, int s1, int b0, int b1, int frame_exp,
                                  XsLv &est) {
-  const int16_t inv_width = xaac_sbr_inv_int_table[s1 - s0];
+  const int16_t inv_width = XS_TAB_INVINT(s1 - s0);
   XS_LANES(c, 0, b1 - b0) est.own(c) = xs_energy_of_subband(x, s0, s1, b0 + c, frame_exp << 1, inv_width);
 }
 
@@ -798,7 +813,7 @@ FX_HD void xs_energy_per_subband(const XsCx &cx, const Q &x, int s0, int s1, int
 template <class Q>
 FX_HD void xs_energy_per_sfb(const XsCx &cx, const Q &x, int nsf, const int16_t *tbl, int s0, int s1, int max_sb,
                              int frame_exp, XsWork *w, XsLv &est) {
-  const int16_t inv_width = xaac_sbr_inv_int_table[s1 - s0];
+  const int16_t inv_width = XS_TAB_INVINT(s1 - s0);
   frame_exp <<= 1;
   int j0 = 0;
   while (j0 < nsf && cx.uni(tbl[j0]) < max_sb) j0++;
@@ -828,7 +843,7 @@ FX_HD void xs_energy_per_sfb(const XsCx &cx, const Q &x, int nsf, const int16_t 
       sum_e = 0;
     } else {
       sum_m = xs_mult16_shl_sat(sum_m, inv_width);
-      sum_m = xs_mult16_shl_sat(sum_m, xaac_sbr_inv_int_table[ui - li]);
+      sum_m = xs_mult16_shl_sat(sum_m, XS_TAB_INVINT(ui - li));
       sum_e = ((frame_exp + (Q::HQ ? 10 : 11)) - shift) - (pre << 1);
     }
     for (int k = li; k < ui; k++) {
@@ -1350,6 +1365,98 @@ FX_HD int xs_qsel(int q, const int *v) { return q ? v[1] : v[0]; }
 /* xs_energy_per_subband (env_calc.c:1211, complex matrix) for a pass: element (q, c) = band b0 + c over envelope q's slots
    [s0[q], s1[q]).  Both envelopes walk their slots together; a lane whose envelope is the shorter one re-reads its last
    slot (harmless for the maximum) and adds nothing. */
+/* One (envelope, band) element of a pass, its slots held in registers: N >= n slots of band k from row `first` on, every
+   load in flight before the first use (one LDS latency for the lane's whole column part instead of one per four slots,
+   twice), words past the element's own n slots zeroed (they add nothing to the maximum's OR or to the sum).  Returns the
+   packed (mantissa, exponent) estimate of env_calc.c:1211.  The OR of the magnitudes has the maximum's leading bit, which is
+   all the norm looks at. */
+template <int N, class Q>
+FX_HD int32_t xs_energy_element_pk(const Q &x, int first, int n, int k, int16_t inv_width, int frame_exp2) {
+  int32_t re[N], im[N];
+  XS_UNROLL
+  for (int j = 0; j < N; j++) {
+    const int row = first + (j < n ? j : n - 1);
+    re[j] = x(row, k);
+    im[j] = x.im(row, k);
+  }
+  int32_t mx = 1;
+  XS_UNROLL
+  for (int j = 0; j < N; j++) {
+    XS_KEEP(re[j]); /* (the loads stay unconditional and together: as operands of a select alone each was sunk into a
+                       predicated region of its own, with a full wait inside) */
+    XS_KEEP(im[j]);
+    re[j] = j < n ? re[j] : 0;
+    im[j] = j < n ? im[j] : 0;
+    mx |= fx_abs_nrm(re[j]) | fx_abs_nrm(im[j]);
+  }
+  const int pre = xs_pnorm32(mx) - 4;
+  int shift = 16 - pre;
+  const int e_shr = shift > 0 ? shift & 31 : 0, e_shl = shift > 0 ? 0 : (-shift) & 31;
+  int32_t accu = 0;
+  XS_UNROLL
+  for (int j = 0; j < N; j++) {
+    int16_t t = (int16_t)((int32_t)((uint32_t)re[j] << e_shl) >> e_shr);
+    accu = fx_add(accu, (int32_t)t * t);
+    t = (int16_t)((int32_t)((uint32_t)im[j] << e_shl) >> e_shr);
+    accu = fx_add(accu, (int32_t)t * t);
+  }
+  if (accu == 0) return 0;
+  shift = -xs_pnorm32(accu);
+  int16_t sum_m = (int16_t)xs_shr_dir_sat_limit(accu, 16 + shift);
+  sum_m = xs_mult16_shl_sat(sum_m, inv_width);
+  shift = shift - (pre << 1);
+  return xs_me(sum_m, (int16_t)(frame_exp2 + shift + 1));
+}
+/* the same for any number of slots: two walks over the column part, eight slots' loads in flight at a time */
+template <class Q>
+FX_HD int32_t xs_energy_element_long(const Q &x, int first, int n, int nmax, int k, int16_t inv_width, int frame_exp2) {
+  int32_t mx = 1;
+  for (int j0 = 0; j0 < nmax; j0 += 8) {
+    int32_t re[8], im[8];
+    XS_UNROLL
+    for (int j = 0; j < 8; j++) {
+      const int row = first + (j0 + j < n ? j0 + j : n - 1);
+      re[j] = x(row, k);
+      im[j] = x.im(row, k);
+    }
+    XS_UNROLL
+    for (int j = 0; j < 8; j++) {
+      XS_KEEP(re[j]);
+      XS_KEEP(im[j]);
+      mx |= fx_abs_nrm(re[j]) | fx_abs_nrm(im[j]); /* (a slot read twice changes no maximum) */
+    }
+  }
+  const int pre = xs_pnorm32(mx) - 4;
+  int shift = 16 - pre;
+  const int e_shr = shift > 0 ? shift & 31 : 0, e_shl = shift > 0 ? 0 : (-shift) & 31;
+  int32_t accu = 0;
+  for (int j0 = 0; j0 < nmax; j0 += 8) {
+    int32_t re[8], im[8];
+    XS_UNROLL
+    for (int j = 0; j < 8; j++) {
+      const int row = first + (j0 + j < n ? j0 + j : n - 1);
+      re[j] = x(row, k);
+      im[j] = x.im(row, k);
+    }
+    XS_UNROLL
+    for (int j = 0; j < 8; j++) {
+      XS_KEEP(re[j]);
+      XS_KEEP(im[j]);
+      re[j] = j0 + j < n ? re[j] : 0;
+      im[j] = j0 + j < n ? im[j] : 0;
+      int16_t t = (int16_t)((int32_t)((uint32_t)re[j] << e_shl) >> e_shr);
+      accu = fx_add(accu, (int32_t)t * t);
+      t = (int16_t)((int32_t)((uint32_t)im[j] << e_shl) >> e_shr);
+      accu = fx_add(accu, (int32_t)t * t);
+    }
+  }
+  if (accu == 0) return 0;
+  shift = -xs_pnorm32(accu);
+  int16_t sum_m = (int16_t)xs_shr_dir_sat_limit(accu, 16 + shift);
+  sum_m = xs_mult16_shl_sat(sum_m, inv_width);
+  shift = shift - (pre << 1);
+  return xs_me(sum_m, (int16_t)(frame_exp2 + shift + 1));
+}
 template <class Q>
 FX_HD void xs_energy_per_subband_pk(const XsCx &cx, const Q &x, const XsPass &ps, const int *s0, const int *s1, int b0,
                                     int nb, int frame_exp, XsLv &est) {
@@ -1360,35 +1467,13 @@ FX_HD void xs_energy_per_subband_pk(const XsCx &cx, const Q &x, const XsPass &ps
     int32_t e = 0;
     if (q < ps.n && c < nb) {
       const int first = xs_qsel(q, s0), n = q ? n1 : n0, k = b0 + c;
-      const int16_t inv_width = xaac_sbr_inv_int_table[n];
-      int32_t mx = 1;
-      XS_UNROLL4
-      for (int j = 0; j < nmax; j++) {
-        const int row = first + (j < n ? j : n - 1);
-        int32_t a = fx_abs_nrm(x(row, k));
-        if (a > mx) mx = a;
-        a = fx_abs_nrm(x.im(row, k));
-        if (a > mx) mx = a;
-      }
-      const int pre = xs_pnorm32(mx) - 4;
-      int32_t accu = 0;
-      int shift = 16 - pre;
-      const int e_shr = shift > 0 ? shift & 31 : 0, e_shl = shift > 0 ? 0 : (-shift) & 31;
-      XS_UNROLL4
-      for (int j = 0; j < nmax; j++) {
-        const int row = first + (j < n ? j : n - 1);
-        int16_t t = (int16_t)((int32_t)((uint32_t)x(row, k) << e_shl) >> e_shr);
-        accu = fx_add(accu, j < n ? (int32_t)t * t : 0);
-        t = (int16_t)((int32_t)((uint32_t)x.im(row, k) << e_shl) >> e_shr);
-        accu = fx_add(accu, j < n ? (int32_t)t * t : 0);
-      }
-      if (accu != 0) {
-        shift = -xs_pnorm32(accu);
-        int16_t sum_m = (int16_t)xs_shr_dir_sat_limit(accu, 16 + shift);
-        sum_m = xs_mult16_shl_sat(sum_m, inv_width);
-        shift = shift - (pre << 1);
-        e = xs_me(sum_m, (int16_t)(frame_exp2 + shift + 1));
-      }
+      const int16_t inv_width = XS_TAB_INVINT(n);
+      if (nmax <= 8) /* (uniform) */
+        e = xs_energy_element_pk<8>(x, first, n, k, inv_width, frame_exp2);
+      else if (nmax <= 16)
+        e = xs_energy_element_pk<16>(x, first, n, k, inv_width, frame_exp2);
+      else
+        e = xs_energy_element_long(x, first, n, nmax, k, inv_width, frame_exp2);
     }
     est.own(l) = e;
   }
@@ -1539,6 +1624,7 @@ FX_HD void xs_noiselimiting_pk(const XsCx &cx, const xaac_sbr_header *h, const X
     }
   }
   cx.sync();
+  XS_T(16);
   XS_LANES(r, 0, 32) {
     const int q = r >> 4, c = r & 15;
     if (q < ps.n && c < nlf) {
@@ -1585,6 +1671,7 @@ FX_HD void xs_noiselimiting_pk(const XsCx &cx, const xaac_sbr_header *h, const X
     }
   }
   cx.sync();
+  XS_T(17);
   {
     XsLv a_m, a_e, b_me, emax, with_b;
     a_m.fill(0);
@@ -1632,6 +1719,7 @@ FX_HD void xs_noiselimiting_pk(const XsCx &cx, const xaac_sbr_header *h, const X
     }
   }
   cx.sync();
+  XS_T(18);
   XS_LANES(r, 0, 32) {
     const int q = r >> 4, c = r & 15;
     if (q < ps.n && c < nlf) {
@@ -1666,6 +1754,7 @@ FX_HD void xs_noiselimiting_pk(const XsCx &cx, const xaac_sbr_header *h, const X
     }
   }
   cx.sync();
+  XS_T(19);
   XS_LANES(l, 0, 64) {
     const int c_of = mine.own(l);
     if (c_of < 0) continue;
@@ -1677,6 +1766,7 @@ FX_HD void xs_noiselimiting_pk(const XsCx &cx, const xaac_sbr_header *h, const X
     v.noise.own(l) = xs_me(xs_mult16_shl(xs_m(nl), bg_m), (int16_t)(xs_e(nl) + bg_e));
   }
   cx.sync();
+  XS_T(20);
 }
 
 /* env_calc.c:423 */
@@ -2010,6 +2100,7 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
     }
   }
   cx.sync();
+  XS_T(29);
   /* band values seen from the lane that owns filter-buffer entry i = skip + k */
   XsLv gain_i = v.gain.shifted(cx, -skip), noise_i = v.noise.shifted(cx, -skip), sine_i = v.sine.shifted(cx, -skip);
   /* With at most 32 entries the two halves of the wave share the walk: lane 32 g + i takes half g of every segment's slots
@@ -2060,7 +2151,7 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
       ph = (ph + bands) & 511;
       harm = (harm + 1) & 3;
       if (k < 0) continue;
-      const int16_t smooth = xaac_sbr_smooth_filter[l - s0];
+      const int16_t smooth = XS_TAB_SMOOTH(l - s0);
       int16_t sg = gm, snz = nl;
       if (smooth) {
         const int16_t direct = fx_sat16(0x7fff - (int32_t)smooth);
@@ -2104,6 +2195,7 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
         x.im(l, col) = im;
       }
     }
+    XS_T(30);
     /* 2. the rest in at most two segments, slots below 32 and from 32 on: inside a segment every per-slot quantity
        but the random phase and the harmonic index is a constant of the band, so the slots go in bursts of eight
        (rows and random phases fetched together, no control flow between the slots) */
@@ -2300,8 +2392,19 @@ FX_HD void xs_lpc_coeffs_hq(const XsCovHq *s, int16_t *a) {
 template <class Q>
 FX_HD void xs_patch_band_hq(const xaac_sbr_header *h, const Q &x, int lb, int hb, const int16_t *alpha,
                             const int32_t *bw_array, int start_idx, int stop_idx) {
-  int bi = 0; /* the reference's per-patch running index: first border above hb, capped (lpp_tran.c:1218) */
-  while (bi < XAAC_SBR_MAX_PATCHES - 1 && bi < XAAC_SBR_MAX_NOISE_VALUES && hb >= h->bw_borders[bi]) bi++;
+  /* the reference's per-patch running index: first border above hb, capped (lpp_tran.c:1218).  The walk stops at the first
+     border above hb; all the borders it may look at are fetched together (one LDS latency instead of one per step) */
+  constexpr int kBwCap = XAAC_SBR_MAX_PATCHES - 1 < XAAC_SBR_MAX_NOISE_VALUES ? XAAC_SBR_MAX_PATCHES - 1 : XAAC_SBR_MAX_NOISE_VALUES;
+  int bord[kBwCap];
+  XS_UNROLL
+  for (int i = 0; i < kBwCap; i++) bord[i] = h->bw_borders[i];
+  int bi = 0;
+  bool on = true;
+  XS_UNROLL
+  for (int i = 0; i < kBwCap; i++) {
+    on = on && hb >= bord[i];
+    bi += on ? 1 : 0;
+  }
   int16_t bw = (int16_t)(bw_array[bi] >> 16);
   const int16_t a0r = xs_mult16_shl_sat(bw, alpha[0]), a0i = xs_mult16_shl_sat(bw, alpha[1]);
   bw = xs_mult16_shl_sat(bw, bw);
@@ -2385,6 +2488,7 @@ FX_HD void xs_hf_generator_hq(const XsCx &cx, const xaac_sbr_header *h, ST *st, 
   }
   if (cw < 64)
     for (int i = 0; i < 8; i++) cv[i] = cv[i].fold(cw);
+  XS_T(31);
   XS_LANES(lb, start_patch, stop_patch) {
     XsCovHq c;
     c.phi_11 = cv[0].own(lb);
@@ -2538,9 +2642,12 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
   if constexpr (Q::HQ) if (packed) {
     /* two envelopes per pass of the gain mathematics (see "two envelopes side by side") */
     XsLv jn_hi, jn_lo;
+    XS_T(8);
     xs_band_maps(cx, h, nsb, jn_hi, jn_lo);
+    XS_T(9);
     const int bands = nsb - skip, input_e = 15 - hb_scale, nnf = cx.uni(h->num_nf_bands);
-    const int16_t *lim_tab = &xaac_sbr_lim_gains_m[2 * cx.uni(h->limiter_gains)];
+    const int16_t *lim_tab = &XS_TAB_LIMG(2 * cx.uni(h->limiter_gains));
+    const int smooth_len_on = (1 - cx.uni(h->smoothing_mode)) << 2;
     int nf_off = 0;
     /* the frame's borders, resolutions and noise borders as lane vectors: a scalar of the pass loop is then a v_readlane,
        not an LDS round trip (with the wave stalled on it) each */
@@ -2595,6 +2702,7 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
         }
       }
       /* energies: each envelope's own slots, side by side in v.est */
+      XS_T(23);
       xs_energy_per_subband_pk(cx, x, ps, s0, s1, max_sb, bands, input_e, v.est);
       XS_T(4);
       xs_subband_gain_meta_pk(cx, ps, jn_hi, jn_lo, nsb, skip, v);
@@ -2604,15 +2712,19 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
       xs_noiselimiting_pk(cx, h, ps, skip, bands, v, w, lim_tab, lim_of);
       XS_T(7);
       xs_erg_to_amplitude_hq_pk(cx, ps, bands, v);
+      XS_T(28);
       /* the envelopes' slots, one envelope after the other */
       for (int q = 0; q < ps.n; q++) {
         XsEnv vq;
         vq.gain = q ? v.gain.shifted(cx, XS_PK) : v.gain;
         vq.noise = q ? v.noise.shifted(cx, XS_PK) : v.noise;
         vq.sine = q ? v.sine.shifted(cx, XS_PK) : v.sine;
-        const int smooth_length = ps.noise_absc[q] ? 0 : ((1 - cx.uni(h->smoothing_mode)) << 2);
-        xs_adapt_noise_gain_hq(cx, st, vq, ps.noise_e[q], nsb, skip, s0[q], s1[q], input_e, adj_e, final_e, max_sb,
-                               ps.noise_absc[q], smooth_length, x);
+        /* (the pass's per-envelope values by selects: indexed by the run-time q the arrays lived in scratch memory, and the
+           two loads were two exposed memory latencies per envelope) */
+        const int absc_q = xs_qsel(q, ps.noise_absc), noise_e_q = xs_qsel(q, ps.noise_e);
+        const int smooth_length = absc_q ? 0 : smooth_len_on;
+        xs_adapt_noise_gain_hq(cx, st, vq, noise_e_q, nsb, skip, xs_qsel(q, s0), xs_qsel(q, s1), input_e, adj_e, final_e, max_sb,
+                               absc_q, smooth_length, x);
       }
       XS_T(10);
       i += ps.n;
@@ -2642,7 +2754,7 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
     XS_T(5);
     xs_calc_subband_gains(cx, xs_pick_env(sfv, i), noise_floor, i, n_meta, skip, v, noise_absc);
     XS_T(6);
-    xs_noiselimiting(cx, h, skip, n_meta, v, w, &xaac_sbr_lim_gains_m[2 * cx.uni(h->limiter_gains)], noise_absc, lim_of);
+    xs_noiselimiting(cx, h, skip, n_meta, v, w, &XS_TAB_LIMG(2 * cx.uni(h->limiter_gains)), noise_absc, lim_of);
     XS_T(7);
     const int16_t noise_e = (int16_t)(s0 < 32 ? adj_e : final_e);
     if constexpr (!Q::HQ) {
@@ -2811,6 +2923,7 @@ FX_HD int xs_sbr_core(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
     if (Q::HQ) m |= fx_abs_nrm(st->lpc_imag[0][k]) | fx_abs_nrm(st->lpc_imag[1][k]);
   }
   const int reserve_ov2 = xs_pnorm32(cx.wave_or(m));
+  XS_T(27);
   if (reserve_ov2 < reserve_ov1) reserve_ov1 = reserve_ov2;
   const int lb_scale0 = cx.uni(st->lb_scale), ov_lb_scale0 = cx.uni(st->ov_lb_scale);
   const int shift1 = lb_scale0 + reserve, shift2 = ov_lb_scale0 + reserve_ov1;

@@ -23,16 +23,16 @@
 #include <stdint.h>
 
 #ifdef XS_PROFILE
-/* phase timers (tools/prof_sbr_core.py): cycles of lane 0 between XS_T hooks, summed over channels */
-__shared__ long long xs_prof_last;
-__shared__ long long xs_prof_acc[32];
-#define XS_T(i)                                   \
-  do {                                            \
-    if (threadIdx.x == 0) {                       \
-      long long t_ = clock64();                   \
-      xs_prof_acc[i] += t_ - xs_prof_last;        \
-      xs_prof_last = t_;                          \
-    }                                             \
+/* phase timers (tools/prof_sbr_core.py): cycles of each wave's lane 0 between XS_T hooks, summed over channels */
+__shared__ long long xs_prof_last[4];
+__shared__ unsigned xs_prof_acc[4][32]; /* per stream: fits 32 bits (and two workgroups still fit a CU's LDS) */
+#define XS_T(i)                                                  \
+  do {                                                           \
+    if ((threadIdx.x & 63) == 0) {                               \
+      long long t_ = clock64();                                  \
+      xs_prof_acc[threadIdx.x >> 6][i] += (unsigned)(t_ - xs_prof_last[threadIdx.x >> 6]); \
+      xs_prof_last[threadIdx.x >> 6] = t_;                       \
+    }                                                            \
   } while (0)
 #endif
 /* LDS copies of the two tables behind every pseudo-float divide / square root (sbr_core.h: XS_TAB_*): a lookup in
@@ -43,6 +43,13 @@ __shared__ int16_t xs_lds_sqrt_table[258];
    low-power one -- a kernel only allocates the one it references.  All three tables are shared by a workgroup's waves */
 __shared__ int32_t xs_lds_rand_ph[568];
 __shared__ int16_t xs_lds_rand_hi[568];
+/* ... and the four small ones (186 bytes): limiter gains [8], smoothing filter [4], 1 / n [49] | chirp targets [16] */
+__shared__ int16_t xs_lds_small16[8 + 4 + 50];
+__shared__ int32_t xs_lds_new_bw[16];
+#define XS_TAB_LIMG(i) xs_lds_small16[i]
+#define XS_TAB_SMOOTH(i) xs_lds_small16[8 + (i)]
+#define XS_TAB_INVINT(i) xs_lds_small16[12 + (i)]
+#define XS_TAB_NEWBW(i) xs_lds_new_bw[i]
 #define XS_TAB_RAND(i) xs_lds_rand_ph[i]
 #define XS_SYNC_WAVE_LDS 1 /* XsCx::sync(): wave-level, LDS only (see sbr_core.h) */
 #define XS_TAB_INV(i) xs_lds_inv_table[i]
@@ -127,6 +134,12 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
   int32_t *gx = p.x + (size_t)ch * XWG;
   const int32_t *gstw = reinterpret_cast<const int32_t *>(gst);
 
+#ifdef XS_PROFILE
+  if (lane == 0) {
+    for (int i = 0; i < 32; i++) xs_prof_acc[threadIdx.x >> 6][i] = 0;
+    xs_prof_last[threadIdx.x >> 6] = clock64();
+  }
+#endif
   /* ---- copy-in: every global load of the channel-frame is issued before the first LDS store, so the wave pays one
      memory latency here, not one per piece (the kernel is latency bound: a wave's lifetime is its cost) ---- */
   constexpr int NH = (sizeof(xaac_sbr_header) / 4 + 63) / 64, NF = (kFrameHeadBytes / 4 + 63) / 64;
@@ -190,10 +203,7 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
   }
   xs_wave_sync();
 #ifdef XS_PROFILE
-  if (lane == 0) {
-    for (int i = 0; i < 32; i++) xs_prof_acc[i] = 0;
-    xs_prof_last = clock64();
-  }
+  XS_T(24);
 #endif
 
   const XsCx cx = {lane, 64};
@@ -234,6 +244,7 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
   }
   xs_wave_sync();
   int save_lb_scale = 0;
+  XS_T(26);
 #ifdef XS_SKIP_CORE
   const int rc = 0;
 #else
@@ -244,7 +255,6 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
   xs_wave_sync();
 #ifdef XS_PROFILE
   XS_T(15);
-  if (lane < 32 && p.status) atomicAdd(reinterpret_cast<unsigned long long *>(p.status) + lane, (unsigned long long)xs_prof_acc[lane]);
 #endif
 
   /* ---- copy-out ---- */
@@ -298,6 +308,11 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
     if (lane < 2) gw[kHeadOff / 4 + lane] = m[lane];
     copy_words(gw + kTailOff / 4, m + 2, kTailWords, lane);
   }
+#ifdef XS_PROFILE
+  XS_T(25);
+  xs_wave_sync();
+  if (lane < 32 && p.status) atomicAdd(reinterpret_cast<unsigned long long *>(p.status) + lane, (unsigned long long)xs_prof_acc[threadIdx.x >> 6][lane]);
+#endif
   return true;
 }
 
@@ -313,6 +328,10 @@ __device__ __forceinline__ void stage_tables(int tid) {
   for (int j = 0; j < NI; j++) ti[j] = tid + THREADS * j < 256 ? xaac_sbr_inv_table[tid + THREADS * j] : (int16_t)0;
 #pragma unroll
   for (int j = 0; j < NS; j++) ts[j] = tid + THREADS * j < 257 ? xaac_sbr_sqrt_table[tid + THREADS * j] : (int16_t)0;
+  if (tid < 8) xs_lds_small16[tid] = xaac_sbr_lim_gains_m[tid];
+  if (tid >= 8 && tid < 12) xs_lds_small16[tid] = xaac_sbr_smooth_filter[tid - 8];
+  if (tid >= 12 && tid < 12 + 49) xs_lds_small16[tid] = xaac_sbr_inv_int_table[tid - 12];
+  if (tid < 16) xs_lds_new_bw[tid] = xaac_sbr_new_bw_table[tid];
 #pragma unroll
   for (int j = 0; j < NR; j++)
     if (tid + THREADS * j < 568) {

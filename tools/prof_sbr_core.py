@@ -11,11 +11,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 NAMES = {1: "block floating point", 2: "hf generator (total)", 3: "env: init/sineflags/adj_e", 4: "env: energies",
-         5: "env: gain meta (lane 0)", 6: "env: subband gains", 7: "env: noise limiting", 8: "env: alias groups+reduction",
-         9: "env: erg->amplitude", 10: "env: apply (adapt_noise_gain)", 11: "env: final adjust", 12: "hf: setup/clears",
-         13: "hf: covariance+lpc", 14: "hf: degree alias (LP) / patches (HQ)", 15: "tail (state, lpc save)", 16: "lim: avggain", 17: "lim: limit loop", 18: "lim: accumulate",
+         5: "env: gain meta (lane 0)", 6: "env: subband gains", 7: "env: noise limiting", 8: "env: alias groups+reduction (LP) / limiter bands, regular-frame test (HQ)",
+         9: "env: erg->amplitude (LP) / band maps (HQ)", 10: "env: apply (adapt_noise_gain)", 11: "env: final adjust", 12: "hf: setup/clears",
+         13: "hf: lpc coefficients (+covariance in LP)", 14: "hf: degree alias (LP) / patches (HQ)", 15: "tail (state, lpc save)", 16: "lim: avggain", 17: "lim: limit loop", 18: "lim: accumulate",
          19: "lim: boost div", 20: "lim: scale loop", 21: "apply: startup/equalize/tones", 22: "apply: slot loop",
-         23: "alias: groups (lane 0)"}
+         23: "alias: groups (LP) / pass set-up (HQ)", 24: "copy-in (global -> LDS)", 25: "copy-out (LDS -> global)",
+         26: "side-info check, narrow-row check, rescale overlap", 27: "bfp: headroom scans", 28: "env: erg->amplitude (pairs)",
+         29: "apply: equalize filt buf", 30: "apply: smoothed slots", 19: "lim: boost div", 31: "hf: covariance sums"}
 
 
 PS_NAMES = {1: "sanitize, init_ps_scale", 2: "P1 hybrid analysis", 3: "P2 envelope walk", 4: "P3 band powers, inputs",
@@ -53,7 +55,7 @@ def main_ps():
     raw = status.cpu().numpy()[:128].view(np.uint64).astype(np.float64) / (steps * n)
     core, ps = raw[:32], raw[32:48]
     print("HQ core kernel:")
-    for i in range(1, 24):
+    for i in range(1, 32):
         if core[i]:
             print("%2d %-34s %9.0f cycles/channel-frame %5.1f%%" % (i, NAMES.get(i, "?"), core[i], 100 * core[i] / core.sum()))
     print("   total %.0f cycles" % core.sum())
