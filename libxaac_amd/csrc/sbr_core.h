@@ -325,6 +325,18 @@ struct XsLv {
 #endif
 };
 
+/* OR of all 64 elements */
+FX_HD int32_t xs_lv_or(const XsCx &cx, const XsLv &v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return cx.wave_or(v.v);
+#else
+  int32_t m = 0;
+  for (int i = 0; i < 64; i++) m |= v.a[i];
+  (void)cx;
+  return m;
+#endif
+}
+
 /* (mantissa, exponent) pseudo-float packed into one lane-vector element */
 FX_HD int32_t xs_me(int16_t m, int16_t e) { return (int32_t)(((uint32_t)(uint16_t)e << 16) | (uint16_t)m); }
 FX_HD int16_t xs_m(int32_t v) { return (int16_t)v; }
@@ -2033,6 +2045,7 @@ struct XsApplyHq {
   int ls, rs, keep, col, step, kk, harm_lane; /* ls / rs / keep: the segment's shift, see xs_adapt_noise_gain_hq */
   int16_t sg, snz;
   bool tone, noise, fi, live;
+  int32_t hr, hr_keep; /* OR of the magnitudes written (hr_keep: -1 where they count -- slots below 32 --, else 0) */
 };
 template <int N, class Q>
 FX_HD void xs_apply_slots_hq(const Q &x, XsApplyHq &a, int l, int &ph, int &harm) {
@@ -2061,6 +2074,7 @@ FX_HD void xs_apply_slots_hq(const Q &x, XsApplyHq &a, int l, int &ph, int &harm
     const int32_t im_n = xs_mac16x16_shl_sat(im, (int16_t)rp[j], a.snz);
     xr[j] = a.tone ? re_t : (a.noise ? re_n : re);
     xi[j] = a.tone ? im_t : (a.noise ? im_n : im);
+    a.hr |= (fx_abs_nrm(xr[j]) | fx_abs_nrm(xi[j])) & a.hr_keep;
   }
   if (a.live) {
     XS_UNROLL
@@ -2079,44 +2093,102 @@ FX_HD void xs_apply_slots_hq(const Q &x, XsApplyHq &a, int l, int &ph, int &harm
    noise (complex random phase) or sine (real part for harmonic index 0/2, imaginary for 1/3, sign
    alternating with the band) per band.  Bands are independent; lane i owns filter-buffer entry i and,
    from skip on, band i - skip. */
-template <class ST, class Q>
-FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e, int nsb, int skip, int s0, int s1,
-                                  int input_e, int adj_e, int final_e, int sb_start, int noise_absc,
-                                  int smooth_length, const Q &x) {
-  const int bands = nsb - skip;
-  const int start_up = cx.uni(st->start_up);
-  const int ph0 = cx.uni(st->ph_index), harm0 = cx.uni(st->harm_index);
-  const int fb_noise_e0 = start_up ? noise_e : cx.uni(st->filt_buf_noise_e);
-  cx.sync();
-  XS_LANES(k, 0, bands) {
-    int16_t g[2] = {xs_m(v.gain.own(k)), xs_e(v.gain.own(k))};
-    if (start_up) {
-      st->filt_buf_me[2 * (skip + k)] = g[0];
-      st->filt_buf_me[2 * (skip + k) + 1] = g[1];
-      st->filt_buf_noise_m[skip + k] = xs_m(v.noise.own(k));
-    } else {
-      xs_equalize_filt_buf(&st->filt_buf_me[2 * (skip + k)], g);
-      v.gain.own(k) = xs_me(g[0], g[1]);
+/* The envelope adjuster's memory (ixheaacd_env_calc.h:23-32) while a frame is worked on, HQ mode: the smoothing filter's
+   gain and noise entries as lane vectors, the four scalars as wave-uniform values -- loaded once per frame and stored once,
+   where every envelope used to go through the state's LDS copy half a dozen times (each a wait in a serial stretch).
+   Element li holds entry i = li & 31 when the SBR range fits 32 bands (`two`: both halves of the wave hold the same entries,
+   see xs_adapt_noise_gain_hq), else entry li. */
+struct XsAdjMem {
+  XsLv fb, fn; /* filt_buf_me as (mantissa | exponent << 16), filt_buf_noise_m */
+  XsLv hr;     /* OR of the magnitudes the envelopes have written to slots 0..31 so far (env_calc.c:961's headroom, taken on
+                  the way instead of by a scan of the matrix afterwards) */
+  int start_up, ph_index, harm_index, filt_buf_noise_e;
+  bool two;
+};
+template <class ST>
+FX_HD void xs_adj_load(const XsCx &cx, const ST *st, int nsb, XsAdjMem &m) {
+  m.two = nsb <= 32;
+  m.fb.fill(0);
+  m.fn.fill(0);
+  m.hr.fill(0);
+  XS_LANES(li, 0, 64) {
+    const int i = m.two ? li & 31 : li;
+    if (i < nsb && i < XS_MAXF) {
+      m.fb.own(li) = xs_me(st->filt_buf_me[2 * i], st->filt_buf_me[2 * i + 1]);
+      m.fn.own(li) = st->filt_buf_noise_m[i];
     }
   }
+  m.start_up = cx.uni(st->start_up);
+  m.ph_index = cx.uni(st->ph_index);
+  m.harm_index = cx.uni(st->harm_index);
+  m.filt_buf_noise_e = cx.uni(st->filt_buf_noise_e);
+}
+template <class ST>
+FX_HD void xs_adj_store(const XsCx &cx, ST *st, int nsb, const XsAdjMem &m) {
+  XS_LANES(li, 0, m.two ? 32 : 64) {
+    if (li < nsb && li < XS_MAXF) {
+      st->filt_buf_me[2 * li] = xs_m(m.fb.own(li));
+      st->filt_buf_me[2 * li + 1] = xs_e(m.fb.own(li));
+      st->filt_buf_noise_m[li] = (int16_t)m.fn.own(li);
+    }
+  }
+  XS_ONE {
+    st->start_up = (int16_t)m.start_up;
+    st->ph_index = (int16_t)m.ph_index;
+    st->harm_index = (int16_t)m.harm_index;
+    st->filt_buf_noise_e = (int16_t)m.filt_buf_noise_e;
+  }
   cx.sync();
-  XS_T(29);
-  /* band values seen from the lane that owns filter-buffer entry i = skip + k */
-  XsLv gain_i = v.gain.shifted(cx, -skip), noise_i = v.noise.shifted(cx, -skip), sine_i = v.sine.shifted(cx, -skip);
+}
+
+/* env_calc.c:479 (HQ branch) with ixheaacd_adj_timeslot (env_dec.c:845) and ixheaacd_harm_idx_zerotwo /
+   _onethree (env_calc.c:1759 / :1827): gain smoothing over the first slots of an envelope, then gain,
+   noise (complex random phase) or sine (real part for harmonic index 0/2, imaginary for 1/3, sign
+   alternating with the band) per band.  Bands are independent; lane i owns filter-buffer entry i and,
+   from skip on, band i - skip.  v: the envelope's gains / noise / sine levels, element lane_off + k = band k (lane_off = 32
+   for the second envelope of a pass). */
+template <class Q>
+FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, XsAdjMem &m, const XsEnv &v, int lane_off, int noise_e, int nsb, int skip,
+                                  int s0, int s1, int input_e, int adj_e, int final_e, int sb_start, int noise_absc,
+                                  int smooth_length, const Q &x) {
+  const int bands = nsb - skip;
+  const int start_up = m.start_up;
+  const int ph0 = m.ph_index, harm0 = m.harm_index;
+  const int fb_noise_e0 = start_up ? noise_e : m.filt_buf_noise_e;
   /* With at most 32 entries the two halves of the wave share the walk: lane 32 g + i takes half g of every segment's slots
      of entry i (a slot's result depends on its number only -- random phase, harmonic index -- once the smoothed start is
-     over; the smoothed slots, a recursion, stay with g = 0, and so does everything that is written to the state). */
-  const bool two = nsb <= 32;
-  if (two) {
+     over; the smoothed slots, a recursion, are walked by both halves alike, and so is everything that goes to the memory:
+     the halves' copies stay equal).  Band values seen from the lane that owns entry i = skip + k: one gather each. */
+  const bool two = m.two;
+  XsLv gain_i, noise_i, sine_i;
+  {
     XsLv idx;
     idx.fill(0);
-    XS_LANES(l, 0, 64) idx.own(l) = l & 31;
-    gain_i = gain_i.gather(idx);
-    noise_i = noise_i.gather(idx);
-    sine_i = sine_i.gather(idx);
+    XS_LANES(li, 0, 64) idx.own(li) = ((two ? li & 31 : li) - skip + lane_off) & 63;
+    gain_i = v.gain.gather(idx);
+    noise_i = v.noise.gather(idx);
+    sine_i = v.sine.gather(idx);
   }
-  XsLv noise_out;
-  noise_out.fill(0);
+  XS_LANES(li, 0, 64) {
+    const int i = two ? li & 31 : li;
+    const bool band = i >= skip && i < nsb;
+    gain_i.own(li) = band ? gain_i.own(li) : 0;
+    noise_i.own(li) = band ? noise_i.own(li) : 0;
+    sine_i.own(li) = band ? sine_i.own(li) : 0;
+    if (band) { /* env_calc.c:1017: the buffer meets the new gain's exponent (or, at start-up, takes the gain) */
+      int16_t g[2] = {xs_m(gain_i.own(li)), xs_e(gain_i.own(li))};
+      if (start_up) {
+        m.fb.own(li) = gain_i.own(li);
+        m.fn.own(li) = xs_m(noise_i.own(li));
+      } else {
+        int16_t fb[2] = {xs_m(m.fb.own(li)), xs_e(m.fb.own(li))};
+        xs_equalize_filt_buf(fb, g);
+        m.fb.own(li) = xs_me(fb[0], fb[1]);
+        gain_i.own(li) = xs_me(g[0], g[1]);
+      }
+    }
+  }
+  XS_T(29);
   XS_T(21);
   XS_LANES(li, 0, two ? 64 : nsb) {
     const int g = two ? li >> 5 : 0, i = two ? li & 31 : li;
@@ -2125,9 +2197,11 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
     const int16_t gm = xs_m(gain_i.own(li)), ge = xs_e(gain_i.own(li));
     const int16_t sm = xs_m(sine_i.own(li)), se = xs_e(sine_i.own(li));
     int16_t nl = xs_m(noise_i.own(li));
-    int16_t fbm = st->filt_buf_me[2 * i], fbn = st->filt_buf_noise_m[i];
+    int16_t fbm = xs_m(m.fb.own(li)), fbn = (int16_t)m.fn.own(li);
     int ne = noise_e, fbe = fb_noise_e0, ph = ph0, harm = harm0;
-    const int harm_lane0 = st->harm_index; /* = harm0, but a per-lane value on the GPU (see xs_apply_slots_hq) */
+    int32_t hr = 0;
+    int harm_lane0 = harm0; /* a per-lane value on the GPU (see xs_apply_slots_hq) */
+    XS_KEEP(harm_lane0);
     const int col = sb_start + (k >= 0 ? k : 0), kk = k >= 0 ? k : 0;
     /* 1. the envelope's first slots while the gains are smoothed (at most four; the reference's slot body as it is) */
     int l = s0;
@@ -2190,6 +2264,7 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
         re = xs_mac16x16_shl_sat(re, (int16_t)(rp >> 16), snz);
         im = xs_mac16x16_shl_sat(im, (int16_t)rp, snz);
       }
+      hr |= (g == 0 && l < 32) ? (fx_abs_nrm(re) | fx_abs_nrm(im)) : 0; /* (the half that writes the slot) */
       if (g == 0) {
         x(l, col) = re;
         x.im(l, col) = im;
@@ -2235,6 +2310,8 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
       a.col = col;
       a.step = bands;
       a.kk = kk;
+      a.hr = 0;
+      a.hr_keep = (k >= 0 && l < 32) ? -1 : 0;
       /* this lane's share of the segment's slots [l, seg_end) */
       const int count = seg_end - l, half = two ? (count + 1) >> 1 : count;
       int lg = g ? l + half : l, phg = g ? (ph + half * bands) & 511 : ph, harmg = g ? (harm + half) & 3 : harm;
@@ -2253,36 +2330,27 @@ FX_HD void xs_adapt_noise_gain_hq(const XsCx &cx, ST *st, XsEnv &v, int noise_e,
         xs_apply_slots_hq<1>(x, a, lg, phg, harmg);
         lg += 1;
       }
+      hr |= a.hr;
       ph = (ph + count * bands) & 511;
       harm = (harm + count) & 3;
       l = seg_end;
     }
-    if (g == 0) {
-      st->filt_buf_me[2 * i] = fbm;
-      st->filt_buf_noise_m[i] = fbn;
-      noise_out.own(li) = nl;
-    }
+    /* the memory as the envelope leaves it (env_calc.c:1060): a band's entry takes the envelope's gain and noise level */
+    m.fb.own(li) = xs_me(k >= 0 ? gm : fbm, xs_e(m.fb.own(li)));
+    m.fn.own(li) = k >= 0 ? nl : fbn;
+    m.hr.own(li) |= hr;
   }
   cx.sync();
   XS_T(22);
   {
-    const XsLv nb = noise_out.shifted(cx, skip); /* back to band indexing */
-    XS_LANES(k, 0, bands) {
-      v.noise.own(k) = xs_me((int16_t)nb.own(k), xs_e(v.noise.own(k)));
-      st->filt_buf_me[2 * (skip + k)] = xs_m(v.gain.own(k)); /* env_calc.c:1060 */
-      st->filt_buf_noise_m[skip + k] = (int16_t)nb.own(k);
-    }
-  }
-  XS_ONE {
     const int n = s1 > s0 ? s1 - s0 : 0;
     int ne = noise_e;
     if (s0 < 32 && s1 > 32) ne = final_e;
-    st->start_up = 0;
-    st->filt_buf_noise_e = n > 0 ? ne : fb_noise_e0;
-    st->ph_index = (int16_t)((ph0 + n * bands) & 511);
-    st->harm_index = (int16_t)((harm0 + n) & 3);
+    m.start_up = 0;
+    m.filt_buf_noise_e = n > 0 ? ne : fb_noise_e0;
+    m.ph_index = (int16_t)((ph0 + n * bands) & 511);
+    m.harm_index = (int16_t)((harm0 + n) & 3);
   }
-  cx.sync();
 }
 
 /* lpp_tran.c:372: complex covariances of low band k over `slots` (= 38) slots starting at row 0, with the
@@ -2556,6 +2624,12 @@ FX_HD void xs_hf_generator_hq(const XsCx &cx, const xaac_sbr_header *h, ST *st, 
   cx.sync();
 }
 
+/* env_calc.c:975-1003: the two shifts that bring the adjusted range to one exponent -- bands [b0, b1): slots [0, first_start)
+   by sh_ov, slots [first_start, 32) by sh_main (xs_adjust's meaning).  A caller that is about to move the matrix anyway (the
+   GPU core kernel's copy-out) asks for them instead of having them applied in place. */
+struct XsPendingAdjust {
+  int b0, b1, first_start, sh_ov, sh_main;
+};
 /* env_calc.c:692, AAC-LC/HE-AAC (not ELD), 1024-sample frames, low-power (Q = XsQmf) or HQ (XsQmfHq).
    deg64: aliasing degree per QMF band from the low-power HF generator.  Returns 0 or -1. */
 template <class ST, class Q>
@@ -2564,7 +2638,7 @@ template <class ST, class Q>
    envelope: it stays in global memory there) -- nothing below may reach them through `f`. */
 FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f,
                               const int16_t *env_sf_all, const int16_t *noise_floor_all, ST *st, const Q &x,
-                              XsWork *w, const int16_t *rand_hi, const XsLv &deg64) {
+                              XsWork *w, const int16_t *rand_hi, const XsLv &deg64, XsPendingAdjust *pend = nullptr) {
   const int num_env = cx.uni(f->num_env);
   const int16_t *border = f->border_vec;
   const int16_t *noise_floor = noise_floor_all;
@@ -2635,6 +2709,8 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
   const int tansient_env_prev = cx.uni(st->tansient_env_prev);
   const int hb_scale = cx.uni(st->hb_scale), lb_scale = cx.uni(st->lb_scale);
   const XsLv lim_of = xs_limiter_band_of(cx, h, skip);
+  XsAdjMem adj; /* HQ: the adjuster's memory in registers from here to the end of the envelopes */
+  if constexpr (Q::HQ) xs_adj_load(cx, st, nsb, adj);
   bool packed = false;
 #ifndef XS_NO_ENV_PAIRS /* (a checker build runs every frame through the one-envelope chain: tests/test_env_pairs_cpu.py) */
   if constexpr (Q::HQ) packed = xs_pack_frame_ok(cx, h);
@@ -2664,8 +2740,10 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
       /* envelope i: the reference's checks, in its order */
       s0[0] = 2 * bordv.get(i);
       s1[0] = 2 * bordv.get(i + 1);
-      if (s0[0] >= 38 || s1[0] > 38) return -1;
-      if (nf_idx >= XAAC_SBR_MAX_NOISE_ENVELOPES) return -1;
+      if (s0[0] >= 38 || s1[0] > 38 || nf_idx >= XAAC_SBR_MAX_NOISE_ENVELOPES) {
+        if constexpr (Q::HQ) xs_adj_store(cx, st, nsb, adj);
+        return -1;
+      }
       if (bordv.get(i) == nbordv.get(nf_idx + 1)) {
         nf_off += nnf;
         nf_idx++;
@@ -2715,16 +2793,12 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
       XS_T(28);
       /* the envelopes' slots, one envelope after the other */
       for (int q = 0; q < ps.n; q++) {
-        XsEnv vq;
-        vq.gain = q ? v.gain.shifted(cx, XS_PK) : v.gain;
-        vq.noise = q ? v.noise.shifted(cx, XS_PK) : v.noise;
-        vq.sine = q ? v.sine.shifted(cx, XS_PK) : v.sine;
         /* (the pass's per-envelope values by selects: indexed by the run-time q the arrays lived in scratch memory, and the
            two loads were two exposed memory latencies per envelope) */
         const int absc_q = xs_qsel(q, ps.noise_absc), noise_e_q = xs_qsel(q, ps.noise_e);
         const int smooth_length = absc_q ? 0 : smooth_len_on;
-        xs_adapt_noise_gain_hq(cx, st, vq, noise_e_q, nsb, skip, xs_qsel(q, s0), xs_qsel(q, s1), input_e, adj_e, final_e, max_sb,
-                               absc_q, smooth_length, x);
+        xs_adapt_noise_gain_hq(cx, adj, v, q ? XS_PK : 0, noise_e_q, nsb, skip, xs_qsel(q, s0), xs_qsel(q, s1), input_e, adj_e,
+                               final_e, max_sb, absc_q, smooth_length, x);
       }
       XS_T(10);
       i += ps.n;
@@ -2732,11 +2806,13 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
   }
   for (int i = packed ? num_env : 0; i < num_env; i++) {
     const int s0 = 2 * cx.uni(border[i]), s1 = 2 * cx.uni(border[i + 1]);
-    if (s0 >= 38 || s1 > 38) return -1;
+    if (s0 >= 38 || s1 > 38 || nf_idx >= XAAC_SBR_MAX_NOISE_ENVELOPES) {
+      if constexpr (Q::HQ) xs_adj_store(cx, st, nsb, adj);
+      return -1;
+    }
     const int fr = cx.uni(f->freq_res[i]);
     const int16_t *tbl = fr ? h->freq_band_tbl_hi : h->freq_band_tbl_lo;
     const int nsf = cx.uni(h->num_sf_bands[fr]);
-    if (nf_idx >= XAAC_SBR_MAX_NOISE_ENVELOPES) return -1;
     if (cx.uni(border[i]) == cx.uni(f->noise_border_vec[nf_idx + 1])) {
       noise_floor += cx.uni(h->num_nf_bands);
       nf_idx++;
@@ -2749,7 +2825,10 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
     else
       xs_energy_per_sfb(cx, x, nsf, tbl, s0, s1, max_sb, input_e, w, v.est);
     XS_T(4);
-    if (cx.uni(tbl[0]) < sb_start) return -1;
+    if (cx.uni(tbl[0]) < sb_start) {
+      if constexpr (Q::HQ) xs_adj_store(cx, st, nsb, adj);
+      return -1;
+    }
     const int n_meta = xs_subband_gain_meta(cx, h, max_sb, tbl, nsf, i, v);
     XS_T(5);
     xs_calc_subband_gains(cx, xs_pick_env(sfv, i), noise_floor, i, n_meta, skip, v, noise_absc);
@@ -2770,21 +2849,37 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
                              (int16_t)(15 - lb_scale), noise_absc, x);
     } else {
       xs_erg_to_amplitude_hq(cx, nsb - skip, noise_e, v);
-      xs_adapt_noise_gain_hq(cx, st, v, noise_e, nsb, skip, s0, s1, input_e, adj_e, final_e, max_sb, noise_absc,
+      xs_adapt_noise_gain_hq(cx, adj, v, 0, noise_e, nsb, skip, s0, s1, input_e, adj_e, final_e, max_sb, noise_absc,
                              smooth_length, x);
     }
     XS_T(10);
   }
+  if constexpr (Q::HQ) xs_adj_store(cx, st, nsb, adj);
   const int first_start = cx.uni(border[0]) * 2;
   const int ov_adj_e = 15 - cx.uni(st->ov_hb_scale);
   int ov_reserve = 0, reserve = 0; /* env_calc.c:961: only taken for parametric stereo */
   if (cx.uni(h->channel_mode) == 3) {
     ov_reserve = xs_headroom(cx, x, max_sb, sb_end, 0, first_start);
-    reserve = xs_headroom(cx, x, max_sb, sb_end, first_start, 32);
+    /* the envelopes tile [first_start, 32) (the parser's grids do): every word of the range has been written by the slot
+       walks, which kept the OR of the magnitudes (XsAdjMem::hr); else the scan */
+    bool tiled = Q::HQ && num_env > 0 && 2 * cx.uni(border[num_env]) >= 32;
+    for (int i = 0; i < num_env; i++) tiled = tiled && cx.uni(border[i]) < cx.uni(border[i + 1]);
+    if (tiled)
+      reserve = xs_pnorm32(xs_lv_or(cx, adj.hr) | 1);
+    else
+      reserve = xs_headroom(cx, x, max_sb, sb_end, first_start, 32);
   }
   const int output_e = (ov_adj_e - ov_reserve) > (adj_e - reserve) ? (ov_adj_e - ov_reserve) : (adj_e - reserve);
-  xs_adjust(cx, x, max_sb, sb_end, 0, first_start, ov_adj_e - output_e);
-  xs_adjust(cx, x, max_sb, sb_end, first_start, cx.uni(h->num_time_slots) * cx.uni(h->time_step), adj_e - output_e);
+  if (pend) {
+    pend->b0 = max_sb;
+    pend->b1 = sb_end;
+    pend->first_start = first_start;
+    pend->sh_ov = ov_adj_e - output_e;
+    pend->sh_main = adj_e - output_e;
+  } else {
+    xs_adjust(cx, x, max_sb, sb_end, 0, first_start, ov_adj_e - output_e);
+    xs_adjust(cx, x, max_sb, sb_end, first_start, cx.uni(h->num_time_slots) * cx.uni(h->time_step), adj_e - output_e);
+  }
   cx.sync();
   XS_ONE {
     st->hb_scale = (int16_t)(15 - output_e);
@@ -2899,28 +2994,21 @@ FX_HD int xs_side_info_bad(const XsCx &cx, const xaac_sbr_header *h, const xaac_
 }
 
 
-/* The part of ixheaacd_sbr_dec between the two QMF banks (sbr_dec.c:1050-1245), low-power (Q = XsQmf) or
-   HQ (Q = XsQmfHq) mode.
-   On entry x holds the 6 overlap slots (already through xs_rescale_x_overlap) and the 32 freshly
-   analysed slots (bands 0..31); on exit x is ready for the synthesis bank and the state carries the
-   new scale factors, LPC history and envelope-adjuster memory.  rand_hi[i] = xaac_sbr_rand_ph[i] >> 16
-   (the only part of that table this mode uses; an LDS copy on the GPU).  Returns 0 or -1. */
-template <class ST, class Q>
-FX_HD int xs_sbr_core(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, const int16_t *env_sf_all,
-                      const int16_t *noise_floor_all, ST *st, const Q &x, XsWork *w, const int16_t *rand_hi,
-                      int *save_lb_scale_out) {
-  /* the frame grid this implementation (and the reference's MAX_ENV_COLS buffers, sbr_dec.c:733-748) is laid
-     out for: 16 time slots of 2 QMF slots; anything else is refused like the reference refuses its own limits */
-  if (cx.uni(h->num_time_slots) * cx.uni(h->time_step) != 32 || cx.uni(h->num_columns) != 32) return -1;
-  /* xs_side_info_bad has been run by the caller, before xs_rescale_x_overlap touched the overlap slots */
-  const int usb = cx.uni(st->codec_usb);
-  int reserve = xs_headroom(cx, x, 0, usb, 6, 38);
-  int reserve_ov1 = xs_headroom(cx, x, 0, usb, 0, 6);
-  const int max_samp_val = reserve < reserve_ov1 ? reserve : reserve_ov1;
+/* sbr_dec.c:1050-1120, everything but the matrix: from the headrooms of the low bands' analysed slots (reserve) and overlap
+   slots (reserve_ov1) to the two shifts the matrix takes.  Rescales the LPC history rows of the state and writes its
+   ov_lb_scale / lb_scale. */
+struct XsBfp {
+  int sh_ov, sh_main; /* shift of slots 0..5 / 6..37 of bands [0, usb) (xs_adjust's meaning: left if positive) */
+  int save_lb_scale, max_samp_val;
+};
+template <int HQ, class ST>
+FX_HD XsBfp xs_bfp_shifts(const XsCx &cx, ST *st, int usb, int reserve, int reserve_ov1) {
+  XsBfp b;
+  b.max_samp_val = reserve < reserve_ov1 ? reserve : reserve_ov1;
   int32_t m = 1;
   XS_PAR(k, 0, usb) {
     m |= fx_abs_nrm(st->lpc_real[0][k]) | fx_abs_nrm(st->lpc_real[1][k]);
-    if (Q::HQ) m |= fx_abs_nrm(st->lpc_imag[0][k]) | fx_abs_nrm(st->lpc_imag[1][k]);
+    if (HQ) m |= fx_abs_nrm(st->lpc_imag[0][k]) | fx_abs_nrm(st->lpc_imag[1][k]);
   }
   const int reserve_ov2 = xs_pnorm32(cx.wave_or(m));
   XS_T(27);
@@ -2931,29 +3019,43 @@ FX_HD int xs_sbr_core(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
   const int shift_over = shift2 - min_shift;
   reserve -= (shift1 - min_shift);
   cx.sync();
-  xs_adjust(cx, x, 0, usb, 0, 6, reserve_ov1 - shift_over);
-  xs_adjust(cx, x, 0, usb, 6, 38, reserve);
+  b.sh_ov = reserve_ov1 - shift_over;
+  b.sh_main = reserve;
   {
-    int sh = reserve_ov1 - shift_over;
+    int sh = b.sh_ov;
     if (sh != 0) {
       if (sh > 31) sh = 31;
       if (sh < -31) sh = -31;
       XS_PAR(k, 0, usb)
         for (int i = 0; i < 2; i++) {
           st->lpc_real[i][k] = sh > 0 ? fx_shlw(st->lpc_real[i][k], sh) : (st->lpc_real[i][k] >> -sh);
-          if (Q::HQ) st->lpc_imag[i][k] = sh > 0 ? fx_shlw(st->lpc_imag[i][k], sh) : (st->lpc_imag[i][k] >> -sh);
+          if (HQ) st->lpc_imag[i][k] = sh > 0 ? fx_shlw(st->lpc_imag[i][k], sh) : (st->lpc_imag[i][k] >> -sh);
         }
     }
   }
-  const int save_lb_scale = (int16_t)(lb_scale0 + reserve);
+  b.save_lb_scale = (int16_t)(lb_scale0 + reserve);
   XS_ONE {
-    st->ov_lb_scale = (int16_t)(ov_lb_scale0 + (reserve_ov1 - shift_over));
-    st->lb_scale = (int16_t)save_lb_scale;
+    st->ov_lb_scale = (int16_t)(ov_lb_scale0 + b.sh_ov);
+    st->lb_scale = (int16_t)b.save_lb_scale;
   }
-  *save_lb_scale_out = save_lb_scale;
-  xs_clear(cx, x, 32, Q::NB, 6, 38); /* bands 32 and up of the analysed slots */
-  cx.sync();
-  XS_T(1);
+  return b;
+}
+/* xs_adjust (env_calc.c:1099) on one word; shift != 0 */
+FX_HD int32_t xs_adjust_word(int32_t v, int shift) {
+  if (shift > 31) shift = 31;
+  if (shift < -31) shift = -31;
+  return shift > 0 ? fx_shlw(v, shift) : (v >> -shift);
+}
+
+/* sbr_dec.c:1121-1245, :1283-1308: what follows the block floating point of the low bands -- HF generation, envelope
+   adjustment, the state's scale factors, LPC history.  The matrix has been through xs_adjust with b's shifts and its
+   analysed slots are zero from band 32 on. */
+template <class ST, class Q>
+FX_HD int xs_sbr_core_tail(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, const int16_t *env_sf_all,
+                           const int16_t *noise_floor_all, ST *st, const Q &x, XsWork *w, const int16_t *rand_hi,
+                           const XsBfp &b, XsPendingAdjust *pend = nullptr) {
+  const int save_lb_scale = b.save_lb_scale, max_samp_val = b.max_samp_val;
+  (void)max_samp_val;
   if (cx.uni(f->apply_processing)) {
     XsLv deg64;
     deg64.fill(0);
@@ -2968,7 +3070,7 @@ FX_HD int xs_sbr_core(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
     XS_T(2);
     XS_ONE st->hb_scale = (int16_t)((st->ov_lb_scale < st->lb_scale ? st->ov_lb_scale : st->lb_scale) - 2);
     cx.sync();
-    if (xs_calc_sbrenvelope(cx, h, f, env_sf_all, noise_floor_all, st, x, w, rand_hi, deg64)) return -1;
+    if (xs_calc_sbrenvelope(cx, h, f, env_sf_all, noise_floor_all, st, x, w, rand_hi, deg64, pend)) return -1;
     XS_PAR(i, 0, h->num_if_bands) st->prev_invf_mode[i] = f->sbr_invf_mode[i];
     XS_ONE {
       st->prev_coupling_mode = f->coupling_mode;
@@ -2984,6 +3086,35 @@ FX_HD int xs_sbr_core(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
   cx.sync();
   XS_T(15);
   return 0;
+}
+
+/* The part of ixheaacd_sbr_dec between the two QMF banks (sbr_dec.c:1050-1245), low-power (Q = XsQmf) or
+   HQ (Q = XsQmfHq) mode.
+   On entry x holds the 6 overlap slots (already through xs_rescale_x_overlap) and the 32 freshly
+   analysed slots (bands 0..31); on exit x is ready for the synthesis bank and the state carries the
+   new scale factors, LPC history and envelope-adjuster memory.  rand_hi[i] = xaac_sbr_rand_ph[i] >> 16
+   (the only part of that table this mode uses; an LDS copy on the GPU).  Returns 0 or -1.
+   (The GPU core kernel takes the headrooms and applies the shifts while the matrix words pass through its registers on their
+   way into LDS, and calls xs_bfp_shifts / xs_sbr_core_tail itself: sbr_core_kernel.hip.) */
+template <class ST, class Q>
+FX_HD int xs_sbr_core(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, const int16_t *env_sf_all,
+                      const int16_t *noise_floor_all, ST *st, const Q &x, XsWork *w, const int16_t *rand_hi,
+                      int *save_lb_scale_out) {
+  /* the frame grid this implementation (and the reference's MAX_ENV_COLS buffers, sbr_dec.c:733-748) is laid
+     out for: 16 time slots of 2 QMF slots; anything else is refused like the reference refuses its own limits */
+  if (cx.uni(h->num_time_slots) * cx.uni(h->time_step) != 32 || cx.uni(h->num_columns) != 32) return -1;
+  /* xs_side_info_bad has been run by the caller, before xs_rescale_x_overlap touched the overlap slots */
+  const int usb = cx.uni(st->codec_usb);
+  const int reserve = xs_headroom(cx, x, 0, usb, 6, 38);
+  const int reserve_ov1 = xs_headroom(cx, x, 0, usb, 0, 6);
+  const XsBfp b = xs_bfp_shifts<Q::HQ>(cx, st, usb, reserve, reserve_ov1);
+  xs_adjust(cx, x, 0, usb, 0, 6, b.sh_ov);
+  xs_adjust(cx, x, 0, usb, 6, 38, b.sh_main);
+  *save_lb_scale_out = b.save_lb_scale;
+  xs_clear(cx, x, 32, Q::NB, 6, 38); /* bands 32 and up of the analysed slots */
+  cx.sync();
+  XS_T(1);
+  return xs_sbr_core_tail(cx, h, f, env_sf_all, noise_floor_all, st, x, w, rand_hi, b);
 }
 
 #endif /* XAAC_SBR_CORE_H */

@@ -182,11 +182,14 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
     for (int i = lane; i < 2 * ROW; i += 64) s.x[i] = 0;
     if (!HQ)
       for (int i = lane; i < 128; i += 64) s.x[XAAC_SBR_X_ROWS * ROW + i] = 0;
-    /* a run of 64 words of a global row is one part (real | imaginary) of one slot with band = lane (HQ), or one slot
-       (LP): the LDS place follows from j and the lane with one predicate, band < NB */
-    const bool held = NB == 64 || lane < NB;
+  }
+  /* a run of 64 words of a global row is one part (real | imaginary) of one slot with band = lane (HQ), or one slot
+     (LP): the LDS place follows from j and the lane with one predicate, band < NB.  The matrix words stay in their registers
+     until the block floating point of the low bands has been through them (below). */
+  const bool held = NB == 64 || lane < NB;
 #pragma unroll
-    for (int j = 0; j < NOV; j++) above |= held ? 0 : r_ov[j];
+  for (int j = 0; j < NOV; j++) above |= held ? 0 : r_ov[j];
+  auto store_matrix = [&]() {
     if (held) { /* one predicated region for the twelve stores */
 #pragma unroll
       for (int j = 0; j < NOV; j++) {
@@ -200,7 +203,12 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
       const int row = HQ ? (i >> 6) : (i >> 5), col = HQ ? ((i & 31) + ((i & 32) ? Q::IM : 0)) : (i & 31);
       s.x[(8 + row) * ROW + col] = r_an[j];
     }
-  }
+    /* what the analysis bank does not write is 0: bands 32 and up of the analysed slots (sbr_dec.c:1121) */
+    for (int i = lane; i < 32 * (HQ ? 2 : 1) * (NB - 32); i += 64) {
+      const int row = i / ((HQ ? 2 : 1) * (NB - 32)), c = i % ((HQ ? 2 : 1) * (NB - 32));
+      s.x[(8 + row) * ROW + (c < NB - 32 ? 32 + c : Q::IM + 32 + (c - (NB - 32)))] = 0;
+    }
+  };
   xs_wave_sync();
 #ifdef XS_PROFILE
   XS_T(24);
@@ -229,13 +237,16 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
     }
     if (cx.wave_max(top) > NB || cx.wave_or(above) != 0) return false;
   }
-  if (refused) { /* the matrix goes on as it came; what the analysis bank does not write is defined as 0 */
-    for (int i = lane; i < 32 * (HQ ? 2 : 1) * (NB - 32); i += 64) {
-      const int row = i / ((HQ ? 2 : 1) * (NB - 32)), c = i % ((HQ ? 2 : 1) * (NB - 32));
-      s.x[(8 + row) * ROW + (c < NB - 32 ? 32 + c : Q::IM + 32 + (c - (NB - 32)))] = 0;
-    }
-  }
-  if (f->apply_processing && !refused) xs_rescale_x_overlap(cx, &s.h, f, &s.st, x);
+  /* The block floating point of the low bands (sbr_dec.c:1050-1120: headroom of the overlap slots and of the analysed slots,
+     two shifts) is taken from, and applied to, the words while they are in registers -- as two scans and two read-modify-write
+     walks over the matrix in LDS it was a tenth of the kernel.  A frame whose overlap slots xs_rescale_x_overlap has to walk
+     first (the cross-over band moved: rare) goes through LDS as before, and so does a refused one. */
+  const int apply = __builtin_amdgcn_readfirstlane((int)f->apply_processing);
+  const int old_lsb = __builtin_amdgcn_readfirstlane((int)s.st.prev_max_qmf_subband_aac);
+  const int new_lsb = __builtin_amdgcn_readfirstlane((int)f->max_qmf_subband_aac);
+  const bool in_regs = !refused && !(apply && new_lsb != old_lsb && old_lsb > 0);
+  if (!in_regs) store_matrix();
+  if (apply && !refused) xs_rescale_x_overlap(cx, &s.h, f, &s.st, x); /* in_regs: only its two state words */
   /* what ixheaacd_cplx_anal_qmffilt leaves in the scale struct (generic:630-631) */
   xs_wave_sync();
   if (lane == 0) {
@@ -244,13 +255,41 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
   }
   xs_wave_sync();
   int save_lb_scale = 0;
+  XsPendingAdjust pend = {0, 0, 0, 0, 0}; /* the envelope adjuster's last two shifts, applied on the way out (copy-out) */
   XS_T(26);
 #ifdef XS_SKIP_CORE
   const int rc = 0;
+  if (in_regs) store_matrix();
 #else
-  const int rc = refused ? -1
-                         : xs_sbr_core(cx, &s.h, f, p.frame[ch].int_env_sf_arr, reinterpret_cast<const int16_t *>(s.noise_floor),
-                                       &s.st, x, &s.w, HQ ? nullptr : xs_lds_rand_hi, &save_lb_scale);
+  int rc = -1;
+  if (in_regs) {
+    const int usb = __builtin_amdgcn_readfirstlane((int)s.st.codec_usb);
+    int32_t m_ov = 1, m_an = 1;
+    const bool low_ov = lane < usb, low_an = (lane & 31) < usb;
+#pragma unroll
+    for (int j = 0; j < NOV; j++) m_ov |= low_ov ? fx_abs_nrm(r_ov[j]) : 0;
+#pragma unroll
+    for (int j = 0; j < NAS; j++) m_an |= low_an ? fx_abs_nrm(r_an[j]) : 0;
+    const int reserve = xs_pnorm32(cx.wave_or(m_an)), reserve_ov1 = xs_pnorm32(cx.wave_or(m_ov));
+    const XsBfp b = xs_bfp_shifts<HQ>(cx, &s.st, usb, reserve, reserve_ov1);
+    if (b.sh_ov != 0) {
+#pragma unroll
+      for (int j = 0; j < NOV; j++) r_ov[j] = low_ov ? xs_adjust_word(r_ov[j], b.sh_ov) : r_ov[j];
+    }
+    if (b.sh_main != 0) {
+#pragma unroll
+      for (int j = 0; j < NAS; j++) r_an[j] = low_an ? xs_adjust_word(r_an[j], b.sh_main) : r_an[j];
+    }
+    store_matrix();
+    save_lb_scale = b.save_lb_scale;
+    xs_wave_sync();
+    XS_T(1);
+    rc = xs_sbr_core_tail(cx, &s.h, f, p.frame[ch].int_env_sf_arr, reinterpret_cast<const int16_t *>(s.noise_floor), &s.st, x,
+                          &s.w, HQ ? nullptr : xs_lds_rand_hi, b, &pend);
+  } else if (!refused) {
+    rc = xs_sbr_core(cx, &s.h, f, p.frame[ch].int_env_sf_arr, reinterpret_cast<const int16_t *>(s.noise_floor), &s.st, x, &s.w,
+                     HQ ? nullptr : xs_lds_rand_hi, &save_lb_scale);
+  }
 #endif
   xs_wave_sync();
 #ifdef XS_PROFILE
@@ -279,6 +318,17 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
     constexpr int NW = 38 * ROWG / 64; /* runs of 64 words: (slot, part) with band = lane */
     const bool held = NB == 64 || lane < NB;
     const int lane_h = held ? lane : 0; /* every lane reads (a select, not a predicated region per word) */
+    /* env_calc.c:975-1003 on the way: the adjusted bands' slots below 32 take the shift xs_calc_sbrenvelope left pending (a
+       left count and a right count of which one is zero, per slot range) */
+    const bool adj_band = lane >= pend.b0 && lane < pend.b1;
+    const auto counts = [](int sh, int &l, int &r) {
+      sh = sh > 31 ? 31 : (sh < -31 ? -31 : sh);
+      l = sh > 0 ? sh : 0;
+      r = sh < 0 ? -sh : 0;
+    };
+    int ov_l, ov_r, mn_l, mn_r;
+    counts(pend.sh_ov, ov_l, ov_r);
+    counts(pend.sh_main, mn_l, mn_r);
 #pragma unroll
     for (int j0 = 0; j0 < NW; j0 += 8) {
       int32_t t[8];
@@ -286,7 +336,12 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
       for (int j = 0; j < 8; j++)
         if (j0 + j < NW) {
           const int row = HQ ? (j0 + j) >> 1 : j0 + j, part = HQ ? (j0 + j) & 1 : 0;
-          const int32_t v = s.x[(2 + row) * ROW + part * NB + lane_h];
+          int32_t v = s.x[(2 + row) * ROW + part * NB + lane_h];
+          if (row < 32) {
+            const int sl = row < pend.first_start ? ov_l : mn_l, sr = row < pend.first_start ? ov_r : mn_r; /* (uniform) */
+            const int32_t w = (int32_t)((uint32_t)v << sl) >> sr;
+            v = adj_band ? w : v;
+          }
           t[j] = held ? v : 0;
         }
 #pragma unroll
