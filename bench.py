@@ -554,14 +554,40 @@ def cpu_baseline_sbr(workload, seconds_budget=10.0):
     st = [ctypes.create_string_buffer(st0, len(st0)) for _ in range(workers)]
     ps = [ctypes.create_string_buffer(ps0, len(ps0)) for _ in range(workers)] if hq else None
     out = [np.zeros(per_thread * (4096 if hq else 2048), np.int16) for _ in range(workers)]
+    # ... and the core decoder's back end in front of it, as in the GPU step: one 1024-line IMDCT + overlap-add per
+    # channel-frame (the reference's ixheaacd_imdct_process through oracle/ref_harness.c, or the restatement), on the
+    # synthetic spectra the GPU leg uses.  The SBR calls keep their captured core samples: same work, two data sets
+    P32, P16, PU8, p = oracle_lib.P32, oracle_lib.P16, oracle_lib.PU8, oracle_lib._p
+    ref_imdct = kind == "reference" and hasattr(ref.lib, "ref_imdct_batch")
+    orc = None if ref_imdct else oracle_lib.load_oracle()
+    if ref_imdct:
+        ref.lib.ref_imdct_batch.restype = None
+        ref.lib.ref_imdct_batch.argtypes = [ctypes.c_int, P32, P32, P16, P16, PU8, PU8, P16]
+    rng = np.random.default_rng(0xC0FFEE)
+    spec0 = rng.integers(-(1 << 17), 1 << 17, (per_thread, 1024)).astype(np.int32)
+    spec0[:, 640:] = 0
+    ispec = [spec0.copy() for _ in range(workers)]
+    iovl = [np.zeros((per_thread, 512), np.int32) for _ in range(workers)]
+    iz16 = [np.zeros((2, per_thread), np.int16) for _ in range(workers)]
+    iseq = np.zeros(per_thread, np.uint8)
+    ishape = (np.arange(per_thread) % 2).astype(np.uint8)
+    ipcm = [np.zeros((per_thread, 1024), np.int16) for _ in range(workers)]
 
     def reset():
         for t in range(workers):
             ctypes.memmove(st[t], st0, len(st0))
             if hq:
                 ctypes.memmove(ps[t], ps0, len(ps0))
+            if ref_imdct:
+                ispec[t][:] = spec0      # the reference transforms its input in place
 
     def work(t):
+        if ref_imdct:
+            ref.lib.ref_imdct_batch(per_thread, p(ispec[t], P32), p(iovl[t], P32), p(iz16[t][0], P16), p(iz16[t][1], P16),
+                                    p(iseq, PU8), p(ishape, PU8), p(ipcm[t], P16))
+        else:
+            orc.lib.xo_imdct_batch(per_thread, p(ispec[t], P32), p(iovl[t], P32), p(iz16[t][0], P16), p(iz16[t][1], P16),
+                                   p(iseq, PU8), p(ishape, PU8), None, p(ipcm[t], P16), None, 0)
         if hq:
             fn(per_thread, hdr, frm, st[t], psf, ps[t], pin.ctypes.data, out[t].ctypes.data)
         else:
@@ -573,8 +599,9 @@ def cpu_baseline_sbr(workload, seconds_budget=10.0):
     per_frame = 1.0 if hq else 0.5     # C3 counts stereo frames: two channel calls each
     return baseline_report(workers * per_thread * per_frame / best, per_thread * per_frame / t1, workers, info, kind,
                            "%d ixheaacd_sbr_dec calls per worker per pass (one C loop per worker, buffers allocated and state "
-                           "reset outside the timed span) on the committed reference-captured frames, %d passes; SBR chain "
-                           "only, the core IMDCT is not in it" % (per_thread, passes))
+                           "reset outside the timed span) on the committed reference-captured frames, each behind one "
+                           "ixheaacd_imdct_process per channel-frame on the GPU leg's synthetic spectra (IMDCT + SBR chain, as "
+                           "the GPU step), %d passes" % (per_thread, passes))
 
 
 def cpu_baseline(seconds_budget=12.0, limiter=False):

@@ -413,69 +413,69 @@ typedef struct xaac_ctx xaac_ctx;
 
 /* Create a context bound to HIP device `device`.  `hip_stream` is a
  * hipStream_t to launch on (NULL: the context creates and owns one). */
-int32_t xaac_create(xaac_ctx **ctx, int32_t device, void *hip_stream);
-int32_t xaac_destroy(xaac_ctx *ctx);
+XAAC_API int32_t xaac_create(xaac_ctx **ctx, int32_t device, void *hip_stream);
+XAAC_API int32_t xaac_destroy(xaac_ctx *ctx);
 /* Rebind the context to another hipStream_t; NULL here means the device's
  * legacy null stream (unlike xaac_create, nothing is created). */
-int32_t xaac_set_stream(xaac_ctx *ctx, void *hip_stream);
+XAAC_API int32_t xaac_set_stream(xaac_ctx *ctx, void *hip_stream);
 /* Block until everything queued on the context's stream has finished. */
-int32_t xaac_sync(xaac_ctx *ctx);
+XAAC_API int32_t xaac_sync(xaac_ctx *ctx);
 /* Loads every kernel's code object onto the context's device now (the HIP runtime otherwise does that at a module's first launch:
    some 20 ms inside the first batch a process decodes).  Optional; no reference counterpart. */
-int32_t xaac_warm_up(xaac_ctx *ctx);
+XAAC_API int32_t xaac_warm_up(xaac_ctx *ctx);
 
 /* Enqueue one IMDCT + overlap-add pass over the batch (asynchronous). */
-int32_t xaac_imdct_process_batch(xaac_ctx *ctx, const xaac_imdct_batch *batch);
+XAAC_API int32_t xaac_imdct_process_batch(xaac_ctx *ctx, const xaac_imdct_batch *batch);
 /* Same with host buffers: copies in, runs, copies the outputs and state back,
  * synchronises.  PCIe-inclusive convenience path. */
-int32_t xaac_imdct_process_batch_host(xaac_ctx *ctx, const xaac_imdct_batch *batch);
+XAAC_API int32_t xaac_imdct_process_batch_host(xaac_ctx *ctx, const xaac_imdct_batch *batch);
 /* ixheaacd_imdct_process with ics->frame_length == 960 (the 960-line profile of DAB+ / DRM: ixheaacd_mdct_960 and eight
  * ixheaacd_inverse_transform_960, decoder/ixheaacd_aac_imdct.c:1672 / :1624, the 960- and 120-sample windows, the 960
  * branches of lpfuncs.c:347-802).  The same descriptor with 960 for 1024 and 480 for 512: spec [n_ch][960], overlap
  * [n_ch][480], out32 / pcm16 [n_ch * 960] interleaved at ch_fac; pcm16 is the plain hand-off of pcm_mode per sample. */
-int32_t xaac_imdct960_process_batch(xaac_ctx *ctx, const xaac_imdct_batch *batch);
+XAAC_API int32_t xaac_imdct960_process_batch(xaac_ctx *ctx, const xaac_imdct_batch *batch);
 /* ixheaacd_imdct_process for AAC-LD / AAC-ELD frames (512 or 480 lines), device pointers, asynchronous */
-int32_t xaac_imdct_ld_process_batch(xaac_ctx *ctx, const xaac_imdct_ld_batch *batch);
+XAAC_API int32_t xaac_imdct_ld_process_batch(xaac_ctx *ctx, const xaac_imdct_ld_batch *batch);
 
 /* SBR QMF banks, device pointers, asynchronous on the context's stream. */
-int32_t xaac_qmf_analysis_batch(xaac_ctx *ctx, const xaac_qmf_ana_batch *batch);
-int32_t xaac_qmf_synthesis_batch(xaac_ctx *ctx, const xaac_qmf_syn_batch *batch);
+XAAC_API int32_t xaac_qmf_analysis_batch(xaac_ctx *ctx, const xaac_qmf_ana_batch *batch);
+XAAC_API int32_t xaac_qmf_synthesis_batch(xaac_ctx *ctx, const xaac_qmf_syn_batch *batch);
 
 /* USAC FD IMDCT + windowing + overlap-add, device pointers, asynchronous on the context's stream. */
-int32_t xaac_usac_imdct_process_batch(xaac_ctx *ctx, const xaac_usac_imdct_batch *batch);
+XAAC_API int32_t xaac_usac_imdct_process_batch(xaac_ctx *ctx, const xaac_usac_imdct_batch *batch);
 
 /* eSBR (Path A) QMF banks, device pointers, asynchronous on the context's stream. */
-int32_t xaac_esbr_qmf_analysis_batch(xaac_ctx *ctx, const xaac_esbr_ana_batch *batch);
+XAAC_API int32_t xaac_esbr_qmf_analysis_batch(xaac_ctx *ctx, const xaac_esbr_ana_batch *batch);
 /* ixheaacd_cplx_anal_qmffilt for AAC-LD / ELD cores (complex bank, 16 or 15 slots per frame) */
-int32_t xaac_qmf_analysis_eld_batch(xaac_ctx *ctx, const xaac_qmf_ana_eld_batch *batch);
+XAAC_API int32_t xaac_qmf_analysis_eld_batch(xaac_ctx *ctx, const xaac_qmf_ana_eld_batch *batch);
 /* ixheaacd_cplx_synt_qmffilt for AAC-LD / ELD (complex bank, 64 channels, 16 or 15 slots per frame) */
-int32_t xaac_qmf_synthesis_eld_batch(xaac_ctx *ctx, const xaac_qmf_syn_eld_batch *batch);
-int32_t xaac_esbr_qmf_synthesis_batch(xaac_ctx *ctx, const xaac_esbr_syn_batch *batch);
+XAAC_API int32_t xaac_qmf_synthesis_eld_batch(xaac_ctx *ctx, const xaac_qmf_syn_eld_batch *batch);
+XAAC_API int32_t xaac_esbr_qmf_synthesis_batch(xaac_ctx *ctx, const xaac_esbr_syn_batch *batch);
 
 /* Low-power SBR channel-frames (QMF analysis -> HF generation + envelope adjustment -> QMF synthesis). */
-uint64_t xaac_sbr_lp_workspace_bytes(int32_t n_ch);
-int32_t xaac_sbr_lp_process_batch(xaac_ctx *ctx, const xaac_sbr_lp_batch *batch);
+XAAC_API uint64_t xaac_sbr_lp_workspace_bytes(int32_t n_ch);
+XAAC_API int32_t xaac_sbr_lp_process_batch(xaac_ctx *ctx, const xaac_sbr_lp_batch *batch);
 
 /* HQ SBR stream-frames (complex QMF analysis -> LPP transposer + envelope adjustment -> [parametric
  * stereo] -> complex QMF synthesis, once per output channel). */
-uint64_t xaac_sbr_hq_workspace_bytes(int32_t n_ch, int32_t with_ps);
-int32_t xaac_sbr_hq_process_batch(xaac_ctx *ctx, const xaac_sbr_hq_batch *batch);
+XAAC_API uint64_t xaac_sbr_hq_workspace_bytes(int32_t n_ch, int32_t with_ps);
+XAAC_API int32_t xaac_sbr_hq_process_batch(xaac_ctx *ctx, const xaac_sbr_hq_batch *batch);
 
 /* Channel-configuration hand-overs (device pointers, asynchronous). */
-int32_t xaac_sbr_state_handover(xaac_ctx *ctx, const xaac_sbr_handover_batch *batch);
-int32_t xaac_sbr_state_apply_side_batch(xaac_ctx *ctx, const xaac_sbr_apply_side_batch *batch);
+XAAC_API int32_t xaac_sbr_state_handover(xaac_ctx *ctx, const xaac_sbr_handover_batch *batch);
+XAAC_API int32_t xaac_sbr_state_apply_side_batch(xaac_ctx *ctx, const xaac_sbr_apply_side_batch *batch);
 
 /* ixheaacd_peak_limiter_init (peak_limiter.c:46-77) on a host-side state; returns the limiter delay in
  * samples (attack_time_samples) or a fatal code when the rate / channel count does not fit the struct. */
-int32_t xaac_peak_limiter_init(xaac_limiter_state *state, uint32_t num_channels, uint32_t sample_rate);
+XAAC_API int32_t xaac_peak_limiter_init(xaac_limiter_state *state, uint32_t num_channels, uint32_t sample_rate);
 /* One frame of every stream through the limiter (device pointers, asynchronous). */
-uint64_t xaac_peak_limiter_workspace_bytes(int32_t n_streams);
-int32_t xaac_peak_limiter_process_batch(xaac_ctx *ctx, const xaac_limiter_batch *batch);
+XAAC_API uint64_t xaac_peak_limiter_workspace_bytes(int32_t n_streams);
+XAAC_API int32_t xaac_peak_limiter_process_batch(xaac_ctx *ctx, const xaac_limiter_batch *batch);
 
 /* Launch geometry the library used for the last batch (for reports). */
-int32_t xaac_last_launch(xaac_ctx *ctx, int32_t *grid, int32_t *block, int32_t *lds_bytes);
+XAAC_API int32_t xaac_last_launch(xaac_ctx *ctx, int32_t *grid, int32_t *block, int32_t *lds_bytes);
 /* "libxaac_amd <version> gfx950" */
-const char *xaac_version(void);
+XAAC_API const char *xaac_version(void);
 
 #ifdef __cplusplus
 }

@@ -120,14 +120,14 @@ typedef struct xaac_esbr_pcm_out_batch {
 #ifdef __cplusplus
 extern "C" {
 #endif
-int32_t xaac_esbr_core_from_pcm16_batch(xaac_ctx *ctx, const xaac_esbr_core_in_batch *batch);
-int32_t xaac_esbr_pcm16_from_float_batch(xaac_ctx *ctx, const xaac_esbr_pcm_out_batch *batch);
+XAAC_API int32_t xaac_esbr_core_from_pcm16_batch(xaac_ctx *ctx, const xaac_esbr_core_in_batch *batch);
+XAAC_API int32_t xaac_esbr_pcm16_from_float_batch(xaac_ctx *ctx, const xaac_esbr_pcm_out_batch *batch);
 /* One frame of every channel through the Path A branch of ixheaacd_sbr_dec (mono / stereo channels; with ps_* set:
  * HE-AACv2 streams, ixheaacd_esbr_apply_ps ps_dec_flt.c:389 between regrouping and the two synthesis banks):
  * history shift (sbr_dec.c:835-857), ixheaacd_esbr_analysis_filt_block, ixheaacd_generate_hf (sbrdec_lpfuncs.c:981),
  * ixheaacd_sbr_env_calc (esbr_envcal.c:71), ixheaacd_esbr_synthesis_regrp + the synthesis bank (sbr_dec.c:297 / :447). */
-uint64_t xaac_esbr_workspace_bytes(int32_t n_ch);
-int32_t xaac_esbr_sbr_process_batch(xaac_ctx *ctx, const xaac_esbr_sbr_batch *batch);
+XAAC_API uint64_t xaac_esbr_workspace_bytes(int32_t n_ch);
+XAAC_API int32_t xaac_esbr_sbr_process_batch(xaac_ctx *ctx, const xaac_esbr_sbr_batch *batch);
 #ifdef __cplusplus
 }
 #endif

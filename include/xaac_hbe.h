@@ -93,19 +93,19 @@ extern "C" {
 #endif
 
 /* ixheaacd_real_synth_filt for n_ch channels: one frame's QMF columns -> synth_size real samples per column */
-int32_t xaac_hbe_real_synth_batch(xaac_ctx *ctx, const xaac_hbe_synth_batch *batch);
+XAAC_API int32_t xaac_hbe_real_synth_batch(xaac_ctx *ctx, const xaac_hbe_synth_batch *batch);
 /* ixheaacd_complex_anal_filt for n_ch channels: no_bins / 2 columns of 2 * synth_size complex sub-band samples */
-int32_t xaac_hbe_cplx_anal_batch(xaac_ctx *ctx, const xaac_hbe_anal_batch *batch);
+XAAC_API int32_t xaac_hbe_cplx_anal_batch(xaac_ctx *ctx, const xaac_hbe_anal_batch *batch);
 
 /* ixheaacd_dft_hbe_cplx_anal_filt (esbr_polyphase.c:276-338) for n_ch channels */
-int32_t xaac_hbe_dft_anal_batch_run(xaac_ctx *ctx, const xaac_hbe_dft_anal_batch *batch);
+XAAC_API int32_t xaac_hbe_dft_anal_batch_run(xaac_ctx *ctx, const xaac_hbe_dft_anal_batch *batch);
 
 /* ixheaacd_qmf_hbe_apply (hbe_trans.c:224-296) for n_ch channels: time-signal shift, synthesis bank, analysis bank,
    stretch-by-2/3/4 products into qmf_out_buf (with the pitch-adaptive cross products when pitch_in_bins / 12 >= 1),
    rotation of the frame's 32 output rows into pv_re / pv_im.  fft_ready mirrors whether the reference's transposer has its FFT
    pointers: while it has not (a new stream; always for synth_size 20, whose case sets none, hbe_trans.c:159-164) the
    reference re-initialises on every call and so clears both delay lines first (:240-248, :124, :174). */
-int32_t xaac_hbe_apply_batch(xaac_ctx *ctx, const xaac_hbe_apply_batch_desc *batch);
+XAAC_API int32_t xaac_hbe_apply_batch(xaac_ctx *ctx, const xaac_hbe_apply_batch_desc *batch);
 
 #ifdef __cplusplus
 }

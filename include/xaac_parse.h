@@ -82,39 +82,39 @@ typedef struct xaac_sbr_side {
 
 typedef struct xaac_parser xaac_parser;
 
-int32_t xaac_parser_create(xaac_parser **p);
-void xaac_parser_destroy(xaac_parser *p);
+XAAC_API int32_t xaac_parser_create(xaac_parser **p);
+XAAC_API void xaac_parser_destroy(xaac_parser *p);
 
 /* The ADTS header at data[0 .. n): XAAC_PARSE_OK, _NEED_DATA (n < 7 / 9), _ERR_SYNC or _ERR_HEADER. */
-int32_t xaac_adts_parse_header(const uint8_t *data, size_t n, xaac_adts_header *h);
+XAAC_API int32_t xaac_adts_parse_header(const uint8_t *data, size_t n, xaac_adts_header *h);
 
 /* Decodes the ADTS frame at data[0 .. n) (one raw_data_block) into `out`.  stage 2: spectra as the IMDCT takes them;
    stage 1: as they are before the M/S, intensity, PNS and TNS tools (the entry of ixheaacd_channel_pair_process).
    *consumed = the frame's length.  The parser keeps what outlives a frame (PNS random seed, SBR / PS decoding state). */
-int32_t xaac_parse_adts_frame(xaac_parser *p, const uint8_t *data, size_t n, int32_t stage, xaac_core_frame *out,
+XAAC_API int32_t xaac_parse_adts_frame(xaac_parser *p, const uint8_t *data, size_t n, int32_t stage, xaac_core_frame *out,
                               size_t *consumed);
 
 /* The SBR / PS side info of the frame xaac_parse_adts_frame decoded last (its payload is in the parser; a frame without
    one counts as a frame whose SBR data is missing, as in the reference).  ps_enable: parametric stereo allowed (mono
    streams).  The first call fixes the stream's SBR configuration (output rate = twice the core rate).  Returns
    XAAC_PARSE_OK, or XAAC_PARSE_ERR_SYNTAX where the reference returns a fatal error from ixheaacd_applysbr. */
-int32_t xaac_parse_sbr_side(xaac_parser *p, int32_t ps_enable, xaac_sbr_side *side);
+XAAC_API int32_t xaac_parse_sbr_side(xaac_parser *p, int32_t ps_enable, xaac_sbr_side *side);
 
 /* The reference's default interpretation of the SBR payload (-esbr:1, "Path A": decoder/ixheaacd_sbrdecoder.c:479-493 the
    payload runs one frame late; the ENHSBR extension element with patching mode / pitch, env_extr.c:595-714; scale factors
    and noise floors handed to the float tools, env_dec.c:52-72, :586-626) instead of the -esbr:0 one.  To be chosen before
    the stream's first xaac_parse_sbr_side call; esbr 0 / 1. */
-int32_t xaac_parser_set_esbr(xaac_parser *p, int32_t esbr);
+XAAC_API int32_t xaac_parser_set_esbr(xaac_parser *p, int32_t esbr);
 /* ... and for such a stream, after xaac_parse_sbr_side: the xaac_esbr_side of channel 0 / 1 of the frame (what
    xaac_esbr_sbr_process_batch takes beside header and frame) */
-int32_t xaac_parse_esbr_side(xaac_parser *p, int32_t channel, xaac_esbr_side *side);
+XAAC_API int32_t xaac_parse_esbr_side(xaac_parser *p, int32_t channel, xaac_esbr_side *side);
 /* ... and for a frame with side.reset: the pitch_in_bins that ixheaacd_sbr_dec_reset hands to its two transposer runs (the
    first channel's, from the payload before this frame's: sbrdecoder.c:547-550) */
-int32_t xaac_parse_reset_pitch(xaac_parser *p, int32_t *pitch_in_bins);
+XAAC_API int32_t xaac_parse_reset_pitch(xaac_parser *p, int32_t *pitch_in_bins);
 
 /* The inverse quantiser of spectral magnitudes, |q|^(4/3) in Q13, exactly as the reference computes it (table up to 128, its
    linear interpolation beyond, decoder/ixheaacd_channel.c:1055-1093; _ERR_ESCAPE past 8191 + 32).  Exposed for tests. */
-int32_t xaac_inverse_quant(int32_t magnitude, int32_t *out);
+XAAC_API int32_t xaac_inverse_quant(int32_t magnitude, int32_t *out);
 
 /* ---- one frame of N streams at once ----------------------------------------------------------------------------------
  * What a batched host runs per step: every stream's next ADTS frame parsed (core, and SBR / PS side info when with_sbr)
@@ -162,7 +162,7 @@ typedef struct xaac_parse_batch {
 } xaac_parse_batch;
 
 /* returns the number of streams whose status is XAAC_PARSE_OK, or a negative XAAC_PARSE_ERR_* for a bad descriptor */
-int32_t xaac_parse_batch_run(const xaac_parse_batch *b);
+XAAC_API int32_t xaac_parse_batch_run(const xaac_parse_batch *b);
 /* The same call in two halves, for a host whose calling thread has other work meanwhile (queueing the copies and launches
    of the step before): _start hands the batch to the worker team (all `threads` of them team threads: the caller does not
    parse along) and returns at once; _wait blocks until every stream is parsed and returns what _run would have.  The
@@ -170,22 +170,22 @@ int32_t xaac_parse_batch_run(const xaac_parse_batch *b);
    every _start needs its _wait (on any thread) before the next _start or _run gets the team; _wait without a _start returns
    XAAC_PARSE_ERR_SYNTAX.  busy_seconds (optional): how long the team parsed, from _start until its last thread ran out of
    streams -- what the caller overlapped, or waited for. */
-int32_t xaac_parse_batch_start(const xaac_parse_batch *b);
-int32_t xaac_parse_batch_wait(double *busy_seconds);
+XAAC_API int32_t xaac_parse_batch_start(const xaac_parse_batch *b);
+XAAC_API int32_t xaac_parse_batch_wait(double *busy_seconds);
 
 /* ---- the states of a new stream, and the frame-level state changes of ixheaacd_applysbr -------------------------------
  * Host-side helpers on HOST copies of the boundary structs (the host writes them to the device once per stream, and on
  * the rare frames with side->reset / side->upsampling reads the stream's state back, applies the change, writes it again). */
 /* ixheaacd_init_sbr for one channel: decoder/ixheaacd_sbrdec_initfuncs.c:1133-1135 (bank scales), :1235-1238 (scale
    factors), :870-898 (envelope calculator, previous-frame data) */
-void xaac_sbr_state_init(xaac_sbr_state *s);
+XAAC_API void xaac_sbr_state_init(xaac_sbr_state *s);
 /* ... and the parametric stereo tool with the right channel's bank: :1050-1059 */
-void xaac_ps_state_init(xaac_ps_state *s);
+XAAC_API void xaac_ps_state_init(xaac_ps_state *s);
 /* the Path A (-esbr:1) states of a new stream: zeros but esbr_start_up = 1 (sbrdec_initfuncs.c:1018) and the PS mixing
    matrix's h11 / h12 real parts = 1.0 (ps_dec_flt.c:349-352); the transposer's parameters are zero until the first reset */
-void xaac_esbr_state_init(xaac_esbr_state *s);
-void xaac_esbr_ps_state_init(xaac_esbr_ps_state *s);
-void xaac_hbe_state_init(xaac_hbe_state *s);
+XAAC_API void xaac_esbr_state_init(xaac_esbr_state *s);
+XAAC_API void xaac_esbr_ps_state_init(xaac_esbr_ps_state *s);
+XAAC_API void xaac_hbe_state_init(xaac_hbe_state *s);
 /* ixheaacd_qmf_hbe_data_reinit (decoder/ixheaacd_hbe_trans.c:102-222) as ixheaacd_sbr_dec_reset calls it for a 2:1 stream
    with 1024-line core frames: the bank size, first band, band range and cross-over bands of the QMF transposer from the
    header's band tables; clears the two banks' delay lines.  `s` is the channel's state as it is (a new stream's, or the one a
@@ -193,18 +193,18 @@ void xaac_hbe_state_init(xaac_hbe_state *s);
    -1 where the reference returns an error.
    (The reset's two transposer runs over the rows the channel holds, sbrdecoder.c:196-236, are the caller's:
    xaac_hbe_apply_batch on the device-resident state.) */
-int32_t xaac_hbe_state_reinit(xaac_hbe_state *s, const xaac_sbr_header *header);
+XAAC_API int32_t xaac_hbe_state_reinit(xaac_hbe_state *s, const xaac_sbr_header *header);
 /* ... for n channels at once, on the states' integer tails alone (everything from synth_size on: the members the re-initialisation
    computes; a batched host keeps them beside the device-resident states and clears the two delay lines on the device):
    tails [n][XAAC_HBE_TAIL_BYTES] in / out, headers [n].  Returns -1, or the index of the first channel whose band tables the
    reference would refuse (the tails behind it are left as they were). */
 #define XAAC_HBE_TAIL_BYTES (sizeof(xaac_hbe_state) - offsetof(xaac_hbe_state, synth_size))
-int32_t xaac_hbe_state_reinit_tails(uint8_t *tails, const xaac_sbr_header *headers, int32_t n);
+XAAC_API int32_t xaac_hbe_state_reinit_tails(uint8_t *tails, const xaac_sbr_header *headers, int32_t n);
 /* what ixheaacd_sbr_dec_reset (sbrdecoder.c:103-252) and ixheaacd_prepare_upsamp (:254-276) do to one channel's state
    for this frame's side info; channel = 0 or 1 (no-op beyond side->reset_channels / for frames without either) */
-void xaac_sbr_state_apply_side(xaac_sbr_state *s, const xaac_sbr_side *side, int32_t channel);
+XAAC_API void xaac_sbr_state_apply_side(xaac_sbr_state *s, const xaac_sbr_side *side, int32_t channel);
 /* the same for the right channel's synthesis bank kept in the PS state (channel 1 of a mono + PS stream) */
-void xaac_ps_state_apply_side(xaac_ps_state *s, const xaac_sbr_side *side);
+XAAC_API void xaac_ps_state_apply_side(xaac_ps_state *s, const xaac_sbr_side *side);
 
 #ifdef __cplusplus
 }

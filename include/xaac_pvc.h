@@ -62,7 +62,7 @@ typedef struct xaac_pvc_batch {
 extern "C" {
 #endif
 
-int32_t xaac_pvc_process_batch(xaac_ctx *ctx, const xaac_pvc_batch *batch);
+XAAC_API int32_t xaac_pvc_process_batch(xaac_ctx *ctx, const xaac_pvc_batch *batch);
 
 #ifdef __cplusplus
 }

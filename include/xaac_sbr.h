@@ -11,6 +11,12 @@
 
 #include <stdint.h>
 
+/* The libraries are built with -fvisibility=hidden: the functions these headers declare are everything they export
+   (tests/test_abi.py compares `nm -D` with the declarations). */
+#ifndef XAAC_API
+#define XAAC_API __attribute__((visibility("default")))
+#endif
+
 #define XAAC_SBR_MAX_ENVELOPES 8       /* MAX_ENVELOPES, decoder/ixheaacd_sbrdecsettings.h:50 */
 #define XAAC_SBR_MAX_NOISE_ENVELOPES 2
 #define XAAC_SBR_MAX_FREQ_COEFFS 56

@@ -36,6 +36,21 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
 
 
+def _exported(path):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    return sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+
+
+def test_libraries_export_nothing_but_the_declared_symbols():
+    """-fvisibility=hidden + XAAC_API (and libxaac_amd/csrc/exports.map for what the HIP front end forces visible): the
+    dynamic symbol tables are the headers' function lists, no launch helpers, kernel handles or C++ names beside them"""
+    from libxaac_amd import decoder
+    libxaac_amd.load_library()
+    decoder.load_host_library()
+    assert _exported(libxaac_amd.library_path()) == _declared_functions()
+    assert _exported(decoder.host_library_path()) == _declared_functions(host=True)
+
+
 def test_host_library_exports_every_declared_symbol():
     """include/xaac_parse.h <-> libxaac_amd/libxaac_host.so (CPU only: loads and parses without a GPU)"""
     from libxaac_amd import decoder
