@@ -57,6 +57,13 @@ __shared__ int32_t xs_lds_new_bw[16];
 #include "sbr_core.h"
 #include "sbr_core_kernel.h"
 
+#ifndef XS_STAGGER_G
+#define XS_STAGGER_G 64     /* wave groups of the persistent launch's staggered start (1: none) */
+#endif
+#ifndef XS_STAGGER_SLEEP
+#define XS_STAGGER_SLEEP 16 /* x 64 cycles between neighbouring groups */
+#endif
+
 namespace {
 
 __device__ __forceinline__ void xs_wave_sync() { /* = XsCx::sync() */
@@ -415,6 +422,18 @@ __global__ __launch_bounds__(64 * WAVES) void xaac_sbr_core_kernel(XaacSbrCorePa
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   stage_tables<HQ, 64 * WAVES>(threadIdx.x);
   __syncthreads();
+  /* Staggered start (persistent launch only).  The resident waves all start together and a channel-frame takes every wave
+     about the same time, so their copy phases -- 13 KB in, 22 KB out per channel-frame -- come as chip-wide bursts: for those
+     microseconds the memory system runs at its limit and nothing computes, then everything computes and the memory system
+     idles (phase timers: copy-in + copy-out = 24 % of a wave's life for 2 % of its instructions).  Wave group g of
+     XS_STAGGER_G starts g x XS_STAGGER_SLEEP x 64 cycles late (64 groups x 0.43 us: the last one 27 us behind the first, two
+     thirds of a channel-frame's time), which spreads the phases for the launch's four rounds; the work counter evens out
+     what the late starters do not get to.  Measured on one box (profiles/r05_b_stagger.txt): none 189.7 us; 2 groups x 6.8 us
+     187; 4 x 3.4 us 181.6; 8 x 3.4 us 175.7; 32 x 0.85 us 175.3; 64 x 0.43 us 172.8; 8 x 6.8 us 186; 16 x 3.4 us 185. */
+  if (XS_STAGGER_G > 1 && p.work_counter && p.n_ch >= 3 * (int)gridDim.x * WAVES) { /* (a small batch has no second round to gain in) */
+    const int g = ((int)blockIdx.x * WAVES + wave) % XS_STAGGER_G;
+    for (int t = 0; t < g; t++) __builtin_amdgcn_s_sleep(XS_STAGGER_SLEEP);
+  }
   for (bool first = true;; first = false) { /* one call site: one copy of the core in the kernel's code */
     int ch = 0;
     if (p.work_counter) {

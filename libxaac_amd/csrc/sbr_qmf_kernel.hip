@@ -550,6 +550,13 @@ __device__ __forceinline__ int32_t clamp_med3(int32_t a, int32_t lo, int32_t hi)
 typedef short xq_short2 __attribute__((ext_vector_type(2)));
 }  // namespace
 
+#ifndef XQ_STAGGER_G
+#define XQ_STAGGER_G 64
+#define XQ_STAGGER_SLEEP 4    /* x 64 cycles */
+#endif
+#ifndef XQ_STAGGER_FIRST
+#define XQ_STAGGER_FIRST 1536 /* six workgroups per CU: the ones that start together */
+#endif
 __global__ __launch_bounds__(128) void xaac_qmf_synthesis_pair_kernel(XaacQmfSynPairParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = 65;          /* padded LDS row stride (dwords) of tiles and pair rows */
@@ -565,6 +572,10 @@ __global__ __launch_bounds__(128) void xaac_qmf_synthesis_pair_kernel(XaacQmfSyn
   int32_t *E = reinterpret_cast<int32_t *>(smem); /* [2][EROWS][RS], aliases the tiles once they are dead */
   const int lch = lane >> 5, lrow = lane & 31; /* the lane's (channel, slot) */
   const int i = blockIdx.x;
+  /* staggered start, as in the SBR core kernel (sbr_core_kernel.hip): the workgroups the chip takes at once begin with 32 KB
+     of row loads each; spread over 6.6 us (64 groups x 0.1 us) their bursts do not meet.  112.5 -> 109.3 us. */
+  if (XQ_STAGGER_G > 1 && i < XQ_STAGGER_FIRST && (int)gridDim.x >= 3 * XQ_STAGGER_FIRST)
+    for (int t = 0; t < i % XQ_STAGGER_G; t++) __builtin_amdgcn_s_sleep(XQ_STAGGER_SLEEP);
   const int inactive0 = __builtin_amdgcn_readfirstlane(p.scale[0][8 * (size_t)i + 6]);
   const int inactive1 = __builtin_amdgcn_readfirstlane(p.scale[1][8 * (size_t)i + 6]);
   /* this wave's channel for history / state: channel w */
