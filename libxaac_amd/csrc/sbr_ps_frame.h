@@ -41,6 +41,7 @@
 #define XP_T(i) /* optional phase timer hook (tools/prof_sbr_core.py ps) */
 #endif
 
+#define XP_NO_PS_SCALE 0x7fffffff
 #define XP_MAX_SEG (XAAC_PS_MAX_ENV + 2) /* the segment carried in from the last frame + one per border (env 0..5) */
 
 #if defined(__HIPCC__)
@@ -147,7 +148,8 @@ FX_HD int32_t xp_bin_power_hyb(const XpTables *T, int bin, const int32_t *re, co
    lb/ov_lb/hb_scale, st_syn, lsb, usb: what the SBR core left for the synthesis bank.  Returns ps_scale. */
 template <class PS>
 FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_frame *pf, XpFrameWork *w, int32_t *xl,
-                      int32_t *xr, int lb_scale, int ov_lb_scale, int hb_scale, int st_syn, int lsb, int usb) {
+                      int32_t *xr, int lb_scale, int ov_lb_scale, int hb_scale, int st_syn, int lsb, int usb,
+                      int ps_scale_done = XP_NO_PS_SCALE) {
 #if defined(__HIP_DEVICE_COMPILE__)
   /* The matrix rows this frame reads before anything rewrites them, fetched now: P1's look-ahead words of QMF bands
      0..2 (lane = slot) and P3's 32 slots of the lane's band.  Issued ahead of the state rescale and the hybrid
@@ -167,7 +169,9 @@ FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_f
     }
   }
 #endif
-  const int ps_scale = xp_init_ps_scale(cx, ps, lb_scale, ov_lb_scale, hb_scale); /* sbr_dec.c:1252 */
+  /* sbr_dec.c:1252.  The GPU kernel has been through it already, on the state words in registers on their way into LDS
+     (sbr_ps_kernel.hip: xp_init_ps_scale_regs), and hands the result in */
+  const int ps_scale = ps_scale_done != XP_NO_PS_SCALE ? ps_scale_done : xp_init_ps_scale(cx, ps, lb_scale, ov_lb_scale, hb_scale);
   const int ov_lb_shift = ps_scale - ov_lb_scale, lb_shift = ps_scale - lb_scale, hb_shift = ps_scale - hb_scale;
   const int common_shift = (st_syn - ps_scale) - 8;
   XP_T(1);

@@ -86,6 +86,75 @@ __device__ __forceinline__ void copy_words(int32_t *dst, const int32_t *src, int
   }
 }
 
+/* xp_init_ps_scale (sbr_ps.h; ps_dec.c:134-210, thumb_ps_dec.c:101) on the state's words while they are in registers between
+   global memory and LDS: word w of the head is in rs[w / 64] of lane w % 64.  Headroom of the delay lines (16-bit pairs) and the
+   hybrid filter history (32-bit), the scale that follows from it and the core's three scales, and the shift applied to every
+   member xp_scale_states names -- as passes over the LDS copy (2-byte accesses) this was an eighth of the kernel.  Which
+   words: ser[j][i][6..45] for j < sample_ser[i], ap[m][6..45], ld, sd[0..57], sub, sub_ser (pairs); peak_decay_diff /
+   energy_prev / peak_decay_diff_prev (32-bit, twice the shift, not in the headroom); hyb_buf (32-bit). */
+template <int NS>
+__device__ __forceinline__ int xp_init_ps_scale_regs(const XsCx &cx, int32_t (&rs)[NS], int lb_scale, int ov_lb_scale, int hb_scale) {
+  constexpr int W_AP = offsetof(XpLdsState, ap) / 4, W_LD = offsetof(XpLdsState, ld) / 4, W_SD = offsetof(XpLdsState, sd) / 4;
+  constexpr int W_SUB = offsetof(XpLdsState, sub) / 4, W_IDX = offsetof(XpLdsState, idx_ser) / 4;
+  constexpr int W_PK = offsetof(XpLdsState, peak_decay_diff) / 4, W_HYB = offsetof(XpLdsState, hyb_buf) / 4;
+  constexpr int W_H = offsetof(XpLdsState, h11_h12_vec) / 4, W_DBS = offsetof(XpLdsState, delay_buffer_scale) / 4;
+  static_assert(offsetof(XpLdsState, ser) == 0 && W_AP == 480 && W_LD == W_AP + 64 && W_SD == W_LD + 168 && W_SUB == W_SD + 32, "layout");
+  static_assert(W_IDX == W_SUB + 32 + 240 && offsetof(XpLdsState, sample_ser) == 4 * W_IDX + 6 && W_PK == W_IDX + 4, "layout");
+  static_assert(W_HYB == W_PK + 60 && W_H == W_HYB + 72 && offsetof(XpLdsState, delay_buffer_scale) % 4 == 0 && W_DBS < 64 * NS, "layout");
+  const auto word_of = [&](int w) { return __builtin_amdgcn_readlane(rs[w / 64], w % 64); }; /* w: a constant */
+  /* sample_ser[0] is the high half of word W_IDX + 1, [1] and [2] are word W_IDX + 2 */
+  const int ss0 = word_of(W_IDX + 1) >> 16, ss1 = (int16_t)word_of(W_IDX + 2), ss2 = word_of(W_IDX + 2) >> 16;
+  const auto is_pair = [&](int w) -> bool { /* a pair of 16-bit delay-line samples that takes part */
+    const int k = w & 31, blk = w >> 5;
+    const bool mid = k >= 3 && k <= 22; /* elements 6..45 of a row of 64 */
+    if (w < W_AP) {
+      const int i = blk % 3, j = blk / 3;
+      return mid && j < (i == 0 ? ss0 : (i == 1 ? ss1 : ss2));
+    }
+    if (w < W_LD) return mid;
+    if (w < W_SD + 29) return true;
+    if (w < W_SUB) return false;
+    return w < W_IDX;
+  };
+  int32_t m16 = 0, m32 = 0;
+#pragma unroll
+  for (int j = 0; j < NS; j++) {
+    const int w = cx.lane + 64 * j;
+    const int32_t v = rs[j], lo = (int16_t)v, hi = v >> 16;
+    m16 |= is_pair(w) ? (fx_abs_nrm(lo) | fx_abs_nrm(hi)) : 0;
+    if (64 * j + 63 >= W_HYB && 64 * j < W_H) m32 |= (w >= W_HYB && w < W_H) ? fx_abs_nrm(v) : 0;
+  }
+  const int reserve = xs_pnorm32(cx.wave_or((int32_t)((uint32_t)m16 << 16) | m32));
+  const int dbs = (int16_t)((int16_t)word_of(W_DBS) + reserve);
+  int16_t t = (int16_t)(lb_scale < ov_lb_scale ? lb_scale : ov_lb_scale);
+  if (hb_scale < t) t = (int16_t)hb_scale;
+  if (dbs < t) t = (int16_t)dbs;
+  const int ps_scale = t - 1;
+  const int scale = (int16_t)((ps_scale - dbs) + reserve);
+  if (scale != 0) { /* (uniform) */
+    const int l16 = scale > 0 ? (scale > 15 ? 15 : scale) : 0, r16 = scale < 0 ? (-scale > 31 ? 31 : -scale) : 0;
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+      const int w = cx.lane + 64 * j;
+      const int32_t v = rs[j];
+      if (64 * j < W_IDX) { /* xp_scale16 on both halves: left saturating, right arithmetic; one of the counts is 0 */
+        const int32_t lo = (int16_t)v, hi = v >> 16;
+        const int16_t a = fx_sat16(xs_shl(lo, l16) >> r16), b = fx_sat16(xs_shl(hi, l16) >> r16);
+        rs[j] = is_pair(w) ? (int32_t)xp_pack16(a, b) : v;
+      }
+      if (64 * j + 63 >= W_PK && 64 * j < W_H) { /* xp_scale32: the detector's three arrays by 2 x scale, the filter history by scale */
+        const bool pk = w >= W_PK && w < W_HYB, hy = w >= W_HYB && w < W_H;
+        const int sc = pk ? 2 * scale : scale;
+        const int32_t r = sc > 0 ? fx_shl_sat(rs[j], sc) : fx_shr(rs[j], -sc);
+        rs[j] = (pk || hy) ? r : rs[j];
+      }
+    }
+  }
+  /* ps->delay_buffer_scale = ps_scale: the low half of word W_DBS */
+  if (cx.lane == W_DBS % 64) rs[W_DBS / 64] = (int32_t)((uint32_t)rs[W_DBS / 64] & 0xffff0000u) | (uint16_t)(int16_t)ps_scale;
+  return ps_scale;
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(64 * kPsWaves, XP_WAVES_PER_EU) void xaac_ps_kernel(XaacPsParams p) {
@@ -126,6 +195,10 @@ __global__ __launch_bounds__(64 * kPsWaves, XP_WAVES_PER_EU) void xaac_ps_kernel
       }
       continue;
     }
+    const int lb_scale = __builtin_amdgcn_readlane(par_v, 0), ov_lb_scale = __builtin_amdgcn_readlane(par_v, 1);
+    const int hb_scale = __builtin_amdgcn_readlane(par_v, 2), st_syn = __builtin_amdgcn_readlane(par_v, 3);
+    const int lsb = __builtin_amdgcn_readlane(par_v, 4), usb = __builtin_amdgcn_readlane(par_v, 5);
+    const int ps_scale_done = xp_init_ps_scale_regs<NS>(cx, rs, lb_scale, ov_lb_scale, hb_scale);
     xp_wave_sync(); /* the previous stream's state has left the LDS copy */
 #pragma unroll
     for (int j = 0; j < NS; j++)
@@ -138,11 +211,8 @@ __global__ __launch_bounds__(64 * kPsWaves, XP_WAVES_PER_EU) void xaac_ps_kernel
     if (threadIdx.x == 0) xp_prof_last = clock64();
 #endif
     const int ps_clamped = xp_frame_sanitize(cx, &s.pf); /* indices a parser cannot produce: contained, reported */
-    const int lb_scale = __builtin_amdgcn_readlane(par_v, 0), ov_lb_scale = __builtin_amdgcn_readlane(par_v, 1);
-    const int hb_scale = __builtin_amdgcn_readlane(par_v, 2), st_syn = __builtin_amdgcn_readlane(par_v, 3);
-    const int lsb = __builtin_amdgcn_readlane(par_v, 4), usb = __builtin_amdgcn_readlane(par_v, 5);
     const int ps_scale =
-        xp_ps_frame(cx, tabs, &s.ps, &s.pf, &s.w, gx, gr, lb_scale, ov_lb_scale, hb_scale, st_syn, lsb, usb);
+        xp_ps_frame(cx, tabs, &s.ps, &s.pf, &s.w, gx, gr, lb_scale, ov_lb_scale, hb_scale, st_syn, lsb, usb, ps_scale_done);
     /* ---- state and the two synthesis launches' parameters ---- */
     xp_wave_sync();
     {
