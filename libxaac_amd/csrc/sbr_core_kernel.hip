@@ -429,7 +429,8 @@ __global__ __launch_bounds__(64 * WAVES) void xaac_sbr_core_kernel(XaacSbrCorePa
      XS_STAGGER_G starts g x XS_STAGGER_SLEEP x 64 cycles late (64 groups x 0.43 us: the last one 27 us behind the first, two
      thirds of a channel-frame's time), which spreads the phases for the launch's four rounds; the work counter evens out
      what the late starters do not get to.  Measured on one box (profiles/r05_b_stagger.txt): none 189.7 us; 2 groups x 6.8 us
-     187; 4 x 3.4 us 181.6; 8 x 3.4 us 175.7; 32 x 0.85 us 175.3; 64 x 0.43 us 172.8; 8 x 6.8 us 186; 16 x 3.4 us 185. */
+     187; 4 x 3.4 us 181.6; 8 x 3.4 us 175.7; 32 x 0.85 us 175.3; 64 x 0.43 us 172.8; 8 x 6.8 us 186; 16 x 3.4 us 185.
+     The one-shot low-power launch (6.4 rounds of workgroups that start as others end) only loses by it: 404 -> 415-436 us. */
   if (XS_STAGGER_G > 1 && p.work_counter && p.n_ch >= 3 * (int)gridDim.x * WAVES) { /* (a small batch has no second round to gain in) */
     const int g = ((int)blockIdx.x * WAVES + wave) % XS_STAGGER_G;
     for (int t = 0; t < g; t++) __builtin_amdgcn_s_sleep(XS_STAGGER_SLEEP);

@@ -155,6 +155,34 @@ __device__ __forceinline__ int xp_init_ps_scale_regs(const XsCx &cx, int32_t (&r
   return ps_scale;
 }
 
+/* xp_frame_sanitize (sbr_ps.h) the same way, on the side info's words in registers: borders into 0..32, IID indices into
+   +-7 (+-15 fine), ICC indices into 0..7; returns whether anything had to be changed */
+template <int NF>
+__device__ __forceinline__ int xp_frame_sanitize_regs(const XsCx &cx, int32_t (&rf)[NF]) {
+  constexpr int E_BORDER = offsetof(xaac_ps_frame, border_position) / 2, E_IID = offsetof(xaac_ps_frame, iid_par_table) / 2;
+  constexpr int E_ICC = offsetof(xaac_ps_frame, icc_par_table) / 2, E_END = sizeof(xaac_ps_frame) / 2;
+  static_assert(offsetof(xaac_ps_frame, iid_quant) == 0 && E_BORDER + XAAC_PS_MAX_ENV + 2 < E_IID && E_IID % 2 == 0 && E_ICC % 2 == 0, "layout");
+  const int steps = (int16_t)__builtin_amdgcn_readlane(rf[0], 0) ? 15 : 7;
+  int bad = 0;
+#pragma unroll
+  for (int j = 0; j < NF; j++) {
+    const int w = cx.lane + 64 * j;
+    const int32_t v = rf[j];
+    int h[2] = {(int16_t)v, v >> 16};
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const int e = 2 * w + c; /* element number */
+      const bool border = e >= E_BORDER && e < E_BORDER + XAAC_PS_MAX_ENV + 2, iid = e >= E_IID && e < E_ICC, icc = e >= E_ICC && e < E_END;
+      const int lo = border ? 0 : (iid ? -steps : (icc ? 0 : -32768)), hi = border ? 32 : (iid ? steps : (icc ? 7 : 32767));
+      const int t = h[c] < lo ? lo : (h[c] > hi ? hi : h[c]);
+      bad |= t != h[c];
+      h[c] = t;
+    }
+    rf[j] = (int32_t)xp_pack16((int16_t)h[0], (int16_t)h[1]);
+  }
+  return cx.wave_or(bad) != 0;
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(64 * kPsWaves, XP_WAVES_PER_EU) void xaac_ps_kernel(XaacPsParams p) {
@@ -199,6 +227,7 @@ __global__ __launch_bounds__(64 * kPsWaves, XP_WAVES_PER_EU) void xaac_ps_kernel
     const int hb_scale = __builtin_amdgcn_readlane(par_v, 2), st_syn = __builtin_amdgcn_readlane(par_v, 3);
     const int lsb = __builtin_amdgcn_readlane(par_v, 4), usb = __builtin_amdgcn_readlane(par_v, 5);
     const int ps_scale_done = xp_init_ps_scale_regs<NS>(cx, rs, lb_scale, ov_lb_scale, hb_scale);
+    const int ps_clamped = xp_frame_sanitize_regs<NF>(cx, rf); /* indices a parser cannot produce: contained, reported */
     xp_wave_sync(); /* the previous stream's state has left the LDS copy */
 #pragma unroll
     for (int j = 0; j < NS; j++)
@@ -210,7 +239,6 @@ __global__ __launch_bounds__(64 * kPsWaves, XP_WAVES_PER_EU) void xaac_ps_kernel
 #ifdef XS_PROFILE
     if (threadIdx.x == 0) xp_prof_last = clock64();
 #endif
-    const int ps_clamped = xp_frame_sanitize(cx, &s.pf); /* indices a parser cannot produce: contained, reported */
     const int ps_scale =
         xp_ps_frame(cx, tabs, &s.ps, &s.pf, &s.w, gx, gr, lb_scale, ov_lb_scale, hb_scale, st_syn, lsb, usb, ps_scale_done);
     /* ---- state and the two synthesis launches' parameters ---- */
