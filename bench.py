@@ -706,7 +706,7 @@ def alg_bytes_per_step(w):
 class Workload:
     """Inputs, per-step launch sequence and the self-check of one of the four workloads on one rank."""
 
-    def __init__(self, w, torch, libxaac_amd, ctx, dev, stream, sets, seed):
+    def __init__(self, w, torch, libxaac_amd, ctx, dev, stream, sets, seed, hip_streams=1):
         self.w, self.torch, self.x, self.ctx, self.dev, self.stream = w, torch, libxaac_amd, ctx, dev, stream
         c3, c4, c2l = w == "c3", w == "c4", w == "c2l"
         self.batches = (make_inputs_c3(torch, dev, sets, seed) if c3 else make_inputs_c4(torch, dev, sets, seed) if c4
@@ -717,6 +717,17 @@ class Workload:
         self.status = torch.zeros(n_units, dtype=torch.int32, device=dev) if (c3 or c4 or c2l) else None
         self.imdct_status = torch.zeros(FRAMES_PER_STEP * (1 if c4 else CH), dtype=torch.int32, device=dev)
         self.ws = self._workspace(FRAMES_PER_STEP)
+        # Steps dealt out over `hip_streams` HIP streams, step i on stream i % hip_streams, each with its own context, workspace
+        # and status rows: the stream sets are independent batches (a host decoding many streams submits them exactly so),
+        # and set j always meets stream j % hip_streams, so the frames of one set stay in order.  One kernel's tail (and the
+        # persistent kernels' staggered start) then overlaps with the other stream's kernels instead of leaving CUs idle.
+        assert hip_streams >= 1 and sets % hip_streams == 0, "every stream set has to stay on one HIP stream"
+        self.lanes = [(ctx, stream, self.ws, self.status, self.imdct_status)]
+        for _ in range(hip_streams - 1):
+            st = torch.cuda.Stream(device=dev)
+            self.lanes.append((libxaac_amd.XaacContext(dev.index or 0, st.cuda_stream), st, self._workspace(FRAMES_PER_STEP),
+                               None if self.status is None else torch.zeros_like(self.status),
+                               torch.zeros_like(self.imdct_status)))
 
     def _workspace(self, frames):
         t, ctx, w = self.torch, self.ctx, self.w
@@ -724,9 +735,9 @@ class Workload:
                   if w == "c4" else ctx.peak_limiter_workspace_bytes(frames) if w == "c2l" else 0)
         return t.zeros(nbytes, dtype=t.uint8, device=self.dev) if nbytes else None
 
-    def launch(self, b, frames_idx, k=None, ws=None, status=None, imdct_status=None):
+    def launch(self, b, frames_idx, k=None, ws=None, status=None, imdct_status=None, ctx=None):
         """one frame of the first k streams of batch b (k = None: all of them)"""
-        ctx, x, w = self.ctx, self.x, self.w
+        ctx, x, w = (self.ctx if ctx is None else ctx), self.x, self.w
         ws = self.ws if ws is None else ws
         status = self.status if status is None else status
         imdct_status = self.imdct_status if imdct_status is None else imdct_status
@@ -762,24 +773,37 @@ class Workload:
 
     def step(self, i, ev=None):
         b = self.batches[i % len(self.batches)]
+        ctx, stream, ws, status, imdct_status = self.lanes[i % len(self.lanes)]
         if ev is not None:
-            ev[0].record(self.stream)
-        self.launch(b, i // len(self.batches))
+            ev[0].record(stream)
+        self.launch(b, i // len(self.batches), ws=ws, status=status, imdct_status=imdct_status, ctx=ctx)
         if ev is not None:
-            ev[1].record(self.stream)
+            ev[1].record(stream)
 
     def run(self, steps, warmup, barrier):
+        """(wall seconds of the K steps, milliseconds of GPU time per step from HIP events on the launch streams).  One HIP
+        stream: the mean of the steps' own event pairs.  Several: the steps of different streams overlap, so a step's own pair
+        says little; the span from the first stream's start event to the last stream's end event, over K."""
         torch = self.torch
         for i in range(warmup):
             self.step(i)
         events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        many = len(self.lanes) > 1
+        span = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in self.lanes]
         barrier()
         t0 = time.perf_counter()
+        for q, lane in enumerate(self.lanes):
+            span[q][0].record(lane[1])
         for i in range(steps):
-            self.step(warmup + i, events[i])
+            self.step(warmup + i, None if many else events[i])
+        for q, lane in enumerate(self.lanes):
+            span[q][1].record(lane[1])
         barrier()
         elapsed = time.perf_counter() - t0
-        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
+        if many:
+            kern_ms = max(a[0].elapsed_time(b[1]) for a in span for b in span) / max(1, steps)
+        else:
+            kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
         self.next_step = warmup + steps
         return elapsed, kern_ms
 
@@ -787,9 +811,11 @@ class Workload:
         """fraction of the last step's units the kernels refused (status != 0): must be zero for the timed work to
         be the whole work"""
         bad = 0.0
-        if self.status is not None:
-            bad = float((self.status != 0).float().mean().item())
-        return max(bad, float((self.imdct_status != 0).float().mean().item()))
+        for _, _, _, status, imdct_status in self.lanes:
+            if status is not None:
+                bad = max(bad, float((status != 0).float().mean().item()))
+            bad = max(bad, float((imdct_status != 0).float().mean().item()))
+        return bad
 
     def verify(self, k=256):
         """Decode one more frame of the first k streams of the next batch twice from the same device state: by
@@ -921,6 +947,9 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--sets", type=int, default=4, help="independent 8192-stream batches cycled per rank")
+    ap.add_argument("--hip-streams", type=int, default=2,
+                    help="HIP streams per rank the steps are dealt out over (step i on stream i %% N; must divide --sets): "
+                         "neighbouring steps decode different stream sets, so they share nothing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short C2 / C3 runs of the N=1 report")
     ap.add_argument("--workload", choices=["c2", "c2l", "c3", "c4"], default="c4",
@@ -965,7 +994,7 @@ def main():
         torch.cuda.synchronize()
 
     w = args.workload
-    job = Workload(w, torch, libxaac_amd, ctx, dev, stream, args.sets, rank)
+    job = Workload(w, torch, libxaac_amd, ctx, dev, stream, args.sets, rank, hip_streams=args.hip_streams)
     own_elapsed, kern_ms = job.run(args.steps, args.warmup, barrier)
     elapsed = xdist.max_over_ranks(dist, own_elapsed, dev)
     refused = job.refused()
@@ -1006,7 +1035,7 @@ def main():
         del job.batches, job.ws
         torch.cuda.empty_cache()
         for w2 in ("c2", "c3"):
-            j2 = Workload(w2, torch, libxaac_amd, ctx, dev, stream, args.sets, rank)
+            j2 = Workload(w2, torch, libxaac_amd, ctx, dev, stream, args.sets, rank, hip_streams=args.hip_streams)
             e2, k2 = j2.run(max(20, args.steps // 2), max(4, args.warmup // 2), barrier)
             steps2 = max(20, args.steps // 2)
             ab = alg_bytes_per_step(w2)
@@ -1052,6 +1081,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": WORKLOAD[w] % args.sets,
                        "frames_per_step": FRAMES_PER_STEP, "channels": 1 if w == "c4" else CH, "launch": ctx.last_launch(),
+                       "hip_streams": args.hip_streams,
+                       "hip_streams_note": "step i is launched on HIP stream i % hip_streams (its own context and workspace); "
+                                           "a stream set always meets the same stream, so its frames stay in order",
                        "sharding": "streams split across ranks (%d per rank), no data-path collective" % FRAMES_PER_STEP},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #ifdef XS_PROFILE
 /* phase timers (tools/prof_sbr_core.py): cycles of each wave's lane 0 between XS_T hooks, summed over channels */
@@ -487,7 +488,12 @@ extern "C" hipError_t xaac_launch_sbr_core_hq(const XaacSbrCoreParams *p, hipStr
     if (e != hipSuccess) return e;
   }
   constexpr int W = XAAC_SBR_CORE_HQ_WAVES;
-  const int resident = 2 * (p->num_cu > 0 ? p->num_cu : 256), need = (p->n_ch + W - 1) / W;
+  static int per_cu = 0; /* developer override: XAAC_CORE_WG_PER_CU (two fill a CU's LDS) */
+  if (!per_cu) {
+    const char *e = getenv("XAAC_CORE_WG_PER_CU");
+    per_cu = e && atoi(e) > 0 ? atoi(e) : 2;
+  }
+  const int resident = per_cu * (p->num_cu > 0 ? p->num_cu : 256), need = (p->n_ch + W - 1) / W;
   hipLaunchKernelGGL((xaac_sbr_core_kernel<1, XAAC_SBR_NARROW_BANDS, W>), dim3(need < resident ? need : resident), dim3(64 * W), 0,
                      stream, *p);
   const int grid = p->n_ch < 64 ? p->n_ch : 64;

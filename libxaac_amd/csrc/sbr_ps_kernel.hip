@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #ifdef XS_PROFILE
 /* phase timers (tools/prof_sbr_core.py ps): cycles of lane 0 between XP_T hooks, summed over streams */
@@ -194,6 +195,10 @@ __global__ __launch_bounds__(64 * kPsWaves, XP_WAVES_PER_EU) void xaac_ps_kernel
   for (int i = threadIdx.x; i < (kTabBytes + 3) / 4; i += 64 * kPsWaves) s_tabs[i] = reinterpret_cast<const int32_t *>(&xaac_ps_tables)[i];
   __syncthreads(); /* the only workgroup barrier: from here on the waves run their own streams */
   const XpTables *tabs = reinterpret_cast<const XpTables *>(s_tabs);
+#ifdef XP_STAGGER_G
+  if (p.n >= 3 * (int)gridDim.x * kPsWaves)
+    for (int t = 0; t < ((int)blockIdx.x * kPsWaves + wave) % XP_STAGGER_G; t++) __builtin_amdgcn_s_sleep(XP_STAGGER_SLEEP);
+#endif
 #ifdef XS_PROFILE
   if (threadIdx.x == 0) {
     for (int i = 0; i < 16; i++) xp_prof_acc[i] = 0;
@@ -350,6 +355,8 @@ extern "C" hipError_t xaac_launch_ps(const XaacPsParams *p, hipStream_t stream) 
     hipDeviceProp_t prop;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, xaac_ps_kernel, 64 * kPsWaves, 0) != hipSuccess || per_cu < 1) per_cu = 2;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+    const char *e = getenv("XAAC_PS_WG_PER_CU"); /* developer override */
+    if (e && atoi(e) > 0) per_cu = atoi(e);
     resident = per_cu * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
   }
   const int need = (p->n + kPsWaves - 1) / kPsWaves, grid = need < resident ? need : resident;
