@@ -576,40 +576,55 @@ __global__ __launch_bounds__(128) void xaac_qmf_synthesis_pair_kernel(XaacQmfSyn
      of row loads each; spread over 6.6 us (64 groups x 0.1 us) their bursts do not meet.  112.5 -> 109.3 us. */
   if (XQ_STAGGER_G > 1 && i < XQ_STAGGER_FIRST && (int)gridDim.x >= 3 * XQ_STAGGER_FIRST)
     for (int t = 0; t < i % XQ_STAGGER_G; t++) __builtin_amdgcn_s_sleep(XQ_STAGGER_SLEEP);
-  const int inactive0 = __builtin_amdgcn_readfirstlane(p.scale[0][8 * (size_t)i + 6]);
-  const int inactive1 = __builtin_amdgcn_readfirstlane(p.scale[1][8 * (size_t)i + 6]);
-  /* this wave's channel for history / state: channel w */
+  /* ---- phase A: half rows in (lane = band), rescaled, through the tile to lane = (channel, slot) ---------------
+     Everything the workgroup's head reads is in flight together: the two channels' parameter rows (eight shorts each: scales,
+     band limits, the inactive flag), the two ring offsets and the 64 half rows.  (Read where they
+     were used -- a scale inside the branch that needed it, the offsets in front of the validity check, the rows behind
+     all of them -- a workgroup paid five or six memory round trips before its first row arrived.) */
+  typedef int xq_int4 __attribute__((ext_vector_type(4)));
   xaac_qmf_syn_state *st_w = reinterpret_cast<xaac_qmf_syn_state *>(reinterpret_cast<char *>(p.state[w]) + (size_t)i * p.state_stride[w]);
-  const int d_old = __builtin_amdgcn_readfirstlane(st_w->drc_offset);
+  const xaac_qmf_syn_state *st_o = reinterpret_cast<const xaac_qmf_syn_state *>(reinterpret_cast<const char *>(p.state[1 - w]) + (size_t)i * p.state_stride[1 - w]);
+  const xq_int4 par0 = *reinterpret_cast<const xq_int4 *>(p.scale[0] + 8 * (size_t)i);
+  const xq_int4 par1 = *reinterpret_cast<const xq_int4 *>(p.scale[1] + 8 * (size_t)i);
+  const int d_old_v = st_w->drc_offset, d_oth_v = st_o->drc_offset;
+  int32_t x[64];
+  int32_t tmp[64]; /* (behind the small loads: memory operations return in order, so what follows waits for those four only) */
+#pragma unroll
+  for (int r = 0; r < 64; r++) {
+    const int c = r >> 5;
+    tmp[r] = (p.qmf[c] + (size_t)i * p.qmf_stride[c] + (size_t)(r & 31) * 128 + 64 * w)[lane];
+  }
+  const auto lo16 = [](int v) { return (int)(int16_t)v; };
+  const auto hi16 = [](int v) { return v >> 16; };
+  const int u0 = __builtin_amdgcn_readfirstlane(par0.x), u1 = __builtin_amdgcn_readfirstlane(par0.y);
+  const int u2 = __builtin_amdgcn_readfirstlane(par0.z), u3 = __builtin_amdgcn_readfirstlane(par0.w);
+  const int v0 = __builtin_amdgcn_readfirstlane(par1.x), v1 = __builtin_amdgcn_readfirstlane(par1.y);
+  const int v2 = __builtin_amdgcn_readfirstlane(par1.z), v3 = __builtin_amdgcn_readfirstlane(par1.w);
+  const int inactive0 = lo16(u3), inactive1 = lo16(v3);
+  const int st_syn0 = hi16(u1), st_syn1 = hi16(v1);
+  /* this wave's channel for history / state: channel w */
+  const int d_old = __builtin_amdgcn_readfirstlane(d_old_v);
   {
-    const xaac_qmf_syn_state *st_o = reinterpret_cast<const xaac_qmf_syn_state *>(reinterpret_cast<const char *>(p.state[1 - w]) + (size_t)i * p.state_stride[1 - w]);
-    const int d_oth = __builtin_amdgcn_readfirstlane(st_o->drc_offset);
+    const int d_oth = __builtin_amdgcn_readfirstlane(d_oth_v);
     if (((d_old | d_oth) & 127) != 0 || d_old < 0 || d_old >= RING || d_oth < 0 || d_oth >= RING) {
       if (threadIdx.x == 0 && p.status) p.status[i] = -1;
       return; /* uniform over the workgroup */
     }
   }
-  /* ---- phase A: half rows in (lane = band), rescaled, through the tile to lane = (channel, slot) --------------- */
-  int32_t x[64];
   {
     int shl[2][2], shr[2][2]; /* [channel][slot < split] for band = 64 w' + lane -> the band is lane (both halves: re | im of band lane) */
 #pragma unroll
     for (int c = 0; c < 2; c++) {
-      const int16_t *sf = p.scale[c] + 8 * (size_t)i;
-      const int st_syn = sf[3], lsb = sf[4], usb = sf[5];
+      const int w0 = c ? v0 : u0, w1 = c ? v1 : u1, w2 = c ? v2 : u2;
+      const int st_syn = hi16(w1), lsb = lo16(w2), usb = hi16(w2), hb = lo16(w1);
 #pragma unroll
       for (int ov = 0; ov < 2; ov++) {
-        int sh = lane < lsb ? (st_syn - sf[ov]) - 8 : (lane < usb ? (st_syn - sf[2]) - 8 : 0);
+        const int lo_sf = ov ? hi16(w0) : lo16(w0); /* sf[ov]: lb_scale, ov_lb_scale */
+        int sh = lane < lsb ? (st_syn - lo_sf) - 8 : (lane < usb ? (st_syn - hb) - 8 : 0);
         sh = sh > 31 ? 31 : (sh < -31 ? -31 : sh); /* env_calc.c:1099 */
         shl[c][ov] = sh > 0 ? sh : 0;
         shr[c][ov] = sh < 0 ? -sh : 0;
       }
-    }
-    int32_t tmp[64]; /* all 64 half rows in flight: one memory latency */
-#pragma unroll
-    for (int r = 0; r < 64; r++) {
-      const int c = r >> 5;
-      tmp[r] = (p.qmf[c] + (size_t)i * p.qmf_stride[c] + (size_t)(r & 31) * 128 + 64 * w)[lane];
     }
 #pragma unroll
     for (int c = 0; c < 2; c++) {
@@ -659,7 +674,7 @@ __global__ __launch_bounds__(128) void xaac_qmf_synthesis_pair_kernel(XaacQmfSyn
   }
   {
     const int ch = lane >> 5, slot = lane & 31;
-    const int shift = -(p.scale[ch][8 * (size_t)i + 3] - 3) + 1;
+    const int shift = -((ch ? st_syn1 : st_syn0) - 3) + 1;
     const int32_t hi = FX_MAX32 >> shift, lo = FX_MIN32 >> shift;
     /* round16(shl_sat(a, b)) == round16(clamp(a, MIN >> b, MAX >> b) << b): the clamped value's top 17 bits decide */
     int16_t *row = reinterpret_cast<int16_t *>(E + (ch * EROWS + 9 + slot) * RS);
