@@ -217,6 +217,11 @@ __global__ __launch_bounds__(64 * kPsWaves, XP_WAVES_PER_EU) void xaac_ps_kernel
     const int32_t *gs = reinterpret_cast<const int32_t *>(gps), *gf = reinterpret_cast<const int32_t *>(p.frame + n);
     const int apply_v = p.sbr_frame[n].apply_processing, mode_v = p.header[n].channel_mode;
     const int par_v = lane < 6 ? par[lane] : 0;
+    /* the right bank's scale and band limits, for the parameter row written at the end: read here with the rest -- read there,
+       by one lane, they came back behind every store of the stream (a wave's memory operations retire in order) and the row,
+       and the next stream's loads behind it, waited for that */
+    const int tail_v = lane < 3 ? (lane == 0 ? gps->st_syn_scale_r : (lane == 1 ? gps->syn_lsb_r : gps->syn_usb_r)) : 0;
+
 #pragma unroll
     for (int j = 0; j < NS; j++) rs[j] = lane + 64 * j < kHeadWords ? gs[lane + 64 * j] : 0;
 #pragma unroll
@@ -258,9 +263,9 @@ __global__ __launch_bounds__(64 * kPsWaves, XP_WAVES_PER_EU) void xaac_ps_kernel
       const int16_t ready = (int16_t)(st_syn - 8); /* makes the bank's own rescale a no-op: data is in place */
       par[0] = par[1] = par[2] = ready;
       pr[0] = pr[1] = pr[2] = (int16_t)ps_scale;
-      pr[3] = gps->st_syn_scale_r;
-      pr[4] = gps->syn_lsb_r;
-      pr[5] = gps->syn_usb_r;
+      pr[3] = (int16_t)__builtin_amdgcn_readlane(tail_v, 0);
+      pr[4] = (int16_t)__builtin_amdgcn_readlane(tail_v, 1);
+      pr[5] = (int16_t)__builtin_amdgcn_readlane(tail_v, 2);
       pr[6] = 0;
       par[6] = 0;
       gps->lb_scale_r = gps->ov_lb_scale_r = gps->hb_scale_r = (int16_t)ps_scale; /* sbr_dec.c:1261-1264 */

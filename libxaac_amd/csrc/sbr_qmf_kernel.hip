@@ -210,25 +210,40 @@ __global__ __launch_bounds__(128) void xaac_qmf_analysis_hq_kernel(XaacQmfAnaPar
   const bool live = chw < p.n_ch;
   if (p.zero_words && blockIdx.x == 0 && threadIdx.x < 2) p.zero_words[threadIdx.x] = 0;
   xaac_qmf_ana_state *st = reinterpret_cast<xaac_qmf_ana_state *>(reinterpret_cast<char *>(p.state) + (size_t)(live ? chw : 0) * p.state_stride);
-  int wr = 0;
+  int wr = 0, phase_old = 0;
+  /* what the final rotation needs of the lane's channel (lanes 0..31: the pair's first channel, 32..63: its second): read
+     here, with everything else the workgroup reads, instead of as two dependent round trips in front of the rotation */
+  int rot_apply = 0, rot_sub = 0, rot_usb = 0;
+  const bool rot_live = p.frame && 2 * pair + (lane >> 5) < p.n_ch;
+  if (rot_live) {
+    const int ch = 2 * pair + (lane >> 5);
+    const xaac_sbr_frame *f = p.frame + ch;
+    const xaac_sbr_state *sst = reinterpret_cast<const xaac_sbr_state *>(reinterpret_cast<const char *>(p.state) + (size_t)ch * p.state_stride);
+    rot_apply = f->apply_processing;
+    rot_sub = f->max_qmf_subband_aac;
+    rot_usb = sst->codec_usb;
+  }
   /* ---- history + new samples of channel w, time ordered ---- */
   {
     int16_t *h = hist[w];
     if (live) {
-      wr = st->wr;
+      /* the ring is fetched by position, not by age: the loads then do not wait for the write position, which only says
+         where in the time-ordered history a fetched sample belongs */
+      const int wr_v = st->wr;
+      phase_old = st->phase;
       const int cf = p.ch_fac;
       const int16_t *src = p.pcm + (size_t)(chw / cf) * 1024 * cf + (chw % cf);
       int16_t hr[5], hp[16];
 #pragma unroll
-      for (int j = 0; j < 5; j++) {
-        const int a = lane + 64 * j;
-        hr[j] = a < 288 ? st->ring[ana_ring_pos(wr, a)] : (int16_t)0;
-      }
+      for (int j = 0; j < 5; j++) hr[j] = st->ring[lane + 64 * j];
 #pragma unroll
       for (int j = 0; j < 16; j++) hp[j] = src[(size_t)(lane + 64 * j) * cf];
+      wr = __builtin_amdgcn_readfirstlane(wr_v);
 #pragma unroll
       for (int j = 0; j < 5; j++) {
-        const int a = lane + 64 * j;
+        int a = lane + 64 * j - wr - 32; /* age of the sample at this position: ana_ring_pos(wr, a) = position */
+        a += a < 0 ? 320 : 0;
+        a += a < 0 ? 320 : 0;
         if (a < 288) h[287 - a] = hr[j];
       }
 #pragma unroll
@@ -285,16 +300,8 @@ __global__ __launch_bounds__(128) void xaac_qmf_analysis_hq_kernel(XaacQmfAnaPar
     int32_t o[32];
 #pragma unroll
     for (int k = 0; k < 32; k++) o[k] = other[33 * lane + k];
-    int nrot = p.usb;
-    if (p.frame) { /* lanes 0..31 are the slots of the pair's first channel, 32..63 of its second */
-      const int ch = 2 * pair + (lane >> 5);
-      if (ch < p.n_ch) {
-        const xaac_sbr_frame *f = p.frame + ch;
-        const xaac_sbr_state *sst = reinterpret_cast<const xaac_sbr_state *>(
-            reinterpret_cast<const char *>(p.state) + (size_t)ch * p.state_stride);
-        nrot = f->apply_processing ? f->max_qmf_subband_aac : sst->codec_usb;
-      }
-    }
+    /* lanes 0..31 are the slots of the pair's first channel, 32..63 of its second */
+    const int nrot = rot_live ? (rot_apply ? rot_sub : rot_usb) : p.usb;
     const int16_t *tc = XQ_T(t_cos_sin_l32);
 #pragma unroll
     for (int i = 0; i < 32; i++) { /* generic:650-656: own = real (wave 0) / imaginary (wave 1) part, o = the other */
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(128) void xaac_qmf_analysis_hq_kernel(XaacQmfAnaPar
   /* ---- state: the ring as the reference leaves it after 32 slots ---- */
   {
     const int wr_new = (wr + 256) % 320;
-    const int ph_new = ana_phase_after_frame(st->phase);
+    const int ph_new = ana_phase_after_frame(phase_old);
     const int16_t *h = hist[w];
 #pragma unroll
     for (int j = 0; j < 5; j++) {
