@@ -2638,7 +2638,8 @@ template <class ST, class Q>
    envelope: it stays in global memory there) -- nothing below may reach them through `f`. */
 FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f,
                               const int16_t *env_sf_all, const int16_t *noise_floor_all, ST *st, const Q &x,
-                              XsWork *w, const int16_t *rand_hi, const XsLv &deg64, XsPendingAdjust *pend = nullptr) {
+                              XsWork *w, const int16_t *rand_hi, const XsLv &deg64, XsPendingAdjust *pend = nullptr,
+                              const int32_t *sf_words = nullptr) {
   const int num_env = cx.uni(f->num_env);
   const int16_t *border = f->border_vec;
   const int16_t *noise_floor = noise_floor_all;
@@ -2680,7 +2681,25 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
       sfv[i].fill(0);
       if (i < num_env) {
         const int nsf = cx.uni(h->num_sf_bands[f->freq_res[i]]);
-        XS_LANES(j, 0, nsf) sfv[i].own(j) = env_sf_all[base + j];
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (sf_words) {
+          /* the GPU core kernel fetched the whole array with the channel-frame's other loads (sbr_core_kernel.hip: r_sf): word
+             k of it is in lane k % 64 of sf_words[k / 64]; element base + j comes out of those registers by a lane gather --
+             no memory round trip in the middle of the frame */
+          const int e = base + cx.lane, k = e >> 1;
+          int32_t wv = 0;
+          XS_UNROLL
+          for (int q = 0; q < (int)((sizeof(((xaac_sbr_frame *)0)->int_env_sf_arr) / 4 + 63) / 64); q++) {
+            const int32_t t = __shfl(sf_words[q], k & 63);
+            wv = (k >> 6) == q ? t : wv;
+          }
+          const int16_t hv = (int16_t)((e & 1) ? (wv >> 16) : wv);
+          XS_LANES(j, 0, nsf) sfv[i].own(j) = hv;
+        } else
+#endif
+        {
+          XS_LANES(j, 0, nsf) sfv[i].own(j) = env_sf_all[base + j];
+        }
         base += nsf;
       }
     }
@@ -3053,7 +3072,7 @@ FX_HD int32_t xs_adjust_word(int32_t v, int shift) {
 template <class ST, class Q>
 FX_HD int xs_sbr_core_tail(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, const int16_t *env_sf_all,
                            const int16_t *noise_floor_all, ST *st, const Q &x, XsWork *w, const int16_t *rand_hi,
-                           const XsBfp &b, XsPendingAdjust *pend = nullptr) {
+                           const XsBfp &b, XsPendingAdjust *pend = nullptr, const int32_t *sf_words = nullptr) {
   const int save_lb_scale = b.save_lb_scale, max_samp_val = b.max_samp_val;
   (void)max_samp_val;
   if (cx.uni(f->apply_processing)) {
@@ -3070,7 +3089,7 @@ FX_HD int xs_sbr_core_tail(const XsCx &cx, const xaac_sbr_header *h, const xaac_
     XS_T(2);
     XS_ONE st->hb_scale = (int16_t)((st->ov_lb_scale < st->lb_scale ? st->ov_lb_scale : st->lb_scale) - 2);
     cx.sync();
-    if (xs_calc_sbrenvelope(cx, h, f, env_sf_all, noise_floor_all, st, x, w, rand_hi, deg64, pend)) return -1;
+    if (xs_calc_sbrenvelope(cx, h, f, env_sf_all, noise_floor_all, st, x, w, rand_hi, deg64, pend, sf_words)) return -1;
     XS_PAR(i, 0, h->num_if_bands) st->prev_invf_mode[i] = f->sbr_invf_mode[i];
     XS_ONE {
       st->prev_coupling_mode = f->coupling_mode;

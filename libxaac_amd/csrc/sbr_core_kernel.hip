@@ -154,13 +154,19 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
   constexpr int NT = (kTailWords + 63) / 64, NOV = 6 * ROWG / 64, NAS = 32 * 32 * (HQ ? 2 : 1) / 64;
   constexpr int NNF = sizeof(s.noise_floor) / 4;
   static_assert(NOV * 64 == 6 * ROWG && NF == 1, "whole rows of lanes");
-  int32_t r_h[NH], r_f, r_nf = 0, r_hd = 0, r_t[NT], r_ov[NOV], r_an[NAS];
+  constexpr int NSF = (sizeof(((xaac_sbr_frame *)0)->int_env_sf_arr) / 4 + 63) / 64; /* the envelopes' scale factors: 224 words */
+  int32_t r_h[NH], r_f, r_nf = 0, r_hd = 0, r_t[NT], r_ov[NOV], r_an[NAS], r_sf[NSF];
   {
     const int32_t *gh = reinterpret_cast<const int32_t *>(p.header + ch), *gf = reinterpret_cast<const int32_t *>(p.frame + ch);
 #pragma unroll
     for (int j = 0; j < NH; j++) r_h[j] = lane + 64 * j < (int)(sizeof(xaac_sbr_header) / 4) ? gh[lane + 64 * j] : 0;
     r_f = lane < kFrameHeadBytes / 4 ? gf[lane] : 0;
     if (lane < NNF) r_nf = reinterpret_cast<const int32_t *>(p.frame[ch].int_noise_floor)[lane];
+    /* (kept in registers until the envelope adjuster asks for them: read there they were a memory round trip in the middle of
+       the frame, and LDS has no 896 bytes to spare) */
+#pragma unroll
+    for (int j = 0; j < NSF; j++)
+      r_sf[j] = lane + 64 * j < (int)(sizeof(((xaac_sbr_frame *)0)->int_env_sf_arr) / 4) ? reinterpret_cast<const int32_t *>(p.frame[ch].int_env_sf_arr)[lane + 64 * j] : 0;
     if (lane < 2) r_hd = gstw[kHeadOff / 4 + lane];
 #pragma unroll
     for (int j = 0; j < NT; j++) r_t[j] = lane + 64 * j < kTailWords ? gstw[kTailOff / 4 + lane + 64 * j] : 0;
@@ -293,7 +299,7 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
     xs_wave_sync();
     XS_T(1);
     rc = xs_sbr_core_tail(cx, &s.h, f, p.frame[ch].int_env_sf_arr, reinterpret_cast<const int16_t *>(s.noise_floor), &s.st, x,
-                          &s.w, HQ ? nullptr : xs_lds_rand_hi, b, &pend);
+                          &s.w, HQ ? nullptr : xs_lds_rand_hi, b, &pend, r_sf);
   } else if (!refused) {
     rc = xs_sbr_core(cx, &s.h, f, p.frame[ch].int_env_sf_arr, reinterpret_cast<const int16_t *>(s.noise_floor), &s.st, x, &s.w,
                      HQ ? nullptr : xs_lds_rand_hi, &save_lb_scale);
