@@ -391,16 +391,23 @@ __device__ __forceinline__ void stage_tables(int tid) {
   constexpr int NR = (568 + THREADS - 1) / THREADS, NI = (256 + THREADS - 1) / THREADS, NS = (257 + THREADS - 1) / THREADS;
   int32_t tr[NR];
   int16_t ti[NI], ts[NS];
+  /* every load unconditional (an index past a table's end reads its last entry and the value is dropped): as `in range ? load : 0`
+     each became a branch around a load with its own wait -- ten memory round trips one after the other at the start of every
+     workgroup, which the one-shot low-power launch pays per pair of channel-frames */
+  const auto upto = [](int i, int n) { return i < n ? i : n - 1; };
 #pragma unroll
-  for (int j = 0; j < NR; j++) tr[j] = tid + THREADS * j < 568 ? xaac_sbr_rand_ph[tid + THREADS * j] : 0;
+  for (int j = 0; j < NR; j++) tr[j] = xaac_sbr_rand_ph[upto(tid + THREADS * j, 568)];
 #pragma unroll
-  for (int j = 0; j < NI; j++) ti[j] = tid + THREADS * j < 256 ? xaac_sbr_inv_table[tid + THREADS * j] : (int16_t)0;
+  for (int j = 0; j < NI; j++) ti[j] = xaac_sbr_inv_table[upto(tid + THREADS * j, 256)];
 #pragma unroll
-  for (int j = 0; j < NS; j++) ts[j] = tid + THREADS * j < 257 ? xaac_sbr_sqrt_table[tid + THREADS * j] : (int16_t)0;
-  if (tid < 8) xs_lds_small16[tid] = xaac_sbr_lim_gains_m[tid];
-  if (tid >= 8 && tid < 12) xs_lds_small16[tid] = xaac_sbr_smooth_filter[tid - 8];
-  if (tid >= 12 && tid < 12 + 49) xs_lds_small16[tid] = xaac_sbr_inv_int_table[tid - 12];
-  if (tid < 16) xs_lds_new_bw[tid] = xaac_sbr_new_bw_table[tid];
+  for (int j = 0; j < NS; j++) ts[j] = xaac_sbr_sqrt_table[upto(tid + THREADS * j, 257)];
+  const int16_t s_lim = xaac_sbr_lim_gains_m[upto(tid, 8)], s_smooth = xaac_sbr_smooth_filter[upto(tid - 8 < 0 ? 0 : tid - 8, 4)];
+  const int16_t s_inv = xaac_sbr_inv_int_table[upto(tid - 12 < 0 ? 0 : tid - 12, 49)];
+  const int32_t s_bw = xaac_sbr_new_bw_table[upto(tid, 16)];
+  if (tid < 8) xs_lds_small16[tid] = s_lim;
+  if (tid >= 8 && tid < 12) xs_lds_small16[tid] = s_smooth;
+  if (tid >= 12 && tid < 12 + 49) xs_lds_small16[tid] = s_inv;
+  if (tid < 16) xs_lds_new_bw[tid] = s_bw;
 #pragma unroll
   for (int j = 0; j < NR; j++)
     if (tid + THREADS * j < 568) {
@@ -477,6 +484,16 @@ extern "C" hipError_t xaac_launch_sbr_core_lp(const XaacSbrCoreParams *p, hipStr
 #define XS_LP_WAVES 2 /* measured: 1: 457 us, 2: 410 (30 KB of LDS per workgroup: ten waves per CU instead of nine), 3: 454 */
 #endif
   constexpr int W = XS_LP_WAVES; /* waves (channel-frames) per workgroup: they share one staging of the tables */
+#ifndef XS_LP_PERSISTENT
+#define XS_LP_PERSISTENT 1
+#endif
+  if (XS_LP_PERSISTENT && p->work_counter && p->counters_zeroed) {
+    /* persistent, like the HQ launch: as many workgroups as the chip holds (five per CU: 31.6 KB of LDS each), channel-frames
+       off the work counter, the tables staged once per workgroup instead of once per pair of channel-frames, staggered start */
+    const int resident = 5 * (p->num_cu > 0 ? p->num_cu : 256), need = (p->n_ch + W - 1) / W;
+    hipLaunchKernelGGL((xaac_sbr_core_kernel<0, 64, W>), dim3(need < resident ? need : resident), dim3(64 * W), 0, stream, *p);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL((xaac_sbr_core_kernel<0, 64, W>), dim3((p->n_ch + W - 1) / W), dim3(64 * W), 0, stream, q);
   return hipGetLastError();
 }

@@ -79,6 +79,7 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_analysis_kernel(XaacQ
 #pragma unroll
   for (int j = 0; j < 5; j++) coef[j] = xaac_qmf_qmf_c[2 * lane + 128 * j];
 
+  if (p.zero_words && blockIdx.x == 0 && threadIdx.x < 2) p.zero_words[threadIdx.x] = 0;
   const int n_pairs = (p.n_ch + 1) >> 1;
   const int waves_total = gridDim.x * XAAC_QMF_WAVES;
   for (int pair = blockIdx.x * XAAC_QMF_WAVES + wave; pair < n_pairs; pair += waves_total) {

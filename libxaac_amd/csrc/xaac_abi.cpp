@@ -524,7 +524,7 @@ int32_t xaac_hbe_apply_batch(xaac_ctx *c, const xaac_hbe_apply_batch_desc *b) {
 
 uint64_t xaac_sbr_lp_workspace_bytes(int32_t n_ch) {
   if (n_ch < 0) return 0;
-  return (uint64_t)n_ch * (XAAC_SBR_X_WORDS * 4 + 8 * 2) + 256;
+  return (uint64_t)n_ch * (XAAC_SBR_X_WORDS * 4 + 8 * 2) + 256 + 128; /* matrix, synthesis parameters, the core's counters */
 }
 
 int32_t xaac_sbr_lp_process_batch(xaac_ctx *c, const xaac_sbr_lp_batch *b) {
@@ -546,11 +546,15 @@ int32_t xaac_sbr_lp_process_batch(xaac_ctx *c, const xaac_sbr_lp_batch *b) {
   pa.pcm = b->pcm_in;
   pa.state = reinterpret_cast<xaac_qmf_ana_state *>(st + offsetof(xaac_sbr_state, ana_ring));
   pa.qmf = x + (2 + 6) * 64;
+  /* the core's work counter (and its neighbour) behind the synthesis parameters; the analysis launch clears them on its way */
+  int32_t *counters = reinterpret_cast<int32_t *>(((uintptr_t)(par + (size_t)b->n_ch * 8) + 63) & ~(uintptr_t)63);
+  pa.zero_words = counters;
   if (!hip_ok(xaac_launch_qmf_analysis(&pa, qmf_grid(c, b->n_ch, 0), c->stream))) return XAAC_FATAL_HIP;
   /* 2. everything between the banks */
   XaacSbrCoreParams pc = {};
   pc.n_ch = b->n_ch; pc.header = b->header; pc.frame = b->frame; pc.state = b->state; pc.x = x; pc.syn_par = par;
   pc.status = b->status;
+  pc.defer_count = counters; pc.work_counter = counters + 1; pc.num_cu = c->num_cu; pc.counters_zeroed = 1;
   if (!hip_ok(xaac_launch_sbr_core_lp(&pc, c->stream))) return XAAC_FATAL_HIP;
   /* 3. synthesis bank over rows 2..33 (the 6 delayed + first 26 new slots) */
   XaacQmfSynParams ps = {};
