@@ -528,7 +528,8 @@ FX_HD void xs_lpc_save(const XsCx &cx, ST *st, const Q &x, int usb) {
 
 /* ---- HF generator, low-power mode ------------------------------------------------------------------ */
 /* lpp_tran.c:271: real autocorrelation of band k over `len` (= 38) slots starting at row -2 */
-FX_HD void xs_covariance_lp(const XsQmf &x, int k, int len, XsCov *c) {
+template <class Q>
+FX_HD void xs_covariance_lp(const Q &x, int k, int len, XsCov *c) {
   int32_t p01 = 0, p02 = 0, p11 = 0;
   int row = -2;
   const int32_t first = fx_shr(x(-2, k), 3), second = fx_shr(x(-1, k), 3);
@@ -649,7 +650,8 @@ FX_HD void xs_degree_alias_lp(const XsCx &cx, const XsLv &k1v, XsLv &deg, int st
 /* lpp_tran.c:629 + :665, second half: copy / inverse-filter low band lb into each patch's high band.
    The reference advances a per-patch index into bw_borders as hb grows; hb grows with lb inside a
    patch, so that index is the first border above hb. */
-FX_HD void xs_patch_band_lp(const xaac_sbr_header *h, const XsQmf &x, int lb, int16_t alpha0, int16_t alpha1,
+template <class Q>
+FX_HD void xs_patch_band_lp(const xaac_sbr_header *h, const Q &x, int lb, int16_t alpha0, int16_t alpha1,
                             const int32_t *bw_array, int start_idx, int stop_idx, int max_qmf_subband) {
   for (int patch = 0; patch < h->num_patches; patch++) {
     const xaac_sbr_patch *pp = &h->patch[patch];
@@ -684,8 +686,8 @@ FX_HD void xs_patch_band_lp(const xaac_sbr_header *h, const XsQmf &x, int lb, in
 
 /* lpp_tran.c:843.  deg (64 aliasing degrees by QMF band) must be zeroed by the caller.  Writes
    bw_array_prev. */
-template <class ST>
-FX_HD void xs_low_pow_hf_generator(const XsCx &cx, const xaac_sbr_header *h, ST *st, const XsQmf &x, XsWork *w,
+template <class ST, class Q>
+FX_HD void xs_low_pow_hf_generator(const XsCx &cx, const xaac_sbr_header *h, ST *st, const Q &x, XsWork *w,
                                    XsLv &deg, int start_idx, int last_slot_offset, int max_qmf_subband,
                                    const int32_t *invf_mode, const int32_t *invf_mode_prev, int norm_max) {
   const int num_patches = cx.uni(h->num_patches);
@@ -1848,10 +1850,10 @@ FX_HD int16_t xs_noise_rescale(int16_t v, int diff) {
    spelled out per band, what is added to the gained sample is a per-envelope constant `term1` (its
    negative when the harmonic index is 3).  Shifts by 0 are the identity in both directions, which
    is why the reference's "> 0" / ">= 0" variants need no distinction. */
-template <class ST>
+template <class ST, class Q>
 FX_HD void xs_adapt_noise_gain_lp(const XsCx &cx, ST *st, XsEnv &v, const int16_t *rand_hi, int noise_e, int nsb,
                                   int skip, int s0, int s1, int input_e, int adj_e, int final_e, int sb_start,
-                                  int lb_scale, int noise_absc, const XsQmf &x) {
+                                  int lb_scale, int noise_absc, const Q &x) {
   const int bands = nsb - skip;
   const int start_up = cx.uni(st->start_up);
   const int ph0 = cx.uni(st->ph_index), harm0 = cx.uni(st->harm_index);
