@@ -42,21 +42,41 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_ps_kernel(XaacEsbrPsParams p)
   float *lre = p.l_re + (size_t)n * XAAC_ESBR_L_ROWS * 64, *lim = p.l_im + (size_t)n * XAAC_ESBR_L_ROWS * 64;
   float *rre = p.r_re + (size_t)n * 2048, *rim = p.r_im + (size_t)n * 2048;
   const XeMat L = {lre, lim}, R = {rre, rim};
-  bool bad = pf->num_env < 1 || pf->num_env > XAAC_PS_MAX_ENV || pf->border_position[0] < 0;
-  if (!bad)
-    for (int e = 0; e < pf->num_env; e++) bad |= pf->border_position[e] > pf->border_position[e + 1] || pf->border_position[e + 1] > 32;
-  if (p.frame[n].apply_processing && !bad) {
+  /* the side info's head (quantiser flags, seven borders, the envelope count: five words), the frame's processing flag and the
+     band limit, one load each and all in flight together (read member by member inside the checks they were up to ten memory
+     round trips one behind the other) */
+  static_assert(offsetof(xaac_ps_frame, border_position) == 4 && offsetof(xaac_ps_frame, num_env) == 18, "layout");
+  const int head_v = lane < 5 ? reinterpret_cast<const int32_t *>(pf)[lane] : 0;
+  const int apply_v = p.frame[n].apply_processing, sbe_v = p.header[n].sub_band_end;
+  const auto head16 = [&](int e) { /* element e of the head, a short */
+    const int wv = __builtin_amdgcn_readlane(head_v, e >> 1);
+    return (int)(int16_t)((e & 1) ? (wv >> 16) : wv);
+  };
+  int border[XAAC_PS_MAX_ENV + 2];
+#pragma unroll
+  for (int e = 0; e < XAAC_PS_MAX_ENV + 2; e++) border[e] = head16(2 + e);
+  const int num_env = head16(9);
+  bool bad = num_env < 1 || num_env > XAAC_PS_MAX_ENV || border[0] < 0;
+  if (!bad) {
+#pragma unroll
+    for (int e = 0; e < XAAC_PS_MAX_ENV; e++) bad |= e < num_env && (border[e] > border[e + 1] || border[e + 1] > 32);
+  }
+  const int apply = __builtin_amdgcn_readfirstlane(apply_v), sub_band_end = __builtin_amdgcn_readfirstlane(sbe_v);
+  if (apply && !bad) {
     /* The right channel's rows: inside the frame's PS range [border 0, last border) the decorrelator writes every band from 3
        up and the hybrid synthesis bands 0..2 of every row, so only rows outside the range (none, for the borders 0 and 32 an
        encoder sends) have to be cleared -- not 16 KB of zeros per stream that the same kernel then overwrites */
-    const int k0 = pf->border_position[0], k1 = pf->border_position[pf->num_env];
+    int k1 = border[1];
+#pragma unroll
+    for (int e = 2; e <= XAAC_PS_MAX_ENV; e++) k1 = e == num_env ? border[e] : k1;
+    const int k0 = border[0];
     for (int i = 0; i < 32; i++)
       if (i < k0 || i >= k1) { /* (uniform) */
         rre[64 * i + lane] = 0.0f;
         rim[64 * i + lane] = 0.0f;
       }
     __syncthreads();
-    xf_apply_ps(cx, pf, p.ps_state + n, &w, L, R, p.header[n].sub_band_end);
+    xf_apply_ps(cx, pf, p.ps_state + n, &w, L, R, sub_band_end);
 #ifdef XE_PROFILE
     if (lane < 16) atomicAdd(reinterpret_cast<unsigned long long *>(p.status) + 16 + lane, (unsigned long long)xe_prof_acc[lane]);
 #endif
@@ -65,7 +85,7 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_ps_kernel(XaacEsbrPsParams p)
       rre[64 * i + lane] = lre[64 * i + lane];
       rim[64 * i + lane] = lim[64 * i + lane];
     }
-    if (lane == 0 && bad && p.frame[n].apply_processing && p.status) p.status[n] = -1;
+    if (lane == 0 && bad && apply && p.status) p.status[n] = -1;
   }
 }
 

@@ -56,16 +56,45 @@ __global__ __launch_bounds__(64) void xaac_esbr_analysis_kernel(XaacEsbrAnaParam
   int32_t coef[5]; /* c[2 m + 128 j] of this lane's polyphase branch m = lane */
 #pragma unroll
   for (int j = 0; j < 5; j++) coef[j] = xaac_qmf_esbr_qmf_c[2 * lane + 128 * j];
+  /* Everything the pair reads is in flight together: both channels' ring positions and window offsets, their rings (fetched by
+     position, not by age: the loads then do not wait for the position, which only says where in the time-ordered history a
+     fetched sample belongs) and their 1024 core samples.  (One after the other -- position, then ring, then samples, channel by
+     channel -- the workgroup paid half a dozen memory round trips before its first multiply.) */
+  int pos_v[2] = {0, 0}, win_v[2] = {0, 0};
+  int32_t rg[2][5];
+  float sv[2][16];
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    const int ch = 2 * pair + c;
+    if (ch < p.n_ch) { /* (uniform) */
+      const xaac_esbr_ana_state *st = reinterpret_cast<const xaac_esbr_ana_state *>(reinterpret_cast<const char *>(p.state) + (size_t)ch * p.state_stride);
+      const float *src = p.core + (size_t)ch * 1024;
+      pos_v[c] = st->pos;
+      win_v[c] = st->win_off;
+#pragma unroll
+      for (int j = 0; j < 5; j++) rg[c][j] = st->ring[lane + 64 * j];
+#pragma unroll
+      for (int j = 0; j < 16; j++) sv[c][j] = src[lane + 64 * j];
+    }
+  }
+  int wr_c[2];
+#pragma unroll
   for (int c = 0; c < 2; c++) {
     const int ch = 2 * pair + c;
     int32_t *h = hist + c * kHist;
+    int wr = __builtin_amdgcn_readfirstlane(pos_v[c]);
+    wr = ((wr % 320 + 320) % 320) & ~31; /* a block start (the position moves by 32 from 0) */
+    wr_c[c] = wr;
     if (ch < p.n_ch) {
-      const xaac_esbr_ana_state *st = reinterpret_cast<const xaac_esbr_ana_state *>(reinterpret_cast<const char *>(p.state) + (size_t)ch * p.state_stride);
-      int wr = st->pos;
-      wr = ((wr % 320 + 320) % 320) & ~31; /* a block start (the position moves by 32 from 0) */
-      const float *src = p.core + (size_t)ch * 1024;
-      for (int a = lane; a < 288; a += 64) h[287 - a] = st->ring[ring_pos(wr, a)];
-      for (int i = lane; i < 1024; i += 64) h[288 + i] = fx_f2i_trunc(src[i] * 32768.0f); /* sbr_dec.c:248 */
+#pragma unroll
+      for (int j = 0; j < 5; j++) {
+        int a = lane + 64 * j - wr - 32; /* age of the sample at this position: ring_pos(wr, a) = position */
+        a += a < 0 ? 320 : 0;
+        a += a < 0 ? 320 : 0;
+        if (a < 288) h[287 - a] = rg[c][j];
+      }
+#pragma unroll
+      for (int j = 0; j < 16; j++) h[288 + lane + 64 * j] = fx_f2i_trunc(sv[c][j] * 32768.0f); /* sbr_dec.c:248 */
     } else {
       for (int i = lane; i < kHist; i += 64) h[i] = 0;
     }
@@ -85,10 +114,8 @@ __global__ __launch_bounds__(64) void xaac_esbr_analysis_kernel(XaacEsbrAnaParam
     const int ch = 2 * pair + c;
     if (ch >= p.n_ch) break;
     xaac_esbr_ana_state *st = reinterpret_cast<xaac_esbr_ana_state *>(reinterpret_cast<char *>(p.state) + (size_t)ch * p.state_stride);
-    int wr = st->pos;
-    wr = ((wr % 320 + 320) % 320) & ~31;
-    const int wr_new = (wr + 256) % 320;
-    const int w_new = win_after_frame(st->win_off);
+    const int wr_new = (wr_c[c] + 256) % 320;
+    const int w_new = win_after_frame(__builtin_amdgcn_readfirstlane(win_v[c]));
     const int32_t *h = hist + c * kHist;
     int32_t keep[5];
 #pragma unroll

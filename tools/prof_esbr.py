@@ -9,4 +9,5 @@ import libxaac_amd
 import bench
 dev = torch.device("cuda:0")
 ctx = libxaac_amd.XaacContext(0, torch.cuda.current_stream(dev).cuda_stream)
-print(json.dumps(bench.secondary_esbr(torch, libxaac_amd, ctx, dev, int(os.environ.get("STEPS", "20")), 3)))
+print(json.dumps(bench.secondary_esbr(torch, libxaac_amd, ctx, dev, int(os.environ.get("STEPS", "20")), 3,
+                                      hip_streams=int(os.environ.get("HIP_STREAMS", "1")))))
