@@ -217,7 +217,7 @@ def make_inputs_c4(torch, device, sets, seed):
     return batches
 
 
-def secondary_f4(torch, libxaac_amd, ctx, dev, n=16384, launches=20):
+def secondary_f4(torch, libxaac_amd, ctx, dev, n=16384, launches=20, hip_streams=2):
     """SURVEY.md row f4's transforms outside the C4 chain -- USAC FD, 960-line, AAC-LD and AAC-ELD IMDCT -- on resident synthetic
     batches of n channel-frames: microseconds per launch (wall clock around `launches` back-to-back launches on the
     library's stream) and the fraction of the HBM roof their algorithmic bytes reach.  Parity: tests/test_usac_imdct.py,
@@ -226,17 +226,25 @@ def secondary_f4(torch, libxaac_amd, ctx, dev, n=16384, launches=20):
     rng = np.random.default_rng(4)
     out = {}
 
-    def timed(name, fn, alg_bytes):
-        for _ in range(3):
-            fn()
-        ctx.sync()
+    # launches dealt out over `hip_streams` HIP streams like the headline's steps: lane q = its own context and its own carried
+    # buffers (overlap, window state, outputs: `fresh` clones them), an independent batch of n channel-frames; inputs are shared
+    streams = [torch.cuda.Stream(device=dev) for _ in range(hip_streams - 1)]    # (kept alive with their contexts)
+    ctxs = [ctx] + [libxaac_amd.XaacContext(dev.index or 0, sq.cuda_stream) for sq in streams]
+    fresh = lambda *ts: [ts] + [tuple(t.clone() for t in ts) for _ in ctxs[1:]]
+
+    def timed(name, fn, alg_bytes, nl=None):
+        """fn(q): one launch on lane q; nl: lanes used (default: all)"""
+        nl = len(ctxs) if nl is None else nl
+        for i in range(3 * nl):
+            fn(i % nl)
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(launches):
-            fn()
-        ctx.sync()
+        for i in range(launches):
+            fn(i % nl)
+        torch.cuda.synchronize()
         us = (time.perf_counter() - t0) / launches * 1e6
         out[name] = {"us_per_launch": round(us, 1), "channel_frames_per_s": round(n / us * 1e6),
-                     "roofline_frac": round(alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+                     "roofline_frac": round(alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "hip_streams": nl}
 
     spec = torch.from_numpy(rng.integers(-2 ** 17, 2 ** 17, (n, 1024)).astype(np.int32)).to(dev)
     z8 = lambda *shape: torch.zeros(shape, dtype=torch.uint8, device=dev)
@@ -244,12 +252,15 @@ def secondary_f4(torch, libxaac_amd, ctx, dev, n=16384, launches=20):
     o32 = torch.zeros((n, 1024), dtype=torch.int32, device=dev)
     ics_u = torch.tensor([[0, 1]] * n, dtype=torch.uint8, device=dev)
     sp_u = z8(n)
-    timed("usac_fd_1024", lambda: ctx.usac_imdct_process_batch(spec, ics_u, ov, sp_u, o32), n * 16384)
+    lu = fresh(ov, sp_u, o32)
+    # (the USAC kernel's launches do not gain from a second stream -- 120 us alone, 139 us dealt out over two -- so it runs on one)
+    timed("usac_fd_1024", lambda q: ctxs[q].usac_imdct_process_batch(spec, ics_u, lu[q][0], lu[q][1], lu[q][2]), n * 16384, nl=1)
     spec9 = spec[:, :960].contiguous()
     ov9 = torch.zeros((n, 480), dtype=torch.int32, device=dev)
     out9 = torch.zeros(n * 960, dtype=torch.int32, device=dev)
     ics9, st9 = z8(n, 2), z8(n, 2)
-    timed("aac_960", lambda: ctx.imdct960_process_batch(spec9, ics9, ov9, st9, out9), n * 11520)
+    l9 = fresh(ov9, st9, out9)
+    timed("aac_960", lambda q: ctxs[q].imdct960_process_batch(spec9, ics9, l9[q][0], l9[q][1], l9[q][2]), n * 11520)
     for fl in (512, 480):
         for eld in (0, 1):
             nov = 3 * fl if eld else fl // 2
@@ -257,11 +268,13 @@ def secondary_f4(torch, libxaac_amd, ctx, dev, n=16384, launches=20):
             ol = torch.zeros((n, nov), dtype=torch.int32, device=dev)
             shp, spv = z8(n), z8(n)
             pcm = torch.zeros(n * fl, dtype=torch.int16, device=dev)
+            ll = fresh(ol, spv, pcm)
             timed("%s_%d" % ("aac_eld" if eld else "aac_ld", fl),
-                  lambda sl=sl, ol=ol, shp=shp, spv=spv, pcm=pcm, fl=fl, eld=eld: ctx.imdct_ld_process_batch(sl, shp, ol, spv, pcm, fl, eld),
+                  lambda q, sl=sl, ll=ll, shp=shp, fl=fl, eld=eld: ctxs[q].imdct_ld_process_batch(sl, shp, ll[q][0], ll[q][1], ll[q][2], fl, eld),
                   n * (4 * fl + 2 * fl + (4 * nov + 11 * fl if eld else 8 * nov)))
     out["n_channel_frames"] = n
-    out["timing"] = "wall clock around back-to-back launches (launch overhead included): roofline_frac is on the step's own clock"
+    out["timing"] = ("wall clock around back-to-back launches dealt out over %d HIP streams (launch overhead included): roofline_frac is on "
+                     "the step's own clock" % len(ctxs))
     # the PVC envelope decoder (tests/test_pvc.py): 2:1 frames at start band 12, the QMF rows of one stream-frame per channel
     fr = np.zeros((n, libxaac_amd.PVC_FRAME_BYTES), np.uint8)
     fr[:, 0], fr[:, 2], fr[:, 4] = 1 + (np.arange(n) & 1), 2, 12           # pvc_mode, pvc_rate, first_bnd_idx
@@ -269,7 +282,8 @@ def secondary_f4(torch, libxaac_amd, ctx, dev, n=16384, launches=20):
     pv_f = torch.from_numpy(fr).to(dev)
     pv_q = torch.randn((2048, 64, 64), dtype=torch.float32, device=dev).mul_(900.0).repeat(n // 2048, 1, 1)
     pv_st, pv_out = z8(n, libxaac_amd.PVC_STATE_BYTES), torch.zeros((n, 16, 64), dtype=torch.float32, device=dev)
-    timed("esbr_pvc", lambda: ctx.pvc_process_batch(pv_f, pv_q, pv_q, pv_st, pv_out), n * (32 * 16 * 2 * 4 + 228 + 4096 + 188))
+    lp = fresh(pv_st, pv_out)
+    timed("esbr_pvc", lambda q: ctxs[q].pvc_process_batch(pv_f, pv_q, pv_q, lp[q][0], lp[q][1]), n * (32 * 16 * 2 * 4 + 228 + 4096 + 188))
     return out
 
 
@@ -394,9 +408,10 @@ def secondary_esbr(torch, libxaac_amd, ctx, dev, steps, warmup, hip_streams=2):
     status = torch.zeros(n, dtype=torch.int32, device=dev)
     # the timed steps are dealt out over `hip_streams` HIP streams like the headline's (Workload): lane q = its own context,
     # states, workspace and outputs (an independent batch of the same streams); the side info and the core samples are shared
-    lanes = [(ctx, st, pst, ws, out_l, out_r, status)]
+    lanes, lane_streams = [(ctx, st, pst, ws, out_l, out_r, status)], []
     for _ in range(hip_streams - 1):
         sq = torch.cuda.Stream(device=dev)
+        lane_streams.append(sq)    # (kept alive with its context)
         lanes.append((libxaac_amd.XaacContext(dev.index or 0, sq.cuda_stream), st0.clone(), ps0.clone(), torch.zeros_like(ws),
                       torch.zeros_like(out_l), torch.zeros_like(out_r), torch.zeros_like(status)))
     run_on = lambda q, **kw: lanes[q][0].esbr_sbr_process_batch(core, hd, fr, sd, lanes[q][1], lanes[q][4], lanes[q][3], lanes[q][6],
@@ -1062,7 +1077,7 @@ def main():
             secondary["c4_esbr"] = {"error": repr(e)}
         torch.cuda.empty_cache()
         try:
-            secondary["f4_transforms"] = secondary_f4(torch, libxaac_amd, ctx, dev)
+            secondary["f4_transforms"] = secondary_f4(torch, libxaac_amd, ctx, dev, hip_streams=args.hip_streams)
         except Exception as e:
             secondary["f4_transforms"] = {"error": repr(e)}
         torch.cuda.empty_cache()

@@ -29,19 +29,25 @@ __global__ __launch_bounds__(64 * XAAC_I960_WAVES_PER_WG) void xaac_imdct960_ker
   const int ch = blockIdx.x * XAAC_I960_WAVES_PER_WG + wave;
   if (ch >= p.n_ch) return;
   int32_t *y = smem + wave * (960 + 960), *a = y + 960;
-  const int seq = p.ics[ch].window_sequence, shape = p.ics[ch].window_shape;
-  const int pseq = p.state[ch].window_sequence, pshape = p.state[ch].window_shape;
+  /* the window words and the 960 lines: in flight together (the lines used to wait for the window check's round trip) */
+  const int32_t *spec = p.spec + (size_t)ch * 960;
+  int32_t *gov = p.overlap + (size_t)ch * 480;
+  static_assert(sizeof(p.ics[0]) == 2 && sizeof(p.state[0]) == 2, "two bytes each: sequence, shape");
+  const int ics_v = *reinterpret_cast<const uint16_t *>(p.ics + ch), st_v = *reinterpret_cast<const uint16_t *>(p.state + ch);
+  int32_t sv[15];
+#pragma unroll
+  for (int k = 0; k < 15; k++) sv[k] = spec[lane + 64 * k];
+  const int ics_bits = __builtin_amdgcn_readfirstlane(ics_v), st_bits = __builtin_amdgcn_readfirstlane(st_v);
+  const int seq = ics_bits & 0xff, shape = ics_bits >> 8, pseq = st_bits & 0xff, pshape = st_bits >> 8;
   if (seq > 3 || shape > 1 || pseq > 3 || pshape > 1) { /* values the bitstream fields cannot carry: left untouched */
     if (lane == 0 && p.status) p.status[ch] = XAAC_FATAL_BAD_WINDOW_SEQ;
     return;
   }
-  const int32_t *spec = p.spec + (size_t)ch * 960;
-  int32_t *gov = p.overlap + (size_t)ch * 480;
   int32_t acc = 0;
-  X9_FOR(i, 960) {
-    const int32_t v = spec[i];
-    a[i] = v;
-    acc |= fx_abs_nrm(v);
+#pragma unroll
+  for (int k = 0; k < 15; k++) {
+    a[lane + 64 * k] = sv[k];
+    acc |= fx_abs_nrm(sv[k]);
   }
   const int headroom = fx_norm32(wave_or(acc));
   x9_sync();

@@ -30,18 +30,30 @@ __global__ __launch_bounds__(64 * XAAC_LD_WAVES_PER_WG) void xaac_imdct_ld_kerne
   const int ch = blockIdx.x * XAAC_LD_WAVES_PER_WG + wave;
   if (ch >= p.n_ch) return;
   int32_t *a = smem + wave * PER_WAVE, *b = a + 1024;
-  const int shape = p.window_shape[ch], shape_prev = p.shape_prev[ch];
+  /* the two window shapes, the F lines and (LD) the F / 2 old overlap words: every load the channel-frame starts with is in
+     flight before the first is looked at (shapes, then lines, then -- behind the transform -- the overlap were three memory round
+     trips in a kernel whose arithmetic takes less time than one) */
+  const int32_t *spec = p.spec + (size_t)ch * F;
+  int32_t *gov = p.overlap + (size_t)ch * NOV;
+  const int shape_v = p.window_shape[ch], shape_prev_v = p.shape_prev[ch];
+  constexpr int NSV = (F + 63) / 64, NOR = ELD ? 1 : (NOV + 63) / 64;
+  int32_t sv[NSV], ovr[NOR];
+#pragma unroll
+  for (int k = 0; k < NSV; k++) sv[k] = lane + 64 * k < F ? spec[lane + 64 * k] : 0;
+  if (!ELD) {
+#pragma unroll
+    for (int k = 0; k < NOR; k++) ovr[k] = lane + 64 * k < NOV ? gov[lane + 64 * k] : 0;
+  }
+  const int shape = __builtin_amdgcn_readfirstlane(shape_v), shape_prev = __builtin_amdgcn_readfirstlane(shape_prev_v);
   if (shape > 1 || shape_prev > 1) { /* values the one-bit field cannot carry: left untouched */
     if (lane == 0 && p.status) p.status[ch] = XAAC_FATAL_BAD_WINDOW_SEQ;
     return;
   }
-  const int32_t *spec = p.spec + (size_t)ch * F;
-  int32_t *gov = p.overlap + (size_t)ch * NOV;
   int32_t acc = 0;
-  X9_FOR(i, F) { /* the lines wait in the upper half of a: the pre twiddle is their only reader */
-    const int32_t v = spec[i];
-    a[512 + i] = v;
-    acc |= fx_abs_nrm(v);
+#pragma unroll
+  for (int k = 0; k < NSV; k++) { /* the lines wait in the upper half of a: the pre twiddle is their only reader */
+    if (lane + 64 * k < F) a[512 + lane + 64 * k] = sv[k];
+    acc |= fx_abs_nrm(sv[k]);
   }
   const int e = fx_norm32(wave_or(acc)) - 1;
   x9_sync();
@@ -52,7 +64,9 @@ __global__ __launch_bounds__(64 * XAAC_LD_WAVES_PER_WG) void xaac_imdct_ld_kerne
        overwritten F / 64 iterations later (program order within the wave: each iteration's store consumes its own load) */
     xl_eld_overlap_add<F>(a, gov, gov, pcm, p.ch_fac, q, lane, nl);
   } else { /* LD: the F / 2 old overlap words move into the free work array before the new ones overwrite their source */
-    X9_FOR(i, NOV) b[i] = gov[i];
+#pragma unroll
+    for (int k = 0; k < NOR; k++)
+      if (lane + 64 * k < NOV) b[lane + 64 * k] = ovr[k];
     x9_sync();
     xl_ld_overlap_add<F>(a, b, gov, pcm, p.ch_fac, q, shape_prev, lane, nl);
   }

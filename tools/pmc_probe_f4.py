@@ -14,7 +14,7 @@ def main():
     import bench
     dev = torch.device("cuda:0")
     ctx = libxaac_amd.XaacContext(0, torch.cuda.current_stream().cuda_stream)
-    print(bench.secondary_f4(torch, libxaac_amd, ctx, dev, launches=6))
+    print(bench.secondary_f4(torch, libxaac_amd, ctx, dev, launches=6, hip_streams=int(os.environ.get('HIP_STREAMS', '1'))))
 
 
 if __name__ == "__main__":
