@@ -84,8 +84,11 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_analysis_kernel(XaacQ
   const int waves_total = gridDim.x * XAAC_QMF_WAVES;
   for (int pair = blockIdx.x * XAAC_QMF_WAVES + wave; pair < n_pairs; pair += waves_total) {
     /* ---- history + new samples, time ordered ------------------------------------------ */
+    int wr_v[2] = {0, 0}, ph_v[2] = {0, 0};
     {
       /* all loads of both channels (5 ring + 16 PCM per lane and channel) in flight before the first LDS store */
+      /* (the rings by position, not by age: their loads then do not wait for the write positions, which only say where in the
+         time-ordered history a fetched sample belongs; write position and window phase are read here for the state update too) */
       int16_t hr[2][5], hp[2][16];
 #pragma unroll
       for (int c = 0; c < 2; c++) {
@@ -93,14 +96,12 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_analysis_kernel(XaacQ
         if (ch < p.n_ch) { /* (uniform) */
           const xaac_qmf_ana_state *st = reinterpret_cast<const xaac_qmf_ana_state *>(
               reinterpret_cast<const char *>(p.state) + (size_t)ch * p.state_stride);
-          const int wr = st->wr;
+          wr_v[c] = st->wr;
+          ph_v[c] = st->phase;
           const int cf = p.ch_fac;
           const int16_t *src = p.pcm + (size_t)(ch / cf) * 1024 * cf + (ch % cf);
 #pragma unroll
-          for (int j = 0; j < 5; j++) {
-            const int a = lane + 64 * j;
-            hr[c][j] = a < 288 ? st->ring[ana_ring_pos(wr, a)] : (int16_t)0;
-          }
+          for (int j = 0; j < 5; j++) hr[c][j] = st->ring[lane + 64 * j];
 #pragma unroll
           for (int j = 0; j < 16; j++) hp[c][j] = src[(size_t)(lane + 64 * j) * cf];
         }
@@ -110,9 +111,12 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_analysis_kernel(XaacQ
         const int ch = 2 * pair + c;
         int16_t *h = hist + c * kHist;
         if (ch < p.n_ch) {
+          const int wr = __builtin_amdgcn_readfirstlane(wr_v[c]);
 #pragma unroll
           for (int j = 0; j < 5; j++) {
-            const int a = lane + 64 * j;
+            int a = lane + 64 * j - wr - 32; /* age of the sample at this position: ana_ring_pos(wr, a) = position */
+            a += a < 0 ? 320 : 0;
+            a += a < 0 ? 320 : 0;
             if (a < 288) h[287 - a] = hr[c][j];
           }
 #pragma unroll
@@ -179,8 +183,8 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_analysis_kernel(XaacQ
       if (ch >= p.n_ch) break;
       xaac_qmf_ana_state *st =
           reinterpret_cast<xaac_qmf_ana_state *>(reinterpret_cast<char *>(p.state) + (size_t)ch * p.state_stride);
-      const int wr_new = (st->wr + 256) % 320;
-      const int ph_new = ana_phase_after_frame(st->phase);
+      const int wr_new = (__builtin_amdgcn_readfirstlane(wr_v[c]) + 256) % 320;
+      const int ph_new = ana_phase_after_frame(__builtin_amdgcn_readfirstlane(ph_v[c]));
       const int16_t *h = hist + c * kHist;
       for (int a = lane; a < 320; a += 64) st->ring[ana_ring_pos(wr_new, a)] = h[kHist - 1 - a];
       if (lane == 0) {
@@ -394,6 +398,28 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
 #define XQ_SYN_GROUP_LP 16 /* measured on the LP chain: 8: 141 us, 16: 129, 32: 129, 64: 132 */
 #endif
     constexpr int G = LP ? XQ_SYN_GROUP_LP : 8;
+    /* the lane's channel's scale row, the two ring offsets and the two inactive flags: asked for here, in front of the rows, and
+       looked at behind the transform -- read where they are used they were three more memory round trips per pair */
+    int16_t sfv[6] = {0, 0, 0, 0, 0, 0};
+    int d_v[2] = {0, 0}, off_v[2] = {0, 0};
+    {
+      const int ch = 2 * pair + (lane >> 5);
+      const int16_t *sf = p.scale + (size_t)p.scale_stride * (ch < p.n_ch ? ch : p.n_ch - 1);
+#pragma unroll
+      for (int k = 0; k < 4; k++) sfv[k] = sf[k];
+      if (p.per_ch_bands) {
+        sfv[4] = sf[4];
+        sfv[5] = sf[5];
+      }
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        const int chc = 2 * pair + c;
+        if (chc < p.n_ch) {
+          d_v[c] = reinterpret_cast<const xaac_qmf_syn_state *>(reinterpret_cast<const char *>(p.state) + (size_t)chc * p.state_stride)->drc_offset;
+          if (p.per_ch_bands) off_v[c] = p.scale[(size_t)p.scale_stride * chc + 6];
+        }
+      }
+    }
     for (int r0 = 0; r0 < 64; r0 += G) {
       int32_t tmp[G][ROW / 64];
 #pragma unroll
@@ -414,9 +440,7 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
     /* ---- per-slot: region rescale (qmf_dec.c:937-953) + inverse modulation; lane = slot ----------- */
     int16_t b[BLK];
     {
-      const int ch = 2 * pair + (lane >> 5);
-      const int chc = ch < p.n_ch ? ch : p.n_ch - 1;
-      const int16_t *sf = p.scale + (size_t)p.scale_stride * chc; /* lb_scale, ov_lb_scale, hb_scale, st_syn_scale */
+      const int16_t *sf = sfv; /* lb_scale, ov_lb_scale, hb_scale, st_syn_scale (+ lsb, usb) of the lane's channel */
       const int st_syn = sf[3];
       const int lsb = p.per_ch_bands ? sf[4] : p.lsb, usb = p.per_ch_bands ? sf[5] : p.usb;
       const int bias = LP ? 4 : 8;
@@ -460,7 +484,7 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
       if (ch >= p.n_ch) break;
       const xaac_qmf_syn_state *st = reinterpret_cast<const xaac_qmf_syn_state *>(
           reinterpret_cast<const char *>(p.state) + (size_t)ch * p.state_stride);
-      const int d = st->drc_offset;
+      const int d = __builtin_amdgcn_readfirstlane(d_v[c]);
       constexpr int HJ = 9 * BLK / 64;
       int16_t hist[HJ]; /* 9 slots x BLK samples over 64 lanes: all loads in flight together */
 #pragma unroll
@@ -483,7 +507,7 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
     for (int c = 0; c < 2; c++) {
       const int ch = 2 * pair + c;
       if (ch >= p.n_ch) break;
-      if (p.per_ch_bands && p.scale[(size_t)p.scale_stride * ch + 6]) continue; /* channel inactive this frame */
+      if (p.per_ch_bands && __builtin_amdgcn_readfirstlane(off_v[c])) continue; /* channel inactive this frame */
       const int cf = p.pcm_sample_stride ? p.pcm_sample_stride : p.ch_fac;
       int16_t *dst = p.pcm_sample_stride ? p.pcm + (size_t)ch * p.pcm_ch_stride
                                          : p.pcm + (size_t)(ch / cf) * (32 * NC) * cf + (ch % cf);
@@ -503,10 +527,10 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
     for (int c = 0; c < 2; c++) {
       const int ch = 2 * pair + c;
       if (ch >= p.n_ch) break;
-      if (p.per_ch_bands && p.scale[(size_t)p.scale_stride * ch + 6]) continue;
+      if (p.per_ch_bands && __builtin_amdgcn_readfirstlane(off_v[c])) continue;
       xaac_qmf_syn_state *st =
           reinterpret_cast<xaac_qmf_syn_state *>(reinterpret_cast<char *>(p.state) + (size_t)ch * p.state_stride);
-      const int d_new = (st->drc_offset + RING - (32 * BLK) % RING) % RING; /* 32 slots of BLK downwards */
+      const int d_new = (__builtin_amdgcn_readfirstlane(d_v[c]) + RING - (32 * BLK) % RING) % RING; /* 32 slots of BLK downwards */
       const int ph_new = (st->phase + 128) % 640;
       for (int i = lane; i < RING; i += 64) {
         const int A = 1 + i / BLK; /* age relative to the NEXT frame's slot 0: 1..10 */
