@@ -17,7 +17,7 @@ summary() { python $R/tools/rocprof_summary.py "$@"; }
 
 chain() { # $1 = c4 | c3: kernel stats of the bench command, HBM and SQ counter passes over the probe
   W=$1
-  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/ks_${TAG}_$W -o r -- python $R/bench.py --workload $W --steps 60 --warmup 6 --no-cpu-baseline --no-secondary > $O/${TAG}_${W}_bench_under_rocprof.json 2> /dev/null
+  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/ks_${TAG}_$W -o r -- python $R/bench.py --workload $W --hip-streams 1 --steps 60 --warmup 6 --no-cpu-baseline --no-secondary > $O/${TAG}_${W}_bench_under_rocprof.json 2> /dev/null
   summary stats $(find /tmp/ks_${TAG}_$W -name "*.db") > $O/${TAG}_${W}_kernel_stats.txt
   i=0
   for C in "FETCH_SIZE" "WRITE_SIZE" "$SQ1"; do
