@@ -468,7 +468,8 @@ int main(int argc, char **argv) {
   struct Pending {
     bool valid, mono_twice, first;
     int slot, which;
-  } pending = {false, false, false, 0, 0};
+    bool some_mono; /* a PS batch with streams that have no PS in this frame: their left samples also go to the right */
+  } pending = {false, false, false, 0, 0, false};
   auto consume = [&]() {
     if (!pending.valid) return;
     HIP(hipEventSynchronize(ev_down[pending.slot]));
@@ -482,6 +483,13 @@ int main(int argc, char **argv) {
     }
     if (pending.mono_twice) /* mono duplicated to stereo (api.c:3639-3660), from the back so that it can be done in place */
       for (long k = (long)N * 2048 - 1; k >= 0; k--) h_pcm[2 * k] = h_pcm[2 * k + 1] = h_pcm[k];
+    if (pending.some_mono) { /* the same for the streams of a PS batch whose frame carried no PS: the bank pair wrote their left
+                                samples into the interleaved rows and left the right ones alone */
+      const std::vector<int32_t> &fl = st[pending.which].flags;
+      for (int i = 0; i < N; i++)
+        if (alive[(size_t)i] == 0 && fl[(size_t)i * 8 + 5] == 0)
+          for (int k = 0; k < 2048; k++) h_pcm[(size_t)i * 4096 + 2 * k + 1] = h_pcm[(size_t)i * 4096 + 2 * k];
+    }
     lap(2);
     const size_t skip = (!sbr && pending.first) ? (size_t)delay * out_ch : 0; /* the limiter's delay is cut from the first frame */
     /* (with -esbr:1 the reference's command line decoder does not write an SBR stream's first frame:
@@ -504,7 +512,7 @@ int main(int argc, char **argv) {
     if (s.delivered == 0) break;
     int16_t *d_pcm = d_pcm2[slot], *d_mono = d_mono2[slot];
     int32_t *d_status = d_status2[slot];
-    bool mono_twice = false;
+    bool mono_twice = false, some_mono = false;
     if (s.delivered != N) {
       if (!list_mode) die("streams of different lengths in one batch");
       for (int i = 0; i < N; i++)
@@ -655,7 +663,10 @@ int main(int argc, char **argv) {
           with_ps += s.status[(size_t)i] == 0 && s.flags[(size_t)i * 8 + 5] != 0;
           if (s.status[(size_t)i] == 0 && s.flags[(size_t)i * 8 + 6]) idx.push_back(i), starts++;
         }
-        if (with_ps != 0 && with_ps != s.delivered) die("a batch mixing PS and non-PS frames");
+        /* streams with and without parametric stereo in one step (independent HE-AAC / HE-AACv2 streams, or streams whose PS
+           starts at different frames): the batch runs with the PS launch, which passes a stream without PS through as the mono
+           frame it is (sbr_ps_kernel.hip: sbr_dec.c:1246) -- its right bank stays idle, its left samples are doubled on the host */
+        some_mono = with_ps != 0 && with_ps != s.delivered;
         xaac_sbr_hq_batch b;
         memset(&b, 0, sizeof(b));
         b.n_ch = N, b.in_ch_fac = 1, b.out_ch_fac = 1, b.pcm_in = d_core, b.header = d_header, b.frame = d_frame;
@@ -686,7 +697,7 @@ int main(int argc, char **argv) {
     if (sbr) HIP(hipMemcpyAsync(h_status2[slot], d_status, (size_t)NC * 4, hipMemcpyDeviceToHost, down));
     HIP(hipEventRecord(ev_down[slot], down));
     consume(); /* the step before this one: its PCM has been on its way while this step's work was queued */
-    pending = {true, mono_twice, first, slot, which};
+    pending = {true, mono_twice, first, slot, which, some_mono};
     if (profile) consume(); /* phase timing wants one step at a time */
     first = false;
   }

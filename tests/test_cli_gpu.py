@@ -105,3 +105,39 @@ def test_a_damaged_stream_of_a_list_ends_alone(tmp_path):
     with wave.open(str(out / "damaged.wav")) as w:
         part = w.readframes(w.getnframes())
         assert w.getnframes() == 20 * 2048 and part == whole[:len(part)]
+
+
+def _adts_frames(data):
+    pos, out = 0, []
+    while pos + 7 <= len(data):
+        n = ((data[pos + 3] & 3) << 11) | (data[pos + 4] << 3) | (data[pos + 5] >> 5)
+        out.append(data[pos:pos + n])
+        pos += n
+    return out
+
+
+def test_a_batch_mixing_streams_with_and_without_parametric_stereo(tmp_path):
+    """-ilist, -esbr:0: an HE-AAC (mono) stream, an HE-AACv2 one and two streams whose parametric stereo starts at different
+    frames (HE-AAC frames with HE-AACv2 frames behind them) decoded in lock step -- every step sees frames with and without PS.
+    Each WAV must equal what the reference decoder writes for that stream alone (`oracle/_ref/xaacdec -esbr:0`)."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "xaacdec")
+    if not os.path.exists(ref):
+        pytest.fail("oracle/_ref/xaacdec missing: the reference binary did not travel with the snapshot")
+    v1 = _adts_frames(open(os.path.join(STREAMS, "mono_aot5_32k.aac"), "rb").read())
+    v2 = _adts_frames(open(os.path.join(STREAMS, "mix_aot29_32k.aac"), "rb").read())
+    files = {"mono_aot5_32k": b"".join(v1), "mix_aot29_32k": b"".join(v2), "late_ps_a": b"".join(v1[:7] + v2),
+             "late_ps_b": b"".join(v1[:16] + v2[:20])}
+    lst = tmp_path / "list.txt"
+    for n, d in files.items():
+        (tmp_path / (n + ".aac")).write_bytes(d)
+    lst.write_text("\n".join(str(tmp_path / (n + ".aac")) for n in files) + "\n")
+    out = tmp_path / "out"
+    out.mkdir()
+    p = subprocess.run([CLI, "-ilist:" + str(lst), "-odir:" + str(out), "-esbr:0"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-500:]
+    for n in files:
+        want = str(tmp_path / (n + "_ref.wav"))
+        subprocess.run([ref, "-ifile:" + str(tmp_path / (n + ".aac")), "-ofile:" + want, "-esbr:0"], check=True, capture_output=True)
+        with wave.open(want) as a, wave.open(str(out / (n + ".wav"))) as b:
+            assert (a.getnchannels(), a.getframerate(), a.getnframes()) == (b.getnchannels(), b.getframerate(), b.getnframes()), n
+            assert a.readframes(a.getnframes()) == b.readframes(b.getnframes()), n
