@@ -441,6 +441,8 @@ void batch_launch(const xaac_parse_batch *b, bool caller_works) {
 
 int32_t xaac_parse_batch_run(const xaac_parse_batch *b) {
   if (!batch_ok(b)) return XAAC_PARSE_ERR_SYNTAX;
+  /* between _start and _wait the team belongs to that batch: waiting for it here would wait for the caller's own _wait */
+  if (g_job.in_flight.load(std::memory_order_acquire)) return XAAC_PARSE_ERR_SYNTAX;
   batch_launch(b, true);
   team().join(true);
   const int ok = g_job.ok.load();
@@ -450,17 +452,21 @@ int32_t xaac_parse_batch_run(const xaac_parse_batch *b) {
 
 int32_t xaac_parse_batch_start(const xaac_parse_batch *b) {
   if (!batch_ok(b)) return XAAC_PARSE_ERR_SYNTAX;
+  /* one batch in flight at a time, claimed before the team is taken: a second _start (or a _run) behind an unanswered _start is
+     an error the caller gets back, not a wait for a release that only its own _wait would bring */
+  bool idle = false;
+  if (!g_job.in_flight.compare_exchange_strong(idle, true, std::memory_order_acq_rel)) return XAAC_PARSE_ERR_SYNTAX;
   batch_launch(b, false);
-  g_job.in_flight.store(true, std::memory_order_release);
   return XAAC_PARSE_OK;
 }
 
 int32_t xaac_parse_batch_wait(double *busy_seconds) {
-  if (!g_job.in_flight.exchange(false, std::memory_order_acq_rel)) return XAAC_PARSE_ERR_SYNTAX; /* nothing was started */
+  if (!g_job.in_flight.load(std::memory_order_acquire)) return XAAC_PARSE_ERR_SYNTAX; /* nothing was started */
   team().join(false);
   const int ok = g_job.ok.load();
   if (busy_seconds) *busy_seconds = team().helpers_busy_seconds();
   team().release();
+  g_job.in_flight.store(false, std::memory_order_release); /* (behind the release: a _start that sees it finds the team free) */
   return ok;
 }
 

@@ -636,12 +636,17 @@ int main(int argc, char **argv) {
         bool any = false;
         for (int i = 0; i < N; i++) {
           const int32_t *f = &s.flags[(size_t)i * 8];
-          const bool live = s.status[(size_t)i] == 0;
-          for (int k = 0; k < 8; k++) h_flags[(size_t)i * 8 + k] = live ? f[k] : 0;
-          any = any || (live && (f[1] || f[3]));
+          any = any || (s.status[(size_t)i] == 0 && (f[1] || f[3]));
         }
         if (any) {
-          HIP(hipStreamSynchronize(stream)); /* (h_flags is one buffer: the step before may still be reading it) */
+          /* h_flags is one pinned buffer: an earlier step's copy up may still be reading it, so the stream is drained BEFORE the
+             rows are rewritten (rewriting first and draining behind, as this did, could hand that copy the new rows) */
+          HIP(hipStreamSynchronize(stream));
+          for (int i = 0; i < N; i++) {
+            const int32_t *f = &s.flags[(size_t)i * 8];
+            const bool live = s.status[(size_t)i] == 0;
+            for (int k = 0; k < 8; k++) h_flags[(size_t)i * 8 + k] = live ? f[k] : 0;
+          }
           HIP(hipMemcpyAsync(d_flags, h_flags, (size_t)N * 8 * 4, hipMemcpyHostToDevice, stream));
           xaac_sbr_apply_side_batch ab;
           memset(&ab, 0, sizeof(ab));

@@ -271,3 +271,30 @@ def test_batch_parser_equals_the_single_stream_parser(name, mode):
         ok, _ = bp.wait_step(check=False)   # the call started behind the last one: nothing left to parse
         assert ok == 0
     bp.close()
+
+
+def test_a_second_start_or_a_run_behind_an_unanswered_start_is_an_error_not_a_deadlock():
+    """xaac_parse_batch_start twice, or xaac_parse_batch_run between _start and _wait: an error code comes back (the call used to
+    wait for the team its own _wait would have released), the first batch still completes, and a _wait with nothing started is
+    an error too"""
+    import ctypes
+    import pytest
+    from libxaac_amd import PS_FRAME_BYTES, SBR_FRAME_BYTES, SBR_HEADER_BYTES
+    data = stream("mix_aot29_32k")
+    bp = decoder.BatchParser([data] * 4, threads=2)
+    n = bp.n
+    spec, ics = np.zeros((n, 1024), np.int32), np.zeros((n, 2), np.uint8)
+    hdr, frm, psf = np.zeros((n, SBR_HEADER_BYTES), np.uint8), np.zeros((n, SBR_FRAME_BYTES), np.uint8), np.zeros((n, PS_FRAME_BYTES), np.uint8)
+    flags = np.zeros((n, 8), np.int32)
+    try:
+        bp.start_step(spec, ics, hdr, frm, psf, flags)
+        with pytest.raises(RuntimeError):
+            bp.start_step(spec, ics, hdr, frm, psf, flags)
+        bp._in_flight = True      # (the failed call above must not make close() forget the batch that IS in flight)
+        b = bp._descriptor(spec, ics, hdr, frm, psf, flags, bp.sbr)
+        assert bp.lib.xaac_parse_batch_run(ctypes.byref(b)) != 0
+        good, _ = bp.wait_step()
+        assert good.all()
+        assert bp.lib.xaac_parse_batch_wait(None) != 0
+    finally:
+        bp.close()
