@@ -435,6 +435,15 @@ FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_f
          operands in flight meanwhile.  The body has no lane-dependent branches: every lane runs the chain arithmetic
          (on don't-care values where it has no chain), band classes are selects, only the stores are predicated. */
       const int is_ap = sb < 23, is_d14 = sb >= 23 && sb < 35;
+      /* the band's scale shift as the two counts of xp_adj_word, for the overlap slots (l < 6) and for the others: lane
+         constants, chosen per slot by a uniform condition (worked out per word they were a dozen instructions of every slot) */
+      int shl_ov, shr_ov, shl_lb, shr_lb;
+      {
+        const int s_ov = sb < lsb ? ov_lb_shift : (sb < usb ? hb_shift : 0), s_lb = sb < lsb ? lb_shift : (sb < usb ? hb_shift : 0);
+        const int c_ov = s_ov > 31 ? 31 : (s_ov < -31 ? -31 : s_ov), c_lb = s_lb > 31 ? 31 : (s_lb < -31 ? -31 : s_lb);
+        shl_ov = c_ov > 0 ? c_ov : 0, shr_ov = c_ov < 0 ? -c_ov : 0;
+        shl_lb = c_lb > 0 ? c_lb : 0, shr_lb = c_lb < 0 ? -c_lb : 0;
+      }
       const int ldj = is_d14 ? 2 * (sb - 23) : 0, dlj = is_d14 ? sb - 23 : 12, apj = hyb_chain ? csb : 10;
       int16_t tr_nx = w->ratio[0][bin_sb];
       int32_t hre_nx = w->hyb_l[0][csb], him_nx = w->hyb_l[0][10 + csb];
@@ -474,8 +483,8 @@ FX_HD int xp_ps_frame(const XsCx &cx, const XpTables *T, PS *ps, const xaac_ps_f
             him_nx = w->hyb_l[ln][10 + csb];
             ld_nx = xp_pack16(ps->ld[pn][ldj], ps->ld[pn][ldj + 1]);
           }
-          const int sh = sb < lsb ? (l < 6 ? ov_lb_shift : lb_shift) : (sb < usb ? hb_shift : 0);
-          const int32_t re0 = xp_adj_word(cre[j], sh), im0 = xp_adj_word(cim[j], sh);
+          const int shl = l < 6 ? shl_ov : shl_lb, shr = l < 6 ? shr_ov : shr_lb;
+          const int32_t re0 = (int32_t)((uint32_t)cre[j] << shl) >> shr, im0 = (int32_t)((uint32_t)cim[j] << shl) >> shr;
           const int16_t q_re = fx_round16(re0), q_im = fx_round16(im0);
           const uint32_t q = xp_pack16(q_re, q_im);
           /* the chain */
