@@ -335,6 +335,7 @@ struct BatchJob {
   xaac_parse_batch b;
   std::atomic<int> ok{0};
   std::atomic<bool> in_flight{false}; /* an xaac_parse_batch_start whose _wait has not come yet */
+  std::atomic<uint64_t> owner{0};     /* ... and the thread that made it */
 };
 BatchJob g_job;
 
@@ -431,8 +432,15 @@ int batch_threads(const xaac_parse_batch *b) {
 }
 
 /* takes the team, hands it the batch (a copy of the descriptor: the caller's may go out of scope before the team is done) */
+uint64_t this_thread() { return (uint64_t)std::hash<std::thread::id>()(std::this_thread::get_id()) | 1u; }
+
 void batch_launch(const xaac_parse_batch *b, bool caller_works) {
   team().acquire();
+  if (!caller_works) { /* _start: the batch in flight is this thread's from the moment the team is (a _wait on another thread
+                          finds the flag set as soon as this call has the team) */
+    g_job.owner.store(this_thread(), std::memory_order_relaxed);
+    g_job.in_flight.store(true, std::memory_order_release);
+  }
   g_job.b = *b;
   g_job.ok.store(0, std::memory_order_relaxed);
   team().launch(b->n_streams, batch_threads(b), [](int i) { parse_item(&g_job.b, i, &g_job.ok); }, caller_works);
@@ -441,8 +449,10 @@ void batch_launch(const xaac_parse_batch *b, bool caller_works) {
 
 int32_t xaac_parse_batch_run(const xaac_parse_batch *b) {
   if (!batch_ok(b)) return XAAC_PARSE_ERR_SYNTAX;
-  /* between _start and _wait the team belongs to that batch: waiting for it here would wait for the caller's own _wait */
-  if (g_job.in_flight.load(std::memory_order_acquire)) return XAAC_PARSE_ERR_SYNTAX;
+  /* between this thread's _start and its _wait the team belongs to that batch: waiting for it here would wait for the caller's
+     own _wait (another thread's batch in flight is simply waited for, as two _run calls wait for each other) */
+  if (g_job.in_flight.load(std::memory_order_acquire) && g_job.owner.load(std::memory_order_relaxed) == this_thread())
+    return XAAC_PARSE_ERR_SYNTAX;
   batch_launch(b, true);
   team().join(true);
   const int ok = g_job.ok.load();
@@ -452,21 +462,20 @@ int32_t xaac_parse_batch_run(const xaac_parse_batch *b) {
 
 int32_t xaac_parse_batch_start(const xaac_parse_batch *b) {
   if (!batch_ok(b)) return XAAC_PARSE_ERR_SYNTAX;
-  /* one batch in flight at a time, claimed before the team is taken: a second _start (or a _run) behind an unanswered _start is
-     an error the caller gets back, not a wait for a release that only its own _wait would bring */
-  bool idle = false;
-  if (!g_job.in_flight.compare_exchange_strong(idle, true, std::memory_order_acq_rel)) return XAAC_PARSE_ERR_SYNTAX;
+  /* a second _start (or a _run) of the thread whose _start is unanswered is an error it gets back, not a wait for a release that
+     only its own _wait would bring; behind another thread's batch the call waits like any other */
+  if (g_job.in_flight.load(std::memory_order_acquire) && g_job.owner.load(std::memory_order_relaxed) == this_thread())
+    return XAAC_PARSE_ERR_SYNTAX;
   batch_launch(b, false);
   return XAAC_PARSE_OK;
 }
 
 int32_t xaac_parse_batch_wait(double *busy_seconds) {
-  if (!g_job.in_flight.load(std::memory_order_acquire)) return XAAC_PARSE_ERR_SYNTAX; /* nothing was started */
+  if (!g_job.in_flight.exchange(false, std::memory_order_acq_rel)) return XAAC_PARSE_ERR_SYNTAX; /* nothing was started */
   team().join(false);
   const int ok = g_job.ok.load();
   if (busy_seconds) *busy_seconds = team().helpers_busy_seconds();
   team().release();
-  g_job.in_flight.store(false, std::memory_order_release); /* (behind the release: a _start that sees it finds the team free) */
   return ok;
 }
 
