@@ -95,12 +95,19 @@ cpu_set_t gpu_node_cpus(int device, bool *known) {
   fclose(f);
   return set;
 }
+int g_device = 0; /* the HIP device of this run (pinned<T>() asks for its NUMA node) */
 template <class T>
 T *pinned(size_t n) {
   static bool known = false;
-  static const cpu_set_t near = gpu_node_cpus(0, &known);
-  cpu_set_t before;
-  const bool moved = known && sched_getaffinity(0, sizeof(before), &before) == 0 && sched_setaffinity(0, sizeof(near), &near) == 0;
+  static const cpu_set_t near = gpu_node_cpus(g_device, &known);
+  cpu_set_t before, both;
+  /* first touch on the GPU's NUMA node: only CPUs this process may run on anyway (a cpuset that does not meet the node leaves the
+     thread where it is) */
+  bool moved = false;
+  if (known && sched_getaffinity(0, sizeof(before), &before) == 0) {
+    CPU_AND(&both, &before, &near);
+    moved = CPU_COUNT(&both) > 0 && sched_setaffinity(0, sizeof(both), &both) == 0;
+  }
   void *p = nullptr;
   HIP(hipHostMalloc(&p, n * sizeof(T) ? n * sizeof(T) : 16, hipHostMallocDefault));
   memset(p, 0, n * sizeof(T) ? n * sizeof(T) : 16);
