@@ -217,6 +217,21 @@ def make_inputs_c4(torch, device, sets, seed):
     return batches
 
 
+_LANES = {}
+
+
+def extra_lanes(torch, libxaac_amd, dev, n):
+    """n further (HIP stream, context) pairs on dev, the same ones every time: every leg of a run that deals its steps out over
+    several streams uses these.  (A stream per leg left the process with half a dozen streams by the time the end-to-end leg ran,
+    and that leg's own copy and compute streams then shared hardware queues: 3.1 -> 2.6 x 10^6 frames/s on the same box.)"""
+    key = (dev.index or 0)
+    have = _LANES.setdefault(key, [])
+    while len(have) < n:
+        st = torch.cuda.Stream(device=dev)
+        have.append((st, libxaac_amd.XaacContext(dev.index or 0, st.cuda_stream)))
+    return have[:n]
+
+
 def secondary_f4(torch, libxaac_amd, ctx, dev, n=16384, launches=20, hip_streams=2):
     """SURVEY.md row f4's transforms outside the C4 chain -- USAC FD, 960-line, AAC-LD and AAC-ELD IMDCT -- on resident synthetic
     batches of n channel-frames: microseconds per launch (wall clock around `launches` back-to-back launches on the
@@ -228,8 +243,7 @@ def secondary_f4(torch, libxaac_amd, ctx, dev, n=16384, launches=20, hip_streams
 
     # launches dealt out over `hip_streams` HIP streams like the headline's steps: lane q = its own context and its own carried
     # buffers (overlap, window state, outputs: `fresh` clones them), an independent batch of n channel-frames; inputs are shared
-    streams = [torch.cuda.Stream(device=dev) for _ in range(hip_streams - 1)]    # (kept alive with their contexts)
-    ctxs = [ctx] + [libxaac_amd.XaacContext(dev.index or 0, sq.cuda_stream) for sq in streams]
+    ctxs = [ctx] + [c for _, c in extra_lanes(torch, libxaac_amd, dev, hip_streams - 1)]
     fresh = lambda *ts: [ts] + [tuple(t.clone() for t in ts) for _ in ctxs[1:]]
 
     def timed(name, fn, alg_bytes, nl=None):
@@ -374,6 +388,22 @@ def secondary_end_to_end(copies=4096):
                      "pcm_equals_reference_decoder": exact_e, "native_cli": native_esbr}}
 
 
+def end_to_end_in_its_own_process():
+    """secondary_end_to_end() in a fresh interpreter: the decoder's loop has its own three HIP streams (copies up, kernels, copies
+    down), and in a process that has already driven two compute streams they lose a fifth of their rate to each other (measured on
+    one box, same library: 3.1 x 10^6 frames/s behind a one-stream run of the legs above, 2.6-2.8 behind a two-stream run) -- a
+    property of this process's history, not of the decoder, which a host would run in a process of its own anyway."""
+    import subprocess
+    code = "import json, bench; print('E2E_JSON ' + json.dumps(bench.secondary_end_to_end()))"
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    for line in p.stdout.splitlines()[::-1]:
+        if line.startswith("E2E_JSON "):
+            out = json.loads(line[len("E2E_JSON "):])
+            out["process"] = "its own (a fresh interpreter started by bench.py)"
+            return out
+    raise RuntimeError("end-to-end subprocess: rc %d, %s" % (p.returncode, p.stderr[-300:]))
+
+
 def secondary_esbr(torch, libxaac_amd, ctx, dev, steps, warmup, hip_streams=2):
     """The same HE-AACv2 streams through the reference's DEFAULT SBR path (-esbr:1, "Path A": 32-bit-ring QMF banks, float
     LPP transposer / envelope adjuster / parametric stereo; docs/NOTEBOOK.md 5f): xaac_esbr_sbr_process_batch on float core
@@ -408,12 +438,10 @@ def secondary_esbr(torch, libxaac_amd, ctx, dev, steps, warmup, hip_streams=2):
     status = torch.zeros(n, dtype=torch.int32, device=dev)
     # the timed steps are dealt out over `hip_streams` HIP streams like the headline's (Workload): lane q = its own context,
     # states, workspace and outputs (an independent batch of the same streams); the side info and the core samples are shared
-    lanes, lane_streams = [(ctx, st, pst, ws, out_l, out_r, status)], []
-    for _ in range(hip_streams - 1):
-        sq = torch.cuda.Stream(device=dev)
-        lane_streams.append(sq)    # (kept alive with its context)
-        lanes.append((libxaac_amd.XaacContext(dev.index or 0, sq.cuda_stream), st0.clone(), ps0.clone(), torch.zeros_like(ws),
-                      torch.zeros_like(out_l), torch.zeros_like(out_r), torch.zeros_like(status)))
+    lanes = [(ctx, st, pst, ws, out_l, out_r, status)]
+    for _, cq in extra_lanes(torch, libxaac_amd, dev, hip_streams - 1):
+        lanes.append((cq, st0.clone(), ps0.clone(), torch.zeros_like(ws), torch.zeros_like(out_l), torch.zeros_like(out_r),
+                      torch.zeros_like(status)))
     run_on = lambda q, **kw: lanes[q][0].esbr_sbr_process_batch(core, hd, fr, sd, lanes[q][1], lanes[q][4], lanes[q][3], lanes[q][6],
                                                                pf, lanes[q][2], lanes[q][5], **kw)
     run = lambda: run_on(0)
@@ -743,10 +771,8 @@ class Workload:
         # persistent kernels' staggered start) then overlaps with the other stream's kernels instead of leaving CUs idle.
         assert hip_streams >= 1 and sets % hip_streams == 0, "every stream set has to stay on one HIP stream"
         self.lanes = [(ctx, stream, self.ws, self.status, self.imdct_status)]
-        for _ in range(hip_streams - 1):
-            st = torch.cuda.Stream(device=dev)
-            self.lanes.append((libxaac_amd.XaacContext(dev.index or 0, st.cuda_stream), st, self._workspace(FRAMES_PER_STEP),
-                               None if self.status is None else torch.zeros_like(self.status),
+        for st, cq in extra_lanes(torch, libxaac_amd, dev, hip_streams - 1):
+            self.lanes.append((cq, st, self._workspace(FRAMES_PER_STEP), None if self.status is None else torch.zeros_like(self.status),
                                torch.zeros_like(self.imdct_status)))
 
     def _workspace(self, frames):
@@ -1091,7 +1117,7 @@ def main():
             secondary["f4_transforms"] = {"error": repr(e)}
         torch.cuda.empty_cache()
         try:
-            secondary["end_to_end"] = secondary_end_to_end()
+            secondary["end_to_end"] = end_to_end_in_its_own_process()
         except Exception as e:
             secondary["end_to_end"] = {"error": repr(e)}
         torch.cuda.empty_cache()

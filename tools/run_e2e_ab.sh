@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for S in 1 2; do
+for S in 2; do
 python bench.py --hip-streams $S --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); e=d['secondary']['end_to_end']
