@@ -83,7 +83,10 @@ typedef struct xaac_esbr_sbr_batch {
   const xaac_esbr_side *side;      /* [n_ch] */
   xaac_esbr_state *state;          /* [n_ch] in/out */
   float *out;                      /* [n_ch][2048] time_sample_buf out (left channel with PS) */
-  const xaac_ps_frame *ps_frame;   /* [n_ch], or NULL together with ps_state / out_r: no parametric stereo */
+  const xaac_ps_frame *ps_frame;   /* [n_ch], or NULL together with ps_state / out_r: no parametric stereo.  With PS, a stream
+                                      whose header.channel_mode is not PS_STEREO (3) has no right channel in this frame: its
+                                      out_r row and its right bank's state are left alone, as the reference leaves that bank
+                                      alone until PS starts (the caller doubles the left samples, api.c:3639-3660) */
   xaac_esbr_ps_state *ps_state;    /* [n_ch] in/out */
   float *out_r;                    /* [n_ch][2048] right channel (ps_dec->time_sample_buf[1]) */
   int32_t *status;                 /* optional [n_ch]: 0, or -1 where the reference returns an error */

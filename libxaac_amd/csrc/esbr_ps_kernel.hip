@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_ps_kernel(XaacEsbrPsParams p)
      round trips one behind the other) */
   static_assert(offsetof(xaac_ps_frame, border_position) == 4 && offsetof(xaac_ps_frame, num_env) == 18, "layout");
   const int head_v = lane < 5 ? reinterpret_cast<const int32_t *>(pf)[lane] : 0;
-  const int apply_v = p.frame[n].apply_processing, sbe_v = p.header[n].sub_band_end;
+  const int apply_v = p.frame[n].apply_processing, sbe_v = p.header[n].sub_band_end, mode_v = p.header[n].channel_mode;
   const auto head16 = [&](int e) { /* element e of the head, a short */
     const int wv = __builtin_amdgcn_readlane(head_v, e >> 1);
     return (int)(int16_t)((e & 1) ? (wv >> 16) : wv);
@@ -62,6 +62,9 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_ps_kernel(XaacEsbrPsParams p)
     for (int e = 0; e < XAAC_PS_MAX_ENV; e++) bad |= e < num_env && (border[e] > border[e + 1] || border[e + 1] > 32);
   }
   const int apply = __builtin_amdgcn_readfirstlane(apply_v), sub_band_end = __builtin_amdgcn_readfirstlane(sbe_v);
+  /* a stream without parametric stereo in a PS batch (channel_mode != PS_STEREO, as the fixed-point PS kernel reads it): its
+     side-info row means nothing and it has no right channel */
+  if (__builtin_amdgcn_readfirstlane(mode_v) != 3) return; /* (the right bank's launch skips the stream too; out_r is left as it is) */
   if (apply && !bad) {
     /* The right channel's rows: inside the frame's PS range [border 0, last border) the decorrelator writes every band from 3
        up and the hybrid synthesis bands 0..2 of every row, so only rows outside the range (none, for the borders 0 and 32 an

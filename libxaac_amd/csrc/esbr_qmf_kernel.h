@@ -25,6 +25,7 @@ typedef struct XaacEsbrSynParams {
   float *out;                   /* [n_ch][2048] */
   int32_t state_stride;         /* bytes between consecutive channels' states */
   int32_t in_stride;            /* floats between consecutive channels' row blocks (>= 2048) */
+  const xaac_sbr_header *only_ps; /* optional [n_ch]: channels whose channel_mode is not PS_STEREO are left alone (right bank) */
 } XaacEsbrSynParams;
 
 typedef struct XaacEsbrCoreInParams {

@@ -237,6 +237,9 @@ __global__ __launch_bounds__(128, XE_SYN_MIN_WAVES) void xaac_esbr_synthesis_ker
   for (int c = 0; c < 2; c++) { /* one channel's ring samples in LDS at a time */
     const int ch = 2 * pair + c;
     if (ch >= p.n_ch) break; /* (uniform) */
+    /* the right bank of a PS batch: a stream without parametric stereo (channel_mode != PS_STEREO) has no right channel -- no
+       output, no state change, as the reference leaves that bank alone until PS starts (uniform over the workgroup) */
+    if (p.only_ps && __builtin_amdgcn_readfirstlane((int)p.only_ps[ch].channel_mode) != 3) continue;
     xaac_esbr_syn_state *st = reinterpret_cast<xaac_esbr_syn_state *>(reinterpret_cast<char *>(p.state) + (size_t)ch * p.state_stride);
     if (lch == c) {
       int32_t *dst = v + (9 + lrow) * VROW + 64 * w;

@@ -367,7 +367,7 @@ int32_t xaac_esbr_sbr_process_batch(xaac_ctx *c, const xaac_esbr_sbr_batch *b) {
   XaacEsbrSynParams ps = {b->n_ch, syn_re, syn_im, &b->state->syn, b->out, (int32_t)sizeof(xaac_esbr_state), XAAC_ESBR_L_ROWS * 64};
   if (!hip_ok(xaac_launch_esbr_synthesis(&ps, c->stream))) return XAAC_FATAL_HIP;
   if (with_ps) {
-    XaacEsbrSynParams pr = {b->n_ch, r_re, r_im, &b->ps_state->syn_r, b->out_r, (int32_t)sizeof(xaac_esbr_ps_state), 2048};
+    XaacEsbrSynParams pr = {b->n_ch, r_re, r_im, &b->ps_state->syn_r, b->out_r, (int32_t)sizeof(xaac_esbr_ps_state), 2048, b->header};
     if (!hip_ok(xaac_launch_esbr_synthesis(&pr, c->stream))) return XAAC_FATAL_HIP;
   }
   c->last_grid = b->n_ch; c->last_block = 64; c->last_lds = 0;

@@ -556,7 +556,10 @@ int main(int argc, char **argv) {
       int resets = 0, with_ps = 0;
       for (int i = 0; i < N; i++)
         if (s.status[(size_t)i] == 0) resets += s.flags[(size_t)i * 8 + 1] != 0, with_ps += s.flags[(size_t)i * 8 + 5] != 0;
-      if ((resets != 0 && resets != s.delivered) || (with_ps != 0 && with_ps != s.delivered)) die("a batch mixing kinds of frames");
+      /* streams with and without PS in one step: the float PS launch copies left to right for those without (esbr_ps_kernel.hip);
+         a step in which only some streams reset the SBR decoder is not taken yet (the transposer's re-initialisation below runs
+         over the whole batch) */
+      if (resets != 0 && resets != s.delivered) die("a batch in which only some streams reset the SBR decoder (-esbr:1)");
       const size_t row = 64 * sizeof(float), st_pitch = sizeof(xaac_esbr_state), q_pitch = 2048 * sizeof(float);
       float *older_re = d_older, *older_im = d_older + (size_t)NC * 24 * 64;
       if (resets) {
@@ -628,6 +631,8 @@ int main(int argc, char **argv) {
         HIP(hipMemcpyAsync(d_psf, s.ps, (size_t)N * sizeof(xaac_ps_frame), hipMemcpyHostToDevice, stream));
         b.ps_frame = d_psf, b.ps_state = d_eps, b.out_r = d_out_r;
         ob.right = d_out_r;
+        some_mono = with_ps != s.delivered; /* streams without PS in this step: no right channel comes back for them (their right
+                                               bank is left alone); their left samples are doubled on the host */
       } else if (n_ch == 2) {
         ob.stride = 4096, ob.right = d_out_l + 2048;
       }

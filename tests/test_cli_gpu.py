@@ -116,10 +116,11 @@ def _adts_frames(data):
     return out
 
 
-def test_a_batch_mixing_streams_with_and_without_parametric_stereo(tmp_path):
-    """-ilist, -esbr:0: an HE-AAC (mono) stream, an HE-AACv2 one and two streams whose parametric stereo starts at different
+@pytest.mark.parametrize("flags", [("-esbr:0",), ()], ids=["esbr0", "default"])
+def test_a_batch_mixing_streams_with_and_without_parametric_stereo(flags, tmp_path):
+    """-ilist (-esbr:0 and the default -esbr:1): an HE-AAC (mono) stream, an HE-AACv2 one and two streams whose parametric stereo starts at different
     frames (HE-AAC frames with HE-AACv2 frames behind them) decoded in lock step -- every step sees frames with and without PS.
-    Each WAV must equal what the reference decoder writes for that stream alone (`oracle/_ref/xaacdec -esbr:0`)."""
+    Each WAV must equal what the reference decoder writes for that stream alone (`oracle/_ref/xaacdec`, same flags)."""
     ref = os.path.join(ROOT, "oracle", "_ref", "xaacdec")
     if not os.path.exists(ref):
         pytest.fail("oracle/_ref/xaacdec missing: the reference binary did not travel with the snapshot")
@@ -133,11 +134,11 @@ def test_a_batch_mixing_streams_with_and_without_parametric_stereo(tmp_path):
     lst.write_text("\n".join(str(tmp_path / (n + ".aac")) for n in files) + "\n")
     out = tmp_path / "out"
     out.mkdir()
-    p = subprocess.run([CLI, "-ilist:" + str(lst), "-odir:" + str(out), "-esbr:0"], capture_output=True, text=True, timeout=300)
+    p = subprocess.run([CLI, "-ilist:" + str(lst), "-odir:" + str(out), *flags], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-500:]
     for n in files:
         want = str(tmp_path / (n + "_ref.wav"))
-        subprocess.run([ref, "-ifile:" + str(tmp_path / (n + ".aac")), "-ofile:" + want, "-esbr:0"], check=True, capture_output=True)
+        subprocess.run([ref, "-ifile:" + str(tmp_path / (n + ".aac")), "-ofile:" + want, *flags], check=True, capture_output=True)
         with wave.open(want) as a, wave.open(str(out / (n + ".wav"))) as b:
             assert (a.getnchannels(), a.getframerate(), a.getnframes()) == (b.getnchannels(), b.getframerate(), b.getnframes()), n
             assert a.readframes(a.getnframes()) == b.readframes(b.getnframes()), n
