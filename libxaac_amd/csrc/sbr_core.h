@@ -1391,19 +1391,20 @@ FX_HD int32_t xs_energy_element_pk(const Q &x, int first, int n, int k, int16_t 
   for (int j = 0; j < N; j++) {
     const int row = first + (j < n ? j : n - 1);
     re[j] = x(row, k);
-    im[j] = x.im(row, k);
+    if constexpr (Q::HQ) im[j] = x.im(row, k); else im[j] = 0;
   }
   int32_t mx = 1;
   XS_UNROLL
   for (int j = 0; j < N; j++) {
     XS_KEEP(re[j]); /* (the loads stay unconditional and together: as operands of a select alone each was sunk into a
                        predicated region of its own, with a full wait inside) */
-    XS_KEEP(im[j]);
+    if constexpr (Q::HQ) XS_KEEP(im[j]);
     re[j] = j < n ? re[j] : 0;
     im[j] = j < n ? im[j] : 0;
-    mx |= fx_abs_nrm(re[j]) | fx_abs_nrm(im[j]);
+    mx |= fx_abs_nrm(re[j]);
+    if constexpr (Q::HQ) mx |= fx_abs_nrm(im[j]);
   }
-  const int pre = xs_pnorm32(mx) - 4;
+  const int pre = xs_pnorm32(mx) - (Q::HQ ? 4 : 3);
   int shift = 16 - pre;
   const int e_shr = shift > 0 ? shift & 31 : 0, e_shl = shift > 0 ? 0 : (-shift) & 31;
   int32_t accu = 0;
@@ -1411,14 +1412,16 @@ FX_HD int32_t xs_energy_element_pk(const Q &x, int first, int n, int k, int16_t 
   for (int j = 0; j < N; j++) {
     int16_t t = (int16_t)((int32_t)((uint32_t)re[j] << e_shl) >> e_shr);
     accu = fx_add(accu, (int32_t)t * t);
-    t = (int16_t)((int32_t)((uint32_t)im[j] << e_shl) >> e_shr);
-    accu = fx_add(accu, (int32_t)t * t);
+    if constexpr (Q::HQ) {
+      t = (int16_t)((int32_t)((uint32_t)im[j] << e_shl) >> e_shr);
+      accu = fx_add(accu, (int32_t)t * t);
+    }
   }
   if (accu == 0) return 0;
   shift = -xs_pnorm32(accu);
   int16_t sum_m = (int16_t)xs_shr_dir_sat_limit(accu, 16 + shift);
   sum_m = xs_mult16_shl_sat(sum_m, inv_width);
-  shift = shift - (pre << 1);
+  shift = shift - (pre << 1) + (Q::HQ ? 0 : 1);
   return xs_me(sum_m, (int16_t)(frame_exp2 + shift + 1));
 }
 /* the same for any number of slots: two walks over the column part, eight slots' loads in flight at a time */
@@ -1431,16 +1434,17 @@ FX_HD int32_t xs_energy_element_long(const Q &x, int first, int n, int nmax, int
     for (int j = 0; j < 8; j++) {
       const int row = first + (j0 + j < n ? j0 + j : n - 1);
       re[j] = x(row, k);
-      im[j] = x.im(row, k);
+      if constexpr (Q::HQ) im[j] = x.im(row, k); else im[j] = 0;
     }
     XS_UNROLL
     for (int j = 0; j < 8; j++) {
       XS_KEEP(re[j]);
-      XS_KEEP(im[j]);
-      mx |= fx_abs_nrm(re[j]) | fx_abs_nrm(im[j]); /* (a slot read twice changes no maximum) */
+      if constexpr (Q::HQ) XS_KEEP(im[j]);
+      mx |= fx_abs_nrm(re[j]); /* (a slot read twice changes no maximum) */
+      if constexpr (Q::HQ) mx |= fx_abs_nrm(im[j]);
     }
   }
-  const int pre = xs_pnorm32(mx) - 4;
+  const int pre = xs_pnorm32(mx) - (Q::HQ ? 4 : 3);
   int shift = 16 - pre;
   const int e_shr = shift > 0 ? shift & 31 : 0, e_shl = shift > 0 ? 0 : (-shift) & 31;
   int32_t accu = 0;
@@ -1450,25 +1454,27 @@ FX_HD int32_t xs_energy_element_long(const Q &x, int first, int n, int nmax, int
     for (int j = 0; j < 8; j++) {
       const int row = first + (j0 + j < n ? j0 + j : n - 1);
       re[j] = x(row, k);
-      im[j] = x.im(row, k);
+      if constexpr (Q::HQ) im[j] = x.im(row, k); else im[j] = 0;
     }
     XS_UNROLL
     for (int j = 0; j < 8; j++) {
       XS_KEEP(re[j]);
-      XS_KEEP(im[j]);
+      if constexpr (Q::HQ) XS_KEEP(im[j]);
       re[j] = j0 + j < n ? re[j] : 0;
       im[j] = j0 + j < n ? im[j] : 0;
       int16_t t = (int16_t)((int32_t)((uint32_t)re[j] << e_shl) >> e_shr);
       accu = fx_add(accu, (int32_t)t * t);
-      t = (int16_t)((int32_t)((uint32_t)im[j] << e_shl) >> e_shr);
-      accu = fx_add(accu, (int32_t)t * t);
+      if constexpr (Q::HQ) {
+        t = (int16_t)((int32_t)((uint32_t)im[j] << e_shl) >> e_shr);
+        accu = fx_add(accu, (int32_t)t * t);
+      }
     }
   }
   if (accu == 0) return 0;
   shift = -xs_pnorm32(accu);
   int16_t sum_m = (int16_t)xs_shr_dir_sat_limit(accu, 16 + shift);
   sum_m = xs_mult16_shl_sat(sum_m, inv_width);
-  shift = shift - (pre << 1);
+  shift = shift - (pre << 1) + (Q::HQ ? 0 : 1);
   return xs_me(sum_m, (int16_t)(frame_exp2 + shift + 1));
 }
 template <class Q>
@@ -1542,8 +1548,9 @@ FX_HD void xs_subband_gain_meta_pk(const XsCx &cx, const XsPass &ps, const XsLv 
       flags.own(l) = ((i == 0 || (jn.own(l) & 255) != (jprev.own(l) & 255)) ? 1 : 0) | ((xs_qsel(q, ps.env) >= sm.own(l)) ? 2 : 0) | 4;
   }
   const uint64_t sfb_start = xs_ballot(cx, flags, 1, 64), sine_here = xs_ballot(cx, flags, 2, 64);
-  XsLv mt;
+  XsLv mt, ar;
   mt.fill(0);
+  ar.fill(0);
   XS_LANES(l, 0, 64) {
     const int q = l / XS_PK, i = l & (XS_PK - 1);
     if (q < ps.n && i < nsb) {
@@ -1554,8 +1561,10 @@ FX_HD void xs_subband_gain_meta_pk(const XsCx &cx, const XsPass &ps, const XsLv 
       const uint64_t seg = (((uint64_t)1 << end) - 1) & ~(((uint64_t)1 << first) - 1);
       const int present = (sn_q & seg) != 0;
       mt.own(l) = jn.own(l) | (present << 16);
+      ar.own(l) = !present;
     }
   }
+  v.alias_red = ar; /* (low-power passes: element (q, i) = band sub_band_start + i of envelope q; nothing reads it in HQ mode) */
   /* meta is indexed from max_qmf_subband_aac: element (q, c) = band (q, c + skip) */
   XsLv src;
   src.fill(0);
@@ -2018,6 +2027,156 @@ FX_HD void xs_erg_to_amplitude_hq_pk(const XsCx &cx, const XsPass &ps, int bands
         if (shift < -31) shift = -31;
         nl[0] = (int16_t)xs_shl(nl[0], -shift);
       }
+      v.sine.own(l) = xs_me(sn[0], sn[1]);
+      v.gain.own(l) = xs_me(g[0], g[1]);
+      v.noise.own(l) = xs_me(nl[0], nl[1]);
+    }
+  }
+}
+
+/* ---- two envelopes side by side, low-power mode ------------------------------------------------------------------------
+ * The same arrangement for the low-power chain (env_calc.c:692 with low_pow_flag): the energies (real matrix), the gain
+ * mathematics and the limiter are the functions above; the alias reduction (env_calc.c:78) and the amplitude conversion
+ * (env_calc.c:423) follow here on the same lanes -- element k of envelope q on lane 32 q + k -- and the slots of the two
+ * envelopes are then adjusted one after the other by xs_adapt_noise_gain_lp on the envelope's half of the vectors.  Taken
+ * for regular frames (xs_pack_frame_ok) whose adjusted range starts at sub_band_start (the reference indexes its gain
+ * arrays from max_qmf_subband_aac and the aliasing degrees from sub_band_start with one counter; with the two apart the
+ * one-envelope chain restates what that does). */
+
+/* xs_alias_groups for a pass.  deg1p: element (q, k) = deg1[k].  A run cannot leave its half: the last band of an envelope
+   (k = nsb - 1 <= 31) is never in a run. */
+FX_HD uint64_t xs_alias_groups_pk(const XsCx &cx, const XsPass &ps, const XsLv &deg1p, const XsLv &alias_red, int nsb,
+                                  XsLv &end) {
+  XsLv f;
+  f.fill(0);
+  XS_LANES(l, 0, 64) {
+    const int q = l / XS_PK, k = l & (XS_PK - 1);
+    if (q < ps.n && k < nsb)
+      f.own(l) = ((k < nsb - 1 && deg1p.own(l) != 0 && alias_red.own(l)) ? 1 : 0) | (alias_red.own(l) ? 2 : 0);
+  }
+  const uint64_t in_run = xs_ballot(cx, f, 1, 64), red = xs_ballot(cx, f, 2, 64);
+  XsLv st;
+  st.fill(0);
+  XS_LANES(l, 0, 64) {
+    if (!((in_run >> l) & 1)) continue;
+    const int base = l & ~(XS_PK - 1);
+    const uint64_t gaps_below = ~in_run & (xs_mask_upto(l) >> 1);
+    int run_start = gaps_below ? 64 - xs_clz64(gaps_below) : 0;
+    if (run_start < base) run_start = base;
+    if ((l - run_start) & 3) continue;
+    st.own(l) = 1;
+    int e;
+    if (((in_run >> l) & 15) == 15) {
+      e = l + 4;
+    } else {
+      const int z = l + xs_ctz64(~(in_run >> l)); /* first lane at or above l outside the run */
+      if (z - base >= nsb - 1)
+        e = base + nsb;
+      else
+        e = ((red >> z) & 1) ? z + 1 : z;
+    }
+    end.own(l) = e;
+  }
+  return xs_ballot(cx, st, 1, 64);
+}
+/* xs_alias_reduction for a pass: groups, sums and results by lane number (a group's lanes are neighbours in its half) */
+FX_HD void xs_alias_reduction_pk(const XsCx &cx, const XsPass &ps, XsEnv &v, const XsLv &degp, const XsLv &deg1p, XsWork *w,
+                                 uint64_t starts, const XsLv &end, int nsb) {
+  if (starts == 0) return;
+  XS_LANES(l, 0, 64) {
+    w->fold_a[l][0] = v.est.own(l);
+    w->fold_a[l][1] = v.gain.own(l);
+  }
+  cx.sync();
+  XS_LANES(s, 0, 64) {
+    if (!((starts >> s) & 1)) continue;
+    int16_t amp_m, amp_e, gg_m, gg_e;
+    xs_avggain(w->fold_a, s, end.own(s), &amp_m, &amp_e, &gg_m, &gg_e, 1);
+    w->res_a[s][0] = amp_m;
+    w->res_a[s][1] = amp_e;
+    w->res_a[s][2] = gg_m;
+    w->res_a[s][3] = gg_e;
+    w->res_b[s][0] = (int16_t)end.own(s);
+  }
+  cx.sync();
+  XsLv mine;
+  mine.fill(-1);
+  XS_LANES(l, 0, 64) {
+    const int q = l / XS_PK, k = l & (XS_PK - 1);
+    if (!(q < ps.n && k < nsb)) continue;
+    const uint64_t below = starts & xs_mask_upto(l);
+    if (!below) continue;
+    const int s = 63 - xs_clz64(below);
+    if (l >= w->res_b[s][0]) continue; /* (a group of the other half ends below this half: never taken for it) */
+    mine.own(l) = s;
+    const int16_t gg_m = w->res_a[s][2], gg_e = w->res_a[s][3];
+    int16_t alpha = (int16_t)degp.own(l);
+    if (k < nsb - 1 && (int16_t)deg1p.own(l) > alpha) alpha = (int16_t)deg1p.own(l);
+    int32_t gain_m = (int32_t)alpha * gg_m;
+    int16_t one_minus = (int16_t)(0x7fff - alpha);
+    int32_t tm = xs_m(v.gain.own(l)), te = xs_e(v.gain.own(l));
+    tm = ((int32_t)one_minus * tm) >> 15;
+    int32_t d = gg_e - te;
+    if (d >= 0) {
+      te = gg_e;
+      tm = fx_shr(tm, d);
+      tm = (gain_m >> 15) + tm;
+    } else {
+      tm = fx_shr(gain_m, 15 - d) + tm;
+    }
+    v.gain.own(l) = xs_me((int16_t)tm, (int16_t)te);
+    w->fold_b[l][0] = (int32_t)((uint32_t)tm * (uint32_t)(int32_t)xs_m(v.est.own(l))) >> 16;
+    w->fold_b[l][1] = te + xs_e(v.est.own(l)) + 1;
+  }
+  cx.sync();
+  XS_LANES(s, 0, 64) {
+    if (!((starts >> s) & 1)) continue;
+    int32_t mod_m = 0, mod_e = 0;
+    const int e = end.own(s);
+    for (int k = s; k < e; k++) xs_acc_me(&mod_m, &mod_e, w->fold_b[k][0], w->fold_b[k][1]);
+    int nv = 16 - xs_pnorm32(mod_m);
+    if (nv > 0) {
+      mod_m >>= nv;
+      mod_e += nv;
+    }
+    int16_t comp_m;
+    int comp_e = xs_fix_mant_div(w->res_a[s][0], (int16_t)mod_m, &comp_m);
+    comp_e = (int16_t)(comp_e + w->res_a[s][1] - (int16_t)mod_e + 1 + 1);
+    w->res_b[s][1] = comp_m;
+    w->res_a[s][3] = (int16_t)comp_e;
+  }
+  cx.sync();
+  XS_LANES(l, 0, 64) {
+    const int s = mine.own(l);
+    if (s < 0) continue;
+    const int16_t comp_m = w->res_b[s][1], comp_e = w->res_a[s][3];
+    const int32_t g2 = v.gain.own(l);
+    v.gain.own(l) = xs_me((int16_t)(((int32_t)xs_m(g2) * comp_m) >> 16), (int16_t)(xs_e(g2) + comp_e));
+  }
+  cx.sync();
+}
+/* xs_erg_to_amplitude_lp for a pass */
+FX_HD void xs_erg_to_amplitude_lp_pk(const XsCx &cx, const XsPass &ps, int bands, XsEnv &v) {
+  XS_LANES(l, 0, 64) {
+    const int q = l / XS_PK, c = l & (XS_PK - 1);
+    if (q < ps.n && c < bands) {
+      const int noise_e = (int16_t)xs_qsel(q, ps.noise_e);
+      int16_t sn[2] = {xs_m(v.sine.own(l)), xs_e(v.sine.own(l))};
+      int16_t g[2] = {xs_m(v.gain.own(l)), xs_e(v.gain.own(l))};
+      int16_t nl[2] = {xs_m(v.noise.own(l)), xs_e(v.noise.own(l))};
+      xs_mant_exp_sqrt(sn);
+      xs_mant_exp_sqrt(g);
+      xs_mant_exp_sqrt(nl);
+      int shift = (noise_e - nl[1]) - 4;
+      if (shift > 0)
+        nl[0] = (int16_t)xs_sar(nl[0], shift);
+      else
+        nl[0] = (int16_t)xs_shl(nl[0], -shift);
+      shift = sn[1] - noise_e;
+      if (shift > 0)
+        sn[0] = xs_shl16_sat(sn[0], (int16_t)shift);
+      else
+        sn[0] = (int16_t)xs_sar(sn[0], (int16_t)-shift);
       v.sine.own(l) = xs_me(sn[0], sn[1]);
       v.gain.own(l) = xs_me(g[0], g[1]);
       v.noise.own(l) = xs_me(nl[0], nl[1]);
@@ -2734,9 +2893,9 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
   if constexpr (Q::HQ) xs_adj_load(cx, st, nsb, adj);
   bool packed = false;
 #ifndef XS_NO_ENV_PAIRS /* (a checker build runs every frame through the one-envelope chain: tests/test_env_pairs_cpu.py) */
-  if constexpr (Q::HQ) packed = xs_pack_frame_ok(cx, h);
+  packed = xs_pack_frame_ok(cx, h) && (Q::HQ || skip == 0);
 #endif
-  if constexpr (Q::HQ) if (packed) {
+  if (packed) {
     /* two envelopes per pass of the gain mathematics (see "two envelopes side by side") */
     XsLv jn_hi, jn_lo;
     XS_T(8);
@@ -2755,6 +2914,14 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
     XS_LANES(j, 0, XAAC_SBR_MAX_ENVELOPES + 1) bordv.own(j) = border[j];
     XS_LANES(j, 0, XAAC_SBR_MAX_ENVELOPES) resv.own(j) = f->freq_res[j];
     XS_LANES(j, 0, XAAC_SBR_MAX_NOISE_ENVELOPES + 1) nbordv.own(j) = f->noise_border_vec[j];
+    XsLv degp, deg1p; /* low-power passes: the aliasing degrees on both halves */
+    {
+      XsLv idx;
+      idx.fill(0);
+      XS_LANES(l, 0, 64) idx.own(l) = l & (XS_PK - 1);
+      degp = v.deg.gather(idx);
+      deg1p = v.deg1.gather(idx);
+    }
     for (int i = 0; i < num_env;) {
       XsPass ps;
       int s0[2], s1[2];
@@ -2810,16 +2977,38 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
       XS_T(6);
       xs_noiselimiting_pk(cx, h, ps, skip, bands, v, w, lim_tab, lim_of);
       XS_T(7);
-      xs_erg_to_amplitude_hq_pk(cx, ps, bands, v);
-      XS_T(28);
-      /* the envelopes' slots, one envelope after the other */
-      for (int q = 0; q < ps.n; q++) {
-        /* (the pass's per-envelope values by selects: indexed by the run-time q the arrays lived in scratch memory, and the
-           two loads were two exposed memory latencies per envelope) */
-        const int absc_q = xs_qsel(q, ps.noise_absc), noise_e_q = xs_qsel(q, ps.noise_e);
-        const int smooth_length = absc_q ? 0 : smooth_len_on;
-        xs_adapt_noise_gain_hq(cx, adj, v, q ? XS_PK : 0, noise_e_q, nsb, skip, xs_qsel(q, s0), xs_qsel(q, s1), input_e, adj_e,
-                               final_e, max_sb, absc_q, smooth_length, x);
+      if constexpr (Q::HQ) {
+        xs_erg_to_amplitude_hq_pk(cx, ps, bands, v);
+        XS_T(28);
+        /* the envelopes' slots, one envelope after the other */
+        for (int q = 0; q < ps.n; q++) {
+          /* (the pass's per-envelope values by selects: indexed by the run-time q the arrays lived in scratch memory, and
+             the two loads were two exposed memory latencies per envelope) */
+          const int absc_q = xs_qsel(q, ps.noise_absc), noise_e_q = xs_qsel(q, ps.noise_e);
+          const int smooth_length = absc_q ? 0 : smooth_len_on;
+          xs_adapt_noise_gain_hq(cx, adj, v, q ? XS_PK : 0, noise_e_q, nsb, skip, xs_qsel(q, s0), xs_qsel(q, s1), input_e,
+                                 adj_e, final_e, max_sb, absc_q, smooth_length, x);
+        }
+      } else {
+        XsLv grp_end;
+        grp_end.fill(0);
+        const uint64_t grp_starts = xs_alias_groups_pk(cx, ps, deg1p, v.alias_red, nsb, grp_end);
+        XS_T(23);
+        xs_alias_reduction_pk(cx, ps, v, degp, deg1p, w, grp_starts, grp_end, nsb);
+        XS_T(8);
+        xs_erg_to_amplitude_lp_pk(cx, ps, bands, v);
+        XS_T(9);
+        /* the envelopes' slots, one envelope after the other, each on its half of the vectors */
+        for (int q = 0; q < ps.n; q++) {
+          XsEnv vq = v;
+          if (q) {
+            vq.gain = v.gain.shifted(cx, XS_PK);
+            vq.noise = v.noise.shifted(cx, XS_PK);
+            vq.sine = v.sine.shifted(cx, XS_PK);
+          }
+          xs_adapt_noise_gain_lp(cx, st, vq, rand_hi, xs_qsel(q, ps.noise_e), nsb, skip, xs_qsel(q, s0), xs_qsel(q, s1),
+                                 input_e, adj_e, final_e, max_sb, (int16_t)(15 - lb_scale), xs_qsel(q, ps.noise_absc), x);
+        }
       }
       XS_T(10);
       i += ps.n;

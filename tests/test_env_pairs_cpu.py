@@ -140,3 +140,67 @@ def test_fuzzed_chains(oracle):
             if a[0] == 0:
                 st, ps = a[2], a[3]
     assert taken > 150 and refused < taken
+
+
+# ---- the low-power chain (HE-AACv1: alias reduction, real matrix) -------------------------------------------------------
+GOLDEN_LP = os.path.join(ROOT, "tests", "golden", "sbr_lp_records.bin.gz")
+
+
+def both_lp(oracle, h, f, st, pcm):
+    outs = []
+    for name in ("xo_sbr_dec_lp", "xo_sbr_dec_lp_seq"):
+        s = cap.State.from_buffer_copy(bytes(st))
+        out = np.zeros(2048, np.int16)
+        rc = getattr(oracle.lib, name)(ctypes.byref(h), ctypes.byref(f), ctypes.byref(s), pcm.ctypes.data_as(P16), 1,
+                                       out.ctypes.data_as(P16), 1)
+        outs.append((rc, out, s))
+    return outs
+
+
+def same_lp(a, b, tag):
+    assert a[0] == b[0], (tag, a[0], b[0])
+    if a[0] != 0:
+        return
+    assert not cap.diff_state(a[2], b[2]), (tag, cap.diff_state(a[2], b[2])[:4])
+    assert np.array_equal(a[1], b[1]), (tag, "pcm", int(np.sum(a[1] != b[1])))
+
+
+def test_lp_reference_records(oracle):
+    """low-power frames: paired passes == one-envelope chain == the reference's own outputs"""
+    n = 0
+    for i, r in enumerate(cap.read_records(GOLDEN_LP)):
+        a, b = both_lp(oracle, r["header"], r["frame"], r["st0"], np.ascontiguousarray(r["pcm_in"]))
+        same_lp(a, b, i)
+        assert a[0] == 0
+        assert np.array_equal(a[1], np.asarray(r["pcm_out"]).reshape(-1)[:2048])
+        assert not cap.diff_state(a[2], r["st1"])
+        n += 1
+    assert n >= 24
+
+
+def test_lp_fuzzed_chains(oracle):
+    recs = cap.read_records(GOLDEN_LP)
+    rng = np.random.default_rng(5051)
+    refused = taken = 0
+    for i, r in enumerate(recs):
+        st = cap.State.from_buffer_copy(bytes(r["st0"]))
+        h = cap.Header.from_buffer_copy(bytes(r["header"]))
+        h.interpol_freq = 1 if i % 3 else h.interpol_freq      # most chains take the paired passes
+        for step in range(10):
+            f = cap.Frame.from_buffer_copy(bytes(r["frame"]))
+            _fuzz_frame(rng, h, f, (i + step) % 3)
+            if step % 4 == 3:      # the band limit moves: skip != 0 sends the frame through the one-envelope chain
+                f.max_qmf_subband_aac = int(np.clip(f.max_qmf_subband_aac + rng.integers(-6, 7), h.sub_band_start, 32))
+            if step == 6:
+                h.smoothing_mode = 1 - h.smoothing_mode
+            if step == 8:
+                h.limiter_gains = int(rng.integers(0, 4))
+            amp = [30000, 3000, 200, 12, 0][step % 5]
+            pcm = rng.integers(-amp, amp + 1, 1024).astype(np.int16)
+            a, b = both_lp(oracle, h, f, st, pcm)
+            same_lp(a, b, (i, step))
+            refused += a[0] != 0
+            taken += a[0] == 0
+            if a[0] == 0:
+                st = a[2]
+    assert taken > 150 and refused < taken
