@@ -430,8 +430,13 @@ __device__ __forceinline__ void stage_tables(int tid) {
    WAVES waves per workgroup share the tables; every wave takes channel-frames off a work counter until none is left
    (p.work_counter, zeroed by the launch; without one: workgroup i's wave w takes channel WAVES i + w).  With NB < 64 a
    stream that needs the full rows is appended to p.defer_list. */
+/* The low-power instantiation is asked to fit three waves per SIMD (168 VGPRs; it takes 189 with the two-envelope passes
+   otherwise, which leaves four of the five workgroups a CU's LDS holds: 326 us per C3 step; capped, without spills, 299) */
+#ifndef XS_LP_MIN_WAVES
+#define XS_LP_MIN_WAVES 3
+#endif
 template <int HQ, int NB, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void xaac_sbr_core_kernel(XaacSbrCoreParams p) {
+__global__ __launch_bounds__(64 * WAVES, HQ ? 1 : XS_LP_MIN_WAVES) void xaac_sbr_core_kernel(XaacSbrCoreParams p) {
   __shared__ XsLds<HQ, NB> s[WAVES];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   stage_tables<HQ, 64 * WAVES>(threadIdx.x);
@@ -490,7 +495,10 @@ extern "C" hipError_t xaac_launch_sbr_core_lp(const XaacSbrCoreParams *p, hipStr
   if (XS_LP_PERSISTENT && p->work_counter && p->counters_zeroed) {
     /* persistent, like the HQ launch: as many workgroups as the chip holds (five per CU: 31.6 KB of LDS each), channel-frames
        off the work counter, the tables staged once per workgroup instead of once per pair of channel-frames, staggered start */
-    const int resident = 5 * (p->num_cu > 0 ? p->num_cu : 256), need = (p->n_ch + W - 1) / W;
+#ifndef XS_LP_WG_PER_CU
+#define XS_LP_WG_PER_CU 5
+#endif
+    const int resident = XS_LP_WG_PER_CU * (p->num_cu > 0 ? p->num_cu : 256), need = (p->n_ch + W - 1) / W;
     hipLaunchKernelGGL((xaac_sbr_core_kernel<0, 64, W>), dim3(need < resident ? need : resident), dim3(64 * W), 0, stream, *p);
     return hipGetLastError();
   }

@@ -49,17 +49,30 @@ struct LdsStrided { /* words of the sub-sequence T j + s of an interleaved (re, 
    side (N = L/16).  For ccfl 768 a block's points go through three M-point transforms (M = 128 | 16) and the
    three-point stage (usac_imdct.h); every pass is spread over the lanes: L/8 radix-4 butterflies per pass either way. */
 template <int L, bool SHORT>
-__device__ __forceinline__ int transform(const int32_t *coef, int32_t *A, int32_t *B, int lane, int shiftp, bool &all_zero) {
+__device__ __forceinline__ int transform(const int32_t *coef, const int2 *c, int32_t *A, int32_t *B, int lane, int shiftp,
+                                         bool &all_zero) {
   constexpr int N = SHORT ? L / 16 : L / 2;   /* complex points per block */
   constexpr int M = xu_sub_points<N>();       /* ... of the power-of-two transform they go through */
   constexpr int T = N / M;                    /* 1, or 3 thirds */
   constexpr int PP = L / 128;                 /* line pairs (= points) per lane */
   int32_t xa[PP], xb[PP];
+  /* Point q = lane + 64 m (block q / N, point i = q % N) needs the lines (x[2 i], x[2 N - 1 - 2 i]) of its block.  The frame's
+     lines arrived in natural order, lane q's register m = (x[2 q], x[2 q + 1]) (frame(): one 8-byte load per lane and
+     register, asked for before anything else of the channel-frame is known); the second line of point i is the odd line of
+     pair N - 1 - i of the block: the mirrored lane's mirrored register in a long frame (N = 64 PP), the mirrored lane's
+     same register in a short frame of 64-point blocks.  The 48-point blocks of a short 768-line frame do not fall on lane
+     boundaries: those lines are read again (they are in the cache). */
 #pragma unroll
   for (int m = 0; m < PP; m++) {
-    const int q = lane + 64 * m, blk = q / N, i = q % N;
-    xa[m] = coef[2 * N * blk + 2 * i];
-    xb[m] = coef[2 * N * blk + 2 * N - 1 - 2 * i];
+    xa[m] = c[m].x;
+    if (!SHORT)
+      xb[m] = __shfl(c[PP - 1 - m].y, 63 - lane);
+    else if (N == 64)
+      xb[m] = __shfl(c[m].y, 63 - lane);
+    else {
+      const int q = lane + 64 * m, blk = q / N, i = q % N;
+      xb[m] = coef[2 * N * blk + 2 * N - 1 - 2 * i];
+    }
   }
   int32_t mx = 0;
 #pragma unroll
@@ -177,24 +190,42 @@ __device__ __forceinline__ int transform(const int32_t *coef, int32_t *A, int32_
   return shiftp;
 }
 
+/* the old overlap word of the lane's current sample: every position of the windowing reads overlap[i] for output sample
+   i and nothing else of it (usac_imdct.h: xu_long_sample_lpd / xu_short_sample_lpd), so the 16 words a lane needs are fetched
+   with the lines, in front of the transform, instead of behind it */
+struct OvReg {
+  int32_t cur;
+  __device__ __forceinline__ int32_t operator[](int) const { return cur; }
+};
+
 /* one channel-frame of L = ccfl lines; returns XAAC_OK or the status of a refused frame (nothing written then) */
 template <int L>
-__device__ __forceinline__ int frame(const XaacUsacImdctParams &p, int ch, int32_t *A, int32_t *B, int lane, int seq, int shape,
-                                     int shape_prev) {
+__device__ __forceinline__ int frame(const XaacUsacImdctParams &p, int ch, int32_t *A, int32_t *B, int lane) {
+  constexpr int SP = L / 64; /* samples per lane */
+  constexpr int PP = L / 128;
+  const int32_t *coef = p.coef + (size_t)ch * L;
+  int32_t *gov = p.overlap + (size_t)ch * L;
+  /* everything the channel-frame reads, asked for together: window words, LPD flags, FAC exponent, lines, old overlap (the
+     window check, the FAC checks and the transform then start one memory latency after the wave does, not four) */
+  const int seq = p.ics[ch].window_sequence, shape = p.ics[ch].window_shape, shape_prev = p.shape_prev[ch];
   const int flags = p.lpd_flags ? p.lpd_flags[ch] : 0;
-  const XuLpd lp = {flags & 1, (flags >> 1) & 1, (p.fac && (flags & 2)) ? p.fac[ch].q : 0};
+  const int fac_q_in = p.fac ? p.fac[ch].q : 0;
+  int2 c[PP];
+  int32_t ovr[SP];
+#pragma unroll
+  for (int m = 0; m < PP; m++) c[m] = *reinterpret_cast<const int2 *>(coef + 2 * (lane + 64 * m));
+#pragma unroll
+  for (int m = 0; m < SP; m++) ovr[m] = gov[lane + 64 * m];
+  if (seq > 4 || shape > 1 || shape_prev > 1) return XAAC_FATAL_BAD_WINDOW_SEQ; /* values the bitstream fields cannot carry */
+  const XuLpd lp = {flags & 1, (flags >> 1) & 1, (p.fac && (flags & 2)) ? fac_q_in : 0};
   /* FAC data only ever follows an LPD frame and needs its signal; ccfl 1024 has no 256-tap KBD window (calc_window fails) */
   if (lp.fac && (!lp.td_prev || !p.fac)) return XAAC_FATAL_BAD_ARG;
   if (xu_lpd_window_missing<L>(lp.td_prev != 0, seq, shape_prev)) return XAAC_FATAL_BAD_WINDOW_SEQ;
-  const int32_t *coef = p.coef + (size_t)ch * L;
-  int32_t *gov = p.overlap + (size_t)ch * L;
   bool all_zero;
-  const int shiftp = seq == 2 ? transform<L, true>(coef, A, B, lane, 0, all_zero) : transform<L, false>(coef, A, B, lane, 0, all_zero);
+  const int shiftp = seq == 2 ? transform<L, true>(coef, c, A, B, lane, 0, all_zero) : transform<L, false>(coef, c, A, B, lane, 0, all_zero);
   if (lp.fac && (seq == 2 || seq == 3 || seq == 4) && !xu_fac_q_ok(shiftp, all_zero, seq == 2, lp.fac_q)) return XAAC_FATAL_BAD_ARG;
   const Lds x = {A};
-  const Glb ov = {gov};
   const Glb fac = {lp.fac ? p.fac[ch].data : gov};
-  constexpr int SP = L / 64; /* samples per lane */
   int32_t out[SP], nov[SP];
   if (seq != 2) {
     const bool stop_like = seq == 3 || seq == 4;
@@ -202,6 +233,7 @@ __device__ __forceinline__ int frame(const XaacUsacImdctParams &p, int ch, int32
 #pragma unroll
     for (int m = 0; m < SP; m++) {
       const int i = lane + 64 * m;
+      const OvReg ov = {ovr[m]};
       out[m] = xu_scale_adj(xu_long_sample_lpd<L>(x, ov, fac, i, shiftp, stop_like, shape_prev, lp), oq);
       nov[m] = xu_long_overlap<L>(x, i, shiftp);
     }
@@ -210,6 +242,7 @@ __device__ __forceinline__ int frame(const XaacUsacImdctParams &p, int ch, int32
 #pragma unroll
     for (int m = 0; m < SP; m++) {
       const int i = lane + 64 * m;
+      const OvReg ov = {ovr[m]}; /* (positions L + i read no overlap) */
       out[m] = xu_scale(xu_short_sample_lpd<L>(x, ov, fac, i, shiftp, shape, shape_prev, lp), oq, 15);
       nov[m] = xu_scale(xu_short_sample_lpd<L>(x, ov, fac, L + i, shiftp, shape, shape_prev, lp), oq, XU_SHIFT_OLAP);
     }
@@ -227,20 +260,18 @@ __device__ __forceinline__ int frame(const XaacUsacImdctParams &p, int ch, int32
 
 }  // namespace
 
-__global__ __launch_bounds__(64 * XAAC_USAC_WAVES_PER_WG) void xaac_usac_imdct_kernel(XaacUsacImdctParams p) {
+#ifndef XU_MIN_WAVES
+#define XU_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(64 * XAAC_USAC_WAVES_PER_WG, XU_MIN_WAVES) void xaac_usac_imdct_kernel(XaacUsacImdctParams p) {
   extern __shared__ __attribute__((aligned(16))) int32_t smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ch = blockIdx.x * XAAC_USAC_WAVES_PER_WG + wave;
   if (ch >= p.n_ch) return;
   int32_t *A = smem + wave * 2048, *B = A + 1024;
-  const int seq = p.ics[ch].window_sequence, shape = p.ics[ch].window_shape, shape_prev = p.shape_prev[ch];
-  if (seq > 4 || shape > 1 || shape_prev > 1) { /* values the bitstream fields cannot carry: left untouched */
-    if (lane == 0 && p.status) p.status[ch] = XAAC_FATAL_BAD_WINDOW_SEQ;
-    return;
-  }
-  const int rc = p.ccfl == 768 ? frame<768>(p, ch, A, B, lane, seq, shape, shape_prev) : frame<1024>(p, ch, A, B, lane, seq, shape, shape_prev);
+  const int rc = p.ccfl == 768 ? frame<768>(p, ch, A, B, lane) : frame<1024>(p, ch, A, B, lane);
   if (lane == 0) {
-    if (rc == XAAC_OK) p.shape_prev[ch] = (uint8_t)shape; /* ext_ch_ele.c:1015 */
+    if (rc == XAAC_OK) p.shape_prev[ch] = (uint8_t)p.ics[ch].window_shape; /* ext_ch_ele.c:1015 */
     if (p.status) p.status[ch] = rc;
   }
 }
