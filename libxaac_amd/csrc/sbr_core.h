@@ -1983,6 +1983,148 @@ FX_HD void xs_adapt_noise_gain_lp(const XsCx &cx, ST *st, XsEnv &v, const int16_
   cx.sync();
 }
 
+/* xs_adapt_noise_gain_lp for an envelope of a pass (nsb <= 32; the envelope's gains, noise and sine levels on lanes
+   off .. off + nsb - 1 of v): the slots of the envelope on the two halves of the wave, lane 32 h + k = band k, slots
+   s0 + h, s0 + h + 2, ...  Nothing in the low-power slot loop runs from slot to slot -- the phase index and the harmonic
+   index are s0's plus a multiple of the slot number, the noise level and the noise exponent change once, where the slots
+   pass 32 (env_calc.c:560-575), and the noise filter buffer is only rescaled along the way --, and a slot's edge columns
+   are touched by that slot alone, so each half does every second slot and the state that is left behind (filter buffers,
+   indices) is what the slot-by-slot walk leaves. */
+template <class ST, class Q>
+FX_HD void xs_adapt_noise_gain_lp_split(const XsCx &cx, ST *st, const XsEnv &v, int off, const int16_t *rand_hi, int noise_e,
+                                        int nsb, int skip, int s0, int s1, int input_e, int adj_e, int final_e, int sb_start,
+                                        int lb_scale, int noise_absc, const Q &x) {
+  const int bands = nsb - skip;
+  const int start_up = cx.uni(st->start_up);
+  const int ph0 = cx.uni(st->ph_index), harm0 = cx.uni(st->harm_index);
+  const int fb_noise_e0 = start_up ? noise_e : cx.uni(st->filt_buf_noise_e);
+  cx.sync(); /* everyone has read the scalars before they are updated */
+  XsLv idx;
+  idx.fill(0);
+  XS_LANES(l, 0, 64) idx.own(l) = off + (l & (XS_PK - 1));
+  XsLv gain = v.gain.gather(idx);
+  const XsLv noise = v.noise.gather(idx), sine = v.sine.gather(idx);
+  XS_LANES(k, 0, bands) { /* (the lower half: band k's state) */
+    int16_t g[2] = {xs_m(gain.own(k)), xs_e(gain.own(k))};
+    if (start_up) {
+      st->filt_buf_me[2 * (skip + k)] = g[0];
+      st->filt_buf_me[2 * (skip + k) + 1] = g[1];
+      st->filt_buf_noise_m[skip + k] = xs_m(noise.own(k));
+    } else {
+      xs_equalize_filt_buf(&st->filt_buf_me[2 * (skip + k)], g);
+      gain.own(k) = xs_me(g[0], g[1]);
+    }
+  }
+  cx.sync();
+  XsLv lo;
+  lo.fill(0);
+  XS_LANES(l, 0, 64) lo.own(l) = l & (XS_PK - 1);
+  gain = gain.gather(lo); /* the equalised gains on both halves */
+  const XsLv tone = xs_prefix_nonzero_m(cx, sine, nsb).gather(lo); /* (lanes 0 .. nsb - 1 hold the counts) */
+  const XsLv s_prev = sine.shifted(cx, -1), s_next = sine.shifted(cx, 1);
+  XS_T(21);
+  const int nm1 = nsb - 1;
+  int fi0 = !(sb_start & 1); /* freq_inv for harmonic index 1; index 3 negates it */
+  fi0 = (fi0 << 1) - 1;
+  const int n = s1 > s0 ? s1 - s0 : 0;
+  const bool crosses = s0 < 32 && s1 > 32;
+  XsLv nl_out, fbn_out;
+  nl_out.fill(0);
+  fbn_out.fill(0);
+  XS_LANES(l, 0, 64) {
+    const int h = l / XS_PK, k = l & (XS_PK - 1);
+    if (k >= nsb) continue;
+    const int16_t gm = xs_m(gain.own(l)), ge = xs_e(gain.own(l));
+    const int16_t sl = xs_m(sine.own(l));
+    const int16_t sl_prev = k > 0 ? xs_m(s_prev.own(l)) : (int16_t)0;
+    const int16_t sl_next = (k + 1 < nsb) ? xs_m(s_next.own(l)) : (int16_t)0;
+    const int16_t nl_a = xs_m(noise.own(l));
+    const int16_t nl_b = k < bands ? xs_noise_rescale(nl_a, final_e - noise_e) : nl_a;
+    const int with_noise = !noise_absc && sl == 0;
+    const int few_tones = tone.own(l) <= 16;
+    const int32_t sine32 = xs_shl(sl, 16);
+    int32_t term1;
+    if (k == 0) {
+      term1 = fx_mul32x16(XS_FACTOR, sl_next);
+      if (fi0 < 0) term1 = -term1;
+    } else if (k < nm1) {
+      const int32_t add = fx_mul32x16(XS_FACTOR, (int16_t)(sl_prev - sl_next));
+      term1 = few_tones ? (((k & 1) ? fi0 : -fi0) < 0 ? -add : add) : 0;
+    } else {
+      const int32_t tms = fx_mul32x16(XS_FACTOR, sl_prev);
+      term1 = few_tones ? (((nm1 & 1) ? fi0 : -fi0) > 0 ? tms : -tms) : 0;
+    }
+    int32_t edge1 = 0;
+    int edge_col = -1;
+    if (k == 0) {
+      edge1 = fx_mul32x16(XS_FACTOR, sl);
+      edge_col = sb_start - 1;
+    }
+    if (k == nm1 && nm1 > 0 && few_tones && k + sb_start < 62) {
+      const int32_t tm2 = fx_mul32x16(XS_FACTOR, sl);
+      edge1 = ((nm1 & 1) ? fi0 : -fi0) > 0 ? -tm2 : tm2;
+      edge_col = sb_start + k + 1;
+    }
+    const int sh_a = ge - ((adj_e - input_e) - 1), sh_b = ge - ((final_e - input_e) - 1);
+    const int shl_a = sh_a > 0 ? (sh_a & 31) : 0, shr_a = sh_a > 0 ? 0 : ((-sh_a) & 31);
+    const int shl_b = sh_b > 0 ? (sh_b & 31) : 0, shr_b = sh_b > 0 ? 0 : ((-sh_b) & 31);
+    for (int sl_i = s0 + h; sl_i < s1; sl_i += 2) {
+      const int j = sl_i - s0;
+      const bool late = sl_i >= 32 && s0 < 32; /* behind the change of the noise exponent */
+      const int ne = late ? final_e : noise_e;
+      const int16_t nl = late ? nl_b : nl_a;
+      const int ph = (ph0 + j * nsb) & 511, hi = (harm0 + j) & 3;
+      const int16_t rp = rand_hi[ph + 1 + k];
+      int32_t val = fx_mul32x16(x(sl_i, sb_start + k), gm);
+      val = (int32_t)((uint32_t)val << (sl_i < 32 ? shl_a : shl_b)) >> (sl_i < 32 ? shr_a : shr_b);
+      const int32_t noisy = xs_mac16x16_shl_sat(val, rp, nl);
+      if (!(hi & 1)) {
+        const int32_t toned = hi == 0 ? fx_add_sat(val, sine32) : fx_sub_sat(val, sine32);
+        val = with_noise ? noisy : toned;
+      } else {
+        val = with_noise ? noisy : val;
+        val = fx_add_sat(val, hi == 1 ? term1 : -term1);
+        if (edge_col >= 0) {
+          int32_t t = edge1;
+          const int neg = (hi == 1 ? fi0 : -fi0) < 0;
+          if (k == 0) {
+            const int16_t nexp = (int16_t)((ne - 16) - lb_scale);
+            t = nexp > 0 ? fx_shl(t, nexp) : fx_shr(t, -nexp);
+            x(sl_i, edge_col) = neg ? fx_add_sat(x(sl_i, edge_col), t) : fx_sub_sat(x(sl_i, edge_col), t);
+          } else {
+            x(sl_i, edge_col) = hi == 1 ? fx_add_sat(x(sl_i, edge_col), t) : fx_sub_sat(x(sl_i, edge_col), t);
+          }
+        }
+      }
+      x(sl_i, sb_start + k) = val;
+    }
+    /* what the walk leaves: the noise filter buffer rescaled at the first slot and where the exponent changes, the noise
+       level of the last slot */
+    int16_t fbn = st->filt_buf_noise_m[k];
+    if (n > 0) fbn = xs_noise_rescale(fbn, fb_noise_e0 - noise_e);
+    if (crosses) fbn = xs_noise_rescale(fbn, noise_e - final_e);
+    fbn_out.own(l) = fbn;
+    nl_out.own(l) = crosses ? nl_b : nl_a;
+  }
+  cx.sync();
+  XS_T(22);
+  XS_LANES(k, 0, nsb) st->filt_buf_noise_m[k] = (int16_t)fbn_out.own(k);
+  cx.sync();
+  XS_LANES(k, 0, bands) {
+    st->filt_buf_me[2 * (skip + k)] = xs_m(gain.own(k));
+    st->filt_buf_noise_m[skip + k] = (int16_t)nl_out.own(k);
+  }
+  XS_ONE {
+    int ne = noise_e;
+    if (crosses) ne = final_e;
+    st->start_up = 0;
+    st->filt_buf_noise_e = n > 0 ? ne : fb_noise_e0;
+    st->ph_index = (int16_t)((ph0 + n * nsb) & 511);
+    st->harm_index = (int16_t)((harm0 + n) & 3);
+  }
+  cx.sync();
+}
+
 /* ---- HQ (complex) mode -------------------------------------------------------------------------- */
 /* env_calc.c:450 */
 FX_HD void xs_erg_to_amplitude_hq(const XsCx &cx, int bands, int16_t noise_e, XsEnv &v) {
@@ -2998,17 +3140,11 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
         XS_T(8);
         xs_erg_to_amplitude_lp_pk(cx, ps, bands, v);
         XS_T(9);
-        /* the envelopes' slots, one envelope after the other, each on its half of the vectors */
-        for (int q = 0; q < ps.n; q++) {
-          XsEnv vq = v;
-          if (q) {
-            vq.gain = v.gain.shifted(cx, XS_PK);
-            vq.noise = v.noise.shifted(cx, XS_PK);
-            vq.sine = v.sine.shifted(cx, XS_PK);
-          }
-          xs_adapt_noise_gain_lp(cx, st, vq, rand_hi, xs_qsel(q, ps.noise_e), nsb, skip, xs_qsel(q, s0), xs_qsel(q, s1),
-                                 input_e, adj_e, final_e, max_sb, (int16_t)(15 - lb_scale), xs_qsel(q, ps.noise_absc), x);
-        }
+        /* the envelopes' slots, one envelope after the other, every second slot on each half of the wave */
+        for (int q = 0; q < ps.n; q++)
+          xs_adapt_noise_gain_lp_split(cx, st, v, q ? XS_PK : 0, rand_hi, xs_qsel(q, ps.noise_e), nsb, skip, xs_qsel(q, s0),
+                                       xs_qsel(q, s1), input_e, adj_e, final_e, max_sb, (int16_t)(15 - lb_scale),
+                                       xs_qsel(q, ps.noise_absc), x);
       }
       XS_T(10);
       i += ps.n;
