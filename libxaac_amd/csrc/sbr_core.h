@@ -11,7 +11,7 @@
  *   xs_headroom / xs_adjust                               ixheaacd_env_calc.c:1159 / :1099
  *   xs_rescale_x_overlap                                  ixheaacd_sbrdec_lpfuncs.c:453
  *   xs_invfilt_level_emphasis                             ixheaacd_sbrdec_lpfuncs.c:735
- *   xs_covariance_lp / xs_filter1_lp / xs_low_pow_hf_generator   ixheaacd_lpp_tran.c:271 / :665 / :843
+ *   xs_low_pow_hf_generator (with the autocorrelation and the patch filter)   ixheaacd_lpp_tran.c:843 (:271, :629 / :665)
  *   xs_map_sineflags                                      ixheaacd_sbrdec_lpfuncs.c:529
  *   xs_energy_per_subband / xs_energy_per_sfb             ixheaacd_env_calc.c:1211 / :1298
  *   xs_subbandgain / xs_calc_subband_gains                ixheaacd_env_calc.c:1382 / :616
@@ -527,38 +527,6 @@ FX_HD void xs_lpc_save(const XsCx &cx, ST *st, const Q &x, int usb) {
 }
 
 /* ---- HF generator, low-power mode ------------------------------------------------------------------ */
-/* lpp_tran.c:271: real autocorrelation of band k over `len` (= 38) slots starting at row -2 */
-template <class Q>
-FX_HD void xs_covariance_lp(const Q &x, int k, int len, XsCov *c) {
-  int32_t p01 = 0, p02 = 0, p11 = 0;
-  int row = -2;
-  const int32_t first = fx_shr(x(-2, k), 3), second = fx_shr(x(-1, k), 3);
-  int32_t t1 = first, t2 = second, t3 = 0;
-  row += 2;
-  /* the reference walks three samples at a time; the running sums only depend on the sample order */
-  XS_UNROLL4
-  for (int j = 0; j < len; j++) {
-    t3 = fx_shr(x(row++, k), 3);
-    p01 = fx_add(p01, xs_mul_hi16(t3, t2));
-    p02 = fx_add(p02, xs_mul_hi16(t3, t1));
-    p11 = fx_add(p11, xs_mul_hi16(t2, t2));
-    t1 = t2;
-    t2 = t3;
-  }
-  /* after the loop (t1, t2) are the last two samples; the reference's temp1/temp3 at that point */
-  int32_t last1 = t2, last3 = t1;
-  int32_t p12 = fx_add(fx_sub(p01, xs_mul_hi16(last1, last3)), xs_mul_hi16(second, first));
-  int32_t p22 = fx_add(fx_sub(p11, xs_mul_hi16(last3, last3)), xs_mul_hi16(first, first));
-  int32_t mx = fx_abs_nrm(p01) | fx_abs_nrm(p02) | fx_abs_nrm(p12) | p11 | p22;
-  int q = xs_pnorm32(mx);
-  c->phi_11 = xs_shl(p11, q);
-  c->phi_22 = xs_shl(p22, q);
-  c->phi_01 = xs_shl(p01, q);
-  c->phi_02 = xs_shl(p02, q);
-  c->phi_12 = xs_shl(p12, q);
-  c->d = fx_sub_sat(fx_mul32(c->phi_22, c->phi_11), fx_mul32(c->phi_12, c->phi_12));
-}
-
 /* sbrdec_lpfuncs.c:735 (at most 5 inverse-filtering bands: one per lane) */
 FX_HD void xs_invfilt_level_emphasis(const XsCx &cx, const int32_t *bw_prev, int n, const int32_t *mode,
                                      const int32_t *mode_prev, int32_t *bw) {
@@ -647,43 +615,6 @@ FX_HD void xs_degree_alias_lp(const XsCx &cx, const XsLv &k1v, XsLv &deg, int st
   }
 }
 
-/* lpp_tran.c:629 + :665, second half: copy / inverse-filter low band lb into each patch's high band.
-   The reference advances a per-patch index into bw_borders as hb grows; hb grows with lb inside a
-   patch, so that index is the first border above hb. */
-template <class Q>
-FX_HD void xs_patch_band_lp(const xaac_sbr_header *h, const Q &x, int lb, int16_t alpha0, int16_t alpha1,
-                            const int32_t *bw_array, int start_idx, int stop_idx, int max_qmf_subband) {
-  for (int patch = 0; patch < h->num_patches; patch++) {
-    const xaac_sbr_patch *pp = &h->patch[patch];
-    int hb = xs_shl(lb + pp->dst_end_band, 8) >> 8;
-    if (lb < pp->src_start_band || lb >= pp->src_end_band || hb < max_qmf_subband) continue;
-    int bi = 0;
-    while (hb >= h->bw_borders[bi]) bi++;
-    int16_t bw = (int16_t)(bw_array[bi] >> 16);
-    int32_t a0 = xs_mult16x16_shl(bw, alpha0);
-    bw = xs_mult16_shl_sat(bw, bw);
-    int32_t a1 = xs_mult16x16_shl(bw, alpha1);
-    const int len = stop_idx - start_idx - 1;
-    /* the reference produces two slots per step: an odd count runs one slot past stop_idx */
-    const int n_out = len >= 0 ? ((len >> 1) + 1) * 2 : 0;
-    if (bw > 0) {
-      /* lpp_tran.c:629: y[n] = x[n]/4 + 2 (a1 x[n-2] + a0 x[n-1]) */
-      int32_t xm2 = x(start_idx - 2, lb), xm1 = x(start_idx - 1, lb);
-      XS_UNROLL4
-      for (int i = 0; i < n_out; i++) {
-        const int32_t cur = x(start_idx + i, lb);
-        const int32_t t = xs_mul_hi16(xm2, a1);
-        x(start_idx + i, hb) = fx_add_sat(cur >> 2, fx_shlw(fx_add(t, xs_mul_hi16(xm1, a0)), 1));
-        xm2 = xm1;
-        xm1 = cur;
-      }
-    } else {
-      XS_UNROLL4
-      for (int i = 0; i <= len; i++) x(start_idx + i, hb) = x(start_idx + i, lb) >> 2;
-    }
-  }
-}
-
 /* lpp_tran.c:843.  deg (64 aliasing degrees by QMF band) must be zeroed by the caller.  Writes
    bw_array_prev. */
 template <class ST, class Q>
@@ -718,9 +649,61 @@ FX_HD void xs_low_pow_hf_generator(const XsCx &cx, const xaac_sbr_header *h, ST 
   XsLv k1v, alpha;
   k1v.fill(0);
   alpha.fill(0);
+  /* lpp_tran.c:271: real autocorrelation of band k over auto_corr_len (= 38) slots from row -2 on (the reference walks
+     three samples at a time; the running sums only depend on the sample order).  The sums wrap (fx_add), so their order is free: the slots of a band are split over as many
+     lane groups as the low bands leave room for (W lanes per group: lane l takes the band congruent to l modulo W and
+     the l / W-th part of the slots) and the parts are added up across the groups; lane k then finishes band k. */
+  const int nlow = stop_patch - start_patch;
+  const int W = nlow <= 16 ? 16 : nlow <= 32 ? 32 : 64, G = 64 / W;
+  XsLv p01v, p02v, p11v;
+  p01v.fill(0);
+  p02v.fill(0);
+  p11v.fill(0);
+  if (norm_max != 30) {
+    XS_LANES(l, 0, 64) {
+      const int k = start_patch + ((l - start_patch) & (W - 1)), g = l / W;
+      if (k < stop_patch) {
+        const int j0 = g * auto_corr_len / G, j1 = (g + 1) * auto_corr_len / G;
+        int32_t p01 = 0, p02 = 0, p11 = 0;
+        int32_t t1 = fx_shr(x(j0 - 2, k), 3), t2 = fx_shr(x(j0 - 1, k), 3);
+        XS_UNROLL4
+        for (int j = j0; j < j1; j++) {
+          const int32_t t3 = fx_shr(x(j, k), 3);
+          p01 = fx_add(p01, xs_mul_hi16(t3, t2));
+          p02 = fx_add(p02, xs_mul_hi16(t3, t1));
+          p11 = fx_add(p11, xs_mul_hi16(t2, t2));
+          t1 = t2;
+          t2 = t3;
+        }
+        p01v.own(l) = p01;
+        p02v.own(l) = p02;
+        p11v.own(l) = p11;
+      }
+    }
+    if (G > 1) {
+      p01v = p01v.fold(W);
+      p02v = p02v.fold(W);
+      p11v = p11v.fold(W);
+    }
+  }
   XS_LANES(k, start_patch, stop_patch) {
     XsCov c = {0, 0, 0, 0, 0, 0};
-    if (norm_max != 30) xs_covariance_lp(x, k, auto_corr_len, &c);
+    if (norm_max != 30) {
+      /* lpp_tran.c:271 behind its loop: the samples at the two ends of the 38 slots */
+      const int32_t p01 = p01v.own(k), p02 = p02v.own(k), p11 = p11v.own(k);
+      const int32_t first = fx_shr(x(-2, k), 3), second = fx_shr(x(-1, k), 3);
+      const int32_t last1 = fx_shr(x(auto_corr_len - 1, k), 3), last3 = fx_shr(x(auto_corr_len - 2, k), 3);
+      const int32_t p12 = fx_add(fx_sub(p01, xs_mul_hi16(last1, last3)), xs_mul_hi16(second, first));
+      const int32_t p22 = fx_add(fx_sub(p11, xs_mul_hi16(last3, last3)), xs_mul_hi16(first, first));
+      const int32_t mx = fx_abs_nrm(p01) | fx_abs_nrm(p02) | fx_abs_nrm(p12) | p11 | p22;
+      const int q = xs_pnorm32(mx);
+      c.phi_11 = xs_shl(p11, q);
+      c.phi_22 = xs_shl(p22, q);
+      c.phi_01 = xs_shl(p01, q);
+      c.phi_02 = xs_shl(p02, q);
+      c.phi_12 = xs_shl(p12, q);
+      c.d = fx_sub_sat(fx_mul32(c.phi_22, c.phi_11), fx_mul32(c.phi_12, c.phi_12));
+    }
     int16_t a0, a1, k1;
     xs_lpc_coeffs_lp(&c, &a0, &a1, &k1);
     alpha.own(k) = xs_me(a0, a1);
@@ -729,9 +712,61 @@ FX_HD void xs_low_pow_hf_generator(const XsCx &cx, const xaac_sbr_header *h, ST 
   XS_T(13);
   xs_degree_alias_lp(cx, k1v, deg, start_patch, stop_patch);
   XS_T(14);
-  XS_LANES(lb, start_patch, stop_patch)
-    xs_patch_band_lp(h, x, lb, xs_m(alpha.own(lb)), xs_e(alpha.own(lb)), w->bw_array, start_idx, stop_idx,
-                     max_qmf_subband);
+  /* lpp_tran.c:629 + :665, second half: low band lb copied / inverse-filtered into each patch's high band.  One lane per
+     HIGH band (the reference walks the low bands and, per low band, the patches: fifteen lanes with three patches each in a
+     common stream); with at most 32 high bands the two halves of the wave share a band's slots.  A slot of a high band reads
+     its low band's slots only, so the split is free; the patches' destinations are disjoint (a later patch would win). */
+  {
+    const int nhigh = actual_stop - stop_patch;
+    const bool halves = nhigh <= 32;
+    XsLv lbv, pv;
+    lbv.fill(0);
+    pv.fill(-1);
+    XS_LANES(l, 0, 64) {
+      const int hb = halves ? stop_patch + (l & 31) : l;
+      if (hb < max_qmf_subband || hb >= 64) continue;
+      for (int patch = 0; patch < num_patches; patch++) {
+        const xaac_sbr_patch *pp = &h->patch[patch];
+        const int lb = hb - pp->dst_end_band;
+        if (lb < start_patch || lb >= stop_patch || lb < pp->src_start_band || lb >= pp->src_end_band) continue;
+        if ((xs_shl(lb + pp->dst_end_band, 8) >> 8) != hb) continue;
+        lbv.own(l) = lb;
+        pv.own(l) = patch;
+      }
+    }
+    const XsLv al = alpha.gather(lbv);
+    XS_LANES(l, 0, 64) {
+      if (pv.own(l) < 0) continue;
+      const int hb = halves ? stop_patch + (l & 31) : l, part = halves ? l >> 5 : 0, lb = lbv.own(l);
+      const int16_t alpha0 = xs_m(al.own(l)), alpha1 = xs_e(al.own(l));
+      int bi = 0;
+      while (hb >= h->bw_borders[bi]) bi++;
+      int16_t bw = (int16_t)(w->bw_array[bi] >> 16);
+      const int32_t a0 = xs_mult16x16_shl(bw, alpha0);
+      bw = xs_mult16_shl_sat(bw, bw);
+      const int32_t a1 = xs_mult16x16_shl(bw, alpha1);
+      const int len = stop_idx - start_idx - 1;
+      /* the reference produces two slots per step when it filters: an odd count runs one slot past stop_idx */
+      const int n_tot = bw > 0 ? (len >= 0 ? ((len >> 1) + 1) * 2 : 0) : len + 1;
+      const int n_half = halves ? (n_tot + 1) >> 1 : n_tot;
+      const int i0 = part ? n_half : 0, i1 = part ? n_tot : n_half;
+      if (bw > 0) {
+        /* lpp_tran.c:629: y[n] = x[n]/4 + 2 (a1 x[n-2] + a0 x[n-1]) */
+        int32_t xm2 = x(start_idx + i0 - 2, lb), xm1 = x(start_idx + i0 - 1, lb);
+        XS_UNROLL4
+        for (int i = i0; i < i1; i++) {
+          const int32_t cur = x(start_idx + i, lb);
+          const int32_t t = xs_mul_hi16(xm2, a1);
+          x(start_idx + i, hb) = fx_add_sat(cur >> 2, fx_shlw(fx_add(t, xs_mul_hi16(xm1, a0)), 1));
+          xm2 = xm1;
+          xm1 = cur;
+        }
+      } else {
+        XS_UNROLL4
+        for (int i = i0; i < i1; i++) x(start_idx + i, hb) = x(start_idx + i, lb) >> 2;
+      }
+    }
+  }
   /* lpp_tran.c:905: the high bands inherit the aliasing degree of their source band (patch
      destinations are disjoint and above the source range, so one shifted copy per patch) */
   {
