@@ -267,9 +267,7 @@ def secondary_f4(torch, libxaac_amd, ctx, dev, n=16384, launches=20, hip_streams
     ics_u = torch.tensor([[0, 1]] * n, dtype=torch.uint8, device=dev)
     sp_u = z8(n)
     lu = fresh(ov, sp_u, o32)
-    # (the USAC kernel's launches do not gain from a second stream -- 120 us alone, 139 us dealt out over two -- so it runs on one)
-    timed("usac_fd_1024", lambda q: ctxs[q].usac_imdct_process_batch(spec, ics_u, lu[q][0], lu[q][1], lu[q][2]), n * 16384,
-          nl=min(len(ctxs), int(os.environ.get("XAAC_USAC_LANES", "1"))))
+    timed("usac_fd_1024", lambda q: ctxs[q].usac_imdct_process_batch(spec, ics_u, lu[q][0], lu[q][1], lu[q][2]), n * 16384)
     spec9 = spec[:, :960].contiguous()
     ov9 = torch.zeros((n, 480), dtype=torch.int32, device=dev)
     out9 = torch.zeros(n * 960, dtype=torch.int32, device=dev)

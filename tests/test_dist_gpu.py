@@ -42,7 +42,7 @@ whole = xdist.gather_pcm(dist, pcm)
 per_rank, info = xdist.post_run_report(dist, pcm, 123.0, dev)
 dist.barrier()
 dist.destroy_process_group()
-print(json.dumps({"t": t, "same": bool(torch.equal(whole, pcm)), "per_rank": per_rank, "ok": info["ok"],
+print("RESULT " + json.dumps({"t": t, "same": bool(torch.equal(whole, pcm)), "per_rank": per_rank, "ok": info["ok"],
                   "bytes": info["bytes_per_rank"]}))
 '''
 
@@ -55,6 +55,8 @@ def test_single_rank_nccl_group_runs_every_collective_of_the_bench():
     r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     import json
-    out = json.loads(r.stdout.strip().splitlines()[-1])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert lines, (r.stdout[-1000:], r.stderr[-1000:])
+    out = json.loads(lines[-1][7:])
     assert out["t"] == 1.25 and out["same"] and out["ok"] is True and out["per_rank"] == [123.0]
     assert out["bytes"] == 256 * 1024 * 2
