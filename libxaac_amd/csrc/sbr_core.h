@@ -2019,11 +2019,11 @@ FX_HD void xs_adapt_noise_gain_lp(const XsCx &cx, ST *st, XsEnv &v, const int16_
 }
 
 /* xs_adapt_noise_gain_lp for an envelope of a pass (nsb <= 32; the envelope's gains, noise and sine levels on lanes
-   off .. off + nsb - 1 of v): the slots of the envelope on the two halves of the wave, lane 32 h + k = band k, slots
-   s0 + h, s0 + h + 2, ...  Nothing in the low-power slot loop runs from slot to slot -- the phase index and the harmonic
+   off .. off + nsb - 1 of v): the slots of the envelope on the two halves of the wave, lane 32 h + k = band k, the first
+   n_half slots on the lower half, the others on the upper one.  Nothing in the low-power slot loop runs from slot to slot -- the phase index and the harmonic
    index are s0's plus a multiple of the slot number, the noise level and the noise exponent change once, where the slots
    pass 32 (env_calc.c:560-575), and the noise filter buffer is only rescaled along the way --, and a slot's edge columns
-   are touched by that slot alone, so each half does every second slot and the state that is left behind (filter buffers,
+   are touched by that slot alone, so each half does its share of the slots and the state that is left behind (filter buffers,
    indices) is what the slot-by-slot walk leaves. */
 template <class ST, class Q>
 FX_HD void xs_adapt_noise_gain_lp_split(const XsCx &cx, ST *st, const XsEnv &v, int off, const int16_t *rand_hi, int noise_e,
@@ -2063,6 +2063,7 @@ FX_HD void xs_adapt_noise_gain_lp_split(const XsCx &cx, ST *st, const XsEnv &v, 
   fi0 = (fi0 << 1) - 1;
   const int n = s1 > s0 ? s1 - s0 : 0;
   const bool crosses = s0 < 32 && s1 > 32;
+  const int n_half = (((n + 1) >> 1) + 1) & ~1; /* slots of the lower half of the wave: even, at least half of them */
   XsLv nl_out, fbn_out;
   nl_out.fill(0);
   fbn_out.fill(0);
@@ -2103,17 +2104,20 @@ FX_HD void xs_adapt_noise_gain_lp_split(const XsCx &cx, ST *st, const XsEnv &v, 
     const int sh_a = ge - ((adj_e - input_e) - 1), sh_b = ge - ((final_e - input_e) - 1);
     const int shl_a = sh_a > 0 ? (sh_a & 31) : 0, shr_a = sh_a > 0 ? 0 : ((-sh_a) & 31);
     const int shl_b = sh_b > 0 ? (sh_b & 31) : 0, shr_b = sh_b > 0 ? 0 : ((-sh_b) & 31);
-    for (int sl_i = s0 + h; sl_i < s1; sl_i += 2) {
-      const int j = sl_i - s0;
+    /* half h walks the slots from s0 + h n_half on; n_half is even, so a step's harmonic index is even on both halves or odd
+       on both: which of the two bodies (env_calc.c:1564 / :1617) a step runs is a scalar branch, not both under masks */
+    const int first = s0 + h * n_half;
+    for (int u = 0; u < n_half; u++) {
+      const int sl_i = first + u, j = sl_i - s0;
+      if (sl_i >= s1) continue;
       const bool late = sl_i >= 32 && s0 < 32; /* behind the change of the noise exponent */
-      const int ne = late ? final_e : noise_e;
       const int16_t nl = late ? nl_b : nl_a;
       const int ph = (ph0 + j * nsb) & 511, hi = (harm0 + j) & 3;
       const int16_t rp = rand_hi[ph + 1 + k];
       int32_t val = fx_mul32x16(x(sl_i, sb_start + k), gm);
       val = (int32_t)((uint32_t)val << (sl_i < 32 ? shl_a : shl_b)) >> (sl_i < 32 ? shr_a : shr_b);
       const int32_t noisy = xs_mac16x16_shl_sat(val, rp, nl);
-      if (!(hi & 1)) {
+      if (!((harm0 + u) & 1)) { /* (uniform) */
         const int32_t toned = hi == 0 ? fx_add_sat(val, sine32) : fx_sub_sat(val, sine32);
         val = with_noise ? noisy : toned;
       } else {
@@ -2123,6 +2127,7 @@ FX_HD void xs_adapt_noise_gain_lp_split(const XsCx &cx, ST *st, const XsEnv &v, 
           int32_t t = edge1;
           const int neg = (hi == 1 ? fi0 : -fi0) < 0;
           if (k == 0) {
+            const int ne = late ? final_e : noise_e;
             const int16_t nexp = (int16_t)((ne - 16) - lb_scale);
             t = nexp > 0 ? fx_shl(t, nexp) : fx_shr(t, -nexp);
             x(sl_i, edge_col) = neg ? fx_add_sat(x(sl_i, edge_col), t) : fx_sub_sat(x(sl_i, edge_col), t);
