@@ -126,13 +126,22 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_analysis_kernel(XaacQ
         }
       }
     }
-    /* ---- window-add: lanes = polyphase branch m, loop over the 2 x 32 slots ------------- */
-    for (int r = 0; r < 64; r++) {
-      const int16_t *h = hist + (r >> 5) * kHist + 288 + 32 * (r & 31) + 31 - lane;
-      int32_t acc = 0;
+    /* ---- window-add: lanes = polyphase branch m; a channel's 40 history words of the branch are read once and the 32 slots'
+       sums formed from registers (as a loop over the slots with five 2-byte LDS reads each, and scalar address arithmetic
+       around them, this was most of the low-power bank's time: 1.6 scalar instructions per vector one) ------------- */
 #pragma unroll
-      for (int j = 0; j < 5; j++) acc += (int32_t)h[-64 * j] * coef[j]; /* |acc| < 2^30: exact */
-      z[65 * r + lane] = acc;
+    for (int c = 0; c < 2; c++) {
+      const int16_t *h = hist + c * kHist + 288 + 31 - lane;
+      int32_t u[40]; /* u[8 + k] = x[32 k + 31 - m], k = -8 .. 31 */
+#pragma unroll
+      for (int k = 0; k < 40; k++) u[k] = h[32 * (k - 8)];
+#pragma unroll
+      for (int sl = 0; sl < 32; sl++) {
+        int32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 5; j++) acc += u[8 + sl - 2 * j] * coef[j]; /* |acc| < 2^30: exact */
+        z[65 * (32 * c + sl) + lane] = acc;
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     /* ---- per-slot transform: lane = slot ------------------------------------------------ */
@@ -167,13 +176,20 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_analysis_kernel(XaacQ
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     /* ---- rows out: coalesced, real bands at +0, imaginary (HQ) at +64 ---------------------- */
-    for (int r = 0; r < 64; r++) {
-      const int ch = 2 * pair + (r >> 5);
-      if (ch >= p.n_ch) break;
-      int32_t *row = p.qmf + (size_t)ch * p.qmf_ch_stride + (size_t)(r & 31) * p.slot_stride;
-      if (LP) {
-        if (lane < 32) row[lane] = z[65 * r + lane];
-      } else {
+    if (LP) {
+      /* 32 real bands per row: lanes 0..31 write the first channel's row r, lanes 32..63 the second channel's */
+      const int ch = 2 * pair + (lane >> 5);
+      if (ch < p.n_ch) {
+        int32_t *row = p.qmf + (size_t)ch * p.qmf_ch_stride + (lane & 31);
+        const int32_t *src = z + 65 * 32 * (lane >> 5) + (lane & 31);
+#pragma unroll 8
+        for (int r = 0; r < 32; r++) row[(size_t)r * p.slot_stride] = src[65 * r];
+      }
+    } else {
+      for (int r = 0; r < 64; r++) {
+        const int ch = 2 * pair + (r >> 5);
+        if (ch >= p.n_ch) break;
+        int32_t *row = p.qmf + (size_t)ch * p.qmf_ch_stride + (size_t)(r & 31) * p.slot_stride;
         row[(lane & 31) + 64 * (lane >> 5)] = z[65 * r + lane];
       }
     }
