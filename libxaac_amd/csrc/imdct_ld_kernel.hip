@@ -20,6 +20,35 @@ __device__ __forceinline__ int32_t wave_or(int32_t v) {
   for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
   return v;
 }
+/* xl_eld_overlap_add (imdct_ld.h) with the 3 F old overlap words in registers: ov1[i] = word lane + 64 i (what output sample
+   lane + 64 i adds), ov2[i] = word F + lane + 64 i (what new overlap word lane + 64 i adds), fetched at the top of the kernel
+   with the lines.  Read where they lie -- in place, between the stores of the new words -- every one of the 30 loop steps
+   waited for its own load (the bank spent 0.7 of its wave cycles waiting). */
+template <int F>
+__device__ __forceinline__ void eld_overlap_add_regs(const int32_t *out, const int32_t *ov1, const int32_t *ov2, int32_t *ov_new,
+                                                     int16_t *pcm, int stride, int q_shift, int lane) {
+  constexpr int delay = F / 4;
+  const int16_t *win = F == 512 ? xaac_ld_win_eld_512 : xaac_ld_win_eld_480;
+  const int q = q_shift + 2;
+#pragma unroll
+  for (int i = 0; i < (F + 63) / 64; i++) {
+    const int n = lane + 64 * i;
+    if (n < F) {
+      const int32_t w = fx_mul32x16(xl_eld_z<F>(out, delay + n), win[delay + n]);
+      const int32_t v = fx_add_sat(q >= 0 ? fx_shl(w, q) : fx_shr(w, -q), ov1[i]);
+      pcm[stride * n] = fx_round16(q >= 0 ? fx_shl_sat(v, 1) : fx_shl(v, 1));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < (3 * F - delay + 63) / 64; i++) {
+    const int k = lane + 64 * i;
+    if (k < 3 * F - delay) {
+      const int32_t w = fx_mul32x16(xl_eld_z<F>(out, delay + F + k), win[delay + F + k]);
+      const int32_t sh = q >= 0 ? fx_shl(w, q) : fx_shr(w, -q);
+      ov_new[k] = (i < (2 * F + 63) / 64 && k < 2 * F) ? fx_add_sat(sh, ov2[i < (2 * F + 63) / 64 ? i : 0]) : sh;
+    }
+  }
+}
 }  // namespace
 
 template <int F, bool ELD>
@@ -37,12 +66,18 @@ __global__ __launch_bounds__(64 * XAAC_LD_WAVES_PER_WG) void xaac_imdct_ld_kerne
   int32_t *gov = p.overlap + (size_t)ch * NOV;
   const int shape_v = p.window_shape[ch], shape_prev_v = p.shape_prev[ch];
   constexpr int NSV = (F + 63) / 64, NOR = ELD ? 1 : (NOV + 63) / 64;
-  int32_t sv[NSV], ovr[NOR];
+  constexpr int NE1 = ELD ? (F + 63) / 64 : 1, NE2 = ELD ? (2 * F + 63) / 64 : 1;
+  int32_t sv[NSV], ovr[NOR], ov1[NE1], ov2[NE2];
 #pragma unroll
   for (int k = 0; k < NSV; k++) sv[k] = lane + 64 * k < F ? spec[lane + 64 * k] : 0;
   if (!ELD) {
 #pragma unroll
     for (int k = 0; k < NOR; k++) ovr[k] = lane + 64 * k < NOV ? gov[lane + 64 * k] : 0;
+  } else { /* the 3 F old overlap words: see eld_overlap_add_regs */
+#pragma unroll
+    for (int k = 0; k < NE1; k++) ov1[k] = lane + 64 * k < F ? gov[lane + 64 * k] : 0;
+#pragma unroll
+    for (int k = 0; k < NE2; k++) ov2[k] = lane + 64 * k < 2 * F ? gov[F + lane + 64 * k] : 0;
   }
   const int shape = __builtin_amdgcn_readfirstlane(shape_v), shape_prev = __builtin_amdgcn_readfirstlane(shape_prev_v);
   if (shape > 1 || shape_prev > 1) { /* values the one-bit field cannot carry: left untouched */
@@ -60,9 +95,7 @@ __global__ __launch_bounds__(64 * XAAC_LD_WAVES_PER_WG) void xaac_imdct_ld_kerne
   const int q = xl_transform<F, ELD>(a + 512, a, b, e, lane, nl);
   int16_t *pcm = p.pcm16 + (size_t)(ch / p.ch_fac) * F * p.ch_fac + ch % p.ch_fac;
   if (ELD) {
-    /* the 3 F old overlap words are read where they lie: output n reads word n, new word k reads word F + k, which is only
-       overwritten F / 64 iterations later (program order within the wave: each iteration's store consumes its own load) */
-    xl_eld_overlap_add<F>(a, gov, gov, pcm, p.ch_fac, q, lane, nl);
+    eld_overlap_add_regs<F>(a, ov1, ov2, gov, pcm, p.ch_fac, q, lane);
   } else { /* LD: the F / 2 old overlap words move into the free work array before the new ones overwrite their source */
 #pragma unroll
     for (int k = 0; k < NOR; k++)
