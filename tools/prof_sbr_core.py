@@ -91,6 +91,13 @@ def main():
     for i in range(1, 24):
         print("%2d %-34s %9.0f cycles/channel-frame %5.1f%%" % (i, NAMES[i], acc[i], 100 * acc[i] / tot))
     print("   total %.0f cycles" % tot)
+    # the low-power synthesis bank's own timers (sbr_qmf_kernel.hip: XQ_TIME, counters 64 ..; one wave = a pair of channels)
+    syn = status.cpu().numpy()[:160].view(np.uint64).astype(np.float64)[64:70] / (steps * n / 2)
+    names = ["wait for the last pair's stores", "rows in (global -> LDS tile)", "rescale + inverse modulation (lane = slot)",
+             "ring samples + history into LDS", "window-add, PCM out", "ring state out"]
+    print("LP synthesis bank (cycles per pair of channel-frames):")
+    for i in range(6):
+        print("   %-44s %9.0f %5.1f%%" % (names[i], syn[i], 100 * syn[i] / max(1.0, syn.sum())))
 
 
 if __name__ == "__main__":
