@@ -395,19 +395,6 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
   char *wbase = smem + wave * (LP ? XAAC_QMF_SYN_LDS_PER_WAVE_LP : XAAC_QMF_SYN_LDS_PER_WAVE_HQ);
   int32_t *rows = reinterpret_cast<int32_t *>(wbase);  /* [64][RS] slot rows, later aliased by ... */
   int16_t *v = reinterpret_cast<int16_t *>(wbase);     /* ... [2][VSLOTS][VROW] ring samples */
-  /* Low-power banks: this frame's 2 x 32 slots of ring samples take exactly the row tile's bytes (2 x 32 x 130 x 2 = 64 x 65 x 4)
-     and the 2 x 9 history slots lie behind it, so the history can be fetched while the rows still arrive -- its loads then
-     share the rows' memory latency instead of paying their own behind the transform (a quarter of the bank's time, with
-     the 2-byte ring accesses), and the ring goes in and out as 4-byte words when its offset is even (it always is unless a
-     caller hands in an odd one). */
-  constexpr bool EARLY = LP;
-  constexpr int HB = (64 * 65 * 4) / 2; /* int16 index of the history slots */
-  static_assert(!LP || (2 * 32 * VROW * 2 <= 64 * 65 * 4 && (64 * 65 * 4) + 2 * 9 * VROW * 2 <= XAAC_QMF_SYN_LDS_PER_WAVE_LP), "LDS layout");
-  /* start of slot idx (0..8: history, oldest first; 9 + s: slot s of this frame) of channel c in v */
-  const auto vslot = [&](int c, int idx) -> int {
-    if (!EARLY) return (c * VSLOTS + idx) * VROW;
-    return idx < 9 ? HB + (c * 9 + idx) * VROW : (c * 32 + idx - 9) * VROW;
-  };
 
   int32_t coef[10]; /* c[64 A + k], k = lane; down-sampled: every second one, k = lane & 31 (qmf_dec.c:749) */
 #pragma unroll
@@ -449,7 +436,11 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
         }
       }
     }
-    constexpr int HP = (9 * BLK / 2 + 63) / 64; /* history as pairs of samples: words per lane and channel */
+    /* Low-power banks: the 2 x 9 history slots of the ring are asked for while the rows still arrive -- as pairs of samples (4-byte
+       words; the ring's offset is even unless a caller hands in an odd one), kept in registers through the transform and
+       put into place behind it: read there, behind the transform, their loads paid a memory latency of their own */
+    constexpr bool EARLY = LP;
+    constexpr int HP = (9 * BLK / 2 + 63) / 64; /* words per lane and channel */
     int32_t hpair[2][HP];
     bool hist_words = false;
     for (int r0 = 0; r0 < 64; r0 += G) {
@@ -467,11 +458,9 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
 #pragma unroll
         for (int q = 0; q < ROW / 64; q++) rows[RS * r + lane + 64 * q] = ch < p.n_ch ? tmp[j][q] : 0;
       }
-      if (EARLY && r0 == 0) {
-        /* the ring offsets have arrived with the first rows: the history's loads go out in front of the other rows' */
+      if (EARLY && r0 == 0) { /* the ring offsets have arrived with the first rows */
         const int d0 = __builtin_amdgcn_readfirstlane(d_v[0]), d1 = __builtin_amdgcn_readfirstlane(d_v[1]);
-        hist_words = ((d0 | d1) & 1) == 0 && (p.state_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(p.state) & 3) == 0 &&
-                     (offsetof(xaac_qmf_syn_state, ring) & 3) == 0;
+        hist_words = ((d0 | d1) & 1) == 0 && (p.state_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(p.state) & 3) == 0;
         if (hist_words) {
 #pragma unroll
           for (int c = 0; c < 2; c++) {
@@ -489,17 +478,6 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
               hpair[c][j] = *reinterpret_cast<const int32_t *>(&st->ring[pos]);
             }
           }
-        }
-      }
-    }
-    if (EARLY && hist_words) {
-#pragma unroll
-      for (int c = 0; c < 2; c++) {
-        if (2 * pair + c >= p.n_ch) break;
-#pragma unroll
-        for (int j = 0; j < HP; j++) {
-          const int i = 2 * (lane + 64 * j);
-          if (i < 9 * BLK) *reinterpret_cast<int32_t *>(&v[vslot(c, i / BLK) + i % BLK]) = hpair[c][j];
         }
       }
     }
@@ -541,15 +519,26 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
        re-used through an int16 view: keep the compiler from moving accesses across this point) */
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     {
-      int16_t *dst = v + vslot(lane >> 5, 9 + (lane & 31));
+      int16_t *dst = v + ((lane >> 5) * VSLOTS + 9 + (lane & 31)) * VROW;
 #pragma unroll
       for (int i = 0; i < BLK; i += 2)
         *reinterpret_cast<int32_t *>(dst + i) = (int32_t)((uint32_t)(uint16_t)b[i] | ((uint32_t)(uint16_t)b[i + 1] << 16));
     }
+    if (EARLY && hist_words) {
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        if (2 * pair + c >= p.n_ch) break;
+#pragma unroll
+        for (int j = 0; j < HP; j++) {
+          const int i = 2 * (lane + 64 * j);
+          if (i < 9 * BLK) *reinterpret_cast<int32_t *>(&v[(c * VSLOTS + i / BLK) * VROW + i % BLK]) = hpair[c][j];
+        }
+      }
+    }
     for (int c = 0; c < 2; c++) {
       const int ch = 2 * pair + c;
       if (ch >= p.n_ch) break;
-      if (EARLY && hist_words) break; /* (the history is in place already) */
+      if (EARLY && hist_words) break; /* (in place already) */
       const xaac_qmf_syn_state *st = reinterpret_cast<const xaac_qmf_syn_state *>(
           reinterpret_cast<const char *>(p.state) + (size_t)ch * p.state_stride);
       const int d = __builtin_amdgcn_readfirstlane(d_v[c]);
@@ -566,7 +555,7 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
 #pragma unroll
       for (int j = 0; j < HJ; j++) {
         const int i = lane + 64 * j;
-        v[vslot(c, i / BLK) + i % BLK] = hist[j];
+        v[(c * VSLOTS + i / BLK) * VROW + i % BLK] = hist[j];
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -583,9 +572,10 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
       /* a wave covers one slot of 64 samples, or two slots of 32 */
       for (int s0 = 0; s0 < 32; s0 += 64 / NC) {
         const int s = DS ? s0 + (lane >> 5) : s0, k = DS ? (lane & 31) : lane;
+        const int16_t *vs = v + (c * VSLOTS + 9 + s) * VROW + k;
         int32_t acc = 0x8000 >> shift;
 #pragma unroll
-        for (int A = 0; A < 10; A++) acc += (int32_t)v[vslot(c, 9 + s - A) + k + NC * (A & 1)] * coef[A]; /* < 2^31: exact */
+        for (int A = 0; A < 10; A++) acc += (int32_t)vs[-VROW * A + NC * (A & 1)] * coef[A]; /* < 2^31: exact */
         dst[(size_t)(NC * s + k) * cf] = (int16_t)(fx_shl_sat(acc, shift) >> 16);
       }
     }
@@ -599,22 +589,12 @@ __global__ __launch_bounds__(XAAC_QMF_BLOCK) void xaac_qmf_synthesis_kernel(Xaac
           reinterpret_cast<xaac_qmf_syn_state *>(reinterpret_cast<char *>(p.state) + (size_t)ch * p.state_stride);
       const int d_new = (__builtin_amdgcn_readfirstlane(d_v[c]) + RING - (32 * BLK) % RING) % RING; /* 32 slots of BLK downwards */
       const int ph_new = (st->phase + 128) % 640;
-      if (EARLY && hist_words) { /* (d_new is even with d: pairs of samples, as they came) */
-        for (int i = 2 * lane; i < RING; i += 128) {
-          const int A = 1 + i / BLK;
-          int pos = d_new + BLK * A + i % BLK;
-          if (pos >= RING) pos -= RING;
-          if (pos >= RING) pos -= RING;
-          *reinterpret_cast<int32_t *>(&st->ring[pos]) = *reinterpret_cast<const int32_t *>(&v[vslot(c, 9 + 32 - A) + i % BLK]);
-        }
-      } else {
-        for (int i = lane; i < RING; i += 64) {
-          const int A = 1 + i / BLK; /* age relative to the NEXT frame's slot 0: 1..10 */
-          int pos = d_new + BLK * A + i % BLK;
-          if (pos >= RING) pos -= RING;
-          if (pos >= RING) pos -= RING;
-          st->ring[pos] = v[vslot(c, 9 + 32 - A) + i % BLK];
-        }
+      for (int i = lane; i < RING; i += 64) {
+        const int A = 1 + i / BLK; /* age relative to the NEXT frame's slot 0: 1..10 */
+        int pos = d_new + BLK * A + i % BLK;
+        if (pos >= RING) pos -= RING;
+        if (pos >= RING) pos -= RING;
+        st->ring[pos] = v[(c * VSLOTS + 9 + 32 - A) * VROW + i % BLK];
       }
       if (lane == 0) {
         st->drc_offset = (int16_t)d_new;
