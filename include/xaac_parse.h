@@ -147,8 +147,7 @@ typedef struct xaac_parse_batch {
                                  starts at data[i] + pos[i] with bytes[i] - pos[i] bytes available, and pos[i] moves on by the
                                  frame's length where status is XAAC_PARSE_OK.  A host that leaves data / bytes as the whole
                                  streams can then issue the next step's call without touching its arrays in between.
-                                 (Appended in round 4: a descriptor built for the older layout must be zero-initialised at the
-                                 new size.) */
+                                 (Appended in round 4, like the two members below: see xaac_parse_batch_run_sized.) */
   int32_t frames;             /* 0 or 1: one frame per stream and call.  T > 1 (needs pos): up to T consecutive frames of every
                                  stream per call -- a stream's parser state and bytes are fetched once for T frames -- with every
                                  output array T times as long, step t's rows behind step t - 1's (spec [T][n_streams][n_ch][1024],
@@ -172,6 +171,17 @@ XAAC_API int32_t xaac_parse_batch_run(const xaac_parse_batch *b);
    streams -- what the caller overlapped, or waited for. */
 XAAC_API int32_t xaac_parse_batch_start(const xaac_parse_batch *b);
 XAAC_API int32_t xaac_parse_batch_wait(double *busy_seconds);
+/* The descriptor has grown at its end (round 4: pos, frames, lines) and may again.  _run_sized / _start_sized take the size of
+   the caller's struct: members behind it read as zero, whatever lies behind the caller's shorter struct is not looked at.
+   The symbols xaac_parse_batch_run / _start themselves keep the ORIGINAL layout's meaning -- they read the descriptor up to and
+   including reset_pitch, as a binary built before the growth expects --; code compiled against this header reaches the sized
+   entry points with its own sizeof through the two macros below (define XAAC_PARSE_NO_SIZED_MACROS to call the symbols). */
+XAAC_API int32_t xaac_parse_batch_run_sized(const xaac_parse_batch *b, uint64_t struct_size);
+XAAC_API int32_t xaac_parse_batch_start_sized(const xaac_parse_batch *b, uint64_t struct_size);
+#ifndef XAAC_PARSE_NO_SIZED_MACROS
+#define xaac_parse_batch_run(b) xaac_parse_batch_run_sized((b), sizeof(xaac_parse_batch))
+#define xaac_parse_batch_start(b) xaac_parse_batch_start_sized((b), sizeof(xaac_parse_batch))
+#endif
 
 /* ---- the states of a new stream, and the frame-level state changes of ixheaacd_applysbr -------------------------------
  * Host-side helpers on HOST copies of the boundary structs (the host writes them to the device once per stream, and on

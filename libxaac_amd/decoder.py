@@ -284,8 +284,10 @@ class BatchParser:
 
     def __init__(self, streams, threads=0, stage=2, esbr=False):
         self.lib = load_host_library()
-        self.lib.xaac_parse_batch_run.argtypes = [ctypes.c_void_p]
+        self.lib.xaac_parse_batch_run.argtypes = [ctypes.c_void_p]       # (the original layout's symbols: no pos / frames / lines)
         self.lib.xaac_parse_batch_start.argtypes = [ctypes.c_void_p]
+        self.lib.xaac_parse_batch_run_sized.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+        self.lib.xaac_parse_batch_start_sized.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
         self.lib.xaac_parse_batch_wait.argtypes = [ctypes.c_void_p]
         self.esbr = bool(esbr)
         self.n = n = len(streams)
@@ -366,7 +368,7 @@ class BatchParser:
         """parses the next frame of every stream into the staging arrays; -> bool[n]: which streams delivered a frame
         (the others are at their end: their rows are left as they were)"""
         b = self._descriptor(spec, ics, hdr, frm, psf, flags, self.sbr, eside)
-        return self._advance(self.lib.xaac_parse_batch_run(ctypes.byref(b)))
+        return self._advance(self.lib.xaac_parse_batch_run_sized(ctypes.byref(b), ctypes.sizeof(b)))
 
     def start_step(self, spec, ics, hdr=None, frm=None, psf=None, flags=None, eside=None, status=None, reset_pitch=None, frames=1,
                    lines=None):
@@ -378,7 +380,7 @@ class BatchParser:
         lines: int32[T, n] out, xaac_parse_batch::lines."""
         self._status_in_flight = status
         b = self._descriptor(spec, ics, hdr, frm, psf, flags, self.sbr, eside, status, reset_pitch, frames, lines)
-        rc = self.lib.xaac_parse_batch_start(ctypes.byref(b))
+        rc = self.lib.xaac_parse_batch_start_sized(ctypes.byref(b), ctypes.sizeof(b))
         if rc:
             raise RuntimeError("xaac_parse_batch_start: %d" % rc)
         self._in_flight = True

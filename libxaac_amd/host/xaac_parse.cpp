@@ -2,7 +2,9 @@
  * xaac_parse.cpp -- C ABI of the host-side bitstream front end (include/xaac_parse.h): ADTS framing around the AAC-LC
  * syntax decoder of aac_core.cpp.
  */
+#define XAAC_PARSE_NO_SIZED_MACROS /* this file defines the symbols of both generations */
 #include "../../include/xaac_parse.h"
+#include <stddef.h>
 
 #include <atomic>
 #include <chrono>
@@ -447,7 +449,18 @@ void batch_launch(const xaac_parse_batch *b, bool caller_works) {
 }
 }  // namespace
 
-int32_t xaac_parse_batch_run(const xaac_parse_batch *b) {
+/* the caller's descriptor at the library's size: what the caller's struct does not hold reads as zero */
+static bool batch_sized(const xaac_parse_batch *b, uint64_t struct_size, xaac_parse_batch *out) {
+  if (!b || struct_size < offsetof(xaac_parse_batch, pos)) return false; /* (the original layout ends in front of pos) */
+  memset(out, 0, sizeof(*out));
+  memcpy(out, b, struct_size < sizeof(*out) ? (size_t)struct_size : sizeof(*out));
+  return true;
+}
+
+int32_t xaac_parse_batch_run_sized(const xaac_parse_batch *b_in, uint64_t struct_size) {
+  xaac_parse_batch full;
+  if (!batch_sized(b_in, struct_size, &full)) return XAAC_PARSE_ERR_SYNTAX;
+  const xaac_parse_batch *b = &full;
   if (!batch_ok(b)) return XAAC_PARSE_ERR_SYNTAX;
   /* between this thread's _start and its _wait the team belongs to that batch: waiting for it here would wait for the caller's
      own _wait (another thread's batch in flight is simply waited for, as two _run calls wait for each other) */
@@ -460,7 +473,10 @@ int32_t xaac_parse_batch_run(const xaac_parse_batch *b) {
   return ok;
 }
 
-int32_t xaac_parse_batch_start(const xaac_parse_batch *b) {
+int32_t xaac_parse_batch_start_sized(const xaac_parse_batch *b_in, uint64_t struct_size) {
+  xaac_parse_batch full;
+  if (!batch_sized(b_in, struct_size, &full)) return XAAC_PARSE_ERR_SYNTAX;
+  const xaac_parse_batch *b = &full;
   if (!batch_ok(b)) return XAAC_PARSE_ERR_SYNTAX;
   /* a second _start (or a _run) of the thread whose _start is unanswered is an error it gets back, not a wait for a release that
      only its own _wait would bring; behind another thread's batch the call waits like any other */
@@ -469,6 +485,10 @@ int32_t xaac_parse_batch_start(const xaac_parse_batch *b) {
   batch_launch(b, false);
   return XAAC_PARSE_OK;
 }
+
+/* the symbols of the original layout (include/xaac_parse.h): the descriptor up to and including reset_pitch */
+int32_t xaac_parse_batch_run(const xaac_parse_batch *b) { return xaac_parse_batch_run_sized(b, offsetof(xaac_parse_batch, pos)); }
+int32_t xaac_parse_batch_start(const xaac_parse_batch *b) { return xaac_parse_batch_start_sized(b, offsetof(xaac_parse_batch, pos)); }
 
 int32_t xaac_parse_batch_wait(double *busy_seconds) {
   if (!g_job.in_flight.exchange(false, std::memory_order_acq_rel)) return XAAC_PARSE_ERR_SYNTAX; /* nothing was started */

@@ -298,3 +298,45 @@ def test_a_second_start_or_a_run_behind_an_unanswered_start_is_an_error_not_a_de
         assert bp.lib.xaac_parse_batch_wait(None) != 0
     finally:
         bp.close()
+
+
+def test_batch_descriptor_of_the_original_layout_is_read_up_to_its_own_end():
+    """xaac_parse_batch grew at its end (pos, frames, lines).  A caller built against the original layout calls the symbols
+    xaac_parse_batch_run / _start: they must not look behind reset_pitch (garbage there, where such a caller's struct ends).
+    _run_sized with the original size behaves the same; with the full size it reads the new members; a size that ends inside
+    the original layout is refused."""
+    import ctypes
+    from libxaac_amd import PS_FRAME_BYTES, SBR_FRAME_BYTES, SBR_HEADER_BYTES
+    data = stream("mix_aot29_32k")
+
+    def run(how):
+        bp = decoder.BatchParser([data] * 3, threads=2)
+        n = bp.n
+        spec, ics = np.zeros((n, 1024), np.int32), np.zeros((n, 2), np.uint8)
+        hdr, frm, psf = np.zeros((n, SBR_HEADER_BYTES), np.uint8), np.zeros((n, SBR_FRAME_BYTES), np.uint8), np.zeros((n, PS_FRAME_BYTES), np.uint8)
+        flags = np.zeros((n, 8), np.int32)
+        try:
+            b = bp._descriptor(spec, ics, hdr, frm, psf, flags, bp.sbr)
+            old_size = type(b).pos.offset
+            if how != "full":          # what lies behind an original-layout struct: not the library's business
+                b.pos = 0x10
+                b.frames = 0x7fffffff
+                b.lines = 0x18
+            if how == "symbol":
+                rc = bp.lib.xaac_parse_batch_run(ctypes.byref(b))
+            elif how == "sized_old":
+                rc = bp.lib.xaac_parse_batch_run_sized(ctypes.byref(b), old_size)
+            elif how == "short":
+                return bp.lib.xaac_parse_batch_run_sized(ctypes.byref(b), old_size - 8), None
+            else:
+                rc = bp.lib.xaac_parse_batch_run_sized(ctypes.byref(b), ctypes.sizeof(b))
+            return rc, np.concatenate([spec.reshape(-1).view(np.uint8), ics.reshape(-1), hdr.reshape(-1), frm.reshape(-1)])
+        finally:
+            bp.close()
+
+    full = run("full")
+    assert full[0] == 3 and np.any(full[1])      # (window bytes, SBR header and frame of the streams' first frames)
+    for how in ("symbol", "sized_old"):
+        rc, spec = run(how)
+        assert rc == 3 and np.array_equal(spec, full[1]), how
+    assert run("short")[0] < 0
