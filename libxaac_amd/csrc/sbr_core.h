@@ -853,7 +853,8 @@ FX_HD int32_t xs_energy_of_subband(const Q &x, int s0, int s1, int k, int frame_
 template <class Q>
 FX_HD void xs_energy_per_subband(const XsCx &cx, const Q &x, int s0, int s1, int b0, int b1, int frame_exp,
                                  XsLv &est) {
-  const int16_t inv_width = XS_TAB_INVINT(s1 - s0);
+  const int16_t inv_width = XS_TAB_INVINT(s1 > s0 ? s1 - s0 : 0); /* (an envelope with its borders out of order has no slots: the
+                                                                     reference reads in front of its table there) */
   XS_LANES(c, 0, b1 - b0) est.own(c) = xs_energy_of_subband(x, s0, s1, b0 + c, frame_exp << 1, inv_width);
 }
 
@@ -862,7 +863,8 @@ FX_HD void xs_energy_per_subband(const XsCx &cx, const Q &x, int s0, int s1, int
 template <class Q>
 FX_HD void xs_energy_per_sfb(const XsCx &cx, const Q &x, int nsf, const int16_t *tbl, int s0, int s1, int max_sb,
                              int frame_exp, XsWork *w, XsLv &est) {
-  const int16_t inv_width = XS_TAB_INVINT(s1 - s0);
+  const int16_t inv_width = XS_TAB_INVINT(s1 > s0 ? s1 - s0 : 0); /* (an envelope with its borders out of order has no slots: the
+                                                                     reference reads in front of its table there) */
   frame_exp <<= 1;
   int j0 = 0;
   while (j0 < nsf && cx.uni(tbl[j0]) < max_sb) j0++;
@@ -1522,7 +1524,7 @@ FX_HD void xs_energy_per_subband_pk(const XsCx &cx, const Q &x, const XsPass &ps
     int32_t e = 0;
     if (q < ps.n && c < nb) {
       const int first = xs_qsel(q, s0), n = q ? n1 : n0, k = b0 + c;
-      const int16_t inv_width = XS_TAB_INVINT(n);
+      const int16_t inv_width = XS_TAB_INVINT(n > 0 ? n : 0);
       if (nmax <= 8) /* (uniform) */
         e = xs_energy_element_pk<8>(x, first, n, k, inv_width, frame_exp2);
       else if (nmax <= 16)
@@ -3295,7 +3297,9 @@ FX_HD void xs_rescale_x_overlap(const XsCx &cx, const xaac_sbr_header *h, const 
     cx.sync();
     return;
   }
-  xs_clear(cx, x, old_lsb, new_lsb, start_slot, 6);
+  /* (a previous frame that ended before slot 16 -- no parser's grid does -- gives a negative start: the reference then clears
+     rows in front of its buffer; the rows that exist are cleared) */
+  xs_clear(cx, x, old_lsb, new_lsb, start_slot < 0 ? 0 : start_slot, 6);
   int source, target, t_lsb, t_usb;
   if (new_lsb > old_lsb) {
     source = ov_hb;

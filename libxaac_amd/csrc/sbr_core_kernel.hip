@@ -370,7 +370,13 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
     for (int j = 0; j < 6; j++) {
       const int row = HQ ? j >> 1 : j, part = HQ ? j & 1 : 0;
       const bool held = NB == 64 || lane < NB;
-      const int32_t v = s.x[(2 + 32 + row) * ROW + part * NB + (held ? lane : 0)];
+      int32_t v = s.x[(2 + 32 + row) * ROW + part * NB + (held ? lane : 0)];
+      /* (a first border behind slot 32 -- no parser's grid has one -- leaves the pending overlap-side shift to these rows too:
+         env_calc.c:975 adjusts slots 0 .. first border) */
+      if (32 + row < pend.first_start && lane >= pend.b0 && lane < pend.b1) {
+        const int sh = pend.sh_ov > 31 ? 31 : (pend.sh_ov < -31 ? -31 : pend.sh_ov);
+        v = sh > 0 ? (int32_t)((uint32_t)v << sh) : (v >> -sh);
+      }
       gw[offsetof(xaac_sbr_state, overlap) / 4 + 64 * j + lane] = held ? v : 0;
     }
     const int32_t *m = reinterpret_cast<const int32_t *>(&s.st);

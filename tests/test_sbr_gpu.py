@@ -163,3 +163,54 @@ def test_side_info_outside_the_structs_capacity_is_refused(ctx):
             assert status[i] == r["ret"]
             assert np.array_equal(out[2048 * i:2048 * (i + 1)], r["pcm_out"][0]), i
             assert not cap.diff_state(cap.State.from_buffer_copy(st[i].tobytes()), r["st1"]), i
+
+
+def test_fuzzed_envelope_grids_and_moving_band_limit_vs_oracle(ctx, oracle):
+    """what decides between the core's two-envelope passes and its one-envelope chain, fuzzed per frame and carried over ten
+    frames on the device: envelope borders (parser-like grids, variable frames, anything in 0..19: unsorted, empty, behind
+    slot 32), frequency resolutions that differ inside a pair, noise-floor rows that switch between two envelopes,
+    transient envelopes, interpol_freq, and a band limit that moves off sub_band_start (skip != 0: the one-envelope chain).
+    Every frame must equal the oracle (whose own paired / one-envelope arrangements are held against each other and against
+    the reference in tests/test_env_pairs_cpu.py)."""
+    from test_env_pairs_cpu import _fuzz_frame
+    recs = cap.read_records(os.path.join(ROOT, "tests", "golden", "sbr_lp_records.bin.gz"))
+    n = len(recs)
+    rng = np.random.default_rng(77)
+    states = [cap.State.from_buffer_copy(bytes(r["st0"])) for r in recs]
+    hdrs = [cap.Header.from_buffer_copy(bytes(r["header"])) for r in recs]
+    for i, h in enumerate(hdrs):
+        h.interpol_freq = 1 if i % 3 else h.interpol_freq
+    refused = taken = 0
+    for step in range(10):
+        frames = []
+        for i, r in enumerate(recs):
+            f = cap.Frame.from_buffer_copy(bytes(r["frame"]))
+            _fuzz_frame(rng, hdrs[i], f, (i + step) % 3)
+            if step % 4 == 3:
+                f.max_qmf_subband_aac = int(np.clip(f.max_qmf_subband_aac + rng.integers(-6, 7), hdrs[i].sub_band_start, 32))
+            frames.append(f)
+        if step == 6:
+            for h in hdrs:
+                h.smoothing_mode = 1 - h.smoothing_mode
+        amp = [30000, 3000, 200, 12, 0][step % 5]
+        pcm = rng.integers(-amp, amp + 1, (n, 1024)).astype(np.int16)
+        out, st_bytes, status = gpu_run(ctx, hdrs, frames, states, pcm.reshape(-1))
+        new_states = []
+        for i in range(n):
+            st = cap.State.from_buffer_copy(bytes(states[i]))
+            want = np.zeros(2048, np.int16)
+            pin = np.ascontiguousarray(pcm[i])
+            rc = oracle.lib.xo_sbr_dec_lp(ctypes.byref(hdrs[i]), ctypes.byref(frames[i]), ctypes.byref(st),
+                                          pin.ctypes.data_as(P16), 1, want.ctypes.data_as(P16), 1)
+            assert status[i] == rc, (step, i, int(status[i]), rc)
+            if rc == 0:
+                assert np.array_equal(out[2048 * i:2048 * (i + 1)], want), ("pcm", step, i)
+                got = cap.State.from_buffer_copy(st_bytes[i].tobytes())
+                assert not cap.diff_state(got, st), (step, i, cap.diff_state(got, st)[:3])
+                new_states.append(st)
+                taken += 1
+            else:                      # a refused frame leaves the oracle's state half-written; the chain goes on from the GPU's
+                new_states.append(cap.State.from_buffer_copy(st_bytes[i].tobytes()))
+                refused += 1
+        states = new_states
+    assert taken > 400 and refused < taken
