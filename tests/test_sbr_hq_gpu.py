@@ -239,3 +239,56 @@ def test_streams_outside_the_narrow_rows_take_the_list_kernel(ctx, oracle):
             gp = cap.PsState.from_buffer_copy(ps_bytes[i].tobytes())
             assert not cap.diff_state(gs, states[i]), (step, i, cap.diff_state(gs, states[i])[:3])
             assert not cap.diff_state(gp, pstates[i]), (step, i, cap.diff_state(gp, pstates[i])[:3])
+
+
+def test_fuzzed_envelope_grids_and_moving_band_limit_vs_oracle(ctx, oracle):
+    """the HQ + PS chain on what decides between the core's two-envelope passes and its one-envelope chain and on what moves
+    its rows about: envelope borders of every kind (parser-like grids, variable frames, anything in 0..19: unsorted, empty,
+    behind slot 32, grids that end before slot 16), frequency resolutions that differ inside a pair, noise-floor rows that
+    switch between two envelopes, transient envelopes, and a band limit that moves (xs_rescale_x_overlap's branches, rows
+    wider than the narrow instantiation holds).  Ten frames with the state on the device, every frame against the oracle."""
+    from test_env_pairs_cpu import _fuzz_frame
+    recs = cap.read_records(GOLDEN)
+    n = len(recs)
+    rng = np.random.default_rng(88)
+    states = [cap.State.from_buffer_copy(bytes(r["st0"])) for r in recs]
+    pstates = [cap.PsState.from_buffer_copy(bytes(r["ps0"])) for r in recs]
+    hdrs = [cap.Header.from_buffer_copy(bytes(r["header"])) for r in recs]
+    pframes = [cap.PsFrame.from_buffer_copy(bytes(r["ps_frame"])) for r in recs]
+    taken = refused = 0
+    for step in range(10):
+        frames = []
+        for i, r in enumerate(recs):
+            f = cap.Frame.from_buffer_copy(bytes(r["frame"]))
+            _fuzz_frame(rng, hdrs[i], f, (i + step) % 3)
+            if step % 4 == 3:
+                f.max_qmf_subband_aac = int(np.clip(f.max_qmf_subband_aac + rng.integers(-6, 7), hdrs[i].sub_band_start, 32))
+            frames.append(f)
+        if step == 6:
+            for h in hdrs:
+                h.smoothing_mode = 1 - h.smoothing_mode
+        amp = [30000, 3000, 200, 12, 0][step % 5]
+        pcm = rng.integers(-amp, amp + 1, (n, 1024)).astype(np.int16)
+        out, st_bytes, ps_bytes, status = gpu_run(ctx, hdrs, frames, states, pframes, pstates, pcm.reshape(-1))
+        new_states, new_ps = [], []
+        for i in range(n):
+            so = cap.State.from_buffer_copy(bytes(states[i]))
+            po = cap.PsState.from_buffer_copy(bytes(pstates[i]))
+            ref_out = np.zeros(4096, np.int16)
+            rc = oracle.lib.xo_sbr_dec_hq(ctypes.byref(hdrs[i]), ctypes.byref(frames[i]), ctypes.byref(so),
+                                          ctypes.byref(pframes[i]), ctypes.byref(po), pcm[i].ctypes.data_as(P16), 1,
+                                          ref_out.ctypes.data_as(P16), 2)
+            assert status[i] == rc, (step, i, int(status[i]), rc)
+            gs = cap.State.from_buffer_copy(st_bytes[i].tobytes())
+            gp = cap.PsState.from_buffer_copy(ps_bytes[i].tobytes())
+            if rc == 0:
+                assert np.array_equal(out[4096 * i:4096 * (i + 1)], ref_out), ("pcm", step, i)
+                assert not cap.diff_state(gs, so), (step, i, cap.diff_state(gs, so)[:3])
+                assert not cap.diff_state(gp, po), (step, i, cap.diff_state(gp, po)[:3])
+                new_states.append(so); new_ps.append(po)
+                taken += 1
+            else:          # a refused frame leaves the oracle's states half-written: the chain goes on from the GPU's
+                new_states.append(gs); new_ps.append(gp)
+                refused += 1
+        states, pstates = new_states, new_ps
+    assert taken > 250 and refused < taken
