@@ -33,6 +33,13 @@ static const int16_t *rand_hi_table() {
   return tab.v;
 }
 
+/* the QMF matrices: static per thread (the callers are test loops), or -- XO_MATRIX_ON_STACK, tests/test_sbr_core_sanitized.py --
+   on the stack, where AddressSanitizer sees a write in front of or behind them */
+#ifdef XO_MATRIX_ON_STACK
+#define XO_MATRIX
+#else
+#define XO_MATRIX static thread_local
+#endif
 /* down-sampled synthesis bank (32 channels) for the call in flight: set by the *_ds entry points */
 static thread_local int g_ds = 0;
 /* 1: run the parametric-stereo tool through the product's frame-at-once arrangement (sbr_ps_frame.h, lane count 1)
@@ -41,7 +48,7 @@ static thread_local int g_ps_phased = 0;
 
 extern "C" int xo_sbr_dec_lp(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st,
                              const int16_t *pcm_in, int in_stride, int16_t *pcm_out, int out_stride) {
-  static thread_local int32_t buf[40 * 64];
+  XO_MATRIX int32_t buf[40 * 64];
   XsQmf x = {buf};
   const XsCx cx = {0, 1}; /* sequential execution of the shared core */
   XsWork w;
@@ -100,7 +107,7 @@ static inline int32_t adj_word(int32_t v, int shift) { /* env_calc.c:1099 on one
 extern "C" int xo_sbr_dec_hq(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st,
                              const xaac_ps_frame *pf, xaac_ps_state *ps, const int16_t *pcm_in, int in_stride,
                              int16_t *pcm_out, int out_stride) {
-  static thread_local int32_t buf[41 * 128];
+  XO_MATRIX int32_t buf[41 * 128];
   XsQmfHq x = {buf};
   const XsCx cx = {0, 1};
   XsWork w;
@@ -134,7 +141,7 @@ extern "C" int xo_sbr_dec_hq(const xaac_sbr_header *h, const xaac_sbr_frame *f, 
     pf_clean = *pf;
     ps_clamped = xp_frame_sanitize(cx, &pf_clean);
     static thread_local XpFrameWork wk;
-    static thread_local int32_t xr[32 * 128];
+    XO_MATRIX int32_t xr[32 * 128];
     const int st_syn = st->st_syn_scale;
     const int ps_scale = xp_ps_frame(cx, &xaac_ps_tables, ps, &pf_clean, &wk, &x(0, 0), xr, st->lb_scale, st->ov_lb_scale,
                                      st->hb_scale, st_syn, st->syn_lsb, st->syn_usb);
