@@ -11,6 +11,14 @@
 
 #include "../libxaac_amd/csrc/esbr_ps.h"
 
+/* the work structs and matrices: static per thread, or -- XO_MATRIX_ON_STACK, tests/test_sbr_core_sanitized.py -- on the stack,
+   where AddressSanitizer sees an access outside them */
+#ifdef XO_MATRIX_ON_STACK
+#define XO_MATRIX
+#else
+#define XO_MATRIX static thread_local
+#endif
+
 extern "C" {
 void xo_esbr_analysis(const float *core, int32_t *ring, int32_t *pos, int32_t *win_off, float *re, float *im);
 void xo_esbr_synthesis(const float *re, const float *im, int32_t *ring, int32_t *drc_off, int32_t *filt_off, float *out);
@@ -21,7 +29,7 @@ void xo_esbr_synthesis(const float *re, const float *im, int32_t *ring, int32_t 
 int xo_esbr_hf_env_h(const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd, xaac_esbr_state *st,
                      float *qmf_re, float *qmf_im, float *out_re, float *out_im, float *ph_re, float *ph_im,
                      const int32_t *x_over_qmf) {
-  static thread_local XeWork w;
+  XO_MATRIX XeWork w;
   const XsCx cx = {0, 1};
   const XeMat src = {qmf_re + 128, qmf_im + 128}, dst = {out_re + 128, out_im + 128};
   const XeMat ph = {ph_re ? ph_re + 128 : nullptr, ph_im ? ph_im + 128 : nullptr};
@@ -36,7 +44,7 @@ int xo_esbr_hf_env(const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac
 
 /* the float parametric-stereo tool alone: l_* [38][64], r_* [32][64] */
 int xo_esbr_apply_ps(const xaac_ps_frame *pf, xaac_esbr_ps_state *st, float *l_re, float *l_im, float *r_re, float *r_im, int usb) {
-  static thread_local XfWork w;
+  XO_MATRIX XfWork w;
   const XsCx cx = {0, 1};
   const XeMat L = {l_re, l_im}, R = {r_re, r_im};
   xf_apply_ps(cx, pf, st, &w, L, R, usb);
@@ -67,9 +75,9 @@ int xo_esbr_sbr_frame_ps(const float *core, const xaac_sbr_header *h, const xaac
 int xo_esbr_sbr_frame_hbe(const float *core, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
                           xaac_esbr_state *st, const xaac_ps_frame *pf, xaac_esbr_ps_state *pst, float *out, float *out_r,
                           xaac_hbe_state *hst) {
-  static thread_local float phr[40][64], phi[40][64];
-  static thread_local float qre[XAAC_ESBR_ROWS][64], qim[XAAC_ESBR_ROWS][64], ore[42][64], oim[42][64];
-  static thread_local float rre[38][64], rim[38][64], xre[32][64], xim[32][64];
+  XO_MATRIX float phr[40][64], phi[40][64];
+  XO_MATRIX float qre[XAAC_ESBR_ROWS][64], qim[XAAC_ESBR_ROWS][64], ore[42][64], oim[42][64];
+  XO_MATRIX float rre[38][64], rim[38][64], xre[32][64], xim[32][64];
   int rc = 0;
   if (sd->qmf_sb_prev >= 0 && sd->qmf_sb_prev <= 64) {
     const XsCx cx = {0, 1};

@@ -4,7 +4,6 @@ over frames with envelope grids of every kind -- unsorted and empty envelopes, g
 slot 32 -- and a band limit that moves.  Side info no parser produces, but the boundary does not trust its caller: a row
 index in front of the matrix is the neighbouring wave's LDS on the GPU (round 5 found xs_rescale_x_overlap clearing such
 rows).  CPU only."""
-import glob
 import os
 import subprocess
 import sys
@@ -47,17 +46,73 @@ print("calls", calls)
 '''
 
 
-def test_fuzzed_grids_and_moving_band_limit_touch_nothing_outside_the_matrices(tmp_path):
-    lib = str(tmp_path / "oracle_sbr_asan.so")
-    srcs = [os.path.join(ROOT, "oracle", "oracle_sbr.cpp")] + sorted(glob.glob(os.path.join(ROOT, "oracle", "oracle_qmf*.cpp")))
-    csrc = os.path.join(ROOT, "oracle", "oracle_imdct.c")
-    obj = str(tmp_path / "oracle_c.o")
-    subprocess.check_call(["gcc", "-O1", "-std=c99", "-fPIC", "-c", csrc, "-o", obj])
+@pytest.fixture(scope="module")
+def asan_oracle(tmp_path_factory):
+    """the oracle's SBR / eSBR / transposer / PVC sources with their matrices on the stack, under AddressSanitizer"""
+    d = tmp_path_factory.mktemp("asan")
+    lib, obj = str(d / "oracle_sbr_asan.so"), str(d / "oracle_c.o")
+    srcs = [os.path.join(ROOT, "oracle", "oracle_%s.cpp" % n) for n in ("sbr", "qmf", "esbr", "hbe", "pvc")]
+    subprocess.check_call(["gcc", "-O1", "-std=c99", "-fPIC", "-c", os.path.join(ROOT, "oracle", "oracle_imdct.c"), "-o", obj])
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-w", "-DXO_MATRIX_ON_STACK",
                            "-fsanitize=address", "-fno-omit-frame-pointer", *srcs, obj, "-o", lib])
     asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
-    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0")
-    code = CHILD % {"tests": os.path.join(ROOT, "tests"), "lib": lib, "golden": os.path.join(ROOT, "tests", "golden")}
+    return lib, dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0")
+
+
+def run_child(asan_oracle, template):
+    lib, env = asan_oracle
+    code = template % {"tests": os.path.join(ROOT, "tests"), "tools": os.path.join(ROOT, "tools"), "lib": lib,
+                       "golden": os.path.join(ROOT, "tests", "golden")}
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0 and "AddressSanitizer" not in p.stderr, (p.stdout[-300:], p.stderr[-3000:])
-    assert "calls 1440" in p.stdout
+    return p.stdout
+
+
+def test_fuzzed_grids_and_moving_band_limit_touch_nothing_outside_the_matrices(asan_oracle):
+    assert "calls 1440" in run_child(asan_oracle, CHILD)
+
+
+CHILD_ESBR = r'''
+import ctypes, sys
+import numpy as np
+sys.path.insert(0, %(tests)r); sys.path.insert(0, %(tools)r)
+import sbr_capture as cap
+from test_env_pairs_cpu import _fuzz_frame
+from make_golden_esbr_chains import chain_core
+PF = ctypes.POINTER(ctypes.c_float)
+CH = np.load(%(golden)r + "/esbr_chains.npz")
+lib = ctypes.CDLL(%(lib)r)
+fn = lib.xo_esbr_sbr_frame_hbe
+fn.restype = ctypes.c_int
+fn.argtypes = [PF] + [ctypes.c_void_p] * 6 + [PF, PF, ctypes.c_void_p]
+vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+sc = CH["step_chain"]
+rng = np.random.default_rng(3)
+calls = refused = 0
+for c in range(len(CH["chain_len"])):
+    rows = np.nonzero(sc == c)[0]
+    run, cid, eps = int(CH["chain_run"][c]), int(CH["chain_id"][c]), bool(CH["chain_ps"][c])
+    st, hb, ps = CH["est0"][c].copy(), CH["hbs0"][c].copy(), CH["eps0"][c].copy()
+    for s, r in enumerate(rows[:6]):
+        core = np.ascontiguousarray(chain_core(run, cid, s))
+        out, out_r = np.zeros(2048, np.float32), np.zeros(2048, np.float32)
+        h, f, sd, pf = (np.ascontiguousarray(CH[k][r]).copy() for k in ("header", "frame", "side", "ps_frame"))
+        hh, ff = cap.Header.from_buffer(h), cap.Frame.from_buffer(f)
+        if s %% 2 == 1:
+            _fuzz_frame(rng, hh, ff, (c + s) %% 3)
+        if s %% 4 == 3:
+            ff.max_qmf_subband_aac = int(np.clip(ff.max_qmf_subband_aac + rng.integers(-6, 7), hh.sub_band_start, 32))
+        rc = fn(core.ctypes.data_as(PF), vp(h), vp(f), vp(sd), vp(st), vp(pf) if eps else None, vp(ps) if eps else None,
+                out.ctypes.data_as(PF), out_r.ctypes.data_as(PF) if eps else None, vp(hb))
+        calls += 1
+        refused += rc != 0
+print("calls", calls, "refused", refused)
+'''
+
+
+def test_path_a_chain_on_fuzzed_grids_touches_nothing_outside_its_matrices(asan_oracle):
+    """the float chain (eSBR HF generator, envelope adjuster, float PS, transposer in the chain: esbr_core.h, esbr_ps.h,
+    hbe_*.h) on the reference-made chains' frames with every second frame's grid fuzzed and the band limit moving"""
+    out = run_child(asan_oracle, CHILD_ESBR)
+    n, r = (int(t) for t in out.split()[1::2])
+    assert n > 250 and r < n // 2
