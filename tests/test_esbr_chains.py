@@ -139,3 +139,76 @@ def test_gpu_walks_the_reference_chains():
                 if with_ps:
                     assert crc(psn[j]) == want[4], ("ps state", chains[act[j]], s)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_on_fuzzed_grids_and_a_moving_band_limit_equals_the_oracle(oracle):
+    """the first six frames of every chain with every second frame's envelope grid fuzzed (parser-like, variable, anything in
+    0..19: unsorted, empty, behind slot 32, ending before slot 16) and the band limit moving -- side info no parser makes,
+    which the boundary has to contain: the GPU chain (three states on the device) against the oracle frame by frame: return
+    codes, output words, the states' checksums.  (tests/test_sbr_core_sanitized.py runs the same frames under ASan.)"""
+    import torch
+    import libxaac_amd
+    import sbr_capture as cap
+    from test_env_pairs_cpu import _fuzz_frame
+    fn = oracle.lib.xo_esbr_sbr_frame_hbe
+    fn.restype = ctypes.c_int
+    fn.argtypes = [PF] + [ctypes.c_void_p] * 6 + [PF, PF, ctypes.c_void_p]
+    ctx = libxaac_amd.XaacContext(0, 0)
+    dev = torch.device("cuda:0")
+    order = steps_of_chains()
+    rng = np.random.default_rng(3)
+    taken = refused = 0
+    for with_ps in (False, True):
+        chains = [c for c in range(len(order)) if bool(CH["chain_ps"][c]) == with_ps and len(order[c]) >= 6]
+        n = len(chains)
+        st = [CH["est0"][c].copy() for c in chains]
+        hb = [CH["hbs0"][c].copy() for c in chains]
+        ps = [CH["eps0"][c].copy() for c in chains]
+        for s in range(6):
+            hdr, frm, side, psf, cores = [], [], [], [], []
+            for i, c in enumerate(chains):
+                r = order[c][s]
+                h, f = np.ascontiguousarray(CH["header"][r]).copy(), np.ascontiguousarray(CH["frame"][r]).copy()
+                hh, ff = cap.Header.from_buffer(h), cap.Frame.from_buffer(f)
+                if s % 2 == 1:
+                    _fuzz_frame(rng, hh, ff, (c + s) % 3)
+                if s % 4 == 3:
+                    ff.max_qmf_subband_aac = int(np.clip(ff.max_qmf_subband_aac + rng.integers(-6, 7), hh.sub_band_start, 32))
+                hdr.append(h); frm.append(f)
+                side.append(np.ascontiguousarray(CH["side"][r])); psf.append(np.ascontiguousarray(CH["ps_frame"][r]))
+                cores.append(np.ascontiguousarray(chain_core(int(CH["chain_run"][c]), int(CH["chain_id"][c]), s)))
+            up = lambda rows: torch.from_numpy(np.stack(rows)).to(dev)
+            t_st, t_hb, t_ps = up(st), up(hb), (up(ps) if with_ps else None)
+            out = torch.zeros((n, 2048), dtype=torch.float32, device=dev)
+            out_r = torch.zeros((n, 2048), dtype=torch.float32, device=dev) if with_ps else None
+            status = torch.full((n,), 7, dtype=torch.int32, device=dev)
+            ws = torch.zeros(ctx.esbr_workspace_bytes(n), dtype=torch.uint8, device=dev)
+            ctx.esbr_sbr_process_batch(up(cores), up(hdr), up(frm), up(side), t_st, out, ws, status,
+                                       ps_frame=up(psf) if with_ps else None, ps_state=t_ps, out_r=out_r, hbe_state=t_hb)
+            ctx.sync()
+            g_rc, g_out = status.cpu().numpy(), out.cpu().numpy()
+            g_outr = out_r.cpu().numpy() if with_ps else None
+            g_st, g_hb, g_ps = t_st.cpu().numpy(), t_hb.cpu().numpy(), (t_ps.cpu().numpy() if with_ps else None)
+            for i, c in enumerate(chains):
+                o, orr = np.zeros(2048, np.float32), np.zeros(2048, np.float32)
+                rc = fn(cores[i].ctypes.data_as(PF), vp(hdr[i]), vp(frm[i]), vp(side[i]), vp(st[i]), vp(psf[i]) if with_ps else None,
+                        vp(ps[i]) if with_ps else None, o.ctypes.data_as(PF), orr.ctypes.data_as(PF) if with_ps else None, vp(hb[i]))
+                assert g_rc[i] == rc, ("rc", c, s, int(g_rc[i]), rc)
+                if rc != 0:        # a refused frame: the chain goes on from the device's states
+                    st[i], hb[i] = g_st[i].copy(), g_hb[i].copy()
+                    if with_ps:
+                        ps[i] = g_ps[i].copy()
+                    refused += 1
+                    continue
+                taken += 1
+                apply = cap.Frame.from_buffer_copy(frm[i].tobytes()).apply_processing
+                assert np.array_equal(g_out[i].view(np.uint32), o.view(np.uint32)), ("out", c, s)
+                if with_ps and apply:
+                    assert np.array_equal(g_outr[i].view(np.uint32), orr.view(np.uint32)), ("out_r", c, s)
+                assert state_crc(g_st[i], hdr[i], frm[i], apply) == state_crc(st[i], hdr[i], frm[i], apply), ("state", c, s)
+                assert crc(g_hb[i]) == crc(hb[i]), ("transposer state", c, s)
+                if with_ps:
+                    assert crc(g_ps[i]) == crc(ps[i]), ("ps state", c, s)
+    ctx.close()
+    assert taken > 150 and refused < taken
