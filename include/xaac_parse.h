@@ -88,9 +88,13 @@ XAAC_API void xaac_parser_destroy(xaac_parser *p);
 /* The ADTS header at data[0 .. n): XAAC_PARSE_OK, _NEED_DATA (n < 7 / 9), _ERR_SYNC or _ERR_HEADER. */
 XAAC_API int32_t xaac_adts_parse_header(const uint8_t *data, size_t n, xaac_adts_header *h);
 
-/* Decodes the ADTS frame at data[0 .. n) (one raw_data_block) into `out`.  stage 2: spectra as the IMDCT takes them;
-   stage 1: as they are before the M/S, intensity, PNS and TNS tools (the entry of ixheaacd_channel_pair_process).
-   *consumed = the frame's length.  The parser keeps what outlives a frame (PNS random seed, SBR / PS decoding state). */
+/* Decodes the next raw_data_block -- one frame of 1024 samples per channel -- of the ADTS stream at data[0 .. n) into `out`.
+   stage 2: spectra as the IMDCT takes them; stage 1: as they are before the M/S, intensity, PNS and TNS tools (the entry
+   of ixheaacd_channel_pair_process).  *consumed = what the call used up: the ADTS frame's length, or -- in a frame with
+   number_of_raw_data_blocks_in_frame > 0 (headerdecode.c:353, api.c:2909-2925) -- header + first block for the first call and
+   one block (+ its CRC word in a protected frame) for each of the following ones, which must be handed the bytes right
+   behind what the call before consumed.  The parser keeps what outlives a call (the blocks left in the frame, PNS random
+   seed, SBR / PS decoding state). */
 XAAC_API int32_t xaac_parse_adts_frame(xaac_parser *p, const uint8_t *data, size_t n, int32_t stage, xaac_core_frame *out,
                               size_t *consumed);
 

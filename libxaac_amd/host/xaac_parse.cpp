@@ -33,6 +33,10 @@ struct xaac_parser {
   XhElement el;
   int sbr_ready, sampling_rate, esbr;
   XsDecoder sbr;
+  /* an ADTS frame with several raw data blocks (api.c:2909-2925, :3760-3767): the blocks of the frame still to come, the bytes
+     of the frame behind the last delivered block, and whether a 16-bit CRC follows every block (headerdecode.c:356-362) */
+  int blocks_left, block_crc;
+  size_t frame_left;
 };
 
 /* A small persistent team for xaac_parse_batch_run.  Workers wait for the next call on a generation counter: a short spin
@@ -245,11 +249,33 @@ static int32_t tools_of(const XhElement &el) {
 
 /* the frame at data[0 .. n) into p->el */
 static int32_t parse_frame(xaac_parser *p, const uint8_t *data, size_t n, int32_t stage, size_t *consumed) {
+  /* the frame's lines live in a buffer of the calling thread until the caller has copied them out (both entry points do,
+     before they return): nothing of a stream outlives the frame there */
+  static thread_local int32_t lines[2][XH_SPEC_WORDS];
+  if (p->blocks_left > 0) {
+    /* the next raw data block of the ADTS frame the call before started (data points behind what that call consumed): the
+       reference reads a header only when its block count has run out (api.c:2914) */
+    if (n < p->frame_left) return XAAC_PARSE_NEED_DATA;
+    XhBits br(data, p->frame_left);
+    p->el.ch[0].spec_mem = lines[0], p->el.ch[1].spec_mem = lines[1];
+    const int32_t r = xh_parse_raw_data_block(&p->core, &br, &p->el, stage);
+    if (r) {
+      p->blocks_left = 0; /* (the rest of the frame goes with it: the caller looks for the next header) */
+      if (consumed) *consumed = p->frame_left;
+      return r;
+    }
+    size_t used = br.pos / 8 + (p->block_crc ? 2 : 0);
+    p->blocks_left--;
+    if (p->blocks_left == 0 || used > p->frame_left) used = p->frame_left; /* the last block ends the frame */
+    p->frame_left -= used;
+    if (consumed) *consumed = used;
+    return XAAC_PARSE_OK;
+  }
   xaac_adts_header h;
   const int32_t e = xaac_adts_parse_header(data, n, &h);
   if (e) return e;
   if (n < (size_t)h.frame_bytes) return XAAC_PARSE_NEED_DATA;
-  if (h.raw_blocks != 0 || h.frame_bytes < h.header_bytes) return XAAC_PARSE_ERR_UNSUPPORTED;
+  if (h.frame_bytes < h.header_bytes) return XAAC_PARSE_ERR_UNSUPPORTED;
   if (consumed) *consumed = (size_t)h.frame_bytes;
   if (p->sr_index != h.sr_index) {
     const XhCoreState keep = p->core;
@@ -262,11 +288,18 @@ static int32_t parse_frame(xaac_parser *p, const uint8_t *data, size_t n, int32_
     p->sampling_rate = h.sampling_rate;
   }
   XhBits br(data + h.header_bytes, (size_t)(h.frame_bytes - h.header_bytes));
-  /* the frame's lines live in a buffer of the calling thread until the caller has copied them out (both entry points do,
-     before they return): nothing of a stream outlives the frame there */
-  static thread_local int32_t lines[2][XH_SPEC_WORDS];
   p->el.ch[0].spec_mem = lines[0], p->el.ch[1].spec_mem = lines[1];
-  return xh_parse_raw_data_block(&p->core, &br, &p->el, stage);
+  const int32_t r = xh_parse_raw_data_block(&p->core, &br, &p->el, stage);
+  if (r || h.raw_blocks == 0) return r;
+  /* number_of_raw_data_blocks_in_frame > 0 (headerdecode.c:353): this call delivers the first block and consumes the header
+     and that block (+ its CRC in a protected frame); the calls that follow deliver the others, one each */
+  size_t used = (size_t)h.header_bytes + br.pos / 8 + (h.protection_absent ? 0 : 2);
+  if (used > (size_t)h.frame_bytes) used = (size_t)h.frame_bytes;
+  p->blocks_left = h.raw_blocks;
+  p->block_crc = h.protection_absent ? 0 : 1;
+  p->frame_left = (size_t)h.frame_bytes - used;
+  if (consumed) *consumed = used;
+  return XAAC_PARSE_OK;
 }
 
 int32_t xaac_parse_adts_frame(xaac_parser *p, const uint8_t *data, size_t n, int32_t stage, xaac_core_frame *out,

@@ -133,3 +133,23 @@ def test_the_pipelined_loop_equals_the_plain_one(esbr):
         for a, b in zip(plain, piped):
             assert np.array_equal(a, b), name
         assert len(plain[1]) < len(plain[0]) and len(plain[3]) < len(plain[1])
+
+
+@pytest.mark.gpu
+def test_adts_frames_with_several_raw_data_blocks_decode_like_the_plain_stream():
+    """number_of_raw_data_blocks_in_frame > 0 end to end: the committed streams regrouped into ADTS frames of 1..4 blocks
+    (tests/test_parser.py: the parser delivers one block per call; the reference decoder writes the same file for both
+    layouts) next to their originals in one batch, both flag settings, PCM against the committed CRCs of the reference"""
+    from libxaac_amd import decoder
+    from test_parser import _remux_several_blocks_per_frame
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "decoder_ref.npz"))
+    for name in ("mix_aot2_64k", "mix_aot5_48k", "mix_aot29_32k"):
+        k = GOLD_ORDER.index(name)
+        data = open(os.path.join(STREAMS, name + ".aac"), "rb").read()
+        remux, prot = _remux_several_blocks_per_frame(data), _remux_several_blocks_per_frame(data, groups=(3, 4), protected=True)
+        for esbr, key in ((False, "crc"), (True, "crc_esbr")):
+            if esbr and name == "mix_aot2_64k":
+                continue                       # (AAC-LC has no second reading)
+            got, _ = decoder.decode_streams([remux, data, prot], esbr=esbr)
+            for g in got:
+                assert zlib.crc32(np.ascontiguousarray(g).tobytes()) & 0xffffffff == int(gold[key][k]), (name, esbr)

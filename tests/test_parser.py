@@ -340,3 +340,66 @@ def test_batch_descriptor_of_the_original_layout_is_read_up_to_its_own_end():
         rc, spec = run(how)
         assert rc == 3 and np.array_equal(spec, full[1]), how
     assert run("short")[0] < 0
+
+
+def _remux_several_blocks_per_frame(data, groups=(2, 1, 4, 3), protected=False):
+    """the stream's raw data blocks regrouped: ADTS frames with number_of_raw_data_blocks_in_frame = g - 1 for g cycling through
+    `groups` (headerdecode.c:353; every block of the committed streams is a whole frame's payload, byte aligned).  protected:
+    protection_absent = 0 with the block positions and the CRC words in place (their values are not what a checker would
+    compute: for parsers that skip them)."""
+    frames, pos = [], 0
+    for n in _frame_lengths(data):
+        frames.append(data[pos:pos + n])
+        pos += n
+    out, i, k = bytearray(), 0, 0
+    while i < len(frames):
+        g = min(groups[k % len(groups)], len(frames) - i)
+        k += 1
+        hdr = bytearray(frames[i][:7])
+        assert hdr[1] & 1, "the committed streams have no CRC"
+        payloads = [f[7:] for f in frames[i:i + g]]
+        extra = b""
+        if protected:
+            hdr[1] &= 0xfe
+            posw = b"".join((0).to_bytes(2, "big") for _ in range(g - 1))
+            extra = posw + b"\x12\x34"                                   # raw_data_block_position[] + crc_check
+            if g > 1:
+                payloads = [p + b"\xab\xcd" for p in payloads]           # a CRC behind every block
+        body = extra + b"".join(payloads)
+        length = 7 + len(body)
+        hdr[3] = (hdr[3] & 0xfc) | ((length >> 11) & 3)
+        hdr[4] = (length >> 3) & 0xff
+        hdr[5] = ((length & 7) << 5) | (hdr[5] & 0x1f)
+        hdr[6] = (hdr[6] & 0xfc) | (g - 1)
+        out += bytes(hdr) + body
+        i += g
+    return bytes(out)
+
+
+@pytest.mark.parametrize("name", ["mix_aot2_64k", "mix_aot5_48k", "mix_aot29_32k"])
+def test_adts_frames_with_several_raw_data_blocks(name, tmp_path):
+    """number_of_raw_data_blocks_in_frame > 0: every call delivers one block, as the reference's decode call does
+    (api.c:2909-2925, :3760-3767): the regrouped stream parses into the same frames as the original, with and without the
+    protected layout; and the real reference decoder writes the same file for both (unprotected layout)"""
+    data = stream(name)
+    want = decoder.parse_stream(data, stage=2)
+    for protected in (False, True):
+        got = decoder.parse_stream(_remux_several_blocks_per_frame(data, protected=protected), stage=2)
+        assert len(got) == len(want), (protected, len(got), len(want))
+        for f, ((s, ics, t, side), (s0, ics0, t0, side0)) in enumerate(zip(got, want)):
+            assert np.array_equal(s, s0) and np.array_equal(ics, ics0) and t == t0, (protected, f)
+            assert (side is None) == (side0 is None)
+            if side is not None:
+                assert bytes(side.header) == bytes(side0.header) and bytes(side.frame[0]) == bytes(side0.frame[0]), (protected, f)
+                assert bool(side.ps) == bool(side0.ps) and (not side.ps or bytes(side.ps_frame) == bytes(side0.ps_frame))
+    ref = os.path.join(ROOT, "oracle", "_ref", "xaacdec")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/xaacdec missing (built where /root/reference exists): the parser half has run")
+    a, b = str(tmp_path / "a.aac"), str(tmp_path / "b.aac")
+    open(a, "wb").write(data)
+    open(b, "wb").write(_remux_several_blocks_per_frame(data))
+    wavs = []
+    for src in (a, b):
+        subprocess.run([ref, "-ifile:" + src, "-ofile:" + src + ".wav"], check=True, capture_output=True)
+        wavs.append(open(src + ".wav", "rb").read())
+    assert len(wavs[0]) > 10000 and wavs[0] == wavs[1]
