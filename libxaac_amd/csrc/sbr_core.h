@@ -3341,15 +3341,25 @@ FX_HD void xs_rescale_x_overlap(const XsCx &cx, const xaac_sbr_header *h, const 
 template <class ST>
 FX_HD int xs_side_info_bad(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, const ST *st) {
   int bad = 0;
+  /* A frame without SBR processing (apply_processing 0: the decoder has no valid SBR header yet, or lost it) is up-sampled
+     by the two banks alone (xs_sbr_core_tail): header and frame side info are whatever the parser last held -- the
+     reference's own front end leaves a band range of 32..64 beside a band limit of 15 there -- and nothing below reads
+     them, so only the state members that still become band numbers are looked at. */
+  const int apply = cx.uni(f->apply_processing) != 0;
+  XS_ONE {
+    const auto in = [](int v, int lo, int hi) -> int { return v < lo || v > hi; };
+    bad |= in(st->prev_end_position, 0, 19) | in(st->prev_max_qmf_subband_aac, 0, 64) | in(st->codec_usb, 0, 64);
+    bad |= in(st->syn_lsb, 0, 64) | in(st->syn_usb, 0, 64);
+  }
+  if (!apply) return cx.wave_or(bad) != 0;
   XS_ONE {
     const auto in = [](int v, int lo, int hi) -> int { return v < lo || v > hi; };
     /* the frame grid this implementation (and the reference's MAX_ENV_COLS buffers, sbr_dec.c:733-748) is laid out
        for: 16 time slots of 2 QMF slots, 32 columns -- decided here, before xs_rescale_x_overlap turns
        time_step * (prev_end_position - num_time_slots) into a row index */
     bad |= (h->num_time_slots != 16) | (h->time_step != 2) | (h->num_columns != 32);
-    /* state members that become row / band indices (a state is the host's to initialise: sbrdec_initfuncs.c) */
-    bad |= in(st->prev_end_position, 0, 19) | in(st->prev_max_qmf_subband_aac, 0, 64) | in(st->codec_usb, 0, 64);
-    bad |= in(st->syn_lsb, 0, 64) | in(st->syn_usb, 0, 64);
+    /* (the state members that become row / band indices are looked at above: a state is the host's to initialise,
+       sbrdec_initfuncs.c) */
     bad |= in(h->num_sf_bands[0], 0, XAAC_SBR_MAX_FREQ_COEFFS / 2) | in(h->num_sf_bands[1], 0, XAAC_SBR_MAX_FREQ_COEFFS);
     bad |= in(h->num_nf_bands, 0, XAAC_SBR_MAX_NOISE_COEFFS) | in(h->num_lf_bands, 0, XAAC_SBR_MAX_LIMITERS);
     bad |= in(h->num_if_bands, 0, XAAC_SBR_MAX_NOISE_VALUES) | in(h->limiter_gains, 0, 3);

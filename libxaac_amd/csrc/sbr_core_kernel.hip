@@ -237,16 +237,19 @@ __device__ __forceinline__ bool core_one(const XaacSbrCoreParams &p, const int c
        bank limits xs_rescale_x_overlap walks between (all within 0..64 once xs_side_info_bad has passed) */
     int32_t top = 0;
     if (!refused) {
-      top = s.h.sub_band_end;
-      const int32_t lim[5] = {s.st.syn_usb, s.st.syn_lsb, s.st.codec_usb, s.st.prev_max_qmf_subband_aac, f->max_qmf_subband_aac};
-      for (int i = 0; i < 5; i++) top = lim[i] > top ? lim[i] : top;
-      if (lane <= s.h.num_sf_bands[1] && s.h.freq_band_tbl_hi[lane] > top) top = s.h.freq_band_tbl_hi[lane];
-      if (lane <= s.h.num_sf_bands[0] && s.h.freq_band_tbl_lo[lane] > top) top = s.h.freq_band_tbl_lo[lane];
-      if (lane < s.h.num_patches) {
-        const xaac_sbr_patch *pp = &s.h.patch[lane];
-        const int a = pp->src_end_band + pp->dst_end_band, b = pp->dst_start_band + pp->num_bands_in_patch;
-        top = a > top ? a : top;
-        top = b > top ? b : top;
+      const int32_t lim[4] = {s.st.syn_usb, s.st.syn_lsb, s.st.codec_usb, s.st.prev_max_qmf_subband_aac};
+      for (int i = 0; i < 4; i++) top = lim[i] > top ? lim[i] : top;
+      if (f->apply_processing) { /* (a frame without SBR processing reads none of the header's or the frame's band numbers) */
+        top = s.h.sub_band_end > top ? s.h.sub_band_end : top;
+        top = f->max_qmf_subband_aac > top ? f->max_qmf_subband_aac : top;
+        if (lane <= s.h.num_sf_bands[1] && s.h.freq_band_tbl_hi[lane] > top) top = s.h.freq_band_tbl_hi[lane];
+        if (lane <= s.h.num_sf_bands[0] && s.h.freq_band_tbl_lo[lane] > top) top = s.h.freq_band_tbl_lo[lane];
+        if (lane < s.h.num_patches) {
+          const xaac_sbr_patch *pp = &s.h.patch[lane];
+          const int a = pp->src_end_band + pp->dst_end_band, b = pp->dst_start_band + pp->num_bands_in_patch;
+          top = a > top ? a : top;
+          top = b > top ? b : top;
+        }
       }
     }
     if (cx.wave_max(top) > NB || cx.wave_or(above) != 0) return false;

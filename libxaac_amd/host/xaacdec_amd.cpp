@@ -279,7 +279,7 @@ int main(int argc, char **argv) {
   /* Path A (-esbr:1) */
   xaac_esbr_side *d_eside = nullptr;
   xaac_esbr_state *d_estate = nullptr;
-  xaac_hbe_state *d_hbe = nullptr;
+  xaac_hbe_state *d_hbe = nullptr, *d_hbe_tmp = nullptr; /* d_hbe_tmp: the resetting channels of a step gathered (partial resets) */
   xaac_esbr_ps_state *d_eps = nullptr;
   float *d_fcore = nullptr, *d_out_l = nullptr, *d_out_r = nullptr, *d_q = nullptr, *d_pv = nullptr;
   std::vector<uint8_t> hbe_tail; /* every channel's transposer integers, kept between resets: some survive one (max_stretch, fft_ready) */
@@ -556,13 +556,69 @@ int main(int argc, char **argv) {
       int resets = 0, with_ps = 0;
       for (int i = 0; i < N; i++)
         if (s.status[(size_t)i] == 0) resets += s.flags[(size_t)i * 8 + 1] != 0, with_ps += s.flags[(size_t)i * 8 + 5] != 0;
-      /* streams with and without PS in one step: the float PS launch copies left to right for those without (esbr_ps_kernel.hip);
-         a step in which only some streams reset the SBR decoder is not taken yet (the transposer's re-initialisation below runs
-         over the whole batch) */
-      if (resets != 0 && resets != s.delivered) die("a batch in which only some streams reset the SBR decoder (-esbr:1)");
+      /* streams with and without PS in one step: the float PS launch copies left to right for those without (esbr_ps_kernel.hip) */
       const size_t row = 64 * sizeof(float), st_pitch = sizeof(xaac_esbr_state), q_pitch = 2048 * sizeof(float);
       float *older_re = d_older, *older_im = d_older + (size_t)NC * 24 * 64;
-      if (resets) {
+      if (resets != 0 && resets != s.delivered) {
+        /* Only some of the step's streams reset the SBR decoder (their headers changed: independent streams do that at
+           different frames).  The same sequence as below for every stream at once, on those streams' channels gathered into
+           a compact batch: their transposer states into d_hbe_tmp (new parameters from the band tables, delay lines
+           cleared), their rows into the first slots of the scratch planes, the two transposer runs over that batch, states
+           and ph rows back to their places.  The other streams' states are not touched. */
+        static xaac_hbe_state h0;
+        constexpr size_t kTail = sizeof(xaac_hbe_state) - offsetof(xaac_hbe_state, synth_size);
+        if (hbe_tail.empty()) hbe_tail.assign((size_t)NC * kTail, 0);
+        std::vector<int> chs;
+        for (int i = 0; i < NC; i++)
+          if (s.status[(size_t)(i / n_ch)] == 0 && s.flags[(size_t)(i / n_ch) * 8 + 1] != 0) chs.push_back(i);
+        const int nr = (int)chs.size();
+        if (!d_hbe_tmp) d_hbe_tmp = dev<xaac_hbe_state>((size_t)NC);
+        if (!d_q) d_q = dev<float>((size_t)NC * 2 * 2048), d_pv = dev<float>((size_t)NC * 2 * 2048);
+        if (!d_idx) d_idx = dev<int32_t>((size_t)NC);
+        float *q_re = d_q, *q_im = d_q + (size_t)NC * 2048, *pv_re = d_pv, *pv_im = d_pv + (size_t)NC * 2048;
+        std::vector<int32_t> pitch((size_t)nr);
+        HIP(hipStreamSynchronize(stream));
+        const auto d2d = [&](void *dst, const void *src, size_t bytes) { HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream)); };
+        for (int k = 0; k < nr; k++) {
+          const int i = chs[(size_t)k];
+          xaac_hbe_state_init(&h0);
+          memcpy(&h0.synth_size, &hbe_tail[(size_t)i * kTail], kTail);
+          if (xaac_hbe_state_reinit(&h0, &s.header[(size_t)i])) die("the QMF transposer refused the SBR band tables");
+          memcpy(&hbe_tail[(size_t)i * kTail], &h0.synth_size, kTail);
+          d2d(&d_hbe_tmp[k], &d_hbe[i], sizeof(xaac_hbe_state));
+          HIP(hipMemcpyAsync(&d_hbe_tmp[k].synth_size, &hbe_tail[(size_t)i * kTail], kTail, hipMemcpyHostToDevice, stream));
+          HIP(hipMemsetAsync(&d_hbe_tmp[k].synth_buf[0], 0, sizeof(h0.synth_buf), stream));
+          HIP(hipMemsetAsync(&d_hbe_tmp[k].analy_buf[0], 0, sizeof(h0.analy_buf), stream));
+          pitch[(size_t)k] = s.reset_pitch[(size_t)(i / n_ch)];
+          /* run 1: buffer rows 8..39 = the 24 older rows, then the state's first eight */
+          d2d(q_re + (size_t)k * 2048, older_re + (size_t)i * 24 * 64, 24 * row);
+          d2d(q_im + (size_t)k * 2048, older_im + (size_t)i * 24 * 64, 24 * row);
+          d2d(q_re + (size_t)k * 2048 + 24 * 64, &d_estate[i].qmf_re[0][0], 8 * row);
+          d2d(q_im + (size_t)k * 2048 + 24 * 64, &d_estate[i].qmf_im[0][0], 8 * row);
+        }
+        HIP(hipMemcpyAsync(d_idx, pitch.data(), (size_t)nr * 4, hipMemcpyHostToDevice, stream));
+        HIP(hipStreamSynchronize(stream)); /* (pitch and the tails are host memory of this scope) */
+        xaac_hbe_apply_batch_desc hb;
+        memset(&hb, 0, sizeof(hb));
+        hb.n_ch = nr, hb.qmf_re = q_re, hb.qmf_im = q_im, hb.state = d_hbe_tmp, hb.pv_re = pv_re, hb.pv_im = pv_im, hb.status = d_status;
+        hb.pitch_in_bins = d_idx;
+        hb.max_synth_size = hbe_hint();
+        XA(xaac_hbe_apply_batch(ctx, &hb));
+        for (int k = 0; k < nr; k++) { /* run 2: buffer rows 40..71; its output rows 24..31 start from the state's ph rows */
+          const int i = chs[(size_t)k];
+          d2d(q_re + (size_t)k * 2048, &d_estate[i].qmf_re[8][0], 32 * row);
+          d2d(q_im + (size_t)k * 2048, &d_estate[i].qmf_im[8][0], 32 * row);
+          d2d(pv_re + (size_t)k * 2048 + 24 * 64, &d_estate[i].ph_re[0][0], 8 * row);
+          d2d(pv_im + (size_t)k * 2048 + 24 * 64, &d_estate[i].ph_im[0][0], 8 * row);
+        }
+        XA(xaac_hbe_apply_batch(ctx, &hb));
+        for (int k = 0; k < nr; k++) {
+          const int i = chs[(size_t)k];
+          d2d(&d_estate[i].ph_re[0][0], pv_re + (size_t)k * 2048 + 24 * 64, 8 * row);
+          d2d(&d_estate[i].ph_im[0][0], pv_im + (size_t)k * 2048 + 24 * 64, 8 * row);
+          d2d(&d_hbe[i], &d_hbe_tmp[k], sizeof(xaac_hbe_state));
+        }
+      } else if (resets) {
         /* ixheaacd_sbr_dec_reset for Path A (sbrdecoder.c:175-236): the transposer's parameters from the new band tables (its
            two delay lines cleared, hbe_trans.c:102-222), then its two runs over rows 8..39 and 40..71 of the QMF buffer (the codec bank's num_time_slots is 32) as the
            frame before left it: rows 8..31 are what that frame found as its history rows 8..31 (d_older), rows 32..71 are

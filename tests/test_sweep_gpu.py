@@ -33,3 +33,15 @@ def test_spliced_streams_with_sbr_header_changes_in_the_middle(tmp_path):
                        env=dict(os.environ, SWEEP_TMP=str(tmp_path)))
     lines = p.stdout.strip().splitlines()
     assert lines and lines[-1] == "bad 0" and sum("identical" in l for l in lines) == 16, p.stdout[-1200:] + p.stderr[-600:]
+
+
+def test_a_batch_of_streams_whose_sbr_headers_change_at_different_frames(tmp_path):
+    """tools/splice_list_check.py: five files per kind (HE-AAC stereo, mono, HE-AACv2, HE-AAC with ENHSBR elements), parts of
+    different bit rates joined at different frames, decoded as one -ilist batch with -esbr:0 and with the default flags: most
+    steps see no reset of the SBR decoder, some see one or two streams reset while the others go on (Path A: the reset-time
+    transposer runs on those streams' rows alone); a part that starts a file brings frames without SBR processing whose
+    header still holds the parser's defaults.  Every WAV equals the reference decoder's for that file alone."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "splice_list_check.py")], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, SWEEP_TMP=str(tmp_path)))
+    lines = p.stdout.strip().splitlines()
+    assert lines and lines[-1] == "bad 0" and sum("identical" in l for l in lines) == 40, p.stdout[-1500:] + p.stderr[-600:]
