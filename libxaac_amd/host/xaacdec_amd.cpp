@@ -472,6 +472,7 @@ int main(int argc, char **argv) {
     cv.wait(lk, [&] { return done >= step; });
   };
   /* what a step leaves for the host once its copy down has arrived */
+  std::vector<uint8_t> refused((size_t)N, 0); /* -ilist: streams a kernel refused a frame of (their output has ended) */
   struct Pending {
     bool valid, mono_twice, first;
     int slot, which;
@@ -485,8 +486,17 @@ int main(int argc, char **argv) {
     const std::vector<int32_t> &alive = st[pending.which].status; /* 0: the stream delivered a frame in that step */
     if (sbr) { /* (rows of streams that are over re-run their last staging rows: what the kernels say about those is not looked at) */
       const int rows = (pending.mono_twice || (n_ch == 1 && !esbr)) ? N : NC;
-      for (int i = 0; i < rows; i++)
-        if (h_status[i] < 0 && alive[(size_t)(rows == N ? i : i / n_ch)] == 0) die("the SBR kernels refused a frame", i);
+      for (int i = 0; i < rows; i++) {
+        const size_t si = (size_t)(rows == N ? i : i / n_ch);
+        if (h_status[i] < 0 && alive[si] == 0 && !refused[si]) {
+          /* side info the kernels do not take (the boundary's own checks: a parser's output passes them, a damaged payload that
+             still parses may not).  One file of a list must not take the others' output along: that stream's output ends in
+             front of this frame, the batch goes on (its rows keep running; nothing more of them is written) */
+          if (!list_mode) die("the SBR kernels refused a frame", i);
+          fprintf(stderr, "xaacdec_amd: stream %zu: the SBR kernels refused a frame: the stream ends here\n", si);
+          refused[si] = 1;
+        }
+      }
     }
     if (pending.mono_twice) /* mono duplicated to stereo (api.c:3639-3660), from the back so that it can be done in place */
       for (long k = (long)N * 2048 - 1; k >= 0; k--) h_pcm[2 * k] = h_pcm[2 * k + 1] = h_pcm[k];
@@ -503,7 +513,7 @@ int main(int argc, char **argv) {
        test/decoder/ixheaacd_main.c:2181-2186) */
     if (!(esbr && pending.first))
       for (size_t i = 0; i < pcms.size(); i++)
-        if (alive[i] == 0) pcms[i].insert(pcms[i].end(), h_pcm + i * per * out_ch + skip, h_pcm + (i + 1) * per * out_ch);
+        if (alive[i] == 0 && !refused[i]) pcms[i].insert(pcms[i].end(), h_pcm + i * per * out_ch + skip, h_pcm + (i + 1) * per * out_ch);
     for (int i = 1; verify && i < N; i++)
       mismatched += memcmp(h_pcm, h_pcm + (size_t)i * per * out_ch, (size_t)per * out_ch * 2) != 0;
     frames += st[pending.which].delivered;
