@@ -740,7 +740,9 @@ FX_HD void xs_low_pow_hf_generator(const XsCx &cx, const xaac_sbr_header *h, ST 
       const int hb = halves ? stop_patch + (l & 31) : l, part = halves ? l >> 5 : 0, lb = lbv.own(l);
       const int16_t alpha0 = xs_m(al.own(l)), alpha1 = xs_e(al.own(l));
       int bi = 0;
-      while (hb >= h->bw_borders[bi]) bi++;
+      /* (the reference's running index, lpp_tran.c:665: the first border above the band -- the last border of a parser's
+         table is sub_band_end; stopped where bw_array ends for a table that has none above) */
+      while (bi < XAAC_SBR_MAX_PATCHES - 1 && hb >= h->bw_borders[bi]) bi++;
       int16_t bw = (int16_t)(w->bw_array[bi] >> 16);
       const int32_t a0 = xs_mult16x16_shl(bw, alpha0);
       bw = xs_mult16_shl_sat(bw, bw);
