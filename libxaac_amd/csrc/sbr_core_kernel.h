@@ -10,7 +10,9 @@
 #define XAAC_SBR_X_ROWS 40                       /* 2 LPC history rows + 6 overlap slots + 32 new slots */
 #define XAAC_SBR_X_WORDS (XAAC_SBR_X_ROWS * 64)  /* int32 words of one channel's QMF matrix */
 #define XAAC_SBR_NARROW_BANDS 48                 /* bands per LDS row of the HQ core's narrow-row kernel */
+#ifndef XAAC_SBR_CORE_HQ_WAVES
 #define XAAC_SBR_CORE_HQ_WAVES 4                 /* its waves per workgroup (they share the lookup tables in LDS) */
+#endif
 
 typedef struct XaacSbrCoreParams {
   int32_t n_ch;

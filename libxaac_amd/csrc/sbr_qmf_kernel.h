@@ -8,7 +8,12 @@
 #include "../../include/xaac_amd.h"
 #include "../../include/xaac_sbr.h"
 
-#define XAAC_QMF_WAVES 2                       /* waves per workgroup; each wave owns two channel-frames */
+/* waves per workgroup of the generic banks; each wave owns two channel-frames.  One: seven workgroups of 21 KB fit a CU
+   where three pairs did, and with a host that keeps two HIP streams busy (bench.py) single-wave workgroups find room
+   beside the other stream's kernels -- C3 on two streams 0.477 -> 0.442 ms (one stream: synthesis 119 -> 117 us) */
+#ifndef XAAC_QMF_WAVES
+#define XAAC_QMF_WAVES 1
+#endif
 #define XAAC_QMF_BLOCK (64 * XAAC_QMF_WAVES)
 /* analysis: 2 x 1312 int16 history (+pad) and a 64 x 65 int32 exchange tile */
 #define XAAC_QMF_ANA_LDS_PER_WAVE (2 * 1312 * 2 + 32 + 64 * 65 * 4)
