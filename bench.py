@@ -52,16 +52,34 @@ PMC_FILE = os.path.join(ROOT, "profiles", "pmc_latest.json")       # tools/pmc_t
 PMC_FILE_C2 = os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")   # round-1 C2 counters (that kernel has not changed)
 VALU_CYCLES_PER_WAVE_INSTR = 4.4   # measured: tools/ubench/valu_rate.hip, profiles/r01_m_c2_sq_detail.txt (v_mul_hi_i32 = a shift)
 SIMDS, CLOCK_GHZ = 1024, 2.4       # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md peak engine clock
+PREWARM_STEPS = 60                 # untimed steps before the counted warm-up (Workload.run; profiles/r06_a_clock_probe.txt)
+
+
+def library_build_id():
+    """the id xaac_version() carries: sha256 of the sources the loaded library was built from (csrc/Makefile: BUILD_ID)"""
+    try:
+        import libxaac_amd
+        v = libxaac_amd.load_library().xaac_version().decode()
+        return v.split(" build ")[1] if " build " in v else None
+    except Exception:
+        return None
 
 
 def measured_traffic(workload):
     """HBM bytes per step from the last committed PMC profile of this workload's kernels (rocprofv3 FETCH_SIZE
-    x2 + WRITE_SIZE summed over the chain's launches, calibrated as MI355X_MICROARCH.md prescribes), or {}."""
+    x2 + WRITE_SIZE summed over the chain's launches, calibrated as MI355X_MICROARCH.md prescribes), or {}.  The C4
+    profile names the build id of the library it was taken on (tools/pmc_to_json.py); a line printed by another build
+    reports traffic null and says why."""
     try:
         if workload == "c4":
             with open(PMC_FILE) as f:
                 d = json.load(f)
-            return {"bytes_per_step": d["c4"]["bytes_per_step"], "source": d["source"]}
+            have, want = library_build_id(), d.get("build_id")
+            if want is None or have != want:
+                return {"bytes_per_step": None,
+                        "source": "%s holds counters of library build %s; this run's library is build %s: not this library's "
+                                  "traffic" % (os.path.relpath(PMC_FILE, ROOT), want, have)}
+            return {"bytes_per_step": d["c4"]["bytes_per_step"], "source": d["source"] + " (library build %s)" % want}
         with open(PMC_FILE_C2) as f:
             return json.load(f).get(workload) or {}
     except (OSError, ValueError, KeyError):
@@ -825,13 +843,20 @@ class Workload:
         if ev is not None:
             ev[1].record(stream)
 
-    def run(self, steps, warmup, barrier):
+    def run(self, steps, warmup, barrier, prewarm=0):
         """(wall seconds of the K steps, milliseconds of GPU time per step from HIP events on the launch streams).  One HIP
         stream: the mean of the steps' own event pairs.  Several: the steps of different streams overlap, so a step's own pair
-        says little; the span from the first stream's start event to the last stream's end event, over K."""
+        says little; the span from the first stream's start event to the last stream's end event, over K.
+        prewarm: untimed steps in front of the W counted warm-up steps (config.prewarm_steps).  A process that has just built
+        its inputs meets a device that is not in its steady state yet -- measured, profiles/r06_a_clock_probe.txt: 20 steps
+        behind 5 warm-up steps take 0.525-0.540 ms each, the same 20 steps behind 60 take 0.488-0.509, like the steps of a
+        100- or 400-step run (0.490-0.504); a step is 0.5 ms, so W = 5 is 2.5 ms of work after seconds of host-side set-up."""
         torch = self.torch
-        for i in range(warmup):
+        for i in range(prewarm):
             self.step(i)
+        for i in range(prewarm, prewarm + warmup):
+            self.step(i)
+        warmup += prewarm
         events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         many = len(self.lanes) > 1
         span = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in self.lanes]
@@ -991,6 +1016,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--prewarm", type=int, default=PREWARM_STEPS,
+                    help="untimed steps in front of the W counted warm-up steps, so that a short run (the driver's --steps 20 "
+                         "--warmup 5) is timed on a device in the same state as a long one (profiles/r06_a_clock_probe.txt)")
     ap.add_argument("--sets", type=int, default=4, help="independent 8192-stream batches cycled per rank")
     ap.add_argument("--hip-streams", type=int, default=2,
                     help="HIP streams per rank the steps are dealt out over (step i on stream i %% N; must divide --sets): "
@@ -1040,7 +1068,7 @@ def main():
 
     w = args.workload
     job = Workload(w, torch, libxaac_amd, ctx, dev, stream, args.sets, rank, hip_streams=args.hip_streams)
-    own_elapsed, kern_ms = job.run(args.steps, args.warmup, barrier)
+    own_elapsed, kern_ms = job.run(args.steps, args.warmup, barrier, prewarm=args.prewarm)
     elapsed = xdist.max_over_ranks(dist, own_elapsed, dev)
     refused = job.refused()
     try:
@@ -1090,7 +1118,7 @@ def main():
         torch.cuda.empty_cache()
         for w2 in ("c2", "c3"):
             j2 = Workload(w2, torch, libxaac_amd, ctx, dev, stream, args.sets, rank, hip_streams=args.hip_streams)
-            e2, k2 = j2.run(max(20, args.steps // 2), max(4, args.warmup // 2), barrier)
+            e2, k2 = j2.run(max(20, args.steps // 2), max(4, args.warmup // 2), barrier, prewarm=args.prewarm)
             steps2 = max(20, args.steps // 2)
             ab = alg_bytes_per_step(w2)
             try:
@@ -1135,7 +1163,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": WORKLOAD[w] % args.sets,
                        "frames_per_step": FRAMES_PER_STEP, "channels": 1 if w == "c4" else CH, "launch": ctx.last_launch(),
-                       "hip_streams": args.hip_streams,
+                       "hip_streams": args.hip_streams, "prewarm_steps": args.prewarm,
+                       "prewarm_note": "untimed steps in front of the W counted warm-up steps: the timed K steps of a short run "
+                                       "then meet the device in the state a long run times it in",
                        "hip_streams_note": "step i is launched on HIP stream i % hip_streams (its own context and workspace); "
                                            "a stream set always meets the same stream, so its frames stay in order",
                        "sharding": "streams split across ranks (%d per rank), no data-path collective" % FRAMES_PER_STEP},

@@ -94,7 +94,9 @@ XAAC_API int32_t xaac_adts_parse_header(const uint8_t *data, size_t n, xaac_adts
    number_of_raw_data_blocks_in_frame > 0 (headerdecode.c:353, api.c:2909-2925) -- header + first block for the first call and
    one block (+ its CRC word in a protected frame) for each of the following ones, which must be handed the bytes right
    behind what the call before consumed.  The parser keeps what outlives a call (the blocks left in the frame, PNS random
-   seed, SBR / PS decoding state). */
+   seed, SBR / PS decoding state).  Protected frames (protection_absent == 0) with several blocks follow ISO/IEC 13818-7 --
+   a crc_check word behind every block -- which deliberately differs from the reference: its api.c:3760-3767 never skips
+   those words in the follow-up calls (its per-call `adts` struct is zero there) and misparses blocks 2..N. */
 XAAC_API int32_t xaac_parse_adts_frame(xaac_parser *p, const uint8_t *data, size_t n, int32_t stage, xaac_core_frame *out,
                               size_t *consumed);
 

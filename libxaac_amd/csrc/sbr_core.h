@@ -1428,7 +1428,7 @@ FX_HD int32_t xs_energy_element_pk(const Q &x, int first, int n, int k, int16_t 
   int32_t re[N], im[N];
   XS_UNROLL
   for (int j = 0; j < N; j++) {
-    const int row = first + (j < n ? j : n - 1);
+    const int row = first + (j < n ? j : (n > 0 ? n - 1 : 0)); /* (an element without slots -- borders out of order -- reads its first row: masked below) */
     re[j] = x(row, k);
     if constexpr (Q::HQ) im[j] = x.im(row, k); else im[j] = 0;
   }
@@ -1471,7 +1471,7 @@ FX_HD int32_t xs_energy_element_long(const Q &x, int first, int n, int nmax, int
     int32_t re[8], im[8];
     XS_UNROLL
     for (int j = 0; j < 8; j++) {
-      const int row = first + (j0 + j < n ? j0 + j : n - 1);
+      const int row = first + (j0 + j < n ? j0 + j : (n > 0 ? n - 1 : 0));
       re[j] = x(row, k);
       if constexpr (Q::HQ) im[j] = x.im(row, k); else im[j] = 0;
     }
@@ -1491,7 +1491,7 @@ FX_HD int32_t xs_energy_element_long(const Q &x, int first, int n, int nmax, int
     int32_t re[8], im[8];
     XS_UNROLL
     for (int j = 0; j < 8; j++) {
-      const int row = first + (j0 + j < n ? j0 + j : n - 1);
+      const int row = first + (j0 + j < n ? j0 + j : (n > 0 ? n - 1 : 0));
       re[j] = x(row, k);
       if constexpr (Q::HQ) im[j] = x.im(row, k); else im[j] = 0;
     }

@@ -6,6 +6,7 @@
  * without a HIP device xaac_create fails with XAAC_FATAL_NO_DEVICE.
  */
 #include <hip/hip_runtime_api.h>
+#include "build_id.h" /* build/build_id.h: XAAC_BUILD_ID (Makefile) */
 
 #include <cstdint>
 #include <cstdlib>
@@ -74,7 +75,8 @@ int32_t check_batch(const xaac_imdct_batch *b) {
 
 extern "C" {
 
-const char *xaac_version(void) { return "libxaac_amd 0.3 gfx950"; }
+/* "... build <id>": the sha256 of the library's sources (Makefile: BUILD_ID), so that a counter profile names its library */
+const char *xaac_version(void) { return "libxaac_amd 0.4 gfx950 build " XAAC_BUILD_ID; }
 
 int32_t xaac_create(xaac_ctx **out, int32_t device, void *hip_stream) {
   if (!out) return XAAC_FATAL_NULL_ARG;

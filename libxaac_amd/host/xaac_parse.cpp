@@ -33,8 +33,14 @@ struct xaac_parser {
   XhElement el;
   int sbr_ready, sampling_rate, esbr;
   XsDecoder sbr;
-  /* an ADTS frame with several raw data blocks (api.c:2909-2925, :3760-3767): the blocks of the frame still to come, the bytes
-     of the frame behind the last delivered block, and whether a 16-bit CRC follows every block (headerdecode.c:356-362) */
+  /* an ADTS frame with several raw data blocks (api.c:2909-2925): the blocks of the frame still to come, the bytes of the
+     frame behind the last delivered block, and whether a 16-bit CRC follows every block (ISO/IEC 13818-7 adts_frame():
+     raw_data_block() + crc_check per block when protection_absent == 0; headerdecode.c:356-362 reads the positions).
+     DELIBERATELY NOT THE REFERENCE'S BEHAVIOUR for protected multi-block frames: api.c:3760-3767 means to skip that word,
+     but its `adts` struct (api.c:2626, zero-initialised per call) is only filled by the call that reads a header, so in the
+     follow-up calls no_raw_data_blocks reads 0, the CRC is never skipped and blocks 2..N of a protected multi-block frame are
+     misparsed there.  This parser follows the syntax; parity with the reference is claimed (and tested against the real
+     decoder) for the unprotected layout only. */
   int blocks_left, block_crc;
   size_t frame_left;
 };
@@ -381,7 +387,13 @@ int32_t parse_one(const xaac_parse_batch *b, int i, int t, std::atomic<int> *ok)
   xaac_parser *p = b->parser[i];
   size_t used = 0;
   const uint64_t at = b->pos ? (b->pos[i] < b->bytes[i] ? b->pos[i] : b->bytes[i]) : 0;
+  /* a step that fails behind a successful parse_frame (channel count, SBR side info) leaves the stream's read position where
+     it was, so the multi-block bookkeeping parse_frame has already moved on has to go back with it: the next call would
+     otherwise read the ADTS header it is pointed at as a raw data block */
+  const int32_t keep_blocks = p->blocks_left, keep_crc = p->block_crc;
+  const size_t keep_left = p->frame_left;
   int32_t r = parse_frame(p, b->data[i] + at, (size_t)(b->bytes[i] - at), b->stage, &used);
+  const bool framed = r == 0;
   if (r == 0 && p->el.n_ch != n_ch) r = XAAC_PARSE_ERR_UNSUPPORTED;
   xaac_sbr_side *side = nullptr;
   if (r == 0 && b->with_sbr) {
@@ -390,7 +402,10 @@ int32_t parse_one(const xaac_parse_batch *b, int i, int t, std::atomic<int> *ok)
     r = xaac_parse_sbr_side(p, b->ps_enable, side);
   }
   b->status[S + i] = r;
-  if (r) return r;
+  if (r) {
+    if (framed) p->blocks_left = keep_blocks, p->block_crc = keep_crc, p->frame_left = keep_left;
+    return r;
+  }
   (*ok)++;
   b->consumed[i] += used;
   if (b->pos) b->pos[i] = at + used;
@@ -471,14 +486,15 @@ uint64_t this_thread() { return (uint64_t)std::hash<std::thread::id>()(std::this
 
 void batch_launch(const xaac_parse_batch *b, bool caller_works) {
   team().acquire();
-  if (!caller_works) { /* _start: the batch in flight is this thread's from the moment the team is (a _wait on another thread
-                          finds the flag set as soon as this call has the team) */
-    g_job.owner.store(this_thread(), std::memory_order_relaxed);
-    g_job.in_flight.store(true, std::memory_order_release);
-  }
+  /* _start: the owner is known from the moment this call has the team (the self-deadlock checks of _run / _start read it),
+     but the batch only counts as in flight once the team has been handed it -- a _wait on another thread that found the flag
+     set before the launch would join a team whose pending count still is the previous job's zero, return at once and release
+     the team under the starter's feet.  Until the flag is set such a _wait gets ERR_SYNTAX ("nothing was started") */
+  if (!caller_works) g_job.owner.store(this_thread(), std::memory_order_relaxed);
   g_job.b = *b;
   g_job.ok.store(0, std::memory_order_relaxed);
   team().launch(b->n_streams, batch_threads(b), [](int i) { parse_item(&g_job.b, i, &g_job.ok); }, caller_works);
+  if (!caller_works) g_job.in_flight.store(true, std::memory_order_release);
 }
 }  // namespace
 

@@ -379,8 +379,11 @@ def _remux_several_blocks_per_frame(data, groups=(2, 1, 4, 3), protected=False):
 @pytest.mark.parametrize("name", ["mix_aot2_64k", "mix_aot5_48k", "mix_aot29_32k"])
 def test_adts_frames_with_several_raw_data_blocks(name, tmp_path):
     """number_of_raw_data_blocks_in_frame > 0: every call delivers one block, as the reference's decode call does
-    (api.c:2909-2925, :3760-3767): the regrouped stream parses into the same frames as the original, with and without the
-    protected layout; and the real reference decoder writes the same file for both (unprotected layout)"""
+    (api.c:2909-2925): the regrouped stream parses into the same frames as the original, with and without the protected
+    layout; and the real reference decoder writes the same file for both -- for the UNPROTECTED layout only: in a protected
+    multi-block frame this parser skips the crc_check word behind every block as ISO/IEC 13818-7 lays it out, which the
+    reference does not (api.c:3760-3767 tests a per-call zeroed `adts` struct), so the protected case is checked against
+    this parser's own reading of the plain stream, not against the reference"""
     data = stream(name)
     want = decoder.parse_stream(data, stage=2)
     for protected in (False, True):

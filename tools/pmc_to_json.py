@@ -29,6 +29,11 @@ def main(tag):
     sq = table(os.path.join(ROOT, "profiles", tag + "_sbr_pmc_sq.txt"))
     out = {"source": "profiles/%s_sbr_pmc_hbm.txt, profiles/%s_sbr_pmc_sq.txt: rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_* "
                      "in separate runs) over tools/pmc_probe_sbr.py, one C4 step = 8192 stream-frames" % (tag, tag), "kernels": {}}
+    # the library the counters were taken on: tools/profile_r06.sh writes xaac_version()'s build id beside the passes
+    try:
+        out["build_id"] = open(os.path.join(ROOT, "profiles", tag + "_build_id.txt")).read().strip() or None
+    except OSError:
+        out["build_id"] = None
     tot = {"bytes": 0, "valu": 0, "salu": 0, "lds": 0}
     for name in sorted(set(hbm) | set(sq)):
         if not any(name.replace("void ", "").startswith(k) for k in C4_KERNELS):
