@@ -7,6 +7,14 @@
  *
  *   xaacdec_amd -ifile:<in.aac> -ofile:<out.wav> [-esbr:<0|1>] [-copies:<N>] [-verify] [-threads:<T>] [-quiet]
  *   xaacdec_amd -ilist:<file with one input path per line> -odir:<directory> [-esbr:<0|1>] [-threads:<T>] [-quiet]
+ *   ... [-gpus:<G>] [-device:<k>] [-plan]
+ *
+ * -gpus:G shards the batch's streams over G devices of this node (k, k + 1, ... from -device:k, default 0): contiguous ranges
+ * whose sizes differ by at most one -- libxaac_amd/dist.py: shard_range, the split bench.py --gpus N makes over ranks -- one host
+ * thread, HIP context, stream and set of resident states per device, nothing shared between the shards but the read-only
+ * inputs (streams are independent: no data-path exchange; the PCM of every shard comes down to its own host thread).
+ * -plan prints the split and exits before anything touches a device (tests/test_cli_plan_cpu.py); -wrap_devices lets the
+ * shards wrap around the devices the node has (two shards on one device: the -gpus host path on a one-GPU box, tests/test_cli_gpu.py).
  *
  * -copies:N decodes N instances of the stream in one lock-step batch (the first one's PCM is written; with -verify all N are
  * compared with it word for word) and prints the end-to-end rate: the shape a serving host has, with one input here for brevity.
@@ -95,13 +103,25 @@ cpu_set_t gpu_node_cpus(int device, bool *known) {
   fclose(f);
   return set;
 }
-int g_device = 0; /* the HIP device of this run (pinned<T>() asks for its NUMA node) */
+/* the GPU's NUMA node is looked up once per device (the shards of a -gpus run sit on different nodes of a two-socket host) */
+cpu_set_t near_cpus(int device, bool *known) { /* (by value: the table may grow under another shard's thread) */
+  static std::mutex mu;
+  static std::vector<std::pair<int, std::pair<bool, cpu_set_t>>> seen;
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto &e : seen)
+    if (e.first == device) return *known = e.second.first, e.second.second;
+  bool k = false;
+  const cpu_set_t set = gpu_node_cpus(device, &k);
+  seen.push_back({device, {k, set}});
+  *known = k;
+  return seen.back().second.second;
+}
 template <class T>
-T *pinned(size_t n) {
-  static bool known = false;
-  static const cpu_set_t near = gpu_node_cpus(g_device, &known);
+T *pinned(size_t n, int device) {
+  bool known = false;
+  const cpu_set_t near = near_cpus(device, &known);
   cpu_set_t before, both;
-  /* first touch on the GPU's NUMA node: only CPUs this process may run on anyway (a cpuset that does not meet the node leaves the
+  /* first touch on the GPU's NUMA node: only CPUs this thread may run on anyway (a cpuset that does not meet the node leaves the
      thread where it is) */
   bool moved = false;
   if (known && sched_getaffinity(0, sizeof(before), &before) == 0) {
@@ -147,93 +167,40 @@ void write_wav(const std::string &path, const std::vector<int16_t> &pcm, int cha
   fclose(f);
 }
 
-}  // namespace
-
-int main(int argc, char **argv) {
-  std::string in, out, ilist, odir;
-  int copies = 1, threads = 0, quiet = 0, verify = 0, profile = 0, esbr = 1;
-  for (int i = 1; i < argc; i++) {
-    const std::string a = argv[i];
-    if (a.rfind("-ifile:", 0) == 0) in = a.substr(7);
-    else if (a.rfind("-ofile:", 0) == 0) out = a.substr(7);
-    else if (a.rfind("-ilist:", 0) == 0) ilist = a.substr(7);
-    else if (a.rfind("-odir:", 0) == 0) odir = a.substr(6);
-    else if (a.rfind("-copies:", 0) == 0) copies = atoi(a.c_str() + 8);
-    else if (a.rfind("-threads:", 0) == 0) threads = atoi(a.c_str() + 9);
-    else if (a == "-quiet") quiet = 1;
-    else if (a == "-verify") verify = 1;
-    else if (a == "-profile") profile = 1; /* synchronise behind every phase of a step and report the seconds spent in each */
-    else if (a == "-esbr:0") esbr = 0;
-    else if (a == "-esbr:1") esbr = 1;
-    else if (a.rfind("-esbr", 0) == 0) die("-esbr:0 or -esbr:1");
-  }
-  std::vector<std::string> inputs;
-  if (!ilist.empty()) {
-    FILE *f = fopen(ilist.c_str(), "r");
-    if (!f) die("fopen(-ilist)");
-    char line[4096];
-    while (fgets(line, sizeof(line), f)) {
-      std::string sline(line);
-      while (!sline.empty() && (sline.back() == '\n' || sline.back() == '\r' || sline.back() == ' ')) sline.pop_back();
-      if (!sline.empty()) inputs.push_back(sline);
-    }
-    fclose(f);
-    if (inputs.empty() || odir.empty()) die("-ilist needs paths and -odir");
-    copies = 1, verify = 0;
-  } else if (!in.empty()) {
-    inputs.push_back(in);
-  }
-  if (inputs.empty() || (ilist.empty() && out.empty()) || copies < 1) {
-    fprintf(stderr, "usage: xaacdec_amd -ifile:<in.aac> -ofile:<out.wav> [-esbr:0|1] [-copies:N] [-threads:T] [-quiet]\n");
-    return 1;
-  }
-  std::vector<std::vector<uint8_t>> datas(inputs.size());
-  for (size_t k = 0; k < inputs.size(); k++) {
-    FILE *f = fopen(inputs[k].c_str(), "rb");
-    if (!f) die("fopen(input)");
-    fseek(f, 0, SEEK_END);
-    const long n = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    datas[k].resize((size_t)n + 16);
-    if (fread(datas[k].data(), 1, (size_t)n, f) != (size_t)n) die("fread");
-    fclose(f);
-    datas[k].resize((size_t)n);
-  }
-  const std::vector<uint8_t> &data = datas[0];
-  /* a look at frame 0: channels, SBR or not (api.c:3369-3373: the SBR tools run for frames with an SBR payload; a stream at
-     24 kHz and below has an SBR decoder object by implicit signalling, api.c:2160, which is never called without payloads) */
+/* what the command line fixes for every shard */
+struct Job {
+  std::vector<std::vector<uint8_t>> datas; /* -ilist: one per stream; else the one input */
   xaac_adts_header hdr;
-  if (xaac_adts_parse_header(data.data(), data.size(), &hdr)) die("ADTS header");
-  int n_ch, sbr;
-  {
-    xaac_parser *probe = nullptr;
-    XA(xaac_parser_create(&probe));
-    std::vector<xaac_core_frame> cf(1);
-    size_t used = 0;
-    const int32_t rc = xaac_parse_adts_frame(probe, data.data(), data.size(), 1, cf.data(), &used);
-    if (rc) die("first frame", rc);
-    n_ch = cf[0].n_ch;
-    sbr = cf[0].sbr_bytes > 0;
-    xaac_parser_destroy(probe);
-    for (size_t k = 1; k < datas.size(); k++) { /* -ilist: one kind of stream per batch */
-      xaac_adts_header h2;
-      if (xaac_adts_parse_header(datas[k].data(), datas[k].size(), &h2)) die("ADTS header");
-      XA(xaac_parser_create(&probe));
-      if (xaac_parse_adts_frame(probe, datas[k].data(), datas[k].size(), 1, cf.data(), &used)) die("first frame");
-      if (h2.sampling_rate != hdr.sampling_rate || cf[0].n_ch != n_ch || (cf[0].sbr_bytes > 0) != (sbr != 0))
-        die("-ilist: streams of different kinds (sampling rate, channels, SBR) in one batch");
-      xaac_parser_destroy(probe);
-    }
-  }
-  if (!sbr) esbr = 0; /* AAC-LC streams decode the same either way */
-  const int out_ch = sbr ? 2 : n_ch; /* SBR streams come out in stereo (PS, or the mono column twice); AAC-LC as coded */
-  const int N = ilist.empty() ? copies : (int)datas.size(), NC = N * n_ch, NCD = NC, rate = hdr.sampling_rate, out_rate = sbr ? 2 * rate : rate, per = sbr ? 2048 : 1024;
+  int n_ch, sbr, esbr, out_ch, rate, out_rate, per;
+  int threads, verify, profile;
+  bool list_mode;
+};
+/* one device's share of the batch: streams [lo, lo + n) on HIP device `device`, decoded by one host thread */
+struct Shard {
+  int device, lo, n;
+  std::vector<std::vector<int16_t>> pcms; /* every stream's output (-ilist), or the shard's first stream's */
+  long frames = 0, mismatched = 0, first_frames = 0;
+  double parse_s = 0, wall = 0, steady = 0, phase_s[4] = {0, 0, 0, 0};
+};
 
+/* libxaac_amd/dist.py: shard_range -- contiguous [lo, hi) of n items owned by shard r of g; sizes differ by at most one */
+void shard_range(int n, int r, int g, int *lo, int *hi) {
+  const int base = n / g, rem = n % g;
+  *lo = r * base + (r < rem ? r : rem);
+  *hi = *lo + base + (r < rem ? 1 : 0);
+}
+
+void decode_shard(const Job &J, Shard &S) {
+  const int device = S.device, N = S.n, n_ch = J.n_ch, sbr = J.sbr, esbr = J.esbr, out_ch = J.out_ch, rate = J.rate, per = J.per;
+  const int threads = J.threads, verify = J.verify, profile = J.profile;
+  const bool list_mode = J.list_mode;
+  const int NC = N * n_ch, NCD = NC;
+  S.first_frames = N;
   xaac_ctx *ctx = nullptr;
   hipStream_t stream;
-  HIP(hipSetDevice(0));
+  HIP(hipSetDevice(device));
   HIP(hipStreamCreate(&stream));
-  XA(xaac_create(&ctx, 0, stream));
+  XA(xaac_create(&ctx, device, stream));
   XA(xaac_warm_up(ctx)); /* the kernels' code objects are on the device before the first batch (and the run's clock) */
   std::vector<xaac_parser *> parser((size_t)N);
   for (auto &p : parser) {
@@ -242,7 +209,6 @@ int main(int argc, char **argv) {
   }
   std::vector<const uint8_t *> ptr((size_t)N);
   std::vector<uint64_t> left((size_t)N), pos((size_t)N, 0);
-  const bool list_mode = !ilist.empty();
   std::vector<char> broken((size_t)N, 0); /* -ilist: a stream whose frame did not parse is treated as over from there on */
 
   /* device-resident state and per-step device buffers */
@@ -257,8 +223,8 @@ int main(int argc, char **argv) {
   hipEvent_t ev_kernels[2], ev_down[2];
   HIP(hipStreamCreate(&down));
   for (int k = 0; k < 2; k++) {
-    d_pcm2[k] = dev<int16_t>((size_t)N * per * out_ch), h_pcm2[k] = pinned<int16_t>((size_t)N * per * 2);
-    d_status2[k] = dev<int32_t>((size_t)NC), h_status2[k] = pinned<int32_t>((size_t)NC);
+    d_pcm2[k] = dev<int16_t>((size_t)N * per * out_ch), h_pcm2[k] = pinned<int16_t>((size_t)N * per * 2, device);
+    d_status2[k] = dev<int32_t>((size_t)NC), h_status2[k] = pinned<int32_t>((size_t)NC, device);
     HIP(hipEventCreateWithFlags(&ev_kernels[k], hipEventDisableTiming));
     HIP(hipEventCreateWithFlags(&ev_down[k], hipEventDisableTiming));
   }
@@ -311,14 +277,14 @@ int main(int argc, char **argv) {
     d_fcore = dev<float>((size_t)NC * 1024);
     d_out_l = dev<float>((size_t)NC * 2048);
     d_older = dev<float>((size_t)2 * NC * 24 * 64);
-    static xaac_esbr_state e0;
+    static thread_local xaac_esbr_state e0; /* (thread_local: one decode_shard per device thread) */
     xaac_esbr_state_init(&e0);
     for (int i = 0; i < NC; i++) HIP(hipMemcpy(d_estate + i, &e0, sizeof(e0), hipMemcpyHostToDevice));
     if (n_ch == 1) {
       d_psf = dev<xaac_ps_frame>((size_t)N);
       d_eps = dev<xaac_esbr_ps_state>((size_t)N);
       d_out_r = dev<float>((size_t)N * 2048);
-      static xaac_esbr_ps_state p0;
+      static thread_local xaac_esbr_ps_state p0;
       xaac_esbr_ps_state_init(&p0);
       for (int i = 0; i < N; i++) HIP(hipMemcpy(d_eps + i, &p0, sizeof(p0), hipMemcpyHostToDevice));
     }
@@ -334,7 +300,7 @@ int main(int argc, char **argv) {
       std::vector<xaac_sbr_state> all((size_t)NC, s0);
       HIP(hipMemcpy(d_state, all.data(), all.size() * sizeof(s0), hipMemcpyHostToDevice));
     }
-    d_flags = dev<int32_t>((size_t)N * 8), h_flags = pinned<int32_t>((size_t)N * 8);
+    d_flags = dev<int32_t>((size_t)N * 8), h_flags = pinned<int32_t>((size_t)N * 8, device);
     if (n_ch == 1) {
       d_psf = dev<xaac_ps_frame>((size_t)N);
       d_ps_state = dev<xaac_ps_state>((size_t)N);
@@ -360,12 +326,12 @@ int main(int argc, char **argv) {
   Staging st[3 * T];
   StagingGroup grp[3];
   for (int g = 0; g < 3; g++) {
-    int32_t *spec = pinned<int32_t>((size_t)T * NC * 1024);
-    uint8_t *ics = pinned<uint8_t>((size_t)T * NC * 2);
-    xaac_sbr_header *header = sbr ? pinned<xaac_sbr_header>((size_t)T * NC) : nullptr;
-    xaac_sbr_frame *frame = sbr ? pinned<xaac_sbr_frame>((size_t)T * NC) : nullptr;
-    xaac_ps_frame *psf = (sbr && n_ch == 1) ? pinned<xaac_ps_frame>((size_t)T * N) : nullptr;
-    xaac_esbr_side *eside = esbr ? pinned<xaac_esbr_side>((size_t)T * NC) : nullptr;
+    int32_t *spec = pinned<int32_t>((size_t)T * NC * 1024, device);
+    uint8_t *ics = pinned<uint8_t>((size_t)T * NC * 2, device);
+    xaac_sbr_header *header = sbr ? pinned<xaac_sbr_header>((size_t)T * NC, device) : nullptr;
+    xaac_sbr_frame *frame = sbr ? pinned<xaac_sbr_frame>((size_t)T * NC, device) : nullptr;
+    xaac_ps_frame *psf = (sbr && n_ch == 1) ? pinned<xaac_ps_frame>((size_t)T * N, device) : nullptr;
+    xaac_esbr_side *eside = esbr ? pinned<xaac_esbr_side>((size_t)T * NC, device) : nullptr;
     grp[g].flags.assign((size_t)T * N * 8, 0), grp[g].status.assign((size_t)T * N, 0), grp[g].reset_pitch.assign((size_t)T * N, 0);
     grp[g].lines.assign((size_t)T * N, 0), grp[g].consumed.assign((size_t)N, 0);
     for (int t = 0; t < T; t++) {
@@ -378,10 +344,10 @@ int main(int argc, char **argv) {
     }
   }
   for (int i = 0; i < N; i++) {
-    const std::vector<uint8_t> &d = datas[datas.size() > 1 ? (size_t)i : 0];
+    const std::vector<uint8_t> &d = J.datas[list_mode ? (size_t)(S.lo + i) : 0];
     ptr[(size_t)i] = d.data(), left[(size_t)i] = d.size(); /* the whole streams: the library keeps the read positions (pos) */
   }
-  double parse_s = 0;
+  double &parse_s = S.parse_s;
   auto parse = [&](int g) { /* the next kFramesPerParse frames of every stream into one group of staging sets */
     const auto t0 = std::chrono::steady_clock::now();
     StagingGroup &G = grp[g];
@@ -407,7 +373,7 @@ int main(int argc, char **argv) {
              here (what it delivered so far is written), the batch goes on */
           if (!list_mode) die("a frame does not parse", r);
           if (!broken[(size_t)i])
-            fprintf(stderr, "xaacdec_amd: stream %d: a frame does not parse (%d) at byte %llu: the stream ends here\n", i, r,
+            fprintf(stderr, "xaacdec_amd: stream %d: a frame does not parse (%d) at byte %llu: the stream ends here\n", S.lo + i, r,
                     (unsigned long long)pos[(size_t)i]);
           broken[(size_t)i] = 1;
           r = XAAC_PARSE_NEED_DATA;
@@ -426,7 +392,7 @@ int main(int argc, char **argv) {
     parse_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   };
 
-  double phase_s[4] = {0, 0, 0, 0}; /* -profile: copies up, kernels, copies down, host work on the PCM */
+  double (&phase_s)[4] = S.phase_s; /* -profile: copies up, kernels, copies down, host work on the PCM */
   auto t_phase = std::chrono::steady_clock::now();
   auto lap = [&](int k) {
     if (!profile) return;
@@ -435,12 +401,12 @@ int main(int argc, char **argv) {
     phase_s[k] += std::chrono::duration<double>(now - t_phase).count();
     t_phase = now;
   };
-  std::vector<std::vector<int16_t>> pcms((size_t)(list_mode ? N : 1)); /* every stream's output (-ilist), or stream 0's */
-  std::vector<int16_t> &pcm = pcms[0];
+  std::vector<std::vector<int16_t>> &pcms = S.pcms;
+  pcms.assign((size_t)(list_mode ? N : 1), std::vector<int16_t>()); /* every stream's output (-ilist), or stream 0's */
   std::vector<char> ended((size_t)N, 0);
   std::vector<xaac_limiter_state> lim_at_end; /* -ilist, AAC-LC: the limiter state a stream leaves behind its last frame */
   if (list_mode && !sbr) lim_at_end.resize((size_t)N);
-  long frames = 0, mismatched = 0;
+  long &frames = S.frames, &mismatched = S.mismatched;
   int lines_held = 0; /* leading spectral lines that may be non-zero in d_spec */
   bool first = true;
   const auto t_all = std::chrono::steady_clock::now();
@@ -493,7 +459,7 @@ int main(int argc, char **argv) {
              still parses may not).  One file of a list must not take the others' output along: that stream's output ends in
              front of this frame, the batch goes on (its rows keep running; nothing more of them is written) */
           if (!list_mode) die("the SBR kernels refused a frame", i);
-          fprintf(stderr, "xaacdec_amd: stream %zu: the SBR kernels refused a frame: the stream ends here\n", si);
+          fprintf(stderr, "xaacdec_amd: stream %zu: the SBR kernels refused a frame: the stream ends here\n", (size_t)S.lo + si);
           refused[si] = 1;
         }
       }
@@ -575,7 +541,7 @@ int main(int argc, char **argv) {
            a compact batch: their transposer states into d_hbe_tmp (new parameters from the band tables, delay lines
            cleared), their rows into the first slots of the scratch planes, the two transposer runs over that batch, states
            and ph rows back to their places.  The other streams' states are not touched. */
-        static xaac_hbe_state h0;
+        static thread_local xaac_hbe_state h0;
         constexpr size_t kTail = sizeof(xaac_hbe_state) - offsetof(xaac_hbe_state, synth_size);
         if (hbe_tail.empty()) hbe_tail.assign((size_t)NC * kTail, 0);
         std::vector<int> chs;
@@ -634,7 +600,7 @@ int main(int argc, char **argv) {
            frame before left it: rows 8..31 are what that frame found as its history rows 8..31 (d_older), rows 32..71 are
            the state's history.  The second run's last eight output rows are the state's ph rows (bands outside
            the transposer's range keep what they held). */
-        static xaac_hbe_state h0;
+        static thread_local xaac_hbe_state h0;
         constexpr size_t kTail = sizeof(xaac_hbe_state) - offsetof(xaac_hbe_state, synth_size); /* the integers behind the buffers */
         if (hbe_tail.empty()) hbe_tail.assign((size_t)NC * kTail, 0);
         std::vector<uint8_t> &tail = hbe_tail;
@@ -792,10 +758,10 @@ int main(int argc, char **argv) {
   }
   worker.join();
   const auto t_end = std::chrono::steady_clock::now();
-  const double wall = std::chrono::duration<double>(t_end - t_all).count();
-  const double steady = std::chrono::duration<double>(t_end - t_first).count();
+  S.wall = std::chrono::duration<double>(t_end - t_all).count();
+  S.steady = std::chrono::duration<double>(t_end - t_first).count();
   if (!sbr) { /* the limiter's delay line holds the last attack_time_samples samples: api.c:2824-2866 */
-    static xaac_limiter_state l;
+    static thread_local xaac_limiter_state l;
     for (size_t i = 0; i < pcms.size(); i++) {
       if (list_mode && ended[i]) l = lim_at_end[i];
       else HIP(hipMemcpy(&l, d_lim + i, sizeof(l), hipMemcpyDeviceToHost));
@@ -810,23 +776,170 @@ int main(int argc, char **argv) {
         }
     }
   }
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  std::string in, out, ilist, odir;
+  int copies = 1, threads = 0, quiet = 0, verify = 0, profile = 0, esbr = 1, gpus = 1, device0 = 0, plan = 0, wrap = 0;
+  for (int i = 1; i < argc; i++) {
+    const std::string a = argv[i];
+    if (a.rfind("-ifile:", 0) == 0) in = a.substr(7);
+    else if (a.rfind("-ofile:", 0) == 0) out = a.substr(7);
+    else if (a.rfind("-ilist:", 0) == 0) ilist = a.substr(7);
+    else if (a.rfind("-odir:", 0) == 0) odir = a.substr(6);
+    else if (a.rfind("-copies:", 0) == 0) copies = atoi(a.c_str() + 8);
+    else if (a.rfind("-threads:", 0) == 0) threads = atoi(a.c_str() + 9);
+    else if (a.rfind("-gpus:", 0) == 0) gpus = atoi(a.c_str() + 6);
+    else if (a.rfind("-device:", 0) == 0) device0 = atoi(a.c_str() + 8);
+    else if (a == "-plan") plan = 1;
+    else if (a == "-wrap_devices") wrap = 1; /* shard r on device (k + r) mod the node's count: the -gpus host path on a box with fewer devices */
+    else if (a == "-quiet") quiet = 1;
+    else if (a == "-verify") verify = 1;
+    else if (a == "-profile") profile = 1; /* synchronise behind every phase of a step and report the seconds spent in each */
+    else if (a == "-esbr:0") esbr = 0;
+    else if (a == "-esbr:1") esbr = 1;
+    else if (a.rfind("-esbr", 0) == 0) die("-esbr:0 or -esbr:1");
+  }
+  std::vector<std::string> inputs;
+  if (!ilist.empty()) {
+    FILE *f = fopen(ilist.c_str(), "r");
+    if (!f) die("fopen(-ilist)");
+    char line[4096];
+    while (fgets(line, sizeof(line), f)) {
+      std::string sline(line);
+      while (!sline.empty() && (sline.back() == '\n' || sline.back() == '\r' || sline.back() == ' ')) sline.pop_back();
+      if (!sline.empty()) inputs.push_back(sline);
+    }
+    fclose(f);
+    if (inputs.empty() || odir.empty()) die("-ilist needs paths and -odir");
+    copies = 1, verify = 0;
+  } else if (!in.empty()) {
+    inputs.push_back(in);
+  }
+  if (inputs.empty() || (ilist.empty() && out.empty() && !plan) || copies < 1 || gpus < 1 || device0 < 0) {
+    fprintf(stderr, "usage: xaacdec_amd -ifile:<in.aac> -ofile:<out.wav> [-esbr:0|1] [-copies:N] [-threads:T] [-gpus:G] [-device:k] [-plan] [-quiet]\n");
+    return 1;
+  }
+  std::vector<std::vector<uint8_t>> datas(inputs.size());
+  for (size_t k = 0; k < inputs.size(); k++) {
+    FILE *f = fopen(inputs[k].c_str(), "rb");
+    if (!f) die("fopen(input)");
+    fseek(f, 0, SEEK_END);
+    const long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    datas[k].resize((size_t)n + 16);
+    if (fread(datas[k].data(), 1, (size_t)n, f) != (size_t)n) die("fread");
+    fclose(f);
+    datas[k].resize((size_t)n);
+  }
+  const std::vector<uint8_t> &data = datas[0];
+  /* a look at frame 0: channels, SBR or not (api.c:3369-3373: the SBR tools run for frames with an SBR payload; a stream at
+     24 kHz and below has an SBR decoder object by implicit signalling, api.c:2160, which is never called without payloads) */
+  xaac_adts_header hdr;
+  if (xaac_adts_parse_header(data.data(), data.size(), &hdr)) die("ADTS header");
+  int n_ch, sbr;
+  {
+    xaac_parser *probe = nullptr;
+    XA(xaac_parser_create(&probe));
+    std::vector<xaac_core_frame> cf(1);
+    size_t used = 0;
+    const int32_t rc = xaac_parse_adts_frame(probe, data.data(), data.size(), 1, cf.data(), &used);
+    if (rc) die("first frame", rc);
+    n_ch = cf[0].n_ch;
+    sbr = cf[0].sbr_bytes > 0;
+    xaac_parser_destroy(probe);
+    for (size_t k = 1; k < datas.size(); k++) { /* -ilist: one kind of stream per batch */
+      xaac_adts_header h2;
+      if (xaac_adts_parse_header(datas[k].data(), datas[k].size(), &h2)) die("ADTS header");
+      XA(xaac_parser_create(&probe));
+      if (xaac_parse_adts_frame(probe, datas[k].data(), datas[k].size(), 1, cf.data(), &used)) die("first frame");
+      if (h2.sampling_rate != hdr.sampling_rate || cf[0].n_ch != n_ch || (cf[0].sbr_bytes > 0) != (sbr != 0))
+        die("-ilist: streams of different kinds (sampling rate, channels, SBR) in one batch");
+      xaac_parser_destroy(probe);
+    }
+  }
+  if (!sbr) esbr = 0; /* AAC-LC streams decode the same either way */
+  const int out_ch = sbr ? 2 : n_ch; /* SBR streams come out in stereo (PS, or the mono column twice); AAC-LC as coded */
+  const int N = ilist.empty() ? copies : (int)datas.size(), rate = hdr.sampling_rate, out_rate = sbr ? 2 * rate : rate, per = sbr ? 2048 : 1024;
+
+
+  /* the split: contiguous stream ranges over the devices, as bench.py --gpus N splits over ranks (a shard without streams is
+     not started: -gpus larger than the batch uses as many devices as there are streams) */
+  const bool list_mode = !ilist.empty();
+  if (gpus > N) gpus = N;
+  std::vector<Shard> shards((size_t)gpus);
+  for (int r = 0; r < gpus; r++) {
+    int lo, hi;
+    shard_range(N, r, gpus, &lo, &hi);
+    shards[(size_t)r].device = device0 + r, shards[(size_t)r].lo = lo, shards[(size_t)r].n = hi - lo;
+  }
+  if (plan) { /* nothing below this line runs: no HIP call has been made */
+    printf("{\"streams\": %d, \"gpus\": %d, \"channels\": %d, \"sbr\": %d, \"esbr\": %d, \"shards\": [", N, gpus, n_ch, sbr, esbr);
+    for (int r = 0; r < gpus; r++)
+      printf("%s{\"device\": %d, \"lo\": %d, \"n\": %d}", r ? ", " : "", shards[(size_t)r].device, shards[(size_t)r].lo, shards[(size_t)r].n);
+    printf("]}\n");
+    return 0;
+  }
+  {
+    int have = 0;
+    HIP(hipGetDeviceCount(&have));
+    if (wrap && have > 0)
+      for (Shard &S : shards) S.device %= have;
+    else if (device0 + gpus > have) {
+      fprintf(stderr, "xaacdec_amd: -device:%d -gpus:%d asks for devices %d..%d, the node has %d\n", device0, gpus, device0, device0 + gpus - 1, have);
+      return 2;
+    }
+  }
+  Job J;
+  J.datas = std::move(datas);
+  J.hdr = hdr;
+  J.n_ch = n_ch, J.sbr = sbr, J.esbr = esbr, J.out_ch = out_ch, J.rate = rate, J.out_rate = out_rate, J.per = per;
+  J.threads = threads, J.verify = verify, J.profile = profile, J.list_mode = list_mode;
+  const auto t_run = std::chrono::steady_clock::now();
+  if (gpus == 1) {
+    decode_shard(J, shards[0]);
+  } else {
+    std::vector<std::thread> team;
+    for (int r = 0; r < gpus; r++) team.emplace_back([&, r] { decode_shard(J, shards[(size_t)r]); });
+    for (auto &t : team) t.join();
+  }
+  const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run).count();
+  long frames = 0, mismatched = 0, first_frames = 0;
+  double parse_s = 0, steady = 0, phase_s[4] = {0, 0, 0, 0};
+  for (const Shard &S : shards) {
+    frames += S.frames, mismatched += S.mismatched, first_frames += S.first_frames;
+    parse_s = S.parse_s > parse_s ? S.parse_s : parse_s;
+    steady = S.steady > steady ? S.steady : steady;
+    for (int k = 0; k < 4; k++) phase_s[k] = S.phase_s[k] > phase_s[k] ? S.phase_s[k] : phase_s[k];
+    /* -verify: every shard's copies were compared with its first one; the shards' first ones with the first shard's */
+    if (verify && !list_mode && &S != &shards[0]) mismatched += S.pcms[0] != shards[0].pcms[0];
+  }
+  const std::vector<int16_t> &pcm = shards[0].pcms[0];
   if (list_mode) {
-    for (size_t i = 0; i < pcms.size(); i++) {
-      std::string base = inputs[i];
+    for (const Shard &S : shards)
+    for (size_t i = 0; i < S.pcms.size(); i++) {
+      std::string base = inputs[(size_t)S.lo + i];
       const size_t slash = base.find_last_of('/');
       if (slash != std::string::npos) base = base.substr(slash + 1);
       const size_t dot = base.find_last_of('.');
       if (dot != std::string::npos) base = base.substr(0, dot);
-      write_wav(odir + "/" + base + ".wav", pcms[i], out_ch, out_rate);
+      write_wav(odir + "/" + base + ".wav", S.pcms[i], out_ch, out_rate);
     }
   } else
   write_wav(out, pcm, out_ch, out_rate);
+  if (!quiet && gpus > 1) { /* (the run's own line stays the last one) */
+    printf("{\"per_gpu_frames_per_s\": [");
+    for (size_t r = 0; r < shards.size(); r++) printf("%s%.1f", r ? ", " : "", shards[r].wall > 0 ? shards[r].frames / shards[r].wall : 0.0);
+    printf("]}\n");
+  }
   if (!quiet)
     printf("{\"frames\": %ld, \"streams\": %d, \"wall_s\": %.4f, \"parse_s\": %.4f, \"frames_per_s\": %.1f, "
            "\"frames_per_s_after_first_step\": %.1f, \"mismatched_copies\": %ld, \"samples\": %zu, \"rate\": %d, \"sbr\": %d, "
-           "\"channels\": %d, \"esbr\": %d}\n",
-           frames, N, wall, parse_s, frames / wall, frames > N && steady > 0 ? (frames - N) / steady : 0.0, mismatched,
-           pcm.size() / out_ch, out_rate, sbr, n_ch, esbr);
+           "\"channels\": %d, \"esbr\": %d, \"gpus\": %d}\n",
+           frames, N, wall, parse_s, frames / wall, frames > first_frames && steady > 0 ? (frames - first_frames) / steady : 0.0, mismatched,
+           pcm.size() / out_ch, out_rate, sbr, n_ch, esbr, gpus);
   if (profile)
     printf("{\"h2d_s\": %.4f, \"kernels_s\": %.4f, \"d2h_s\": %.4f, \"host_pcm_s\": %.4f}\n", phase_s[0], phase_s[1], phase_s[2], phase_s[3]);
   return mismatched ? 3 : 0;

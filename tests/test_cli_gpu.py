@@ -142,3 +142,42 @@ def test_a_batch_mixing_streams_with_and_without_parametric_stereo(flags, tmp_pa
         with wave.open(want) as a, wave.open(str(out / (n + ".wav"))) as b:
             assert (a.getnchannels(), a.getframerate(), a.getnframes()) == (b.getnchannels(), b.getframerate(), b.getnframes()), n
             assert a.readframes(a.getnframes()) == b.readframes(b.getnframes()), n
+
+
+@pytest.mark.parametrize("flags", [(), ("-esbr:0",)], ids=["default", "esbr0"])
+@pytest.mark.parametrize("name", ["mix_aot29_32k", "mix_aot5_48k", "mix_aot2_64k"])
+def test_gpus_flag_shards_the_batch(name, flags, tmp_path):
+    """-gpus:G / -device:k (the native multi-GPU host): with one device the output is today's; the sharded host path -- one
+    thread, HIP context, stream and set of resident states per shard, the parser team shared -- runs here with three shards
+    wrapped onto the box's one device (-wrap_devices) and must write the same PCM for every copy of every shard; asking for
+    devices the node lacks is refused before any work"""
+    one, _, _, _ = run(name, tmp_path, *flags)
+    same, _, info, _ = run(name, tmp_path, "-gpus:1", "-device:0", "-copies:7", "-verify", *flags)
+    assert same == one and info["gpus"] == 1 and info["mismatched_copies"] == 0
+    many, _, info, _ = run(name, tmp_path, "-gpus:3", "-wrap_devices", "-copies:64", "-verify", *flags)
+    assert many == one and info["gpus"] == 3 and info["streams"] == 64 and info["mismatched_copies"] == 0
+    p = subprocess.run([CLI, "-ifile:" + os.path.join(STREAMS, name + ".aac"), "-ofile:" + str(tmp_path / "x.wav"), "-copies:64",
+                        "-gpus:64", *flags], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and "asks for devices" in p.stderr
+
+
+def test_gpus_flag_with_a_list(tmp_path):
+    """-ilist + -gpus: every stream's WAV comes out of the shard that owns it"""
+    names = ("mix_aot5_48k", "harm_aot5_48k", "mix_aot5_48k")
+    src = []
+    for i, n in enumerate(names):             # distinct file names for the same stream
+        dst = tmp_path / ("s%d_%s.aac" % (i, n))
+        dst.write_bytes(open(os.path.join(STREAMS, n + ".aac"), "rb").read())
+        src.append(str(dst))
+    lst = tmp_path / "list.txt"
+    lst.write_text("\n".join(src) + "\n")
+    out = tmp_path / "out"
+    out.mkdir()
+    p = subprocess.run([CLI, "-ilist:" + str(lst), "-odir:" + str(out), "-gpus:2", "-wrap_devices", "-esbr:0"], capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-500:]
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "decoder_ref.npz"))
+    for i, n in enumerate(names):
+        k = GOLD_ORDER.index(n)
+        with wave.open(str(out / ("s%d_%s.wav" % (i, n)))) as w:
+            assert zlib.crc32(w.readframes(w.getnframes())) & 0xffffffff == int(gold["crc"][k]), n   # ("crc": the -esbr:0 output)
