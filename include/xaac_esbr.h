@@ -2,8 +2,9 @@
  * xaac_esbr.h -- boundary formats of the eSBR ("Path A", the reference's default -esbr:1) SBR tool for HE-AAC streams:
  * what ixheaacd_sbr_dec's Path A branch (decoder/ixheaacd_sbr_dec.c:816-1009) reads beyond xaac_sbr_header /
  * xaac_sbr_frame (xaac_sbr.h), and the per-channel state it keeps between frames.
- * Scope: 2:1 SBR of AAC-LC cores (usac_flag = 0), with or without parametric stereo, LPP or harmonic patching (the QMF
- * transposer of xaac_hbe.h), pre-flattening of LPP patches: no PVC, no MPS.
+ * Scope: 2:1 SBR of AAC-LC cores (usac_flag = 0), with or without parametric stereo, and of USAC channels (usac_flag = 1,
+ * stereoConfigIndex 0: the reference's USAC front end hands its core samples and SBR side info to the same seam), LPP or
+ * harmonic patching (the QMF transposer of xaac_hbe.h), pre-flattening of LPP patches, inter-TES: no MPS.
  */
 #ifndef XAAC_ESBR_H
 #define XAAC_ESBR_H
@@ -18,7 +19,14 @@
 #define XAAC_ESBR_OUT_HIST_ROWS 8 /* op_delay 6 + SBR_HF_ADJ_OFFSET 2 rows of sbr_qmf_out_real/_imag kept */
 #define XAAC_ESBR_ROWS (XAAC_ESBR_HIST_ROWS + 32)
 
-enum { XAAC_ESBR_HARMONIC = 1, XAAC_ESBR_PRE_FLATTEN = 2 }; /* bits of xaac_esbr_side::harmonic_sbr */
+/* bits of xaac_esbr_side::harmonic_sbr.  XAAC_ESBR_USAC: header usac_flag -- the clearing of the history rows above the old
+   cross-over band is an AAC-only step (sbr_dec.c:868-874).  XAAC_ESBR_NO_X_DELAY: codec_x_delay = 0 (sbr_dec.c:819-826: a USAC
+   channel without a harmonic transposer): the frame's 32 analysis rows are rows 8..39 of the QMF buffer, not rows 40..71 --
+   the tools work six slots behind the analysis bank instead of thirty-eight, the state keeps eight history rows (rows 8..39
+   of qmf_re / qmf_im are zero between frames, as in the reference's buffer).  XAAC_ESBR_SKIP_ADJUST: the frame's sbr_mode is
+   not ORIG_SBR (UNKNOWN_SBR in a USAC channel's first frames): the HF generator runs, the envelope adjuster only does its
+   reset and its end-of-frame bookkeeping (esbr_envcal.c:646: every envelope's work is inside `if (sbr_mode == ORIG_SBR)`). */
+enum { XAAC_ESBR_HARMONIC = 1, XAAC_ESBR_PRE_FLATTEN = 2, XAAC_ESBR_USAC = 4, XAAC_ESBR_NO_X_DELAY = 8, XAAC_ESBR_SKIP_ADJUST = 16 };
 
 /* Per-frame side info: ia_sbr_header_data_struct / ia_freq_band_data_struct / ia_sbr_frame_info_data_struct members
  * (decoder/ixheaacd_env_extr_part.h:33-100, ixheaacd_env_extr.h:54-120) the float path reads and the fixed path does not. */

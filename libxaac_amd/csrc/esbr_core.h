@@ -472,9 +472,12 @@ FX_HD void xe_generate_hf(const XsCx &cx, const xaac_sbr_header *h, const xaac_s
     }
     w->bw_array[i] = bw;
   }
+  /* sbrdec_lpfuncs.c:1065 / :1252: harmonic patches need sbr_patching_mode 0 AND a transposer (hbe_flag); a USAC channel without
+     one (XAAC_ESBR_NO_X_DELAY) carries sbr_patching_mode 0 in every FD frame and takes the LPP patches */
+  const bool harmonic = (sd->harmonic_sbr & XAAC_ESBR_HARMONIC) && !(sd->harmonic_sbr & XAAC_ESBR_NO_X_DELAY);
   XS_ONE {
     w->err = 0;
-    if (!(sd->harmonic_sbr & XAAC_ESBR_HARMONIC)) xe_build_patches(h, sd, st, w);
+    if (!harmonic) xe_build_patches(h, sd, st, w);
     else if (!HARM || !ph) w->err = -1; /* no transposer behind this channel */
   }
   XS_PAR(k, usb, 64)
@@ -483,7 +486,7 @@ FX_HD void xe_generate_hf(const XsCx &cx, const xaac_sbr_header *h, const xaac_s
       dst.i(l, k) = 0.0f;
     }
   if constexpr (HARM) {
-    if (sd->harmonic_sbr & XAAC_ESBR_HARMONIC) {
+    if (harmonic) {
       cx.sync();
       if (w->err) return;
       xe_harmonic_patch(cx, h, st, w, dst, *ph, start, end, usb, num_if);
@@ -681,9 +684,13 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
   cx.sync();
   if (w->err) return -1;
   int kk = 0, next = -1, m = 0;
+  /* a frame whose sbr_mode is not ORIG_SBR (a USAC channel's first frames: UNKNOWN_SBR) passes the envelopes by: all of an
+     envelope's work sits inside `if (sbr_mode == ORIG_SBR)` (esbr_envcal.c:646-857); the reset above and the bookkeeping below run */
+  const bool skip_adjust = (sd->harmonic_sbr & XAAC_ESBR_SKIP_ADJUST) != 0;
   for (int i = 0; i < num_env; i++) {
     if (kk > XAAC_SBR_MAX_NOISE_ENVELOPES) return -1;
     if (f->border_vec[i] == f->noise_border_vec[kk]) kk++, next++;
+    if (skip_adjust) continue;
     if (next < 0) return -1; /* the reference would read in front of flt_noise_floor */
     const int noise_absc = (i == trans_env || i == st->env_short_flag_prev) ? 1 : 0;
     const int smooth_length = noise_absc ? 0 : smoothing_length;

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
   __shared__ xaac_esbr_side ssd;
   static_assert(sizeof(xaac_sbr_header) % 4 == 0 && sizeof(xaac_sbr_frame) % 4 == 0 && sizeof(xaac_esbr_side) % 4 == 0, "word copies");
   xaac_esbr_state *st = p.state + ch;
+  const float *are = p.ana_re + (size_t)ch * 2048, *aim = p.ana_im + (size_t)ch * 2048;
   float hist_re[8], hist_im[8]; /* sbr_qmf_out's eight rows of history: fetched with the side info, stored below */
   { /* header, frame, side info and the random-phase table: every load in flight before the first LDS store -- one memory
        latency for the lot (as four copies one behind the other they were four, and the history rows a fifth) */
@@ -109,7 +110,6 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
   XE_T(0);
   float *ore = p.out_re + (size_t)ch * XAAC_ESBR_OUT_ROWS * 64, *oim = p.out_im + (size_t)ch * XAAC_ESBR_OUT_ROWS * 64;
   float *rre = p.syn_re + (size_t)ch * XAAC_ESBR_L_ROWS * 64, *rim = p.syn_im + (size_t)ch * XAAC_ESBR_L_ROWS * 64;
-  const float *are = p.ana_re + (size_t)ch * 2048, *aim = p.ana_im + (size_t)ch * 2048;
   const int apply = f->apply_processing != 0;
   int rc = 0;
   if (apply && xe_side_info_bad(h, f, sd)) rc = -1;
@@ -128,7 +128,26 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
     }
   }
   __syncthreads();
-  if (sd->qmf_sb_prev >= 0 && sd->qmf_sb_prev <= 64) xe_hbe_history_clear(cx, st, sd->qmf_sb_prev);
+  /* USAC channels (xaac_esbr.h: XAAC_ESBR_USAC / _NO_X_DELAY): no clearing above the old cross-over band (sbr_dec.c:868); without a
+     transposer the analysis rows of THIS frame are rows 8..39 of the buffer the tools read (codec_x_delay 0, sbr_dec.c:819-826) */
+  const bool no_x_delay = (sd->harmonic_sbr & XAAC_ESBR_NO_X_DELAY) != 0;
+  if (no_x_delay) {
+    for (int j0 = 0; j0 < 32; j0 += 16) {
+      float a[16], b[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        a[j] = lane < 32 ? are[64 * (j0 + j) + lane] : 0.0f;
+        b[j] = lane < 32 ? aim[64 * (j0 + j) + lane] : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        st->qmf_re[8 + j0 + j][lane] = a[j];
+        st->qmf_im[8 + j0 + j][lane] = b[j];
+      }
+    }
+    __syncthreads();
+  }
+  if (!(sd->harmonic_sbr & XAAC_ESBR_USAC) && sd->qmf_sb_prev >= 0 && sd->qmf_sb_prev <= 64) xe_hbe_history_clear(cx, st, sd->qmf_sb_prev);
   XE_T(1);
   const XeMat src = {&st->qmf_re[0][0] + 128, &st->qmf_im[0][0] + 128}, dst = {ore + 128, oim + 128};
   /* the harmonic transposer's rows (sbr_dec.c:859-868): its launches wrote rows 8..39 of the scratch matrix for this frame
@@ -221,10 +240,11 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
       st->out_re[r][lane] = u0[r];
       st->out_im[r][lane] = u1[r];
     }
+    /* (codec_x_delay 0: the analysis rows were this frame's rows 8..39 and are not history; the reference's rows 40..71 stay zero) */
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-      st->qmf_re[8 + j][lane] = a[j];
-      st->qmf_im[8 + j][lane] = b[j];
+      st->qmf_re[8 + j][lane] = no_x_delay ? 0.0f : a[j];
+      st->qmf_im[8 + j][lane] = no_x_delay ? 0.0f : b[j];
     }
 #pragma unroll
     for (int j = 0; j < 16; j++) {
@@ -233,8 +253,8 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
     }
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-      st->qmf_re[24 + j][lane] = a[j];
-      st->qmf_im[24 + j][lane] = b[j];
+      st->qmf_re[24 + j][lane] = no_x_delay ? 0.0f : a[j];
+      st->qmf_im[24 + j][lane] = no_x_delay ? 0.0f : b[j];
     }
   }
 #ifdef XE_PROFILE

@@ -79,7 +79,10 @@ int xo_esbr_sbr_frame_hbe(const float *core, const xaac_sbr_header *h, const xaa
   XO_MATRIX float qre[XAAC_ESBR_ROWS][64], qim[XAAC_ESBR_ROWS][64], ore[42][64], oim[42][64];
   XO_MATRIX float rre[38][64], rim[38][64], xre[32][64], xim[32][64];
   int rc = 0;
-  if (sd->qmf_sb_prev >= 0 && sd->qmf_sb_prev <= 64) {
+  /* USAC channels (xaac_esbr.h): no clearing above the old cross-over band (sbr_dec.c:868); codec_x_delay 0 without a transposer
+     (sbr_dec.c:819-826): the frame's analysis rows are rows 8..39 of the buffer, rows 40..71 stay what they were (zero) */
+  const int ana_row = (sd->harmonic_sbr & XAAC_ESBR_NO_X_DELAY) ? XAAC_ESBR_OUT_HIST_ROWS : XAAC_ESBR_HIST_ROWS;
+  if (!(sd->harmonic_sbr & XAAC_ESBR_USAC) && sd->qmf_sb_prev >= 0 && sd->qmf_sb_prev <= 64) {
     const XsCx cx = {0, 1};
     xe_hbe_history_clear(cx, st, sd->qmf_sb_prev);
   }
@@ -87,11 +90,15 @@ int xo_esbr_sbr_frame_hbe(const float *core, const xaac_sbr_header *h, const xaa
   memcpy(qim, st->qmf_im, sizeof(st->qmf_im));
   memset(qre + XAAC_ESBR_HIST_ROWS, 0, sizeof(float) * 32 * 64);
   memset(qim + XAAC_ESBR_HIST_ROWS, 0, sizeof(float) * 32 * 64);
+  if (ana_row != XAAC_ESBR_HIST_ROWS) {
+    memset(qre + ana_row, 0, sizeof(float) * 32 * 64);
+    memset(qim + ana_row, 0, sizeof(float) * 32 * 64);
+  }
   memset(ore, 0, sizeof(ore));
   memset(oim, 0, sizeof(oim));
   memcpy(ore, st->out_re, sizeof(st->out_re));
   memcpy(oim, st->out_im, sizeof(st->out_im));
-  xo_esbr_analysis(core, st->ana.ring, &st->ana.pos, &st->ana.win_off, &qre[XAAC_ESBR_HIST_ROWS][0], &qim[XAAC_ESBR_HIST_ROWS][0]);
+  xo_esbr_analysis(core, st->ana.ring, &st->ana.pos, &st->ana.win_off, &qre[ana_row][0], &qim[ana_row][0]);
   bool have_ph = false;
   if (hst && f->apply_processing) { /* sbr_dec.c:882-909: the frame's 32 new analysis rows through the transposer */
     memcpy(phr, st->ph_re, sizeof(st->ph_re));

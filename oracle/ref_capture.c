@@ -74,7 +74,8 @@ static void chain_core(int run, int chain, int step, float *dst) {
 static int esbr_path(const ia_sbr_dec_struct *d, const ia_sbr_header_data_struct *h, const ia_sbr_frame_info_data_struct *f,
                      const ia_ps_dec_struct *ps, const ia_sbr_qmf_filter_bank_struct *synth_r, FLAG drc_on, WORD32 aot,
                      WORD32 ldmps, WORD32 mps) {
-  return h->enh_sbr && aot != AOT_ER_AAC_ELD && aot != AOT_ER_AAC_LD && !h->usac_flag && h->hbe_flag && d->p_hbe_txposer != NULL &&
+  return h->enh_sbr && aot != AOT_ER_AAC_ELD && aot != AOT_ER_AAC_LD &&
+         (h->usac_flag ? ((!h->hbe_flag || d->p_hbe_txposer != NULL) && f->stereo_config_idx == 0) : (h->hbe_flag && d->p_hbe_txposer != NULL)) &&
          !h->esbr_hq &&
          (h->channel_mode == PS_STEREO ? (ps != NULL && synth_r != NULL && !ps->use_34_st_bands && !ps->use_pca_rot_flg && ps->ps_mode == 0)
                                        : !h->enh_sbr_ps) &&
@@ -118,7 +119,8 @@ static WORD32 esbr_chain_call(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_he
   d->str_synthesis_qmf_bank.filter_pos_syn_32 += q->esbr_qmf_c - d->str_synthesis_qmf_bank.p_filter_32;
   d->str_synthesis_qmf_bank.p_filter_32 = q->esbr_qmf_c;
   to_esbr_state(d, h, f, &est);
-  to_hbe_state(d->p_hbe_txposer, &hbs);
+  if (h->hbe_flag && d->p_hbe_txposer) to_hbe_state(d->p_hbe_txposer, &hbs);
+  else memset(&hbs, 0, sizeof(hbs)); /* (a USAC channel without a harmonic transposer) */
   if (eps) to_esbr_ps_state(ps, synth_r, &epss);
   for (c = n_chains - 1; c >= 0 && chains[c] != d; c--) {}
   /* the decoder's own layers may touch the state between two calls (sync-state changes, header resets re-create the
@@ -162,7 +164,7 @@ static WORD32 esbr_chain_call(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_he
       for (i = 0; i < fb->num_sf_bands[1]; i++) f->add_harmonics[i] = 0;
     if (rnd(3) == 0)
       for (i = 0; i < f->str_frame_info_details.num_env; i++) f->inter_temp_shape_mode[i] = (WORD32)rnd(2);
-    if (rnd(4) != 0) { /* harmonic patching on / off, with and without a pitch (env_extr.c:610-632: 7 bits) */
+    if (h->hbe_flag && rnd(4) != 0) { /* harmonic patching on / off, with and without a pitch (env_extr.c:610-632: 7 bits) */
       f->sbr_patching_mode = (WORD32)rnd(2);
       f->pitch_in_bins = f->sbr_patching_mode == 0 && rnd(2) ? (WORD32)rnd(128) : 0;
     }
@@ -213,7 +215,8 @@ static WORD32 esbr_chain_call(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_he
   ret = __real_ixheaacd_sbr_dec(d, time_data, h, f, p, ps, synth_r, sf_r, apply, low_pow, work, tabs, common, ch_fac, pvc,
                                 drc_on, drc, aot, ldmps, self, mps, ec);
   to_esbr_state(d, h, f, &est);
-  to_hbe_state(d->p_hbe_txposer, &hbs);
+  if (h->hbe_flag && d->p_hbe_txposer) to_hbe_state(d->p_hbe_txposer, &hbs);
+  else memset(&hbs, 0, sizeof(hbs));
   if (seed && apply) {
     h->limiter_gains = h_keep.limiter_gains;
     h->interpol_freq = h_keep.interpol_freq;
@@ -335,6 +338,9 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
   if (getenv("XAAC_ESBR_CHAIN_FILE") && esbr_path(d, h, f, ps, synth_r, drc_on, aot, ldmps, mps))
     return esbr_chain_call(d, time_data, h, f, p, ps, synth_r, sf_r, apply, low_pow, work, tabs, common, ch_fac, pvc, drc_on, drc,
                            aot, ldmps, self, mps, ec);
+  if (getenv("XAAC_ESBR_CHAIN_FILE")) /* a chain run: calls outside the chains' branch (a USAC stream's PVC frames) are the reference's own */
+    return __real_ixheaacd_sbr_dec(d, time_data, h, f, p, ps, synth_r, sf_r, apply, low_pow, work, tabs, common, ch_fac, pvc, drc_on,
+                                   drc, aot, ldmps, self, mps, ec);
   if (!g_out) {
     const char *path = getenv("XAAC_CAPTURE_FILE");
     g_out = fopen(path ? path : "/tmp/xaac_capture.bin", "wb");

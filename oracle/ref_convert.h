@@ -299,8 +299,45 @@ static void to_esbr_side(const ia_sbr_header_data_struct *h, const ia_sbr_frame_
   for (i = 0; i < XAAC_SBR_MAX_ENVELOPES; i++) o->inter_temp_shape_mode[i] = f->inter_temp_shape_mode[i];
   memcpy(o->flt_env_sf_arr, f->flt_env_sf_arr, sizeof(o->flt_env_sf_arr));
   memcpy(o->flt_noise_floor, f->flt_noise_floor, sizeof(o->flt_noise_floor));
-  o->harmonic_sbr = (int16_t)((f->sbr_patching_mode == 0 ? XAAC_ESBR_HARMONIC : 0) | (h->pre_proc_flag ? XAAC_ESBR_PRE_FLATTEN : 0));
+  o->harmonic_sbr = (int16_t)((f->sbr_patching_mode == 0 ? XAAC_ESBR_HARMONIC : 0) | (h->pre_proc_flag ? XAAC_ESBR_PRE_FLATTEN : 0) |
+                              (h->usac_flag ? XAAC_ESBR_USAC : 0) |
+                              (h->usac_flag && !h->hbe_flag ? XAAC_ESBR_NO_X_DELAY : 0) | /* sbr_dec.c:819-826: codec_x_delay */
+                              (f->sbr_mode != ORIG_SBR && f->sbr_mode != PVC_SBR ? XAAC_ESBR_SKIP_ADJUST : 0));
   o->pitch_in_bins = f->pitch_in_bins;
+}
+
+/* USAC, an ORIG_SBR frame served outside the reference: what sbr_dec.c:931-953 and the tail of ixheaacd_sbr_env_calc
+   (esbr_envcal.c:861-899) leave for a PVC frame that may follow -- the PVC decoder's "previous frame" words, the harmonic
+   flags of this and the last frame, the frame grid, the last noise floor.  harm_prev_before: harm_flag_prev as the call found it. */
+static void usac_keep_harm_flags(const ia_sbr_frame_info_data_struct *f, WORD8 *harm_prev_before) {
+  memcpy(harm_prev_before, f->harm_flag_prev, 64);
+}
+static void usac_orig_sbr_bookkeeping(const ia_sbr_header_data_struct *h, ia_sbr_frame_info_data_struct *f, ia_pvc_data_struct *pvc,
+                                      const WORD8 *harm_prev_before) {
+  const ia_freq_band_data_struct *fb = h->pstr_freq_band_data;
+  WORD8 harmonics[64];
+  int i;
+  if (pvc) {
+    pvc->pvc_rate = (UWORD8)h->upsamp_fac;
+    pvc->prev_pvc_flg = 0;
+    pvc->prev_first_bnd_idx = fb->sub_band_start;
+    pvc->prev_pvc_rate = pvc->pvc_rate;
+  }
+  memset(harmonics, 0, sizeof(harmonics));
+  for (i = 0; i < fb->num_sf_bands[1]; i++) {
+    const int t = ((fb->freq_band_tbl_hi[i + 1] + fb->freq_band_tbl_hi[i]) - (fb->sub_band_start << 1)) >> 1;
+    if (t >= 0 && t < 64) harmonics[t] = (WORD8)f->add_harmonics[i];
+  }
+  for (i = 0; i < 64; i++) {
+    f->harm_flag_varlen_prev[i] = harm_prev_before[i];
+    f->harm_flag_varlen[i] = harmonics[i];
+  }
+  memcpy(&f->str_frame_info_prev, &f->str_frame_info_details, sizeof(ia_frame_info_struct));
+  if (f->str_frame_info_details.num_env == 1) f->var_len_id_prev = 0;
+  else if (f->str_frame_info_details.num_env == 2) f->var_len_id_prev = 1;
+  if (f->str_frame_info_details.num_noise_env >= 1 && f->str_frame_info_details.num_noise_env <= 2)
+    for (i = 0; i < fb->num_nf_bands; i++)
+      f->prev_noise_level[i] = f->flt_noise_floor[(f->str_frame_info_details.num_noise_env - 1) * fb->num_nf_bands + i];
 }
 
 /* the state as the call finds it: this library's rows 0.. are the rows the reference is about to move down from row 32 */

@@ -42,7 +42,7 @@ static struct {
   void *ews;
 } g;
 static long g_eld_ana_calls, g_eld_syn_calls;
-static long g_imdct_calls, g_sbr_calls, g_lim_calls, g_esbr_calls, g_esbr_harm_calls, g_imdct960_calls, g_imdct_ld_calls;
+static long g_imdct_calls, g_sbr_calls, g_lim_calls, g_esbr_calls, g_esbr_harm_calls, g_esbr_usac_calls, g_sbr_ref_calls, g_imdct960_calls, g_imdct_ld_calls;
 static struct { int32_t *overlap; int16_t *pcm; uint8_t *shape; } gl; /* AAC-LD / ELD: 3 x 512 overlap words, 512 samples, 2 bytes */
 
 static void die(const char *what) {
@@ -59,6 +59,7 @@ static void report(void) {
   fprintf(stderr, "xaacdec_dropin: %ld peak_limiter_process calls ran on the GPU\n", g_lim_calls);
   fprintf(stderr, "xaacdec_dropin: %ld sbr_dec calls took the eSBR (Path A) branch on the GPU\n", g_esbr_calls);
   fprintf(stderr, "xaacdec_dropin: %ld of them with harmonic patching (the QMF transposer's output)\n", g_esbr_harm_calls);
+  fprintf(stderr, "xaacdec_dropin: %ld of them for USAC channels, %ld sbr_dec calls left to the reference\n", g_esbr_usac_calls, g_sbr_ref_calls);
 }
 
 static void setup(void) {
@@ -94,7 +95,7 @@ static void setup(void) {
   HIP(hipMalloc((void **)&gl.overlap, 3 * 512 * 4));
   HIP(hipMalloc((void **)&gl.pcm, 512 * 2));
   HIP(hipMalloc((void **)&gl.shape, 2));
-  atexit(report);
+  if (!g_sbr_ref_calls) atexit(report);
 }
 
 /* developer aid: the numeric code behind the command-line tool's "error unlisted" */
@@ -434,7 +435,11 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
      at sbr_dec.c:816-1009 does for such a channel -- history shift, analysis, HF generator, envelope adjuster,
      regrouping, synthesis -- is one xaac_esbr_sbr_process_batch call; the state lives in the reference's structs
      between calls (to_esbr_state / from_esbr_state) */
-  if (h->enh_sbr && aot != AOT_ER_AAC_ELD && aot != AOT_ER_AAC_LD && !h->usac_flag && h->hbe_flag && d->p_hbe_txposer != NULL && !h->esbr_hq &&
+  /* USAC channels (stereoConfigIndex 0, ORIG_SBR frames) come through the same branch: with a transposer like the AAC ones,
+     without one with codec_x_delay 0 (sbr_dec.c:819-826; xaac_esbr.h: XAAC_ESBR_USAC / _NO_X_DELAY) */
+  if (h->enh_sbr && aot != AOT_ER_AAC_ELD && aot != AOT_ER_AAC_LD && !h->esbr_hq &&
+      (h->usac_flag ? ((!h->hbe_flag || d->p_hbe_txposer != NULL) && f->stereo_config_idx == 0 && !getenv("XAAC_DROPIN_NO_USAC"))
+                    : (h->hbe_flag && d->p_hbe_txposer != NULL)) &&
       (h->channel_mode == PS_STEREO ? (ps != NULL && synth_r != NULL && !ps->use_34_st_bands && !ps->use_pca_rot_flg && ps->ps_mode == 0)
                                     : !h->enh_sbr_ps) &&
       !drc_on && !ldmps && !mps && !f->mps_sbr_flag && f->sbr_mode != PVC_SBR &&
@@ -444,6 +449,7 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     static xaac_esbr_state est;
     static xaac_esbr_ps_state epss;
     static xaac_hbe_state hbs;
+    static WORD8 usac_harm_prev[64];
     xaac_esbr_sbr_batch b;
     const ia_qmf_dec_tables_struct *q = tabs->qmf_dec_tables_ptr;
     const int eps = h->channel_mode == PS_STEREO;
@@ -466,8 +472,10 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     /* the channel's harmonic transposer: the reference runs it on every processed frame of such a stream
        (sbr_dec.c:882-909) and frames with sbr_patching_mode 0 (ENHSBR payload) take the HF generator's input from it;
        pre-flattening (pre_proc_flag) only acts on LPP patches (sbrdec_lpfuncs.c:1220), so it is moot for those frames */
-    to_hbe_state(d->p_hbe_txposer, &hbs);
-    HIP(hipMemcpy(g.hbe, &hbs, sizeof(hbs), hipMemcpyHostToDevice));
+    if (h->hbe_flag) {
+      to_hbe_state(d->p_hbe_txposer, &hbs);
+      HIP(hipMemcpy(g.hbe, &hbs, sizeof(hbs), hipMemcpyHostToDevice));
+    }
     HIP(hipMemcpy(g.core, d->time_sample_buf, 4096, hipMemcpyHostToDevice));
     memset(&b, 0, sizeof(b));
     b.n_ch = 1;
@@ -489,7 +497,8 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     b.status = g.status;
     b.workspace = g.ews;
     b.workspace_bytes = xaac_esbr_workspace_bytes(1);
-    b.hbe_state = g.hbe;
+    b.hbe_state = h->hbe_flag ? g.hbe : NULL;
+    if (h->usac_flag) usac_keep_harm_flags(f, usac_harm_prev);
     if (xaac_esbr_sbr_process_batch(g_ctx, &b) != XAAC_OK || xaac_sync(g_ctx) != XAAC_OK) die("xaac_esbr_sbr_process_batch");
     HIP(hipMemcpy(&status, g.status, 4, hipMemcpyDeviceToHost));
     if (status && getenv("XAAC_DROPIN_DEBUG")) {
@@ -503,10 +512,11 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     HIP(hipMemcpy(&est, g.estate, sizeof(est), hipMemcpyDeviceToHost));
     HIP(hipMemcpy(d->time_sample_buf, g.time, 8192, hipMemcpyDeviceToHost));
     from_esbr_state(&est, d, h, f);
-    if (apply) {
+    if (apply && h->hbe_flag) {
       HIP(hipMemcpy(&hbs, g.hbe, sizeof(hbs), hipMemcpyDeviceToHost));
       from_hbe_state(&hbs, d->p_hbe_txposer, h);
     }
+    if (h->usac_flag && apply && !f->mps_sbr_flag) usac_orig_sbr_bookkeeping(h, f, pvc, usac_harm_prev);
     if (eps) { /* right channel out, PS state back, and what the second synthesis call leaves in channel 1's frame data */
       HIP(hipMemcpy(&epss, g.epss, sizeof(epss), hipMemcpyDeviceToHost));
       HIP(hipMemcpy(ps->time_sample_buf[1], g.time_r, 8192, hipMemcpyDeviceToHost));
@@ -519,6 +529,7 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     f->reset_flag = 0;
     f->prev_sbr_mode = f->sbr_mode;
     g_esbr_calls++;
+    if (h->usac_flag) g_esbr_usac_calls++;
     if (apply && f->sbr_patching_mode == 0) g_esbr_harm_calls++;
     return 0;
   }
@@ -534,6 +545,8 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
   /* outside the paths this library covers (USAC / PS / HBE eSBR, LD/ELD, DRC inside the bank, MPS): the reference's own code */
   if (h->enh_sbr || aot == AOT_ER_AAC_ELD || aot == AOT_ER_AAC_LD || drc_on || ldmps || mps ||
       h->num_time_slots * h->time_step != 32) {
+    if (!g_ctx && !g_sbr_ref_calls) atexit(report); /* (a stream none of whose calls reaches the library still gets its summary) */
+    g_sbr_ref_calls++;
     rc = __real_ixheaacd_sbr_dec(d, time_data, h, f, p, ps, synth_r, sf_r, apply, low_pow, work, tabs, common, ch_fac,
                                  pvc, drc_on, drc, aot, ldmps, self, mps, ec);
     if (rc && getenv("XAAC_DROPIN_DEBUG")) fprintf(stderr, "xaacdec_dropin: the reference's own ixheaacd_sbr_dec returned %d\n", rc);

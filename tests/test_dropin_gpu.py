@@ -96,3 +96,37 @@ def test_other_frame_lengths_through_the_gpu(aac, flags, tmp_path):
         assert int(mb.group(1)) > 100 and int(mb.group(2)) > 100, mb.groups()
     a, b = open(ref_wav, "rb").read(), open(gpu_wav, "rb").read()
     assert len(a) > 100000 and a == b, (len(a), len(b), n960, nld)
+
+
+STREAMS_USAC = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "streams_usac", "*.aac")))
+
+
+@pytest.mark.parametrize("aac", STREAMS_USAC, ids=[os.path.basename(s) for s in STREAMS_USAC])
+def test_usac_streams_esbr_through_the_gpu(aac, tmp_path):
+    """USAC (xHE-AAC) streams made by the reference encoder (tools/make_golden_streams.py: -aot:42; stereo 2:1 eSBR without
+    and with harmonic SBR, a switched FD / LPD core, mono streams whose LPD frames use PVC, 4:1 eSBR): the reference's own
+    USAC front end -- arithmetic decoder, LPD, stereo tools, all CPU -- hands its core samples and SBR side info to the same
+    ixheaacd_sbr_dec seam, and every ORIG_SBR 2:1 call of it runs on the GPU (xaac_esbr_sbr_process_batch with the
+    XAAC_ESBR_USAC / _NO_X_DELAY / _SKIP_ADJUST side flags); PVC frames and 4:1 streams stay the reference's.  The decoded
+    file is byte-identical to the unmodified decoder's."""
+    if not (os.path.exists(os.path.join(REF, "xaacdec")) and os.path.exists(os.path.join(REF, "xaacdec_dropin"))):
+        pytest.fail("oracle/_ref/xaacdec[_dropin] missing: the reference binaries did not travel with the snapshot")
+    extra = ("-mp4:1", "-imeta:" + aac[:-4] + ".txt")
+    ref_wav, gpu_wav = str(tmp_path / "ref.wav"), str(tmp_path / "gpu.wav")
+    _decode("xaacdec", aac, ref_wav, extra=extra)
+    log = _decode("xaacdec_dropin", aac, gpu_wav, extra=extra)
+    m = re.search(r"(\d+) of them for USAC channels, (\d+) sbr_dec calls left to the reference", log)
+    assert m, log[-600:]
+    on_gpu, left = int(m.group(1)), int(m.group(2))
+    name = os.path.basename(aac)
+    if name.startswith("u41"):          # 4:1 eSBR: not covered, all the reference's
+        assert on_gpu == 0 and left > 30
+    elif "pvc" in name:                 # ORIG_SBR frames on the GPU, PVC frames the reference's (m21tdpvc: every frame is PVC)
+        assert on_gpu + left > 30 and (on_gpu > 0 or "td" in name)
+    else:
+        assert on_gpu > 60 and left == 0, (on_gpu, left)
+    if "harm" in name:
+        mh = re.search(r"(\d+) of them with harmonic patching", log)
+        assert mh and int(mh.group(1)) > 20, log[-600:]
+    a, b = open(ref_wav, "rb").read(), open(gpu_wav, "rb").read()
+    assert len(a) > 100000 and a == b, (len(a), len(b), on_gpu, left)

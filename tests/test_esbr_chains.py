@@ -22,7 +22,18 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from make_golden_esbr_chains import chain_core  # noqa: E402  (the generator's own input function: data, not reference code)
 
 PF = ctypes.POINTER(ctypes.c_float)
-CH = np.load(os.path.join(ROOT, "tests", "golden", "esbr_chains.npz"))
+FIXTURES = {"aac": np.load(os.path.join(ROOT, "tests", "golden", "esbr_chains.npz")),
+            # the same chains for USAC channels (tools/make_golden_esbr_chains.py usac: stereo 2:1 eSBR with codec_x_delay 0, with the
+            # harmonic transposer, a switched FD / LPD core's and a PVC stream's ORIG_SBR frames; 1482 calls in 78 chains)
+            "usac": np.load(os.path.join(ROOT, "tests", "golden", "esbr_usac_chains.npz"))}
+CH = FIXTURES["aac"]
+NO_X_DELAY, USAC = 8, 4     # include/xaac_esbr.h: bits of xaac_esbr_side::harmonic_sbr
+
+
+def chain_has_transposer(CH, rows):
+    """a USAC channel without a harmonic transposer (XAAC_ESBR_NO_X_DELAY in its side info) is run without an hbe_state"""
+    from esbr_structs import EsbrSide
+    return not (int(CH["side"][rows[0]].view(np.int16)[EsbrSide.harmonic_sbr.offset // 2]) & NO_X_DELAY)
 
 
 def crc(a):
@@ -51,7 +62,7 @@ def state_crc(st, header, frame, apply):
     return crc(b)
 
 
-def steps_of_chains():
+def steps_of_chains(CH=CH):
     sc, si = CH["step_chain"], CH["step_idx"]
     order = [np.nonzero(sc == c)[0] for c in range(len(CH["chain_len"]))]
     for c, rows in enumerate(order):
@@ -70,19 +81,31 @@ def test_fixture_is_what_it_says():
     assert (CH["chain_ps"] != 0).sum() >= 4
 
 
-def test_oracle_walks_the_reference_chains(oracle):
+def test_usac_fixture_is_what_it_says():
+    U = FIXTURES["usac"]
+    from esbr_structs import EsbrSide
+    flags = U["side"].view(np.int16)[:, EsbrSide.harmonic_sbr.offset // 2]
+    assert U["ret"].size >= 1000 and not U["ret"].any() and (flags & USAC).all()
+    assert ((flags & NO_X_DELAY) != 0).sum() > 500 and ((flags & NO_X_DELAY) == 0).sum() > 200      # without / with a transposer
+    assert ((flags & 1) != 0).sum() > 100                                                            # harmonic patching frames
+
+
+@pytest.mark.parametrize("which", ["aac", "usac"])
+def test_oracle_walks_the_reference_chains(oracle, which):
+    CH = FIXTURES[which]
     fn = oracle.lib.xo_esbr_sbr_frame_hbe
     fn.restype = ctypes.c_int
     fn.argtypes = [PF] + [ctypes.c_void_p] * 6 + [PF, PF, ctypes.c_void_p]
-    for c, rows in enumerate(steps_of_chains()):
+    for c, rows in enumerate(steps_of_chains(CH)):
         run, cid, eps = int(CH["chain_run"][c]), int(CH["chain_id"][c]), bool(CH["chain_ps"][c])
         st, hb, ps = CH["est0"][c].copy(), CH["hbs0"][c].copy(), CH["eps0"][c].copy()
+        with_hb = chain_has_transposer(CH, rows)
         for s, r in enumerate(rows):
             core = np.ascontiguousarray(chain_core(run, cid, s))
             out, out_r = np.zeros(2048, np.float32), np.zeros(2048, np.float32)
             h, f, sd, pf = (np.ascontiguousarray(CH[k][r]) for k in ("header", "frame", "side", "ps_frame"))
             rc = fn(core.ctypes.data_as(PF), vp(h), vp(f), vp(sd), vp(st), vp(pf) if eps else None, vp(ps) if eps else None,
-                    out.ctypes.data_as(PF), out_r.ctypes.data_as(PF) if eps else None, vp(hb))
+                    out.ctypes.data_as(PF), out_r.ctypes.data_as(PF) if eps else None, vp(hb) if with_hb else None)
             want = CH["crc"][r]
             assert rc == CH["ret"][r], (c, s)
             assert crc(out) == want[0], ("out", c, s)
@@ -95,15 +118,21 @@ def test_oracle_walks_the_reference_chains(oracle):
 
 
 @pytest.mark.gpu
-def test_gpu_walks_the_reference_chains():
+@pytest.mark.parametrize("which", ["aac", "usac"])
+def test_gpu_walks_the_reference_chains(which):
     import torch
     import libxaac_amd
+    CH = FIXTURES[which]
     ctx = libxaac_amd.XaacContext(0, 0)
     dev = torch.device("cuda:0")
-    order = steps_of_chains()
-    for with_ps in (False, True):      # the PS streams form their own batch (ps_frame / ps_state / out_r are per launch)
-        chains = [c for c in range(len(order)) if bool(CH["chain_ps"][c]) == with_ps]
+    order = steps_of_chains(CH)
+    # the PS streams form their own batch (ps_frame / ps_state / out_r are per launch), and so do the channels without a
+    # harmonic transposer (hbe_state is per launch)
+    for with_ps, with_hb in ((False, True), (True, True), (False, False)):
+        chains = [c for c in range(len(order)) if bool(CH["chain_ps"][c]) == with_ps and chain_has_transposer(CH, order[c]) == with_hb]
         n = len(chains)
+        if n == 0:
+            continue
         t_st = torch.from_numpy(np.ascontiguousarray(CH["est0"][chains])).to(dev)
         t_hb = torch.from_numpy(np.ascontiguousarray(CH["hbs0"][chains])).to(dev)
         t_ps = torch.from_numpy(np.ascontiguousarray(CH["eps0"][chains])).to(dev) if with_ps else None
@@ -121,7 +150,8 @@ def test_gpu_walks_the_reference_chains():
             status = torch.full((m,), 7, dtype=torch.int32, device=dev)
             ws = torch.zeros(ctx.esbr_workspace_bytes(m), dtype=torch.uint8, device=dev)
             ctx.esbr_sbr_process_batch(core, g("header"), g("frame"), g("side"), st, out, ws, status,
-                                       ps_frame=g("ps_frame") if with_ps else None, ps_state=ps, out_r=out_r, hbe_state=hb)
+                                       ps_frame=g("ps_frame") if with_ps else None, ps_state=ps, out_r=out_r,
+                                       hbe_state=hb if with_hb else None)
             ctx.sync()
             t_st[idx], t_hb[idx] = st, hb
             if with_ps:

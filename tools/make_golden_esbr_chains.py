@@ -26,6 +26,12 @@ from make_golden_sbr_chains import chain_pcm  # noqa: E402
 # to the other streams, with inter-TES)
 STREAMS = ("mix_aot5_48k", "mono_aot5_32k", "mix_aot29_32k", "harm_aot5_48k")
 PASSES = 10           # decoder runs per stream; pass 0 is unfuzzed
+# `python tools/make_golden_esbr_chains.py usac` -> tests/golden/esbr_usac_chains.npz: the same chains for USAC channels
+# (tests/golden/streams_usac, raw access units + the encoder's frame-size list: xaacdec -mp4:1 -imeta:) -- stereo 2:1 eSBR
+# without a harmonic transposer (codec_x_delay 0: xaac_esbr.h XAAC_ESBR_NO_X_DELAY), with one (sbr_patching_mode 0 frames),
+# a switched FD / LPD core (the ORIG_SBR frames of it)
+USAC_STREAMS = ("u21", "u21harm", "u21sw", "m21swpvc")
+USAC_PASSES = 6
 
 
 def chain_core(run, chain, step):
@@ -64,18 +70,19 @@ def parse(path, run, z):
     return recs
 
 
-def main():
+def main(usac=False):
     z = sizes()
     cap = os.path.join(ROOT, "oracle", "_ref", "xaacdec_capture")
     recs = []
     run = 0
-    for p in range(PASSES):
-        for s in STREAMS:
+    for p in range(USAC_PASSES if usac else PASSES):
+        for s in (USAC_STREAMS if usac else STREAMS):
             tmp = "/tmp/xaac_esbr_chain_%d.bin" % run
             env = dict(os.environ, XAAC_ESBR_CHAIN_FILE=tmp, XAAC_ESBR_CHAIN_SEED=str(0 if p == 0 else 100 * p + run),
                        XAAC_ESBR_CHAIN_RUN=str(run))
-            subprocess.run([cap, "-ifile:" + os.path.join(ROOT, "tests", "golden", "streams", s + ".aac"), "-ofile:/tmp/xaac_esbr_chain.wav"],
-                           env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            src = os.path.join(ROOT, "tests", "golden", "streams_usac" if usac else "streams", s + ".aac")
+            args = ["-ifile:" + src, "-ofile:/tmp/xaac_esbr_chain.wav"] + (["-mp4:1", "-imeta:" + src[:-4] + ".txt"] if usac else [])
+            subprocess.run([cap] + args, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
             recs += parse(tmp, run, z)
             os.remove(tmp)
             run += 1
@@ -102,7 +109,7 @@ def main():
             d["hbs0"][i] = u8(r["hbs0"], 0)
             if r["eps"]:
                 d["eps0"][i] = u8(r["eps0"], 0)
-    dst = os.path.join(ROOT, "tests", "golden", "esbr_chains.npz")
+    dst = os.path.join(ROOT, "tests", "golden", "esbr_usac_chains.npz" if usac else "esbr_chains.npz")
     np.savez_compressed(dst, **d)
     from esbr_structs import EsbrSide
     harm = sum(1 for r in recs if r["apply"] and np.frombuffer(r["sd"], np.int16)[EsbrSide.harmonic_sbr.offset // 2] != 0)
@@ -112,4 +119,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(usac=len(sys.argv) > 1 and sys.argv[1] == "usac")
