@@ -14,6 +14,7 @@
 #include "xaac_amd.h"
 #include "xaac_sbr.h"
 #include "xaac_hbe.h"
+#include "xaac_pvc.h"
 
 #define XAAC_ESBR_HIST_ROWS 40 /* op_delay 6 + SBR_HF_ADJ_OFFSET 2 + codec_x_delay 32 rows of qmf_buf_real/_imag kept */
 #define XAAC_ESBR_OUT_HIST_ROWS 8 /* op_delay 6 + SBR_HF_ADJ_OFFSET 2 rows of sbr_qmf_out_real/_imag kept */
@@ -67,6 +68,34 @@ typedef struct xaac_esbr_state {
                                                          the frame's shift (sbr_dec.c:859-868): the transposer's last rows */
 } xaac_esbr_state;
 
+/* ---- PVC frames of USAC channels (sbr_mode == PVC_SBR): what ixheaacd_sbr_dec (sbr_dec.c:931-953: energies of the low band,
+ * ixheaacd_pvc_process) and the PVC branch of ixheaacd_sbr_env_calc (esbr_envcal.c:194-607) read and keep beyond the structs
+ * above.  A batch that hands both in runs PVC frames on the device and keeps the bookkeeping ORIG_SBR frames leave for a
+ * PVC frame that may follow (esbr_envcal.c:861-899, sbr_dec.c:947-953). */
+#define XAAC_ESBR_PVC_COLS 48 /* MAX_FREQ_COEFFS_SBR: time slots a qmapped_pvc row holds */
+enum { XAAC_ESBR_SBR_UNKNOWN = 0, XAAC_ESBR_SBR_ORIG = 1, XAAC_ESBR_SBR_PVC = 2 }; /* SBR_TYPE_ID, ixheaacd_sbrdecoder.h:66 */
+
+typedef struct xaac_esbr_pvc_side {
+  int16_t sbr_mode;                                   /* frame: sbr_mode (XAAC_ESBR_SBR_*) */
+  int16_t sine_position;                              /* frame: sine_position (env_extr.c:288-294; 31 = ESC_SIN_POS) */
+  int16_t sin_start_for_cur_top, sin_len_for_cur_top; /* frame: the sinusoids the frame before started beyond its own end */
+  int16_t border_vec[XAAC_SBR_MAX_ENVELOPES + 1];     /* frame: str_pvc_frame_info.border_vec (PVC time slots) */
+  int16_t freq_res[XAAC_SBR_MAX_ENVELOPES];           /* frame: str_pvc_frame_info.freq_res */
+  int16_t pad_;
+  xaac_pvc_frame pvc;                                 /* the PVC decoder's frame (xaac_pvc.h); read for sbr_mode PVC only */
+} xaac_esbr_pvc_side;
+
+typedef struct xaac_esbr_pvc_state {
+  xaac_pvc_state pvc;                                 /* ia_pvc_data_struct: the decoder's history */
+  float qmapped[64][XAAC_ESBR_PVC_COLS];              /* frame_data: qmapped_pvc */
+  float prev_noise_level[XAAC_SBR_MAX_NOISE_VALUES];  /* frame_data: prev_noise_level */
+  int8_t harm_flag_varlen_prev[64], harm_flag_varlen[64];
+  int16_t prev_freq_res[2];                           /* frame_data: str_frame_info_prev.freq_res[0..1] (var_len_id_prev indexes it) */
+  int16_t var_len_id_prev;
+  int16_t prev_sbr_mode;                              /* frame_data: prev_sbr_mode */
+  int32_t esbr_start_up_pvc;                          /* header: esbr_start_up_pvc; 1 for a new stream */
+} xaac_esbr_pvc_state;
+
 /* Per-stream persistent state of the float parametric-stereo tool (ia_ps_dec_struct's float members,
  * decoder/ixheaacd_ps_dec.h:162-237, 20-band configuration) + the right channel's synthesis bank. */
 typedef struct xaac_esbr_ps_state {
@@ -107,6 +136,9 @@ typedef struct xaac_esbr_sbr_batch {
                                        synth_size, known to the host from xaac_hbe_state_reinit): the banks kernel then takes less
                                        LDS per channel and more channels run per CU; a channel with a larger bank is refused
                                        (status -1).  0: any size. */
+  const xaac_esbr_pvc_side *pvc_side; /* [n_ch], or NULL together with pvc_state: no channel of the batch has PVC frames (a frame
+                                       whose side says sbr_mode PVC is then refused by its XAAC_ESBR_* flags' owner, the host) */
+  xaac_esbr_pvc_state *pvc_state;   /* [n_ch] in/out */
 } xaac_esbr_sbr_batch;
 
 /* The hand-offs on either side of the branch in ixheaacd_dec_execute: the core decoder's PCM16 (after the 32 -> 16 bit

@@ -636,19 +636,268 @@ FX_HD void xe_inter_tes(const XsCx &cx, XeWork *w, const XeMat &low, const XeMat
   cx.sync();
 }
 
+/* ---- ixheaacd_sbr_env_calc, PVC_SBR (esbr_envcal.c:194-607) -----------------------------------------------------------
+   The envelope is the PVC decoder's: one reference energy per band and PVC time slot (= two QMF slots), so gains, limiter and
+   boost are made per time slot; the reference makes them for all of an envelope's slots first and applies them afterwards -- a
+   slot's gains read nothing an earlier slot's application writes (rows 2 t, 2 t + 1 of sbr_qmf_out only), so here slot t is
+   adjusted as soon as its gains exist and the [64][48] work matrices never materialise.  lane = band for the element-wise
+   steps, lane = limiter band for the three sums in band order, as in the ORIG_SBR branch.
+   The frame grids: the noise floor is mapped to qmapped_pvc with the SBR grid (str_frame_info_details), the envelopes walk the
+   PVC grid (pvs->border_vec / freq_res); slots below sin_len_for_cur_top use the previous frame's frequency resolution and
+   the sinusoids that frame announced (harm_flag_varlen).  Returns 0 or -1. */
+FX_HD int xe_env_calc_pvc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
+                          xaac_esbr_state *st, XeWork *w, const XeMat &x, const xaac_esbr_pvc_side *pvs, xaac_esbr_pvc_state *pst,
+                          const float *env_out, int &phase_index, int &harm_index, int &start_up, int &start_up_pvc) {
+  const int sb_start = h->sub_band_start, num_sb = h->sub_band_end - h->sub_band_start;
+  const int num_env = f->num_env, trans_env = f->transient_env, num_nf = h->num_nf_bands;
+  const int smoothing_length = h->smoothing_mode ? 0 : 4, int_mode = h->interpol_freq;
+  const int lim_band = sd->limiter_bands & 3, lim_gains = h->limiter_gains & 3;
+  const double guard = 1e-17;
+  if (!env_out) return -1;
+  /* grids the reference indexes with: its own checks (esbr_envcal.c:234, :283) and the [16][64] envelope's extent */
+  for (int i = 0; i < num_env; i++) {
+    if (f->border_vec[i] < 0 || f->border_vec[i + 1] > XAAC_ESBR_PVC_COLS) return -1;
+    if (pvs->border_vec[i] < 0 || pvs->border_vec[i + 1] > XAAC_PVC_SLOTS) return -1;
+    if ((unsigned)pvs->freq_res[i] > 1u) return -1;
+  }
+  /* (the reference's first loop over an envelope's slots, :299, runs on to sin_len_for_cur_top even past the envelope's end;
+     what it makes there is made again by the next envelope's loops before anything reads it, so each envelope's own slots are
+     all that counts) */
+  if ((unsigned)pst->var_len_id_prev > 1u || (unsigned)pst->prev_freq_res[pst->var_len_id_prev] > 1u) return -1;
+  /* :210-214: the slots in front of this frame's first border are what the frame before mapped beyond its sixteenth */
+  XS_PAR(c, 0, 64)
+    for (int t = 0; t < f->border_vec[0]; t++) pst->qmapped[c][t] = pst->qmapped[c][t + 16];
+  cx.sync();
+  { /* :216-262: the noise floor of every band and slot, on the SBR grid */
+    int kk = 0, next = -1;
+    for (int i = 0; i < num_env; i++) {
+      if (kk > XAAC_SBR_MAX_NOISE_ENVELOPES) return -1;
+      if (f->border_vec[i] == f->noise_border_vec[kk]) kk++, next++;
+      if (next < 0) return -1; /* the reference would read in front of flt_noise_floor */
+      const int res = f->freq_res[i] ? 1 : 0, nsf = h->num_sf_bands[res];
+      const int16_t *ftab = res ? h->freq_band_tbl_hi : h->freq_band_tbl_lo;
+      const int n_bands = ftab[nsf] - ftab[0];
+      XS_PAR(c, 0, n_bands < 64 ? n_bands : 64) {
+        const int kabs = ftab[0] + c;
+        int o = 0;
+        for (int q = 1; q < num_nf; q++) o += kabs >= h->freq_band_tbl_noise[q];
+        const float nf = sd->flt_noise_floor[next * num_nf + o];
+        for (int t = f->border_vec[i]; t < f->border_vec[i + 1]; t++) pst->qmapped[c][t] = nf;
+      }
+    }
+  }
+  cx.sync();
+  int kk = 0, next = -1;
+  for (int i = 0; i < num_env; i++) {
+    if (kk > XAAC_SBR_MAX_NOISE_ENVELOPES) return -1;
+    if (f->border_vec[i] == f->noise_border_vec[kk]) kk++, next++;
+    const int start_pos = pvs->border_vec[i], end_pos = pvs->border_vec[i + 1];
+    int noise_absc = (i == trans_env || i == st->env_short_flag_prev) ? 1 : 0;
+    if (pst->prev_sbr_mode == XAAC_ESBR_SBR_ORIG) noise_absc = 0; /* :294 */
+    const int smooth_length = noise_absc ? 0 : smoothing_length;
+    const float *filt = smooth_length ? xaac_esbr_fir_4 : xaac_esbr_fir_0;
+    for (int t = start_pos; t < end_pos; t++) {
+      const bool tail = t < pvs->sin_len_for_cur_top; /* :299 / :432: the two loops over an envelope's slots */
+      const int res = (tail ? pst->prev_freq_res[pst->var_len_id_prev] : pvs->freq_res[i]) ? 1 : 0, nsf = h->num_sf_bands[res];
+      const int16_t *ftab = res ? h->freq_band_tbl_hi : h->freq_band_tbl_lo;
+      /* which bands' sinusoids count in this slot: the old frame's announcement in its tail, this frame's behind it */
+      XS_PAR(cc, 0, 64)
+        w->own_tone[cc] = (int8_t)(tail ? (pst->harm_flag_varlen[cc] && (t >= pvs->sin_start_for_cur_top || pst->harm_flag_varlen_prev[(cc + sb_start) & 63]))
+                                        : (w->harmonics[cc] && (t >= pvs->sine_position || w->harm_prev[(cc + sb_start) & 63])));
+      cx.sync();
+      XS_PAR(c, 0, num_sb) {
+        const int kabs = sb_start + c;
+        int j = 0, o = 0;
+        for (int q = 1; q < nsf; q++) j += kabs >= ftab[q];
+        const int li = ftab[j], ui = ftab[j + 1];
+        int flag = 0;
+        for (int k = li; k < ui; k++) flag |= w->own_tone[(k - sb_start) & 63];
+        for (int q = 1; q < num_nf; q++) o += kabs >= h->freq_band_tbl_noise[q];
+        w->sfb_first[c] = (int8_t)(li - sb_start);
+        w->sfb_len[c] = (int8_t)(ui - li);
+        w->flag[c] = (int8_t)flag;
+        w->o_idx[c] = (int8_t)o;
+        float nrg = 0; /* :322-327: the slot's two QMF rows */
+        for (int l = 0; l < 2; l++) nrg += (x.r(2 * t + l, kabs) * x.r(2 * t + l, kabs)) + (x.i(2 * t + l, kabs) * x.i(2 * t + l, kabs));
+        w->nrg_est[c] = nrg / 2;
+      }
+      cx.sync();
+      XS_PAR(c, 0, num_sb) {
+        float est = w->nrg_est[c];
+        if (!int_mode) {
+          float nrg = 0;
+          const int n = w->sfb_len[c], c0 = w->sfb_first[c];
+          for (int k = c0; k < c0 + n; k++) nrg += w->nrg_est[k];
+          est = nrg / (float)n;
+        }
+        const float ref = env_out[64 * t + sb_start + c];
+        const float q = pst->qmapped[c][t];
+        const double tmp = q / (1 + q + guard);
+        float gain, tone = 0;
+        if (w->flag[c]) {
+          gain = (float)xe_sqrt(ref * tmp / (est + 1));
+          /* :360-367: this frame's own sinusoid ... */
+          if (w->harmonics[c] && (t >= pvs->sine_position || w->harm_prev[(c + sb_start) & 63])) tone = (float)xe_sqrt(ref * tmp / (q + guard));
+          if (tail) { /* :369-375: ... and, in the tail, the old frame's, over the old noise level */
+            if (pst->harm_flag_varlen[c] && (t >= pvs->sin_start_for_cur_top || pst->harm_flag_varlen_prev[(c + sb_start) & 63]))
+              tone = (float)xe_sqrt(ref * tmp / (pst->prev_noise_level[w->o_idx[c]] + guard));
+          }
+        } else if (noise_absc) {
+          gain = (float)xe_sqrt(ref / (est + 1));
+        } else {
+          gain = (float)xe_sqrt(ref * tmp / ((est + 1) * (q + guard)));
+        }
+        w->nrg_ref[c] = ref;
+        w->nrg_gain[c] = gain;
+        w->nrg_tone[c] = tone;
+        w->noise_level[c] = (float)xe_sqrt(ref * tmp);
+        w->pow_lo[c] = est;
+      }
+      cx.sync();
+      XS_PAR(c, 0, num_sb) w->nrg_est[c] = w->pow_lo[c];
+      cx.sync();
+      /* the limiter (:390-428 / :513-551), as in the ORIG_SBR branch */
+      const int n_lim = st->gate_mode[lim_band] < 12 ? st->gate_mode[lim_band] : 12;
+      XS_PAR(c, 0, n_lim) {
+        const int k0 = w->lim_tab[c], k1r = w->lim_tab[c + 1], k1 = k1r < num_sb ? k1r : num_sb;
+        float p_ref = 0, p_est = 0, g_max = 0;
+        if (k0 >= 0 && k0 <= k1) {
+          for (int k = k0; k < k1; k++) {
+            p_ref += w->nrg_ref[k];
+            p_est += w->nrg_est[k];
+          }
+          const float avg_gain = (float)xe_sqrt((p_ref + 1e-12f) / (p_est + 1e-12f));
+          g_max = avg_gain * xaac_esbr_g_lim_gains[lim_gains];
+          if (g_max > 1.0e5f) g_max = 1.0e5f;
+        }
+        w->lim_pref[c] = p_ref;
+        w->lim_gmax[c] = g_max;
+      }
+      cx.sync();
+      XS_PAR(k, 0, num_sb) {
+        int lb = -1;
+        for (int c = 0; c < n_lim; c++) {
+          const int k0 = w->lim_tab[c], k1r = w->lim_tab[c + 1], k1 = k1r < num_sb ? k1r : num_sb;
+          if (lb < 0 && k0 >= 0 && k >= k0 && k < k1) lb = c;
+        }
+        w->lim_of[k] = (int8_t)lb;
+        float ta = 0.0f, tb = 0.0f;
+        if (lb >= 0) {
+          const float g_max = w->lim_gmax[lb];
+          if (g_max <= w->nrg_gain[k]) {
+            w->noise_level[k] = (float)(w->noise_level[k] * (g_max / (w->nrg_gain[k] + guard)));
+            w->nrg_gain[k] = g_max;
+          }
+          ta = w->nrg_gain[k] * w->nrg_gain[k] * w->nrg_est[k];
+          if (w->nrg_tone[k]) tb = w->nrg_tone[k] * w->nrg_tone[k];
+          else if (!noise_absc) tb = w->noise_level[k] * w->noise_level[k];
+        }
+        w->pow_hi[k] = ta;
+        w->tes_gain[k] = tb;
+      }
+      cx.sync();
+      XS_PAR(c, 0, n_lim) {
+        const int k0 = w->lim_tab[c], k1r = w->lim_tab[c + 1], k1 = k1r < num_sb ? k1r : num_sb;
+        float boost = 1.0f;
+        if (k0 >= 0 && k0 <= k1) {
+          float p_adj = 0;
+          for (int k = k0; k < k1; k++) {
+            p_adj += w->pow_hi[k];
+            p_adj += w->tes_gain[k];
+          }
+          boost = (float)xe_sqrt((w->lim_pref[c] + 1e-12f) / (p_adj + 1e-12f));
+          boost = boost > 1.584893192f ? 1.584893192f : boost;
+        }
+        w->lim_gmax[c] = boost;
+      }
+      cx.sync();
+      XS_PAR(k, 0, num_sb) {
+        const int lb = w->lim_of[k];
+        if (lb >= 0) {
+          const float boost = w->lim_gmax[lb];
+          w->nrg_gain[k] *= boost;
+          w->noise_level[k] *= boost;
+          w->nrg_tone[k] *= boost;
+        }
+      }
+      cx.sync();
+      if (t == start_pos && start_up_pvc) { /* :554-563: the smoothing histories start from the envelope's first slot */
+        XS_PAR(k, 0, num_sb)
+          for (int n = 0; n < 4; n++) {
+            st->e_gain[n][k] = w->nrg_gain[k];
+            st->noise_buf[n][k] = w->noise_level[k];
+          }
+        start_up_pvc = 0;
+        start_up = 0;
+      }
+      cx.sync();
+      XS_PAR(k, 0, 64) { /* :564-606: the slot's two QMF rows; the five-deep histories rotate once per row for all 64 bands */
+        float eg[5], nb[5];
+        for (int n = 0; n < 5; n++) {
+          eg[n] = st->e_gain[n][k];
+          nb[n] = st->noise_buf[n][k];
+        }
+        const bool active = k < num_sb;
+        const float gain = active ? w->nrg_gain[k] : 0.0f, nl = active ? w->noise_level[k] : 0.0f, tone = active ? w->nrg_tone[k] : 0.0f;
+        const bool no_noise = active && (tone != 0 || noise_absc);
+        const int kk2 = sb_start + k, freq_inv = (kk2 & 1) ? -1 : 1;
+        const float hp[2][4] = {{1.0f, 0.0f, -1.0f, 0.0f}, {0.0f, 1.0f, 0.0f, -1.0f}};
+        for (int j = 0; j < 2; j++) {
+          if (active) {
+            eg[4] = gain;
+            nb[4] = nl;
+            float sb_gain = 0, sb_noise = 0;
+            int c = 0;
+            for (int n = 4 - smooth_length; n <= 4; n++) {
+              sb_gain += eg[n] * filt[c];
+              sb_noise += nb[n] * filt[c++];
+            }
+            const int ph = (phase_index + j * num_sb + k + 1) & 511, hi = (harm_index + j) & 3;
+            if (no_noise) sb_noise = 0;
+            const float re = x.r(2 * t + j, kk2), im = x.i(2 * t + j, kk2);
+            x.r(2 * t + j, kk2) = re * sb_gain + sb_noise * XE_RANDOM_PHASE(2 * ph) + tone * hp[0][hi];
+            x.i(2 * t + j, kk2) = im * sb_gain + sb_noise * XE_RANDOM_PHASE(2 * ph + 1) + tone * (float)freq_inv * hp[1][hi];
+          }
+          const float t0 = eg[0], t1 = nb[0];
+          for (int n = 0; n < 4; n++) {
+            eg[n] = eg[n + 1];
+            nb[n] = nb[n + 1];
+          }
+          eg[4] = t0;
+          nb[4] = t1;
+        }
+        for (int n = 0; n < 5; n++) {
+          st->e_gain[n][k] = eg[n];
+          st->noise_buf[n][k] = nb[n];
+        }
+      }
+      phase_index = (phase_index + 2 * num_sb) & 511;
+      harm_index = (harm_index + 2) & 3;
+      cx.sync();
+    }
+  }
+  return 0;
+}
+
 /* ---- ixheaacd_sbr_env_calc, ORIG_SBR ------------------------------------------------------------------------------- */
+/* pvs / pst / env_out: the PVC side info, state and the PVC decoder's envelope [16][64] of a channel whose host tracks them
+   (xaac_esbr.h), or NULL: a frame with pvs->sbr_mode == PVC takes xe_env_calc_pvc's envelopes, and every frame leaves the
+   bookkeeping a PVC frame behind it reads (esbr_envcal.c:861-899) */
 FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
                       xaac_esbr_state *st, XeWork *w, const XeMat &x /* sbr_qmf_out */, const XeMat &low /* qmf_buf */,
-                      const int32_t *x_over_qmf = nullptr /* the transposer's, where the host tracks one */) {
+                      const int32_t *x_over_qmf = nullptr /* the transposer's, where the host tracks one */,
+                      const xaac_esbr_pvc_side *pvs = nullptr, xaac_esbr_pvc_state *pst = nullptr, const float *env_out = nullptr) {
   const int sb_start = h->sub_band_start, num_sb = h->sub_band_end - h->sub_band_start;
   const int num_env = f->num_env, trans_env = f->transient_env, num_nf = h->num_nf_bands;
   const int smoothing_length = h->smoothing_mode ? 0 : 4, int_mode = h->interpol_freq;
   const int lim_band = sd->limiter_bands & 3, lim_gains = h->limiter_gains & 3;
   const double guard = 1e-17;
   int phase_index = st->phase_index, harm_index = st->harm_index, start_up = st->esbr_start_up;
+  int start_up_pvc = pst ? pst->esbr_start_up_pvc : 0;
   if (num_sb < 0 || num_sb > 64) return -1;
   if (sd->reset_flag) {
     start_up = 1;
+    start_up_pvc = 1;
     phase_index = 0;
     XS_ONE w->err = xe_limiter_bands(h, st, (sd->harmonic_sbr & XAAC_ESBR_HARMONIC) != 0, x_over_qmf, reinterpret_cast<int32_t *>(w->pow_lo));
     cx.sync();
@@ -683,11 +932,15 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
   }
   cx.sync();
   if (w->err) return -1;
+  const bool pvc_frame = pvs && pst && pvs->sbr_mode == XAAC_ESBR_SBR_PVC;
+  if (pvc_frame) {
+    if (xe_env_calc_pvc(cx, h, f, sd, st, w, x, pvs, pst, env_out, phase_index, harm_index, start_up, start_up_pvc)) return -1;
+  }
   int kk = 0, next = -1, m = 0;
   /* a frame whose sbr_mode is not ORIG_SBR (a USAC channel's first frames: UNKNOWN_SBR) passes the envelopes by: all of an
      envelope's work sits inside `if (sbr_mode == ORIG_SBR)` (esbr_envcal.c:646-857); the reset above and the bookkeeping below run */
   const bool skip_adjust = (sd->harmonic_sbr & XAAC_ESBR_SKIP_ADJUST) != 0;
-  for (int i = 0; i < num_env; i++) {
+  for (int i = 0; i < (pvc_frame ? 0 : num_env); i++) {
     if (kk > XAAC_SBR_MAX_NOISE_ENVELOPES) return -1;
     if (f->border_vec[i] == f->noise_border_vec[kk]) kk++, next++;
     if (skip_adjust) continue;
@@ -847,6 +1100,7 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
           st->noise_buf[n][k] = w->noise_level[k];
         }
       start_up = 0;
+      start_up_pvc = 0; /* esbr_envcal.c:768-769 */
     }
     const bool tes = xaac_esbr_q_gamma[sd->inter_temp_shape_mode[i] & 3] > 0; /* inter-TES works across bands: through memory */
     XS_PAR(k, 0, 64) { /* apply: smoothed gain, noise; the two five-deep histories rotate once per slot, :771-817 */
@@ -923,6 +1177,20 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
     }
     if (l1 > l0) harm_index = (harm_index + (l1 - l0)) & 3;
     cx.sync();
+  }
+  if (pst) { /* esbr_envcal.c:861-864, :873-899: what a PVC frame behind this one reads */
+    XS_PAR(k, 0, 64) {
+      pst->harm_flag_varlen_prev[k] = w->harm_prev[k];
+      pst->harm_flag_varlen[k] = w->harmonics[k];
+    }
+    XS_PAR(k, 0, num_nf) pst->prev_noise_level[k] = sd->flt_noise_floor[(f->num_noise_env - 1) * num_nf + k];
+    XS_ONE {
+      pst->prev_freq_res[0] = f->freq_res[0];
+      pst->prev_freq_res[1] = f->freq_res[1];
+      if (num_env == 1) pst->var_len_id_prev = 0;
+      else if (num_env == 2) pst->var_len_id_prev = 1;
+      pst->esbr_start_up_pvc = start_up_pvc;
+    }
   }
   XS_PAR(k, 0, 64) if (k >= sb_start) st->harm_flag_prev[k] = w->harmonics[k - sb_start];
   XS_ONE {

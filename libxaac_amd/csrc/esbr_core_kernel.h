@@ -10,7 +10,7 @@
 #define XAAC_ESBR_OUT_ROWS 42                                   /* 8 history + 32 + 2 rows a VARVAR frame can reach */
 #define XAAC_ESBR_L_ROWS 38                                     /* 32 regrouped rows + the 6 look-ahead rows of the PS hybrid filter */
 #define XAAC_ESBR_PH_ROWS 40                                    /* ph_vocod_qmf: 8 history rows + the transposer's 32 */
-#define XAAC_ESBR_WS_FLOATS (2 * 2048 + 2 * XAAC_ESBR_OUT_ROWS * 64 + 2 * XAAC_ESBR_L_ROWS * 64 + 2 * 2048 + 2 * XAAC_ESBR_PH_ROWS * 64) /* analysis rows, sbr_qmf_out, left rows, right rows, transposer rows */
+#define XAAC_ESBR_WS_FLOATS (2 * 2048 + 2 * XAAC_ESBR_OUT_ROWS * 64 + 2 * XAAC_ESBR_L_ROWS * 64 + 2 * 2048 + 2 * XAAC_ESBR_PH_ROWS * 64 + 16 * 64) /* analysis rows, sbr_qmf_out, left rows, right rows, transposer rows, the PVC decoder's envelope */
 
 typedef struct XaacEsbrCoreParams {
   int32_t n_ch;
@@ -27,6 +27,9 @@ typedef struct XaacEsbrCoreParams {
   const xaac_hbe_state *hbe;    /* [n_ch] or NULL: the channels' harmonic transposers, already run on this frame */
   float *ph_re, *ph_im;         /* [n_ch][40][64] scratch: ph_vocod_qmf (rows 8..39 written by the transposer) */
   int32_t hbe_lds_synth_size;   /* the transposer launches' LDS hint (hbe_kernel.h): a channel whose bank is larger was not run */
+  const xaac_esbr_pvc_side *pvc_side; /* [n_ch] or NULL (with pvc_state, pvc_out): channels with PVC frames (xaac_esbr.h) */
+  xaac_esbr_pvc_state *pvc_state;
+  float *pvc_out;               /* [n_ch][16][64] scratch: pvc_dec_out_buf */
 } XaacEsbrCoreParams;
 
 #ifdef __cplusplus

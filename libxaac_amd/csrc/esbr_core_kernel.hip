@@ -33,6 +33,7 @@ __shared__ float xe_lds_random_phase[1024];
    70 spills); the float PS kernel stays at eight (twelve: 320 -> 350 us) */
 #define XE_CH 12
 #include "esbr_core.h"
+#include "pvc.h"       /* xp_process: the PVC decoder of a USAC channel's PVC frames, run in this kernel */
 #include "hbe_trans.h" /* xh_apply_params_ok */
 #include "hbe_kernel.h" /* XAAC_HBE_LDS_OK */
 #include "esbr_core_kernel.h"
@@ -53,7 +54,8 @@ __device__ __forceinline__ void xe_copy_words(int32_t *dst, const int32_t *src, 
 }  // namespace
 
 /* HARM: with the harmonic transposer's rows (batches that hand in hbe_state); the other variant carries none of that code */
-template <bool HARM>
+/* PVC: channels whose host tracks the PVC side info and state (USAC; xaac_esbr.h): PVC frames decoded and adjusted here */
+template <bool HARM, bool PVC = false>
 __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParams p) { /* 168 VGPRs: 12 waves per CU (measured best of 8 / 12 / 16) */
 #ifdef XE_PROFILE
   if (threadIdx.x == 0) {
@@ -183,12 +185,28 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
     __syncthreads();
   }
   const XeMat ph = {phr + 128, phi + 128};
+  const xaac_esbr_pvc_side *pvs = PVC ? p.pvc_side + ch : nullptr;
+  xaac_esbr_pvc_state *pst = PVC ? p.pvc_state + ch : nullptr;
+  float *penv = PVC ? p.pvc_out + (size_t)ch * XAAC_PVC_SLOTS * 64 : nullptr;
   if (apply && rc == 0) {
     xe_generate_hf<HARM>(cx, h, f, sd, st, &w, src, dst, have_ph ? &ph : nullptr);
     __syncthreads();
     XE_T(2);
-    rc = w.err ? -1 : xe_env_calc(cx, h, f, sd, st, &w, dst, src, (HARM && have_ph) ? p.hbe[ch].x_over_qmf : nullptr);
+    if constexpr (PVC) { /* sbr_dec.c:931-953: the low band's energies through the PVC decoder, or its "no PVC frame" bookkeeping */
+      if (pvs->sbr_mode == XAAC_ESBR_SBR_PVC) {
+        __shared__ XpWork pw;
+        const XpCx pcx = {lane, 64};
+        if (!w.err && xp_process(pcx, &pw, &pvs->pvc, &st->qmf_re[2][0], &st->qmf_im[2][0], (size_t)32 * 64, &pst->pvc, penv)) w.err = -1;
+      } else if (lane == 0) {
+        pst->pvc.prev_pvc_flg = 0;
+        pst->pvc.prev_first_bnd_idx = h->sub_band_start;
+        pst->pvc.prev_pvc_rate = 2;
+      }
+      __syncthreads();
+    }
+    rc = w.err ? -1 : xe_env_calc(cx, h, f, sd, st, &w, dst, src, (HARM && have_ph) ? p.hbe[ch].x_over_qmf : nullptr, pvs, pst, penv);
   }
+  if (PVC && lane == 0) pst->prev_sbr_mode = pvs->sbr_mode; /* sbr_dec.c:1006 */
   __syncthreads();
   XE_T(3);
   {
@@ -266,13 +284,16 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
 }
 
 extern "C" hipError_t xaac_launch_esbr_core(const XaacEsbrCoreParams *p, hipStream_t stream) {
-  if (p->hbe) hipLaunchKernelGGL(xaac_esbr_core_kernel<true>, dim3(p->n_ch), dim3(64), 0, stream, *p);
-  else hipLaunchKernelGGL(xaac_esbr_core_kernel<false>, dim3(p->n_ch), dim3(64), 0, stream, *p);
+  if (p->pvc_side) { /* USAC channels with PVC frames: their own instantiations, the others carry none of that code */
+    if (p->hbe) hipLaunchKernelGGL((xaac_esbr_core_kernel<true, true>), dim3(p->n_ch), dim3(64), 0, stream, *p);
+    else hipLaunchKernelGGL((xaac_esbr_core_kernel<false, true>), dim3(p->n_ch), dim3(64), 0, stream, *p);
+  } else if (p->hbe) hipLaunchKernelGGL((xaac_esbr_core_kernel<true, false>), dim3(p->n_ch), dim3(64), 0, stream, *p);
+  else hipLaunchKernelGGL((xaac_esbr_core_kernel<false, false>), dim3(p->n_ch), dim3(64), 0, stream, *p);
   return hipGetLastError();
 }
 
 /* xaac_warm_up (xaac_abi.cpp): asking for a kernel's attributes puts this translation unit's code object on the device */
 extern "C" hipError_t xaac_warm_esbr_core(void) {
   hipFuncAttributes a;
-  return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&xaac_esbr_core_kernel<false>));
+  return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&xaac_esbr_core_kernel<false, false>));
 }

@@ -337,6 +337,7 @@ int32_t xaac_esbr_sbr_process_batch(xaac_ctx *c, const xaac_esbr_sbr_batch *b) {
   if (!b->core || !b->header || !b->frame || !b->side || !b->state || !b->out || !b->workspace) return XAAC_FATAL_NULL_ARG;
   const bool with_ps = b->ps_frame != nullptr;
   if (with_ps != (b->ps_state != nullptr) || with_ps != (b->out_r != nullptr)) return XAAC_FATAL_BAD_ARG;
+  if ((b->pvc_side != nullptr) != (b->pvc_state != nullptr)) return XAAC_FATAL_BAD_ARG;
   if (b->workspace_bytes < xaac_esbr_workspace_bytes(b->n_ch)) return XAAC_FATAL_BAD_ARG;
   if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
   const size_t n = (size_t)b->n_ch;
@@ -346,6 +347,7 @@ int32_t xaac_esbr_sbr_process_batch(xaac_ctx *c, const xaac_esbr_sbr_batch *b) {
   float *syn_re = out_im + n * XAAC_ESBR_OUT_ROWS * 64, *syn_im = syn_re + n * XAAC_ESBR_L_ROWS * 64;
   float *r_re = syn_im + n * XAAC_ESBR_L_ROWS * 64, *r_im = r_re + n * 2048;
   float *ph_re = r_im + n * 2048, *ph_im = ph_re + n * XAAC_ESBR_PH_ROWS * 64;
+  float *pvc_out = ph_im + n * XAAC_ESBR_PH_ROWS * 64;
   /* the banks' states are members of xaac_esbr_state / xaac_esbr_ps_state: the bank kernels take them at that stride */
   XaacEsbrAnaParams pa = {b->n_ch, b->core, &b->state->ana, ana_re, ana_im, (int32_t)sizeof(xaac_esbr_state)};
   if (!hip_ok(xaac_launch_esbr_analysis(&pa, c->stream))) return XAAC_FATAL_HIP;
@@ -360,7 +362,8 @@ int32_t xaac_esbr_sbr_process_batch(xaac_ctx *c, const xaac_esbr_sbr_batch *b) {
     if (!hip_ok(xaac_launch_hbe_post(&hp, c->stream))) return XAAC_FATAL_HIP;
   }
   XaacEsbrCoreParams pc = {b->n_ch, b->header, b->frame, b->side, b->state, ana_re, ana_im, out_re, out_im, syn_re, syn_im,
-                           with_ps ? 1 : 0, b->status, b->hbe_state, ph_re, ph_im, b->hbe_max_synth_size};
+                           with_ps ? 1 : 0, b->status, b->hbe_state, ph_re, ph_im, b->hbe_max_synth_size,
+                           b->pvc_side, b->pvc_state, pvc_out};
   if (!hip_ok(xaac_launch_esbr_core(&pc, c->stream))) return XAAC_FATAL_HIP;
   if (with_ps) {
     XaacEsbrPsParams pp = {b->n_ch, b->header, b->frame, b->ps_frame, b->ps_state, syn_re, syn_im, r_re, r_im, b->status};

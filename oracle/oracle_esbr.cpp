@@ -26,16 +26,34 @@ void xo_esbr_synthesis(const float *re, const float *im, int32_t *ring, int32_t 
 /* the two float stages alone, on the reference's own buffers: qmf / out = qmf_buf_real.. / sbr_qmf_out_real.. as
    [rows][64] arrays starting at the reference's row 0 (the stages work from row SBR_HF_ADJ_OFFSET = 2) */
 /* ph_re / ph_im: the harmonic transposer's rows [40][64] from the reference's row 0, and its cross-over bands, or NULL */
-int xo_esbr_hf_env_h(const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd, xaac_esbr_state *st,
-                     float *qmf_re, float *qmf_im, float *out_re, float *out_im, float *ph_re, float *ph_im,
-                     const int32_t *x_over_qmf) {
+int xo_pvc_process(const xaac_pvc_frame *f, const float *qmf_re, const float *qmf_im, xaac_pvc_state *st, float *out); /* oracle_pvc.cpp */
+/* pvs / pst: the PVC side info and state of a USAC channel whose host tracks them, or NULL (sbr_dec.c:931-953 + the PVC branch
+   of ixheaacd_sbr_env_calc) */
+static int hf_env_pvc(const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd, xaac_esbr_state *st,
+                      float *qmf_re, float *qmf_im, float *out_re, float *out_im, float *ph_re, float *ph_im,
+                      const int32_t *x_over_qmf, const xaac_esbr_pvc_side *pvs, xaac_esbr_pvc_state *pst) {
   XO_MATRIX XeWork w;
+  XO_MATRIX float env_out[XAAC_PVC_SLOTS * 64];
   const XsCx cx = {0, 1};
   const XeMat src = {qmf_re + 128, qmf_im + 128}, dst = {out_re + 128, out_im + 128};
   const XeMat ph = {ph_re ? ph_re + 128 : nullptr, ph_im ? ph_im + 128 : nullptr};
   xe_generate_hf(cx, h, f, sd, st, &w, src, dst, ph_re ? &ph : nullptr);
+  if (pvs && pst) {
+    if (pvs->sbr_mode == XAAC_ESBR_SBR_PVC) {
+      if (!w.err && xo_pvc_process(&pvs->pvc, qmf_re + 128, qmf_im + 128, &pst->pvc, env_out)) w.err = -1;
+    } else {
+      pst->pvc.prev_pvc_flg = 0;
+      pst->pvc.prev_first_bnd_idx = h->sub_band_start;
+      pst->pvc.prev_pvc_rate = 2;
+    }
+  }
   if (w.err) return -1;
-  return xe_env_calc(cx, h, f, sd, st, &w, dst, src, ph_re ? x_over_qmf : nullptr);
+  return xe_env_calc(cx, h, f, sd, st, &w, dst, src, ph_re ? x_over_qmf : nullptr, pvs, pst, env_out);
+}
+int xo_esbr_hf_env_h(const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd, xaac_esbr_state *st,
+                     float *qmf_re, float *qmf_im, float *out_re, float *out_im, float *ph_re, float *ph_im,
+                     const int32_t *x_over_qmf) {
+  return hf_env_pvc(h, f, sd, st, qmf_re, qmf_im, out_re, out_im, ph_re, ph_im, x_over_qmf, nullptr, nullptr);
 }
 int xo_esbr_hf_env(const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd, xaac_esbr_state *st,
                    float *qmf_re, float *qmf_im, float *out_re, float *out_im) {
@@ -72,9 +90,18 @@ int xo_esbr_sbr_frame_ps(const float *core, const xaac_sbr_header *h, const xaac
 
 /* ... with the channel's harmonic transposer (hst, or NULL): it runs on every processed frame (sbr_dec.c:882-909) and a
    frame with harmonic_sbr set takes the HF generator's input from it */
+int xo_esbr_sbr_frame_pvc(const float *core, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
+                          xaac_esbr_state *st, const xaac_ps_frame *pf, xaac_esbr_ps_state *pst, float *out, float *out_r,
+                          xaac_hbe_state *hst, const xaac_esbr_pvc_side *pvs, xaac_esbr_pvc_state *pvst);
 int xo_esbr_sbr_frame_hbe(const float *core, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
                           xaac_esbr_state *st, const xaac_ps_frame *pf, xaac_esbr_ps_state *pst, float *out, float *out_r,
                           xaac_hbe_state *hst) {
+  return xo_esbr_sbr_frame_pvc(core, h, f, sd, st, pf, pst, out, out_r, hst, nullptr, nullptr);
+}
+/* ... of a USAC channel whose host tracks PVC (pvs / pvst, or NULL): PVC frames through the PVC decoder and the adjuster's PVC branch */
+int xo_esbr_sbr_frame_pvc(const float *core, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
+                          xaac_esbr_state *st, const xaac_ps_frame *pf, xaac_esbr_ps_state *pst, float *out, float *out_r,
+                          xaac_hbe_state *hst, const xaac_esbr_pvc_side *pvs, xaac_esbr_pvc_state *pvst) {
   XO_MATRIX float phr[40][64], phi[40][64];
   XO_MATRIX float qre[XAAC_ESBR_ROWS][64], qim[XAAC_ESBR_ROWS][64], ore[42][64], oim[42][64];
   XO_MATRIX float rre[38][64], rim[38][64], xre[32][64], xim[32][64];
@@ -113,9 +140,9 @@ int xo_esbr_sbr_frame_hbe(const float *core, const xaac_sbr_header *h, const xaa
   }
   if (f->apply_processing) { /* a refused or failed frame still runs the banks and the history shift, like the kernel */
     rc = xe_side_info_bad(h, f, sd) ? -1
-                                    : xo_esbr_hf_env_h(h, f, sd, st, &qre[0][0], &qim[0][0], &ore[0][0], &oim[0][0],
-                                                       have_ph ? &phr[0][0] : nullptr, have_ph ? &phi[0][0] : nullptr,
-                                                       hst ? hst->x_over_qmf : nullptr);
+                                    : hf_env_pvc(h, f, sd, st, &qre[0][0], &qim[0][0], &ore[0][0], &oim[0][0],
+                                                 have_ph ? &phr[0][0] : nullptr, have_ph ? &phi[0][0] : nullptr,
+                                                 hst ? hst->x_over_qmf : nullptr, pvs, pvst);
   } else {
     memset(ore, 0, sizeof(ore));
     memset(oim, 0, sizeof(oim));
@@ -155,6 +182,7 @@ int xo_esbr_sbr_frame_hbe(const float *core, const xaac_sbr_header *h, const xaa
   memcpy(st->qmf_im, qim + 32, sizeof(st->qmf_im));
   memcpy(st->out_re, ore + 32, sizeof(st->out_re));
   memcpy(st->out_im, oim + 32, sizeof(st->out_im));
+  if (pvs && pvst) pvst->prev_sbr_mode = pvs->sbr_mode; /* sbr_dec.c:1006 */
   return rc;
 }
 }
