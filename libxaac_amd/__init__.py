@@ -71,7 +71,8 @@ class _EsbrSbrBatch(ctypes.Structure):
                 ("frame", ctypes.c_void_p), ("side", ctypes.c_void_p), ("state", ctypes.c_void_p),
                 ("out", ctypes.c_void_p), ("ps_frame", ctypes.c_void_p), ("ps_state", ctypes.c_void_p),
                 ("out_r", ctypes.c_void_p), ("status", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
-                ("workspace_bytes", ctypes.c_uint64), ("hbe_state", ctypes.c_void_p), ("hbe_max_synth_size", ctypes.c_int32)]
+                ("workspace_bytes", ctypes.c_uint64), ("hbe_state", ctypes.c_void_p), ("hbe_max_synth_size", ctypes.c_int32),
+                ("pvc_side", ctypes.c_void_p), ("pvc_state", ctypes.c_void_p)]
 
 
 class _EsbrCoreInBatch(ctypes.Structure):
@@ -187,6 +188,7 @@ class _EsbrSynBatch(ctypes.Structure):
 
 
 ESBR_SIDE_BYTES, ESBR_STATE_BYTES, ESBR_PS_STATE_BYTES = 2036, 38012, 23048   # include/xaac_esbr.h (tests/test_abi.py checks them)
+ESBR_PVC_SIDE_BYTES, ESBR_PVC_STATE_BYTES = 84, 12656                          # xaac_esbr_pvc_side / xaac_esbr_pvc_state
 ESBR_ANA_STATE_WORDS = 322   # struct xaac_esbr_ana_state: ring[320], pos, win_off (int32)
 ESBR_SYN_STATE_WORDS = 1282  # struct xaac_esbr_syn_state: ring[1280], drc_offset, filt_off (int32)
 
@@ -513,7 +515,7 @@ class XaacContext:
         return int(self._lib.xaac_esbr_workspace_bytes(int(n_ch)))
 
     def esbr_sbr_process_batch(self, core, header, frame, side, state, out, workspace, status=None, ps_frame=None,
-                               ps_state=None, out_r=None, hbe_state=None, hbe_max_synth_size=0):
+                               ps_state=None, out_r=None, hbe_state=None, hbe_max_synth_size=0, pvc_side=None, pvc_state=None):
         """One frame of every channel through the Path A (eSBR, -esbr:1) branch of ixheaacd_sbr_dec, mono / stereo
         channels without PS: core float32[n_ch, 1024]; header / frame / side / state uint8 views of the xaac_sbr_header,
         xaac_sbr_frame, xaac_esbr_side, xaac_esbr_state arrays; out float32[n_ch, 2048].  With ps_frame / ps_state (uint8
@@ -537,6 +539,9 @@ class XaacContext:
         b.workspace_bytes = workspace.numel()
         b.hbe_state = _ptr(hbe_state, "uint8", n_ch * HBE_STATE_BYTES, allow_none=True, device_ok=True)
         b.hbe_max_synth_size = int(hbe_max_synth_size)   # 4 / 8: no larger transposer bank in the batch (less LDS per channel); 0: any
+        # USAC channels with PVC frames: uint8 views of the xaac_esbr_pvc_side / xaac_esbr_pvc_state arrays (both or neither)
+        b.pvc_side = _ptr(pvc_side, "uint8", n_ch * ESBR_PVC_SIDE_BYTES, allow_none=True, device_ok=True)
+        b.pvc_state = _ptr(pvc_state, "uint8", n_ch * ESBR_PVC_STATE_BYTES, allow_none=True, device_ok=True)
         rc = self._lib.xaac_esbr_sbr_process_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_esbr_sbr_process_batch")

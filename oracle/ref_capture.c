@@ -79,7 +79,8 @@ static int esbr_path(const ia_sbr_dec_struct *d, const ia_sbr_header_data_struct
          !h->esbr_hq &&
          (h->channel_mode == PS_STEREO ? (ps != NULL && synth_r != NULL && !ps->use_34_st_bands && !ps->use_pca_rot_flg && ps->ps_mode == 0)
                                        : !h->enh_sbr_ps) &&
-         !drc_on && !ldmps && !mps && !f->mps_sbr_flag && f->sbr_mode != PVC_SBR && h->sbr_ratio_idx != SBR_UPSAMPLE_IDX_4_1 &&
+         !drc_on && !ldmps && !mps && !f->mps_sbr_flag && (f->sbr_mode != PVC_SBR || (h->usac_flag && getenv("XAAC_ESBR_CHAIN_PVC"))) &&
+         h->sbr_ratio_idx != SBR_UPSAMPLE_IDX_4_1 &&
          h->num_time_slots == 16 && d->str_codec_qmf_bank.no_channels == 32 &&
          d->str_synthesis_qmf_bank.no_channels == 64;
 }
@@ -92,7 +93,10 @@ static WORD32 esbr_chain_call(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_he
   static FILE *out;
   static ia_sbr_dec_struct *chains[32]; /* chain -> channel; a channel's newest chain is the live one */
   static int steps[32], n_chains, run, seed;
-  static uint32_t last_crc[32][3];
+  static uint32_t last_crc[32][4];
+  static xaac_esbr_pvc_side pvs;   /* $XAAC_ESBR_CHAIN_PVC (USAC streams): the PVC side info and state ride along, PVC frames are steps */
+  static xaac_esbr_pvc_state pvst;
+  const int with_pvc = getenv("XAAC_ESBR_CHAIN_PVC") != NULL;
   static xaac_sbr_header hd;
   static xaac_sbr_frame fr;
   static xaac_esbr_side sd;
@@ -122,11 +126,13 @@ static WORD32 esbr_chain_call(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_he
   if (h->hbe_flag && d->p_hbe_txposer) to_hbe_state(d->p_hbe_txposer, &hbs);
   else memset(&hbs, 0, sizeof(hbs)); /* (a USAC channel without a harmonic transposer) */
   if (eps) to_esbr_ps_state(ps, synth_r, &epss);
+  if (with_pvc) to_esbr_pvc_state(h, f, pvc, &pvst);
   for (c = n_chains - 1; c >= 0 && chains[c] != d; c--) {}
   /* the decoder's own layers may touch the state between two calls (sync-state changes, header resets re-create the
      banks and the transposer): a chain only lasts while the state found equals the state left */
   if (c >= 0 && (last_crc[c][0] != crc32_buf(&est, sizeof(est)) || last_crc[c][1] != crc32_buf(&hbs, sizeof(hbs)) ||
-                 (eps && last_crc[c][2] != crc32_buf(&epss, sizeof(epss))))) {
+                 (eps && last_crc[c][2] != crc32_buf(&epss, sizeof(epss))) ||
+                 (with_pvc && last_crc[c][3] != crc32_buf(&pvst, sizeof(pvst))))) {
     if (getenv("XAAC_ESBR_CHAIN_DEBUG")) {
       static xaac_esbr_state keep[32];
       fprintf(stderr, "chain %d breaks after %d steps: est %d hbs %d eps %d\n", c, steps[c], last_crc[c][0] != crc32_buf(&est, sizeof(est)),
@@ -207,11 +213,16 @@ static WORD32 esbr_chain_call(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_he
     fwrite(&est, sizeof(est), 1, out);
     fwrite(&hbs, sizeof(hbs), 1, out);
     if (eps) fwrite(&epss, sizeof(epss), 1, out);
+    if (with_pvc) fwrite(&pvst, sizeof(pvst), 1, out);
   }
   fwrite(&hd, sizeof(hd), 1, out);
   fwrite(&fr, sizeof(fr), 1, out);
   fwrite(&sd, sizeof(sd), 1, out);
   fwrite(&psf, sizeof(psf), 1, out);
+  if (with_pvc) {
+    to_esbr_pvc_side(h, f, pvc, low_pow, &pvs);
+    fwrite(&pvs, sizeof(pvs), 1, out);
+  }
   ret = __real_ixheaacd_sbr_dec(d, time_data, h, f, p, ps, synth_r, sf_r, apply, low_pow, work, tabs, common, ch_fac, pvc,
                                 drc_on, drc, aot, ldmps, self, mps, ec);
   to_esbr_state(d, h, f, &est);
@@ -262,10 +273,16 @@ static WORD32 esbr_chain_call(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_he
   last_crc[c][1] = (uint32_t)meta[4];
   last_crc[c][2] = (uint32_t)meta[5];
   fwrite(meta, 4, 6, out);
+  if (with_pvc) {
+    to_esbr_pvc_state(h, f, pvc, &pvst);
+    last_crc[c][3] = crc32_buf(&pvst, sizeof(pvst));
+    fwrite(&last_crc[c][3], 4, 1, out);
+  }
   if (getenv("XAAC_ESBR_CHAIN_FULL")) { /* debugging aid: the whole states after the call */
     fwrite(&est, sizeof(est), 1, out);
     fwrite(&hbs, sizeof(hbs), 1, out);
     if (eps) fwrite(&epss, sizeof(epss), 1, out);
+    if (with_pvc) fwrite(&pvst, sizeof(pvst), 1, out);
     fwrite(eps ? ps->time_sample_buf[0] : d->time_sample_buf, 4, 2048, out);
   }
   fflush(out);

@@ -306,38 +306,68 @@ static void to_esbr_side(const ia_sbr_header_data_struct *h, const ia_sbr_frame_
   o->pitch_in_bins = f->pitch_in_bins;
 }
 
-/* USAC, an ORIG_SBR frame served outside the reference: what sbr_dec.c:931-953 and the tail of ixheaacd_sbr_env_calc
-   (esbr_envcal.c:861-899) leave for a PVC frame that may follow -- the PVC decoder's "previous frame" words, the harmonic
-   flags of this and the last frame, the frame grid, the last noise floor.  harm_prev_before: harm_flag_prev as the call found it. */
-static void usac_keep_harm_flags(const ia_sbr_frame_info_data_struct *f, WORD8 *harm_prev_before) {
-  memcpy(harm_prev_before, f->harm_flag_prev, 64);
-}
-static void usac_orig_sbr_bookkeeping(const ia_sbr_header_data_struct *h, ia_sbr_frame_info_data_struct *f, ia_pvc_data_struct *pvc,
-                                      const WORD8 *harm_prev_before) {
-  const ia_freq_band_data_struct *fb = h->pstr_freq_band_data;
-  WORD8 harmonics[64];
+/* ---- PVC (USAC channels): xaac_esbr_pvc_side / xaac_esbr_pvc_state <-> the reference's frame data, header and ia_pvc_data_struct */
+static void to_esbr_pvc_side(const ia_sbr_header_data_struct *h, const ia_sbr_frame_info_data_struct *f, const ia_pvc_data_struct *pvc,
+                             FLAG low_pow, xaac_esbr_pvc_side *o) {
   int i;
+  memset(o, 0, sizeof(*o));
+  o->sbr_mode = (int16_t)f->sbr_mode;
+  o->sine_position = (int16_t)f->sine_position;
+  o->sin_start_for_cur_top = (int16_t)f->sin_start_for_cur_top;
+  o->sin_len_for_cur_top = (int16_t)f->sin_len_for_cur_top;
+  for (i = 0; i <= XAAC_SBR_MAX_ENVELOPES; i++) o->border_vec[i] = f->str_pvc_frame_info.border_vec[i];
+  for (i = 0; i < XAAC_SBR_MAX_ENVELOPES; i++) o->freq_res[i] = f->str_pvc_frame_info.freq_res[i];
   if (pvc) {
+    o->pvc.pvc_mode = pvc->pvc_mode;
+    o->pvc.ns_mode = pvc->ns_mode;
+    o->pvc.pvc_rate = (uint8_t)h->upsamp_fac; /* sbr_dec.c:931 */
+    o->pvc.low_power = (uint8_t)(low_pow != 0);
+    o->pvc.first_bnd_idx = h->pstr_freq_band_data->sub_band_start;
+    o->pvc.first_pvc_timeslot = f->str_pvc_frame_info.border_vec[0];
+    for (i = 0; i < XAAC_PVC_SLOTS; i++) o->pvc.pvc_id[i] = pvc->pvc_id[i];
+  }
+}
+static void to_esbr_pvc_state(const ia_sbr_header_data_struct *h, const ia_sbr_frame_info_data_struct *f, const ia_pvc_data_struct *pvc,
+                              xaac_esbr_pvc_state *o) {
+  memset(o, 0, sizeof(*o));
+  if (pvc) {
+    memcpy(o->pvc.esg, pvc->esg, sizeof(o->pvc.esg));
+    o->pvc.prev_first_bnd_idx = pvc->prev_first_bnd_idx;
+    o->pvc.prev_pvc_id = pvc->prev_pvc_id;
+    o->pvc.prev_pvc_flg = pvc->prev_pvc_flg;
+    o->pvc.prev_pvc_rate = pvc->prev_pvc_rate;
+  }
+  memcpy(o->qmapped, f->qmapped_pvc, sizeof(o->qmapped));
+  memcpy(o->prev_noise_level, f->prev_noise_level, sizeof(o->prev_noise_level));
+  memcpy(o->harm_flag_varlen_prev, f->harm_flag_varlen_prev, 64);
+  memcpy(o->harm_flag_varlen, f->harm_flag_varlen, 64);
+  o->prev_freq_res[0] = f->str_frame_info_prev.freq_res[0];
+  o->prev_freq_res[1] = f->str_frame_info_prev.freq_res[1];
+  o->var_len_id_prev = (int16_t)f->var_len_id_prev;
+  o->prev_sbr_mode = (int16_t)f->prev_sbr_mode;
+  o->esbr_start_up_pvc = h->esbr_start_up_pvc;
+}
+/* back into the reference's structs; `processed`: the call ran its tools (apply_processing and no refusal) */
+static void from_esbr_pvc_state(const xaac_esbr_pvc_state *o, int processed, ia_sbr_header_data_struct *h, ia_sbr_frame_info_data_struct *f,
+                                ia_pvc_data_struct *pvc) {
+  if (pvc && processed) {
+    memcpy(pvc->esg, o->pvc.esg, sizeof(o->pvc.esg));
+    pvc->prev_first_bnd_idx = o->pvc.prev_first_bnd_idx;
+    pvc->prev_pvc_id = o->pvc.prev_pvc_id;
+    pvc->prev_pvc_flg = o->pvc.prev_pvc_flg;
+    pvc->prev_pvc_rate = o->pvc.prev_pvc_rate;
     pvc->pvc_rate = (UWORD8)h->upsamp_fac;
-    pvc->prev_pvc_flg = 0;
-    pvc->prev_first_bnd_idx = fb->sub_band_start;
-    pvc->prev_pvc_rate = pvc->pvc_rate;
   }
-  memset(harmonics, 0, sizeof(harmonics));
-  for (i = 0; i < fb->num_sf_bands[1]; i++) {
-    const int t = ((fb->freq_band_tbl_hi[i + 1] + fb->freq_band_tbl_hi[i]) - (fb->sub_band_start << 1)) >> 1;
-    if (t >= 0 && t < 64) harmonics[t] = (WORD8)f->add_harmonics[i];
+  memcpy(f->qmapped_pvc, o->qmapped, sizeof(o->qmapped));
+  memcpy(f->prev_noise_level, o->prev_noise_level, sizeof(o->prev_noise_level));
+  memcpy(f->harm_flag_varlen_prev, o->harm_flag_varlen_prev, 64);
+  memcpy(f->harm_flag_varlen, o->harm_flag_varlen, 64);
+  if (processed) { /* (str_frame_info_prev is a copy of the frame's own grid: esbr_envcal.c:873) */
+    memcpy(&f->str_frame_info_prev, &f->str_frame_info_details, sizeof(ia_frame_info_struct));
   }
-  for (i = 0; i < 64; i++) {
-    f->harm_flag_varlen_prev[i] = harm_prev_before[i];
-    f->harm_flag_varlen[i] = harmonics[i];
-  }
-  memcpy(&f->str_frame_info_prev, &f->str_frame_info_details, sizeof(ia_frame_info_struct));
-  if (f->str_frame_info_details.num_env == 1) f->var_len_id_prev = 0;
-  else if (f->str_frame_info_details.num_env == 2) f->var_len_id_prev = 1;
-  if (f->str_frame_info_details.num_noise_env >= 1 && f->str_frame_info_details.num_noise_env <= 2)
-    for (i = 0; i < fb->num_nf_bands; i++)
-      f->prev_noise_level[i] = f->flt_noise_floor[(f->str_frame_info_details.num_noise_env - 1) * fb->num_nf_bands + i];
+  f->var_len_id_prev = o->var_len_id_prev;
+  f->prev_sbr_mode = o->prev_sbr_mode;
+  h->esbr_start_up_pvc = o->esbr_start_up_pvc;
 }
 
 /* the state as the call finds it: this library's rows 0.. are the rows the reference is about to move down from row 32 */

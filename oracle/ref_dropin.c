@@ -40,9 +40,11 @@ static struct {
   xaac_esbr_state *estate;
   xaac_hbe_state *hbe;         /* Path A: the channel's QMF harmonic transposer */
   void *ews;
+  xaac_esbr_pvc_side *pvs;     /* USAC channels: the PVC side info and state (xaac_esbr.h) */
+  xaac_esbr_pvc_state *pvst;
 } g;
 static long g_eld_ana_calls, g_eld_syn_calls;
-static long g_imdct_calls, g_sbr_calls, g_lim_calls, g_esbr_calls, g_esbr_harm_calls, g_esbr_usac_calls, g_sbr_ref_calls, g_imdct960_calls, g_imdct_ld_calls;
+static long g_imdct_calls, g_sbr_calls, g_lim_calls, g_esbr_calls, g_esbr_harm_calls, g_esbr_usac_calls, g_esbr_pvc_calls, g_sbr_ref_calls, g_imdct960_calls, g_imdct_ld_calls;
 static struct { int32_t *overlap; int16_t *pcm; uint8_t *shape; } gl; /* AAC-LD / ELD: 3 x 512 overlap words, 512 samples, 2 bytes */
 
 static void die(const char *what) {
@@ -60,6 +62,7 @@ static void report(void) {
   fprintf(stderr, "xaacdec_dropin: %ld sbr_dec calls took the eSBR (Path A) branch on the GPU\n", g_esbr_calls);
   fprintf(stderr, "xaacdec_dropin: %ld of them with harmonic patching (the QMF transposer's output)\n", g_esbr_harm_calls);
   fprintf(stderr, "xaacdec_dropin: %ld of them for USAC channels, %ld sbr_dec calls left to the reference\n", g_esbr_usac_calls, g_sbr_ref_calls);
+  fprintf(stderr, "xaacdec_dropin: %ld of the USAC calls were PVC frames (PVC decoder + the adjuster's PVC branch on the GPU)\n", g_esbr_pvc_calls);
 }
 
 static void setup(void) {
@@ -90,6 +93,8 @@ static void setup(void) {
   HIP(hipMalloc((void **)&g.epss, sizeof(xaac_esbr_ps_state)));
   HIP(hipMalloc((void **)&g.side, sizeof(xaac_esbr_side)));
   HIP(hipMalloc((void **)&g.estate, sizeof(xaac_esbr_state)));
+  HIP(hipMalloc((void **)&g.pvs, sizeof(xaac_esbr_pvc_side)));
+  HIP(hipMalloc((void **)&g.pvst, sizeof(xaac_esbr_pvc_state)));
   HIP(hipMalloc((void **)&g.hbe, sizeof(xaac_hbe_state)));
   HIP(hipMalloc(&g.ews, xaac_esbr_workspace_bytes(1)));
   HIP(hipMalloc((void **)&gl.overlap, 3 * 512 * 4));
@@ -442,14 +447,16 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
                     : (h->hbe_flag && d->p_hbe_txposer != NULL)) &&
       (h->channel_mode == PS_STEREO ? (ps != NULL && synth_r != NULL && !ps->use_34_st_bands && !ps->use_pca_rot_flg && ps->ps_mode == 0)
                                     : !h->enh_sbr_ps) &&
-      !drc_on && !ldmps && !mps && !f->mps_sbr_flag && f->sbr_mode != PVC_SBR &&
+      !drc_on && !ldmps && !mps && !f->mps_sbr_flag &&
+      (f->sbr_mode != PVC_SBR || (h->usac_flag && pvc != NULL && !low_pow && !getenv("XAAC_DROPIN_NO_PVC"))) &&
       h->sbr_ratio_idx != SBR_UPSAMPLE_IDX_4_1 && h->num_time_slots == 16 &&
       d->str_codec_qmf_bank.no_channels == 32 && d->str_synthesis_qmf_bank.no_channels == 64 && !getenv("XAAC_DROPIN_NO_ESBR")) {
     static xaac_esbr_side sd;
     static xaac_esbr_state est;
     static xaac_esbr_ps_state epss;
     static xaac_hbe_state hbs;
-    static WORD8 usac_harm_prev[64];
+    static xaac_esbr_pvc_side pvs;
+    static xaac_esbr_pvc_state pvst;
     xaac_esbr_sbr_batch b;
     const ia_qmf_dec_tables_struct *q = tabs->qmf_dec_tables_ptr;
     const int eps = h->channel_mode == PS_STEREO;
@@ -498,7 +505,14 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     b.workspace = g.ews;
     b.workspace_bytes = xaac_esbr_workspace_bytes(1);
     b.hbe_state = h->hbe_flag ? g.hbe : NULL;
-    if (h->usac_flag) usac_keep_harm_flags(f, usac_harm_prev);
+    if (h->usac_flag) { /* every USAC call carries the PVC side info and state: ORIG_SBR frames leave what a PVC frame behind them reads */
+      to_esbr_pvc_side(h, f, pvc, low_pow, &pvs);
+      to_esbr_pvc_state(h, f, pvc, &pvst);
+      HIP(hipMemcpy(g.pvs, &pvs, sizeof(pvs), hipMemcpyHostToDevice));
+      HIP(hipMemcpy(g.pvst, &pvst, sizeof(pvst), hipMemcpyHostToDevice));
+      b.pvc_side = g.pvs;
+      b.pvc_state = g.pvst;
+    }
     if (xaac_esbr_sbr_process_batch(g_ctx, &b) != XAAC_OK || xaac_sync(g_ctx) != XAAC_OK) die("xaac_esbr_sbr_process_batch");
     HIP(hipMemcpy(&status, g.status, 4, hipMemcpyDeviceToHost));
     if (status && getenv("XAAC_DROPIN_DEBUG")) {
@@ -516,7 +530,11 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
       HIP(hipMemcpy(&hbs, g.hbe, sizeof(hbs), hipMemcpyDeviceToHost));
       from_hbe_state(&hbs, d->p_hbe_txposer, h);
     }
-    if (h->usac_flag && apply && !f->mps_sbr_flag) usac_orig_sbr_bookkeeping(h, f, pvc, usac_harm_prev);
+    if (h->usac_flag) {
+      HIP(hipMemcpy(&pvst, g.pvst, sizeof(pvst), hipMemcpyDeviceToHost));
+      from_esbr_pvc_state(&pvst, apply != 0, h, f, pvc);
+      if (f->sbr_mode == PVC_SBR) g_esbr_pvc_calls++;
+    }
     if (eps) { /* right channel out, PS state back, and what the second synthesis call leaves in channel 1's frame data */
       HIP(hipMemcpy(&epss, g.epss, sizeof(epss), hipMemcpyDeviceToHost));
       HIP(hipMemcpy(ps->time_sample_buf[1], g.time_r, 8192, hipMemcpyDeviceToHost));

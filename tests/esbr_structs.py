@@ -49,3 +49,18 @@ def new_ps_state():
         st.h_prev[0][j] = 1.0
         st.h_prev[1][j] = 1.0
     return st
+
+
+# ---- PVC frames of USAC channels (include/xaac_esbr.h: xaac_esbr_pvc_side / xaac_esbr_pvc_state)
+from pvc_structs import PvcFrame, PvcState  # noqa: E402
+
+
+class EsbrPvcSide(ctypes.Structure):
+    _fields_ = [("sbr_mode", I16), ("sine_position", I16), ("sin_start_for_cur_top", I16), ("sin_len_for_cur_top", I16),
+                ("border_vec", I16 * 9), ("freq_res", I16 * 8), ("pad_", I16), ("pvc", PvcFrame)]
+
+
+class EsbrPvcState(ctypes.Structure):
+    _fields_ = [("pvc", PvcState), ("qmapped", (F32 * 48) * 64), ("prev_noise_level", F32 * 10), ("harm_flag_varlen_prev", I8 * 64),
+                ("harm_flag_varlen", I8 * 64), ("prev_freq_res", I16 * 2), ("var_len_id_prev", I16), ("prev_sbr_mode", I16),
+                ("esbr_start_up_pvc", I32)]

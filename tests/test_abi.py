@@ -116,7 +116,8 @@ def test_round2_struct_layouts_match_headers(tmp_path):
     pairs = [("xaac_esbr_ana_batch", libxaac_amd._EsbrAnaBatch, "qmf_im"), ("xaac_esbr_syn_batch", libxaac_amd._EsbrSynBatch, "out"),
              ("xaac_usac_imdct_batch", libxaac_amd._UsacImdctBatch, "status"), ("xaac_sbr_handover_batch", libxaac_amd._HandoverBatch, "ps_state"),
              ("xaac_sbr_apply_side_batch", libxaac_amd._ApplySideBatch, "ps_state"),
-             ("xaac_esbr_sbr_batch", libxaac_amd._EsbrSbrBatch, "hbe_state"), ("xaac_esbr_side", es.EsbrSide, "pitch_in_bins"),
+             ("xaac_esbr_sbr_batch", libxaac_amd._EsbrSbrBatch, "pvc_state"), ("xaac_esbr_side", es.EsbrSide, "pitch_in_bins"),
+             ("xaac_esbr_pvc_side", es.EsbrPvcSide, "pvc"), ("xaac_esbr_pvc_state", es.EsbrPvcState, "esbr_start_up_pvc"),
              ("xaac_esbr_state", es.EsbrState, "ph_im"), ("xaac_esbr_ps_state", es.EsbrPsState, "syn_r"),
              ("xaac_esbr_ana_state", es.EsbrAna, "win_off"), ("xaac_esbr_syn_state", es.EsbrSyn, "filt_off")]
     body = "".join('printf("%%zu %%zu\\n", sizeof(%s), offsetof(%s, %s));' % (c, c, last) for c, _, last in pairs)
@@ -132,6 +133,7 @@ def test_round2_struct_layouts_match_headers(tmp_path):
     assert ctypes.sizeof(es.EsbrAna) == 4 * libxaac_amd.ESBR_ANA_STATE_WORDS and ctypes.sizeof(es.EsbrSyn) == 4 * libxaac_amd.ESBR_SYN_STATE_WORDS
     assert (ctypes.sizeof(es.EsbrSide), ctypes.sizeof(es.EsbrState), ctypes.sizeof(es.EsbrPsState)) == \
         (libxaac_amd.ESBR_SIDE_BYTES, libxaac_amd.ESBR_STATE_BYTES, libxaac_amd.ESBR_PS_STATE_BYTES)
+    assert (ctypes.sizeof(es.EsbrPvcSide), ctypes.sizeof(es.EsbrPvcState)) == (libxaac_amd.ESBR_PVC_SIDE_BYTES, libxaac_amd.ESBR_PVC_STATE_BYTES)
 
 
 def test_hbe_struct_layouts_match_header(tmp_path):

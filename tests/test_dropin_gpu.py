@@ -107,8 +107,9 @@ def test_usac_streams_esbr_through_the_gpu(aac, tmp_path):
     and with harmonic SBR, a switched FD / LPD core, mono streams whose LPD frames use PVC, 4:1 eSBR): the reference's own
     USAC front end -- arithmetic decoder, LPD, stereo tools, all CPU -- hands its core samples and SBR side info to the same
     ixheaacd_sbr_dec seam, and every ORIG_SBR 2:1 call of it runs on the GPU (xaac_esbr_sbr_process_batch with the
-    XAAC_ESBR_USAC / _NO_X_DELAY / _SKIP_ADJUST side flags); PVC frames and 4:1 streams stay the reference's.  The decoded
-    file is byte-identical to the unmodified decoder's."""
+    XAAC_ESBR_USAC / _NO_X_DELAY / _SKIP_ADJUST side flags), PVC frames included (the PVC decoder and the envelope adjuster's
+    PVC branch run inside the same call, xaac_esbr_pvc_side / _state); 4:1 streams stay the reference's.  The decoded file
+    is byte-identical to the unmodified decoder's."""
     if not (os.path.exists(os.path.join(REF, "xaacdec")) and os.path.exists(os.path.join(REF, "xaacdec_dropin"))):
         pytest.fail("oracle/_ref/xaacdec[_dropin] missing: the reference binaries did not travel with the snapshot")
     extra = ("-mp4:1", "-imeta:" + aac[:-4] + ".txt")
@@ -121,8 +122,9 @@ def test_usac_streams_esbr_through_the_gpu(aac, tmp_path):
     name = os.path.basename(aac)
     if name.startswith("u41"):          # 4:1 eSBR: not covered, all the reference's
         assert on_gpu == 0 and left > 30
-    elif "pvc" in name:                 # ORIG_SBR frames on the GPU, PVC frames the reference's (m21tdpvc: every frame is PVC)
-        assert on_gpu + left > 30 and (on_gpu > 0 or "td" in name)
+    elif "pvc" in name:                 # PVC frames too: the PVC decoder and the adjuster's PVC branch inside the same call
+        mp = re.search(r"(\d+) of the USAC calls were PVC frames", log)
+        assert on_gpu > 30 and left == 0 and mp and int(mp.group(1)) > (30 if "td" in name else 5), (on_gpu, left, log[-300:])
     else:
         assert on_gpu > 60 and left == 0, (on_gpu, left)
     if "harm" in name:

@@ -88,24 +88,30 @@ def test_usac_fixture_is_what_it_says():
     assert U["ret"].size >= 1000 and not U["ret"].any() and (flags & USAC).all()
     assert ((flags & NO_X_DELAY) != 0).sum() > 500 and ((flags & NO_X_DELAY) == 0).sum() > 200      # without / with a transposer
     assert ((flags & 1) != 0).sum() > 100                                                            # harmonic patching frames
+    from esbr_structs import EsbrPvcSide
+    mode = U["pvc_side"].view(np.int16)[:, EsbrPvcSide.sbr_mode.offset // 2]
+    assert (mode == 2).sum() > 150 and (mode == 1).sum() > 1000 and (mode == 0).sum() > 0      # PVC_SBR, ORIG_SBR, UNKNOWN_SBR frames
 
 
 @pytest.mark.parametrize("which", ["aac", "usac"])
 def test_oracle_walks_the_reference_chains(oracle, which):
     CH = FIXTURES[which]
-    fn = oracle.lib.xo_esbr_sbr_frame_hbe
+    fn = oracle.lib.xo_esbr_sbr_frame_pvc
     fn.restype = ctypes.c_int
-    fn.argtypes = [PF] + [ctypes.c_void_p] * 6 + [PF, PF, ctypes.c_void_p]
+    fn.argtypes = [PF] + [ctypes.c_void_p] * 6 + [PF, PF, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    pvc = "pvc_side" in CH.files     # the USAC fixture: PVC side info per step, PVC state per chain, a sixth CRC
     for c, rows in enumerate(steps_of_chains(CH)):
         run, cid, eps = int(CH["chain_run"][c]), int(CH["chain_id"][c]), bool(CH["chain_ps"][c])
         st, hb, ps = CH["est0"][c].copy(), CH["hbs0"][c].copy(), CH["eps0"][c].copy()
         with_hb = chain_has_transposer(CH, rows)
+        pv = CH["pvst0"][c].copy() if pvc else None
         for s, r in enumerate(rows):
             core = np.ascontiguousarray(chain_core(run, cid, s))
             out, out_r = np.zeros(2048, np.float32), np.zeros(2048, np.float32)
             h, f, sd, pf = (np.ascontiguousarray(CH[k][r]) for k in ("header", "frame", "side", "ps_frame"))
             rc = fn(core.ctypes.data_as(PF), vp(h), vp(f), vp(sd), vp(st), vp(pf) if eps else None, vp(ps) if eps else None,
-                    out.ctypes.data_as(PF), out_r.ctypes.data_as(PF) if eps else None, vp(hb) if with_hb else None)
+                    out.ctypes.data_as(PF), out_r.ctypes.data_as(PF) if eps else None, vp(hb) if with_hb else None,
+                    vp(np.ascontiguousarray(CH["pvc_side"][r])) if pvc else None, vp(pv) if pvc else None)
             want = CH["crc"][r]
             assert rc == CH["ret"][r], (c, s)
             assert crc(out) == want[0], ("out", c, s)
@@ -115,6 +121,8 @@ def test_oracle_walks_the_reference_chains(oracle, which):
             assert crc(hb) == want[3], ("transposer state", c, s)
             if eps:
                 assert crc(ps) == want[4], ("ps state", c, s)
+            if pvc:
+                assert crc(pv) == want[5], ("pvc state", c, s)
 
 
 @pytest.mark.gpu
@@ -136,6 +144,8 @@ def test_gpu_walks_the_reference_chains(which):
         t_st = torch.from_numpy(np.ascontiguousarray(CH["est0"][chains])).to(dev)
         t_hb = torch.from_numpy(np.ascontiguousarray(CH["hbs0"][chains])).to(dev)
         t_ps = torch.from_numpy(np.ascontiguousarray(CH["eps0"][chains])).to(dev) if with_ps else None
+        pvc = "pvc_side" in CH.files
+        t_pv = torch.from_numpy(np.ascontiguousarray(CH["pvst0"][chains])).to(dev) if pvc else None
         for s in range(max(len(order[c]) for c in chains)):
             act = [i for i, c in enumerate(chains) if s < len(order[c])]      # chains that still have a step s
             rows = [order[chains[i]][s] for i in act]
@@ -145,20 +155,24 @@ def test_gpu_walks_the_reference_chains(which):
             g = lambda k: torch.from_numpy(np.ascontiguousarray(CH[k][rows])).to(dev)
             st, hb = t_st[idx].contiguous(), t_hb[idx].contiguous()
             ps = t_ps[idx].contiguous() if with_ps else None
+            pv = t_pv[idx].contiguous() if pvc else None
             out = torch.zeros((m, 2048), dtype=torch.float32, device=dev)
             out_r = torch.zeros((m, 2048), dtype=torch.float32, device=dev) if with_ps else None
             status = torch.full((m,), 7, dtype=torch.int32, device=dev)
             ws = torch.zeros(ctx.esbr_workspace_bytes(m), dtype=torch.uint8, device=dev)
             ctx.esbr_sbr_process_batch(core, g("header"), g("frame"), g("side"), st, out, ws, status,
                                        ps_frame=g("ps_frame") if with_ps else None, ps_state=ps, out_r=out_r,
-                                       hbe_state=hb if with_hb else None)
+                                       hbe_state=hb if with_hb else None, pvc_side=g("pvc_side") if pvc else None, pvc_state=pv)
             ctx.sync()
             t_st[idx], t_hb[idx] = st, hb
+            if pvc:
+                t_pv[idx] = pv
             if with_ps:
                 t_ps[idx] = ps
             assert np.array_equal(status.cpu().numpy(), CH["ret"][rows]), s
             o, orr = out.cpu().numpy(), (out_r.cpu().numpy() if with_ps else None)
             stn, hbn, psn = st.cpu().numpy(), hb.cpu().numpy(), (ps.cpu().numpy() if with_ps else None)
+            pvn = pv.cpu().numpy() if pvc else None
             for j, r in enumerate(rows):
                 want = CH["crc"][r]
                 assert crc(o[j]) == want[0], ("out", chains[act[j]], s)
@@ -168,6 +182,8 @@ def test_gpu_walks_the_reference_chains(which):
                 assert crc(hbn[j]) == want[3], ("transposer state", chains[act[j]], s)
                 if with_ps:
                     assert crc(psn[j]) == want[4], ("ps state", chains[act[j]], s)
+                if pvc:
+                    assert crc(pvn[j]) == want[5], ("pvc state", chains[act[j]], s)
     ctx.close()
 
 

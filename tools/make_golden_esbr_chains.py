@@ -30,7 +30,7 @@ PASSES = 10           # decoder runs per stream; pass 0 is unfuzzed
 # (tests/golden/streams_usac, raw access units + the encoder's frame-size list: xaacdec -mp4:1 -imeta:) -- stereo 2:1 eSBR
 # without a harmonic transposer (codec_x_delay 0: xaac_esbr.h XAAC_ESBR_NO_X_DELAY), with one (sbr_patching_mode 0 frames),
 # a switched FD / LPD core (the ORIG_SBR frames of it)
-USAC_STREAMS = ("u21", "u21harm", "u21sw", "m21swpvc")
+USAC_STREAMS = ("u21", "u21harm", "u21sw", "m21swpvc", "m21tdpvc")
 USAC_PASSES = 6
 
 
@@ -45,10 +45,13 @@ def sizes():
     import hbe_structs as hs
     import sbr_capture as c
     return dict(hd=ctypes.sizeof(c.Header), fr=ctypes.sizeof(c.Frame), sd=ctypes.sizeof(es.EsbrSide), psf=ctypes.sizeof(c.PsFrame),
-                est=ctypes.sizeof(es.EsbrState), hbs=ctypes.sizeof(hs.HbeState), eps=ctypes.sizeof(es.EsbrPsState))
+                est=ctypes.sizeof(es.EsbrState), hbs=ctypes.sizeof(hs.HbeState), eps=ctypes.sizeof(es.EsbrPsState),
+                pvs=ctypes.sizeof(es.EsbrPvcSide), pvst=ctypes.sizeof(es.EsbrPvcState))
 
 
-def parse(path, run, z):
+def parse(path, run, z, pvc=False):
+    """pvc: a $XAAC_ESBR_CHAIN_PVC run -- the PVC state behind a chain's first states, the PVC side info behind every step's
+    PS frame, a sixth CRC (the PVC state after the call)"""
     b = open(path, "rb").read()
     o, recs = 0, []
     while o < len(b):
@@ -61,11 +64,13 @@ def parse(path, run, z):
             r["hbs0"] = b[o:o + z["hbs"]]; o += z["hbs"]
             if eps:
                 r["eps0"] = b[o:o + z["eps"]]; o += z["eps"]
-        for k in ("hd", "fr", "sd", "psf"):
+            if pvc:
+                r["pvst0"] = b[o:o + z["pvst"]]; o += z["pvst"]
+        for k in ("hd", "fr", "sd", "psf") + (("pvs",) if pvc else ()):
             r[k] = b[o:o + z[k]]; o += z[k]
-        r["ret"], *crcs = struct.unpack_from("<i5I", b, o)
+        r["ret"], *crcs = struct.unpack_from("<i6I" if pvc else "<i5I", b, o)
         r["crc"] = crcs
-        o += 24
+        o += 28 if pvc else 24
         recs.append(r)
     return recs
 
@@ -80,10 +85,12 @@ def main(usac=False):
             tmp = "/tmp/xaac_esbr_chain_%d.bin" % run
             env = dict(os.environ, XAAC_ESBR_CHAIN_FILE=tmp, XAAC_ESBR_CHAIN_SEED=str(0 if p == 0 else 100 * p + run),
                        XAAC_ESBR_CHAIN_RUN=str(run))
+            if usac:
+                env["XAAC_ESBR_CHAIN_PVC"] = "1"
             src = os.path.join(ROOT, "tests", "golden", "streams_usac" if usac else "streams", s + ".aac")
             args = ["-ifile:" + src, "-ofile:/tmp/xaac_esbr_chain.wav"] + (["-mp4:1", "-imeta:" + src[:-4] + ".txt"] if usac else [])
             subprocess.run([cap] + args, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
-            recs += parse(tmp, run, z)
+            recs += parse(tmp, run, z, pvc=usac)
             os.remove(tmp)
             run += 1
     chains = sorted({(r["run"], r["chain"]) for r in recs})
@@ -100,6 +107,12 @@ def main(usac=False):
         "header": np.stack([u8(r["hd"], 0) for r in recs]), "frame": np.stack([u8(r["fr"], 0) for r in recs]),
         "side": np.stack([u8(r["sd"], 0) for r in recs]), "ps_frame": np.stack([u8(r["psf"], 0) for r in recs]),
     }
+    if usac:
+        d["pvc_side"] = np.stack([u8(r["pvs"], 0) for r in recs])
+        d["pvst0"] = np.zeros((nc, z["pvst"]), np.uint8)
+        for r in recs:
+            if r["first"]:
+                d["pvst0"][cidx[(r["run"], r["chain"])]] = u8(r["pvst0"], 0)
     for r in recs:
         i = cidx[(r["run"], r["chain"])]
         d["chain_len"][i] += 1
