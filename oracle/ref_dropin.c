@@ -44,7 +44,7 @@ static struct {
   xaac_esbr_pvc_state *pvst;
 } g;
 static long g_eld_ana_calls, g_eld_syn_calls;
-static long g_imdct_calls, g_sbr_calls, g_lim_calls, g_esbr_calls, g_esbr_harm_calls, g_esbr_usac_calls, g_esbr_pvc_calls, g_sbr_ref_calls, g_imdct960_calls, g_imdct_ld_calls;
+static long g_imdct_calls, g_sbr_calls, g_lim_calls, g_esbr_calls, g_esbr_harm_calls, g_esbr_usac_calls, g_esbr_pvc_calls, g_sbr_ref_calls, g_usac_imdct_calls, g_usac_imdct_fac, g_usac_imdct_lpd, g_imdct960_calls, g_imdct_ld_calls;
 static struct { int32_t *overlap; int16_t *pcm; uint8_t *shape; } gl; /* AAC-LD / ELD: 3 x 512 overlap words, 512 samples, 2 bytes */
 
 static void die(const char *what) {
@@ -62,6 +62,8 @@ static void report(void) {
   fprintf(stderr, "xaacdec_dropin: %ld sbr_dec calls took the eSBR (Path A) branch on the GPU\n", g_esbr_calls);
   fprintf(stderr, "xaacdec_dropin: %ld of them with harmonic patching (the QMF transposer's output)\n", g_esbr_harm_calls);
   fprintf(stderr, "xaacdec_dropin: %ld of them for USAC channels, %ld sbr_dec calls left to the reference\n", g_esbr_usac_calls, g_sbr_ref_calls);
+  fprintf(stderr, "xaacdec_dropin: %ld USAC fd_frm_dec calls ran on the GPU, %ld with a FAC signal, %ld behind an LPD frame\n", g_usac_imdct_calls,
+          g_usac_imdct_fac, g_usac_imdct_lpd);
   fprintf(stderr, "xaacdec_dropin: %ld of the USAC calls were PVC frames (PVC decoder + the adjuster's PVC branch on the GPU)\n", g_esbr_pvc_calls);
 }
 
@@ -101,6 +103,17 @@ static void setup(void) {
   HIP(hipMalloc((void **)&gl.pcm, 512 * 2));
   HIP(hipMalloc((void **)&gl.shape, 2));
   if (!g_sbr_ref_calls) atexit(report);
+}
+
+/* for ref_dropin_usac.c (the USAC FD seam lives in a file of its own: ia_usac_data_struct's headers) */
+xaac_ctx *dropin_ctx(void) {
+  setup();
+  return g_ctx;
+}
+void dropin_count_usac_imdct(int with_fac, int behind_lpd) {
+  g_usac_imdct_calls++;
+  g_usac_imdct_fac += with_fac != 0;
+  g_usac_imdct_lpd += behind_lpd != 0;
 }
 
 /* developer aid: the numeric code behind the command-line tool's "error unlisted" */

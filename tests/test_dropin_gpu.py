@@ -120,7 +120,18 @@ def test_usac_streams_esbr_through_the_gpu(aac, tmp_path):
     assert m, log[-600:]
     on_gpu, left = int(m.group(1)), int(m.group(2))
     name = os.path.basename(aac)
-    if name.startswith("u41"):          # 4:1 eSBR: not covered, all the reference's
+    # the USAC frequency-domain seam: ixheaacd_fd_frm_dec through xaac_usac_imdct_process_batch (1024- and 768-line frames; FAC
+    # signal and bass post filter of LPD -> FD transitions stay the LPD decoder's, oracle/ref_dropin_usac.c)
+    mi = re.search(r"(\d+) USAC fd_frm_dec calls ran on the GPU, (\d+) with a FAC signal, (\d+) behind an LPD frame", log)
+    assert mi, log[-600:]
+    n_fd, n_fac, n_lpd = (int(v) for v in mi.groups())
+    if "td" in name:
+        assert n_fd == 0                # LPD frames only
+    elif "sw" in name:
+        assert n_fd > 10 and n_lpd > 0 and (n_fac > 0 or "pvc" in name), (n_fd, n_fac, n_lpd)   # a switched core: LPD -> FD transitions (u21sw: with a FAC signal)
+    else:
+        assert n_fd > 30, n_fd
+    if name.startswith("u41") or name.startswith("u83"):   # 4:1 and 8:3 eSBR: not covered, all the reference's
         assert on_gpu == 0 and left > 30
     elif "pvc" in name:                 # PVC frames too: the PVC decoder and the adjuster's PVC branch inside the same call
         mp = re.search(r"(\d+) of the USAC calls were PVC frames", log)

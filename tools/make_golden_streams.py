@@ -71,7 +71,7 @@ def main():
 
     # USAC (xHE-AAC, -aot:42) streams for the eSBR seam behind the reference's own USAC front end (tests/golden/streams_usac;
     # raw access units + frame-size list like the LD streams): stereo 2:1 eSBR without / with harmonic SBR (u21, u21harm),
-    # a switched FD / LPD core (u21sw), 4:1 eSBR (u41); mono streams whose LPD frames carry PVC (m21swpvc: switched,
+    # a switched FD / LPD core (u21sw), 4:1 eSBR (u41), a 768-line core with 8:3 eSBR (u83); mono streams whose LPD frames carry PVC (m21swpvc: switched,
     # ORIG_SBR and PVC_SBR frames; m21tdpvc: LPD only, every frame PVC)
     out_usac = os.path.join(ROOT, "tests", "golden", "streams_usac")
     os.makedirs(out_usac, exist_ok=True)
@@ -79,6 +79,7 @@ def main():
                             ("u21harm", "/tmp/xaac_golden_mix.wav", ["-ccfl_idx:3", "-harmonic_sbr:1"]),
                             ("u21sw", "/tmp/xaac_golden_mix.wav", ["-ccfl_idx:3", "-usac:0"]),
                             ("u41", "/tmp/xaac_golden_mix.wav", ["-ccfl_idx:4"]),
+                            ("u83", "/tmp/xaac_golden_mix.wav", ["-ccfl_idx:2"]),   # 768-line core, 8:3 eSBR
                             ("m21swpvc", "/tmp/xaac_golden_mono.wav", ["-ccfl_idx:3", "-usac:0", "-pvc_enc:1"]),
                             ("m21tdpvc", "/tmp/xaac_golden_mono.wav", ["-ccfl_idx:3", "-usac:2", "-pvc_enc:1"])):
         aac = os.path.join(out_usac, name + ".aac")
