@@ -253,6 +253,37 @@ typedef struct xaac_sbr_hq_batch {
   uint64_t workspace_bytes;
 } xaac_sbr_hq_batch;
 
+/* --- low-delay SBR channel-frames of AAC-ELD ---------------------------------------------------------------------------
+ * ref: ixheaacd_sbr_dec with audio_object_type AOT_ER_AAC_ELD, low_pow_flag 0 (decoder/ixheaacd_sbr_dec.c:706-775, :1025-1308):
+ *      the LD complex analysis bank (generic:590), block floating point, ixheaacd_hf_generator and ixheaacd_calc_sbrenvelope
+ *      on a frame of 16 (512-sample core frames) or 15 (480) QMF slots with one slot per time slot and no overlap slots
+ *      (op_delay 0: nothing of the matrix is carried; lpp_tran.c:1027-1052, env_calc.c:811-849, :962), the LD complex
+ *      synthesis bank (qmf_dec.c:811).  One channel per entry: core PCM16 32 n_slots samples in, 64 n_slots out. */
+typedef struct xaac_sbr_eld_state {
+  xaac_qmf_ana_eld_state ana;                 /* str_codec_qmf_bank */
+  xaac_qmf_syn_eld_state syn;                 /* str_synthesis_qmf_bank */
+  int16_t codec_usb;                          /* str_codec_qmf_bank.usb */
+  int16_t syn_lsb, syn_usb;                   /* str_synthesis_qmf_bank.lsb / .usb */
+  int16_t pad2_;
+  XAAC_SBR_STATE_TAIL_FIELDS
+} xaac_sbr_eld_state; /* a new stream: the banks' initial states (above), xaac_sbr_state_init's values for the rest */
+
+typedef struct xaac_sbr_eld_batch {
+  int32_t n_ch;
+  int32_t n_slots;                 /* 16 or 15: header num_time_slots (time_step 1, num_columns = n_slots) of every channel */
+  int32_t in_ch_fac, out_ch_fac;   /* interleave strides of pcm_in (32 n_slots samples per channel) and pcm_out (64 n_slots) */
+  const int16_t *pcm_in;
+  const xaac_sbr_header *header;   /* [n_ch] */
+  const xaac_sbr_frame *frame;     /* [n_ch] */
+  xaac_sbr_eld_state *state;       /* [n_ch] in/out */
+  int16_t *pcm_out;
+  int32_t *status;                 /* optional [n_ch]: 0, -1 where the reference returns an error or the side info is outside the tables */
+  void *workspace;                 /* device scratch, >= xaac_sbr_eld_workspace_bytes(n_ch) */
+  uint64_t workspace_bytes;
+  int32_t *qmf_handed_on;          /* optional [n_ch][n_slots][128]: the region-rescaled matrix the reference hands on through
+                                      p_arr_qmf_buf_real / _imag (qmf_dec.c:966-976) */
+} xaac_sbr_eld_batch;
+
 /* ---- state hand-overs at a change of channel configuration ------------------------------------------------------
  * xaac_sbr_state_handover <-> the two memcpy blocks of ixheaacd_sbr_dec_apply, decoder/ixheaacd_sbrdecoder.c:762-806:
  * a stream that was mono (no PS) in the previous frame and carries parametric stereo now starts the right synthesis
@@ -458,6 +489,8 @@ XAAC_API int32_t xaac_sbr_lp_process_batch(xaac_ctx *ctx, const xaac_sbr_lp_batc
 
 /* HQ SBR stream-frames (complex QMF analysis -> LPP transposer + envelope adjustment -> [parametric
  * stereo] -> complex QMF synthesis, once per output channel). */
+XAAC_API uint64_t xaac_sbr_eld_workspace_bytes(int32_t n_ch);
+XAAC_API int32_t xaac_sbr_eld_process_batch(xaac_ctx *ctx, const xaac_sbr_eld_batch *batch);
 XAAC_API uint64_t xaac_sbr_hq_workspace_bytes(int32_t n_ch, int32_t with_ps);
 XAAC_API int32_t xaac_sbr_hq_process_batch(xaac_ctx *ctx, const xaac_sbr_hq_batch *batch);
 

@@ -429,10 +429,14 @@ FX_HD XsLv xs_seg_running_max(const XsCx &cx, const XsLv &seg, const XsLv &e, in
 /* NB_: bands a row holds.  64 is the reference's layout; the GPU core kernel keeps rows of NB_ < 64 bands (less LDS,
    more resident waves) for streams that provably touch no band at or above NB_ and sends the others through the
    64-band instantiation (sbr_core_kernel.hip: "narrow rows"). */
-template <int HQ_, int NB_ = 64>
+/* LD_: the low-delay SBR of AAC-ELD (sbr_dec.c:706-775: op_delay 0 -- no overlap slots, nothing carried in the matrix --, one QMF
+   slot per time slot, 16 or 15 slots a frame): rows -2, -1 the LPC history, rows 0 .. cols - 1 the frame's slots. */
+template <int HQ_, int NB_ = 64, int LD_ = 0>
 struct XsQmfT {
   static constexpr int HQ = HQ_;
   static constexpr int NB = NB_;
+  static constexpr int LD = LD_;
+  static constexpr int OV = LD_ ? 0 : 6; /* op_delay: the overlap slots in front of the frame's own */
   static constexpr int IM = NB_;                    /* offset of a row's imaginary columns */
   static constexpr int ROW = HQ_ ? 2 * NB_ : NB_;
   int32_t *p;
@@ -515,13 +519,13 @@ FX_HD void xs_clear(const XsCx &cx, const Q &x, int b0, int b1, int s0, int s1) 
 }
 /* sbr_dec.c:1221-1236: the last two slots of the low bands are the next frame's LPC history */
 template <class ST, class Q>
-FX_HD void xs_lpc_save(const XsCx &cx, ST *st, const Q &x, int usb) {
+FX_HD void xs_lpc_save(const XsCx &cx, ST *st, const Q &x, int usb, int no_bins = 32) {
   XS_PAR(k, 0, usb) {
-    st->lpc_real[0][k] = x(30, k);
-    st->lpc_real[1][k] = x(31, k);
+    st->lpc_real[0][k] = x(no_bins - 2, k);
+    st->lpc_real[1][k] = x(no_bins - 1, k);
     if (Q::HQ) {
-      st->lpc_imag[0][k] = x.im(30, k);
-      st->lpc_imag[1][k] = x.im(31, k);
+      st->lpc_imag[0][k] = x.im(no_bins - 2, k);
+      st->lpc_imag[1][k] = x.im(no_bins - 1, k);
     }
   }
 }
@@ -2882,15 +2886,17 @@ FX_HD void xs_hf_generator_hq(const XsCx &cx, const xaac_sbr_header *h, ST *st, 
   al23.fill(0);
   /* covariances over num_columns + 6 = 38 slots (lpp_tran.c:1034).  All eight sums wrap, so the slots are dealt out
      to the 64 / w lane groups of w lanes (lane = group * w + low band) and the groups' parts added up. */
-  const int cw = stop_patch <= 16 ? 16 : (stop_patch <= 32 ? 32 : 64), cper = (38 * cw + 63) / 64;
+  /* (low-delay SBR: over the frame's own num_columns = 16 or 15 slots, lpp_tran.c:1040-1052) */
+  const int ncov = Q::LD ? cx.uni(h->num_columns) : 38;
+  const int cw = stop_patch <= 16 ? 16 : (stop_patch <= 32 ? 32 : 64), cper = (ncov * cw + 63) / 64;
   XsLv cv[8];
   for (int i = 0; i < 8; i++) cv[i].fill(0);
   XS_LANES(c, 0, 64) {
     const int lb = c & (cw - 1), g = c / cw;
-    const int n0 = g * cper, n1 = n0 + cper < 38 ? n0 + cper : 38;
+    const int n0 = g * cper, n1 = n0 + cper < ncov ? n0 + cper : ncov;
     if (lb >= start_patch && lb < stop_patch && n0 < n1) {
       XsCovHq part;
-      xs_covariance_hq(x, lb, n0, n1, 38, g == 0, &part);
+      xs_covariance_hq(x, lb, n0, n1, ncov, g == 0, &part);
       cv[0].own(c) = part.phi_11;
       cv[1].own(c) = part.phi_22;
       cv[2].own(c) = part.phi_01;
@@ -3052,6 +3058,10 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
     }
   }
   int final_e = 0;
+  /* the frame's grid: two QMF slots per time slot and rows up to MAX_ENV_COLS = 38, or -- low-delay SBR, env_calc.c:847-849 --
+     one, inside the frame's own rows; the time slot at which an envelope counts for the next frame's exponent: env_calc.c:811-837 */
+  const int t_step = Q::LD ? 1 : 2, nts_hdr = cx.uni(h->num_time_slots);
+  const int row_limit = Q::LD ? nts_hdr : 38, frame_end_slot = (Q::LD && nts_hdr == 15) ? 15 : 16;
   {
     XS_UNROLL
     for (int i = 0; i < XAAC_SBR_MAX_ENVELOPES; i++) {
@@ -3065,8 +3075,8 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
       mx = cx.wave_max(mx);
       mx -= 16;
       int t = (mx + 13) >> 1;
-      if (cx.uni(border[i]) < 16 && t > adj_e) adj_e = (int16_t)t;
-      if (cx.uni(border[i + 1]) > 16 && t > final_e) final_e = (int16_t)t;
+      if (cx.uni(border[i]) < frame_end_slot && t > adj_e) adj_e = (int16_t)t;
+      if (cx.uni(border[i + 1]) > frame_end_slot && t > final_e) final_e = (int16_t)t;
     }
   }
   cx.sync();
@@ -3079,7 +3089,7 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
   if constexpr (Q::HQ) xs_adj_load(cx, st, nsb, adj);
   bool packed = false;
 #ifndef XS_NO_ENV_PAIRS /* (a checker build runs every frame through the one-envelope chain: tests/test_env_pairs_cpu.py) */
-  packed = xs_pack_frame_ok(cx, h) && (Q::HQ || skip == 0);
+  packed = !Q::LD && xs_pack_frame_ok(cx, h) && (Q::HQ || skip == 0);
 #endif
   if (packed) {
     /* two envelopes per pass of the gain mathematics (see "two envelopes side by side") */
@@ -3195,8 +3205,8 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
     }
   }
   for (int i = packed ? num_env : 0; i < num_env; i++) {
-    const int s0 = 2 * cx.uni(border[i]), s1 = 2 * cx.uni(border[i + 1]);
-    if (s0 >= 38 || s1 > 38 || nf_idx >= XAAC_SBR_MAX_NOISE_ENVELOPES) {
+    const int s0 = t_step * cx.uni(border[i]), s1 = t_step * cx.uni(border[i + 1]);
+    if (s0 >= row_limit || s1 > row_limit || nf_idx >= XAAC_SBR_MAX_NOISE_ENVELOPES) {
       if constexpr (Q::HQ) xs_adj_store(cx, st, nsb, adj);
       return -1;
     }
@@ -3247,8 +3257,8 @@ FX_HD int xs_calc_sbrenvelope(const XsCx &cx, const xaac_sbr_header *h, const xa
   if constexpr (Q::HQ) xs_adj_store(cx, st, nsb, adj);
   const int first_start = cx.uni(border[0]) * 2;
   const int ov_adj_e = 15 - cx.uni(st->ov_hb_scale);
-  int ov_reserve = 0, reserve = 0; /* env_calc.c:961: only taken for parametric stereo */
-  if (cx.uni(h->channel_mode) == 3) {
+  int ov_reserve = 0, reserve = 0; /* env_calc.c:961: only taken for parametric stereo (never in low-delay SBR, :962) */
+  if (!Q::LD && cx.uni(h->channel_mode) == 3) {
     ov_reserve = xs_headroom(cx, x, max_sb, sb_end, 0, first_start);
     /* the envelopes tile [first_start, 32) (the parser's grids do): every word of the range has been written by the slot
        walks, which kept the OR of the magnitudes (XsAdjMem::hr); else the scan */
@@ -3301,7 +3311,9 @@ FX_HD void xs_rescale_x_overlap(const XsCx &cx, const xaac_sbr_header *h, const 
   }
   /* (a previous frame that ended before slot 16 -- no parser's grid does -- gives a negative start: the reference then clears
      rows in front of its buffer; the rows that exist are cleared) */
-  xs_clear(cx, x, old_lsb, new_lsb, start_slot < 0 ? 0 : start_slot, 6);
+  /* (low-delay SBR: the rows are this frame's own first slots, cleared before the analysis bank fills them -- its 32 bands -- and
+     before sbr_dec.c:1121 zeroes the rest: nothing of the clearing survives, and here the bank has already run) */
+  if (!Q::LD) xs_clear(cx, x, old_lsb, new_lsb, start_slot < 0 ? 0 : start_slot, 6);
   int source, target, t_lsb, t_usb;
   if (new_lsb > old_lsb) {
     source = ov_hb;
@@ -3341,7 +3353,7 @@ FX_HD void xs_rescale_x_overlap(const XsCx &cx, const xaac_sbr_header *h, const 
    frame outside these bounds is refused with -1 like the grid checks of sbr_dec.c:733-748 instead of being indexed.
    A frame the reference decodes always passes. */
 template <class ST>
-FX_HD int xs_side_info_bad(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, const ST *st) {
+FX_HD int xs_side_info_bad(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, const ST *st, int ld = 0) {
   int bad = 0;
   /* A frame without SBR processing (apply_processing 0: the decoder has no valid SBR header yet, or lost it) is up-sampled
      by the two banks alone (xs_sbr_core_tail): header and frame side info are whatever the parser last held -- the
@@ -3359,7 +3371,8 @@ FX_HD int xs_side_info_bad(const XsCx &cx, const xaac_sbr_header *h, const xaac_
     /* the frame grid this implementation (and the reference's MAX_ENV_COLS buffers, sbr_dec.c:733-748) is laid out
        for: 16 time slots of 2 QMF slots, 32 columns -- decided here, before xs_rescale_x_overlap turns
        time_step * (prev_end_position - num_time_slots) into a row index */
-    bad |= (h->num_time_slots != 16) | (h->time_step != 2) | (h->num_columns != 32);
+    if (!ld) bad |= (h->num_time_slots != 16) | (h->time_step != 2) | (h->num_columns != 32);
+    else bad |= (h->num_time_slots != 16 && h->num_time_slots != 15) | (h->time_step != 1) | (h->num_columns != h->num_time_slots); /* low-delay SBR */
     /* (the state members that become row / band indices are looked at above: a state is the host's to initialise,
        sbrdec_initfuncs.c) */
     bad |= in(h->num_sf_bands[0], 0, XAAC_SBR_MAX_FREQ_COEFFS / 2) | in(h->num_sf_bands[1], 0, XAAC_SBR_MAX_FREQ_COEFFS);
@@ -3388,7 +3401,7 @@ FX_HD int xs_side_info_bad(const XsCx &cx, const xaac_sbr_header *h, const xaac_
       /* a patch's high bands (low band + dst_end_band, the reference's name for the offset) stay inside the row */
       bad |= pp->src_end_band > pp->src_start_band && pp->src_end_band + pp->dst_end_band > 64;
     }
-    if (i <= n_env && i <= XAAC_SBR_MAX_ENVELOPES) bad |= (unsigned)f->border_vec[i] > 19u;
+    if (i <= n_env && i <= XAAC_SBR_MAX_ENVELOPES) bad |= (unsigned)f->border_vec[i] > (ld ? (unsigned)h->num_time_slots : 19u); /* (low-delay: the matrix holds the frame's own rows) */
     if (i < n_env && i < XAAC_SBR_MAX_ENVELOPES) bad |= (unsigned)f->freq_res[i] > 1u;
     if (i <= n_nenv && i <= XAAC_SBR_MAX_NOISE_ENVELOPES) bad |= (unsigned)f->noise_border_vec[i] > 19u;
   }
@@ -3484,7 +3497,7 @@ FX_HD int xs_sbr_core_tail(const XsCx &cx, const xaac_sbr_header *h, const xaac_
     XS_ONE st->hb_scale = (int16_t)save_lb_scale;
   }
   cx.sync();
-  xs_lpc_save(cx, st, x, cx.uni(st->codec_usb));
+  xs_lpc_save(cx, st, x, cx.uni(st->codec_usb), Q::LD ? cx.uni(h->num_time_slots) * cx.uni(h->time_step) : 32);
   cx.sync();
   XS_T(15);
   return 0;
@@ -3504,16 +3517,20 @@ FX_HD int xs_sbr_core(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
                       int *save_lb_scale_out) {
   /* the frame grid this implementation (and the reference's MAX_ENV_COLS buffers, sbr_dec.c:733-748) is laid
      out for: 16 time slots of 2 QMF slots; anything else is refused like the reference refuses its own limits */
-  if (cx.uni(h->num_time_slots) * cx.uni(h->time_step) != 32 || cx.uni(h->num_columns) != 32) return -1;
+  const int no_bins = cx.uni(h->num_time_slots) * cx.uni(h->time_step);
+  if (Q::LD ? ((no_bins != 16 && no_bins != 15) || cx.uni(h->time_step) != 1 || cx.uni(h->num_columns) != no_bins)
+            : (no_bins != 32 || cx.uni(h->num_columns) != 32))
+    return -1;
   /* xs_side_info_bad has been run by the caller, before xs_rescale_x_overlap touched the overlap slots */
   const int usb = cx.uni(st->codec_usb);
-  const int reserve = xs_headroom(cx, x, 0, usb, 6, 38);
-  const int reserve_ov1 = xs_headroom(cx, x, 0, usb, 0, 6);
+  constexpr int OV = Q::OV;
+  const int reserve = xs_headroom(cx, x, 0, usb, OV, OV + no_bins);
+  const int reserve_ov1 = Q::LD ? reserve : xs_headroom(cx, x, 0, usb, 0, OV); /* sbr_dec.c:1059-1080: one scan without overlap slots */
   const XsBfp b = xs_bfp_shifts<Q::HQ>(cx, st, usb, reserve, reserve_ov1);
-  xs_adjust(cx, x, 0, usb, 0, 6, b.sh_ov);
-  xs_adjust(cx, x, 0, usb, 6, 38, b.sh_main);
+  xs_adjust(cx, x, 0, usb, 0, OV, b.sh_ov);
+  xs_adjust(cx, x, 0, usb, OV, OV + no_bins, b.sh_main);
   *save_lb_scale_out = b.save_lb_scale;
-  xs_clear(cx, x, 32, Q::NB, 6, 38); /* bands 32 and up of the analysed slots */
+  xs_clear(cx, x, 32, Q::NB, OV, OV + no_bins); /* bands 32 and up of the analysed slots */
   cx.sync();
   XS_T(1);
   return xs_sbr_core_tail(cx, h, f, env_sf_all, noise_floor_all, st, x, w, rand_hi, b);

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #endif
 
+#include "../include/xaac_amd.h" /* xaac_sbr_eld_state */
 #include "../libxaac_amd/csrc/sbr_core.h"
 #include "../libxaac_amd/csrc/sbr_ps.h"
 #include "../libxaac_amd/csrc/sbr_ps_frame.h"
@@ -244,6 +245,48 @@ extern "C" int xo_sbr_dec_lp_batch(int n, const xaac_sbr_header *h, const xaac_s
     bad += xo_sbr_dec_lp(h + i, f + i, st + i, pcm_in + 1024 * (size_t)i, 1, pcm_out + 2048 * (size_t)i, 1) != 0;
   return bad;
 }
+/* ixheaacd_sbr_dec for an AAC-ELD channel (low-delay SBR: sbr_dec.c:706-775, :1025-1308 with AOT_ER_AAC_ELD, low_pow_flag 0): no
+   overlap slots, n = num_time_slots (16 or 15) QMF slots a frame, the LD banks.  pcm_in: 32 n samples, pcm_out: 64 n.
+   handed_on (optional, [n][128]): the region-rescaled rows the synthesis bank leaves / hands on (qmf_dec.c:937-976). */
+extern "C" {
+void xo_qmf_analysis_eld(const int16_t *pcm, int stride, int16_t *ring, int16_t *state4, int n_slots, int usb, int32_t *qmf,
+                         int slot_stride);
+void xo_qmf_eld_region_scale(const int32_t *qmf, int slot_stride, const int16_t *sf, int lsb, int usb, int split, int n_slots,
+                             int32_t *out);
+void xo_qmf_synthesis_eld(const int32_t *qmf, int slot_stride, const int16_t *sf, int lsb, int usb, int split, int16_t *ring,
+                          int16_t *state4, int n_slots, int16_t *pcm, int stride);
+}
+extern "C" int xo_sbr_dec_eld(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_eld_state *st, const int16_t *pcm_in,
+                              int in_stride, int16_t *pcm_out, int out_stride, int32_t *handed_on) {
+  XO_MATRIX int32_t buf[(2 + 16) * 128];
+  XsQmfT<1, 64, 1> x = {buf};
+  const XsCx cx = {0, 1};
+  XsWork w;
+  memset(buf, 0, sizeof(buf));
+  if (xs_side_info_bad(cx, h, f, st, 1)) return -1;
+  const int n = h->num_time_slots;
+  st->lb_scale = 0;                                                   /* sbr_dec.c:767 */
+  if (f->apply_processing) xs_rescale_x_overlap(cx, h, f, st, x);     /* its two state words and scale bookkeeping: no rows */
+  {
+    int16_t s4[4] = {st->ana.wr, st->ana.f1, st->ana.f2, st->ana.fp};
+    xo_qmf_analysis_eld(pcm_in, in_stride, st->ana.ring, s4, n, st->codec_usb, &x(0, 0), 128);
+    st->ana.wr = s4[0], st->ana.f1 = s4[1], st->ana.f2 = s4[2], st->ana.fp = s4[3];
+    st->st_lb_scale = 0;
+    st->lb_scale = -9; /* generic:630-636 */
+  }
+  int save_lb_scale = 0;
+  if (xs_sbr_core(cx, h, f, f->int_env_sf_arr, f->int_noise_floor, st, x, &w, rand_hi_table(), &save_lb_scale)) return -1;
+  {
+    const int16_t sf[4] = {st->lb_scale, st->ov_lb_scale, st->hb_scale, st->st_syn_scale};
+    int16_t s4[4] = {st->syn.drc_offset, st->syn.phase, st->syn.fp, st->syn.sixty4};
+    if (handed_on) xo_qmf_eld_region_scale(&x(0, 0), 128, sf, st->syn_lsb, st->syn_usb, 0, n, handed_on);
+    xo_qmf_synthesis_eld(&x(0, 0), 128, sf, st->syn_lsb, st->syn_usb, 0, st->syn.ring, s4, n, pcm_out, out_stride);
+    st->syn.drc_offset = s4[0], st->syn.phase = s4[1], st->syn.fp = s4[2], st->syn.sixty4 = s4[3];
+  }
+  st->ov_lb_scale = (int16_t)save_lb_scale; /* sbr_dec.c:1304 */
+  return 0;
+}
+
 extern "C" int xo_sbr_dec_hq_batch(int n, const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st,
                                    const xaac_ps_frame *pf, xaac_ps_state *ps, const int16_t *pcm_in, int16_t *pcm_out) {
   int bad = 0;

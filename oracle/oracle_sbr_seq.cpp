@@ -13,4 +13,5 @@
 #define xo_sbr_dec_hq_phased xo_sbr_dec_hq_phased_seq
 #define xo_sbr_dec_lp_ds xo_sbr_dec_lp_ds_seq
 #define xo_sbr_dec_hq_ds xo_sbr_dec_hq_ds_seq
+#define xo_sbr_dec_eld xo_sbr_dec_eld_seq
 #include "oracle_sbr.cpp"

@@ -9,6 +9,7 @@
  * settings, interpolation off ... that the reference encoder never emits -- and compare with the
  * oracle / the GPU.  Linked into oracle/_ref/libref_harness.so.  No reference code is copied.
  */
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -52,11 +53,14 @@
 #include "ixheaacd_sbr_dec.h"
 #include "ixheaacd_audioobjtypes.h"
 
-#include "xaac_sbr.h"
+#include "xaac_amd.h" /* xaac_sbr_eld_state */
 
 /* one channel-frame through the real ixheaacd_sbr_dec: low-power (HE-AACv1), HQ, or HQ + parametric stereo
    (pf / ps given and channel_mode = PS_STEREO: right channel at pcm_out[n * out_stride + 1]) */
 static int g_down_sample; /* ref_sbr_set_down_sample() */
+/* ref_sbr_dec_eld(): the call runs as an AAC-ELD channel's (low-delay SBR) with these bank states; handed-on rows out */
+static __thread xaac_sbr_eld_state *g_eld;
+static __thread int32_t *g_eld_handed_on;
 static int run_sbr_dec(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st, const xaac_ps_frame *psf,
                        xaac_ps_state *pss, int low_pow, const int16_t *pcm_in, int in_stride, int16_t *pcm_out,
                        int out_stride) {
@@ -181,12 +185,38 @@ static int run_sbr_dec(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_s
   d.str_sbr_calc_env.harm_index = st->harm_index;
   memcpy(d.str_sbr_calc_env.harm_flags_prev, st->harm_flags_prev, sizeof(st->harm_flags_prev));
   for (i = 0; i < MAX_ENV_COLS; i++) d.p_arr_qmf_buf_real[i] = d.p_arr_qmf_buf_imag[i] = copy_re[i];
+  static __thread WORD32 copy_im[MAX_ENV_COLS][64];
+  static __thread WORD16 eld_ana_ring[320], eld_syn_ring[1280];
+  const int n_eld = g_eld ? h->num_time_slots : 0;
+  if (g_eld) { /* the LD / ELD banks in the states ixheaacd_cplx_anal_qmffilt / _synt_qmffilt keep for AOT_ER_AAC_ELD */
+    ia_sbr_qmf_filter_bank_struct *a = &d.str_codec_qmf_bank, *sy = &d.str_synthesis_qmf_bank;
+    for (i = 0; i < MAX_ENV_COLS; i++) d.p_arr_qmf_buf_imag[i] = copy_im[i];
+    memcpy(eld_ana_ring, g_eld->ana.ring, sizeof(eld_ana_ring));
+    memcpy(eld_syn_ring, g_eld->syn.ring, sizeof(eld_syn_ring));
+    a->num_time_slots = n_eld;
+    a->anal_filter_states = eld_ana_ring;
+    a->core_samples_buffer = eld_ana_ring + g_eld->ana.wr;
+    a->analy_win_coeff = qt->qmf_c_eld3;
+    a->filter_pos = qt->qmf_c_eld3 + g_eld->ana.f1;
+    a->filter_2 = qt->qmf_c_eld3 + g_eld->ana.f2;
+    a->fp1_anal = eld_ana_ring + g_eld->ana.fp;
+    a->fp2_anal = eld_ana_ring + (32 - g_eld->ana.fp);
+    sy->num_time_slots = n_eld;
+    sy->no_channels = 64;
+    sy->filter_states = eld_syn_ring;
+    sy->p_filter = qt->qmf_c_eld;
+    sy->filter_pos_syn = qt->qmf_c_eld + g_eld->syn.phase;
+    sy->ixheaacd_drc_offset = g_eld->syn.drc_offset;
+    sy->fp1_syn = eld_syn_ring + g_eld->syn.fp;
+    sy->sixty4 = g_eld->syn.sixty4;
+    sy->fp2_syn = sy->fp1_syn + sy->sixty4;
+  }
   memcpy(pf.sbr_invf_mode, st->prev_invf_mode, sizeof(pf.sbr_invf_mode));
   pf.max_qmf_subband_aac = st->prev_max_qmf_subband_aac;
   pf.coupling_mode = st->prev_coupling_mode;
   pf.end_position = st->prev_end_position;
   pf.amp_res = st->prev_amp_res;
-  for (i = 0; i < 1024; i++) time_data[i * (use_ps ? 2 : 1)] = pcm_in[(size_t)i * in_stride];
+  for (i = 0; i < (g_eld ? 32 * n_eld : 1024); i++) time_data[i * (use_ps ? 2 : 1)] = pcm_in[(size_t)i * in_stride];
   if (use_ps) { /* ia_ps_dec_struct over local copies of the boundary state (layout: sbrdec_initfuncs.c:976) */
     memset(&psd, 0, sizeof(psd));
     memset(&bank_r, 0, sizeof(bank_r));
@@ -259,7 +289,28 @@ static int run_sbr_dec(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_s
   ret = ixheaacd_sbr_dec(&d, time_data, &hd, fr, &pf, use_ps ? &psd : NULL, use_ps ? &bank_r : NULL,
                          use_ps ? &sf_r : NULL, f->apply_processing, low_pow, work, &tabs,
                          (ixheaacd_misc_tables *)&ixheaacd_str_fft_n_transcendent_tables, use_ps ? 2 : 1, NULL, 0, NULL,
-                         use_ps ? AOT_PS : AOT_SBR, 0, NULL, 0, 0);
+                         g_eld ? AOT_ER_AAC_ELD : (use_ps ? AOT_PS : AOT_SBR), 0, NULL, 0, 0);
+  if (g_eld) { /* output, bank states and the handed-on rows of the low-delay call */
+    ia_sbr_qmf_filter_bank_struct *a = &d.str_codec_qmf_bank, *sy = &d.str_synthesis_qmf_bank;
+    int k;
+    for (i = 0; i < 64 * n_eld; i++) pcm_out[(size_t)i * out_stride] = time_data[i];
+    memcpy(g_eld->ana.ring, eld_ana_ring, sizeof(eld_ana_ring));
+    g_eld->ana.wr = (int16_t)(a->core_samples_buffer - eld_ana_ring);
+    g_eld->ana.f1 = (int16_t)(a->filter_pos - qt->qmf_c_eld3);
+    g_eld->ana.f2 = (int16_t)(a->filter_2 - qt->qmf_c_eld3);
+    g_eld->ana.fp = (int16_t)(a->fp1_anal - eld_ana_ring);
+    memcpy(g_eld->syn.ring, eld_syn_ring, sizeof(eld_syn_ring));
+    g_eld->syn.drc_offset = (int16_t)sy->ixheaacd_drc_offset;
+    g_eld->syn.phase = (int16_t)(sy->filter_pos_syn - qt->qmf_c_eld);
+    g_eld->syn.fp = (int16_t)(sy->fp1_syn - eld_syn_ring);
+    g_eld->syn.sixty4 = (int16_t)sy->sixty4;
+    if (g_eld_handed_on)
+      for (i = 0; i < n_eld; i++)
+        for (k = 0; k < 64; k++) {
+          g_eld_handed_on[128 * i + k] = copy_re[i][k];
+          g_eld_handed_on[128 * i + 64 + k] = copy_im[i][k];
+        }
+  } else
   if (use_ps) {
     for (i = 0; i < (g_down_sample ? 1024 : 2048); i++) {
       pcm_out[(size_t)i * out_stride] = time_data[2 * i];
@@ -338,6 +389,25 @@ void ref_sbr_set_down_sample(int on) { g_down_sample = on; }
 int ref_sbr_dec_lp(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st, const int16_t *pcm_in,
                    int in_stride, int16_t *pcm_out, int out_stride) {
   return run_sbr_dec(h, f, st, NULL, NULL, 1, pcm_in, in_stride, pcm_out, out_stride);
+}
+
+/* an AAC-ELD channel's frame (low-delay SBR): the tail of the state travels through an xaac_sbr_state, the banks through g_eld */
+int ref_sbr_dec_eld(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_eld_state *est, const int16_t *pcm_in, int in_stride,
+                    int16_t *pcm_out, int out_stride, int32_t *handed_on) {
+  static __thread xaac_sbr_state tmp;
+  const size_t tail = sizeof(xaac_sbr_state) - offsetof(xaac_sbr_state, lpc_real);
+  int ret;
+  memset(&tmp, 0, sizeof(tmp));
+  tmp.codec_usb = est->codec_usb, tmp.syn_lsb = est->syn_lsb, tmp.syn_usb = est->syn_usb;
+  memcpy(&tmp.lpc_real, &est->lpc_real, tail);
+  g_eld = est;
+  g_eld_handed_on = handed_on;
+  ret = run_sbr_dec(h, f, &tmp, NULL, NULL, 0, pcm_in, in_stride, pcm_out, out_stride);
+  g_eld = NULL;
+  g_eld_handed_on = NULL;
+  est->codec_usb = tmp.codec_usb, est->syn_lsb = tmp.syn_lsb, est->syn_usb = tmp.syn_usb;
+  memcpy(&est->lpc_real, &tmp.lpc_real, tail);
+  return ret;
 }
 
 int ref_sbr_dec_hq(const xaac_sbr_header *h, const xaac_sbr_frame *f, xaac_sbr_state *st, const xaac_ps_frame *pf,

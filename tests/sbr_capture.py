@@ -100,3 +100,28 @@ def read_records(path, limit=None):
             if limit and len(recs) >= limit:
                 break
     return recs
+
+
+# ---- AAC-ELD channels (low-delay SBR): include/xaac_amd.h xaac_sbr_eld_state
+class EldAna(ctypes.Structure):
+    _fields_ = [("ring", I16 * 320), ("wr", I16), ("f1", I16), ("f2", I16), ("fp", I16)]
+
+
+class EldSyn(ctypes.Structure):
+    _fields_ = [("ring", I16 * 1280), ("drc_offset", I16), ("phase", I16), ("fp", I16), ("sixty4", I16)]
+
+
+class EldState(ctypes.Structure):
+    _fields_ = [("ana", EldAna), ("syn", EldSyn), ("codec_usb", I16), ("syn_lsb", I16), ("syn_usb", I16), ("pad2_", I16)] + \
+               State._fields_[State._fields_.index(("lpc_real", (I32 * 32) * 2)):]
+
+
+def eld_state_from(st):
+    """a new AAC-ELD channel's state: the banks as sbrdec_initfuncs.c:1122-1148 / :1181-1209 leave them, the rest (the
+    members ixheaacd_sbr_dec's core works on) taken from a captured xaac_sbr_state image of the reference's structs"""
+    e = EldState()
+    e.ana.f2, e.syn.sixty4 = 32, 64
+    e.codec_usb, e.syn_lsb, e.syn_usb = st.codec_usb, st.syn_lsb, st.syn_usb
+    off = State.lpc_real.offset
+    ctypes.memmove(ctypes.addressof(e) + EldState.lpc_real.offset, ctypes.addressof(st) + off, ctypes.sizeof(State) - off)
+    return e
