@@ -211,6 +211,14 @@ class _SbrHqBatch(ctypes.Structure):
                 ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_uint64)]
 
 
+class _SbrEldBatch(ctypes.Structure):
+    # struct xaac_sbr_eld_batch
+    _fields_ = [("n_ch", ctypes.c_int32), ("n_slots", ctypes.c_int32), ("in_ch_fac", ctypes.c_int32), ("out_ch_fac", ctypes.c_int32),
+                ("pcm_in", ctypes.c_void_p), ("header", ctypes.c_void_p), ("frame", ctypes.c_void_p), ("state", ctypes.c_void_p),
+                ("pcm_out", ctypes.c_void_p), ("status", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
+                ("workspace_bytes", ctypes.c_uint64), ("qmf_handed_on", ctypes.c_void_p)]
+
+
 class _LimiterBatch(ctypes.Structure):
     # struct xaac_limiter_batch
     _fields_ = [("n_streams", ctypes.c_int32), ("frame_len", ctypes.c_int32), ("samples", ctypes.c_void_p),
@@ -235,6 +243,7 @@ class LimiterState(ctypes.Structure):
 
 LIMITER_STATE_BYTES = ctypes.sizeof(LimiterState)   # 17328
 SBR_HEADER_BYTES, SBR_FRAME_BYTES, SBR_STATE_BYTES = 336, 1072, 7300   # include/xaac_sbr.h
+SBR_ELD_STATE_BYTES = 4236                                             # xaac_sbr_eld_state (include/xaac_amd.h)
 PS_FRAME_BYTES, PS_STATE_BYTES = 972, 7764
 QMF_ANA_STATE_WORDS = 322    # int16 words of struct xaac_qmf_ana_state: ring[320], wr, phase
 QMF_SYN_STATE_WORDS = 1282   # int16 words of struct xaac_qmf_syn_state: ring[1280], drc_offset, phase
@@ -309,6 +318,9 @@ def load_library():
     lib.xaac_sbr_lp_workspace_bytes.restype = ctypes.c_uint64
     lib.xaac_sbr_hq_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_SbrHqBatch)]
     lib.xaac_sbr_hq_process_batch.restype = ctypes.c_int32
+    lib.xaac_sbr_eld_workspace_bytes.argtypes = [ctypes.c_int32]
+    lib.xaac_sbr_eld_workspace_bytes.restype = ctypes.c_uint64
+    lib.xaac_sbr_eld_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_SbrEldBatch)]
     lib.xaac_sbr_hq_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32]
     lib.xaac_sbr_hq_workspace_bytes.restype = ctypes.c_uint64
     lib.xaac_peak_limiter_init.argtypes = [ctypes.POINTER(LimiterState), ctypes.c_uint32, ctypes.c_uint32]
@@ -765,6 +777,29 @@ class XaacContext:
         rc = self._lib.xaac_esbr_qmf_synthesis_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_esbr_qmf_synthesis_batch")
+
+    def sbr_eld_workspace_bytes(self, n_ch):
+        return int(self._lib.xaac_sbr_eld_workspace_bytes(int(n_ch)))
+
+    def sbr_eld_process_batch(self, pcm_in, header, frame, state, pcm_out, workspace, n_slots, status=None, in_ch_fac=1,
+                              out_ch_fac=1, qmf_handed_on=None):
+        """Batched ixheaacd_sbr_dec for AAC-ELD channels (low-delay SBR): pcm_in int16[n_ch * 32 n_slots], state
+        uint8[n_ch, SBR_ELD_STATE_BYTES] (xaac_sbr_eld_state), pcm_out int16[n_ch * 64 n_slots]; n_slots 16 or 15"""
+        n_ch = state.shape[0]
+        b = _SbrEldBatch()
+        b.n_ch, b.n_slots, b.in_ch_fac, b.out_ch_fac = n_ch, int(n_slots), int(in_ch_fac), int(out_ch_fac)
+        b.pcm_in = _ptr(pcm_in, "int16", n_ch * 32 * int(n_slots), device_ok=True)
+        b.header = _ptr(header, "uint8", n_ch * SBR_HEADER_BYTES, device_ok=True)
+        b.frame = _ptr(frame, "uint8", n_ch * SBR_FRAME_BYTES, device_ok=True)
+        b.state = _ptr(state, "uint8", n_ch * SBR_ELD_STATE_BYTES, device_ok=True)
+        b.pcm_out = _ptr(pcm_out, "int16", n_ch * 64 * int(n_slots), device_ok=True)
+        b.status = _ptr(status, "int32", n_ch, allow_none=True, device_ok=True)
+        b.workspace = _ptr(workspace, "uint8", device_ok=True)
+        b.workspace_bytes = workspace.numel()
+        b.qmf_handed_on = _ptr(qmf_handed_on, "int32", n_ch * int(n_slots) * 128, allow_none=True, device_ok=True)
+        rc = self._lib.xaac_sbr_eld_process_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_sbr_eld_process_batch")
 
     def sbr_hq_workspace_bytes(self, n_ch, with_ps=True):
         return int(self._lib.xaac_sbr_hq_workspace_bytes(int(n_ch), int(bool(with_ps))))

@@ -77,7 +77,20 @@ extern "C" {
 hipError_t xaac_launch_qmf_synthesis_pair(const XaacQmfSynPairParams *p, hipStream_t stream);
 hipError_t xaac_launch_qmf_analysis(const XaacQmfAnaParams *p, int grid, hipStream_t stream);
 #define XAAC_QMF_ELD_LDS (4 * (288 + 512) * 2 + 64 * 65 * 4) /* four channels' time-ordered history + the exchange tile */
+/* the LD / ELD banks inside the low-delay SBR chain (xaac_sbr_eld_process_batch): the public batch + where the chain keeps
+   things.  All optional: zero = the stand-alone entry points' tight arrays and batch-wide band limits. */
+typedef struct XaacQmfEldChain {
+  int32_t state_stride;         /* bytes between consecutive channels' bank states (0: the state struct's own size) */
+  int32_t pcm_ch_fac;           /* interleave stride of the PCM (0 / 1: planar) */
+  const xaac_sbr_frame *frame;  /* analysis: the band limit of the final rotation is per channel -- what ixheaacd_rescale_x_overlap
+                                   leaves in str_codec_qmf_bank.usb in front of the bank: the frame's max_qmf_subband_aac when it is
+                                   processed, else codec_usb */
+  const int16_t *codec_usb;     /* ... of channel 0, the others state_stride bytes apart */
+  const int16_t *syn_par;       /* synthesis, [n_ch][8]: lb, ov_lb, hb, st_syn scales, lsb, usb, [6] != 0: channel left alone */
+} XaacQmfEldChain;
 hipError_t xaac_launch_qmf_analysis_eld(const xaac_qmf_ana_eld_batch *p, hipStream_t stream);
+hipError_t xaac_launch_qmf_analysis_eld_chain(const xaac_qmf_ana_eld_batch *p, const XaacQmfEldChain *c, hipStream_t stream);
+hipError_t xaac_launch_qmf_synthesis_eld_chain(const xaac_qmf_syn_eld_batch *p, const XaacQmfEldChain *c, hipStream_t stream);
 #define XAAC_QMF_ELD_SYN_LDS (4 * 25 * 130 * 2) /* four channels x (9 + 16) slots of ring samples, padded rows */
 hipError_t xaac_launch_qmf_synthesis_eld(const xaac_qmf_syn_eld_batch *p, hipStream_t stream);
 hipError_t xaac_launch_qmf_synthesis(const XaacQmfSynParams *p, int grid, hipStream_t stream);

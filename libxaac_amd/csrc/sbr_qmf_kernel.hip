@@ -871,7 +871,12 @@ __device__ __forceinline__ int eld_phase(const xaac_qmf_ana_eld_state *st) { /* 
 }
 }  // namespace
 
-__global__ __launch_bounds__(64) void xaac_qmf_analysis_eld_kernel(xaac_qmf_ana_eld_batch p) {
+__global__ __launch_bounds__(64) void xaac_qmf_analysis_eld_kernel(xaac_qmf_ana_eld_batch p, XaacQmfEldChain cn) {
+  const auto state_of = [&](int ch) {
+    return reinterpret_cast<xaac_qmf_ana_eld_state *>(reinterpret_cast<char *>(p.state) +
+                                                      (size_t)ch * (cn.state_stride ? cn.state_stride : (int)sizeof(xaac_qmf_ana_eld_state)));
+  };
+  const int fac = cn.pcm_ch_fac > 1 ? cn.pcm_ch_fac : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int H = 288 + 512;
   int16_t *hist = reinterpret_cast<int16_t *>(smem);              /* [4][H], oldest first */
@@ -885,13 +890,13 @@ __global__ __launch_bounds__(64) void xaac_qmf_analysis_eld_kernel(xaac_qmf_ana_
     const int ch = 4 * quad + c;
     int16_t *h = hist + c * H;
     phase[c] = -1;
-    if (ch < p.n_ch) phase[c] = eld_phase(p.state + ch);
+    if (ch < p.n_ch) phase[c] = eld_phase(state_of(ch));
     if (phase[c] >= 0) {
-      const xaac_qmf_ana_eld_state *st = p.state + ch;
+      const xaac_qmf_ana_eld_state *st = state_of(ch);
       const int wr = st->wr;
       for (int a = lane; a < 288; a += 64) h[287 - a] = st->ring[ana_ring_pos(wr, a)];
-      const int16_t *src = p.pcm + (size_t)ch * 32 * ns;
-      for (int i = lane; i < 32 * ns; i += 64) h[288 + i] = src[i];
+      const int16_t *src = p.pcm + (size_t)(ch / fac) * 32 * ns * fac + ch % fac;
+      for (int i = lane; i < 32 * ns; i += 64) h[288 + i] = src[(size_t)i * fac];
     } else {
       for (int i = lane; i < H; i += 64) h[i] = 0;
     }
@@ -913,7 +918,17 @@ __global__ __launch_bounds__(64) void xaac_qmf_analysis_eld_kernel(xaac_qmf_ana_
     int32_t in[64], sb[128], t[128];
 #pragma unroll
     for (int k = 0; k < 64; k++) in[k] = z[65 * lane + k];
-    xq_fwd_modulation(in, sb, t, p.usb, true);
+    int usb = p.usb;
+    if (cn.frame) { /* the lane's channel: what ixheaacd_rescale_x_overlap leaves in the bank (sbrdec_lpfuncs.c:470) */
+      const int chl = 4 * quad + (lane >> 4);
+      if (chl < p.n_ch) {
+        const xaac_sbr_frame *fr = cn.frame + chl;
+        usb = fr->apply_processing ? fr->max_qmf_subband_aac
+                                   : *reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(cn.codec_usb) + (size_t)chl * cn.state_stride);
+        usb = usb < 0 ? 0 : (usb > 32 ? 32 : usb);
+      }
+    }
+    xq_fwd_modulation(in, sb, t, usb, true);
 #pragma unroll
     for (int k = 0; k < 32; k++) {
       z[65 * lane + k] = sb[k];
@@ -930,7 +945,7 @@ __global__ __launch_bounds__(64) void xaac_qmf_analysis_eld_kernel(xaac_qmf_ana_
   for (int c = 0; c < 4; c++) { /* the ring and the pointers as the reference leaves them after n_slots slots */
     const int ch = 4 * quad + c;
     if (ch >= p.n_ch || phase[c] < 0) continue;
-    xaac_qmf_ana_eld_state *st = p.state + ch;
+    xaac_qmf_ana_eld_state *st = state_of(ch);
     const int t = (phase[c] + ns) % 10, wr_new = (320 - 32 * t) % 320;
     const int16_t *h = hist + c * H + 288 + 32 * ns; /* one past the newest sample */
     for (int a = lane; a < 320; a += 64) st->ring[ana_ring_pos(wr_new, a)] = h[-1 - a];
@@ -956,7 +971,12 @@ __device__ __forceinline__ int eld_syn_phase(const xaac_qmf_syn_eld_state *st) {
 }
 }  // namespace
 
-__global__ __launch_bounds__(64) void xaac_qmf_synthesis_eld_kernel(xaac_qmf_syn_eld_batch p) {
+__global__ __launch_bounds__(64) void xaac_qmf_synthesis_eld_kernel(xaac_qmf_syn_eld_batch p, XaacQmfEldChain cn) {
+  const auto state_of = [&](int ch) {
+    return reinterpret_cast<xaac_qmf_syn_eld_state *>(reinterpret_cast<char *>(p.state) +
+                                                      (size_t)ch * (cn.state_stride ? cn.state_stride : (int)sizeof(xaac_qmf_syn_eld_state)));
+  };
+  const int fac = cn.pcm_ch_fac > 1 ? cn.pcm_ch_fac : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int VR = 130, VS = 25; /* padded row (int16), rows per channel: 9 of history + up to 16 slots */
   int16_t *v = reinterpret_cast<int16_t *>(smem); /* [4][VS][VR] */
@@ -967,11 +987,13 @@ __global__ __launch_bounds__(64) void xaac_qmf_synthesis_eld_kernel(xaac_qmf_syn
   int phase[4];
   for (int c = 0; c < 4; c++) {
     const int ch = 4 * quad + c;
-    phase[c] = ch < p.n_ch ? eld_syn_phase(p.state + ch) : -1;
-    if (lane == 0 && p.status && ch < p.n_ch) p.status[ch] = phase[c] >= 0 ? 0 : -1;
+    phase[c] = ch < p.n_ch ? eld_syn_phase(state_of(ch)) : -1;
+    const bool skipped = ch < p.n_ch && cn.syn_par && cn.syn_par[8 * (size_t)ch + 6] != 0; /* the chain's core refused the frame */
+    if (lane == 0 && p.status && ch < p.n_ch && !skipped && (!cn.syn_par || phase[c] < 0)) p.status[ch] = phase[c] >= 0 ? 0 : -1;
+    if (skipped) phase[c] = -1;
     int16_t *vc = v + c * VS * VR;
     if (phase[c] >= 0) {
-      const xaac_qmf_syn_eld_state *st = p.state + ch;
+      const xaac_qmf_syn_eld_state *st = state_of(ch);
       const int d0 = st->drc_offset;
       for (int e = lane; e < 9 * 128; e += 64) { /* slot -A (A = 1..9) lives 128 A behind the write offset */
         const int a = 1 + e / 128, o = e % 128;
@@ -984,7 +1006,8 @@ __global__ __launch_bounds__(64) void xaac_qmf_synthesis_eld_kernel(xaac_qmf_syn
   {
     const int c = lane >> 4, s = lane & 15, ch = 4 * quad + c;
     if (phase[c] >= 0 && s < ns) {
-      const int16_t *sf = p.scale + 4 * (size_t)ch;
+      const int16_t *sf = cn.syn_par ? cn.syn_par + 8 * (size_t)ch : p.scale + 4 * (size_t)ch;
+      const int lsb = cn.syn_par ? sf[4] : p.lsb, usb = cn.syn_par ? sf[5] : p.usb;
       const int st_syn = sf[3];
       const int ov_lb_shift = (st_syn - sf[1]) - 7, lb_shift = (st_syn - sf[0]) - 7, hb_shift = (st_syn - sf[2]) - 7;
       const int32_t *row = p.qmf + ((size_t)ch * ns + s) * p.slot_stride;
@@ -994,8 +1017,8 @@ __global__ __launch_bounds__(64) void xaac_qmf_synthesis_eld_kernel(xaac_qmf_syn
       for (int k = 0; k < 128; k++) {
         const int band = k & 63;
         int32_t val = row[k];
-        if (band < p.lsb) val = adj_scale(val, s < p.split ? ov_lb_shift : lb_shift);
-        else if (band < p.usb) val = adj_scale(val, hb_shift);
+        if (band < lsb) val = adj_scale(val, s < p.split ? ov_lb_shift : lb_shift);
+        else if (band < usb) val = adj_scale(val, hb_shift);
         x[k] = val;
       }
       if (p.qmf_scaled) {
@@ -1017,12 +1040,12 @@ __global__ __launch_bounds__(64) void xaac_qmf_synthesis_eld_kernel(xaac_qmf_syn
     int32_t acc = 0x8000 >> 2;
 #pragma unroll
     for (int a = 0; a < 10; a++) acc += (int32_t)vc[(9 + s - a) * VR + 64 * (a & 1) + lane] * coef[a];
-    p.pcm[((size_t)ch * ns + s) * 64 + lane] = (int16_t)(fx_shl_sat(acc, 2) >> 16);
+    p.pcm[(size_t)(ch / fac) * 64 * ns * fac + ((size_t)s * 64 + lane) * fac + ch % fac] = (int16_t)(fx_shl_sat(acc, 2) >> 16);
   }
   for (int c = 0; c < 4; c++) { /* the ring = the last ten slots' samples at the offsets the reference wrote them to */
     const int ch = 4 * quad + c;
     if (phase[c] < 0) continue;
-    xaac_qmf_syn_eld_state *st = p.state + ch;
+    xaac_qmf_syn_eld_state *st = state_of(ch);
     const int d0 = st->drc_offset, t = (phase[c] + ns) % 10;
     const int16_t *vc = v + c * VS * VR;
     for (int e = lane; e < 1280; e += 64) {
@@ -1038,14 +1061,22 @@ __global__ __launch_bounds__(64) void xaac_qmf_synthesis_eld_kernel(xaac_qmf_syn
   }
 }
 
-extern "C" hipError_t xaac_launch_qmf_synthesis_eld(const xaac_qmf_syn_eld_batch *p, hipStream_t stream) {
-  hipLaunchKernelGGL(xaac_qmf_synthesis_eld_kernel, dim3((p->n_ch + 3) / 4), dim3(64), XAAC_QMF_ELD_SYN_LDS, stream, *p);
+extern "C" hipError_t xaac_launch_qmf_synthesis_eld_chain(const xaac_qmf_syn_eld_batch *p, const XaacQmfEldChain *c, hipStream_t stream) {
+  hipLaunchKernelGGL(xaac_qmf_synthesis_eld_kernel, dim3((p->n_ch + 3) / 4), dim3(64), XAAC_QMF_ELD_SYN_LDS, stream, *p, *c);
   return hipGetLastError();
 }
+extern "C" hipError_t xaac_launch_qmf_synthesis_eld(const xaac_qmf_syn_eld_batch *p, hipStream_t stream) {
+  const XaacQmfEldChain none = {};
+  return xaac_launch_qmf_synthesis_eld_chain(p, &none, stream);
+}
 
-extern "C" hipError_t xaac_launch_qmf_analysis_eld(const xaac_qmf_ana_eld_batch *p, hipStream_t stream) {
-  hipLaunchKernelGGL(xaac_qmf_analysis_eld_kernel, dim3((p->n_ch + 3) / 4), dim3(64), XAAC_QMF_ELD_LDS, stream, *p);
+extern "C" hipError_t xaac_launch_qmf_analysis_eld_chain(const xaac_qmf_ana_eld_batch *p, const XaacQmfEldChain *c, hipStream_t stream) {
+  hipLaunchKernelGGL(xaac_qmf_analysis_eld_kernel, dim3((p->n_ch + 3) / 4), dim3(64), XAAC_QMF_ELD_LDS, stream, *p, *c);
   return hipGetLastError();
+}
+extern "C" hipError_t xaac_launch_qmf_analysis_eld(const xaac_qmf_ana_eld_batch *p, hipStream_t stream) {
+  const XaacQmfEldChain none = {};
+  return xaac_launch_qmf_analysis_eld_chain(p, &none, stream);
 }
 
 extern "C" hipError_t xaac_launch_qmf_analysis(const XaacQmfAnaParams *p, int grid, hipStream_t stream) {

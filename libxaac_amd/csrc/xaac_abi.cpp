@@ -16,6 +16,7 @@
 #include "imdct_kernel.h"
 #include "sbr_qmf_kernel.h"
 #include "sbr_core_kernel.h"
+#include "sbr_ld_core_kernel.h"
 #include "sbr_ps_kernel.h"
 #include "limiter_kernel.h"
 #include "esbr_qmf_kernel.h"
@@ -129,7 +130,7 @@ int32_t xaac_set_stream(xaac_ctx *c, void *hip_stream) {
 extern "C" {
 hipError_t xaac_warm_imdct(void), xaac_warm_sbr_qmf(void), xaac_warm_sbr_core(void), xaac_warm_sbr_ps(void), xaac_warm_limiter(void),
     xaac_warm_esbr_qmf(void), xaac_warm_esbr_core(void), xaac_warm_esbr_ps(void), xaac_warm_hbe(void), xaac_warm_usac_imdct(void),
-    xaac_warm_imdct960(void), xaac_warm_imdct_ld(void), xaac_warm_pvc(void);
+    xaac_warm_imdct960(void), xaac_warm_imdct_ld(void), xaac_warm_pvc(void), xaac_warm_sbr_ld_core(void);
 }
 
 int32_t xaac_warm_up(xaac_ctx *c) {
@@ -137,7 +138,7 @@ int32_t xaac_warm_up(xaac_ctx *c) {
   if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
   hipError_t (*const hooks[])(void) = {xaac_warm_imdct,     xaac_warm_sbr_qmf,   xaac_warm_sbr_core, xaac_warm_sbr_ps,     xaac_warm_limiter,
                                        xaac_warm_esbr_qmf,  xaac_warm_esbr_core, xaac_warm_esbr_ps,  xaac_warm_hbe,        xaac_warm_usac_imdct,
-                                       xaac_warm_imdct960,  xaac_warm_imdct_ld,  xaac_warm_pvc};
+                                       xaac_warm_imdct960,  xaac_warm_imdct_ld,  xaac_warm_pvc,      xaac_warm_sbr_ld_core};
   for (auto h : hooks)
     if (!hip_ok(h())) return XAAC_FATAL_HIP;
   return XAAC_OK;
@@ -581,6 +582,47 @@ uint64_t xaac_sbr_hq_workspace_bytes(int32_t n_ch, int32_t with_ps) {
   uint64_t per = 2 * XAAC_SBR_X_WORDS * 4 + 8 * 2 + 4; /* matrix, synthesis parameters, an entry of the core's stream list */
   if (with_ps) per += 32 * 128 * 4 + 8 * 2;
   return (uint64_t)n_ch * per + 512 + 128;
+}
+
+/* the low-delay SBR chain of AAC-ELD channels: LD analysis bank -> core (sbr_ld_core_kernel.hip) -> LD synthesis bank */
+uint64_t xaac_sbr_eld_workspace_bytes(int32_t n_ch) {
+  return n_ch > 0 ? (uint64_t)n_ch * (16 * 128 * 4 + 8 * 2) + 512 : 0; /* the matrices, the synthesis parameters, alignment */
+}
+int32_t xaac_sbr_eld_process_batch(xaac_ctx *c, const xaac_sbr_eld_batch *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n_ch < 0 || (b->n_slots != 16 && b->n_slots != 15)) return XAAC_FATAL_BAD_ARG;
+  if ((b->in_ch_fac != 1 && b->in_ch_fac != 2) || (b->out_ch_fac != 1 && b->out_ch_fac != 2)) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch % b->in_ch_fac || b->n_ch % b->out_ch_fac) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch == 0) return XAAC_OK;
+  if (!b->pcm_in || !b->header || !b->frame || !b->state || !b->pcm_out || !b->workspace) return XAAC_FATAL_NULL_ARG;
+  if (b->workspace_bytes < xaac_sbr_eld_workspace_bytes(b->n_ch)) return XAAC_FATAL_BAD_ARG;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  const size_t n = (size_t)b->n_ch;
+  int32_t *x = reinterpret_cast<int32_t *>(((uintptr_t)b->workspace + 255) & ~(uintptr_t)255);
+  int16_t *par = reinterpret_cast<int16_t *>(x + n * 16 * 128);
+  char *st = reinterpret_cast<char *>(b->state);
+  XaacQmfEldChain cn = {};
+  cn.state_stride = (int32_t)sizeof(xaac_sbr_eld_state);
+  /* 1. analysis: n_slots slots of 32 real | 32 imaginary bands into each channel's matrix */
+  xaac_qmf_ana_eld_batch a = {};
+  a.n_ch = b->n_ch; a.n_slots = b->n_slots; a.usb = 32; a.slot_stride = 128; a.pcm = b->pcm_in;
+  a.state = reinterpret_cast<xaac_qmf_ana_eld_state *>(st + offsetof(xaac_sbr_eld_state, ana));
+  a.qmf = x; a.status = nullptr;
+  cn.pcm_ch_fac = b->in_ch_fac; cn.frame = b->frame;
+  cn.codec_usb = reinterpret_cast<const int16_t *>(st + offsetof(xaac_sbr_eld_state, codec_usb));
+  if (!hip_ok(xaac_launch_qmf_analysis_eld_chain(&a, &cn, c->stream))) return XAAC_FATAL_HIP;
+  /* 2. between the banks */
+  XaacSbrLdCoreParams pc = {b->n_ch, b->n_slots, b->header, b->frame, b->state, x, par, b->status};
+  if (!hip_ok(xaac_launch_sbr_ld_core(&pc, c->stream))) return XAAC_FATAL_HIP;
+  /* 3. synthesis */
+  xaac_qmf_syn_eld_batch sy = {};
+  sy.n_ch = b->n_ch; sy.n_slots = b->n_slots; sy.split = 0; sy.slot_stride = 128; sy.qmf = x; sy.scale = par;
+  sy.state = reinterpret_cast<xaac_qmf_syn_eld_state *>(st + offsetof(xaac_sbr_eld_state, syn));
+  sy.pcm = b->pcm_out; sy.status = nullptr; sy.qmf_scaled = b->qmf_handed_on;
+  cn.pcm_ch_fac = b->out_ch_fac; cn.syn_par = par;
+  if (!hip_ok(xaac_launch_qmf_synthesis_eld_chain(&sy, &cn, c->stream))) return XAAC_FATAL_HIP;
+  c->last_grid = b->n_ch; c->last_block = 64; c->last_lds = 0;
+  return XAAC_OK;
 }
 
 int32_t xaac_sbr_hq_process_batch(xaac_ctx *c, const xaac_sbr_hq_batch *b) {

@@ -247,6 +247,55 @@ static void from_state(const xaac_sbr_state *o, int low_pow, ia_sbr_dec_struct *
   memcpy(e->harm_flags_prev, o->harm_flags_prev, sizeof(o->harm_flags_prev));
 }
 
+/* ---- AAC-ELD channels (low-delay SBR): xaac_sbr_eld_state <-> the reference's structs.  The members ixheaacd_sbr_dec's core
+   works on are the ones to_state / from_state carry; the LD banks keep four rotating pointers each (generic:609-741, qmf_dec.c:
+   862-1135), stored as offsets.  `t`: the QMF tables (the banks are re-based onto qmf_c_eld3 / qmf_c_eld first, as the two
+   functions do on entry). */
+#include <stddef.h>
+#include "xaac_amd.h"
+static void to_eld_state(ia_sbr_dec_struct *d, const ia_sbr_prev_frame_data_struct *p, ia_qmf_dec_tables_struct *t, xaac_sbr_eld_state *o) {
+  static xaac_sbr_state tmp;
+  ia_sbr_qmf_filter_bank_struct *a = &d->str_codec_qmf_bank, *s = &d->str_synthesis_qmf_bank;
+  to_state(d, p, 0, &tmp);
+  memset(o, 0, sizeof(*o));
+  o->codec_usb = tmp.codec_usb, o->syn_lsb = tmp.syn_lsb, o->syn_usb = tmp.syn_usb;
+  memcpy(&o->lpc_real, &tmp.lpc_real, sizeof(xaac_sbr_state) - offsetof(xaac_sbr_state, lpc_real));
+  a->filter_pos += t->qmf_c_eld3 - a->analy_win_coeff;
+  a->analy_win_coeff = t->qmf_c_eld3;
+  memcpy(o->ana.ring, a->anal_filter_states, sizeof(o->ana.ring));
+  o->ana.wr = (int16_t)(a->core_samples_buffer - a->anal_filter_states);
+  o->ana.f1 = (int16_t)(a->filter_pos - t->qmf_c_eld3);
+  o->ana.f2 = (int16_t)(a->filter_2 - t->qmf_c_eld3);
+  o->ana.fp = (int16_t)(a->fp1_anal - a->anal_filter_states);
+  s->filter_pos_syn += t->qmf_c_eld - s->p_filter;
+  s->p_filter = t->qmf_c_eld;
+  memcpy(o->syn.ring, s->filter_states, sizeof(o->syn.ring));
+  o->syn.drc_offset = (int16_t)s->ixheaacd_drc_offset;
+  o->syn.phase = (int16_t)(s->filter_pos_syn - t->qmf_c_eld);
+  o->syn.fp = (int16_t)(s->fp1_syn - s->filter_states);
+  o->syn.sixty4 = (int16_t)s->sixty4;
+}
+static void from_eld_state(const xaac_sbr_eld_state *o, ia_sbr_dec_struct *d, ia_sbr_prev_frame_data_struct *p, ia_qmf_dec_tables_struct *t) {
+  static xaac_sbr_state tmp;
+  ia_sbr_qmf_filter_bank_struct *a = &d->str_codec_qmf_bank, *s = &d->str_synthesis_qmf_bank;
+  to_state(d, p, 0, &tmp); /* (the AAC banks' words and the overlap buffer go back as they came) */
+  tmp.codec_usb = o->codec_usb, tmp.syn_lsb = o->syn_lsb, tmp.syn_usb = o->syn_usb;
+  memcpy(&tmp.lpc_real, &o->lpc_real, sizeof(xaac_sbr_state) - offsetof(xaac_sbr_state, lpc_real));
+  from_state(&tmp, 0, d, p);
+  memcpy(a->anal_filter_states, o->ana.ring, sizeof(o->ana.ring));
+  a->core_samples_buffer = a->anal_filter_states + o->ana.wr;
+  a->filter_pos = t->qmf_c_eld3 + o->ana.f1;
+  a->filter_2 = t->qmf_c_eld3 + o->ana.f2;
+  a->fp1_anal = a->anal_filter_states + o->ana.fp;
+  a->fp2_anal = a->anal_filter_states + (32 - o->ana.fp);
+  memcpy(s->filter_states, o->syn.ring, sizeof(o->syn.ring));
+  s->ixheaacd_drc_offset = o->syn.drc_offset;
+  s->filter_pos_syn = t->qmf_c_eld + o->syn.phase;
+  s->fp1_syn = s->filter_states + o->syn.fp;
+  s->sixty4 = o->syn.sixty4;
+  s->fp2_syn = s->fp1_syn + s->sixty4;
+}
+
 static void from_ps_state(const xaac_ps_state *o, ia_ps_dec_struct *ps, ia_sbr_qmf_filter_bank_struct *sr,
                           ia_sbr_scale_fact_struct *sf_r) {
   int i;

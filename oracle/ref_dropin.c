@@ -44,7 +44,7 @@ static struct {
   xaac_esbr_pvc_state *pvst;
 } g;
 static long g_eld_ana_calls, g_eld_syn_calls;
-static long g_imdct_calls, g_sbr_calls, g_lim_calls, g_esbr_calls, g_esbr_harm_calls, g_esbr_usac_calls, g_esbr_pvc_calls, g_sbr_ref_calls, g_usac_imdct_calls, g_usac_imdct_fac, g_usac_imdct_lpd, g_imdct960_calls, g_imdct_ld_calls;
+static long g_imdct_calls, g_sbr_calls, g_lim_calls, g_esbr_calls, g_esbr_harm_calls, g_esbr_usac_calls, g_esbr_pvc_calls, g_sbr_ref_calls, g_usac_imdct_calls, g_usac_imdct_fac, g_usac_imdct_lpd, g_eld_sbr_calls, g_imdct960_calls, g_imdct_ld_calls;
 static struct { int32_t *overlap; int16_t *pcm; uint8_t *shape; } gl; /* AAC-LD / ELD: 3 x 512 overlap words, 512 samples, 2 bytes */
 
 static void die(const char *what) {
@@ -58,6 +58,7 @@ static void report(void) {
   fprintf(stderr, "xaacdec_dropin: %ld imdct_process calls of 960-line frames and %ld of AAC-LD / ELD frames ran on the GPU\n",
           g_imdct960_calls, g_imdct_ld_calls);
   fprintf(stderr, "xaacdec_dropin: %ld LD / ELD analysis-bank and %ld synthesis-bank calls ran on the GPU\n", g_eld_ana_calls, g_eld_syn_calls);
+  fprintf(stderr, "xaacdec_dropin: %ld whole low-delay SBR calls (AAC-ELD: banks + core) ran on the GPU\n", g_eld_sbr_calls);
   fprintf(stderr, "xaacdec_dropin: %ld peak_limiter_process calls ran on the GPU\n", g_lim_calls);
   fprintf(stderr, "xaacdec_dropin: %ld sbr_dec calls took the eSBR (Path A) branch on the GPU\n", g_esbr_calls);
   fprintf(stderr, "xaacdec_dropin: %ld of them with harmonic patching (the QMF transposer's output)\n", g_esbr_harm_calls);
@@ -572,6 +573,70 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
               (int)h->enh_sbr_ps, (int)h->channel_mode, (int)drc_on, (int)ldmps, (int)mps, (int)f->mps_sbr_flag, (int)f->sbr_mode,
               (int)h->sbr_ratio_idx, (int)h->pre_proc_flag, (int)h->num_time_slots, (int)d->str_codec_qmf_bank.no_channels,
               (int)d->str_synthesis_qmf_bank.no_channels, (int)f->sbr_patching_mode);
+  }
+  /* AAC-ELD channels: the whole call -- LD analysis bank, low-delay SBR core, LD synthesis bank -- as one xaac_sbr_eld_process_batch
+     (the two banks' own seams above stay for what this does not take: LD-MPS, DRC inside the bank, the low-power flag) */
+  if (aot == AOT_ER_AAC_ELD && !low_pow && !drc_on && !ldmps && !mps && (h->num_time_slots == 16 || h->num_time_slots == 15) &&
+      h->time_step == 1 && d->str_codec_qmf_bank.no_channels == 32 && d->str_synthesis_qmf_bank.no_channels == 64 &&
+      d->str_hf_generator.pstr_settings->num_columns == h->num_time_slots && !getenv("XAAC_DROPIN_NO_ELD_SBR")) {
+    static xaac_sbr_eld_state est;
+    static struct { xaac_sbr_eld_state *st; int16_t *in, *out; int32_t *hand; void *ws; } e;
+    static int16_t ein[512], eout[1024];
+    static int32_t hand[16][128];
+    ia_qmf_dec_tables_struct *t = tabs->qmf_dec_tables_ptr;
+    const int ns = h->num_time_slots;
+    xaac_sbr_eld_batch b;
+    int k;
+    setup();
+    if (!e.st) {
+      HIP(hipMalloc((void **)&e.st, sizeof(est)));
+      HIP(hipMalloc((void **)&e.in, sizeof(ein)));
+      HIP(hipMalloc((void **)&e.out, sizeof(eout)));
+      HIP(hipMalloc((void **)&e.hand, sizeof(hand)));
+      HIP(hipMalloc(&e.ws, xaac_sbr_eld_workspace_bytes(1)));
+    }
+    /* what the two bank functions do to their banks besides the filtering (generic:609-651, qmf_dec.c:862-875) */
+    d->str_codec_qmf_bank.cos_twiddle = (WORD16 *)t->sbr_sin_cos_twiddle_l32;
+    d->str_codec_qmf_bank.alt_sin_twiddle = (WORD16 *)t->sbr_alt_sin_twiddle_l32;
+    d->str_codec_qmf_bank.t_cos = (WORD16 *)t->ixheaacd_sbr_t_cos_sin_l32_eld;
+    d->str_synthesis_qmf_bank.cos_twiddle = (WORD16 *)t->sbr_sin_cos_twiddle_l64;
+    d->str_synthesis_qmf_bank.alt_sin_twiddle = (WORD16 *)t->sbr_alt_sin_twiddle_l64;
+    to_header(h, d, &hd);
+    to_frame(f, apply, &fr);
+    to_eld_state(d, p, t, &est);
+    for (i = 0; i < 32 * ns; i++) ein[i] = time_data[i * ch_fac];
+    HIP(hipMemcpy(g.hdr, &hd, sizeof(hd), hipMemcpyHostToDevice));
+    HIP(hipMemcpy(g.frame, &fr, sizeof(fr), hipMemcpyHostToDevice));
+    HIP(hipMemcpy(e.st, &est, sizeof(est), hipMemcpyHostToDevice));
+    HIP(hipMemcpy(e.in, ein, 2 * 32 * ns, hipMemcpyHostToDevice));
+    memset(&b, 0, sizeof(b));
+    b.n_ch = 1;
+    b.n_slots = ns;
+    b.in_ch_fac = b.out_ch_fac = 1;
+    b.pcm_in = e.in;
+    b.header = g.hdr;
+    b.frame = g.frame;
+    b.state = e.st;
+    b.pcm_out = e.out;
+    b.status = g.status;
+    b.workspace = e.ws;
+    b.workspace_bytes = xaac_sbr_eld_workspace_bytes(1);
+    b.qmf_handed_on = e.hand;
+    if (xaac_sbr_eld_process_batch(g_ctx, &b) != XAAC_OK || xaac_sync(g_ctx) != XAAC_OK) die("xaac_sbr_eld_process_batch");
+    HIP(hipMemcpy(&status, g.status, 4, hipMemcpyDeviceToHost));
+    if (status) return status;
+    HIP(hipMemcpy(&est, e.st, sizeof(est), hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(eout, e.out, 2 * 64 * ns, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(hand, e.hand, 512 * ns, hipMemcpyDeviceToHost));
+    from_eld_state(&est, d, p, t);
+    for (i = 0; i < 64 * ns; i++) time_data[i * ch_fac] = eout[i];
+    for (i = 0; i < ns; i++) /* the rescaled rows the synthesis bank hands on (qmf_dec.c:966-976) */
+      for (k = 0; k < 64; k++) {
+        d->p_arr_qmf_buf_real[i][k] = hand[i][k];
+        d->p_arr_qmf_buf_imag[i][k] = hand[i][64 + k];
+      }
+    g_eld_sbr_calls++;
+    return 0;
   }
   /* outside the paths this library covers (USAC / PS / HBE eSBR, LD/ELD, DRC inside the bank, MPS): the reference's own code */
   if (h->enh_sbr || aot == AOT_ER_AAC_ELD || aot == AOT_ER_AAC_LD || drc_on || ldmps || mps ||

@@ -88,12 +88,20 @@ def test_null_and_bad_arguments_are_fatal_codes():
     assert lib.xaac_imdct_process_batch(None, None) & 0x80000000
 
 
+def _eld_state():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import sbr_capture
+    assert ctypes.sizeof(sbr_capture.EldState) == libxaac_amd.SBR_ELD_STATE_BYTES
+    return sbr_capture.EldState
+
+
 def test_struct_layout_matches_header(tmp_path):
     """every batch descriptor's ctypes mirror against what a C compiler makes of include/xaac_amd.h"""
     import subprocess
     pairs = [("xaac_imdct_batch", libxaac_amd._ImdctBatch, "status"), ("xaac_qmf_ana_batch", libxaac_amd._QmfAnaBatch, "qmf"),
              ("xaac_qmf_syn_batch", libxaac_amd._QmfSynBatch, "pcm"), ("xaac_sbr_lp_batch", libxaac_amd._SbrLpBatch, "workspace_bytes"),
-             ("xaac_sbr_hq_batch", libxaac_amd._SbrHqBatch, "workspace_bytes")]
+             ("xaac_sbr_hq_batch", libxaac_amd._SbrHqBatch, "workspace_bytes"),
+             ("xaac_sbr_eld_batch", libxaac_amd._SbrEldBatch, "qmf_handed_on"), ("xaac_sbr_eld_state", _eld_state(), "harm_flags_prev")]
     body = "".join('printf("%%zu %%zu\\n", sizeof(%s), offsetof(%s, %s));' % (c, c, last) for c, _, last in pairs)
     src = tmp_path / "layout.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "xaac_amd.h"\nint main(void) { %s return 0; }\n' % body)

@@ -76,9 +76,9 @@ STREAMS_LD = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "streams_ld"
 def test_other_frame_lengths_through_the_gpu(aac, flags, tmp_path):
     """AAC-LC with 960-line frames, AAC-LD and AAC-ELD with 512- and 480-line frames (made by the reference encoder,
     tools/make_golden_streams.py): the real reference decoder with ixheaacd_imdct_process served by
-    xaac_imdct960_process_batch / xaac_imdct_ld_process_batch writes the same bytes as the unmodified one; in the ELD streams'
-    low-delay SBR (the reference's code) the two complex QMF banks are diverted to xaac_qmf_analysis_eld_batch /
-    xaac_qmf_synthesis_eld_batch."""
+    xaac_imdct960_process_batch / xaac_imdct_ld_process_batch writes the same bytes as the unmodified one; the ELD streams'
+    low-delay SBR runs whole on the GPU (xaac_sbr_eld_process_batch: LD analysis bank, core, LD synthesis bank), and with
+    the core left to the reference its two complex QMF banks alone (xaac_qmf_analysis_eld_batch / xaac_qmf_synthesis_eld_batch)."""
     if not (os.path.exists(os.path.join(REF, "xaacdec")) and os.path.exists(os.path.join(REF, "xaacdec_dropin"))):
         pytest.fail("oracle/_ref/xaacdec[_dropin] missing: the reference binaries (built by oracle/Makefile.ref where /root/reference exists, git-ignored) did not travel with the snapshot -- the drop-in evidence must not vanish silently")
     meta = aac[:-4] + ".txt"
@@ -92,8 +92,15 @@ def test_other_frame_lengths_through_the_gpu(aac, flags, tmp_path):
     assert (n960 > 100 and nld == 0) if "lc960" in aac else (nld > 100 and n960 == 0), (n960, nld)
     mb = re.search(r"(\d+) LD / ELD analysis-bank and (\d+) synthesis-bank calls ran on the GPU", log)
     assert mb, log[-600:]
-    if "eld" in os.path.basename(aac):   # low-delay SBR: its two complex QMF banks (16 / 15 slots) ran on the GPU as well
-        assert int(mb.group(1)) > 100 and int(mb.group(2)) > 100, mb.groups()
+    if "eld" in os.path.basename(aac):   # low-delay SBR: every ixheaacd_sbr_dec call whole -- LD banks (16 / 15 slots) + core -- on the GPU
+        me = re.search(r"(\d+) whole low-delay SBR calls", log)
+        assert me and int(me.group(1)) > 100, log[-600:]
+        # ... and with the core left to the reference (XAAC_DROPIN_NO_ELD_SBR) its two banks alone, as before
+        bank_wav = str(tmp_path / "banks.wav")
+        log2 = _decode("xaacdec_dropin", aac, bank_wav, extra=extra, env=dict(os.environ, XAAC_DROPIN_NO_ELD_SBR="1"))
+        mb2 = re.search(r"(\d+) LD / ELD analysis-bank and (\d+) synthesis-bank calls ran on the GPU", log2)
+        assert mb2 and int(mb2.group(1)) > 100 and int(mb2.group(2)) > 100, log2[-600:]
+        assert open(bank_wav, "rb").read() == open(ref_wav, "rb").read()
     a, b = open(ref_wav, "rb").read(), open(gpu_wav, "rb").read()
     assert len(a) > 100000 and a == b, (len(a), len(b), n960, nld)
 

@@ -57,3 +57,36 @@ def test_oracle_walks_the_reference_chains(oracle):
             assert crc(po) == want[0], ("pcm", c, s)
             assert crc(st) == want[1], ("state", c, s)
             assert crc(hand[:128 * n]) == want[2], ("handed-on rows", c, s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_slots", [16, 15])
+def test_gpu_walks_the_reference_chains(n_slots):
+    import torch
+    import libxaac_amd
+    ctx = libxaac_amd.XaacContext(0, 0)
+    dev = torch.device("cuda:0")
+    order = chains()
+    mine = [c for c in range(len(order)) if int(CH["n_slots"][c]) == n_slots]
+    assert len(mine) >= 4
+    m = len(mine)
+    assert CH["st0"].shape[1] == libxaac_amd.SBR_ELD_STATE_BYTES
+    t_st = torch.from_numpy(np.ascontiguousarray(CH["st0"][mine])).to(dev)
+    ws = torch.zeros(ctx.sbr_eld_workspace_bytes(m), dtype=torch.uint8, device=dev)
+    for s in range(min(len(order[c]) for c in mine)):
+        rows = [order[c][s] for c in mine]
+        pin = torch.from_numpy(np.concatenate([chain_pcm(3, c, s)[:32 * n_slots] for c in mine])).to(dev)
+        g = lambda k: torch.from_numpy(np.ascontiguousarray(CH[k][rows])).to(dev)
+        out = torch.zeros(m * 64 * n_slots, dtype=torch.int16, device=dev)
+        hand = torch.zeros(m * n_slots * 128, dtype=torch.int32, device=dev)
+        status = torch.full((m,), 7, dtype=torch.int32, device=dev)
+        ctx.sbr_eld_process_batch(pin, g("header"), g("frame"), t_st, out, ws, n_slots, status=status, qmf_handed_on=hand)
+        ctx.sync()
+        assert np.array_equal(status.cpu().numpy(), CH["ret"][rows]), s
+        o, hd, stn = out.cpu().numpy().reshape(m, -1), hand.cpu().numpy().reshape(m, -1), t_st.cpu().numpy()
+        for j, r in enumerate(rows):
+            want = CH["crc"][r]
+            assert crc(o[j]) == want[0], ("pcm", mine[j], s)
+            assert crc(stn[j]) == want[1], ("state", mine[j], s)
+            assert crc(hd[j]) == want[2], ("handed-on rows", mine[j], s)
+    ctx.close()
