@@ -387,6 +387,19 @@ typedef struct xaac_esbr_ana_batch {
   float *qmf_re, *qmf_im;      /* [n_ch][32 slots][64]: bands 0..31 written (qmf_buf_real / _imag rows) */
 } xaac_esbr_ana_batch;
 
+/* The analysis banks of USAC's other SBR ratios (sbr_dec.c:213-236, sbrdec_initfuncs.c:766-816): 24 channels for 8:3 SBR (768
+ * core samples -> 32 slots), 16 channels for 4:1 SBR (1024 -> 64 slots).  Same state struct (the ring holds 10 n_bands words;
+ * win_off counts from esbr_qmf_c_24 for 24 channels). */
+typedef struct xaac_esbr_ana_nb_batch {
+  int32_t n_ch;
+  int32_t n_bands;             /* 24 | 16 */
+  int32_t n_slots;             /* <= 64, n_bands * n_slots <= 1024 */
+  int32_t core_stride;         /* floats between consecutive channels' core rows (>= n_bands * n_slots) */
+  const float *core;           /* [n_ch][core_stride] */
+  xaac_esbr_ana_state *state;  /* [n_ch] in/out */
+  float *qmf_re, *qmf_im;      /* [n_ch][n_slots][64]: bands 0..n_bands-1 written, n_bands..31 zeroed */
+} xaac_esbr_ana_nb_batch;
+
 typedef struct xaac_esbr_syn_batch {
   int32_t n_ch;
   const float *qmf_re, *qmf_im; /* [n_ch][32 slots][64] */
@@ -477,6 +490,7 @@ XAAC_API int32_t xaac_usac_imdct_process_batch(xaac_ctx *ctx, const xaac_usac_im
 
 /* eSBR (Path A) QMF banks, device pointers, asynchronous on the context's stream. */
 XAAC_API int32_t xaac_esbr_qmf_analysis_batch(xaac_ctx *ctx, const xaac_esbr_ana_batch *batch);
+XAAC_API int32_t xaac_esbr_qmf_analysis_nb_batch(xaac_ctx *ctx, const xaac_esbr_ana_nb_batch *batch);
 /* ixheaacd_cplx_anal_qmffilt for AAC-LD / ELD cores (complex bank, 16 or 15 slots per frame) */
 XAAC_API int32_t xaac_qmf_analysis_eld_batch(xaac_ctx *ctx, const xaac_qmf_ana_eld_batch *batch);
 /* ixheaacd_cplx_synt_qmffilt for AAC-LD / ELD (complex bank, 64 channels, 16 or 15 slots per frame) */

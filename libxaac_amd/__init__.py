@@ -140,6 +140,13 @@ class _EsbrAnaBatch(ctypes.Structure):
                 ("qmf_re", ctypes.c_void_p), ("qmf_im", ctypes.c_void_p)]
 
 
+class _EsbrAnaNbBatch(ctypes.Structure):
+    # struct xaac_esbr_ana_nb_batch
+    _fields_ = [("n_ch", ctypes.c_int32), ("n_bands", ctypes.c_int32), ("n_slots", ctypes.c_int32),
+                ("core_stride", ctypes.c_int32), ("core", ctypes.c_void_p), ("state", ctypes.c_void_p),
+                ("qmf_re", ctypes.c_void_p), ("qmf_im", ctypes.c_void_p)]
+
+
 class _HbeSynthBatch(ctypes.Structure):
     # struct xaac_hbe_synth_batch
     _fields_ = [("n_ch", ctypes.c_int32), ("num_columns", ctypes.c_int32), ("qmf_re", ctypes.c_void_p),
@@ -310,6 +317,8 @@ def load_library():
     lib.xaac_qmf_synthesis_eld_batch.restype = ctypes.c_int32
     lib.xaac_esbr_qmf_analysis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_EsbrAnaBatch)]
     lib.xaac_esbr_qmf_analysis_batch.restype = ctypes.c_int32
+    lib.xaac_esbr_qmf_analysis_nb_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_EsbrAnaNbBatch)]
+    lib.xaac_esbr_qmf_analysis_nb_batch.restype = ctypes.c_int32
     lib.xaac_esbr_qmf_synthesis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_EsbrSynBatch)]
     lib.xaac_esbr_qmf_synthesis_batch.restype = ctypes.c_int32
     lib.xaac_sbr_lp_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_SbrLpBatch)]
@@ -762,6 +771,21 @@ class XaacContext:
         rc = self._lib.xaac_esbr_qmf_analysis_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_esbr_qmf_analysis_batch")
+
+    def esbr_qmf_analysis_nb_batch(self, n_bands, n_slots, core, state, qmf_re, qmf_im):
+        """The 24- / 16-channel analysis banks of 8:3 / 4:1 SBR (sbr_dec.c:213-236): core float32[n_ch, core_stride];
+        state int32[n_ch, 322] in/out; qmf_re / qmf_im float32[n_ch, n_slots, 64]."""
+        n_ch = state.shape[0]
+        b = _EsbrAnaNbBatch()
+        b.n_ch, b.n_bands, b.n_slots = n_ch, n_bands, n_slots
+        b.core_stride = int(core.shape[1])
+        b.core = _ptr(core, "float32", n_ch * b.core_stride, device_ok=True)
+        b.state = _ptr(state, "int32", n_ch * ESBR_ANA_STATE_WORDS, device_ok=True)
+        b.qmf_re = _ptr(qmf_re, "float32", n_ch * n_slots * 64, device_ok=True)
+        b.qmf_im = _ptr(qmf_im, "float32", n_ch * n_slots * 64, device_ok=True)
+        rc = self._lib.xaac_esbr_qmf_analysis_nb_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_esbr_qmf_analysis_nb_batch")
 
     def esbr_qmf_synthesis_batch(self, qmf_re, qmf_im, state, out):
         """Batched synthesis bank of ixheaacd_esbr_synthesis_filt_block (eSBR / Path A, 64 channels):

@@ -18,6 +18,16 @@ typedef struct XaacEsbrAnaParams {
   int32_t state_stride;         /* bytes between consecutive channels' states */
 } XaacEsbrAnaParams;
 
+typedef struct XaacEsbrAnaNbParams { /* the 24- / 16-channel banks of 8:3 / 4:1 SBR */
+  int32_t n_ch, nb, n_slots;    /* nb 24 | 16; n_slots <= 64, nb * n_slots <= 1024 */
+  const float *core;            /* [n_ch][core_stride], nb * n_slots samples used */
+  int32_t core_stride;
+  xaac_esbr_ana_state *state;   /* [n_ch]; ring[0 .. 10 nb - 1] used */
+  int32_t state_stride;         /* bytes between consecutive channels' states */
+  float *qmf_re, *qmf_im;       /* [n_ch][out_stride]: n_slots rows of 64, bands 0..nb-1 written, nb..31 zeroed */
+  int32_t out_stride;
+} XaacEsbrAnaNbParams;
+
 typedef struct XaacEsbrSynParams {
   int32_t n_ch;
   const float *qmf_re, *qmf_im; /* [n_ch][32][64] */
@@ -46,6 +56,7 @@ extern "C" {
 hipError_t xaac_launch_esbr_core_from_pcm16(const XaacEsbrCoreInParams *p, hipStream_t stream);
 hipError_t xaac_launch_esbr_pcm16_from_float(const XaacEsbrPcmOutParams *p, hipStream_t stream);
 hipError_t xaac_launch_esbr_analysis(const XaacEsbrAnaParams *p, hipStream_t stream);
+hipError_t xaac_launch_esbr_analysis_nb(const XaacEsbrAnaNbParams *p, hipStream_t stream);
 hipError_t xaac_launch_esbr_synthesis(const XaacEsbrSynParams *p, hipStream_t stream);
 #ifdef __cplusplus
 }

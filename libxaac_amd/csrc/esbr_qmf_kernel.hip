@@ -154,6 +154,84 @@ __global__ __launch_bounds__(64) void xaac_esbr_analysis_kernel(XaacEsbrAnaParam
   }
 }
 
+/* The 24- and 16-channel banks of 8:3 and 4:1 SBR (sbr_dec.c:213-236): one wave per channel-frame, lane = time slot (32 of 24
+   samples, 64 of 16).  Nothing here is closed-form: a lane forms its slot exactly as the reference's loop does at that slot --
+   the ring as it stands then (the newest write of this frame to a block, or the word the state holds), the window pointers
+   after that many steps -- so any state the reference can hand over gives the reference's result.  These banks are not on
+   the headline path (HE-AAC is 2:1); the kernel is written for exactness and a short critical path, not tuned. */
+namespace {
+template <int NB>
+struct XeRingAt {        /* anal_filter_states_32 at slot s of this frame */
+  const int32_t *old_ring; /* LDS: the state's ring */
+  const int32_t *frame;    /* LDS: (WORD32)(core * 2^15), time order */
+  int pb, s;               /* block the frame's first slot writes; this lane's slot */
+  __device__ __forceinline__ int32_t operator()(int pos) const {
+    const int b = pos / NB, r = pos - b * NB;
+    int k0 = pb - b;
+    k0 += k0 < 0 ? 10 : 0;                              /* first slot of the frame that writes block b; then every tenth */
+    if (k0 > s) return old_ring[pos];
+    const int k = k0 + 10 * ((s - k0) / 10);
+    return frame[k * NB + NB - 1 - r];                  /* sbr_dec.c:247-250: the block holds the slot's samples reversed */
+  }
+};
+}  // namespace
+
+template <int NB>
+__global__ __launch_bounds__(64) void xaac_esbr_analysis_nb_kernel(XaacEsbrAnaNbParams p) {
+  constexpr int RS = 65;
+  __shared__ int32_t old_ring[10 * NB];
+  __shared__ int32_t frame[1024];
+  __shared__ int32_t tile[64 * RS];
+  const int lane = threadIdx.x, ch = blockIdx.x, n_slots = p.n_slots;
+  xaac_esbr_ana_state *st = reinterpret_cast<xaac_esbr_ana_state *>(reinterpret_cast<char *>(p.state) + (size_t)ch * p.state_stride);
+  const float *src = p.core + (size_t)ch * p.core_stride;
+  int pos0 = st->pos, win0 = st->win_off;
+  for (int i = lane; i < 10 * NB; i += 64) old_ring[i] = st->ring[i];
+  for (int i = lane; i < NB * n_slots; i += 64) frame[i] = fx_f2i_trunc(src[i] * 32768.0f); /* sbr_dec.c:248 */
+  pos0 = __builtin_amdgcn_readfirstlane(pos0);
+  win0 = __builtin_amdgcn_readfirstlane(win0);
+  /* states no run of the reference produces (a position off the block grid, a window offset off its step) are brought onto
+     the grid instead of being followed out of the arrays */
+  int pb = pos0 / NB;
+  pb = pb < 0 ? 0 : (pb > 9 ? 9 : pb);
+  constexpr int fo = XqEsbrAna<NB>::fo;
+  win0 = win0 < 0 ? 0 : (win0 > 9 * fo ? 9 * fo : win0 / fo * fo);
+  __syncthreads();
+  if (lane < n_slots) {
+    int w1 = win0, w2 = win0 + fo;
+    for (int k = 0; k < lane; k++) xq_esbr_win_step<NB>(w1, w2);
+    const XeRingAt<NB> rg = {old_ring, frame, pb, lane};
+    int32_t anal[2 * NB], sb[128], t[128];
+    xq_esbr_winadd_nb<NB>(rg, (lane & 1) ? NB : 0, (lane & 1) ? 0 : NB, w1, w2, anal);
+    xq_esbr_fwd_modulation_nb<NB>(anal, sb, t);
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      tile[RS * lane + k] = sb[k];
+      tile[RS * lane + 32 + k] = sb[64 + k];
+    }
+  }
+  __syncthreads();
+  { /* rows out: lanes 0..31 the real bands, 32..63 the imaginary ones; bands NB..31 are never written by the reference and are
+       zero in its buffers: written as zeros here, for the kernels behind that read 32 bands of a row */
+    const float gain = XqEsbrAna<NB>::gain();
+    float *dst = (lane < 32 ? p.qmf_re : p.qmf_im) + (size_t)ch * p.out_stride;
+    const int k = lane & 31;
+    for (int r = 0; r < n_slots; r++) dst[64 * r + k] = k < NB ? (float)tile[RS * r + lane] * gain : 0.0f;
+  }
+  { /* the state as the reference leaves it: every block's newest write, the pointers after n_slots steps */
+    const XeRingAt<NB> rg = {old_ring, frame, pb, n_slots - 1};
+    for (int i = lane; i < 10 * NB; i += 64) st->ring[i] = n_slots > 0 ? rg(i) : old_ring[i];
+    if (lane == 0) {
+      int w1 = win0, w2 = win0 + fo;
+      for (int k = 0; k < n_slots; k++) xq_esbr_win_step<NB>(w1, w2);
+      int pn = (pb - n_slots) % 10;
+      pn += pn < 0 ? 10 : 0;
+      st->pos = pn * NB;
+      st->win_off = w1;
+    }
+  }
+}
+
 /* Two waves per channel pair, as in xaac_qmf_synthesis_pair_kernel (sbr_qmf_kernel.hip): the slot transform's two independent
    halves (sbr_qmf.h: xq_cos_sin_mod_half) run on the workgroup's two waves -- wave h takes the real (h = 0) or imaginary
    (h = 1) half rows of all 64 rows (2 channels x 32 slots, lane = (channel, slot)) through its own half-size tile, a lane
@@ -334,6 +412,12 @@ extern "C" hipError_t xaac_launch_esbr_pcm16_from_float(const XaacEsbrPcmOutPara
 
 extern "C" hipError_t xaac_launch_esbr_analysis(const XaacEsbrAnaParams *p, hipStream_t stream) {
   hipLaunchKernelGGL(xaac_esbr_analysis_kernel, dim3((p->n_ch + 1) / 2), dim3(64), XAAC_ESBR_ANA_LDS, stream, *p);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t xaac_launch_esbr_analysis_nb(const XaacEsbrAnaNbParams *p, hipStream_t stream) {
+  if (p->nb == 24) hipLaunchKernelGGL(xaac_esbr_analysis_nb_kernel<24>, dim3(p->n_ch), dim3(64), 0, stream, *p);
+  else hipLaunchKernelGGL(xaac_esbr_analysis_nb_kernel<16>, dim3(p->n_ch), dim3(64), 0, stream, *p);
   return hipGetLastError();
 }
 

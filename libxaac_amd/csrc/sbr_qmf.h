@@ -103,8 +103,12 @@ struct XqW32 {
   }
   static FX_MEMBER const T *w32() { return XQ_T(esbr_w_32); }
   static FX_MEMBER const T *w16() { return XQ_T(esbr_w_16); }
-  template <int M> static FX_MEMBER const T *tw() { return M == 32 ? XQ_T(esbr_sin_cos_twiddle_l64) : XQ_T(esbr_sin_cos_twiddle_l32); }
-  template <int M> static FX_MEMBER const T *alt() { return M == 32 ? XQ_T(esbr_alt_sin_twiddle_l64) : XQ_T(esbr_alt_sin_twiddle_l32); }
+  template <int M> static FX_MEMBER const T *tw() {
+    return M == 32 ? XQ_T(esbr_sin_cos_twiddle_l64) : M == 16 ? XQ_T(esbr_sin_cos_twiddle_l32) : M == 12 ? XQ_T(esbr_sin_cos_twiddle_l24) : XQ_T(esbr_sin_cos_twiddle_l16);
+  }
+  template <int M> static FX_MEMBER const T *alt() {
+    return M == 32 ? XQ_T(esbr_alt_sin_twiddle_l64) : M == 16 ? XQ_T(esbr_alt_sin_twiddle_l32) : M == 12 ? XQ_T(esbr_alt_sin_twiddle_l24) : XQ_T(esbr_alt_sin_twiddle_l16);
+  }
 };
 
 /* radix-4 pass over interleaved complex x; twiddles (si1,co1,si2,co2,si3,co3) per column */
@@ -249,6 +253,129 @@ FX_HD void xq_dct3_32(int32_t *in, int32_t *out) {
   out[31] = in[16];
 }
 
+/* ---- the general FFT's forward transforms of 4, 8 and 12 points (ixheaacd_complex_fft_p2_dec / _p3 with fft_mode = -1,
+   decoder/ixheaacd_fft.c:1412 / :2531): what ixheaacd_esbr_cos_sin_mod (generic:1317-1369) calls for the 24- and 16-channel
+   analysis banks of 8:3 and 4:1 SBR.  xr / xi: separate real and imaginary words, in place. ------------------------------ */
+FX_HD int32_t xq_mul31_sat(int32_t a, int32_t b) { return fx_sat64(((int64_t)a * (int64_t)b) >> 31); } /* fft.c:48 */
+/* the radix-4 butterfly of the first pass (fft.c:1476-1501); results in the reference's store order */
+FX_HD void xq_fwd_bfly4(int32_t x0r, int32_t x0i, int32_t x1r, int32_t x1i, int32_t x2r, int32_t x2i, int32_t x3r, int32_t x3i, int32_t *y) {
+  x0r = fx_add_sat(x0r, x2r);
+  x0i = fx_add_sat(x0i, x2i);
+  x2r = fx_sub_sat(x0r, fx_shl_sat(x2r, 1));
+  x2i = fx_sub_sat(x0i, fx_shl_sat(x2i, 1));
+  x1r = fx_add_sat(x1r, x3r);
+  x1i = fx_add_sat(x1i, x3i);
+  x3r = fx_sub_sat(x1r, fx_shl_sat(x3r, 1));
+  x3i = fx_sub_sat(x1i, fx_shl_sat(x3i, 1));
+  x0r = fx_add_sat(x0r, x1r);
+  x0i = fx_add_sat(x0i, x1i);
+  x1r = fx_sub_sat(x0r, fx_shl_sat(x1r, 1));
+  x1i = fx_sub_sat(x0i, fx_shl_sat(x1i, 1));
+  x2r = fx_add_sat(x2r, x3i);
+  x2i = fx_sub_sat(x2i, x3r);
+  x3i = fx_sub_sat(x2r, fx_shl_sat(x3i, 1));
+  x3r = fx_add_sat(x2i, fx_shl_sat(x3r, 1));
+  y[0] = x0r; y[1] = x0i; y[2] = x2r; y[3] = x2i; y[4] = x1r; y[5] = x1i; y[6] = x3i; y[7] = x3r;
+}
+/* 4 points: input / 8 (C's truncating division, fft.c:1443), one butterfly on the points in natural order (:1452: the digit
+   reversal of 0 is 0, the legs are npoints / 2 words apart) */
+FX_HD void xq_fft_fwd4(int32_t *xr, int32_t *xi) {
+  int32_t y[8];
+  xq_fwd_bfly4(xr[0] / 8, xi[0] / 8, xr[1] / 8, xi[1] / 8, xr[2] / 8, xi[2] / 8, xr[3] / 8, xi[3] / 8, y);
+  XQ_UNROLL
+  for (int i = 0; i < 4; i++) {
+    xr[i] = y[2 * i];
+    xi[i] = y[2 * i + 1];
+  }
+}
+/* 8 points: input / 8, two butterflies (even points, odd points: :1452-1457 with not_power_4), then the radix-2 stage
+   (:1903-1963; del 4, twiddles at node spacing 128 = the table's words 0, 1 and 256, 257).  The reference reports an
+   exponent of 4 for it, which its caller applies (generic:1348). */
+FX_HD void xq_fft_fwd8(int32_t *xr, int32_t *xi) {
+  int32_t y[16];
+  xq_fwd_bfly4(xr[0] / 8, xi[0] / 8, xr[2] / 8, xi[2] / 8, xr[4] / 8, xi[4] / 8, xr[6] / 8, xi[6] / 8, y);
+  xq_fwd_bfly4(xr[1] / 8, xi[1] / 8, xr[3] / 8, xi[3] / 8, xr[5] / 8, xi[5] / 8, xr[7] / 8, xi[7] / 8, y + 8);
+  const int32_t *tw = XQ_T(esbr_fft8_tw);
+  XQ_UNROLL
+  for (int q = 0; q < 4; q++) { /* complex points q and q + 4 */
+    const int32_t w1h = tw[2 * (q & 1)], w1l = tw[2 * (q & 1) + 1];
+    const int32_t x0r = y[2 * q], x0i = y[2 * q + 1];
+    int32_t x1r = y[2 * q + 8], x1i = y[2 * q + 9], tmp;
+    if (q < 2) {
+      tmp = fx_sub_sat(xq_mul31_sat(x1r, w1l), xq_mul31_sat(x1i, w1h));
+      x1i = fx_add_sat(xq_mul31_sat(x1r, w1h), xq_mul31_sat(x1i, w1l));
+    } else {
+      tmp = fx_add_sat(xq_mul31_sat(x1r, w1h), xq_mul31_sat(x1i, w1l));
+      x1i = fx_sub_sat(xq_mul31_sat(x1i, w1h), xq_mul31_sat(x1r, w1l));
+    }
+    x1r = tmp;
+    y[2 * q + 8] = x0r / 2 - x1r / 2;
+    y[2 * q + 9] = x0i / 2 - x1i / 2;
+    y[2 * q] = x0r / 2 + x1r / 2;
+    y[2 * q + 1] = x0i / 2 + x1i / 2;
+  }
+  XQ_UNROLL
+  for (int i = 0; i < 8; i++) {
+    xr[i] = y[2 * i];
+    xi[i] = y[2 * i + 1];
+  }
+}
+/* 12 points (fft.c:2531): three 4-point transforms over the points 3 j + i, halving, the two rotations of a group
+   (fft_mode < 0: :2586-2607), the 3-point butterfly with sign_dir = -1 (:2493), results to g, 4 + g, 8 + g */
+FX_HD void xq_fft_fwd12(int32_t *xr, int32_t *xi) {
+  XQ_UNROLL
+  for (int i = 0; i < 3; i++) {
+    int32_t ar[4], ai[4];
+    XQ_UNROLL
+    for (int j = 0; j < 4; j++) {
+      ar[j] = xr[3 * j + i];
+      ai[j] = xi[3 * j + i];
+    }
+    xq_fft_fwd4(ar, ai);
+    XQ_UNROLL
+    for (int j = 0; j < 4; j++) {
+      xr[3 * j + i] = ar[j];
+      xi[3 * j + i] = ai[j];
+    }
+  }
+  const int32_t *wr = XQ_T(esbr_fft12_tw_r), *wi = XQ_T(esbr_fft12_tw_i);
+  int32_t yr[12], yi[12];
+  XQ_UNROLL
+  for (int g = 0; g < 4; g++) {
+    int32_t in[6];
+    XQ_UNROLL
+    for (int q = 0; q < 3; q++) {
+      in[2 * q] = xr[3 * g + q] >> 1;
+      in[2 * q + 1] = xi[3 * g + q] >> 1;
+    }
+    XQ_UNROLL
+    for (int q = 1; q < 3; q++) {
+      const int32_t c = wr[2 * g + q - 1], sn = wi[2 * g + q - 1];
+      const int32_t tmp = fx_sub_sat(xq_mul31_sat(in[2 * q], c), xq_mul31_sat(in[2 * q + 1], sn));
+      in[2 * q + 1] = fx_add_sat(xq_mul31_sat(in[2 * q], sn), xq_mul31_sat(in[2 * q + 1], c));
+      in[2 * q] = tmp;
+    }
+    const int32_t sinmu = 1859775393; /* -1859775393 * sign_dir */
+    const int32_t temp_real = fx_add_sat(in[0], in[2]), temp_imag = fx_add_sat(in[1], in[3]);
+    const int32_t add_r = fx_add_sat(in[2], in[4]), add_i = fx_add_sat(in[3], in[5]);
+    const int32_t sub_r = fx_sub_sat(in[2], in[4]), sub_i = fx_sub_sat(in[3], in[5]);
+    const int32_t p1 = add_r >> 1, p4 = add_i >> 1;
+    const int32_t p2 = fx_shlw(fx_mulhi(sub_i, sinmu), 1), p3 = fx_shlw(fx_mulhi(sub_r, sinmu), 1); /* ixheaac_mult32_shl */
+    const int32_t temp = fx_sub(in[0], p1);
+    yr[g] = fx_add_sat(temp_real, in[4]);
+    yi[g] = fx_add_sat(temp_imag, in[5]);
+    yr[4 + g] = fx_add_sat(temp, p2);
+    yi[4 + g] = fx_sub_sat(fx_sub_sat(in[1], p3), p4);
+    yr[8 + g] = fx_sub_sat(temp, p2);
+    yi[8 + g] = fx_sub_sat(fx_add_sat(in[1], p3), p4);
+  }
+  XQ_UNROLL
+  for (int i = 0; i < 12; i++) {
+    xr[i] = yr[i];
+    xi[i] = yi[i];
+  }
+}
+
 /* complex modulation core shared by HQ analysis (M = 16) and HQ synthesis (M = 32), generic:259.  The reference
    walks a "real" and an "imaginary" half (s[0..2M-1] and s[64..64+2M-1]) side by side through pre-rotation, an
    M-point complex FFT and post-rotation; the halves never meet inside, so each is a function of its own 2M words
@@ -289,9 +416,23 @@ FX_HD void xq_cos_sin_mod_half(int32_t *s, int32_t *t) {
     xq_radix4<W>(W::w32(), t, 1, 8);
     xq_radix4<W>(W::w32() + 48, t, 4, 2);
     xq_postradix2(s, t);
-  } else {
+  } else if (M == 16) {
     xq_radix4<W>(W::w16(), t, 1, 4);
     xq_postradix4(s, t);
+  } else { /* the 24- and 16-channel eSBR analysis banks: the general FFT on separated words (generic:1317-1369) */
+    int32_t xr[M], xi[M];
+    XQ_UNROLL
+    for (int z = 0; z < M; z++) {
+      xr[z] = t[2 * z];
+      xi[z] = t[2 * z + 1];
+    }
+    if (M == 12) xq_fft_fwd12(xr, xi);
+    else xq_fft_fwd8(xr, xi);
+    XQ_UNROLL
+    for (int z = 0; z < M; z++) { /* M = 8: << scaleshift (4), a plain C shift */
+      s[2 * z] = M == 12 ? xr[z] : fx_shlw(xr[z], 4);
+      s[2 * z + 1] = M == 12 ? xi[z] : fx_shlw(xi[z], 4);
+    }
   }
   /* post-rotation, in place and order-sensitive (each value is consumed before it is overwritten) */
   int lo = 0, hi = 2 * M - 1, pa = 0;
@@ -545,6 +686,66 @@ FX_HD void xq_esbr_fwd_modulation(const int32_t *in, int32_t *s, int32_t *t) {
     const int32_t re = s[i], im = s[64 + i], c = tc[2 * i], sn = tc[2 * i + 1];
     s[i] = (int32_t)(xq_add64((int64_t)re * c, (int64_t)im * sn) >> 31);
     s[64 + i] = (int32_t)(xq_sub64_sat((int64_t)im * c, (int64_t)re * sn) >> 31);
+  }
+}
+
+/* The 24- and 16-channel analysis banks of 8:3 and 4:1 SBR (sbr_dec.c:213-236; sbrdec_initfuncs.c:766-816).
+   NB channels: 2 NB window-add outputs -> NB complex subbands, s[0..NB-1] real, s[64..64+NB-1] imaginary. */
+template <int NB>
+FX_HD void xq_esbr_fwd_modulation_nb(const int32_t *in, int32_t *s, int32_t *t) {
+  XQ_UNROLL
+  for (int i = 0; i < NB; i++) {
+    const int32_t a = fx_shr(in[i], 4), b = fx_shr(in[2 * NB - 1 - i], 4);
+    s[i] = fx_sub_sat(a, b);
+    s[64 + i] = fx_add_sat(a, b);
+  }
+  xq_cos_sin_mod<NB / 2, XqW32>(s, t);
+  const int32_t *tc = NB == 32 ? XQ_T(esbr_t_cos_sin_l32) : NB == 24 ? XQ_T(esbr_t_cos_sin_l24) : XQ_T(esbr_t_cos_sin_l16);
+  XQ_UNROLL
+  for (int i = 0; i < NB; i++) {
+    const int32_t re = s[i], im = s[64 + i], c = tc[2 * i], sn = tc[2 * i + 1];
+    s[i] = (int32_t)(xq_add64((int64_t)re * c, (int64_t)im * sn) >> 31);
+    s[64 + i] = (int32_t)(xq_sub64_sat((int64_t)im * c, (int64_t)re * sn) >> 31);
+  }
+}
+/* what distinguishes the three banks in ixheaacd_esbr_analysis_filt_block / ixheaacd_esbr_qmfanal32_winadd (qmf_dec.c:537-731):
+   the prototype's table and the stride it is read with, the step of the window pointers, the output gain */
+template <int NB> struct XqEsbrAna {
+  static FX_MEMBER const int32_t *win() { return NB == 24 ? XQ_T(esbr_qmf_c_24) : XQ_T(esbr_qmf_c); }
+  static constexpr int cs = NB == 32 ? 2 : NB == 24 ? 1 : 4; /* stride of the coefficient reads */
+  static constexpr int fo = NB == 24 ? 24 : 64;              /* filt_offset */
+  static FX_MEMBER float gain() { return 1.0f / (NB == 32 ? 256.0f : NB == 24 ? 12.0f : 128.0f); }
+};
+/* one slot's window-add: ring(pos) = the word the reference's anal_filter_states_32 holds at pos when the slot is formed;
+   f1 / f2: the two ring offsets (0 and NB, swapped per slot), w1 / w2: the two window offsets; anal: 2 NB words */
+template <int NB, class Ring>
+FX_HD void xq_esbr_winadd_nb(const Ring &ring, int f1, int f2, int w1, int w2, int32_t *anal) {
+  const int32_t *c = XqEsbrAna<NB>::win();
+  constexpr int cs = XqEsbrAna<NB>::cs;
+  XQ_UNROLL
+  for (int n = 0; n < NB; n++) {
+    int64_t a1 = 0, a2 = 0;
+    XQ_UNROLL
+    for (int j = 0; j < 5; j++) {
+      a1 = xq_add64(a1, (int64_t)ring(f1 + n + 2 * NB * j) * c[w1 + cs * (n + 2 * NB * j)]);
+      a2 = xq_add64(a2, (int64_t)ring(f2 + n + 2 * NB * j) * c[w2 + cs * (n + 2 * NB * j)]);
+    }
+    anal[n] = (int32_t)(a1 >> 31);
+    anal[NB + n] = (int32_t)(a2 >> 31);
+  }
+}
+/* the window pointers' step after a slot (sbr_dec.c:267-277) */
+template <int NB>
+FX_HD void xq_esbr_win_step(int &w1, int &w2) {
+  constexpr int fo = XqEsbrAna<NB>::fo;
+  w1 += fo;
+  w2 += fo;
+  const int tmp = w1;
+  w1 = w2;
+  w2 = tmp;
+  if (w2 > fo * 10) {
+    w1 = 0;
+    w2 = fo;
   }
 }
 

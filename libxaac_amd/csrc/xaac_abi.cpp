@@ -450,6 +450,21 @@ int32_t xaac_esbr_qmf_analysis_batch(xaac_ctx *c, const xaac_esbr_ana_batch *b) 
   return XAAC_OK;
 }
 
+int32_t xaac_esbr_qmf_analysis_nb_batch(xaac_ctx *c, const xaac_esbr_ana_nb_batch *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n_ch < 0 || (b->n_bands != 24 && b->n_bands != 16) || b->n_slots < 0 || b->n_slots > 64 || b->n_bands * b->n_slots > 1024 ||
+      b->core_stride < b->n_bands * b->n_slots)
+    return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch == 0) return XAAC_OK;
+  if (!b->core || !b->state || !b->qmf_re || !b->qmf_im) return XAAC_FATAL_NULL_ARG;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  XaacEsbrAnaNbParams p = {b->n_ch, b->n_bands, b->n_slots, b->core, b->core_stride, b->state, (int32_t)sizeof(xaac_esbr_ana_state),
+                           b->qmf_re, b->qmf_im, b->n_slots * 64};
+  if (!hip_ok(xaac_launch_esbr_analysis_nb(&p, c->stream))) return XAAC_FATAL_HIP;
+  c->last_grid = b->n_ch; c->last_block = 64; c->last_lds = 0;
+  return XAAC_OK;
+}
+
 int32_t xaac_esbr_qmf_synthesis_batch(xaac_ctx *c, const xaac_esbr_syn_batch *b) {
   if (!c || !b) return XAAC_FATAL_NULL_ARG;
   if (b->n_ch < 0) return XAAC_FATAL_BAD_ARG;

@@ -341,6 +341,46 @@ void xo_esbr_analysis(const float *core, int32_t *ring, int32_t *pos, int32_t *w
   *win_off = w1;
 }
 
+/* The same block for the banks of 8:3 and 4:1 SBR (sbr_dec.c:213-236): nb = 24 | 16 (| 32) analysis channels, n_slots time
+   slots of nb core samples each; ring: WORD32[10 nb]; win_off: filter_pos_32 - analy_win_coeff_32 (esbr_qmf_c_24 for 24
+   channels); re / im: [n_slots][64] floats, bands 0..nb-1 written */
+}  // extern "C"
+namespace {
+struct XoRing {
+  const int32_t *r;
+  int32_t operator()(int i) const { return r[i]; }
+};
+template <int NB>
+void esbr_analysis_nb(const float *core, int n_slots, int32_t *ring, int32_t *pos, int32_t *win_off, float *re, float *im) {
+  int p = *pos, w1 = *win_off, w2 = *win_off + XqEsbrAna<NB>::fo;
+  int f1 = 0, f2 = NB;
+  const float gain = XqEsbrAna<NB>::gain();
+  for (int s = 0; s < n_slots; s++) {
+    for (int z = 0; z < NB; z++) ring[p + NB - 1 - z] = fx_f2i_trunc(core[NB * s + z] * 32768.0f);
+    int32_t anal[64], sb[128], t[128];
+    const XoRing rg = {ring};
+    xq_esbr_winadd_nb<NB>(rg, f1, f2, w1, w2, anal);
+    p -= NB;
+    if (p < 0) p = 10 * NB - NB;
+    { const int tmp = f1; f1 = f2; f2 = tmp; }
+    xq_esbr_win_step<NB>(w1, w2);
+    xq_esbr_fwd_modulation_nb<NB>(anal, sb, t);
+    for (int z = 0; z < NB; z++) {
+      re[64 * s + z] = (float)sb[z] * gain;
+      im[64 * s + z] = (float)sb[64 + z] * gain;
+    }
+  }
+  *pos = p;
+  *win_off = w1;
+}
+}  // namespace
+extern "C" {
+void xo_esbr_analysis_nb(const float *core, int nb, int n_slots, int32_t *ring, int32_t *pos, int32_t *win_off, float *re, float *im) {
+  if (nb == 24) esbr_analysis_nb<24>(core, n_slots, ring, pos, win_off, re, im);
+  else if (nb == 16) esbr_analysis_nb<16>(core, n_slots, ring, pos, win_off, re, im);
+  else esbr_analysis_nb<32>(core, n_slots, ring, pos, win_off, re, im);
+}
+
 /* re / im: [32][64] floats; ring: WORD32[1280]; drc_off: ixheaacd_drc_offset; filt_off: filter_pos_syn_32 - esbr_qmf_c;
    out: 2048 floats */
 void xo_esbr_synthesis(const float *re, const float *im, int32_t *ring, int32_t *drc_off, int32_t *filt_off, float *out) {

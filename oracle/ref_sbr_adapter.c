@@ -483,6 +483,38 @@ void ref_esbr_analysis(const float *core, int32_t *ring, int32_t *pos, int32_t *
   *win_off = (int32_t)(b->filter_pos_32 - q->esbr_qmf_c);
 }
 
+/* the banks of 8:3 and 4:1 SBR through the same function: nb = 24 | 16 | 32 channels (tables as sbrdec_initfuncs.c:724-816 sets
+   them), n_slots slots of nb samples; ring: WORD32[10 nb]; re / im: [n_slots][64] */
+void ref_esbr_analysis_nb(const float *core, int nb, int n_slots, int32_t *ring, int32_t *pos, int32_t *win_off, float *re, float *im) {
+  static __thread ia_sbr_dec_struct d;
+  ia_qmf_dec_tables_struct *q = esbr_tabs()->qmf_dec_tables_ptr;
+  ia_sbr_qmf_filter_bank_struct *b = &d.str_codec_qmf_bank;
+  static __thread float in[1024];
+  WORD32 *win = nb == 24 ? q->esbr_qmf_c_24 : q->esbr_qmf_c;
+  memset(b, 0, sizeof(*b));
+  memset(d.qmf_buf_real, 0, sizeof(d.qmf_buf_real));
+  memset(d.qmf_buf_imag, 0, sizeof(d.qmf_buf_imag));
+  memcpy(in, core, (size_t)nb * n_slots * sizeof(float));
+  b->no_channels = nb;
+  b->num_time_slots = n_slots;
+  b->anal_filter_states_32 = ring;
+  b->state_new_samples_pos_low_32 = ring + *pos;
+  b->analy_win_coeff_32 = win;
+  b->filter_pos_32 = win + *win_off;
+  b->esbr_cos_twiddle = nb == 24 ? q->esbr_sin_cos_twiddle_l24 : nb == 16 ? q->esbr_sin_cos_twiddle_l16 : q->esbr_sin_cos_twiddle_l32;
+  b->esbr_alt_sin_twiddle = nb == 24 ? q->esbr_alt_sin_twiddle_l24 : nb == 16 ? q->esbr_alt_sin_twiddle_l16 : q->esbr_alt_sin_twiddle_l32;
+  b->esbr_t_cos = nb == 24 ? q->esbr_t_cos_sin_l24 : nb == 16 ? q->esbr_t_cos_sin_l16 : q->esbr_t_cos_sin_l32;
+  b->lsb = 0;
+  d.time_sample_buf = in;
+  ixheaacd_esbr_analysis_filt_block(&d, esbr_tabs(), 0);
+  for (int s = 0; s < n_slots; s++) {
+    memcpy(re + 64 * s, d.qmf_buf_real[s], 64 * sizeof(float));
+    memcpy(im + 64 * s, d.qmf_buf_imag[s], 64 * sizeof(float));
+  }
+  *pos = (int32_t)(b->state_new_samples_pos_low_32 - ring);
+  *win_off = (int32_t)(b->filter_pos_32 - win);
+}
+
 /* re / im: [32 slots][64] floats; ring: WORD32[1280]; drc_off / filt_off: ixheaacd_drc_offset and filter_pos_syn_32 - esbr_qmf_c;
    out: 2048 floats */
 void ref_esbr_synthesis(const float *re, const float *im, int32_t *ring, int32_t *drc_off, int32_t *filt_off, float *out) {

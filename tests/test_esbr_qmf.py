@@ -12,7 +12,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-from make_golden_esbr_qmf import CHAINS, FRAMES, chain_input  # noqa: E402
+from make_golden_esbr_qmf import CHAINS, FRAMES, NB_BANKS, chain_input, chain_input_nb  # noqa: E402
 import test_esbr_qmf_oracle_vs_reference as t  # noqa: E402
 
 GOLD = np.load(os.path.join(ROOT, "tests", "golden", "esbr_qmf_ref.npz"))
@@ -36,6 +36,48 @@ def test_oracle_matches_reference_chains(oracle):
             o, drc, filt = t.syn(os_, re, im, ring, drc, filt)
             assert (crc(o), crc(ring), (drc << 16) | filt) == tuple(int(x) for x in GOLD["syn_crc"][c, f]), (c, f)
         assert np.array_equal(o.view(np.uint32), GOLD["syn_last"][c].view(np.uint32))
+
+
+@pytest.mark.parametrize("nb,slots", NB_BANKS)
+def test_oracle_matches_reference_chains_of_the_8_3_and_4_1_banks(oracle, nb, slots):
+    fn = t._bind_nb(oracle.lib, "xo")
+    for c in range(CHAINS):
+        ring, pos, win = np.zeros(320, np.int32), 0, 0
+        for f in range(FRAMES):
+            re, im, pos, win = t.ana_nb(fn, chain_input_nb(nb, c, f), nb, slots, ring, pos, win)
+            assert (crc(re), crc(im), crc(ring), (pos << 16) | win) == tuple(int(x) for x in GOLD["ana%d_crc" % nb][c, f]), (c, f)
+        assert np.array_equal(re.view(np.uint32), GOLD["ana%d_last" % nb][c, 0].view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb,slots", NB_BANKS)
+def test_gpu_analysis_chains_of_the_8_3_and_4_1_banks(nb, slots):
+    """xaac_esbr_qmf_analysis_nb_batch (24 channels x 32 slots, 16 x 64) on the reference-made chains, all chains as one batch
+    with the core rows 1024 floats apart: float words, rings and positions identical, bands nb..31 zeroed, 32..63 untouched"""
+    import torch
+    import libxaac_amd
+    dev = torch.device("cuda:0")
+    ctx = libxaac_amd.XaacContext(0, None)
+    n = CHAINS + 1
+    state = torch.zeros((n, libxaac_amd.ESBR_ANA_STATE_WORDS), dtype=torch.int32, device=dev)
+    re = torch.full((n, slots, 64), 7.0, dtype=torch.float32, device=dev)
+    im = torch.full((n, slots, 64), 7.0, dtype=torch.float32, device=dev)
+    for f in range(FRAMES):
+        core = np.full((n, 1024), 3.0, np.float32)
+        for c in range(n):
+            core[c, :nb * slots] = chain_input_nb(nb, c % CHAINS, f)
+        ctx.esbr_qmf_analysis_nb_batch(nb, slots, torch.from_numpy(core).to(dev), state, re, im)
+        ctx.sync()
+        r, i, st = re.cpu().numpy(), im.cpu().numpy(), state.cpu().numpy()
+        assert np.all(r[:, :, 32:] == 7.0) and np.all(i[:, :, 32:] == 7.0)
+        assert not np.any(r[:, :, nb:32]) and not np.any(i[:, :, nb:32])
+        r[:, :, 32:] = 0
+        i[:, :, 32:] = 0
+        for c in range(CHAINS):
+            got = (crc(r[c]), crc(i[c]), crc(st[c, :320]), (int(st[c, 320]) << 16) | int(st[c, 321]))
+            assert got == tuple(int(x) for x in GOLD["ana%d_crc" % nb][c, f]), (c, f)
+        assert np.array_equal(r[CHAINS], r[0]) and np.array_equal(st[CHAINS], st[0])
+    assert np.array_equal(r[:CHAINS].view(np.uint32), GOLD["ana%d_last" % nb][:, 0].view(np.uint32))
 
 
 @pytest.mark.gpu

@@ -99,3 +99,42 @@ def test_analysis_into_synthesis_round_trip(oracle, reference):
     yr, yo = np.concatenate(outs["r"]), np.concatenate(outs["o"])
     assert np.array_equal(yr.view(np.uint32), yo.view(np.uint32))
     assert np.abs(yo).max() > 0.1
+
+
+def _bind_nb(lib, prefix):
+    a = getattr(lib, prefix + "_esbr_analysis_nb")
+    a.restype = None
+    a.argtypes = [PF, ctypes.c_int, ctypes.c_int, P32, P32, P32, PF, PF]
+    return a
+
+
+def ana_nb(fn, core, nb, n_slots, ring, pos, win):
+    re, im = np.zeros((n_slots, 64), np.float32), np.zeros((n_slots, 64), np.float32)
+    p, w = ctypes.c_int32(pos), ctypes.c_int32(win)
+    fn(core.ctypes.data_as(PF), nb, n_slots, ring.ctypes.data_as(P32), ctypes.byref(p), ctypes.byref(w),
+       re.ctypes.data_as(PF), im.ctypes.data_as(PF))
+    return re, im, p.value, w.value
+
+
+@pytest.mark.parametrize("nb,n_slots", [(24, 32), (16, 64), (32, 32), (24, 30), (16, 60)])
+@pytest.mark.parametrize("amp", [1.0, 0.05, 1e-4, 0.999, 2e6])
+def test_analysis_chain_of_the_8_3_and_4_1_banks(oracle, reference, nb, n_slots, amp):
+    """The 24- and 16-channel banks (sbr_dec.c:213-236; the general FFT's 12- and 8-point forward transforms inside
+    ixheaacd_esbr_cos_sin_mod, generic:1317-1369) against the reference's own function, state carried over 13 frames (the
+    10-block ring and the window pointers wrap several times)."""
+    ra, oa = _bind_nb(reference.lib, "ref"), _bind_nb(oracle.lib, "xo")
+    rng = np.random.default_rng(int(amp * 1e6) + nb)
+    ring_r, ring_o = np.zeros(320, np.int32), np.zeros(320, np.int32)
+    pr = wr = po = wo = 0
+    for f in range(13):
+        core = np.ascontiguousarray((rng.uniform(-1, 1, nb * n_slots) * amp).astype(np.float32))
+        if f == 3:
+            core[::7] = np.float32(amp)
+            core[1::7] = np.float32(-amp)
+        rr, ri, pr, wr = ana_nb(ra, core, nb, n_slots, ring_r, pr, wr)
+        xr, xi, po, wo = ana_nb(oa, core, nb, n_slots, ring_o, po, wo)
+        assert (pr, wr) == (po, wo), f
+        assert np.array_equal(ring_r, ring_o), f
+        assert np.array_equal(rr.view(np.uint32), xr.view(np.uint32)), (f, int(np.sum(rr != xr)))
+        assert np.array_equal(ri.view(np.uint32), xi.view(np.uint32)), f
+        assert (amp < 0.01 or np.any(rr[:, :nb] != 0)) and not np.any(rr[:, nb:])

@@ -49,6 +49,14 @@ def chain_input(kind, chain, frame):
     return re, im
 
 
+NB_BANKS = ((24, 32), (16, 64))   # (analysis channels, time slots): 8:3 and 4:1 SBR
+
+
+def chain_input_nb(nb, chain, frame):
+    """core samples of a frame of the 24- / 16-channel bank: the first nb * slots values of the 32-channel chain's frame"""
+    return np.ascontiguousarray(chain_input(0, chain + (nb << 4), frame)[:nb * dict(NB_BANKS)[nb]])
+
+
 def crc(a):
     return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xffffffff
 
@@ -75,8 +83,19 @@ def main():
             o, drc, filt = t.syn(rs, re, im, ring, drc, filt)
             s_crc[c, f] = crc(o), crc(ring), (drc << 16) | filt
         s_last[c] = o
+    for nb, slots in NB_BANKS:   # sbr_dec.c:213-236: the banks of 8:3 and 4:1 SBR, the same function on their own tables
+        fn = t._bind_nb(ref.lib, "ref")
+        n_crc = np.zeros((CHAINS, FRAMES, 4), np.uint32)
+        n_last = np.zeros((CHAINS, 2, slots, 64), np.float32)
+        for c in range(CHAINS):
+            ring, pos, win = np.zeros(320, np.int32), 0, 0
+            for f in range(FRAMES):
+                re, im, pos, win = t.ana_nb(fn, chain_input_nb(nb, c, f), nb, slots, ring, pos, win)
+                n_crc[c, f] = crc(re), crc(im), crc(ring), (pos << 16) | win
+            n_last[c, 0], n_last[c, 1] = re, im
+        out["ana%d_crc" % nb], out["ana%d_last" % nb] = n_crc, n_last
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "esbr_qmf_ref.npz"), ana_crc=a_crc, syn_crc=s_crc,
-                        ana_last=a_last, syn_last=s_last)
+                        ana_last=a_last, syn_last=s_last, **out)
     print("wrote", CHAINS, "chains x", FRAMES, "frames per bank")
 
 
