@@ -19,6 +19,9 @@
 #define XAAC_ESBR_HIST_ROWS 40 /* op_delay 6 + SBR_HF_ADJ_OFFSET 2 + codec_x_delay 32 rows of qmf_buf_real/_imag kept */
 #define XAAC_ESBR_OUT_HIST_ROWS 8 /* op_delay 6 + SBR_HF_ADJ_OFFSET 2 rows of sbr_qmf_out_real/_imag kept */
 #define XAAC_ESBR_ROWS (XAAC_ESBR_HIST_ROWS + 32)
+#define XAAC_ESBR_OUT_HIST_ROWS_4_1 14 /* 4:1 SBR: op_delay 12 (sbr_dec.c:719) + SBR_HF_ADJ_OFFSET 2 rows of both matrices kept: qmf_re /
+                                          qmf_im rows 0..13; sbr_qmf_out's in out_re / out_im (rows 0..7) and ph_re / ph_im rows 0..5
+                                          (rows 8..13) -- a 4:1 channel has no transposer in this library, whose rows those are */
 
 /* bits of xaac_esbr_side::harmonic_sbr.  XAAC_ESBR_USAC: header usac_flag -- the clearing of the history rows above the old
    cross-over band is an AAC-only step (sbr_dec.c:868-874).  XAAC_ESBR_NO_X_DELAY: codec_x_delay = 0 (sbr_dec.c:819-826: a USAC
@@ -139,7 +142,15 @@ typedef struct xaac_esbr_sbr_batch {
   const xaac_esbr_pvc_side *pvc_side; /* [n_ch], or NULL together with pvc_state: no channel of the batch has PVC frames (a frame
                                        whose side says sbr_mode PVC is then refused by its XAAC_ESBR_* flags' owner, the host) */
   xaac_esbr_pvc_state *pvc_state;   /* [n_ch] in/out */
+  int32_t sbr_ratio;                /* XAAC_ESBR_RATIO_*: the SBR ratio of every channel of the batch (header: sbr_ratio_idx).
+                                       2:1 (0): as described above.  8:3: the first 768 floats of a core row through the 24-channel
+                                       analysis bank (sbr_dec.c:218), everything behind it as for 2:1.  4:1: 1024 core samples through
+                                       the 16-channel bank into 64 slots, four to an envelope time slot (is_usf_4: sbrdec_lpfuncs.c:1036,
+                                       esbr_envcal.c:152), out rows of 4096 floats, workspace of xaac_esbr_workspace_bytes_ratio;
+                                       USAC channels without a transposer only (side flags XAAC_ESBR_USAC | _NO_X_DELAY; ps_frame and
+                                       hbe_state NULL) -- a 4:1 channel with harmonic SBR stays the caller's */
 } xaac_esbr_sbr_batch;
+enum { XAAC_ESBR_RATIO_2_1 = 0, XAAC_ESBR_RATIO_8_3 = 1, XAAC_ESBR_RATIO_4_1 = 2 };
 
 /* The hand-offs on either side of the branch in ixheaacd_dec_execute: the core decoder's PCM16 (after the 32 -> 16 bit
  * conversion of xaac_imdct_process_batch's XAAC_PCM_SBR mode, channels of an element interleaved) as floats, one plane per
@@ -170,6 +181,7 @@ XAAC_API int32_t xaac_esbr_pcm16_from_float_batch(xaac_ctx *ctx, const xaac_esbr
  * history shift (sbr_dec.c:835-857), ixheaacd_esbr_analysis_filt_block, ixheaacd_generate_hf (sbrdec_lpfuncs.c:981),
  * ixheaacd_sbr_env_calc (esbr_envcal.c:71), ixheaacd_esbr_synthesis_regrp + the synthesis bank (sbr_dec.c:297 / :447). */
 XAAC_API uint64_t xaac_esbr_workspace_bytes(int32_t n_ch);
+XAAC_API uint64_t xaac_esbr_workspace_bytes_ratio(int32_t n_ch, int32_t sbr_ratio); /* the larger scratch of a 4:1 batch */
 XAAC_API int32_t xaac_esbr_sbr_process_batch(xaac_ctx *ctx, const xaac_esbr_sbr_batch *batch);
 #ifdef __cplusplus
 }

@@ -72,7 +72,10 @@ class _EsbrSbrBatch(ctypes.Structure):
                 ("out", ctypes.c_void_p), ("ps_frame", ctypes.c_void_p), ("ps_state", ctypes.c_void_p),
                 ("out_r", ctypes.c_void_p), ("status", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
                 ("workspace_bytes", ctypes.c_uint64), ("hbe_state", ctypes.c_void_p), ("hbe_max_synth_size", ctypes.c_int32),
-                ("pvc_side", ctypes.c_void_p), ("pvc_state", ctypes.c_void_p)]
+                ("pvc_side", ctypes.c_void_p), ("pvc_state", ctypes.c_void_p), ("sbr_ratio", ctypes.c_int32)]
+
+
+ESBR_RATIO_2_1, ESBR_RATIO_8_3, ESBR_RATIO_4_1 = 0, 1, 2   # xaac_esbr.h: XAAC_ESBR_RATIO_*
 
 
 class _EsbrCoreInBatch(ctypes.Structure):
@@ -293,6 +296,8 @@ def load_library():
     lib.xaac_qmf_synthesis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_QmfSynBatch)]
     lib.xaac_esbr_workspace_bytes.argtypes = [ctypes.c_int32]
     lib.xaac_esbr_workspace_bytes.restype = ctypes.c_uint64
+    lib.xaac_esbr_workspace_bytes_ratio.argtypes = [ctypes.c_int32, ctypes.c_int32]
+    lib.xaac_esbr_workspace_bytes_ratio.restype = ctypes.c_uint64
     lib.xaac_esbr_sbr_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_EsbrSbrBatch)]
     lib.xaac_esbr_sbr_process_batch.restype = ctypes.c_int32
     lib.xaac_sbr_state_handover.argtypes = [ctypes.c_void_p, ctypes.POINTER(_HandoverBatch)]
@@ -532,26 +537,29 @@ class XaacContext:
         if rc != 0:
             raise XaacError(rc, "xaac_qmf_synthesis_batch")
 
-    def esbr_workspace_bytes(self, n_ch):
-        return int(self._lib.xaac_esbr_workspace_bytes(int(n_ch)))
+    def esbr_workspace_bytes(self, n_ch, sbr_ratio=0):
+        return int(self._lib.xaac_esbr_workspace_bytes_ratio(int(n_ch), int(sbr_ratio)))
 
     def esbr_sbr_process_batch(self, core, header, frame, side, state, out, workspace, status=None, ps_frame=None,
-                               ps_state=None, out_r=None, hbe_state=None, hbe_max_synth_size=0, pvc_side=None, pvc_state=None):
+                               ps_state=None, out_r=None, hbe_state=None, hbe_max_synth_size=0, pvc_side=None, pvc_state=None,
+                               sbr_ratio=0):
         """One frame of every channel through the Path A (eSBR, -esbr:1) branch of ixheaacd_sbr_dec, mono / stereo
         channels without PS: core float32[n_ch, 1024]; header / frame / side / state uint8 views of the xaac_sbr_header,
         xaac_sbr_frame, xaac_esbr_side, xaac_esbr_state arrays; out float32[n_ch, 2048].  With ps_frame / ps_state (uint8
         views of xaac_ps_frame / xaac_esbr_ps_state arrays) / out_r: HE-AACv2 streams, float parametric stereo, out = left.
         hbe_state (uint8[n_ch, HBE_STATE_BYTES]): the harmonic transposer runs on every frame and frames with harmonic_sbr
-        set take its output."""
+        set take its output.  sbr_ratio ESBR_RATIO_8_3: 768 samples of a core row through the 24-channel bank;
+        ESBR_RATIO_4_1: the 16-channel bank, 64 slots, out float32[n_ch, 4096], workspace of esbr_workspace_bytes(n_ch, ratio)."""
         n_ch = out.shape[0]
         b = _EsbrSbrBatch()
+        b.sbr_ratio = int(sbr_ratio)
         b.n_ch = n_ch
         b.core = _ptr(core, "float32", n_ch * 1024, device_ok=True)
         b.header = _ptr(header, "uint8", n_ch * SBR_HEADER_BYTES, device_ok=True)
         b.frame = _ptr(frame, "uint8", n_ch * SBR_FRAME_BYTES, device_ok=True)
         b.side = _ptr(side, "uint8", n_ch * ESBR_SIDE_BYTES, device_ok=True)
         b.state = _ptr(state, "uint8", n_ch * ESBR_STATE_BYTES, device_ok=True)
-        b.out = _ptr(out, "float32", n_ch * 2048, device_ok=True)
+        b.out = _ptr(out, "float32", n_ch * (4096 if b.sbr_ratio == ESBR_RATIO_4_1 else 2048), device_ok=True)
         b.ps_frame = _ptr(ps_frame, "uint8", n_ch * PS_FRAME_BYTES, allow_none=True, device_ok=True)
         b.ps_state = _ptr(ps_state, "uint8", n_ch * ESBR_PS_STATE_BYTES, allow_none=True, device_ok=True)
         b.out_r = _ptr(out_r, "float32", n_ch * 2048, allow_none=True, device_ok=True)

@@ -277,16 +277,16 @@ FX_HD void xe_patch_bw_index(const XsCx &cx, const xaac_sbr_header *h, XeWork *w
 
 /* covariance of band k over 38 slots from row -2 on (ixheaacd_esbr_calc_co_variance, sbrdec_lpfuncs.c:781) and the
    second-order prediction coefficients of :1077-1120 */
-FX_HD void xe_covar_alpha(const XeMat &src, int k, float &a0r, float &a0i, float &a1r, float &a1i) {
+FX_HD void xe_covar_alpha(const XeMat &src, int k, float &a0r, float &a0i, float &a1r, float &a1i, int len = 38 /* co_var_len: 76 for 4:1 SBR, :1040 */) {
   a0r = a0i = a1r = a1i = 0;
   float p01r = 0, p01i = 0, p02r = 0, p02i = 0, p11 = 0, p12r = 0, p12i = 0, p22 = 0;
   float r2 = src.r(-2, k), i2 = src.i(-2, k), r1 = src.r(-1, k), i1 = src.i(-1, k);
   XE_NOUNROLL
-  for (int j0 = 0; j0 < 38; j0 += XE_CH) {
+  for (int j0 = 0; j0 < len; j0 += XE_CH) {
     float cr[XE_CH] = {0}, ci[XE_CH] = {0};
-    xe_rows_load(src, k, j0, 38, cr, ci);
+    xe_rows_load(src, k, j0, len, cr, ci);
     XE_UNROLL
-    for (int jj = 0; jj < XE_CH; jj++) if (j0 + jj < 38) {
+    for (int jj = 0; jj < XE_CH; jj++) if (j0 + jj < len) {
     const float r0 = cr[jj], i0 = ci[jj];
     p01r += r0 * r1 + i0 * i1;
     p01i += i0 * r1 - r0 * i1;
@@ -456,8 +456,9 @@ XE_NOINLINE FX_HD void xe_pre_flatten(const XsCx cx, XeWork *w, const XeMat src,
 template <bool HARM = true>
 FX_HD void xe_generate_hf(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
                           xaac_esbr_state *st, XeWork *w, const XeMat &src, const XeMat &dst,
-                          const XeMat *ph = nullptr /* ph_vocod_qmf rows (row 0 = the reference's + 2), harmonic patching */) {
-  const int start = 2 * f->border_vec[0], end = 32 + 2 * (f->border_vec[f->num_env] - 16);
+                          const XeMat *ph = nullptr /* ph_vocod_qmf rows (row 0 = the reference's + 2), harmonic patching */,
+                          int rate = 2 /* QMF slots per envelope time slot: 4 for 4:1 SBR (is_usf_4, :1036-1044) */) {
+  const int start = rate * f->border_vec[0], end = 16 * rate + rate * (f->border_vec[f->num_env] - 16);
   const int lsb = sd->f_master_tbl[0], usb = sd->f_master_tbl[sd->num_mf_bands];
   const int num_if = h->num_nf_bands;
   XS_PAR(i, 0, XAAC_SBR_MAX_PATCHES) { /* chirp factors, :832 */
@@ -500,7 +501,7 @@ FX_HD void xe_generate_hf(const XsCx &cx, const xaac_sbr_header *h, const xaac_s
   }
   XS_PAR(k, 0, 64) {
     float a0r = 0, a0i = 0, a1r = 0, a1i = 0;
-    if (k >= 1 && k < lsb) xe_covar_alpha(src, k, a0r, a0i, a1r, a1i);
+    if (k >= 1 && k < lsb) xe_covar_alpha(src, k, a0r, a0i, a1r, a1i, rate == 4 ? 76 : 38);
     w->alpha_r[k][0] = a0r; w->alpha_i[k][0] = a0i;
     w->alpha_r[k][1] = a1r; w->alpha_i[k][1] = a1i;
   }
@@ -647,7 +648,7 @@ FX_HD void xe_inter_tes(const XsCx &cx, XeWork *w, const XeMat &low, const XeMat
    the sinusoids that frame announced (harm_flag_varlen).  Returns 0 or -1. */
 FX_HD int xe_env_calc_pvc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
                           xaac_esbr_state *st, XeWork *w, const XeMat &x, const xaac_esbr_pvc_side *pvs, xaac_esbr_pvc_state *pst,
-                          const float *env_out, int &phase_index, int &harm_index, int &start_up, int &start_up_pvc) {
+                          const float *env_out, int &phase_index, int &harm_index, int &start_up, int &start_up_pvc, int rate = 2) {
   const int sb_start = h->sub_band_start, num_sb = h->sub_band_end - h->sub_band_start;
   const int num_env = f->num_env, trans_env = f->transient_env, num_nf = h->num_nf_bands;
   const int smoothing_length = h->smoothing_mode ? 0 : 4, int_mode = h->interpol_freq;
@@ -717,9 +718,9 @@ FX_HD int xe_env_calc_pvc(const XsCx &cx, const xaac_sbr_header *h, const xaac_s
         w->sfb_len[c] = (int8_t)(ui - li);
         w->flag[c] = (int8_t)flag;
         w->o_idx[c] = (int8_t)o;
-        float nrg = 0; /* :322-327: the slot's two QMF rows */
-        for (int l = 0; l < 2; l++) nrg += (x.r(2 * t + l, kabs) * x.r(2 * t + l, kabs)) + (x.i(2 * t + l, kabs) * x.i(2 * t + l, kabs));
-        w->nrg_est[c] = nrg / 2;
+        float nrg = 0; /* :322-327: the slot's QMF rows (two; four for 4:1 SBR) */
+        for (int l = 0; l < rate; l++) nrg += (x.r(rate * t + l, kabs) * x.r(rate * t + l, kabs)) + (x.i(rate * t + l, kabs) * x.i(rate * t + l, kabs));
+        w->nrg_est[c] = nrg / rate;
       }
       cx.sync();
       XS_PAR(c, 0, num_sb) {
@@ -842,7 +843,7 @@ FX_HD int xe_env_calc_pvc(const XsCx &cx, const xaac_sbr_header *h, const xaac_s
         const bool no_noise = active && (tone != 0 || noise_absc);
         const int kk2 = sb_start + k, freq_inv = (kk2 & 1) ? -1 : 1;
         const float hp[2][4] = {{1.0f, 0.0f, -1.0f, 0.0f}, {0.0f, 1.0f, 0.0f, -1.0f}};
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < rate; j++) {
           if (active) {
             eg[4] = gain;
             nb[4] = nl;
@@ -854,9 +855,9 @@ FX_HD int xe_env_calc_pvc(const XsCx &cx, const xaac_sbr_header *h, const xaac_s
             }
             const int ph = (phase_index + j * num_sb + k + 1) & 511, hi = (harm_index + j) & 3;
             if (no_noise) sb_noise = 0;
-            const float re = x.r(2 * t + j, kk2), im = x.i(2 * t + j, kk2);
-            x.r(2 * t + j, kk2) = re * sb_gain + sb_noise * XE_RANDOM_PHASE(2 * ph) + tone * hp[0][hi];
-            x.i(2 * t + j, kk2) = im * sb_gain + sb_noise * XE_RANDOM_PHASE(2 * ph + 1) + tone * (float)freq_inv * hp[1][hi];
+            const float re = x.r(rate * t + j, kk2), im = x.i(rate * t + j, kk2);
+            x.r(rate * t + j, kk2) = re * sb_gain + sb_noise * XE_RANDOM_PHASE(2 * ph) + tone * hp[0][hi];
+            x.i(rate * t + j, kk2) = im * sb_gain + sb_noise * XE_RANDOM_PHASE(2 * ph + 1) + tone * (float)freq_inv * hp[1][hi];
           }
           const float t0 = eg[0], t1 = nb[0];
           for (int n = 0; n < 4; n++) {
@@ -871,8 +872,8 @@ FX_HD int xe_env_calc_pvc(const XsCx &cx, const xaac_sbr_header *h, const xaac_s
           st->noise_buf[n][k] = nb[n];
         }
       }
-      phase_index = (phase_index + 2 * num_sb) & 511;
-      harm_index = (harm_index + 2) & 3;
+      phase_index = (phase_index + rate * num_sb) & 511;
+      harm_index = (harm_index + rate) & 3;
       cx.sync();
     }
   }
@@ -886,7 +887,8 @@ FX_HD int xe_env_calc_pvc(const XsCx &cx, const xaac_sbr_header *h, const xaac_s
 FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
                       xaac_esbr_state *st, XeWork *w, const XeMat &x /* sbr_qmf_out */, const XeMat &low /* qmf_buf */,
                       const int32_t *x_over_qmf = nullptr /* the transposer's, where the host tracks one */,
-                      const xaac_esbr_pvc_side *pvs = nullptr, xaac_esbr_pvc_state *pst = nullptr, const float *env_out = nullptr) {
+                      const xaac_esbr_pvc_side *pvs = nullptr, xaac_esbr_pvc_state *pst = nullptr, const float *env_out = nullptr,
+                      int rate = 2 /* 4 for 4:1 SBR (esbr_envcal.c:152) */) {
   const int sb_start = h->sub_band_start, num_sb = h->sub_band_end - h->sub_band_start;
   const int num_env = f->num_env, trans_env = f->transient_env, num_nf = h->num_nf_bands;
   const int smoothing_length = h->smoothing_mode ? 0 : 4, int_mode = h->interpol_freq;
@@ -934,7 +936,7 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
   if (w->err) return -1;
   const bool pvc_frame = pvs && pst && pvs->sbr_mode == XAAC_ESBR_SBR_PVC;
   if (pvc_frame) {
-    if (xe_env_calc_pvc(cx, h, f, sd, st, w, x, pvs, pst, env_out, phase_index, harm_index, start_up, start_up_pvc)) return -1;
+    if (xe_env_calc_pvc(cx, h, f, sd, st, w, x, pvs, pst, env_out, phase_index, harm_index, start_up, start_up_pvc, rate)) return -1;
   }
   int kk = 0, next = -1, m = 0;
   /* a frame whose sbr_mode is not ORIG_SBR (a USAC channel's first frames: UNKNOWN_SBR) passes the envelopes by: all of an
@@ -950,7 +952,7 @@ FX_HD int xe_env_calc(const XsCx &cx, const xaac_sbr_header *h, const xaac_sbr_f
     const float *filt = smooth_length ? xaac_esbr_fir_4 : xaac_esbr_fir_0;
     const int res = f->freq_res[i] ? 1 : 0, nsf = h->num_sf_bands[res];
     const int16_t *ftab = res ? h->freq_band_tbl_hi : h->freq_band_tbl_lo;
-    const int l0 = 2 * f->border_vec[i], l1 = 2 * f->border_vec[i + 1];
+    const int l0 = rate * f->border_vec[i], l1 = rate * f->border_vec[i + 1];
     /* band -> scale-factor band / noise band map of this envelope (esbr_envcal.c:657-699).  The reference walks the bands
        once, stepping its noise-band counter whenever a band reaches the next noise border; with the strictly increasing
        tables xe_side_info_bad insists on, that counter is the number of inner noise borders at or below the band, so

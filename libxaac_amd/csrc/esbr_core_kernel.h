@@ -12,6 +12,13 @@
 #define XAAC_ESBR_PH_ROWS 40                                    /* ph_vocod_qmf: 8 history rows + the transposer's 32 */
 #define XAAC_ESBR_WS_FLOATS (2 * 2048 + 2 * XAAC_ESBR_OUT_ROWS * 64 + 2 * XAAC_ESBR_L_ROWS * 64 + 2 * 2048 + 2 * XAAC_ESBR_PH_ROWS * 64 + 16 * 64) /* analysis rows, sbr_qmf_out, left rows, right rows, transposer rows, the PVC decoder's envelope */
 
+/* 4:1 SBR (64 slots, four to an envelope time slot; op_delay 12): the low-band matrix is a scratch of its own -- 14 history rows,
+   the 16-channel bank's 64 rows (written in place by the bank), 2 rows of zeros -- and sbr_qmf_out grows likewise; no PS rows,
+   no transposer rows */
+#define XAAC_ESBR_Q_ROWS_4_1 80
+#define XAAC_ESBR_OUT_ROWS_4_1 82
+#define XAAC_ESBR_WS_FLOATS_4_1 (2 * XAAC_ESBR_Q_ROWS_4_1 * 64 + 2 * XAAC_ESBR_OUT_ROWS_4_1 * 64 + 2 * 64 * 64 + 16 * 64)
+
 typedef struct XaacEsbrCoreParams {
   int32_t n_ch;
   const xaac_sbr_header *header;
@@ -30,6 +37,8 @@ typedef struct XaacEsbrCoreParams {
   const xaac_esbr_pvc_side *pvc_side; /* [n_ch] or NULL (with pvc_state, pvc_out): channels with PVC frames (xaac_esbr.h) */
   xaac_esbr_pvc_state *pvc_state;
   float *pvc_out;               /* [n_ch][16][64] scratch: pvc_dec_out_buf */
+  int32_t usf4;                 /* 4:1 SBR: out_re / out_im [n_ch][82][64], syn_re / syn_im [n_ch][64][64], and */
+  float *q_re, *q_im;           /* [n_ch][80][64]: qmf_buf rows, 14..77 written by the analysis bank (ana_re / ana_im unused) */
 } XaacEsbrCoreParams;
 
 #ifdef __cplusplus

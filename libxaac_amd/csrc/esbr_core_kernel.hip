@@ -55,7 +55,9 @@ __device__ __forceinline__ void xe_copy_words(int32_t *dst, const int32_t *src, 
 
 /* HARM: with the harmonic transposer's rows (batches that hand in hbe_state); the other variant carries none of that code */
 /* PVC: channels whose host tracks the PVC side info and state (USAC; xaac_esbr.h): PVC frames decoded and adjusted here */
-template <bool HARM, bool PVC = false>
+/* USF4: 4:1 SBR (USAC channels without a transposer): 64 slots, four to an envelope time slot; the low-band matrix is the
+   80-row scratch the 16-channel analysis bank wrote rows 8..71 of, not the channel's 40-row state */
+template <bool HARM, bool PVC = false, bool USF4 = false>
 __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParams p) { /* 168 VGPRs: 12 waves per CU (measured best of 8 / 12 / 16) */
 #ifdef XE_PROFILE
   if (threadIdx.x == 0) {
@@ -72,8 +74,14 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
   __shared__ xaac_esbr_side ssd;
   static_assert(sizeof(xaac_sbr_header) % 4 == 0 && sizeof(xaac_sbr_frame) % 4 == 0 && sizeof(xaac_esbr_side) % 4 == 0, "word copies");
   xaac_esbr_state *st = p.state + ch;
+  constexpr int RATE = USF4 ? 4 : 2, SLOTS = USF4 ? 64 : 32;
+  constexpr int OUT_ROWS = USF4 ? XAAC_ESBR_OUT_ROWS_4_1 : XAAC_ESBR_OUT_ROWS, L_ROWS = USF4 ? 64 : XAAC_ESBR_L_ROWS;
   const float *are = p.ana_re + (size_t)ch * 2048, *aim = p.ana_im + (size_t)ch * 2048;
-  float hist_re[8], hist_im[8]; /* sbr_qmf_out's eight rows of history: fetched with the side info, stored below */
+  /* the low-band matrix the tools read (qmf_buf_real / _imag from the reference's row 0) */
+  float *qre = USF4 ? p.q_re + (size_t)ch * XAAC_ESBR_Q_ROWS_4_1 * 64 : &st->qmf_re[0][0];
+  float *qim = USF4 ? p.q_im + (size_t)ch * XAAC_ESBR_Q_ROWS_4_1 * 64 : &st->qmf_im[0][0];
+  constexpr int HIST = USF4 ? XAAC_ESBR_OUT_HIST_ROWS_4_1 : XAAC_ESBR_OUT_HIST_ROWS; /* op_delay + 2 rows of both matrices carried */
+  float hist_re[HIST], hist_im[HIST]; /* sbr_qmf_out's rows of history: fetched with the side info, stored below */
   { /* header, frame, side info and the random-phase table: every load in flight before the first LDS store -- one memory
        latency for the lot (as four copies one behind the other they were four, and the history rows a fifth) */
     constexpr int NH = (sizeof(sh) / 4 + 63) / 64, NF = (sizeof(sf) / 4 + 63) / 64, NS = (sizeof(ssd) / 4 + 63) / 64, NR = 1024 / 64;
@@ -89,9 +97,9 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
 #pragma unroll
     for (int j = 0; j < NR; j++) tr[j] = gr[lane + 64 * j];
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-      hist_re[r] = st->out_re[r][lane];
-      hist_im[r] = st->out_im[r][lane];
+    for (int r = 0; r < HIST; r++) { /* (4:1: rows 8..13 ride in the state's ph rows, xaac_esbr.h) */
+      hist_re[r] = r < 8 ? st->out_re[r][lane] : st->ph_re[r - 8][lane];
+      hist_im[r] = r < 8 ? st->out_im[r][lane] : st->ph_im[r - 8][lane];
     }
 #pragma unroll
     for (int j = 0; j < NH; j++)
@@ -110,21 +118,22 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
   const xaac_sbr_frame *f = &sf;
   const xaac_esbr_side *sd = &ssd;
   XE_T(0);
-  float *ore = p.out_re + (size_t)ch * XAAC_ESBR_OUT_ROWS * 64, *oim = p.out_im + (size_t)ch * XAAC_ESBR_OUT_ROWS * 64;
-  float *rre = p.syn_re + (size_t)ch * XAAC_ESBR_L_ROWS * 64, *rim = p.syn_im + (size_t)ch * XAAC_ESBR_L_ROWS * 64;
+  float *ore = p.out_re + (size_t)ch * OUT_ROWS * 64, *oim = p.out_im + (size_t)ch * OUT_ROWS * 64;
+  float *rre = p.syn_re + (size_t)ch * L_ROWS * 64, *rim = p.syn_im + (size_t)ch * L_ROWS * 64;
   const int apply = f->apply_processing != 0;
   int rc = 0;
   if (apply && xe_side_info_bad(h, f, sd)) rc = -1;
+  if (USF4 && !(sd->harmonic_sbr & XAAC_ESBR_NO_X_DELAY)) rc = -1; /* 4:1 with a transposer's delay: not built */
   /* sbr_qmf_out: 8 rows of history; the stages write every cell of rows 8..31 that is read later, so those are cleared
      only for a frame without SBR processing (the reference zeroes the whole buffer then, sbr_dec.c:956-961) */
   {
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
+    for (int r = 0; r < HIST; r++) {
       ore[64 * r + lane] = apply ? hist_re[r] : 0.0f;
       oim[64 * r + lane] = apply ? hist_im[r] : 0.0f;
     }
     /* rows 32.. become the next frame's history: cleared, the stages fill what they reach */
-    for (int i = ((!apply || rc) ? 8 : 32) * 64 + lane; i < XAAC_ESBR_OUT_ROWS * 64; i += 64) {
+    for (int i = ((!apply || rc) ? HIST : SLOTS) * 64 + lane; i < OUT_ROWS * 64; i += 64) {
       ore[i] = 0.0f;
       oim[i] = 0.0f;
     }
@@ -133,7 +142,23 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
   /* USAC channels (xaac_esbr.h: XAAC_ESBR_USAC / _NO_X_DELAY): no clearing above the old cross-over band (sbr_dec.c:868); without a
      transposer the analysis rows of THIS frame are rows 8..39 of the buffer the tools read (codec_x_delay 0, sbr_dec.c:819-826) */
   const bool no_x_delay = (sd->harmonic_sbr & XAAC_ESBR_NO_X_DELAY) != 0;
-  if (no_x_delay) {
+  if constexpr (USF4) { /* rows 0..13: the history; 14..77: the analysis bank's, in place; 78, 79: zero */
+#pragma unroll
+    for (int r = 0; r < HIST; r++) {
+      qre[64 * r + lane] = st->qmf_re[r][lane];
+      qim[64 * r + lane] = st->qmf_im[r][lane];
+    }
+    for (int r = HIST + 64; r < XAAC_ESBR_Q_ROWS_4_1; r++) {
+      qre[64 * r + lane] = 0.0f;
+      qim[64 * r + lane] = 0.0f;
+    }
+    if (lane >= 32) /* the bank wrote bands 0..31 of its rows (16 of them zeros); the upper half is the reference's never-written zeros */
+      for (int r = HIST; r < HIST + 64; r++) {
+        qre[64 * r + lane] = 0.0f;
+        qim[64 * r + lane] = 0.0f;
+      }
+    __syncthreads();
+  } else if (no_x_delay) {
     for (int j0 = 0; j0 < 32; j0 += 16) {
       float a[16], b[16];
 #pragma unroll
@@ -151,7 +176,7 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
   }
   if (!(sd->harmonic_sbr & XAAC_ESBR_USAC) && sd->qmf_sb_prev >= 0 && sd->qmf_sb_prev <= 64) xe_hbe_history_clear(cx, st, sd->qmf_sb_prev);
   XE_T(1);
-  const XeMat src = {&st->qmf_re[0][0] + 128, &st->qmf_im[0][0] + 128}, dst = {ore + 128, oim + 128};
+  const XeMat src = {qre + 128, qim + 128}, dst = {ore + 128, oim + 128};
   /* the harmonic transposer's rows (sbr_dec.c:859-868): its launches wrote rows 8..39 of the scratch matrix for this frame
      if the channel has one with usable parameters; rows 0..7 are the previous frame's last rows */
   float *phr = p.ph_re + (size_t)ch * XAAC_ESBR_PH_ROWS * 64, *phi = p.ph_im + (size_t)ch * XAAC_ESBR_PH_ROWS * 64;
@@ -189,36 +214,36 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
   xaac_esbr_pvc_state *pst = PVC ? p.pvc_state + ch : nullptr;
   float *penv = PVC ? p.pvc_out + (size_t)ch * XAAC_PVC_SLOTS * 64 : nullptr;
   if (apply && rc == 0) {
-    xe_generate_hf<HARM>(cx, h, f, sd, st, &w, src, dst, have_ph ? &ph : nullptr);
+    xe_generate_hf<HARM>(cx, h, f, sd, st, &w, src, dst, have_ph ? &ph : nullptr, RATE);
     __syncthreads();
     XE_T(2);
     if constexpr (PVC) { /* sbr_dec.c:931-953: the low band's energies through the PVC decoder, or its "no PVC frame" bookkeeping */
       if (pvs->sbr_mode == XAAC_ESBR_SBR_PVC) {
         __shared__ XpWork pw;
         const XpCx pcx = {lane, 64};
-        if (!w.err && xp_process(pcx, &pw, &pvs->pvc, &st->qmf_re[2][0], &st->qmf_im[2][0], (size_t)32 * 64, &pst->pvc, penv)) w.err = -1;
+        if (!w.err && xp_process(pcx, &pw, &pvs->pvc, qre + 128, qim + 128, (size_t)SLOTS * 64, &pst->pvc, penv)) w.err = -1;
       } else if (lane == 0) {
         pst->pvc.prev_pvc_flg = 0;
         pst->pvc.prev_first_bnd_idx = h->sub_band_start;
-        pst->pvc.prev_pvc_rate = 2;
+        pst->pvc.prev_pvc_rate = RATE;
       }
       __syncthreads();
     }
-    rc = w.err ? -1 : xe_env_calc(cx, h, f, sd, st, &w, dst, src, (HARM && have_ph) ? p.hbe[ch].x_over_qmf : nullptr, pvs, pst, penv);
+    rc = w.err ? -1 : xe_env_calc(cx, h, f, sd, st, &w, dst, src, (HARM && have_ph) ? p.hbe[ch].x_over_qmf : nullptr, pvs, pst, penv, RATE);
   }
   if (PVC && lane == 0) pst->prev_sbr_mode = pvs->sbr_mode; /* sbr_dec.c:1006 */
   __syncthreads();
   XE_T(3);
   {
-    const int stop = apply ? 2 * f->border_vec[0] : 0;
+    const int stop = apply ? RATE * f->border_vec[0] : 0;
     const int xo_prev = sd->qmf_sb_prev, xo_now = h->sub_band_start;
-    for (int i0 = 0; i0 < 32; i0 += 16) { /* regrouping, sbr_dec.c:365-395; sixteen rows (32 words a lane) in flight */
+    for (int i0 = 0; i0 < SLOTS; i0 += 16) { /* regrouping, sbr_dec.c:365-395; sixteen rows (32 words a lane) in flight */
       float a[16], b[16];
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         const int i = i0 + j, xo = i < stop ? xo_prev : xo_now;
-        a[j] = lane < xo ? st->qmf_re[2 + i][lane] : ore[64 * (2 + i) + lane];
-        b[j] = lane < xo ? st->qmf_im[2 + i][lane] : oim[64 * (2 + i) + lane];
+        a[j] = lane < xo ? qre[64 * (2 + i) + lane] : ore[64 * (2 + i) + lane];
+        b[j] = lane < xo ? qim[64 * (2 + i) + lane] : oim[64 * (2 + i) + lane];
       }
 #pragma unroll
       for (int j = 0; j < 16; j++) {
@@ -227,7 +252,7 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
       }
     }
   }
-  if (p.with_ps) /* the six look-ahead rows of the PS hybrid filter: bands 0..4 of qmf_buf rows 34..39 (sbr_dec.c:487-505) */
+  if (!USF4 && p.with_ps) /* the six look-ahead rows of the PS hybrid filter: bands 0..4 of qmf_buf rows 34..39 (sbr_dec.c:487-505) */
     for (int i = 32; i < 38; i++) {
       rre[64 * i + lane] = lane < 5 ? st->qmf_re[2 + i][lane] : 0.0f;
       rim[64 * i + lane] = lane < 5 ? st->qmf_im[2 + i][lane] : 0.0f;
@@ -236,7 +261,36 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
   XE_T(4);
   /* histories: rows 32.. of this frame's buffers become rows 0.. of the next frame's (sbr_dec.c:835-857).  Loads of one
      batch all in flight: the two 8-row tails first, then the analysis bank's 32 new rows sixteen at a time */
-  {
+  if constexpr (USF4) { /* rows 64..77 of both matrices; behind them the state holds the zeros the reference's unwritten rows are */
+    float t0[HIST], t1[HIST], u0[HIST], u1[HIST];
+#pragma unroll
+    for (int r = 0; r < HIST; r++) {
+      t0[r] = qre[64 * (64 + r) + lane];
+      t1[r] = qim[64 * (64 + r) + lane];
+      u0[r] = ore[64 * (64 + r) + lane];
+      u1[r] = oim[64 * (64 + r) + lane];
+    }
+#pragma unroll
+    for (int r = 0; r < HIST; r++) {
+      st->qmf_re[r][lane] = t0[r];
+      st->qmf_im[r][lane] = t1[r];
+      if (r < 8) {
+        st->out_re[r][lane] = u0[r];
+        st->out_im[r][lane] = u1[r];
+      } else {
+        st->ph_re[r - 8][lane] = u0[r];
+        st->ph_im[r - 8][lane] = u1[r];
+      }
+    }
+    for (int r = HIST; r < XAAC_ESBR_HIST_ROWS; r++) {
+      st->qmf_re[r][lane] = 0.0f;
+      st->qmf_im[r][lane] = 0.0f;
+    }
+    for (int r = HIST - 8; r < 8; r++) {
+      st->ph_re[r][lane] = 0.0f;
+      st->ph_im[r][lane] = 0.0f;
+    }
+  } else {
     float t0[8], t1[8], u0[8], u1[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
@@ -284,7 +338,10 @@ __global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParam
 }
 
 extern "C" hipError_t xaac_launch_esbr_core(const XaacEsbrCoreParams *p, hipStream_t stream) {
-  if (p->pvc_side) { /* USAC channels with PVC frames: their own instantiations, the others carry none of that code */
+  if (p->usf4) { /* 4:1 SBR: USAC channels without a transposer */
+    if (p->pvc_side) hipLaunchKernelGGL((xaac_esbr_core_kernel<false, true, true>), dim3(p->n_ch), dim3(64), 0, stream, *p);
+    else hipLaunchKernelGGL((xaac_esbr_core_kernel<false, false, true>), dim3(p->n_ch), dim3(64), 0, stream, *p);
+  } else if (p->pvc_side) { /* USAC channels with PVC frames: their own instantiations, the others carry none of that code */
     if (p->hbe) hipLaunchKernelGGL((xaac_esbr_core_kernel<true, true>), dim3(p->n_ch), dim3(64), 0, stream, *p);
     else hipLaunchKernelGGL((xaac_esbr_core_kernel<false, true>), dim3(p->n_ch), dim3(64), 0, stream, *p);
   } else if (p->hbe) hipLaunchKernelGGL((xaac_esbr_core_kernel<true, false>), dim3(p->n_ch), dim3(64), 0, stream, *p);

@@ -36,6 +36,7 @@ typedef struct XaacEsbrSynParams {
   int32_t state_stride;         /* bytes between consecutive channels' states */
   int32_t in_stride;            /* floats between consecutive channels' row blocks (>= 2048) */
   const xaac_sbr_header *only_ps; /* optional [n_ch]: channels whose channel_mode is not PS_STEREO are left alone (right bank) */
+  int32_t out_stride;           /* floats between consecutive channels' output rows; 0 = 2048 */
 } XaacEsbrSynParams;
 
 typedef struct XaacEsbrCoreInParams {

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(128, XE_SYN_MIN_WAVES) void xaac_esbr_synthesis_ker
     }
     __syncthreads();
     { /* window-add (ixheaacd_esbr_qmfsyn64_winadd, generic:1544), x 2^-16 to float: wave w takes slots 16 w .. 16 w + 15 */
-      float *dst = p.out + (size_t)ch * 2048;
+      float *dst = p.out + (size_t)ch * (p.out_stride ? p.out_stride : 2048);
 #pragma unroll 4
       for (int s = 16 * w; s < 16 * w + 16; s++) {
         const int32_t *vs = v + (9 + s) * VROW + lane;

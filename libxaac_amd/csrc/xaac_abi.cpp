@@ -330,6 +330,11 @@ int32_t xaac_qmf_synthesis_batch(xaac_ctx *c, const xaac_qmf_syn_batch *b) {
 }
 
 uint64_t xaac_esbr_workspace_bytes(int32_t n_ch) { return n_ch > 0 ? (uint64_t)n_ch * XAAC_ESBR_WS_FLOATS * sizeof(float) : 0; }
+uint64_t xaac_esbr_workspace_bytes_ratio(int32_t n_ch, int32_t sbr_ratio) {
+  if (sbr_ratio != XAAC_ESBR_RATIO_4_1) return xaac_esbr_workspace_bytes(n_ch);
+  return n_ch > 0 ? (uint64_t)n_ch * XAAC_ESBR_WS_FLOATS_4_1 * sizeof(float) : 0;
+}
+
 
 int32_t xaac_esbr_sbr_process_batch(xaac_ctx *c, const xaac_esbr_sbr_batch *b) {
   if (!c || !b) return XAAC_FATAL_NULL_ARG;
@@ -339,10 +344,31 @@ int32_t xaac_esbr_sbr_process_batch(xaac_ctx *c, const xaac_esbr_sbr_batch *b) {
   const bool with_ps = b->ps_frame != nullptr;
   if (with_ps != (b->ps_state != nullptr) || with_ps != (b->out_r != nullptr)) return XAAC_FATAL_BAD_ARG;
   if ((b->pvc_side != nullptr) != (b->pvc_state != nullptr)) return XAAC_FATAL_BAD_ARG;
-  if (b->workspace_bytes < xaac_esbr_workspace_bytes(b->n_ch)) return XAAC_FATAL_BAD_ARG;
+  if (b->sbr_ratio < XAAC_ESBR_RATIO_2_1 || b->sbr_ratio > XAAC_ESBR_RATIO_4_1) return XAAC_FATAL_BAD_ARG;
+  if (b->workspace_bytes < xaac_esbr_workspace_bytes_ratio(b->n_ch, b->sbr_ratio)) return XAAC_FATAL_BAD_ARG;
   if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
   const size_t n = (size_t)b->n_ch;
   float *ws = static_cast<float *>(b->workspace);
+  if (b->sbr_ratio == XAAC_ESBR_RATIO_4_1) { /* 16-channel bank -> 64-slot core -> the synthesis bank in two runs of 32 slots */
+    if (with_ps || b->hbe_state) return XAAC_FATAL_BAD_ARG;
+    float *q_re = ws, *q_im = q_re + n * XAAC_ESBR_Q_ROWS_4_1 * 64;
+    float *o_re = q_im + n * XAAC_ESBR_Q_ROWS_4_1 * 64, *o_im = o_re + n * XAAC_ESBR_OUT_ROWS_4_1 * 64;
+    float *s_re = o_im + n * XAAC_ESBR_OUT_ROWS_4_1 * 64, *s_im = s_re + n * 64 * 64;
+    float *pvc_o = s_im + n * 64 * 64;
+    XaacEsbrAnaNbParams pa = {b->n_ch, 16, 64, b->core, 1024, &b->state->ana, (int32_t)sizeof(xaac_esbr_state),
+                              q_re + XAAC_ESBR_OUT_HIST_ROWS_4_1 * 64, q_im + XAAC_ESBR_OUT_HIST_ROWS_4_1 * 64, XAAC_ESBR_Q_ROWS_4_1 * 64};
+    if (!hip_ok(xaac_launch_esbr_analysis_nb(&pa, c->stream))) return XAAC_FATAL_HIP;
+    XaacEsbrCoreParams pc = {b->n_ch, b->header, b->frame, b->side, b->state, nullptr, nullptr, o_re, o_im, s_re, s_im,
+                             0, b->status, nullptr, nullptr, nullptr, 0, b->pvc_side, b->pvc_state, pvc_o, 1, q_re, q_im};
+    if (!hip_ok(xaac_launch_esbr_core(&pc, c->stream))) return XAAC_FATAL_HIP;
+    for (int half = 0; half < 2; half++) {
+      XaacEsbrSynParams ps = {b->n_ch, s_re + half * 2048, s_im + half * 2048, &b->state->syn, b->out + half * 2048,
+                              (int32_t)sizeof(xaac_esbr_state), 64 * 64, nullptr, 4096};
+      if (!hip_ok(xaac_launch_esbr_synthesis(&ps, c->stream))) return XAAC_FATAL_HIP;
+    }
+    c->last_grid = b->n_ch; c->last_block = 64; c->last_lds = 0;
+    return XAAC_OK;
+  }
   float *ana_re = ws, *ana_im = ana_re + n * 2048;
   float *out_re = ana_im + n * 2048, *out_im = out_re + n * XAAC_ESBR_OUT_ROWS * 64;
   float *syn_re = out_im + n * XAAC_ESBR_OUT_ROWS * 64, *syn_im = syn_re + n * XAAC_ESBR_L_ROWS * 64;
@@ -350,8 +376,13 @@ int32_t xaac_esbr_sbr_process_batch(xaac_ctx *c, const xaac_esbr_sbr_batch *b) {
   float *ph_re = r_im + n * 2048, *ph_im = ph_re + n * XAAC_ESBR_PH_ROWS * 64;
   float *pvc_out = ph_im + n * XAAC_ESBR_PH_ROWS * 64;
   /* the banks' states are members of xaac_esbr_state / xaac_esbr_ps_state: the bank kernels take them at that stride */
-  XaacEsbrAnaParams pa = {b->n_ch, b->core, &b->state->ana, ana_re, ana_im, (int32_t)sizeof(xaac_esbr_state)};
-  if (!hip_ok(xaac_launch_esbr_analysis(&pa, c->stream))) return XAAC_FATAL_HIP;
+  if (b->sbr_ratio == XAAC_ESBR_RATIO_8_3) { /* 768 samples a frame through the 24-channel bank; bands 24..31 of the rows zeroed */
+    XaacEsbrAnaNbParams pn = {b->n_ch, 24, 32, b->core, 1024, &b->state->ana, (int32_t)sizeof(xaac_esbr_state), ana_re, ana_im, 2048};
+    if (!hip_ok(xaac_launch_esbr_analysis_nb(&pn, c->stream))) return XAAC_FATAL_HIP;
+  } else {
+    XaacEsbrAnaParams pa = {b->n_ch, b->core, &b->state->ana, ana_re, ana_im, (int32_t)sizeof(xaac_esbr_state)};
+    if (!hip_ok(xaac_launch_esbr_analysis(&pa, c->stream))) return XAAC_FATAL_HIP;
+  }
   if (b->hbe_state) {
     /* sbr_dec.c:882-909: the frame's new analysis rows through the channel's harmonic transposer (two launches),
        its 32 output rows into rows 8..39 of the ph scratch matrix; channels without SBR processing are skipped */

@@ -21,6 +21,7 @@
 
 extern "C" {
 void xo_esbr_analysis(const float *core, int32_t *ring, int32_t *pos, int32_t *win_off, float *re, float *im);
+void xo_esbr_analysis_nb(const float *core, int nb, int n_slots, int32_t *ring, int32_t *pos, int32_t *win_off, float *re, float *im);
 void xo_esbr_synthesis(const float *re, const float *im, int32_t *ring, int32_t *drc_off, int32_t *filt_off, float *out);
 
 /* the two float stages alone, on the reference's own buffers: qmf / out = qmf_buf_real.. / sbr_qmf_out_real.. as
@@ -31,24 +32,24 @@ int xo_pvc_process(const xaac_pvc_frame *f, const float *qmf_re, const float *qm
    of ixheaacd_sbr_env_calc) */
 static int hf_env_pvc(const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd, xaac_esbr_state *st,
                       float *qmf_re, float *qmf_im, float *out_re, float *out_im, float *ph_re, float *ph_im,
-                      const int32_t *x_over_qmf, const xaac_esbr_pvc_side *pvs, xaac_esbr_pvc_state *pst) {
+                      const int32_t *x_over_qmf, const xaac_esbr_pvc_side *pvs, xaac_esbr_pvc_state *pst, int rate = 2) {
   XO_MATRIX XeWork w;
   XO_MATRIX float env_out[XAAC_PVC_SLOTS * 64];
   const XsCx cx = {0, 1};
   const XeMat src = {qmf_re + 128, qmf_im + 128}, dst = {out_re + 128, out_im + 128};
   const XeMat ph = {ph_re ? ph_re + 128 : nullptr, ph_im ? ph_im + 128 : nullptr};
-  xe_generate_hf(cx, h, f, sd, st, &w, src, dst, ph_re ? &ph : nullptr);
+  xe_generate_hf(cx, h, f, sd, st, &w, src, dst, ph_re ? &ph : nullptr, rate);
   if (pvs && pst) {
     if (pvs->sbr_mode == XAAC_ESBR_SBR_PVC) {
       if (!w.err && xo_pvc_process(&pvs->pvc, qmf_re + 128, qmf_im + 128, &pst->pvc, env_out)) w.err = -1;
     } else {
       pst->pvc.prev_pvc_flg = 0;
       pst->pvc.prev_first_bnd_idx = h->sub_band_start;
-      pst->pvc.prev_pvc_rate = 2;
+      pst->pvc.prev_pvc_rate = (uint8_t)rate;
     }
   }
   if (w.err) return -1;
-  return xe_env_calc(cx, h, f, sd, st, &w, dst, src, ph_re ? x_over_qmf : nullptr, pvs, pst, env_out);
+  return xe_env_calc(cx, h, f, sd, st, &w, dst, src, ph_re ? x_over_qmf : nullptr, pvs, pst, env_out, rate);
 }
 int xo_esbr_hf_env_h(const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd, xaac_esbr_state *st,
                      float *qmf_re, float *qmf_im, float *out_re, float *out_im, float *ph_re, float *ph_im,
@@ -76,6 +77,12 @@ int xo_esbr_sbr_frame_hbe(const float *core, const xaac_sbr_header *h, const xaa
                           xaac_esbr_state *st, const xaac_ps_frame *pf, xaac_esbr_ps_state *pst, float *out, float *out_r,
                           xaac_hbe_state *hst);
 int xo_hbe_apply(xaac_hbe_state *st, const float *qmf_re, const float *qmf_im, int pitch_in_bins, float *pv_re, float *pv_im);
+int xo_esbr_sbr_frame_pvc(const float *core, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
+                          xaac_esbr_state *st, const xaac_ps_frame *pf, xaac_esbr_ps_state *pst, float *out, float *out_r,
+                          xaac_hbe_state *hst, const xaac_esbr_pvc_side *pvs, xaac_esbr_pvc_state *pvst);
+int xo_esbr_sbr_frame_ratio(const float *core, int ratio, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
+                            xaac_esbr_state *st, const xaac_ps_frame *pf, xaac_esbr_ps_state *pst, float *out, float *out_r,
+                            xaac_hbe_state *hst, const xaac_esbr_pvc_side *pvs, xaac_esbr_pvc_state *pvst);
 
 int xo_esbr_sbr_frame(const float *core, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
                       xaac_esbr_state *st, float *out) {
@@ -90,42 +97,61 @@ int xo_esbr_sbr_frame_ps(const float *core, const xaac_sbr_header *h, const xaac
 
 /* ... with the channel's harmonic transposer (hst, or NULL): it runs on every processed frame (sbr_dec.c:882-909) and a
    frame with harmonic_sbr set takes the HF generator's input from it */
-int xo_esbr_sbr_frame_pvc(const float *core, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
-                          xaac_esbr_state *st, const xaac_ps_frame *pf, xaac_esbr_ps_state *pst, float *out, float *out_r,
-                          xaac_hbe_state *hst, const xaac_esbr_pvc_side *pvs, xaac_esbr_pvc_state *pvst);
 int xo_esbr_sbr_frame_hbe(const float *core, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
                           xaac_esbr_state *st, const xaac_ps_frame *pf, xaac_esbr_ps_state *pst, float *out, float *out_r,
                           xaac_hbe_state *hst) {
   return xo_esbr_sbr_frame_pvc(core, h, f, sd, st, pf, pst, out, out_r, hst, nullptr, nullptr);
 }
+/* ratio (xaac_esbr.h: XAAC_ESBR_RATIO_*): 2:1 -- 1024 core samples through the 32-channel bank, 32 slots, 2048 samples out;
+   8:3 -- 768 through the 24-channel bank, 32 slots, 2048 out; 4:1 -- 1024 through the 16-channel bank, 64 slots of which four make
+   an envelope time slot, 4096 out (USAC channels without a transposer only: codec_x_delay 0, no PS) */
 /* ... of a USAC channel whose host tracks PVC (pvs / pvst, or NULL): PVC frames through the PVC decoder and the adjuster's PVC branch */
 int xo_esbr_sbr_frame_pvc(const float *core, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
                           xaac_esbr_state *st, const xaac_ps_frame *pf, xaac_esbr_ps_state *pst, float *out, float *out_r,
                           xaac_hbe_state *hst, const xaac_esbr_pvc_side *pvs, xaac_esbr_pvc_state *pvst) {
+  return xo_esbr_sbr_frame_ratio(core, XAAC_ESBR_RATIO_2_1, h, f, sd, st, pf, pst, out, out_r, hst, pvs, pvst);
+}
+int xo_esbr_sbr_frame_ratio(const float *core, int ratio, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
+                            xaac_esbr_state *st, const xaac_ps_frame *pf, xaac_esbr_ps_state *pst, float *out, float *out_r,
+                            xaac_hbe_state *hst, const xaac_esbr_pvc_side *pvs, xaac_esbr_pvc_state *pvst) {
+  /* rows: 8 of history + (32 of codec_x_delay +) the frame's 32 or 64 + what a grid running past the frame's end reads (zeros) */
+  constexpr int QROWS = 104, OROWS = 82; /* (104: the 40-row history is copied from row 64 on for 4:1) */
+  static_assert(QROWS >= XAAC_ESBR_ROWS, "2:1 with codec_x_delay");
   XO_MATRIX float phr[40][64], phi[40][64];
-  XO_MATRIX float qre[XAAC_ESBR_ROWS][64], qim[XAAC_ESBR_ROWS][64], ore[42][64], oim[42][64];
-  XO_MATRIX float rre[38][64], rim[38][64], xre[32][64], xim[32][64];
+  XO_MATRIX float qre[QROWS][64], qim[QROWS][64], ore[OROWS][64], oim[OROWS][64];
+  XO_MATRIX float rre[64 + 6][64], rim[64 + 6][64], xre[32][64], xim[32][64];
+  const int usf4 = ratio == XAAC_ESBR_RATIO_4_1, slots = usf4 ? 64 : 32, rate = usf4 ? 4 : 2;
+  const int nb = usf4 ? 16 : (ratio == XAAC_ESBR_RATIO_8_3 ? 24 : 32);
   int rc = 0;
+  if (usf4 && (!(sd->harmonic_sbr & XAAC_ESBR_NO_X_DELAY) || pf || hst)) return -1; /* not restated: 4:1 with a transposer, with PS */
   /* USAC channels (xaac_esbr.h): no clearing above the old cross-over band (sbr_dec.c:868); codec_x_delay 0 without a transposer
      (sbr_dec.c:819-826): the frame's analysis rows are rows 8..39 of the buffer, rows 40..71 stay what they were (zero) */
-  const int ana_row = (sd->harmonic_sbr & XAAC_ESBR_NO_X_DELAY) ? XAAC_ESBR_OUT_HIST_ROWS : XAAC_ESBR_HIST_ROWS;
+  /* 4:1: op_delay is 12 (sbr_dec.c:719), so both matrices carry 14 rows of history; sbr_qmf_out's rows 8..13 live in the state's
+     ph rows 0..5 (xaac_esbr.h: a 4:1 channel has no transposer here) */
+  const int hist = usf4 ? XAAC_ESBR_OUT_HIST_ROWS_4_1 : XAAC_ESBR_OUT_HIST_ROWS;
+  const int ana_row = (sd->harmonic_sbr & XAAC_ESBR_NO_X_DELAY) ? hist : XAAC_ESBR_HIST_ROWS;
   if (!(sd->harmonic_sbr & XAAC_ESBR_USAC) && sd->qmf_sb_prev >= 0 && sd->qmf_sb_prev <= 64) {
     const XsCx cx = {0, 1};
     xe_hbe_history_clear(cx, st, sd->qmf_sb_prev);
   }
+  memset(qre, 0, sizeof(qre));
+  memset(qim, 0, sizeof(qim));
   memcpy(qre, st->qmf_re, sizeof(st->qmf_re));
   memcpy(qim, st->qmf_im, sizeof(st->qmf_im));
-  memset(qre + XAAC_ESBR_HIST_ROWS, 0, sizeof(float) * 32 * 64);
-  memset(qim + XAAC_ESBR_HIST_ROWS, 0, sizeof(float) * 32 * 64);
   if (ana_row != XAAC_ESBR_HIST_ROWS) {
-    memset(qre + ana_row, 0, sizeof(float) * 32 * 64);
-    memset(qim + ana_row, 0, sizeof(float) * 32 * 64);
+    memset(qre + ana_row, 0, sizeof(float) * (QROWS - ana_row) * 64);
+    memset(qim + ana_row, 0, sizeof(float) * (QROWS - ana_row) * 64);
   }
   memset(ore, 0, sizeof(ore));
   memset(oim, 0, sizeof(oim));
   memcpy(ore, st->out_re, sizeof(st->out_re));
   memcpy(oim, st->out_im, sizeof(st->out_im));
-  xo_esbr_analysis(core, st->ana.ring, &st->ana.pos, &st->ana.win_off, &qre[ana_row][0], &qim[ana_row][0]);
+  if (usf4) {
+    memcpy(ore + 8, st->ph_re, sizeof(float) * 6 * 64);
+    memcpy(oim + 8, st->ph_im, sizeof(float) * 6 * 64);
+  }
+  if (nb == 32) xo_esbr_analysis(core, st->ana.ring, &st->ana.pos, &st->ana.win_off, &qre[ana_row][0], &qim[ana_row][0]);
+  else xo_esbr_analysis_nb(core, nb, slots, st->ana.ring, &st->ana.pos, &st->ana.win_off, &qre[ana_row][0], &qim[ana_row][0]);
   bool have_ph = false;
   if (hst && f->apply_processing) { /* sbr_dec.c:882-909: the frame's 32 new analysis rows through the transposer */
     memcpy(phr, st->ph_re, sizeof(st->ph_re));
@@ -142,14 +168,14 @@ int xo_esbr_sbr_frame_pvc(const float *core, const xaac_sbr_header *h, const xaa
     rc = xe_side_info_bad(h, f, sd) ? -1
                                     : hf_env_pvc(h, f, sd, st, &qre[0][0], &qim[0][0], &ore[0][0], &oim[0][0],
                                                  have_ph ? &phr[0][0] : nullptr, have_ph ? &phi[0][0] : nullptr,
-                                                 hst ? hst->x_over_qmf : nullptr, pvs, pvst);
+                                                 hst ? hst->x_over_qmf : nullptr, pvs, pvst, rate);
   } else {
     memset(ore, 0, sizeof(ore));
     memset(oim, 0, sizeof(oim));
   }
   { /* ixheaacd_esbr_synthesis_regrp, sbr_dec.c:365-395 */
-    const int stop = f->apply_processing ? 2 * f->border_vec[0] : 0;
-    for (int i = 0; i < 32; i++) {
+    const int stop = f->apply_processing ? rate * f->border_vec[0] : 0;
+    for (int i = 0; i < slots; i++) {
       const int xo = i < stop ? sd->qmf_sb_prev : h->sub_band_start;
       for (int k = 0; k < 64; k++) {
         rre[i][k] = k < xo ? qre[2 + i][k] : ore[2 + i][k];
@@ -177,11 +203,18 @@ int xo_esbr_sbr_frame_pvc(const float *core, const xaac_sbr_header *h, const xaa
     }
     xo_esbr_synthesis(&xre[0][0], &xim[0][0], pst->syn_r.ring, &pst->syn_r.drc_offset, &pst->syn_r.filt_off, out_r);
   }
-  xo_esbr_synthesis(&rre[0][0], &rim[0][0], st->syn.ring, &st->syn.drc_offset, &st->syn.filt_off, out);
-  memcpy(st->qmf_re, qre + 32, sizeof(st->qmf_re));
-  memcpy(st->qmf_im, qim + 32, sizeof(st->qmf_im));
-  memcpy(st->out_re, ore + 32, sizeof(st->out_re));
-  memcpy(st->out_im, oim + 32, sizeof(st->out_im));
+  for (int s0 = 0; s0 < slots; s0 += 32) /* the bank is a running filter: 64 slots are two runs of 32 */
+    xo_esbr_synthesis(&rre[s0][0], &rim[s0][0], st->syn.ring, &st->syn.drc_offset, &st->syn.filt_off, out + 64 * s0);
+  memcpy(st->qmf_re, qre + slots, sizeof(st->qmf_re));
+  memcpy(st->qmf_im, qim + slots, sizeof(st->qmf_im));
+  memcpy(st->out_re, ore + slots, sizeof(st->out_re));
+  memcpy(st->out_im, oim + slots, sizeof(st->out_im));
+  if (usf4) {
+    memset(st->ph_re, 0, sizeof(st->ph_re));
+    memset(st->ph_im, 0, sizeof(st->ph_im));
+    memcpy(st->ph_re, ore + slots + 8, sizeof(float) * 6 * 64);
+    memcpy(st->ph_im, oim + slots + 8, sizeof(float) * 6 * 64);
+  }
   if (pvs && pvst) pvst->prev_sbr_mode = pvs->sbr_mode; /* sbr_dec.c:1006 */
   return rc;
 }

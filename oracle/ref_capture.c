@@ -80,8 +80,13 @@ static int esbr_path(const ia_sbr_dec_struct *d, const ia_sbr_header_data_struct
          (h->channel_mode == PS_STEREO ? (ps != NULL && synth_r != NULL && !ps->use_34_st_bands && !ps->use_pca_rot_flg && ps->ps_mode == 0)
                                        : !h->enh_sbr_ps) &&
          !drc_on && !ldmps && !mps && !f->mps_sbr_flag && (f->sbr_mode != PVC_SBR || (h->usac_flag && getenv("XAAC_ESBR_CHAIN_PVC"))) &&
-         h->sbr_ratio_idx != SBR_UPSAMPLE_IDX_4_1 &&
-         h->num_time_slots == 16 && d->str_codec_qmf_bank.no_channels == 32 &&
+         /* 2:1, 8:3 (24-channel bank), 4:1 (16-channel bank, 64 slots) without a transposer */
+         /* (the header's num_time_slots is core_frame_size / 64: 12 for the 768-sample frames of 8:3; the branch itself counts
+            slots with the bank's own num_time_slots, 32 or 64) */
+         (h->num_time_slots == 16 || (h->num_time_slots == 12 && h->sbr_ratio_idx == SBR_UPSAMPLE_IDX_8_3)) &&
+         (d->str_codec_qmf_bank.no_channels == 32 ||
+                                     (h->usac_flag && h->sbr_ratio_idx == SBR_UPSAMPLE_IDX_8_3 && d->str_codec_qmf_bank.no_channels == 24) ||
+                                     (h->usac_flag && h->sbr_ratio_idx == SBR_UPSAMPLE_IDX_4_1 && d->str_codec_qmf_bank.no_channels == 16 && !h->hbe_flag)) &&
          d->str_synthesis_qmf_bank.no_channels == 64;
 }
 static WORD32 esbr_chain_call(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_header_data_struct *h,
@@ -147,6 +152,9 @@ static WORD32 esbr_chain_call(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_he
     chains[c] = d;
   }
   first = steps[c] == 0 || getenv("XAAC_ESBR_CHAIN_FULL") != NULL;
+  const int ratio = h->sbr_ratio_idx == SBR_UPSAMPLE_IDX_4_1 ? XAAC_ESBR_RATIO_4_1
+                    : (h->sbr_ratio_idx == SBR_UPSAMPLE_IDX_8_3 ? XAAC_ESBR_RATIO_8_3 : XAAC_ESBR_RATIO_2_1);
+  const int slots = ratio == XAAC_ESBR_RATIO_4_1 ? 64 : 32;
   /* -- reference-side fuzz: only what a bitstream can say, on the reference's own structs; the fuzzed members are put
      back after the call (the parser decodes the next frame's PS indices and header fields relative to its own) -- */
   static ia_sbr_header_data_struct h_keep;
@@ -205,7 +213,7 @@ static WORD32 esbr_chain_call(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_he
   meta[0] = 0x58414332; /* "XAC2" */
   meta[1] = c;
   meta[2] = steps[c];
-  meta[3] = eps;
+  meta[3] = eps | (ratio << 8); /* ratio: XAAC_ESBR_RATIO_* */
   meta[4] = first;
   meta[5] = apply;
   fwrite(meta, 4, 6, out);
@@ -247,7 +255,7 @@ static WORD32 esbr_chain_call(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_he
     }
   }
   meta[0] = ret;
-  meta[1] = (int32_t)crc32_buf(eps ? ps->time_sample_buf[0] : d->time_sample_buf, 2048 * sizeof(float));
+  meta[1] = (int32_t)crc32_buf(eps ? ps->time_sample_buf[0] : d->time_sample_buf, (size_t)64 * slots * sizeof(float));
   meta[2] = (eps && apply) ? (int32_t)crc32_buf(ps->time_sample_buf[1], 2048 * sizeof(float)) : 0;
   last_crc[c][0] = crc32_buf(&est, sizeof(est)); /* continuity is judged on the whole state */
   { /* The CRC the tests compare: sbr_qmf_out entries no later call can read are left out.  The reference's 64-row output
@@ -257,11 +265,15 @@ static WORD32 esbr_chain_call(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_he
     static xaac_esbr_state canon;
     const int kx = h->pstr_freq_band_data->sub_band_start;
     const int nenv = f->str_frame_info_details.num_env;
-    int keep = apply ? 2 + 2 * f->str_frame_info_details.border_vec[nenv] - 32 : XAAC_ESBR_OUT_HIST_ROWS, r, k;
+    const int hist = slots == 64 ? XAAC_ESBR_OUT_HIST_ROWS_4_1 : XAAC_ESBR_OUT_HIST_ROWS;
+    int keep = apply ? 2 + (slots / 16) * f->str_frame_info_details.border_vec[nenv] - slots : hist, r, k;
     canon = est;
-    for (r = 0; r < XAAC_ESBR_OUT_HIST_ROWS; r++)
+    for (r = 0; r < hist; r++)
       for (k = 0; k < 64; k++)
-        if (r >= keep || k < kx) canon.out_re[r][k] = canon.out_im[r][k] = 0.0f;
+        if (r >= keep || k < kx) {
+          if (r < XAAC_ESBR_OUT_HIST_ROWS) canon.out_re[r][k] = canon.out_im[r][k] = 0.0f;
+          else canon.ph_re[r - 8][k] = canon.ph_im[r - 8][k] = 0.0f; /* 4:1: rows 8..13 of the history (xaac_esbr.h) */
+        }
     meta[3] = (int32_t)crc32_buf(&canon, sizeof(canon));
   }
   meta[4] = (int32_t)crc32_buf(&hbs, sizeof(hbs));
@@ -283,7 +295,7 @@ static WORD32 esbr_chain_call(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_he
     fwrite(&hbs, sizeof(hbs), 1, out);
     if (eps) fwrite(&epss, sizeof(epss), 1, out);
     if (with_pvc) fwrite(&pvst, sizeof(pvst), 1, out);
-    fwrite(eps ? ps->time_sample_buf[0] : d->time_sample_buf, 4, 2048, out);
+    fwrite(eps ? ps->time_sample_buf[0] : d->time_sample_buf, 4, (size_t)64 * slots, out);
   }
   fflush(out);
   steps[c]++;
@@ -352,6 +364,11 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     return __real_ixheaacd_sbr_dec(d, time_data, h, f, p, ps, synth_r, sf_r, apply, low_pow, work, tabs, common, ch_fac, pvc, drc_on,
                                    drc, aot, ldmps, self, mps, ec);
   }
+  if (getenv("XAAC_ESBR_CHAIN_WHY"))
+    fprintf(stderr, "enh %d aot %d usac %d hbe %d tx %p sci %d hq %d mode %d drc %d ldmps %d mps %d mpsf %d sbr_mode %d ratio %d nts %d nch %d syn %d\n",
+            h->enh_sbr, aot, h->usac_flag, h->hbe_flag, (void *)d->p_hbe_txposer, f->stereo_config_idx, h->esbr_hq, h->channel_mode, drc_on,
+            ldmps, mps, f->mps_sbr_flag, f->sbr_mode, h->sbr_ratio_idx, h->num_time_slots, d->str_codec_qmf_bank.no_channels,
+            d->str_synthesis_qmf_bank.no_channels);
   if (getenv("XAAC_ESBR_CHAIN_FILE") && esbr_path(d, h, f, ps, synth_r, drc_on, aot, ldmps, mps))
     return esbr_chain_call(d, time_data, h, f, p, ps, synth_r, sf_r, apply, low_pow, work, tabs, common, ch_fac, pvc, drc_on, drc,
                            aot, ldmps, self, mps, ec);

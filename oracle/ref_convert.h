@@ -423,6 +423,7 @@ static void from_esbr_pvc_state(const xaac_esbr_pvc_state *o, int processed, ia_
 static void to_esbr_state(const ia_sbr_dec_struct *d, const ia_sbr_header_data_struct *h,
                           const ia_sbr_frame_info_data_struct *f, xaac_esbr_state *o) {
   const ia_sbr_qmf_filter_bank_struct *a = &d->str_codec_qmf_bank, *s = &d->str_synthesis_qmf_bank;
+  const int nts = a->num_time_slots == 64 ? 64 : 32; /* 4:1 SBR: the next frame's history starts at row 64 (sbr_dec.c:835-857) */
   int i;
   memset(o, 0, sizeof(*o));
   memcpy(o->ana.ring, a->anal_filter_states_32, sizeof(o->ana.ring));
@@ -431,10 +432,10 @@ static void to_esbr_state(const ia_sbr_dec_struct *d, const ia_sbr_header_data_s
   memcpy(o->syn.ring, s->filter_states_32, sizeof(o->syn.ring));
   o->syn.drc_offset = s->ixheaacd_drc_offset;
   o->syn.filt_off = (int32_t)(s->filter_pos_syn_32 - s->p_filter_32);
-  memcpy(o->qmf_re, d->qmf_buf_real[32], sizeof(o->qmf_re));
-  memcpy(o->qmf_im, d->qmf_buf_imag[32], sizeof(o->qmf_im));
-  memcpy(o->out_re, d->sbr_qmf_out_real[32], sizeof(o->out_re));
-  memcpy(o->out_im, d->sbr_qmf_out_imag[32], sizeof(o->out_im));
+  memcpy(o->qmf_re, d->qmf_buf_real[nts], sizeof(o->qmf_re));
+  memcpy(o->qmf_im, d->qmf_buf_imag[nts], sizeof(o->qmf_im));
+  memcpy(o->out_re, d->sbr_qmf_out_real[nts], sizeof(o->out_re));
+  memcpy(o->out_im, d->sbr_qmf_out_imag[nts], sizeof(o->out_im));
   memcpy(o->bw_array_prev, f->bw_array_prev, sizeof(o->bw_array_prev));
   memcpy(o->e_gain, f->e_gain, sizeof(o->e_gain));
   memcpy(o->noise_buf, f->noise_buf, sizeof(o->noise_buf));
@@ -450,11 +451,18 @@ static void to_esbr_state(const ia_sbr_dec_struct *d, const ia_sbr_header_data_s
   o->prev_sbr_patching_mode = f->prev_sbr_patching_mode;
   memcpy(o->ph_re, d->ph_vocod_qmf_real[32], sizeof(o->ph_re));
   memcpy(o->ph_im, d->ph_vocod_qmf_imag[32], sizeof(o->ph_im));
+  if (nts == 64) { /* xaac_esbr.h, XAAC_ESBR_OUT_HIST_ROWS_4_1: rows 8..13 of sbr_qmf_out's 14-row history ride in the ph rows */
+    memset(o->ph_re, 0, sizeof(o->ph_re));
+    memset(o->ph_im, 0, sizeof(o->ph_im));
+    memcpy(o->ph_re, d->sbr_qmf_out_real[nts + 8], sizeof(float) * 6 * 64);
+    memcpy(o->ph_im, d->sbr_qmf_out_imag[nts + 8], sizeof(float) * 6 * 64);
+  }
 }
 
 static void from_esbr_state(const xaac_esbr_state *o, ia_sbr_dec_struct *d, ia_sbr_header_data_struct *h,
                             ia_sbr_frame_info_data_struct *f) {
   ia_sbr_qmf_filter_bank_struct *a = &d->str_codec_qmf_bank, *s = &d->str_synthesis_qmf_bank;
+  const int nts = a->num_time_slots == 64 ? 64 : 32;
   int i;
   memcpy(a->anal_filter_states_32, o->ana.ring, sizeof(o->ana.ring));
   a->state_new_samples_pos_low_32 = a->anal_filter_states_32 + o->ana.pos;
@@ -462,10 +470,10 @@ static void from_esbr_state(const xaac_esbr_state *o, ia_sbr_dec_struct *d, ia_s
   memcpy(s->filter_states_32, o->syn.ring, sizeof(o->syn.ring));
   s->ixheaacd_drc_offset = o->syn.drc_offset;
   s->filter_pos_syn_32 = (WORD32 *)s->p_filter_32 + o->syn.filt_off;
-  memcpy(d->qmf_buf_real[32], o->qmf_re, sizeof(o->qmf_re));
-  memcpy(d->qmf_buf_imag[32], o->qmf_im, sizeof(o->qmf_im));
-  memcpy(d->sbr_qmf_out_real[32], o->out_re, sizeof(o->out_re));
-  memcpy(d->sbr_qmf_out_imag[32], o->out_im, sizeof(o->out_im));
+  memcpy(d->qmf_buf_real[nts], o->qmf_re, sizeof(o->qmf_re));
+  memcpy(d->qmf_buf_imag[nts], o->qmf_im, sizeof(o->qmf_im));
+  memcpy(d->sbr_qmf_out_real[nts], o->out_re, sizeof(o->out_re));
+  memcpy(d->sbr_qmf_out_imag[nts], o->out_im, sizeof(o->out_im));
   memcpy(f->bw_array_prev, o->bw_array_prev, sizeof(o->bw_array_prev));
   memcpy(f->e_gain, o->e_gain, sizeof(o->e_gain));
   memcpy(f->noise_buf, o->noise_buf, sizeof(o->noise_buf));
@@ -479,8 +487,13 @@ static void from_esbr_state(const xaac_esbr_state *o, ia_sbr_dec_struct *d, ia_s
   for (i = 0; i <= XAAC_SBR_MAX_PATCHES; i++) f->patch_param.start_subband[i] = o->patch_start_subband[i];
   memcpy(f->harm_flag_prev, o->harm_flag_prev, sizeof(o->harm_flag_prev));
   f->prev_sbr_patching_mode = o->prev_sbr_patching_mode;
-  memcpy(d->ph_vocod_qmf_real[32], o->ph_re, sizeof(o->ph_re));
-  memcpy(d->ph_vocod_qmf_imag[32], o->ph_im, sizeof(o->ph_im));
+  if (nts == 64) {
+    memcpy(d->sbr_qmf_out_real[nts + 8], o->ph_re, sizeof(float) * 6 * 64);
+    memcpy(d->sbr_qmf_out_imag[nts + 8], o->ph_im, sizeof(float) * 6 * 64);
+  } else {
+    memcpy(d->ph_vocod_qmf_real[32], o->ph_re, sizeof(o->ph_re));
+    memcpy(d->ph_vocod_qmf_imag[32], o->ph_im, sizeof(o->ph_im));
+  }
 }
 
 /* the QMF harmonic transposer (ia_esbr_hbe_txposer_struct, ixheaacd_sbr_dec.h:30-100) <-> xaac_hbe_state */

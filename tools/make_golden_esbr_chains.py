@@ -31,6 +31,10 @@ PASSES = 10           # decoder runs per stream; pass 0 is unfuzzed
 # without a harmonic transposer (codec_x_delay 0: xaac_esbr.h XAAC_ESBR_NO_X_DELAY), with one (sbr_patching_mode 0 frames),
 # a switched FD / LPD core (the ORIG_SBR frames of it)
 USAC_STREAMS = ("u21", "u21harm", "u21sw", "m21swpvc", "m21tdpvc")
+# `python tools/make_golden_esbr_chains.py ratios` -> tests/golden/esbr_ratio_chains.npz: USAC channels at the other two SBR
+# ratios -- 8:3 (768-sample core frames through the 24-channel bank) and 4:1 (the 16-channel bank, 64 slots) -- plain, with
+# PVC frames (the reference encoder makes no harmonic SBR at these ratios); "chain_ratio" says which (xaac_esbr.h: XAAC_ESBR_RATIO_*)
+RATIO_STREAMS = ("u83", "m83swpvc", "u41", "m41swpvc", "m41tdpvc")
 USAC_PASSES = 6
 
 
@@ -58,7 +62,8 @@ def parse(path, run, z, pvc=False):
         magic, chain, step, eps, first, apply = struct.unpack_from("<6i", b, o)
         assert magic == 0x58414332, hex(magic)
         o += 24
-        r = dict(run=run, chain=chain, step=step, eps=eps, first=first, apply=apply)
+        eps, ratio = eps & 0xff, eps >> 8
+        r = dict(run=run, chain=chain, step=step, eps=eps, first=first, apply=apply, ratio=ratio)
         if first:
             r["est0"] = b[o:o + z["est"]]; o += z["est"]
             r["hbs0"] = b[o:o + z["hbs"]]; o += z["hbs"]
@@ -75,13 +80,14 @@ def parse(path, run, z, pvc=False):
     return recs
 
 
-def main(usac=False):
+def main(usac=False, ratios=False):
+    usac = usac or ratios
     z = sizes()
     cap = os.path.join(ROOT, "oracle", "_ref", "xaacdec_capture")
     recs = []
     run = 0
     for p in range(USAC_PASSES if usac else PASSES):
-        for s in (USAC_STREAMS if usac else STREAMS):
+        for s in (RATIO_STREAMS if ratios else USAC_STREAMS if usac else STREAMS):
             tmp = "/tmp/xaac_esbr_chain_%d.bin" % run
             env = dict(os.environ, XAAC_ESBR_CHAIN_FILE=tmp, XAAC_ESBR_CHAIN_SEED=str(0 if p == 0 else 100 * p + run),
                        XAAC_ESBR_CHAIN_RUN=str(run))
@@ -109,6 +115,9 @@ def main(usac=False):
     }
     if usac:
         d["pvc_side"] = np.stack([u8(r["pvs"], 0) for r in recs])
+        d["chain_ratio"] = np.zeros(nc, np.int32)
+        for r in recs:
+            d["chain_ratio"][cidx[(r["run"], r["chain"])]] = r["ratio"]
         d["pvst0"] = np.zeros((nc, z["pvst"]), np.uint8)
         for r in recs:
             if r["first"]:
@@ -122,7 +131,7 @@ def main(usac=False):
             d["hbs0"][i] = u8(r["hbs0"], 0)
             if r["eps"]:
                 d["eps0"][i] = u8(r["eps0"], 0)
-    dst = os.path.join(ROOT, "tests", "golden", "esbr_usac_chains.npz" if usac else "esbr_chains.npz")
+    dst = os.path.join(ROOT, "tests", "golden", "esbr_ratio_chains.npz" if ratios else "esbr_usac_chains.npz" if usac else "esbr_chains.npz")
     np.savez_compressed(dst, **d)
     from esbr_structs import EsbrSide
     harm = sum(1 for r in recs if r["apply"] and np.frombuffer(r["sd"], np.int16)[EsbrSide.harmonic_sbr.offset // 2] != 0)
@@ -132,4 +141,4 @@ def main(usac=False):
 
 
 if __name__ == "__main__":
-    main(usac=len(sys.argv) > 1 and sys.argv[1] == "usac")
+    main(usac=len(sys.argv) > 1 and sys.argv[1] == "usac", ratios=len(sys.argv) > 1 and sys.argv[1] == "ratios")

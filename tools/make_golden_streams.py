@@ -81,7 +81,11 @@ def main():
                             ("u41", "/tmp/xaac_golden_mix.wav", ["-ccfl_idx:4"]),
                             ("u83", "/tmp/xaac_golden_mix.wav", ["-ccfl_idx:2"]),   # 768-line core, 8:3 eSBR
                             ("m21swpvc", "/tmp/xaac_golden_mono.wav", ["-ccfl_idx:3", "-usac:0", "-pvc_enc:1"]),
-                            ("m21tdpvc", "/tmp/xaac_golden_mono.wav", ["-ccfl_idx:3", "-usac:2", "-pvc_enc:1"])):
+                            ("m21tdpvc", "/tmp/xaac_golden_mono.wav", ["-ccfl_idx:3", "-usac:2", "-pvc_enc:1"]),
+                            # the other two SBR ratios with the tools of the 2:1 set: PVC frames at 8:3 and 4:1 (-harmonic_sbr:1 changes nothing at these ratios: the encoder's streams come out identical)
+                            ("m83swpvc", "/tmp/xaac_golden_mono.wav", ["-ccfl_idx:2", "-usac:0", "-pvc_enc:1"]),
+                            ("m41swpvc", "/tmp/xaac_golden_mono.wav", ["-ccfl_idx:4", "-usac:0", "-pvc_enc:1"]),
+                            ("m41tdpvc", "/tmp/xaac_golden_mono.wav", ["-ccfl_idx:4", "-usac:2", "-pvc_enc:1"])):
         aac = os.path.join(out_usac, name + ".aac")
         subprocess.run([os.path.join(REF, "xaacenc"), "-ifile:" + wav, "-ofile:" + aac, "-aot:42", "-br:48000"] + args,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
