@@ -44,7 +44,7 @@ static struct {
   xaac_esbr_pvc_state *pvst;
 } g;
 static long g_eld_ana_calls, g_eld_syn_calls;
-static long g_imdct_calls, g_sbr_calls, g_lim_calls, g_esbr_calls, g_esbr_harm_calls, g_esbr_usac_calls, g_esbr_pvc_calls, g_sbr_ref_calls, g_usac_imdct_calls, g_usac_imdct_fac, g_usac_imdct_lpd, g_eld_sbr_calls, g_imdct960_calls, g_imdct_ld_calls;
+static long g_imdct_calls, g_sbr_calls, g_lim_calls, g_esbr_calls, g_esbr_harm_calls, g_esbr_usac_calls, g_esbr_pvc_calls, g_esbr_83_calls, g_esbr_41_calls, g_sbr_ref_calls, g_usac_imdct_calls, g_usac_imdct_fac, g_usac_imdct_lpd, g_eld_sbr_calls, g_imdct960_calls, g_imdct_ld_calls;
 static struct { int32_t *overlap; int16_t *pcm; uint8_t *shape; } gl; /* AAC-LD / ELD: 3 x 512 overlap words, 512 samples, 2 bytes */
 
 static void die(const char *what) {
@@ -66,6 +66,7 @@ static void report(void) {
   fprintf(stderr, "xaacdec_dropin: %ld USAC fd_frm_dec calls ran on the GPU, %ld with a FAC signal, %ld behind an LPD frame\n", g_usac_imdct_calls,
           g_usac_imdct_fac, g_usac_imdct_lpd);
   fprintf(stderr, "xaacdec_dropin: %ld of the USAC calls were PVC frames (PVC decoder + the adjuster's PVC branch on the GPU)\n", g_esbr_pvc_calls);
+  fprintf(stderr, "xaacdec_dropin: %ld of the USAC calls at 8:3 SBR (24-channel bank), %ld at 4:1 (16-channel bank, 64 slots)\n", g_esbr_83_calls, g_esbr_41_calls);
 }
 
 static void setup(void) {
@@ -91,7 +92,7 @@ static void setup(void) {
   g.ws_bytes = a > b ? a : b;
   HIP(hipMalloc(&g.ws, g.ws_bytes));
   HIP(hipMalloc((void **)&g.core, 4096));
-  HIP(hipMalloc((void **)&g.time, 8192));
+  HIP(hipMalloc((void **)&g.time, 16384)); /* 4096 floats: a 4:1 frame */
   HIP(hipMalloc((void **)&g.time_r, 8192));
   HIP(hipMalloc((void **)&g.epss, sizeof(xaac_esbr_ps_state)));
   HIP(hipMalloc((void **)&g.side, sizeof(xaac_esbr_side)));
@@ -99,7 +100,7 @@ static void setup(void) {
   HIP(hipMalloc((void **)&g.pvs, sizeof(xaac_esbr_pvc_side)));
   HIP(hipMalloc((void **)&g.pvst, sizeof(xaac_esbr_pvc_state)));
   HIP(hipMalloc((void **)&g.hbe, sizeof(xaac_hbe_state)));
-  HIP(hipMalloc(&g.ews, xaac_esbr_workspace_bytes(1)));
+  HIP(hipMalloc(&g.ews, xaac_esbr_workspace_bytes(1) + xaac_esbr_workspace_bytes_ratio(1, XAAC_ESBR_RATIO_4_1)));
   HIP(hipMalloc((void **)&gl.overlap, 3 * 512 * 4));
   HIP(hipMalloc((void **)&gl.pcm, 512 * 2));
   HIP(hipMalloc((void **)&gl.shape, 2));
@@ -463,8 +464,17 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
                                     : !h->enh_sbr_ps) &&
       !drc_on && !ldmps && !mps && !f->mps_sbr_flag &&
       (f->sbr_mode != PVC_SBR || (h->usac_flag && pvc != NULL && !low_pow && !getenv("XAAC_DROPIN_NO_PVC"))) &&
-      h->sbr_ratio_idx != SBR_UPSAMPLE_IDX_4_1 && h->num_time_slots == 16 &&
-      d->str_codec_qmf_bank.no_channels == 32 && d->str_synthesis_qmf_bank.no_channels == 64 && !getenv("XAAC_DROPIN_NO_ESBR")) {
+      /* the three SBR ratios: 2:1; 8:3 (USAC, 768-sample frames, 24-channel bank; the header counts 12 time slots there: core
+         frame / 64); 4:1 (USAC, 16-channel bank, 64 slots) without a transposer */
+      ((h->num_time_slots == 16 && d->str_codec_qmf_bank.no_channels == 32) ||
+       (h->usac_flag && h->sbr_ratio_idx == SBR_UPSAMPLE_IDX_8_3 && h->num_time_slots == 12 && d->str_codec_qmf_bank.no_channels == 24 &&
+        !getenv("XAAC_DROPIN_NO_RATIOS")) ||
+       (h->usac_flag && h->sbr_ratio_idx == SBR_UPSAMPLE_IDX_4_1 && h->num_time_slots == 16 && d->str_codec_qmf_bank.no_channels == 16 &&
+        !h->hbe_flag && !getenv("XAAC_DROPIN_NO_RATIOS"))) &&
+      d->str_synthesis_qmf_bank.no_channels == 64 && !getenv("XAAC_DROPIN_NO_ESBR")) {
+    const int ratio = d->str_codec_qmf_bank.no_channels == 16 ? XAAC_ESBR_RATIO_4_1
+                      : (d->str_codec_qmf_bank.no_channels == 24 ? XAAC_ESBR_RATIO_8_3 : XAAC_ESBR_RATIO_2_1);
+    const int out_floats = ratio == XAAC_ESBR_RATIO_4_1 ? 4096 : 2048;
     static xaac_esbr_side sd;
     static xaac_esbr_state est;
     static xaac_esbr_ps_state epss;
@@ -517,7 +527,8 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     }
     b.status = g.status;
     b.workspace = g.ews;
-    b.workspace_bytes = xaac_esbr_workspace_bytes(1);
+    b.sbr_ratio = ratio;
+    b.workspace_bytes = xaac_esbr_workspace_bytes_ratio(1, ratio);
     b.hbe_state = h->hbe_flag ? g.hbe : NULL;
     if (h->usac_flag) { /* every USAC call carries the PVC side info and state: ORIG_SBR frames leave what a PVC frame behind them reads */
       to_esbr_pvc_side(h, f, pvc, low_pow, &pvs);
@@ -538,7 +549,7 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     }
     if (status) return status;
     HIP(hipMemcpy(&est, g.estate, sizeof(est), hipMemcpyDeviceToHost));
-    HIP(hipMemcpy(d->time_sample_buf, g.time, 8192, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(d->time_sample_buf, g.time, (size_t)out_floats * 4, hipMemcpyDeviceToHost));
     from_esbr_state(&est, d, h, f);
     if (apply && h->hbe_flag) {
       HIP(hipMemcpy(&hbs, g.hbe, sizeof(hbs), hipMemcpyDeviceToHost));
@@ -562,6 +573,8 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     f->prev_sbr_mode = f->sbr_mode;
     g_esbr_calls++;
     if (h->usac_flag) g_esbr_usac_calls++;
+    if (ratio == XAAC_ESBR_RATIO_8_3) g_esbr_83_calls++;
+    if (ratio == XAAC_ESBR_RATIO_4_1) g_esbr_41_calls++;
     if (apply && f->sbr_patching_mode == 0) g_esbr_harm_calls++;
     return 0;
   }
