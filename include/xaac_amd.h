@@ -427,6 +427,13 @@ typedef struct xaac_usac_fac {
   int32_t data[256];         /* fac_idata[0 .. 2 lfac), lfac <= FAC_LENGTH = 128 */
 } xaac_usac_fac;
 
+typedef struct xaac_usac_fac_in {
+  int32_t fac_data[129];     /* usac_data->fac_data[ch]: [0] the gain index, [1 .. lfac] the quantised FAC lines (not modified here;
+                                the reference scales its copy in place, which nothing reads afterwards) */
+  float lpc_prev[17];        /* usac_data->lpc_prev[ch]: the previous frame's LPC filter, ORDER + 1 coefficients */
+  float acelp_in[256];       /* usac_data->acelp_in[ch][0 .. ccfl / 4): the ACELP zero-input response */
+} xaac_usac_fac_in;
+
 typedef struct xaac_usac_imdct_batch {
   int32_t n_ch;
   int32_t ccfl;              /* usac_data->ccfl: 1024 or 768; 0 = 1024.  (Added in round 3 where LP64 had four bytes of padding in
@@ -451,6 +458,13 @@ typedef struct xaac_usac_imdct_batch {
      host applies its filter to `time` and converts back. */
   const uint8_t *lpd_flags;
   const struct xaac_usac_fac *fac;
+  /* ... or the signal made on the device: fac_in, optional [n_ch] -- the LPD-side inputs of ixheaacd_cal_fac_data (imdct.c:210) for the
+     channels with both flags set, as the LPD decoder leaves them in usac_data; the function then runs here (its transform of lfac
+     lines, the previous LPC filter's weighted recursion, the zero-input response through the window's slopes) and `fac` is not
+     read.  fac_work: [n_ch] scratch for the signals, required with fac_in.  A frame for which the reference's function returns an
+     error is refused with XAAC_FATAL_BAD_ARG like one with an unusable exponent. */
+  const struct xaac_usac_fac_in *fac_in;
+  struct xaac_usac_fac *fac_work;
 } xaac_usac_imdct_batch;
 
 typedef struct xaac_ctx xaac_ctx;

@@ -108,7 +108,11 @@ class _UsacImdctBatch(ctypes.Structure):
     # struct xaac_usac_imdct_batch
     _fields_ = [("n_ch", ctypes.c_int32), ("ccfl", ctypes.c_int32), ("coef", ctypes.c_void_p), ("ics", ctypes.c_void_p),
                 ("overlap", ctypes.c_void_p), ("shape_prev", ctypes.c_void_p), ("out32", ctypes.c_void_p),
-                ("time", ctypes.c_void_p), ("status", ctypes.c_void_p), ("lpd_flags", ctypes.c_void_p), ("fac", ctypes.c_void_p)]
+                ("time", ctypes.c_void_p), ("status", ctypes.c_void_p), ("lpd_flags", ctypes.c_void_p), ("fac", ctypes.c_void_p),
+                ("fac_in", ctypes.c_void_p), ("fac_work", ctypes.c_void_p)]
+
+
+USAC_FAC_IN_WORDS = 129 + 17 + 256   # struct xaac_usac_fac_in: fac_data int32[129], lpc_prev float[17], acelp_in float[256]
 
 
 class _QmfAnaEldBatch(ctypes.Structure):
@@ -628,7 +632,7 @@ class XaacContext:
             raise XaacError(rc, "xaac_sbr_state_apply_side_batch")
 
     def usac_imdct_process_batch(self, coef, ics, overlap, shape_prev, out32=None, time=None, status=None, ccfl=1024,
-                                 lpd_flags=None, fac=None):
+                                 lpd_flags=None, fac=None, fac_in=None, fac_work=None):
         """Batched ixheaacd_fd_frm_dec (USAC FD frame after an FD frame, ccfl 1024 or 768, no FAC): coef int32[n_ch, ccfl];
         ics uint8[n_ch, 2] (window_sequence 0..4, window_shape); overlap int32[n_ch, ccfl] in/out; shape_prev uint8[n_ch]
         in/out; out32 int32[n_ch, ccfl] (Q15) and / or time float32[n_ch, ccfl]; status int32[n_ch]."""
@@ -646,6 +650,10 @@ class XaacContext:
         # (struct xaac_usac_fac: q, data[256])
         b.lpd_flags = _ptr(lpd_flags, "uint8", n_ch, allow_none=True, device_ok=True)
         b.fac = _ptr(fac, "int32", n_ch * 257, allow_none=True, device_ok=True)
+        # ... or the signal made on the device (ixheaacd_cal_fac_data): fac_in int32 view of [n_ch] xaac_usac_fac_in, fac_work
+        # int32[n_ch, 257] scratch
+        b.fac_in = _ptr(fac_in, "int32", n_ch * USAC_FAC_IN_WORDS, allow_none=True, device_ok=True)
+        b.fac_work = _ptr(fac_work, "int32", n_ch * 257, allow_none=True, device_ok=True)
         rc = self._lib.xaac_usac_imdct_process_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_usac_imdct_process_batch")

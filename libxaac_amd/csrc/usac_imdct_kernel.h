@@ -23,9 +23,19 @@ typedef struct XaacUsacImdctParams {
   const xaac_usac_fac *fac;  /* optional [n_ch] */
 } XaacUsacImdctParams;
 
+typedef struct XaacUsacFacParams { /* ixheaacd_cal_fac_data for the channels with both LPD flags set */
+  int32_t n_ch, ccfl;
+  const xaac_usac_ics *ics;
+  const uint8_t *lpd_flags;
+  const xaac_usac_fac_in *in;
+  xaac_usac_fac *out;        /* [n_ch]: data, q; q = XAAC_USAC_FAC_REFUSED where the reference's function returns an error */
+} XaacUsacFacParams;
+#define XAAC_USAC_FAC_REFUSED 0x7fffffff
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+hipError_t xaac_launch_usac_fac(const XaacUsacFacParams *p, hipStream_t stream);
 hipError_t xaac_launch_usac_imdct(const XaacUsacImdctParams *p, hipStream_t stream);
 #ifdef __cplusplus
 }

@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include "usac_imdct.h"
+#include "usac_fac.h"
 #include "usac_imdct_kernel.h"
 
 namespace {
@@ -220,6 +221,7 @@ __device__ __forceinline__ int frame(const XaacUsacImdctParams &p, int ch, int32
   const XuLpd lp = {flags & 1, (flags >> 1) & 1, (p.fac && (flags & 2)) ? fac_q_in : 0};
   /* FAC data only ever follows an LPD frame and needs its signal; ccfl 1024 has no 256-tap KBD window (calc_window fails) */
   if (lp.fac && (!lp.td_prev || !p.fac)) return XAAC_FATAL_BAD_ARG;
+  if (lp.fac && fac_q_in == XAAC_USAC_FAC_REFUSED) return XAAC_FATAL_BAD_ARG; /* xaac_usac_fac_kernel: ixheaacd_cal_fac_data's error */
   if (xu_lpd_window_missing<L>(lp.td_prev != 0, seq, shape_prev)) return XAAC_FATAL_BAD_WINDOW_SEQ;
   bool all_zero;
   const int shiftp = seq == 2 ? transform<L, true>(coef, c, A, B, lane, 0, all_zero) : transform<L, false>(coef, c, A, B, lane, 0, all_zero);
@@ -274,6 +276,27 @@ __global__ __launch_bounds__(64 * XAAC_USAC_WAVES_PER_WG, XU_MIN_WAVES) void xaa
     if (rc == XAAC_OK) p.shape_prev[ch] = (uint8_t)p.ics[ch].window_shape; /* ext_ch_ele.c:1015 */
     if (p.status) p.status[ch] = rc;
   }
+}
+
+/* ixheaacd_cal_fac_data (imdct.c:210) for the channels whose frame follows an LPD frame and carries FAC data: one wave per
+   channel, the work arrays in LDS, arithmetic and order of usac_fac.h -- element-wise loops over the lanes, the 24- to 64-point
+   transform and the order-16 recursion on one lane (a frame in a few hundred of a switched stream's comes here) */
+__global__ __launch_bounds__(64) void xaac_usac_fac_kernel(XaacUsacFacParams p) {
+  __shared__ XfWork w;
+  const int ch = blockIdx.x, lane = threadIdx.x;
+  const int flags = p.lpd_flags[ch];
+  if ((flags & 3) != 3) return; /* (uniform) */
+  const int seq = p.ics[ch].window_sequence;
+  const int lfac = seq == 2 ? p.ccfl >> 4 : p.ccfl >> 3; /* imdct.c:620-626, td_frame_prev set */
+  const XfCx cx = {lane, 64};
+  int32_t q = 0;
+  const int rc = xf_cal_fac_data(cx, &w, p.in + ch, p.ccfl, lfac, p.out[ch].data, &q);
+  if (lane == 0) p.out[ch].q = rc ? XAAC_USAC_FAC_REFUSED : w.s_q_out;
+}
+
+extern "C" hipError_t xaac_launch_usac_fac(const XaacUsacFacParams *p, hipStream_t stream) {
+  hipLaunchKernelGGL(xaac_usac_fac_kernel, dim3(p->n_ch), dim3(64), 0, stream, *p);
+  return hipGetLastError();
 }
 
 extern "C" hipError_t xaac_launch_usac_imdct(const XaacUsacImdctParams *p, hipStream_t stream) {

@@ -460,8 +460,15 @@ int32_t xaac_usac_imdct_process_batch(xaac_ctx *c, const xaac_usac_imdct_batch *
   if (b->ccfl != 0 && b->ccfl != 1024 && b->ccfl != 768) return XAAC_FATAL_BAD_ARG;
   if (!b->coef || !b->ics || !b->overlap || !b->shape_prev) return XAAC_FATAL_NULL_ARG;
   if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  const xaac_usac_fac *fac = b->fac;
+  if (b->fac_in) { /* the FAC signals of this batch's LPD -> FD transitions, made on the device first */
+    if (!b->fac_work || !b->lpd_flags) return XAAC_FATAL_NULL_ARG;
+    XaacUsacFacParams pf = {b->n_ch, b->ccfl ? b->ccfl : 1024, b->ics, b->lpd_flags, b->fac_in, b->fac_work};
+    if (!hip_ok(xaac_launch_usac_fac(&pf, c->stream))) return XAAC_FATAL_HIP;
+    fac = b->fac_work;
+  }
   XaacUsacImdctParams p = {b->n_ch, b->ccfl ? b->ccfl : 1024, b->coef, b->ics, b->overlap, b->shape_prev, b->out32, b->time, b->status,
-                           b->lpd_flags, b->fac};
+                           b->lpd_flags, fac};
   if (!hip_ok(xaac_launch_usac_imdct(&p, c->stream))) return XAAC_FATAL_HIP;
   c->last_grid = (b->n_ch + XAAC_USAC_WAVES_PER_WG - 1) / XAAC_USAC_WAVES_PER_WG;
   c->last_block = 64 * XAAC_USAC_WAVES_PER_WG;

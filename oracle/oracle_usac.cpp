@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include "../libxaac_amd/csrc/usac_imdct.h"
+#include "../libxaac_amd/csrc/usac_fac.h"
 
 namespace {
 
@@ -148,6 +149,28 @@ int xo_usac_fd_imdct_lpd(int32_t *coef, int32_t *overlap, int ccfl, int seq, int
 }
 int xo_usac_fd_imdct(int32_t *coef, int32_t *overlap, int seq, int shape, int shape_prev, int32_t *out) {
   return fd_imdct<1024>(coef, overlap, seq, shape, shape_prev, out);
+}
+
+/* ixheaacd_cal_fac_data (imdct.c:210) on the LPD-side inputs of a channel: fac_data[129] (gain index + quantised lines), lpc_prev[17],
+   acelp_in[ccfl / 4]; lfac as ixheaacd_fd_frm_dec chooses it from the window sequence and td_frame_prev (:620-632).  fac_out: 2 lfac
+   words, *q_out: the exponent.  Returns 0 or -1 like the reference. */
+struct XoFacIn {
+  const int32_t *fac_data;
+  const float *lpc_prev, *acelp_in;
+};
+int xo_usac_cal_fac(int ccfl, int seq, int td_prev, const int32_t *fac_data, const float *lpc_prev, const float *acelp_in, int32_t *fac_out,
+                    int32_t *q_out) {
+  static thread_local XfWork w;
+  const XfCx cx = {0, 1};
+  const XoFacIn in = {fac_data, lpc_prev, acelp_in};
+  const int lfac = td_prev ? (seq == 2 ? ccfl >> 4 : ccfl >> 3) : 128;
+  return xf_cal_fac_data(cx, &w, &in, ccfl, lfac, fac_out, q_out);
+}
+/* the general FFT's forward transform alone (ixheaacd_complex_fft with fft_mode = -1, fft.c:2664): n = 2^k or 3 * 2^k; returns the
+   exponent the reference reports (for *preshift = 0) */
+int xo_fft_fwd(int32_t *xr, int32_t *xi, int n) {
+  static thread_local int32_t y[2048], tr[512], ti[512];
+  return (n & (n - 1)) ? xf_fft_fwd_p3(xr, xi, n, y, tr, ti) : xf_fft_fwd_p2(xr, xi, n, y);
 }
 
 }  // extern "C"

@@ -44,6 +44,7 @@ static struct {
   xaac_esbr_pvc_state *pvst;
 } g;
 static long g_eld_ana_calls, g_eld_syn_calls;
+static long g_usac_fac_dev;
 static long g_imdct_calls, g_sbr_calls, g_lim_calls, g_esbr_calls, g_esbr_harm_calls, g_esbr_usac_calls, g_esbr_pvc_calls, g_esbr_83_calls, g_esbr_41_calls, g_sbr_ref_calls, g_usac_imdct_calls, g_usac_imdct_fac, g_usac_imdct_lpd, g_eld_sbr_calls, g_imdct960_calls, g_imdct_ld_calls;
 static struct { int32_t *overlap; int16_t *pcm; uint8_t *shape; } gl; /* AAC-LD / ELD: 3 x 512 overlap words, 512 samples, 2 bytes */
 
@@ -65,6 +66,7 @@ static void report(void) {
   fprintf(stderr, "xaacdec_dropin: %ld of them for USAC channels, %ld sbr_dec calls left to the reference\n", g_esbr_usac_calls, g_sbr_ref_calls);
   fprintf(stderr, "xaacdec_dropin: %ld USAC fd_frm_dec calls ran on the GPU, %ld with a FAC signal, %ld behind an LPD frame\n", g_usac_imdct_calls,
           g_usac_imdct_fac, g_usac_imdct_lpd);
+  fprintf(stderr, "xaacdec_dropin: %ld FAC signals made on the device (ixheaacd_cal_fac_data)\n", g_usac_fac_dev);
   fprintf(stderr, "xaacdec_dropin: %ld of the USAC calls were PVC frames (PVC decoder + the adjuster's PVC branch on the GPU)\n", g_esbr_pvc_calls);
   fprintf(stderr, "xaacdec_dropin: %ld of the USAC calls at 8:3 SBR (24-channel bank), %ld at 4:1 (16-channel bank, 64 slots)\n", g_esbr_83_calls, g_esbr_41_calls);
 }
@@ -117,6 +119,8 @@ void dropin_count_usac_imdct(int with_fac, int behind_lpd) {
   g_usac_imdct_fac += with_fac != 0;
   g_usac_imdct_lpd += behind_lpd != 0;
 }
+void dropin_count_usac_fac_on_device(void) { g_usac_fac_dev++; }
+
 
 /* developer aid: the numeric code behind the command-line tool's "error unlisted" */
 int __real_ixheaacd_error_handler(void *info, char *context, int code);

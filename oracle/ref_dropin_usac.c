@@ -3,9 +3,10 @@
  *
  * The USAC frequency-domain seam of the drop-in: ixheaacd_fd_frm_dec (decoder/ixheaacd_imdct.c:596, call sites
  * ixheaacd_ext_ch_ele.c:799 / :991) served by xaac_usac_imdct_process_batch -- the stub INTEGRATION.md section 7 describes, as
- * code.  What belongs to the LPD decoder stays the reference's and runs on the host exactly where it ran: the
- * forward-aliasing-cancellation signal (ixheaacd_cal_fac_data, imdct.c:210: previous LPC filter + ACELP zero-input response)
- * in front of the call, the bass post filter (ixheaacd_lpd_bpf_fix, lpc.c:749) behind it.  Contains no reference code; the
+ * code.  The forward-aliasing-cancellation signal of a frame behind an LPD frame (ixheaacd_cal_fac_data, imdct.c:210) is made on
+ * the device from the LPD decoder's three inputs -- FAC lines, previous LPC filter, ACELP zero-input response: xaac_usac_fac_in --
+ * ($XAAC_DROPIN_HOST_FAC: by the reference's own function on the host, the signal handed over instead); the LPD decoder's bass
+ * post filter (ixheaacd_lpd_bpf_fix, lpc.c:749) stays the reference's and runs behind the call where it ran.  Contains no reference code; the
  * header list is what ia_usac_data_struct's definition needs (as in ref_usac_adapter.c).
  */
 #include <stdio.h>
@@ -41,6 +42,7 @@
 
 xaac_ctx *dropin_ctx(void);        /* ref_dropin.c: the drop-in's context (created, and the summary registered, on first use) */
 void dropin_count_usac_imdct(int with_fac, int behind_lpd);
+void dropin_count_usac_fac_on_device(void);
 
 WORD32 __real_ixheaacd_fd_frm_dec(ia_usac_data_struct *usac_data, WORD32 i_ch);
 IA_ERRORCODE ixheaacd_cal_fac_data(ia_usac_data_struct *usac_data, WORD32 i_ch, WORD32 n_long, WORD32 lfac, WORD32 *fac_idata,
@@ -49,7 +51,9 @@ IA_ERRORCODE ixheaacd_cal_fac_data(ia_usac_data_struct *usac_data, WORD32 i_ch, 
 #define HIPU(x) do { if ((x) != hipSuccess) { fprintf(stderr, "xaacdec_dropin: %s failed\n", #x); exit(3); } } while (0)
 
 WORD32 __wrap_ixheaacd_fd_frm_dec(ia_usac_data_struct *u, WORD32 ch) {
-  static struct { int32_t *coef, *overlap, *out32, *status; xaac_usac_ics *ics; uint8_t *shape_prev, *flags; xaac_usac_fac *fac; } d;
+  static struct { int32_t *coef, *overlap, *out32, *status; xaac_usac_ics *ics; uint8_t *shape_prev, *flags; xaac_usac_fac *fac; xaac_usac_fac_in *fac_in; } d;
+  static xaac_usac_fac_in fin;
+  const int host_fac = getenv("XAAC_DROPIN_HOST_FAC") != NULL;
   const int ccfl = u->ccfl, seq = u->window_sequence[ch];
   const int td_prev = u->td_frame_prev[ch] != 0, fac_apply = u->fac_data_present[ch] && u->frame_ok == 1;
   xaac_usac_imdct_batch b;
@@ -70,9 +74,16 @@ WORD32 __wrap_ixheaacd_fd_frm_dec(ia_usac_data_struct *u, WORD32 ch) {
     HIPU(hipMalloc((void **)&d.shape_prev, 1));
     HIPU(hipMalloc((void **)&d.flags, 1));
     HIPU(hipMalloc((void **)&d.fac, sizeof(xaac_usac_fac)));
+    HIPU(hipMalloc((void **)&d.fac_in, sizeof(xaac_usac_fac_in)));
   }
   memset(&fac, 0, sizeof(fac));
-  if (fac_apply) { /* the LPD side's own code, unchanged (imdct.c:618-640) */
+  if (fac_apply && td_prev && !host_fac) { /* the function's inputs as the LPD decoder left them (imdct.c:226-229); it runs on the device */
+    memset(&fin, 0, sizeof(fin));
+    memcpy(fin.fac_data, u->fac_data[ch], sizeof(fin.fac_data));
+    memcpy(fin.lpc_prev, u->lpc_prev[ch], sizeof(fin.lpc_prev));
+    memcpy(fin.acelp_in, u->acelp_in[ch], sizeof(float) * (size_t)(ccfl / 4));
+    HIPU(hipMemcpy(d.fac_in, &fin, sizeof(fin), hipMemcpyHostToDevice));
+  } else if (fac_apply) { /* the LPD side's own code, unchanged (imdct.c:618-640) */
     WORD32 fac_idata[2 * FAC_LENGTH + 16];
     WORD8 q = 0;
     const int lfac = td_prev ? (seq == EIGHT_SHORT_SEQUENCE ? ccfl >> 4 : ccfl >> 3) : FAC_LENGTH;
@@ -104,6 +115,10 @@ WORD32 __wrap_ixheaacd_fd_frm_dec(ia_usac_data_struct *u, WORD32 ch) {
   b.status = d.status;
   b.lpd_flags = d.flags;
   b.fac = d.fac;
+  if (fac_apply && td_prev && !host_fac) {
+    b.fac_in = d.fac_in;
+    b.fac_work = d.fac;
+  }
   if (xaac_usac_imdct_process_batch(ctx, &b) != XAAC_OK || xaac_sync(ctx) != XAAC_OK) {
     fprintf(stderr, "xaacdec_dropin: xaac_usac_imdct_process_batch failed\n");
     exit(3);
@@ -128,5 +143,6 @@ WORD32 __wrap_ixheaacd_fd_frm_dec(ia_usac_data_struct *u, WORD32 ch) {
     for (k = 0; k < ccfl; k++) o[k] = (WORD32)(t[k] * (1 << 15));
   }
   dropin_count_usac_imdct(fac_apply, td_prev);
+  if (fac_apply && td_prev && !host_fac) dropin_count_usac_fac_on_device();
   return 0;
 }

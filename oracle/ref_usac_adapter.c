@@ -115,3 +115,11 @@ int ref_usac_fd_imdct_lpd(WORD32 *coef, WORD32 *overlap, int ccfl, int seq, int 
   memcpy(out, u->output_data_ptr[0], sizeof(WORD32) * ccfl);
   return err;
 }
+
+/* the general FFT alone: ixheaacd_complex_fft (fft.c:2664) with fft_mode = -1; returns what it leaves in *preshift (0 on entry) */
+VOID ixheaacd_complex_fft(WORD32 *data_r, WORD32 *data_i, WORD32 nlength, WORD32 fft_mode, WORD32 *preshift);
+int ref_fft_fwd(WORD32 *xr, WORD32 *xi, int n) {
+  WORD32 pre = 0;
+  ixheaacd_complex_fft(xr, xi, n, -1, &pre);
+  return pre;
+}

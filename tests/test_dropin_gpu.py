@@ -133,6 +133,8 @@ def test_usac_streams_esbr_through_the_gpu(aac, tmp_path):
     mi = re.search(r"(\d+) USAC fd_frm_dec calls ran on the GPU, (\d+) with a FAC signal, (\d+) behind an LPD frame", log)
     assert mi, log[-600:]
     n_fd, n_fac, n_lpd = (int(v) for v in mi.groups())
+    md = re.search(r"(\d+) FAC signals made on the device", log)
+    assert md and int(md.group(1)) == n_fac, log[-600:]     # ixheaacd_cal_fac_data itself on the GPU (xaac_usac_fac_in), not handed over
     if "td" in name:
         assert n_fd == 0                # LPD frames only
     elif "sw" in name:

@@ -149,3 +149,65 @@ def test_chain_with_lpd_transitions(oracle, reference, seed, ccfl):
         shape_prev = shape
         seq = int(rng.choice(NEXT[seq]))
     assert {(2, 1, 1), (3, 1, 1), (4, 1, 1), (2, 1, 0), (3, 1, 0), (4, 1, 0)} <= seen
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32, 64, 128, 256, 512, 12, 24, 48, 96, 192, 384])
+def test_forward_fft_equals_the_reference(oracle, reference, n):
+    """ixheaacd_complex_fft with fft_mode = -1 (fft.c:1449-1965, :2531) -- the transform inside ixheaacd_acelp_mdct -- restated in
+    usac_fac.h: words and reported exponent equal at every size, small, mid-scale and saturating inputs"""
+    rf, of = reference.lib.ref_fft_fwd, oracle.lib.xo_fft_fwd
+    for fn in (rf, of):
+        fn.restype = ctypes.c_int
+        fn.argtypes = [P32, P32, ctypes.c_int]
+    rng = np.random.default_rng(n)
+    for amp in (1 << 8, 1 << 20, 1 << 28, (1 << 31) - 1):
+        for _ in range(6):
+            xr = rng.integers(-amp, amp, n, dtype=np.int64).astype(np.int32)
+            xi = rng.integers(-amp, amp, n, dtype=np.int64).astype(np.int32)
+            ar, ai, br, bi = xr.copy(), xi.copy(), xr.copy(), xi.copy()
+            pr = rf(_p(ar), _p(ai), n)
+            po = of(_p(br), _p(bi), n)
+            assert pr == po, (n, amp, pr, po)
+            assert np.array_equal(ar, br) and np.array_equal(ai, bi), (n, amp, int(np.sum(ar != br)), np.nonzero(ar != br)[0][:6])
+
+
+def wild_side(rng, ccfl, kind):
+    """LPD-side inputs of ixheaacd_cal_fac_data over more than the plausible: huge and tiny gains, silent and loud zero-input
+    responses, filters with large coefficients, FAC lines up to the quantiser's range"""
+    fac_data = np.zeros(129, np.int32)
+    fac_data[0] = rng.integers(0, 128) if kind != 3 else rng.integers(100, 128)
+    span = (41, 2, 1 << 15, 1 << 30)[kind]
+    fac_data[1:] = rng.integers(-span, span + 1, 128) * (rng.integers(0, 3, 128) != 0)
+    lpc = np.zeros(17, np.float32)
+    lpc[0] = 1.0
+    lpc[1:] = (rng.standard_normal(16) * (0.4, 0.01, 3.0, 20.0)[kind]).astype(np.float32)
+    zir = (rng.standard_normal(256) * (800.0, 0.0, 30000.0, 1e-3)[kind]).astype(np.float32)
+    return fac_data, lpc, zir
+
+
+@pytest.mark.parametrize("ccfl", [1024, 768])
+def test_cal_fac_data_equals_the_reference(oracle, reference, ccfl):
+    """ixheaacd_cal_fac_data (imdct.c:210): the oracle's restatement (usac_fac.h) against the reference's own function on drawn
+    LPD-side inputs -- every window sequence behind an LPD frame (lfac = ccfl / 8, ccfl / 16), the frames it refuses, plausible and
+    wild inputs: the 2 lfac words of the signal and its exponent equal"""
+    fn = oracle.lib.xo_usac_cal_fac
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int] * 3 + [P32, PF, PF, P32, P32]
+    rng = np.random.default_rng(ccfl + 5)
+    coef, ov = np.zeros(ccfl, np.int32), np.zeros(ccfl, np.int32)
+    n_ok = 0
+    for it in range(400):
+        seq, td_prev = int(rng.integers(0, 5)), int(it % 7 != 0)
+        side = lpd_side(rng, ccfl, seq, 1) if it % 2 == 0 else wild_side(rng, ccfl, int(rng.integers(0, 4)))
+        rc_r, _, _, _, fac_r, q_r = ref_call_lpd(reference, coef, ov, seq, 0, 0, td_prev, 1, side)
+        fac_o, q_o = np.zeros(256, np.int32), np.zeros(1, np.int32)
+        rc_o = fn(ccfl, seq, td_prev, _p(side[0]), _p(side[1], PF), _p(side[2], PF), _p(fac_o), _p(q_o))
+        assert (rc_r != 0) == (rc_o != 0), (it, seq, td_prev, rc_r, rc_o)
+        if rc_r:
+            continue
+        lfac = (ccfl >> 4 if seq == 2 else ccfl >> 3) if td_prev else 128
+        assert q_r == int(q_o[0]), (it, seq, td_prev, q_r, int(q_o[0]))
+        assert np.array_equal(fac_r[:2 * lfac], fac_o[:2 * lfac]), (it, seq, td_prev, int(np.sum(fac_r[:2 * lfac] != fac_o[:2 * lfac])),
+                                                                     np.nonzero(fac_r[:2 * lfac] != fac_o[:2 * lfac])[0][:6])
+        n_ok += 1
+    assert n_ok > 200
