@@ -251,6 +251,14 @@ typedef struct xaac_sbr_hq_batch {
   int32_t *status;                 /* optional [n_ch] */
   void *workspace;                 /* device scratch, >= xaac_sbr_hq_workspace_bytes(n_ch, ps_frame != NULL) */
   uint64_t workspace_bytes;
+  int32_t max_band_hint;           /* optional hint, like xaac_esbr_sbr_batch.hbe_max_synth_size: 48 = the caller knows that no stream of
+                                      the batch reaches above QMF band 48 -- SBR range, frequency tables, patches, the banks' band limits of
+                                      this frame and of the frames still in its overlap rows (true once a stream's headers have kept
+                                      sub_band_end <= 48 since its start, as the 24 / 32 kHz-core streams of HE-AACv2 services do).  The core
+                                      then works on 48-band rows only and the launch that takes other streams through 64-band rows is
+                                      left out; a stream for which the assertion does not hold is refused (status XAAC_FATAL_BAD_ARG:
+                                      the frame is not decoded, the stream cannot be continued from its state).  0: no assertion, any stream
+                                      is decoded. */
 } xaac_sbr_hq_batch;
 
 /* --- low-delay SBR channel-frames of AAC-ELD ---------------------------------------------------------------------------

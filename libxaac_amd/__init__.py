@@ -222,7 +222,7 @@ class _SbrHqBatch(ctypes.Structure):
                 ("down_sample", ctypes.c_int32), ("pcm_in", ctypes.c_void_p), ("header", ctypes.c_void_p),
                 ("frame", ctypes.c_void_p), ("state", ctypes.c_void_p), ("ps_frame", ctypes.c_void_p),
                 ("ps_state", ctypes.c_void_p), ("pcm_out", ctypes.c_void_p), ("status", ctypes.c_void_p),
-                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_uint64)]
+                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_uint64), ("max_band_hint", ctypes.c_int32)]
 
 
 class _SbrEldBatch(ctypes.Structure):
@@ -845,7 +845,7 @@ class XaacContext:
         return int(self._lib.xaac_sbr_hq_workspace_bytes(int(n_ch), int(bool(with_ps))))
 
     def sbr_hq_process_batch(self, pcm_in, header, frame, state, pcm_out, workspace, ps_frame=None, ps_state=None,
-                             status=None, in_ch_fac=1, out_ch_fac=1, down_sample=False):
+                             status=None, in_ch_fac=1, out_ch_fac=1, down_sample=False, max_band_hint=0):
         """Batched ixheaacd_sbr_dec, HQ mode: one frame per stream.  With ps_frame / ps_state (uint8[n, PS_*_BYTES])
         the parametric-stereo tool runs too (HE-AACv2) and pcm_out is int16[n*2048*2] of L,R pairs; without them
         pcm_out is int16[n*2048] (HE-AAC mono, HQ)."""
@@ -864,6 +864,7 @@ class XaacContext:
         b.status = _ptr(status, "int32", n_ch, allow_none=True, device_ok=True)
         b.workspace = _ptr(workspace, "uint8", device_ok=True)
         b.workspace_bytes = workspace.numel()
+        b.max_band_hint = int(max_band_hint)   # 48: no stream of the batch reaches above QMF band 48 (xaac_amd.h); 0: no assertion
         rc = self._lib.xaac_sbr_hq_process_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_sbr_hq_process_batch")

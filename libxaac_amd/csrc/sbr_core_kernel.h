@@ -28,6 +28,8 @@ typedef struct XaacSbrCoreParams {
   int32_t *work_counter; /* = defer_count + 1: the persistent waves' next channel-frame */
   int32_t num_cu;        /* compute units of the device (grid of the persistent launch) */
   int32_t counters_zeroed; /* 1: an earlier launch on the stream has cleared defer_count / work_counter */
+  int32_t narrow_only;     /* the caller's assertion (xaac_sbr_hq_batch.max_band_hint): no list launch; a stream that needs the 64-band
+                              rows is refused */
 } XaacSbrCoreParams;
 
 #ifdef __cplusplus

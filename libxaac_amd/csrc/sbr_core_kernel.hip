@@ -472,7 +472,13 @@ __global__ __launch_bounds__(64 * WAVES, HQ ? 1 : XS_LP_MIN_WAVES) void xaac_sbr
       ch = first ? (int)blockIdx.x * WAVES + wave : p.n_ch;
     }
     if (ch >= p.n_ch) break;
-    if (!core_one<HQ, NB>(p, ch, s[wave], lane) && lane == 0) p.defer_list[atomicAdd(p.defer_count, 1)] = ch;
+    if (!core_one<HQ, NB>(p, ch, s[wave], lane) && lane == 0) {
+      if (p.narrow_only) { /* the hint was wrong for this stream: refused, nothing of it written */
+        if (p.status) p.status[ch] = XAAC_FATAL_BAD_ARG;
+      } else {
+        p.defer_list[atomicAdd(p.defer_count, 1)] = ch;
+      }
+    }
     xs_wave_sync();
   }
 }
@@ -536,6 +542,7 @@ extern "C" hipError_t xaac_launch_sbr_core_hq(const XaacSbrCoreParams *p, hipStr
   const int resident = per_cu * (p->num_cu > 0 ? p->num_cu : 256), need = (p->n_ch + W - 1) / W;
   hipLaunchKernelGGL((xaac_sbr_core_kernel<1, XAAC_SBR_NARROW_BANDS, W>), dim3(need < resident ? need : resident), dim3(64 * W), 0,
                      stream, *p);
+  if (p->narrow_only) return hipGetLastError(); /* the caller knows the list stays empty (xaac_sbr_hq_batch.max_band_hint) */
   const int grid = p->n_ch < 64 ? p->n_ch : 64;
   hipLaunchKernelGGL((xaac_sbr_core_list_kernel<1>), dim3(grid), dim3(64), 0, stream, *p);
   return hipGetLastError();

@@ -717,6 +717,7 @@ int32_t xaac_sbr_hq_process_batch(xaac_ctx *c, const xaac_sbr_hq_batch *b) {
   pc.status = b->status;
   pc.defer_count = counters; pc.work_counter = counters + 1; pc.defer_list = counters + 2; pc.num_cu = c->num_cu;
   pc.counters_zeroed = 1;
+  pc.narrow_only = b->max_band_hint == XAAC_SBR_NARROW_BANDS ? 1 : 0;
   if (!hip_ok(xaac_launch_sbr_core_hq(&pc, c->stream))) return XAAC_FATAL_HIP;
   /* 3. parametric stereo: rows 2..33 become the left channel, xr the right one */
   if (with_ps) {

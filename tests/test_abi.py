@@ -100,7 +100,7 @@ def test_struct_layout_matches_header(tmp_path):
     import subprocess
     pairs = [("xaac_imdct_batch", libxaac_amd._ImdctBatch, "status"), ("xaac_qmf_ana_batch", libxaac_amd._QmfAnaBatch, "qmf"),
              ("xaac_qmf_syn_batch", libxaac_amd._QmfSynBatch, "pcm"), ("xaac_sbr_lp_batch", libxaac_amd._SbrLpBatch, "workspace_bytes"),
-             ("xaac_sbr_hq_batch", libxaac_amd._SbrHqBatch, "workspace_bytes"),
+             ("xaac_sbr_hq_batch", libxaac_amd._SbrHqBatch, "max_band_hint"),
              ("xaac_sbr_eld_batch", libxaac_amd._SbrEldBatch, "qmf_handed_on"), ("xaac_sbr_eld_state", _eld_state(), "harm_flags_prev")]
     body = "".join('printf("%%zu %%zu\\n", sizeof(%s), offsetof(%s, %s));' % (c, c, last) for c, _, last in pairs)
     src = tmp_path / "layout.c"

@@ -23,7 +23,7 @@ def ctx():
     c.close()
 
 
-def gpu_run(ctx, headers, frames, states, ps_frames, ps_states, pcm_in):
+def gpu_run(ctx, headers, frames, states, ps_frames, ps_states, pcm_in, max_band_hint=0):
     import torch
     n = len(states)
     t = lambda objs: torch.from_numpy(np.frombuffer(b"".join(bytes(o) for o in objs), np.uint8).reshape(n, -1).copy()).cuda()
@@ -34,7 +34,7 @@ def gpu_run(ctx, headers, frames, states, ps_frames, ps_states, pcm_in):
     status = torch.full((n,), 7, dtype=torch.int32, device="cuda")
     ws = torch.zeros(ctx.sbr_hq_workspace_bytes(n, with_ps), dtype=torch.uint8, device="cuda")
     ctx.sbr_hq_process_batch(torch.from_numpy(np.ascontiguousarray(pcm_in)).cuda(), t_h, t_f, t_s, out, ws, t_pf, t_ps,
-                             status)
+                             status, max_band_hint=max_band_hint)
     torch.cuda.synchronize()
     return out.cpu().numpy(), t_s.cpu().numpy(), (t_ps.cpu().numpy() if with_ps else None), status.cpu().numpy()
 
@@ -239,6 +239,37 @@ def test_streams_outside_the_narrow_rows_take_the_list_kernel(ctx, oracle):
             gp = cap.PsState.from_buffer_copy(ps_bytes[i].tobytes())
             assert not cap.diff_state(gs, states[i]), (step, i, cap.diff_state(gs, states[i])[:3])
             assert not cap.diff_state(gp, pstates[i]), (step, i, cap.diff_state(gp, pstates[i])[:3])
+
+
+def test_max_band_hint_leaves_the_list_launch_out_and_refuses_what_it_does_not_cover(ctx):
+    """xaac_sbr_hq_batch.max_band_hint = 48: the caller's knowledge that no stream reaches above band 48.  The reference records
+    (24 kHz cores) decode to the same words with and without it; a stream that does reach higher -- a synthesis bank limit at band
+    52 here, overlap content above band 48 there -- is refused with XAAC_FATAL_BAD_ARG instead of taking the 64-band pass, and the
+    streams beside it are untouched by that."""
+    recs = cap.read_records(GOLDEN)
+    n = len(recs)
+    pcm_in = np.concatenate([r["pcm_in"] for r in recs])
+    args = lambda states: ([r["header"] for r in recs], [r["frame"] for r in recs], states, [r["ps_frame"] for r in recs],
+                           [r["ps0"] for r in recs], pcm_in)
+    plain = gpu_run(ctx, *args([r["st0"] for r in recs]))
+    hinted = gpu_run(ctx, *args([r["st0"] for r in recs]), max_band_hint=48)
+    assert not hinted[3].any() or np.array_equal(hinted[3], plain[3])
+    for a, b in zip(plain, hinted):
+        assert np.array_equal(a, b)
+    states = [cap.State.from_buffer_copy(bytes(r["st0"])) for r in recs]
+    states[1].syn_usb = 52
+    ov = np.frombuffer(states[4], dtype=np.int32, count=6 * 128, offset=cap.State.overlap.offset).reshape(6, 2, 64)
+    ov[:, :, 50:] = 77
+    wide = gpu_run(ctx, *args(states))                       # no hint: both streams go through the list launch
+    out, st, ps, status = gpu_run(ctx, *args(states), max_band_hint=48)
+    bad_arg = np.int32(np.uint32(0xFFFF8001))                # XAAC_FATAL_BAD_ARG
+    assert status[1] == status[4] == bad_arg and wide[3][1] == recs[1]["ret"]
+    for i in range(n):
+        if i in (1, 4):
+            continue
+        assert status[i] == recs[i]["ret"]
+        assert np.array_equal(out[4096 * i:4096 * (i + 1)], wide[0][4096 * i:4096 * (i + 1)]), i
+        assert np.array_equal(st[i], wide[1][i]) and np.array_equal(ps[i], wide[2][i]), i
 
 
 def test_fuzzed_envelope_grids_and_moving_band_limit_vs_oracle(ctx, oracle):
