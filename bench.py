@@ -771,7 +771,7 @@ KERNELS = {
     "c2": "xaac_imdct_ola_kernel",
     "c2l": "imdct_ola + limiter_front + limiter_gain + limiter_apply (4 launches)",
     "c3": "imdct_ola + qmf_analysis + sbr_core_lp + qmf_synthesis (4 launches)",
-    "c4": "imdct_ola + qmf_analysis_hq + sbr_core_hq (narrow rows; + its list launch) + ps + qmf_synthesis_pair (6 launches)",
+    "c4": "imdct_ola + qmf_analysis_hq + sbr_core_hq (narrow rows; max_band_hint 48: no list launch) + ps + qmf_synthesis_pair (5 launches)",
 }
 
 
@@ -1100,7 +1100,7 @@ def main():
     secondary = None
     if world == 1 and not args.no_secondary and w == "c4":
         secondary = {}
-        try:   # what a caller with smaller batches gets: the same six launches per step on the first k streams
+        try:   # what a caller with smaller batches gets: the same launches per step on the first k streams
             sweep = {}
             for k in (256, 1024, 4096):
                 ws_k = [job._workspace(k) for _ in job.lanes]
@@ -1120,7 +1120,7 @@ def main():
                 barrier()
                 dt = (time.perf_counter() - t0) / 40
                 sweep[str(k)] = {"ms_per_step": round(dt * 1e3, 4), "frames_per_s": round(k / dt, 1)}
-            sweep["note"] = ("C4 chain on the first k streams of the batches (six launches per step, no HIP graph), steps dealt out "
+            sweep["note"] = ("C4 chain on the first k streams of the batches (five launches per step, no HIP graph), steps dealt out "
                              "over the run's %d HIP streams like the headline's: one stream-frame takes about 0.11 ms through the "
                              "six kernels whatever the batch (one wave per stream in the two long ones), so below a few thousand "
                              "streams a step is that latency and most of the chip idles unless independent batches overlap"

@@ -58,7 +58,7 @@ __device__ __forceinline__ void xe_copy_words(int32_t *dst, const int32_t *src, 
 /* USF4: 4:1 SBR (USAC channels without a transposer): 64 slots, four to an envelope time slot; the low-band matrix is the
    80-row scratch the 16-channel analysis bank wrote rows 8..71 of, not the channel's 40-row state */
 template <bool HARM, bool PVC = false, bool USF4 = false>
-__global__ __launch_bounds__(64, 3) void xaac_esbr_core_kernel(XaacEsbrCoreParams p) { /* 168 VGPRs: 12 waves per CU (measured best of 8 / 12 / 16) */
+__global__ __launch_bounds__(64, USF4 ? 2 : 3) void xaac_esbr_core_kernel(XaacEsbrCoreParams p) { /* (4:1: the 14-row histories in flight take the registers of a two-wave budget) */ /* 168 VGPRs: 12 waves per CU (measured best of 8 / 12 / 16) */
 #ifdef XE_PROFILE
   if (threadIdx.x == 0) {
     for (int i = 0; i < 16; i++) xe_prof_acc[i] = 0;

@@ -110,3 +110,66 @@ def test_gpu_walks_the_reference_chains(ratio):
             assert state_crc(stn[j], CH["header"][r], CH["frame"][r], CH["apply"][r], ratio) == want[2], ("state", chains[act[j]], s)
             assert crc(pvn[j]) == want[5], ("pvc state", chains[act[j]], s)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_on_fuzzed_grids_equals_the_oracle(oracle):
+    """the first six frames of every chain with every second frame's envelope grid fuzzed (anything in 0..19: unsorted, empty,
+    running past the frame's end) and the band limit moving -- side info no parser makes, which the boundary has to contain -- at
+    8:3 and at 4:1 (where a border is four QMF rows and the matrices are the 80- / 82-row scratch): the GPU chain against the oracle
+    frame by frame: return codes, output words, state checksums.  (tests/test_sbr_core_sanitized.py runs the same under ASan.)"""
+    import torch
+    import libxaac_amd
+    import sbr_capture as cap
+    from test_env_pairs_cpu import _fuzz_frame
+    fn = oracle.lib.xo_esbr_sbr_frame_ratio
+    fn.restype = ctypes.c_int
+    fn.argtypes = [PF, ctypes.c_int] + [ctypes.c_void_p] * 6 + [PF, PF, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    ctx = libxaac_amd.XaacContext(0, 0)
+    dev = torch.device("cuda:0")
+    order = steps_of_chains(CH)
+    rng = np.random.default_rng(int(os.environ.get("XAAC_FUZZ_SEED", "4")))
+    taken = refused = 0
+    for ratio in (RATIO_8_3, RATIO_4_1):
+        chains = [c for c in range(len(order)) if int(CH["chain_ratio"][c]) == ratio and len(order[c]) >= 6]
+        n, width = len(chains), 4096 if ratio == RATIO_4_1 else 2048
+        st = [CH["est0"][c].copy() for c in chains]
+        pv = [CH["pvst0"][c].copy() for c in chains]
+        for s in range(6):
+            hdr, frm, side, pvs, cores = [], [], [], [], []
+            for i, c in enumerate(chains):
+                r = order[c][s]
+                h, f = np.ascontiguousarray(CH["header"][r]).copy(), np.ascontiguousarray(CH["frame"][r]).copy()
+                hh, ff = cap.Header.from_buffer(h), cap.Frame.from_buffer(f)
+                if s % 2 == 1:
+                    _fuzz_frame(rng, hh, ff, (c + s) % 3)
+                if s % 4 == 3:
+                    ff.max_qmf_subband_aac = int(np.clip(ff.max_qmf_subband_aac + rng.integers(-6, 7), hh.sub_band_start, 32))
+                hdr.append(h); frm.append(f)
+                side.append(np.ascontiguousarray(CH["side"][r])); pvs.append(np.ascontiguousarray(CH["pvc_side"][r]))
+                cores.append(np.ascontiguousarray(chain_core(int(CH["chain_run"][c]), int(CH["chain_id"][c]), s)))
+            up = lambda rows: torch.from_numpy(np.stack(rows)).to(dev)
+            t_st, t_pv = up(st), up(pv)
+            out = torch.zeros((n, width), dtype=torch.float32, device=dev)
+            status = torch.full((n,), 7, dtype=torch.int32, device=dev)
+            ws = torch.zeros(ctx.esbr_workspace_bytes(n, ratio), dtype=torch.uint8, device=dev)
+            ctx.esbr_sbr_process_batch(up(cores), up(hdr), up(frm), up(side), t_st, out, ws, status, pvc_side=up(pvs), pvc_state=t_pv,
+                                       sbr_ratio=ratio)
+            ctx.sync()
+            g_rc, g_out, g_st, g_pv = status.cpu().numpy(), out.cpu().numpy(), t_st.cpu().numpy(), t_pv.cpu().numpy()
+            for i, c in enumerate(chains):
+                o = np.zeros(width, np.float32)
+                rc = fn(cores[i].ctypes.data_as(PF), ratio, vp(hdr[i]), vp(frm[i]), vp(side[i]), vp(st[i]), None, None,
+                        o.ctypes.data_as(PF), None, None, vp(pvs[i]), vp(pv[i]))
+                assert g_rc[i] == rc, ("rc", c, s, int(g_rc[i]), rc)
+                if rc != 0:        # a refused frame: the chain goes on from the device's states
+                    st[i], pv[i] = g_st[i].copy(), g_pv[i].copy()
+                    refused += 1
+                    continue
+                taken += 1
+                apply = cap.Frame.from_buffer_copy(frm[i].tobytes()).apply_processing
+                assert np.array_equal(g_out[i].view(np.uint32), o.view(np.uint32)), ("out", c, s, ratio)
+                assert state_crc(g_st[i], hdr[i], frm[i], apply, ratio) == state_crc(st[i], hdr[i], frm[i], apply, ratio), ("state", c, s, ratio)
+                assert crc(g_pv[i]) == crc(pv[i]), ("pvc state", c, s, ratio)
+    ctx.close()
+    assert taken > 150 and refused < taken

@@ -116,3 +116,48 @@ def test_path_a_chain_on_fuzzed_grids_touches_nothing_outside_its_matrices(asan_
     out = run_child(asan_oracle, CHILD_ESBR)
     n, r = (int(t) for t in out.split()[1::2])
     assert n > 250 and r < n // 2
+
+
+CHILD_RATIO = r'''
+import ctypes, sys
+import numpy as np
+sys.path.insert(0, %(tests)r); sys.path.insert(0, %(tools)r)
+import sbr_capture as cap
+from test_env_pairs_cpu import _fuzz_frame
+from make_golden_esbr_chains import chain_core
+PF = ctypes.POINTER(ctypes.c_float)
+CH = np.load(%(golden)r + "/esbr_ratio_chains.npz")
+lib = ctypes.CDLL(%(lib)r)
+fn = lib.xo_esbr_sbr_frame_ratio
+fn.restype = ctypes.c_int
+fn.argtypes = [PF, ctypes.c_int] + [ctypes.c_void_p] * 6 + [PF, PF, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+sc = CH["step_chain"]
+rng = np.random.default_rng(3)
+calls = refused = 0
+for c in range(len(CH["chain_len"])):
+    rows = np.nonzero(sc == c)[0]
+    run, cid, ratio = int(CH["chain_run"][c]), int(CH["chain_id"][c]), int(CH["chain_ratio"][c])
+    st, pv = CH["est0"][c].copy(), CH["pvst0"][c].copy()
+    for s, r in enumerate(rows[:6]):
+        core = np.ascontiguousarray(chain_core(run, cid, s))
+        out = np.zeros(4096, np.float32)
+        h, f, sd, ps = (np.ascontiguousarray(CH[k][r]).copy() for k in ("header", "frame", "side", "pvc_side"))
+        hh, ff = cap.Header.from_buffer(h), cap.Frame.from_buffer(f)
+        if s %% 2 == 1:
+            _fuzz_frame(rng, hh, ff, (c + s) %% 3)
+        if s %% 4 == 3:
+            ff.max_qmf_subband_aac = int(np.clip(ff.max_qmf_subband_aac + rng.integers(-6, 7), hh.sub_band_start, 32))
+        rc = fn(core.ctypes.data_as(PF), ratio, vp(h), vp(f), vp(sd), vp(st), None, None, out.ctypes.data_as(PF), None, None, vp(ps), vp(pv))
+        calls += 1
+        refused += rc != 0
+print("calls", calls, "refused", refused)
+'''
+
+
+def test_8_3_and_4_1_chains_on_fuzzed_grids_touch_nothing_outside_their_matrices(asan_oracle):
+    """the same at the other two SBR ratios (tests/golden/esbr_ratio_chains.npz): 4:1's rows are four to a border and its matrices
+    the 64-slot ones; PVC frames with the PVC decoder in the chain"""
+    out = run_child(asan_oracle, CHILD_RATIO)
+    n, r = (int(t) for t in out.split()[1::2])
+    assert n > 250 and r < n // 2

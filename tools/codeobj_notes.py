@@ -51,10 +51,10 @@ def main():
         shutil.rmtree(tmp)
     for k, n in zip(ks, demangle([k["name"] for k in ks])):
         k["name"] = n
-    print("# %s: code-object metadata (llvm-readelf --notes); waves/SIMD = min(8, 512 // alloc(vgpr + agpr), LDS limit)" % os.path.basename(lib))
+    print("# %s: code-object metadata (llvm-readelf --notes); waves/SIMD = min(8, 512 // alloc(vgpr: the unified count, agpr included), LDS limit)" % os.path.basename(lib))
     print("%-58s %5s %5s %5s %8s %8s %7s %7s %5s %11s" % ("kernel", "vgpr", "agpr", "sgpr", "lds_B", "scratch", "v_spill", "s_spill", "wg", "waves/SIMD"))
     for k in sorted(ks, key=lambda k: k["name"]):
-        regs = k["vgpr"] + k["agpr"]
+        regs = k["vgpr"]  # gfx90a and later: .vgpr_count is the unified total, the AccVGPRs (.agpr_count) included
         alloc = max(8, (regs + 7) // 8 * 8)
         by_regs = min(8, 512 // alloc)
         waves_wg = max(1, k["wg"] // 64)
