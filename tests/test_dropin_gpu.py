@@ -156,3 +156,38 @@ def test_usac_streams_esbr_through_the_gpu(aac, tmp_path):
         assert mh and int(mh.group(1)) > 20, log[-600:]
     a, b = open(ref_wav, "rb").read(), open(gpu_wav, "rb").read()
     assert len(a) > 100000 and a == b, (len(a), len(b), on_gpu, left)
+
+
+STREAMS_WIDE = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "streams_wide", "*.aac")))
+
+
+@pytest.mark.parametrize("aac", STREAMS_WIDE, ids=[os.path.basename(s) for s in STREAMS_WIDE])
+@pytest.mark.parametrize("flags", [("-esbr:0",), ()], ids=["esbr0", "default"])
+def test_wider_streams_through_the_same_seams(aac, flags, tmp_path):
+    """Streams wider than the scope table, made by the reference encoder (tools/make_golden_streams.py: streams_wide).
+    5.1 AAC-LC and HE-AAC: the reference's channel-element loop calls the same three seams once per channel / element, so every
+    IMDCT, every SBR call (fixed-point with -esbr:0, Path A with the default flags) and the limiter's six-channel calls run on
+    the GPU unchanged.  HE-AAC / HE-AACv2 with 960-line frames (the DAB+ profile): the 960-line IMDCT is the library's, the SBR
+    calls of 15 time slots (30 QMF slots) are left to the reference, counted as such.  Byte-identical output either way."""
+    if not (os.path.exists(os.path.join(REF, "xaacdec")) and os.path.exists(os.path.join(REF, "xaacdec_dropin"))):
+        pytest.fail("oracle/_ref/xaacdec[_dropin] missing: the reference binaries did not travel with the snapshot")
+    meta = aac[:-4] + ".txt"
+    extra = tuple(flags) + (("-mp4:1", "-imeta:" + meta) if os.path.exists(meta) else ())
+    ref_wav, gpu_wav = str(tmp_path / "ref.wav"), str(tmp_path / "gpu.wav")
+    _decode("xaacdec", aac, ref_wav, extra=extra)
+    log = _decode("xaacdec_dropin", aac, gpu_wav, extra=extra)
+    num = lambda pat: [int(v) for v in re.search(pat, log).groups()]
+    n_imdct, n_sbr = num(r"(\d+) imdct_process and (\d+) sbr_dec calls ran on the GPU")
+    n960, _ = num(r"(\d+) imdct_process calls of 960-line frames and (\d+) of AAC-LD")
+    n_lim, = num(r"(\d+) peak_limiter_process calls ran on the GPU")
+    n_esbr, = num(r"(\d+) sbr_dec calls took the eSBR \(Path A\) branch on the GPU")
+    _, n_left = num(r"(\d+) of them for USAC channels, (\d+) sbr_dec calls left to the reference")
+    name = os.path.basename(aac)
+    if name.startswith("mc6_aot2"):
+        assert n_imdct > 250 and n_lim > 40 and n_sbr == n_esbr == n_left == 0, log[-900:]
+    elif name.startswith("mc6_aot5"):        # three channel pair / single elements + LFE a frame: one SBR call per element
+        assert n_imdct > 140 and n_left == 0 and (n_sbr if flags else n_esbr) > 140, log[-900:]
+    else:                                    # 960-line HE-AAC: the transform on the GPU, the 15-time-slot SBR calls the reference's
+        assert n960 > 40 and n_imdct == n_sbr == n_esbr == 0 and (not flags or n_left > 40), log[-900:]
+    a, b = open(ref_wav, "rb").read(), open(gpu_wav, "rb").read()
+    assert len(a) > 100000 and a == b, (len(a), len(b))

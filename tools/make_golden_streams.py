@@ -91,6 +91,27 @@ def main():
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
         print(aac, os.path.getsize(aac))
 
+    # wider than the scope table (tests/golden/streams_wide; tests/test_dropin_gpu.py::test_wider_streams...): 5.1 streams -- the
+    # reference's channel-element loop calls the same seams once per channel / element, so the drop-in serves them unchanged -- and
+    # HE-AAC / HE-AACv2 with 960-line frames (the DAB+ profile: 30 QMF slots a frame; the 960-line IMDCT is the library's, the
+    # 15-time-slot SBR calls stay the reference's)
+    out_w = os.path.join(ROOT, "tests", "golden", "streams_wide")
+    os.makedirs(out_w, exist_ok=True)
+    n = x.shape[0]
+    six = np.stack([x[:, 0], x[:, 1], 0.5 * (x[:, 0] + x[:, 1]), 0.3 * np.roll(x[:, 0], 700), 0.6 * np.roll(x[:, 1], 311),
+                    0.6 * np.roll(x[:, 0], 1500) - 0.2 * x[:, 1]], 1)[: n * 5 // 8]
+    wav6 = "/tmp/xaac_golden_6ch.wav"
+    with wave.open(wav6, "wb") as w:
+        w.setnchannels(6), w.setsampwidth(2), w.setframerate(48000)
+        w.writeframes(np.clip(np.round(six * 32767.0), -32768, 32767).astype(np.int16).tobytes())
+    for name, wav, args in (("mc6_aot2", wav6, ["-aot:2", "-br:192000", "-adts:1"]), ("mc6_aot5", wav6, ["-aot:5", "-br:128000", "-adts:1"]),
+                            ("he960_aot5", "/tmp/xaac_golden_mix.wav", ["-aot:5", "-br:48000", "-framesize:960"]),
+                            ("he960_aot29", "/tmp/xaac_golden_mix.wav", ["-aot:29", "-br:32000", "-framesize:960"])):
+        aac = os.path.join(out_w, name + ".aac")
+        subprocess.run([os.path.join(REF, "xaacenc"), "-ifile:" + wav, "-ofile:" + aac] + args, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, check=True)
+        print(aac, os.path.getsize(aac))
+
 
 if __name__ == "__main__":
     main()
