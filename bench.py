@@ -433,6 +433,126 @@ def end_to_end_in_its_own_process():
     raise RuntimeError("end-to-end subprocess: rc %d, %s" % (p.returncode, p.stderr[-300:]))
 
 
+def secondary_round6(torch, libxaac_amd, ctx, dev, steps=20, n=8192):
+    """The rows built in round 6, each on the step's own clock (one HIP stream, wall time over back-to-back steps): USAC channels
+    at 8:3 and 4:1 SBR through xaac_esbr_sbr_process_batch (sbr_ratio), AAC-ELD's low-delay SBR call through
+    xaac_sbr_eld_process_batch, the USAC FD frame with its forward-aliasing-cancellation signal made on the device (fac_in).
+    Side info, states and inputs are tiled from the committed reference-made chain fixtures (first step of every chain, the
+    fixtures' own input generators), so every set-up is one the reference decoder produced; the first step of every distinct
+    set-up is compared with the fixture's reference CRCs."""
+    import zlib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    crc = lambda a: zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xffffffff
+    out = {"n_channel_frames": n, "timing": "wall clock over %d back-to-back steps on one HIP stream (launch overhead included)" % steps}
+
+    def timed(step):
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    def entry(ms, alg, ok, refused, what):
+        return {"ms_per_step": round(ms, 4), "channel_frames_per_s": round(n / ms * 1e3, 1), "alg_bytes_per_step": int(alg),
+                "roofline_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "first_step_equals_reference_crc": ok,
+                "refused_frac": refused, "workload": what}
+
+    # -- USAC channels at 8:3 / 4:1 SBR (tests/golden/esbr_ratio_chains.npz) ------------------------------------------------
+    try:
+        from make_golden_esbr_chains import chain_core
+        CH = np.load(os.path.join(ROOT, "tests", "golden", "esbr_ratio_chains.npz"))
+        first = [np.nonzero(CH["step_chain"] == c)[0][0] for c in range(len(CH["chain_len"]))]
+        for ratio, name in ((1, "usac_esbr_8_3"), (2, "usac_esbr_4_1")):
+            cs = [c for c in range(len(first)) if int(CH["chain_ratio"][c]) == ratio]
+            rows = [first[c] for c in cs]
+            tile = lambda a: torch.from_numpy(np.ascontiguousarray(np.stack([a[i % len(a)] for i in range(n)]))).to(dev)
+            hd, fr, sd, pvs = (tile(CH[k][rows]) for k in ("header", "frame", "side", "pvc_side"))
+            st, pv = tile(CH["est0"][cs]), tile(CH["pvst0"][cs])
+            core = tile(np.stack([chain_core(int(CH["chain_run"][c]), int(CH["chain_id"][c]), 0) for c in cs]))
+            width = 4096 if ratio == 2 else 2048
+            o = torch.zeros((n, width), dtype=torch.float32, device=dev)
+            status = torch.zeros(n, dtype=torch.int32, device=dev)
+            ws = torch.zeros(ctx.esbr_workspace_bytes(n, ratio), dtype=torch.uint8, device=dev)
+            step = lambda: ctx.esbr_sbr_process_batch(core, hd, fr, sd, st, o, ws, status, pvc_side=pvs, pvc_state=pv, sbr_ratio=ratio)
+            step()
+            torch.cuda.synchronize()
+            og = o[:len(cs)].cpu().numpy()
+            ok = bool(all(crc(og[j]) == int(CH["crc"][rows[j]][0]) for j in range(len(cs))))
+            ms = timed(step)
+            refused = float(status.cpu().numpy().astype(bool).mean())
+            alg = n * (4 * (768 if ratio == 1 else 1024) + 4 * width + 2 * st.shape[1] + 2 * pv.shape[1] + hd.shape[1] + fr.shape[1]
+                       + sd.shape[1] + pvs.shape[1])
+            out[name] = entry(ms, alg, ok, refused, "%d USAC channel-frames a step, %s: %d-channel analysis bank -> float HF generator / "
+                              "envelope adjuster (PVC frames: the PVC decoder inside) -> 64-band synthesis bank%s; %d distinct "
+                              "reference-made set-ups tiled" % (n, "8:3 SBR, 768-sample core frames" if ratio == 1 else "4:1 SBR, 64 QMF slots",
+                                                                24 if ratio == 1 else 16, " in two runs" if ratio == 2 else "", len(cs)))
+    except Exception as e:
+        out["usac_esbr_ratios"] = "unavailable: %r" % (e,)
+    # -- AAC-ELD low-delay SBR (tests/golden/sbr_eld_chains.npz) ----------------------------------------------------------------
+    try:
+        from make_golden_sbr_chains import chain_pcm
+        CE = np.load(os.path.join(ROOT, "tests", "golden", "sbr_eld_chains.npz"))
+        cs = [c for c in range(len(CE["n_slots"])) if int(CE["n_slots"][c]) == 16]
+        rows = [np.nonzero(CE["step_chain"] == c)[0][0] for c in cs]
+        tile = lambda a: torch.from_numpy(np.ascontiguousarray(np.stack([a[i % len(a)] for i in range(n)]))).to(dev)
+        hd, fr, st = tile(CE["header"][rows]), tile(CE["frame"][rows]), tile(CE["st0"][cs])
+        pin = tile(np.stack([chain_pcm(3, c, 0)[:512] for c in cs])).reshape(-1)
+        o = torch.zeros(n * 1024, dtype=torch.int16, device=dev)
+        status = torch.zeros(n, dtype=torch.int32, device=dev)
+        ws = torch.zeros(ctx.sbr_eld_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        step = lambda: ctx.sbr_eld_process_batch(pin, hd, fr, st, o, ws, 16, status=status)
+        step()
+        torch.cuda.synchronize()
+        og = o.view(n, 1024)[:len(cs)].cpu().numpy()
+        ok = bool(all(crc(og[j]) == int(CE["crc"][rows[j]][0]) for j in range(len(cs))))
+        ms = timed(step)
+        alg = n * (2 * 512 + 2 * 1024 + 2 * st.shape[1] + hd.shape[1] + fr.shape[1])
+        out["aac_eld_sbr_512"] = entry(ms, alg, ok, float(status.cpu().numpy().astype(bool).mean()),
+                                       "%d AAC-ELD channel-frames a step (512-sample core frames, 16 QMF slots): LD complex analysis bank -> "
+                                       "fixed-point LD-SBR core -> LD complex synthesis bank (3 launches); %d distinct reference-made "
+                                       "set-ups tiled" % (n, len(cs)))
+    except Exception as e:
+        out["aac_eld_sbr_512"] = "unavailable: %r" % (e,)
+    # -- USAC FD frames behind an LPD frame, every one with FAC data: the signal made on the device ----------------------------------
+    try:
+        rng = np.random.default_rng(11)
+        ccfl = 1024
+        fin = np.zeros((n, libxaac_amd.USAC_FAC_IN_WORDS), np.int32)
+        fin[:, 0] = rng.integers(0, 120, n)
+        fin[:, 1:129] = rng.integers(-40, 41, (n, 128)) * (rng.integers(0, 4, (n, 128)) == 0)
+        lpc = np.zeros((n, 17), np.float32)
+        lpc[:, 0] = 1.0
+        lpc[:, 1:] = (rng.standard_normal((n, 16)) * 0.4 * 0.8 ** np.arange(16)).astype(np.float32)
+        fin[:, 129:146] = lpc.view(np.int32)
+        fin[:, 146:] = (rng.standard_normal((n, 256)) * 100.0).astype(np.float32).view(np.int32)
+        coef = torch.from_numpy(rng.integers(-(1 << 20), 1 << 20, (n, ccfl)).astype(np.int32)).to(dev)
+        ics = torch.zeros((n, 2), dtype=torch.uint8, device=dev)
+        ics[:, 0] = torch.from_numpy(np.array([3, 2, 4, 3], np.uint8)[np.arange(n) % 4]).to(dev)   # LONG_STOP, EIGHT_SHORT, STOP_START
+        ov = torch.zeros((n, ccfl), dtype=torch.int32, device=dev)
+        sp = torch.zeros(n, dtype=torch.uint8, device=dev)
+        o32 = torch.zeros((n, ccfl), dtype=torch.int32, device=dev)
+        status = torch.zeros(n, dtype=torch.int32, device=dev)
+        work = torch.zeros((n, 257), dtype=torch.int32, device=dev)
+        t_fin = torch.from_numpy(fin).to(dev)
+        res = {}
+        for label, flags_v, kw in (("fd_behind_lpd", 1, {}), ("fd_behind_lpd_with_fac_on_device", 3, {"fac_in": t_fin, "fac_work": work})):
+            flags = torch.full((n,), flags_v, dtype=torch.uint8, device=dev)
+            step = lambda: ctx.usac_imdct_process_batch(coef, ics, ov, sp, o32, None, status, ccfl=ccfl, lpd_flags=flags, **kw)
+            res[label] = round(timed(step), 4)
+            res[label + "_refused_frac"] = float(status.cpu().numpy().astype(bool).mean())
+        res["workload"] = ("%d USAC FD channel-frames a step, every one behind an LPD frame; second figure: every one with FAC data and "
+                           "ixheaacd_cal_fac_data on the device (xaac_usac_fac_kernel, one wave per frame) in front of the transform -- in a "
+                           "stream a frame in hundreds is such a frame" % n)
+        out["usac_fd_fac_ms_per_step"] = res
+    except Exception as e:
+        out["usac_fd_fac_ms_per_step"] = "unavailable: %r" % (e,)
+    return out
+
+
 def secondary_esbr(torch, libxaac_amd, ctx, dev, steps, warmup, hip_streams=2):
     """The same HE-AACv2 streams through the reference's DEFAULT SBR path (-esbr:1, "Path A": 32-bit-ring QMF banks, float
     LPP transposer / envelope adjuster / parametric stereo; docs/NOTEBOOK.md 5f): xaac_esbr_sbr_process_batch on float core
@@ -1156,6 +1276,11 @@ def main():
             secondary["f4_transforms"] = secondary_f4(torch, libxaac_amd, ctx, dev, hip_streams=args.hip_streams)
         except Exception as e:
             secondary["f4_transforms"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+        try:
+            secondary["round6_rows"] = secondary_round6(torch, libxaac_amd, ctx, dev)
+        except Exception as e:
+            secondary["round6_rows"] = {"error": repr(e)}
         torch.cuda.empty_cache()
         try:
             secondary["end_to_end"] = end_to_end_in_its_own_process()

@@ -401,7 +401,7 @@ typedef struct xaac_esbr_ana_batch {
 typedef struct xaac_esbr_ana_nb_batch {
   int32_t n_ch;
   int32_t n_bands;             /* 24 | 16 */
-  int32_t n_slots;             /* <= 64, n_bands * n_slots <= 1024 */
+  int32_t n_slots;             /* <= 32 with 24 bands, <= 64 with 16 (n_bands * n_slots <= 1024) */
   int32_t core_stride;         /* floats between consecutive channels' core rows (>= n_bands * n_slots) */
   const float *core;           /* [n_ch][core_stride] */
   xaac_esbr_ana_state *state;  /* [n_ch] in/out */

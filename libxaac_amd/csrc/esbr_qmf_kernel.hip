@@ -154,77 +154,137 @@ __global__ __launch_bounds__(64) void xaac_esbr_analysis_kernel(XaacEsbrAnaParam
   }
 }
 
-/* The 24- and 16-channel banks of 8:3 and 4:1 SBR (sbr_dec.c:213-236): one wave per channel-frame, lane = time slot (32 of 24
-   samples, 64 of 16).  Nothing here is closed-form: a lane forms its slot exactly as the reference's loop does at that slot --
-   the ring as it stands then (the newest write of this frame to a block, or the word the state holds), the window pointers
-   after that many steps -- so any state the reference can hand over gives the reference's result.  These banks are not on
-   the headline path (HE-AAC is 2:1); the kernel is written for exactness and a short critical path, not tuned. */
+/* The 24- and 16-channel banks of 8:3 and 4:1 SBR (sbr_dec.c:213-236): lane = time slot -- 64 slots of 16 samples fill a wave,
+   32 slots of 24 samples half of one, so a wave takes two 24-channel channel-frames.  Nothing here is closed-form: a lane forms
+   its slot exactly as the reference's loop does at that slot -- the ring as it stands then (per block of NB words: the newest
+   write of this frame to it, or the words the state holds), the window pointers after that many steps -- so any state the
+   reference can hand over gives the reference's result.  The ring is ten blocks, a slot's window-add reads five of them per
+   half: where a block's words come from is worked out once per block, not per tap. */
 namespace {
 template <int NB>
 struct XeRingAt {        /* anal_filter_states_32 at slot s of this frame */
   const int32_t *old_ring; /* LDS: the state's ring */
-  const int32_t *frame;    /* LDS: (WORD32)(core * 2^15), time order */
-  int pb, s;               /* block the frame's first slot writes; this lane's slot */
-  __device__ __forceinline__ int32_t operator()(int pos) const {
-    const int b = pos / NB, r = pos - b * NB;
+  const int32_t *frame;    /* LDS: (WORD32)(core * 2^15), slot k's NB samples at k (NB + 1): lanes are slots, and rows NB words
+                              apart would put all of a wave's reads of one tap on two (NB 16) or four (NB 24) of the 32 banks */
+  int pb, s;               /* block the frame's first slot writes; the slot */
+  /* block b at slot s: its word r is base[dir * r] */
+  __device__ __forceinline__ void block(int b, const int32_t *&base, int &dir) const {
     int k0 = pb - b;
     k0 += k0 < 0 ? 10 : 0;                              /* first slot of the frame that writes block b; then every tenth */
-    if (k0 > s) return old_ring[pos];
-    const int k = k0 + 10 * ((s - k0) / 10);
-    return frame[k * NB + NB - 1 - r];                  /* sbr_dec.c:247-250: the block holds the slot's samples reversed */
+    if (k0 > s) {
+      base = old_ring + b * NB;
+      dir = 1;
+    } else {
+      const int k = k0 + 10 * ((s - k0) / 10);
+      base = frame + k * (NB + 1) + NB - 1;             /* sbr_dec.c:247-250: the block holds the slot's samples reversed */
+      dir = -1;
+    }
+  }
+  __device__ __forceinline__ int32_t operator()(int pos) const {
+    const int b = pos / NB;
+    const int32_t *base;
+    int dir;
+    block(b, base, dir);
+    return base[dir * (pos - b * NB)];
   }
 };
 }  // namespace
 
 template <int NB>
 __global__ __launch_bounds__(64) void xaac_esbr_analysis_nb_kernel(XaacEsbrAnaNbParams p) {
-  constexpr int RS = 65;
-  __shared__ int32_t old_ring[10 * NB];
-  __shared__ int32_t frame[1024];
+  constexpr int RS = 2 * NB + 1, CPW = NB == 24 ? 2 : 1, SL = 64 / CPW; /* tile row: NB real | NB imaginary words (+ 1: no bank conflicts); channel-frames a wave takes, lanes (slots) of each */
+  __shared__ int32_t old_ring[CPW][10 * NB];
+  __shared__ int32_t frame[CPW][(1024 / NB) * (NB + 1)];
   __shared__ int32_t tile[64 * RS];
-  const int lane = threadIdx.x, ch = blockIdx.x, n_slots = p.n_slots;
-  xaac_esbr_ana_state *st = reinterpret_cast<xaac_esbr_ana_state *>(reinterpret_cast<char *>(p.state) + (size_t)ch * p.state_stride);
-  const float *src = p.core + (size_t)ch * p.core_stride;
-  int pos0 = st->pos, win0 = st->win_off;
-  for (int i = lane; i < 10 * NB; i += 64) old_ring[i] = st->ring[i];
-  for (int i = lane; i < NB * n_slots; i += 64) frame[i] = fx_f2i_trunc(src[i] * 32768.0f); /* sbr_dec.c:248 */
-  pos0 = __builtin_amdgcn_readfirstlane(pos0);
-  win0 = __builtin_amdgcn_readfirstlane(win0);
-  /* states no run of the reference produces (a position off the block grid, a window offset off its step) are brought onto
-     the grid instead of being followed out of the arrays */
-  int pb = pos0 / NB;
-  pb = pb < 0 ? 0 : (pb > 9 ? 9 : pb);
+  /* the window: a lane's offsets into it depend on its slot.  With 64 slots a wave the reads go through LDS (169 -> 98 us per 8192
+     channel-frames); with two channel-frames of 32 slots the vector cache serves them as well and the LDS is better spent on
+     occupancy (87 us against 94) */
+  constexpr int NWIN = NB == 24 ? 1 : 1280;
+  __shared__ int32_t win_lds[NWIN];
+  const int lane = threadIdx.x, n_slots = p.n_slots;
+  if (NB != 24)
+    for (int i = lane; i < NWIN; i += 64) win_lds[i] = XqEsbrAna<NB>::win()[i];
+  const int lc = lane / SL, slot = lane % SL, my_ch = (int)blockIdx.x * CPW + lc;
   constexpr int fo = XqEsbrAna<NB>::fo;
-  win0 = win0 < 0 ? 0 : (win0 > 9 * fo ? 9 * fo : win0 / fo * fo);
+  int pb_c[CPW], win_c[CPW];
+#pragma unroll
+  for (int c = 0; c < CPW; c++) {
+    const int ch = (int)blockIdx.x * CPW + c;
+    pb_c[c] = win_c[c] = 0;
+    if (ch >= p.n_ch) continue; /* (uniform) */
+    const xaac_esbr_ana_state *st = reinterpret_cast<const xaac_esbr_ana_state *>(reinterpret_cast<const char *>(p.state) + (size_t)ch * p.state_stride);
+    const float *src = p.core + (size_t)ch * p.core_stride;
+    int pos0 = st->pos, win0 = st->win_off;
+    for (int i = lane; i < 10 * NB; i += 64) old_ring[c][i] = st->ring[i];
+    for (int i = lane; i < NB * n_slots; i += 64) frame[c][i + i / NB] = fx_f2i_trunc(src[i] * 32768.0f); /* sbr_dec.c:248 */
+    pos0 = __builtin_amdgcn_readfirstlane(pos0);
+    win0 = __builtin_amdgcn_readfirstlane(win0);
+    /* states no run of the reference produces (a position off the block grid, a window offset off its step) are brought onto
+       the grid instead of being followed out of the arrays */
+    int pb = pos0 / NB;
+    pb_c[c] = pb < 0 ? 0 : (pb > 9 ? 9 : pb);
+    win_c[c] = win0 < 0 ? 0 : (win0 > 9 * fo ? 9 * fo : win0 / fo * fo);
+  }
   __syncthreads();
-  if (lane < n_slots) {
+  const int pb = CPW == 2 && lc ? pb_c[CPW - 1] : pb_c[0], win0 = CPW == 2 && lc ? win_c[CPW - 1] : win_c[0];
+  if (slot < n_slots && my_ch < p.n_ch) {
     int w1 = win0, w2 = win0 + fo;
-    for (int k = 0; k < lane; k++) xq_esbr_win_step<NB>(w1, w2);
-    const XeRingAt<NB> rg = {old_ring, frame, pb, lane};
+    for (int k = 0; k < slot; k++) xq_esbr_win_step<NB>(w1, w2);
+    const XeRingAt<NB> rg = {old_ring[lc], frame[lc], pb, slot};
+    const int32_t *bp[10];
+    int bd[10];
+#pragma unroll
+    for (int b = 0; b < 10; b++) rg.block(b, bp[b], bd[b]);
+    /* ixheaacd_esbr_qmfanal32_winadd (qmf_dec.c:537): the first NB outputs from the ring at offset f1 with the window at w1, the
+       second NB at f2 / w2; f1 is 0 in even slots and NB in odd ones (sbr_dec.c:262-265): blocks 2 j + odd | 2 j + 1 - odd */
+    const int odd = slot & 1;
+    const int32_t *cw = NB == 24 ? XqEsbrAna<NB>::win() : win_lds;
+    constexpr int cs = XqEsbrAna<NB>::cs;
     int32_t anal[2 * NB], sb[128], t[128];
-    xq_esbr_winadd_nb<NB>(rg, (lane & 1) ? NB : 0, (lane & 1) ? 0 : NB, w1, w2, anal);
+#pragma unroll
+    for (int n = 0; n < NB; n++) {
+      int64_t a1 = 0, a2 = 0;
+#pragma unroll
+      for (int j = 0; j < 5; j++) {
+        const int32_t *p1 = odd ? bp[2 * j + 1] : bp[2 * j], *p2 = odd ? bp[2 * j] : bp[2 * j + 1];
+        const int d1 = odd ? bd[2 * j + 1] : bd[2 * j], d2 = odd ? bd[2 * j] : bd[2 * j + 1];
+        a1 = xq_add64(a1, (int64_t)p1[d1 * n] * cw[w1 + cs * (n + 2 * NB * j)]);
+        a2 = xq_add64(a2, (int64_t)p2[d2 * n] * cw[w2 + cs * (n + 2 * NB * j)]);
+      }
+      anal[n] = (int32_t)(a1 >> 31);
+      anal[NB + n] = (int32_t)(a2 >> 31);
+    }
     xq_esbr_fwd_modulation_nb<NB>(anal, sb, t);
 #pragma unroll
     for (int k = 0; k < NB; k++) {
       tile[RS * lane + k] = sb[k];
-      tile[RS * lane + 32 + k] = sb[64 + k];
+      tile[RS * lane + NB + k] = sb[64 + k];
     }
   }
   __syncthreads();
   { /* rows out: lanes 0..31 the real bands, 32..63 the imaginary ones; bands NB..31 are never written by the reference and are
        zero in its buffers: written as zeros here, for the kernels behind that read 32 bands of a row */
     const float gain = XqEsbrAna<NB>::gain();
-    float *dst = (lane < 32 ? p.qmf_re : p.qmf_im) + (size_t)ch * p.out_stride;
     const int k = lane & 31;
-    for (int r = 0; r < n_slots; r++) dst[64 * r + k] = k < NB ? (float)tile[RS * r + lane] * gain : 0.0f;
+#pragma unroll
+    for (int c = 0; c < CPW; c++) {
+      const int ch = (int)blockIdx.x * CPW + c;
+      if (ch >= p.n_ch) continue;
+      float *dst = (lane < 32 ? p.qmf_re : p.qmf_im) + (size_t)ch * p.out_stride;
+      for (int r = 0; r < n_slots; r++) dst[64 * r + k] = k < NB ? (float)tile[RS * (c * SL + r) + (lane < 32 ? k : NB + k)] * gain : 0.0f;
+    }
   }
-  { /* the state as the reference leaves it: every block's newest write, the pointers after n_slots steps */
-    const XeRingAt<NB> rg = {old_ring, frame, pb, n_slots - 1};
-    for (int i = lane; i < 10 * NB; i += 64) st->ring[i] = n_slots > 0 ? rg(i) : old_ring[i];
+#pragma unroll
+  for (int c = 0; c < CPW; c++) { /* the state as the reference leaves it: every block's newest write, the pointers after n_slots steps */
+    const int ch = (int)blockIdx.x * CPW + c;
+    if (ch >= p.n_ch) continue;
+    xaac_esbr_ana_state *st = reinterpret_cast<xaac_esbr_ana_state *>(reinterpret_cast<char *>(p.state) + (size_t)ch * p.state_stride);
+    const XeRingAt<NB> rg = {old_ring[c], frame[c], pb_c[c], n_slots - 1};
+    for (int i = lane; i < 10 * NB; i += 64) st->ring[i] = n_slots > 0 ? rg(i) : old_ring[c][i];
     if (lane == 0) {
-      int w1 = win0, w2 = win0 + fo;
+      int w1 = win_c[c], w2 = win_c[c] + fo;
       for (int k = 0; k < n_slots; k++) xq_esbr_win_step<NB>(w1, w2);
-      int pn = (pb - n_slots) % 10;
+      int pn = (pb_c[c] - n_slots) % 10;
       pn += pn < 0 ? 10 : 0;
       st->pos = pn * NB;
       st->win_off = w1;
@@ -416,7 +476,7 @@ extern "C" hipError_t xaac_launch_esbr_analysis(const XaacEsbrAnaParams *p, hipS
 }
 
 extern "C" hipError_t xaac_launch_esbr_analysis_nb(const XaacEsbrAnaNbParams *p, hipStream_t stream) {
-  if (p->nb == 24) hipLaunchKernelGGL(xaac_esbr_analysis_nb_kernel<24>, dim3(p->n_ch), dim3(64), 0, stream, *p);
+  if (p->nb == 24) hipLaunchKernelGGL(xaac_esbr_analysis_nb_kernel<24>, dim3((p->n_ch + 1) / 2), dim3(64), 0, stream, *p); /* two channel-frames a wave */
   else hipLaunchKernelGGL(xaac_esbr_analysis_nb_kernel<16>, dim3(p->n_ch), dim3(64), 0, stream, *p);
   return hipGetLastError();
 }

@@ -490,7 +490,8 @@ int32_t xaac_esbr_qmf_analysis_batch(xaac_ctx *c, const xaac_esbr_ana_batch *b) 
 
 int32_t xaac_esbr_qmf_analysis_nb_batch(xaac_ctx *c, const xaac_esbr_ana_nb_batch *b) {
   if (!c || !b) return XAAC_FATAL_NULL_ARG;
-  if (b->n_ch < 0 || (b->n_bands != 24 && b->n_bands != 16) || b->n_slots < 0 || b->n_slots > 64 || b->n_bands * b->n_slots > 1024 ||
+  if (b->n_ch < 0 || (b->n_bands != 24 && b->n_bands != 16) || b->n_slots < 0 || b->n_slots > (b->n_bands == 24 ? 32 : 64) ||
+      b->n_bands * b->n_slots > 1024 ||
       b->core_stride < b->n_bands * b->n_slots)
     return XAAC_FATAL_BAD_ARG;
   if (b->n_ch == 0) return XAAC_OK;
