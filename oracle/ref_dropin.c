@@ -44,7 +44,7 @@ static struct {
   xaac_esbr_pvc_state *pvst;
 } g;
 static long g_eld_ana_calls, g_eld_syn_calls;
-static long g_usac_fac_dev;
+static long g_usac_fac_dev, g_sbr_ds_calls;
 static long g_imdct_calls, g_sbr_calls, g_lim_calls, g_esbr_calls, g_esbr_harm_calls, g_esbr_usac_calls, g_esbr_pvc_calls, g_esbr_83_calls, g_esbr_41_calls, g_sbr_ref_calls, g_usac_imdct_calls, g_usac_imdct_fac, g_usac_imdct_lpd, g_eld_sbr_calls, g_imdct960_calls, g_imdct_ld_calls;
 static struct { int32_t *overlap; int16_t *pcm; uint8_t *shape; } gl; /* AAC-LD / ELD: 3 x 512 overlap words, 512 samples, 2 bytes */
 
@@ -56,6 +56,7 @@ static void die(const char *what) {
 
 static void report(void) {
   fprintf(stderr, "xaacdec_dropin: %ld imdct_process and %ld sbr_dec calls ran on the GPU\n", g_imdct_calls, g_sbr_calls);
+  fprintf(stderr, "xaacdec_dropin: %ld of the sbr_dec calls with the down-sampled synthesis bank\n", g_sbr_ds_calls);
   fprintf(stderr, "xaacdec_dropin: %ld imdct_process calls of 960-line frames and %ld of AAC-LD / ELD frames ran on the GPU\n",
           g_imdct960_calls, g_imdct_ld_calls);
   fprintf(stderr, "xaacdec_dropin: %ld LD / ELD analysis-bank and %ld synthesis-bank calls ran on the GPU\n", g_eld_ana_calls, g_eld_syn_calls);
@@ -656,8 +657,12 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     return 0;
   }
   /* outside the paths this library covers (USAC / PS / HBE eSBR, LD/ELD, DRC inside the bank, MPS): the reference's own code */
+  /* the down-sampled synthesis bank (-dsample:1, or an output rate above 48 kHz: 32 channels, 1024 samples out; sbrdec_initfuncs.c:622)
+     is the library's too (down_sample in both descriptors) -- not together with PS, where the reference itself hands the right
+     bank half a slot (qmf_dec.c:1117-1119) */
+  const int ds = d->str_synthesis_qmf_bank.no_channels == 32;
   if (h->enh_sbr || aot == AOT_ER_AAC_ELD || aot == AOT_ER_AAC_LD || drc_on || ldmps || mps ||
-      h->num_time_slots * h->time_step != 32) {
+      h->num_time_slots * h->time_step != 32 || (ds && with_ps) || (!ds && d->str_synthesis_qmf_bank.no_channels != 64)) {
     if (!g_ctx && !g_sbr_ref_calls) atexit(report); /* (a stream none of whose calls reaches the library still gets its summary) */
     g_sbr_ref_calls++;
     rc = __real_ixheaacd_sbr_dec(d, time_data, h, f, p, ps, synth_r, sf_r, apply, low_pow, work, tabs, common, ch_fac,
@@ -679,6 +684,7 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     memset(&b, 0, sizeof(b));
     b.n_ch = 1;
     b.in_ch_fac = b.out_ch_fac = 1;
+    b.down_sample = ds;
     b.pcm_in = g.pcm_in;
     b.header = g.hdr;
     b.frame = g.frame;
@@ -693,6 +699,7 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     memset(&b, 0, sizeof(b));
     b.n_ch = 1;
     b.in_ch_fac = b.out_ch_fac = 1;
+    b.down_sample = ds;
     b.pcm_in = g.pcm_in;
     b.header = g.hdr;
     b.frame = g.frame;
@@ -725,9 +732,10 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
       if (ps_on) time_data[i * ch_fac + 1] = outp[2 * i + 1];
     }
   } else {
-    for (i = 0; i < 2048; i++) time_data[i * ch_fac] = outp[i];
+    for (i = 0; i < (ds ? 1024 : 2048); i++) time_data[i * ch_fac] = outp[i];
   }
   g_sbr_calls++;
+  if (ds) g_sbr_ds_calls++;
   return 0;
 }
 

@@ -64,6 +64,32 @@ def test_default_flags_he_aac_takes_the_esbr_path_on_the_gpu(aac, tmp_path):
     assert open(fix_wav, "rb").read() != a
 
 
+@pytest.mark.parametrize("aac", [s for s in STREAMS if "aot5_" in s or "aot29_" in s], ids=lambda s: os.path.basename(s))
+def test_down_sampled_sbr_through_the_gpu(aac, tmp_path):
+    """-dsample:1 -esbr:0: the 32-channel synthesis bank (1024 samples a frame out; sbrdec_initfuncs.c:622) behind the fixed-point SBR
+    chain -- xaac_sbr_lp / _hq_process_batch with down_sample -- byte-identical; HE-AACv2 streams, where the reference itself gives
+    the right bank half a slot with this flag (qmf_dec.c:1117), are left to it and counted so.  (A survey of decoder flags late in
+    round 6 found this combination decoded by the 64-channel bank in the drop-in: the hook had not looked at the bank's size.)"""
+    if not (os.path.exists(os.path.join(REF, "xaacdec")) and os.path.exists(os.path.join(REF, "xaacdec_dropin"))):
+        pytest.fail("oracle/_ref/xaacdec[_dropin] missing: the reference binaries did not travel with the snapshot")
+    ref_wav, gpu_wav = str(tmp_path / "ref.wav"), str(tmp_path / "gpu.wav")
+    extra = ("-esbr:0", "-dsample:1")
+    _decode("xaacdec", aac, ref_wav, extra=extra)
+    log = _decode("xaacdec_dropin", aac, gpu_wav, extra=extra)
+    n_sbr = int(re.search(r"and (\d+) sbr_dec calls ran on the GPU", log).group(1))
+    n_ds = int(re.search(r"(\d+) of the sbr_dec calls with the down-sampled synthesis bank", log).group(1))
+    n_left = int(re.search(r"(\d+) sbr_dec calls left to the reference", log).group(1))
+    if "aot29_" in aac:
+        assert n_sbr == 0 and n_left > 30, log[-600:]
+    else:
+        assert n_sbr == n_ds and n_ds > 30 and n_left == 0, log[-600:]
+    a, b = open(ref_wav, "rb").read(), open(gpu_wav, "rb").read()
+    assert len(a) > 50000 and a == b, (len(a), len(b))
+    full = str(tmp_path / "full.wav")
+    _decode("xaacdec", aac, full)
+    assert len(open(full, "rb").read()) > 1.8 * (len(a) - 44)      # half the samples of the plain decode
+
+
 def test_streams_present():
     assert len(STREAMS) >= 3
 
