@@ -760,4 +760,15 @@ FX_HD void xq_esbr_synth_slot(int32_t *s, int32_t *t, int32_t *b, int shift) {
   }
 }
 
+/* the same for the down-sampled bank (32 synthesis channels: -dsample / output rates above 48 kHz; sbr_dec.c:556-569, :605-628):
+   s[0..31] real, s[64..95] imaginary (clobbered) -> the slot's 64 WORD32 ring samples */
+FX_HD void xq_esbr_synth_slot_ds(int32_t *s, int32_t *t, int32_t *b, int shift) {
+  xq_cos_sin_mod<16, XqW32>(s, t);
+  XQ_UNROLL
+  for (int c = 0; c < 32; c++) {
+    b[c] = fx_shl_sat(fx_sub_sat(s[64 + c], s[c]), shift);
+    b[32 + c] = fx_shl_sat(fx_add_sat(s[64 + 31 - c], s[31 - c]), shift);
+  }
+}
+
 #endif /* XAAC_SBR_QMF_H */

@@ -23,6 +23,7 @@ extern "C" {
 void xo_esbr_analysis(const float *core, int32_t *ring, int32_t *pos, int32_t *win_off, float *re, float *im);
 void xo_esbr_analysis_nb(const float *core, int nb, int n_slots, int32_t *ring, int32_t *pos, int32_t *win_off, float *re, float *im);
 void xo_esbr_synthesis(const float *re, const float *im, int32_t *ring, int32_t *drc_off, int32_t *filt_off, float *out);
+void xo_esbr_synthesis_ds(const float *re, const float *im, int32_t *ring, int32_t *drc_off, int32_t *filt_off, float *out);
 
 /* the two float stages alone, on the reference's own buffers: qmf / out = qmf_buf_real.. / sbr_qmf_out_real.. as
    [rows][64] arrays starting at the reference's row 0 (the stages work from row SBR_HF_ADJ_OFFSET = 2) */
@@ -111,9 +112,9 @@ int xo_esbr_sbr_frame_pvc(const float *core, const xaac_sbr_header *h, const xaa
                           xaac_hbe_state *hst, const xaac_esbr_pvc_side *pvs, xaac_esbr_pvc_state *pvst) {
   return xo_esbr_sbr_frame_ratio(core, XAAC_ESBR_RATIO_2_1, h, f, sd, st, pf, pst, out, out_r, hst, pvs, pvst);
 }
-int xo_esbr_sbr_frame_ratio(const float *core, int ratio, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
-                            xaac_esbr_state *st, const xaac_ps_frame *pf, xaac_esbr_ps_state *pst, float *out, float *out_r,
-                            xaac_hbe_state *hst, const xaac_esbr_pvc_side *pvs, xaac_esbr_pvc_state *pvst) {
+static int esbr_frame(const float *core, int ratio, int ds, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
+                      xaac_esbr_state *st, const xaac_ps_frame *pf, xaac_esbr_ps_state *pst, float *out, float *out_r,
+                      xaac_hbe_state *hst, const xaac_esbr_pvc_side *pvs, xaac_esbr_pvc_state *pvst) {
   /* rows: 8 of history + (32 of codec_x_delay +) the frame's 32 or 64 + what a grid running past the frame's end reads (zeros) */
   constexpr int QROWS = 104, OROWS = 82; /* (104: the 40-row history is copied from row 64 on for 4:1) */
   static_assert(QROWS >= XAAC_ESBR_ROWS, "2:1 with codec_x_delay");
@@ -201,10 +202,11 @@ int xo_esbr_sbr_frame_ratio(const float *core, int ratio, const xaac_sbr_header 
       memcpy(xim, rim, sizeof(xim));
       if (bad && f->apply_processing) rc = -1;
     }
-    xo_esbr_synthesis(&xre[0][0], &xim[0][0], pst->syn_r.ring, &pst->syn_r.drc_offset, &pst->syn_r.filt_off, out_r);
+    (ds ? xo_esbr_synthesis_ds : xo_esbr_synthesis)(&xre[0][0], &xim[0][0], pst->syn_r.ring, &pst->syn_r.drc_offset, &pst->syn_r.filt_off, out_r);
   }
   for (int s0 = 0; s0 < slots; s0 += 32) /* the bank is a running filter: 64 slots are two runs of 32 */
-    xo_esbr_synthesis(&rre[s0][0], &rim[s0][0], st->syn.ring, &st->syn.drc_offset, &st->syn.filt_off, out + 64 * s0);
+    (ds ? xo_esbr_synthesis_ds : xo_esbr_synthesis)(&rre[s0][0], &rim[s0][0], st->syn.ring, &st->syn.drc_offset, &st->syn.filt_off,
+                                                    out + (ds ? 32 : 64) * s0);
   memcpy(st->qmf_re, qre + slots, sizeof(st->qmf_re));
   memcpy(st->qmf_im, qim + slots, sizeof(st->qmf_im));
   memcpy(st->out_re, ore + slots, sizeof(st->out_re));
@@ -217,5 +219,16 @@ int xo_esbr_sbr_frame_ratio(const float *core, int ratio, const xaac_sbr_header 
   }
   if (pvs && pvst) pvst->prev_sbr_mode = pvs->sbr_mode; /* sbr_dec.c:1006 */
   return rc;
+}
+int xo_esbr_sbr_frame_ratio(const float *core, int ratio, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
+                            xaac_esbr_state *st, const xaac_ps_frame *pf, xaac_esbr_ps_state *pst, float *out, float *out_r,
+                            xaac_hbe_state *hst, const xaac_esbr_pvc_side *pvs, xaac_esbr_pvc_state *pvst) {
+  return esbr_frame(core, ratio, 0, h, f, sd, st, pf, pst, out, out_r, hst, pvs, pvst);
+}
+/* ... with the down-sampled synthesis bank(s) (-dsample / output rates above 48 kHz: 32 synthesis channels, half the samples out) */
+int xo_esbr_sbr_frame_ds(const float *core, int ratio, int down_sample, const xaac_sbr_header *h, const xaac_sbr_frame *f,
+                         const xaac_esbr_side *sd, xaac_esbr_state *st, const xaac_ps_frame *pf, xaac_esbr_ps_state *pst, float *out,
+                         float *out_r, xaac_hbe_state *hst, const xaac_esbr_pvc_side *pvs, xaac_esbr_pvc_state *pvst) {
+  return esbr_frame(core, ratio, down_sample != 0, h, f, sd, st, pf, pst, out, out_r, hst, pvs, pvst);
 }
 }

@@ -412,4 +412,35 @@ void xo_esbr_synthesis(const float *re, const float *im, int32_t *ring, int32_t 
   *filt_off = fl;
 }
 
+/* ... with the down-sampled bank (no_synthesis_channels 32: sbr_dec.c:605-628, ixheaacd_esbr_qmfsyn32_winadd generic:1577): the ring's
+   first 640 words, 1024 floats out */
+void xo_esbr_synthesis_ds(const float *re, const float *im, int32_t *ring, int32_t *drc_off, int32_t *filt_off, float *out) {
+  const int32_t *c = xaac_qmf_esbr_qmf_c;
+  int d = *drc_off, fl = *filt_off;
+  int f1 = 0, f2 = 32, step = 32;
+  for (int s = 0; s < 32; s++) {
+    int32_t x[128], t[128];
+    for (int k = 0; k < 64; k++) {
+      x[k] = fx_f2i_trunc(re[64 * s + k] * 64);
+      x[64 + k] = fx_f2i_trunc(im[64 * s + k] * 64);
+    }
+    xq_esbr_synth_slot_ds(x, t, ring + d, 5 + 1);
+    for (int k = 0; k < 32; k++) {
+      int64_t acc = 0;
+      for (int j = 0; j < 5; j++) acc = xq_add64(acc, (int64_t)ring[f1 + 128 * j + k] * c[fl + 2 * (k + 64 * j)]);
+      for (int j = 0; j < 5; j++) acc = xq_add64(acc, (int64_t)ring[f2 + 64 + 128 * j + k] * c[fl + 2 * (k + 32 + 64 * j)]);
+      out[32 * s + k] = (float)(int32_t)(acc >> 31) / 65536.0f;
+    }
+    f1 += step;
+    f2 -= step;
+    step = -step;
+    d -= 64;
+    if (d < 0) d += 640;
+    fl += 64;
+    if (fl == 640) fl = 0;
+  }
+  *drc_off = d;
+  *filt_off = fl;
+}
+
 }  // extern "C"

@@ -540,3 +540,27 @@ void ref_esbr_synthesis(const float *re, const float *im, int32_t *ring, int32_t
   *drc_off = b->ixheaacd_drc_offset;
   *filt_off = (int32_t)(b->filter_pos_syn_32 - q->esbr_qmf_c);
 }
+/* the same call with the down-sampled bank (no_channels 32): ring WORD32[640], out 1024 floats */
+void ref_esbr_synthesis_ds(const float *re, const float *im, int32_t *ring, int32_t *drc_off, int32_t *filt_off, float *out) {
+  static __thread ia_sbr_dec_struct d;
+  static __thread ia_sbr_frame_info_data_struct fr;
+  static __thread float rows_re[32][64], rows_im[32][64], time[2048];
+  float *pr[32], *pi[32];
+  ia_qmf_dec_tables_struct *q = esbr_tabs()->qmf_dec_tables_ptr;
+  ia_sbr_qmf_filter_bank_struct *b = &d.str_synthesis_qmf_bank;
+  memset(b, 0, sizeof(*b));
+  memcpy(rows_re, re, sizeof(rows_re));
+  memcpy(rows_im, im, sizeof(rows_im));
+  for (int s = 0; s < 32; s++) { pr[s] = rows_re[s]; pi[s] = rows_im[s]; }
+  b->no_channels = 32;
+  b->filter_states_32 = ring;
+  b->ixheaacd_drc_offset = (WORD16)*drc_off;
+  b->p_filter_32 = q->esbr_qmf_c;
+  b->filter_pos_syn_32 = q->esbr_qmf_c + *filt_off;
+  d.str_codec_qmf_bank.num_time_slots = 32;
+  d.time_sample_buf = time;
+  ixheaacd_esbr_synthesis_filt_block(&d, NULL, &fr, 1, pr, pi, 0, esbr_tabs(), 0, 1, 0, 1, NULL, 0, NULL);
+  memcpy(out, time, 1024 * sizeof(float));
+  *drc_off = b->ixheaacd_drc_offset;
+  *filt_off = (int32_t)(b->filter_pos_syn_32 - q->esbr_qmf_c);
+}

@@ -138,3 +138,25 @@ def test_analysis_chain_of_the_8_3_and_4_1_banks(oracle, reference, nb, n_slots,
         assert np.array_equal(rr.view(np.uint32), xr.view(np.uint32)), (f, int(np.sum(rr != xr)))
         assert np.array_equal(ri.view(np.uint32), xi.view(np.uint32)), f
         assert (amp < 0.01 or np.any(rr[:, :nb] != 0)) and not np.any(rr[:, nb:])
+
+
+@pytest.mark.parametrize("amp", [1.0, 30.0, 1e-3, 4000.0, 3e8])
+def test_down_sampled_synthesis_chain(oracle, reference, amp):
+    """the 32-channel synthesis bank of the eSBR branch (-dsample: sbr_dec.c:605-628) against the reference's own function, state
+    carried over 13 frames (ring and window positions wrap)"""
+    fr_, fo_ = reference.lib.ref_esbr_synthesis_ds, oracle.lib.xo_esbr_synthesis_ds
+    for fn in (fr_, fo_):
+        fn.restype = None
+        fn.argtypes = [PF, PF, P32, P32, P32, PF]
+    rng = np.random.default_rng(int(amp * 1e3) + 9)
+    ring_r, ring_o = np.zeros(1280, np.int32), np.zeros(1280, np.int32)
+    dr = fr = do = fo = 0
+    for f in range(13):
+        re = np.ascontiguousarray((rng.standard_normal((32, 64)) * amp).astype(np.float32))
+        im = np.ascontiguousarray((rng.standard_normal((32, 64)) * amp).astype(np.float32))
+        outr, dr, fr = syn(fr_, re, im, ring_r, dr, fr)
+        outo, do, fo = syn(fo_, re, im, ring_o, do, fo)
+        assert (dr, fr) == (do, fo), f
+        assert np.array_equal(ring_r, ring_o), f
+        assert np.array_equal(outr[:1024].view(np.uint32), outo[:1024].view(np.uint32)), (f, int(np.sum(outr[:1024] != outo[:1024])))
+        assert (amp < 0.01 or np.any(outr[:1024] != 0)) and not np.any(outo[1024:])
