@@ -518,6 +518,9 @@ XAAC_API int32_t xaac_qmf_analysis_eld_batch(xaac_ctx *ctx, const xaac_qmf_ana_e
 /* ixheaacd_cplx_synt_qmffilt for AAC-LD / ELD (complex bank, 64 channels, 16 or 15 slots per frame) */
 XAAC_API int32_t xaac_qmf_synthesis_eld_batch(xaac_ctx *ctx, const xaac_qmf_syn_eld_batch *batch);
 XAAC_API int32_t xaac_esbr_qmf_synthesis_batch(xaac_ctx *ctx, const xaac_esbr_syn_batch *batch);
+/* the same bank down-sampled (32 synthesis channels: -dsample, output rates above 48 kHz; sbr_dec.c:605-628): the same descriptor,
+   out [n_ch][1024], the state's ring used up to word 640 */
+XAAC_API int32_t xaac_esbr_qmf_synthesis_ds_batch(xaac_ctx *ctx, const xaac_esbr_syn_batch *batch);
 
 /* Low-power SBR channel-frames (QMF analysis -> HF generation + envelope adjustment -> QMF synthesis). */
 XAAC_API uint64_t xaac_sbr_lp_workspace_bytes(int32_t n_ch);

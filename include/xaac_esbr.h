@@ -149,6 +149,9 @@ typedef struct xaac_esbr_sbr_batch {
                                        esbr_envcal.c:152), out rows of 4096 floats, workspace of xaac_esbr_workspace_bytes_ratio;
                                        USAC channels without a transposer only (side flags XAAC_ESBR_USAC | _NO_X_DELAY; ps_frame and
                                        hbe_state NULL) -- a 4:1 channel with harmonic SBR stays the caller's */
+  int32_t down_sample;              /* 1: the down-sampled synthesis bank(s) (32 channels; the reference's -dsample:1, or an output rate above
+                                       48 kHz, sbrdec_initfuncs.c:622): out / out_r rows hold half the samples (1024; 2048 at 4:1), at the
+                                       same row pitch */
 } xaac_esbr_sbr_batch;
 enum { XAAC_ESBR_RATIO_2_1 = 0, XAAC_ESBR_RATIO_8_3 = 1, XAAC_ESBR_RATIO_4_1 = 2 };
 

@@ -72,7 +72,8 @@ class _EsbrSbrBatch(ctypes.Structure):
                 ("out", ctypes.c_void_p), ("ps_frame", ctypes.c_void_p), ("ps_state", ctypes.c_void_p),
                 ("out_r", ctypes.c_void_p), ("status", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
                 ("workspace_bytes", ctypes.c_uint64), ("hbe_state", ctypes.c_void_p), ("hbe_max_synth_size", ctypes.c_int32),
-                ("pvc_side", ctypes.c_void_p), ("pvc_state", ctypes.c_void_p), ("sbr_ratio", ctypes.c_int32)]
+                ("pvc_side", ctypes.c_void_p), ("pvc_state", ctypes.c_void_p), ("sbr_ratio", ctypes.c_int32),
+                ("down_sample", ctypes.c_int32)]
 
 
 ESBR_RATIO_2_1, ESBR_RATIO_8_3, ESBR_RATIO_4_1 = 0, 1, 2   # xaac_esbr.h: XAAC_ESBR_RATIO_*
@@ -330,6 +331,8 @@ def load_library():
     lib.xaac_esbr_qmf_analysis_nb_batch.restype = ctypes.c_int32
     lib.xaac_esbr_qmf_synthesis_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_EsbrSynBatch)]
     lib.xaac_esbr_qmf_synthesis_batch.restype = ctypes.c_int32
+    lib.xaac_esbr_qmf_synthesis_ds_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_EsbrSynBatch)]
+    lib.xaac_esbr_qmf_synthesis_ds_batch.restype = ctypes.c_int32
     lib.xaac_sbr_lp_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_SbrLpBatch)]
     lib.xaac_sbr_lp_process_batch.restype = ctypes.c_int32
     lib.xaac_sbr_lp_workspace_bytes.argtypes = [ctypes.c_int32]
@@ -546,7 +549,7 @@ class XaacContext:
 
     def esbr_sbr_process_batch(self, core, header, frame, side, state, out, workspace, status=None, ps_frame=None,
                                ps_state=None, out_r=None, hbe_state=None, hbe_max_synth_size=0, pvc_side=None, pvc_state=None,
-                               sbr_ratio=0):
+                               sbr_ratio=0, down_sample=False):
         """One frame of every channel through the Path A (eSBR, -esbr:1) branch of ixheaacd_sbr_dec, mono / stereo
         channels without PS: core float32[n_ch, 1024]; header / frame / side / state uint8 views of the xaac_sbr_header,
         xaac_sbr_frame, xaac_esbr_side, xaac_esbr_state arrays; out float32[n_ch, 2048].  With ps_frame / ps_state (uint8
@@ -557,6 +560,7 @@ class XaacContext:
         n_ch = out.shape[0]
         b = _EsbrSbrBatch()
         b.sbr_ratio = int(sbr_ratio)
+        b.down_sample = int(bool(down_sample))    # the 32-channel synthesis bank(s): half the samples at the same row pitch
         b.n_ch = n_ch
         b.core = _ptr(core, "float32", n_ch * 1024, device_ok=True)
         b.header = _ptr(header, "uint8", n_ch * SBR_HEADER_BYTES, device_ok=True)
@@ -817,6 +821,19 @@ class XaacContext:
         rc = self._lib.xaac_esbr_qmf_synthesis_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_esbr_qmf_synthesis_batch")
+
+    def esbr_qmf_synthesis_ds_batch(self, qmf_re, qmf_im, state, out):
+        """The same bank down-sampled (32 synthesis channels, sbr_dec.c:605-628): out float32[n_ch, 1024]."""
+        n_ch = state.shape[0]
+        b = _EsbrSynBatch()
+        b.n_ch = n_ch
+        b.qmf_re = _ptr(qmf_re, "float32", n_ch * 2048, device_ok=True)
+        b.qmf_im = _ptr(qmf_im, "float32", n_ch * 2048, device_ok=True)
+        b.state = _ptr(state, "int32", n_ch * ESBR_SYN_STATE_WORDS, device_ok=True)
+        b.out = _ptr(out, "float32", n_ch * 1024, device_ok=True)
+        rc = self._lib.xaac_esbr_qmf_synthesis_ds_batch(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_esbr_qmf_synthesis_ds_batch")
 
     def sbr_eld_workspace_bytes(self, n_ch):
         return int(self._lib.xaac_sbr_eld_workspace_bytes(int(n_ch)))

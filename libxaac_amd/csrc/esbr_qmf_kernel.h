@@ -59,6 +59,7 @@ hipError_t xaac_launch_esbr_pcm16_from_float(const XaacEsbrPcmOutParams *p, hipS
 hipError_t xaac_launch_esbr_analysis(const XaacEsbrAnaParams *p, hipStream_t stream);
 hipError_t xaac_launch_esbr_analysis_nb(const XaacEsbrAnaNbParams *p, hipStream_t stream);
 hipError_t xaac_launch_esbr_synthesis(const XaacEsbrSynParams *p, hipStream_t stream);
+hipError_t xaac_launch_esbr_synthesis_ds(const XaacEsbrSynParams *p, hipStream_t stream); /* 32 synthesis channels: out [n_ch][out_stride | 1024] */
 #ifdef __cplusplus
 }
 #endif

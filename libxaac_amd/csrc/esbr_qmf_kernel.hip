@@ -459,6 +459,98 @@ __global__ __launch_bounds__(256) void xaac_esbr_pcm16_from_float_kernel(XaacEsb
   reinterpret_cast<short2 *>(p.pcm)[e] = o;
 }
 
+/* The down-sampled synthesis bank of the eSBR branch (-dsample:1, output rates above 48 kHz: 32 synthesis channels, sbr_dec.c:556-569,
+   :605-628; ixheaacd_esbr_qmfsyn32_winadd generic:1577): 32 samples a slot, the ring's first 640 words.  Lane = slot, two channel-frames
+   a wave, as in the 24-channel analysis bank above and with its way of finding a ring block's words at a given slot: the slot's own 64
+   new words, an earlier slot's of this frame, or the words the state holds.  Not a headline kernel: exact, short, untuned. */
+__global__ __launch_bounds__(64) void xaac_esbr_synthesis_ds_kernel(XaacEsbrSynParams p) {
+  constexpr int RS = 65, TS = 33;
+  __shared__ int32_t old_ring[2][640];
+  __shared__ int32_t blk[2][32 * RS]; /* slot k's 64 ring words */
+  __shared__ int32_t win_lds[1280];
+  __shared__ float tile[64 * TS];
+  const int lane = threadIdx.x, lc = lane >> 5, slot = lane & 31;
+  for (int i = lane; i < 1280; i += 64) win_lds[i] = xaac_qmf_esbr_qmf_c[i];
+  int pb_c[2] = {0, 0}, fl_c[2] = {0, 0};
+  bool live_c[2] = {false, false};
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    const int ch = 2 * (int)blockIdx.x + c;
+    if (ch >= p.n_ch) continue;
+    if (p.only_ps && __builtin_amdgcn_readfirstlane((int)p.only_ps[ch].channel_mode) != 3) continue; /* no right channel in this frame */
+    live_c[c] = true;
+    const xaac_esbr_syn_state *st = reinterpret_cast<const xaac_esbr_syn_state *>(reinterpret_cast<const char *>(p.state) + (size_t)ch * p.state_stride);
+    int d0 = st->drc_offset, fl0 = st->filt_off;
+    for (int i = lane; i < 640; i += 64) old_ring[c][i] = st->ring[i];
+    d0 = __builtin_amdgcn_readfirstlane(d0);
+    fl0 = __builtin_amdgcn_readfirstlane(fl0);
+    /* positions no run of the reference produces are brought onto the grids (blocks of 64 words, window steps of 64) */
+    pb_c[c] = d0 < 0 ? 0 : (d0 >= 640 ? 9 : d0 / 64);
+    fl_c[c] = fl0 < 0 ? 0 : (fl0 >= 640 ? 576 : fl0 / 64 * 64);
+  }
+  const int my_ch = 2 * (int)blockIdx.x + lc;
+  const bool live = lc ? live_c[1] : live_c[0];
+  const int pb = lc ? pb_c[1] : pb_c[0], fl0 = lc ? fl_c[1] : fl_c[0];
+  if (live) { /* the slot's transform: rows in as (WORD32)(x * 64) (sbr_dec.c:592-595), its 64 ring words out */
+    const float *re = p.qmf_re + (size_t)my_ch * p.in_stride + (size_t)slot * 64, *im = p.qmf_im + (size_t)my_ch * p.in_stride + (size_t)slot * 64;
+    int32_t x[128], t[128], b[64];
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+      x[k] = fx_f2i_trunc(re[k] * 64.0f);
+      x[64 + k] = fx_f2i_trunc(im[k] * 64.0f);
+    }
+    xq_esbr_synth_slot_ds(x, t, b, 5 + 1);
+#pragma unroll
+    for (int k = 0; k < 64; k++) blk[lc][RS * slot + k] = b[k];
+  }
+  __syncthreads();
+  /* block B of the ring as it stands at slot s: slot k wrote it if (pb - k) mod 10 == B; the newest such k <= s, or the state's words */
+  const auto block_at = [&](int c, int pbc, int B, int s) -> const int32_t * {
+    int k0 = pbc - B;
+    k0 += k0 < 0 ? 10 : 0;
+    if (k0 > s) return old_ring[c] + 64 * B;
+    return blk[c] + RS * (k0 + 10 * ((s - k0) / 10));
+  };
+  if (live) { /* window-add: tmp1 = ring + f1, tmp2 = ring + f2, f1 0 | 32 by the slot's parity (sbr_dec.c:621-623) */
+    const int f1 = (slot & 1) ? 32 : 0, f2 = 32 - f1;
+    int fl = fl0 + 64 * slot;
+    fl -= 640 * (fl / 640);
+    const int32_t *bp[10];
+#pragma unroll
+    for (int B = 0; B < 10; B++) bp[B] = block_at(lc, pb, B, slot);
+#pragma unroll 4
+    for (int k = 0; k < 32; k++) {
+      int64_t acc = 0;
+#pragma unroll
+      for (int j = 0; j < 5; j++) acc = xq_add64(acc, (int64_t)bp[2 * j][f1 + k] * win_lds[fl + 2 * (k + 64 * j)]);
+#pragma unroll
+      for (int j = 0; j < 5; j++) acc = xq_add64(acc, (int64_t)bp[2 * j + 1][f2 + k] * win_lds[fl + 2 * (k + 32 + 64 * j)]);
+      tile[TS * lane + k] = (float)(int32_t)(acc >> 31) / 65536.0f;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    if (!live_c[c]) continue;
+    const int ch = 2 * (int)blockIdx.x + c;
+    float *dst = p.out + (size_t)ch * (p.out_stride ? p.out_stride : 1024);
+    for (int i = lane; i < 1024; i += 64) dst[i] = tile[TS * (32 * c + (i >> 5)) + (i & 31)];
+    xaac_esbr_syn_state *st = reinterpret_cast<xaac_esbr_syn_state *>(reinterpret_cast<char *>(p.state) + (size_t)ch * p.state_stride);
+    for (int i = lane; i < 640; i += 64) st->ring[i] = block_at(c, pb_c[c], i >> 6, 31)[i & 63];
+    if (lane == 0) {
+      int d = (pb_c[c] - 32) % 10;
+      d += d < 0 ? 10 : 0;
+      st->drc_offset = 64 * d;
+      st->filt_off = (fl_c[c] + 64 * 32) % 640;
+    }
+  }
+}
+
+extern "C" hipError_t xaac_launch_esbr_synthesis_ds(const XaacEsbrSynParams *p, hipStream_t stream) {
+  hipLaunchKernelGGL(xaac_esbr_synthesis_ds_kernel, dim3((p->n_ch + 1) / 2), dim3(64), 0, stream, *p);
+  return hipGetLastError();
+}
+
 extern "C" hipError_t xaac_launch_esbr_core_from_pcm16(const XaacEsbrCoreInParams *p, hipStream_t stream) {
   const size_t total = (size_t)p->n_ch * 1024;
   hipLaunchKernelGGL(xaac_esbr_core_from_pcm16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, *p);

@@ -361,10 +361,10 @@ int32_t xaac_esbr_sbr_process_batch(xaac_ctx *c, const xaac_esbr_sbr_batch *b) {
     XaacEsbrCoreParams pc = {b->n_ch, b->header, b->frame, b->side, b->state, nullptr, nullptr, o_re, o_im, s_re, s_im,
                              0, b->status, nullptr, nullptr, nullptr, 0, b->pvc_side, b->pvc_state, pvc_o, 1, q_re, q_im};
     if (!hip_ok(xaac_launch_esbr_core(&pc, c->stream))) return XAAC_FATAL_HIP;
-    for (int half = 0; half < 2; half++) {
-      XaacEsbrSynParams ps = {b->n_ch, s_re + half * 2048, s_im + half * 2048, &b->state->syn, b->out + half * 2048,
+    for (int half = 0; half < 2; half++) { /* (down-sampled: half the samples of each run, at the same row pitch) */
+      XaacEsbrSynParams ps = {b->n_ch, s_re + half * 2048, s_im + half * 2048, &b->state->syn, b->out + half * (b->down_sample ? 1024 : 2048),
                               (int32_t)sizeof(xaac_esbr_state), 64 * 64, nullptr, 4096};
-      if (!hip_ok(xaac_launch_esbr_synthesis(&ps, c->stream))) return XAAC_FATAL_HIP;
+      if (!hip_ok((b->down_sample ? xaac_launch_esbr_synthesis_ds : xaac_launch_esbr_synthesis)(&ps, c->stream))) return XAAC_FATAL_HIP;
     }
     c->last_grid = b->n_ch; c->last_block = 64; c->last_lds = 0;
     return XAAC_OK;
@@ -401,11 +401,12 @@ int32_t xaac_esbr_sbr_process_batch(xaac_ctx *c, const xaac_esbr_sbr_batch *b) {
     XaacEsbrPsParams pp = {b->n_ch, b->header, b->frame, b->ps_frame, b->ps_state, syn_re, syn_im, r_re, r_im, b->status};
     if (!hip_ok(xaac_launch_esbr_ps(&pp, c->stream))) return XAAC_FATAL_HIP;
   }
-  XaacEsbrSynParams ps = {b->n_ch, syn_re, syn_im, &b->state->syn, b->out, (int32_t)sizeof(xaac_esbr_state), XAAC_ESBR_L_ROWS * 64};
-  if (!hip_ok(xaac_launch_esbr_synthesis(&ps, c->stream))) return XAAC_FATAL_HIP;
+  const auto syn = b->down_sample ? xaac_launch_esbr_synthesis_ds : xaac_launch_esbr_synthesis;
+  XaacEsbrSynParams ps = {b->n_ch, syn_re, syn_im, &b->state->syn, b->out, (int32_t)sizeof(xaac_esbr_state), XAAC_ESBR_L_ROWS * 64, nullptr, 2048};
+  if (!hip_ok(syn(&ps, c->stream))) return XAAC_FATAL_HIP;
   if (with_ps) {
-    XaacEsbrSynParams pr = {b->n_ch, r_re, r_im, &b->ps_state->syn_r, b->out_r, (int32_t)sizeof(xaac_esbr_ps_state), 2048, b->header};
-    if (!hip_ok(xaac_launch_esbr_synthesis(&pr, c->stream))) return XAAC_FATAL_HIP;
+    XaacEsbrSynParams pr = {b->n_ch, r_re, r_im, &b->ps_state->syn_r, b->out_r, (int32_t)sizeof(xaac_esbr_ps_state), 2048, b->header, 2048};
+    if (!hip_ok(syn(&pr, c->stream))) return XAAC_FATAL_HIP;
   }
   c->last_grid = b->n_ch; c->last_block = 64; c->last_lds = 0;
   return XAAC_OK;
@@ -513,6 +514,18 @@ int32_t xaac_esbr_qmf_synthesis_batch(xaac_ctx *c, const xaac_esbr_syn_batch *b)
   XaacEsbrSynParams p = {b->n_ch, b->qmf_re, b->qmf_im, b->state, b->out, (int32_t)sizeof(xaac_esbr_syn_state), 2048};
   if (!hip_ok(xaac_launch_esbr_synthesis(&p, c->stream))) return XAAC_FATAL_HIP;
   c->last_grid = (b->n_ch + 1) / 2; c->last_block = 64; c->last_lds = XAAC_ESBR_SYN_LDS;
+  return XAAC_OK;
+}
+
+int32_t xaac_esbr_qmf_synthesis_ds_batch(xaac_ctx *c, const xaac_esbr_syn_batch *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n_ch < 0) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch == 0) return XAAC_OK;
+  if (!b->qmf_re || !b->qmf_im || !b->state || !b->out) return XAAC_FATAL_NULL_ARG;
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  XaacEsbrSynParams p = {b->n_ch, b->qmf_re, b->qmf_im, b->state, b->out, (int32_t)sizeof(xaac_esbr_syn_state), 2048, nullptr, 1024};
+  if (!hip_ok(xaac_launch_esbr_synthesis_ds(&p, c->stream))) return XAAC_FATAL_HIP;
+  c->last_grid = (b->n_ch + 1) / 2; c->last_block = 64; c->last_lds = 0;
   return XAAC_OK;
 }
 

@@ -44,7 +44,7 @@ static struct {
   xaac_esbr_pvc_state *pvst;
 } g;
 static long g_eld_ana_calls, g_eld_syn_calls;
-static long g_usac_fac_dev, g_sbr_ds_calls;
+static long g_usac_fac_dev, g_sbr_ds_calls, g_esbr_ds_calls;
 static long g_imdct_calls, g_sbr_calls, g_lim_calls, g_esbr_calls, g_esbr_harm_calls, g_esbr_usac_calls, g_esbr_pvc_calls, g_esbr_83_calls, g_esbr_41_calls, g_sbr_ref_calls, g_usac_imdct_calls, g_usac_imdct_fac, g_usac_imdct_lpd, g_eld_sbr_calls, g_imdct960_calls, g_imdct_ld_calls;
 static struct { int32_t *overlap; int16_t *pcm; uint8_t *shape; } gl; /* AAC-LD / ELD: 3 x 512 overlap words, 512 samples, 2 bytes */
 
@@ -64,6 +64,7 @@ static void report(void) {
   fprintf(stderr, "xaacdec_dropin: %ld peak_limiter_process calls ran on the GPU\n", g_lim_calls);
   fprintf(stderr, "xaacdec_dropin: %ld sbr_dec calls took the eSBR (Path A) branch on the GPU\n", g_esbr_calls);
   fprintf(stderr, "xaacdec_dropin: %ld of them with harmonic patching (the QMF transposer's output)\n", g_esbr_harm_calls);
+  fprintf(stderr, "xaacdec_dropin: %ld of the eSBR calls with the down-sampled synthesis bank(s)\n", g_esbr_ds_calls);
   fprintf(stderr, "xaacdec_dropin: %ld of them for USAC channels, %ld sbr_dec calls left to the reference\n", g_esbr_usac_calls, g_sbr_ref_calls);
   fprintf(stderr, "xaacdec_dropin: %ld USAC fd_frm_dec calls ran on the GPU, %ld with a FAC signal, %ld behind an LPD frame\n", g_usac_imdct_calls,
           g_usac_imdct_fac, g_usac_imdct_lpd);
@@ -476,10 +477,14 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
         !getenv("XAAC_DROPIN_NO_RATIOS")) ||
        (h->usac_flag && h->sbr_ratio_idx == SBR_UPSAMPLE_IDX_4_1 && h->num_time_slots == 16 && d->str_codec_qmf_bank.no_channels == 16 &&
         !h->hbe_flag && !getenv("XAAC_DROPIN_NO_RATIOS"))) &&
-      d->str_synthesis_qmf_bank.no_channels == 64 && !getenv("XAAC_DROPIN_NO_ESBR")) {
+      (d->str_synthesis_qmf_bank.no_channels == 64 ||   /* or the down-sampled bank(s): -dsample:1, output rates above 48 kHz */
+       (d->str_synthesis_qmf_bank.no_channels == 32 && (h->channel_mode != PS_STEREO || synth_r->no_channels == 32) &&
+        !getenv("XAAC_DROPIN_NO_ESBR_DS"))) &&
+      !getenv("XAAC_DROPIN_NO_ESBR")) {
+    const int esbr_ds = d->str_synthesis_qmf_bank.no_channels == 32;
     const int ratio = d->str_codec_qmf_bank.no_channels == 16 ? XAAC_ESBR_RATIO_4_1
                       : (d->str_codec_qmf_bank.no_channels == 24 ? XAAC_ESBR_RATIO_8_3 : XAAC_ESBR_RATIO_2_1);
-    const int out_floats = ratio == XAAC_ESBR_RATIO_4_1 ? 4096 : 2048;
+    const int out_floats = (ratio == XAAC_ESBR_RATIO_4_1 ? 4096 : 2048) >> esbr_ds;
     static xaac_esbr_side sd;
     static xaac_esbr_state est;
     static xaac_esbr_ps_state epss;
@@ -533,6 +538,7 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     b.status = g.status;
     b.workspace = g.ews;
     b.sbr_ratio = ratio;
+    b.down_sample = esbr_ds;
     b.workspace_bytes = xaac_esbr_workspace_bytes_ratio(1, ratio);
     b.hbe_state = h->hbe_flag ? g.hbe : NULL;
     if (h->usac_flag) { /* every USAC call carries the PVC side info and state: ORIG_SBR frames leave what a PVC frame behind them reads */
@@ -567,7 +573,7 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     }
     if (eps) { /* right channel out, PS state back, and what the second synthesis call leaves in channel 1's frame data */
       HIP(hipMemcpy(&epss, g.epss, sizeof(epss), hipMemcpyDeviceToHost));
-      HIP(hipMemcpy(ps->time_sample_buf[1], g.time_r, 8192, hipMemcpyDeviceToHost));
+      HIP(hipMemcpy(ps->time_sample_buf[1], g.time_r, (size_t)out_floats * 4, hipMemcpyDeviceToHost));
       from_esbr_ps_state(&epss, ps, synth_r);
       ps->use_34_st_bands_prev = ps->use_34_st_bands;
       ((ia_sbr_frame_info_data_struct *)((ia_handle_sbr_dec_inst_struct)self)->frame_buffer[1])->reset_flag = 0;
@@ -578,6 +584,7 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     f->prev_sbr_mode = f->sbr_mode;
     g_esbr_calls++;
     if (h->usac_flag) g_esbr_usac_calls++;
+    if (esbr_ds) g_esbr_ds_calls++;
     if (ratio == XAAC_ESBR_RATIO_8_3) g_esbr_83_calls++;
     if (ratio == XAAC_ESBR_RATIO_4_1) g_esbr_41_calls++;
     if (apply && f->sbr_patching_mode == 0) g_esbr_harm_calls++;

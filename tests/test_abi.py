@@ -125,7 +125,7 @@ def test_round2_struct_layouts_match_headers(tmp_path):
              ("xaac_esbr_syn_batch", libxaac_amd._EsbrSynBatch, "out"),
              ("xaac_usac_imdct_batch", libxaac_amd._UsacImdctBatch, "fac_work"), ("xaac_sbr_handover_batch", libxaac_amd._HandoverBatch, "ps_state"),
              ("xaac_sbr_apply_side_batch", libxaac_amd._ApplySideBatch, "ps_state"),
-             ("xaac_esbr_sbr_batch", libxaac_amd._EsbrSbrBatch, "sbr_ratio"), ("xaac_esbr_side", es.EsbrSide, "pitch_in_bins"),
+             ("xaac_esbr_sbr_batch", libxaac_amd._EsbrSbrBatch, "down_sample"), ("xaac_esbr_side", es.EsbrSide, "pitch_in_bins"),
              ("xaac_esbr_pvc_side", es.EsbrPvcSide, "pvc"), ("xaac_esbr_pvc_state", es.EsbrPvcState, "esbr_start_up_pvc"),
              ("xaac_esbr_state", es.EsbrState, "ph_im"), ("xaac_esbr_ps_state", es.EsbrPsState, "syn_r"),
              ("xaac_esbr_ana_state", es.EsbrAna, "win_off"), ("xaac_esbr_syn_state", es.EsbrSyn, "filt_off")]

@@ -90,6 +90,26 @@ def test_down_sampled_sbr_through_the_gpu(aac, tmp_path):
     assert len(open(full, "rb").read()) > 1.8 * (len(a) - 44)      # half the samples of the plain decode
 
 
+@pytest.mark.parametrize("aac", [s for s in STREAMS if "aot5_" in s or "aot29_" in s], ids=lambda s: os.path.basename(s))
+def test_down_sampled_esbr_through_the_gpu(aac, tmp_path):
+    """-dsample:1 with the reference's default flags: the eSBR branch with its 32-channel synthesis bank(s) (sbr_dec.c:605-628;
+    xaac_esbr_sbr_batch.down_sample -> xaac_esbr_synthesis_ds_kernel), HE-AAC and HE-AACv2 (both banks): every call on the GPU,
+    byte-identical (the reference's USAC decoder does not take the flag)"""
+    if not (os.path.exists(os.path.join(REF, "xaacdec")) and os.path.exists(os.path.join(REF, "xaacdec_dropin"))):
+        pytest.fail("oracle/_ref/xaacdec[_dropin] missing: the reference binaries did not travel with the snapshot")
+    meta = aac[:-4] + ".txt"
+    extra = ("-dsample:1",) + (("-mp4:1", "-imeta:" + meta) if os.path.exists(meta) else ())
+    ref_wav, gpu_wav = str(tmp_path / "ref.wav"), str(tmp_path / "gpu.wav")
+    _decode("xaacdec", aac, ref_wav, extra=extra)
+    log = _decode("xaacdec_dropin", aac, gpu_wav, extra=extra)
+    n_esbr = int(re.search(r"(\d+) sbr_dec calls took the eSBR \(Path A\) branch on the GPU", log).group(1))
+    n_ds = int(re.search(r"(\d+) of the eSBR calls with the down-sampled synthesis bank", log).group(1))
+    n_left = int(re.search(r"(\d+) sbr_dec calls left to the reference", log).group(1))
+    assert n_esbr > 30 and n_ds == n_esbr and n_left == 0, log[-900:]
+    a, b = open(ref_wav, "rb").read(), open(gpu_wav, "rb").read()
+    assert len(a) > 50000 and a == b, (len(a), len(b))
+
+
 def test_streams_present():
     assert len(STREAMS) >= 3
 

@@ -167,3 +167,40 @@ def test_gpu_analysis_then_synthesis_vs_oracle(oracle):
             assert np.array_equal(xo.view(np.uint32), o[c].view(np.uint32)), (f, c)
             assert np.array_equal(s_st[c], np.concatenate([ring, [drc, filt]])), (f, c)
         assert np.any(o != 0)
+
+
+@pytest.mark.gpu
+def test_gpu_down_sampled_synthesis_chain_equals_the_oracle(oracle):
+    """xaac_esbr_qmf_synthesis_ds_batch (32 synthesis channels: sbr_dec.c:605-628) against the oracle's restatement -- itself pinned on
+    the reference's function, tests/test_esbr_qmf_oracle_vs_reference.py -- over 12 frames with the state carried on the device: an odd
+    number of channels (the last wave half empty), several signal levels, ring and window positions wrapping"""
+    import ctypes
+    import torch
+    import libxaac_amd
+    PF, P32 = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)
+    fn = oracle.lib.xo_esbr_synthesis_ds
+    fn.restype = None
+    fn.argtypes = [PF, PF, P32, P32, P32, PF]
+    dev = torch.device("cuda:0")
+    ctx = libxaac_amd.XaacContext(0, None)
+    n = 7
+    rng = np.random.default_rng(21)
+    state = torch.zeros((n, libxaac_amd.ESBR_SYN_STATE_WORDS), dtype=torch.int32, device=dev)
+    rings = [np.zeros(1280, np.int32) for _ in range(n)]
+    pos = [[0, 0] for _ in range(n)]
+    out = torch.full((n, 1024), 5.0, dtype=torch.float32, device=dev)
+    for f in range(12):
+        amp = np.float32([1.0, 30.0, 1e-3, 4000.0, 3e8, 200.0, 0.0][(f + 1) % 7])
+        re = (rng.standard_normal((n, 32, 64)) * amp).astype(np.float32)
+        im = (rng.standard_normal((n, 32, 64)) * amp).astype(np.float32)
+        ctx.esbr_qmf_synthesis_ds_batch(torch.from_numpy(re).to(dev), torch.from_numpy(im).to(dev), state, out)
+        ctx.sync()
+        o, st = out.cpu().numpy(), state.cpu().numpy()
+        for c in range(n):
+            want = np.zeros(2048, np.float32)
+            d, fl = ctypes.c_int32(pos[c][0]), ctypes.c_int32(pos[c][1])
+            fn(re[c].ctypes.data_as(PF), im[c].ctypes.data_as(PF), rings[c].ctypes.data_as(P32), ctypes.byref(d), ctypes.byref(fl),
+               want.ctypes.data_as(PF))
+            pos[c] = [d.value, fl.value]
+            assert np.array_equal(o[c].view(np.uint32), want[:1024].view(np.uint32)), (f, c, int(np.sum(o[c] != want[:1024])))
+            assert np.array_equal(st[c, :640], rings[c][:640]) and (int(st[c, 1280]), int(st[c, 1281])) == (d.value, fl.value), (f, c)
