@@ -203,7 +203,14 @@ static WORD32 esbr_chain_call(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_he
         }
     }
   }
-  chain_core(run, c, steps[c], d->time_sample_buf);
+  if (getenv("XAAC_ESBR_CHAIN_CORE_FILE")) { /* debugging aid: the stream's own core samples stay and are written out, call by call */
+    static FILE *fc;
+    if (!fc) fc = fopen(getenv("XAAC_ESBR_CHAIN_CORE_FILE"), "wb");
+    fwrite(d->time_sample_buf, sizeof(FLOAT32), 1024, fc);
+    fflush(fc);
+  } else {
+    chain_core(run, c, steps[c], d->time_sample_buf);
+  }
   to_header(h, d, &hd);
   to_frame(f, apply, &fr);
   to_esbr_side(h, f, &sd);

@@ -506,6 +506,9 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     to_frame(f, apply, &fr);
     to_esbr_side(h, f, &sd);
     to_esbr_state(d, h, f, &est);
+    static float in_re[32][64], in_im[32][64]; /* the history rows 0..31 the call starts from: see behind the call */
+    memcpy(in_re, est.qmf_re, sizeof(in_re));
+    memcpy(in_im, est.qmf_im, sizeof(in_im));
     HIP(hipMemcpy(g.hdr, &hd, sizeof(hd), hipMemcpyHostToDevice));
     HIP(hipMemcpy(g.frame, &fr, sizeof(fr), hipMemcpyHostToDevice));
     HIP(hipMemcpy(g.side, &sd, sizeof(sd), hipMemcpyHostToDevice));
@@ -518,6 +521,13 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
       HIP(hipMemcpy(g.hbe, &hbs, sizeof(hbs), hipMemcpyHostToDevice));
     }
     HIP(hipMemcpy(g.core, d->time_sample_buf, 4096, hipMemcpyHostToDevice));
+    if (getenv("XAAC_DROPIN_TRACE_FILE")) { /* developer aid: what every eSBR call is handed (tools compare it with a capture run's) */
+      static FILE *ft;
+      if (!ft) ft = fopen(getenv("XAAC_DROPIN_TRACE_FILE"), "wb");
+      fwrite(&est, sizeof(est), 1, ft), fwrite(&hbs, sizeof(hbs), 1, ft), fwrite(&hd, sizeof(hd), 1, ft), fwrite(&fr, sizeof(fr), 1, ft);
+      fwrite(&sd, sizeof(sd), 1, ft), fwrite(d->time_sample_buf, 4, 1024, ft);
+      fflush(ft);
+    }
     memset(&b, 0, sizeof(b));
     b.n_ch = 1;
     b.core = g.core;
@@ -562,6 +572,21 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     HIP(hipMemcpy(&est, g.estate, sizeof(est), hipMemcpyDeviceToHost));
     HIP(hipMemcpy(d->time_sample_buf, g.time, (size_t)out_floats * 4, hipMemcpyDeviceToHost));
     from_esbr_state(&est, d, h, f);
+    if (h->hbe_flag) {
+      /* What else the reference's buffers hold behind its own call: rows 0..31 of qmf_buf are the history the call started from
+         (shifted down at its top, sbr_dec.c:835-845; for a non-USAC stream rows 2..7 with the byte-counted clear of :866-872).  The
+         next call never reads them -- it shifts rows 32.. over them -- but ixheaacd_applysbr does when a header resets the SBR
+         decoder: it runs the transposer over rows 6..69 of these buffers before the call (sbrdecoder.c:196-226).  (Found by
+         tools/sweep_streams.py through the drop-in: a 32 kHz stream whose first SBR header arrives behind nine frames of audio.) */
+      int r;
+      if (!h->usac_flag && sd.qmf_sb_prev >= 0 && sd.qmf_sb_prev <= 64)
+        for (r = 2; r < 8; r++) {
+          memset(&in_re[r][sd.qmf_sb_prev], 0, (size_t)(64 - sd.qmf_sb_prev));
+          memset(&in_im[r][sd.qmf_sb_prev], 0, (size_t)(64 - sd.qmf_sb_prev));
+        }
+      memcpy(d->qmf_buf_real[0], in_re, sizeof(in_re));
+      memcpy(d->qmf_buf_imag[0], in_im, sizeof(in_im));
+    }
     if (apply && h->hbe_flag) {
       HIP(hipMemcpy(&hbs, g.hbe, sizeof(hbs), hipMemcpyDeviceToHost));
       from_hbe_state(&hbs, d->p_hbe_txposer, h);

@@ -49,7 +49,7 @@ def main():
             for aot, brs in ((2, (32000, 96000)), (5, (24000, 48000)), (29, (18000, 32000))):
                 if aot == 29 and ch != 2:
                     continue       # parametric stereo codes a stereo input
-                if aot != 2 and fs < 32000:
+                if aot != 2 and fs < 32000 and not os.environ.get("SWEEP_ALL_SBR_RATES"):
                     continue       # SBR at twice a low core rate: the encoder's supported range
                 for br in brs:
                     cases.append((fs, ch, aot, br, wav))
@@ -79,13 +79,17 @@ def main():
         if r.returncode or not os.path.exists(aac) or os.path.getsize(aac) < 100:
             print(name, "encoder refused")
             continue
-        for flags in ((), ("-esbr:0",)):
+        dropin = os.environ.get("SWEEP_DECODER") == "dropin"   # the reference decoder with its seams served by the library
+        for flags in (((), ("-esbr:0",), ("-dsample:1",), ("-dsample:1", "-esbr:0")) if dropin else ((), ("-esbr:0",))):
             a, b = os.path.join(TMP, "ref.wav"), os.path.join(TMP, "own.wav")
             for f in (a, b):
                 if os.path.exists(f):
                     os.remove(f)
             r1 = subprocess.run([os.path.join(REF, "xaacdec"), "-ifile:" + aac, "-ofile:" + a, *flags], capture_output=True)
-            r2 = subprocess.run([CLI, "-ifile:" + aac, "-ofile:" + b, "-quiet", *flags], capture_output=True, text=True)
+            if dropin:
+                r2 = subprocess.run([os.path.join(REF, "xaacdec_dropin"), "-ifile:" + aac, "-ofile:" + b, *flags], capture_output=True, text=True)
+            else:
+                r2 = subprocess.run([CLI, "-ifile:" + aac, "-ofile:" + b, "-quiet", *flags], capture_output=True, text=True)
             total += 1
             if r1.returncode or not os.path.exists(a):
                 print(name, flags, "reference decoder failed")
