@@ -1112,7 +1112,7 @@ def self_launch(n, launch_check):
     import subprocess
     if not launch_check:
         import torch
-        need_gpus(torch, n)
+        need_gpus(torch, 1 if "--share-device" in sys.argv else n)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -1166,6 +1166,10 @@ def main():
                     help="no decode, no GPU: start the N ranks exactly as a real run does, rendezvous over gloo and run the "
                          "post-run report (per-rank rates + the PCM gather) on host tensors; prints a line that is NOT a "
                          "measurement (tests/test_dist_cpu.py)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="a box with fewer GPUs than ranks: rank r decodes on device r mod the node's count and the ranks meet "
+                         "over gloo on host tensors instead of RCCL (tests/test_dist_gpu.py: the N > 1 path of the HIP product on "
+                         "a one-GPU box; the line says shared_device and is not a scaling measurement)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -1183,10 +1187,16 @@ def main():
         sys.exit("bench.py: --gpus %d but the launcher's WORLD_SIZE is %d" % (args.gpus, world))
     if args.launch_check:
         return launch_check(torch, xdist, rank, world)
-    need_gpus(torch, max(args.gpus, local_rank + 1))
+    shared = bool(args.share_device and world > 1)
+    if shared:
+        need_gpus(torch, 1)
+        local_rank = local_rank % torch.cuda.device_count()
+    else:
+        need_gpus(torch, max(args.gpus, local_rank + 1))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = xdist.init("nccl")       # RCCL; None at world 1
+    dist = xdist.init("gloo" if shared else "nccl")       # RCCL; None at world 1
+    cdev = torch.device("cpu") if shared else dev         # where the collectives' tensors live
     if dist is not None:
         assert dist.get_world_size() == args.gpus and dist.get_rank() == rank
 
@@ -1196,13 +1206,17 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])   # the rank's own GPU, said explicitly
+            if shared:
+                torch.cuda.synchronize()
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])   # the rank's own GPU, said explicitly
         torch.cuda.synchronize()
 
     w = args.workload
     job = Workload(w, torch, libxaac_amd, ctx, dev, stream, args.sets, rank, hip_streams=args.hip_streams)
     own_elapsed, kern_ms = job.run(args.steps, args.warmup, barrier, prewarm=args.prewarm)
-    elapsed = xdist.max_over_ranks(dist, own_elapsed, dev)
+    elapsed = xdist.max_over_ranks(dist, own_elapsed, cdev)
     refused = job.refused()
     max_band_hint = job.batches[0].get("max_band_hint", 0) if w == "c4" else None
     try:
@@ -1214,7 +1228,7 @@ def main():
     per_rank, gather = None, None
     if dist is not None:
         pcm = job.batches[0]["pcm"].view(FRAMES_PER_STEP, -1)
-        per_rank, gather = xdist.post_run_report(dist, pcm, FRAMES_PER_STEP * args.steps / own_elapsed, dev, barrier)
+        per_rank, gather = xdist.post_run_report(dist, pcm.cpu() if shared else pcm, FRAMES_PER_STEP * args.steps / own_elapsed, cdev, barrier)
         assert gather["ok"] is not False, "the gathered PCM differs from the ranks' shards"
 
     secondary = None
@@ -1320,6 +1334,10 @@ def main():
         if per_rank is not None:
             out["per_rank_frames_per_s"] = per_rank
             out["gather"] = gather
+        if shared:
+            out["shared_device"] = ("%d ranks on %d device(s), rendezvous / max-over-ranks / PCM gather over gloo on host tensors: the N > 1 "
+                                    "path of the product on a box with fewer GPUs than ranks -- NOT a scaling measurement"
+                                    % (world, torch.cuda.device_count()))
         if secondary is not None:
             out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:

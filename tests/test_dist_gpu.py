@@ -60,3 +60,26 @@ def test_single_rank_nccl_group_runs_every_collective_of_the_bench():
     out = json.loads(lines[-1][7:])
     assert out["t"] == 1.25 and out["same"] and out["ok"] is True and out["per_rank"] == [123.0]
     assert out["bytes"] == 256 * 1024 * 2
+
+
+@pytest.mark.gpu
+def test_two_ranks_of_the_bench_decode_on_one_gpu():
+    """The N > 1 path of the product on hardware: `bench.py --gpus 2 --share-device` starts two ranks the way the driver's
+    command does (torch.distributed.run, one process per rank); each decodes its own 8192 streams with the HIP library on
+    the box's one GPU, the ranks meet over gloo (barriers, max-over-ranks timing, the per-rank rates, the final PCM gather
+    into rank 0) and rank 0 prints the line.  Rank 0's output is checked against the oracle, the gathered PCM of both against the
+    ranks' checksums.  (RCCL itself runs at world 1 above; with two ranks on one device it refuses.)"""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--steps", "4", "--warmup", "2",
+                        "--no-secondary", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, (r.stdout[-1000:], r.stderr[-1000:])
+    out = json.loads(lines[-1])
+    assert out["n_gpus"] == 2 and "shared_device" in out and out["scaling"] == "weak"
+    assert out["bit_exact_vs_oracle"] is True and out["refused_frac"] == 0.0
+    assert len(out["per_rank_frames_per_s"]) == 2 and all(v > 0 for v in out["per_rank_frames_per_s"])
+    assert out["gather"]["ok"] is True
+    # the whole job's frames over the slower rank's time
+    assert abs(out["value"] - 2 * 8192 * 4 / (out["ms_per_step"] * 4e-3)) / out["value"] < 1e-3
