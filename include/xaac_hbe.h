@@ -8,11 +8,13 @@
  *   xaac_hbe_cplx_anal_batch   <-> ixheaacd_complex_anal_filt   (esbr_polyphase.c:48-155)
  *   xaac_hbe_apply_batch       <-> ixheaacd_qmf_hbe_apply       (hbe_trans.c:224-296)
  *   xaac_hbe_dft_anal_batch_run <-> ixheaacd_dft_hbe_cplx_anal_filt (esbr_polyphase.c:276-338; the DFT transposer's bank)
+ *   xaac_hbe_dft_apply_batch_run <-> ixheaacd_dft_hbe_apply      (hbe_dft_trans.c:771-941; -esbr_hq:1)
  *
  * Scope: the QMF transposer (esbr_hq = 0) at 2:1 SBR of 1024-sample cores: no_bins = 32 QMF columns per frame, bank
- * sizes synth_size = 4, 8, 12, 16, 20 (hbe_trans.c:111-112).  Of the DFT transposer (esbr_hq) only its polyphase bank is
- * built.  All samples are FLOAT32; results are bit-identical to the reference's x86-64 build (float operations in the
- * reference's order, no contraction).
+ * sizes synth_size = 4, 8, 12, 16, 20 (hbe_trans.c:111-112), and the DFT transposer (esbr_hq = 1) at the sizes its
+ * transforms exist for.  All samples are FLOAT32; the QMF transposer's and the banks' results are bit-identical to the
+ * reference's x86-64 build (float operations in the reference's order, no contraction); the DFT transposer's agree to float
+ * rounding (see below).
  */
 #ifndef XAAC_HBE_H
 #define XAAC_HBE_H
@@ -82,6 +84,51 @@ typedef struct xaac_hbe_dft_anal_batch {
   int32_t *status;              /* [n_ch] or NULL */
 } xaac_hbe_dft_anal_batch;
 
+/* ---- the DFT transposer itself (-esbr_hq:1): ixheaacd_dft_hbe_apply, decoder/ixheaacd_hbe_dft_trans.c:771-941 -------------
+ * Per frame: the time-signal shift and the real synthesis bank (esbr_polyphase.c:157, its esbr_hq layout), then eight hops of
+ * window -> real FFT -> polar form -> stretch by 2, 3, 4 with the pitch-adaptive cross products (:576-769) -> inverse real FFT
+ * -> window -> overlap-add, then the analysis bank above.  FLOAT32 samples; atan2 / cos / sin / pow / cbrt / sqrt are the
+ * device's double-precision ones where the reference calls glibc's, and the transforms are this library's own (two-pass
+ * Cooley-Tukey, 16 x N/16) where the reference has hand-unrolled ones: results agree with the reference to float rounding
+ * (tests: relative 2e-5 of the frame's peak), not bit for bit -- the tolerance BASELINE.json's north_star gives float SBR
+ * is +-1 LSB of the 16-bit PCM, which the drop-in test holds the decoded streams to.
+ * Bank sizes: the transforms the reference has (hbe_dft_trans.c:508-549): synth_size 12 or 16 (8 with oversampling),
+ * analy_size 28 or 32; anything else is refused (status -1, state left alone) where the reference fails the frame. */
+#define XAAC_HBE_DFT_MAX_ANA 512 /* ana_fft_size[0] = 32 * synth_size */
+#define XAAC_HBE_DFT_MAX_SYN 512 /* syn_fft_size[0] = 16 * analy_size */
+typedef struct xaac_hbe_dft_state {
+  float input_buf[2 * XAAC_HBE_DFT_MAX_ANA];  /* ptr_input_buf: 2 * ana_fft_size[0] samples in use */
+  float output_buf[4 * XAAC_HBE_DFT_MAX_SYN]; /* ptr_output_buf: 4 * syn_fft_size[0] samples in use */
+  float synth_buf[1280];                      /* the real synthesis bank's delay line */
+  xaac_hbe_dft_anal_state anal;               /* the analysis bank's delay line, analy_size, a_start */
+  int32_t synth_size, k_start;                /* hbe_dft_trans.c:287-288 */
+  int32_t start_band, end_band;               /* :283-284 (not read by the transposer itself) */
+  int32_t max_stretch;                        /* 2 .. 4 */
+  int32_t reserved[3];
+} xaac_hbe_dft_state;
+
+/* What ixheaacd_dft_hbe_data_reinit derives from the SBR frequency tables besides the sizes above: the two time windows and
+   the frequency-domain cross-over windows of the (up to three) patches, for fft_size 1024 and 1536 (oversampling).  Made
+   on the host when a header resets the SBR decoder; channels of one configuration share one. */
+typedef struct xaac_hbe_dft_cfg {
+  float anal_window[XAAC_HBE_DFT_MAX_ANA];  /* anal_window: ana_fft_size[0] coefficients */
+  float synth_window[XAAC_HBE_DFT_MAX_SYN]; /* synth_window: syn_fft_size[0] coefficients */
+  float fd_win[3][2][772];                  /* fd_win_buf[trans_fac - 2][oversampling][0 .. fft_size / 2] */
+} xaac_hbe_dft_cfg;
+
+typedef struct xaac_hbe_dft_apply_batch {
+  int32_t n_ch;
+  const float *qmf_re, *qmf_im;    /* [n_ch][32][64]: the frame's rows of qmf_buf_real / _imag at the transposer's delay */
+  const int32_t *pitch_in_bins;    /* [n_ch] or NULL (all 0) */
+  const int32_t *oversampling;     /* [n_ch] or NULL (all 0): the frame's over_sampling_flag (sbr_dec.c:884) */
+  const xaac_hbe_dft_cfg *cfg_tab; /* [n_cfg] */
+  const float *coef_re, *coef_im;  /* [n_cfg][64][128]: str_dft_hbe_anal_coeff, as in xaac_hbe_dft_anal_batch */
+  const int32_t *cfg;              /* [n_ch] or NULL (all 0) */
+  xaac_hbe_dft_state *state;       /* [n_ch] in/out */
+  float *pv_re, *pv_im;            /* [n_ch][34][64] in/out: ph_vocod_qmf_real / _imag rows as xaac_hbe_dft_anal_batch.qmf_re / _im */
+  int32_t *status;                 /* [n_ch] or NULL: 0, or -1 (sizes outside the reference's transforms): state and rows untouched */
+} xaac_hbe_dft_apply_batch;
+
 typedef struct xaac_hbe_anal_batch {
   int32_t n_ch;
   xaac_hbe_state *state;        /* [n_ch] in/out: input_buf read, analy_buf, qmf_in_buf rows 12..27 written */
@@ -99,6 +146,9 @@ XAAC_API int32_t xaac_hbe_cplx_anal_batch(xaac_ctx *ctx, const xaac_hbe_anal_bat
 
 /* ixheaacd_dft_hbe_cplx_anal_filt (esbr_polyphase.c:276-338) for n_ch channels */
 XAAC_API int32_t xaac_hbe_dft_anal_batch_run(xaac_ctx *ctx, const xaac_hbe_dft_anal_batch *batch);
+
+/* ixheaacd_dft_hbe_apply (hbe_dft_trans.c:771-941) for n_ch channels */
+XAAC_API int32_t xaac_hbe_dft_apply_batch_run(xaac_ctx *ctx, const xaac_hbe_dft_apply_batch *batch);
 
 /* ixheaacd_qmf_hbe_apply (hbe_trans.c:224-296) for n_ch channels: time-signal shift, synthesis bank, analysis bank,
    stretch-by-2/3/4 products into qmf_out_buf (with the pitch-adaptive cross products when pitch_in_bins / 12 >= 1),

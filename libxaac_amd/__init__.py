@@ -178,6 +178,18 @@ class _HbeDftAnalBatch(ctypes.Structure):
 HBE_DFT_STATE_BYTES = 4 * 642   # struct xaac_hbe_dft_anal_state
 
 
+class _HbeDftApplyBatch(ctypes.Structure):
+    # struct xaac_hbe_dft_apply_batch
+    _fields_ = [("n_ch", ctypes.c_int32), ("qmf_re", ctypes.c_void_p), ("qmf_im", ctypes.c_void_p), ("pitch_in_bins", ctypes.c_void_p),
+                ("oversampling", ctypes.c_void_p), ("cfg_tab", ctypes.c_void_p), ("coef_re", ctypes.c_void_p), ("coef_im", ctypes.c_void_p),
+                ("cfg", ctypes.c_void_p), ("state", ctypes.c_void_p), ("pv_re", ctypes.c_void_p), ("pv_im", ctypes.c_void_p),
+                ("status", ctypes.c_void_p)]
+
+
+HBE_DFT_FULL_STATE_BYTES = 4 * (1024 + 2048 + 1280 + 642 + 8)   # struct xaac_hbe_dft_state
+HBE_DFT_CFG_BYTES = 4 * (512 + 512 + 3 * 2 * 772)               # struct xaac_hbe_dft_cfg
+
+
 class _PvcBatch(ctypes.Structure):
     # struct xaac_pvc_batch (include/xaac_pvc.h)
     _fields_ = [("n_ch", ctypes.c_int32), ("frame", ctypes.c_void_p), ("qmf_re", ctypes.c_void_p), ("qmf_im", ctypes.c_void_p),
@@ -317,6 +329,8 @@ def load_library():
     lib.xaac_hbe_dft_anal_batch_run.restype = ctypes.c_int32
     lib.xaac_pvc_process_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_PvcBatch)]
     lib.xaac_pvc_process_batch.restype = ctypes.c_int32
+    lib.xaac_hbe_dft_apply_batch_run.argtypes = [ctypes.c_void_p, ctypes.POINTER(_HbeDftApplyBatch)]
+    lib.xaac_hbe_dft_apply_batch_run.restype = ctypes.c_int32
     lib.xaac_hbe_apply_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_HbeApplyBatch)]
     lib.xaac_hbe_apply_batch.restype = ctypes.c_int32
     lib.xaac_hbe_cplx_anal_batch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_HbeAnalBatch)]
@@ -714,6 +728,31 @@ class XaacContext:
         rc = self._lib.xaac_hbe_dft_anal_batch_run(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_hbe_dft_anal_batch_run")
+
+    def hbe_dft_apply_batch(self, qmf_re, qmf_im, cfg_tab, coef_re, coef_im, state, pv_re, pv_im, status, pitch_in_bins=None,
+                            oversampling=None, cfg=None):
+        """Batched ixheaacd_dft_hbe_apply (the DFT harmonic transposer, -esbr_hq:1): qmf_re / qmf_im float32[n_ch, 32, 64];
+        cfg_tab uint8[n_cfg, HBE_DFT_CFG_BYTES]; coef_re / coef_im float32[n_cfg, 64, 128]; state
+        uint8[n_ch, HBE_DFT_FULL_STATE_BYTES] in/out; pv_re / pv_im float32[n_ch, 34, 64] in/out; status int32[n_ch];
+        pitch_in_bins / oversampling / cfg int32[n_ch] or None."""
+        n_ch = state.shape[0]
+        b = _HbeDftApplyBatch()
+        b.n_ch = n_ch
+        b.qmf_re = _ptr(qmf_re, "float32", n_ch * 2048, device_ok=True)
+        b.qmf_im = _ptr(qmf_im, "float32", n_ch * 2048, device_ok=True)
+        b.pitch_in_bins = _ptr(pitch_in_bins, "int32", n_ch, device_ok=True) if pitch_in_bins is not None else None
+        b.oversampling = _ptr(oversampling, "int32", n_ch, device_ok=True) if oversampling is not None else None
+        b.cfg_tab = _ptr(cfg_tab, "uint8", device_ok=True)
+        b.coef_re = _ptr(coef_re, "float32", device_ok=True)
+        b.coef_im = _ptr(coef_im, "float32", device_ok=True)
+        b.cfg = _ptr(cfg, "int32", n_ch, device_ok=True) if cfg is not None else None
+        b.state = _ptr(state, "uint8", n_ch * HBE_DFT_FULL_STATE_BYTES, device_ok=True)
+        b.pv_re = _ptr(pv_re, "float32", n_ch * 34 * 64, device_ok=True)
+        b.pv_im = _ptr(pv_im, "float32", n_ch * 34 * 64, device_ok=True)
+        b.status = _ptr(status, "int32", n_ch, device_ok=True)
+        rc = self._lib.xaac_hbe_dft_apply_batch_run(self._h, ctypes.byref(b))
+        if rc != 0:
+            raise XaacError(rc, "xaac_hbe_dft_apply_batch_run")
 
     def pvc_process_batch(self, frame, qmf_re, qmf_im, state, out, status=None):
         """Batched PVC envelope decoder (ixheaacd_qmf_enrg_calc + ixheaacd_pvc_process): frame uint8[n_ch, PVC_FRAME_BYTES];

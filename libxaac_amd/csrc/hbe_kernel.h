@@ -72,12 +72,32 @@ typedef struct XaacHbeDftParams {
   xaac_hbe_dft_anal_state *state;
   float *qmf_re, *qmf_im;
   int32_t *status;
+  int32_t state_stride; /* bytes between consecutive channels' states; 0: sizeof(xaac_hbe_dft_anal_state) */
+  int32_t chain;        /* 1: behind xaac_hbe_dft_core_kernel -- a channel that kernel refused (status != 0) is left alone,
+                           status is not written */
 } XaacHbeDftParams;
+
+/* the DFT transposer up to its output signal (hbe_kernel.hip: xaac_hbe_dft_core_kernel; arithmetic: hbe_dft.h): 256 threads
+   per channel-frame.  LDS: the input and output signals, the two transforms' twiddles, and the larger of the synthesis bank's
+   work space (41 columns of 2 s values, 32 x s inputs, 32 x 96 transform words) and the hop's (spectrum, transposed spectrum,
+   magnitude, phase, transform scratch). */
+#define XAAC_HBE_DFT_CORE_THREADS 256
+#define XAAC_HBE_DFT_CORE_U_FLOATS XAAC_HBE_MAX2(41 * 32 + 32 * 16 + 32 * 96, 1536 + 1540 + 772 + 772 + 768)
+#define XAAC_HBE_DFT_CORE_LDS ((2 * XAAC_HBE_DFT_MAX_ANA + 4 * XAAC_HBE_DFT_MAX_SYN + 2 * 768 + XAAC_HBE_DFT_CORE_U_FLOATS) * 4)
+typedef struct XaacHbeDftCoreParams {
+  int32_t n_ch;
+  const float *qmf_re, *qmf_im; /* [n_ch][32][64] */
+  const int32_t *pitch, *oversampling, *cfg;
+  const xaac_hbe_dft_cfg *cfg_tab;
+  xaac_hbe_dft_state *state;
+  int32_t *status;
+} XaacHbeDftCoreParams;
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 hipError_t xaac_launch_hbe_dft_anal(const XaacHbeDftParams *p, hipStream_t stream);
+hipError_t xaac_launch_hbe_dft_core(const XaacHbeDftCoreParams *p, hipStream_t stream);
 hipError_t xaac_launch_hbe_banks(const XaacHbeBanksParams *p, hipStream_t stream);
 hipError_t xaac_launch_hbe_post(const XaacHbePostParams *p, hipStream_t stream);
 #ifdef __cplusplus

@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "hbe_trans.h"
+#include "hbe_dft.h"
 #include "hbe_kernel.h"
 
 #ifdef XE_PROFILE /* tools/prof_hbe_post.py: thread 0's cycles between the hooks of the products kernel, summed over channels */
@@ -336,10 +337,12 @@ __global__ __launch_bounds__(256) void xaac_hbe_dft_anal_kernel(XaacHbeDftParams
   extern __shared__ float lds[];
   float(*u)[128] = reinterpret_cast<float(*)[128]>(lds);
   const int ch = blockIdx.x, tid = threadIdx.x, nb = p.no_bins;
-  xaac_hbe_dft_anal_state *st = p.state + ch;
+  if (p.chain && p.status && p.status[ch] != 0) return;
+  xaac_hbe_dft_anal_state *st = reinterpret_cast<xaac_hbe_dft_anal_state *>(
+      reinterpret_cast<char *>(p.state) + (size_t)ch * (p.state_stride ? (size_t)p.state_stride : sizeof(xaac_hbe_dft_anal_state)));
   const int L = st->analy_size, a0 = st->a_start;
   const bool bad = L < 4 || L > 64 || (L & 3) || a0 < 0 || a0 + L > 64 || nb < 1 || nb > 32;
-  if (tid == 0 && p.status) p.status[ch] = bad ? -1 : 0;
+  if (tid == 0 && p.status && !p.chain) p.status[ch] = bad ? -1 : 0;
   if (bad) return;
   const float *tin = p.time_in + (size_t)ch * p.in_stride, *win = xh_window_dft(L);
   const size_t c = p.cfg ? (size_t)p.cfg[ch] : 0;
@@ -370,6 +373,74 @@ __global__ __launch_bounds__(256) void xaac_hbe_dft_anal_kernel(XaacHbeDftParams
     const int n = tid + 256 * q;
     if (n < 10 * L) st->analy_buf[n] = keep[q];
   }
+}
+
+/* ixheaacd_dft_hbe_apply up to its output signal (hbe_dft_trans.c:771-937): the signals' shifts, the real synthesis bank in
+   its esbr_hq layout (esbr_polyphase.c:170-182: column idx's samples at ana_fft_size[0] + (idx - 1) synth_size), the eight
+   hops.  One workgroup per channel-frame; every loop of hbe_dft.h spreads over the 256 lanes with a barrier per phase.  The
+   analysis bank (xaac_hbe_dft_anal_kernel, chain mode) follows as its own launch on the output signal in the state. */
+__global__ __launch_bounds__(XAAC_HBE_DFT_CORE_THREADS) void xaac_hbe_dft_core_kernel(XaacHbeDftCoreParams p) {
+  extern __shared__ float lds[];
+  const int ch = blockIdx.x, lane = threadIdx.x;
+  constexpr int NT = XAAC_HBE_DFT_CORE_THREADS;
+  xaac_hbe_dft_state *st = p.state + ch;
+  const int ovs = p.oversampling && p.oversampling[ch] ? 1 : 0;
+  const int pitch = p.pitch ? p.pitch[ch] : 0;
+  const xaac_hbe_dft_cfg *cfg = p.cfg_tab + (p.cfg ? p.cfg[ch] : 0);
+  XdSizes z;
+  const bool ok = xd_sizes(st, ovs, &z); /* (uniform: every lane reads the same words) */
+  if (lane == 0 && p.status) p.status[ch] = ok ? 0 : -1;
+  if (!ok) return;
+  float *in = lds, *out = in + 2 * XAAC_HBE_DFT_MAX_ANA;
+  XdC *wa = reinterpret_cast<XdC *>(out + 4 * XAAC_HBE_DFT_MAX_SYN), *ws = wa + 384;
+  float *U = reinterpret_cast<float *>(ws + 384);
+  const int s = z.s, ks = st->k_start;
+  const XhWaveTeam cx = {lane, NT};
+  /* :800-809: the signals move down by a frame; the output's upper half starts from zero */
+  for (int e = lane; e < z.ana0; e += NT) in[e] = st->input_buf[z.ana0 + e];
+  for (int e = 2 * z.ana0 - s + lane; e < 2 * z.ana0; e += NT) in[e] = st->input_buf[e]; /* (what column 32 would write: kept) */
+  for (int e = lane; e < 2 * z.syn0; e += NT) {
+    out[e] = st->output_buf[2 * z.syn0 + e];
+    out[2 * z.syn0 + e] = 0.0f;
+  }
+  { /* the synthesis bank: as xaac_hbe_banks_body's first phase */
+    float *vv = U;                 /* [9 + 32][2 s] */
+    float *xin = vv + 41 * 2 * s;  /* [32][s] */
+    float *work = xin + 32 * s;    /* [32][4 s], [32][96] for the 24-point transforms */
+    for (int e = lane; e < 9 * 2 * s; e += NT) {
+      const int c = -1 - e / (2 * s), t = e % (2 * s);
+      vv[(c + 9) * 2 * s + t] = xh_synth_hist(st->synth_buf, s, c, t);
+    }
+    const float *qre = p.qmf_re + (size_t)ch * 2048, *qim = p.qmf_im + (size_t)ch * 2048;
+    for (int e = lane; e < 32 * s; e += NT) {
+      const int c = e / s, k = e % s;
+      xin[e] = xh_synth_xin(qre + 64 * c, qim + 64 * c, ks, k);
+    }
+    __syncthreads();
+    xh_synth_team(cx, [&](int c, int k) { return xin[s * c + k]; }, [&](int c) { return vv + (c + 9) * 2 * s; }, 32, s, work);
+    const auto at = [&](int c, int t) { return vv[(c + 9) * 2 * s + t]; };
+    for (int o = lane; o < 32 * s; o += NT) in[z.ana0 - s + o] = xh_synth_out(at, s, o / s, o % s);
+    for (int e = lane; e < 20 * s; e += NT) st->synth_buf[e] = vv[(31 - e / (2 * s) + 9) * 2 * s + e % (2 * s)];
+    __syncthreads(); /* vv is dead: the hops' arrays take its place */
+  }
+  XdWork w;
+  w.in = in;
+  w.out = out;
+  w.spec = U;
+  w.tx = U + 1536;
+  w.mag = w.tx + 1540;
+  w.phase = w.mag + 772;
+  w.wa = wa;
+  w.ws = ws;
+  w.tmp = reinterpret_cast<XdC *>(w.phase + 772);
+  xd_hops(cx, z, cfg, ovs, pitch, &w);
+  for (int e = lane; e < 2 * z.ana0; e += NT) st->input_buf[e] = in[e];
+  for (int e = lane; e < 4 * z.syn0; e += NT) st->output_buf[e] = out[e];
+}
+
+extern "C" hipError_t xaac_launch_hbe_dft_core(const XaacHbeDftCoreParams *p, hipStream_t stream) {
+  hipLaunchKernelGGL(xaac_hbe_dft_core_kernel, dim3(p->n_ch), dim3(XAAC_HBE_DFT_CORE_THREADS), XAAC_HBE_DFT_CORE_LDS, stream, *p);
+  return hipGetLastError();
 }
 
 extern "C" hipError_t xaac_launch_hbe_dft_anal(const XaacHbeDftParams *p, hipStream_t stream) {

@@ -566,6 +566,28 @@ int32_t xaac_hbe_dft_anal_batch_run(xaac_ctx *c, const xaac_hbe_dft_anal_batch *
   return XAAC_OK;
 }
 
+int32_t xaac_hbe_dft_apply_batch_run(xaac_ctx *c, const xaac_hbe_dft_apply_batch *b) {
+  if (!c || !b) return XAAC_FATAL_NULL_ARG;
+  if (b->n_ch < 0) return XAAC_FATAL_BAD_ARG;
+  if (b->n_ch == 0) return XAAC_OK;
+  if (!b->qmf_re || !b->qmf_im || !b->cfg_tab || !b->coef_re || !b->coef_im || !b->state || !b->pv_re || !b->pv_im || !b->status)
+    return XAAC_FATAL_NULL_ARG; /* (status is how the second launch learns which channels the first one refused) */
+  if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
+  XaacHbeDftCoreParams pc = {b->n_ch, b->qmf_re, b->qmf_im, b->pitch_in_bins, b->oversampling, b->cfg, b->cfg_tab, b->state, b->status};
+  if (!hip_ok(xaac_launch_hbe_dft_core(&pc, c->stream))) return XAAC_FATAL_HIP;
+  XaacHbeDftParams pa = {};
+  pa.n_ch = b->n_ch; pa.no_bins = XAAC_HBE_NO_BINS;
+  pa.time_in = reinterpret_cast<const float *>(reinterpret_cast<const char *>(b->state) + offsetof(xaac_hbe_dft_state, output_buf));
+  pa.in_stride = (int32_t)(sizeof(xaac_hbe_dft_state) / sizeof(float));
+  pa.coef_re = b->coef_re; pa.coef_im = b->coef_im; pa.cfg = b->cfg;
+  pa.state = reinterpret_cast<xaac_hbe_dft_anal_state *>(reinterpret_cast<char *>(b->state) + offsetof(xaac_hbe_dft_state, anal));
+  pa.state_stride = (int32_t)sizeof(xaac_hbe_dft_state);
+  pa.qmf_re = b->pv_re; pa.qmf_im = b->pv_im; pa.status = b->status; pa.chain = 1;
+  if (!hip_ok(xaac_launch_hbe_dft_anal(&pa, c->stream))) return XAAC_FATAL_HIP;
+  c->last_grid = b->n_ch; c->last_block = XAAC_HBE_DFT_CORE_THREADS; c->last_lds = XAAC_HBE_DFT_CORE_LDS;
+  return XAAC_OK;
+}
+
 int32_t xaac_pvc_process_batch(xaac_ctx *c, const xaac_pvc_batch *b) {
   if (!c || !b) return XAAC_FATAL_NULL_ARG;
   if (b->n_ch < 0 || b->qmf_stride < 32 * 64) return XAAC_FATAL_BAD_ARG;

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "../libxaac_amd/csrc/hbe_trans.h"
+#include "../libxaac_amd/csrc/hbe_dft.h"
 
 extern "C" {
 
@@ -71,6 +72,41 @@ int xo_hbe_dft_anal(xaac_hbe_dft_anal_state *st, const float *time_in, const flo
 }
 
 /* test coverage: how many (band, column) pairs took a cross product, per stretch factor, since the last reset */
+/* ixheaacd_dft_hbe_apply (hbe_dft_trans.c:771-941): the sequential run of libxaac_amd/csrc/hbe_dft.h.  qmf_re / qmf_im: [32][64];
+   pv_re / pv_im: [34][64] in/out (as xo_hbe_dft_anal).  Pinned against the compiled reference to float rounding, not bit for
+   bit (include/xaac_hbe.h says why): tests/test_hbe_dft.py.  Returns 0, or -1 for sizes the reference has no transforms for. */
+int xo_hbe_dft_apply(xaac_hbe_dft_state *st, const xaac_hbe_dft_cfg *cfg, const float *coef_re, const float *coef_im, const float *qmf_re,
+                     const float *qmf_im, int pitch_in_bins, int oversampling, float *pv_re, float *pv_im) {
+  XdSizes z;
+  const int ovs = oversampling ? 1 : 0;
+  if (!xd_sizes(st, ovs, &z)) return -1;
+  const XhSeq cx = {0, 1};
+  const int s = z.s, ks = st->k_start;
+  /* :800-802 */
+  memmove(st->input_buf, st->input_buf + z.ana0, sizeof(float) * z.ana0);
+  { /* ixheaacd_real_synth_filt with esbr_hq = 1 (esbr_polyphase.c:170-182): column idx's samples land at ana0 + (idx - 1) s */
+    static thread_local float v[32 + 9][40], wk[XH_FFT_SCRATCH];
+    for (int c = -9; c < 0; c++)
+      for (int t = 0; t < 2 * s; t++) v[c + 9][t] = xh_synth_hist(st->synth_buf, s, c, t);
+    for (int idx = 0; idx < 32; idx++) xh_synth_column(qmf_re + 64 * idx, qmf_im + 64 * idx, s, ks, v[idx + 9], wk);
+    const auto vv = [&](int c, int t) { return v[c + 9][t]; };
+    for (int idx = 0; idx < 32; idx++)
+      for (int i = 0; i < s; i++) st->input_buf[z.ana0 + (idx - 1) * s + i] = xh_synth_out(vv, s, idx, i);
+    float nb[400];
+    for (int m = 0; m < 10; m++)
+      for (int t = 0; t < 2 * s; t++) nb[2 * s * m + t] = v[31 - m + 9][t];
+    memcpy(st->synth_buf, nb, sizeof(float) * 20 * s);
+  }
+  /* :805-809 */
+  memmove(st->output_buf, st->output_buf + 2 * z.syn0, sizeof(float) * 2 * z.syn0);
+  memset(st->output_buf + 2 * z.syn0, 0, sizeof(float) * 2 * z.syn0);
+  static thread_local float spec[1536], tx[1536 + 2], mag[768 + 2], phase[768 + 2];
+  static thread_local XdC wa[384], ws[384], tmp[384];
+  const XdWork w = {st->input_buf, st->output_buf, spec, tx, mag, phase, wa, ws, tmp};
+  xd_hops(cx, z, cfg, ovs, pitch_in_bins, &w);
+  return xo_hbe_dft_anal(&st->anal, st->output_buf, coef_re, coef_im, 32, pv_re, pv_im);
+}
+
 static long xo_hbe_cross_taken[3];
 long xo_hbe_cross_count(int factor, int reset) {
   const long v = xo_hbe_cross_taken[factor - 2];

@@ -179,3 +179,73 @@ int ref_hbe_dft_anal(const int16_t *tbl_lo, int n_lo, const int16_t *tbl_hi, int
   memcpy(st->analy_buf, hbe_t.analy_buf, sizeof(st->analy_buf));
   return i;
 }
+
+WORD32 ixheaacd_dft_hbe_apply(ia_esbr_hbe_txposer_struct *ptr_hbe_txposer, FLOAT32 qmf_buf_real[][64], FLOAT32 qmf_buf_imag[][64],
+                              WORD32 num_columns, FLOAT32 pv_qmf_buf_real[][64], FLOAT32 pv_qmf_buf_imag[][64], WORD32 pitch_in_bins,
+                              FLOAT32 *dft_hbe_scratch_buf);
+
+/* the DFT transposer the reference sets up from two frequency tables (ixheaacd_dft_hbe_data_reinit): sizes into st, windows
+   into cfg, the analysis bank's coefficient matrices into coef_re / coef_im ([64][128]).  max_stretch goes in through st (the
+   reference keeps the old value when four patches fit below the end band) and comes back as derived. */
+static int hbe_dft_setup(const int16_t *tbl_lo, int n_lo, const int16_t *tbl_hi, int n_hi, int max_stretch_in) {
+  WORD32 used = 0;
+  int i;
+  static __thread WORD16 lo[64], hi[64], nsf[2];
+  WORD16 *tab[2];
+  if (n_lo < 0 || n_lo > 62 || n_hi < 0 || n_hi > 62) return -1;
+  ixheaacd_esbr_hbe_data_init(&hbe_t, 1024, 0, 2048, hbe_mem, &used);
+  for (i = 0; i <= n_lo; i++) lo[i] = tbl_lo[i];
+  for (i = 0; i <= n_hi; i++) hi[i] = tbl_hi[i];
+  nsf[0] = (WORD16)n_lo;
+  nsf[1] = (WORD16)n_hi;
+  tab[0] = lo;
+  tab[1] = hi;
+  hbe_t.max_stretch = max_stretch_in;
+  return ixheaacd_dft_hbe_data_reinit(&hbe_t, tab, nsf) ? -1 : 0;
+}
+
+int ref_hbe_dft_reinit(const int16_t *tbl_lo, int n_lo, const int16_t *tbl_hi, int n_hi, xaac_hbe_dft_state *st, xaac_hbe_dft_cfg *cfg,
+                       float *coef_re, float *coef_im) {
+  int t, o;
+  if (hbe_dft_setup(tbl_lo, n_lo, tbl_hi, n_hi, st->max_stretch)) return -1;
+  st->synth_size = hbe_t.synth_size;
+  st->k_start = hbe_t.k_start;
+  st->start_band = hbe_t.start_band;
+  st->end_band = hbe_t.end_band;
+  st->max_stretch = hbe_t.max_stretch;
+  st->anal.analy_size = hbe_t.analy_size;
+  st->anal.a_start = hbe_t.a_start;
+  memset(cfg, 0, sizeof(*cfg));
+  if (hbe_t.ana_fft_size[0] > XAAC_HBE_DFT_MAX_ANA || hbe_t.syn_fft_size[0] > XAAC_HBE_DFT_MAX_SYN) return -4;
+  memcpy(cfg->anal_window, hbe_t.analysis_window_buf, sizeof(float) * hbe_t.ana_fft_size[0]);
+  memcpy(cfg->synth_window, hbe_t.synthesis_window_buf, sizeof(float) * hbe_t.syn_fft_size[0]);
+  for (t = 0; t < 3; t++)
+    for (o = 0; o < 2; o++) memcpy(cfg->fd_win[t][o], hbe_t.fd_win_buf[t][o], sizeof(cfg->fd_win[t][o]));
+  memcpy(coef_re, hbe_t.str_dft_hbe_anal_coeff.real, sizeof(hbe_t.str_dft_hbe_anal_coeff.real));
+  memcpy(coef_im, hbe_t.str_dft_hbe_anal_coeff.imag, sizeof(hbe_t.str_dft_hbe_anal_coeff.imag));
+  return 0;
+}
+
+/* ixheaacd_dft_hbe_apply on a transposer set up from the tables, with st's signals and delay lines; pv_re / pv_im: [34][64]
+   in/out.  -2: the tables do not give st's sizes. */
+int ref_hbe_dft_apply(const int16_t *tbl_lo, int n_lo, const int16_t *tbl_hi, int n_hi, int max_stretch_before, xaac_hbe_dft_state *st,
+                      const float *qmf_re, const float *qmf_im, int pitch_in_bins, int oversampling, float *pv_re, float *pv_im) {
+  static __thread FLOAT32 scratch[16384];
+  int rc;
+  if (hbe_dft_setup(tbl_lo, n_lo, tbl_hi, n_hi, max_stretch_before)) return -1;
+  if (hbe_t.synth_size != st->synth_size || hbe_t.k_start != st->k_start || hbe_t.max_stretch != st->max_stretch ||
+      hbe_t.analy_size != st->anal.analy_size || hbe_t.a_start != st->anal.a_start)
+    return -2;
+  memcpy(hbe_t.ptr_input_buf, st->input_buf, sizeof(st->input_buf));
+  memcpy(hbe_t.output_buf, st->output_buf, sizeof(st->output_buf));
+  memcpy(hbe_t.synth_buf, st->synth_buf, sizeof(st->synth_buf));
+  memcpy(hbe_t.analy_buf, st->anal.analy_buf, sizeof(st->anal.analy_buf));
+  hbe_t.oversampling_flag = oversampling ? 1 : 0;
+  rc = ixheaacd_dft_hbe_apply(&hbe_t, (FLOAT32(*)[64])qmf_re, (FLOAT32(*)[64])qmf_im, XAAC_HBE_NO_BINS, (FLOAT32(*)[64])pv_re,
+                              (FLOAT32(*)[64])pv_im, pitch_in_bins, scratch);
+  memcpy(st->input_buf, hbe_t.ptr_input_buf, sizeof(st->input_buf));
+  memcpy(st->output_buf, hbe_t.output_buf, sizeof(st->output_buf));
+  memcpy(st->synth_buf, hbe_t.synth_buf, sizeof(st->synth_buf));
+  memcpy(st->anal.analy_buf, hbe_t.analy_buf, sizeof(st->anal.analy_buf));
+  return rc;
+}
