@@ -44,7 +44,7 @@ static struct {
   xaac_esbr_pvc_state *pvst;
 } g;
 static long g_eld_ana_calls, g_eld_syn_calls;
-static long g_usac_fac_dev, g_sbr_ds_calls, g_esbr_ds_calls;
+static long g_usac_fac_dev, g_sbr_ds_calls, g_esbr_ds_calls, g_dft_calls, g_dft_ref_calls;
 static long g_imdct_calls, g_sbr_calls, g_lim_calls, g_esbr_calls, g_esbr_harm_calls, g_esbr_usac_calls, g_esbr_pvc_calls, g_esbr_83_calls, g_esbr_41_calls, g_sbr_ref_calls, g_usac_imdct_calls, g_usac_imdct_fac, g_usac_imdct_lpd, g_eld_sbr_calls, g_imdct960_calls, g_imdct_ld_calls;
 static struct { int32_t *overlap; int16_t *pcm; uint8_t *shape; } gl; /* AAC-LD / ELD: 3 x 512 overlap words, 512 samples, 2 bytes */
 
@@ -70,6 +70,8 @@ static void report(void) {
           g_usac_imdct_fac, g_usac_imdct_lpd);
   fprintf(stderr, "xaacdec_dropin: %ld FAC signals made on the device (ixheaacd_cal_fac_data)\n", g_usac_fac_dev);
   fprintf(stderr, "xaacdec_dropin: %ld of the USAC calls were PVC frames (PVC decoder + the adjuster's PVC branch on the GPU)\n", g_esbr_pvc_calls);
+  fprintf(stderr, "xaacdec_dropin: %ld dft_hbe_apply calls (-esbr_hq:1: the DFT harmonic transposer) ran on the GPU, %ld left to the reference\n", g_dft_calls,
+          g_dft_ref_calls);
   fprintf(stderr, "xaacdec_dropin: %ld of the USAC calls at 8:3 SBR (24-channel bank), %ld at 4:1 (16-channel bank, 64 slots)\n", g_esbr_83_calls, g_esbr_41_calls);
 }
 
@@ -820,4 +822,95 @@ VOID __wrap_ixheaacd_peak_limiter_process(ia_peak_limiter_struct *lim, VOID *sam
     memcpy(delayed, st.delayed_input, (size_t)a * nch * sizeof(FLOAT32));
   }
   g_lim_calls++;
+}
+
+
+/* ---- -esbr_hq:1: the DFT harmonic transposer (ixheaacd_dft_hbe_apply, hbe_dft_trans.c:771; call sites sbr_dec.c:884 and the
+   reset-time one in sbrdecoder.c) -> xaac_hbe_dft_apply_batch_run.  The rest of such a frame's sbr_dec call stays the
+   reference's (the Path A hook above leaves esbr_hq frames alone).  The transposer's signals and delay lines live in the
+   reference's struct between calls; the windows and the analysis bank's matrices its re-initialisation made go up with every
+   call (a test harness: 90 KB a call). */
+WORD32 __real_ixheaacd_dft_hbe_apply(ia_esbr_hbe_txposer_struct *t, FLOAT32 qre[][64], FLOAT32 qim[][64], WORD32 num_columns, FLOAT32 pvr[][64],
+                                     FLOAT32 pvi[][64], WORD32 pitch_in_bins, FLOAT32 *scratch);
+WORD32 __wrap_ixheaacd_dft_hbe_apply(ia_esbr_hbe_txposer_struct *t, FLOAT32 qre[][64], FLOAT32 qim[][64], WORD32 num_columns, FLOAT32 pvr[][64],
+                                     FLOAT32 pvi[][64], WORD32 pitch_in_bins, FLOAT32 *scratch) {
+  static xaac_hbe_dft_state st;
+  static xaac_hbe_dft_cfg cfg;
+  static struct { xaac_hbe_dft_state *st; xaac_hbe_dft_cfg *cfg; float *coef, *q, *pv; int32_t *par; } d;
+  xaac_hbe_dft_apply_batch b;
+  int32_t par[3], status = 0;
+  int tr, o;
+  const int ana0 = t->ana_fft_size[0], syn0 = t->syn_fft_size[0];
+  if (num_columns != 32 || ana0 < 0 || ana0 > XAAC_HBE_DFT_MAX_ANA || syn0 < 0 || syn0 > XAAC_HBE_DFT_MAX_SYN || ana0 != 32 * t->synth_size ||
+      syn0 != 16 * t->analy_size || getenv("XAAC_DROPIN_NO_DFT")) {
+    g_dft_ref_calls++;
+    return __real_ixheaacd_dft_hbe_apply(t, qre, qim, num_columns, pvr, pvi, pitch_in_bins, scratch);
+  }
+  setup();
+  if (!d.st) {
+    HIP(hipMalloc((void **)&d.st, sizeof(st)));
+    HIP(hipMalloc((void **)&d.cfg, sizeof(cfg)));
+    HIP(hipMalloc((void **)&d.coef, 2 * 64 * 128 * 4));
+    HIP(hipMalloc((void **)&d.q, 2 * 2048 * 4));
+    HIP(hipMalloc((void **)&d.pv, 2 * 34 * 64 * 4));
+    HIP(hipMalloc((void **)&d.par, 16));
+  }
+  memset(&st, 0, sizeof(st));
+  memcpy(st.input_buf, t->ptr_input_buf, sizeof(float) * 2 * ana0);
+  memcpy(st.output_buf, t->ptr_output_buf, sizeof(float) * 4 * syn0);
+  memcpy(st.synth_buf, t->synth_buf, sizeof(st.synth_buf));
+  memcpy(st.anal.analy_buf, t->analy_buf, sizeof(st.anal.analy_buf));
+  st.anal.analy_size = t->analy_size;
+  st.anal.a_start = t->a_start;
+  st.synth_size = t->synth_size;
+  st.k_start = t->k_start;
+  st.start_band = t->start_band;
+  st.end_band = t->end_band;
+  st.max_stretch = t->max_stretch;
+  memset(&cfg, 0, sizeof(cfg));
+  memcpy(cfg.anal_window, t->anal_window, sizeof(float) * ana0);
+  memcpy(cfg.synth_window, t->synth_window, sizeof(float) * syn0);
+  for (tr = 0; tr < 3; tr++)
+    for (o = 0; o < 2; o++) memcpy(cfg.fd_win[tr][o], t->fd_win_buf[tr][o], sizeof(cfg.fd_win[tr][o]));
+  par[0] = pitch_in_bins;
+  par[1] = t->oversampling_flag ? 1 : 0;
+  par[2] = 0;
+  HIP(hipMemcpy(d.st, &st, sizeof(st), hipMemcpyHostToDevice));
+  HIP(hipMemcpy(d.cfg, &cfg, sizeof(cfg), hipMemcpyHostToDevice));
+  HIP(hipMemcpy(d.coef, t->str_dft_hbe_anal_coeff.real, 64 * 128 * 4, hipMemcpyHostToDevice));
+  HIP(hipMemcpy(d.coef + 64 * 128, t->str_dft_hbe_anal_coeff.imag, 64 * 128 * 4, hipMemcpyHostToDevice));
+  HIP(hipMemcpy(d.q, qre, 2048 * 4, hipMemcpyHostToDevice));
+  HIP(hipMemcpy(d.q + 2048, qim, 2048 * 4, hipMemcpyHostToDevice));
+  HIP(hipMemcpy(d.pv, pvr, 34 * 64 * 4, hipMemcpyHostToDevice));
+  HIP(hipMemcpy(d.pv + 34 * 64, pvi, 34 * 64 * 4, hipMemcpyHostToDevice));
+  HIP(hipMemcpy(d.par, par, sizeof(par), hipMemcpyHostToDevice));
+  memset(&b, 0, sizeof(b));
+  b.n_ch = 1;
+  b.qmf_re = d.q;
+  b.qmf_im = d.q + 2048;
+  b.pitch_in_bins = d.par;
+  b.oversampling = d.par + 1;
+  b.cfg_tab = d.cfg;
+  b.coef_re = d.coef;
+  b.coef_im = d.coef + 64 * 128;
+  b.state = d.st;
+  b.pv_re = d.pv;
+  b.pv_im = d.pv + 34 * 64;
+  b.status = d.par + 2;
+  if (xaac_hbe_dft_apply_batch_run(g_ctx, &b) != XAAC_OK) die("xaac_hbe_dft_apply_batch_run");
+  HIP(hipDeviceSynchronize());
+  HIP(hipMemcpy(&status, d.par + 2, 4, hipMemcpyDeviceToHost));
+  if (status) { /* sizes without a transform: the reference fails the frame itself */
+    g_dft_ref_calls++;
+    return __real_ixheaacd_dft_hbe_apply(t, qre, qim, num_columns, pvr, pvi, pitch_in_bins, scratch);
+  }
+  HIP(hipMemcpy(&st, d.st, sizeof(st), hipMemcpyDeviceToHost));
+  HIP(hipMemcpy(pvr, d.pv, 34 * 64 * 4, hipMemcpyDeviceToHost));
+  HIP(hipMemcpy(pvi, d.pv + 34 * 64, 34 * 64 * 4, hipMemcpyDeviceToHost));
+  memcpy(t->ptr_input_buf, st.input_buf, sizeof(float) * 2 * ana0);
+  memcpy(t->ptr_output_buf, st.output_buf, sizeof(float) * 4 * syn0);
+  memcpy(t->synth_buf, st.synth_buf, sizeof(st.synth_buf));
+  memcpy(t->analy_buf, st.anal.analy_buf, sizeof(st.anal.analy_buf));
+  g_dft_calls++;
+  return 0;
 }

@@ -153,7 +153,9 @@ def test_hbe_struct_layouts_match_header(tmp_path):
     pairs = [("xaac_hbe_state", hs.HbeState, "max_stretch"), ("xaac_hbe_synth_batch", libxaac_amd._HbeSynthBatch, "status"),
              ("xaac_hbe_anal_batch", libxaac_amd._HbeAnalBatch, "status"),
              ("xaac_hbe_apply_batch_desc", libxaac_amd._HbeApplyBatch, "status"),
-             ("xaac_hbe_dft_anal_batch", libxaac_amd._HbeDftAnalBatch, "status"), ("xaac_hbe_dft_anal_state", hs.HbeDftState, "a_start")]
+             ("xaac_hbe_dft_anal_batch", libxaac_amd._HbeDftAnalBatch, "status"), ("xaac_hbe_dft_anal_state", hs.HbeDftState, "a_start"),
+             ("xaac_hbe_dft_state", hs.HbeDftFullState, "max_stretch"), ("xaac_hbe_dft_cfg", hs.HbeDftCfg, "fd_win"),
+             ("xaac_hbe_dft_apply_batch", libxaac_amd._HbeDftApplyBatch, "status")]
     body = "".join('printf("%%zu %%zu\\n", sizeof(%s), offsetof(%s, %s));' % (c, c, last) for c, _, last in pairs)
     src = tmp_path / "layout3.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "xaac_hbe.h"\nint main(void) { %s return 0; }\n' % body)
@@ -165,6 +167,7 @@ def test_hbe_struct_layouts_match_header(tmp_path):
         want += [ctypes.sizeof(cls), getattr(cls, last).offset]
     assert got == want
     assert ctypes.sizeof(hs.HbeState) == libxaac_amd.HBE_STATE_BYTES
+    assert (ctypes.sizeof(hs.HbeDftFullState), ctypes.sizeof(hs.HbeDftCfg)) == (libxaac_amd.HBE_DFT_FULL_STATE_BYTES, libxaac_amd.HBE_DFT_CFG_BYTES)
     src2 = tmp_path / "layout4.c"
     src2.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "xaac_amd.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", '
                     'sizeof(xaac_qmf_ana_eld_state), offsetof(xaac_qmf_ana_eld_state, fp), sizeof(xaac_qmf_ana_eld_batch), '

@@ -237,3 +237,34 @@ def test_wider_streams_through_the_same_seams(aac, flags, tmp_path):
         assert n960 > 40 and n_imdct == n_sbr == n_esbr == 0 and (not flags or n_left > 40), log[-900:]
     a, b = open(ref_wav, "rb").read(), open(gpu_wav, "rb").read()
     assert len(a) > 100000 and a == b, (len(a), len(b))
+
+
+@pytest.mark.parametrize("aac", [s for s in STREAMS if "aot5_" in s or "aot29_" in s], ids=lambda s: os.path.basename(s))
+def test_dft_harmonic_transposer_behind_the_reference_decoder(aac, tmp_path):
+    """-esbr_hq:1: every ixheaacd_dft_hbe_apply call of the reference decoder (hbe_dft_trans.c:771; one per channel and frame, two
+    more where a header resets the SBR decoder) served by xaac_hbe_dft_apply_batch_run.  This path is float with libm calls and
+    transforms of the library's own: the decoded file is held to the tolerance BASELINE.json's north_star gives float SBR --
+    every 16-bit sample within 1 LSB of the unmodified decoder's -- and in fact most streams come out identical (the
+    transposer's rows are only read where the stream asks for harmonic patching: harm_aot5_48k, 0.1 % of its samples off by one)."""
+    import wave
+    import numpy as np
+    if not (os.path.exists(os.path.join(REF, "xaacdec")) and os.path.exists(os.path.join(REF, "xaacdec_dropin"))):
+        pytest.fail("oracle/_ref/xaacdec[_dropin] missing: the reference binaries did not travel with the snapshot")
+    ref_wav, gpu_wav = str(tmp_path / "ref.wav"), str(tmp_path / "gpu.wav")
+    _decode("xaacdec", aac, ref_wav, extra=("-esbr_hq:1",))
+    log = _decode("xaacdec_dropin", aac, gpu_wav, extra=("-esbr_hq:1",))
+    m = re.search(r"(\d+) dft_hbe_apply calls .* ran on the GPU, (\d+) left to the reference", log)
+    assert m and int(m.group(1)) > 30 and int(m.group(2)) == 0, log[-800:]
+
+    def samples(path):
+        with wave.open(path) as w:
+            return w.getnchannels(), w.getframerate(), np.frombuffer(w.readframes(w.getnframes()), np.int16).astype(np.int32)
+    a, b = samples(ref_wav), samples(gpu_wav)
+    assert a[:2] == b[:2] and a[2].size == b[2].size and a[2].size > 50000
+    d = np.abs(a[2] - b[2])
+    assert d.max() <= 1 and (d != 0).mean() < 0.005, (int(d.max()), float((d != 0).mean()))
+    # and the flag does change the decode where the stream uses harmonic patching
+    if "harm_" in aac:
+        plain = str(tmp_path / "plain.wav")
+        _decode("xaacdec", aac, plain, extra=())
+        assert not np.array_equal(samples(plain)[2], a[2])

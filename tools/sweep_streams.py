@@ -80,7 +80,13 @@ def main():
             print(name, "encoder refused")
             continue
         dropin = os.environ.get("SWEEP_DECODER") == "dropin"   # the reference decoder with its seams served by the library
-        for flags in (((), ("-esbr:0",), ("-dsample:1",), ("-dsample:1", "-esbr:0")) if dropin else ((), ("-esbr:0",))):
+        flag_sets = ((), ("-esbr:0",), ("-dsample:1",), ("-dsample:1", "-esbr:0")) if dropin else ((), ("-esbr:0",))
+        tol = int(os.environ.get("SWEEP_TOL", "0"))   # largest sample difference taken as equal (float paths: +-1 LSB)
+        if os.environ.get("SWEEP_FLAGS"):             # one flag set instead, e.g. "-esbr_hq:1"
+            flag_sets = (tuple(os.environ["SWEEP_FLAGS"].split()),)
+            if aot == 2:
+                continue
+        for flags in flag_sets:
             a, b = os.path.join(TMP, "ref.wav"), os.path.join(TMP, "own.wav")
             for f in (a, b):
                 if os.path.exists(f):
@@ -101,6 +107,10 @@ def main():
             pa, pb = payload(a), payload(b)
             if pa == pb:
                 print(name, flags, "identical", pa[0], "ch", pa[1], "Hz", len(pa[2]) // (2 * pa[0]), "samples")
+            elif tol and pa[:2] == pb[:2] and len(pa[2]) == len(pb[2]) and \
+                    int(np.abs(np.frombuffer(pa[2], np.int16).astype(int) - np.frombuffer(pb[2], np.int16)).max()) <= tol:
+                nd = int((np.frombuffer(pa[2], np.int16) != np.frombuffer(pb[2], np.int16)).sum())
+                print(name, flags, "identical within", tol, "LSB:", nd, "of", len(pa[2]) // 2, "samples differ")
             else:
                 bad += 1
                 if pa[:2] != pb[:2] or len(pa[2]) != len(pb[2]):
