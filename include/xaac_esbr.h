@@ -30,7 +30,8 @@
    of qmf_re / qmf_im are zero between frames, as in the reference's buffer).  XAAC_ESBR_SKIP_ADJUST: the frame's sbr_mode is
    not ORIG_SBR (UNKNOWN_SBR in a USAC channel's first frames): the HF generator runs, the envelope adjuster only does its
    reset and its end-of-frame bookkeeping (esbr_envcal.c:646: every envelope's work is inside `if (sbr_mode == ORIG_SBR)`). */
-enum { XAAC_ESBR_HARMONIC = 1, XAAC_ESBR_PRE_FLATTEN = 2, XAAC_ESBR_USAC = 4, XAAC_ESBR_NO_X_DELAY = 8, XAAC_ESBR_SKIP_ADJUST = 16 };
+enum { XAAC_ESBR_HARMONIC = 1, XAAC_ESBR_PRE_FLATTEN = 2, XAAC_ESBR_USAC = 4, XAAC_ESBR_NO_X_DELAY = 8, XAAC_ESBR_SKIP_ADJUST = 16,
+       XAAC_ESBR_OVERSAMPLING = 32 /* frame: over_sampling_flag (read by the DFT transposer only, sbr_dec.c:884) */ };
 
 /* Per-frame side info: ia_sbr_header_data_struct / ia_freq_band_data_struct / ia_sbr_frame_info_data_struct members
  * (decoder/ixheaacd_env_extr_part.h:33-100, ixheaacd_env_extr.h:54-120) the float path reads and the fixed path does not. */
@@ -152,6 +153,14 @@ typedef struct xaac_esbr_sbr_batch {
   int32_t down_sample;              /* 1: the down-sampled synthesis bank(s) (32 channels; the reference's -dsample:1, or an output rate above
                                        48 kHz, sbrdec_initfuncs.c:622): out / out_r rows hold half the samples (1024; 2048 at 4:1), at the
                                        same row pitch */
+  /* -esbr_hq:1: the DFT harmonic transposer (xaac_hbe.h: xaac_hbe_dft_state) in the place of the QMF one -- hand in these
+     INSTEAD of hbe_state (all NULL otherwise).  ixheaacd_dft_hbe_apply runs on each processed frame (sbr_dec.c:880-892), with the
+     frame's pitch_in_bins and XAAC_ESBR_OVERSAMPLING flag; the limiter bands take hbe_dft_state's x_over_qmf.  A channel whose
+     sizes have no transform (hbe_dft_state.last_status -1) is refused for a frame that asks for harmonic patching. */
+  xaac_hbe_dft_state *hbe_dft_state;       /* [n_ch] in/out */
+  const xaac_hbe_dft_cfg *hbe_dft_cfg_tab; /* [n_cfg] */
+  const float *hbe_dft_coef_re, *hbe_dft_coef_im; /* [n_cfg][64][128] */
+  const int32_t *hbe_dft_cfg;              /* [n_ch] or NULL (all 0) */
 } xaac_esbr_sbr_batch;
 enum { XAAC_ESBR_RATIO_2_1 = 0, XAAC_ESBR_RATIO_8_3 = 1, XAAC_ESBR_RATIO_4_1 = 2 };
 

@@ -93,7 +93,8 @@ typedef struct xaac_hbe_dft_anal_batch {
  * (tests: relative 2e-5 of the frame's peak), not bit for bit -- the tolerance BASELINE.json's north_star gives float SBR
  * is +-1 LSB of the 16-bit PCM, which the drop-in test holds the decoded streams to.
  * Bank sizes: the transforms the reference has (hbe_dft_trans.c:508-549): synth_size 12 or 16 (8 with oversampling),
- * analy_size 28 or 32; anything else is refused (status -1, state left alone) where the reference fails the frame. */
+ * analy_size 28 or 32; anything else is refused (status -1, state left alone but for last_status) where the reference fails the
+ * frame. */
 #define XAAC_HBE_DFT_MAX_ANA 512 /* ana_fft_size[0] = 32 * synth_size */
 #define XAAC_HBE_DFT_MAX_SYN 512 /* syn_fft_size[0] = 16 * analy_size */
 typedef struct xaac_hbe_dft_state {
@@ -104,7 +105,10 @@ typedef struct xaac_hbe_dft_state {
   int32_t synth_size, k_start;                /* hbe_dft_trans.c:287-288 */
   int32_t start_band, end_band;               /* :283-284 (not read by the transposer itself) */
   int32_t max_stretch;                        /* 2 .. 4 */
-  int32_t reserved[3];
+  int32_t x_over_qmf[6];                      /* the patches' cross-over bands (:399-445): not read by the transposer; the envelope
+                                                 adjuster's limiter bands take them inside the Path A chain (xaac_esbr.h) */
+  int32_t last_status;                        /* written by every call: 0, or -1 where the sizes had no transform (the chain's
+                                                 later stages read it) */
 } xaac_hbe_dft_state;
 
 /* What ixheaacd_dft_hbe_data_reinit derives from the SBR frequency tables besides the sizes above: the two time windows and
@@ -126,7 +130,7 @@ typedef struct xaac_hbe_dft_apply_batch {
   const int32_t *cfg;              /* [n_ch] or NULL (all 0) */
   xaac_hbe_dft_state *state;       /* [n_ch] in/out */
   float *pv_re, *pv_im;            /* [n_ch][34][64] in/out: ph_vocod_qmf_real / _imag rows as xaac_hbe_dft_anal_batch.qmf_re / _im */
-  int32_t *status;                 /* [n_ch] or NULL: 0, or -1 (sizes outside the reference's transforms): state and rows untouched */
+  int32_t *status;                 /* [n_ch]: 0, or -1 (sizes outside the reference's transforms): state (but last_status) and rows untouched */
 } xaac_hbe_dft_apply_batch;
 
 typedef struct xaac_hbe_anal_batch {

@@ -73,7 +73,8 @@ class _EsbrSbrBatch(ctypes.Structure):
                 ("out_r", ctypes.c_void_p), ("status", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
                 ("workspace_bytes", ctypes.c_uint64), ("hbe_state", ctypes.c_void_p), ("hbe_max_synth_size", ctypes.c_int32),
                 ("pvc_side", ctypes.c_void_p), ("pvc_state", ctypes.c_void_p), ("sbr_ratio", ctypes.c_int32),
-                ("down_sample", ctypes.c_int32)]
+                ("down_sample", ctypes.c_int32), ("hbe_dft_state", ctypes.c_void_p), ("hbe_dft_cfg_tab", ctypes.c_void_p),
+                ("hbe_dft_coef_re", ctypes.c_void_p), ("hbe_dft_coef_im", ctypes.c_void_p), ("hbe_dft_cfg", ctypes.c_void_p)]
 
 
 ESBR_RATIO_2_1, ESBR_RATIO_8_3, ESBR_RATIO_4_1 = 0, 1, 2   # xaac_esbr.h: XAAC_ESBR_RATIO_*
@@ -186,7 +187,7 @@ class _HbeDftApplyBatch(ctypes.Structure):
                 ("status", ctypes.c_void_p)]
 
 
-HBE_DFT_FULL_STATE_BYTES = 4 * (1024 + 2048 + 1280 + 642 + 8)   # struct xaac_hbe_dft_state
+HBE_DFT_FULL_STATE_BYTES = 4 * (1024 + 2048 + 1280 + 642 + 12)   # struct xaac_hbe_dft_state
 HBE_DFT_CFG_BYTES = 4 * (512 + 512 + 3 * 2 * 772)               # struct xaac_hbe_dft_cfg
 
 
@@ -563,14 +564,16 @@ class XaacContext:
 
     def esbr_sbr_process_batch(self, core, header, frame, side, state, out, workspace, status=None, ps_frame=None,
                                ps_state=None, out_r=None, hbe_state=None, hbe_max_synth_size=0, pvc_side=None, pvc_state=None,
-                               sbr_ratio=0, down_sample=False):
+                               sbr_ratio=0, down_sample=False, hbe_dft=None):
         """One frame of every channel through the Path A (eSBR, -esbr:1) branch of ixheaacd_sbr_dec, mono / stereo
         channels without PS: core float32[n_ch, 1024]; header / frame / side / state uint8 views of the xaac_sbr_header,
         xaac_sbr_frame, xaac_esbr_side, xaac_esbr_state arrays; out float32[n_ch, 2048].  With ps_frame / ps_state (uint8
         views of xaac_ps_frame / xaac_esbr_ps_state arrays) / out_r: HE-AACv2 streams, float parametric stereo, out = left.
         hbe_state (uint8[n_ch, HBE_STATE_BYTES]): the harmonic transposer runs on every frame and frames with harmonic_sbr
         set take its output.  sbr_ratio ESBR_RATIO_8_3: 768 samples of a core row through the 24-channel bank;
-        ESBR_RATIO_4_1: the 16-channel bank, 64 slots, out float32[n_ch, 4096], workspace of esbr_workspace_bytes(n_ch, ratio)."""
+        ESBR_RATIO_4_1: the 16-channel bank, 64 slots, out float32[n_ch, 4096], workspace of esbr_workspace_bytes(n_ch, ratio).
+        hbe_dft = (state uint8[n_ch, HBE_DFT_FULL_STATE_BYTES], cfg_tab uint8[n_cfg, HBE_DFT_CFG_BYTES], coef_re, coef_im
+        float32[n_cfg, 64, 128], cfg int32[n_ch] or None) instead of hbe_state: -esbr_hq:1, the DFT transposer."""
         n_ch = out.shape[0]
         b = _EsbrSbrBatch()
         b.sbr_ratio = int(sbr_ratio)
@@ -593,6 +596,13 @@ class XaacContext:
         # USAC channels with PVC frames: uint8 views of the xaac_esbr_pvc_side / xaac_esbr_pvc_state arrays (both or neither)
         b.pvc_side = _ptr(pvc_side, "uint8", n_ch * ESBR_PVC_SIDE_BYTES, allow_none=True, device_ok=True)
         b.pvc_state = _ptr(pvc_state, "uint8", n_ch * ESBR_PVC_STATE_BYTES, allow_none=True, device_ok=True)
+        if hbe_dft is not None:
+            d_state, d_cfg_tab, d_cre, d_cim, d_cfg = hbe_dft
+            b.hbe_dft_state = _ptr(d_state, "uint8", n_ch * HBE_DFT_FULL_STATE_BYTES, device_ok=True)
+            b.hbe_dft_cfg_tab = _ptr(d_cfg_tab, "uint8", device_ok=True)
+            b.hbe_dft_coef_re = _ptr(d_cre, "float32", device_ok=True)
+            b.hbe_dft_coef_im = _ptr(d_cim, "float32", device_ok=True)
+            b.hbe_dft_cfg = _ptr(d_cfg, "int32", n_ch, allow_none=True, device_ok=True)
         rc = self._lib.xaac_esbr_sbr_process_batch(self._h, ctypes.byref(b))
         if rc != 0:
             raise XaacError(rc, "xaac_esbr_sbr_process_batch")

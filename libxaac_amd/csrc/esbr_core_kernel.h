@@ -39,6 +39,8 @@ typedef struct XaacEsbrCoreParams {
   float *pvc_out;               /* [n_ch][16][64] scratch: pvc_dec_out_buf */
   int32_t usf4;                 /* 4:1 SBR: out_re / out_im [n_ch][82][64], syn_re / syn_im [n_ch][64][64], and */
   float *q_re, *q_im;           /* [n_ch][80][64]: qmf_buf rows, 14..77 written by the analysis bank (ana_re / ana_im unused) */
+  const xaac_hbe_dft_state *dft; /* [n_ch] or NULL, instead of hbe: the channels' DFT transposers (-esbr_hq:1), already run on this
+                                    frame (last_status says whether) */
 } XaacEsbrCoreParams;
 
 #ifdef __cplusplus

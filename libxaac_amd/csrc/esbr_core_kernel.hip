@@ -182,8 +182,12 @@ __global__ __launch_bounds__(64, USF4 ? 2 : 3) void xaac_esbr_core_kernel(XaacEs
   float *phr = p.ph_re + (size_t)ch * XAAC_ESBR_PH_ROWS * 64, *phi = p.ph_im + (size_t)ch * XAAC_ESBR_PH_ROWS * 64;
   bool have_ph = false;
   if constexpr (HARM) {
-    have_ph = p.hbe && apply && xh_apply_params_ok(p.hbe + ch, sd->pitch_in_bins);
-    if (have_ph && !XAAC_HBE_LDS_OK(p.hbe[ch].synth_size, p.hbe_lds_synth_size)) have_ph = false, rc = -1; /* the host's hint was wrong */
+    if (p.dft) {
+      have_ph = apply && p.dft[ch].last_status == 0;
+    } else {
+      have_ph = p.hbe && apply && xh_apply_params_ok(p.hbe + ch, sd->pitch_in_bins);
+      if (have_ph && !XAAC_HBE_LDS_OK(p.hbe[ch].synth_size, p.hbe_lds_synth_size)) have_ph = false, rc = -1; /* the host's hint was wrong */
+    }
   }
   if (HARM && have_ph) {
     float t0[8], t1[8];
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(64, USF4 ? 2 : 3) void xaac_esbr_core_kernel(XaacEs
       }
       __syncthreads();
     }
-    rc = w.err ? -1 : xe_env_calc(cx, h, f, sd, st, &w, dst, src, (HARM && have_ph) ? p.hbe[ch].x_over_qmf : nullptr, pvs, pst, penv, RATE);
+    rc = w.err ? -1 : xe_env_calc(cx, h, f, sd, st, &w, dst, src, (HARM && have_ph) ? (p.dft ? p.dft[ch].x_over_qmf : p.hbe[ch].x_over_qmf) : nullptr, pvs, pst, penv, RATE);
   }
   if (PVC && lane == 0) pst->prev_sbr_mode = pvs->sbr_mode; /* sbr_dec.c:1006 */
   __syncthreads();
@@ -342,9 +346,9 @@ extern "C" hipError_t xaac_launch_esbr_core(const XaacEsbrCoreParams *p, hipStre
     if (p->pvc_side) hipLaunchKernelGGL((xaac_esbr_core_kernel<false, true, true>), dim3(p->n_ch), dim3(64), 0, stream, *p);
     else hipLaunchKernelGGL((xaac_esbr_core_kernel<false, false, true>), dim3(p->n_ch), dim3(64), 0, stream, *p);
   } else if (p->pvc_side) { /* USAC channels with PVC frames: their own instantiations, the others carry none of that code */
-    if (p->hbe) hipLaunchKernelGGL((xaac_esbr_core_kernel<true, true>), dim3(p->n_ch), dim3(64), 0, stream, *p);
+    if (p->hbe || p->dft) hipLaunchKernelGGL((xaac_esbr_core_kernel<true, true>), dim3(p->n_ch), dim3(64), 0, stream, *p);
     else hipLaunchKernelGGL((xaac_esbr_core_kernel<false, true>), dim3(p->n_ch), dim3(64), 0, stream, *p);
-  } else if (p->hbe) hipLaunchKernelGGL((xaac_esbr_core_kernel<true, false>), dim3(p->n_ch), dim3(64), 0, stream, *p);
+  } else if (p->hbe || p->dft) hipLaunchKernelGGL((xaac_esbr_core_kernel<true, false>), dim3(p->n_ch), dim3(64), 0, stream, *p);
   else hipLaunchKernelGGL((xaac_esbr_core_kernel<false, false>), dim3(p->n_ch), dim3(64), 0, stream, *p);
   return hipGetLastError();
 }

@@ -73,8 +73,15 @@ typedef struct XaacHbeDftParams {
   float *qmf_re, *qmf_im;
   int32_t *status;
   int32_t state_stride; /* bytes between consecutive channels' states; 0: sizeof(xaac_hbe_dft_anal_state) */
-  int32_t chain;        /* 1: behind xaac_hbe_dft_core_kernel -- a channel that kernel refused (status != 0) is left alone,
-                           status is not written */
+  int32_t chain;        /* 1: behind xaac_hbe_dft_core_kernel -- a channel that kernel refused or skipped (*status_in != 0) is left
+                           alone, status is not written */
+  const int32_t *status_in; /* chain: the first channel's word */
+  int32_t status_stride;    /* chain: bytes between the channels' words */
+  int32_t qmf_stride;       /* floats between consecutive channels' rows; 0: (no_bins + 2) * 64 */
+  int32_t max_rows;         /* rows a channel owns (0: no_bins + 2): what the reference's clears reach beyond them is left out */
+  int32_t zero_below;       /* 1: sub-bands below a_start of rows 0 .. no_bins - 1 are written as zeros too (scratch rows that
+                               start with anything; the reference's buffer holds zeros there) */
+  const xaac_sbr_frame *frame; /* inside the Path A chain: a channel without SBR processing is skipped; NULL elsewhere */
 } XaacHbeDftParams;
 
 /* the DFT transposer up to its output signal (hbe_kernel.hip: xaac_hbe_dft_core_kernel; arithmetic: hbe_dft.h): 256 threads
@@ -91,6 +98,10 @@ typedef struct XaacHbeDftCoreParams {
   const xaac_hbe_dft_cfg *cfg_tab;
   xaac_hbe_dft_state *state;
   int32_t *status;
+  /* inside the Path A chain (xaac_esbr_sbr_process_batch): pitch and oversampling come from the side info, a channel whose frame
+     has no SBR processing is skipped (sbr_dec.c:880; its last_status becomes 1: nothing ran); NULL elsewhere */
+  const xaac_sbr_frame *frame;
+  const xaac_esbr_side *side;
 } XaacHbeDftCoreParams;
 
 #ifdef __cplusplus

@@ -337,7 +337,8 @@ __global__ __launch_bounds__(256) void xaac_hbe_dft_anal_kernel(XaacHbeDftParams
   extern __shared__ float lds[];
   float(*u)[128] = reinterpret_cast<float(*)[128]>(lds);
   const int ch = blockIdx.x, tid = threadIdx.x, nb = p.no_bins;
-  if (p.chain && p.status && p.status[ch] != 0) return;
+  if (p.chain && *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(p.status_in) + (size_t)ch * p.status_stride) != 0) return;
+  if (hbe_skip(p.frame, ch)) return;
   xaac_hbe_dft_anal_state *st = reinterpret_cast<xaac_hbe_dft_anal_state *>(
       reinterpret_cast<char *>(p.state) + (size_t)ch * (p.state_stride ? (size_t)p.state_stride : sizeof(xaac_hbe_dft_anal_state)));
   const int L = st->analy_size, a0 = st->a_start;
@@ -347,7 +348,9 @@ __global__ __launch_bounds__(256) void xaac_hbe_dft_anal_kernel(XaacHbeDftParams
   const float *tin = p.time_in + (size_t)ch * p.in_stride, *win = xh_window_dft(L);
   const size_t c = p.cfg ? (size_t)p.cfg[ch] : 0;
   const float *cre = p.coef_re + c * 64 * 128, *cim = p.coef_im + c * 64 * 128;
-  float *qre = p.qmf_re + (size_t)ch * (nb + 2) * 64, *qim = p.qmf_im + (size_t)ch * (nb + 2) * 64;
+  const size_t qs = p.qmf_stride ? (size_t)p.qmf_stride : (size_t)(nb + 2) * 64;
+  const int rows = p.max_rows ? p.max_rows : nb + 2;
+  float *qre = p.qmf_re + (size_t)ch * qs, *qim = p.qmf_im + (size_t)ch * qs;
   for (int e = tid; e < nb * 2 * L; e += 256) u[e / (2 * L)][e % (2 * L)] = xh_anal_u_w(tin, st->analy_buf, L, e / (2 * L), e % (2 * L), win);
   float keep[3];
 #pragma unroll
@@ -356,8 +359,13 @@ __global__ __launch_bounds__(256) void xaac_hbe_dft_anal_kernel(XaacHbeDftParams
     keep[q] = n < 10 * L ? xh_anal_x(tin, st->analy_buf, L, nb - 1, n) : 0.0f;
   }
   __syncthreads();
-  for (int e = tid; e < (nb + 2) * 64; e += 256) {
+  for (int e = tid; e < rows * 64; e += 256) {
     const int idx = e >> 6, k = e & 63;
+    if (p.zero_below && idx < nb && k < a0) {
+      qre[e] = 0.0f;
+      qim[e] = 0.0f;
+      continue;
+    }
     if (idx < nb && k >= a0 && k < a0 + L) {
       float o_r, o_i;
       xh_dft_anal_band(u[idx], 2 * L, cre + 128 * (k - a0), cim + 128 * (k - a0), o_r, o_i);
@@ -384,12 +392,19 @@ __global__ __launch_bounds__(XAAC_HBE_DFT_CORE_THREADS) void xaac_hbe_dft_core_k
   const int ch = blockIdx.x, lane = threadIdx.x;
   constexpr int NT = XAAC_HBE_DFT_CORE_THREADS;
   xaac_hbe_dft_state *st = p.state + ch;
-  const int ovs = p.oversampling && p.oversampling[ch] ? 1 : 0;
-  const int pitch = p.pitch ? p.pitch[ch] : 0;
+  if (hbe_skip(p.frame, ch)) {
+    if (lane == 0) st->last_status = 1;
+    return;
+  }
+  const int ovs = p.side ? ((p.side[ch].harmonic_sbr & XAAC_ESBR_OVERSAMPLING) ? 1 : 0) : (p.oversampling && p.oversampling[ch] ? 1 : 0);
+  const int pitch = hbe_pitch(p.pitch, p.side, ch);
   const xaac_hbe_dft_cfg *cfg = p.cfg_tab + (p.cfg ? p.cfg[ch] : 0);
   XdSizes z;
   const bool ok = xd_sizes(st, ovs, &z); /* (uniform: every lane reads the same words) */
-  if (lane == 0 && p.status) p.status[ch] = ok ? 0 : -1;
+  if (lane == 0) {
+    if (p.status) p.status[ch] = ok ? 0 : -1;
+    st->last_status = ok ? 0 : -1;
+  }
   if (!ok) return;
   float *in = lds, *out = in + 2 * XAAC_HBE_DFT_MAX_ANA;
   XdC *wa = reinterpret_cast<XdC *>(out + 4 * XAAC_HBE_DFT_MAX_SYN), *ws = wa + 384;

@@ -345,6 +345,10 @@ int32_t xaac_esbr_sbr_process_batch(xaac_ctx *c, const xaac_esbr_sbr_batch *b) {
   if (with_ps != (b->ps_state != nullptr) || with_ps != (b->out_r != nullptr)) return XAAC_FATAL_BAD_ARG;
   if ((b->pvc_side != nullptr) != (b->pvc_state != nullptr)) return XAAC_FATAL_BAD_ARG;
   if (b->sbr_ratio < XAAC_ESBR_RATIO_2_1 || b->sbr_ratio > XAAC_ESBR_RATIO_4_1) return XAAC_FATAL_BAD_ARG;
+  if (b->hbe_dft_state) { /* the DFT transposer: in the QMF one's place, 2:1 only */
+    if (b->hbe_state || b->sbr_ratio != XAAC_ESBR_RATIO_2_1) return XAAC_FATAL_BAD_ARG;
+    if (!b->hbe_dft_cfg_tab || !b->hbe_dft_coef_re || !b->hbe_dft_coef_im) return XAAC_FATAL_NULL_ARG;
+  }
   if (b->workspace_bytes < xaac_esbr_workspace_bytes_ratio(b->n_ch, b->sbr_ratio)) return XAAC_FATAL_BAD_ARG;
   if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
   const size_t n = (size_t)b->n_ch;
@@ -383,7 +387,24 @@ int32_t xaac_esbr_sbr_process_batch(xaac_ctx *c, const xaac_esbr_sbr_batch *b) {
     XaacEsbrAnaParams pa = {b->n_ch, b->core, &b->state->ana, ana_re, ana_im, (int32_t)sizeof(xaac_esbr_state)};
     if (!hip_ok(xaac_launch_esbr_analysis(&pa, c->stream))) return XAAC_FATAL_HIP;
   }
-  if (b->hbe_state) {
+  if (b->hbe_dft_state) {
+    /* sbr_dec.c:880-892 (-esbr_hq:1): the DFT transposer in the QMF one's place -- its output signal, then its analysis bank into
+       rows 8..39 of the ph scratch matrix (the reference's clears beyond row 39 left out, sub-bands below a_start zeroed) */
+    XaacHbeDftCoreParams dc = {b->n_ch, ana_re, ana_im, nullptr, nullptr, b->hbe_dft_cfg, b->hbe_dft_cfg_tab, b->hbe_dft_state, nullptr, b->frame, b->side};
+    if (!hip_ok(xaac_launch_hbe_dft_core(&dc, c->stream))) return XAAC_FATAL_HIP;
+    XaacHbeDftParams da = {};
+    da.n_ch = b->n_ch; da.no_bins = XAAC_HBE_NO_BINS;
+    da.time_in = reinterpret_cast<const float *>(reinterpret_cast<const char *>(b->hbe_dft_state) + offsetof(xaac_hbe_dft_state, output_buf));
+    da.in_stride = (int32_t)(sizeof(xaac_hbe_dft_state) / sizeof(float));
+    da.coef_re = b->hbe_dft_coef_re; da.coef_im = b->hbe_dft_coef_im; da.cfg = b->hbe_dft_cfg;
+    da.state = reinterpret_cast<xaac_hbe_dft_anal_state *>(reinterpret_cast<char *>(b->hbe_dft_state) + offsetof(xaac_hbe_dft_state, anal));
+    da.state_stride = (int32_t)sizeof(xaac_hbe_dft_state);
+    da.qmf_re = ph_re + 8 * 64; da.qmf_im = ph_im + 8 * 64; da.qmf_stride = XAAC_ESBR_PH_ROWS * 64; da.max_rows = 32; da.zero_below = 1;
+    da.chain = 1; da.frame = b->frame;
+    da.status_in = reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(b->hbe_dft_state) + offsetof(xaac_hbe_dft_state, last_status));
+    da.status_stride = (int32_t)sizeof(xaac_hbe_dft_state);
+    if (!hip_ok(xaac_launch_hbe_dft_anal(&da, c->stream))) return XAAC_FATAL_HIP;
+  } else if (b->hbe_state) {
     /* sbr_dec.c:882-909: the frame's new analysis rows through the channel's harmonic transposer (two launches),
        its 32 output rows into rows 8..39 of the ph scratch matrix; channels without SBR processing are skipped */
     XaacHbeBanksParams hs = {b->n_ch, XAAC_HBE_NO_BINS, ana_re, ana_im, b->hbe_state, nullptr, nullptr, 1, b->frame, b->side, 2048,
@@ -396,6 +417,7 @@ int32_t xaac_esbr_sbr_process_batch(xaac_ctx *c, const xaac_esbr_sbr_batch *b) {
   XaacEsbrCoreParams pc = {b->n_ch, b->header, b->frame, b->side, b->state, ana_re, ana_im, out_re, out_im, syn_re, syn_im,
                            with_ps ? 1 : 0, b->status, b->hbe_state, ph_re, ph_im, b->hbe_max_synth_size,
                            b->pvc_side, b->pvc_state, pvc_out};
+  pc.dft = b->hbe_dft_state;
   if (!hip_ok(xaac_launch_esbr_core(&pc, c->stream))) return XAAC_FATAL_HIP;
   if (with_ps) {
     XaacEsbrPsParams pp = {b->n_ch, b->header, b->frame, b->ps_frame, b->ps_state, syn_re, syn_im, r_re, r_im, b->status};
@@ -573,7 +595,7 @@ int32_t xaac_hbe_dft_apply_batch_run(xaac_ctx *c, const xaac_hbe_dft_apply_batch
   if (!b->qmf_re || !b->qmf_im || !b->cfg_tab || !b->coef_re || !b->coef_im || !b->state || !b->pv_re || !b->pv_im || !b->status)
     return XAAC_FATAL_NULL_ARG; /* (status is how the second launch learns which channels the first one refused) */
   if (!hip_ok(hipSetDevice(c->device))) return XAAC_FATAL_HIP;
-  XaacHbeDftCoreParams pc = {b->n_ch, b->qmf_re, b->qmf_im, b->pitch_in_bins, b->oversampling, b->cfg, b->cfg_tab, b->state, b->status};
+  XaacHbeDftCoreParams pc = {b->n_ch, b->qmf_re, b->qmf_im, b->pitch_in_bins, b->oversampling, b->cfg, b->cfg_tab, b->state, b->status, nullptr, nullptr};
   if (!hip_ok(xaac_launch_hbe_dft_core(&pc, c->stream))) return XAAC_FATAL_HIP;
   XaacHbeDftParams pa = {};
   pa.n_ch = b->n_ch; pa.no_bins = XAAC_HBE_NO_BINS;
@@ -583,6 +605,7 @@ int32_t xaac_hbe_dft_apply_batch_run(xaac_ctx *c, const xaac_hbe_dft_apply_batch
   pa.state = reinterpret_cast<xaac_hbe_dft_anal_state *>(reinterpret_cast<char *>(b->state) + offsetof(xaac_hbe_dft_state, anal));
   pa.state_stride = (int32_t)sizeof(xaac_hbe_dft_state);
   pa.qmf_re = b->pv_re; pa.qmf_im = b->pv_im; pa.status = b->status; pa.chain = 1;
+  pa.status_in = b->status; pa.status_stride = 4;
   if (!hip_ok(xaac_launch_hbe_dft_anal(&pa, c->stream))) return XAAC_FATAL_HIP;
   c->last_grid = b->n_ch; c->last_block = XAAC_HBE_DFT_CORE_THREADS; c->last_lds = XAAC_HBE_DFT_CORE_LDS;
   return XAAC_OK;

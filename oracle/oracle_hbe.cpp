@@ -80,6 +80,7 @@ int xo_hbe_dft_apply(xaac_hbe_dft_state *st, const xaac_hbe_dft_cfg *cfg, const 
   XdSizes z;
   const int ovs = oversampling ? 1 : 0;
   if (!xd_sizes(st, ovs, &z)) return -1;
+  st->last_status = 0;
   const XhSeq cx = {0, 1};
   const int s = z.s, ks = st->k_start;
   /* :800-802 */

@@ -349,7 +349,7 @@ static void to_esbr_side(const ia_sbr_header_data_struct *h, const ia_sbr_frame_
   memcpy(o->flt_env_sf_arr, f->flt_env_sf_arr, sizeof(o->flt_env_sf_arr));
   memcpy(o->flt_noise_floor, f->flt_noise_floor, sizeof(o->flt_noise_floor));
   o->harmonic_sbr = (int16_t)((f->sbr_patching_mode == 0 ? XAAC_ESBR_HARMONIC : 0) | (h->pre_proc_flag ? XAAC_ESBR_PRE_FLATTEN : 0) |
-                              (h->usac_flag ? XAAC_ESBR_USAC : 0) |
+                              (h->usac_flag ? XAAC_ESBR_USAC : 0) | (f->over_sampling_flag ? XAAC_ESBR_OVERSAMPLING : 0) |
                               (h->usac_flag && !h->hbe_flag ? XAAC_ESBR_NO_X_DELAY : 0) | /* sbr_dec.c:819-826: codec_x_delay */
                               (f->sbr_mode != ORIG_SBR && f->sbr_mode != PVC_SBR ? XAAC_ESBR_SKIP_ADJUST : 0));
   o->pitch_in_bins = f->pitch_in_bins;

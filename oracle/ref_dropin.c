@@ -44,7 +44,7 @@ static struct {
   xaac_esbr_pvc_state *pvst;
 } g;
 static long g_eld_ana_calls, g_eld_syn_calls;
-static long g_usac_fac_dev, g_sbr_ds_calls, g_esbr_ds_calls, g_dft_calls, g_dft_ref_calls;
+static long g_usac_fac_dev, g_sbr_ds_calls, g_esbr_ds_calls, g_dft_calls, g_dft_ref_calls, g_esbr_dft_calls;
 static long g_imdct_calls, g_sbr_calls, g_lim_calls, g_esbr_calls, g_esbr_harm_calls, g_esbr_usac_calls, g_esbr_pvc_calls, g_esbr_83_calls, g_esbr_41_calls, g_sbr_ref_calls, g_usac_imdct_calls, g_usac_imdct_fac, g_usac_imdct_lpd, g_eld_sbr_calls, g_imdct960_calls, g_imdct_ld_calls;
 static struct { int32_t *overlap; int16_t *pcm; uint8_t *shape; } gl; /* AAC-LD / ELD: 3 x 512 overlap words, 512 samples, 2 bytes */
 
@@ -70,6 +70,7 @@ static void report(void) {
           g_usac_imdct_fac, g_usac_imdct_lpd);
   fprintf(stderr, "xaacdec_dropin: %ld FAC signals made on the device (ixheaacd_cal_fac_data)\n", g_usac_fac_dev);
   fprintf(stderr, "xaacdec_dropin: %ld of the USAC calls were PVC frames (PVC decoder + the adjuster's PVC branch on the GPU)\n", g_esbr_pvc_calls);
+  fprintf(stderr, "xaacdec_dropin: %ld of the eSBR calls with the DFT transposer inside the chain (-esbr_hq:1)\n", g_esbr_dft_calls);
   fprintf(stderr, "xaacdec_dropin: %ld dft_hbe_apply calls (-esbr_hq:1: the DFT harmonic transposer) ran on the GPU, %ld left to the reference\n", g_dft_calls,
           g_dft_ref_calls);
   fprintf(stderr, "xaacdec_dropin: %ld of the USAC calls at 8:3 SBR (24-channel bank), %ld at 4:1 (16-channel bank, 64 slots)\n", g_esbr_83_calls, g_esbr_41_calls);
@@ -439,6 +440,65 @@ WORD32 __real_ixheaacd_sbr_dec(ia_sbr_dec_struct *, WORD16 *, ia_sbr_header_data
                                ia_sbr_tables_struct *, ixheaacd_misc_tables *, WORD, ia_pvc_data_struct *, FLAG,
                                WORD32[][64], WORD32, WORD32, VOID *, WORD32, WORD32);
 
+/* ---- -esbr_hq:1: the DFT harmonic transposer's struct members <-> include/xaac_hbe.h (xaac_hbe_dft_state / _cfg) ---- */
+static struct { xaac_hbe_dft_state *st; xaac_hbe_dft_cfg *cfg; float *coef, *q, *pv; int32_t *par; } gd;
+static void dft_alloc(void) {
+  if (gd.st) return;
+  HIP(hipMalloc((void **)&gd.st, sizeof(xaac_hbe_dft_state)));
+  HIP(hipMalloc((void **)&gd.cfg, sizeof(xaac_hbe_dft_cfg)));
+  HIP(hipMalloc((void **)&gd.coef, 2 * 64 * 128 * 4));
+  HIP(hipMalloc((void **)&gd.q, 2 * 2048 * 4));
+  HIP(hipMalloc((void **)&gd.pv, 2 * 34 * 64 * 4));
+  HIP(hipMalloc((void **)&gd.par, 16));
+}
+static int dft_sizes_fit(const ia_esbr_hbe_txposer_struct *t) {
+  const int ana0 = t->ana_fft_size[0], syn0 = t->syn_fft_size[0];
+  return ana0 >= 0 && ana0 <= XAAC_HBE_DFT_MAX_ANA && syn0 >= 0 && syn0 <= XAAC_HBE_DFT_MAX_SYN && ana0 == 32 * t->synth_size &&
+         syn0 == 16 * t->analy_size;
+}
+/* state and windows up (the windows and the analysis bank's matrices with every call: a test harness, 90 KB a call) */
+static void dft_upload(const ia_esbr_hbe_txposer_struct *t) {
+  static xaac_hbe_dft_state st;
+  static xaac_hbe_dft_cfg cfg;
+  const int ana0 = t->ana_fft_size[0], syn0 = t->syn_fft_size[0];
+  int tr, o;
+  dft_alloc();
+  memset(&st, 0, sizeof(st));
+  memcpy(st.input_buf, t->ptr_input_buf, sizeof(float) * 2 * ana0);
+  memcpy(st.output_buf, t->ptr_output_buf, sizeof(float) * 4 * syn0);
+  memcpy(st.synth_buf, t->synth_buf, sizeof(st.synth_buf));
+  memcpy(st.anal.analy_buf, t->analy_buf, sizeof(st.anal.analy_buf));
+  st.anal.analy_size = t->analy_size;
+  st.anal.a_start = t->a_start;
+  st.synth_size = t->synth_size;
+  st.k_start = t->k_start;
+  st.start_band = t->start_band;
+  st.end_band = t->end_band;
+  st.max_stretch = t->max_stretch;
+  for (o = 0; o < 6; o++) st.x_over_qmf[o] = t->x_over_qmf[o];
+  memset(&cfg, 0, sizeof(cfg));
+  memcpy(cfg.anal_window, t->anal_window, sizeof(float) * ana0);
+  memcpy(cfg.synth_window, t->synth_window, sizeof(float) * syn0);
+  for (tr = 0; tr < 3; tr++)
+    for (o = 0; o < 2; o++) memcpy(cfg.fd_win[tr][o], t->fd_win_buf[tr][o], sizeof(cfg.fd_win[tr][o]));
+  HIP(hipMemcpy(gd.st, &st, sizeof(st), hipMemcpyHostToDevice));
+  HIP(hipMemcpy(gd.cfg, &cfg, sizeof(cfg), hipMemcpyHostToDevice));
+  HIP(hipMemcpy(gd.coef, t->str_dft_hbe_anal_coeff.real, 64 * 128 * 4, hipMemcpyHostToDevice));
+  HIP(hipMemcpy(gd.coef + 64 * 128, t->str_dft_hbe_anal_coeff.imag, 64 * 128 * 4, hipMemcpyHostToDevice));
+}
+/* the signals and delay lines back; returns last_status */
+static int dft_download(ia_esbr_hbe_txposer_struct *t) {
+  static xaac_hbe_dft_state st;
+  const int ana0 = t->ana_fft_size[0], syn0 = t->syn_fft_size[0];
+  HIP(hipMemcpy(&st, gd.st, sizeof(st), hipMemcpyDeviceToHost));
+  if (st.last_status) return st.last_status;
+  memcpy(t->ptr_input_buf, st.input_buf, sizeof(float) * 2 * ana0);
+  memcpy(t->ptr_output_buf, st.output_buf, sizeof(float) * 4 * syn0);
+  memcpy(t->synth_buf, st.synth_buf, sizeof(st.synth_buf));
+  memcpy(t->analy_buf, st.anal.analy_buf, sizeof(st.anal.analy_buf));
+  return 0;
+}
+
 WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_header_data_struct *h,
                                ia_sbr_frame_info_data_struct *f, ia_sbr_prev_frame_data_struct *p,
                                ia_ps_dec_struct *ps, ia_sbr_qmf_filter_bank_struct *synth_r,
@@ -465,7 +525,11 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
      between calls (to_esbr_state / from_esbr_state) */
   /* USAC channels (stereoConfigIndex 0, ORIG_SBR frames) come through the same branch: with a transposer like the AAC ones,
      without one with codec_x_delay 0 (sbr_dec.c:819-826; xaac_esbr.h: XAAC_ESBR_USAC / _NO_X_DELAY) */
-  if (h->enh_sbr && aot != AOT_ER_AAC_ELD && aot != AOT_ER_AAC_LD && !h->esbr_hq &&
+  /* -esbr_hq:1 (the DFT transposer in the QMF one's place): the same call with xaac_esbr_sbr_batch.hbe_dft_state, where the
+     reference has transforms for the transposer's sizes; the reset-time calls of ixheaacd_applysbr go through the seam on
+     ixheaacd_dft_hbe_apply at the end of this file */
+  if (h->enh_sbr && aot != AOT_ER_AAC_ELD && aot != AOT_ER_AAC_LD &&
+      (!h->esbr_hq || (!h->usac_flag && h->hbe_flag && d->p_hbe_txposer != NULL && dft_sizes_fit(d->p_hbe_txposer) && !getenv("XAAC_DROPIN_NO_DFT_CHAIN"))) &&
       (h->usac_flag ? ((!h->hbe_flag || d->p_hbe_txposer != NULL) && f->stereo_config_idx == 0 && !getenv("XAAC_DROPIN_NO_USAC"))
                     : (h->hbe_flag && d->p_hbe_txposer != NULL)) &&
       (h->channel_mode == PS_STEREO ? (ps != NULL && synth_r != NULL && !ps->use_34_st_bands && !ps->use_pca_rot_flg && ps->ps_mode == 0)
@@ -518,7 +582,9 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     /* the channel's harmonic transposer: the reference runs it on every processed frame of such a stream
        (sbr_dec.c:882-909) and frames with sbr_patching_mode 0 (ENHSBR payload) take the HF generator's input from it;
        pre-flattening (pre_proc_flag) only acts on LPP patches (sbrdec_lpfuncs.c:1220), so it is moot for those frames */
-    if (h->hbe_flag) {
+    if (h->hbe_flag && h->esbr_hq) {
+      dft_upload(d->p_hbe_txposer);
+    } else if (h->hbe_flag) {
       to_hbe_state(d->p_hbe_txposer, &hbs);
       HIP(hipMemcpy(g.hbe, &hbs, sizeof(hbs), hipMemcpyHostToDevice));
     }
@@ -552,7 +618,13 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     b.sbr_ratio = ratio;
     b.down_sample = esbr_ds;
     b.workspace_bytes = xaac_esbr_workspace_bytes_ratio(1, ratio);
-    b.hbe_state = h->hbe_flag ? g.hbe : NULL;
+    b.hbe_state = (h->hbe_flag && !h->esbr_hq) ? g.hbe : NULL;
+    if (h->hbe_flag && h->esbr_hq) {
+      b.hbe_dft_state = gd.st;
+      b.hbe_dft_cfg_tab = gd.cfg;
+      b.hbe_dft_coef_re = gd.coef;
+      b.hbe_dft_coef_im = gd.coef + 64 * 128;
+    }
     if (h->usac_flag) { /* every USAC call carries the PVC side info and state: ORIG_SBR frames leave what a PVC frame behind them reads */
       to_esbr_pvc_side(h, f, pvc, low_pow, &pvs);
       to_esbr_pvc_state(h, f, pvc, &pvst);
@@ -589,7 +661,10 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
       memcpy(d->qmf_buf_real[0], in_re, sizeof(in_re));
       memcpy(d->qmf_buf_imag[0], in_im, sizeof(in_im));
     }
-    if (apply && h->hbe_flag) {
+    if (apply && h->hbe_flag && h->esbr_hq) {
+      dft_download(d->p_hbe_txposer);
+      g_esbr_dft_calls++;
+    } else if (apply && h->hbe_flag) {
       HIP(hipMemcpy(&hbs, g.hbe, sizeof(hbs), hipMemcpyDeviceToHost));
       from_hbe_state(&hbs, d->p_hbe_txposer, h);
     }
@@ -834,83 +909,43 @@ WORD32 __real_ixheaacd_dft_hbe_apply(ia_esbr_hbe_txposer_struct *t, FLOAT32 qre[
                                      FLOAT32 pvi[][64], WORD32 pitch_in_bins, FLOAT32 *scratch);
 WORD32 __wrap_ixheaacd_dft_hbe_apply(ia_esbr_hbe_txposer_struct *t, FLOAT32 qre[][64], FLOAT32 qim[][64], WORD32 num_columns, FLOAT32 pvr[][64],
                                      FLOAT32 pvi[][64], WORD32 pitch_in_bins, FLOAT32 *scratch) {
-  static xaac_hbe_dft_state st;
-  static xaac_hbe_dft_cfg cfg;
-  static struct { xaac_hbe_dft_state *st; xaac_hbe_dft_cfg *cfg; float *coef, *q, *pv; int32_t *par; } d;
   xaac_hbe_dft_apply_batch b;
-  int32_t par[3], status = 0;
-  int tr, o;
-  const int ana0 = t->ana_fft_size[0], syn0 = t->syn_fft_size[0];
-  if (num_columns != 32 || ana0 < 0 || ana0 > XAAC_HBE_DFT_MAX_ANA || syn0 < 0 || syn0 > XAAC_HBE_DFT_MAX_SYN || ana0 != 32 * t->synth_size ||
-      syn0 != 16 * t->analy_size || getenv("XAAC_DROPIN_NO_DFT")) {
+  int32_t par[3];
+  if (num_columns != 32 || !dft_sizes_fit(t) || getenv("XAAC_DROPIN_NO_DFT")) {
     g_dft_ref_calls++;
     return __real_ixheaacd_dft_hbe_apply(t, qre, qim, num_columns, pvr, pvi, pitch_in_bins, scratch);
   }
   setup();
-  if (!d.st) {
-    HIP(hipMalloc((void **)&d.st, sizeof(st)));
-    HIP(hipMalloc((void **)&d.cfg, sizeof(cfg)));
-    HIP(hipMalloc((void **)&d.coef, 2 * 64 * 128 * 4));
-    HIP(hipMalloc((void **)&d.q, 2 * 2048 * 4));
-    HIP(hipMalloc((void **)&d.pv, 2 * 34 * 64 * 4));
-    HIP(hipMalloc((void **)&d.par, 16));
-  }
-  memset(&st, 0, sizeof(st));
-  memcpy(st.input_buf, t->ptr_input_buf, sizeof(float) * 2 * ana0);
-  memcpy(st.output_buf, t->ptr_output_buf, sizeof(float) * 4 * syn0);
-  memcpy(st.synth_buf, t->synth_buf, sizeof(st.synth_buf));
-  memcpy(st.anal.analy_buf, t->analy_buf, sizeof(st.anal.analy_buf));
-  st.anal.analy_size = t->analy_size;
-  st.anal.a_start = t->a_start;
-  st.synth_size = t->synth_size;
-  st.k_start = t->k_start;
-  st.start_band = t->start_band;
-  st.end_band = t->end_band;
-  st.max_stretch = t->max_stretch;
-  memset(&cfg, 0, sizeof(cfg));
-  memcpy(cfg.anal_window, t->anal_window, sizeof(float) * ana0);
-  memcpy(cfg.synth_window, t->synth_window, sizeof(float) * syn0);
-  for (tr = 0; tr < 3; tr++)
-    for (o = 0; o < 2; o++) memcpy(cfg.fd_win[tr][o], t->fd_win_buf[tr][o], sizeof(cfg.fd_win[tr][o]));
+  dft_upload(t);
   par[0] = pitch_in_bins;
   par[1] = t->oversampling_flag ? 1 : 0;
   par[2] = 0;
-  HIP(hipMemcpy(d.st, &st, sizeof(st), hipMemcpyHostToDevice));
-  HIP(hipMemcpy(d.cfg, &cfg, sizeof(cfg), hipMemcpyHostToDevice));
-  HIP(hipMemcpy(d.coef, t->str_dft_hbe_anal_coeff.real, 64 * 128 * 4, hipMemcpyHostToDevice));
-  HIP(hipMemcpy(d.coef + 64 * 128, t->str_dft_hbe_anal_coeff.imag, 64 * 128 * 4, hipMemcpyHostToDevice));
-  HIP(hipMemcpy(d.q, qre, 2048 * 4, hipMemcpyHostToDevice));
-  HIP(hipMemcpy(d.q + 2048, qim, 2048 * 4, hipMemcpyHostToDevice));
-  HIP(hipMemcpy(d.pv, pvr, 34 * 64 * 4, hipMemcpyHostToDevice));
-  HIP(hipMemcpy(d.pv + 34 * 64, pvi, 34 * 64 * 4, hipMemcpyHostToDevice));
-  HIP(hipMemcpy(d.par, par, sizeof(par), hipMemcpyHostToDevice));
+  HIP(hipMemcpy(gd.q, qre, 2048 * 4, hipMemcpyHostToDevice));
+  HIP(hipMemcpy(gd.q + 2048, qim, 2048 * 4, hipMemcpyHostToDevice));
+  HIP(hipMemcpy(gd.pv, pvr, 34 * 64 * 4, hipMemcpyHostToDevice));
+  HIP(hipMemcpy(gd.pv + 34 * 64, pvi, 34 * 64 * 4, hipMemcpyHostToDevice));
+  HIP(hipMemcpy(gd.par, par, sizeof(par), hipMemcpyHostToDevice));
   memset(&b, 0, sizeof(b));
   b.n_ch = 1;
-  b.qmf_re = d.q;
-  b.qmf_im = d.q + 2048;
-  b.pitch_in_bins = d.par;
-  b.oversampling = d.par + 1;
-  b.cfg_tab = d.cfg;
-  b.coef_re = d.coef;
-  b.coef_im = d.coef + 64 * 128;
-  b.state = d.st;
-  b.pv_re = d.pv;
-  b.pv_im = d.pv + 34 * 64;
-  b.status = d.par + 2;
+  b.qmf_re = gd.q;
+  b.qmf_im = gd.q + 2048;
+  b.pitch_in_bins = gd.par;
+  b.oversampling = gd.par + 1;
+  b.cfg_tab = gd.cfg;
+  b.coef_re = gd.coef;
+  b.coef_im = gd.coef + 64 * 128;
+  b.state = gd.st;
+  b.pv_re = gd.pv;
+  b.pv_im = gd.pv + 34 * 64;
+  b.status = gd.par + 2;
   if (xaac_hbe_dft_apply_batch_run(g_ctx, &b) != XAAC_OK) die("xaac_hbe_dft_apply_batch_run");
   HIP(hipDeviceSynchronize());
-  HIP(hipMemcpy(&status, d.par + 2, 4, hipMemcpyDeviceToHost));
-  if (status) { /* sizes without a transform: the reference fails the frame itself */
+  if (dft_download(t)) { /* sizes without a transform: the reference fails the frame itself */
     g_dft_ref_calls++;
     return __real_ixheaacd_dft_hbe_apply(t, qre, qim, num_columns, pvr, pvi, pitch_in_bins, scratch);
   }
-  HIP(hipMemcpy(&st, d.st, sizeof(st), hipMemcpyDeviceToHost));
-  HIP(hipMemcpy(pvr, d.pv, 34 * 64 * 4, hipMemcpyDeviceToHost));
-  HIP(hipMemcpy(pvi, d.pv + 34 * 64, 34 * 64 * 4, hipMemcpyDeviceToHost));
-  memcpy(t->ptr_input_buf, st.input_buf, sizeof(float) * 2 * ana0);
-  memcpy(t->ptr_output_buf, st.output_buf, sizeof(float) * 4 * syn0);
-  memcpy(t->synth_buf, st.synth_buf, sizeof(st.synth_buf));
-  memcpy(t->analy_buf, st.anal.analy_buf, sizeof(st.anal.analy_buf));
+  HIP(hipMemcpy(pvr, gd.pv, 34 * 64 * 4, hipMemcpyDeviceToHost));
+  HIP(hipMemcpy(pvi, gd.pv + 34 * 64, 34 * 64 * 4, hipMemcpyDeviceToHost));
   g_dft_calls++;
   return 0;
 }

@@ -213,6 +213,7 @@ int ref_hbe_dft_reinit(const int16_t *tbl_lo, int n_lo, const int16_t *tbl_hi, i
   st->start_band = hbe_t.start_band;
   st->end_band = hbe_t.end_band;
   st->max_stretch = hbe_t.max_stretch;
+  for (t = 0; t < 6; t++) st->x_over_qmf[t] = hbe_t.x_over_qmf[t];
   st->anal.analy_size = hbe_t.analy_size;
   st->anal.a_start = hbe_t.a_start;
   memset(cfg, 0, sizeof(*cfg));

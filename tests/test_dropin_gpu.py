@@ -242,7 +242,8 @@ def test_wider_streams_through_the_same_seams(aac, flags, tmp_path):
 @pytest.mark.parametrize("aac", [s for s in STREAMS if "aot5_" in s or "aot29_" in s], ids=lambda s: os.path.basename(s))
 def test_dft_harmonic_transposer_behind_the_reference_decoder(aac, tmp_path):
     """-esbr_hq:1: every ixheaacd_dft_hbe_apply call of the reference decoder (hbe_dft_trans.c:771; one per channel and frame, two
-    more where a header resets the SBR decoder) served by xaac_hbe_dft_apply_batch_run.  This path is float with libm calls and
+    more where a header resets the SBR decoder) served by the library: inside xaac_esbr_sbr_process_batch (hbe_dft_state) for the
+    frames' calls, by xaac_hbe_dft_apply_batch_run for the reset-time ones.  This path is float with libm calls and
     transforms of the library's own: the decoded file is held to the tolerance BASELINE.json's north_star gives float SBR --
     every 16-bit sample within 1 LSB of the unmodified decoder's -- and in fact most streams come out identical (the
     transposer's rows are only read where the stream asks for harmonic patching: harm_aot5_48k, 0.1 % of its samples off by one)."""
@@ -254,7 +255,16 @@ def test_dft_harmonic_transposer_behind_the_reference_decoder(aac, tmp_path):
     _decode("xaacdec", aac, ref_wav, extra=("-esbr_hq:1",))
     log = _decode("xaacdec_dropin", aac, gpu_wav, extra=("-esbr_hq:1",))
     m = re.search(r"(\d+) dft_hbe_apply calls .* ran on the GPU, (\d+) left to the reference", log)
-    assert m and int(m.group(1)) > 30 and int(m.group(2)) == 0, log[-800:]
+    mc = re.search(r"(\d+) of the eSBR calls with the DFT transposer inside the chain", log)
+    ml = re.search(r"(\d+) sbr_dec calls left to the reference", log)
+    # the frames' calls run inside the Path A chain (xaac_esbr_sbr_batch.hbe_dft_state), the reset-time ones of ixheaacd_applysbr through
+    # the seam on the function itself; nothing of such a stream's SBR is left to the reference
+    assert m and mc and ml and int(mc.group(1)) > 30 and int(m.group(1)) >= 2 and int(m.group(2)) == 0 and int(ml.group(1)) == 0, log[-900:]
+    if "XAAC_DROPIN_NO_DFT_CHAIN" not in os.environ:   # ... and with the chain held back every call goes through the function's seam
+        log2 = _decode("xaacdec_dropin", aac, str(tmp_path / "gpu2.wav"), extra=("-esbr_hq:1",), env=dict(os.environ, XAAC_DROPIN_NO_DFT_CHAIN="1"))
+        m2 = re.search(r"(\d+) dft_hbe_apply calls .* ran on the GPU, (\d+) left to the reference", log2)
+        assert m2 and int(m2.group(1)) > 30 and int(m2.group(2)) == 0, log2[-800:]
+        assert open(gpu_wav, "rb").read() == open(str(tmp_path / "gpu2.wav"), "rb").read()   # the same kernels either way
 
     def samples(path):
         with wave.open(path) as w:

@@ -265,7 +265,7 @@ def test_gpu_against_the_oracle_on_fresh_chains_and_refusals(oracle):
                       _p(po[1])) == 0
             worst = max(worst, close(po[0], pr[i], (i, frame, "re")), close(po[1], pi[i], (i, frame, "im")))
     host = state.cpu().numpy()
-    assert host[bad].tobytes() == bad_before
+    assert host[bad].tobytes()[:-4] == bad_before[:-4] and HbeDftFullState.from_buffer_copy(host[bad].tobytes()).last_status == -1
     for i in range(n - 1):
         close(state_signals(sts[i]), state_signals(HbeDftFullState.from_buffer_copy(host[i].tobytes())), (i, "state"))
     assert worst < REL
