@@ -550,6 +550,47 @@ def secondary_round6(torch, libxaac_amd, ctx, dev, steps=20, n=8192):
         out["usac_fd_fac_ms_per_step"] = res
     except Exception as e:
         out["usac_fd_fac_ms_per_step"] = "unavailable: %r" % (e,)
+    # -- the DFT harmonic transposer (-esbr_hq:1; tests/golden/hbe_dft_ref.npz) -----------------------------------------------------
+    try:
+        import ctypes
+        import test_hbe_dft as td
+        G = np.load(td.GOLDEN)
+        cases = [int(c) for c in G["cases"]]
+        base = [td.golden_case(G, c) for c in cases]
+        m = n // 2                                    # 20 KB of state a channel
+        tile = lambda rows: torch.from_numpy(np.ascontiguousarray(np.stack([rows[i % len(rows)] for i in range(m)]))).to(dev)
+        st = tile([np.frombuffer(bytes(b[0]), np.uint8) for b in base])
+        cfg_tab = torch.from_numpy(np.stack([np.frombuffer(bytes(b[1]), np.uint8) for b in base])).to(dev)
+        cre = torch.from_numpy(np.stack([b[2][0] for b in base])).to(dev)
+        cim = torch.from_numpy(np.stack([b[2][1] for b in base])).to(dev)
+        cfg_idx = torch.tensor([i % len(cases) for i in range(m)], dtype=torch.int32, device=dev)
+        rngs = [np.random.default_rng(4000 + c) for c in cases]
+        ins = [td.golden_inputs(c, 0, r) for c, r in zip(cases, rngs)]
+        qre, qim = tile([i[0][0] for i in ins]), tile([i[0][1] for i in ins])
+        pvr, pvi = tile([i[1][0] for i in ins]), tile([i[1][1] for i in ins])
+        ovs = torch.tensor([ins[i % len(cases)][2] for i in range(m)], dtype=torch.int32, device=dev)
+        pitch = torch.tensor([ins[i % len(cases)][3] for i in range(m)], dtype=torch.int32, device=dev)
+        status = torch.zeros(m, dtype=torch.int32, device=dev)
+        step = lambda: ctx.hbe_dft_apply_batch(qre, qim, cfg_tab, cre, cim, st, pvr, pvi, status, pitch_in_bins=pitch, oversampling=ovs, cfg=cfg_idx)
+        step()
+        torch.cuda.synchronize()
+        got = pvr[:len(cases)].cpu().numpy()
+        ok = True
+        for j, c in enumerate(cases):                 # float path: the reference's rows to 2e-5 of their peak (include/xaac_hbe.h)
+            L, a0 = base[j][0].anal.analy_size, base[j][0].anal.a_start
+            ref = G["rows_%d" % c][0, 0]
+            ok = ok and bool(np.abs(got[j][:, a0:a0 + L] - ref).max() <= 2e-5 * np.abs(ref).max())
+        ms = timed(step)
+        alg = m * (2 * 2048 * 4 + 2 * 32 * 32 * 4 + 2 * (st.shape[1] - 4 * 1280))
+        e = entry(ms, alg, ok, float(status.cpu().numpy().astype(bool).mean()),
+                  "%d channel-frames a step through ixheaacd_dft_hbe_apply (xaac_hbe_dft_apply_batch_run: synthesis bank, eight hops of "
+                  "real FFT / polar stretch by 2..4 / inverse FFT / overlap-add, analysis bank); %d reference-made configurations "
+                  "(synth_size 8 / 12 / 16, analy_size 28 / 32, with and without oversampling and pitch) tiled" % (m, len(cases)))
+        e["channel_frames_per_s"] = round(m / ms * 1e3, 1)
+        e["first_step_within_2e-5_of_reference"] = e.pop("first_step_equals_reference_crc")
+        out["hbe_dft_transposer"] = e
+    except Exception as e:
+        out["hbe_dft_transposer"] = "unavailable: %r" % (e,)
     return out
 
 

@@ -49,18 +49,18 @@ def test_a_batch_of_streams_whose_sbr_headers_change_at_different_frames(tmp_pat
 
 def test_the_sweep_through_the_drop_in(tmp_path):
     """The same streams (and SBR at the three low core rates too) through the reference's own decoder with its seams served by
-    the library (oracle/_ref/xaacdec_dropin), with the default flags, -esbr:0, -dsample:1 and -dsample:1 -esbr:0: 372 decodes of 0.8 s streams.
+    the library (oracle/_ref/xaacdec_dropin), with the default flags, -esbr:0, -dsample:1 and -dsample:1 -esbr:0, at three of the six sampling rates (the whole sweep: profiles/r06_k_dropin_sweep.txt): 192 decodes of 0.8 s streams.
     (This is the sweep that found the reset-time rows the drop-in's eSBR seam had left stale: a 32 kHz stream with ENHSBR
     elements whose first SBR header arrives behind nine frames of audio.)"""
     for exe in ("oracle/_ref/xaacenc", "oracle/_ref/xaacdec", "oracle/_ref/xaacdec_dropin"):
         if not os.path.exists(os.path.join(ROOT, exe)):
             pytest.fail(exe + " missing: it did not travel with the snapshot / was not built")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_streams.py")], capture_output=True, text=True, timeout=1500,
-                       env=dict(os.environ, SWEEP_TMP=str(tmp_path), SWEEP_DECODER="dropin", SWEEP_ALL_SBR_RATES="1", SWEEP_SECONDS="0.8"))
+                       env=dict(os.environ, SWEEP_TMP=str(tmp_path), SWEEP_DECODER="dropin", SWEEP_ALL_SBR_RATES="1", SWEEP_SECONDS="0.8", SWEEP_RATES="22050,32000,48000"))
     lines = p.stdout.strip().splitlines()
     assert lines and lines[-1].startswith("cases "), p.stdout[-600:] + p.stderr[-600:]
     total, bad = int(lines[-1].split()[1]), int(lines[-1].split()[3])
-    assert total >= 340 and bad == 0 and p.returncode == 0, "\n".join(l for l in lines if "identical" not in l)
+    assert total >= 180 and bad == 0 and p.returncode == 0, "\n".join(l for l in lines if "identical" not in l)
 
 
 def test_the_sweep_with_the_dft_transposer(tmp_path):
