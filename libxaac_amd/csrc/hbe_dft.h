@@ -215,6 +215,7 @@ FX_HD void xd_polar(const CX &cx, const float *sp, float *mag, float *phase, int
 }
 
 #define XD_MIN(a, b) ((a) < (b) ? (a) : (b))
+FX_HD void xd_sincos(double x, double *s, double *c) { sincos(x, s, c); }
 
 /* The pitch-adaptive search all three variants share (:612-623, :681-692, :744-755): the source bin pair whose weaker magnitude
    is largest.  Returns m_val; m_tr / utk are written when a pair was found. */
@@ -246,6 +247,7 @@ FX_HD void xd_transpose_bin(const float *mag, const float *phase, const WIN &win
     const float w = win(T);
     if (w == 0.0f) continue;
     float mag_t = 0, phase_t;
+    double sn, cs; /* sin and cos of one argument come from one call (the values of the two separate calls the reference makes) */
     int m_tr = 0;
     if (T == 2) { /* ixheaacd_dft_hbe_apply_polar_t2 */
       int utk = i;
@@ -254,16 +256,18 @@ FX_HD void xd_transpose_bin(const float *mag, const float *phase, const WIN &win
       if (phase_t == 0.0) {
         sr += mag_t;
       } else {
-        sr += mag_t * (float)cos((double)phase_t);
-        si += mag_t * (float)sin((double)phase_t);
+        xd_sincos((double)phase_t, &sn, &cs);
+        sr += mag_t * (float)cs;
+        si += mag_t * (float)sn;
       }
       if (p > 0) {
         const float m_val = xd_cross_search(mag, i, T, p, p_flt, fft_size, &m_tr, &utk);
         if (m_val > q_thr * mag[2 * i / T]) {
           mag_t = (float)((double)w * sqrt((double)mag[utk]) * sqrt((double)mag[utk + p]));
           phase_t = (T - m_tr) * phase[utk] + m_tr * phase[utk + p];
-          sr += (float)((double)mag_t * cos((double)phase_t));
-          si += (float)((double)mag_t * sin((double)phase_t));
+          xd_sincos((double)phase_t, &sn, &cs);
+          sr += (float)((double)mag_t * cs);
+          si += (float)((double)mag_t * sn);
         }
       }
     } else if (T == 3) { /* ixheaacd_dft_hbe_apply_polar_t3 */
@@ -280,8 +284,9 @@ FX_HD void xd_transpose_bin(const float *mag, const float *phase, const WIN &win
         mag_t = w * (float)pow((double)mag[utk], 1.0 - (double)ptk) * k;
       }
       phase_t = T * ((1 - ptk) * phase[utk] + ptk * phase[utk + 1]);
-      sr += mag_t * (float)cos((double)phase_t);
-      si += mag_t * (float)sin((double)phase_t);
+      xd_sincos((double)phase_t, &sn, &cs);
+      sr += mag_t * (float)cs;
+      si += mag_t * (float)sn;
       if (p > 0) {
         const float m_val = xd_cross_search(mag, i, T, p, p_flt, fft_size, &m_tr, &utk);
         if (m_val > q_thr * mag[2 * i / T]) {
@@ -295,8 +300,9 @@ FX_HD void xd_transpose_bin(const float *mag, const float *phase, const WIN &win
             mag_t = w * k * (float)pow((double)mag[utk + p], (double)r);
             phase_t = phase[utk] + m_tr * phase[utk + p];
           }
-          sr += mag_t * (float)cos((double)phase_t);
-          si += mag_t * (float)sin((double)phase_t);
+          xd_sincos((double)phase_t, &sn, &cs);
+          sr += mag_t * (float)cs;
+          si += mag_t * (float)sn;
         }
       }
     } else { /* ixheaacd_dft_hbe_apply_polar_t */
@@ -304,16 +310,18 @@ FX_HD void xd_transpose_bin(const float *mag, const float *phase, const WIN &win
       const float ptk = (2.0f * i / T) - utk;
       mag_t = w * (float)pow((double)mag[utk], (double)(1.0f - ptk)) * (float)pow((double)mag[utk + 1], (double)ptk);
       phase_t = T * ((1 - ptk) * phase[utk] + ptk * phase[utk + 1]);
-      sr += mag_t * (float)cos((double)phase_t);
-      si += mag_t * (float)sin((double)phase_t);
+      xd_sincos((double)phase_t, &sn, &cs);
+      sr += mag_t * (float)cs;
+      si += mag_t * (float)sn;
       if (p > 0) {
         const float m_val = xd_cross_search(mag, i, T, p, p_flt, fft_size, &m_tr, &utk);
         if (m_val > q_thr * mag[2 * i / T]) {
           const float r = (float)m_tr / T;
           mag_t = w * (float)pow((double)mag[utk], 1.0 - (double)r) * (float)pow((double)mag[utk + p], (double)r);
           phase_t = (T - m_tr) * phase[utk] + m_tr * phase[utk + p];
-          sr += mag_t * (float)cos((double)phase_t);
-          si += mag_t * (float)sin((double)phase_t);
+          xd_sincos((double)phase_t, &sn, &cs);
+          sr += mag_t * (float)cs;
+          si += mag_t * (float)sn;
         }
       }
     }
