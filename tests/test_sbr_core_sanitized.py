@@ -161,3 +161,48 @@ def test_8_3_and_4_1_chains_on_fuzzed_grids_touch_nothing_outside_their_matrices
     out = run_child(asan_oracle, CHILD_RATIO)
     n, r = (int(t) for t in out.split()[1::2])
     assert n > 250 and r < n // 2
+
+
+CHILD_DFT = r'''
+import ctypes, sys
+import numpy as np
+sys.path.insert(0, %(tests)r)
+import test_hbe_dft as t
+from hbe_structs import HbeDftCfg, HbeDftFullState
+PF = ctypes.POINTER(ctypes.c_float)
+G = np.load(t.GOLDEN)
+lib = ctypes.CDLL(%(lib)r)
+fn = lib.xo_hbe_dft_apply
+fn.restype = ctypes.c_int
+fn.argtypes = [ctypes.POINTER(HbeDftFullState), ctypes.POINTER(HbeDftCfg), PF, PF, PF, PF, ctypes.c_int, ctypes.c_int, PF, PF]
+rng = np.random.default_rng(11)
+calls = refused = 0
+for case in [int(c) for c in G["cases"]]:
+    st0, cfg, coef = t.golden_case(G, case)
+    for trial in range(14):
+        st = t.clone(st0)
+        if trial %% 3 == 1:     # sizes and offsets the tables would never give: refused, or run inside the buffers
+            st.k_start = int(rng.integers(-2, 40)); st.anal.a_start = int(rng.integers(-2, 70)); st.max_stretch = int(rng.integers(-1, 7))
+        if trial %% 5 == 4:
+            st.synth_size = int(rng.choice([4, 8, 12, 16, 20, 7])); st.anal.analy_size = int(rng.choice([4, 24, 28, 32, 36, 64]))
+        for frame in range(2):
+            q = [np.ascontiguousarray(a) for a in t.frame_rows(rng, frame, t.CASES[case][0])]
+            if trial %% 4 == 2:   # values no decoder produces: the index arithmetic must not follow them anywhere
+                q[0][rng.integers(0, 32), rng.integers(0, 64)] = np.float32(rng.choice([np.inf, -np.inf, np.nan, 3e38]))
+            pv = [np.zeros((34, 64), np.float32) for _ in range(2)]
+            pitch = int(rng.choice([0, 1, 11, 12, 60, 127, 4000, -5, 2 ** 20]))
+            rc = fn(ctypes.byref(st), ctypes.byref(cfg), t._p(coef[0]), t._p(coef[1]), t._p(q[0]), t._p(q[1]), pitch, int(rng.integers(0, 2)),
+                    t._p(pv[0]), t._p(pv[1]))
+            calls += 1
+            refused += rc != 0
+print("calls", calls, "refused", refused)
+'''
+
+
+def test_dft_transposer_on_fuzzed_sizes_pitches_and_non_finite_rows_touches_nothing_outside_its_arrays(asan_oracle):
+    """xo_hbe_dft_apply (hbe_dft.h, the code the kernel runs) under AddressSanitizer: the committed configurations with start
+    bands, sizes and stretch counts no table gives, pitches far outside the 7 bits the stream carries, infinities and NaNs in
+    the rows -- refused or run, never outside a buffer"""
+    out = run_child(asan_oracle, CHILD_DFT)
+    n, r = (int(t) for t in out.split()[1::2])
+    assert n == 7 * 14 * 2 and 0 < r < n
