@@ -216,6 +216,14 @@ XAAC_API int32_t xaac_hbe_state_reinit(xaac_hbe_state *s, const xaac_sbr_header 
    reference would refuse (the tails behind it are left as they were). */
 #define XAAC_HBE_TAIL_BYTES (sizeof(xaac_hbe_state) - offsetof(xaac_hbe_state, synth_size))
 XAAC_API int32_t xaac_hbe_state_reinit_tails(uint8_t *tails, const xaac_sbr_header *headers, int32_t n);
+/* ixheaacd_dft_hbe_data_reinit (decoder/ixheaacd_hbe_dft_trans.c:272-455; -esbr_hq:1) for a 2:1 stream with 1024-line core frames:
+   the DFT transposer's sizes, band range and cross-over bands into `s` (its synthesis bank's delay line cleared, :302;
+   max_stretch carries over where the reference leaves it alone), the two time windows and the patches' cross-over windows into
+   `cfg`, the analysis bank's coefficient matrices into coef_re / coef_im ([64][128] floats each: :374-388, libm cos / sin as
+   the reference calls them).  Returns 0, or -1 where the reference returns an error or the sizes have no room in the structs
+   (xaac_hbe.h: sizes the reference has transforms for always fit). */
+XAAC_API int32_t xaac_hbe_dft_state_reinit(xaac_hbe_dft_state *s, xaac_hbe_dft_cfg *cfg, float *coef_re, float *coef_im,
+                                           const xaac_sbr_header *header);
 /* what ixheaacd_sbr_dec_reset (sbrdecoder.c:103-252) and ixheaacd_prepare_upsamp (:254-276) do to one channel's state
    for this frame's side info; channel = 0 or 1 (no-op beyond side->reset_channels / for frames without either) */
 XAAC_API void xaac_sbr_state_apply_side(xaac_sbr_state *s, const xaac_sbr_side *side, int32_t channel);

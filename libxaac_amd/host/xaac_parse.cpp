@@ -14,6 +14,7 @@
 #include <thread>
 #include <vector>
 #include <limits.h>
+#include <math.h>
 #include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -608,6 +609,118 @@ int32_t xaac_hbe_state_reinit(xaac_hbe_state *s, const xaac_sbr_header *h) {
       break;
     }
   }
+  return s->k_start < 0 ? -1 : 0;
+}
+
+namespace {
+#include "tables_hbe_dft.inc"
+
+/* ixheaacd_calc_anal_synth_window (hbe_dft_trans.c:140-270) for the transform sizes the reference has transforms for:
+   sin(pi (j + 1/2) / fft_size) put together from the ROM's sines in float arithmetic, as the reference does */
+bool xd_time_window(int fft_size, float *win) {
+  const float *tab;
+  int hop, stride;
+  switch (fft_size) {
+    case 128: tab = xd_sine_pi_n_by_1024, hop = 8, stride = 512; break;
+    case 256: tab = xd_sine_pi_n_by_1024, hop = 4, stride = 512; break;
+    case 512: tab = xd_sine_pi_n_by_1024, hop = 2, stride = 512; break;
+    case 192: tab = xd_sine_pi_n_by_768, hop = 4, stride = 384; break;
+    case 384: tab = xd_sine_pi_n_by_768, hop = 2, stride = 384; break;
+    case 448: tab = xd_sine_pi_n_by_896, hop = 2, stride = 448; break;
+    default: return false; /* (the other sizes of the reference's switch have no transform behind them: hbe_dft_trans.c:508-549) */
+  }
+  const float sin_pi_2_n = tab[hop >> 1], cos_pi_2_n = tab[stride + (hop >> 1)];
+  int i = 0, j = 0;
+  for (; j < (fft_size >> 1); i += hop, j++) {
+    const float cos_val = tab[i + stride], sin_val = tab[i];
+    win[j] = cos_val * sin_pi_2_n + sin_val * cos_pi_2_n;
+  }
+  for (; j < fft_size; j++, i += hop) {
+    const float cos_val = tab[i - stride], sin_val = tab[i];
+    win[j] = sin_val * cos_pi_2_n - cos_val * sin_pi_2_n;
+  }
+  return true;
+}
+
+/* ixheaacd_create_dft_hbe_window (:113-138): zero, a rising slope around x_over_bin1, one, a falling slope around x_over_bin2, zero --
+   the first 772 entries of the reference's `size` (the transposer reads bins 0 .. fft_size / 2 <= 768); false where the
+   rising slope would start in front of the array (the reference writes outside its own there) */
+bool xd_fd_window(float *win, int x1, int x2, int ts, int size) {
+  const float *slope = ts == 12 ? xd_window_ts_12 : xd_window_ts_18;
+  if (x1 - ts / 2 < 0) return false;
+  const auto put = [&](int n, float v) {
+    if (n < 772) win[n] = v;
+  };
+  int n;
+  for (n = 0; n < x1 - ts / 2; n++) put(n, 0);
+  for (n = x1 - ts / 2; n <= x1 + ts / 2; n++) put(n, slope[n - (x1 - ts / 2)]);
+  for (n = x1 + ts / 2 + 1; n < x2 - ts / 2; n++) put(n, 1.0f);
+  for (n = x2 - ts / 2; n <= x2 + ts / 2; n++)
+    if (n >= 0) put(n, 1.0f - slope[n - (x2 - ts / 2)]);
+  for (n = x2 + ts / 2 + 1; n < size; n++)
+    if (n >= 0) put(n, 0.0f);
+  return true;
+}
+}  // namespace
+
+int32_t xaac_hbe_dft_state_reinit(xaac_hbe_dft_state *s, xaac_hbe_dft_cfg *cfg, float *coef_re, float *coef_im, const xaac_sbr_header *h) {
+  const int n_lo = h->num_sf_bands[0], n_hi = h->num_sf_bands[1];
+  if (n_lo < 0 || n_lo > XAAC_SBR_MAX_FREQ_COEFFS / 2 || n_hi < 0 || n_hi > XAAC_SBR_MAX_FREQ_COEFFS) return -1;
+  const int16_t *lo = h->freq_band_tbl_lo, *hi = h->freq_band_tbl_hi;
+  if (lo[0] < 0 || lo[0] > 32) return -1;
+  const int fft_size[2] = {1024, 1536}, trans_samp[2] = {12, 18};
+  s->start_band = lo[0];
+  s->end_band = lo[n_lo];
+  s->synth_size = 4 * ((s->start_band + 4) / 8 + 1);
+  s->k_start = xs_hbe_k_start(s->start_band);
+  const int ana0 = (int)(s->synth_size / 32.0f * fft_size[0]);
+  memset(cfg, 0, sizeof(*cfg));
+  if (ana0 > XAAC_HBE_DFT_MAX_ANA || !xd_time_window(ana0, cfg->anal_window)) return -1;
+  memset(s->synth_buf, 0, sizeof(s->synth_buf));
+  const int temp_start = 2 * ((s->start_band - 1) / 2);
+  const int top = (s->end_band + 1 < 64 ? s->end_band + 1 : 64);
+  s->anal.analy_size = 4 * ((top - temp_start - 1) / 4 + 1);
+  const int over = temp_start + s->anal.analy_size - 64;
+  s->anal.a_start = temp_start - (over > 0 ? over : 0);
+  const int L = s->anal.analy_size;
+  const int syn0 = (int)(L / 64.0f * fft_size[0]);
+  if (L < 4 || L > 64 || syn0 > XAAC_HBE_DFT_MAX_SYN || !xd_time_window(syn0, cfg->synth_window)) return -1;
+  memset(s->x_over_qmf, 0, sizeof(s->x_over_qmf));
+  int x_over_bin[4][2];
+  memset(x_over_bin, 0, sizeof(x_over_bin));
+  memset(coef_re, 0, sizeof(float) * 64 * 128);
+  memset(coef_im, 0, sizeof(float) * 64 * 128);
+  for (int k = 0; k < L; k++)
+    for (int l = 0; l < 2 * L; l++) {
+      const double a = 3.14159265358979323846 / (2 * L) * ((k + 0.5) * (2 * l - L / 64.0) - L / 64.0 * s->anal.a_start);
+      coef_re[128 * k + l] = (float)cos(a);
+      coef_im[128 * k + l] = (float)sin(a);
+    }
+  int sfb = 0;
+  for (int patch = 1; patch <= 4; patch++) {
+    while (sfb <= n_lo && lo[sfb] <= patch * s->start_band) sfb++;
+    int band;
+    if (sfb <= n_lo) {
+      if (sfb > 0 && patch * s->start_band - lo[sfb - 1] <= 3) {
+        band = lo[sfb - 1];
+      } else {
+        int k = 0;
+        while (k <= n_hi && hi[k] <= patch * s->start_band) k++;
+        band = k > 0 ? hi[k - 1] : 0;
+      }
+      s->x_over_qmf[patch - 1] = band;
+      for (int o = 0; o < 2; o++) x_over_bin[patch - 1][o] = (int)(fft_size[o] * band / 128 + 0.5);
+    } else {
+      s->x_over_qmf[patch - 1] = s->end_band;
+      for (int o = 0; o < 2; o++) x_over_bin[patch - 1][o] = (int)(fft_size[o] * s->end_band / 128 + 0.5);
+      s->max_stretch = patch < 4 ? patch : 4;
+      break;
+    }
+  }
+  for (int patch = 0; patch < s->max_stretch - 1 && patch < 3; patch++)
+    for (int o = 0; o < 2; o++)
+      if (!xd_fd_window(cfg->fd_win[patch][o], x_over_bin[patch][o], x_over_bin[patch + 1][o], trans_samp[o], fft_size[o])) return -1;
+  s->last_status = 0;
   return s->k_start < 0 ? -1 : 0;
 }
 

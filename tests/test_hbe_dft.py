@@ -269,3 +269,53 @@ def test_gpu_against_the_oracle_on_fresh_chains_and_refusals(oracle):
     for i in range(n - 1):
         close(state_signals(sts[i]), state_signals(HbeDftFullState.from_buffer_copy(host[i].tobytes())), (i, "state"))
     assert worst < REL
+
+
+# ---- the host's re-initialisation (libxaac_host.so: xaac_hbe_dft_state_reinit) against the reference's ------------------------
+def test_host_reinit_makes_what_the_reference_makes(reference):
+    """ixheaacd_dft_hbe_data_reinit (hbe_dft_trans.c:272-455) for every start / end band pair whose sizes the reference has
+    transforms for (and a spread of those it has none for): sizes, cross-over bands, the two time windows, the patches'
+    cross-over windows and the analysis bank's matrices, word for word"""
+    sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import sys
+    sys.path.insert(0, sys_path)
+    from libxaac_amd import decoder
+    import sbr_capture as cap
+    host = decoder.load_host_library()
+    fn = host.xaac_hbe_dft_state_reinit
+    fn.restype = ctypes.c_int32
+    fn.argtypes = [ctypes.POINTER(HbeDftFullState), ctypes.POINTER(HbeDftCfg), PF, PF, ctypes.POINTER(cap.Header)]
+    rr = reference.lib.ref_hbe_dft_reinit
+    rr.restype = ctypes.c_int
+    rr.argtypes = [P16, ctypes.c_int, P16, ctypes.c_int, ctypes.POINTER(HbeDftFullState), ctypes.POINTER(HbeDftCfg), PF, PF]
+    same = refused = 0
+    for sb in range(5, 28):
+        for end in range(sb + 12, min(sb + 36, 65)):
+            lo, hi = tables(sb, end)
+            if len(lo) - 1 > 28 or len(hi) - 1 > 56:
+                continue
+            for prev_ms in (0, 3):
+                sr, so, cr, co = HbeDftFullState(), HbeDftFullState(), HbeDftCfg(), HbeDftCfg()
+                sr.max_stretch = so.max_stretch = prev_ms
+                kr = [np.zeros((64, 128), np.float32) for _ in range(2)]
+                ko = [np.full((64, 128), 7, np.float32) for _ in range(2)]
+                rc_r = rr(lo.ctypes.data_as(P16), len(lo) - 1, hi.ctypes.data_as(P16), len(hi) - 1, ctypes.byref(sr), ctypes.byref(cr), _p(kr[0]), _p(kr[1]))
+                h = cap.Header()
+                h.num_sf_bands[0], h.num_sf_bands[1] = len(lo) - 1, len(hi) - 1
+                for i, v in enumerate(lo):
+                    h.freq_band_tbl_lo[i] = int(v)
+                for i, v in enumerate(hi):
+                    h.freq_band_tbl_hi[i] = int(v)
+                rc_o = fn(ctypes.byref(so), ctypes.byref(co), _p(ko[0]), _p(ko[1]), ctypes.byref(h))
+                fits = rc_r == 0 and 32 * sr.synth_size in (256, 384, 512) and 16 * sr.anal.analy_size in (448, 512)
+                if not fits:
+                    refused += rc_o != 0
+                    continue
+                assert rc_o == 0, (sb, end, prev_ms)
+                for nm in ("synth_size", "k_start", "start_band", "end_band", "max_stretch"):
+                    assert getattr(sr, nm) == getattr(so, nm), (nm, sb, end)
+                assert (sr.anal.analy_size, sr.anal.a_start) == (so.anal.analy_size, so.anal.a_start) and list(sr.x_over_qmf) == list(so.x_over_qmf)
+                assert bytes(cr) == bytes(co), ("windows", sb, end, prev_ms)
+                assert np.array_equal(kr[0].view(np.uint32), ko[0].view(np.uint32)) and np.array_equal(kr[1].view(np.uint32), ko[1].view(np.uint32))
+                same += 1
+    assert same > 150 and refused > 50, (same, refused)

@@ -106,6 +106,10 @@ def test_hbe_tables_equal_reference_rom(tmp_path):
     _regenerated_equals_committed("gen_tables_hbe", "tables_hbe.inc", tmp_path)
 
 
+def test_hbe_dft_host_tables_equal_reference_rom(tmp_path):
+    _regenerated_equals_committed("gen_tables_hbe_dft_host", "tables_hbe_dft.inc", tmp_path, where="host")
+
+
 def test_pvc_tables_equal_reference_rom(tmp_path):
     _regenerated_equals_committed("gen_tables_pvc", "tables_pvc.inc", tmp_path)
 
