@@ -26,6 +26,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef XD_T
+#define XD_T(i) /* stage timers of profiling builds (hbe_kernel.hip, tools/prof_hbe_dft.py) */
+#endif
+
 struct XdC {
   float r, i;
 };
@@ -124,17 +128,6 @@ FX_HD void xd_cfft(const CX &cx, XdC *x, XdC *tmp, const XdC *w, int n, int sign
     }
     x[k1 + 16 * k2].r = ar;
     x[k1 + 16 * k2].i = ai;
-  }
-  cx.sync();
-}
-
-/* ixheaacd_dft_hbe_fft_memmove (:448): the halves of `size` floats change places */
-template <class CX>
-FX_HD void xd_swap_halves(const CX &cx, float *p, int size) {
-  for (int m = cx.lane; m < size / 2; m += cx.n) {
-    const float t = p[m];
-    p[m] = p[m + size / 2];
-    p[m + size / 2] = t;
   }
   cx.sync();
 }
@@ -308,7 +301,10 @@ FX_HD void xd_transpose_bin(const float *mag, const float *phase, const WIN &win
     } else { /* ixheaacd_dft_hbe_apply_polar_t */
       int utk = 2 * i / T;
       const float ptk = (2.0f * i / T) - utk;
-      mag_t = w * (float)pow((double)mag[utk], (double)(1.0f - ptk)) * (float)pow((double)mag[utk + 1], (double)ptk);
+      if (ptk == 0.0f) /* every second bin: pow(x, 1) is x and pow(y, 0) is 1, exactly (C99 F.9.4.4) -- the two calls left out */
+        mag_t = w * mag[utk] * 1.0f;
+      else
+        mag_t = w * (float)pow((double)mag[utk], (double)(1.0f - ptk)) * (float)pow((double)mag[utk + 1], (double)ptk);
       phase_t = T * ((1 - ptk) * phase[utk] + ptk * phase[utk + 1]);
       xd_sincos((double)phase_t, &sn, &cs);
       sr += mag_t * (float)cs;
@@ -334,7 +330,8 @@ FX_HD void xd_transpose_bin(const float *mag, const float *phase, const WIN &win
 struct XdWork {
   float *in;    /* [2 ana0]  ptr_input_buf */
   float *out;   /* [4 syn0]  ptr_output_buf */
-  float *spec;  /* [fft]     ptr_spectrum */
+  float *spec;  /* [ana]     ptr_spectrum + ana_fft_offset: the words the transform works on */
+  float *awin;  /* [ana0]    anal_window */
   float *tx;    /* [fft + 2] ptr_spectrum_tx */
   float *mag;   /* [fft / 2 + 2] */
   float *phase; /* [fft / 2 + 2] */
@@ -343,30 +340,37 @@ struct XdWork {
 };
 
 /* The eight hops (:814-935) on the signals in w->in / w->out (input already shifted and filled by the synthesis bank, output
-   already shifted and its upper half cleared). */
+   already shifted and its upper half cleared).  Of ptr_spectrum only the ana_fft_size words behind ana_fft_offset are ever read
+   (the transform, then ixheaacd_karth2polar), so only those are made -- with the halves already in the places
+   ixheaacd_dft_hbe_fft_memmove gives them; mag / phase outside that range stay the zeros they start as; the way back reads the
+   transform's output through the same exchange of halves.  w->awin: the analysis window where the hops read it fastest. */
 template <class CX>
 FX_HD void xd_hops(const CX &cx, const XdSizes &z, const xaac_hbe_dft_cfg *cfg, int ovs, int pitch_in_bins, const XdWork *w) {
   xd_twiddles(cx, w->wa, z.ana / 2);
   xd_twiddles(cx, w->ws, z.syn / 2);
-  cx.sync();
   const int half = z.fft / 2;
+  for (int e = cx.lane; e < half + 2; e += cx.n) {
+    w->mag[e] = 0.0f;
+    w->phase[e] = 0.0f;
+  }
+  for (int e = cx.lane; e < z.ana0; e += cx.n) w->awin[e] = cfg->anal_window[e];
+  cx.sync();
+  XD_T(0);
   for (int hop = 0; hop < 8; hop++) {
     const float *src = w->in + hop * z.in_hop;
-    /* :815-824 */
-    for (int e = cx.lane; e < z.fft; e += cx.n) {
-      const int j = e - (z.ana_pad + z.ana_off);
-      w->spec[e] = (j >= 0 && j < z.ana0) ? src[j] * cfg->anal_window[j] : 0.0f;
-    }
-    for (int e = cx.lane; e < half + 2; e += cx.n) {
-      w->mag[e] = 0.0f;
-      w->phase[e] = 0.0f;
+    float *a = w->spec; /* = ptr_spectrum + ana_fft_offset */
+    /* :815-826: word r of the range comes from word r +- ana / 2 of the windowed, padded block */
+    for (int r = cx.lane; r < z.ana; r += cx.n) {
+      const int j = (r < z.ana / 2 ? r + z.ana / 2 : r - z.ana / 2) - z.ana_pad;
+      a[r] = (j >= 0 && j < z.ana0) ? src[j] * w->awin[j] : 0.0f;
     }
     cx.sync();
-    float *a = w->spec + z.ana_off;
-    xd_swap_halves(cx, a, z.ana);
+    XD_T(1);
     xd_cfft(cx, reinterpret_cast<XdC *>(a), w->tmp, w->wa, z.ana / 2, -1);
     xd_real_post(cx, a, z.ana);
+    XD_T(2);
     xd_polar(cx, a, w->mag + z.ana_off / 2, w->phase + z.ana_off / 2, z.ana);
+    XD_T(3);
     /* :862-891 (ptr_spectrum_tx has fft_size + 2 words) */
     for (int i = cx.lane; i <= half; i += cx.n) {
       float r, im;
@@ -375,15 +379,19 @@ FX_HD void xd_hops(const CX &cx, const XdSizes &z, const xaac_hbe_dft_cfg *cfg, 
       w->tx[2 * i + 1] = im;
     }
     cx.sync();
+    XD_T(4);
     float *b = w->tx + z.syn_off;
     if (cx.lane == 0) b[1] = b[z.syn]; /* :893 */
     cx.sync();
     xd_real_pre(cx, b, z.syn);
     xd_cfft(cx, reinterpret_cast<XdC *>(b), w->tmp, w->ws, z.syn / 2, 1);
-    xd_swap_halves(cx, b, z.syn);
     float *dst = w->out + hop * z.out_hop;
-    for (int j = cx.lane; j < z.syn0; j += cx.n) dst[j] += b[z.syn_pad + j] * cfg->synth_window[j]; /* :930-937 */
+    for (int j = cx.lane; j < z.syn0; j += cx.n) { /* :928-937 */
+      const int r = z.syn_pad + j;
+      dst[j] += b[r < z.syn / 2 ? r + z.syn / 2 : r - z.syn / 2] * cfg->synth_window[j];
+    }
     cx.sync();
+    XD_T(5);
   }
 }
 

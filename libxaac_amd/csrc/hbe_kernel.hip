@@ -15,6 +15,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifdef XE_PROFILE /* stage timers of the DFT transposer's hops (tools/prof_hbe_dft.py): thread 0's cycles into xh_prof_total[0..5] */
+extern __device__ unsigned long long xh_prof_total[8];
+__shared__ long long xd_prof_last;
+#define XD_T(i)                                                                   \
+  do {                                                                            \
+    if (threadIdx.x == 0) {                                                       \
+      const long long t_ = clock64();                                             \
+      atomicAdd(&xh_prof_total[i], (unsigned long long)(t_ - xd_prof_last));      \
+      xd_prof_last = t_;                                                          \
+    }                                                                             \
+  } while (0)
+#endif
 #include "hbe_trans.h"
 #include "hbe_dft.h"
 #include "hbe_kernel.h"
@@ -399,6 +411,9 @@ __global__ __launch_bounds__(XAAC_HBE_DFT_CORE_THREADS) void xaac_hbe_dft_core_k
   const int ovs = p.side ? ((p.side[ch].harmonic_sbr & XAAC_ESBR_OVERSAMPLING) ? 1 : 0) : (p.oversampling && p.oversampling[ch] ? 1 : 0);
   const int pitch = hbe_pitch(p.pitch, p.side, ch);
   const xaac_hbe_dft_cfg *cfg = p.cfg_tab + (p.cfg ? p.cfg[ch] : 0);
+#ifdef XE_PROFILE
+  const long long xd_t_start = clock64();
+#endif
   XdSizes z;
   const bool ok = xd_sizes(st, ovs, &z); /* (uniform: every lane reads the same words) */
   if (lane == 0) {
@@ -438,10 +453,18 @@ __global__ __launch_bounds__(XAAC_HBE_DFT_CORE_THREADS) void xaac_hbe_dft_core_k
     for (int e = lane; e < 20 * s; e += NT) st->synth_buf[e] = vv[(31 - e / (2 * s) + 9) * 2 * s + e % (2 * s)];
     __syncthreads(); /* vv is dead: the hops' arrays take its place */
   }
+#ifdef XE_PROFILE
+  if (threadIdx.x == 0) { /* [6]: everything in front of the hops (loads, the synthesis bank) */
+    const long long t_ = clock64();
+    atomicAdd(&xh_prof_total[6], (unsigned long long)(t_ - xd_t_start));
+    xd_prof_last = t_;
+  }
+#endif
   XdWork w;
   w.in = in;
   w.out = out;
-  w.spec = U;
+  w.spec = U;        /* 768 words */
+  w.awin = U + 768;  /* 512 words (+ 256 spare: the hop's arrays keep the places the 1536-word spectrum gave them) */
   w.tx = U + 1536;
   w.mag = w.tx + 1540;
   w.phase = w.mag + 772;

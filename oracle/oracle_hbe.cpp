@@ -101,9 +101,9 @@ int xo_hbe_dft_apply(xaac_hbe_dft_state *st, const xaac_hbe_dft_cfg *cfg, const 
   /* :805-809 */
   memmove(st->output_buf, st->output_buf + 2 * z.syn0, sizeof(float) * 2 * z.syn0);
   memset(st->output_buf + 2 * z.syn0, 0, sizeof(float) * 2 * z.syn0);
-  static thread_local float spec[1536], tx[1536 + 2], mag[768 + 2], phase[768 + 2];
+  static thread_local float spec[768], awin[512], tx[1536 + 2], mag[768 + 2], phase[768 + 2];
   static thread_local XdC wa[384], ws[384], tmp[384];
-  const XdWork w = {st->input_buf, st->output_buf, spec, tx, mag, phase, wa, ws, tmp};
+  const XdWork w = {st->input_buf, st->output_buf, spec, awin, tx, mag, phase, wa, ws, tmp};
   xd_hops(cx, z, cfg, ovs, pitch_in_bins, &w);
   return xo_hbe_dft_anal(&st->anal, st->output_buf, coef_re, coef_im, 32, pv_re, pv_im);
 }
