@@ -86,6 +86,16 @@ def test_null_and_bad_arguments_are_fatal_codes():
     assert lib.xaac_destroy(None) & 0x80000000
     assert lib.xaac_sync(None) & 0x80000000
     assert lib.xaac_imdct_process_batch(None, None) & 0x80000000
+    # every batch entry point turns a missing context or descriptor into a fatal code before it looks at anything else
+    import re
+    text = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("xaac_amd.h", "xaac_esbr.h", "xaac_hbe.h", "xaac_pvc.h"))
+    names = set(re.findall(r"XAAC_API int32_t (xaac_\w+)\(xaac_ctx \*\w+, const \w+ \*\w+\);", text))
+    assert len(names) >= 25 and "xaac_hbe_dft_apply_batch_run" in names and "xaac_esbr_sbr_process_batch" in names
+    for n in sorted(names):
+        fn = getattr(lib, n)
+        fn.restype = ctypes.c_int32
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        assert fn(None, None) & 0x80000000, n
 
 
 def _eld_state():
