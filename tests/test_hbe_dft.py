@@ -319,3 +319,99 @@ def test_host_reinit_makes_what_the_reference_makes(reference):
                 assert np.array_equal(kr[0].view(np.uint32), ko[0].view(np.uint32)) and np.array_equal(kr[1].view(np.uint32), ko[1].view(np.uint32))
                 same += 1
     assert same > 150 and refused > 50, (same, refused)
+
+
+@pytest.mark.gpu
+def test_path_a_chain_with_the_dft_transposer_is_the_same_for_a_batch_and_for_its_channels_alone():
+    """xaac_esbr_sbr_process_batch with hbe_dft_state on the committed reference-made Path A chains (HE-AAC channels with their
+    harmonic frames): every chain gets the DFT transposer the host's re-initialisation makes from its header's band tables (a
+    new one where the tables change), chains whose sizes have no transform stay in the batch as refused channels.  The whole batch
+    walked step by step against every chain walked alone: outputs, Path A states and transposer states byte for byte -- the
+    per-channel strides, configuration indices, skipped (no SBR processing) and refused channels of the chained launches.
+    (What the chain computes is held to the reference through the drop-in: tests/test_dropin_gpu.py, tests/test_sweep_gpu.py.)"""
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import libxaac_amd
+    from libxaac_amd import decoder
+    import sbr_capture as cap
+    import test_esbr_chains as tc
+    from make_golden_esbr_chains import chain_core
+    host = decoder.load_host_library()
+    reinit = host.xaac_hbe_dft_state_reinit
+    reinit.restype = ctypes.c_int32
+    reinit.argtypes = [ctypes.POINTER(HbeDftFullState), ctypes.POINTER(HbeDftCfg), PF, PF, ctypes.c_void_p]
+    CH = tc.FIXTURES["aac"]
+    order = tc.steps_of_chains(CH)
+    chains = [c for c in range(len(order)) if not CH["chain_ps"][c] and tc.chain_has_transposer(CH, order[c]) and len(order[c]) >= 8][:20]
+    n = len(chains)
+    assert n >= 8
+    spoiled = {chains[3]}       # one channel whose transposer gets a bank size without a transform: refused inside the batch
+    dev = torch.device("cuda:0")
+    ctx = libxaac_amd.XaacContext(0, 0)
+    steps = 8
+
+    def tables_of(row):
+        h = cap.Header.from_buffer_copy(CH["header"][row].tobytes())
+        return bytes(h)[cap.Header.num_sf_bands.offset:cap.Header.freq_band_tbl_noise.offset]
+
+    def walk(members):
+        """the chains `members` as one batch; returns per step (out, state, dft state) arrays"""
+        m = len(members)
+        dst = [HbeDftFullState() for _ in members]
+        cfgs = [HbeDftCfg() for _ in members]
+        coefs = [[np.zeros((64, 128), np.float32) for _ in range(2)] for _ in members]
+        seen = [None] * m
+        t_st = torch.from_numpy(np.ascontiguousarray(CH["est0"][members])).to(dev)
+        t_d = None
+        trace = []
+        for s in range(steps):
+            rows = [order[c][s] for c in members]
+            host_d = t_d.cpu().numpy() if t_d is not None else None
+            for i, r in enumerate(rows):                      # a header with other band tables: a new transposer, signals kept
+                tb = tables_of(r)
+                if tb != seen[i]:
+                    seen[i] = tb
+                    if host_d is not None:
+                        dst[i] = HbeDftFullState.from_buffer_copy(host_d[i].tobytes())
+                    hdr = np.ascontiguousarray(CH["header"][r])
+                    reinit(ctypes.byref(dst[i]), ctypes.byref(cfgs[i]), _p(coefs[i][0]), _p(coefs[i][1]), hdr.ctypes.data_as(ctypes.c_void_p))
+                    if members[i] in spoiled:
+                        dst[i].synth_size = 20
+                    if host_d is not None:
+                        host_d[i] = np.frombuffer(bytes(dst[i]), np.uint8)
+            if t_d is None:
+                host_d = np.stack([np.frombuffer(bytes(d), np.uint8) for d in dst])
+            t_d = torch.from_numpy(np.ascontiguousarray(host_d)).to(dev)
+            cfg_tab = torch.from_numpy(np.stack([np.frombuffer(bytes(c), np.uint8) for c in cfgs])).to(dev)
+            cre = torch.from_numpy(np.stack([k[0] for k in coefs])).to(dev)
+            cim = torch.from_numpy(np.stack([k[1] for k in coefs])).to(dev)
+            core = torch.from_numpy(np.stack([chain_core(int(CH["chain_run"][c]), int(CH["chain_id"][c]), s) for c in members])).to(dev)
+            g = lambda k: torch.from_numpy(np.ascontiguousarray(CH[k][rows])).to(dev)
+            out = torch.zeros((m, 2048), dtype=torch.float32, device=dev)
+            status = torch.full((m,), 7, dtype=torch.int32, device=dev)
+            ws = torch.zeros(ctx.esbr_workspace_bytes(m), dtype=torch.uint8, device=dev)
+            ctx.esbr_sbr_process_batch(core, g("header"), g("frame"), g("side"), t_st, out, ws, status,
+                                       hbe_dft=(t_d, cfg_tab, cre, cim, torch.arange(m, dtype=torch.int32, device=dev)))
+            ctx.sync()
+            trace.append((out.cpu().numpy(), t_st.cpu().numpy(), t_d.cpu().numpy(), status.cpu().numpy()))
+        return trace
+
+    whole = walk(chains)
+    ran = refused = 0
+    for i, c in enumerate(chains):
+        alone = walk([c])
+        for s in range(steps):
+            for k, nm in enumerate(("out", "state", "transposer state", "status")):
+                assert np.array_equal(whole[s][k][i], alone[s][k][0]), (nm, c, s)
+            last = HbeDftFullState.from_buffer_copy(whole[s][2][i].tobytes()).last_status
+            ran += last == 0
+            refused += last == -1
+    assert ran > 100 and refused == steps, (ran, refused)
+    # the transposer's rows reach the output where a frame asks for harmonic patching: such frames exist in the chains walked
+    from esbr_structs import EsbrSide
+    off = EsbrSide.harmonic_sbr.offset
+    assert any(int(np.frombuffer(CH["side"][order[c][s]].tobytes()[off:off + 2], np.int16)[0]) & 1 for c in chains for s in range(steps))
+    ctx.close()
