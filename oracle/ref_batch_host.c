@@ -61,6 +61,7 @@ typedef struct {
   sem_t done;
   volatile int req;   /* REQ_* while the instance waits */
   volatile int lim_nch, lim_len;
+  volatile int dft;   /* the eSBR request in flight carries a DFT transposer (-esbr_hq:1) */
   long calls[REQ_KINDS];
 } inst_t;
 
@@ -87,6 +88,12 @@ typedef struct {
   xaac_esbr_state *est;
   xaac_esbr_ps_state *eps;
   xaac_hbe_state *ehb; /* the channels' QMF harmonic transposers (run on every processed frame, as the reference does) */
+  /* -esbr_hq:1: the DFT transposers in their place: state, the windows and the analysis bank's matrices the reference's
+     re-initialisation made (one configuration per instance) */
+  xaac_hbe_dft_state *edf;
+  xaac_hbe_dft_cfg *ecf;
+  float *ecoef; /* [2][n][64][128]: the real matrices of all instances, then the imaginary ones */
+  int32_t *ecfg; /* [n]: i */
   float *ecore, *etime, *etime_r;
   /* limiter */
   int32_t *lx;
@@ -114,8 +121,9 @@ static size_t group_bytes(int n) {
   size_t per = 4096 + 2048 + 4096 + 8 + 8 + 8 + sizeof(xaac_sbr_header) + sizeof(xaac_sbr_frame) + sizeof(xaac_sbr_state) +
                sizeof(xaac_ps_frame) + sizeof(xaac_ps_state) + 2048 + 8192 + 4 + 1024 * LIM_MAX_CH * 4 + 8 +
                sizeof(xaac_limiter_state) + sizeof(inst_t) + sizeof(xaac_esbr_side) + sizeof(xaac_esbr_state) +
-               sizeof(xaac_esbr_ps_state) + sizeof(xaac_hbe_state) + 4096 + 8192 + 8192;
-  return (size_t)n * per + 96 * 256;
+               sizeof(xaac_esbr_ps_state) + sizeof(xaac_hbe_state) + 4096 + 8192 + 8192 + sizeof(xaac_hbe_dft_state) +
+               sizeof(xaac_hbe_dft_cfg) + 2 * 64 * 128 * 4 + 4;
+  return (size_t)n * per + 128 * 256;
 }
 
 static void group_layout(group_t *g, int n, char *base) {
@@ -146,6 +154,10 @@ static void group_layout(group_t *g, int n, char *base) {
   g->ecore = carve(&cur, (size_t)n * 4096);
   g->etime = carve(&cur, (size_t)n * 8192);
   g->etime_r = carve(&cur, (size_t)n * 8192);
+  g->edf = carve(&cur, sizeof(xaac_hbe_dft_state) * n);
+  g->ecf = carve(&cur, sizeof(xaac_hbe_dft_cfg) * n);
+  g->ecoef = carve(&cur, (size_t)n * 2 * 64 * 128 * 4);
+  g->ecfg = carve(&cur, (size_t)n * 4);
 }
 
 /* ---- child side: post the request, sleep until the parent has the results in the staging row ------------------- */
@@ -187,6 +199,49 @@ VOID __wrap_ixheaacd_imdct_process(ia_aac_dec_overlap_info *oi, WORD32 *spec, ia
   ics->qshift_adj = g->qadj[i];
 }
 
+/* ---- -esbr_hq:1: the DFT transposer's struct members <-> the group's rows (as oracle/ref_dropin.c: dft_upload / dft_download) ---- */
+static int dft_sizes_fit(const ia_esbr_hbe_txposer_struct *t) {
+  const int ana0 = t->ana_fft_size[0], syn0 = t->syn_fft_size[0];
+  return ana0 >= 0 && ana0 <= XAAC_HBE_DFT_MAX_ANA && syn0 >= 0 && syn0 <= XAAC_HBE_DFT_MAX_SYN && ana0 == 32 * t->synth_size &&
+         syn0 == 16 * t->analy_size;
+}
+static void dft_to_rows(const ia_esbr_hbe_txposer_struct *t, group_t *g, int i) {
+  xaac_hbe_dft_state *st = &g->edf[i];
+  xaac_hbe_dft_cfg *cfg = &g->ecf[i];
+  const int ana0 = t->ana_fft_size[0], syn0 = t->syn_fft_size[0];
+  int tr, o;
+  memset(st, 0, sizeof(*st));
+  memcpy(st->input_buf, t->ptr_input_buf, sizeof(float) * 2 * ana0);
+  memcpy(st->output_buf, t->ptr_output_buf, sizeof(float) * 4 * syn0);
+  memcpy(st->synth_buf, t->synth_buf, sizeof(st->synth_buf));
+  memcpy(st->anal.analy_buf, t->analy_buf, sizeof(st->anal.analy_buf));
+  st->anal.analy_size = t->analy_size;
+  st->anal.a_start = t->a_start;
+  st->synth_size = t->synth_size;
+  st->k_start = t->k_start;
+  st->start_band = t->start_band;
+  st->end_band = t->end_band;
+  st->max_stretch = t->max_stretch;
+  for (o = 0; o < 6; o++) st->x_over_qmf[o] = t->x_over_qmf[o];
+  memset(cfg, 0, sizeof(*cfg));
+  memcpy(cfg->anal_window, t->anal_window, sizeof(float) * ana0);
+  memcpy(cfg->synth_window, t->synth_window, sizeof(float) * syn0);
+  for (tr = 0; tr < 3; tr++)
+    for (o = 0; o < 2; o++) memcpy(cfg->fd_win[tr][o], t->fd_win_buf[tr][o], sizeof(cfg->fd_win[tr][o]));
+  memcpy(g->ecoef + (size_t)i * 64 * 128, t->str_dft_hbe_anal_coeff.real, 64 * 128 * 4);
+  memcpy(g->ecoef + ((size_t)g->n + i) * 64 * 128, t->str_dft_hbe_anal_coeff.imag, 64 * 128 * 4);
+  g->ecfg[i] = i;
+}
+static void dft_from_rows(const group_t *g, int i, ia_esbr_hbe_txposer_struct *t) {
+  const xaac_hbe_dft_state *st = &g->edf[i];
+  const int ana0 = t->ana_fft_size[0], syn0 = t->syn_fft_size[0];
+  if (st->last_status) return;
+  memcpy(t->ptr_input_buf, st->input_buf, sizeof(float) * 2 * ana0);
+  memcpy(t->ptr_output_buf, st->output_buf, sizeof(float) * 4 * syn0);
+  memcpy(t->synth_buf, st->synth_buf, sizeof(st->synth_buf));
+  memcpy(t->analy_buf, st->anal.analy_buf, sizeof(st->anal.analy_buf));
+}
+
 WORD32 __real_ixheaacd_sbr_dec(ia_sbr_dec_struct *, WORD16 *, ia_sbr_header_data_struct *,
                                ia_sbr_frame_info_data_struct *, ia_sbr_prev_frame_data_struct *, ia_ps_dec_struct *,
                                ia_sbr_qmf_filter_bank_struct *, ia_sbr_scale_fact_struct *, FLAG, FLAG, WORD32 *,
@@ -205,7 +260,8 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
   const int ps_on = with_ps && apply;
   /* the reference's default flags: the eSBR branch (sbr_dec.c:816-1009) of an HE-AAC channel / HE-AACv2 stream, as in
      oracle/ref_dropin.c */
-  if (g && h->enh_sbr && aot != AOT_ER_AAC_ELD && aot != AOT_ER_AAC_LD && !h->usac_flag && h->hbe_flag && d->p_hbe_txposer != NULL && !h->esbr_hq &&
+  if (g && h->enh_sbr && aot != AOT_ER_AAC_ELD && aot != AOT_ER_AAC_LD && !h->usac_flag && h->hbe_flag && d->p_hbe_txposer != NULL &&
+      (!h->esbr_hq || dft_sizes_fit(d->p_hbe_txposer)) &&
       (h->channel_mode == PS_STEREO ? (ps != NULL && synth_r != NULL && !ps->use_34_st_bands && !ps->use_pca_rot_flg && ps->ps_mode == 0)
                                     : !h->enh_sbr_ps) &&
       !drc_on && !ldmps && !mps && !f->mps_sbr_flag && f->sbr_mode != PVC_SBR && h->sbr_ratio_idx != SBR_UPSAMPLE_IDX_4_1 &&
@@ -223,7 +279,9 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     to_frame(f, apply, &g->frm[i]);
     to_esbr_side(h, f, &g->esd[i]);
     to_esbr_state(d, h, f, &g->est[i]);
-    to_hbe_state(d->p_hbe_txposer, &g->ehb[i]);
+    g->inst[i].dft = h->esbr_hq ? 1 : 0;
+    if (h->esbr_hq) dft_to_rows(d->p_hbe_txposer, g, i);
+    else to_hbe_state(d->p_hbe_txposer, &g->ehb[i]);
     memcpy(g->ecore + 1024 * (size_t)i, d->time_sample_buf, 4096);
     if (eps) {
       to_ps_frame(ps, &g->psf[i]);
@@ -233,7 +291,8 @@ WORD32 __wrap_ixheaacd_sbr_dec(ia_sbr_dec_struct *d, WORD16 *time_data, ia_sbr_h
     if (g->status[i]) return g->status[i];
     memcpy(d->time_sample_buf, g->etime + 2048 * (size_t)i, 8192);
     from_esbr_state(&g->est[i], d, h, f);
-    if (apply) from_hbe_state(&g->ehb[i], d->p_hbe_txposer, h);
+    if (apply && h->esbr_hq) dft_from_rows(g, i, d->p_hbe_txposer);
+    else if (apply) from_hbe_state(&g->ehb[i], d->p_hbe_txposer, h);
     if (eps) {
       memcpy(ps->time_sample_buf[1], g->etime_r + 2048 * (size_t)i, 8192);
       from_esbr_ps_state(&g->eps[i], ps, synth_r);
@@ -334,6 +393,7 @@ static void die(const char *what) {
 
 /* all live instances of the group wait at a seam: one batch for each kind of request present (one kind, unless the
    streams of a group differ) */
+static long g_batches_dft; /* eSBR batches that carried DFT transposers */
 static void launch_group(group_t *g, gpu_group_t *gg, long *batches) {
   const size_t n = (size_t)g->n;
   int kinds[REQ_KINDS] = {0};
@@ -366,16 +426,32 @@ static void launch_group(group_t *g, gpu_group_t *gg, long *batches) {
       xaac_esbr_sbr_batch b;
       memset(&b, 0, sizeof(b));
       H2D(hdr, n * sizeof(xaac_sbr_header)); H2D(frm, n * sizeof(xaac_sbr_frame)); H2D(esd, n * sizeof(xaac_esbr_side));
-      H2D(est, n * sizeof(xaac_esbr_state)); H2D(ehb, n * sizeof(xaac_hbe_state)); H2D(ecore, n * 4096);
+      int dft = 0; /* -esbr_hq:1 is the run's flag: the instances of a rendezvous agree on it */
+      for (int i = 0; i < g->n; i++)
+        if (g->inst[i].req == req && g->inst[i].dft) dft = 1;
+      H2D(est, n * sizeof(xaac_esbr_state)); H2D(ecore, n * 4096);
+      if (dft) {
+        H2D(edf, n * sizeof(xaac_hbe_dft_state)); H2D(ecf, n * sizeof(xaac_hbe_dft_cfg)); H2D(ecoef, n * 2 * 64 * 128 * 4); H2D(ecfg, n * 4);
+      } else {
+        H2D(ehb, n * sizeof(xaac_hbe_state));
+      }
       b.n_ch = g->n; b.core = gg->d.ecore; b.header = gg->d.hdr; b.frame = gg->d.frm; b.side = gg->d.esd; b.state = gg->d.est;
       b.out = gg->d.etime; b.status = gg->d.status; b.workspace = gg->ws; b.workspace_bytes = gg->ws_bytes;
-      b.hbe_state = gg->d.ehb;
+      if (dft) { /* instance i's configuration is number i */
+        b.hbe_dft_state = gg->d.edf; b.hbe_dft_cfg_tab = gg->d.ecf; b.hbe_dft_cfg = gg->d.ecfg;
+        b.hbe_dft_coef_re = gg->d.ecoef; b.hbe_dft_coef_im = gg->d.ecoef + n * 64 * 128;
+        g_batches_dft++;
+      } else {
+        b.hbe_state = gg->d.ehb;
+      }
       if (req == REQ_ESBR_PS) {
         H2D(psf, n * sizeof(xaac_ps_frame)); H2D(eps, n * sizeof(xaac_esbr_ps_state));
         b.ps_frame = gg->d.psf; b.ps_state = gg->d.eps; b.out_r = gg->d.etime_r;
       }
       if (xaac_esbr_sbr_process_batch(gg->ctx, &b) != XAAC_OK) die("xaac_esbr_sbr_process_batch");
-      D2H(etime, n * 8192); D2H(est, n * sizeof(xaac_esbr_state)); D2H(ehb, n * sizeof(xaac_hbe_state)); D2H(status, n * 4);
+      D2H(etime, n * 8192); D2H(est, n * sizeof(xaac_esbr_state)); D2H(status, n * 4);
+      if (dft) D2H(edf, n * sizeof(xaac_hbe_dft_state));
+      else D2H(ehb, n * sizeof(xaac_hbe_state));
       if (req == REQ_ESBR_PS) { D2H(etime_r, n * 8192); D2H(eps, n * sizeof(xaac_esbr_ps_state)); }
     } else {
       H2D(hdr, n * sizeof(xaac_sbr_header)); H2D(frm, n * sizeof(xaac_sbr_frame)); H2D(sst, n * sizeof(xaac_sbr_state));
@@ -562,10 +638,10 @@ int main(int argc, char **argv) {
       for (int r = 0; r < REQ_KINDS; r++) calls[r] += g_grp[k].inst[i].calls[r];
   printf("{\"streams\": %d, \"groups\": %d, \"failed\": %d, \"pinned\": %d, \"seconds\": %.6f, "
          "\"calls\": {\"imdct\": %ld, \"sbr_lp\": %ld, \"sbr_hq\": %ld, \"sbr_ps\": %ld, \"limiter\": %ld, \"esbr\": %ld, \"esbr_ps\": %ld}, "
-         "\"batches\": {\"imdct\": %ld, \"sbr_lp\": %ld, \"sbr_hq\": %ld, \"sbr_ps\": %ld, \"limiter\": %ld, \"esbr\": %ld, \"esbr_ps\": %ld}}\n",
+         "\"batches\": {\"imdct\": %ld, \"sbr_lp\": %ld, \"sbr_hq\": %ld, \"sbr_ps\": %ld, \"limiter\": %ld, \"esbr\": %ld, \"esbr_ps\": %ld, \"esbr_with_dft_transposer\": %ld}}\n",
          total, n_groups, failed, pinned, (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec), calls[REQ_IMDCT],
          calls[REQ_SBR_LP], calls[REQ_SBR_HQ], calls[REQ_SBR_PS], calls[REQ_LIM], calls[REQ_ESBR], calls[REQ_ESBR_PS],
          batches[REQ_IMDCT], batches[REQ_SBR_LP], batches[REQ_SBR_HQ], batches[REQ_SBR_PS], batches[REQ_LIM], batches[REQ_ESBR],
-         batches[REQ_ESBR_PS]);
+         batches[REQ_ESBR_PS], g_batches_dft);
   return failed ? 1 : 0;
 }

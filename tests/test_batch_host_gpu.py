@@ -90,3 +90,31 @@ def test_default_flags_mixed_groups_every_instance_byte_identical(tmp_path):
     c, b = summary["calls"], summary["batches"]
     assert c["esbr"] > 0 and c["esbr_ps"] > 0 and c["sbr_lp"] == 0 and c["sbr_ps"] == 0
     assert b["esbr_ps"] * 32 == c["esbr_ps"]
+
+
+def test_esbr_hq_groups_with_the_dft_transposer_in_the_batched_chain(tmp_path):
+    """-esbr_hq:1 for every instance: each group's eSBR rendezvous is one xaac_esbr_sbr_process_batch with 32 DFT harmonic
+    transposers (hbe_dft_state; every instance brings the windows its own decoder's re-initialisation made as a configuration of
+    its own), the reset-time runs stay in the instances' own code.  The float tolerance of this path: every instance's samples
+    within 1 LSB of the plain reference decoder's -esbr_hq:1 output, and the 32 instances of a group identical to each other."""
+    import wave
+    import numpy as np
+    _need()
+    streams = [s for s in STREAMS if "aot5_" in s or "aot29_" in s]
+    groups = [(32, s) for s in streams]
+    summary, outs = run_batch(tmp_path, groups, flags=("-esbr_hq:1",))
+    assert summary["failed"] == 0 and summary["streams"] == 32 * len(groups)
+
+    def samples(path):
+        with wave.open(path) as w:
+            return np.frombuffer(w.readframes(w.getnframes()), np.int16).astype(np.int32)
+    for k, (n, aac) in enumerate(groups):
+        assert len({_md5(w) for w in outs[k]}) == 1, os.path.basename(aac)
+        ref = str(tmp_path / ("ref_hq_" + os.path.basename(aac) + ".wav"))
+        subprocess.run([os.path.join(REF, "xaacdec"), "-ifile:" + aac, "-ofile:" + ref, "-esbr_hq:1"], stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, timeout=600, check=False)
+        a, b = samples(ref), samples(outs[k][0])
+        assert a.size == b.size and a.size > 50000 and np.abs(a - b).max() <= 1 and (a != b).mean() < 0.005, os.path.basename(aac)
+    c, b = summary["calls"], summary["batches"]
+    assert c["esbr"] + c["esbr_ps"] > 0 and b["esbr_with_dft_transposer"] == b["esbr"] + b["esbr_ps"] and b["esbr_with_dft_transposer"] > 100
+    assert b["esbr"] * 32 == c["esbr"] and b["esbr_ps"] * 32 == c["esbr_ps"]
