@@ -74,7 +74,9 @@ def main():
         enc_extra = enc_extra[0] if enc_extra else ()
         name = "s%s_c%d_a%d_b%d%s" % (fs, ch, aot, br, "_enh" if enc_extra else "")
         aac = os.path.join(TMP, name + ".aac")
-        r = subprocess.run([os.path.join(REF, "xaacenc"), "-ifile:" + wav, "-ofile:" + aac, "-aot:%d" % aot, "-br:%d" % br, "-adts:1", *enc_extra],
+        # SWEEP_ENC_EXTRA: encoder options for every stream of the run, e.g. "-tns:0", "-full_bandwidth:1", "-max_out_buffer_per_ch:6144"
+        r = subprocess.run([os.path.join(REF, "xaacenc"), "-ifile:" + wav, "-ofile:" + aac, "-aot:%d" % aot, "-br:%d" % br, "-adts:1", *enc_extra,
+                            *os.environ.get("SWEEP_ENC_EXTRA", "").split()],
                            capture_output=True)
         if r.returncode or not os.path.exists(aac) or os.path.getsize(aac) < 100:
             print(name, "encoder refused")
