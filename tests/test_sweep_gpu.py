@@ -75,3 +75,21 @@ def test_the_sweep_with_the_dft_transposer(tmp_path):
     total, bad = int(lines[-1].split()[1]), int(lines[-1].split()[3])
     assert total >= 60 and bad == 0 and p.returncode == 0, "\n".join(l for l in lines if "identical" not in l)
     assert sum("identical" in l and "within" not in l for l in lines) >= total // 2
+
+
+def test_usac_streams_made_on_the_spot_through_the_drop_in(tmp_path):
+    """tools/sweep_usac.py at one sampling rate (the three-rate run: profiles/r06_s_usac_sweep.txt, 168 streams): the reference
+    encoder's USAC modes -- FD / switched / TD cores, 2:1, 8:3 and 4:1 SBR and none, harmonic SBR, PVC, inter-TES, complex
+    prediction, noise filling -- mono and stereo at two bit rates, decoded by the reference decoder with ixheaacd_fd_frm_dec and
+    ixheaacd_sbr_dec served by the library: byte-identical, and no SBR call left to the reference."""
+    for exe in ("oracle/_ref/xaacenc", "oracle/_ref/xaacdec", "oracle/_ref/xaacdec_dropin"):
+        if not os.path.exists(os.path.join(ROOT, exe)):
+            pytest.fail(exe + " missing: it did not travel with the snapshot / was not built")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_usac.py")], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, SWEEP_TMP=str(tmp_path), SWEEP_SECONDS="0.8", SWEEP_RATES="44100"))
+    lines = p.stdout.strip().splitlines()
+    assert lines and lines[-1].startswith("cases "), p.stdout[-600:] + p.stderr[-600:]
+    w = lines[-1].split()
+    total, bad, gpu_calls = int(w[1]), int(w[3]), int(w[7])
+    assert total >= 50 and bad == 0 and gpu_calls > 2000 and p.returncode == 0, "\n".join(l for l in lines if "identical" not in l)
+    assert all(l.endswith("reference 0") for l in lines[:-1] if "identical" in l)
