@@ -23,6 +23,12 @@ CONFIGS = [("fd21", ["-ccfl_idx:3", "-usac:1"]), ("sw21", ["-ccfl_idx:3", "-usac
            ("sw21pvc", ["-ccfl_idx:3", "-usac:0", "-pvc_enc:1"]), ("fd21tes", ["-ccfl_idx:3", "-usac:1", "-inter_tes_enc:1"]),
            ("fd1024", ["-ccfl_idx:1", "-usac:1"]), ("sw768", ["-ccfl_idx:0", "-usac:0"]),
            ("fd21cplx", ["-ccfl_idx:3", "-usac:1", "-cmpx_pred:1"]), ("fd21nf", ["-ccfl_idx:3", "-usac:1", "-nf:1"])]
+CONFIGS = [(n, ["-aot:42"] + a) for n, a in CONFIGS]
+# SWEEP_PROFILE=ld: the other frame lengths instead -- AAC-LD / AAC-ELD with 512- and 480-line frames (ELD brings its low-delay SBR
+# where the encoder turns it on), AAC-LC / HE-AAC / HE-AACv2 with 960-line frames (raw access units behind an AudioSpecificConfig)
+LD_CONFIGS = [("ld512", ["-aot:23", "-framesize:512"]), ("ld480", ["-aot:23", "-framesize:480"]), ("eld512", ["-aot:39", "-framesize:512"]),
+              ("eld480", ["-aot:39", "-framesize:480"]), ("lc960", ["-aot:2", "-framesize:960"]), ("he960", ["-aot:5", "-framesize:960"]),
+              ("hev2_960", ["-aot:29", "-framesize:960"])]
 
 
 def main():
@@ -40,13 +46,15 @@ def main():
                 w.setnchannels(ch); w.setsampwidth(2); w.setframerate(fs)
                 w.writeframes(pcm.tobytes())
             for br in ((24000, 64000) if ch == 1 else (32000, 96000)):
-                for name, args in CONFIGS:
+                for name, args in (LD_CONFIGS if os.environ.get("SWEEP_PROFILE") == "ld" else CONFIGS):
+                    if name == "hev2_960" and ch != 2:
+                        continue
                     tag = "u%d_c%d_b%d_%s" % (fs, ch, br, name)
                     aac = os.path.join(TMP, tag + ".aac")
                     for f in (aac, aac[:-4] + ".txt"):
                         if os.path.exists(f):
                             os.remove(f)
-                    r = subprocess.run([os.path.join(REF, "xaacenc"), "-ifile:" + wav, "-ofile:" + aac, "-aot:42", "-br:%d" % br] + args,
+                    r = subprocess.run([os.path.join(REF, "xaacenc"), "-ifile:" + wav, "-ofile:" + aac, "-br:%d" % br] + args,
                                        capture_output=True)
                     if r.returncode or not os.path.exists(aac) or os.path.getsize(aac) < 100 or not os.path.exists(aac[:-4] + ".txt"):
                         print(tag, "encoder refused")
@@ -67,6 +75,10 @@ def main():
                     mm = re.search(r"(\d+) USAC fd_frm_dec calls ran on the GPU", r2.stderr)
                     ms = re.search(r"(\d+) of them for USAC channels, (\d+) sbr_dec calls left", r2.stderr)
                     calls = (int(mm.group(1)) if mm else 0, int(ms.group(1)) if ms else 0, int(ms.group(2)) if ms else -1)
+                    if os.environ.get("SWEEP_PROFILE") == "ld":   # (IMDCT calls of 960-line + LD / ELD frames, whole low-delay SBR calls)
+                        m1 = re.search(r"(\d+) imdct_process calls of 960-line frames and (\d+) of AAC-LD / ELD frames", r2.stderr)
+                        m2 = re.search(r"(\d+) whole low-delay SBR calls", r2.stderr)
+                        calls = (int(m1.group(1)) + int(m1.group(2)) if m1 else 0, int(m2.group(1)) if m2 else 0, calls[2])
                     gpu_calls += calls[0] + calls[1]
                     same = os.path.exists(b) and open(a, "rb").read() == open(b, "rb").read()
                     bad += not same
