@@ -112,13 +112,23 @@ int xo_esbr_sbr_frame_pvc(const float *core, const xaac_sbr_header *h, const xaa
                           xaac_hbe_state *hst, const xaac_esbr_pvc_side *pvs, xaac_esbr_pvc_state *pvst) {
   return xo_esbr_sbr_frame_ratio(core, XAAC_ESBR_RATIO_2_1, h, f, sd, st, pf, pst, out, out_r, hst, pvs, pvst);
 }
+/* -esbr_hq:1: the DFT transposer in the QMF one's place (xaac_esbr_sbr_batch.hbe_dft_state); set by xo_esbr_sbr_frame_dft around a call */
+struct XoDft {
+  xaac_hbe_dft_state *st;
+  const xaac_hbe_dft_cfg *cfg;
+  const float *coef_re, *coef_im;
+};
+static thread_local const XoDft *xo_dft;
+int xo_hbe_dft_apply(xaac_hbe_dft_state *st, const xaac_hbe_dft_cfg *cfg, const float *coef_re, const float *coef_im, const float *qmf_re,
+                     const float *qmf_im, int pitch_in_bins, int oversampling, float *pv_re, float *pv_im);
+
 static int esbr_frame(const float *core, int ratio, int ds, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd,
                       xaac_esbr_state *st, const xaac_ps_frame *pf, xaac_esbr_ps_state *pst, float *out, float *out_r,
                       xaac_hbe_state *hst, const xaac_esbr_pvc_side *pvs, xaac_esbr_pvc_state *pvst) {
   /* rows: 8 of history + (32 of codec_x_delay +) the frame's 32 or 64 + what a grid running past the frame's end reads (zeros) */
   constexpr int QROWS = 104, OROWS = 82; /* (104: the 40-row history is copied from row 64 on for 4:1) */
   static_assert(QROWS >= XAAC_ESBR_ROWS, "2:1 with codec_x_delay");
-  XO_MATRIX float phr[40][64], phi[40][64];
+  XO_MATRIX float phr[42][64], phi[42][64]; /* (rows 40, 41: what the DFT transposer's analysis bank clears beyond its 32 rows) */
   XO_MATRIX float qre[QROWS][64], qim[QROWS][64], ore[OROWS][64], oim[OROWS][64];
   XO_MATRIX float rre[64 + 6][64], rim[64 + 6][64], xre[32][64], xim[32][64];
   const int usf4 = ratio == XAAC_ESBR_RATIO_4_1, slots = usf4 ? 64 : 32, rate = usf4 ? 4 : 2;
@@ -165,11 +175,28 @@ static int esbr_frame(const float *core, int ratio, int ds, const xaac_sbr_heade
       memcpy(st->ph_im, phi + 32, sizeof(st->ph_im));
     }
   }
+  const int32_t *x_over = hst ? hst->x_over_qmf : nullptr;
+  if (xo_dft && !hst && f->apply_processing) { /* sbr_dec.c:880-892 */
+    memcpy(phr, st->ph_re, sizeof(st->ph_re));
+    memcpy(phi, st->ph_im, sizeof(st->ph_im));
+    memset(phr + 8, 0, sizeof(float) * 34 * 64);
+    memset(phi + 8, 0, sizeof(float) * 34 * 64);
+    have_ph = xo_hbe_dft_apply(xo_dft->st, xo_dft->cfg, xo_dft->coef_re, xo_dft->coef_im, &qre[XAAC_ESBR_HIST_ROWS][0], &qim[XAAC_ESBR_HIST_ROWS][0],
+                               sd->pitch_in_bins, (sd->harmonic_sbr & XAAC_ESBR_OVERSAMPLING) != 0, &phr[8][0], &phi[8][0]) == 0;
+    if (!have_ph) xo_dft->st->last_status = -1;
+    if (have_ph) {
+      memcpy(st->ph_re, phr + 32, sizeof(st->ph_re));
+      memcpy(st->ph_im, phi + 32, sizeof(st->ph_im));
+      x_over = xo_dft->st->x_over_qmf;
+    }
+  } else if (xo_dft && !hst) {
+    xo_dft->st->last_status = 1; /* skipped: no SBR processing in this frame */
+  }
   if (f->apply_processing) { /* a refused or failed frame still runs the banks and the history shift, like the kernel */
     rc = xe_side_info_bad(h, f, sd) ? -1
                                     : hf_env_pvc(h, f, sd, st, &qre[0][0], &qim[0][0], &ore[0][0], &oim[0][0],
                                                  have_ph ? &phr[0][0] : nullptr, have_ph ? &phi[0][0] : nullptr,
-                                                 hst ? hst->x_over_qmf : nullptr, pvs, pvst, rate);
+                                                 x_over, pvs, pvst, rate);
   } else {
     memset(ore, 0, sizeof(ore));
     memset(oim, 0, sizeof(oim));
@@ -226,6 +253,16 @@ int xo_esbr_sbr_frame_ratio(const float *core, int ratio, const xaac_sbr_header 
   return esbr_frame(core, ratio, 0, h, f, sd, st, pf, pst, out, out_r, hst, pvs, pvst);
 }
 /* ... with the down-sampled synthesis bank(s) (-dsample / output rates above 48 kHz: 32 synthesis channels, half the samples out) */
+/* ... with the DFT transposer (-esbr_hq:1): 2:1 channels without PS here */
+int xo_esbr_sbr_frame_dft(const float *core, const xaac_sbr_header *h, const xaac_sbr_frame *f, const xaac_esbr_side *sd, xaac_esbr_state *st,
+                          float *out, xaac_hbe_dft_state *dst, const xaac_hbe_dft_cfg *cfg, const float *coef_re, const float *coef_im) {
+  const XoDft d = {dst, cfg, coef_re, coef_im};
+  xo_dft = &d;
+  const int rc = esbr_frame(core, XAAC_ESBR_RATIO_2_1, 0, h, f, sd, st, nullptr, nullptr, out, nullptr, nullptr, nullptr, nullptr);
+  xo_dft = nullptr;
+  return rc;
+}
+
 int xo_esbr_sbr_frame_ds(const float *core, int ratio, int down_sample, const xaac_sbr_header *h, const xaac_sbr_frame *f,
                          const xaac_esbr_side *sd, xaac_esbr_state *st, const xaac_ps_frame *pf, xaac_esbr_ps_state *pst, float *out,
                          float *out_r, xaac_hbe_state *hst, const xaac_esbr_pvc_side *pvs, xaac_esbr_pvc_state *pvst) {

@@ -322,12 +322,14 @@ def test_host_reinit_makes_what_the_reference_makes(reference):
 
 
 @pytest.mark.gpu
-def test_path_a_chain_with_the_dft_transposer_is_the_same_for_a_batch_and_for_its_channels_alone():
+def test_path_a_chain_with_the_dft_transposer_is_the_same_for_a_batch_and_for_its_channels_alone(oracle):
     """xaac_esbr_sbr_process_batch with hbe_dft_state on the committed reference-made Path A chains (HE-AAC channels with their
     harmonic frames): every chain gets the DFT transposer the host's re-initialisation makes from its header's band tables (a
     new one where the tables change), chains whose sizes have no transform stay in the batch as refused channels.  The whole batch
     walked step by step against every chain walked alone: outputs, Path A states and transposer states byte for byte -- the
     per-channel strides, configuration indices, skipped (no SBR processing) and refused channels of the chained launches.
+    And every chain walked by the oracle (oracle/oracle_esbr.cpp: xo_esbr_sbr_frame_dft, the sequential run of the same headers):
+    the frames' 2048 output samples to 1e-4 of their peak, the return codes equal.
     (What the chain computes is held to the reference through the drop-in: tests/test_dropin_gpu.py, tests/test_sweep_gpu.py.)"""
     import sys
     import torch
@@ -400,10 +402,43 @@ def test_path_a_chain_with_the_dft_transposer_is_the_same_for_a_batch_and_for_it
         return trace
 
     whole = walk(chains)
+    ofn = oracle.lib.xo_esbr_sbr_frame_dft
+    ofn.restype = ctypes.c_int
+    ofn.argtypes = [PF] + [ctypes.c_void_p] * 4 + [PF, ctypes.POINTER(HbeDftFullState), ctypes.POINTER(HbeDftCfg), PF, PF]
+
+    def oracle_walk(c):
+        dst, cfg = HbeDftFullState(), HbeDftCfg()
+        coef = [np.zeros((64, 128), np.float32) for _ in range(2)]
+        st = np.ascontiguousarray(CH["est0"][c]).copy()
+        seen, outs = None, []
+        for s in range(steps):
+            r = order[c][s]
+            if tables_of(r) != seen:
+                seen = tables_of(r)
+                hdr = np.ascontiguousarray(CH["header"][r])
+                reinit(ctypes.byref(dst), ctypes.byref(cfg), _p(coef[0]), _p(coef[1]), hdr.ctypes.data_as(ctypes.c_void_p))
+                if c in spoiled:
+                    dst.synth_size = 20
+            core = np.ascontiguousarray(chain_core(int(CH["chain_run"][c]), int(CH["chain_id"][c]), s))
+            out = np.zeros(2048, np.float32)
+            vp = lambda a: np.ascontiguousarray(a).ctypes.data_as(ctypes.c_void_p)
+            hd, fr, sd = (np.ascontiguousarray(CH[k][r]) for k in ("header", "frame", "side"))
+            rc = ofn(_p(core), vp(hd), vp(fr), vp(sd), st.ctypes.data_as(ctypes.c_void_p), _p(out), ctypes.byref(dst), ctypes.byref(cfg), _p(coef[0]),
+                     _p(coef[1]))
+            outs.append((out, rc, dst.last_status))
+        return outs
     ran = refused = 0
+    worst = 0.0
     for i, c in enumerate(chains):
         alone = walk([c])
+        orc = oracle_walk(c)
         for s in range(steps):
+            o_out, o_rc, o_last = orc[s]
+            assert int(whole[s][3][i]) == o_rc and HbeDftFullState.from_buffer_copy(whole[s][2][i].tobytes()).last_status == o_last, (c, s, o_rc, o_last)
+            peak = max(np.abs(o_out).max(), 1e-20)
+            err = np.abs(whole[s][0][i] - o_out).max() / peak
+            worst = max(worst, err)
+            assert err <= 1e-4, ("oracle", c, s, err, peak)
             for k, nm in enumerate(("out", "state", "transposer state", "status")):
                 assert np.array_equal(whole[s][k][i], alone[s][k][0]), (nm, c, s)
             last = HbeDftFullState.from_buffer_copy(whole[s][2][i].tobytes()).last_status
