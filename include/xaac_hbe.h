@@ -93,10 +93,10 @@ typedef struct xaac_hbe_dft_anal_batch {
  * (tests: relative 2e-5 of the frame's peak), not bit for bit -- the tolerance BASELINE.json's north_star gives float SBR
  * is +-1 LSB of the 16-bit PCM, which the drop-in test holds the decoded streams to.
  * Bank sizes: the transforms the reference has (hbe_dft_trans.c:508-549): synth_size 12 or 16 (8 with oversampling),
- * analy_size 28 or 32; anything else is refused (status -1, state left alone but for last_status) where the reference fails the
+ * analy_size 28, 32 or (without oversampling) 48; anything else is refused (status -1, state left alone but for last_status) where the reference fails the
  * frame. */
 #define XAAC_HBE_DFT_MAX_ANA 512 /* ana_fft_size[0] = 32 * synth_size */
-#define XAAC_HBE_DFT_MAX_SYN 512 /* syn_fft_size[0] = 16 * analy_size */
+#define XAAC_HBE_DFT_MAX_SYN 768 /* syn_fft_size[0] = 16 * analy_size */
 typedef struct xaac_hbe_dft_state {
   float input_buf[2 * XAAC_HBE_DFT_MAX_ANA];  /* ptr_input_buf: 2 * ana_fft_size[0] samples in use */
   float output_buf[4 * XAAC_HBE_DFT_MAX_SYN]; /* ptr_output_buf: 4 * syn_fft_size[0] samples in use */
@@ -131,6 +131,10 @@ typedef struct xaac_hbe_dft_apply_batch {
   xaac_hbe_dft_state *state;       /* [n_ch] in/out */
   float *pv_re, *pv_im;            /* [n_ch][34][64] in/out: ph_vocod_qmf_real / _imag rows as xaac_hbe_dft_anal_batch.qmf_re / _im */
   int32_t *status;                 /* [n_ch]: 0, or -1 (sizes outside the reference's transforms): state (but last_status) and rows untouched */
+  int32_t rows32;                  /* 1: pv_re / pv_im are [n_ch][32][64] blocks that need not hold anything on entry: the clears the
+                                      reference's bank makes beyond its 32 rows are left out and sub-bands below a_start are written as
+                                      zeros (what the reference's buffer holds there: nothing else ever writes them) -- for a host
+                                      that keeps ph_vocod_qmf's rows in an array of its own */
 } xaac_hbe_dft_apply_batch;
 
 typedef struct xaac_hbe_anal_batch {

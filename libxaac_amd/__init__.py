@@ -184,11 +184,11 @@ class _HbeDftApplyBatch(ctypes.Structure):
     _fields_ = [("n_ch", ctypes.c_int32), ("qmf_re", ctypes.c_void_p), ("qmf_im", ctypes.c_void_p), ("pitch_in_bins", ctypes.c_void_p),
                 ("oversampling", ctypes.c_void_p), ("cfg_tab", ctypes.c_void_p), ("coef_re", ctypes.c_void_p), ("coef_im", ctypes.c_void_p),
                 ("cfg", ctypes.c_void_p), ("state", ctypes.c_void_p), ("pv_re", ctypes.c_void_p), ("pv_im", ctypes.c_void_p),
-                ("status", ctypes.c_void_p)]
+                ("status", ctypes.c_void_p), ("rows32", ctypes.c_int32)]
 
 
-HBE_DFT_FULL_STATE_BYTES = 4 * (1024 + 2048 + 1280 + 642 + 12)   # struct xaac_hbe_dft_state
-HBE_DFT_CFG_BYTES = 4 * (512 + 512 + 3 * 2 * 772)               # struct xaac_hbe_dft_cfg
+HBE_DFT_FULL_STATE_BYTES = 4 * (1024 + 3072 + 1280 + 642 + 12)   # struct xaac_hbe_dft_state
+HBE_DFT_CFG_BYTES = 4 * (512 + 768 + 3 * 2 * 772)               # struct xaac_hbe_dft_cfg
 
 
 class _PvcBatch(ctypes.Structure):
@@ -740,7 +740,7 @@ class XaacContext:
             raise XaacError(rc, "xaac_hbe_dft_anal_batch_run")
 
     def hbe_dft_apply_batch(self, qmf_re, qmf_im, cfg_tab, coef_re, coef_im, state, pv_re, pv_im, status, pitch_in_bins=None,
-                            oversampling=None, cfg=None):
+                            oversampling=None, cfg=None, rows32=False):
         """Batched ixheaacd_dft_hbe_apply (the DFT harmonic transposer, -esbr_hq:1): qmf_re / qmf_im float32[n_ch, 32, 64];
         cfg_tab uint8[n_cfg, HBE_DFT_CFG_BYTES]; coef_re / coef_im float32[n_cfg, 64, 128]; state
         uint8[n_ch, HBE_DFT_FULL_STATE_BYTES] in/out; pv_re / pv_im float32[n_ch, 34, 64] in/out; status int32[n_ch];
@@ -757,8 +757,9 @@ class XaacContext:
         b.coef_im = _ptr(coef_im, "float32", device_ok=True)
         b.cfg = _ptr(cfg, "int32", n_ch, device_ok=True) if cfg is not None else None
         b.state = _ptr(state, "uint8", n_ch * HBE_DFT_FULL_STATE_BYTES, device_ok=True)
-        b.pv_re = _ptr(pv_re, "float32", n_ch * 34 * 64, device_ok=True)
-        b.pv_im = _ptr(pv_im, "float32", n_ch * 34 * 64, device_ok=True)
+        b.rows32 = int(bool(rows32))      # pv blocks of 32 rows, written whole (see include/xaac_hbe.h)
+        b.pv_re = _ptr(pv_re, "float32", n_ch * (32 if rows32 else 34) * 64, device_ok=True)
+        b.pv_im = _ptr(pv_im, "float32", n_ch * (32 if rows32 else 34) * 64, device_ok=True)
         b.status = _ptr(status, "int32", n_ch, device_ok=True)
         rc = self._lib.xaac_hbe_dft_apply_batch_run(self._h, ctypes.byref(b))
         if rc != 0:

@@ -48,7 +48,7 @@ struct XdSizes {
 FX_HD bool xd_sizes(const xaac_hbe_dft_state *st, int ovs, XdSizes *z) {
   const int s = st->synth_size, L = st->anal.analy_size, ks = st->k_start, a0 = st->anal.a_start;
   if (s != 8 && s != 12 && s != 16) return false;
-  if (L < 4 || L > 32 || (L & 3)) return false;
+  if (L < 4 || L > 48 || (L & 3)) return false;
   z->s = s;
   z->L = L;
   z->ana0 = 32 * s;

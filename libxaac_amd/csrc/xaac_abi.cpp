@@ -606,6 +606,7 @@ int32_t xaac_hbe_dft_apply_batch_run(xaac_ctx *c, const xaac_hbe_dft_apply_batch
   pa.state_stride = (int32_t)sizeof(xaac_hbe_dft_state);
   pa.qmf_re = b->pv_re; pa.qmf_im = b->pv_im; pa.status = b->status; pa.chain = 1;
   pa.status_in = b->status; pa.status_stride = 4;
+  if (b->rows32) pa.qmf_stride = 32 * 64, pa.max_rows = 32, pa.zero_below = 1;
   if (!hip_ok(xaac_launch_hbe_dft_anal(&pa, c->stream))) return XAAC_FATAL_HIP;
   c->last_grid = b->n_ch; c->last_block = XAAC_HBE_DFT_CORE_THREADS; c->last_lds = XAAC_HBE_DFT_CORE_LDS;
   return XAAC_OK;

@@ -1528,7 +1528,8 @@ void xs_export_esbr_side(const XsDecoder *d, int c, xaac_esbr_side *o) { /* orac
   memcpy(o->f_master_tbl, h->f_master, sizeof(o->f_master_tbl));
   o->qmf_sb_prev = (int16_t)d->qmf_sb_prev_frame;
   o->reset_flag = (int16_t)f->reset_flag_frame;
-  o->harmonic_sbr = (int16_t)((f->patching_mode == 0 ? XAAC_ESBR_HARMONIC : 0) | (h->pre_flatten ? XAAC_ESBR_PRE_FLATTEN : 0));
+  o->harmonic_sbr = (int16_t)((f->patching_mode == 0 ? XAAC_ESBR_HARMONIC : 0) | (h->pre_flatten ? XAAC_ESBR_PRE_FLATTEN : 0) |
+                              (f->over_sampling ? XAAC_ESBR_OVERSAMPLING : 0));
   memcpy(o->sbr_invf_mode_prev, f->invf_mode_prev, sizeof(o->sbr_invf_mode_prev));
   memcpy(o->flt_env_sf_arr, f->flt_env_sf, sizeof(o->flt_env_sf_arr));
   memcpy(o->flt_noise_floor, f->flt_noise_floor, sizeof(o->flt_noise_floor));

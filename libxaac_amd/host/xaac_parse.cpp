@@ -619,7 +619,7 @@ namespace {
    sin(pi (j + 1/2) / fft_size) put together from the ROM's sines in float arithmetic, as the reference does */
 bool xd_time_window(int fft_size, float *win) {
   const float *tab;
-  int hop, stride;
+  int hop, stride, by2 = -1; /* by2: where the ROM holds sin / cos(pi / (2 N)) itself (the sizes that use every entry of their table) */
   switch (fft_size) {
     case 128: tab = xd_sine_pi_n_by_1024, hop = 8, stride = 512; break;
     case 256: tab = xd_sine_pi_n_by_1024, hop = 4, stride = 512; break;
@@ -627,9 +627,10 @@ bool xd_time_window(int fft_size, float *win) {
     case 192: tab = xd_sine_pi_n_by_768, hop = 4, stride = 384; break;
     case 384: tab = xd_sine_pi_n_by_768, hop = 2, stride = 384; break;
     case 448: tab = xd_sine_pi_n_by_896, hop = 2, stride = 448; break;
+    case 768: tab = xd_sine_pi_n_by_768, hop = 1, stride = 384, by2 = 8; break;
     default: return false; /* (the other sizes of the reference's switch have no transform behind them: hbe_dft_trans.c:508-549) */
   }
-  const float sin_pi_2_n = tab[hop >> 1], cos_pi_2_n = tab[stride + (hop >> 1)];
+  const float sin_pi_2_n = by2 >= 0 ? xd_sine_pi_by_2_n[by2] : tab[hop >> 1], cos_pi_2_n = by2 >= 0 ? xd_sine_pi_by_2_n[by2 + 1] : tab[stride + (hop >> 1)];
   int i = 0, j = 0;
   for (; j < (fft_size >> 1); i += hop, j++) {
     const float cos_val = tab[i + stride], sin_val = tab[i];

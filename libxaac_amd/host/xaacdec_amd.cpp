@@ -35,6 +35,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <thread>
 #include <vector>
@@ -172,6 +173,7 @@ struct Job {
   std::vector<std::vector<uint8_t>> datas; /* -ilist: one per stream; else the one input */
   xaac_adts_header hdr;
   int n_ch, sbr, esbr, out_ch, rate, out_rate, per;
+  int hq; /* -esbr_hq:1: the DFT harmonic transposer in the QMF one's place (Path A only) */
   int threads, verify, profile;
   bool list_mode;
 };
@@ -192,7 +194,7 @@ void shard_range(int n, int r, int g, int *lo, int *hi) {
 
 void decode_shard(const Job &J, Shard &S) {
   const int device = S.device, N = S.n, n_ch = J.n_ch, sbr = J.sbr, esbr = J.esbr, out_ch = J.out_ch, rate = J.rate, per = J.per;
-  const int threads = J.threads, verify = J.verify, profile = J.profile;
+  const int threads = J.threads, verify = J.verify, profile = J.profile, hq = J.esbr && J.hq;
   const bool list_mode = J.list_mode;
   const int NC = N * n_ch, NCD = NC;
   S.first_frames = N;
@@ -255,6 +257,15 @@ void decode_shard(const Job &J, Shard &S) {
     for (size_t i = 0; i * kTail < hbe_tail.size(); i++) memcpy(&v, &hbe_tail[i * kTail], 4), smax = v > smax ? v : smax;
     return smax <= 8 ? 8 : 0;
   };
+  /* -esbr_hq:1: every channel's DFT transposer, the configurations their headers' band tables gave (shared by channels with the
+     same tables), and what the host keeps between resets: max_stretch (the re-initialisation leaves it alone when four patches
+     fit), the last processed frame's over_sampling_flag (the reset-time runs use the transposer's: sbr_dec.c:884 sets it) */
+  xaac_hbe_dft_state *d_dft = nullptr, *d_dft_tmp = nullptr;
+  xaac_hbe_dft_cfg *d_dcfg = nullptr;
+  float *d_dcoef = nullptr;       /* [2][NC][64][128]: real matrices of the configurations, then the imaginary ones */
+  int32_t *d_dslot = nullptr, *d_dslot_tmp = nullptr, *d_dovs = nullptr; /* [NC] configuration of a channel; of the gathered channels; their flags */
+  std::vector<int32_t> dft_ms, dft_ovs, dft_slot;
+  std::map<std::string, int> dft_cfgs;
   float *d_older = nullptr; /* [2][NC][24][64]: rows 8..31 of the QMF history as the frame before found them (see the reset) */
   void *d_ws = nullptr;
   uint64_t ws_bytes = 0;
@@ -273,7 +284,16 @@ void decode_shard(const Job &J, Shard &S) {
     d_frame = dev<xaac_sbr_frame>((size_t)NC);
     d_eside = dev<xaac_esbr_side>((size_t)NC);
     d_estate = dev<xaac_esbr_state>((size_t)NC);
-    d_hbe = dev<xaac_hbe_state>((size_t)NC); /* all zero for a new stream */
+    if (hq) {
+      d_dft = dev<xaac_hbe_dft_state>((size_t)NC); /* all zero for a new stream: refused (last_status -1) until a header sets it up */
+      d_dft_tmp = dev<xaac_hbe_dft_state>((size_t)NC);
+      d_dcfg = dev<xaac_hbe_dft_cfg>((size_t)NC);
+      d_dcoef = dev<float>((size_t)2 * NC * 64 * 128);
+      d_dslot = dev<int32_t>((size_t)NC), d_dslot_tmp = dev<int32_t>((size_t)NC), d_dovs = dev<int32_t>((size_t)NC);
+      dft_ms.assign((size_t)NC, 0), dft_ovs.assign((size_t)NC, 0), dft_slot.assign((size_t)NC, 0);
+    } else {
+      d_hbe = dev<xaac_hbe_state>((size_t)NC); /* all zero for a new stream */
+    }
     d_fcore = dev<float>((size_t)NC * 1024);
     d_out_l = dev<float>((size_t)NC * 2048);
     d_older = dev<float>((size_t)2 * NC * 24 * 64);
@@ -535,7 +555,81 @@ void decode_shard(const Job &J, Shard &S) {
       /* streams with and without PS in one step: the float PS launch copies left to right for those without (esbr_ps_kernel.hip) */
       const size_t row = 64 * sizeof(float), st_pitch = sizeof(xaac_esbr_state), q_pitch = 2048 * sizeof(float);
       float *older_re = d_older, *older_im = d_older + (size_t)NC * 24 * 64;
-      if (resets != 0 && resets != s.delivered) {
+      if (resets != 0 && hq) {
+        /* ixheaacd_sbr_dec_reset with -esbr_hq:1 (sbrdecoder.c:175-236): the resetting channels gathered into a compact batch (all
+           of them, or the few whose headers changed): ixheaacd_dft_hbe_data_reinit on the host (xaac_hbe_dft_state_reinit: sizes,
+           windows, matrices; a configuration is shared by the channels whose band tables are the same), then the transposer's
+           two runs over rows 8..39 and 40..71 of the QMF buffer as the frame before left it.  Its output rows are written whole
+           (rows32): the second run's last eight become the state's ph rows. */
+        std::vector<int> chs;
+        for (int i = 0; i < NC; i++)
+          if (s.status[(size_t)(i / n_ch)] == 0 && s.flags[(size_t)(i / n_ch) * 8 + 1] != 0) chs.push_back(i);
+        const int nr = (int)chs.size();
+        if (!d_q) d_q = dev<float>((size_t)NC * 2 * 2048), d_pv = dev<float>((size_t)NC * 2 * 2048);
+        if (!d_idx) d_idx = dev<int32_t>((size_t)NC);
+        float *q_re = d_q, *q_im = d_q + (size_t)NC * 2048, *pv_re = d_pv, *pv_im = d_pv + (size_t)NC * 2048;
+        std::vector<int32_t> pitch((size_t)nr), slots((size_t)nr), ovs((size_t)nr);
+        HIP(hipStreamSynchronize(stream));
+        const auto d2d = [&](void *dst, const void *src, size_t bytes) { HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream)); };
+        static thread_local xaac_hbe_dft_state h0;
+        static thread_local xaac_hbe_dft_cfg c0;
+        static thread_local float k_re[64 * 128], k_im[64 * 128];
+        constexpr size_t kInts = sizeof(xaac_hbe_dft_state) - offsetof(xaac_hbe_dft_state, anal.analy_size); /* the integers behind the signals */
+        for (int k = 0; k < nr; k++) {
+          const int i = chs[(size_t)k];
+          const xaac_sbr_header &hd = s.header[(size_t)i];
+          memset(&h0, 0, sizeof(h0));
+          h0.max_stretch = dft_ms[(size_t)i];
+          if (xaac_hbe_dft_state_reinit(&h0, &c0, k_re, k_im, &hd)) die("the DFT transposer has no windows for the SBR band tables");
+          dft_ms[(size_t)i] = h0.max_stretch;
+          const std::string key(reinterpret_cast<const char *>(&hd.num_sf_bands[0]),
+                                reinterpret_cast<const char *>(&hd.freq_band_tbl_noise[0]) - reinterpret_cast<const char *>(&hd.num_sf_bands[0]));
+          const std::string key2 = key + std::string(reinterpret_cast<const char *>(&h0.max_stretch), 4);
+          auto it = dft_cfgs.find(key2);
+          if (it == dft_cfgs.end()) { /* a configuration no channel of the shard has had yet: its windows and matrices go up (synchronously: host temporaries) */
+            const int slot = (int)dft_cfgs.size();
+            if (slot >= NC) die("more DFT transposer configurations than channels");
+            it = dft_cfgs.emplace(key2, slot).first;
+            HIP(hipMemcpy(&d_dcfg[slot], &c0, sizeof(c0), hipMemcpyHostToDevice));
+            HIP(hipMemcpy(d_dcoef + (size_t)slot * 64 * 128, k_re, sizeof(k_re), hipMemcpyHostToDevice));
+            HIP(hipMemcpy(d_dcoef + ((size_t)NC + slot) * 64 * 128, k_im, sizeof(k_im), hipMemcpyHostToDevice));
+          }
+          dft_slot[(size_t)i] = slots[(size_t)k] = it->second;
+          HIP(hipMemcpy(&d_dft[i].anal.analy_size, &h0.anal.analy_size, kInts, hipMemcpyHostToDevice));
+          HIP(hipMemset(&d_dft[i].synth_buf[0], 0, sizeof(h0.synth_buf))); /* hbe_dft_trans.c:302 */
+          d2d(&d_dft_tmp[k], &d_dft[i], sizeof(xaac_hbe_dft_state));
+          pitch[(size_t)k] = s.reset_pitch[(size_t)(i / n_ch)];
+          ovs[(size_t)k] = dft_ovs[(size_t)i];
+          /* run 1: buffer rows 8..39 = the 24 older rows, then the state's first eight */
+          d2d(q_re + (size_t)k * 2048, older_re + (size_t)i * 24 * 64, 24 * row);
+          d2d(q_im + (size_t)k * 2048, older_im + (size_t)i * 24 * 64, 24 * row);
+          d2d(q_re + (size_t)k * 2048 + 24 * 64, &d_estate[i].qmf_re[0][0], 8 * row);
+          d2d(q_im + (size_t)k * 2048 + 24 * 64, &d_estate[i].qmf_im[0][0], 8 * row);
+        }
+        HIP(hipMemcpyAsync(d_idx, pitch.data(), (size_t)nr * 4, hipMemcpyHostToDevice, stream));
+        HIP(hipMemcpyAsync(d_dslot_tmp, slots.data(), (size_t)nr * 4, hipMemcpyHostToDevice, stream));
+        HIP(hipMemcpyAsync(d_dovs, ovs.data(), (size_t)nr * 4, hipMemcpyHostToDevice, stream));
+        HIP(hipMemcpyAsync(d_dslot, dft_slot.data(), (size_t)NC * 4, hipMemcpyHostToDevice, stream));
+        HIP(hipStreamSynchronize(stream)); /* (the vectors are host memory of this scope) */
+        xaac_hbe_dft_apply_batch db;
+        memset(&db, 0, sizeof(db));
+        db.n_ch = nr, db.qmf_re = q_re, db.qmf_im = q_im, db.pitch_in_bins = d_idx, db.oversampling = d_dovs, db.cfg_tab = d_dcfg;
+        db.coef_re = d_dcoef, db.coef_im = d_dcoef + (size_t)NC * 64 * 128, db.cfg = d_dslot_tmp, db.state = d_dft_tmp;
+        db.pv_re = pv_re, db.pv_im = pv_im, db.status = d_status, db.rows32 = 1;
+        XA(xaac_hbe_dft_apply_batch_run(ctx, &db));
+        for (int k = 0; k < nr; k++) { /* run 2: buffer rows 40..71 */
+          const int i = chs[(size_t)k];
+          d2d(q_re + (size_t)k * 2048, &d_estate[i].qmf_re[8][0], 32 * row);
+          d2d(q_im + (size_t)k * 2048, &d_estate[i].qmf_im[8][0], 32 * row);
+        }
+        XA(xaac_hbe_dft_apply_batch_run(ctx, &db));
+        for (int k = 0; k < nr; k++) {
+          const int i = chs[(size_t)k];
+          d2d(&d_estate[i].ph_re[0][0], pv_re + (size_t)k * 2048 + 24 * 64, 8 * row);
+          d2d(&d_estate[i].ph_im[0][0], pv_im + (size_t)k * 2048 + 24 * 64, 8 * row);
+          d2d(&d_dft[i], &d_dft_tmp[k], sizeof(xaac_hbe_dft_state));
+        }
+      } else if (resets != 0 && resets != s.delivered) {
         /* Only some of the step's streams reset the SBR decoder (their headers changed: independent streams do that at
            different frames).  The same sequence as below for every stream at once, on those streams' channels gathered into
            a compact batch: their transposer states into d_hbe_tmp (new parameters from the band tables, delay lines
@@ -656,8 +750,17 @@ void decode_shard(const Job &J, Shard &S) {
       xaac_esbr_sbr_batch b;
       memset(&b, 0, sizeof(b));
       b.n_ch = NC, b.core = d_fcore, b.header = d_header, b.frame = d_frame, b.side = d_eside, b.state = d_estate, b.out = d_out_l;
-      b.status = d_status, b.workspace = d_ws, b.workspace_bytes = ws_bytes, b.hbe_state = d_hbe;
-      b.hbe_max_synth_size = hbe_hint();
+      b.status = d_status, b.workspace = d_ws, b.workspace_bytes = ws_bytes;
+      if (hq) {
+        b.hbe_dft_state = d_dft, b.hbe_dft_cfg_tab = d_dcfg, b.hbe_dft_cfg = d_dslot;
+        b.hbe_dft_coef_re = d_dcoef, b.hbe_dft_coef_im = d_dcoef + (size_t)NC * 64 * 128;
+        for (int i = 0; i < NC; i++) /* the flag the transposer keeps for a reset that may follow */
+          if (s.status[(size_t)(i / n_ch)] == 0 && s.frame[(size_t)i].apply_processing)
+            dft_ovs[(size_t)i] = (s.eside[(size_t)i].harmonic_sbr & XAAC_ESBR_OVERSAMPLING) ? 1 : 0;
+      } else {
+        b.hbe_state = d_hbe;
+        b.hbe_max_synth_size = hbe_hint();
+      }
       xaac_esbr_pcm_out_batch ob = {N, 2048, d_out_l, d_out_l, d_pcm}; /* a mono channel twice (api.c:3639-3660) */
       if (with_ps) {
         HIP(hipMemcpyAsync(d_psf, s.ps, (size_t)N * sizeof(xaac_ps_frame), hipMemcpyHostToDevice, stream));
@@ -782,7 +885,7 @@ void decode_shard(const Job &J, Shard &S) {
 
 int main(int argc, char **argv) {
   std::string in, out, ilist, odir;
-  int copies = 1, threads = 0, quiet = 0, verify = 0, profile = 0, esbr = 1, gpus = 1, device0 = 0, plan = 0, wrap = 0;
+  int copies = 1, threads = 0, quiet = 0, verify = 0, profile = 0, esbr = 1, gpus = 1, device0 = 0, plan = 0, wrap = 0, hq = 0;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
     if (a.rfind("-ifile:", 0) == 0) in = a.substr(7);
@@ -800,7 +903,9 @@ int main(int argc, char **argv) {
     else if (a == "-profile") profile = 1; /* synchronise behind every phase of a step and report the seconds spent in each */
     else if (a == "-esbr:0") esbr = 0;
     else if (a == "-esbr:1") esbr = 1;
-    else if (a.rfind("-esbr", 0) == 0) die("-esbr:0 or -esbr:1");
+    else if (a == "-esbr_hq:1") hq = 1;
+    else if (a == "-esbr_hq:0") hq = 0;
+    else if (a.rfind("-esbr", 0) == 0) die("-esbr:0 or -esbr:1 (and -esbr_hq:0 or -esbr_hq:1)");
   }
   std::vector<std::string> inputs;
   if (!ilist.empty()) {
@@ -819,7 +924,7 @@ int main(int argc, char **argv) {
     inputs.push_back(in);
   }
   if (inputs.empty() || (ilist.empty() && out.empty() && !plan) || copies < 1 || gpus < 1 || device0 < 0) {
-    fprintf(stderr, "usage: xaacdec_amd -ifile:<in.aac> -ofile:<out.wav> [-esbr:0|1] [-copies:N] [-threads:T] [-gpus:G] [-device:k] [-plan] [-quiet]\n");
+    fprintf(stderr, "usage: xaacdec_amd -ifile:<in.aac> -ofile:<out.wav> [-esbr:0|1] [-esbr_hq:0|1] [-copies:N] [-threads:T] [-gpus:G] [-device:k] [-plan] [-quiet]\n");
     return 1;
   }
   std::vector<std::vector<uint8_t>> datas(inputs.size());
@@ -895,6 +1000,7 @@ int main(int argc, char **argv) {
   Job J;
   J.datas = std::move(datas);
   J.hdr = hdr;
+  J.hq = hq;
   J.n_ch = n_ch, J.sbr = sbr, J.esbr = esbr, J.out_ch = out_ch, J.rate = rate, J.out_rate = out_rate, J.per = per;
   J.threads = threads, J.verify = verify, J.profile = profile, J.list_mode = list_mode;
   const auto t_run = std::chrono::steady_clock::now();

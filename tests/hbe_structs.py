@@ -60,10 +60,10 @@ def state_from_tables(lo, hi, prev_max_stretch=0):
 
 
 class HbeDftFullState(ctypes.Structure):   # xaac_hbe_dft_state
-    _fields_ = [("input_buf", F * 1024), ("output_buf", F * 2048), ("synth_buf", F * 1280), ("anal", HbeDftState),
+    _fields_ = [("input_buf", F * 1024), ("output_buf", F * 3072), ("synth_buf", F * 1280), ("anal", HbeDftState),
                 ("synth_size", I32), ("k_start", I32), ("start_band", I32), ("end_band", I32), ("max_stretch", I32),
                 ("x_over_qmf", I32 * 6), ("last_status", I32)]
 
 
 class HbeDftCfg(ctypes.Structure):         # xaac_hbe_dft_cfg
-    _fields_ = [("anal_window", F * 512), ("synth_window", F * 512), ("fd_win", ((F * 772) * 2) * 3)]
+    _fields_ = [("anal_window", F * 512), ("synth_window", F * 768), ("fd_win", ((F * 772) * 2) * 3)]

@@ -165,7 +165,7 @@ def test_hbe_struct_layouts_match_header(tmp_path):
              ("xaac_hbe_apply_batch_desc", libxaac_amd._HbeApplyBatch, "status"),
              ("xaac_hbe_dft_anal_batch", libxaac_amd._HbeDftAnalBatch, "status"), ("xaac_hbe_dft_anal_state", hs.HbeDftState, "a_start"),
              ("xaac_hbe_dft_state", hs.HbeDftFullState, "last_status"), ("xaac_hbe_dft_cfg", hs.HbeDftCfg, "fd_win"),
-             ("xaac_hbe_dft_apply_batch", libxaac_amd._HbeDftApplyBatch, "status")]
+             ("xaac_hbe_dft_apply_batch", libxaac_amd._HbeDftApplyBatch, "rows32")]
     body = "".join('printf("%%zu %%zu\\n", sizeof(%s), offsetof(%s, %s));' % (c, c, last) for c, _, last in pairs)
     src = tmp_path / "layout3.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "xaac_hbe.h"\nint main(void) { %s return 0; }\n' % body)

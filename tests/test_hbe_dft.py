@@ -28,7 +28,7 @@ def tables(sb, end):
 # (start band, end band, oversampling, pitch_in_bins): synth_size 12 / 16 / 8, analy_size 28 / 32; the reference has transforms
 # for 8 only with oversampling
 CASES = [(12, 36, 0, 0), (12, 40, 0, 0), (14, 41, 1, 0), (20, 44, 0, 0), (20, 48, 1, 0), (8, 32, 1, 0), (13, 39, 0, 37),
-         (12, 40, 1, 90), (21, 47, 0, 128), (15, 38, 0, 250)]
+         (12, 40, 1, 90), (21, 47, 0, 128), (15, 38, 0, 250), (20, 64, 0, 0), (17, 64, 0, 61)]   # the last two: analy_size 48
 
 
 def close(a, b, what):
@@ -83,7 +83,7 @@ def test_oracle_follows_the_reference_through_chains_of_frames(oracle, reference
     rr, ra, oa = fns(oracle, reference)
     sb, end, ovs, pitch = CASES[case]
     lo, hi, st0, cfg, coef = setup(rr, sb, end)
-    assert st0.synth_size in (8, 12, 16) and st0.anal.analy_size in (28, 32) and 2 <= st0.max_stretch <= 4, (st0.synth_size, st0.anal.analy_size)
+    assert st0.synth_size in (8, 12, 16) and st0.anal.analy_size in (28, 32, 48) and 2 <= st0.max_stretch <= 4, (st0.synth_size, st0.anal.analy_size)
     rng = np.random.default_rng(4000 + case)
     sr, so = clone(st0), clone(st0)
     worst = 0.0
@@ -244,7 +244,7 @@ def test_gpu_against_the_oracle_on_fresh_chains_and_refusals(oracle):
     for frame in range(4):
         qs = [frame_rows(rng, frame, CASES[cases[i % len(cases)]][0]) for i in range(n)]
         befores = [[rng.standard_normal((34, 64)).astype(np.float32) for _ in range(2)] for _ in range(n)]
-        ovs = [int(rng.integers(0, 2)) if sts[i].synth_size != 8 else 1 for i in range(n)]
+        ovs = [(0 if sts[i].anal.analy_size == 48 else int(rng.integers(0, 2))) if sts[i].synth_size != 8 else 1 for i in range(n)]  # (the sizes' valid flags)
         pitch = [int(rng.choice([0, 0, 24, 61, 140, 300])) for _ in range(n)]
         qre = torch.tensor(np.stack([q[0] for q in qs]), device=dev)
         qim = torch.tensor(np.stack([q[1] for q in qs]), device=dev)
@@ -307,7 +307,7 @@ def test_host_reinit_makes_what_the_reference_makes(reference):
                 for i, v in enumerate(hi):
                     h.freq_band_tbl_hi[i] = int(v)
                 rc_o = fn(ctypes.byref(so), ctypes.byref(co), _p(ko[0]), _p(ko[1]), ctypes.byref(h))
-                fits = rc_r == 0 and 32 * sr.synth_size in (256, 384, 512) and 16 * sr.anal.analy_size in (448, 512)
+                fits = rc_r == 0 and 32 * sr.synth_size in (256, 384, 512) and 16 * sr.anal.analy_size in (448, 512, 768)
                 if not fits:
                     refused += rc_o != 0
                     continue

@@ -66,7 +66,7 @@ def test_the_sweep_through_the_drop_in(tmp_path):
 def test_the_sweep_with_the_dft_transposer(tmp_path):
     """-esbr_hq:1 through the drop-in (ixheaacd_dft_hbe_apply on the GPU) over the sweep's HE-AAC / HE-AACv2 streams at all six
     sampling rates, with and without ENHSBR elements: every sample within 1 LSB of the reference decoder's (the float tolerance of
-    BASELINE.json's north_star); 66 decodes, 61 of them identical when this was written."""
+    BASELINE.json's north_star) wherever the reference decodes the stream with this flag: 50 of 66, 45 of them identical when this was written."""
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_streams.py")], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, SWEEP_TMP=str(tmp_path), SWEEP_DECODER="dropin", SWEEP_ALL_SBR_RATES="1", SWEEP_SECONDS="0.8",
                                 SWEEP_FLAGS="-esbr_hq:1", SWEEP_TOL="1"))
@@ -74,7 +74,7 @@ def test_the_sweep_with_the_dft_transposer(tmp_path):
     assert lines and lines[-1].startswith("cases "), p.stdout[-600:] + p.stderr[-600:]
     total, bad = int(lines[-1].split()[1]), int(lines[-1].split()[3])
     assert total >= 60 and bad == 0 and p.returncode == 0, "\n".join(l for l in lines if "identical" not in l)
-    assert sum("identical" in l and "within" not in l for l in lines) >= total // 2
+    assert sum("identical" in l and "within" not in l for l in lines) >= 30
 
 
 def test_usac_streams_made_on_the_spot_through_the_drop_in(tmp_path):
@@ -93,3 +93,16 @@ def test_usac_streams_made_on_the_spot_through_the_drop_in(tmp_path):
     total, bad, gpu_calls = int(w[1]), int(w[3]), int(w[7])
     assert total >= 50 and bad == 0 and gpu_calls > 2000 and p.returncode == 0, "\n".join(l for l in lines if "identical" not in l)
     assert all(l.endswith("reference 0") for l in lines[:-1] if "identical" in l)
+
+
+def test_the_repos_own_decoder_with_the_dft_transposer(tmp_path):
+    """xaacdec_amd -esbr_hq:1 (own front end, xaac_hbe_dft_state_reinit on the host, the reset-time runs and the frames' chain on
+    the GPU) over the sweep's HE-AAC / HE-AACv2 streams: within 1 LSB of the reference decoder wherever that one decodes the
+    stream with this flag (it writes nothing for transposer sizes it has no transforms for: a fifth of the sweep)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_streams.py")], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, SWEEP_TMP=str(tmp_path), SWEEP_ALL_SBR_RATES="1", SWEEP_SECONDS="0.8", SWEEP_FLAGS="-esbr_hq:1", SWEEP_TOL="1"))
+    lines = p.stdout.strip().splitlines()
+    assert lines and lines[-1].startswith("cases "), p.stdout[-600:] + p.stderr[-600:]
+    total, bad = int(lines[-1].split()[1]), int(lines[-1].split()[3])
+    compared = sum("identical" in l for l in lines)
+    assert total >= 60 and bad == 0 and compared >= 40 and p.returncode == 0, "\n".join(l for l in lines if "identical" not in l)

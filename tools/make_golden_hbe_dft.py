@@ -18,7 +18,7 @@ import oracle_lib  # noqa: E402
 import test_hbe_dft as t  # noqa: E402
 
 FRAMES = 5
-GOLDEN_CASES = (0, 1, 2, 4, 5, 7, 9)
+GOLDEN_CASES = (0, 1, 2, 4, 5, 7, 9, 10, 11)
 
 
 def main():

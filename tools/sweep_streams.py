@@ -99,8 +99,9 @@ def main():
             else:
                 r2 = subprocess.run([CLI, "-ifile:" + aac, "-ofile:" + b, "-quiet", *flags], capture_output=True, text=True)
             total += 1
-            if r1.returncode or not os.path.exists(a):
-                print(name, flags, "reference decoder failed")
+            if r1.returncode or not os.path.exists(a) or len(payload(a)[2]) == 0:
+                # (e.g. -esbr_hq:1 on a stream whose transposer sizes the reference has no transforms for: it writes no sample)
+                print(name, flags, "reference decoder failed or wrote nothing: not compared")
                 continue
             if r2.returncode or not os.path.exists(b):
                 print(name, flags, "OWN DECODER FAILED:", r2.stderr.strip()[-200:])
